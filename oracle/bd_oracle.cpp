@@ -1,0 +1,978 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY.  Not shipped, not on the product path.
+//
+// A sequential CPU restatement of BreakDancerMax's anomalous read-pair clustering path,
+// written from a reading of the reference (citations are file:line under /root/reference/src).
+// It deliberately keeps the reference's *shape* (one record at a time, name-keyed maps, an
+// ordered map-of-maps graph, greedy walk with consumption) so that it is an independent check
+// of the product, whose GPU pipeline is organised completely differently (prefix sums,
+// segmented cuts, hash join, pair-group aggregation).
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+//
+// PINNING STATUS
+//   * SV tables: pinned on the reference's own golden files test-data/expected_output{,.af,
+//     .cn_per_lib,.cn_per_lib.af} (tests/golden/chr21), with and without -o 21.
+//   * Option paths those four files do not exercise (-t, -l, -f, -m, -b cadence, multi-tid
+//     merges ...) follow the cited code but are NOT pinned by any reference fixture.
+//   * Poisson / chi-square tails: Boost.Math 1.54 (vendor/boost-1.54-breakdancer.tar.gz, absent
+//     from /root/reference) is replaced by the textbook series / continued fraction for the
+//     regularised incomplete gamma in long double; pinned on mpmath vectors
+//     (tests/golden/poisson_vectors.json), not on Boost output: "parity unpinned" vs Boost.
+//   The reference itself cannot be built here (needs Boost headers; no stand-ins allowed).
+//
+// The reference is C++ and leans on std::map iteration order, so this restatement is C++ too.
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <iomanip>
+#include <map>
+#include <queue>
+#include <regex>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+// ---- common/ReadFlags.hpp:14-27, ReadFlags.cpp:4-14 ------------------------------------------
+enum Flag { NA = 0, ARP_FF, ARP_LARGE_INSERT, ARP_SMALL_INSERT, ARP_RF, ARP_RR, NORMAL_FR, NORMAL_RF,
+            ARP_CTX, MATE_UNMAPPED, UNMAPPED, NFLAGS };
+const int kPrintedFlagValue[NFLAGS] = {0, 1, 2, 3, 4, 8, 18, 20, 32, 64, 192};
+
+// ---- common/Options.cpp:27-41 (defaults live on the caller's side; this is the carrier) --------
+struct Opts {
+    int32_t min_len, cut_sd, max_sd, min_map_qual, min_read_pair, seq_coverage_lim, buffer_size;
+    int32_t transchr_rearrange, fisher, illumina_long_insert, cn_lib, print_af, score_threshold;
+    int32_t chr_tid;  // -1: all sequences; >=0: "-o <name>" resolved to a tid (opts.chr non-empty)
+};
+
+// ---- io/LibraryConfig.hpp:11-24 -----------------------------------------------------------------
+struct Lib {
+    size_t index = 0;
+    std::string name;
+    size_t bam_file_index = 0;
+    std::string bam_file;
+    float mean_insertsize = 0, std_insertsize = 0, uppercutoff = 0, lowercutoff = 0, readlens = 0;
+    int min_mapping_quality = -1;
+    bool same(Lib const& o) const {
+        return index == o.index && name == o.name && bam_file_index == o.bam_file_index && bam_file == o.bam_file &&
+               mean_insertsize == o.mean_insertsize && std_insertsize == o.std_insertsize &&
+               uppercutoff == o.uppercutoff && lowercutoff == o.lowercutoff && readlens == o.readlens &&
+               min_mapping_quality == o.min_mapping_quality;
+    }
+};
+
+// ---- io/BamConfigEntry.cpp:31-86 ------------------------------------------------------------------
+enum Field { BAM_FILE, LIBRARY_NAME, READ_GROUP, INSERT_SIZE_MEAN, INSERT_SIZE_STDDEV, READ_LENGTH,
+             INSERT_SIZE_UPPER_CUTOFF, INSERT_SIZE_LOWER_CUTOFF, MIN_MAP_QUAL, SAMPLE_NAME, UNKNOWN };
+
+Field translate_token(std::string const& tok) {
+    // The reference keeps (regex -> field) in a flat_map keyed by the regex object, i.e. iterated in
+    // pattern-string order (BamConfigEntry.cpp:43-54); first hit of regex_search wins (:57-65).
+    static const std::vector<std::pair<std::string, Field>> table = [] {
+        std::vector<std::pair<std::string, Field>> t = {
+            {"map$", BAM_FILE}, {"lib\\w*$", LIBRARY_NAME}, {"group$", READ_GROUP}, {"mean\\w*$", INSERT_SIZE_MEAN},
+            {"std\\w*$", INSERT_SIZE_STDDEV}, {"readlen\\w*$", READ_LENGTH}, {"upp\\w*$", INSERT_SIZE_UPPER_CUTOFF},
+            {"low\\w*$", INSERT_SIZE_LOWER_CUTOFF}, {"map\\w*qual\\w*$", MIN_MAP_QUAL}, {"samp\\w*$", SAMPLE_NAME}};
+        std::sort(t.begin(), t.end(), [](auto const& a, auto const& b) { return a.first < b.first; });
+        return t;
+    }();
+    for (auto const& e : table) {
+        std::regex re(e.first, std::regex::icase);
+        if (std::regex_search(tok, re)) return e.second;
+    }
+    return UNKNOWN;
+}
+
+struct Entry {
+    std::map<Field, std::string> directives;
+    explicit Entry(std::string const& line) {
+        size_t b = 0;
+        while (true) {  // boost::split on '\t' keeps empty fields (:73)
+            size_t e = line.find('\t', b);
+            std::string f = line.substr(b, e == std::string::npos ? std::string::npos : e - b);
+            size_t colon = f.find(':');
+            if (colon != std::string::npos) {
+                Field fn = translate_token(f.substr(0, colon));
+                if (fn != UNKNOWN) directives[fn] = f.substr(colon + 1);
+            }
+            if (e == std::string::npos) break;
+            b = e + 1;
+        }
+    }
+    bool get(Field f, std::string& v) const {
+        auto it = directives.find(f);
+        if (it == directives.end()) return false;
+        v = it->second;
+        return true;
+    }
+    bool get(Field f, float& v) const {  // boost::lexical_cast<float>: whole token must parse
+        std::string s;
+        if (!get(f, s)) return false;
+        char* end = nullptr;
+        v = strtof(s.c_str(), &end);
+        if (s.empty() || *end != 0) throw std::runtime_error("bad lexical cast: source type value could not be interpreted as target");
+        return true;
+    }
+    bool get(Field f, int& v) const {
+        std::string s;
+        if (!get(f, s)) return false;
+        char* end = nullptr;
+        long x = strtol(s.c_str(), &end, 10);
+        if (s.empty() || *end != 0) throw std::runtime_error("bad lexical cast: source type value could not be interpreted as target");
+        v = (int)x;
+        return true;
+    }
+};
+
+// ---- io/BamConfig.cpp:19-122 ------------------------------------------------------------------------
+struct Config {
+    std::vector<std::string> bam_files;
+    std::map<std::string, std::string> bam_library;        // ordered like the reference's flat_map
+    std::map<std::string, size_t> lib_names_to_indices;
+    std::vector<Lib> libs;
+    std::map<std::string, std::string> readgroup_library;
+    int max_read_window_size = 100000000;  // BamConfig.cpp:12
+
+    void parse(std::string const& text, int cutoff_sd) {
+        std::map<std::string, Lib> tmp;
+        std::istringstream in(text);
+        std::string line;
+        size_t line_num = 0;
+        while (std::getline(in, line)) {
+            ++line_num;
+            if (line.empty()) break;  // :29-30
+            Entry entry(line);
+            std::string fmap, lib, readgroup;
+            float mean = 0, stddev = 0, readlen = 0, upper = 0, lower = 0;
+            int mqual = -1;
+            if (!entry.get(LIBRARY_NAME, lib)) entry.get(SAMPLE_NAME, lib);  // :44-45
+            if (!entry.get(BAM_FILE, fmap)) {
+                std::ostringstream m;
+                m << "Required field 'map' not found in config at line " << line_num << "!";
+                throw std::runtime_error(m.str());
+            }
+            if (!entry.get(READ_GROUP, readgroup)) readgroup = lib;  // :48-49
+            readgroup_library[readgroup] = lib;                      // :51
+            bam_library[fmap] = lib;                                 // :52
+            entry.get(READ_LENGTH, readlen);
+            entry.get(MIN_MAP_QUAL, mqual);
+            bool have_mean = entry.get(INSERT_SIZE_MEAN, mean);
+            bool have_std = entry.get(INSERT_SIZE_STDDEV, stddev);
+            bool have_lower = entry.get(INSERT_SIZE_LOWER_CUTOFF, lower);
+            bool have_upper = entry.get(INSERT_SIZE_UPPER_CUTOFF, upper);
+            if (have_mean && have_std && (!have_upper || !have_lower)) {  // :64-68
+                upper = mean + stddev * cutoff_sd;
+                lower = mean - stddev * cutoff_sd;
+                lower = lower > 0 ? lower : 0;
+            }
+            Lib lc;
+            lc.name = lib;
+            lc.bam_file = fmap;
+            lc.min_mapping_quality = mqual;
+            lc.mean_insertsize = mean;
+            lc.std_insertsize = stddev;
+            lc.uppercutoff = upper;
+            lc.lowercutoff = lower;
+            lc.readlens = readlen;
+            auto ins = tmp.insert(std::make_pair(lib, lc));
+            if (!ins.second && !ins.first->second.same(lc)) ins.first->second = lc;  // :86-90
+            int t = mean - readlen * 2;                                              // :92 (float -> int)
+            max_read_window_size = std::min(max_read_window_size, t);
+        }
+        for (auto& kv : tmp) {  // :97-101 sorted-name order
+            kv.second.index = libs.size();
+            lib_names_to_indices[kv.first] = kv.second.index;
+            libs.push_back(kv.second);
+        }
+        for (auto const& kv : bam_library) bam_files.push_back(kv.first);  // :103-106
+        for (auto& l : libs) {
+            auto it = std::find(bam_files.begin(), bam_files.end(), l.bam_file);
+            if (it == bam_files.end())
+                throw std::runtime_error("Bam file '" + l.bam_file + "' referenced by library '" + l.name +
+                                         "' but not found in bam list!");
+            l.bam_file_index = it - bam_files.begin();
+        }
+        max_read_window_size = std::max(max_read_window_size, 50);  // :121
+    }
+    // BamConfig.hpp:62-72 + AlignmentSource.hpp:57-62
+    size_t lib_of_readgroup(std::string const& rg) const {
+        auto it = readgroup_library.find(rg);
+        std::string const& lib = it != readgroup_library.end() ? it->second : bam_library.begin()->second;
+        return lib_names_to_indices.at(lib);
+    }
+};
+
+// ---- io/Alignment.hpp:56-69 -------------------------------------------------------------------------
+struct Rec {
+    int32_t tid, pos, mtid, mpos, abs_isize, qlen;
+    uint16_t sam;
+    uint8_t bdqual;
+    uint32_t lib;
+    uint64_t name;   // exact name id (bijection of qname strings, made by the test loader)
+    int32_t bam;     // physical source file
+    int64_t src;     // index within its physical stream
+    int flag;        // ReadFlag, mutable like Alignment::_bdflag
+    bool proper_pair() const { return (sam & (0x2 | 0x4 | 0x8 | 0x1 | 0x400)) == (0x2 | 0x1); }  // Alignment.hpp:144-148
+    bool either_unmapped() const { return sam & (0x4 | 0x8); }                                    // :151-153
+    bool interchrom() const { return tid != mtid; }                                               // :156-158
+    bool leftmost() const { return pos < mpos; }                                                  // :72-75
+    bool rev() const { return sam & 0x10; }                                                       // :107-110
+};
+
+// ---- io/IlluminaPEReadClassifier.cpp:13-101 --------------------------------------------------------
+int classify(Rec const& a, Lib const& lc) {
+    bool dup = a.sam & 0x400, paired = a.sam & 0x1, unmapped = a.sam & 0x4, mate_unmapped = a.sam & 0x8;
+    if (dup || !paired) return NA;
+    if (unmapped) return UNMAPPED;
+    if (mate_unmapped) return MATE_UNMAPPED;
+    if (a.interchrom()) return ARP_CTX;
+    bool read_reversed = a.sam & 0x10, mate_reversed = a.sam & 0x20;
+    bool large_insert = a.abs_isize > lc.uppercutoff;  // int vs float compare, as in the reference
+    bool small_insert = a.abs_isize < lc.lowercutoff;
+    if (read_reversed == mate_reversed) return read_reversed ? ARP_RR : ARP_FF;
+    if (a.leftmost() == read_reversed) return ARP_RF;
+    if (large_insert) return ARP_LARGE_INSERT;
+    if (small_insert) return ARP_SMALL_INSERT;
+    return NORMAL_FR;
+}
+
+void long_insert_remap(Rec& a, Lib const& lc) {  // BamSummary.cpp:97-107 == BreakDancer.cpp:182-192
+    if (a.abs_isize > lc.uppercutoff && a.flag == NORMAL_RF) a.flag = ARP_RF;
+    if (a.abs_isize < lc.uppercutoff && a.flag == ARP_RF) a.flag = NORMAL_RF;
+    if (a.abs_isize < lc.lowercutoff && a.flag == NORMAL_RF) a.flag = ARP_SMALL_INSERT;
+}
+
+// ---- regularised incomplete gamma (stands in for Boost.Math; see header) ----------------------------
+typedef long double ld;
+ld gamma_p_series(ld a, ld x) {  // P(a,x), x < a+1
+    ld sum = 1.0L / a, term = sum, ap = a;
+    for (int n = 0; n < 100000; ++n) {
+        ap += 1;
+        term *= x / ap;
+        sum += term;
+        if (fabsl(term) < fabsl(sum) * 1e-21L) break;
+    }
+    return sum * expl(-x + a * logl(x) - lgammal(a));
+}
+ld gamma_q_cf(ld a, ld x) {  // Q(a,x), x >= a+1, modified Lentz
+    const ld tiny = 1e-4000L;
+    ld b = x + 1 - a, c = 1 / tiny, d = 1 / b, h = d;
+    for (int i = 1; i < 100000; ++i) {
+        ld an = -i * (i - a);
+        b += 2;
+        d = an * d + b;
+        if (fabsl(d) < tiny) d = tiny;
+        c = b + an / c;
+        if (fabsl(c) < tiny) c = tiny;
+        d = 1 / d;
+        ld del = d * c;
+        h *= del;
+        if (fabsl(del - 1) < 1e-21L) break;
+    }
+    return expl(-x + a * logl(x) - lgammal(a)) * h;
+}
+double gamma_p(double a, double x) {
+    if (x <= 0) return 0;
+    if (x < a + 1) return (double)gamma_p_series(a, x);
+    return (double)(1.0L - gamma_q_cf(a, x));
+}
+double gamma_q(double a, double x) {
+    if (x <= 0) return 1;
+    if (x < a + 1) return (double)(1.0L - gamma_p_series(a, x));
+    return (double)gamma_q_cf(a, x);
+}
+// cdf(complement(poisson(lambda), k)) = P(X > k) = P(k+1, lambda)   (Boost poisson.hpp)
+double poisson_upper_tail(double lambda, int k) {
+    if (lambda == 0) return 0;
+    if (k == 0) return -expm1(-lambda);
+    return gamma_p((double)k + 1, lambda);
+}
+// cdf(complement(chi_squared(df), x)) = Q(df/2, x/2)
+double chisq_upper_tail(double df, double x) { return gamma_q(df / 2, x / 2); }
+
+// ---- breakdancer/BasicRegion.hpp:11-76 -----------------------------------------------------------------
+struct Region {
+    int index, chr, start, end, normal_read_pairs, fwd = 0, rev = 0;
+    std::vector<int> reads;  // indices into the merged record vector
+    int size() const { return end - start + 1; }
+};
+
+typedef std::map<std::string, uint32_t> Counts;  // breakdancer/ReadCountsByLib.hpp (only non-zero keys)
+void counts_add(Counts& a, Counts const& b) {    // operator+= -> merge_maps(plus)
+    for (auto const& kv : b) {
+        auto ins = a.insert(kv);
+        if (!ins.second) ins.first->second += kv.second;
+    }
+}
+Counts counts_sub(Counts a, Counts const& b) {  // operator-= (ReadCountsByLib.hpp:77-88)
+    for (auto const& kv : b) {
+        auto ins = a.insert(std::make_pair(kv.first, (uint32_t)(0 - kv.second)));
+        if (!ins.second) {
+            ins.first->second -= kv.second;
+            if (ins.first->second == 0) a.erase(ins.first);
+        }
+    }
+    return a;
+}
+
+struct SvOut {
+    int chr[2], pos[2], fwd[2], rev[2];
+    int flag, size, score, num_reads, printed;
+    double logp;
+    float af;
+    std::vector<std::pair<int, int>> lib_counts;       // (lib index, count) of the dominant flag
+    std::vector<std::pair<int, float>> copy_number;    // (key index: lib if -a else bam, value)
+    std::vector<int> support;                          // merged-record indices, SvBuilder order
+};
+
+struct Oracle {
+    Opts o;
+    Config cfg;
+    std::vector<std::string> targets;
+    std::vector<std::vector<Rec>> streams;  // per physical BAM, in cfg.bam_files order
+    std::string err;
+
+    // pass-1 results (io/BamSummary.hpp)
+    uint32_t covered_ref_len = 0;
+    std::vector<uint32_t> read_count_per_bam;
+    std::vector<uint32_t> lib_read_count;
+    std::vector<std::vector<uint32_t>> hist;  // [lib][flag]
+    std::vector<float> seqcov;
+    int W = 0;
+    std::vector<float> density;  // keyed like the reference's _read_density (lib or bam name)
+    std::map<std::string, float> read_density;
+
+    // pass-2 state (breakdancer/BreakDancer.hpp)
+    std::vector<Rec> merged;
+    std::vector<uint8_t> cls;  // per merged record: final flag | pass<<4 | proper<<5 (for product parity)
+    std::vector<int> cur;
+    bool collecting = false;
+    int nnormal = 0, ntotal_nuc = 0, max_readlen = 0, buffered = 0;
+    int rs_tid = -1, rs_pos = -1, re_tid = -1, re_pos = -1;
+    Counts nread_ROI, nread_FR;
+    std::vector<Counts> roi_map, fr_map;
+    std::vector<Region*> regions;
+    std::vector<Region> region_log;  // snapshot at creation (for parity dumps)
+    std::vector<int> region_log_stored;
+    std::unordered_map<uint64_t, std::vector<int>> read_regions;
+    std::map<int, std::map<int, int>> graph;
+    std::vector<std::array<int, 3>> edge_log;  // (lo, hi, +1) increments, for dumps
+    std::vector<SvOut> svs;
+    std::ostringstream out;
+    bool sticky_fixed = false;  // Q21: cout << fixed << setprecision(2) is never reset
+
+    ~Oracle() { for (auto r : regions) delete r; }
+
+    int min_mapq(Lib const& l) const { return l.min_mapping_quality < 0 ? o.min_map_qual : l.min_mapping_quality; }
+
+    // ---- io/BamSummary.cpp:47-150 --------------------------------------------------------------------
+    void pass1() {
+        size_t nl = cfg.libs.size();
+        lib_read_count.assign(nl, 0);
+        hist.assign(nl, std::vector<uint32_t>(NFLAGS, 0));
+        read_count_per_bam.assign(cfg.bam_files.size(), 0);
+        for (size_t b = 0; b < streams.size(); ++b) {
+            int last_pos = 0, last_tid = -1;
+            size_t ref_len = 0;
+            uint32_t read_count = 0;
+            for (Rec const& r0 : streams[b]) {
+                if (o.chr_tid >= 0 && r0.tid != o.chr_tid) continue;  // RegionLimitedBamReader (BamIo.cpp:16-18)
+                Rec a = r0;
+                Lib const& lc = cfg.libs[a.lib];
+                a.flag = classify(a, lc);
+                if (last_tid >= 0 && last_tid == a.tid) ref_len += a.pos - last_pos;
+                last_pos = a.pos;
+                last_tid = a.tid;
+                if (a.bdqual <= min_mapq(lc)) continue;
+                if (a.proper_pair()) { ++lib_read_count[lc.index]; ++read_count; }
+                if (a.flag == NA || a.either_unmapped() || (o.transchr_rearrange && !a.interchrom())) continue;
+                if (o.illumina_long_insert) long_insert_remap(a, lc);
+                if (a.flag == NORMAL_FR || a.flag == NORMAL_RF) continue;
+                ++hist[lc.index][a.flag];
+            }
+            read_count_per_bam[b] = read_count;
+            if (covered_ref_len < ref_len) covered_ref_len = (uint32_t)ref_len;
+        }
+        seqcov.assign(nl, 0.f);
+        for (size_t i = 0; i < nl; ++i) {
+            float covg = 0;
+            if (lib_read_count[i] != 0 && covered_ref_len != 0)
+                covg = float(lib_read_count[i]) * cfg.libs[i].readlens / covered_ref_len;
+            seqcov[i] = covg;
+        }
+    }
+
+    // ---- exe/breakdancer-max/BreakDancerMax.cpp:75-153 -------------------------------------------------
+    void header() {
+        W = cfg.max_read_window_size;
+        out << "#Library Statistics:" << std::endl;
+        for (size_t i = 0; i < cfg.libs.size(); ++i) {
+            Lib const& lc = cfg.libs[i];
+            uint32_t lrc = lib_read_count[i];
+            float physical_coverage = float(lrc * lc.mean_insertsize) / covered_ref_len / 2;
+            float dens = 0.000001f;
+            if (o.cn_lib) {
+                if (lrc != 0) dens = float(lrc) / covered_ref_len;
+            } else {
+                uint32_t nreads = read_count_per_bam[lc.bam_file_index];
+                dens = float(nreads) / covered_ref_len;
+            }
+            read_density[o.cn_lib ? lc.name : lc.bam_file] = dens;
+            int nd = hist[i][ARP_LARGE_INSERT] + hist[i][ARP_SMALL_INSERT];
+            int tmp = (nd > 0) ? (float)covered_ref_len / (float)nd : 50;
+            W = std::min(W, tmp);
+            out << "#" << lc.bam_file << "\tmean:" << lc.mean_insertsize << "\tstd:" << lc.std_insertsize
+                << "\tuppercutoff:" << lc.uppercutoff << "\tlowercutoff:" << lc.lowercutoff << "\treadlen:" << lc.readlens
+                << "\tlibrary:" << lc.name << "\treflen:" << covered_ref_len << "\tseqcov:" << seqcov[i]
+                << "\tphycov:" << physical_coverage;
+            for (int j = 0; j < NFLAGS; ++j)
+                if (hist[i][j]) out << "\t" << kPrintedFlagValue[j] << ":" << hist[i][j];
+            out << "\n";
+        }
+        out << "#Chr1\tPos1\tOrientation1\tChr2\tPos2\tOrientation2\tType\tSize\tScore\tnum_Reads\tnum_Reads_lib";
+        if (o.print_af) out << "\tAllele_frequency";
+        if (!o.cn_lib)
+            for (auto const& b : cfg.bam_files) {
+                size_t p = b.rfind("/");
+                out << "\t" << (p != std::string::npos ? b.substr(p + 1) : b);
+            }
+        out << "\n";
+    }
+
+    // ---- io/BamMerger.cpp:40-126: k-way merge by (tid,pos,strand) with std::priority_queue --------------
+    struct Stream {
+        std::vector<Rec> const* v;
+        size_t i;
+        int chr_tid;
+        bool valid() const { return i < v->size(); }
+        void skip() { while (i < v->size() && chr_tid >= 0 && (*v)[i].tid != chr_tid) ++i; }
+        Rec const& top() const { return (*v)[i]; }
+        bool greater(Stream const& r) const {
+            Rec const &x = top(), &y = r.top();
+            if (x.tid > y.tid) return true;
+            if (y.tid > x.tid) return false;
+            if (x.pos > y.pos) return true;
+            if (y.pos > x.pos) return false;
+            return (int)x.rev() > (int)y.rev();
+        }
+    };
+    struct StreamCmp { bool operator()(Stream const* a, Stream const* b) const { return a->greater(*b); } };
+
+    void merge() {
+        std::vector<Stream> ss(streams.size());
+        std::priority_queue<Stream*, std::vector<Stream*>, StreamCmp> pq;
+        for (size_t b = 0; b < streams.size(); ++b) {
+            ss[b] = Stream{&streams[b], 0, o.chr_tid};
+            ss[b].skip();
+            if (ss[b].valid()) pq.push(&ss[b]);
+        }
+        while (!pq.empty()) {
+            Stream* s = pq.top();
+            pq.pop();
+            merged.push_back(s->top());
+            ++s->i;
+            s->skip();
+            if (s->valid()) pq.push(s);
+        }
+    }
+
+    std::string const& count_key(Lib const& lc) const { return o.cn_lib ? lc.name : lc.bam_file; }
+
+    // ---- breakdancer/BreakDancer.cpp:147-242 ---------------------------------------------------------------
+    void push_read(int idx) {
+        Rec& a = merged[idx];
+        Lib const& lc = cfg.libs[a.lib];
+        a.flag = classify(a, lc);
+        bool pass = !(a.flag == NA || a.either_unmapped() || a.bdqual <= min_mapq(lc) ||
+                      (o.transchr_rearrange && !a.interchrom()) || (a.flag != ARP_CTX && a.abs_isize > o.max_sd));
+        if (!pass) { cls[idx] = (uint8_t)a.flag; return; }
+        if (a.proper_pair()) {
+            ++nread_ROI[count_key(lc)];
+            ++nread_FR[count_key(lc)];
+        }
+        if (o.illumina_long_insert) long_insert_remap(a, lc);
+        if (a.flag == ARP_RR) a.flag = ARP_FF;
+        cls[idx] = (uint8_t)(a.flag | 0x10 | (a.proper_pair() ? 0x20 : 0));
+        if (a.flag == NORMAL_FR || a.flag == NORMAL_RF) {
+            if (collecting && a.leftmost()) ++nnormal;
+            return;
+        }
+        if (collecting) {
+            ntotal_nuc += a.qlen;
+            max_readlen = std::max(max_readlen, a.qlen);
+        }
+        bool do_break = a.tid != re_tid || a.pos - re_pos > W;
+        if (do_break) {
+            process_breakpoint();
+            rs_tid = a.tid;
+            rs_pos = a.pos;
+            cur.clear();
+            collecting = false;
+            nnormal = 0;
+            max_readlen = 0;
+            ntotal_nuc = 0;
+            nread_ROI.clear();
+            nread_FR.clear();
+        }
+        cur.push_back(idx);
+        if (cur.size() == 1) collecting = true;
+        re_tid = a.tid;
+        re_pos = a.pos;
+        nread_ROI.clear();
+    }
+
+    // ---- BreakDancer.cpp:244-264 -------------------------------------------------------------------------------
+    void process_breakpoint() {
+        float seq_coverage = ntotal_nuc / float(re_pos - rs_pos + 1 + max_readlen);
+        if (re_pos - rs_pos > o.min_len && seq_coverage < o.seq_coverage_lim) {
+            add_region();
+            ++buffered;
+            if (buffered > o.buffer_size) {
+                build_connection();
+                buffered = 0;
+            }
+        } else {
+            collapse();
+        }
+    }
+
+    // ---- ReadRegionData.cpp:89-124, :207-217 -----------------------------------------------------------------------
+    void add_region() {
+        int id = (int)regions.size();
+        Region* r = new Region;
+        r->index = id; r->chr = rs_tid; r->start = rs_pos; r->end = re_pos; r->normal_read_pairs = nnormal;
+        regions.push_back(r);
+        if ((size_t)id >= roi_map.size()) roi_map.resize(2 * (id + 1));
+        roi_map[id] = nread_ROI;
+        if ((size_t)id >= fr_map.size()) fr_map.resize(2 * (id + 1));
+        fr_map[id] = counts_sub(nread_FR, nread_ROI);
+        int non_ctx = 0;
+        for (int idx : cur) {
+            Rec const& a = merged[idx];
+            if (a.flag != ARP_CTX) ++non_ctx;
+            if (!a.rev()) ++r->fwd; else ++r->rev;
+            std::vector<int>& rr = read_regions[a.name];
+            rr.push_back(id);
+            if (rr.size() == 2) {  // Graph.hpp:41-46
+                ++graph[rr[0]][rr[1]];
+                if (rr[0] != rr[1]) ++graph[rr[1]][rr[0]];
+                edge_log.push_back({std::min(rr[0], rr[1]), std::max(rr[0], rr[1]), 1});
+            }
+        }
+        int valid_reads = o.chr_tid < 0 ? (int)cur.size() : non_ctx;
+        bool stored = valid_reads >= o.min_read_pair;
+        region_log.push_back(*r);
+        region_log.back().reads = cur;
+        region_log_stored.push_back(stored);
+        if (stored) r->reads.swap(cur);
+    }
+
+    // ---- ReadRegionData.cpp:177-199 ---------------------------------------------------------------------------------
+    void collapse() {
+        if (!regions.empty()) counts_add(roi_map[regions.size() - 1], nread_FR);
+        for (int idx : cur) read_regions.erase(merged[idx].name);
+    }
+
+    bool region_exists(size_t i) const { return i < regions.size() && regions[i]; }
+    bool read_exists(int idx) const { return read_regions.find(merged[idx].name) != read_regions.end(); }
+
+    // ---- ReadRegionData.cpp:126-142 -----------------------------------------------------------------------------------
+    bool is_region_final(size_t i) const {
+        if (!region_exists(i) || i == regions.size() - 1) return false;
+        for (int idx : regions[i]->reads) {
+            Rec const& a = merged[idx];
+            if (o.chr_tid >= 0 && a.flag == ARP_CTX) continue;
+            auto f = read_regions.find(a.name);
+            if (f == read_regions.end() || f->second.size() != 2) return false;
+        }
+        return true;
+    }
+    // ---- ReadRegionData.cpp:152-175 -------------------------------------------------------------------------------------
+    void clear_region(size_t i) {
+        if (!region_exists(i)) return;
+        for (int idx : regions[i]->reads) {
+            auto f = read_regions.find(merged[idx].name);
+            if (f != read_regions.end()) {
+                std::vector<int> nr;
+                for (int x : f->second) if (x != (int)i) nr.push_back(x);
+                if (!nr.empty()) f->second.swap(nr); else read_regions.erase(f);
+            }
+        }
+        delete regions[i];
+        regions[i] = nullptr;
+    }
+
+    // ---- BreakDancer.cpp:266-346 ---------------------------------------------------------------------------------------------
+    void build_connection() {
+        std::vector<int> active;
+        for (auto const& kv : graph) active.push_back(kv.first);
+        auto ii = graph.begin();
+        while (ii != graph.end()) {
+            std::vector<int> tails{ii->first};
+            bool need_inc = true;
+            while (!tails.empty()) {
+                std::vector<int> newtails;
+                for (int tail : tails) {
+                    if (!region_exists(tail)) continue;
+                    auto found = graph.find(tail);
+                    if (found == graph.end()) continue;
+                    auto& gt = found->second;
+                    auto it = gt.begin();
+                    while (it != gt.end()) {
+                        int s1 = it->first, nlinks = it->second;
+                        gt.erase(it++);
+                        if (nlinks < o.min_read_pair || !region_exists(s1)) continue;
+                        std::vector<int> snodes;
+                        if (tail != s1) {
+                            auto a = graph.find(s1); if (a != graph.end()) a->second.erase(tail);
+                            auto b = graph.find(tail); if (b != graph.end()) b->second.erase(s1);
+                            snodes.push_back(std::min(s1, tail));
+                            snodes.push_back(std::max(s1, tail));
+                        } else {
+                            snodes.push_back(s1);
+                        }
+                        newtails.push_back(s1);
+                        process_sv(snodes);
+                    }
+                    // NB: once the start vertex has been erased `ii` may already be end(); the reference
+                    // dereferences it regardless (UB that in practice compares against a non-vertex word).
+                    if (ii != graph.end() && tail == ii->first) {
+                        graph.erase(ii++);
+                        need_inc = false;
+                    } else {
+                        graph.erase(tail);
+                    }
+                }
+                tails.swap(newtails);
+            }
+            if (need_inc) ++ii;
+        }
+        for (int i : active)
+            if (is_region_final(i)) clear_region(i);
+        graph.clear();
+    }
+
+    // ---- BreakDancer.cpp:44-84 ------------------------------------------------------------------------------------------------------
+    double prob_score(int total_region_size, std::map<size_t, int> const& rc, int type) {
+        double lambda, logp = 0.0, err = 0.0;
+        for (auto const& kv : rc) {
+            Lib const& lc = cfg.libs[kv.first];
+            uint32_t n = hist[lc.index][type];
+            lambda = double(total_region_size) * (double(n) / double(covered_ref_len));
+            lambda = std::max(1.0e-10, lambda);
+            double tmp_a = log(poisson_upper_tail(lambda, kv.second)) - err;
+            double tmp_b = logp + tmp_a;
+            err = (tmp_b - logp) - tmp_a;
+            logp = tmp_b;
+        }
+        if (o.fisher && logp < 0) {
+            // Boost's chi_squared cdf throws on a non-finite argument; the reference catches, warns and keeps logp (:71-81)
+            if (std::isfinite(-2 * logp)) {
+                double fisherP = chisq_upper_tail(2.0 * rc.size(), -2 * logp);
+                logp = fisherP > exp(-99.0) ? log(fisherP) : -99;
+            }
+        }
+        return logp;
+    }
+
+    std::string sv_type(int flag) const {  // Options.cpp:105-119
+        if (o.illumina_long_insert) {
+            switch (flag) { case ARP_FF: return "INV"; case ARP_SMALL_INSERT: return "INS"; case ARP_RF: return "DEL";
+                            case ARP_RR: return "INV"; case ARP_CTX: return "CTX"; default: return ""; }
+        }
+        switch (flag) { case ARP_FF: return "INV"; case ARP_LARGE_INSERT: return "DEL"; case ARP_SMALL_INSERT: return "INS";
+                        case ARP_RF: return "ITX"; case ARP_RR: return "INV"; case ARP_CTX: return "CTX"; default: return ""; }
+    }
+
+    // ---- BreakDancer.cpp:348-512 + SvBuilder.cpp:18-118 ------------------------------------------------------------------------------
+    void process_sv(std::vector<int> const& snodes) {
+        int n = (int)snodes.size();
+        Region const* reg[2] = {nullptr, nullptr};
+        for (int i = 0; i < n; ++i) reg[i] = regions[snodes[i]];
+
+        // SvBuilder ctor
+        int num_pairs = 0;
+        int flag_counts[NFLAGS] = {0};
+        std::map<size_t, int> type_lib_rc[NFLAGS], type_lib_span[NFLAGS];
+        std::map<uint64_t, int> observed;
+        std::vector<uint64_t> reads_to_free;
+        std::vector<int> support;
+        int fwd[2] = {0, 0}, rv[2] = {0, 0}, chr[2] = {0, 0}, pos[2] = {0, 0};
+        for (int i = 0; i < n; ++i) {
+            for (int idx : reg[i]->reads) {
+                if (!read_exists(idx)) continue;  // region_reads_range filter (ReadRegionData.cpp:201-205)
+                Rec const& a = merged[idx];
+                auto ins = observed.insert(std::make_pair(a.name, idx));
+                if (!ins.second) {
+                    ++flag_counts[a.flag];
+                    ++type_lib_rc[a.flag][a.lib];
+                    type_lib_span[a.flag][a.lib] += a.abs_isize;
+                    ++num_pairs;
+                    reads_to_free.push_back(a.name);
+                    support.push_back(idx);
+                    support.push_back(ins.first->second);
+                    observed.erase(ins.first);
+                }
+            }
+            fwd[i] = reg[i]->fwd;
+            rv[i] = reg[i]->rev;
+        }
+        int flag = NA;  // choose_sv_flag: first maximum
+        {
+            int best = 0;
+            for (int f = 0; f < NFLAGS; ++f) if (flag_counts[f] > flag_counts[best]) best = f;
+            if (flag_counts[best] > 0) flag = best;
+        }
+        chr[0] = reg[0]->chr; pos[0] = reg[0]->start; pos[1] = reg[0]->end;
+        if (n == 2) {
+            if (flag == ARP_RF) pos[1] = reg[1]->end + max_readlen - 5;
+            else if (flag == ARP_FF) { pos[0] = pos[1]; pos[1] = reg[1]->end + max_readlen - 5; }
+            else if (flag == ARP_RR) pos[1] = reg[1]->start;
+            else { pos[0] = pos[1]; pos[1] = reg[1]->start; }
+            chr[1] = reg[1]->chr;
+        } else {
+            fwd[1] = fwd[0]; rv[1] = rv[0]; chr[1] = reg[0]->chr; pos[1] = reg[0]->end;
+        }
+
+        // remove paired reads from the regions (BreakDancer.cpp:363-368)
+        for (int i = 0; i < n; ++i) {
+            std::vector<int> keep;
+            for (int idx : regions[snodes[i]]->reads)
+                if (read_exists(idx) && observed.count(merged[idx].name) != 0) keep.push_back(idx);
+            regions[snodes[i]]->reads.swap(keep);
+        }
+        if (num_pairs < o.min_read_pair) return;
+        if (flag_counts[flag] < o.min_read_pair) return;
+
+        Counts acc;
+        if (n == 2) {  // ReadRegionData.cpp:70-78
+            size_t b = snodes[0], e = snodes[1];
+            for (size_t i = b; i < std::min(e, roi_map.size()); ++i) {
+                counts_add(acc, roi_map[i]);
+                if (i > b && i < fr_map.size()) counts_add(acc, fr_map[i]);
+            }
+        }
+        std::map<std::string, float> copy_number;  // SvBuilder.cpp:75-87
+        float cn_sum = 0.0f;
+        for (auto const& kv : acc) {
+            copy_number[kv.first] = kv.second / (read_density.at(kv.first) * float(pos[1] - pos[0])) * 2.0f;
+            cn_sum += copy_number[kv.first];
+        }
+        cn_sum /= 2.0f * acc.size();
+        float allele_frequency = 1 - cn_sum;
+
+        if (flag != ARP_RF && flag != ARP_RR && pos[0] + max_readlen - 5 < pos[1]) pos[0] += max_readlen - 5;
+
+        std::string sptype;
+        float diff = 0;
+        if (o.cn_lib) {
+            for (auto const& kv : type_lib_rc[flag]) {
+                Lib const& lc = cfg.libs[kv.first];
+                std::string cn_str = "NA";
+                if (flag != ARP_CTX) {
+                    auto f = copy_number.find(lc.name);
+                    if (f != copy_number.end()) {
+                        std::stringstream s;
+                        s << std::fixed << std::setprecision(2) << f->second;
+                        cn_str = s.str();
+                    }
+                }
+                if (!sptype.empty()) sptype += ":";
+                sptype += lc.name + "|" + std::to_string(kv.second) + "," + cn_str;
+                diff += float(type_lib_span[flag][kv.first]) - float(type_lib_rc[flag][kv.first]) * lc.mean_insertsize;
+            }
+        } else {
+            std::map<std::string, int> bam_rc;
+            for (auto const& kv : type_lib_rc[flag]) {
+                Lib const& lc = cfg.libs[kv.first];
+                bam_rc[lc.bam_file] += kv.second;
+                diff += float(type_lib_span[flag][kv.first]) - float(type_lib_rc[flag][kv.first]) * lc.mean_insertsize;
+            }
+            for (auto const& kv : bam_rc) {
+                if (!sptype.empty()) sptype += ":";
+                sptype += kv.first + "|" + std::to_string(kv.second);
+            }
+            if (sptype.empty()) sptype = "NA";
+        }
+        int diffspan = int(diff / float(flag_counts[flag]) + 0.5);
+
+        int total_region_size = 0;
+        for (int s : snodes) total_region_size += regions[s]->size();
+        double logp = prob_score(total_region_size, type_lib_rc[flag], flag);
+        double phred_tmp = -10 * logp / log(10);
+        int phred = phred_tmp > 99 ? 99 : int(phred_tmp + 0.5);
+        ++pos[0];
+        ++pos[1];
+
+        SvOut sv;
+        for (int i = 0; i < 2; ++i) { sv.chr[i] = chr[i]; sv.pos[i] = pos[i]; sv.fwd[i] = fwd[i]; sv.rev[i] = rv[i]; }
+        sv.flag = flag; sv.size = diffspan; sv.score = phred; sv.num_reads = flag_counts[flag];
+        sv.logp = logp; sv.af = allele_frequency; sv.printed = phred > o.score_threshold;
+        for (auto const& kv : type_lib_rc[flag]) sv.lib_counts.push_back({(int)kv.first, kv.second});
+        for (auto const& kv : copy_number) {
+            int key = -1;
+            if (o.cn_lib) key = (int)cfg.lib_names_to_indices.at(kv.first);
+            else key = (int)(std::find(cfg.bam_files.begin(), cfg.bam_files.end(), kv.first) - cfg.bam_files.begin());
+            sv.copy_number.push_back({key, kv.second});
+        }
+        sv.support = support;
+        svs.push_back(sv);
+
+        if (sv.printed) {
+            auto tname = [&](int t) { return (t >= 0 && (size_t)t < targets.size()) ? targets[t] : std::to_string(t); };
+            out << tname(chr[0]) << "\t" << pos[0] << "\t" << fwd[0] << "+" << rv[0] << "-"
+                << "\t" << tname(chr[1]) << "\t" << pos[1] << "\t" << fwd[1] << "+" << rv[1] << "-"
+                << "\t" << sv_type(flag) << "\t" << diffspan << "\t" << phred << "\t" << flag_counts[flag] << "\t" << sptype;
+            if (o.print_af) out << "\t" << allele_frequency;
+            if (!o.cn_lib && flag != ARP_CTX) {
+                for (auto const& b : cfg.bam_files) {
+                    auto f = copy_number.find(b);
+                    if (f == copy_number.end()) out << "\tNA";
+                    else { out << "\t"; out << std::fixed; out << std::setprecision(2) << f->second; }
+                }
+            }
+            out << "\n";
+        }
+        for (uint64_t nm : reads_to_free) read_regions.erase(nm);
+    }
+
+    int run() {
+        try {
+            pass1();
+            header();
+            merge();
+            cls.assign(merged.size(), 0);
+            for (size_t i = 0; i < merged.size(); ++i) push_read((int)i);
+            if (!cur.empty()) process_breakpoint();  // BreakDancer.cpp:536-541
+            build_connection();
+            return 0;
+        } catch (std::exception const& e) {
+            err = e.what();
+            return 1;
+        }
+    }
+};
+
+}  // namespace
+
+// ---- flat C API for ctypes -------------------------------------------------------------------------------------
+extern "C" {
+
+void* bdo_new(const char* config_text, const int32_t* opts14) {
+    Oracle* h = new Oracle;
+    memcpy(&h->o, opts14, sizeof(Opts));
+    try {
+        h->cfg.parse(config_text, h->o.cut_sd);
+        h->streams.resize(h->cfg.bam_files.size());
+    } catch (std::exception const& e) {
+        h->err = e.what();
+    }
+    return h;
+}
+void bdo_free(void* p) { delete (Oracle*)p; }
+const char* bdo_error(void* p) { return ((Oracle*)p)->err.c_str(); }
+int bdo_nlibs(void* p) { return (int)((Oracle*)p)->cfg.libs.size(); }
+int bdo_nbams(void* p) { return (int)((Oracle*)p)->cfg.bam_files.size(); }
+int bdo_w0(void* p) { return ((Oracle*)p)->cfg.max_read_window_size; }
+const char* bdo_lib_name(void* p, int i) { return ((Oracle*)p)->cfg.libs[i].name.c_str(); }
+const char* bdo_bam_name(void* p, int i) { return ((Oracle*)p)->cfg.bam_files[i].c_str(); }
+// out: mean,std,upper,lower,readlen (float) ; iout: min_mapq, bam_index
+void bdo_lib_params(void* p, int i, float* out, int32_t* iout) {
+    Lib const& l = ((Oracle*)p)->cfg.libs[i];
+    out[0] = l.mean_insertsize; out[1] = l.std_insertsize; out[2] = l.uppercutoff; out[3] = l.lowercutoff; out[4] = l.readlens;
+    iout[0] = l.min_mapping_quality; iout[1] = (int32_t)l.bam_file_index;
+}
+int bdo_lib_of_readgroup(void* p, const char* rg) { return (int)((Oracle*)p)->cfg.lib_of_readgroup(rg); }
+void bdo_set_targets(void* p, int n, const char** names) {
+    Oracle* h = (Oracle*)p;
+    h->targets.assign(names, names + n);
+}
+// one physical BAM's primary+aligned records in file order; lib already resolved through bdo_lib_of_readgroup
+void bdo_set_stream(void* p, int bam, int64_t n, const int32_t* tid, const int32_t* pos, const int32_t* mtid,
+                    const int32_t* mpos, const int32_t* isize, const uint16_t* flag, const int32_t* qlen,
+                    const uint8_t* bdqual, const int32_t* lib, const uint64_t* name) {
+    Oracle* h = (Oracle*)p;
+    std::vector<Rec>& v = h->streams[bam];
+    v.resize(n);
+    for (int64_t i = 0; i < n; ++i) {
+        Rec& r = v[i];
+        r.tid = tid[i]; r.pos = pos[i]; r.mtid = mtid[i]; r.mpos = mpos[i]; r.abs_isize = abs(isize[i]); r.qlen = qlen[i];
+        r.sam = flag[i]; r.bdqual = bdqual[i]; r.lib = (uint32_t)lib[i]; r.name = name[i]; r.bam = bam; r.src = i; r.flag = NA;
+    }
+}
+int bdo_run(void* p) { return ((Oracle*)p)->run(); }
+
+int64_t bdo_text(void* p, char* buf, int64_t cap) {
+    std::string s = ((Oracle*)p)->out.str();
+    if (buf && cap > 0) { size_t n = std::min((size_t)cap, s.size()); memcpy(buf, s.data(), n); }
+    return (int64_t)s.size();
+}
+// summary: [covered_ref_len, W, n_merged, n_regions_created, n_svs]
+void bdo_summary(void* p, int64_t* out5) {
+    Oracle* h = (Oracle*)p;
+    out5[0] = h->covered_ref_len; out5[1] = h->W; out5[2] = (int64_t)h->merged.size();
+    out5[3] = (int64_t)h->region_log.size(); out5[4] = (int64_t)h->svs.size();
+}
+void bdo_counters(void* p, uint32_t* lib_cnt, uint32_t* bam_cnt, uint32_t* hist /*[nlibs][11]*/, float* seqcov) {
+    Oracle* h = (Oracle*)p;
+    for (size_t i = 0; i < h->cfg.libs.size(); ++i) {
+        lib_cnt[i] = h->lib_read_count[i];
+        seqcov[i] = h->seqcov[i];
+        for (int f = 0; f < NFLAGS; ++f) hist[i * NFLAGS + f] = h->hist[i][f];
+    }
+    for (size_t b = 0; b < h->cfg.bam_files.size(); ++b) bam_cnt[b] = h->read_count_per_bam[b];
+}
+// merged order + per-record class byte (flag | pass<<4 | proper<<5)
+void bdo_merged(void* p, int32_t* bam, int64_t* src, uint8_t* cls) {
+    Oracle* h = (Oracle*)p;
+    for (size_t i = 0; i < h->merged.size(); ++i) { bam[i] = h->merged[i].bam; src[i] = h->merged[i].src; cls[i] = h->cls[i]; }
+}
+// regions as created: [index, chr, start, end, normal_read_pairs, fwd, rev, nreads, stored] x n
+void bdo_regions(void* p, int32_t* out9) {
+    Oracle* h = (Oracle*)p;
+    for (size_t i = 0; i < h->region_log.size(); ++i) {
+        Region const& r = h->region_log[i];
+        int32_t* o = out9 + 9 * i;
+        o[0] = r.index; o[1] = r.chr; o[2] = r.start; o[3] = r.end; o[4] = r.normal_read_pairs; o[5] = r.fwd; o[6] = r.rev;
+        o[7] = (int32_t)r.reads.size(); o[8] = h->region_log_stored[i];
+    }
+}
+// SV table: ints [chr0,pos0,fwd0,rev0,chr1,pos1,fwd1,rev1,flag,size,score,num_reads,printed,nlib,ncn] x n ; doubles [logp, af] x n
+void bdo_svs(void* p, int32_t* iout15, double* dout2) {
+    Oracle* h = (Oracle*)p;
+    for (size_t i = 0; i < h->svs.size(); ++i) {
+        SvOut const& s = h->svs[i];
+        int32_t* o = iout15 + 15 * i;
+        o[0] = s.chr[0]; o[1] = s.pos[0]; o[2] = s.fwd[0]; o[3] = s.rev[0];
+        o[4] = s.chr[1]; o[5] = s.pos[1]; o[6] = s.fwd[1]; o[7] = s.rev[1];
+        o[8] = s.flag; o[9] = s.size; o[10] = s.score; o[11] = s.num_reads; o[12] = s.printed;
+        o[13] = (int32_t)s.lib_counts.size(); o[14] = (int32_t)s.copy_number.size();
+        dout2[2 * i] = s.logp; dout2[2 * i + 1] = (double)s.af;
+    }
+}
+// flattened per-SV (lib,count) and (key,cn) lists, concatenated in SV order
+void bdo_sv_lists(void* p, int32_t* lib_counts2, int32_t* cn_keys, float* cn_vals) {
+    Oracle* h = (Oracle*)p;
+    size_t a = 0, b = 0;
+    for (auto const& s : h->svs) {
+        for (auto const& lc : s.lib_counts) { lib_counts2[2 * a] = lc.first; lib_counts2[2 * a + 1] = lc.second; ++a; }
+        for (auto const& c : s.copy_number) { cn_keys[b] = c.first; cn_vals[b] = c.second; ++b; }
+    }
+}
+double bdo_poisson_upper_tail(double lambda, int k) { return poisson_upper_tail(lambda, k); }
+double bdo_chisq_upper_tail(double df, double x) { return chisq_upper_tail(df, x); }
+int bdo_classify(int sam, int tid, int mtid, int pos, int mpos, int abs_isize, float upper, float lower) {
+    Rec a{}; a.sam = (uint16_t)sam; a.tid = tid; a.mtid = mtid; a.pos = pos; a.mpos = mpos; a.abs_isize = abs_isize;
+    Lib l; l.uppercutoff = upper; l.lowercutoff = lower;
+    return classify(a, l);
+}
+int bdo_translate_token(const char* tok) { return (int)translate_token(tok); }
+
+}  // extern "C"
