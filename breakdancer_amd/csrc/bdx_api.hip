@@ -1,0 +1,614 @@
+// libbdx: context, HBM-resident read store, stage orchestration and the extern "C" boundary (include/bdx.h).
+//
+// One context = one GPU = one HIP stream.  The whole record stream stays resident in HBM (a 30x human
+// genome is ~33 GB of SoA, well inside 288 GB), so pass 1 and pass 2 of the reference collapse into one
+// read of the data: K1 -> finalize -> K2 -> K3 -> K4 on the device, one small readback, the host walk,
+// K5 for the scores.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bdx.h"
+#include "bdx_dev.h"
+#include "bdx_k3.h"
+#include "bdx_scan.h"
+#include "bdx_walk.h"
+
+using namespace bdx;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t b) {
+        if (b <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        size_t want = b + b / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct PinBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t b) {
+        if (b <= bytes) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+        size_t want = b + b / 8 + 256;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+constexpr int kNumStages = 8;
+constexpr int kK1MaxGrid = 2048;  // 256 CUs x 8 resident workgroups; the rest of the tiles are grid-strided
+
+}  // namespace
+
+struct bdx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bdx_opts opts{};
+    std::vector<bdx_lib> libs;
+    int nlibs = 0, nbams = 0, ntids = 0, nkeys = 0, w0 = 0;
+    std::string err;
+
+    // resident reads
+    ReadsSoA d{};
+    size_t n = 0, cap = 0;
+    bool adopted = false;
+    DevBuf b_tid, b_pos, b_mtid, b_mpos, b_isize, b_flag, b_qlen, b_mapq, b_lib, b_bam, b_key;
+
+    // stage buffers
+    DevBuf b_libs, b_cls, b_tile_tot, b_tile_pre, b_tile_mono, b_tile_mono_sum, b_blk_cnt, b_cnt, b_p1;
+    DevBuf b_c_tid, b_c_pos, b_c_isize, b_c_meta, b_c_key, b_c_nn, b_c_pk;
+    DevBuf b_cand, b_pre_q, b_pre_rev, b_pre_nonctx, b_c_first, b_c_maxq, b_c_accept, b_c_n, b_c_rev, b_c_nonctx,
+        b_c_nnormal, b_c_rid, b_r_rec, b_r_pk, b_ws_u4, b_ws_u32, b_totals, b_counts;
+    DevBuf b_bcnt, b_boff, b_bcur, b_e_key, b_e_idx, b_partner, b_t_key, b_t_idx, b_g_rec;
+    DevBuf b_lam, b_k, b_logt;
+    PinBuf h_p1, h_cnt, h_counts, h_regs, h_pk, h_groups, h_terms;
+
+    // results
+    bool ran = false;
+    Pass1 p1{};
+    StageCounts counts{};
+    std::vector<uint32_t> cnt;  // hist[nlibs*11], lib_cnt[nlibs], bam_cnt[nbams]
+    std::vector<float> seqcov, lib_density, key_density;
+    std::vector<HostRegion> regions;
+    std::vector<uint32_t> r_pk;
+    std::vector<GroupPart> parts;
+    WalkResult walk;
+    uint32_t n_printed = 0;
+    float stage_ms[kNumStages] = {0};
+    hipEvent_t ev[8] = {nullptr};
+};
+
+namespace {
+
+int fail(bdx_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+int hipfail(bdx_ctx* c, hipError_t e, const char* what) {
+    return fail(c, BDX_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPCHK(ctx, expr)                                   \
+    do {                                                    \
+        hipError_t _e = (expr);                             \
+        if (_e != hipSuccess) return hipfail(ctx, _e, #expr); \
+    } while (0)
+
+size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+int alloc_reads(bdx_ctx* c, size_t cap) {
+    cap = round_up(std::max<size_t>(cap, 1), kTile);
+    if (cap <= c->cap) return BDX_OK;
+    struct Col { DevBuf* b; size_t esz; const void** slot; };
+    Col cols[] = {{&c->b_tid, 4, (const void**)&c->d.tid},     {&c->b_pos, 4, (const void**)&c->d.pos},
+                  {&c->b_mtid, 4, (const void**)&c->d.mtid},   {&c->b_mpos, 4, (const void**)&c->d.mpos},
+                  {&c->b_isize, 4, (const void**)&c->d.isize}, {&c->b_flag, 2, (const void**)&c->d.flag},
+                  {&c->b_qlen, 2, (const void**)&c->d.qlen},   {&c->b_mapq, 1, (const void**)&c->d.mapq},
+                  {&c->b_lib, 1, (const void**)&c->d.lib},     {&c->b_bam, 1, (const void**)&c->d.bam},
+                  {&c->b_key, 8, (const void**)&c->d.key}};
+    for (Col& col : cols) {
+        DevBuf nb;
+        HIPCHK(c, nb.ensure(cap * col.esz));
+        if (c->n) HIPCHK(c, hipMemcpyAsync(nb.p, col.b->p, c->n * col.esz, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        col.b->release();
+        *col.b = nb;
+        *col.slot = nb.p;
+    }
+    c->cap = cap;
+    return BDX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void bdx_opts_default(bdx_opts* o) {  // common/Options.cpp:27-41
+    if (!o) return;
+    o->min_len = 7; o->cut_sd = 3; o->max_sd = 1000000000; o->min_map_qual = 35; o->min_read_pair = 2;
+    o->seq_coverage_lim = 1000; o->buffer_size = 100; o->transchr_rearrange = 0; o->fisher = 0;
+    o->illumina_long_insert = 0; o->cn_lib = 0; o->print_af = 0; o->score_threshold = 30; o->chr_restricted = 0;
+}
+
+const char* bdx_strerror(int code) {
+    switch (code) {
+        case BDX_OK: return "ok";
+        case BDX_EINVAL: return "invalid argument";
+        case BDX_ENOMEM: return "out of memory";
+        case BDX_EHIP: return "HIP runtime error";
+        case BDX_ESTATE: return "call out of order";
+        case BDX_ELIMIT: return "limit exceeded";
+        default: return "internal error";
+    }
+}
+const char* bdx_last_error(const bdx_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
+int bdx_device(const bdx_ctx* ctx) { return ctx ? ctx->device : -1; }
+void* bdx_stream(const bdx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int bdx_create(bdx_ctx** out, const bdx_opts* opts, const bdx_lib* libs, int nlibs, int nbams, int ntids,
+               int max_read_window_size0, int device) {
+    if (!out || !opts || !libs || nlibs < 1 || nbams < 1) return BDX_EINVAL;
+    if (nlibs > 255 || nbams > 254) return BDX_ELIMIT;
+    const int nkeys = opts->cn_lib ? nlibs : nbams;
+    if (nkeys > 60) return BDX_ELIMIT;
+    for (int i = 0; i < nlibs; ++i)
+        if (libs[i].bam_index < 0 || libs[i].bam_index >= nbams) return BDX_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return BDX_EHIP;
+    if (hipSetDevice(device) != hipSuccess) return BDX_EHIP;
+    bdx_ctx* c = new (std::nothrow) bdx_ctx;
+    if (!c) return BDX_ENOMEM;
+    c->device = device;
+    c->opts = *opts;
+    c->libs.assign(libs, libs + nlibs);
+    c->nlibs = nlibs; c->nbams = nbams; c->ntids = ntids; c->nkeys = nkeys; c->w0 = max_read_window_size0;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return BDX_EHIP; }
+    for (auto& e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) { delete c; return BDX_EHIP; }
+    std::vector<DevLib> dl(nlibs);
+    for (int i = 0; i < nlibs; ++i) {
+        dl[i].upper = libs[i].uppercutoff;
+        dl[i].lower = libs[i].lowercutoff;
+        dl[i].min_mapq = libs[i].min_mapping_quality < 0 ? opts->min_map_qual : libs[i].min_mapping_quality;
+        dl[i].key = opts->cn_lib ? i : libs[i].bam_index;
+    }
+    if (c->b_libs.ensure(nlibs * sizeof(DevLib)) != hipSuccess ||
+        hipMemcpy(c->b_libs.p, dl.data(), nlibs * sizeof(DevLib), hipMemcpyHostToDevice) != hipSuccess) {
+        bdx_destroy(c);
+        return BDX_EHIP;
+    }
+    *out = c;
+    return BDX_OK;
+}
+
+void bdx_destroy(bdx_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->b_tid, &c->b_pos, &c->b_mtid, &c->b_mpos, &c->b_isize, &c->b_flag, &c->b_qlen, &c->b_mapq, &c->b_lib,
+                      &c->b_bam, &c->b_key, &c->b_libs, &c->b_cls, &c->b_tile_tot, &c->b_tile_pre, &c->b_tile_mono,
+                      &c->b_tile_mono_sum, &c->b_blk_cnt, &c->b_cnt, &c->b_p1, &c->b_c_tid, &c->b_c_pos, &c->b_c_isize,
+                      &c->b_c_meta, &c->b_c_key, &c->b_c_nn, &c->b_c_pk, &c->b_cand, &c->b_pre_q, &c->b_pre_rev,
+                      &c->b_pre_nonctx, &c->b_c_first, &c->b_c_maxq, &c->b_c_accept, &c->b_c_n, &c->b_c_rev, &c->b_c_nonctx,
+                      &c->b_c_nnormal, &c->b_c_rid, &c->b_r_rec, &c->b_r_pk, &c->b_ws_u4, &c->b_ws_u32, &c->b_totals,
+                      &c->b_counts, &c->b_bcnt, &c->b_boff, &c->b_bcur, &c->b_e_key, &c->b_e_idx, &c->b_partner, &c->b_t_key,
+                      &c->b_t_idx, &c->b_g_rec, &c->b_lam, &c->b_k, &c->b_logt};
+    for (DevBuf* b : bufs) b->release();
+    PinBuf* pins[] = {&c->h_p1, &c->h_cnt, &c->h_counts, &c->h_regs, &c->h_pk, &c->h_groups, &c->h_terms};
+    for (PinBuf* b : pins) b->release();
+    for (auto& e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int bdx_reserve(bdx_ctx* c, size_t n_reads) {
+    if (!c) return BDX_EINVAL;
+    if (c->adopted) return fail(c, BDX_ESTATE, "reads were adopted from the caller");
+    HIPCHK(c, hipSetDevice(c->device));
+    return alloc_reads(c, n_reads);
+}
+
+int bdx_push(bdx_ctx* c, const bdx_batch* b) {
+    if (!c || !b) return BDX_EINVAL;
+    if (c->adopted) return fail(c, BDX_ESTATE, "reads were adopted from the caller");
+    if (b->n == 0) return BDX_OK;
+    if (!b->tid || !b->pos || !b->mtid || !b->mpos || !b->isize || !b->flag || !b->qlen || !b->mapq || !b->lib || !b->bam ||
+        !b->name_key)
+        return fail(c, BDX_EINVAL, "null array in batch");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->n + b->n > c->cap) {
+        int rc = alloc_reads(c, std::max(c->n + b->n, c->cap * 2));
+        if (rc != BDX_OK) return rc;
+    }
+    const size_t o = c->n, n = b->n;
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.tid + o), b->tid, n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.pos + o), b->pos, n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.mtid + o), b->mtid, n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.mpos + o), b->mpos, n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.isize + o), b->isize, n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.flag + o), b->flag, n * 2, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.qlen + o), b->qlen, n * 2, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.mapq + o), b->mapq, n, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.lib + o), b->lib, n, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.bam + o), b->bam, n, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.key + o), b->name_key, n * 8, hipMemcpyHostToDevice, s));
+    c->n += n;
+    c->ran = false;
+    return BDX_OK;
+}
+
+int bdx_set_device_reads(bdx_ctx* c, const bdx_batch* b) {
+    if (!c || !b) return BDX_EINVAL;
+    if (c->n && !c->adopted) return fail(c, BDX_ESTATE, "context already holds pushed reads");
+    const void* ptrs[] = {b->tid, b->pos, b->mtid, b->mpos, b->isize, b->flag, b->qlen, b->mapq, b->lib, b->bam, b->name_key};
+    for (const void* p : ptrs)
+        if (b->n && (!p || ((uintptr_t)p & 15))) return fail(c, BDX_EINVAL, "device arrays must be non-null and 16-byte aligned");
+    c->d.tid = b->tid; c->d.pos = b->pos; c->d.mtid = b->mtid; c->d.mpos = b->mpos; c->d.isize = b->isize;
+    c->d.flag = b->flag; c->d.qlen = b->qlen; c->d.mapq = b->mapq; c->d.lib = b->lib; c->d.bam = b->bam; c->d.key = b->name_key;
+    c->n = b->n;
+    c->cap = b->n;
+    c->adopted = true;
+    c->ran = false;
+    return BDX_OK;
+}
+
+int bdx_run(bdx_ctx* c) {
+    if (!c) return BDX_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const auto t_begin = std::chrono::steady_clock::now();
+    const int nlibs = c->nlibs, nbams = c->nbams, nkeys = c->nkeys;
+    const int ncols = 2 + nkeys, ncnt = nlibs * kNumFlags + nlibs + nbams;
+    if (c->n >= ((size_t)1 << 32) * 256) return fail(c, BDX_ELIMIT, "too many reads");
+    const uint32_t ntiles = (uint32_t)((c->n + kTile - 1) / kTile);
+    const uint32_t tstride = (uint32_t)round_up(std::max<uint32_t>(ntiles, 4), 4);
+    const int grid1 = (int)std::min<uint32_t>(ntiles, kK1MaxGrid);
+    c->ran = false;
+    c->regions.clear(); c->r_pk.clear(); c->parts.clear();
+    c->walk = WalkResult();
+    c->n_printed = 0;
+    memset(&c->counts, 0, sizeof(c->counts));
+
+    // ---- stage buffers --------------------------------------------------------------------------------
+    HIPCHK(c, c->b_cls.ensure(std::max<size_t>(c->n, 16)));
+    HIPCHK(c, c->b_tile_tot.ensure((size_t)ncols * tstride * 4));
+    HIPCHK(c, c->b_tile_pre.ensure((size_t)ncols * tstride * 4));
+    HIPCHK(c, c->b_tile_mono.ensure((size_t)nbams * 4 * tstride * 4));
+    HIPCHK(c, c->b_tile_mono_sum.ensure((size_t)nbams * tstride * 8));
+    HIPCHK(c, c->b_blk_cnt.ensure((size_t)std::max(grid1, 1) * ncnt * 4));
+    HIPCHK(c, c->b_cnt.ensure((size_t)ncnt * 4));
+    HIPCHK(c, c->b_p1.ensure(sizeof(Pass1)));
+    HIPCHK(c, c->h_p1.ensure(sizeof(Pass1)));
+    HIPCHK(c, c->h_cnt.ensure((size_t)ncnt * 4));
+    HIPCHK(c, c->h_counts.ensure(sizeof(StageCounts)));
+    HIPCHK(c, c->b_counts.ensure(sizeof(StageCounts)));
+    HIPCHK(c, hipMemsetAsync(c->b_tile_tot.p, 0, (size_t)ncols * tstride * 4, s));
+    HIPCHK(c, hipMemsetAsync(c->b_p1.p, 0, sizeof(Pass1), s));
+    HIPCHK(c, hipMemsetAsync(c->b_counts.p, 0, sizeof(StageCounts), s));
+
+    // ---- K1 + finalize ----------------------------------------------------------------------------------
+    HIPCHK(c, hipEventRecord(c->ev[0], s));
+    K1Params k1{};
+    k1.r = c->d; k1.n = c->n; k1.ntiles = ntiles; k1.tstride = tstride;
+    k1.nlibs = nlibs; k1.nbams = nbams; k1.nkeys = nkeys;
+    k1.max_sd = c->opts.max_sd; k1.opt_t = c->opts.transchr_rearrange; k1.opt_l = c->opts.illumina_long_insert;
+    k1.libs = c->b_libs.as<DevLib>(); k1.cls = c->b_cls.as<uint8_t>(); k1.tile_tot = c->b_tile_tot.as<uint32_t>();
+    k1.tile_mono = c->b_tile_mono.as<int32_t>(); k1.tile_mono_sum = c->b_tile_mono_sum.as<long long>();
+    k1.blk_cnt = c->b_blk_cnt.as<uint32_t>();
+    if (ntiles) launch_k1(k1, grid1, k1_lds_bytes(nlibs, nbams, nkeys), s);
+    HIPCHK(c, hipEventRecord(c->ev[1], s));
+    FinalizeParams fp{};
+    fp.ntiles = ntiles; fp.tstride = tstride; fp.nblk = ntiles ? grid1 : 0;
+    fp.nlibs = nlibs; fp.nbams = nbams; fp.nkeys = nkeys; fp.ncols = ncols; fp.ncnt = ncnt; fp.w0 = c->w0;
+    fp.tile_tot = k1.tile_tot; fp.tile_pre = c->b_tile_pre.as<uint32_t>(); fp.tile_mono = k1.tile_mono;
+    fp.tile_mono_sum = k1.tile_mono_sum; fp.blk_cnt = k1.blk_cnt; fp.cnt = c->b_cnt.as<uint32_t>(); fp.p1 = c->b_p1.as<Pass1>();
+    launch_finalize(fp, s);
+    HIPCHK(c, hipMemcpyAsync(c->h_p1.p, c->b_p1.p, sizeof(Pass1), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->h_cnt.p, c->b_cnt.p, (size_t)ncnt * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipGetLastError());
+    c->p1 = *c->h_p1.as<Pass1>();
+    c->cnt.assign(c->h_cnt.as<uint32_t>(), c->h_cnt.as<uint32_t>() + ncnt);
+    const uint32_t na = c->p1.n_anom;
+
+    // host-side scalars of main() (BreakDancerMax.cpp:88-107, BamSummary.cpp:140-149), float32 like the reference
+    const uint32_t* hist = c->cnt.data();
+    const uint32_t* lib_cnt = hist + nlibs * kNumFlags;
+    const uint32_t* bam_cnt = lib_cnt + nlibs;
+    const uint32_t covered = c->p1.covered_ref_len;
+    c->seqcov.assign(nlibs, 0.f);
+    c->lib_density.assign(nlibs, 0.f);
+    c->key_density.assign(nkeys, 0.000001f);
+    for (int i = 0; i < nlibs; ++i) {
+        float covg = 0;
+        if (lib_cnt[i] != 0 && covered != 0) covg = float(lib_cnt[i]) * c->libs[i].readlens / covered;
+        c->seqcov[i] = covg;
+        float dens = 0.000001f;
+        if (c->opts.cn_lib) {
+            if (lib_cnt[i] != 0) dens = float(lib_cnt[i]) / covered;
+        } else {
+            dens = float(bam_cnt[c->libs[i].bam_index]) / covered;
+        }
+        c->lib_density[i] = dens;
+        c->key_density[c->opts.cn_lib ? i : c->libs[i].bam_index] = dens;
+    }
+
+    // ---- K2 .. K4 ------------------------------------------------------------------------------------------
+    HIPCHK(c, hipEventRecord(c->ev[2], s));
+    Compact cp{};
+    K3Arrays k3{};
+    K4Arrays k4{};
+    if (na) {
+        if (na > kMaxRegions) return fail(c, BDX_ELIMIT, "too many anomalous reads for the packed group key");
+        const size_t cap = na;
+        HIPCHK(c, c->b_c_tid.ensure(cap * 4)); HIPCHK(c, c->b_c_pos.ensure(cap * 4)); HIPCHK(c, c->b_c_isize.ensure(cap * 4));
+        HIPCHK(c, c->b_c_meta.ensure(cap * 4)); HIPCHK(c, c->b_c_key.ensure(cap * 8)); HIPCHK(c, c->b_c_nn.ensure(cap * 4));
+        HIPCHK(c, c->b_c_pk.ensure(cap * 4 * nkeys));
+        cp.tid = c->b_c_tid.as<int32_t>(); cp.pos = c->b_c_pos.as<int32_t>(); cp.isize = c->b_c_isize.as<int32_t>();
+        cp.meta = c->b_c_meta.as<uint32_t>(); cp.key = c->b_c_key.as<uint64_t>(); cp.nn = c->b_c_nn.as<uint32_t>();
+        cp.pk = c->b_c_pk.as<uint32_t>(); cp.cap = na;
+        K2Params k2{};
+        k2.r = c->d; k2.n = c->n; k2.ntiles = ntiles; k2.tstride = tstride; k2.nkeys = nkeys; k2.libs = k1.libs;
+        k2.cls = k1.cls; k2.tile_pre = fp.tile_pre; k2.c = cp;
+        launch_k2(k2, k2_lds_bytes(nkeys), s);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[3], s));
+    if (na) {
+        const size_t cap = na;
+        DevBuf* u32bufs[] = {&c->b_cand, &c->b_pre_q, &c->b_pre_rev, &c->b_pre_nonctx, &c->b_c_first, &c->b_c_maxq, &c->b_c_accept,
+                             &c->b_c_n, &c->b_c_rev, &c->b_c_nonctx, &c->b_c_nnormal, &c->b_c_rid};
+        for (DevBuf* b : u32bufs) HIPCHK(c, b->ensure(cap * 4));
+        HIPCHK(c, c->b_r_rec.ensure(cap * sizeof(RegionRec)));
+        HIPCHK(c, c->b_r_pk.ensure(cap * 2 * nkeys * 4));
+        const size_t nblk = scan_grid(na) + 1;
+        HIPCHK(c, c->b_ws_u4.ensure(nblk * sizeof(U4)));
+        HIPCHK(c, c->b_ws_u32.ensure(nblk * 4));
+        HIPCHK(c, c->b_totals.ensure(64));
+        k3.cap = na;
+        k3.cand = c->b_cand.as<int32_t>(); k3.pre_q = c->b_pre_q.as<uint32_t>(); k3.pre_rev = c->b_pre_rev.as<uint32_t>();
+        k3.pre_nonctx = c->b_pre_nonctx.as<uint32_t>(); k3.c_first = c->b_c_first.as<uint32_t>();
+        k3.c_maxq = c->b_c_maxq.as<int32_t>(); k3.c_accept = c->b_c_accept.as<uint32_t>(); k3.c_n = c->b_c_n.as<uint32_t>();
+        k3.c_rev = c->b_c_rev.as<uint32_t>(); k3.c_nonctx = c->b_c_nonctx.as<uint32_t>();
+        k3.c_nnormal = c->b_c_nnormal.as<uint32_t>(); k3.c_rid = c->b_c_rid.as<int32_t>();
+        k3.r_rec = c->b_r_rec.as<RegionRec>(); k3.r_pk = c->b_r_pk.as<uint32_t>();
+        k3.ws_u4 = c->b_ws_u4.as<U4>(); k3.head_total = (U4*)c->b_totals.p; k3.ws_u32 = c->b_ws_u32.as<uint32_t>();
+        k3.acc_total = (uint32_t*)((char*)c->b_totals.p + 32); k3.counts = c->b_counts.as<StageCounts>();
+        launch_k3(k3, cp, fp.p1, na, c->opts.min_len, c->opts.seq_coverage_lim, nkeys, s);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[4], s));
+    if (na) {
+        uint32_t nb = 1, lg = 0;
+        while (nb < (uint32_t)kMaxBuckets && (size_t)nb * 1536 < na) { nb <<= 1; ++lg; }
+        k4.nbuckets = nb; k4.log2b = lg;
+        HIPCHK(c, c->b_bcnt.ensure(nb * 4)); HIPCHK(c, c->b_boff.ensure((nb + 1) * 4)); HIPCHK(c, c->b_bcur.ensure(nb * 4));
+        HIPCHK(c, c->b_e_key.ensure((size_t)na * 8)); HIPCHK(c, c->b_e_idx.ensure((size_t)na * 4));
+        HIPCHK(c, c->b_partner.ensure((size_t)na * 4));
+        HIPCHK(c, c->b_t_key.ensure((size_t)na * 16)); HIPCHK(c, c->b_t_idx.ensure((size_t)na * 8));
+        k4.g_cap = na / 2 + 1;
+        HIPCHK(c, c->b_g_rec.ensure((size_t)k4.g_cap * sizeof(GroupRec)));
+        k4.bcnt = c->b_bcnt.as<uint32_t>(); k4.boff = c->b_boff.as<uint32_t>(); k4.bcur = c->b_bcur.as<uint32_t>();
+        k4.e_key = c->b_e_key.as<uint64_t>(); k4.e_idx = c->b_e_idx.as<uint32_t>(); k4.partner = c->b_partner.as<int32_t>();
+        k4.t_key = c->b_t_key.as<uint64_t>(); k4.t_idx = c->b_t_idx.as<int32_t>(); k4.g_rec = c->b_g_rec.as<GroupRec>();
+        launch_k4(k4, k3, cp, fp.p1, na, s);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[5], s));
+
+    // ---- readback ---------------------------------------------------------------------------------------------
+    if (na) {
+        HIPCHK(c, hipMemcpyAsync(c->h_counts.p, c->b_counts.p, sizeof(StageCounts), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        HIPCHK(c, hipGetLastError());
+        c->counts = *c->h_counts.as<StageCounts>();
+        if (c->counts.overflow) return fail(c, BDX_EINTERNAL, "group list overflow");
+        const uint32_t nr = c->counts.n_regions, ng = c->counts.n_groups;
+        HIPCHK(c, c->h_regs.ensure((size_t)std::max<uint32_t>(nr, 1) * sizeof(RegionRec)));
+        HIPCHK(c, c->h_pk.ensure((size_t)std::max<uint32_t>(nr, 1) * 2 * nkeys * 4));
+        HIPCHK(c, c->h_groups.ensure((size_t)std::max<uint32_t>(ng, 1) * sizeof(GroupRec)));
+        if (nr) {
+            HIPCHK(c, hipMemcpyAsync(c->h_regs.p, k3.r_rec, (size_t)nr * sizeof(RegionRec), hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(c->h_pk.p, k3.r_pk, (size_t)nr * 2 * nkeys * 4, hipMemcpyDeviceToHost, s));
+        }
+        if (ng) HIPCHK(c, hipMemcpyAsync(c->h_groups.p, k4.g_rec, (size_t)ng * sizeof(GroupRec), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        // The very first anomalous read "breaks" an empty accumulator (start = end = -1, no reads).  With a negative
+        // -s that empty candidate passes process_breakpoint's test (0 > min_len, coverage 0) and the reference
+        // registers a read-less region 0 (BreakDancer.cpp:216-231, 244-252); every real region id shifts by one.
+        const uint32_t ph = (0 > c->opts.min_len && 0.0f < (float)c->opts.seq_coverage_lim) ? 1u : 0u;
+        c->regions.resize(nr + ph);
+        if (ph) c->regions[0] = HostRegion{-1, -1, -1, 0, 0, 0, 0, 0};
+        const RegionRec* rr = c->h_regs.as<RegionRec>();
+        for (uint32_t i = 0; i < nr; ++i)
+            c->regions[i + ph] = HostRegion{rr[i].tid, rr[i].start, rr[i].end, rr[i].n, rr[i].rev, rr[i].nonctx, rr[i].nnormal, rr[i].maxq};
+        c->r_pk.assign((size_t)ph * 2 * nkeys, 0u);
+        c->r_pk.insert(c->r_pk.end(), c->h_pk.as<uint32_t>(), c->h_pk.as<uint32_t>() + (size_t)nr * 2 * nkeys);
+        c->parts.resize(ng);
+        const GroupRec* gr = c->h_groups.as<GroupRec>();
+        for (uint32_t i = 0; i < ng; ++i) {
+            const uint64_t k = gr[i].key;
+            c->parts[i] = GroupPart{(uint32_t)(k >> 38) + ph, (uint32_t)((k >> 12) & ((1u << 26) - 1)) + ph, (uint8_t)(k & 15),
+                                    (uint8_t)((k >> 4) & 255), gr[i].pairs, gr[i].sum_isize};
+        }
+    }
+    HIPCHK(c, hipEventRecord(c->ev[6], s));
+    const auto t_walk0 = std::chrono::steady_clock::now();
+
+    // ---- H1 walk ------------------------------------------------------------------------------------------------
+    WalkInput wi{};
+    wi.opts = c->opts; wi.libs = c->libs.data(); wi.nlibs = nlibs; wi.nbams = nbams; wi.nkeys = nkeys;
+    wi.hist = hist; wi.covered_ref_len = covered; wi.key_density = c->key_density.data();
+    wi.regions = &c->regions; wi.r_pk = c->r_pk.data(); wi.parts = &c->parts; wi.last_maxq = c->counts.last_maxq;
+    wi.any_anomalous = na != 0;
+    greedy_walk(wi, c->walk);
+    const auto t_walk1 = std::chrono::steady_clock::now();
+
+    // ---- K5 -------------------------------------------------------------------------------------------------------
+    const uint32_t nt = (uint32_t)c->walk.terms.size();
+    std::vector<double> log_tail(nt);
+    if (nt) {
+        HIPCHK(c, c->b_lam.ensure((size_t)nt * 8)); HIPCHK(c, c->b_k.ensure((size_t)nt * 4)); HIPCHK(c, c->b_logt.ensure((size_t)nt * 8));
+        HIPCHK(c, c->h_terms.ensure((size_t)nt * 20));
+        double* hl = c->h_terms.as<double>();
+        double* ho = hl + nt;
+        int32_t* hk = (int32_t*)(ho + nt);
+        for (uint32_t i = 0; i < nt; ++i) { hl[i] = c->walk.terms[i].lambda; hk[i] = c->walk.terms[i].k; }
+        HIPCHK(c, hipMemcpyAsync(c->b_lam.p, hl, (size_t)nt * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->b_k.p, hk, (size_t)nt * 4, hipMemcpyHostToDevice, s));
+        launch_k5(c->b_lam.as<double>(), c->b_k.as<int32_t>(), c->b_logt.as<double>(), nt, s);
+        HIPCHK(c, hipMemcpyAsync(ho, c->b_logt.p, (size_t)nt * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        HIPCHK(c, hipGetLastError());
+        for (uint32_t i = 0; i < nt; ++i) log_tail[i] = ho[i];
+    }
+    finish_scores(wi, log_tail, c->walk, &c->n_printed);
+    HIPCHK(c, hipEventRecord(c->ev[7], s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const auto t_end = std::chrono::steady_clock::now();
+
+    auto evms = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[a], c->ev[b]); return ms; };
+    auto chms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<float, std::milli>(b - a).count();
+    };
+    c->stage_ms[0] = evms(0, 1);
+    c->stage_ms[1] = evms(2, 3);
+    c->stage_ms[2] = evms(3, 4);
+    c->stage_ms[3] = evms(4, 5);
+    c->stage_ms[4] = evms(5, 6);
+    c->stage_ms[5] = chms(t_walk0, t_walk1);
+    c->stage_ms[6] = chms(t_walk1, t_end);
+    c->stage_ms[7] = chms(t_begin, t_end);
+    c->ran = true;
+    return BDX_OK;
+}
+
+int bdx_get_summary(const bdx_ctx* c, bdx_summary* o) {
+    if (!c || !o) return BDX_EINVAL;
+    if (!c->ran) return BDX_ESTATE;
+    o->n_reads = c->n; o->n_anomalous = c->p1.n_anom; o->covered_ref_len = c->p1.covered_ref_len; o->window = c->p1.window;
+    o->n_candidates = c->counts.n_cand; o->n_regions = (uint32_t)c->regions.size(); o->n_pairs = c->counts.n_pairs;
+    o->n_groups = c->walk.n_groups; o->n_svs = (uint32_t)c->walk.svs.size(); o->n_svs_printed = c->n_printed;
+    return BDX_OK;
+}
+
+int bdx_get_counters(const bdx_ctx* c, uint32_t* lib_read_count, uint32_t* bam_read_count, uint32_t* flag_hist, float* seqcov,
+                     float* density) {
+    if (!c) return BDX_EINVAL;
+    if (!c->ran) return BDX_ESTATE;
+    const uint32_t* hist = c->cnt.data();
+    const uint32_t* lib_cnt = hist + c->nlibs * kNumFlags;
+    const uint32_t* bam_cnt = lib_cnt + c->nlibs;
+    if (flag_hist) memcpy(flag_hist, hist, (size_t)c->nlibs * kNumFlags * 4);
+    if (lib_read_count) memcpy(lib_read_count, lib_cnt, (size_t)c->nlibs * 4);
+    if (bam_read_count) memcpy(bam_read_count, bam_cnt, (size_t)c->nbams * 4);
+    if (seqcov) memcpy(seqcov, c->seqcov.data(), (size_t)c->nlibs * 4);
+    if (density) memcpy(density, c->lib_density.data(), (size_t)c->nlibs * 4);
+    return BDX_OK;
+}
+
+int bdx_get_regions(const bdx_ctx* c, bdx_region* out, size_t cap) {
+    if (!c || (!out && cap)) return BDX_EINVAL;
+    if (!c->ran) return BDX_ESTATE;
+    const size_t n = std::min(cap, c->regions.size());
+    for (size_t i = 0; i < n; ++i) {
+        const HostRegion& r = c->regions[i];
+        const int valid = c->opts.chr_restricted ? (int)r.nonctx : (int)r.n;
+        out[i] = bdx_region{r.tid, r.start, r.end, (int32_t)r.nnormal, (int32_t)(r.n - r.rev), (int32_t)r.rev, (int32_t)r.n,
+                            valid >= c->opts.min_read_pair ? 1 : 0, r.maxq};
+    }
+    return BDX_OK;
+}
+
+int bdx_get_svs(const bdx_ctx* c, bdx_sv* out, size_t cap) {
+    if (!c || (!out && cap)) return BDX_EINVAL;
+    if (!c->ran) return BDX_ESTATE;
+    const size_t n = std::min(cap, c->walk.svs.size());
+    for (size_t i = 0; i < n; ++i) out[i] = c->walk.svs[i].sv;
+    return BDX_OK;
+}
+
+int bdx_get_sv_lists(const bdx_ctx* c, int32_t* lib_index, int32_t* lib_pairs, size_t lib_cap, int32_t* cn_key, float* cn_value,
+                     size_t cn_cap) {
+    if (!c) return BDX_EINVAL;
+    if (!c->ran) return BDX_ESTATE;
+    const size_t nl = std::min(lib_cap, c->walk.lib_index.size());
+    if (lib_index) memcpy(lib_index, c->walk.lib_index.data(), nl * 4);
+    if (lib_pairs) memcpy(lib_pairs, c->walk.lib_pairs.data(), nl * 4);
+    const size_t nc = std::min(cn_cap, c->walk.cn_key.size());
+    if (cn_key) memcpy(cn_key, c->walk.cn_key.data(), nc * 4);
+    if (cn_value) memcpy(cn_value, c->walk.cn_value.data(), nc * 4);
+    return BDX_OK;
+}
+
+int bdx_get_read_class(const bdx_ctx* c, uint8_t* out, size_t cap) {
+    if (!c || !out) return BDX_EINVAL;
+    if (!c->ran) return BDX_ESTATE;
+    const size_t n = std::min(cap, c->n);
+    if (n && hipMemcpy(out, c->b_cls.p, n, hipMemcpyDeviceToHost) != hipSuccess) return BDX_EHIP;
+    return BDX_OK;
+}
+
+int bdx_get_timings(const bdx_ctx* c, float* ms, int cap) {
+    if (!c || !ms) return 0;
+    const int n = std::min(cap, kNumStages);
+    for (int i = 0; i < n; ++i) ms[i] = c->stage_ms[i];
+    return n;
+}
+
+int bdx_classify(const bdx_opts* opts, const bdx_lib* libs, int nlibs, const bdx_batch* b, uint8_t* cls_out, int device) {
+    if (!opts || !libs || !b || !cls_out) return BDX_EINVAL;
+    int nbams = 1;
+    for (int i = 0; i < nlibs; ++i) nbams = std::max(nbams, libs[i].bam_index + 1);
+    for (size_t i = 0; i < b->n; ++i) nbams = std::max(nbams, (int)b->bam[i] + 1);
+    bdx_ctx* c = nullptr;
+    int rc = bdx_create(&c, opts, libs, nlibs, nbams, 0, 100000000, device);
+    if (rc != BDX_OK) return rc;
+    rc = bdx_push(c, b);
+    if (rc == BDX_OK) rc = bdx_run(c);
+    if (rc == BDX_OK) rc = bdx_get_read_class(c, cls_out, b->n);
+    bdx_destroy(c);
+    return rc;
+}
+
+int bdx_poisson_log_upper_tail(const double* lambda, const int32_t* k, double* out, size_t n, int device) {
+    if (!lambda || !k || !out) return BDX_EINVAL;
+    if (n == 0) return BDX_OK;
+    if (hipSetDevice(device) != hipSuccess) return BDX_EHIP;
+    DevBuf bl, bk, bo;
+    if (bl.ensure(n * 8) != hipSuccess || bk.ensure(n * 4) != hipSuccess || bo.ensure(n * 8) != hipSuccess) return BDX_ENOMEM;
+    int rc = BDX_OK;
+    if (hipMemcpy(bl.p, lambda, n * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(bk.p, k, n * 4, hipMemcpyHostToDevice) != hipSuccess)
+        rc = BDX_EHIP;
+    if (rc == BDX_OK) {
+        launch_k5(bl.as<double>(), bk.as<int32_t>(), bo.as<double>(), (uint32_t)n, nullptr);
+        if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) rc = BDX_EHIP;
+    }
+    if (rc == BDX_OK && hipMemcpy(out, bo.p, n * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = BDX_EHIP;
+    bl.release(); bk.release(); bo.release();
+    return rc;
+}
+
+}  // extern "C"

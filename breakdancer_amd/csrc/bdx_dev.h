@@ -1,0 +1,123 @@
+// Shared device-side declarations of libbdx (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bdx {
+
+constexpr int kTile = 1024;     // reads per tile = 256 threads x 4 consecutive reads
+constexpr int kBlock = 256;     // threads per workgroup (4 wave64)
+constexpr int kWaves = kBlock / 64;
+constexpr int kNumFlags = 11;
+
+enum : int { F_NA = 0, F_FF = 1, F_LARGE = 2, F_SMALL = 3, F_RF = 4, F_RR = 5, F_NORMAL_FR = 6, F_NORMAL_RF = 7,
+             F_CTX = 8, F_MATE_UNMAPPED = 9, F_UNMAPPED = 10 };
+
+struct DevLib {
+    float upper, lower;
+    int32_t min_mapq;  // already resolved against opts.min_map_qual
+    int32_t key;       // normal-read counter key: library index (-a) or the library's BAM index
+};
+
+struct ReadsSoA {
+    const int32_t *tid, *pos, *mtid, *mpos, *isize;
+    const uint16_t *flag, *qlen;
+    const uint8_t *mapq, *lib, *bam;
+    const uint64_t* key;
+};
+
+// tile-total columns: 0 anomalous, 1 normal leftmost, 2.. per normal-read key
+constexpr int kColAnom = 0, kColNormal = 1, kColKey0 = 2;
+
+struct K1Params {
+    ReadsSoA r;
+    uint64_t n;
+    uint32_t ntiles, tstride;  // tstride = padded row length of the per-tile tables
+    int nlibs, nbams, nkeys;
+    int max_sd, opt_t, opt_l;
+    const DevLib* libs;
+    uint8_t* cls;              // [n]
+    uint32_t* tile_tot;        // [2+nkeys][tstride]
+    int32_t* tile_mono;        // [nbams][4][tstride]: first_tid, first_pos, last_tid, last_pos (first_tid==INT_MIN: none)
+    long long* tile_mono_sum;  // [nbams][tstride]
+    uint32_t* blk_cnt;         // [gridDim.x][ncnt], ncnt = nlibs*11 + nlibs + nbams
+};
+
+// results of pass 1, produced on the device and mirrored to the host
+struct Pass1 {
+    uint32_t covered_ref_len;
+    int32_t window;
+    uint32_t n_anom;      // total anomalous reads
+    uint32_t n_normal;    // total normal-leftmost reads
+    uint32_t key_tot[60]; // proper read totals per key
+};
+
+struct FinalizeParams {
+    uint32_t ntiles, tstride, nblk;
+    int nlibs, nbams, nkeys, ncols, ncnt;
+    int w0;
+    const uint32_t* tile_tot;
+    uint32_t* tile_pre;         // exclusive scan of tile_tot per column
+    const int32_t* tile_mono;
+    const long long* tile_mono_sum;
+    const uint32_t* blk_cnt;
+    uint32_t* cnt;              // [ncnt] reduced counters
+    Pass1* p1;
+};
+
+// compact anomalous-read records (one per read entering the region accumulator)
+struct Compact {
+    int32_t* tid;
+    int32_t* pos;
+    int32_t* isize;     // |isize|
+    uint32_t* meta;     // flag (4) | rev<<4 | lib<<8 | qlen<<16
+    uint64_t* key;
+    uint32_t* nn;       // normal-leftmost reads seen before this read (stream order)
+    uint32_t* pk;       // [nkeys][cap]: proper reads of key k seen up to and including this read
+    uint32_t cap;
+};
+
+struct K2Params {
+    ReadsSoA r;
+    uint64_t n;
+    uint32_t ntiles, tstride;
+    int nkeys;
+    const DevLib* libs;
+    const uint8_t* cls;
+    const uint32_t* tile_pre;
+    Compact c;
+};
+
+__device__ __forceinline__ uint32_t meta_pack(int flag, int rev, int lib, int qlen) {
+    return (uint32_t)flag | ((uint32_t)rev << 4) | ((uint32_t)lib << 8) | ((uint32_t)qlen << 16);
+}
+__host__ __device__ __forceinline__ int meta_flag(uint32_t m) { return m & 15; }
+__host__ __device__ __forceinline__ int meta_rev(uint32_t m) { return (m >> 4) & 1; }
+__host__ __device__ __forceinline__ int meta_lib(uint32_t m) { return (m >> 8) & 255; }
+__host__ __device__ __forceinline__ int meta_qlen(uint32_t m) { return m >> 16; }
+
+// ---- wave helpers (wave64) ----------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
+__device__ __forceinline__ int popc64(uint64_t m) { return __popcll(m); }
+
+// inclusive wave scan of a u32 (6 shuffle steps)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    const int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o);
+        if (l >= o) v += t;
+    }
+    return v;
+}
+
+// launchers (host side, defined in the .hip files)
+void launch_k1(const K1Params& p, int grid, size_t lds, hipStream_t s);
+size_t k1_lds_bytes(int nlibs, int nbams, int nkeys);
+void launch_finalize(const FinalizeParams& p, hipStream_t s);
+void launch_k2(const K2Params& p, size_t lds, hipStream_t s);
+size_t k2_lds_bytes(int nkeys);
+
+}  // namespace bdx

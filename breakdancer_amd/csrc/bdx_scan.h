@@ -1,0 +1,128 @@
+// Device-wide inclusive scan in three launches (block sums -> scan of sums -> rescan with offsets),
+// generic over the element type (uint32_t or a 4-column struct) and over load/store functors so the
+// callers fuse their own per-element work into phase 1 / phase 3.  Element count may live on the device
+// (n_ptr) so no host round trip is needed between dependent stages.
+#pragma once
+#include "bdx_dev.h"
+
+namespace bdx {
+
+struct U4 {
+    uint32_t x, y, z, w;
+};
+__host__ __device__ __forceinline__ U4 operator+(const U4& a, const U4& b) { return U4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+__host__ __device__ __forceinline__ U4 operator-(const U4& a, const U4& b) { return U4{a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+
+template <class T> __device__ __forceinline__ T zero_of();
+template <> __device__ __forceinline__ uint32_t zero_of<uint32_t>() { return 0u; }
+template <> __device__ __forceinline__ U4 zero_of<U4>() { return U4{0, 0, 0, 0}; }
+
+__device__ __forceinline__ uint32_t shfl_up_t(uint32_t v, int o) { return __shfl_up(v, o); }
+__device__ __forceinline__ U4 shfl_up_t(const U4& v, int o) {
+    return U4{(uint32_t)__shfl_up(v.x, o), (uint32_t)__shfl_up(v.y, o), (uint32_t)__shfl_up(v.z, o), (uint32_t)__shfl_up(v.w, o)};
+}
+
+template <class T> __device__ __forceinline__ T wave_incl_scan_t(T v) {
+    const int l = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        T t = shfl_up_t(v, o);
+        if (l >= o) v = v + t;
+    }
+    return v;
+}
+
+constexpr int kScanBlock = 256;
+constexpr int kScanIters = 8;
+constexpr int kScanChunk = kScanBlock * kScanIters;  // elements per workgroup
+
+// block-wide inclusive scan of one element per thread; returns the inclusive value, *total = block sum
+template <class T> __device__ __forceinline__ T block_incl_scan(T v, T* s_ws /*[4]*/, T* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    T inc = wave_incl_scan_t(v);
+    if (lane == 63) s_ws[w] = inc;
+    __syncthreads();
+    T off = zero_of<T>();
+    T tot = zero_of<T>();
+#pragma unroll
+    for (int k = 0; k < kScanBlock / 64; ++k) {
+        if (k < w) off = off + s_ws[k];
+        tot = tot + s_ws[k];
+    }
+    __syncthreads();
+    *total = tot;
+    return off + inc;
+}
+
+template <class T, class In> __global__ __launch_bounds__(kScanBlock) void scan_phase1(In in, const uint32_t* n_ptr, T* blk) {
+    __shared__ T s_ws[kScanBlock / 64];
+    const uint32_t n = *n_ptr;
+    const uint32_t base = blockIdx.x * kScanChunk;
+    if (base >= n) return;
+    T acc = zero_of<T>();
+#pragma unroll
+    for (int it = 0; it < kScanIters; ++it) {
+        const uint32_t j = base + it * kScanBlock + threadIdx.x;
+        if (j < n) acc = acc + in(j, n);
+    }
+    T tot;
+    block_incl_scan(acc, s_ws, &tot);
+    if (threadIdx.x == 0) blk[blockIdx.x] = tot;
+}
+
+// single workgroup: in-place exclusive scan of the block sums, grand total -> *total
+template <class T> __global__ __launch_bounds__(1024) void scan_phase2(T* blk, const uint32_t* n_ptr, T* total) {
+    __shared__ T s_ws[16];
+    __shared__ T s_carry;
+    const uint32_t n = *n_ptr;
+    const uint32_t nb = (n + kScanChunk - 1) / kScanChunk;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = zero_of<T>();
+    __syncthreads();
+    for (uint32_t base = 0; base < nb; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        T v = i < nb ? blk[i] : zero_of<T>();
+        T inc = wave_incl_scan_t(v);
+        if (lane == 63) s_ws[w] = inc;
+        __syncthreads();
+        T off = s_carry;
+        for (int k = 0; k < w; ++k) off = off + s_ws[k];
+        if (i < nb) blk[i] = off + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = off + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = s_carry;
+}
+
+template <class T, class In, class Out>
+__global__ __launch_bounds__(kScanBlock) void scan_phase3(In in, Out out, const uint32_t* n_ptr, const T* blk) {
+    __shared__ T s_ws[kScanBlock / 64];
+    const uint32_t n = *n_ptr;
+    const uint32_t base = blockIdx.x * kScanChunk;
+    if (base >= n) return;
+    T carry = blk[blockIdx.x];
+#pragma unroll 1
+    for (int it = 0; it < kScanIters; ++it) {
+        const uint32_t j = base + it * kScanBlock + threadIdx.x;
+        if (base + it * kScanBlock >= n) break;
+        T e = j < n ? in(j, n) : zero_of<T>();
+        T tot;
+        T inc = carry + block_incl_scan(e, s_ws, &tot);
+        if (j < n) out(j, n, inc, e);
+        carry = carry + tot;
+    }
+}
+
+// host helper: grid for an upper bound on the element count
+inline uint32_t scan_grid(uint32_t n_upper) { return n_upper ? (n_upper + kScanChunk - 1) / kScanChunk : 1; }
+
+template <class T, class In, class Out>
+void scan_launch(In in, Out out, const uint32_t* n_ptr, uint32_t n_upper, T* blk_ws, T* total, hipStream_t s) {
+    const uint32_t g = scan_grid(n_upper);
+    hipLaunchKernelGGL((scan_phase1<T, In>), dim3(g), dim3(kScanBlock), 0, s, in, n_ptr, blk_ws);
+    hipLaunchKernelGGL((scan_phase2<T>), dim3(1), dim3(1024), 0, s, blk_ws, n_ptr, total);
+    hipLaunchKernelGGL((scan_phase3<T, In, Out>), dim3(g), dim3(kScanBlock), 0, s, in, out, n_ptr, blk_ws);
+}
+
+}  // namespace bdx

@@ -1,0 +1,121 @@
+// K3 -- cut the compacted anomalous reads into candidate regions and decide which become regions.
+//
+// Replaces (reference file:line under src/lib/breakdancer):
+//   BreakDancer.cpp:209-241   nucleotide / max-readlen accumulation, the do_break test, region start/end
+//   BreakDancer.cpp:244-264   process_breakpoint: coverage test, accept / collapse
+//   ReadRegionData.cpp:89-124 add_region: fwd/rev counts, non-CTX count, "stored" test
+//   ReadRegionData.cpp:177-199, 207-217 and ReadRegionData.hpp:158-172: the ROI/FR normal-read
+//     counters, which telescope to prefix-count differences sampled at region first/last reads
+//
+// The reference walks reads one at a time; here the cut is a segmented scan: head flag = tid change or
+// gap > W to the previous anomalous read, candidate id = inclusive scan of heads, and every per-candidate
+// quantity is a difference of inclusive prefix sums (or one atomicMax for the max read length).
+#include "bdx_k3.h"
+
+#include "bdx_scan.h"
+
+namespace bdx {
+
+struct HeadIn {
+    const int32_t* tid;
+    const int32_t* pos;
+    const uint32_t* meta;
+    const Pass1* p1;
+    __device__ U4 operator()(uint32_t j, uint32_t) const {
+        const int W = p1->window;
+        const bool head = j == 0 || tid[j] != tid[j - 1] || pos[j] - pos[j - 1] > W;
+        const uint32_t m = meta[j];
+        return U4{head ? 1u : 0u, (uint32_t)meta_qlen(m), (uint32_t)meta_rev(m), meta_flag(m) != F_CTX ? 1u : 0u};
+    }
+};
+
+struct HeadOut {
+    K3Arrays a;
+    __device__ void operator()(uint32_t j, uint32_t, const U4& inc, const U4& e) const {
+        const int c = (int)inc.x - 1;
+        a.cand[j] = c;
+        a.pre_q[j] = inc.y;
+        a.pre_rev[j] = inc.z;
+        a.pre_nonctx[j] = inc.w;
+        if (e.x) a.c_first[c] = j;
+        // Q4: the first read of a candidate is not counted for it, the breaking read (first read of the
+        // next candidate) is (BreakDancer.cpp:209-212 runs before the break test at :216)
+        const int target = e.x ? c - 1 : c;
+        if (target >= 0) atomicMax(&a.c_maxq[target], (int)e.y);
+    }
+};
+
+__global__ __launch_bounds__(256) void k3_candidates_kernel(K3Arrays a, Compact cp, const Pass1* p1, const U4* head_total,
+                                                            int min_len, int seq_coverage_lim, int nkeys) {
+    const uint32_t nc = head_total->x;
+    const uint32_t na = p1->n_anom;
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && threadIdx.x == 0) a.counts->n_cand = nc;
+    if (c >= nc) return;
+    const uint32_t f = a.c_first[c];
+    const uint32_t nxt = c + 1 < nc ? a.c_first[c + 1] : na;
+    const uint32_t l = nxt - 1;
+    const int start = cp.pos[f], end = cp.pos[l];
+    const uint32_t rev = a.pre_rev[l] - (f ? a.pre_rev[f - 1] : 0u);
+    const uint32_t nonctx = a.pre_nonctx[l] - (f ? a.pre_nonctx[f - 1] : 0u);
+    const uint32_t e = c + 1 < nc ? nxt : l;
+    const int qsum = (int)(a.pre_q[e] - a.pre_q[f]);
+    const int maxq = a.c_maxq[c];
+    const float cov = __fdiv_rn((float)qsum, (float)(end - start + 1 + maxq));
+    const bool accept = (end - start > min_len) && (cov < (float)seq_coverage_lim);
+    a.c_accept[c] = accept ? 1u : 0u;
+    a.c_n[c] = nxt - f;
+    a.c_rev[c] = rev;
+    a.c_nonctx[c] = nonctx;
+    // normal read pairs seen while the candidate was open (BreakDancer.cpp:202-206): between its first
+    // read and the breaking read, or the end of the stream
+    const uint32_t nn_end = c + 1 < nc ? cp.nn[nxt] : p1->n_normal;
+    a.c_nnormal[c] = nn_end - cp.nn[f];
+}
+
+struct AcceptIn {
+    const uint32_t* acc;
+    __device__ uint32_t operator()(uint32_t c, uint32_t) const { return acc[c]; }
+};
+struct AcceptOut {
+    K3Arrays a;
+    Compact cp;
+    int nkeys;
+    __device__ void operator()(uint32_t c, uint32_t n, uint32_t inc, uint32_t e) const {
+        a.c_rid[c] = e ? (int)inc - 1 : -1;
+        if (c == n - 1) a.counts->last_maxq = a.c_maxq[c];
+        if (!e) return;
+        const uint32_t r = inc - 1;
+        const uint32_t f = a.c_first[c];
+        const uint32_t l = f + a.c_n[c] - 1;
+        RegionRec rr;
+        rr.tid = cp.tid[f]; rr.start = cp.pos[f]; rr.end = cp.pos[l];
+        rr.n = a.c_n[c]; rr.rev = a.c_rev[c]; rr.nonctx = a.c_nonctx[c]; rr.nnormal = a.c_nnormal[c];
+        rr.maxq = a.c_maxq[c];
+        a.r_rec[r] = rr;
+        for (int k = 0; k < nkeys; ++k) {
+            a.r_pk[(size_t)r * 2 * nkeys + k] = cp.pk[(size_t)k * cp.cap + f];
+            a.r_pk[(size_t)r * 2 * nkeys + nkeys + k] = cp.pk[(size_t)k * cp.cap + l];
+        }
+    }
+};
+
+__global__ void k3_store_counts(K3Arrays a, const uint32_t* acc_total) { a.counts->n_regions = *acc_total; }
+
+void launch_k3(const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n_anom_host, int min_len, int seq_coverage_lim,
+               int nkeys, hipStream_t s) {
+    if (n_anom_host == 0) return;
+    (void)hipMemsetAsync(a.c_maxq, 0, (size_t)n_anom_host * 4, s);
+    const uint32_t* n_ptr = &p1->n_anom;
+    HeadIn hin{cp.tid, cp.pos, cp.meta, p1};
+    HeadOut hout{a};
+    scan_launch<U4>(hin, hout, n_ptr, n_anom_host, a.ws_u4, a.head_total, s);
+    const uint32_t g = (n_anom_host + 255) / 256;
+    hipLaunchKernelGGL(k3_candidates_kernel, dim3(g), dim3(256), 0, s, a, cp, p1, a.head_total, min_len, seq_coverage_lim, nkeys);
+    AcceptIn ain{a.c_accept};
+    AcceptOut aout{a, cp, nkeys};
+    scan_launch<uint32_t>(ain, aout, &a.counts->n_cand, n_anom_host, a.ws_u32, a.acc_total, s);
+    hipLaunchKernelGGL(k3_store_counts, dim3(1), dim3(1), 0, s, a, a.acc_total);
+}
+
+}  // namespace bdx

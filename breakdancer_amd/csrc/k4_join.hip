@@ -1,0 +1,228 @@
+// K4 -- mate join and region x region connection groups.
+//
+// Replaces (reference file:line under src/lib/breakdancer):
+//   ReadRegionData.cpp:108-113   _read_regions[qname] -> [region ids]; 2nd sighting increments an edge
+//   ReadRegionData.cpp:177-199   collapse: names of reads in rejected candidates are forgotten
+//   SvBuilder.cpp:101-118        _observe_read: pair mates by name; the *second observed* mate decides
+//                                flag, library and |isize| of the pair
+//
+// A pair exists iff both mates sit in accepted regions.  Reads of accepted regions are partitioned by a
+// hash of the name key into buckets that fit an LDS table (160 KiB per CU on gfx950), each bucket is
+// joined by one workgroup with open addressing in LDS, and the pairs are then aggregated per
+// (region_lo, region_hi, flag, library) in a second LDS table keyed by the packed group id.  The edge
+// weight of the reference's graph is the sum of a group's pair counts.
+#include "bdx_k3.h"
+
+namespace bdx {
+
+__device__ __forceinline__ uint64_t mix64(uint64_t h) {
+    h ^= h >> 33;
+    h *= 0xff51afd7ed558ccdull;
+    h ^= h >> 33;
+    h *= 0xc4ceb9fe1a85ec53ull;
+    h ^= h >> 33;
+    return h;
+}
+__device__ __forceinline__ uint32_t bucket_of(uint64_t h, uint32_t log2b) { return log2b ? (uint32_t)(h >> (64 - log2b)) : 0u; }
+
+constexpr int kPartChunk = 2048;  // compact reads per workgroup in the partition kernels
+
+__global__ __launch_bounds__(256) void k4_count_kernel(K4Arrays k4, K3Arrays a, Compact cp, const Pass1* p1) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* s_h = (uint32_t*)smem;
+    const uint32_t na = p1->n_anom;
+    const uint32_t base = blockIdx.x * kPartChunk;
+    if (base >= na) return;
+    for (uint32_t b = threadIdx.x; b < k4.nbuckets; b += 256) s_h[b] = 0;
+    __syncthreads();
+    for (int it = 0; it < kPartChunk / 256; ++it) {
+        const uint32_t j = base + it * 256 + threadIdx.x;
+        if (j < na && a.c_rid[a.cand[j]] >= 0) atomicAdd(&s_h[bucket_of(mix64(cp.key[j]), k4.log2b)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < k4.nbuckets; b += 256)
+        if (s_h[b]) atomicAdd(&k4.bcnt[b], s_h[b]);
+}
+
+__global__ __launch_bounds__(1024) void k4_bucket_scan_kernel(K4Arrays k4, StageCounts* counts) {
+    __shared__ uint32_t s_ws[16];
+    __shared__ uint32_t s_carry;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < k4.nbuckets; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < k4.nbuckets ? k4.bcnt[i] : 0u;
+        const uint32_t inc = wave_incl_scan(v);
+        if (lane == 63) s_ws[w] = inc;
+        __syncthreads();
+        uint32_t off = s_carry;
+        for (int k = 0; k < w; ++k) off += s_ws[k];
+        if (i < k4.nbuckets) { k4.boff[i] = off + inc - v; k4.bcur[i] = 0; }
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = off + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { k4.boff[k4.nbuckets] = s_carry; counts->n_entries = s_carry; }
+}
+
+__global__ __launch_bounds__(256) void k4_scatter_kernel(K4Arrays k4, K3Arrays a, Compact cp, const Pass1* p1) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* s_h = (uint32_t*)smem;
+    uint32_t* s_base = s_h + k4.nbuckets;
+    const uint32_t na = p1->n_anom;
+    const uint32_t base = blockIdx.x * kPartChunk;
+    if (base >= na) return;
+    for (uint32_t b = threadIdx.x; b < k4.nbuckets; b += 256) s_h[b] = 0;
+    __syncthreads();
+    for (int it = 0; it < kPartChunk / 256; ++it) {
+        const uint32_t j = base + it * 256 + threadIdx.x;
+        if (j < na && a.c_rid[a.cand[j]] >= 0) atomicAdd(&s_h[bucket_of(mix64(cp.key[j]), k4.log2b)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < k4.nbuckets; b += 256) {
+        const uint32_t c = s_h[b];
+        if (c) s_base[b] = k4.boff[b] + atomicAdd(&k4.bcur[b], c);
+        s_h[b] = 0;
+    }
+    __syncthreads();
+    for (int it = 0; it < kPartChunk / 256; ++it) {
+        const uint32_t j = base + it * 256 + threadIdx.x;
+        if (j < na && a.c_rid[a.cand[j]] >= 0) {
+            const uint64_t key = cp.key[j];
+            const uint32_t b = bucket_of(mix64(key), k4.log2b);
+            const uint32_t slot = s_base[b] + atomicAdd(&s_h[b], 1u);
+            k4.e_key[slot] = key;
+            k4.e_idx[slot] = j;
+        }
+    }
+}
+
+// One workgroup joins one bucket.  Two phases around a barrier: (A) every entry claims its own slot by
+// linear probing from hash(key) (no key comparison, so the table is a multiset), (B) every entry walks its
+// probe run until the first empty slot and takes the other entry with the same key as its mate.
+template <bool kLds>
+__device__ __forceinline__ void join_bucket(uint64_t* tkey, int32_t* tidx, uint32_t cap, const K4Arrays& k4, uint32_t off,
+                                            uint32_t cnt) {
+    for (uint32_t s = threadIdx.x; s < cap; s += blockDim.x) tidx[s] = -1;
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < cnt; e += blockDim.x) {
+        const uint64_t key = k4.e_key[off + e];
+        const int32_t j = (int32_t)k4.e_idx[off + e];
+        uint32_t s = (uint32_t)(mix64(key) & 0xffffffffu) % cap;
+        while (atomicCAS(&tidx[s], -1, j) != -1) s = s + 1 == cap ? 0 : s + 1;
+        tkey[s] = key;
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < cnt; e += blockDim.x) {
+        const uint64_t key = k4.e_key[off + e];
+        const int32_t j = (int32_t)k4.e_idx[off + e];
+        uint32_t s = (uint32_t)(mix64(key) & 0xffffffffu) % cap;
+        int32_t mate = -1;
+        for (uint32_t probes = 0; probes < cap; ++probes) {
+            const int32_t o = tidx[s];
+            if (o == -1) break;
+            if (o != j && tkey[s] == key) { mate = o; break; }
+            s = s + 1 == cap ? 0 : s + 1;
+        }
+        k4.partner[j] = mate;
+    }
+}
+
+__global__ __launch_bounds__(256) void k4_join_kernel(K4Arrays k4) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t b = blockIdx.x;
+    const uint32_t off = k4.boff[b], cnt = k4.boff[b + 1] - off;
+    if (cnt == 0) return;
+    if (2 * cnt <= (uint32_t)kJoinLdsSlots) {
+        uint64_t* tkey = (uint64_t*)smem;
+        int32_t* tidx = (int32_t*)(tkey + kJoinLdsSlots);
+        join_bucket<true>(tkey, tidx, 2 * cnt, k4, off, cnt);
+    } else {
+        join_bucket<false>(k4.t_key + 2 * (size_t)off, k4.t_idx + 2 * (size_t)off, 2 * cnt, k4, off, cnt);
+    }
+}
+
+constexpr uint64_t kEmptyGroup = ~0ull;
+
+__global__ __launch_bounds__(256) void k4_aggregate_kernel(K4Arrays k4, K3Arrays a, Compact cp, const Pass1* p1) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* s_key = (unsigned long long*)smem;  // [kAggSlots]
+    uint32_t* s_cnt = (uint32_t*)(s_key + kAggSlots);
+    uint32_t* s_sum = s_cnt + kAggSlots;
+    uint32_t* s_ws = s_sum + kAggSlots;  // [4]; everything lives in the dynamic region (keeps its base 16-B aligned)
+    uint32_t& s_base = s_ws[4];
+    uint32_t& s_pairs = s_ws[5];
+    const uint32_t na = p1->n_anom;
+    const uint32_t base = blockIdx.x * kPartChunk;
+    if (base >= na) return;
+    for (int s = threadIdx.x; s < kAggSlots; s += 256) { s_key[s] = kEmptyGroup; s_cnt[s] = 0; s_sum[s] = 0; }
+    if (threadIdx.x == 0) s_pairs = 0;
+    __syncthreads();
+    uint32_t mypairs = 0;
+    for (int it = 0; it < kPartChunk / 256; ++it) {
+        const uint32_t j = base + it * 256 + threadIdx.x;
+        if (j >= na) continue;
+        const int rj = a.c_rid[a.cand[j]];
+        if (rj < 0) continue;
+        const int32_t p = k4.partner[j];
+        if (p < 0 || (uint32_t)p >= j) continue;  // j is the second-observed mate (Q9): the later read in stream order
+        const int rp = a.c_rid[a.cand[p]];
+        const uint32_t m = cp.meta[j];
+        const uint64_t gk = group_pack((uint32_t)rp, (uint32_t)rj, (uint32_t)meta_lib(m), (uint32_t)meta_flag(m));
+        uint32_t s = (uint32_t)(mix64(gk) & (kAggSlots - 1));
+        while (true) {
+            const unsigned long long old = atomicCAS(&s_key[s], (unsigned long long)kEmptyGroup, (unsigned long long)gk);
+            if (old == kEmptyGroup || old == gk) break;
+            s = (s + 1) & (kAggSlots - 1);
+        }
+        atomicAdd(&s_cnt[s], 1u);
+        atomicAdd(&s_sum[s], (uint32_t)cp.isize[j]);
+        ++mypairs;
+    }
+    if (mypairs) atomicAdd(&s_pairs, mypairs);
+    __syncthreads();
+    // flush: count occupied slots (16 per thread), reserve a range of the output list once per workgroup
+    uint32_t occ = 0;
+    for (int q = 0; q < kAggSlots / 256; ++q) occ += s_key[threadIdx.x * (kAggSlots / 256) + q] != kEmptyGroup;
+    const uint32_t inc = wave_incl_scan(occ);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 63) s_ws[w] = inc;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+    for (int k = 0; k < 4; ++k) { if (k < w) off += s_ws[k]; tot += s_ws[k]; }
+    if (threadIdx.x == 0) {
+        s_base = tot ? atomicAdd(&a.counts->n_groups, tot) : 0u;
+        if (s_pairs) atomicAdd(&a.counts->n_pairs, s_pairs);
+    }
+    __syncthreads();
+    uint32_t o = s_base + off + inc - occ;
+    for (int q = 0; q < kAggSlots / 256; ++q) {
+        const int s = threadIdx.x * (kAggSlots / 256) + q;
+        if (s_key[s] != kEmptyGroup) {
+            if (o < k4.g_cap) { GroupRec g; g.key = s_key[s]; g.pairs = s_cnt[s]; g.sum_isize = s_sum[s]; k4.g_rec[o] = g; }
+            else a.counts->overflow = 1;
+            ++o;
+        }
+    }
+}
+
+void launch_k4(const K4Arrays& k4, const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n_anom_host, hipStream_t s) {
+    if (n_anom_host == 0) return;
+    const uint32_t g = (n_anom_host + kPartChunk - 1) / kPartChunk;
+    (void)hipMemsetAsync(k4.bcnt, 0, (size_t)k4.nbuckets * 4, s);
+    (void)hipMemsetAsync(k4.partner, 0xFF, (size_t)n_anom_host * 4, s);
+    hipLaunchKernelGGL(k4_count_kernel, dim3(g), dim3(256), (size_t)k4.nbuckets * 4, s, k4, a, cp, p1);
+    hipLaunchKernelGGL(k4_bucket_scan_kernel, dim3(1), dim3(1024), 0, s, k4, a.counts);
+    hipLaunchKernelGGL(k4_scatter_kernel, dim3(g), dim3(256), (size_t)k4.nbuckets * 8, s, k4, a, cp, p1);
+    static bool attr_set = false;
+    if (!attr_set) {  // more than 64 KiB of dynamic LDS has to be opted into
+        (void)hipFuncSetAttribute((const void*)k4_join_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kJoinLdsSlots * 12);
+        (void)hipFuncSetAttribute((const void*)k4_aggregate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kAggSlots * 16 + 32);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k4_join_kernel, dim3(k4.nbuckets), dim3(256), (size_t)kJoinLdsSlots * 12, s, k4);
+    hipLaunchKernelGGL(k4_aggregate_kernel, dim3(g), dim3(256), (size_t)kAggSlots * 16 + 32, s, k4, a, cp, p1);
+}
+
+}  // namespace bdx

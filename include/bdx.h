@@ -1,0 +1,188 @@
+/* bdx.h -- C ABI of libbdx, the MI355X-native anomalous read-pair clustering path of BreakDancerMax.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.  The reference has no
+ * FFI for this path; what it has are C++ seams, and each entry point below names the one it replaces
+ * (file:line under the reference's src/).  A maintainer's binding is shown in INTEGRATION.md.
+ *
+ * Data contract: the caller (the BAM producer) hands over the *merged, position-sorted* stream of
+ * records that survive the reference's reader filter (primary, tid >= 0; io/AlignmentFilter.hpp:24-34,
+ * io/BamIo.cpp:11-18), as structure-of-arrays batches.  With "-o <chr>" the stream is the records of
+ * that tid only (io/RegionLimitedBamReader.hpp:63-71) and opts.chr_restricted is 1.
+ */
+#ifndef BDX_H
+#define BDX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bdx_ctx bdx_ctx;
+
+/* status codes (the reference throws C++ exceptions caught in main(), BreakDancerMax.cpp:157-160) */
+enum {
+    BDX_OK = 0,
+    BDX_EINVAL = 1,    /* bad argument */
+    BDX_ENOMEM = 2,    /* host or device allocation failed */
+    BDX_EHIP = 3,      /* HIP runtime error (no device, launch failure ...) */
+    BDX_ESTATE = 4,    /* call out of order (e.g. results before bdx_run) */
+    BDX_ELIMIT = 5,    /* input exceeds a documented limit */
+    BDX_EINTERNAL = 6
+};
+
+/* ReadFlag, common/ReadFlags.hpp:14-27 (values are part of the output contract) */
+enum {
+    BDX_NA = 0, BDX_ARP_FF = 1, BDX_ARP_LARGE_INSERT = 2, BDX_ARP_SMALL_INSERT = 3, BDX_ARP_RF = 4, BDX_ARP_RR = 5,
+    BDX_NORMAL_FR = 6, BDX_NORMAL_RF = 7, BDX_ARP_CTX = 8, BDX_MATE_UNMAPPED = 9, BDX_UNMAPPED = 10, BDX_NUM_FLAGS = 11
+};
+
+/* per-read class byte written by the classifier kernel (bdx_get_read_class / bdx_classify):
+ *   bits 0-3  ReadFlag after the pass-2 remaps (-l, RR->FF) when the read passes the filters,
+ *             the raw classifier flag otherwise
+ *   bit 4     read passes the pass-2 filter chain (breakdancer/BreakDancer.cpp:159-167)
+ *   bit 5     pass && Alignment::proper_pair() (io/Alignment.hpp:144-148)
+ *   bit 6     pass && NORMAL_* && Alignment::leftmost() (counted as a normal read pair, BreakDancer.cpp:202-206) */
+#define BDX_CLS_FLAG(c) ((c) & 15)
+#define BDX_CLS_PASS 0x10
+#define BDX_CLS_PROPER 0x20
+#define BDX_CLS_NORMAL_LEFT 0x40
+
+/* Options, common/Options.hpp:24-45 / defaults Options.cpp:27-41 */
+typedef struct bdx_opts {
+    int32_t min_len;               /* -s */
+    int32_t cut_sd;                /* -c (consumed by the config parser) */
+    int32_t max_sd;                /* -m */
+    int32_t min_map_qual;          /* -q */
+    int32_t min_read_pair;         /* -r */
+    int32_t seq_coverage_lim;      /* -x */
+    int32_t buffer_size;           /* -b */
+    int32_t transchr_rearrange;    /* -t */
+    int32_t fisher;                /* -f */
+    int32_t illumina_long_insert;  /* -l */
+    int32_t cn_lib;                /* -a */
+    int32_t print_af;              /* -h */
+    int32_t score_threshold;       /* -y */
+    int32_t chr_restricted;        /* 1 when -o was given (opts.chr non-empty) */
+} bdx_opts;
+
+void bdx_opts_default(bdx_opts* o);
+
+/* LibraryConfig, io/LibraryConfig.hpp:11-24; libraries are indexed in sorted-name order
+ * (io/BamConfig.cpp:97-101); bam_index indexes the sorted BAM path list (:103-119). */
+typedef struct bdx_lib {
+    float mean_insertsize, std_insertsize, uppercutoff, lowercutoff, readlens;
+    int32_t min_mapping_quality; /* -1: use opts.min_map_qual */
+    int32_t bam_index;
+} bdx_lib;
+
+/* One batch of records (what io/AlignmentSource.hpp:48-65 + io/Alignment.cpp:45-64 produce per read).
+ *   isize     raw BAM isize (the kernels take |isize|)
+ *   flag      SAM flag bits
+ *   qlen      l_qseq
+ *   mapq      "bdqual": AM aux tag if present else MAPQ, as uint8 (io/Alignment.cpp:12-23)
+ *   lib       library index resolved from the RG tag (io/BamConfig.hpp:62-72 fallback included)
+ *   bam       index of the physical file the record came from (pass-1 counters are per file,
+ *             io/BamSummary.cpp:123,135-138)
+ *   name_key  64-bit key of the read name; mates share it (ReadRegionData.cpp:109 joins on qname) */
+typedef struct bdx_batch {
+    const int32_t *tid, *pos, *mtid, *mpos, *isize;
+    const uint16_t *flag, *qlen;
+    const uint8_t *mapq, *lib, *bam;
+    const uint64_t* name_key;
+    size_t n;
+} bdx_batch;
+
+/* Replaces: ConfigLoader + BreakDancer construction (io/ConfigLoader.cpp:18-44, BreakDancer.cpp:87-128).
+ * max_read_window_size0 is BamConfig::max_read_window_size() (io/BamConfig.cpp:92-93,121). */
+int bdx_create(bdx_ctx** out, const bdx_opts* opts, const bdx_lib* libs, int nlibs, int nbams, int ntids,
+               int max_read_window_size0, int device);
+void bdx_destroy(bdx_ctx* ctx);
+const char* bdx_strerror(int code);
+const char* bdx_last_error(const bdx_ctx* ctx);
+
+/* Replaces: AlignmentSource::next feeding BamSummary::_analyze_bam and BreakDancer::push_read.
+ * bdx_push copies a host batch (pinned recommended) into the HBM-resident SoA asynchronously;
+ * bdx_set_device_reads adopts arrays that already live in HBM (no copy; must stay valid until
+ * bdx_destroy; every array base 16-byte aligned). */
+int bdx_reserve(bdx_ctx* ctx, size_t n_reads);
+int bdx_push(bdx_ctx* ctx, const bdx_batch* host_batch);
+int bdx_set_device_reads(bdx_ctx* ctx, const bdx_batch* device_batch);
+
+/* Replaces: BamSummary::_analyze_bams (io/BamSummary.cpp:129-150), main()'s density/window block
+ * (BreakDancerMax.cpp:83-116) and BreakDancer::run (BreakDancer.cpp:131-144) up to the scored SV list. */
+int bdx_run(bdx_ctx* ctx);
+
+typedef struct bdx_summary {
+    uint64_t n_reads;
+    uint64_t n_anomalous;        /* reads entering the region accumulator */
+    uint32_t covered_ref_len;    /* BamSummary::covered_reference_length() */
+    int32_t window;              /* final max_read_window_size (BreakDancerMax.cpp:109-116) */
+    uint32_t n_candidates;       /* candidate regions cut by the sliding window */
+    uint32_t n_regions;          /* accepted regions (ReadRegionData::add_region calls) */
+    uint32_t n_pairs;            /* mate pairs with both reads in accepted regions */
+    uint32_t n_groups;           /* distinct region x region connections */
+    uint32_t n_svs;              /* SV candidates that reached scoring */
+    uint32_t n_svs_printed;      /* ... with score > opts.score_threshold */
+} bdx_summary;
+int bdx_get_summary(const bdx_ctx* ctx, bdx_summary* out);
+
+/* pass-1 counters: lib_read_count[nlibs], bam_read_count[nbams], flag_hist[nlibs*11] (BamSummary /
+ * LibraryFlagDistribution), seqcov[nlibs] (BamSummary.cpp:140-149), density[nlibs] (read density of the
+ * library's key, BreakDancerMax.cpp:94-107).  Any pointer may be NULL. */
+int bdx_get_counters(const bdx_ctx* ctx, uint32_t* lib_read_count, uint32_t* bam_read_count, uint32_t* flag_hist,
+                     float* seqcov, float* density);
+
+/* BasicRegion (breakdancer/BasicRegion.hpp:24-46) as created by add_region */
+typedef struct bdx_region {
+    int32_t tid, start, end, normal_read_pairs, fwd_read_count, rev_read_count;
+    int32_t n_reads;  /* anomalous reads in the region */
+    int32_t stored;   /* reads kept for SV building (ReadRegionData.cpp:118-121) */
+    int32_t max_qlen; /* BreakDancer::_max_readlen when the region closed */
+} bdx_region;
+int bdx_get_regions(const bdx_ctx* ctx, bdx_region* out, size_t cap);
+
+/* One SV candidate = one process_sv call that reached the score (BreakDancer.cpp:348-497).
+ * pos[] are 1-based as printed.  lib_* / cn_* index the flat lists below. */
+typedef struct bdx_sv {
+    int32_t chr[2], pos[2], fwd[2], rev[2];
+    int32_t flag;       /* dominant ReadFlag (SvBuilder::choose_sv_flag) */
+    int32_t size;       /* diffspan */
+    int32_t score;      /* PhredQ */
+    int32_t num_reads;  /* flag_counts[flag] */
+    int32_t printed;    /* score > opts.score_threshold */
+    int32_t region[2];  /* region ids; region[1] = -1 for a single-region SV */
+    int32_t lib_begin, lib_count; /* (library, pairs) of the dominant flag, ascending library index */
+    int32_t cn_begin, cn_count;   /* (key, copy number); key = library index with -a else BAM index */
+    float allele_frequency;
+    double logp;        /* ComputeProbScore result (BreakDancer.cpp:44-84) */
+} bdx_sv;
+int bdx_get_svs(const bdx_ctx* ctx, bdx_sv* out, size_t cap);
+int bdx_get_sv_lists(const bdx_ctx* ctx, int32_t* lib_index, int32_t* lib_pairs, size_t lib_cap, int32_t* cn_key,
+                     float* cn_value, size_t cn_cap);
+
+/* debug / parity: per-read class byte of the last bdx_run (n_reads bytes) */
+int bdx_get_read_class(const bdx_ctx* ctx, uint8_t* out, size_t cap);
+
+/* stage timings of the last bdx_run in milliseconds (HIP events on the context's stream):
+ * [0] classify kernel, [1] compaction, [2] region cut, [3] mate join + grouping, [4] device->host,
+ * [5] host walk, [6] score kernel + readback, [7] whole run.  Returns the number written. */
+int bdx_get_timings(const bdx_ctx* ctx, float* ms, int cap);
+
+/* Kernel-level entry points for parity tests.
+ * bdx_classify replaces IAlignmentClassifier::classify (io/IlluminaPEReadClassifier.cpp:59-101) plus the
+ * filter/remap half of push_read: host arrays in, class bytes out.
+ * bdx_poisson_log_upper_tail replaces log(cdf(complement(poisson(lambda), k))) (BreakDancer.cpp:64-65). */
+int bdx_classify(const bdx_opts* opts, const bdx_lib* libs, int nlibs, const bdx_batch* host_batch, uint8_t* cls_out,
+                 int device);
+int bdx_poisson_log_upper_tail(const double* lambda, const int32_t* k, double* out, size_t n, int device);
+
+/* device the context is bound to and the HIP stream it launches on (as void*), for callers that time it */
+int bdx_device(const bdx_ctx* ctx);
+void* bdx_stream(const bdx_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BDX_H */

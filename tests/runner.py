@@ -1,0 +1,92 @@
+"""Shared machinery of the parity tests: run the oracle, run the product on the same merged stream, compare."""
+import numpy as np
+
+from helpers import OracleRun, make_opts
+
+import breakdancer_amd as bda
+from breakdancer_amd.api import Options, LibraryConfig
+
+
+def oracle_case(config, streams, targets, opts):
+    run = OracleRun(config, opts)
+    run.set_targets(targets)
+    for b, st in enumerate(streams):
+        d = dict(st)
+        d["lib"] = np.array([run.lib_of_rg(g) for g in st["rg"]], dtype=np.int32)
+        run.set_stream(b, d)
+    return run.run()
+
+
+def product_options(opts):
+    return Options(min_len=opts["min_len"], cut_sd=opts["cut_sd"], max_sd=opts["max_sd"], min_map_qual=opts["min_map_qual"],
+                   min_read_pair=opts["min_read_pair"], seq_coverage_lim=opts["seq_coverage_lim"],
+                   buffer_size=opts["buffer_size"], transchr_rearrange=bool(opts["transchr_rearrange"]),
+                   fisher=bool(opts["fisher"]), Illumina_long_insert=bool(opts["illumina_long_insert"]),
+                   CN_lib=bool(opts["cn_lib"]), print_AF=bool(opts["print_af"]), score_threshold=opts["score_threshold"],
+                   chr="x" if opts["chr_tid"] >= 0 else "")
+
+
+def product_from_oracle(run, device=0):
+    """Feed the product the exact merged stream the oracle consumed (the producer's job in the CLI)."""
+    libs = [LibraryConfig(*[float(x) for x in run.lib_f[i]], min_mapping_quality=int(run.lib_i[i, 0]),
+                          bam_file_index=int(run.lib_i[i, 1]), name=run.lib_names[i]) for i in range(run.nlibs)]
+    bd = bda.BreakDancer(product_options(run.opts), libs, run.nbams, ntids=0, max_read_window_size=run.w0, device=device)
+    soa = run.merged_soa()
+    if run.n_merged:
+        bd.push_reads(soa)
+    bd.run()
+    return bd
+
+
+def compare(run, bd, logp_tol=1e-9):
+    s = bd.summary()
+    assert s["n_reads"] == run.n_merged
+    assert s["covered_ref_len"] == run.ref_len, (s["covered_ref_len"], run.ref_len)
+    assert s["window"] == run.W, (s["window"], run.W)
+    c = bd.counters()
+    np.testing.assert_array_equal(c["lib_read_count"], run.lib_cnt)
+    np.testing.assert_array_equal(c["bam_read_count"], run.bam_cnt)
+    np.testing.assert_array_equal(c["flag_hist"], run.hist)
+    np.testing.assert_array_equal(c["seqcov"].view(np.uint32), run.seqcov.view(np.uint32))
+    if run.n_merged:
+        cls = bd.read_class()
+        np.testing.assert_array_equal(cls & 0x3F, run.cls)
+    # regions as created by add_region
+    regs = bd.regions()
+    assert len(regs) == run.n_regions, (len(regs), run.n_regions)
+    if run.n_regions:
+        o = run.regions
+        for name, col in (("tid", 1), ("start", 2), ("end", 3), ("normal_read_pairs", 4), ("fwd_read_count", 5),
+                          ("rev_read_count", 6), ("n_reads", 7), ("stored", 8)):
+            np.testing.assert_array_equal(regs[name], o[:, col], err_msg=name)
+    svs, (li, lp), (ck, cv) = bd.svs()
+    assert len(svs) == run.n_svs, (len(svs), run.n_svs)
+    if run.n_svs:
+        oi, od = run.sv_i, run.sv_d
+        np.testing.assert_array_equal(svs["chr"][:, 0], oi[:, 0]); np.testing.assert_array_equal(svs["pos"][:, 0], oi[:, 1])
+        np.testing.assert_array_equal(svs["fwd"][:, 0], oi[:, 2]); np.testing.assert_array_equal(svs["rev"][:, 0], oi[:, 3])
+        np.testing.assert_array_equal(svs["chr"][:, 1], oi[:, 4]); np.testing.assert_array_equal(svs["pos"][:, 1], oi[:, 5])
+        np.testing.assert_array_equal(svs["fwd"][:, 1], oi[:, 6]); np.testing.assert_array_equal(svs["rev"][:, 1], oi[:, 7])
+        np.testing.assert_array_equal(svs["flag"], oi[:, 8], err_msg="flag")
+        np.testing.assert_array_equal(svs["size"], oi[:, 9], err_msg="size")
+        np.testing.assert_array_equal(svs["num_reads"], oi[:, 11], err_msg="num_reads")
+        np.testing.assert_array_equal(svs["lib_count"], oi[:, 13]); np.testing.assert_array_equal(svs["cn_count"], oi[:, 14])
+        # float32 copy numbers / allele frequency: bit-exact (NaNs compared by bit pattern up to sign/payload class)
+        af_p, af_o = svs["allele_frequency"], od[:, 1].astype(np.float32)
+        np.testing.assert_array_equal(np.isnan(af_p), np.isnan(af_o))
+        m = ~np.isnan(af_o)
+        np.testing.assert_array_equal(af_p[m].view(np.uint32), af_o[m].view(np.uint32))
+        np.testing.assert_array_equal(li, run.sv_lib[:, 0]); np.testing.assert_array_equal(lp, run.sv_lib[:, 1])
+        np.testing.assert_array_equal(ck, run.sv_cn_key)
+        np.testing.assert_array_equal(cv.view(np.uint32), run.sv_cn_val.view(np.uint32))
+        # Poisson log tail: tolerance stated by north_star is 1e-6; we hold 1e-9 relative
+        lp_p, lp_o = svs["logp"], od[:, 0]
+        np.testing.assert_array_equal(np.isnan(lp_p), np.isnan(lp_o))
+        np.testing.assert_array_equal(np.isinf(lp_p), np.isinf(lp_o))
+        f = np.isfinite(lp_o)
+        if f.any():
+            err = np.abs(lp_p[f] - lp_o[f]) / np.maximum(1.0, np.abs(lp_o[f]))
+            assert err.max() < logp_tol, err.max()
+        np.testing.assert_array_equal(svs["score"], oi[:, 10], err_msg="score")
+        np.testing.assert_array_equal(svs["printed"], oi[:, 12], err_msg="printed")
+    return s

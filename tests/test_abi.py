@@ -1,0 +1,55 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/bdx.h declares (no compute calls)."""
+import os
+import re
+
+import pytest
+
+import breakdancer_amd._lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "bdx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bdx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(L.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = L.load()
+    syms = declared_symbols()
+    assert len(syms) >= 18
+    for s in syms:
+        assert hasattr(lib, s), "libbdx.so does not export %s" % s
+    assert set(syms) == set(L.EXPORTS)
+
+
+def test_struct_layouts_match_the_header():
+    assert L.SV_DTYPE.itemsize == 88 and L.SV_DTYPE.fields["logp"][1] == 80
+    assert L.REGION_DTYPE.itemsize == 36
+    import ctypes as C
+    assert C.sizeof(L.bdx_opts) == 56 and C.sizeof(L.bdx_lib) == 28 and C.sizeof(L.bdx_batch) == 96
+    assert C.sizeof(L.bdx_summary) == 48
+
+
+def test_no_gpu_means_loud_failure():
+    """On a box without a GPU bdx_create must fail (no CPU fallback on the product path)."""
+    import ctypes as C
+    lib = L.load()
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("GPU present")
+    except ImportError:
+        pass
+    o = L.bdx_opts()
+    lib.bdx_opts_default(C.byref(o))
+    assert o.min_map_qual == 35 and o.score_threshold == 30 and o.buffer_size == 100
+    libs = (L.bdx_lib * 1)()
+    h = C.c_void_p()
+    rc = lib.bdx_create(C.byref(h), C.byref(o), libs, 1, 1, 1, 100, 0)
+    assert rc != 0
+    assert lib.bdx_strerror(rc).decode() != "ok"

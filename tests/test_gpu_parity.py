@@ -1,0 +1,169 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on identical inputs."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from fuzzgen import OPTION_SETS, make_case
+from helpers import GOLDEN, OracleRun, load_chr21, make_opts
+from runner import compare, oracle_case, product_from_oracle
+
+pytestmark = pytest.mark.gpu
+TID21 = 22
+
+
+def test_native_library_is_the_one_running():
+    import breakdancer_amd._lib as L
+    lib = L.load()
+    assert os.path.samefile(lib._name, os.path.join(os.path.dirname(L.__file__), "libbdx.so"))
+
+
+CHR21_SETS = [dict(chr_tid=TID21), dict(), dict(chr_tid=TID21, print_af=1), dict(chr_tid=TID21, cn_lib=1),
+              dict(chr_tid=TID21, cn_lib=1, print_af=1), dict(transchr_rearrange=1), dict(illumina_long_insert=1),
+              dict(buffer_size=1), dict(buffer_size=2), dict(min_read_pair=1, score_threshold=-1), dict(min_map_qual=0),
+              dict(min_len=0, score_threshold=-1), dict(fisher=1), dict(max_sd=600), dict(seq_coverage_lim=1)]
+
+
+@pytest.mark.parametrize("kw", CHR21_SETS)
+def test_chr21_fixtures_match_oracle(kw):
+    run = load_chr21(make_opts(**kw)).run()
+    bd = product_from_oracle(run)
+    s = compare(run, bd)
+    if not kw or kw == dict(chr_tid=TID21):
+        assert s["n_svs_printed"] == 4 and s["window"] == 287 and s["covered_ref_len"] == 5626088
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_differential_fuzz(seed):
+    cfg, streams, targets = make_case(seed)
+    for o in (OPTION_SETS[seed % len(OPTION_SETS)], OPTION_SETS[(seed * 7 + 3) % len(OPTION_SETS)]):
+        run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1, **o))
+        bd = product_from_oracle(run)
+        compare(run, bd)
+        bd.close()
+
+
+def test_empty_and_tiny_inputs():
+    cfg = "readgroup:rg1\tmap:a.bam\treadlen:100\tlib:l1\tmean:400\tstd:30\tlower:310\tupper:490\n"
+    empty = dict(tid=np.zeros(0, np.int32), pos=np.zeros(0, np.int32), mtid=np.zeros(0, np.int32), mpos=np.zeros(0, np.int32),
+                 isize=np.zeros(0, np.int32), flag=np.zeros(0, np.uint16), qlen=np.zeros(0, np.int32),
+                 bdqual=np.zeros(0, np.uint8), rg=[], name_id=np.zeros(0, np.uint64))
+    run = oracle_case(cfg, [empty], ["c1"], make_opts())
+    bd = product_from_oracle(run)
+    compare(run, bd)
+    assert bd.summary()["window"] == 50
+    # one pair, one anomalous read each: a single candidate region closed by the end of the stream
+    one = dict(tid=np.array([0, 0], np.int32), pos=np.array([100, 5000], np.int32), mtid=np.array([0, 0], np.int32),
+               mpos=np.array([5000, 100], np.int32), isize=np.array([5000, -5000], np.int32),
+               flag=np.array([0x1 | 0x20 | 0x40, 0x1 | 0x10 | 0x80], np.uint16), qlen=np.array([100, 100], np.int32),
+               bdqual=np.array([60, 60], np.uint8), rg=["rg1", "rg1"], name_id=np.array([7, 7], np.uint64))
+    run = oracle_case(cfg, [one], ["c1"], make_opts(min_read_pair=1, min_len=-1, score_threshold=-1))
+    compare(run, product_from_oracle(run))
+
+
+def test_ragged_batch_is_rejected():
+    import breakdancer_amd as bda
+    from breakdancer_amd.api import LibraryConfig, Options
+    bd = bda.BreakDancer(Options(), [LibraryConfig(400, 30, 490, 310, 100)], 1)
+    from breakdancer_amd.synth import make_chromosome
+    d = make_chromosome(length=200000, seed=3)
+    d["pos"] = d["pos"][:-1]
+    with pytest.raises(ValueError):
+        bd.push_reads(d)
+
+
+def test_poisson_kernel_against_mpmath_vectors():
+    """north_star: Poisson scores within 1e-6; the kernel holds 1e-10 relative on log p"""
+    from breakdancer_amd.api import poisson_log_upper_tail
+    v = json.load(open(os.path.join(GOLDEN, "poisson_vectors.json")))["poisson"]
+    lam = np.array([float(r["lambda"]) for r in v])
+    k = np.array([r["k"] for r in v], np.int32)
+    got = poisson_log_upper_tail(lam, k)
+    for r, g in zip(v, got):
+        if r["p_double_positive"]:
+            want = float(r["logp"])
+            assert abs(g - want) <= 1e-10 * max(1.0, abs(want)), (r, g)
+        else:
+            assert g == -math.inf or g < -700, (r, g)
+
+
+def _synth_case(length, seed, **kw):
+    from breakdancer_amd.synth import LIB_C2, make_chromosome
+    d = make_chromosome(length=length, seed=seed, **kw)
+    cfg = "readgroup:rg1\tplatform:illumina\tmap:syn.bam\treadlen:100.00\tlib:lib1\tlower:310.00\tupper:490.00\tmean:400.00\tstd:30.00\n"
+    st = dict(tid=d["tid"], pos=d["pos"], mtid=d["mtid"], mpos=d["mpos"], isize=d["isize"], flag=d["flag"],
+              qlen=d["qlen"].astype(np.int32), bdqual=d["mapq"], rg=["rg1"] * len(d["tid"]), name_id=d["name_key"])
+    return cfg, st
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(buffer_size=10), dict(cn_lib=1, print_af=1), dict(min_read_pair=5)])
+def test_synthetic_10mbp_matches_oracle(opts):
+    """scaled-down configs[1] (10 Mbp, 3 M reads): every intermediate and every SV row bit-exact vs the oracle"""
+    cfg, st = _synth_case(10_000_000, seed=11)
+    run = OracleRun(cfg, make_opts(**opts))
+    run.set_targets(["chrS"])
+    st = dict(st)
+    st["lib"] = np.zeros(len(st["tid"]), np.int32)
+    run.set_stream(0, st)
+    run.run()
+    assert run.n_svs > 100
+    compare(run, product_from_oracle(run))
+
+
+def test_full_size_properties():
+    """configs[1] at full size (50 Mbp, 15 M reads): size-independent properties of the path."""
+    import breakdancer_amd as bda
+    from breakdancer_amd.api import LibraryConfig, Options
+    from breakdancer_amd.synth import LIB_C2, make_chromosome
+    d = make_chromosome(length=50_000_000, seed=1)
+    n = len(d["tid"])
+
+    def run(arrs, **ow):
+        bd = bda.BreakDancer(Options(**ow), [LibraryConfig(**LIB_C2)], 1, max_read_window_size=200)
+        bd.push_reads(arrs)
+        return bd.run()
+
+    a = run(d)
+    sa = a.summary()
+    # (1) classifier census against a numpy restatement of the predicates (linearity of the counters)
+    sam = d["flag"].astype(np.int64)
+    ai = np.abs(d["isize"])
+    fr = ((sam & 0x10) != 0) != ((sam & 0x20) != 0)
+    left = d["pos"] < d["mpos"]
+    rf = fr & (left == ((sam & 0x10) != 0))
+    large = fr & ~rf & (ai > 490)
+    small = fr & ~rf & ~large & (ai < 310)
+    anom_all = (~fr) | rf | large | small
+    mq_ok = d["mapq"] > 35
+    assert sa["n_anomalous"] == int((anom_all & mq_ok).sum())
+    c = a.counters()
+    assert c["flag_hist"][0, 2] == int((large & mq_ok).sum()) and c["flag_hist"][0, 3] == int((small & mq_ok).sum())
+    assert c["lib_read_count"][0] == int(((sam & 0x2) != 0)[mq_ok].sum())
+    assert sa["covered_ref_len"] == int(d["pos"].max() - d["pos"].min())
+    # (2) idempotence / determinism: a second context over the same input gives identical results
+    b = run(d)
+    assert b.summary() == sa
+    np.testing.assert_array_equal(a.regions(), b.regions())
+    sv_a, la, ca = a.svs()
+    sv_b, lb, cb = b.svs()
+    assert sv_a.tobytes() == sv_b.tobytes()
+    # (3) regions are sorted, disjoint and respect the window: consecutive regions are separated by > W or rejected reads
+    r = a.regions()
+    assert (r["start"][1:] > r["end"][:-1]).all() and (r["end"] >= r["start"]).all()
+    assert int(r["n_reads"].sum()) <= sa["n_anomalous"]
+    # (4) pairs: every pair has both mates in accepted regions, so 2*pairs <= reads in accepted regions
+    assert 2 * sa["n_pairs"] <= int(r["n_reads"].sum())
+    # (5) batching invariance: pushing the same stream in 7 ragged batches changes nothing
+    bd = bda.BreakDancer(Options(), [LibraryConfig(**LIB_C2)], 1, max_read_window_size=200)
+    cuts = [0, 1, 1025, 300000, 4000001, 9999999, 12345678, n]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        bd.push_reads({k: v[lo:hi] for k, v in d.items()})
+    bd.run()
+    assert bd.summary() == sa
+    assert bd.svs()[0].tobytes() == sv_a.tobytes()
+    # (6) planted clusters are recovered: most DEL calls have ~12 supporting pairs and size ~ 1550-400
+    dels = sv_a[(sv_a["flag"] == 2) & (sv_a["printed"] == 1)]
+    assert len(dels) > 1000
+    assert abs(np.median(dels["size"]) - 1150) < 40
