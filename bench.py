@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""bench.py -- read-pairs/s of the anomalous read-pair clustering hot path on N MI355X (one rank per GPU).
+
+Workload (BASELINE.json configs[1]): synthetic single chromosome, 50 Mbp, 30x, 2x100 bp, 1 library, ~1 % discordant
+pairs -> 15 M records = 7.5 M read pairs per GPU, resident in HBM before the timed region.  A "step" is one full pass
+of the hot path (bdx_run: classify -> compact -> region cut -> mate join -> host walk -> Poisson score) over that
+batch.  With N > 1 every rank owns its own chromosome (the path shards by chromosome, no data-path collective), so
+scaling is weak and `value` is the aggregate over all ranks.
+
+One JSON line on rank 0; see the task contract for the fields.  `roofline` is for the dominant kernel (K1, the
+streaming classifier): algorithmic bytes = 28 B/read x reads per launch, divided by the kernel's
+average duration measured with HIP events on the context's stream (bdx_get_timings).  `cpu_baseline` times the CPU
+oracle (a single-threaded port of the reference's path; the reference itself needs Boost and cannot be built here)
+on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_READ = 28          # 27 B SoA record read + 1 B class byte written
+HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec (MI355X_MICROARCH.md)
+CHROM_LEN = 50_000_000
+CPU_SAMPLE_LEN = 50_000_000       # CPU baseline sample: the full configs[1] chromosome, repeated until ~12 s of CPU work
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--length", type=int, default=CHROM_LEN, help="chromosome length per GPU (default: configs[1])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(seed):
+    """Time the oracle (oracle/libbdoracle.so, single thread) on a bounded sample of the workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import OracleRun, make_opts
+    from breakdancer_amd.synth import make_chromosome
+    d = make_chromosome(length=CPU_SAMPLE_LEN, seed=seed)
+    n = len(d["tid"])
+    cfg = "readgroup:rg1\tplatform:illumina\tmap:syn.bam\treadlen:100.00\tlib:lib1\tlower:310.00\tupper:490.00\tmean:400.00\tstd:30.00\n"
+    best, spent, reps = None, 0.0, 0
+    while spent < 12.0 and reps < 40:
+        run = OracleRun(cfg, make_opts())
+        run.set_targets(["chrS"])
+        st = dict(tid=d["tid"], pos=d["pos"], mtid=d["mtid"], mpos=d["mpos"], isize=d["isize"], flag=d["flag"],
+                  qlen=d["qlen"].astype(np.int32), bdqual=d["mapq"], lib=np.zeros(n, np.int32), name_id=d["name_key"])
+        run.set_stream(0, st)
+        t0 = time.perf_counter()
+        run.L.bdo_run(run.h)
+        dt = time.perf_counter() - t0
+        del run
+        best = dt if best is None else min(best, dt)
+        spent += dt
+        reps += 1
+    return {"value": (n / 2) / best, "unit": "read-pairs/s", "cores": 1, "kind": "port",
+            "sample": "oracle (single-thread C++ port of the reference path, records already decoded to SoA) on %d Mbp of "
+                      "the same synthetic workload = %d read pairs; best of %d runs (%.1f s of CPU work), %.2f s per run"
+                      % (CPU_SAMPLE_LEN // 1000000, n // 2, reps, spent, best)}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import breakdancer_amd as bda
+    from breakdancer_amd.api import BATCH_FIELDS, LibraryConfig, Options
+    from breakdancer_amd.synth import LIB_C2, make_chromosome
+
+    d = make_chromosome(length=a.length, seed=1 + rank, name_base=rank << 40)
+    n = len(d["tid"])
+    # inputs resident in HBM before the timed region (torch owns the memory; libbdx adopts the pointers)
+    tens = {}
+    for k, dt in BATCH_FIELDS:
+        arr = np.ascontiguousarray(d[k], dtype=dt)
+        view = {np.dtype(np.uint16): np.int16, np.dtype(np.uint64): np.int64}.get(arr.dtype)
+        tens[k] = torch.from_numpy(arr.view(view) if view else arr).to(dev)
+    torch.cuda.synchronize()
+    bd = bda.BreakDancer(Options(), [LibraryConfig(**LIB_C2)], 1, ntids=1, max_read_window_size=200, device=local)
+    bd.set_device_reads({k: t.data_ptr() for k, t in tens.items()}, n)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        bd.run()
+    barrier()
+    k1_ms, stage = [], {}
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        bd.run()
+        tm = bd.timings()
+        k1_ms.append(tm["classify"])
+        for k, v in tm.items():
+            stage[k] = stage.get(k, 0.0) + v
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    summary = bd.summary()
+
+    if rank == 0:
+        pairs = n // 2
+        value = world * pairs * a.steps / dt
+        k1_avg_ms = float(np.mean(k1_ms))
+        achieved = ALGO_BYTES_PER_READ * n / (k1_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "k1_traffic.json")
+        if os.path.exists(tp):
+            try:
+                tj = json.load(open(tp))
+                if tj.get("reads_per_launch") == n:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "anomalous read-pairs/s (end-to-end SV call)", "value": value, "unit": "read-pairs/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "configs[1]: synthetic single chromosome %d Mbp, 30x, 2x100 bp, 1 library, ~1%% discordant "
+                                   "pairs; %d read pairs (%d records) per GPU, HBM-resident SoA" % (a.length // 1000000, pairs, n),
+                       "sharding": "one chromosome per GPU, no data-path collective", "svs_per_gpu": summary["n_svs_printed"],
+                       "stage_ms": {k: v / a.steps for k, v in stage.items()}},
+            "roofline": {"bound": "hbm", "kernel": "k1_classify_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_READ * n,
+                         "avg_kernel_ms": k1_avg_ms},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(seed=1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,69 +14,118 @@
 
 #include <algorithm>
 #include <cmath>
-#include <map>
-#include <unordered_map>
 
 namespace bdx {
 
 namespace {
 
+// Flat, allocation-light replay.  Groups are kept sorted by (hi, lo); a flush covers the groups whose
+// later region `hi` was added since the previous flush, so a vertex's adjacency in ascending neighbour order
+// is [groups with hi == v, ascending lo (the self group last)] followed by [groups with lo == v, ascending hi],
+// the latter threaded through `next_fwd` in insertion order.  "Erased from the graph" == visited.
 struct Group {
-    uint32_t lo, hi;
-    uint32_t weight = 0;  // pairs = the reference's edge weight
-    bool alive = true;
-    std::vector<GroupPart> parts;
+    uint32_t lo, hi, weight;
+    uint32_t pbeg, pcnt;
+    int32_t next_fwd;
+    bool alive, edge_done;
+};
+
+struct OldVertex {  // endpoint from an earlier flush: only has edges to regions of the current window
+    uint32_t id;
+    int32_t head, tail;
+    bool visited;
 };
 
 struct Walker {
     const WalkInput& in;
     WalkResult& out;
+    std::vector<GroupPart> parts;  // sorted by (hi, lo, flag, lib), duplicates merged
     std::vector<Group> groups;
-    std::unordered_map<uint64_t, uint32_t> gindex;
+    std::vector<uint32_t> ghi;     // groups with hi == r are [ghi[r], ghi[r+1])
+    std::vector<uint8_t> stored_;
     int max_readlen = 0;
 
     Walker(const WalkInput& i, WalkResult& o) : in(i), out(o) {}
 
-    static uint64_t gkey(uint32_t lo, uint32_t hi) { return ((uint64_t)lo << 32) | hi; }
-
-    bool stored(uint32_t r) const {  // ReadRegionData.cpp:118-121
-        const HostRegion& R = (*in.regions)[r];
-        const int valid = in.opts.chr_restricted ? (int)R.nonctx : (int)R.n;
-        return valid >= in.opts.min_read_pair;
-    }
-
     void build_groups() {
-        for (const GroupPart& p : *in.parts) {
-            const uint64_t k = gkey(p.lo, p.hi);
-            auto it = gindex.find(k);
-            uint32_t gi;
-            if (it == gindex.end()) {
-                gi = (uint32_t)groups.size();
-                gindex.emplace(k, gi);
-                groups.emplace_back();
-                groups.back().lo = p.lo;
-                groups.back().hi = p.hi;
-            } else {
-                gi = it->second;
+        const std::vector<GroupPart>& src = *in.parts;
+        const uint32_t NR = (uint32_t)in.regions->size();
+        // counting sort by hi, then tiny insertion sorts inside each hi bucket
+        std::vector<uint32_t> cnt(NR + 2, 0);
+        for (const GroupPart& p : src) ++cnt[p.hi + 1];
+        for (uint32_t r = 0; r <= NR; ++r) cnt[r + 1] += cnt[r];
+        parts.resize(src.size());
+        {
+            std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
+            for (const GroupPart& p : src) parts[cur[p.hi]++] = p;
+        }
+        auto less = [](const GroupPart& a, const GroupPart& b) {
+            if (a.lo != b.lo) return a.lo < b.lo;
+            if (a.flag != b.flag) return a.flag < b.flag;
+            return a.lib < b.lib;
+        };
+        for (uint32_t r = 0; r < NR; ++r) {
+            const uint32_t b = cnt[r], e = cnt[r + 1];
+            for (uint32_t i = b + 1; i < e; ++i) {
+                GroupPart x = parts[i];
+                uint32_t j = i;
+                while (j > b && less(x, parts[j - 1])) { parts[j] = parts[j - 1]; --j; }
+                parts[j] = x;
             }
-            Group& g = groups[gi];
-            g.weight += p.pairs;
-            bool merged = false;
-            for (GroupPart& q : g.parts)
-                if (q.flag == p.flag && q.lib == p.lib) { q.pairs += p.pairs; q.sum_isize += p.sum_isize; merged = true; break; }
-            if (!merged) g.parts.push_back(p);
+        }
+        // merge duplicates (a group can straddle two K4 workgroups) and cut into groups
+        ghi.assign(NR + 1, 0);
+        size_t w = 0;
+        groups.reserve(parts.size());
+        for (size_t i = 0; i < parts.size(); ++i) {
+            const GroupPart p = parts[i];
+            if (w && parts[w - 1].hi == p.hi && parts[w - 1].lo == p.lo && parts[w - 1].flag == p.flag && parts[w - 1].lib == p.lib) {
+                parts[w - 1].pairs += p.pairs;
+                parts[w - 1].sum_isize += p.sum_isize;
+                groups.back().weight += p.pairs;
+                continue;
+            }
+            if (groups.empty() || groups.back().hi != p.hi || groups.back().lo != p.lo) {
+                Group g;
+                g.lo = p.lo; g.hi = p.hi; g.weight = 0; g.pbeg = (uint32_t)w; g.pcnt = 0; g.next_fwd = -1;
+                g.alive = true; g.edge_done = false;
+                groups.push_back(g);
+            }
+            parts[w++] = p;
+            groups.back().weight += p.pairs;
+            groups.back().pcnt++;
+        }
+        parts.resize(w);
+        {
+            uint32_t gi = 0;
+            for (uint32_t r = 0; r < NR; ++r) {
+                ghi[r] = gi;
+                while (gi < groups.size() && groups[gi].hi == r) ++gi;
+            }
+            ghi[NR] = gi;
         }
         out.n_groups = (uint32_t)groups.size();
+        stored_.resize(NR);
+        for (uint32_t r = 0; r < NR; ++r) {  // ReadRegionData.cpp:118-121
+            const HostRegion& R = (*in.regions)[r];
+            const int valid = in.opts.chr_restricted ? (int)R.nonctx : (int)R.n;
+            stored_[r] = valid >= in.opts.min_read_pair;
+        }
     }
 
     Group* alive_group(uint32_t lo, uint32_t hi) {
-        auto it = gindex.find(gkey(lo, hi));
-        if (it == gindex.end()) return nullptr;
-        Group& g = groups[it->second];
-        if (!g.alive) return nullptr;
-        if (!stored(lo) || !stored(hi)) return nullptr;  // mates of an unstored region never complete a pair
-        return &g;
+        for (uint32_t g = ghi[hi]; g < ghi[hi + 1]; ++g) {
+            if (groups[g].lo != lo) continue;
+            if (!groups[g].alive) return nullptr;
+            if (!stored_[lo] || !stored_[hi]) return nullptr;  // mates of an unstored region never complete a pair
+            return &groups[g];
+        }
+        return nullptr;
     }
+
+    struct LibAcc {
+        int lib, rc, span;
+    };
 
     void process_sv(const int* snodes, int n) {
         const std::vector<HostRegion>& R = *in.regions;
@@ -84,14 +133,12 @@ struct Walker {
         const int A = snodes[0], B = n == 2 ? snodes[1] : -1;
         int num_pairs = 0;
         int flag_counts[BDX_NUM_FLAGS] = {0};
-        std::map<int, int> rc[BDX_NUM_FLAGS], span[BDX_NUM_FLAGS];
         Group* gs[3] = {alive_group(A, A), n == 2 ? alive_group(A, B) : nullptr, n == 2 ? alive_group(B, B) : nullptr};
         for (Group* g : gs) {
             if (!g) continue;
-            for (const GroupPart& p : g->parts) {
+            for (uint32_t i = 0; i < g->pcnt; ++i) {
+                const GroupPart& p = parts[g->pbeg + i];
                 flag_counts[p.flag] += (int)p.pairs;
-                rc[p.flag][p.lib] += (int)p.pairs;
-                span[p.flag][p.lib] += (int)p.sum_isize;
                 num_pairs += (int)p.pairs;
             }
             g->alive = false;  // paired reads leave both regions before any gate (BreakDancer.cpp:363-368)
@@ -105,6 +152,21 @@ struct Walker {
             if (flag_counts[best] > 0) flag = best;
         }
         if (flag_counts[flag] < o.min_read_pair) return;
+        // per-library pairs / spans of the dominant flag, ascending library index (std::map order in the reference)
+        std::vector<LibAcc>& la = lib_acc_;
+        la.clear();
+        for (Group* g : gs) {
+            if (!g) continue;
+            for (uint32_t i = 0; i < g->pcnt; ++i) {
+                const GroupPart& p = parts[g->pbeg + i];
+                if (p.flag != flag) continue;
+                size_t k = 0;
+                while (k < la.size() && la[k].lib < (int)p.lib) ++k;
+                if (k < la.size() && la[k].lib == (int)p.lib) { la[k].rc += (int)p.pairs; la[k].span += (int)p.sum_isize; }
+                else la.insert(la.begin() + k, LibAcc{(int)p.lib, (int)p.pairs, (int)p.sum_isize});
+            }
+        }
+        const int nacc = (int)la.size();
 
         int chr[2], pos[2], fwd[2], rev[2];
         const HostRegion& ra = R[A];
@@ -143,8 +205,7 @@ struct Walker {
         if (flag != BDX_ARP_RF && flag != BDX_ARP_RR && pos[0] + max_readlen - 5 < pos[1]) pos[0] += max_readlen - 5;
 
         float diff = 0;
-        for (auto const& kv : rc[flag])
-            diff += float(span[flag][kv.first]) - float(kv.second) * in.libs[kv.first].mean_insertsize;
+        for (int i = 0; i < nacc; ++i) diff += float(la[i].span) - float(la[i].rc) * in.libs[la[i].lib].mean_insertsize;
         const int diffspan = int(diff / float(flag_counts[flag]) + 0.5);
 
         int total_region_size = ra.end - ra.start + 1;
@@ -155,106 +216,133 @@ struct Walker {
         for (int i = 0; i < 2; ++i) { sv.chr[i] = chr[i]; sv.pos[i] = pos[i] + 1; sv.fwd[i] = fwd[i]; sv.rev[i] = rev[i]; }
         sv.flag = flag; sv.size = diffspan; sv.score = 0; sv.num_reads = flag_counts[flag]; sv.printed = 0;
         sv.region[0] = A; sv.region[1] = B;
-        sv.lib_begin = (int)out.lib_index.size(); sv.lib_count = (int)rc[flag].size();
+        sv.lib_begin = (int)out.lib_index.size(); sv.lib_count = nacc;
         sv.cn_begin = cn_begin; sv.cn_count = nkeys_present;
         sv.allele_frequency = allele_frequency; sv.logp = 0;
         hs.term_begin = (uint32_t)out.terms.size();
-        hs.term_count = (uint32_t)rc[flag].size();
-        for (auto const& kv : rc[flag]) {
-            out.lib_index.push_back(kv.first);
-            out.lib_pairs.push_back(kv.second);
-            const uint32_t nflag = in.hist[(size_t)kv.first * BDX_NUM_FLAGS + flag];
+        hs.term_count = (uint32_t)nacc;
+        for (int i = 0; i < nacc; ++i) {
+            out.lib_index.push_back(la[i].lib);
+            out.lib_pairs.push_back(la[i].rc);
+            const uint32_t nflag = in.hist[(size_t)la[i].lib * BDX_NUM_FLAGS + flag];
             double lambda = double(total_region_size) * (double(nflag) / double(in.covered_ref_len));
             lambda = std::max(1.0e-10, lambda);
-            out.terms.push_back(SvTerm{lambda, kv.second});
+            out.terms.push_back(SvTerm{lambda, la[i].rc});
         }
         out.svs.push_back(hs);
     }
 
-    // BreakDancer.cpp:266-346 over the edges whose later region was added since the previous flush
-    void flush(std::map<int, std::map<int, int>>& graph) {
-        const int mrp = in.opts.min_read_pair;
-        auto ii = graph.begin();
-        while (ii != graph.end()) {
-            std::vector<int> tails{ii->first};
-            bool need_inc = true;
-            while (!tails.empty()) {
-                std::vector<int> newtails;
-                for (int tail : tails) {
-                    auto found = graph.find(tail);
-                    if (found == graph.end()) continue;
-                    auto& gt = found->second;
-                    auto it = gt.begin();
-                    while (it != gt.end()) {
-                        const int s1 = it->first, nlinks = it->second;
-                        gt.erase(it++);
-                        if (nlinks < mrp) continue;
-                        int snodes[2];
-                        int n;
-                        if (tail != s1) {
-                            auto a = graph.find(s1);
-                            if (a != graph.end()) a->second.erase(tail);
-                            snodes[0] = std::min(s1, tail);
-                            snodes[1] = std::max(s1, tail);
-                            n = 2;
-                        } else {
-                            snodes[0] = s1;
-                            n = 1;
-                        }
-                        newtails.push_back(s1);
-                        process_sv(snodes, n);
-                    }
-                    // `ii` may already be end() here; the reference dereferences it anyway (UB that in practice
-                    // compares against a non-vertex word), so it is treated as "not the start vertex"
-                    if (ii != graph.end() && tail == ii->first) {
-                        graph.erase(ii++);
-                        need_inc = false;
-                    } else {
-                        graph.erase(tail);
-                    }
-                }
-                tails.swap(newtails);
-            }
-            if (need_inc) ++ii;
+    // ---- one flush (BreakDancer.cpp:266-346) over the groups with hi in (prev, last] ----------------------------
+    std::vector<LibAcc> lib_acc_;
+    std::vector<int32_t> win_head, win_tail;
+    std::vector<uint8_t> win_visited;
+    std::vector<OldVertex> olds;
+    std::vector<int> tails, newtails;
+
+    OldVertex* find_old(uint32_t id) {
+        for (OldVertex& o : olds)
+            if (o.id == id) return &o;
+        return nullptr;
+    }
+
+    void try_edge(uint32_t gi, int tail, int s1) {
+        Group& g = groups[gi];
+        // an entry below the gate is skipped every time it is met (from either endpoint); one above it is
+        // consumed from the side that reaches it first (erase_edge removes the reverse entry)
+        if (g.edge_done || (int)g.weight < in.opts.min_read_pair) return;
+        g.edge_done = true;
+        int snodes[2];
+        int n;
+        if (tail != s1) { snodes[0] = std::min(s1, tail); snodes[1] = std::max(s1, tail); n = 2; }
+        else { snodes[0] = s1; n = 1; }
+        newtails.push_back(s1);
+        process_sv(snodes, n);
+    }
+
+    void visit(int tail, int64_t prev) {
+        if (tail > prev) {
+            for (uint32_t gi = ghi[tail]; gi < ghi[tail + 1]; ++gi) try_edge(gi, tail, (int)groups[gi].lo);
+            for (int32_t gi = win_head[tail - prev - 1]; gi >= 0; gi = groups[gi].next_fwd) try_edge((uint32_t)gi, tail, (int)groups[gi].hi);
+            win_visited[tail - prev - 1] = 1;
+        } else {
+            OldVertex* ov = find_old((uint32_t)tail);
+            for (int32_t gi = ov->head; gi >= 0; gi = groups[gi].next_fwd) try_edge((uint32_t)gi, tail, (int)groups[gi].hi);
+            ov->visited = true;
         }
-        graph.clear();
+    }
+
+    bool is_visited(int v, int64_t prev) {
+        if (v > prev) return win_visited[v - prev - 1];
+        OldVertex* ov = find_old((uint32_t)v);
+        return !ov || ov->visited;
+    }
+
+    void bfs_from(int v, int64_t prev) {
+        tails.clear();
+        tails.push_back(v);
+        while (!tails.empty()) {
+            newtails.clear();
+            for (size_t i = 0; i < tails.size(); ++i) {
+                const int tail = tails[i];
+                if (is_visited(tail, prev)) continue;
+                visit(tail, prev);
+            }
+            tails.swap(newtails);
+        }
+    }
+
+    void flush(int64_t prev, int64_t last) {
+        if (last <= prev) return;
+        const uint32_t g0 = ghi[prev + 1], g1 = ghi[last + 1];
+        if (g0 == g1) return;
+        const size_t wn = (size_t)(last - prev);
+        win_head.assign(wn, -1);
+        win_tail.assign(wn, -1);
+        win_visited.assign(wn, 0);
+        olds.clear();
+        for (uint32_t gi = g0; gi < g1; ++gi) {
+            Group& g = groups[gi];
+            g.next_fwd = -1;
+            if (g.lo == g.hi) continue;
+            if ((int64_t)g.lo > prev) {
+                const size_t i = (size_t)(g.lo - prev - 1);
+                if (win_tail[i] < 0) win_head[i] = (int32_t)gi; else groups[win_tail[i]].next_fwd = (int32_t)gi;
+                win_tail[i] = (int32_t)gi;
+            } else {
+                OldVertex* ov = find_old(g.lo);
+                if (!ov) olds.push_back(OldVertex{g.lo, (int32_t)gi, (int32_t)gi, false});
+                else { groups[ov->tail].next_fwd = (int32_t)gi; ov->tail = (int32_t)gi; }
+            }
+        }
+        std::sort(olds.begin(), olds.end(), [](const OldVertex& a, const OldVertex& b) { return a.id < b.id; });
+        for (size_t i = 0; i < olds.size(); ++i)
+            if (!olds[i].visited) bfs_from((int)olds[i].id, prev);
+        for (int64_t v = prev + 1; v <= last; ++v) {
+            const size_t i = (size_t)(v - prev - 1);
+            if (win_visited[i]) continue;
+            if (ghi[v] == ghi[v + 1] && win_head[i] < 0) continue;  // not a vertex of this flush's graph
+            bfs_from((int)v, prev);
+        }
     }
 
     void run() {
         build_groups();
         const std::vector<HostRegion>& R = *in.regions;
-        const uint32_t NR = (uint32_t)R.size();
+        const int64_t NR = (int64_t)R.size();
         if (!in.any_anomalous) return;
-        // groups ordered by the region that completed them
-        std::vector<uint32_t> order(groups.size());
-        for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
-        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-            return groups[a].hi != groups[b].hi ? groups[a].hi < groups[b].hi : groups[a].lo < groups[b].lo;
-        });
         const int64_t period = std::max<int64_t>(1, (int64_t)in.opts.buffer_size + 1);
-        size_t next = 0;
-        std::map<int, std::map<int, int>> graph;
-        auto add_edges_upto = [&](uint32_t last) {
-            while (next < order.size() && groups[order[next]].hi <= last) {
-                const Group& g = groups[order[next]];
-                graph[(int)g.lo][(int)g.hi] += (int)g.weight;
-                if (g.lo != g.hi) graph[(int)g.hi][(int)g.lo] += (int)g.weight;
-                ++next;
-            }
-        };
-        for (uint32_t r = 0; r < NR; ++r) {
-            if ((int64_t)(r + 1) % period != 0) continue;
-            add_edges_upto(r);
+        int64_t prev = -1;
+        for (int64_t r = period - 1; r < NR; r += period) {
             max_readlen = R[r].maxq;  // stale _max_readlen: the value of the candidate closing at this flush (Q5)
-            flush(graph);
+            flush(prev, r);
+            prev = r;
         }
-        if (NR) add_edges_upto(NR - 1);
         max_readlen = in.last_maxq;
-        flush(graph);
+        flush(prev, NR - 1);
     }
 };
 
-double chisq_upper_tail_int(int half_df, double x) {  // Q(n, x/2 -> here x already halved) = e^-x sum_{i<n} x^i / i!
+double chisq_upper_tail_int(int half_df, double x) {  // Q(n, x) = e^-x sum_{i<n} x^i / i!  (x already halved)
     double term = 1.0, sum = 1.0;
     for (int i = 1; i < half_df; ++i) {
         term *= x / i;

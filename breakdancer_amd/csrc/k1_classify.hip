@@ -357,6 +357,7 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(const FinalizeParam
     __shared__ uint32_t s_carry;
     __shared__ Mono s_mono[kFinBlock / 64];
     __shared__ unsigned long long s_ref[256];
+    __shared__ uint32_t s_acc[255 * 12 + 256];  // nlibs*11 + nlibs + nbams at the documented limits
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
 
     if ((int)blockIdx.x < p.ncols) {
@@ -389,12 +390,18 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(const FinalizeParam
         return;
     }
 
-    // counters: [nblk][ncnt] -> [ncnt]
-    for (int i = t; i < p.ncnt; i += kFinBlock) {
-        uint32_t acc = 0;
-        for (uint32_t b = 0; b < p.nblk; ++b) acc += p.blk_cnt[(size_t)b * p.ncnt + i];
-        p.cnt[i] = acc;
+    // counters: [nblk][ncnt] -> [ncnt]; coalesced sweep over the whole table, LDS atomics do the transpose
+    for (int i = t; i < p.ncnt; i += kFinBlock) s_acc[i] = 0;
+    __syncthreads();
+    {
+        const uint32_t total = p.nblk * (uint32_t)p.ncnt;
+        for (uint32_t i = t; i < total; i += kFinBlock) {
+            const uint32_t v = p.blk_cnt[i];
+            if (v) atomicAdd(&s_acc[i % (uint32_t)p.ncnt], v);
+        }
     }
+    __syncthreads();
+    for (int i = t; i < p.ncnt; i += kFinBlock) p.cnt[i] = s_acc[i];
     // reference-length monoids, in tile order (associative, not commutative)
     const uint32_t per = (p.ntiles + kFinBlock - 1) / kFinBlock;
     for (int b = 0; b < p.nbams; ++b) {
