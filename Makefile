@@ -6,9 +6,9 @@ HOST := breakdancer_amd/host
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result -Iinclude
 KERNELS := $(CSRC)/k1_classify.hip $(CSRC)/k2_compact.hip $(CSRC)/k3_regions.hip $(CSRC)/k4_join.hip $(CSRC)/k5_poisson.hip $(CSRC)/bdx_api.hip
 OBJS := $(KERNELS:.hip=.o) $(CSRC)/bdx_walk.o
-HOSTSRC := $(wildcard $(HOST)/*.cpp)
+HOSTCOMMON := $(HOST)/options.cpp $(HOST)/config.cpp $(HOST)/bam_reader.cpp $(HOST)/producer.cpp
 
-all: breakdancer_amd/libbdx.so bin/breakdancer-max oracle
+all: breakdancer_amd/libbdx.so bin/breakdancer-max bin/bdx-dump-reads oracle
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/bdx.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -19,15 +19,21 @@ $(CSRC)/bdx_walk.o: $(CSRC)/bdx_walk.cpp $(CSRC)/bdx_walk.h include/bdx.h
 breakdancer_amd/libbdx.so: $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(OBJS)
 
-bin/breakdancer-max: $(HOSTSRC) $(wildcard $(HOST)/*.h) breakdancer_amd/libbdx.so
+HOSTFLAGS := -O2 -std=c++17 -ffp-contract=off -Wall -Iinclude -pthread
+
+bin/breakdancer-max: $(HOSTCOMMON) $(HOST)/main.cpp $(wildcard $(HOST)/*.h) breakdancer_amd/libbdx.so
 	@mkdir -p bin
-	g++ -O2 -std=c++17 -ffp-contract=off -Wall -Iinclude -o $@ $(HOSTSRC) -Lbreakdancer_amd -lbdx -lz -Wl,-rpath,'$$ORIGIN/../breakdancer_amd' -Wl,-rpath,/opt/rocm/lib
+	g++ $(HOSTFLAGS) -o $@ $(HOSTCOMMON) $(HOST)/main.cpp -Lbreakdancer_amd -lbdx -lz -Wl,-rpath,'$$ORIGIN/../breakdancer_amd' -Wl,-rpath,/opt/rocm/lib
+
+bin/bdx-dump-reads: $(HOSTCOMMON) $(HOST)/dump_main.cpp $(wildcard $(HOST)/*.h) breakdancer_amd/libbdx.so
+	@mkdir -p bin
+	g++ $(HOSTFLAGS) -o $@ $(HOSTCOMMON) $(HOST)/dump_main.cpp -Lbreakdancer_amd -lbdx -lz -Wl,-rpath,'$$ORIGIN/../breakdancer_amd' -Wl,-rpath,/opt/rocm/lib
 
 oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(CSRC)/*.o breakdancer_amd/libbdx.so bin/breakdancer-max
+	rm -f $(CSRC)/*.o breakdancer_amd/libbdx.so bin/breakdancer-max bin/bdx-dump-reads
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

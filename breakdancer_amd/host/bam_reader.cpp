@@ -1,0 +1,232 @@
+#include "bam_reader.h"
+
+#include <zlib.h>
+
+#include <cstring>
+#include <stdexcept>
+#include <thread>
+
+namespace bdhost {
+
+namespace {
+
+constexpr size_t kReadChunk = 32u << 20;   // compressed bytes fetched per read()
+constexpr size_t kMaxBlocksPerFill = 2048;  // <= 128 MiB decompressed per fill
+
+inline uint32_t le32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline uint16_t le16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+struct Block {
+    size_t coff, clen;   // deflate payload within comp_
+    size_t uoff, ulen;   // destination within buf_
+};
+
+void inflate_block(const uint8_t* src, size_t clen, uint8_t* dst, size_t ulen) {
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("zlib inflateInit2 failed");
+    zs.next_in = const_cast<Bytef*>(src);
+    zs.avail_in = (uInt)clen;
+    zs.next_out = dst;
+    zs.avail_out = (uInt)ulen;
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    if (rc != Z_STREAM_END || zs.avail_out != 0) throw std::runtime_error("corrupt BGZF block");
+}
+
+}  // namespace
+
+uint64_t hash_name(const char* s, size_t n) {
+    // 64-bit multiply-xorshift over 8-byte words (names are short; collisions ~ n^2 / 2^65)
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, s + i, 8);
+        h = (h ^ w) * 0xff51afd7ed558ccdull;
+        h ^= h >> 32;
+    }
+    uint64_t w = 0;
+    if (i < n) memcpy(&w, s + i, n - i);
+    h = (h ^ w) * 0xc4ceb9fe1a85ec53ull;
+    h ^= h >> 29;
+    h *= 0xbf58476d1ce4e5b9ull;
+    h ^= h >> 32;
+    return h;
+}
+
+BamReader::BamReader(const std::string& path, int threads) : path_(path), threads_(threads < 1 ? 1 : threads) {
+    fp_ = fopen(path.c_str(), "rb");
+    if (!fp_) throw std::runtime_error("Failed to open samfile " + path);
+    if (!ensure(12) || memcmp(buf_.data() + cur_, "BAM\1", 4) != 0) throw std::runtime_error(path + " is not a valid bam file");
+    const uint32_t l_text = le32(buf_.data() + cur_ + 4);
+    cur_ += 8;
+    if (!ensure((size_t)l_text + 4)) throw std::runtime_error(path + " is not a valid bam file");
+    cur_ += l_text;
+    const uint32_t n_ref = le32(buf_.data() + cur_);
+    cur_ += 4;
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        if (!ensure(4)) throw std::runtime_error(path + " is not a valid bam file");
+        const uint32_t l = le32(buf_.data() + cur_);
+        if (!ensure((size_t)4 + l + 4)) throw std::runtime_error(path + " is not a valid bam file");
+        targets_.emplace_back((const char*)buf_.data() + cur_ + 4, l ? l - 1 : 0);
+        cur_ += 4 + l + 4;
+    }
+}
+
+BamReader::~BamReader() {
+    if (fp_) fclose(fp_);
+}
+
+int BamReader::tid_of(const std::string& name) const {
+    for (size_t i = 0; i < targets_.size(); ++i)
+        if (targets_[i] == name) return (int)i;
+    return -1;
+}
+
+bool BamReader::fill() {
+    if (cur_ > 0) {  // drop consumed decompressed bytes
+        buf_.erase(buf_.begin(), buf_.begin() + cur_);
+        cur_ = 0;
+    }
+    std::vector<Block> blocks;
+    size_t uoff = buf_.size();
+    while (true) {
+        if (!eof_ && comp_.size() - comp_off_ < (size_t)(128u << 10)) {  // top up the compressed window
+            comp_.erase(comp_.begin(), comp_.begin() + comp_off_);
+            comp_off_ = 0;
+            const size_t old = comp_.size();
+            comp_.resize(old + kReadChunk);
+            const size_t got = fread(comp_.data() + old, 1, kReadChunk, fp_);
+            comp_.resize(old + got);
+            if (got < kReadChunk) eof_ = true;
+        }
+        while (blocks.size() < kMaxBlocksPerFill) {
+            const size_t avail = comp_.size() - comp_off_;
+            if (avail < 18) break;
+            const uint8_t* h = comp_.data() + comp_off_;
+            if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) throw std::runtime_error("not a BGZF file: " + path_);
+            const uint16_t xlen = le16(h + 10);
+            if (avail < (size_t)12 + xlen) break;
+            int bsize = -1;
+            for (size_t x = 12; x + 4 <= (size_t)12 + xlen;) {
+                const uint16_t slen = le16(h + x + 2);
+                if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2) bsize = le16(h + x + 4);
+                x += 4 + (size_t)slen;
+            }
+            if (bsize < 0) throw std::runtime_error("BGZF block without BC field: " + path_);
+            const size_t total = (size_t)bsize + 1;
+            if (avail < total) break;
+            const uint32_t isize = le32(h + total - 4);
+            Block b;
+            b.coff = comp_off_ + 12 + xlen;
+            b.clen = total - 12 - xlen - 8;
+            b.uoff = uoff;
+            b.ulen = isize;
+            uoff += isize;
+            comp_off_ += total;
+            if (isize) blocks.push_back(b);
+        }
+        if (!blocks.empty()) break;
+        if (eof_) {
+            if (comp_.size() - comp_off_ != 0) throw std::runtime_error("truncated BGZF file: " + path_);
+            return false;
+        }
+    }
+    buf_.resize(uoff);
+    const int nt = (int)std::min<size_t>((size_t)threads_, blocks.size());
+    if (nt <= 1) {
+        for (const Block& b : blocks) inflate_block(comp_.data() + b.coff, b.clen, buf_.data() + b.uoff, b.ulen);
+    } else {
+        std::vector<std::thread> th;
+        std::vector<std::string> errs(nt);
+        for (int t = 0; t < nt; ++t)
+            th.emplace_back([&, t] {
+                try {
+                    for (size_t i = (size_t)t; i < blocks.size(); i += (size_t)nt)
+                        inflate_block(comp_.data() + blocks[i].coff, blocks[i].clen, buf_.data() + blocks[i].uoff, blocks[i].ulen);
+                } catch (std::exception const& e) { errs[t] = e.what(); }
+            });
+        for (auto& x : th) x.join();
+        for (auto& e : errs)
+            if (!e.empty()) throw std::runtime_error(e + ": " + path_);
+    }
+    return true;
+}
+
+bool BamReader::ensure(size_t need) {
+    while (buf_.size() - cur_ < need)
+        if (!fill()) return buf_.size() - cur_ >= need;
+    return true;
+}
+
+bool BamReader::next(BamRecord& r) {
+    if (!ensure(4)) return false;
+    const uint32_t bs = le32(buf_.data() + cur_);
+    if (!ensure((size_t)4 + bs)) throw std::runtime_error("truncated BAM record in " + path_);
+    const uint8_t* p = buf_.data() + cur_ + 4;
+    const uint8_t* end = p + bs;
+    cur_ += 4 + bs;
+    r.tid = (int32_t)le32(p);
+    r.pos = (int32_t)le32(p + 4);
+    const uint32_t l_read_name = p[8];
+    r.mapq = p[9];
+    const uint32_t n_cigar = le16(p + 12);
+    r.flag = le16(p + 14);
+    r.l_qseq = (int32_t)le32(p + 16);
+    r.mtid = (int32_t)le32(p + 20);
+    r.mpos = (int32_t)le32(p + 24);
+    r.isize = (int32_t)le32(p + 28);
+    r.qname = (const char*)p + 32;
+    r.l_qname = l_read_name ? l_read_name - 1 : 0;
+    const uint8_t* q = p + 32 + l_read_name + 4 * (size_t)n_cigar;
+    r.seq = q;
+    q += ((size_t)r.l_qseq + 1) / 2;
+    r.qual = q;
+    q += (size_t)r.l_qseq;
+    r.rg = nullptr;
+    r.l_rg = 0;
+    r.bdqual = r.mapq;
+    bool have_am = false;
+    // one sweep over the aux block: RG:Z and AM:<int> (bam_aux_get / bam_aux2i semantics)
+    while (q + 3 <= end) {
+        const uint8_t t0 = q[0], t1 = q[1], ty = q[2];
+        q += 3;
+        size_t sz = 0;
+        long ival = 0;
+        bool is_int = false;
+        switch (ty) {
+            case 'A': sz = 1; break;
+            case 'c': sz = 1; ival = (int8_t)q[0]; is_int = true; break;
+            case 'C': sz = 1; ival = q[0]; is_int = true; break;
+            case 's': sz = 2; ival = (int16_t)le16(q); is_int = true; break;
+            case 'S': sz = 2; ival = le16(q); is_int = true; break;
+            case 'i': sz = 4; ival = (int32_t)le32(q); is_int = true; break;
+            case 'I': sz = 4; ival = (long)le32(q); is_int = true; break;
+            case 'f': sz = 4; break;
+            case 'd': sz = 8; break;
+            case 'Z':
+            case 'H': {
+                const uint8_t* z = (const uint8_t*)memchr(q, 0, (size_t)(end - q));
+                if (!z) { q = end; continue; }
+                if (t0 == 'R' && t1 == 'G' && ty == 'Z' && !r.rg) { r.rg = (const char*)q; r.l_rg = (uint32_t)(z - q); }
+                q = z + 1;
+                continue;
+            }
+            case 'B': {
+                if (q + 5 > end) { q = end; continue; }
+                const uint8_t sub = q[0];
+                const uint32_t cnt = le32(q + 1);
+                const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                q += 5 + (size_t)cnt * es;
+                continue;
+            }
+            default: q = end; continue;
+        }
+        if (t0 == 'A' && t1 == 'M' && !have_am) { r.bdqual = (uint8_t)(is_int ? ival : 0); have_am = true; }  // bam_aux2i: 0 for non-integer types
+        q += sz;
+    }
+    return true;
+}
+
+}  // namespace bdhost

@@ -1,0 +1,161 @@
+// breakdancer-max: same command line, configuration format and output columns as the reference
+// (exe/breakdancer-max/BreakDancerMax.cpp:38-163); the clustering path runs on the GPU through libbdx.
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <thread>
+#include <vector>
+
+#include "bdx.h"
+#include "config.h"
+#include "options.h"
+#include "producer.h"
+
+using namespace bdhost;
+
+namespace {
+
+const int kPrintedFlagValue[BDX_NUM_FLAGS] = {0, 1, 2, 3, 4, 8, 18, 20, 32, 64, 192};  // common/ReadFlags.cpp:4-14
+
+void check(bdx_ctx* ctx, int rc, const char* what) {
+    if (rc == BDX_OK) return;
+    std::string msg = std::string(what) + ": " + bdx_strerror(rc);
+    if (ctx && bdx_last_error(ctx)[0]) msg += std::string(" (") + bdx_last_error(ctx) + ")";
+    throw std::runtime_error(msg);
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    bdx_ctx* ctx = nullptr;
+    try {
+        Options opts(argc, argv);
+        if (!opts.restore_file.empty() || !opts.cache_file.empty())
+            throw std::runtime_error("-C / -R (pass-1 cache) are not supported: pass 1 is part of the single GPU pass");
+        if (!opts.prefix_fastq.empty() || !opts.dump_BED.empty())
+            throw std::runtime_error("-d / -g (FASTQ / BED dumps of supporting reads) are not implemented yet");
+        std::ifstream cfg_stream(opts.bam_config_path.c_str());
+        if (!cfg_stream.is_open()) throw std::runtime_error("unable to open config file '" + opts.bam_config_path + "'");
+        BamConfig cfg(cfg_stream, opts.o.cut_sd);
+        if (cfg.num_bams() == 0) {
+            std::cout << "Error: no bams files in config file!\n";
+            return 1;
+        }
+        const unsigned hw = std::thread::hardware_concurrency();
+        ReadStream reads;
+        produce(cfg, opts.chr, hw ? (int)std::min(hw, 16u) : 4, reads);
+
+        const std::vector<bdx_lib> libs = cfg.abi_libs();
+        const int nlibs = (int)libs.size(), nbams = (int)cfg.num_bams();
+        check(nullptr, bdx_create(&ctx, &opts.o, libs.data(), nlibs, nbams, (int)reads.targets.size(), cfg.max_read_window_size(),
+                                  opts.device), "bdx_create");
+        const bdx_batch batch = reads.batch();
+        check(ctx, bdx_reserve(ctx, batch.n), "bdx_reserve");
+        check(ctx, bdx_push(ctx, &batch), "bdx_push");
+        check(ctx, bdx_run(ctx), "bdx_run");
+
+        bdx_summary sum;
+        check(ctx, bdx_get_summary(ctx, &sum), "bdx_get_summary");
+        std::vector<uint32_t> lib_cnt(nlibs), bam_cnt(nbams), hist((size_t)nlibs * BDX_NUM_FLAGS);
+        std::vector<float> seqcov(nlibs), dens(nlibs);
+        check(ctx, bdx_get_counters(ctx, lib_cnt.data(), bam_cnt.data(), hist.data(), seqcov.data(), dens.data()), "bdx_get_counters");
+
+        using std::cout;
+        cout << "#Software: breakdancer-max-mi355x (libbdx)" << std::endl;
+        cout << "#Command: ";
+        for (auto const& a : opts.orig_argv) cout << a << " ";
+        cout << std::endl;
+        cout << "#Library Statistics:" << std::endl;
+        const uint32_t covered = sum.covered_ref_len;
+        for (int i = 0; i < nlibs; ++i) {  // BreakDancerMax.cpp:83-137
+            const LibraryConfig& lc = cfg.library_config(i);
+            const float physical_coverage = float(lib_cnt[i] * lc.mean_insertsize) / covered / 2;
+            cout << "#" << lc.bam_file << "\tmean:" << lc.mean_insertsize << "\tstd:" << lc.std_insertsize
+                 << "\tuppercutoff:" << lc.uppercutoff << "\tlowercutoff:" << lc.lowercutoff << "\treadlen:" << lc.readlens
+                 << "\tlibrary:" << lc.name << "\treflen:" << covered << "\tseqcov:" << seqcov[i] << "\tphycov:" << physical_coverage;
+            for (int f = 0; f < BDX_NUM_FLAGS; ++f) {
+                const uint32_t c = hist[(size_t)i * BDX_NUM_FLAGS + f];
+                if (c) cout << "\t" << kPrintedFlagValue[f] << ":" << c;
+            }
+            cout << "\n";
+        }
+        cout << "#Chr1\tPos1\tOrientation1\tChr2\tPos2\tOrientation2\tType\tSize\tScore\tnum_Reads\tnum_Reads_lib";
+        if (opts.o.print_af) cout << "\tAllele_frequency";
+        if (!opts.o.cn_lib)
+            for (auto const& b : cfg.bam_files()) {
+                const size_t p = b.rfind("/");
+                cout << "\t" << (p != std::string::npos ? b.substr(p + 1) : b);
+            }
+        cout << "\n";
+
+        std::vector<bdx_sv> svs(sum.n_svs);
+        check(ctx, bdx_get_svs(ctx, svs.data(), svs.size()), "bdx_get_svs");
+        size_t nl = 0, nc = 0;
+        for (auto const& s : svs) { nl = std::max<size_t>(nl, s.lib_begin + s.lib_count); nc = std::max<size_t>(nc, s.cn_begin + s.cn_count); }
+        std::vector<int32_t> li(nl), lp(nl), ck(nc);
+        std::vector<float> cv(nc);
+        check(ctx, bdx_get_sv_lists(ctx, li.data(), lp.data(), nl, ck.data(), cv.data(), nc), "bdx_get_sv_lists");
+
+        auto tname = [&](int t) { return (t >= 0 && (size_t)t < reads.targets.size()) ? reads.targets[t] : std::to_string(t); };
+        for (auto const& s : svs) {  // BreakDancer.cpp:395-497
+            if (!s.printed) continue;
+            std::map<int, float> cn;  // key -> copy number
+            for (int i = 0; i < s.cn_count; ++i) cn[ck[s.cn_begin + i]] = cv[s.cn_begin + i];
+            std::string sptype;
+            if (opts.o.cn_lib) {
+                for (int i = 0; i < s.lib_count; ++i) {
+                    const int lib = li[s.lib_begin + i];
+                    std::string cn_str = "NA";
+                    if (s.flag != BDX_ARP_CTX) {
+                        auto f = cn.find(lib);
+                        if (f != cn.end()) {
+                            std::stringstream ss;
+                            ss << std::fixed << std::setprecision(2) << f->second;
+                            cn_str = ss.str();
+                        }
+                    }
+                    if (!sptype.empty()) sptype += ":";
+                    sptype += cfg.library_config(lib).name + "|" + std::to_string(lp[s.lib_begin + i]) + "," + cn_str;
+                }
+            } else {
+                std::map<std::string, int> bam_rc;
+                for (int i = 0; i < s.lib_count; ++i) bam_rc[cfg.library_config(li[s.lib_begin + i]).bam_file] += lp[s.lib_begin + i];
+                for (auto const& kv : bam_rc) {
+                    if (!sptype.empty()) sptype += ":";
+                    sptype += kv.first + "|" + std::to_string(kv.second);
+                }
+                if (sptype.empty()) sptype = "NA";
+            }
+            cout << tname(s.chr[0]) << "\t" << s.pos[0] << "\t" << s.fwd[0] << "+" << s.rev[0] << "-"
+                 << "\t" << tname(s.chr[1]) << "\t" << s.pos[1] << "\t" << s.fwd[1] << "+" << s.rev[1] << "-"
+                 << "\t" << opts.sv_type(s.flag) << "\t" << s.size << "\t" << s.score << "\t" << s.num_reads << "\t" << sptype;
+            if (opts.o.print_af) cout << "\t" << s.allele_frequency;
+            if (!opts.o.cn_lib && s.flag != BDX_ARP_CTX) {
+                for (size_t b = 0; b < cfg.num_bams(); ++b) {
+                    auto f = cn.find((int)b);
+                    if (f == cn.end()) cout << "\tNA";
+                    else {
+                        // the reference never resets these manipulators on cout: later allele frequencies print
+                        // fixed with two decimals as well (BreakDancer.cpp:492-493)
+                        cout << "\t";
+                        cout << std::fixed;
+                        cout << std::setprecision(2) << f->second;
+                    }
+                }
+            }
+            cout << "\n";
+        }
+        bdx_destroy(ctx);
+        ctx = nullptr;
+    } catch (std::exception const& e) {
+        std::cerr << "ERROR: " << e.what() << "\n";
+        if (ctx) bdx_destroy(ctx);
+        return 1;
+    }
+    return 0;
+}

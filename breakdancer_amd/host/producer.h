@@ -1,0 +1,28 @@
+// Host producer: BAM files -> one merged, position-sorted SoA record stream (the bdx_batch layout).
+// Stands where the reference has AlignmentSource over BamMerger over BamReader<IsPrimary && IsAligned>
+// (io/AlignmentSource.hpp:48-65, io/BamMerger.cpp:40-126, io/BamIo.cpp:6-31), decoding every BAM ONCE
+// (the reference decodes each file twice: pass 1 per file, pass 2 merged).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "bdx.h"
+#include "config.h"
+
+namespace bdhost {
+
+struct ReadStream {
+    std::vector<int32_t> tid, pos, mtid, mpos, isize;
+    std::vector<uint16_t> flag, qlen;
+    std::vector<uint8_t> mapq, lib, bam;
+    std::vector<uint64_t> name_key;
+    std::vector<std::string> targets;  // sequence names of the first BAM (BamMerger.cpp:78)
+    size_t size() const { return tid.size(); }
+    bdx_batch batch() const;
+};
+
+// chr: empty = all sequences, otherwise the -o sequence name (whole sequence; "name:beg-end" is not supported)
+void produce(const BamConfig& cfg, const std::string& chr, int threads, ReadStream& out);
+
+}  // namespace bdhost

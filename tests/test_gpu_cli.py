@@ -1,0 +1,43 @@
+"""GPU tests: the breakdancer-max CLI (BAM -> producer -> libbdx -> formatter) against the reference's golden
+files, the way integration-test/breakdancer_test.py does (stdout minus #Command / #Software lines)."""
+import os
+import subprocess
+
+import pytest
+
+from helpers import GOLDEN, ROOT, filter_cmd_lines, load_chr21, make_opts
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(ROOT, "bin", "breakdancer-max")
+CWD = os.path.join(GOLDEN, "chr21")
+
+# integration-test/breakdancer_test.py:32,46,60,74,88,102
+CASES = [("expected_output.cn_per_lib", ["-a", "-o", "21"]), ("expected_output.cn_per_lib.af", ["-a", "-h", "-o", "21"]),
+         ("expected_output.af", ["-h", "-o", "21"]), ("expected_output", ["-o", "21"]), ("expected_output", []),
+         ("expected_output.af", ["-h"])]
+
+
+def run_cli(args):
+    p = subprocess.run([EXE] + args + ["inv_del_bam_config"], cwd=CWD, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    return p.stdout.decode()
+
+
+@pytest.mark.parametrize("fn,args", CASES)
+def test_cli_reproduces_reference_golden_output(fn, args):
+    got = filter_cmd_lines(run_cli(args))
+    exp = filter_cmd_lines(open(os.path.join(CWD, fn)).read())
+    assert got == exp
+
+
+OPTSETS = [(["-t"], dict(transchr_rearrange=1)), (["-l", "-y", "-1"], dict(illumina_long_insert=1, score_threshold=-1)),
+           (["-b", "1", "-r", "1", "-y", "-1"], dict(buffer_size=1, min_read_pair=1, score_threshold=-1)),
+           (["-q", "0", "-s", "0", "-a", "-h"], dict(min_map_qual=0, min_len=0, cn_lib=1, print_af=1)),
+           (["-f", "-m", "600", "-x", "2", "-c", "2"], dict(fisher=1, max_sd=600, seq_coverage_lim=2, cut_sd=2))]
+
+
+@pytest.mark.parametrize("args,kw", OPTSETS)
+def test_cli_text_equals_oracle_text_on_other_option_sets(args, kw):
+    """option paths the golden files do not cover: the CLI's full stdout against the oracle's rendering"""
+    run = load_chr21(make_opts(**kw)).run()
+    assert filter_cmd_lines(run_cli(args)) == filter_cmd_lines(run.text)

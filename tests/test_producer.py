@@ -1,0 +1,60 @@
+"""CPU tests of the host producer (BGZF/BAM decode, reader filter, RG->library, merge order, config parser):
+bin/bdx-dump-reads against the independent pure-Python decode + the oracle's priority-queue merge."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, ROOT, load_chr21, make_opts
+
+DUMP = os.path.join(ROOT, "bin", "bdx-dump-reads")
+
+
+def dump(args, cwd):
+    if not os.path.exists(DUMP):
+        import __graft_entry__ as g
+        g.build()
+    out = subprocess.run([DUMP] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout.decode()
+    head = [l for l in out.splitlines() if l.startswith("#")]
+    data = [l.split("\t") for l in out.splitlines() if not l.startswith("#")]
+    rows = np.array([[int(x) for x in f[:10]] for f in data], dtype=np.int64).reshape(-1, 10)
+    keys = np.array([int(f[10]) for f in data], dtype=np.uint64)
+    return head, rows, keys
+
+
+@pytest.mark.parametrize("chr_args,chr_tid", [([], -1), (["-o", "21"], 22)])
+def test_producer_stream_equals_independent_decode(chr_args, chr_tid):
+    run = load_chr21(make_opts(chr_tid=chr_tid)).run()
+    head, rows, keys = dump(chr_args + ["inv_del_bam_config"], os.path.join(GOLDEN, "chr21"))
+    soa = run.merged_soa()
+    assert len(rows) == run.n_merged == 5917
+    for col, k in enumerate(("tid", "pos", "mtid", "mpos", "isize", "flag", "qlen", "bdqual", "lib", "bam")):
+        want = soa[k].astype(np.int64)
+        got = rows[:, col].astype(np.int64)
+        np.testing.assert_array_equal(got, want, err_msg=k)
+    # the name key is a function of the read name: equal ids <-> equal keys
+    key, nid = keys, soa["name_id"]
+    m = {}
+    for k, i in zip(key.tolist(), nid.tolist()):
+        assert m.setdefault(i, k) == k
+    assert len(set(m.values())) == len(m)
+    # config-derived header: W0 and the library table
+    assert head[0].startswith("#w0=%d nlibs=2 nbams=2" % run.w0)
+    for i in range(run.nlibs):
+        f = head[1 + i].split("\t")
+        assert f[2] == run.lib_names[i] and int(f[4]) == run.lib_i[i, 1] and int(f[10]) == run.lib_i[i, 0]
+        np.testing.assert_array_equal(np.array([float(x) for x in f[5:10]], dtype=np.float32), run.lib_f[i])
+
+
+def test_unknown_chromosome_is_an_error():
+    p = subprocess.run([DUMP, "-o", "nope", "inv_del_bam_config"], cwd=os.path.join(GOLDEN, "chr21"), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE)
+    assert p.returncode == 1 and b"Failed to parse bam region 'nope'" in p.stderr
+
+
+def test_missing_map_field_is_an_error(tmp_path):
+    cfg = tmp_path / "cfg"
+    cfg.write_text("readgroup:rg1\tlib:l1\tmean:400\tstd:30\n")
+    p = subprocess.run([DUMP, str(cfg)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 1 and b"Required field 'map' not found in config at line 1!" in p.stderr
