@@ -59,7 +59,7 @@ struct PinBuf {
 };
 
 constexpr int kNumStages = 8;
-constexpr int kK1MaxGrid = 2048;  // 256 CUs x 8 resident workgroups; the rest of the tiles are grid-strided
+constexpr int kK1MaxGrid = 8192;  // measured best on MI355X (tools/k1_probe.hip): 256 CUs x 32 workgroups queued, 4 independent waves each
 
 }  // namespace
 
@@ -78,7 +78,7 @@ struct bdx_ctx {
     DevBuf b_tid, b_pos, b_mtid, b_mpos, b_isize, b_flag, b_qlen, b_mapq, b_lib, b_bam, b_key;
 
     // stage buffers
-    DevBuf b_libs, b_cls, b_tile_tot, b_tile_pre, b_tile_mono, b_tile_mono_sum, b_blk_cnt, b_cnt, b_p1;
+    DevBuf b_libs, b_cls, b_tile_tot, b_tile_pre, b_tile_mono, b_blk_cnt, b_cnt, b_p1;
     DevBuf b_c_tid, b_c_pos, b_c_isize, b_c_meta, b_c_key, b_c_nn, b_c_pk;
     DevBuf b_cand, b_pre_q, b_pre_rev, b_pre_nonctx, b_c_first, b_c_maxq, b_c_accept, b_c_n, b_c_rev, b_c_nonctx,
         b_c_nnormal, b_c_rid, b_r_rec, b_r_pk, b_ws_u4, b_ws_u32, b_totals, b_counts;
@@ -96,6 +96,7 @@ struct bdx_ctx {
     std::vector<uint32_t> r_pk;
     std::vector<GroupPart> parts;
     WalkResult walk;
+    WalkScratch* walk_scratch = nullptr;
     uint32_t n_printed = 0;
     float stage_ms[kNumStages] = {0};
     hipEvent_t ev[8] = {nullptr};
@@ -119,7 +120,7 @@ int hipfail(bdx_ctx* c, hipError_t e, const char* what) {
 size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
 int alloc_reads(bdx_ctx* c, size_t cap) {
-    cap = round_up(std::max<size_t>(cap, 1), kTile);
+    cap = round_up(std::max<size_t>(cap, 1), 1024);
     if (cap <= c->cap) return BDX_OK;
     struct Col { DevBuf* b; size_t esz; const void** slot; };
     Col cols[] = {{&c->b_tid, 4, (const void**)&c->d.tid},     {&c->b_pos, 4, (const void**)&c->d.pos},
@@ -209,7 +210,7 @@ void bdx_destroy(bdx_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->b_tid, &c->b_pos, &c->b_mtid, &c->b_mpos, &c->b_isize, &c->b_flag, &c->b_qlen, &c->b_mapq, &c->b_lib,
                       &c->b_bam, &c->b_key, &c->b_libs, &c->b_cls, &c->b_tile_tot, &c->b_tile_pre, &c->b_tile_mono,
-                      &c->b_tile_mono_sum, &c->b_blk_cnt, &c->b_cnt, &c->b_p1, &c->b_c_tid, &c->b_c_pos, &c->b_c_isize,
+                      &c->b_blk_cnt, &c->b_cnt, &c->b_p1, &c->b_c_tid, &c->b_c_pos, &c->b_c_isize,
                       &c->b_c_meta, &c->b_c_key, &c->b_c_nn, &c->b_c_pk, &c->b_cand, &c->b_pre_q, &c->b_pre_rev,
                       &c->b_pre_nonctx, &c->b_c_first, &c->b_c_maxq, &c->b_c_accept, &c->b_c_n, &c->b_c_rev, &c->b_c_nonctx,
                       &c->b_c_nnormal, &c->b_c_rid, &c->b_r_rec, &c->b_r_pk, &c->b_ws_u4, &c->b_ws_u32, &c->b_totals,
@@ -218,6 +219,7 @@ void bdx_destroy(bdx_ctx* c) {
     for (DevBuf* b : bufs) b->release();
     PinBuf* pins[] = {&c->h_p1, &c->h_cnt, &c->h_counts, &c->h_regs, &c->h_pk, &c->h_groups, &c->h_terms};
     for (PinBuf* b : pins) b->release();
+    if (c->walk_scratch) walk_scratch_free(c->walk_scratch);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -285,11 +287,12 @@ int bdx_run(bdx_ctx* c) {
     const int ncols = 2 + nkeys, ncnt = nlibs * kNumFlags + nlibs + nbams;
     if (c->n >= ((size_t)1 << 32) * 256) return fail(c, BDX_ELIMIT, "too many reads");
     const uint32_t ntiles = (uint32_t)((c->n + kTile - 1) / kTile);
-    const uint32_t tstride = (uint32_t)round_up(std::max<uint32_t>(ntiles, 4), 4);
-    const int grid1 = (int)std::min<uint32_t>(ntiles, kK1MaxGrid);
+    const uint32_t tstride = (uint32_t)round_up(std::max<uint32_t>(ntiles, 16), 16);
+    const int grid1 = (int)std::min<uint32_t>((ntiles + kWaves - 1) / kWaves, kK1MaxGrid);
     c->ran = false;
     c->regions.clear(); c->r_pk.clear(); c->parts.clear();
-    c->walk = WalkResult();
+    c->walk.clear();
+    if (!c->walk_scratch) c->walk_scratch = walk_scratch_new();
     c->n_printed = 0;
     memset(&c->counts, 0, sizeof(c->counts));
 
@@ -297,9 +300,8 @@ int bdx_run(bdx_ctx* c) {
     HIPCHK(c, c->b_cls.ensure(std::max<size_t>(c->n, 16)));
     HIPCHK(c, c->b_tile_tot.ensure((size_t)ncols * tstride * 4));
     HIPCHK(c, c->b_tile_pre.ensure((size_t)ncols * tstride * 4));
-    HIPCHK(c, c->b_tile_mono.ensure((size_t)nbams * 4 * tstride * 4));
-    HIPCHK(c, c->b_tile_mono_sum.ensure((size_t)nbams * tstride * 8));
-    HIPCHK(c, c->b_blk_cnt.ensure((size_t)std::max(grid1, 1) * ncnt * 4));
+    HIPCHK(c, c->b_tile_mono.ensure((size_t)nbams * tstride * sizeof(MonoRec)));
+    HIPCHK(c, c->b_blk_cnt.ensure((size_t)kCntCopies * ncnt * 4));
     HIPCHK(c, c->b_cnt.ensure((size_t)ncnt * 4));
     HIPCHK(c, c->b_p1.ensure(sizeof(Pass1)));
     HIPCHK(c, c->h_p1.ensure(sizeof(Pass1)));
@@ -307,6 +309,8 @@ int bdx_run(bdx_ctx* c) {
     HIPCHK(c, c->h_counts.ensure(sizeof(StageCounts)));
     HIPCHK(c, c->b_counts.ensure(sizeof(StageCounts)));
     HIPCHK(c, hipMemsetAsync(c->b_tile_tot.p, 0, (size_t)ncols * tstride * 4, s));
+    HIPCHK(c, hipMemsetAsync(c->b_tile_mono.p, 0xFF, (size_t)nbams * tstride * sizeof(MonoRec), s));
+    HIPCHK(c, hipMemsetAsync(c->b_blk_cnt.p, 0, (size_t)kCntCopies * ncnt * 4, s));
     HIPCHK(c, hipMemsetAsync(c->b_p1.p, 0, sizeof(Pass1), s));
     HIPCHK(c, hipMemsetAsync(c->b_counts.p, 0, sizeof(StageCounts), s));
 
@@ -317,7 +321,7 @@ int bdx_run(bdx_ctx* c) {
     k1.nlibs = nlibs; k1.nbams = nbams; k1.nkeys = nkeys;
     k1.max_sd = c->opts.max_sd; k1.opt_t = c->opts.transchr_rearrange; k1.opt_l = c->opts.illumina_long_insert;
     k1.libs = c->b_libs.as<DevLib>(); k1.cls = c->b_cls.as<uint8_t>(); k1.tile_tot = c->b_tile_tot.as<uint32_t>();
-    k1.tile_mono = c->b_tile_mono.as<int32_t>(); k1.tile_mono_sum = c->b_tile_mono_sum.as<long long>();
+    k1.tile_mono = c->b_tile_mono.as<MonoRec>();
     k1.blk_cnt = c->b_blk_cnt.as<uint32_t>();
     if (ntiles) launch_k1(k1, grid1, k1_lds_bytes(nlibs, nbams, nkeys), s);
     HIPCHK(c, hipEventRecord(c->ev[1], s));
@@ -325,7 +329,7 @@ int bdx_run(bdx_ctx* c) {
     fp.ntiles = ntiles; fp.tstride = tstride; fp.nblk = ntiles ? grid1 : 0;
     fp.nlibs = nlibs; fp.nbams = nbams; fp.nkeys = nkeys; fp.ncols = ncols; fp.ncnt = ncnt; fp.w0 = c->w0;
     fp.tile_tot = k1.tile_tot; fp.tile_pre = c->b_tile_pre.as<uint32_t>(); fp.tile_mono = k1.tile_mono;
-    fp.tile_mono_sum = k1.tile_mono_sum; fp.blk_cnt = k1.blk_cnt; fp.cnt = c->b_cnt.as<uint32_t>(); fp.p1 = c->b_p1.as<Pass1>();
+    fp.blk_cnt = k1.blk_cnt; fp.cnt = c->b_cnt.as<uint32_t>(); fp.p1 = c->b_p1.as<Pass1>();
     launch_finalize(fp, s);
     HIPCHK(c, hipMemcpyAsync(c->h_p1.p, c->b_p1.p, sizeof(Pass1), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(c->h_cnt.p, c->b_cnt.p, (size_t)ncnt * 4, hipMemcpyDeviceToHost, s));
@@ -462,7 +466,7 @@ int bdx_run(bdx_ctx* c) {
     wi.hist = hist; wi.covered_ref_len = covered; wi.key_density = c->key_density.data();
     wi.regions = &c->regions; wi.r_pk = c->r_pk.data(); wi.parts = &c->parts; wi.last_maxq = c->counts.last_maxq;
     wi.any_anomalous = na != 0;
-    greedy_walk(wi, c->walk);
+    greedy_walk(wi, c->walk_scratch, c->walk);
     const auto t_walk1 = std::chrono::steady_clock::now();
 
     // ---- K5 -------------------------------------------------------------------------------------------------------

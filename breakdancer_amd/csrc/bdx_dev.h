@@ -5,10 +5,11 @@
 
 namespace bdx {
 
-constexpr int kTile = 1024;     // reads per tile = 256 threads x 4 consecutive reads
+constexpr int kTile = 256;      // reads per tile = one wave64 x 4 consecutive reads per lane (no workgroup barrier per tile)
 constexpr int kBlock = 256;     // threads per workgroup (4 wave64)
 constexpr int kWaves = kBlock / 64;
 constexpr int kNumFlags = 11;
+constexpr int kCntCopies = 64;   // replication factor of the global pass-1 counters (power of two)
 
 enum : int { F_NA = 0, F_FF = 1, F_LARGE = 2, F_SMALL = 3, F_RF = 4, F_RR = 5, F_NORMAL_FR = 6, F_NORMAL_RF = 7,
              F_CTX = 8, F_MATE_UNMAPPED = 9, F_UNMAPPED = 10 };
@@ -26,6 +27,13 @@ struct ReadsSoA {
     const uint64_t* key;
 };
 
+// reference-length monoid of one (tile, source file): BamSummary.cpp:70-74 adds pos - last_pos for consecutive
+// same-tid records of a file; (first, last, interior sum) composes associatively across tiles
+struct MonoRec {
+    int32_t ft, fp, lt, lp;
+    long long sum;
+};
+
 // tile-total columns: 0 anomalous, 1 normal leftmost, 2.. per normal-read key
 constexpr int kColAnom = 0, kColNormal = 1, kColKey0 = 2;
 
@@ -38,9 +46,8 @@ struct K1Params {
     const DevLib* libs;
     uint8_t* cls;              // [n]
     uint32_t* tile_tot;        // [2+nkeys][tstride]
-    int32_t* tile_mono;        // [nbams][4][tstride]: first_tid, first_pos, last_tid, last_pos (first_tid==INT_MIN: none)
-    long long* tile_mono_sum;  // [nbams][tstride]
-    uint32_t* blk_cnt;         // [gridDim.x][ncnt], ncnt = nlibs*11 + nlibs + nbams
+    MonoRec* tile_mono;        // [nbams][tstride], pre-set to 0xFF (ft == -1: file absent from the tile)
+    uint32_t* blk_cnt;         // [kCntCopies][ncnt] zero-filled, ncnt = nlibs*11 + nlibs + nbams
 };
 
 // results of pass 1, produced on the device and mirrored to the host
@@ -58,8 +65,7 @@ struct FinalizeParams {
     int w0;
     const uint32_t* tile_tot;
     uint32_t* tile_pre;         // exclusive scan of tile_tot per column
-    const int32_t* tile_mono;
-    const long long* tile_mono_sum;
+    const MonoRec* tile_mono;
     const uint32_t* blk_cnt;
     uint32_t* cnt;              // [ncnt] reduced counters
     Pass1* p1;

@@ -13,11 +13,12 @@
 #include "bdx_walk.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 namespace bdx {
-
-namespace {
 
 // Flat, allocation-light replay.  Groups are kept sorted by (hi, lo); a flush covers the groups whose
 // later region `hi` was added since the previous flush, so a vertex's adjacency in ascending neighbour order
@@ -36,27 +37,58 @@ struct OldVertex {  // endpoint from an earlier flush: only has edges to regions
     bool visited;
 };
 
-struct Walker {
-    const WalkInput& in;
-    WalkResult& out;
+struct LibAcc {
+    int lib, rc, span;
+};
+
+struct WalkScratch {
     std::vector<GroupPart> parts;  // sorted by (hi, lo, flag, lib), duplicates merged
     std::vector<Group> groups;
     std::vector<uint32_t> ghi;     // groups with hi == r are [ghi[r], ghi[r+1])
     std::vector<uint8_t> stored_;
+    std::vector<uint32_t> cnt, cur;
+    std::vector<LibAcc> lib_acc_;
+    std::vector<int32_t> win_head, win_tail;
+    std::vector<uint8_t> win_visited;
+    std::vector<OldVertex> olds;
+    std::vector<int> tails, newtails;
+};
+WalkScratch* walk_scratch_new() { return new WalkScratch; }
+void walk_scratch_free(WalkScratch* s) { delete s; }
+
+namespace {
+
+struct Walker {
+    const WalkInput& in;
+    WalkResult& out;
+    WalkScratch& S;
+    std::vector<GroupPart>& parts;
+    std::vector<Group>& groups;
+    std::vector<uint32_t>& ghi;
+    std::vector<uint8_t>& stored_;
+    std::vector<LibAcc>& lib_acc_;
+    std::vector<int32_t>&win_head, &win_tail;
+    std::vector<uint8_t>& win_visited;
+    std::vector<OldVertex>& olds;
+    std::vector<int>&tails, &newtails;
     int max_readlen = 0;
 
-    Walker(const WalkInput& i, WalkResult& o) : in(i), out(o) {}
+    Walker(const WalkInput& i, WalkScratch& s, WalkResult& o)
+        : in(i), out(o), S(s), parts(s.parts), groups(s.groups), ghi(s.ghi), stored_(s.stored_), lib_acc_(s.lib_acc_),
+          win_head(s.win_head), win_tail(s.win_tail), win_visited(s.win_visited), olds(s.olds), tails(s.tails), newtails(s.newtails) {}
 
     void build_groups() {
         const std::vector<GroupPart>& src = *in.parts;
         const uint32_t NR = (uint32_t)in.regions->size();
         // counting sort by hi, then tiny insertion sorts inside each hi bucket
-        std::vector<uint32_t> cnt(NR + 2, 0);
+        std::vector<uint32_t>& cnt = S.cnt;
+        cnt.assign(NR + 2, 0);
         for (const GroupPart& p : src) ++cnt[p.hi + 1];
         for (uint32_t r = 0; r <= NR; ++r) cnt[r + 1] += cnt[r];
         parts.resize(src.size());
         {
-            std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
+            std::vector<uint32_t>& cur = S.cur;
+            cur.assign(cnt.begin(), cnt.end() - 1);
             for (const GroupPart& p : src) parts[cur[p.hi]++] = p;
         }
         auto less = [](const GroupPart& a, const GroupPart& b) {
@@ -76,6 +108,7 @@ struct Walker {
         // merge duplicates (a group can straddle two K4 workgroups) and cut into groups
         ghi.assign(NR + 1, 0);
         size_t w = 0;
+        groups.clear();
         groups.reserve(parts.size());
         for (size_t i = 0; i < parts.size(); ++i) {
             const GroupPart p = parts[i];
@@ -122,10 +155,6 @@ struct Walker {
         }
         return nullptr;
     }
-
-    struct LibAcc {
-        int lib, rc, span;
-    };
 
     void process_sv(const int* snodes, int n) {
         const std::vector<HostRegion>& R = *in.regions;
@@ -233,12 +262,6 @@ struct Walker {
     }
 
     // ---- one flush (BreakDancer.cpp:266-346) over the groups with hi in (prev, last] ----------------------------
-    std::vector<LibAcc> lib_acc_;
-    std::vector<int32_t> win_head, win_tail;
-    std::vector<uint8_t> win_visited;
-    std::vector<OldVertex> olds;
-    std::vector<int> tails, newtails;
-
     OldVertex* find_old(uint32_t id) {
         for (OldVertex& o : olds)
             if (o.id == id) return &o;
@@ -326,7 +349,12 @@ struct Walker {
     }
 
     void run() {
+        const bool prof = getenv("BDX_WALK_PROFILE") != nullptr;
+        const auto tp0 = std::chrono::steady_clock::now();
         build_groups();
+        if (prof) fprintf(stderr, "[walk] build_groups %.1f us (parts %zu groups %zu regions %zu)\n",
+                          std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp0).count(), in.parts->size(),
+                          groups.size(), in.regions->size());
         const std::vector<HostRegion>& R = *in.regions;
         const int64_t NR = (int64_t)R.size();
         if (!in.any_anomalous) return;
@@ -353,8 +381,8 @@ double chisq_upper_tail_int(int half_df, double x) {  // Q(n, x) = e^-x sum_{i<n
 
 }  // namespace
 
-void greedy_walk(const WalkInput& in, WalkResult& out) {
-    Walker w(in, out);
+void greedy_walk(const WalkInput& in, WalkScratch* scratch, WalkResult& out) {
+    Walker w(in, *scratch, out);
     w.run();
 }
 

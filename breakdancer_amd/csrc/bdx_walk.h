@@ -52,9 +52,18 @@ struct WalkResult {
     std::vector<int32_t> cn_key;
     std::vector<float> cn_value;
     uint32_t n_groups = 0;
+    void clear() {
+        svs.clear(); terms.clear(); lib_index.clear(); lib_pairs.clear(); cn_key.clear(); cn_value.clear();
+        n_groups = 0;
+    }
 };
 
-void greedy_walk(const WalkInput& in, WalkResult& out);
+// scratch vectors of the walk, kept by the context so that steady-state runs do not allocate
+struct WalkScratch;
+WalkScratch* walk_scratch_new();
+void walk_scratch_free(WalkScratch* s);
+
+void greedy_walk(const WalkInput& in, WalkScratch* scratch, WalkResult& out);
 
 // combine the per-library log tails into the final score exactly as ComputeProbScore does
 void finish_scores(const WalkInput& in, const std::vector<double>& log_tail, WalkResult& out, uint32_t* n_printed);

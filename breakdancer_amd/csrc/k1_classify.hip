@@ -6,11 +6,12 @@
 //   breakdancer/BreakDancer.cpp:155-207      filter chain, -l remaps, RR->FF fold, normal-read tests
 //
 // HBM-bound: 25 B/read in (5 x i32, u16 flag, u8 mapq/lib/bam), 1 B/read out (class byte).
-// Layout: a tile is 1024 consecutive reads; thread t of the 256-thread workgroup owns reads
-// [4t, 4t+4) so every array is fetched with one 16/8/4-byte load per lane (1 KiB per wave-instruction
-// for the i32 arrays).  No atomics leave the CU: counters are privatised in LDS and written per
-// workgroup; per-tile totals and per-tile reference-length monoids go to plain per-tile tables that a
-// tiny follow-up kernel scans/reduces.
+// Layout: a tile is 256 consecutive reads = one wave64, lane l owns reads [4l, 4l+4), so every column is
+// fetched with one 16/8/4-byte load per lane (1 KiB per wave-instruction for the i32 columns).  Waves are
+// independent: there is NO workgroup barrier inside the tile loop and NO global atomic at all.  Per-tile
+// totals come from ballots + popcounts, the pass-1 counters are privatised in LDS and written once per
+// workgroup, and the per-file reference-length monoid of each tile goes to a plain per-tile table that a tiny
+// follow-up kernel folds in order.
 #include "bdx_dev.h"
 
 #include <limits.h>
@@ -41,16 +42,11 @@ __device__ __forceinline__ int remap_long_insert(int f, int ai, float upper, flo
 }
 
 size_t k1_lds_bytes(int nlibs, int nbams, int nkeys) {
-    size_t b = 0;
-    b += (size_t)nlibs * sizeof(DevLib);
+    size_t b = (size_t)nlibs * sizeof(DevLib);
     b += (size_t)(nlibs * kNumFlags + nlibs + nbams) * 4;
-    b += (size_t)(2 + nkeys) * 4;
-    b += 16 * 4;                          // per-wave tid / uniform / valid words
-    b += (size_t)kWaves * nbams * 3 * 4;  // per-wave per-bam (present, first_pos, last_pos)
     b = (b + 15) & ~(size_t)15;
-    b += kTile * 4 * 2 + kTile;           // general-path staging: tid, pos, bam
-    b = (b + 15) & ~(size_t)15;
-    b += (size_t)nbams * (8 + 4 * 4);     // general-path per-bam sum, first(tid,pos), first idx, last idx
+    b += (size_t)kWaves * nbams * sizeof(MonoRec);  // lane-0 state of the exact (tid-boundary) path
+    (void)nkeys;
     return (b + 15) & ~(size_t)15;
 }
 
@@ -61,34 +57,21 @@ __global__ __launch_bounds__(kBlock) void k1_classify_kernel(const K1Params p) {
     const int ncols = 2 + nkeys;
     DevLib* s_lib = (DevLib*)smem;
     uint32_t* s_cnt = (uint32_t*)(s_lib + nlibs);
-    uint32_t* s_tile = s_cnt + ncnt;
-    int32_t* s_wave = (int32_t*)(s_tile + ncols);  // [16]
-    int32_t* s_mw = s_wave + 16;                   // [kWaves][nbams][3]
-    size_t off = (size_t)((unsigned char*)(s_mw + kWaves * nbams * 3) - smem);
+    size_t off = (size_t)nlibs * sizeof(DevLib) + (size_t)ncnt * 4;
     off = (off + 15) & ~(size_t)15;
-    int32_t* g_tid = (int32_t*)(smem + off);
-    int32_t* g_pos = g_tid + kTile;
-    uint8_t* g_bam = (uint8_t*)(g_pos + kTile);
-    off += kTile * 9;
-    off = (off + 15) & ~(size_t)15;
-    long long* g_sum = (long long*)(smem + off);
-    int32_t* g_first = (int32_t*)(g_sum + nbams);  // [nbams][2]
-    int32_t* g_fidx = g_first + 2 * nbams;
-    int32_t* g_lidx = g_fidx + nbams;
+    MonoRec* s_mono = (MonoRec*)(smem + off);
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     for (int i = t; i < nlibs; i += kBlock) s_lib[i] = p.libs[i];
     for (int i = t; i < ncnt; i += kBlock) s_cnt[i] = 0;
     uint32_t* s_libcnt = s_cnt + nlibs * kNumFlags;
     uint32_t* s_bamcnt = s_libcnt + nlibs;
+    MonoRec* my_mono = s_mono + (size_t)w * nbams;
     __syncthreads();
 
-    for (uint32_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-        for (int i = t; i < ncols; i += kBlock) s_tile[i] = 0;
-        for (int i = t; i < kWaves * nbams; i += kBlock) s_mw[i * 3] = 0;
-        __syncthreads();
-
-        const uint64_t base = (uint64_t)tile * kTile + (uint64_t)t * 4;
+    const uint32_t nwaves = gridDim.x * kWaves;
+    for (uint32_t tile = blockIdx.x * kWaves + w; tile < p.ntiles; tile += nwaves) {
+        const uint64_t base = (uint64_t)tile * kTile + (uint64_t)lane * 4;
         int nvalid = 0;
         int tid[4], pos[4], mtid[4], mpos[4], isz[4];
         unsigned sam[4], mq[4], lib[4], bam[4];
@@ -159,15 +142,12 @@ __global__ __launch_bounds__(kBlock) void k1_classify_kernel(const K1Params p) {
                 if (r < nvalid) p.cls[base + r] = (uint8_t)cls4[r];
         }
 
-        // ---- per-tile totals and block counters: ballots + popcounts, one LDS add per wave -------------
+        // ---- per-tile totals (lane c keeps column c) and workgroup counters: ballots + popcounts --------------
         {
             unsigned na = 0, nn = 0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { na += popc64(ballot64(anom[r])); nn += popc64(ballot64(nleft[r])); }
-            if (lane == 0) {
-                if (na) atomicAdd(&s_tile[kColAnom], na);
-                if (nn) atomicAdd(&s_tile[kColNormal], nn);
-            }
+            unsigned colval = lane == kColAnom ? na : (lane == kColNormal ? nn : 0u);
             // uniform fast path: every lane/slot has the same library and source file (the usual case)
             const unsigned L0 = __shfl(lib[0], 0), B0 = __shfl(bam[0], 0);
             const bool uni = __all(lib[0] == L0 && lib[1] == L0 && lib[2] == L0 && lib[3] == L0 && bam[0] == B0 &&
@@ -176,10 +156,9 @@ __global__ __launch_bounds__(kBlock) void k1_classify_kernel(const K1Params p) {
                 unsigned c1 = 0, ck = 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { c1 += popc64(ballot64(p1c[r])); ck += popc64(ballot64(pk[r])); }
-                if (lane == 0) {
-                    if (c1) { atomicAdd(&s_libcnt[L0], c1); atomicAdd(&s_bamcnt[B0], c1); }
-                    if (ck) atomicAdd(&s_tile[kColKey0 + key[0]], ck);
-                }
+                const int k0 = __shfl(key[0], 0);
+                if (lane == kColKey0 + k0) colval = ck;
+                if (lane == 0 && c1) { atomicAdd(&s_libcnt[L0], c1); atomicAdd(&s_bamcnt[B0], c1); }
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -199,28 +178,28 @@ __global__ __launch_bounds__(kBlock) void k1_classify_kernel(const K1Params p) {
                         if (lane == 0) atomicAdd(&s_bamcnt[v], (unsigned)popc64(m));
                         todo &= ~m;
                     }
-                    todo = ballot64(pk[r]);
-                    while (todo) {  // peel distinct normal-read keys
-                        const int ld = __ffsll((long long)todo) - 1;
-                        const int v = __shfl(key[r], ld);
-                        const uint64_t m = ballot64(pk[r] && key[r] == v);
-                        if (lane == 0) atomicAdd(&s_tile[kColKey0 + v], (unsigned)popc64(m));
-                        todo &= ~m;
-                    }
+                }
+                for (int k = 0; k < nkeys; ++k) {  // mixed wave: one ballot per key and slot
+                    unsigned ck = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ck += popc64(ballot64(pk[r] && key[r] == k));
+                    if (lane == kColKey0 + k) colval = ck;  // ncols <= 62 (bdx_create limits nkeys to 60)
                 }
             }
+            if (lane < ncols) p.tile_tot[(size_t)lane * p.tstride + tile] = colval;
         }
 
-        // ---- reference-length monoid per source file (BamSummary.cpp:70-74), wave part -------------------
+        // ---- reference-length monoid per source file (BamSummary.cpp:70-74) ---------------------------------------
         {
-            const uint64_t vm = ballot64(nvalid > 0);
-            if (vm) {
-                const int tw = __shfl(tid[0], 0);
-                bool same = true;
+            const int tw = __shfl(tid[0], 0);
+            bool same = true;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) same = same && (r >= nvalid || tid[r] == tw);
-                const bool wuni = __all(same);
-                if (lane == 0) { s_wave[w * 3] = tw; s_wave[w * 3 + 1] = wuni; s_wave[w * 3 + 2] = 1; }
+            for (int r = 0; r < 4; ++r) same = same && (r >= nvalid || tid[r] == tw);
+            if (__all(same) && nbams <= 64) {
+                // all records of the tile share one tid: consecutive same-file differences telescope to
+                // last - first, found with ballots; lane v keeps the record of file v
+                int my_first = 0, my_last = 0;
+                bool present = false;
                 unsigned pending = (1u << nvalid) - 1u;
                 while (true) {
                     const uint64_t any = ballot64(pending != 0);
@@ -237,87 +216,47 @@ __global__ __launch_bounds__(kBlock) void k1_classify_kernel(const K1Params p) {
                     const int fl = __ffsll((long long)M) - 1, ll = 63 - __clzll((long long)M);
                     const int fs = mine ? __ffs(mine) - 1 : 0, ls = mine ? 31 - __clz(mine) : 0;
                     const int first = __shfl(pos[fs], fl), last = __shfl(pos[ls], ll);
-                    if (lane == 0) { int32_t* e = s_mw + (w * nbams + v) * 3; e[0] = 1; e[1] = first; e[2] = last; }
+                    if (lane == (int)v) { present = true; my_first = first; my_last = last; }
                 }
-            } else if (lane == 0) {
-                s_wave[w * 3 + 2] = 0;
+                if (present) {
+                    MonoRec m;
+                    m.ft = tw; m.fp = my_first; m.lt = tw; m.lp = my_last; m.sum = (long long)my_last - (long long)my_first;
+                    p.tile_mono[(size_t)lane * p.tstride + tile] = m;
+                }
+            } else {
+                // a tid boundary falls inside the tile (or > 64 files): replay the reference's recurrence exactly,
+                // records in order, state held by lane 0 in its wave-private LDS slice
+                if (lane == 0)
+                    for (int b = 0; b < nbams; ++b) my_mono[b].ft = -1;
+                for (int L = 0; L < 64; ++L) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int nv = __shfl(nvalid, L);
+                        if (r >= nv) continue;
+                        const int rt = __shfl(tid[r], L), rp = __shfl(pos[r], L);
+                        const unsigned rb = __shfl(bam[r], L);
+                        if (lane == 0) {
+                            MonoRec m = my_mono[rb];
+                            if (m.ft == -1) { m.ft = rt; m.fp = rp; m.sum = 0; }
+                            else if (m.lt == rt) m.sum += (long long)rp - (long long)m.lp;
+                            m.lt = rt; m.lp = rp;
+                            my_mono[rb] = m;
+                        }
+                    }
+                }
+                if (lane == 0)
+                    for (int b = 0; b < nbams; ++b)
+                        if (my_mono[b].ft != -1) p.tile_mono[(size_t)b * p.tstride + tile] = my_mono[b];
             }
         }
-        __syncthreads();
-
-        for (int c = t; c < ncols; c += kBlock) p.tile_tot[(size_t)c * p.tstride + tile] = s_tile[c];
-
-        bool tile_uniform = true;
-        int tile_tid = 0;
-        {
-            bool have = false;
-#pragma unroll
-            for (int ww = 0; ww < kWaves; ++ww) {
-                if (!s_wave[ww * 3 + 2]) continue;
-                if (!s_wave[ww * 3 + 1]) tile_uniform = false;
-                if (!have) { tile_tid = s_wave[ww * 3]; have = true; }
-                else if (s_wave[ww * 3] != tile_tid) tile_uniform = false;
-            }
-        }
-        if (tile_uniform) {
-            // all records of the tile share one tid: consecutive same-file differences telescope exactly
-            for (int b = t; b < nbams; b += kBlock) {
-                bool have = false;
-                int first = 0, last = 0;
-#pragma unroll
-                for (int ww = 0; ww < kWaves; ++ww) {
-                    const int32_t* e = s_mw + (ww * nbams + b) * 3;
-                    if (!e[0]) continue;
-                    if (!have) { first = e[1]; have = true; }
-                    last = e[2];
-                }
-                int32_t* mo = p.tile_mono + (size_t)b * 4 * p.tstride + tile;
-                mo[0] = have ? tile_tid : INT_MIN;
-                mo[p.tstride] = first;
-                mo[2 * (size_t)p.tstride] = tile_tid;
-                mo[3 * (size_t)p.tstride] = last;
-                p.tile_mono_sum[(size_t)b * p.tstride + tile] = have ? (long long)last - (long long)first : 0;
-            }
-        } else {
-            // general path (a tid boundary falls inside the tile): exact recurrence via LDS staging
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                g_tid[t * 4 + r] = tid[r];
-                g_pos[t * 4 + r] = pos[r];
-                g_bam[t * 4 + r] = r < nvalid ? (uint8_t)bam[r] : (uint8_t)255;
-            }
-            for (int b = t; b < nbams; b += kBlock) { g_sum[b] = 0; g_fidx[b] = INT_MAX; g_lidx[b] = -1; }
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (r >= nvalid) continue;
-                const int q = t * 4 + r;
-                const unsigned v = bam[r];
-                int qq = q - 1;
-                while (qq >= 0 && g_bam[qq] != v) --qq;
-                if (qq >= 0) {
-                    if (g_tid[qq] == tid[r]) atomicAdd((unsigned long long*)&g_sum[v], (unsigned long long)((long long)pos[r] - (long long)g_pos[qq]));
-                } else {
-                    g_fidx[v] = q;
-                }
-                atomicMax(&g_lidx[v], q);
-            }
-            __syncthreads();
-            for (int b = t; b < nbams; b += kBlock) {
-                const bool have = g_lidx[b] >= 0;
-                int32_t* mo = p.tile_mono + (size_t)b * 4 * p.tstride + tile;
-                mo[0] = have ? g_tid[g_fidx[b]] : INT_MIN;
-                mo[p.tstride] = have ? g_pos[g_fidx[b]] : 0;
-                mo[2 * (size_t)p.tstride] = have ? g_tid[g_lidx[b]] : 0;
-                mo[3 * (size_t)p.tstride] = have ? g_pos[g_lidx[b]] : 0;
-                p.tile_mono_sum[(size_t)b * p.tstride + tile] = have ? g_sum[b] : 0;
-            }
-        }
-        __syncthreads();
     }
-
-    uint32_t* out = p.blk_cnt + (size_t)blockIdx.x * ncnt;
-    for (int i = t; i < ncnt; i += kBlock) out[i] = s_cnt[i];
+    __syncthreads();
+    // flush: kCntCopies-way replicated global counters keep same-address atomics to gridDim/kCntCopies per word
+    uint32_t* out = p.blk_cnt + (size_t)(blockIdx.x & (kCntCopies - 1)) * ncnt;
+    for (int i = t; i < ncnt; i += kBlock) {
+        const uint32_t v = s_cnt[i];
+        if (v) atomicAdd(&out[i], v);
+    }
 }
 
 void launch_k1(const K1Params& p, int grid, size_t lds, hipStream_t s) {
@@ -333,20 +272,16 @@ void launch_k1(const K1Params& p, int grid, size_t lds, hipStream_t s) {
 // -------------------------------------------------------------------------------------------------------
 constexpr int kFinBlock = 1024;
 
-struct Mono {
-    int ft, fp, lt, lp;
-    long long sum;
-};
-__device__ __forceinline__ Mono mono_combine(const Mono& a, const Mono& b) {
-    if (a.ft == INT_MIN) return b;
-    if (b.ft == INT_MIN) return a;
-    Mono r;
+__device__ __forceinline__ MonoRec mono_combine(const MonoRec& a, const MonoRec& b) {
+    if (a.ft == -1) return b;
+    if (b.ft == -1) return a;
+    MonoRec r;
     r.ft = a.ft; r.fp = a.fp; r.lt = b.lt; r.lp = b.lp;
     r.sum = a.sum + b.sum + (a.lt == b.ft ? (long long)b.fp - (long long)a.lp : 0ll);
     return r;
 }
-__device__ __forceinline__ Mono mono_shfl_down(const Mono& a, int o) {
-    Mono r;
+__device__ __forceinline__ MonoRec mono_shfl_down(const MonoRec& a, int o) {
+    MonoRec r;
     r.ft = __shfl_down(a.ft, o); r.fp = __shfl_down(a.fp, o); r.lt = __shfl_down(a.lt, o); r.lp = __shfl_down(a.lp, o);
     r.sum = __shfl_down(a.sum, o);
     return r;
@@ -355,7 +290,7 @@ __device__ __forceinline__ Mono mono_shfl_down(const Mono& a, int o) {
 __global__ __launch_bounds__(kFinBlock) void finalize_kernel(const FinalizeParams p) {
     __shared__ uint32_t s_ws[kFinBlock / 64];
     __shared__ uint32_t s_carry;
-    __shared__ Mono s_mono[kFinBlock / 64];
+    __shared__ MonoRec s_mono[kFinBlock / 64];
     __shared__ unsigned long long s_ref[256];
     __shared__ uint32_t s_acc[255 * 12 + 256];  // nlibs*11 + nlibs + nbams at the documented limits
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -366,20 +301,29 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(const FinalizeParam
         uint32_t* out = p.tile_pre + (size_t)c * p.tstride;
         if (t == 0) s_carry = 0;
         __syncthreads();
-        for (uint32_t base = 0; base < p.ntiles; base += kFinBlock * 4) {
-            const uint32_t i = base + t * 4;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (i < p.ntiles) v = *(const uint4*)(in + i);  // rows are padded to a multiple of 4 and zero-filled
-            const uint32_t s1 = v.x, s2 = s1 + v.y, s3 = s2 + v.z, s4 = s3 + v.w;
-            const uint32_t inc = wave_incl_scan(s4);
+        for (uint32_t base = 0; base < p.ntiles; base += kFinBlock * 16) {
+            const uint32_t i = base + t * 16;
+            uint32_t v[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // rows are padded to a multiple of 16 and zero-filled
+                uint4 x = make_uint4(0, 0, 0, 0);
+                if (i + q * 4 < p.tstride) x = *(const uint4*)(in + i + q * 4);
+                v[q * 4] = x.x; v[q * 4 + 1] = x.y; v[q * 4 + 2] = x.z; v[q * 4 + 3] = x.w;
+            }
+            uint32_t tsum = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { const uint32_t e = v[q]; v[q] = tsum; tsum += e; }
+            const uint32_t inc = wave_incl_scan(tsum);
             if (lane == 63) s_ws[w] = inc;
             __syncthreads();
             uint32_t woff = 0;
             for (int k = 0; k < w; ++k) woff += s_ws[k];
-            const uint32_t ex = s_carry + woff + inc - s4;
-            if (i < p.ntiles) *(uint4*)(out + i) = make_uint4(ex, ex + s1, ex + s2, ex + s3);
+            const uint32_t ex = s_carry + woff + inc - tsum;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (i + q * 4 < p.tstride) *(uint4*)(out + i + q * 4) = make_uint4(ex + v[q * 4], ex + v[q * 4 + 1], ex + v[q * 4 + 2], ex + v[q * 4 + 3]);
             __syncthreads();
-            if (t == kFinBlock - 1) s_carry = ex + s4;
+            if (t == kFinBlock - 1) s_carry = ex + tsum;
             __syncthreads();
         }
         if (t == 0) {
@@ -390,43 +334,42 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(const FinalizeParam
         return;
     }
 
-    // counters: [nblk][ncnt] -> [ncnt]; coalesced sweep over the whole table, LDS atomics do the transpose
-    for (int i = t; i < p.ncnt; i += kFinBlock) s_acc[i] = 0;
-    __syncthreads();
-    {
-        const uint32_t total = p.nblk * (uint32_t)p.ncnt;
-        for (uint32_t i = t; i < total; i += kFinBlock) {
-            const uint32_t v = p.blk_cnt[i];
-            if (v) atomicAdd(&s_acc[i % (uint32_t)p.ncnt], v);
-        }
+    // counters: [kCntCopies][ncnt] -> [ncnt]
+    for (int i = t; i < p.ncnt; i += kFinBlock) {
+        uint32_t acc = 0;
+#pragma unroll 8
+        for (int c = 0; c < kCntCopies; ++c) acc += p.blk_cnt[(size_t)c * p.ncnt + i];
+        s_acc[i] = acc;
+        p.cnt[i] = acc;
     }
-    __syncthreads();
-    for (int i = t; i < p.ncnt; i += kFinBlock) p.cnt[i] = s_acc[i];
     // reference-length monoids, in tile order (associative, not commutative)
     const uint32_t per = (p.ntiles + kFinBlock - 1) / kFinBlock;
     for (int b = 0; b < p.nbams; ++b) {
-        const int32_t* mo = p.tile_mono + (size_t)b * 4 * p.tstride;
-        const long long* ms = p.tile_mono_sum + (size_t)b * p.tstride;
-        Mono acc;
-        acc.ft = INT_MIN; acc.fp = 0; acc.lt = 0; acc.lp = 0; acc.sum = 0;
+        const MonoRec* mo = p.tile_mono + (size_t)b * p.tstride;
+        MonoRec acc;
+        acc.ft = -1; acc.fp = 0; acc.lt = 0; acc.lp = 0; acc.sum = 0;
         const uint32_t t0 = (uint32_t)t * per, t1 = min(t0 + per, p.ntiles);
-        for (uint32_t i = t0; i < t1; ++i) {
-            Mono e;
-            e.ft = mo[i]; e.fp = mo[p.tstride + i]; e.lt = mo[2 * (size_t)p.tstride + i]; e.lp = mo[3 * (size_t)p.tstride + i];
-            e.sum = ms[i];
-            acc = mono_combine(acc, e);
+        for (uint32_t i = t0; i < t1; i += 8) {  // batches of 8 independent loads, then the ordered fold
+            MonoRec e[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (i + q < t1) e[q] = mo[i + q];
+                else e[q].ft = -1;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc = mono_combine(acc, e[q]);
         }
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const Mono other = mono_shfl_down(acc, o);
+            const MonoRec other = mono_shfl_down(acc, o);
             if (lane + o < 64 && ((lane & (2 * o - 1)) == 0)) acc = mono_combine(acc, other);
         }
         if (lane == 0) s_mono[w] = acc;
         __syncthreads();
         if (t == 0) {
-            Mono tot = s_mono[0];
+            MonoRec tot = s_mono[0];
             for (int k = 1; k < kFinBlock / 64; ++k) tot = mono_combine(tot, s_mono[k]);
-            if (b < 256) s_ref[b] = (unsigned long long)tot.sum;  // size_t ref_len, wraps like the reference
+            if (b < 256) s_ref[b] = tot.ft == -1 ? 0ull : (unsigned long long)tot.sum;  // size_t ref_len, wraps like the reference
         }
         __syncthreads();
     }
@@ -435,14 +378,9 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(const FinalizeParam
         for (int b = 0; b < p.nbams && b < 256; ++b)
             if ((unsigned long long)covered < s_ref[b]) covered = (uint32_t)s_ref[b];
         p.p1->covered_ref_len = covered;
-    }
-    __syncthreads();
-    if (t == 0) {
-        // p.cnt was written by other threads of this workgroup above; __syncthreads() orders it
         int W = p.w0;
-        const uint32_t covered = p.p1->covered_ref_len;
         for (int i = 0; i < p.nlibs; ++i) {
-            const int nd = (int)(p.cnt[i * kNumFlags + F_LARGE] + p.cnt[i * kNumFlags + F_SMALL]);
+            const int nd = (int)(s_acc[i * kNumFlags + F_LARGE] + s_acc[i * kNumFlags + F_SMALL]);
             const int tmp = nd > 0 ? (int)__fdiv_rn((float)covered, (float)nd) : 50;
             W = min(W, tmp);
         }

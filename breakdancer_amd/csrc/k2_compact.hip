@@ -6,39 +6,33 @@
 // (normal-read pairs, per-key proper reads) become prefix sums that are *sampled* at the anomalous reads.
 //
 // Input: class bytes from K1 + exclusive per-tile prefixes.  Output: one compact record per anomalous
-// read, in stream order.  HBM traffic: 1-2 B per read plus a gather of ~35 B per anomalous read.
+// read, in stream order.  One wave per 256-read tile, in-tile scans are wave shuffles on 16-bit packed
+// counters: no LDS, no barrier, and tiles without an anomalous read are skipped after one ballot.
+// HBM traffic: 1-2 B per read plus a gather of ~35 B per anomalous read.
 #include "bdx_dev.h"
 
 namespace bdx {
 
-size_t k2_lds_bytes(int nkeys) { return (size_t)(1 + (nkeys + 1) / 2) * kBlock * 4; }
+size_t k2_lds_bytes(int) { return 0; }
 
 __global__ __launch_bounds__(kBlock) void k2_compact_kernel(const K2Params p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* s_tt = (uint32_t*)smem;  // [words][256] packed 16-bit counters
     const int nkeys = p.nkeys;
-    const int words = 1 + (nkeys + 1) / 2;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-
-    for (uint32_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-        const uint64_t base = (uint64_t)tile * kTile + (uint64_t)t * 4;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t nwaves = gridDim.x * kWaves;
+    for (uint32_t tile = blockIdx.x * kWaves + w; tile < p.ntiles; tile += nwaves) {
+        const uint64_t base = (uint64_t)tile * kTile + (uint64_t)lane * 4;
         unsigned c[4] = {0, 0, 0, 0}, lib[4] = {0, 0, 0, 0};
         int nvalid = 0;
         if (base + 4 <= p.n) {
             nvalid = 4;
             const uchar4 q = *(const uchar4*)(p.cls + base);
             c[0] = q.x; c[1] = q.y; c[2] = q.z; c[3] = q.w;
-            if (nkeys > 1) {
-                const uchar4 l = *(const uchar4*)(p.r.lib + base);
-                lib[0] = l.x; lib[1] = l.y; lib[2] = l.z; lib[3] = l.w;
-            }
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (base + r < p.n) { ++nvalid; c[r] = p.cls[base + r]; lib[r] = nkeys > 1 ? p.r.lib[base + r] : 0; }
+                if (base + r < p.n) { ++nvalid; c[r] = p.cls[base + r]; }
         }
         bool anom[4], nleft[4], pk[4];
-        int key[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool valid = r < nvalid;
@@ -48,70 +42,64 @@ __global__ __launch_bounds__(kBlock) void k2_compact_kernel(const K2Params p) {
             anom[r] = pass && !normal;
             nleft[r] = pass && (c[r] & 0x40u);
             pk[r] = pass && (c[r] & 0x20u);
-            key[r] = nkeys > 1 ? p.libs[lib[r]].key : 0;
         }
-        // packed per-thread totals -> LDS
-        {
-            uint32_t tot = 0;
+        if (!__any(anom[0] || anom[1] || anom[2] || anom[3])) continue;  // wave-uniform
+
+        uint32_t tot = 0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) tot += (anom[r] ? 1u : 0u) + (nleft[r] ? 0x10000u : 0u);
-            s_tt[t] = tot;
-            for (int wd = 1; wd < words; ++wd) {
-                const int k0 = (wd - 1) * 2;
-                uint32_t v = 0;
+        for (int r = 0; r < 4; ++r) tot += (anom[r] ? 1u : 0u) + (nleft[r] ? 0x10000u : 0u);
+        const uint32_t ex0 = wave_incl_scan(tot) - tot;
+        uint32_t rank = p.tile_pre[(size_t)kColAnom * p.tstride + tile] + (ex0 & 0xFFFFu);
+        uint32_t nn = p.tile_pre[(size_t)kColNormal * p.tstride + tile] + (ex0 >> 16);
+        uint32_t jj[4] = {0, 0, 0, 0};
+        int key[4] = {0, 0, 0, 0};
+        if (nkeys > 1) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (pk[r]) v += (key[r] == k0 ? 1u : 0u) + (key[r] == k0 + 1 ? 0x10000u : 0u);
-                s_tt[wd * kBlock + t] = v;
+            for (int r = 0; r < 4; ++r)
+                if (r < nvalid) { lib[r] = p.r.lib[base + r]; key[r] = p.libs[lib[r]].key; }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (anom[r]) {
+                const uint64_t i = base + r;
+                const uint32_t j = rank++;
+                jj[r] = j;
+                const unsigned sam = p.r.flag[i];
+                const unsigned L = nkeys > 1 ? lib[r] : p.r.lib[i];
+                p.c.tid[j] = p.r.tid[i];
+                p.c.pos[j] = p.r.pos[i];
+                p.c.isize[j] = abs(p.r.isize[i]);
+                p.c.meta[j] = meta_pack((int)(c[r] & 15u), (sam >> 4) & 1u, (int)L, (int)p.r.qlen[i]);
+                p.c.key[j] = p.r.key[i];
+                p.c.nn[j] = nn;
             }
+            if (nleft[r]) ++nn;
         }
-        __syncthreads();
-        // each wave turns whole rows into exclusive prefixes (256 entries = 4 per lane)
-        for (int wd = w; wd < words; wd += kWaves) {
-            uint4 v = *(uint4*)(s_tt + wd * kBlock + lane * 4);
-            const uint32_t s4 = v.x + v.y + v.z + v.w;
-            const uint32_t ex = wave_incl_scan(s4) - s4;
-            *(uint4*)(s_tt + wd * kBlock + lane * 4) = make_uint4(ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z);
-        }
-        __syncthreads();
-        const bool any = anom[0] || anom[1] || anom[2] || anom[3];
-        if (any) {
-            const uint32_t ex0 = s_tt[t];
-            uint32_t rank = p.tile_pre[(size_t)kColAnom * p.tstride + tile] + (ex0 & 0xFFFFu);
-            uint32_t nn = p.tile_pre[(size_t)kColNormal * p.tstride + tile] + (ex0 >> 16);
+        // per-key proper-read prefix counts (inclusive of the read itself), two keys per packed scan
+        for (int k0 = 0; k0 < nkeys; k0 += 2) {
+            uint32_t v = 0, inc4[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (anom[r]) {
-                    const uint64_t i = base + r;
-                    const uint32_t j = rank;
-                    const unsigned sam = p.r.flag[i];
-                    const int isz = p.r.isize[i];
-                    const unsigned L = nkeys > 1 ? lib[r] : p.r.lib[i];
-                    p.c.tid[j] = p.r.tid[i];
-                    p.c.pos[j] = p.r.pos[i];
-                    p.c.isize[j] = abs(isz);
-                    p.c.meta[j] = meta_pack((int)(c[r] & 15u), (sam >> 4) & 1u, (int)L, (int)p.r.qlen[i]);
-                    p.c.key[j] = p.r.key[i];
-                    p.c.nn[j] = nn;
-                    for (int k = 0; k < nkeys; ++k) {
-                        const uint32_t pw = s_tt[(1 + k / 2) * kBlock + t];
-                        uint32_t v = p.tile_pre[(size_t)(kColKey0 + k) * p.tstride + tile] + ((pw >> (16 * (k & 1))) & 0xFFFFu);
+                if (pk[r]) v += (key[r] == k0 ? 1u : 0u) + (key[r] == k0 + 1 ? 0x10000u : 0u);
+                inc4[r] = v;
+            }
+            const uint32_t ex = wave_incl_scan(v) - v;
+            const uint32_t b0 = p.tile_pre[(size_t)(kColKey0 + k0) * p.tstride + tile];
+            const uint32_t b1 = k0 + 1 < nkeys ? p.tile_pre[(size_t)(kColKey0 + k0 + 1) * p.tstride + tile] : 0u;
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr)
-                            if (rr <= r && pk[rr] && key[rr] == k) ++v;
-                        p.c.pk[(size_t)k * p.c.cap + j] = v;
-                    }
-                    ++rank;
-                }
-                if (nleft[r]) ++nn;
+            for (int r = 0; r < 4; ++r) {
+                if (!anom[r]) continue;
+                const uint32_t s = ex + inc4[r];
+                p.c.pk[(size_t)k0 * p.c.cap + jj[r]] = b0 + (s & 0xFFFFu);
+                if (k0 + 1 < nkeys) p.c.pk[(size_t)(k0 + 1) * p.c.cap + jj[r]] = b1 + (s >> 16);
             }
         }
-        __syncthreads();
     }
 }
 
 void launch_k2(const K2Params& p, size_t lds, hipStream_t s) {
-    const uint32_t grid = p.ntiles < 2048u ? p.ntiles : 2048u;
+    const uint32_t nblk = (p.ntiles + kWaves - 1) / kWaves;
+    const uint32_t grid = nblk < 2048u ? nblk : 2048u;
     hipLaunchKernelGGL(k2_compact_kernel, dim3(grid), dim3(kBlock), lds, s, p);
 }
 
