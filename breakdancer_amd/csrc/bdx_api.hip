@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstddef>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -81,16 +82,27 @@ struct bdx_ctx {
     DevBuf b_libs, b_cls, b_tile_tot, b_tile_pre, b_tile_mono, b_blk_cnt, b_cnt, b_p1;
     DevBuf b_c_tid, b_c_pos, b_c_isize, b_c_meta, b_c_key, b_c_nn, b_c_pk;
     DevBuf b_cand, b_pre_q, b_pre_rev, b_pre_nonctx, b_c_first, b_c_maxq, b_c_accept, b_c_n, b_c_rev, b_c_nonctx,
-        b_c_nnormal, b_c_rid, b_r_rec, b_r_pk, b_ws_u4, b_ws_u32, b_totals, b_counts;
+        b_c_nnormal, b_c_rid, b_region_of, b_r_rec, b_r_pk, b_ws_u4, b_ws_u32, b_totals, b_counts;
     DevBuf b_bcnt, b_boff, b_bcur, b_e_key, b_e_idx, b_partner, b_t_key, b_t_idx, b_g_rec;
     DevBuf b_lam, b_k, b_logt;
+    DevBuf b_x_key, b_x_order, b_x_region, b_x_meta, b_x_isize, b_x_n;
     PinBuf h_p1, h_cnt, h_counts, h_regs, h_pk, h_groups, h_terms;
 
     // results
     bool ran = false;
     Pass1 p1{};
     StageCounts counts{};
-    std::vector<uint32_t> cnt;  // hist[nlibs*11], lib_cnt[nlibs], bam_cnt[nbams]
+    std::vector<uint32_t> cnt;        // adopted counters: hist[nlibs*11], lib_cnt[nlibs], bam_cnt[nbams]
+    std::vector<uint32_t> cnt_local;  // this context's own counters
+    uint32_t g_covered = 0;
+    int32_t g_window = 0;
+    uint32_t nn_base = 0;
+    int stage = 0;                    // 0 nothing, 1 pass 1 done, 2 statistics adopted, 3 regions cut, 4 walked
+    uint32_t ntiles = 0, tstride = 0;
+    Compact cp{};
+    K3Arrays k3{};
+    K4Arrays k4{};
+    std::vector<double> log_tail;
     std::vector<float> seqcov, lib_density, key_density;
     std::vector<HostRegion> regions;
     std::vector<uint32_t> r_pk;
@@ -213,9 +225,10 @@ void bdx_destroy(bdx_ctx* c) {
                       &c->b_blk_cnt, &c->b_cnt, &c->b_p1, &c->b_c_tid, &c->b_c_pos, &c->b_c_isize,
                       &c->b_c_meta, &c->b_c_key, &c->b_c_nn, &c->b_c_pk, &c->b_cand, &c->b_pre_q, &c->b_pre_rev,
                       &c->b_pre_nonctx, &c->b_c_first, &c->b_c_maxq, &c->b_c_accept, &c->b_c_n, &c->b_c_rev, &c->b_c_nonctx,
-                      &c->b_c_nnormal, &c->b_c_rid, &c->b_r_rec, &c->b_r_pk, &c->b_ws_u4, &c->b_ws_u32, &c->b_totals,
+                      &c->b_c_nnormal, &c->b_c_rid, &c->b_region_of, &c->b_r_rec, &c->b_r_pk, &c->b_ws_u4, &c->b_ws_u32, &c->b_totals,
                       &c->b_counts, &c->b_bcnt, &c->b_boff, &c->b_bcur, &c->b_e_key, &c->b_e_idx, &c->b_partner, &c->b_t_key,
-                      &c->b_t_idx, &c->b_g_rec, &c->b_lam, &c->b_k, &c->b_logt};
+                      &c->b_t_idx, &c->b_g_rec, &c->b_lam, &c->b_k, &c->b_logt, &c->b_x_key, &c->b_x_order, &c->b_x_region,
+                      &c->b_x_meta, &c->b_x_isize, &c->b_x_n};
     for (DevBuf* b : bufs) b->release();
     PinBuf* pins[] = {&c->h_p1, &c->h_cnt, &c->h_counts, &c->h_regs, &c->h_pk, &c->h_groups, &c->h_terms};
     for (PinBuf* b : pins) b->release();
@@ -278,25 +291,37 @@ int bdx_set_device_reads(bdx_ctx* c, const bdx_batch* b) {
     return BDX_OK;
 }
 
-int bdx_run(bdx_ctx* c) {
-    if (!c) return BDX_EINVAL;
+// ---------------------------------------------------------------------------------------------------------
+// Stages.  bdx_run chains them on one context; the bdx_stage_* entry points expose the same stages so that
+// several contexts (one per chromosome, spread over GPUs) can exchange the few global quantities between them.
+// ---------------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+float ms_between(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<float, std::milli>(b - a).count();
+}
+
+// K1 + finalize: class bytes, per-tile tables, *local* pass-1 counters
+int do_pass1(bdx_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    const auto t_begin = std::chrono::steady_clock::now();
     const int nlibs = c->nlibs, nbams = c->nbams, nkeys = c->nkeys;
     const int ncols = 2 + nkeys, ncnt = nlibs * kNumFlags + nlibs + nbams;
-    if (c->n >= ((size_t)1 << 32) * 256) return fail(c, BDX_ELIMIT, "too many reads");
+    if (c->n >= ((size_t)1 << 32) * 64) return fail(c, BDX_ELIMIT, "too many reads");
     const uint32_t ntiles = (uint32_t)((c->n + kTile - 1) / kTile);
     const uint32_t tstride = (uint32_t)round_up(std::max<uint32_t>(ntiles, 16), 16);
     const int grid1 = (int)std::min<uint32_t>((ntiles + kWaves - 1) / kWaves, kK1MaxGrid);
-    c->ran = false;
+    c->ntiles = ntiles; c->tstride = tstride;
+    c->ran = false; c->stage = 0;
     c->regions.clear(); c->r_pk.clear(); c->parts.clear();
     c->walk.clear();
     if (!c->walk_scratch) c->walk_scratch = walk_scratch_new();
     c->n_printed = 0;
     memset(&c->counts, 0, sizeof(c->counts));
+    for (float& m : c->stage_ms) m = 0;
 
-    // ---- stage buffers --------------------------------------------------------------------------------
     HIPCHK(c, c->b_cls.ensure(std::max<size_t>(c->n, 16)));
     HIPCHK(c, c->b_tile_tot.ensure((size_t)ncols * tstride * 4));
     HIPCHK(c, c->b_tile_pre.ensure((size_t)ncols * tstride * 4));
@@ -314,7 +339,6 @@ int bdx_run(bdx_ctx* c) {
     HIPCHK(c, hipMemsetAsync(c->b_p1.p, 0, sizeof(Pass1), s));
     HIPCHK(c, hipMemsetAsync(c->b_counts.p, 0, sizeof(StageCounts), s));
 
-    // ---- K1 + finalize ----------------------------------------------------------------------------------
     HIPCHK(c, hipEventRecord(c->ev[0], s));
     K1Params k1{};
     k1.r = c->d; k1.n = c->n; k1.ntiles = ntiles; k1.tstride = tstride;
@@ -326,7 +350,7 @@ int bdx_run(bdx_ctx* c) {
     if (ntiles) launch_k1(k1, grid1, k1_lds_bytes(nlibs, nbams, nkeys), s);
     HIPCHK(c, hipEventRecord(c->ev[1], s));
     FinalizeParams fp{};
-    fp.ntiles = ntiles; fp.tstride = tstride; fp.nblk = ntiles ? grid1 : 0;
+    fp.ntiles = ntiles; fp.tstride = tstride; fp.nblk = 0;
     fp.nlibs = nlibs; fp.nbams = nbams; fp.nkeys = nkeys; fp.ncols = ncols; fp.ncnt = ncnt; fp.w0 = c->w0;
     fp.tile_tot = k1.tile_tot; fp.tile_pre = c->b_tile_pre.as<uint32_t>(); fp.tile_mono = k1.tile_mono;
     fp.blk_cnt = k1.blk_cnt; fp.cnt = c->b_cnt.as<uint32_t>(); fp.p1 = c->b_p1.as<Pass1>();
@@ -336,14 +360,35 @@ int bdx_run(bdx_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, hipGetLastError());
     c->p1 = *c->h_p1.as<Pass1>();
-    c->cnt.assign(c->h_cnt.as<uint32_t>(), c->h_cnt.as<uint32_t>() + ncnt);
-    const uint32_t na = c->p1.n_anom;
+    c->cnt_local.assign(c->h_cnt.as<uint32_t>(), c->h_cnt.as<uint32_t>() + ncnt);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+    c->stage_ms[0] = ms;
+    c->stage = 1;
+    return BDX_OK;
+}
 
+// final window from the (global) counters: BreakDancerMax.cpp:109-116
+int32_t window_from(const bdx_ctx* c, const uint32_t* cnt, uint32_t covered) {
+    int W = c->w0;
+    for (int i = 0; i < c->nlibs; ++i) {
+        const int nd = (int)(cnt[i * kNumFlags + F_LARGE] + cnt[i * kNumFlags + F_SMALL]);
+        const int tmp = nd > 0 ? (int)((float)covered / (float)nd) : 50;
+        W = std::min(W, tmp);
+    }
+    return W;
+}
+
+// adopt the pass-1 statistics the rest of the path runs with (the context's own, or all-reduced ones)
+int set_pass1(bdx_ctx* c, const uint32_t* cnt, uint32_t covered, int32_t window) {
+    const int nlibs = c->nlibs, nkeys = c->nkeys;
+    const int ncnt = nlibs * kNumFlags + nlibs + c->nbams;
+    c->cnt.assign(cnt, cnt + ncnt);
+    c->g_covered = covered;
+    c->g_window = window;
     // host-side scalars of main() (BreakDancerMax.cpp:88-107, BamSummary.cpp:140-149), float32 like the reference
-    const uint32_t* hist = c->cnt.data();
-    const uint32_t* lib_cnt = hist + nlibs * kNumFlags;
+    const uint32_t* lib_cnt = c->cnt.data() + nlibs * kNumFlags;
     const uint32_t* bam_cnt = lib_cnt + nlibs;
-    const uint32_t covered = c->p1.covered_ref_len;
     c->seqcov.assign(nlibs, 0.f);
     c->lib_density.assign(nlibs, 0.f);
     c->key_density.assign(nkeys, 0.000001f);
@@ -360,12 +405,26 @@ int bdx_run(bdx_ctx* c) {
         c->lib_density[i] = dens;
         c->key_density[c->opts.cn_lib ? i : c->libs[i].bam_index] = dens;
     }
+    // the region cut reads the window from the device copy of Pass1
+    struct { uint32_t covered; int32_t window; } hdr{covered, window};
+    static_assert(offsetof(Pass1, covered_ref_len) == 0 && offsetof(Pass1, window) == 4, "Pass1 header layout");
+    HIPCHK(c, hipMemcpyAsync(c->b_p1.p, &hdr, sizeof(hdr), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stage = 2;
+    return BDX_OK;
+}
 
-    // ---- K2 .. K4 ------------------------------------------------------------------------------------------
+// K2: compact anomalous reads (prefix counters offset by the bases of earlier shards)
+int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base) {
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int nkeys = c->nkeys;
+    const uint32_t na = c->p1.n_anom;
     HIPCHK(c, hipEventRecord(c->ev[2], s));
-    Compact cp{};
-    K3Arrays k3{};
-    K4Arrays k4{};
+    Compact& cp = c->cp;
+    K3Arrays& k3 = c->k3;
+    cp = Compact{};
+    k3 = K3Arrays{};
     if (na) {
         if (na > kMaxRegions) return fail(c, BDX_ELIMIT, "too many anomalous reads for the packed group key");
         const size_t cap = na;
@@ -376,15 +435,32 @@ int bdx_run(bdx_ctx* c) {
         cp.meta = c->b_c_meta.as<uint32_t>(); cp.key = c->b_c_key.as<uint64_t>(); cp.nn = c->b_c_nn.as<uint32_t>();
         cp.pk = c->b_c_pk.as<uint32_t>(); cp.cap = na;
         K2Params k2{};
-        k2.r = c->d; k2.n = c->n; k2.ntiles = ntiles; k2.tstride = tstride; k2.nkeys = nkeys; k2.libs = k1.libs;
-        k2.cls = k1.cls; k2.tile_pre = fp.tile_pre; k2.c = cp;
+        k2.r = c->d; k2.n = c->n; k2.ntiles = c->ntiles; k2.tstride = c->tstride; k2.nkeys = nkeys; k2.libs = c->b_libs.as<DevLib>();
+        k2.cls = c->b_cls.as<uint8_t>(); k2.tile_pre = c->b_tile_pre.as<uint32_t>(); k2.c = cp;
+        k2.nn_base = nn_base;
+        for (int k = 0; k < nkeys; ++k) k2.pk_base[k] = pk_base ? pk_base[k] : 0u;
         launch_k2(k2, k2_lds_bytes(nkeys), s);
     }
     HIPCHK(c, hipEventRecord(c->ev[3], s));
+    c->nn_base = nn_base;
+    return BDX_OK;
+}
+
+// K3: cut regions.  In a whole-genome run the last candidate of a chromosome is closed by the first anomalous read
+// of the next chromosome, which still counts for its nucleotide sum / max read length / normal-pair count
+// (BreakDancer.cpp:202-231): has_next / next_qlen / next_nn carry that read across contexts.
+int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn) {
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int nkeys = c->nkeys;
+    const uint32_t na = c->p1.n_anom;
+    const uint32_t nn_base = c->nn_base;
+    Compact& cp = c->cp;
+    K3Arrays& k3 = c->k3;
     if (na) {
         const size_t cap = na;
         DevBuf* u32bufs[] = {&c->b_cand, &c->b_pre_q, &c->b_pre_rev, &c->b_pre_nonctx, &c->b_c_first, &c->b_c_maxq, &c->b_c_accept,
-                             &c->b_c_n, &c->b_c_rev, &c->b_c_nonctx, &c->b_c_nnormal, &c->b_c_rid};
+                             &c->b_c_n, &c->b_c_rev, &c->b_c_nonctx, &c->b_c_nnormal, &c->b_c_rid, &c->b_region_of};
         for (DevBuf* b : u32bufs) HIPCHK(c, b->ensure(cap * 4));
         HIPCHK(c, c->b_r_rec.ensure(cap * sizeof(RegionRec)));
         HIPCHK(c, c->b_r_pk.ensure(cap * 2 * nkeys * 4));
@@ -397,81 +473,99 @@ int bdx_run(bdx_ctx* c) {
         k3.pre_nonctx = c->b_pre_nonctx.as<uint32_t>(); k3.c_first = c->b_c_first.as<uint32_t>();
         k3.c_maxq = c->b_c_maxq.as<int32_t>(); k3.c_accept = c->b_c_accept.as<uint32_t>(); k3.c_n = c->b_c_n.as<uint32_t>();
         k3.c_rev = c->b_c_rev.as<uint32_t>(); k3.c_nonctx = c->b_c_nonctx.as<uint32_t>();
-        k3.c_nnormal = c->b_c_nnormal.as<uint32_t>(); k3.c_rid = c->b_c_rid.as<int32_t>();
+        k3.c_nnormal = c->b_c_nnormal.as<uint32_t>(); k3.c_rid = c->b_c_rid.as<int32_t>(); k3.region_of = c->b_region_of.as<int32_t>();
         k3.r_rec = c->b_r_rec.as<RegionRec>(); k3.r_pk = c->b_r_pk.as<uint32_t>();
         k3.ws_u4 = c->b_ws_u4.as<U4>(); k3.head_total = (U4*)c->b_totals.p; k3.ws_u32 = c->b_ws_u32.as<uint32_t>();
         k3.acc_total = (uint32_t*)((char*)c->b_totals.p + 32); k3.counts = c->b_counts.as<StageCounts>();
-        launch_k3(k3, cp, fp.p1, na, c->opts.min_len, c->opts.seq_coverage_lim, nkeys, s);
+        K3Tail tail{has_next, next_qlen, next_nn};
+        launch_k3(k3, cp, c->b_p1.as<Pass1>(), na, c->opts.min_len, c->opts.seq_coverage_lim, nkeys, nn_base, tail, s);
     }
     HIPCHK(c, hipEventRecord(c->ev[4], s));
-    if (na) {
-        uint32_t nb = 1, lg = 0;
-        while (nb < (uint32_t)kMaxBuckets && (size_t)nb * 1536 < na) { nb <<= 1; ++lg; }
-        k4.nbuckets = nb; k4.log2b = lg;
-        HIPCHK(c, c->b_bcnt.ensure(nb * 4)); HIPCHK(c, c->b_boff.ensure((nb + 1) * 4)); HIPCHK(c, c->b_bcur.ensure(nb * 4));
-        HIPCHK(c, c->b_e_key.ensure((size_t)na * 8)); HIPCHK(c, c->b_e_idx.ensure((size_t)na * 4));
-        HIPCHK(c, c->b_partner.ensure((size_t)na * 4));
-        HIPCHK(c, c->b_t_key.ensure((size_t)na * 16)); HIPCHK(c, c->b_t_idx.ensure((size_t)na * 8));
-        k4.g_cap = na / 2 + 1;
-        HIPCHK(c, c->b_g_rec.ensure((size_t)k4.g_cap * sizeof(GroupRec)));
-        k4.bcnt = c->b_bcnt.as<uint32_t>(); k4.boff = c->b_boff.as<uint32_t>(); k4.bcur = c->b_bcur.as<uint32_t>();
-        k4.e_key = c->b_e_key.as<uint64_t>(); k4.e_idx = c->b_e_idx.as<uint32_t>(); k4.partner = c->b_partner.as<int32_t>();
-        k4.t_key = c->b_t_key.as<uint64_t>(); k4.t_idx = c->b_t_idx.as<int32_t>(); k4.g_rec = c->b_g_rec.as<GroupRec>();
-        launch_k4(k4, k3, cp, fp.p1, na, s);
-    }
-    HIPCHK(c, hipEventRecord(c->ev[5], s));
+    c->stage = 3;
+    return BDX_OK;
+}
 
-    // ---- readback ---------------------------------------------------------------------------------------------
-    if (na) {
-        HIPCHK(c, hipMemcpyAsync(c->h_counts.p, c->b_counts.p, sizeof(StageCounts), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
-        HIPCHK(c, hipGetLastError());
-        c->counts = *c->h_counts.as<StageCounts>();
-        if (c->counts.overflow) return fail(c, BDX_EINTERNAL, "group list overflow");
-        const uint32_t nr = c->counts.n_regions, ng = c->counts.n_groups;
-        HIPCHK(c, c->h_regs.ensure((size_t)std::max<uint32_t>(nr, 1) * sizeof(RegionRec)));
-        HIPCHK(c, c->h_pk.ensure((size_t)std::max<uint32_t>(nr, 1) * 2 * nkeys * 4));
-        HIPCHK(c, c->h_groups.ensure((size_t)std::max<uint32_t>(ng, 1) * sizeof(GroupRec)));
-        if (nr) {
-            HIPCHK(c, hipMemcpyAsync(c->h_regs.p, k3.r_rec, (size_t)nr * sizeof(RegionRec), hipMemcpyDeviceToHost, s));
-            HIPCHK(c, hipMemcpyAsync(c->h_pk.p, k3.r_pk, (size_t)nr * 2 * nkeys * 4, hipMemcpyDeviceToHost, s));
-        }
-        if (ng) HIPCHK(c, hipMemcpyAsync(c->h_groups.p, k4.g_rec, (size_t)ng * sizeof(GroupRec), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
-        // The very first anomalous read "breaks" an empty accumulator (start = end = -1, no reads).  With a negative
-        // -s that empty candidate passes process_breakpoint's test (0 > min_len, coverage 0) and the reference
-        // registers a read-less region 0 (BreakDancer.cpp:216-231, 244-252); every real region id shifts by one.
-        const uint32_t ph = (0 > c->opts.min_len && 0.0f < (float)c->opts.seq_coverage_lim) ? 1u : 0u;
-        c->regions.resize(nr + ph);
-        if (ph) c->regions[0] = HostRegion{-1, -1, -1, 0, 0, 0, 0, 0};
-        const RegionRec* rr = c->h_regs.as<RegionRec>();
-        for (uint32_t i = 0; i < nr; ++i)
-            c->regions[i + ph] = HostRegion{rr[i].tid, rr[i].start, rr[i].end, rr[i].n, rr[i].rev, rr[i].nonctx, rr[i].nnormal, rr[i].maxq};
-        c->r_pk.assign((size_t)ph * 2 * nkeys, 0u);
-        c->r_pk.insert(c->r_pk.end(), c->h_pk.as<uint32_t>(), c->h_pk.as<uint32_t>() + (size_t)nr * 2 * nkeys);
-        c->parts.resize(ng);
-        const GroupRec* gr = c->h_groups.as<GroupRec>();
-        for (uint32_t i = 0; i < ng; ++i) {
-            const uint64_t k = gr[i].key;
-            c->parts[i] = GroupPart{(uint32_t)(k >> 38) + ph, (uint32_t)((k >> 12) & ((1u << 26) - 1)) + ph, (uint8_t)(k & 15),
-                                    (uint8_t)((k >> 4) & 255), gr[i].pairs, gr[i].sum_isize};
-        }
-    }
-    HIPCHK(c, hipEventRecord(c->ev[6], s));
-    const auto t_walk0 = std::chrono::steady_clock::now();
+// K4 on the context's own reads (single-context run)
+int do_join_local(bdx_ctx* c, uint32_t n, const Entries& en, const uint32_t* n_ptr) {
+    hipStream_t s = c->stream;
+    K4Arrays& k4 = c->k4;
+    k4 = K4Arrays{};
+    if (!n) return BDX_OK;
+    uint32_t nb = 1, lg = 0;
+    while (nb < (uint32_t)kMaxBuckets && (size_t)nb * 1536 < n) { nb <<= 1; ++lg; }
+    k4.nbuckets = nb; k4.log2b = lg;
+    HIPCHK(c, c->b_bcnt.ensure(nb * 4)); HIPCHK(c, c->b_boff.ensure((nb + 1) * 4)); HIPCHK(c, c->b_bcur.ensure(nb * 4));
+    HIPCHK(c, c->b_e_key.ensure((size_t)n * 8)); HIPCHK(c, c->b_e_idx.ensure((size_t)n * 4));
+    HIPCHK(c, c->b_partner.ensure((size_t)n * 4));
+    HIPCHK(c, c->b_t_key.ensure((size_t)n * 16)); HIPCHK(c, c->b_t_idx.ensure((size_t)n * 8));
+    k4.g_cap = n / 2 + 1;
+    HIPCHK(c, c->b_g_rec.ensure((size_t)k4.g_cap * sizeof(GroupRec)));
+    k4.bcnt = c->b_bcnt.as<uint32_t>(); k4.boff = c->b_boff.as<uint32_t>(); k4.bcur = c->b_bcur.as<uint32_t>();
+    k4.e_key = c->b_e_key.as<uint64_t>(); k4.e_idx = c->b_e_idx.as<uint32_t>(); k4.partner = c->b_partner.as<int32_t>();
+    k4.t_key = c->b_t_key.as<uint64_t>(); k4.t_idx = c->b_t_idx.as<int32_t>(); k4.g_rec = c->b_g_rec.as<GroupRec>();
+    launch_k4(k4, en, n_ptr, n, c->b_counts.as<StageCounts>(), s);
+    return BDX_OK;
+}
 
-    // ---- H1 walk ------------------------------------------------------------------------------------------------
+// counts + region table (+ groups) to the host
+int readback(bdx_ctx* c, bool with_groups) {
+    hipStream_t s = c->stream;
+    const int nkeys = c->nkeys;
+    const uint32_t na = c->p1.n_anom;
+    if (!na) return BDX_OK;
+    HIPCHK(c, hipMemcpyAsync(c->h_counts.p, c->b_counts.p, sizeof(StageCounts), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipGetLastError());
+    c->counts = *c->h_counts.as<StageCounts>();
+    if (c->counts.overflow) return fail(c, BDX_EINTERNAL, "group list overflow");
+    const uint32_t nr = c->counts.n_regions, ng = with_groups ? c->counts.n_groups : 0;
+    HIPCHK(c, c->h_regs.ensure((size_t)std::max<uint32_t>(nr, 1) * sizeof(RegionRec)));
+    HIPCHK(c, c->h_pk.ensure((size_t)std::max<uint32_t>(nr, 1) * 2 * nkeys * 4));
+    HIPCHK(c, c->h_groups.ensure((size_t)std::max<uint32_t>(ng, 1) * sizeof(GroupRec)));
+    if (nr) {
+        HIPCHK(c, hipMemcpyAsync(c->h_regs.p, c->k3.r_rec, (size_t)nr * sizeof(RegionRec), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(c->h_pk.p, c->k3.r_pk, (size_t)nr * 2 * nkeys * 4, hipMemcpyDeviceToHost, s));
+    }
+    if (ng) HIPCHK(c, hipMemcpyAsync(c->h_groups.p, c->k4.g_rec, (size_t)ng * sizeof(GroupRec), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return BDX_OK;
+}
+
+void decode_regions(bdx_ctx* c, const RegionRec* rr, const uint32_t* pk, uint32_t nr, uint32_t ph) {
+    const int nkeys = c->nkeys;
+    c->regions.resize(nr + ph);
+    if (ph) c->regions[0] = HostRegion{-1, -1, -1, 0, 0, 0, 0, 0};
+    for (uint32_t i = 0; i < nr; ++i)
+        c->regions[i + ph] = HostRegion{rr[i].tid, rr[i].start, rr[i].end, rr[i].n, rr[i].rev, rr[i].nonctx, rr[i].nnormal, rr[i].maxq};
+    c->r_pk.assign((size_t)ph * 2 * nkeys, 0u);
+    c->r_pk.insert(c->r_pk.end(), pk, pk + (size_t)nr * 2 * nkeys);
+}
+
+void decode_groups(bdx_ctx* c, const GroupRec* gr, uint32_t ng, uint32_t ph) {
+    c->parts.resize(ng);
+    for (uint32_t i = 0; i < ng; ++i) {
+        const uint64_t k = gr[i].key;
+        c->parts[i] = GroupPart{(uint32_t)(k >> 38) + ph, (uint32_t)((k >> 12) & ((1u << 26) - 1)) + ph, (uint8_t)(k & 15),
+                                (uint8_t)((k >> 4) & 255), gr[i].pairs, gr[i].sum_isize};
+    }
+}
+
+// H1 walk + K5 + score combination over c->regions / c->r_pk / c->parts with the adopted pass-1 statistics
+int do_walk(bdx_ctx* c, int32_t last_maxq, bool any_anomalous) {
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const auto t0 = std::chrono::steady_clock::now();
     WalkInput wi{};
-    wi.opts = c->opts; wi.libs = c->libs.data(); wi.nlibs = nlibs; wi.nbams = nbams; wi.nkeys = nkeys;
-    wi.hist = hist; wi.covered_ref_len = covered; wi.key_density = c->key_density.data();
-    wi.regions = &c->regions; wi.r_pk = c->r_pk.data(); wi.parts = &c->parts; wi.last_maxq = c->counts.last_maxq;
-    wi.any_anomalous = na != 0;
+    wi.opts = c->opts; wi.libs = c->libs.data(); wi.nlibs = c->nlibs; wi.nbams = c->nbams; wi.nkeys = c->nkeys;
+    wi.hist = c->cnt.data(); wi.covered_ref_len = c->g_covered; wi.key_density = c->key_density.data();
+    wi.regions = &c->regions; wi.r_pk = c->r_pk.data(); wi.parts = &c->parts; wi.last_maxq = last_maxq;
+    wi.any_anomalous = any_anomalous;
+    c->walk.clear();
     greedy_walk(wi, c->walk_scratch, c->walk);
-    const auto t_walk1 = std::chrono::steady_clock::now();
-
-    // ---- K5 -------------------------------------------------------------------------------------------------------
+    const auto t1 = std::chrono::steady_clock::now();
     const uint32_t nt = (uint32_t)c->walk.terms.size();
-    std::vector<double> log_tail(nt);
+    std::vector<double>& log_tail = c->log_tail;
+    log_tail.resize(nt);
     if (nt) {
         HIPCHK(c, c->b_lam.ensure((size_t)nt * 8)); HIPCHK(c, c->b_k.ensure((size_t)nt * 4)); HIPCHK(c, c->b_logt.ensure((size_t)nt * 8));
         HIPCHK(c, c->h_terms.ensure((size_t)nt * 20));
@@ -488,30 +582,193 @@ int bdx_run(bdx_ctx* c) {
         for (uint32_t i = 0; i < nt; ++i) log_tail[i] = ho[i];
     }
     finish_scores(wi, log_tail, c->walk, &c->n_printed);
-    HIPCHK(c, hipEventRecord(c->ev[7], s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    const auto t_end = std::chrono::steady_clock::now();
+    const auto t2 = std::chrono::steady_clock::now();
+    c->stage_ms[5] = ms_between(t0, t1);
+    c->stage_ms[6] = ms_between(t1, t2);
+    c->ran = true;
+    c->stage = 4;
+    return BDX_OK;
+}
 
+}  // namespace
+
+extern "C" {
+
+int bdx_run(bdx_ctx* c) {
+    if (!c) return BDX_EINVAL;
+    const auto t_begin = std::chrono::steady_clock::now();
+    int rc = do_pass1(c);
+    if (rc != BDX_OK) return rc;
+    rc = set_pass1(c, c->cnt_local.data(), c->p1.covered_ref_len, c->p1.window);
+    if (rc != BDX_OK) return rc;
+    rc = do_compact(c, 0, nullptr);
+    if (rc != BDX_OK) return rc;
+    rc = do_cut(c, 0, 0, 0);
+    if (rc != BDX_OK) return rc;
+    hipStream_t s = c->stream;
+    const uint32_t na = c->p1.n_anom;
+    if (na) {
+        Entries en{c->cp.key, c->k3.region_of, nullptr, c->cp.meta, c->cp.isize};
+        rc = do_join_local(c, na, en, &c->b_p1.as<Pass1>()->n_anom);
+        if (rc != BDX_OK) return rc;
+    }
+    HIPCHK(c, hipEventRecord(c->ev[5], s));
+    rc = readback(c, true);
+    if (rc != BDX_OK) return rc;
+    if (na) {
+        // The very first anomalous read "breaks" an empty accumulator (start = end = -1, no reads).  With a negative
+        // -s that empty candidate passes process_breakpoint's test (0 > min_len, coverage 0) and the reference
+        // registers a read-less region 0 (BreakDancer.cpp:216-231, 244-252); every real region id shifts by one.
+        const uint32_t ph = (0 > c->opts.min_len && 0.0f < (float)c->opts.seq_coverage_lim) ? 1u : 0u;
+        decode_regions(c, c->h_regs.as<RegionRec>(), c->h_pk.as<uint32_t>(), c->counts.n_regions, ph);
+        decode_groups(c, c->h_groups.as<GroupRec>(), c->counts.n_groups, ph);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[6], s));
+    rc = do_walk(c, c->counts.last_maxq, na != 0);
+    if (rc != BDX_OK) return rc;
+    const auto t_end = std::chrono::steady_clock::now();
     auto evms = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[a], c->ev[b]); return ms; };
-    auto chms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-        return std::chrono::duration<float, std::milli>(b - a).count();
-    };
-    c->stage_ms[0] = evms(0, 1);
     c->stage_ms[1] = evms(2, 3);
     c->stage_ms[2] = evms(3, 4);
     c->stage_ms[3] = evms(4, 5);
     c->stage_ms[4] = evms(5, 6);
-    c->stage_ms[5] = chms(t_walk0, t_walk1);
-    c->stage_ms[6] = chms(t_walk1, t_end);
-    c->stage_ms[7] = chms(t_begin, t_end);
-    c->ran = true;
+    c->stage_ms[7] = ms_between(t_begin, t_end);
     return BDX_OK;
+}
+
+// ---- staged entry points (multi-context / multi-GPU runs) ------------------------------------------------------
+int bdx_stage_pass1(bdx_ctx* c) { return c ? do_pass1(c) : BDX_EINVAL; }
+
+int bdx_get_pass1_local(const bdx_ctx* c, uint32_t* counters, uint64_t* ref_len_per_bam, uint32_t* totals) {
+    if (!c) return BDX_EINVAL;
+    if (c->stage < 1) return BDX_ESTATE;
+    if (counters) memcpy(counters, c->cnt_local.data(), c->cnt_local.size() * 4);
+    if (ref_len_per_bam)
+        for (int b = 0; b < c->nbams; ++b) ref_len_per_bam[b] = c->p1.ref_len[b];
+    if (totals) {
+        totals[0] = c->p1.n_anom; totals[1] = c->p1.n_normal;
+        for (int k = 0; k < c->nkeys; ++k) totals[2 + k] = c->p1.key_tot[k];
+    }
+    return BDX_OK;
+}
+
+int bdx_set_pass1_global(bdx_ctx* c, const uint32_t* counters, uint32_t covered_ref_len, int32_t window) {
+    if (!c || !counters) return BDX_EINVAL;
+    if (c->stage < 1) return BDX_ESTATE;
+    if (window < 0) window = window_from(c, counters, covered_ref_len);
+    return set_pass1(c, counters, covered_ref_len, window);
+}
+
+int bdx_stage_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, int32_t* first_qlen, uint32_t* first_nn) {
+    if (!c) return BDX_EINVAL;
+    if (c->stage < 2) return BDX_ESTATE;
+    if (c->opts.min_len < 0) return fail(c, BDX_ELIMIT, "staged runs do not support a negative -s");
+    int rc = do_compact(c, nn_base, pk_base);
+    if (rc != BDX_OK) return rc;
+    if (first_qlen) *first_qlen = 0;
+    if (first_nn) *first_nn = 0;
+    if (c->p1.n_anom) {  // the first anomalous read of this chromosome closes the previous chromosome's last candidate
+        uint32_t meta = 0, nn = 0;
+        HIPCHK(c, hipMemcpyAsync(&meta, c->cp.meta, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&nn, c->cp.nn, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (first_qlen) *first_qlen = meta_qlen(meta);
+        if (first_nn) *first_nn = nn;
+    }
+    return BDX_OK;
+}
+
+int bdx_stage_regions(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn) {
+    if (!c) return BDX_EINVAL;
+    if (c->stage < 2) return BDX_ESTATE;
+    int rc = do_cut(c, has_next, next_qlen, next_nn);
+    if (rc != BDX_OK) return rc;
+    return readback(c, false);
+}
+
+int bdx_get_stage_regions(const bdx_ctx* c, uint32_t* n_regions, uint32_t* n_anomalous, int32_t* last_maxq) {
+    if (!c) return BDX_EINVAL;
+    if (c->stage < 3) return BDX_ESTATE;
+    if (n_regions) *n_regions = c->counts.n_regions;
+    if (n_anomalous) *n_anomalous = c->p1.n_anom;
+    if (last_maxq) *last_maxq = c->counts.last_maxq;
+    return BDX_OK;
+}
+
+int bdx_get_region_records(const bdx_ctx* c, bdx_region_rec* out, uint32_t* pk, size_t cap) {
+    if (!c) return BDX_EINVAL;
+    if (c->stage < 3) return BDX_ESTATE;
+    const size_t n = std::min<size_t>(cap, c->counts.n_regions);
+    static_assert(sizeof(bdx_region_rec) == sizeof(RegionRec), "region record layout");
+    if (out && n) memcpy(out, c->h_regs.p, n * sizeof(RegionRec));
+    if (pk && n) memcpy(pk, c->h_pk.p, n * 2 * c->nkeys * 4);
+    return BDX_OK;
+}
+
+int bdx_get_compact(const bdx_ctx* c, uint64_t* key, int32_t* region, uint32_t* meta, int32_t* isize, size_t cap) {
+    if (!c) return BDX_EINVAL;
+    if (c->stage < 3) return BDX_ESTATE;
+    const size_t n = std::min<size_t>(cap, c->p1.n_anom);
+    if (!n) return BDX_OK;
+    if (hipSetDevice(c->device) != hipSuccess) return BDX_EHIP;
+    if (key && hipMemcpy(key, c->cp.key, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return BDX_EHIP;
+    if (region && hipMemcpy(region, c->k3.region_of, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return BDX_EHIP;
+    if (meta && hipMemcpy(meta, c->cp.meta, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return BDX_EHIP;
+    if (isize && hipMemcpy(isize, c->cp.isize, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return BDX_EHIP;
+    return BDX_OK;
+}
+
+int bdx_join_entries(bdx_ctx* c, size_t n, const uint64_t* key, const uint32_t* order, const int32_t* region, const uint32_t* meta,
+                     const int32_t* isize, bdx_group* out, size_t cap, uint32_t* n_groups, uint32_t* n_pairs) {
+    if (!c || (n && (!key || !order || !region || !meta || !isize))) return BDX_EINVAL;
+    if (n > kMaxRegions) return fail(c, BDX_ELIMIT, "too many join entries");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    if (n_groups) *n_groups = 0;
+    if (n_pairs) *n_pairs = 0;
+    if (!n) return BDX_OK;
+    HIPCHK(c, c->b_x_key.ensure(n * 8)); HIPCHK(c, c->b_x_order.ensure(n * 4)); HIPCHK(c, c->b_x_region.ensure(n * 4));
+    HIPCHK(c, c->b_x_meta.ensure(n * 4)); HIPCHK(c, c->b_x_isize.ensure(n * 4)); HIPCHK(c, c->b_x_n.ensure(16));
+    HIPCHK(c, c->b_counts.ensure(sizeof(StageCounts))); HIPCHK(c, c->h_counts.ensure(sizeof(StageCounts)));
+    const uint32_t n32 = (uint32_t)n;
+    HIPCHK(c, hipMemcpyAsync(c->b_x_key.p, key, n * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->b_x_order.p, order, n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->b_x_region.p, region, n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->b_x_meta.p, meta, n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->b_x_isize.p, isize, n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->b_x_n.p, &n32, 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemsetAsync(c->b_counts.p, 0, sizeof(StageCounts), s));
+    Entries en{c->b_x_key.as<uint64_t>(), c->b_x_region.as<int32_t>(), c->b_x_order.as<uint32_t>(), c->b_x_meta.as<uint32_t>(),
+               c->b_x_isize.as<int32_t>()};
+    int rc = do_join_local(c, n32, en, c->b_x_n.as<uint32_t>());
+    if (rc != BDX_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->h_counts.p, c->b_counts.p, sizeof(StageCounts), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipGetLastError());
+    const StageCounts sc = *c->h_counts.as<StageCounts>();
+    if (sc.overflow) return fail(c, BDX_EINTERNAL, "group list overflow");
+    if (n_groups) *n_groups = sc.n_groups;
+    if (n_pairs) *n_pairs = sc.n_pairs;
+    const size_t ng = std::min<size_t>(cap, sc.n_groups);
+    static_assert(sizeof(bdx_group) == sizeof(GroupRec), "group record layout");
+    if (out && ng) HIPCHK(c, hipMemcpy(out, c->k4.g_rec, ng * sizeof(GroupRec), hipMemcpyDeviceToHost));
+    return BDX_OK;
+}
+
+int bdx_stage_walk(bdx_ctx* c, size_t nregions, const bdx_region_rec* regions, const uint32_t* pk, size_t ngroups,
+                   const bdx_group* groups, int32_t last_maxq, int any_anomalous) {
+    if (!c || (nregions && (!regions || !pk)) || (ngroups && !groups)) return BDX_EINVAL;
+    if (c->stage < 2) return BDX_ESTATE;
+    decode_regions(c, (const RegionRec*)regions, pk, (uint32_t)nregions, 0);
+    decode_groups(c, (const GroupRec*)groups, (uint32_t)ngroups, 0);
+    c->counts.n_regions = (uint32_t)nregions;
+    return do_walk(c, last_maxq, any_anomalous != 0);
 }
 
 int bdx_get_summary(const bdx_ctx* c, bdx_summary* o) {
     if (!c || !o) return BDX_EINVAL;
     if (!c->ran) return BDX_ESTATE;
-    o->n_reads = c->n; o->n_anomalous = c->p1.n_anom; o->covered_ref_len = c->p1.covered_ref_len; o->window = c->p1.window;
+    o->n_reads = c->n; o->n_anomalous = c->p1.n_anom; o->covered_ref_len = c->g_covered; o->window = c->g_window;
     o->n_candidates = c->counts.n_cand; o->n_regions = (uint32_t)c->regions.size(); o->n_pairs = c->counts.n_pairs;
     o->n_groups = c->walk.n_groups; o->n_svs = (uint32_t)c->walk.svs.size(); o->n_svs_printed = c->n_printed;
     return BDX_OK;

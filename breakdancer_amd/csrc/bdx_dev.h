@@ -57,6 +57,7 @@ struct Pass1 {
     uint32_t n_anom;      // total anomalous reads
     uint32_t n_normal;    // total normal-leftmost reads
     uint32_t key_tot[60]; // proper read totals per key
+    unsigned long long ref_len[256];  // per source file: sum of pos - last_pos (BamSummary.cpp:70-74)
 };
 
 struct FinalizeParams {
@@ -92,6 +93,8 @@ struct K2Params {
     const uint8_t* cls;
     const uint32_t* tile_pre;
     Compact c;
+    uint32_t nn_base;      // normal read pairs / proper reads of earlier shards (0 for a single context)
+    uint32_t pk_base[60];
 };
 
 __device__ __forceinline__ uint32_t meta_pack(int flag, int rev, int lib, int qlen) {

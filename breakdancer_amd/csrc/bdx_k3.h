@@ -39,6 +39,7 @@ struct K3Arrays {
     int32_t* c_maxq;
     uint32_t *c_accept, *c_n, *c_rev, *c_nonctx, *c_nnormal;
     int32_t* c_rid;
+    int32_t* region_of;  // per compact read: accepted region id or -1
     // per accepted region (array-of-structs so one copy brings the table to the host)
     RegionRec* r_rec;
     uint32_t* r_pk;  // [cap][2*nkeys]: proper-read prefix counts at the region's first read (nkeys), then last read (nkeys)
@@ -50,8 +51,15 @@ struct K3Arrays {
     StageCounts* counts;
 };
 
+// the read that closes the last candidate when the stream continues in another context (next chromosome)
+struct K3Tail {
+    int has_next;
+    int32_t qlen;
+    uint32_t nn;
+};
+
 void launch_k3(const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n_anom_host, int min_len, int seq_coverage_lim,
-               int nkeys, hipStream_t s);
+               int nkeys, uint32_t nn_base, K3Tail tail, hipStream_t s);
 
 // ---- K4 ---------------------------------------------------------------------------------------------
 constexpr int kMaxBuckets = 8192;
@@ -79,7 +87,16 @@ __host__ __device__ __forceinline__ uint64_t group_pack(uint32_t rlo, uint32_t r
 }
 constexpr uint32_t kMaxRegions = (1u << 26) - 2;
 
-void launch_k4(const K4Arrays& k4, const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n_anom_host, hipStream_t s);
+// join input: one entry per anomalous read (region < 0: not in an accepted region, skipped)
+struct Entries {
+    const uint64_t* key;
+    const int32_t* region;   // region id (global ids when the entries come from several shards)
+    const uint32_t* order;   // position in the merged stream order; nullptr = the entry index itself
+    const uint32_t* meta;    // flag | rev<<4 | lib<<8 | qlen<<16
+    const int32_t* isize;    // |isize|
+};
+
+void launch_k4(const K4Arrays& k4, const Entries& e, const uint32_t* n_ptr, uint32_t n_upper, StageCounts* counts, hipStream_t s);
 
 // ---- K5 ---------------------------------------------------------------------------------------------
 void launch_k5(const double* lambda, const int32_t* k, double* out, uint32_t n, hipStream_t s);

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(const FinalizeParam
         if (t == 0) {
             MonoRec tot = s_mono[0];
             for (int k = 1; k < kFinBlock / 64; ++k) tot = mono_combine(tot, s_mono[k]);
-            if (b < 256) s_ref[b] = tot.ft == -1 ? 0ull : (unsigned long long)tot.sum;  // size_t ref_len, wraps like the reference
+            if (b < 256) { s_ref[b] = tot.ft == -1 ? 0ull : (unsigned long long)tot.sum; p.p1->ref_len[b] = s_ref[b]; }  // size_t ref_len, wraps like the reference
         }
         __syncthreads();
     }

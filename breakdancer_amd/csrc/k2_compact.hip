@@ -50,7 +50,7 @@ __global__ __launch_bounds__(kBlock) void k2_compact_kernel(const K2Params p) {
         for (int r = 0; r < 4; ++r) tot += (anom[r] ? 1u : 0u) + (nleft[r] ? 0x10000u : 0u);
         const uint32_t ex0 = wave_incl_scan(tot) - tot;
         uint32_t rank = p.tile_pre[(size_t)kColAnom * p.tstride + tile] + (ex0 & 0xFFFFu);
-        uint32_t nn = p.tile_pre[(size_t)kColNormal * p.tstride + tile] + (ex0 >> 16);
+        uint32_t nn = p.nn_base + p.tile_pre[(size_t)kColNormal * p.tstride + tile] + (ex0 >> 16);
         uint32_t jj[4] = {0, 0, 0, 0};
         int key[4] = {0, 0, 0, 0};
         if (nkeys > 1) {
@@ -84,8 +84,8 @@ __global__ __launch_bounds__(kBlock) void k2_compact_kernel(const K2Params p) {
                 inc4[r] = v;
             }
             const uint32_t ex = wave_incl_scan(v) - v;
-            const uint32_t b0 = p.tile_pre[(size_t)(kColKey0 + k0) * p.tstride + tile];
-            const uint32_t b1 = k0 + 1 < nkeys ? p.tile_pre[(size_t)(kColKey0 + k0 + 1) * p.tstride + tile] : 0u;
+            const uint32_t b0 = p.pk_base[k0] + p.tile_pre[(size_t)(kColKey0 + k0) * p.tstride + tile];
+            const uint32_t b1 = k0 + 1 < nkeys ? p.pk_base[k0 + 1] + p.tile_pre[(size_t)(kColKey0 + k0 + 1) * p.tstride + tile] : 0u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (!anom[r]) continue;

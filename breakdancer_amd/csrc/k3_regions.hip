@@ -46,7 +46,7 @@ struct HeadOut {
 };
 
 __global__ __launch_bounds__(256) void k3_candidates_kernel(K3Arrays a, Compact cp, const Pass1* p1, const U4* head_total,
-                                                            int min_len, int seq_coverage_lim, int nkeys) {
+                                                            int min_len, int seq_coverage_lim, int nkeys, uint32_t nn_base, K3Tail tail) {
     const uint32_t nc = head_total->x;
     const uint32_t na = p1->n_anom;
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -59,8 +59,14 @@ __global__ __launch_bounds__(256) void k3_candidates_kernel(K3Arrays a, Compact 
     const uint32_t rev = a.pre_rev[l] - (f ? a.pre_rev[f - 1] : 0u);
     const uint32_t nonctx = a.pre_nonctx[l] - (f ? a.pre_nonctx[f - 1] : 0u);
     const uint32_t e = c + 1 < nc ? nxt : l;
-    const int qsum = (int)(a.pre_q[e] - a.pre_q[f]);
-    const int maxq = a.c_maxq[c];
+    int qsum = (int)(a.pre_q[e] - a.pre_q[f]);
+    int maxq = a.c_maxq[c];
+    const bool tail_closes = c + 1 == nc && tail.has_next;  // closed by the first anomalous read of the next chromosome
+    if (tail_closes) {
+        qsum += tail.qlen;
+        maxq = max(maxq, tail.qlen);
+        a.c_maxq[c] = maxq;
+    }
     const float cov = __fdiv_rn((float)qsum, (float)(end - start + 1 + maxq));
     const bool accept = (end - start > min_len) && (cov < (float)seq_coverage_lim);
     a.c_accept[c] = accept ? 1u : 0u;
@@ -69,7 +75,7 @@ __global__ __launch_bounds__(256) void k3_candidates_kernel(K3Arrays a, Compact 
     a.c_nonctx[c] = nonctx;
     // normal read pairs seen while the candidate was open (BreakDancer.cpp:202-206): between its first
     // read and the breaking read, or the end of the stream
-    const uint32_t nn_end = c + 1 < nc ? cp.nn[nxt] : p1->n_normal;
+    const uint32_t nn_end = c + 1 < nc ? cp.nn[nxt] : (tail_closes ? tail.nn : nn_base + p1->n_normal);
     a.c_nnormal[c] = nn_end - cp.nn[f];
 }
 
@@ -102,8 +108,13 @@ struct AcceptOut {
 
 __global__ void k3_store_counts(K3Arrays a, const uint32_t* acc_total) { a.counts->n_regions = *acc_total; }
 
+__global__ __launch_bounds__(256) void k3_region_of_kernel(K3Arrays a, const Pass1* p1) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < p1->n_anom) a.region_of[j] = a.c_rid[a.cand[j]];
+}
+
 void launch_k3(const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n_anom_host, int min_len, int seq_coverage_lim,
-               int nkeys, hipStream_t s) {
+               int nkeys, uint32_t nn_base, K3Tail tail, hipStream_t s) {
     if (n_anom_host == 0) return;
     (void)hipMemsetAsync(a.c_maxq, 0, (size_t)n_anom_host * 4, s);
     const uint32_t* n_ptr = &p1->n_anom;
@@ -111,11 +122,12 @@ void launch_k3(const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n
     HeadOut hout{a};
     scan_launch<U4>(hin, hout, n_ptr, n_anom_host, a.ws_u4, a.head_total, s);
     const uint32_t g = (n_anom_host + 255) / 256;
-    hipLaunchKernelGGL(k3_candidates_kernel, dim3(g), dim3(256), 0, s, a, cp, p1, a.head_total, min_len, seq_coverage_lim, nkeys);
+    hipLaunchKernelGGL(k3_candidates_kernel, dim3(g), dim3(256), 0, s, a, cp, p1, a.head_total, min_len, seq_coverage_lim, nkeys, nn_base, tail);
     AcceptIn ain{a.c_accept};
     AcceptOut aout{a, cp, nkeys};
     scan_launch<uint32_t>(ain, aout, &a.counts->n_cand, n_anom_host, a.ws_u32, a.acc_total, s);
     hipLaunchKernelGGL(k3_store_counts, dim3(1), dim3(1), 0, s, a, a.acc_total);
+    hipLaunchKernelGGL(k3_region_of_kernel, dim3(g), dim3(256), 0, s, a, p1);
 }
 
 }  // namespace bdx

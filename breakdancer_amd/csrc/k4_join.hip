@@ -27,17 +27,17 @@ __device__ __forceinline__ uint32_t bucket_of(uint64_t h, uint32_t log2b) { retu
 
 constexpr int kPartChunk = 2048;  // compact reads per workgroup in the partition kernels
 
-__global__ __launch_bounds__(256) void k4_count_kernel(K4Arrays k4, K3Arrays a, Compact cp, const Pass1* p1) {
+__global__ __launch_bounds__(256) void k4_count_kernel(K4Arrays k4, Entries en, const uint32_t* n_ptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* s_h = (uint32_t*)smem;
-    const uint32_t na = p1->n_anom;
+    const uint32_t na = *n_ptr;
     const uint32_t base = blockIdx.x * kPartChunk;
     if (base >= na) return;
     for (uint32_t b = threadIdx.x; b < k4.nbuckets; b += 256) s_h[b] = 0;
     __syncthreads();
     for (int it = 0; it < kPartChunk / 256; ++it) {
         const uint32_t j = base + it * 256 + threadIdx.x;
-        if (j < na && a.c_rid[a.cand[j]] >= 0) atomicAdd(&s_h[bucket_of(mix64(cp.key[j]), k4.log2b)], 1u);
+        if (j < na && en.region[j] >= 0) atomicAdd(&s_h[bucket_of(mix64(en.key[j]), k4.log2b)], 1u);
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < k4.nbuckets; b += 256)
@@ -66,18 +66,18 @@ __global__ __launch_bounds__(1024) void k4_bucket_scan_kernel(K4Arrays k4, Stage
     if (threadIdx.x == 0) { k4.boff[k4.nbuckets] = s_carry; counts->n_entries = s_carry; }
 }
 
-__global__ __launch_bounds__(256) void k4_scatter_kernel(K4Arrays k4, K3Arrays a, Compact cp, const Pass1* p1) {
+__global__ __launch_bounds__(256) void k4_scatter_kernel(K4Arrays k4, Entries en, const uint32_t* n_ptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* s_h = (uint32_t*)smem;
     uint32_t* s_base = s_h + k4.nbuckets;
-    const uint32_t na = p1->n_anom;
+    const uint32_t na = *n_ptr;
     const uint32_t base = blockIdx.x * kPartChunk;
     if (base >= na) return;
     for (uint32_t b = threadIdx.x; b < k4.nbuckets; b += 256) s_h[b] = 0;
     __syncthreads();
     for (int it = 0; it < kPartChunk / 256; ++it) {
         const uint32_t j = base + it * 256 + threadIdx.x;
-        if (j < na && a.c_rid[a.cand[j]] >= 0) atomicAdd(&s_h[bucket_of(mix64(cp.key[j]), k4.log2b)], 1u);
+        if (j < na && en.region[j] >= 0) atomicAdd(&s_h[bucket_of(mix64(en.key[j]), k4.log2b)], 1u);
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < k4.nbuckets; b += 256) {
@@ -88,8 +88,8 @@ __global__ __launch_bounds__(256) void k4_scatter_kernel(K4Arrays k4, K3Arrays a
     __syncthreads();
     for (int it = 0; it < kPartChunk / 256; ++it) {
         const uint32_t j = base + it * 256 + threadIdx.x;
-        if (j < na && a.c_rid[a.cand[j]] >= 0) {
-            const uint64_t key = cp.key[j];
+        if (j < na && en.region[j] >= 0) {
+            const uint64_t key = en.key[j];
             const uint32_t b = bucket_of(mix64(key), k4.log2b);
             const uint32_t slot = s_base[b] + atomicAdd(&s_h[b], 1u);
             k4.e_key[slot] = key;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k4_join_kernel(K4Arrays k4) {
 
 constexpr uint64_t kEmptyGroup = ~0ull;
 
-__global__ __launch_bounds__(256) void k4_aggregate_kernel(K4Arrays k4, K3Arrays a, Compact cp, const Pass1* p1) {
+__global__ __launch_bounds__(256) void k4_aggregate_kernel(K4Arrays k4, Entries en, const uint32_t* n_ptr, StageCounts* counts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* s_key = (unsigned long long*)smem;  // [kAggSlots]
     uint32_t* s_cnt = (uint32_t*)(s_key + kAggSlots);
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void k4_aggregate_kernel(K4Arrays k4, K3Arrays
     uint32_t* s_ws = s_sum + kAggSlots;  // [4]; everything lives in the dynamic region (keeps its base 16-B aligned)
     uint32_t& s_base = s_ws[4];
     uint32_t& s_pairs = s_ws[5];
-    const uint32_t na = p1->n_anom;
+    const uint32_t na = *n_ptr;
     const uint32_t base = blockIdx.x * kPartChunk;
     if (base >= na) return;
     for (int s = threadIdx.x; s < kAggSlots; s += 256) { s_key[s] = kEmptyGroup; s_cnt[s] = 0; s_sum[s] = 0; }
@@ -163,12 +163,15 @@ __global__ __launch_bounds__(256) void k4_aggregate_kernel(K4Arrays k4, K3Arrays
     for (int it = 0; it < kPartChunk / 256; ++it) {
         const uint32_t j = base + it * 256 + threadIdx.x;
         if (j >= na) continue;
-        const int rj = a.c_rid[a.cand[j]];
+        const int rj = en.region[j];
         if (rj < 0) continue;
         const int32_t p = k4.partner[j];
-        if (p < 0 || (uint32_t)p >= j) continue;  // j is the second-observed mate (Q9): the later read in stream order
-        const int rp = a.c_rid[a.cand[p]];
-        const uint32_t m = cp.meta[j];
+        if (p < 0) continue;
+        // j must be the second-observed mate (Q9): the later read in merged stream order
+        const uint32_t oj = en.order ? en.order[j] : j, op = en.order ? en.order[p] : (uint32_t)p;
+        if (op >= oj) continue;
+        const int rp = en.region[p];
+        const uint32_t m = en.meta[j];
         const uint64_t gk = group_pack((uint32_t)rp, (uint32_t)rj, (uint32_t)meta_lib(m), (uint32_t)meta_flag(m));
         uint32_t s = (uint32_t)(mix64(gk) & (kAggSlots - 1));
         while (true) {
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256) void k4_aggregate_kernel(K4Arrays k4, K3Arrays
             s = (s + 1) & (kAggSlots - 1);
         }
         atomicAdd(&s_cnt[s], 1u);
-        atomicAdd(&s_sum[s], (uint32_t)cp.isize[j]);
+        atomicAdd(&s_sum[s], (uint32_t)en.isize[j]);
         ++mypairs;
     }
     if (mypairs) atomicAdd(&s_pairs, mypairs);
@@ -192,8 +195,8 @@ __global__ __launch_bounds__(256) void k4_aggregate_kernel(K4Arrays k4, K3Arrays
     uint32_t off = 0, tot = 0;
     for (int k = 0; k < 4; ++k) { if (k < w) off += s_ws[k]; tot += s_ws[k]; }
     if (threadIdx.x == 0) {
-        s_base = tot ? atomicAdd(&a.counts->n_groups, tot) : 0u;
-        if (s_pairs) atomicAdd(&a.counts->n_pairs, s_pairs);
+        s_base = tot ? atomicAdd(&counts->n_groups, tot) : 0u;
+        if (s_pairs) atomicAdd(&counts->n_pairs, s_pairs);
     }
     __syncthreads();
     uint32_t o = s_base + off + inc - occ;
@@ -201,20 +204,20 @@ __global__ __launch_bounds__(256) void k4_aggregate_kernel(K4Arrays k4, K3Arrays
         const int s = threadIdx.x * (kAggSlots / 256) + q;
         if (s_key[s] != kEmptyGroup) {
             if (o < k4.g_cap) { GroupRec g; g.key = s_key[s]; g.pairs = s_cnt[s]; g.sum_isize = s_sum[s]; k4.g_rec[o] = g; }
-            else a.counts->overflow = 1;
+            else counts->overflow = 1;
             ++o;
         }
     }
 }
 
-void launch_k4(const K4Arrays& k4, const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n_anom_host, hipStream_t s) {
+void launch_k4(const K4Arrays& k4, const Entries& en, const uint32_t* n_ptr, uint32_t n_anom_host, StageCounts* counts, hipStream_t s) {
     if (n_anom_host == 0) return;
     const uint32_t g = (n_anom_host + kPartChunk - 1) / kPartChunk;
     (void)hipMemsetAsync(k4.bcnt, 0, (size_t)k4.nbuckets * 4, s);
     (void)hipMemsetAsync(k4.partner, 0xFF, (size_t)n_anom_host * 4, s);
-    hipLaunchKernelGGL(k4_count_kernel, dim3(g), dim3(256), (size_t)k4.nbuckets * 4, s, k4, a, cp, p1);
-    hipLaunchKernelGGL(k4_bucket_scan_kernel, dim3(1), dim3(1024), 0, s, k4, a.counts);
-    hipLaunchKernelGGL(k4_scatter_kernel, dim3(g), dim3(256), (size_t)k4.nbuckets * 8, s, k4, a, cp, p1);
+    hipLaunchKernelGGL(k4_count_kernel, dim3(g), dim3(256), (size_t)k4.nbuckets * 4, s, k4, en, n_ptr);
+    hipLaunchKernelGGL(k4_bucket_scan_kernel, dim3(1), dim3(1024), 0, s, k4, counts);
+    hipLaunchKernelGGL(k4_scatter_kernel, dim3(g), dim3(256), (size_t)k4.nbuckets * 8, s, k4, en, n_ptr);
     static bool attr_set = false;
     if (!attr_set) {  // more than 64 KiB of dynamic LDS has to be opted into
         (void)hipFuncSetAttribute((const void*)k4_join_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kJoinLdsSlots * 12);
@@ -222,7 +225,7 @@ void launch_k4(const K4Arrays& k4, const K3Arrays& a, const Compact& cp, const P
         attr_set = true;
     }
     hipLaunchKernelGGL(k4_join_kernel, dim3(k4.nbuckets), dim3(256), (size_t)kJoinLdsSlots * 12, s, k4);
-    hipLaunchKernelGGL(k4_aggregate_kernel, dim3(g), dim3(256), (size_t)kAggSlots * 16 + 32, s, k4, a, cp, p1);
+    hipLaunchKernelGGL(k4_aggregate_kernel, dim3(g), dim3(256), (size_t)kAggSlots * 16 + 32, s, k4, en, n_ptr, counts);
 }
 
 }  // namespace bdx

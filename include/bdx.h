@@ -178,6 +178,49 @@ int bdx_classify(const bdx_opts* opts, const bdx_lib* libs, int nlibs, const bdx
                  int device);
 int bdx_poisson_log_upper_tail(const double* lambda, const int32_t* k, double* out, size_t n, int device);
 
+/* ---- staged execution: several contexts (one per chromosome, possibly on several GPUs) sharing one result ----
+ * The single-context bdx_run is pass1 -> adopt own statistics -> regions -> join -> walk.  With chromosomes spread
+ * over contexts the same stages run per context and the caller exchanges the few global quantities in between
+ * (breakdancer_amd/shard.py does it with torch.distributed: all-reduce of the pass-1 counters, all-gather of the
+ * per-chromosome totals, all-to-all of the join entries over RCCL, gather of regions/groups to the walking rank):
+ *   bdx_stage_pass1          K1 + finalize on this context's reads
+ *   bdx_get_pass1_local      counters [nlibs*11 + nlibs + nbams], per-file reference length sums, totals
+ *                            [n_anomalous, n_normal_pairs, proper reads per key...]
+ *   bdx_set_pass1_global     adopt (all-reduced) counters, covered_ref_len and window (window < 0: derive it)
+ *   bdx_stage_compact        K2; nn_base / pk_base = totals of the chromosomes that precede this one; returns the
+ *                            qlen / normal-pair count of this chromosome's first anomalous read (it closes the
+ *                            previous chromosome's last candidate region, BreakDancer.cpp:202-231)
+ *   bdx_stage_regions        K3; has_next / next_qlen / next_nn describe that closing read of the NEXT chromosome
+ *   bdx_get_region_records   accepted regions of this context (local ids) + their prefix-count samples
+ *   bdx_get_compact          per anomalous read: name key, local region id (-1 none), meta, |isize|
+ *   bdx_join_entries         K4 on caller-supplied entries with global region ids / global stream order
+ *   bdx_stage_walk           H1 walk + K5 over caller-supplied (global) regions and groups; results through
+ *                            bdx_get_summary / bdx_get_svs as usual
+ * Not supported in staged runs: negative -s. */
+typedef struct bdx_region_rec {
+    int32_t tid, start, end;
+    uint32_t n_reads, rev_reads, nonctx_reads, normal_read_pairs;
+    int32_t max_qlen;
+} bdx_region_rec;
+typedef struct bdx_group {  /* partial aggregate of one (region_lo, region_hi, flag, lib) connection group */
+    uint64_t key;           /* region_lo << 38 | region_hi << 12 | lib << 4 | flag */
+    uint32_t pairs;
+    uint32_t sum_isize;
+} bdx_group;
+int bdx_stage_pass1(bdx_ctx* ctx);
+int bdx_get_pass1_local(const bdx_ctx* ctx, uint32_t* counters, uint64_t* ref_len_per_bam, uint32_t* totals);
+int bdx_set_pass1_global(bdx_ctx* ctx, const uint32_t* counters, uint32_t covered_ref_len, int32_t window);
+int bdx_stage_compact(bdx_ctx* ctx, uint32_t nn_base, const uint32_t* pk_base, int32_t* first_qlen, uint32_t* first_nn);
+int bdx_stage_regions(bdx_ctx* ctx, int has_next, int32_t next_qlen, uint32_t next_nn);
+int bdx_get_stage_regions(const bdx_ctx* ctx, uint32_t* n_regions, uint32_t* n_anomalous, int32_t* last_maxq);
+int bdx_get_region_records(const bdx_ctx* ctx, bdx_region_rec* out, uint32_t* pk, size_t cap);
+int bdx_get_compact(const bdx_ctx* ctx, uint64_t* key, int32_t* region, uint32_t* meta, int32_t* isize, size_t cap);
+int bdx_join_entries(bdx_ctx* ctx, size_t n, const uint64_t* key, const uint32_t* order, const int32_t* region,
+                     const uint32_t* meta, const int32_t* isize, bdx_group* out, size_t cap, uint32_t* n_groups,
+                     uint32_t* n_pairs);
+int bdx_stage_walk(bdx_ctx* ctx, size_t nregions, const bdx_region_rec* regions, const uint32_t* pk, size_t ngroups,
+                   const bdx_group* groups, int32_t last_maxq, int any_anomalous);
+
 /* device the context is bound to and the HIP stream it launches on (as void*), for callers that time it */
 int bdx_device(const bdx_ctx* ctx);
 void* bdx_stream(const bdx_ctx* ctx);
