@@ -1,0 +1,80 @@
+"""Minimal BGZF/BAM writer for synthetic inputs (numpy-vectorised fixed-size records).  Tooling for tests and
+end-to-end measurements only: the product never writes BAM (BamWriter is out of scope)."""
+import struct
+import zlib
+
+import numpy as np
+
+_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def _bgzf_block(data, level):
+    co = zlib.compressobj(level, zlib.DEFLATED, -15)
+    comp = co.compress(data) + co.flush()
+    bsize = len(comp) + 25
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + comp +
+            struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+
+
+def write_bam(path, soa, targets, rg="rg1", readlen=None, level=1, seed=0, names=None):
+    """soa: dict with tid,pos,mtid,mpos,isize,flag,qlen,mapq (+name_key used to derive the read names).
+    Every record gets `readlen` random bases / qualities (default: soa['qlen'][0]), a 100M-style CIGAR and RG:Z:<rg>."""
+    n = len(soa["tid"])
+    L = int(readlen if readlen is not None else (soa["qlen"][0] if n else 100))
+    rng = np.random.default_rng(seed)
+    if names is None:  # mates share the name: derive it from the name key (16 hex digits)
+        keys = soa["name_key"].astype(np.uint64)
+        hexd = np.frombuffer(b"0123456789abcdef", np.uint8)
+        nm = np.empty((n, 17), np.uint8)
+        for i in range(16):
+            nm[:, 15 - i] = hexd[((keys >> np.uint64(4 * i)) & np.uint64(15)).astype(np.int64)]
+        nm[:, 16] = 0
+    else:
+        w = max(len(x) for x in names) + 1
+        nm = np.zeros((n, w), np.uint8)
+        for i, x in enumerate(names):
+            nm[i, :len(x)] = np.frombuffer(x.encode(), np.uint8)
+    lname = nm.shape[1]
+    aux = b"RGZ" + rg.encode() + b"\0"
+    rec_len = 32 + lname + 4 + (L + 1) // 2 + L + len(aux)
+    rec = np.zeros((n, 4 + rec_len), np.uint8)
+
+    def put(col, arr, dt):
+        a = np.ascontiguousarray(arr.astype(dt)).view(np.uint8).reshape(n, -1)
+        rec[:, col:col + a.shape[1]] = a
+
+    put(0, np.full(n, rec_len), "<i4")
+    put(4, soa["tid"], "<i4")
+    put(8, soa["pos"], "<i4")
+    rec[:, 12] = lname
+    rec[:, 13] = soa["mapq"]
+    put(14, np.zeros(n), "<u2")
+    put(16, np.ones(n), "<u2")
+    put(18, soa["flag"], "<u2")
+    put(20, np.full(n, L), "<i4")
+    put(24, soa["mtid"], "<i4")
+    put(28, soa["mpos"], "<i4")
+    put(32, soa["isize"], "<i4")
+    o = 36
+    rec[:, o:o + lname] = nm
+    o += lname
+    put(o, np.full(n, (L << 4) | 0), "<u4")
+    o += 4
+    nb = (L + 1) // 2
+    codes = np.array([1, 2, 4, 8], np.uint8)
+    rec[:, o:o + nb] = (codes[rng.integers(0, 4, (n, nb))] << 4) | codes[rng.integers(0, 4, (n, nb))]
+    o += nb
+    rec[:, o:o + L] = rng.integers(2, 41, (n, L), dtype=np.uint8)
+    o += L
+    rec[:, o:o + len(aux)] = np.frombuffer(aux, np.uint8)
+    text = "@HD\tVN:1.0\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (t, 300000000) for t in targets) + \
+           "@RG\tID:%s\tLB:lib1\tSM:s\n" % rg
+    hdr = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(targets))
+    for t in targets:
+        hdr += struct.pack("<i", len(t) + 1) + t.encode() + b"\0" + struct.pack("<i", 300000000)
+    raw = hdr + rec.tobytes()
+    with open(path, "wb") as f:
+        for i in range(0, len(raw), 65280):
+            f.write(_bgzf_block(raw[i:i + 65280], level))
+        f.write(_EOF)
+    return path

@@ -367,6 +367,8 @@ struct Walker {
         }
         max_readlen = in.last_maxq;
         flush(prev, NR - 1);
+        if (prof) fprintf(stderr, "[walk] total %.1f us, svs %zu\n",
+                          std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp0).count(), out.svs.size());
     }
 };
 

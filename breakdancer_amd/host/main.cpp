@@ -1,6 +1,8 @@
 // breakdancer-max: same command line, configuration format and output columns as the reference
 // (exe/breakdancer-max/BreakDancerMax.cpp:38-163); the clustering path runs on the GPU through libbdx.
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <fstream>
 #include <iomanip>
@@ -48,7 +50,14 @@ int main(int argc, char** argv) {
         }
         const unsigned hw = std::thread::hardware_concurrency();
         ReadStream reads;
+        const bool timing = getenv("BDX_TIMING") != nullptr;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double>(b - a).count();
+        };
+        const auto t_start = now();
         produce(cfg, opts.chr, hw ? (int)std::min(hw, 16u) : 4, reads);
+        const auto t_decoded = now();
 
         const std::vector<bdx_lib> libs = cfg.abi_libs();
         const int nlibs = (int)libs.size(), nbams = (int)cfg.num_bams();
@@ -56,8 +65,11 @@ int main(int argc, char** argv) {
                                   opts.device), "bdx_create");
         const bdx_batch batch = reads.batch();
         check(ctx, bdx_reserve(ctx, batch.n), "bdx_reserve");
+        const auto t_created = now();
         check(ctx, bdx_push(ctx, &batch), "bdx_push");
+        const auto t_pushed = now();
         check(ctx, bdx_run(ctx), "bdx_run");
+        const auto t_ran = now();
 
         bdx_summary sum;
         check(ctx, bdx_get_summary(ctx, &sum), "bdx_get_summary");
@@ -149,6 +161,14 @@ int main(int argc, char** argv) {
                 }
             }
             cout << "\n";
+        }
+        if (timing) {
+            float ms[8] = {0};
+            bdx_get_timings(ctx, ms, 8);
+            fprintf(stderr, "[bdx timing] reads=%zu decode+merge=%.3fs (BGZF inflate on %u threads, single pass) gpu_init=%.3fs h2d_push=%.3fs "
+                            "bdx_run=%.4fs (classify %.3f ms) format=%.3fs total=%.3fs\n",
+                    reads.size(), secs(t_start, t_decoded), hw ? std::min(hw, 16u) : 4u, secs(t_decoded, t_created), secs(t_created, t_pushed),
+                    secs(t_pushed, t_ran), ms[0], secs(t_ran, now()), secs(t_start, now()));
         }
         bdx_destroy(ctx);
         ctx = nullptr;

@@ -58,3 +58,22 @@ def test_missing_map_field_is_an_error(tmp_path):
     cfg.write_text("readgroup:rg1\tlib:l1\tmean:400\tstd:30\n")
     p = subprocess.run([DUMP, str(cfg)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 1 and b"Required field 'map' not found in config at line 1!" in p.stderr
+
+
+def test_producer_decodes_a_multi_block_synthetic_bam(tmp_path):
+    """a few thousand BGZF blocks, records straddling block boundaries, parallel inflate"""
+    from breakdancer_amd.bamwrite import write_bam
+    from breakdancer_amd.synth import make_chromosome
+    d = make_chromosome(length=300000, seed=5)
+    write_bam(str(tmp_path / "syn.bam"), d, ["chrS"], seed=1)
+    (tmp_path / "cfg").write_text("readgroup:rg1\tplatform:illumina\tmap:syn.bam\treadlen:100.00\tlib:lib1\tlower:310.00\tupper:490.00\tmean:400.00\tstd:30.00\n")
+    head, rows, keys = dump(["cfg"], str(tmp_path))
+    n = len(d["tid"])
+    assert len(rows) == n and n > 80000
+    for col, k in enumerate(("tid", "pos", "mtid", "mpos", "isize", "flag", "qlen", "mapq", "lib", "bam")):
+        np.testing.assert_array_equal(rows[:, col], d[k].astype(np.int64), err_msg=k)
+    # mates share a key, distinct pairs do not
+    m = {}
+    for k, i in zip(keys.tolist(), d["name_key"].tolist()):
+        assert m.setdefault(i, k) == k
+    assert len(set(m.values())) == len(m)
