@@ -46,10 +46,10 @@ EXPORTS = ["bdx_opts_default", "bdx_create", "bdx_destroy", "bdx_strerror", "bdx
            "bdx_set_device_reads", "bdx_run", "bdx_get_summary", "bdx_get_counters", "bdx_get_regions", "bdx_get_svs",
            "bdx_get_sv_lists", "bdx_get_read_class", "bdx_get_timings", "bdx_classify", "bdx_poisson_log_upper_tail",
            "bdx_device", "bdx_stream", "bdx_stage_pass1", "bdx_get_pass1_local", "bdx_set_pass1_global", "bdx_stage_compact", "bdx_stage_regions",
-           "bdx_get_stage_regions", "bdx_get_region_records", "bdx_get_compact", "bdx_join_entries", "bdx_stage_walk"]
+           "bdx_get_stage_regions", "bdx_get_region_records", "bdx_get_compact", "bdx_join_entries", "bdx_stage_walk", "bdx_set_collect_support", "bdx_get_sv_support"]
 
 REGION_REC_DTYPE = np.dtype([("tid", "<i4"), ("start", "<i4"), ("end", "<i4"), ("n_reads", "<u4"), ("rev_reads", "<u4"),
-                             ("nonctx_reads", "<u4"), ("normal_read_pairs", "<u4"), ("max_qlen", "<i4")])
+                             ("nonctx_reads", "<u4"), ("normal_read_pairs", "<u4"), ("max_qlen", "<i4"), ("first_read", "<u4")])
 GROUP_DTYPE = np.dtype([("key", "<u8"), ("pairs", "<u4"), ("sum_isize", "<u4")])
 
 _lib = None
@@ -101,5 +101,7 @@ def load():
     L.bdx_get_compact.argtypes = [vp, vp, vp, vp, vp, C.c_size_t]
     L.bdx_join_entries.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, vp]
     L.bdx_stage_walk.argtypes = [vp, C.c_size_t, vp, vp, C.c_size_t, vp, C.c_int32, C.c_int]
+    L.bdx_set_collect_support.argtypes = [vp, C.c_int]
+    L.bdx_get_sv_support.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
     _lib = L
     return L

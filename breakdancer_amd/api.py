@@ -176,6 +176,20 @@ class BreakDancer:
         self._chk(self.lib.bdx_get_sv_lists(self.h, p(li), p(lp), nl, p(ck), p(cv), nc), "bdx_get_sv_lists")
         return out, (li, lp), (ck, cv)
 
+    def collect_support(self, on=True):
+        self._chk(self.lib.bdx_set_collect_support(self.h, int(on)), "bdx_set_collect_support")
+
+    def sv_support(self):
+        """(offsets[n_svs+1], read_index, read_flag): supporting reads per SV in the reference's order"""
+        n = self.summary()["n_svs"]
+        off = np.zeros(n + 1, np.uint32)
+        tot = C.c_size_t()
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._chk(self.lib.bdx_get_sv_support(self.h, p(off), None, None, 0, C.byref(tot)), "bdx_get_sv_support")
+        idx, flg = np.zeros(tot.value, np.uint64), np.zeros(tot.value, np.uint8)
+        self._chk(self.lib.bdx_get_sv_support(self.h, p(off), p(idx), p(flg), tot.value, C.byref(tot)), "bdx_get_sv_support")
+        return off, idx, flg
+
     def read_class(self):
         n = self.summary()["n_reads"]
         out = np.zeros(n, np.uint8)

@@ -80,7 +80,7 @@ struct bdx_ctx {
 
     // stage buffers
     DevBuf b_libs, b_cls, b_tile_tot, b_tile_pre, b_tile_mono, b_blk_cnt, b_cnt, b_p1;
-    DevBuf b_c_tid, b_c_pos, b_c_isize, b_c_meta, b_c_key, b_c_nn, b_c_pk;
+    DevBuf b_c_tid, b_c_pos, b_c_isize, b_c_meta, b_c_key, b_c_idx, b_c_nn, b_c_pk;
     DevBuf b_cand, b_pre_q, b_pre_rev, b_pre_nonctx, b_c_first, b_c_maxq, b_c_accept, b_c_n, b_c_rev, b_c_nonctx,
         b_c_nnormal, b_c_rid, b_region_of, b_r_rec, b_r_pk, b_ws_u4, b_ws_u32, b_totals, b_counts;
     DevBuf b_bcnt, b_boff, b_bcur, b_e_key, b_e_idx, b_partner, b_t_key, b_t_idx, b_g_rec;
@@ -103,6 +103,12 @@ struct bdx_ctx {
     K3Arrays k3{};
     K4Arrays k4{};
     std::vector<double> log_tail;
+    bool collect_support = false;
+    std::vector<uint32_t> sup_off;    // [n_svs + 1]
+    std::vector<uint64_t> sup_idx;
+    std::vector<uint8_t> sup_flag;
+    std::vector<uint32_t> reg_first;  // compact index of each region's first read (host ids, incl. the phantom shift)
+    std::vector<uint32_t> reg_n;
     std::vector<float> seqcov, lib_density, key_density;
     std::vector<HostRegion> regions;
     std::vector<uint32_t> r_pk;
@@ -223,7 +229,7 @@ void bdx_destroy(bdx_ctx* c) {
     DevBuf* bufs[] = {&c->b_tid, &c->b_pos, &c->b_mtid, &c->b_mpos, &c->b_isize, &c->b_flag, &c->b_qlen, &c->b_mapq, &c->b_lib,
                       &c->b_bam, &c->b_key, &c->b_libs, &c->b_cls, &c->b_tile_tot, &c->b_tile_pre, &c->b_tile_mono,
                       &c->b_blk_cnt, &c->b_cnt, &c->b_p1, &c->b_c_tid, &c->b_c_pos, &c->b_c_isize,
-                      &c->b_c_meta, &c->b_c_key, &c->b_c_nn, &c->b_c_pk, &c->b_cand, &c->b_pre_q, &c->b_pre_rev,
+                      &c->b_c_meta, &c->b_c_key, &c->b_c_idx, &c->b_c_nn, &c->b_c_pk, &c->b_cand, &c->b_pre_q, &c->b_pre_rev,
                       &c->b_pre_nonctx, &c->b_c_first, &c->b_c_maxq, &c->b_c_accept, &c->b_c_n, &c->b_c_rev, &c->b_c_nonctx,
                       &c->b_c_nnormal, &c->b_c_rid, &c->b_region_of, &c->b_r_rec, &c->b_r_pk, &c->b_ws_u4, &c->b_ws_u32, &c->b_totals,
                       &c->b_counts, &c->b_bcnt, &c->b_boff, &c->b_bcur, &c->b_e_key, &c->b_e_idx, &c->b_partner, &c->b_t_key,
@@ -430,9 +436,11 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base) {
         const size_t cap = na;
         HIPCHK(c, c->b_c_tid.ensure(cap * 4)); HIPCHK(c, c->b_c_pos.ensure(cap * 4)); HIPCHK(c, c->b_c_isize.ensure(cap * 4));
         HIPCHK(c, c->b_c_meta.ensure(cap * 4)); HIPCHK(c, c->b_c_key.ensure(cap * 8)); HIPCHK(c, c->b_c_nn.ensure(cap * 4));
+        HIPCHK(c, c->b_c_idx.ensure(cap * 4));
         HIPCHK(c, c->b_c_pk.ensure(cap * 4 * nkeys));
         cp.tid = c->b_c_tid.as<int32_t>(); cp.pos = c->b_c_pos.as<int32_t>(); cp.isize = c->b_c_isize.as<int32_t>();
         cp.meta = c->b_c_meta.as<uint32_t>(); cp.key = c->b_c_key.as<uint64_t>(); cp.nn = c->b_c_nn.as<uint32_t>();
+        cp.idx = c->b_c_idx.as<uint32_t>();
         cp.pk = c->b_c_pk.as<uint32_t>(); cp.cap = na;
         K2Params k2{};
         k2.r = c->d; k2.n = c->n; k2.ntiles = c->ntiles; k2.tstride = c->tstride; k2.nkeys = nkeys; k2.libs = c->b_libs.as<DevLib>();
@@ -534,9 +542,14 @@ int readback(bdx_ctx* c, bool with_groups) {
 void decode_regions(bdx_ctx* c, const RegionRec* rr, const uint32_t* pk, uint32_t nr, uint32_t ph) {
     const int nkeys = c->nkeys;
     c->regions.resize(nr + ph);
+    c->reg_first.assign(nr + ph, 0);
+    c->reg_n.assign(nr + ph, 0);
     if (ph) c->regions[0] = HostRegion{-1, -1, -1, 0, 0, 0, 0, 0};
-    for (uint32_t i = 0; i < nr; ++i)
+    for (uint32_t i = 0; i < nr; ++i) {
         c->regions[i + ph] = HostRegion{rr[i].tid, rr[i].start, rr[i].end, rr[i].n, rr[i].rev, rr[i].nonctx, rr[i].nnormal, rr[i].maxq};
+        c->reg_first[i + ph] = rr[i].first;
+        c->reg_n[i + ph] = rr[i].n;
+    }
     c->r_pk.assign((size_t)ph * 2 * nkeys, 0u);
     c->r_pk.insert(c->r_pk.end(), pk, pk + (size_t)nr * 2 * nkeys);
 }
@@ -590,6 +603,44 @@ int do_walk(bdx_ctx* c, int32_t last_maxq, bool any_anomalous) {
     return BDX_OK;
 }
 
+// Supporting reads per SV, in SvBuilder's observation order (SvBuilder.cpp:101-118): reads of region A then region B
+// are visited in stream order and a pair is recorded when its second mate shows up, second mate first.
+int collect_support(bdx_ctx* c, uint32_t ph) {
+    c->sup_off.assign(1, 0);
+    c->sup_idx.clear();
+    c->sup_flag.clear();
+    const uint32_t na = c->p1.n_anom;
+    std::vector<int32_t> partner(na), region_of(na);
+    std::vector<uint32_t> idx(na), meta(na);
+    if (na) {
+        HIPCHK(c, hipMemcpy(partner.data(), c->k4.partner, (size_t)na * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(region_of.data(), c->k3.region_of, (size_t)na * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(idx.data(), c->cp.idx, (size_t)na * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(meta.data(), c->cp.meta, (size_t)na * 4, hipMemcpyDeviceToHost));
+    }
+    std::vector<std::pair<uint32_t, uint32_t>> pairs;  // (second-observed j, its mate p)
+    for (const HostSv& hs : c->walk.svs) {
+        pairs.clear();
+        for (uint32_t g = 0; g < hs.ngrp; ++g) {
+            const uint32_t lo = hs.grp_lo[g], hi = hs.grp_hi[g];
+            const uint32_t f = c->reg_first[hi], n = c->reg_n[hi];
+            for (uint32_t j = f; j < f + n; ++j) {
+                const int32_t p = partner[j];
+                if (p < 0 || (uint32_t)p >= j) continue;
+                if ((uint32_t)(region_of[p] + (int32_t)ph) != lo) continue;
+                pairs.emplace_back(j, (uint32_t)p);
+            }
+        }
+        std::sort(pairs.begin(), pairs.end());
+        for (auto const& pr : pairs) {
+            c->sup_idx.push_back(idx[pr.first]); c->sup_flag.push_back((uint8_t)meta_flag(meta[pr.first]));
+            c->sup_idx.push_back(idx[pr.second]); c->sup_flag.push_back((uint8_t)meta_flag(meta[pr.second]));
+        }
+        c->sup_off.push_back((uint32_t)c->sup_idx.size());
+    }
+    return BDX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -626,6 +677,11 @@ int bdx_run(bdx_ctx* c) {
     HIPCHK(c, hipEventRecord(c->ev[6], s));
     rc = do_walk(c, c->counts.last_maxq, na != 0);
     if (rc != BDX_OK) return rc;
+    if (c->collect_support) {
+        const uint32_t ph = (na && 0 > c->opts.min_len && 0.0f < (float)c->opts.seq_coverage_lim) ? 1u : 0u;
+        rc = collect_support(c, ph);
+        if (rc != BDX_OK) return rc;
+    }
     const auto t_end = std::chrono::steady_clock::now();
     auto evms = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[a], c->ev[b]); return ms; };
     c->stage_ms[1] = evms(2, 3);
@@ -820,6 +876,23 @@ int bdx_get_sv_lists(const bdx_ctx* c, int32_t* lib_index, int32_t* lib_pairs, s
     const size_t nc = std::min(cn_cap, c->walk.cn_key.size());
     if (cn_key) memcpy(cn_key, c->walk.cn_key.data(), nc * 4);
     if (cn_value) memcpy(cn_value, c->walk.cn_value.data(), nc * 4);
+    return BDX_OK;
+}
+
+int bdx_set_collect_support(bdx_ctx* c, int on) {
+    if (!c) return BDX_EINVAL;
+    c->collect_support = on != 0;
+    return BDX_OK;
+}
+
+int bdx_get_sv_support(const bdx_ctx* c, uint32_t* sv_offsets, uint64_t* read_index, uint8_t* read_flag, size_t cap, size_t* n_total) {
+    if (!c) return BDX_EINVAL;
+    if (!c->ran || !c->collect_support || c->sup_off.size() != c->walk.svs.size() + 1) return BDX_ESTATE;
+    if (n_total) *n_total = c->sup_idx.size();
+    if (sv_offsets) memcpy(sv_offsets, c->sup_off.data(), c->sup_off.size() * 4);
+    const size_t n = std::min(cap, c->sup_idx.size());
+    if (read_index && n) memcpy(read_index, c->sup_idx.data(), n * 8);
+    if (read_flag && n) memcpy(read_flag, c->sup_flag.data(), n);
     return BDX_OK;
 }
 

@@ -79,6 +79,7 @@ struct Compact {
     int32_t* isize;     // |isize|
     uint32_t* meta;     // flag (4) | rev<<4 | lib<<8 | qlen<<16
     uint64_t* key;
+    uint32_t* idx;      // index of the read in the resident stream
     uint32_t* nn;       // normal-leftmost reads seen before this read (stream order)
     uint32_t* pk;       // [nkeys][cap]: proper reads of key k seen up to and including this read
     uint32_t cap;

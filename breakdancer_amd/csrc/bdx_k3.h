@@ -21,6 +21,7 @@ struct RegionRec {
     int32_t tid, start, end;
     uint32_t n, rev, nonctx, nnormal;
     int32_t maxq;
+    uint32_t first;  // compact index of the region's first read (its reads are [first, first + n))
 };
 
 struct GroupRec {  // partial aggregate of one (region_lo, region_hi, flag, lib) group

@@ -250,6 +250,9 @@ struct Walker {
         sv.allele_frequency = allele_frequency; sv.logp = 0;
         hs.term_begin = (uint32_t)out.terms.size();
         hs.term_count = (uint32_t)nacc;
+        hs.ngrp = 0;
+        for (Group* g : gs)
+            if (g) { hs.grp_lo[hs.ngrp] = g->lo; hs.grp_hi[hs.ngrp] = g->hi; ++hs.ngrp; }
         for (int i = 0; i < nacc; ++i) {
             out.lib_index.push_back(la[i].lib);
             out.lib_pairs.push_back(la[i].rc);

@@ -29,6 +29,8 @@ struct SvTerm {  // one Poisson term to be scored by K5
 struct HostSv {
     bdx_sv sv;
     uint32_t term_begin, term_count;  // into WalkResult::terms
+    uint32_t ngrp;                    // pair groups this SV consumed, (lo, hi) region ids
+    uint32_t grp_lo[3], grp_hi[3];
 };
 
 struct WalkInput {

@@ -71,6 +71,7 @@ __global__ __launch_bounds__(kBlock) void k2_compact_kernel(const K2Params p) {
                 p.c.isize[j] = abs(p.r.isize[i]);
                 p.c.meta[j] = meta_pack((int)(c[r] & 15u), (sam >> 4) & 1u, (int)L, (int)p.r.qlen[i]);
                 p.c.key[j] = p.r.key[i];
+                p.c.idx[j] = (uint32_t)i;
                 p.c.nn[j] = nn;
             }
             if (nleft[r]) ++nn;

@@ -98,6 +98,7 @@ struct AcceptOut {
         rr.tid = cp.tid[f]; rr.start = cp.pos[f]; rr.end = cp.pos[l];
         rr.n = a.c_n[c]; rr.rev = a.c_rev[c]; rr.nonctx = a.c_nonctx[c]; rr.nnormal = a.c_nnormal[c];
         rr.maxq = a.c_maxq[c];
+        rr.first = f;
         a.r_rec[r] = rr;
         for (int k = 0; k < nkeys; ++k) {
             a.r_pk[(size_t)r * 2 * nkeys + k] = cp.pk[(size_t)k * cp.cap + f];

@@ -7,7 +7,9 @@
 #include <fstream>
 #include <iomanip>
 #include <iostream>
+#include <algorithm>
 #include <map>
+#include <memory>
 #include <sstream>
 #include <stdexcept>
 #include <thread>
@@ -15,6 +17,7 @@
 
 #include "bdx.h"
 #include "config.h"
+#include "dumps.h"
 #include "options.h"
 #include "producer.h"
 
@@ -39,8 +42,7 @@ int main(int argc, char** argv) {
         Options opts(argc, argv);
         if (!opts.restore_file.empty() || !opts.cache_file.empty())
             throw std::runtime_error("-C / -R (pass-1 cache) are not supported: pass 1 is part of the single GPU pass");
-        if (!opts.prefix_fastq.empty() || !opts.dump_BED.empty())
-            throw std::runtime_error("-d / -g (FASTQ / BED dumps of supporting reads) are not implemented yet");
+        const bool want_dumps = !opts.prefix_fastq.empty() || !opts.dump_BED.empty();
         std::ifstream cfg_stream(opts.bam_config_path.c_str());
         if (!cfg_stream.is_open()) throw std::runtime_error("unable to open config file '" + opts.bam_config_path + "'");
         BamConfig cfg(cfg_stream, opts.o.cut_sd);
@@ -66,6 +68,7 @@ int main(int argc, char** argv) {
         const bdx_batch batch = reads.batch();
         check(ctx, bdx_reserve(ctx, batch.n), "bdx_reserve");
         const auto t_created = now();
+        if (want_dumps) check(ctx, bdx_set_collect_support(ctx, 1), "bdx_set_collect_support");
         check(ctx, bdx_push(ctx, &batch), "bdx_push");
         const auto t_pushed = now();
         check(ctx, bdx_run(ctx), "bdx_run");
@@ -114,7 +117,33 @@ int main(int argc, char** argv) {
         check(ctx, bdx_get_sv_lists(ctx, li.data(), lp.data(), nl, ck.data(), cv.data(), nc), "bdx_get_sv_lists");
 
         auto tname = [&](int t) { return (t >= 0 && (size_t)t < reads.targets.size()) ? reads.targets[t] : std::to_string(t); };
+
+        // supporting reads of the printed SVs: a second decode pass fetches just those records (the reference keeps
+        // sequence data for every anomalous read in memory instead)
+        std::vector<uint32_t> sup_off;
+        std::vector<uint64_t> sup_idx, wanted;
+        std::vector<uint8_t> sup_flag;
+        std::vector<SupportRead> sup_reads;
+        std::unique_ptr<BedDump> bed;
+        std::unique_ptr<FastqDump> fastq;
+        if (want_dumps) {
+            if (!opts.prefix_fastq.empty()) fastq.reset(new FastqDump(opts.prefix_fastq, cfg));
+            if (!opts.dump_BED.empty()) bed.reset(new BedDump(opts.dump_BED, cfg, reads.targets));
+            size_t total = 0;
+            sup_off.resize(svs.size() + 1);
+            check(ctx, bdx_get_sv_support(ctx, sup_off.data(), nullptr, nullptr, 0, &total), "bdx_get_sv_support");
+            sup_idx.resize(total);
+            sup_flag.resize(total);
+            check(ctx, bdx_get_sv_support(ctx, sup_off.data(), sup_idx.data(), sup_flag.data(), total, &total), "bdx_get_sv_support");
+            for (size_t i = 0; i < svs.size(); ++i)
+                if (svs[i].printed) wanted.insert(wanted.end(), sup_idx.begin() + sup_off[i], sup_idx.begin() + sup_off[i + 1]);
+            std::sort(wanted.begin(), wanted.end());
+            wanted.erase(std::unique(wanted.begin(), wanted.end()), wanted.end());
+            collect_reads(cfg, opts.chr, hw ? (int)std::min(hw, 16u) : 4, wanted, sup_reads);
+        }
+        size_t sv_i = 0;
         for (auto const& s : svs) {  // BreakDancer.cpp:395-497
+            const size_t this_sv = sv_i++;
             if (!s.printed) continue;
             std::map<int, float> cn;  // key -> copy number
             for (int i = 0; i < s.cn_count; ++i) cn[ck[s.cn_begin + i]] = cv[s.cn_begin + i];
@@ -161,6 +190,17 @@ int main(int argc, char** argv) {
                 }
             }
             cout << "\n";
+            if (want_dumps) {
+                SvForDump d;
+                d.chr0 = tname(s.chr[0]); d.pos0 = s.pos[0]; d.type = opts.sv_type(s.flag); d.size = s.size; d.flag = s.flag;
+                for (uint32_t k = sup_off[this_sv]; k < sup_off[this_sv + 1]; ++k) {
+                    const size_t w = std::lower_bound(wanted.begin(), wanted.end(), sup_idx[k]) - wanted.begin();
+                    d.reads.push_back(&sup_reads[w]);
+                    d.read_flags.push_back(sup_flag[k]);
+                }
+                if (bed) bed->write(d);
+                if (fastq) fastq->write(d);
+            }
         }
         if (timing) {
             float ms[8] = {0};

@@ -50,9 +50,10 @@ struct StreamGreater {  // BamMerger::Stream::operator> (io/BamMerger.cpp:40-61)
     }
 };
 
-}  // namespace
 
-void produce(const BamConfig& cfg, const std::string& chr, int threads, ReadStream& out) {
+// opens the BAMs and runs the k-way merge, calling f(stream_index, record, bam_index, library) per merged record
+template <class F>
+void merge_streams(const BamConfig& cfg, const std::string& chr, int threads, std::vector<std::string>* targets, F&& f) {
     std::vector<std::unique_ptr<Stream>> streams;
     for (size_t b = 0; b < cfg.num_bams(); ++b) {
         std::unique_ptr<Stream> s(new Stream);
@@ -66,7 +67,7 @@ void produce(const BamConfig& cfg, const std::string& chr, int threads, ReadStre
         streams.push_back(std::move(s));
     }
     if (streams.empty()) throw std::runtime_error("BamMerger created with no input streams!");
-    out.targets = streams[0]->rd->target_names();
+    if (targets) *targets = streams[0]->rd->target_names();
 
     // read-group string -> library index (io/BamConfig.hpp:62-72), cached per distinct RG value
     std::unordered_map<std::string, uint8_t> rg_cache;
@@ -77,23 +78,49 @@ void produce(const BamConfig& cfg, const std::string& chr, int threads, ReadStre
     for (auto& s : streams)
         if (s->advance()) pq.push(s.get());
     std::string rgtmp;
+    uint64_t index = 0;
     while (!pq.empty()) {
         Stream* s = pq.top();
         pq.pop();
         const BamRecord& r = s->cur;
-        out.tid.push_back(r.tid); out.pos.push_back(r.pos); out.mtid.push_back(r.mtid); out.mpos.push_back(r.mpos);
-        out.isize.push_back(r.isize); out.flag.push_back(r.flag);
-        out.qlen.push_back((uint16_t)(r.l_qseq > 65535 ? 65535 : (r.l_qseq < 0 ? 0 : r.l_qseq)));
-        out.mapq.push_back(r.bdqual);
         uint8_t lib = fallback;
         rgtmp.assign(r.rg ? r.rg : "", r.rg ? r.l_rg : 0);
         auto it = rg_cache.find(rgtmp);
         if (it != rg_cache.end()) lib = it->second;
-        out.lib.push_back(lib);
-        out.bam.push_back((uint8_t)s->bam_index);
-        out.name_key.push_back(hash_name(r.qname, r.l_qname));
+        f(index++, r, s->bam_index, lib);
         if (s->advance()) pq.push(s);
     }
+}
+
+}  // namespace
+
+void produce(const BamConfig& cfg, const std::string& chr, int threads, ReadStream& out) {
+    merge_streams(cfg, chr, threads, &out.targets, [&](uint64_t, const BamRecord& r, int bam_index, uint8_t lib) {
+        out.tid.push_back(r.tid); out.pos.push_back(r.pos); out.mtid.push_back(r.mtid); out.mpos.push_back(r.mpos);
+        out.isize.push_back(r.isize); out.flag.push_back(r.flag);
+        out.qlen.push_back((uint16_t)(r.l_qseq > 65535 ? 65535 : (r.l_qseq < 0 ? 0 : r.l_qseq)));
+        out.mapq.push_back(r.bdqual);
+        out.lib.push_back(lib);
+        out.bam.push_back((uint8_t)bam_index);
+        out.name_key.push_back(hash_name(r.qname, r.l_qname));
+    });
+}
+
+void collect_reads(const BamConfig& cfg, const std::string& chr, int threads, const std::vector<uint64_t>& wanted,
+                   std::vector<SupportRead>& out) {
+    out.assign(wanted.size(), SupportRead());
+    size_t w = 0;
+    static const char* nt16 = "=ACMGRSVTWYHKDBN";  // bam_nt16_rev_table
+    merge_streams(cfg, chr, threads, nullptr, [&](uint64_t index, const BamRecord& r, int, uint8_t lib) {
+        if (w >= wanted.size() || wanted[w] != index) return;
+        SupportRead& sr = out[w++];
+        sr.tid = r.tid; sr.pos = r.pos; sr.l_qseq = r.l_qseq; sr.bdqual = r.bdqual; sr.lib = lib; sr.rev = (r.flag & 0x10) != 0;
+        sr.name.assign(r.qname, r.l_qname);
+        sr.bases.resize(r.l_qseq > 0 ? r.l_qseq : 0);
+        for (int i = 0; i < r.l_qseq; ++i) sr.bases[i] = nt16[(r.seq[i >> 1] >> ((~i & 1) << 2)) & 0xf];
+        sr.has_qual = r.l_qseq > 0 && r.qual[0] != 0xff;
+        if (sr.has_qual) sr.qual.assign((const char*)r.qual, r.l_qseq);
+    });
 }
 
 }  // namespace bdhost

@@ -22,6 +22,20 @@ struct ReadStream {
     bdx_batch batch() const;
 };
 
+// One supporting read kept for the -g BED / -d FASTQ dumps (what Alignment holds when seq_data is on,
+// io/Alignment.cpp:45-64)
+struct SupportRead {
+    int32_t tid = 0, pos = 0, l_qseq = 0;
+    uint8_t bdqual = 0, lib = 0;
+    bool rev = false, has_qual = false;
+    std::string name, bases, qual;  // bases already decoded to letters, qual = raw phred bytes
+};
+
+// Second decode pass for the dumps: replays the merge and keeps the records whose stream index is in `wanted`
+// (sorted, unique); out[i] corresponds to wanted[i].
+void collect_reads(const BamConfig& cfg, const std::string& chr, int threads, const std::vector<uint64_t>& wanted,
+                   std::vector<SupportRead>& out);
+
 // chr: empty = all sequences, otherwise the -o sequence name (whole sequence; "name:beg-end" is not supported)
 void produce(const BamConfig& cfg, const std::string& chr, int threads, ReadStream& out);
 

@@ -162,6 +162,15 @@ int bdx_get_svs(const bdx_ctx* ctx, bdx_sv* out, size_t cap);
 int bdx_get_sv_lists(const bdx_ctx* ctx, int32_t* lib_index, int32_t* lib_pairs, size_t lib_cap, int32_t* cn_key,
                      float* cn_value, size_t cn_cap);
 
+/* Supporting reads of every SV candidate (SvBuilder::support_reads, SvBuilder.cpp:101-118), for the -g BED and
+ * -d FASTQ dumps (BedWriter.cpp:21-56, BreakDancer.cpp:514-534).  Call bdx_set_collect_support(ctx, 1) before
+ * bdx_run; afterwards sv_offsets[i]..sv_offsets[i+1] delimit SV i's reads in read_index (index into the pushed
+ * stream) / read_flag (the read's ReadFlag after the pass-2 remaps), in the reference's order: per pair the
+ * second-observed mate, then its mate; pairs in observation order.  Single-context runs only. */
+int bdx_set_collect_support(bdx_ctx* ctx, int on);
+int bdx_get_sv_support(const bdx_ctx* ctx, uint32_t* sv_offsets, uint64_t* read_index, uint8_t* read_flag, size_t cap,
+                       size_t* n_total);
+
 /* debug / parity: per-read class byte of the last bdx_run (n_reads bytes) */
 int bdx_get_read_class(const bdx_ctx* ctx, uint8_t* out, size_t cap);
 
@@ -201,6 +210,7 @@ typedef struct bdx_region_rec {
     int32_t tid, start, end;
     uint32_t n_reads, rev_reads, nonctx_reads, normal_read_pairs;
     int32_t max_qlen;
+    uint32_t first_read;  /* context-local index of the region's first anomalous read */
 } bdx_region_rec;
 typedef struct bdx_group {  /* partial aggregate of one (region_lo, region_hi, flag, lib) connection group */
     uint64_t key;           /* region_lo << 38 | region_hi << 12 | lib << 4 | flag */

@@ -966,6 +966,21 @@ void bdo_sv_lists(void* p, int32_t* lib_counts2, int32_t* cn_keys, float* cn_val
         for (auto const& c : s.copy_number) { cn_keys[b] = c.first; cn_vals[b] = c.second; ++b; }
     }
 }
+// supporting reads per SV (SvBuilder::support_reads): offsets[n_svs+1], merged-record indices and their final flags
+int64_t bdo_sv_support(void* p, int64_t* offsets, int64_t* idx, uint8_t* flag) {
+    Oracle* h = (Oracle*)p;
+    int64_t n = 0;
+    if (offsets) offsets[0] = 0;
+    for (size_t i = 0; i < h->svs.size(); ++i) {
+        for (int m : h->svs[i].support) {
+            if (idx) idx[n] = m;
+            if (flag) flag[n] = (uint8_t)h->merged[m].flag;
+            ++n;
+        }
+        if (offsets) offsets[i + 1] = n;
+    }
+    return n;
+}
 double bdo_poisson_upper_tail(double lambda, int k) { return poisson_upper_tail(lambda, k); }
 double bdo_chisq_upper_tail(double df, double x) { return chisq_upper_tail(df, x); }
 int bdo_classify(int sam, int tid, int mtid, int pos, int mpos, int abs_isize, float upper, float lower) {

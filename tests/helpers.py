@@ -158,6 +158,8 @@ def oracle_lib():
         L.bdo_svs.argtypes = [C.c_void_p] * 3
         L.bdo_sv_lists.argtypes = [C.c_void_p] * 4
         L.bdo_translate_token.argtypes = [C.c_char_p]
+        L.bdo_sv_support.restype = C.c_int64
+        L.bdo_sv_support.argtypes = [C.c_void_p] * 4
         _oracle = L
     return _oracle
 
@@ -245,6 +247,11 @@ class OracleRun:
         self.sv_cn_key = np.zeros(nc, dtype=np.int32)
         self.sv_cn_val = np.zeros(nc, dtype=np.float32)
         self.L.bdo_sv_lists(self.h, _p(self.sv_lib), _p(self.sv_cn_key), _p(self.sv_cn_val))
+        ns = self.L.bdo_sv_support(self.h, None, None, None)
+        self.sup_off = np.zeros(self.n_svs + 1, dtype=np.int64)
+        self.sup_idx = np.zeros(ns, dtype=np.int64)
+        self.sup_flag = np.zeros(ns, dtype=np.uint8)
+        self.L.bdo_sv_support(self.h, _p(self.sup_off), _p(self.sup_idx), _p(self.sup_flag))
         return self
 
     def merged_soa(self):

@@ -26,12 +26,14 @@ def product_options(opts):
                    chr="x" if opts["chr_tid"] >= 0 else "")
 
 
-def product_from_oracle(run, device=0):
+def product_from_oracle(run, device=0, support=False):
     """Feed the product the exact merged stream the oracle consumed (the producer's job in the CLI)."""
     libs = [LibraryConfig(*[float(x) for x in run.lib_f[i]], min_mapping_quality=int(run.lib_i[i, 0]),
                           bam_file_index=int(run.lib_i[i, 1]), name=run.lib_names[i]) for i in range(run.nlibs)]
     bd = bda.BreakDancer(product_options(run.opts), libs, run.nbams, ntids=0, max_read_window_size=run.w0, device=device)
     soa = run.merged_soa()
+    if support:
+        bd.collect_support()
     if run.n_merged:
         bd.push_reads(soa)
     bd.run()
@@ -112,3 +114,11 @@ def sharded_from_oracle(run, comm=None, device=0):
     for tid, arrs in split_by_tid(run.merged_soa()).items():
         sr.add_chromosome(tid, arrs)
     return sr.run()
+
+
+def compare_support(run, bd):
+    """supporting reads of every SV: same reads, same order, same per-read flags as SvBuilder::support_reads"""
+    off, idx, flg = bd.sv_support()
+    np.testing.assert_array_equal(off.astype(np.int64), run.sup_off)
+    np.testing.assert_array_equal(idx.astype(np.int64), run.sup_idx)
+    np.testing.assert_array_equal(flg, run.sup_flag)

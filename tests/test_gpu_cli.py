@@ -41,3 +41,23 @@ def test_cli_text_equals_oracle_text_on_other_option_sets(args, kw):
     """option paths the golden files do not cover: the CLI's full stdout against the oracle's rendering"""
     run = load_chr21(make_opts(**kw)).run()
     assert filter_cmd_lines(run_cli(args)) == filter_cmd_lines(run.text)
+
+
+def test_cli_bed_dump_matches_reference(tmp_path):
+    """integration-test/breakdancer_test.py:117-131 (test_breakdancer_bed_dump)"""
+    bed = str(tmp_path / "out.bed")
+    out = run_cli(["-g", bed])
+    assert filter_cmd_lines(out) == filter_cmd_lines(open(os.path.join(CWD, "expected_output")).read())
+    assert open(bed).read() == open(os.path.join(CWD, "expected.bed")).read()
+
+
+def test_cli_fastq_dump_matches_reference(tmp_path):
+    """integration-test/breakdancer_test.py:133-146 (test_breakdancer_fastq_dump)"""
+    prefix = str(tmp_path / "actual")
+    out = run_cli(["-o", "21", "-d", prefix])
+    assert filter_cmd_lines(out) == filter_cmd_lines(open(os.path.join(CWD, "expected_output")).read())
+    for lib in ("H_IJ-NA19238-NA19238-extlibs", "H_IJ-NA19240-NA19240-extlibs"):
+        for k in ("1", "2"):
+            got = open("%s.%s.%s.fastq" % (prefix, lib, k)).read()
+            exp = open(os.path.join(CWD, "expected.%s.%s.fastq" % (lib, k))).read()
+            assert got == exp, (lib, k)
