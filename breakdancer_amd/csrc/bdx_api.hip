@@ -500,7 +500,7 @@ int do_join_local(bdx_ctx* c, uint32_t n, const Entries& en, const uint32_t* n_p
     k4 = K4Arrays{};
     if (!n) return BDX_OK;
     uint32_t nb = 1, lg = 0;
-    while (nb < (uint32_t)kMaxBuckets && (size_t)nb * 1536 < n) { nb <<= 1; ++lg; }
+    while (nb < (uint32_t)kMaxBuckets && (size_t)nb * 384 < n) { nb <<= 1; ++lg; }  // ~256-512 entries per bucket: >= 1 workgroup per CU early
     k4.nbuckets = nb; k4.log2b = lg;
     HIPCHK(c, c->b_bcnt.ensure(nb * 4)); HIPCHK(c, c->b_boff.ensure((nb + 1) * 4)); HIPCHK(c, c->b_bcur.ensure(nb * 4));
     HIPCHK(c, c->b_e_key.ensure((size_t)n * 8)); HIPCHK(c, c->b_e_idx.ensure((size_t)n * 4));
@@ -580,15 +580,15 @@ int do_walk(bdx_ctx* c, int32_t last_maxq, bool any_anomalous) {
     std::vector<double>& log_tail = c->log_tail;
     log_tail.resize(nt);
     if (nt) {
-        HIPCHK(c, c->b_lam.ensure((size_t)nt * 8)); HIPCHK(c, c->b_k.ensure((size_t)nt * 4)); HIPCHK(c, c->b_logt.ensure((size_t)nt * 8));
-        HIPCHK(c, c->h_terms.ensure((size_t)nt * 20));
+        // one pinned staging buffer [lambda f64 x nt | k i32 x nt] -> one H2D copy; results come back into a second region
+        HIPCHK(c, c->b_lam.ensure((size_t)nt * 12)); HIPCHK(c, c->b_logt.ensure((size_t)nt * 8));
+        HIPCHK(c, c->h_terms.ensure((size_t)nt * 20 + 16));
         double* hl = c->h_terms.as<double>();
-        double* ho = hl + nt;
-        int32_t* hk = (int32_t*)(ho + nt);
+        int32_t* hk = (int32_t*)(hl + nt);
+        double* ho = (double*)((char*)c->h_terms.p + (((size_t)nt * 12 + 7) & ~(size_t)7));
         for (uint32_t i = 0; i < nt; ++i) { hl[i] = c->walk.terms[i].lambda; hk[i] = c->walk.terms[i].k; }
-        HIPCHK(c, hipMemcpyAsync(c->b_lam.p, hl, (size_t)nt * 8, hipMemcpyHostToDevice, s));
-        HIPCHK(c, hipMemcpyAsync(c->b_k.p, hk, (size_t)nt * 4, hipMemcpyHostToDevice, s));
-        launch_k5(c->b_lam.as<double>(), c->b_k.as<int32_t>(), c->b_logt.as<double>(), nt, s);
+        HIPCHK(c, hipMemcpyAsync(c->b_lam.p, hl, (size_t)nt * 12, hipMemcpyHostToDevice, s));
+        launch_k5(c->b_lam.as<double>(), (const int32_t*)(c->b_lam.as<double>() + nt), c->b_logt.as<double>(), nt, s);
         HIPCHK(c, hipMemcpyAsync(ho, c->b_logt.p, (size_t)nt * 8, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         HIPCHK(c, hipGetLastError());
