@@ -470,8 +470,10 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn) {
         DevBuf* u32bufs[] = {&c->b_cand, &c->b_pre_q, &c->b_pre_rev, &c->b_pre_nonctx, &c->b_c_first, &c->b_c_maxq, &c->b_c_accept,
                              &c->b_c_n, &c->b_c_rev, &c->b_c_nonctx, &c->b_c_nnormal, &c->b_c_rid, &c->b_region_of};
         for (DevBuf* b : u32bufs) HIPCHK(c, b->ensure(cap * 4));
-        HIPCHK(c, c->b_r_rec.ensure(cap * sizeof(RegionRec)));
-        HIPCHK(c, c->b_r_pk.ensure(cap * 2 * nkeys * 4));
+        // the region table and (below) the group list are written by the kernels straight into pinned host memory:
+        // they are write-once, read-never on the device, so the PCIe writes overlap the kernels and no D2H copy is needed
+        HIPCHK(c, c->h_regs.ensure(cap * sizeof(RegionRec)));
+        HIPCHK(c, c->h_pk.ensure(cap * 2 * nkeys * 4));
         const size_t nblk = scan_grid(na) + 1;
         HIPCHK(c, c->b_ws_u4.ensure(nblk * sizeof(U4)));
         HIPCHK(c, c->b_ws_u32.ensure(nblk * 4));
@@ -482,7 +484,7 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn) {
         k3.c_maxq = c->b_c_maxq.as<int32_t>(); k3.c_accept = c->b_c_accept.as<uint32_t>(); k3.c_n = c->b_c_n.as<uint32_t>();
         k3.c_rev = c->b_c_rev.as<uint32_t>(); k3.c_nonctx = c->b_c_nonctx.as<uint32_t>();
         k3.c_nnormal = c->b_c_nnormal.as<uint32_t>(); k3.c_rid = c->b_c_rid.as<int32_t>(); k3.region_of = c->b_region_of.as<int32_t>();
-        k3.r_rec = c->b_r_rec.as<RegionRec>(); k3.r_pk = c->b_r_pk.as<uint32_t>();
+        k3.r_rec = c->h_regs.as<RegionRec>(); k3.r_pk = c->h_pk.as<uint32_t>();
         k3.ws_u4 = c->b_ws_u4.as<U4>(); k3.head_total = (U4*)c->b_totals.p; k3.ws_u32 = c->b_ws_u32.as<uint32_t>();
         k3.acc_total = (uint32_t*)((char*)c->b_totals.p + 32); k3.counts = c->b_counts.as<StageCounts>();
         K3Tail tail{has_next, next_qlen, next_nn};
@@ -507,10 +509,10 @@ int do_join_local(bdx_ctx* c, uint32_t n, const Entries& en, const uint32_t* n_p
     HIPCHK(c, c->b_partner.ensure((size_t)n * 4));
     HIPCHK(c, c->b_t_key.ensure((size_t)n * 16)); HIPCHK(c, c->b_t_idx.ensure((size_t)n * 8));
     k4.g_cap = n / 2 + 1;
-    HIPCHK(c, c->b_g_rec.ensure((size_t)k4.g_cap * sizeof(GroupRec)));
+    HIPCHK(c, c->h_groups.ensure((size_t)k4.g_cap * sizeof(GroupRec)));
     k4.bcnt = c->b_bcnt.as<uint32_t>(); k4.boff = c->b_boff.as<uint32_t>(); k4.bcur = c->b_bcur.as<uint32_t>();
     k4.e_key = c->b_e_key.as<uint64_t>(); k4.e_idx = c->b_e_idx.as<uint32_t>(); k4.partner = c->b_partner.as<int32_t>();
-    k4.t_key = c->b_t_key.as<uint64_t>(); k4.t_idx = c->b_t_idx.as<int32_t>(); k4.g_rec = c->b_g_rec.as<GroupRec>();
+    k4.t_key = c->b_t_key.as<uint64_t>(); k4.t_idx = c->b_t_idx.as<int32_t>(); k4.g_rec = c->h_groups.as<GroupRec>();
     launch_k4(k4, en, n_ptr, n, c->b_counts.as<StageCounts>(), s);
     return BDX_OK;
 }
@@ -518,7 +520,6 @@ int do_join_local(bdx_ctx* c, uint32_t n, const Entries& en, const uint32_t* n_p
 // counts + region table (+ groups) to the host
 int readback(bdx_ctx* c, bool with_groups) {
     hipStream_t s = c->stream;
-    const int nkeys = c->nkeys;
     const uint32_t na = c->p1.n_anom;
     if (!na) return BDX_OK;
     HIPCHK(c, hipMemcpyAsync(c->h_counts.p, c->b_counts.p, sizeof(StageCounts), hipMemcpyDeviceToHost, s));
@@ -526,16 +527,7 @@ int readback(bdx_ctx* c, bool with_groups) {
     HIPCHK(c, hipGetLastError());
     c->counts = *c->h_counts.as<StageCounts>();
     if (c->counts.overflow) return fail(c, BDX_EINTERNAL, "group list overflow");
-    const uint32_t nr = c->counts.n_regions, ng = with_groups ? c->counts.n_groups : 0;
-    HIPCHK(c, c->h_regs.ensure((size_t)std::max<uint32_t>(nr, 1) * sizeof(RegionRec)));
-    HIPCHK(c, c->h_pk.ensure((size_t)std::max<uint32_t>(nr, 1) * 2 * nkeys * 4));
-    HIPCHK(c, c->h_groups.ensure((size_t)std::max<uint32_t>(ng, 1) * sizeof(GroupRec)));
-    if (nr) {
-        HIPCHK(c, hipMemcpyAsync(c->h_regs.p, c->k3.r_rec, (size_t)nr * sizeof(RegionRec), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(c->h_pk.p, c->k3.r_pk, (size_t)nr * 2 * nkeys * 4, hipMemcpyDeviceToHost, s));
-    }
-    if (ng) HIPCHK(c, hipMemcpyAsync(c->h_groups.p, c->k4.g_rec, (size_t)ng * sizeof(GroupRec), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    (void)with_groups;  // regions / prefix samples / groups already sit in pinned host memory (see do_cut / do_join_local)
     return BDX_OK;
 }
 
@@ -807,7 +799,7 @@ int bdx_join_entries(bdx_ctx* c, size_t n, const uint64_t* key, const uint32_t* 
     if (n_pairs) *n_pairs = sc.n_pairs;
     const size_t ng = std::min<size_t>(cap, sc.n_groups);
     static_assert(sizeof(bdx_group) == sizeof(GroupRec), "group record layout");
-    if (out && ng) HIPCHK(c, hipMemcpy(out, c->k4.g_rec, ng * sizeof(GroupRec), hipMemcpyDeviceToHost));
+    if (out && ng) memcpy(out, c->k4.g_rec, ng * sizeof(GroupRec));
     return BDX_OK;
 }
 

@@ -84,3 +84,45 @@ def make_chromosome(length=50_000_000, coverage=30.0, seed=1, tid=0, lib=0, bam=
 
 def concat(parts):
     return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+
+
+def make_genome(lengths, coverage=30.0, seed=1, libs=((400.0, 30.0),), lib_bam=(0,), n_translocations=0, ctx_pairs=15):
+    """Multi-chromosome, multi-library synthetic input (configs[2]-[4] shapes, scaled by `lengths`).
+    Every library contributes coverage/len(libs); `lib_bam[i]` is the source file of library i.  Planted
+    translocations add clusters of `ctx_pairs` inter-chromosomal pairs (both mates carry tid != mtid, isize 0).
+    Returns the merged, (tid, pos, strand)-sorted SoA."""
+    rng = np.random.default_rng(seed)
+    parts = []
+    base = 0
+    for tid, L in enumerate(lengths):
+        for li, (mean, std) in enumerate(libs):
+            d = make_chromosome(length=L, coverage=coverage / len(libs), seed=seed * 1000 + tid * 16 + li, tid=tid, lib=li,
+                                bam=lib_bam[li], name_base=base, mean=mean, std=std)
+            base += 1 << 36
+            parts.append(d)
+    if n_translocations:
+        n = n_translocations * ctx_pairs
+        ta = rng.integers(0, len(lengths), n_translocations)
+        tb = (ta + 1 + rng.integers(0, len(lengths) - 1, n_translocations)) % len(lengths)
+        ca = np.array([rng.integers(1000, lengths[t] - 5000) for t in ta])
+        cb = np.array([rng.integers(1000, lengths[t] - 5000) for t in tb])
+        ta, tb, ca, cb = (np.repeat(x, ctx_pairs) for x in (ta, tb, ca, cb))
+        pa = ca + rng.integers(0, 200, n)
+        pb = cb + rng.integers(0, 200, n)
+        li = rng.integers(0, len(libs), n)
+        key = splitmix64(np.arange(n, dtype=np.uint64) + np.uint64(base))
+        mq = np.where(rng.random(n) < 0.03, 20, 60).astype(np.uint8)
+        bam = np.asarray(lib_bam, np.uint8)[li]
+
+        def rec(tid, pos, mtid, mpos, rev, mrev, first):
+            flag = np.full(n, 0x1, np.uint16) | np.where(rev, 0x10, 0).astype(np.uint16) | np.where(mrev, 0x20, 0).astype(np.uint16)
+            flag |= np.uint16(0x40 if first else 0x80)
+            return dict(tid=tid.astype(np.int32), pos=pos.astype(np.int32), mtid=mtid.astype(np.int32), mpos=mpos.astype(np.int32),
+                        isize=np.zeros(n, np.int32), flag=flag, qlen=np.full(n, READLEN, np.uint16), mapq=mq,
+                        lib=li.astype(np.uint8), bam=bam, name_key=key)
+        f = np.zeros(n, bool)
+        parts.append(rec(ta, pa, tb, pb, f, ~f, True))
+        parts.append(rec(tb, pb, ta, pa, ~f, f, False))
+    d = concat(parts)
+    order = np.lexsort(((d["flag"] >> 4) & 1, d["pos"], d["tid"]))
+    return {k: v[order] for k, v in d.items()}

@@ -1,0 +1,72 @@
+"""GPU parity on scaled-down shapes of BASELINE.json configs[2]-[4]: multi-chromosome / 4 libraries (configs[2]),
+planted translocations with -t (configs[3]), tumour/normal 2 BAMs with -a -h (configs[4]); single context and the
+chromosome-sharded staged path, each against ONE oracle run."""
+import numpy as np
+import pytest
+
+from helpers import OracleRun, make_opts
+from runner import compare, product_from_oracle, sharded_from_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_from_soa(d, cfg, bams, opts, targets):
+    run = OracleRun(cfg, opts)
+    run.set_targets(targets)
+    assert run.bam_names == bams
+    for b in range(len(bams)):
+        m = d["bam"] == b
+        st = {k: d[k][m] for k in ("tid", "pos", "mtid", "mpos", "isize", "flag")}
+        st["qlen"] = d["qlen"][m].astype(np.int32)
+        st["bdqual"] = d["mapq"][m]
+        st["lib"] = d["lib"][m].astype(np.int32)
+        st["name_id"] = d["name_key"][m]
+        run.set_stream(b, st)
+    return run.run()
+
+
+def cfg_line(rg, bam, lib, mean, std):
+    return "readgroup:%s\tplatform:illumina\tmap:%s\treadlen:100.00\tlib:%s\tlower:%.2f\tupper:%.2f\tmean:%.2f\tstd:%.2f\n" % (
+        rg, bam, lib, mean - 3 * std, mean + 3 * std, mean, std)
+
+
+LIBS4 = ((400.0, 30.0), (350.0, 40.0), (500.0, 50.0), (300.0, 25.0))
+
+
+def test_config2_shape_four_libraries_three_chromosomes():
+    from breakdancer_amd.synth import make_genome
+    d = make_genome([4_000_000, 3_000_000, 2_000_000], coverage=20.0, seed=3, libs=LIBS4, lib_bam=(0, 0, 0, 0))
+    cfg = "".join(cfg_line("rg%d" % i, "wgs.bam", "lib%d" % i, m, s) for i, (m, s) in enumerate(LIBS4))
+    for kw in (dict(), dict(cn_lib=1, print_af=1)):
+        run = oracle_from_soa(d, cfg, ["wgs.bam"], make_opts(**kw), ["c1", "c2", "c3"])
+        assert run.n_svs > 300
+        compare(run, product_from_oracle(run))
+        compare(run, sharded_from_oracle(run), check_cls=False)
+
+
+def test_config3_shape_translocations_with_dash_t():
+    from breakdancer_amd.synth import make_genome
+    d = make_genome([3_000_000, 2_500_000, 2_000_000, 1_500_000], coverage=15.0, seed=5, n_translocations=300)
+    cfg = cfg_line("rg0", "wgs.bam", "lib0", 400.0, 30.0)
+    for kw in (dict(transchr_rearrange=1), dict()):
+        run = oracle_from_soa(d, cfg, ["wgs.bam"], make_opts(**kw), ["c1", "c2", "c3", "c4"])
+        ctx_rows = int((run.sv_i[:, 8] == 8).sum())
+        assert ctx_rows > 250, ctx_rows
+        if kw:
+            assert run.W == 50  # -t: no insert-size flags are counted, the window drops to 50 (BreakDancerMax.cpp:114)
+        compare(run, product_from_oracle(run))
+        compare(run, sharded_from_oracle(run), check_cls=False)
+
+
+def test_config4_shape_tumour_normal_two_bams():
+    from breakdancer_amd.synth import make_genome
+    libs = ((400.0, 30.0), (420.0, 35.0), (380.0, 28.0))
+    d = make_genome([5_000_000, 3_000_000], coverage=30.0, seed=9, libs=libs, lib_bam=(0, 0, 1))
+    cfg = cfg_line("rgT1", "tumour.bam", "libT1", *libs[2]) + cfg_line("rgN1", "normal.bam", "libN1", *libs[0]) + \
+        cfg_line("rgN2", "normal.bam", "libN2", *libs[1])
+    # sorted names: libraries libN1, libN2, libT1 ; files normal.bam (0), tumour.bam (1)
+    for kw in (dict(cn_lib=1, print_af=1), dict(print_af=1)):
+        run = oracle_from_soa(d, cfg, ["normal.bam", "tumour.bam"], make_opts(**kw), ["c1", "c2"])
+        assert run.lib_names == ["libN1", "libN2", "libT1"] and run.n_svs > 300
+        compare(run, product_from_oracle(run))
+        compare(run, sharded_from_oracle(run), check_cls=False)
