@@ -79,7 +79,7 @@ struct bdx_ctx {
     DevBuf b_tid, b_pos, b_mtid, b_mpos, b_isize, b_flag, b_qlen, b_mapq, b_lib, b_bam, b_key;
 
     // stage buffers
-    DevBuf b_libs, b_cls, b_tile_tot, b_tile_pre, b_tile_mono, b_blk_cnt, b_cnt, b_p1;
+    DevBuf b_libs, b_cls, b_tile_tot, b_tile_pre, b_tile_mono, b_blk_cnt, b_cnt, b_p1, b_fold;
     DevBuf b_c_tid, b_c_pos, b_c_isize, b_c_meta, b_c_key, b_c_idx, b_c_nn, b_c_pk;
     DevBuf b_cand, b_pre_q, b_pre_rev, b_pre_nonctx, b_c_first, b_c_maxq, b_c_accept, b_c_n, b_c_rev, b_c_nonctx,
         b_c_nnormal, b_c_rid, b_region_of, b_r_rec, b_r_pk, b_ws_u4, b_ws_u32, b_totals, b_counts;
@@ -234,7 +234,7 @@ void bdx_destroy(bdx_ctx* c) {
                       &c->b_c_nnormal, &c->b_c_rid, &c->b_region_of, &c->b_r_rec, &c->b_r_pk, &c->b_ws_u4, &c->b_ws_u32, &c->b_totals,
                       &c->b_counts, &c->b_bcnt, &c->b_boff, &c->b_bcur, &c->b_e_key, &c->b_e_idx, &c->b_partner, &c->b_t_key,
                       &c->b_t_idx, &c->b_g_rec, &c->b_lam, &c->b_k, &c->b_logt, &c->b_x_key, &c->b_x_order, &c->b_x_region,
-                      &c->b_x_meta, &c->b_x_isize, &c->b_x_n};
+                      &c->b_x_meta, &c->b_x_isize, &c->b_x_n, &c->b_fold};
     for (DevBuf* b : bufs) b->release();
     PinBuf* pins[] = {&c->h_p1, &c->h_cnt, &c->h_counts, &c->h_regs, &c->h_pk, &c->h_groups, &c->h_terms};
     for (PinBuf* b : pins) b->release();
@@ -357,6 +357,9 @@ int do_pass1(bdx_ctx* c) {
     HIPCHK(c, hipEventRecord(c->ev[1], s));
     FinalizeParams fp{};
     fp.ntiles = ntiles; fp.tstride = tstride; fp.nblk = 0;
+    fp.nfold = std::max<uint32_t>(1, std::min<uint32_t>(64, (ntiles + 1023) / 1024));
+    HIPCHK(c, c->b_fold.ensure((size_t)nbams * fp.nfold * sizeof(MonoRec)));
+    fp.fold_part = c->b_fold.as<MonoRec>();
     fp.nlibs = nlibs; fp.nbams = nbams; fp.nkeys = nkeys; fp.ncols = ncols; fp.ncnt = ncnt; fp.w0 = c->w0;
     fp.tile_tot = k1.tile_tot; fp.tile_pre = c->b_tile_pre.as<uint32_t>(); fp.tile_mono = k1.tile_mono;
     fp.blk_cnt = k1.blk_cnt; fp.cnt = c->b_cnt.as<uint32_t>(); fp.p1 = c->b_p1.as<Pass1>();

@@ -62,6 +62,8 @@ struct Pass1 {
 
 struct FinalizeParams {
     uint32_t ntiles, tstride, nblk;
+    uint32_t nfold;             // workgroups folding the monoid table (first level)
+    MonoRec* fold_part;         // [nbams][nfold]
     int nlibs, nbams, nkeys, ncols, ncnt;
     int w0;
     const uint32_t* tile_tot;

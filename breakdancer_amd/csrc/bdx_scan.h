@@ -33,7 +33,7 @@ template <class T> __device__ __forceinline__ T wave_incl_scan_t(T v) {
 }
 
 constexpr int kScanBlock = 256;
-constexpr int kScanIters = 8;
+constexpr int kScanIters = 2;   // 512 elements per workgroup: ~300 workgroups at 150 k elements, enough to cover 256 CUs
 constexpr int kScanChunk = kScanBlock * kScanIters;  // elements per workgroup
 
 // block-wide inclusive scan of one element per thread; returns the inclusive value, *total = block sum

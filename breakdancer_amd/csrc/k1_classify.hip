@@ -159,6 +159,20 @@ __global__ __launch_bounds__(kBlock) void k1_classify_kernel(const K1Params p) {
                 const int k0 = __shfl(key[0], 0);
                 if (lane == kColKey0 + k0) colval = ck;
                 if (lane == 0 && c1) { atomicAdd(&s_libcnt[L0], c1); atomicAdd(&s_bamcnt[B0], c1); }
+            } else if (nlibs <= 8 && nbams <= 8) {
+                // mixed wave, few libraries / files: one ballot per (value, slot), no divergence
+                for (int v = 0; v < nlibs; ++v) {
+                    unsigned c = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) c += popc64(ballot64(p1c[r] && lib[r] == (unsigned)v));
+                    if (lane == 0 && c) atomicAdd(&s_libcnt[v], c);
+                }
+                for (int v = 0; v < nbams; ++v) {
+                    unsigned c = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) c += popc64(ballot64(p1c[r] && bam[r] == (unsigned)v));
+                    if (lane == 0 && c) atomicAdd(&s_bamcnt[v], c);
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -179,6 +193,8 @@ __global__ __launch_bounds__(kBlock) void k1_classify_kernel(const K1Params p) {
                         todo &= ~m;
                     }
                 }
+            }
+            if (!uni) {
                 for (int k = 0; k < nkeys; ++k) {  // mixed wave: one ballot per key and slot
                     unsigned ck = 0;
 #pragma unroll
@@ -287,12 +303,11 @@ __device__ __forceinline__ MonoRec mono_shfl_down(const MonoRec& a, int o) {
     return r;
 }
 
+// workgroups [0, ncols): tile scans; workgroups [ncols, ncols + nfold): ordered partial folds of the monoid table
 __global__ __launch_bounds__(kFinBlock) void finalize_kernel(const FinalizeParams p) {
     __shared__ uint32_t s_ws[kFinBlock / 64];
     __shared__ uint32_t s_carry;
     __shared__ MonoRec s_mono[kFinBlock / 64];
-    __shared__ unsigned long long s_ref[256];
-    __shared__ uint32_t s_acc[255 * 12 + 256];  // nlibs*11 + nlibs + nbams at the documented limits
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
 
     if ((int)blockIdx.x < p.ncols) {
@@ -334,21 +349,17 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(const FinalizeParam
         return;
     }
 
-    // counters: [kCntCopies][ncnt] -> [ncnt]
-    for (int i = t; i < p.ncnt; i += kFinBlock) {
-        uint32_t acc = 0;
-#pragma unroll 8
-        for (int c = 0; c < kCntCopies; ++c) acc += p.blk_cnt[(size_t)c * p.ncnt + i];
-        s_acc[i] = acc;
-        p.cnt[i] = acc;
-    }
-    // reference-length monoids, in tile order (associative, not commutative)
-    const uint32_t per = (p.ntiles + kFinBlock - 1) / kFinBlock;
+    // reference-length monoids, in tile order (associative, not commutative): this workgroup folds the tiles
+    // [fb * chunk, (fb+1) * chunk) of every source file into one partial record
+    const uint32_t fb = blockIdx.x - p.ncols;
+    const uint32_t chunk = (p.ntiles + p.nfold - 1) / p.nfold;
+    const uint32_t c0 = fb * chunk, c1 = min(c0 + chunk, p.ntiles);
+    const uint32_t per = (chunk + kFinBlock - 1) / kFinBlock;
     for (int b = 0; b < p.nbams; ++b) {
         const MonoRec* mo = p.tile_mono + (size_t)b * p.tstride;
         MonoRec acc;
         acc.ft = -1; acc.fp = 0; acc.lt = 0; acc.lp = 0; acc.sum = 0;
-        const uint32_t t0 = (uint32_t)t * per, t1 = min(t0 + per, p.ntiles);
+        const uint32_t t0 = min(c0 + (uint32_t)t * per, c1), t1 = min(t0 + per, c1);
         for (uint32_t i = t0; i < t1; i += 8) {  // batches of 8 independent loads, then the ordered fold
             MonoRec e[8];
 #pragma unroll
@@ -369,13 +380,37 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(const FinalizeParam
         if (t == 0) {
             MonoRec tot = s_mono[0];
             for (int k = 1; k < kFinBlock / 64; ++k) tot = mono_combine(tot, s_mono[k]);
-            if (b < 256) { s_ref[b] = tot.ft == -1 ? 0ull : (unsigned long long)tot.sum; p.p1->ref_len[b] = s_ref[b]; }  // size_t ref_len, wraps like the reference
+            p.fold_part[(size_t)b * p.nfold + fb] = tot;
         }
         __syncthreads();
     }
+}
+
+// one small workgroup: counters, the last level of the monoid fold, covered_ref_len (BamSummary.cpp:123-126) and the
+// final window (BreakDancerMax.cpp:109-116)
+__global__ __launch_bounds__(256) void finalize2_kernel(const FinalizeParams p) {
+    __shared__ uint32_t s_acc[255 * 12 + 256];  // nlibs*11 + nlibs + nbams at the documented limits
+    __shared__ unsigned long long s_ref[256];
+    const int t = threadIdx.x;
+    for (int i = t; i < p.ncnt; i += 256) {  // counters: [kCntCopies][ncnt] -> [ncnt]
+        uint32_t acc = 0;
+#pragma unroll 8
+        for (int c = 0; c < kCntCopies; ++c) acc += p.blk_cnt[(size_t)c * p.ncnt + i];
+        s_acc[i] = acc;
+        p.cnt[i] = acc;
+    }
+    for (int b = t; b < p.nbams; b += 256) {
+        MonoRec tot;
+        tot.ft = -1; tot.fp = 0; tot.lt = 0; tot.lp = 0; tot.sum = 0;
+        for (uint32_t f = 0; f < p.nfold; ++f) tot = mono_combine(tot, p.fold_part[(size_t)b * p.nfold + f]);
+        const unsigned long long r = tot.ft == -1 ? 0ull : (unsigned long long)tot.sum;  // size_t ref_len, wraps like the reference
+        s_ref[b] = r;
+        p.p1->ref_len[b] = r;
+    }
+    __syncthreads();
     if (t == 0) {
         uint32_t covered = 0;
-        for (int b = 0; b < p.nbams && b < 256; ++b)
+        for (int b = 0; b < p.nbams; ++b)
             if ((unsigned long long)covered < s_ref[b]) covered = (uint32_t)s_ref[b];
         p.p1->covered_ref_len = covered;
         int W = p.w0;
@@ -389,7 +424,8 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(const FinalizeParam
 }
 
 void launch_finalize(const FinalizeParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(finalize_kernel, dim3(p.ncols + 1), dim3(kFinBlock), 0, s, p);
+    hipLaunchKernelGGL(finalize_kernel, dim3(p.ncols + p.nfold), dim3(kFinBlock), 0, s, p);
+    hipLaunchKernelGGL(finalize2_kernel, dim3(1), dim3(256), 0, s, p);
 }
 
 }  // namespace bdx

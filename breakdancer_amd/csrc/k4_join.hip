@@ -25,7 +25,7 @@ __device__ __forceinline__ uint64_t mix64(uint64_t h) {
 }
 __device__ __forceinline__ uint32_t bucket_of(uint64_t h, uint32_t log2b) { return log2b ? (uint32_t)(h >> (64 - log2b)) : 0u; }
 
-constexpr int kPartChunk = 2048;  // compact reads per workgroup in the partition kernels
+constexpr int kPartChunk = 512;   // compact reads per workgroup in the partition kernels (>= 1 workgroup per CU at 150 k reads)
 
 __global__ __launch_bounds__(256) void k4_count_kernel(K4Arrays k4, Entries en, const uint32_t* n_ptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

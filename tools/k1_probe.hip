@@ -80,6 +80,30 @@ int main(int argc, char** argv) {
                    bytes_algo / best / 1e6, bytes_real / best / 1e6);
         }
     }
+    // finalize kernel: whole, without the monoid fold (nbams = 0), scan workgroups only (ncols blocks, via grid trick)
+    {
+        FinalizeParams fp{};
+        fp.ntiles = ntiles; fp.tstride = tstride; fp.nblk = 0; fp.nlibs = nlibs; fp.nbams = nbams; fp.nkeys = nkeys; fp.ncols = ncols;
+        fp.ncnt = ncnt; fp.w0 = 200; fp.tile_tot = k.tile_tot; fp.tile_mono = k.tile_mono; fp.blk_cnt = k.blk_cnt;
+        CK(hipMalloc(&p, (size_t)ncols * tstride * 4)); fp.tile_pre = (uint32_t*)p;
+        CK(hipMalloc(&p, 4096)); fp.cnt = (uint32_t*)p;
+        CK(hipMalloc(&p, sizeof(Pass1))); fp.p1 = (Pass1*)p;
+        fp.nfold = 58; CK(hipMalloc(&p, 64 * sizeof(MonoRec))); fp.fold_part = (MonoRec*)p;
+        launch_k1(k, 8192, lds, 0);
+        for (int variant = 0; variant < 2; ++variant) {
+            FinalizeParams q = fp;
+            if (variant == 1) q.nbams = 0;
+            float best = 1e9;
+            for (int rep = 0; rep < 10; ++rep) {
+                CK(hipEventRecord(e0));
+                launch_finalize(q, 0);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep >= 2 && ms < best) best = ms;
+            }
+            printf("finalize %-22s %8.1f us (ntiles %u)\n", variant ? "without monoid fold" : "full", best * 1e3, ntiles);
+        }
+    }
     CK(hipGetLastError());
     return 0;
 }
