@@ -78,3 +78,38 @@ def write_bam(path, soa, targets, rg="rg1", readlen=None, level=1, seed=0, names
             f.write(_bgzf_block(raw[i:i + 65280], level))
         f.write(_EOF)
     return path
+
+
+def write_bam_records(path, recs, targets, rgs=(), level=1, seed=0):
+    """Generic (slow, per-record) writer for small test inputs.  recs: list of dicts with tid,pos,mtid,mpos,isize,flag,
+    qlen,mapq,name and optional rg (str or ''), am (int or None); random bases/qualities of length qlen."""
+    rng = np.random.default_rng(seed)
+    text = "@HD\tVN:1.0\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (t, 300000000) for t in targets) + \
+           "".join("@RG\tID:%s\tLB:x\tSM:s\n" % r for r in rgs)
+    out = bytearray(b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(targets)))
+    for t in targets:
+        out += struct.pack("<i", len(t) + 1) + t.encode() + b"\0" + struct.pack("<i", 300000000)
+    codes = np.array([1, 2, 4, 8], np.uint8)
+    for r in recs:
+        L = int(r["qlen"])
+        name = r["name"].encode() + b"\0"
+        nb = (L + 1) // 2
+        seq = ((codes[rng.integers(0, 4, nb)] << 4) | codes[rng.integers(0, 4, nb)]).astype(np.uint8).tobytes()
+        qual = rng.integers(2, 41, L, dtype=np.uint8).tobytes()
+        aux = b""
+        if r.get("am") is not None:
+            aux += b"AMC" + struct.pack("<B", int(r["am"]) & 0xFF)
+        if r.get("rg"):
+            aux += b"RGZ" + r["rg"].encode() + b"\0"
+        aux += b"NMi" + struct.pack("<i", 1)
+        ncig = 1 if L else 0
+        body = struct.pack("<iiBBHHHiiii", int(r["tid"]), int(r["pos"]), len(name), int(r["mapq"]), 0, ncig, int(r["flag"]), L,
+                           int(r["mtid"]), int(r["mpos"]), int(r["isize"])) + name + (struct.pack("<I", (L << 4) | 0) if ncig else b"") + \
+            seq + qual + aux
+        out += struct.pack("<i", len(body)) + body
+    raw = bytes(out)
+    with open(path, "wb") as f:
+        for i in range(0, len(raw), 65280):
+            f.write(_bgzf_block(raw[i:i + 65280], level))
+        f.write(_EOF)
+    return path

@@ -1,0 +1,51 @@
+"""GPU tests: multi-BAM fuzz inputs written as real BAM files, run through bin/breakdancer-max (BGZF decode, aux tags,
+reader filter, RG->library fallback, k-way merge tie order, GPU path, formatter) and compared with the oracle's rendering
+of the same records."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from fuzzgen import make_case
+from helpers import ROOT, filter_cmd_lines, make_opts
+from runner import oracle_case
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(ROOT, "bin", "breakdancer-max")
+
+FLAGSETS = [([], dict()), (["-a", "-h"], dict(cn_lib=1, print_af=1)), (["-t"], dict(transchr_rearrange=1)),
+            (["-o", "c2"], dict(chr_tid=1)), (["-b", "2", "-r", "1"], dict(buffer_size=2, min_read_pair=1)),
+            (["-q", "36", "-s", "0"], dict(min_map_qual=36, min_len=0)), (["-l"], dict(illumina_long_insert=1)),
+            (["-m", "900", "-x", "3", "-c", "2", "-f"], dict(max_sd=900, seq_coverage_lim=3, cut_sd=2, fisher=1))]
+
+
+def write_case(tmp, streams, targets, rng):
+    from breakdancer_amd.bamwrite import write_bam_records
+    for b, (fn, st) in enumerate(zip(("a.bam", "b.bam"), streams)):
+        recs = []
+        for i in range(len(st["tid"])):
+            bq, q = int(st["bdqual"][i]), int(st["bdqual"][i])
+            am = None
+            if rng.random() < 0.5:   # bdqual through the AM tag, MAPQ something else
+                am, q = bq, int(rng.integers(0, 61))
+            recs.append(dict(tid=st["tid"][i], pos=st["pos"][i], mtid=st["mtid"][i], mpos=st["mpos"][i], isize=st["isize"][i],
+                             flag=st["flag"][i], qlen=st["qlen"][i], mapq=q, am=am, rg=st["rg"][i], name="read%d" % int(st["name_id"][i])))
+            if rng.random() < 0.02:  # a secondary and a supplementary copy: dropped by the reader filter
+                extra = dict(recs[-1])
+                extra["flag"] = int(extra["flag"]) | (0x100 if rng.random() < 0.5 else 0x800)
+                recs.append(extra)
+        write_bam_records(os.path.join(tmp, fn), recs, targets, rgs=("rg1", "rg2", "rg3"), seed=b)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_cli_on_fuzz_bams_equals_oracle(seed, tmp_path):
+    rng = np.random.default_rng(seed)
+    cfg, streams, targets = make_case(500 + seed)
+    write_case(str(tmp_path), streams, targets, rng)
+    (tmp_path / "cfg").write_text(cfg)
+    for args, kw in (FLAGSETS[seed % len(FLAGSETS)], FLAGSETS[(3 * seed + 1) % len(FLAGSETS)]):
+        run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1, **kw))
+        p = subprocess.run([EXE, "-y", "-1"] + args + ["cfg"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()
+        assert filter_cmd_lines(p.stdout.decode()) == filter_cmd_lines(run.text), (args, p.stderr.decode())
