@@ -18,6 +18,14 @@
 
 namespace bdx {
 
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef unsigned short v4us __attribute__((ext_vector_type(4)));
+typedef unsigned char v4uc __attribute__((ext_vector_type(4)));
+// streaming (non-temporal) loads: every input byte is used exactly once
+__device__ __forceinline__ int4 ldnt(const int32_t* p) { const v4i v = __builtin_nontemporal_load((const v4i*)p); return make_int4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ ushort4 ldnt(const uint16_t* p) { const v4us v = __builtin_nontemporal_load((const v4us*)p); return make_ushort4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uchar4 ldnt(const uint8_t* p) { const v4uc v = __builtin_nontemporal_load((const v4uc*)p); return make_uchar4(v.x, v.y, v.z, v.w); }
+
 __device__ __forceinline__ int classify_read(unsigned sam, int tid, int mtid, int pos, int mpos, int ai, float upper,
                                              float lower) {
     if ((sam & 0x400u) || !(sam & 0x1u)) return F_NA;
@@ -77,15 +85,15 @@ __global__ __launch_bounds__(kBlock) void k1_classify_kernel(const K1Params p) {
         unsigned sam[4], mq[4], lib[4], bam[4];
         if (base + 4 <= p.n) {
             nvalid = 4;
-            const int4 a = *(const int4*)(p.r.tid + base);
-            const int4 b = *(const int4*)(p.r.pos + base);
-            const int4 c = *(const int4*)(p.r.mtid + base);
-            const int4 d = *(const int4*)(p.r.mpos + base);
-            const int4 e = *(const int4*)(p.r.isize + base);
-            const ushort4 f = *(const ushort4*)(p.r.flag + base);
-            const uchar4 q = *(const uchar4*)(p.r.mapq + base);
-            const uchar4 l = *(const uchar4*)(p.r.lib + base);
-            const uchar4 m = *(const uchar4*)(p.r.bam + base);
+            const int4 a = ldnt(p.r.tid + base);
+            const int4 b = ldnt(p.r.pos + base);
+            const int4 c = ldnt(p.r.mtid + base);
+            const int4 d = ldnt(p.r.mpos + base);
+            const int4 e = ldnt(p.r.isize + base);
+            const ushort4 f = ldnt(p.r.flag + base);
+            const uchar4 q = ldnt(p.r.mapq + base);
+            const uchar4 l = ldnt(p.r.lib + base);
+            const uchar4 m = ldnt(p.r.bam + base);
             tid[0] = a.x; tid[1] = a.y; tid[2] = a.z; tid[3] = a.w;
             pos[0] = b.x; pos[1] = b.y; pos[2] = b.z; pos[3] = b.w;
             mtid[0] = c.x; mtid[1] = c.y; mtid[2] = c.z; mtid[3] = c.w;
