@@ -78,6 +78,10 @@ struct Walker {
           win_head(s.win_head), win_tail(s.win_tail), win_visited(s.win_visited), olds(s.olds), tails(s.tails), newtails(s.newtails) {}
 
     void build_groups() {
+        const bool prof = getenv("BDX_WALK_PROFILE") != nullptr;
+        auto tnow = [] { return std::chrono::steady_clock::now(); };
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        const auto b0 = tnow();
         const std::vector<GroupPart>& src = *in.parts;
         const uint32_t NR = (uint32_t)in.regions->size();
         // counting sort by hi, then tiny insertion sorts inside each hi bucket
@@ -91,6 +95,7 @@ struct Walker {
             cur.assign(cnt.begin(), cnt.end() - 1);
             for (const GroupPart& p : src) parts[cur[p.hi]++] = p;
         }
+        const auto b1 = tnow();
         auto less = [](const GroupPart& a, const GroupPart& b) {
             if (a.lo != b.lo) return a.lo < b.lo;
             if (a.flag != b.flag) return a.flag < b.flag;
@@ -105,8 +110,10 @@ struct Walker {
                 parts[j] = x;
             }
         }
+        const auto b2 = tnow();
         // merge duplicates (a group can straddle two K4 workgroups) and cut into groups
-        ghi.assign(NR + 1, 0);
+        ghi.resize(NR + 1);
+        uint32_t next_hi = 0;  // ghi[0..next_hi) already filled
         size_t w = 0;
         groups.clear();
         groups.reserve(parts.size());
@@ -119,6 +126,7 @@ struct Walker {
                 continue;
             }
             if (groups.empty() || groups.back().hi != p.hi || groups.back().lo != p.lo) {
+                while (next_hi <= p.hi) ghi[next_hi++] = (uint32_t)groups.size();
                 Group g;
                 g.lo = p.lo; g.hi = p.hi; g.weight = 0; g.pbeg = (uint32_t)w; g.pcnt = 0; g.next_fwd = -1;
                 g.alive = true; g.edge_done = false;
@@ -129,28 +137,24 @@ struct Walker {
             groups.back().pcnt++;
         }
         parts.resize(w);
-        {
-            uint32_t gi = 0;
-            for (uint32_t r = 0; r < NR; ++r) {
-                ghi[r] = gi;
-                while (gi < groups.size() && groups[gi].hi == r) ++gi;
-            }
-            ghi[NR] = gi;
-        }
+        const auto b3 = tnow();
+        while (next_hi <= NR) ghi[next_hi++] = (uint32_t)groups.size();
         out.n_groups = (uint32_t)groups.size();
-        stored_.resize(NR);
-        for (uint32_t r = 0; r < NR; ++r) {  // ReadRegionData.cpp:118-121
-            const HostRegion& R = (*in.regions)[r];
-            const int valid = in.opts.chr_restricted ? (int)R.nonctx : (int)R.n;
-            stored_[r] = valid >= in.opts.min_read_pair;
-        }
+        if (prof) fprintf(stderr, "[walk] build: count+scatter %.1f, insertion %.1f, merge %.1f, index+stored %.1f us\n", us(b0, b1), us(b1, b2),
+                          us(b2, b3), us(b3, tnow()));
+    }
+
+    bool stored(uint32_t r) const {  // ReadRegionData.cpp:118-121
+        const HostRegion& R = (*in.regions)[r];
+        const int valid = in.opts.chr_restricted ? (int)R.nonctx : (int)R.n;
+        return valid >= in.opts.min_read_pair;
     }
 
     Group* alive_group(uint32_t lo, uint32_t hi) {
         for (uint32_t g = ghi[hi]; g < ghi[hi + 1]; ++g) {
             if (groups[g].lo != lo) continue;
             if (!groups[g].alive) return nullptr;
-            if (!stored_[lo] || !stored_[hi]) return nullptr;  // mates of an unstored region never complete a pair
+            if (!stored(lo) || !stored(hi)) return nullptr;  // mates of an unstored region never complete a pair
             return &groups[g];
         }
         return nullptr;
