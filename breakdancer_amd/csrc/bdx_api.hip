@@ -575,16 +575,14 @@ int do_walk(bdx_ctx* c, int32_t last_maxq, bool any_anomalous) {
     std::vector<double>& log_tail = c->log_tail;
     log_tail.resize(nt);
     if (nt) {
-        // one pinned staging buffer [lambda f64 x nt | k i32 x nt] -> one H2D copy; results come back into a second region
-        HIPCHK(c, c->b_lam.ensure((size_t)nt * 12)); HIPCHK(c, c->b_logt.ensure((size_t)nt * 8));
+        // zero-copy: the kernel reads lambda / k from pinned host memory and writes the log tails back into it (a few
+        // tens of KB; the PCIe traffic overlaps the kernel and no copy engine round trips are paid)
         HIPCHK(c, c->h_terms.ensure((size_t)nt * 20 + 16));
         double* hl = c->h_terms.as<double>();
         int32_t* hk = (int32_t*)(hl + nt);
         double* ho = (double*)((char*)c->h_terms.p + (((size_t)nt * 12 + 7) & ~(size_t)7));
         for (uint32_t i = 0; i < nt; ++i) { hl[i] = c->walk.terms[i].lambda; hk[i] = c->walk.terms[i].k; }
-        HIPCHK(c, hipMemcpyAsync(c->b_lam.p, hl, (size_t)nt * 12, hipMemcpyHostToDevice, s));
-        launch_k5(c->b_lam.as<double>(), (const int32_t*)(c->b_lam.as<double>() + nt), c->b_logt.as<double>(), nt, s);
-        HIPCHK(c, hipMemcpyAsync(ho, c->b_logt.p, (size_t)nt * 8, hipMemcpyDeviceToHost, s));
+        launch_k5(hl, hk, ho, nt, s);
         HIPCHK(c, hipStreamSynchronize(s));
         HIPCHK(c, hipGetLastError());
         for (uint32_t i = 0; i < nt; ++i) log_tail[i] = ho[i];
