@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <fstream>
+#include <future>
 #include <iomanip>
 #include <iostream>
 #include <algorithm>
@@ -58,13 +59,21 @@ int main(int argc, char** argv) {
             return std::chrono::duration<double>(b - a).count();
         };
         const auto t_start = now();
-        produce(cfg, opts.chr, hw ? (int)std::min(hw, 16u) : 4, reads);
-        const auto t_decoded = now();
-
+        // the GPU context (HIP runtime start-up, ~0.1 s) comes up on a helper thread while the BAMs are decoded
         const std::vector<bdx_lib> libs = cfg.abi_libs();
         const int nlibs = (int)libs.size(), nbams = (int)cfg.num_bams();
-        check(nullptr, bdx_create(&ctx, &opts.o, libs.data(), nlibs, nbams, (int)reads.targets.size(), cfg.max_read_window_size(),
-                                  opts.device), "bdx_create");
+        std::future<int> ctx_ready = std::async(std::launch::async, [&] {
+            return bdx_create(&ctx, &opts.o, libs.data(), nlibs, nbams, 0, cfg.max_read_window_size(), opts.device);
+        });
+        try {
+            produce(cfg, opts.chr, hw ? (int)std::min(hw, 16u) : 4, reads);
+        } catch (...) {
+            ctx_ready.wait();
+            throw;
+        }
+        const auto t_decoded = now();
+
+        check(nullptr, ctx_ready.get(), "bdx_create");
         const bdx_batch batch = reads.batch();
         check(ctx, bdx_reserve(ctx, batch.n), "bdx_reserve");
         const auto t_created = now();

@@ -1,5 +1,7 @@
 #include "producer.h"
 
+#include <cstring>
+#include <sys/stat.h>
 #include <memory>
 #include <queue>
 #include <stdexcept>
@@ -77,17 +79,32 @@ void merge_streams(const BamConfig& cfg, const std::string& chr, int threads, st
     std::priority_queue<Stream*, std::vector<Stream*>, StreamGreater> pq;
     for (auto& s : streams)
         if (s->advance()) pq.push(s.get());
-    std::string rgtmp;
+    std::string rgtmp, last_rg;
+    uint8_t last_lib = fallback;
+    bool have_last = false;
     uint64_t index = 0;
+    auto lib_of = [&](const BamRecord& r) {
+        const size_t n = r.rg ? r.l_rg : 0;
+        if (have_last && last_rg.size() == n && (n == 0 || memcmp(last_rg.data(), r.rg, n) == 0)) return last_lib;  // runs of one RG
+        rgtmp.assign(r.rg ? r.rg : "", n);
+        auto it = rg_cache.find(rgtmp);
+        last_lib = it != rg_cache.end() ? it->second : fallback;
+        last_rg = rgtmp;
+        have_last = true;
+        return last_lib;
+    };
+    if (pq.size() == 1) {  // one BAM: nothing to merge
+        Stream* s = pq.top();
+        do {
+            f(index++, s->cur, s->bam_index, lib_of(s->cur));
+        } while (s->advance());
+        return;
+    }
     while (!pq.empty()) {
         Stream* s = pq.top();
         pq.pop();
         const BamRecord& r = s->cur;
-        uint8_t lib = fallback;
-        rgtmp.assign(r.rg ? r.rg : "", r.rg ? r.l_rg : 0);
-        auto it = rg_cache.find(rgtmp);
-        if (it != rg_cache.end()) lib = it->second;
-        f(index++, r, s->bam_index, lib);
+        f(index++, r, s->bam_index, lib_of(r));
         if (s->advance()) pq.push(s);
     }
 }
@@ -95,6 +112,17 @@ void merge_streams(const BamConfig& cfg, const std::string& chr, int threads, st
 }  // namespace
 
 void produce(const BamConfig& cfg, const std::string& chr, int threads, ReadStream& out) {
+    {   // reserve from the compressed sizes (~60-100 B per record) so that the column vectors do not regrow all the way
+        size_t bytes = 0;
+        for (auto const& f : cfg.bam_files()) {
+            struct stat st;
+            if (stat(f.c_str(), &st) == 0) bytes += (size_t)st.st_size;
+        }
+        const size_t guess = bytes / 100 + 1024;
+        out.tid.reserve(guess); out.pos.reserve(guess); out.mtid.reserve(guess); out.mpos.reserve(guess); out.isize.reserve(guess);
+        out.flag.reserve(guess); out.qlen.reserve(guess); out.mapq.reserve(guess); out.lib.reserve(guess); out.bam.reserve(guess);
+        out.name_key.reserve(guess);
+    }
     merge_streams(cfg, chr, threads, &out.targets, [&](uint64_t, const BamRecord& r, int bam_index, uint8_t lib) {
         out.tid.push_back(r.tid); out.pos.push_back(r.pos); out.mtid.push_back(r.mtid); out.mpos.push_back(r.mpos);
         out.isize.push_back(r.isize); out.flag.push_back(r.flag);
