@@ -70,3 +70,25 @@ def test_config4_shape_tumour_normal_two_bams():
         assert run.lib_names == ["libN1", "libN2", "libT1"] and run.n_svs > 300
         compare(run, product_from_oracle(run))
         compare(run, sharded_from_oracle(run), check_cls=False)
+
+
+def test_many_files_and_libraries_take_the_general_paths():
+    """70 source files / 70 libraries: beyond the 64-lane monoid fast path and the small-count ballot paths of K1,
+    and 70 counter keys without -a; interleaved at random so that every wave mixes files and libraries"""
+    rng = np.random.default_rng(17)
+    nb = 60
+    from breakdancer_amd.synth import make_chromosome, concat
+    parts, cfg = [], ""
+    for i in range(nb):
+        mean, std = 300.0 + 5 * i, 25.0
+        parts.append(make_chromosome(length=600_000, coverage=1.2, seed=100 + i, lib=i, bam=i, name_base=i << 36, mean=mean, std=std,
+                                     discordant=0.05))
+        cfg += cfg_line("rg%02d" % i, "f%02d.bam" % i, "lib%02d" % i, mean, std)
+    d = concat(parts)
+    order = np.lexsort(((d["flag"] >> 4) & 1, d["pos"], d["tid"]))
+    d = {k: v[order] for k, v in d.items()}
+    bams = ["f%02d.bam" % i for i in range(nb)]
+    for kw in (dict(min_read_pair=1), dict(cn_lib=1, print_af=1)):
+        run = oracle_from_soa(d, cfg, bams, make_opts(**kw), ["c1"])
+        assert run.nlibs == nb and run.nbams == nb and run.n_svs > 50
+        compare(run, product_from_oracle(run))
