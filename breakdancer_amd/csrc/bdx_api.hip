@@ -82,9 +82,8 @@ struct bdx_ctx {
     DevBuf b_libs, b_cls, b_tile_tot, b_tile_pre, b_tile_mono, b_blk_cnt, b_cnt, b_p1, b_fold;
     DevBuf b_c_tid, b_c_pos, b_c_isize, b_c_meta, b_c_key, b_c_idx, b_c_nn, b_c_pk;
     DevBuf b_cand, b_pre_q, b_pre_rev, b_pre_nonctx, b_c_first, b_c_maxq, b_c_accept, b_c_n, b_c_rev, b_c_nonctx,
-        b_c_nnormal, b_c_rid, b_region_of, b_r_rec, b_r_pk, b_ws_u4, b_ws_u32, b_totals, b_counts;
-    DevBuf b_bcnt, b_boff, b_bcur, b_e_key, b_e_idx, b_partner, b_t_key, b_t_idx, b_g_rec;
-    DevBuf b_lam, b_k, b_logt;
+        b_c_nnormal, b_c_rid, b_region_of, b_ws_u4, b_ws_u32, b_totals, b_counts;
+    DevBuf b_bcnt, b_boff, b_bcur, b_e_key, b_e_idx, b_partner, b_t_key, b_t_idx;
     DevBuf b_x_key, b_x_order, b_x_region, b_x_meta, b_x_isize, b_x_n;
     PinBuf h_p1, h_cnt, h_counts, h_regs, h_pk, h_groups, h_terms;
 
@@ -231,9 +230,9 @@ void bdx_destroy(bdx_ctx* c) {
                       &c->b_blk_cnt, &c->b_cnt, &c->b_p1, &c->b_c_tid, &c->b_c_pos, &c->b_c_isize,
                       &c->b_c_meta, &c->b_c_key, &c->b_c_idx, &c->b_c_nn, &c->b_c_pk, &c->b_cand, &c->b_pre_q, &c->b_pre_rev,
                       &c->b_pre_nonctx, &c->b_c_first, &c->b_c_maxq, &c->b_c_accept, &c->b_c_n, &c->b_c_rev, &c->b_c_nonctx,
-                      &c->b_c_nnormal, &c->b_c_rid, &c->b_region_of, &c->b_r_rec, &c->b_r_pk, &c->b_ws_u4, &c->b_ws_u32, &c->b_totals,
+                      &c->b_c_nnormal, &c->b_c_rid, &c->b_region_of, &c->b_ws_u4, &c->b_ws_u32, &c->b_totals,
                       &c->b_counts, &c->b_bcnt, &c->b_boff, &c->b_bcur, &c->b_e_key, &c->b_e_idx, &c->b_partner, &c->b_t_key,
-                      &c->b_t_idx, &c->b_g_rec, &c->b_lam, &c->b_k, &c->b_logt, &c->b_x_key, &c->b_x_order, &c->b_x_region,
+                      &c->b_t_idx, &c->b_x_key, &c->b_x_order, &c->b_x_region,
                       &c->b_x_meta, &c->b_x_isize, &c->b_x_n, &c->b_fold};
     for (DevBuf* b : bufs) b->release();
     PinBuf* pins[] = {&c->h_p1, &c->h_cnt, &c->h_counts, &c->h_regs, &c->h_pk, &c->h_groups, &c->h_terms};

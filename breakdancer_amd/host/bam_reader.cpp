@@ -180,6 +180,15 @@ bool BamReader::next(BamRecord& r) {
     r.qname = (const char*)p + 32;
     r.l_qname = l_read_name ? l_read_name - 1 : 0;
     const uint8_t* q = p + 32 + l_read_name + 4 * (size_t)n_cigar;
+    {   // samtools bam_calend (bam.c:17-45) for the region overlap test; the rarely used 'B' operator is ignored
+        const uint8_t* cg = p + 32 + l_read_name;
+        int32_t endp = r.pos;
+        for (uint32_t k = 0; k < n_cigar; ++k) {
+            const uint32_t c = le32(cg + 4 * k), op = c & 15, len = c >> 4;
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) endp += (int32_t)len;  // M D N = X consume the reference
+        }
+        r.end_pos = n_cigar ? endp : r.pos + 1;
+    }
     r.seq = q;
     q += ((size_t)r.l_qseq + 1) / 2;
     r.qual = q;

@@ -20,6 +20,7 @@ struct BamRecord {
     uint32_t l_rg;
     const uint8_t* seq;     // 4-bit packed bases, (l_qseq+1)/2 bytes
     const uint8_t* qual;    // l_qseq bytes
+    int32_t end_pos;        // bam_calend: pos + reference bases consumed by the CIGAR (pos + 1 without a CIGAR)
 };
 
 class BamReader {

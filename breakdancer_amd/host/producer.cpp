@@ -1,5 +1,7 @@
 #include "producer.h"
 
+#include <cctype>
+#include <cstdlib>
 #include <cstring>
 #include <sys/stat.h>
 #include <memory>
@@ -22,10 +24,54 @@ bdx_batch ReadStream::batch() const {
 
 namespace {
 
+// samtools region strings as the reference accepts them for -o (bam_aux.c:107-160 bam_parse_region): "name",
+// "name:beg" or "name:beg-end" (1-based, commas allowed); a name that itself contains ':' is tried as a whole
+bool parse_region(const BamReader& rd, const std::string& str, int& tid, int& beg, int& end) {
+    std::string s;
+    for (char c : str)
+        if (!isspace((unsigned char)c)) s += c;
+    size_t l = s.size(), name_end = l;
+    const size_t colon = s.rfind(':');
+    if (colon != std::string::npos) name_end = colon;
+    tid = -1;
+    if (name_end < l) {
+        int n_hyphen = 0;
+        size_t i = name_end + 1;
+        for (; i < l; ++i) {
+            if (s[i] == '-') ++n_hyphen;
+            else if (!isdigit((unsigned char)s[i]) && s[i] != ',') break;
+        }
+        if (i < l || n_hyphen > 1) name_end = l;
+        tid = rd.tid_of(s.substr(0, name_end));
+        if (tid < 0) {
+            tid = rd.tid_of(str);
+            if (tid < 0) return false;
+            name_end = l;
+        }
+    } else {
+        tid = rd.tid_of(str);
+        if (tid < 0) return false;
+    }
+    if (name_end < l) {
+        std::string t;
+        for (size_t i = name_end + 1; i < l; ++i)
+            if (s[i] != ',') t += s[i];
+        beg = atoi(t.c_str());
+        const size_t h = t.find('-');
+        end = h != std::string::npos ? atoi(t.c_str() + h + 1) : 1 << 29;
+        if (beg > 0) --beg;
+    } else {
+        beg = 0;
+        end = 1 << 29;
+    }
+    return beg <= end;
+}
+
 struct Stream {
     std::unique_ptr<BamReader> rd;
     int bam_index = 0;
     int only_tid = -1;
+    int beg = 0, end = 1 << 29;
     BamRecord cur{};
     bool valid = false;
     // reader filter of the reference: primary (not secondary / supplementary) and tid >= 0
@@ -34,7 +80,8 @@ struct Stream {
         while (rd->next(cur)) {
             if (cur.flag & (0x100 | 0x800)) continue;
             if (cur.tid < 0) continue;
-            if (only_tid >= 0 && cur.tid != only_tid) continue;
+            // bam_iter_read keeps the records of the region that overlap it (bam_index.c:571-576 is_overlap)
+            if (only_tid >= 0 && (cur.tid != only_tid || !((uint32_t)cur.end_pos > (uint32_t)beg && (uint32_t)cur.pos < (uint32_t)end))) continue;
             return valid = true;
         }
         return valid = false;
@@ -61,11 +108,8 @@ void merge_streams(const BamConfig& cfg, const std::string& chr, int threads, st
         std::unique_ptr<Stream> s(new Stream);
         s->rd.reset(new BamReader(cfg.bam_files()[b], threads));
         s->bam_index = (int)b;
-        if (!chr.empty()) {
-            s->only_tid = s->rd->tid_of(chr);
-            if (s->only_tid < 0)
-                throw std::runtime_error("Failed to parse bam region '" + chr + "' in file " + cfg.bam_files()[b] + ". ");
-        }
+        if (!chr.empty() && !parse_region(*s->rd, chr, s->only_tid, s->beg, s->end))
+            throw std::runtime_error("Failed to parse bam region '" + chr + "' in file " + cfg.bam_files()[b] + ". ");
         streams.push_back(std::move(s));
     }
     if (streams.empty()) throw std::runtime_error("BamMerger created with no input streams!");

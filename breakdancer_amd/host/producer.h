@@ -36,7 +36,7 @@ struct SupportRead {
 void collect_reads(const BamConfig& cfg, const std::string& chr, int threads, const std::vector<uint64_t>& wanted,
                    std::vector<SupportRead>& out);
 
-// chr: empty = all sequences, otherwise the -o sequence name (whole sequence; "name:beg-end" is not supported)
+// chr: empty = all sequences, otherwise the -o region in samtools syntax ("name", "name:beg" or "name:beg-end")
 void produce(const BamConfig& cfg, const std::string& chr, int threads, ReadStream& out);
 
 }  // namespace bdhost

@@ -81,7 +81,7 @@ def read_bam(path):
         o += 4
         targets.append(d[o:o + l - 1].decode())
         o += l + 4
-    cols = {k: [] for k in ("tid", "pos", "mtid", "mpos", "isize", "flag", "qlen", "mapq", "bdqual")}
+    cols = {k: [] for k in ("tid", "pos", "mtid", "mpos", "isize", "flag", "qlen", "mapq", "bdqual", "rend")}
     names, rgs, seqs, quals = [], [], [], []
     while o < len(d):
         bs, = struct.unpack_from("<i", d, o)
@@ -89,6 +89,13 @@ def read_bam(path):
         tid, pos, l_rn, mapq, _bin, n_cig, flag, l_seq, mtid, mpos, isize = struct.unpack_from("<iiBBHHHiiii", d, o)
         p = o + 32
         name = d[p:p + l_rn - 1].decode()
+        rend = pos
+        for k in range(n_cig):
+            cg, = struct.unpack_from("<I", d, p + l_rn + 4 * k)
+            if (cg & 15) in (0, 2, 3, 7, 8):  # M D N = X consume the reference (samtools bam_calend)
+                rend += cg >> 4
+        if n_cig == 0:
+            rend = pos + 1
         p += l_rn + 4 * n_cig
         seq = d[p:p + (l_seq + 1) // 2]
         p += (l_seq + 1) // 2
@@ -101,14 +108,14 @@ def read_bam(path):
         am = aux.get(b"AM")
         bdqual = (am[1] & 0xFF) if am is not None else mapq  # io/Alignment.cpp:12-23 (uint8_t truncation)
         rg = aux.get(b"RG")
-        for k, v in zip(cols, (tid, pos, mtid, mpos, isize, flag, l_seq, mapq, bdqual)):
+        for k, v in zip(cols, (tid, pos, mtid, mpos, isize, flag, l_seq, mapq, bdqual, rend)):
             cols[k].append(v)
         names.append(name)
         rgs.append(rg[1] if rg is not None and rg[0] == b"Z" else "")
         seqs.append(seq)
         quals.append(qual)
     dt = dict(tid=np.int32, pos=np.int32, mtid=np.int32, mpos=np.int32, isize=np.int32, flag=np.uint16,
-              qlen=np.int32, mapq=np.uint8, bdqual=np.uint8)
+              qlen=np.int32, mapq=np.uint8, bdqual=np.uint8, rend=np.int32)
     recs = {k: np.array(v, dtype=dt[k]) for k, v in cols.items()}
     recs["name"] = names
     recs["rg"] = rgs

@@ -77,3 +77,20 @@ def test_producer_decodes_a_multi_block_synthetic_bam(tmp_path):
     for k, i in zip(keys.tolist(), d["name_key"].tolist()):
         assert m.setdefault(i, k) == k
     assert len(set(m.values())) == len(m)
+
+
+@pytest.mark.parametrize("region,beg,end", [("21:29,185,000-29,186,200", 29184999, 29186200), ("21:34809000", 34808999, 1 << 29),
+                                            ("21", 0, 1 << 29)])
+def test_region_strings_follow_samtools_semantics(region, beg, end):
+    """-o accepts samtools region strings (bam_aux.c:107-160); records overlapping [beg, end) are kept
+    (bam_index.c:571-576), end of a record = pos + reference length of its CIGAR"""
+    from helpers import read_bam
+    gd = os.path.join(GOLDEN, "chr21")
+    head, rows, keys = dump(["-o", region, "inv_del_bam_config"], gd)
+    want = 0
+    for b in ("NA19238_chr21_del_inv.bam", "NA19240_chr21_del_inv.bam"):
+        targets, recs = read_bam(os.path.join(gd, b))
+        tid = targets.index("21")
+        want += int(((recs["tid"] == tid) & (recs["rend"] > beg) & (recs["pos"] < end)).sum())
+    assert len(rows) == want and want > 0
+    assert (rows[:, 0] == 22).all() and (rows[:, 1] < end).all()
