@@ -506,7 +506,11 @@ int do_join_local(bdx_ctx* c, uint32_t n, const Entries& en, const uint32_t* n_p
     uint32_t nb = 1, lg = 0;
     while (nb < (uint32_t)kMaxBuckets && (size_t)nb * 384 < n) { nb <<= 1; ++lg; }  // ~256-512 entries per bucket: >= 1 workgroup per CU early
     k4.nbuckets = nb; k4.log2b = lg;
-    HIPCHK(c, c->b_bcnt.ensure(nb * 4)); HIPCHK(c, c->b_boff.ensure((nb + 1) * 4)); HIPCHK(c, c->b_bcur.ensure(nb * 4));
+    if ((size_t)nb * 4 > c->b_bcnt.bytes) {  // (re)allocated: the partition histogram has to start from zero once
+        HIPCHK(c, c->b_bcnt.ensure((size_t)kMaxBuckets * 4));
+        HIPCHK(c, hipMemsetAsync(c->b_bcnt.p, 0, c->b_bcnt.bytes, s));
+    }
+    HIPCHK(c, c->b_boff.ensure((nb + 1) * 4)); HIPCHK(c, c->b_bcur.ensure(nb * 4));
     HIPCHK(c, c->b_e_key.ensure((size_t)n * 8)); HIPCHK(c, c->b_e_idx.ensure((size_t)n * 4));
     HIPCHK(c, c->b_partner.ensure((size_t)n * 4));
     HIPCHK(c, c->b_t_key.ensure((size_t)n * 16)); HIPCHK(c, c->b_t_idx.ensure((size_t)n * 8));

@@ -7,7 +7,8 @@
 //
 // Input: class bytes from K1 + exclusive per-tile prefixes.  Output: one compact record per anomalous
 // read, in stream order.  One wave per 256-read tile, in-tile scans are wave shuffles on 16-bit packed
-// counters: no LDS, no barrier, and tiles without an anomalous read are skipped after one ballot.
+// counters, no workgroup barrier; tiles without an anomalous read are skipped after one ballot; the anomalous
+// slots of a tile are compacted through a wave-private LDS slice so that the gather runs with dense lanes.
 // HBM traffic: 1-2 B per read plus a gather of ~35 B per anomalous read.
 #include "bdx_dev.h"
 
@@ -16,6 +17,8 @@ namespace bdx {
 size_t k2_lds_bytes(int) { return 0; }
 
 __global__ __launch_bounds__(kBlock) void k2_compact_kernel(const K2Params p) {
+    __shared__ uint32_t s_src[kWaves * kTile];  // per wave: offset in tile | class byte << 8, by in-tile rank
+    __shared__ uint32_t s_nn[kWaves * kTile];
     const int nkeys = p.nkeys;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t nwaves = gridDim.x * kWaves;
@@ -49,7 +52,6 @@ __global__ __launch_bounds__(kBlock) void k2_compact_kernel(const K2Params p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) tot += (anom[r] ? 1u : 0u) + (nleft[r] ? 0x10000u : 0u);
         const uint32_t ex0 = wave_incl_scan(tot) - tot;
-        uint32_t rank = p.tile_pre[(size_t)kColAnom * p.tstride + tile] + (ex0 & 0xFFFFu);
         uint32_t nn = p.nn_base + p.tile_pre[(size_t)kColNormal * p.tstride + tile] + (ex0 >> 16);
         uint32_t jj[4] = {0, 0, 0, 0};
         int key[4] = {0, 0, 0, 0};
@@ -58,24 +60,42 @@ __global__ __launch_bounds__(kBlock) void k2_compact_kernel(const K2Params p) {
             for (int r = 0; r < 4; ++r)
                 if (r < nvalid) { lib[r] = p.r.lib[base + r]; key[r] = p.libs[lib[r]].key; }
         }
+        // Wave-level compaction before the gather: every anomalous slot drops (offset in tile, class byte, nn) into the
+        // wave's LDS slice at its in-tile rank; then lanes 0..cnt-1 each fetch ONE whole record, so the eight column
+        // gathers are issued once per wave with all lanes busy and the compact stores are contiguous.
+        const uint32_t rank0 = p.tile_pre[(size_t)kColAnom * p.tstride + tile];
+        const uint32_t cnt = __shfl((ex0 + tot) & 0xFFFFu, 63);
+        {
+            uint32_t local = ex0 & 0xFFFFu;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (anom[r]) {
-                const uint64_t i = base + r;
-                const uint32_t j = rank++;
-                jj[r] = j;
+            for (int r = 0; r < 4; ++r) {
+                if (anom[r]) {
+                    jj[r] = rank0 + local;
+                    s_src[w * kTile + local] = (uint32_t)(lane * 4 + r) | (c[r] << 8);
+                    s_nn[w * kTile + local] = nn;
+                    ++local;
+                }
+                if (nleft[r]) ++nn;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t b = 0; b < cnt; b += 64) {
+            const uint32_t q = b + lane;
+            if (q < cnt) {
+                const uint32_t src = s_src[w * kTile + q];
+                const uint64_t i = (uint64_t)tile * kTile + (src & 255u);
+                const uint32_t j = rank0 + q;
                 const unsigned sam = p.r.flag[i];
-                const unsigned L = nkeys > 1 ? lib[r] : p.r.lib[i];
                 p.c.tid[j] = p.r.tid[i];
                 p.c.pos[j] = p.r.pos[i];
                 p.c.isize[j] = abs(p.r.isize[i]);
-                p.c.meta[j] = meta_pack((int)(c[r] & 15u), (sam >> 4) & 1u, (int)L, (int)p.r.qlen[i]);
+                p.c.meta[j] = meta_pack((int)((src >> 8) & 15u), (sam >> 4) & 1u, (int)p.r.lib[i], (int)p.r.qlen[i]);
                 p.c.key[j] = p.r.key[i];
                 p.c.idx[j] = (uint32_t)i;
-                p.c.nn[j] = nn;
+                p.c.nn[j] = s_nn[w * kTile + q];
             }
-            if (nleft[r]) ++nn;
         }
+        __builtin_amdgcn_wave_barrier();
         // per-key proper-read prefix counts (inclusive of the read itself), two keys per packed scan
         for (int k0 = 0; k0 < nkeys; k0 += 2) {
             uint32_t v = 0, inc4[4];
@@ -100,7 +120,7 @@ __global__ __launch_bounds__(kBlock) void k2_compact_kernel(const K2Params p) {
 
 void launch_k2(const K2Params& p, size_t lds, hipStream_t s) {
     const uint32_t nblk = (p.ntiles + kWaves - 1) / kWaves;
-    const uint32_t grid = nblk < 2048u ? nblk : 2048u;
+    const uint32_t grid = nblk < 65536u ? nblk : 65536u;  // latency-bound (dependent loads per tile): one tile per wave wherever possible
     hipLaunchKernelGGL(k2_compact_kernel, dim3(grid), dim3(kBlock), lds, s, p);
 }
 

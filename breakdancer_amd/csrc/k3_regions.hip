@@ -89,7 +89,7 @@ struct AcceptOut {
     int nkeys;
     __device__ void operator()(uint32_t c, uint32_t n, uint32_t inc, uint32_t e) const {
         a.c_rid[c] = e ? (int)inc - 1 : -1;
-        if (c == n - 1) a.counts->last_maxq = a.c_maxq[c];
+        if (c == n - 1) { a.counts->last_maxq = a.c_maxq[c]; a.counts->n_regions = inc; }  // inc of the last candidate = #accepted
         if (!e) return;
         const uint32_t r = inc - 1;
         const uint32_t f = a.c_first[c];
@@ -107,7 +107,6 @@ struct AcceptOut {
     }
 };
 
-__global__ void k3_store_counts(K3Arrays a, const uint32_t* acc_total) { a.counts->n_regions = *acc_total; }
 
 __global__ __launch_bounds__(256) void k3_region_of_kernel(K3Arrays a, const Pass1* p1) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -127,7 +126,6 @@ void launch_k3(const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n
     AcceptIn ain{a.c_accept};
     AcceptOut aout{a, cp, nkeys};
     scan_launch<uint32_t>(ain, aout, &a.counts->n_cand, n_anom_host, a.ws_u32, a.acc_total, s);
-    hipLaunchKernelGGL(k3_store_counts, dim3(1), dim3(1), 0, s, a, a.acc_total);
     hipLaunchKernelGGL(k3_region_of_kernel, dim3(g), dim3(256), 0, s, a, p1);
 }
 

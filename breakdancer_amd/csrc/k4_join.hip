@@ -58,7 +58,7 @@ __global__ __launch_bounds__(1024) void k4_bucket_scan_kernel(K4Arrays k4, Stage
         __syncthreads();
         uint32_t off = s_carry;
         for (int k = 0; k < w; ++k) off += s_ws[k];
-        if (i < k4.nbuckets) { k4.boff[i] = off + inc - v; k4.bcur[i] = 0; }
+        if (i < k4.nbuckets) { k4.boff[i] = off + inc - v; k4.bcur[i] = 0; k4.bcnt[i] = 0; }  // bcnt is left clean for the next run
         __syncthreads();
         if (threadIdx.x == 1023) s_carry = off + inc;
         __syncthreads();
@@ -213,8 +213,8 @@ __global__ __launch_bounds__(256) void k4_aggregate_kernel(K4Arrays k4, Entries 
 void launch_k4(const K4Arrays& k4, const Entries& en, const uint32_t* n_ptr, uint32_t n_anom_host, StageCounts* counts, hipStream_t s) {
     if (n_anom_host == 0) return;
     const uint32_t g = (n_anom_host + kPartChunk - 1) / kPartChunk;
-    (void)hipMemsetAsync(k4.bcnt, 0, (size_t)k4.nbuckets * 4, s);
-    (void)hipMemsetAsync(k4.partner, 0xFF, (size_t)n_anom_host * 4, s);
+    // bcnt is zero on entry (zeroed at allocation, then by every bucket scan); partner[] needs no initialisation: the join
+    // kernel writes the entry of every read of an accepted region and nothing else is ever read
     hipLaunchKernelGGL(k4_count_kernel, dim3(g), dim3(256), (size_t)k4.nbuckets * 4, s, k4, en, n_ptr);
     hipLaunchKernelGGL(k4_bucket_scan_kernel, dim3(1), dim3(1024), 0, s, k4, counts);
     hipLaunchKernelGGL(k4_scatter_kernel, dim3(g), dim3(256), (size_t)k4.nbuckets * 8, s, k4, en, n_ptr);
