@@ -532,6 +532,7 @@ int readback(bdx_ctx* c, bool with_groups) {
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, hipGetLastError());
     c->counts = *c->h_counts.as<StageCounts>();
+    if (c->counts.overflow == 2) return fail(c, BDX_ELIMIT, "a read-name key is shared by thousands of reads (malformed input)");
     if (c->counts.overflow) return fail(c, BDX_EINTERNAL, "group list overflow");
     (void)with_groups;  // regions / prefix samples / groups already sit in pinned host memory (see do_cut / do_join_local)
     return BDX_OK;
@@ -798,6 +799,7 @@ int bdx_join_entries(bdx_ctx* c, size_t n, const uint64_t* key, const uint32_t* 
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, hipGetLastError());
     const StageCounts sc = *c->h_counts.as<StageCounts>();
+    if (sc.overflow == 2) return fail(c, BDX_ELIMIT, "a read-name key is shared by thousands of reads (malformed input)");
     if (sc.overflow) return fail(c, BDX_EINTERNAL, "group list overflow");
     if (n_groups) *n_groups = sc.n_groups;
     if (n_pairs) *n_pairs = sc.n_pairs;

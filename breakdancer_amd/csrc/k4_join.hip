@@ -101,17 +101,25 @@ __global__ __launch_bounds__(256) void k4_scatter_kernel(K4Arrays k4, Entries en
 // One workgroup joins one bucket.  Two phases around a barrier: (A) every entry claims its own slot by
 // linear probing from hash(key) (no key comparison, so the table is a multiset), (B) every entry walks its
 // probe run until the first empty slot and takes the other entry with the same key as its mate.
+constexpr uint32_t kMaxProbes = 4096;  // a name key shared by thousands of reads is malformed input: fail instead of crawling
+
 template <bool kLds>
 __device__ __forceinline__ void join_bucket(uint64_t* tkey, int32_t* tidx, uint32_t cap, const K4Arrays& k4, uint32_t off,
-                                            uint32_t cnt) {
+                                            uint32_t cnt, StageCounts* counts) {
     for (uint32_t s = threadIdx.x; s < cap; s += blockDim.x) tidx[s] = -1;
     __syncthreads();
     for (uint32_t e = threadIdx.x; e < cnt; e += blockDim.x) {
         const uint64_t key = k4.e_key[off + e];
         const int32_t j = (int32_t)k4.e_idx[off + e];
         uint32_t s = (uint32_t)(mix64(key) & 0xffffffffu) % cap;
-        while (atomicCAS(&tidx[s], -1, j) != -1) s = s + 1 == cap ? 0 : s + 1;
-        tkey[s] = key;
+        uint32_t probes = 0;
+        bool placed = true;
+        while (atomicCAS(&tidx[s], -1, j) != -1) {
+            s = s + 1 == cap ? 0 : s + 1;
+            if (++probes > kMaxProbes) { placed = false; break; }
+        }
+        if (placed) tkey[s] = key;
+        else counts->overflow = 2;
     }
     __syncthreads();
     for (uint32_t e = threadIdx.x; e < cnt; e += blockDim.x) {
@@ -119,7 +127,8 @@ __device__ __forceinline__ void join_bucket(uint64_t* tkey, int32_t* tidx, uint3
         const int32_t j = (int32_t)k4.e_idx[off + e];
         uint32_t s = (uint32_t)(mix64(key) & 0xffffffffu) % cap;
         int32_t mate = -1;
-        for (uint32_t probes = 0; probes < cap; ++probes) {
+        const uint32_t lim = cap < kMaxProbes ? cap : kMaxProbes;
+        for (uint32_t probes = 0; probes < lim; ++probes) {
             const int32_t o = tidx[s];
             if (o == -1) break;
             if (o != j && tkey[s] == key) { mate = o; break; }
@@ -129,7 +138,7 @@ __device__ __forceinline__ void join_bucket(uint64_t* tkey, int32_t* tidx, uint3
     }
 }
 
-__global__ __launch_bounds__(256) void k4_join_kernel(K4Arrays k4) {
+__global__ __launch_bounds__(256) void k4_join_kernel(K4Arrays k4, StageCounts* counts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t b = blockIdx.x;
     const uint32_t off = k4.boff[b], cnt = k4.boff[b + 1] - off;
@@ -137,9 +146,9 @@ __global__ __launch_bounds__(256) void k4_join_kernel(K4Arrays k4) {
     if (2 * cnt <= (uint32_t)kJoinLdsSlots) {
         uint64_t* tkey = (uint64_t*)smem;
         int32_t* tidx = (int32_t*)(tkey + kJoinLdsSlots);
-        join_bucket<true>(tkey, tidx, 2 * cnt, k4, off, cnt);
+        join_bucket<true>(tkey, tidx, 2 * cnt, k4, off, cnt, counts);
     } else {
-        join_bucket<false>(k4.t_key + 2 * (size_t)off, k4.t_idx + 2 * (size_t)off, 2 * cnt, k4, off, cnt);
+        join_bucket<false>(k4.t_key + 2 * (size_t)off, k4.t_idx + 2 * (size_t)off, 2 * cnt, k4, off, cnt, counts);
     }
 }
 
@@ -224,7 +233,7 @@ void launch_k4(const K4Arrays& k4, const Entries& en, const uint32_t* n_ptr, uin
         (void)hipFuncSetAttribute((const void*)k4_aggregate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kAggSlots * 16 + 32);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k4_join_kernel, dim3(k4.nbuckets), dim3(256), (size_t)kJoinLdsSlots * 12, s, k4);
+    hipLaunchKernelGGL(k4_join_kernel, dim3(k4.nbuckets), dim3(256), (size_t)kJoinLdsSlots * 12, s, k4, counts);
     hipLaunchKernelGGL(k4_aggregate_kernel, dim3(g), dim3(256), (size_t)kAggSlots * 16 + 32, s, k4, en, n_ptr, counts);
 }
 

@@ -183,3 +183,26 @@ def test_full_size_properties():
     dels = sv_a[(sv_a["flag"] == 2) & (sv_a["printed"] == 1)]
     assert len(dels) > 1000
     assert abs(np.median(dels["size"]) - 1150) < 40
+
+
+def test_degenerate_inputs_do_not_hang():
+    """all reads anomalous (every tile overflows the lane count); and one name key shared by thousands of reads, which
+    must be reported as an error instead of crawling through a quadratic probe sequence"""
+    import breakdancer_amd as bda
+    from breakdancer_amd.api import BdxError, LibraryConfig, Options
+    n = 20000
+    rng = np.random.default_rng(3)
+    pos = np.sort(rng.integers(1000, 200000, n)).astype(np.int32)
+    base = dict(tid=np.zeros(n, np.int32), pos=pos, mtid=np.zeros(n, np.int32), mpos=pos + 5000, isize=np.full(n, 5100, np.int32),
+                flag=np.full(n, 0x1 | 0x20 | 0x40, np.uint16), qlen=np.full(n, 100, np.uint16), mapq=np.full(n, 60, np.uint8),
+                lib=np.zeros(n, np.uint8), bam=np.zeros(n, np.uint8))
+    bd = bda.BreakDancer(Options(), [LibraryConfig(400, 30, 490, 310, 100)], 1, max_read_window_size=200)
+    bd.push_reads(dict(base, name_key=np.arange(n, dtype=np.uint64) // 2 + 1))   # every read anomalous, mates adjacent
+    s = bd.run().summary()
+    assert s["n_anomalous"] == n and s["n_pairs"] > 0
+    bd.close()
+    bd = bda.BreakDancer(Options(), [LibraryConfig(400, 30, 490, 310, 100)], 1, max_read_window_size=200)
+    bd.push_reads(dict(base, name_key=np.full(n, 42, np.uint64)))
+    with pytest.raises(BdxError):
+        bd.run()
+    bd.close()
