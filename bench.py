@@ -142,7 +142,8 @@ def main():
             "config": {"workload": "configs[1]: synthetic single chromosome %d Mbp, 30x, 2x100 bp, 1 library, ~1%% discordant "
                                    "pairs; %d read pairs (%d records) per GPU, HBM-resident SoA" % (a.length // 1000000, pairs, n),
                        "sharding": "one chromosome per GPU, no data-path collective", "svs_per_gpu": summary["n_svs_printed"],
-                       "stage_ms": {k: v / a.steps for k, v in stage.items()}},
+                       "stage_ms": {k: v / a.steps for k, v in stage.items()},
+                       "sv_candidates": dict(zip(("assembled_on_device", "from_host_walk", "groups_to_host_walk"), bd.walk_split()))},
             "roofline": {"bound": "hbm", "kernel": "k1_classify_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_READ * n,
                          "avg_kernel_ms": k1_avg_ms},

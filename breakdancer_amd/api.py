@@ -196,6 +196,17 @@ class BreakDancer:
         self._chk(self.lib.bdx_get_read_class(self.h, out.ctypes.data_as(C.c_void_p), n), "bdx_get_read_class")
         return out
 
+    def set_host_walk(self, on=True):
+        """Send every component of the region graph through the host walk (same results as the device assembly)."""
+        self._chk(self.lib.bdx_set_host_walk(self.h, int(on)), "bdx_set_host_walk")
+        return self
+
+    def walk_split(self):
+        """(SVs assembled on the device, SVs from the host walk, pair groups handed to the host walk)"""
+        v = [C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)]
+        self._chk(self.lib.bdx_get_walk_split(self.h, C.byref(v[0]), C.byref(v[1]), C.byref(v[2])), "bdx_get_walk_split")
+        return tuple(x.value for x in v)
+
     def timings(self):
         ms = np.zeros(8, np.float32)
         self.lib.bdx_get_timings(self.h, ms.ctypes.data_as(C.c_void_p), 8)

@@ -85,7 +85,14 @@ struct bdx_ctx {
         b_c_nnormal, b_c_rid, b_region_of, b_ws_u4, b_ws_u32, b_totals, b_counts;
     DevBuf b_bcnt, b_boff, b_bcur, b_e_key, b_e_idx, b_partner, b_t_key, b_t_idx;
     DevBuf b_x_key, b_x_order, b_x_region, b_x_meta, b_x_isize, b_x_n;
+    DevBuf b_r_rec, b_r_pk, b_out_deg, b_out_hi, b_p_key, b_p_pairs, b_p_sum, b_rs, b_slot, b_slot_info, b_lib_stage, b_cn_stage,
+        b_t_lambda, b_t_k, b_ws6, b_k6const;
     PinBuf h_p1, h_cnt, h_counts, h_regs, h_pk, h_groups, h_terms;
+    PinBuf h_counts0, h_counts2, h_sv_out, h_lib_index, h_lib_pairs, h_cn_key, h_cn_value, h_ltail_dev, h_k6const;
+    hipEvent_t ev_groups = nullptr, ev_regions = nullptr;
+    bool host_walk_only = false;      // BDX_HOST_WALK=1: every component goes through the host walk (A/B testing of K6)
+    K6Arrays k6{};
+    WalkResult merged;
 
     // results
     bool ran = false;
@@ -106,15 +113,17 @@ struct bdx_ctx {
     std::vector<uint32_t> sup_off;    // [n_svs + 1]
     std::vector<uint64_t> sup_idx;
     std::vector<uint8_t> sup_flag;
-    std::vector<uint32_t> reg_first;  // compact index of each region's first read (host ids, incl. the phantom shift)
-    std::vector<uint32_t> reg_n;
     std::vector<float> seqcov, lib_density, key_density;
-    std::vector<HostRegion> regions;
+    std::vector<HostRegion> regions;  // owned copies (staged runs, phantom shift); otherwise reg/rpk point into pinned memory
     std::vector<uint32_t> r_pk;
+    const HostRegion* reg = nullptr;
+    size_t nreg = 0;
+    const uint32_t* rpk = nullptr;
     std::vector<GroupPart> parts;
     WalkResult walk;
     WalkScratch* walk_scratch = nullptr;
     uint32_t n_printed = 0;
+    uint32_t n_sv_host = 0;
     float stage_ms[kNumStages] = {0};
     hipEvent_t ev[8] = {nullptr};
 };
@@ -205,6 +214,12 @@ int bdx_create(bdx_ctx** out, const bdx_opts* opts, const bdx_lib* libs, int nli
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return BDX_EHIP; }
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete c; return BDX_EHIP; }
+    if (hipEventCreateWithFlags(&c->ev_groups, hipEventDisableTiming) != hipSuccess) { delete c; return BDX_EHIP; }
+    if (hipEventCreateWithFlags(&c->ev_regions, hipEventDisableTiming) != hipSuccess) { delete c; return BDX_EHIP; }
+    {
+        const char* hw = getenv("BDX_HOST_WALK");
+        c->host_walk_only = hw && hw[0] == '1';
+    }
     std::vector<DevLib> dl(nlibs);
     for (int i = 0; i < nlibs; ++i) {
         dl[i].upper = libs[i].uppercutoff;
@@ -233,13 +248,18 @@ void bdx_destroy(bdx_ctx* c) {
                       &c->b_c_nnormal, &c->b_c_rid, &c->b_region_of, &c->b_ws_u4, &c->b_ws_u32, &c->b_totals,
                       &c->b_counts, &c->b_bcnt, &c->b_boff, &c->b_bcur, &c->b_e_key, &c->b_e_idx, &c->b_partner, &c->b_t_key,
                       &c->b_t_idx, &c->b_x_key, &c->b_x_order, &c->b_x_region,
-                      &c->b_x_meta, &c->b_x_isize, &c->b_x_n, &c->b_fold};
+                      &c->b_x_meta, &c->b_x_isize, &c->b_x_n, &c->b_fold, &c->b_r_rec, &c->b_r_pk, &c->b_out_deg, &c->b_out_hi,
+                      &c->b_p_key, &c->b_p_pairs, &c->b_p_sum, &c->b_rs, &c->b_slot, &c->b_slot_info, &c->b_lib_stage,
+                      &c->b_cn_stage, &c->b_t_lambda, &c->b_t_k, &c->b_ws6, &c->b_k6const};
     for (DevBuf* b : bufs) b->release();
-    PinBuf* pins[] = {&c->h_p1, &c->h_cnt, &c->h_counts, &c->h_regs, &c->h_pk, &c->h_groups, &c->h_terms};
+    PinBuf* pins[] = {&c->h_p1, &c->h_cnt, &c->h_counts, &c->h_regs, &c->h_pk, &c->h_groups, &c->h_terms, &c->h_counts0, &c->h_counts2,
+                      &c->h_sv_out, &c->h_lib_index, &c->h_lib_pairs, &c->h_cn_key, &c->h_cn_value, &c->h_ltail_dev, &c->h_k6const};
     for (PinBuf* b : pins) b->release();
     if (c->walk_scratch) walk_scratch_free(c->walk_scratch);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
+    if (c->ev_groups) (void)hipEventDestroy(c->ev_groups);
+    if (c->ev_regions) (void)hipEventDestroy(c->ev_regions);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -321,7 +341,9 @@ int do_pass1(bdx_ctx* c) {
     c->ntiles = ntiles; c->tstride = tstride;
     c->ran = false; c->stage = 0;
     c->regions.clear(); c->r_pk.clear(); c->parts.clear();
+    c->reg = nullptr; c->nreg = 0; c->rpk = nullptr;
     c->walk.clear();
+    c->merged.clear();
     if (!c->walk_scratch) c->walk_scratch = walk_scratch_new();
     c->n_printed = 0;
     memset(&c->counts, 0, sizeof(c->counts));
@@ -388,7 +410,7 @@ int32_t window_from(const bdx_ctx* c, const uint32_t* cnt, uint32_t covered) {
 }
 
 // adopt the pass-1 statistics the rest of the path runs with (the context's own, or all-reduced ones)
-int set_pass1(bdx_ctx* c, const uint32_t* cnt, uint32_t covered, int32_t window) {
+int set_pass1(bdx_ctx* c, const uint32_t* cnt, uint32_t covered, int32_t window, bool upload) {
     const int nlibs = c->nlibs, nkeys = c->nkeys;
     const int ncnt = nlibs * kNumFlags + nlibs + c->nbams;
     c->cnt.assign(cnt, cnt + ncnt);
@@ -416,8 +438,10 @@ int set_pass1(bdx_ctx* c, const uint32_t* cnt, uint32_t covered, int32_t window)
     // the region cut reads the window from the device copy of Pass1
     struct { uint32_t covered; int32_t window; } hdr{covered, window};
     static_assert(offsetof(Pass1, covered_ref_len) == 0 && offsetof(Pass1, window) == 4, "Pass1 header layout");
-    HIPCHK(c, hipMemcpyAsync(c->b_p1.p, &hdr, sizeof(hdr), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (upload) {  // a single-context run adopts its own statistics: the device copy already holds them
+        HIPCHK(c, hipMemcpyAsync(c->b_p1.p, &hdr, sizeof(hdr), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     c->stage = 2;
     return BDX_OK;
 }
@@ -459,7 +483,7 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base) {
 // K3: cut regions.  In a whole-genome run the last candidate of a chromosome is closed by the first anomalous read
 // of the next chromosome, which still counts for its nucleotide sum / max read length / normal-pair count
 // (BreakDancer.cpp:202-231): has_next / next_qlen / next_nn carry that read across contexts.
-int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn) {
+int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool for_k6) {
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const int nkeys = c->nkeys;
@@ -487,6 +511,12 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn) {
         k3.c_rev = c->b_c_rev.as<uint32_t>(); k3.c_nonctx = c->b_c_nonctx.as<uint32_t>();
         k3.c_nnormal = c->b_c_nnormal.as<uint32_t>(); k3.c_rid = c->b_c_rid.as<int32_t>(); k3.region_of = c->b_region_of.as<int32_t>();
         k3.r_rec = c->h_regs.as<RegionRec>(); k3.r_pk = c->h_pk.as<uint32_t>();
+        if (for_k6) {  // the device-side SV assembly reads the region table back: keep a copy in HBM
+            HIPCHK(c, c->b_r_rec.ensure(cap * sizeof(RegionRec)));
+            HIPCHK(c, c->b_r_pk.ensure(cap * 2 * nkeys * 4));
+            HIPCHK(c, c->b_out_deg.ensure(cap * 4));
+            k3.r_rec_dev = c->b_r_rec.as<RegionRec>(); k3.r_pk_dev = c->b_r_pk.as<uint32_t>(); k3.out_deg = c->b_out_deg.as<uint32_t>();
+        }
         k3.ws_u4 = c->b_ws_u4.as<U4>(); k3.head_total = (U4*)c->b_totals.p; k3.ws_u32 = c->b_ws_u32.as<uint32_t>();
         k3.acc_total = (uint32_t*)((char*)c->b_totals.p + 32); k3.counts = c->b_counts.as<StageCounts>();
         K3Tail tail{has_next, next_qlen, next_nn};
@@ -498,7 +528,7 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn) {
 }
 
 // K4 on the context's own reads (single-context run)
-int do_join_local(bdx_ctx* c, uint32_t n, const Entries& en, const uint32_t* n_ptr) {
+int do_join_local(bdx_ctx* c, uint32_t n, const Entries& en, const uint32_t* n_ptr, bool join_only) {
     hipStream_t s = c->stream;
     K4Arrays& k4 = c->k4;
     k4 = K4Arrays{};
@@ -519,7 +549,8 @@ int do_join_local(bdx_ctx* c, uint32_t n, const Entries& en, const uint32_t* n_p
     k4.bcnt = c->b_bcnt.as<uint32_t>(); k4.boff = c->b_boff.as<uint32_t>(); k4.bcur = c->b_bcur.as<uint32_t>();
     k4.e_key = c->b_e_key.as<uint64_t>(); k4.e_idx = c->b_e_idx.as<uint32_t>(); k4.partner = c->b_partner.as<int32_t>();
     k4.t_key = c->b_t_key.as<uint64_t>(); k4.t_idx = c->b_t_idx.as<int32_t>(); k4.g_rec = c->h_groups.as<GroupRec>();
-    launch_k4(k4, en, n_ptr, n, c->b_counts.as<StageCounts>(), s);
+    if (join_only) launch_k4_join_only(k4, en, n_ptr, n, c->b_counts.as<StageCounts>(), s);
+    else launch_k4(k4, en, n_ptr, n, c->b_counts.as<StageCounts>(), s);
     return BDX_OK;
 }
 
@@ -538,19 +569,21 @@ int readback(bdx_ctx* c, bool with_groups) {
     return BDX_OK;
 }
 
-void decode_regions(bdx_ctx* c, const RegionRec* rr, const uint32_t* pk, uint32_t nr, uint32_t ph) {
+// region table for the host side.  borrow: rr / pk stay valid (the context's pinned buffers) and no id shift is
+// needed, so the walk and the getters read them in place.
+void decode_regions(bdx_ctx* c, const RegionRec* rr, const uint32_t* pk, uint32_t nr, uint32_t ph, bool borrow) {
+    static_assert(sizeof(HostRegion) == sizeof(RegionRec) && offsetof(HostRegion, first) == offsetof(RegionRec, first), "region layout");
     const int nkeys = c->nkeys;
-    c->regions.resize(nr + ph);
-    c->reg_first.assign(nr + ph, 0);
-    c->reg_n.assign(nr + ph, 0);
-    if (ph) c->regions[0] = HostRegion{-1, -1, -1, 0, 0, 0, 0, 0};
-    for (uint32_t i = 0; i < nr; ++i) {
-        c->regions[i + ph] = HostRegion{rr[i].tid, rr[i].start, rr[i].end, rr[i].n, rr[i].rev, rr[i].nonctx, rr[i].nnormal, rr[i].maxq};
-        c->reg_first[i + ph] = rr[i].first;
-        c->reg_n[i + ph] = rr[i].n;
+    if (borrow && !ph) {
+        c->reg = (const HostRegion*)rr; c->nreg = nr; c->rpk = pk;
+        return;
     }
+    c->regions.resize(nr + ph);
+    if (ph) c->regions[0] = HostRegion{-1, -1, -1, 0, 0, 0, 0, 0, 0};
+    if (nr) memcpy(c->regions.data() + ph, rr, (size_t)nr * sizeof(RegionRec));
     c->r_pk.assign((size_t)ph * 2 * nkeys, 0u);
     c->r_pk.insert(c->r_pk.end(), pk, pk + (size_t)nr * 2 * nkeys);
+    c->reg = c->regions.data(); c->nreg = c->regions.size(); c->rpk = c->r_pk.data();
 }
 
 void decode_groups(bdx_ctx* c, const GroupRec* gr, uint32_t ng, uint32_t ph) {
@@ -562,22 +595,84 @@ void decode_groups(bdx_ctx* c, const GroupRec* gr, uint32_t ng, uint32_t ph) {
     }
 }
 
-// H1 walk + K5 + score combination over c->regions / c->r_pk / c->parts with the adopted pass-1 statistics
-int do_walk(bdx_ctx* c, int32_t last_maxq, bool any_anomalous) {
+// K6 on the context's own regions (single-context runs): pair groups per region, SV assembly of the components that need
+// no traversal, everything else listed for the host walk; then the dense results and K5 for the device-assembled SVs.
+int do_k6(bdx_ctx* c, bool force_host) {
+    hipStream_t s = c->stream;
+    const uint32_t na = c->p1.n_anom;
+    const int nkeys = c->nkeys, nlibs = c->nlibs;
+    K6Arrays& a = c->k6;
+    a = K6Arrays{};
+    if (!na) return BDX_OK;
+    const size_t cap = na;
+    const uint32_t stride = (uint32_t)std::min(kK6MaxParts, nlibs);
+    HIPCHK(c, c->b_out_hi.ensure(cap * 4));
+    HIPCHK(c, c->b_p_key.ensure(cap * 8)); HIPCHK(c, c->b_p_pairs.ensure(cap * 4)); HIPCHK(c, c->b_p_sum.ensure(cap * 4));
+    HIPCHK(c, c->b_rs.ensure(cap * sizeof(RegSum)));
+    HIPCHK(c, c->b_slot.ensure(3 * cap * sizeof(SvOut))); HIPCHK(c, c->b_slot_info.ensure(3 * cap * 4));
+    HIPCHK(c, c->b_lib_stage.ensure(3 * cap * stride * sizeof(LibStage)));
+    HIPCHK(c, c->b_cn_stage.ensure(3 * cap * (size_t)nkeys * sizeof(CnStage)));
+    a.sv_cap = na / 2 + 1; a.term_cap = na / 2 + 1; a.cn_cap = (na / 2 + 1) * (uint32_t)nkeys;
+    HIPCHK(c, c->b_t_lambda.ensure((size_t)a.term_cap * 8)); HIPCHK(c, c->b_t_k.ensure((size_t)a.term_cap * 4));
+    const size_t nblk = scan_grid(3 * na) + 1;
+    HIPCHK(c, c->b_ws6.ensure(nblk * sizeof(U4) + 64));
+    HIPCHK(c, c->h_sv_out.ensure((size_t)a.sv_cap * sizeof(SvOut)));
+    HIPCHK(c, c->h_lib_index.ensure((size_t)a.term_cap * 4)); HIPCHK(c, c->h_lib_pairs.ensure((size_t)a.term_cap * 4));
+    HIPCHK(c, c->h_cn_key.ensure((size_t)a.cn_cap * 4 + 16)); HIPCHK(c, c->h_cn_value.ensure((size_t)a.cn_cap * 4 + 16));
+    HIPCHK(c, c->h_ltail_dev.ensure((size_t)a.term_cap * 8));
+    HIPCHK(c, c->h_counts2.ensure(sizeof(StageCounts)));
+    // run constants: adopted flag histogram, read densities per counter key, library mean insert sizes
+    const size_t nconst = (size_t)nlibs * kNumFlags + nkeys + nlibs;
+    HIPCHK(c, c->h_k6const.ensure(nconst * 4)); HIPCHK(c, c->b_k6const.ensure(nconst * 4));
+    {
+        uint32_t* hh = c->h_k6const.as<uint32_t>();
+        memcpy(hh, c->cnt.data(), (size_t)nlibs * kNumFlags * 4);
+        float* hd = (float*)(hh + (size_t)nlibs * kNumFlags);
+        for (int k = 0; k < nkeys; ++k) hd[k] = c->key_density[k];
+        for (int i = 0; i < nlibs; ++i) hd[nkeys + i] = c->libs[i].mean_insertsize;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->b_k6const.p, c->h_k6const.p, nconst * 4, hipMemcpyHostToDevice, s));
+    a.cap = na;
+    a.r_rec = c->b_r_rec.as<RegionRec>(); a.r_pk = c->b_r_pk.as<uint32_t>();
+    a.region_of = c->k3.region_of; a.partner = c->k4.partner; a.meta = c->cp.meta; a.isize = c->cp.isize;
+    a.p_key = c->b_p_key.as<uint64_t>(); a.p_pairs = c->b_p_pairs.as<uint32_t>(); a.p_sum = c->b_p_sum.as<uint32_t>();
+    a.rs = c->b_rs.as<RegSum>(); a.out_deg = c->b_out_deg.as<uint32_t>(); a.out_hi = c->b_out_hi.as<uint32_t>();
+    a.slot = c->b_slot.as<SvOut>(); a.slot_info = c->b_slot_info.as<uint32_t>();
+    a.lib_stage = c->b_lib_stage.as<LibStage>(); a.cn_stage = c->b_cn_stage.as<CnStage>(); a.acc_stride = stride;
+    a.sv_out = c->h_sv_out.as<SvOut>(); a.lib_index = c->h_lib_index.as<int32_t>(); a.lib_pairs = c->h_lib_pairs.as<int32_t>();
+    a.cn_key = c->h_cn_key.as<int32_t>(); a.cn_value = c->h_cn_value.as<float>();
+    a.t_lambda = c->b_t_lambda.as<double>(); a.t_k = c->b_t_k.as<int32_t>();
+    a.g_rec = c->k4.g_rec; a.g_cap = c->k4.g_cap;
+    a.ws_u4 = c->b_ws6.as<U4>(); a.total_u4 = (U4*)((char*)c->b_ws6.p + nblk * sizeof(U4));
+    a.counts = c->b_counts.as<StageCounts>();
+    a.hist = c->b_k6const.as<uint32_t>();
+    a.key_density = (const float*)(a.hist + (size_t)nlibs * kNumFlags);
+    a.lib_mean = a.key_density + nkeys;
+    a.covered_ref_len = c->g_covered;
+    a.nkeys = nkeys; a.min_read_pair = c->opts.min_read_pair; a.chr_restricted = c->opts.chr_restricted;
+    a.period = std::max(1, c->opts.buffer_size + 1);
+    a.force_host = force_host ? 1 : 0;
+    launch_k6_groups(a, na, s);
+    HIPCHK(c, hipMemcpyAsync(c->h_counts.p, c->b_counts.p, sizeof(StageCounts), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipEventRecord(c->ev_groups, s));  // the host walk of the remaining components can start here
+    launch_k6_compact(a, na, s);
+    launch_k5_dev(a.t_lambda, a.t_k, c->h_ltail_dev.as<double>(), &a.counts->n_terms_dev, a.term_cap, s);
+    HIPCHK(c, hipMemcpyAsync(c->h_counts2.p, c->b_counts.p, sizeof(StageCounts), hipMemcpyDeviceToHost, s));
+    return BDX_OK;
+}
+
+// H1 walk over c->regions / c->r_pk / c->parts with the adopted pass-1 statistics; K5 for its terms is enqueued
+int host_walk(bdx_ctx* c, int32_t last_maxq, bool any_anomalous) {
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    const auto t0 = std::chrono::steady_clock::now();
     WalkInput wi{};
     wi.opts = c->opts; wi.libs = c->libs.data(); wi.nlibs = c->nlibs; wi.nbams = c->nbams; wi.nkeys = c->nkeys;
     wi.hist = c->cnt.data(); wi.covered_ref_len = c->g_covered; wi.key_density = c->key_density.data();
-    wi.regions = &c->regions; wi.r_pk = c->r_pk.data(); wi.parts = &c->parts; wi.last_maxq = last_maxq;
+    wi.regions = c->reg; wi.nregions = c->nreg; wi.r_pk = c->rpk; wi.parts = &c->parts; wi.last_maxq = last_maxq;
     wi.any_anomalous = any_anomalous;
     c->walk.clear();
-    greedy_walk(wi, c->walk_scratch, c->walk);
-    const auto t1 = std::chrono::steady_clock::now();
+    if (!c->parts.empty()) greedy_walk(wi, c->walk_scratch, c->walk);
     const uint32_t nt = (uint32_t)c->walk.terms.size();
-    std::vector<double>& log_tail = c->log_tail;
-    log_tail.resize(nt);
     if (nt) {
         // zero-copy: the kernel reads lambda / k from pinned host memory and writes the log tails back into it (a few
         // tens of KB; the PCIe traffic overlaps the kernel and no copy engine round trips are paid)
@@ -587,14 +682,77 @@ int do_walk(bdx_ctx* c, int32_t last_maxq, bool any_anomalous) {
         double* ho = (double*)((char*)c->h_terms.p + (((size_t)nt * 12 + 7) & ~(size_t)7));
         for (uint32_t i = 0; i < nt; ++i) { hl[i] = c->walk.terms[i].lambda; hk[i] = c->walk.terms[i].k; }
         launch_k5(hl, hk, ho, nt, s);
-        HIPCHK(c, hipStreamSynchronize(s));
-        HIPCHK(c, hipGetLastError());
-        for (uint32_t i = 0; i < nt; ++i) log_tail[i] = ho[i];
     }
-    finish_scores(wi, log_tail, c->walk, &c->n_printed);
-    const auto t2 = std::chrono::steady_clock::now();
-    c->stage_ms[5] = ms_between(t0, t1);
-    c->stage_ms[6] = ms_between(t1, t2);
+    return BDX_OK;
+}
+
+// wait for the device, interleave the device-assembled SVs with the host walk's in the reference's output order,
+// combine the per-library log tails into the scores
+int finish_walk(bdx_ctx* c, bool with_dev) {
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipGetLastError());
+    static_assert(sizeof(HostSv) == sizeof(SvOut) && offsetof(HostSv, grp_mask) == offsetof(SvOut, grp_mask) &&
+                      offsetof(HostSv, start) == offsetof(SvOut, start), "SV record layout");
+    const uint32_t nt = (uint32_t)c->walk.terms.size();
+    const double* host_tail = nt ? (const double*)((char*)c->h_terms.p + (((size_t)nt * 12 + 7) & ~(size_t)7)) : nullptr;
+    uint32_t nd = 0, ndt = 0, ndc = 0;
+    if (with_dev) {
+        const StageCounts c2 = *c->h_counts2.as<StageCounts>();
+        if (c2.overflow) return fail(c, BDX_EINTERNAL, "SV list overflow");
+        nd = c2.n_sv_dev; ndt = c2.n_terms_dev; ndc = c2.n_cn_dev;
+        c->counts.n_sv_dev = nd; c->counts.n_terms_dev = ndt; c->counts.n_cn_dev = ndc; c->counts.n_groups_dev = c2.n_groups_dev;
+        c->counts.n_pairs = c2.n_pairs;
+    }
+    std::vector<double>& log_tail = c->log_tail;
+    c->n_sv_host = (uint32_t)c->walk.svs.size();
+    if (!nd) {
+        log_tail.assign(host_tail, host_tail + nt);
+    } else {
+        WalkResult& H = c->walk;
+        WalkResult& M = c->merged;
+        M.clear();
+        const HostSv* d = c->h_sv_out.as<HostSv>();
+        const int32_t *d_li = c->h_lib_index.as<int32_t>(), *d_lp = c->h_lib_pairs.as<int32_t>(), *d_ck = c->h_cn_key.as<int32_t>();
+        const float* d_cv = c->h_cn_value.as<float>();
+        const double* d_lt = c->h_ltail_dev.as<double>();
+        const size_t nh = H.svs.size();
+        M.svs.resize((size_t)nd + nh);
+        if (!nh) {  // everything was assembled on the device: its lists are already in output order
+            memcpy(M.svs.data(), d, (size_t)nd * sizeof(HostSv));
+            M.lib_index.assign(d_li, d_li + ndt); M.lib_pairs.assign(d_lp, d_lp + ndt);
+            M.cn_key.assign(d_ck, d_ck + ndc); M.cn_value.assign(d_cv, d_cv + ndc);
+            log_tail.assign(d_lt, d_lt + ndt);
+        } else {    // interleave by output order and re-pack the flat lists in that order
+            const uint64_t period = (uint64_t)std::max(1, c->opts.buffer_size + 1);
+            const size_t ntot = (size_t)ndt + nt, nctot = (size_t)ndc + H.cn_key.size();
+            M.lib_index.resize(ntot); M.lib_pairs.resize(ntot); log_tail.resize(ntot);
+            M.cn_key.resize(nctot); M.cn_value.resize(nctot);
+            size_t i = 0, j = 0, o = 0, lo = 0, co = 0;
+            while (i < nd || j < nh) {
+                bool take_dev = j == nh;
+                if (!take_dev && i < nd) take_dev = sv_order_key(d[i].start / period, false, d[i].start) < H.sv_key[j];
+                HostSv hs = take_dev ? d[i] : H.svs[j];
+                const int32_t lb = hs.sv.lib_begin, cb = hs.sv.cn_begin;
+                for (int32_t q = 0; q < hs.sv.lib_count; ++q) {
+                    M.lib_index[lo + q] = take_dev ? d_li[lb + q] : H.lib_index[lb + q];
+                    M.lib_pairs[lo + q] = take_dev ? d_lp[lb + q] : H.lib_pairs[lb + q];
+                    log_tail[lo + q] = take_dev ? d_lt[lb + q] : host_tail[lb + q];
+                }
+                for (int32_t q = 0; q < hs.sv.cn_count; ++q) {
+                    M.cn_key[co + q] = take_dev ? d_ck[cb + q] : H.cn_key[cb + q];
+                    M.cn_value[co + q] = take_dev ? d_cv[cb + q] : H.cn_value[cb + q];
+                }
+                hs.sv.lib_begin = (int32_t)lo; hs.sv.cn_begin = (int32_t)co;
+                lo += (size_t)hs.sv.lib_count; co += (size_t)hs.sv.cn_count;
+                M.svs[o++] = hs;
+                if (take_dev) ++i; else ++j;
+            }
+        }
+        M.n_groups = H.n_groups + c->counts.n_groups_dev;
+        std::swap(c->walk, c->merged);
+    }
+    finish_scores(c->opts, log_tail.data(), c->walk.svs.data(), c->walk.svs.size(), &c->n_printed);
     c->ran = true;
     c->stage = 4;
     return BDX_OK;
@@ -618,9 +776,12 @@ int collect_support(bdx_ctx* c, uint32_t ph) {
     std::vector<std::pair<uint32_t, uint32_t>> pairs;  // (second-observed j, its mate p)
     for (const HostSv& hs : c->walk.svs) {
         pairs.clear();
-        for (uint32_t g = 0; g < hs.ngrp; ++g) {
-            const uint32_t lo = hs.grp_lo[g], hi = hs.grp_hi[g];
-            const uint32_t f = c->reg_first[hi], n = c->reg_n[hi];
+        const uint32_t rA = (uint32_t)hs.sv.region[0], rB = (uint32_t)hs.sv.region[1];
+        const uint32_t glo[3] = {rA, rA, rB}, ghi_[3] = {rA, rB, rB};
+        for (uint32_t g = 0; g < 3; ++g) {
+            if (!(hs.grp_mask & (1u << g))) continue;
+            const uint32_t lo = glo[g], hi = ghi_[g];
+            const uint32_t f = c->reg[hi].first, n = c->reg[hi].n;
             for (uint32_t j = f; j < f + n; ++j) {
                 const int32_t p = partner[j];
                 if (p < 0 || (uint32_t)p >= j) continue;
@@ -647,35 +808,51 @@ int bdx_run(bdx_ctx* c) {
     const auto t_begin = std::chrono::steady_clock::now();
     int rc = do_pass1(c);
     if (rc != BDX_OK) return rc;
-    rc = set_pass1(c, c->cnt_local.data(), c->p1.covered_ref_len, c->p1.window);
+    rc = set_pass1(c, c->cnt_local.data(), c->p1.covered_ref_len, c->p1.window, false);
     if (rc != BDX_OK) return rc;
     rc = do_compact(c, 0, nullptr);
     if (rc != BDX_OK) return rc;
-    rc = do_cut(c, 0, 0, 0);
+    rc = do_cut(c, 0, 0, 0, true);
     if (rc != BDX_OK) return rc;
     hipStream_t s = c->stream;
     const uint32_t na = c->p1.n_anom;
+    // The very first anomalous read "breaks" an empty accumulator (start = end = -1, no reads).  With a negative
+    // -s that empty candidate passes process_breakpoint's test (0 > min_len, coverage 0) and the reference
+    // registers a read-less region 0 (BreakDancer.cpp:216-231, 244-252); every real region id shifts by one.
+    const uint32_t ph = (na && 0 > c->opts.min_len && 0.0f < (float)c->opts.seq_coverage_lim) ? 1u : 0u;
+    // shifted region ids and a non-positive -r are left to the host walk entirely
+    const bool force_host = c->host_walk_only || ph || c->opts.min_read_pair < 1;
     if (na) {
+        // the region table is final after K3: the host takes its copy while the device joins the mates
+        HIPCHK(c, c->h_counts0.ensure(sizeof(StageCounts)));
+        HIPCHK(c, hipMemcpyAsync(c->h_counts0.p, c->b_counts.p, sizeof(StageCounts), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipEventRecord(c->ev_regions, s));
         Entries en{c->cp.key, c->k3.region_of, nullptr, c->cp.meta, c->cp.isize};
-        rc = do_join_local(c, na, en, &c->b_p1.as<Pass1>()->n_anom);
+        rc = do_join_local(c, na, en, &c->b_p1.as<Pass1>()->n_anom, true);
+        if (rc != BDX_OK) return rc;
+        rc = do_k6(c, force_host);
         if (rc != BDX_OK) return rc;
     }
     HIPCHK(c, hipEventRecord(c->ev[5], s));
-    rc = readback(c, true);
-    if (rc != BDX_OK) return rc;
+    const auto t_h0 = std::chrono::steady_clock::now();
     if (na) {
-        // The very first anomalous read "breaks" an empty accumulator (start = end = -1, no reads).  With a negative
-        // -s that empty candidate passes process_breakpoint's test (0 > min_len, coverage 0) and the reference
-        // registers a read-less region 0 (BreakDancer.cpp:216-231, 244-252); every real region id shifts by one.
-        const uint32_t ph = (0 > c->opts.min_len && 0.0f < (float)c->opts.seq_coverage_lim) ? 1u : 0u;
-        decode_regions(c, c->h_regs.as<RegionRec>(), c->h_pk.as<uint32_t>(), c->counts.n_regions, ph);
+        HIPCHK(c, hipEventSynchronize(c->ev_regions));
+        // (the table sits in pinned memory the device has just written: one streaming copy into ordinary memory is much
+        // cheaper than the walk's scattered reads of it)
+        decode_regions(c, c->h_regs.as<RegionRec>(), c->h_pk.as<uint32_t>(), c->h_counts0.as<StageCounts>()->n_regions, ph, false);
+        HIPCHK(c, hipEventSynchronize(c->ev_groups));
+        c->counts = *c->h_counts.as<StageCounts>();
+        if (c->counts.overflow == 2) return fail(c, BDX_ELIMIT, "a read-name key is shared by thousands of reads (malformed input)");
+        if (c->counts.overflow) return fail(c, BDX_EINTERNAL, "group list overflow");
         decode_groups(c, c->h_groups.as<GroupRec>(), c->counts.n_groups, ph);
     }
-    HIPCHK(c, hipEventRecord(c->ev[6], s));
-    rc = do_walk(c, c->counts.last_maxq, na != 0);
+    const auto t_h1 = std::chrono::steady_clock::now();
+    rc = host_walk(c, c->counts.last_maxq, na != 0);
+    if (rc != BDX_OK) return rc;
+    const auto t_h2 = std::chrono::steady_clock::now();
+    rc = finish_walk(c, na != 0);
     if (rc != BDX_OK) return rc;
     if (c->collect_support) {
-        const uint32_t ph = (na && 0 > c->opts.min_len && 0.0f < (float)c->opts.seq_coverage_lim) ? 1u : 0u;
         rc = collect_support(c, ph);
         if (rc != BDX_OK) return rc;
     }
@@ -684,7 +861,9 @@ int bdx_run(bdx_ctx* c) {
     c->stage_ms[1] = evms(2, 3);
     c->stage_ms[2] = evms(3, 4);
     c->stage_ms[3] = evms(4, 5);
-    c->stage_ms[4] = evms(5, 6);
+    c->stage_ms[4] = ms_between(t_h0, t_h1);
+    c->stage_ms[5] = ms_between(t_h1, t_h2);
+    c->stage_ms[6] = ms_between(t_h2, t_end);
     c->stage_ms[7] = ms_between(t_begin, t_end);
     return BDX_OK;
 }
@@ -709,7 +888,7 @@ int bdx_set_pass1_global(bdx_ctx* c, const uint32_t* counters, uint32_t covered_
     if (!c || !counters) return BDX_EINVAL;
     if (c->stage < 1) return BDX_ESTATE;
     if (window < 0) window = window_from(c, counters, covered_ref_len);
-    return set_pass1(c, counters, covered_ref_len, window);
+    return set_pass1(c, counters, covered_ref_len, window, true);
 }
 
 int bdx_stage_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, int32_t* first_qlen, uint32_t* first_nn) {
@@ -734,7 +913,7 @@ int bdx_stage_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, int
 int bdx_stage_regions(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn) {
     if (!c) return BDX_EINVAL;
     if (c->stage < 2) return BDX_ESTATE;
-    int rc = do_cut(c, has_next, next_qlen, next_nn);
+    int rc = do_cut(c, has_next, next_qlen, next_nn, false);
     if (rc != BDX_OK) return rc;
     return readback(c, false);
 }
@@ -793,7 +972,7 @@ int bdx_join_entries(bdx_ctx* c, size_t n, const uint64_t* key, const uint32_t* 
     HIPCHK(c, hipMemsetAsync(c->b_counts.p, 0, sizeof(StageCounts), s));
     Entries en{c->b_x_key.as<uint64_t>(), c->b_x_region.as<int32_t>(), c->b_x_order.as<uint32_t>(), c->b_x_meta.as<uint32_t>(),
                c->b_x_isize.as<int32_t>()};
-    int rc = do_join_local(c, n32, en, c->b_x_n.as<uint32_t>());
+    int rc = do_join_local(c, n32, en, c->b_x_n.as<uint32_t>(), false);
     if (rc != BDX_OK) return rc;
     HIPCHK(c, hipMemcpyAsync(c->h_counts.p, c->b_counts.p, sizeof(StageCounts), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
@@ -813,17 +992,24 @@ int bdx_stage_walk(bdx_ctx* c, size_t nregions, const bdx_region_rec* regions, c
                    const bdx_group* groups, int32_t last_maxq, int any_anomalous) {
     if (!c || (nregions && (!regions || !pk)) || (ngroups && !groups)) return BDX_EINVAL;
     if (c->stage < 2) return BDX_ESTATE;
-    decode_regions(c, (const RegionRec*)regions, pk, (uint32_t)nregions, 0);
+    decode_regions(c, (const RegionRec*)regions, pk, (uint32_t)nregions, 0, false);
     decode_groups(c, (const GroupRec*)groups, (uint32_t)ngroups, 0);
     c->counts.n_regions = (uint32_t)nregions;
-    return do_walk(c, last_maxq, any_anomalous != 0);
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = host_walk(c, last_maxq, any_anomalous != 0);
+    if (rc != BDX_OK) return rc;
+    const auto t1 = std::chrono::steady_clock::now();
+    rc = finish_walk(c, false);
+    c->stage_ms[5] = ms_between(t0, t1);
+    c->stage_ms[6] = ms_between(t1, std::chrono::steady_clock::now());
+    return rc;
 }
 
 int bdx_get_summary(const bdx_ctx* c, bdx_summary* o) {
     if (!c || !o) return BDX_EINVAL;
     if (!c->ran) return BDX_ESTATE;
     o->n_reads = c->n; o->n_anomalous = c->p1.n_anom; o->covered_ref_len = c->g_covered; o->window = c->g_window;
-    o->n_candidates = c->counts.n_cand; o->n_regions = (uint32_t)c->regions.size(); o->n_pairs = c->counts.n_pairs;
+    o->n_candidates = c->counts.n_cand; o->n_regions = (uint32_t)c->nreg; o->n_pairs = c->counts.n_pairs;
     o->n_groups = c->walk.n_groups; o->n_svs = (uint32_t)c->walk.svs.size(); o->n_svs_printed = c->n_printed;
     return BDX_OK;
 }
@@ -846,9 +1032,9 @@ int bdx_get_counters(const bdx_ctx* c, uint32_t* lib_read_count, uint32_t* bam_r
 int bdx_get_regions(const bdx_ctx* c, bdx_region* out, size_t cap) {
     if (!c || (!out && cap)) return BDX_EINVAL;
     if (!c->ran) return BDX_ESTATE;
-    const size_t n = std::min(cap, c->regions.size());
+    const size_t n = std::min(cap, c->nreg);
     for (size_t i = 0; i < n; ++i) {
-        const HostRegion& r = c->regions[i];
+        const HostRegion& r = c->reg[i];
         const int valid = c->opts.chr_restricted ? (int)r.nonctx : (int)r.n;
         out[i] = bdx_region{r.tid, r.start, r.end, (int32_t)r.nnormal, (int32_t)(r.n - r.rev), (int32_t)r.rev, (int32_t)r.n,
                             valid >= c->opts.min_read_pair ? 1 : 0, r.maxq};
@@ -899,6 +1085,21 @@ int bdx_get_read_class(const bdx_ctx* c, uint8_t* out, size_t cap) {
     if (!c->ran) return BDX_ESTATE;
     const size_t n = std::min(cap, c->n);
     if (n && hipMemcpy(out, c->b_cls.p, n, hipMemcpyDeviceToHost) != hipSuccess) return BDX_EHIP;
+    return BDX_OK;
+}
+
+int bdx_set_host_walk(bdx_ctx* c, int on) {
+    if (!c) return BDX_EINVAL;
+    c->host_walk_only = on != 0;
+    return BDX_OK;
+}
+
+int bdx_get_walk_split(const bdx_ctx* c, uint32_t* n_sv_device, uint32_t* n_sv_host, uint32_t* n_groups_host) {
+    if (!c) return BDX_EINVAL;
+    if (!c->ran) return BDX_ESTATE;
+    if (n_sv_device) *n_sv_device = c->counts.n_sv_dev;
+    if (n_sv_host) *n_sv_host = c->n_sv_host;
+    if (n_groups_host) *n_groups_host = c->counts.n_groups;
     return BDX_OK;
 }
 

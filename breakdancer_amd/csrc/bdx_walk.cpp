@@ -72,6 +72,7 @@ struct Walker {
     std::vector<OldVertex>& olds;
     std::vector<int>&tails, &newtails;
     int max_readlen = 0;
+    uint64_t cur_key = 0;  // order key of the traversal in progress
 
     Walker(const WalkInput& i, WalkScratch& s, WalkResult& o)
         : in(i), out(o), S(s), parts(s.parts), groups(s.groups), ghi(s.ghi), stored_(s.stored_), lib_acc_(s.lib_acc_),
@@ -83,7 +84,7 @@ struct Walker {
         auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
         const auto b0 = tnow();
         const std::vector<GroupPart>& src = *in.parts;
-        const uint32_t NR = (uint32_t)in.regions->size();
+        const uint32_t NR = (uint32_t)in.nregions;
         // counting sort by hi, then tiny insertion sorts inside each hi bucket
         std::vector<uint32_t>& cnt = S.cnt;
         cnt.assign(NR + 2, 0);
@@ -145,7 +146,7 @@ struct Walker {
     }
 
     bool stored(uint32_t r) const {  // ReadRegionData.cpp:118-121
-        const HostRegion& R = (*in.regions)[r];
+        const HostRegion& R = in.regions[r];
         const int valid = in.opts.chr_restricted ? (int)R.nonctx : (int)R.n;
         return valid >= in.opts.min_read_pair;
     }
@@ -161,7 +162,7 @@ struct Walker {
     }
 
     void process_sv(const int* snodes, int n) {
-        const std::vector<HostRegion>& R = *in.regions;
+        const HostRegion* R = in.regions;
         const bdx_opts& o = in.opts;
         const int A = snodes[0], B = n == 2 ? snodes[1] : -1;
         int num_pairs = 0;
@@ -252,11 +253,8 @@ struct Walker {
         sv.lib_begin = (int)out.lib_index.size(); sv.lib_count = nacc;
         sv.cn_begin = cn_begin; sv.cn_count = nkeys_present;
         sv.allele_frequency = allele_frequency; sv.logp = 0;
-        hs.term_begin = (uint32_t)out.terms.size();
-        hs.term_count = (uint32_t)nacc;
-        hs.ngrp = 0;
-        for (Group* g : gs)
-            if (g) { hs.grp_lo[hs.ngrp] = g->lo; hs.grp_hi[hs.ngrp] = g->hi; ++hs.ngrp; }
+        hs.grp_mask = (gs[0] ? 1u : 0u) | (gs[1] ? 2u : 0u) | (gs[2] ? 4u : 0u);
+        hs.start = (uint32_t)(cur_key & 0xffffffffu);
         for (int i = 0; i < nacc; ++i) {
             out.lib_index.push_back(la[i].lib);
             out.lib_pairs.push_back(la[i].rc);
@@ -266,6 +264,7 @@ struct Walker {
             out.terms.push_back(SvTerm{lambda, la[i].rc});
         }
         out.svs.push_back(hs);
+        out.sv_key.push_back(cur_key);
     }
 
     // ---- one flush (BreakDancer.cpp:266-346) over the groups with hi in (prev, last] ----------------------------
@@ -345,12 +344,17 @@ struct Walker {
             }
         }
         std::sort(olds.begin(), olds.end(), [](const OldVertex& a, const OldVertex& b) { return a.id < b.id; });
+        const uint64_t window = (uint64_t)(prev + 1) / (uint64_t)std::max<int64_t>(1, (int64_t)in.opts.buffer_size + 1);
         for (size_t i = 0; i < olds.size(); ++i)
-            if (!olds[i].visited) bfs_from((int)olds[i].id, prev);
+            if (!olds[i].visited) {
+                cur_key = sv_order_key(window, true, olds[i].id);
+                bfs_from((int)olds[i].id, prev);
+            }
         for (int64_t v = prev + 1; v <= last; ++v) {
             const size_t i = (size_t)(v - prev - 1);
             if (win_visited[i]) continue;
             if (ghi[v] == ghi[v + 1] && win_head[i] < 0) continue;  // not a vertex of this flush's graph
+            cur_key = sv_order_key(window, false, (uint32_t)v);
             bfs_from((int)v, prev);
         }
     }
@@ -361,9 +365,9 @@ struct Walker {
         build_groups();
         if (prof) fprintf(stderr, "[walk] build_groups %.1f us (parts %zu groups %zu regions %zu)\n",
                           std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp0).count(), in.parts->size(),
-                          groups.size(), in.regions->size());
-        const std::vector<HostRegion>& R = *in.regions;
-        const int64_t NR = (int64_t)R.size();
+                          groups.size(), in.nregions);
+        const HostRegion* R = in.regions;
+        const int64_t NR = (int64_t)in.nregions;
         if (!in.any_anomalous) return;
         const int64_t period = std::max<int64_t>(1, (int64_t)in.opts.buffer_size + 1);
         int64_t prev = -1;
@@ -396,24 +400,26 @@ void greedy_walk(const WalkInput& in, WalkScratch* scratch, WalkResult& out) {
 }
 
 // BreakDancer.cpp:56-84 (Kahan-compensated sum of the per-library log tails, optional Fisher) and :459-465
-void finish_scores(const WalkInput& in, const std::vector<double>& log_tail, WalkResult& out, uint32_t* n_printed) {
+void finish_scores(const bdx_opts& opts, const double* log_tail, HostSv* svs, size_t nsvs, uint32_t* n_printed) {
     uint32_t printed = 0;
-    for (HostSv& hs : out.svs) {
+    const double ln10 = std::log(10);
+    for (size_t q = 0; q < nsvs; ++q) {
+        HostSv& hs = svs[q];
         double logpvalue = 0.0, err = 0.0;
-        for (uint32_t i = 0; i < hs.term_count; ++i) {
-            const double tmp_a = log_tail[hs.term_begin + i] - err;
+        for (int32_t i = 0; i < hs.sv.lib_count; ++i) {
+            const double tmp_a = log_tail[hs.sv.lib_begin + i] - err;
             const double tmp_b = logpvalue + tmp_a;
             err = (tmp_b - logpvalue) - tmp_a;
             logpvalue = tmp_b;
         }
-        if (in.opts.fisher && logpvalue < 0) {
+        if (opts.fisher && logpvalue < 0) {
             const double x = -2 * logpvalue;
             if (std::isfinite(x)) {  // Boost's chi_squared cdf throws on a non-finite argument; the reference keeps logp
-                const double fisherP = chisq_upper_tail_int((int)hs.term_count, x / 2);
+                const double fisherP = chisq_upper_tail_int((int)hs.sv.lib_count, x / 2);
                 logpvalue = fisherP > std::exp(-99.0) ? std::log(fisherP) : -99;
             }
         }
-        const double phred_tmp = -10 * logpvalue / std::log(10);
+        const double phred_tmp = -10 * logpvalue / ln10;
         // int(NaN) is INT_MIN on x86-64 (cvttsd2si): the silent multi-library drop the reference exhibits (Q15)
         int phred;
         if (phred_tmp > 99) phred = 99;
@@ -421,7 +427,7 @@ void finish_scores(const WalkInput& in, const std::vector<double>& log_tail, Wal
         else phred = int(phred_tmp + 0.5);
         hs.sv.logp = logpvalue;
         hs.sv.score = phred;
-        hs.sv.printed = phred > in.opts.score_threshold;
+        hs.sv.printed = phred > opts.score_threshold;
         printed += hs.sv.printed;
     }
     *n_printed = printed;

@@ -8,10 +8,11 @@
 
 namespace bdx {
 
-struct HostRegion {
+struct HostRegion {  // same layout as the device's RegionRec (bdx_k3.h): the walk reads the table the kernels wrote
     int32_t tid, start, end;
     uint32_t n, rev, nonctx, nnormal;
     int32_t maxq;
+    uint32_t first;   // compact index of the region's first read
 };
 
 struct GroupPart {  // one (flag, lib) slice of a region x region group, as emitted by K4
@@ -26,12 +27,17 @@ struct SvTerm {  // one Poisson term to be scored by K5
     int32_t k;
 };
 
-struct HostSv {
-    bdx_sv sv;
-    uint32_t term_begin, term_count;  // into WalkResult::terms
-    uint32_t ngrp;                    // pair groups this SV consumed, (lo, hi) region ids
-    uint32_t grp_lo[3], grp_hi[3];
+struct HostSv {         // same layout as the device's SvOut (bdx_k3.h)
+    bdx_sv sv;            // its Poisson terms are WalkResult::terms[sv.lib_begin .. + sv.lib_count)
+    uint32_t grp_mask;    // pair groups this SV consumed: bit 0 (A,A), bit 1 (A,B), bit 2 (B,B) with A, B = sv.region[0..1]
+    uint32_t start;       // start vertex of the traversal that emitted it
 };
+
+// output order of the reference's walk: flush windows ascending; inside a window first the traversals started from
+// vertices of earlier windows (ascending id), then the window's own vertices ascending
+inline uint64_t sv_order_key(uint64_t window, bool old_vertex, uint32_t start) {
+    return (window << 33) | (old_vertex ? 0ull : 1ull << 32) | start;
+}
 
 struct WalkInput {
     bdx_opts opts;
@@ -40,7 +46,8 @@ struct WalkInput {
     const uint32_t* hist;        // [nlibs][11]
     uint32_t covered_ref_len;
     const float* key_density;    // [nkeys] read density per counter key
-    const std::vector<HostRegion>* regions;
+    const HostRegion* regions;
+    size_t nregions;
     const uint32_t* r_pk;        // [nregions][2*nkeys]: prefix counts at first read (nkeys), at last read (nkeys)
     const std::vector<GroupPart>* parts;
     int32_t last_maxq;           // _max_readlen at the final flush
@@ -49,13 +56,14 @@ struct WalkInput {
 
 struct WalkResult {
     std::vector<HostSv> svs;
+    std::vector<uint64_t> sv_key;  // sv_order_key of every entry of svs
     std::vector<SvTerm> terms;
     std::vector<int32_t> lib_index, lib_pairs;
     std::vector<int32_t> cn_key;
     std::vector<float> cn_value;
     uint32_t n_groups = 0;
     void clear() {
-        svs.clear(); terms.clear(); lib_index.clear(); lib_pairs.clear(); cn_key.clear(); cn_value.clear();
+        svs.clear(); sv_key.clear(); terms.clear(); lib_index.clear(); lib_pairs.clear(); cn_key.clear(); cn_value.clear();
         n_groups = 0;
     }
 };
@@ -68,6 +76,6 @@ void walk_scratch_free(WalkScratch* s);
 void greedy_walk(const WalkInput& in, WalkScratch* scratch, WalkResult& out);
 
 // combine the per-library log tails into the final score exactly as ComputeProbScore does
-void finish_scores(const WalkInput& in, const std::vector<double>& log_tail, WalkResult& out, uint32_t* n_printed);
+void finish_scores(const bdx_opts& opts, const double* log_tail, HostSv* svs, size_t nsvs, uint32_t* n_printed);
 
 }  // namespace bdx

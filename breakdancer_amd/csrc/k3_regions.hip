@@ -100,9 +100,12 @@ struct AcceptOut {
         rr.maxq = a.c_maxq[c];
         rr.first = f;
         a.r_rec[r] = rr;
+        if (a.r_rec_dev) a.r_rec_dev[r] = rr;
         for (int k = 0; k < nkeys; ++k) {
-            a.r_pk[(size_t)r * 2 * nkeys + k] = cp.pk[(size_t)k * cp.cap + f];
-            a.r_pk[(size_t)r * 2 * nkeys + nkeys + k] = cp.pk[(size_t)k * cp.cap + l];
+            const uint32_t pf = cp.pk[(size_t)k * cp.cap + f], pl = cp.pk[(size_t)k * cp.cap + l];
+            a.r_pk[(size_t)r * 2 * nkeys + k] = pf;
+            a.r_pk[(size_t)r * 2 * nkeys + nkeys + k] = pl;
+            if (a.r_pk_dev) { a.r_pk_dev[(size_t)r * 2 * nkeys + k] = pf; a.r_pk_dev[(size_t)r * 2 * nkeys + nkeys + k] = pl; }
         }
     }
 };
@@ -110,7 +113,10 @@ struct AcceptOut {
 
 __global__ __launch_bounds__(256) void k3_region_of_kernel(K3Arrays a, const Pass1* p1) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < p1->n_anom) a.region_of[j] = a.c_rid[a.cand[j]];
+    if (j < p1->n_anom) {
+        a.region_of[j] = a.c_rid[a.cand[j]];
+        if (a.out_deg) a.out_deg[j] = 0;
+    }
 }
 
 void launch_k3(const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n_anom_host, int min_len, int seq_coverage_lim,

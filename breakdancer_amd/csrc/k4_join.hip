@@ -219,7 +219,8 @@ __global__ __launch_bounds__(256) void k4_aggregate_kernel(K4Arrays k4, Entries 
     }
 }
 
-void launch_k4(const K4Arrays& k4, const Entries& en, const uint32_t* n_ptr, uint32_t n_anom_host, StageCounts* counts, hipStream_t s) {
+static void launch_k4_impl(const K4Arrays& k4, const Entries& en, const uint32_t* n_ptr, uint32_t n_anom_host, StageCounts* counts,
+                           hipStream_t s, bool aggregate) {
     if (n_anom_host == 0) return;
     const uint32_t g = (n_anom_host + kPartChunk - 1) / kPartChunk;
     // bcnt is zero on entry (zeroed at allocation, then by every bucket scan); partner[] needs no initialisation: the join
@@ -234,7 +235,16 @@ void launch_k4(const K4Arrays& k4, const Entries& en, const uint32_t* n_ptr, uin
         attr_set = true;
     }
     hipLaunchKernelGGL(k4_join_kernel, dim3(k4.nbuckets), dim3(256), (size_t)kJoinLdsSlots * 12, s, k4, counts);
-    hipLaunchKernelGGL(k4_aggregate_kernel, dim3(g), dim3(256), (size_t)kAggSlots * 16 + 32, s, k4, en, n_ptr, counts);
+    if (aggregate) hipLaunchKernelGGL(k4_aggregate_kernel, dim3(g), dim3(256), (size_t)kAggSlots * 16 + 32, s, k4, en, n_ptr, counts);
+}
+
+void launch_k4(const K4Arrays& k4, const Entries& en, const uint32_t* n_ptr, uint32_t n_anom_host, StageCounts* counts, hipStream_t s) {
+    launch_k4_impl(k4, en, n_ptr, n_anom_host, counts, s, true);
+}
+// mate join only: the pair groups are then formed per region by K6 (single-context runs, where region ids follow the stream)
+void launch_k4_join_only(const K4Arrays& k4, const Entries& en, const uint32_t* n_ptr, uint32_t n_anom_host, StageCounts* counts,
+                         hipStream_t s) {
+    launch_k4_impl(k4, en, n_ptr, n_anom_host, counts, s, false);
 }
 
 }  // namespace bdx

@@ -175,9 +175,17 @@ int bdx_get_sv_support(const bdx_ctx* ctx, uint32_t* sv_offsets, uint64_t* read_
 int bdx_get_read_class(const bdx_ctx* ctx, uint8_t* out, size_t cap);
 
 /* stage timings of the last bdx_run in milliseconds (HIP events on the context's stream):
- * [0] classify kernel, [1] compaction, [2] region cut, [3] mate join + grouping, [4] device->host,
- * [5] host walk, [6] score kernel + readback, [7] whole run.  Returns the number written. */
+ * [0] classify kernel, [1] compaction, [2] region cut, [3] mate join + grouping + SV assembly + scores on the device,
+ * [4] host: wait for the host's share of the groups, [5] host walk of that share, [6] host: final wait, merge, score
+ * combination, [7] whole run.  Returns the number written. */
 int bdx_get_timings(const bdx_ctx* ctx, float* ms, int cap);
+
+/* Where the SV candidates of the last bdx_run were assembled.  Components of the region graph that are one region, or
+ * two regions of one flush window joined by one connection, are walked on the device (build_connection /
+ * process_sv, BreakDancer.cpp:266-497); every other component goes through the host walk.  bdx_set_host_walk(ctx, 1)
+ * sends everything through the host walk (same results; used by the parity tests).  Any pointer may be NULL. */
+int bdx_set_host_walk(bdx_ctx* ctx, int on);
+int bdx_get_walk_split(const bdx_ctx* ctx, uint32_t* n_sv_device, uint32_t* n_sv_host, uint32_t* n_groups_host);
 
 /* Kernel-level entry points for parity tests.
  * bdx_classify replaces IAlignmentClassifier::classify (io/IlluminaPEReadClassifier.cpp:59-101) plus the

@@ -26,7 +26,7 @@ def product_options(opts):
                    chr="x" if opts["chr_tid"] >= 0 else "")
 
 
-def product_from_oracle(run, device=0, support=False):
+def product_from_oracle(run, device=0, support=False, host_walk=False):
     """Feed the product the exact merged stream the oracle consumed (the producer's job in the CLI)."""
     libs = [LibraryConfig(*[float(x) for x in run.lib_f[i]], min_mapping_quality=int(run.lib_i[i, 0]),
                           bam_file_index=int(run.lib_i[i, 1]), name=run.lib_names[i]) for i in range(run.nlibs)]
@@ -34,6 +34,8 @@ def product_from_oracle(run, device=0, support=False):
     soa = run.merged_soa()
     if support:
         bd.collect_support()
+    if host_walk:
+        bd.set_host_walk(True)
     if run.n_merged:
         bd.push_reads(soa)
     bd.run()

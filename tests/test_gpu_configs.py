@@ -92,3 +92,43 @@ def test_many_files_and_libraries_take_the_general_paths():
         run = oracle_from_soa(d, cfg, bams, make_opts(**kw), ["c1"])
         assert run.nlibs == nb and run.nbams == nb and run.n_svs > 50
         compare(run, product_from_oracle(run))
+
+
+SPLIT_SETS = [dict(), dict(buffer_size=1), dict(buffer_size=2), dict(buffer_size=7, min_read_pair=1), dict(min_read_pair=3),
+              dict(min_read_pair=4, cn_lib=1, print_af=1), dict(fisher=1), dict(chr_tid=1), dict(transchr_rearrange=1),
+              dict(min_len=30, seq_coverage_lim=3), dict(max_sd=900), dict(illumina_long_insert=1)]
+
+
+@pytest.mark.parametrize("kw", SPLIT_SETS)
+def test_device_assembly_and_host_walk_agree_with_the_oracle(kw):
+    """The SV candidates of simple components are assembled on the device (K6), the rest by the host walk; forcing
+    everything through the host walk must give the same rows, and both must equal the oracle's."""
+    from breakdancer_amd.synth import make_genome
+    libs = ((400.0, 30.0), (330.0, 25.0), (480.0, 45.0))
+    d = make_genome([2_500_000, 2_000_000, 1_500_000], coverage=24.0, seed=21, libs=libs, lib_bam=(0, 1, 1), n_translocations=120)
+    cfg = cfg_line("rgA", "a.bam", "libA", *libs[0]) + cfg_line("rgB", "b.bam", "libB", *libs[1]) + cfg_line("rgC", "b.bam", "libC", *libs[2])
+    run = oracle_from_soa(d, cfg, ["a.bam", "b.bam"], make_opts(score_threshold=-1, **kw), ["c1", "c2", "c3"])
+    assert run.n_svs > 10
+    bd = product_from_oracle(run)
+    compare(run, bd)
+    n_dev, n_host, _ = bd.walk_split()
+    assert n_dev > 0 and n_dev + n_host == run.n_svs, (n_dev, n_host, run.n_svs)
+    bd.close()
+    bh = product_from_oracle(run, host_walk=True)
+    compare(run, bh)
+    assert bh.walk_split()[0] == 0
+    bh.close()
+
+
+def test_regions_larger_than_a_wave_go_through_the_host_walk():
+    """clusters of 90 pairs: regions with more than 64 reads are not sorted in registers; their groups reach the host
+    walk in pieces and are merged there"""
+    from breakdancer_amd.synth import make_chromosome
+    d = make_chromosome(length=3_000_000, coverage=30.0, seed=5, cluster=90, discordant=0.03)
+    cfg = cfg_line("rg0", "wgs.bam", "lib0", 400.0, 30.0)
+    run = oracle_from_soa(d, cfg, ["wgs.bam"], make_opts(score_threshold=-1), ["c1"])
+    assert run.n_svs > 50 and int(run.regions[:, 7].max()) > 64
+    bd = product_from_oracle(run)
+    compare(run, bd)
+    assert bd.walk_split()[1] > 0
+    bd.close()
