@@ -124,6 +124,7 @@ struct bdx_ctx {
     WalkScratch* walk_scratch = nullptr;
     uint32_t n_printed = 0;
     uint32_t n_sv_host = 0;
+    uint32_t join_table_clean = 0;    // slots of the direct join table already set to -1 (by K2), 0 = none
     float stage_ms[kNumStages] = {0};
     hipEvent_t ev[8] = {nullptr};
 };
@@ -360,11 +361,22 @@ int do_pass1(bdx_ctx* c) {
     HIPCHK(c, c->h_cnt.ensure((size_t)ncnt * 4));
     HIPCHK(c, c->h_counts.ensure(sizeof(StageCounts)));
     HIPCHK(c, c->b_counts.ensure(sizeof(StageCounts)));
-    HIPCHK(c, hipMemsetAsync(c->b_tile_tot.p, 0, (size_t)ncols * tstride * 4, s));
-    HIPCHK(c, hipMemsetAsync(c->b_tile_mono.p, 0xFF, (size_t)nbams * tstride * sizeof(MonoRec), s));
-    HIPCHK(c, hipMemsetAsync(c->b_blk_cnt.p, 0, (size_t)kCntCopies * ncnt * 4, s));
-    HIPCHK(c, hipMemsetAsync(c->b_p1.p, 0, sizeof(Pass1), s));
-    HIPCHK(c, hipMemsetAsync(c->b_counts.p, 0, sizeof(StageCounts), s));
+    {
+        const size_t w_tot = (size_t)ncols * tstride, w_mono = (size_t)nbams * tstride * sizeof(MonoRec) / 4;
+        if (w_tot > 0xFFFFFFFFull || w_mono > 0xFFFFFFFFull) {  // beyond the init kernel's 32-bit word counts
+            HIPCHK(c, hipMemsetAsync(c->b_tile_tot.p, 0, w_tot * 4, s));
+            HIPCHK(c, hipMemsetAsync(c->b_tile_mono.p, 0xFF, w_mono * 4, s));
+        }
+        InitList il{};
+        int k = 0;
+        auto add = [&](void* p, size_t words, uint32_t value) { il.ptr[k] = (uint32_t*)p; il.words[k] = (uint32_t)words; il.value[k] = value; ++k; };
+        if (w_tot <= 0xFFFFFFFFull && w_mono <= 0xFFFFFFFFull) { add(c->b_tile_tot.p, w_tot, 0u); add(c->b_tile_mono.p, w_mono, 0xFFFFFFFFu); }
+        add(c->b_blk_cnt.p, (size_t)kCntCopies * ncnt, 0u);
+        add(c->b_p1.p, sizeof(Pass1) / 4, 0u);
+        add(c->b_counts.p, sizeof(StageCounts) / 4, 0u);
+        il.n = k;
+        launch_init(il, s);
+    }
 
     HIPCHK(c, hipEventRecord(c->ev[0], s));
     K1Params k1{};
@@ -384,9 +396,9 @@ int do_pass1(bdx_ctx* c) {
     fp.nlibs = nlibs; fp.nbams = nbams; fp.nkeys = nkeys; fp.ncols = ncols; fp.ncnt = ncnt; fp.w0 = c->w0;
     fp.tile_tot = k1.tile_tot; fp.tile_pre = c->b_tile_pre.as<uint32_t>(); fp.tile_mono = k1.tile_mono;
     fp.blk_cnt = k1.blk_cnt; fp.cnt = c->b_cnt.as<uint32_t>(); fp.p1 = c->b_p1.as<Pass1>();
+    fp.cnt_host = c->h_cnt.as<uint32_t>(); fp.p1_host = c->h_p1.as<Pass1>();  // written by the kernel: no copy commands
+    memset(c->h_p1.p, 0, sizeof(Pass1));
     launch_finalize(fp, s);
-    HIPCHK(c, hipMemcpyAsync(c->h_p1.p, c->b_p1.p, sizeof(Pass1), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(c->h_cnt.p, c->b_cnt.p, (size_t)ncnt * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, hipGetLastError());
     c->p1 = *c->h_p1.as<Pass1>();
@@ -447,7 +459,7 @@ int set_pass1(bdx_ctx* c, const uint32_t* cnt, uint32_t covered, int32_t window,
 }
 
 // K2: compact anomalous reads (prefix counters offset by the bases of earlier shards)
-int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base) {
+int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepare_join) {
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const int nkeys = c->nkeys;
@@ -473,6 +485,18 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base) {
         k2.cls = c->b_cls.as<uint8_t>(); k2.tile_pre = c->b_tile_pre.as<uint32_t>(); k2.c = cp;
         k2.nn_base = nn_base;
         for (int k = 0; k < nkeys; ++k) k2.pk_base[k] = pk_base ? pk_base[k] : 0u;
+        // scratch of the later stages cleared by this launch: the per-candidate max read length of K3, and (when this
+        // context joins its own reads) the slot indices of K4's direct table
+        HIPCHK(c, c->b_c_maxq.ensure(cap * 4));
+        k2.fill_ptr[0] = c->b_c_maxq.as<uint32_t>(); k2.fill_words[0] = na; k2.fill_value[0] = 0u;
+        c->join_table_clean = 0;
+        if (prepare_join && na <= kDirectJoinMax) {
+            uint32_t slots = 1024;
+            while (slots < 2 * na) slots <<= 1;
+            HIPCHK(c, c->b_t_key.ensure((size_t)slots * 8)); HIPCHK(c, c->b_t_idx.ensure((size_t)slots * 4));
+            k2.fill_ptr[1] = c->b_t_idx.as<uint32_t>(); k2.fill_words[1] = slots; k2.fill_value[1] = 0xFFFFFFFFu;
+            c->join_table_clean = slots;
+        }
         launch_k2(k2, k2_lds_bytes(nkeys), s);
     }
     HIPCHK(c, hipEventRecord(c->ev[3], s));
@@ -533,6 +557,24 @@ int do_join_local(bdx_ctx* c, uint32_t n, const Entries& en, const uint32_t* n_p
     K4Arrays& k4 = c->k4;
     k4 = K4Arrays{};
     if (!n) return BDX_OK;
+    k4.g_cap = n / 2 + 1;
+    HIPCHK(c, c->h_groups.ensure((size_t)k4.g_cap * sizeof(GroupRec)));
+    HIPCHK(c, c->b_partner.ensure((size_t)n * 4));
+    k4.partner = c->b_partner.as<int32_t>(); k4.g_rec = c->h_groups.as<GroupRec>();
+    if (n <= kDirectJoinMax) {
+        uint32_t slots = 1024;
+        while (slots < 2 * n) slots <<= 1;
+        if (c->join_table_clean != slots) {
+            HIPCHK(c, c->b_t_key.ensure((size_t)slots * 8)); HIPCHK(c, c->b_t_idx.ensure((size_t)slots * 4));
+            HIPCHK(c, hipMemsetAsync(c->b_t_idx.p, 0xFF, (size_t)slots * 4, s));
+        }
+        c->join_table_clean = 0;
+        k4.direct = 1; k4.t_mask = slots - 1;
+        k4.t_key = c->b_t_key.as<uint64_t>(); k4.t_idx = c->b_t_idx.as<int32_t>();
+        if (join_only) launch_k4_join_only(k4, en, n_ptr, n, c->b_counts.as<StageCounts>(), s);
+        else launch_k4(k4, en, n_ptr, n, c->b_counts.as<StageCounts>(), s);
+        return BDX_OK;
+    }
     uint32_t nb = 1, lg = 0;
     while (nb < (uint32_t)kMaxBuckets && (size_t)nb * 384 < n) { nb <<= 1; ++lg; }  // ~256-512 entries per bucket: >= 1 workgroup per CU early
     k4.nbuckets = nb; k4.log2b = lg;
@@ -542,13 +584,10 @@ int do_join_local(bdx_ctx* c, uint32_t n, const Entries& en, const uint32_t* n_p
     }
     HIPCHK(c, c->b_boff.ensure((nb + 1) * 4)); HIPCHK(c, c->b_bcur.ensure(nb * 4));
     HIPCHK(c, c->b_e_key.ensure((size_t)n * 8)); HIPCHK(c, c->b_e_idx.ensure((size_t)n * 4));
-    HIPCHK(c, c->b_partner.ensure((size_t)n * 4));
     HIPCHK(c, c->b_t_key.ensure((size_t)n * 16)); HIPCHK(c, c->b_t_idx.ensure((size_t)n * 8));
-    k4.g_cap = n / 2 + 1;
-    HIPCHK(c, c->h_groups.ensure((size_t)k4.g_cap * sizeof(GroupRec)));
     k4.bcnt = c->b_bcnt.as<uint32_t>(); k4.boff = c->b_boff.as<uint32_t>(); k4.bcur = c->b_bcur.as<uint32_t>();
-    k4.e_key = c->b_e_key.as<uint64_t>(); k4.e_idx = c->b_e_idx.as<uint32_t>(); k4.partner = c->b_partner.as<int32_t>();
-    k4.t_key = c->b_t_key.as<uint64_t>(); k4.t_idx = c->b_t_idx.as<int32_t>(); k4.g_rec = c->h_groups.as<GroupRec>();
+    k4.e_key = c->b_e_key.as<uint64_t>(); k4.e_idx = c->b_e_idx.as<uint32_t>();
+    k4.t_key = c->b_t_key.as<uint64_t>(); k4.t_idx = c->b_t_idx.as<int32_t>();
     if (join_only) launch_k4_join_only(k4, en, n_ptr, n, c->b_counts.as<StageCounts>(), s);
     else launch_k4(k4, en, n_ptr, n, c->b_counts.as<StageCounts>(), s);
     return BDX_OK;
@@ -810,7 +849,7 @@ int bdx_run(bdx_ctx* c) {
     if (rc != BDX_OK) return rc;
     rc = set_pass1(c, c->cnt_local.data(), c->p1.covered_ref_len, c->p1.window, false);
     if (rc != BDX_OK) return rc;
-    rc = do_compact(c, 0, nullptr);
+    rc = do_compact(c, 0, nullptr, true);
     if (rc != BDX_OK) return rc;
     rc = do_cut(c, 0, 0, 0, true);
     if (rc != BDX_OK) return rc;
@@ -895,7 +934,7 @@ int bdx_stage_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, int
     if (!c) return BDX_EINVAL;
     if (c->stage < 2) return BDX_ESTATE;
     if (c->opts.min_len < 0) return fail(c, BDX_ELIMIT, "staged runs do not support a negative -s");
-    int rc = do_compact(c, nn_base, pk_base);
+    int rc = do_compact(c, nn_base, pk_base, false);
     if (rc != BDX_OK) return rc;
     if (first_qlen) *first_qlen = 0;
     if (first_nn) *first_nn = 0;

@@ -72,7 +72,18 @@ struct FinalizeParams {
     const uint32_t* blk_cnt;
     uint32_t* cnt;              // [ncnt] reduced counters
     Pass1* p1;
+    uint32_t* cnt_host;         // pinned host mirrors written by the last kernel (no copy command on the stream); may be null
+    Pass1* p1_host;
 };
+
+// one launch that sets several scratch buffers to their start values (replaces a chain of small fill commands)
+struct InitList {
+    uint32_t* ptr[6];
+    uint32_t words[6];
+    uint32_t value[6];
+    int n;
+};
+void launch_init(const InitList& l, hipStream_t s);
 
 // compact anomalous-read records (one per read entering the region accumulator)
 struct Compact {
@@ -98,6 +109,10 @@ struct K2Params {
     Compact c;
     uint32_t nn_base;      // normal read pairs / proper reads of earlier shards (0 for a single context)
     uint32_t pk_base[60];
+    // initialisation of later stages' scratch folded into this launch (its grid is large and mostly idle)
+    uint32_t* fill_ptr[2];
+    uint32_t fill_words[2];
+    uint32_t fill_value[2];
 };
 
 __device__ __forceinline__ uint32_t meta_pack(int flag, int rev, int lib, int qlen) {

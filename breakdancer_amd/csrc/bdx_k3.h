@@ -74,6 +74,7 @@ void launch_k3(const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n
 // ---- K4 ---------------------------------------------------------------------------------------------
 constexpr int kMaxBuckets = 8192;
 constexpr int kJoinLdsSlots = 8192;  // 8192 x (8 B key + 4 B index) = 96 KiB of the CU's 160 KiB LDS
+constexpr uint32_t kDirectJoinMax = 1u << 22;  // entries up to which the direct table (<= 96 MiB) is used
 constexpr int kAggSlots = 4096;      // block-local group table: 4096 x 16 B = 64 KiB
 
 struct K4Arrays {
@@ -85,8 +86,10 @@ struct K4Arrays {
     uint64_t* e_key;     // [cap] bucketed entries
     uint32_t* e_idx;     // [cap]
     int32_t* partner;    // [cap] compact index of the mate, -1 if none
-    uint64_t* t_key;     // [2*cap] global fallback table
-    int32_t* t_idx;      // [2*cap]
+    uint64_t* t_key;     // [2*cap] global fallback table of the bucketed path; [t_mask + 1] table of the direct path
+    int32_t* t_idx;
+    uint32_t direct;     // 1: one open-addressing table for all entries (it stays in L2 / Infinity Cache), no partitioning
+    uint32_t t_mask;     // direct path: slots - 1 (slots = power of two >= 2 x entries); t_idx must be all -1 on entry
     // output: partial aggregates of (r_lo, r_hi, flag, lib) -> (pairs, sum |isize|)
     GroupRec* g_rec;
     uint32_t g_cap;

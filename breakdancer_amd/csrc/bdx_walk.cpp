@@ -306,18 +306,24 @@ struct Walker {
         return !ov || ov->visited;
     }
 
+    size_t prof_hist[8] = {0}, prof_old = 0;
+    bool prof_on = false;
     void bfs_from(int v, int64_t prev) {
         tails.clear();
         tails.push_back(v);
+        size_t nv = 0;
+        const size_t sv0 = out.svs.size();
         while (!tails.empty()) {
             newtails.clear();
             for (size_t i = 0; i < tails.size(); ++i) {
                 const int tail = tails[i];
                 if (is_visited(tail, prev)) continue;
                 visit(tail, prev);
+                ++nv;
             }
             tails.swap(newtails);
         }
+        if (prof_on && out.svs.size() > sv0) { prof_hist[std::min<size_t>(nv, 7)] += out.svs.size() - sv0; if (v <= prev) prof_old += out.svs.size() - sv0; }
     }
 
     void flush(int64_t prev, int64_t last) {
@@ -361,6 +367,7 @@ struct Walker {
 
     void run() {
         const bool prof = getenv("BDX_WALK_PROFILE") != nullptr;
+        prof_on = prof;
         const auto tp0 = std::chrono::steady_clock::now();
         build_groups();
         if (prof) fprintf(stderr, "[walk] build_groups %.1f us (parts %zu groups %zu regions %zu)\n",
@@ -378,6 +385,8 @@ struct Walker {
         }
         max_readlen = in.last_maxq;
         flush(prev, NR - 1);
+        if (prof) fprintf(stderr, "[walk] SVs by vertices visited in their traversal: 1:%zu 2:%zu 3:%zu 4:%zu 5:%zu 6:%zu 7+:%zu (from old vertices %zu)\n",
+                          prof_hist[1], prof_hist[2], prof_hist[3], prof_hist[4], prof_hist[5], prof_hist[6], prof_hist[7], prof_old);
         if (prof) fprintf(stderr, "[walk] total %.1f us, svs %zu\n",
                           std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp0).count(), out.svs.size());
     }

@@ -12,6 +12,8 @@
 // totals come from ballots + popcounts, the pass-1 counters are privatised in LDS and written once per
 // workgroup, and the per-file reference-length monoid of each tile goes to a plain per-tile table that a tiny
 // follow-up kernel folds in order.
+#include <cstddef>
+
 #include "bdx_dev.h"
 
 #include <limits.h>
@@ -399,21 +401,34 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(const FinalizeParam
 __global__ __launch_bounds__(256) void finalize2_kernel(const FinalizeParams p) {
     __shared__ uint32_t s_acc[255 * 12 + 256];  // nlibs*11 + nlibs + nbams at the documented limits
     __shared__ unsigned long long s_ref[256];
-    const int t = threadIdx.x;
-    for (int i = t; i < p.ncnt; i += 256) {  // counters: [kCntCopies][ncnt] -> [ncnt]
-        uint32_t acc = 0;
-#pragma unroll 8
-        for (int c = 0; c < kCntCopies; ++c) acc += p.blk_cnt[(size_t)c * p.ncnt + i];
-        s_acc[i] = acc;
-        p.cnt[i] = acc;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    static_assert(kCntCopies == 64, "one lane per counter copy");
+    for (int i0 = 0; i0 < p.ncnt; i0 += 4) {  // counters: [kCntCopies][ncnt] -> [ncnt], one wave per counter
+        const int i = i0 + w;
+        uint32_t v = i < p.ncnt ? p.blk_cnt[(size_t)lane * p.ncnt + i] : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0 && i < p.ncnt) {
+            s_acc[i] = v;
+            p.cnt[i] = v;
+            if (p.cnt_host) p.cnt_host[i] = v;
+        }
     }
-    for (int b = t; b < p.nbams; b += 256) {
-        MonoRec tot;
-        tot.ft = -1; tot.fp = 0; tot.lt = 0; tot.lp = 0; tot.sum = 0;
-        for (uint32_t f = 0; f < p.nfold; ++f) tot = mono_combine(tot, p.fold_part[(size_t)b * p.nfold + f]);
-        const unsigned long long r = tot.ft == -1 ? 0ull : (unsigned long long)tot.sum;  // size_t ref_len, wraps like the reference
-        s_ref[b] = r;
-        p.p1->ref_len[b] = r;
+    for (int b0 = 0; b0 < p.nbams; b0 += 4) {  // one wave per source file: ordered tree fold of its <= 64 partial folds
+        const int b = b0 + w;
+        MonoRec acc;
+        acc.ft = -1; acc.fp = 0; acc.lt = 0; acc.lp = 0; acc.sum = 0;
+        if (b < p.nbams && (uint32_t)lane < p.nfold) acc = p.fold_part[(size_t)b * p.nfold + lane];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const MonoRec other = mono_shfl_down(acc, o);
+            if (lane + o < 64 && ((lane & (2 * o - 1)) == 0)) acc = mono_combine(acc, other);
+        }
+        if (lane == 0 && b < p.nbams) {
+            const unsigned long long r = acc.ft == -1 ? 0ull : (unsigned long long)acc.sum;  // size_t ref_len, wraps like the reference
+            s_ref[b] = r;
+            p.p1->ref_len[b] = r;
+        }
     }
     __syncthreads();
     if (t == 0) {
@@ -429,6 +444,27 @@ __global__ __launch_bounds__(256) void finalize2_kernel(const FinalizeParams p) 
         }
         p.p1->window = W;
     }
+    if (p.p1_host) {  // mirror the finished record into pinned host memory
+        __threadfence();
+        __syncthreads();
+        const uint32_t* src = (const uint32_t*)p.p1;
+        uint32_t* dst = (uint32_t*)p.p1_host;
+        const int words = (int)((offsetof(Pass1, ref_len) + sizeof(unsigned long long) * (size_t)p.nbams) / 4);
+        for (int i = t; i < words; i += 256) dst[i] = __builtin_nontemporal_load(src + i);
+    }
+}
+
+__global__ __launch_bounds__(256) void k0_init_kernel(const InitList l) {
+    for (int f = 0; f < l.n; ++f)
+        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < l.words[f]; i += gridDim.x * 256) l.ptr[f][i] = l.value[f];
+}
+
+void launch_init(const InitList& l, hipStream_t s) {
+    uint32_t mx = 0;
+    for (int f = 0; f < l.n; ++f) mx = l.words[f] > mx ? l.words[f] : mx;
+    if (!mx) return;
+    const uint32_t g = (mx + 1023) / 1024;
+    hipLaunchKernelGGL(k0_init_kernel, dim3(g < 1024u ? g : 1024u), dim3(256), 0, s, l);
 }
 
 void launch_finalize(const FinalizeParams& p, hipStream_t s) {

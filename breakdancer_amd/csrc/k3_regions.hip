@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void k3_region_of_kernel(K3Arrays a, const Pas
 void launch_k3(const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n_anom_host, int min_len, int seq_coverage_lim,
                int nkeys, uint32_t nn_base, K3Tail tail, hipStream_t s) {
     if (n_anom_host == 0) return;
-    (void)hipMemsetAsync(a.c_maxq, 0, (size_t)n_anom_host * 4, s);
+    // a.c_maxq[0 .. n_anom) must be zero on entry (K2 clears it while compacting)
     const uint32_t* n_ptr = &p1->n_anom;
     HeadIn hin{cp.tid, cp.pos, cp.meta, p1};
     HeadOut hout{a};

@@ -152,6 +152,39 @@ __global__ __launch_bounds__(256) void k4_join_kernel(K4Arrays k4, StageCounts* 
     }
 }
 
+// Direct path: every entry claims a slot of one table (phase A), a second launch finds the mates (phase B).  At the
+// sizes of one chromosome the table (12 B per slot, load <= 0.5) lives in L2 / Infinity Cache, and the three
+// partitioning launches of the bucketed path are not worth their latency.
+__global__ __launch_bounds__(256) void k4_direct_insert_kernel(K4Arrays k4, Entries en, const uint32_t* n_ptr, StageCounts* counts) {
+    const uint32_t na = *n_ptr;
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= na || en.region[j] < 0) return;
+    const uint64_t key = en.key[j];
+    uint32_t s = (uint32_t)mix64(key) & k4.t_mask;
+    uint32_t probes = 0;
+    while (atomicCAS(&k4.t_idx[s], -1, (int32_t)j) != -1) {
+        s = (s + 1) & k4.t_mask;
+        if (++probes > kMaxProbes) { counts->overflow = 2; return; }
+    }
+    k4.t_key[s] = key;
+}
+
+__global__ __launch_bounds__(256) void k4_direct_probe_kernel(K4Arrays k4, Entries en, const uint32_t* n_ptr) {
+    const uint32_t na = *n_ptr;
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= na || en.region[j] < 0) return;
+    const uint64_t key = en.key[j];
+    uint32_t s = (uint32_t)mix64(key) & k4.t_mask;
+    int32_t mate = -1;
+    for (uint32_t probes = 0; probes <= kMaxProbes; ++probes) {
+        const int32_t o = k4.t_idx[s];
+        if (o == -1) break;
+        if (o != (int32_t)j && k4.t_key[s] == key) { mate = o; break; }
+        s = (s + 1) & k4.t_mask;
+    }
+    k4.partner[j] = mate;
+}
+
 constexpr uint64_t kEmptyGroup = ~0ull;
 
 __global__ __launch_bounds__(256) void k4_aggregate_kernel(K4Arrays k4, Entries en, const uint32_t* n_ptr, StageCounts* counts) {
@@ -223,6 +256,16 @@ static void launch_k4_impl(const K4Arrays& k4, const Entries& en, const uint32_t
                            hipStream_t s, bool aggregate) {
     if (n_anom_host == 0) return;
     const uint32_t g = (n_anom_host + kPartChunk - 1) / kPartChunk;
+    if (k4.direct) {
+        const uint32_t gd = (n_anom_host + 255) / 256;
+        hipLaunchKernelGGL(k4_direct_insert_kernel, dim3(gd), dim3(256), 0, s, k4, en, n_ptr, counts);
+        hipLaunchKernelGGL(k4_direct_probe_kernel, dim3(gd), dim3(256), 0, s, k4, en, n_ptr);
+        if (aggregate) {
+            (void)hipFuncSetAttribute((const void*)k4_aggregate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kAggSlots * 16 + 32);
+            hipLaunchKernelGGL(k4_aggregate_kernel, dim3(g), dim3(256), (size_t)kAggSlots * 16 + 32, s, k4, en, n_ptr, counts);
+        }
+        return;
+    }
     // bcnt is zero on entry (zeroed at allocation, then by every bucket scan); partner[] needs no initialisation: the join
     // kernel writes the entry of every read of an accepted region and nothing else is ever read
     hipLaunchKernelGGL(k4_count_kernel, dim3(g), dim3(256), (size_t)k4.nbuckets * 4, s, k4, en, n_ptr);
