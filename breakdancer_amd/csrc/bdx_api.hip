@@ -90,6 +90,7 @@ struct bdx_ctx {
     PinBuf h_p1, h_cnt, h_counts, h_regs, h_pk, h_groups, h_terms;
     PinBuf h_counts0, h_counts2, h_sv_out, h_lib_index, h_lib_pairs, h_cn_key, h_cn_value, h_ltail_dev, h_k6const;
     hipEvent_t ev_groups = nullptr, ev_regions = nullptr;
+    bool bucketed_join = false;       // BDX_BUCKETED_JOIN=1: use the partitioned LDS join at every size (it is the path for > 4 M entries)
     bool host_walk_only = false;      // BDX_HOST_WALK=1: every component goes through the host walk (A/B testing of K6)
     K6Arrays k6{};
     WalkResult merged;
@@ -220,6 +221,8 @@ int bdx_create(bdx_ctx** out, const bdx_opts* opts, const bdx_lib* libs, int nli
     {
         const char* hw = getenv("BDX_HOST_WALK");
         c->host_walk_only = hw && hw[0] == '1';
+        const char* bj = getenv("BDX_BUCKETED_JOIN");
+        c->bucketed_join = bj && bj[0] == '1';
     }
     std::vector<DevLib> dl(nlibs);
     for (int i = 0; i < nlibs; ++i) {
@@ -490,11 +493,11 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepa
         HIPCHK(c, c->b_c_maxq.ensure(cap * 4));
         k2.fill_ptr[0] = c->b_c_maxq.as<uint32_t>(); k2.fill_words[0] = na; k2.fill_value[0] = 0u;
         c->join_table_clean = 0;
-        if (prepare_join && na <= kDirectJoinMax) {
-            uint32_t slots = 1024;
-            while (slots < 2 * na) slots <<= 1;
-            HIPCHK(c, c->b_t_key.ensure((size_t)slots * 8)); HIPCHK(c, c->b_t_idx.ensure((size_t)slots * 4));
-            k2.fill_ptr[1] = c->b_t_idx.as<uint32_t>(); k2.fill_words[1] = slots; k2.fill_value[1] = 0xFFFFFFFFu;
+        if (prepare_join && !c->bucketed_join && na <= kDirectJoinMax) {
+            const uint32_t slots = direct_join_slots(na);
+            HIPCHK(c, c->b_t_key.ensure((size_t)slots * 8)); HIPCHK(c, c->b_partner.ensure((size_t)na * 4));
+            k2.fill_ptr[1] = c->b_t_key.as<uint32_t>(); k2.fill_words[1] = 2 * slots; k2.fill_value[1] = 0xFFFFFFFFu;
+            k2.fill_ptr[2] = c->b_partner.as<uint32_t>(); k2.fill_words[2] = na; k2.fill_value[2] = 0xFFFFFFFFu;
             c->join_table_clean = slots;
         }
         launch_k2(k2, k2_lds_bytes(nkeys), s);
@@ -561,12 +564,12 @@ int do_join_local(bdx_ctx* c, uint32_t n, const Entries& en, const uint32_t* n_p
     HIPCHK(c, c->h_groups.ensure((size_t)k4.g_cap * sizeof(GroupRec)));
     HIPCHK(c, c->b_partner.ensure((size_t)n * 4));
     k4.partner = c->b_partner.as<int32_t>(); k4.g_rec = c->h_groups.as<GroupRec>();
-    if (n <= kDirectJoinMax) {
-        uint32_t slots = 1024;
-        while (slots < 2 * n) slots <<= 1;
+    if (!c->bucketed_join && n <= kDirectJoinMax) {
+        const uint32_t slots = direct_join_slots(n);
         if (c->join_table_clean != slots) {
-            HIPCHK(c, c->b_t_key.ensure((size_t)slots * 8)); HIPCHK(c, c->b_t_idx.ensure((size_t)slots * 4));
-            HIPCHK(c, hipMemsetAsync(c->b_t_idx.p, 0xFF, (size_t)slots * 4, s));
+            HIPCHK(c, c->b_t_key.ensure((size_t)slots * 8));
+            HIPCHK(c, hipMemsetAsync(c->b_t_key.p, 0xFF, (size_t)slots * 8, s));
+            HIPCHK(c, hipMemsetAsync(c->b_partner.p, 0xFF, (size_t)n * 4, s));
         }
         c->join_table_clean = 0;
         k4.direct = 1; k4.t_mask = slots - 1;
@@ -602,7 +605,7 @@ int readback(bdx_ctx* c, bool with_groups) {
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, hipGetLastError());
     c->counts = *c->h_counts.as<StageCounts>();
-    if (c->counts.overflow == 2) return fail(c, BDX_ELIMIT, "a read-name key is shared by thousands of reads (malformed input)");
+    if (c->counts.overflow == 2) return fail(c, BDX_ELIMIT, "more than two primary reads share one read name (malformed input)");
     if (c->counts.overflow) return fail(c, BDX_EINTERNAL, "group list overflow");
     (void)with_groups;  // regions / prefix samples / groups already sit in pinned host memory (see do_cut / do_join_local)
     return BDX_OK;
@@ -881,7 +884,7 @@ int bdx_run(bdx_ctx* c) {
         decode_regions(c, c->h_regs.as<RegionRec>(), c->h_pk.as<uint32_t>(), c->h_counts0.as<StageCounts>()->n_regions, ph, false);
         HIPCHK(c, hipEventSynchronize(c->ev_groups));
         c->counts = *c->h_counts.as<StageCounts>();
-        if (c->counts.overflow == 2) return fail(c, BDX_ELIMIT, "a read-name key is shared by thousands of reads (malformed input)");
+        if (c->counts.overflow == 2) return fail(c, BDX_ELIMIT, "more than two primary reads share one read name (malformed input)");
         if (c->counts.overflow) return fail(c, BDX_EINTERNAL, "group list overflow");
         decode_groups(c, c->h_groups.as<GroupRec>(), c->counts.n_groups, ph);
     }
@@ -1017,7 +1020,7 @@ int bdx_join_entries(bdx_ctx* c, size_t n, const uint64_t* key, const uint32_t* 
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, hipGetLastError());
     const StageCounts sc = *c->h_counts.as<StageCounts>();
-    if (sc.overflow == 2) return fail(c, BDX_ELIMIT, "a read-name key is shared by thousands of reads (malformed input)");
+    if (sc.overflow == 2) return fail(c, BDX_ELIMIT, "more than two primary reads share one read name (malformed input)");
     if (sc.overflow) return fail(c, BDX_EINTERNAL, "group list overflow");
     if (n_groups) *n_groups = sc.n_groups;
     if (n_pairs) *n_pairs = sc.n_pairs;

@@ -74,7 +74,12 @@ void launch_k3(const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n
 // ---- K4 ---------------------------------------------------------------------------------------------
 constexpr int kMaxBuckets = 8192;
 constexpr int kJoinLdsSlots = 8192;  // 8192 x (8 B key + 4 B index) = 96 KiB of the CU's 160 KiB LDS
-constexpr uint32_t kDirectJoinMax = 1u << 22;  // entries up to which the direct table (<= 96 MiB) is used
+constexpr uint32_t kDirectJoinMax = 1u << 22;  // entries up to which the direct table (<= 128 MiB) is used
+inline uint32_t direct_join_slots(uint32_t n) {
+    uint32_t slots = 1024;
+    while (slots < 4 * (uint64_t)n) slots <<= 1;
+    return slots;
+}
 constexpr int kAggSlots = 4096;      // block-local group table: 4096 x 16 B = 64 KiB
 
 struct K4Arrays {
@@ -89,7 +94,8 @@ struct K4Arrays {
     uint64_t* t_key;     // [2*cap] global fallback table of the bucketed path; [t_mask + 1] table of the direct path
     int32_t* t_idx;
     uint32_t direct;     // 1: one open-addressing table for all entries (it stays in L2 / Infinity Cache), no partitioning
-    uint32_t t_mask;     // direct path: slots - 1 (slots = power of two >= 2 x entries); t_idx must be all -1 on entry
+    uint32_t t_mask;     // direct path: slots - 1 (slots = power of two >= 4 x entries) of 64-bit words in t_key, all ones on
+                         // entry; partner[] must be -1 on entry
     // output: partial aggregates of (r_lo, r_hi, flag, lib) -> (pairs, sum |isize|)
     GroupRec* g_rec;
     uint32_t g_cap;

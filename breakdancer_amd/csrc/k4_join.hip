@@ -128,10 +128,13 @@ __device__ __forceinline__ void join_bucket(uint64_t* tkey, int32_t* tidx, uint3
         uint32_t s = (uint32_t)(mix64(key) & 0xffffffffu) % cap;
         int32_t mate = -1;
         const uint32_t lim = cap < kMaxProbes ? cap : kMaxProbes;
-        for (uint32_t probes = 0; probes < lim; ++probes) {
+        for (uint32_t probes = 0; probes < lim; ++probes) {  // to the end of the probe run: a second match is malformed input
             const int32_t o = tidx[s];
             if (o == -1) break;
-            if (o != j && tkey[s] == key) { mate = o; break; }
+            if (o != j && tkey[s] == key) {
+                if (mate != -1) counts->overflow = 2;
+                mate = o;
+            }
             s = s + 1 == cap ? 0 : s + 1;
         }
         k4.partner[j] = mate;
@@ -152,37 +155,35 @@ __global__ __launch_bounds__(256) void k4_join_kernel(K4Arrays k4, StageCounts* 
     }
 }
 
-// Direct path: every entry claims a slot of one table (phase A), a second launch finds the mates (phase B).  At the
-// sizes of one chromosome the table (12 B per slot, load <= 0.5) lives in L2 / Infinity Cache, and the three
-// partitioning launches of the bucketed path are not worth their latency.
-__global__ __launch_bounds__(256) void k4_direct_insert_kernel(K4Arrays k4, Entries en, const uint32_t* n_ptr, StageCounts* counts) {
+// Direct path: one table of 64-bit words (hash tag << 32 | entry index) for all entries, one launch.  The first mate
+// to arrive claims the first free slot of its probe sequence; the second walks the same sequence, meets that word
+// (slots are never freed), confirms the full key and records the pair for both.  At the sizes of one chromosome the
+// table (8 B per slot, load <= 0.25) lives in L2 / Infinity Cache, and the partitioning launches of the bucketed
+// path are not worth their latency.  partner[] must be -1 and the table all ones on entry.
+__global__ __launch_bounds__(256) void k4_direct_join_kernel(K4Arrays k4, Entries en, const uint32_t* n_ptr, StageCounts* counts) {
     const uint32_t na = *n_ptr;
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
     if (j >= na || en.region[j] < 0) return;
     const uint64_t key = en.key[j];
-    uint32_t s = (uint32_t)mix64(key) & k4.t_mask;
-    uint32_t probes = 0;
-    while (atomicCAS(&k4.t_idx[s], -1, (int32_t)j) != -1) {
-        s = (s + 1) & k4.t_mask;
-        if (++probes > kMaxProbes) { counts->overflow = 2; return; }
-    }
-    k4.t_key[s] = key;
-}
-
-__global__ __launch_bounds__(256) void k4_direct_probe_kernel(K4Arrays k4, Entries en, const uint32_t* n_ptr) {
-    const uint32_t na = *n_ptr;
-    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= na || en.region[j] < 0) return;
-    const uint64_t key = en.key[j];
-    uint32_t s = (uint32_t)mix64(key) & k4.t_mask;
-    int32_t mate = -1;
+    const uint64_t h = mix64(key);
+    const uint32_t tag = (uint32_t)(h >> 32);
+    unsigned long long* table = (unsigned long long*)k4.t_key;
+    const unsigned long long mine = ((unsigned long long)tag << 32) | j;
+    uint32_t s = (uint32_t)h & k4.t_mask;
     for (uint32_t probes = 0; probes <= kMaxProbes; ++probes) {
-        const int32_t o = k4.t_idx[s];
-        if (o == -1) break;
-        if (o != (int32_t)j && k4.t_key[s] == key) { mate = o; break; }
+        const unsigned long long old = atomicCAS(&table[s], ~0ull, mine);
+        if (old == ~0ull) return;  // first of its name so far
+        if ((uint32_t)(old >> 32) == tag) {
+            const uint32_t o = (uint32_t)old;
+            if (en.key[o] == key) {
+                k4.partner[j] = (int32_t)o;
+                if (atomicExch(&k4.partner[o], (int32_t)j) != -1) counts->overflow = 2;  // a third read with this name
+                return;
+            }
+        }
         s = (s + 1) & k4.t_mask;
     }
-    k4.partner[j] = mate;
+    counts->overflow = 2;
 }
 
 constexpr uint64_t kEmptyGroup = ~0ull;
@@ -258,8 +259,7 @@ static void launch_k4_impl(const K4Arrays& k4, const Entries& en, const uint32_t
     const uint32_t g = (n_anom_host + kPartChunk - 1) / kPartChunk;
     if (k4.direct) {
         const uint32_t gd = (n_anom_host + 255) / 256;
-        hipLaunchKernelGGL(k4_direct_insert_kernel, dim3(gd), dim3(256), 0, s, k4, en, n_ptr, counts);
-        hipLaunchKernelGGL(k4_direct_probe_kernel, dim3(gd), dim3(256), 0, s, k4, en, n_ptr);
+        hipLaunchKernelGGL(k4_direct_join_kernel, dim3(gd), dim3(256), 0, s, k4, en, n_ptr, counts);
         if (aggregate) {
             (void)hipFuncSetAttribute((const void*)k4_aggregate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kAggSlots * 16 + 32);
             hipLaunchKernelGGL(k4_aggregate_kernel, dim3(g), dim3(256), (size_t)kAggSlots * 16 + 32, s, k4, en, n_ptr, counts);

@@ -206,3 +206,31 @@ def test_degenerate_inputs_do_not_hang():
     with pytest.raises(BdxError):
         bd.run()
     bd.close()
+    # three primary reads with one name (the reference's filter leaves at most two, AlignmentFilter.hpp:24-28): refused
+    keys = np.arange(n, dtype=np.uint64) // 2 + 1
+    keys[2::50] = keys[0::50]   # (only triples inside accepted regions reach the join; with 400 of them some do)
+    bd = bda.BreakDancer(Options(), [LibraryConfig(400, 30, 490, 310, 100)], 1, max_read_window_size=200)
+    bd.push_reads(dict(base, name_key=keys))
+    with pytest.raises(BdxError):
+        bd.run()
+    bd.close()
+
+
+@pytest.mark.parametrize("seed", [3, 17, 29])
+def test_bucketed_join_path(seed, monkeypatch):
+    """inputs above 4 M join entries are partitioned into LDS-sized buckets; force that path on small inputs"""
+    monkeypatch.setenv("BDX_BUCKETED_JOIN", "1")
+    cfg, streams, targets = make_case(seed)
+    run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1))
+    bd = product_from_oracle(run, support=True)
+    compare(run, bd)
+    compare_support(run, bd)
+    bd.close()
+    cfg, st = _synth_case(4_000_000, seed=5)
+    run = OracleRun(cfg, make_opts())
+    run.set_targets(["chrS"])
+    st = dict(st)
+    st["lib"] = np.zeros(len(st["tid"]), np.int32)
+    run.set_stream(0, st)
+    run.run()
+    compare(run, product_from_oracle(run))
