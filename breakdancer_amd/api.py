@@ -208,9 +208,10 @@ class BreakDancer:
         return tuple(x.value for x in v)
 
     def timings(self):
-        ms = np.zeros(8, np.float32)
-        self.lib.bdx_get_timings(self.h, ms.ctypes.data_as(C.c_void_p), 8)
-        return dict(zip(("classify", "compact", "regions", "join", "readback", "walk", "score", "total"), ms.tolist()))
+        ms = np.zeros(12, np.float32)
+        self.lib.bdx_get_timings(self.h, ms.ctypes.data_as(C.c_void_p), 12)
+        return dict(zip(("classify", "compact", "regions", "join", "readback", "walk", "score", "total", "final_wait", "merge",
+                         "combine_scores"), ms.tolist()))
 
 
 def poisson_log_upper_tail(lam, k, device=0):

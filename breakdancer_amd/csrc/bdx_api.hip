@@ -45,13 +45,14 @@ struct DevBuf {
 struct PinBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    unsigned flags = hipHostMallocDefault;
     hipError_t ensure(size_t b) {
         if (b <= bytes) return hipSuccess;
         if (p) (void)hipHostFree(p);
         p = nullptr;
         bytes = 0;
         size_t want = b + b / 8 + 256;
-        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(&p, want, flags);
         if (e == hipSuccess) bytes = want;
         return e;
     }
@@ -59,7 +60,7 @@ struct PinBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
-constexpr int kNumStages = 8;
+constexpr int kNumStages = 12;
 constexpr int kK1MaxGrid = 8192;  // measured best on MI355X (tools/k1_probe.hip): 256 CUs x 32 workgroups queued, 4 independent waves each
 
 }  // namespace
@@ -85,7 +86,8 @@ struct bdx_ctx {
         b_c_nnormal, b_c_rid, b_region_of, b_ws_u4, b_ws_u32, b_totals, b_counts;
     DevBuf b_bcnt, b_boff, b_bcur, b_e_key, b_e_idx, b_partner, b_t_key, b_t_idx;
     DevBuf b_x_key, b_x_order, b_x_region, b_x_meta, b_x_isize, b_x_n;
-    DevBuf b_r_rec, b_r_pk, b_out_deg, b_out_hi, b_p_key, b_p_pairs, b_p_sum, b_rs, b_slot, b_slot_info, b_lib_stage, b_cn_stage,
+    DevBuf b_lib_mean;
+    DevBuf b_r_rec, b_r_pk, b_out_deg, b_out_hi, b_parts, b_kdens, b_rs, b_slot, b_members, b_own, b_lib_stage, b_cn_stage,
         b_t_lambda, b_t_k, b_ws6, b_k6const;
     PinBuf h_p1, h_cnt, h_counts, h_regs, h_pk, h_groups, h_terms;
     PinBuf h_counts0, h_counts2, h_sv_out, h_lib_index, h_lib_pairs, h_cn_key, h_cn_value, h_ltail_dev, h_k6const;
@@ -218,6 +220,9 @@ int bdx_create(bdx_ctx** out, const bdx_opts* opts, const bdx_lib* libs, int nli
         if (hipEventCreate(&e) != hipSuccess) { delete c; return BDX_EHIP; }
     if (hipEventCreateWithFlags(&c->ev_groups, hipEventDisableTiming) != hipSuccess) { delete c; return BDX_EHIP; }
     if (hipEventCreateWithFlags(&c->ev_regions, hipEventDisableTiming) != hipSuccess) { delete c; return BDX_EHIP; }
+    if (const char* nc = getenv("BDX_PIN_NONCOHERENT"); nc && nc[0] == '1')
+        for (PinBuf* b : {&c->h_sv_out, &c->h_lib_index, &c->h_lib_pairs, &c->h_cn_key, &c->h_cn_value, &c->h_ltail_dev, &c->h_regs, &c->h_pk})
+            b->flags = hipHostMallocNonCoherent;
     {
         const char* hw = getenv("BDX_HOST_WALK");
         c->host_walk_only = hw && hw[0] == '1';
@@ -231,8 +236,12 @@ int bdx_create(bdx_ctx** out, const bdx_opts* opts, const bdx_lib* libs, int nli
         dl[i].min_mapq = libs[i].min_mapping_quality < 0 ? opts->min_map_qual : libs[i].min_mapping_quality;
         dl[i].key = opts->cn_lib ? i : libs[i].bam_index;
     }
+    std::vector<float> means(nlibs);
+    for (int i = 0; i < nlibs; ++i) means[i] = libs[i].mean_insertsize;
     if (c->b_libs.ensure(nlibs * sizeof(DevLib)) != hipSuccess ||
-        hipMemcpy(c->b_libs.p, dl.data(), nlibs * sizeof(DevLib), hipMemcpyHostToDevice) != hipSuccess) {
+        hipMemcpy(c->b_libs.p, dl.data(), nlibs * sizeof(DevLib), hipMemcpyHostToDevice) != hipSuccess ||
+        c->b_lib_mean.ensure(nlibs * 4) != hipSuccess ||
+        hipMemcpy(c->b_lib_mean.p, means.data(), nlibs * 4, hipMemcpyHostToDevice) != hipSuccess) {
         bdx_destroy(c);
         return BDX_EHIP;
     }
@@ -252,8 +261,8 @@ void bdx_destroy(bdx_ctx* c) {
                       &c->b_c_nnormal, &c->b_c_rid, &c->b_region_of, &c->b_ws_u4, &c->b_ws_u32, &c->b_totals,
                       &c->b_counts, &c->b_bcnt, &c->b_boff, &c->b_bcur, &c->b_e_key, &c->b_e_idx, &c->b_partner, &c->b_t_key,
                       &c->b_t_idx, &c->b_x_key, &c->b_x_order, &c->b_x_region,
-                      &c->b_x_meta, &c->b_x_isize, &c->b_x_n, &c->b_fold, &c->b_r_rec, &c->b_r_pk, &c->b_out_deg, &c->b_out_hi,
-                      &c->b_p_key, &c->b_p_pairs, &c->b_p_sum, &c->b_rs, &c->b_slot, &c->b_slot_info, &c->b_lib_stage,
+                      &c->b_x_meta, &c->b_x_isize, &c->b_x_n, &c->b_fold, &c->b_lib_mean, &c->b_r_rec, &c->b_r_pk, &c->b_out_deg, &c->b_out_hi,
+                      &c->b_parts, &c->b_kdens, &c->b_rs, &c->b_slot, &c->b_members, &c->b_own, &c->b_lib_stage,
                       &c->b_cn_stage, &c->b_t_lambda, &c->b_t_k, &c->b_ws6, &c->b_k6const};
     for (DevBuf* b : bufs) b->release();
     PinBuf* pins[] = {&c->h_p1, &c->h_cnt, &c->h_counts, &c->h_regs, &c->h_pk, &c->h_groups, &c->h_terms, &c->h_counts0, &c->h_counts2,
@@ -399,6 +408,8 @@ int do_pass1(bdx_ctx* c) {
     fp.nlibs = nlibs; fp.nbams = nbams; fp.nkeys = nkeys; fp.ncols = ncols; fp.ncnt = ncnt; fp.w0 = c->w0;
     fp.tile_tot = k1.tile_tot; fp.tile_pre = c->b_tile_pre.as<uint32_t>(); fp.tile_mono = k1.tile_mono;
     fp.blk_cnt = k1.blk_cnt; fp.cnt = c->b_cnt.as<uint32_t>(); fp.p1 = c->b_p1.as<Pass1>();
+    HIPCHK(c, c->b_kdens.ensure(64 * 4));
+    fp.libs = c->b_libs.as<DevLib>(); fp.cn_lib = c->opts.cn_lib; fp.key_density = c->b_kdens.as<float>();
     fp.cnt_host = c->h_cnt.as<uint32_t>(); fp.p1_host = c->h_p1.as<Pass1>();  // written by the kernel: no copy commands
     memset(c->h_p1.p, 0, sizeof(Pass1));
     launch_finalize(fp, s);
@@ -541,11 +552,16 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool f
         if (for_k6) {  // the device-side SV assembly reads the region table back: keep a copy in HBM
             HIPCHK(c, c->b_r_rec.ensure(cap * sizeof(RegionRec)));
             HIPCHK(c, c->b_r_pk.ensure(cap * 2 * nkeys * 4));
-            HIPCHK(c, c->b_out_deg.ensure(cap * 4));
+            HIPCHK(c, c->b_out_deg.ensure(cap * 6 * 4));
             k3.r_rec_dev = c->b_r_rec.as<RegionRec>(); k3.r_pk_dev = c->b_r_pk.as<uint32_t>(); k3.out_deg = c->b_out_deg.as<uint32_t>();
         }
         k3.ws_u4 = c->b_ws_u4.as<U4>(); k3.head_total = (U4*)c->b_totals.p; k3.ws_u32 = c->b_ws_u32.as<uint32_t>();
         k3.acc_total = (uint32_t*)((char*)c->b_totals.p + 32); k3.counts = c->b_counts.as<StageCounts>();
+        if (for_k6) {
+            HIPCHK(c, c->h_counts0.ensure(sizeof(StageCounts)));
+            memset(c->h_counts0.p, 0, sizeof(StageCounts));
+            k3.counts_host = c->h_counts0.as<StageCounts>();
+        }
         K3Tail tail{has_next, next_qlen, next_nn};
         launch_k3(k3, cp, c->b_p1.as<Pass1>(), na, c->opts.min_len, c->opts.seq_coverage_lim, nkeys, nn_base, tail, s);
     }
@@ -647,59 +663,57 @@ int do_k6(bdx_ctx* c, bool force_host) {
     a = K6Arrays{};
     if (!na) return BDX_OK;
     const size_t cap = na;
-    const uint32_t stride = (uint32_t)std::min(kK6MaxParts, nlibs);
-    HIPCHK(c, c->b_out_hi.ensure(cap * 4));
-    HIPCHK(c, c->b_p_key.ensure(cap * 8)); HIPCHK(c, c->b_p_pairs.ensure(cap * 4)); HIPCHK(c, c->b_p_sum.ensure(cap * 4));
+    HIPCHK(c, c->b_parts.ensure(cap * sizeof(PartRec)));
     HIPCHK(c, c->b_rs.ensure(cap * sizeof(RegSum)));
-    HIPCHK(c, c->b_slot.ensure(3 * cap * sizeof(SvOut))); HIPCHK(c, c->b_slot_info.ensure(3 * cap * 4));
-    HIPCHK(c, c->b_lib_stage.ensure(3 * cap * stride * sizeof(LibStage)));
-    HIPCHK(c, c->b_cn_stage.ensure(3 * cap * (size_t)nkeys * sizeof(CnStage)));
+    HIPCHK(c, c->b_members.ensure(cap * kK6MaxMembers * sizeof(MemberInfo)));
+    HIPCHK(c, c->b_own.ensure(cap * (3 + kK6MaxSv) * 4));
     a.sv_cap = na / 2 + 1; a.term_cap = na / 2 + 1; a.cn_cap = (na / 2 + 1) * (uint32_t)nkeys;
+    a.lib_stride = (uint32_t)std::min(nlibs, kK6LibStride);
+    HIPCHK(c, c->b_slot.ensure(cap * sizeof(SvOut)));
+    HIPCHK(c, c->b_lib_stage.ensure(cap * a.lib_stride * sizeof(LibStage)));
+    HIPCHK(c, c->b_cn_stage.ensure(cap * (size_t)nkeys * sizeof(CnStage) + 16));
     HIPCHK(c, c->b_t_lambda.ensure((size_t)a.term_cap * 8)); HIPCHK(c, c->b_t_k.ensure((size_t)a.term_cap * 4));
-    const size_t nblk = scan_grid(3 * na) + 1;
+    const size_t nblk = scan_grid(na) + 1;
     HIPCHK(c, c->b_ws6.ensure(nblk * sizeof(U4) + 64));
     HIPCHK(c, c->h_sv_out.ensure((size_t)a.sv_cap * sizeof(SvOut)));
     HIPCHK(c, c->h_lib_index.ensure((size_t)a.term_cap * 4)); HIPCHK(c, c->h_lib_pairs.ensure((size_t)a.term_cap * 4));
     HIPCHK(c, c->h_cn_key.ensure((size_t)a.cn_cap * 4 + 16)); HIPCHK(c, c->h_cn_value.ensure((size_t)a.cn_cap * 4 + 16));
     HIPCHK(c, c->h_ltail_dev.ensure((size_t)a.term_cap * 8));
     HIPCHK(c, c->h_counts2.ensure(sizeof(StageCounts)));
-    // run constants: adopted flag histogram, read densities per counter key, library mean insert sizes
-    const size_t nconst = (size_t)nlibs * kNumFlags + nkeys + nlibs;
-    HIPCHK(c, c->h_k6const.ensure(nconst * 4)); HIPCHK(c, c->b_k6const.ensure(nconst * 4));
-    {
-        uint32_t* hh = c->h_k6const.as<uint32_t>();
-        memcpy(hh, c->cnt.data(), (size_t)nlibs * kNumFlags * 4);
-        float* hd = (float*)(hh + (size_t)nlibs * kNumFlags);
-        for (int k = 0; k < nkeys; ++k) hd[k] = c->key_density[k];
-        for (int i = 0; i < nlibs; ++i) hd[nkeys + i] = c->libs[i].mean_insertsize;
-    }
-    HIPCHK(c, hipMemcpyAsync(c->b_k6const.p, c->h_k6const.p, nconst * 4, hipMemcpyHostToDevice, s));
     a.cap = na;
     a.r_rec = c->b_r_rec.as<RegionRec>(); a.r_pk = c->b_r_pk.as<uint32_t>();
     a.region_of = c->k3.region_of; a.partner = c->k4.partner; a.meta = c->cp.meta; a.isize = c->cp.isize;
-    a.p_key = c->b_p_key.as<uint64_t>(); a.p_pairs = c->b_p_pairs.as<uint32_t>(); a.p_sum = c->b_p_sum.as<uint32_t>();
-    a.rs = c->b_rs.as<RegSum>(); a.out_deg = c->b_out_deg.as<uint32_t>(); a.out_hi = c->b_out_hi.as<uint32_t>();
-    a.slot = c->b_slot.as<SvOut>(); a.slot_info = c->b_slot_info.as<uint32_t>();
-    a.lib_stage = c->b_lib_stage.as<LibStage>(); a.cn_stage = c->b_cn_stage.as<CnStage>(); a.acc_stride = stride;
+    a.parts = c->b_parts.as<PartRec>();
+    a.rs = c->b_rs.as<RegSum>();
+    a.out_deg = c->b_out_deg.as<uint32_t>(); a.label = a.out_deg + cap; a.bad_v = a.out_deg + 2 * cap; a.bad = a.out_deg + 3 * cap;
+    a.mcount = a.out_deg + 4 * cap; a.pcount = a.out_deg + 5 * cap;
+    a.members = c->b_members.as<MemberInfo>();
+    a.own_nsv = c->b_own.as<uint32_t>(); a.own_nacc = a.own_nsv + cap; a.own_ncn = a.own_nsv + 2 * cap; a.own_slots = a.own_nsv + 3 * cap;
+    a.sv_stage = c->b_slot.as<SvOut>(); a.lib_stage = c->b_lib_stage.as<LibStage>(); a.cn_stage = c->b_cn_stage.as<CnStage>();
     a.sv_out = c->h_sv_out.as<SvOut>(); a.lib_index = c->h_lib_index.as<int32_t>(); a.lib_pairs = c->h_lib_pairs.as<int32_t>();
     a.cn_key = c->h_cn_key.as<int32_t>(); a.cn_value = c->h_cn_value.as<float>();
     a.t_lambda = c->b_t_lambda.as<double>(); a.t_k = c->b_t_k.as<int32_t>();
     a.g_rec = c->k4.g_rec; a.g_cap = c->k4.g_cap;
     a.ws_u4 = c->b_ws6.as<U4>(); a.total_u4 = (U4*)((char*)c->b_ws6.p + nblk * sizeof(U4));
     a.counts = c->b_counts.as<StageCounts>();
-    a.hist = c->b_k6const.as<uint32_t>();
-    a.key_density = (const float*)(a.hist + (size_t)nlibs * kNumFlags);
-    a.lib_mean = a.key_density + nkeys;
+    // run constants: the flag histogram is the device's own reduced counter table (a single-context run adopts its own
+    // statistics), the read densities per counter key travel in the kernel arguments
+    a.hist = c->b_cnt.as<uint32_t>();
+    a.key_density = c->b_kdens.as<float>();
+    a.lib_mean = c->b_lib_mean.as<float>();
+    a.counts_host = c->h_counts.as<StageCounts>();
+    a.counts_host2 = c->h_counts2.as<StageCounts>();
+    memset(c->h_counts.p, 0, sizeof(StageCounts));
+    memset(c->h_counts2.p, 0, sizeof(StageCounts));
     a.covered_ref_len = c->g_covered;
-    a.nkeys = nkeys; a.min_read_pair = c->opts.min_read_pair; a.chr_restricted = c->opts.chr_restricted;
+    a.nlibs = nlibs; a.nkeys = nkeys; a.min_read_pair = c->opts.min_read_pair; a.chr_restricted = c->opts.chr_restricted;
     a.period = std::max(1, c->opts.buffer_size + 1);
     a.force_host = force_host ? 1 : 0;
     launch_k6_groups(a, na, s);
-    HIPCHK(c, hipMemcpyAsync(c->h_counts.p, c->b_counts.p, sizeof(StageCounts), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipEventRecord(c->ev_groups, s));  // the host walk of the remaining components can start here
+    launch_k6_walk(a, na, s);
     launch_k6_compact(a, na, s);
     launch_k5_dev(a.t_lambda, a.t_k, c->h_ltail_dev.as<double>(), &a.counts->n_terms_dev, a.term_cap, s);
-    HIPCHK(c, hipMemcpyAsync(c->h_counts2.p, c->b_counts.p, sizeof(StageCounts), hipMemcpyDeviceToHost, s));
     return BDX_OK;
 }
 
@@ -732,8 +746,10 @@ int host_walk(bdx_ctx* c, int32_t last_maxq, bool any_anomalous) {
 // combine the per-library log tails into the scores
 int finish_walk(bdx_ctx* c, bool with_dev) {
     hipStream_t s = c->stream;
+    const auto tf0 = std::chrono::steady_clock::now();
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, hipGetLastError());
+    const auto tf1 = std::chrono::steady_clock::now();
     static_assert(sizeof(HostSv) == sizeof(SvOut) && offsetof(HostSv, grp_mask) == offsetof(SvOut, grp_mask) &&
                       offsetof(HostSv, start) == offsetof(SvOut, start), "SV record layout");
     const uint32_t nt = (uint32_t)c->walk.terms.size();
@@ -743,8 +759,7 @@ int finish_walk(bdx_ctx* c, bool with_dev) {
         const StageCounts c2 = *c->h_counts2.as<StageCounts>();
         if (c2.overflow) return fail(c, BDX_EINTERNAL, "SV list overflow");
         nd = c2.n_sv_dev; ndt = c2.n_terms_dev; ndc = c2.n_cn_dev;
-        c->counts.n_sv_dev = nd; c->counts.n_terms_dev = ndt; c->counts.n_cn_dev = ndc; c->counts.n_groups_dev = c2.n_groups_dev;
-        c->counts.n_pairs = c2.n_pairs;
+        c->counts.n_sv_dev = nd; c->counts.n_terms_dev = ndt; c->counts.n_cn_dev = ndc;  // (the rest arrived with the groups)
     }
     std::vector<double>& log_tail = c->log_tail;
     c->n_sv_host = (uint32_t)c->walk.svs.size();
@@ -765,36 +780,63 @@ int finish_walk(bdx_ctx* c, bool with_dev) {
             M.lib_index.assign(d_li, d_li + ndt); M.lib_pairs.assign(d_lp, d_lp + ndt);
             M.cn_key.assign(d_ck, d_ck + ndc); M.cn_value.assign(d_cv, d_cv + ndc);
             log_tail.assign(d_lt, d_lt + ndt);
-        } else {    // interleave by output order and re-pack the flat lists in that order
+        } else {
+            // Interleave by output order.  Both lists are sorted; the host walk's few SVs cut the device's list into
+            // runs that are copied in bulk, their list offsets shifted by what the host has inserted before them.
             const uint64_t period = (uint64_t)std::max(1, c->opts.buffer_size + 1);
             const size_t ntot = (size_t)ndt + nt, nctot = (size_t)ndc + H.cn_key.size();
             M.lib_index.resize(ntot); M.lib_pairs.resize(ntot); log_tail.resize(ntot);
             M.cn_key.resize(nctot); M.cn_value.resize(nctot);
-            size_t i = 0, j = 0, o = 0, lo = 0, co = 0;
-            while (i < nd || j < nh) {
-                bool take_dev = j == nh;
-                if (!take_dev && i < nd) take_dev = sv_order_key(d[i].start / period, false, d[i].start) < H.sv_key[j];
-                HostSv hs = take_dev ? d[i] : H.svs[j];
+            size_t i0 = 0, o = 0, lo = 0, co = 0;
+            int32_t hl = 0, hc = 0;  // host entries inserted so far
+            auto copy_run = [&](size_t i1) {
+                if (i1 == i0) return;
+                const size_t l0 = (size_t)d[i0].sv.lib_begin, l1 = i1 < nd ? (size_t)d[i1].sv.lib_begin : (size_t)ndt;
+                const size_t c0 = (size_t)d[i0].sv.cn_begin, c1 = i1 < nd ? (size_t)d[i1].sv.cn_begin : (size_t)ndc;
+                memcpy(&M.svs[o], d + i0, (i1 - i0) * sizeof(HostSv));
+                if (hl || hc)
+                    for (size_t q = o; q < o + (i1 - i0); ++q) { M.svs[q].sv.lib_begin += hl; M.svs[q].sv.cn_begin += hc; }
+                memcpy(&M.lib_index[lo], d_li + l0, (l1 - l0) * 4); memcpy(&M.lib_pairs[lo], d_lp + l0, (l1 - l0) * 4);
+                memcpy(&log_tail[lo], d_lt + l0, (l1 - l0) * 8);
+                memcpy(&M.cn_key[co], d_ck + c0, (c1 - c0) * 4); memcpy(&M.cn_value[co], d_cv + c0, (c1 - c0) * 4);
+                o += i1 - i0; lo += l1 - l0; co += c1 - c0;
+                i0 = i1;
+            };
+            for (size_t j = 0; j < nh; ++j) {
+                // device SVs come from traversals started at a window's own vertices; this host SV precedes those whose
+                // start vertex is not below T: its own start vertex, or the first vertex of its window if it started
+                // from an earlier window's vertex
+                const uint64_t key = H.sv_key[j];
+                const bool from_old = !((key >> 32) & 1ull);
+                const uint64_t T = from_old ? (key >> 33) * period : (key & 0xffffffffull);
+                size_t lo_i = i0, hi_i = nd;
+                while (lo_i < hi_i) {
+                    const size_t mid = (lo_i + hi_i) / 2;
+                    if ((uint64_t)d[mid].start < T) lo_i = mid + 1; else hi_i = mid;
+                }
+                copy_run(lo_i);
+                HostSv hs = H.svs[j];
                 const int32_t lb = hs.sv.lib_begin, cb = hs.sv.cn_begin;
                 for (int32_t q = 0; q < hs.sv.lib_count; ++q) {
-                    M.lib_index[lo + q] = take_dev ? d_li[lb + q] : H.lib_index[lb + q];
-                    M.lib_pairs[lo + q] = take_dev ? d_lp[lb + q] : H.lib_pairs[lb + q];
-                    log_tail[lo + q] = take_dev ? d_lt[lb + q] : host_tail[lb + q];
+                    M.lib_index[lo + q] = H.lib_index[lb + q]; M.lib_pairs[lo + q] = H.lib_pairs[lb + q]; log_tail[lo + q] = host_tail[lb + q];
                 }
-                for (int32_t q = 0; q < hs.sv.cn_count; ++q) {
-                    M.cn_key[co + q] = take_dev ? d_ck[cb + q] : H.cn_key[cb + q];
-                    M.cn_value[co + q] = take_dev ? d_cv[cb + q] : H.cn_value[cb + q];
-                }
+                for (int32_t q = 0; q < hs.sv.cn_count; ++q) { M.cn_key[co + q] = H.cn_key[cb + q]; M.cn_value[co + q] = H.cn_value[cb + q]; }
                 hs.sv.lib_begin = (int32_t)lo; hs.sv.cn_begin = (int32_t)co;
                 lo += (size_t)hs.sv.lib_count; co += (size_t)hs.sv.cn_count;
+                hl += hs.sv.lib_count; hc += hs.sv.cn_count;
                 M.svs[o++] = hs;
-                if (take_dev) ++i; else ++j;
             }
+            copy_run(nd);
         }
         M.n_groups = H.n_groups + c->counts.n_groups_dev;
         std::swap(c->walk, c->merged);
     }
+    const auto tf2 = std::chrono::steady_clock::now();
     finish_scores(c->opts, log_tail.data(), c->walk.svs.data(), c->walk.svs.size(), &c->n_printed);
+    const auto tf3 = std::chrono::steady_clock::now();
+    c->stage_ms[8] = ms_between(tf0, tf1);
+    c->stage_ms[9] = ms_between(tf1, tf2);
+    c->stage_ms[10] = ms_between(tf2, tf3);
     c->ran = true;
     c->stage = 4;
     return BDX_OK;
@@ -866,8 +908,6 @@ int bdx_run(bdx_ctx* c) {
     const bool force_host = c->host_walk_only || ph || c->opts.min_read_pair < 1;
     if (na) {
         // the region table is final after K3: the host takes its copy while the device joins the mates
-        HIPCHK(c, c->h_counts0.ensure(sizeof(StageCounts)));
-        HIPCHK(c, hipMemcpyAsync(c->h_counts0.p, c->b_counts.p, sizeof(StageCounts), hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipEventRecord(c->ev_regions, s));
         Entries en{c->cp.key, c->k3.region_of, nullptr, c->cp.meta, c->cp.isize};
         rc = do_join_local(c, na, en, &c->b_p1.as<Pass1>()->n_anom, true);

@@ -74,6 +74,9 @@ struct FinalizeParams {
     Pass1* p1;
     uint32_t* cnt_host;         // pinned host mirrors written by the last kernel (no copy command on the stream); may be null
     Pass1* p1_host;
+    const DevLib* libs;         // for the read densities per counter key (BreakDancerMax.cpp:94-107)
+    int cn_lib;
+    float* key_density;         // [nkeys]; may be null
 };
 
 // one launch that sets several scratch buffers to their start values (replaces a chain of small fill commands)

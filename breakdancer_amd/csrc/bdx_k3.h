@@ -15,12 +15,15 @@ struct StageCounts {
     uint32_t n_groups;   // partial (flag, lib) aggregates written by K4
     uint32_t n_entries;  // reads of accepted regions entering the join
     uint32_t overflow;   // set if an output list ran out of capacity
-    uint32_t n_slots;    // K6: 3 x n_regions SV slots
+    uint32_t n_slots;    // (unused)
     uint32_t n_sv_dev;   // K6: SV candidates assembled on the device
     uint32_t n_terms_dev;  // K6: their (library, pairs) entries == Poisson terms
     uint32_t n_cn_dev;     // K6: their copy-number entries
     uint32_t n_groups_dev; // K6: region x region groups of the components handled on the device
-    uint32_t pad[4];
+    uint32_t stage_sv;     // K6: bump allocators of the staging lists
+    uint32_t stage_lib;
+    uint32_t stage_cn;
+    uint32_t done;         // K6: workgroups of k6_walk_kernel that have finished (reset by the last one)
 };
 
 struct RegionRec {
@@ -52,13 +55,15 @@ struct K3Arrays {
     uint32_t* r_pk;  // [cap][2*nkeys]: proper-read prefix counts at the region's first read (nkeys), then last read (nkeys)
     RegionRec* r_rec_dev;  // device-resident copies for K6 (r_rec / r_pk live in pinned host memory); may be null
     uint32_t* r_pk_dev;
-    uint32_t* out_deg;     // [cap] K6 out-degree counters, zeroed by k3_region_of_kernel; may be null
+    uint32_t* out_deg;     // K6 per-region scratch reset by k3_region_of_kernel: [6][cap] = out_deg, label (= index),
+                           // bad_v, bad, mcount, pcount; may be null
     // scan workspace and totals
     U4* ws_u4;
     U4* head_total;
     uint32_t* ws_u32;
     uint32_t* acc_total;
     StageCounts* counts;
+    StageCounts* counts_host;  // pinned host mirror: n_cand / n_regions / last_maxq are stored there as well (may be null)
 };
 
 // the read that closes the last candidate when the stream continues in another context (next chromosome)
@@ -124,26 +129,51 @@ void launch_k5(const double* lambda, const int32_t* k, double* out, uint32_t n, 
 // term count read from device memory (the SV assembly of K6 decides it); n_upper only sizes the grid
 void launch_k5_dev(const double* lambda, const int32_t* k, double* out, const uint32_t* n_ptr, uint32_t n_upper, hipStream_t s);
 
-// ---- K6: pair groups per region, component classification, SV assembly on the device ----------------------
-// A connected component of the region graph that is a single region, or two regions of the same flush window joined
-// by one group, is walked by one thread exactly as build_connection / process_sv would; every other component is
-// handed to the host walk (bdx_walk.cpp) as a list of pair groups.
+// ---- K6: pair groups per region, small components walked on the device -----------------------------------
+// Connectivity of the region graph comes from the groups whose weight passes the gate (-r): lighter groups are
+// skipped by every try_edge of build_connection and never reach process_sv.  A connected component of at most
+// kK6MaxMembers regions inside one flush window is walked by ONE thread exactly as build_connection / process_sv
+// would (BreakDancer.cpp:266-497); every other component is handed to the host walk (bdx_walk.cpp) as a list of
+// pair groups.
+constexpr int kK6MaxMembers = 4;   // regions per device-walked component
+constexpr int kK6MaxIn = 3;        // incoming gate-passing groups per region (a member of such a component has <= 3)
+constexpr int kK6MaxSv = 10;       // SV candidates of one component: 4 self groups + 6 groups between members
+constexpr int kK6LibStride = 16;   // staged (library, pairs) entries per candidate; components that could need more go to the host
+constexpr int kK6LdsParts = 12;    // parts of a component kept in LDS by its walking thread (more: read from HBM)
+constexpr int kK6LabelRounds = 3;  // min-label propagation rounds: enough for a diameter of 3; a component that has
+                                   // not converged fails the closure check and goes to the host
+
 struct RegSum {        // per accepted region r, written by k6_pairs_kernel
     uint32_t np_all;   // sorted, merged (lo, flag, lib) parts of the pairs whose second mate is in r, at parts[first ..)
-    uint32_t np_emit;  // those the host walk would need: the self group and every group that can pass the weight gate
-    uint32_t in_off;   // with n_in == 1: offset and count of the parts of that one incoming group
-    uint32_t np_in;
+    uint32_t np_emit;  // those the host walk would need: the self group and every group that passes the gate
     uint32_t np_self;  // parts with lo == r: the last np_self of the np_all
-    uint32_t n_in;     // groups (lo, r), lo < r, whose weight passes the gate (-r); lighter ones are never traversed
-                       // or consumed by build_connection, so they do not connect anything
-    uint32_t in_lo;    // that lo when n_in == 1
-    uint32_t w_in;     // its weight
     uint32_t w_self;   // pairs with lo == r (weight of the self edge)
+    uint32_t n_in;     // groups (lo, r), lo < r, passing the gate
     uint32_t n_pairs;  // all pairs whose second mate is in r
     uint32_t n_weak;   // groups (lo, r), lo < r, below the gate
     uint32_t big;      // more reads than one wave sorts at once: its parts went straight to the host list
+    uint32_t e_lo[kK6MaxIn];   // the first kK6MaxIn incoming gate-passing groups: region, weight, parts [off, off + cnt)
+    uint32_t e_w[kK6MaxIn];
+    uint32_t e_off[kK6MaxIn];
+    uint32_t e_cnt[kK6MaxIn];
 };
 constexpr uint64_t kWeakPart = 1ull << 63;  // flag on a part key: belongs to a group below the weight gate
+
+struct PartRec {       // one (lo, flag, lib) slice of the pairs whose second-observed mate is in a region
+    uint64_t key;      // lo << 12 | lib << 4 | flag (| kWeakPart)
+    uint32_t pairs;
+    uint32_t sum;      // sum of |isize| of the second-observed mates
+};
+
+struct MemberInfo {    // what the walk needs to know about one region of a component, stored with the component's label
+    uint32_t r;
+    RegionRec rec;
+    uint32_t np_all, np_self, w_self, n_in;
+    uint32_t e_lo[kK6MaxIn], e_w[kK6MaxIn], e_off[kK6MaxIn], e_cnt[kK6MaxIn];
+    uint32_t stored;   // ReadRegionData.cpp:118-121
+    uint32_t pad;
+};
+constexpr int kMemberWords = sizeof(MemberInfo) / 4;
 
 struct SvOut {         // == HostSv (bdx_walk.h)
     bdx_sv sv;
@@ -162,18 +192,27 @@ struct K6Arrays {
     const int32_t* partner;
     const uint32_t* meta;
     const int32_t* isize;
-    uint64_t* p_key;               // [cap] sorted parts of region r at [first_r, ...): lo << 12 | lib << 4 | flag
-    uint32_t* p_pairs;
-    uint32_t* p_sum;
+    PartRec* parts;                // [cap] sorted parts of region r at [first_r, ...)
     RegSum* rs;                    // [cap]
-    uint32_t* out_deg;             // [cap] groups (r, hi) with hi > r
-    uint32_t* out_hi;              // [cap] the hi of one of them
-    // SV slots: 3 per region (start vertex, sequence number)
-    SvOut* slot;                   // [3 cap]
-    uint32_t* slot_info;           // [3 cap] valid | nacc << 1 | ncn << 8
-    LibStage* lib_stage;           // [3 cap][acc_stride]
-    CnStage* cn_stage;             // [3 cap][nkeys]
-    uint32_t acc_stride;
+    // component analysis; the six arrays below are reset by k3_region_of_kernel (label[r] = r, the others 0)
+    uint32_t* out_deg;             // [cap] gate-passing groups (r, hi) with hi > r
+    uint32_t* label;               // [cap] smallest region id seen so far in r's component
+    uint32_t* bad_v;               // [cap] r itself cannot be walked on the device (too large, too many incoming groups)
+    uint32_t* bad;                 // [cap] by label: the component goes to the host
+    uint32_t* mcount;              // [cap] by label: members registered
+    uint32_t* pcount;              // [cap] by label: parts its walk can touch (bounds the libraries of one SV candidate)
+    MemberInfo* members;           // [cap][kK6MaxMembers] by label
+    // SV candidates of the device-walked components.  Staging slots need no allocation: the candidate that consumes the
+    // group (A, B) sits at first_B + (index of that group among B's incoming ones), the one of B's self group right
+    // after them -- every group owns at least one read of its later region, so the slots exist and are distinct.
+    uint32_t* own_nsv;             // [cap] per start vertex (smallest region of a component): candidates emitted ...
+    uint32_t* own_nacc;            // [cap] ... the sum of their (library, pairs) entries ...
+    uint32_t* own_ncn;             // [cap] ... and of their copy-number entries
+    uint32_t* own_slots;           // [cap][kK6MaxSv] their staging slots in emission order
+    SvOut* sv_stage;               // [cap]
+    LibStage* lib_stage;           // [cap][lib_stride]
+    CnStage* cn_stage;             // [cap][nkeys]
+    uint32_t lib_stride;           // min(nlibs, kK6LibStride)
     // dense outputs
     SvOut* sv_out;                 // pinned host
     int32_t* lib_index;            // pinned host
@@ -189,16 +228,18 @@ struct K6Arrays {
     U4* ws_u4;
     U4* total_u4;
     StageCounts* counts;
+    StageCounts* counts_host;      // pinned: all counters after k6_walk_kernel (written by its last workgroup)
+    StageCounts* counts_host2;     // pinned: n_sv_dev / n_terms_dev / n_cn_dev / overflow after the compaction
     // run constants
     const uint32_t* hist;          // [nlibs][11] adopted flag histogram
-    const float* key_density;      // [nkeys]
+    const float* key_density;      // [nkeys] read density per counter key (finalize2_kernel)
     const float* lib_mean;         // [nlibs]
     uint32_t covered_ref_len;
-    int nkeys, min_read_pair, chr_restricted, period, force_host;
+    int nlibs, nkeys, min_read_pair, chr_restricted, period, force_host;
 };
 
-constexpr int kK6MaxParts = 32;
-void launch_k6_groups(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s);   // pair groups, host list, SV slots
-void launch_k6_compact(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s);  // slots -> dense SV records and lists
+void launch_k6_groups(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s);   // pair groups, components, the host's list
+void launch_k6_walk(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s);     // device-walked components -> SV staging
+void launch_k6_compact(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s);  // staging -> dense SV records and lists
 
 }  // namespace bdx

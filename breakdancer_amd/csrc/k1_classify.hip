@@ -443,6 +443,21 @@ __global__ __launch_bounds__(256) void finalize2_kernel(const FinalizeParams p) 
             W = min(W, tmp);
         }
         p.p1->window = W;
+        if (p.key_density) {  // same float32 expressions as the host side (set_pass1 in bdx_api.hip)
+            const uint32_t* lib_cnt = s_acc + p.nlibs * kNumFlags;
+            const uint32_t* bam_cnt = lib_cnt + p.nlibs;
+            for (int k = 0; k < p.nkeys; ++k) p.key_density[k] = 0.000001f;
+            for (int i = 0; i < p.nlibs; ++i) {
+                const int key = p.libs[i].key;  // library index with -a, else the library's source file
+                float dens = 0.000001f;
+                if (p.cn_lib) {
+                    if (lib_cnt[i] != 0) dens = __fdiv_rn((float)lib_cnt[i], (float)covered);
+                } else {
+                    dens = __fdiv_rn((float)bam_cnt[key], (float)covered);
+                }
+                p.key_density[key] = dens;
+            }
+        }
     }
     if (p.p1_host) {  // mirror the finished record into pinned host memory
         __threadfence();

@@ -50,7 +50,10 @@ __global__ __launch_bounds__(256) void k3_candidates_kernel(K3Arrays a, Compact 
     const uint32_t nc = head_total->x;
     const uint32_t na = p1->n_anom;
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && threadIdx.x == 0) a.counts->n_cand = nc;
+    if (c == 0 && threadIdx.x == 0) {
+        a.counts->n_cand = nc;
+        if (a.counts_host) a.counts_host->n_cand = nc;
+    }
     if (c >= nc) return;
     const uint32_t f = a.c_first[c];
     const uint32_t nxt = c + 1 < nc ? a.c_first[c + 1] : na;
@@ -89,7 +92,10 @@ struct AcceptOut {
     int nkeys;
     __device__ void operator()(uint32_t c, uint32_t n, uint32_t inc, uint32_t e) const {
         a.c_rid[c] = e ? (int)inc - 1 : -1;
-        if (c == n - 1) { a.counts->last_maxq = a.c_maxq[c]; a.counts->n_regions = inc; }  // inc of the last candidate = #accepted
+        if (c == n - 1) {  // inc of the last candidate = #accepted
+            a.counts->last_maxq = a.c_maxq[c]; a.counts->n_regions = inc;
+            if (a.counts_host) { a.counts_host->last_maxq = a.c_maxq[c]; a.counts_host->n_regions = inc; }
+        }
         if (!e) return;
         const uint32_t r = inc - 1;
         const uint32_t f = a.c_first[c];
@@ -115,7 +121,14 @@ __global__ __launch_bounds__(256) void k3_region_of_kernel(K3Arrays a, const Pas
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < p1->n_anom) {
         a.region_of[j] = a.c_rid[a.cand[j]];
-        if (a.out_deg) a.out_deg[j] = 0;
+        if (a.out_deg) {  // K6's component scratch: out_deg, label, bad_v, bad, mcount, pcount
+            a.out_deg[j] = 0;
+            a.out_deg[(size_t)a.cap + j] = j;
+            a.out_deg[2 * (size_t)a.cap + j] = 0;
+            a.out_deg[3 * (size_t)a.cap + j] = 0;
+            a.out_deg[4 * (size_t)a.cap + j] = 0;
+            a.out_deg[5 * (size_t)a.cap + j] = 0;
+        }
     }
 }
 

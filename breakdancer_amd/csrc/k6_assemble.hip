@@ -1,18 +1,21 @@
-// K6 -- region x region pair groups, component classification and SV assembly on the device.
+// K6 -- region x region pair groups, component analysis and SV assembly on the device.
 //
-// Replaces, for the components of the region graph that need no real traversal (reference file:line under
-// src/lib/breakdancer):
+// Replaces, for the small components of the region graph (reference file:line under src/lib/breakdancer):
 //   ReadRegionData.cpp:108-113   edge weights: pairs per (region, region)
-//   BreakDancer.cpp:266-346      build_connection: a single region with a self edge, or two regions of one flush
-//                                window joined by one edge, are visited in a fixed order (A's self edge, the edge
-//                                A-B, then B's self edge), so the whole component is one thread's straight-line code
+//   BreakDancer.cpp:266-346      build_connection: ascending start vertices, BFS frontier, neighbours in ascending
+//                                order, every edge consumed by the side that reaches it first, edges below the
+//                                weight gate (-r) skipped each time they are met
 //   BreakDancer.cpp:348-497      process_sv: gates, breakpoints, copy number, size, score inputs
 //   SvBuilder.cpp:18-118         dominant flag, per-library counts of the second-observed mates, positions
 //
 // Region ids increase with the stream, and a pair is keyed by the region of its second-observed mate, so the
 // pairs of region r sit in r's own slice of the compact read list: one wave sorts and run-length merges them
-// in registers (k6_pairs_kernel).  Every component that is not of the two shapes above -- and any region with more
-// reads than a wave sorts at once -- is handed to the host walk (bdx_walk.cpp) as a list of pair groups.
+// in registers (k6_pairs_kernel).  Groups below the weight gate are inert in the reference's walk (never traversed,
+// never consumed), so connectivity is taken over the gate-passing groups only: min-label propagation plus a closure
+// check finds the components of at most kK6MaxMembers regions that lie inside one flush window, and one thread
+// replays the walk of such a component from its smallest region (k6_walk_kernel).  Everything else -- larger or
+// window-crossing components, regions with more reads than a wave sorts at once -- is handed to the host walk
+// (bdx_walk.cpp) as a list of pair groups.
 // float32 / float64 operations are spelled with the round-to-nearest intrinsics so that no fused multiply-add can
 // change a result against the host code (and the oracle).
 #include <algorithm>
@@ -35,6 +38,16 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
+}
+
+// wave-aggregated bump allocation: every lane asks for `need` entries, one atomic per wave
+__device__ __forceinline__ uint32_t wave_reserve(uint32_t need, uint32_t* counter) {
+    const uint32_t inc = wave_incl_scan(need);
+    const uint32_t tot = (uint32_t)__shfl((int)inc, 63);
+    uint32_t base = 0;
+    if ((threadIdx.x & 63) == 63 && tot) base = atomicAdd(counter, tot);
+    base = (uint32_t)__shfl((int)base, 63);
+    return base + inc - need;
 }
 
 struct GrpRange {
@@ -92,52 +105,52 @@ __global__ __launch_bounds__(256) void k6_pairs_kernel(K6Arrays a) {
             }
             const bool leader = has && eq_before == 0;
             const uint64_t lmask = __ballot(leader);
-            uint32_t rank = 0;
+            uint32_t rank = 0, gparts = 0;  // gparts: parts of my group
             bool lo_first = true;
             for (uint64_t mm = lmask; mm; mm &= mm - 1) {
                 const int t = __builtin_ctzll(mm);
                 const uint64_t kt = readlane64(key, t);
+                const bool same_lo = (kt >> 12) == (key >> 12);
+                gparts += same_lo ? 1u : 0u;
                 if (kt < key) {
                     ++rank;
-                    if ((kt >> 12) == (key >> 12)) lo_first = false;
+                    if (same_lo) lo_first = false;
                 }
             }
-            const bool gleader = leader && lo_first;  // one lane per (lo, r) group
+            const bool gleader = leader && lo_first;  // one lane per (lo, r) group, holding its first part
             rs.w_self += (uint32_t)__popcll(__ballot(has && lo == r));
             if (!big) {
                 // groups below the weight gate are skipped by every try_edge and never reach process_sv: inert
                 const bool strong = gw >= mrp;
                 const uint64_t gl_in = __ballot(gleader && lo < r && strong);
-                if (gleader && lo < r && strong) {
-                    atomicAdd(&a.out_deg[lo], 1u);
-                    a.out_hi[lo] = r;
-                }
+                if (gleader && lo < r && strong) atomicAdd(&a.out_deg[lo], 1u);
                 rs.np_all = (uint32_t)__popcll(lmask);
                 rs.np_self = (uint32_t)__popcll(__ballot(leader && lo == r));
                 rs.np_emit = (uint32_t)__popcll(__ballot(leader && (lo == r || strong)));
                 rs.n_weak = (uint32_t)__popcll(__ballot(gleader && lo < r && !strong));
                 rs.n_in = (uint32_t)__popcll(gl_in);
-                if (gl_in) {
-                    const int t = __builtin_ctzll(gl_in);
-                    rs.in_lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, t);
-                    rs.w_in = (uint32_t)__builtin_amdgcn_readlane((int)gw, t);
-                    rs.in_off = (uint32_t)__builtin_amdgcn_readlane((int)rank, t);
-                    rs.np_in = (uint32_t)__popcll(__ballot(leader && lo == rs.in_lo));
+                if (rs.n_in > (uint32_t)kK6MaxIn) {  // too many connections for a device-walked component
+                    if (gleader && lo < r && strong) a.bad_v[lo] = 1u;
+                    if (lane == 0) a.bad_v[r] = 1u;
+                } else {
+                    int e = 0;
+                    for (uint64_t mm = gl_in; mm; mm &= mm - 1, ++e) {
+                        const int t = __builtin_ctzll(mm);
+                        rs.e_lo[e] = (uint32_t)__builtin_amdgcn_readlane((int)lo, t);
+                        rs.e_w[e] = (uint32_t)__builtin_amdgcn_readlane((int)gw, t);
+                        rs.e_off[e] = (uint32_t)__builtin_amdgcn_readlane((int)rank, t);
+                        rs.e_cnt[e] = (uint32_t)__builtin_amdgcn_readlane((int)gparts, t);
+                    }
                 }
-                if (leader) {
-                    a.p_key[first + rank] = (lo < r && !strong) ? (key | kWeakPart) : key;
-                    a.p_pairs[first + rank] = cnt;
-                    a.p_sum[first + rank] = sum;
-                }
+                if (leader) a.parts[first + rank] = PartRec{(lo < r && !strong) ? (key | kWeakPart) : key, cnt, sum};
             } else {
                 // too many reads for one in-register sort: the chunk's partial aggregates go to the host, which merges
                 // them; every group counts as a connection (a chunk cannot know the whole group's weight)
-                const uint64_t gl_in = __ballot(gleader && lo < r);
                 if (gleader && lo < r) {
                     atomicAdd(&a.out_deg[lo], 1u);
-                    a.out_hi[lo] = r;
+                    a.bad_v[lo] = 1u;
                 }
-                rs.n_in += (uint32_t)__popcll(gl_in);
+                if (lane == 0) a.bad_v[r] = 1u;
                 const uint32_t nl = (uint32_t)__popcll(lmask);
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(&a.counts->n_groups, nl);
@@ -160,25 +173,77 @@ __global__ __launch_bounds__(256) void k6_pairs_kernel(K6Arrays a) {
     }
 }
 
+// one round of min-label propagation over the gate-passing groups (each is stored with its later region)
+__global__ __launch_bounds__(256) void k6_label_kernel(K6Arrays a) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.counts->n_regions) return;
+    const RegSum* s = &a.rs[r];
+    const uint32_t n_in = s->n_in;
+    if (s->big || n_in == 0 || n_in > (uint32_t)kK6MaxIn) return;
+    for (uint32_t e = 0; e < n_in; ++e) {
+        const uint32_t lo = s->e_lo[e];
+        const uint32_t lr = a.label[r], ll = a.label[lo];
+        if (lr < ll) atomicMin(&a.label[lo], lr);
+        else if (ll < lr) atomicMin(&a.label[r], ll);
+    }
+}
+
+// closure check and member registration: a label whose members only have groups among themselves, all inside one
+// flush window, is a complete component
+__global__ __launch_bounds__(256) void k6_classify_kernel(K6Arrays a) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.counts->n_regions) return;
+    const RegSum* s = &a.rs[r];
+    const uint32_t n_in = s->n_in;
+    const bool hub = s->big || n_in > (uint32_t)kK6MaxIn;
+    if (!hub && n_in == 0 && a.out_deg[r] == 0 && s->np_self == 0) return;  // no group that could ever be consumed
+    const uint32_t L = a.label[r];
+    if (hub || a.bad_v[r]) a.bad[L] = 1u;
+    if (!hub)
+        for (uint32_t e = 0; e < n_in; ++e) {
+            const uint32_t ll = a.label[s->e_lo[e]];
+            if (ll != L) { a.bad[L] = 1u; a.bad[ll] = 1u; }
+        }
+    const uint32_t period = (uint32_t)a.period;
+    if (r / period != L / period) a.bad[L] = 1u;
+    const uint32_t slot = atomicAdd(&a.mcount[L], 1u);
+    if (slot < (uint32_t)kK6MaxMembers) {
+        MemberInfo mi;
+        mi.r = r;
+        mi.rec = a.r_rec[r];
+        mi.np_all = s->np_all; mi.np_self = s->np_self; mi.w_self = s->w_self; mi.n_in = hub ? 0u : n_in;
+        for (int e = 0; e < kK6MaxIn; ++e) { mi.e_lo[e] = s->e_lo[e]; mi.e_w[e] = s->e_w[e]; mi.e_off[e] = s->e_off[e]; mi.e_cnt[e] = s->e_cnt[e]; }
+        mi.stored = region_stored(mi.rec, a) ? 1u : 0u;
+        mi.pad = 0;
+        a.members[(size_t)L * kK6MaxMembers + slot] = mi;
+    }
+    if (s->np_emit) atomicAdd(&a.pcount[L], s->np_emit);
+}
+
 namespace {
 
 // process_sv (BreakDancer.cpp:348-497) + SvBuilder for region A (and B when B >= 0) over the alive groups gs[0..2] =
-// (A,A), (A,B), (B,B).  Writes the slot's staging record; slot_info stays 0 when a gate rejects the candidate.
-__device__ void assemble_sv(const K6Arrays& a, uint32_t A, int32_t B, const GrpRange (&gs)[3], int max_readlen, uint32_t slot,
-                            uint32_t start) {
+// (A,A), (A,B), (B,B).  Returns false when a gate rejects the candidate; otherwise the record and its entries are
+// written to the staging slot (by the lane with `store` set).
+__device__ bool assemble_sv(const K6Arrays& a, const PartRec* P, uint32_t A, int32_t B, const RegionRec& ra, const RegionRec& rb,
+                            const uint32_t* pk_last_a, const uint32_t* pk_first_b, const GrpRange (&gs)[3], int max_readlen,
+                            uint32_t slot, uint32_t start, bool store, int* flag_counts /* [kNumFlags], LDS */, uint32_t* nacc_out,
+                            uint32_t* ncn_out) {
+    const uint32_t lib_room = a.lib_stride;
     const int mrp = a.min_read_pair;
-    int flag_counts[kNumFlags];
 #pragma unroll
     for (int f = 0; f < kNumFlags; ++f) flag_counts[f] = 0;
     int num_pairs = 0;
+#pragma unroll
     for (int g = 0; g < 3; ++g)
         for (uint32_t i = 0; i < gs[g].cnt; ++i) {
-            const int f = (int)(a.p_key[gs[g].beg + i] & 15);
-            const int pr = (int)a.p_pairs[gs[g].beg + i];
+            const PartRec q = P[gs[g].beg + i];
+            const int f = (int)(q.key & 15);
+            const int pr = (int)q.pairs;
             if (f < kNumFlags) flag_counts[f] += pr;
             num_pairs += pr;
         }
-    if (num_pairs < mrp) return;
+    if (num_pairs < mrp) return false;
     int flag = BDX_NA;
     {
         int best = 0;
@@ -186,15 +251,13 @@ __device__ void assemble_sv(const K6Arrays& a, uint32_t A, int32_t B, const GrpR
             if (flag_counts[f] > flag_counts[best]) best = f;
         if (flag_counts[best] > 0) flag = best;
     }
-    if (flag_counts[flag] < mrp) return;
+    if (flag_counts[flag] < mrp) return false;
 
-    const RegionRec ra = a.r_rec[A];
     int chr[2], pos[2], fwd[2], rev[2];
     chr[0] = ra.tid; pos[0] = ra.start; pos[1] = ra.end;
     fwd[0] = (int)(ra.n - ra.rev); rev[0] = (int)ra.rev;
     int total_region_size = ra.end - ra.start + 1;
     if (B >= 0) {
-        const RegionRec rb = a.r_rec[B];
         fwd[1] = (int)(rb.n - rb.rev); rev[1] = (int)rb.rev;
         if (flag == BDX_ARP_RF) pos[1] = rb.end + max_readlen - 5;
         else if (flag == BDX_ARP_FF) { pos[0] = pos[1]; pos[1] = rb.end + max_readlen - 5; }
@@ -208,35 +271,36 @@ __device__ void assemble_sv(const K6Arrays& a, uint32_t A, int32_t B, const GrpR
 
     // per-library pairs / spans of the dominant flag in ascending library order: a three-way merge, the parts of a
     // group being sorted by (flag, library)
-    uint32_t idx[3] = {0, 0, 0};
-    auto skip = [&](int g) {
-        while (idx[g] < gs[g].cnt && (int)(a.p_key[gs[g].beg + idx[g]] & 15) != flag) ++idx[g];
-    };
-    skip(0); skip(1); skip(2);
-    LibStage* ls = a.lib_stage + (size_t)slot * a.acc_stride;
+    uint32_t idx[3] = {0, 0, 0};  // (every loop over g below is unrolled: static indices, registers)
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+        while (idx[g] < gs[g].cnt && (int)(P[gs[g].beg + idx[g]].key & 15) != flag) ++idx[g];
+    LibStage* ls = a.lib_stage + (size_t)slot * a.lib_stride;
     uint32_t nacc = 0;
     float diff = 0.0f;
     while (true) {
         int best = 256;
+#pragma unroll
         for (int g = 0; g < 3; ++g)
-            if (idx[g] < gs[g].cnt) best = min(best, (int)((a.p_key[gs[g].beg + idx[g]] >> 4) & 255));
+            if (idx[g] < gs[g].cnt) best = min(best, (int)((P[gs[g].beg + idx[g]].key >> 4) & 255));
         if (best == 256) break;
         int rc = 0, span = 0;
+#pragma unroll
         for (int g = 0; g < 3; ++g)
-            if (idx[g] < gs[g].cnt && (int)((a.p_key[gs[g].beg + idx[g]] >> 4) & 255) == best) {
-                rc += (int)a.p_pairs[gs[g].beg + idx[g]];
-                span += (int)a.p_sum[gs[g].beg + idx[g]];
+            if (idx[g] < gs[g].cnt && (int)((P[gs[g].beg + idx[g]].key >> 4) & 255) == best) {
+                rc += (int)P[gs[g].beg + idx[g]].pairs;
+                span += (int)P[gs[g].beg + idx[g]].sum;
                 ++idx[g];
-                skip(g);
+                while (idx[g] < gs[g].cnt && (int)(P[gs[g].beg + idx[g]].key & 15) != flag) ++idx[g];
             }
         diff = __fadd_rn(diff, __fsub_rn((float)span, __fmul_rn((float)rc, a.lib_mean[best])));
         const uint32_t nflag = a.hist[(size_t)best * kNumFlags + flag];
         double lambda = __dmul_rn((double)total_region_size, __ddiv_rn((double)nflag, (double)a.covered_ref_len));
         lambda = (1.0e-10 < lambda) ? lambda : 1.0e-10;
-        if (nacc < a.acc_stride) ls[nacc] = LibStage{best, rc, lambda};
+        if (store && nacc < lib_room) ls[nacc] = LibStage{best, rc, lambda};
         ++nacc;
     }
-    if (nacc > a.acc_stride) { a.counts->overflow = 3; return; }  // cannot happen: distinct libraries <= min(nlibs, parts)
+    if (nacc > lib_room) { a.counts->overflow = 3; return false; }  // cannot happen: distinct libraries <= min(nlibs, parts)
 
     // normal reads between the regions: proper reads after A's last read up to and including B's first
     CnStage* cs = a.cn_stage + (size_t)slot * a.nkeys;
@@ -246,10 +310,10 @@ __device__ void assemble_sv(const K6Arrays& a, uint32_t A, int32_t B, const GrpR
         const int nk = a.nkeys;
         const float span = (float)(pos[1] - pos[0]);
         for (int k = 0; k < nk; ++k) {
-            const uint32_t cnt = a.r_pk[(size_t)B * 2 * nk + k] - a.r_pk[(size_t)A * 2 * nk + nk + k];
+            const uint32_t cnt = pk_first_b[k] - pk_last_a[k];
             if (cnt == 0) continue;
             const float cn = __fmul_rn(__fdiv_rn((float)cnt, __fmul_rn(a.key_density[k], span)), 2.0f);
-            cs[ncn] = CnStage{k, cn};
+            if (store) cs[ncn] = CnStage{k, cn};
             ++ncn;
             cn_sum = __fadd_rn(cn_sum, cn);
         }
@@ -271,62 +335,55 @@ __device__ void assemble_sv(const K6Arrays& a, uint32_t A, int32_t B, const GrpR
     o.sv.allele_frequency = allele_frequency; o.sv.logp = 0.0;
     o.grp_mask = (gs[0].cnt ? 1u : 0u) | (gs[1].cnt ? 2u : 0u) | (gs[2].cnt ? 4u : 0u);
     o.start = start;
-    a.slot[slot] = o;
-    a.slot_info[slot] = 1u | (nacc << 1) | (ncn << 8);
+    if (store) a.sv_stage[slot] = o;
+    *nacc_out = nacc;
+    *ncn_out = ncn;
+    return true;
+}
+
+__device__ __forceinline__ int pair_index(int x, int y) {  // x < y < 4 -> 0..5
+    return x == 0 ? y - 1 : (x == 1 ? y + 1 : 5);
 }
 
 }  // namespace
 
-// One thread per region: decide who handles its component, hand foreign components to the host, walk its own.
-__global__ __launch_bounds__(256) void k6_sv_kernel(K6Arrays a) {
+namespace {
+
+// is the component with label L walked on the device?  (evaluated identically by every member and by the walk)
+__device__ __forceinline__ bool component_on_device(const K6Arrays& a, uint32_t L) {
+    return !a.force_host && !a.bad[L] && a.mcount[L] <= (uint32_t)kK6MaxMembers &&
+           min((uint32_t)a.nlibs, a.pcount[L]) <= a.lib_stride;
+}
+
+}  // namespace
+
+// One thread per region: the groups of the components that are not walked here go to the host list; totals; the last
+// workgroup mirrors the counters into pinned host memory, so the host's share is complete when this kernel ends.
+__global__ __launch_bounds__(256) void k6_emit_kernel(K6Arrays a) {
     const int lane = threadIdx.x & 63;
     const uint32_t NR = a.counts->n_regions;
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
     const bool active = r < NR;
-    const int mrp = a.min_read_pair;
-    const uint32_t period = (uint32_t)a.period;
     RegSum s{};
-    uint32_t od = 0;
-    if (active) { s = a.rs[r]; od = a.out_deg[r]; }
-    bool single = false, pairA = false, pairB = false;
-    uint32_t B = 0;
-    RegSum sB{};
-    if (active && !a.force_host && !s.big) {
-        if (s.n_in == 0 && od == 0) {
-            single = s.np_self > 0 && s.np_self <= (uint32_t)kK6MaxParts;
-        } else if (s.n_in == 0 && od == 1) {
-            B = a.out_hi[r];
-            sB = a.rs[B];
-            pairA = !sB.big && sB.n_in == 1 && a.out_deg[B] == 0 && B / period == r / period &&
-                    s.np_self + sB.np_in + sB.np_self <= (uint32_t)kK6MaxParts;
-        } else if (s.n_in == 1 && od == 0) {
-            const uint32_t A = s.in_lo;
-            const RegSum sA = a.rs[A];
-            pairB = !sA.big && sA.n_in == 0 && a.out_deg[A] == 1 && A / period == r / period &&
-                    sA.np_self + s.np_in + s.np_self <= (uint32_t)kK6MaxParts;
-        }
-    }
-    const bool covered = single || pairA || pairB;
-
-    // groups of the components this kernel does not walk -> host list (one reservation per wave)
+    uint32_t od = 0, L = 0;
+    if (active) { s = a.rs[r]; od = a.out_deg[r]; L = a.label[r]; a.own_nsv[r] = 0; a.own_nacc[r] = 0; a.own_ncn[r] = 0; }
+    const bool hub = s.big || s.n_in > (uint32_t)kK6MaxIn;
+    const bool registered = active && (hub || s.n_in > 0 || od > 0 || s.np_self > 0);
+    const bool covered = registered && component_on_device(a, L);
     {
-        const uint32_t need = (active && !covered && !s.big) ? s.np_emit : 0u;
-        const uint32_t inc = wave_incl_scan(need);
-        const uint32_t tot = (uint32_t)__shfl((int)inc, 63);
-        uint32_t base = 0;
-        if (lane == 63 && tot) base = atomicAdd(&a.counts->n_groups, tot);
-        base = (uint32_t)__shfl((int)base, 63);
+        const uint32_t need = (registered && !covered && !s.big) ? s.np_emit : 0u;
+        uint32_t o = wave_reserve(need, &a.counts->n_groups);
         if (need) {
             const uint32_t first = a.r_rec[r].first;
-            uint32_t o = base + inc - need;
             for (uint32_t i = 0; i < s.np_all; ++i) {
-                const uint64_t key = a.p_key[first + i];
+                const PartRec q = a.parts[first + i];
+                const uint64_t key = q.key;
                 if (key & kWeakPart) continue;
                 if (o < a.g_cap) {
                     GroupRec g;
                     g.key = ((key >> 12) << 38) | ((uint64_t)r << 12) | (key & 0xFFFull);
-                    g.pairs = a.p_pairs[first + i];
-                    g.sum_isize = a.p_sum[first + i];
+                    g.pairs = q.pairs;
+                    g.sum_isize = q.sum;
                     a.g_rec[o] = g;
                 } else {
                     a.counts->overflow = 1;
@@ -335,106 +392,259 @@ __global__ __launch_bounds__(256) void k6_sv_kernel(K6Arrays a) {
             }
         }
     }
-    // totals: pairs of all regions, groups of the components walked here
-    {
+    {   // pairs of all regions; connections: inert ones everywhere, the others where the component is walked on the device
         const uint32_t pairs = active ? s.n_pairs : 0u;
-        uint32_t grp = active ? s.n_weak : 0u;  // inert connections are counted but never listed
-        if (single) grp += 1;
-        else if (pairA) grp += 1u + (s.np_self ? 1u : 0u) + (sB.np_self ? 1u : 0u);
+        const uint32_t grp = (active ? s.n_weak : 0u) + (covered ? s.n_in + (s.np_self ? 1u : 0u) : 0u);
         const uint32_t tp = wave_sum_u32(pairs), tg = wave_sum_u32(grp);
         if (lane == 0) {
             if (tp) atomicAdd(&a.counts->n_pairs, tp);
             if (tg) atomicAdd(&a.counts->n_groups_dev, tg);
         }
     }
-    if (r == 0) a.counts->n_slots = 3 * NR;
-    if (!active || pairB) return;  // the slots of a pair's second region are written by the thread of the first
+}
 
-    // _max_readlen at this window's flush: the value of the candidate that closes there (BreakDancer.cpp:254-259)
-    const uint32_t rl = (r / period + 1) * period - 1;
-    const int max_readlen = rl < NR ? a.r_rec[rl].maxq : a.counts->last_maxq;
-    a.slot_info[3 * r] = 0; a.slot_info[3 * r + 1] = 0; a.slot_info[3 * r + 2] = 0;
-    const GrpRange none{0, 0};
-    if (single) {
-        const RegionRec RA = a.r_rec[r];
-        if ((int)s.w_self >= mrp) {
-            const GrpRange gs[3] = {region_stored(RA, a) ? GrpRange{RA.first + s.np_all - s.np_self, s.np_self} : none, none, none};
-            assemble_sv(a, r, -1, gs, max_readlen, 3 * r, r);
+// the counters after k6_emit_kernel, mirrored into pinned host memory (a per-workgroup fence + last-block copy inside
+// that kernel costs an L2 write-back per workgroup on this multi-die part; one tiny launch does not)
+__global__ __launch_bounds__(64) void k6_mirror_kernel(K6Arrays a) {
+    if (threadIdx.x < sizeof(StageCounts) / 4) ((uint32_t*)a.counts_host)[threadIdx.x] = ((const uint32_t*)a.counts)[threadIdx.x];
+}
+
+// One WAVE per region.  Every lane runs the same scalar code, so the data-dependent control flow of the walk does not
+// diverge; the lanes only split up to fetch the component's description (written next to its label by
+// k6_classify_kernel), its parts and its normal-read samples into LDS in one round trip each, and lane 0 stores.
+// The smallest region of a device-walked component replays build_connection over it.
+constexpr int kK6LdsPk = 16;  // 2 x nkeys words per member kept in LDS (more keys: read from HBM)
+
+__global__ __launch_bounds__(256) void k6_walk_kernel(K6Arrays a) {
+    __shared__ uint32_t s_desc[4][kK6MaxMembers * kMemberWords];
+    __shared__ PartRec s_parts[4][kK6LdsParts];
+    __shared__ uint32_t s_pk[4][kK6MaxMembers * kK6LdsPk];
+    // the walk's small tables are indexed by run-time values: in LDS (every lane writes the same word) they cost a few
+    // cycles, as private arrays they would live in scratch memory
+    struct Tables {
+        GrpRange S[kK6MaxMembers], E[6];
+        uint32_t Sw[kK6MaxMembers], Ew[6], Sslot[kK6MaxMembers], Eslot[6];
+        int ord[kK6MaxMembers], tails[12], newtails[12], flag_counts[kNumFlags];
+    };
+    __shared__ Tables s_tab[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    Tables& T = s_tab[w];
+    GrpRange* const S = T.S;
+    GrpRange* const E = T.E;
+    uint32_t* const Sw = T.Sw;
+    uint32_t* const Ew = T.Ew;
+    uint32_t* const Sslot = T.Sslot;
+    uint32_t* const Eslot = T.Eslot;
+    int* const ord = T.ord;
+    int* const tails = T.tails;
+    int* const newtails = T.newtails;
+    const uint32_t nwaves = gridDim.x * 4;
+    const uint32_t NR = a.counts->n_regions;
+    const int mrp = a.min_read_pair;
+    const int nk = a.nkeys;
+    const uint32_t period = (uint32_t)a.period;
+    for (uint32_t r = blockIdx.x * 4 + w; r < NR; r += nwaves) {
+        if (a.label[r] != r) continue;  // not the smallest region of its component
+        const uint32_t k_raw = a.mcount[r];
+        if (k_raw == 0 || !component_on_device(a, r)) continue;
+        const int k = (int)k_raw;
+        // _max_readlen at this window's flush: the value of the candidate that closes there (BreakDancer.cpp:254-259)
+        const uint32_t rl = (r / period + 1) * period - 1;
+        const int max_readlen = rl < NR ? a.r_rec[rl].maxq : a.counts->last_maxq;
+        {   // the component's description: one coalesced fetch
+            const uint32_t* src = (const uint32_t*)(a.members + (size_t)r * kK6MaxMembers);
+            for (int i = lane; i < k * kMemberWords; i += 64) s_desc[w][i] = src[i];
         }
-    } else if (pairA) {
-        a.slot_info[3 * B] = 0; a.slot_info[3 * B + 1] = 0; a.slot_info[3 * B + 2] = 0;
-        const RegionRec RA = a.r_rec[r], RB = a.r_rec[B];
-        const bool stA = region_stored(RA, a), stB = region_stored(RB, a);
-        const GrpRange AA{RA.first + s.np_all - s.np_self, s.np_self}, AB{RB.first + sB.in_off, sB.np_in},
-            BB{RB.first + sB.np_all - sB.np_self, sB.np_self};
-        bool aliveAA = AA.cnt > 0, aliveBB = BB.cnt > 0;
-        if (AA.cnt > 0 && (int)s.w_self >= mrp) {  // visit(A): its self edge first
-            const GrpRange gs[3] = {stA ? AA : none, none, none};
-            assemble_sv(a, r, -1, gs, max_readlen, 3 * r, r);
-            if (stA) aliveAA = false;
+        __builtin_amdgcn_wave_barrier();
+        const MemberInfo* D = (const MemberInfo*)s_desc[w];
+        for (int i = 0; i < k; ++i) ord[i] = i;  // members in ascending region order
+        for (int i = 1; i < k; ++i) {  // insertion sort, k <= 4
+            const int x = ord[i];
+            int j = i;
+            while (j > 0 && D[ord[j - 1]].r > D[x].r) { ord[j] = ord[j - 1]; --j; }
+            ord[j] = x;
         }
-        const bool passed = (int)sB.w_in >= mrp;  // then the edge A-B: B joins the frontier whatever process_sv decides
-        if (passed) {
-            const GrpRange gs[3] = {(aliveAA && stA) ? AA : none, (stA && stB) ? AB : none, (aliveBB && stB) ? BB : none};
-            assemble_sv(a, r, (int32_t)B, gs, max_readlen, 3 * r + 1, r);
-            if (stA) aliveAA = false;
-            if (stB) aliveBB = false;
+        for (int e = 0; e < 6; ++e) { E[e] = GrpRange{0, 0}; Ew[e] = 0; Eslot[e] = 0; }
+        for (int i = 0; i < k; ++i) {
+            const MemberInfo& M = D[ord[i]];
+            S[i] = GrpRange{M.rec.first + M.np_all - M.np_self, M.np_self};
+            Sw[i] = M.w_self;
+            Sslot[i] = M.rec.first + M.n_in;
+            for (uint32_t e = 0; e < M.n_in; ++e) {
+                int x = 0;
+                while (x < i && D[ord[x]].r != M.e_lo[e]) ++x;  // the closure check guarantees it is a member
+                if (x < i) {
+                    const int pi = pair_index(x, i);
+                    E[pi] = GrpRange{M.rec.first + M.e_off[e], M.e_cnt[e]};
+                    Ew[pi] = M.e_w[e];
+                    Eslot[pi] = M.rec.first + e;
+                }
+            }
         }
-        if (BB.cnt > 0 && (int)sB.w_self >= mrp) {  // visit(B): from A's frontier, or later as its own start vertex
-            const GrpRange gs[3] = {(aliveBB && stB) ? BB : none, none, none};
-            assemble_sv(a, B, -1, gs, max_readlen, passed ? 3 * r + 2 : 3 * B, passed ? r : B);
+        // the parts the walk can touch: into LDS when they fit, one lane per part
+        const PartRec* P = a.parts;
+        {
+            uint32_t n_rel = 0;
+            for (int i = 0; i < k; ++i) n_rel += S[i].cnt;
+            for (int e = 0; e < 6; ++e) n_rel += E[e].cnt;
+            if (n_rel <= (uint32_t)kK6LdsParts) {
+                uint32_t o = 0;
+                for (int i = 0; i < k; ++i) {
+                    if ((uint32_t)lane >= o && (uint32_t)lane < o + S[i].cnt) s_parts[w][lane] = a.parts[S[i].beg + (lane - o)];
+                    S[i].beg = o;
+                    o += S[i].cnt;
+                }
+                for (int e = 0; e < 6; ++e) {
+                    if ((uint32_t)lane >= o && (uint32_t)lane < o + E[e].cnt) s_parts[w][lane] = a.parts[E[e].beg + (lane - o)];
+                    E[e].beg = o;
+                    o += E[e].cnt;
+                }
+                P = s_parts[w];
+            }
         }
+        // proper-read samples of the members (first read: nkeys words, last read: nkeys words)
+        const bool pk_lds = 2 * nk <= kK6LdsPk;
+        if (pk_lds)
+            for (int i = lane; i < k * 2 * nk; i += 64) {
+                const int mi = i / (2 * nk), q = i - mi * 2 * nk;
+                s_pk[w][mi * kK6LdsPk + q] = a.r_pk[(size_t)D[ord[mi]].r * 2 * nk + q];
+            }
+        __builtin_amdgcn_wave_barrier();
+
+        uint32_t nsv = 0, nacc_tot = 0, ncn_tot = 0;
+        uint32_t visited = 0, self_done = 0, edge_done = 0, self_alive = 0, edge_alive = 0;
+        for (int i = 0; i < k; ++i)
+            if (S[i].cnt) self_alive |= 1u << i;
+        for (int e = 0; e < 6; ++e)
+            if (E[e].cnt) edge_alive |= 1u << e;
+        int nt = 1, nn = 0;
+        tails[0] = 0;  // the smallest member is the start vertex; the gate-passing groups connect all of them
+        const GrpRange none{0, 0};
+        while (nt) {
+            nn = 0;
+            for (int ti = 0; ti < nt; ++ti) {
+                const int tail = tails[ti];
+                if (visited & (1u << tail)) continue;
+                for (int nb = 0; nb < k; ++nb) {  // neighbours in ascending order, the vertex itself at its own place
+                    int A, B;
+                    uint32_t slot;
+                    if (nb == tail) {
+                        if (!S[tail].cnt || (self_done & (1u << tail)) || (int)Sw[tail] < mrp) continue;
+                        self_done |= 1u << tail;
+                        A = tail; B = -1;
+                        slot = Sslot[tail];
+                    } else {
+                        const int x = min(nb, tail), y = max(nb, tail), pi = pair_index(x, y);
+                        if (!E[pi].cnt || (edge_done & (1u << pi)) || (int)Ew[pi] < mrp) continue;
+                        edge_done |= 1u << pi;
+                        A = x; B = y;
+                        slot = Eslot[pi];
+                    }
+                    if (nn < 12) newtails[nn++] = nb;
+                    const MemberInfo& MA = D[ord[A]];
+                    const MemberInfo& MB = D[ord[B >= 0 ? B : A]];
+                    GrpRange gs[3] = {none, none, none};
+                    if ((self_alive & (1u << A)) && MA.stored) gs[0] = S[A];
+                    if (B >= 0) {
+                        const int pi = pair_index(A, B);
+                        if ((edge_alive & (1u << pi)) && MA.stored && MB.stored) gs[1] = E[pi];
+                        if ((self_alive & (1u << B)) && MB.stored) gs[2] = S[B];
+                    }
+                    // paired reads leave their regions before any gate (BreakDancer.cpp:363-368)
+                    if (gs[0].cnt) self_alive &= ~(1u << A);
+                    if (gs[1].cnt) edge_alive &= ~(1u << pair_index(A, B));
+                    if (gs[2].cnt) self_alive &= ~(1u << B);
+                    const uint32_t* pkA = pk_lds ? &s_pk[w][A * kK6LdsPk + nk] : a.r_pk + (size_t)MA.r * 2 * nk + nk;
+                    const uint32_t* pkB = pk_lds ? &s_pk[w][(B >= 0 ? B : A) * kK6LdsPk] : a.r_pk + (size_t)MB.r * 2 * nk;
+                    uint32_t nacc = 0, ncn = 0;
+                    if (nsv < (uint32_t)kK6MaxSv &&
+                        assemble_sv(a, P, MA.r, B >= 0 ? (int32_t)MB.r : -1, MA.rec, MB.rec, pkA, pkB, gs, max_readlen, slot, r, lane == 0,
+                                    T.flag_counts, &nacc, &ncn)) {
+                        if (lane == 0) a.own_slots[(size_t)r * kK6MaxSv + nsv] = slot;
+                        ++nsv;
+                        nacc_tot += nacc;
+                        ncn_tot += ncn;
+                    }
+                }
+                visited |= 1u << tail;
+            }
+            nt = nn;
+            for (int i = 0; i < nn; ++i) tails[i] = newtails[i];
+        }
+        if (lane == 0) { a.own_nsv[r] = nsv; a.own_nacc[r] = nacc_tot; a.own_ncn[r] = ncn_tot; }
+        __builtin_amdgcn_wave_barrier();  // the LDS slices are reused by the wave's next region
     }
 }
 
-struct SlotIn {
-    const uint32_t* info;
-    __device__ U4 operator()(uint32_t i, uint32_t) const {
-        const uint32_t v = info[i];
-        return U4{v & 1u, (v >> 1) & 127u, (v >> 8) & 127u, 0u};
-    }
+struct OwnIn {
+    const uint32_t *nsv, *nacc, *ncn;
+    __device__ U4 operator()(uint32_t i, uint32_t) const { return U4{nsv[i], nacc[i], ncn[i], 0u}; }
 };
 
-struct SlotOut {
+struct OwnOut {
     K6Arrays a;
     __device__ void operator()(uint32_t i, uint32_t n, const U4& inc, const U4& e) const {
-        if (i == n - 1) { a.counts->n_sv_dev = inc.x; a.counts->n_terms_dev = inc.y; a.counts->n_cn_dev = inc.z; }
-        if (!e.x) return;
-        const uint32_t d = inc.x - 1, lb = inc.y - e.y, cb = inc.z - e.z;
-        if (d >= a.sv_cap || lb + e.y > a.term_cap || cb + e.z > a.cn_cap) { a.counts->overflow = 1; return; }
-        SvOut o = a.slot[i];
-        o.sv.lib_begin = (int32_t)lb;
-        o.sv.cn_begin = (int32_t)cb;
-        a.sv_out[d] = o;
-        const LibStage* ls = a.lib_stage + (size_t)i * a.acc_stride;
-        for (uint32_t q = 0; q < e.y; ++q) {
-            const LibStage l = ls[q];
-            a.lib_index[lb + q] = l.lib;
-            a.lib_pairs[lb + q] = l.rc;
-            a.t_lambda[lb + q] = l.lambda;
-            a.t_k[lb + q] = l.rc;
+        if (i == n - 1) {
+            a.counts->n_sv_dev = inc.x; a.counts->n_terms_dev = inc.y; a.counts->n_cn_dev = inc.z;
+            if (a.counts_host2) { a.counts_host2->n_sv_dev = inc.x; a.counts_host2->n_terms_dev = inc.y; a.counts_host2->n_cn_dev = inc.z; }
         }
-        const CnStage* cs = a.cn_stage + (size_t)i * a.nkeys;
-        for (uint32_t q = 0; q < e.z; ++q) {
-            const CnStage cn = cs[q];
-            a.cn_key[cb + q] = cn.key;
-            a.cn_value[cb + q] = cn.value;
+        if (!e.x) return;
+        uint32_t d = inc.x - e.x, lb = inc.y - e.y, cb = inc.z - e.z;
+        if (inc.x > a.sv_cap || inc.y > a.term_cap || inc.z > a.cn_cap) {
+            a.counts->overflow = 1;
+            if (a.counts_host2) a.counts_host2->overflow = 1;
+            return;
+        }
+        for (uint32_t q = 0; q < e.x; ++q) {
+            const uint32_t slot = a.own_slots[(size_t)i * kK6MaxSv + q];
+            SvOut o = a.sv_stage[slot];
+            const LibStage* ls = a.lib_stage + (size_t)slot * a.lib_stride;
+            for (int32_t t = 0; t < o.sv.lib_count; ++t) {
+                const LibStage l = ls[t];
+                a.lib_index[lb + t] = l.lib;
+                a.lib_pairs[lb + t] = l.rc;
+                a.t_lambda[lb + t] = l.lambda;
+                a.t_k[lb + t] = l.rc;
+            }
+            const CnStage* cs = a.cn_stage + (size_t)slot * a.nkeys;
+            for (int32_t t = 0; t < o.sv.cn_count; ++t) {
+                const CnStage cn = cs[t];
+                a.cn_key[cb + t] = cn.key;
+                a.cn_value[cb + t] = cn.value;
+            }
+            o.sv.lib_begin = (int32_t)lb;
+            o.sv.cn_begin = (int32_t)cb;
+            lb += (uint32_t)o.sv.lib_count;
+            cb += (uint32_t)o.sv.cn_count;
+            a.sv_out[d++] = o;
         }
     }
 };
 
 void launch_k6_groups(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
     if (n_anom_host == 0) return;
-    const uint32_t gp = std::min<uint32_t>((n_anom_host + 3) / 4, 1024u);
+    // regions <= anomalous reads, typically a tenth of them: about one wave per region, a grid-stride loop for the rest
+    const uint32_t gp = std::min<uint32_t>((n_anom_host / 8 + 3) / 4 + 1, 16384u);
+    const uint32_t gr = (n_anom_host + 255) / 256;
     hipLaunchKernelGGL(k6_pairs_kernel, dim3(gp), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k6_sv_kernel, dim3((n_anom_host + 255) / 256), dim3(256), 0, s, a);
+    if (!a.force_host)
+        for (int i = 0; i < kK6LabelRounds; ++i) hipLaunchKernelGGL(k6_label_kernel, dim3(gr), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k6_classify_kernel, dim3(gr), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k6_emit_kernel, dim3(gr), dim3(256), 0, s, a);
+    if (a.counts_host) hipLaunchKernelGGL(k6_mirror_kernel, dim3(1), dim3(64), 0, s, a);
+}
+
+void launch_k6_walk(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
+    if (n_anom_host == 0 || a.force_host) return;
+    const uint32_t gp = std::min<uint32_t>((n_anom_host / 8 + 3) / 4 + 1, 16384u);
+    hipLaunchKernelGGL(k6_walk_kernel, dim3(gp), dim3(256), 0, s, a);
 }
 
 void launch_k6_compact(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
     if (n_anom_host == 0) return;
-    SlotIn in{a.slot_info};
-    SlotOut out{a};
-    scan_launch<U4>(in, out, &a.counts->n_slots, 3 * n_anom_host, a.ws_u4, a.total_u4, s);
+    OwnIn in{a.own_nsv, a.own_nacc, a.own_ncn};
+    OwnOut out{a};
+    scan_launch<U4>(in, out, &a.counts->n_regions, n_anom_host, a.ws_u4, a.total_u4, s);
 }
 
 }  // namespace bdx
