@@ -90,6 +90,10 @@ struct bdx_ctx {
     DevBuf b_r_rec, b_r_pk, b_out_deg, b_out_hi, b_parts, b_kdens, b_rs, b_slot, b_members, b_own, b_lib_stage, b_cn_stage,
         b_t_lambda, b_t_k, b_ws6, b_k6const;
     PinBuf h_p1, h_cnt, h_counts, h_regs, h_pk, h_groups, h_terms;
+    DevBuf b_sv_terms, b_ltail;
+    PinBuf h_hs_rec, h_hs_aux, h_hs_lists;
+    bool materialized = true;         // c->walk holds the final table (false: it still sits in the pinned buffers only)
+    uint32_t n_sv_total = 0, n_groups_total = 0, n_terms_total = 0, n_cn_total = 0;
     PinBuf h_counts0, h_counts2, h_sv_out, h_lib_index, h_lib_pairs, h_cn_key, h_cn_value, h_ltail_dev, h_k6const;
     hipEvent_t ev_groups = nullptr, ev_regions = nullptr;
     bool bucketed_join = false;       // BDX_BUCKETED_JOIN=1: use the partitioned LDS join at every size (it is the path for > 4 M entries)
@@ -261,11 +265,11 @@ void bdx_destroy(bdx_ctx* c) {
                       &c->b_c_nnormal, &c->b_c_rid, &c->b_region_of, &c->b_ws_u4, &c->b_ws_u32, &c->b_totals,
                       &c->b_counts, &c->b_bcnt, &c->b_boff, &c->b_bcur, &c->b_e_key, &c->b_e_idx, &c->b_partner, &c->b_t_key,
                       &c->b_t_idx, &c->b_x_key, &c->b_x_order, &c->b_x_region,
-                      &c->b_x_meta, &c->b_x_isize, &c->b_x_n, &c->b_fold, &c->b_lib_mean, &c->b_r_rec, &c->b_r_pk, &c->b_out_deg, &c->b_out_hi,
+                      &c->b_x_meta, &c->b_x_isize, &c->b_x_n, &c->b_fold, &c->b_lib_mean, &c->b_sv_terms, &c->b_ltail, &c->b_r_rec, &c->b_r_pk, &c->b_out_deg, &c->b_out_hi,
                       &c->b_parts, &c->b_kdens, &c->b_rs, &c->b_slot, &c->b_members, &c->b_own, &c->b_lib_stage,
                       &c->b_cn_stage, &c->b_t_lambda, &c->b_t_k, &c->b_ws6, &c->b_k6const};
     for (DevBuf* b : bufs) b->release();
-    PinBuf* pins[] = {&c->h_p1, &c->h_cnt, &c->h_counts, &c->h_regs, &c->h_pk, &c->h_groups, &c->h_terms, &c->h_counts0, &c->h_counts2,
+    PinBuf* pins[] = {&c->h_p1, &c->h_cnt, &c->h_counts, &c->h_regs, &c->h_pk, &c->h_groups, &c->h_terms, &c->h_hs_rec, &c->h_hs_aux, &c->h_hs_lists, &c->h_counts0, &c->h_counts2,
                       &c->h_sv_out, &c->h_lib_index, &c->h_lib_pairs, &c->h_cn_key, &c->h_cn_value, &c->h_ltail_dev, &c->h_k6const};
     for (PinBuf* b : pins) b->release();
     if (c->walk_scratch) walk_scratch_free(c->walk_scratch);
@@ -680,6 +684,8 @@ int do_k6(bdx_ctx* c, bool force_host) {
     HIPCHK(c, c->h_cn_key.ensure((size_t)a.cn_cap * 4 + 16)); HIPCHK(c, c->h_cn_value.ensure((size_t)a.cn_cap * 4 + 16));
     HIPCHK(c, c->h_ltail_dev.ensure((size_t)a.term_cap * 8));
     HIPCHK(c, c->h_counts2.ensure(sizeof(StageCounts)));
+    HIPCHK(c, c->b_sv_terms.ensure((size_t)a.sv_cap * sizeof(uint2))); HIPCHK(c, c->b_ltail.ensure((size_t)a.term_cap * 8));
+    a.sv_terms = c->b_sv_terms.as<uint2>(); a.ltail = c->b_ltail.as<double>();
     a.cap = na;
     a.r_rec = c->b_r_rec.as<RegionRec>(); a.r_pk = c->b_r_pk.as<uint32_t>();
     a.region_of = c->k3.region_of; a.partner = c->k4.partner; a.meta = c->cp.meta; a.isize = c->cp.isize;
@@ -712,12 +718,107 @@ int do_k6(bdx_ctx* c, bool force_host) {
     launch_k6_groups(a, na, s);
     HIPCHK(c, hipEventRecord(c->ev_groups, s));  // the host walk of the remaining components can start here
     launch_k6_walk(a, na, s);
-    launch_k6_compact(a, na, s);
-    launch_k5_dev(a.t_lambda, a.t_k, c->h_ltail_dev.as<double>(), &a.counts->n_terms_dev, a.term_cap, s);
     return BDX_OK;
 }
 
-// H1 walk over c->regions / c->r_pk / c->parts with the adopted pass-1 statistics; K5 for its terms is enqueued
+// second half of K6, enqueued once the host walk has produced its share: the host's SV candidates (pinned memory) are
+// interleaved with the device's by the compaction, K5 scores every term, the score kernel finishes every candidate --
+// the final table is assembled by the device in pinned host memory, in the reference's output order.
+int do_k6_table(bdx_ctx* c) {
+    hipStream_t s = c->stream;
+    const uint32_t na = c->p1.n_anom;
+    K6Arrays& a = c->k6;
+    if (!na) return BDX_OK;
+    const WalkResult& H = c->walk;
+    const uint32_t nh = (uint32_t)H.svs.size(), nt = (uint32_t)H.terms.size(), nc = (uint32_t)H.cn_key.size();
+    a.nh = nh;
+    if (nh) {
+        const uint64_t period = (uint64_t)std::max(1, c->opts.buffer_size + 1);
+        HIPCHK(c, c->h_hs_rec.ensure((size_t)nh * sizeof(SvOut)));
+        HIPCHK(c, c->h_hs_aux.ensure(((size_t)nh * 3 + 2) * 4));
+        HIPCHK(c, c->h_hs_lists.ensure((size_t)nt * 16 + (size_t)nc * 8 + 16));
+        memcpy(c->h_hs_rec.p, H.svs.data(), (size_t)nh * sizeof(HostSv));
+        uint32_t* T = c->h_hs_aux.as<uint32_t>();
+        uint32_t* pre_l = T + nh;
+        uint32_t* pre_c = pre_l + nh + 1;
+        uint32_t sl = 0, sc = 0;
+        for (uint32_t j = 0; j < nh; ++j) {
+            // a device candidate comes from a traversal started at one of a window's own vertices; this host candidate
+            // precedes those whose start vertex is not below its own start vertex -- or not below the first vertex of
+            // its window when its traversal started from a vertex of an earlier window
+            const uint64_t key = H.sv_key[j];
+            const bool from_old = !((key >> 32) & 1ull);
+            T[j] = (uint32_t)(from_old ? (key >> 33) * period : (key & 0xffffffffull));
+            if (a.force_host) T[j] = 0;  // no device candidates to interleave with (and the ids may carry the phantom shift)
+            pre_l[j] = sl; pre_c[j] = sc;
+            sl += (uint32_t)H.svs[j].sv.lib_count; sc += (uint32_t)H.svs[j].sv.cn_count;
+        }
+        pre_l[nh] = sl; pre_c[nh] = sc;
+        double* lam = c->h_hs_lists.as<double>();
+        int32_t* li = (int32_t*)(lam + nt);
+        int32_t* lp = li + nt;
+        int32_t* ck = lp + nt;
+        float* cv = (float*)(ck + nc);
+        for (uint32_t i = 0; i < nt; ++i) { lam[i] = H.terms[i].lambda; li[i] = H.lib_index[i]; lp[i] = H.lib_pairs[i]; }
+        for (uint32_t i = 0; i < nc; ++i) { ck[i] = H.cn_key[i]; cv[i] = H.cn_value[i]; }
+        a.hs_rec = c->h_hs_rec.as<SvOut>(); a.hs_T = T; a.hs_pre_l = pre_l; a.hs_pre_c = pre_c;
+        a.hs_lambda = lam; a.hs_lib_index = li; a.hs_lib_pairs = lp; a.hs_cn_key = ck; a.hs_cn_value = cv;
+    }
+    launch_k6_compact(a, na, s);
+    launch_k5_dev(a.t_lambda, a.t_k, c->h_ltail_dev.as<double>(), a.ltail, &a.counts->n_terms_dev, a.term_cap, s);
+    if (!c->opts.fisher) launch_k6_score(a, std::log(10), c->opts.score_threshold, s);
+    return BDX_OK;
+}
+
+// copy the final table out of the pinned buffers the device assembled it in (getters, support lists, Fisher scores)
+int materialize(bdx_ctx* c) {
+    if (c->materialized) return BDX_OK;
+    WalkResult& M = c->walk;
+    M.clear();
+    const uint32_t n = c->n_sv_total, nt = c->n_terms_total, nc = c->n_cn_total;
+    const HostSv* d = c->h_sv_out.as<HostSv>();
+    M.svs.assign(d, d + n);
+    M.lib_index.assign(c->h_lib_index.as<int32_t>(), c->h_lib_index.as<int32_t>() + nt);
+    M.lib_pairs.assign(c->h_lib_pairs.as<int32_t>(), c->h_lib_pairs.as<int32_t>() + nt);
+    M.cn_key.assign(c->h_cn_key.as<int32_t>(), c->h_cn_key.as<int32_t>() + nc);
+    M.cn_value.assign(c->h_cn_value.as<float>(), c->h_cn_value.as<float>() + nc);
+    c->log_tail.assign(c->h_ltail_dev.as<double>(), c->h_ltail_dev.as<double>() + nt);
+    M.n_groups = c->n_groups_total;
+    c->materialized = true;
+    return BDX_OK;
+}
+
+// end of a single-context run: wait for the device's table
+int finish_table(bdx_ctx* c) {
+    hipStream_t s = c->stream;
+    const auto tf0 = std::chrono::steady_clock::now();
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipGetLastError());
+    const auto tf1 = std::chrono::steady_clock::now();
+    static_assert(sizeof(HostSv) == sizeof(SvOut) && offsetof(HostSv, grp_mask) == offsetof(SvOut, grp_mask) &&
+                      offsetof(HostSv, start) == offsetof(SvOut, start), "SV record layout");
+    c->n_sv_host = (uint32_t)c->walk.svs.size();
+    c->n_groups_total = c->walk.n_groups + c->counts.n_groups_dev;
+    const StageCounts c2 = *c->h_counts2.as<StageCounts>();
+    if (c2.overflow) return fail(c, BDX_EINTERNAL, "SV list overflow");
+    c->n_sv_total = c2.n_sv_dev; c->n_terms_total = c2.n_terms_dev; c->n_cn_total = c2.n_cn_dev;
+    c->counts.n_sv_dev = c2.n_sv_dev - c->n_sv_host;
+    c->n_printed = c2.n_printed;
+    c->materialized = false;
+    if (c->opts.fisher) {  // Fisher's combination (BreakDancer.cpp:71-81) uses the host's exp / log
+        materialize(c);
+        finish_scores(c->opts, c->log_tail.data(), c->walk.svs.data(), c->walk.svs.size(), &c->n_printed);
+    }
+    const auto tf2 = std::chrono::steady_clock::now();
+    c->stage_ms[8] = ms_between(tf0, tf1);
+    c->stage_ms[9] = ms_between(tf1, tf2);
+    c->stage_ms[10] = 0;
+    c->ran = true;
+    c->stage = 4;
+    return BDX_OK;
+}
+
+// H1 walk over c->regions / c->r_pk / c->parts with the adopted pass-1 statistics
 int host_walk(bdx_ctx* c, int32_t last_maxq, bool any_anomalous) {
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
@@ -728,6 +829,12 @@ int host_walk(bdx_ctx* c, int32_t last_maxq, bool any_anomalous) {
     wi.any_anomalous = any_anomalous;
     c->walk.clear();
     if (!c->parts.empty()) greedy_walk(wi, c->walk_scratch, c->walk);
+    return BDX_OK;
+}
+
+// K5 for the host walk's terms (staged runs: the whole walk is the host's)
+int score_host_terms(bdx_ctx* c) {
+    hipStream_t s = c->stream;
     const uint32_t nt = (uint32_t)c->walk.terms.size();
     if (nt) {
         // zero-copy: the kernel reads lambda / k from pinned host memory and writes the log tails back into it (a few
@@ -742,101 +849,20 @@ int host_walk(bdx_ctx* c, int32_t last_maxq, bool any_anomalous) {
     return BDX_OK;
 }
 
-// wait for the device, interleave the device-assembled SVs with the host walk's in the reference's output order,
-// combine the per-library log tails into the scores
-int finish_walk(bdx_ctx* c, bool with_dev) {
+// staged runs: the walk, the list and the score combination are the host's
+int finish_host_walk(bdx_ctx* c) {
     hipStream_t s = c->stream;
-    const auto tf0 = std::chrono::steady_clock::now();
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, hipGetLastError());
-    const auto tf1 = std::chrono::steady_clock::now();
-    static_assert(sizeof(HostSv) == sizeof(SvOut) && offsetof(HostSv, grp_mask) == offsetof(SvOut, grp_mask) &&
-                      offsetof(HostSv, start) == offsetof(SvOut, start), "SV record layout");
     const uint32_t nt = (uint32_t)c->walk.terms.size();
     const double* host_tail = nt ? (const double*)((char*)c->h_terms.p + (((size_t)nt * 12 + 7) & ~(size_t)7)) : nullptr;
-    uint32_t nd = 0, ndt = 0, ndc = 0;
-    if (with_dev) {
-        const StageCounts c2 = *c->h_counts2.as<StageCounts>();
-        if (c2.overflow) return fail(c, BDX_EINTERNAL, "SV list overflow");
-        nd = c2.n_sv_dev; ndt = c2.n_terms_dev; ndc = c2.n_cn_dev;
-        c->counts.n_sv_dev = nd; c->counts.n_terms_dev = ndt; c->counts.n_cn_dev = ndc;  // (the rest arrived with the groups)
-    }
-    std::vector<double>& log_tail = c->log_tail;
-    c->n_sv_host = (uint32_t)c->walk.svs.size();
-    if (!nd) {
-        log_tail.assign(host_tail, host_tail + nt);
-    } else {
-        WalkResult& H = c->walk;
-        WalkResult& M = c->merged;
-        M.clear();
-        const HostSv* d = c->h_sv_out.as<HostSv>();
-        const int32_t *d_li = c->h_lib_index.as<int32_t>(), *d_lp = c->h_lib_pairs.as<int32_t>(), *d_ck = c->h_cn_key.as<int32_t>();
-        const float* d_cv = c->h_cn_value.as<float>();
-        const double* d_lt = c->h_ltail_dev.as<double>();
-        const size_t nh = H.svs.size();
-        M.svs.resize((size_t)nd + nh);
-        if (!nh) {  // everything was assembled on the device: its lists are already in output order
-            memcpy(M.svs.data(), d, (size_t)nd * sizeof(HostSv));
-            M.lib_index.assign(d_li, d_li + ndt); M.lib_pairs.assign(d_lp, d_lp + ndt);
-            M.cn_key.assign(d_ck, d_ck + ndc); M.cn_value.assign(d_cv, d_cv + ndc);
-            log_tail.assign(d_lt, d_lt + ndt);
-        } else {
-            // Interleave by output order.  Both lists are sorted; the host walk's few SVs cut the device's list into
-            // runs that are copied in bulk, their list offsets shifted by what the host has inserted before them.
-            const uint64_t period = (uint64_t)std::max(1, c->opts.buffer_size + 1);
-            const size_t ntot = (size_t)ndt + nt, nctot = (size_t)ndc + H.cn_key.size();
-            M.lib_index.resize(ntot); M.lib_pairs.resize(ntot); log_tail.resize(ntot);
-            M.cn_key.resize(nctot); M.cn_value.resize(nctot);
-            size_t i0 = 0, o = 0, lo = 0, co = 0;
-            int32_t hl = 0, hc = 0;  // host entries inserted so far
-            auto copy_run = [&](size_t i1) {
-                if (i1 == i0) return;
-                const size_t l0 = (size_t)d[i0].sv.lib_begin, l1 = i1 < nd ? (size_t)d[i1].sv.lib_begin : (size_t)ndt;
-                const size_t c0 = (size_t)d[i0].sv.cn_begin, c1 = i1 < nd ? (size_t)d[i1].sv.cn_begin : (size_t)ndc;
-                memcpy(&M.svs[o], d + i0, (i1 - i0) * sizeof(HostSv));
-                if (hl || hc)
-                    for (size_t q = o; q < o + (i1 - i0); ++q) { M.svs[q].sv.lib_begin += hl; M.svs[q].sv.cn_begin += hc; }
-                memcpy(&M.lib_index[lo], d_li + l0, (l1 - l0) * 4); memcpy(&M.lib_pairs[lo], d_lp + l0, (l1 - l0) * 4);
-                memcpy(&log_tail[lo], d_lt + l0, (l1 - l0) * 8);
-                memcpy(&M.cn_key[co], d_ck + c0, (c1 - c0) * 4); memcpy(&M.cn_value[co], d_cv + c0, (c1 - c0) * 4);
-                o += i1 - i0; lo += l1 - l0; co += c1 - c0;
-                i0 = i1;
-            };
-            for (size_t j = 0; j < nh; ++j) {
-                // device SVs come from traversals started at a window's own vertices; this host SV precedes those whose
-                // start vertex is not below T: its own start vertex, or the first vertex of its window if it started
-                // from an earlier window's vertex
-                const uint64_t key = H.sv_key[j];
-                const bool from_old = !((key >> 32) & 1ull);
-                const uint64_t T = from_old ? (key >> 33) * period : (key & 0xffffffffull);
-                size_t lo_i = i0, hi_i = nd;
-                while (lo_i < hi_i) {
-                    const size_t mid = (lo_i + hi_i) / 2;
-                    if ((uint64_t)d[mid].start < T) lo_i = mid + 1; else hi_i = mid;
-                }
-                copy_run(lo_i);
-                HostSv hs = H.svs[j];
-                const int32_t lb = hs.sv.lib_begin, cb = hs.sv.cn_begin;
-                for (int32_t q = 0; q < hs.sv.lib_count; ++q) {
-                    M.lib_index[lo + q] = H.lib_index[lb + q]; M.lib_pairs[lo + q] = H.lib_pairs[lb + q]; log_tail[lo + q] = host_tail[lb + q];
-                }
-                for (int32_t q = 0; q < hs.sv.cn_count; ++q) { M.cn_key[co + q] = H.cn_key[cb + q]; M.cn_value[co + q] = H.cn_value[cb + q]; }
-                hs.sv.lib_begin = (int32_t)lo; hs.sv.cn_begin = (int32_t)co;
-                lo += (size_t)hs.sv.lib_count; co += (size_t)hs.sv.cn_count;
-                hl += hs.sv.lib_count; hc += hs.sv.cn_count;
-                M.svs[o++] = hs;
-            }
-            copy_run(nd);
-        }
-        M.n_groups = H.n_groups + c->counts.n_groups_dev;
-        std::swap(c->walk, c->merged);
-    }
-    const auto tf2 = std::chrono::steady_clock::now();
-    finish_scores(c->opts, log_tail.data(), c->walk.svs.data(), c->walk.svs.size(), &c->n_printed);
-    const auto tf3 = std::chrono::steady_clock::now();
-    c->stage_ms[8] = ms_between(tf0, tf1);
-    c->stage_ms[9] = ms_between(tf1, tf2);
-    c->stage_ms[10] = ms_between(tf2, tf3);
+    c->log_tail.assign(host_tail, host_tail + nt);
+    finish_scores(c->opts, c->log_tail.data(), c->walk.svs.data(), c->walk.svs.size(), &c->n_printed);
+    c->n_sv_host = c->n_sv_total = (uint32_t)c->walk.svs.size();
+    c->n_terms_total = nt; c->n_cn_total = (uint32_t)c->walk.cn_key.size();
+    c->n_groups_total = c->walk.n_groups;
+    c->counts.n_sv_dev = 0;
+    c->materialized = true;
     c->ran = true;
     c->stage = 4;
     return BDX_OK;
@@ -932,9 +958,16 @@ int bdx_run(bdx_ctx* c) {
     rc = host_walk(c, c->counts.last_maxq, na != 0);
     if (rc != BDX_OK) return rc;
     const auto t_h2 = std::chrono::steady_clock::now();
-    rc = finish_walk(c, na != 0);
+    if (na) {
+        rc = do_k6_table(c);
+        if (rc != BDX_OK) return rc;
+        rc = finish_table(c);
+    } else {
+        rc = finish_host_walk(c);
+    }
     if (rc != BDX_OK) return rc;
     if (c->collect_support) {
+        materialize(c);
         rc = collect_support(c, ph);
         if (rc != BDX_OK) return rc;
     }
@@ -1081,7 +1114,8 @@ int bdx_stage_walk(bdx_ctx* c, size_t nregions, const bdx_region_rec* regions, c
     int rc = host_walk(c, last_maxq, any_anomalous != 0);
     if (rc != BDX_OK) return rc;
     const auto t1 = std::chrono::steady_clock::now();
-    rc = finish_walk(c, false);
+    rc = score_host_terms(c);
+    if (rc == BDX_OK) rc = finish_host_walk(c);
     c->stage_ms[5] = ms_between(t0, t1);
     c->stage_ms[6] = ms_between(t1, std::chrono::steady_clock::now());
     return rc;
@@ -1092,7 +1126,7 @@ int bdx_get_summary(const bdx_ctx* c, bdx_summary* o) {
     if (!c->ran) return BDX_ESTATE;
     o->n_reads = c->n; o->n_anomalous = c->p1.n_anom; o->covered_ref_len = c->g_covered; o->window = c->g_window;
     o->n_candidates = c->counts.n_cand; o->n_regions = (uint32_t)c->nreg; o->n_pairs = c->counts.n_pairs;
-    o->n_groups = c->walk.n_groups; o->n_svs = (uint32_t)c->walk.svs.size(); o->n_svs_printed = c->n_printed;
+    o->n_groups = c->n_groups_total; o->n_svs = c->n_sv_total; o->n_svs_printed = c->n_printed;
     return BDX_OK;
 }
 
@@ -1127,6 +1161,7 @@ int bdx_get_regions(const bdx_ctx* c, bdx_region* out, size_t cap) {
 int bdx_get_svs(const bdx_ctx* c, bdx_sv* out, size_t cap) {
     if (!c || (!out && cap)) return BDX_EINVAL;
     if (!c->ran) return BDX_ESTATE;
+    materialize(const_cast<bdx_ctx*>(c));
     const size_t n = std::min(cap, c->walk.svs.size());
     for (size_t i = 0; i < n; ++i) out[i] = c->walk.svs[i].sv;
     return BDX_OK;
@@ -1136,6 +1171,7 @@ int bdx_get_sv_lists(const bdx_ctx* c, int32_t* lib_index, int32_t* lib_pairs, s
                      size_t cn_cap) {
     if (!c) return BDX_EINVAL;
     if (!c->ran) return BDX_ESTATE;
+    materialize(const_cast<bdx_ctx*>(c));
     const size_t nl = std::min(lib_cap, c->walk.lib_index.size());
     if (lib_index) memcpy(lib_index, c->walk.lib_index.data(), nl * 4);
     if (lib_pairs) memcpy(lib_pairs, c->walk.lib_pairs.data(), nl * 4);

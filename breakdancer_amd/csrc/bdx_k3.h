@@ -15,7 +15,7 @@ struct StageCounts {
     uint32_t n_groups;   // partial (flag, lib) aggregates written by K4
     uint32_t n_entries;  // reads of accepted regions entering the join
     uint32_t overflow;   // set if an output list ran out of capacity
-    uint32_t n_slots;    // (unused)
+    uint32_t n_printed;  // K6: SV candidates with score > opts.score_threshold
     uint32_t n_sv_dev;   // K6: SV candidates assembled on the device
     uint32_t n_terms_dev;  // K6: their (library, pairs) entries == Poisson terms
     uint32_t n_cn_dev;     // K6: their copy-number entries
@@ -127,7 +127,8 @@ void launch_k4_join_only(const K4Arrays& k4, const Entries& e, const uint32_t* n
 // ---- K5 ---------------------------------------------------------------------------------------------
 void launch_k5(const double* lambda, const int32_t* k, double* out, uint32_t n, hipStream_t s);
 // term count read from device memory (the SV assembly of K6 decides it); n_upper only sizes the grid
-void launch_k5_dev(const double* lambda, const int32_t* k, double* out, const uint32_t* n_ptr, uint32_t n_upper, hipStream_t s);
+void launch_k5_dev(const double* lambda, const int32_t* k, double* out, double* out2, const uint32_t* n_ptr, uint32_t n_upper,
+                   hipStream_t s);  // out2 (may be null): second copy of the results
 
 // ---- K6: pair groups per region, small components walked on the device -----------------------------------
 // Connectivity of the region graph comes from the groups whose weight passes the gate (-r): lighter groups are
@@ -222,6 +223,20 @@ struct K6Arrays {
     double* t_lambda;              // device
     int32_t* t_k;                  // device
     uint32_t sv_cap, term_cap, cn_cap;
+    uint2* sv_terms;               // device [sv_cap]: (first term, terms) of every final SV candidate, for the score combination
+    double* ltail;                 // device [term_cap]: log tails (K5 also writes them to pinned host memory)
+    // SV candidates of the host walk (pinned host memory), interleaved with the device's by the compaction: candidate j
+    // precedes the device's candidates whose start vertex is not below hs_T[j]
+    const SvOut* hs_rec;           // [nh] lib_begin / cn_begin index the host lists below
+    const uint32_t* hs_T;          // [nh] ascending
+    const uint32_t* hs_pre_l;      // [nh + 1] entries of the host candidates before j in the (library, pairs) lists ...
+    const uint32_t* hs_pre_c;      // [nh + 1] ... and in the copy-number lists
+    const int32_t* hs_lib_index;
+    const int32_t* hs_lib_pairs;
+    const double* hs_lambda;
+    const int32_t* hs_cn_key;
+    const float* hs_cn_value;
+    uint32_t nh;
     // groups of the components left to the host
     GroupRec* g_rec;               // pinned host
     uint32_t g_cap;
@@ -240,6 +255,8 @@ struct K6Arrays {
 
 void launch_k6_groups(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s);   // pair groups, components, the host's list
 void launch_k6_walk(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s);     // device-walked components -> SV staging
-void launch_k6_compact(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s);  // staging -> dense SV records and lists
+void launch_k6_compact(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s);  // staging + host candidates -> final table
+// ComputeProbScore's combination (BreakDancer.cpp:56-69) + PhredQ (:459-465) for every candidate of the final table
+void launch_k6_score(const K6Arrays& a, double ln10, int score_threshold, hipStream_t s);
 
 }  // namespace bdx

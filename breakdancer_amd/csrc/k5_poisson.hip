@@ -77,12 +77,16 @@ __global__ __launch_bounds__(256) void k5_poisson_kernel(const double* __restric
 
 // same, with the term count in device memory and the waves striding over the terms
 __global__ __launch_bounds__(256) void k5_poisson_dev_kernel(const double* __restrict__ lambda, const int32_t* __restrict__ kk,
-                                                             double* __restrict__ out, const uint32_t* __restrict__ n_ptr) {
+                                                             double* __restrict__ out, double* __restrict__ out2,
+                                                             const uint32_t* __restrict__ n_ptr) {
     const uint32_t n = *n_ptr;
     const int lane = threadIdx.x & 63;
     for (uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6); item < n; item += gridDim.x * 4) {
         const double result = poisson_log_upper_tail(lambda[item], kk[item], lane);
-        if (lane == 0) out[item] = result;
+        if (lane == 0) {
+            out[item] = result;
+            if (out2) out2[item] = result;
+        }
     }
 }
 
@@ -91,10 +95,11 @@ void launch_k5(const double* lambda, const int32_t* k, double* out, uint32_t n, 
     hipLaunchKernelGGL(k5_poisson_kernel, dim3((n + 3) / 4), dim3(256), 0, s, lambda, k, out, n);
 }
 
-void launch_k5_dev(const double* lambda, const int32_t* k, double* out, const uint32_t* n_ptr, uint32_t n_upper, hipStream_t s) {
+void launch_k5_dev(const double* lambda, const int32_t* k, double* out, double* out2, const uint32_t* n_ptr, uint32_t n_upper,
+                   hipStream_t s) {
     if (!n_upper) return;
     const uint32_t g = (n_upper + 3) / 4;
-    hipLaunchKernelGGL(k5_poisson_dev_kernel, dim3(g < 2048u ? g : 2048u), dim3(256), 0, s, lambda, k, out, n_ptr);
+    hipLaunchKernelGGL(k5_poisson_dev_kernel, dim3(g < 2048u ? g : 2048u), dim3(256), 0, s, lambda, k, out, out2, n_ptr);
 }
 
 }  // namespace bdx

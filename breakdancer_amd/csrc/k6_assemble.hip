@@ -19,6 +19,7 @@
 // float32 / float64 operations are spelled with the round-to-nearest intrinsics so that no fused multiply-add can
 // change a result against the host code (and the oracle).
 #include <algorithm>
+#include <cstdint>
 
 #include "bdx_k3.h"
 
@@ -581,45 +582,123 @@ struct OwnIn {
     __device__ U4 operator()(uint32_t i, uint32_t) const { return U4{nsv[i], nacc[i], ncn[i], 0u}; }
 };
 
+namespace {
+__device__ __forceinline__ uint32_t count_below(const uint32_t* v, uint32_t n, uint32_t x) {  // #elements < x, v ascending
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (v[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+}  // namespace
+
+// Third phase of the scan over the start vertices: the final table.  Vertex i first places the host walk's candidates
+// whose threshold is i, then its own.
 struct OwnOut {
     K6Arrays a;
+    __device__ void put_entries(uint32_t lb, uint32_t cb, const SvOut& o, const LibStage* ls, const CnStage* cs) const {
+        for (int32_t t = 0; t < o.sv.lib_count; ++t) {
+            const LibStage l = ls[t];
+            a.lib_index[lb + t] = l.lib;
+            a.lib_pairs[lb + t] = l.rc;
+            a.t_lambda[lb + t] = l.lambda;
+            a.t_k[lb + t] = l.rc;
+        }
+        for (int32_t t = 0; t < o.sv.cn_count; ++t) {
+            const CnStage cn = cs[t];
+            a.cn_key[cb + t] = cn.key;
+            a.cn_value[cb + t] = cn.value;
+        }
+    }
     __device__ void operator()(uint32_t i, uint32_t n, const U4& inc, const U4& e) const {
+        const uint32_t nh = a.nh;
+        const uint32_t hb0 = nh ? count_below(a.hs_T, nh, i) : 0u, hb1 = nh ? count_below(a.hs_T, nh, i + 1) : 0u;
+        const uint32_t h_l = nh ? a.hs_pre_l[nh] : 0u, h_c = nh ? a.hs_pre_c[nh] : 0u;
+        const uint32_t ex_sv = inc.x - e.x, ex_l = inc.y - e.y, ex_c = inc.z - e.z;
         if (i == n - 1) {
-            a.counts->n_sv_dev = inc.x; a.counts->n_terms_dev = inc.y; a.counts->n_cn_dev = inc.z;
-            if (a.counts_host2) { a.counts_host2->n_sv_dev = inc.x; a.counts_host2->n_terms_dev = inc.y; a.counts_host2->n_cn_dev = inc.z; }
-        }
-        if (!e.x) return;
-        uint32_t d = inc.x - e.x, lb = inc.y - e.y, cb = inc.z - e.z;
-        if (inc.x > a.sv_cap || inc.y > a.term_cap || inc.z > a.cn_cap) {
-            a.counts->overflow = 1;
-            if (a.counts_host2) a.counts_host2->overflow = 1;
-            return;
-        }
-        for (uint32_t q = 0; q < e.x; ++q) {
-            const uint32_t slot = a.own_slots[(size_t)i * kK6MaxSv + q];
-            SvOut o = a.sv_stage[slot];
-            const LibStage* ls = a.lib_stage + (size_t)slot * a.lib_stride;
-            for (int32_t t = 0; t < o.sv.lib_count; ++t) {
-                const LibStage l = ls[t];
-                a.lib_index[lb + t] = l.lib;
-                a.lib_pairs[lb + t] = l.rc;
-                a.t_lambda[lb + t] = l.lambda;
-                a.t_k[lb + t] = l.rc;
+            const uint32_t tsv = inc.x + nh, tl = inc.y + h_l, tc = inc.z + h_c;
+            a.counts->n_sv_dev = tsv; a.counts->n_terms_dev = tl; a.counts->n_cn_dev = tc;
+            if (a.counts_host2) { a.counts_host2->n_sv_dev = tsv; a.counts_host2->n_terms_dev = tl; a.counts_host2->n_cn_dev = tc; }
+            if (tsv > a.sv_cap || tl > a.term_cap || tc > a.cn_cap) {
+                a.counts->overflow = 1;
+                if (a.counts_host2) a.counts_host2->overflow = 1;
             }
-            const CnStage* cs = a.cn_stage + (size_t)slot * a.nkeys;
+        }
+        if (hb1 == hb0 && !e.x) return;
+        if (inc.x + nh > a.sv_cap || inc.y + h_l > a.term_cap || inc.z + h_c > a.cn_cap) return;  // reported by the last vertex
+        for (uint32_t j = hb0; j < hb1; ++j) {  // the host walk's candidates that come right before this vertex's
+            SvOut o = a.hs_rec[j];
+            const uint32_t pos = ex_sv + j, lb = ex_l + a.hs_pre_l[j], cb = ex_c + a.hs_pre_c[j];
+            for (int32_t t = 0; t < o.sv.lib_count; ++t) {
+                const int32_t q = o.sv.lib_begin + t;
+                a.lib_index[lb + t] = a.hs_lib_index[q];
+                a.lib_pairs[lb + t] = a.hs_lib_pairs[q];
+                a.t_lambda[lb + t] = a.hs_lambda[q];
+                a.t_k[lb + t] = a.hs_lib_pairs[q];
+            }
             for (int32_t t = 0; t < o.sv.cn_count; ++t) {
-                const CnStage cn = cs[t];
-                a.cn_key[cb + t] = cn.key;
-                a.cn_value[cb + t] = cn.value;
+                a.cn_key[cb + t] = a.hs_cn_key[o.sv.cn_begin + t];
+                a.cn_value[cb + t] = a.hs_cn_value[o.sv.cn_begin + t];
             }
             o.sv.lib_begin = (int32_t)lb;
             o.sv.cn_begin = (int32_t)cb;
+            a.sv_out[pos] = o;
+            a.sv_terms[pos] = make_uint2(lb, (uint32_t)o.sv.lib_count);
+        }
+        uint32_t d = ex_sv + hb1, lb = ex_l + (nh ? a.hs_pre_l[hb1] : 0u), cb = ex_c + (nh ? a.hs_pre_c[hb1] : 0u);
+        for (uint32_t q = 0; q < e.x; ++q) {
+            const uint32_t slot = a.own_slots[(size_t)i * kK6MaxSv + q];
+            SvOut o = a.sv_stage[slot];
+            put_entries(lb, cb, o, a.lib_stage + (size_t)slot * a.lib_stride, a.cn_stage + (size_t)slot * a.nkeys);
+            o.sv.lib_begin = (int32_t)lb;
+            o.sv.cn_begin = (int32_t)cb;
+            a.sv_terms[d] = make_uint2(lb, (uint32_t)o.sv.lib_count);
             lb += (uint32_t)o.sv.lib_count;
             cb += (uint32_t)o.sv.cn_count;
             a.sv_out[d++] = o;
         }
     }
 };
+
+// Score combination for the final table: Kahan-compensated sum of the per-library log tails (BreakDancer.cpp:56-69),
+// PhredQ = min(99, int(-10 logp / ln 10 + 0.5)) (:459-465, NaN -> INT_MIN as cvttsd2si does), printed = PhredQ > -y.
+// One workgroup: a few thousand candidates, and the printed count needs no atomics.
+__global__ __launch_bounds__(1024) void k6_score_kernel(K6Arrays a, double ln10, int score_threshold) {
+    __shared__ uint32_t s_cnt[16];
+    const uint32_t n = a.counts->n_sv_dev;
+    uint32_t printed = 0;
+    for (uint32_t pos = threadIdx.x; pos < n; pos += 1024) {
+        const uint2 t = a.sv_terms[pos];
+        double logp = 0.0, err = 0.0;
+        for (uint32_t q = 0; q < t.y; ++q) {
+            const double tmp_a = __dsub_rn(a.ltail[t.x + q], err);
+            const double tmp_b = __dadd_rn(logp, tmp_a);
+            err = __dsub_rn(__dsub_rn(tmp_b, logp), tmp_a);
+            logp = tmp_b;
+        }
+        const double phred_tmp = __ddiv_rn(__dmul_rn(-10.0, logp), ln10);
+        const double r = __dadd_rn(phred_tmp, 0.5);
+        int phred;
+        if (phred_tmp > 99.0) phred = 99;
+        else if (r != r || r >= 2147483648.0 || r <= -2147483649.0) phred = INT32_MIN;
+        else phred = (int)r;
+        const int pr = phred > score_threshold ? 1 : 0;
+        a.sv_out[pos].sv.logp = logp;
+        a.sv_out[pos].sv.score = phred;
+        a.sv_out[pos].sv.printed = pr;
+        printed += (uint32_t)pr;
+    }
+    printed = wave_sum_u32(printed);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = printed;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int k = 0; k < 16; ++k) tot += s_cnt[k];
+        a.counts->n_printed = tot;
+        if (a.counts_host2) a.counts_host2->n_printed = tot;
+    }
+}
 
 void launch_k6_groups(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
     if (n_anom_host == 0) return;
@@ -638,6 +717,10 @@ void launch_k6_walk(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
     if (n_anom_host == 0 || a.force_host) return;
     const uint32_t gp = std::min<uint32_t>((n_anom_host / 8 + 3) / 4 + 1, 16384u);
     hipLaunchKernelGGL(k6_walk_kernel, dim3(gp), dim3(256), 0, s, a);
+}
+
+void launch_k6_score(const K6Arrays& a, double ln10, int score_threshold, hipStream_t s) {
+    hipLaunchKernelGGL(k6_score_kernel, dim3(1), dim3(1024), 0, s, a, ln10, score_threshold);
 }
 
 void launch_k6_compact(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
