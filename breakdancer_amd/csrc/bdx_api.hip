@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -92,6 +93,9 @@ struct bdx_ctx {
     PinBuf h_p1, h_cnt, h_counts, h_regs, h_pk, h_groups, h_terms;
     DevBuf b_sv_terms, b_ltail;
     PinBuf h_hs_rec, h_hs_aux, h_hs_lists;
+    PinBuf h_flags;                   // [0] pass 1 ready, [1] host's groups ready, [2] final table ready (= run sequence number)
+    uint32_t seq = 0;
+    bool poll = true;                 // BDX_NO_POLL=1: wait with stream / event synchronisation only
     bool materialized = true;         // c->walk holds the final table (false: it still sits in the pinned buffers only)
     uint32_t n_sv_total = 0, n_groups_total = 0, n_terms_total = 0, n_cn_total = 0;
     PinBuf h_counts0, h_counts2, h_sv_out, h_lib_index, h_lib_pairs, h_cn_key, h_cn_value, h_ltail_dev, h_k6const;
@@ -230,6 +234,8 @@ int bdx_create(bdx_ctx** out, const bdx_opts* opts, const bdx_lib* libs, int nli
     {
         const char* hw = getenv("BDX_HOST_WALK");
         c->host_walk_only = hw && hw[0] == '1';
+        const char* np = getenv("BDX_NO_POLL");
+        c->poll = !(np && np[0] == '1');
         const char* bj = getenv("BDX_BUCKETED_JOIN");
         c->bucketed_join = bj && bj[0] == '1';
     }
@@ -269,7 +275,7 @@ void bdx_destroy(bdx_ctx* c) {
                       &c->b_parts, &c->b_kdens, &c->b_rs, &c->b_slot, &c->b_members, &c->b_own, &c->b_lib_stage,
                       &c->b_cn_stage, &c->b_t_lambda, &c->b_t_k, &c->b_ws6, &c->b_k6const};
     for (DevBuf* b : bufs) b->release();
-    PinBuf* pins[] = {&c->h_p1, &c->h_cnt, &c->h_counts, &c->h_regs, &c->h_pk, &c->h_groups, &c->h_terms, &c->h_hs_rec, &c->h_hs_aux, &c->h_hs_lists, &c->h_counts0, &c->h_counts2,
+    PinBuf* pins[] = {&c->h_p1, &c->h_cnt, &c->h_counts, &c->h_regs, &c->h_pk, &c->h_groups, &c->h_terms, &c->h_flags, &c->h_hs_rec, &c->h_hs_aux, &c->h_hs_lists, &c->h_counts0, &c->h_counts2,
                       &c->h_sv_out, &c->h_lib_index, &c->h_lib_pairs, &c->h_cn_key, &c->h_cn_value, &c->h_ltail_dev, &c->h_k6const};
     for (PinBuf* b : pins) b->release();
     if (c->walk_scratch) walk_scratch_free(c->walk_scratch);
@@ -340,6 +346,19 @@ int bdx_set_device_reads(bdx_ctx* c, const bdx_batch* b) {
 }  // extern "C"
 
 namespace {
+
+// Spin on a word of pinned host memory that a kernel sets once its results are written there.  Much shorter than the
+// wake-up of a blocking stream / event wait; falls back to the caller's blocking wait if the word does not show up.
+bool wait_flag(const bdx_ctx* c, int idx, uint32_t value) {
+    if (!c->poll || !c->h_flags.p) return false;
+    volatile uint32_t* f = (volatile uint32_t*)c->h_flags.p + idx;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spin = 0;; ++spin) {
+        if (*f == value) { std::atomic_thread_fence(std::memory_order_acquire); return true; }
+        __builtin_ia32_pause();
+        if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) return false;
+    }
+}
 
 float ms_between(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<float, std::milli>(b - a).count();
@@ -416,9 +435,11 @@ int do_pass1(bdx_ctx* c) {
     fp.libs = c->b_libs.as<DevLib>(); fp.cn_lib = c->opts.cn_lib; fp.key_density = c->b_kdens.as<float>();
     fp.cnt_host = c->h_cnt.as<uint32_t>(); fp.p1_host = c->h_p1.as<Pass1>();  // written by the kernel: no copy commands
     memset(c->h_p1.p, 0, sizeof(Pass1));
+    HIPCHK(c, c->h_flags.ensure(64));
+    ++c->seq;
+    fp.flag_host = c->h_flags.as<uint32_t>(); fp.flag_value = c->seq;
     launch_finalize(fp, s);
-    HIPCHK(c, hipStreamSynchronize(s));
-    HIPCHK(c, hipGetLastError());
+    if (!wait_flag(c, 0, c->seq)) HIPCHK(c, hipStreamSynchronize(s));
     c->p1 = *c->h_p1.as<Pass1>();
     c->cnt_local.assign(c->h_cnt.as<uint32_t>(), c->h_cnt.as<uint32_t>() + ncnt);
     float ms = 0;
@@ -709,6 +730,7 @@ int do_k6(bdx_ctx* c, bool force_host) {
     a.lib_mean = c->b_lib_mean.as<float>();
     a.counts_host = c->h_counts.as<StageCounts>();
     a.counts_host2 = c->h_counts2.as<StageCounts>();
+    a.flag_groups = c->h_flags.as<uint32_t>() + 1; a.flag_done = c->h_flags.as<uint32_t>() + 2; a.flag_value = c->seq;
     memset(c->h_counts.p, 0, sizeof(StageCounts));
     memset(c->h_counts2.p, 0, sizeof(StageCounts));
     a.covered_ref_len = c->g_covered;
@@ -792,8 +814,7 @@ int materialize(bdx_ctx* c) {
 int finish_table(bdx_ctx* c) {
     hipStream_t s = c->stream;
     const auto tf0 = std::chrono::steady_clock::now();
-    HIPCHK(c, hipStreamSynchronize(s));
-    HIPCHK(c, hipGetLastError());
+    if (c->opts.fisher || !wait_flag(c, 2, c->seq)) HIPCHK(c, hipStreamSynchronize(s));
     const auto tf1 = std::chrono::steady_clock::now();
     static_assert(sizeof(HostSv) == sizeof(SvOut) && offsetof(HostSv, grp_mask) == offsetof(SvOut, grp_mask) &&
                       offsetof(HostSv, start) == offsetof(SvOut, start), "SV record layout");
@@ -821,7 +842,6 @@ int finish_table(bdx_ctx* c) {
 // H1 walk over c->regions / c->r_pk / c->parts with the adopted pass-1 statistics
 int host_walk(bdx_ctx* c, int32_t last_maxq, bool any_anomalous) {
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t s = c->stream;
     WalkInput wi{};
     wi.opts = c->opts; wi.libs = c->libs.data(); wi.nlibs = c->nlibs; wi.nbams = c->nbams; wi.nkeys = c->nkeys;
     wi.hist = c->cnt.data(); wi.covered_ref_len = c->g_covered; wi.key_density = c->key_density.data();
@@ -948,7 +968,7 @@ int bdx_run(bdx_ctx* c) {
         // (the table sits in pinned memory the device has just written: one streaming copy into ordinary memory is much
         // cheaper than the walk's scattered reads of it)
         decode_regions(c, c->h_regs.as<RegionRec>(), c->h_pk.as<uint32_t>(), c->h_counts0.as<StageCounts>()->n_regions, ph, false);
-        HIPCHK(c, hipEventSynchronize(c->ev_groups));
+        if (!wait_flag(c, 1, c->seq)) HIPCHK(c, hipEventSynchronize(c->ev_groups));
         c->counts = *c->h_counts.as<StageCounts>();
         if (c->counts.overflow == 2) return fail(c, BDX_ELIMIT, "more than two primary reads share one read name (malformed input)");
         if (c->counts.overflow) return fail(c, BDX_EINTERNAL, "group list overflow");
@@ -972,6 +992,7 @@ int bdx_run(bdx_ctx* c) {
         if (rc != BDX_OK) return rc;
     }
     const auto t_end = std::chrono::steady_clock::now();
+    (void)hipEventSynchronize(c->ev[5]);  // (complete by now; makes the elapsed-time queries valid)
     auto evms = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[a], c->ev[b]); return ms; };
     c->stage_ms[1] = evms(2, 3);
     c->stage_ms[2] = evms(3, 4);

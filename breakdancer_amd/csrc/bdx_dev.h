@@ -77,6 +77,8 @@ struct FinalizeParams {
     const DevLib* libs;         // for the read densities per counter key (BreakDancerMax.cpp:94-107)
     int cn_lib;
     float* key_density;         // [nkeys]; may be null
+    uint32_t* flag_host;        // pinned word set to flag_value once the mirrors are written (the host polls it); may be null
+    uint32_t flag_value;
 };
 
 // one launch that sets several scratch buffers to their start values (replaces a chain of small fill commands)

@@ -466,6 +466,11 @@ __global__ __launch_bounds__(256) void finalize2_kernel(const FinalizeParams p) 
         uint32_t* dst = (uint32_t*)p.p1_host;
         const int words = (int)((offsetof(Pass1, ref_len) + sizeof(unsigned long long) * (size_t)p.nbams) / 4);
         for (int i = t; i < words; i += 256) dst[i] = __builtin_nontemporal_load(src + i);
+        if (p.flag_host) {
+            __threadfence_system();
+            __syncthreads();
+            if (t == 0) *(volatile uint32_t*)p.flag_host = p.flag_value;
+        }
     }
 }
 

@@ -408,6 +408,11 @@ __global__ __launch_bounds__(256) void k6_emit_kernel(K6Arrays a) {
 // that kernel costs an L2 write-back per workgroup on this multi-die part; one tiny launch does not)
 __global__ __launch_bounds__(64) void k6_mirror_kernel(K6Arrays a) {
     if (threadIdx.x < sizeof(StageCounts) / 4) ((uint32_t*)a.counts_host)[threadIdx.x] = ((const uint32_t*)a.counts)[threadIdx.x];
+    if (a.flag_groups) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) *(volatile uint32_t*)a.flag_groups = a.flag_value;
+    }
 }
 
 // One WAVE per region.  Every lane runs the same scalar code, so the data-dependent control flow of the walk does not
@@ -697,6 +702,11 @@ __global__ __launch_bounds__(1024) void k6_score_kernel(K6Arrays a, double ln10,
         for (int k = 0; k < 16; ++k) tot += s_cnt[k];
         a.counts->n_printed = tot;
         if (a.counts_host2) a.counts_host2->n_printed = tot;
+    }
+    if (a.flag_done) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) *(volatile uint32_t*)a.flag_done = a.flag_value;
     }
 }
 
