@@ -214,16 +214,20 @@ struct K6Arrays {
     LibStage* lib_stage;           // [cap][lib_stride]
     CnStage* cn_stage;             // [cap][nkeys]
     uint32_t lib_stride;           // min(nlibs, kK6LibStride)
-    // dense outputs
+    // final table: built densely in HBM by the compaction, scored, then written to pinned host memory in one coalesced
+    // pass by k6_score_kernel
+    SvOut* sv_dense;               // device [sv_cap]
+    int32_t* d_lib_index;          // device [term_cap]
+    int32_t* d_cn_key;             // device [cn_cap]
+    float* d_cn_value;             // device [cn_cap]
+    double* t_lambda;              // device [term_cap]
+    int32_t* t_k;                  // device [term_cap] (= library pair counts)
     SvOut* sv_out;                 // pinned host
     int32_t* lib_index;            // pinned host
     int32_t* lib_pairs;            // pinned host
     int32_t* cn_key;               // pinned host
     float* cn_value;               // pinned host
-    double* t_lambda;              // device
-    int32_t* t_k;                  // device
     uint32_t sv_cap, term_cap, cn_cap;
-    uint2* sv_terms;               // device [sv_cap]: (first term, terms) of every final SV candidate, for the score combination
     double* ltail;                 // device [term_cap]: log tails (K5 also writes them to pinned host memory)
     // SV candidates of the host walk (pinned host memory), interleaved with the device's by the compaction: candidate j
     // precedes the device's candidates whose start vertex is not below hs_T[j]
@@ -260,6 +264,6 @@ void launch_k6_groups(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s);  
 void launch_k6_walk(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s);     // device-walked components -> SV staging
 void launch_k6_compact(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s);  // staging + host candidates -> final table
 // ComputeProbScore's combination (BreakDancer.cpp:56-69) + PhredQ (:459-465) for every candidate of the final table
-void launch_k6_score(const K6Arrays& a, double ln10, int score_threshold, hipStream_t s);
+void launch_k6_score(const K6Arrays& a, double ln10, int score_threshold, int with_scores, hipStream_t s);
 
 }  // namespace bdx

@@ -605,15 +605,14 @@ struct OwnOut {
     __device__ void put_entries(uint32_t lb, uint32_t cb, const SvOut& o, const LibStage* ls, const CnStage* cs) const {
         for (int32_t t = 0; t < o.sv.lib_count; ++t) {
             const LibStage l = ls[t];
-            a.lib_index[lb + t] = l.lib;
-            a.lib_pairs[lb + t] = l.rc;
+            a.d_lib_index[lb + t] = l.lib;
             a.t_lambda[lb + t] = l.lambda;
             a.t_k[lb + t] = l.rc;
         }
         for (int32_t t = 0; t < o.sv.cn_count; ++t) {
             const CnStage cn = cs[t];
-            a.cn_key[cb + t] = cn.key;
-            a.cn_value[cb + t] = cn.value;
+            a.d_cn_key[cb + t] = cn.key;
+            a.d_cn_value[cb + t] = cn.value;
         }
     }
     __device__ void operator()(uint32_t i, uint32_t n, const U4& inc, const U4& e) const {
@@ -637,19 +636,17 @@ struct OwnOut {
             const uint32_t pos = ex_sv + j, lb = ex_l + a.hs_pre_l[j], cb = ex_c + a.hs_pre_c[j];
             for (int32_t t = 0; t < o.sv.lib_count; ++t) {
                 const int32_t q = o.sv.lib_begin + t;
-                a.lib_index[lb + t] = a.hs_lib_index[q];
-                a.lib_pairs[lb + t] = a.hs_lib_pairs[q];
+                a.d_lib_index[lb + t] = a.hs_lib_index[q];
                 a.t_lambda[lb + t] = a.hs_lambda[q];
                 a.t_k[lb + t] = a.hs_lib_pairs[q];
             }
             for (int32_t t = 0; t < o.sv.cn_count; ++t) {
-                a.cn_key[cb + t] = a.hs_cn_key[o.sv.cn_begin + t];
-                a.cn_value[cb + t] = a.hs_cn_value[o.sv.cn_begin + t];
+                a.d_cn_key[cb + t] = a.hs_cn_key[o.sv.cn_begin + t];
+                a.d_cn_value[cb + t] = a.hs_cn_value[o.sv.cn_begin + t];
             }
             o.sv.lib_begin = (int32_t)lb;
             o.sv.cn_begin = (int32_t)cb;
-            a.sv_out[pos] = o;
-            a.sv_terms[pos] = make_uint2(lb, (uint32_t)o.sv.lib_count);
+            a.sv_dense[pos] = o;
         }
         uint32_t d = ex_sv + hb1, lb = ex_l + (nh ? a.hs_pre_l[hb1] : 0u), cb = ex_c + (nh ? a.hs_pre_c[hb1] : 0u);
         for (uint32_t q = 0; q < e.x; ++q) {
@@ -658,55 +655,71 @@ struct OwnOut {
             put_entries(lb, cb, o, a.lib_stage + (size_t)slot * a.lib_stride, a.cn_stage + (size_t)slot * a.nkeys);
             o.sv.lib_begin = (int32_t)lb;
             o.sv.cn_begin = (int32_t)cb;
-            a.sv_terms[d] = make_uint2(lb, (uint32_t)o.sv.lib_count);
             lb += (uint32_t)o.sv.lib_count;
             cb += (uint32_t)o.sv.cn_count;
-            a.sv_out[d++] = o;
+            a.sv_dense[d++] = o;
         }
     }
 };
 
 // Score combination for the final table: Kahan-compensated sum of the per-library log tails (BreakDancer.cpp:56-69),
 // PhredQ = min(99, int(-10 logp / ln 10 + 0.5)) (:459-465, NaN -> INT_MIN as cvttsd2si does), printed = PhredQ > -y.
-// One workgroup: a few thousand candidates, and the printed count needs no atomics.
-__global__ __launch_bounds__(1024) void k6_score_kernel(K6Arrays a, double ln10, int score_threshold) {
-    __shared__ uint32_t s_cnt[16];
-    const uint32_t n = a.counts->n_sv_dev;
-    uint32_t printed = 0;
-    for (uint32_t pos = threadIdx.x; pos < n; pos += 1024) {
-        const uint2 t = a.sv_terms[pos];
-        double logp = 0.0, err = 0.0;
-        for (uint32_t q = 0; q < t.y; ++q) {
-            const double tmp_a = __dsub_rn(a.ltail[t.x + q], err);
-            const double tmp_b = __dadd_rn(logp, tmp_a);
-            err = __dsub_rn(__dsub_rn(tmp_b, logp), tmp_a);
-            logp = tmp_b;
-        }
-        const double phred_tmp = __ddiv_rn(__dmul_rn(-10.0, logp), ln10);
-        const double r = __dadd_rn(phred_tmp, 0.5);
-        int phred;
-        if (phred_tmp > 99.0) phred = 99;
-        else if (r != r || r >= 2147483648.0 || r <= -2147483649.0) phred = INT32_MIN;
-        else phred = (int)r;
-        const int pr = phred > score_threshold ? 1 : 0;
-        a.sv_out[pos].sv.logp = logp;
-        a.sv_out[pos].sv.score = phred;
-        a.sv_out[pos].sv.printed = pr;
-        printed += (uint32_t)pr;
-    }
-    printed = wave_sum_u32(printed);
-    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = printed;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (int k = 0; k < 16; ++k) tot += s_cnt[k];
-        a.counts->n_printed = tot;
-        if (a.counts_host2) a.counts_host2->n_printed = tot;
-    }
-    if (a.flag_done) {
-        __threadfence_system();
+// A workgroup takes 64 candidates: their records go through LDS, get their scores there, and leave for pinned host
+// memory as one contiguous 6 KiB write (single scattered stores over PCIe are several times slower); the flat lists
+// follow with a grid-stride copy.
+constexpr int kScoreSvs = 64;
+constexpr int kSvWords = sizeof(SvOut) / 4;
+
+__global__ __launch_bounds__(256) void k6_score_kernel(K6Arrays a, double ln10, int score_threshold, int with_scores) {
+    __shared__ uint32_t s_rec[kScoreSvs * kSvWords];
+    __shared__ uint32_t s_printed;
+    const uint32_t n = a.counts->n_sv_dev, nt = a.counts->n_terms_dev, nc = a.counts->n_cn_dev;
+    const uint32_t base = blockIdx.x * kScoreSvs;
+    if (threadIdx.x == 0) s_printed = 0;
+    if (base < n) {
+        const uint32_t cnt = min((uint32_t)kScoreSvs, n - base);
+        const uint32_t* src = (const uint32_t*)(a.sv_dense + base);
+        for (uint32_t i = threadIdx.x; i < cnt * kSvWords; i += 256) s_rec[i] = src[i];
         __syncthreads();
-        if (threadIdx.x == 0) *(volatile uint32_t*)a.flag_done = a.flag_value;
+        if (threadIdx.x < cnt && with_scores) {
+            SvOut* o = (SvOut*)s_rec + threadIdx.x;
+            double logp = 0.0, err = 0.0;
+            for (int32_t q = 0; q < o->sv.lib_count; ++q) {
+                const double tmp_a = __dsub_rn(a.ltail[o->sv.lib_begin + q], err);
+                const double tmp_b = __dadd_rn(logp, tmp_a);
+                err = __dsub_rn(__dsub_rn(tmp_b, logp), tmp_a);
+                logp = tmp_b;
+            }
+            const double phred_tmp = __ddiv_rn(__dmul_rn(-10.0, logp), ln10);
+            const double r = __dadd_rn(phred_tmp, 0.5);
+            int phred;
+            if (phred_tmp > 99.0) phred = 99;
+            else if (r != r || r >= 2147483648.0 || r <= -2147483649.0) phred = INT32_MIN;
+            else phred = (int)r;
+            const int pr = phred > score_threshold ? 1 : 0;
+            o->sv.logp = logp;
+            o->sv.score = phred;
+            o->sv.printed = pr;
+            if (pr) atomicAdd(&s_printed, 1u);
+        }
+        __syncthreads();
+        uint32_t* dst = (uint32_t*)(a.sv_out + base);
+        for (uint32_t i = threadIdx.x; i < cnt * kSvWords; i += 256) dst[i] = s_rec[i];
+        if (threadIdx.x == 0 && s_printed) atomicAdd(&a.counts->n_printed, s_printed);
+    }
+    const uint32_t gsz = gridDim.x * 256;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nt; i += gsz) { a.lib_index[i] = a.d_lib_index[i]; a.lib_pairs[i] = a.t_k[i]; }
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nc; i += gsz) { a.cn_key[i] = a.d_cn_key[i]; a.cn_value[i] = a.d_cn_value[i]; }
+}
+
+// the end of the run: printed count and the word the host polls
+__global__ __launch_bounds__(64) void k6_done_kernel(K6Arrays a) {
+    if (threadIdx.x == 0) {
+        if (a.counts_host2) a.counts_host2->n_printed = a.counts->n_printed;
+        if (a.flag_done) {
+            __threadfence_system();
+            *(volatile uint32_t*)a.flag_done = a.flag_value;
+        }
     }
 }
 
@@ -729,8 +742,10 @@ void launch_k6_walk(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
     hipLaunchKernelGGL(k6_walk_kernel, dim3(gp), dim3(256), 0, s, a);
 }
 
-void launch_k6_score(const K6Arrays& a, double ln10, int score_threshold, hipStream_t s) {
-    hipLaunchKernelGGL(k6_score_kernel, dim3(1), dim3(1024), 0, s, a, ln10, score_threshold);
+void launch_k6_score(const K6Arrays& a, double ln10, int score_threshold, int with_scores, hipStream_t s) {
+    const uint32_t g = std::min<uint32_t>(a.sv_cap / kScoreSvs + 1, 2048u);  // candidates are unknown to the host: enough groups for
+    hipLaunchKernelGGL(k6_score_kernel, dim3(g), dim3(256), 0, s, a, ln10, score_threshold, with_scores);  // a.sv_cap, most exit at once
+    hipLaunchKernelGGL(k6_done_kernel, dim3(1), dim3(64), 0, s, a);
 }
 
 void launch_k6_compact(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
