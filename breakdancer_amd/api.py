@@ -196,6 +196,11 @@ class BreakDancer:
         self._chk(self.lib.bdx_get_read_class(self.h, out.ctypes.data_as(C.c_void_p), n), "bdx_get_read_class")
         return out
 
+    def set_stage_timing(self, on=True):
+        """HIP events between the stages (compact / regions / join timings); costs a few microseconds per event."""
+        self._chk(self.lib.bdx_set_stage_timing(self.h, int(on)), "bdx_set_stage_timing")
+        return self
+
     def set_host_walk(self, on=True):
         """Send every component of the region graph through the host walk (same results as the device assembly)."""
         self._chk(self.lib.bdx_set_host_walk(self.h, int(on)), "bdx_set_host_walk")

@@ -95,6 +95,7 @@ struct bdx_ctx {
     PinBuf h_hs_rec, h_hs_aux, h_hs_lists;
     PinBuf h_flags;                   // [0] pass 1 ready, [1] host's groups ready, [2] final table ready (= run sequence number)
     uint32_t seq = 0;
+    bool stage_timing = false;        // HIP events around K2 / K3 / K4+K6 (each costs a few microseconds of idle GPU)
     bool poll = true;                 // BDX_NO_POLL=1: wait with stream / event synchronisation only
     bool materialized = true;         // c->walk holds the final table (false: it still sits in the pinned buffers only)
     uint32_t n_sv_total = 0, n_groups_total = 0, n_terms_total = 0, n_cn_total = 0;
@@ -234,6 +235,8 @@ int bdx_create(bdx_ctx** out, const bdx_opts* opts, const bdx_lib* libs, int nli
     {
         const char* hw = getenv("BDX_HOST_WALK");
         c->host_walk_only = hw && hw[0] == '1';
+        const char* stt = getenv("BDX_STAGE_TIMING");
+        c->stage_timing = stt && stt[0] == '1';
         const char* np = getenv("BDX_NO_POLL");
         c->poll = !(np && np[0] == '1');
         const char* bj = getenv("BDX_BUCKETED_JOIN");
@@ -503,7 +506,7 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepa
     hipStream_t s = c->stream;
     const int nkeys = c->nkeys;
     const uint32_t na = c->p1.n_anom;
-    HIPCHK(c, hipEventRecord(c->ev[2], s));
+    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
     Compact& cp = c->cp;
     K3Arrays& k3 = c->k3;
     cp = Compact{};
@@ -538,7 +541,7 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepa
         }
         launch_k2(k2, k2_lds_bytes(nkeys), s);
     }
-    HIPCHK(c, hipEventRecord(c->ev[3], s));
+    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[3], s));
     c->nn_base = nn_base;
     return BDX_OK;
 }
@@ -586,11 +589,12 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool f
             HIPCHK(c, c->h_counts0.ensure(sizeof(StageCounts)));
             memset(c->h_counts0.p, 0, sizeof(StageCounts));
             k3.counts_host = c->h_counts0.as<StageCounts>();
+            k3.flag_host = c->h_flags.as<uint32_t>() + 3; k3.flag_value = c->seq;
         }
         K3Tail tail{has_next, next_qlen, next_nn};
         launch_k3(k3, cp, c->b_p1.as<Pass1>(), na, c->opts.min_len, c->opts.seq_coverage_lim, nkeys, nn_base, tail, s);
     }
-    HIPCHK(c, hipEventRecord(c->ev[4], s));
+    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[4], s));
     c->stage = 3;
     return BDX_OK;
 }
@@ -740,7 +744,7 @@ int do_k6(bdx_ctx* c, bool force_host) {
     a.period = std::max(1, c->opts.buffer_size + 1);
     a.force_host = force_host ? 1 : 0;
     launch_k6_groups(a, na, s);
-    HIPCHK(c, hipEventRecord(c->ev_groups, s));  // the host walk of the remaining components can start here
+    if (!c->poll) HIPCHK(c, hipEventRecord(c->ev_groups, s));  // (the host normally polls the word k6_mirror_kernel sets)
     launch_k6_walk(a, na, s);
     return BDX_OK;
 }
@@ -956,21 +960,25 @@ int bdx_run(bdx_ctx* c) {
     const bool force_host = c->host_walk_only || ph || c->opts.min_read_pair < 1;
     if (na) {
         // the region table is final after K3: the host takes its copy while the device joins the mates
-        HIPCHK(c, hipEventRecord(c->ev_regions, s));
+        if (!c->poll) HIPCHK(c, hipEventRecord(c->ev_regions, s));  // (normally: the word k3_region_of_kernel sets)
         Entries en{c->cp.key, c->k3.region_of, nullptr, c->cp.meta, c->cp.isize};
         rc = do_join_local(c, na, en, &c->b_p1.as<Pass1>()->n_anom, true);
         if (rc != BDX_OK) return rc;
         rc = do_k6(c, force_host);
         if (rc != BDX_OK) return rc;
     }
-    HIPCHK(c, hipEventRecord(c->ev[5], s));
+    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[5], s));
     const auto t_h0 = std::chrono::steady_clock::now();
     if (na) {
-        HIPCHK(c, hipEventSynchronize(c->ev_regions));
+        if (!wait_flag(c, 3, c->seq)) {
+            if (c->poll) HIPCHK(c, hipStreamSynchronize(s)); else HIPCHK(c, hipEventSynchronize(c->ev_regions));
+        }
         // (the table sits in pinned memory the device has just written: one streaming copy into ordinary memory is much
         // cheaper than the walk's scattered reads of it)
         decode_regions(c, c->h_regs.as<RegionRec>(), c->h_pk.as<uint32_t>(), c->h_counts0.as<StageCounts>()->n_regions, ph, false);
-        if (!wait_flag(c, 1, c->seq)) HIPCHK(c, hipEventSynchronize(c->ev_groups));
+        if (!wait_flag(c, 1, c->seq)) {
+            if (c->poll) HIPCHK(c, hipStreamSynchronize(s)); else HIPCHK(c, hipEventSynchronize(c->ev_groups));
+        }
         c->counts = *c->h_counts.as<StageCounts>();
         if (c->counts.overflow == 2) return fail(c, BDX_ELIMIT, "more than two primary reads share one read name (malformed input)");
         if (c->counts.overflow) return fail(c, BDX_EINTERNAL, "group list overflow");
@@ -994,11 +1002,13 @@ int bdx_run(bdx_ctx* c) {
         if (rc != BDX_OK) return rc;
     }
     const auto t_end = std::chrono::steady_clock::now();
-    (void)hipEventSynchronize(c->ev[5]);  // (complete by now; makes the elapsed-time queries valid)
-    auto evms = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[a], c->ev[b]); return ms; };
-    c->stage_ms[1] = evms(2, 3);
-    c->stage_ms[2] = evms(3, 4);
-    c->stage_ms[3] = evms(4, 5);
+    if (c->stage_timing) {
+        (void)hipEventSynchronize(c->ev[5]);  // (complete by now; makes the elapsed-time queries valid)
+        auto evms = [&](int a, int b) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[a], c->ev[b]); return ms; };
+        c->stage_ms[1] = evms(2, 3);
+        c->stage_ms[2] = evms(3, 4);
+        c->stage_ms[3] = evms(4, 5);
+    }
     c->stage_ms[4] = ms_between(t_h0, t_h1);
     c->stage_ms[5] = ms_between(t_h1, t_h2);
     c->stage_ms[6] = ms_between(t_h2, t_end);
@@ -1226,6 +1236,12 @@ int bdx_get_read_class(const bdx_ctx* c, uint8_t* out, size_t cap) {
     if (!c->ran) return BDX_ESTATE;
     const size_t n = std::min(cap, c->n);
     if (n && hipMemcpy(out, c->b_cls.p, n, hipMemcpyDeviceToHost) != hipSuccess) return BDX_EHIP;
+    return BDX_OK;
+}
+
+int bdx_set_stage_timing(bdx_ctx* c, int on) {
+    if (!c) return BDX_EINVAL;
+    c->stage_timing = on != 0;
     return BDX_OK;
 }
 

@@ -64,6 +64,8 @@ struct K3Arrays {
     uint32_t* acc_total;
     StageCounts* counts;
     StageCounts* counts_host;  // pinned host mirror: n_cand / n_regions / last_maxq are stored there as well (may be null)
+    uint32_t* flag_host;       // pinned word set to flag_value by k3_region_of_kernel: the region table is complete
+    uint32_t flag_value;
 };
 
 // the read that closes the last candidate when the stream continues in another context (next chromosome)

@@ -119,6 +119,10 @@ struct AcceptOut {
 
 __global__ __launch_bounds__(256) void k3_region_of_kernel(K3Arrays a, const Pass1* p1) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0 && a.flag_host) {  // the kernel before this one wrote the last region record
+        __threadfence_system();
+        *(volatile uint32_t*)a.flag_host = a.flag_value;
+    }
     if (j < p1->n_anom) {
         a.region_of[j] = a.c_rid[a.cand[j]];
         if (a.out_deg) {  // K6's component scratch: out_deg, label, bad_v, bad, mcount, pcount

@@ -180,6 +180,8 @@ int bdx_get_read_class(const bdx_ctx* ctx, uint8_t* out, size_t cap);
  * combination, [7] whole run; [8]-[10] split [6] into the final wait, the merge of the device's and the host's SV lists,
  * and the score combination.  Returns the number written. */
 int bdx_get_timings(const bdx_ctx* ctx, float* ms, int cap);
+/* [1]-[3] need HIP events between the stages, which idle the GPU for a few microseconds each: off by default */
+int bdx_set_stage_timing(bdx_ctx* ctx, int on);
 
 /* Where the SV candidates of the last bdx_run were assembled.  Components of the region graph that are one region, or
  * two regions of one flush window joined by one connection, are walked on the device (build_connection /
