@@ -136,6 +136,7 @@ struct bdx_ctx {
     WalkScratch* walk_scratch = nullptr;
     uint32_t n_printed = 0;
     uint32_t n_sv_host = 0;
+    bool region_of_fused = false;
     uint32_t join_table_clean = 0;    // slots of the direct join table already set to -1 (by K2), 0 = none
     float stage_ms[kNumStages] = {0};
     hipEvent_t ev[8] = {nullptr};
@@ -592,7 +593,9 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool f
             k3.flag_host = c->h_flags.as<uint32_t>() + 3; k3.flag_value = c->seq;
         }
         K3Tail tail{has_next, next_qlen, next_nn};
-        launch_k3(k3, cp, c->b_p1.as<Pass1>(), na, c->opts.min_len, c->opts.seq_coverage_lim, nkeys, nn_base, tail, s);
+        // single-context runs that take the direct join let that kernel do k3_region_of_kernel's work
+        c->region_of_fused = for_k6 && !c->bucketed_join && na <= kDirectJoinMax;
+        launch_k3(k3, cp, c->b_p1.as<Pass1>(), na, c->opts.min_len, c->opts.seq_coverage_lim, nkeys, nn_base, tail, !c->region_of_fused, s);
     }
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[4], s));
     c->stage = 3;
@@ -961,7 +964,13 @@ int bdx_run(bdx_ctx* c) {
     if (na) {
         // the region table is final after K3: the host takes its copy while the device joins the mates
         if (!c->poll) HIPCHK(c, hipEventRecord(c->ev_regions, s));  // (normally: the word k3_region_of_kernel sets)
-        Entries en{c->cp.key, c->k3.region_of, nullptr, c->cp.meta, c->cp.isize};
+        Entries en{};
+        en.key = c->cp.key; en.region = c->k3.region_of; en.meta = c->cp.meta; en.isize = c->cp.isize;
+        if (c->region_of_fused) {
+            en.cand = c->k3.cand; en.c_rid = c->k3.c_rid; en.region_out = c->k3.region_of;
+            en.k6_scratch = c->k3.out_deg; en.scratch_cap = c->k3.cap;
+            en.flag_host = c->h_flags.as<uint32_t>() + 3; en.flag_value = c->seq;
+        }
         rc = do_join_local(c, na, en, &c->b_p1.as<Pass1>()->n_anom, true);
         if (rc != BDX_OK) return rc;
         rc = do_k6(c, force_host);
@@ -1118,8 +1127,9 @@ int bdx_join_entries(bdx_ctx* c, size_t n, const uint64_t* key, const uint32_t* 
     HIPCHK(c, hipMemcpyAsync(c->b_x_isize.p, isize, n * 4, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->b_x_n.p, &n32, 4, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemsetAsync(c->b_counts.p, 0, sizeof(StageCounts), s));
-    Entries en{c->b_x_key.as<uint64_t>(), c->b_x_region.as<int32_t>(), c->b_x_order.as<uint32_t>(), c->b_x_meta.as<uint32_t>(),
-               c->b_x_isize.as<int32_t>()};
+    Entries en{};
+    en.key = c->b_x_key.as<uint64_t>(); en.region = c->b_x_region.as<int32_t>(); en.order = c->b_x_order.as<uint32_t>();
+    en.meta = c->b_x_meta.as<uint32_t>(); en.isize = c->b_x_isize.as<int32_t>();
     int rc = do_join_local(c, n32, en, c->b_x_n.as<uint32_t>(), false);
     if (rc != BDX_OK) return rc;
     HIPCHK(c, hipMemcpyAsync(c->h_counts.p, c->b_counts.p, sizeof(StageCounts), hipMemcpyDeviceToHost, s));

@@ -76,7 +76,7 @@ struct K3Tail {
 };
 
 void launch_k3(const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n_anom_host, int min_len, int seq_coverage_lim,
-               int nkeys, uint32_t nn_base, K3Tail tail, hipStream_t s);
+               int nkeys, uint32_t nn_base, K3Tail tail, bool region_of_launch, hipStream_t s);
 
 // ---- K4 ---------------------------------------------------------------------------------------------
 constexpr int kMaxBuckets = 8192;
@@ -120,6 +120,15 @@ struct Entries {
     const uint32_t* order;   // position in the merged stream order; nullptr = the entry index itself
     const uint32_t* meta;    // flag | rev<<4 | lib<<8 | qlen<<16
     const int32_t* isize;    // |isize|
+    // single-context runs with the direct join: the join kernel derives the region itself (region = c_rid[cand[j]]),
+    // stores it into region_out and resets K6's per-region scratch -- k3_region_of_kernel's work without its launch
+    const int32_t* cand;
+    const int32_t* c_rid;
+    int32_t* region_out;
+    uint32_t* k6_scratch;    // [6][scratch_cap]
+    uint32_t scratch_cap;
+    uint32_t* flag_host;     // pinned word: the region table (written by the kernel before) is complete
+    uint32_t flag_value;
 };
 
 void launch_k4(const K4Arrays& k4, const Entries& e, const uint32_t* n_ptr, uint32_t n_upper, StageCounts* counts, hipStream_t s);

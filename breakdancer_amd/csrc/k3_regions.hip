@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k3_region_of_kernel(K3Arrays a, const Pas
 }
 
 void launch_k3(const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n_anom_host, int min_len, int seq_coverage_lim,
-               int nkeys, uint32_t nn_base, K3Tail tail, hipStream_t s) {
+               int nkeys, uint32_t nn_base, K3Tail tail, bool region_of_launch, hipStream_t s) {
     if (n_anom_host == 0) return;
     // a.c_maxq[0 .. n_anom) must be zero on entry (K2 clears it while compacting)
     const uint32_t* n_ptr = &p1->n_anom;
@@ -149,7 +149,7 @@ void launch_k3(const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n
     AcceptIn ain{a.c_accept};
     AcceptOut aout{a, cp, nkeys};
     scan_launch<uint32_t>(ain, aout, &a.counts->n_cand, n_anom_host, a.ws_u32, a.acc_total, s);
-    hipLaunchKernelGGL(k3_region_of_kernel, dim3(g), dim3(256), 0, s, a, p1);
+    if (region_of_launch) hipLaunchKernelGGL(k3_region_of_kernel, dim3(g), dim3(256), 0, s, a, p1);  // else: fused into the join
 }
 
 }  // namespace bdx

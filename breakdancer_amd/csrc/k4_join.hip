@@ -163,7 +163,24 @@ __global__ __launch_bounds__(256) void k4_join_kernel(K4Arrays k4, StageCounts* 
 __global__ __launch_bounds__(256) void k4_direct_join_kernel(K4Arrays k4, Entries en, const uint32_t* n_ptr, StageCounts* counts) {
     const uint32_t na = *n_ptr;
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= na || en.region[j] < 0) return;
+    if (j == 0 && en.flag_host) {  // the kernel before this one wrote the last region record
+        __threadfence_system();
+        *(volatile uint32_t*)en.flag_host = en.flag_value;
+    }
+    if (j >= na) return;
+    int rj;
+    if (en.c_rid) {
+        rj = en.c_rid[en.cand[j]];
+        en.region_out[j] = rj;
+        if (en.k6_scratch) {  // out_deg, label, bad_v, bad, mcount, pcount
+            const size_t cap = en.scratch_cap;
+            en.k6_scratch[j] = 0; en.k6_scratch[cap + j] = j; en.k6_scratch[2 * cap + j] = 0; en.k6_scratch[3 * cap + j] = 0;
+            en.k6_scratch[4 * cap + j] = 0; en.k6_scratch[5 * cap + j] = 0;
+        }
+    } else {
+        rj = en.region[j];
+    }
+    if (rj < 0) return;
     const uint64_t key = en.key[j];
     const uint64_t h = mix64(key);
     const uint32_t tag = (uint32_t)(h >> 32);

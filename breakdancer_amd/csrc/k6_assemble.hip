@@ -134,6 +134,12 @@ __global__ __launch_bounds__(256) void k6_pairs_kernel(K6Arrays a) {
                     if (gleader && lo < r && strong) a.bad_v[lo] = 1u;
                     if (lane == 0) a.bad_v[r] = 1u;
                 } else {
+                    // (first round of the min-label propagation: each gate-passing group joins its two regions)
+                    if (gleader && lo < r && strong && !a.force_host) {
+                        const uint32_t lr = a.label[r], ll = a.label[lo];
+                        if (lr < ll) atomicMin(&a.label[lo], lr);
+                        else if (ll < lr) atomicMin(&a.label[r], ll);
+                    }
                     int e = 0;
                     for (uint64_t mm = gl_in; mm; mm &= mm - 1, ++e) {
                         const int t = __builtin_ctzll(mm);
@@ -730,7 +736,7 @@ void launch_k6_groups(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
     const uint32_t gr = (n_anom_host + 255) / 256;
     hipLaunchKernelGGL(k6_pairs_kernel, dim3(gp), dim3(256), 0, s, a);
     if (!a.force_host)
-        for (int i = 0; i < kK6LabelRounds; ++i) hipLaunchKernelGGL(k6_label_kernel, dim3(gr), dim3(256), 0, s, a);
+        for (int i = 1; i < kK6LabelRounds; ++i) hipLaunchKernelGGL(k6_label_kernel, dim3(gr), dim3(256), 0, s, a);  // round 1: k6_pairs
     hipLaunchKernelGGL(k6_classify_kernel, dim3(gr), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k6_emit_kernel, dim3(gr), dim3(256), 0, s, a);
     if (a.counts_host) hipLaunchKernelGGL(k6_mirror_kernel, dim3(1), dim3(64), 0, s, a);
