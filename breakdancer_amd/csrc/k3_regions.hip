@@ -31,8 +31,9 @@ struct HeadIn {
 
 struct HeadOut {
     K3Arrays a;
-    __device__ void operator()(uint32_t j, uint32_t, const U4& inc, const U4& e) const {
+    __device__ void operator()(uint32_t j, uint32_t n, const U4& inc, const U4& e) const {
         const int c = (int)inc.x - 1;
+        if (j == n - 1) a.counts->n_cand = inc.x;  // the accept scan runs over this many candidates
         a.cand[j] = c;
         a.pre_q[j] = inc.y;
         a.pre_rev[j] = inc.z;
@@ -45,65 +46,74 @@ struct HeadOut {
     }
 };
 
-__global__ __launch_bounds__(256) void k3_candidates_kernel(K3Arrays a, Compact cp, const Pass1* p1, const U4* head_total,
-                                                            int min_len, int seq_coverage_lim, int nkeys, uint32_t nn_base, K3Tail tail) {
-    const uint32_t nc = head_total->x;
-    const uint32_t na = p1->n_anom;
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && threadIdx.x == 0) {
-        a.counts->n_cand = nc;
-        if (a.counts_host) a.counts_host->n_cand = nc;
-    }
-    if (c >= nc) return;
-    const uint32_t f = a.c_first[c];
-    const uint32_t nxt = c + 1 < nc ? a.c_first[c + 1] : na;
-    const uint32_t l = nxt - 1;
-    const int start = cp.pos[f], end = cp.pos[l];
-    const uint32_t rev = a.pre_rev[l] - (f ? a.pre_rev[f - 1] : 0u);
-    const uint32_t nonctx = a.pre_nonctx[l] - (f ? a.pre_nonctx[f - 1] : 0u);
-    const uint32_t e = c + 1 < nc ? nxt : l;
-    int qsum = (int)(a.pre_q[e] - a.pre_q[f]);
-    int maxq = a.c_maxq[c];
-    const bool tail_closes = c + 1 == nc && tail.has_next;  // closed by the first anomalous read of the next chromosome
-    if (tail_closes) {
-        qsum += tail.qlen;
-        maxq = max(maxq, tail.qlen);
-        a.c_maxq[c] = maxq;
-    }
-    const float cov = __fdiv_rn((float)qsum, (float)(end - start + 1 + maxq));
-    const bool accept = (end - start > min_len) && (cov < (float)seq_coverage_lim);
-    a.c_accept[c] = accept ? 1u : 0u;
-    a.c_n[c] = nxt - f;
-    a.c_rev[c] = rev;
-    a.c_nonctx[c] = nonctx;
-    // normal read pairs seen while the candidate was open (BreakDancer.cpp:202-206): between its first
-    // read and the breaking read, or the end of the stream
-    const uint32_t nn_end = c + 1 < nc ? cp.nn[nxt] : (tail_closes ? tail.nn : nn_base + p1->n_normal);
-    a.c_nnormal[c] = nn_end - cp.nn[f];
-}
-
-struct AcceptIn {
-    const uint32_t* acc;
-    __device__ uint32_t operator()(uint32_t c, uint32_t) const { return acc[c]; }
+// Everything about candidate c is a difference of the prefix arrays written by the head scan: computed on the fly by
+// both passes of the accept scan (no separate launch, no per-candidate arrays).
+struct CandStats {
+    uint32_t first, last, n, rev, nonctx, nnormal;
+    int32_t maxq;
+    bool accept;
 };
-struct AcceptOut {
+
+struct CandCtx {
     K3Arrays a;
     Compact cp;
+    const Pass1* p1;
+    int min_len, seq_coverage_lim;
+    uint32_t nn_base;
+    K3Tail tail;
+    __device__ CandStats stats(uint32_t c, uint32_t nc) const {
+        CandStats s;
+        const uint32_t na = p1->n_anom;
+        const uint32_t f = a.c_first[c];
+        const uint32_t nxt = c + 1 < nc ? a.c_first[c + 1] : na;
+        const uint32_t l = nxt - 1;
+        const int start = cp.pos[f], end = cp.pos[l];
+        s.first = f; s.last = l; s.n = nxt - f;
+        s.rev = a.pre_rev[l] - (f ? a.pre_rev[f - 1] : 0u);
+        s.nonctx = a.pre_nonctx[l] - (f ? a.pre_nonctx[f - 1] : 0u);
+        const uint32_t e = c + 1 < nc ? nxt : l;
+        int qsum = (int)(a.pre_q[e] - a.pre_q[f]);
+        int maxq = a.c_maxq[c];
+        const bool tail_closes = c + 1 == nc && tail.has_next;  // closed by the first anomalous read of the next chromosome
+        if (tail_closes) {
+            qsum += tail.qlen;
+            maxq = max(maxq, tail.qlen);
+        }
+        s.maxq = maxq;
+        const float cov = __fdiv_rn((float)qsum, (float)(end - start + 1 + maxq));
+        s.accept = (end - start > min_len) && (cov < (float)seq_coverage_lim);
+        // normal read pairs seen while the candidate was open (BreakDancer.cpp:202-206): between its first
+        // read and the breaking read, or the end of the stream
+        const uint32_t nn_end = c + 1 < nc ? cp.nn[nxt] : (tail_closes ? tail.nn : nn_base + p1->n_normal);
+        s.nnormal = nn_end - cp.nn[f];
+        return s;
+    }
+};
+
+struct AcceptIn {
+    CandCtx x;
+    __device__ uint32_t operator()(uint32_t c, uint32_t nc) const { return x.stats(c, nc).accept ? 1u : 0u; }
+};
+struct AcceptOut {
+    CandCtx x;
     int nkeys;
     __device__ void operator()(uint32_t c, uint32_t n, uint32_t inc, uint32_t e) const {
+        const K3Arrays& a = x.a;
+        const Compact& cp = x.cp;
         a.c_rid[c] = e ? (int)inc - 1 : -1;
+        if (c != n - 1 && !e) return;
+        const CandStats st = x.stats(c, n);
         if (c == n - 1) {  // inc of the last candidate = #accepted
-            a.counts->last_maxq = a.c_maxq[c]; a.counts->n_regions = inc;
-            if (a.counts_host) { a.counts_host->last_maxq = a.c_maxq[c]; a.counts_host->n_regions = inc; }
+            a.counts->last_maxq = st.maxq; a.counts->n_regions = inc;
+            if (a.counts_host) { a.counts_host->last_maxq = st.maxq; a.counts_host->n_regions = inc; a.counts_host->n_cand = n; }
         }
         if (!e) return;
         const uint32_t r = inc - 1;
-        const uint32_t f = a.c_first[c];
-        const uint32_t l = f + a.c_n[c] - 1;
+        const uint32_t f = st.first, l = st.last;
         RegionRec rr;
         rr.tid = cp.tid[f]; rr.start = cp.pos[f]; rr.end = cp.pos[l];
-        rr.n = a.c_n[c]; rr.rev = a.c_rev[c]; rr.nonctx = a.c_nonctx[c]; rr.nnormal = a.c_nnormal[c];
-        rr.maxq = a.c_maxq[c];
+        rr.n = st.n; rr.rev = st.rev; rr.nonctx = st.nonctx; rr.nnormal = st.nnormal;
+        rr.maxq = st.maxq;
         rr.first = f;
         a.r_rec[r] = rr;
         if (a.r_rec_dev) a.r_rec_dev[r] = rr;
@@ -145,9 +155,9 @@ void launch_k3(const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n
     HeadOut hout{a};
     scan_launch<U4>(hin, hout, n_ptr, n_anom_host, a.ws_u4, a.head_total, s);
     const uint32_t g = (n_anom_host + 255) / 256;
-    hipLaunchKernelGGL(k3_candidates_kernel, dim3(g), dim3(256), 0, s, a, cp, p1, a.head_total, min_len, seq_coverage_lim, nkeys, nn_base, tail);
-    AcceptIn ain{a.c_accept};
-    AcceptOut aout{a, cp, nkeys};
+    const CandCtx cx{a, cp, p1, min_len, seq_coverage_lim, nn_base, tail};
+    AcceptIn ain{cx};
+    AcceptOut aout{cx, nkeys};
     scan_launch<uint32_t>(ain, aout, &a.counts->n_cand, n_anom_host, a.ws_u32, a.acc_total, s);
     if (region_of_launch) hipLaunchKernelGGL(k3_region_of_kernel, dim3(g), dim3(256), 0, s, a, p1);  // else: fused into the join
 }
