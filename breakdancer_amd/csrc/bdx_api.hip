@@ -91,7 +91,7 @@ struct bdx_ctx {
     DevBuf b_r_rec, b_r_pk, b_out_deg, b_out_hi, b_parts, b_kdens, b_rs, b_slot, b_members, b_own, b_lib_stage, b_cn_stage,
         b_t_lambda, b_t_k, b_ws6, b_k6const;
     PinBuf h_p1, h_cnt, h_counts, h_regs, h_pk, h_groups, h_terms;
-    DevBuf b_sv_dense, b_dlists, b_ltail;
+    DevBuf b_sv_src, b_dlists, b_ltail;
     PinBuf h_hs_rec, h_hs_aux, h_hs_lists;
     PinBuf h_flags;                   // [0] pass 1 ready, [1] host's groups ready, [2] final table ready (= run sequence number)
     uint32_t seq = 0;
@@ -278,7 +278,7 @@ void bdx_destroy(bdx_ctx* c) {
                       &c->b_c_nnormal, &c->b_c_rid, &c->b_region_of, &c->b_ws_u4, &c->b_ws_u32, &c->b_totals,
                       &c->b_counts, &c->b_bcnt, &c->b_boff, &c->b_bcur, &c->b_e_key, &c->b_e_idx, &c->b_partner, &c->b_t_key,
                       &c->b_t_idx, &c->b_x_key, &c->b_x_order, &c->b_x_region,
-                      &c->b_x_meta, &c->b_x_isize, &c->b_x_n, &c->b_fold, &c->b_lib_mean, &c->b_sv_dense, &c->b_dlists, &c->b_ltail, &c->b_r_rec, &c->b_r_pk, &c->b_out_deg, &c->b_out_hi,
+                      &c->b_x_meta, &c->b_x_isize, &c->b_x_n, &c->b_fold, &c->b_lib_mean, &c->b_sv_src, &c->b_dlists, &c->b_ltail, &c->b_r_rec, &c->b_r_pk, &c->b_out_deg, &c->b_out_hi,
                       &c->b_parts, &c->b_kdens, &c->b_rs, &c->b_slot, &c->b_members, &c->b_own, &c->b_lib_stage,
                       &c->b_cn_stage, &c->b_t_lambda, &c->b_t_k, &c->b_ws6, &c->b_k6const};
     for (DevBuf* b : bufs) b->release();
@@ -718,9 +718,9 @@ int do_k6(bdx_ctx* c, bool force_host) {
     HIPCHK(c, c->h_cn_key.ensure((size_t)a.cn_cap * 4 + 16)); HIPCHK(c, c->h_cn_value.ensure((size_t)a.cn_cap * 4 + 16));
     HIPCHK(c, c->h_ltail_dev.ensure((size_t)a.term_cap * 8));
     HIPCHK(c, c->h_counts2.ensure(sizeof(StageCounts)));
-    HIPCHK(c, c->b_sv_dense.ensure((size_t)a.sv_cap * sizeof(SvOut))); HIPCHK(c, c->b_ltail.ensure((size_t)a.term_cap * 8));
+    HIPCHK(c, c->b_sv_src.ensure((size_t)a.sv_cap * 12)); HIPCHK(c, c->b_ltail.ensure((size_t)a.term_cap * 8));
     HIPCHK(c, c->b_dlists.ensure((size_t)a.term_cap * 4 + (size_t)a.cn_cap * 8 + 64));
-    a.sv_dense = c->b_sv_dense.as<SvOut>(); a.ltail = c->b_ltail.as<double>();
+    a.sv_begin = c->b_sv_src.as<uint2>(); a.sv_src = (uint32_t*)(a.sv_begin + a.sv_cap); a.ltail = c->b_ltail.as<double>();
     a.d_lib_index = c->b_dlists.as<int32_t>(); a.d_cn_key = a.d_lib_index + a.term_cap; a.d_cn_value = (float*)(a.d_cn_key + a.cn_cap);
     a.cap = na;
     a.r_rec = c->b_r_rec.as<RegionRec>(); a.r_pk = c->b_r_pk.as<uint32_t>();

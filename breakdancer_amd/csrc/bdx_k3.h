@@ -227,7 +227,9 @@ struct K6Arrays {
     uint32_t lib_stride;           // min(nlibs, kK6LibStride)
     // final table: built densely in HBM by the compaction, scored, then written to pinned host memory in one coalesced
     // pass by k6_score_kernel
-    SvOut* sv_dense;               // device [sv_cap]
+    uint32_t* sv_src;              // device [sv_cap]: staging slot of the candidate at each final position, or 0x80000000 | j for
+                                   // the host walk's candidate j
+    uint2* sv_begin;               // device [sv_cap]: its first entries in the two flat lists
     int32_t* d_lib_index;          // device [term_cap]
     int32_t* d_cn_key;             // device [cn_cap]
     float* d_cn_value;             // device [cn_cap]

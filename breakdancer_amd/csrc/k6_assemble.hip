@@ -608,14 +608,14 @@ __device__ __forceinline__ uint32_t count_below(const uint32_t* v, uint32_t n, u
 // whose threshold is i, then its own.
 struct OwnOut {
     K6Arrays a;
-    __device__ void put_entries(uint32_t lb, uint32_t cb, const SvOut& o, const LibStage* ls, const CnStage* cs) const {
-        for (int32_t t = 0; t < o.sv.lib_count; ++t) {
+    __device__ void put_entries(uint32_t lb, uint32_t cb, int32_t nl, int32_t ncn, const LibStage* ls, const CnStage* cs) const {
+        for (int32_t t = 0; t < nl; ++t) {
             const LibStage l = ls[t];
             a.d_lib_index[lb + t] = l.lib;
             a.t_lambda[lb + t] = l.lambda;
             a.t_k[lb + t] = l.rc;
         }
-        for (int32_t t = 0; t < o.sv.cn_count; ++t) {
+        for (int32_t t = 0; t < ncn; ++t) {
             const CnStage cn = cs[t];
             a.d_cn_key[cb + t] = cn.key;
             a.d_cn_value[cb + t] = cn.value;
@@ -650,20 +650,19 @@ struct OwnOut {
                 a.d_cn_key[cb + t] = a.hs_cn_key[o.sv.cn_begin + t];
                 a.d_cn_value[cb + t] = a.hs_cn_value[o.sv.cn_begin + t];
             }
-            o.sv.lib_begin = (int32_t)lb;
-            o.sv.cn_begin = (int32_t)cb;
-            a.sv_dense[pos] = o;
+            a.sv_src[pos] = 0x80000000u | j;
+            a.sv_begin[pos] = make_uint2(lb, cb);
         }
         uint32_t d = ex_sv + hb1, lb = ex_l + (nh ? a.hs_pre_l[hb1] : 0u), cb = ex_c + (nh ? a.hs_pre_c[hb1] : 0u);
         for (uint32_t q = 0; q < e.x; ++q) {
             const uint32_t slot = a.own_slots[(size_t)i * kK6MaxSv + q];
-            SvOut o = a.sv_stage[slot];
-            put_entries(lb, cb, o, a.lib_stage + (size_t)slot * a.lib_stride, a.cn_stage + (size_t)slot * a.nkeys);
-            o.sv.lib_begin = (int32_t)lb;
-            o.sv.cn_begin = (int32_t)cb;
-            lb += (uint32_t)o.sv.lib_count;
-            cb += (uint32_t)o.sv.cn_count;
-            a.sv_dense[d++] = o;
+            const int32_t nl = a.sv_stage[slot].sv.lib_count, ncn = a.sv_stage[slot].sv.cn_count;
+            put_entries(lb, cb, nl, ncn, a.lib_stage + (size_t)slot * a.lib_stride, a.cn_stage + (size_t)slot * a.nkeys);
+            a.sv_src[d] = slot;
+            a.sv_begin[d] = make_uint2(lb, cb);
+            lb += (uint32_t)nl;
+            cb += (uint32_t)ncn;
+            ++d;
         }
     }
 };
@@ -684,9 +683,19 @@ __global__ __launch_bounds__(256) void k6_score_kernel(K6Arrays a, double ln10, 
     if (threadIdx.x == 0) s_printed = 0;
     if (base < n) {
         const uint32_t cnt = min((uint32_t)kScoreSvs, n - base);
-        const uint32_t* src = (const uint32_t*)(a.sv_dense + base);
-        for (uint32_t i = threadIdx.x; i < cnt * kSvWords; i += 256) s_rec[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < cnt * kSvWords; i += 256) {  // gather the records from the staging slots / the host's list
+            const uint32_t sv = i / kSvWords, w = i - sv * kSvWords;
+            const uint32_t from = a.sv_src[base + sv];
+            const uint32_t* src = (from & 0x80000000u) ? (const uint32_t*)(a.hs_rec + (from & 0x7FFFFFFFu)) : (const uint32_t*)(a.sv_stage + from);
+            s_rec[i] = src[w];
+        }
         __syncthreads();
+        if (threadIdx.x < cnt) {
+            SvOut* o = (SvOut*)s_rec + threadIdx.x;
+            const uint2 bg = a.sv_begin[base + threadIdx.x];
+            o->sv.lib_begin = (int32_t)bg.x;
+            o->sv.cn_begin = (int32_t)bg.y;
+        }
         if (threadIdx.x < cnt && with_scores) {
             SvOut* o = (SvOut*)s_rec + threadIdx.x;
             double logp = 0.0, err = 0.0;
