@@ -8,7 +8,7 @@ KERNELS := $(CSRC)/k1_classify.hip $(CSRC)/k2_compact.hip $(CSRC)/k3_regions.hip
 OBJS := $(KERNELS:.hip=.o) $(CSRC)/bdx_walk.o
 HOSTCOMMON := $(HOST)/options.cpp $(HOST)/config.cpp $(HOST)/bam_reader.cpp $(HOST)/producer.cpp $(HOST)/dumps.cpp
 
-all: breakdancer_amd/libbdx.so bin/breakdancer-max bin/bdx-dump-reads oracle
+all: breakdancer_amd/libbdx.so bin/breakdancer-max bin/bdx-dump-reads bin/bam2cfg oracle
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/bdx.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -25,6 +25,10 @@ bin/breakdancer-max: $(HOSTCOMMON) $(HOST)/main.cpp $(wildcard $(HOST)/*.h) brea
 	@mkdir -p bin
 	g++ $(HOSTFLAGS) -o $@ $(HOSTCOMMON) $(HOST)/main.cpp -Lbreakdancer_amd -lbdx -lz -Wl,-rpath,'$$ORIGIN/../breakdancer_amd' -Wl,-rpath,/opt/rocm/lib
 
+bin/bam2cfg: $(HOST)/bam2cfg_main.cpp $(HOST)/bam_reader.cpp $(HOST)/bam_reader.h
+	@mkdir -p bin
+	g++ $(HOSTFLAGS) -o $@ $(HOST)/bam2cfg_main.cpp $(HOST)/bam_reader.cpp -lz -lpthread
+
 bin/bdx-dump-reads: $(HOSTCOMMON) $(HOST)/dump_main.cpp $(wildcard $(HOST)/*.h) breakdancer_amd/libbdx.so
 	@mkdir -p bin
 	g++ $(HOSTFLAGS) -o $@ $(HOSTCOMMON) $(HOST)/dump_main.cpp -Lbreakdancer_amd -lbdx -lz -Wl,-rpath,'$$ORIGIN/../breakdancer_amd' -Wl,-rpath,/opt/rocm/lib
@@ -33,7 +37,7 @@ oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(CSRC)/*.o breakdancer_amd/libbdx.so bin/breakdancer-max bin/bdx-dump-reads
+	rm -f $(CSRC)/*.o breakdancer_amd/libbdx.so bin/breakdancer-max bin/bdx-dump-reads bin/bam2cfg
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

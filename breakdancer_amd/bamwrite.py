@@ -85,7 +85,8 @@ def write_bam_records(path, recs, targets, rgs=(), level=1, seed=0):
     qlen,mapq,name and optional rg (str or ''), am (int or None); random bases/qualities of length qlen."""
     rng = np.random.default_rng(seed)
     text = "@HD\tVN:1.0\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (t, 300000000) for t in targets) + \
-           "".join("@RG\tID:%s\tLB:x\tSM:s\n" % r for r in rgs)
+           "".join(("@RG\tID:%s\tLB:x\tSM:s\n" % r) if isinstance(r, str) else ("@RG\tID:%s\tPL:%s\tLB:%s\tSM:s\n" % (r[0], r[2], r[1]))
+                   for r in rgs)  # (id, library, platform) tuples give full @RG lines
     out = bytearray(b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(targets)))
     for t in targets:
         out += struct.pack("<i", len(t) + 1) + t.encode() + b"\0" + struct.pack("<i", 300000000)

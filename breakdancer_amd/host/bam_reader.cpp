@@ -62,6 +62,7 @@ BamReader::BamReader(const std::string& path, int threads) : path_(path), thread
     const uint32_t l_text = le32(buf_.data() + cur_ + 4);
     cur_ += 8;
     if (!ensure((size_t)l_text + 4)) throw std::runtime_error(path + " is not a valid bam file");
+    header_text_.assign((const char*)buf_.data() + cur_, l_text);
     cur_ += l_text;
     const uint32_t n_ref = le32(buf_.data() + cur_);
     cur_ += 4;

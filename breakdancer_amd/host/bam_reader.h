@@ -32,6 +32,7 @@ public:
 
     const std::string& path() const { return path_; }
     const std::vector<std::string>& target_names() const { return targets_; }
+    const std::string& header_text() const { return header_text_; }  // the SAM header (@HD/@SQ/@RG ... lines)
     int tid_of(const std::string& name) const;  // -1 if absent
     // next record of the file (no filtering); false at end of file
     bool next(BamRecord& r);
@@ -48,6 +49,7 @@ private:
     std::vector<uint8_t> buf_;         // decompressed bytes
     size_t cur_ = 0;
     std::vector<std::string> targets_;
+    std::string header_text_;
 };
 
 uint64_t hash_name(const char* s, size_t n);  // 64-bit name key shared by the two mates of a pair

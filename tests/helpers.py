@@ -66,12 +66,14 @@ def _parse_aux(buf):
     return out
 
 
-def read_bam(path):
+def read_bam(path, keep_all=False):
     """Decode one BAM.  Returns (targets, recs) where recs holds numpy arrays over the records that pass
-    the reference's reader filter (primary, tid >= 0: io/AlignmentFilter.hpp:24-34, io/BamIo.cpp:11-18)."""
+    the reference's reader filter (primary, tid >= 0: io/AlignmentFilter.hpp:24-34, io/BamIo.cpp:11-18);
+    keep_all=True keeps every record and adds the SAM header text as recs["header"]."""
     d = gzip.decompress(open(path, "rb").read())
     assert d[:4] == b"BAM\1"
     l_text, = struct.unpack_from("<i", d, 4)
+    header_text = d[8:8 + l_text].decode(errors="replace")
     o = 8 + l_text
     n_ref, = struct.unpack_from("<i", d, o)
     o += 4
@@ -103,7 +105,7 @@ def read_bam(path):
         p += l_seq
         aux = _parse_aux(d[p:o + bs])
         o += bs
-        if (flag & (0x100 | 0x800)) or tid < 0:
+        if not keep_all and ((flag & (0x100 | 0x800)) or tid < 0):
             continue
         am = aux.get(b"AM")
         bdqual = (am[1] & 0xFF) if am is not None else mapq  # io/Alignment.cpp:12-23 (uint8_t truncation)
@@ -121,6 +123,8 @@ def read_bam(path):
     recs["rg"] = rgs
     recs["seq"] = seqs
     recs["qual"] = quals
+    if keep_all:
+        recs["header"] = header_text
     return targets, recs
 
 
