@@ -3,13 +3,14 @@
 
 Workload (BASELINE.json configs[1]): synthetic single chromosome, 50 Mbp, 30x, 2x100 bp, 1 library, ~1 % discordant
 pairs -> 15 M records = 7.5 M read pairs per GPU, resident in HBM before the timed region.  A "step" is one full pass
-of the hot path (bdx_run: classify -> compact -> region cut -> mate join -> host walk -> Poisson score) over that
-batch.  With N > 1 every rank owns its own chromosome (the path shards by chromosome, no data-path collective), so
+of the hot path (bdx_run: classify -> compact -> region cut -> mate join -> pair groups -> component walk on the device
+(host walk for the few large components) -> Poisson scores -> final SV table in pinned host memory) over that batch.  With N > 1 every rank owns its own chromosome (the path shards by chromosome, no data-path collective), so
 scaling is weak and `value` is the aggregate over all ranks.
 
 One JSON line on rank 0; see the task contract for the fields.  `roofline` is for the dominant kernel (K1, the
 streaming classifier): algorithmic bytes = 28 B/read x reads per launch, divided by the kernel's
-average duration measured with HIP events on the context's stream (bdx_get_timings).  `cpu_baseline` times the CPU
+average duration measured with HIP events on the context's stream during the timed steps (bdx_get_timings; the kernel
+is bracketed by events on every 4th step, because an event pair idles the GPU for ~10 us).  `cpu_baseline` times the CPU
 oracle (a single-threaded port of the reference's path; the reference itself needs Boost and cannot be built here)
 on a bounded sample of the same workload.
 """

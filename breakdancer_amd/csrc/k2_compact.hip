@@ -10,6 +10,8 @@
 // counters, no workgroup barrier; tiles without an anomalous read are skipped after one ballot; the anomalous
 // slots of a tile are compacted through a wave-private LDS slice so that the gather runs with dense lanes.
 // HBM traffic: 1-2 B per read plus a gather of ~35 B per anomalous read.
+#include <cstdlib>
+
 #include "bdx_dev.h"
 
 namespace bdx {
@@ -27,6 +29,12 @@ __global__ __launch_bounds__(kBlock) void k2_compact_kernel(const K2Params p) {
         for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < p.fill_words[f]; i += gridDim.x * kBlock) p.fill_ptr[f][i] = p.fill_value[f];
     for (uint32_t tile = blockIdx.x * kWaves + w; tile < p.ntiles; tile += nwaves) {
         const uint64_t base = (uint64_t)tile * kTile + (uint64_t)lane * 4;
+        // the tile's prefix bases are fetched together with its class bytes (one round trip instead of two; the 7 % of
+        // tiles without an anomalous read pay two wasted loads)
+        const uint32_t pre_norm = p.tile_pre[(size_t)kColNormal * p.tstride + tile];
+        const uint32_t rank0 = p.tile_pre[(size_t)kColAnom * p.tstride + tile];
+        const uint32_t pre_k0 = p.tile_pre[(size_t)kColKey0 * p.tstride + tile];
+        const uint32_t pre_k1 = nkeys > 1 ? p.tile_pre[(size_t)(kColKey0 + 1) * p.tstride + tile] : 0u;
         unsigned c[4] = {0, 0, 0, 0}, lib[4] = {0, 0, 0, 0};
         int nvalid = 0;
         if (base + 4 <= p.n) {
@@ -55,7 +63,7 @@ __global__ __launch_bounds__(kBlock) void k2_compact_kernel(const K2Params p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) tot += (anom[r] ? 1u : 0u) + (nleft[r] ? 0x10000u : 0u);
         const uint32_t ex0 = wave_incl_scan(tot) - tot;
-        uint32_t nn = p.nn_base + p.tile_pre[(size_t)kColNormal * p.tstride + tile] + (ex0 >> 16);
+        uint32_t nn = p.nn_base + pre_norm + (ex0 >> 16);
         uint32_t jj[4] = {0, 0, 0, 0};
         int key[4] = {0, 0, 0, 0};
         if (nkeys > 1) {
@@ -66,7 +74,6 @@ __global__ __launch_bounds__(kBlock) void k2_compact_kernel(const K2Params p) {
         // Wave-level compaction before the gather: every anomalous slot drops (offset in tile, class byte, nn) into the
         // wave's LDS slice at its in-tile rank; then lanes 0..cnt-1 each fetch ONE whole record, so the eight column
         // gathers are issued once per wave with all lanes busy and the compact stores are contiguous.
-        const uint32_t rank0 = p.tile_pre[(size_t)kColAnom * p.tstride + tile];
         const uint32_t cnt = __shfl((ex0 + tot) & 0xFFFFu, 63);
         {
             uint32_t local = ex0 & 0xFFFFu;
@@ -108,8 +115,8 @@ __global__ __launch_bounds__(kBlock) void k2_compact_kernel(const K2Params p) {
                 inc4[r] = v;
             }
             const uint32_t ex = wave_incl_scan(v) - v;
-            const uint32_t b0 = p.pk_base[k0] + p.tile_pre[(size_t)(kColKey0 + k0) * p.tstride + tile];
-            const uint32_t b1 = k0 + 1 < nkeys ? p.pk_base[k0 + 1] + p.tile_pre[(size_t)(kColKey0 + k0 + 1) * p.tstride + tile] : 0u;
+            const uint32_t b0 = p.pk_base[k0] + (k0 == 0 ? pre_k0 : p.tile_pre[(size_t)(kColKey0 + k0) * p.tstride + tile]);
+            const uint32_t b1 = k0 + 1 < nkeys ? p.pk_base[k0 + 1] + (k0 == 0 ? pre_k1 : p.tile_pre[(size_t)(kColKey0 + k0 + 1) * p.tstride + tile]) : 0u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (!anom[r]) continue;
@@ -123,7 +130,10 @@ __global__ __launch_bounds__(kBlock) void k2_compact_kernel(const K2Params p) {
 
 void launch_k2(const K2Params& p, size_t lds, hipStream_t s) {
     const uint32_t nblk = (p.ntiles + kWaves - 1) / kWaves;
-    const uint32_t grid = nblk < 65536u ? nblk : 65536u;  // latency-bound (dependent loads per tile): one tile per wave wherever possible
+    // measured on MI355X at 58.6 k tiles: 2048 workgroups 54 us, 4096 46 us, 8192 43 us, one tile per wave (14.6 k) 45 us -- the
+    // kernel is bound by its scattered 32-byte sector gathers (8 columns per anomalous read), not by wave count
+    static const uint32_t cap = getenv("BDX_K2_GRID") ? (uint32_t)atoi(getenv("BDX_K2_GRID")) : 8192u;
+    const uint32_t grid = nblk < cap ? nblk : cap;
     hipLaunchKernelGGL(k2_compact_kernel, dim3(grid), dim3(kBlock), lds, s, p);
 }
 
