@@ -83,13 +83,12 @@ struct bdx_ctx {
     // stage buffers
     DevBuf b_libs, b_cls, b_tile_tot, b_tile_pre, b_tile_mono, b_blk_cnt, b_cnt, b_p1, b_fold;
     DevBuf b_c_tid, b_c_pos, b_c_isize, b_c_meta, b_c_key, b_c_idx, b_c_nn, b_c_pk;
-    DevBuf b_cand, b_pre_q, b_pre_rev, b_pre_nonctx, b_c_first, b_c_maxq, b_c_accept, b_c_n, b_c_rev, b_c_nonctx,
-        b_c_nnormal, b_c_rid, b_region_of, b_ws_u4, b_ws_u32, b_totals, b_counts;
+    DevBuf b_cand, b_pre_q, b_pre_rev, b_pre_nonctx, b_c_first, b_c_maxq, b_c_rid, b_region_of, b_ws_u4, b_ws_u32, b_totals, b_counts;
     DevBuf b_bcnt, b_boff, b_bcur, b_e_key, b_e_idx, b_partner, b_t_key, b_t_idx;
     DevBuf b_x_key, b_x_order, b_x_region, b_x_meta, b_x_isize, b_x_n;
     DevBuf b_lib_mean;
-    DevBuf b_r_rec, b_r_pk, b_out_deg, b_out_hi, b_parts, b_kdens, b_rs, b_slot, b_members, b_own, b_lib_stage, b_cn_stage,
-        b_t_lambda, b_t_k, b_ws6, b_k6const;
+    DevBuf b_r_rec, b_r_pk, b_out_deg, b_parts, b_kdens, b_rs, b_slot, b_members, b_own, b_lib_stage, b_cn_stage,
+        b_t_lambda, b_t_k, b_ws6;
     PinBuf h_p1, h_cnt, h_counts, h_regs, h_pk, h_groups, h_terms;
     DevBuf b_sv_src, b_dlists, b_ltail;
     PinBuf h_hs_rec, h_hs_aux, h_hs_lists;
@@ -101,12 +100,11 @@ struct bdx_ctx {
     bool poll = true;                 // BDX_NO_POLL=1: wait with stream / event synchronisation only
     bool materialized = true;         // c->walk holds the final table (false: it still sits in the pinned buffers only)
     uint32_t n_sv_total = 0, n_groups_total = 0, n_terms_total = 0, n_cn_total = 0;
-    PinBuf h_counts0, h_counts2, h_sv_out, h_lib_index, h_lib_pairs, h_cn_key, h_cn_value, h_ltail_dev, h_k6const;
+    PinBuf h_counts0, h_counts2, h_sv_out, h_lib_index, h_lib_pairs, h_cn_key, h_cn_value, h_ltail_dev;
     hipEvent_t ev_groups = nullptr, ev_regions = nullptr;
     bool bucketed_join = false;       // BDX_BUCKETED_JOIN=1: use the partitioned LDS join at every size (it is the path for > 4 M entries)
     bool host_walk_only = false;      // BDX_HOST_WALK=1: every component goes through the host walk (A/B testing of K6)
     K6Arrays k6{};
-    WalkResult merged;
 
     // results
     bool ran = false;
@@ -274,16 +272,15 @@ void bdx_destroy(bdx_ctx* c) {
                       &c->b_bam, &c->b_key, &c->b_libs, &c->b_cls, &c->b_tile_tot, &c->b_tile_pre, &c->b_tile_mono,
                       &c->b_blk_cnt, &c->b_cnt, &c->b_p1, &c->b_c_tid, &c->b_c_pos, &c->b_c_isize,
                       &c->b_c_meta, &c->b_c_key, &c->b_c_idx, &c->b_c_nn, &c->b_c_pk, &c->b_cand, &c->b_pre_q, &c->b_pre_rev,
-                      &c->b_pre_nonctx, &c->b_c_first, &c->b_c_maxq, &c->b_c_accept, &c->b_c_n, &c->b_c_rev, &c->b_c_nonctx,
-                      &c->b_c_nnormal, &c->b_c_rid, &c->b_region_of, &c->b_ws_u4, &c->b_ws_u32, &c->b_totals,
+                      &c->b_pre_nonctx, &c->b_c_first, &c->b_c_maxq, &c->b_c_rid, &c->b_region_of, &c->b_ws_u4, &c->b_ws_u32, &c->b_totals,
                       &c->b_counts, &c->b_bcnt, &c->b_boff, &c->b_bcur, &c->b_e_key, &c->b_e_idx, &c->b_partner, &c->b_t_key,
                       &c->b_t_idx, &c->b_x_key, &c->b_x_order, &c->b_x_region,
-                      &c->b_x_meta, &c->b_x_isize, &c->b_x_n, &c->b_fold, &c->b_lib_mean, &c->b_sv_src, &c->b_dlists, &c->b_ltail, &c->b_r_rec, &c->b_r_pk, &c->b_out_deg, &c->b_out_hi,
+                      &c->b_x_meta, &c->b_x_isize, &c->b_x_n, &c->b_fold, &c->b_lib_mean, &c->b_sv_src, &c->b_dlists, &c->b_ltail, &c->b_r_rec, &c->b_r_pk, &c->b_out_deg,
                       &c->b_parts, &c->b_kdens, &c->b_rs, &c->b_slot, &c->b_members, &c->b_own, &c->b_lib_stage,
-                      &c->b_cn_stage, &c->b_t_lambda, &c->b_t_k, &c->b_ws6, &c->b_k6const};
+                      &c->b_cn_stage, &c->b_t_lambda, &c->b_t_k, &c->b_ws6};
     for (DevBuf* b : bufs) b->release();
     PinBuf* pins[] = {&c->h_p1, &c->h_cnt, &c->h_counts, &c->h_regs, &c->h_pk, &c->h_groups, &c->h_terms, &c->h_flags, &c->h_hs_rec, &c->h_hs_aux, &c->h_hs_lists, &c->h_counts0, &c->h_counts2,
-                      &c->h_sv_out, &c->h_lib_index, &c->h_lib_pairs, &c->h_cn_key, &c->h_cn_value, &c->h_ltail_dev, &c->h_k6const};
+                      &c->h_sv_out, &c->h_lib_index, &c->h_lib_pairs, &c->h_cn_key, &c->h_cn_value, &c->h_ltail_dev};
     for (PinBuf* b : pins) b->release();
     if (c->walk_scratch) walk_scratch_free(c->walk_scratch);
     for (auto& e : c->ev)
@@ -386,7 +383,6 @@ int do_pass1(bdx_ctx* c) {
     c->regions.clear(); c->r_pk.clear(); c->parts.clear();
     c->reg = nullptr; c->nreg = 0; c->rpk = nullptr;
     c->walk.clear();
-    c->merged.clear();
     if (!c->walk_scratch) c->walk_scratch = walk_scratch_new();
     c->n_printed = 0;
     memset(&c->counts, 0, sizeof(c->counts));
@@ -566,8 +562,8 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool f
     K3Arrays& k3 = c->k3;
     if (na) {
         const size_t cap = na;
-        DevBuf* u32bufs[] = {&c->b_cand, &c->b_pre_q, &c->b_pre_rev, &c->b_pre_nonctx, &c->b_c_first, &c->b_c_maxq, &c->b_c_accept,
-                             &c->b_c_n, &c->b_c_rev, &c->b_c_nonctx, &c->b_c_nnormal, &c->b_c_rid, &c->b_region_of};
+        DevBuf* u32bufs[] = {&c->b_cand, &c->b_pre_q, &c->b_pre_rev, &c->b_pre_nonctx, &c->b_c_first, &c->b_c_maxq, &c->b_c_rid,
+                             &c->b_region_of};
         for (DevBuf* b : u32bufs) HIPCHK(c, b->ensure(cap * 4));
         // the region table and (below) the group list are written by the kernels straight into pinned host memory:
         // they are write-once, read-never on the device, so the PCIe writes overlap the kernels and no D2H copy is needed
@@ -580,9 +576,7 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool f
         k3.cap = na;
         k3.cand = c->b_cand.as<int32_t>(); k3.pre_q = c->b_pre_q.as<uint32_t>(); k3.pre_rev = c->b_pre_rev.as<uint32_t>();
         k3.pre_nonctx = c->b_pre_nonctx.as<uint32_t>(); k3.c_first = c->b_c_first.as<uint32_t>();
-        k3.c_maxq = c->b_c_maxq.as<int32_t>(); k3.c_accept = c->b_c_accept.as<uint32_t>(); k3.c_n = c->b_c_n.as<uint32_t>();
-        k3.c_rev = c->b_c_rev.as<uint32_t>(); k3.c_nonctx = c->b_c_nonctx.as<uint32_t>();
-        k3.c_nnormal = c->b_c_nnormal.as<uint32_t>(); k3.c_rid = c->b_c_rid.as<int32_t>(); k3.region_of = c->b_region_of.as<int32_t>();
+        k3.c_maxq = c->b_c_maxq.as<int32_t>(); k3.c_rid = c->b_c_rid.as<int32_t>(); k3.region_of = c->b_region_of.as<int32_t>();
         k3.r_rec = c->h_regs.as<RegionRec>(); k3.r_pk = c->h_pk.as<uint32_t>();
         if (for_k6) {  // the device-side SV assembly reads the region table back: keep a copy in HBM
             HIPCHK(c, c->b_r_rec.ensure(cap * sizeof(RegionRec)));

@@ -47,7 +47,6 @@ struct K3Arrays {
     // per candidate
     uint32_t* c_first;
     int32_t* c_maxq;
-    uint32_t *c_accept, *c_n, *c_rev, *c_nonctx, *c_nnormal;
     int32_t* c_rid;
     int32_t* region_of;  // per compact read: accepted region id or -1
     // per accepted region (array-of-structs so one copy brings the table to the host)
