@@ -96,6 +96,7 @@ struct bdx_ctx {
     uint32_t seq = 0;
     uint32_t k1_event_period = 4;     // K1 is bracketed by HIP events on every n-th run (an event pair idles the GPU ~10 us)
     float k1_ms_last = 0;
+    bool k1_timed = false;
     bool stage_timing = false;        // HIP events around K2 / K3 / K4+K6 (each costs a few microseconds of idle GPU)
     bool poll = true;                 // BDX_NO_POLL=1: wait with stream / event synchronisation only
     bool materialized = true;         // c->walk holds the final table (false: it still sits in the pinned buffers only)
@@ -136,6 +137,14 @@ struct bdx_ctx {
     WalkScratch* walk_scratch = nullptr;
     uint32_t n_printed = 0;
     uint32_t n_sv_host = 0;
+    // enqueue-ahead: a context that has just run an input of the same size sizes the later stages from that run's count of
+    // anomalous reads (+12 %) and enqueues them before the pass-1 record is back, so the device does not idle at the
+    // host's decision; finalize2_kernel neutralises them if the guess was too small and the host runs them again
+    bool speculate = true;            // BDX_NO_SPECULATE=1 turns it off
+    int spec_test = 0;                // BDX_SPEC_TEST=1: guess half of the last count (forces the retry path)
+    uint32_t last_na = 0;
+    size_t last_n = 0;
+    uint32_t na_alloc = 0;            // the count the later stages are sized and launched with
     bool region_of_fused = false;
     uint32_t join_table_clean = 0;    // slots of the direct join table already set to -1 (by K2), 0 = none
     float stage_ms[kNumStages] = {0};
@@ -239,6 +248,8 @@ int bdx_create(bdx_ctx** out, const bdx_opts* opts, const bdx_lib* libs, int nli
         const char* stt = getenv("BDX_STAGE_TIMING");
         c->stage_timing = stt && stt[0] == '1';
         if (const char* kp = getenv("BDX_K1_EVENT_PERIOD")) c->k1_event_period = (uint32_t)std::max(1, atoi(kp));
+        if (const char* ns = getenv("BDX_NO_SPECULATE")) c->speculate = !(ns[0] == '1');
+        if (const char* st = getenv("BDX_SPEC_TEST")) c->spec_test = atoi(st);
         const char* np = getenv("BDX_NO_POLL");
         c->poll = !(np && np[0] == '1');
         const char* bj = getenv("BDX_BUCKETED_JOIN");
@@ -369,7 +380,10 @@ float ms_between(std::chrono::steady_clock::time_point a, std::chrono::steady_cl
 }
 
 // K1 + finalize: class bytes, per-tile tables, *local* pass-1 counters
-int do_pass1(bdx_ctx* c) {
+int do_pass1(bdx_ctx* c, uint32_t na_cap = 0, bool wait = true);
+int wait_pass1(bdx_ctx* c);
+
+int do_pass1(bdx_ctx* c, uint32_t na_cap, bool wait) {
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const int nlibs = c->nlibs, nbams = c->nbams, nkeys = c->nkeys;
@@ -380,6 +394,7 @@ int do_pass1(bdx_ctx* c) {
     const int grid1 = (int)std::min<uint32_t>((ntiles + kWaves - 1) / kWaves, kK1MaxGrid);
     c->ntiles = ntiles; c->tstride = tstride;
     c->ran = false; c->stage = 0;
+    c->na_alloc = 0;
     c->regions.clear(); c->r_pk.clear(); c->parts.clear();
     c->reg = nullptr; c->nreg = 0; c->rpk = nullptr;
     c->walk.clear();
@@ -442,15 +457,24 @@ int do_pass1(bdx_ctx* c) {
     HIPCHK(c, c->h_flags.ensure(64));
     ++c->seq;
     fp.flag_host = c->h_flags.as<uint32_t>(); fp.flag_value = c->seq;
+    fp.na_cap = na_cap;
     launch_finalize(fp, s);
-    if (!wait_flag(c, 0, c->seq)) HIPCHK(c, hipStreamSynchronize(s));
+    c->k1_timed = time_k1;
+    return wait ? wait_pass1(c) : BDX_OK;
+}
+
+// the pass-1 record and counters, written into pinned memory by finalize2_kernel
+int wait_pass1(bdx_ctx* c) {
+    const int ncnt = c->nlibs * kNumFlags + c->nlibs + c->nbams;
+    if (!wait_flag(c, 0, c->seq)) HIPCHK(c, hipStreamSynchronize(c->stream));
     c->p1 = *c->h_p1.as<Pass1>();
     c->cnt_local.assign(c->h_cnt.as<uint32_t>(), c->h_cnt.as<uint32_t>() + ncnt);
-    if (time_k1) {
+    if (c->k1_timed) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->k1_ms_last = ms;
     }
     c->stage_ms[0] = c->k1_ms_last;  // the latest measured launch
+    if (!c->na_alloc) c->na_alloc = c->p1.n_anom;  // (an enqueue-ahead run has set its guess already)
     c->stage = 1;
     return BDX_OK;
 }
@@ -508,7 +532,7 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepa
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const int nkeys = c->nkeys;
-    const uint32_t na = c->p1.n_anom;
+    const uint32_t na = c->na_alloc;
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
     Compact& cp = c->cp;
     K3Arrays& k3 = c->k3;
@@ -556,7 +580,7 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool f
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const int nkeys = c->nkeys;
-    const uint32_t na = c->p1.n_anom;
+    const uint32_t na = c->na_alloc;
     const uint32_t nn_base = c->nn_base;
     Compact& cp = c->cp;
     K3Arrays& k3 = c->k3;
@@ -689,7 +713,7 @@ void decode_groups(bdx_ctx* c, const GroupRec* gr, uint32_t ng, uint32_t ph) {
 // no traversal, everything else listed for the host walk; then the dense results and K5 for the device-assembled SVs.
 int do_k6(bdx_ctx* c, bool force_host) {
     hipStream_t s = c->stream;
-    const uint32_t na = c->p1.n_anom;
+    const uint32_t na = c->na_alloc;
     const int nkeys = c->nkeys, nlibs = c->nlibs;
     K6Arrays& a = c->k6;
     a = K6Arrays{};
@@ -742,7 +766,7 @@ int do_k6(bdx_ctx* c, bool force_host) {
     a.flag_groups = c->h_flags.as<uint32_t>() + 1; a.flag_done = c->h_flags.as<uint32_t>() + 2; a.flag_value = c->seq;
     memset(c->h_counts.p, 0, sizeof(StageCounts));
     memset(c->h_counts2.p, 0, sizeof(StageCounts));
-    a.covered_ref_len = c->g_covered;
+    a.p1 = c->b_p1.as<Pass1>();
     a.nlibs = nlibs; a.nkeys = nkeys; a.min_read_pair = c->opts.min_read_pair; a.chr_restricted = c->opts.chr_restricted;
     a.period = std::max(1, c->opts.buffer_size + 1);
     a.force_host = force_host ? 1 : 0;
@@ -757,7 +781,7 @@ int do_k6(bdx_ctx* c, bool force_host) {
 // the final table is assembled by the device in pinned host memory, in the reference's output order.
 int do_k6_table(bdx_ctx* c) {
     hipStream_t s = c->stream;
-    const uint32_t na = c->p1.n_anom;
+    const uint32_t na = c->na_alloc;
     K6Arrays& a = c->k6;
     if (!na) return BDX_OK;
     const WalkResult& H = c->walk;
@@ -945,25 +969,22 @@ extern "C" {
 int bdx_run(bdx_ctx* c) {
     if (!c) return BDX_EINVAL;
     const auto t_begin = std::chrono::steady_clock::now();
-    int rc = do_pass1(c);
-    if (rc != BDX_OK) return rc;
-    rc = set_pass1(c, c->cnt_local.data(), c->p1.covered_ref_len, c->p1.window, false);
-    if (rc != BDX_OK) return rc;
-    rc = do_compact(c, 0, nullptr, true);
-    if (rc != BDX_OK) return rc;
-    rc = do_cut(c, 0, 0, 0, true);
-    if (rc != BDX_OK) return rc;
     hipStream_t s = c->stream;
-    const uint32_t na = c->p1.n_anom;
     // The very first anomalous read "breaks" an empty accumulator (start = end = -1, no reads).  With a negative
     // -s that empty candidate passes process_breakpoint's test (0 > min_len, coverage 0) and the reference
     // registers a read-less region 0 (BreakDancer.cpp:216-231, 244-252); every real region id shifts by one.
-    const uint32_t ph = (na && 0 > c->opts.min_len && 0.0f < (float)c->opts.seq_coverage_lim) ? 1u : 0u;
+    const bool ph_opt = 0 > c->opts.min_len && 0.0f < (float)c->opts.seq_coverage_lim;
     // shifted region ids and a non-positive -r are left to the host walk entirely
-    const bool force_host = c->host_walk_only || ph || c->opts.min_read_pair < 1;
-    if (na) {
+    const bool force_host = c->host_walk_only || ph_opt || c->opts.min_read_pair < 1;
+    // K2 .. K6 (first half) for c->na_alloc anomalous reads
+    auto enqueue_middle = [&]() -> int {
+        int r = do_compact(c, 0, nullptr, true);
+        if (r != BDX_OK) return r;
+        r = do_cut(c, 0, 0, 0, true);
+        if (r != BDX_OK) return r;
+        if (!c->na_alloc) return BDX_OK;
         // the region table is final after K3: the host takes its copy while the device joins the mates
-        if (!c->poll) HIPCHK(c, hipEventRecord(c->ev_regions, s));  // (normally: the word k3_region_of_kernel sets)
+        if (!c->poll) HIPCHK(c, hipEventRecord(c->ev_regions, s));  // (normally: the word the join kernel sets)
         Entries en{};
         en.key = c->cp.key; en.region = c->k3.region_of; en.meta = c->cp.meta; en.isize = c->cp.isize;
         if (c->region_of_fused) {
@@ -971,11 +992,48 @@ int bdx_run(bdx_ctx* c) {
             en.k6_scratch = c->k3.out_deg; en.scratch_cap = c->k3.cap;
             en.flag_host = c->h_flags.as<uint32_t>() + 3; en.flag_value = c->seq;
         }
-        rc = do_join_local(c, na, en, &c->b_p1.as<Pass1>()->n_anom, true);
+        r = do_join_local(c, c->na_alloc, en, &c->b_p1.as<Pass1>()->n_anom, true);
+        if (r != BDX_OK) return r;
+        return do_k6(c, force_host);
+    };
+    // enqueue-ahead when this context has just run an input of the same size
+    uint32_t guess = 0;
+    if (c->speculate && c->ran && c->last_n == c->n && c->last_na) {
+        guess = c->spec_test ? std::max(1u, c->last_na / 2) : c->last_na + c->last_na / 8 + 1024;
+        if (guess > kMaxRegions) guess = 0;
+    }
+    int rc;
+    if (guess) {
+        rc = do_pass1(c, guess, false);
         if (rc != BDX_OK) return rc;
-        rc = do_k6(c, force_host);
+        c->na_alloc = guess;
+        rc = enqueue_middle();
+        if (rc != BDX_OK) return rc;
+        rc = wait_pass1(c);
+        if (rc != BDX_OK) return rc;
+        rc = set_pass1(c, c->cnt_local.data(), c->p1.covered_ref_len, c->p1.window, false);
+        if (rc != BDX_OK) return rc;
+        if (c->p1.n_anom > guess) {  // more anomalous reads than guessed: the enqueued stages saw none; run them properly
+            HIPCHK(c, hipStreamSynchronize(s));
+            HIPCHK(c, hipMemcpy(&c->b_p1.as<Pass1>()->n_anom, &c->p1.n_anom, 4, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemset(c->b_counts.p, 0, sizeof(StageCounts)));
+            ++c->seq;  // fresh ready-words: the ones of the neutralised launches are already set
+            c->na_alloc = c->p1.n_anom;
+            rc = enqueue_middle();
+            if (rc != BDX_OK) return rc;
+        }
+    } else {
+        rc = do_pass1(c);
+        if (rc != BDX_OK) return rc;
+        rc = set_pass1(c, c->cnt_local.data(), c->p1.covered_ref_len, c->p1.window, false);
+        if (rc != BDX_OK) return rc;
+        rc = enqueue_middle();
         if (rc != BDX_OK) return rc;
     }
+    c->last_n = c->n;
+    c->last_na = c->p1.n_anom;
+    const uint32_t na = c->p1.n_anom;
+    const uint32_t ph = (na && ph_opt) ? 1u : 0u;
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[5], s));
     const auto t_h0 = std::chrono::steady_clock::now();
     if (na) {

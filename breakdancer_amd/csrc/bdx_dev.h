@@ -79,6 +79,9 @@ struct FinalizeParams {
     float* key_density;         // [nkeys]; may be null
     uint32_t* flag_host;        // pinned word set to flag_value once the mirrors are written (the host polls it); may be null
     uint32_t flag_value;
+    uint32_t na_cap;            // 0, or the capacity the later stages were already enqueued with: if there are more anomalous
+                                // reads, the device copy of n_anom is zeroed (they then do nothing) and the host, which still
+                                // gets the true count, runs them again
 };
 
 // one launch that sets several scratch buffers to their start values (replaces a chain of small fill commands)

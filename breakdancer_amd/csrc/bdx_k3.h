@@ -268,7 +268,7 @@ struct K6Arrays {
     const uint32_t* hist;          // [nlibs][11] adopted flag histogram
     const float* key_density;      // [nkeys] read density per counter key (finalize2_kernel)
     const float* lib_mean;         // [nlibs]
-    uint32_t covered_ref_len;
+    const Pass1* p1;               // covered_ref_len is read from the device's pass-1 record
     int nlibs, nkeys, min_read_pair, chr_restricted, period, force_host;
 };
 

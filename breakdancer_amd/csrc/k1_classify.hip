@@ -472,6 +472,10 @@ __global__ __launch_bounds__(256) void finalize2_kernel(const FinalizeParams p) 
             if (t == 0) *(volatile uint32_t*)p.flag_host = p.flag_value;
         }
     }
+    if (p.na_cap) {
+        __syncthreads();
+        if (t == 0 && p.p1->n_anom > p.na_cap) p.p1->n_anom = 0;
+    }
 }
 
 __global__ __launch_bounds__(256) void k0_init_kernel(const InitList l) {

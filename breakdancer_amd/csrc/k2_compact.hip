@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kBlock) void k2_compact_kernel(const K2Params p) {
         __builtin_amdgcn_wave_barrier();
         for (uint32_t b = 0; b < cnt; b += 64) {
             const uint32_t q = b + lane;
-            if (q < cnt) {
+            if (q < cnt && rank0 + q < p.c.cap) {  // (the capacity can be a guess of an enqueue-ahead run)
                 const uint32_t src = s_src[w * kTile + q];
                 const uint64_t i = (uint64_t)tile * kTile + (src & 255u);
                 const uint32_t j = rank0 + q;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kBlock) void k2_compact_kernel(const K2Params p) {
             const uint32_t b1 = k0 + 1 < nkeys ? p.pk_base[k0 + 1] + (k0 == 0 ? pre_k1 : p.tile_pre[(size_t)(kColKey0 + k0 + 1) * p.tstride + tile]) : 0u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (!anom[r]) continue;
+                if (!anom[r] || jj[r] >= p.c.cap) continue;
                 const uint32_t s = ex + inc4[r];
                 p.c.pk[(size_t)k0 * p.c.cap + jj[r]] = b0 + (s & 0xFFFFu);
                 if (k0 + 1 < nkeys) p.c.pk[(size_t)(k0 + 1) * p.c.cap + jj[r]] = b1 + (s >> 16);

@@ -302,7 +302,7 @@ __device__ bool assemble_sv(const K6Arrays& a, const PartRec* P, uint32_t A, int
             }
         diff = __fadd_rn(diff, __fsub_rn((float)span, __fmul_rn((float)rc, a.lib_mean[best])));
         const uint32_t nflag = a.hist[(size_t)best * kNumFlags + flag];
-        double lambda = __dmul_rn((double)total_region_size, __ddiv_rn((double)nflag, (double)a.covered_ref_len));
+        double lambda = __dmul_rn((double)total_region_size, __ddiv_rn((double)nflag, (double)a.p1->covered_ref_len));
         lambda = (1.0e-10 < lambda) ? lambda : 1.0e-10;
         if (store && nacc < lib_room) ls[nacc] = LibStage{best, rc, lambda};
         ++nacc;

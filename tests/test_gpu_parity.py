@@ -234,3 +234,27 @@ def test_bucketed_join_path(seed, monkeypatch):
     run.set_stream(0, st)
     run.run()
     compare(run, product_from_oracle(run))
+
+
+@pytest.mark.parametrize("mode", ["ahead", "retry", "off"])
+def test_repeated_runs_on_one_context(mode, monkeypatch):
+    """a context that runs again on an input of the same size enqueues the later stages before the pass-1 record is back,
+    sized from the previous run ("ahead"); BDX_SPEC_TEST=1 makes that guess too small, so the stages are neutralised on
+    the device and run again ("retry"); every run must give the oracle's table"""
+    if mode == "retry":
+        monkeypatch.setenv("BDX_SPEC_TEST", "1")
+    if mode == "off":
+        monkeypatch.setenv("BDX_NO_SPECULATE", "1")
+    cfg, st = _synth_case(6_000_000, seed=23)
+    run = OracleRun(cfg, make_opts())
+    run.set_targets(["chrS"])
+    st = dict(st)
+    st["lib"] = np.zeros(len(st["tid"]), np.int32)
+    run.set_stream(0, st)
+    run.run()
+    bd = product_from_oracle(run)
+    compare(run, bd)
+    for _ in range(3):
+        bd.run()
+        compare(run, bd)
+    bd.close()
