@@ -102,3 +102,93 @@ OPTION_SETS = [dict(), dict(cn_lib=1, print_af=1), dict(print_af=1), dict(transc
                dict(buffer_size=1), dict(buffer_size=2), dict(buffer_size=5), dict(min_map_qual=0), dict(min_map_qual=36),
                dict(seq_coverage_lim=3), dict(max_sd=900), dict(cut_sd=2), dict(illumina_long_insert=1), dict(fisher=1),
                dict(transchr_rearrange=1, min_read_pair=1)]
+
+
+def make_graph_case(seed, n_slots=240):
+    """Many small, separate components of the region graph with every shape the walk distinguishes: "slots" 3 kb apart
+    (far beyond the window) each become one region; groups of 1-5 consecutive slots get random connections of 1-4 pairs
+    (around the -r gate), random self groups, mixed flags / libraries, some reaching into the other contig (CTX).
+    Returns (config, streams, targets) like make_case."""
+    rng = np.random.default_rng(10_000 + seed)
+    libs = [dict(name="libA", bam="a.bam", rg="rgA", mean=300, std=20, readlen=50),
+            dict(name="libB", bam="b.bam", rg="rgB", mean=380, std=25, readlen=50)]
+    config = "".join("readgroup:%s\tplatform:illumina\tmap:%s\treadlen:%d.00\tlib:%s\tnum:10001\tlower:%.2f\tupper:%.2f\tmean:%.2f\tstd:%.2f\n"
+                     % (l["rg"], l["bam"], l["readlen"], l["name"], l["mean"] - 3 * l["std"], l["mean"] + 3 * l["std"], l["mean"], l["std"])
+                     for l in libs)
+    contigs = (n_slots * 3000 // 2 + 20000, n_slots * 3000 // 2 + 20000)
+    slot_tid = [0 if i < n_slots // 2 else 1 for i in range(n_slots)]
+    slot_pos = [5000 + (i if i < n_slots // 2 else i - n_slots // 2) * 3000 for i in range(n_slots)]
+    recs = {0: [], 1: []}
+    pid = [0]
+
+    def add_pair(sa, sb, kind, li):
+        """one read pair: first mate in slot sa, second in slot sb (sa <= sb in stream order)"""
+        l = libs[li]
+        rl = l["readlen"]
+        ta, tb = slot_tid[sa], slot_tid[sb]
+        pa = slot_pos[sa] + int(rng.integers(0, 150))
+        pb = slot_pos[sb] + int(rng.integers(0, 150))
+        if sa == sb:
+            if kind == "small":
+                pb = pa + int(rng.integers(8, 60))
+            else:
+                pb = pa + int(rng.integers(8, 140))
+        ra, rb = {"fr": (False, True), "small": (False, True), "ff": (False, False), "rr": (True, True), "rf": (True, False)}[kind]
+        isz = (pb + rl - pa) if ta == tb else 0
+        pid[0] += 1
+        base = 0x1
+        fa = base | 0x40 | (0x10 if ra else 0) | (0x20 if rb else 0)
+        fb = base | 0x80 | (0x10 if rb else 0) | (0x20 if ra else 0)
+        bam = 0 if l["bam"] == "a.bam" else 1
+        recs[bam].append(dict(tid=ta, pos=pa, mtid=tb, mpos=pb, isize=isz, flag=fa, qlen=rl, bdqual=60, rg=l["rg"], name=pid[0]))
+        recs[bam].append(dict(tid=tb, pos=pb, mtid=ta, mpos=pa, isize=-isz, flag=fb, qlen=rl, bdqual=60, rg=l["rg"], name=pid[0]))
+
+    # background: properly paired normal reads so that the counters, densities and copy numbers are non-trivial
+    for _ in range(600):
+        li = int(rng.integers(0, 2))
+        l = libs[li]
+        tid = int(rng.integers(0, 2))
+        p1 = int(rng.integers(1000, contigs[tid] - 2000))
+        ins = int(max(l["readlen"] + 10, rng.normal(l["mean"], l["std"] / 2)))
+        p2 = p1 + ins - l["readlen"]
+        pid[0] += 1
+        bam = 0 if l["bam"] == "a.bam" else 1
+        recs[bam].append(dict(tid=tid, pos=p1, mtid=tid, mpos=p2, isize=ins, flag=0x1 | 0x2 | 0x40 | 0x20, qlen=l["readlen"], bdqual=60, rg=l["rg"], name=pid[0]))
+        recs[bam].append(dict(tid=tid, pos=p2, mtid=tid, mpos=p1, isize=-ins, flag=0x1 | 0x2 | 0x80 | 0x10, qlen=l["readlen"], bdqual=60, rg=l["rg"], name=pid[0]))
+    kinds = ["fr", "ff", "rr", "rf"]
+    s = 0
+    while s < n_slots:
+        k = int(rng.choice([1, 2, 2, 3, 3, 3, 4, 4, 5]))
+        members = list(range(s, min(s + k, n_slots)))
+        for a in members:  # self groups
+            if rng.random() < 0.5:
+                for _ in range(int(rng.integers(1, 4))):
+                    add_pair(a, a, str(rng.choice(["small", "ff", "rf"])), int(rng.integers(0, 2)))
+        for i, a in enumerate(members):  # connections
+            for b in members[i + 1:]:
+                if rng.random() < (0.9 if b == a + 1 else 0.35):
+                    kind = str(rng.choice(kinds))
+                    for _ in range(int(rng.integers(1, 5))):
+                        add_pair(a, b, kind if rng.random() < 0.8 else str(rng.choice(kinds)), int(rng.integers(0, 2)))
+        if rng.random() < 0.08 and members[-1] < n_slots // 2:  # a link into the other contig
+            far = int(rng.integers(n_slots // 2, n_slots))
+            for _ in range(int(rng.integers(1, 4))):
+                add_pair(members[0], far, "fr", int(rng.integers(0, 2)))
+        for a in members:  # every slot needs two reads a few bases apart to become a region at all
+            add_pair(a, a, "ff", int(rng.integers(0, 2))) if rng.random() < 0.3 else None
+        s += k + (1 if rng.random() < 0.3 else 0)
+    streams = []
+    for b in (0, 1):
+        rr = sorted(recs[b], key=lambda r: (r["tid"], r["pos"]))
+        d = {k: np.array([r[k] for r in rr], dtype=dt) for k, dt in
+             (("tid", np.int32), ("pos", np.int32), ("mtid", np.int32), ("mpos", np.int32), ("isize", np.int32),
+              ("flag", np.uint16), ("qlen", np.int32), ("bdqual", np.uint8))}
+        d["rg"] = [r["rg"] for r in rr]
+        d["name_id"] = np.array([r["name"] for r in rr], dtype=np.uint64)
+        streams.append(d)
+    return config, streams, ["c1", "c2"]
+
+
+GRAPH_OPTION_SETS = [dict(), dict(min_read_pair=1), dict(min_read_pair=3), dict(min_read_pair=4), dict(buffer_size=1), dict(buffer_size=2),
+                     dict(buffer_size=3, min_read_pair=1), dict(buffer_size=7), dict(cn_lib=1, print_af=1), dict(chr_tid=0),
+                     dict(chr_tid=0, min_read_pair=1), dict(transchr_rearrange=1, min_read_pair=1), dict(min_len=40), dict(fisher=1)]

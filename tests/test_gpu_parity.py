@@ -258,3 +258,25 @@ def test_repeated_runs_on_one_context(mode, monkeypatch):
         bd.run()
         compare(run, bd)
     bd.close()
+
+
+@pytest.mark.parametrize("seed", range(28))
+def test_small_component_graphs(seed):
+    """hundreds of separate 1-5 region components with random connections around the weight gate, self groups, mixed
+    flags and libraries, links across contigs: the device walk (components of <= 4 regions) and the host walk (the
+    rest) against the oracle, and the device walk against the host walk"""
+    from fuzzgen import GRAPH_OPTION_SETS, make_graph_case
+    cfg, streams, targets = make_graph_case(seed)
+    o = GRAPH_OPTION_SETS[seed % len(GRAPH_OPTION_SETS)]
+    run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1, **o))
+    few = bool(o.get("transchr_rearrange"))  # -t keeps the inter-chromosomal pairs only
+    assert run.n_svs > (0 if few else 15), run.n_svs
+    bd = product_from_oracle(run, support=True)
+    compare(run, bd)
+    compare_support(run, bd)
+    n_dev, n_host, _ = bd.walk_split()
+    assert (few or n_dev > 5) and n_dev + n_host == run.n_svs, (n_dev, n_host)
+    bd.close()
+    bh = product_from_oracle(run, host_walk=True)
+    compare(run, bh)
+    bh.close()
