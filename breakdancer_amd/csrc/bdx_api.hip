@@ -729,7 +729,7 @@ int do_k6(bdx_ctx* c, bool force_host) {
     HIPCHK(c, c->b_lib_stage.ensure(cap * a.lib_stride * sizeof(LibStage)));
     HIPCHK(c, c->b_cn_stage.ensure(cap * (size_t)nkeys * sizeof(CnStage) + 16));
     HIPCHK(c, c->b_t_lambda.ensure((size_t)a.term_cap * 8)); HIPCHK(c, c->b_t_k.ensure((size_t)a.term_cap * 4));
-    const size_t nblk = scan_grid(na) + 1;
+    const size_t nblk = scan_grid(na, 1) + 1;
     HIPCHK(c, c->b_ws6.ensure(nblk * sizeof(U4) + 64));
     HIPCHK(c, c->h_sv_out.ensure((size_t)a.sv_cap * sizeof(SvOut)));
     HIPCHK(c, c->h_lib_index.ensure((size_t)a.term_cap * 4)); HIPCHK(c, c->h_lib_pairs.ensure((size_t)a.term_cap * 4));

@@ -33,8 +33,8 @@ template <class T> __device__ __forceinline__ T wave_incl_scan_t(T v) {
 }
 
 constexpr int kScanBlock = 256;
-constexpr int kScanIters = 2;   // 512 elements per workgroup: ~300 workgroups at 150 k elements, enough to cover 256 CUs
-constexpr int kScanChunk = kScanBlock * kScanIters;  // elements per workgroup
+constexpr int kScanIters = 2;   // default: 512 elements per workgroup (~300 workgroups at 150 k elements, enough to cover 256 CUs);
+                                // scans over few elements with a heavy output functor take 1 (template parameter kIters)
 
 // block-wide inclusive scan of one element per thread; returns the inclusive value, *total = block sum
 template <class T> __device__ __forceinline__ T block_incl_scan(T v, T* s_ws /*[4]*/, T* total) {
@@ -54,14 +54,15 @@ template <class T> __device__ __forceinline__ T block_incl_scan(T v, T* s_ws /*[
     return off + inc;
 }
 
-template <class T, class In> __global__ __launch_bounds__(kScanBlock) void scan_phase1(In in, const uint32_t* n_ptr, T* blk) {
+template <class T, class In, int kIters> __global__ __launch_bounds__(kScanBlock) void scan_phase1(In in, const uint32_t* n_ptr, T* blk) {
+    constexpr int kScanChunk = kScanBlock * kIters;
     __shared__ T s_ws[kScanBlock / 64];
     const uint32_t n = *n_ptr;
     const uint32_t base = blockIdx.x * kScanChunk;
     if (base >= n) return;
     T acc = zero_of<T>();
 #pragma unroll
-    for (int it = 0; it < kScanIters; ++it) {
+    for (int it = 0; it < kIters; ++it) {
         const uint32_t j = base + it * kScanBlock + threadIdx.x;
         if (j < n) acc = acc + in(j, n);
     }
@@ -71,7 +72,8 @@ template <class T, class In> __global__ __launch_bounds__(kScanBlock) void scan_
 }
 
 // single workgroup: in-place exclusive scan of the block sums, grand total -> *total
-template <class T> __global__ __launch_bounds__(1024) void scan_phase2(T* blk, const uint32_t* n_ptr, T* total) {
+template <class T, int kIters> __global__ __launch_bounds__(1024) void scan_phase2(T* blk, const uint32_t* n_ptr, T* total) {
+    constexpr int kScanChunk = kScanBlock * kIters;
     __shared__ T s_ws[16];
     __shared__ T s_carry;
     const uint32_t n = *n_ptr;
@@ -95,15 +97,16 @@ template <class T> __global__ __launch_bounds__(1024) void scan_phase2(T* blk, c
     if (threadIdx.x == 0) *total = s_carry;
 }
 
-template <class T, class In, class Out>
+template <class T, class In, class Out, int kIters>
 __global__ __launch_bounds__(kScanBlock) void scan_phase3(In in, Out out, const uint32_t* n_ptr, const T* blk) {
+    constexpr int kScanChunk = kScanBlock * kIters;
     __shared__ T s_ws[kScanBlock / 64];
     const uint32_t n = *n_ptr;
     const uint32_t base = blockIdx.x * kScanChunk;
     if (base >= n) return;
     T carry = blk[blockIdx.x];
 #pragma unroll 1
-    for (int it = 0; it < kScanIters; ++it) {
+    for (int it = 0; it < kIters; ++it) {
         const uint32_t j = base + it * kScanBlock + threadIdx.x;
         if (base + it * kScanBlock >= n) break;
         T e = j < n ? in(j, n) : zero_of<T>();
@@ -115,14 +118,17 @@ __global__ __launch_bounds__(kScanBlock) void scan_phase3(In in, Out out, const 
 }
 
 // host helper: grid for an upper bound on the element count
-inline uint32_t scan_grid(uint32_t n_upper) { return n_upper ? (n_upper + kScanChunk - 1) / kScanChunk : 1; }
+inline uint32_t scan_grid(uint32_t n_upper, int iters = kScanIters) {
+    const uint32_t chunk = (uint32_t)(kScanBlock * iters);
+    return n_upper ? (n_upper + chunk - 1) / chunk : 1;
+}
 
-template <class T, class In, class Out>
+template <class T, int kIters = kScanIters, class In, class Out>
 void scan_launch(In in, Out out, const uint32_t* n_ptr, uint32_t n_upper, T* blk_ws, T* total, hipStream_t s) {
-    const uint32_t g = scan_grid(n_upper);
-    hipLaunchKernelGGL((scan_phase1<T, In>), dim3(g), dim3(kScanBlock), 0, s, in, n_ptr, blk_ws);
-    hipLaunchKernelGGL((scan_phase2<T>), dim3(1), dim3(1024), 0, s, blk_ws, n_ptr, total);
-    hipLaunchKernelGGL((scan_phase3<T, In, Out>), dim3(g), dim3(kScanBlock), 0, s, in, out, n_ptr, blk_ws);
+    const uint32_t g = scan_grid(n_upper, kIters);
+    hipLaunchKernelGGL((scan_phase1<T, In, kIters>), dim3(g), dim3(kScanBlock), 0, s, in, n_ptr, blk_ws);
+    hipLaunchKernelGGL((scan_phase2<T, kIters>), dim3(1), dim3(1024), 0, s, blk_ws, n_ptr, total);
+    hipLaunchKernelGGL((scan_phase3<T, In, Out, kIters>), dim3(g), dim3(kScanBlock), 0, s, in, out, n_ptr, blk_ws);
 }
 
 }  // namespace bdx

@@ -767,7 +767,7 @@ void launch_k6_compact(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
     if (n_anom_host == 0) return;
     OwnIn in{a.own_nsv, a.own_nacc, a.own_ncn};
     OwnOut out{a};
-    scan_launch<U4>(in, out, &a.counts->n_regions, n_anom_host, a.ws_u4, a.total_u4, s);
+    scan_launch<U4, 1>(in, out, &a.counts->n_regions, n_anom_host, a.ws_u4, a.total_u4, s);  // few elements, heavy output: one per thread
 }
 
 }  // namespace bdx
