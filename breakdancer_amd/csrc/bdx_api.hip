@@ -770,6 +770,10 @@ int do_k6(bdx_ctx* c, bool force_host) {
     a.nlibs = nlibs; a.nkeys = nkeys; a.min_read_pair = c->opts.min_read_pair; a.chr_restricted = c->opts.chr_restricted;
     a.period = std::max(1, c->opts.buffer_size + 1);
     a.force_host = force_host ? 1 : 0;
+    {
+        static const int rounds = getenv("BDX_LABEL_ROUNDS") ? std::max(1, atoi(getenv("BDX_LABEL_ROUNDS"))) : kK6LabelRounds;
+        a.label_rounds = rounds;
+    }
     launch_k6_groups(a, na, s);
     if (!c->poll) HIPCHK(c, hipEventRecord(c->ev_groups, s));  // (the host normally polls the word k6_mirror_kernel sets)
     launch_k6_walk(a, na, s);

@@ -270,6 +270,7 @@ struct K6Arrays {
     const float* lib_mean;         // [nlibs]
     const Pass1* p1;               // covered_ref_len is read from the device's pass-1 record
     int nlibs, nkeys, min_read_pair, chr_restricted, period, force_host;
+    int label_rounds;              // min-label propagation rounds incl. the one inside k6_pairs_kernel (default kK6LabelRounds)
 };
 
 void launch_k6_groups(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s);   // pair groups, components, the host's list

@@ -745,7 +745,7 @@ void launch_k6_groups(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
     const uint32_t gr = (n_anom_host + 255) / 256;
     hipLaunchKernelGGL(k6_pairs_kernel, dim3(gp), dim3(256), 0, s, a);
     if (!a.force_host)
-        for (int i = 1; i < kK6LabelRounds; ++i) hipLaunchKernelGGL(k6_label_kernel, dim3(gr), dim3(256), 0, s, a);  // round 1: k6_pairs
+        for (int i = 1; i < a.label_rounds; ++i) hipLaunchKernelGGL(k6_label_kernel, dim3(gr), dim3(256), 0, s, a);  // round 1: k6_pairs
     hipLaunchKernelGGL(k6_classify_kernel, dim3(gr), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k6_emit_kernel, dim3(gr), dim3(256), 0, s, a);
     if (a.counts_host) hipLaunchKernelGGL(k6_mirror_kernel, dim3(1), dim3(64), 0, s, a);
