@@ -722,7 +722,7 @@ int do_k6(bdx_ctx* c, bool force_host) {
     HIPCHK(c, c->b_parts.ensure(cap * sizeof(PartRec)));
     HIPCHK(c, c->b_rs.ensure(cap * sizeof(RegSum)));
     HIPCHK(c, c->b_members.ensure(cap * kK6MaxMembers * sizeof(MemberInfo)));
-    HIPCHK(c, c->b_own.ensure(cap * (3 + kK6MaxSv) * 4));
+    HIPCHK(c, c->b_own.ensure(cap * (4 + kK6MaxSv) * 4));
     a.sv_cap = na / 2 + 1; a.term_cap = na / 2 + 1; a.cn_cap = (na / 2 + 1) * (uint32_t)nkeys;
     a.lib_stride = (uint32_t)std::min(nlibs, kK6LibStride);
     HIPCHK(c, c->b_slot.ensure(cap * sizeof(SvOut)));
@@ -748,7 +748,7 @@ int do_k6(bdx_ctx* c, bool force_host) {
     a.out_deg = c->b_out_deg.as<uint32_t>(); a.label = a.out_deg + cap; a.bad_v = a.out_deg + 2 * cap; a.bad = a.out_deg + 3 * cap;
     a.mcount = a.out_deg + 4 * cap; a.pcount = a.out_deg + 5 * cap;
     a.members = c->b_members.as<MemberInfo>();
-    a.own_nsv = c->b_own.as<uint32_t>(); a.own_nacc = a.own_nsv + cap; a.own_ncn = a.own_nsv + 2 * cap; a.own_slots = a.own_nsv + 3 * cap;
+    a.own_nsv = c->b_own.as<uint32_t>(); a.own_nacc = a.own_nsv + cap; a.own_ncn = a.own_nsv + 2 * cap; a.own_slots = a.own_nsv + 3 * cap; a.owners = a.own_nsv + (3 + kK6MaxSv) * cap;
     a.sv_stage = c->b_slot.as<SvOut>(); a.lib_stage = c->b_lib_stage.as<LibStage>(); a.cn_stage = c->b_cn_stage.as<CnStage>();
     a.sv_out = c->h_sv_out.as<SvOut>(); a.lib_index = c->h_lib_index.as<int32_t>(); a.lib_pairs = c->h_lib_pairs.as<int32_t>();
     a.cn_key = c->h_cn_key.as<int32_t>(); a.cn_value = c->h_cn_value.as<float>();

@@ -23,7 +23,7 @@ struct StageCounts {
     uint32_t stage_sv;     // K6: bump allocators of the staging lists
     uint32_t stage_lib;
     uint32_t stage_cn;
-    uint32_t done;         // K6: workgroups of k6_walk_kernel that have finished (reset by the last one)
+    uint32_t n_owners;     // K6: device-walked components (entries of K6Arrays::owners)
 };
 
 struct RegionRec {
@@ -213,6 +213,7 @@ struct K6Arrays {
     uint32_t* mcount;              // [cap] by label: members registered
     uint32_t* pcount;              // [cap] by label: parts its walk can touch (bounds the libraries of one SV candidate)
     MemberInfo* members;           // [cap][kK6MaxMembers] by label
+    uint32_t* owners;              // [cap] smallest regions of the device-walked components (k6_emit_kernel), any order
     // SV candidates of the device-walked components.  Staging slots need no allocation: the candidate that consumes the
     // group (A, B) sits at first_B + (index of that group among B's incoming ones), the one of B's self group right
     // after them -- every group owns at least one read of its later region, so the slots exist and are distinct.

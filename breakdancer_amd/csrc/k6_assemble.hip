@@ -399,6 +399,11 @@ __global__ __launch_bounds__(256) void k6_emit_kernel(K6Arrays a) {
             }
         }
     }
+    {   // work list of the walk kernel: the smallest region of every device-walked component
+        const bool owner = covered && L == r;
+        const uint32_t o = wave_reserve(owner ? 1u : 0u, &a.counts->n_owners);
+        if (owner) a.owners[o] = r;
+    }
     {   // pairs of all regions; connections: inert ones everywhere, the others where the component is walked on the device
         const uint32_t pairs = active ? s.n_pairs : 0u;
         const uint32_t grp = (active ? s.n_weak : 0u) + (covered ? s.n_in + (s.np_self ? 1u : 0u) : 0u);
@@ -455,11 +460,10 @@ __global__ __launch_bounds__(256) void k6_walk_kernel(K6Arrays a) {
     const int mrp = a.min_read_pair;
     const int nk = a.nkeys;
     const uint32_t period = (uint32_t)a.period;
-    for (uint32_t r = blockIdx.x * 4 + w; r < NR; r += nwaves) {
-        if (a.label[r] != r) continue;  // not the smallest region of its component
-        const uint32_t k_raw = a.mcount[r];
-        if (k_raw == 0 || !component_on_device(a, r)) continue;
-        const int k = (int)k_raw;
+    const uint32_t n_owners = a.counts->n_owners;
+    for (uint32_t oi = blockIdx.x * 4 + w; oi < n_owners; oi += nwaves) {
+        const uint32_t r = a.owners[oi];  // smallest region of a component that is walked here (k6_emit_kernel's list)
+        const int k = (int)a.mcount[r];
         // _max_readlen at this window's flush: the value of the candidate that closes there (BreakDancer.cpp:254-259)
         const uint32_t rl = (r / period + 1) * period - 1;
         const int max_readlen = rl < NR ? a.r_rec[rl].maxq : a.counts->last_maxq;
