@@ -474,7 +474,10 @@ int wait_pass1(bdx_ctx* c) {
         if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->k1_ms_last = ms;
     }
     c->stage_ms[0] = c->k1_ms_last;  // the latest measured launch
-    if (!c->na_alloc) c->na_alloc = c->p1.n_anom;  // (an enqueue-ahead run has set its guess already)
+    if (c->p1.n_anom > kMaxRegions) return fail(c, BDX_ELIMIT, "too many anomalous reads for the packed group key");
+    // capacity of the later stages: the count plus the headroom an enqueue-ahead run of the same input will ask for, so that
+    // its buffers are these buffers (an enqueue-ahead run has set its guess already)
+    if (!c->na_alloc && c->p1.n_anom) c->na_alloc = (uint32_t)std::min<uint64_t>((uint64_t)c->p1.n_anom + c->p1.n_anom / 8 + 1024, kMaxRegions);
     c->stage = 1;
     return BDX_OK;
 }
