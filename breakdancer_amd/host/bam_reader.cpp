@@ -55,27 +55,42 @@ uint64_t hash_name(const char* s, size_t n) {
     return h;
 }
 
+namespace {
+constexpr size_t kFrontGap = 4u << 20;  // room in front of a batch for the unparsed tail of the previous one
+}  // namespace
+
+void BamReader::Chunk::reserve(size_t n) {
+    if (n <= cap) return;
+    std::unique_ptr<uint8_t[]> nd(new uint8_t[n]);  // (not value-initialised: 128 MiB of zeroes per batch is real time)
+    if (end > beg) memcpy(nd.get() + beg, data.get() + beg, end - beg);
+    data = std::move(nd);
+    cap = n;
+}
+
 BamReader::BamReader(const std::string& path, int threads) : path_(path), threads_(threads < 1 ? 1 : threads) {
     fp_ = fopen(path.c_str(), "rb");
     if (!fp_) throw std::runtime_error("Failed to open samfile " + path);
-    if (!ensure(12) || memcmp(buf_.data() + cur_, "BAM\1", 4) != 0) throw std::runtime_error(path + " is not a valid bam file");
-    const uint32_t l_text = le32(buf_.data() + cur_ + 4);
+    if (!ensure(12) || memcmp(at(), "BAM\1", 4) != 0) throw std::runtime_error(path + " is not a valid bam file");
+    const uint32_t l_text = le32(at() + 4);
     cur_ += 8;
     if (!ensure((size_t)l_text + 4)) throw std::runtime_error(path + " is not a valid bam file");
-    header_text_.assign((const char*)buf_.data() + cur_, l_text);
+    header_text_.assign((const char*)at(), l_text);
     cur_ += l_text;
-    const uint32_t n_ref = le32(buf_.data() + cur_);
+    const uint32_t n_ref = le32(at());
     cur_ += 4;
     for (uint32_t i = 0; i < n_ref; ++i) {
         if (!ensure(4)) throw std::runtime_error(path + " is not a valid bam file");
-        const uint32_t l = le32(buf_.data() + cur_);
+        const uint32_t l = le32(at());
         if (!ensure((size_t)4 + l + 4)) throw std::runtime_error(path + " is not a valid bam file");
-        targets_.emplace_back((const char*)buf_.data() + cur_ + 4, l ? l - 1 : 0);
+        targets_.emplace_back((const char*)at() + 4, l ? l - 1 : 0);
         cur_ += 4 + l + 4;
     }
 }
 
 BamReader::~BamReader() {
+    if (next_ready_.valid()) {
+        try { next_ready_.get(); } catch (...) {}
+    }
     if (fp_) fclose(fp_);
 }
 
@@ -85,13 +100,9 @@ int BamReader::tid_of(const std::string& name) const {
     return -1;
 }
 
-bool BamReader::fill() {
-    if (cur_ > 0) {  // drop consumed decompressed bytes
-        buf_.erase(buf_.begin(), buf_.begin() + cur_);
-        cur_ = 0;
-    }
+bool BamReader::fill(Chunk& c) {
     std::vector<Block> blocks;
-    size_t uoff = buf_.size();
+    size_t uoff = kFrontGap;
     while (true) {
         if (!eof_ && comp_.size() - comp_off_ < (size_t)(128u << 10)) {  // top up the compressed window
             comp_.erase(comp_.begin(), comp_.begin() + comp_off_);
@@ -134,10 +145,12 @@ bool BamReader::fill() {
             return false;
         }
     }
-    buf_.resize(uoff);
+    c.beg = c.end = 0;
+    c.reserve(std::max(uoff, kFrontGap + (size_t)40 * 1024 * 1024));  // sized once: fresh pages under eight writers are slow
+    uint8_t* out = c.data.get();
     const int nt = (int)std::min<size_t>((size_t)threads_, blocks.size());
     if (nt <= 1) {
-        for (const Block& b : blocks) inflate_block(comp_.data() + b.coff, b.clen, buf_.data() + b.uoff, b.ulen);
+        for (const Block& b : blocks) inflate_block(comp_.data() + b.coff, b.clen, out + b.uoff, b.ulen);
     } else {
         std::vector<std::thread> th;
         std::vector<std::string> errs(nt);
@@ -145,29 +158,85 @@ bool BamReader::fill() {
             th.emplace_back([&, t] {
                 try {
                     for (size_t i = (size_t)t; i < blocks.size(); i += (size_t)nt)
-                        inflate_block(comp_.data() + blocks[i].coff, blocks[i].clen, buf_.data() + blocks[i].uoff, blocks[i].ulen);
+                        inflate_block(comp_.data() + blocks[i].coff, blocks[i].clen, out + blocks[i].uoff, blocks[i].ulen);
                 } catch (std::exception const& e) { errs[t] = e.what(); }
             });
         for (auto& x : th) x.join();
         for (auto& e : errs)
             if (!e.empty()) throw std::runtime_error(e + ": " + path_);
     }
+    c.beg = kFrontGap;
+    c.end = uoff;
+    return true;
+}
+
+// The batch after the current one is inflated on a helper thread while the caller parses; here the caller takes it over
+// (moving its unparsed tail into the gap in front of the new batch) and starts the one after it.
+bool BamReader::advance() {
+    if (!started_) {
+        started_ = true;
+        next_ready_ = std::async(std::launch::async, [this] { return fill(chunk_[0]); });
+        cur_chunk_ = 1;  // (so that the first take-over lands on chunk 0)
+    }
+    if (!next_ready_.valid()) return false;
+    const bool got = next_ready_.get();
+    if (!got) return false;
+    const int nxt = cur_chunk_ ^ 1;
+    Chunk& n = chunk_[nxt];
+    const size_t tail = end_ - cur_;
+    if (tail) {
+        const uint8_t* src = chunk_[cur_chunk_].data.get() + cur_;
+        if (tail <= n.beg) {
+            memcpy(n.data.get() + n.beg - tail, src, tail);
+            n.beg -= tail;
+        } else {  // a tail longer than the gap (a record of several MiB): make room the slow way
+            std::unique_ptr<uint8_t[]> nd(new uint8_t[tail + (n.end - n.beg) + kFrontGap]);
+            memcpy(nd.get() + kFrontGap, src, tail);
+            memcpy(nd.get() + kFrontGap + tail, n.data.get() + n.beg, n.end - n.beg);
+            n.cap = tail + (n.end - n.beg) + kFrontGap;
+            n.end = kFrontGap + tail + (n.end - n.beg);
+            n.beg = kFrontGap;
+            n.data = std::move(nd);
+        }
+    }
+    const int prev = cur_chunk_;
+    cur_chunk_ = nxt;
+    cur_ = n.beg;
+    end_ = n.end;
+    next_ready_ = std::async(std::launch::async, [this, prev] { return fill(chunk_[prev]); });
     return true;
 }
 
 bool BamReader::ensure(size_t need) {
-    while (buf_.size() - cur_ < need)
-        if (!fill()) return buf_.size() - cur_ >= need;
+    while (end_ - cur_ < need)
+        if (!advance()) return end_ - cur_ >= need;
     return true;
 }
 
 bool BamReader::next(BamRecord& r) {
     if (!ensure(4)) return false;
-    const uint32_t bs = le32(buf_.data() + cur_);
+    const uint32_t bs = le32(at());
     if (!ensure((size_t)4 + bs)) throw std::runtime_error("truncated BAM record in " + path_);
-    const uint8_t* p = buf_.data() + cur_ + 4;
-    const uint8_t* end = p + bs;
+    {   // The batch was just written by the inflate threads on other cores: every record starts on cold lines, and the next
+        // record's address is only known from this one's size.  Neighbouring records have similar sizes, so the lines
+        // where the next few records should start are requested now (a wrong guess costs nothing).
+        const uint8_t* p = at();
+        const size_t step = (size_t)4 + bs;
+        if (cur_ + 5 * step + 128 < end_) {
+            __builtin_prefetch(p + step); __builtin_prefetch(p + step + 64);
+            __builtin_prefetch(p + 2 * step); __builtin_prefetch(p + 2 * step + 64);
+            __builtin_prefetch(p + 3 * step); __builtin_prefetch(p + 4 * step);
+        }
+    }
+    parse_record(at(), r);
     cur_ += 4 + bs;
+    return true;
+}
+
+void BamReader::parse_record(const uint8_t* rec, BamRecord& r) {
+    const uint32_t bs = le32(rec);
+    const uint8_t* p = rec + 4;
+    const uint8_t* end = p + bs;
     r.tid = (int32_t)le32(p);
     r.pos = (int32_t)le32(p + 4);
     const uint32_t l_read_name = p[8];
@@ -236,7 +305,6 @@ bool BamReader::next(BamRecord& r) {
         if (t0 == 'A' && t1 == 'M' && !have_am) { r.bdqual = (uint8_t)(is_int ? ival : 0); have_am = true; }  // bam_aux2i: 0 for non-integer types
         q += sz;
     }
-    return true;
 }
 
 }  // namespace bdhost

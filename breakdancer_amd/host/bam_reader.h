@@ -4,6 +4,8 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <future>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -36,18 +38,32 @@ public:
     int tid_of(const std::string& name) const;  // -1 if absent
     // next record of the file (no filtering); false at end of file
     bool next(BamRecord& r);
+    // decode the record whose block_size word is at p (thread-safe: touches nothing but its arguments)
+    static void parse_record(const uint8_t* p, BamRecord& r);
 
 private:
-    bool fill();                       // inflate the next batch of BGZF blocks; false at EOF
+    // decompressed bytes of one batch of BGZF blocks: valid in [beg, end) of a buffer that is allocated once and never
+    // zero-filled; the gap in front takes the unparsed tail of the previous batch (a record can straddle two batches)
+    struct Chunk {
+        std::unique_ptr<uint8_t[]> data;
+        size_t cap = 0, beg = 0, end = 0;
+        void reserve(size_t n);
+    };
+    bool fill(Chunk& c);               // inflate the next batch of BGZF blocks into c; false at EOF (runs on the helper thread)
+    bool advance();                    // make the next batch current, start inflating the one after it; false at EOF
     bool ensure(size_t need);          // make `need` decompressed bytes available at cur_
+    const uint8_t* at() const { return chunk_[cur_chunk_].data.get() + cur_; }
     std::string path_;
     FILE* fp_ = nullptr;
     int threads_;
-    std::vector<uint8_t> comp_;        // compressed bytes not yet consumed
+    std::vector<uint8_t> comp_;        // compressed bytes not yet consumed (helper thread only)
     size_t comp_off_ = 0;
     bool eof_ = false;
-    std::vector<uint8_t> buf_;         // decompressed bytes
-    size_t cur_ = 0;
+    Chunk chunk_[2];                   // one being parsed, one being inflated
+    int cur_chunk_ = 0;
+    size_t cur_ = 0, end_ = 0;         // parse position / end of the valid bytes in the current chunk
+    std::future<bool> next_ready_;     // the helper thread's fill() of the other chunk
+    bool started_ = false;
     std::vector<std::string> targets_;
     std::string header_text_;
 };

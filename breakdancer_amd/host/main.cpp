@@ -52,6 +52,10 @@ int main(int argc, char** argv) {
             return 1;
         }
         const unsigned hw = std::thread::hardware_concurrency();
+        // BGZF inflate threads: zlib manages ~100-150 MB/s per core on read data, the record parse that consumes the
+        // output ~15 M records/s on one core; measured on a 256-thread host, 3 M reads / 408 MB: 8 threads 0.36 s, 16 0.26 s,
+        // 32 0.22 s, 64 0.20 s (then the parse is the limit).  A quarter of the hardware threads, at most 64 (BDX_THREADS overrides)
+        const unsigned io_threads = getenv("BDX_THREADS") ? (unsigned)std::max(1, atoi(getenv("BDX_THREADS"))) : (hw ? std::min(std::max(hw / 4, 4u), 64u) : 4u);
         ReadStream reads;
         const bool timing = getenv("BDX_TIMING") != nullptr;
         auto now = [] { return std::chrono::steady_clock::now(); };
@@ -66,7 +70,7 @@ int main(int argc, char** argv) {
             return bdx_create(&ctx, &opts.o, libs.data(), nlibs, nbams, 0, cfg.max_read_window_size(), opts.device);
         });
         try {
-            produce(cfg, opts.chr, hw ? (int)std::min(hw, 16u) : 4, reads);
+            produce(cfg, opts.chr, (int)io_threads, reads);
         } catch (...) {
             ctx_ready.wait();
             throw;
@@ -148,7 +152,7 @@ int main(int argc, char** argv) {
                 if (svs[i].printed) wanted.insert(wanted.end(), sup_idx.begin() + sup_off[i], sup_idx.begin() + sup_off[i + 1]);
             std::sort(wanted.begin(), wanted.end());
             wanted.erase(std::unique(wanted.begin(), wanted.end()), wanted.end());
-            collect_reads(cfg, opts.chr, hw ? (int)std::min(hw, 16u) : 4, wanted, sup_reads);
+            collect_reads(cfg, opts.chr, (int)io_threads, wanted, sup_reads);
         }
         size_t sv_i = 0;
         for (auto const& s : svs) {  // BreakDancer.cpp:395-497
@@ -216,7 +220,7 @@ int main(int argc, char** argv) {
             bdx_get_timings(ctx, ms, 8);
             fprintf(stderr, "[bdx timing] reads=%zu decode+merge=%.3fs (BGZF inflate on %u threads, single pass) gpu_init=%.3fs h2d_push=%.3fs "
                             "bdx_run=%.4fs (classify %.3f ms) format=%.3fs total=%.3fs\n",
-                    reads.size(), secs(t_start, t_decoded), hw ? std::min(hw, 16u) : 4u, secs(t_decoded, t_created), secs(t_created, t_pushed),
+                    reads.size(), secs(t_start, t_decoded), io_threads, secs(t_decoded, t_created), secs(t_created, t_pushed),
                     secs(t_pushed, t_ran), ms[0], secs(t_ran, now()), secs(t_start, now()));
         }
         bdx_destroy(ctx);
