@@ -617,12 +617,15 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool f
             HIPCHK(c, c->h_counts0.ensure(sizeof(StageCounts)));
             memset(c->h_counts0.p, 0, sizeof(StageCounts));
             k3.counts_host = c->h_counts0.as<StageCounts>();
-            k3.flag_host = c->h_flags.as<uint32_t>() + 3; k3.flag_value = c->seq;
         }
         K3Tail tail{has_next, next_qlen, next_nn};
         // single-context runs that take the direct join let that kernel do k3_region_of_kernel's work
         c->region_of_fused = for_k6 && !c->bucketed_join && na <= kDirectJoinMax;
         launch_k3(k3, cp, c->b_p1.as<Pass1>(), na, c->opts.min_len, c->opts.seq_coverage_lim, nkeys, nn_base, tail, !c->region_of_fused, s);
+        // Ready-word for the region table in pinned memory.  It has to come from a stream command: a word stored by a
+        // *kernel* after the kernel boundary can overtake the table's own writes (other dies, megabytes still in flight;
+        // seen at 166 k regions), a stream write is performed only after the earlier commands have completed.
+        if (for_k6 && c->poll) HIPCHK(c, hipStreamWriteValue32(s, c->h_flags.as<uint32_t>() + 3, c->seq, 0));
     }
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[4], s));
     c->stage = 3;
@@ -766,7 +769,6 @@ int do_k6(bdx_ctx* c, bool force_host) {
     a.lib_mean = c->b_lib_mean.as<float>();
     a.counts_host = c->h_counts.as<StageCounts>();
     a.counts_host2 = c->h_counts2.as<StageCounts>();
-    a.flag_groups = c->h_flags.as<uint32_t>() + 1; a.flag_done = c->h_flags.as<uint32_t>() + 2; a.flag_value = c->seq;
     memset(c->h_counts.p, 0, sizeof(StageCounts));
     memset(c->h_counts2.p, 0, sizeof(StageCounts));
     a.p1 = c->b_p1.as<Pass1>();
@@ -778,6 +780,7 @@ int do_k6(bdx_ctx* c, bool force_host) {
         a.label_rounds = rounds;
     }
     launch_k6_groups(a, na, s);
+    if (c->poll) HIPCHK(c, hipStreamWriteValue32(s, c->h_flags.as<uint32_t>() + 1, c->seq, 0));  // the host's share of the groups is complete
     if (!c->poll) HIPCHK(c, hipEventRecord(c->ev_groups, s));  // (the host normally polls the word k6_mirror_kernel sets)
     launch_k6_walk(a, na, s);
     return BDX_OK;
@@ -829,6 +832,7 @@ int do_k6_table(bdx_ctx* c) {
     launch_k6_compact(a, na, s);
     launch_k5_dev(a.t_lambda, a.t_k, c->h_ltail_dev.as<double>(), a.ltail, &a.counts->n_terms_dev, a.term_cap, s);
     launch_k6_score(a, std::log(10), c->opts.score_threshold, c->opts.fisher ? 0 : 1, s);
+    if (c->poll) HIPCHK(c, hipStreamWriteValue32(s, c->h_flags.as<uint32_t>() + 2, c->seq, 0));  // the final table is complete
     return BDX_OK;
 }
 
@@ -997,7 +1001,6 @@ int bdx_run(bdx_ctx* c) {
         if (c->region_of_fused) {
             en.cand = c->k3.cand; en.c_rid = c->k3.c_rid; en.region_out = c->k3.region_of;
             en.k6_scratch = c->k3.out_deg; en.scratch_cap = c->k3.cap;
-            en.flag_host = c->h_flags.as<uint32_t>() + 3; en.flag_value = c->seq;
         }
         r = do_join_local(c, c->na_alloc, en, &c->b_p1.as<Pass1>()->n_anom, true);
         if (r != BDX_OK) return r;

@@ -683,9 +683,9 @@ __global__ __launch_bounds__(256) void k6_score_kernel(K6Arrays a, double ln10, 
     __shared__ uint32_t s_rec[kScoreSvs * kSvWords];
     __shared__ uint32_t s_printed;
     const uint32_t n = a.counts->n_sv_dev, nt = a.counts->n_terms_dev, nc = a.counts->n_cn_dev;
-    const uint32_t base = blockIdx.x * kScoreSvs;
     if (threadIdx.x == 0) s_printed = 0;
-    if (base < n) {
+    for (uint32_t base = blockIdx.x * kScoreSvs; base < n; base += gridDim.x * kScoreSvs) {  // (the grid is capped: stride over the table)
+        __syncthreads();
         const uint32_t cnt = min((uint32_t)kScoreSvs, n - base);
         for (uint32_t i = threadIdx.x; i < cnt * kSvWords; i += 256) {  // gather the records from the staging slots / the host's list
             const uint32_t sv = i / kSvWords, w = i - sv * kSvWords;
@@ -724,8 +724,9 @@ __global__ __launch_bounds__(256) void k6_score_kernel(K6Arrays a, double ln10, 
         __syncthreads();
         uint32_t* dst = (uint32_t*)(a.sv_out + base);
         for (uint32_t i = threadIdx.x; i < cnt * kSvWords; i += 256) dst[i] = s_rec[i];
-        if (threadIdx.x == 0 && s_printed) atomicAdd(&a.counts->n_printed, s_printed);
     }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_printed) atomicAdd(&a.counts->n_printed, s_printed);
     const uint32_t gsz = gridDim.x * 256;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nt; i += gsz) { a.lib_index[i] = a.d_lib_index[i]; a.lib_pairs[i] = a.t_k[i]; }
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nc; i += gsz) { a.cn_key[i] = a.d_cn_key[i]; a.cn_value[i] = a.d_cn_value[i]; }

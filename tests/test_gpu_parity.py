@@ -280,3 +280,19 @@ def test_small_component_graphs(seed):
     bh = product_from_oracle(run, host_walk=True)
     compare(run, bh)
     bh.close()
+
+
+def test_sv_table_larger_than_one_pass_of_the_score_kernel():
+    """several hundred thousand SV candidates (tiny clusters of two pairs): the kernels that are launched with a capped
+    grid have to stride over the whole table (the score kernel once wrote only its first 131072 records)"""
+    cfg, st = _synth_case(32_000_000, seed=31, discordant=0.25, cluster=2)
+    run = OracleRun(cfg, make_opts())
+    run.set_targets(["chrS"])
+    st = dict(st)
+    st["lib"] = np.zeros(len(st["tid"]), np.int32)
+    run.set_stream(0, st)
+    run.run()
+    assert run.n_svs > 150_000, run.n_svs  # well beyond 131072
+    bd = product_from_oracle(run)
+    compare(run, bd)
+    bd.close()
