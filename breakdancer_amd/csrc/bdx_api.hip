@@ -610,6 +610,9 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool f
             HIPCHK(c, c->b_r_pk.ensure(cap * 2 * nkeys * 4));
             HIPCHK(c, c->b_out_deg.ensure(cap * 6 * 4));
             k3.r_rec_dev = c->b_r_rec.as<RegionRec>(); k3.r_pk_dev = c->b_r_pk.as<uint32_t>(); k3.out_deg = c->b_out_deg.as<uint32_t>();
+            // with the direct join right behind K3, that kernel forwards the table to the host
+            static const bool no_forward = getenv("BDX_NO_FORWARD") != nullptr;
+            k3.host_copy_later = (!no_forward && !c->bucketed_join && na <= kDirectJoinMax) ? 1 : 0;
         }
         k3.ws_u4 = c->b_ws_u4.as<U4>(); k3.head_total = (U4*)c->b_totals.p; k3.ws_u32 = c->b_ws_u32.as<uint32_t>();
         k3.acc_total = (uint32_t*)((char*)c->b_totals.p + 32); k3.counts = c->b_counts.as<StageCounts>();
@@ -625,7 +628,7 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool f
         // Ready-word for the region table in pinned memory.  It has to come from a stream command: a word stored by a
         // *kernel* after the kernel boundary can overtake the table's own writes (other dies, megabytes still in flight;
         // seen at 166 k regions), a stream write is performed only after the earlier commands have completed.
-        if (for_k6 && c->poll) HIPCHK(c, hipStreamWriteValue32(s, c->h_flags.as<uint32_t>() + 3, c->seq, 0));
+        if (for_k6 && c->poll && !k3.host_copy_later) HIPCHK(c, hipStreamWriteValue32(s, c->h_flags.as<uint32_t>() + 3, c->seq, 0));
     }
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[4], s));
     c->stage = 3;
@@ -995,15 +998,23 @@ int bdx_run(bdx_ctx* c) {
         if (r != BDX_OK) return r;
         if (!c->na_alloc) return BDX_OK;
         // the region table is final after K3: the host takes its copy while the device joins the mates
-        if (!c->poll) HIPCHK(c, hipEventRecord(c->ev_regions, s));  // (normally: the word the join kernel sets)
+        if (!c->poll && !c->k3.host_copy_later) HIPCHK(c, hipEventRecord(c->ev_regions, s));  // (normally: a polled ready-word)
         Entries en{};
         en.key = c->cp.key; en.region = c->k3.region_of; en.meta = c->cp.meta; en.isize = c->cp.isize;
         if (c->region_of_fused) {
             en.cand = c->k3.cand; en.c_rid = c->k3.c_rid; en.region_out = c->k3.region_of;
             en.k6_scratch = c->k3.out_deg; en.scratch_cap = c->k3.cap;
+            if (c->k3.host_copy_later) {
+                en.r_rec_dev = c->k3.r_rec_dev; en.r_pk_dev = c->k3.r_pk_dev; en.r_rec_host = c->k3.r_rec; en.r_pk_host = c->k3.r_pk;
+                en.counts = c->b_counts.as<StageCounts>(); en.nkeys2 = 2 * c->nkeys;
+            }
         }
         r = do_join_local(c, c->na_alloc, en, &c->b_p1.as<Pass1>()->n_anom, true);
         if (r != BDX_OK) return r;
+        if (c->k3.host_copy_later) {  // the join kernel has forwarded the region table to pinned memory
+            if (c->poll) HIPCHK(c, hipStreamWriteValue32(s, c->h_flags.as<uint32_t>() + 3, c->seq, 0));
+            else HIPCHK(c, hipEventRecord(c->ev_regions, s));
+        }
         return do_k6(c, force_host);
     };
     // enqueue-ahead when this context has just run an input of the same size

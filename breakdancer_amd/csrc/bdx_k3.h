@@ -54,6 +54,7 @@ struct K3Arrays {
     uint32_t* r_pk;  // [cap][2*nkeys]: proper-read prefix counts at the region's first read (nkeys), then last read (nkeys)
     RegionRec* r_rec_dev;  // device-resident copies for K6 (r_rec / r_pk live in pinned host memory); may be null
     uint32_t* r_pk_dev;
+    int host_copy_later;   // 1: write only the device copies here; the join kernel forwards them to r_rec / r_pk
     uint32_t* out_deg;     // K6 per-region scratch reset by k3_region_of_kernel: [6][cap] = out_deg, label (= index),
                            // bad_v, bad, mcount, pcount; may be null
     // scan workspace and totals
@@ -124,6 +125,14 @@ struct Entries {
     const int32_t* cand;
     const int32_t* c_rid;
     int32_t* region_out;
+    // ... and copies the region table from HBM into pinned host memory (K3 then writes the HBM copy only: the PCIe writes
+    // overlap this latency-bound kernel instead of stretching the scan's last pass)
+    const RegionRec* r_rec_dev;
+    const uint32_t* r_pk_dev;
+    RegionRec* r_rec_host;
+    uint32_t* r_pk_host;
+    const StageCounts* counts;
+    int nkeys2;              // 2 x nkeys words of proper-read samples per region
     uint32_t* k6_scratch;    // [6][scratch_cap]
     uint32_t scratch_cap;
     uint32_t* flag_host;     // pinned word: the region table (written by the kernel before) is complete

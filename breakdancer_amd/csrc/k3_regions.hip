@@ -115,12 +115,15 @@ struct AcceptOut {
         rr.n = st.n; rr.rev = st.rev; rr.nonctx = st.nonctx; rr.nnormal = st.nnormal;
         rr.maxq = st.maxq;
         rr.first = f;
-        a.r_rec[r] = rr;
+        const bool to_host = !a.host_copy_later;
+        if (to_host) a.r_rec[r] = rr;
         if (a.r_rec_dev) a.r_rec_dev[r] = rr;
         for (int k = 0; k < nkeys; ++k) {
             const uint32_t pf = cp.pk[(size_t)k * cp.cap + f], pl = cp.pk[(size_t)k * cp.cap + l];
-            a.r_pk[(size_t)r * 2 * nkeys + k] = pf;
-            a.r_pk[(size_t)r * 2 * nkeys + nkeys + k] = pl;
+            if (to_host) {
+                a.r_pk[(size_t)r * 2 * nkeys + k] = pf;
+                a.r_pk[(size_t)r * 2 * nkeys + nkeys + k] = pl;
+            }
             if (a.r_pk_dev) { a.r_pk_dev[(size_t)r * 2 * nkeys + k] = pf; a.r_pk_dev[(size_t)r * 2 * nkeys + nkeys + k] = pl; }
         }
     }

@@ -167,6 +167,15 @@ __global__ __launch_bounds__(256) void k4_direct_join_kernel(K4Arrays k4, Entrie
         __threadfence_system();
         *(volatile uint32_t*)en.flag_host = en.flag_value;
     }
+    if (en.r_rec_host) {  // forward the region table to the host (grid-stride over its words; the grid covers na >= regions)
+        const uint32_t nr = en.counts->n_regions;
+        const uint32_t gsz = gridDim.x * 256;
+        const uint32_t* src = (const uint32_t*)en.r_rec_dev;
+        uint32_t* dst = (uint32_t*)en.r_rec_host;
+        constexpr uint32_t kw = sizeof(RegionRec) / 4;
+        for (uint32_t i = j; i < nr * kw; i += gsz) dst[i] = src[i];
+        for (uint32_t i = j; i < nr * (uint32_t)en.nkeys2; i += gsz) en.r_pk_host[i] = en.r_pk_dev[i];
+    }
     if (j >= na) return;
     int rj;
     if (en.c_rid) {
