@@ -375,6 +375,23 @@ bool wait_flag(const bdx_ctx* c, int idx, uint32_t value) {
     }
 }
 
+// Tell the host that everything enqueued so far has completed: a stream write-value into a polled pinned word, or (polling
+// off / the stream operation unavailable) an event.  The word must come from a stream command rather than from the last
+// kernel itself: a store made by a kernel after a kernel boundary is not ordered by the memory model behind the previous
+// kernels' stores to host memory issued from other compute dies.
+int signal_ready(bdx_ctx* c, int idx, hipEvent_t ev) {
+    if (c->poll) {
+        if (hipStreamWriteValue32(c->stream, c->h_flags.as<uint32_t>() + idx, c->seq, 0) == hipSuccess) return BDX_OK;
+        (void)hipGetLastError();
+        c->poll = false;  // not supported here: blocking waits from now on
+    }
+    if (ev) {
+        hipError_t e = hipEventRecord(ev, c->stream);
+        if (e != hipSuccess) return hipfail(c, e, "hipEventRecord");
+    }
+    return BDX_OK;
+}
+
 float ms_between(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<float, std::milli>(b - a).count();
 }
@@ -625,10 +642,10 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool f
         // single-context runs that take the direct join let that kernel do k3_region_of_kernel's work
         c->region_of_fused = for_k6 && !c->bucketed_join && na <= kDirectJoinMax;
         launch_k3(k3, cp, c->b_p1.as<Pass1>(), na, c->opts.min_len, c->opts.seq_coverage_lim, nkeys, nn_base, tail, !c->region_of_fused, s);
-        // Ready-word for the region table in pinned memory.  It has to come from a stream command: a word stored by a
-        // *kernel* after the kernel boundary can overtake the table's own writes (other dies, megabytes still in flight;
-        // seen at 166 k regions), a stream write is performed only after the earlier commands have completed.
-        if (for_k6 && c->poll && !k3.host_copy_later) HIPCHK(c, hipStreamWriteValue32(s, c->h_flags.as<uint32_t>() + 3, c->seq, 0));
+        if (for_k6 && !k3.host_copy_later) {  // the region table is in pinned memory
+            const int rc = signal_ready(c, 3, c->ev_regions);
+            if (rc != BDX_OK) return rc;
+        }
     }
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[4], s));
     c->stage = 3;
@@ -783,8 +800,10 @@ int do_k6(bdx_ctx* c, bool force_host) {
         a.label_rounds = rounds;
     }
     launch_k6_groups(a, na, s);
-    if (c->poll) HIPCHK(c, hipStreamWriteValue32(s, c->h_flags.as<uint32_t>() + 1, c->seq, 0));  // the host's share of the groups is complete
-    if (!c->poll) HIPCHK(c, hipEventRecord(c->ev_groups, s));  // (the host normally polls the word k6_mirror_kernel sets)
+    {   // the host's share of the groups is complete
+        const int rc = signal_ready(c, 1, c->ev_groups);
+        if (rc != BDX_OK) return rc;
+    }
     launch_k6_walk(a, na, s);
     return BDX_OK;
 }
@@ -835,7 +854,10 @@ int do_k6_table(bdx_ctx* c) {
     launch_k6_compact(a, na, s);
     launch_k5_dev(a.t_lambda, a.t_k, c->h_ltail_dev.as<double>(), a.ltail, &a.counts->n_terms_dev, a.term_cap, s);
     launch_k6_score(a, std::log(10), c->opts.score_threshold, c->opts.fisher ? 0 : 1, s);
-    if (c->poll) HIPCHK(c, hipStreamWriteValue32(s, c->h_flags.as<uint32_t>() + 2, c->seq, 0));  // the final table is complete
+    {   // the final table is complete (without polling: finish_table waits for the stream)
+        const int rc = signal_ready(c, 2, nullptr);
+        if (rc != BDX_OK) return rc;
+    }
     return BDX_OK;
 }
 
@@ -998,7 +1020,6 @@ int bdx_run(bdx_ctx* c) {
         if (r != BDX_OK) return r;
         if (!c->na_alloc) return BDX_OK;
         // the region table is final after K3: the host takes its copy while the device joins the mates
-        if (!c->poll && !c->k3.host_copy_later) HIPCHK(c, hipEventRecord(c->ev_regions, s));  // (normally: a polled ready-word)
         Entries en{};
         en.key = c->cp.key; en.region = c->k3.region_of; en.meta = c->cp.meta; en.isize = c->cp.isize;
         if (c->region_of_fused) {
@@ -1012,8 +1033,8 @@ int bdx_run(bdx_ctx* c) {
         r = do_join_local(c, c->na_alloc, en, &c->b_p1.as<Pass1>()->n_anom, true);
         if (r != BDX_OK) return r;
         if (c->k3.host_copy_later) {  // the join kernel has forwarded the region table to pinned memory
-            if (c->poll) HIPCHK(c, hipStreamWriteValue32(s, c->h_flags.as<uint32_t>() + 3, c->seq, 0));
-            else HIPCHK(c, hipEventRecord(c->ev_regions, s));
+            r = signal_ready(c, 3, c->ev_regions);
+            if (r != BDX_OK) return r;
         }
         return do_k6(c, force_host);
     };
