@@ -90,7 +90,7 @@ struct bdx_ctx {
     DevBuf b_r_rec, b_r_pk, b_out_deg, b_parts, b_kdens, b_rs, b_slot, b_members, b_own, b_lib_stage, b_cn_stage,
         b_t_lambda, b_t_k, b_ws6;
     PinBuf h_p1, h_cnt, h_counts, h_regs, h_pk, h_groups, h_terms;
-    DevBuf b_sv_src, b_dlists, b_ltail;
+    DevBuf b_sv_src, b_dlists, b_ltail, b_pair_lo;
     PinBuf h_hs_rec, h_hs_aux, h_hs_lists;
     PinBuf h_flags;                   // [0] pass 1 ready, [1] host's groups ready, [2] final table ready (= run sequence number)
     uint32_t seq = 0;
@@ -286,7 +286,7 @@ void bdx_destroy(bdx_ctx* c) {
                       &c->b_pre_nonctx, &c->b_c_first, &c->b_c_maxq, &c->b_c_rid, &c->b_region_of, &c->b_ws_u4, &c->b_ws_u32, &c->b_totals,
                       &c->b_counts, &c->b_bcnt, &c->b_boff, &c->b_bcur, &c->b_e_key, &c->b_e_idx, &c->b_partner, &c->b_t_key,
                       &c->b_t_idx, &c->b_x_key, &c->b_x_order, &c->b_x_region,
-                      &c->b_x_meta, &c->b_x_isize, &c->b_x_n, &c->b_fold, &c->b_lib_mean, &c->b_sv_src, &c->b_dlists, &c->b_ltail, &c->b_r_rec, &c->b_r_pk, &c->b_out_deg,
+                      &c->b_x_meta, &c->b_x_isize, &c->b_x_n, &c->b_fold, &c->b_lib_mean, &c->b_pair_lo, &c->b_sv_src, &c->b_dlists, &c->b_ltail, &c->b_r_rec, &c->b_r_pk, &c->b_out_deg,
                       &c->b_parts, &c->b_kdens, &c->b_rs, &c->b_slot, &c->b_members, &c->b_own, &c->b_lib_stage,
                       &c->b_cn_stage, &c->b_t_lambda, &c->b_t_k, &c->b_ws6};
     for (DevBuf* b : bufs) b->release();
@@ -584,6 +584,8 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepa
             HIPCHK(c, c->b_t_key.ensure((size_t)slots * 8)); HIPCHK(c, c->b_partner.ensure((size_t)na * 4));
             k2.fill_ptr[1] = c->b_t_key.as<uint32_t>(); k2.fill_words[1] = 2 * slots; k2.fill_value[1] = 0xFFFFFFFFu;
             k2.fill_ptr[2] = c->b_partner.as<uint32_t>(); k2.fill_words[2] = na; k2.fill_value[2] = 0xFFFFFFFFu;
+            HIPCHK(c, c->b_pair_lo.ensure((size_t)na * 4));
+            k2.fill_ptr[3] = c->b_pair_lo.as<uint32_t>(); k2.fill_words[3] = na; k2.fill_value[3] = 0xFFFFFFFFu;
             c->join_table_clean = slots;
         }
         launch_k2(k2, k2_lds_bytes(nkeys), s);
@@ -669,6 +671,7 @@ int do_join_local(bdx_ctx* c, uint32_t n, const Entries& en, const uint32_t* n_p
             HIPCHK(c, hipMemsetAsync(c->b_t_key.p, 0xFF, (size_t)slots * 8, s));
             HIPCHK(c, hipMemsetAsync(c->b_partner.p, 0xFF, (size_t)n * 4, s));
         }
+        k4.pair_lo = (c->join_table_clean == slots && en.c_rid) ? c->b_pair_lo.as<int32_t>() : nullptr;  // preset to -1 by K2
         c->join_table_clean = 0;
         k4.direct = 1; k4.t_mask = slots - 1;
         k4.t_key = c->b_t_key.as<uint64_t>(); k4.t_idx = c->b_t_idx.as<int32_t>();
@@ -768,7 +771,7 @@ int do_k6(bdx_ctx* c, bool force_host) {
     a.d_lib_index = c->b_dlists.as<int32_t>(); a.d_cn_key = a.d_lib_index + a.term_cap; a.d_cn_value = (float*)(a.d_cn_key + a.cn_cap);
     a.cap = na;
     a.r_rec = c->b_r_rec.as<RegionRec>(); a.r_pk = c->b_r_pk.as<uint32_t>();
-    a.region_of = c->k3.region_of; a.partner = c->k4.partner; a.meta = c->cp.meta; a.isize = c->cp.isize;
+    a.region_of = c->k3.region_of; a.partner = c->k4.partner; a.pair_lo = c->k4.pair_lo; a.meta = c->cp.meta; a.isize = c->cp.isize;
     a.parts = c->b_parts.as<PartRec>();
     a.rs = c->b_rs.as<RegSum>();
     a.out_deg = c->b_out_deg.as<uint32_t>(); a.label = a.out_deg + cap; a.bad_v = a.out_deg + 2 * cap; a.bad = a.out_deg + 3 * cap;

@@ -118,9 +118,9 @@ struct K2Params {
     uint32_t nn_base;      // normal read pairs / proper reads of earlier shards (0 for a single context)
     uint32_t pk_base[60];
     // initialisation of later stages' scratch folded into this launch (its grid is large and mostly idle)
-    uint32_t* fill_ptr[3];
-    uint32_t fill_words[3];
-    uint32_t fill_value[3];
+    uint32_t* fill_ptr[4];
+    uint32_t fill_words[4];
+    uint32_t fill_value[4];
 };
 
 __device__ __forceinline__ uint32_t meta_pack(int flag, int rev, int lib, int qlen) {

@@ -98,6 +98,8 @@ struct K4Arrays {
     uint64_t* e_key;     // [cap] bucketed entries
     uint32_t* e_idx;     // [cap]
     int32_t* partner;    // [cap] compact index of the mate, -1 if none
+    int32_t* pair_lo;    // [cap] direct join of a single-context run: at the second-observed mate of a pair, the region of the
+                         // first-observed one (else -1, preset); saves K6 a dependent load per read.  May be null
     uint64_t* t_key;     // [2*cap] global fallback table of the bucketed path; [t_mask + 1] table of the direct path
     int32_t* t_idx;
     uint32_t direct;     // 1: one open-addressing table for all entries (it stays in L2 / Infinity Cache), no partitioning
@@ -210,6 +212,7 @@ struct K6Arrays {
     const uint32_t* r_pk;
     const int32_t* region_of;
     const int32_t* partner;
+    const int32_t* pair_lo;        // see K4Arrays::pair_lo; null: derive it from partner and region_of
     const uint32_t* meta;
     const int32_t* isize;
     PartRec* parts;                // [cap] sorted parts of region r at [first_r, ...)

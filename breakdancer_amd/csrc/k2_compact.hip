@@ -25,7 +25,7 @@ __global__ __launch_bounds__(kBlock) void k2_compact_kernel(const K2Params p) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t nwaves = gridDim.x * kWaves;
 #pragma unroll
-    for (int f = 0; f < 3; ++f)
+    for (int f = 0; f < 4; ++f)
         for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < p.fill_words[f]; i += gridDim.x * kBlock) p.fill_ptr[f][i] = p.fill_value[f];
     for (uint32_t tile = blockIdx.x * kWaves + w; tile < p.ntiles; tile += nwaves) {
         const uint64_t base = (uint64_t)tile * kTile + (uint64_t)lane * 4;

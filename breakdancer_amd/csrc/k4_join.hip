@@ -204,6 +204,10 @@ __global__ __launch_bounds__(256) void k4_direct_join_kernel(K4Arrays k4, Entrie
             if (en.key[o] == key) {
                 k4.partner[j] = (int32_t)o;
                 if (atomicExch(&k4.partner[o], (int32_t)j) != -1) counts->overflow = 2;  // a third read with this name
+                if (k4.pair_lo && en.c_rid) {  // the later read in stream order is the second-observed mate
+                    if (o < j) k4.pair_lo[j] = en.c_rid[en.cand[o]];
+                    else k4.pair_lo[o] = rj;
+                }
                 return;
             }
         }

@@ -81,9 +81,15 @@ __global__ __launch_bounds__(256) void k6_pairs_kernel(K6Arrays a) {
             bool has = false;
             if (i < n) {
                 const uint32_t j = first + i;
-                const int32_t p = a.partner[j];
-                if (p >= 0 && (uint32_t)p < j) {  // j is the second-observed mate (SvBuilder.cpp:101-118)
-                    lo = (uint32_t)a.region_of[p];
+                int32_t plo;  // region of the first-observed mate if j is the second-observed one (SvBuilder.cpp:101-118), else -1
+                if (a.pair_lo) {
+                    plo = a.pair_lo[j];
+                } else {
+                    const int32_t p = a.partner[j];
+                    plo = (p >= 0 && (uint32_t)p < j) ? a.region_of[p] : -1;
+                }
+                if (plo >= 0) {
+                    lo = (uint32_t)plo;
                     const uint32_t m = a.meta[j];
                     key = ((uint64_t)lo << 12) | ((uint64_t)meta_lib(m) << 4) | (uint64_t)meta_flag(m);
                     is = (uint32_t)a.isize[j];
