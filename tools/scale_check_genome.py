@@ -17,7 +17,11 @@ t0 = time.time()
 d = make_genome(lengths, coverage=30.0, seed=77, libs=libs, lib_bam=(0, 0, 1, 1), n_translocations=int(4000 * scale))
 print("generated", len(d["tid"]), "reads in %.1fs" % (time.time() - t0), flush=True)
 cfg = "".join(cfg_line("rg%d" % i, "a.bam" if i < 2 else "b.bam", "lib%d" % i, m, s) for i, (m, s) in enumerate(libs))
-for kw in (dict(), dict(cn_lib=1, print_af=1), dict(transchr_rearrange=1)):
+SETS = (dict(), dict(cn_lib=1, print_af=1), dict(transchr_rearrange=1))
+if len(sys.argv) > 2 and sys.argv[2] == "more":
+    SETS = (dict(buffer_size=1), dict(buffer_size=3, min_read_pair=1), dict(min_read_pair=4), dict(chr_tid=1), dict(min_len=50, seq_coverage_lim=5),
+            dict(illumina_long_insert=1), dict(max_sd=700), dict(fisher=1, score_threshold=0), dict(min_map_qual=10))
+for kw in SETS:
     t0 = time.time()
     run = oracle_from_soa(d, cfg, ["a.bam", "b.bam"], make_opts(**kw), ["c1", "c2", "c3", "c4"])
     print(kw, "oracle %.1fs: regions %d svs %d" % (time.time() - t0, run.n_regions, run.n_svs), flush=True)
