@@ -92,6 +92,7 @@ struct bdx_ctx {
     PinBuf h_p1, h_cnt, h_counts, h_regs, h_pk, h_groups, h_terms;
     DevBuf b_sv_src, b_dlists, b_ltail, b_pair_lo;
     PinBuf h_hs_rec, h_hs_aux, h_hs_lists;
+    DevBuf b_ins;
     PinBuf h_flags;                   // [0] pass 1 ready, [1] host's groups ready, [2] final table ready (= run sequence number)
     uint32_t seq = 0;
     uint32_t k1_event_period = 4;     // K1 is bracketed by HIP events on every n-th run (an event pair idles the GPU ~10 us)
@@ -288,7 +289,7 @@ void bdx_destroy(bdx_ctx* c) {
                       &c->b_t_idx, &c->b_x_key, &c->b_x_order, &c->b_x_region,
                       &c->b_x_meta, &c->b_x_isize, &c->b_x_n, &c->b_fold, &c->b_lib_mean, &c->b_pair_lo, &c->b_sv_src, &c->b_dlists, &c->b_ltail, &c->b_r_rec, &c->b_r_pk, &c->b_out_deg,
                       &c->b_parts, &c->b_kdens, &c->b_rs, &c->b_slot, &c->b_members, &c->b_own, &c->b_lib_stage,
-                      &c->b_cn_stage, &c->b_t_lambda, &c->b_t_k, &c->b_ws6};
+                      &c->b_cn_stage, &c->b_t_lambda, &c->b_t_k, &c->b_ws6, &c->b_ins};
     for (DevBuf* b : bufs) b->release();
     PinBuf* pins[] = {&c->h_p1, &c->h_cnt, &c->h_counts, &c->h_regs, &c->h_pk, &c->h_groups, &c->h_terms, &c->h_flags, &c->h_hs_rec, &c->h_hs_aux, &c->h_hs_lists, &c->h_counts0, &c->h_counts2,
                       &c->h_sv_out, &c->h_lib_index, &c->h_lib_pairs, &c->h_cn_key, &c->h_cn_value, &c->h_ltail_dev};
@@ -767,6 +768,15 @@ int do_k6(bdx_ctx* c, bool force_host) {
     HIPCHK(c, c->h_counts2.ensure(sizeof(StageCounts)));
     HIPCHK(c, c->b_sv_src.ensure((size_t)a.sv_cap * 12)); HIPCHK(c, c->b_ltail.ensure((size_t)a.term_cap * 8));
     HIPCHK(c, c->b_dlists.ensure((size_t)a.term_cap * 4 + (size_t)a.cn_cap * 8 + 64));
+    {   // the inserted list (k6_insert_kernel): device order keys padded to a power of two for the sort
+        size_t p2 = 1;
+        while (p2 < a.sv_cap) p2 <<= 1;
+        const size_t svc = a.sv_cap;
+        HIPCHK(c, c->b_ins.ensure(p2 * 12 + svc * 8 + (svc + 1) * 16 + 64));
+        a.old_key = c->b_ins.as<uint64_t>(); a.hs_key_dev = a.old_key + p2;
+        a.old_slot = (uint32_t*)(a.hs_key_dev + svc); a.ins_T = a.old_slot + p2; a.ins_src = a.ins_T + svc + 1;
+        a.ins_pre_l = a.ins_src + svc + 1; a.ins_pre_c = a.ins_pre_l + svc + 1;
+    }
     a.sv_begin = c->b_sv_src.as<uint2>(); a.sv_src = (uint32_t*)(a.sv_begin + a.sv_cap); a.ltail = c->b_ltail.as<double>();
     a.d_lib_index = c->b_dlists.as<int32_t>(); a.d_cn_key = a.d_lib_index + a.term_cap; a.d_cn_value = (float*)(a.d_cn_key + a.cn_cap);
     a.cap = na;
@@ -825,25 +835,22 @@ int do_k6_table(bdx_ctx* c) {
     if (nh) {
         const uint64_t period = (uint64_t)std::max(1, c->opts.buffer_size + 1);
         HIPCHK(c, c->h_hs_rec.ensure((size_t)nh * sizeof(SvOut)));
-        HIPCHK(c, c->h_hs_aux.ensure(((size_t)nh * 3 + 2) * 4));
+        HIPCHK(c, c->h_hs_aux.ensure((size_t)nh * 12 + 16));
         HIPCHK(c, c->h_hs_lists.ensure((size_t)nt * 16 + (size_t)nc * 8 + 16));
         memcpy(c->h_hs_rec.p, H.svs.data(), (size_t)nh * sizeof(HostSv));
-        uint32_t* T = c->h_hs_aux.as<uint32_t>();
-        uint32_t* pre_l = T + nh;
-        uint32_t* pre_c = pre_l + nh + 1;
-        uint32_t sl = 0, sc = 0;
+        uint64_t* hkey = c->h_hs_aux.as<uint64_t>();
+        uint32_t* hcnt = (uint32_t*)(hkey + nh);
         for (uint32_t j = 0; j < nh; ++j) {
-            // a device candidate comes from a traversal started at one of a window's own vertices; this host candidate
-            // precedes those whose start vertex is not below its own start vertex -- or not below the first vertex of
-            // its window when its traversal started from a vertex of an earlier window
+            // order key (see K6Arrays): a traversal started at one of its window's own vertices is placed right before the
+            // device's candidates of that start vertex, one started from an earlier window's vertex before all of its window
             const uint64_t key = H.sv_key[j];
             const bool from_old = !((key >> 32) & 1ull);
-            T[j] = (uint32_t)(from_old ? (key >> 33) * period : (key & 0xffffffffull));
-            if (a.force_host) T[j] = 0;  // no device candidates to interleave with (and the ids may carry the phantom shift)
-            pre_l[j] = sl; pre_c[j] = sc;
-            sl += (uint32_t)H.svs[j].sv.lib_count; sc += (uint32_t)H.svs[j].sv.cn_count;
+            const uint64_t start = key & 0xffffffffull;
+            const uint64_t T = from_old ? (key >> 33) * period : start;
+            hkey[j] = (T << 31) | (from_old ? 0ull : 1ull << 30) | (start << 4);
+            if (a.force_host) hkey[j] = 0;  // no device candidates to interleave with (and the ids may carry the phantom shift)
+            hcnt[j] = (uint32_t)H.svs[j].sv.lib_count | ((uint32_t)H.svs[j].sv.cn_count << 16);
         }
-        pre_l[nh] = sl; pre_c[nh] = sc;
         double* lam = c->h_hs_lists.as<double>();
         int32_t* li = (int32_t*)(lam + nt);
         int32_t* lp = li + nt;
@@ -851,7 +858,7 @@ int do_k6_table(bdx_ctx* c) {
         float* cv = (float*)(ck + nc);
         for (uint32_t i = 0; i < nt; ++i) { lam[i] = H.terms[i].lambda; li[i] = H.lib_index[i]; lp[i] = H.lib_pairs[i]; }
         for (uint32_t i = 0; i < nc; ++i) { ck[i] = H.cn_key[i]; cv[i] = H.cn_value[i]; }
-        a.hs_rec = c->h_hs_rec.as<SvOut>(); a.hs_T = T; a.hs_pre_l = pre_l; a.hs_pre_c = pre_c;
+        a.hs_rec = c->h_hs_rec.as<SvOut>(); a.hs_key = hkey; a.hs_cnt = hcnt;
         a.hs_lambda = lam; a.hs_lib_index = li; a.hs_lib_pairs = lp; a.hs_cn_key = ck; a.hs_cn_value = cv;
     }
     launch_k6_compact(a, na, s);

@@ -24,6 +24,8 @@ struct StageCounts {
     uint32_t stage_lib;
     uint32_t stage_cn;
     uint32_t n_owners;     // K6: device-walked components (entries of K6Arrays::owners)
+    uint32_t n_old;        // K6: device candidates of traversals started from a vertex of an earlier flush window
+    uint32_t n_ins;        // K6: candidates the compaction inserts by order key (the host walk's + n_old)
 };
 
 struct RegionRec {
@@ -254,12 +256,21 @@ struct K6Arrays {
     float* cn_value;               // pinned host
     uint32_t sv_cap, term_cap, cn_cap;
     double* ltail;                 // device [term_cap]: log tails (K5 also writes them to pinned host memory)
-    // SV candidates of the host walk (pinned host memory), interleaved with the device's by the compaction: candidate j
-    // precedes the device's candidates whose start vertex is not below hs_T[j]
+    // Candidates that are placed by their order key instead of by their start vertex: the host walk's (pinned host
+    // memory) and the device's own whose traversal started from a vertex of an earlier flush window.  k6_insert_kernel
+    // merges the two lists by key; entry j of the merged list precedes the candidates of start vertex ins_T[j] and after.
+    // Order key: (T << 31) | (started at a vertex of its own window ? 1 << 30 : 0) | (start vertex << 4) | sequence number,
+    // T = the start vertex, or the first vertex of the flush window for a traversal started from an earlier window's vertex.
     const SvOut* hs_rec;           // [nh] lib_begin / cn_begin index the host lists below
-    const uint32_t* hs_T;          // [nh] ascending
-    const uint32_t* hs_pre_l;      // [nh + 1] entries of the host candidates before j in the (library, pairs) lists ...
-    const uint32_t* hs_pre_c;      // [nh + 1] ... and in the copy-number lists
+    const uint64_t* hs_key;        // [nh] ascending order keys
+    const uint32_t* hs_cnt;        // [nh] lib_count | cn_count << 16
+    uint64_t* old_key;             // device [pow2 >= sv_cap] order keys of the device's list (k6_walk_kernel, any order) ...
+    uint32_t* old_slot;            // ... and their staging slots
+    uint64_t* hs_key_dev;          // device [sv_cap] copy of hs_key
+    uint32_t* ins_T;               // device [sv_cap] merged list: threshold vertex ...
+    uint32_t* ins_src;             // ... staging slot, or 0x80000000 | j for the host walk's candidate j
+    uint32_t* ins_pre_l;           // [sv_cap + 1] entries of the list's candidates before j in the (library, pairs) lists ...
+    uint32_t* ins_pre_c;           // [sv_cap + 1] ... and in the copy-number lists
     const int32_t* hs_lib_index;
     const int32_t* hs_lib_pairs;
     const double* hs_lambda;

@@ -54,7 +54,7 @@ template <class T> __device__ __forceinline__ T block_incl_scan(T v, T* s_ws /*[
     return off + inc;
 }
 
-template <class T, class In, int kIters> __global__ __launch_bounds__(kScanBlock) void scan_phase1(In in, const uint32_t* n_ptr, T* blk) {
+template <class T, class In, int kIters> __device__ __forceinline__ void scan_phase1_body(const In& in, const uint32_t* n_ptr, T* blk) {
     constexpr int kScanChunk = kScanBlock * kIters;
     __shared__ T s_ws[kScanBlock / 64];
     const uint32_t n = *n_ptr;
@@ -69,6 +69,17 @@ template <class T, class In, int kIters> __global__ __launch_bounds__(kScanBlock
     T tot;
     block_incl_scan(acc, s_ws, &tot);
     if (threadIdx.x == 0) blk[blockIdx.x] = tot;
+}
+
+template <class T, class In, int kIters> __global__ __launch_bounds__(kScanBlock) void scan_phase1(In in, const uint32_t* n_ptr, T* blk) {
+    scan_phase1_body<T, In, kIters>(in, n_ptr, blk);
+}
+
+// phase 1 with one extra workgroup (the last) that runs an independent side job of the caller
+template <class T, class In, class Side, int kIters>
+__global__ __launch_bounds__(kScanBlock) void scan_phase1_side(In in, Side side, const uint32_t* n_ptr, T* blk) {
+    if (blockIdx.x == gridDim.x - 1) side();
+    else scan_phase1_body<T, In, kIters>(in, n_ptr, blk);
 }
 
 // single workgroup: in-place exclusive scan of the block sums, grand total -> *total
@@ -127,6 +138,16 @@ template <class T, int kIters = kScanIters, class In, class Out>
 void scan_launch(In in, Out out, const uint32_t* n_ptr, uint32_t n_upper, T* blk_ws, T* total, hipStream_t s) {
     const uint32_t g = scan_grid(n_upper, kIters);
     hipLaunchKernelGGL((scan_phase1<T, In, kIters>), dim3(g), dim3(kScanBlock), 0, s, in, n_ptr, blk_ws);
+    hipLaunchKernelGGL((scan_phase2<T, kIters>), dim3(1), dim3(1024), 0, s, blk_ws, n_ptr, total);
+    hipLaunchKernelGGL((scan_phase3<T, In, Out, kIters>), dim3(g), dim3(kScanBlock), 0, s, in, out, n_ptr, blk_ws);
+}
+
+// the same scan with a side job (a device functor run by one extra workgroup of kScanBlock threads during phase 1; its
+// results are complete before phase 3's output functor runs)
+template <class T, int kIters = kScanIters, class In, class Out, class Side>
+void scan_launch_side(In in, Out out, Side side, const uint32_t* n_ptr, uint32_t n_upper, T* blk_ws, T* total, hipStream_t s) {
+    const uint32_t g = scan_grid(n_upper, kIters);
+    hipLaunchKernelGGL((scan_phase1_side<T, In, Side, kIters>), dim3(g + 1), dim3(kScanBlock), 0, s, in, side, n_ptr, blk_ws);
     hipLaunchKernelGGL((scan_phase2<T, kIters>), dim3(1), dim3(1024), 0, s, blk_ws, n_ptr, total);
     hipLaunchKernelGGL((scan_phase3<T, In, Out, kIters>), dim3(g), dim3(kScanBlock), 0, s, in, out, n_ptr, blk_ws);
 }

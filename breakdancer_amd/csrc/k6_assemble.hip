@@ -217,8 +217,6 @@ __global__ __launch_bounds__(256) void k6_classify_kernel(K6Arrays a) {
             const uint32_t ll = a.label[s->e_lo[e]];
             if (ll != L) { a.bad[L] = 1u; a.bad[ll] = 1u; }
         }
-    const uint32_t period = (uint32_t)a.period;
-    if (r / period != L / period) a.bad[L] = 1u;
     const uint32_t slot = atomicAdd(&a.mcount[L], 1u);
     if (slot < (uint32_t)kK6MaxMembers) {
         MemberInfo mi;
@@ -470,9 +468,6 @@ __global__ __launch_bounds__(256) void k6_walk_kernel(K6Arrays a) {
     for (uint32_t oi = blockIdx.x * 4 + w; oi < n_owners; oi += nwaves) {
         const uint32_t r = a.owners[oi];  // smallest region of a component that is walked here (k6_emit_kernel's list)
         const int k = (int)a.mcount[r];
-        // _max_readlen at this window's flush: the value of the candidate that closes there (BreakDancer.cpp:254-259)
-        const uint32_t rl = (r / period + 1) * period - 1;
-        const int max_readlen = rl < NR ? a.r_rec[rl].maxq : a.counts->last_maxq;
         {   // the component's description: one coalesced fetch
             const uint32_t* src = (const uint32_t*)(a.members + (size_t)r * kK6MaxMembers);
             for (int i = lane; i < k * kMemberWords; i += 64) s_desc[w][i] = src[i];
@@ -533,67 +528,96 @@ __global__ __launch_bounds__(256) void k6_walk_kernel(K6Arrays a) {
             }
         __builtin_amdgcn_wave_barrier();
 
-        uint32_t nsv = 0, nacc_tot = 0, ncn_tot = 0;
-        uint32_t visited = 0, self_done = 0, edge_done = 0, self_alive = 0, edge_alive = 0;
+        uint32_t self_done = 0, edge_done = 0, self_alive = 0, edge_alive = 0;
         for (int i = 0; i < k; ++i)
             if (S[i].cnt) self_alive |= 1u << i;
         for (int e = 0; e < 6; ++e)
             if (E[e].cnt) edge_alive |= 1u << e;
-        int nt = 1, nn = 0;
-        tails[0] = 0;  // the smallest member is the start vertex; the gate-passing groups connect all of them
         const GrpRange none{0, 0};
-        while (nt) {
-            nn = 0;
-            for (int ti = 0; ti < nt; ++ti) {
-                const int tail = tails[ti];
-                if (visited & (1u << tail)) continue;
-                for (int nb = 0; nb < k; ++nb) {  // neighbours in ascending order, the vertex itself at its own place
-                    int A, B;
-                    uint32_t slot;
-                    if (nb == tail) {
-                        if (!S[tail].cnt || (self_done & (1u << tail)) || (int)Sw[tail] < mrp) continue;
-                        self_done |= 1u << tail;
-                        A = tail; B = -1;
-                        slot = Sslot[tail];
-                    } else {
-                        const int x = min(nb, tail), y = max(nb, tail), pi = pair_index(x, y);
-                        if (!E[pi].cnt || (edge_done & (1u << pi)) || (int)Ew[pi] < mrp) continue;
-                        edge_done |= 1u << pi;
-                        A = x; B = y;
-                        slot = Eslot[pi];
+        // One flush (BreakDancer.cpp:266-346) per window that holds members, in ascending order.  A group is part of
+        // the flush of its later region's window; the flush starts traversals first from the members of earlier windows
+        // that have a group in it, then from the window's own members, each in ascending order.
+        for (int f = 0; f < k;) {
+            const uint32_t W = D[ord[f]].r / period;
+            int fe = f + 1;
+            while (fe < k && D[ord[fe]].r / period == W) ++fe;
+            // _max_readlen at this window's flush: the value of the candidate that closes there (BreakDancer.cpp:254-259)
+            const uint32_t rl = (W + 1) * period - 1;
+            const int max_readlen = rl < NR ? a.r_rec[rl].maxq : a.counts->last_maxq;
+            uint32_t visited = 0, nseq = 0;
+            for (int sv = 0; sv < fe; ++sv) {
+                if (visited & (1u << sv)) continue;
+                const bool from_old = sv < f;
+                const uint32_t start = D[ord[sv]].r;
+                uint32_t nsv = 0, nacc_tot = 0, ncn_tot = 0;
+                int nt = 1, nn = 0;
+                tails[0] = sv;
+                while (nt) {
+                    nn = 0;
+                    for (int ti = 0; ti < nt; ++ti) {
+                        const int tail = tails[ti];
+                        if (visited & (1u << tail)) continue;
+                        for (int nb = 0; nb < fe; ++nb) {  // neighbours in ascending order, the vertex itself at its own place
+                            int A, B;
+                            uint32_t slot;
+                            if (nb == tail) {
+                                if (tail < f) continue;  // its self group belonged to an earlier flush
+                                if (!S[tail].cnt || (self_done & (1u << tail)) || (int)Sw[tail] < mrp) continue;
+                                self_done |= 1u << tail;
+                                A = tail; B = -1;
+                                slot = Sslot[tail];
+                            } else {
+                                const int x = min(nb, tail), y = max(nb, tail), pi = pair_index(x, y);
+                                if (y < f) continue;     // a group of an earlier flush
+                                if (!E[pi].cnt || (edge_done & (1u << pi)) || (int)Ew[pi] < mrp) continue;
+                                edge_done |= 1u << pi;
+                                A = x; B = y;
+                                slot = Eslot[pi];
+                            }
+                            if (nn < 12) newtails[nn++] = nb;
+                            const MemberInfo& MA = D[ord[A]];
+                            const MemberInfo& MB = D[ord[B >= 0 ? B : A]];
+                            GrpRange gs[3] = {none, none, none};
+                            if ((self_alive & (1u << A)) && MA.stored) gs[0] = S[A];
+                            if (B >= 0) {
+                                const int pi = pair_index(A, B);
+                                if ((edge_alive & (1u << pi)) && MA.stored && MB.stored) gs[1] = E[pi];
+                                if ((self_alive & (1u << B)) && MB.stored) gs[2] = S[B];
+                            }
+                            // paired reads leave their regions before any gate (BreakDancer.cpp:363-368)
+                            if (gs[0].cnt) self_alive &= ~(1u << A);
+                            if (gs[1].cnt) edge_alive &= ~(1u << pair_index(A, B));
+                            if (gs[2].cnt) self_alive &= ~(1u << B);
+                            const uint32_t* pkA = pk_lds ? &s_pk[w][A * kK6LdsPk + nk] : a.r_pk + (size_t)MA.r * 2 * nk + nk;
+                            const uint32_t* pkB = pk_lds ? &s_pk[w][(B >= 0 ? B : A) * kK6LdsPk] : a.r_pk + (size_t)MB.r * 2 * nk;
+                            uint32_t nacc = 0, ncn = 0;
+                            if (nsv < (uint32_t)kK6MaxSv &&
+                                assemble_sv(a, P, MA.r, B >= 0 ? (int32_t)MB.r : -1, MA.rec, MB.rec, pkA, pkB, gs, max_readlen, slot, start,
+                                            lane == 0, T.flag_counts, &nacc, &ncn)) {
+                                if (from_old) {  // placed by its order key: after the earlier windows, before this window's own
+                                    if (lane == 0) {
+                                        const uint32_t q = atomicAdd(&a.counts->n_old, 1u);
+                                        a.old_key[q] = ((uint64_t)(W * period) << 31) | ((uint64_t)start << 4) | (uint64_t)(nseq & 15u);
+                                        a.old_slot[q] = slot;
+                                    }
+                                    ++nseq;
+                                } else if (lane == 0) {
+                                    a.own_slots[(size_t)start * kK6MaxSv + nsv] = slot;
+                                }
+                                ++nsv;
+                                nacc_tot += nacc;
+                                ncn_tot += ncn;
+                            }
+                        }
+                        visited |= 1u << tail;
                     }
-                    if (nn < 12) newtails[nn++] = nb;
-                    const MemberInfo& MA = D[ord[A]];
-                    const MemberInfo& MB = D[ord[B >= 0 ? B : A]];
-                    GrpRange gs[3] = {none, none, none};
-                    if ((self_alive & (1u << A)) && MA.stored) gs[0] = S[A];
-                    if (B >= 0) {
-                        const int pi = pair_index(A, B);
-                        if ((edge_alive & (1u << pi)) && MA.stored && MB.stored) gs[1] = E[pi];
-                        if ((self_alive & (1u << B)) && MB.stored) gs[2] = S[B];
-                    }
-                    // paired reads leave their regions before any gate (BreakDancer.cpp:363-368)
-                    if (gs[0].cnt) self_alive &= ~(1u << A);
-                    if (gs[1].cnt) edge_alive &= ~(1u << pair_index(A, B));
-                    if (gs[2].cnt) self_alive &= ~(1u << B);
-                    const uint32_t* pkA = pk_lds ? &s_pk[w][A * kK6LdsPk + nk] : a.r_pk + (size_t)MA.r * 2 * nk + nk;
-                    const uint32_t* pkB = pk_lds ? &s_pk[w][(B >= 0 ? B : A) * kK6LdsPk] : a.r_pk + (size_t)MB.r * 2 * nk;
-                    uint32_t nacc = 0, ncn = 0;
-                    if (nsv < (uint32_t)kK6MaxSv &&
-                        assemble_sv(a, P, MA.r, B >= 0 ? (int32_t)MB.r : -1, MA.rec, MB.rec, pkA, pkB, gs, max_readlen, slot, r, lane == 0,
-                                    T.flag_counts, &nacc, &ncn)) {
-                        if (lane == 0) a.own_slots[(size_t)r * kK6MaxSv + nsv] = slot;
-                        ++nsv;
-                        nacc_tot += nacc;
-                        ncn_tot += ncn;
-                    }
+                    nt = nn;
+                    for (int i = 0; i < nn; ++i) tails[i] = newtails[i];
                 }
-                visited |= 1u << tail;
+                if (!from_old && nsv && lane == 0) { a.own_nsv[start] = nsv; a.own_nacc[start] = nacc_tot; a.own_ncn[start] = ncn_tot; }
             }
-            nt = nn;
-            for (int i = 0; i < nn; ++i) tails[i] = newtails[i];
+            f = fe;
         }
-        if (lane == 0) { a.own_nsv[r] = nsv; a.own_nacc[r] = nacc_tot; a.own_ncn[r] = ncn_tot; }
         __builtin_amdgcn_wave_barrier();  // the LDS slices are reused by the wave's next region
     }
 }
@@ -612,10 +636,115 @@ __device__ __forceinline__ uint32_t count_below(const uint32_t* v, uint32_t n, u
     }
     return lo;
 }
+__device__ __forceinline__ uint32_t count_below64(const uint64_t* v, uint32_t n, uint64_t x) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (v[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
 }  // namespace
 
-// Third phase of the scan over the start vertices: the final table.  Vertex i first places the host walk's candidates
-// whose threshold is i, then its own.
+// The candidates that are placed by order key -- the host walk's list (sorted, pinned host memory) and the device's
+// candidates from traversals started at a vertex of an earlier window (k6_walk_kernel's list, any order) -- merged into
+// one list sorted by key, with the running totals of their list entries.  One workgroup (an extra one of the
+// compaction scan's first phase): sort the device's list
+// (bitonic, in LDS when it fits), then every entry finds its place by a binary search in the other list (no key occurs
+// in both: a start vertex belongs to one component, and that is walked either here or by the host).
+constexpr uint32_t kInsLds = 2048;
+
+struct InsertJob {
+    K6Arrays a;
+    __device__ void operator()() const;
+};
+
+__device__ void InsertJob::operator()() const {
+    constexpr uint32_t kThreads = kScanBlock;
+    __shared__ uint64_t s_dk[kInsLds];
+    __shared__ uint32_t s_dv[kInsLds];
+    __shared__ uint64_t s_hk[kInsLds];
+    __shared__ uint32_t s_ws[2][kThreads / 64];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nh = a.nh, nd = a.counts->n_old;
+    const uint32_t n = nh + nd;
+    if (n > a.sv_cap) {  // cannot happen: every candidate consumes at least one read pair
+        if (tid == 0) { a.counts->overflow = 1; a.counts->n_ins = 0; a.ins_pre_l[0] = 0; a.ins_pre_c[0] = 0; }
+        return;
+    }
+    if (tid == 0) a.counts->n_ins = n;
+    if (n == 0) {
+        if (tid == 0) { a.ins_pre_l[0] = 0; a.ins_pre_c[0] = 0; }
+        return;
+    }
+    uint64_t* hk = nh <= kInsLds ? s_hk : a.hs_key_dev;
+    for (uint32_t i = tid; i < nh; i += kThreads) hk[i] = a.hs_key[i];
+    uint32_t m = 1;
+    while (m < nd) m <<= 1;
+    uint64_t* dk;
+    uint32_t* dv;
+    if (m <= kInsLds) {
+        dk = s_dk; dv = s_dv;
+        for (uint32_t i = tid; i < m; i += kThreads) { dk[i] = i < nd ? a.old_key[i] : ~0ull; dv[i] = i < nd ? a.old_slot[i] : 0u; }
+    } else {
+        dk = a.old_key; dv = a.old_slot;
+        for (uint32_t i = nd + tid; i < m; i += kThreads) dk[i] = ~0ull;
+    }
+    __syncthreads();
+    for (uint32_t ksz = 2; ksz <= m; ksz <<= 1)
+        for (uint32_t j = ksz >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < m / 2; t += kThreads) {
+                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                const bool up = (lo & ksz) == 0;
+                const uint64_t x = dk[lo], y = dk[hi];
+                if ((x > y) == up) {
+                    dk[lo] = y; dk[hi] = x;
+                    const uint32_t vx = dv[lo];
+                    dv[lo] = dv[hi]; dv[hi] = vx;
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t j = tid; j < nh; j += kThreads) {
+        const uint64_t key = hk[j];
+        const uint32_t pos = j + count_below64(dk, nd, key), cnt = a.hs_cnt[j];
+        a.ins_T[pos] = (uint32_t)(key >> 31);
+        a.ins_src[pos] = 0x80000000u | j;
+        a.ins_pre_l[pos] = cnt & 0xffffu;
+        a.ins_pre_c[pos] = cnt >> 16;
+    }
+    for (uint32_t d = tid; d < nd; d += kThreads) {
+        const uint64_t key = dk[d];
+        const uint32_t pos = d + count_below64(hk, nh, key), slot = dv[d];
+        a.ins_T[pos] = (uint32_t)(key >> 31);
+        a.ins_src[pos] = slot;
+        a.ins_pre_l[pos] = (uint32_t)a.sv_stage[slot].sv.lib_count;
+        a.ins_pre_c[pos] = (uint32_t)a.sv_stage[slot].sv.cn_count;
+    }
+    __syncthreads();
+    // exclusive running totals, the grand totals at [n]
+    const int lane = tid & 63, w = tid >> 6;
+    uint32_t carry_l = 0, carry_c = 0;
+    for (uint32_t base = 0; base < n; base += kThreads) {
+        const uint32_t i = base + tid;
+        const uint32_t l = i < n ? a.ins_pre_l[i] : 0u, c = i < n ? a.ins_pre_c[i] : 0u;
+        const uint32_t il = wave_incl_scan_t(l), ic = wave_incl_scan_t(c);
+        if (lane == 63) { s_ws[0][w] = il; s_ws[1][w] = ic; }
+        __syncthreads();
+        uint32_t ol = carry_l, oc = carry_c, tl = 0, tc = 0;
+        for (int q = 0; q < (int)kThreads / 64; ++q) {
+            if (q < w) { ol += s_ws[0][q]; oc += s_ws[1][q]; }
+            tl += s_ws[0][q]; tc += s_ws[1][q];
+        }
+        if (i < n) { a.ins_pre_l[i] = ol + il - l; a.ins_pre_c[i] = oc + ic - c; }
+        carry_l += tl; carry_c += tc;
+        __syncthreads();
+    }
+    if (tid == 0) { a.ins_pre_l[n] = carry_l; a.ins_pre_c[n] = carry_c; }
+}
+
+// Third phase of the scan over the start vertices: the final table.  Vertex i first places the candidates of the
+// inserted list whose threshold is i, then those of the traversal that started at i in i's own window.
 struct OwnOut {
     K6Arrays a;
     __device__ void put_entries(uint32_t lb, uint32_t cb, int32_t nl, int32_t ncn, const LibStage* ls, const CnStage* cs) const {
@@ -631,10 +760,15 @@ struct OwnOut {
             a.d_cn_value[cb + t] = cn.value;
         }
     }
+    __device__ void put_staged(uint32_t pos, uint32_t lb, uint32_t cb, uint32_t slot, int32_t nl, int32_t ncn) const {
+        put_entries(lb, cb, nl, ncn, a.lib_stage + (size_t)slot * a.lib_stride, a.cn_stage + (size_t)slot * a.nkeys);
+        a.sv_src[pos] = slot;
+        a.sv_begin[pos] = make_uint2(lb, cb);
+    }
     __device__ void operator()(uint32_t i, uint32_t n, const U4& inc, const U4& e) const {
-        const uint32_t nh = a.nh;
-        const uint32_t hb0 = nh ? count_below(a.hs_T, nh, i) : 0u, hb1 = nh ? count_below(a.hs_T, nh, i + 1) : 0u;
-        const uint32_t h_l = nh ? a.hs_pre_l[nh] : 0u, h_c = nh ? a.hs_pre_c[nh] : 0u;
+        const uint32_t nh = a.counts->n_ins;
+        const uint32_t hb0 = nh ? count_below(a.ins_T, nh, i) : 0u, hb1 = nh ? count_below(a.ins_T, nh, i + 1) : 0u;
+        const uint32_t h_l = a.ins_pre_l[nh], h_c = a.ins_pre_c[nh];
         const uint32_t ex_sv = inc.x - e.x, ex_l = inc.y - e.y, ex_c = inc.z - e.z;
         if (i == n - 1) {
             const uint32_t tsv = inc.x + nh, tl = inc.y + h_l, tc = inc.z + h_c;
@@ -647,29 +781,33 @@ struct OwnOut {
         }
         if (hb1 == hb0 && !e.x) return;
         if (inc.x + nh > a.sv_cap || inc.y + h_l > a.term_cap || inc.z + h_c > a.cn_cap) return;  // reported by the last vertex
-        for (uint32_t j = hb0; j < hb1; ++j) {  // the host walk's candidates that come right before this vertex's
-            SvOut o = a.hs_rec[j];
-            const uint32_t pos = ex_sv + j, lb = ex_l + a.hs_pre_l[j], cb = ex_c + a.hs_pre_c[j];
-            for (int32_t t = 0; t < o.sv.lib_count; ++t) {
-                const int32_t q = o.sv.lib_begin + t;
-                a.d_lib_index[lb + t] = a.hs_lib_index[q];
-                a.t_lambda[lb + t] = a.hs_lambda[q];
-                a.t_k[lb + t] = a.hs_lib_pairs[q];
+        for (uint32_t j = hb0; j < hb1; ++j) {  // the inserted candidates that come right before this vertex's own
+            const uint32_t pos = ex_sv + j, lb = ex_l + a.ins_pre_l[j], cb = ex_c + a.ins_pre_c[j];
+            const uint32_t src = a.ins_src[j];
+            if (!(src & 0x80000000u)) {
+                put_staged(pos, lb, cb, src, (int32_t)(a.ins_pre_l[j + 1] - a.ins_pre_l[j]), (int32_t)(a.ins_pre_c[j + 1] - a.ins_pre_c[j]));
+                continue;
             }
-            for (int32_t t = 0; t < o.sv.cn_count; ++t) {
-                a.d_cn_key[cb + t] = a.hs_cn_key[o.sv.cn_begin + t];
-                a.d_cn_value[cb + t] = a.hs_cn_value[o.sv.cn_begin + t];
+            const bdx_sv* o = &a.hs_rec[src & 0x7FFFFFFFu].sv;
+            const int32_t l0 = o->lib_begin, c0 = o->cn_begin;
+            const int32_t nl = (int32_t)(a.ins_pre_l[j + 1] - a.ins_pre_l[j]), ncn = (int32_t)(a.ins_pre_c[j + 1] - a.ins_pre_c[j]);
+            for (int32_t t = 0; t < nl; ++t) {
+                a.d_lib_index[lb + t] = a.hs_lib_index[l0 + t];
+                a.t_lambda[lb + t] = a.hs_lambda[l0 + t];
+                a.t_k[lb + t] = a.hs_lib_pairs[l0 + t];
             }
-            a.sv_src[pos] = 0x80000000u | j;
+            for (int32_t t = 0; t < ncn; ++t) {
+                a.d_cn_key[cb + t] = a.hs_cn_key[c0 + t];
+                a.d_cn_value[cb + t] = a.hs_cn_value[c0 + t];
+            }
+            a.sv_src[pos] = src;
             a.sv_begin[pos] = make_uint2(lb, cb);
         }
-        uint32_t d = ex_sv + hb1, lb = ex_l + (nh ? a.hs_pre_l[hb1] : 0u), cb = ex_c + (nh ? a.hs_pre_c[hb1] : 0u);
+        uint32_t d = ex_sv + hb1, lb = ex_l + a.ins_pre_l[hb1], cb = ex_c + a.ins_pre_c[hb1];
         for (uint32_t q = 0; q < e.x; ++q) {
             const uint32_t slot = a.own_slots[(size_t)i * kK6MaxSv + q];
             const int32_t nl = a.sv_stage[slot].sv.lib_count, ncn = a.sv_stage[slot].sv.cn_count;
-            put_entries(lb, cb, nl, ncn, a.lib_stage + (size_t)slot * a.lib_stride, a.cn_stage + (size_t)slot * a.nkeys);
-            a.sv_src[d] = slot;
-            a.sv_begin[d] = make_uint2(lb, cb);
+            put_staged(d, lb, cb, slot, nl, ncn);
             lb += (uint32_t)nl;
             cb += (uint32_t)ncn;
             ++d;
@@ -778,7 +916,7 @@ void launch_k6_compact(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
     if (n_anom_host == 0) return;
     OwnIn in{a.own_nsv, a.own_nacc, a.own_ncn};
     OwnOut out{a};
-    scan_launch<U4, 1>(in, out, &a.counts->n_regions, n_anom_host, a.ws_u4, a.total_u4, s);  // few elements, heavy output: one per thread
+    scan_launch_side<U4, 1>(in, out, InsertJob{a}, &a.counts->n_regions, n_anom_host, a.ws_u4, a.total_u4, s);  // few elements, heavy output: one per thread
 }
 
 }  // namespace bdx
