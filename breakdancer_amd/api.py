@@ -212,6 +212,12 @@ class BreakDancer:
         self._chk(self.lib.bdx_get_walk_split(self.h, C.byref(v[0]), C.byref(v[1]), C.byref(v[2])), "bdx_get_walk_split")
         return tuple(x.value for x in v)
 
+    def cross_window_svs(self):
+        """device-assembled SVs whose traversal started from a region of an earlier flush window"""
+        v = C.c_uint32(0)
+        self._chk(self.lib.bdx_get_cross_window_svs(self.h, C.byref(v)), "bdx_get_cross_window_svs")
+        return v.value
+
     def timings(self):
         ms = np.zeros(12, np.float32)
         self.lib.bdx_get_timings(self.h, ms.ctypes.data_as(C.c_void_p), 12)

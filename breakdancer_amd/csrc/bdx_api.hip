@@ -904,6 +904,7 @@ int finish_table(bdx_ctx* c) {
     c->n_sv_total = c2.n_sv_dev; c->n_terms_total = c2.n_terms_dev; c->n_cn_total = c2.n_cn_dev;
     c->counts.n_sv_dev = c2.n_sv_dev - c->n_sv_host;
     c->n_printed = c2.n_printed;
+    c->counts.n_old = c2.n_old;
     c->materialized = false;
     if (c->opts.fisher) {  // Fisher's combination (BreakDancer.cpp:71-81) uses the host's exp / log
         materialize(c);
@@ -1377,6 +1378,13 @@ int bdx_get_walk_split(const bdx_ctx* c, uint32_t* n_sv_device, uint32_t* n_sv_h
     if (n_sv_device) *n_sv_device = c->counts.n_sv_dev;
     if (n_sv_host) *n_sv_host = c->n_sv_host;
     if (n_groups_host) *n_groups_host = c->counts.n_groups;
+    return BDX_OK;
+}
+
+int bdx_get_cross_window_svs(const bdx_ctx* c, uint32_t* n_sv_device) {
+    if (!c || !n_sv_device) return BDX_EINVAL;
+    if (!c->ran) return BDX_ESTATE;
+    *n_sv_device = c->counts.n_old;
     return BDX_OK;
 }
 

@@ -1,4 +1,5 @@
-// Device-wide inclusive scan in three launches (block sums -> scan of sums -> rescan with offsets),
+// Device-wide inclusive scan in three launches (block sums -> scan of sums -> rescan with offsets; two when the
+// workgroups are few enough to add up the block sums themselves),
 // generic over the element type (uint32_t or a 4-column struct) and over load/store functors so the
 // callers fuse their own per-element work into phase 1 / phase 3.  Element count may live on the device
 // (n_ptr) so no host round trip is needed between dependent stages.
@@ -108,14 +109,23 @@ template <class T, int kIters> __global__ __launch_bounds__(1024) void scan_phas
     if (threadIdx.x == 0) *total = s_carry;
 }
 
-template <class T, class In, class Out, int kIters>
+// kSelfSum: blk holds phase 1's raw block sums and every workgroup adds up the ones before its own (few workgroups:
+// cheaper than the extra launch of phase 2)
+template <class T, class In, class Out, int kIters, bool kSelfSum>
 __global__ __launch_bounds__(kScanBlock) void scan_phase3(In in, Out out, const uint32_t* n_ptr, const T* blk) {
     constexpr int kScanChunk = kScanBlock * kIters;
     __shared__ T s_ws[kScanBlock / 64];
     const uint32_t n = *n_ptr;
     const uint32_t base = blockIdx.x * kScanChunk;
     if (base >= n) return;
-    T carry = blk[blockIdx.x];
+    T carry;
+    if (kSelfSum) {
+        T acc = zero_of<T>();
+        for (uint32_t i = threadIdx.x; i < blockIdx.x; i += kScanBlock) acc = acc + blk[i];
+        block_incl_scan(acc, s_ws, &carry);
+    } else {
+        carry = blk[blockIdx.x];
+    }
 #pragma unroll 1
     for (int it = 0; it < kIters; ++it) {
         const uint32_t j = base + it * kScanBlock + threadIdx.x;
@@ -134,12 +144,18 @@ inline uint32_t scan_grid(uint32_t n_upper, int iters = kScanIters) {
     return n_upper ? (n_upper + chunk - 1) / chunk : 1;
 }
 
+constexpr uint32_t kScanSelfSumMax = 1024;  // workgroups up to which phase 3 sums the block totals itself
+
 template <class T, int kIters = kScanIters, class In, class Out>
 void scan_launch(In in, Out out, const uint32_t* n_ptr, uint32_t n_upper, T* blk_ws, T* total, hipStream_t s) {
     const uint32_t g = scan_grid(n_upper, kIters);
     hipLaunchKernelGGL((scan_phase1<T, In, kIters>), dim3(g), dim3(kScanBlock), 0, s, in, n_ptr, blk_ws);
+    if (g <= kScanSelfSumMax) {
+        hipLaunchKernelGGL((scan_phase3<T, In, Out, kIters, true>), dim3(g), dim3(kScanBlock), 0, s, in, out, n_ptr, blk_ws);
+        return;
+    }
     hipLaunchKernelGGL((scan_phase2<T, kIters>), dim3(1), dim3(1024), 0, s, blk_ws, n_ptr, total);
-    hipLaunchKernelGGL((scan_phase3<T, In, Out, kIters>), dim3(g), dim3(kScanBlock), 0, s, in, out, n_ptr, blk_ws);
+    hipLaunchKernelGGL((scan_phase3<T, In, Out, kIters, false>), dim3(g), dim3(kScanBlock), 0, s, in, out, n_ptr, blk_ws);
 }
 
 // the same scan with a side job (a device functor run by one extra workgroup of kScanBlock threads during phase 1; its
@@ -148,8 +164,12 @@ template <class T, int kIters = kScanIters, class In, class Out, class Side>
 void scan_launch_side(In in, Out out, Side side, const uint32_t* n_ptr, uint32_t n_upper, T* blk_ws, T* total, hipStream_t s) {
     const uint32_t g = scan_grid(n_upper, kIters);
     hipLaunchKernelGGL((scan_phase1_side<T, In, Side, kIters>), dim3(g + 1), dim3(kScanBlock), 0, s, in, side, n_ptr, blk_ws);
+    if (g <= kScanSelfSumMax) {
+        hipLaunchKernelGGL((scan_phase3<T, In, Out, kIters, true>), dim3(g), dim3(kScanBlock), 0, s, in, out, n_ptr, blk_ws);
+        return;
+    }
     hipLaunchKernelGGL((scan_phase2<T, kIters>), dim3(1), dim3(1024), 0, s, blk_ws, n_ptr, total);
-    hipLaunchKernelGGL((scan_phase3<T, In, Out, kIters>), dim3(g), dim3(kScanBlock), 0, s, in, out, n_ptr, blk_ws);
+    hipLaunchKernelGGL((scan_phase3<T, In, Out, kIters, false>), dim3(g), dim3(kScanBlock), 0, s, in, out, n_ptr, blk_ws);
 }
 
 }  // namespace bdx

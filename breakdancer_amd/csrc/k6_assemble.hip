@@ -661,12 +661,20 @@ struct InsertJob {
 
 __device__ void InsertJob::operator()() const {
     constexpr uint32_t kThreads = kScanBlock;
+    constexpr uint32_t kPer = kInsLds / kThreads;  // list entries per thread in the LDS prefix pass
     __shared__ uint64_t s_dk[kInsLds];
     __shared__ uint32_t s_dv[kInsLds];
     __shared__ uint64_t s_hk[kInsLds];
+    __shared__ uint32_t s_cnt[kInsLds];   // lib_count | cn_count << 16 of the merged list
+    __shared__ uint64_t s_tmp[kThreads];
     __shared__ uint32_t s_ws[2][kThreads / 64];
     const uint32_t tid = threadIdx.x;
-    const uint32_t nh = a.nh, nd = a.counts->n_old;
+    const int lane = tid & 63, w = tid >> 6;
+    const uint32_t nh = a.nh;
+    const uint32_t nd = a.counts->n_old;
+    // the host's keys and counts come over the link: ask for them before anything waits
+    uint64_t* hk = nh <= kInsLds ? s_hk : a.hs_key_dev;
+    for (uint32_t i = tid; i < nh; i += kThreads) hk[i] = a.hs_key[i];
     const uint32_t n = nh + nd;
     if (n > a.sv_cap) {  // cannot happen: every candidate consumes at least one read pair
         if (tid == 0) { a.counts->overflow = 1; a.counts->n_ins = 0; a.ins_pre_l[0] = 0; a.ins_pre_c[0] = 0; }
@@ -677,53 +685,101 @@ __device__ void InsertJob::operator()() const {
         if (tid == 0) { a.ins_pre_l[0] = 0; a.ins_pre_c[0] = 0; }
         return;
     }
-    uint64_t* hk = nh <= kInsLds ? s_hk : a.hs_key_dev;
-    for (uint32_t i = tid; i < nh; i += kThreads) hk[i] = a.hs_key[i];
-    uint32_t m = 1;
-    while (m < nd) m <<= 1;
+    const bool small = n <= kInsLds;  // the merged list's counts stay in LDS for the running totals
     uint64_t* dk;
     uint32_t* dv;
-    if (m <= kInsLds) {
+    uint32_t my_cnt = 0;              // rank-sort path: lib_count | cn_count << 16 of this thread's device entry
+    const bool by_rank = nd <= kThreads;
+    if (by_rank) {
+        // one entry per thread: its rank is the number of smaller keys (all keys differ)
         dk = s_dk; dv = s_dv;
-        for (uint32_t i = tid; i < m; i += kThreads) { dk[i] = i < nd ? a.old_key[i] : ~0ull; dv[i] = i < nd ? a.old_slot[i] : 0u; }
-    } else {
-        dk = a.old_key; dv = a.old_slot;
-        for (uint32_t i = nd + tid; i < m; i += kThreads) dk[i] = ~0ull;
-    }
-    __syncthreads();
-    for (uint32_t ksz = 2; ksz <= m; ksz <<= 1)
-        for (uint32_t j = ksz >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < m / 2; t += kThreads) {
-                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
-                const bool up = (lo & ksz) == 0;
-                const uint64_t x = dk[lo], y = dk[hi];
-                if ((x > y) == up) {
-                    dk[lo] = y; dk[hi] = x;
-                    const uint32_t vx = dv[lo];
-                    dv[lo] = dv[hi]; dv[hi] = vx;
-                }
-            }
-            __syncthreads();
+        const uint64_t key = tid < nd ? a.old_key[tid] : ~0ull;
+        const uint32_t slot = tid < nd ? a.old_slot[tid] : 0u;
+        if (tid < nd) my_cnt = (uint32_t)a.sv_stage[slot].sv.lib_count | ((uint32_t)a.sv_stage[slot].sv.cn_count << 16);
+        s_tmp[tid] = key;
+        __syncthreads();
+        uint32_t rank = 0;
+        for (uint32_t q = 0; q < nd; ++q) rank += s_tmp[q] < key ? 1u : 0u;
+        if (tid < nd) { dk[rank] = key; dv[rank] = slot; }
+        __syncthreads();
+        if (tid < nd) {
+            const uint32_t pos = rank + count_below64(hk, nh, key);
+            a.ins_T[pos] = (uint32_t)(key >> 31);
+            a.ins_src[pos] = slot;
+            if (small) s_cnt[pos] = my_cnt;
+            else { a.ins_pre_l[pos] = my_cnt & 0xffffu; a.ins_pre_c[pos] = my_cnt >> 16; }
         }
+    } else {
+        uint32_t m = 1;
+        while (m < nd) m <<= 1;
+        if (m <= kInsLds) {
+            dk = s_dk; dv = s_dv;
+            for (uint32_t i = tid; i < m; i += kThreads) { dk[i] = i < nd ? a.old_key[i] : ~0ull; dv[i] = i < nd ? a.old_slot[i] : 0u; }
+        } else {
+            dk = a.old_key; dv = a.old_slot;
+            for (uint32_t i = nd + tid; i < m; i += kThreads) dk[i] = ~0ull;
+        }
+        __syncthreads();
+        for (uint32_t ksz = 2; ksz <= m; ksz <<= 1)
+            for (uint32_t j = ksz >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = tid; t < m / 2; t += kThreads) {
+                    const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                    const bool up = (lo & ksz) == 0;
+                    const uint64_t x = dk[lo], y = dk[hi];
+                    if ((x > y) == up) {
+                        dk[lo] = y; dk[hi] = x;
+                        const uint32_t vx = dv[lo];
+                        dv[lo] = dv[hi]; dv[hi] = vx;
+                    }
+                }
+                __syncthreads();
+            }
+        for (uint32_t d = tid; d < nd; d += kThreads) {
+            const uint64_t key = dk[d];
+            const uint32_t pos = d + count_below64(hk, nh, key), slot = dv[d];
+            const uint32_t cnt = (uint32_t)a.sv_stage[slot].sv.lib_count | ((uint32_t)a.sv_stage[slot].sv.cn_count << 16);
+            a.ins_T[pos] = (uint32_t)(key >> 31);
+            a.ins_src[pos] = slot;
+            if (small) s_cnt[pos] = cnt;
+            else { a.ins_pre_l[pos] = cnt & 0xffffu; a.ins_pre_c[pos] = cnt >> 16; }
+        }
+    }
     for (uint32_t j = tid; j < nh; j += kThreads) {
         const uint64_t key = hk[j];
         const uint32_t pos = j + count_below64(dk, nd, key), cnt = a.hs_cnt[j];
         a.ins_T[pos] = (uint32_t)(key >> 31);
         a.ins_src[pos] = 0x80000000u | j;
-        a.ins_pre_l[pos] = cnt & 0xffffu;
-        a.ins_pre_c[pos] = cnt >> 16;
-    }
-    for (uint32_t d = tid; d < nd; d += kThreads) {
-        const uint64_t key = dk[d];
-        const uint32_t pos = d + count_below64(hk, nh, key), slot = dv[d];
-        a.ins_T[pos] = (uint32_t)(key >> 31);
-        a.ins_src[pos] = slot;
-        a.ins_pre_l[pos] = (uint32_t)a.sv_stage[slot].sv.lib_count;
-        a.ins_pre_c[pos] = (uint32_t)a.sv_stage[slot].sv.cn_count;
+        if (small) s_cnt[pos] = cnt;
+        else { a.ins_pre_l[pos] = cnt & 0xffffu; a.ins_pre_c[pos] = cnt >> 16; }
     }
     __syncthreads();
     // exclusive running totals, the grand totals at [n]
-    const int lane = tid & 63, w = tid >> 6;
+    if (small) {
+        uint32_t l[kPer], c[kPer], sl = 0, sc = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < kPer; ++q) {
+            const uint32_t i = tid * kPer + q;
+            const uint32_t v = i < n ? s_cnt[i] : 0u;
+            l[q] = v & 0xffffu; c[q] = v >> 16;
+            sl += l[q]; sc += c[q];
+        }
+        const uint32_t il = wave_incl_scan_t(sl), ic = wave_incl_scan_t(sc);
+        if (lane == 63) { s_ws[0][w] = il; s_ws[1][w] = ic; }
+        __syncthreads();
+        uint32_t ol = il - sl, oc = ic - sc, tl = 0, tc = 0;
+        for (int q = 0; q < (int)kThreads / 64; ++q) {
+            if (q < w) { ol += s_ws[0][q]; oc += s_ws[1][q]; }
+            tl += s_ws[0][q]; tc += s_ws[1][q];
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < kPer; ++q) {
+            const uint32_t i = tid * kPer + q;
+            if (i < n) { a.ins_pre_l[i] = ol; a.ins_pre_c[i] = oc; }
+            ol += l[q]; oc += c[q];
+        }
+        if (tid == 0) { a.ins_pre_l[n] = tl; a.ins_pre_c[n] = tc; }
+        return;
+    }
     uint32_t carry_l = 0, carry_c = 0;
     for (uint32_t base = 0; base < n; base += kThreads) {
         const uint32_t i = base + tid;
@@ -773,7 +829,7 @@ struct OwnOut {
         if (i == n - 1) {
             const uint32_t tsv = inc.x + nh, tl = inc.y + h_l, tc = inc.z + h_c;
             a.counts->n_sv_dev = tsv; a.counts->n_terms_dev = tl; a.counts->n_cn_dev = tc;
-            if (a.counts_host2) { a.counts_host2->n_sv_dev = tsv; a.counts_host2->n_terms_dev = tl; a.counts_host2->n_cn_dev = tc; }
+            if (a.counts_host2) { a.counts_host2->n_sv_dev = tsv; a.counts_host2->n_terms_dev = tl; a.counts_host2->n_cn_dev = tc; a.counts_host2->n_old = a.counts->n_old; }
             if (tsv > a.sv_cap || tl > a.term_cap || tc > a.cn_cap) {
                 a.counts->overflow = 1;
                 if (a.counts_host2) a.counts_host2->overflow = 1;

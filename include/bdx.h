@@ -189,6 +189,9 @@ int bdx_set_stage_timing(bdx_ctx* ctx, int on);
  * sends everything through the host walk (same results; used by the parity tests).  Any pointer may be NULL. */
 int bdx_set_host_walk(bdx_ctx* ctx, int on);
 int bdx_get_walk_split(const bdx_ctx* ctx, uint32_t* n_sv_device, uint32_t* n_sv_host, uint32_t* n_groups_host);
+/* Of the device-assembled candidates, those whose traversal started from a region of an earlier flush window (the
+ * reference's flush cadence, BreakDancer.cpp:254-264; they are placed in the output by order key, not by position). */
+int bdx_get_cross_window_svs(const bdx_ctx* ctx, uint32_t* n_sv_device);
 
 /* Kernel-level entry points for parity tests.
  * bdx_classify replaces IAlignmentClassifier::classify (io/IlluminaPEReadClassifier.cpp:59-101) plus the

@@ -296,3 +296,23 @@ def test_sv_table_larger_than_one_pass_of_the_score_kernel():
     bd = product_from_oracle(run)
     compare(run, bd)
     bd.close()
+
+
+@pytest.mark.parametrize("buffer_size,min_cross", [(1, 2048), (3, 256), (0, 2048)])
+def test_components_spanning_flush_windows_are_walked_on_the_device(buffer_size, min_cross):
+    """small flush windows (-b): most two-region components have their regions in different windows, so their SVs come
+    from traversals started at an earlier window's region and are placed by order key -- enough of them to take the
+    insertion list through its sort beyond one LDS tile"""
+    cfg, st = _synth_case(12_000_000, seed=37, discordant=0.02, cluster=6)
+    run = OracleRun(cfg, make_opts(buffer_size=buffer_size, min_read_pair=2))
+    run.set_targets(["chrS"])
+    st = dict(st)
+    st["lib"] = np.zeros(len(st["tid"]), np.int32)
+    run.set_stream(0, st)
+    run.run()
+    bd = product_from_oracle(run)
+    compare(run, bd)
+    n_dev, n_host, _ = bd.walk_split()
+    assert bd.cross_window_svs() > min_cross, (bd.cross_window_svs(), n_dev, n_host)
+    assert n_dev > 10 * max(n_host, 1), (n_dev, n_host)
+    bd.close()
