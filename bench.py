@@ -204,7 +204,8 @@ def main():
                                    "pairs; %d read pairs (%d records) per GPU, HBM-resident SoA" % (a.length // 1000000, pairs, n),
                        "sharding": "one chromosome per GPU, no data-path collective", "contexts_in_flight": len(ctxs), "svs_per_gpu": summary["n_svs_printed"],
                        "stage_ms_profiled_steps": {k: v / 3 for k, v in stage.items()},
-                       "sv_candidates": dict(zip(("assembled_on_device", "from_host_walk", "groups_to_host_walk"), bd.walk_split()))},
+                       "sv_candidates": dict(zip(("assembled_on_device", "from_host_walk", "groups_to_host_walk", "device_placed_by_order_key"),
+                                                 bd.walk_split() + (bd.cross_window_svs(),)))},
             "roofline": {"bound": "hbm", "kernel": "k1_classify_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_READ * n,
                          "avg_kernel_ms": k1_avg_ms},
