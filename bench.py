@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_READ = 28          # 27 B SoA record read + 1 B class byte written
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec (MI355X_MICROARCH.md)
+PATH_BYTES_PER_PAIR = 57.3        # whole path, per read pair, at 1 % discordant pairs
 CHROM_LEN = 50_000_000
 CPU_SAMPLE_LEN = 50_000_000       # CPU baseline sample: the full configs[1] chromosome, repeated until ~12 s of CPU work
 
@@ -208,7 +209,12 @@ def main():
                                                  bd.walk_split() + (bd.cross_window_svs(),)))},
             "roofline": {"bound": "hbm", "kernel": "k1_classify_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_READ * n,
-                         "avg_kernel_ms": k1_avg_ms},
+                         "avg_kernel_ms": k1_avg_ms,
+                         # SURVEY.md 8d's whole-path figure: 57.3 algorithmic bytes per read pair (28 B per read + 64 B per
+                         # anomalous read at 1 % discordant) over the wall time of the step, not only the dominant kernel
+                         "whole_path": {"algorithmic_bytes_per_read_pair": PATH_BYTES_PER_PAIR,
+                                        "achieved": value / world * PATH_BYTES_PER_PAIR / 1e9,
+                                        "frac": value / world * PATH_BYTES_PER_PAIR / 1e9 / HBM_PEAK_GBS}},
         }
         if overlapped:
             out["config"]["overlapped_contexts_untimed"] = overlapped
