@@ -92,7 +92,7 @@ struct bdx_ctx {
     PinBuf h_p1, h_cnt, h_counts, h_regs, h_pk, h_groups, h_terms;
     DevBuf b_sv_src, b_dlists, b_ltail, b_pair_lo;
     PinBuf h_hs_rec, h_hs_aux, h_hs_lists;
-    DevBuf b_ins;
+    DevBuf b_ins, b_member_ids;
     PinBuf h_flags;                   // [0] pass 1 ready, [1] host's groups ready, [2] final table ready (= run sequence number)
     uint32_t seq = 0;
     uint32_t k1_event_period = 4;     // K1 is bracketed by HIP events on every n-th run (an event pair idles the GPU ~10 us)
@@ -104,6 +104,9 @@ struct bdx_ctx {
     uint32_t n_sv_total = 0, n_groups_total = 0, n_terms_total = 0, n_cn_total = 0;
     PinBuf h_counts0, h_counts2, h_sv_out, h_lib_index, h_lib_pairs, h_cn_key, h_cn_value, h_ltail_dev;
     hipEvent_t ev_groups = nullptr, ev_regions = nullptr;
+    int big_walk_mode = -1;           // BDX_BIG_WALK=1 / 0: components of 5..64 regions always / never walked on the device; default: when
+                                      // the host's share is large enough to matter (see do_k6)
+    int64_t last_big_groups = -1;     // groups of such components in the previous run of this context (device + host share)
     bool bucketed_join = false;       // BDX_BUCKETED_JOIN=1: use the partitioned LDS join at every size (it is the path for > 4 M entries)
     bool host_walk_only = false;      // BDX_HOST_WALK=1: every component goes through the host walk (A/B testing of K6)
     K6Arrays k6{};
@@ -255,6 +258,7 @@ int bdx_create(bdx_ctx** out, const bdx_opts* opts, const bdx_lib* libs, int nli
         c->poll = !(np && np[0] == '1');
         const char* bj = getenv("BDX_BUCKETED_JOIN");
         c->bucketed_join = bj && bj[0] == '1';
+        if (const char* bw = getenv("BDX_BIG_WALK")) c->big_walk_mode = bw[0] == '1' ? 1 : 0;
     }
     std::vector<DevLib> dl(nlibs);
     for (int i = 0; i < nlibs; ++i) {
@@ -289,7 +293,7 @@ void bdx_destroy(bdx_ctx* c) {
                       &c->b_t_idx, &c->b_x_key, &c->b_x_order, &c->b_x_region,
                       &c->b_x_meta, &c->b_x_isize, &c->b_x_n, &c->b_fold, &c->b_lib_mean, &c->b_pair_lo, &c->b_sv_src, &c->b_dlists, &c->b_ltail, &c->b_r_rec, &c->b_r_pk, &c->b_out_deg,
                       &c->b_parts, &c->b_kdens, &c->b_rs, &c->b_slot, &c->b_members, &c->b_own, &c->b_lib_stage,
-                      &c->b_cn_stage, &c->b_t_lambda, &c->b_t_k, &c->b_ws6, &c->b_ins};
+                      &c->b_cn_stage, &c->b_t_lambda, &c->b_t_k, &c->b_ws6, &c->b_ins, &c->b_member_ids};
     for (DevBuf* b : bufs) b->release();
     PinBuf* pins[] = {&c->h_p1, &c->h_cnt, &c->h_counts, &c->h_regs, &c->h_pk, &c->h_groups, &c->h_terms, &c->h_flags, &c->h_hs_rec, &c->h_hs_aux, &c->h_hs_lists, &c->h_counts0, &c->h_counts2,
                       &c->h_sv_out, &c->h_lib_index, &c->h_lib_pairs, &c->h_cn_key, &c->h_cn_value, &c->h_ltail_dev};
@@ -752,7 +756,8 @@ int do_k6(bdx_ctx* c, bool force_host) {
     HIPCHK(c, c->b_parts.ensure(cap * sizeof(PartRec)));
     HIPCHK(c, c->b_rs.ensure(cap * sizeof(RegSum)));
     HIPCHK(c, c->b_members.ensure(cap * kK6MaxMembers * sizeof(MemberInfo)));
-    HIPCHK(c, c->b_own.ensure(cap * (4 + kK6MaxSv) * 4));
+    HIPCHK(c, c->b_own.ensure(cap * 7 * 4));
+    HIPCHK(c, c->b_member_ids.ensure(cap * kK6BigMembers * 4));
     a.sv_cap = na / 2 + 1; a.term_cap = na / 2 + 1; a.cn_cap = (na / 2 + 1) * (uint32_t)nkeys;
     a.lib_stride = (uint32_t)std::min(nlibs, kK6LibStride);
     HIPCHK(c, c->b_slot.ensure(cap * sizeof(SvOut)));
@@ -787,7 +792,8 @@ int do_k6(bdx_ctx* c, bool force_host) {
     a.out_deg = c->b_out_deg.as<uint32_t>(); a.label = a.out_deg + cap; a.bad_v = a.out_deg + 2 * cap; a.bad = a.out_deg + 3 * cap;
     a.mcount = a.out_deg + 4 * cap; a.pcount = a.out_deg + 5 * cap;
     a.members = c->b_members.as<MemberInfo>();
-    a.own_nsv = c->b_own.as<uint32_t>(); a.own_nacc = a.own_nsv + cap; a.own_ncn = a.own_nsv + 2 * cap; a.own_slots = a.own_nsv + 3 * cap; a.owners = a.own_nsv + (3 + kK6MaxSv) * cap;
+    a.own_nsv = c->b_own.as<uint32_t>(); a.own_nacc = a.own_nsv + cap; a.own_ncn = a.own_nsv + 2 * cap; a.own_first = a.own_nsv + 3 * cap; a.slot_next = a.own_nsv + 4 * cap; a.owners = a.own_nsv + 5 * cap; a.owners_big = a.own_nsv + 6 * cap;
+    a.member_ids = c->b_member_ids.as<uint32_t>();
     a.sv_stage = c->b_slot.as<SvOut>(); a.lib_stage = c->b_lib_stage.as<LibStage>(); a.cn_stage = c->b_cn_stage.as<CnStage>();
     a.sv_out = c->h_sv_out.as<SvOut>(); a.lib_index = c->h_lib_index.as<int32_t>(); a.lib_pairs = c->h_lib_pairs.as<int32_t>();
     a.cn_key = c->h_cn_key.as<int32_t>(); a.cn_value = c->h_cn_value.as<float>();
@@ -808,9 +814,14 @@ int do_k6(bdx_ctx* c, bool force_host) {
     a.nlibs = nlibs; a.nkeys = nkeys; a.min_read_pair = c->opts.min_read_pair; a.chr_restricted = c->opts.chr_restricted;
     a.period = std::max(1, c->opts.buffer_size + 1);
     a.force_host = force_host ? 1 : 0;
+    // Components of 5..64 regions cost one more launch (k6_walk_big_kernel).  Few of them are walked by the host behind
+    // the device's own walk for free; many (dense data) make the host walk the longest stage.  Without a previous run to
+    // go by, the number of anomalous reads decides.
+    a.big_walk = c->big_walk_mode >= 0 ? c->big_walk_mode : (c->last_big_groups >= 0 ? c->last_big_groups > 2000 : na > 500000u);
     {
-        static const int rounds = getenv("BDX_LABEL_ROUNDS") ? std::max(1, atoi(getenv("BDX_LABEL_ROUNDS"))) : kK6LabelRounds;
-        a.label_rounds = rounds;
+        static const int rounds = getenv("BDX_LABEL_ROUNDS") ? std::max(1, atoi(getenv("BDX_LABEL_ROUNDS"))) : 0;
+        // (long chains need more rounds to agree on one label; with the general walk on, the step is long enough not to care)
+        a.label_rounds = rounds ? rounds : (a.big_walk ? kK6LabelRoundsBig : kK6LabelRounds);
     }
     launch_k6_groups(a, na, s);
     {   // the host's share of the groups is complete
@@ -847,7 +858,7 @@ int do_k6_table(bdx_ctx* c) {
             const bool from_old = !((key >> 32) & 1ull);
             const uint64_t start = key & 0xffffffffull;
             const uint64_t T = from_old ? (key >> 33) * period : start;
-            hkey[j] = (T << 31) | (from_old ? 0ull : 1ull << 30) | (start << 4);
+            hkey[j] = (T << 34) | (from_old ? 0ull : 1ull << 33) | (start << 7);
             if (a.force_host) hkey[j] = 0;  // no device candidates to interleave with (and the ids may carry the phantom shift)
             hcnt[j] = (uint32_t)H.svs[j].sv.lib_count | ((uint32_t)H.svs[j].sv.cn_count << 16);
         }
@@ -1103,6 +1114,7 @@ int bdx_run(bdx_ctx* c) {
         if (c->counts.overflow == 2) return fail(c, BDX_ELIMIT, "more than two primary reads share one read name (malformed input)");
         if (c->counts.overflow) return fail(c, BDX_EINTERNAL, "group list overflow");
         decode_groups(c, c->h_groups.as<GroupRec>(), c->counts.n_groups, ph);
+        c->last_big_groups = (int64_t)c->counts.n_groups + c->counts.n_groups_big;  // (the host's share: mostly such components)
     }
     const auto t_h1 = std::chrono::steady_clock::now();
     rc = host_walk(c, c->counts.last_maxq, na != 0);

@@ -24,6 +24,8 @@ struct StageCounts {
     uint32_t stage_lib;
     uint32_t stage_cn;
     uint32_t n_owners;     // K6: device-walked components (entries of K6Arrays::owners)
+    uint32_t n_owners_big; // K6: entries of K6Arrays::owners_big
+    uint32_t n_groups_big; // K6: groups of those components
     uint32_t n_old;        // K6: device candidates of traversals started from a vertex of an earlier flush window
     uint32_t n_ins;        // K6: candidates the compaction inserts by order key (the host walk's + n_old)
 };
@@ -161,9 +163,10 @@ void launch_k5_dev(const double* lambda, const int32_t* k, double* out, double* 
 // pair groups.
 constexpr int kK6MaxMembers = 4;   // regions per device-walked component
 constexpr int kK6MaxIn = 3;        // incoming gate-passing groups per region (a member of such a component has <= 3)
-constexpr int kK6MaxSv = 10;       // SV candidates of one component: 4 self groups + 6 groups between members
+constexpr int kK6BigMembers = 64;  // regions per component walked by the general device path (one wave, member lists in LDS)
 constexpr int kK6LibStride = 16;   // staged (library, pairs) entries per candidate; components that could need more go to the host
 constexpr int kK6LdsParts = 12;    // parts of a component kept in LDS by its walking thread (more: read from HBM)
+constexpr int kK6LabelRoundsBig = 8; // ... with the general walk (components of up to kK6BigMembers regions) enabled
 constexpr int kK6LabelRounds = 3;  // min-label propagation rounds: enough for a diameter of 3; a component that has
                                    // not converged fails the closure check and goes to the host
 
@@ -234,7 +237,10 @@ struct K6Arrays {
     uint32_t* own_nsv;             // [cap] per start vertex (smallest region of a component): candidates emitted ...
     uint32_t* own_nacc;            // [cap] ... the sum of their (library, pairs) entries ...
     uint32_t* own_ncn;             // [cap] ... and of their copy-number entries
-    uint32_t* own_slots;           // [cap][kK6MaxSv] their staging slots in emission order
+    uint32_t* own_first;           // [cap] staging slot of the first of them ...
+    uint32_t* slot_next;           // [cap] ... and, by staging slot, the slot of the next one in emission order
+    uint32_t* owners_big;          // [cap] smallest regions of the device-walked components of more than kK6MaxMembers regions
+    uint32_t* member_ids;          // [cap][kK6BigMembers] by label: the regions of a component (k6_classify_kernel, any order)
     SvOut* sv_stage;               // [cap]
     LibStage* lib_stage;           // [cap][lib_stride]
     CnStage* cn_stage;             // [cap][nkeys]
@@ -259,7 +265,7 @@ struct K6Arrays {
     // Candidates that are placed by their order key instead of by their start vertex: the host walk's (pinned host
     // memory) and the device's own whose traversal started from a vertex of an earlier flush window.  k6_insert_kernel
     // merges the two lists by key; entry j of the merged list precedes the candidates of start vertex ins_T[j] and after.
-    // Order key: (T << 31) | (started at a vertex of its own window ? 1 << 30 : 0) | (start vertex << 4) | sequence number,
+    // Order key: (T << 34) | (started at a vertex of its own window ? 1 << 33 : 0) | (start vertex << 7) | sequence number,
     // T = the start vertex, or the first vertex of the flush window for a traversal started from an earlier window's vertex.
     const SvOut* hs_rec;           // [nh] lib_begin / cn_begin index the host lists below
     const uint64_t* hs_key;        // [nh] ascending order keys
@@ -294,6 +300,7 @@ struct K6Arrays {
     const float* lib_mean;         // [nlibs]
     const Pass1* p1;               // covered_ref_len is read from the device's pass-1 record
     int nlibs, nkeys, min_read_pair, chr_restricted, period, force_host;
+    int big_walk;                  // components of up to kK6BigMembers regions are walked on the device (k6_walk_big_kernel); 0: up to kK6MaxMembers
     int label_rounds;              // min-label propagation rounds incl. the one inside k6_pairs_kernel (default kK6LabelRounds)
 };
 

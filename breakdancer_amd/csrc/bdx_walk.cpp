@@ -387,6 +387,30 @@ struct Walker {
         flush(prev, NR - 1);
         if (prof) fprintf(stderr, "[walk] SVs by vertices visited in their traversal: 1:%zu 2:%zu 3:%zu 4:%zu 5:%zu 6:%zu 7+:%zu (from old vertices %zu)\n",
                           prof_hist[1], prof_hist[2], prof_hist[3], prof_hist[4], prof_hist[5], prof_hist[6], prof_hist[7], prof_old);
+        if (prof) {  // sizes of the connected components over the gate-passing groups the host was handed
+            std::vector<uint32_t> parent((size_t)NR);
+            for (int64_t i = 0; i < NR; ++i) parent[(size_t)i] = (uint32_t)i;
+            auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+            std::vector<uint8_t> seen((size_t)NR, 0);
+            for (const Group& g : groups) {
+                if ((int)g.weight < in.opts.min_read_pair && g.lo != g.hi) continue;
+                seen[g.lo] = seen[g.hi] = 1;
+                const uint32_t a = find(g.lo), b = find(g.hi);
+                if (a != b) parent[std::max(a, b)] = std::min(a, b);
+            }
+            std::vector<uint32_t> size((size_t)NR, 0);
+            for (int64_t i = 0; i < NR; ++i) if (seen[(size_t)i]) ++size[find((uint32_t)i)];
+            size_t h[8] = {0};  // 1-4, 5-8, 9-16, 17-32, 33-64, 65-256, 257+
+            size_t regions_in[8] = {0};
+            for (int64_t i = 0; i < NR; ++i) {
+                const uint32_t z = size[(size_t)i];
+                if (!z) continue;
+                const int b = z <= 4 ? 0 : z <= 8 ? 1 : z <= 16 ? 2 : z <= 32 ? 3 : z <= 64 ? 4 : z <= 256 ? 5 : 6;
+                ++h[b]; regions_in[b] += z;
+            }
+            fprintf(stderr, "[walk] host components by regions: <=4:%zu 5-8:%zu 9-16:%zu 17-32:%zu 33-64:%zu 65-256:%zu 257+:%zu; regions in them: %zu %zu %zu %zu %zu %zu %zu\n",
+                    h[0], h[1], h[2], h[3], h[4], h[5], h[6], regions_in[0], regions_in[1], regions_in[2], regions_in[3], regions_in[4], regions_in[5], regions_in[6]);
+        }
         if (prof) fprintf(stderr, "[walk] total %.1f us, svs %zu\n",
                           std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp0).count(), out.svs.size());
     }

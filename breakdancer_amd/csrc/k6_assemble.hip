@@ -199,6 +199,10 @@ __global__ __launch_bounds__(256) void k6_label_kernel(K6Arrays a) {
         if (lr < ll) atomicMin(&a.label[lo], lr);
         else if (ll < lr) atomicMin(&a.label[r], ll);
     }
+    // pointer jumping: adopt the label of the region this one points at (chains of many regions converge in a few rounds;
+    // whatever has not converged fails k6_classify_kernel's closure check and goes to the host)
+    const uint32_t l = a.label[r], l2 = a.label[l];
+    if (l2 < l) atomicMin(&a.label[r], l2);
 }
 
 // closure check and member registration: a label whose members only have groups among themselves, all inside one
@@ -218,6 +222,7 @@ __global__ __launch_bounds__(256) void k6_classify_kernel(K6Arrays a) {
             if (ll != L) { a.bad[L] = 1u; a.bad[ll] = 1u; }
         }
     const uint32_t slot = atomicAdd(&a.mcount[L], 1u);
+    if (slot < (uint32_t)kK6BigMembers) a.member_ids[(size_t)L * kK6BigMembers + slot] = r;
     if (slot < (uint32_t)kK6MaxMembers) {
         MemberInfo mi;
         mi.r = r;
@@ -362,7 +367,7 @@ namespace {
 
 // is the component with label L walked on the device?  (evaluated identically by every member and by the walk)
 __device__ __forceinline__ bool component_on_device(const K6Arrays& a, uint32_t L) {
-    return !a.force_host && !a.bad[L] && a.mcount[L] <= (uint32_t)kK6MaxMembers &&
+    return !a.force_host && !a.bad[L] && a.mcount[L] <= (uint32_t)(a.big_walk ? kK6BigMembers : kK6MaxMembers) &&
            min((uint32_t)a.nlibs, a.pcount[L]) <= a.lib_stride;
 }
 
@@ -405,16 +410,21 @@ __global__ __launch_bounds__(256) void k6_emit_kernel(K6Arrays a) {
     }
     {   // work list of the walk kernel: the smallest region of every device-walked component
         const bool owner = covered && L == r;
-        const uint32_t o = wave_reserve(owner ? 1u : 0u, &a.counts->n_owners);
-        if (owner) a.owners[o] = r;
+        const bool small = owner && a.mcount[L] <= (uint32_t)kK6MaxMembers;
+        const uint32_t o = wave_reserve(small ? 1u : 0u, &a.counts->n_owners);
+        if (small) a.owners[o] = r;
+        const uint32_t ob = wave_reserve(owner && !small ? 1u : 0u, &a.counts->n_owners_big);
+        if (owner && !small) a.owners_big[ob] = r;
     }
     {   // pairs of all regions; connections: inert ones everywhere, the others where the component is walked on the device
         const uint32_t pairs = active ? s.n_pairs : 0u;
         const uint32_t grp = (active ? s.n_weak : 0u) + (covered ? s.n_in + (s.np_self ? 1u : 0u) : 0u);
-        const uint32_t tp = wave_sum_u32(pairs), tg = wave_sum_u32(grp);
+        const uint32_t gb = (covered && a.mcount[L] > (uint32_t)kK6MaxMembers) ? s.n_in + (s.np_self ? 1u : 0u) : 0u;
+        const uint32_t tp = wave_sum_u32(pairs), tg = wave_sum_u32(grp), tb = wave_sum_u32(gb);
         if (lane == 0) {
             if (tp) atomicAdd(&a.counts->n_pairs, tp);
             if (tg) atomicAdd(&a.counts->n_groups_dev, tg);
+            if (tb) atomicAdd(&a.counts->n_groups_big, tb);
         }
     }
 }
@@ -434,7 +444,153 @@ __global__ __launch_bounds__(64) void k6_mirror_kernel(K6Arrays a) {
 // diverge; the lanes only split up to fetch the component's description (written next to its label by
 // k6_classify_kernel), its parts and its normal-read samples into LDS in one round trip each, and lane 0 stores.
 // The smallest region of a device-walked component replays build_connection over it.
+// order key of a candidate that is placed by key (see K6Arrays)
+constexpr int kKeyShiftT = 34, kKeyShiftStart = 7;
+constexpr uint32_t kKeySeqMask = 127u;
 constexpr int kK6LdsPk = 16;  // 2 x nkeys words per member kept in LDS (more keys: read from HBM)
+
+// The general path of the walk: a component of up to kK6BigMembers (64) regions, its members' records in LDS and the groups
+// found through each member's list of incoming groups instead of a table of all pairs.  Same replay as the main path
+// of k6_walk_kernel below (which keeps the components of up to kK6MaxMembers regions: one coalesced fetch, pair table).
+struct BigTab {
+    uint32_t rid[kK6BigMembers];
+    RegionRec rec[kK6BigMembers];
+    RegSum rs[kK6BigMembers];
+    uint8_t elo[kK6BigMembers][4];   // member index of each incoming group's earlier region
+    int tails[4 * kK6BigMembers], newtails[4 * kK6BigMembers];
+};
+
+__device__ __forceinline__ void walk_big(const K6Arrays& a, BigTab& B, int* flag_counts, uint32_t L, int lane, uint32_t NR) {
+    const int k = (int)a.mcount[L];
+    const int mrp = a.min_read_pair, nk = a.nkeys;
+    const uint32_t period = (uint32_t)a.period;
+    {   // member ids in ascending order: rank by counting (they all differ)
+        const uint32_t id = lane < k ? a.member_ids[(size_t)L * kK6BigMembers + lane] : 0xffffffffu;
+        uint32_t rank = 0;
+        for (int q = 0; q < k; ++q) rank += (uint32_t)__shfl((int)id, q) < id ? 1u : 0u;
+        if (lane < k) B.rid[rank] = id;
+    }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int kRecW = sizeof(RegionRec) / 4, kRsW = sizeof(RegSum) / 4;
+    for (int i = lane; i < k * (kRecW + kRsW); i += 64) {
+        const int m = i / (kRecW + kRsW), wd = i - m * (kRecW + kRsW);
+        const uint32_t r = B.rid[m];
+        if (wd < kRecW) ((uint32_t*)&B.rec[m])[wd] = ((const uint32_t*)&a.r_rec[r])[wd];
+        else ((uint32_t*)&B.rs[m])[wd - kRecW] = ((const uint32_t*)&a.rs[r])[wd - kRecW];
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < k * kK6MaxIn; i += 64) {
+        const int m = i / kK6MaxIn, e = i - m * kK6MaxIn;
+        uint32_t x = 255u;
+        if ((uint32_t)e < B.rs[m].n_in)
+            for (int q = 0; q < m; ++q)
+                if (B.rid[q] == B.rs[m].e_lo[e]) x = (uint32_t)q;  // the closure check guarantees it is a member
+        B.elo[m][e] = (uint8_t)x;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // per-member state as 64-bit masks; a group (earlier region, m) is bit m of the mask of its place e in m's list
+    uint64_t stored = 0, self_alive = 0, self_done = 0;
+    uint64_t ea0 = 0, ea1 = 0, ea2 = 0, ed0 = 0, ed1 = 0, ed2 = 0;  // groups alive / done, by place in the list
+    for (int m = 0; m < k; ++m) {
+        const uint64_t bm = 1ull << m;
+        if (region_stored(B.rec[m], a)) stored |= bm;
+        if (B.rs[m].np_self) self_alive |= bm;
+        const uint32_t ni = B.rs[m].n_in;
+        if (ni > 0 && B.rs[m].e_cnt[0] && B.elo[m][0] != 255u) ea0 |= bm;
+        if (ni > 1 && B.rs[m].e_cnt[1] && B.elo[m][1] != 255u) ea1 |= bm;
+        if (ni > 2 && B.rs[m].e_cnt[2] && B.elo[m][2] != 255u) ea2 |= bm;
+    }
+    const GrpRange none{0, 0};
+    int* const tails = B.tails;
+    int* const newtails = B.newtails;
+    for (int f = 0; f < k;) {
+        const uint32_t W = B.rid[f] / period;
+        int fe = f + 1;
+        while (fe < k && B.rid[fe] / period == W) ++fe;
+        const uint32_t rl = (W + 1) * period - 1;
+        const int max_readlen = rl < NR ? a.r_rec[rl].maxq : a.counts->last_maxq;
+        uint64_t visited = 0;
+        uint32_t nseq = 0;
+        for (int sv = 0; sv < fe; ++sv) {
+            if (visited & (1ull << sv)) continue;
+            const bool from_old = sv < f;
+            const uint32_t start = B.rid[sv];
+            uint32_t nsv = 0, nacc_tot = 0, ncn_tot = 0, prev_slot = 0;
+            int nt = 1, nn = 0;
+            tails[0] = sv;
+            while (nt) {
+                nn = 0;
+                for (int ti = 0; ti < nt; ++ti) {
+                    const int tail = tails[ti];
+                    if (visited & (1ull << tail)) continue;
+                    for (int nb = 0; nb < fe; ++nb) {  // neighbours in ascending order, the vertex itself at its own place
+                        int A, Bm, eidx = -1;
+                        uint32_t slot;
+                        if (nb == tail) {
+                            if (tail < f) continue;  // its self group belonged to an earlier flush
+                            if (!B.rs[tail].np_self || (self_done & (1ull << tail)) || (int)B.rs[tail].w_self < mrp) continue;
+                            self_done |= 1ull << tail;
+                            A = tail; Bm = -1;
+                            slot = B.rec[tail].first + B.rs[tail].n_in;
+                        } else {
+                            const int x = min(nb, tail), y = max(nb, tail);
+                            if (y < f) continue;     // a group of an earlier flush
+                            for (uint32_t e = 0; e < B.rs[y].n_in; ++e)
+                                if (B.elo[y][e] == (uint8_t)x) eidx = (int)e;
+                            if (eidx < 0) continue;
+                            const uint64_t bit = 1ull << y;
+                            const uint64_t done = eidx == 0 ? ed0 : (eidx == 1 ? ed1 : ed2);
+                            if ((done & bit) || (int)B.rs[y].e_w[eidx] < mrp) continue;
+                            if (eidx == 0) ed0 |= bit; else if (eidx == 1) ed1 |= bit; else ed2 |= bit;
+                            A = x; Bm = y;
+                            slot = B.rec[y].first + (uint32_t)eidx;
+                        }
+                        if (nn < 4 * kK6BigMembers) newtails[nn++] = nb;
+                        const int Bi = Bm >= 0 ? Bm : A;
+                        GrpRange gs[3] = {none, none, none};
+                        const bool stA = (stored >> A) & 1ull, stB = (stored >> Bi) & 1ull;
+                        if ((self_alive & (1ull << A)) && stA) gs[0] = GrpRange{B.rec[A].first + B.rs[A].np_all - B.rs[A].np_self, B.rs[A].np_self};
+                        if (Bm >= 0) {
+                            const uint64_t bit = 1ull << Bm;
+                            const uint64_t alive = eidx == 0 ? ea0 : (eidx == 1 ? ea1 : ea2);
+                            if ((alive & bit) && stA && stB) gs[1] = GrpRange{B.rec[Bm].first + B.rs[Bm].e_off[eidx], B.rs[Bm].e_cnt[eidx]};
+                            if ((self_alive & bit) && stB) gs[2] = GrpRange{B.rec[Bm].first + B.rs[Bm].np_all - B.rs[Bm].np_self, B.rs[Bm].np_self};
+                            if (gs[1].cnt) { if (eidx == 0) ea0 &= ~bit; else if (eidx == 1) ea1 &= ~bit; else ea2 &= ~bit; }
+                        }
+                        // paired reads leave their regions before any gate (BreakDancer.cpp:363-368)
+                        if (gs[0].cnt) self_alive &= ~(1ull << A);
+                        if (gs[2].cnt) self_alive &= ~(1ull << Bm);
+                        const uint32_t* pkA = a.r_pk + (size_t)B.rid[A] * 2 * nk + nk;
+                        const uint32_t* pkB = a.r_pk + (size_t)B.rid[Bi] * 2 * nk;
+                        uint32_t nacc = 0, ncn = 0;
+                        if (assemble_sv(a, a.parts, B.rid[A], Bm >= 0 ? (int32_t)B.rid[Bm] : -1, B.rec[A], B.rec[Bi], pkA, pkB, gs, max_readlen, slot,
+                                        start, lane == 0, flag_counts, &nacc, &ncn)) {
+                            if (from_old) {
+                                if (lane == 0) {
+                                    const uint32_t q = atomicAdd(&a.counts->n_old, 1u);
+                                    a.old_key[q] = ((uint64_t)(W * period) << kKeyShiftT) | ((uint64_t)start << kKeyShiftStart) | (uint64_t)(nseq & kKeySeqMask);
+                                    a.old_slot[q] = slot;
+                                }
+                                ++nseq;
+                            } else if (lane == 0) {
+                                if (nsv == 0) a.own_first[start] = slot; else a.slot_next[prev_slot] = slot;
+                            }
+                            prev_slot = slot;
+                            ++nsv;
+                            nacc_tot += nacc;
+                            ncn_tot += ncn;
+                        }
+                    }
+                    visited |= 1ull << tail;
+                }
+                nt = nn;
+                for (int i = 0; i < nn; ++i) tails[i] = newtails[i];
+            }
+            if (!from_old && nsv && lane == 0) { a.own_nsv[start] = nsv; a.own_nacc[start] = nacc_tot; a.own_ncn[start] = ncn_tot; }
+        }
+        f = fe;
+    }
+}
 
 __global__ __launch_bounds__(256) void k6_walk_kernel(K6Arrays a) {
     __shared__ uint32_t s_desc[4][kK6MaxMembers * kMemberWords];
@@ -549,7 +705,7 @@ __global__ __launch_bounds__(256) void k6_walk_kernel(K6Arrays a) {
                 if (visited & (1u << sv)) continue;
                 const bool from_old = sv < f;
                 const uint32_t start = D[ord[sv]].r;
-                uint32_t nsv = 0, nacc_tot = 0, ncn_tot = 0;
+                uint32_t nsv = 0, nacc_tot = 0, ncn_tot = 0, prev_slot = 0;
                 int nt = 1, nn = 0;
                 tails[0] = sv;
                 while (nt) {
@@ -591,19 +747,19 @@ __global__ __launch_bounds__(256) void k6_walk_kernel(K6Arrays a) {
                             const uint32_t* pkA = pk_lds ? &s_pk[w][A * kK6LdsPk + nk] : a.r_pk + (size_t)MA.r * 2 * nk + nk;
                             const uint32_t* pkB = pk_lds ? &s_pk[w][(B >= 0 ? B : A) * kK6LdsPk] : a.r_pk + (size_t)MB.r * 2 * nk;
                             uint32_t nacc = 0, ncn = 0;
-                            if (nsv < (uint32_t)kK6MaxSv &&
-                                assemble_sv(a, P, MA.r, B >= 0 ? (int32_t)MB.r : -1, MA.rec, MB.rec, pkA, pkB, gs, max_readlen, slot, start,
+                            if (assemble_sv(a, P, MA.r, B >= 0 ? (int32_t)MB.r : -1, MA.rec, MB.rec, pkA, pkB, gs, max_readlen, slot, start,
                                             lane == 0, T.flag_counts, &nacc, &ncn)) {
                                 if (from_old) {  // placed by its order key: after the earlier windows, before this window's own
                                     if (lane == 0) {
                                         const uint32_t q = atomicAdd(&a.counts->n_old, 1u);
-                                        a.old_key[q] = ((uint64_t)(W * period) << 31) | ((uint64_t)start << 4) | (uint64_t)(nseq & 15u);
+                                        a.old_key[q] = ((uint64_t)(W * period) << kKeyShiftT) | ((uint64_t)start << kKeyShiftStart) | (uint64_t)(nseq & kKeySeqMask);
                                         a.old_slot[q] = slot;
                                     }
                                     ++nseq;
                                 } else if (lane == 0) {
-                                    a.own_slots[(size_t)start * kK6MaxSv + nsv] = slot;
+                                    if (nsv == 0) a.own_first[start] = slot; else a.slot_next[prev_slot] = slot;
                                 }
+                                prev_slot = slot;
                                 ++nsv;
                                 nacc_tot += nacc;
                                 ncn_tot += ncn;
@@ -619,6 +775,19 @@ __global__ __launch_bounds__(256) void k6_walk_kernel(K6Arrays a) {
             f = fe;
         }
         __builtin_amdgcn_wave_barrier();  // the LDS slices are reused by the wave's next region
+    }
+}
+
+// the components of more than kK6MaxMembers regions (its own launch: inside the kernel above its registers and LDS
+// would cost the common case a third of its occupancy)
+__global__ __launch_bounds__(256) void k6_walk_big_kernel(K6Arrays a) {
+    __shared__ BigTab s_big[4];
+    __shared__ int s_flag_counts[4][kNumFlags];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t NR = a.counts->n_regions, n = a.counts->n_owners_big;
+    for (uint32_t oi = blockIdx.x * 4 + w; oi < n; oi += gridDim.x * 4) {
+        walk_big(a, s_big[w], s_flag_counts[w], a.owners_big[oi], lane, NR);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -704,7 +873,7 @@ __device__ void InsertJob::operator()() const {
         __syncthreads();
         if (tid < nd) {
             const uint32_t pos = rank + count_below64(hk, nh, key);
-            a.ins_T[pos] = (uint32_t)(key >> 31);
+            a.ins_T[pos] = (uint32_t)(key >> kKeyShiftT);
             a.ins_src[pos] = slot;
             if (small) s_cnt[pos] = my_cnt;
             else { a.ins_pre_l[pos] = my_cnt & 0xffffu; a.ins_pre_c[pos] = my_cnt >> 16; }
@@ -738,7 +907,7 @@ __device__ void InsertJob::operator()() const {
             const uint64_t key = dk[d];
             const uint32_t pos = d + count_below64(hk, nh, key), slot = dv[d];
             const uint32_t cnt = (uint32_t)a.sv_stage[slot].sv.lib_count | ((uint32_t)a.sv_stage[slot].sv.cn_count << 16);
-            a.ins_T[pos] = (uint32_t)(key >> 31);
+            a.ins_T[pos] = (uint32_t)(key >> kKeyShiftT);
             a.ins_src[pos] = slot;
             if (small) s_cnt[pos] = cnt;
             else { a.ins_pre_l[pos] = cnt & 0xffffu; a.ins_pre_c[pos] = cnt >> 16; }
@@ -747,7 +916,7 @@ __device__ void InsertJob::operator()() const {
     for (uint32_t j = tid; j < nh; j += kThreads) {
         const uint64_t key = hk[j];
         const uint32_t pos = j + count_below64(dk, nd, key), cnt = a.hs_cnt[j];
-        a.ins_T[pos] = (uint32_t)(key >> 31);
+        a.ins_T[pos] = (uint32_t)(key >> kKeyShiftT);
         a.ins_src[pos] = 0x80000000u | j;
         if (small) s_cnt[pos] = cnt;
         else { a.ins_pre_l[pos] = cnt & 0xffffu; a.ins_pre_c[pos] = cnt >> 16; }
@@ -860,8 +1029,8 @@ struct OwnOut {
             a.sv_begin[pos] = make_uint2(lb, cb);
         }
         uint32_t d = ex_sv + hb1, lb = ex_l + a.ins_pre_l[hb1], cb = ex_c + a.ins_pre_c[hb1];
-        for (uint32_t q = 0; q < e.x; ++q) {
-            const uint32_t slot = a.own_slots[(size_t)i * kK6MaxSv + q];
+        uint32_t slot = e.x ? a.own_first[i] : 0u;
+        for (uint32_t q = 0; q < e.x; ++q, slot = a.slot_next[slot]) {
             const int32_t nl = a.sv_stage[slot].sv.lib_count, ncn = a.sv_stage[slot].sv.cn_count;
             put_staged(d, lb, cb, slot, nl, ncn);
             lb += (uint32_t)nl;
@@ -960,6 +1129,7 @@ void launch_k6_walk(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
     if (n_anom_host == 0 || a.force_host) return;
     const uint32_t gp = std::min<uint32_t>((n_anom_host / 8 + 3) / 4 + 1, 16384u);
     hipLaunchKernelGGL(k6_walk_kernel, dim3(gp), dim3(256), 0, s, a);
+    if (a.big_walk) hipLaunchKernelGGL(k6_walk_big_kernel, dim3(gp / 8 + 1), dim3(256), 0, s, a);
 }
 
 void launch_k6_score(const K6Arrays& a, double ln10, int score_threshold, int with_scores, hipStream_t s) {

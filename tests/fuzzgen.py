@@ -104,9 +104,9 @@ OPTION_SETS = [dict(), dict(cn_lib=1, print_af=1), dict(print_af=1), dict(transc
                dict(transchr_rearrange=1, min_read_pair=1)]
 
 
-def make_graph_case(seed, n_slots=240):
+def make_graph_case(seed, n_slots=240, sizes=(1, 2, 2, 3, 3, 3, 4, 4, 5)):
     """Many small, separate components of the region graph with every shape the walk distinguishes: "slots" 3 kb apart
-    (far beyond the window) each become one region; groups of 1-5 consecutive slots get random connections of 1-4 pairs
+    (far beyond the window) each become one region; groups of 1-5 (or `sizes`) consecutive slots get random connections of 1-4 pairs
     (around the -r gate), random self groups, mixed flags / libraries, some reaching into the other contig (CTX).
     Returns (config, streams, targets) like make_case."""
     rng = np.random.default_rng(10_000 + seed)
@@ -158,7 +158,7 @@ def make_graph_case(seed, n_slots=240):
     kinds = ["fr", "ff", "rr", "rf"]
     s = 0
     while s < n_slots:
-        k = int(rng.choice([1, 2, 2, 3, 3, 3, 4, 4, 5]))
+        k = int(rng.choice(list(sizes)))
         members = list(range(s, min(s + k, n_slots)))
         for a in members:  # self groups
             if rng.random() < 0.5:
@@ -166,7 +166,7 @@ def make_graph_case(seed, n_slots=240):
                     add_pair(a, a, str(rng.choice(["small", "ff", "rf"])), int(rng.integers(0, 2)))
         for i, a in enumerate(members):  # connections
             for b in members[i + 1:]:
-                if rng.random() < (0.9 if b == a + 1 else 0.35):
+                if rng.random() < (0.9 if b == a + 1 else (0.35 if k <= 5 else 0.1)):
                     kind = str(rng.choice(kinds))
                     for _ in range(int(rng.integers(1, 5))):
                         add_pair(a, b, kind if rng.random() < 0.8 else str(rng.choice(kinds)), int(rng.integers(0, 2)))

@@ -282,6 +282,28 @@ def test_small_component_graphs(seed):
     bh.close()
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_medium_component_graphs(seed, monkeypatch):
+    """components of 1-66 regions with the general device walk (member lists instead of a pair table, up to 64
+    regions; BDX_BIG_WALK=1 turns it on whatever the input size) against the oracle, support lists included"""
+    from fuzzgen import GRAPH_OPTION_SETS, make_graph_case
+    monkeypatch.setenv("BDX_BIG_WALK", "1")
+    cfg, streams, targets = make_graph_case(100 + seed, n_slots=400, sizes=(1, 3, 5, 6, 8, 10, 14, 20, 30, 45, 66))
+    o = GRAPH_OPTION_SETS[seed % len(GRAPH_OPTION_SETS)]
+    run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1, **o))
+    bd = product_from_oracle(run, support=True)
+    compare(run, bd)
+    compare_support(run, bd)
+    n_dev, n_host, _ = bd.walk_split()
+    assert n_dev + n_host == run.n_svs, (n_dev, n_host)
+    bd.close()
+    monkeypatch.setenv("BDX_BIG_WALK", "0")
+    bs = product_from_oracle(run)
+    compare(run, bs)
+    assert bs.walk_split()[0] <= n_dev  # without the general walk those components go to the host
+    bs.close()
+
+
 def test_sv_table_larger_than_one_pass_of_the_score_kernel():
     """several hundred thousand SV candidates (tiny clusters of two pairs): the kernels that are launched with a capped
     grid have to stride over the whole table (the score kernel once wrote only its first 131072 records)"""

@@ -11,7 +11,8 @@ from runner import compare, compare_support, oracle_case, product_from_oracle
 a, b = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
 for seed in range(a, b):
-    for gen, sets, tag in ((make_graph_case, GRAPH_OPTION_SETS, "graph"), (make_case, OPTION_SETS, "dense")):
+    for gen, sets, tag in ((make_graph_case, GRAPH_OPTION_SETS, "graph"), (make_case, OPTION_SETS, "dense"),
+                           (lambda sd: make_graph_case(sd, n_slots=400, sizes=(1, 3, 5, 6, 8, 10, 14, 20, 30, 45, 66)), GRAPH_OPTION_SETS, "medium")):
         cfg, streams, targets = gen(seed)
         o = sets[(seed * 5 + 1) % len(sets)]
         run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1, **o))
