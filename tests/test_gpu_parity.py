@@ -282,6 +282,29 @@ def test_small_component_graphs(seed):
     bh.close()
 
 
+def test_long_insertion_list_from_both_walks(monkeypatch):
+    """dense chains of clusters with one region per flush window: thousands of order-key candidates from the device AND
+    tens of thousands from the host walk -- the insertion list's merge beyond its LDS tiles on both sides"""
+    monkeypatch.setenv("BDX_BIG_WALK", "0")
+    cfg, st = _synth_case(12_000_000, seed=37, discordant=0.08, cluster=3)
+    run = OracleRun(cfg, make_opts(buffer_size=0, min_read_pair=2))
+    run.set_targets(["chrS"])
+    st = dict(st)
+    st["lib"] = np.zeros(len(st["tid"]), np.int32)
+    run.set_stream(0, st)
+    run.run()
+    bd = product_from_oracle(run)
+    compare(run, bd)
+    n_dev, n_host, _ = bd.walk_split()
+    assert bd.cross_window_svs() > 2048 and n_host > 2048, (bd.cross_window_svs(), n_dev, n_host)
+    bd.close()
+    monkeypatch.setenv("BDX_BIG_WALK", "1")  # the same with the general device walk taking most of the host's share
+    bb = product_from_oracle(run)
+    compare(run, bb)
+    assert bb.walk_split()[1] < n_host
+    bb.close()
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_medium_component_graphs(seed, monkeypatch):
     """components of 1-66 regions with the general device walk (member lists instead of a pair table, up to 64
