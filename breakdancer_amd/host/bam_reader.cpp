@@ -1,7 +1,14 @@
 #include "bam_reader.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <thread>
@@ -10,8 +17,18 @@ namespace bdhost {
 
 namespace {
 
-constexpr size_t kReadChunk = 32u << 20;   // compressed bytes fetched per read()
-constexpr size_t kMaxBlocksPerFill = 2048;  // <= 128 MiB decompressed per fill
+constexpr size_t kMaxBlocksPerFillDefault = 2048;  // <= 128 MiB decompressed per fill
+constexpr size_t kSegBytesDefault = 2u << 20;      // decompressed bytes per decode thread, at least
+
+// test knobs: BDX_BAM_FILL_BLOCKS / BDX_BAM_SEG_BYTES shrink the batches / the decode segments so that small files go
+// through many batch hand-overs and many guessed record boundaries
+size_t env_or(const char* name, size_t dflt) {
+    const char* v = getenv(name);
+    const long long x = v ? atoll(v) : 0;
+    return x > 0 ? (size_t)x : dflt;
+}
+const size_t kMaxBlocksPerFill = env_or("BDX_BAM_FILL_BLOCKS", kMaxBlocksPerFillDefault);
+const size_t kSegBytes = env_or("BDX_BAM_SEG_BYTES", kSegBytesDefault);
 
 inline uint32_t le32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 inline uint16_t le16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
@@ -68,8 +85,20 @@ void BamReader::Chunk::reserve(size_t n) {
 }
 
 BamReader::BamReader(const std::string& path, int threads) : path_(path), threads_(threads < 1 ? 1 : threads) {
-    fp_ = fopen(path.c_str(), "rb");
-    if (!fp_) throw std::runtime_error("Failed to open samfile " + path);
+    {
+        const int fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error("Failed to open samfile " + path);
+        struct stat st;
+        if (fstat(fd, &st) != 0) { close(fd); throw std::runtime_error("Failed to open samfile " + path); }
+        map_size_ = (size_t)st.st_size;
+        if (map_size_) {
+            void* m = mmap(nullptr, map_size_, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { close(fd); throw std::runtime_error("Failed to map samfile " + path); }
+            map_ = (const uint8_t*)m;
+            madvise(m, map_size_, MADV_SEQUENTIAL);
+        }
+        close(fd);
+    }
     if (!ensure(12) || memcmp(at(), "BAM\1", 4) != 0) throw std::runtime_error(path + " is not a valid bam file");
     const uint32_t l_text = le32(at() + 4);
     cur_ += 8;
@@ -85,13 +114,23 @@ BamReader::BamReader(const std::string& path, int threads) : path_(path), thread
         targets_.emplace_back((const char*)at() + 4, l ? l - 1 : 0);
         cur_ += 4 + l + 4;
     }
+    // the records follow: decode the rest of this batch now, and let the helper thread prepare the next one
+    records_mode_ = true;
+    Chunk& c = chunk_[cur_chunk_];
+    c.beg = cur_;
+    c.end = end_;
+    parse_chunk(c);
+    part_ = rec_ = 0;
+    const Chunk* cur = &c;
+    const int other = cur_chunk_ ^ 1;
+    next_ready_ = std::async(std::launch::async, [this, other, cur] { return fill_and_parse(chunk_[other], cur); });
 }
 
 BamReader::~BamReader() {
     if (next_ready_.valid()) {
         try { next_ready_.get(); } catch (...) {}
     }
-    if (fp_) fclose(fp_);
+    if (map_) munmap((void*)map_, map_size_);
 }
 
 int BamReader::tid_of(const std::string& name) const {
@@ -103,54 +142,42 @@ int BamReader::tid_of(const std::string& name) const {
 bool BamReader::fill(Chunk& c) {
     std::vector<Block> blocks;
     size_t uoff = kFrontGap;
-    while (true) {
-        if (!eof_ && comp_.size() - comp_off_ < (size_t)(128u << 10)) {  // top up the compressed window
-            comp_.erase(comp_.begin(), comp_.begin() + comp_off_);
-            comp_off_ = 0;
-            const size_t old = comp_.size();
-            comp_.resize(old + kReadChunk);
-            const size_t got = fread(comp_.data() + old, 1, kReadChunk, fp_);
-            comp_.resize(old + got);
-            if (got < kReadChunk) eof_ = true;
+    // the compressed file is mapped, not read: the inflate threads take their input straight from the page cache
+    while (blocks.size() < kMaxBlocksPerFill) {
+        const size_t avail = map_size_ - comp_off_;
+        if (avail == 0) break;
+        if (avail < 18) throw std::runtime_error("truncated BGZF file: " + path_);
+        const uint8_t* h = map_ + comp_off_;
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) throw std::runtime_error("not a BGZF file: " + path_);
+        const uint16_t xlen = le16(h + 10);
+        if (avail < (size_t)12 + xlen) throw std::runtime_error("truncated BGZF file: " + path_);
+        int bsize = -1;
+        for (size_t x = 12; x + 4 <= (size_t)12 + xlen;) {
+            const uint16_t slen = le16(h + x + 2);
+            if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2) bsize = le16(h + x + 4);
+            x += 4 + (size_t)slen;
         }
-        while (blocks.size() < kMaxBlocksPerFill) {
-            const size_t avail = comp_.size() - comp_off_;
-            if (avail < 18) break;
-            const uint8_t* h = comp_.data() + comp_off_;
-            if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) throw std::runtime_error("not a BGZF file: " + path_);
-            const uint16_t xlen = le16(h + 10);
-            if (avail < (size_t)12 + xlen) break;
-            int bsize = -1;
-            for (size_t x = 12; x + 4 <= (size_t)12 + xlen;) {
-                const uint16_t slen = le16(h + x + 2);
-                if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2) bsize = le16(h + x + 4);
-                x += 4 + (size_t)slen;
-            }
-            if (bsize < 0) throw std::runtime_error("BGZF block without BC field: " + path_);
-            const size_t total = (size_t)bsize + 1;
-            if (avail < total) break;
-            const uint32_t isize = le32(h + total - 4);
-            Block b;
-            b.coff = comp_off_ + 12 + xlen;
-            b.clen = total - 12 - xlen - 8;
-            b.uoff = uoff;
-            b.ulen = isize;
-            uoff += isize;
-            comp_off_ += total;
-            if (isize) blocks.push_back(b);
-        }
-        if (!blocks.empty()) break;
-        if (eof_) {
-            if (comp_.size() - comp_off_ != 0) throw std::runtime_error("truncated BGZF file: " + path_);
-            return false;
-        }
+        if (bsize < 0) throw std::runtime_error("BGZF block without BC field: " + path_);
+        const size_t total = (size_t)bsize + 1;
+        if (avail < total || total < (size_t)12 + xlen + 8) throw std::runtime_error("truncated BGZF file: " + path_);
+        const uint32_t isize = le32(h + total - 4);
+        Block b;
+        b.coff = comp_off_ + 12 + xlen;
+        b.clen = total - 12 - xlen - 8;
+        b.uoff = uoff;
+        b.ulen = isize;
+        uoff += isize;
+        comp_off_ += total;
+        if (isize) blocks.push_back(b);
     }
+    if (blocks.empty()) return false;
+    const uint8_t* comp = map_;
     c.beg = c.end = 0;
     c.reserve(std::max(uoff, kFrontGap + (size_t)40 * 1024 * 1024));  // sized once: fresh pages under eight writers are slow
     uint8_t* out = c.data.get();
     const int nt = (int)std::min<size_t>((size_t)threads_, blocks.size());
     if (nt <= 1) {
-        for (const Block& b : blocks) inflate_block(comp_.data() + b.coff, b.clen, out + b.uoff, b.ulen);
+        for (const Block& b : blocks) inflate_block(comp + b.coff, b.clen, out + b.uoff, b.ulen);
     } else {
         std::vector<std::thread> th;
         std::vector<std::string> errs(nt);
@@ -158,7 +185,7 @@ bool BamReader::fill(Chunk& c) {
             th.emplace_back([&, t] {
                 try {
                     for (size_t i = (size_t)t; i < blocks.size(); i += (size_t)nt)
-                        inflate_block(comp_.data() + blocks[i].coff, blocks[i].clen, out + blocks[i].uoff, blocks[i].ulen);
+                        inflate_block(comp + blocks[i].coff, blocks[i].clen, out + blocks[i].uoff, blocks[i].ulen);
                 } catch (std::exception const& e) { errs[t] = e.what(); }
             });
         for (auto& x : th) x.join();
@@ -170,40 +197,31 @@ bool BamReader::fill(Chunk& c) {
     return true;
 }
 
-// The batch after the current one is inflated on a helper thread while the caller parses; here the caller takes it over
-// (moving its unparsed tail into the gap in front of the new batch) and starts the one after it.
-bool BamReader::advance() {
-    if (!started_) {
-        started_ = true;
-        next_ready_ = std::async(std::launch::async, [this] { return fill(chunk_[0]); });
-        cur_chunk_ = 1;  // (so that the first take-over lands on chunk 0)
+void BamReader::attach_tail(Chunk& n, const uint8_t* src, size_t tail) {
+    if (!tail) return;
+    if (tail <= n.beg) {
+        memcpy(n.data.get() + n.beg - tail, src, tail);
+        n.beg -= tail;
+    } else {  // a tail longer than the gap (a record of several MiB): make room the slow way
+        std::unique_ptr<uint8_t[]> nd(new uint8_t[tail + (n.end - n.beg) + kFrontGap]);
+        memcpy(nd.get() + kFrontGap, src, tail);
+        memcpy(nd.get() + kFrontGap + tail, n.data.get() + n.beg, n.end - n.beg);
+        n.cap = tail + (n.end - n.beg) + kFrontGap;
+        n.end = kFrontGap + tail + (n.end - n.beg);
+        n.beg = kFrontGap;
+        n.data = std::move(nd);
     }
-    if (!next_ready_.valid()) return false;
-    const bool got = next_ready_.get();
-    if (!got) return false;
+}
+
+// Header mode (constructor): the next batch is inflated synchronously, the unread bytes of the current one go in front.
+bool BamReader::advance() {
     const int nxt = cur_chunk_ ^ 1;
     Chunk& n = chunk_[nxt];
-    const size_t tail = end_ - cur_;
-    if (tail) {
-        const uint8_t* src = chunk_[cur_chunk_].data.get() + cur_;
-        if (tail <= n.beg) {
-            memcpy(n.data.get() + n.beg - tail, src, tail);
-            n.beg -= tail;
-        } else {  // a tail longer than the gap (a record of several MiB): make room the slow way
-            std::unique_ptr<uint8_t[]> nd(new uint8_t[tail + (n.end - n.beg) + kFrontGap]);
-            memcpy(nd.get() + kFrontGap, src, tail);
-            memcpy(nd.get() + kFrontGap + tail, n.data.get() + n.beg, n.end - n.beg);
-            n.cap = tail + (n.end - n.beg) + kFrontGap;
-            n.end = kFrontGap + tail + (n.end - n.beg);
-            n.beg = kFrontGap;
-            n.data = std::move(nd);
-        }
-    }
-    const int prev = cur_chunk_;
+    if (!fill(n)) return false;
+    if (end_ > cur_) attach_tail(n, chunk_[cur_chunk_].data.get() + cur_, end_ - cur_);
     cur_chunk_ = nxt;
     cur_ = n.beg;
     end_ = n.end;
-    next_ready_ = std::async(std::launch::async, [this, prev] { return fill(chunk_[prev]); });
     return true;
 }
 
@@ -213,24 +231,169 @@ bool BamReader::ensure(size_t need) {
     return true;
 }
 
-bool BamReader::next(BamRecord& r) {
-    if (!ensure(4)) return false;
-    const uint32_t bs = le32(at());
-    if (!ensure((size_t)4 + bs)) throw std::runtime_error("truncated BAM record in " + path_);
-    {   // The batch was just written by the inflate threads on other cores: every record starts on cold lines, and the next
-        // record's address is only known from this one's size.  Neighbouring records have similar sizes, so the lines
-        // where the next few records should start are requested now (a wrong guess costs nothing).
-        const uint8_t* p = at();
-        const size_t step = (size_t)4 + bs;
-        if (cur_ + 5 * step + 128 < end_) {
-            __builtin_prefetch(p + step); __builtin_prefetch(p + step + 64);
-            __builtin_prefetch(p + 2 * step); __builtin_prefetch(p + 2 * step + 64);
-            __builtin_prefetch(p + 3 * step); __builtin_prefetch(p + 4 * step);
-        }
-    }
-    parse_record(at(), r);
-    cur_ += 4 + bs;
+namespace {
+
+// Does a BAM record start at data[pos]?  Field ranges, the size equation and the read name have to fit; `next` receives
+// the position right after it.
+bool plausible_record(const uint8_t* data, size_t pos, size_t end, int32_t n_targets, size_t* next) {
+    if (pos + 36 > end) return false;
+    const uint8_t* p = data + pos;
+    const uint32_t bs = le32(p);
+    if (bs < 32 || bs > (1u << 26)) return false;
+    const int32_t tid = (int32_t)le32(p + 4), rpos = (int32_t)le32(p + 8);
+    const uint32_t l_name = p[12], n_cigar = le16(p + 16);
+    const int32_t l_seq = (int32_t)le32(p + 20), mtid = (int32_t)le32(p + 24), mpos = (int32_t)le32(p + 28);
+    if (tid < -1 || tid >= n_targets || mtid < -1 || mtid >= n_targets || rpos < -1 || mpos < -1 || l_seq < 0 || l_name < 1) return false;
+    const uint64_t need = 32ull + l_name + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq;
+    if (need > bs) return false;
+    if (pos + 36 + l_name > end) return false;
+    const uint8_t* nm = p + 36;
+    if (nm[l_name - 1] != 0) return false;
+    for (uint32_t i = 0; i + 1 < l_name; ++i)
+        if (nm[i] < 33 || nm[i] > 126) return false;
+    *next = pos + 4 + (size_t)bs;
     return true;
+}
+
+// first position in [from, seg_end) where three records in a row look valid; seg_end if there is none
+size_t guess_record_start(const uint8_t* data, size_t from, size_t seg_end, size_t end, int32_t n_targets) {
+    for (size_t pos = from; pos < seg_end; ++pos) {
+        size_t a, b, c;
+        if (plausible_record(data, pos, end, n_targets, &a) && plausible_record(data, a, end, n_targets, &b) &&
+            plausible_record(data, b, end, n_targets, &c))
+            return pos;
+    }
+    return seg_end;
+}
+
+// decode the records that start in [start, seg_end) and are complete before `end`; returns where it stopped.  `trusted`:
+// start is a known record boundary, so a record that does not add up means a corrupt file (otherwise: a wrong guess)
+size_t parse_range(const uint8_t* data, size_t start, size_t seg_end, size_t end, bool trusted, const std::string& path,
+                   std::vector<BamRecord>& out) {
+    size_t pos = start;
+    while (pos < seg_end) {
+        if (pos + 4 > end) break;
+        const uint8_t* p = data + pos;
+        const uint32_t bs = le32(p);
+        if (pos + 4 + (size_t)bs > end) {
+            if (trusted && bs > (1u << 30)) throw std::runtime_error("corrupt BAM record in " + path);
+            break;  // incomplete: the rest of it comes with the next batch
+        }
+        bool ok = bs >= 32;
+        if (ok) {
+            const uint32_t l_name = p[12], n_cigar = le16(p + 16);
+            const int32_t l_seq = (int32_t)le32(p + 20);
+            ok = l_seq >= 0 && 32ull + l_name + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq <= bs;
+        }
+        if (!ok) {
+            if (trusted) throw std::runtime_error("corrupt BAM record in " + path);
+            break;
+        }
+        out.emplace_back();
+        BamRecord& r = out.back();
+        BamReader::parse_record(p, r);
+        r.name_key = hash_name(r.qname, r.l_qname);
+        r.rg_key = r.rg ? (hash_name(r.rg, r.l_rg) | 1ull) : 0ull;
+        pos += 4 + (size_t)bs;
+    }
+    return pos;
+}
+
+}  // namespace
+
+// Every complete record of the batch, decoded by several threads.  A record's position is only known from the sizes of
+// all records before it, so every thread but the first GUESSES where the first record of its segment starts (three
+// records in a row whose fields, size equation and read name fit) and decodes from there; afterwards the guesses are
+// checked against the chain of true boundaries, and a segment whose guess was wrong is decoded again from the right place.
+void BamReader::parse_chunk(Chunk& c) {
+    const uint8_t* data = c.data.get();
+    const size_t n = c.end - c.beg;
+    int P = (int)std::min<size_t>({(size_t)std::max(1, threads_), (size_t)16, n / kSegBytes + 1});
+    if ((int)c.parts.size() < P) c.parts.resize(P);
+    for (auto& v : c.parts) v.clear();
+    std::vector<size_t> seg(P + 1), start(P), stop(P);
+    for (int i = 0; i <= P; ++i) seg[i] = c.beg + n * (size_t)i / (size_t)P;
+    const int32_t nt = (int32_t)targets_.size();
+    std::vector<std::string> errs(P);
+    auto work = [&](int i) {
+        try {
+            c.parts[i].reserve((seg[i + 1] - seg[i]) / 160 + 16);
+            start[i] = i == 0 ? c.beg : guess_record_start(data, seg[i], seg[i + 1], c.end, nt);
+            stop[i] = parse_range(data, start[i], seg[i + 1], c.end, i == 0, path_, c.parts[i]);
+        } catch (std::exception const& e) { errs[i] = e.what(); }
+    };
+    if (P == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int i = 1; i < P; ++i) th.emplace_back(work, i);
+        work(0);
+        for (auto& t : th) t.join();
+    }
+    for (auto& e : errs)
+        if (!e.empty()) throw std::runtime_error(e);
+    size_t pos = stop[0];
+    for (int i = 1; i < P; ++i) {
+        if (pos >= seg[i + 1]) { c.parts[i].clear(); continue; }  // the record that began earlier covers the whole segment
+        if (start[i] == pos) { pos = stop[i]; continue; }
+        c.parts[i].clear();                                        // wrong guess: decode the segment from the true boundary
+        pos = parse_range(data, pos, seg[i + 1], c.end, true, path_, c.parts[i]);
+    }
+    c.tail = pos;
+}
+
+bool BamReader::fill_and_parse(Chunk& c, const Chunk* prev) {
+    static const bool prof = getenv("BDX_BAM_PROFILE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!fill(c)) {
+        if (prev && prev->end > prev->tail) throw std::runtime_error("truncated BAM record in " + path_);
+        return false;
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    if (prev && prev->end > prev->tail) attach_tail(c, prev->data.get() + prev->tail, prev->end - prev->tail);
+    parse_chunk(c);
+    if (prof) {
+        const auto t2 = std::chrono::steady_clock::now();
+        size_t nrec = 0;
+        for (auto const& v : c.parts) nrec += v.size();
+        fprintf(stderr, "[bam] batch: inflate %.1f ms (%zu bytes), decode %.1f ms (%zu records, %zu parts)\n",
+                std::chrono::duration<double, std::milli>(t1 - t0).count(), c.end - c.beg,
+                std::chrono::duration<double, std::milli>(t2 - t1).count(), nrec, c.parts.size());
+    }
+    return true;
+}
+
+// Record mode: the batch after the current one is inflated AND decoded on a helper thread while the caller consumes the
+// current one; here the caller takes it over and starts the one after it (whose front gap receives this one's tail).
+bool BamReader::advance_records() {
+    if (!next_ready_.valid()) return false;
+    static const bool prof = getenv("BDX_BAM_PROFILE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    const bool got = next_ready_.get();
+    if (prof) fprintf(stderr, "[bam] consumer waited %.1f ms for the next batch\n",
+                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    if (!got) return false;
+    const int prev = cur_chunk_;
+    cur_chunk_ ^= 1;
+    part_ = rec_ = 0;
+    const Chunk* cur = &chunk_[cur_chunk_];
+    next_ready_ = std::async(std::launch::async, [this, prev, cur] { return fill_and_parse(chunk_[prev], cur); });
+    return true;
+}
+
+bool BamReader::next(BamRecord& r) {
+    while (true) {
+        const Chunk& c = chunk_[cur_chunk_];
+        while (part_ < c.parts.size()) {
+            if (rec_ < c.parts[part_].size()) {
+                r = c.parts[part_][rec_++];
+                return true;
+            }
+            ++part_;
+            rec_ = 0;
+        }
+        if (!advance_records()) return false;
+    }
 }
 
 void BamReader::parse_record(const uint8_t* rec, BamRecord& r) {

@@ -23,6 +23,9 @@ struct BamRecord {
     const uint8_t* seq;     // 4-bit packed bases, (l_qseq+1)/2 bytes
     const uint8_t* qual;    // l_qseq bytes
     int32_t end_pos;        // bam_calend: pos + reference bases consumed by the CIGAR (pos + 1 without a CIGAR)
+    uint64_t name_key;      // hash_name(qname)
+    uint64_t rg_key;        // hash_name(rg), 0 without an RG tag: lets a consumer recognise runs of one read group without
+                            // touching the record's bytes (they were decoded on another core)
 };
 
 class BamReader {
@@ -47,23 +50,31 @@ private:
     struct Chunk {
         std::unique_ptr<uint8_t[]> data;
         size_t cap = 0, beg = 0, end = 0;
+        // the records that start in [beg, tail): decoded by several threads as soon as the batch is inflated, each from a
+        // guessed (and then verified) record boundary -- see parse_chunk
+        std::vector<std::vector<BamRecord>> parts;
+        size_t tail = 0;               // first byte of the incomplete record at the end of the batch (== end if none)
         void reserve(size_t n);
     };
     bool fill(Chunk& c);               // inflate the next batch of BGZF blocks into c; false at EOF (runs on the helper thread)
-    bool advance();                    // make the next batch current, start inflating the one after it; false at EOF
-    bool ensure(size_t need);          // make `need` decompressed bytes available at cur_
+    void attach_tail(Chunk& c, const uint8_t* src, size_t n);  // put n bytes in front of c's bytes
+    void parse_chunk(Chunk& c);        // decode every complete record of c (several threads)
+    bool fill_and_parse(Chunk& c, const Chunk* prev);  // the helper thread's job in record mode
+    bool advance();                    // header mode: make the next batch current; false at EOF
+    bool advance_records();            // record mode: take over the batch the helper thread prepared, start the next one
+    bool ensure(size_t need);          // header mode: make `need` decompressed bytes available at cur_
     const uint8_t* at() const { return chunk_[cur_chunk_].data.get() + cur_; }
     std::string path_;
-    FILE* fp_ = nullptr;
+    const uint8_t* map_ = nullptr;     // the compressed file, memory-mapped
+    size_t map_size_ = 0;
     int threads_;
-    std::vector<uint8_t> comp_;        // compressed bytes not yet consumed (helper thread only)
-    size_t comp_off_ = 0;
-    bool eof_ = false;
+    size_t comp_off_ = 0;              // first compressed byte not yet consumed
     Chunk chunk_[2];                   // one being parsed, one being inflated
-    int cur_chunk_ = 0;
+    int cur_chunk_ = 1;                // (the first batch lands in chunk 0)
     size_t cur_ = 0, end_ = 0;         // parse position / end of the valid bytes in the current chunk
-    std::future<bool> next_ready_;     // the helper thread's fill() of the other chunk
-    bool started_ = false;
+    std::future<bool> next_ready_;     // the helper thread's fill_and_parse() of the other chunk
+    bool records_mode_ = false;        // false while the header is read byte-wise
+    size_t part_ = 0, rec_ = 0;        // next record to hand out: chunk_[cur_chunk_].parts[part_][rec_]
     std::vector<std::string> targets_;
     std::string header_text_;
 };

@@ -123,19 +123,23 @@ void merge_streams(const BamConfig& cfg, const std::string& chr, int threads, st
     std::priority_queue<Stream*, std::vector<Stream*>, StreamGreater> pq;
     for (auto& s : streams)
         if (s->advance()) pq.push(s.get());
-    std::string rgtmp, last_rg;
+    // The records were decoded on other cores: their bytes are cold here, so runs of one read group are recognised by the
+    // 64-bit key the decoder computed, and the RG string itself is only read the first time a key is seen.
+    std::string rgtmp;
+    std::unordered_map<uint64_t, uint8_t> by_key;
+    uint64_t last_key = ~0ull;
     uint8_t last_lib = fallback;
-    bool have_last = false;
     uint64_t index = 0;
     auto lib_of = [&](const BamRecord& r) {
-        const size_t n = r.rg ? r.l_rg : 0;
-        if (have_last && last_rg.size() == n && (n == 0 || memcmp(last_rg.data(), r.rg, n) == 0)) return last_lib;  // runs of one RG
-        rgtmp.assign(r.rg ? r.rg : "", n);
-        auto it = rg_cache.find(rgtmp);
-        last_lib = it != rg_cache.end() ? it->second : fallback;
-        last_rg = rgtmp;
-        have_last = true;
-        return last_lib;
+        if (r.rg_key == last_key) return last_lib;  // runs of one RG
+        auto hit = by_key.find(r.rg_key);  // (a key stands for its string: two RG ids with one 64-bit key are not expected)
+        if (hit == by_key.end()) {
+            rgtmp.assign(r.rg ? r.rg : "", r.rg ? r.l_rg : 0);
+            auto it = rg_cache.find(rgtmp);
+            hit = by_key.emplace(r.rg_key, it != rg_cache.end() ? it->second : fallback).first;
+        }
+        last_key = r.rg_key;
+        return last_lib = hit->second;
     };
     if (pq.size() == 1) {  // one BAM: nothing to merge
         Stream* s = pq.top();
@@ -174,7 +178,7 @@ void produce(const BamConfig& cfg, const std::string& chr, int threads, ReadStre
         out.mapq.push_back(r.bdqual);
         out.lib.push_back(lib);
         out.bam.push_back((uint8_t)bam_index);
-        out.name_key.push_back(hash_name(r.qname, r.l_qname));
+        out.name_key.push_back(r.name_key);
     });
 }
 

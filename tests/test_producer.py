@@ -11,11 +11,13 @@ from helpers import GOLDEN, ROOT, load_chr21, make_opts
 DUMP = os.path.join(ROOT, "bin", "bdx-dump-reads")
 
 
-def dump(args, cwd):
+def dump(args, cwd, env=None):
     if not os.path.exists(DUMP):
         import __graft_entry__ as g
         g.build()
-    out = subprocess.run([DUMP] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout.decode()
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run([DUMP] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True, env=e).stdout.decode()
     head = [l for l in out.splitlines() if l.startswith("#")]
     data = [l.split("\t") for l in out.splitlines() if not l.startswith("#")]
     rows = np.array([[int(x) for x in f[:10]] for f in data], dtype=np.int64).reshape(-1, 10)
@@ -60,14 +62,18 @@ def test_missing_map_field_is_an_error(tmp_path):
     assert p.returncode == 1 and b"Required field 'map' not found in config at line 1!" in p.stderr
 
 
-def test_producer_decodes_a_multi_block_synthetic_bam(tmp_path):
-    """a few thousand BGZF blocks, records straddling block boundaries, parallel inflate"""
+@pytest.mark.parametrize("env", [{}, {"BDX_BAM_SEG_BYTES": "3000", "BDX_BAM_FILL_BLOCKS": "5"},
+                                 {"BDX_BAM_SEG_BYTES": "100", "BDX_BAM_FILL_BLOCKS": "1"}, {"BDX_THREADS": "1"}])
+def test_producer_decodes_a_multi_block_synthetic_bam(tmp_path, env):
+    """a few thousand BGZF blocks, records straddling block boundaries, parallel inflate, records decoded by several
+    threads from guessed boundaries (the knobs shrink batches and segments: hundreds of hand-overs and guesses, segments
+    shorter than a record)"""
     from breakdancer_amd.bamwrite import write_bam
     from breakdancer_amd.synth import make_chromosome
     d = make_chromosome(length=300000, seed=5)
     write_bam(str(tmp_path / "syn.bam"), d, ["chrS"], seed=1)
     (tmp_path / "cfg").write_text("readgroup:rg1\tplatform:illumina\tmap:syn.bam\treadlen:100.00\tlib:lib1\tlower:310.00\tupper:490.00\tmean:400.00\tstd:30.00\n")
-    head, rows, keys = dump(["cfg"], str(tmp_path))
+    head, rows, keys = dump(["cfg"], str(tmp_path), env)
     n = len(d["tid"])
     assert len(rows) == n and n > 80000
     for col, k in enumerate(("tid", "pos", "mtid", "mpos", "isize", "flag", "qlen", "mapq", "lib", "bam")):
