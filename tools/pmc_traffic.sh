@@ -1,0 +1,25 @@
+#!/bin/bash
+# HBM traffic counters of every kernel of a step (one PMC pass per counter; run on the GPU box from the repo root)
+R=$(pwd)
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmct_$c
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmct_$c -o p -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > /tmp/pmct_$c.log 2>&1
+done
+cd $R
+python - <<'PY'
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.defaultdict(lambda: collections.defaultdict(int))
+for f in glob.glob("/tmp/pmct_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].replace("bdx::", "")[:50]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[k][r["Counter_Name"]] += 1
+print("rocprofv3 --kernel-trace --pmc <counter> (one pass per counter), bench.py --steps 6 --warmup 2; mean Counter_Value per launch in KB.")
+print("gfx950 correction (MI355X_MICROARCH.md, calibrated in r01_k1_pmc.txt): HBM bytes read = FETCH_SIZE x 2 KB; WRITE_SIZE as reported.")
+print("%-50s %12s %12s %8s" % ("kernel", "FETCH_SIZE", "WRITE_SIZE", "launches"))
+rows = sorted(agg, key=lambda k: -agg[k]["FETCH_SIZE"] / max(1, cnt[k]["FETCH_SIZE"]))
+for k in rows:
+    print("%-50s %12.1f %12.1f %8d" % (k, agg[k]["FETCH_SIZE"] / max(1, cnt[k]["FETCH_SIZE"]), agg[k]["WRITE_SIZE"] / max(1, cnt[k]["WRITE_SIZE"]), cnt[k]["FETCH_SIZE"]))
+PY
