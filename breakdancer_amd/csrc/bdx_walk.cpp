@@ -408,6 +408,24 @@ struct Walker {
                 const int b = z <= 4 ? 0 : z <= 8 ? 1 : z <= 16 ? 2 : z <= 32 ? 3 : z <= 64 ? 4 : z <= 256 ? 5 : 6;
                 ++h[b]; regions_in[b] += z;
             }
+            {   // why they are here: components holding a region of more than 64 reads / with more than 3 incoming groups
+                std::vector<uint32_t> indeg((size_t)NR, 0);
+                for (const Group& g : groups)
+                    if (g.lo != g.hi && (int)g.weight >= in.opts.min_read_pair) ++indeg[g.hi];
+                std::vector<uint8_t> why((size_t)NR, 0);
+                for (int64_t i = 0; i < NR; ++i) {
+                    if (!seen[(size_t)i]) continue;
+                    const uint32_t root = find((uint32_t)i);
+                    if (R[i].n > 64) why[root] |= 1;
+                    if (indeg[(size_t)i] > 3) why[root] |= 2;
+                }
+                size_t nb = 0, nh = 0, nboth = 0, nnone = 0;
+                for (int64_t i = 0; i < NR; ++i) {
+                    if (!size[(size_t)i]) continue;
+                    if (why[(size_t)i] == 1) ++nb; else if (why[(size_t)i] == 2) ++nh; else if (why[(size_t)i] == 3) ++nboth; else ++nnone;
+                }
+                fprintf(stderr, "[walk] host components with a region of > 64 reads: %zu, with > 3 incoming groups: %zu, both: %zu, neither: %zu\n", nb, nh, nboth, nnone);
+            }
             fprintf(stderr, "[walk] host components by regions: <=4:%zu 5-8:%zu 9-16:%zu 17-32:%zu 33-64:%zu 65-256:%zu 257+:%zu; regions in them: %zu %zu %zu %zu %zu %zu %zu\n",
                     h[0], h[1], h[2], h[3], h[4], h[5], h[6], regions_in[0], regions_in[1], regions_in[2], regions_in[3], regions_in[4], regions_in[5], regions_in[6]);
         }

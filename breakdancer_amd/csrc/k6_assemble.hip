@@ -62,125 +62,203 @@ __device__ __forceinline__ bool region_stored(const RegionRec& R, const K6Arrays
 
 }  // namespace
 
+// Sort-and-merge of up to 64 items (one per lane) by their 64-bit key, in registers: equal keys become one part (the lane
+// with the lowest index keeps it: `leader`), `rank` is the part's place in key order.  An item is a read (weight 1, its
+// insert size) or, kWeighted, the partial part of a chunk of reads (its pairs, its insert-size sum).
+struct Merged {
+    uint32_t cnt, sum;    // pairs and insert-size sum of my part (all items with my key)
+    uint32_t gw;          // pairs of my (lo, r) group = its weight as a connection
+    uint32_t rank, gparts;  // my part's place in key order; parts of my group
+    uint32_t total, wself;  // pairs of all items / of the items whose first mate is in region r itself
+    uint64_t lmask;       // lanes holding a part
+    bool leader, gleader; // gleader: one lane per (lo, r) group, holding its first part
+};
+
+template <bool kWeighted>
+__device__ __forceinline__ Merged merge_items(uint64_t key, uint32_t wc, uint32_t ws, bool has, uint32_t r, int lane) {
+    Merged m{};
+    const uint64_t hasmask = __ballot(has);
+    uint32_t eq_before = 0;
+    for (uint64_t mm = hasmask; mm; mm &= mm - 1) {
+        const int t = __builtin_ctzll(mm);
+        const uint64_t kt = readlane64(key, t);
+        const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)ws, t);
+        const uint32_t ct = kWeighted ? (uint32_t)__builtin_amdgcn_readlane((int)wc, t) : 1u;
+        const bool eq = kt == key;
+        m.cnt += eq ? ct : 0u;
+        m.sum += eq ? st : 0u;
+        eq_before += (eq && t < lane) ? 1u : 0u;
+        m.gw += ((kt >> 12) == (key >> 12)) ? ct : 0u;
+        if (kWeighted) {
+            m.total += ct;
+            m.wself += (uint32_t)(kt >> 12) == r ? ct : 0u;
+        }
+    }
+    if (!kWeighted) {
+        m.total = (uint32_t)__popcll(hasmask);
+        m.wself = (uint32_t)__popcll(__ballot(has && (uint32_t)(key >> 12) == r));
+    }
+    m.leader = has && eq_before == 0;
+    m.lmask = __ballot(m.leader);
+    bool lo_first = true;
+    for (uint64_t mm = m.lmask; mm; mm &= mm - 1) {
+        const int t = __builtin_ctzll(mm);
+        const uint64_t kt = readlane64(key, t);
+        const bool same_lo = (kt >> 12) == (key >> 12);
+        m.gparts += same_lo ? 1u : 0u;
+        if (kt < key) {
+            ++m.rank;
+            if (same_lo) lo_first = false;
+        }
+    }
+    m.gleader = m.leader && lo_first;
+    return m;
+}
+
 // One wave per accepted region: its pairs (second-observed mate in the region) -> sorted, merged (lo, flag, lib) parts.
+// A region of more than 64 reads is merged 64 reads at a time; the chunks' parts (at most 64 in total, else the host
+// gets them) are merged once more.
 __global__ __launch_bounds__(256) void k6_pairs_kernel(K6Arrays a) {
-    const int lane = threadIdx.x & 63;
+    __shared__ PartRec s_stash[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t nwaves = gridDim.x * 4;
     const uint32_t NR = a.counts->n_regions;
     const uint32_t mrp = (uint32_t)max(a.min_read_pair, 0);
     for (uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6); r < NR; r += nwaves) {
         const RegionRec rr = a.r_rec[r];
         const uint32_t first = rr.first, n = rr.n;
-        const bool big = n > 64;
         RegSum rs{};
-        rs.big = big ? 1u : 0u;
-        for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+        // the lane's read of chunk c0: key = (region of the first-observed mate, library, flag) if it is the second-observed
+        // mate of a pair (SvBuilder.cpp:101-118)
+        auto load_read = [&](uint32_t c0, uint64_t& key, uint32_t& is) -> bool {
             const uint32_t i = c0 + lane;
-            uint64_t key = ~0ull;
-            uint32_t is = 0, lo = 0;
-            bool has = false;
-            if (i < n) {
-                const uint32_t j = first + i;
-                int32_t plo;  // region of the first-observed mate if j is the second-observed one (SvBuilder.cpp:101-118), else -1
-                if (a.pair_lo) {
-                    plo = a.pair_lo[j];
-                } else {
-                    const int32_t p = a.partner[j];
-                    plo = (p >= 0 && (uint32_t)p < j) ? a.region_of[p] : -1;
-                }
-                if (plo >= 0) {
-                    lo = (uint32_t)plo;
-                    const uint32_t m = a.meta[j];
-                    key = ((uint64_t)lo << 12) | ((uint64_t)meta_lib(m) << 4) | (uint64_t)meta_flag(m);
-                    is = (uint32_t)a.isize[j];
-                    has = true;
-                }
-            }
-            const uint64_t hasmask = __ballot(has);
-            if (!hasmask) continue;
-            rs.n_pairs += (uint32_t)__popcll(hasmask);
-            uint32_t eq_before = 0, cnt = 0, sum = 0, gw = 0;  // gw: pairs of my (lo, r) group = its edge weight
-            for (uint64_t mm = hasmask; mm; mm &= mm - 1) {
-                const int t = __builtin_ctzll(mm);
-                const uint64_t kt = readlane64(key, t);
-                const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)is, t);
-                const bool eq = kt == key;
-                cnt += eq ? 1u : 0u;
-                sum += eq ? it : 0u;
-                eq_before += (eq && t < lane) ? 1u : 0u;
-                gw += ((kt >> 12) == (key >> 12)) ? 1u : 0u;
-            }
-            const bool leader = has && eq_before == 0;
-            const uint64_t lmask = __ballot(leader);
-            uint32_t rank = 0, gparts = 0;  // gparts: parts of my group
-            bool lo_first = true;
-            for (uint64_t mm = lmask; mm; mm &= mm - 1) {
-                const int t = __builtin_ctzll(mm);
-                const uint64_t kt = readlane64(key, t);
-                const bool same_lo = (kt >> 12) == (key >> 12);
-                gparts += same_lo ? 1u : 0u;
-                if (kt < key) {
-                    ++rank;
-                    if (same_lo) lo_first = false;
-                }
-            }
-            const bool gleader = leader && lo_first;  // one lane per (lo, r) group, holding its first part
-            rs.w_self += (uint32_t)__popcll(__ballot(has && lo == r));
-            if (!big) {
-                // groups below the weight gate are skipped by every try_edge and never reach process_sv: inert
-                const bool strong = gw >= mrp;
-                const uint64_t gl_in = __ballot(gleader && lo < r && strong);
-                if (gleader && lo < r && strong) atomicAdd(&a.out_deg[lo], 1u);
-                rs.np_all = (uint32_t)__popcll(lmask);
-                rs.np_self = (uint32_t)__popcll(__ballot(leader && lo == r));
-                rs.np_emit = (uint32_t)__popcll(__ballot(leader && (lo == r || strong)));
-                rs.n_weak = (uint32_t)__popcll(__ballot(gleader && lo < r && !strong));
-                rs.n_in = (uint32_t)__popcll(gl_in);
-                if (rs.n_in > (uint32_t)kK6MaxIn) {  // too many connections for a device-walked component
-                    if (gleader && lo < r && strong) a.bad_v[lo] = 1u;
-                    if (lane == 0) a.bad_v[r] = 1u;
-                } else {
-                    // (first round of the min-label propagation: each gate-passing group joins its two regions)
-                    if (gleader && lo < r && strong && !a.force_host) {
-                        const uint32_t lr = a.label[r], ll = a.label[lo];
-                        if (lr < ll) atomicMin(&a.label[lo], lr);
-                        else if (ll < lr) atomicMin(&a.label[r], ll);
-                    }
-                    int e = 0;
-                    for (uint64_t mm = gl_in; mm; mm &= mm - 1, ++e) {
-                        const int t = __builtin_ctzll(mm);
-                        rs.e_lo[e] = (uint32_t)__builtin_amdgcn_readlane((int)lo, t);
-                        rs.e_w[e] = (uint32_t)__builtin_amdgcn_readlane((int)gw, t);
-                        rs.e_off[e] = (uint32_t)__builtin_amdgcn_readlane((int)rank, t);
-                        rs.e_cnt[e] = (uint32_t)__builtin_amdgcn_readlane((int)gparts, t);
-                    }
-                }
-                if (leader) a.parts[first + rank] = PartRec{(lo < r && !strong) ? (key | kWeakPart) : key, cnt, sum};
+            key = ~0ull;
+            is = 0;
+            if (i >= n) return false;
+            const uint32_t j = first + i;
+            int32_t plo;
+            if (a.pair_lo) {
+                plo = a.pair_lo[j];
             } else {
-                // too many reads for one in-register sort: the chunk's partial aggregates go to the host, which merges
-                // them; every group counts as a connection (a chunk cannot know the whole group's weight)
-                if (gleader && lo < r) {
-                    atomicAdd(&a.out_deg[lo], 1u);
-                    a.bad_v[lo] = 1u;
+                const int32_t p = a.partner[j];
+                plo = (p >= 0 && (uint32_t)p < j) ? a.region_of[p] : -1;
+            }
+            if (plo < 0) return false;
+            const uint32_t m = a.meta[j];
+            key = ((uint64_t)(uint32_t)plo << 12) | ((uint64_t)meta_lib(m) << 4) | (uint64_t)meta_flag(m);
+            is = (uint32_t)a.isize[j];
+            return true;
+        };
+        uint64_t key = ~0ull;
+        uint32_t is = 0;
+        bool has = false, merged = false;
+        Merged m{};
+        if (n <= 64) {
+            has = load_read(0, key, is);
+            if (__ballot(has)) {
+                m = merge_items<false>(key, 1u, is, has, r, lane);
+                merged = true;
+            }
+        } else {
+            // chunks of 64 reads -> their parts, stashed in LDS in any order
+            uint32_t np = 0;
+            bool fits = true;
+            for (uint32_t c0 = 0; c0 < n && fits; c0 += 64) {
+                uint64_t ck;
+                uint32_t ci;
+                const bool ch = load_read(c0, ck, ci);
+                if (!__ballot(ch)) continue;
+                const Merged cm = merge_items<false>(ck, 1u, ci, ch, r, lane);
+                const uint32_t nl = (uint32_t)__popcll(cm.lmask);
+                if (np + nl > 64u) { fits = false; break; }
+                if (cm.leader) s_stash[w][np + cm.rank] = PartRec{ck, cm.cnt, cm.sum};
+                np += nl;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (fits) {
+                if (np) {
+                    has = (uint32_t)lane < np;
+                    const PartRec q = has ? s_stash[w][lane] : PartRec{~0ull, 0u, 0u};
+                    key = q.key;
+                    m = merge_items<true>(key, q.pairs, q.sum, has, r, lane);
+                    merged = true;
                 }
-                if (lane == 0) a.bad_v[r] = 1u;
-                const uint32_t nl = (uint32_t)__popcll(lmask);
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&a.counts->n_groups, nl);
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (leader) {
-                    const uint32_t o = base + rank;
-                    if (o < a.g_cap) {
-                        GroupRec g;
-                        g.key = group_pack(lo, r, (uint32_t)((key >> 4) & 255), (uint32_t)(key & 15));
-                        g.pairs = cnt;
-                        g.sum_isize = sum;
-                        a.g_rec[o] = g;
-                    } else {
-                        a.counts->overflow = 1;
+            } else {
+                // more than 64 distinct parts: every chunk's parts go to the host, which merges them; every group counts
+                // as a connection (a chunk cannot know the whole group's weight)
+                rs.big = 1u;
+                for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+                    uint64_t ck;
+                    uint32_t ci;
+                    const bool ch = load_read(c0, ck, ci);
+                    if (!__ballot(ch)) continue;
+                    const Merged cm = merge_items<false>(ck, 1u, ci, ch, r, lane);
+                    const uint32_t clo = (uint32_t)(ck >> 12);
+                    rs.n_pairs += cm.total;
+                    rs.w_self += cm.wself;
+                    if (cm.gleader && clo < r) {
+                        atomicAdd(&a.out_deg[clo], 1u);
+                        a.bad_v[clo] = 1u;
+                    }
+                    if (lane == 0) a.bad_v[r] = 1u;
+                    const uint32_t nl = (uint32_t)__popcll(cm.lmask);
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&a.counts->n_groups, nl);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    if (cm.leader) {
+                        const uint32_t o = base + cm.rank;
+                        if (o < a.g_cap) {
+                            GroupRec g;
+                            g.key = group_pack(clo, r, (uint32_t)((ck >> 4) & 255), (uint32_t)(ck & 15));
+                            g.pairs = cm.cnt;
+                            g.sum_isize = cm.sum;
+                            a.g_rec[o] = g;
+                        } else {
+                            a.counts->overflow = 1;
+                        }
                     }
                 }
             }
+            __builtin_amdgcn_wave_barrier();  // the stash is reused by the wave's next region
+        }
+        if (merged) {
+            const uint32_t lo = (uint32_t)(key >> 12);
+            rs.n_pairs = m.total;
+            rs.w_self = m.wself;
+            // groups below the weight gate are skipped by every try_edge and never reach process_sv: inert
+            const bool strong = m.gw >= mrp;
+            const bool in_edge = m.gleader && lo < r && strong;
+            const uint64_t gl_in = __ballot(in_edge);
+            if (in_edge) atomicAdd(&a.out_deg[lo], 1u);
+            rs.np_all = (uint32_t)__popcll(m.lmask);
+            rs.np_self = (uint32_t)__popcll(__ballot(m.leader && lo == r));
+            rs.np_emit = (uint32_t)__popcll(__ballot(m.leader && (lo == r || strong)));
+            rs.n_weak = (uint32_t)__popcll(__ballot(m.gleader && lo < r && !strong));
+            rs.n_in = (uint32_t)__popcll(gl_in);
+            if (rs.n_in > (uint32_t)kK6MaxIn) {  // too many connections for a device-walked component
+                if (in_edge) a.bad_v[lo] = 1u;
+                if (lane == 0) a.bad_v[r] = 1u;
+            } else {
+                // (first round of the min-label propagation: each gate-passing group joins its two regions)
+                if (in_edge && !a.force_host) {
+                    const uint32_t lr = a.label[r], ll = a.label[lo];
+                    if (lr < ll) atomicMin(&a.label[lo], lr);
+                    else if (ll < lr) atomicMin(&a.label[r], ll);
+                }
+                uint64_t mm = gl_in;
+#pragma unroll
+                for (int e = 0; e < kK6MaxIn; ++e) {  // (static indices: the record stays in registers)
+                    if (mm) {
+                        const int t = __builtin_ctzll(mm);
+                        mm &= mm - 1;
+                        rs.e_lo[e] = (uint32_t)__builtin_amdgcn_readlane((int)lo, t);
+                        rs.e_w[e] = (uint32_t)__builtin_amdgcn_readlane((int)m.gw, t);
+                        rs.e_off[e] = (uint32_t)__builtin_amdgcn_readlane((int)m.rank, t);
+                        rs.e_cnt[e] = (uint32_t)__builtin_amdgcn_readlane((int)m.gparts, t);
+                    }
+                }
+            }
+            if (m.leader) a.parts[first + m.rank] = PartRec{(lo < r && !strong) ? (key | kWeakPart) : key, m.cnt, m.sum};
         }
         if (lane == 0) a.rs[r] = rs;
     }

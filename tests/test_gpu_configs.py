@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from helpers import OracleRun, make_opts
-from runner import compare, product_from_oracle, sharded_from_oracle
+from runner import compare, compare_support, product_from_oracle, sharded_from_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -120,14 +120,34 @@ def test_device_assembly_and_host_walk_agree_with_the_oracle(kw):
     bh.close()
 
 
-def test_regions_larger_than_a_wave_go_through_the_host_walk():
-    """clusters of 90 pairs: regions with more than 64 reads are not sorted in registers; their groups reach the host
-    walk in pieces and are merged there"""
+def test_regions_larger_than_a_wave_are_merged_in_two_levels():
+    """clusters of 90 pairs: a region with more than 64 reads is sorted and merged 64 reads at a time, and the chunks'
+    parts once more -- still on the device"""
     from breakdancer_amd.synth import make_chromosome
     d = make_chromosome(length=3_000_000, coverage=30.0, seed=5, cluster=90, discordant=0.03)
     cfg = cfg_line("rg0", "wgs.bam", "lib0", 400.0, 30.0)
     run = oracle_from_soa(d, cfg, ["wgs.bam"], make_opts(score_threshold=-1), ["c1"])
     assert run.n_svs > 50 and int(run.regions[:, 7].max()) > 64
+    bd = product_from_oracle(run, support=True)
+    compare(run, bd)
+    compare_support(run, bd)
+    n_dev, n_host, _ = bd.walk_split()
+    assert n_dev > 10 * max(1, n_host), (n_dev, n_host)
+    bd.close()
+
+
+def test_regions_with_more_parts_than_a_wave_go_through_the_host_walk():
+    """clusters of 250 pairs drawn from 120 libraries: more than 64 distinct (region, flag, library) parts in one region
+    cannot be merged in registers; the chunks' parts reach the host walk in pieces and are merged there"""
+    from breakdancer_amd.synth import make_chromosome
+    nl = 120
+    d = make_chromosome(length=3_000_000, coverage=30.0, seed=9, cluster=250, discordant=0.04)
+    d = dict(d)
+    d["lib"] = ((d["name_key"] * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(40)).astype(np.int64) % nl  # one library per pair
+    d["lib"] = d["lib"].astype(np.uint8)
+    cfg = "".join(cfg_line("rg%03d" % i, "wgs.bam", "lib%03d" % i, 400.0, 30.0) for i in range(nl))
+    run = oracle_from_soa(d, cfg, ["wgs.bam"], make_opts(score_threshold=-1), ["c1"])
+    assert run.n_svs > 20 and int(run.regions[:, 7].max()) > 200
     bd = product_from_oracle(run)
     compare(run, bd)
     assert bd.walk_split()[1] > 0
