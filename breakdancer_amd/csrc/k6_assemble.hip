@@ -294,22 +294,31 @@ __global__ __launch_bounds__(256) void k6_classify_kernel(K6Arrays a) {
     if (!hub && n_in == 0 && a.out_deg[r] == 0 && s->np_self == 0) return;  // no group that could ever be consumed
     const uint32_t L = a.label[r];
     if (hub || a.bad_v[r]) a.bad[L] = 1u;
-    if (!hub)
-        for (uint32_t e = 0; e < n_in; ++e) {
-            const uint32_t ll = a.label[s->e_lo[e]];
-            if (ll != L) { a.bad[L] = 1u; a.bad[ll] = 1u; }
+    if (!hub) {
+#pragma unroll
+        for (uint32_t e = 0; e < (uint32_t)kK6MaxIn; ++e) {  // (static trip count: no private array behind the loop)
+            if (e < n_in) {
+                const uint32_t ll = a.label[s->e_lo[e]];
+                if (ll != L) { a.bad[L] = 1u; a.bad[ll] = 1u; }
+            }
         }
+    }
     const uint32_t slot = atomicAdd(&a.mcount[L], 1u);
     if (slot < (uint32_t)kK6BigMembers) a.member_ids[(size_t)L * kK6BigMembers + slot] = r;
     if (slot < (uint32_t)kK6MaxMembers) {
-        MemberInfo mi;
-        mi.r = r;
-        mi.rec = a.r_rec[r];
-        mi.np_all = s->np_all; mi.np_self = s->np_self; mi.w_self = s->w_self; mi.n_in = hub ? 0u : n_in;
-        for (int e = 0; e < kK6MaxIn; ++e) { mi.e_lo[e] = s->e_lo[e]; mi.e_w[e] = s->e_w[e]; mi.e_off[e] = s->e_off[e]; mi.e_cnt[e] = s->e_cnt[e]; }
-        mi.stored = region_stored(mi.rec, a) ? 1u : 0u;
-        mi.pad = 0;
-        a.members[(size_t)L * kK6MaxMembers + slot] = mi;
+        MemberInfo* mi = &a.members[(size_t)L * kK6MaxMembers + slot];  // (written field by field: no private copy)
+        mi->r = r;
+        {   // (word by word: a struct assignment goes through a private copy here)
+            const uint32_t* src = (const uint32_t*)&a.r_rec[r];
+            uint32_t* dst = (uint32_t*)&mi->rec;
+#pragma unroll
+            for (int wd = 0; wd < (int)(sizeof(RegionRec) / 4); ++wd) dst[wd] = src[wd];
+        }
+        mi->np_all = s->np_all; mi->np_self = s->np_self; mi->w_self = s->w_self; mi->n_in = hub ? 0u : n_in;
+#pragma unroll
+        for (int e = 0; e < kK6MaxIn; ++e) { mi->e_lo[e] = s->e_lo[e]; mi->e_w[e] = s->e_w[e]; mi->e_off[e] = s->e_off[e]; mi->e_cnt[e] = s->e_cnt[e]; }
+        mi->stored = (int)(a.chr_restricted ? a.r_rec[r].nonctx : a.r_rec[r].n) >= a.min_read_pair ? 1u : 0u;  // region_stored()
+        mi->pad = 0;
     }
     if (s->np_emit) atomicAdd(&a.pcount[L], s->np_emit);
 }
