@@ -326,14 +326,26 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(const FinalizeParam
         uint32_t* out = p.tile_pre + (size_t)c * p.tstride;
         if (t == 0) s_carry = 0;
         __syncthreads();
+        // (the next round's 16 values are requested before this round's barriers: the rounds only depend on each other
+        // through the carry, not through their loads)
+        uint4 nx[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // rows are padded to a multiple of 16 and zero-filled
+            nx[q] = make_uint4(0, 0, 0, 0);
+            if ((uint32_t)t * 16 + q * 4 < p.tstride) nx[q] = *(const uint4*)(in + t * 16 + q * 4);
+        }
         for (uint32_t base = 0; base < p.ntiles; base += kFinBlock * 16) {
             const uint32_t i = base + t * 16;
             uint32_t v[16];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {  // rows are padded to a multiple of 16 and zero-filled
-                uint4 x = make_uint4(0, 0, 0, 0);
-                if (i + q * 4 < p.tstride) x = *(const uint4*)(in + i + q * 4);
-                v[q * 4] = x.x; v[q * 4 + 1] = x.y; v[q * 4 + 2] = x.z; v[q * 4 + 3] = x.w;
+            for (int q = 0; q < 4; ++q) { v[q * 4] = nx[q].x; v[q * 4 + 1] = nx[q].y; v[q * 4 + 2] = nx[q].z; v[q * 4 + 3] = nx[q].w; }
+            if (base + kFinBlock * 16 < p.ntiles) {
+                const uint32_t j = i + kFinBlock * 16;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    nx[q] = make_uint4(0, 0, 0, 0);
+                    if (j + q * 4 < p.tstride) nx[q] = *(const uint4*)(in + j + q * 4);
+                }
             }
             uint32_t tsum = 0;
 #pragma unroll

@@ -1079,7 +1079,9 @@ struct OwnOut {
     }
     __device__ void operator()(uint32_t i, uint32_t n, const U4& inc, const U4& e) const {
         const uint32_t nh = a.counts->n_ins;
-        const uint32_t hb0 = nh ? count_below(a.ins_T, nh, i) : 0u, hb1 = nh ? count_below(a.ins_T, nh, i + 1) : 0u;
+        const uint32_t hb0 = nh ? count_below(a.ins_T, nh, i) : 0u;
+        uint32_t hb1 = hb0;  // (entries with threshold i follow each other: one look ahead instead of a second search)
+        while (hb1 < nh && a.ins_T[hb1] == i) ++hb1;
         const uint32_t h_l = a.ins_pre_l[nh], h_c = a.ins_pre_c[nh];
         const uint32_t ex_sv = inc.x - e.x, ex_l = inc.y - e.y, ex_c = inc.z - e.z;
         if (i == n - 1) {
