@@ -873,7 +873,7 @@ int do_k6_table(bdx_ctx* c) {
         a.hs_lambda = lam; a.hs_lib_index = li; a.hs_lib_pairs = lp; a.hs_cn_key = ck; a.hs_cn_value = cv;
     }
     launch_k6_compact(a, na, s);
-    launch_k5_dev(a.t_lambda, a.t_k, c->h_ltail_dev.as<double>(), a.ltail, &a.counts->n_terms_dev, a.term_cap, s);
+    a.ltail_host = c->h_ltail_dev.as<double>();  // (K5 runs inside the score kernel: one launch less)
     launch_k6_score(a, std::log(10), c->opts.score_threshold, c->opts.fisher ? 0 : 1, s);
     {   // the final table is complete (without polling: finish_table waits for the stream)
         const int rc = signal_ready(c, 2, nullptr);

@@ -261,7 +261,8 @@ struct K6Arrays {
     int32_t* cn_key;               // pinned host
     float* cn_value;               // pinned host
     uint32_t sv_cap, term_cap, cn_cap;
-    double* ltail;                 // device [term_cap]: log tails (K5 also writes them to pinned host memory)
+    double* ltail;                 // device [term_cap]: log tails of the terms ...
+    double* ltail_host;            // ... and their copy in pinned host memory (both written by k6_score_kernel)
     // Candidates that are placed by their order key instead of by their start vertex: the host walk's (pinned host
     // memory) and the device's own whose traversal started from a vertex of an earlier flush window.  k6_insert_kernel
     // merges the two lists by key; entry j of the merged list precedes the candidates of start vertex ins_T[j] and after.

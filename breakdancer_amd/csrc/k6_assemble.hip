@@ -23,6 +23,7 @@
 
 #include "bdx_k3.h"
 
+#include "bdx_poisson.h"
 #include "bdx_scan.h"
 
 namespace bdx {
@@ -1129,7 +1130,8 @@ struct OwnOut {
     }
 };
 
-// Score combination for the final table: Kahan-compensated sum of the per-library log tails (BreakDancer.cpp:56-69),
+// K5 + score combination for the final table: the Poisson log tail of every (candidate, library) term
+// (bdx_poisson.h), their Kahan-compensated sum (BreakDancer.cpp:56-69),
 // PhredQ = min(99, int(-10 logp / ln 10 + 0.5)) (:459-465, NaN -> INT_MIN as cvttsd2si does), printed = PhredQ > -y.
 // A workgroup takes 64 candidates: their records go through LDS, get their scores there, and leave for pinned host
 // memory as one contiguous 6 KiB write (single scattered stores over PCIe are several times slower); the flat lists
@@ -1158,15 +1160,29 @@ __global__ __launch_bounds__(256) void k6_score_kernel(K6Arrays a, double ln10, 
             o->sv.lib_begin = (int32_t)bg.x;
             o->sv.cn_begin = (int32_t)bg.y;
         }
-        if (threadIdx.x < cnt && with_scores) {
-            SvOut* o = (SvOut*)s_rec + threadIdx.x;
+        if (threadIdx.x < 64) {
+            // wave 0, one candidate per lane: K5 for its terms (all 64 lanes take part: a term with a long series is summed
+            // by the whole wave), their log tails also go to the host's list
+            const bool act = threadIdx.x < cnt;
+            SvOut* o = (SvOut*)s_rec + (act ? threadIdx.x : 0);
+            const int32_t nl = act ? o->sv.lib_count : 0, lb = act ? o->sv.lib_begin : 0;
+            int32_t max_nl = nl;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) max_nl = max(max_nl, __shfl_xor(max_nl, off));
             double logp = 0.0, err = 0.0;
-            for (int32_t q = 0; q < o->sv.lib_count; ++q) {
-                const double tmp_a = __dsub_rn(a.ltail[o->sv.lib_begin + q], err);
-                const double tmp_b = __dadd_rn(logp, tmp_a);
-                err = __dsub_rn(__dsub_rn(tmp_b, logp), tmp_a);
-                logp = tmp_b;
+            for (int32_t q = 0; q < max_nl; ++q) {
+                const bool a2 = q < nl;
+                const double lt = poisson_term(a2 ? a.t_lambda[lb + q] : 1.0, a2 ? a.t_k[lb + q] : 0, a2, (int)threadIdx.x);
+                if (a2) {
+                    a.ltail[lb + q] = lt;
+                    a.ltail_host[lb + q] = lt;
+                    const double tmp_a = __dsub_rn(lt, err);
+                    const double tmp_b = __dadd_rn(logp, tmp_a);
+                    err = __dsub_rn(__dsub_rn(tmp_b, logp), tmp_a);
+                    logp = tmp_b;
+                }
             }
+            if (act && with_scores) {
             const double phred_tmp = __ddiv_rn(__dmul_rn(-10.0, logp), ln10);
             const double r = __dadd_rn(phred_tmp, 0.5);
             int phred;
@@ -1178,6 +1194,7 @@ __global__ __launch_bounds__(256) void k6_score_kernel(K6Arrays a, double ln10, 
             o->sv.score = phred;
             o->sv.printed = pr;
             if (pr) atomicAdd(&s_printed, 1u);
+            }
         }
         __syncthreads();
         uint32_t* dst = (uint32_t*)(a.sv_out + base);
