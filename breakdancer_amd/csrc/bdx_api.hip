@@ -91,7 +91,7 @@ struct bdx_ctx {
         b_t_lambda, b_t_k, b_ws6;
     PinBuf h_p1, h_cnt, h_counts, h_regs, h_pk, h_groups, h_terms;
     DevBuf b_sv_src, b_dlists, b_ltail, b_pair_lo;
-    PinBuf h_hs_rec, h_hs_aux, h_hs_lists;
+    PinBuf h_hs_rec, h_hs_aux, h_hs_lists, h_printed;
     DevBuf b_ins, b_member_ids;
     PinBuf h_flags;                   // [0] pass 1 ready, [1] host's groups ready, [2] final table ready (= run sequence number)
     uint32_t seq = 0;
@@ -295,7 +295,7 @@ void bdx_destroy(bdx_ctx* c) {
                       &c->b_parts, &c->b_kdens, &c->b_rs, &c->b_slot, &c->b_members, &c->b_own, &c->b_lib_stage,
                       &c->b_cn_stage, &c->b_t_lambda, &c->b_t_k, &c->b_ws6, &c->b_ins, &c->b_member_ids};
     for (DevBuf* b : bufs) b->release();
-    PinBuf* pins[] = {&c->h_p1, &c->h_cnt, &c->h_counts, &c->h_regs, &c->h_pk, &c->h_groups, &c->h_terms, &c->h_flags, &c->h_hs_rec, &c->h_hs_aux, &c->h_hs_lists, &c->h_counts0, &c->h_counts2,
+    PinBuf* pins[] = {&c->h_p1, &c->h_cnt, &c->h_counts, &c->h_regs, &c->h_pk, &c->h_groups, &c->h_terms, &c->h_flags, &c->h_hs_rec, &c->h_hs_aux, &c->h_hs_lists, &c->h_printed, &c->h_counts0, &c->h_counts2,
                       &c->h_sv_out, &c->h_lib_index, &c->h_lib_pairs, &c->h_cn_key, &c->h_cn_value, &c->h_ltail_dev};
     for (PinBuf* b : pins) b->release();
     if (c->walk_scratch) walk_scratch_free(c->walk_scratch);
@@ -874,6 +874,8 @@ int do_k6_table(bdx_ctx* c) {
     }
     launch_k6_compact(a, na, s);
     a.ltail_host = c->h_ltail_dev.as<double>();  // (K5 runs inside the score kernel: one launch less)
+    HIPCHK(c, c->h_printed.ensure((size_t)k6_score_grid(a) * 4));
+    a.printed_host = c->h_printed.as<uint32_t>();
     launch_k6_score(a, std::log(10), c->opts.score_threshold, c->opts.fisher ? 0 : 1, s);
     {   // the final table is complete (without polling: finish_table waits for the stream)
         const int rc = signal_ready(c, 2, nullptr);
@@ -914,7 +916,14 @@ int finish_table(bdx_ctx* c) {
     if (c2.overflow) return fail(c, BDX_EINTERNAL, "SV list overflow");
     c->n_sv_total = c2.n_sv_dev; c->n_terms_total = c2.n_terms_dev; c->n_cn_total = c2.n_cn_dev;
     c->counts.n_sv_dev = c2.n_sv_dev - c->n_sv_host;
-    c->n_printed = c2.n_printed;
+    {
+        // printed candidates: every workgroup of the score kernel left its count (no run: none)
+        const uint32_t g = c->k6.printed_host ? k6_score_grid(c->k6) : 0u;
+        const uint32_t* pb = c->k6.printed_host;
+        uint32_t np = 0;
+        for (uint32_t i = 0; i < g; ++i) np += pb[i];
+        c->n_printed = np;
+    }
     c->counts.n_old = c2.n_old;
     c->materialized = false;
     if (c->opts.fisher) {  // Fisher's combination (BreakDancer.cpp:71-81) uses the host's exp / log

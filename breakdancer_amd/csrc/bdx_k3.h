@@ -262,6 +262,7 @@ struct K6Arrays {
     float* cn_value;               // pinned host
     uint32_t sv_cap, term_cap, cn_cap;
     double* ltail;                 // device [term_cap]: log tails of the terms ...
+    uint32_t* printed_host;        // pinned host [k6_score_grid()]: printed candidates per workgroup of k6_score_kernel; may be null
     double* ltail_host;            // ... and their copy in pinned host memory (both written by k6_score_kernel)
     // Candidates that are placed by their order key instead of by their start vertex: the host walk's (pinned host
     // memory) and the device's own whose traversal started from a vertex of an earlier flush window.  k6_insert_kernel
@@ -310,5 +311,6 @@ void launch_k6_walk(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s);    
 void launch_k6_compact(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s);  // staging + host candidates -> final table
 // ComputeProbScore's combination (BreakDancer.cpp:56-69) + PhredQ (:459-465) for every candidate of the final table
 void launch_k6_score(const K6Arrays& a, double ln10, int score_threshold, int with_scores, hipStream_t s);
+uint32_t k6_score_grid(const K6Arrays& a);  // workgroups of k6_score_kernel == entries of K6Arrays::printed_host
 
 }  // namespace bdx

@@ -1201,7 +1201,12 @@ __global__ __launch_bounds__(256) void k6_score_kernel(K6Arrays a, double ln10, 
         for (uint32_t i = threadIdx.x; i < cnt * kSvWords; i += 256) dst[i] = s_rec[i];
     }
     __syncthreads();
-    if (threadIdx.x == 0 && s_printed) atomicAdd(&a.counts->n_printed, s_printed);
+    if (threadIdx.x == 0) {
+        if (s_printed) atomicAdd(&a.counts->n_printed, s_printed);
+        // every workgroup leaves its count in the host's array (one plain store; the host adds them up): no follow-up launch
+        // that copies the total (system-scope atomics on host memory are ~1 us each and serialise)
+        if (a.printed_host) a.printed_host[blockIdx.x] = s_printed;
+    }
     const uint32_t gsz = gridDim.x * 256;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nt; i += gsz) { a.lib_index[i] = a.d_lib_index[i]; a.lib_pairs[i] = a.t_k[i]; }
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nc; i += gsz) { a.cn_key[i] = a.d_cn_key[i]; a.cn_value[i] = a.d_cn_value[i]; }
@@ -1238,10 +1243,12 @@ void launch_k6_walk(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
     if (a.big_walk) hipLaunchKernelGGL(k6_walk_big_kernel, dim3(gp / 8 + 1), dim3(256), 0, s, a);
 }
 
+uint32_t k6_score_grid(const K6Arrays& a) { return std::min<uint32_t>(a.sv_cap / kScoreSvs + 1, 2048u); }
+
 void launch_k6_score(const K6Arrays& a, double ln10, int score_threshold, int with_scores, hipStream_t s) {
-    const uint32_t g = std::min<uint32_t>(a.sv_cap / kScoreSvs + 1, 2048u);  // candidates are unknown to the host: enough groups for
+    const uint32_t g = k6_score_grid(a);  // candidates are unknown to the host: enough groups for
     hipLaunchKernelGGL(k6_score_kernel, dim3(g), dim3(256), 0, s, a, ln10, score_threshold, with_scores);  // a.sv_cap, most exit at once
-    hipLaunchKernelGGL(k6_done_kernel, dim3(1), dim3(64), 0, s, a);
+    if (!a.printed_host || a.flag_done) hipLaunchKernelGGL(k6_done_kernel, dim3(1), dim3(64), 0, s, a);
 }
 
 void launch_k6_compact(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
