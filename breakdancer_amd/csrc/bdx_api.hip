@@ -381,9 +381,11 @@ bool wait_flag(const bdx_ctx* c, int idx, uint32_t value) {
 }
 
 // Tell the host that everything enqueued so far has completed: a stream write-value into a polled pinned word, or (polling
-// off / the stream operation unavailable) an event.  The word must come from a stream command rather than from the last
-// kernel itself: a store made by a kernel after a kernel boundary is not ordered by the memory model behind the previous
-// kernels' stores to host memory issued from other compute dies.
+// off / the stream operation unavailable) an event.  The word must be written AFTER a kernel boundary behind the kernels
+// whose results it announces (their stores to host memory come from several compute dies; only the end of the kernel
+// orders them).  On this runtime the write-value command is itself a one-thread kernel (__amd_rocclr_streamOpsWrite in
+// the kernel trace, ~4 us on the stream), so where another kernel follows anyway its first thread sets the word instead
+// (K6Arrays::flag_regions / flag_groups); the command remains for the end of the run.
 int signal_ready(bdx_ctx* c, int idx, hipEvent_t ev) {
     if (c->poll) {
         if (hipStreamWriteValue32(c->stream, c->h_flags.as<uint32_t>() + idx, c->seq, 0) == hipSuccess) return BDX_OK;
@@ -823,8 +825,13 @@ int do_k6(bdx_ctx* c, bool force_host) {
         // (long chains need more rounds to agree on one label; with the general walk on, the step is long enough not to care)
         a.label_rounds = rounds ? rounds : (a.big_walk ? kK6LabelRoundsBig : kK6LabelRounds);
     }
+    if (c->poll) {  // ready words set by the kernels themselves (first thread of k6_pairs_kernel / k6_mirror_kernel)
+        a.flag_value = c->seq;
+        a.flag_groups = c->h_flags.as<uint32_t>() + 1;
+        if (c->k3.host_copy_later) a.flag_regions = c->h_flags.as<uint32_t>() + 3;
+    }
     launch_k6_groups(a, na, s);
-    {   // the host's share of the groups is complete
+    if (!c->poll) {  // the host's share of the groups is complete
         const int rc = signal_ready(c, 1, c->ev_groups);
         if (rc != BDX_OK) return rc;
     }
@@ -1063,8 +1070,8 @@ int bdx_run(bdx_ctx* c) {
         }
         r = do_join_local(c, c->na_alloc, en, &c->b_p1.as<Pass1>()->n_anom, true);
         if (r != BDX_OK) return r;
-        if (c->k3.host_copy_later) {  // the join kernel has forwarded the region table to pinned memory
-            r = signal_ready(c, 3, c->ev_regions);
+        if (c->k3.host_copy_later && !c->poll) {  // the join kernel has forwarded the region table to pinned memory
+            r = signal_ready(c, 3, c->ev_regions);  // (polling: the next kernel, k6_pairs_kernel, sets the ready word itself)
             if (r != BDX_OK) return r;
         }
         return do_k6(c, force_host);

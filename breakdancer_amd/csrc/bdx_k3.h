@@ -293,6 +293,8 @@ struct K6Arrays {
     StageCounts* counts;
     StageCounts* counts_host;      // pinned: all counters after k6_walk_kernel (written by its last workgroup)
     StageCounts* counts_host2;     // pinned: n_sv_dev / n_terms_dev / n_cn_dev / overflow after the compaction
+    uint32_t* flag_regions;        // pinned word set to flag_value by k6_pairs_kernel's first thread: everything enqueued before that kernel
+                                   // (the join, which forwards the region table to the host) has completed; may be null
     uint32_t* flag_groups;         // pinned words the host polls: set to flag_value when the host's share of the groups is
     uint32_t* flag_done;           // complete (k6_mirror_kernel) and when the final table is (k6_score_kernel)
     uint32_t flag_value;

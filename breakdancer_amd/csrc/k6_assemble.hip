@@ -123,6 +123,12 @@ __global__ __launch_bounds__(256) void k6_pairs_kernel(K6Arrays a) {
     __shared__ PartRec s_stash[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t nwaves = gridDim.x * 4;
+    // the kernels before this one are complete (kernel boundary): tell the polling host, as a stream write-value command
+    // -- itself a one-thread kernel on this runtime -- would, without its launch
+    if (a.flag_regions && blockIdx.x == 0 && threadIdx.x == 0) {
+        __threadfence_system();
+        *(volatile uint32_t*)a.flag_regions = a.flag_value;
+    }
     const uint32_t NR = a.counts->n_regions;
     const uint32_t mrp = (uint32_t)max(a.min_read_pair, 0);
     for (uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6); r < NR; r += nwaves) {
