@@ -829,6 +829,7 @@ int do_k6(bdx_ctx* c, bool force_host) {
         a.flag_value = c->seq;
         a.flag_groups = c->h_flags.as<uint32_t>() + 1;
         if (c->k3.host_copy_later) a.flag_regions = c->h_flags.as<uint32_t>() + 3;
+        a.mirror_in_walk = force_host ? 0 : 1;  // (k6_walk_kernel follows k6_emit_kernel unless everything goes to the host)
     }
     launch_k6_groups(a, na, s);
     if (!c->poll) {  // the host's share of the groups is complete

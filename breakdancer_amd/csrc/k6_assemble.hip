@@ -710,6 +710,14 @@ __global__ __launch_bounds__(256) void k6_walk_kernel(K6Arrays a) {
     int* const tails = T.tails;
     int* const newtails = T.newtails;
     const uint32_t nwaves = gridDim.x * 4;
+    if (a.mirror_in_walk && blockIdx.x == 0 && w == 0) {
+        // k6_mirror_kernel's job, done by the first wave of the kernel that follows k6_emit_kernel anyway: the counters are
+        // final (kernel boundary), they go to the host's record and the word the host polls is set behind them
+        if (lane < (int)(sizeof(StageCounts) / 4)) ((uint32_t*)a.counts_host)[lane] = ((const uint32_t*)a.counts)[lane];
+        __threadfence_system();
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0 && a.flag_groups) *(volatile uint32_t*)a.flag_groups = a.flag_value;
+    }
     const uint32_t NR = a.counts->n_regions;
     const int mrp = a.min_read_pair;
     const int nk = a.nkeys;
@@ -1239,7 +1247,7 @@ void launch_k6_groups(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
         for (int i = 1; i < a.label_rounds; ++i) hipLaunchKernelGGL(k6_label_kernel, dim3(gr), dim3(256), 0, s, a);  // round 1: k6_pairs
     hipLaunchKernelGGL(k6_classify_kernel, dim3(gr), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k6_emit_kernel, dim3(gr), dim3(256), 0, s, a);
-    if (a.counts_host) hipLaunchKernelGGL(k6_mirror_kernel, dim3(1), dim3(64), 0, s, a);
+    if (a.counts_host && !a.mirror_in_walk) hipLaunchKernelGGL(k6_mirror_kernel, dim3(1), dim3(64), 0, s, a);
 }
 
 void launch_k6_walk(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
