@@ -107,6 +107,8 @@ struct bdx_ctx {
     int big_walk_mode = -1;           // BDX_BIG_WALK=1 / 0: components of 5..64 regions always / never walked on the device; default: when
                                       // the host's share is large enough to matter (see do_k6)
     int64_t last_big_groups = -1;     // groups of such components in the previous run of this context (device + host share)
+    FinalizeParams fp_deferred{};     // second level of the pass-1 finalisation, to be run by K2's launch (enqueue-ahead runs)
+    bool finalize2_deferred = false;
     bool bucketed_join = false;       // BDX_BUCKETED_JOIN=1: use the partitioned LDS join at every size (it is the path for > 4 M entries)
     bool host_walk_only = false;      // BDX_HOST_WALK=1: every component goes through the host walk (A/B testing of K6)
     K6Arrays k6{};
@@ -404,10 +406,10 @@ float ms_between(std::chrono::steady_clock::time_point a, std::chrono::steady_cl
 }
 
 // K1 + finalize: class bytes, per-tile tables, *local* pass-1 counters
-int do_pass1(bdx_ctx* c, uint32_t na_cap = 0, bool wait = true);
+int do_pass1(bdx_ctx* c, uint32_t na_cap = 0, bool wait = true, bool defer_second = false);
 int wait_pass1(bdx_ctx* c);
 
-int do_pass1(bdx_ctx* c, uint32_t na_cap, bool wait) {
+int do_pass1(bdx_ctx* c, uint32_t na_cap, bool wait, bool defer_second) {
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const int nlibs = c->nlibs, nbams = c->nbams, nkeys = c->nkeys;
@@ -482,7 +484,10 @@ int do_pass1(bdx_ctx* c, uint32_t na_cap, bool wait) {
     ++c->seq;
     fp.flag_host = c->h_flags.as<uint32_t>(); fp.flag_value = c->seq;
     fp.na_cap = na_cap;
-    launch_finalize(fp, s);
+    // enqueue-ahead: K2 follows without a host decision in between, so its launch takes the one-workgroup second level along
+    c->fp_deferred = fp;
+    c->finalize2_deferred = defer_second;
+    launch_finalize(fp, s, !defer_second);
     c->k1_timed = time_k1;
     return wait ? wait_pass1(c) : BDX_OK;
 }
@@ -595,7 +600,12 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepa
             k2.fill_ptr[3] = c->b_pair_lo.as<uint32_t>(); k2.fill_words[3] = na; k2.fill_value[3] = 0xFFFFFFFFu;
             c->join_table_clean = slots;
         }
-        launch_k2(k2, k2_lds_bytes(nkeys), s);
+        launch_k2(k2, k2_lds_bytes(nkeys), s, c->finalize2_deferred ? &c->fp_deferred : nullptr);
+        c->finalize2_deferred = false;
+    }
+    if (c->finalize2_deferred) {  // (no K2 launch to ride on)
+        launch_finalize2_only(c->fp_deferred, s);
+        c->finalize2_deferred = false;
     }
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[3], s));
     c->nn_base = nn_base;
@@ -1085,7 +1095,7 @@ int bdx_run(bdx_ctx* c) {
     }
     int rc;
     if (guess) {
-        rc = do_pass1(c, guess, false);
+        rc = do_pass1(c, guess, false, true);
         if (rc != BDX_OK) return rc;
         c->na_alloc = guess;
         rc = enqueue_middle();

@@ -151,8 +151,9 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 // launchers (host side, defined in the .hip files)
 void launch_k1(const K1Params& p, int grid, size_t lds, hipStream_t s);
 size_t k1_lds_bytes(int nlibs, int nbams, int nkeys);
-void launch_finalize(const FinalizeParams& p, hipStream_t s);
-void launch_k2(const K2Params& p, size_t lds, hipStream_t s);
+void launch_finalize(const FinalizeParams& p, hipStream_t s, bool second_level = true);
+void launch_finalize2_only(const FinalizeParams& p, hipStream_t s);
+void launch_k2(const K2Params& p, size_t lds, hipStream_t s, const FinalizeParams* side = nullptr);  // side: finalize2_body as an extra workgroup
 size_t k2_lds_bytes(int nkeys);
 
 }  // namespace bdx

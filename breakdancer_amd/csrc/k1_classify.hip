@@ -15,6 +15,7 @@
 #include <cstddef>
 
 #include "bdx_dev.h"
+#include "bdx_finalize.h"
 
 #include <limits.h>
 
@@ -298,21 +299,6 @@ void launch_k1(const K1Params& p, int grid, size_t lds, hipStream_t s) {
 // -------------------------------------------------------------------------------------------------------
 constexpr int kFinBlock = 1024;
 
-__device__ __forceinline__ MonoRec mono_combine(const MonoRec& a, const MonoRec& b) {
-    if (a.ft == -1) return b;
-    if (b.ft == -1) return a;
-    MonoRec r;
-    r.ft = a.ft; r.fp = a.fp; r.lt = b.lt; r.lp = b.lp;
-    r.sum = a.sum + b.sum + (a.lt == b.ft ? (long long)b.fp - (long long)a.lp : 0ll);
-    return r;
-}
-__device__ __forceinline__ MonoRec mono_shfl_down(const MonoRec& a, int o) {
-    MonoRec r;
-    r.ft = __shfl_down(a.ft, o); r.fp = __shfl_down(a.fp, o); r.lt = __shfl_down(a.lt, o); r.lp = __shfl_down(a.lp, o);
-    r.sum = __shfl_down(a.sum, o);
-    return r;
-}
-
 // workgroups [0, ncols): tile scans; workgroups [ncols, ncols + nfold): ordered partial folds of the monoid table
 __global__ __launch_bounds__(kFinBlock) void finalize_kernel(const FinalizeParams p) {
     __shared__ uint32_t s_ws[kFinBlock / 64];
@@ -408,87 +394,7 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(const FinalizeParam
     }
 }
 
-// one small workgroup: counters, the last level of the monoid fold, covered_ref_len (BamSummary.cpp:123-126) and the
-// final window (BreakDancerMax.cpp:109-116)
-__global__ __launch_bounds__(256) void finalize2_kernel(const FinalizeParams p) {
-    __shared__ uint32_t s_acc[255 * 12 + 256];  // nlibs*11 + nlibs + nbams at the documented limits
-    __shared__ unsigned long long s_ref[256];
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    static_assert(kCntCopies == 64, "one lane per counter copy");
-    for (int i0 = 0; i0 < p.ncnt; i0 += 4) {  // counters: [kCntCopies][ncnt] -> [ncnt], one wave per counter
-        const int i = i0 + w;
-        uint32_t v = i < p.ncnt ? p.blk_cnt[(size_t)lane * p.ncnt + i] : 0u;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0 && i < p.ncnt) {
-            s_acc[i] = v;
-            p.cnt[i] = v;
-            if (p.cnt_host) p.cnt_host[i] = v;
-        }
-    }
-    for (int b0 = 0; b0 < p.nbams; b0 += 4) {  // one wave per source file: ordered tree fold of its <= 64 partial folds
-        const int b = b0 + w;
-        MonoRec acc;
-        acc.ft = -1; acc.fp = 0; acc.lt = 0; acc.lp = 0; acc.sum = 0;
-        if (b < p.nbams && (uint32_t)lane < p.nfold) acc = p.fold_part[(size_t)b * p.nfold + lane];
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const MonoRec other = mono_shfl_down(acc, o);
-            if (lane + o < 64 && ((lane & (2 * o - 1)) == 0)) acc = mono_combine(acc, other);
-        }
-        if (lane == 0 && b < p.nbams) {
-            const unsigned long long r = acc.ft == -1 ? 0ull : (unsigned long long)acc.sum;  // size_t ref_len, wraps like the reference
-            s_ref[b] = r;
-            p.p1->ref_len[b] = r;
-        }
-    }
-    __syncthreads();
-    if (t == 0) {
-        uint32_t covered = 0;
-        for (int b = 0; b < p.nbams; ++b)
-            if ((unsigned long long)covered < s_ref[b]) covered = (uint32_t)s_ref[b];
-        p.p1->covered_ref_len = covered;
-        int W = p.w0;
-        for (int i = 0; i < p.nlibs; ++i) {
-            const int nd = (int)(s_acc[i * kNumFlags + F_LARGE] + s_acc[i * kNumFlags + F_SMALL]);
-            const int tmp = nd > 0 ? (int)__fdiv_rn((float)covered, (float)nd) : 50;
-            W = min(W, tmp);
-        }
-        p.p1->window = W;
-        if (p.key_density) {  // same float32 expressions as the host side (set_pass1 in bdx_api.hip)
-            const uint32_t* lib_cnt = s_acc + p.nlibs * kNumFlags;
-            const uint32_t* bam_cnt = lib_cnt + p.nlibs;
-            for (int k = 0; k < p.nkeys; ++k) p.key_density[k] = 0.000001f;
-            for (int i = 0; i < p.nlibs; ++i) {
-                const int key = p.libs[i].key;  // library index with -a, else the library's source file
-                float dens = 0.000001f;
-                if (p.cn_lib) {
-                    if (lib_cnt[i] != 0) dens = __fdiv_rn((float)lib_cnt[i], (float)covered);
-                } else {
-                    dens = __fdiv_rn((float)bam_cnt[key], (float)covered);
-                }
-                p.key_density[key] = dens;
-            }
-        }
-    }
-    if (p.p1_host) {  // mirror the finished record into pinned host memory
-        __threadfence();
-        __syncthreads();
-        const uint32_t* src = (const uint32_t*)p.p1;
-        uint32_t* dst = (uint32_t*)p.p1_host;
-        const int words = (int)((offsetof(Pass1, ref_len) + sizeof(unsigned long long) * (size_t)p.nbams) / 4);
-        for (int i = t; i < words; i += 256) dst[i] = __builtin_nontemporal_load(src + i);
-        if (p.flag_host) {
-            __threadfence_system();
-            __syncthreads();
-            if (t == 0) *(volatile uint32_t*)p.flag_host = p.flag_value;
-        }
-    }
-    if (p.na_cap) {
-        __syncthreads();
-        if (t == 0 && p.p1->n_anom > p.na_cap) p.p1->n_anom = 0;
-    }
-}
+__global__ __launch_bounds__(256) void finalize2_kernel(const FinalizeParams p) { finalize2_body(p); }
 
 __global__ __launch_bounds__(256) void k0_init_kernel(const InitList l) {
     for (int f = 0; f < l.n; ++f)
@@ -503,9 +409,11 @@ void launch_init(const InitList& l, hipStream_t s) {
     hipLaunchKernelGGL(k0_init_kernel, dim3(g < 1024u ? g : 1024u), dim3(256), 0, s, l);
 }
 
-void launch_finalize(const FinalizeParams& p, hipStream_t s) {
+void launch_finalize(const FinalizeParams& p, hipStream_t s, bool second_level) {
     hipLaunchKernelGGL(finalize_kernel, dim3(p.ncols + p.nfold), dim3(kFinBlock), 0, s, p);
-    hipLaunchKernelGGL(finalize2_kernel, dim3(1), dim3(256), 0, s, p);
+    if (second_level) hipLaunchKernelGGL(finalize2_kernel, dim3(1), dim3(256), 0, s, p);  // (else: a workgroup of K2 does it)
 }
+
+void launch_finalize2_only(const FinalizeParams& p, hipStream_t s) { hipLaunchKernelGGL(finalize2_kernel, dim3(1), dim3(256), 0, s, p); }
 
 }  // namespace bdx

@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "bdx_dev.h"
+#include "bdx_finalize.h"
 
 namespace bdx {
 
@@ -36,15 +37,13 @@ __device__ __forceinline__ unsigned class_byte(const uint64_t (&cq)[kSub / 2], i
     return (unsigned)((v >> (8 * (r & 7))) & 255u);
 }
 
-__global__ __launch_bounds__(kBlock) void k2_compact_kernel(const K2Params p) {
+// nblk: workgroups that compact (the launch can hold one more, see k2_compact_side_kernel)
+__device__ __forceinline__ void k2_body(const K2Params& p, uint32_t nblk) {
     __shared__ uint32_t s_src[kWaves * kSlice];  // per wave: offset in super tile | class byte << kOffBits, by in-tile rank
     __shared__ uint32_t s_nn[kWaves * kSlice];
     const int nkeys = p.nkeys;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t nwaves = gridDim.x * kWaves;
-#pragma unroll
-    for (int f = 0; f < 4; ++f)
-        for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < p.fill_words[f]; i += gridDim.x * kBlock) p.fill_ptr[f][i] = p.fill_value[f];
+    const uint32_t nwaves = nblk * kWaves;
     const uint32_t ntiles2 = (p.ntiles + kSub - 1) / kSub;
     for (uint32_t tile2 = blockIdx.x * kWaves + w; tile2 < ntiles2; tile2 += nwaves) {
         const uint32_t tile = tile2 * kSub;  // the first of its K1 tiles: that one's exclusive prefixes are the super tile's
@@ -158,14 +157,37 @@ __global__ __launch_bounds__(kBlock) void k2_compact_kernel(const K2Params p) {
     }
 }
 
-void launch_k2(const K2Params& p, size_t lds, hipStream_t s) {
+__device__ __forceinline__ void k2_fills(const K2Params& p) {  // (every workgroup of the launch takes part)
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+        for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < p.fill_words[f]; i += gridDim.x * kBlock) p.fill_ptr[f][i] = p.fill_value[f];
+}
+
+__global__ __launch_bounds__(kBlock) void k2_compact_kernel(const K2Params p) {
+    k2_fills(p);
+    k2_body(p, gridDim.x);
+}
+
+// the same with one more workgroup, the last, that runs the second level of the pass-1 finalisation: when K2 is enqueued
+// without waiting for the pass-1 record (enqueue-ahead) that one-workgroup kernel would only sit between two launches
+__global__ __launch_bounds__(kBlock) void k2_compact_side_kernel(const K2Params p, const FinalizeParams fp) {
+    k2_fills(p);
+    if (blockIdx.x == gridDim.x - 1) {
+        finalize2_body(fp);
+        return;
+    }
+    k2_body(p, gridDim.x - 1);
+}
+
+void launch_k2(const K2Params& p, size_t lds, hipStream_t s, const FinalizeParams* side) {
     const uint32_t ntiles2 = (p.ntiles + kSub - 1) / kSub;
     const uint32_t nblk = (ntiles2 + kWaves - 1) / kWaves;
     // measured on MI355X at 58.6 k tiles: 2048 workgroups 54 us, 4096 46 us, 8192 43 us, one tile per wave (14.6 k) 45 us -- the
     // kernel is bound by its scattered 32-byte sector gathers (8 columns per anomalous read), not by wave count
     static const uint32_t cap = getenv("BDX_K2_GRID") ? (uint32_t)atoi(getenv("BDX_K2_GRID")) : 8192u;
     const uint32_t grid = nblk < cap ? nblk : cap;
-    hipLaunchKernelGGL(k2_compact_kernel, dim3(grid), dim3(kBlock), lds, s, p);
+    if (side) hipLaunchKernelGGL(k2_compact_side_kernel, dim3(grid + 1), dim3(kBlock), lds, s, p, *side);
+    else hipLaunchKernelGGL(k2_compact_kernel, dim3(grid), dim3(kBlock), lds, s, p);
 }
 
 }  // namespace bdx
