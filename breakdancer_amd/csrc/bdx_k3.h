@@ -167,8 +167,9 @@ constexpr int kK6BigMembers = 64;  // regions per component walked by the genera
 constexpr int kK6LibStride = 16;   // staged (library, pairs) entries per candidate; components that could need more go to the host
 constexpr int kK6LdsParts = 12;    // parts of a component kept in LDS by its walking thread (more: read from HBM)
 constexpr int kK6LabelRoundsBig = 8; // ... with the general walk (components of up to kK6BigMembers regions) enabled
-constexpr int kK6LabelRounds = 3;  // min-label propagation rounds: enough for a diameter of 3; a component that has
-                                   // not converged fails the closure check and goes to the host
+constexpr int kK6LabelRounds = 2;  // min-label propagation rounds (the first inside k6_pairs_kernel, the others with pointer jumping):
+                                   // two settle chains of four regions in practice; a component that has not converged fails
+                                   // the closure check and goes to the host
 
 struct RegSum {        // per accepted region r, written by k6_pairs_kernel
     uint32_t np_all;   // sorted, merged (lo, flag, lib) parts of the pairs whose second mate is in r, at parts[first ..)
