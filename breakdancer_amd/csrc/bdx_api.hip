@@ -835,7 +835,7 @@ int do_k6(bdx_ctx* c, bool force_host) {
         // (long chains need more rounds to agree on one label; with the general walk on, the step is long enough not to care)
         a.label_rounds = rounds ? rounds : (a.big_walk ? kK6LabelRoundsBig : kK6LabelRounds);
     }
-    if (c->poll) {  // ready words set by the kernels themselves (first thread of k6_pairs_kernel / k6_mirror_kernel)
+    if (c->poll) {  // ready words set by the kernels themselves (first thread of k6_pairs_kernel / first wave of k6_walk_kernel)
         a.flag_value = c->seq;
         a.flag_groups = c->h_flags.as<uint32_t>() + 1;
         if (c->k3.host_copy_later) a.flag_regions = c->h_flags.as<uint32_t>() + 3;

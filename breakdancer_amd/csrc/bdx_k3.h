@@ -292,12 +292,12 @@ struct K6Arrays {
     U4* ws_u4;
     U4* total_u4;
     StageCounts* counts;
-    StageCounts* counts_host;      // pinned: all counters after k6_walk_kernel (written by its last workgroup)
+    StageCounts* counts_host;      // pinned: all counters after k6_emit_kernel (k6_mirror_kernel, or the first wave of k6_walk_kernel)
     StageCounts* counts_host2;     // pinned: n_sv_dev / n_terms_dev / n_cn_dev / overflow after the compaction
     uint32_t* flag_regions;        // pinned word set to flag_value by k6_pairs_kernel's first thread: everything enqueued before that kernel
                                    // (the join, which forwards the region table to the host) has completed; may be null
-    uint32_t* flag_groups;         // pinned words the host polls: set to flag_value when the host's share of the groups is
-    uint32_t* flag_done;           // complete (k6_mirror_kernel) and when the final table is (k6_score_kernel)
+    uint32_t* flag_groups;         // pinned word set to flag_value behind counts_host: the host's share of the groups is complete; may be null
+    uint32_t* flag_done;           // pinned word set by k6_done_kernel when the final table is complete; null when a stream command does it
     uint32_t flag_value;
     // run constants
     const uint32_t* hist;          // [nlibs][11] adopted flag histogram
