@@ -9,6 +9,7 @@ constexpr int kTile = 256;      // reads per tile = one wave64 x 4 consecutive r
 constexpr int kBlock = 256;     // threads per workgroup (4 wave64)
 constexpr int kWaves = kBlock / 64;
 constexpr int kNumFlags = 11;
+constexpr int kK2TilesPerWave = 4; // K2 compacts four of K1's tiles per wave and needs the prefixes at those boundaries only
 constexpr int kCntCopies = 64;   // replication factor of the global pass-1 counters (power of two)
 
 enum : int { F_NA = 0, F_FF = 1, F_LARGE = 2, F_SMALL = 3, F_RF = 4, F_RR = 5, F_NORMAL_FR = 6, F_NORMAL_RF = 7,
@@ -67,7 +68,7 @@ struct FinalizeParams {
     int nlibs, nbams, nkeys, ncols, ncnt;
     int w0;
     const uint32_t* tile_tot;
-    uint32_t* tile_pre;         // exclusive scan of tile_tot per column
+    uint32_t* tile_pre;         // [ncols][tstride]: exclusive scan of tile_tot per column at every kK2TilesPerWave-th tile, entry tile / kK2TilesPerWave
     const MonoRec* tile_mono;
     const uint32_t* blk_cnt;
     uint32_t* cnt;              // [ncnt] reduced counters

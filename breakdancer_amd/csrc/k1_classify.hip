@@ -312,30 +312,23 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(const FinalizeParam
         uint32_t* out = p.tile_pre + (size_t)c * p.tstride;
         if (t == 0) s_carry = 0;
         __syncthreads();
-        // (the next round's 16 values are requested before this round's barriers: the rounds only depend on each other
-        // through the carry, not through their loads)
-        uint4 nx[4];
+        // K2 takes one wave per kK2TilesPerWave tiles and only needs the prefix at those boundaries: a thread loads 64
+        // consecutive tile totals (16 x 16 bytes in flight), adds them up in fours, scans the 16 sums and stores 16
+        // consecutive prefixes (row c of tile_pre, indexed by tile / kK2TilesPerWave) -- 65,536 tiles per round
+        constexpr int kPerThread = 64;
+        static_assert(kPerThread == 16 * kK2TilesPerWave && kK2TilesPerWave == 4, "one sum per K2 wave");
+        for (uint32_t base = 0; base < p.ntiles; base += kFinBlock * kPerThread) {
+            const uint32_t i = base + t * kPerThread;
+            uint4 x[16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {  // rows are padded to a multiple of 16 and zero-filled
-            nx[q] = make_uint4(0, 0, 0, 0);
-            if ((uint32_t)t * 16 + q * 4 < p.tstride) nx[q] = *(const uint4*)(in + t * 16 + q * 4);
-        }
-        for (uint32_t base = 0; base < p.ntiles; base += kFinBlock * 16) {
-            const uint32_t i = base + t * 16;
-            uint32_t v[16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { v[q * 4] = nx[q].x; v[q * 4 + 1] = nx[q].y; v[q * 4 + 2] = nx[q].z; v[q * 4 + 3] = nx[q].w; }
-            if (base + kFinBlock * 16 < p.ntiles) {
-                const uint32_t j = i + kFinBlock * 16;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    nx[q] = make_uint4(0, 0, 0, 0);
-                    if (j + q * 4 < p.tstride) nx[q] = *(const uint4*)(in + j + q * 4);
-                }
+            for (int q = 0; q < 16; ++q) {  // rows are padded to a multiple of 16 and zero-filled
+                x[q] = make_uint4(0, 0, 0, 0);
+                if (i + q * 4 < p.tstride) x[q] = *(const uint4*)(in + i + q * 4);
             }
+            uint32_t v[16];
             uint32_t tsum = 0;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) { const uint32_t e = v[q]; v[q] = tsum; tsum += e; }
+            for (int q = 0; q < 16; ++q) { v[q] = tsum; tsum += x[q].x + x[q].y + x[q].z + x[q].w; }
             const uint32_t inc = wave_incl_scan(tsum);
             if (lane == 63) s_ws[w] = inc;
             __syncthreads();
@@ -344,7 +337,8 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(const FinalizeParam
             const uint32_t ex = s_carry + woff + inc - tsum;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (i + q * 4 < p.tstride) *(uint4*)(out + i + q * 4) = make_uint4(ex + v[q * 4], ex + v[q * 4 + 1], ex + v[q * 4 + 2], ex + v[q * 4 + 3]);
+                if (i + q * 16 < p.tstride)
+                    *(uint4*)(out + i / 4 + q * 4) = make_uint4(ex + v[q * 4], ex + v[q * 4 + 1], ex + v[q * 4 + 2], ex + v[q * 4 + 3]);
             __syncthreads();
             if (t == kFinBlock - 1) s_carry = ex + tsum;
             __syncthreads();

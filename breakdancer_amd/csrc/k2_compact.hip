@@ -22,7 +22,7 @@ namespace bdx {
 
 size_t k2_lds_bytes(int) { return 0; }
 
-constexpr int kSub = 4;                 // K1 tiles per wave
+constexpr int kSub = kK2TilesPerWave;   // K1 tiles per wave (finalize_kernel writes the prefixes for these boundaries)
 constexpr int kPerLane = 4 * kSub;      // consecutive reads per lane (<= 32: the per-lane state is 32-bit masks)
 constexpr int kTile2 = kTile * kSub;    // reads per wave
 constexpr int kSlice = 256;             // anomalous reads compacted through LDS at a time (more in one super tile: several rounds)
@@ -46,13 +46,12 @@ __device__ __forceinline__ void k2_body(const K2Params& p, uint32_t nblk) {
     const uint32_t nwaves = nblk * kWaves;
     const uint32_t ntiles2 = (p.ntiles + kSub - 1) / kSub;
     for (uint32_t tile2 = blockIdx.x * kWaves + w; tile2 < ntiles2; tile2 += nwaves) {
-        const uint32_t tile = tile2 * kSub;  // the first of its K1 tiles: that one's exclusive prefixes are the super tile's
         const uint64_t base = (uint64_t)tile2 * kTile2 + (uint64_t)lane * kPerLane;
         // the prefix bases are fetched together with the class bytes (one round trip instead of two)
-        const uint32_t pre_norm = p.tile_pre[(size_t)kColNormal * p.tstride + tile];
-        const uint32_t rank0 = p.tile_pre[(size_t)kColAnom * p.tstride + tile];
-        const uint32_t pre_k0 = p.tile_pre[(size_t)kColKey0 * p.tstride + tile];
-        const uint32_t pre_k1 = nkeys > 1 ? p.tile_pre[(size_t)(kColKey0 + 1) * p.tstride + tile] : 0u;
+        const uint32_t pre_norm = p.tile_pre[(size_t)kColNormal * p.tstride + tile2];
+        const uint32_t rank0 = p.tile_pre[(size_t)kColAnom * p.tstride + tile2];
+        const uint32_t pre_k0 = p.tile_pre[(size_t)kColKey0 * p.tstride + tile2];
+        const uint32_t pre_k1 = nkeys > 1 ? p.tile_pre[(size_t)(kColKey0 + 1) * p.tstride + tile2] : 0u;
         uint64_t cq[kSub / 2];  // the lane's class bytes, 8 per word
 #pragma unroll
         for (int q = 0; q < kSub / 2; ++q) cq[q] = 0;
@@ -143,8 +142,8 @@ __device__ __forceinline__ void k2_body(const K2Params& p, uint32_t nblk) {
             }
             const uint32_t v = (uint32_t)__popc(mk0) + ((uint32_t)__popc(mk1) << 16);
             const uint32_t ex = wave_incl_scan(v) - v;
-            const uint32_t b0 = p.pk_base[k0] + (k0 == 0 ? pre_k0 : p.tile_pre[(size_t)(kColKey0 + k0) * p.tstride + tile]);
-            const uint32_t b1 = k0 + 1 < nkeys ? p.pk_base[k0 + 1] + (k0 == 0 ? pre_k1 : p.tile_pre[(size_t)(kColKey0 + k0 + 1) * p.tstride + tile]) : 0u;
+            const uint32_t b0 = p.pk_base[k0] + (k0 == 0 ? pre_k0 : p.tile_pre[(size_t)(kColKey0 + k0) * p.tstride + tile2]);
+            const uint32_t b1 = k0 + 1 < nkeys ? p.pk_base[k0 + 1] + (k0 == 0 ? pre_k1 : p.tile_pre[(size_t)(kColKey0 + k0 + 1) * p.tstride + tile2]) : 0u;
             uint32_t j = rank0 + local0;
             for (uint32_t mm = m_anom; mm; mm &= mm - 1, ++j) {
                 if (j >= p.c.cap) break;
