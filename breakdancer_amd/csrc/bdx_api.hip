@@ -632,7 +632,7 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool f
         // they are write-once, read-never on the device, so the PCIe writes overlap the kernels and no D2H copy is needed
         HIPCHK(c, c->h_regs.ensure(cap * sizeof(RegionRec)));
         HIPCHK(c, c->h_pk.ensure(cap * 2 * nkeys * 4));
-        const size_t nblk = scan_grid(na) + 1;
+        const size_t nblk = scan_grid(na, 1) + 1;  // (sized for one element per thread, the finest split the scans use)
         HIPCHK(c, c->b_ws_u4.ensure(nblk * sizeof(U4)));
         HIPCHK(c, c->b_ws_u32.ensure(nblk * 4));
         HIPCHK(c, c->b_totals.ensure(64));

@@ -156,12 +156,12 @@ void launch_k3(const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n
     const uint32_t* n_ptr = &p1->n_anom;
     HeadIn hin{cp.tid, cp.pos, cp.meta, p1};
     HeadOut hout{a};
-    scan_launch<U4>(hin, hout, n_ptr, n_anom_host, a.ws_u4, a.head_total, s);
+    scan_launch<U4, 1>(hin, hout, n_ptr, n_anom_host, a.ws_u4, a.head_total, s);
     const uint32_t g = (n_anom_host + 255) / 256;
     const CandCtx cx{a, cp, p1, min_len, seq_coverage_lim, nn_base, tail};
     AcceptIn ain{cx};
     AcceptOut aout{cx, nkeys};
-    scan_launch<uint32_t>(ain, aout, &a.counts->n_cand, n_anom_host, a.ws_u32, a.acc_total, s);
+    scan_launch<uint32_t, 1>(ain, aout, &a.counts->n_cand, n_anom_host, a.ws_u32, a.acc_total, s);
     if (region_of_launch) hipLaunchKernelGGL(k3_region_of_kernel, dim3(g), dim3(256), 0, s, a, p1);  // else: fused into the join
 }
 
