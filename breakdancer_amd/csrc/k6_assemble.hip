@@ -1161,6 +1161,8 @@ __global__ __launch_bounds__(256) void k6_score_kernel(K6Arrays a, double ln10, 
     for (uint32_t base = blockIdx.x * kScoreSvs; base < n; base += gridDim.x * kScoreSvs) {  // (the grid is capped: stride over the table)
         __syncthreads();
         const uint32_t cnt = min((uint32_t)kScoreSvs, n - base);
+        uint2 bg = make_uint2(0u, 0u);  // (requested together with the gather below, used after it)
+        if (threadIdx.x < cnt) bg = a.sv_begin[base + threadIdx.x];
         for (uint32_t i = threadIdx.x; i < cnt * kSvWords; i += 256) {  // gather the records from the staging slots / the host's list
             const uint32_t sv = i / kSvWords, w = i - sv * kSvWords;
             const uint32_t from = a.sv_src[base + sv];
@@ -1170,7 +1172,6 @@ __global__ __launch_bounds__(256) void k6_score_kernel(K6Arrays a, double ln10, 
         __syncthreads();
         if (threadIdx.x < cnt) {
             SvOut* o = (SvOut*)s_rec + threadIdx.x;
-            const uint2 bg = a.sv_begin[base + threadIdx.x];
             o->sv.lib_begin = (int32_t)bg.x;
             o->sv.cn_begin = (int32_t)bg.y;
         }
