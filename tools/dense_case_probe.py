@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Steady-state step time of a dense synthetic case (200 Mbp, 8 % discordant pairs, 60 M reads, ~166 k SV candidates) with
+the general device walk off and on: python tools/dense_case_probe.py  (BDX_WALK_PROFILE=1 adds the host walk's share)."""
 import sys, os, time
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np
