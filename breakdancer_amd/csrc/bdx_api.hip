@@ -769,7 +769,11 @@ int do_k6(bdx_ctx* c, bool force_host) {
     HIPCHK(c, c->b_rs.ensure(cap * sizeof(RegSum)));
     HIPCHK(c, c->b_members.ensure(cap * kK6MaxMembers * sizeof(MemberInfo)));
     HIPCHK(c, c->b_own.ensure(cap * 7 * 4));
-    HIPCHK(c, c->b_member_ids.ensure(cap * kK6BigMembers * 4));
+    // Components of 5..64 regions cost one more launch (k6_walk_big_kernel) and a member table of 256 B per label.  Few of
+    // them are walked by the host behind the device's own walk for free; many (dense data) make the host walk the longest
+    // stage.  Without a previous run to go by, the number of anomalous reads decides.
+    const int big_walk = c->big_walk_mode >= 0 ? c->big_walk_mode : (c->last_big_groups >= 0 ? c->last_big_groups > 2000 : na > 500000u);
+    if (big_walk) HIPCHK(c, c->b_member_ids.ensure(cap * kK6BigMembers * 4));
     a.sv_cap = na / 2 + 1; a.term_cap = na / 2 + 1; a.cn_cap = (na / 2 + 1) * (uint32_t)nkeys;
     a.lib_stride = (uint32_t)std::min(nlibs, kK6LibStride);
     HIPCHK(c, c->b_slot.ensure(cap * sizeof(SvOut)));
@@ -805,7 +809,7 @@ int do_k6(bdx_ctx* c, bool force_host) {
     a.mcount = a.out_deg + 4 * cap; a.pcount = a.out_deg + 5 * cap;
     a.members = c->b_members.as<MemberInfo>();
     a.own_nsv = c->b_own.as<uint32_t>(); a.own_nacc = a.own_nsv + cap; a.own_ncn = a.own_nsv + 2 * cap; a.own_first = a.own_nsv + 3 * cap; a.slot_next = a.own_nsv + 4 * cap; a.owners = a.own_nsv + 5 * cap; a.owners_big = a.own_nsv + 6 * cap;
-    a.member_ids = c->b_member_ids.as<uint32_t>();
+    a.member_ids = big_walk ? c->b_member_ids.as<uint32_t>() : nullptr;
     a.sv_stage = c->b_slot.as<SvOut>(); a.lib_stage = c->b_lib_stage.as<LibStage>(); a.cn_stage = c->b_cn_stage.as<CnStage>();
     a.sv_out = c->h_sv_out.as<SvOut>(); a.lib_index = c->h_lib_index.as<int32_t>(); a.lib_pairs = c->h_lib_pairs.as<int32_t>();
     a.cn_key = c->h_cn_key.as<int32_t>(); a.cn_value = c->h_cn_value.as<float>();
@@ -826,10 +830,7 @@ int do_k6(bdx_ctx* c, bool force_host) {
     a.nlibs = nlibs; a.nkeys = nkeys; a.min_read_pair = c->opts.min_read_pair; a.chr_restricted = c->opts.chr_restricted;
     a.period = std::max(1, c->opts.buffer_size + 1);
     a.force_host = force_host ? 1 : 0;
-    // Components of 5..64 regions cost one more launch (k6_walk_big_kernel).  Few of them are walked by the host behind
-    // the device's own walk for free; many (dense data) make the host walk the longest stage.  Without a previous run to
-    // go by, the number of anomalous reads decides.
-    a.big_walk = c->big_walk_mode >= 0 ? c->big_walk_mode : (c->last_big_groups >= 0 ? c->last_big_groups > 2000 : na > 500000u);
+    a.big_walk = big_walk;
     {
         static const int rounds = getenv("BDX_LABEL_ROUNDS") ? std::max(1, atoi(getenv("BDX_LABEL_ROUNDS"))) : 0;
         // (long chains need more rounds to agree on one label; with the general walk on, the step is long enough not to care)

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void k6_classify_kernel(K6Arrays a) {
         }
     }
     const uint32_t slot = atomicAdd(&a.mcount[L], 1u);
-    if (slot < (uint32_t)kK6BigMembers) a.member_ids[(size_t)L * kK6BigMembers + slot] = r;
+    if (a.big_walk && slot < (uint32_t)kK6BigMembers) a.member_ids[(size_t)L * kK6BigMembers + slot] = r;
     if (slot < (uint32_t)kK6MaxMembers) {
         MemberInfo* mi = &a.members[(size_t)L * kK6MaxMembers + slot];  // (written field by field: no private copy)
         mi->r = r;
