@@ -127,6 +127,7 @@ class BreakDancer:
 
     def push_reads(self, arrs):
         b, keep = make_batch(arrs)
+        self._keep.append(keep)  # the H2D copies are asynchronous: the arrays must outlive them (released by run())
         self._chk(self.lib.bdx_push(self.h, C.byref(b)), "bdx_push")
 
     def set_device_reads(self, ptrs, n):
@@ -139,6 +140,7 @@ class BreakDancer:
 
     def run(self):
         self._chk(self.lib.bdx_run(self.h), "bdx_run")
+        self._keep.clear()  # bdx_run has waited for the stream: every pushed batch is in HBM
         return self
 
     # ---- results ----------------------------------------------------------------------------------------
@@ -199,6 +201,11 @@ class BreakDancer:
     def set_stage_timing(self, on=True):
         """HIP events between the stages (compact / regions / join timings); costs a few microseconds per event."""
         self._chk(self.lib.bdx_set_stage_timing(self.h, int(on)), "bdx_set_stage_timing")
+        return self
+
+    def set_enqueue_ahead(self, on=True):
+        """Repeated runs of one context may launch the later stages ahead of the pass-1 read-back (default on)."""
+        self._chk(self.lib.bdx_set_enqueue_ahead(self.h, int(on)), "bdx_set_enqueue_ahead")
         return self
 
     def set_host_walk(self, on=True):

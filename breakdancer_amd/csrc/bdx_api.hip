@@ -1406,6 +1406,12 @@ int bdx_set_stage_timing(bdx_ctx* c, int on) {
     return BDX_OK;
 }
 
+int bdx_set_enqueue_ahead(bdx_ctx* c, int on) {
+    if (!c) return BDX_EINVAL;
+    c->speculate = on != 0;
+    return BDX_OK;
+}
+
 int bdx_set_host_walk(bdx_ctx* c, int on) {
     if (!c) return BDX_EINVAL;
     c->host_walk_only = on != 0;

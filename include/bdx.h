@@ -182,6 +182,10 @@ int bdx_get_read_class(const bdx_ctx* ctx, uint8_t* out, size_t cap);
 int bdx_get_timings(const bdx_ctx* ctx, float* ms, int cap);
 /* [1]-[3] need HIP events between the stages, which idle the GPU for a few microseconds each: off by default */
 int bdx_set_stage_timing(bdx_ctx* ctx, int on);
+/* Enqueue-ahead (on by default): a context that has just run an input of the same size launches the later stages
+ * before the pass-1 record is back, sized from the previous run's count of anomalous reads.  It only ever applies to a
+ * repeated run; 0 makes every bdx_run take the path a first run takes (what bench.py times). */
+int bdx_set_enqueue_ahead(bdx_ctx* ctx, int on);
 
 /* Where the SV candidates of the last bdx_run were assembled.  Components of the region graph that are one region, or
  * two regions of one flush window joined by one connection, are walked on the device (build_connection /

@@ -171,6 +171,10 @@ def oracle_lib():
         L.bdo_translate_token.argtypes = [C.c_char_p]
         L.bdo_sv_support.restype = C.c_int64
         L.bdo_sv_support.argtypes = [C.c_void_p] * 4
+        L.bdo_bam_load.restype = C.c_int64
+        L.bdo_bam_load.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.bdo_bam_error.restype = C.c_char_p
+        L.bdo_bam_tid.argtypes = [C.c_char_p, C.c_char_p]
         _oracle = L
     return _oracle
 
@@ -226,6 +230,15 @@ class OracleRun:
         n = len(a["tid"])
         self.L.bdo_set_stream(self.h, bam, n, *[_p(a[k]) for k in
                               ("tid", "pos", "mtid", "mpos", "isize", "flag", "qlen", "bdqual", "lib", "name_id")])
+
+    def load_bam(self, bam, path, only_tid=-1, passes=1, set_targets=False):
+        """Decode `path` with the oracle's own single-threaded BGZF/BAM front end (oracle/bd_oracle_bam.cpp) `passes`
+        times and use its records as the stream of physical file `bam`.  Returns (records, seconds spent decoding)."""
+        sec = C.c_double(0)
+        n = self.L.bdo_bam_load(self.h, bam, path.encode(), only_tid, passes, int(set_targets), C.byref(sec))
+        if n < 0:
+            raise RuntimeError(self.L.bdo_bam_error().decode())
+        return int(n), sec.value
 
     def run(self):
         rc = self.L.bdo_run(self.h)

@@ -24,6 +24,23 @@ def test_oracle_reproduces_reference_golden_tables(fn, kw):
     assert filter_cmd_lines(run.text) == exp
 
 
+@pytest.mark.parametrize("fn,kw", CASES)
+def test_oracle_bam_front_end_reproduces_the_golden_tables(fn, kw):
+    """the same six invocations with the records decoded by oracle/bd_oracle_bam.cpp (the single-threaded, reference-shaped
+    reader bench.py's cpu_baseline times) instead of the pure-Python decoder"""
+    gd = os.path.join(GOLDEN, "chr21")
+    run = OracleRun(open(os.path.join(gd, "inv_del_bam_config")).read(), make_opts(**kw))
+    counts = []
+    for b, name in enumerate(run.bam_names):
+        n, _ = run.load_bam(b, os.path.join(gd, name), only_tid=kw.get("chr_tid", -1), passes=2, set_targets=(b == 0))
+        counts.append(n)
+    if "chr_tid" not in kw:
+        assert counts == [3069, 2848]
+    run.run()
+    assert filter_cmd_lines(run.text) == filter_cmd_lines(open(os.path.join(gd, fn)).read())
+    assert oracle_lib().bdo_bam_tid(os.path.join(gd, run.bam_names[0]).encode(), b"21") == TID21
+
+
 def test_chr21_read_counts():
     """test-data/TestData.hpp.in:21-24: 3069 / 2848 primary aligned records"""
     run = load_chr21(make_opts())
