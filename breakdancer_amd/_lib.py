@@ -48,7 +48,7 @@ EXPORTS = ["bdx_opts_default", "bdx_create", "bdx_destroy", "bdx_strerror", "bdx
            "bdx_device", "bdx_stream", "bdx_stage_pass1", "bdx_get_pass1_local", "bdx_set_pass1_global", "bdx_stage_compact", "bdx_stage_regions",
            "bdx_get_stage_regions", "bdx_get_region_records", "bdx_get_compact", "bdx_join_entries", "bdx_stage_walk", "bdx_set_collect_support", "bdx_get_sv_support",
            "bdx_set_host_walk", "bdx_get_walk_split", "bdx_set_stage_timing", "bdx_get_cross_window_svs",
-           "bdx_set_enqueue_ahead"]
+           "bdx_set_enqueue_ahead", "bdx_was_replayed"]
 
 REGION_REC_DTYPE = np.dtype([("tid", "<i4"), ("start", "<i4"), ("end", "<i4"), ("n_reads", "<u4"), ("rev_reads", "<u4"),
                              ("nonctx_reads", "<u4"), ("normal_read_pairs", "<u4"), ("max_qlen", "<i4"), ("first_read", "<u4")])
@@ -91,6 +91,7 @@ def load():
     L.bdx_set_host_walk.argtypes = [vp, C.c_int]
     L.bdx_set_stage_timing.argtypes = [vp, C.c_int]
     L.bdx_set_enqueue_ahead.argtypes = [vp, C.c_int]
+    L.bdx_was_replayed.argtypes = [vp]
     L.bdx_get_walk_split.argtypes = [vp, vp, vp, vp]
     L.bdx_get_cross_window_svs.argtypes = [vp, vp]
     L.bdx_classify.argtypes = [C.POINTER(bdx_opts), C.POINTER(bdx_lib), C.c_int, C.POINTER(bdx_batch), vp, C.c_int]

@@ -219,6 +219,10 @@ class BreakDancer:
         self._chk(self.lib.bdx_get_walk_split(self.h, C.byref(v[0]), C.byref(v[1]), C.byref(v[2])), "bdx_get_walk_split")
         return tuple(x.value for x in v)
 
+    def was_replayed(self):
+        """True if the last run met a read name more than twice and replayed the region graph read by read on the host"""
+        return bool(self.lib.bdx_was_replayed(self.h))
+
     def cross_window_svs(self):
         """device-assembled SVs whose traversal started from a region of an earlier flush window"""
         v = C.c_uint32(0)

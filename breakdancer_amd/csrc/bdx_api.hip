@@ -129,6 +129,7 @@ struct bdx_ctx {
     K4Arrays k4{};
     std::vector<double> log_tail;
     bool collect_support = false;
+    bool replayed = false;            // the last run went through the read-level host replay (a read name seen more than twice)
     std::vector<uint32_t> sup_off;    // [n_svs + 1]
     std::vector<uint64_t> sup_idx;
     std::vector<uint8_t> sup_flag;
@@ -419,7 +420,7 @@ int do_pass1(bdx_ctx* c, uint32_t na_cap, bool wait, bool defer_second) {
     const uint32_t tstride = (uint32_t)round_up(std::max<uint32_t>(ntiles, 16), 16);
     const int grid1 = (int)std::min<uint32_t>((ntiles + kWaves - 1) / kWaves, kK1MaxGrid);
     c->ntiles = ntiles; c->tstride = tstride;
-    c->ran = false; c->stage = 0;
+    c->ran = false; c->stage = 0; c->replayed = false;
     c->na_alloc = 0;
     c->regions.clear(); c->r_pk.clear(); c->parts.clear();
     c->reg = nullptr; c->nreg = 0; c->rpk = nullptr;
@@ -723,7 +724,6 @@ int readback(bdx_ctx* c, bool with_groups) {
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, hipGetLastError());
     c->counts = *c->h_counts.as<StageCounts>();
-    if (c->counts.overflow == 2) return fail(c, BDX_ELIMIT, "more than two primary reads share one read name (malformed input)");
     if (c->counts.overflow) return fail(c, BDX_EINTERNAL, "group list overflow");
     (void)with_groups;  // regions / prefix samples / groups already sit in pinned host memory (see do_cut / do_join_local)
     return BDX_OK;
@@ -1048,6 +1048,50 @@ int collect_support(bdx_ctx* c, uint32_t ph) {
     return BDX_OK;
 }
 
+// A read name occurs more than twice (StageCounts::irregular): everything behind the region cut is replayed one read at a
+// time on the host (H2), from the compact records; the scores still come from K5.  Names clashing across merged BAMs are the
+// usual cause -- the reference keeps running on them (ReadRegionData.cpp:108-113), so does this.
+int replay_reads(bdx_ctx* c, uint32_t ph) {
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipStreamSynchronize(s));  // K6's kernels were enqueued on the pair model: let them finish, their results are dropped
+    const uint32_t na = c->p1.n_anom;
+    std::vector<uint64_t> key(na);
+    std::vector<int32_t> region_of(na), isize(na);
+    std::vector<uint32_t> meta(na);
+    HIPCHK(c, hipMemcpy(key.data(), c->cp.key, (size_t)na * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(region_of.data(), c->k3.region_of, (size_t)na * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(meta.data(), c->cp.meta, (size_t)na * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(isize.data(), c->cp.isize, (size_t)na * 4, hipMemcpyDeviceToHost));
+    if (ph)
+        for (int32_t& r : region_of)
+            if (r >= 0) r += (int32_t)ph;
+    ReadWalkInput ri{};
+    WalkInput& wi = ri.base;
+    wi.opts = c->opts; wi.libs = c->libs.data(); wi.nlibs = c->nlibs; wi.nbams = c->nbams; wi.nkeys = c->nkeys;
+    wi.hist = c->cnt.data(); wi.covered_ref_len = c->g_covered; wi.key_density = c->key_density.data();
+    wi.regions = c->reg; wi.nregions = c->nreg; wi.r_pk = c->rpk; wi.parts = nullptr; wi.last_maxq = c->counts.last_maxq;
+    wi.any_anomalous = na != 0;
+    ri.n_reads = na; ri.key = key.data(); ri.region_of = region_of.data(); ri.meta = meta.data(); ri.isize = isize.data();
+    ri.phantom = ph;
+    std::vector<uint32_t> sup;
+    if (c->collect_support) { ri.support_off = &c->sup_off; ri.support = &sup; }
+    c->walk.clear();
+    read_level_walk(ri, c->walk);
+    c->counts.n_groups = 0; c->counts.n_pairs = 0;
+    int rc = score_host_terms(c);
+    if (rc == BDX_OK) rc = finish_host_walk(c);
+    if (rc != BDX_OK) return rc;
+    c->replayed = true;
+    if (c->collect_support) {  // compact indices -> stream indices and flags
+        std::vector<uint32_t> idx(na);
+        HIPCHK(c, hipMemcpy(idx.data(), c->cp.idx, (size_t)na * 4, hipMemcpyDeviceToHost));
+        c->sup_idx.resize(sup.size());
+        c->sup_flag.resize(sup.size());
+        for (size_t i = 0; i < sup.size(); ++i) { c->sup_idx[i] = idx[sup[i]]; c->sup_flag[i] = (uint8_t)meta_flag(meta[sup[i]]); }
+    }
+    return BDX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1128,6 +1172,7 @@ int bdx_run(bdx_ctx* c) {
     const uint32_t ph = (na && ph_opt) ? 1u : 0u;
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[5], s));
     const auto t_h0 = std::chrono::steady_clock::now();
+    auto t_h1 = t_h0;
     if (na) {
         if (!wait_flag(c, 3, c->seq)) {
             if (c->poll) HIPCHK(c, hipStreamSynchronize(s)); else HIPCHK(c, hipEventSynchronize(c->ev_regions));
@@ -1139,12 +1184,19 @@ int bdx_run(bdx_ctx* c) {
             if (c->poll) HIPCHK(c, hipStreamSynchronize(s)); else HIPCHK(c, hipEventSynchronize(c->ev_groups));
         }
         c->counts = *c->h_counts.as<StageCounts>();
-        if (c->counts.overflow == 2) return fail(c, BDX_ELIMIT, "more than two primary reads share one read name (malformed input)");
+        if (c->counts.irregular) {  // a read name seen more than twice: the pair model does not hold (see bdx_walk_reads.cpp)
+            t_h1 = std::chrono::steady_clock::now();
+            rc = replay_reads(c, ph);
+            if (rc != BDX_OK) return rc;
+            const auto t_r = std::chrono::steady_clock::now();
+            c->stage_ms[4] = ms_between(t_h0, t_h1); c->stage_ms[5] = ms_between(t_h1, t_r); c->stage_ms[7] = ms_between(t_begin, t_r);
+            return BDX_OK;
+        }
         if (c->counts.overflow) return fail(c, BDX_EINTERNAL, "group list overflow");
         decode_groups(c, c->h_groups.as<GroupRec>(), c->counts.n_groups, ph);
         c->last_big_groups = (int64_t)c->counts.n_groups + c->counts.n_groups_big;  // (the host's share: mostly such components)
     }
-    const auto t_h1 = std::chrono::steady_clock::now();
+    t_h1 = std::chrono::steady_clock::now();
     rc = host_walk(c, c->counts.last_maxq, na != 0);
     if (rc != BDX_OK) return rc;
     const auto t_h2 = std::chrono::steady_clock::now();
@@ -1287,7 +1339,7 @@ int bdx_join_entries(bdx_ctx* c, size_t n, const uint64_t* key, const uint32_t* 
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, hipGetLastError());
     const StageCounts sc = *c->h_counts.as<StageCounts>();
-    if (sc.overflow == 2) return fail(c, BDX_ELIMIT, "more than two primary reads share one read name (malformed input)");
+    if (sc.irregular) return fail(c, BDX_ELIMIT, "a read name occurs more than twice: staged runs cannot replay it (run the chromosomes in one context)");
     if (sc.overflow) return fail(c, BDX_EINTERNAL, "group list overflow");
     if (n_groups) *n_groups = sc.n_groups;
     if (n_pairs) *n_pairs = sc.n_pairs;
@@ -1433,6 +1485,8 @@ int bdx_get_cross_window_svs(const bdx_ctx* c, uint32_t* n_sv_device) {
     *n_sv_device = c->counts.n_old;
     return BDX_OK;
 }
+
+int bdx_was_replayed(const bdx_ctx* c) { return c && c->ran && c->replayed ? 1 : 0; }
 
 int bdx_get_timings(const bdx_ctx* c, float* ms, int cap) {
     if (!c || !ms) return 0;

@@ -28,6 +28,8 @@ struct StageCounts {
     uint32_t n_groups_big; // K6: groups of those components
     uint32_t n_old;        // K6: device candidates of traversals started from a vertex of an earlier flush window
     uint32_t n_ins;        // K6: candidates the compaction inserts by order key (the host walk's + n_old)
+    uint32_t irregular;    // K4: some read name was seen more than twice among the anomalous reads (ReadRegionData.cpp:108-113
+                           // keeps appending): the pair model does not hold, the run is replayed read by read on the host
 };
 
 struct RegionRec {
@@ -101,7 +103,8 @@ struct K4Arrays {
     uint32_t* bcur;      // [nbuckets]
     uint64_t* e_key;     // [cap] bucketed entries
     uint32_t* e_idx;     // [cap]
-    int32_t* partner;    // [cap] compact index of the mate, -1 if none
+    int32_t* partner;    // [cap] compact index of the mate; -1 name seen once; -2 name seen twice but a mate sits in a rejected
+                         // candidate region (ReadRegionData.cpp:177-199 forgets the name: no pair)
     int32_t* pair_lo;    // [cap] direct join of a single-context run: at the second-observed mate of a pair, the region of the
                          // first-observed one (else -1, preset); saves K6 a dependent load per read.  May be null
     uint64_t* t_key;     // [2*cap] global fallback table of the bucketed path; [t_mask + 1] table of the direct path
@@ -119,7 +122,8 @@ __host__ __device__ __forceinline__ uint64_t group_pack(uint32_t rlo, uint32_t r
 }
 constexpr uint32_t kMaxRegions = (1u << 26) - 2;
 
-// join input: one entry per anomalous read (region < 0: not in an accepted region, skipped)
+// join input: one entry per anomalous read (region < 0: in a rejected candidate region -- it still enters the table so that
+// a name seen three times is noticed wherever its reads lie, but it never forms a pair)
 struct Entries {
     const uint64_t* key;
     const int32_t* region;   // region id (global ids when the entries come from several shards)

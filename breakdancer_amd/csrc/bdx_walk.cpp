@@ -37,10 +37,6 @@ struct OldVertex {  // endpoint from an earlier flush: only has edges to regions
     bool visited;
 };
 
-struct LibAcc {
-    int lib, rc, span;
-};
-
 struct WalkScratch {
     std::vector<GroupPart> parts;  // sorted by (hi, lo, flag, lib), duplicates merged
     std::vector<Group> groups;
@@ -55,6 +51,79 @@ struct WalkScratch {
 };
 WalkScratch* walk_scratch_new() { return new WalkScratch; }
 void walk_scratch_free(WalkScratch* s) { delete s; }
+
+// Second half of process_sv (BreakDancer.cpp:370-497) and of the SvBuilder constructor (SvBuilder.cpp:36-66): everything that
+// follows the pairing and the two support gates.  flag_counts / la (pairs and span sums of the dominant flag per library,
+// ascending library index) come from the pair-group aggregates (H1) or from the reads themselves (bdx_walk_reads.cpp).
+void emit_sv(const WalkInput& in, WalkResult& out, int A, int B, const int* flag_counts, int flag, const LibAcc* la, int nacc,
+             int max_readlen, uint32_t grp_mask, uint64_t cur_key) {
+    const HostRegion* R = in.regions;
+    const int n = B >= 0 ? 2 : 1;
+
+    int chr[2], pos[2], fwd[2], rev[2];
+    const HostRegion& ra = R[A];
+    chr[0] = ra.tid; pos[0] = ra.start; pos[1] = ra.end;
+    fwd[0] = (int)(ra.n - ra.rev); rev[0] = (int)ra.rev;
+    if (n == 2) {
+        const HostRegion& rb = R[B];
+        fwd[1] = (int)(rb.n - rb.rev); rev[1] = (int)rb.rev;
+        if (flag == BDX_ARP_RF) pos[1] = rb.end + max_readlen - 5;
+        else if (flag == BDX_ARP_FF) { pos[0] = pos[1]; pos[1] = rb.end + max_readlen - 5; }
+        else if (flag == BDX_ARP_RR) pos[1] = rb.start;
+        else { pos[0] = pos[1]; pos[1] = rb.start; }
+        chr[1] = rb.tid;
+    } else {
+        fwd[1] = fwd[0]; rev[1] = rev[0]; chr[1] = ra.tid; pos[1] = ra.end;
+    }
+
+    // normal reads between the regions: proper reads after A's last read up to and including B's first
+    const int cn_begin = (int)out.cn_key.size();
+    float cn_sum = 0.0f;
+    int nkeys_present = 0;
+    if (n == 2) {
+        for (int k = 0; k < in.nkeys; ++k) {
+            const uint32_t cnt = in.r_pk[(size_t)B * 2 * in.nkeys + k] - in.r_pk[(size_t)A * 2 * in.nkeys + in.nkeys + k];
+            if (cnt == 0) continue;
+            const float cn = cnt / (in.key_density[k] * float(pos[1] - pos[0])) * 2.0f;
+            out.cn_key.push_back(k);
+            out.cn_value.push_back(cn);
+            cn_sum += cn;
+            ++nkeys_present;
+        }
+    }
+    cn_sum /= 2.0f * (size_t)nkeys_present;
+    const float allele_frequency = 1 - cn_sum;
+
+    if (flag != BDX_ARP_RF && flag != BDX_ARP_RR && pos[0] + max_readlen - 5 < pos[1]) pos[0] += max_readlen - 5;
+
+    float diff = 0;
+    for (int i = 0; i < nacc; ++i) diff += float(la[i].span) - float(la[i].rc) * in.libs[la[i].lib].mean_insertsize;
+    const int diffspan = int(diff / float(flag_counts[flag]) + 0.5);
+
+    int total_region_size = ra.end - ra.start + 1;
+    if (n == 2) total_region_size += R[B].end - R[B].start + 1;
+
+    HostSv hs;
+    bdx_sv& sv = hs.sv;
+    for (int i = 0; i < 2; ++i) { sv.chr[i] = chr[i]; sv.pos[i] = pos[i] + 1; sv.fwd[i] = fwd[i]; sv.rev[i] = rev[i]; }
+    sv.flag = flag; sv.size = diffspan; sv.score = 0; sv.num_reads = flag_counts[flag]; sv.printed = 0;
+    sv.region[0] = A; sv.region[1] = B;
+    sv.lib_begin = (int)out.lib_index.size(); sv.lib_count = nacc;
+    sv.cn_begin = cn_begin; sv.cn_count = nkeys_present;
+    sv.allele_frequency = allele_frequency; sv.logp = 0;
+    hs.grp_mask = grp_mask;
+    hs.start = (uint32_t)(cur_key & 0xffffffffu);
+    for (int i = 0; i < nacc; ++i) {
+        out.lib_index.push_back(la[i].lib);
+        out.lib_pairs.push_back(la[i].rc);
+        const uint32_t nflag = in.hist[(size_t)la[i].lib * BDX_NUM_FLAGS + flag];
+        double lambda = double(total_region_size) * (double(nflag) / double(in.covered_ref_len));
+        lambda = std::max(1.0e-10, lambda);
+        out.terms.push_back(SvTerm{lambda, la[i].rc});
+    }
+    out.svs.push_back(hs);
+    out.sv_key.push_back(cur_key);
+}
 
 namespace {
 
@@ -200,71 +269,8 @@ struct Walker {
                 else la.insert(la.begin() + k, LibAcc{(int)p.lib, (int)p.pairs, (int)p.sum_isize});
             }
         }
-        const int nacc = (int)la.size();
-
-        int chr[2], pos[2], fwd[2], rev[2];
-        const HostRegion& ra = R[A];
-        chr[0] = ra.tid; pos[0] = ra.start; pos[1] = ra.end;
-        fwd[0] = (int)(ra.n - ra.rev); rev[0] = (int)ra.rev;
-        if (n == 2) {
-            const HostRegion& rb = R[B];
-            fwd[1] = (int)(rb.n - rb.rev); rev[1] = (int)rb.rev;
-            if (flag == BDX_ARP_RF) pos[1] = rb.end + max_readlen - 5;
-            else if (flag == BDX_ARP_FF) { pos[0] = pos[1]; pos[1] = rb.end + max_readlen - 5; }
-            else if (flag == BDX_ARP_RR) pos[1] = rb.start;
-            else { pos[0] = pos[1]; pos[1] = rb.start; }
-            chr[1] = rb.tid;
-        } else {
-            fwd[1] = fwd[0]; rev[1] = rev[0]; chr[1] = ra.tid; pos[1] = ra.end;
-        }
-
-        // normal reads between the regions: proper reads after A's last read up to and including B's first
-        const int cn_begin = (int)out.cn_key.size();
-        float cn_sum = 0.0f;
-        int nkeys_present = 0;
-        if (n == 2) {
-            for (int k = 0; k < in.nkeys; ++k) {
-                const uint32_t cnt = in.r_pk[(size_t)B * 2 * in.nkeys + k] - in.r_pk[(size_t)A * 2 * in.nkeys + in.nkeys + k];
-                if (cnt == 0) continue;
-                const float cn = cnt / (in.key_density[k] * float(pos[1] - pos[0])) * 2.0f;
-                out.cn_key.push_back(k);
-                out.cn_value.push_back(cn);
-                cn_sum += cn;
-                ++nkeys_present;
-            }
-        }
-        cn_sum /= 2.0f * (size_t)nkeys_present;
-        const float allele_frequency = 1 - cn_sum;
-
-        if (flag != BDX_ARP_RF && flag != BDX_ARP_RR && pos[0] + max_readlen - 5 < pos[1]) pos[0] += max_readlen - 5;
-
-        float diff = 0;
-        for (int i = 0; i < nacc; ++i) diff += float(la[i].span) - float(la[i].rc) * in.libs[la[i].lib].mean_insertsize;
-        const int diffspan = int(diff / float(flag_counts[flag]) + 0.5);
-
-        int total_region_size = ra.end - ra.start + 1;
-        if (n == 2) total_region_size += R[B].end - R[B].start + 1;
-
-        HostSv hs;
-        bdx_sv& sv = hs.sv;
-        for (int i = 0; i < 2; ++i) { sv.chr[i] = chr[i]; sv.pos[i] = pos[i] + 1; sv.fwd[i] = fwd[i]; sv.rev[i] = rev[i]; }
-        sv.flag = flag; sv.size = diffspan; sv.score = 0; sv.num_reads = flag_counts[flag]; sv.printed = 0;
-        sv.region[0] = A; sv.region[1] = B;
-        sv.lib_begin = (int)out.lib_index.size(); sv.lib_count = nacc;
-        sv.cn_begin = cn_begin; sv.cn_count = nkeys_present;
-        sv.allele_frequency = allele_frequency; sv.logp = 0;
-        hs.grp_mask = (gs[0] ? 1u : 0u) | (gs[1] ? 2u : 0u) | (gs[2] ? 4u : 0u);
-        hs.start = (uint32_t)(cur_key & 0xffffffffu);
-        for (int i = 0; i < nacc; ++i) {
-            out.lib_index.push_back(la[i].lib);
-            out.lib_pairs.push_back(la[i].rc);
-            const uint32_t nflag = in.hist[(size_t)la[i].lib * BDX_NUM_FLAGS + flag];
-            double lambda = double(total_region_size) * (double(nflag) / double(in.covered_ref_len));
-            lambda = std::max(1.0e-10, lambda);
-            out.terms.push_back(SvTerm{lambda, la[i].rc});
-        }
-        out.svs.push_back(hs);
-        out.sv_key.push_back(cur_key);
+        const uint32_t grp_mask = (gs[0] ? 1u : 0u) | (gs[1] ? 2u : 0u) | (gs[2] ? 4u : 0u);
+        emit_sv(in, out, A, B, flag_counts, flag, la.data(), (int)la.size(), max_readlen, grp_mask, cur_key);
     }
 
     // ---- one flush (BreakDancer.cpp:266-346) over the groups with hi in (prev, last] ----------------------------

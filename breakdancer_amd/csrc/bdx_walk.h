@@ -68,6 +68,27 @@ struct WalkResult {
     }
 };
 
+struct LibAcc {  // pairs and |isize| sum of one library for the dominant flag of an SV candidate
+    int lib, rc, span;
+};
+void emit_sv(const WalkInput& in, WalkResult& out, int A, int B, const int* flag_counts, int flag, const LibAcc* la, int nacc,
+             int max_readlen, uint32_t grp_mask, uint64_t cur_key);
+
+// H2 (bdx_walk_reads.cpp): the same replay one read at a time, for inputs in which a read name occurs more than twice.
+// base.parts is unused; base.regions / r_pk already carry the phantom shift (region_of too).
+struct ReadWalkInput {
+    WalkInput base;
+    uint32_t n_reads;          // anomalous (compact) reads in stream order
+    const uint64_t* key;       // name key
+    const int32_t* region_of;  // accepted region id, or -1 for a read of a rejected candidate
+    const uint32_t* meta;      // flag | rev<<4 | lib<<8 | qlen<<16
+    const int32_t* isize;      // |isize|
+    uint32_t phantom;          // 1: region 0 is the read-less region a negative -s registers
+    std::vector<uint32_t>* support_off;  // optional: [n_svs + 1] offsets into support
+    std::vector<uint32_t>* support;      // optional: compact indices of the supporting reads, SvBuilder order
+};
+void read_level_walk(const ReadWalkInput& in, WalkResult& out);
+
 // scratch vectors of the walk, kept by the context so that steady-state runs do not allocate
 struct WalkScratch;
 WalkScratch* walk_scratch_new();

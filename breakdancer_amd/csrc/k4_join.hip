@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k4_count_kernel(K4Arrays k4, Entries en, 
     __syncthreads();
     for (int it = 0; it < kPartChunk / 256; ++it) {
         const uint32_t j = base + it * 256 + threadIdx.x;
-        if (j < na && en.region[j] >= 0) atomicAdd(&s_h[bucket_of(mix64(en.key[j]), k4.log2b)], 1u);
+        if (j < na) atomicAdd(&s_h[bucket_of(mix64(en.key[j]), k4.log2b)], 1u);
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < k4.nbuckets; b += 256)
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k4_scatter_kernel(K4Arrays k4, Entries en
     __syncthreads();
     for (int it = 0; it < kPartChunk / 256; ++it) {
         const uint32_t j = base + it * 256 + threadIdx.x;
-        if (j < na && en.region[j] >= 0) atomicAdd(&s_h[bucket_of(mix64(en.key[j]), k4.log2b)], 1u);
+        if (j < na) atomicAdd(&s_h[bucket_of(mix64(en.key[j]), k4.log2b)], 1u);
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < k4.nbuckets; b += 256) {
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k4_scatter_kernel(K4Arrays k4, Entries en
     __syncthreads();
     for (int it = 0; it < kPartChunk / 256; ++it) {
         const uint32_t j = base + it * 256 + threadIdx.x;
-        if (j < na && en.region[j] >= 0) {
+        if (j < na) {
             const uint64_t key = en.key[j];
             const uint32_t b = bucket_of(mix64(key), k4.log2b);
             const uint32_t slot = s_base[b] + atomicAdd(&s_h[b], 1u);
@@ -104,8 +104,8 @@ __global__ __launch_bounds__(256) void k4_scatter_kernel(K4Arrays k4, Entries en
 constexpr uint32_t kMaxProbes = 4096;  // a name key shared by thousands of reads is malformed input: fail instead of crawling
 
 template <bool kLds>
-__device__ __forceinline__ void join_bucket(uint64_t* tkey, int32_t* tidx, uint32_t cap, const K4Arrays& k4, uint32_t off,
-                                            uint32_t cnt, StageCounts* counts) {
+__device__ __forceinline__ void join_bucket(uint64_t* tkey, int32_t* tidx, uint32_t cap, const K4Arrays& k4, const int32_t* region,
+                                            uint32_t off, uint32_t cnt, StageCounts* counts) {
     for (uint32_t s = threadIdx.x; s < cap; s += blockDim.x) tidx[s] = -1;
     __syncthreads();
     for (uint32_t e = threadIdx.x; e < cnt; e += blockDim.x) {
@@ -119,7 +119,7 @@ __device__ __forceinline__ void join_bucket(uint64_t* tkey, int32_t* tidx, uint3
             if (++probes > kMaxProbes) { placed = false; break; }
         }
         if (placed) tkey[s] = key;
-        else counts->overflow = 2;
+        else counts->irregular = 1;
     }
     __syncthreads();
     for (uint32_t e = threadIdx.x; e < cnt; e += blockDim.x) {
@@ -128,20 +128,21 @@ __device__ __forceinline__ void join_bucket(uint64_t* tkey, int32_t* tidx, uint3
         uint32_t s = (uint32_t)(mix64(key) & 0xffffffffu) % cap;
         int32_t mate = -1;
         const uint32_t lim = cap < kMaxProbes ? cap : kMaxProbes;
-        for (uint32_t probes = 0; probes < lim; ++probes) {  // to the end of the probe run: a second match is malformed input
+        for (uint32_t probes = 0; probes < lim; ++probes) {  // to the end of the probe run: a second match is a name seen three times
             const int32_t o = tidx[s];
             if (o == -1) break;
             if (o != j && tkey[s] == key) {
-                if (mate != -1) counts->overflow = 2;
+                if (mate != -1) counts->irregular = 1;
                 mate = o;
             }
             s = s + 1 == cap ? 0 : s + 1;
         }
+        if (mate >= 0 && (region[j] < 0 || region[mate] < 0)) mate = -2;  // a mate in a rejected candidate: the name was forgotten
         k4.partner[j] = mate;
     }
 }
 
-__global__ __launch_bounds__(256) void k4_join_kernel(K4Arrays k4, StageCounts* counts) {
+__global__ __launch_bounds__(256) void k4_join_kernel(K4Arrays k4, const int32_t* region, StageCounts* counts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t b = blockIdx.x;
     const uint32_t off = k4.boff[b], cnt = k4.boff[b + 1] - off;
@@ -149,9 +150,9 @@ __global__ __launch_bounds__(256) void k4_join_kernel(K4Arrays k4, StageCounts* 
     if (2 * cnt <= (uint32_t)kJoinLdsSlots) {
         uint64_t* tkey = (uint64_t*)smem;
         int32_t* tidx = (int32_t*)(tkey + kJoinLdsSlots);
-        join_bucket<true>(tkey, tidx, 2 * cnt, k4, off, cnt, counts);
+        join_bucket<true>(tkey, tidx, 2 * cnt, k4, region, off, cnt, counts);
     } else {
-        join_bucket<false>(k4.t_key + 2 * (size_t)off, k4.t_idx + 2 * (size_t)off, 2 * cnt, k4, off, cnt, counts);
+        join_bucket<false>(k4.t_key + 2 * (size_t)off, k4.t_idx + 2 * (size_t)off, 2 * cnt, k4, region, off, cnt, counts);
     }
 }
 
@@ -189,7 +190,8 @@ __global__ __launch_bounds__(256) void k4_direct_join_kernel(K4Arrays k4, Entrie
     } else {
         rj = en.region[j];
     }
-    if (rj < 0) return;
+    // (a read of a rejected candidate joins the table as well: it never forms a pair, but a third sighting of its name
+    // must be noticed wherever the three reads lie)
     const uint64_t key = en.key[j];
     const uint64_t h = mix64(key);
     const uint32_t tag = (uint32_t)(h >> 32);
@@ -202,10 +204,12 @@ __global__ __launch_bounds__(256) void k4_direct_join_kernel(K4Arrays k4, Entrie
         if ((uint32_t)(old >> 32) == tag) {
             const uint32_t o = (uint32_t)old;
             if (en.key[o] == key) {
-                k4.partner[j] = (int32_t)o;
-                if (atomicExch(&k4.partner[o], (int32_t)j) != -1) counts->overflow = 2;  // a third read with this name
-                if (k4.pair_lo && en.c_rid) {  // the later read in stream order is the second-observed mate
-                    if (o < j) k4.pair_lo[j] = en.c_rid[en.cand[o]];
+                const int ro = en.c_rid ? en.c_rid[en.cand[o]] : en.region[o];
+                const bool alive = rj >= 0 && ro >= 0;  // both mates in accepted regions (ReadRegionData.cpp:177-199)
+                k4.partner[j] = alive ? (int32_t)o : -2;
+                if (atomicExch(&k4.partner[o], alive ? (int32_t)j : -2) != -1) counts->irregular = 1;  // a third read with this name
+                if (alive && k4.pair_lo && en.c_rid) {  // the later read in stream order is the second-observed mate
+                    if (o < j) k4.pair_lo[j] = ro;
                     else k4.pair_lo[o] = rj;
                 }
                 return;
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256) void k4_direct_join_kernel(K4Arrays k4, Entrie
         }
         s = (s + 1) & k4.t_mask;
     }
-    counts->overflow = 2;
+    counts->irregular = 1;  // (a probe sequence this long: thousands of reads share one name)
 }
 
 constexpr uint64_t kEmptyGroup = ~0ull;
@@ -307,7 +311,7 @@ static void launch_k4_impl(const K4Arrays& k4, const Entries& en, const uint32_t
         (void)hipFuncSetAttribute((const void*)k4_aggregate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kAggSlots * 16 + 32);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k4_join_kernel, dim3(k4.nbuckets), dim3(256), (size_t)kJoinLdsSlots * 12, s, k4, counts);
+    hipLaunchKernelGGL(k4_join_kernel, dim3(k4.nbuckets), dim3(256), (size_t)kJoinLdsSlots * 12, s, k4, en.region, counts);
     if (aggregate) hipLaunchKernelGGL(k4_aggregate_kernel, dim3(g), dim3(256), (size_t)kAggSlots * 16 + 32, s, k4, en, n_ptr, counts);
 }
 

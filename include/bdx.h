@@ -196,6 +196,10 @@ int bdx_get_walk_split(const bdx_ctx* ctx, uint32_t* n_sv_device, uint32_t* n_sv
 /* Of the device-assembled candidates, those whose traversal started from a region of an earlier flush window (the
  * reference's flush cadence, BreakDancer.cpp:254-264; they are placed in the output by order key, not by position). */
 int bdx_get_cross_window_svs(const bdx_ctx* ctx, uint32_t* n_sv_device);
+/* 1 if the last bdx_run met a read name more than twice among the anomalous reads (e.g. merged BAMs with clashing read
+ * names) and therefore replayed everything behind the region cut one read at a time on the host, with the reference's
+ * semantics for such names (ReadRegionData.cpp:108-113,152-175, SvBuilder.cpp:101-118, BreakDancer.cpp:357-368); 0 otherwise. */
+int bdx_was_replayed(const bdx_ctx* ctx);
 
 /* Kernel-level entry points for parity tests.
  * bdx_classify replaces IAlignmentClassifier::classify (io/IlluminaPEReadClassifier.cpp:59-101) plus the

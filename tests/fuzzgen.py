@@ -192,3 +192,22 @@ def make_graph_case(seed, n_slots=240, sizes=(1, 2, 2, 3, 3, 3, 4, 4, 5)):
 GRAPH_OPTION_SETS = [dict(), dict(min_read_pair=1), dict(min_read_pair=3), dict(min_read_pair=4), dict(buffer_size=1), dict(buffer_size=2),
                      dict(buffer_size=3, min_read_pair=1), dict(buffer_size=7), dict(cn_lib=1, print_af=1), dict(chr_tid=0),
                      dict(chr_tid=0, min_read_pair=1), dict(transchr_rearrange=1, min_read_pair=1), dict(min_len=40), dict(fisher=1)]
+
+
+def clash_names(streams, seed, frac=0.04):
+    """Give a fraction of the records the name of another record, within and across the BAMs: names then occur three,
+    four ... times (what merged BAMs with clashing read names look like).  The reference keeps running on such input
+    (ReadRegionData.cpp:108-113 appends every sighting, SvBuilder.cpp:101-118 pairs first come first paired)."""
+    rng = np.random.default_rng(77_000 + seed)
+    out = [dict(s) for s in streams]
+    allnames = np.concatenate([s["name_id"] for s in out])
+    for s in out:
+        n = len(s["name_id"])
+        if n == 0 or len(allnames) == 0:
+            continue
+        ids = s["name_id"].copy()
+        k = max(1, int(n * frac))
+        victims = rng.choice(n, size=min(k, n), replace=False)
+        ids[victims] = rng.choice(allnames, size=len(victims))
+        s["name_id"] = ids
+    return out

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from fuzzgen import OPTION_SETS, make_case
+from fuzzgen import GRAPH_OPTION_SETS, OPTION_SETS, make_case, make_graph_case
 from helpers import GOLDEN, OracleRun, load_chr21, make_opts
 from runner import compare, compare_support, oracle_case, product_from_oracle
 
@@ -185,35 +185,59 @@ def test_full_size_properties():
     assert abs(np.median(dels["size"]) - 1150) < 40
 
 
-def test_degenerate_inputs_do_not_hang():
-    """all reads anomalous (every tile overflows the lane count); and one name key shared by thousands of reads, which
-    must be reported as an error instead of crawling through a quadratic probe sequence"""
-    import breakdancer_amd as bda
-    from breakdancer_amd.api import BdxError, LibraryConfig, Options
-    n = 20000
-    rng = np.random.default_rng(3)
+def _raw_case(n, keys, seed=3):
+    """n anomalous reads (FF, insert 5100) on one chromosome with the given name ids, as one BAM stream + config"""
+    rng = np.random.default_rng(seed)
     pos = np.sort(rng.integers(1000, 200000, n)).astype(np.int32)
-    base = dict(tid=np.zeros(n, np.int32), pos=pos, mtid=np.zeros(n, np.int32), mpos=pos + 5000, isize=np.full(n, 5100, np.int32),
-                flag=np.full(n, 0x1 | 0x20 | 0x40, np.uint16), qlen=np.full(n, 100, np.uint16), mapq=np.full(n, 60, np.uint8),
-                lib=np.zeros(n, np.uint8), bam=np.zeros(n, np.uint8))
-    bd = bda.BreakDancer(Options(), [LibraryConfig(400, 30, 490, 310, 100)], 1, max_read_window_size=200)
-    bd.push_reads(dict(base, name_key=np.arange(n, dtype=np.uint64) // 2 + 1))   # every read anomalous, mates adjacent
-    s = bd.run().summary()
-    assert s["n_anomalous"] == n and s["n_pairs"] > 0
-    bd.close()
-    bd = bda.BreakDancer(Options(), [LibraryConfig(400, 30, 490, 310, 100)], 1, max_read_window_size=200)
-    bd.push_reads(dict(base, name_key=np.full(n, 42, np.uint64)))
-    with pytest.raises(BdxError):
-        bd.run()
-    bd.close()
-    # three primary reads with one name (the reference's filter leaves at most two, AlignmentFilter.hpp:24-28): refused
-    keys = np.arange(n, dtype=np.uint64) // 2 + 1
-    keys[2::50] = keys[0::50]   # (only triples inside accepted regions reach the join; with 400 of them some do)
-    bd = bda.BreakDancer(Options(), [LibraryConfig(400, 30, 490, 310, 100)], 1, max_read_window_size=200)
-    bd.push_reads(dict(base, name_key=keys))
-    with pytest.raises(BdxError):
-        bd.run()
-    bd.close()
+    st = dict(tid=np.zeros(n, np.int32), pos=pos, mtid=np.zeros(n, np.int32), mpos=pos + 5000, isize=np.full(n, 5100, np.int32),
+              flag=np.full(n, 0x1 | 0x20 | 0x40, np.uint16), qlen=np.full(n, 100, np.int32), bdqual=np.full(n, 60, np.uint8),
+              rg=["rg1"] * n, name_id=np.asarray(keys, np.uint64))
+    cfg = "readgroup:rg1\tplatform:illumina\tmap:x.bam\treadlen:100.00\tlib:lib1\tlower:310.00\tupper:490.00\tmean:400.00\tstd:30.00\n"
+    return cfg, [st], ["c1"]
+
+
+def test_degenerate_inputs_do_not_hang():
+    """all reads anomalous (every tile overflows the lane count); one name shared by thousands of reads; names shared by
+    three reads.  The reference runs on all of them (ReadRegionData.cpp:108-113 just keeps appending; only the list
+    reaching two adds an edge), so the product must produce the oracle's output, not an error."""
+    n = 20000
+    pairs = np.arange(n, dtype=np.uint64) // 2 + 1
+    triples = pairs.copy()
+    triples[2::50] = triples[0::50]
+    for keys, expect_replay in ((pairs, False), (np.full(n, 42, np.uint64), True), (triples, True)):
+        cfg, streams, targets = _raw_case(n, keys)
+        for o in (dict(), dict(min_read_pair=1, buffer_size=3)):
+            run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1, **o))
+            bd = product_from_oracle(run, support=True)
+            s = compare(run, bd)
+            compare_support(run, bd)
+            assert s["n_anomalous"] == n
+            assert bd.was_replayed() == expect_replay
+            bd.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_read_names_seen_more_than_twice(seed):
+    """merged BAMs with clashing read names: triples, quadruples, duplicates across files and across accepted / rejected
+    candidate regions.  The product notices the third sighting in the join and replays the region graph read by read with
+    the reference's semantics (bdx_walk_reads.cpp); output and supporting reads must equal the oracle's."""
+    from fuzzgen import clash_names
+    if seed % 2 == 0:
+        cfg, streams, targets = make_case(900 + seed)
+        osets = OPTION_SETS
+    else:
+        cfg, streams, targets = make_graph_case(900 + seed)
+        osets = GRAPH_OPTION_SETS
+    streams = clash_names(streams, seed, frac=0.02 + 0.02 * (seed % 4))
+    replayed = 0
+    for o in (osets[seed % len(osets)], osets[(seed * 5 + 2) % len(osets)], dict(min_read_pair=1, buffer_size=1)):
+        run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1, **o))
+        bd = product_from_oracle(run, support=True)
+        compare(run, bd)
+        compare_support(run, bd)
+        replayed += bd.was_replayed()
+        bd.close()
+    assert replayed > 0
 
 
 @pytest.mark.parametrize("seed", [3, 17, 29])
