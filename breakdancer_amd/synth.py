@@ -86,20 +86,29 @@ def concat(parts):
     return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
 
 
-def make_genome(lengths, coverage=30.0, seed=1, libs=((400.0, 30.0),), lib_bam=(0,), n_translocations=0, ctx_pairs=15):
+def make_genome(lengths, coverage=30.0, seed=1, libs=((400.0, 30.0),), lib_bam=(0,), n_translocations=0, ctx_pairs=15, threads=None):
     """Multi-chromosome, multi-library synthetic input (configs[2]-[4] shapes, scaled by `lengths`).
-    Every library contributes coverage/len(libs); `lib_bam[i]` is the source file of library i.  Planted
-    translocations add clusters of `ctx_pairs` inter-chromosomal pairs (both mates carry tid != mtid, isize 0).
-    Returns the merged, (tid, pos, strand)-sorted SoA."""
+    Every library contributes coverage/len(libs) (`coverage` may also be a sequence with one value per library, e.g. a 60x
+    tumour and a 30x normal file); `lib_bam[i]` is the source file of library i.  Planted translocations add clusters of
+    `ctx_pairs` inter-chromosomal pairs (both mates carry tid != mtid, isize 0).
+    Returns the merged, (tid, pos, strand)-sorted SoA.  The (chromosome, library) parts are generated and the chromosomes
+    sorted on `threads` threads (numpy releases the GIL), which is what makes full-size inputs practical in a test."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
     rng = np.random.default_rng(seed)
-    parts = []
+    cov = list(coverage) if hasattr(coverage, "__len__") else [coverage / len(libs)] * len(libs)
+    jobs = []
     base = 0
     for tid, L in enumerate(lengths):
         for li, (mean, std) in enumerate(libs):
-            d = make_chromosome(length=L, coverage=coverage / len(libs), seed=seed * 1000 + tid * 16 + li, tid=tid, lib=li,
-                                bam=lib_bam[li], name_base=base, mean=mean, std=std)
+            jobs.append(dict(length=L, coverage=cov[li], seed=seed * 1000 + tid * 16 + li, tid=tid, lib=li, bam=lib_bam[li],
+                             name_base=base, mean=mean, std=std))
             base += 1 << 36
-            parts.append(d)
+    if threads is None:
+        threads = max(1, min(32, (os.cpu_count() or 2) // 2))
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        parts = list(ex.map(lambda kw: make_chromosome(**kw), jobs))
+    per_tid = [[p for p, j in zip(parts, jobs) if j["tid"] == t] for t in range(len(lengths))]
     if n_translocations:
         n = n_translocations * ctx_pairs
         ta = rng.integers(0, len(lengths), n_translocations)
@@ -121,8 +130,16 @@ def make_genome(lengths, coverage=30.0, seed=1, libs=((400.0, 30.0),), lib_bam=(
                         isize=np.zeros(n, np.int32), flag=flag, qlen=np.full(n, READLEN, np.uint16), mapq=mq,
                         lib=li.astype(np.uint8), bam=bam, name_key=key)
         f = np.zeros(n, bool)
-        parts.append(rec(ta, pa, tb, pb, f, ~f, True))
-        parts.append(rec(tb, pb, ta, pa, ~f, f, False))
-    d = concat(parts)
-    order = np.lexsort(((d["flag"] >> 4) & 1, d["pos"], d["tid"]))
-    return {k: v[order] for k, v in d.items()}
+        for part in (rec(ta, pa, tb, pb, f, ~f, True), rec(tb, pb, ta, pa, ~f, f, False)):
+            for t in range(len(lengths)):  # (part order inside a chromosome as in one global stable sort)
+                m = part["tid"] == t
+                if m.any():
+                    per_tid[t].append({k: v[m] for k, v in part.items()})
+
+    def sort_tid(ps):
+        d = concat(ps)
+        order = np.lexsort(((d["flag"] >> 4) & 1, d["pos"]))
+        return {k: v[order] for k, v in d.items()}
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        chroms = list(ex.map(sort_tid, [ps for ps in per_tid if ps]))
+    return concat(chroms)
