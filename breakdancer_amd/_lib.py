@@ -28,6 +28,11 @@ class bdx_batch(C.Structure):
                                            "name_key")] + [("n", C.c_size_t)]
 
 
+class bdx_batch_buf(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("tid", "pos", "mtid", "mpos", "isize", "flag", "qlen", "mapq", "lib", "bam",
+                                           "name_key")] + [("capacity", C.c_size_t)]
+
+
 class bdx_summary(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_anomalous", C.c_uint64), ("covered_ref_len", C.c_uint32),
                 ("window", C.c_int32), ("n_candidates", C.c_uint32), ("n_regions", C.c_uint32), ("n_pairs", C.c_uint32),
@@ -48,7 +53,7 @@ EXPORTS = ["bdx_opts_default", "bdx_create", "bdx_destroy", "bdx_strerror", "bdx
            "bdx_device", "bdx_stream", "bdx_stage_pass1", "bdx_get_pass1_local", "bdx_set_pass1_global", "bdx_stage_compact", "bdx_stage_regions",
            "bdx_get_stage_regions", "bdx_get_region_records", "bdx_get_compact", "bdx_join_entries", "bdx_stage_walk", "bdx_set_collect_support", "bdx_get_sv_support",
            "bdx_set_host_walk", "bdx_get_walk_split", "bdx_set_stage_timing", "bdx_get_cross_window_svs",
-           "bdx_set_enqueue_ahead", "bdx_was_replayed"]
+           "bdx_set_enqueue_ahead", "bdx_was_replayed", "bdx_acquire_batch", "bdx_submit_batch", "bdx_reset_reads"]
 
 REGION_REC_DTYPE = np.dtype([("tid", "<i4"), ("start", "<i4"), ("end", "<i4"), ("n_reads", "<u4"), ("rev_reads", "<u4"),
                              ("nonctx_reads", "<u4"), ("normal_read_pairs", "<u4"), ("max_qlen", "<i4"), ("first_read", "<u4")])
@@ -92,6 +97,9 @@ def load():
     L.bdx_set_stage_timing.argtypes = [vp, C.c_int]
     L.bdx_set_enqueue_ahead.argtypes = [vp, C.c_int]
     L.bdx_was_replayed.argtypes = [vp]
+    L.bdx_acquire_batch.argtypes = [vp, C.c_size_t, C.POINTER(bdx_batch_buf)]
+    L.bdx_submit_batch.argtypes = [vp, C.c_size_t]
+    L.bdx_reset_reads.argtypes = [vp]
     L.bdx_get_walk_split.argtypes = [vp, vp, vp, vp]
     L.bdx_get_cross_window_svs.argtypes = [vp, vp]
     L.bdx_classify.argtypes = [C.POINTER(bdx_opts), C.POINTER(bdx_lib), C.c_int, C.POINTER(bdx_batch), vp, C.c_int]

@@ -130,6 +130,31 @@ class BreakDancer:
         self._keep.append(keep)  # the H2D copies are asynchronous: the arrays must outlive them (released by run())
         self._chk(self.lib.bdx_push(self.h, C.byref(b)), "bdx_push")
 
+    def stream_reads(self, arrs, batch=1 << 20):
+        """The streaming producer's path: fill the context's pinned staging buffers batch by batch (bdx_acquire_batch /
+        bdx_submit_batch); copies and the classifier overlap the filling of the next buffer."""
+        n = len(arrs["tid"])
+        cols = {}
+        for k, dt in BATCH_FIELDS:
+            src = arrs.get(k)
+            if src is None and k == "mapq":
+                src = arrs.get("bdqual")
+            if src is None and k == "name_key":
+                src = arrs.get("name_id")
+            cols[k] = np.ascontiguousarray(src, dtype=dt)
+        for lo in range(0, n, batch):
+            m = min(batch, n - lo)
+            buf = L.bdx_batch_buf()
+            self._chk(self.lib.bdx_acquire_batch(self.h, m, C.byref(buf)), "bdx_acquire_batch")
+            for k, dt in BATCH_FIELDS:
+                C.memmove(getattr(buf, k), cols[k][lo:lo + m].ctypes.data, m * np.dtype(dt).itemsize)
+            self._chk(self.lib.bdx_submit_batch(self.h, m), "bdx_submit_batch")
+
+    def reset_reads(self):
+        self._chk(self.lib.bdx_reset_reads(self.h), "bdx_reset_reads")
+        self._keep.clear()
+        return self
+
     def set_device_reads(self, ptrs, n):
         """ptrs: dict field -> device pointer (int); arrays stay owned by the caller."""
         b = L.bdx_batch()

@@ -156,6 +156,27 @@ struct bdx_ctx {
     uint32_t join_table_clean = 0;    // slots of the direct join table already set to -1 (by K2), 0 = none
     float stage_ms[kNumStages] = {0};
     hipEvent_t ev[8] = {nullptr};
+
+    // ---- streamed input (bdx_push / bdx_acquire_batch + bdx_submit_batch) ----
+    hipStream_t copy_stream = nullptr;  // H2D copies of the batches; the classifier follows each batch on `stream` behind ev_copy
+    hipEvent_t ev_copy = nullptr;
+    bool copy_pending = false;          // copies enqueued since the last run: `stream` has to wait for ev_copy
+    // pass 1 as the reads arrive: the tile tables are laid out for k1_cap_tiles tiles and tiles [0, k1_done) are classified
+    bool k1_live = false;
+    uint32_t k1_done = 0, k1_cap_tiles = 0;
+    struct Stage {                      // one pinned staging buffer of the ring
+        PinBuf buf;
+        size_t cap = 0;
+        hipEvent_t done = nullptr;
+        bool busy = false;
+    };
+    Stage ring[4];
+    int ring_next = 0, ring_cur = -1;
+    // name keys that stay in the caller's pinned memory (bdx_push): one segment per batch; host == nullptr: that range of
+    // keys was copied into the resident column
+    struct KeySeg { uint64_t begin; const uint64_t* host; };
+    std::vector<KeySeg> key_segs;
+    DevBuf b_seg;
 };
 
 namespace {
@@ -178,6 +199,9 @@ size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 int alloc_reads(bdx_ctx* c, size_t cap) {
     cap = round_up(std::max<size_t>(cap, 1), 1024);
     if (cap <= c->cap) return BDX_OK;
+    if (c->copy_stream) HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->k1_live = false;  // the tile tables were laid out for the old capacity: bdx_run classifies from the first tile again
     struct Col { DevBuf* b; size_t esz; const void** slot; };
     Col cols[] = {{&c->b_tid, 4, (const void**)&c->d.tid},     {&c->b_pos, 4, (const void**)&c->d.pos},
                   {&c->b_mtid, 4, (const void**)&c->d.mtid},   {&c->b_mpos, 4, (const void**)&c->d.mpos},
@@ -195,6 +219,87 @@ int alloc_reads(bdx_ctx* c, size_t cap) {
         *col.slot = nb.p;
     }
     c->cap = cap;
+    return BDX_OK;
+}
+
+// columns of a staging buffer: every column starts 8-byte aligned (the stride is a multiple of 64 records)
+void stage_view(const bdx_ctx::Stage& st, bdx_batch_buf* out) {
+    char* p = (char*)st.buf.p;
+    const size_t K = st.cap;
+    out->name_key = (uint64_t*)p; p += K * 8;
+    out->tid = (int32_t*)p; p += K * 4;
+    out->pos = (int32_t*)p; p += K * 4;
+    out->mtid = (int32_t*)p; p += K * 4;
+    out->mpos = (int32_t*)p; p += K * 4;
+    out->isize = (int32_t*)p; p += K * 4;
+    out->flag = (uint16_t*)p; p += K * 2;
+    out->qlen = (uint16_t*)p; p += K * 2;
+    out->mapq = (uint8_t*)p; p += K;
+    out->lib = (uint8_t*)p; p += K;
+    out->bam = (uint8_t*)p;
+    out->capacity = K;
+}
+
+int pass1_prepare(bdx_ctx* c, uint32_t tiles_cap);
+int pass1_classify(bdx_ctx* c, uint32_t upto, bool timed);
+
+constexpr uint32_t kStreamTilesMin = 4096;  // classify behind a batch only once this many new tiles (1 M reads) are complete
+
+// One batch of host records into the resident store: H2D copies on the copy stream, then -- for a store that is being
+// filled from empty -- the classifier over the tiles the batch completed, on the compute stream behind the copies.
+// lazy_keys: the batch is the caller's own memory and stays valid until bdx_run returns, so pinned name keys need not
+// travel: K2 fetches the keys of the anomalous reads (about 1 %) straight from there.
+int enqueue_batch(bdx_ctx* c, const bdx_batch& b, bool lazy_keys) {
+    if (c->n + b.n > c->cap) {
+        const int rc = alloc_reads(c, std::max(c->n + b.n, c->cap * 2));
+        if (rc != BDX_OK) return rc;
+    }
+    const size_t o = c->n, n = b.n;
+    hipStream_t s = c->copy_stream;
+    if (o == 0) {  // a fresh store: pass 1 runs as the reads arrive
+        c->key_segs.clear();
+        const uint64_t tiles = (c->cap + kTile - 1) / kTile;
+        if (tiles <= 0xFFFFFFFFull) {
+            const int rc = pass1_prepare(c, (uint32_t)tiles);
+            if (rc != BDX_OK) return rc;
+            c->k1_live = true;
+        }
+    }
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.tid + o), b.tid, n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.pos + o), b.pos, n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.mtid + o), b.mtid, n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.mpos + o), b.mpos, n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.isize + o), b.isize, n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.flag + o), b.flag, n * 2, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.qlen + o), b.qlen, n * 2, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.mapq + o), b.mapq, n, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.lib + o), b.lib, n, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.bam + o), b.bam, n, hipMemcpyHostToDevice, s));
+    const uint64_t* dev_view = nullptr;
+    if (lazy_keys && c->key_segs.size() < 64) {
+        hipPointerAttribute_t attr{};
+        void* dp = nullptr;
+        if (hipPointerGetAttributes(&attr, b.name_key) == hipSuccess && attr.type == hipMemoryTypeHost &&
+            hipHostGetDevicePointer(&dp, (void*)b.name_key, 0) == hipSuccess && dp)
+            dev_view = (const uint64_t*)dp;
+        else
+            (void)hipGetLastError();  // ordinary pageable memory: not an error
+    }
+    if (!dev_view) HIPCHK(c, hipMemcpyAsync((void*)(c->d.key + o), b.name_key, n * 8, hipMemcpyHostToDevice, s));
+    if (c->key_segs.empty() || dev_view || c->key_segs.back().host) c->key_segs.push_back(bdx_ctx::KeySeg{(uint64_t)o, dev_view});
+    HIPCHK(c, hipEventRecord(c->ev_copy, s));
+    c->copy_pending = true;
+    c->n += n;
+    c->ran = false;
+    if (c->k1_live) {
+        const uint32_t full = (uint32_t)(c->n / kTile);
+        if (full >= c->k1_done + kStreamTilesMin) {
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copy, 0));
+            c->copy_pending = false;
+            const int rc = pass1_classify(c, full, false);
+            if (rc != BDX_OK) return rc;
+        }
+    }
     return BDX_OK;
 }
 
@@ -244,6 +349,10 @@ int bdx_create(bdx_ctx** out, const bdx_opts* opts, const bdx_lib* libs, int nli
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return BDX_EHIP; }
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete c; return BDX_EHIP; }
+    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return BDX_EHIP; }
+    if (hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess) { delete c; return BDX_EHIP; }
+    for (auto& st : c->ring)
+        if (hipEventCreateWithFlags(&st.done, hipEventDisableTiming) != hipSuccess) { delete c; return BDX_EHIP; }
     if (hipEventCreateWithFlags(&c->ev_groups, hipEventDisableTiming) != hipSuccess) { delete c; return BDX_EHIP; }
     if (hipEventCreateWithFlags(&c->ev_regions, hipEventDisableTiming) != hipSuccess) { delete c; return BDX_EHIP; }
     if (const char* nc = getenv("BDX_PIN_NONCOHERENT"); nc && nc[0] == '1')
@@ -286,7 +395,15 @@ int bdx_create(bdx_ctx** out, const bdx_opts* opts, const bdx_lib* libs, int nli
 void bdx_destroy(bdx_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& st : c->ring) {
+        st.buf.release();
+        if (st.done) (void)hipEventDestroy(st.done);
+    }
+    c->b_seg.release();
+    if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     DevBuf* bufs[] = {&c->b_tid, &c->b_pos, &c->b_mtid, &c->b_mpos, &c->b_isize, &c->b_flag, &c->b_qlen, &c->b_mapq, &c->b_lib,
                       &c->b_bam, &c->b_key, &c->b_libs, &c->b_cls, &c->b_tile_tot, &c->b_tile_pre, &c->b_tile_mono,
                       &c->b_blk_cnt, &c->b_cnt, &c->b_p1, &c->b_c_tid, &c->b_c_pos, &c->b_c_isize,
@@ -325,25 +442,63 @@ int bdx_push(bdx_ctx* c, const bdx_batch* b) {
         !b->name_key)
         return fail(c, BDX_EINVAL, "null array in batch");
     HIPCHK(c, hipSetDevice(c->device));
-    if (c->n + b->n > c->cap) {
-        int rc = alloc_reads(c, std::max(c->n + b->n, c->cap * 2));
-        if (rc != BDX_OK) return rc;
+    return enqueue_batch(c, *b, true);
+}
+
+int bdx_acquire_batch(bdx_ctx* c, size_t capacity, bdx_batch_buf* out) {
+    if (!c || !out || capacity == 0) return BDX_EINVAL;
+    if (c->adopted) return fail(c, BDX_ESTATE, "reads were adopted from the caller");
+    if (c->ring_cur >= 0) return fail(c, BDX_ESTATE, "the previous batch was not submitted");
+    HIPCHK(c, hipSetDevice(c->device));
+    bdx_ctx::Stage& st = c->ring[c->ring_next];
+    if (st.busy) {  // all staging buffers are in flight: wait for the oldest copy
+        HIPCHK(c, hipEventSynchronize(st.done));
+        st.busy = false;
     }
-    const size_t o = c->n, n = b->n;
-    hipStream_t s = c->stream;
-    HIPCHK(c, hipMemcpyAsync((void*)(c->d.tid + o), b->tid, n * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync((void*)(c->d.pos + o), b->pos, n * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync((void*)(c->d.mtid + o), b->mtid, n * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync((void*)(c->d.mpos + o), b->mpos, n * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync((void*)(c->d.isize + o), b->isize, n * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync((void*)(c->d.flag + o), b->flag, n * 2, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync((void*)(c->d.qlen + o), b->qlen, n * 2, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync((void*)(c->d.mapq + o), b->mapq, n, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync((void*)(c->d.lib + o), b->lib, n, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync((void*)(c->d.bam + o), b->bam, n, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync((void*)(c->d.key + o), b->name_key, n * 8, hipMemcpyHostToDevice, s));
-    c->n += n;
+    st.cap = round_up(capacity, 64);
+    HIPCHK(c, st.buf.ensure(st.cap * 35 + 64));
+    stage_view(st, out);
+    c->ring_cur = c->ring_next;
+    c->ring_next = (c->ring_next + 1) % 4;
+    return BDX_OK;
+}
+
+int bdx_submit_batch(bdx_ctx* c, size_t n) {
+    if (!c) return BDX_EINVAL;
+    if (c->ring_cur < 0) return fail(c, BDX_ESTATE, "no batch was acquired");
+    bdx_ctx::Stage& st = c->ring[c->ring_cur];
+    c->ring_cur = -1;
+    if (n == 0) return BDX_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    bdx_batch_buf v{};
+    stage_view(st, &v);  // the layout bdx_acquire_batch handed out
+    if (n > v.capacity) return fail(c, BDX_EINVAL, "more records than the acquired batch holds");
+    bdx_batch b{v.tid, v.pos, v.mtid, v.mpos, v.isize, v.flag, v.qlen, v.mapq, v.lib, v.bam, v.name_key, n};
+    const int rc = enqueue_batch(c, b, false);  // (the buffer is recycled: its name keys travel with the other columns)
+    if (rc != BDX_OK) return rc;
+    HIPCHK(c, hipEventRecord(st.done, c->copy_stream));
+    st.busy = true;
+    return BDX_OK;
+}
+
+int bdx_reset_reads(bdx_ctx* c) {
+    if (!c) return BDX_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->copy_stream) HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->adopted) {
+        c->d = ReadsSoA{};
+        c->cap = 0;
+        c->adopted = false;
+    }
+    c->n = 0;
     c->ran = false;
+    c->k1_live = false;
+    c->k1_done = 0;
+    c->copy_pending = false;
+    c->key_segs.clear();
+    c->ring_cur = -1;
+    for (auto& st : c->ring) st.busy = false;
     return BDX_OK;
 }
 
@@ -359,6 +514,8 @@ int bdx_set_device_reads(bdx_ctx* c, const bdx_batch* b) {
     c->cap = b->n;
     c->adopted = true;
     c->ran = false;
+    c->k1_live = false;
+    c->key_segs.clear();
     return BDX_OK;
 }
 
@@ -410,27 +567,17 @@ float ms_between(std::chrono::steady_clock::time_point a, std::chrono::steady_cl
 int do_pass1(bdx_ctx* c, uint32_t na_cap = 0, bool wait = true, bool defer_second = false);
 int wait_pass1(bdx_ctx* c);
 
-int do_pass1(bdx_ctx* c, uint32_t na_cap, bool wait, bool defer_second) {
+// Start of a pass 1: per-tile tables laid out for tiles_cap tiles, counters and tables at their start values.
+int pass1_prepare(bdx_ctx* c, uint32_t tiles_cap) {
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const int nlibs = c->nlibs, nbams = c->nbams, nkeys = c->nkeys;
     const int ncols = 2 + nkeys, ncnt = nlibs * kNumFlags + nlibs + nbams;
-    if (c->n >= ((size_t)1 << 32) * 64) return fail(c, BDX_ELIMIT, "too many reads");
-    const uint32_t ntiles = (uint32_t)((c->n + kTile - 1) / kTile);
-    const uint32_t tstride = (uint32_t)round_up(std::max<uint32_t>(ntiles, 16), 16);
-    const int grid1 = (int)std::min<uint32_t>((ntiles + kWaves - 1) / kWaves, kK1MaxGrid);
-    c->ntiles = ntiles; c->tstride = tstride;
-    c->ran = false; c->stage = 0; c->replayed = false;
-    c->na_alloc = 0;
-    c->regions.clear(); c->r_pk.clear(); c->parts.clear();
-    c->reg = nullptr; c->nreg = 0; c->rpk = nullptr;
-    c->walk.clear();
-    if (!c->walk_scratch) c->walk_scratch = walk_scratch_new();
-    c->n_printed = 0;
-    memset(&c->counts, 0, sizeof(c->counts));
-    for (float& m : c->stage_ms) m = 0;
-
-    HIPCHK(c, c->b_cls.ensure(std::max<size_t>(c->n, 16)));
+    const uint32_t tstride = (uint32_t)round_up(std::max<uint32_t>(tiles_cap, 16), 16);
+    c->tstride = tstride;
+    c->k1_cap_tiles = tiles_cap;
+    c->k1_done = 0;
+    HIPCHK(c, c->b_cls.ensure(std::max<size_t>((size_t)tiles_cap * kTile, 16)));
     HIPCHK(c, c->b_tile_tot.ensure((size_t)ncols * tstride * 4));
     HIPCHK(c, c->b_tile_pre.ensure((size_t)ncols * tstride * 4));
     HIPCHK(c, c->b_tile_mono.ensure((size_t)nbams * tstride * sizeof(MonoRec)));
@@ -441,42 +588,85 @@ int do_pass1(bdx_ctx* c, uint32_t na_cap, bool wait, bool defer_second) {
     HIPCHK(c, c->h_cnt.ensure((size_t)ncnt * 4));
     HIPCHK(c, c->h_counts.ensure(sizeof(StageCounts)));
     HIPCHK(c, c->b_counts.ensure(sizeof(StageCounts)));
-    {
-        const size_t w_tot = (size_t)ncols * tstride, w_mono = (size_t)nbams * tstride * sizeof(MonoRec) / 4;
-        if (w_tot > 0xFFFFFFFFull || w_mono > 0xFFFFFFFFull) {  // beyond the init kernel's 32-bit word counts
-            HIPCHK(c, hipMemsetAsync(c->b_tile_tot.p, 0, w_tot * 4, s));
-            HIPCHK(c, hipMemsetAsync(c->b_tile_mono.p, 0xFF, w_mono * 4, s));
-        }
-        InitList il{};
-        int k = 0;
-        auto add = [&](void* p, size_t words, uint32_t value) { il.ptr[k] = (uint32_t*)p; il.words[k] = (uint32_t)words; il.value[k] = value; ++k; };
-        if (w_tot <= 0xFFFFFFFFull && w_mono <= 0xFFFFFFFFull) { add(c->b_tile_tot.p, w_tot, 0u); add(c->b_tile_mono.p, w_mono, 0xFFFFFFFFu); }
-        add(c->b_blk_cnt.p, (size_t)kCntCopies * ncnt, 0u);
-        add(c->b_p1.p, sizeof(Pass1) / 4, 0u);
-        add(c->b_counts.p, sizeof(StageCounts) / 4, 0u);
-        il.n = k;
-        launch_init(il, s);
+    const size_t w_tot = (size_t)ncols * tstride, w_mono = (size_t)nbams * tstride * sizeof(MonoRec) / 4;
+    if (w_tot > 0xFFFFFFFFull || w_mono > 0xFFFFFFFFull) {  // beyond the init kernel's 32-bit word counts
+        HIPCHK(c, hipMemsetAsync(c->b_tile_tot.p, 0, w_tot * 4, s));
+        HIPCHK(c, hipMemsetAsync(c->b_tile_mono.p, 0xFF, w_mono * 4, s));
     }
+    InitList il{};
+    int k = 0;
+    auto add = [&](void* p, size_t words, uint32_t value) { il.ptr[k] = (uint32_t*)p; il.words[k] = (uint32_t)words; il.value[k] = value; ++k; };
+    if (w_tot <= 0xFFFFFFFFull && w_mono <= 0xFFFFFFFFull) { add(c->b_tile_tot.p, w_tot, 0u); add(c->b_tile_mono.p, w_mono, 0xFFFFFFFFu); }
+    add(c->b_blk_cnt.p, (size_t)kCntCopies * ncnt, 0u);
+    add(c->b_p1.p, sizeof(Pass1) / 4, 0u);
+    add(c->b_counts.p, sizeof(StageCounts) / 4, 0u);
+    il.n = k;
+    launch_init(il, s);
+    return BDX_OK;
+}
 
-    const bool time_k1 = c->stage_timing || c->seq % c->k1_event_period == 0;
-    if (time_k1) HIPCHK(c, hipEventRecord(c->ev[0], s));
+// K1 over the tiles [k1_done, upto) of the c->n reads that are (or, behind ev_copy, will be) in HBM
+int pass1_classify(bdx_ctx* c, uint32_t upto, bool timed) {
+    hipStream_t s = c->stream;
+    if (upto <= c->k1_done) return BDX_OK;
     K1Params k1{};
-    k1.r = c->d; k1.n = c->n; k1.ntiles = ntiles; k1.tstride = tstride;
-    k1.nlibs = nlibs; k1.nbams = nbams; k1.nkeys = nkeys;
+    k1.r = c->d; k1.n = c->n; k1.ntiles = upto; k1.tstride = c->tstride; k1.tile0 = c->k1_done;
+    k1.nlibs = c->nlibs; k1.nbams = c->nbams; k1.nkeys = c->nkeys;
     k1.max_sd = c->opts.max_sd; k1.opt_t = c->opts.transchr_rearrange; k1.opt_l = c->opts.illumina_long_insert;
     k1.libs = c->b_libs.as<DevLib>(); k1.cls = c->b_cls.as<uint8_t>(); k1.tile_tot = c->b_tile_tot.as<uint32_t>();
     k1.tile_mono = c->b_tile_mono.as<MonoRec>();
     k1.blk_cnt = c->b_blk_cnt.as<uint32_t>();
-    if (ntiles) launch_k1(k1, grid1, k1_lds_bytes(nlibs, nbams, nkeys), s);
-    if (time_k1) HIPCHK(c, hipEventRecord(c->ev[1], s));
+    const uint32_t span = upto - c->k1_done;
+    const int grid1 = (int)std::min<uint32_t>((span + kWaves - 1) / kWaves, kK1MaxGrid);
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[0], s));
+    launch_k1(k1, grid1, k1_lds_bytes(c->nlibs, c->nbams, c->nkeys), s);
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[1], s));
+    c->k1_done = upto;
+    return BDX_OK;
+}
+
+int do_pass1(bdx_ctx* c, uint32_t na_cap, bool wait, bool defer_second) {
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int nlibs = c->nlibs, nbams = c->nbams, nkeys = c->nkeys;
+    const int ncols = 2 + nkeys, ncnt = nlibs * kNumFlags + nlibs + nbams;
+    if (c->n >= ((size_t)1 << 32)) return fail(c, BDX_ELIMIT, "more than 2^32 - 1 reads in one context (read indices and the prefix counters are 32-bit)");
+    const uint32_t ntiles = (uint32_t)((c->n + kTile - 1) / kTile);
+    c->ntiles = ntiles;
+    c->ran = false; c->stage = 0; c->replayed = false;
+    c->na_alloc = 0;
+    c->regions.clear(); c->r_pk.clear(); c->parts.clear();
+    c->reg = nullptr; c->nreg = 0; c->rpk = nullptr;
+    c->walk.clear();
+    if (!c->walk_scratch) c->walk_scratch = walk_scratch_new();
+    c->n_printed = 0;
+    memset(&c->counts, 0, sizeof(c->counts));
+    for (float& m : c->stage_ms) m = 0;
+
+    if (c->copy_pending) {  // batches pushed since the last classifier launch
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_copy, 0));
+        c->copy_pending = false;
+    }
+    // a store that was filled from empty has its first tiles classified already; anything else starts from tile 0
+    if (!(c->k1_live && c->k1_cap_tiles >= ntiles)) {
+        const int rc = pass1_prepare(c, ntiles);
+        if (rc != BDX_OK) return rc;
+    }
+    c->k1_live = false;  // (consumed: a repeated run classifies everything again)
+    const uint32_t tstride = c->tstride;
+    const bool time_k1 = (c->stage_timing || c->seq % c->k1_event_period == 0) && c->k1_done == 0 && ntiles > 0;
+    {
+        const int rc = pass1_classify(c, ntiles, time_k1);
+        if (rc != BDX_OK) return rc;
+    }
     FinalizeParams fp{};
     fp.ntiles = ntiles; fp.tstride = tstride; fp.nblk = 0;
     fp.nfold = std::max<uint32_t>(1, std::min<uint32_t>(64, (ntiles + 1023) / 1024));
     HIPCHK(c, c->b_fold.ensure((size_t)nbams * fp.nfold * sizeof(MonoRec)));
     fp.fold_part = c->b_fold.as<MonoRec>();
     fp.nlibs = nlibs; fp.nbams = nbams; fp.nkeys = nkeys; fp.ncols = ncols; fp.ncnt = ncnt; fp.w0 = c->w0;
-    fp.tile_tot = k1.tile_tot; fp.tile_pre = c->b_tile_pre.as<uint32_t>(); fp.tile_mono = k1.tile_mono;
-    fp.blk_cnt = k1.blk_cnt; fp.cnt = c->b_cnt.as<uint32_t>(); fp.p1 = c->b_p1.as<Pass1>();
+    fp.tile_tot = c->b_tile_tot.as<uint32_t>(); fp.tile_pre = c->b_tile_pre.as<uint32_t>(); fp.tile_mono = c->b_tile_mono.as<MonoRec>();
+    fp.blk_cnt = c->b_blk_cnt.as<uint32_t>(); fp.cnt = c->b_cnt.as<uint32_t>(); fp.p1 = c->b_p1.as<Pass1>();
     HIPCHK(c, c->b_kdens.ensure(64 * 4));
     fp.libs = c->b_libs.as<DevLib>(); fp.cn_lib = c->opts.cn_lib; fp.key_density = c->b_kdens.as<float>();
     fp.cnt_host = c->h_cnt.as<uint32_t>(); fp.p1_host = c->h_p1.as<Pass1>();  // written by the kernel: no copy commands
@@ -600,6 +790,26 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepa
             HIPCHK(c, c->b_pair_lo.ensure((size_t)na * 4));
             k2.fill_ptr[3] = c->b_pair_lo.as<uint32_t>(); k2.fill_words[3] = na; k2.fill_value[3] = 0xFFFFFFFFu;
             c->join_table_clean = slots;
+        }
+        {   // name keys the caller's pinned batches still hold (bdx_push): one segment per batch
+            bool any_host = false;
+            for (auto const& sg : c->key_segs) any_host |= sg.host != nullptr;
+            if (any_host && !c->adopted) {
+                const size_t ns = c->key_segs.size();
+                std::vector<uint64_t> tab(2 * ns + 1);
+                for (size_t i = 0; i < ns; ++i) {
+                    tab[i] = c->key_segs[i].begin;
+                    const uint64_t* base = c->key_segs[i].host ? c->key_segs[i].host - c->key_segs[i].begin : c->d.key;
+                    tab[ns + 1 + i] = (uint64_t)(uintptr_t)base;
+                }
+                tab[ns] = c->n;
+                HIPCHK(c, c->b_seg.ensure(tab.size() * 8));
+                HIPCHK(c, hipMemcpyAsync(c->b_seg.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, s));
+                HIPCHK(c, hipStreamSynchronize(s));  // (tab is a local; this path is PCIe-bound anyway)
+                k2.nseg = (int)ns;
+                k2.seg_begin = c->b_seg.as<uint64_t>();
+                k2.seg_ptr = (const uint64_t* const*)(c->b_seg.as<uint64_t>() + ns + 1);
+            }
         }
         launch_k2(k2, k2_lds_bytes(nkeys), s, c->finalize2_deferred ? &c->fp_deferred : nullptr);
         c->finalize2_deferred = false;

@@ -42,6 +42,7 @@ struct K1Params {
     ReadsSoA r;
     uint64_t n;
     uint32_t ntiles, tstride;  // tstride = padded row length of the per-tile tables
+    uint32_t tile0;            // first tile of this launch (streamed input: tiles are classified as their reads arrive)
     int nlibs, nbams, nkeys;
     int max_sd, opt_t, opt_l;
     const DevLib* libs;
@@ -122,6 +123,11 @@ struct K2Params {
     uint32_t* fill_ptr[4];
     uint32_t fill_words[4];
     uint32_t fill_value[4];
+    // name keys left in the caller's pinned host memory (bdx_push): read i's key is seg_ptr[s][i] for the segment s with
+    // seg_begin[s] <= i < seg_begin[s+1]; only the ~1 % anomalous reads ever fetch theirs (over PCIe).  nseg = 0: r.key
+    int nseg;
+    const uint64_t* seg_begin;          // [nseg + 1]
+    const uint64_t* const* seg_ptr;     // [nseg] device-visible, biased by -seg_begin[s]
 };
 
 __device__ __forceinline__ uint32_t meta_pack(int flag, int rev, int lib, int qlen) {

@@ -231,7 +231,6 @@ struct Walker {
     }
 
     void process_sv(const int* snodes, int n) {
-        const HostRegion* R = in.regions;
         const bdx_opts& o = in.opts;
         const int A = snodes[0], B = n == 2 ? snodes[1] : -1;
         int num_pairs = 0;

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kBlock) void k1_classify_kernel(const K1Params p) {
     __syncthreads();
 
     const uint32_t nwaves = gridDim.x * kWaves;
-    for (uint32_t tile = blockIdx.x * kWaves + w; tile < p.ntiles; tile += nwaves) {
+    for (uint32_t tile = p.tile0 + blockIdx.x * kWaves + w; tile < p.ntiles; tile += nwaves) {
         const uint64_t base = (uint64_t)tile * kTile + (uint64_t)lane * 4;
         int nvalid = 0;
         int tid[4], pos[4], mtid[4], mpos[4], isz[4];

@@ -102,13 +102,38 @@ void bdx_destroy(bdx_ctx* ctx);
 const char* bdx_strerror(int code);
 const char* bdx_last_error(const bdx_ctx* ctx);
 
-/* Replaces: AlignmentSource::next feeding BamSummary::_analyze_bam and BreakDancer::push_read.
- * bdx_push copies a host batch (pinned recommended) into the HBM-resident SoA asynchronously;
- * bdx_set_device_reads adopts arrays that already live in HBM (no copy; must stay valid until
- * bdx_destroy; every array base 16-byte aligned). */
+/* Replaces: AlignmentSource::next feeding BamSummary::_analyze_bam and BreakDancer::push_read
+ * (io/AlignmentSource.hpp:48-65: one record stream, consumed as it is produced).  Three ways in:
+ *
+ *   bdx_acquire_batch / bdx_submit_batch   the streaming producer's path.  acquire hands out the columns of a pinned staging
+ *       buffer owned by the context (a ring of four; it blocks only while all four are still being copied), the producer
+ *       fills the first n records and submits them: the H2D copies run on the context's copy stream and the classifier
+ *       (K1) follows on the tiles the batch completed, so decode, PCIe and pass 1 overlap and host memory stays bounded
+ *       by the ring.  The buffer belongs to the context again as soon as bdx_submit_batch returns.
+ *   bdx_push             a batch in the caller's own memory.  The copies are asynchronous: every array of the batch must
+ *       stay valid and unchanged until the next bdx_run on this context has returned.  Arrays in pinned (page-locked)
+ *       memory are copied at PCIe speed; a pinned name_key array is not copied at all -- only the anomalous reads
+ *       (about 1 %) need their key and the compaction kernel fetches those straight from the caller's array (27 instead
+ *       of 35 bytes per read cross the bus).
+ *   bdx_set_device_reads adopts arrays that already live in HBM (no copy; must stay valid until bdx_destroy or
+ *       bdx_reset_reads; every array base 16-byte aligned).
+ *
+ * bdx_reserve sizes the resident store up front (growing it later re-lays the per-tile tables: the classifier then starts
+ * over in bdx_run).  bdx_reset_reads empties the store (capacity is kept) so that one context can take the next
+ * chromosome.  One context holds at most 2^32 - 1 reads. */
+typedef struct bdx_batch_buf {
+    int32_t *tid, *pos, *mtid, *mpos, *isize;
+    uint16_t *flag, *qlen;
+    uint8_t *mapq, *lib, *bam;
+    uint64_t* name_key;
+    size_t capacity;   /* records the buffer holds (>= the capacity asked for) */
+} bdx_batch_buf;
 int bdx_reserve(bdx_ctx* ctx, size_t n_reads);
 int bdx_push(bdx_ctx* ctx, const bdx_batch* host_batch);
+int bdx_acquire_batch(bdx_ctx* ctx, size_t capacity, bdx_batch_buf* out);
+int bdx_submit_batch(bdx_ctx* ctx, size_t n);
 int bdx_set_device_reads(bdx_ctx* ctx, const bdx_batch* device_batch);
+int bdx_reset_reads(bdx_ctx* ctx);
 
 /* Replaces: BamSummary::_analyze_bams (io/BamSummary.cpp:129-150), main()'s density/window block
  * (BreakDancerMax.cpp:83-116) and BreakDancer::run (BreakDancer.cpp:131-144) up to the scored SV list. */
