@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip timings (ii) and (iii)")
     ap.add_argument("--cpu-parallel", type=int, default=-1,
-                    help="processes of the README's one-process-per-chromosome mode in cpu_baseline (default: min(host cores / 2, 24), "
+                    help="processes of the README's one-process-per-chromosome mode in cpu_baseline (default: min(usable CPUs, 24), "
                          "bounded by free memory; 0 = skip)")
     ap.add_argument("--overlap", action="store_true",
                     help="after the timed region, also measure the same steps with three contexts in flight (reported under "
@@ -146,6 +146,18 @@ def cpu_model():
     return "unknown"
 
 
+def usable_cpus():
+    """hardware threads capped by the cgroup CPU quota (a container may see 256 threads and own 16)"""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def mem_available_gb():
     try:
         for line in open("/proc/meminfo"):
@@ -161,8 +173,9 @@ def cpu_baseline(bam, n_reads, want_parallel):
     one = json.loads(subprocess.run(me + ["2"], check=True, stdout=subprocess.PIPE).stdout.decode().strip().splitlines()[-1])
     pairs = n_reads / 2
     nproc = os.cpu_count() or 1
+    usable = usable_cpus()
     out = {"value": pairs / one["total_s"], "unit": "read-pairs/s", "cores": 1, "kind": "port",
-           "cpu": cpu_model(), "host_threads": nproc,
+           "cpu": cpu_model(), "host_threads": nproc, "usable_cpus": usable,
            "sample": "the full configs[1] chromosome as BAM (%d records, random bases and qualities): single-threaded BGZF inflate + record "
                      "decode x 2 passes (%.1f s) + the oracle's sequential path on the decoded records (%.2f s) = %.1f s on one core"
                      % (n_reads, one["decode_s"], one["path_s"], one["total_s"]),
@@ -170,7 +183,7 @@ def cpu_baseline(bam, n_reads, want_parallel):
                             "note": "oracle path alone on already-decoded records (what BENCH_r01 reported)"}}
     par = want_parallel
     if par < 0:
-        par = min(max(nproc // 2, 1), 24)
+        par = min(usable, 24)   # one process per core this container may use (its CPU quota), at most one per chromosome
     par = int(min(par, max(1.0, mem_available_gb() * 0.5 / 3.0)))  # ~3 GB per process
     if par > 1:
         t0 = time.perf_counter()

@@ -161,6 +161,7 @@ bool BamReader::fill(Chunk& c) {
         const size_t total = (size_t)bsize + 1;
         if (avail < total || total < (size_t)12 + xlen + 8) throw std::runtime_error("truncated BGZF file: " + path_);
         const uint32_t isize = le32(h + total - 4);
+        if (isize > 65536) throw std::runtime_error("BGZF block larger than 64 KiB: " + path_);
         Block b;
         b.coff = comp_off_ + 12 + xlen;
         b.clen = total - 12 - xlen - 8;
@@ -255,8 +256,10 @@ bool plausible_record(const uint8_t* data, size_t pos, size_t end, int32_t n_tar
     return true;
 }
 
+}  // namespace
+
 // first position in [from, seg_end) where three records in a row look valid; seg_end if there is none
-size_t guess_record_start(const uint8_t* data, size_t from, size_t seg_end, size_t end, int32_t n_targets) {
+size_t bam_guess_record_start(const uint8_t* data, size_t from, size_t seg_end, size_t end, int32_t n_targets) {
     for (size_t pos = from; pos < seg_end; ++pos) {
         size_t a, b, c;
         if (plausible_record(data, pos, end, n_targets, &a) && plausible_record(data, a, end, n_targets, &b) &&
@@ -265,6 +268,8 @@ size_t guess_record_start(const uint8_t* data, size_t from, size_t seg_end, size
     }
     return seg_end;
 }
+
+namespace {
 
 // decode the records that start in [start, seg_end) and are complete before `end`; returns where it stopped.  `trusted`:
 // start is a known record boundary, so a record that does not add up means a corrupt file (otherwise: a wrong guess)
@@ -318,7 +323,7 @@ void BamReader::parse_chunk(Chunk& c) {
     auto work = [&](int i) {
         try {
             c.parts[i].reserve((seg[i + 1] - seg[i]) / 160 + 16);
-            start[i] = i == 0 ? c.beg : guess_record_start(data, seg[i], seg[i + 1], c.end, nt);
+            start[i] = i == 0 ? c.beg : bam_guess_record_start(data, seg[i], seg[i + 1], c.end, nt);
             stop[i] = parse_range(data, start[i], seg[i + 1], c.end, i == 0, path_, c.parts[i]);
         } catch (std::exception const& e) { errs[i] = e.what(); }
     };
@@ -437,14 +442,15 @@ void BamReader::parse_record(const uint8_t* rec, BamRecord& r) {
         size_t sz = 0;
         long ival = 0;
         bool is_int = false;
+        const size_t left = (size_t)(end - q);  // (a truncated aux block ends the sweep: nothing is read past the record)
         switch (ty) {
             case 'A': sz = 1; break;
-            case 'c': sz = 1; ival = (int8_t)q[0]; is_int = true; break;
-            case 'C': sz = 1; ival = q[0]; is_int = true; break;
-            case 's': sz = 2; ival = (int16_t)le16(q); is_int = true; break;
-            case 'S': sz = 2; ival = le16(q); is_int = true; break;
-            case 'i': sz = 4; ival = (int32_t)le32(q); is_int = true; break;
-            case 'I': sz = 4; ival = (long)le32(q); is_int = true; break;
+            case 'c': sz = 1; if (left >= 1) { ival = (int8_t)q[0]; is_int = true; } break;
+            case 'C': sz = 1; if (left >= 1) { ival = q[0]; is_int = true; } break;
+            case 's': sz = 2; if (left >= 2) { ival = (int16_t)le16(q); is_int = true; } break;
+            case 'S': sz = 2; if (left >= 2) { ival = le16(q); is_int = true; } break;
+            case 'i': sz = 4; if (left >= 4) { ival = (int32_t)le32(q); is_int = true; } break;
+            case 'I': sz = 4; if (left >= 4) { ival = (long)le32(q); is_int = true; } break;
             case 'f': sz = 4; break;
             case 'd': sz = 8; break;
             case 'Z':
@@ -460,11 +466,13 @@ void BamReader::parse_record(const uint8_t* rec, BamRecord& r) {
                 const uint8_t sub = q[0];
                 const uint32_t cnt = le32(q + 1);
                 const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
-                q += 5 + (size_t)cnt * es;
+                const size_t bytes = (size_t)cnt * es;
+                q = bytes > (size_t)(end - q - 5) ? end : q + 5 + bytes;
                 continue;
             }
             default: q = end; continue;
         }
+        if (sz > left) { q = end; continue; }
         if (t0 == 'A' && t1 == 'M' && !have_am) { r.bdqual = (uint8_t)(is_int ? ival : 0); have_am = true; }  // bam_aux2i: 0 for non-integer types
         q += sz;
     }

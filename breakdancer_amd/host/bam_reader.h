@@ -81,4 +81,8 @@ private:
 
 uint64_t hash_name(const char* s, size_t n);  // 64-bit name key shared by the two mates of a pair
 
+// first position in [from, seg_end) of `data` where three BAM records in a row look valid (field ranges, size equation, read
+// name; `end` bounds what may be read); seg_end if there is none.  A guess: callers verify it against the true boundary chain
+size_t bam_guess_record_start(const uint8_t* data, size_t from, size_t seg_end, size_t end, int32_t n_targets);
+
 }  // namespace bdhost

@@ -14,6 +14,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <thread>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <vector>
 
@@ -36,11 +37,53 @@ void check(bdx_ctx* ctx, int rc, const char* what) {
     throw std::runtime_error(msg);
 }
 
+// CPUs this process can use: hardware threads, capped by the cgroup v2 / v1 CPU quota if one is set
+unsigned usable_cpus() {
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[64] = {0};
+        long period = 0;
+        if (fscanf(f, "%63s %ld", quota, &period) == 2 && period > 0 && quota[0] != 'm')
+            n = std::min<unsigned>(n, (unsigned)std::max(1L, (atol(quota) + period - 1) / period));
+        fclose(f);
+    } else {
+        long q = -1, per = 0;
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%ld", &q) != 1) q = -1; fclose(g); }
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%ld", &per) != 1) per = 0; fclose(g); }
+        if (q > 0 && per > 0) n = std::min<unsigned>(n, (unsigned)std::max(1L, (q + per - 1) / per));
+    }
+    return n;
+}
+
+// The producer's batches go straight into the context's pinned staging ring: while the decode threads work on the next
+// pieces of the BAMs, the previous batch crosses PCIe and the classifier runs over it (AlignmentSource.hpp:48-65: one
+// record stream, consumed as it is produced).  The context is created on a helper thread (the HIP runtime takes ~0.1 s
+// to come up) and only waited for when the first batch is ready.
+struct GpuSink : BatchSink {
+    std::future<int>& ready;
+    bdx_ctx*& ctx;
+    size_t reserve;
+    bool up = false;
+    GpuSink(std::future<int>& r, bdx_ctx*& c, size_t res) : ready(r), ctx(c), reserve(res) {}
+    void bring_up() {
+        if (up) return;
+        check(nullptr, ready.get(), "bdx_create");
+        check(ctx, bdx_reserve(ctx, reserve), "bdx_reserve");
+        up = true;
+    }
+    bdx_batch_buf acquire(size_t capacity) override {
+        bring_up();
+        bdx_batch_buf b{};
+        check(ctx, bdx_acquire_batch(ctx, capacity, &b), "bdx_acquire_batch");
+        return b;
+    }
+    void submit(size_t n) override { check(ctx, bdx_submit_batch(ctx, n), "bdx_submit_batch"); }
+};
+
 }  // namespace
 
 int main(int argc, char** argv) {
     bdx_ctx* ctx = nullptr;
-    const bool tidy_exit = getenv("BDX_TIDY_EXIT") != nullptr;  // free everything and run the runtime's teardown (leak checks)
     try {
         Options opts(argc, argv);
         if (!opts.restore_file.empty() || !opts.cache_file.empty())
@@ -53,12 +96,13 @@ int main(int argc, char** argv) {
             std::cout << "Error: no bams files in config file!\n";
             return 1;
         }
-        const unsigned hw = std::thread::hardware_concurrency();
-        // BGZF inflate threads: zlib manages ~100-150 MB/s per core on read data, the record parse that consumes the
-        // output ~15 M records/s on one core; measured on a 256-thread host, 3 M reads / 408 MB: 8 threads 0.36 s, 16 0.26 s,
-        // 32 0.22 s, 64 0.20 s (then the parse is the limit).  A quarter of the hardware threads, at most 64 (BDX_THREADS overrides)
-        const unsigned io_threads = getenv("BDX_THREADS") ? (unsigned)std::max(1, atoi(getenv("BDX_THREADS"))) : (hw ? std::min(std::max(hw / 4, 4u), 64u) : 4u);
-        ReadStream reads;
+        // Decode threads: the work is CPU-bound on zlib (~375 MB/s of inflated bytes per core), so what counts is the number of
+        // cores this process may really use -- the cgroup's CPU quota when there is one (a container with "16 CPUs" on a
+        // 256-thread host: 16 threads 0.64 s, 32 0.55 s, 64 0.70 s for 15 M records), else the hardware threads.  Twice that
+        // many threads keep the cores busy across their waits; BDX_THREADS overrides.
+        const unsigned io_threads = getenv("BDX_THREADS") ? (unsigned)std::max(1, atoi(getenv("BDX_THREADS")))
+                                                          : std::min(std::max(2 * usable_cpus(), 4u), 64u);
+        std::vector<std::string> targets;
         const bool timing = getenv("BDX_TIMING") != nullptr;
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
@@ -71,21 +115,25 @@ int main(int argc, char** argv) {
         std::future<int> ctx_ready = std::async(std::launch::async, [&] {
             return bdx_create(&ctx, &opts.o, libs.data(), nlibs, nbams, 0, cfg.max_read_window_size(), opts.device);
         });
+        // resident store sized from the compressed files (a record takes 50-150 bytes of BAM; a store that is too small
+        // grows, at the price of classifying from the first tile again)
+        size_t reserve = 1 << 20;
+        for (auto const& f : cfg.bam_files()) {
+            struct stat st;
+            if (stat(f.c_str(), &st) == 0) reserve += (size_t)st.st_size / 48;
+        }
+        reserve = std::min<size_t>(reserve, 0xFFFFFFFFull - 1024);
+        GpuSink sink(ctx_ready, ctx, reserve);
+        size_t n_reads = 0;
         try {
-            produce(cfg, opts.chr, (int)io_threads, reads);
+            n_reads = produce_stream(cfg, opts.chr, (int)io_threads, &targets, sink);
+            sink.bring_up();  // (an input without records never asked for a batch)
         } catch (...) {
-            ctx_ready.wait();
+            if (ctx_ready.valid()) ctx_ready.wait();
             throw;
         }
         const auto t_decoded = now();
-
-        check(nullptr, ctx_ready.get(), "bdx_create");
-        const bdx_batch batch = reads.batch();
-        check(ctx, bdx_reserve(ctx, batch.n), "bdx_reserve");
-        const auto t_created = now();
         if (want_dumps) check(ctx, bdx_set_collect_support(ctx, 1), "bdx_set_collect_support");
-        check(ctx, bdx_push(ctx, &batch), "bdx_push");
-        const auto t_pushed = now();
         check(ctx, bdx_run(ctx), "bdx_run");
         const auto t_ran = now();
 
@@ -131,7 +179,7 @@ int main(int argc, char** argv) {
         std::vector<float> cv(nc);
         check(ctx, bdx_get_sv_lists(ctx, li.data(), lp.data(), nl, ck.data(), cv.data(), nc), "bdx_get_sv_lists");
 
-        auto tname = [&](int t) { return (t >= 0 && (size_t)t < reads.targets.size()) ? reads.targets[t] : std::to_string(t); };
+        auto tname = [&](int t) { return (t >= 0 && (size_t)t < targets.size()) ? targets[t] : std::to_string(t); };
 
         // supporting reads of the printed SVs: a second decode pass fetches just those records (the reference keeps
         // sequence data for every anomalous read in memory instead)
@@ -143,7 +191,7 @@ int main(int argc, char** argv) {
         std::unique_ptr<FastqDump> fastq;
         if (want_dumps) {
             if (!opts.prefix_fastq.empty()) fastq.reset(new FastqDump(opts.prefix_fastq, cfg));
-            if (!opts.dump_BED.empty()) bed.reset(new BedDump(opts.dump_BED, cfg, reads.targets));
+            if (!opts.dump_BED.empty()) bed.reset(new BedDump(opts.dump_BED, cfg, targets));
             size_t total = 0;
             sup_off.resize(svs.size() + 1);
             check(ctx, bdx_get_sv_support(ctx, sup_off.data(), nullptr, nullptr, 0, &total), "bdx_get_sv_support");
@@ -220,26 +268,16 @@ int main(int argc, char** argv) {
         if (timing) {
             float ms[8] = {0};
             bdx_get_timings(ctx, ms, 8);
-            fprintf(stderr, "[bdx timing] reads=%zu decode+merge=%.3fs (BGZF inflate on %u threads, single pass) gpu_init=%.3fs h2d_push=%.3fs "
-                            "bdx_run=%.4fs (classify %.3f ms) format=%.3fs total=%.3fs\n",
-                    reads.size(), secs(t_start, t_decoded), io_threads, secs(t_decoded, t_created), secs(t_created, t_pushed),
-                    secs(t_pushed, t_ran), ms[0], secs(t_ran, now()), secs(t_start, now()));
+            fprintf(stderr, "[bdx timing] reads=%zu decode+merge+stream=%.3fs (%u decode threads, single pass, batches copied and classified "
+                            "as they are produced) bdx_run=%.4fs format=%.3fs total=%.3fs\n",
+                    n_reads, secs(t_start, t_decoded), io_threads, secs(t_decoded, t_ran), secs(t_ran, now()), secs(t_start, now()));
         }
-        if (tidy_exit) {
-            bdx_destroy(ctx);
-            ctx = nullptr;
-        }
+        bdx_destroy(ctx);
+        ctx = nullptr;
     } catch (std::exception const& e) {
         std::cerr << "ERROR: " << e.what() << "\n";
         if (ctx) bdx_destroy(ctx);
         return 1;
-    }
-    if (!tidy_exit) {
-        // everything is written (the dump writers closed with their scope): leave without freeing the device buffers one by
-        // one and without the runtime's teardown, which together cost more than the GPU work of a whole chromosome
-        std::cout.flush();
-        fflush(nullptr);
-        _exit(0);
     }
     return 0;
 }

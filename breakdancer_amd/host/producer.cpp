@@ -1,6 +1,8 @@
 #include "producer.h"
 
 #include <cctype>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <sys/stat.h>
@@ -10,6 +12,7 @@
 #include <unordered_map>
 
 #include "bam_reader.h"
+#include "column_reader.h"
 
 namespace bdhost {
 
@@ -26,7 +29,8 @@ namespace {
 
 // samtools region strings as the reference accepts them for -o (bam_aux.c:107-160 bam_parse_region): "name",
 // "name:beg" or "name:beg-end" (1-based, commas allowed); a name that itself contains ':' is tried as a whole
-bool parse_region(const BamReader& rd, const std::string& str, int& tid, int& beg, int& end) {
+template <class Reader>
+bool parse_region(const Reader& rd, const std::string& str, int& tid, int& beg, int& end) {
     std::string s;
     for (char c : str)
         if (!isspace((unsigned char)c)) s += c;
@@ -159,27 +163,168 @@ void merge_streams(const BamConfig& cfg, const std::string& chr, int threads, st
 
 }  // namespace
 
-void produce(const BamConfig& cfg, const std::string& chr, int threads, ReadStream& out) {
-    {   // reserve from the compressed sizes (~60-100 B per record) so that the column vectors do not regrow all the way
-        size_t bytes = 0;
-        for (auto const& f : cfg.bam_files()) {
-            struct stat st;
-            if (stat(f.c_str(), &st) == 0) bytes += (size_t)st.st_size;
+namespace {
+
+// appends records to the sink's current batch and submits it when it is full
+class BatchWriter {
+public:
+    BatchWriter(BatchSink& sink, size_t batch_records) : sink_(sink), batch_(batch_records) {}
+    void append_range(const ColumnChunk& c, size_t lo, size_t hi, uint8_t bam) {
+        while (lo < hi) {
+            if (!open_) open();
+            const size_t m = std::min(hi - lo, buf_.capacity - used_);
+            memcpy(buf_.tid + used_, c.tid.data() + lo, m * 4); memcpy(buf_.pos + used_, c.pos.data() + lo, m * 4);
+            memcpy(buf_.mtid + used_, c.mtid.data() + lo, m * 4); memcpy(buf_.mpos + used_, c.mpos.data() + lo, m * 4);
+            memcpy(buf_.isize + used_, c.isize.data() + lo, m * 4);
+            memcpy(buf_.flag + used_, c.flag.data() + lo, m * 2); memcpy(buf_.qlen + used_, c.qlen.data() + lo, m * 2);
+            memcpy(buf_.mapq + used_, c.mapq.data() + lo, m); memcpy(buf_.lib + used_, c.lib.data() + lo, m);
+            memset(buf_.bam + used_, bam, m);
+            memcpy(buf_.name_key + used_, c.name_key.data() + lo, m * 8);
+            used_ += m; lo += m; total_ += m;
+            if (used_ == buf_.capacity) close();
         }
-        const size_t guess = bytes / 100 + 1024;
-        out.tid.reserve(guess); out.pos.reserve(guess); out.mtid.reserve(guess); out.mpos.reserve(guess); out.isize.reserve(guess);
-        out.flag.reserve(guess); out.qlen.reserve(guess); out.mapq.reserve(guess); out.lib.reserve(guess); out.bam.reserve(guess);
-        out.name_key.reserve(guess);
     }
-    merge_streams(cfg, chr, threads, &out.targets, [&](uint64_t, const BamRecord& r, int bam_index, uint8_t lib) {
-        out.tid.push_back(r.tid); out.pos.push_back(r.pos); out.mtid.push_back(r.mtid); out.mpos.push_back(r.mpos);
-        out.isize.push_back(r.isize); out.flag.push_back(r.flag);
-        out.qlen.push_back((uint16_t)(r.l_qseq > 65535 ? 65535 : (r.l_qseq < 0 ? 0 : r.l_qseq)));
-        out.mapq.push_back(r.bdqual);
-        out.lib.push_back(lib);
-        out.bam.push_back((uint8_t)bam_index);
-        out.name_key.push_back(r.name_key);
-    });
+    void append_one(const ColumnChunk& c, size_t i, uint8_t bam) {
+        if (!open_) open();
+        const size_t u = used_;
+        buf_.tid[u] = c.tid[i]; buf_.pos[u] = c.pos[i]; buf_.mtid[u] = c.mtid[i]; buf_.mpos[u] = c.mpos[i]; buf_.isize[u] = c.isize[i];
+        buf_.flag[u] = c.flag[i]; buf_.qlen[u] = c.qlen[i]; buf_.mapq[u] = c.mapq[i]; buf_.lib[u] = c.lib[i]; buf_.bam[u] = bam;
+        buf_.name_key[u] = c.name_key[i];
+        ++used_; ++total_;
+        if (used_ == buf_.capacity) close();
+    }
+    void finish() { if (open_) close(); }
+    size_t total() const { return total_; }
+
+private:
+    void open() {
+        const auto t0 = std::chrono::steady_clock::now();
+        buf_ = sink_.acquire(batch_); used_ = 0; open_ = true;
+        acquire_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    void close() {
+        const auto t0 = std::chrono::steady_clock::now();
+        sink_.submit(used_); open_ = false;
+        submit_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+public:
+    double acquire_s_ = 0, submit_s_ = 0, copy_s_ = 0;
+private:
+    BatchSink& sink_;
+    size_t batch_;
+    bdx_batch_buf buf_{};
+    size_t used_ = 0, total_ = 0;
+    bool open_ = false;
+};
+
+struct Cursor {  // one file's position in the merge: record i of the chunk the reader handed out last
+    std::unique_ptr<ColumnReader> rd;
+    const ColumnChunk* chunk = nullptr;
+    size_t i = 0;
+    uint8_t bam = 0;
+    bool advance() {  // to the next record; false at the end of the file
+        if (chunk && ++i < chunk->size()) return true;
+        do {
+            chunk = rd->next();
+            i = 0;
+        } while (chunk && chunk->size() == 0);
+        return chunk != nullptr;
+    }
+    bool first() {
+        do {
+            chunk = rd->next();
+            i = 0;
+        } while (chunk && chunk->size() == 0);
+        return chunk != nullptr;
+    }
+};
+
+struct CursorGreater {  // BamMerger::Stream::operator> (io/BamMerger.cpp:40-61): tid, pos, strand
+    bool operator()(const Cursor* a, const Cursor* b) const {
+        const ColumnChunk &x = *a->chunk, &y = *b->chunk;
+        const size_t i = a->i, j = b->i;
+        if (x.tid[i] > y.tid[j]) return true;
+        if (y.tid[j] > x.tid[i]) return false;
+        if (x.pos[i] > y.pos[j]) return true;
+        if (y.pos[j] > x.pos[i]) return false;
+        return ((x.flag[i] >> 4) & 1) > ((y.flag[j] >> 4) & 1);
+    }
+};
+
+struct VectorSink : BatchSink {  // batches appended to a ReadStream
+    ReadStream& out;
+    size_t base = 0;
+    explicit VectorSink(ReadStream& o) : out(o) {}
+    bdx_batch_buf acquire(size_t cap) override {
+        base = out.size();
+        const size_t n = base + cap;
+        out.tid.resize(n); out.pos.resize(n); out.mtid.resize(n); out.mpos.resize(n); out.isize.resize(n); out.flag.resize(n);
+        out.qlen.resize(n); out.mapq.resize(n); out.lib.resize(n); out.bam.resize(n); out.name_key.resize(n);
+        bdx_batch_buf b{};
+        b.tid = out.tid.data() + base; b.pos = out.pos.data() + base; b.mtid = out.mtid.data() + base; b.mpos = out.mpos.data() + base;
+        b.isize = out.isize.data() + base; b.flag = out.flag.data() + base; b.qlen = out.qlen.data() + base;
+        b.mapq = out.mapq.data() + base; b.lib = out.lib.data() + base; b.bam = out.bam.data() + base;
+        b.name_key = out.name_key.data() + base;
+        b.capacity = cap;
+        return b;
+    }
+    void submit(size_t n) override {
+        const size_t m = base + n;
+        out.tid.resize(m); out.pos.resize(m); out.mtid.resize(m); out.mpos.resize(m); out.isize.resize(m); out.flag.resize(m);
+        out.qlen.resize(m); out.mapq.resize(m); out.lib.resize(m); out.bam.resize(m); out.name_key.resize(m);
+    }
+};
+
+}  // namespace
+
+size_t produce_stream(const BamConfig& cfg, const std::string& chr, int threads, std::vector<std::string>* targets, BatchSink& sink,
+                      size_t batch_records) {
+    const LibraryResolver libs(cfg);
+    const size_t nb = cfg.num_bams();
+    if (nb == 0) throw std::runtime_error("BamMerger created with no input streams!");
+    const int per = std::max(1, threads / (int)nb);
+    std::vector<std::unique_ptr<Cursor>> cur;
+    for (size_t b = 0; b < nb; ++b) {
+        std::unique_ptr<Cursor> c(new Cursor);
+        c->rd.reset(new ColumnReader(cfg.bam_files()[b], per, &libs));
+        c->bam = (uint8_t)b;
+        RecordFilter f;
+        if (!chr.empty() && !parse_region(*c->rd, chr, f.only_tid, f.beg, f.end))
+            throw std::runtime_error("Failed to parse bam region '" + chr + "' in file " + cfg.bam_files()[b] + ". ");
+        c->rd->start(f);
+        cur.push_back(std::move(c));
+    }
+    if (targets) *targets = cur[0]->rd->target_names();
+    BatchWriter w(sink, batch_records);
+    if (nb == 1) {  // one file: nothing to merge, whole chunks are copied
+        Cursor& c = *cur[0];
+        while (const ColumnChunk* ch = c.rd->next()) {
+            const auto t0 = std::chrono::steady_clock::now();
+            if (ch->size()) w.append_range(*ch, 0, ch->size(), c.bam);
+            w.copy_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
+        w.finish();
+        if (getenv("BDX_BAM_PROFILE"))
+            fprintf(stderr, "[producer] consumer: copying into batches %.3f s (of which acquire %.3f s, submit %.3f s)\n", w.copy_s_, w.acquire_s_, w.submit_s_);
+        return w.total();
+    }
+    // the reference's k-way merge: a priority queue on (tid, pos, strand), same push / pop sequence as BamMerger
+    std::priority_queue<Cursor*, std::vector<Cursor*>, CursorGreater> pq;
+    for (auto& c : cur)
+        if (c->first()) pq.push(c.get());
+    while (!pq.empty()) {
+        Cursor* c = pq.top();
+        pq.pop();
+        w.append_one(*c->chunk, c->i, c->bam);
+        if (c->advance()) pq.push(c);
+    }
+    w.finish();
+    return w.total();
+}
+
+void produce(const BamConfig& cfg, const std::string& chr, int threads, ReadStream& out) {
+    VectorSink sink(out);
+    produce_stream(cfg, chr, threads, &out.targets, sink);
 }
 
 void collect_reads(const BamConfig& cfg, const std::string& chr, int threads, const std::vector<uint64_t>& wanted,

@@ -36,7 +36,20 @@ struct SupportRead {
 void collect_reads(const BamConfig& cfg, const std::string& chr, int threads, const std::vector<uint64_t>& wanted,
                    std::vector<SupportRead>& out);
 
-// chr: empty = all sequences, otherwise the -o region in samtools syntax ("name", "name:beg" or "name:beg-end")
+// Where the producer puts the merged stream: batches of SoA columns.  acquire() returns columns with room for at least
+// `capacity` records, submit(n) hands the first n back.  Two sinks exist: the GPU context's pinned staging ring
+// (bdx_acquire_batch / bdx_submit_batch: copies and the classifier overlap the decoding of the next batch) and ReadStream.
+struct BatchSink {
+    virtual ~BatchSink() {}
+    virtual bdx_batch_buf acquire(size_t capacity) = 0;
+    virtual void submit(size_t n) = 0;
+};
+
+// chr: empty = all sequences, otherwise the -o region in samtools syntax ("name", "name:beg" or "name:beg-end").
+// Every BAM is decoded once, by `threads` threads in all (column_reader.h); several files are merged in the reference's
+// order (io/BamMerger.cpp:40-126).  Returns the number of records; targets receives the first file's sequence names.
+size_t produce_stream(const BamConfig& cfg, const std::string& chr, int threads, std::vector<std::string>* targets, BatchSink& sink,
+                      size_t batch_records = 1u << 20);
 void produce(const BamConfig& cfg, const std::string& chr, int threads, ReadStream& out);
 
 }  // namespace bdhost

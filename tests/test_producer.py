@@ -62,12 +62,11 @@ def test_missing_map_field_is_an_error(tmp_path):
     assert p.returncode == 1 and b"Required field 'map' not found in config at line 1!" in p.stderr
 
 
-@pytest.mark.parametrize("env", [{}, {"BDX_BAM_SEG_BYTES": "3000", "BDX_BAM_FILL_BLOCKS": "5"},
-                                 {"BDX_BAM_SEG_BYTES": "100", "BDX_BAM_FILL_BLOCKS": "1"}, {"BDX_THREADS": "1"}])
+@pytest.mark.parametrize("env", [{}, {"BDX_BAM_PIECE_BLOCKS": "1"}, {"BDX_BAM_PIECE_BLOCKS": "3"}, {"BDX_BAM_PIECE_BLOCKS": "7"}])
 def test_producer_decodes_a_multi_block_synthetic_bam(tmp_path, env):
-    """a few thousand BGZF blocks, records straddling block boundaries, parallel inflate, records decoded by several
-    threads from guessed boundaries (the knobs shrink batches and segments: hundreds of hand-overs and guesses, segments
-    shorter than a record)"""
+    """a few hundred BGZF blocks, records straddling block boundaries, pieces of the file inflated and decoded by several
+    threads from guessed record boundaries (the knob shrinks the pieces to 1 / 3 / 7 blocks: hundreds of guesses and of
+    records that run into the next piece)"""
     from breakdancer_amd.bamwrite import write_bam
     from breakdancer_amd.synth import make_chromosome
     d = make_chromosome(length=300000, seed=5)
@@ -100,3 +99,30 @@ def test_region_strings_follow_samtools_semantics(region, beg, end):
         want += int(((recs["tid"] == tid) & (recs["rend"] > beg) & (recs["pos"] < end)).sum())
     assert len(rows) == want and want > 0
     assert (rows[:, 0] == 22).all() and (rows[:, 1] < end).all()
+
+
+def test_read_names_the_boundary_guess_rejects_are_still_decoded(tmp_path):
+    """read names with bytes outside the printable range defeat the record-boundary guess of every piece; the consumer then
+    decodes the piece again from the true boundary -- same stream"""
+    from breakdancer_amd.bamwrite import write_bam
+    from breakdancer_amd.synth import make_chromosome
+    d = make_chromosome(length=120000, seed=9)
+    n = len(d["tid"])
+    names = ["r\x01%07d" % int(k % 9999991) for k in d["name_key"]]
+    write_bam(str(tmp_path / "syn.bam"), d, ["chrS"], seed=1, names=names)
+    (tmp_path / "cfg").write_text("readgroup:rg1\tplatform:illumina\tmap:syn.bam\treadlen:100.00\tlib:lib1\tlower:310.00\tupper:490.00\tmean:400.00\tstd:30.00\n")
+    for env in ({}, {"BDX_BAM_PIECE_BLOCKS": "2"}):
+        head, rows, keys = dump(["cfg"], str(tmp_path), env)
+        assert len(rows) == n
+        for col, k in enumerate(("tid", "pos", "mtid", "mpos", "isize", "flag")):
+            np.testing.assert_array_equal(rows[:, col], d[k].astype(np.int64), err_msg=k)
+
+
+def test_two_files_merge_in_the_reference_order_at_every_piece_size():
+    run = load_chr21(make_opts()).run()
+    soa = run.merged_soa()
+    for env in ({"BDX_BAM_PIECE_BLOCKS": "1"}, {"BDX_BAM_PIECE_BLOCKS": "2"}):
+        head, rows, keys = dump(["inv_del_bam_config"], os.path.join(GOLDEN, "chr21"), env)
+        assert len(rows) == run.n_merged
+        for col, k in enumerate(("tid", "pos", "mtid", "mpos", "isize", "flag", "qlen", "bdqual", "lib", "bam")):
+            np.testing.assert_array_equal(rows[:, col], soa[k].astype(np.int64), err_msg=k)
