@@ -174,7 +174,7 @@ struct bdx_ctx {
     int ring_next = 0, ring_cur = -1;
     // name keys that stay in the caller's pinned memory (bdx_push): one segment per batch; host == nullptr: that range of
     // keys was copied into the resident column
-    struct KeySeg { uint64_t begin; const uint64_t* host; };
+    struct KeySeg { uint64_t begin; const uint64_t* host; const uint16_t* host_qlen; };
     std::vector<KeySeg> key_segs;
     DevBuf b_seg;
 };
@@ -265,28 +265,39 @@ int enqueue_batch(bdx_ctx* c, const bdx_batch& b, bool lazy_keys) {
             c->k1_live = true;
         }
     }
+    // (one stream: splitting the columns over two copy streams measured 10.8 ms against 9.1 ms for 15 M records)
+    hipStream_t s2 = s;
     HIPCHK(c, hipMemcpyAsync((void*)(c->d.tid + o), b.tid, n * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync((void*)(c->d.pos + o), b.pos, n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.pos + o), b.pos, n * 4, hipMemcpyHostToDevice, s2));
     HIPCHK(c, hipMemcpyAsync((void*)(c->d.mtid + o), b.mtid, n * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync((void*)(c->d.mpos + o), b.mpos, n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.mpos + o), b.mpos, n * 4, hipMemcpyHostToDevice, s2));
     HIPCHK(c, hipMemcpyAsync((void*)(c->d.isize + o), b.isize, n * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync((void*)(c->d.flag + o), b.flag, n * 2, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync((void*)(c->d.qlen + o), b.qlen, n * 2, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync((void*)(c->d.mapq + o), b.mapq, n, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync((void*)(c->d.lib + o), b.lib, n, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync((void*)(c->d.bam + o), b.bam, n, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.flag + o), b.flag, n * 2, hipMemcpyHostToDevice, s2));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.mapq + o), b.mapq, n, hipMemcpyHostToDevice, s2));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.lib + o), b.lib, n, hipMemcpyHostToDevice, s2));
+    HIPCHK(c, hipMemcpyAsync((void*)(c->d.bam + o), b.bam, n, hipMemcpyHostToDevice, s2));
+    // name keys and read lengths are only needed for the anomalous reads (about 1 %): pinned ones stay where they are
     const uint64_t* dev_view = nullptr;
+    const uint16_t* dev_qlen = nullptr;
     if (lazy_keys && c->key_segs.size() < 64) {
-        hipPointerAttribute_t attr{};
-        void* dp = nullptr;
-        if (hipPointerGetAttributes(&attr, b.name_key) == hipSuccess && attr.type == hipMemoryTypeHost &&
-            hipHostGetDevicePointer(&dp, (void*)b.name_key, 0) == hipSuccess && dp)
-            dev_view = (const uint64_t*)dp;
-        else
+        auto device_view = [](const void* hp) -> void* {
+            hipPointerAttribute_t attr{};
+            void* dp = nullptr;
+            if (hipPointerGetAttributes(&attr, hp) == hipSuccess && attr.type == hipMemoryTypeHost &&
+                hipHostGetDevicePointer(&dp, (void*)hp, 0) == hipSuccess)
+                return dp;
             (void)hipGetLastError();  // ordinary pageable memory: not an error
+            return nullptr;
+        };
+        dev_view = (const uint64_t*)device_view(b.name_key);
+        dev_qlen = dev_view ? (const uint16_t*)device_view(b.qlen) : nullptr;
+        if (!dev_qlen) dev_view = nullptr;
     }
-    if (!dev_view) HIPCHK(c, hipMemcpyAsync((void*)(c->d.key + o), b.name_key, n * 8, hipMemcpyHostToDevice, s));
-    if (c->key_segs.empty() || dev_view || c->key_segs.back().host) c->key_segs.push_back(bdx_ctx::KeySeg{(uint64_t)o, dev_view});
+    if (!dev_view) {
+        HIPCHK(c, hipMemcpyAsync((void*)(c->d.key + o), b.name_key, n * 8, hipMemcpyHostToDevice, s2));
+        HIPCHK(c, hipMemcpyAsync((void*)(c->d.qlen + o), b.qlen, n * 2, hipMemcpyHostToDevice, s));
+    }
+    if (c->key_segs.empty() || dev_view || c->key_segs.back().host) c->key_segs.push_back(bdx_ctx::KeySeg{(uint64_t)o, dev_view, dev_qlen});
     HIPCHK(c, hipEventRecord(c->ev_copy, s));
     c->copy_pending = true;
     c->n += n;
@@ -796,11 +807,12 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepa
             for (auto const& sg : c->key_segs) any_host |= sg.host != nullptr;
             if (any_host && !c->adopted) {
                 const size_t ns = c->key_segs.size();
-                std::vector<uint64_t> tab(2 * ns + 1);
+                std::vector<uint64_t> tab(3 * ns + 1);
                 for (size_t i = 0; i < ns; ++i) {
-                    tab[i] = c->key_segs[i].begin;
-                    const uint64_t* base = c->key_segs[i].host ? c->key_segs[i].host - c->key_segs[i].begin : c->d.key;
-                    tab[ns + 1 + i] = (uint64_t)(uintptr_t)base;
+                    const bdx_ctx::KeySeg& sg = c->key_segs[i];
+                    tab[i] = sg.begin;
+                    tab[ns + 1 + i] = (uint64_t)(uintptr_t)(sg.host ? sg.host - sg.begin : c->d.key);
+                    tab[2 * ns + 1 + i] = (uint64_t)(uintptr_t)(sg.host ? sg.host_qlen - sg.begin : c->d.qlen);
                 }
                 tab[ns] = c->n;
                 HIPCHK(c, c->b_seg.ensure(tab.size() * 8));
@@ -809,6 +821,7 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepa
                 k2.nseg = (int)ns;
                 k2.seg_begin = c->b_seg.as<uint64_t>();
                 k2.seg_ptr = (const uint64_t* const*)(c->b_seg.as<uint64_t>() + ns + 1);
+                k2.seg_qlen = (const uint16_t* const*)(c->b_seg.as<uint64_t>() + 2 * ns + 1);
             }
         }
         launch_k2(k2, k2_lds_bytes(nkeys), s, c->finalize2_deferred ? &c->fp_deferred : nullptr);

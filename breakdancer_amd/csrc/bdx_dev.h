@@ -123,11 +123,13 @@ struct K2Params {
     uint32_t* fill_ptr[4];
     uint32_t fill_words[4];
     uint32_t fill_value[4];
-    // name keys left in the caller's pinned host memory (bdx_push): read i's key is seg_ptr[s][i] for the segment s with
-    // seg_begin[s] <= i < seg_begin[s+1]; only the ~1 % anomalous reads ever fetch theirs (over PCIe).  nseg = 0: r.key
+    // name keys and read lengths left in the caller's pinned host memory (bdx_push): read i's key is seg_ptr[s][i], its
+    // length seg_qlen[s][i], for the segment s with seg_begin[s] <= i < seg_begin[s+1]; only the ~1 % anomalous reads ever
+    // fetch theirs (over PCIe).  nseg = 0: r.key / r.qlen
     int nseg;
     const uint64_t* seg_begin;          // [nseg + 1]
     const uint64_t* const* seg_ptr;     // [nseg] device-visible, biased by -seg_begin[s]
+    const uint16_t* const* seg_qlen;    // [nseg] likewise
 };
 
 __device__ __forceinline__ uint32_t meta_pack(int flag, int rev, int lib, int qlen) {

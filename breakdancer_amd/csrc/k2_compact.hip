@@ -37,19 +37,24 @@ __device__ __forceinline__ unsigned class_byte(const uint64_t (&cq)[kSub / 2], i
     return (unsigned)((v >> (8 * (r & 7))) & 255u);
 }
 
-// nblk: workgroups that compact (the launch can hold one more, see k2_compact_side_kernel)
-// name key of read i: from the resident column, or -- when bdx_push left the keys in the caller's pinned host memory --
-// from the segment (one per pushed batch) that holds it; only anomalous reads (about 1 %) get here
-__device__ __forceinline__ uint64_t name_key_of(const K2Params& p, uint64_t i) {
-    if (p.nseg == 0) return p.r.key[i];
+// name key and length of read i: from the resident columns, or -- when bdx_push left them in the caller's pinned host
+// memory -- from the segment (one per pushed batch) that holds them; only anomalous reads (about 1 %) get here
+__device__ __forceinline__ void key_and_qlen_of(const K2Params& p, uint64_t i, uint64_t& key, int& qlen) {
+    if (p.nseg == 0) {
+        key = p.r.key[i];
+        qlen = (int)p.r.qlen[i];
+        return;
+    }
     int lo = 0, hi = p.nseg - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (p.seg_begin[mid] <= i) lo = mid; else hi = mid - 1;
     }
-    return p.seg_ptr[lo][i];
+    key = p.seg_ptr[lo][i];
+    qlen = (int)p.seg_qlen[lo][i];
 }
 
+// nblk: workgroups that compact (the launch can hold one more, see k2_compact_side_kernel)
 __device__ __forceinline__ void k2_body(const K2Params& p, uint32_t nblk) {
     __shared__ uint32_t s_src[kWaves * kSlice];  // per wave: offset in super tile | class byte << kOffBits, by in-tile rank
     __shared__ uint32_t s_nn[kWaves * kSlice];
@@ -124,8 +129,11 @@ __device__ __forceinline__ void k2_body(const K2Params& p, uint32_t nblk) {
                     p.c.tid[j] = p.r.tid[i];
                     p.c.pos[j] = p.r.pos[i];
                     p.c.isize[j] = abs(p.r.isize[i]);
-                    p.c.meta[j] = meta_pack((int)((src >> kOffBits) & 15u), (sam >> 4) & 1u, (int)p.r.lib[i], (int)p.r.qlen[i]);
-                    p.c.key[j] = name_key_of(p, i);
+                    uint64_t key;
+                    int qlen;
+                    key_and_qlen_of(p, i, key, qlen);
+                    p.c.meta[j] = meta_pack((int)((src >> kOffBits) & 15u), (sam >> 4) & 1u, (int)p.r.lib[i], qlen);
+                    p.c.key[j] = key;
                     p.c.idx[j] = (uint32_t)i;
                     p.c.nn[j] = s_nn[w * kSlice + q];
                 }

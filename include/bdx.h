@@ -112,8 +112,8 @@ const char* bdx_last_error(const bdx_ctx* ctx);
  *       by the ring.  The buffer belongs to the context again as soon as bdx_submit_batch returns.
  *   bdx_push             a batch in the caller's own memory.  The copies are asynchronous: every array of the batch must
  *       stay valid and unchanged until the next bdx_run on this context has returned.  Arrays in pinned (page-locked)
- *       memory are copied at PCIe speed; a pinned name_key array is not copied at all -- only the anomalous reads
- *       (about 1 %) need their key and the compaction kernel fetches those straight from the caller's array (27 instead
+ *       memory are copied at PCIe speed; pinned name_key and qlen arrays are not copied at all -- only the anomalous reads
+ *       (about 1 %) need them and the compaction kernel fetches those straight from the caller's arrays (25 instead
  *       of 35 bytes per read cross the bus).
  *   bdx_set_device_reads adopts arrays that already live in HBM (no copy; must stay valid until bdx_destroy or
  *       bdx_reset_reads; every array base 16-byte aligned).

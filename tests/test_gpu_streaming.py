@@ -85,8 +85,8 @@ def test_staging_ring_of_the_streaming_producer(case):
 
 
 def test_pinned_batches_keep_their_name_keys_on_the_host(case):
-    """bdx_push of pinned arrays: 27 of the 35 bytes per read are copied, the compaction kernel fetches the name keys of the
-    anomalous reads from the caller's memory"""
+    """bdx_push of pinned arrays: 25 of the 35 bytes per read are copied, the compaction kernel fetches the name keys and
+    read lengths of the anomalous reads from the caller's memory"""
     import ctypes as C
     d, run = case
     hip = C.CDLL("libamdhip64.so")
