@@ -109,12 +109,27 @@ class BreakDancer:
             raise BdxError("bdx_create: %s" % self.lib.bdx_strerror(rc).decode())
         self._keep = []
 
+    @classmethod
+    def borrow(cls, handle, opts, libs, nbams):
+        """wrap a context that somebody else owns (a chromosome or the result of a sharded run, dist.py): never destroyed here"""
+        self = cls.__new__(cls)
+        self.lib = L.load()
+        self.opts, self.libs = opts, list(libs)
+        self.nlibs, self.nbams = len(self.libs), nbams
+        self.h = C.c_void_p(handle)
+        self._keep = []
+        self._borrowed = True
+        return self
+
     def _chk(self, rc, what):
         if rc != 0:
             raise BdxError("%s: %s (%s)" % (what, self.lib.bdx_strerror(rc).decode(),
                                            self.lib.bdx_last_error(self.h).decode()))
 
     def close(self):
+        if getattr(self, "_borrowed", False):
+            self.h = C.c_void_p()
+            return
         if getattr(self, "h", None) is not None and self.h.value:
             self.lib.bdx_destroy(self.h)
             self.h = C.c_void_p()

@@ -839,7 +839,7 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepa
 // K3: cut regions.  In a whole-genome run the last candidate of a chromosome is closed by the first anomalous read
 // of the next chromosome, which still counts for its nucleotide sum / max read length / normal-pair count
 // (BreakDancer.cpp:202-231): has_next / next_qlen / next_nn carry that read across contexts.
-int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool for_k6) {
+int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool for_k6, bool keep_dev = false) {
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const int nkeys = c->nkeys;
@@ -880,6 +880,12 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool f
             HIPCHK(c, c->h_counts0.ensure(sizeof(StageCounts)));
             memset(c->h_counts0.p, 0, sizeof(StageCounts));
             k3.counts_host = c->h_counts0.as<StageCounts>();
+        }
+        if (keep_dev && !for_k6) {  // sharded runs: the region table is sent on from HBM (and still mirrored to the host)
+            HIPCHK(c, c->b_r_rec.ensure(cap * sizeof(RegionRec)));
+            HIPCHK(c, c->b_r_pk.ensure(cap * 2 * nkeys * 4));
+            k3.r_rec_dev = c->b_r_rec.as<RegionRec>(); k3.r_pk_dev = c->b_r_pk.as<uint32_t>();
+            k3.host_copy_later = 0;
         }
         K3Tail tail{has_next, next_qlen, next_nn};
         // single-context runs that take the direct join let that kernel do k3_region_of_kernel's work
@@ -1753,3 +1759,5 @@ int bdx_poisson_log_upper_tail(const double* lambda, const int32_t* k, double* o
 }
 
 }  // extern "C"
+
+#include "bdx_dist_impl.h"

@@ -1,0 +1,596 @@
+// Chromosome-sharded runs: one whole-genome result from chromosomes spread over several GPUs (include/bdx.h, bdx_dist_*).
+// Included at the end of bdx_api.hip (it drives the stage functions of that translation unit).
+//
+// The path shards by chromosome -- regions never span tids (BreakDancer.cpp:216) -- and what a single breakdancer-max run
+// couples across chromosomes is small: the pass-1 statistics (window, lambda, densities: BamSummary.cpp:129-150,
+// BreakDancerMax.cpp:83-116), the running counters sampled at region boundaries, the read that closes a chromosome's
+// last candidate region (BreakDancer.cpp:202-231), the region numbering / flush cadence (BreakDancer.cpp:254-259), and the
+// inter-chromosomal read pairs (-t, ARP_CTX).  Every rank (one per GPU) runs K1-K4 on its own chromosomes; between the
+// stages the ranks exchange
+//   C1  an all-reduce of the pass-1 counters, per-file reference lengths and per-chromosome totals,
+//   C2  an all-reduce of each chromosome's first anomalous read and C3 of its region count / last read length
+//       (every table entry is owned by exactly one rank, so a sum is a gather),
+//   C4  ONE all-to-all of the CTX join records to owner(name key) (k7_exchange.hip): the only exchange on the data path.
+//       Pairs with both mates on one chromosome never leave their GPU,
+//   C5  a gather of the region tables and pair groups to rank 0, which walks the region graph (build_connection is
+//       inherently ordered: BreakDancer.cpp:266-346) and scores the candidates (K5).
+// Payloads stay in HBM: the collectives run on device buffers through RCCL (ncclAllReduce, ncclAllToAllv, grouped
+// ncclSend / ncclRecv), xGMI between the GPUs of a node.  A second backend runs the ranks as threads of one process
+// (tests on a single GPU; a host program that drives several GPUs itself).
+#include <dlfcn.h>
+
+#include <condition_variable>
+#include <map>
+#include <memory>
+#include <mutex>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------------
+// communicators
+// ------------------------------------------------------------------------------------------------------------------
+struct Comm {
+    int rank = 0, world = 1;
+    std::string err;
+    virtual ~Comm() {}
+    // in place sum over the ranks of n 64-bit words in device memory
+    virtual bool allreduce_u64(uint64_t* dev, size_t n, hipStream_t s) = 0;
+    // rank r sends scount[d] words from send + sdispl[d] to rank d and receives rcount[d] words from rank d at recv + rdispl[d]
+    virtual bool alltoallv_u64(const uint64_t* send, const size_t* scount, const size_t* sdispl, uint64_t* recv, const size_t* rcount,
+                               const size_t* rdispl, hipStream_t s) = 0;
+    // every rank sends n bytes (n a multiple of 8) to the root, which places rank r's at recv + displ[r] (count[r] bytes)
+    virtual bool gatherv_bytes(const void* send, size_t n, void* recv, const size_t* count, const size_t* displ, int root, hipStream_t s) = 0;
+};
+
+// ---- RCCL (one process per GPU) -- resolved at run time so that single-GPU users do not depend on librccl ----
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, bdx_unique_id, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*AllToAllv)(const void*, const size_t*, const size_t*, void*, const size_t*, const size_t*, int, void*, hipStream_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string err;
+    bool load() {
+        if (lib) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) { err = std::string("librccl not found: ") + dlerror(); return false; }
+        auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) err = std::string("librccl lacks ") + n; return p; };
+        GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
+        AllToAllv = (decltype(AllToAllv))sym("ncclAllToAllv");
+        Send = (decltype(Send))sym("ncclSend");
+        Recv = (decltype(Recv))sym("ncclRecv");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        return err.empty();
+    }
+};
+RcclApi& rccl() { static RcclApi a; return a; }
+constexpr int kNcclUint8 = 1, kNcclUint64 = 5, kNcclSum = 0;  // ncclDataType_t / ncclRedOp_t values of rccl.h
+
+struct RcclComm : Comm {
+    void* comm = nullptr;
+    bool ok(int rc, const char* what) {
+        if (rc == 0) return true;
+        err = std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "RCCL error");
+        return false;
+    }
+    ~RcclComm() override { if (comm) (void)rccl().CommDestroy(comm); }
+    bool allreduce_u64(uint64_t* dev, size_t n, hipStream_t s) override {
+        return ok(rccl().AllReduce(dev, dev, n, kNcclUint64, kNcclSum, comm, s), "ncclAllReduce");
+    }
+    bool alltoallv_u64(const uint64_t* send, const size_t* scount, const size_t* sdispl, uint64_t* recv, const size_t* rcount,
+                       const size_t* rdispl, hipStream_t s) override {
+        return ok(rccl().AllToAllv(send, scount, sdispl, recv, rcount, rdispl, kNcclUint64, comm, s), "ncclAllToAllv");
+    }
+    bool gatherv_bytes(const void* send, size_t n, void* recv, const size_t* count, const size_t* displ, int root, hipStream_t s) override {
+        if (!ok(rccl().GroupStart(), "ncclGroupStart")) return false;
+        bool good = true;
+        if (n) good = ok(rccl().Send(send, n, kNcclUint8, root, comm, s), "ncclSend");
+        if (good && rank == root)
+            for (int r = 0; r < world && good; ++r)
+                if (count[r]) good = ok(rccl().Recv((char*)recv + displ[r], count[r], kNcclUint8, r, comm, s), "ncclRecv");
+        const bool ended = ok(rccl().GroupEnd(), "ncclGroupEnd");
+        return good && ended;
+    }
+};
+
+// ---- ranks as threads of one process: collectives as device-to-device copies around a barrier ----
+struct ThreadGroup {
+    int world = 1;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    std::vector<const void*> ptr;      // what every rank published for the collective in progress
+    std::vector<const size_t*> cnt, dsp;
+    std::vector<std::vector<uint64_t>> host;  // allreduce staging
+    bool failed = false;
+    explicit ThreadGroup(int w) : world(w), ptr(w), cnt(w), dsp(w), host(w) {}
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t g = generation;
+        if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != g; });
+    }
+};
+
+struct ThreadComm : Comm {
+    std::shared_ptr<ThreadGroup> g;
+    bool hip(hipError_t e, const char* what) {
+        if (e == hipSuccess) return true;
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        g->failed = true;
+        return false;
+    }
+    bool allreduce_u64(uint64_t* dev, size_t n, hipStream_t s) override {
+        std::vector<uint64_t>& mine = g->host[rank];
+        mine.resize(n);
+        bool good = hip(hipMemcpyAsync(mine.data(), dev, n * 8, hipMemcpyDeviceToHost, s), "hipMemcpyAsync") && hip(hipStreamSynchronize(s), "sync");
+        g->barrier();
+        std::vector<uint64_t> sum(n, 0);
+        for (int r = 0; r < world; ++r)
+            for (size_t i = 0; i < n && i < g->host[r].size(); ++i) sum[i] += g->host[r][i];
+        g->barrier();  // (everybody has read everybody's words)
+        good = good && hip(hipMemcpyAsync(dev, sum.data(), n * 8, hipMemcpyHostToDevice, s), "hipMemcpyAsync") && hip(hipStreamSynchronize(s), "sync");
+        return good && !g->failed;
+    }
+    bool alltoallv_u64(const uint64_t* send, const size_t* scount, const size_t* sdispl, uint64_t* recv, const size_t* rcount,
+                       const size_t* rdispl, hipStream_t s) override {
+        bool good = hip(hipStreamSynchronize(s), "sync");  // the send buffer is complete
+        g->ptr[rank] = send; g->cnt[rank] = scount; g->dsp[rank] = sdispl;
+        g->barrier();
+        for (int r = 0; r < world && good; ++r) {
+            const size_t n = g->cnt[r][rank];
+            if (n != rcount[r]) { err = "all-to-all counts disagree"; g->failed = true; good = false; break; }
+            if (n) good = hip(hipMemcpyAsync(recv + rdispl[r], (const uint64_t*)g->ptr[r] + g->dsp[r][rank], n * 8, hipMemcpyDefault, s), "hipMemcpyAsync");
+        }
+        good = good && hip(hipStreamSynchronize(s), "sync");
+        g->barrier();  // (the send buffers may be reused)
+        return good && !g->failed;
+    }
+    bool gatherv_bytes(const void* send, size_t n, void* recv, const size_t* count, const size_t* displ, int root, hipStream_t s) override {
+        bool good = hip(hipStreamSynchronize(s), "sync");
+        g->ptr[rank] = send;
+        g->barrier();
+        if (rank == root) {
+            for (int r = 0; r < world && good; ++r)
+                if (count[r]) good = hip(hipMemcpyAsync((char*)recv + displ[r], g->ptr[r], count[r], hipMemcpyDefault, s), "hipMemcpyAsync");
+            good = good && hip(hipStreamSynchronize(s), "sync");
+        }
+        (void)n;
+        g->barrier();
+        return good && !g->failed;
+    }
+};
+
+}  // namespace
+
+struct bdx_dist {
+    int device = 0, ntids = 0, nlibs = 0, nbams = 0, nkeys = 0, w0 = 0;
+    bdx_opts opts{};
+    std::vector<bdx_lib> libs;
+    std::unique_ptr<Comm> comm;
+    std::map<int, bdx_ctx*> chrom;   // the chromosomes this rank owns
+    bdx_ctx* util = nullptr;         // joins the CTX records this rank owns, and on rank 0 walks and holds the result
+    DevBuf b_words, b_cnt, b_send, b_recv, b_pack, b_all;
+    std::string err;
+    uint64_t ctx_sent = 0, ctx_received = 0, gathered_bytes = 0;
+    float ms_total = 0, ms_exchange = 0;
+    bool ran = false;
+};
+
+namespace {
+
+int dfail(bdx_dist* d, int code, const std::string& msg) {
+    if (d) d->err = msg;
+    return code;
+}
+#define DHIP(d, expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) return dfail(d, BDX_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+#define DCTX(d, c, expr)                                                                     \
+    do {                                                                                     \
+        const int _rc = (expr);                                                              \
+        if (_rc != BDX_OK) return dfail(d, _rc, std::string(#expr) + ": " + (c)->err);       \
+    } while (0)
+
+// host vector -> device words -> all-reduce -> host vector
+int allreduce_host(bdx_dist* d, std::vector<uint64_t>& v) {
+    if (v.empty()) return BDX_OK;
+    hipStream_t s = d->util->stream;
+    DHIP(d, d->b_words.ensure(v.size() * 8));
+    DHIP(d, hipMemcpyAsync(d->b_words.p, v.data(), v.size() * 8, hipMemcpyHostToDevice, s));
+    if (!d->comm->allreduce_u64(d->b_words.as<uint64_t>(), v.size(), s)) return dfail(d, BDX_EHIP, d->comm->err);
+    DHIP(d, hipMemcpyAsync(v.data(), d->b_words.p, v.size() * 8, hipMemcpyDeviceToHost, s));
+    DHIP(d, hipStreamSynchronize(s));
+    return BDX_OK;
+}
+
+int dist_create_common(bdx_dist** out, const bdx_opts* opts, const bdx_lib* libs, int nlibs, int nbams, int ntids, int w0, int device,
+                       std::unique_ptr<Comm> comm) {
+    if (!out || !opts || !libs || nlibs < 1 || nbams < 1 || ntids < 1) return BDX_EINVAL;
+    if (opts->min_len < 0) return BDX_ELIMIT;  // (a negative -s registers a read-less region 0: single-context runs only)
+    if (comm->world > kMaxRanks) return BDX_ELIMIT;
+    bdx_dist* d = new (std::nothrow) bdx_dist;
+    if (!d) return BDX_ENOMEM;
+    d->device = device; d->ntids = ntids; d->nlibs = nlibs; d->nbams = nbams; d->w0 = w0;
+    d->opts = *opts;
+    d->libs.assign(libs, libs + nlibs);
+    d->nkeys = opts->cn_lib ? nlibs : nbams;
+    d->comm = std::move(comm);
+    const int rc = bdx_create(&d->util, opts, libs, nlibs, nbams, ntids, w0, device);
+    if (rc != BDX_OK) { delete d; return rc; }
+    *out = d;
+    return BDX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bdx_dist_unique_id(bdx_unique_id* out) {
+    if (!out) return BDX_EINVAL;
+    if (!rccl().load()) return BDX_EHIP;
+    return rccl().GetUniqueId(out) == 0 ? BDX_OK : BDX_EHIP;
+}
+
+int bdx_dist_create(bdx_dist** out, const bdx_opts* opts, const bdx_lib* libs, int nlibs, int nbams, int ntids,
+                    int max_read_window_size0, int device, int rank, int world, const bdx_unique_id* id) {
+    if (!out || world < 1 || rank < 0 || rank >= world || !id) return BDX_EINVAL;
+    if (!rccl().load()) return BDX_EHIP;
+    if (hipSetDevice(device) != hipSuccess) return BDX_EHIP;
+    std::unique_ptr<RcclComm> c(new RcclComm);
+    c->rank = rank; c->world = world;
+    if (rccl().CommInitRank(&c->comm, world, *id, rank) != 0) return BDX_EHIP;
+    return dist_create_common(out, opts, libs, nlibs, nbams, ntids, max_read_window_size0, device, std::move(c));
+}
+
+int bdx_dist_create_threads(bdx_dist** out, const bdx_opts* opts, const bdx_lib* libs, int nlibs, int nbams, int ntids,
+                            int max_read_window_size0, const int* devices, int world) {
+    if (!out || !devices || world < 1) return BDX_EINVAL;
+    std::shared_ptr<ThreadGroup> g(new ThreadGroup(world));
+    for (int r = 0; r < world; ++r) out[r] = nullptr;
+    for (int r = 0; r < world; ++r) {
+        std::unique_ptr<ThreadComm> c(new ThreadComm);
+        c->rank = r; c->world = world; c->g = g;
+        const int rc = dist_create_common(&out[r], opts, libs, nlibs, nbams, ntids, max_read_window_size0, devices[r], std::move(c));
+        if (rc != BDX_OK) {
+            for (int q = 0; q < r; ++q) { bdx_dist_destroy(out[q]); out[q] = nullptr; }
+            return rc;
+        }
+    }
+    return BDX_OK;
+}
+
+void bdx_dist_destroy(bdx_dist* d) {
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    for (auto& kv : d->chrom) bdx_destroy(kv.second);
+    if (d->util) bdx_destroy(d->util);
+    for (DevBuf* b : {&d->b_words, &d->b_cnt, &d->b_send, &d->b_recv, &d->b_pack, &d->b_all}) b->release();
+    delete d;
+}
+
+const char* bdx_dist_last_error(const bdx_dist* d) { return d ? d->err.c_str() : ""; }
+int bdx_dist_rank(const bdx_dist* d) { return d ? d->comm->rank : -1; }
+int bdx_dist_world(const bdx_dist* d) { return d ? d->comm->world : 0; }
+
+bdx_ctx* bdx_dist_chromosome(bdx_dist* d, int tid) {
+    if (!d || tid < 0 || tid >= d->ntids) return nullptr;
+    auto f = d->chrom.find(tid);
+    if (f != d->chrom.end()) return f->second;
+    bdx_ctx* c = nullptr;
+    if (bdx_create(&c, &d->opts, d->libs.data(), d->nlibs, d->nbams, d->ntids, d->w0, d->device) != BDX_OK) return nullptr;
+    d->chrom[tid] = c;
+    return c;
+}
+
+bdx_ctx* bdx_dist_result(bdx_dist* d) { return d && d->ran && d->comm->rank == 0 ? d->util : nullptr; }
+
+int bdx_dist_get_exchange(const bdx_dist* d, uint64_t* ctx_records_sent, uint64_t* ctx_records_received, uint64_t* gathered_bytes,
+                          float* ms_total, float* ms_exchange) {
+    if (!d) return BDX_EINVAL;
+    if (!d->ran) return BDX_ESTATE;
+    if (ctx_records_sent) *ctx_records_sent = d->ctx_sent;
+    if (ctx_records_received) *ctx_records_received = d->ctx_received;
+    if (gathered_bytes) *gathered_bytes = d->gathered_bytes;
+    if (ms_total) *ms_total = d->ms_total;
+    if (ms_exchange) *ms_exchange = d->ms_exchange;
+    return BDX_OK;
+}
+
+int bdx_dist_owner(uint64_t name_key, int world) { return world > 0 ? (int)exchange_owner(name_key, (uint32_t)world) : -1; }
+
+// longest-processing-time packing: chromosomes in descending weight, each onto the least loaded rank (ties: lower rank)
+int bdx_dist_plan(const uint64_t* weight, int ntids, int world, int* rank_of_tid) {
+    if (!weight || !rank_of_tid || ntids < 0 || world < 1) return BDX_EINVAL;
+    std::vector<int> order(ntids);
+    for (int i = 0; i < ntids; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return weight[a] > weight[b]; });
+    std::vector<uint64_t> load(world, 0);
+    for (int t : order) {
+        int best = 0;
+        for (int r = 1; r < world; ++r)
+            if (load[r] < load[best]) best = r;
+        rank_of_tid[t] = best;
+        load[best] += weight[t];
+    }
+    return BDX_OK;
+}
+
+int bdx_dist_run(bdx_dist* d) {
+    if (!d) return BDX_EINVAL;
+    const auto t_begin = std::chrono::steady_clock::now();
+    Comm& comm = *d->comm;
+    const int world = comm.world, rank = comm.rank;
+    const int nlibs = d->nlibs, nbams = d->nbams, nkeys = d->nkeys, ntids = d->ntids;
+    const int ncnt = nlibs * kNumFlags + nlibs + nbams;
+    DHIP(d, hipSetDevice(d->device));
+    bdx_ctx* U = d->util;
+    hipStream_t us = U->stream;
+    d->ran = false;
+    d->ctx_sent = d->ctx_received = d->gathered_bytes = 0;
+
+    // ---- pass 1 on the own chromosomes; C1: counters, per-file reference lengths, per-chromosome totals ----
+    const size_t tw = 2 + (size_t)nkeys;  // per chromosome: anomalous reads, normal pairs, proper reads per key
+    std::vector<uint64_t> v1((size_t)ncnt + nbams + (size_t)ntids * tw, 0);
+    for (auto& kv : d->chrom) DCTX(d, kv.second, do_pass1(kv.second, 0, false, false));  // all enqueued, then waited for
+    for (auto& kv : d->chrom) {
+        bdx_ctx* c = kv.second;
+        DCTX(d, c, wait_pass1(c));
+        for (int i = 0; i < ncnt; ++i) v1[i] += c->cnt_local[i];
+        for (int b = 0; b < nbams; ++b) v1[ncnt + b] += c->p1.ref_len[b];
+        uint64_t* t = &v1[(size_t)ncnt + nbams + (size_t)kv.first * tw];
+        t[0] = c->p1.n_anom; t[1] = c->p1.n_normal;
+        for (int k = 0; k < nkeys; ++k) t[2 + k] = c->p1.key_tot[k];
+    }
+    DCTX(d, U, do_pass1(U));  // (no reads: brings the utility context's buffers up)
+    int rc = allreduce_host(d, v1);
+    if (rc != BDX_OK) return rc;
+    std::vector<uint32_t> cnt_g(ncnt);
+    for (int i = 0; i < ncnt; ++i) cnt_g[i] = (uint32_t)v1[i];
+    uint32_t covered = 0;  // BamSummary.cpp:123-126: a uint32 maximum compared against each file's size_t sum
+    for (int b = 0; b < nbams; ++b)
+        if ((uint64_t)covered < v1[ncnt + b]) covered = (uint32_t)v1[ncnt + b];
+    const int32_t window = window_from(U, cnt_g.data(), covered);
+    auto tot = [&](int tid, int k) { return v1[(size_t)ncnt + nbams + (size_t)tid * tw + k]; };
+    std::vector<uint64_t> base((size_t)(ntids + 1) * tw, 0);  // exclusive prefix over the chromosomes in stream order
+    for (int t = 0; t < ntids; ++t)
+        for (size_t k = 0; k < tw; ++k) base[(size_t)(t + 1) * tw + k] = base[(size_t)t * tw + k] + tot(t, (int)k);
+    if (base[(size_t)ntids * tw] > kMaxRegions) return dfail(d, BDX_ELIMIT, "too many anomalous reads for the packed group key");
+
+    // ---- compaction with the counters of the chromosomes in front; C2: every chromosome's first anomalous read ----
+    std::vector<uint64_t> v2((size_t)ntids * 3, 0);
+    for (auto& kv : d->chrom) {
+        bdx_ctx* c = kv.second;
+        DCTX(d, c, set_pass1(c, cnt_g.data(), covered, window, true));
+        std::vector<uint32_t> pkb(nkeys);
+        for (int k = 0; k < nkeys; ++k) pkb[k] = (uint32_t)base[(size_t)kv.first * tw + 2 + k];
+        DCTX(d, c, do_compact(c, (uint32_t)base[(size_t)kv.first * tw + 1], pkb.data(), false));
+    }
+    for (auto& kv : d->chrom) {
+        bdx_ctx* c = kv.second;
+        if (!c->p1.n_anom) continue;
+        uint32_t meta = 0, nn = 0;
+        DHIP(d, hipMemcpyAsync(&meta, c->cp.meta, 4, hipMemcpyDeviceToHost, c->stream));
+        DHIP(d, hipMemcpyAsync(&nn, c->cp.nn, 4, hipMemcpyDeviceToHost, c->stream));
+        DHIP(d, hipStreamSynchronize(c->stream));
+        uint64_t* t = &v2[(size_t)kv.first * 3];
+        t[0] = 1; t[1] = (uint64_t)meta_qlen(meta); t[2] = nn;
+    }
+    rc = allreduce_host(d, v2);
+    if (rc != BDX_OK) return rc;
+
+    // ---- regions; the first anomalous read of the next chromosome closes a chromosome's last candidate.  C3 ----
+    std::vector<int> next_anom(ntids, -1);
+    for (int t = ntids - 1, nx = -1; t >= 0; --t) {
+        next_anom[t] = nx;
+        if (tot(t, 0) > 0) nx = t;
+    }
+    std::vector<uint64_t> v3((size_t)ntids * 2, 0);
+    for (auto& kv : d->chrom) {
+        bdx_ctx* c = kv.second;
+        const int nx = next_anom[kv.first];
+        if (nx >= 0) DCTX(d, c, do_cut(c, 1, (int32_t)v2[(size_t)nx * 3 + 1], (uint32_t)v2[(size_t)nx * 3 + 2], false, true));
+        else DCTX(d, c, do_cut(c, 0, 0, 0, false, true));
+    }
+    for (auto& kv : d->chrom) {
+        bdx_ctx* c = kv.second;
+        DCTX(d, c, readback(c, false));
+        v3[(size_t)kv.first * 2] = c->counts.n_regions;
+        v3[(size_t)kv.first * 2 + 1] = (uint32_t)c->counts.last_maxq;
+    }
+
+    // ---- joins: pairs within a chromosome where they are; CTX records to owner(name key) ----
+    DHIP(d, d->b_cnt.ensure((size_t)world * 8 + 64));
+    uint32_t* d_cnt = d->b_cnt.as<uint32_t>();      // [world] records per destination
+    uint32_t* d_cur = d_cnt + world;                // [world] scatter cursors
+    DHIP(d, hipMemsetAsync(d_cnt, 0, (size_t)world * 4, us));
+    DHIP(d, hipStreamSynchronize(us));
+    // (the chromosomes' streams are independent: the counts are complete once each has been waited for, below)
+    for (auto& kv : d->chrom) {
+        bdx_ctx* c = kv.second;
+        const uint32_t na = c->p1.n_anom;
+        if (na) launch_k7_count(c->cp.key, c->cp.meta, &c->b_p1.as<Pass1>()->n_anom, na, (uint32_t)world, d_cnt, c->stream);
+    }
+    for (auto& kv : d->chrom) DHIP(d, hipStreamSynchronize(kv.second->stream));
+    std::vector<uint32_t> h_cnt(world, 0);
+    DHIP(d, hipMemcpy(h_cnt.data(), d_cnt, (size_t)world * 4, hipMemcpyDeviceToHost));
+    rc = allreduce_host(d, v3);
+    if (rc != BDX_OK) return rc;
+    std::vector<uint64_t> rbase(ntids + 1, 0);
+    for (int t = 0; t < ntids; ++t) rbase[t + 1] = rbase[t] + v3[(size_t)t * 2];
+    const uint64_t NR = rbase[ntids];
+    if (NR > kMaxRegions) return dfail(d, BDX_ELIMIT, "too many regions for the packed group key");
+    int last_anom_tid = -1;
+    for (int t = 0; t < ntids; ++t)
+        if (tot(t, 0) > 0) last_anom_tid = t;
+
+    const auto t_x0 = std::chrono::steady_clock::now();
+    std::vector<uint64_t> v4((size_t)world * world, 0);  // send-count matrix: row = sender
+    for (int q = 0; q < world; ++q) v4[(size_t)rank * world + q] = h_cnt[q];
+    rc = allreduce_host(d, v4);
+    if (rc != BDX_OK) return rc;
+    std::vector<size_t> scount(world), sdispl(world), rcount(world), rdispl(world);
+    size_t nsend = 0, nrecv = 0;
+    for (int q = 0; q < world; ++q) {
+        scount[q] = (size_t)v4[(size_t)rank * world + q] * 3; sdispl[q] = nsend * 3; nsend += v4[(size_t)rank * world + q];
+        rcount[q] = (size_t)v4[(size_t)q * world + rank] * 3; rdispl[q] = nrecv * 3; nrecv += v4[(size_t)q * world + rank];
+    }
+    if (nrecv > kMaxRegions) return dfail(d, BDX_ELIMIT, "too many inter-chromosomal join records on one rank");
+    DHIP(d, d->b_send.ensure(std::max<size_t>(nsend, 1) * sizeof(ExchangeEntry)));
+    DHIP(d, d->b_recv.ensure(std::max<size_t>(nrecv, 1) * sizeof(ExchangeEntry)));
+    {
+        std::vector<uint32_t> cur(world);
+        for (int q = 0; q < world; ++q) cur[q] = (uint32_t)(sdispl[q] / 3);
+        DHIP(d, hipMemcpy(d_cur, cur.data(), (size_t)world * 4, hipMemcpyHostToDevice));
+    }
+    for (auto& kv : d->chrom) {
+        bdx_ctx* c = kv.second;
+        const uint32_t na = c->p1.n_anom;
+        if (!na) continue;
+        // the chromosome's own pairs: K4 on its compact reads, pair groups with genome-wide region ids
+        Entries en{};
+        en.key = c->cp.key; en.region = c->k3.region_of; en.meta = c->cp.meta; en.isize = c->cp.isize;
+        en.region_base = (int32_t)rbase[kv.first];
+        DCTX(d, c, do_join_local(c, na, en, &c->b_p1.as<Pass1>()->n_anom, false));
+        launch_k7_scatter(c->cp.key, c->k3.region_of, c->cp.meta, c->cp.isize, &c->b_p1.as<Pass1>()->n_anom, na, (uint32_t)world,
+                          (uint32_t)base[(size_t)kv.first * tw], (int32_t)rbase[kv.first], d_cur, d->b_send.as<ExchangeEntry>(), c->stream);
+    }
+    for (auto& kv : d->chrom) DHIP(d, hipStreamSynchronize(kv.second->stream));
+    // C4: the all-to-all of the CTX records (three 64-bit words each)
+    if (!comm.alltoallv_u64(d->b_send.as<uint64_t>(), scount.data(), sdispl.data(), d->b_recv.as<uint64_t>(), rcount.data(), rdispl.data(), us))
+        return dfail(d, BDX_EHIP, comm.err);
+    d->ctx_sent = nsend; d->ctx_received = nrecv;
+    // join what arrived
+    uint32_t ng_ctx = 0;
+    if (nrecv) {
+        const uint32_t n32 = (uint32_t)nrecv;
+        DHIP(d, U->b_x_key.ensure(nrecv * 8)); DHIP(d, U->b_x_order.ensure(nrecv * 4)); DHIP(d, U->b_x_region.ensure(nrecv * 4));
+        DHIP(d, U->b_x_meta.ensure(nrecv * 4)); DHIP(d, U->b_x_isize.ensure(nrecv * 4)); DHIP(d, U->b_x_n.ensure(16));
+        launch_k7_unpack(d->b_recv.as<ExchangeEntry>(), n32, U->b_x_key.as<uint64_t>(), U->b_x_order.as<uint32_t>(), U->b_x_region.as<int32_t>(),
+                         U->b_x_meta.as<uint32_t>(), U->b_x_isize.as<int32_t>(), us);
+        DHIP(d, hipMemcpyAsync(U->b_x_n.p, &n32, 4, hipMemcpyHostToDevice, us));
+        DHIP(d, hipMemsetAsync(U->b_counts.p, 0, sizeof(StageCounts), us));
+        Entries en{};
+        en.key = U->b_x_key.as<uint64_t>(); en.region = U->b_x_region.as<int32_t>(); en.order = U->b_x_order.as<uint32_t>();
+        en.meta = U->b_x_meta.as<uint32_t>(); en.isize = U->b_x_isize.as<int32_t>();
+        DCTX(d, U, do_join_local(U, n32, en, U->b_x_n.as<uint32_t>(), false));
+        DHIP(d, hipMemcpyAsync(U->h_counts.p, U->b_counts.p, sizeof(StageCounts), hipMemcpyDeviceToHost, us));
+        DHIP(d, hipStreamSynchronize(us));
+        const StageCounts sc = *U->h_counts.as<StageCounts>();
+        if (sc.irregular) return dfail(d, BDX_ELIMIT, "a read name occurs more than twice among the inter-chromosomal reads: run the chromosomes in one context");
+        if (sc.overflow) return dfail(d, BDX_EINTERNAL, "group list overflow");
+        ng_ctx = sc.n_groups;
+    }
+    const auto t_x1 = std::chrono::steady_clock::now();
+
+    // ---- C5: region tables and pair groups to rank 0 ----
+    // this rank's package: per owned chromosome (ascending) its region records and prefix samples, then all pair groups
+    size_t nreg_mine = 0, ng_mine = ng_ctx;
+    for (auto& kv : d->chrom) {
+        bdx_ctx* c = kv.second;
+        if (!c->p1.n_anom) continue;
+        DCTX(d, c, readback(c, true));
+        if (c->counts.irregular) return dfail(d, BDX_ELIMIT, "a read name occurs more than twice: run the chromosomes in one context");
+        nreg_mine += c->counts.n_regions;
+        ng_mine += c->counts.n_groups;
+    }
+    const size_t rrec = sizeof(RegionRec), rpk = (size_t)2 * nkeys * 4, grec = sizeof(GroupRec);
+    const size_t pack_bytes = round_up(nreg_mine * (rrec + rpk) + ng_mine * grec, 8);
+    DHIP(d, d->b_pack.ensure(std::max<size_t>(pack_bytes, 8)));
+    {
+        char* p = (char*)d->b_pack.p;
+        for (auto& kv : d->chrom) {  // records of all own chromosomes, then their prefix samples, then the groups
+            bdx_ctx* c = kv.second;
+            const size_t nr = c->p1.n_anom ? c->counts.n_regions : 0;
+            if (nr) DHIP(d, hipMemcpyAsync(p, c->b_r_rec.p, nr * rrec, hipMemcpyDeviceToDevice, us));
+            p += nr * rrec;
+        }
+        for (auto& kv : d->chrom) {
+            bdx_ctx* c = kv.second;
+            const size_t nr = c->p1.n_anom ? c->counts.n_regions : 0;
+            if (nr) DHIP(d, hipMemcpyAsync(p, c->b_r_pk.p, nr * rpk, hipMemcpyDeviceToDevice, us));
+            p += nr * rpk;
+        }
+        for (auto& kv : d->chrom) {
+            bdx_ctx* c = kv.second;
+            const size_t ng = c->p1.n_anom ? c->counts.n_groups : 0;
+            if (ng) DHIP(d, hipMemcpyAsync(p, c->k4.g_rec, ng * grec, hipMemcpyDefault, us));
+            p += ng * grec;
+        }
+        if (ng_ctx) DHIP(d, hipMemcpyAsync(p, U->k4.g_rec, (size_t)ng_ctx * grec, hipMemcpyDefault, us));
+    }
+    std::vector<uint64_t> v5((size_t)world * 3, 0);
+    v5[(size_t)rank * 3] = nreg_mine; v5[(size_t)rank * 3 + 1] = ng_mine; v5[(size_t)rank * 3 + 2] = pack_bytes;
+    rc = allreduce_host(d, v5);
+    if (rc != BDX_OK) return rc;
+    std::vector<size_t> gcount(world), gdispl(world);
+    size_t all_bytes = 0, ng_all = 0;
+    for (int q = 0; q < world; ++q) { gcount[q] = (size_t)v5[(size_t)q * 3 + 2]; gdispl[q] = all_bytes; all_bytes += gcount[q]; ng_all += v5[(size_t)q * 3 + 1]; }
+    if (rank == 0) DHIP(d, d->b_all.ensure(std::max<size_t>(all_bytes, 8)));
+    if (!comm.gatherv_bytes(d->b_pack.p, pack_bytes, d->b_all.p, gcount.data(), gdispl.data(), 0, us)) return dfail(d, BDX_EHIP, comm.err);
+    DHIP(d, hipStreamSynchronize(us));
+    d->gathered_bytes = all_bytes;
+    d->ms_exchange = ms_between(t_x0, t_x1);
+
+    if (rank == 0) {
+        // which rank owns which chromosome follows from the packages themselves: every region record carries its tid
+        std::vector<char> host(all_bytes);
+        if (all_bytes) DHIP(d, hipMemcpy(host.data(), d->b_all.p, all_bytes, hipMemcpyDeviceToHost));
+        std::vector<RegionRec> regs(NR);
+        std::vector<uint32_t> pk((size_t)NR * 2 * nkeys);
+        std::vector<GroupRec> groups(ng_all);
+        std::vector<uint64_t> fill(ntids, 0);
+        size_t gi = 0;
+        for (int q = 0; q < world; ++q) {
+            const size_t nr = (size_t)v5[(size_t)q * 3], ng = (size_t)v5[(size_t)q * 3 + 1];
+            const RegionRec* rr = (const RegionRec*)(host.data() + gdispl[q]);
+            const uint32_t* rp = (const uint32_t*)(host.data() + gdispl[q] + nr * rrec);
+            const GroupRec* rg = (const GroupRec*)(host.data() + gdispl[q] + nr * (rrec + rpk));
+            for (size_t i = 0; i < nr; ++i) {
+                const int t = rr[i].tid;
+                if (t < 0 || t >= ntids || fill[t] >= v3[(size_t)t * 2]) return dfail(d, BDX_EINTERNAL, "region table of the gather does not add up");
+                const size_t g = (size_t)rbase[t] + fill[t]++;
+                regs[g] = rr[i];
+                memcpy(&pk[g * 2 * nkeys], rp + i * 2 * nkeys, rpk);
+            }
+            if (ng) memcpy(&groups[gi], rg, ng * grec);
+            gi += ng;
+        }
+        for (int t = 0; t < ntids; ++t)
+            if (fill[t] != v3[(size_t)t * 2]) return dfail(d, BDX_EINTERNAL, "region table of the gather does not add up");
+        DCTX(d, U, set_pass1(U, cnt_g.data(), covered, window, true));
+        decode_regions(U, regs.data(), pk.data(), (uint32_t)NR, 0, false);
+        decode_groups(U, groups.data(), (uint32_t)ng_all, 0);
+        U->counts.n_regions = (uint32_t)NR;
+        U->n = 0;
+        const int32_t lm = last_anom_tid >= 0 ? (int32_t)(uint32_t)v3[(size_t)last_anom_tid * 2 + 1] : 0;
+        DCTX(d, U, host_walk(U, lm, last_anom_tid >= 0));
+        DCTX(d, U, score_host_terms(U));
+        DCTX(d, U, finish_host_walk(U));
+        U->p1.n_anom = (uint32_t)base[(size_t)ntids * tw];
+    } else {
+        DCTX(d, U, set_pass1(U, cnt_g.data(), covered, window, true));
+    }
+    d->ran = true;
+    d->ms_total = ms_between(t_begin, std::chrono::steady_clock::now());
+    return BDX_OK;
+}
+
+}  // extern "C"

@@ -130,6 +130,7 @@ struct Entries {
     const uint32_t* order;   // position in the merged stream order; nullptr = the entry index itself
     const uint32_t* meta;    // flag | rev<<4 | lib<<8 | qlen<<16
     const int32_t* isize;    // |isize|
+    int32_t region_base;     // added to both region ids of a pair group (a chromosome's local ids -> genome-wide ids)
     // single-context runs with the direct join: the join kernel derives the region itself (region = c_rid[cand[j]]),
     // stores it into region_out and resets K6's per-region scratch -- k3_region_of_kernel's work without its launch
     const int32_t* cand;
@@ -150,6 +151,30 @@ struct Entries {
 };
 
 void launch_k4(const K4Arrays& k4, const Entries& e, const uint32_t* n_ptr, uint32_t n_upper, StageCounts* counts, hipStream_t s);
+
+// ---- K7: exchange of inter-chromosomal mate records between the GPUs of a chromosome-sharded run ------------------
+constexpr int kMaxRanks = 64;
+struct ExchangeEntry {  // one CTX read on its way to the rank that joins its name
+    uint64_t key;
+    uint32_t order;     // position among the anomalous reads of the whole genome (stream order: decides the second-observed mate)
+    int32_t region;     // global region id, -1: the read sits in a rejected candidate region
+    uint32_t meta;
+    int32_t isize;
+};
+static_assert(sizeof(ExchangeEntry) == 24, "exchange entries travel as three 64-bit words");
+// the rank that joins a name key: a mixed hash, so that the two mates of a pair (same key) meet on one rank
+__host__ __device__ __forceinline__ uint32_t exchange_owner(uint64_t k, uint32_t world) {
+    k = (k ^ (k >> 33)) * 0xff51afd7ed558ccdull;
+    k ^= k >> 29;
+    return (uint32_t)(k % world);
+}
+void launch_k7_count(const uint64_t* key, const uint32_t* meta, const uint32_t* n_ptr, uint32_t n_upper, uint32_t world, uint32_t* cnt,
+                     hipStream_t s);
+void launch_k7_scatter(const uint64_t* key, const int32_t* region_of, const uint32_t* meta, const int32_t* isize, const uint32_t* n_ptr,
+                       uint32_t n_upper, uint32_t world, uint32_t order_base, int32_t region_base, uint32_t* cursor, ExchangeEntry* out,
+                       hipStream_t s);
+void launch_k7_unpack(const ExchangeEntry* in, uint32_t n, uint64_t* key, uint32_t* order, int32_t* region, uint32_t* meta, int32_t* isize,
+                      hipStream_t s);
 
 void launch_k4_join_only(const K4Arrays& k4, const Entries& e, const uint32_t* n_ptr, uint32_t n_upper, StageCounts* counts, hipStream_t s);
 

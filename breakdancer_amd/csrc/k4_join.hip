@@ -249,7 +249,8 @@ __global__ __launch_bounds__(256) void k4_aggregate_kernel(K4Arrays k4, Entries 
         if (op >= oj) continue;
         const int rp = en.region[p];
         const uint32_t m = en.meta[j];
-        const uint64_t gk = group_pack((uint32_t)rp, (uint32_t)rj, (uint32_t)meta_lib(m), (uint32_t)meta_flag(m));
+        const uint64_t gk = group_pack((uint32_t)(rp + en.region_base), (uint32_t)(rj + en.region_base), (uint32_t)meta_lib(m),
+                                       (uint32_t)meta_flag(m));
         uint32_t s = (uint32_t)(mix64(gk) & (kAggSlots - 1));
         while (true) {
             const unsigned long long old = atomicCAS(&s_key[s], (unsigned long long)kEmptyGroup, (unsigned long long)gk);

@@ -6,11 +6,13 @@ The path shards by chromosome: regions never span tids (breakdancer/BreakDancer.
   (README:31,73; pass 1 is restricted to the chromosome as well, io/BamSummary.cpp:136).  Chromosomes are
   independent units: no data-path collective, rank 0 only gathers the SV rows.
 * `ShardedRun`          -- one whole-genome run (what a single `breakdancer-max cfg` prints, incl. `-t`), with the
-  chromosomes spread over ranks.  Needs three small exchanges: an all-reduce of the pass-1 counters (window, lambda and
-  densities are global), an all-gather of per-chromosome totals (bases of the prefix counters / region ids / stream
-  order), and ONE all-to-all of the join entries {name key, stream order, region, meta, |isize|} to owner(hash(key)) so
-  that inter-chromosomal mates meet -- the only real exchange step of the path.  Regions and pair groups are then
-  gathered to rank 0 for the (inherently sequential) walk.  All payloads are KBs..MBs: latency-bound, one hop each.
+  chromosomes spread over ranks: a thin front end of the native path (dist.py, csrc/bdx_dist_impl.h), where the
+  orchestration and every exchange live -- all-reduces of the pass-1 statistics and per-chromosome totals, ONE
+  all-to-all over RCCL of the inter-chromosomal (CTX) join records to owner(hash(key)), a gather of region tables and
+  pair groups on rank 0 for the (inherently ordered) walk.
+
+The numpy helpers below (owner_of, plan_chromosomes, covered_from, prefix_bases, TorchComm) restate the routing and
+bookkeeping rules of the native path so that they can be exercised without a GPU (tests/test_distributed.py).
 """
 import ctypes as C
 
@@ -134,172 +136,51 @@ def prefix_bases(per_tid_totals):
     return bases
 
 
-class _Ctx(BreakDancer):
-    """BreakDancer plus the staged entry points"""
-
-    def stage_pass1(self):
-        self._chk(self.lib.bdx_stage_pass1(self.h), "bdx_stage_pass1")
-        nkeys = self.nlibs if self.opts.CN_lib else self.nbams
-        cnt = np.zeros(self.nlibs * 12 + self.nbams, np.uint32)
-        ref = np.zeros(self.nbams, np.uint64)
-        tot = np.zeros(2 + nkeys, np.uint32)
-        p = lambda a: a.ctypes.data_as(C.c_void_p)
-        self._chk(self.lib.bdx_get_pass1_local(self.h, p(cnt), p(ref), p(tot)), "bdx_get_pass1_local")
-        return cnt, ref, tot
-
-    def set_global(self, cnt, covered, window=-1):
-        cnt = np.ascontiguousarray(cnt, np.uint32)
-        self._chk(self.lib.bdx_set_pass1_global(self.h, cnt.ctypes.data_as(C.c_void_p), int(covered), int(window)), "bdx_set_pass1_global")
-
-    def stage_compact(self, nn_base, pk_base):
-        pk = np.ascontiguousarray(pk_base, np.uint32)
-        q, nn = C.c_int32(), C.c_uint32()
-        self._chk(self.lib.bdx_stage_compact(self.h, int(nn_base), pk.ctypes.data_as(C.c_void_p), C.byref(q), C.byref(nn)),
-                  "bdx_stage_compact")
-        return q.value, nn.value
-
-    def stage_regions(self, has_next, next_qlen, next_nn):
-        self._chk(self.lib.bdx_stage_regions(self.h, int(has_next), int(next_qlen), int(next_nn)), "bdx_stage_regions")
-        nr, na, lm = C.c_uint32(), C.c_uint32(), C.c_int32()
-        self._chk(self.lib.bdx_get_stage_regions(self.h, C.byref(nr), C.byref(na), C.byref(lm)), "bdx_get_stage_regions")
-        return nr.value, na.value, lm.value
-
-    def region_records(self, nr):
-        nkeys = self.nlibs if self.opts.CN_lib else self.nbams
-        recs = np.zeros(nr, L.REGION_REC_DTYPE)
-        pk = np.zeros((nr, 2 * nkeys), np.uint32)
-        p = lambda a: a.ctypes.data_as(C.c_void_p)
-        self._chk(self.lib.bdx_get_region_records(self.h, p(recs), p(pk), nr), "bdx_get_region_records")
-        return recs, pk
-
-    def compact(self, na):
-        key, region = np.zeros(na, np.uint64), np.zeros(na, np.int32)
-        meta, isize = np.zeros(na, np.uint32), np.zeros(na, np.int32)
-        p = lambda a: a.ctypes.data_as(C.c_void_p)
-        self._chk(self.lib.bdx_get_compact(self.h, p(key), p(region), p(meta), p(isize), na), "bdx_get_compact")
-        return key, region, meta, isize
-
-    def join(self, ent):
-        n = len(ent)
-        out = np.zeros(n // 2 + 1, L.GROUP_DTYPE)
-        ng, npairs = C.c_uint32(), C.c_uint32()
-        cols = [np.ascontiguousarray(ent[k]) for k in ("key", "order", "region", "meta", "isize")]
-        p = lambda a: a.ctypes.data_as(C.c_void_p)
-        self._chk(self.lib.bdx_join_entries(self.h, n, *[p(c) for c in cols], p(out), len(out), C.byref(ng), C.byref(npairs)),
-                  "bdx_join_entries")
-        return out[:ng.value], npairs.value
-
-    def walk(self, recs, pk, groups, last_maxq, any_anom):
-        recs = np.ascontiguousarray(recs, L.REGION_REC_DTYPE)
-        pk = np.ascontiguousarray(pk, np.uint32)
-        groups = np.ascontiguousarray(groups, L.GROUP_DTYPE)
-        p = lambda a: a.ctypes.data_as(C.c_void_p)
-        self._chk(self.lib.bdx_stage_walk(self.h, len(recs), p(recs), p(pk), len(groups), p(groups), int(last_maxq), int(any_anom)),
-                  "bdx_stage_walk")
-
-
 class ShardedRun:
-    """Whole-genome-equivalent run with chromosomes spread over ranks (see module docstring)."""
+    """Whole-genome-equivalent run with the chromosomes spread over ranks, on the native path (dist.py -> bdx_dist_*).
 
-    def __init__(self, opts, libs, nbams, max_read_window_size, comm=None, device=0):
+    comm=None: the ranks are threads of this process -- `world` of them, all on `device` (what the single-GPU tests use to
+    run the whole multi-rank orchestration, including the CTX all-to-all); chromosomes are dealt to the ranks by
+    longest-processing-time packing.  comm=TorchComm: one process per GPU over RCCL; add_chromosome only for the tids this
+    rank owns (plan_chromosomes)."""
+
+    def __init__(self, opts, libs, nbams, max_read_window_size, comm=None, device=0, ntids=None, world=1):
+        from . import dist as D
         if opts.min_len < 0:
             raise BdxError("staged runs do not support a negative -s")
         self.opts, self.libs, self.nbams, self.w0 = opts, list(libs), nbams, max_read_window_size
-        self.comm = comm or LocalComm()
-        self.device = device
-        self.ctx = {}
-        self.util = _Ctx(opts, libs, nbams, 0, max_read_window_size, device)  # joins / walks; owns no reads
+        self.comm, self.device, self.ntids, self.world = comm, device, ntids, (comm.world if comm else world)
+        self.D = D
+        self.pending = {}
 
     def add_chromosome(self, tid, arrs):
-        c = _Ctx(self.opts, self.libs, self.nbams, 0, self.w0, self.device)
-        if len(arrs["tid"]):
-            c.push_reads(arrs)
-        self.ctx[int(tid)] = c
+        self.pending[int(tid)] = arrs
 
     def run(self):
-        comm, util = self.comm, self.util
-        nkeys = len(self.libs) if self.opts.CN_lib else self.nbams
-        ncnt = len(self.libs) * 12 + self.nbams
-        # (1) pass 1 per chromosome, (C1) all-reduce of the counters, (C2) all-gather of per-chromosome totals
-        cnt_sum, ref_sum, totals = np.zeros(ncnt, np.uint64), np.zeros(self.nbams, np.uint64), {}
-        for tid in sorted(self.ctx):
-            cnt, ref, tot = self.ctx[tid].stage_pass1()
-            cnt_sum += cnt
-            ref_sum += ref
-            totals[tid] = tot.astype(np.int64)
-        util.stage_pass1()
-        red = comm.allreduce_sum(np.concatenate([cnt_sum, ref_sum]))
-        cnt_g, ref_g = red[:ncnt].astype(np.uint32), red[ncnt:]
-        covered = covered_from(ref_g)
-        all_tot = {}
-        for d in comm.allgather_obj(totals):
-            all_tot.update(d)
-        bases = prefix_bases(all_tot)
-        # (2) compaction per chromosome with the bases of the preceding chromosomes; the first anomalous read of a
-        #     chromosome closes the last candidate region of the previous one, so that read is all-gathered too
-        firsts = {}
-        for tid in sorted(self.ctx):
-            c = self.ctx[tid]
-            c.set_global(cnt_g, covered)
-            b = bases[tid]
-            firsts[tid] = c.stage_compact(b[1], b[2:])
-        all_first = {}
-        for d in comm.allgather_obj(firsts):
-            all_first.update(d)
-        anom_tids = [t for t in sorted(all_tot) if all_tot[t][0] > 0]
-        nxt = {t: anom_tids[i + 1] for i, t in enumerate(anom_tids[:-1])}
-        # (3) regions per chromosome with the global window
-        nreg, last_maxq = {}, {}
-        for tid in sorted(self.ctx):
-            c = self.ctx[tid]
-            if tid in nxt:
-                q, nn = all_first[nxt[tid]]
-                nr, na, lm = c.stage_regions(1, q, nn)
-            else:
-                nr, na, lm = c.stage_regions(0, 0, 0)
-            nreg[tid] = nr
-            last_maxq[tid] = lm
-        util.set_global(cnt_g, covered)
-        all_nreg, all_lm = {}, {}
-        for d, e in comm.allgather_obj((nreg, last_maxq)):
-            all_nreg.update(d)
-            all_lm.update(e)
-        rbase = prefix_bases({t: [n] for t, n in all_nreg.items()})
-        # (4) join entries -> owner(hash(key)): the one real exchange step (C3)
-        ents, reg_out = [], {}
-        for tid in sorted(self.ctx):
-            c = self.ctx[tid]
-            na = int(all_tot[tid][0])
-            key, region, meta, isize = c.compact(na)
-            m = region >= 0
-            e = np.zeros(int(m.sum()), ENTRY_DTYPE)
-            e["key"], e["meta"], e["isize"] = key[m], meta[m], isize[m]
-            e["region"] = region[m] + int(rbase[tid][0])
-            e["order"] = (np.arange(na, dtype=np.int64)[m] + int(bases[tid][0])).astype(np.uint32)
-            ents.append(e)
-            reg_out[tid] = c.region_records(nreg[tid])
-        mine = np.concatenate(ents) if ents else np.zeros(0, ENTRY_DTYPE)
-        recv = comm.alltoall_bytes(route_entries(mine, comm.world))
-        got = np.concatenate([np.frombuffer(r.tobytes(), ENTRY_DTYPE) for r in recv]) if recv else np.zeros(0, ENTRY_DTYPE)
-        groups, npairs = util.join(got)
-        # (5) regions + groups to rank 0, walk there
-        gathered = comm.gather_obj((reg_out, groups, npairs), root=0)
-        if comm.rank != 0:
-            return None
-        regs, allg, pairs = {}, [], 0
-        for ro, g, npr in gathered:
-            regs.update(ro)
-            allg.append(g)
-            pairs += npr
-        tids = sorted(regs)
-        recs = np.concatenate([regs[t][0] for t in tids]) if tids else np.zeros(0, L.REGION_REC_DTYPE)
-        pk = np.concatenate([regs[t][1] for t in tids]) if tids else np.zeros((0, 2 * nkeys), np.uint32)
-        allg = np.concatenate(allg) if allg else np.zeros(0, L.GROUP_DTYPE)
-        with_anom = [t for t in sorted(all_tot) if all_tot[t][0] > 0]
-        lm = all_lm[with_anom[-1]] if with_anom else 0
-        util.walk(recs, pk, allg, lm, bool(with_anom))
-        self.n_pairs = pairs
-        return util
+        D = self.D
+        ntids = self.ntids if self.ntids is not None else (max(self.pending) + 1 if self.pending else 1)
+        if self.comm is not None and self.comm.world > 1:
+            ntids = max(self.comm.allgather_obj(ntids))
+            d = D.DistRun.from_process_group(self.opts, self.libs, self.nbams, ntids, self.w0, self.device)
+            for tid, arrs in sorted(self.pending.items()):
+                c = d.chromosome(tid)
+                if len(arrs["tid"]):
+                    c.push_reads(arrs)
+            d.run()
+            self.exchange = d.exchange()
+            self._ranks = [d]
+            return d.result()
+        ranks = D.DistRun.threads(self.opts, self.libs, self.nbams, ntids, self.w0, [self.device] * self.world)
+        counts = {t: len(a["tid"]) for t, a in self.pending.items()}
+        for r, tids in enumerate(plan_chromosomes(counts, self.world)):
+            for tid in tids:
+                c = ranks[r].chromosome(tid)
+                if len(self.pending[tid]["tid"]):
+                    c.push_reads(self.pending[tid])
+        res = D.run_threads(ranks)
+        self.exchange = [r.exchange() for r in ranks]
+        self._ranks = ranks  # (the result lives in rank 0's context: keep the ranks alive with it)
+        return res
 
 
 def run_per_chromosome(opts, libs, nbams, max_read_window_size, chromosomes, comm=None, device=0, runner=None):

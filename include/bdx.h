@@ -278,6 +278,50 @@ int bdx_join_entries(bdx_ctx* ctx, size_t n, const uint64_t* key, const uint32_t
 int bdx_stage_walk(bdx_ctx* ctx, size_t nregions, const bdx_region_rec* regions, const uint32_t* pk, size_t ngroups,
                    const bdx_group* groups, int32_t last_maxq, int any_anomalous);
 
+/* ---- chromosome-sharded runs on several GPUs: ONE whole-genome result (what a single `breakdancer-max cfg` run prints,
+ * -t included) with the chromosomes spread over ranks, one rank per GPU.  Regions never span chromosomes
+ * (breakdancer/BreakDancer.cpp:216), so every rank runs classify / compact / region cut / mate join on its own chromosomes;
+ * the ranks exchange the global pass-1 statistics and per-chromosome totals (all-reduces of a few KB), the inter-chromosomal
+ * (ARP_CTX) join records in ONE all-to-all to owner(name key) -- pairs with both mates on one chromosome never leave their
+ * GPU --, and finally gather region tables and pair groups on rank 0, which walks the region graph and holds the result.
+ * The collectives run on device buffers over RCCL (xGMI inside a node).
+ *
+ *   bdx_dist_unique_id       rank 0 obtains the communicator id (ncclGetUniqueId); the caller hands the 128 bytes to every
+ *                            rank by whatever means it has (torch.distributed, MPI, a file)
+ *   bdx_dist_create          one per process: joins the communicator (ncclCommInitRank) -- collective
+ *   bdx_dist_create_threads  the same ranks as threads of ONE process (out[world], one per device in `devices`, which may
+ *                            repeat a device); every out[r] is then driven by its own thread.  Collectives are
+ *                            device-to-device copies around a barrier
+ *   bdx_dist_chromosome      the context of a chromosome this rank owns (created on first use): feed it with bdx_push /
+ *                            bdx_acquire_batch as usual, do NOT call bdx_run on it.  ntids = number of reference sequences;
+ *                            every chromosome that has reads must be owned by exactly one rank
+ *   bdx_dist_run             collective: all ranks call it once their chromosomes are loaded
+ *   bdx_dist_result          rank 0 after bdx_dist_run: a context whose getters (bdx_get_summary, bdx_get_counters,
+ *                            bdx_get_regions, bdx_get_svs, bdx_get_sv_lists) return the whole-genome result; NULL on other ranks
+ *   bdx_dist_owner           the rank that joins a name key (the routing rule of the all-to-all)
+ *   bdx_dist_plan            chromosomes -> ranks by longest-processing-time packing on `weight` (reads or length)
+ * Not supported in sharded runs: a negative -s, the -g/-d support lists, read names that occur more than twice. */
+typedef struct bdx_dist bdx_dist;
+typedef struct bdx_unique_id { char internal[128]; } bdx_unique_id;
+int bdx_dist_unique_id(bdx_unique_id* out);
+int bdx_dist_create(bdx_dist** out, const bdx_opts* opts, const bdx_lib* libs, int nlibs, int nbams, int ntids,
+                    int max_read_window_size0, int device, int rank, int world, const bdx_unique_id* id);
+int bdx_dist_create_threads(bdx_dist** out, const bdx_opts* opts, const bdx_lib* libs, int nlibs, int nbams, int ntids,
+                            int max_read_window_size0, const int* devices, int world);
+void bdx_dist_destroy(bdx_dist* d);
+const char* bdx_dist_last_error(const bdx_dist* d);
+int bdx_dist_rank(const bdx_dist* d);
+int bdx_dist_world(const bdx_dist* d);
+bdx_ctx* bdx_dist_chromosome(bdx_dist* d, int tid);
+int bdx_dist_run(bdx_dist* d);
+bdx_ctx* bdx_dist_result(bdx_dist* d);
+/* after bdx_dist_run: CTX join records this rank sent / received in the all-to-all, bytes gathered on rank 0, wall time
+ * of the whole run and of the exchange + CTX join (ms).  Any pointer may be NULL. */
+int bdx_dist_get_exchange(const bdx_dist* d, uint64_t* ctx_records_sent, uint64_t* ctx_records_received, uint64_t* gathered_bytes,
+                          float* ms_total, float* ms_exchange);
+int bdx_dist_owner(uint64_t name_key, int world);
+int bdx_dist_plan(const uint64_t* weight, int ntids, int world, int* rank_of_tid);
+
 /* device the context is bound to and the HIP stream it launches on (as void*), for callers that time it */
 int bdx_device(const bdx_ctx* ctx);
 void* bdx_stream(const bdx_ctx* ctx);

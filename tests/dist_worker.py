@@ -4,8 +4,7 @@ mode "comm" (CPU, gloo): exercises breakdancer_amd.shard's collectives -- planni
 all-gather, the all-to-all routing of join entries, the gather to rank 0 -- with a numpy stand-in for the join so that
 the result can be checked against a single-process computation.  No GPU, no libbdx compute calls.
 
-mode "gpu" (GPU box; gloo for the control plane, every rank computes on cuda:0): the real staged path with two
-processes; rank 0 compares the result with the CPU oracle's single whole-genome run."""
+(The native multi-rank run needs GPUs: tests/test_gpu_sharded.py drives it with the ranks as threads on one device.)"""
 import json
 import os
 import sys
@@ -101,35 +100,5 @@ def mode_comm(out_path):
     dist.destroy_process_group()
 
 
-def mode_gpu(out_path):
-    import torch.distributed as dist
-    from breakdancer_amd import shard
-    from breakdancer_amd.api import LibraryConfig
-    from fuzzgen import make_case
-    from helpers import make_opts
-    from runner import compare, oracle_case, product_options, split_by_tid
-    dist.init_process_group("gloo")
-    comm = shard.TorchComm()
-    results = []
-    for seed, o in ((301, dict()), (302, dict(transchr_rearrange=1, min_read_pair=1)), (303, dict(cn_lib=1, buffer_size=2))):
-        cfg, streams, targets = make_case(seed)
-        run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1, **o))
-        chroms = split_by_tid(run.merged_soa())
-        plan = shard.plan_chromosomes({t: len(a["tid"]) for t, a in chroms.items()}, comm.world)
-        libs = [LibraryConfig(*[float(x) for x in run.lib_f[i]], min_mapping_quality=int(run.lib_i[i, 0]),
-                              bam_file_index=int(run.lib_i[i, 1])) for i in range(run.nlibs)]
-        sr = shard.ShardedRun(product_options(run.opts), libs, run.nbams, run.w0, comm=comm, device=0)
-        for t in plan[comm.rank]:
-            sr.add_chromosome(t, chroms[t])
-        util = sr.run()
-        if comm.rank == 0:
-            compare(run, util, check_cls=False)
-            results.append(dict(seed=seed, n_svs=run.n_svs, chromosomes_per_rank=[len(b) for b in plan]))
-    if comm.rank == 0:
-        json.dump({"ok": True, "world": comm.world, "cases": results}, open(out_path, "w"))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
 if __name__ == "__main__":
-    {"comm": mode_comm, "gpu": mode_gpu}[sys.argv[1]](sys.argv[2])
+    {"comm": mode_comm}[sys.argv[1]](sys.argv[2])

@@ -107,15 +107,21 @@ def split_by_tid(soa):
     return out
 
 
-def sharded_from_oracle(run, comm=None, device=0):
-    """the same whole-genome input through the staged multi-context path (one context per chromosome)"""
+def sharded_from_oracle(run, comm=None, device=0, world=1, keep=None):
+    """the same whole-genome input through the chromosome-sharded path: one context per chromosome, the chromosomes dealt
+    to `world` ranks (threads of this process on one GPU when comm is None)"""
     from breakdancer_amd.shard import ShardedRun
     libs = [LibraryConfig(*[float(x) for x in run.lib_f[i]], min_mapping_quality=int(run.lib_i[i, 0]),
                           bam_file_index=int(run.lib_i[i, 1]), name=run.lib_names[i]) for i in range(run.nlibs)]
-    sr = ShardedRun(product_options(run.opts), libs, run.nbams, run.w0, comm=comm, device=device)
+    sr = ShardedRun(product_options(run.opts), libs, run.nbams, run.w0, comm=comm, device=device, world=world,
+                    ntids=len(getattr(run, "targets", [])) or None)
     for tid, arrs in split_by_tid(run.merged_soa()).items():
         sr.add_chromosome(tid, arrs)
-    return sr.run()
+    res = sr.run()
+    res._sharded_run = sr  # the result is a view into rank 0's context
+    if keep is not None:
+        keep.append(sr)
+    return res
 
 
 def compare_support(run, bd):

@@ -1,5 +1,7 @@
-"""GPU tests of the chromosome-sharded paths (breakdancer_amd/shard.py) on one GPU: one context per chromosome,
-LocalComm (world of one).  The staged whole-genome run must equal ONE oracle run over all chromosomes -- including the
+"""GPU tests of the chromosome-sharded path (include/bdx.h bdx_dist_*, csrc/bdx_dist_impl.h) on one GPU: one context
+per chromosome, the chromosomes dealt to 1, 2 or 3 ranks that run as threads of this process and go through every
+exchange of the multi-GPU run (all-reduces, the CTX all-to-all, the gather on rank 0); plus the RCCL backend itself with a
+communicator of one rank.  The sharded whole-genome run must equal ONE oracle run over all chromosomes -- including the
 cross-chromosome effects (global window / lambda, prefix counters, the closing read of the next chromosome, CTX mates)."""
 import numpy as np
 import pytest
@@ -18,17 +20,56 @@ WG_OPTS = [dict(), dict(transchr_rearrange=1), dict(cn_lib=1, print_af=1), dict(
 @pytest.mark.parametrize("seed", range(24))
 def test_staged_whole_genome_equals_single_run(seed):
     cfg, streams, targets = make_case(100 + seed)
-    for o in (WG_OPTS[seed % len(WG_OPTS)], WG_OPTS[(seed * 5 + 2) % len(WG_OPTS)]):
+    for i, o in enumerate((WG_OPTS[seed % len(WG_OPTS)], WG_OPTS[(seed * 5 + 2) % len(WG_OPTS)])):
         run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1, **o))
-        util = sharded_from_oracle(run)
+        util = sharded_from_oracle(run, world=1 + (seed + i) % 3)
         compare(run, util, check_cls=False)
 
 
 def test_staged_chr21_all_sequences():
     run = load_chr21(make_opts()).run()
-    util = sharded_from_oracle(run)
-    s = compare(run, util, check_cls=False)
-    assert s["n_svs_printed"] == 4
+    for world in (1, 2):
+        util = sharded_from_oracle(run, world=world)
+        s = compare(run, util, check_cls=False)
+        assert s["n_svs_printed"] == 4
+
+
+def test_only_inter_chromosomal_records_cross_ranks():
+    """-t on translocation-rich input over 3 ranks: every CTX read travels once (to the owner of its name), nothing else does"""
+    from test_gpu_configs import cfg_line, oracle_from_soa
+    from breakdancer_amd.synth import make_genome
+    d = make_genome([2_000_000, 1_500_000, 1_500_000, 1_000_000], coverage=15.0, seed=5, n_translocations=200)
+    cfg = cfg_line("rg0", "wgs.bam", "lib0", 400.0, 30.0)
+    for kw in (dict(transchr_rearrange=1), dict()):
+        run = oracle_from_soa(d, cfg, ["wgs.bam"], make_opts(**kw), ["c1", "c2", "c3", "c4"])
+        keep = []
+        util = sharded_from_oracle(run, world=3, keep=keep)
+        compare(run, util, check_cls=False)
+        ex = keep[0].exchange
+        n_ctx = int((((util.read_class() if False else run.cls) & 0x1F) == (0x10 | 8)).sum())  # passing reads classified ARP_CTX
+        assert sum(e["ctx_records_sent"] for e in ex) == n_ctx == sum(e["ctx_records_received"] for e in ex)
+        assert n_ctx > 5000 and min(e["ctx_records_received"] for e in ex) > n_ctx // 6   # spread over the owners
+        assert n_ctx < 0.01 * run.n_merged or kw                                            # ... a sliver of the reads
+
+
+def test_rccl_backend_with_a_communicator_of_one():
+    """the RCCL code path itself (ncclCommInitRank, ncclAllReduce, ncclAllToAllv, grouped send / receive) on the one GPU at hand"""
+    from breakdancer_amd import dist as D
+    from breakdancer_amd.api import LibraryConfig
+    cfg, streams, targets = make_case(131)
+    run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1, transchr_rearrange=1, min_read_pair=1))
+    libs = [LibraryConfig(*[float(x) for x in run.lib_f[i]], min_mapping_quality=int(run.lib_i[i, 0]),
+                          bam_file_index=int(run.lib_i[i, 1]), name=run.lib_names[i]) for i in range(run.nlibs)]
+    uid = D.unique_id()
+    assert len(uid) == 128
+    d = D.DistRun.create(product_options(run.opts), libs, run.nbams, len(targets), run.w0, 0, 0, 1, uid)
+    for tid, arrs in split_by_tid(run.merged_soa()).items():
+        d.chromosome(tid).push_reads(arrs)
+    d.run()
+    compare(run, d.result(), check_cls=False)
+    ex = d.exchange()
+    assert ex["ctx_records_sent"] == ex["ctx_records_received"] > 0
+    d.close()
 
 
 @pytest.mark.parametrize("seed", range(6))
