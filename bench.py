@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--dry", action="store_true", help="rendezvous only (no GPU work): prints the world the ranks see")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip timings (ii) and (iii)")
+    ap.add_argument("--no-exchange", action="store_true", help="N > 1: skip the untimed whole-genome -t run over all ranks")
     ap.add_argument("--cpu-parallel", type=int, default=-1,
                     help="processes of the README's one-process-per-chromosome mode in cpu_baseline (default: min(usable CPUs, 24), "
                          "bounded by free memory; 0 = skip)")
@@ -72,6 +73,12 @@ def parse():
 # ---------------------------------------------------------------------------------------------------------------------
 # launch: --gpus N always means N ranks
 # ---------------------------------------------------------------------------------------------------------------------
+# Test hook (tests/test_gpu_bench.py): BDX_BENCH_TEST_SHARED_GPU=1 lets all ranks of an N > 1 run share device 0, with gloo
+# as the process group (RCCL refuses two ranks on one device), so that the N > 1 control flow can be exercised on a
+# one-GPU box.  Never set by the driver; the JSON line says so under config.test_hook.
+SHARED_GPU_TEST = os.environ.get("BDX_BENCH_TEST_SHARED_GPU") == "1"
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -92,7 +99,7 @@ def ensure_world(a):
         return int(os.environ.get("RANK", "0")), world, int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus == 1:
         return 0, 1, 0
-    if not a.dry:
+    if not a.dry and not SHARED_GPU_TEST:
         import torch
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
         if have < a.gpus:
@@ -110,7 +117,7 @@ def init_group(a, world, local):
     if world == 1:
         return None
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if a.dry and not torch.cuda.is_available():
+    if SHARED_GPU_TEST or (a.dry and not torch.cuda.is_available()):
         dist.init_process_group("gloo")
     else:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -252,11 +259,54 @@ def time_bam_cli(bam, cfg, n):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# N > 1: one whole-genome run with -t over all ranks -- the path's one real exchange step (untimed extra)
+# ---------------------------------------------------------------------------------------------------------------------
+EXCHANGE_CHROM_LEN = 5_000_000
+EXCHANGE_TRANSLOCATIONS_PER_RANK = 250
+
+
+def whole_genome_exchange(rank, world, local, dist, out):
+    """configs[3] in miniature over the N GPUs of this run: every rank owns one 5 Mbp chromosome of a genome with planted
+    translocations between all of them; `-t` keeps only inter-chromosomal pairs, whose join records cross ranks in ONE
+    all-to-all over RCCL (bdx_dist_run, csrc/bdx_dist_impl.h).  Fills `out` on rank 0."""
+    import torch
+    from breakdancer_amd import dist as D
+    from breakdancer_amd.api import LibraryConfig, Options
+    from breakdancer_amd.synth import LIB_C2, make_genome
+    ntr = EXCHANGE_TRANSLOCATIONS_PER_RANK * world
+    d = make_genome([EXCHANGE_CHROM_LEN] * world, coverage=30.0, seed=77, n_translocations=ntr, only_tids={rank})
+    run = D.DistRun.from_process_group(Options(transchr_rearrange=True), [LibraryConfig(**LIB_C2)], 1, world, 200, local)
+    run.chromosome(rank).push_reads(d)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    run.run()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    ex = run.exchange()
+    stats = torch.tensor([ex["ctx_records_sent"], ex["ctx_records_received"], len(d["tid"])], dtype=torch.int64,
+                         device=torch.device("cpu") if SHARED_GPU_TEST else torch.device("cuda", local))
+    dist.all_reduce(stats)
+    if rank == 0:
+        s = run.result().summary()
+        out.update({"ranks": world, "backend": "RCCL (ncclAllReduce, ncclAllToAllv, grouped ncclSend/ncclRecv on device buffers)",
+                    "workload": "one genome, %d chromosomes of %d Mbp at 30x (one per rank), %d planted translocations, -t"
+                                % (world, EXCHANGE_CHROM_LEN // 1000000, ntr),
+                    "reads": int(stats[2]), "seconds": dt, "value": int(stats[2]) / 2 / dt, "unit": "read-pairs/s",
+                    "ctx_records_exchanged": int(stats[0]), "ctx_records_received": int(stats[1]),
+                    "rank0_ms_total": ex["ms_total"], "rank0_ms_exchange_and_ctx_join": ex["ms_exchange"],
+                    "ctx_svs_printed": s["n_svs_printed"], "planted_translocations": ntr})
+    run.close()
+
+
 def main():
     a = parse()
     if a.cpu_worker:
         return cpu_worker(a.cpu_worker[0], int(a.cpu_worker[1]))
     rank, world, local = ensure_world(a)
+    if SHARED_GPU_TEST:
+        local = 0
     import torch
     dist = init_group(a, world, local)
     if a.dry:
@@ -380,9 +430,26 @@ def main():
         for x in more[1:]:
             x.close()
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cpu") if SHARED_GPU_TEST else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # untimed extra for N > 1: the sharded whole-genome -t run, whose CTX records cross ranks over RCCL.  It runs on a
+    # helper thread under a watchdog: whatever happens to it, the line below is printed.
+    exchange, exchange_hung = {}, False
+    if world > 1 and not a.no_exchange:
+        import threading
+
+        def guarded():
+            try:
+                whole_genome_exchange(rank, world, local, dist, exchange)
+            except Exception as e:  # noqa: BLE001
+                exchange["error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+        th = threading.Thread(target=guarded, daemon=True)
+        th.start()
+        th.join(180)
+        if th.is_alive():
+            exchange_hung = True
+            exchange["error"] = "no result after 180 s"
 
     if rank == 0:
         pairs = n // 2
@@ -442,12 +509,22 @@ def main():
         }
         if overlapped:
             out["config"]["overlapped_contexts_untimed"] = overlapped
+        if world > 1 and not a.no_exchange:
+            out["config"]["whole_genome_exchange_untimed"] = exchange
+        if SHARED_GPU_TEST:
+            out["config"]["test_hook"] = "BDX_BENCH_TEST_SHARED_GPU: all ranks on device 0, gloo process group -- not a measurement"
         if cpu:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
+    if exchange_hung or "error" in exchange:  # a rank stuck (or a peer lost) in a collective cannot be joined: leave as is
+        sys.stdout.flush()
+        os._exit(0)
     if world > 1:
+        import threading
+        threading.Timer(60, lambda: os._exit(0)).start()  # (peers that left the hard way would leave this barrier waiting)
         dist.barrier()
         dist.destroy_process_group()
+        os._exit(0)
 
 
 if __name__ == "__main__":

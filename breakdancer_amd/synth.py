@@ -86,13 +86,15 @@ def concat(parts):
     return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
 
 
-def make_genome(lengths, coverage=30.0, seed=1, libs=((400.0, 30.0),), lib_bam=(0,), n_translocations=0, ctx_pairs=15, threads=None):
+def make_genome(lengths, coverage=30.0, seed=1, libs=((400.0, 30.0),), lib_bam=(0,), n_translocations=0, ctx_pairs=15, threads=None,
+                only_tids=None):
     """Multi-chromosome, multi-library synthetic input (configs[2]-[4] shapes, scaled by `lengths`).
     Every library contributes coverage/len(libs) (`coverage` may also be a sequence with one value per library, e.g. a 60x
     tumour and a 30x normal file); `lib_bam[i]` is the source file of library i.  Planted translocations add clusters of
     `ctx_pairs` inter-chromosomal pairs (both mates carry tid != mtid, isize 0).
     Returns the merged, (tid, pos, strand)-sorted SoA.  The (chromosome, library) parts are generated and the chromosomes
-    sorted on `threads` threads (numpy releases the GIL), which is what makes full-size inputs practical in a test."""
+    sorted on `threads` threads (numpy releases the GIL), which is what makes full-size inputs practical in a test.
+    only_tids: generate just these chromosomes' records of the same genome (a rank of a sharded run makes its own share)."""
     import os
     from concurrent.futures import ThreadPoolExecutor
     rng = np.random.default_rng(seed)
@@ -101,8 +103,9 @@ def make_genome(lengths, coverage=30.0, seed=1, libs=((400.0, 30.0),), lib_bam=(
     base = 0
     for tid, L in enumerate(lengths):
         for li, (mean, std) in enumerate(libs):
-            jobs.append(dict(length=L, coverage=cov[li], seed=seed * 1000 + tid * 16 + li, tid=tid, lib=li, bam=lib_bam[li],
-                             name_base=base, mean=mean, std=std))
+            if only_tids is None or tid in only_tids:
+                jobs.append(dict(length=L, coverage=cov[li], seed=seed * 1000 + tid * 16 + li, tid=tid, lib=li, bam=lib_bam[li],
+                                 name_base=base, mean=mean, std=std))
             base += 1 << 36
     if threads is None:
         threads = max(1, min(32, (os.cpu_count() or 2) // 2))
@@ -132,6 +135,8 @@ def make_genome(lengths, coverage=30.0, seed=1, libs=((400.0, 30.0),), lib_bam=(
         f = np.zeros(n, bool)
         for part in (rec(ta, pa, tb, pb, f, ~f, True), rec(tb, pb, ta, pa, ~f, f, False)):
             for t in range(len(lengths)):  # (part order inside a chromosome as in one global stable sort)
+                if only_tids is not None and t not in only_tids:
+                    continue
                 m = part["tid"] == t
                 if m.any():
                     per_tid[t].append({k: v[m] for k, v in part.items()})
