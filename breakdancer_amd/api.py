@@ -243,9 +243,12 @@ class BreakDancer:
         self._chk(self.lib.bdx_set_stage_timing(self.h, int(on)), "bdx_set_stage_timing")
         return self
 
-    def set_enqueue_ahead(self, on=True):
-        """Repeated runs of one context may launch the later stages ahead of the pass-1 read-back (default on)."""
-        self._chk(self.lib.bdx_set_enqueue_ahead(self.h, int(on)), "bdx_set_enqueue_ahead")
+    def set_enqueue_ahead(self, mode=2):
+        """How the stages behind pass 1 are sized and launched (bdx_set_enqueue_ahead): 2 ahead of the pass-1 read-back, from
+        the previous run of the same input or else a prior on the read count (default); 1 always from the prior (every run
+        behaves like a first run); 0 only after the read-back.  True / False stand for 2 / 0."""
+        mode = 2 if mode is True else (0 if mode is False else int(mode))
+        self._chk(self.lib.bdx_set_enqueue_ahead(self.h, mode), "bdx_set_enqueue_ahead")
         return self
 
     def set_host_walk(self, on=True):

@@ -207,9 +207,13 @@ int bdx_get_read_class(const bdx_ctx* ctx, uint8_t* out, size_t cap);
 int bdx_get_timings(const bdx_ctx* ctx, float* ms, int cap);
 /* [1]-[3] need HIP events between the stages, which idle the GPU for a few microseconds each: off by default */
 int bdx_set_stage_timing(bdx_ctx* ctx, int on);
-/* Enqueue-ahead (on by default): a context that has just run an input of the same size launches the later stages
- * before the pass-1 record is back, sized from the previous run's count of anomalous reads.  It only ever applies to a
- * repeated run; 0 makes every bdx_run take the path a first run takes (what bench.py times). */
+/* Enqueue-ahead: the stages behind pass 1 are launched before the pass-1 record is back on the host (which would leave
+ * the GPU idle for a host round trip), sized by a guess of the number of anomalous reads; if the guess was too small the
+ * device skips them and the host runs them again with the true count.
+ *   2 (default)  the guess is the previous run's count where this context has just run an input of the same size,
+ *                otherwise a prior of 1/32 of the reads (inputs of a million reads or more)
+ *   1            always the prior: every bdx_run behaves like a first run of its input (what bench.py times)
+ *   0            off: wait for the pass-1 record, then size exactly */
 int bdx_set_enqueue_ahead(bdx_ctx* ctx, int on);
 
 /* Where the SV candidates of the last bdx_run were assembled.  Components of the region graph that are one region, or

@@ -281,6 +281,12 @@ def test_repeated_runs_on_one_context(mode, monkeypatch):
     for _ in range(3):
         bd.run()
         compare(run, bd)
+    # every run sized like a first run (the prior on the read count: 1.8 M reads here, so it applies), and none ahead at all
+    for m in (1, 0, 2):
+        bd.set_enqueue_ahead(m)
+        for _ in range(2):
+            bd.run()
+            compare(run, bd)
     bd.close()
 
 

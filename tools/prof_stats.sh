@@ -3,7 +3,7 @@
 R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_ks
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -o ks -- python $R/bench.py --steps ${1:-20} --warmup 3 --no-cpu-baseline > /tmp/prof_ks.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -o ks -- python $R/bench.py --steps ${1:-40} --warmup 5 --no-cpu-baseline --no-end-to-end > /tmp/prof_ks.log 2>&1
 cd $R
 mkdir -p gpurun_out
 f=$(find /tmp/prof_ks -name '*kernel_stats.csv' | head -1)
