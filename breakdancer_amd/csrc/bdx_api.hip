@@ -177,7 +177,7 @@ struct bdx_ctx {
     // keys was copied into the resident column
     struct KeySeg { uint64_t begin; const uint64_t* host; const uint16_t* host_qlen; };
     std::vector<KeySeg> key_segs;
-    DevBuf b_seg;
+    DevBuf b_seg, b_done, b_lb;
 };
 
 namespace {
@@ -414,6 +414,8 @@ void bdx_destroy(bdx_ctx* c) {
         if (st.done) (void)hipEventDestroy(st.done);
     }
     c->b_seg.release();
+    c->b_done.release();
+    c->b_lb.release();
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     DevBuf* bufs[] = {&c->b_tid, &c->b_pos, &c->b_mtid, &c->b_mpos, &c->b_isize, &c->b_flag, &c->b_qlen, &c->b_mapq, &c->b_lib,
@@ -612,6 +614,8 @@ int pass1_prepare(bdx_ctx* c, uint32_t tiles_cap) {
     add(c->b_blk_cnt.p, (size_t)kCntCopies * ncnt, 0u);
     add(c->b_p1.p, sizeof(Pass1) / 4, 0u);
     add(c->b_counts.p, sizeof(StageCounts) / 4, 0u);
+    HIPCHK(c, c->b_done.ensure(64));
+    add(c->b_done.p, 1, 0u);
     il.n = k;
     launch_init(il, s);
     return BDX_OK;
@@ -687,6 +691,10 @@ int do_pass1(bdx_ctx* c, uint32_t na_cap, bool wait, bool defer_second) {
     ++c->seq;
     fp.flag_host = c->h_flags.as<uint32_t>(); fp.flag_value = c->seq;
     fp.na_cap = na_cap;
+    // The second level as the job of finalize_kernel's last workgroup (BDX_FINALIZE2_FOLD=1) was measured and lost: the
+    // device-scope fences it needs right behind K1's 15 MB of class bytes cost more (step 0.324 ms) than the launch (0.308 ms)
+    static const bool fold = getenv("BDX_FINALIZE2_FOLD") != nullptr;
+    fp.done = fold ? c->b_done.as<uint32_t>() : nullptr;
     // enqueue-ahead: K2 follows without a host decision in between, so its launch takes the one-workgroup second level along
     c->fp_deferred = fp;
     c->finalize2_deferred = defer_second;
@@ -874,6 +882,16 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool f
             // with the direct join right behind K3, that kernel forwards the table to the host
             static const bool no_forward = getenv("BDX_NO_FORWARD") != nullptr;
             k3.host_copy_later = (!no_forward && !c->bucketed_join && na <= kDirectJoinMax) ? 1 : 0;
+        }
+        static const bool three_launch = getenv("BDX_SCAN3") != nullptr;  // (A/B: the block-sums / rescan pair of launches)
+        if (!three_launch) {
+            const size_t words = 5 * nblk;
+            if (c->b_lb.bytes < words * 8) {  // the look-back words must start out zero; afterwards every run brings its own stamp
+                HIPCHK(c, c->b_lb.ensure(words * 8));
+                HIPCHK(c, hipMemsetAsync(c->b_lb.p, 0, c->b_lb.bytes, s));
+            }
+            k3.lb_state = c->b_lb.as<unsigned long long>();
+            k3.lb_stamp = c->seq & 0x3FFFFFFFu ? c->seq & 0x3FFFFFFFu : 1u;
         }
         k3.ws_u4 = c->b_ws_u4.as<U4>(); k3.head_total = (U4*)c->b_totals.p; k3.ws_u32 = c->b_ws_u32.as<uint32_t>();
         k3.acc_total = (uint32_t*)((char*)c->b_totals.p + 32); k3.counts = c->b_counts.as<StageCounts>();

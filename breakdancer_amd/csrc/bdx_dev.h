@@ -81,6 +81,8 @@ struct FinalizeParams {
     float* key_density;         // [nkeys]; may be null
     uint32_t* flag_host;        // pinned word set to flag_value once the mirrors are written (the host polls it); may be null
     uint32_t flag_value;
+    uint32_t* done;             // zeroed ticket counter: the workgroup of finalize_kernel that finishes last runs the second level
+                                // itself (null: the second level is its own launch, or rides on K2)
     uint32_t na_cap;            // 0, or the capacity the later stages were already enqueued with: if there are more anomalous
                                 // reads, the device copy of n_anom is zeroed (they then do nothing) and the host, which still
                                 // gets the true count, runs them again

@@ -68,6 +68,8 @@ struct K3Arrays {
     U4* head_total;
     uint32_t* ws_u32;
     uint32_t* acc_total;
+    unsigned long long* lb_state;  // look-back words of the two scans: [5][scan_grid(cap, 1)], zero at allocation; null: three-launch scans
+    uint32_t lb_stamp;             // run stamp of those words (never 0, changes every run)
     StageCounts* counts;
     StageCounts* counts_host;  // pinned host mirror: n_cand / n_regions / last_maxq are stored there as well (may be null)
     uint32_t* flag_host;       // pinned word set to flag_value by k3_region_of_kernel: the region table is complete

@@ -299,6 +299,22 @@ void launch_k1(const K1Params& p, int grid, size_t lds, hipStream_t s) {
 // -------------------------------------------------------------------------------------------------------
 constexpr int kFinBlock = 1024;
 
+// The second level of the finalisation needs every workgroup's results.  When nothing else is enqueued behind this kernel
+// that could take it along (K2 does on enqueue-ahead runs), the workgroup that finishes LAST runs it: a dozen or so
+// workgroups publish their results with a device-scope fence and take a ticket -- cheaper than one more launch (~7 us).
+__device__ __forceinline__ void finalize_tail(const FinalizeParams& p) {
+    if (!p.done) return;
+    __shared__ uint32_t s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(p.done, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x >= 256) return;  // (finalize2_body is written for four waves; the other waves of this workgroup leave)
+    finalize2_body(p);
+}
+
 // workgroups [0, ncols): tile scans; workgroups [ncols, ncols + nfold): ordered partial folds of the monoid table
 __global__ __launch_bounds__(kFinBlock) void finalize_kernel(const FinalizeParams p) {
     __shared__ uint32_t s_ws[kFinBlock / 64];
@@ -348,6 +364,7 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(const FinalizeParam
             else if (c == kColNormal) p.p1->n_normal = s_carry;
             else p.p1->key_tot[c - kColKey0] = s_carry;
         }
+        finalize_tail(p);
         return;
     }
 
@@ -386,6 +403,7 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(const FinalizeParam
         }
         __syncthreads();
     }
+    finalize_tail(p);
 }
 
 __global__ __launch_bounds__(256) void finalize2_kernel(const FinalizeParams p) { finalize2_body(p); }
@@ -404,8 +422,10 @@ void launch_init(const InitList& l, hipStream_t s) {
 }
 
 void launch_finalize(const FinalizeParams& p, hipStream_t s, bool second_level) {
-    hipLaunchKernelGGL(finalize_kernel, dim3(p.ncols + p.nfold), dim3(kFinBlock), 0, s, p);
-    if (second_level) hipLaunchKernelGGL(finalize2_kernel, dim3(1), dim3(256), 0, s, p);  // (else: a workgroup of K2 does it)
+    FinalizeParams q = p;
+    if (!second_level) q.done = nullptr;  // (a workgroup of K2 runs the second level)
+    hipLaunchKernelGGL(finalize_kernel, dim3(p.ncols + p.nfold), dim3(kFinBlock), 0, s, q);
+    if (second_level && !p.done) hipLaunchKernelGGL(finalize2_kernel, dim3(1), dim3(256), 0, s, p);
 }
 
 void launch_finalize2_only(const FinalizeParams& p, hipStream_t s) { hipLaunchKernelGGL(finalize2_kernel, dim3(1), dim3(256), 0, s, p); }
