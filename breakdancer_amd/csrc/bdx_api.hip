@@ -129,6 +129,8 @@ struct bdx_ctx {
     K4Arrays k4{};
     std::vector<double> log_tail;
     bool collect_support = false;
+    std::vector<uint32_t> ov_cnt;     // bdx_set_pass1_statistics: restored pass-1 counters that replace the run's own
+    uint32_t ov_covered = 0;
     bool replayed = false;            // the last run went through the read-level host replay (a read name seen more than twice)
     std::vector<uint32_t> sup_off;    // [n_svs + 1]
     std::vector<uint64_t> sup_idx;
@@ -1382,10 +1384,11 @@ int bdx_run(bdx_ctx* c) {
     };
     // enqueue-ahead when this context has just run an input of the same size
     uint32_t guess = 0;
-    if (c->speculate == 2 && c->ran && c->last_n == c->n && c->last_na) {
+    const bool restored = !c->ov_cnt.empty();  // (restored statistics are adopted between pass 1 and the rest: nothing ahead)
+    if (!restored && c->speculate == 2 && c->ran && c->last_n == c->n && c->last_na) {
         guess = c->spec_test ? std::max(1u, c->last_na / 2) : c->last_na + c->last_na / 8 + 1024;
         if (guess > kMaxRegions) guess = 0;
-    } else if (c->speculate && c->n >= (1u << 20)) {
+    } else if (!restored && c->speculate && c->n >= (1u << 20)) {
         // no history: a prior.  Anomalous reads are a few percent of a sorted BAM at most (1 % at configs[1]); 1/32 of the
         // reads covers that with room, costs a few microseconds of oversized grids when it is generous, and one more pass
         // over the (short) later stages when it is not.  Small inputs are not worth it: their whole run is launch latency.
@@ -1395,7 +1398,19 @@ int bdx_run(bdx_ctx* c) {
         guess = prior > kMaxRegions ? 0 : (uint32_t)prior;
     }
     int rc;
-    if (guess) {
+    if (restored) {
+        // restored pass-1 statistics (a cache written by an earlier run: ConfigLoader.cpp:19-23): the classifier still runs --
+        // pass 2 needs its class bytes -- but window, densities, lambda and the printed counters come from the cache
+        rc = do_pass1(c);
+        if (rc != BDX_OK) return rc;
+        rc = set_pass1(c, c->ov_cnt.data(), c->ov_covered, window_from(c, c->ov_cnt.data(), c->ov_covered), true);
+        if (rc != BDX_OK) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->b_cnt.p, c->ov_cnt.data(), c->ov_cnt.size() * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->b_kdens.p, c->key_density.data(), c->key_density.size() * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        rc = enqueue_middle();
+        if (rc != BDX_OK) return rc;
+    } else if (guess) {
         rc = do_pass1(c, guess, false, true);
         if (rc != BDX_OK) return rc;
         c->na_alloc = guess;
@@ -1739,6 +1754,15 @@ int bdx_get_cross_window_svs(const bdx_ctx* c, uint32_t* n_sv_device) {
     if (!c || !n_sv_device) return BDX_EINVAL;
     if (!c->ran) return BDX_ESTATE;
     *n_sv_device = c->counts.n_old;
+    return BDX_OK;
+}
+
+int bdx_set_pass1_statistics(bdx_ctx* c, const uint32_t* counters, uint32_t covered_ref_len) {
+    if (!c) return BDX_EINVAL;
+    if (!counters) { c->ov_cnt.clear(); return BDX_OK; }
+    c->ov_cnt.assign(counters, counters + (size_t)c->nlibs * kNumFlags + c->nlibs + c->nbams);
+    c->ov_covered = covered_ref_len;
+    c->ran = false;
     return BDX_OK;
 }
 

@@ -18,7 +18,10 @@
 #include <unistd.h>
 #include <vector>
 
+#include <getopt.h>
+
 #include "bdx.h"
+#include "cache.h"
 #include "config.h"
 #include "dumps.h"
 #include "options.h"
@@ -85,13 +88,31 @@ struct GpuSink : BatchSink {
 int main(int argc, char** argv) {
     bdx_ctx* ctx = nullptr;
     try {
-        Options opts(argc, argv);
-        if (!opts.restore_file.empty() || !opts.cache_file.empty())
-            throw std::runtime_error("-C / -R (pass-1 cache) are not supported: pass 1 is part of the single GPU pass");
+        std::unique_ptr<Options> opts_p(new Options(argc, argv));
+        Pass1Cache cache;
+        const bool restored = !opts_p->restore_file.empty();
+        std::string config_text;
+        if (restored) {
+            // -R <cache>: options, configuration and pass-1 statistics of the run that wrote the cache (ConfigLoader.cpp:19-23)
+            cache = read_cache(opts_p->restore_file);
+            std::vector<char*> av;
+            for (auto& a : cache.argv) av.push_back(&a[0]);
+            optind = 1;
+            opts_p.reset(new Options((int)av.size(), av.data()));
+            config_text = cache.config_text;
+        } else {
+            std::ifstream cfg_stream(opts_p->bam_config_path.c_str());
+            if (!cfg_stream.is_open()) throw std::runtime_error("unable to open config file '" + opts_p->bam_config_path + "'");
+            std::stringstream ss;
+            ss << cfg_stream.rdbuf();
+            config_text = ss.str();
+        }
+        Options& opts = *opts_p;
         const bool want_dumps = !opts.prefix_fastq.empty() || !opts.dump_BED.empty();
-        std::ifstream cfg_stream(opts.bam_config_path.c_str());
-        if (!cfg_stream.is_open()) throw std::runtime_error("unable to open config file '" + opts.bam_config_path + "'");
+        std::istringstream cfg_stream(config_text);
         BamConfig cfg(cfg_stream, opts.o.cut_sd);
+        if (restored && ((int)cfg.num_libs() != cache.nlibs || (int)cfg.num_bams() != cache.nbams))
+            throw std::runtime_error("Failed to load restore file: statistics do not fit its configuration");
         if (cfg.num_bams() == 0) {
             std::cout << "Error: no bams files in config file!\n";
             return 1;
@@ -134,6 +155,7 @@ int main(int argc, char** argv) {
         }
         const auto t_decoded = now();
         if (want_dumps) check(ctx, bdx_set_collect_support(ctx, 1), "bdx_set_collect_support");
+        if (restored) check(ctx, bdx_set_pass1_statistics(ctx, cache.counters.data(), cache.covered_ref_len), "bdx_set_pass1_statistics");
         check(ctx, bdx_run(ctx), "bdx_run");
         const auto t_ran = now();
 
@@ -143,6 +165,21 @@ int main(int argc, char** argv) {
         std::vector<float> seqcov(nlibs), dens(nlibs);
         check(ctx, bdx_get_counters(ctx, lib_cnt.data(), bam_cnt.data(), hist.data(), seqcov.data(), dens.data()), "bdx_get_counters");
 
+        if (!opts.cache_file.empty()) {  // -C <cache>: what a later "-R <cache>" run needs (ConfigLoader.cpp:34-42)
+            Pass1Cache w;
+            for (size_t i = 0; i < opts.orig_argv.size(); ++i) {
+                if (opts.orig_argv[i] == "-C" && i + 1 < opts.orig_argv.size()) { ++i; continue; }
+                if (opts.orig_argv[i].compare(0, 2, "-C") == 0 && opts.orig_argv[i].size() > 2) continue;
+                w.argv.push_back(opts.orig_argv[i]);
+            }
+            w.config_text = config_text;
+            w.covered_ref_len = sum.covered_ref_len;
+            w.nlibs = nlibs; w.nbams = nbams;
+            w.counters = hist;
+            w.counters.insert(w.counters.end(), lib_cnt.begin(), lib_cnt.end());
+            w.counters.insert(w.counters.end(), bam_cnt.begin(), bam_cnt.end());
+            write_cache(opts.cache_file, w);
+        }
         using std::cout;
         cout << "#Software: breakdancer-max-mi355x (libbdx)" << std::endl;
         cout << "#Command: ";

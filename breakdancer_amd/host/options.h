@@ -1,6 +1,5 @@
 // Command line of breakdancer-max: same getopt string, defaults and usage text as the reference
-// (common/Options.cpp:27-122).  -C / -R (Boost-XML cache of pass 1) are accepted by the parser for
-// compatibility but rejected at run time: pass 1 is a by-product of the single GPU pass here.
+// (common/Options.cpp:27-122), -C / -R (the pass-1 cache, cache.h) included.
 #pragma once
 #include <string>
 #include <vector>
@@ -11,8 +10,8 @@ namespace bdhost {
 
 struct Options {
     std::string chr;             // -o
-    std::string cache_file;      // -C (unsupported)
-    std::string restore_file;    // -R (unsupported)
+    std::string cache_file;      // -C: write the pass-1 cache
+    std::string restore_file;    // -R: run from a pass-1 cache (no other argument allowed)
     std::string bam_config_path;
     std::string prefix_fastq;    // -d
     std::string dump_BED;        // -g

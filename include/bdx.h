@@ -139,6 +139,12 @@ int bdx_reset_reads(bdx_ctx* ctx);
  * (BreakDancerMax.cpp:83-116) and BreakDancer::run (BreakDancer.cpp:131-144) up to the scored SV list. */
 int bdx_run(bdx_ctx* ctx);
 
+/* Replaces: a restored BamSummary (io/ConfigLoader.cpp:19-23, the -R cache).  counters = [nlibs*11 flag histogram |
+ * nlibs library read counts | nbams file read counts] in bdx_get_counters' layout, e.g. those of an earlier run over the
+ * whole genome; the following bdx_run calls derive window, read densities, lambda and the reported statistics from them
+ * instead of from their own reads.  NULL switches back to the run's own statistics. */
+int bdx_set_pass1_statistics(bdx_ctx* ctx, const uint32_t* counters, uint32_t covered_ref_len);
+
 typedef struct bdx_summary {
     uint64_t n_reads;
     uint64_t n_anomalous;        /* reads entering the region accumulator */

@@ -61,3 +61,35 @@ def test_cli_fastq_dump_matches_reference(tmp_path):
             got = open("%s.%s.%s.fastq" % (prefix, lib, k)).read()
             exp = open(os.path.join(CWD, "expected.%s.%s.fastq" % (lib, k))).read()
             assert got == exp, (lib, k)
+
+
+@pytest.mark.parametrize("args,fn", [(["-a", "-h", "-o", "21"], "expected_output.cn_per_lib.af"), ([], "expected_output")])
+def test_cli_pass1_cache_write_and_restore(tmp_path, args, fn):
+    """-C writes the pass-1 cache, -R re-runs from it alone: options, configuration and statistics of the cached run
+    (io/ConfigLoader.cpp:18-44; common/Options.cpp:47-53 allows no other argument next to -R)"""
+    cache = str(tmp_path / "pass1.cache")
+    exp = filter_cmd_lines(open(os.path.join(CWD, fn)).read())
+    assert filter_cmd_lines(run_cli(["-C", cache] + args)) == exp
+    assert os.path.getsize(cache) > 100
+    p = subprocess.run([EXE, "-R", cache], cwd=CWD, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    assert filter_cmd_lines(p.stdout.decode()) == exp
+    p = subprocess.run([EXE, "-R", cache, "-o", "21"], cwd=CWD, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 1 and b"When using -R, no other options are allowed" in p.stderr
+
+
+def test_cli_restored_statistics_are_the_ones_used(tmp_path):
+    """a cache whose counters were edited: the restored run must print and use THOSE statistics (the reference takes its
+    BamSummary from the archive, whatever the BAMs hold)"""
+    cache = str(tmp_path / "pass1.cache")
+    base = run_cli(["-C", cache, "-o", "21"])
+    lines = open(cache).read().split("\n")
+    i = [k for k, l in enumerate(lines) if l.startswith("covered_ref_len ")][0]
+    cov = int(lines[i].split()[1])
+    lines[i] = "covered_ref_len %d" % (cov // 4)   # a quarter of the reference length: window, densities, lambda all change
+    open(cache, "w").write("\n".join(lines))
+    p = subprocess.run([EXE, "-R", cache], cwd=CWD, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    out = p.stdout.decode()
+    assert ("reflen:%d" % (cov // 4)) in out and ("reflen:%d" % cov) in base
+    assert filter_cmd_lines(out) != filter_cmd_lines(base)
