@@ -160,6 +160,7 @@ void ColumnReader::read_header() {
         const uint32_t l = le32(h.data() + p);
         need(p + 4 + (size_t)l + 4);
         targets_.emplace_back((const char*)h.data() + p + 4, l ? l - 1 : 0);
+        target_len_.push_back(le32(h.data() + p + 4 + (size_t)l));
         p += 4 + (size_t)l + 4;
     }
     // the block that holds byte p of the inflated stream (the next block if the header ends exactly at a block boundary)

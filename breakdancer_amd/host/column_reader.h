@@ -62,6 +62,7 @@ public:
 
     const std::string& path() const { return path_; }
     const std::vector<std::string>& target_names() const { return targets_; }
+    const std::vector<uint32_t>& target_lengths() const { return target_len_; }
     int tid_of(const std::string& name) const;
     // start decoding; must be called once, before next()
     void start(const RecordFilter& f);
@@ -110,6 +111,7 @@ private:
     const LibraryResolver* libs_;
     RecordFilter filter_;
     std::vector<std::string> targets_;
+    std::vector<uint32_t> target_len_;
     size_t first_block_coff_ = 0;             // compressed offset of the block holding the first record
     uint64_t first_rec_abs_ = 0;              // uncompressed offset of the first record, relative to that block's start
 

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include <getopt.h>
+#include <cstring>
 
 #include "bdx.h"
 #include "cache.h"
@@ -39,6 +40,69 @@ void check(bdx_ctx* ctx, int rc, const char* what) {
     if (ctx && bdx_last_error(ctx)[0]) msg += std::string(" (") + bdx_last_error(ctx) + ")";
     throw std::runtime_error(msg);
 }
+
+// BDX_GPUS: "4" -> devices 0,1,2,3; "0,2,5" -> that list (a device may repeat: several ranks then share it)
+std::vector<int> gpu_list() {
+    std::vector<int> v;
+    const char* e = getenv("BDX_GPUS");
+    if (!e || !*e) return v;
+    const std::string s(e);
+    if (s.find(',') == std::string::npos) {
+        for (int i = 0; i < atoi(e); ++i) v.push_back(i);
+        return v;
+    }
+    size_t p = 0;
+    while (p <= s.size()) {
+        const size_t q = s.find(',', p);
+        v.push_back(atoi(s.substr(p, q == std::string::npos ? std::string::npos : q - p).c_str()));
+        if (q == std::string::npos) break;
+        p = q + 1;
+    }
+    return v;
+}
+
+// Sharded runs: the merged stream is position sorted, so every chromosome is one run of records; each run goes into the
+// staging ring of the context that owns the chromosome (bdx_dist_chromosome of its rank).
+struct RoutingSink : BatchSink {
+    std::vector<bdx_dist*>& ranks;
+    const std::vector<int>& rank_of;
+    std::vector<char> store;
+    bdx_batch_buf cur{};
+    RoutingSink(std::vector<bdx_dist*>& r, const std::vector<int>& ro) : ranks(r), rank_of(ro) {}
+    bdx_batch_buf acquire(size_t capacity) override {
+        const size_t K = (capacity + 63) / 64 * 64;
+        store.resize(K * 35 + 64);
+        char* p = store.data();
+        cur.name_key = (uint64_t*)p; p += K * 8;
+        cur.tid = (int32_t*)p; p += K * 4; cur.pos = (int32_t*)p; p += K * 4; cur.mtid = (int32_t*)p; p += K * 4;
+        cur.mpos = (int32_t*)p; p += K * 4; cur.isize = (int32_t*)p; p += K * 4;
+        cur.flag = (uint16_t*)p; p += K * 2; cur.qlen = (uint16_t*)p; p += K * 2;
+        cur.mapq = (uint8_t*)p; p += K; cur.lib = (uint8_t*)p; p += K; cur.bam = (uint8_t*)p;
+        cur.capacity = K;
+        return cur;
+    }
+    void submit(size_t n) override {
+        size_t lo = 0;
+        while (lo < n) {
+            const int tid = cur.tid[lo];
+            size_t hi = lo + 1;
+            while (hi < n && cur.tid[hi] == tid) ++hi;
+            if (tid < 0 || (size_t)tid >= rank_of.size()) throw std::runtime_error("record with a reference id beyond the header's sequences");
+            bdx_ctx* c = bdx_dist_chromosome(ranks[rank_of[tid]], tid);
+            if (!c) throw std::runtime_error("bdx_dist_chromosome failed");
+            const size_t m = hi - lo;
+            bdx_batch_buf b{};
+            check(c, bdx_acquire_batch(c, m, &b), "bdx_acquire_batch");
+            memcpy(b.tid, cur.tid + lo, m * 4); memcpy(b.pos, cur.pos + lo, m * 4); memcpy(b.mtid, cur.mtid + lo, m * 4);
+            memcpy(b.mpos, cur.mpos + lo, m * 4); memcpy(b.isize, cur.isize + lo, m * 4);
+            memcpy(b.flag, cur.flag + lo, m * 2); memcpy(b.qlen, cur.qlen + lo, m * 2);
+            memcpy(b.mapq, cur.mapq + lo, m); memcpy(b.lib, cur.lib + lo, m); memcpy(b.bam, cur.bam + lo, m);
+            memcpy(b.name_key, cur.name_key + lo, m * 8);
+            check(c, bdx_submit_batch(c, m), "bdx_submit_batch");
+            lo = hi;
+        }
+    }
+};
 
 // CPUs this process can use: hardware threads, capped by the cgroup v2 / v1 CPU quota if one is set
 unsigned usable_cpus() {
@@ -133,9 +197,20 @@ int main(int argc, char** argv) {
         // the GPU context (HIP runtime start-up, ~0.1 s) comes up on a helper thread while the BAMs are decoded
         const std::vector<bdx_lib> libs = cfg.abi_libs();
         const int nlibs = (int)libs.size(), nbams = (int)cfg.num_bams();
-        std::future<int> ctx_ready = std::async(std::launch::async, [&] {
-            return bdx_create(&ctx, &opts.o, libs.data(), nlibs, nbams, 0, cfg.max_read_window_size(), opts.device);
-        });
+        // BDX_GPUS=N (devices 0..N-1) or a list "0,1,2,3": ONE whole-genome run with the chromosomes spread over several
+        // GPUs (bdx_dist_*: one rank per device, here as threads of this process) -- same output as on one GPU
+        const std::vector<int> devices = gpu_list();
+        const bool sharded = devices.size() > 1 && opts.chr.empty();
+        std::vector<bdx_dist*> ranks(sharded ? devices.size() : 0, nullptr);
+        struct RanksGuard {
+            std::vector<bdx_dist*>& r;
+            ~RanksGuard() { for (bdx_dist* d : r) if (d) bdx_dist_destroy(d); }
+        } ranks_guard{ranks};
+        std::future<int> ctx_ready;
+        if (!sharded)
+            ctx_ready = std::async(std::launch::async, [&] {
+                return bdx_create(&ctx, &opts.o, libs.data(), nlibs, nbams, 0, cfg.max_read_window_size(), opts.device);
+            });
         // resident store sized from the compressed files (a record takes 50-150 bytes of BAM; a store that is too small
         // grows, at the price of classifying from the first tile again)
         size_t reserve = 1 << 20;
@@ -144,19 +219,47 @@ int main(int argc, char** argv) {
             if (stat(f.c_str(), &st) == 0) reserve += (size_t)st.st_size / 48;
         }
         reserve = std::min<size_t>(reserve, 0xFFFFFFFFull - 1024);
-        GpuSink sink(ctx_ready, ctx, reserve);
         size_t n_reads = 0;
-        try {
+        auto t_decoded = now();
+        if (sharded) {
+            if (want_dumps) throw std::runtime_error("-g / -d need the supporting reads of every SV: run on one GPU (unset BDX_GPUS)");
+            if (restored) throw std::runtime_error("-R is not supported with BDX_GPUS");
+            std::vector<std::string> names;
+            std::vector<uint32_t> lengths;
+            read_targets(cfg, names, lengths);
+            const int ntids = (int)std::max<size_t>(names.size(), 1), world = (int)devices.size();
+            int rc = bdx_dist_create_threads(ranks.data(), &opts.o, libs.data(), nlibs, nbams, ntids, cfg.max_read_window_size(), devices.data(), world);
+            if (rc != BDX_OK) throw std::runtime_error(std::string("bdx_dist_create_threads: ") + bdx_strerror(rc));
+            std::vector<uint64_t> weight(lengths.begin(), lengths.end());  // chromosomes -> ranks by sequence length
+            weight.resize(ntids, 0);
+            std::vector<int> rank_of(ntids, 0);
+            bdx_dist_plan(weight.data(), ntids, world, rank_of.data());
+            RoutingSink sink(ranks, rank_of);
             n_reads = produce_stream(cfg, opts.chr, (int)io_threads, &targets, sink);
-            sink.bring_up();  // (an input without records never asked for a batch)
-        } catch (...) {
-            if (ctx_ready.valid()) ctx_ready.wait();
-            throw;
+            t_decoded = now();
+            std::vector<int> rcs(world, BDX_OK);
+            std::vector<std::thread> th;
+            for (int r = 0; r < world; ++r) th.emplace_back([&, r] { rcs[r] = bdx_dist_run(ranks[r]); });
+            for (auto& t : th) t.join();
+            for (int r = 0; r < world; ++r)
+                if (rcs[r] != BDX_OK)
+                    throw std::runtime_error(std::string("bdx_dist_run: ") + bdx_strerror(rcs[r]) + " (" + bdx_dist_last_error(ranks[r]) + ")");
+            ctx = bdx_dist_result(ranks[0]);
+            if (!ctx) throw std::runtime_error("bdx_dist_result: no result on rank 0");
+        } else {
+            GpuSink sink(ctx_ready, ctx, reserve);
+            try {
+                n_reads = produce_stream(cfg, opts.chr, (int)io_threads, &targets, sink);
+                sink.bring_up();  // (an input without records never asked for a batch)
+            } catch (...) {
+                if (ctx_ready.valid()) ctx_ready.wait();
+                throw;
+            }
+            t_decoded = now();
+            if (want_dumps) check(ctx, bdx_set_collect_support(ctx, 1), "bdx_set_collect_support");
+            if (restored) check(ctx, bdx_set_pass1_statistics(ctx, cache.counters.data(), cache.covered_ref_len), "bdx_set_pass1_statistics");
+            check(ctx, bdx_run(ctx), "bdx_run");
         }
-        const auto t_decoded = now();
-        if (want_dumps) check(ctx, bdx_set_collect_support(ctx, 1), "bdx_set_collect_support");
-        if (restored) check(ctx, bdx_set_pass1_statistics(ctx, cache.counters.data(), cache.covered_ref_len), "bdx_set_pass1_statistics");
-        check(ctx, bdx_run(ctx), "bdx_run");
         const auto t_ran = now();
 
         bdx_summary sum;
@@ -309,7 +412,7 @@ int main(int argc, char** argv) {
                             "as they are produced) bdx_run=%.4fs format=%.3fs total=%.3fs\n",
                     n_reads, secs(t_start, t_decoded), io_threads, secs(t_decoded, t_ran), secs(t_ran, now()), secs(t_start, now()));
         }
-        bdx_destroy(ctx);
+        if (!sharded) bdx_destroy(ctx);  // (a sharded run's result context belongs to rank 0, released with the ranks)
         ctx = nullptr;
     } catch (std::exception const& e) {
         std::cerr << "ERROR: " << e.what() << "\n";

@@ -322,6 +322,13 @@ size_t produce_stream(const BamConfig& cfg, const std::string& chr, int threads,
     return w.total();
 }
 
+void read_targets(const BamConfig& cfg, std::vector<std::string>& names, std::vector<uint32_t>& lengths) {
+    if (cfg.num_bams() == 0) throw std::runtime_error("BamMerger created with no input streams!");
+    ColumnReader rd(cfg.bam_files()[0], 1, nullptr);  // (parses the header only: nothing is decoded before start())
+    names = rd.target_names();
+    lengths = rd.target_lengths();
+}
+
 void produce(const BamConfig& cfg, const std::string& chr, int threads, ReadStream& out) {
     VectorSink sink(out);
     produce_stream(cfg, chr, threads, &out.targets, sink);

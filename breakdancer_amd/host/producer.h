@@ -50,6 +50,8 @@ struct BatchSink {
 // order (io/BamMerger.cpp:40-126).  Returns the number of records; targets receives the first file's sequence names.
 size_t produce_stream(const BamConfig& cfg, const std::string& chr, int threads, std::vector<std::string>* targets, BatchSink& sink,
                       size_t batch_records = 1u << 20);
+// reference sequences of the first BAM of the configuration (names and lengths from its header; io/BamMerger.cpp:78)
+void read_targets(const BamConfig& cfg, std::vector<std::string>& names, std::vector<uint32_t>& lengths);
 void produce(const BamConfig& cfg, const std::string& chr, int threads, ReadStream& out);
 
 }  // namespace bdhost

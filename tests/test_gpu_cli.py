@@ -93,3 +93,17 @@ def test_cli_restored_statistics_are_the_ones_used(tmp_path):
     out = p.stdout.decode()
     assert ("reflen:%d" % (cov // 4)) in out and ("reflen:%d" % cov) in base
     assert filter_cmd_lines(out) != filter_cmd_lines(base)
+
+
+@pytest.mark.parametrize("gpus", ["0,0", "0,0,0"])
+@pytest.mark.parametrize("args,fn", [([], "expected_output"), (["-h"], "expected_output.af")])
+def test_cli_sharded_over_ranks_reproduces_the_golden_output(gpus, args, fn):
+    """BDX_GPUS: one whole-genome run with the chromosomes spread over several ranks (bdx_dist_*; here the ranks are
+    threads that share the one GPU) must print what the single-GPU run prints"""
+    p = subprocess.run([EXE] + args + ["inv_del_bam_config"], cwd=CWD, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, BDX_GPUS=gpus))
+    assert p.returncode == 0, p.stderr.decode()
+    assert filter_cmd_lines(p.stdout.decode()) == filter_cmd_lines(open(os.path.join(CWD, fn)).read())
+    p = subprocess.run([EXE, "-g", "/dev/null", "inv_del_bam_config"], cwd=CWD, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, BDX_GPUS=gpus))
+    assert p.returncode == 1 and b"run on one GPU" in p.stderr

@@ -49,3 +49,8 @@ def test_cli_on_fuzz_bams_equals_oracle(seed, tmp_path):
         p = subprocess.run([EXE, "-y", "-1"] + args + ["cfg"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert p.returncode == 0, p.stderr.decode()
         assert filter_cmd_lines(p.stdout.decode()) == filter_cmd_lines(run.text), (args, p.stderr.decode())
+        if "-o" not in args:  # the same run with the chromosomes spread over ranks (here: threads sharing the one GPU)
+            env = dict(os.environ, BDX_GPUS="0,0,0" if seed % 2 else "0,0")
+            p = subprocess.run([EXE, "-y", "-1"] + args + ["cfg"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            assert p.returncode == 0, p.stderr.decode()
+            assert filter_cmd_lines(p.stdout.decode()) == filter_cmd_lines(run.text), ("sharded", args, p.stderr.decode())
