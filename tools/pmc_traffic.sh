@@ -4,7 +4,7 @@ R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmct_$c
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmct_$c -o p -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > /tmp/pmct_$c.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmct_$c -o p -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-end-to-end > /tmp/pmct_$c.log 2>&1
 done
 cd $R
 python - <<'PY'
