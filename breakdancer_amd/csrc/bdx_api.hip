@@ -112,6 +112,8 @@ struct bdx_ctx {
     bool bucketed_join = false;       // BDX_BUCKETED_JOIN=1: use the partitioned LDS join at every size (it is the path for > 4 M entries)
     bool host_walk_only = false;      // BDX_HOST_WALK=1: every component goes through the host walk (A/B testing of K6)
     K6Arrays k6{};
+    const GroupRec* k6_in_groups = nullptr;  // sharded runs, rank 0: K6 takes the gathered pair groups instead of counting pairs
+    const uint32_t* k6_in_goff = nullptr;
 
     // results
     bool ran = false;
@@ -1053,6 +1055,7 @@ int do_k6(bdx_ctx* c, bool force_host) {
     a.cap = na;
     a.r_rec = c->b_r_rec.as<RegionRec>(); a.r_pk = c->b_r_pk.as<uint32_t>();
     a.region_of = c->k3.region_of; a.partner = c->k4.partner; a.pair_lo = c->k4.pair_lo; a.meta = c->cp.meta; a.isize = c->cp.isize;
+    a.in_groups = c->k6_in_groups; a.in_goff = c->k6_in_goff;
     a.parts = c->b_parts.as<PartRec>();
     a.rs = c->b_rs.as<RegSum>();
     a.out_deg = c->b_out_deg.as<uint32_t>(); a.label = a.out_deg + cap; a.bad_v = a.out_deg + 2 * cap; a.bad = a.out_deg + 3 * cap;

@@ -185,7 +185,7 @@ struct bdx_dist {
     std::unique_ptr<Comm> comm;
     std::map<int, bdx_ctx*> chrom;   // the chromosomes this rank owns
     bdx_ctx* util = nullptr;         // joins the CTX records this rank owns, and on rank 0 walks and holds the result
-    DevBuf b_words, b_cnt, b_send, b_recv, b_pack, b_all;
+    DevBuf b_words, b_cnt, b_send, b_recv, b_pack, b_all, b_gin;
     std::string err;
     uint64_t ctx_sent = 0, ctx_received = 0, gathered_bytes = 0;
     float ms_total = 0, ms_exchange = 0;
@@ -282,7 +282,7 @@ void bdx_dist_destroy(bdx_dist* d) {
     (void)hipSetDevice(d->device);
     for (auto& kv : d->chrom) bdx_destroy(kv.second);
     if (d->util) bdx_destroy(d->util);
-    for (DevBuf* b : {&d->b_words, &d->b_cnt, &d->b_send, &d->b_recv, &d->b_pack, &d->b_all}) b->release();
+    for (DevBuf* b : {&d->b_words, &d->b_cnt, &d->b_send, &d->b_recv, &d->b_pack, &d->b_all, &d->b_gin}) b->release();
     delete d;
 }
 
@@ -576,14 +576,69 @@ int bdx_dist_run(bdx_dist* d) {
         for (int t = 0; t < ntids; ++t)
             if (fill[t] != v3[(size_t)t * 2]) return dfail(d, BDX_EINTERNAL, "region table of the gather does not add up");
         DCTX(d, U, set_pass1(U, cnt_g.data(), covered, window, true));
-        decode_regions(U, regs.data(), pk.data(), (uint32_t)NR, 0, false);
-        decode_groups(U, groups.data(), (uint32_t)ng_all, 0);
-        U->counts.n_regions = (uint32_t)NR;
         U->n = 0;
         const int32_t lm = last_anom_tid >= 0 ? (int32_t)(uint32_t)v3[(size_t)last_anom_tid * 2 + 1] : 0;
-        DCTX(d, U, host_walk(U, lm, last_anom_tid >= 0));
-        DCTX(d, U, score_host_terms(U));
-        DCTX(d, U, finish_host_walk(U));
+        static const bool host_only = getenv("BDX_DIST_HOST_WALK") != nullptr;  // (A/B: the whole walk on the host, as in round 1)
+        // slot space of K6: region r owns the slots [first, first + n) -- its reads' places in a single-context run; here
+        // simply the regions laid end to end (every group owns at least one read of its later region, so they suffice)
+        uint64_t slots = 0;
+        for (size_t r = 0; r < NR; ++r) { regs[r].first = (uint32_t)slots; slots += regs[r].n; }
+        if (host_only || NR == 0 || ng_all == 0 || slots > kMaxRegions) {
+            decode_regions(U, regs.data(), pk.data(), (uint32_t)NR, 0, false);
+            decode_groups(U, groups.data(), (uint32_t)ng_all, 0);
+            U->counts.n_regions = (uint32_t)NR;
+            DCTX(d, U, host_walk(U, lm, last_anom_tid >= 0));
+            DCTX(d, U, score_host_terms(U));
+            DCTX(d, U, finish_host_walk(U));
+        } else {
+            // the device walk of a single-context run (K6), fed with the gathered groups bucketed by their later region
+            const uint32_t cap = (uint32_t)slots;
+            std::vector<uint32_t> goff(NR + 2, 0);
+            for (const GroupRec& g : groups) ++goff[(size_t)((g.key >> 12) & ((1u << 26) - 1)) + 1];
+            for (size_t r = 0; r < NR; ++r) goff[r + 1] += goff[r];
+            std::vector<GroupRec> sorted(ng_all);
+            {
+                std::vector<uint32_t> cur(goff.begin(), goff.begin() + NR);
+                for (const GroupRec& g : groups) sorted[cur[(size_t)((g.key >> 12) & ((1u << 26) - 1))]++] = g;
+            }
+            DHIP(d, U->b_r_rec.ensure((size_t)cap * sizeof(RegionRec))); DHIP(d, U->b_r_pk.ensure((size_t)cap * 2 * nkeys * 4));
+            DHIP(d, U->b_out_deg.ensure((size_t)cap * 6 * 4));
+            DHIP(d, d->b_gin.ensure(std::max<size_t>(ng_all, 1) * sizeof(GroupRec) + (NR + 2) * 4));
+            GroupRec* d_groups = d->b_gin.as<GroupRec>();
+            uint32_t* d_goff = (uint32_t*)(d_groups + std::max<size_t>(ng_all, 1));
+            DHIP(d, hipMemcpyAsync(U->b_r_rec.p, regs.data(), NR * sizeof(RegionRec), hipMemcpyHostToDevice, us));
+            DHIP(d, hipMemcpyAsync(U->b_r_pk.p, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, us));
+            DHIP(d, hipMemcpyAsync(d_groups, sorted.data(), ng_all * sizeof(GroupRec), hipMemcpyHostToDevice, us));
+            DHIP(d, hipMemcpyAsync(d_goff, goff.data(), (NR + 1) * 4, hipMemcpyHostToDevice, us));
+            DHIP(d, hipMemcpyAsync(U->b_cnt.p, cnt_g.data(), (size_t)ncnt * 4, hipMemcpyHostToDevice, us));
+            DHIP(d, hipMemcpyAsync(U->b_kdens.p, U->key_density.data(), U->key_density.size() * 4, hipMemcpyHostToDevice, us));
+            StageCounts sc{};
+            sc.n_regions = (uint32_t)NR; sc.last_maxq = lm;
+            DHIP(d, hipMemcpyAsync(U->b_counts.p, &sc, sizeof(sc), hipMemcpyHostToDevice, us));
+            DHIP(d, hipStreamSynchronize(us));  // (host vectors above go out of use)
+            launch_k6_scratch_init(U->b_out_deg.as<uint32_t>(), cap, us);
+            U->na_alloc = cap;
+            U->k3 = K3Arrays{}; U->k4 = K4Arrays{}; U->cp = Compact{};
+            U->k4.g_cap = (uint32_t)ng_all + 1;
+            DHIP(d, U->h_groups.ensure((size_t)U->k4.g_cap * sizeof(GroupRec)));
+            U->k4.g_rec = U->h_groups.as<GroupRec>();
+            U->k6_in_groups = d_groups; U->k6_in_goff = d_goff;
+            U->counts.last_maxq = lm;
+            const bool force_host = U->host_walk_only || U->opts.min_read_pair < 1;
+            int rk = do_k6(U, force_host);
+            U->k6_in_groups = nullptr; U->k6_in_goff = nullptr;
+            if (rk != BDX_OK) return dfail(d, rk, "do_k6: " + U->err);
+            decode_regions(U, regs.data(), pk.data(), (uint32_t)NR, 0, false);
+            if (!wait_flag(U, 1, U->seq)) {
+                if (U->poll) DHIP(d, hipStreamSynchronize(us)); else DHIP(d, hipEventSynchronize(U->ev_groups));
+            }
+            U->counts = *U->h_counts.as<StageCounts>();
+            if (U->counts.overflow) return dfail(d, BDX_EINTERNAL, "group list overflow");
+            decode_groups(U, U->h_groups.as<GroupRec>(), U->counts.n_groups, 0);
+            DCTX(d, U, host_walk(U, lm, true));
+            DCTX(d, U, do_k6_table(U));
+            DCTX(d, U, finish_table(U));
+        }
         U->p1.n_anom = (uint32_t)base[(size_t)ntids * tw];
     } else {
         DCTX(d, U, set_pass1(U, cnt_g.data(), covered, window, true));

@@ -252,6 +252,11 @@ struct K6Arrays {
     const int32_t* pair_lo;        // see K4Arrays::pair_lo; null: derive it from partner and region_of
     const uint32_t* meta;
     const int32_t* isize;
+    // sharded runs (rank 0): the pair groups arrive as aggregates gathered from the ranks, bucketed by their later region --
+    // region r's are in_groups[in_goff[r] .. in_goff[r+1]) -- instead of being counted from the reads (partner / meta / isize
+    // are then unused, and a region's `first` is its place in a slot space laid out by the host)
+    const GroupRec* in_groups;
+    const uint32_t* in_goff;
     PartRec* parts;                // [cap] sorted parts of region r at [first_r, ...)
     RegSum* rs;                    // [cap]
     // component analysis; the six arrays below are reset by k3_region_of_kernel (label[r] = r, the others 0)
@@ -342,6 +347,8 @@ struct K6Arrays {
 };
 
 void launch_k6_groups(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s);   // pair groups, components, the host's list
+// start values of the per-region scratch (out_deg, label = index, bad_v, bad, mcount, pcount) when no join kernel has set them
+void launch_k6_scratch_init(uint32_t* out_deg, uint32_t cap, hipStream_t s);
 void launch_k6_walk(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s);     // device-walked components -> SV staging
 void launch_k6_compact(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s);  // staging + host candidates -> final table
 // ComputeProbScore's combination (BreakDancer.cpp:56-69) + PhredQ (:459-465) for every candidate of the final table

@@ -160,7 +160,60 @@ __global__ __launch_bounds__(256) void k6_pairs_kernel(K6Arrays a) {
         uint32_t is = 0;
         bool has = false, merged = false;
         Merged m{};
-        if (n <= 64) {
+        if (a.in_groups) {
+            // sharded run: the region's groups were aggregated on the ranks that joined their pairs; the same weighted merge
+            // that folds the chunks of a large region folds them (a group can arrive in several partial aggregates)
+            const uint32_t g0 = a.in_goff[r], ng = a.in_goff[r + 1] - g0;
+            auto load_group = [&](uint32_t c0, uint64_t& k, uint32_t& cnt, uint32_t& sm) -> bool {
+                const uint32_t i = c0 + lane;
+                k = ~0ull; cnt = 0; sm = 0;
+                if (i >= ng) return false;
+                const GroupRec g = a.in_groups[g0 + i];
+                k = ((g.key >> 38) << 12) | (g.key & 0xFFFull);  // (lo, library, flag): the part key
+                cnt = g.pairs; sm = g.sum_isize;
+                return true;
+            };
+            if (ng <= 64) {
+                uint32_t cnt;
+                has = load_group(0, key, cnt, is);
+                if (__ballot(has)) {
+                    m = merge_items<true>(key, cnt, is, has, r, lane);
+                    merged = true;
+                }
+            } else {  // more aggregates than one wave merges at once: they go to the host as they are
+                rs.big = 1u;
+                for (uint32_t c0 = 0; c0 < ng; c0 += 64) {
+                    uint64_t ck;
+                    uint32_t cc, ci;
+                    const bool ch = load_group(c0, ck, cc, ci);
+                    const Merged cm = merge_items<true>(ck, cc, ci, ch, r, lane);
+                    const uint32_t clo = (uint32_t)(ck >> 12);
+                    rs.n_pairs += cm.total;
+                    rs.w_self += cm.wself;
+                    if (cm.gleader && clo < r) {
+                        atomicAdd(&a.out_deg[clo], 1u);
+                        a.bad_v[clo] = 1u;
+                    }
+                    if (lane == 0) a.bad_v[r] = 1u;
+                    const uint32_t nl = (uint32_t)__popcll(cm.lmask);
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&a.counts->n_groups, nl);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    if (cm.leader) {
+                        const uint32_t o = base + cm.rank;
+                        if (o < a.g_cap) {
+                            GroupRec g;
+                            g.key = group_pack(clo, r, (uint32_t)((ck >> 4) & 255), (uint32_t)(ck & 15));
+                            g.pairs = cm.cnt;
+                            g.sum_isize = cm.sum;
+                            a.g_rec[o] = g;
+                        } else {
+                            a.counts->overflow = 1;
+                        }
+                    }
+                }
+            }
+        } else if (n <= 64) {
             has = load_read(0, key, is);
             if (__ballot(has)) {
                 m = merge_items<false>(key, 1u, is, has, r, lane);
@@ -1236,6 +1289,22 @@ __global__ __launch_bounds__(64) void k6_done_kernel(K6Arrays a) {
             *(volatile uint32_t*)a.flag_done = a.flag_value;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k6_scratch_init_kernel(uint32_t* out_deg, uint32_t cap) {
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < cap; j += gridDim.x * 256) {
+        out_deg[j] = 0;
+        out_deg[(size_t)cap + j] = j;
+        out_deg[2 * (size_t)cap + j] = 0;
+        out_deg[3 * (size_t)cap + j] = 0;
+        out_deg[4 * (size_t)cap + j] = 0;
+        out_deg[5 * (size_t)cap + j] = 0;
+    }
+}
+
+void launch_k6_scratch_init(uint32_t* out_deg, uint32_t cap, hipStream_t s) {
+    if (!cap) return;
+    hipLaunchKernelGGL(k6_scratch_init_kernel, dim3(std::min<uint32_t>((cap + 255) / 256, 4096u)), dim3(256), 0, s, out_deg, cap);
 }
 
 void launch_k6_groups(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {

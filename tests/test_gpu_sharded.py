@@ -17,6 +17,9 @@ WG_OPTS = [dict(), dict(transchr_rearrange=1), dict(cn_lib=1, print_af=1), dict(
            dict(seq_coverage_lim=3), dict(max_sd=900)]
 
 
+dev_total = [0]
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_staged_whole_genome_equals_single_run(seed):
     cfg, streams, targets = make_case(100 + seed)
@@ -24,6 +27,11 @@ def test_staged_whole_genome_equals_single_run(seed):
         run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1, **o))
         util = sharded_from_oracle(run, world=1 + (seed + i) % 3)
         compare(run, util, check_cls=False)
+        n_dev, n_host, _ = util.walk_split()
+        assert n_dev + n_host == run.n_svs
+        dev_total[0] += n_dev
+    if seed == 23:
+        assert dev_total[0] > 100   # the gathered pair groups go through the device walk (K6) on rank 0, not only the host walk
 
 
 def test_staged_chr21_all_sequences():
@@ -45,6 +53,8 @@ def test_only_inter_chromosomal_records_cross_ranks():
         keep = []
         util = sharded_from_oracle(run, world=3, keep=keep)
         compare(run, util, check_cls=False)
+        n_dev, n_host, _ = util.walk_split()
+        assert n_dev > 10 * max(1, n_host) and n_dev + n_host == run.n_svs   # rank 0 walks the gathered groups on the device
         ex = keep[0].exchange
         n_ctx = int((((util.read_class() if False else run.cls) & 0x1F) == (0x10 | 8)).sum())  # passing reads classified ARP_CTX
         assert sum(e["ctx_records_sent"] for e in ex) == n_ctx == sum(e["ctx_records_received"] for e in ex)
