@@ -105,9 +105,51 @@ def write_bam(path, soa, targets, rg="rg1", readlen=None, level=1, seed=0, names
     return path
 
 
-def write_bam_records(path, recs, targets, rgs=(), level=1, seed=0):
+def _reg2bin(beg, end):
+    """UCSC binning scheme of the BAM specification (section 5.3)"""
+    end -= 1
+    if beg >> 14 == end >> 14: return ((1 << 15) - 1) // 7 + (beg >> 14)
+    if beg >> 17 == end >> 17: return ((1 << 12) - 1) // 7 + (beg >> 17)
+    if beg >> 20 == end >> 20: return ((1 << 9) - 1) // 7 + (beg >> 20)
+    if beg >> 23 == end >> 23: return ((1 << 6) - 1) // 7 + (beg >> 23)
+    if beg >> 26 == end >> 26: return ((1 << 3) - 1) // 7 + (beg >> 26)
+    return 0
+
+
+def _write_bai(path, n_ref, entries):
+    """entries: (tid, beg, end, virtual offset of the record, virtual offset behind it) in file order, mapped records only"""
+    bins = [dict() for _ in range(n_ref)]
+    lin = [dict() for _ in range(n_ref)]
+    for tid, beg, end, v0, v1 in entries:
+        b = _reg2bin(beg, end)
+        ch = bins[tid].setdefault(b, [])
+        if ch and ch[-1][1] == v0:
+            ch[-1][1] = v1
+        else:
+            ch.append([v0, v1])
+        for w in range(beg >> 14, ((end - 1) >> 14) + 1):
+            if w not in lin[tid] or v0 < lin[tid][w]:
+                lin[tid][w] = v0
+    out = bytearray(b"BAI\1" + struct.pack("<i", n_ref))
+    for t in range(n_ref):
+        out += struct.pack("<i", len(bins[t]))
+        for b, ch in sorted(bins[t].items()):
+            out += struct.pack("<Ii", b, len(ch))
+            for v0, v1 in ch:
+                out += struct.pack("<QQ", v0, v1)
+        n_intv = (max(lin[t]) + 1) if lin[t] else 0
+        out += struct.pack("<i", n_intv)
+        last = 0
+        for w in range(n_intv):  # (windows without their own entry inherit the previous one, as samtools' index does)
+            last = lin[t].get(w, last)
+            out += struct.pack("<Q", last)
+    open(path, "wb").write(bytes(out))
+
+
+def write_bam_records(path, recs, targets, rgs=(), level=1, seed=0, index=False):
     """Generic (slow, per-record) writer for small test inputs.  recs: list of dicts with tid,pos,mtid,mpos,isize,flag,
-    qlen,mapq,name and optional rg (str or ''), am (int or None); random bases/qualities of length qlen."""
+    qlen,mapq,name and optional rg (str or ''), am (int or None); random bases/qualities of length qlen.
+    index=True also writes <path>.bai (bins + linear index, BAM specification section 5.2)."""
     rng = np.random.default_rng(seed)
     text = "@HD\tVN:1.0\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (t, 300000000) for t in targets) + \
            "".join(("@RG\tID:%s\tLB:x\tSM:s\n" % r) if isinstance(r, str) else ("@RG\tID:%s\tPL:%s\tLB:%s\tSM:s\n" % (r[0], r[2], r[1]))
@@ -116,6 +158,7 @@ def write_bam_records(path, recs, targets, rgs=(), level=1, seed=0):
     for t in targets:
         out += struct.pack("<i", len(t) + 1) + t.encode() + b"\0" + struct.pack("<i", 300000000)
     codes = np.array([1, 2, 4, 8], np.uint8)
+    spans = []  # (tid, beg, end, raw offset of the record, raw offset behind it)
     for r in recs:
         L = int(r["qlen"])
         name = r["name"].encode() + b"\0"
@@ -132,10 +175,20 @@ def write_bam_records(path, recs, targets, rgs=(), level=1, seed=0):
         body = struct.pack("<iiBBHHHiiii", int(r["tid"]), int(r["pos"]), len(name), int(r["mapq"]), 0, ncig, int(r["flag"]), L,
                            int(r["mtid"]), int(r["mpos"]), int(r["isize"])) + name + (struct.pack("<I", (L << 4) | 0) if ncig else b"") + \
             seq + qual + aux
+        start = len(out)
         out += struct.pack("<i", len(body)) + body
+        if int(r["tid"]) >= 0:
+            spans.append((int(r["tid"]), int(r["pos"]), int(r["pos"]) + max(L, 1), start, len(out)))
     raw = bytes(out)
+    coffs = []
     with open(path, "wb") as f:
         for i in range(0, len(raw), 65280):
+            coffs.append(f.tell())
             f.write(_bgzf_block(raw[i:i + 65280], level))
+        coffs.append(f.tell())
         f.write(_EOF)
+    if index:
+        def voff(o):  # raw offset -> BGZF virtual offset
+            return (coffs[o // 65280] << 16) | (o % 65280) if o < len(raw) else (coffs[-1] << 16)
+        _write_bai(path + ".bai", len(targets), [(t, b, e, voff(s0), voff(s1)) for t, b, e, s0, s1 in spans])
     return path

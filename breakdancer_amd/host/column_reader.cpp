@@ -179,6 +179,10 @@ void ColumnReader::start(const RecordFilter& f) {
     if (started_) throw std::logic_error("ColumnReader::start called twice");
     started_ = true;
     filter_ = f;
+    // -o with a BAM index next to the file: start at the region instead of at the first record (the reference reads regions
+    // through the index as well, bam_iter_query behind io/RegionLimitedBamReader.hpp:33-71); without one the whole file is
+    // decoded and filtered
+    if (f.only_tid >= 0 && !getenv("BDX_BAM_NO_INDEX")) seeked_ = seek_with_index(f.only_tid, f.beg);
     expected_abs_ = first_rec_abs_;
     next_scan_ = first_block_coff_;
     // pieces in flight: only columns are kept per piece (~1.4 MB), so the decoders can run far ahead of a consumer that is
@@ -190,6 +194,74 @@ void ColumnReader::start(const RecordFilter& f) {
     }
     scanner_ = std::thread([this] { scan_blocks(); });
     for (int t = 0; t < threads_; ++t) threads_v_.emplace_back([this] { worker(); });
+}
+
+// The linear index of <path>.bai (BAM specification 5.2) gives, per 16 kb window, the smallest virtual offset of a record
+// that overlaps the window; decoding starts there.  Any problem with the index file simply means no seek.
+bool ColumnReader::seek_with_index(int tid, int beg) {
+    std::string bai = path_ + ".bai";
+    FILE* f = fopen(bai.c_str(), "rb");
+    if (!f && path_.size() > 4 && path_.compare(path_.size() - 4, 4, ".bam") == 0) {
+        bai = path_.substr(0, path_.size() - 4) + ".bai";
+        f = fopen(bai.c_str(), "rb");
+    }
+    if (!f) return false;
+    std::vector<uint8_t> d;
+    {
+        uint8_t buf[1 << 16];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof(buf), f)) > 0) d.insert(d.end(), buf, buf + n);
+        fclose(f);
+    }
+    size_t p = 0;
+    auto u32 = [&](uint32_t& v) { if (p + 4 > d.size()) return false; v = le32(d.data() + p); p += 4; return true; };
+    auto u64 = [&](uint64_t& v) {
+        if (p + 8 > d.size()) return false;
+        v = (uint64_t)le32(d.data() + p) | ((uint64_t)le32(d.data() + p + 4) << 32);
+        p += 8;
+        return true;
+    };
+    uint32_t magic, n_ref;
+    if (!u32(magic) || magic != 0x01494142u || !u32(n_ref) || (uint32_t)tid >= n_ref) return false;
+    for (uint32_t r = 0; r < n_ref; ++r) {
+        uint32_t n_bin;
+        if (!u32(n_bin)) return false;
+        uint64_t min_chunk = ~0ull;
+        for (uint32_t b = 0; b < n_bin; ++b) {
+            uint32_t bin, n_chunk;
+            if (!u32(bin) || !u32(n_chunk)) return false;
+            for (uint32_t c = 0; c < n_chunk; ++c) {
+                uint64_t cb, ce;
+                if (!u64(cb) || !u64(ce)) return false;
+                if (bin != 37450 && cb < min_chunk) min_chunk = cb;  // (37450: the metadata pseudo-bin of newer indexers)
+            }
+        }
+        uint32_t n_intv;
+        if (!u32(n_intv)) return false;
+        if ((int)r != tid) {
+            if (p + 8ull * n_intv > d.size()) return false;
+            p += 8ull * n_intv;
+            continue;
+        }
+        uint64_t off = 0;
+        if (n_intv) {
+            uint32_t w = std::min<uint32_t>((uint32_t)std::max(beg, 0) >> 14, n_intv - 1);
+            for (;; --w) {  // a window without an entry: the nearest one before it
+                const size_t q = p + 8ull * w;
+                if (q + 8 > d.size()) return false;
+                off = (uint64_t)le32(d.data() + q) | ((uint64_t)le32(d.data() + q + 4) << 32);
+                if (off || w == 0) break;
+            }
+        }
+        if (!off) off = min_chunk == ~0ull ? 0 : min_chunk;
+        if (!off) return false;  // nothing indexed for this sequence: let the full scan find out
+        const size_t coff = (size_t)(off >> 16);
+        if (coff >= map_size_) return false;
+        first_block_coff_ = coff;
+        first_rec_abs_ = off & 0xFFFF;
+        return true;
+    }
+    return false;
 }
 
 // Index blocks until block i exists (anyone may advance the index: a worker whose last record runs past the blocks indexed
@@ -333,6 +405,7 @@ void ColumnReader::decode_piece(Scratch& sc, Piece& p, bool known_start, uint64_
     if (kProfile) g_inflate_ns += t_pa - t_in;
     struct Acc { long long t0; ~Acc() { if (kProfile) g_parse_ns += now_ns() - t0; } } acc{t_pa};
     p.cols.clear();
+    p.past_region = false;
     size_t pos;
     if (known_start) {
         pos = (size_t)(start_abs - p.abs_begin);
@@ -393,10 +466,24 @@ void ColumnReader::decode_piece(Scratch& sc, Piece& p, bool known_start, uint64_
         // reader filter of the reference: primary (not secondary / supplementary) and tid >= 0
         // (io/AlignmentFilter.hpp:24-34, io/BamIo.cpp:11-18); -o keeps the records overlapping one region
         if (r.flag & (0x100 | 0x800)) continue;
-        if (r.tid < 0) continue;
-        if (filter_.only_tid >= 0 &&
-            (r.tid != filter_.only_tid || !((uint32_t)r.end_pos > (uint32_t)filter_.beg && (uint32_t)r.pos < (uint32_t)filter_.end)))
+        if (r.tid < 0) {
+            if (seeked_) {  // unplaced reads come last in a sorted file
+                p.past_region = true;
+                p.next_abs = p.abs_begin + pos;
+                return;
+            }
             continue;
+        }
+        if (filter_.only_tid >= 0 &&
+            (r.tid != filter_.only_tid || !((uint32_t)r.end_pos > (uint32_t)filter_.beg && (uint32_t)r.pos < (uint32_t)filter_.end))) {
+            // a coordinate-sorted file holds nothing of the region behind the first record past it
+            if (seeked_ && (r.tid > filter_.only_tid || (r.tid == filter_.only_tid && r.pos >= filter_.end))) {
+                p.past_region = true;
+                p.next_abs = p.abs_begin + pos;
+                return;
+            }
+            continue;
+        }
         uint8_t lib = 0;
         if (libs_) {
             const uint32_t lr = r.rg ? r.l_rg : 0;
@@ -425,6 +512,7 @@ const ColumnChunk* ColumnReader::next() {
         release_piece(current_);
         current_ = nullptr;
     }
+    if (region_done_) return nullptr;
     for (;;) {
         Piece* p = nullptr;
         {
@@ -462,6 +550,15 @@ const ColumnChunk* ColumnReader::next() {
         }
         expected_abs_ = p->next_abs;
         current_ = p;
+        if (p->past_region) {  // the rest of the file is behind the region: stop the decoders
+            region_done_ = true;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                stop_ = true;
+            }
+            cv_work_.notify_all();
+            cv_free_.notify_all();
+        }
         return &p->cols;
     }
 }

@@ -81,6 +81,7 @@ private:
         uint64_t first_abs = 0;              // where this piece's first record starts (guessed, except for the first piece)
         uint64_t next_abs = 0;               // where the first record of the following piece starts
         bool found_start = false;
+        bool past_region = false;            // met a record behind the -o region (sorted file: nothing of it follows)
         ColumnChunk cols;
         std::string error;
         bool done = false;
@@ -96,6 +97,7 @@ private:
     };
 
     void read_header();
+    bool seek_with_index(int tid, int beg);   // <path>.bai: start at the first block that can hold a record of the region
     void scan_blocks();                       // scanner thread: the block index, then the pieces' queue
     void worker();
     void decode_piece(Scratch& sc, Piece& p, bool known_start, uint64_t start_abs);
@@ -134,6 +136,8 @@ private:
     Scratch redo_;                            // the consumer's own buffer for a piece it has to decode again
     uint64_t expected_abs_ = 0;
     bool started_ = false;
+    bool seeked_ = false;                     // decoding starts in the middle of the file (-o with a BAM index)
+    bool region_done_ = false;                // a piece ran past the region: the stream ends there
 };
 
 }  // namespace bdhost

@@ -126,3 +126,23 @@ def test_two_files_merge_in_the_reference_order_at_every_piece_size():
         assert len(rows) == run.n_merged
         for col, k in enumerate(("tid", "pos", "mtid", "mpos", "isize", "flag", "qlen", "bdqual", "lib", "bam")):
             np.testing.assert_array_equal(rows[:, col], soa[k].astype(np.int64), err_msg=k)
+
+
+@pytest.mark.parametrize("region", ["c2", "c2:9000-21000", "c3:15,000", "c1:1-4000"])
+def test_region_through_the_bam_index_equals_the_full_scan(tmp_path, region):
+    """-o with a .bai next to the BAMs: decoding starts at the region (linear index) and stops behind it; the stream must be
+    the one the full scan filters out of the whole file, piece size 1 block or default"""
+    from breakdancer_amd.bamwrite import write_bam_records
+    from fuzzgen import make_case
+    cfg, streams, targets = make_case(77, n_pairs=2500)
+    for fn, st in zip(("a.bam", "b.bam"), streams):
+        recs = [dict(tid=st["tid"][i], pos=st["pos"][i], mtid=st["mtid"][i], mpos=st["mpos"][i], isize=st["isize"][i], flag=st["flag"][i],
+                     qlen=st["qlen"][i], mapq=int(st["bdqual"][i]), rg=st["rg"][i], name="read%d" % int(st["name_id"][i])) for i in range(len(st["tid"]))]
+        write_bam_records(str(tmp_path / fn), recs, targets, rgs=("rg1", "rg2", "rg3"), seed=3, index=True)
+    (tmp_path / "cfg").write_text(cfg)
+    _, full, kfull = dump(["-o", region, "cfg"], str(tmp_path), {"BDX_BAM_NO_INDEX": "1"})
+    assert len(full) > 50
+    for env in ({}, {"BDX_BAM_PIECE_BLOCKS": "1"}):
+        _, rows, keys = dump(["-o", region, "cfg"], str(tmp_path), env)
+        np.testing.assert_array_equal(rows, full)
+        np.testing.assert_array_equal(keys, kfull)
