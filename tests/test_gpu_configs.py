@@ -41,7 +41,7 @@ def test_config2_shape_four_libraries_three_chromosomes():
         run = oracle_from_soa(d, cfg, ["wgs.bam"], make_opts(**kw), ["c1", "c2", "c3"])
         assert run.n_svs > 300
         compare(run, product_from_oracle(run))
-        compare(run, sharded_from_oracle(run), check_cls=False)
+        compare(run, sharded_from_oracle(run, world=3), check_cls=False)
 
 
 def test_config3_shape_translocations_with_dash_t():
@@ -55,7 +55,7 @@ def test_config3_shape_translocations_with_dash_t():
         if kw:
             assert run.W == 50  # -t: no insert-size flags are counted, the window drops to 50 (BreakDancerMax.cpp:114)
         compare(run, product_from_oracle(run))
-        compare(run, sharded_from_oracle(run), check_cls=False)
+        compare(run, sharded_from_oracle(run, world=3), check_cls=False)
 
 
 def test_config4_shape_tumour_normal_two_bams():
@@ -69,7 +69,7 @@ def test_config4_shape_tumour_normal_two_bams():
         run = oracle_from_soa(d, cfg, ["normal.bam", "tumour.bam"], make_opts(**kw), ["c1", "c2"])
         assert run.lib_names == ["libN1", "libN2", "libT1"] and run.n_svs > 300
         compare(run, product_from_oracle(run))
-        compare(run, sharded_from_oracle(run), check_cls=False)
+        compare(run, sharded_from_oracle(run, world=3), check_cls=False)
 
 
 def test_many_files_and_libraries_take_the_general_paths():

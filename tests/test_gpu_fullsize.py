@@ -138,6 +138,16 @@ def test_config3_five_thousand_translocations_with_dash_t(genome_share):
     assert (ctx["chr"][:, 0] != ctx["chr"][:, 1]).all()
     assert np.median(ctx["num_reads"]) >= 13
     bd.close()
+    # the same run with the 24 chromosomes spread over 4 ranks (threads sharing this GPU): every CTX read crosses in the one
+    # all-to-all, rank 0 walks the gathered groups -- the multi-GPU shape of configs[3]
+    from runner import sharded_from_oracle
+    keep = []
+    util = sharded_from_oracle(run, world=4, keep=keep)
+    compare(run, util, check_cls=False)
+    ex = keep[0].exchange
+    n_ctx = int(((run.cls & 0x1F) == (0x10 | 8)).sum())
+    assert sum(e["ctx_records_sent"] for e in ex) == n_ctx > 100_000
+    assert min(e["ctx_records_received"] for e in ex) > n_ctx // 8
 
 
 def test_config4_tumour_normal_two_files_copy_number_and_allele_frequency():
