@@ -265,7 +265,7 @@ EXCHANGE_CHROM_LEN = 5_000_000
 EXCHANGE_TRANSLOCATIONS_PER_RANK = 250
 
 
-def whole_genome_exchange(rank, world, local, dist, out):
+def whole_genome_exchange(rank, world, local, dist, out, chroms_per_rank=1):
     """configs[3] in miniature over the N GPUs of this run: every rank owns one 5 Mbp chromosome of a genome with planted
     translocations between all of them; `-t` keeps only inter-chromosomal pairs, whose join records cross ranks in ONE
     all-to-all over RCCL (bdx_dist_run, csrc/bdx_dist_impl.h).  Fills `out` on rank 0."""
@@ -274,9 +274,13 @@ def whole_genome_exchange(rank, world, local, dist, out):
     from breakdancer_amd.api import LibraryConfig, Options
     from breakdancer_amd.synth import LIB_C2, make_genome
     ntr = EXCHANGE_TRANSLOCATIONS_PER_RANK * world
-    d = make_genome([EXCHANGE_CHROM_LEN] * world, coverage=30.0, seed=77, n_translocations=ntr, only_tids={rank})
-    run = D.DistRun.from_process_group(Options(transchr_rearrange=True), [LibraryConfig(**LIB_C2)], 1, world, 200, local)
-    run.chromosome(rank).push_reads(d)
+    nchrom = world * chroms_per_rank
+    mine = set(range(rank * chroms_per_rank, (rank + 1) * chroms_per_rank))
+    d = make_genome([EXCHANGE_CHROM_LEN] * nchrom, coverage=30.0, seed=77, n_translocations=ntr, only_tids=mine)
+    run = D.DistRun.from_process_group(Options(transchr_rearrange=True), [LibraryConfig(**LIB_C2)], 1, nchrom, 200, local)
+    for t in sorted(mine):
+        m = d["tid"] == t
+        run.chromosome(t).push_reads({k: v[m] for k, v in d.items()})
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
@@ -291,8 +295,8 @@ def whole_genome_exchange(rank, world, local, dist, out):
     if rank == 0:
         s = run.result().summary()
         out.update({"ranks": world, "backend": "RCCL (ncclAllReduce, ncclAllToAllv, grouped ncclSend/ncclRecv on device buffers)",
-                    "workload": "one genome, %d chromosomes of %d Mbp at 30x (one per rank), %d planted translocations, -t"
-                                % (world, EXCHANGE_CHROM_LEN // 1000000, ntr),
+                    "workload": "one genome, %d chromosomes of %d Mbp at 30x (%d per rank), %d planted translocations, -t"
+                                % (nchrom, EXCHANGE_CHROM_LEN // 1000000, chroms_per_rank, ntr),
                     "reads": int(stats[2]), "seconds": dt, "value": int(stats[2]) / 2 / dt, "unit": "read-pairs/s",
                     "ctx_records_exchanged": int(stats[0]), "ctx_records_received": int(stats[1]),
                     "rank0_ms_total": ex["ms_total"], "rank0_ms_exchange_and_ctx_join": ex["ms_exchange"],
