@@ -6,9 +6,9 @@ HOST := breakdancer_amd/host
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result -Iinclude
 KERNELS := $(CSRC)/k1_classify.hip $(CSRC)/k2_compact.hip $(CSRC)/k3_regions.hip $(CSRC)/k4_join.hip $(CSRC)/k5_poisson.hip $(CSRC)/k6_assemble.hip $(CSRC)/k7_exchange.hip $(CSRC)/bdx_api.hip
 OBJS := $(KERNELS:.hip=.o) $(CSRC)/bdx_walk.o $(CSRC)/bdx_walk_reads.o
-HOSTCOMMON := $(HOST)/options.cpp $(HOST)/config.cpp $(HOST)/bam_reader.cpp $(HOST)/column_reader.cpp $(HOST)/producer.cpp $(HOST)/dumps.cpp $(HOST)/cache.cpp
+HOSTCOMMON := $(HOST)/options.cpp $(HOST)/config.cpp $(HOST)/bam_reader.cpp $(HOST)/fast_inflate.cpp $(HOST)/column_reader.cpp $(HOST)/producer.cpp $(HOST)/dumps.cpp $(HOST)/cache.cpp
 
-all: breakdancer_amd/libbdx.so bin/breakdancer-max bin/bdx-dump-reads bin/bam2cfg oracle
+all: breakdancer_amd/libbdx.so bin/breakdancer-max bin/bdx-dump-reads bin/bam2cfg bin/bdx-inflate-check oracle
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/bdx.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -27,6 +27,10 @@ HOSTFLAGS := -O2 -std=c++17 -ffp-contract=off -Wall -Iinclude -pthread
 bin/breakdancer-max: $(HOSTCOMMON) $(HOST)/main.cpp $(wildcard $(HOST)/*.h) breakdancer_amd/libbdx.so
 	@mkdir -p bin
 	g++ $(HOSTFLAGS) -o $@ $(HOSTCOMMON) $(HOST)/main.cpp -Lbreakdancer_amd -lbdx -lz -Wl,-rpath,'$$ORIGIN/../breakdancer_amd' -Wl,-rpath,/opt/rocm/lib
+
+bin/bdx-inflate-check: $(HOST)/inflate_check_main.cpp $(HOST)/fast_inflate.cpp $(HOST)/fast_inflate.h
+	@mkdir -p bin
+	g++ $(HOSTFLAGS) -O3 -o $@ $(HOST)/inflate_check_main.cpp $(HOST)/fast_inflate.cpp -lz
 
 bin/bam2cfg: $(HOST)/bam2cfg_main.cpp $(HOST)/bam_reader.cpp $(HOST)/bam_reader.h
 	@mkdir -p bin

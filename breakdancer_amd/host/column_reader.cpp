@@ -14,6 +14,7 @@
 #include <chrono>
 
 #include "bam_reader.h"
+#include "fast_inflate.h"
 
 namespace bdhost {
 
@@ -378,8 +379,13 @@ void ColumnReader::inflate_into(Scratch& sc, const Piece& p, size_t block) {
         b = blocks_[block];
     }
     const size_t at = (size_t)(b.uabs - p.abs_begin);
-    if (sc.buf.size() < at + b.ulen) sc.buf.resize(std::max(at + b.ulen, sc.buf.size() * 2));
-    inflate_raw(map_ + b.coff, b.clen, sc.buf.data() + at, b.ulen, path_);
+    if (sc.buf.size() < at + b.ulen + 16) sc.buf.resize(std::max(at + b.ulen + 16, sc.buf.size() * 2));
+    // own decoder first (fast_inflate.cpp); zlib decides about anything it does not like, and takes the blocks whose payload
+    // ends too close to the end of the mapping for the decoder's 8-byte loads
+    static const bool zlib_only = getenv("BDX_BAM_ZLIB") != nullptr;
+    if (zlib_only || b.coff + b.clen + 32 > map_size_ ||
+        !fast_inflate(map_ + b.coff, b.clen, sc.buf.data() + at, b.ulen, sc.buf.size() - (at + b.ulen)))
+        inflate_raw(map_ + b.coff, b.clen, sc.buf.data() + at, b.ulen, path_);
     sc.filled = at + b.ulen;
 }
 
