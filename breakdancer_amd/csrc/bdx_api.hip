@@ -1033,7 +1033,6 @@ int do_k6(bdx_ctx* c, bool force_host) {
     HIPCHK(c, c->b_cn_stage.ensure(cap * (size_t)nkeys * sizeof(CnStage) + 16));
     HIPCHK(c, c->b_t_lambda.ensure((size_t)a.term_cap * 8)); HIPCHK(c, c->b_t_k.ensure((size_t)a.term_cap * 4));
     const size_t nblk = scan_grid(na, 1) + 1;
-    HIPCHK(c, c->b_ws6.ensure(nblk * sizeof(U4) + 64));
     HIPCHK(c, c->h_sv_out.ensure((size_t)a.sv_cap * sizeof(SvOut)));
     HIPCHK(c, c->h_lib_index.ensure((size_t)a.term_cap * 4)); HIPCHK(c, c->h_lib_pairs.ensure((size_t)a.term_cap * 4));
     HIPCHK(c, c->h_cn_key.ensure((size_t)a.cn_cap * 4 + 16)); HIPCHK(c, c->h_cn_value.ensure((size_t)a.cn_cap * 4 + 16));
@@ -1068,7 +1067,15 @@ int do_k6(bdx_ctx* c, bool force_host) {
     a.cn_key = c->h_cn_key.as<int32_t>(); a.cn_value = c->h_cn_value.as<float>();
     a.t_lambda = c->b_t_lambda.as<double>(); a.t_k = c->b_t_k.as<int32_t>();
     a.g_rec = c->k4.g_rec; a.g_cap = c->k4.g_cap;
-    a.ws_u4 = c->b_ws6.as<U4>(); a.total_u4 = (U4*)((char*)c->b_ws6.p + nblk * sizeof(U4));
+    {   // look-back words of the table scan: zero once, afterwards every run brings its own stamp
+        const size_t words = 4 * nblk;
+        if (c->b_ws6.bytes < words * 8) {
+            HIPCHK(c, c->b_ws6.ensure(words * 8));
+            HIPCHK(c, hipMemsetAsync(c->b_ws6.p, 0, c->b_ws6.bytes, s));
+        }
+        a.lb_state = c->b_ws6.as<unsigned long long>();
+        a.lb_stamp = c->seq & 0x3FFFFFFFu ? c->seq & 0x3FFFFFFFu : 1u;
+    }
     a.counts = c->b_counts.as<StageCounts>();
     // run constants: the flag histogram is the device's own reduced counter table (a single-context run adopts its own
     // statistics), the read densities per counter key travel in the kernel arguments
@@ -1144,11 +1151,10 @@ int do_k6_table(bdx_ctx* c) {
         a.hs_rec = c->h_hs_rec.as<SvOut>(); a.hs_key = hkey; a.hs_cnt = hcnt;
         a.hs_lambda = lam; a.hs_lib_index = li; a.hs_lib_pairs = lp; a.hs_cn_key = ck; a.hs_cn_value = cv;
     }
-    launch_k6_compact(a, na, s);
-    a.ltail_host = c->h_ltail_dev.as<double>();  // (K5 runs inside the score kernel: one launch less)
+    a.ltail_host = c->h_ltail_dev.as<double>();  // (K5 runs inside the table kernel)
     HIPCHK(c, c->h_printed.ensure((size_t)k6_score_grid(a) * 4));
     a.printed_host = c->h_printed.as<uint32_t>();
-    launch_k6_score(a, std::log(10), c->opts.score_threshold, c->opts.fisher ? 0 : 1, s);
+    launch_k6_table(a, na, std::log(10), c->opts.score_threshold, c->opts.fisher ? 0 : 1, s);
     {   // the final table is complete (without polling: finish_table waits for the stream)
         const int rc = signal_ready(c, 2, nullptr);
         if (rc != BDX_OK) return rc;

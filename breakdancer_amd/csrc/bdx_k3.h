@@ -196,7 +196,6 @@ constexpr int kK6MaxMembers = 4;   // regions per device-walked component
 constexpr int kK6MaxIn = 3;        // incoming gate-passing groups per region (a member of such a component has <= 3)
 constexpr int kK6BigMembers = 64;  // regions per component walked by the general device path (one wave, member lists in LDS)
 constexpr int kK6LibStride = 16;   // staged (library, pairs) entries per candidate; components that could need more go to the host
-constexpr int kK6LdsParts = 12;    // parts of a component kept in LDS by its walking thread (more: read from HBM)
 constexpr int kK6LabelRoundsBig = 8; // ... with the general walk (components of up to kK6BigMembers regions) enabled
 constexpr int kK6LabelRounds = 2;  // min-label propagation rounds (the first inside k6_pairs_kernel, the others with pointer jumping):
                                    // two settle chains of four regions in practice; a component that has not converged fails
@@ -299,7 +298,7 @@ struct K6Arrays {
     float* cn_value;               // pinned host
     uint32_t sv_cap, term_cap, cn_cap;
     double* ltail;                 // device [term_cap]: log tails of the terms ...
-    uint32_t* printed_host;        // pinned host [k6_score_grid()]: printed candidates per workgroup of k6_score_kernel; may be null
+    uint32_t* printed_host;        // pinned host [k6_score_grid()]: printed candidates per workgroup of k6_finish_kernel; may be null
     double* ltail_host;            // ... and their copy in pinned host memory (both written by k6_score_kernel)
     // Candidates that are placed by their order key instead of by their start vertex: the host walk's (pinned host
     // memory) and the device's own whose traversal started from a vertex of an earlier flush window.  k6_insert_kernel
@@ -325,8 +324,8 @@ struct K6Arrays {
     // groups of the components left to the host
     GroupRec* g_rec;               // pinned host
     uint32_t g_cap;
-    U4* ws_u4;
-    U4* total_u4;
+    unsigned long long* lb_state;  // look-back words of k6_finish_kernel's scan: [scan_grid(cap, 1)][4], zero at allocation
+    uint32_t lb_stamp;             // run stamp of those words (never 0, changes every run)
     StageCounts* counts;
     StageCounts* counts_host;      // pinned: all counters after k6_emit_kernel (k6_mirror_kernel, or the first wave of k6_walk_kernel)
     StageCounts* counts_host2;     // pinned: n_sv_dev / n_terms_dev / n_cn_dev / overflow after the compaction
@@ -350,9 +349,9 @@ void launch_k6_groups(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s);  
 // start values of the per-region scratch (out_deg, label = index, bad_v, bad, mcount, pcount) when no join kernel has set them
 void launch_k6_scratch_init(uint32_t* out_deg, uint32_t cap, hipStream_t s);
 void launch_k6_walk(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s);     // device-walked components -> SV staging
-void launch_k6_compact(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s);  // staging + host candidates -> final table
+// staging + host candidates -> final table in pinned host memory, scored (k6_insert_kernel, k6_finish_kernel)
+void launch_k6_table(const K6Arrays& a, uint32_t n_anom_host, double ln10, int score_threshold, int with_scores, hipStream_t s);
 // ComputeProbScore's combination (BreakDancer.cpp:56-69) + PhredQ (:459-465) for every candidate of the final table
-void launch_k6_score(const K6Arrays& a, double ln10, int score_threshold, int with_scores, hipStream_t s);
-uint32_t k6_score_grid(const K6Arrays& a);  // workgroups of k6_score_kernel == entries of K6Arrays::printed_host
+uint32_t k6_score_grid(const K6Arrays& a);  // workgroups of k6_finish_kernel == entries of K6Arrays::printed_host
 
 }  // namespace bdx

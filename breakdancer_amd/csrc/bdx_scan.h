@@ -179,20 +179,12 @@ template <> struct ScanCols<U4> {
     __device__ static __forceinline__ void set(U4& v, int c, uint32_t x) { if (c == 0) v.x = x; else if (c == 1) v.y = x; else if (c == 2) v.z = x; else v.w = x; }
 };
 
-template <class T, class In, class Out>
-__global__ __launch_bounds__(kScanBlock) void scan_lookback(In in, Out out, const uint32_t* n_ptr, unsigned long long* state, uint32_t stamp) {
+// The walk itself, for kernels that do more with their prefix than one output per element: every thread of workgroup `bid`
+// calls it with the workgroup's total; it returns the workgroup's exclusive prefix (the same value in all threads).
+template <class T>
+__device__ __forceinline__ T lookback_exclusive(const T& tot, unsigned long long* state, uint32_t stamp, uint32_t bid, uint32_t* s_prefix /* LDS [columns] */) {
     constexpr int kCols = ScanCols<T>::n;
     constexpr int kWin = 64 / kCols;  // predecessors per look-back step
-    __shared__ T s_ws[kScanBlock / 64];
-    __shared__ uint32_t s_prefix[kCols];
-    const uint32_t n = *n_ptr;
-    const uint32_t bid = blockIdx.x;
-    const uint32_t base = bid * kScanBlock;
-    if (base >= n) return;
-    const uint32_t j = base + threadIdx.x;
-    const T e = j < n ? in(j, n) : zero_of<T>();
-    T tot;
-    const T inc_local = block_incl_scan(e, s_ws, &tot);
     const unsigned long long stamp_bits = (unsigned long long)(stamp & 0x3FFFFFFFu) << 32;
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
@@ -235,6 +227,22 @@ __global__ __launch_bounds__(kScanBlock) void scan_lookback(In in, Out out, cons
         __hip_atomic_store(&state[(size_t)bid * kCols + threadIdx.x],
                            (unsigned long long)(s_prefix[threadIdx.x] + ScanCols<T>::get(tot, threadIdx.x)) | stamp_bits | (2ull << 62), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
+    return carry;
+}
+
+template <class T, class In, class Out>
+__global__ __launch_bounds__(kScanBlock) void scan_lookback(In in, Out out, const uint32_t* n_ptr, unsigned long long* state, uint32_t stamp) {
+    __shared__ T s_ws[kScanBlock / 64];
+    __shared__ uint32_t s_prefix[ScanCols<T>::n];
+    const uint32_t n = *n_ptr;
+    const uint32_t bid = blockIdx.x;
+    const uint32_t base = bid * kScanBlock;
+    if (base >= n) return;
+    const uint32_t j = base + threadIdx.x;
+    const T e = j < n ? in(j, n) : zero_of<T>();
+    T tot;
+    const T inc_local = block_incl_scan(e, s_ws, &tot);
+    const T carry = lookback_exclusive<T>(tot, state, stamp, bid, s_prefix);
     if (j < n) out(j, n, carry + inc_local, e);
 }
 

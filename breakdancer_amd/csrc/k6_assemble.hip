@@ -28,6 +28,13 @@
 
 namespace bdx {
 
+#ifdef BDX_KPROF
+__device__ unsigned long long g_kprof[8 * 65536];
+#define KPROF(row, col) do { if ((threadIdx.x & 63) == 0 && (row) < 65536u) g_kprof[(size_t)(row) * 8 + (col)] = wall_clock64(); } while (0)
+#else
+#define KPROF(row, col) do {} while (0)
+#endif
+
 namespace {
 
 __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
@@ -388,9 +395,10 @@ namespace {
 // process_sv (BreakDancer.cpp:348-497) + SvBuilder for region A (and B when B >= 0) over the alive groups gs[0..2] =
 // (A,A), (A,B), (B,B).  Returns false when a gate rejects the candidate; otherwise the record and its entries are
 // written to the staging slot (by the lane with `store` set).
+template <class FlagCounts>
 __device__ bool assemble_sv(const K6Arrays& a, const PartRec* P, uint32_t A, int32_t B, const RegionRec& ra, const RegionRec& rb,
                             const uint32_t* pk_last_a, const uint32_t* pk_first_b, const GrpRange (&gs)[3], int max_readlen,
-                            uint32_t slot, uint32_t start, bool store, int* flag_counts /* [kNumFlags], LDS */, uint32_t* nacc_out,
+                            uint32_t slot, uint32_t start, bool store, FlagCounts flag_counts /* [kNumFlags], LDS: int* or StridedCounts */, uint32_t* nacc_out,
                             uint32_t* ncn_out) {
     const uint32_t lib_room = a.lib_stride;
     const int mrp = a.min_read_pair;
@@ -587,14 +595,9 @@ __global__ __launch_bounds__(64) void k6_mirror_kernel(K6Arrays a) {
     }
 }
 
-// One WAVE per region.  Every lane runs the same scalar code, so the data-dependent control flow of the walk does not
-// diverge; the lanes only split up to fetch the component's description (written next to its label by
-// k6_classify_kernel), its parts and its normal-read samples into LDS in one round trip each, and lane 0 stores.
-// The smallest region of a device-walked component replays build_connection over it.
 // order key of a candidate that is placed by key (see K6Arrays)
 constexpr int kKeyShiftT = 34, kKeyShiftStart = 7;
 constexpr uint32_t kKeySeqMask = 127u;
-constexpr int kK6LdsPk = 16;  // 2 x nkeys words per member kept in LDS (more keys: read from HBM)
 
 // The general path of the walk: a component of up to kK6BigMembers (64) regions, its members' records in LDS and the groups
 // found through each member's list of incoming groups instead of a table of all pairs.  Same replay as the main path
@@ -739,31 +742,50 @@ __device__ __forceinline__ void walk_big(const K6Arrays& a, BigTab& B, int* flag
     }
 }
 
-__global__ __launch_bounds__(256) void k6_walk_kernel(K6Arrays a) {
-    __shared__ uint32_t s_desc[4][kK6MaxMembers * kMemberWords];
-    __shared__ PartRec s_parts[4][kK6LdsParts];
-    __shared__ uint32_t s_pk[4][kK6MaxMembers * kK6LdsPk];
-    // the walk's small tables are indexed by run-time values: in LDS (every lane writes the same word) they cost a few
-    // cycles, as private arrays they would live in scratch memory
-    struct Tables {
-        GrpRange S[kK6MaxMembers], E[6];
-        uint32_t Sw[kK6MaxMembers], Ew[6], Sslot[kK6MaxMembers], Eslot[6];
-        int ord[kK6MaxMembers], tails[12], newtails[12], flag_counts[kNumFlags];
-    };
-    __shared__ Tables s_tab[4];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    Tables& T = s_tab[w];
-    GrpRange* const S = T.S;
-    GrpRange* const E = T.E;
-    uint32_t* const Sw = T.Sw;
-    uint32_t* const Ew = T.Ew;
-    uint32_t* const Sslot = T.Sslot;
-    uint32_t* const Eslot = T.Eslot;
-    int* const ord = T.ord;
-    int* const tails = T.tails;
-    int* const newtails = T.newtails;
-    const uint32_t nwaves = gridDim.x * 4;
-    if (a.mirror_in_walk && blockIdx.x == 0 && w == 0) {
+// The walk's small tables are indexed by run-time values: as private arrays they would live in scratch memory.  Every lane
+// owns one column of a wave-wide LDS table instead: field f of lane l at word f * 64 + l (no bank conflict when the lanes
+// touch the same field, which they mostly do).
+struct WalkTab {
+    uint32_t* p;  // this lane's column
+    static constexpr int kSbeg = 0, kScnt = 4, kEbeg = 8, kEcnt = 14, kSw = 20, kEw = 24, kSslot = 30, kEslot = 34, kOrd = 40, kRid = 44,
+                         kTails = 48, kNewTails = 60, kCalls = 72, kFlags = 82, kFields = 82 + kNumFlags;
+    __device__ __forceinline__ uint32_t& at(int f) const { return p[f * 64]; }
+    __device__ __forceinline__ uint32_t& Sbeg(int i) const { return at(kSbeg + i); }
+    __device__ __forceinline__ uint32_t& Scnt(int i) const { return at(kScnt + i); }
+    __device__ __forceinline__ uint32_t& Ebeg(int e) const { return at(kEbeg + e); }
+    __device__ __forceinline__ uint32_t& Ecnt(int e) const { return at(kEcnt + e); }
+    __device__ __forceinline__ uint32_t& Sw(int i) const { return at(kSw + i); }
+    __device__ __forceinline__ uint32_t& Ew(int e) const { return at(kEw + e); }
+    __device__ __forceinline__ uint32_t& Sslot(int i) const { return at(kSslot + i); }
+    __device__ __forceinline__ uint32_t& Eslot(int e) const { return at(kEslot + e); }
+    __device__ __forceinline__ uint32_t& ord(int i) const { return at(kOrd + i); }    // member (registration order) at place i of the ascending order
+    __device__ __forceinline__ uint32_t& rid(int i) const { return at(kRid + i); }    // its region
+    __device__ __forceinline__ uint32_t& tails(int t) const { return at(kTails + t); }
+    __device__ __forceinline__ uint32_t& newtails(int t) const { return at(kNewTails + t); }
+    __device__ __forceinline__ uint32_t& call(int c) const { return at(kCalls + c); } // the walk's process_sv calls, in order (every group makes at most one)
+};
+struct StridedCounts {  // the lane's flag counters inside its column
+    uint32_t* p;
+    __device__ __forceinline__ int& operator[](int f) const { return *(int*)(p + f * 64); }
+};
+static_assert(kK6MaxMembers == 4 && kK6MaxIn == 3, "WalkTab layout");
+
+// One LANE per component of at most kK6MaxMembers regions, in three converged phases:
+//   0  the component's description (k6_classify_kernel wrote it next to its label) -> the lane's tables, every load of it
+//      issued at once (static indices, registers are free: the kernel needs ~140 waves);
+//   1  the traversal itself -- build_connection's flushes, start vertices, frontier, neighbours in ascending order, every
+//      group consumed by the side that reaches it first -- on the lane's tables only (LDS + registers: its data-dependent
+//      control flow diverges between the lanes, but no memory latency sits inside it); every process_sv call it would make
+//      is recorded instead (which groups are alive at that moment decides what the call sees);
+//   2  the recorded calls, in order: call c of all 64 components side by side (assemble_sv with its dependent loads runs
+//      converged), then the bookkeeping of the traversal the call belongs to.
+// (History: one wave per component, 64 lanes running the same scalar code, took ~8,900 waves of 127 registers for configs[1] --
+// three rounds of ~7 us on the 4,096 wave slots, 37 us; one lane per component with the calls made inside the traversal
+// loops, 40 us: 64 walks reach their calls at different iterations and every one of those pays its own round trips.)
+__global__ __launch_bounds__(64) void k6_walk_kernel(K6Arrays a) {
+    __shared__ uint32_t s_tab[WalkTab::kFields * 64];
+    const int lane = threadIdx.x;
+    if (a.mirror_in_walk && blockIdx.x == 0) {
         // k6_mirror_kernel's job, done by the first wave of the kernel that follows k6_emit_kernel anyway: the counters are
         // final (kernel boundary), they go to the host's record and the word the host polls is set behind them
         if (lane < (int)(sizeof(StageCounts) / 4)) ((uint32_t*)a.counts_host)[lane] = ((const uint32_t*)a.counts)[lane];
@@ -771,166 +793,192 @@ __global__ __launch_bounds__(256) void k6_walk_kernel(K6Arrays a) {
         __builtin_amdgcn_wave_barrier();
         if (lane == 0 && a.flag_groups) *(volatile uint32_t*)a.flag_groups = a.flag_value;
     }
+    const WalkTab T{s_tab + lane};
+    const StridedCounts flag_counts{s_tab + WalkTab::kFlags * 64 + lane};
     const uint32_t NR = a.counts->n_regions;
     const int mrp = a.min_read_pair;
     const int nk = a.nkeys;
     const uint32_t period = (uint32_t)a.period;
+    KPROF(blockIdx.x, 0);
     const uint32_t n_owners = a.counts->n_owners;
-    for (uint32_t oi = blockIdx.x * 4 + w; oi < n_owners; oi += nwaves) {
+    const PartRec* const P = a.parts;
+    for (uint32_t oi = blockIdx.x * 64 + lane; oi < n_owners; oi += gridDim.x * 64) {
         const uint32_t r = a.owners[oi];  // smallest region of a component that is walked here (k6_emit_kernel's list)
         const int k = (int)a.mcount[r];
-        {   // the component's description: one coalesced fetch
-            const uint32_t* src = (const uint32_t*)(a.members + (size_t)r * kK6MaxMembers);
-            for (int i = lane; i < k * kMemberWords; i += 64) s_desc[w][i] = src[i];
-        }
-        __builtin_amdgcn_wave_barrier();
-        const MemberInfo* D = (const MemberInfo*)s_desc[w];
-        for (int i = 0; i < k; ++i) ord[i] = i;  // members in ascending region order
-        for (int i = 1; i < k; ++i) {  // insertion sort, k <= 4
-            const int x = ord[i];
-            int j = i;
-            while (j > 0 && D[ord[j - 1]].r > D[x].r) { ord[j] = ord[j - 1]; --j; }
-            ord[j] = x;
-        }
-        for (int e = 0; e < 6; ++e) { E[e] = GrpRange{0, 0}; Ew[e] = 0; Eslot[e] = 0; }
-        for (int i = 0; i < k; ++i) {
-            const MemberInfo& M = D[ord[i]];
-            S[i] = GrpRange{M.rec.first + M.np_all - M.np_self, M.np_self};
-            Sw[i] = M.w_self;
-            Sslot[i] = M.rec.first + M.n_in;
-            for (uint32_t e = 0; e < M.n_in; ++e) {
-                int x = 0;
-                while (x < i && D[ord[x]].r != M.e_lo[e]) ++x;  // the closure check guarantees it is a member
-                if (x < i) {
-                    const int pi = pair_index(x, i);
-                    E[pi] = GrpRange{M.rec.first + M.e_off[e], M.e_cnt[e]};
-                    Ew[pi] = M.e_w[e];
-                    Eslot[pi] = M.rec.first + e;
-                }
-            }
-        }
-        // the parts the walk can touch: into LDS when they fit, one lane per part
-        const PartRec* P = a.parts;
+        const MemberInfo* D = a.members + (size_t)r * kK6MaxMembers;
+        // ---- phase 0 ----------------------------------------------------------------------------------------------------
+        uint32_t stored = 0;  // bit i: the reads of the member at place i are stored (ReadRegionData.cpp:118-121)
         {
-            uint32_t n_rel = 0;
-            for (int i = 0; i < k; ++i) n_rel += S[i].cnt;
-            for (int e = 0; e < 6; ++e) n_rel += E[e].cnt;
-            if (n_rel <= (uint32_t)kK6LdsParts) {
-                uint32_t o = 0;
-                for (int i = 0; i < k; ++i) {
-                    if ((uint32_t)lane >= o && (uint32_t)lane < o + S[i].cnt) s_parts[w][lane] = a.parts[S[i].beg + (lane - o)];
-                    S[i].beg = o;
-                    o += S[i].cnt;
-                }
-                for (int e = 0; e < 6; ++e) {
-                    if ((uint32_t)lane >= o && (uint32_t)lane < o + E[e].cnt) s_parts[w][lane] = a.parts[E[e].beg + (lane - o)];
-                    E[e].beg = o;
-                    o += E[e].cnt;
-                }
-                P = s_parts[w];
+            uint32_t mr[kK6MaxMembers], first[kK6MaxMembers], n_in[kK6MaxMembers], np_all[kK6MaxMembers], np_self[kK6MaxMembers],
+                w_self[kK6MaxMembers], st[kK6MaxMembers];
+            uint32_t e_lo[kK6MaxMembers][kK6MaxIn], e_w[kK6MaxMembers][kK6MaxIn], e_off[kK6MaxMembers][kK6MaxIn], e_cnt[kK6MaxMembers][kK6MaxIn];
+#pragma unroll
+            for (int i = 0; i < kK6MaxMembers; ++i) {
+                const bool h = i < k;
+                const MemberInfo& M = D[h ? i : 0];
+                mr[i] = h ? M.r : 0xFFFFFFFFu;
+                first[i] = M.rec.first; n_in[i] = h ? M.n_in : 0u; np_all[i] = M.np_all; np_self[i] = M.np_self; w_self[i] = M.w_self; st[i] = M.stored;
+#pragma unroll
+                for (int e = 0; e < kK6MaxIn; ++e) { e_lo[i][e] = M.e_lo[e]; e_w[i][e] = M.e_w[e]; e_off[i][e] = M.e_off[e]; e_cnt[i][e] = M.e_cnt[e]; }
             }
-        }
-        // proper-read samples of the members (first read: nkeys words, last read: nkeys words)
-        const bool pk_lds = 2 * nk <= kK6LdsPk;
-        if (pk_lds)
-            for (int i = lane; i < k * 2 * nk; i += 64) {
-                const int mi = i / (2 * nk), q = i - mi * 2 * nk;
-                s_pk[w][mi * kK6LdsPk + q] = a.r_pk[(size_t)D[ord[mi]].r * 2 * nk + q];
+            // members in ascending region order: a member's place is the number of members with a smaller region
+            int place[kK6MaxMembers];
+#pragma unroll
+            for (int i = 0; i < kK6MaxMembers; ++i) {
+                place[i] = 0;
+#pragma unroll
+                for (int q = 0; q < kK6MaxMembers; ++q) place[i] += mr[q] < mr[i] ? 1 : 0;  // (regions differ)
             }
-        __builtin_amdgcn_wave_barrier();
-
-        uint32_t self_done = 0, edge_done = 0, self_alive = 0, edge_alive = 0;
-        for (int i = 0; i < k; ++i)
-            if (S[i].cnt) self_alive |= 1u << i;
-        for (int e = 0; e < 6; ++e)
-            if (E[e].cnt) edge_alive |= 1u << e;
-        const GrpRange none{0, 0};
-        // One flush (BreakDancer.cpp:266-346) per window that holds members, in ascending order.  A group is part of
-        // the flush of its later region's window; the flush starts traversals first from the members of earlier windows
-        // that have a group in it, then from the window's own members, each in ascending order.
-        for (int f = 0; f < k;) {
-            const uint32_t W = D[ord[f]].r / period;
-            int fe = f + 1;
-            while (fe < k && D[ord[fe]].r / period == W) ++fe;
-            // _max_readlen at this window's flush: the value of the candidate that closes there (BreakDancer.cpp:254-259)
-            const uint32_t rl = (W + 1) * period - 1;
-            const int max_readlen = rl < NR ? a.r_rec[rl].maxq : a.counts->last_maxq;
-            uint32_t visited = 0, nseq = 0;
-            for (int sv = 0; sv < fe; ++sv) {
-                if (visited & (1u << sv)) continue;
-                const bool from_old = sv < f;
-                const uint32_t start = D[ord[sv]].r;
-                uint32_t nsv = 0, nacc_tot = 0, ncn_tot = 0, prev_slot = 0;
-                int nt = 1, nn = 0;
-                tails[0] = sv;
-                while (nt) {
-                    nn = 0;
-                    for (int ti = 0; ti < nt; ++ti) {
-                        const int tail = tails[ti];
-                        if (visited & (1u << tail)) continue;
-                        for (int nb = 0; nb < fe; ++nb) {  // neighbours in ascending order, the vertex itself at its own place
-                            int A, B;
-                            uint32_t slot;
-                            if (nb == tail) {
-                                if (tail < f) continue;  // its self group belonged to an earlier flush
-                                if (!S[tail].cnt || (self_done & (1u << tail)) || (int)Sw[tail] < mrp) continue;
-                                self_done |= 1u << tail;
-                                A = tail; B = -1;
-                                slot = Sslot[tail];
-                            } else {
-                                const int x = min(nb, tail), y = max(nb, tail), pi = pair_index(x, y);
-                                if (y < f) continue;     // a group of an earlier flush
-                                if (!E[pi].cnt || (edge_done & (1u << pi)) || (int)Ew[pi] < mrp) continue;
-                                edge_done |= 1u << pi;
-                                A = x; B = y;
-                                slot = Eslot[pi];
-                            }
-                            if (nn < 12) newtails[nn++] = nb;
-                            const MemberInfo& MA = D[ord[A]];
-                            const MemberInfo& MB = D[ord[B >= 0 ? B : A]];
-                            GrpRange gs[3] = {none, none, none};
-                            if ((self_alive & (1u << A)) && MA.stored) gs[0] = S[A];
-                            if (B >= 0) {
-                                const int pi = pair_index(A, B);
-                                if ((edge_alive & (1u << pi)) && MA.stored && MB.stored) gs[1] = E[pi];
-                                if ((self_alive & (1u << B)) && MB.stored) gs[2] = S[B];
-                            }
-                            // paired reads leave their regions before any gate (BreakDancer.cpp:363-368)
-                            if (gs[0].cnt) self_alive &= ~(1u << A);
-                            if (gs[1].cnt) edge_alive &= ~(1u << pair_index(A, B));
-                            if (gs[2].cnt) self_alive &= ~(1u << B);
-                            const uint32_t* pkA = pk_lds ? &s_pk[w][A * kK6LdsPk + nk] : a.r_pk + (size_t)MA.r * 2 * nk + nk;
-                            const uint32_t* pkB = pk_lds ? &s_pk[w][(B >= 0 ? B : A) * kK6LdsPk] : a.r_pk + (size_t)MB.r * 2 * nk;
-                            uint32_t nacc = 0, ncn = 0;
-                            if (assemble_sv(a, P, MA.r, B >= 0 ? (int32_t)MB.r : -1, MA.rec, MB.rec, pkA, pkB, gs, max_readlen, slot, start,
-                                            lane == 0, T.flag_counts, &nacc, &ncn)) {
-                                if (from_old) {  // placed by its order key: after the earlier windows, before this window's own
-                                    if (lane == 0) {
-                                        const uint32_t q = atomicAdd(&a.counts->n_old, 1u);
-                                        a.old_key[q] = ((uint64_t)(W * period) << kKeyShiftT) | ((uint64_t)start << kKeyShiftStart) | (uint64_t)(nseq & kKeySeqMask);
-                                        a.old_slot[q] = slot;
-                                    }
-                                    ++nseq;
-                                } else if (lane == 0) {
-                                    if (nsv == 0) a.own_first[start] = slot; else a.slot_next[prev_slot] = slot;
-                                }
-                                prev_slot = slot;
-                                ++nsv;
-                                nacc_tot += nacc;
-                                ncn_tot += ncn;
+            for (int e = 0; e < 6; ++e) { T.Ebeg(e) = 0; T.Ecnt(e) = 0; T.Ew(e) = 0; T.Eslot(e) = 0; }
+#pragma unroll
+            for (int i = 0; i < kK6MaxMembers; ++i) {
+                if (i < k) {
+                    const int pl = place[i];
+                    T.ord(pl) = (uint32_t)i;
+                    T.rid(pl) = mr[i];
+                    T.Sbeg(pl) = first[i] + np_all[i] - np_self[i];
+                    T.Scnt(pl) = np_self[i];
+                    T.Sw(pl) = w_self[i];
+                    T.Sslot(pl) = first[i] + n_in[i];
+                    stored |= (st[i] ? 1u : 0u) << pl;
+#pragma unroll
+                    for (int e = 0; e < kK6MaxIn; ++e) {
+                        if ((uint32_t)e < n_in[i]) {
+                            int x = -1;  // place of the member that is the group's earlier region (the closure check guarantees there is one)
+#pragma unroll
+                            for (int q = 0; q < kK6MaxMembers; ++q)
+                                if (mr[q] == e_lo[i][e]) x = place[q];
+                            if (x >= 0 && x < pl) {
+                                const int pi = pair_index(x, pl);
+                                T.Ebeg(pi) = first[i] + e_off[i][e];
+                                T.Ecnt(pi) = e_cnt[i][e];
+                                T.Ew(pi) = e_w[i][e];
+                                T.Eslot(pi) = first[i] + (uint32_t)e;
                             }
                         }
-                        visited |= 1u << tail;
                     }
-                    nt = nn;
-                    for (int i = 0; i < nn; ++i) tails[i] = newtails[i];
                 }
-                if (!from_old && nsv && lane == 0) { a.own_nsv[start] = nsv; a.own_nacc[start] = nacc_tot; a.own_ncn[start] = ncn_tot; }
             }
-            f = fe;
         }
-        __builtin_amdgcn_wave_barrier();  // the LDS slices are reused by the wave's next region
+        KPROF(blockIdx.x, 1);
+        // ---- phase 1 ----------------------------------------------------------------------------------------------------
+        int ncalls = 0;
+        {
+            uint32_t self_done = 0, edge_done = 0, self_alive = 0, edge_alive = 0;
+            for (int i = 0; i < k; ++i)
+                if (T.Scnt(i)) self_alive |= 1u << i;
+            for (int e = 0; e < 6; ++e)
+                if (T.Ecnt(e)) edge_alive |= 1u << e;
+            // One flush (BreakDancer.cpp:266-346) per window that holds members, in ascending order.  A group is part of
+            // the flush of its later region's window; the flush starts traversals first from the members of earlier windows
+            // that have a group in it, then from the window's own members, each in ascending order.
+            for (int f = 0; f < k;) {
+                const uint32_t W = T.rid(f) / period;
+                int fe = f + 1;
+                while (fe < k && T.rid(fe) / period == W) ++fe;
+                uint32_t visited = 0;
+                for (int sv = 0; sv < fe; ++sv) {
+                    if (visited & (1u << sv)) continue;
+                    int nt = 1, nn = 0;
+                    T.tails(0) = (uint32_t)sv;
+                    while (nt) {
+                        nn = 0;
+                        for (int ti = 0; ti < nt; ++ti) {
+                            const int tail = (int)T.tails(ti);
+                            if (visited & (1u << tail)) continue;
+                            for (int nb = 0; nb < fe; ++nb) {  // neighbours in ascending order, the vertex itself at its own place
+                                int A, B;
+                                if (nb == tail) {
+                                    if (tail < f) continue;  // its self group belonged to an earlier flush
+                                    if (!T.Scnt(tail) || (self_done & (1u << tail)) || (int)T.Sw(tail) < mrp) continue;
+                                    self_done |= 1u << tail;
+                                    A = tail; B = -1;
+                                } else {
+                                    const int x = min(nb, tail), y = max(nb, tail), pi = pair_index(x, y);
+                                    if (y < f) continue;     // a group of an earlier flush
+                                    if (!T.Ecnt(pi) || (edge_done & (1u << pi)) || (int)T.Ew(pi) < mrp) continue;
+                                    edge_done |= 1u << pi;
+                                    A = x; B = y;
+                                }
+                                if (nn < 12) T.newtails(nn++) = (uint32_t)nb;
+                                // the groups the call sees: (A,A), (A,B), (B,B) as far as they are alive and their reads stored;
+                                // paired reads leave their regions before any gate (BreakDancer.cpp:363-368)
+                                const bool stA = (stored >> A) & 1u, stB = (stored >> (B >= 0 ? B : A)) & 1u;
+                                uint32_t g = 0;
+                                if ((self_alive & (1u << A)) && stA) { g |= 1u; self_alive &= ~(1u << A); }
+                                if (B >= 0) {
+                                    const int pi = pair_index(A, B);
+                                    if ((edge_alive & (1u << pi)) && stA && stB) { g |= 2u; edge_alive &= ~(1u << pi); }
+                                    if ((self_alive & (1u << B)) && stB) { g |= 4u; self_alive &= ~(1u << B); }
+                                }
+                                T.call(ncalls++) = (uint32_t)A | ((uint32_t)(B + 1) << 2) | (g << 5) | ((uint32_t)sv << 8) | ((uint32_t)f << 10);
+                            }
+                            visited |= 1u << tail;
+                        }
+                        nt = nn;
+                        for (int i = 0; i < nn; ++i) T.tails(i) = T.newtails(i);
+                    }
+                }
+                f = fe;
+            }
+        }
+        KPROF(blockIdx.x, 2);
+        // ---- phase 2 ----------------------------------------------------------------------------------------------------
+        {
+            const GrpRange none{0, 0};
+            int cur_f = -1, cur_sv = -1, max_readlen = 0;
+            uint32_t W = 0, start = 0, nseq = 0, nsv = 0, nacc_tot = 0, ncn_tot = 0, prev_slot = 0;
+            bool from_old = false;
+            for (int c = 0; c < ncalls; ++c) {
+                const uint32_t d = T.call(c);
+                const int A = (int)(d & 3u), B = (int)((d >> 2) & 7u) - 1, sv = (int)((d >> 8) & 3u), f = (int)((d >> 10) & 3u);
+                const uint32_t g = (d >> 5) & 7u;
+                if (f != cur_f) {
+                    // _max_readlen at this window's flush: the value of the candidate that closes there (BreakDancer.cpp:254-259)
+                    W = T.rid(f) / period;
+                    const uint32_t rl = (W + 1) * period - 1;
+                    max_readlen = rl < NR ? a.r_rec[rl].maxq : a.counts->last_maxq;
+                    nseq = 0;
+                }
+                if (f != cur_f || sv != cur_sv) {  // the first call of another traversal
+                    if (cur_f >= 0 && !from_old && nsv) { a.own_nsv[start] = nsv; a.own_nacc[start] = nacc_tot; a.own_ncn[start] = ncn_tot; }
+                    cur_f = f; cur_sv = sv;
+                    start = T.rid(sv);
+                    from_old = sv < f;
+                    nsv = 0; nacc_tot = 0; ncn_tot = 0; prev_slot = 0;
+                }
+                const uint32_t slot = B >= 0 ? T.Eslot(pair_index(A, B)) : T.Sslot(A);
+                const int Bi = B >= 0 ? B : A;
+                GrpRange gs[3] = {none, none, none};
+                if (g & 1u) gs[0] = GrpRange{T.Sbeg(A), T.Scnt(A)};
+                if (g & 2u) gs[1] = GrpRange{T.Ebeg(pair_index(A, Bi)), T.Ecnt(pair_index(A, Bi))};
+                if (g & 4u) gs[2] = GrpRange{T.Sbeg(Bi), T.Scnt(Bi)};
+                const MemberInfo& MA = D[T.ord(A)];
+                const MemberInfo& MB = D[T.ord(Bi)];
+                const uint32_t rA = T.rid(A), rB = T.rid(Bi);
+                // proper-read samples of the two regions (first read: nkeys words, last read: nkeys words)
+                const uint32_t* pkA = a.r_pk + (size_t)rA * 2 * nk + nk;
+                const uint32_t* pkB = a.r_pk + (size_t)rB * 2 * nk;
+                uint32_t nacc = 0, ncn = 0;
+                if (assemble_sv(a, P, rA, B >= 0 ? (int32_t)rB : -1, MA.rec, MB.rec, pkA, pkB, gs, max_readlen, slot, start, true, flag_counts, &nacc, &ncn)) {
+                    if (from_old) {  // placed by its order key: after the earlier windows, before this window's own
+                        const uint32_t q = atomicAdd(&a.counts->n_old, 1u);
+                        a.old_key[q] = ((uint64_t)(W * period) << kKeyShiftT) | ((uint64_t)start << kKeyShiftStart) | (uint64_t)(nseq & kKeySeqMask);
+                        a.old_slot[q] = slot;
+                        ++nseq;
+                    } else {
+                        if (nsv == 0) a.own_first[start] = slot; else a.slot_next[prev_slot] = slot;
+                    }
+                    prev_slot = slot;
+                    ++nsv;
+                    nacc_tot += nacc;
+                    ncn_tot += ncn;
+                }
+            }
+            if (cur_f >= 0 && !from_old && nsv) { a.own_nsv[start] = nsv; a.own_nacc[start] = nacc_tot; a.own_ncn[start] = ncn_tot; }
+        }
     }
+    KPROF(blockIdx.x, 3);
 }
 
 // the components of more than kK6MaxMembers regions (its own launch: inside the kernel above its registers and LDS
@@ -945,11 +993,6 @@ __global__ __launch_bounds__(256) void k6_walk_big_kernel(K6Arrays a) {
         __builtin_amdgcn_wave_barrier();
     }
 }
-
-struct OwnIn {
-    const uint32_t *nsv, *nacc, *ncn;
-    __device__ U4 operator()(uint32_t i, uint32_t) const { return U4{nsv[i], nacc[i], ncn[i], 0u}; }
-};
 
 namespace {
 __device__ __forceinline__ uint32_t count_below(const uint32_t* v, uint32_t n, uint32_t x) {  // #elements < x, v ascending
@@ -972,8 +1015,7 @@ __device__ __forceinline__ uint32_t count_below64(const uint64_t* v, uint32_t n,
 
 // The candidates that are placed by order key -- the host walk's list (sorted, pinned host memory) and the device's
 // candidates from traversals started at a vertex of an earlier window (k6_walk_kernel's list, any order) -- merged into
-// one list sorted by key, with the running totals of their list entries.  One workgroup (an extra one of the
-// compaction scan's first phase): sort the device's list
+// one list sorted by key, with the running totals of their list entries.  One workgroup (k6_insert_kernel): sort the device's list
 // (bitonic, in LDS when it fits), then every entry finds its place by a binary search in the other list (no key occurs
 // in both: a start vertex belongs to one component, and that is walked either here or by the host).
 constexpr uint32_t kInsLds = 2048;
@@ -1123,161 +1165,191 @@ __device__ void InsertJob::operator()() const {
     if (tid == 0) { a.ins_pre_l[n] = carry_l; a.ins_pre_c[n] = carry_c; }
 }
 
-// Third phase of the scan over the start vertices: the final table.  Vertex i first places the candidates of the
-// inserted list whose threshold is i, then those of the traversal that started at i in i's own window.
-struct OwnOut {
-    K6Arrays a;
-    __device__ void put_entries(uint32_t lb, uint32_t cb, int32_t nl, int32_t ncn, const LibStage* ls, const CnStage* cs) const {
-        for (int32_t t = 0; t < nl; ++t) {
-            const LibStage l = ls[t];
-            a.d_lib_index[lb + t] = l.lib;
-            a.t_lambda[lb + t] = l.lambda;
-            a.t_k[lb + t] = l.rc;
-        }
-        for (int32_t t = 0; t < ncn; ++t) {
-            const CnStage cn = cs[t];
-            a.d_cn_key[cb + t] = cn.key;
-            a.d_cn_value[cb + t] = cn.value;
-        }
-    }
-    __device__ void put_staged(uint32_t pos, uint32_t lb, uint32_t cb, uint32_t slot, int32_t nl, int32_t ncn) const {
-        put_entries(lb, cb, nl, ncn, a.lib_stage + (size_t)slot * a.lib_stride, a.cn_stage + (size_t)slot * a.nkeys);
-        a.sv_src[pos] = slot;
-        a.sv_begin[pos] = make_uint2(lb, cb);
-    }
-    __device__ void operator()(uint32_t i, uint32_t n, const U4& inc, const U4& e) const {
-        const uint32_t nh = a.counts->n_ins;
-        const uint32_t hb0 = nh ? count_below(a.ins_T, nh, i) : 0u;
-        uint32_t hb1 = hb0;  // (entries with threshold i follow each other: one look ahead instead of a second search)
-        while (hb1 < nh && a.ins_T[hb1] == i) ++hb1;
-        const uint32_t h_l = a.ins_pre_l[nh], h_c = a.ins_pre_c[nh];
-        const uint32_t ex_sv = inc.x - e.x, ex_l = inc.y - e.y, ex_c = inc.z - e.z;
-        if (i == n - 1) {
-            const uint32_t tsv = inc.x + nh, tl = inc.y + h_l, tc = inc.z + h_c;
-            a.counts->n_sv_dev = tsv; a.counts->n_terms_dev = tl; a.counts->n_cn_dev = tc;
-            if (a.counts_host2) { a.counts_host2->n_sv_dev = tsv; a.counts_host2->n_terms_dev = tl; a.counts_host2->n_cn_dev = tc; a.counts_host2->n_old = a.counts->n_old; }
-            if (tsv > a.sv_cap || tl > a.term_cap || tc > a.cn_cap) {
-                a.counts->overflow = 1;
-                if (a.counts_host2) a.counts_host2->overflow = 1;
-            }
-        }
-        if (hb1 == hb0 && !e.x) return;
-        if (inc.x + nh > a.sv_cap || inc.y + h_l > a.term_cap || inc.z + h_c > a.cn_cap) return;  // reported by the last vertex
-        for (uint32_t j = hb0; j < hb1; ++j) {  // the inserted candidates that come right before this vertex's own
-            const uint32_t pos = ex_sv + j, lb = ex_l + a.ins_pre_l[j], cb = ex_c + a.ins_pre_c[j];
-            const uint32_t src = a.ins_src[j];
-            if (!(src & 0x80000000u)) {
-                put_staged(pos, lb, cb, src, (int32_t)(a.ins_pre_l[j + 1] - a.ins_pre_l[j]), (int32_t)(a.ins_pre_c[j + 1] - a.ins_pre_c[j]));
-                continue;
-            }
-            const bdx_sv* o = &a.hs_rec[src & 0x7FFFFFFFu].sv;
-            const int32_t l0 = o->lib_begin, c0 = o->cn_begin;
-            const int32_t nl = (int32_t)(a.ins_pre_l[j + 1] - a.ins_pre_l[j]), ncn = (int32_t)(a.ins_pre_c[j + 1] - a.ins_pre_c[j]);
-            for (int32_t t = 0; t < nl; ++t) {
-                a.d_lib_index[lb + t] = a.hs_lib_index[l0 + t];
-                a.t_lambda[lb + t] = a.hs_lambda[l0 + t];
-                a.t_k[lb + t] = a.hs_lib_pairs[l0 + t];
-            }
-            for (int32_t t = 0; t < ncn; ++t) {
-                a.d_cn_key[cb + t] = a.hs_cn_key[c0 + t];
-                a.d_cn_value[cb + t] = a.hs_cn_value[c0 + t];
-            }
-            a.sv_src[pos] = src;
-            a.sv_begin[pos] = make_uint2(lb, cb);
-        }
-        uint32_t d = ex_sv + hb1, lb = ex_l + a.ins_pre_l[hb1], cb = ex_c + a.ins_pre_c[hb1];
-        uint32_t slot = e.x ? a.own_first[i] : 0u;
-        for (uint32_t q = 0; q < e.x; ++q, slot = a.slot_next[slot]) {
-            const int32_t nl = a.sv_stage[slot].sv.lib_count, ncn = a.sv_stage[slot].sv.cn_count;
-            put_staged(d, lb, cb, slot, nl, ncn);
-            lb += (uint32_t)nl;
-            cb += (uint32_t)ncn;
-            ++d;
-        }
-    }
-};
-
-// K5 + score combination for the final table: the Poisson log tail of every (candidate, library) term
-// (bdx_poisson.h), their Kahan-compensated sum (BreakDancer.cpp:56-69),
-// PhredQ = min(99, int(-10 logp / ln 10 + 0.5)) (:459-465, NaN -> INT_MIN as cvttsd2si does), printed = PhredQ > -y.
-// A workgroup takes 64 candidates: their records go through LDS, get their scores there, and leave for pinned host
-// memory as one contiguous 6 KiB write (single scattered stores over PCIe are several times slower); the flat lists
-// follow with a grid-stride copy.
-constexpr int kScoreSvs = 64;
+// The final table, one launch: a decoupled look-back scan over the start vertices gives every workgroup the place of its
+// vertices' candidates in the table and in the two flat lists; the workgroup then finishes exactly that slice of the table --
+// K5 (the Poisson log tail of every (candidate, library) term, bdx_poisson.h), their Kahan-compensated sum
+// (BreakDancer.cpp:56-69), PhredQ = min(99, int(-10 logp / ln 10 + 0.5)) (:459-465, NaN -> INT_MIN as cvttsd2si does),
+// printed = PhredQ > -y -- and writes it to pinned host memory.  Vertex i first places the candidates of the inserted list
+// whose threshold is i, then those of the traversal that started at i in i's own window.
+// A wave takes 64 candidates at a time: their records go through LDS, get their scores there, and leave as one contiguous
+// 6 KiB write (single scattered stores over PCIe are several times slower); the list entries of a wave's candidates are
+// neighbours too.  (Three launches before: block sums, rescan + placement into HBM lists, score kernel; 52 us -> see DESIGN.md.)
 constexpr int kSvWords = sizeof(SvOut) / 4;
+constexpr uint32_t kFinList = 1024;  // candidates of a workgroup placed per pass (more: further passes)
+constexpr uint32_t kFinT = 1024;     // thresholds of the inserted list kept in LDS (more: searched in HBM)
 
-__global__ __launch_bounds__(256) void k6_score_kernel(K6Arrays a, double ln10, int score_threshold, int with_scores) {
-    __shared__ uint32_t s_rec[kScoreSvs * kSvWords];
+__global__ __launch_bounds__(kScanBlock) void k6_insert_kernel(K6Arrays a) { InsertJob{a}(); }
+
+__global__ __launch_bounds__(kScanBlock) void k6_finish_kernel(K6Arrays a, double ln10, int score_threshold, int with_scores) {
+    __shared__ U4 s_ws[kScanBlock / 64];
+    __shared__ uint32_t s_prefix[4];
+    __shared__ uint32_t s_T[kFinT];
+    __shared__ uint32_t s_from[kFinList];
+    __shared__ uint2 s_bg[kFinList];
+    __shared__ uint32_t s_rec[kScanBlock / 64][64 * kSvWords];
+    __shared__ uint32_t s_range[2];
     __shared__ uint32_t s_printed;
-    const uint32_t n = a.counts->n_sv_dev, nt = a.counts->n_terms_dev, nc = a.counts->n_cn_dev;
-    if (threadIdx.x == 0) s_printed = 0;
-    for (uint32_t base = blockIdx.x * kScoreSvs; base < n; base += gridDim.x * kScoreSvs) {  // (the grid is capped: stride over the table)
-        __syncthreads();
-        const uint32_t cnt = min((uint32_t)kScoreSvs, n - base);
-        uint2 bg = make_uint2(0u, 0u);  // (requested together with the gather below, used after it)
-        if (threadIdx.x < cnt) bg = a.sv_begin[base + threadIdx.x];
-        for (uint32_t i = threadIdx.x; i < cnt * kSvWords; i += 256) {  // gather the records from the staging slots / the host's list
-            const uint32_t sv = i / kSvWords, w = i - sv * kSvWords;
-            const uint32_t from = a.sv_src[base + sv];
-            const uint32_t* src = (from & 0x80000000u) ? (const uint32_t*)(a.hs_rec + (from & 0x7FFFFFFFu)) : (const uint32_t*)(a.sv_stage + from);
-            s_rec[i] = src[w];
+    const uint32_t tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const uint32_t n = a.counts->n_regions;
+    const uint32_t bid = blockIdx.x, base = bid * kScanBlock;
+    KPROF(32768u + bid * 4 + w, 0);
+    if (base >= n) {
+        if (tid == 0 && a.printed_host) a.printed_host[bid] = 0;
+        return;
+    }
+    if (tid == 0) s_printed = 0;
+    const uint32_t j = base + tid;
+    const bool valid = j < n;
+    const U4 e = valid ? U4{a.own_nsv[j], a.own_nacc[j], a.own_ncn[j], 0u} : U4{0u, 0u, 0u, 0u};
+    const uint32_t slot0 = valid ? a.own_first[j] : 0u;  // (meaningful when the vertex has candidates)
+    const uint32_t nh = a.counts->n_ins;
+    const uint32_t h_l = a.ins_pre_l[nh], h_c = a.ins_pre_c[nh];
+    const bool t_lds = nh <= kFinT;
+    if (t_lds)
+        for (uint32_t i = tid; i < nh; i += kScanBlock) s_T[i] = a.ins_T[i];
+    U4 tot;
+    const U4 inc_local = block_incl_scan(e, s_ws, &tot);  // (its barriers also publish s_T and s_printed)
+    KPROF(32768u + bid * 4 + w, 1);
+    const U4 carry = lookback_exclusive<U4>(tot, a.lb_state, a.lb_stamp, bid, s_prefix);
+    KPROF(32768u + bid * 4 + w, 2);
+    const U4 inc = carry + inc_local;
+    const uint32_t* Tt = t_lds ? s_T : a.ins_T;
+    uint32_t hb0 = 0, hb1 = 0;
+    if (valid && nh) {
+        hb0 = count_below(Tt, nh, j);
+        hb1 = hb0;  // (entries with threshold j follow each other: a look ahead instead of a second search)
+        while (hb1 < nh && Tt[hb1] == j) ++hb1;
+    }
+    const uint32_t ex_sv = inc.x - e.x, ex_l = inc.y - e.y, ex_c = inc.z - e.z;
+    if (valid && j == n - 1) {
+        const uint32_t tsv = inc.x + nh, tl = inc.y + h_l, tc = inc.z + h_c;
+        a.counts->n_sv_dev = tsv; a.counts->n_terms_dev = tl; a.counts->n_cn_dev = tc;
+        if (a.counts_host2) { a.counts_host2->n_sv_dev = tsv; a.counts_host2->n_terms_dev = tl; a.counts_host2->n_cn_dev = tc; a.counts_host2->n_old = a.counts->n_old; }
+        if (tsv > a.sv_cap || tl > a.term_cap || tc > a.cn_cap) {
+            a.counts->overflow = 1;
+            if (a.counts_host2) a.counts_host2->overflow = 1;
+        }
+    }
+    // the workgroup's slice of the table: [P0, P1) (nothing is placed past a capacity: the last vertex reports that)
+    const bool wg_ok = !(carry.x + tot.x + nh > a.sv_cap || carry.y + tot.y + h_l > a.term_cap || carry.z + tot.z + h_c > a.cn_cap);
+    if (tid == 0) s_range[0] = ex_sv + hb0;
+    if (valid && (j == n - 1 || tid == kScanBlock - 1)) s_range[1] = inc.x + hb1;
+    __syncthreads();
+    const uint32_t P0 = s_range[0], P1 = wg_ok ? s_range[1] : s_range[0];
+    const uint32_t lb_own = ex_l + a.ins_pre_l[hb1], cb_own = ex_c + a.ins_pre_c[hb1];
+    for (uint32_t win = P0; win < P1; win += kFinList) {
+        if (valid && (hb1 > hb0 || e.x)) {
+            for (uint32_t jj = hb0; jj < hb1; ++jj) {  // the inserted candidates that come right before this vertex's own
+                const uint32_t pos = ex_sv + jj - win;
+                if (pos < kFinList) {
+                    s_from[pos] = a.ins_src[jj];
+                    s_bg[pos] = make_uint2(ex_l + a.ins_pre_l[jj], ex_c + a.ins_pre_c[jj]);
+                }
+            }
+            uint32_t lb = lb_own, cb = cb_own, slot = slot0;
+            for (uint32_t q = 0; q < e.x; ++q) {
+                const uint32_t pos = ex_sv + hb1 + q - win;
+                if (pos < kFinList) {
+                    s_from[pos] = slot;
+                    s_bg[pos] = make_uint2(lb, cb);
+                } else if ((int32_t)pos > 0) {
+                    break;  // past this pass's window
+                }
+                if (q + 1 < e.x) {  // (a single candidate's entries are the vertex's totals: nothing to look up)
+                    lb += (uint32_t)a.sv_stage[slot].sv.lib_count;
+                    cb += (uint32_t)a.sv_stage[slot].sv.cn_count;
+                    slot = a.slot_next[slot];
+                }
+            }
         }
         __syncthreads();
-        if (threadIdx.x < cnt) {
-            SvOut* o = (SvOut*)s_rec + threadIdx.x;
-            o->sv.lib_begin = (int32_t)bg.x;
-            o->sv.cn_begin = (int32_t)bg.y;
-        }
-        if (threadIdx.x < 64) {
-            // wave 0, one candidate per lane: K5 for its terms (all 64 lanes take part: a term with a long series is summed
-            // by the whole wave), their log tails also go to the host's list
-            const bool act = threadIdx.x < cnt;
-            SvOut* o = (SvOut*)s_rec + (act ? threadIdx.x : 0);
-            const int32_t nl = act ? o->sv.lib_count : 0, lb = act ? o->sv.lib_begin : 0;
-            int32_t max_nl = nl;
+        const uint32_t cntw = min(kFinList, P1 - win);
+        for (uint32_t c0 = (uint32_t)w * 64; c0 < cntw; c0 += kScanBlock) {
+            const uint32_t cnt = min(64u, cntw - c0);
+            const bool act = (uint32_t)lane < cnt;
+            uint32_t* rec = s_rec[w];
+            for (uint32_t i = lane; i < cnt * kSvWords; i += 64) {  // gather the records from the staging slots / the host's list
+                const uint32_t sv = i / kSvWords, wd = i - sv * kSvWords;
+                const uint32_t from = s_from[c0 + sv];
+                const uint32_t* src = (from & 0x80000000u) ? (const uint32_t*)(a.hs_rec + (from & 0x7FFFFFFFu)) : (const uint32_t*)(a.sv_stage + from);
+                rec[i] = src[wd];
+            }
+            __builtin_amdgcn_wave_barrier();
+            KPROF(32768u + bid * 4 + w, 3);
+            SvOut* o = (SvOut*)rec + (act ? lane : 0);
+            const uint32_t from = act ? s_from[c0 + lane] : 0u;
+            const uint2 bg = act ? s_bg[c0 + lane] : make_uint2(0u, 0u);
+            const bool hosted = (from & 0x80000000u) != 0;
+            const int32_t nl = act ? o->sv.lib_count : 0, ncn = act ? o->sv.cn_count : 0;
+            const int32_t l0 = o->sv.lib_begin, k0 = o->sv.cn_begin;  // (a host candidate's entries in the host's lists)
+            if (act) { o->sv.lib_begin = (int32_t)bg.x; o->sv.cn_begin = (int32_t)bg.y; }
+            int32_t max_nl = nl, max_ncn = ncn;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) max_nl = max(max_nl, __shfl_xor(max_nl, off));
+            for (int off = 32; off > 0; off >>= 1) { max_nl = max(max_nl, __shfl_xor(max_nl, off)); max_ncn = max(max_ncn, __shfl_xor(max_ncn, off)); }
+            // one candidate per lane: K5 for its terms (all 64 lanes take part: a term with a long series is summed by the whole
+            // wave); the entries of the two flat lists go straight to the host's arrays
             double logp = 0.0, err = 0.0;
             for (int32_t q = 0; q < max_nl; ++q) {
                 const bool a2 = q < nl;
-                const double lt = poisson_term(a2 ? a.t_lambda[lb + q] : 1.0, a2 ? a.t_k[lb + q] : 0, a2, (int)threadIdx.x);
+                double lam = 1.0;
+                int32_t k = 0, li = 0;
                 if (a2) {
-                    a.ltail[lb + q] = lt;
-                    a.ltail_host[lb + q] = lt;
+                    if (hosted) { lam = a.hs_lambda[l0 + q]; k = a.hs_lib_pairs[l0 + q]; li = a.hs_lib_index[l0 + q]; }
+                    else { const LibStage t = a.lib_stage[(size_t)from * a.lib_stride + q]; lam = t.lambda; k = t.rc; li = t.lib; }
+                }
+                const double lt = poisson_term(lam, k, a2, lane);
+                if (a2) {
+                    a.lib_index[bg.x + q] = li;
+                    a.lib_pairs[bg.x + q] = k;
+                    a.ltail_host[bg.x + q] = lt;
                     const double tmp_a = __dsub_rn(lt, err);
                     const double tmp_b = __dadd_rn(logp, tmp_a);
                     err = __dsub_rn(__dsub_rn(tmp_b, logp), tmp_a);
                     logp = tmp_b;
                 }
             }
-            if (act && with_scores) {
-            const double phred_tmp = __ddiv_rn(__dmul_rn(-10.0, logp), ln10);
-            const double r = __dadd_rn(phred_tmp, 0.5);
-            int phred;
-            if (phred_tmp > 99.0) phred = 99;
-            else if (r != r || r >= 2147483648.0 || r <= -2147483649.0) phred = INT32_MIN;
-            else phred = (int)r;
-            const int pr = phred > score_threshold ? 1 : 0;
-            o->sv.logp = logp;
-            o->sv.score = phred;
-            o->sv.printed = pr;
-            if (pr) atomicAdd(&s_printed, 1u);
+            for (int32_t t = 0; t < max_ncn; ++t) {
+                if (t < ncn) {
+                    int32_t key;
+                    float value;
+                    if (hosted) { key = a.hs_cn_key[k0 + t]; value = a.hs_cn_value[k0 + t]; }
+                    else { const CnStage cn = a.cn_stage[(size_t)from * a.nkeys + t]; key = cn.key; value = cn.value; }
+                    a.cn_key[bg.y + t] = key;
+                    a.cn_value[bg.y + t] = value;
+                }
             }
+            bool pr = false;
+            if (act && with_scores) {
+                const double phred_tmp = __ddiv_rn(__dmul_rn(-10.0, logp), ln10);
+                const double r = __dadd_rn(phred_tmp, 0.5);
+                int phred;
+                if (phred_tmp > 99.0) phred = 99;
+                else if (r != r || r >= 2147483648.0 || r <= -2147483649.0) phred = INT32_MIN;
+                else phred = (int)r;
+                pr = phred > score_threshold;
+                o->sv.logp = logp;
+                o->sv.score = phred;
+                o->sv.printed = pr ? 1 : 0;
+            }
+            const uint32_t npr = (uint32_t)__popcll(__ballot(pr));
+            if (lane == 0 && npr) atomicAdd(&s_printed, npr);
+            KPROF(32768u + bid * 4 + w, 4);
+            __builtin_amdgcn_wave_barrier();
+            uint32_t* dst = (uint32_t*)(a.sv_out + win + c0);
+            for (uint32_t i = lane; i < cnt * kSvWords; i += 64) dst[i] = rec[i];
+            __builtin_amdgcn_wave_barrier();  // (the wave's next 64 candidates reuse the slice)
         }
-        __syncthreads();
-        uint32_t* dst = (uint32_t*)(a.sv_out + base);
-        for (uint32_t i = threadIdx.x; i < cnt * kSvWords; i += 256) dst[i] = s_rec[i];
+        __syncthreads();  // the lists are rewritten by the next pass
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         if (s_printed) atomicAdd(&a.counts->n_printed, s_printed);
         // every workgroup leaves its count in the host's array (one plain store; the host adds them up): no follow-up launch
         // that copies the total (system-scope atomics on host memory are ~1 us each and serialise)
-        if (a.printed_host) a.printed_host[blockIdx.x] = s_printed;
+        if (a.printed_host) a.printed_host[bid] = s_printed;
     }
-    const uint32_t gsz = gridDim.x * 256;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nt; i += gsz) { a.lib_index[i] = a.d_lib_index[i]; a.lib_pairs[i] = a.t_k[i]; }
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nc; i += gsz) { a.cn_key[i] = a.d_cn_key[i]; a.cn_value[i] = a.d_cn_value[i]; }
+    KPROF(32768u + bid * 4 + w, 5);
 }
 
 // the end of the run: printed count and the word the host polls
@@ -1323,23 +1395,28 @@ void launch_k6_groups(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
 void launch_k6_walk(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
     if (n_anom_host == 0 || a.force_host) return;
     const uint32_t gp = std::min<uint32_t>((n_anom_host / 8 + 3) / 4 + 1, 16384u);
-    hipLaunchKernelGGL(k6_walk_kernel, dim3(gp), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k6_walk_kernel, dim3(std::min<uint32_t>(n_anom_host / 64 / 2 + 1, 4096u)), dim3(64), 0, s, a);  // components <= regions <= reads / 2 (grid-stride beyond)
     if (a.big_walk) hipLaunchKernelGGL(k6_walk_big_kernel, dim3(gp / 8 + 1), dim3(256), 0, s, a);
 }
 
-uint32_t k6_score_grid(const K6Arrays& a) { return std::min<uint32_t>(a.sv_cap / kScoreSvs + 1, 2048u); }
+uint32_t k6_score_grid(const K6Arrays& a) { return scan_grid(a.cap, 1); }  // workgroups of k6_finish_kernel (one per 256 regions of the upper bound)
 
-void launch_k6_score(const K6Arrays& a, double ln10, int score_threshold, int with_scores, hipStream_t s) {
-    const uint32_t g = k6_score_grid(a);  // candidates are unknown to the host: enough groups for
-    hipLaunchKernelGGL(k6_score_kernel, dim3(g), dim3(256), 0, s, a, ln10, score_threshold, with_scores);  // a.sv_cap, most exit at once
+// the merged list of the candidates that are placed by key, then the table itself
+void launch_k6_table(const K6Arrays& a, uint32_t n_anom_host, double ln10, int score_threshold, int with_scores, hipStream_t s) {
+    if (n_anom_host) {
+        hipLaunchKernelGGL(k6_insert_kernel, dim3(1), dim3(kScanBlock), 0, s, a);
+        hipLaunchKernelGGL(k6_finish_kernel, dim3(scan_grid(n_anom_host, 1)), dim3(kScanBlock), 0, s, a, ln10, score_threshold, with_scores);
+    }
     if (!a.printed_host || a.flag_done) hipLaunchKernelGGL(k6_done_kernel, dim3(1), dim3(64), 0, s, a);
 }
 
-void launch_k6_compact(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
-    if (n_anom_host == 0) return;
-    OwnIn in{a.own_nsv, a.own_nacc, a.own_ncn};
-    OwnOut out{a};
-    scan_launch_side<U4, 1>(in, out, InsertJob{a}, &a.counts->n_regions, n_anom_host, a.ws_u4, a.total_u4, s);  // few elements, heavy output: one per thread
-}
-
 }  // namespace bdx
+
+#ifdef BDX_KPROF
+extern "C" int bdx_debug_kprof(unsigned long long* out, size_t n) {
+    const int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bdx::g_kprof), n * sizeof(unsigned long long));
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(bdx::g_kprof)) == hipSuccess) (void)hipMemset(p, 0, sizeof(unsigned long long) * 8 * 65536);  // next run starts clean
+    return rc;
+}
+#endif

@@ -1,0 +1,86 @@
+"""In-kernel phase clocks of the walk and score kernels (a measurement build, not the product).
+
+Build:  hipcc ... -DBDX_KPROF -c breakdancer_amd/csrc/k6_assemble.hip -o /tmp/k6_kprof.o, link the other objects of libbdx.so with it
+        into variants/libbdx_kprof.so ("in-kernel clocks").
+Run:    python tools/kprof.py [--length 50000000]
+The kernels store wall_clock64() (100 MHz) at a few places; this script runs configs[1] a few times and prints the distribution
+of the intervals of the LAST run.
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--length", type=int, default=50_000_000)
+    ap.add_argument("--lib", default=os.path.join(ROOT, "variants", "libbdx_kprof.so"))
+    a = ap.parse_args()
+    import breakdancer_amd._lib as lib
+    lib.LIB_PATH = a.lib
+    import torch
+    import breakdancer_amd.api as bda
+    from breakdancer_amd.api import LibraryConfig, Options
+    from breakdancer_amd.synth import LIB_C2, make_chromosome
+    d = make_chromosome(length=a.length, seed=1)
+    n = len(d["pos"])
+    dev = torch.device("cuda", 0)
+    tens = {k: torch.from_numpy(v).to(dev) for k, v in d.items()}
+    bd = bda.BreakDancer(Options(), [LibraryConfig(**LIB_C2)], 1, ntids=1, max_read_window_size=200, device=0)
+    bd.set_device_reads({k: t.data_ptr() for k, t in tens.items()}, n)
+    bd.set_enqueue_ahead(0)
+    L = lib.load()
+    buf = np.zeros(8 * 65536, dtype=np.uint64)
+    L.bdx_debug_kprof.argtypes = [C.c_void_p, C.c_size_t]
+    for _ in range(5):
+        bd.run()
+    torch.cuda.synchronize()
+    L.bdx_debug_kprof(buf.ctypes.data_as(C.c_void_p), buf.size)  # (clears the device buffer)
+    bd.run()
+    torch.cuda.synchronize()
+    rc = L.bdx_debug_kprof(buf.ctypes.data_as(C.c_void_p), buf.size)
+    assert rc == 0, rc
+    t = buf.reshape(65536, 8).astype(np.int64)
+    split = bd.walk_split()
+    print("reads", n, "svs", bd.summary().get("n_sv") if hasattr(bd.summary(), "get") else "", "walk split", split)
+
+    def stats(name, x):
+        x = np.asarray(x, dtype=np.float64) / 100.0  # us
+        if len(x) == 0:
+            print("  %-34s (none)" % name)
+            return
+        print("  %-34s n=%6d  min %7.2f  p50 %7.2f  p90 %7.2f  max %7.2f us" % (name, len(x), x.min(), np.percentile(x, 50), np.percentile(x, 90), x.max()))
+
+    # walk kernel: one lane per component, rows = workgroup (clocks of its lane 0 / of the whole wave at the end)
+    own = t[:32768]
+    have = own[:, 3] > 0
+    k0 = own[:, 0][own[:, 0] > 0].min()
+    print("walk kernel: %d waves" % have.sum())
+    stats("wave entry", own[have, 0] - k0)
+    stats("phase 0: tables (lane 0)", own[have, 1] - own[have, 0])
+    stats("phase 1: traversal (lane 0)", own[have, 2] - own[have, 1])
+    stats("wave end", own[have, 3] - k0)
+    sc = t[32768:]
+    hs = sc[:, 5] > 0
+    if hs.any():
+        s0 = sc[:, 0][sc[:, 0] > 0].min()
+        print("table kernel: %d waves entered, %d waves of workgroups with regions, %d with candidates" % ((sc[:, 0] > 0).sum(), hs.sum(), (sc[:, 4] > 0).sum()))
+        stats("wave entry", sc[:, 0][sc[:, 0] > 0] - s0)
+        stats("loads + block scan", sc[hs, 1] - sc[hs, 0])
+        stats("look-back", sc[hs, 2] - sc[hs, 1])
+        g = sc[:, 4] > 0
+        stats("placement + first gather", sc[g, 3] - sc[g, 2])
+        stats("terms, K5, scores (last chunk)", sc[g, 4] - sc[g, 3])
+        stats("records -> host, end", sc[g, 5] - sc[g, 4])
+        stats("wave end", sc[hs, 5] - s0)
+    bd.close()
+
+
+if __name__ == "__main__":
+    main()
