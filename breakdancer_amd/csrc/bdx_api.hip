@@ -81,7 +81,7 @@ struct bdx_ctx {
     DevBuf b_tid, b_pos, b_mtid, b_mpos, b_isize, b_flag, b_qlen, b_mapq, b_lib, b_bam, b_key;
 
     // stage buffers
-    DevBuf b_libs, b_cls, b_tile_tot, b_tile_pre, b_tile_mono, b_blk_cnt, b_cnt, b_p1, b_fold;
+    DevBuf b_libs, b_cls, b_tile_tot, b_tile_pre, b_tile_mono, b_blk_cnt, b_cnt, b_p1, b_fold, b_stash;
     DevBuf b_c_tid, b_c_pos, b_c_isize, b_c_meta, b_c_key, b_c_idx, b_c_nn, b_c_pk;
     DevBuf b_cand, b_pre_q, b_pre_rev, b_pre_nonctx, b_c_first, b_c_maxq, b_c_rid, b_region_of, b_ws_u4, b_ws_u32, b_totals, b_counts;
     DevBuf b_bcnt, b_boff, b_bcur, b_e_key, b_e_idx, b_partner, b_t_key, b_t_idx;
@@ -134,6 +134,7 @@ struct bdx_ctx {
     std::vector<uint32_t> ov_cnt;     // bdx_set_pass1_statistics: restored pass-1 counters that replace the run's own
     uint32_t ov_covered = 0;
     bool replayed = false;            // the last run went through the read-level host replay (a read name seen more than twice)
+    bool use_stash = false;           // K1 leaves ready-made records of the anomalous reads for K2 (at most kStashKeys counter keys)
     std::vector<uint32_t> sup_off;    // [n_svs + 1]
     std::vector<uint64_t> sup_idx;
     std::vector<uint8_t> sup_flag;
@@ -423,7 +424,7 @@ void bdx_destroy(bdx_ctx* c) {
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     DevBuf* bufs[] = {&c->b_tid, &c->b_pos, &c->b_mtid, &c->b_mpos, &c->b_isize, &c->b_flag, &c->b_qlen, &c->b_mapq, &c->b_lib,
-                      &c->b_bam, &c->b_key, &c->b_libs, &c->b_cls, &c->b_tile_tot, &c->b_tile_pre, &c->b_tile_mono,
+                      &c->b_bam, &c->b_key, &c->b_libs, &c->b_cls, &c->b_stash, &c->b_tile_tot, &c->b_tile_pre, &c->b_tile_mono,
                       &c->b_blk_cnt, &c->b_cnt, &c->b_p1, &c->b_c_tid, &c->b_c_pos, &c->b_c_isize,
                       &c->b_c_meta, &c->b_c_key, &c->b_c_idx, &c->b_c_nn, &c->b_c_pk, &c->b_cand, &c->b_pre_q, &c->b_pre_rev,
                       &c->b_pre_nonctx, &c->b_c_first, &c->b_c_maxq, &c->b_c_rid, &c->b_region_of, &c->b_ws_u4, &c->b_ws_u32, &c->b_totals,
@@ -596,6 +597,10 @@ int pass1_prepare(bdx_ctx* c, uint32_t tiles_cap) {
     c->k1_cap_tiles = tiles_cap;
     c->k1_done = 0;
     HIPCHK(c, c->b_cls.ensure(std::max<size_t>((size_t)tiles_cap * kTile, 16)));
+    // K1's ready-made records for K2: 2 B per read of address space, written (and later read) only where reads are anomalous
+    static const bool no_stash = getenv("BDX_NO_STASH") != nullptr;  // (A/B: K2 gathers everything from the columns)
+    c->use_stash = !no_stash && nkeys <= kStashKeys;
+    if (c->use_stash) HIPCHK(c, c->b_stash.ensure(std::max<size_t>((size_t)tiles_cap * kStashCap * sizeof(StashRec), 64)));
     HIPCHK(c, c->b_tile_tot.ensure((size_t)ncols * tstride * 4));
     HIPCHK(c, c->b_tile_pre.ensure((size_t)ncols * tstride * 4));
     HIPCHK(c, c->b_tile_mono.ensure((size_t)nbams * tstride * sizeof(MonoRec)));
@@ -636,6 +641,7 @@ int pass1_classify(bdx_ctx* c, uint32_t upto, bool timed) {
     k1.libs = c->b_libs.as<DevLib>(); k1.cls = c->b_cls.as<uint8_t>(); k1.tile_tot = c->b_tile_tot.as<uint32_t>();
     k1.tile_mono = c->b_tile_mono.as<MonoRec>();
     k1.blk_cnt = c->b_blk_cnt.as<uint32_t>();
+    k1.stash = c->use_stash ? c->b_stash.as<StashRec>() : nullptr;
     const uint32_t span = upto - c->k1_done;
     const int grid1 = (int)std::min<uint32_t>((span + kWaves - 1) / kWaves, kK1MaxGrid);
     if (timed) HIPCHK(c, hipEventRecord(c->ev[0], s));
@@ -799,6 +805,7 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepa
         K2Params k2{};
         k2.r = c->d; k2.n = c->n; k2.ntiles = c->ntiles; k2.tstride = c->tstride; k2.nkeys = nkeys; k2.libs = c->b_libs.as<DevLib>();
         k2.cls = c->b_cls.as<uint8_t>(); k2.tile_pre = c->b_tile_pre.as<uint32_t>(); k2.c = cp;
+        k2.tile_tot = c->b_tile_tot.as<uint32_t>(); k2.stash = c->use_stash ? c->b_stash.as<StashRec>() : nullptr;
         k2.nn_base = nn_base;
         for (int k = 0; k < nkeys; ++k) k2.pk_base[k] = pk_base ? pk_base[k] : 0u;
         // scratch of the later stages cleared by this launch: the per-candidate max read length of K3, and (when this

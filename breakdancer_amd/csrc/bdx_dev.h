@@ -11,6 +11,22 @@ constexpr int kWaves = kBlock / 64;
 constexpr int kNumFlags = 11;
 constexpr int kK2TilesPerWave = 4; // K2 compacts four of K1's tiles per wave and needs the prefixes at those boundaries only
 constexpr int kCntCopies = 64;   // replication factor of the global pass-1 counters (power of two)
+constexpr int kStashCap = 16;    // anomalous reads per tile that K1 leaves ready-made for K2 (a tile with more is compacted from the columns)
+constexpr int kStashKeys = 2;    // ... when there are at most this many normal-read counter keys (K2's fast path holds their totals in 16 lanes)
+
+// What K1 leaves for K2 about an anomalous read (slot `rank in tile` of the tile's kStashCap slots): everything K2 would
+// otherwise gather from seven columns -- K1 has it in registers anyway -- plus the read's in-tile prefix counts, so that K2
+// needs neither the class bytes nor the columns of a tile whose anomalous reads fit (name key and read length are fetched by
+// K2: K1 does not load those columns).  Only tiles whose reads share one library and source file are served (their normal
+// reads count for one key); slot 0 of any other tile with anomalous reads says so: where == 0xFFFFFFFF.
+struct StashRec {
+    int32_t tid, pos, isize;   // isize = |isize|
+    uint32_t meta;             // flag | rev << 4 | lib << 8 (read length: K2)
+    uint32_t where;            // offset in tile (8 bits) | normal-leftmost reads before it in the tile << 8 | the tile's counter key << 20
+    uint32_t proper;           // proper reads (of that key) up to and including it in the tile
+    uint32_t pad[2];
+};
+static_assert(sizeof(StashRec) == 32, "two 16-byte stores");
 
 enum : int { F_NA = 0, F_FF = 1, F_LARGE = 2, F_SMALL = 3, F_RF = 4, F_RR = 5, F_NORMAL_FR = 6, F_NORMAL_RF = 7,
              F_CTX = 8, F_MATE_UNMAPPED = 9, F_UNMAPPED = 10 };
@@ -50,6 +66,7 @@ struct K1Params {
     uint32_t* tile_tot;        // [2+nkeys][tstride]
     MonoRec* tile_mono;        // [nbams][tstride], pre-set to 0xFF (ft == -1: file absent from the tile)
     uint32_t* blk_cnt;         // [kCntCopies][ncnt] zero-filled, ncnt = nlibs*11 + nlibs + nbams
+    StashRec* stash;           // [tiles][kStashCap]; null: more than kStashKeys counter keys (K2 gathers everything itself)
 };
 
 // results of pass 1, produced on the device and mirrored to the host
@@ -118,6 +135,8 @@ struct K2Params {
     const DevLib* libs;
     const uint8_t* cls;
     const uint32_t* tile_pre;
+    const uint32_t* tile_tot;  // K1's per-tile totals and its ready-made records (stash null: not available)
+    const StashRec* stash;
     Compact c;
     uint32_t nn_base;      // normal read pairs / proper reads of earlier shards (0 for a single context)
     uint32_t pk_base[60];

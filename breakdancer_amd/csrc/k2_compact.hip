@@ -5,8 +5,9 @@
 // string-keyed maps once per read, the running counts the reference samples at region boundaries
 // (normal-read pairs, per-key proper reads) become prefix sums that are *sampled* at the anomalous reads.
 //
-// Input: class bytes from K1 + exclusive per-tile prefixes.  Output: one compact record per anomalous
-// read, in stream order.  One wave per FOUR of K1's tiles (1024 reads, 16 consecutive class bytes = one 16-byte load
+// Input: K1's ready-made records of the anomalous reads (up to kStashCap per tile) + exclusive per-tile prefixes; for tiles with
+// more, and for runs with more than kStashKeys counter keys, the class bytes and the columns.  Output: one compact record per
+// anomalous read, in stream order.  One wave per FOUR of K1's tiles (1024 reads, 16 consecutive class bytes = one 16-byte load
 // per lane): the kernel is bound by dependent round trips per wave (class bytes -> gather -> store), not by bytes, so
 // fewer, fatter waves finish sooner.  Per-lane state is three 16-bit masks; in-wave scans are shuffles on 16-bit
 // packed counters, no workgroup barrier; super tiles without an anomalous read are skipped after one ballot; the
@@ -69,6 +70,61 @@ __device__ __forceinline__ void k2_body(const K2Params& p, uint32_t nblk) {
         const uint32_t rank0 = p.tile_pre[(size_t)kColAnom * p.tstride + tile2];
         const uint32_t pre_k0 = p.tile_pre[(size_t)kColKey0 * p.tstride + tile2];
         const uint32_t pre_k1 = nkeys > 1 ? p.tile_pre[(size_t)(kColKey0 + 1) * p.tstride + tile2] : 0u;
+        if (p.stash) {
+            // K1 left the anomalous reads of a tile ready-made (up to kStashCap of them): their records are copied to their places,
+            // shifted by the prefixes -- no class bytes, no column gather except name key and read length.  Lane c * 4 + t holds
+            // column c's total of the super tile's tile t.
+            static_assert(kSub == 4 && kStashKeys == 2, "lane layout of the totals");
+            const int t = lane & 3, col = lane >> 2;
+            uint32_t v = 0;
+            if (col < 2 + nkeys && tile2 * kSub + t < p.ntiles) v = p.tile_tot[(size_t)col * p.tstride + tile2 * kSub + t];
+            const uint32_t a0 = __shfl(v, 0), a1 = __shfl(v, 1), a2 = __shfl(v, 2), a3 = __shfl(v, 3);
+            const uint32_t A = a0 + a1 + a2 + a3;
+            if (A == 0) continue;  // (wave-uniform)
+            if (max(max(a0, a1), max(a2, a3)) <= (uint32_t)kStashCap) {
+                const uint32_t q = (uint32_t)lane;  // A <= 64: one read per lane
+                const uint32_t tq = (q >= a0 ? 1u : 0u) + (q >= a0 + a1 ? 1u : 0u) + (q >= a0 + a1 + a2 ? 1u : 0u);
+                const uint32_t before = tq == 0 ? 0u : (tq == 1 ? a0 : (tq == 2 ? a0 + a1 : a0 + a1 + a2));
+                // exclusive in-super-tile prefixes of the other columns at tile tq
+                uint32_t e[3];
+#pragma unroll
+                for (int c = 1; c <= 3; ++c) {
+                    const uint32_t x0 = __shfl(v, c * 4), x1 = __shfl(v, c * 4 + 1), x2 = __shfl(v, c * 4 + 2);
+                    e[c - 1] = tq == 0 ? 0u : (tq == 1 ? x0 : (tq == 2 ? x0 + x1 : x0 + x1 + x2));
+                }
+                const uint32_t j = rank0 + q;
+                const uint32_t tile = tile2 * kSub + min(tq, 3u);
+                uint4 r0 = make_uint4(0u, 0u, 0u, 0u);
+                uint2 r1 = make_uint2(0u, 0u);
+                uint32_t first_where = 0;
+                if (q < A) {
+                    const StashRec* src = p.stash + (size_t)tile * kStashCap + (q - before);
+                    r0 = *(const uint4*)src;
+                    r1 = *(const uint2*)&src->where;
+                    first_where = p.stash[(size_t)tile * kStashCap].where;  // (the same line)
+                }
+                if (!__any(first_where == 0xFFFFFFFFu)) {  // no mixed tile among them (else: from the columns, below)
+                    if (q < A && j < p.c.cap) {  // (the capacity can be a guess of an enqueue-ahead run)
+                        const uint64_t i = (uint64_t)tile * kTile + (r1.x & 255u);
+                        const uint32_t k0 = (r1.x >> 20) & 63u;
+                        uint64_t key;
+                        int qlen;
+                        key_and_qlen_of(p, i, key, qlen);
+                        p.c.tid[j] = (int32_t)r0.x;
+                        p.c.pos[j] = (int32_t)r0.y;
+                        p.c.isize[j] = (int32_t)r0.z;
+                        p.c.meta[j] = r0.w | ((uint32_t)qlen << 16);
+                        p.c.key[j] = key;
+                        p.c.idx[j] = (uint32_t)i;
+                        p.c.nn[j] = p.nn_base + pre_norm + e[0] + ((r1.x >> 8) & 511u);
+                        p.c.pk[j] = p.pk_base[0] + pre_k0 + e[1] + (k0 == 0 ? r1.y : 0u);
+                        if (nkeys > 1) p.c.pk[(size_t)p.c.cap + j] = p.pk_base[1] + pre_k1 + e[2] + (k0 == 1 ? r1.y : 0u);
+                    }
+                    continue;
+                }
+            }
+            // a tile with more anomalous reads than K1 keeps: the super tile is compacted from the columns (below)
+        }
         uint64_t cq[kSub / 2];  // the lane's class bytes, 8 per word
 #pragma unroll
         for (int q = 0; q < kSub / 2; ++q) cq[q] = 0;

@@ -395,15 +395,21 @@ namespace {
 // process_sv (BreakDancer.cpp:348-497) + SvBuilder for region A (and B when B >= 0) over the alive groups gs[0..2] =
 // (A,A), (A,B), (B,B).  Returns false when a gate rejects the candidate; otherwise the record and its entries are
 // written to the staging slot (by the lane with `store` set).
-template <class FlagCounts>
-__device__ bool assemble_sv(const K6Arrays& a, const PartRec* P, uint32_t A, int32_t B, const RegionRec& ra, const RegionRec& rb,
+struct RunConst {  // run constants of process_sv, wherever the caller keeps them (HBM, or LDS when they are few)
+    const float* lib_mean;     // [nlibs]
+    const uint32_t* hist;      // [nlibs][kNumFlags]
+    const float* key_density;  // [nkeys]
+    uint32_t covered;          // covered_ref_len
+};
+
+__device__ bool assemble_sv(const K6Arrays& a, const RunConst& rc_, const PartRec* P, uint32_t A, int32_t B, const RegionRec& ra, const RegionRec& rb,
                             const uint32_t* pk_last_a, const uint32_t* pk_first_b, const GrpRange (&gs)[3], int max_readlen,
-                            uint32_t slot, uint32_t start, bool store, FlagCounts flag_counts /* [kNumFlags], LDS: int* or StridedCounts */, uint32_t* nacc_out,
-                            uint32_t* ncn_out) {
+                            uint32_t slot, uint32_t start, bool store, uint32_t* nacc_out, uint32_t* ncn_out) {
     const uint32_t lib_room = a.lib_stride;
     const int mrp = a.min_read_pair;
+    int cv[kNumFlags];  // pairs per flag: registers, every index static (a counter array in LDS costs a dependent round trip per update)
 #pragma unroll
-    for (int f = 0; f < kNumFlags; ++f) flag_counts[f] = 0;
+    for (int f = 0; f < kNumFlags; ++f) cv[f] = 0;
     int num_pairs = 0;
 #pragma unroll
     for (int g = 0; g < 3; ++g)
@@ -411,18 +417,21 @@ __device__ bool assemble_sv(const K6Arrays& a, const PartRec* P, uint32_t A, int
             const PartRec q = P[gs[g].beg + i];
             const int f = (int)(q.key & 15);
             const int pr = (int)q.pairs;
-            if (f < kNumFlags) flag_counts[f] += pr;
+#pragma unroll
+            for (int ff = 0; ff < kNumFlags; ++ff) cv[ff] += f == ff ? pr : 0;
             num_pairs += pr;
         }
     if (num_pairs < mrp) return false;
-    int flag = BDX_NA;
-    {
-        int best = 0;
-        for (int f = 0; f < kNumFlags; ++f)
-            if (flag_counts[f] > flag_counts[best]) best = f;
-        if (flag_counts[best] > 0) flag = best;
+    int flag = BDX_NA, flag_count;
+    {   // the dominant flag (lowest one on ties)
+        int best = 0, bestv = cv[0];
+#pragma unroll
+        for (int f = 1; f < kNumFlags; ++f)
+            if (cv[f] > bestv) { best = f; bestv = cv[f]; }
+        if (bestv > 0) flag = best;
+        flag_count = bestv > 0 ? bestv : cv[BDX_NA];
     }
-    if (flag_counts[flag] < mrp) return false;
+    if (flag_count < mrp) return false;
 
     int chr[2], pos[2], fwd[2], rev[2];
     chr[0] = ra.tid; pos[0] = ra.start; pos[1] = ra.end;
@@ -464,9 +473,9 @@ __device__ bool assemble_sv(const K6Arrays& a, const PartRec* P, uint32_t A, int
                 ++idx[g];
                 while (idx[g] < gs[g].cnt && (int)(P[gs[g].beg + idx[g]].key & 15) != flag) ++idx[g];
             }
-        diff = __fadd_rn(diff, __fsub_rn((float)span, __fmul_rn((float)rc, a.lib_mean[best])));
-        const uint32_t nflag = a.hist[(size_t)best * kNumFlags + flag];
-        double lambda = __dmul_rn((double)total_region_size, __ddiv_rn((double)nflag, (double)a.p1->covered_ref_len));
+        diff = __fadd_rn(diff, __fsub_rn((float)span, __fmul_rn((float)rc, rc_.lib_mean[best])));
+        const uint32_t nflag = rc_.hist[(size_t)best * kNumFlags + flag];
+        double lambda = __dmul_rn((double)total_region_size, __ddiv_rn((double)nflag, (double)rc_.covered));
         lambda = (1.0e-10 < lambda) ? lambda : 1.0e-10;
         if (store && nacc < lib_room) ls[nacc] = LibStage{best, rc, lambda};
         ++nacc;
@@ -483,7 +492,7 @@ __device__ bool assemble_sv(const K6Arrays& a, const PartRec* P, uint32_t A, int
         for (int k = 0; k < nk; ++k) {
             const uint32_t cnt = pk_first_b[k] - pk_last_a[k];
             if (cnt == 0) continue;
-            const float cn = __fmul_rn(__fdiv_rn((float)cnt, __fmul_rn(a.key_density[k], span)), 2.0f);
+            const float cn = __fmul_rn(__fdiv_rn((float)cnt, __fmul_rn(rc_.key_density[k], span)), 2.0f);
             if (store) cs[ncn] = CnStage{k, cn};
             ++ncn;
             cn_sum = __fadd_rn(cn_sum, cn);
@@ -495,11 +504,11 @@ __device__ bool assemble_sv(const K6Arrays& a, const PartRec* P, uint32_t A, int
         ncn ? __fsub_rn(1.0f, __fdiv_rn(cn_sum, __fmul_rn(2.0f, (float)ncn))) : __uint_as_float(0xFFC00000u);
 
     if (flag != BDX_ARP_RF && flag != BDX_ARP_RR && pos[0] + max_readlen - 5 < pos[1]) pos[0] += max_readlen - 5;
-    const int diffspan = (int)((double)__fdiv_rn(diff, (float)flag_counts[flag]) + 0.5);
+    const int diffspan = (int)((double)__fdiv_rn(diff, (float)flag_count) + 0.5);
 
     SvOut o;
     for (int i = 0; i < 2; ++i) { o.sv.chr[i] = chr[i]; o.sv.pos[i] = pos[i] + 1; o.sv.fwd[i] = fwd[i]; o.sv.rev[i] = rev[i]; }
-    o.sv.flag = flag; o.sv.size = diffspan; o.sv.score = 0; o.sv.num_reads = flag_counts[flag]; o.sv.printed = 0;
+    o.sv.flag = flag; o.sv.size = diffspan; o.sv.score = 0; o.sv.num_reads = flag_count; o.sv.printed = 0;
     o.sv.region[0] = (int32_t)A; o.sv.region[1] = B;
     o.sv.lib_begin = 0; o.sv.lib_count = (int32_t)nacc;
     o.sv.cn_begin = 0; o.sv.cn_count = (int32_t)ncn;
@@ -563,11 +572,12 @@ __global__ __launch_bounds__(256) void k6_emit_kernel(K6Arrays a) {
             }
         }
     }
-    {   // work list of the walk kernel: the smallest region of every device-walked component
+    {   // the walk kernels' work: the smallest region of every device-walked component
         const bool owner = covered && L == r;
         const bool small = owner && a.mcount[L] <= (uint32_t)kK6MaxMembers;
-        const uint32_t o = wave_reserve(small ? 1u : 0u, &a.counts->n_owners);
-        if (small) a.owners[o] = r;
+        if (active) a.owners[r] = small ? a.mcount[L] : 0u;  // (the walk kernel takes one lane per region: no list, no indirection)
+        const uint32_t no = (uint32_t)__popcll(__ballot(small));
+        if (lane == 0 && no) atomicAdd(&a.counts->n_owners, no);
         const uint32_t ob = wave_reserve(owner && !small ? 1u : 0u, &a.counts->n_owners_big);
         if (owner && !small) a.owners_big[ob] = r;
     }
@@ -610,10 +620,11 @@ struct BigTab {
     int tails[4 * kK6BigMembers], newtails[4 * kK6BigMembers];
 };
 
-__device__ __forceinline__ void walk_big(const K6Arrays& a, BigTab& B, int* flag_counts, uint32_t L, int lane, uint32_t NR) {
+__device__ __forceinline__ void walk_big(const K6Arrays& a, BigTab& B, uint32_t L, int lane, uint32_t NR) {
     const int k = (int)a.mcount[L];
     const int mrp = a.min_read_pair, nk = a.nkeys;
     const uint32_t period = (uint32_t)a.period;
+    const RunConst rc_{a.lib_mean, a.hist, a.key_density, a.p1->covered_ref_len};
     {   // member ids in ascending order: rank by counting (they all differ)
         const uint32_t id = lane < k ? a.member_ids[(size_t)L * kK6BigMembers + lane] : 0xffffffffu;
         uint32_t rank = 0;
@@ -713,8 +724,8 @@ __device__ __forceinline__ void walk_big(const K6Arrays& a, BigTab& B, int* flag
                         const uint32_t* pkA = a.r_pk + (size_t)B.rid[A] * 2 * nk + nk;
                         const uint32_t* pkB = a.r_pk + (size_t)B.rid[Bi] * 2 * nk;
                         uint32_t nacc = 0, ncn = 0;
-                        if (assemble_sv(a, a.parts, B.rid[A], Bm >= 0 ? (int32_t)B.rid[Bm] : -1, B.rec[A], B.rec[Bi], pkA, pkB, gs, max_readlen, slot,
-                                        start, lane == 0, flag_counts, &nacc, &ncn)) {
+                        if (assemble_sv(a, rc_, a.parts, B.rid[A], Bm >= 0 ? (int32_t)B.rid[Bm] : -1, B.rec[A], B.rec[Bi], pkA, pkB, gs, max_readlen, slot,
+                                        start, lane == 0, &nacc, &ncn)) {
                             if (from_old) {
                                 if (lane == 0) {
                                     const uint32_t q = atomicAdd(&a.counts->n_old, 1u);
@@ -748,7 +759,7 @@ __device__ __forceinline__ void walk_big(const K6Arrays& a, BigTab& B, int* flag
 struct WalkTab {
     uint32_t* p;  // this lane's column
     static constexpr int kSbeg = 0, kScnt = 4, kEbeg = 8, kEcnt = 14, kSw = 20, kEw = 24, kSslot = 30, kEslot = 34, kOrd = 40, kRid = 44,
-                         kTails = 48, kNewTails = 60, kCalls = 72, kFlags = 82, kFields = 82 + kNumFlags;
+                         kCalls = 48, kRtid = 58, kRstart = 62, kRend = 66, kRn = 70, kRrev = 74, kFields = 78;
     __device__ __forceinline__ uint32_t& at(int f) const { return p[f * 64]; }
     __device__ __forceinline__ uint32_t& Sbeg(int i) const { return at(kSbeg + i); }
     __device__ __forceinline__ uint32_t& Scnt(int i) const { return at(kScnt + i); }
@@ -758,15 +769,13 @@ struct WalkTab {
     __device__ __forceinline__ uint32_t& Ew(int e) const { return at(kEw + e); }
     __device__ __forceinline__ uint32_t& Sslot(int i) const { return at(kSslot + i); }
     __device__ __forceinline__ uint32_t& Eslot(int e) const { return at(kEslot + e); }
-    __device__ __forceinline__ uint32_t& ord(int i) const { return at(kOrd + i); }    // member (registration order) at place i of the ascending order
-    __device__ __forceinline__ uint32_t& rid(int i) const { return at(kRid + i); }    // its region
-    __device__ __forceinline__ uint32_t& tails(int t) const { return at(kTails + t); }
-    __device__ __forceinline__ uint32_t& newtails(int t) const { return at(kNewTails + t); }
+    __device__ __forceinline__ uint32_t& rid(int i) const { return at(kRid + i); }    // region of the member at place i of the ascending order
+    __device__ __forceinline__ uint32_t& Rtid(int i) const { return at(kRtid + i); }    // what process_sv reads of the region's record
+    __device__ __forceinline__ uint32_t& Rstart(int i) const { return at(kRstart + i); }
+    __device__ __forceinline__ uint32_t& Rend(int i) const { return at(kRend + i); }
+    __device__ __forceinline__ uint32_t& Rn(int i) const { return at(kRn + i); }
+    __device__ __forceinline__ uint32_t& Rrev(int i) const { return at(kRrev + i); }
     __device__ __forceinline__ uint32_t& call(int c) const { return at(kCalls + c); } // the walk's process_sv calls, in order (every group makes at most one)
-};
-struct StridedCounts {  // the lane's flag counters inside its column
-    uint32_t* p;
-    __device__ __forceinline__ int& operator[](int f) const { return *(int*)(p + f * 64); }
 };
 static_assert(kK6MaxMembers == 4 && kK6MaxIn == 3, "WalkTab layout");
 
@@ -774,16 +783,20 @@ static_assert(kK6MaxMembers == 4 && kK6MaxIn == 3, "WalkTab layout");
 //   0  the component's description (k6_classify_kernel wrote it next to its label) -> the lane's tables, every load of it
 //      issued at once (static indices, registers are free: the kernel needs ~140 waves);
 //   1  the traversal itself -- build_connection's flushes, start vertices, frontier, neighbours in ascending order, every
-//      group consumed by the side that reaches it first -- on the lane's tables only (LDS + registers: its data-dependent
-//      control flow diverges between the lanes, but no memory latency sits inside it); every process_sv call it would make
-//      is recorded instead (which groups are alive at that moment decides what the call sees);
+//      group consumed by the side that reaches it first -- in registers only (gates and liveness as bit masks, the frontier a
+//      packed list: its data-dependent control flow diverges between the lanes, but no memory or LDS latency sits inside
+//      it); every process_sv call it would make is recorded instead (which groups are alive at that moment decides what
+//      the call sees);
 //   2  the recorded calls, in order: call c of all 64 components side by side (assemble_sv with its dependent loads runs
 //      converged), then the bookkeeping of the traversal the call belongs to.
 // (History: one wave per component, 64 lanes running the same scalar code, took ~8,900 waves of 127 registers for configs[1] --
 // three rounds of ~7 us on the 4,096 wave slots, 37 us; one lane per component with the calls made inside the traversal
 // loops, 40 us: 64 walks reach their calls at different iterations and every one of those pays its own round trips.)
+constexpr int kWalkLdsLibs = 16, kWalkLdsKeys = 16;  // run constants of up to this many libraries / counter keys live in LDS
+
 __global__ __launch_bounds__(64) void k6_walk_kernel(K6Arrays a) {
     __shared__ uint32_t s_tab[WalkTab::kFields * 64];
+    __shared__ uint32_t s_const[kWalkLdsLibs * (1 + kNumFlags) + kWalkLdsKeys];
     const int lane = threadIdx.x;
     if (a.mirror_in_walk && blockIdx.x == 0) {
         // k6_mirror_kernel's job, done by the first wave of the kernel that follows k6_emit_kernel anyway: the counters are
@@ -794,32 +807,76 @@ __global__ __launch_bounds__(64) void k6_walk_kernel(K6Arrays a) {
         if (lane == 0 && a.flag_groups) *(volatile uint32_t*)a.flag_groups = a.flag_value;
     }
     const WalkTab T{s_tab + lane};
-    const StridedCounts flag_counts{s_tab + WalkTab::kFlags * 64 + lane};
-    const uint32_t NR = a.counts->n_regions;
     const int mrp = a.min_read_pair;
     const int nk = a.nkeys;
     const uint32_t period = (uint32_t)a.period;
     KPROF(blockIdx.x, 0);
-    const uint32_t n_owners = a.counts->n_owners;
+    // (requested before the constants below are waited for: one round trip for both)
+    const uint32_t NR = a.counts->n_regions;
+    const int mq_last = a.counts->last_maxq;
+    // run constants: in LDS when they are few (every call reads them behind a load it depends on)
+    RunConst rc_{a.lib_mean, a.hist, a.key_density, a.p1->covered_ref_len};
+    if (a.nlibs <= kWalkLdsLibs) {
+        for (int i = lane; i < a.nlibs; i += 64) s_const[i] = __float_as_uint(a.lib_mean[i]);
+        for (int i = lane; i < a.nlibs * kNumFlags; i += 64) s_const[kWalkLdsLibs + i] = a.hist[i];
+        rc_.lib_mean = (const float*)s_const;
+        rc_.hist = s_const + kWalkLdsLibs;
+    }
+    if (nk <= kWalkLdsKeys) {
+        for (int i = lane; i < nk; i += 64) s_const[kWalkLdsLibs * (1 + kNumFlags) + i] = __float_as_uint(a.key_density[i]);
+        rc_.key_density = (const float*)(s_const + kWalkLdsLibs * (1 + kNumFlags));
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (s_const[0] != 0x7FFFFFFFu) KPROF(blockIdx.x, 1);
     const PartRec* const P = a.parts;
-    for (uint32_t oi = blockIdx.x * 64 + lane; oi < n_owners; oi += gridDim.x * 64) {
-        const uint32_t r = a.owners[oi];  // smallest region of a component that is walked here (k6_emit_kernel's list)
-        const int k = (int)a.mcount[r];
+    if (NR != 0xFFFFFFFFu) KPROF(blockIdx.x, 2);
+    // One lane per REGION; the smallest region of a device-walked component (k6_emit_kernel marked it with the component's
+    // size) walks it.  Everything the first phase needs is requested at once, the description (indexed by label = this region)
+    // before it is known whether the region is such an owner: a dependent round trip costs ~1.3 us here, bytes cost nothing.
+    for (uint32_t r = blockIdx.x * 64 + lane; r < NR; r += gridDim.x * 64) {
         const MemberInfo* D = a.members + (size_t)r * kK6MaxMembers;
+        uint4 raw[kK6MaxMembers][7];
+#pragma unroll
+        for (int i = 0; i < kK6MaxMembers; ++i) {
+            const uint4* src = (const uint4*)(D + i);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) raw[i][j] = src[j];
+        }
+        const uint32_t ow = a.owners[r];
+        // _max_readlen at the flush of this region's window: the value of the candidate that closes there (BreakDancer.cpp:254-259)
+        const uint32_t rl0 = (r / period + 1) * period - 1;
+        const int mq0 = a.r_rec[min(rl0, a.cap - 1)].maxq;
+        const int k = (int)ow;
+        if (raw[0][0].x != 0xFFFFFFFEu && raw[3][6].x != 0xFFFFFFFEu) KPROF(blockIdx.x, 3);
+        if (k == 0) continue;
+        const int mrl0 = rl0 < NR ? mq0 : mq_last;
+        uint32_t touch = 0;  // the first words of what the calls will read, requested before the traversal and waited for after it
         // ---- phase 0 ----------------------------------------------------------------------------------------------------
         uint32_t stored = 0;  // bit i: the reads of the member at place i are stored (ReadRegionData.cpp:118-121)
+        uint32_t self_has = 0, self_ok = 0, edge_has = 0, edge_ok = 0;  // bit per place / per pair: the group exists; ... and passes the weight gate (-r)
+        uint32_t win4 = 0;      // flush window of the member at place i, as the place of the window's first member (2 bits each)
         {
             uint32_t mr[kK6MaxMembers], first[kK6MaxMembers], n_in[kK6MaxMembers], np_all[kK6MaxMembers], np_self[kK6MaxMembers],
                 w_self[kK6MaxMembers], st[kK6MaxMembers];
             uint32_t e_lo[kK6MaxMembers][kK6MaxIn], e_w[kK6MaxMembers][kK6MaxIn], e_off[kK6MaxMembers][kK6MaxIn], e_cnt[kK6MaxMembers][kK6MaxIn];
+            int32_t rtid[kK6MaxMembers], rstart[kK6MaxMembers], rend[kK6MaxMembers];
+            uint32_t rn[kK6MaxMembers], rrev[kK6MaxMembers];
+            static_assert(sizeof(MemberInfo) == 7 * 16 && offsetof(MemberInfo, rec) == 4 && offsetof(MemberInfo, np_all) == 40 &&
+                              offsetof(MemberInfo, e_lo) == 56 && offsetof(MemberInfo, stored) == 104 && offsetof(RegionRec, first) == 32,
+                          "a member's record is fetched as seven 16-byte words");
 #pragma unroll
             for (int i = 0; i < kK6MaxMembers; ++i) {
-                const bool h = i < k;
-                const MemberInfo& M = D[h ? i : 0];
-                mr[i] = h ? M.r : 0xFFFFFFFFu;
-                first[i] = M.rec.first; n_in[i] = h ? M.n_in : 0u; np_all[i] = M.np_all; np_self[i] = M.np_self; w_self[i] = M.w_self; st[i] = M.stored;
-#pragma unroll
-                for (int e = 0; e < kK6MaxIn; ++e) { e_lo[i][e] = M.e_lo[e]; e_w[i][e] = M.e_w[e]; e_off[i][e] = M.e_off[e]; e_cnt[i][e] = M.e_cnt[e]; }
+                const uint4 (&q)[7] = raw[i];  // (members past the component's k hold whatever the table held: never used)
+                mr[i] = i < k ? q[0].x : 0xFFFFFFFFu;
+                rtid[i] = (int32_t)q[0].y; rstart[i] = (int32_t)q[0].z; rend[i] = (int32_t)q[0].w;
+                rn[i] = q[1].x; rrev[i] = q[1].y;                      // (q[1].z nonctx, q[1].w nnormal, q[2].x maxq)
+                first[i] = q[2].y; np_all[i] = q[2].z; np_self[i] = q[2].w;
+                w_self[i] = q[3].x; n_in[i] = i < k ? q[3].y : 0u;
+                e_lo[i][0] = q[3].z; e_lo[i][1] = q[3].w; e_lo[i][2] = q[4].x;
+                e_w[i][0] = q[4].y; e_w[i][1] = q[4].z; e_w[i][2] = q[4].w;
+                e_off[i][0] = q[5].x; e_off[i][1] = q[5].y; e_off[i][2] = q[5].z;
+                e_cnt[i][0] = q[5].w; e_cnt[i][1] = q[6].x; e_cnt[i][2] = q[6].y;
+                st[i] = q[6].z;
             }
             // members in ascending region order: a member's place is the number of members with a smaller region
             int place[kK6MaxMembers];
@@ -834,13 +891,14 @@ __global__ __launch_bounds__(64) void k6_walk_kernel(K6Arrays a) {
             for (int i = 0; i < kK6MaxMembers; ++i) {
                 if (i < k) {
                     const int pl = place[i];
-                    T.ord(pl) = (uint32_t)i;
                     T.rid(pl) = mr[i];
                     T.Sbeg(pl) = first[i] + np_all[i] - np_self[i];
                     T.Scnt(pl) = np_self[i];
                     T.Sw(pl) = w_self[i];
                     T.Sslot(pl) = first[i] + n_in[i];
+                    T.Rtid(pl) = (uint32_t)rtid[i]; T.Rstart(pl) = (uint32_t)rstart[i]; T.Rend(pl) = (uint32_t)rend[i]; T.Rn(pl) = rn[i]; T.Rrev(pl) = rrev[i];
                     stored |= (st[i] ? 1u : 0u) << pl;
+                    if (np_self[i]) { self_has |= 1u << pl; if ((int)w_self[i] >= mrp) self_ok |= 1u << pl; }
 #pragma unroll
                     for (int e = 0; e < kK6MaxIn; ++e) {
                         if ((uint32_t)e < n_in[i]) {
@@ -854,53 +912,72 @@ __global__ __launch_bounds__(64) void k6_walk_kernel(K6Arrays a) {
                                 T.Ecnt(pi) = e_cnt[i][e];
                                 T.Ew(pi) = e_w[i][e];
                                 T.Eslot(pi) = first[i] + (uint32_t)e;
+                                if (e_cnt[i][e]) { edge_has |= 1u << pi; if ((int)e_w[i][e] >= mrp) edge_ok |= 1u << pi; }
                             }
                         }
                     }
                 }
             }
+            // flush windows: members in ascending order, a window = period consecutive region ids
+            uint32_t wq[kK6MaxMembers];
+#pragma unroll
+            for (int pl = 0; pl < kK6MaxMembers; ++pl) {
+                wq[pl] = 0xFFFFFFFFu;
+#pragma unroll
+                for (int i = 0; i < kK6MaxMembers; ++i)
+                    if (i < k && place[i] == pl) wq[pl] = mr[i] / period;
+            }
+            int firstp = 0;
+#pragma unroll
+            for (int pl = 0; pl < kK6MaxMembers; ++pl) {
+                if (pl > 0 && wq[pl] != wq[pl - 1]) firstp = pl;
+                win4 |= (uint32_t)firstp << (2 * pl);
+            }
+#pragma unroll
+            for (int i = 0; i < kK6MaxMembers; ++i)
+                if (i < k) {
+                    if (np_all[i]) touch ^= (uint32_t)P[first[i]].key ^ (uint32_t)P[first[i] + np_all[i] - 1].key;
+                    touch ^= a.r_pk[(size_t)mr[i] * 2 * nk] ^ a.r_pk[(size_t)mr[i] * 2 * nk + 2 * nk - 1];
+                }
         }
-        KPROF(blockIdx.x, 1);
+        KPROF(blockIdx.x, 4);
         // ---- phase 1 ----------------------------------------------------------------------------------------------------
         int ncalls = 0;
         {
-            uint32_t self_done = 0, edge_done = 0, self_alive = 0, edge_alive = 0;
-            for (int i = 0; i < k; ++i)
-                if (T.Scnt(i)) self_alive |= 1u << i;
-            for (int e = 0; e < 6; ++e)
-                if (T.Ecnt(e)) edge_alive |= 1u << e;
+            // registers only: the gates are bit masks, the frontier a packed list (2 bits per vertex, 12 entries as in the general walk)
+            uint32_t self_done = 0, edge_done = 0, self_alive = self_has, edge_alive = edge_has;
             // One flush (BreakDancer.cpp:266-346) per window that holds members, in ascending order.  A group is part of
             // the flush of its later region's window; the flush starts traversals first from the members of earlier windows
             // that have a group in it, then from the window's own members, each in ascending order.
             for (int f = 0; f < k;) {
-                const uint32_t W = T.rid(f) / period;
                 int fe = f + 1;
-                while (fe < k && T.rid(fe) / period == W) ++fe;
+                while (fe < k && (int)((win4 >> (2 * fe)) & 3u) == f) ++fe;
                 uint32_t visited = 0;
                 for (int sv = 0; sv < fe; ++sv) {
                     if (visited & (1u << sv)) continue;
-                    int nt = 1, nn = 0;
-                    T.tails(0) = (uint32_t)sv;
+                    int nt = 1;
+                    uint32_t tails = (uint32_t)sv;
                     while (nt) {
-                        nn = 0;
+                        int nn = 0;
+                        uint32_t newtails = 0;
                         for (int ti = 0; ti < nt; ++ti) {
-                            const int tail = (int)T.tails(ti);
+                            const int tail = (int)((tails >> (2 * ti)) & 3u);
                             if (visited & (1u << tail)) continue;
                             for (int nb = 0; nb < fe; ++nb) {  // neighbours in ascending order, the vertex itself at its own place
                                 int A, B;
                                 if (nb == tail) {
                                     if (tail < f) continue;  // its self group belonged to an earlier flush
-                                    if (!T.Scnt(tail) || (self_done & (1u << tail)) || (int)T.Sw(tail) < mrp) continue;
+                                    if (!((self_ok & ~self_done) & (1u << tail))) continue;
                                     self_done |= 1u << tail;
                                     A = tail; B = -1;
                                 } else {
                                     const int x = min(nb, tail), y = max(nb, tail), pi = pair_index(x, y);
                                     if (y < f) continue;     // a group of an earlier flush
-                                    if (!T.Ecnt(pi) || (edge_done & (1u << pi)) || (int)T.Ew(pi) < mrp) continue;
+                                    if (!((edge_ok & ~edge_done) & (1u << pi))) continue;
                                     edge_done |= 1u << pi;
                                     A = x; B = y;
                                 }
-                                if (nn < 12) T.newtails(nn++) = (uint32_t)nb;
+                                if (nn < 12) { newtails |= (uint32_t)nb << (2 * nn); ++nn; }
                                 // the groups the call sees: (A,A), (A,B), (B,B) as far as they are alive and their reads stored;
                                 // paired reads leave their regions before any gate (BreakDancer.cpp:363-368)
                                 const bool stA = (stored >> A) & 1u, stB = (stored >> (B >= 0 ? B : A)) & 1u;
@@ -916,13 +993,14 @@ __global__ __launch_bounds__(64) void k6_walk_kernel(K6Arrays a) {
                             visited |= 1u << tail;
                         }
                         nt = nn;
-                        for (int i = 0; i < nn; ++i) T.tails(i) = T.newtails(i);
+                        tails = newtails;
                     }
                 }
                 f = fe;
             }
         }
-        KPROF(blockIdx.x, 2);
+        if (nk < 0) a.counts->overflow = touch;  // (never: the requested words only have to arrive)
+        KPROF(blockIdx.x, 5);
         // ---- phase 2 ----------------------------------------------------------------------------------------------------
         {
             const GrpRange none{0, 0};
@@ -937,7 +1015,7 @@ __global__ __launch_bounds__(64) void k6_walk_kernel(K6Arrays a) {
                     // _max_readlen at this window's flush: the value of the candidate that closes there (BreakDancer.cpp:254-259)
                     W = T.rid(f) / period;
                     const uint32_t rl = (W + 1) * period - 1;
-                    max_readlen = rl < NR ? a.r_rec[rl].maxq : a.counts->last_maxq;
+                    max_readlen = f == 0 ? mrl0 : (rl < NR ? a.r_rec[rl].maxq : mq_last);
                     nseq = 0;
                 }
                 if (f != cur_f || sv != cur_sv) {  // the first call of another traversal
@@ -953,14 +1031,15 @@ __global__ __launch_bounds__(64) void k6_walk_kernel(K6Arrays a) {
                 if (g & 1u) gs[0] = GrpRange{T.Sbeg(A), T.Scnt(A)};
                 if (g & 2u) gs[1] = GrpRange{T.Ebeg(pair_index(A, Bi)), T.Ecnt(pair_index(A, Bi))};
                 if (g & 4u) gs[2] = GrpRange{T.Sbeg(Bi), T.Scnt(Bi)};
-                const MemberInfo& MA = D[T.ord(A)];
-                const MemberInfo& MB = D[T.ord(Bi)];
+                RegionRec recA{}, recB{};  // (the fields assemble_sv reads)
+                recA.tid = (int32_t)T.Rtid(A); recA.start = (int32_t)T.Rstart(A); recA.end = (int32_t)T.Rend(A); recA.n = T.Rn(A); recA.rev = T.Rrev(A);
+                recB.tid = (int32_t)T.Rtid(Bi); recB.start = (int32_t)T.Rstart(Bi); recB.end = (int32_t)T.Rend(Bi); recB.n = T.Rn(Bi); recB.rev = T.Rrev(Bi);
                 const uint32_t rA = T.rid(A), rB = T.rid(Bi);
                 // proper-read samples of the two regions (first read: nkeys words, last read: nkeys words)
                 const uint32_t* pkA = a.r_pk + (size_t)rA * 2 * nk + nk;
                 const uint32_t* pkB = a.r_pk + (size_t)rB * 2 * nk;
                 uint32_t nacc = 0, ncn = 0;
-                if (assemble_sv(a, P, rA, B >= 0 ? (int32_t)rB : -1, MA.rec, MB.rec, pkA, pkB, gs, max_readlen, slot, start, true, flag_counts, &nacc, &ncn)) {
+                if (assemble_sv(a, rc_, P, rA, B >= 0 ? (int32_t)rB : -1, recA, recB, pkA, pkB, gs, max_readlen, slot, start, true, &nacc, &ncn)) {
                     if (from_old) {  // placed by its order key: after the earlier windows, before this window's own
                         const uint32_t q = atomicAdd(&a.counts->n_old, 1u);
                         a.old_key[q] = ((uint64_t)(W * period) << kKeyShiftT) | ((uint64_t)start << kKeyShiftStart) | (uint64_t)(nseq & kKeySeqMask);
@@ -974,22 +1053,22 @@ __global__ __launch_bounds__(64) void k6_walk_kernel(K6Arrays a) {
                     nacc_tot += nacc;
                     ncn_tot += ncn;
                 }
+                if (c == 0) KPROF(blockIdx.x, 6);
             }
             if (cur_f >= 0 && !from_old && nsv) { a.own_nsv[start] = nsv; a.own_nacc[start] = nacc_tot; a.own_ncn[start] = ncn_tot; }
         }
     }
-    KPROF(blockIdx.x, 3);
+    KPROF(blockIdx.x, 7);
 }
 
 // the components of more than kK6MaxMembers regions (its own launch: inside the kernel above its registers and LDS
 // would cost the common case a third of its occupancy)
 __global__ __launch_bounds__(256) void k6_walk_big_kernel(K6Arrays a) {
     __shared__ BigTab s_big[4];
-    __shared__ int s_flag_counts[4][kNumFlags];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t NR = a.counts->n_regions, n = a.counts->n_owners_big;
     for (uint32_t oi = blockIdx.x * 4 + w; oi < n; oi += gridDim.x * 4) {
-        walk_big(a, s_big[w], s_flag_counts[w], a.owners_big[oi], lane, NR);
+        walk_big(a, s_big[w], a.owners_big[oi], lane, NR);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -1395,7 +1474,7 @@ void launch_k6_groups(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
 void launch_k6_walk(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
     if (n_anom_host == 0 || a.force_host) return;
     const uint32_t gp = std::min<uint32_t>((n_anom_host / 8 + 3) / 4 + 1, 16384u);
-    hipLaunchKernelGGL(k6_walk_kernel, dim3(std::min<uint32_t>(n_anom_host / 64 / 2 + 1, 4096u)), dim3(64), 0, s, a);  // components <= regions <= reads / 2 (grid-stride beyond)
+    hipLaunchKernelGGL(k6_walk_kernel, dim3(std::min<uint32_t>(n_anom_host / 64 / 4 + 1, 4096u)), dim3(64), 0, s, a);  // a lane per region, grid-stride: regions are typically a tenth of the reads
     if (a.big_walk) hipLaunchKernelGGL(k6_walk_big_kernel, dim3(gp / 8 + 1), dim3(256), 0, s, a);
 }
 

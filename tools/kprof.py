@@ -59,13 +59,19 @@ def main():
 
     # walk kernel: one lane per component, rows = workgroup (clocks of its lane 0 / of the whole wave at the end)
     own = t[:32768]
-    have = own[:, 3] > 0
     k0 = own[:, 0][own[:, 0] > 0].min()
-    print("walk kernel: %d waves" % have.sum())
+    have = own[:, 4] > 0  # waves whose lane 0 walks a component
+    print("walk kernel: %d waves, %d with components (clocks of lane 0)" % ((own[:, 7] > 0).sum(), have.sum()))
     stats("wave entry", own[have, 0] - k0)
-    stats("phase 0: tables (lane 0)", own[have, 1] - own[have, 0])
-    stats("phase 1: traversal (lane 0)", own[have, 2] - own[have, 1])
-    stats("wave end", own[have, 3] - k0)
+    stats("run constants in LDS", own[have, 1] - own[have, 0])
+    stats("n_regions known", own[have, 2] - own[have, 1])
+    stats("description arrived", own[have, 3] - own[have, 2])
+    stats("tables built (phase 0)", own[have, 4] - own[have, 3])
+    stats("traversal (phase 1) + touches", own[have, 5] - own[have, 4])
+    c1 = have & (own[:, 6] > 0)
+    stats("first call", own[c1, 6] - own[c1, 5])
+    stats("rest + end", own[c1, 7] - own[c1, 6])
+    stats("wave end", own[have, 7] - k0)
     sc = t[32768:]
     hs = sc[:, 5] > 0
     if hs.any():

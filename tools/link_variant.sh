@@ -1,6 +1,14 @@
 #!/bin/bash
-# links a measurement build of libbdx.so: tools/link_variant.sh <name> <replacement k6 object>   (run from the repo root, after make)
+# links a measurement build of libbdx.so: tools/link_variant.sh <name> <replacement object>...   (run from the repo root, after make)
+# a replacement object named like one of the library's (k1_classify*.o, k6_assemble*.o, ...) takes its place
 set -e
 C=breakdancer_amd/csrc
 mkdir -p variants
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o variants/libbdx_$1.so $C/k1_classify.o $C/k2_compact.o $C/k3_regions.o $C/k4_join.o $C/k5_poisson.o $2 $C/k7_exchange.o $C/bdx_api.o $C/bdx_walk.o $C/bdx_walk_reads.o
+name=$1; shift
+objs=""
+for o in k1_classify k2_compact k3_regions k4_join k5_poisson k6_assemble k7_exchange bdx_api bdx_walk bdx_walk_reads; do
+    use=$C/$o.o
+    for r in "$@"; do case "$(basename $r)" in ${o%%_*}_*) use=$r;; esac; done
+    objs="$objs $use"
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o variants/libbdx_$name.so $objs
