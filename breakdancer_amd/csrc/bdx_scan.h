@@ -8,6 +8,14 @@
 
 namespace bdx {
 
+// in-kernel clocks of a measurement build (-DBDX_KPROF, tools/kprof.py): one table per translation unit
+#ifdef BDX_KPROF
+static __device__ unsigned long long g_kprof[8 * 65536];
+#define KPROF(row, col) do { if ((threadIdx.x & 63) == 0 && (row) < 65536u) g_kprof[(size_t)(row) * 8 + (col)] = wall_clock64(); } while (0)
+#else
+#define KPROF(row, col) do {} while (0)
+#endif
+
 struct U4 {
     uint32_t x, y, z, w;
 };
@@ -195,27 +203,39 @@ __device__ __forceinline__ T lookback_exclusive(const T& tot, unsigned long long
         const int col = lane / kWin, k = lane % kWin;
         uint32_t acc = 0;     // this lane's column: aggregates walked over so far (the same in all lanes of the column)
         bool frozen = false;  // the column has met an inclusive prefix
-        for (uint32_t back = 0;; back += kWin) {
-            const int64_t pred = (int64_t)bid - 1 - (int64_t)back - k;
-            uint32_t val = 0, st = 2;  // past the first workgroup: an inclusive prefix of zero
-            if (!frozen && pred >= 0) {
-                unsigned long long w;
-                do {
-                    w = __hip_atomic_load(&state[(size_t)pred * kCols + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } while ((w & (0x3FFFFFFFull << 32)) != stamp_bits || (w >> 62) == 0);
-                val = (uint32_t)w;
-                st = (uint32_t)(w >> 62);
-            }
-            // the nearest predecessor (smallest k) of the column that carries an inclusive prefix ends the column's walk
-            const uint64_t incl = __ballot(!frozen && st == 2);
-            const uint64_t mine = kWin == 64 ? incl : ((incl >> (col * kWin)) & ((1ull << kWin) - 1));
-            const int stop = mine ? __builtin_ctzll(mine) : kWin;
-            uint32_t part = (!frozen && k <= stop) ? val : 0u;
+        // kAhead windows are requested at once (the chain of dependent round trips through a few hundred workgroups is what the
+        // scan costs: 586 workgroups in steps of 16 took 37 of them), then evaluated nearest first
+        constexpr int kAhead = 4;
+        for (uint32_t back = 0;; back += kWin * kAhead) {
+            unsigned long long w[kAhead];
 #pragma unroll
-            for (int o = 1; o < kWin; o <<= 1) part += __shfl_xor(part, o);
-            acc += part;
-            if (mine) frozen = true;
-            if (!__ballot(!frozen)) break;
+            for (int u = 0; u < kAhead; ++u) {
+                const int64_t pred = (int64_t)bid - 1 - (int64_t)back - (int64_t)u * kWin - k;
+                w[u] = (2ull << 62) | stamp_bits;  // past the first workgroup: an inclusive prefix of zero
+                if (!frozen && pred >= 0) w[u] = __hip_atomic_load(&state[(size_t)pred * kCols + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            bool done = false;
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                if (done) break;  // (wave-uniform)
+                const int64_t pred = (int64_t)bid - 1 - (int64_t)back - (int64_t)u * kWin - k;
+                unsigned long long x = w[u];
+                if (!frozen && pred >= 0)
+                    while ((x & (0x3FFFFFFFull << 32)) != stamp_bits || (x >> 62) == 0)  // not published yet: ask again
+                        x = __hip_atomic_load(&state[(size_t)pred * kCols + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t val = (uint32_t)x, st = (uint32_t)(x >> 62);
+                // the nearest predecessor (smallest k) of the column that carries an inclusive prefix ends the column's walk
+                const uint64_t incl = __ballot(!frozen && st == 2);
+                const uint64_t mine = kWin == 64 ? incl : ((incl >> (col * kWin)) & ((1ull << kWin) - 1));
+                const int stop = mine ? __builtin_ctzll(mine) : kWin;
+                uint32_t part = (!frozen && k <= stop) ? val : 0u;
+#pragma unroll
+                for (int o = 1; o < kWin; o <<= 1) part += __shfl_xor(part, o);
+                acc += part;
+                if (mine) frozen = true;
+                if (!__ballot(!frozen)) done = true;
+            }
+            if (done) break;
         }
         if (k == 0) s_prefix[col] = acc;
     }
@@ -230,28 +250,49 @@ __device__ __forceinline__ T lookback_exclusive(const T& tot, unsigned long long
     return carry;
 }
 
-template <class T, class In, class Out>
+// kIters elements per thread (element it of thread t: base + it * kScanBlock + t): fewer workgroups and fewer steps of the walk, but
+// the input functors' dependent loads run one iteration after the other -- measured slower for both of K3's scans (head scan 16 -> 20 us)
+template <class T, class In, class Out, int kIters>
 __global__ __launch_bounds__(kScanBlock) void scan_lookback(In in, Out out, const uint32_t* n_ptr, unsigned long long* state, uint32_t stamp) {
     __shared__ T s_ws[kScanBlock / 64];
     __shared__ uint32_t s_prefix[ScanCols<T>::n];
     const uint32_t n = *n_ptr;
     const uint32_t bid = blockIdx.x;
-    const uint32_t base = bid * kScanBlock;
+    const uint32_t base = bid * kScanBlock * kIters;
     if (base >= n) return;
-    const uint32_t j = base + threadIdx.x;
-    const T e = j < n ? in(j, n) : zero_of<T>();
-    T tot;
-    const T inc_local = block_incl_scan(e, s_ws, &tot);
+    constexpr uint32_t kRow0 = ScanCols<T>::n == 4 ? 0u : 32768u;  // (clocks: the 4-column scan and the 1-column scan of a translation unit)
+    (void)kRow0;
+    KPROF(kRow0 + bid * 4 + (threadIdx.x >> 6), 0);
+    T e[kIters], inc[kIters];
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {  // (all inputs requested before the first is used)
+        const uint32_t j = base + it * kScanBlock + threadIdx.x;
+        e[it] = j < n ? in(j, n) : zero_of<T>();
+    }
+    T tot = zero_of<T>();
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {
+        T t;
+        inc[it] = tot + block_incl_scan(e[it], s_ws, &t);
+        tot = tot + t;
+    }
+    KPROF(kRow0 + bid * 4 + (threadIdx.x >> 6), 1);
     const T carry = lookback_exclusive<T>(tot, state, stamp, bid, s_prefix);
-    if (j < n) out(j, n, carry + inc_local, e);
+    KPROF(kRow0 + bid * 4 + (threadIdx.x >> 6), 2);
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {
+        const uint32_t j = base + it * kScanBlock + threadIdx.x;
+        if (j < n) out(j, n, carry + inc[it], e[it]);
+    }
+    KPROF(kRow0 + bid * 4 + (threadIdx.x >> 6), 3);
 }
 
-// host side: one launch; state = [scan_grid(n_upper, 1)][columns] 64-bit words, zero once at allocation; stamp != 0 and
-// different from run to run (words of the previous run are then simply "not there yet")
-template <class T, class In, class Out>
+// host side: one launch; state = [scan_grid(n_upper, 1)][columns] 64-bit words (enough for any kIters), zero once at allocation;
+// stamp != 0 and different from run to run (words of the previous run are then simply "not there yet")
+template <class T, int kIters = 1, class In, class Out>
 void scan_launch_lb(In in, Out out, const uint32_t* n_ptr, uint32_t n_upper, unsigned long long* state, uint32_t stamp, hipStream_t s) {
-    const uint32_t g = scan_grid(n_upper, 1);
-    hipLaunchKernelGGL((scan_lookback<T, In, Out>), dim3(g), dim3(kScanBlock), 0, s, in, out, n_ptr, state, stamp);
+    const uint32_t g = scan_grid(n_upper, kIters);
+    hipLaunchKernelGGL((scan_lookback<T, In, Out, kIters>), dim3(g), dim3(kScanBlock), 0, s, in, out, n_ptr, state, stamp);
 }
 
 // the same scan with a side job (a device functor run by one extra workgroup of kScanBlock threads during phase 1; its

@@ -158,9 +158,9 @@ void launch_k3(const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n
     HeadOut hout{a};
     if (a.lb_state) {  // one launch per scan (decoupled look-back) instead of two
         const size_t nblk = scan_grid(a.cap, 1);
-        scan_launch_lb<U4>(hin, hout, n_ptr, n_anom_host, a.lb_state, a.lb_stamp, s);
+        scan_launch_lb<U4, 1>(hin, hout, n_ptr, n_anom_host, a.lb_state, a.lb_stamp, s);
         const CandCtx cx{a, cp, p1, min_len, seq_coverage_lim, nn_base, tail};
-        scan_launch_lb<uint32_t>(AcceptIn{cx}, AcceptOut{cx, nkeys}, &a.counts->n_cand, n_anom_host, a.lb_state + 4 * nblk, a.lb_stamp, s);
+        scan_launch_lb<uint32_t, 1>(AcceptIn{cx}, AcceptOut{cx, nkeys}, &a.counts->n_cand, n_anom_host, a.lb_state + 4 * nblk, a.lb_stamp, s);
         if (region_of_launch) hipLaunchKernelGGL(k3_region_of_kernel, dim3((n_anom_host + 255) / 256), dim3(256), 0, s, a, p1);
         return;
     }
@@ -174,3 +174,12 @@ void launch_k3(const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n
 }
 
 }  // namespace bdx
+
+#ifdef BDX_KPROF
+extern "C" int bdx_debug_kprof3(unsigned long long* out, size_t n) {
+    const int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bdx::g_kprof), n * sizeof(unsigned long long));
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(bdx::g_kprof)) == hipSuccess) (void)hipMemset(p, 0, sizeof(unsigned long long) * 8 * 65536);
+    return rc;
+}
+#endif

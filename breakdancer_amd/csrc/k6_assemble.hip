@@ -28,13 +28,6 @@
 
 namespace bdx {
 
-#ifdef BDX_KPROF
-__device__ unsigned long long g_kprof[8 * 65536];
-#define KPROF(row, col) do { if ((threadIdx.x & 63) == 0 && (row) < 65536u) g_kprof[(size_t)(row) * 8 + (col)] = wall_clock64(); } while (0)
-#else
-#define KPROF(row, col) do {} while (0)
-#endif
-
 namespace {
 
 __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {

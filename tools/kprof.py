@@ -38,15 +38,24 @@ def main():
     L = lib.load()
     buf = np.zeros(8 * 65536, dtype=np.uint64)
     L.bdx_debug_kprof.argtypes = [C.c_void_p, C.c_size_t]
+    buf3 = np.zeros(8 * 65536, dtype=np.uint64)
+    have3 = hasattr(L, "bdx_debug_kprof3")
+    if have3:
+        L.bdx_debug_kprof3.argtypes = [C.c_void_p, C.c_size_t]
     for _ in range(5):
         bd.run()
     torch.cuda.synchronize()
     L.bdx_debug_kprof(buf.ctypes.data_as(C.c_void_p), buf.size)  # (clears the device buffer)
+    if have3:
+        L.bdx_debug_kprof3(buf3.ctypes.data_as(C.c_void_p), buf3.size)
     bd.run()
     torch.cuda.synchronize()
     rc = L.bdx_debug_kprof(buf.ctypes.data_as(C.c_void_p), buf.size)
     assert rc == 0, rc
     t = buf.reshape(65536, 8).astype(np.int64)
+    if have3:
+        L.bdx_debug_kprof3(buf3.ctypes.data_as(C.c_void_p), buf3.size)
+        t3 = buf3.reshape(65536, 8).astype(np.int64)
     split = bd.walk_split()
     print("reads", n, "svs", bd.summary().get("n_sv") if hasattr(bd.summary(), "get") else "", "walk split", split)
 
@@ -85,6 +94,18 @@ def main():
         stats("terms, K5, scores (last chunk)", sc[g, 4] - sc[g, 3])
         stats("records -> host, end", sc[g, 5] - sc[g, 4])
         stats("wave end", sc[hs, 5] - s0)
+    if have3:
+        for name, rows in (("head scan (4 columns)", t3[:32768]), ("accept scan", t3[32768:])):
+            h = rows[:, 3] > 0
+            if not h.any():
+                continue
+            z = rows[h, 0].min()
+            print("%s: %d waves" % (name, h.sum()))
+            stats("wave entry", rows[h, 0] - z)
+            stats("inputs + block scan", rows[h, 1] - rows[h, 0])
+            stats("look-back", rows[h, 2] - rows[h, 1])
+            stats("outputs issued", rows[h, 3] - rows[h, 2])
+            stats("wave end", rows[h, 3] - z)
     bd.close()
 
 
