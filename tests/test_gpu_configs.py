@@ -94,6 +94,32 @@ def test_many_files_and_libraries_take_the_general_paths():
         compare(run, product_from_oracle(run))
 
 
+@pytest.mark.parametrize("cluster,two_files,nostash", [(15, False, False), (17, False, False), (16, True, False), (33, True, False), (16, True, True)])
+def test_ready_made_records_of_k1_and_their_fallbacks(cluster, two_files, nostash, monkeypatch):
+    """K1 leaves the anomalous reads of a tile ready-made for K2 when there are at most 16 of them and the tile's reads share one
+    library and file; tiles with more, mixed tiles (here: two files alternating in 40 kbp blocks, so that tiles inside a block
+    are uniform and the ones at a block edge are not) and runs with BDX_NO_STASH take the column gather.  All must equal the
+    oracle, with one counter key and with two."""
+    from breakdancer_amd.synth import make_chromosome
+    if nostash:
+        monkeypatch.setenv("BDX_NO_STASH", "1")
+    d = make_chromosome(length=2_000_000, coverage=30.0, seed=40 + cluster, cluster=cluster, discordant=0.02)
+    cfg, bams = cfg_line("rg0", "a.bam", "lib0", 400.0, 30.0), ["a.bam"]
+    if two_files:
+        # both mates of a pair go to the file of the pair's left end (the classifier reads lib / file per read, the oracle per stream)
+        left = np.minimum(d["pos"], d["mpos"])
+        blk = ((left // 40_000) & 1).astype(np.uint8)
+        d = dict(d)
+        d["bam"] = blk
+        d["lib"] = blk
+        cfg += cfg_line("rg1", "b.bam", "lib1", 400.0, 30.0)
+        bams = ["a.bam", "b.bam"]
+    for kw in (dict(), dict(cn_lib=1, print_af=1, min_read_pair=3)):
+        run = oracle_from_soa(d, cfg, bams, make_opts(**kw), ["c1"])
+        assert run.n_svs > 100
+        compare(run, product_from_oracle(run))
+
+
 SPLIT_SETS = [dict(), dict(buffer_size=1), dict(buffer_size=2), dict(buffer_size=7, min_read_pair=1), dict(min_read_pair=3),
               dict(min_read_pair=4, cn_lib=1, print_af=1), dict(fisher=1), dict(chr_tid=1), dict(transchr_rearrange=1),
               dict(min_len=30, seq_coverage_lim=3), dict(max_sd=900), dict(illumina_long_insert=1)]
