@@ -27,6 +27,7 @@ __device__ __forceinline__ MonoRec mono_shfl_down(const MonoRec& a, int o) {
 __device__ __forceinline__ void finalize2_body(const FinalizeParams& p) {
     __shared__ uint32_t s_acc[255 * 12 + 256];  // nlibs*11 + nlibs + nbams at the documented limits
     __shared__ unsigned long long s_ref[256];
+    __shared__ uint32_t s_head[2];  // covered_ref_len, window
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     static_assert(kCntCopies == 64, "one lane per counter copy");
     for (int i0 = 0; i0 < p.ncnt; i0 += 4) {  // counters: [kCntCopies][ncnt] -> [ncnt], one wave per counter
@@ -69,6 +70,7 @@ __device__ __forceinline__ void finalize2_body(const FinalizeParams& p) {
             W = min(W, tmp);
         }
         p.p1->window = W;
+        s_head[0] = covered; s_head[1] = (uint32_t)W;
         if (p.key_density) {  // same float32 expressions as the host side (set_pass1 in bdx_api.hip)
             const uint32_t* lib_cnt = s_acc + p.nlibs * kNumFlags;
             const uint32_t* bam_cnt = lib_cnt + p.nlibs;
@@ -85,13 +87,23 @@ __device__ __forceinline__ void finalize2_body(const FinalizeParams& p) {
             }
         }
     }
-    if (p.p1_host) {  // mirror the finished record into pinned host memory
-        __threadfence();
+    if (p.p1_host) {
+        // mirror the finished record into pinned host memory: the column totals are the previous kernel's (plain loads), this
+        // workgroup's own results come from LDS -- reading the record back would cost a fence and a round trip on the path the
+        // host waits for
         __syncthreads();
         const uint32_t* src = (const uint32_t*)p.p1;
         uint32_t* dst = (uint32_t*)p.p1_host;
-        const int words = (int)((offsetof(Pass1, ref_len) + sizeof(unsigned long long) * (size_t)p.nbams) / 4);
-        for (int i = t; i < words; i += 256) dst[i] = __builtin_nontemporal_load(src + i);
+        static_assert(offsetof(Pass1, covered_ref_len) == 0 && offsetof(Pass1, window) == 4 && offsetof(Pass1, ref_len) % 8 == 0, "Pass1 mirror");
+        constexpr int kRefWord = (int)(offsetof(Pass1, ref_len) / 4);
+        const int words = kRefWord + 2 * p.nbams;
+        for (int i = t; i < words; i += 256) {
+            uint32_t v;
+            if (i < 2) v = s_head[i];
+            else if (i < kRefWord) v = src[i];
+            else v = (uint32_t)(s_ref[(i - kRefWord) >> 1] >> (32 * ((i - kRefWord) & 1)));
+            dst[i] = v;
+        }
         if (p.flag_host) {
             __threadfence_system();
             __syncthreads();

@@ -29,19 +29,20 @@ __device__ __forceinline__ int4 ldnt(const int32_t* p) { const v4i v = __builtin
 __device__ __forceinline__ ushort4 ldnt(const uint16_t* p) { const v4us v = __builtin_nontemporal_load((const v4us*)p); return make_ushort4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ uchar4 ldnt(const uint8_t* p) { const v4uc v = __builtin_nontemporal_load((const v4uc*)p); return make_uchar4(v.x, v.y, v.z, v.w); }
 
+// (selects, innermost case first: as nested ifs this compiled to five levels of exec-mask branches per read)
 __device__ __forceinline__ int classify_read(unsigned sam, int tid, int mtid, int pos, int mpos, int ai, float upper,
                                              float lower) {
-    if ((sam & 0x400u) || !(sam & 0x1u)) return F_NA;
-    if (sam & 0x4u) return F_UNMAPPED;
-    if (sam & 0x8u) return F_MATE_UNMAPPED;
-    if (tid != mtid) return F_CTX;
     const bool rr = sam & 0x10u, mr = sam & 0x20u;
-    if (rr == mr) return rr ? F_RR : F_FF;
-    if ((pos < mpos) == rr) return F_RF;
     const float fi = (float)ai;  // the reference compares int against the float cutoffs
-    if (fi > upper) return F_LARGE;
-    if (fi < lower) return F_SMALL;
-    return F_NORMAL_FR;
+    int f = fi < lower ? F_SMALL : F_NORMAL_FR;
+    f = fi > upper ? F_LARGE : f;
+    f = ((pos < mpos) == rr) ? F_RF : f;
+    f = (rr == mr) ? (rr ? F_RR : F_FF) : f;
+    f = tid != mtid ? F_CTX : f;
+    f = (sam & 0x8u) ? F_MATE_UNMAPPED : f;
+    f = (sam & 0x4u) ? F_UNMAPPED : f;
+    f = ((sam & 0x400u) || !(sam & 0x1u)) ? F_NA : f;
+    return f;
 }
 
 __device__ __forceinline__ int remap_long_insert(int f, int ai, float upper, float lower) {
