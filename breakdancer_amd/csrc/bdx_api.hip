@@ -81,7 +81,7 @@ struct bdx_ctx {
     DevBuf b_tid, b_pos, b_mtid, b_mpos, b_isize, b_flag, b_qlen, b_mapq, b_lib, b_bam, b_key;
 
     // stage buffers
-    DevBuf b_libs, b_cls, b_tile_tot, b_tile_pre, b_tile_mono, b_blk_cnt, b_cnt, b_p1, b_fold, b_stash;
+    DevBuf b_libs, b_cls, b_tile_tot, b_tile_pre, b_tile_mono, b_blk_cnt, b_cnt, b_p1, b_fold, b_stash, b_chunk_tot;
     DevBuf b_c_tid, b_c_pos, b_c_isize, b_c_meta, b_c_key, b_c_idx, b_c_nn, b_c_pk;
     DevBuf b_cand, b_pre_q, b_pre_rev, b_pre_nonctx, b_c_first, b_c_maxq, b_c_rid, b_region_of, b_ws_u4, b_ws_u32, b_totals, b_counts;
     DevBuf b_bcnt, b_boff, b_bcur, b_e_key, b_e_idx, b_partner, b_t_key, b_t_idx;
@@ -424,7 +424,7 @@ void bdx_destroy(bdx_ctx* c) {
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     DevBuf* bufs[] = {&c->b_tid, &c->b_pos, &c->b_mtid, &c->b_mpos, &c->b_isize, &c->b_flag, &c->b_qlen, &c->b_mapq, &c->b_lib,
-                      &c->b_bam, &c->b_key, &c->b_libs, &c->b_cls, &c->b_stash, &c->b_tile_tot, &c->b_tile_pre, &c->b_tile_mono,
+                      &c->b_bam, &c->b_key, &c->b_libs, &c->b_cls, &c->b_stash, &c->b_chunk_tot, &c->b_tile_tot, &c->b_tile_pre, &c->b_tile_mono,
                       &c->b_blk_cnt, &c->b_cnt, &c->b_p1, &c->b_c_tid, &c->b_c_pos, &c->b_c_isize,
                       &c->b_c_meta, &c->b_c_key, &c->b_c_idx, &c->b_c_nn, &c->b_c_pk, &c->b_cand, &c->b_pre_q, &c->b_pre_rev,
                       &c->b_pre_nonctx, &c->b_c_first, &c->b_c_maxq, &c->b_c_rid, &c->b_region_of, &c->b_ws_u4, &c->b_ws_u32, &c->b_totals,
@@ -692,6 +692,16 @@ int do_pass1(bdx_ctx* c, uint32_t na_cap, bool wait, bool defer_second) {
     fp.fold_part = c->b_fold.as<MonoRec>();
     fp.nlibs = nlibs; fp.nbams = nbams; fp.nkeys = nkeys; fp.ncols = ncols; fp.ncnt = ncnt; fp.w0 = c->w0;
     fp.tile_tot = c->b_tile_tot.as<uint32_t>(); fp.tile_pre = c->b_tile_pre.as<uint32_t>(); fp.tile_mono = c->b_tile_mono.as<MonoRec>();
+    {   // the tile-total columns are scanned in chunks of whole rounds of a workgroup (4096 super tiles), at most kMaxChunks of them
+        const uint32_t nsuper = (ntiles + kK2TilesPerWave - 1) / kK2TilesPerWave;
+        const uint32_t round = 4096;
+        const uint32_t rounds = std::max<uint32_t>(1, (nsuper + round - 1) / round);
+        fp.chunk_super = round * ((rounds + kMaxChunks - 1) / kMaxChunks);
+        fp.nchunk = std::max<uint32_t>(1, (nsuper + fp.chunk_super - 1) / fp.chunk_super);
+        HIPCHK(c, c->b_chunk_tot.ensure((size_t)ncols * kMaxChunks * 8));
+        fp.chunk_tot = c->b_chunk_tot.as<uint32_t>();
+        fp.chunk_base = fp.chunk_tot + (size_t)ncols * kMaxChunks;
+    }
     fp.blk_cnt = c->b_blk_cnt.as<uint32_t>(); fp.cnt = c->b_cnt.as<uint32_t>(); fp.p1 = c->b_p1.as<Pass1>();
     HIPCHK(c, c->b_kdens.ensure(64 * 4));
     fp.libs = c->b_libs.as<DevLib>(); fp.cn_lib = c->opts.cn_lib; fp.key_density = c->b_kdens.as<float>();
@@ -806,6 +816,7 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepa
         k2.r = c->d; k2.n = c->n; k2.ntiles = c->ntiles; k2.tstride = c->tstride; k2.nkeys = nkeys; k2.libs = c->b_libs.as<DevLib>();
         k2.cls = c->b_cls.as<uint8_t>(); k2.tile_pre = c->b_tile_pre.as<uint32_t>(); k2.c = cp;
         k2.tile_tot = c->b_tile_tot.as<uint32_t>(); k2.stash = c->use_stash ? c->b_stash.as<StashRec>() : nullptr;
+        k2.chunk_tot = c->fp_deferred.chunk_tot; k2.chunk_base = c->fp_deferred.chunk_base; k2.chunk_super = c->fp_deferred.chunk_super;
         k2.nn_base = nn_base;
         for (int k = 0; k < nkeys; ++k) k2.pk_base[k] = pk_base ? pk_base[k] : 0u;
         // scratch of the later stages cleared by this launch: the per-candidate max read length of K3, and (when this

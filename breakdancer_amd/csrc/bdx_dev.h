@@ -11,6 +11,7 @@ constexpr int kWaves = kBlock / 64;
 constexpr int kNumFlags = 11;
 constexpr int kK2TilesPerWave = 4; // K2 compacts four of K1's tiles per wave and needs the prefixes at those boundaries only
 constexpr int kCntCopies = 64;   // replication factor of the global pass-1 counters (power of two)
+constexpr int kMaxChunks = 64;   // chunks a tile-total column is scanned in (one workgroup of finalize_kernel each)
 constexpr int kStashCap = 16;    // anomalous reads per tile that K1 leaves ready-made for K2 (a tile with more is compacted from the columns)
 constexpr int kStashKeys = 2;    // ... when there are at most this many normal-read counter keys (K2's fast path holds their totals in 16 lanes)
 
@@ -86,7 +87,11 @@ struct FinalizeParams {
     int nlibs, nbams, nkeys, ncols, ncnt;
     int w0;
     const uint32_t* tile_tot;
-    uint32_t* tile_pre;         // [ncols][tstride]: exclusive scan of tile_tot per column at every kK2TilesPerWave-th tile, entry tile / kK2TilesPerWave
+    uint32_t* tile_pre;         // [ncols][tstride]: exclusive scan of tile_tot per column at every kK2TilesPerWave-th tile (entry tile /
+                                // kK2TilesPerWave), restarting at every chunk of chunk_super such entries ...
+    uint32_t* chunk_tot;        // [ncols][kMaxChunks]: ... whose totals are here ...
+    uint32_t* chunk_base;       // [ncols][kMaxChunks]: ... and, from the second level, the totals of the chunks before each
+    uint32_t chunk_super, nchunk;
     const MonoRec* tile_mono;
     const uint32_t* blk_cnt;
     uint32_t* cnt;              // [ncnt] reduced counters
@@ -134,7 +139,10 @@ struct K2Params {
     int nkeys;
     const DevLib* libs;
     const uint8_t* cls;
-    const uint32_t* tile_pre;
+    const uint32_t* tile_pre;  // chunk-local prefixes and the chunks' totals (FinalizeParams)
+    const uint32_t* chunk_tot;  // (K2 adds up the chunks before its own when it runs beside the second level ...
+    const uint32_t* chunk_base; // ... and reads the sum otherwise)
+    uint32_t chunk_super;
     const uint32_t* tile_tot;  // K1's per-tile totals and its ready-made records (stash null: not available)
     const StashRec* stash;
     Compact c;

@@ -28,6 +28,7 @@ __device__ __forceinline__ void finalize2_body(const FinalizeParams& p) {
     __shared__ uint32_t s_acc[255 * 12 + 256];  // nlibs*11 + nlibs + nbams at the documented limits
     __shared__ unsigned long long s_ref[256];
     __shared__ uint32_t s_head[2];  // covered_ref_len, window
+    __shared__ uint32_t s_col[64];  // totals of the tile-total columns: n_anom, n_normal, key_tot[]
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     static_assert(kCntCopies == 64, "one lane per counter copy");
     for (int i0 = 0; i0 < p.ncnt; i0 += 4) {  // counters: [kCntCopies][ncnt] -> [ncnt], one wave per counter
@@ -39,6 +40,27 @@ __device__ __forceinline__ void finalize2_body(const FinalizeParams& p) {
             s_acc[i] = v;
             p.cnt[i] = v;
             if (p.cnt_host) p.cnt_host[i] = v;
+        }
+    }
+    for (int c0 = 0; c0 < p.ncols; c0 += 4) {  // one wave per column: its chunks' totals
+        const int c = c0 + w;
+        uint32_t v = (c < p.ncols && (uint32_t)lane < p.nchunk) ? p.chunk_tot[(size_t)c * kMaxChunks + lane] : 0u;
+        {   // what K2 adds to a chunk-local prefix: the totals of the chunks before (exclusive scan over the lanes)
+            uint32_t inc = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t u = __shfl_up(inc, o);
+                if (lane >= o) inc += u;
+            }
+            if (c < p.ncols) p.chunk_base[(size_t)c * kMaxChunks + lane] = inc - v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0 && c < p.ncols) {
+            s_col[c] = v;
+            if (c == kColAnom) p.p1->n_anom = v;
+            else if (c == kColNormal) p.p1->n_normal = v;
+            else p.p1->key_tot[c - kColKey0] = v;
         }
     }
     for (int b0 = 0; b0 < p.nbams; b0 += 4) {  // one wave per source file: ordered tree fold of its <= 64 partial folds
@@ -88,19 +110,19 @@ __device__ __forceinline__ void finalize2_body(const FinalizeParams& p) {
         }
     }
     if (p.p1_host) {
-        // mirror the finished record into pinned host memory: the column totals are the previous kernel's (plain loads), this
-        // workgroup's own results come from LDS -- reading the record back would cost a fence and a round trip on the path the
-        // host waits for
+        // mirror the finished record into pinned host memory, from LDS: reading it back would cost a fence and a round trip on
+        // the path the host waits for
         __syncthreads();
-        const uint32_t* src = (const uint32_t*)p.p1;
         uint32_t* dst = (uint32_t*)p.p1_host;
-        static_assert(offsetof(Pass1, covered_ref_len) == 0 && offsetof(Pass1, window) == 4 && offsetof(Pass1, ref_len) % 8 == 0, "Pass1 mirror");
+        static_assert(offsetof(Pass1, covered_ref_len) == 0 && offsetof(Pass1, window) == 4 && offsetof(Pass1, n_anom) == 8 &&
+                          offsetof(Pass1, n_normal) == 12 && offsetof(Pass1, key_tot) == 16 && offsetof(Pass1, ref_len) % 8 == 0, "Pass1 mirror");
+        static_assert(kColAnom == 0 && kColNormal == 1 && kColKey0 == 2, "the record's words 2.. are the column totals in column order");
         constexpr int kRefWord = (int)(offsetof(Pass1, ref_len) / 4);
         const int words = kRefWord + 2 * p.nbams;
         for (int i = t; i < words; i += 256) {
             uint32_t v;
             if (i < 2) v = s_head[i];
-            else if (i < kRefWord) v = src[i];
+            else if (i < kRefWord) v = i - 2 < p.ncols ? s_col[i - 2] : 0u;
             else v = (uint32_t)(s_ref[(i - kRefWord) >> 1] >> (32 * ((i - kRefWord) & 1)));
             dst[i] = v;
         }
@@ -112,7 +134,7 @@ __device__ __forceinline__ void finalize2_body(const FinalizeParams& p) {
     }
     if (p.na_cap) {
         __syncthreads();
-        if (t == 0 && p.p1->n_anom > p.na_cap) p.p1->n_anom = 0;
+        if (t == 0 && s_col[kColAnom] > p.na_cap) p.p1->n_anom = 0;
     }
 }
 

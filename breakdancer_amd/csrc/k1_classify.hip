@@ -19,6 +19,12 @@
 
 #include <limits.h>
 
+#ifdef BDX_KPROF
+#include "bdx_scan.h"  // in-kernel clocks of a measurement build
+#else
+#define KPROF(row, col) do {} while (0)
+#endif
+
 namespace bdx {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -349,60 +355,76 @@ __device__ __forceinline__ void finalize_tail(const FinalizeParams& p) {
 
 // workgroups [0, ncols): tile scans; workgroups [ncols, ncols + nfold): ordered partial folds of the monoid table
 __global__ __launch_bounds__(kFinBlock) void finalize_kernel(const FinalizeParams p) {
-    __shared__ uint32_t s_ws[kFinBlock / 64];
     __shared__ uint32_t s_carry;
     __shared__ MonoRec s_mono[kFinBlock / 64];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    KPROF(blockIdx.x * 16 + w, 0);
 
-    if ((int)blockIdx.x < p.ncols) {
-        const int c = blockIdx.x;
+    const uint32_t nscan = (uint32_t)p.ncols * p.nchunk;
+    if (blockIdx.x < nscan) {
+        // column c, chunk g: the super tiles [g * chunk_super, (g + 1) * chunk_super) -- one workgroup scanning a whole column
+        // of configs[1] (58.6 k totals) was busy for 10 us, longer than anything else in this kernel
+        const int c = (int)(blockIdx.x / p.nchunk);
+        const uint32_t g = blockIdx.x % p.nchunk;
+        const uint32_t tile_lo = g * p.chunk_super * kK2TilesPerWave;
+        const uint32_t tile_hi = min(p.ntiles, (g + 1) * p.chunk_super * kK2TilesPerWave);
         const uint32_t* in = p.tile_tot + (size_t)c * p.tstride;
         uint32_t* out = p.tile_pre + (size_t)c * p.tstride;
         if (t == 0) s_carry = 0;
         __syncthreads();
-        // K2 takes one wave per kK2TilesPerWave tiles and only needs the prefix at those boundaries: a thread loads 64
-        // consecutive tile totals (16 x 16 bytes in flight), adds them up in fours, scans the 16 sums and stores 16
-        // consecutive prefixes (row c of tile_pre, indexed by tile / kK2TilesPerWave) -- 65,536 tiles per round
-        constexpr int kPerThread = 64;
-        static_assert(kPerThread == 16 * kK2TilesPerWave && kK2TilesPerWave == 4, "one sum per K2 wave");
-        for (uint32_t base = 0; base < p.ntiles; base += kFinBlock * kPerThread) {
-            const uint32_t i = base + t * kPerThread;
-            uint4 x[16];
+        // K2 takes one wave per kK2TilesPerWave tiles and only needs the prefix at those boundaries.  Thread t fetches the
+        // four totals of super tile q * 1024 + t for q = 0..3 of a round (16-byte loads, each one contiguous across the
+        // workgroup: with 64 consecutive totals per thread instead, the 16 k scattered line requests of a workgroup took 6-9 us),
+        // so a thread's super tiles lie 1024 apart: four wave scans side by side, a 4 x 16 table of wave totals scanned by
+        // the first wave, and every thread stores four prefixes, again contiguous across the workgroup.
+        constexpr int kQ = 4;   // (a chunk is a whole number of such rounds: 4096 super tiles)
+        static_assert(kK2TilesPerWave == 4 && kFinBlock == 1024, "one 16-byte load per super tile");
+        __shared__ uint32_t s_wt[kQ * (kFinBlock / 64)];
+        __shared__ uint32_t s_round;
+        const uint32_t row_hi = min(p.tstride, (g + 1) * p.chunk_super * kK2TilesPerWave);  // (rows are padded to a multiple of 16 and zero-filled)
+        for (uint32_t base = tile_lo; base < tile_hi; base += kFinBlock * kQ * 4) {
+            uint32_t sum[kQ], inc[kQ];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {  // rows are padded to a multiple of 16 and zero-filled
-                x[q] = make_uint4(0, 0, 0, 0);
-                if (i + q * 4 < p.tstride) x[q] = *(const uint4*)(in + i + q * 4);
+            for (int q = 0; q < kQ; ++q) {
+                const uint32_t i = base + ((uint32_t)q * kFinBlock + t) * 4;
+                uint4 x = make_uint4(0, 0, 0, 0);
+                if (i < row_hi) x = *(const uint4*)(in + i);
+                sum[q] = x.x + x.y + x.z + x.w;
             }
-            uint32_t v[16];
-            uint32_t tsum = 0;
+            if (sum[0] != 0xFFFFFFFFu) KPROF(blockIdx.x * 16 + w, 1);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) { v[q] = tsum; tsum += x[q].x + x[q].y + x[q].z + x[q].w; }
-            const uint32_t inc = wave_incl_scan(tsum);
-            if (lane == 63) s_ws[w] = inc;
-            __syncthreads();
-            uint32_t woff = 0;
-            for (int k = 0; k < w; ++k) woff += s_ws[k];
-            const uint32_t ex = s_carry + woff + inc - tsum;
+            for (int q = 0; q < kQ; ++q) inc[q] = wave_incl_scan(sum[q]);
+            if (lane == 63) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (i + q * 16 < p.tstride)
-                    *(uint4*)(out + i / 4 + q * 4) = make_uint4(ex + v[q * 4], ex + v[q * 4 + 1], ex + v[q * 4 + 2], ex + v[q * 4 + 3]);
+                for (int q = 0; q < kQ; ++q) s_wt[q * (kFinBlock / 64) + w] = inc[q];
+            }
             __syncthreads();
-            if (t == kFinBlock - 1) s_carry = ex + tsum;
+            if (w == 0) {  // exclusive scan of the 64 wave totals in (q, wave) order
+                static_assert(kQ * (kFinBlock / 64) == 64, "one wave total per lane");
+                const uint32_t v = s_wt[lane];
+                const uint32_t li = wave_incl_scan(v);
+                s_wt[lane] = li - v;
+                if (lane == 63) s_round = li;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < kQ; ++q) {
+                const uint32_t i = base + ((uint32_t)q * kFinBlock + t) * 4;
+                if (i < row_hi) out[i / 4] = s_carry + s_wt[q * (kFinBlock / 64) + w] + inc[q] - sum[q];
+            }
+            __syncthreads();
+            if (t == 0) s_carry += s_round;
             __syncthreads();
         }
-        if (t == 0) {
-            if (c == kColAnom) p.p1->n_anom = s_carry;
-            else if (c == kColNormal) p.p1->n_normal = s_carry;
-            else p.p1->key_tot[c - kColKey0] = s_carry;
-        }
+        if (t == 0) p.chunk_tot[(size_t)c * kMaxChunks + g] = s_carry;  // (the column totals: second level)
+        KPROF(blockIdx.x * 16 + w, 2);
         finalize_tail(p);
         return;
     }
 
     // reference-length monoids, in tile order (associative, not commutative): this workgroup folds the tiles
     // [fb * chunk, (fb+1) * chunk) of every source file into one partial record
-    const uint32_t fb = blockIdx.x - p.ncols;
+    const uint32_t fb = blockIdx.x - nscan;
     const uint32_t chunk = (p.ntiles + p.nfold - 1) / p.nfold;
     const uint32_t c0 = fb * chunk, c1 = min(c0 + chunk, p.ntiles);
     const uint32_t per = (chunk + kFinBlock - 1) / kFinBlock;
@@ -421,6 +443,7 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(const FinalizeParam
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc = mono_combine(acc, e[q]);
         }
+        if (acc.ft != -12345) KPROF(blockIdx.x * 16 + w, 1);
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const MonoRec other = mono_shfl_down(acc, o);
@@ -435,6 +458,7 @@ __global__ __launch_bounds__(kFinBlock) void finalize_kernel(const FinalizeParam
         }
         __syncthreads();
     }
+    KPROF(blockIdx.x * 16 + w, 2);
     finalize_tail(p);
 }
 
@@ -456,10 +480,19 @@ void launch_init(const InitList& l, hipStream_t s) {
 void launch_finalize(const FinalizeParams& p, hipStream_t s, bool second_level) {
     FinalizeParams q = p;
     if (!second_level) q.done = nullptr;  // (a workgroup of K2 runs the second level)
-    hipLaunchKernelGGL(finalize_kernel, dim3(p.ncols + p.nfold), dim3(kFinBlock), 0, s, q);
+    hipLaunchKernelGGL(finalize_kernel, dim3(p.ncols * p.nchunk + p.nfold), dim3(kFinBlock), 0, s, q);
     if (second_level && !p.done) hipLaunchKernelGGL(finalize2_kernel, dim3(1), dim3(256), 0, s, p);
 }
 
 void launch_finalize2_only(const FinalizeParams& p, hipStream_t s) { hipLaunchKernelGGL(finalize2_kernel, dim3(1), dim3(256), 0, s, p); }
 
 }  // namespace bdx
+
+#ifdef BDX_KPROF
+extern "C" int bdx_debug_kprof1(unsigned long long* out, size_t n) {
+    const int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bdx::g_kprof), n * sizeof(unsigned long long));
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(bdx::g_kprof)) == hipSuccess) (void)hipMemset(p, 0, sizeof(unsigned long long) * 8 * 65536);
+    return rc;
+}
+#endif

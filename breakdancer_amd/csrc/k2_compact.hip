@@ -55,8 +55,27 @@ __device__ __forceinline__ void key_and_qlen_of(const K2Params& p, uint64_t i, u
     qlen = (int)p.seg_qlen[lo][i];
 }
 
+// finalize_kernel scanned a tile-total column in chunks: the exclusive prefix at a super tile is its chunk-local prefix plus the
+// totals of the chunks before its own -- lane g holds chunk g's total (every lane loads its word: the row has kMaxChunks entries)
+__device__ __forceinline__ uint32_t wave_sum_below(uint32_t v, uint32_t chunk, int lane) {
+    v = (uint32_t)lane < chunk ? v : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// kBases: the second level of the finalisation ran before this kernel and left the sums (else it runs beside it)
+template <bool kBases> __device__ __forceinline__ uint32_t chunk_word(const K2Params& p, int col, uint32_t chunk, int lane) {
+    return kBases ? p.chunk_base[(size_t)col * kMaxChunks + chunk] : p.chunk_tot[(size_t)col * kMaxChunks + lane];
+}
+template <bool kBases> __device__ __forceinline__ uint32_t chunk_sum(uint32_t word, uint32_t chunk, int lane) {
+    return kBases ? word : wave_sum_below(word, chunk, lane);
+}
+template <bool kBases> __device__ __forceinline__ uint32_t col_prefix(const K2Params& p, int col, uint32_t tile2, uint32_t chunk, int lane) {
+    return p.tile_pre[(size_t)col * p.tstride + tile2] + chunk_sum<kBases>(chunk_word<kBases>(p, col, chunk, lane), chunk, lane);
+}
+
 // nblk: workgroups that compact (the launch can hold one more, see k2_compact_side_kernel)
-__device__ __forceinline__ void k2_body(const K2Params& p, uint32_t nblk) {
+template <bool kBases> __device__ __forceinline__ void k2_body(const K2Params& p, uint32_t nblk) {
     __shared__ uint32_t s_src[kWaves * kSlice];  // per wave: offset in super tile | class byte << kOffBits, by in-tile rank
     __shared__ uint32_t s_nn[kWaves * kSlice];
     const int nkeys = p.nkeys;
@@ -65,11 +84,15 @@ __device__ __forceinline__ void k2_body(const K2Params& p, uint32_t nblk) {
     const uint32_t ntiles2 = (p.ntiles + kSub - 1) / kSub;
     for (uint32_t tile2 = blockIdx.x * kWaves + w; tile2 < ntiles2; tile2 += nwaves) {
         const uint64_t base = (uint64_t)tile2 * kTile2 + (uint64_t)lane * kPerLane;
-        // the prefix bases are fetched together with the class bytes (one round trip instead of two)
-        const uint32_t pre_norm = p.tile_pre[(size_t)kColNormal * p.tstride + tile2];
-        const uint32_t rank0 = p.tile_pre[(size_t)kColAnom * p.tstride + tile2];
-        const uint32_t pre_k0 = p.tile_pre[(size_t)kColKey0 * p.tstride + tile2];
-        const uint32_t pre_k1 = nkeys > 1 ? p.tile_pre[(size_t)(kColKey0 + 1) * p.tstride + tile2] : 0u;
+        // the prefix bases (chunk-local prefix + the totals of the chunks before) are fetched together with the class bytes
+        // (one round trip instead of two)
+        // (requested here, added up -- wave_sum_below -- only once the super tile turns out to hold anomalous reads)
+        const uint32_t chunk = tile2 / p.chunk_super;
+        const uint32_t l_norm = p.tile_pre[(size_t)kColNormal * p.tstride + tile2], c_norm = chunk_word<kBases>(p, kColNormal, chunk, lane);
+        const uint32_t l_anom = p.tile_pre[(size_t)kColAnom * p.tstride + tile2], c_anom = chunk_word<kBases>(p, kColAnom, chunk, lane);
+        const uint32_t l_k0 = p.tile_pre[(size_t)kColKey0 * p.tstride + tile2], c_k0 = chunk_word<kBases>(p, kColKey0, chunk, lane);
+        const uint32_t l_k1 = nkeys > 1 ? p.tile_pre[(size_t)(kColKey0 + 1) * p.tstride + tile2] : 0u;
+        const uint32_t c_k1 = nkeys > 1 ? chunk_word<kBases>(p, kColKey0 + 1, chunk, lane) : 0u;
         if (p.stash) {
             // K1 left the anomalous reads of a tile ready-made (up to kStashCap of them): their records are copied to their places,
             // shifted by the prefixes -- no class bytes, no column gather except name key and read length.  Lane c * 4 + t holds
@@ -82,6 +105,8 @@ __device__ __forceinline__ void k2_body(const K2Params& p, uint32_t nblk) {
             const uint32_t A = a0 + a1 + a2 + a3;
             if (A == 0) continue;  // (wave-uniform)
             if (max(max(a0, a1), max(a2, a3)) <= (uint32_t)kStashCap) {
+                const uint32_t pre_norm = l_norm + chunk_sum<kBases>(c_norm, chunk, lane), rank0 = l_anom + chunk_sum<kBases>(c_anom, chunk, lane);
+                const uint32_t pre_k0 = l_k0 + chunk_sum<kBases>(c_k0, chunk, lane), pre_k1 = l_k1 + chunk_sum<kBases>(c_k1, chunk, lane);
                 const uint32_t q = (uint32_t)lane;  // A <= 64: one read per lane
                 const uint32_t tq = (q >= a0 ? 1u : 0u) + (q >= a0 + a1 ? 1u : 0u) + (q >= a0 + a1 + a2 ? 1u : 0u);
                 const uint32_t before = tq == 0 ? 0u : (tq == 1 ? a0 : (tq == 2 ? a0 + a1 : a0 + a1 + a2));
@@ -154,6 +179,8 @@ __device__ __forceinline__ void k2_body(const K2Params& p, uint32_t nblk) {
             m_pk |= (pass && (c & 0x20u)) ? 1u << r : 0u;
         }
         if (!__any(m_anom != 0)) continue;  // wave-uniform
+        const uint32_t pre_norm = l_norm + chunk_sum<kBases>(c_norm, chunk, lane), rank0 = l_anom + chunk_sum<kBases>(c_anom, chunk, lane);
+        const uint32_t pre_k0 = l_k0 + chunk_sum<kBases>(c_k0, chunk, lane), pre_k1 = l_k1 + chunk_sum<kBases>(c_k1, chunk, lane);
 
         const uint32_t tot = (uint32_t)__popc(m_anom) + ((uint32_t)__popc(m_nleft) << 16);
         const uint32_t ex0 = wave_incl_scan(tot) - tot;
@@ -218,8 +245,8 @@ __device__ __forceinline__ void k2_body(const K2Params& p, uint32_t nblk) {
             }
             const uint32_t v = (uint32_t)__popc(mk0) + ((uint32_t)__popc(mk1) << 16);
             const uint32_t ex = wave_incl_scan(v) - v;
-            const uint32_t b0 = p.pk_base[k0] + (k0 == 0 ? pre_k0 : p.tile_pre[(size_t)(kColKey0 + k0) * p.tstride + tile2]);
-            const uint32_t b1 = k0 + 1 < nkeys ? p.pk_base[k0 + 1] + (k0 == 0 ? pre_k1 : p.tile_pre[(size_t)(kColKey0 + k0 + 1) * p.tstride + tile2]) : 0u;
+            const uint32_t b0 = p.pk_base[k0] + (k0 == 0 ? pre_k0 : col_prefix<kBases>(p, kColKey0 + k0, tile2, chunk, lane));
+            const uint32_t b1 = k0 + 1 < nkeys ? p.pk_base[k0 + 1] + (k0 == 0 ? pre_k1 : col_prefix<kBases>(p, kColKey0 + k0 + 1, tile2, chunk, lane)) : 0u;
             uint32_t j = rank0 + local0;
             for (uint32_t mm = m_anom; mm; mm &= mm - 1, ++j) {
                 if (j >= p.c.cap) break;
@@ -240,7 +267,7 @@ __device__ __forceinline__ void k2_fills(const K2Params& p) {  // (every workgro
 
 __global__ __launch_bounds__(kBlock) void k2_compact_kernel(const K2Params p) {
     k2_fills(p);
-    k2_body(p, gridDim.x);
+    k2_body<true>(p, gridDim.x);
 }
 
 // the same with one more workgroup, the last, that runs the second level of the pass-1 finalisation: when K2 is enqueued
@@ -251,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void k2_compact_side_kernel(const K2Params 
         finalize2_body(fp);
         return;
     }
-    k2_body(p, gridDim.x - 1);
+    k2_body<false>(p, gridDim.x - 1);
 }
 
 void launch_k2(const K2Params& p, size_t lds, hipStream_t s, const FinalizeParams* side) {

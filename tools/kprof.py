@@ -42,9 +42,15 @@ def main():
     have3 = hasattr(L, "bdx_debug_kprof3")
     if have3:
         L.bdx_debug_kprof3.argtypes = [C.c_void_p, C.c_size_t]
+    buf1 = np.zeros(8 * 65536, dtype=np.uint64)
+    have1 = hasattr(L, "bdx_debug_kprof1")
+    if have1:
+        L.bdx_debug_kprof1.argtypes = [C.c_void_p, C.c_size_t]
     for _ in range(5):
         bd.run()
     torch.cuda.synchronize()
+    if have1:
+        L.bdx_debug_kprof1(buf1.ctypes.data_as(C.c_void_p), buf1.size)
     L.bdx_debug_kprof(buf.ctypes.data_as(C.c_void_p), buf.size)  # (clears the device buffer)
     if have3:
         L.bdx_debug_kprof3(buf3.ctypes.data_as(C.c_void_p), buf3.size)
@@ -94,6 +100,18 @@ def main():
         stats("terms, K5, scores (last chunk)", sc[g, 4] - sc[g, 3])
         stats("records -> host, end", sc[g, 5] - sc[g, 4])
         stats("wave end", sc[hs, 5] - s0)
+    if have1:
+        L.bdx_debug_kprof1(buf1.ctypes.data_as(C.c_void_p), buf1.size)
+        t1 = buf1.reshape(65536, 8).astype(np.int64)
+        h = t1[:, 2] > 0
+        z = t1[h, 0].min()
+        print("finalize kernel: %d waves (rows: workgroup * 16 + wave)" % h.sum())
+        for name, sel in (("column scans", np.arange(65536) < 16 * 3), ("monoid folds", np.arange(65536) >= 16 * 3)):
+            m = h & sel
+            if m.any():
+                stats(name + ": entry", t1[m, 0] - z)
+                stats(name + ": inputs arrived", t1[m, 1] - t1[m, 0])
+                stats(name + ": done", t1[m, 2] - z)
     if have3:
         for name, rows in (("head scan (4 columns)", t3[:32768]), ("accept scan", t3[32768:])):
             h = rows[:, 3] > 0
