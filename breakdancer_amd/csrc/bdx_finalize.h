@@ -30,17 +30,19 @@ __device__ __forceinline__ void finalize2_body(const FinalizeParams& p) {
     __shared__ uint32_t s_head[2];  // covered_ref_len, window
     __shared__ uint32_t s_col[64];  // totals of the tile-total columns: n_anom, n_normal, key_tot[]
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    static_assert(kCntCopies == 64, "one lane per counter copy");
-    for (int i0 = 0; i0 < p.ncnt; i0 += 4) {  // counters: [kCntCopies][ncnt] -> [ncnt], one wave per counter
-        const int i = i0 + w;
-        uint32_t v = i < p.ncnt ? p.blk_cnt[(size_t)lane * p.ncnt + i] : 0u;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0 && i < p.ncnt) {
-            s_acc[i] = v;
-            p.cnt[i] = v;
-            if (p.cnt_host) p.cnt_host[i] = v;
-        }
+    // counters: [kCntCopies][ncnt] -> [ncnt].  Every word is requested at once (contiguous across the workgroup) and added into
+    // LDS; a loop of one reduction per counter waited for a round trip per iteration
+    for (int i = t; i < p.ncnt; i += 256) s_acc[i] = 0;
+    __syncthreads();
+    for (int idx = t; idx < kCntCopies * p.ncnt; idx += 256) {
+        const uint32_t v = p.blk_cnt[idx];
+        if (v) atomicAdd(&s_acc[idx % p.ncnt], v);
+    }
+    __syncthreads();
+    for (int i = t; i < p.ncnt; i += 256) {
+        const uint32_t v = s_acc[i];
+        p.cnt[i] = v;
+        if (p.cnt_host) p.cnt_host[i] = v;
     }
     for (int c0 = 0; c0 < p.ncols; c0 += 4) {  // one wave per column: its chunks' totals
         const int c = c0 + w;
