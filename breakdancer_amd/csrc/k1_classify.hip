@@ -161,6 +161,8 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
         }
 
         // ---- per-tile totals (lane c keeps column c) and workgroup counters: ballots + popcounts --------------
+        bool one_file = false;   // (wave-uniform) every record of the tile comes from one source file ...
+        unsigned file0 = 0;      // ... this one
         {
             unsigned na = 0, nn = 0;
             uint64_t ba[4], bn[4];
@@ -171,6 +173,7 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
             const unsigned L0 = __shfl(lib[0], 0), B0 = __shfl(bam[0], 0);
             const bool uni = __all(lib[0] == L0 && lib[1] == L0 && lib[2] == L0 && lib[3] == L0 && bam[0] == B0 &&
                                    bam[1] == B0 && bam[2] == B0 && bam[3] == B0);
+            one_file = uni; file0 = B0;
             if (!uni && p.stash && na && lane == 0) p.stash[(size_t)tile * kStashCap].where = 0xFFFFFFFFu;  // a mixed tile: K2 compacts it from the columns
             if (uni) {
                 unsigned c1 = 0, ck = 0;
@@ -260,7 +263,16 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
             bool same = true;
 #pragma unroll
             for (int r = 0; r < 4; ++r) same = same && (r >= nvalid || tid[r] == tw);
-            if (__all(same) && nbams <= 64) {
+            const bool one_tid = __all(same);
+            if (one_tid && one_file && __all(nvalid == 4)) {
+                // the usual tile: one tid, one file, full -- the differences telescope to (last record) - (first record)
+                const int first = __shfl(pos[0], 0), last = __shfl(pos[3], 63);
+                if (lane == 0) {
+                    MonoRec m;
+                    m.ft = tw; m.fp = first; m.lt = tw; m.lp = last; m.sum = (long long)last - (long long)first;
+                    p.tile_mono[(size_t)file0 * p.tstride + tile] = m;
+                }
+            } else if (one_tid && nbams <= 64) {
                 // all records of the tile share one tid: consecutive same-file differences telescope to
                 // last - first, found with ballots; lane v keeps the record of file v
                 int my_first = 0, my_last = 0;
