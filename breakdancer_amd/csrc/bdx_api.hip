@@ -644,9 +644,7 @@ int pass1_classify(bdx_ctx* c, uint32_t upto, bool timed) {
     k1.stash = c->use_stash ? c->b_stash.as<StashRec>() : nullptr;
     const uint32_t span = upto - c->k1_done;
     const int grid1 = (int)std::min<uint32_t>((span + kWaves - 1) / kWaves, kK1MaxGrid);
-    if (timed) HIPCHK(c, hipEventRecord(c->ev[0], s));
-    launch_k1(k1, grid1, k1_lds_bytes(c->nlibs, c->nbams, c->nkeys), s);
-    if (timed) HIPCHK(c, hipEventRecord(c->ev[1], s));
+    launch_k1(k1, grid1, k1_lds_bytes(c->nlibs, c->nbams, c->nkeys), s, timed ? c->ev[0] : nullptr, timed ? c->ev[1] : nullptr);
     c->k1_done = upto;
     return BDX_OK;
 }

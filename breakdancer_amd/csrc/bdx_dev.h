@@ -187,7 +187,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 }
 
 // launchers (host side, defined in the .hip files)
-void launch_k1(const K1Params& p, int grid, size_t lds, hipStream_t s);
+void launch_k1(const K1Params& p, int grid, size_t lds, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 size_t k1_lds_bytes(int nlibs, int nbams, int nkeys);
 void launch_finalize(const FinalizeParams& p, hipStream_t s, bool second_level = true);
 void launch_finalize2_only(const FinalizeParams& p, hipStream_t s);

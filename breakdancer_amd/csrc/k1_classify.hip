@@ -14,6 +14,8 @@
 // follow-up kernel folds in order.
 #include <cstddef>
 
+#include <hip/hip_ext.h>
+
 #include "bdx_dev.h"
 #include "bdx_finalize.h"
 
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
             const unsigned L = lib[r] < (unsigned)nlibs ? lib[r] : 0u;
             lib[r] = L;
             if (bam[r] >= (unsigned)nbams) bam[r] = 0;
-            const DevLib dl = s_lib[L];
+            const DevLib dl = s_lib[L];  // (one record for the wave when the tile is uniform, fetched before the loop: measured 1.5 us slower)
             const int ai = abs(isz[r]);
             const int f = classify_read(sam[r], tid[r], mtid[r], pos[r], mpos[r], ai, dl.upper, dl.lower);
             const bool mq_ok = (int)mq[r] > dl.min_mapq;
@@ -336,8 +338,11 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
     }
 }
 
-void launch_k1(const K1Params& p, int grid, size_t lds, hipStream_t s) {
-    hipLaunchKernelGGL(k1_classify_kernel, dim3(grid), dim3(kBlock), lds, s, p);
+// start / stop: events that take the kernel's own begin and end timestamps (what rocprofv3 reports for it); an event recorded
+// on the stream before and after the launch also clocks the dispatch around it (+4 us)
+void launch_k1(const K1Params& p, int grid, size_t lds, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
+    if (start && stop) hipExtLaunchKernelGGL(k1_classify_kernel, dim3(grid), dim3(kBlock), (uint32_t)lds, s, start, stop, 0u, p);
+    else hipLaunchKernelGGL(k1_classify_kernel, dim3(grid), dim3(kBlock), lds, s, p);
 }
 
 // -------------------------------------------------------------------------------------------------------
