@@ -106,7 +106,8 @@ def main():
         h = t1[:, 2] > 0
         z = t1[h, 0].min()
         print("finalize kernel: %d waves (rows: workgroup * 16 + wave)" % h.sum())
-        for name, sel in (("column scans", np.arange(65536) < 16 * 3), ("monoid folds", np.arange(65536) >= 16 * 3)):
+        nscan = 3 * 4  # workgroups that scan tile-total columns at configs[1]: 3 columns x 4 chunks (rows: workgroup * 16 + wave)
+        for name, sel in (("column scans", np.arange(65536) < 16 * nscan), ("monoid folds", np.arange(65536) >= 16 * nscan)):
             m = h & sel
             if m.any():
                 stats(name + ": entry", t1[m, 0] - z)
