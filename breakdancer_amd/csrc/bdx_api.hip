@@ -1170,8 +1170,13 @@ int do_k6_table(bdx_ctx* c) {
     a.ltail_host = c->h_ltail_dev.as<double>();  // (K5 runs inside the table kernel)
     HIPCHK(c, c->h_printed.ensure((size_t)k6_score_grid(a) * 4));
     a.printed_host = c->h_printed.as<uint32_t>();
+    // The word the host polls for the end of the run is set by a one-thread kernel behind the table kernel (a kernel boundary
+    // orders it behind that kernel's stores to host memory).  A stream write-value command does the same as a one-thread kernel of
+    // the runtime's own, but starts 5 us after the kernel before it has ended; back-to-back launches follow each other at once.
+    static const bool write_value = getenv("BDX_END_WRITE_VALUE") != nullptr;  // (A/B)
+    if (c->poll && !write_value) { a.flag_done = c->h_flags.as<uint32_t>() + 2; a.flag_value = c->seq; }
     launch_k6_table(a, na, std::log(10), c->opts.score_threshold, c->opts.fisher ? 0 : 1, s);
-    {   // the final table is complete (without polling: finish_table waits for the stream)
+    if (!a.flag_done) {  // (without polling: finish_table waits for the stream)
         const int rc = signal_ready(c, 2, nullptr);
         if (rc != BDX_OK) return rc;
     }
