@@ -694,7 +694,9 @@ int do_pass1(bdx_ctx* c, uint32_t na_cap, bool wait, bool defer_second) {
         const uint32_t nsuper = (ntiles + kK2TilesPerWave - 1) / kK2TilesPerWave;
         const uint32_t round = 4096;
         const uint32_t rounds = std::max<uint32_t>(1, (nsuper + round - 1) / round);
-        fp.chunk_super = round * ((rounds + kMaxChunks - 1) / kMaxChunks);
+        const char* mc = getenv("BDX_MAX_CHUNKS");  // (tests: chunks of several rounds at small sizes; read per run)
+        const uint32_t max_chunks = mc ? (uint32_t)std::min(std::max(atoi(mc), 1), kMaxChunks) : (uint32_t)kMaxChunks;
+        fp.chunk_super = round * ((rounds + max_chunks - 1) / max_chunks);
         fp.nchunk = std::max<uint32_t>(1, (nsuper + fp.chunk_super - 1) / fp.chunk_super);
         HIPCHK(c, c->b_chunk_tot.ensure((size_t)ncols * kMaxChunks * 8));
         fp.chunk_tot = c->b_chunk_tot.as<uint32_t>();

@@ -128,6 +128,23 @@ def test_synthetic_10mbp_matches_oracle(opts):
     compare(run, product_from_oracle(run))
 
 
+@pytest.mark.parametrize("max_chunks", ["1", "2"])
+def test_tile_total_columns_scanned_in_chunks_of_several_rounds(max_chunks, monkeypatch):
+    """finalize_kernel scans a tile-total column in chunks of whole rounds (4096 boundaries each); with at most 64 chunks a chunk
+    takes more than one round only beyond 268 M reads -- BDX_MAX_CHUNKS brings that down to test size (20 Mbp: 5.9 k boundaries
+    = two rounds: one chunk of two rounds / two chunks with BDX_MAX_CHUNKS=1 / 2)"""
+    monkeypatch.setenv("BDX_MAX_CHUNKS", max_chunks)
+    cfg, st = _synth_case(20_000_000, seed=12)
+    run = OracleRun(cfg, make_opts())
+    run.set_targets(["chrS"])
+    st = dict(st)
+    st["lib"] = np.zeros(len(st["tid"]), np.int32)
+    run.set_stream(0, st)
+    run.run()
+    assert run.n_svs > 1000
+    compare(run, product_from_oracle(run))
+
+
 def test_full_size_properties():
     """configs[1] at full size (50 Mbp, 15 M reads): size-independent properties of the path."""
     import breakdancer_amd as bda
