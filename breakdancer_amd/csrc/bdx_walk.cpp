@@ -154,30 +154,39 @@ struct Walker {
         const auto b0 = tnow();
         const std::vector<GroupPart>& src = *in.parts;
         const uint32_t NR = (uint32_t)in.nregions;
-        // counting sort by hi, then tiny insertion sorts inside each hi bucket
-        std::vector<uint32_t>& cnt = S.cnt;
-        cnt.assign(NR + 2, 0);
-        for (const GroupPart& p : src) ++cnt[p.hi + 1];
-        for (uint32_t r = 0; r <= NR; ++r) cnt[r + 1] += cnt[r];
-        parts.resize(src.size());
-        {
-            std::vector<uint32_t>& cur = S.cur;
-            cur.assign(cnt.begin(), cnt.end() - 1);
-            for (const GroupPart& p : src) parts[cur[p.hi]++] = p;
-        }
-        const auto b1 = tnow();
         auto less = [](const GroupPart& a, const GroupPart& b) {
             if (a.lo != b.lo) return a.lo < b.lo;
             if (a.flag != b.flag) return a.flag < b.flag;
             return a.lib < b.lib;
         };
-        for (uint32_t r = 0; r < NR; ++r) {
-            const uint32_t b = cnt[r], e = cnt[r + 1];
-            for (uint32_t i = b + 1; i < e; ++i) {
-                GroupPart x = parts[i];
-                uint32_t j = i;
-                while (j > b && less(x, parts[j - 1])) { parts[j] = parts[j - 1]; --j; }
-                parts[j] = x;
+        auto b1 = b0;
+        if (src.size() * 8 < (size_t)NR) {
+            // few parts (the usual share of the host: a handful of components): a comparison sort; the passes over all regions
+            // below cost ~10 us at 12 k regions, on the path between the device's walk and the launch of the table kernels
+            parts.assign(src.begin(), src.end());
+            std::sort(parts.begin(), parts.end(), [&](const GroupPart& a, const GroupPart& b) { return a.hi != b.hi ? a.hi < b.hi : less(a, b); });
+            b1 = tnow();
+        } else {
+            // counting sort by hi, then tiny insertion sorts inside each hi bucket
+            std::vector<uint32_t>& cnt = S.cnt;
+            cnt.assign(NR + 2, 0);
+            for (const GroupPart& p : src) ++cnt[p.hi + 1];
+            for (uint32_t r = 0; r <= NR; ++r) cnt[r + 1] += cnt[r];
+            parts.resize(src.size());
+            {
+                std::vector<uint32_t>& cur = S.cur;
+                cur.assign(cnt.begin(), cnt.end() - 1);
+                for (const GroupPart& p : src) parts[cur[p.hi]++] = p;
+            }
+            b1 = tnow();
+            for (uint32_t r = 0; r < NR; ++r) {
+                const uint32_t b = cnt[r], e = cnt[r + 1];
+                for (uint32_t i = b + 1; i < e; ++i) {
+                    GroupPart x = parts[i];
+                    uint32_t j = i;
+                    while (j > b && less(x, parts[j - 1])) { parts[j] = parts[j - 1]; --j; }
+                    parts[j] = x;
+                }
             }
         }
         const auto b2 = tnow();
