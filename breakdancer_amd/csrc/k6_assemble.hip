@@ -981,7 +981,8 @@ __global__ __launch_bounds__(64) void k6_walk_kernel(K6Arrays a) {
                                     if ((edge_alive & (1u << pi)) && stA && stB) { g |= 2u; edge_alive &= ~(1u << pi); }
                                     if ((self_alive & (1u << B)) && stB) { g |= 4u; self_alive &= ~(1u << B); }
                                 }
-                                T.call(ncalls++) = (uint32_t)A | ((uint32_t)(B + 1) << 2) | (g << 5) | ((uint32_t)sv << 8) | ((uint32_t)f << 10);
+                                // (a call that sees no group fails process_sv's first gate -- no pairs -- before it has any effect)
+                                if (g != 0 || mrp <= 0) T.call(ncalls++) = (uint32_t)A | ((uint32_t)(B + 1) << 2) | (g << 5) | ((uint32_t)sv << 8) | ((uint32_t)f << 10);
                             }
                             visited |= 1u << tail;
                         }
