@@ -206,7 +206,8 @@ int bdx_get_sv_support(const bdx_ctx* ctx, uint32_t* sv_offsets, uint64_t* read_
 int bdx_get_read_class(const bdx_ctx* ctx, uint8_t* out, size_t cap);
 
 /* stage timings of the last bdx_run in milliseconds (HIP events on the context's stream):
- * [0] classify kernel (bracketed by events on every 4th run by default, BDX_K1_EVENT_PERIOD=n; the latest measurement), [1] compaction, [2] region cut, [3] mate join + grouping + SV assembly + scores on the device,
+ * [0] classify kernel (its own begin-to-end time from kernel-level start/stop events, taken on every 4th run by default,
+ *     BDX_K1_EVENT_PERIOD=n; the latest measurement), [1] compaction, [2] region cut, [3] mate join + grouping + SV assembly + scores on the device,
  * [4] host: wait for the host's share of the groups, [5] host walk of that share, [6] host: final wait, merge, score
  * combination, [7] whole run; [8]-[10] split [6] into the final wait, the merge of the device's and the host's SV lists,
  * and the score combination.  Returns the number written. */
