@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void k6_pairs_kernel(K6Arrays a) {
 
 // one round of min-label propagation over the gate-passing groups (each is stored with its later region)
 __global__ __launch_bounds__(256) void k6_label_kernel(K6Arrays a) {
-    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.counts->n_regions) return;
     const RegSum* s = &a.rs[r];
     const uint32_t n_in = s->n_in;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void k6_label_kernel(K6Arrays a) {
 // closure check and member registration: a label whose members only have groups among themselves, all inside one
 // flush window, is a complete component
 __global__ __launch_bounds__(256) void k6_classify_kernel(K6Arrays a) {
-    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.counts->n_regions) return;
     const RegSum* s = &a.rs[r];
     const uint32_t n_in = s->n_in;
@@ -535,7 +535,7 @@ __device__ __forceinline__ bool component_on_device(const K6Arrays& a, uint32_t 
 __global__ __launch_bounds__(256) void k6_emit_kernel(K6Arrays a) {
     const int lane = threadIdx.x & 63;
     const uint32_t NR = a.counts->n_regions;
-    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = r < NR;
     RegSum s{};
     uint32_t od = 0, L = 0;
@@ -1456,12 +1456,16 @@ void launch_k6_groups(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
     if (n_anom_host == 0) return;
     // regions <= anomalous reads, typically a tenth of them: about one wave per region, a grid-stride loop for the rest
     const uint32_t gp = std::min<uint32_t>((n_anom_host / 8 + 3) / 4 + 1, 16384u);
-    const uint32_t gr = (n_anom_host + 255) / 256;
+    // one thread per region, a wave per workgroup: the regions are about a tenth of the grid's upper bound, and with 256 of them per
+    // workgroup the ~12 k regions of configs[1] would keep 47 of the 256 compute units busy -- each with four waves' worth of
+    // scattered requests (~64 address cycles per memory instruction) through one address pipeline
+    static const uint32_t kRegionThreads = getenv("BDX_REGION_THREADS") ? (uint32_t)atoi(getenv("BDX_REGION_THREADS")) : 64u;
+    const uint32_t grs = (n_anom_host + kRegionThreads - 1) / kRegionThreads;
     hipLaunchKernelGGL(k6_pairs_kernel, dim3(gp), dim3(256), 0, s, a);
     if (!a.force_host)
-        for (int i = 1; i < a.label_rounds; ++i) hipLaunchKernelGGL(k6_label_kernel, dim3(gr), dim3(256), 0, s, a);  // round 1: k6_pairs
-    hipLaunchKernelGGL(k6_classify_kernel, dim3(gr), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k6_emit_kernel, dim3(gr), dim3(256), 0, s, a);
+        for (int i = 1; i < a.label_rounds; ++i) hipLaunchKernelGGL(k6_label_kernel, dim3(grs), dim3(kRegionThreads), 0, s, a);  // round 1: k6_pairs
+    hipLaunchKernelGGL(k6_classify_kernel, dim3(grs), dim3(kRegionThreads), 0, s, a);
+    hipLaunchKernelGGL(k6_emit_kernel, dim3(grs), dim3(kRegionThreads), 0, s, a);
     if (a.counts_host && !a.mirror_in_walk) hipLaunchKernelGGL(k6_mirror_kernel, dim3(1), dim3(64), 0, s, a);
 }
 
