@@ -1109,6 +1109,7 @@ int do_k6(bdx_ctx* c, bool force_host) {
     a.period = std::max(1, c->opts.buffer_size + 1);
     a.force_host = force_host ? 1 : 0;
     a.big_walk = big_walk;
+    a.walk_lanes = 32;  // (measured at configs[1]: 64 regions per wave 23.7 us, 32: 22.4 us, 16: 24.5 us)
     {
         static const int rounds = getenv("BDX_LABEL_ROUNDS") ? std::max(1, atoi(getenv("BDX_LABEL_ROUNDS"))) : 0;
         // (long chains need more rounds to agree on one label; with the general walk on, the step is long enough not to care)

@@ -342,6 +342,7 @@ struct K6Arrays {
     int nlibs, nkeys, min_read_pair, chr_restricted, period, force_host;
     int mirror_in_walk;            // the first wave of k6_walk_kernel mirrors the counters and sets flag_groups (no k6_mirror_kernel launch)
     int big_walk;                  // components of up to kK6BigMembers regions are walked on the device (k6_walk_big_kernel); 0: up to kK6MaxMembers
+    int walk_lanes;                // regions per wave of k6_walk_kernel (<= 64)
     int label_rounds;              // min-label propagation rounds incl. the one inside k6_pairs_kernel (default kK6LabelRounds)
 };
 

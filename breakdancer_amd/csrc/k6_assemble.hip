@@ -826,7 +826,9 @@ __global__ __launch_bounds__(64) void k6_walk_kernel(K6Arrays a) {
     // One lane per REGION; the smallest region of a device-walked component (k6_emit_kernel marked it with the component's
     // size) walks it.  Everything the first phase needs is requested at once, the description (indexed by label = this region)
     // before it is known whether the region is such an owner: a dependent round trip costs ~1.3 us here, bytes cost nothing.
-    for (uint32_t r = blockIdx.x * 64 + lane; r < NR; r += gridDim.x * 64) {
+    const uint32_t wl = (uint32_t)a.walk_lanes;  // components per wave (the other lanes stay idle: fewer addresses per memory instruction)
+    if ((uint32_t)lane >= wl) return;
+    for (uint32_t r = blockIdx.x * wl + lane; r < NR; r += gridDim.x * wl) {
         const MemberInfo* D = a.members + (size_t)r * kK6MaxMembers;
         uint4 raw[kK6MaxMembers][7];
 #pragma unroll
@@ -1472,7 +1474,7 @@ void launch_k6_groups(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
 void launch_k6_walk(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
     if (n_anom_host == 0 || a.force_host) return;
     const uint32_t gp = std::min<uint32_t>((n_anom_host / 8 + 3) / 4 + 1, 16384u);
-    hipLaunchKernelGGL(k6_walk_kernel, dim3(std::min<uint32_t>(n_anom_host / 64 / 4 + 1, 4096u)), dim3(64), 0, s, a);  // a lane per region, grid-stride: regions are typically a tenth of the reads
+    hipLaunchKernelGGL(k6_walk_kernel, dim3(std::min<uint32_t>(n_anom_host / (uint32_t)a.walk_lanes / 4 + 1, 8192u)), dim3(64), 0, s, a);  // a lane per region, grid-stride: regions are typically a tenth of the reads
     if (a.big_walk) hipLaunchKernelGGL(k6_walk_big_kernel, dim3(gp / 8 + 1), dim3(256), 0, s, a);
 }
 
