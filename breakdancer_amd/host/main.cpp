@@ -411,6 +411,8 @@ int main(int argc, char** argv) {
             fprintf(stderr, "[bdx timing] reads=%zu decode+merge+stream=%.3fs (%u decode threads, single pass, batches copied and classified "
                             "as they are produced) bdx_run=%.4fs format=%.3fs total=%.3fs\n",
                     n_reads, secs(t_start, t_decoded), io_threads, secs(t_decoded, t_ran), secs(t_ran, now()), secs(t_start, now()));
+            fprintf(stderr, "[bdx timing] inside bdx_run (ms): classify kernel %.3f, host waits for its share of the groups %.3f, host walk %.3f, "
+                            "final wait + scores %.3f, whole call %.3f\n", ms[0], ms[4], ms[5], ms[6], ms[7]);
         }
         if (!sharded) bdx_destroy(ctx);  // (a sharded run's result context belongs to rank 0, released with the ranks)
         ctx = nullptr;

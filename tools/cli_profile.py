@@ -22,5 +22,5 @@ for env_extra in [dict(BDX_BAM_PROFILE="1")] + [dict(BDX_THREADS=str(t)) for t i
         best = min(best, time.time() - t0)
     err = p.stderr.decode().splitlines()
     print(env_extra, "wall %.3f" % best)
-    for l in err[-8:] if "BDX_BAM_PROFILE" in env_extra else err[-1:]:
+    for l in err[-9:] if "BDX_BAM_PROFILE" in env_extra else err[-2:]:
         print("   ", l)
