@@ -172,7 +172,8 @@ __host__ __device__ __forceinline__ int meta_qlen(uint32_t m) { return m >> 16; 
 // ---- wave helpers (wave64) ----------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
-__device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
+// (the builtin keeps the condition a lane mask; __ballot() goes through a 0/1 integer per lane and a second compare)
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ int popc64(uint64_t m) { return __popcll(m); }
 
 // inclusive wave scan of a u32 (6 shuffle steps)

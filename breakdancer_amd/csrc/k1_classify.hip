@@ -12,6 +12,11 @@
 // totals come from ballots + popcounts, the pass-1 counters are privatised in LDS and written once per
 // workgroup, and the per-file reference-length monoid of each tile goes to a plain per-tile table that a tiny
 // follow-up kernel folds in order.
+//
+// Where the time goes (configs[1], 15 M reads, 400 MB): a kernel that only reads the nine columns in this shape takes 57 us, with
+// the 1 B/read class-byte store 64-66 us (tools/stream_probe.hip: next to the read stream a byte written costs about four read);
+// this kernel takes 68 us without and 73-75 us with the ready-made records for K2.  The instruction stream is not what bounds it:
+// the usual tile's path below has about half the instructions of the general body it was split from, for the same time.
 #include <cstddef>
 
 #include <hip/hip_ext.h>
@@ -61,6 +66,76 @@ __device__ __forceinline__ int remap_long_insert(int f, int ai, float upper, flo
     return f;
 }
 
+
+__device__ __forceinline__ unsigned lane0_of(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+
+// The usual tile: full, every record of one library and one source file.  Same results as the general body in the kernel
+// below, written for the instruction stream: the library record and both indices are wave-uniform, every condition stays a
+// lane mask (no bool crosses a branch), the short-circuit operators of the filter chain are plain ANDs, and the class bytes
+// leave as one word.  Returns the tile's totals through the masks.
+struct TileMasks {
+    uint64_t ba[4], bn[4], bp[4];  // anomalous / normal-leftmost / proper-and-passing, per slot
+    unsigned c1;                   // proper reads above the mapping-quality cutoff (BamSummary.cpp:100-108)
+};
+
+template <bool kLongInsert>
+__device__ __forceinline__ unsigned classify_uniform_tile(const K1Params& p, const DevLib dl, uint32_t* s_hist /* of library L0 */,
+                                                          const int (&tid)[4], const int (&pos)[4], const int (&mtid)[4],
+                                                          const int (&mpos)[4], const int (&isz)[4], const unsigned (&sam)[4],
+                                                          unsigned mqp, TileMasks& tm) {
+    unsigned word = 0;
+    tm.c1 = 0;
+    const bool opt_t = p.opt_t != 0;
+    const uint64_t m_opt_t = opt_t ? ~0ull : 0ull;
+    int hist_f[4];
+    bool hist_on[4];
+    // (one straight block for the four slots: the comparisons, their ballots and the selects interleave freely; a ballot that
+    // sits in another block than its comparison goes through a 0/1 value per lane and a second compare)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const unsigned s = sam[r];
+        const int ai = abs(isz[r]);
+        const float fi = (float)ai;  // the reference compares int against the float cutoffs
+        const bool rr = (s & 0x10u) != 0;
+        const bool same_strand = ((s ^ (s >> 1)) & 0x10u) == 0;
+        const bool left = pos[r] < mpos[r];
+        const bool same_tid = tid[r] == mtid[r];
+        int f = fi < dl.lower ? F_SMALL : F_NORMAL_FR;
+        f = fi > dl.upper ? F_LARGE : f;
+        f = (left == rr) ? F_RF : f;
+        const int ss = rr ? F_RR : F_FF;
+        f = same_strand ? ss : f;
+        f = same_tid ? f : F_CTX;
+        f = (s & 0x8u) ? F_MATE_UNMAPPED : f;
+        f = (s & 0x4u) ? F_UNMAPPED : f;
+        f = ((s & 0x401u) != 0x1u) ? F_NA : f;
+        const bool mq_ok = (int)((mqp >> (8 * r)) & 0xffu) > dl.min_mapq;
+        const bool proper = (s & 0x40Fu) == 0x3u;
+        const bool plain = (s & 0x40Du) == 0x1u;  // f != F_NA and neither end unmapped: one test of the flag word
+        const bool h_ok = mq_ok & plain & !(opt_t & same_tid);
+        const int f1 = kLongInsert ? remap_long_insert(f, ai, dl.upper, dl.lower) : f;
+        const bool normal1 = (f1 & 14) == F_NORMAL_FR;  // F_NORMAL_FR (6) or F_NORMAL_RF (7)
+        hist_f[r] = f1; hist_on[r] = h_ok & !normal1;
+        const bool is_ctx = f == F_CTX, near = ai <= p.max_sd;
+        const bool pass = h_ok & (is_ctx | near);
+        const int f2 = (f1 == F_RR) ? F_FF : f1;
+        const bool nl = pass & normal1 & left;
+        // the wave's masks, combined as 64-bit scalars from the masks of the single comparisons
+        const uint64_t m_mq = ballot64(mq_ok), m_prop = ballot64(proper), m_norm = ballot64(normal1);
+        const uint64_t m_hok = m_mq & ballot64(plain) & ~(m_opt_t & ballot64(same_tid));
+        const uint64_t m_pass = m_hok & (ballot64(is_ctx) | ballot64(near));
+        tm.ba[r] = m_pass & ~m_norm; tm.bn[r] = m_pass & m_norm & ballot64(left); tm.bp[r] = m_pass & m_prop;
+        tm.c1 += popc64(m_mq & m_prop);
+        const unsigned hi = 0x10u | (proper ? 0x20u : 0u) | (nl ? 0x40u : 0u);
+        const unsigned byte = pass ? ((unsigned)f2 | hi) : (unsigned)f;
+        word |= byte << (8 * r);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (hist_on[r]) atomicAdd(&s_hist[hist_f[r]], 1u);
+    return word;
+}
+
 size_t k1_lds_bytes(int nlibs, int nbams, int nkeys) {
     size_t b = (size_t)nlibs * sizeof(DevLib);
     b += (size_t)(nlibs * kNumFlags + nlibs + nbams) * 4;
@@ -70,6 +145,8 @@ size_t k1_lds_bytes(int nlibs, int nbams, int nkeys) {
     return (b + 15) & ~(size_t)15;
 }
 
+// kLongInsert: the -l remaps of BreakDancer.cpp:175-186 (p.opt_l), decided at the launch
+template <bool kLongInsert>
 __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nlibs = p.nlibs, nbams = p.nbams, nkeys = p.nkeys;
@@ -81,6 +158,8 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
     off = (off + 15) & ~(size_t)15;
     MonoRec* s_mono = (MonoRec*)(smem + off);
 
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    __shared__ v4u_t s_stash[kWaves][2 * kStashCap];  // a wave's ready-made records of one tile, before they leave
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     for (int i = t; i < nlibs; i += kBlock) s_lib[i] = p.libs[i];
     for (int i = t; i < ncnt; i += kBlock) s_cnt[i] = 0;
@@ -94,7 +173,8 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
         const uint64_t base = (uint64_t)tile * kTile + (uint64_t)lane * 4;
         int nvalid = 0;
         int tid[4], pos[4], mtid[4], mpos[4], isz[4];
-        unsigned sam[4], mq[4], lib[4], bam[4];
+        unsigned sam[4];
+        unsigned mqp, libp, bamp;  // the four slots' bytes, slot r in byte r
         if (base + 4 <= p.n) {
             nvalid = 4;
             const int4 a = ldnt(p.r.tid + base);
@@ -103,19 +183,17 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
             const int4 d = ldnt(p.r.mpos + base);
             const int4 e = ldnt(p.r.isize + base);
             const ushort4 f = ldnt(p.r.flag + base);
-            const uchar4 q = ldnt(p.r.mapq + base);
-            const uchar4 l = ldnt(p.r.lib + base);
-            const uchar4 m = ldnt(p.r.bam + base);
+            mqp = __builtin_nontemporal_load((const uint32_t*)(p.r.mapq + base));
+            libp = __builtin_nontemporal_load((const uint32_t*)(p.r.lib + base));
+            bamp = __builtin_nontemporal_load((const uint32_t*)(p.r.bam + base));
             tid[0] = a.x; tid[1] = a.y; tid[2] = a.z; tid[3] = a.w;
             pos[0] = b.x; pos[1] = b.y; pos[2] = b.z; pos[3] = b.w;
             mtid[0] = c.x; mtid[1] = c.y; mtid[2] = c.z; mtid[3] = c.w;
             mpos[0] = d.x; mpos[1] = d.y; mpos[2] = d.z; mpos[3] = d.w;
             isz[0] = e.x; isz[1] = e.y; isz[2] = e.z; isz[3] = e.w;
             sam[0] = f.x; sam[1] = f.y; sam[2] = f.z; sam[3] = f.w;
-            mq[0] = q.x; mq[1] = q.y; mq[2] = q.z; mq[3] = q.w;
-            lib[0] = l.x; lib[1] = l.y; lib[2] = l.z; lib[3] = l.w;
-            bam[0] = m.x; bam[1] = m.y; bam[2] = m.z; bam[3] = m.w;
         } else {
+            mqp = libp = bamp = 0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const uint64_t i = base + r;
@@ -123,19 +201,87 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
                 nvalid += v;
                 tid[r] = v ? p.r.tid[i] : 0; pos[r] = v ? p.r.pos[i] : 0; mtid[r] = v ? p.r.mtid[i] : 0;
                 mpos[r] = v ? p.r.mpos[i] : 0; isz[r] = v ? p.r.isize[i] : 0; sam[r] = v ? p.r.flag[i] : 0;
-                mq[r] = v ? p.r.mapq[i] : 0; lib[r] = v ? p.r.lib[i] : 0; bam[r] = v ? p.r.bam[i] : 0;
+                mqp |= (v ? (unsigned)p.r.mapq[i] : 0u) << (8 * r);
+                libp |= (v ? (unsigned)p.r.lib[i] : 0u) << (8 * r);
+                bamp |= (v ? (unsigned)p.r.bam[i] : 0u) << (8 * r);
             }
         }
 
+        bool one_file = false;   // (wave-uniform) every record of the tile comes from one source file ...
+        unsigned file0 = 0;      // ... this one
+        const unsigned l0 = lane0_of(libp) & 0xffu, b0 = lane0_of(bamp) & 0xffu;
+        if (__all(nvalid == 4 && libp == l0 * 0x01010101u && bamp == b0 * 0x01010101u)) {
+            // ---- the usual tile -----------------------------------------------------------------------------------------
+            const unsigned L0 = l0 < (unsigned)nlibs ? l0 : 0u, B0 = b0 < (unsigned)nbams ? b0 : 0u;
+            const DevLib dl = s_lib[L0];
+            TileMasks tm;
+            const unsigned word = classify_uniform_tile<kLongInsert>(p, dl, s_cnt + L0 * kNumFlags, tid, pos, mtid, mpos, isz, sam, mqp, tm);
+            unsigned na = 0, nn = 0, ck = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { na += popc64(tm.ba[r]); nn += popc64(tm.bn[r]); ck += popc64(tm.bp[r]); }
+            *(uint32_t*)(p.cls + base) = word;
+            const int k0 = dl.key;
+            const unsigned colval = lane == kColAnom ? na : (lane == kColNormal ? nn : (lane == kColKey0 + k0 ? ck : 0u));
+            if (lane < ncols) p.tile_tot[(uint32_t)lane * p.tstride + tile] = colval;  // (32 bits hold it: < 62 columns of < 2^24 tiles)
+            if (lane == 0 && tm.c1) { atomicAdd(&s_libcnt[L0], tm.c1); atomicAdd(&s_bamcnt[B0], tm.c1); }
+            one_file = true; file0 = B0;
+            if (p.stash && na) {  // (wave-uniform; about a fifth of the tiles of a 1 % discordant genome)
+                // Ready-made records for K2 (StashRec): a read's rank and prefix counts are the mask bits of the lower lanes plus
+                // the lane's own earlier slots.  Only tiles with anomalous reads pay (half of the tiles of a 1 % discordant
+                // chromosome: its discordant pairs come in clusters).  The records cost this kernel 6 us -- not for their ~250
+                // instructions (halving the instructions of the whole kernel did not change its time) but for their 6 MB of
+                // stores: next to a streaming read a byte written costs about four read (tools/stream_probe.hip).
+                unsigned ra = 0, rn = 0, rk = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ra = __builtin_amdgcn_mbcnt_hi((uint32_t)(tm.ba[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tm.ba[r], ra));
+                    rn = __builtin_amdgcn_mbcnt_hi((uint32_t)(tm.bn[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tm.bn[r], rn));
+                    rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(tm.bp[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tm.bp[r], rk));
+                }
+                // The records are put together in the wave's LDS slice and leave as ONE store of consecutive 16-byte pieces, in
+                // order (written from the lanes that own the reads -- two stores per record, a few lanes per instruction -- they
+                // took the same time).
+                typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                v4u* mine = s_stash[w];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned cb = (word >> (8 * r)) & 0xffu;
+                    const bool pass = (cb & 0x10u) != 0;
+                    const bool an = pass && (cb & 14u) != (unsigned)F_NORMAL_FR;
+                    rk += (cb & 0x30u) == 0x30u ? 1u : 0u;
+                    if (an && ra < (unsigned)kStashCap) {
+                        const v4u x0 = {(uint32_t)tid[r], (uint32_t)pos[r], (uint32_t)abs(isz[r]), (cb & 15u) | (((sam[r] >> 4) & 1u) << 4) | (L0 << 8)};
+                        const v4u x1 = {(uint32_t)(lane * 4 + r) | (rn << 8) | ((uint32_t)k0 << 20), rk, 0u, 0u};
+                        mine[2 * ra] = x0;
+                        mine[2 * ra + 1] = x1;
+                    }
+                    ra += an ? 1u : 0u;
+                    rn += (cb & 0x40u) ? 1u : 0u;
+                }
+                __builtin_amdgcn_wave_barrier();  // (LDS serves a wave's accesses in order; this keeps the compiler from reordering them)
+                const unsigned pieces = 2u * (na < (unsigned)kStashCap ? na : (unsigned)kStashCap);
+                if ((unsigned)lane < pieces) *((v4u*)(p.stash + (size_t)tile * kStashCap) + lane) = mine[lane];  // (plain store: K2 finds some of it in L2)
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+        // ---- any other tile: ragged end of the input, several libraries or files in it ----------------------------------
+        // (opaque copies of the loop invariants this rarely taken body works with: what the compiler derives from them is then
+        // computed here, when needed, instead of before the tile loop, where it took registers from every tile and spilled)
+        int lane_r = lane, nlibs_r = nlibs, nbams_r = nbams, nkeys_r = nkeys;
+        asm volatile("" : "+v"(lane_r), "+s"(nlibs_r), "+s"(nbams_r), "+s"(nkeys_r));
+        const int ncols_r = 2 + nkeys_r;
+        unsigned mq[4], lib[4], bam[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { mq[r] = (mqp >> (8 * r)) & 0xffu; lib[r] = (libp >> (8 * r)) & 0xffu; bam[r] = (bamp >> (8 * r)) & 0xffu; }
         unsigned cls4[4];
         bool p1c[4], pk[4], anom[4], nleft[4];
         int key[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool valid = r < nvalid;
-            const unsigned L = lib[r] < (unsigned)nlibs ? lib[r] : 0u;
+            const unsigned L = lib[r] < (unsigned)nlibs_r ? lib[r] : 0u;
             lib[r] = L;
-            if (bam[r] >= (unsigned)nbams) bam[r] = 0;
+            if (bam[r] >= (unsigned)nbams_r) bam[r] = 0;
             const DevLib dl = s_lib[L];  // (one record for the wave when the tile is uniform, fetched before the loop: measured 1.5 us slower)
             const int ai = abs(isz[r]);
             const int f = classify_read(sam[r], tid[r], mtid[r], pos[r], mpos[r], ai, dl.upper, dl.lower);
@@ -143,7 +289,7 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
             const bool proper = (sam[r] & 0x40Fu) == 0x3u;
             p1c[r] = valid && mq_ok && proper;
             const bool h_ok = valid && mq_ok && f != F_NA && !(sam[r] & 0xCu) && !(p.opt_t && tid[r] == mtid[r]);
-            const int f1 = p.opt_l ? remap_long_insert(f, ai, dl.upper, dl.lower) : f;
+            const int f1 = kLongInsert ? remap_long_insert(f, ai, dl.upper, dl.lower) : f;
             if (h_ok && f1 != F_NORMAL_FR && f1 != F_NORMAL_RF) atomicAdd(&s_cnt[L * kNumFlags + f1], 1u);
             const bool pass = h_ok && !(f != F_CTX && ai > p.max_sd);
             const int f2 = (f1 == F_RR) ? F_FF : f1;
@@ -163,69 +309,39 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
         }
 
         // ---- per-tile totals (lane c keeps column c) and workgroup counters: ballots + popcounts --------------
-        bool one_file = false;   // (wave-uniform) every record of the tile comes from one source file ...
-        unsigned file0 = 0;      // ... this one
         {
             unsigned na = 0, nn = 0;
             uint64_t ba[4], bn[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { ba[r] = ballot64(anom[r]); bn[r] = ballot64(nleft[r]); na += popc64(ba[r]); nn += popc64(bn[r]); }
-            unsigned colval = lane == kColAnom ? na : (lane == kColNormal ? nn : 0u);
-            // uniform fast path: every lane/slot has the same library and source file (the usual case)
+            unsigned colval = lane_r == kColAnom ? na : (lane_r == kColNormal ? nn : 0u);
+            // one library and one source file (a ragged last tile usually): one count per key
             const unsigned L0 = __shfl(lib[0], 0), B0 = __shfl(bam[0], 0);
             const bool uni = __all(lib[0] == L0 && lib[1] == L0 && lib[2] == L0 && lib[3] == L0 && bam[0] == B0 &&
                                    bam[1] == B0 && bam[2] == B0 && bam[3] == B0);
             one_file = uni; file0 = B0;
-            if (!uni && p.stash && na && lane == 0) p.stash[(size_t)tile * kStashCap].where = 0xFFFFFFFFu;  // a mixed tile: K2 compacts it from the columns
+            // this body leaves no ready-made records: slot 0 tells K2 to compact the tile from the columns
+            if (p.stash && na && lane_r == 0) p.stash[(size_t)tile * kStashCap].where = 0xFFFFFFFFu;
             if (uni) {
                 unsigned c1 = 0, ck = 0;
-                uint64_t bp[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { c1 += popc64(ballot64(p1c[r])); bp[r] = ballot64(pk[r]); ck += popc64(bp[r]); }
+                for (int r = 0; r < 4; ++r) { c1 += popc64(ballot64(p1c[r])); ck += popc64(ballot64(pk[r])); }
                 const int k0 = __shfl(key[0], 0);
-                if (lane == kColKey0 + k0) colval = ck;
-                if (lane == 0 && c1) { atomicAdd(&s_libcnt[L0], c1); atomicAdd(&s_bamcnt[B0], c1); }
-                if (p.stash && na) {  // (wave-uniform; about a fifth of the tiles of a 1 % discordant genome)
-                    // Ready-made records for K2 (StashRec): the masks are at hand, a read's rank and prefix counts are the bits of the
-                    // lower lanes plus the lane's own earlier slots.  This kernel is as busy issuing instructions as it is
-                    // fetching (~2,400 SIMD cycles per tile either way: measured, the ~180 instructions below cost the run 4 us
-                    // and the stores 1 us), so only tiles with anomalous reads pay, and only the uniform ones are served.
-                    // Whole 32-byte sectors, streaming stores: nothing is read back before K2.
-                    unsigned ra = 0, rn = 0, rk = 0;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        ra = __builtin_amdgcn_mbcnt_hi((uint32_t)(ba[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ba[r], ra));
-                        rn = __builtin_amdgcn_mbcnt_hi((uint32_t)(bn[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bn[r], rn));
-                        rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(bp[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bp[r], rk));
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        rk += pk[r] ? 1u : 0u;
-                        if (anom[r] && ra < (unsigned)kStashCap) {
-                            StashRec* dst = p.stash + (size_t)tile * kStashCap + ra;
-                            typedef unsigned v4u __attribute__((ext_vector_type(4)));
-                            v4u x0 = {(uint32_t)tid[r], (uint32_t)pos[r], (uint32_t)abs(isz[r]), (cls4[r] & 15u) | (((sam[r] >> 4) & 1u) << 4) | (lib[r] << 8)};
-                            v4u x1 = {(uint32_t)(lane * 4 + r) | (rn << 8) | ((uint32_t)k0 << 20), rk, 0u, 0u};
-                            __builtin_nontemporal_store(x0, (v4u*)dst);
-                            __builtin_nontemporal_store(x1, (v4u*)dst + 1);
-                        }
-                        ra += anom[r] ? 1u : 0u;
-                        rn += nleft[r] ? 1u : 0u;
-                    }
-                }
-            } else if (nlibs <= 8 && nbams <= 8) {
+                if (lane_r == kColKey0 + k0) colval = ck;
+                if (lane_r == 0 && c1) { atomicAdd(&s_libcnt[L0], c1); atomicAdd(&s_bamcnt[B0], c1); }
+            } else if (nlibs_r <= 8 && nbams_r <= 8) {
                 // mixed wave, few libraries / files: one ballot per (value, slot), no divergence
-                for (int v = 0; v < nlibs; ++v) {
+                for (int v = 0; v < nlibs_r; ++v) {
                     unsigned c = 0;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) c += popc64(ballot64(p1c[r] && lib[r] == (unsigned)v));
-                    if (lane == 0 && c) atomicAdd(&s_libcnt[v], c);
+                    if (lane_r == 0 && c) atomicAdd(&s_libcnt[v], c);
                 }
-                for (int v = 0; v < nbams; ++v) {
+                for (int v = 0; v < nbams_r; ++v) {
                     unsigned c = 0;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) c += popc64(ballot64(p1c[r] && bam[r] == (unsigned)v));
-                    if (lane == 0 && c) atomicAdd(&s_bamcnt[v], c);
+                    if (lane_r == 0 && c) atomicAdd(&s_bamcnt[v], c);
                 }
             } else {
 #pragma unroll
@@ -235,7 +351,7 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
                         const int ld = __ffsll((long long)todo) - 1;
                         const unsigned v = __shfl(lib[r], ld);
                         const uint64_t m = ballot64(p1c[r] && lib[r] == v);
-                        if (lane == 0) atomicAdd(&s_libcnt[v], (unsigned)popc64(m));
+                        if (lane_r == 0) atomicAdd(&s_libcnt[v], (unsigned)popc64(m));
                         todo &= ~m;
                     }
                     todo = ballot64(p1c[r]);
@@ -243,40 +359,50 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
                         const int ld = __ffsll((long long)todo) - 1;
                         const unsigned v = __shfl(bam[r], ld);
                         const uint64_t m = ballot64(p1c[r] && bam[r] == v);
-                        if (lane == 0) atomicAdd(&s_bamcnt[v], (unsigned)popc64(m));
+                        if (lane_r == 0) atomicAdd(&s_bamcnt[v], (unsigned)popc64(m));
                         todo &= ~m;
                     }
                 }
             }
             if (!uni) {
-                for (int k = 0; k < nkeys; ++k) {  // mixed wave: one ballot per key and slot
+                for (int k = 0; k < nkeys_r; ++k) {  // mixed wave: one ballot per key and slot
                     unsigned ck = 0;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ck += popc64(ballot64(pk[r] && key[r] == k));
-                    if (lane == kColKey0 + k) colval = ck;  // ncols <= 62 (bdx_create limits nkeys to 60)
+                    if (lane_r == kColKey0 + k) colval = ck;  // ncols <= 62 (bdx_create limits nkeys to 60)
                 }
             }
-            if (lane < ncols) p.tile_tot[(size_t)lane * p.tstride + tile] = colval;
+            if (lane_r < ncols_r) p.tile_tot[(size_t)lane_r * p.tstride + tile] = colval;
+        }
         }
 
         // ---- reference-length monoid per source file (BamSummary.cpp:70-74) ---------------------------------------
         {
-            const int tw = __shfl(tid[0], 0);
+            const int tw = __builtin_amdgcn_readfirstlane(tid[0]);
             bool same = true;
 #pragma unroll
             for (int r = 0; r < 4; ++r) same = same && (r >= nvalid || tid[r] == tw);
             const bool one_tid = __all(same);
             if (one_tid && one_file && __all(nvalid == 4)) {
                 // the usual tile: one tid, one file, full -- the differences telescope to (last record) - (first record)
-                const int first = __shfl(pos[0], 0), last = __shfl(pos[3], 63);
+                const int first = __builtin_amdgcn_readfirstlane(pos[0]), last = __builtin_amdgcn_readlane(pos[3], 63);
                 if (lane == 0) {
                     MonoRec m;
                     m.ft = tw; m.fp = first; m.lt = tw; m.lp = last; m.sum = (long long)last - (long long)first;
                     p.tile_mono[(size_t)file0 * p.tstride + tile] = m;
                 }
-            } else if (one_tid && nbams <= 64) {
+            } else {
+            int lane_m = lane, nbams_m = nbams;  // (opaque, as above)
+            asm volatile("" : "+v"(lane_m), "+s"(nbams_m));
+            unsigned bam[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned v = (bamp >> (8 * r)) & 0xffu;
+                bam[r] = v < (unsigned)nbams_m ? v : 0u;
+            }
+            if (one_tid && nbams_m <= 64) {
                 // all records of the tile share one tid: consecutive same-file differences telescope to
-                // last - first, found with ballots; lane v keeps the record of file v
+                // last - first, found with ballots; lane_m v keeps the record of file v
                 int my_first = 0, my_last = 0;
                 bool present = false;
                 unsigned pending = (1u << nvalid) - 1u;
@@ -295,18 +421,18 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
                     const int fl = __ffsll((long long)M) - 1, ll = 63 - __clzll((long long)M);
                     const int fs = mine ? __ffs(mine) - 1 : 0, ls = mine ? 31 - __clz(mine) : 0;
                     const int first = __shfl(pos[fs], fl), last = __shfl(pos[ls], ll);
-                    if (lane == (int)v) { present = true; my_first = first; my_last = last; }
+                    if (lane_m == (int)v) { present = true; my_first = first; my_last = last; }
                 }
                 if (present) {
                     MonoRec m;
                     m.ft = tw; m.fp = my_first; m.lt = tw; m.lp = my_last; m.sum = (long long)my_last - (long long)my_first;
-                    p.tile_mono[(size_t)lane * p.tstride + tile] = m;
+                    p.tile_mono[(size_t)lane_m * p.tstride + tile] = m;
                 }
             } else {
                 // a tid boundary falls inside the tile (or > 64 files): replay the reference's recurrence exactly,
-                // records in order, state held by lane 0 in its wave-private LDS slice
-                if (lane == 0)
-                    for (int b = 0; b < nbams; ++b) my_mono[b].ft = -1;
+                // records in order, state held by lane_m 0 in its wave-private LDS slice
+                if (lane_m == 0)
+                    for (int b = 0; b < nbams_m; ++b) my_mono[b].ft = -1;
                 for (int L = 0; L < 64; ++L) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -314,7 +440,7 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
                         if (r >= nv) continue;
                         const int rt = __shfl(tid[r], L), rp = __shfl(pos[r], L);
                         const unsigned rb = __shfl(bam[r], L);
-                        if (lane == 0) {
+                        if (lane_m == 0) {
                             MonoRec m = my_mono[rb];
                             if (m.ft == -1) { m.ft = rt; m.fp = rp; m.sum = 0; }
                             else if (m.lt == rt) m.sum += (long long)rp - (long long)m.lp;
@@ -323,9 +449,10 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
                         }
                     }
                 }
-                if (lane == 0)
-                    for (int b = 0; b < nbams; ++b)
+                if (lane_m == 0)
+                    for (int b = 0; b < nbams_m; ++b)
                         if (my_mono[b].ft != -1) p.tile_mono[(size_t)b * p.tstride + tile] = my_mono[b];
+            }
             }
         }
     }
@@ -341,8 +468,9 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
 // start / stop: events that take the kernel's own begin and end timestamps (what rocprofv3 reports for it); an event recorded
 // on the stream before and after the launch also clocks the dispatch around it (+4 us)
 void launch_k1(const K1Params& p, int grid, size_t lds, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
-    if (start && stop) hipExtLaunchKernelGGL(k1_classify_kernel, dim3(grid), dim3(kBlock), (uint32_t)lds, s, start, stop, 0u, p);
-    else hipLaunchKernelGGL(k1_classify_kernel, dim3(grid), dim3(kBlock), lds, s, p);
+    auto kernel = p.opt_l ? k1_classify_kernel<true> : k1_classify_kernel<false>;
+    if (start && stop) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), (uint32_t)lds, s, start, stop, 0u, p);
+    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, s, p);
 }
 
 // -------------------------------------------------------------------------------------------------------
