@@ -37,7 +37,7 @@ struct Cols {
     uint8_t* extra;
 };
 
-template <int kStore>  // 0: no store, 1: one byte per element (a word per lane), 2: also 32 bytes per tile from two lanes (every 5th tile)
+template <int kStore>  // 0: no store, 1: one byte per element (a word per lane), 2: also 128 bytes per fifth tile, 3: as 1 with a non-temporal store
 __global__ __launch_bounds__(256) void column_read(Cols c, uint32_t ntiles, unsigned* sink) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     unsigned acc = 0;
@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void column_read(Cols c, uint32_t ntiles, unsi
         unsigned x = f.x ^ f.y ^ b[0] ^ b[1] ^ b[2];
 #pragma unroll
         for (int k = 0; k < 5; ++k) x ^= a[k].x ^ a[k].y ^ a[k].z ^ a[k].w;
-        if (kStore >= 1) *(unsigned*)(c.out + base) = x;
+        if (kStore == 1 || kStore == 2) *(unsigned*)(c.out + base) = x;
+        if (kStore == 3) __builtin_nontemporal_store(x, (unsigned*)(c.out + base));
         if (kStore == 2 && tile % 5 == 0 && lane < 8) __builtin_nontemporal_store(a[0], (v4u*)(c.extra + (size_t)tile * 512) + lane);
         acc += x;
     }
@@ -94,14 +95,15 @@ int main(int argc, char** argv) {
     for (int k = 0; k < 3; ++k) { void* p; CK(hipMalloc(&p, ne)); CK(hipMemset(p, k + 9, ne)); c.c8[k] = (const uint8_t*)p; }
     { void* p; CK(hipMalloc(&p, ne)); c.out = (uint8_t*)p; }
     { void* p; CK(hipMalloc(&p, (size_t)ntiles * 512)); c.extra = (uint8_t*)p; }
-    for (int store = 0; store < 3; ++store)
+    for (int store = 0; store < 4; ++store)
         for (int grid : {2048, 8192}) {
             float best = 1e9f;
             for (int rep = 0; rep < 12; ++rep) {
                 CK(hipEventRecord(e0));
                 if (store == 0) hipLaunchKernelGGL(column_read<0>, dim3(grid), dim3(256), 0, 0, c, ntiles, sink);
                 else if (store == 1) hipLaunchKernelGGL(column_read<1>, dim3(grid), dim3(256), 0, 0, c, ntiles, sink);
-                else hipLaunchKernelGGL(column_read<2>, dim3(grid), dim3(256), 0, 0, c, ntiles, sink);
+                else if (store == 2) hipLaunchKernelGGL(column_read<2>, dim3(grid), dim3(256), 0, 0, c, ntiles, sink);
+                else hipLaunchKernelGGL(column_read<3>, dim3(grid), dim3(256), 0, 0, c, ntiles, sink);
                 CK(hipEventRecord(e1));
                 CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -109,7 +111,7 @@ int main(int argc, char** argv) {
             }
             const size_t bytes = ne * (25 + (store >= 1 ? 1 : 0)) + (store == 2 ? (size_t)(ntiles / 5) * 128 : 0);
             printf("nine columns, %zu elements, 25 B in%s, grid %5d x 256: %6.1f us  %6.0f GB/s\n", ne,
-                   store == 0 ? "                                     " : (store == 1 ? " + 1 B out per element               " : " + 1 B out + 128 B per fifth tile out"), grid, best * 1e3,
+                   store == 0 ? "                                     " : (store == 1 ? " + 1 B out per element               " : (store == 2 ? " + 1 B out + 128 B per fifth tile out" : " + 1 B out per element, non-temporal ")), grid, best * 1e3,
                    bytes / best / 1e6);
         }
     return 0;
