@@ -220,9 +220,10 @@ def time_host_soa(bda, Options, LibraryConfig, LIB_C2, d, n, local, torch):
         t = torch.from_numpy(arr.view(view) if view else arr).pin_memory()
         pinned[k] = t
         views[k] = t.numpy().view(dt)
-    # A context's first run also allocates every buffer of the later stages (device and pinned host memory: ~2.5 ms at this size),
-    # which says nothing about the path: timed once as `cold_context_seconds`, then the same context takes the input again
-    # (bdx_reset_reads keeps the buffers) -- what a caller that streams one chromosome after the other through a context sees.
+    # bdx_reserve (outside the timed region, like the allocation of the resident store) also sizes the buffers of the later stages,
+    # so a context's first push + run (`cold_context_seconds`) is within a few percent of the later ones; the same context then takes
+    # the input again (bdx_reset_reads keeps the buffers) -- what a caller that streams one chromosome after the other through a
+    # context sees.
     bd = bda.BreakDancer(Options(), [LibraryConfig(**LIB_C2)], 1, ntids=1, max_read_window_size=200, device=local)
     bd.lib.bdx_reserve(bd.h, n)
     torch.cuda.synchronize()
@@ -245,8 +246,8 @@ def time_host_soa(bda, Options, LibraryConfig, LIB_C2, d, n, local, torch):
     lazy = sum(np.dtype(dt).itemsize for k, dt in BATCH_FIELDS if k in ("name_key", "qlen"))
     return {"seconds": best, "value": (n / 2) / best, "unit": "read-pairs/s", "svs": nsv,
             "pcie_gb_per_s": (bytes_per_read - lazy) * n / best / 1e9, "cold_context_seconds": cold,
-            "note": "bdx_push of %d pinned host records + bdx_run on a context that has run before (buffers allocated: its first run, "
-                    "cold_context_seconds, pays ~2.5 ms of hipMalloc / hipHostMalloc); best of 4.  %d of the %d B/read "
+            "note": "bdx_push of %d pinned host records + bdx_run on a context that has run before, best of 4 (cold_context_seconds: the "
+                    "first push + run of a context fresh from bdx_reserve, which sizes the later stages' buffers as well).  %d of the %d B/read "
                     "cross PCIe as copies (name key and read length stay in the caller's pinned arrays; K2 fetches them for the ~1 %% anomalous "
                     "reads), so the rate is the host-to-device bandwidth of the box (pcie_gb_per_s, run time included)"
                     % (n, bytes_per_read - lazy, bytes_per_read)}

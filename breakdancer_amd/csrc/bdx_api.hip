@@ -26,6 +26,9 @@ using namespace bdx;
 
 namespace {
 
+// BDX_ALLOC_TRACE=1: every allocation of a context's buffers with its size and duration on stderr
+inline bool alloc_trace() { static const bool on = getenv("BDX_ALLOC_TRACE") != nullptr; return on; }
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
@@ -35,7 +38,9 @@ struct DevBuf {
         p = nullptr;
         bytes = 0;
         size_t want = b + b / 8 + 256;
+        const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(&p, want);
+        if (alloc_trace()) fprintf(stderr, "[bdx alloc] device %12zu B %8.1f us\n", want, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
         if (e == hipSuccess) bytes = want;
         return e;
     }
@@ -53,7 +58,9 @@ struct PinBuf {
         p = nullptr;
         bytes = 0;
         size_t want = b + b / 8 + 256;
+        const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = hipHostMalloc(&p, want, flags);
+        if (alloc_trace()) fprintf(stderr, "[bdx alloc] pinned %12zu B %8.1f us\n", want, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
         if (e == hipSuccess) bytes = want;
         return e;
     }
@@ -135,6 +142,7 @@ struct bdx_ctx {
     uint32_t ov_covered = 0;
     bool replayed = false;            // the last run went through the read-level host replay (a read name seen more than twice)
     bool use_stash = false;           // K1 leaves ready-made records of the anomalous reads for K2 (at most kStashKeys counter keys)
+    bool alloc_only = false;          // the stage functions only size their buffers (bdx_reserve: a first run's allocations ahead of the data)
     std::vector<uint32_t> sup_off;    // [n_svs + 1]
     std::vector<uint64_t> sup_idx;
     std::vector<uint8_t> sup_flag;
@@ -247,6 +255,7 @@ void stage_view(const bdx_ctx::Stage& st, bdx_batch_buf* out) {
 }
 
 int pass1_prepare(bdx_ctx* c, uint32_t tiles_cap);
+int presize_stages(bdx_ctx* c, uint32_t na);
 int pass1_classify(bdx_ctx* c, uint32_t upto, bool timed);
 
 constexpr uint32_t kStreamTilesMin = 4096;  // classify behind a batch only once this many new tiles (1 M reads) are complete
@@ -450,7 +459,16 @@ int bdx_reserve(bdx_ctx* c, size_t n_reads) {
     if (!c) return BDX_EINVAL;
     if (c->adopted) return fail(c, BDX_ESTATE, "reads were adopted from the caller");
     HIPCHK(c, hipSetDevice(c->device));
-    return alloc_reads(c, n_reads);
+    const int rc = alloc_reads(c, n_reads);
+    if (rc != BDX_OK) return rc;
+    // The buffers of the stages behind pass 1 as well, for the prior a first run sizes them by (1/32 of the reads anomalous, see
+    // bdx_run): ~60 device and pinned allocations, 3-4 ms at 15 M reads, most of it page pinning -- here they happen while the
+    // caller still decodes or copies, not inside its first bdx_run.  Small inputs size theirs exactly, when they run.
+    if (n_reads >= (1u << 20) && !c->ran) {
+        const uint64_t prior = (uint64_t)n_reads / 32 + 4096;
+        if (prior <= kMaxRegions) return presize_stages(c, (uint32_t)prior);
+    }
+    return BDX_OK;
 }
 
 int bdx_push(bdx_ctx* c, const bdx_batch* b) {
@@ -833,6 +851,7 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepa
             k2.fill_ptr[3] = c->b_pair_lo.as<uint32_t>(); k2.fill_words[3] = na; k2.fill_value[3] = 0xFFFFFFFFu;
             c->join_table_clean = slots;
         }
+        if (c->alloc_only) return BDX_OK;
         {   // name keys the caller's pinned batches still hold (bdx_push): one segment per batch
             bool any_host = false;
             for (auto const& sg : c->key_segs) any_host |= sg.host != nullptr;
@@ -928,6 +947,7 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool f
             k3.r_rec_dev = c->b_r_rec.as<RegionRec>(); k3.r_pk_dev = c->b_r_pk.as<uint32_t>();
             k3.host_copy_later = 0;
         }
+        if (c->alloc_only) return BDX_OK;
         K3Tail tail{has_next, next_qlen, next_nn};
         // single-context runs that take the direct join let that kernel do k3_region_of_kernel's work
         c->region_of_fused = for_k6 && !c->bucketed_join && na <= kDirectJoinMax;
@@ -952,6 +972,7 @@ int do_join_local(bdx_ctx* c, uint32_t n, const Entries& en, const uint32_t* n_p
     HIPCHK(c, c->h_groups.ensure((size_t)k4.g_cap * sizeof(GroupRec)));
     HIPCHK(c, c->b_partner.ensure((size_t)n * 4));
     k4.partner = c->b_partner.as<int32_t>(); k4.g_rec = c->h_groups.as<GroupRec>();
+    if (c->alloc_only) return BDX_OK;  // (the direct table is sized by do_compact; the bucketed join sizes its own when it runs)
     if (!c->bucketed_join && n <= kDirectJoinMax) {
         const uint32_t slots = direct_join_slots(n);
         if (c->join_table_clean != slots) {
@@ -1094,6 +1115,7 @@ int do_k6(bdx_ctx* c, bool force_host) {
         a.lb_state = c->b_ws6.as<unsigned long long>();
         a.lb_stamp = c->seq & 0x3FFFFFFFu ? c->seq & 0x3FFFFFFFu : 1u;
     }
+    if (c->alloc_only) return BDX_OK;
     a.counts = c->b_counts.as<StageCounts>();
     // run constants: the flag histogram is the device's own reduced counter table (a single-context run adopts its own
     // statistics), the read densities per counter key travel in the kernel arguments
@@ -1128,6 +1150,23 @@ int do_k6(bdx_ctx* c, bool force_host) {
     }
     launch_k6_walk(a, na, s);
     return BDX_OK;
+}
+
+// bdx_reserve: the stage functions run for their allocations only
+int presize_stages(bdx_ctx* c, uint32_t na) {
+    const uint32_t keep_na = c->na_alloc;
+    const int keep_stage = c->stage;
+    c->alloc_only = true;
+    c->na_alloc = na;
+    int r = do_compact(c, 0, nullptr, true);
+    if (r == BDX_OK) r = do_cut(c, 0, 0, 0, true);
+    if (r == BDX_OK) r = do_join_local(c, na, Entries{}, nullptr, true);
+    if (r == BDX_OK) r = do_k6(c, false);
+    c->alloc_only = false;
+    c->na_alloc = keep_na;
+    c->stage = keep_stage;
+    c->join_table_clean = 0;
+    return r;
 }
 
 // second half of K6, enqueued once the host walk has produced its share: the host's SV candidates (pinned memory) are

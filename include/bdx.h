@@ -119,7 +119,9 @@ const char* bdx_last_error(const bdx_ctx* ctx);
  *       bdx_reset_reads; every array base 16-byte aligned).
  *
  * bdx_reserve sizes the resident store up front (growing it later re-lays the per-tile tables: the classifier then starts
- * over in bdx_run).  bdx_reset_reads empties the store (capacity is kept) so that one context can take the next
+ * over in bdx_run) and, from 2^20 reads on, the buffers of the later stages for the prior a first run goes by (1/32 of the reads
+ * anomalous): a context's ~60 device and pinned allocations then happen here, while the caller still decodes or copies, and not
+ * inside its first bdx_run.  bdx_reset_reads empties the store (capacity is kept) so that one context can take the next
  * chromosome.  One context holds at most 2^32 - 1 reads. */
 typedef struct bdx_batch_buf {
     int32_t *tid, *pos, *mtid, *mpos, *isize;
