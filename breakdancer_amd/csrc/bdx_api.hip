@@ -289,8 +289,9 @@ int enqueue_batch(bdx_ctx* c, const bdx_batch& b, bool lazy_keys) {
     HIPCHK(c, hipMemcpyAsync((void*)(c->d.isize + o), b.isize, n * 4, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync((void*)(c->d.flag + o), b.flag, n * 2, hipMemcpyHostToDevice, s2));
     HIPCHK(c, hipMemcpyAsync((void*)(c->d.mapq + o), b.mapq, n, hipMemcpyHostToDevice, s2));
-    HIPCHK(c, hipMemcpyAsync((void*)(c->d.lib + o), b.lib, n, hipMemcpyHostToDevice, s2));
-    HIPCHK(c, hipMemcpyAsync((void*)(c->d.bam + o), b.bam, n, hipMemcpyHostToDevice, s2));
+    // (with one library / one source file the kernels take every index as 0 and do not read the column)
+    if (c->nlibs > 1) HIPCHK(c, hipMemcpyAsync((void*)(c->d.lib + o), b.lib, n, hipMemcpyHostToDevice, s2));
+    if (c->nbams > 1) HIPCHK(c, hipMemcpyAsync((void*)(c->d.bam + o), b.bam, n, hipMemcpyHostToDevice, s2));
     // name keys and read lengths are only needed for the anomalous reads (about 1 %): pinned ones stay where they are
     const uint64_t* dev_view = nullptr;
     const uint16_t* dev_qlen = nullptr;
@@ -831,7 +832,7 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepa
         cp.idx = c->b_c_idx.as<uint32_t>();
         cp.pk = c->b_c_pk.as<uint32_t>(); cp.cap = na;
         K2Params k2{};
-        k2.r = c->d; k2.n = c->n; k2.ntiles = c->ntiles; k2.tstride = c->tstride; k2.nkeys = nkeys; k2.libs = c->b_libs.as<DevLib>();
+        k2.r = c->d; k2.n = c->n; k2.ntiles = c->ntiles; k2.tstride = c->tstride; k2.nkeys = nkeys; k2.nlibs = c->nlibs; k2.libs = c->b_libs.as<DevLib>();
         k2.cls = c->b_cls.as<uint8_t>(); k2.tile_pre = c->b_tile_pre.as<uint32_t>(); k2.c = cp;
         k2.tile_tot = c->b_tile_tot.as<uint32_t>(); k2.stash = c->use_stash ? c->b_stash.as<StashRec>() : nullptr;
         k2.chunk_tot = c->fp_deferred.chunk_tot; k2.chunk_base = c->fp_deferred.chunk_base; k2.chunk_super = c->fp_deferred.chunk_super;

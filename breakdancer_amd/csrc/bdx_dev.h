@@ -136,7 +136,7 @@ struct K2Params {
     ReadsSoA r;
     uint64_t n;
     uint32_t ntiles, tstride;
-    int nkeys;
+    int nkeys, nlibs;
     const DevLib* libs;
     const uint8_t* cls;
     const uint32_t* tile_pre;  // chunk-local prefixes and the chunks' totals (FinalizeParams)

@@ -5,7 +5,8 @@
 //   io/BamSummary.cpp:68-114                 pass-1 body (ref_len, proper counts, flag histogram)
 //   breakdancer/BreakDancer.cpp:155-207      filter chain, -l remaps, RR->FF fold, normal-read tests
 //
-// HBM-bound: 25 B/read in (5 x i32, u16 flag, u8 mapq/lib/bam), 1 B/read out (class byte).
+// HBM-bound: 25 B/read in (5 x i32, u16 flag, u8 mapq/lib/bam; 24 / 23 B with one library and / or one source file, whose
+// index columns are not read), 1 B/read out (class byte).
 // Layout: a tile is 256 consecutive reads = one wave64, lane l owns reads [4l, 4l+4), so every column is
 // fetched with one 16/8/4-byte load per lane (1 KiB per wave-instruction for the i32 columns).  Waves are
 // independent: there is NO workgroup barrier inside the tile loop and NO global atomic at all.  Per-tile
@@ -184,8 +185,9 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
             const int4 e = ldnt(p.r.isize + base);
             const ushort4 f = ldnt(p.r.flag + base);
             mqp = __builtin_nontemporal_load((const uint32_t*)(p.r.mapq + base));
-            libp = __builtin_nontemporal_load((const uint32_t*)(p.r.lib + base));
-            bamp = __builtin_nontemporal_load((const uint32_t*)(p.r.bam + base));
+            // with one library / one source file every index counts as 0 (as an index out of range does): the column is not read
+            libp = nlibs > 1 ? __builtin_nontemporal_load((const uint32_t*)(p.r.lib + base)) : 0u;
+            bamp = nbams > 1 ? __builtin_nontemporal_load((const uint32_t*)(p.r.bam + base)) : 0u;
             tid[0] = a.x; tid[1] = a.y; tid[2] = a.z; tid[3] = a.w;
             pos[0] = b.x; pos[1] = b.y; pos[2] = b.z; pos[3] = b.w;
             mtid[0] = c.x; mtid[1] = c.y; mtid[2] = c.z; mtid[3] = c.w;
@@ -202,8 +204,8 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
                 tid[r] = v ? p.r.tid[i] : 0; pos[r] = v ? p.r.pos[i] : 0; mtid[r] = v ? p.r.mtid[i] : 0;
                 mpos[r] = v ? p.r.mpos[i] : 0; isz[r] = v ? p.r.isize[i] : 0; sam[r] = v ? p.r.flag[i] : 0;
                 mqp |= (v ? (unsigned)p.r.mapq[i] : 0u) << (8 * r);
-                libp |= (v ? (unsigned)p.r.lib[i] : 0u) << (8 * r);
-                bamp |= (v ? (unsigned)p.r.bam[i] : 0u) << (8 * r);
+                libp |= (v && nlibs > 1 ? (unsigned)p.r.lib[i] : 0u) << (8 * r);
+                bamp |= (v && nbams > 1 ? (unsigned)p.r.bam[i] : 0u) << (8 * r);
             }
         }
 

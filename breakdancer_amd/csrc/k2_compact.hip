@@ -63,6 +63,13 @@ __device__ __forceinline__ uint32_t wave_sum_below(uint32_t v, uint32_t chunk, i
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// a read's library index as K1 takes it: out of range, or with one library (the column is then not even filled), 0
+__device__ __forceinline__ int lib_of(const K2Params& p, uint64_t i) {
+    if (p.nlibs <= 1) return 0;
+    const int l = p.r.lib[i];
+    return l < p.nlibs ? l : 0;
+}
+
 // kBases: the second level of the finalisation ran before this kernel and left the sums (else it runs beside it)
 template <bool kBases> __device__ __forceinline__ uint32_t chunk_word(const K2Params& p, int col, uint32_t chunk, int lane) {
     return kBases ? p.chunk_base[(size_t)col * kMaxChunks + chunk] : p.chunk_tot[(size_t)col * kMaxChunks + lane];
@@ -215,7 +222,7 @@ template <bool kBases> __device__ __forceinline__ void k2_body(const K2Params& p
                     uint64_t key;
                     int qlen;
                     key_and_qlen_of(p, i, key, qlen);
-                    p.c.meta[j] = meta_pack((int)((src >> kOffBits) & 15u), (sam >> 4) & 1u, (int)p.r.lib[i], qlen);
+                    p.c.meta[j] = meta_pack((int)((src >> kOffBits) & 15u), (sam >> 4) & 1u, lib_of(p, i), qlen);
                     p.c.key[j] = key;
                     p.c.idx[j] = (uint32_t)i;
                     p.c.nn[j] = s_nn[w * kSlice + q];
@@ -230,7 +237,7 @@ template <bool kBases> __device__ __forceinline__ void k2_body(const K2Params& p
         if (nkeys > 1) {
 #pragma unroll
             for (int r = 0; r < kPerLane; ++r)
-                if (r < nvalid) kq[r >> 3] |= (uint64_t)(p.libs[p.r.lib[base + r]].key & 255) << (8 * (r & 7));
+                if (r < nvalid) kq[r >> 3] |= (uint64_t)(p.libs[lib_of(p, base + r)].key & 255) << (8 * (r & 7));
         }
         for (int k0 = 0; k0 < nkeys; k0 += 2) {
             uint32_t mk0 = 0, mk1 = 0;

@@ -85,6 +85,8 @@ typedef struct bdx_lib {
  *   lib       library index resolved from the RG tag (io/BamConfig.hpp:62-72 fallback included)
  *   bam       index of the physical file the record came from (pass-1 counters are per file,
  *             io/BamSummary.cpp:123,135-138)
+ *             (an index out of range counts as 0; a context with one library / one file therefore never looks at the
+ *             respective array -- it still has to be there)
  *   name_key  64-bit key of the read name; mates share it (ReadRegionData.cpp:109 joins on qname) */
 typedef struct bdx_batch {
     const int32_t *tid, *pos, *mtid, *mpos, *isize;
@@ -114,7 +116,7 @@ const char* bdx_last_error(const bdx_ctx* ctx);
  *       stay valid and unchanged until the next bdx_run on this context has returned.  Arrays in pinned (page-locked)
  *       memory are copied at PCIe speed; pinned name_key and qlen arrays are not copied at all -- only the anomalous reads
  *       (about 1 %) need them and the compaction kernel fetches those straight from the caller's arrays (25 instead
- *       of 35 bytes per read cross the bus).
+ *       of 35 bytes per read cross the bus; 23 with one library and one BAM, whose index columns are not copied).
  *   bdx_set_device_reads adopts arrays that already live in HBM (no copy; must stay valid until bdx_destroy or
  *       bdx_reset_reads; every array base 16-byte aligned).
  *

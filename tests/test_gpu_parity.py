@@ -128,6 +128,31 @@ def test_synthetic_10mbp_matches_oracle(opts):
     compare(run, product_from_oracle(run))
 
 
+def test_index_columns_of_a_single_library_and_file_are_not_read():
+    """one library, one BAM: every read belongs to them whatever its lib / bam bytes say (an index out of range counts as 0), so
+    the kernels do not read those columns and bdx_push does not copy them -- garbage in them must not show"""
+    from runner import product_options
+    import breakdancer_amd as bda
+    from breakdancer_amd.api import LibraryConfig
+    cfg, st = _synth_case(3_000_000, seed=5)
+    run = OracleRun(cfg, make_opts())
+    run.set_targets(["chrS"])
+    st = dict(st)
+    st["lib"] = np.zeros(len(st["tid"]), np.int32)
+    run.set_stream(0, st)
+    run.run()
+    assert run.nlibs == 1 and run.nbams == 1 and run.n_svs > 20
+    libs = [LibraryConfig(*[float(x) for x in run.lib_f[0]], min_mapping_quality=int(run.lib_i[0, 0]), bam_file_index=0, name=run.lib_names[0])]
+    bd = bda.BreakDancer(product_options(run.opts), libs, 1, ntids=0, max_read_window_size=run.w0, device=0)
+    soa = run.merged_soa()
+    rng = np.random.default_rng(7)
+    soa["lib"] = rng.integers(0, 256, len(soa["tid"])).astype(soa["lib"].dtype)
+    soa["bam"] = rng.integers(0, 256, len(soa["tid"])).astype(np.uint8)
+    bd.push_reads(soa)
+    bd.run()
+    compare(run, bd)
+
+
 @pytest.mark.parametrize("max_chunks", ["1", "2"])
 def test_tile_total_columns_scanned_in_chunks_of_several_rounds(max_chunks, monkeypatch):
     """finalize_kernel scans a tile-total column in chunks of whole rounds (4096 boundaries each); with at most 64 chunks a chunk
