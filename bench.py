@@ -224,13 +224,18 @@ def time_host_soa(bda, Options, LibraryConfig, LIB_C2, d, n, local, torch):
     # so a context's first push + run (`cold_context_seconds`) is within a few percent of the later ones; the same context then takes
     # the input again (bdx_reset_reads keeps the buffers) -- what a caller that streams one chromosome after the other through a
     # context sees.
-    bd = bda.BreakDancer(Options(), [LibraryConfig(**LIB_C2)], 1, ntids=1, max_read_window_size=200, device=local)
-    bd.lib.bdx_reserve(bd.h, n)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    bd.push_reads(views)
-    bd.run()
-    cold = time.perf_counter() - t0
+    cold = None
+    for fresh in range(2):  # (two fresh contexts, the better one: the process's very first push can pay one-time costs of the runtime)
+        if fresh:
+            bd.close()
+        bd = bda.BreakDancer(Options(), [LibraryConfig(**LIB_C2)], 1, ntids=1, max_read_window_size=200, device=local)
+        bd.lib.bdx_reserve(bd.h, n)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        bd.push_reads(views)
+        bd.run()
+        dt_ = time.perf_counter() - t0
+        cold = dt_ if cold is None else min(cold, dt_)
     best = None
     for _ in range(4):
         bd.reset_reads()
