@@ -284,7 +284,7 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
             const unsigned L = lib[r] < (unsigned)nlibs_r ? lib[r] : 0u;
             lib[r] = L;
             if (bam[r] >= (unsigned)nbams_r) bam[r] = 0;
-            const DevLib dl = s_lib[L];  // (one record for the wave when the tile is uniform, fetched before the loop: measured 1.5 us slower)
+            const DevLib dl = s_lib[L];
             const int ai = abs(isz[r]);
             const int f = classify_read(sam[r], tid[r], mtid[r], pos[r], mpos[r], ai, dl.upper, dl.lower);
             const bool mq_ok = (int)mq[r] > dl.min_mapq;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
             }
             if (one_tid && nbams_m <= 64) {
                 // all records of the tile share one tid: consecutive same-file differences telescope to
-                // last - first, found with ballots; lane_m v keeps the record of file v
+                // last - first, found with ballots; lane v keeps the record of file v
                 int my_first = 0, my_last = 0;
                 bool present = false;
                 unsigned pending = (1u << nvalid) - 1u;
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
                 }
             } else {
                 // a tid boundary falls inside the tile (or > 64 files): replay the reference's recurrence exactly,
-                // records in order, state held by lane_m 0 in its wave-private LDS slice
+                // records in order, state held by lane 0 in its wave-private LDS slice
                 if (lane_m == 0)
                     for (int b = 0; b < nbams_m; ++b) my_mono[b].ft = -1;
                 for (int L = 0; L < 64; ++L) {
