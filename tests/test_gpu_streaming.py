@@ -64,6 +64,15 @@ def test_push_in_many_batches_equals_one_batch(case):
     compare(run, reserved.run())
     compare(run, reserved.run())   # a repeated run classifies from the first tile again
     tables_equal(one, reserved)
+    # bdx_reserve also sizes the later stages' buffers (for 1/32 of the reserved reads anomalous): a reservation far below the
+    # input (every buffer has to grow inside the run) and one far above it
+    for guess in (1 << 20, 40_000_000):
+        other = new_ctx(run)
+        other.lib.bdx_reserve(other.h, guess)
+        other.push_reads(d)
+        compare(run, other.run())
+        tables_equal(one, other)
+        other.close()
     for x in (one, many, reserved):
         x.close()
 
