@@ -19,7 +19,7 @@ constexpr int kStashKeys = 2;    // ... when there are at most this many normal-
 // otherwise gather from seven columns -- K1 has it in registers anyway -- plus the read's in-tile prefix counts, so that K2
 // needs neither the class bytes nor the columns of a tile whose anomalous reads fit (name key and read length are fetched by
 // K2: K1 does not load those columns).  Only tiles whose reads share one library and source file are served (their normal
-// reads count for one key); slot 0 of any other tile with anomalous reads says so: where == 0xFFFFFFFF.
+// reads count for one key); the slots K2 would read of any other tile with anomalous reads say so: where == 0xFFFFFFFF.
 struct StashRec {
     int32_t tid, pos, isize;   // isize = |isize|
     uint32_t meta;             // flag | rev << 4 | lib << 8 (read length: K2)

@@ -322,8 +322,8 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
             const bool uni = __all(lib[0] == L0 && lib[1] == L0 && lib[2] == L0 && lib[3] == L0 && bam[0] == B0 &&
                                    bam[1] == B0 && bam[2] == B0 && bam[3] == B0);
             one_file = uni; file0 = B0;
-            // this body leaves no ready-made records: slot 0 tells K2 to compact the tile from the columns
-            if (p.stash && na && lane_r == 0) p.stash[(size_t)tile * kStashCap].where = 0xFFFFFFFFu;
+            // this body leaves no ready-made records: the slots say so, K2 compacts the tile from the columns
+            if (p.stash && (unsigned)lane_r < (na < (unsigned)kStashCap ? na : (unsigned)kStashCap)) p.stash[(size_t)tile * kStashCap + lane_r].where = 0xFFFFFFFFu;  // (every slot K2 would read)
             if (uni) {
                 unsigned c1 = 0, ck = 0;
 #pragma unroll

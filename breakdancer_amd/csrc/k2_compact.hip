@@ -128,14 +128,12 @@ template <bool kBases> __device__ __forceinline__ void k2_body(const K2Params& p
                 const uint32_t tile = tile2 * kSub + min(tq, 3u);
                 uint4 r0 = make_uint4(0u, 0u, 0u, 0u);
                 uint2 r1 = make_uint2(0u, 0u);
-                uint32_t first_where = 0;
                 if (q < A) {
                     const StashRec* src = p.stash + (size_t)tile * kStashCap + (q - before);
                     r0 = *(const uint4*)src;
                     r1 = *(const uint2*)&src->where;
-                    first_where = p.stash[(size_t)tile * kStashCap].where;  // (the same line)
                 }
-                if (!__any(first_where == 0xFFFFFFFFu)) {  // no mixed tile among them (else: from the columns, below)
+                if (!__any(r1.x == 0xFFFFFFFFu)) {  // no mixed tile among them (K1 marks every slot of one; else: from the columns, below)
                     if (q < A && j < p.c.cap) {  // (the capacity can be a guess of an enqueue-ahead run)
                         const uint64_t i = (uint64_t)tile * kTile + (r1.x & 255u);
                         const uint32_t k0 = (r1.x >> 20) & 63u;
