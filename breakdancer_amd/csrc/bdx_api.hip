@@ -69,7 +69,8 @@ struct PinBuf {
 };
 
 constexpr int kNumStages = 12;
-constexpr int kK1MaxGrid = 8192;  // measured best on MI355X (tools/k1_probe.hip): 256 CUs x 32 workgroups queued, 4 independent waves each
+constexpr int kK1MaxGrid = 8192;  // measured best on MI355X (tools/k1_probe.hip; again at the end of round 2, BDX_K1_GRID: 2048 74.6 us, 4096 70.9,
+                                  // 8192 69.9, 12288 72.5, 16384 73.4): 256 CUs x 32 workgroups queued, 4 independent waves each
 
 }  // namespace
 
@@ -662,7 +663,8 @@ int pass1_classify(bdx_ctx* c, uint32_t upto, bool timed) {
     k1.blk_cnt = c->b_blk_cnt.as<uint32_t>();
     k1.stash = c->use_stash ? c->b_stash.as<StashRec>() : nullptr;
     const uint32_t span = upto - c->k1_done;
-    const int grid1 = (int)std::min<uint32_t>((span + kWaves - 1) / kWaves, kK1MaxGrid);
+    static const uint32_t grid_cap = getenv("BDX_K1_GRID") ? (uint32_t)std::max(1, atoi(getenv("BDX_K1_GRID"))) : (uint32_t)kK1MaxGrid;  // (tuning probe)
+    const int grid1 = (int)std::min<uint32_t>((span + kWaves - 1) / kWaves, grid_cap);
     launch_k1(k1, grid1, k1_lds_bytes(c->nlibs, c->nbams, c->nkeys), s, timed ? c->ev[0] : nullptr, timed ? c->ev[1] : nullptr);
     c->k1_done = upto;
     return BDX_OK;
