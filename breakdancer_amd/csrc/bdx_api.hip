@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -103,6 +104,7 @@ struct bdx_ctx {
     DevBuf b_ins, b_member_ids;
     PinBuf h_flags;                   // [0] pass 1 ready, [1] host's groups ready, [2] final table ready (= run sequence number)
     uint32_t seq = 0;
+    uint32_t lb_seq = 0;              // launches of look-back scans so far: every launch stamps its words with its own number (bdx_scan.h)
     uint32_t k1_event_period = 4;     // K1 is bracketed by HIP events on every n-th run (an event pair idles the GPU ~10 us)
     float k1_ms_last = 0;
     bool k1_timed = false;
@@ -210,6 +212,20 @@ int hipfail(bdx_ctx* c, hipError_t e, const char* what) {
     } while (0)
 
 size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+// The stamp of the next look-back launch on this context.  A state array may see a given stamp only once (a word of an
+// earlier launch with the same stamp would read as already published), so the stamp counts LAUNCHES, not runs -- the cut and
+// the table stage can be launched again without a new pass 1 -- and when the 30-bit counter comes round the arrays start
+// from zero again.
+hipError_t next_lb_stamp(bdx_ctx* c, uint32_t* out) {
+    if (((++c->lb_seq) & 0x3FFFFFFFu) == 0) {
+        if (c->b_lb.p) { const hipError_t e = hipMemsetAsync(c->b_lb.p, 0, c->b_lb.bytes, c->stream); if (e != hipSuccess) return e; }
+        if (c->b_ws6.p) { const hipError_t e = hipMemsetAsync(c->b_ws6.p, 0, c->b_ws6.bytes, c->stream); if (e != hipSuccess) return e; }
+        ++c->lb_seq;
+    }
+    *out = c->lb_seq & 0x3FFFFFFFu;
+    return hipSuccess;
+}
 
 int alloc_reads(bdx_ctx* c, size_t cap) {
     cap = round_up(std::max<size_t>(cap, 1), 1024);
@@ -935,7 +951,7 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool f
                 HIPCHK(c, hipMemsetAsync(c->b_lb.p, 0, c->b_lb.bytes, s));
             }
             k3.lb_state = c->b_lb.as<unsigned long long>();
-            k3.lb_stamp = c->seq & 0x3FFFFFFFu ? c->seq & 0x3FFFFFFFu : 1u;
+            HIPCHK(c, next_lb_stamp(c, &k3.lb_stamp));
         }
         k3.ws_u4 = c->b_ws_u4.as<U4>(); k3.head_total = (U4*)c->b_totals.p; k3.ws_u32 = c->b_ws_u32.as<uint32_t>();
         k3.acc_total = (uint32_t*)((char*)c->b_totals.p + 32); k3.counts = c->b_counts.as<StageCounts>();
@@ -1116,7 +1132,7 @@ int do_k6(bdx_ctx* c, bool force_host) {
             HIPCHK(c, hipMemsetAsync(c->b_ws6.p, 0, c->b_ws6.bytes, s));
         }
         a.lb_state = c->b_ws6.as<unsigned long long>();
-        a.lb_stamp = c->seq & 0x3FFFFFFFu ? c->seq & 0x3FFFFFFFu : 1u;
+        HIPCHK(c, next_lb_stamp(c, &a.lb_stamp));
     }
     if (c->alloc_only) return BDX_OK;
     a.counts = c->b_counts.as<StageCounts>();

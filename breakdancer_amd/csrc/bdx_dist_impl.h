@@ -33,6 +33,8 @@ struct Comm {
     int rank = 0, world = 1;
     std::string err;
     virtual ~Comm() {}
+    virtual void begin_run() {}   // start of a bdx_dist_run (collective)
+    virtual void abort() {}       // this rank leaves the run between two collectives: wake whoever waits for it
     // in place sum over the ranks of n 64-bit words in device memory
     virtual bool allreduce_u64(uint64_t* dev, size_t n, hipStream_t s) = 0;
     // rank r sends scount[d] words from send + sdispl[d] to rank d and receives rcount[d] words from rank d at recv + rdispl[d]
@@ -117,13 +119,29 @@ struct ThreadGroup {
     std::vector<const void*> ptr;      // what every rank published for the collective in progress
     std::vector<const size_t*> cnt, dsp;
     std::vector<std::vector<uint64_t>> host;  // allreduce staging
-    bool failed = false;
+    std::atomic<bool> failed{false};   // a collective of the run in progress went wrong on some rank
+    std::atomic<bool> aborted{false};  // a rank left bdx_dist_run early: nobody may wait for it at a barrier
     explicit ThreadGroup(int w) : world(w), ptr(w), cnt(w), dsp(w), host(w) {}
-    void barrier() {
+    // false: the group was aborted (by a rank that gave up between two collectives) -- the caller fails its collective
+    bool barrier() {
         std::unique_lock<std::mutex> lk(mu);
+        if (aborted.load()) return false;
         const uint64_t g = generation;
-        if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); }
-        else cv.wait(lk, [&] { return generation != g; });
+        if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); return true; }
+        cv.wait(lk, [&] { return generation != g || aborted.load(); });
+        return generation != g;
+    }
+    void abort() {
+        { std::lock_guard<std::mutex> lk(mu); aborted.store(true); }
+        cv.notify_all();
+    }
+    // every rank calls this at the start of a run, before its first collective: the flags of the previous run are history.
+    // (Two barriers: nobody clears while somebody may still be reading, nobody proceeds before the flags are clear.)
+    void begin_run(int rank) {
+        if (aborted.load()) return;  // an aborted group stays aborted: its ranks are out of step for good
+        barrier();
+        if (rank == 0) failed.store(false);
+        barrier();
     }
 };
 
@@ -132,18 +150,21 @@ struct ThreadComm : Comm {
     bool hip(hipError_t e, const char* what) {
         if (e == hipSuccess) return true;
         err = std::string(what) + ": " + hipGetErrorString(e);
-        g->failed = true;
+        g->failed.store(true);
         return false;
     }
+    bool gone() { err = "another rank left the run"; return false; }
+    void begin_run() override { g->begin_run(rank); }
+    void abort() override { g->abort(); }
     bool allreduce_u64(uint64_t* dev, size_t n, hipStream_t s) override {
         std::vector<uint64_t>& mine = g->host[rank];
         mine.resize(n);
         bool good = hip(hipMemcpyAsync(mine.data(), dev, n * 8, hipMemcpyDeviceToHost, s), "hipMemcpyAsync") && hip(hipStreamSynchronize(s), "sync");
-        g->barrier();
+        if (!g->barrier()) return gone();
         std::vector<uint64_t> sum(n, 0);
         for (int r = 0; r < world; ++r)
             for (size_t i = 0; i < n && i < g->host[r].size(); ++i) sum[i] += g->host[r][i];
-        g->barrier();  // (everybody has read everybody's words)
+        if (!g->barrier()) return gone();  // (everybody has read everybody's words)
         good = good && hip(hipMemcpyAsync(dev, sum.data(), n * 8, hipMemcpyHostToDevice, s), "hipMemcpyAsync") && hip(hipStreamSynchronize(s), "sync");
         return good && !g->failed;
     }
@@ -151,27 +172,27 @@ struct ThreadComm : Comm {
                        const size_t* rdispl, hipStream_t s) override {
         bool good = hip(hipStreamSynchronize(s), "sync");  // the send buffer is complete
         g->ptr[rank] = send; g->cnt[rank] = scount; g->dsp[rank] = sdispl;
-        g->barrier();
+        if (!g->barrier()) return gone();
         for (int r = 0; r < world && good; ++r) {
             const size_t n = g->cnt[r][rank];
-            if (n != rcount[r]) { err = "all-to-all counts disagree"; g->failed = true; good = false; break; }
+            if (n != rcount[r]) { err = "all-to-all counts disagree"; g->failed.store(true); good = false; break; }
             if (n) good = hip(hipMemcpyAsync(recv + rdispl[r], (const uint64_t*)g->ptr[r] + g->dsp[r][rank], n * 8, hipMemcpyDefault, s), "hipMemcpyAsync");
         }
         good = good && hip(hipStreamSynchronize(s), "sync");
-        g->barrier();  // (the send buffers may be reused)
+        if (!g->barrier()) return gone();  // (the send buffers may be reused)
         return good && !g->failed;
     }
     bool gatherv_bytes(const void* send, size_t n, void* recv, const size_t* count, const size_t* displ, int root, hipStream_t s) override {
         bool good = hip(hipStreamSynchronize(s), "sync");
         g->ptr[rank] = send;
-        g->barrier();
+        if (!g->barrier()) return gone();
         if (rank == root) {
             for (int r = 0; r < world && good; ++r)
                 if (count[r]) good = hip(hipMemcpyAsync((char*)recv + displ[r], g->ptr[r], count[r], hipMemcpyDefault, s), "hipMemcpyAsync");
             good = good && hip(hipStreamSynchronize(s), "sync");
         }
         (void)n;
-        g->barrier();
+        if (!g->barrier()) return gone();
         return good && !g->failed;
     }
 };
@@ -333,6 +354,25 @@ int bdx_dist_plan(const uint64_t* weight, int ntids, int world, int* rank_of_tid
     return BDX_OK;
 }
 
+// A failure that only one rank sees (its own data, its own device) must not make that rank leave while the others enter
+// the next collective: they would wait for it for ever.  Every stage between two collectives therefore runs as a local
+// phase whose status travels with the next all-reduce (one word per rank behind the payload); all ranks look at the
+// summed words and give up together.  What cannot be folded (a device allocation failing between the size exchange and
+// the all-to-all) aborts the communicator of the thread backend, which wakes its waiters with an error.
+struct RunStatus {
+    int rc = BDX_OK;      // this rank's first failure
+    std::string msg;
+};
+
+static int agreed_failure(bdx_dist* d, const RunStatus& st, const std::vector<uint64_t>& v, size_t at, int world) {
+    int first = -1, code = BDX_OK;
+    for (int q = 0; q < world; ++q)
+        if (v[at + q]) { first = q; code = (int)v[at + q]; break; }
+    if (first < 0) return BDX_OK;
+    if (st.rc != BDX_OK) return dfail(d, st.rc, st.msg);
+    return dfail(d, code, "rank " + std::to_string(first) + " failed (" + bdx_strerror(code) + "); all ranks stop");
+}
+
 int bdx_dist_run(bdx_dist* d) {
     if (!d) return BDX_EINVAL;
     const auto t_begin = std::chrono::steady_clock::now();
@@ -345,22 +385,46 @@ int bdx_dist_run(bdx_dist* d) {
     hipStream_t us = U->stream;
     d->ran = false;
     d->ctx_sent = d->ctx_received = d->gathered_bytes = 0;
+    comm.begin_run();
+    RunStatus st;
+    // a phase: local work between two collectives; its failure is recorded, not returned
+    auto phase = [&](const std::function<int()>& body) {
+        if (st.rc != BDX_OK) return;
+        d->err.clear();
+        const int rc = body();
+        if (rc != BDX_OK) { st.rc = rc; st.msg = d->err; }
+    };
+    // all-reduce of v with the ranks' status words appended; afterwards every rank knows whether anybody failed
+    auto exchange = [&](std::vector<uint64_t>& v) -> int {
+        const size_t at = v.size();
+        v.resize(at + (size_t)world, 0);
+        v[at + (size_t)rank] = (uint64_t)st.rc;
+        const int rc = allreduce_host(d, v);
+        if (rc != BDX_OK) { comm.abort(); return rc; }
+        const int f = agreed_failure(d, st, v, at, world);
+        v.resize(at);
+        return f;
+    };
+    auto leave = [&](int rc) { comm.abort(); return rc; };  // failures past the last foldable point
 
     // ---- pass 1 on the own chromosomes; C1: counters, per-file reference lengths, per-chromosome totals ----
     const size_t tw = 2 + (size_t)nkeys;  // per chromosome: anomalous reads, normal pairs, proper reads per key
     std::vector<uint64_t> v1((size_t)ncnt + nbams + (size_t)ntids * tw, 0);
-    for (auto& kv : d->chrom) DCTX(d, kv.second, do_pass1(kv.second, 0, false, false));  // all enqueued, then waited for
-    for (auto& kv : d->chrom) {
-        bdx_ctx* c = kv.second;
-        DCTX(d, c, wait_pass1(c));
-        for (int i = 0; i < ncnt; ++i) v1[i] += c->cnt_local[i];
-        for (int b = 0; b < nbams; ++b) v1[ncnt + b] += c->p1.ref_len[b];
-        uint64_t* t = &v1[(size_t)ncnt + nbams + (size_t)kv.first * tw];
-        t[0] = c->p1.n_anom; t[1] = c->p1.n_normal;
-        for (int k = 0; k < nkeys; ++k) t[2 + k] = c->p1.key_tot[k];
-    }
-    DCTX(d, U, do_pass1(U));  // (no reads: brings the utility context's buffers up)
-    int rc = allreduce_host(d, v1);
+    phase([&]() -> int {
+        for (auto& kv : d->chrom) DCTX(d, kv.second, do_pass1(kv.second, 0, false, false));  // all enqueued, then waited for
+        for (auto& kv : d->chrom) {
+            bdx_ctx* c = kv.second;
+            DCTX(d, c, wait_pass1(c));
+            for (int i = 0; i < ncnt; ++i) v1[i] += c->cnt_local[i];
+            for (int b = 0; b < nbams; ++b) v1[ncnt + b] += c->p1.ref_len[b];
+            uint64_t* t = &v1[(size_t)ncnt + nbams + (size_t)kv.first * tw];
+            t[0] = c->p1.n_anom; t[1] = c->p1.n_normal;
+            for (int k = 0; k < nkeys; ++k) t[2 + k] = c->p1.key_tot[k];
+        }
+        DCTX(d, U, do_pass1(U));  // (no reads: brings the utility context's buffers up)
+        return BDX_OK;
+    });
+    int rc = exchange(v1);
     if (rc != BDX_OK) return rc;
     std::vector<uint32_t> cnt_g(ncnt);
     for (int i = 0; i < ncnt; ++i) cnt_g[i] = (uint32_t)v1[i];
@@ -372,28 +436,32 @@ int bdx_dist_run(bdx_dist* d) {
     std::vector<uint64_t> base((size_t)(ntids + 1) * tw, 0);  // exclusive prefix over the chromosomes in stream order
     for (int t = 0; t < ntids; ++t)
         for (size_t k = 0; k < tw; ++k) base[(size_t)(t + 1) * tw + k] = base[(size_t)t * tw + k] + tot(t, (int)k);
+    // (the same sum on every rank: all of them return here, together)
     if (base[(size_t)ntids * tw] > kMaxRegions) return dfail(d, BDX_ELIMIT, "too many anomalous reads for the packed group key");
 
     // ---- compaction with the counters of the chromosomes in front; C2: every chromosome's first anomalous read ----
     std::vector<uint64_t> v2((size_t)ntids * 3, 0);
-    for (auto& kv : d->chrom) {
-        bdx_ctx* c = kv.second;
-        DCTX(d, c, set_pass1(c, cnt_g.data(), covered, window, true));
-        std::vector<uint32_t> pkb(nkeys);
-        for (int k = 0; k < nkeys; ++k) pkb[k] = (uint32_t)base[(size_t)kv.first * tw + 2 + k];
-        DCTX(d, c, do_compact(c, (uint32_t)base[(size_t)kv.first * tw + 1], pkb.data(), false));
-    }
-    for (auto& kv : d->chrom) {
-        bdx_ctx* c = kv.second;
-        if (!c->p1.n_anom) continue;
-        uint32_t meta = 0, nn = 0;
-        DHIP(d, hipMemcpyAsync(&meta, c->cp.meta, 4, hipMemcpyDeviceToHost, c->stream));
-        DHIP(d, hipMemcpyAsync(&nn, c->cp.nn, 4, hipMemcpyDeviceToHost, c->stream));
-        DHIP(d, hipStreamSynchronize(c->stream));
-        uint64_t* t = &v2[(size_t)kv.first * 3];
-        t[0] = 1; t[1] = (uint64_t)meta_qlen(meta); t[2] = nn;
-    }
-    rc = allreduce_host(d, v2);
+    phase([&]() -> int {
+        for (auto& kv : d->chrom) {
+            bdx_ctx* c = kv.second;
+            DCTX(d, c, set_pass1(c, cnt_g.data(), covered, window, true));
+            std::vector<uint32_t> pkb(nkeys);
+            for (int k = 0; k < nkeys; ++k) pkb[k] = (uint32_t)base[(size_t)kv.first * tw + 2 + k];
+            DCTX(d, c, do_compact(c, (uint32_t)base[(size_t)kv.first * tw + 1], pkb.data(), false));
+        }
+        for (auto& kv : d->chrom) {
+            bdx_ctx* c = kv.second;
+            if (!c->p1.n_anom) continue;
+            uint32_t meta = 0, nn = 0;
+            DHIP(d, hipMemcpyAsync(&meta, c->cp.meta, 4, hipMemcpyDeviceToHost, c->stream));
+            DHIP(d, hipMemcpyAsync(&nn, c->cp.nn, 4, hipMemcpyDeviceToHost, c->stream));
+            DHIP(d, hipStreamSynchronize(c->stream));
+            uint64_t* t = &v2[(size_t)kv.first * 3];
+            t[0] = 1; t[1] = (uint64_t)meta_qlen(meta); t[2] = nn;
+        }
+        return BDX_OK;
+    });
+    rc = exchange(v2);
     if (rc != BDX_OK) return rc;
 
     // ---- regions; the first anomalous read of the next chromosome closes a chromosome's last candidate.  C3 ----
@@ -403,118 +471,136 @@ int bdx_dist_run(bdx_dist* d) {
         if (tot(t, 0) > 0) nx = t;
     }
     std::vector<uint64_t> v3((size_t)ntids * 2, 0);
-    for (auto& kv : d->chrom) {
-        bdx_ctx* c = kv.second;
-        const int nx = next_anom[kv.first];
-        if (nx >= 0) DCTX(d, c, do_cut(c, 1, (int32_t)v2[(size_t)nx * 3 + 1], (uint32_t)v2[(size_t)nx * 3 + 2], false, true));
-        else DCTX(d, c, do_cut(c, 0, 0, 0, false, true));
-    }
-    for (auto& kv : d->chrom) {
-        bdx_ctx* c = kv.second;
-        DCTX(d, c, readback(c, false));
-        v3[(size_t)kv.first * 2] = c->counts.n_regions;
-        v3[(size_t)kv.first * 2 + 1] = (uint32_t)c->counts.last_maxq;
-    }
-
-    // ---- joins: pairs within a chromosome where they are; CTX records to owner(name key) ----
-    DHIP(d, d->b_cnt.ensure((size_t)world * 8 + 64));
-    uint32_t* d_cnt = d->b_cnt.as<uint32_t>();      // [world] records per destination
-    uint32_t* d_cur = d_cnt + world;                // [world] scatter cursors
-    DHIP(d, hipMemsetAsync(d_cnt, 0, (size_t)world * 4, us));
-    DHIP(d, hipStreamSynchronize(us));
-    // (the chromosomes' streams are independent: the counts are complete once each has been waited for, below)
-    for (auto& kv : d->chrom) {
-        bdx_ctx* c = kv.second;
-        const uint32_t na = c->p1.n_anom;
-        if (na) launch_k7_count(c->cp.key, c->cp.meta, &c->b_p1.as<Pass1>()->n_anom, na, (uint32_t)world, d_cnt, c->stream);
-    }
-    for (auto& kv : d->chrom) DHIP(d, hipStreamSynchronize(kv.second->stream));
+    uint32_t* d_cnt = nullptr;      // [world] records per destination
+    uint32_t* d_cur = nullptr;      // [world] scatter cursors
     std::vector<uint32_t> h_cnt(world, 0);
-    DHIP(d, hipMemcpy(h_cnt.data(), d_cnt, (size_t)world * 4, hipMemcpyDeviceToHost));
-    rc = allreduce_host(d, v3);
+    phase([&]() -> int {
+        for (auto& kv : d->chrom) {
+            bdx_ctx* c = kv.second;
+            const int nx = next_anom[kv.first];
+            if (nx >= 0) DCTX(d, c, do_cut(c, 1, (int32_t)v2[(size_t)nx * 3 + 1], (uint32_t)v2[(size_t)nx * 3 + 2], false, true));
+            else DCTX(d, c, do_cut(c, 0, 0, 0, false, true));
+        }
+        for (auto& kv : d->chrom) {
+            bdx_ctx* c = kv.second;
+            DCTX(d, c, readback(c, false));
+            v3[(size_t)kv.first * 2] = c->counts.n_regions;
+            v3[(size_t)kv.first * 2 + 1] = (uint32_t)c->counts.last_maxq;
+        }
+        // ---- joins: pairs within a chromosome where they are; CTX records to owner(name key) ----
+        DHIP(d, d->b_cnt.ensure((size_t)world * 8 + 64));
+        d_cnt = d->b_cnt.as<uint32_t>();
+        d_cur = d_cnt + world;
+        DHIP(d, hipMemsetAsync(d_cnt, 0, (size_t)world * 4, us));
+        DHIP(d, hipStreamSynchronize(us));
+        // (the chromosomes' streams are independent: the counts are complete once each has been waited for, below)
+        for (auto& kv : d->chrom) {
+            bdx_ctx* c = kv.second;
+            const uint32_t na = c->p1.n_anom;
+            if (na) launch_k7_count(c->cp.key, c->cp.meta, &c->b_p1.as<Pass1>()->n_anom, na, (uint32_t)world, d_cnt, c->stream);
+        }
+        for (auto& kv : d->chrom) DHIP(d, hipStreamSynchronize(kv.second->stream));
+        DHIP(d, hipMemcpy(h_cnt.data(), d_cnt, (size_t)world * 4, hipMemcpyDeviceToHost));
+        return BDX_OK;
+    });
+    rc = exchange(v3);
     if (rc != BDX_OK) return rc;
     std::vector<uint64_t> rbase(ntids + 1, 0);
     for (int t = 0; t < ntids; ++t) rbase[t + 1] = rbase[t] + v3[(size_t)t * 2];
     const uint64_t NR = rbase[ntids];
-    if (NR > kMaxRegions) return dfail(d, BDX_ELIMIT, "too many regions for the packed group key");
+    if (NR > kMaxRegions) return dfail(d, BDX_ELIMIT, "too many regions for the packed group key");  // (all ranks alike)
     int last_anom_tid = -1;
     for (int t = 0; t < ntids; ++t)
         if (tot(t, 0) > 0) last_anom_tid = t;
 
     const auto t_x0 = std::chrono::steady_clock::now();
-    std::vector<uint64_t> v4((size_t)world * world, 0);  // send-count matrix: row = sender
-    for (int q = 0; q < world; ++q) v4[(size_t)rank * world + q] = h_cnt[q];
-    rc = allreduce_host(d, v4);
-    if (rc != BDX_OK) return rc;
+    // Everything a rank can do before it knows what the others send happens in front of the count exchange, so that its
+    // failure still travels with it: the send buffer (sized by the rank's own counts), the chromosomes' own joins, the
+    // packing of the CTX records per destination.
     std::vector<size_t> scount(world), sdispl(world), rcount(world), rdispl(world);
     size_t nsend = 0, nrecv = 0;
-    for (int q = 0; q < world; ++q) {
-        scount[q] = (size_t)v4[(size_t)rank * world + q] * 3; sdispl[q] = nsend * 3; nsend += v4[(size_t)rank * world + q];
-        rcount[q] = (size_t)v4[(size_t)q * world + rank] * 3; rdispl[q] = nrecv * 3; nrecv += v4[(size_t)q * world + rank];
-    }
-    if (nrecv > kMaxRegions) return dfail(d, BDX_ELIMIT, "too many inter-chromosomal join records on one rank");
-    DHIP(d, d->b_send.ensure(std::max<size_t>(nsend, 1) * sizeof(ExchangeEntry)));
-    DHIP(d, d->b_recv.ensure(std::max<size_t>(nrecv, 1) * sizeof(ExchangeEntry)));
+    for (int q = 0; q < world; ++q) { scount[q] = (size_t)h_cnt[q] * 3; sdispl[q] = nsend * 3; nsend += h_cnt[q]; }
+    phase([&]() -> int {
+        DHIP(d, d->b_send.ensure(std::max<size_t>(nsend, 1) * sizeof(ExchangeEntry)));
+        {
+            std::vector<uint32_t> cur(world);
+            for (int q = 0; q < world; ++q) cur[q] = (uint32_t)(sdispl[q] / 3);
+            DHIP(d, hipMemcpy(d_cur, cur.data(), (size_t)world * 4, hipMemcpyHostToDevice));
+        }
+        for (auto& kv : d->chrom) {
+            bdx_ctx* c = kv.second;
+            const uint32_t na = c->p1.n_anom;
+            if (!na) continue;
+            // the chromosome's own pairs: K4 on its compact reads, pair groups with genome-wide region ids
+            Entries en{};
+            en.key = c->cp.key; en.region = c->k3.region_of; en.meta = c->cp.meta; en.isize = c->cp.isize;
+            en.region_base = (int32_t)rbase[kv.first];
+            DCTX(d, c, do_join_local(c, na, en, &c->b_p1.as<Pass1>()->n_anom, false));
+            launch_k7_scatter(c->cp.key, c->k3.region_of, c->cp.meta, c->cp.isize, &c->b_p1.as<Pass1>()->n_anom, na, (uint32_t)world,
+                              (uint32_t)base[(size_t)kv.first * tw], (int32_t)rbase[kv.first], d_cur, d->b_send.as<ExchangeEntry>(), c->stream);
+        }
+        for (auto& kv : d->chrom) DHIP(d, hipStreamSynchronize(kv.second->stream));
+        return BDX_OK;
+    });
+    std::vector<uint64_t> v4((size_t)world * world, 0);  // send-count matrix: row = sender
+    for (int q = 0; q < world; ++q) v4[(size_t)rank * world + q] = h_cnt[q];
+    rc = exchange(v4);
+    if (rc != BDX_OK) return rc;
+    for (int q = 0; q < world; ++q) { rcount[q] = (size_t)v4[(size_t)q * world + rank] * 3; rdispl[q] = nrecv * 3; nrecv += v4[(size_t)q * world + rank]; }
     {
-        std::vector<uint32_t> cur(world);
-        for (int q = 0; q < world; ++q) cur[q] = (uint32_t)(sdispl[q] / 3);
-        DHIP(d, hipMemcpy(d_cur, cur.data(), (size_t)world * 4, hipMemcpyHostToDevice));
+        // (the column sums are the same table on every rank: the limit trips everywhere at once)
+        for (int r = 0; r < world; ++r) {
+            uint64_t col = 0;
+            for (int q = 0; q < world; ++q) col += v4[(size_t)q * world + r];
+            if (col > kMaxRegions) return dfail(d, BDX_ELIMIT, "too many inter-chromosomal join records on one rank");
+        }
     }
-    for (auto& kv : d->chrom) {
-        bdx_ctx* c = kv.second;
-        const uint32_t na = c->p1.n_anom;
-        if (!na) continue;
-        // the chromosome's own pairs: K4 on its compact reads, pair groups with genome-wide region ids
-        Entries en{};
-        en.key = c->cp.key; en.region = c->k3.region_of; en.meta = c->cp.meta; en.isize = c->cp.isize;
-        en.region_base = (int32_t)rbase[kv.first];
-        DCTX(d, c, do_join_local(c, na, en, &c->b_p1.as<Pass1>()->n_anom, false));
-        launch_k7_scatter(c->cp.key, c->k3.region_of, c->cp.meta, c->cp.isize, &c->b_p1.as<Pass1>()->n_anom, na, (uint32_t)world,
-                          (uint32_t)base[(size_t)kv.first * tw], (int32_t)rbase[kv.first], d_cur, d->b_send.as<ExchangeEntry>(), c->stream);
-    }
-    for (auto& kv : d->chrom) DHIP(d, hipStreamSynchronize(kv.second->stream));
+    if (d->b_recv.ensure(std::max<size_t>(nrecv, 1) * sizeof(ExchangeEntry)) != hipSuccess)
+        return leave(dfail(d, BDX_ENOMEM, "receive buffer of the all-to-all"));
     // C4: the all-to-all of the CTX records (three 64-bit words each)
     if (!comm.alltoallv_u64(d->b_send.as<uint64_t>(), scount.data(), sdispl.data(), d->b_recv.as<uint64_t>(), rcount.data(), rdispl.data(), us))
-        return dfail(d, BDX_EHIP, comm.err);
+        return leave(dfail(d, BDX_EHIP, comm.err));
     d->ctx_sent = nsend; d->ctx_received = nrecv;
     // join what arrived
     uint32_t ng_ctx = 0;
-    if (nrecv) {
-        const uint32_t n32 = (uint32_t)nrecv;
-        DHIP(d, U->b_x_key.ensure(nrecv * 8)); DHIP(d, U->b_x_order.ensure(nrecv * 4)); DHIP(d, U->b_x_region.ensure(nrecv * 4));
-        DHIP(d, U->b_x_meta.ensure(nrecv * 4)); DHIP(d, U->b_x_isize.ensure(nrecv * 4)); DHIP(d, U->b_x_n.ensure(16));
-        launch_k7_unpack(d->b_recv.as<ExchangeEntry>(), n32, U->b_x_key.as<uint64_t>(), U->b_x_order.as<uint32_t>(), U->b_x_region.as<int32_t>(),
-                         U->b_x_meta.as<uint32_t>(), U->b_x_isize.as<int32_t>(), us);
-        DHIP(d, hipMemcpyAsync(U->b_x_n.p, &n32, 4, hipMemcpyHostToDevice, us));
-        DHIP(d, hipMemsetAsync(U->b_counts.p, 0, sizeof(StageCounts), us));
-        Entries en{};
-        en.key = U->b_x_key.as<uint64_t>(); en.region = U->b_x_region.as<int32_t>(); en.order = U->b_x_order.as<uint32_t>();
-        en.meta = U->b_x_meta.as<uint32_t>(); en.isize = U->b_x_isize.as<int32_t>();
-        DCTX(d, U, do_join_local(U, n32, en, U->b_x_n.as<uint32_t>(), false));
-        DHIP(d, hipMemcpyAsync(U->h_counts.p, U->b_counts.p, sizeof(StageCounts), hipMemcpyDeviceToHost, us));
-        DHIP(d, hipStreamSynchronize(us));
-        const StageCounts sc = *U->h_counts.as<StageCounts>();
-        if (sc.irregular) return dfail(d, BDX_ELIMIT, "a read name occurs more than twice among the inter-chromosomal reads: run the chromosomes in one context");
-        if (sc.overflow) return dfail(d, BDX_EINTERNAL, "group list overflow");
-        ng_ctx = sc.n_groups;
-    }
-    const auto t_x1 = std::chrono::steady_clock::now();
-
-    // ---- C5: region tables and pair groups to rank 0 ----
-    // this rank's package: per owned chromosome (ascending) its region records and prefix samples, then all pair groups
-    size_t nreg_mine = 0, ng_mine = ng_ctx;
-    for (auto& kv : d->chrom) {
-        bdx_ctx* c = kv.second;
-        if (!c->p1.n_anom) continue;
-        DCTX(d, c, readback(c, true));
-        if (c->counts.irregular) return dfail(d, BDX_ELIMIT, "a read name occurs more than twice: run the chromosomes in one context");
-        nreg_mine += c->counts.n_regions;
-        ng_mine += c->counts.n_groups;
-    }
+    auto t_x1 = std::chrono::steady_clock::now();
+    size_t nreg_mine = 0, ng_mine = 0, pack_bytes = 0;
     const size_t rrec = sizeof(RegionRec), rpk = (size_t)2 * nkeys * 4, grec = sizeof(GroupRec);
-    const size_t pack_bytes = round_up(nreg_mine * (rrec + rpk) + ng_mine * grec, 8);
-    DHIP(d, d->b_pack.ensure(std::max<size_t>(pack_bytes, 8)));
-    {
+    phase([&]() -> int {
+        if (nrecv) {
+            const uint32_t n32 = (uint32_t)nrecv;
+            DHIP(d, U->b_x_key.ensure(nrecv * 8)); DHIP(d, U->b_x_order.ensure(nrecv * 4)); DHIP(d, U->b_x_region.ensure(nrecv * 4));
+            DHIP(d, U->b_x_meta.ensure(nrecv * 4)); DHIP(d, U->b_x_isize.ensure(nrecv * 4)); DHIP(d, U->b_x_n.ensure(16));
+            launch_k7_unpack(d->b_recv.as<ExchangeEntry>(), n32, U->b_x_key.as<uint64_t>(), U->b_x_order.as<uint32_t>(), U->b_x_region.as<int32_t>(),
+                             U->b_x_meta.as<uint32_t>(), U->b_x_isize.as<int32_t>(), us);
+            DHIP(d, hipMemcpyAsync(U->b_x_n.p, &n32, 4, hipMemcpyHostToDevice, us));
+            DHIP(d, hipMemsetAsync(U->b_counts.p, 0, sizeof(StageCounts), us));
+            Entries en{};
+            en.key = U->b_x_key.as<uint64_t>(); en.region = U->b_x_region.as<int32_t>(); en.order = U->b_x_order.as<uint32_t>();
+            en.meta = U->b_x_meta.as<uint32_t>(); en.isize = U->b_x_isize.as<int32_t>();
+            DCTX(d, U, do_join_local(U, n32, en, U->b_x_n.as<uint32_t>(), false));
+            DHIP(d, hipMemcpyAsync(U->h_counts.p, U->b_counts.p, sizeof(StageCounts), hipMemcpyDeviceToHost, us));
+            DHIP(d, hipStreamSynchronize(us));
+            const StageCounts sc = *U->h_counts.as<StageCounts>();
+            if (sc.irregular) return dfail(d, BDX_ELIMIT, "a read name occurs more than twice among the inter-chromosomal reads: run the chromosomes in one context");
+            if (sc.overflow) return dfail(d, BDX_EINTERNAL, "group list overflow");
+            ng_ctx = sc.n_groups;
+        }
+        t_x1 = std::chrono::steady_clock::now();
+
+        // ---- C5: region tables and pair groups to rank 0 ----
+        // this rank's package: per owned chromosome (ascending) its region records and prefix samples, then all pair groups
+        ng_mine = ng_ctx;
+        for (auto& kv : d->chrom) {
+            bdx_ctx* c = kv.second;
+            if (!c->p1.n_anom) continue;
+            DCTX(d, c, readback(c, true));
+            if (c->counts.irregular) return dfail(d, BDX_ELIMIT, "a read name occurs more than twice: run the chromosomes in one context");
+            nreg_mine += c->counts.n_regions;
+            ng_mine += c->counts.n_groups;
+        }
+        pack_bytes = round_up(nreg_mine * (rrec + rpk) + ng_mine * grec, 8);
+        DHIP(d, d->b_pack.ensure(std::max<size_t>(pack_bytes, 8)));
         char* p = (char*)d->b_pack.p;
         for (auto& kv : d->chrom) {  // records of all own chromosomes, then their prefix samples, then the groups
             bdx_ctx* c = kv.second;
@@ -535,20 +621,22 @@ int bdx_dist_run(bdx_dist* d) {
             p += ng * grec;
         }
         if (ng_ctx) DHIP(d, hipMemcpyAsync(p, U->k4.g_rec, (size_t)ng_ctx * grec, hipMemcpyDefault, us));
-    }
+        return BDX_OK;
+    });
     std::vector<uint64_t> v5((size_t)world * 3, 0);
-    v5[(size_t)rank * 3] = nreg_mine; v5[(size_t)rank * 3 + 1] = ng_mine; v5[(size_t)rank * 3 + 2] = pack_bytes;
-    rc = allreduce_host(d, v5);
+    if (st.rc == BDX_OK) { v5[(size_t)rank * 3] = nreg_mine; v5[(size_t)rank * 3 + 1] = ng_mine; v5[(size_t)rank * 3 + 2] = pack_bytes; }
+    rc = exchange(v5);
     if (rc != BDX_OK) return rc;
     std::vector<size_t> gcount(world), gdispl(world);
     size_t all_bytes = 0, ng_all = 0;
     for (int q = 0; q < world; ++q) { gcount[q] = (size_t)v5[(size_t)q * 3 + 2]; gdispl[q] = all_bytes; all_bytes += gcount[q]; ng_all += v5[(size_t)q * 3 + 1]; }
-    if (rank == 0) DHIP(d, d->b_all.ensure(std::max<size_t>(all_bytes, 8)));
-    if (!comm.gatherv_bytes(d->b_pack.p, pack_bytes, d->b_all.p, gcount.data(), gdispl.data(), 0, us)) return dfail(d, BDX_EHIP, comm.err);
+    if (rank == 0 && d->b_all.ensure(std::max<size_t>(all_bytes, 8)) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "gather buffer"));
+    if (!comm.gatherv_bytes(d->b_pack.p, pack_bytes, d->b_all.p, gcount.data(), gdispl.data(), 0, us)) return leave(dfail(d, BDX_EHIP, comm.err));
     DHIP(d, hipStreamSynchronize(us));
     d->gathered_bytes = all_bytes;
     d->ms_exchange = ms_between(t_x0, t_x1);
 
+    // (from here on nothing is collective any more: rank 0 finishes on its own)
     if (rank == 0) {
         // which rank owns which chromosome follows from the packages themselves: every region record carries its tid
         std::vector<char> host(all_bytes);

@@ -449,7 +449,9 @@ void ColumnReader::decode_piece(Scratch& sc, Piece& p, bool known_start, uint64_
                 return;
             }
         const uint32_t bs = le32(sc.buf.data() + pos);
-        bool ok = bs >= 32 && bs <= (1u << 29);
+        // from a guessed boundary a record of more than a few MiB is taken for a wrong guess (the consumer decodes the piece again
+        // from the true boundary): a misread size word must not make this worker inflate and hold half a gigabyte
+        bool ok = bs >= 32 && bs <= (known_start ? (1u << 29) : (4u << 20));
         if (ok) {
             while (pos + 4 + (size_t)bs > sc.filled)
                 if (!extend()) {

@@ -151,6 +151,7 @@ struct GpuSink : BatchSink {
 
 int main(int argc, char** argv) {
     bdx_ctx* ctx = nullptr;
+    bool ctx_owned = true;  // false: ctx is a sharded run's result context, which belongs to rank 0's bdx_dist
     try {
         std::unique_ptr<Options> opts_p(new Options(argc, argv));
         Pass1Cache cache;
@@ -244,6 +245,7 @@ int main(int argc, char** argv) {
             for (int r = 0; r < world; ++r)
                 if (rcs[r] != BDX_OK)
                     throw std::runtime_error(std::string("bdx_dist_run: ") + bdx_strerror(rcs[r]) + " (" + bdx_dist_last_error(ranks[r]) + ")");
+            ctx_owned = false;
             ctx = bdx_dist_result(ranks[0]);
             if (!ctx) throw std::runtime_error("bdx_dist_result: no result on rank 0");
         } else {
@@ -414,11 +416,11 @@ int main(int argc, char** argv) {
             fprintf(stderr, "[bdx timing] inside bdx_run (ms): classify kernel %.3f, host waits for its share of the groups %.3f, host walk %.3f, "
                             "final wait + scores %.3f, whole call %.3f\n", ms[0], ms[4], ms[5], ms[6], ms[7]);
         }
-        if (!sharded) bdx_destroy(ctx);  // (a sharded run's result context belongs to rank 0, released with the ranks)
+        if (ctx_owned) bdx_destroy(ctx);  // (a sharded run's result context belongs to rank 0, released with the ranks)
         ctx = nullptr;
     } catch (std::exception const& e) {
         std::cerr << "ERROR: " << e.what() << "\n";
-        if (ctx) bdx_destroy(ctx);
+        if (ctx && ctx_owned) bdx_destroy(ctx);
         return 1;
     }
     return 0;
