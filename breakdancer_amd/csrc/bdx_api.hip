@@ -22,6 +22,7 @@
 #include "bdx_k3.h"
 #include "bdx_scan.h"
 #include "bdx_walk.h"
+#include "bdx_bam_dev.h"
 
 using namespace bdx;
 
@@ -1903,3 +1904,4 @@ int bdx_poisson_log_upper_tail(const double* lambda, const int32_t* k, double* o
 }  // extern "C"
 
 #include "bdx_dist_impl.h"
+#include "bdx_bamdec_impl.h"

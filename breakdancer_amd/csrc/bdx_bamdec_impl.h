@@ -1,0 +1,602 @@
+// bdx_bamdec_*: a BAM file decoded on the GPU (include/bdx.h).  Included at the end of bdx_api.hip: in sink mode the decoded
+// records go straight into a context's resident store and the classifier follows them, like the batches of the staging ring.
+//
+// The caller hands over the file as it is on disk, in pieces of whole BGZF members copied into pinned staging buffers
+// (bdx_bamdec_acquire / bdx_bamdec_submit) together with the members' table (payload offset and length, inflated length: the
+// 18-byte headers and 8-byte footers are the only bytes the host looks at).  Per piece, on three streams:
+//   copy     compressed bytes + block table -> HBM
+//   inflate  KZ, one wave per member, into a ring of inflated bytes
+//   records  one piece behind (a record may end in the next piece): KB chain -> stitch -> fields -> ordered compaction into the
+//            destination columns; the running state (next record boundary, counts, errors) lives in device memory, so the
+//            host never waits for a piece -- it reads a progress record in pinned memory when it wants to know
+// The ring holds a few pieces; a piece that does not fit behind its predecessor starts at the ring's front again, and the
+// front of it is mirrored behind the predecessor so that the record that straddles the two stays contiguous.
+#include <deque>
+
+namespace {
+
+constexpr size_t kBamMargin = (size_t)kMaxDeviceRecord + 65536;   // bytes mirrored behind the piece in front of a wrap
+constexpr int kBamSlots = 4;                                       // staging / compressed buffers in flight
+
+struct BamPiece {
+    uint64_t seq = 0;            // 1-based
+    uint64_t ring_beg = 0, ring_end = 0;
+    uint64_t mirror_end = 0;     // = ring_end, or behind it where the front of a wrapped successor is mirrored
+    uint32_t nblk = 0;
+    bool wrapped = false;        // starts at the ring's front although its predecessor does not end at the ring's end
+    bool records_done = false;   // its record stage has been enqueued
+    int slot = 0;
+    hipEvent_t ev_inflated = nullptr, ev_records = nullptr;
+};
+
+}  // namespace
+
+struct bdx_bamdec {
+    int device = 0;
+    bdx_ctx* sink = nullptr;
+    std::string err;
+    hipStream_t s_copy = nullptr, s_inf = nullptr, s_rec = nullptr;
+    // per slot: pinned staging (compressed bytes, then the block table), device copy, status words
+    struct Slot {
+        PinBuf h_comp, h_blocks;
+        DevBuf d_comp, d_blocks, d_status;
+        hipEvent_t ev_copied = nullptr;   // H2D of this slot done (staging reusable)
+        hipEvent_t ev_free = nullptr;     // inflate of this slot done (device copy reusable)
+        bool busy = false;
+        size_t cap = 0;
+    } slot[kBamSlots];
+    int next_slot = 0, cur_slot = -1;
+    DevBuf d_ring;
+    size_t ring_bytes = 0;        // usable bytes (the allocation has kBamMargin more)
+    uint64_t cursor = 0;
+    std::deque<BamPiece> pieces;  // submitted, oldest first; dropped once their record stage is enqueued and a successor exists
+    std::vector<hipEvent_t> ev_pool;
+    uint64_t n_pieces = 0;
+    bool finished = false, any_submitted = false;
+    // record stage scratch (one piece at a time on s_rec)
+    DevBuf d_cb, d_offs, d_base, d_scan, d_state;
+    DevBuf r_tid, r_pos, r_mtid, r_mpos, r_isize, r_flag, r_qlen, r_mapq, r_lib, r_keep, r_key;
+    uint32_t raw_cap = 0;
+    // read groups
+    DevBuf d_rg_hash, d_rg_off, d_rg_chars, d_rg_lib;
+    RgTable rg{};
+    RecordFilterDev filt{};
+    uint8_t bam_index = 0;
+    // own destination (no sink)
+    DevBuf o_tid, o_pos, o_mtid, o_mpos, o_isize, o_flag, o_qlen, o_mapq, o_lib, o_bam, o_key;
+    size_t own_cap = 0;
+    // progress record in pinned memory: [0] kept records, [1] error | past_region << 8 | redo << 32, [2] raw records, [3] sequence
+    PinBuf h_progress;
+    uint64_t confirmed = 0;       // kept records known to be in the destination
+    uint64_t confirmed_seq = 0;
+    uint64_t bound_in_flight = 0; // upper bound of the records of pieces whose compaction is not confirmed yet
+    std::deque<std::pair<uint64_t, uint64_t>> bounds;  // (sequence, bound)
+    std::deque<std::pair<uint64_t, hipEvent_t>> rec_events;  // (sequence, records-done event) for the sink's classifier
+    float ms_inflate = 0;
+    uint64_t inflated_bytes = 0, compressed_bytes = 0;
+};
+
+namespace {
+
+int bfail(bdx_bamdec* d, int code, const std::string& msg) {
+    if (d) d->err = msg;
+    return code;
+}
+#define BHIP(d, expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) return bfail(d, BDX_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+hipEvent_t bam_event(bdx_bamdec* d) {
+    if (!d->ev_pool.empty()) { hipEvent_t e = d->ev_pool.back(); d->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return e;
+}
+
+DstColumns bam_dst(bdx_bamdec* d, uint64_t* cap) {
+    DstColumns c{};
+    if (d->sink) {
+        bdx_ctx* k = d->sink;
+        c.tid = (int32_t*)k->d.tid; c.pos = (int32_t*)k->d.pos; c.mtid = (int32_t*)k->d.mtid; c.mpos = (int32_t*)k->d.mpos;
+        c.isize = (int32_t*)k->d.isize; c.flag = (uint16_t*)k->d.flag; c.qlen = (uint16_t*)k->d.qlen; c.mapq = (uint8_t*)k->d.mapq;
+        c.lib = (uint8_t*)k->d.lib; c.bam = (uint8_t*)k->d.bam; c.key = (uint64_t*)k->d.key;
+        *cap = k->cap;
+    } else {
+        c.tid = d->o_tid.as<int32_t>(); c.pos = d->o_pos.as<int32_t>(); c.mtid = d->o_mtid.as<int32_t>(); c.mpos = d->o_mpos.as<int32_t>();
+        c.isize = d->o_isize.as<int32_t>(); c.flag = d->o_flag.as<uint16_t>(); c.qlen = d->o_qlen.as<uint16_t>(); c.mapq = d->o_mapq.as<uint8_t>();
+        c.lib = d->o_lib.as<uint8_t>(); c.bam = d->o_bam.as<uint8_t>(); c.key = d->o_key.as<uint64_t>();
+        *cap = d->own_cap;
+    }
+    return c;
+}
+
+// the decoder's own destination columns with room for `cap` records (contents kept)
+int bam_own_reserve(bdx_bamdec* d, size_t cap, uint64_t keep_records) {
+    if (cap <= d->own_cap) return BDX_OK;
+    cap = round_up(cap, 1024);
+    struct Col { DevBuf* b; size_t esz; };
+    Col cols[] = {{&d->o_tid, 4}, {&d->o_pos, 4}, {&d->o_mtid, 4}, {&d->o_mpos, 4}, {&d->o_isize, 4}, {&d->o_flag, 2}, {&d->o_qlen, 2},
+                  {&d->o_mapq, 1}, {&d->o_lib, 1}, {&d->o_bam, 1}, {&d->o_key, 8}};
+    if (d->own_cap) BHIP(d, hipStreamSynchronize(d->s_rec));
+    for (Col& c : cols) {
+        DevBuf nb;
+        BHIP(d, nb.ensure(cap * c.esz));
+        if (keep_records && c.b->p) BHIP(d, hipMemcpy(nb.p, c.b->p, keep_records * c.esz, hipMemcpyDeviceToDevice));
+        c.b->release();
+        *c.b = nb;
+    }
+    d->own_cap = cap;
+    return BDX_OK;
+}
+
+// what the host knows of the device's progress (never blocks)
+void bam_poll(bdx_bamdec* d) {
+    if (!d->h_progress.p) return;
+    volatile uint64_t* pr = (volatile uint64_t*)d->h_progress.p;
+    const uint64_t seq = pr[3];
+    if (seq <= d->confirmed_seq) return;
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    d->confirmed = pr[0];
+    d->confirmed_seq = seq;
+    while (!d->bounds.empty() && d->bounds.front().first <= seq) { d->bound_in_flight -= d->bounds.front().second; d->bounds.pop_front(); }
+}
+
+// sink mode: the classifier over the tiles that the confirmed records complete
+int bam_feed_classifier(bdx_bamdec* d, bool final) {
+    bdx_ctx* c = d->sink;
+    if (!c) return BDX_OK;
+    hipEvent_t latest = nullptr;
+    while (!d->rec_events.empty() && d->rec_events.front().first <= d->confirmed_seq) {
+        if (latest) d->ev_pool.push_back(latest);
+        latest = d->rec_events.front().second;
+        d->rec_events.pop_front();
+    }
+    if (d->confirmed > c->n) {
+        c->n = (size_t)d->confirmed;
+        c->ran = false;
+    }
+    if (latest) {
+        const hipError_t e = hipStreamWaitEvent(c->stream, latest, 0);
+        d->ev_pool.push_back(latest);
+        if (e != hipSuccess) return bfail(d, BDX_EHIP, "hipStreamWaitEvent");
+    }
+    if (c->k1_live) {
+        const uint32_t full = (uint32_t)(c->n / kTile);
+        if (full >= c->k1_done + kStreamTilesMin || (final && full > c->k1_done)) {
+            const int rc = pass1_classify(c, full, false);
+            if (rc != BDX_OK) return bfail(d, rc, c->err);
+        }
+    }
+    return BDX_OK;
+}
+
+int bam_record_stage(bdx_bamdec* d, BamPiece& p, const BamPiece* next, bool is_last) {
+    hipStream_t s = d->s_rec;
+    bdx_bamdec::Slot& sl = d->slot[p.slot];
+    uint64_t avail_end = p.ring_end;
+    if (next) {
+        BHIP(d, hipStreamWaitEvent(s, next->ev_inflated, 0));
+        if (next->wrapped) {   // mirror the front of the ring behind this piece: the straddling record stays contiguous
+            const size_t n = std::min<uint64_t>(kBamMargin, next->ring_end - next->ring_beg);
+            BHIP(d, hipMemcpyAsync((char*)d->d_ring.p + p.ring_end, (char*)d->d_ring.p + next->ring_beg, n, hipMemcpyDeviceToDevice, s));
+            avail_end = p.ring_end + n;
+        } else {
+            avail_end = next->ring_end;
+        }
+    } else {
+        BHIP(d, hipStreamWaitEvent(s, p.ev_inflated, 0));
+    }
+    const uint32_t nblk = p.nblk;
+    // upper bound of the piece's records (36 bytes is the smallest record) -> the raw columns
+    const uint64_t bound = (p.ring_end - p.ring_beg) / 36 + 2;
+    if (bound > d->raw_cap) {
+        BHIP(d, hipStreamSynchronize(s));
+        const size_t cap = round_up((size_t)bound + bound / 8, 1024);
+        BHIP(d, d->r_tid.ensure(cap * 4)); BHIP(d, d->r_pos.ensure(cap * 4)); BHIP(d, d->r_mtid.ensure(cap * 4)); BHIP(d, d->r_mpos.ensure(cap * 4));
+        BHIP(d, d->r_isize.ensure(cap * 4)); BHIP(d, d->r_flag.ensure(cap * 2)); BHIP(d, d->r_qlen.ensure(cap * 2)); BHIP(d, d->r_mapq.ensure(cap));
+        BHIP(d, d->r_lib.ensure(cap)); BHIP(d, d->r_keep.ensure(cap)); BHIP(d, d->r_key.ensure(cap * 8));
+        BHIP(d, d->d_scan.ensure((cap / 256 + 8) * 4));
+        d->raw_cap = (uint32_t)cap;
+    }
+    BHIP(d, d->d_cb.ensure((size_t)std::max(nblk, 1u) * sizeof(ChainBlock)));
+    BHIP(d, d->d_offs.ensure((size_t)std::max(nblk, 1u) * kRecSlots * 2));
+    BHIP(d, d->d_base.ensure(((size_t)nblk + 2) * 4));
+    // destination capacity: everything that may still arrive from pieces in flight must fit
+    bam_poll(d);
+    const uint64_t need = d->confirmed + d->bound_in_flight + bound;
+    if (d->sink) {
+        bdx_ctx* c = d->sink;
+        if (need > c->cap) {
+            BHIP(d, hipStreamSynchronize(s));   // pieces in flight write through the old columns
+            bam_poll(d);
+            c->n = (size_t)d->confirmed;
+            const int rc = alloc_reads(c, std::max<size_t>((size_t)need, c->cap + c->cap / 2));
+            if (rc != BDX_OK) return bfail(d, rc, c->err);
+        }
+    } else {
+        if (need > d->own_cap) {
+            BHIP(d, hipStreamSynchronize(s));
+            bam_poll(d);
+            const int rc = bam_own_reserve(d, std::max<size_t>((size_t)need, d->own_cap + d->own_cap / 2), d->confirmed);
+            if (rc != BDX_OK) return rc;
+        }
+    }
+    const uint8_t* u = d->d_ring.as<uint8_t>();
+    const BgzfBlock* blocks = sl.d_blocks.as<BgzfBlock>();
+    ChainBlock* cb = d->d_cb.as<ChainBlock>();
+    uint16_t* offs = d->d_offs.as<uint16_t>();
+    uint32_t* base = d->d_base.as<uint32_t>();
+    PieceState* st = d->d_state.as<PieceState>();
+    launch_kb_chain(u, blocks, nblk, avail_end, d->filt.n_targets, cb, offs, s);
+    launch_kb_stitch(u, blocks, nblk, avail_end, is_last ? 1 : 0, cb, offs, base, st, sl.d_status.as<uint32_t>(), s);
+    RawColumns raw{d->r_tid.as<int32_t>(), d->r_pos.as<int32_t>(), d->r_mtid.as<int32_t>(), d->r_mpos.as<int32_t>(), d->r_isize.as<int32_t>(),
+                   d->r_flag.as<uint16_t>(), d->r_qlen.as<uint16_t>(), d->r_mapq.as<uint8_t>(), d->r_lib.as<uint8_t>(), d->r_keep.as<uint8_t>(),
+                   d->r_key.as<uint64_t>()};
+    launch_kb_extract(u, blocks, nblk, cb, offs, base, d->rg, d->filt, raw, st, s);
+    uint64_t dst_cap = 0;
+    DstColumns dst = bam_dst(d, &dst_cap);
+    launch_kb_compact(raw, (uint32_t)std::min<uint64_t>(bound, d->raw_cap), dst, dst_cap, d->bam_index, d->d_scan.as<uint32_t>(), st,
+                      (volatile uint64_t*)d->h_progress.p, p.seq, s);
+    p.ev_records = bam_event(d);
+    if (!p.ev_records) return bfail(d, BDX_EHIP, "hipEventCreate");
+    BHIP(d, hipEventRecord(p.ev_records, s));
+    // the slot's device buffers (block table, status) are free once the record stage is through
+    BHIP(d, hipEventRecord(sl.ev_free, s));
+    d->bounds.emplace_back(p.seq, bound);
+    d->bound_in_flight += bound;
+    if (d->sink) {
+        hipEvent_t e = bam_event(d);
+        if (!e) return bfail(d, BDX_EHIP, "hipEventCreate");
+        BHIP(d, hipEventRecord(e, s));
+        d->rec_events.emplace_back(p.seq, e);
+    }
+    p.records_done = true;
+    return BDX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* p) {
+    if (!out || !p || p->n_targets < 0 || p->bam_index < 0 || p->bam_index > 254) return BDX_EINVAL;
+    if (p->n_read_groups && (!p->rg_ids || !p->rg_lib)) return BDX_EINVAL;
+    const int device = sink ? sink->device : p->device;
+    if (hipSetDevice(device) != hipSuccess) return BDX_EHIP;
+    bdx_bamdec* d = new (std::nothrow) bdx_bamdec;
+    if (!d) return BDX_ENOMEM;
+    d->device = device;
+    d->sink = sink;
+    d->bam_index = (uint8_t)p->bam_index;
+    d->filt.only_tid = p->only_tid; d->filt.beg = p->region_beg; d->filt.end = p->region_end; d->filt.n_targets = p->n_targets;
+    auto bad = [&](int code) { bdx_bamdec_destroy(d); return code; };
+    if (hipStreamCreateWithFlags(&d->s_copy, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&d->s_inf, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&d->s_rec, hipStreamNonBlocking) != hipSuccess)
+        return bad(BDX_EHIP);
+    for (auto& sl : d->slot)
+        if (hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&sl.ev_free, hipEventDisableTiming) != hipSuccess)
+            return bad(BDX_EHIP);
+    // read groups
+    {
+        const uint32_t n = p->n_read_groups;
+        std::vector<uint64_t> hash(n);
+        std::vector<uint32_t> off(n + 1, 0);
+        std::string chars;
+        for (uint32_t i = 0; i < n; ++i) {
+            const char* id = p->rg_ids[i] ? p->rg_ids[i] : "";
+            const size_t l = strlen(id);
+            uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)l;
+            size_t k = 0;
+            for (; k + 8 <= l; k += 8) { uint64_t w; memcpy(&w, id + k, 8); h = name_hash_step(h, w); }
+            uint64_t w = 0;
+            if (k < l) memcpy(&w, id + k, l - k);
+            hash[i] = name_hash_finish(h, w);
+            off[i] = (uint32_t)chars.size();
+            chars.append(id, l);
+        }
+        off[n] = (uint32_t)chars.size();
+        if (d->d_rg_hash.ensure(std::max<size_t>(n, 1) * 8) != hipSuccess || d->d_rg_off.ensure(((size_t)n + 1) * 4) != hipSuccess ||
+            d->d_rg_chars.ensure(std::max<size_t>(chars.size(), 1)) != hipSuccess || d->d_rg_lib.ensure(std::max<size_t>(n, 1)) != hipSuccess)
+            return bad(BDX_ENOMEM);
+        if ((n && hipMemcpy(d->d_rg_hash.p, hash.data(), (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess) ||
+            hipMemcpy(d->d_rg_off.p, off.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            (!chars.empty() && hipMemcpy(d->d_rg_chars.p, chars.data(), chars.size(), hipMemcpyHostToDevice) != hipSuccess) ||
+            (n && hipMemcpy(d->d_rg_lib.p, p->rg_lib, n, hipMemcpyHostToDevice) != hipSuccess))
+            return bad(BDX_EHIP);
+        d->rg.hash = d->d_rg_hash.as<uint64_t>(); d->rg.off = d->d_rg_off.as<uint32_t>(); d->rg.chars = d->d_rg_chars.as<char>();
+        d->rg.lib = d->d_rg_lib.as<uint8_t>(); d->rg.n = n; d->rg.fallback = p->fallback_lib;
+    }
+    // ring of inflated bytes
+    d->ring_bytes = p->ring_bytes ? p->ring_bytes : ((size_t)1 << 30);
+    if (d->ring_bytes < ((size_t)1 << 20)) d->ring_bytes = (size_t)1 << 20;
+    if (d->d_ring.ensure(d->ring_bytes + kBamMargin + 64) != hipSuccess) return bad(BDX_ENOMEM);
+    d->ring_bytes = d->d_ring.bytes - kBamMargin - 64;
+    if (d->d_state.ensure(sizeof(PieceState)) != hipSuccess) return bad(BDX_ENOMEM);
+    PieceState st{};
+    st.next_start = p->first_record_offset;
+    if (hipMemcpy(d->d_state.p, &st, sizeof(st), hipMemcpyHostToDevice) != hipSuccess) return bad(BDX_EHIP);
+    if (d->h_progress.ensure(64) != hipSuccess) return bad(BDX_ENOMEM);
+    memset(d->h_progress.p, 0, 64);
+    if (sink) {
+        if (sink->adopted) return bad(BDX_ESTATE);
+        if (sink->n == 0 && sink->cap) {   // pass 1 runs as the records arrive
+            sink->key_segs.clear();
+            const uint64_t tiles = (sink->cap + kTile - 1) / kTile;
+            if (tiles <= 0xFFFFFFFFull) {
+                if (pass1_prepare(sink, (uint32_t)tiles) != BDX_OK) return bad(BDX_EHIP);
+                sink->k1_live = true;
+            }
+        }
+        if (sink->key_segs.empty() || sink->key_segs.back().host) sink->key_segs.push_back(bdx_ctx::KeySeg{(uint64_t)sink->n, nullptr, nullptr});
+        d->confirmed = sink->n;
+        // (records this decoder appends come behind what the store already holds)
+        st.n_kept = sink->n;
+        if (hipMemcpy(d->d_state.p, &st, sizeof(st), hipMemcpyHostToDevice) != hipSuccess) return bad(BDX_EHIP);
+    }
+    *out = d;
+    return BDX_OK;
+}
+
+void bdx_bamdec_destroy(bdx_bamdec* d) {
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    for (hipStream_t s : {d->s_copy, d->s_inf, d->s_rec})
+        if (s) (void)hipStreamSynchronize(s);
+    for (auto& sl : d->slot) {
+        sl.h_comp.release(); sl.h_blocks.release(); sl.d_comp.release(); sl.d_blocks.release(); sl.d_status.release();
+        if (sl.ev_copied) (void)hipEventDestroy(sl.ev_copied);
+        if (sl.ev_free) (void)hipEventDestroy(sl.ev_free);
+    }
+    for (auto& p : d->pieces) {
+        if (p.ev_inflated) (void)hipEventDestroy(p.ev_inflated);
+        if (p.ev_records) (void)hipEventDestroy(p.ev_records);
+    }
+    for (auto& e : d->rec_events) (void)hipEventDestroy(e.second);
+    for (hipEvent_t e : d->ev_pool) (void)hipEventDestroy(e);
+    for (DevBuf* b : {&d->d_ring, &d->d_cb, &d->d_offs, &d->d_base, &d->d_scan, &d->d_state, &d->r_tid, &d->r_pos, &d->r_mtid, &d->r_mpos, &d->r_isize,
+                      &d->r_flag, &d->r_qlen, &d->r_mapq, &d->r_lib, &d->r_keep, &d->r_key, &d->d_rg_hash, &d->d_rg_off, &d->d_rg_chars, &d->d_rg_lib,
+                      &d->o_tid, &d->o_pos, &d->o_mtid, &d->o_mpos, &d->o_isize, &d->o_flag, &d->o_qlen, &d->o_mapq, &d->o_lib, &d->o_bam, &d->o_key})
+        b->release();
+    d->h_progress.release();
+    for (hipStream_t s : {d->s_copy, d->s_inf, d->s_rec})
+        if (s) (void)hipStreamDestroy(s);
+    delete d;
+}
+
+const char* bdx_bamdec_last_error(const bdx_bamdec* d) { return d ? d->err.c_str() : ""; }
+
+int bdx_bamdec_acquire(bdx_bamdec* d, size_t bytes, size_t max_blocks, void** buf, bdx_bgzf_block** blocks) {
+    if (!d || !buf || !blocks || bytes == 0 || max_blocks == 0) return BDX_EINVAL;
+    if (d->cur_slot >= 0) return bfail(d, BDX_ESTATE, "the previous piece was not submitted");
+    if (d->finished) return bfail(d, BDX_ESTATE, "the decoder has finished");
+    BHIP(d, hipSetDevice(d->device));
+    bdx_bamdec::Slot& sl = d->slot[d->next_slot];
+    if (sl.busy) {
+        BHIP(d, hipEventSynchronize(sl.ev_copied));
+        BHIP(d, hipEventSynchronize(sl.ev_free));
+        sl.busy = false;
+    }
+    BHIP(d, sl.h_comp.ensure(bytes + 64));
+    BHIP(d, sl.h_blocks.ensure(max_blocks * sizeof(bdx_bgzf_block) + max_blocks * sizeof(BgzfBlock)));
+    *buf = sl.h_comp.p;
+    *blocks = sl.h_blocks.as<bdx_bgzf_block>();
+    sl.cap = max_blocks;
+    d->cur_slot = d->next_slot;
+    d->next_slot = (d->next_slot + 1) % kBamSlots;
+    return BDX_OK;
+}
+
+int bdx_bamdec_submit(bdx_bamdec* d, size_t bytes, size_t nblocks, int last) {
+    if (!d) return BDX_EINVAL;
+    if (d->cur_slot < 0) return bfail(d, BDX_ESTATE, "no piece was acquired");
+    BHIP(d, hipSetDevice(d->device));
+    const int si = d->cur_slot;
+    bdx_bamdec::Slot& sl = d->slot[si];
+    d->cur_slot = -1;
+    if (nblocks > sl.cap) return bfail(d, BDX_EINVAL, "more blocks than the acquired table holds");
+    const bdx_bgzf_block* hb = sl.h_blocks.as<bdx_bgzf_block>();
+    BgzfBlock* tb = (BgzfBlock*)(hb + sl.cap);   // the device's table is built behind the caller's
+    uint64_t ulen = 0;
+    for (size_t i = 0; i < nblocks; ++i) {
+        if (hb[i].inflated_len > 65536 || hb[i].offset + hb[i].payload_len > bytes) return bfail(d, BDX_EINVAL, "BGZF block table does not fit the piece");
+        ulen += hb[i].inflated_len;
+    }
+    if (ulen * 4 > d->ring_bytes) return bfail(d, BDX_ELIMIT, "piece too large for the inflate ring (it holds four pieces)");
+    // place the piece in the ring
+    BamPiece p;
+    p.seq = ++d->n_pieces;
+    p.slot = si;
+    p.nblk = (uint32_t)nblocks;
+    if (d->cursor + ulen > d->ring_bytes) { p.wrapped = d->any_submitted; d->cursor = 0; }
+    if (!d->any_submitted) {   // the first record offset is relative to the first block: now it has a ring address
+        d->any_submitted = true;
+    }
+    p.ring_beg = d->cursor;
+    p.ring_end = p.mirror_end = d->cursor + ulen;
+    d->cursor = p.ring_end;
+    if (p.wrapped && !d->pieces.empty()) {   // the front of this piece will be mirrored behind its predecessor
+        BamPiece& prev = d->pieces.back();
+        prev.mirror_end = prev.ring_end + std::min<uint64_t>(kBamMargin, ulen);
+    }
+    uint64_t o = p.ring_beg;
+    for (size_t i = 0; i < nblocks; ++i) {
+        tb[i].in_off = hb[i].offset; tb[i].in_len = hb[i].payload_len; tb[i].out_off = o; tb[i].out_len = hb[i].inflated_len;
+        o += hb[i].inflated_len;
+    }
+    // the ring bytes this piece (and the mirror behind it) will overwrite must have been consumed: the record stages of the
+    // pieces that still live there
+    // (its own mirror, should its successor wrap, is written by ITS record stage, on the stream on which all older pieces'
+    // record stages have run by then)
+    for (auto& q : d->pieces) {
+        const bool overlap = q.ring_beg < p.ring_end && p.ring_beg < q.mirror_end;
+        if (!overlap) continue;
+        if (!q.records_done) {
+            // its record stage waits for ITS successor, which would be this piece or an earlier one: cannot happen with a ring of
+            // several pieces, unless the pieces are too large for it
+            return bfail(d, BDX_ELIMIT, "inflate ring too small for the pieces in flight");
+        }
+        BHIP(d, hipStreamWaitEvent(d->s_inf, q.ev_records, 0));
+    }
+    BHIP(d, sl.d_comp.ensure(bytes + 64));
+    BHIP(d, sl.d_blocks.ensure(std::max<size_t>(nblocks, 1) * sizeof(BgzfBlock)));
+    BHIP(d, sl.d_status.ensure(std::max<size_t>(nblocks, 1) * 4));
+    memset((char*)sl.h_comp.p + bytes, 0, 64);
+    BHIP(d, hipMemcpyAsync(sl.d_comp.p, sl.h_comp.p, bytes + 64, hipMemcpyHostToDevice, d->s_copy));
+    if (nblocks) BHIP(d, hipMemcpyAsync(sl.d_blocks.p, tb, nblocks * sizeof(BgzfBlock), hipMemcpyHostToDevice, d->s_copy));
+    BHIP(d, hipEventRecord(sl.ev_copied, d->s_copy));
+    BHIP(d, hipStreamWaitEvent(d->s_inf, sl.ev_copied, 0));
+    launch_kz_inflate(sl.d_comp.as<uint8_t>(), sl.d_blocks.as<BgzfBlock>(), (uint32_t)nblocks, d->d_ring.as<uint8_t>(), sl.d_status.as<uint32_t>(), d->s_inf);
+    p.ev_inflated = bam_event(d);
+    if (!p.ev_inflated) return bfail(d, BDX_EHIP, "hipEventCreate");
+    BHIP(d, hipEventRecord(p.ev_inflated, d->s_inf));
+    sl.busy = true;
+    d->compressed_bytes += bytes;
+    d->inflated_bytes += ulen;
+    d->pieces.push_back(p);
+    // record stage of the piece in front, which now has its successor's bytes behind it
+    if (d->pieces.size() >= 2) {
+        BamPiece& prev = d->pieces[d->pieces.size() - 2];
+        if (!prev.records_done) {
+            const int rc = bam_record_stage(d, prev, &d->pieces.back(), false);
+            if (rc != BDX_OK) return rc;
+        }
+    }
+    if (last) {
+        const int rc = bam_record_stage(d, d->pieces.back(), nullptr, true);
+        if (rc != BDX_OK) return rc;
+        d->finished = true;
+    }
+    // forget pieces whose ring bytes nobody can need any more: all but the last few
+    while (d->pieces.size() > (size_t)kBamSlots + 2 && d->pieces.front().records_done) {
+        BamPiece& f = d->pieces.front();
+        // (a later piece that lands on its bytes waits for ev_records; once the event has completed that wait is void)
+        if (hipEventQuery(f.ev_records) != hipSuccess) break;
+        d->ev_pool.push_back(f.ev_inflated);
+        d->ev_pool.push_back(f.ev_records);
+        d->pieces.pop_front();
+    }
+    bam_poll(d);
+    return bam_feed_classifier(d, false);
+}
+
+int bdx_bamdec_progress(bdx_bamdec* d, uint64_t* n_records, uint64_t* n_raw, int* past_region, uint32_t* error) {
+    if (!d) return BDX_EINVAL;
+    bam_poll(d);
+    volatile uint64_t* pr = (volatile uint64_t*)d->h_progress.p;
+    if (n_records) *n_records = d->confirmed;
+    if (n_raw) *n_raw = pr[2];
+    if (past_region) *past_region = (int)((pr[1] >> 8) & 0xFF);
+    if (error) *error = (uint32_t)(pr[1] & 0xFF);
+    return BDX_OK;
+}
+
+int bdx_bamdec_finish(bdx_bamdec* d, uint64_t* n_records) {
+    if (!d) return BDX_EINVAL;
+    BHIP(d, hipSetDevice(d->device));
+    if (!d->finished) {
+        // the caller stops early (a region read through the index): the pieces in flight still hold whole records only up to the
+        // last stitched boundary; run the record stage of the last piece as far as its bytes go
+        if (!d->pieces.empty() && !d->pieces.back().records_done) {
+            const int rc = bam_record_stage(d, d->pieces.back(), nullptr, false);
+            if (rc != BDX_OK) return rc;
+        }
+        d->finished = true;
+    }
+    BHIP(d, hipStreamSynchronize(d->s_copy));
+    BHIP(d, hipStreamSynchronize(d->s_inf));
+    BHIP(d, hipStreamSynchronize(d->s_rec));
+    PieceState st{};
+    BHIP(d, hipMemcpy(&st, d->d_state.p, sizeof(st), hipMemcpyDeviceToHost));
+    // inflate status of the slots still around is folded into the state by the stitch kernel
+    if (st.error) {
+        static const char* what[] = {"", "corrupt BAM record chain", "BAM record larger than the device path handles", "destination full",
+                                     "truncated BAM record", "corrupt BGZF block"};
+        return bfail(d, st.error == 2 ? BDX_ELIMIT : BDX_EINVAL, what[st.error < 6 ? st.error : 1]);
+    }
+    d->confirmed = st.n_kept;
+    d->confirmed_seq = d->n_pieces;
+    d->bounds.clear();
+    d->bound_in_flight = 0;
+    if (d->sink) {
+        const int rc = bam_feed_classifier(d, true);
+        if (rc != BDX_OK) return rc;
+        d->sink->n = (size_t)st.n_kept;
+        d->sink->ran = false;
+    }
+    if (n_records) *n_records = st.n_kept;
+    return BDX_OK;
+}
+
+int bdx_bamdec_fetch(bdx_bamdec* d, uint64_t first, uint64_t n, const bdx_batch_buf* out) {
+    if (!d || !out) return BDX_EINVAL;
+    if (d->sink) return bfail(d, BDX_ESTATE, "the records went into the sink context");
+    if (!d->finished) return bfail(d, BDX_ESTATE, "bdx_bamdec_finish first");
+    if (first + n > d->confirmed || n > out->capacity) return bfail(d, BDX_EINVAL, "range beyond the decoded records");
+    if (!n) return BDX_OK;
+    BHIP(d, hipSetDevice(d->device));
+    BHIP(d, hipMemcpy(out->tid, d->o_tid.as<int32_t>() + first, n * 4, hipMemcpyDeviceToHost));
+    BHIP(d, hipMemcpy(out->pos, d->o_pos.as<int32_t>() + first, n * 4, hipMemcpyDeviceToHost));
+    BHIP(d, hipMemcpy(out->mtid, d->o_mtid.as<int32_t>() + first, n * 4, hipMemcpyDeviceToHost));
+    BHIP(d, hipMemcpy(out->mpos, d->o_mpos.as<int32_t>() + first, n * 4, hipMemcpyDeviceToHost));
+    BHIP(d, hipMemcpy(out->isize, d->o_isize.as<int32_t>() + first, n * 4, hipMemcpyDeviceToHost));
+    BHIP(d, hipMemcpy(out->flag, d->o_flag.as<uint16_t>() + first, n * 2, hipMemcpyDeviceToHost));
+    BHIP(d, hipMemcpy(out->qlen, d->o_qlen.as<uint16_t>() + first, n * 2, hipMemcpyDeviceToHost));
+    BHIP(d, hipMemcpy(out->mapq, d->o_mapq.as<uint8_t>() + first, n, hipMemcpyDeviceToHost));
+    BHIP(d, hipMemcpy(out->lib, d->o_lib.as<uint8_t>() + first, n, hipMemcpyDeviceToHost));
+    BHIP(d, hipMemcpy(out->bam, d->o_bam.as<uint8_t>() + first, n, hipMemcpyDeviceToHost));
+    BHIP(d, hipMemcpy(out->name_key, d->o_key.as<uint64_t>() + first, n * 8, hipMemcpyDeviceToHost));
+    return BDX_OK;
+}
+
+int bdx_bamdec_stats(const bdx_bamdec* d, uint64_t* compressed_bytes, uint64_t* inflated_bytes, uint64_t* pieces, uint64_t* blocks_walked_twice) {
+    if (!d) return BDX_EINVAL;
+    if (compressed_bytes) *compressed_bytes = d->compressed_bytes;
+    if (inflated_bytes) *inflated_bytes = d->inflated_bytes;
+    if (pieces) *pieces = d->n_pieces;
+    if (blocks_walked_twice) *blocks_walked_twice = d->h_progress.p ? (((volatile uint64_t*)d->h_progress.p)[1] >> 32) : 0;
+    return BDX_OK;
+}
+
+// Kernel-level entry point for the parity tests and bdx-inflate-check: BGZF members inflated by KZ, host buffers in and out.
+int bdx_inflate_blocks(int device, const void* compressed, size_t bytes, const bdx_bgzf_block* blocks, size_t nblocks, void* out, size_t out_bytes,
+                       uint32_t* status, float* kernel_ms) {
+    if (!compressed || !blocks || !out || !status) return BDX_EINVAL;
+    if (hipSetDevice(device) != hipSuccess) return BDX_EHIP;
+    std::vector<BgzfBlock> tb(nblocks);
+    uint64_t o = 0;
+    for (size_t i = 0; i < nblocks; ++i) {
+        if (blocks[i].inflated_len > 65536 || blocks[i].offset + blocks[i].payload_len > bytes) return BDX_EINVAL;
+        tb[i].in_off = blocks[i].offset; tb[i].in_len = blocks[i].payload_len; tb[i].out_off = o; tb[i].out_len = blocks[i].inflated_len;
+        o += blocks[i].inflated_len;
+    }
+    if (o > out_bytes) return BDX_EINVAL;
+    DevBuf d_in, d_out, d_tb, d_st;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = BDX_OK;
+    auto done = [&](int code) {
+        d_in.release(); d_out.release(); d_tb.release(); d_st.release();
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        return code;
+    };
+    if (d_in.ensure(bytes + 64) != hipSuccess || d_out.ensure(o + 64) != hipSuccess || d_tb.ensure(std::max<size_t>(nblocks, 1) * sizeof(BgzfBlock)) != hipSuccess ||
+        d_st.ensure(std::max<size_t>(nblocks, 1) * 4) != hipSuccess)
+        return done(BDX_ENOMEM);
+    if (hipMemset(d_in.p, 0, bytes + 64) != hipSuccess || hipMemcpy(d_in.p, compressed, bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        (nblocks && hipMemcpy(d_tb.p, tb.data(), nblocks * sizeof(BgzfBlock), hipMemcpyHostToDevice) != hipSuccess))
+        return done(BDX_EHIP);
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return done(BDX_EHIP);
+    (void)hipEventRecord(e0, nullptr);
+    launch_kz_inflate(d_in.as<uint8_t>(), d_tb.as<BgzfBlock>(), (uint32_t)nblocks, d_out.as<uint8_t>(), d_st.as<uint32_t>(), nullptr);
+    (void)hipEventRecord(e1, nullptr);
+    if (hipDeviceSynchronize() != hipSuccess) return done(BDX_EHIP);
+    if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, e0, e1);
+    if ((o && hipMemcpy(out, d_out.p, o, hipMemcpyDeviceToHost) != hipSuccess) ||
+        (nblocks && hipMemcpy(status, d_st.p, nblocks * 4, hipMemcpyDeviceToHost) != hipSuccess))
+        return done(BDX_EHIP);
+    return done(rc);
+}
+
+}  // extern "C"

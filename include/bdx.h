@@ -337,6 +337,60 @@ int bdx_dist_get_exchange(const bdx_dist* d, uint64_t* ctx_records_sent, uint64_
 int bdx_dist_owner(uint64_t name_key, int world);
 int bdx_dist_plan(const uint64_t* weight, int ntids, int world, int* rank_of_tid);
 
+/* ---- BAM decode on the device: BGZF inflate + record fields in HBM ----
+ * Replaces, for one BAM file, what the host producer does per byte and per record: bgzf inflate (samtools bgzf.c behind
+ * io/BamReader.hpp:62-70), bam_read1, Alignment's constructor (io/Alignment.cpp:12-29,45-64: core fields, bdqual from the AM tag,
+ * RG), the RG -> library lookup with its fallback (io/BamConfig.hpp:62-72, io/AlignmentSource.hpp:57-62) and the reader filter
+ * (primary, placed: io/AlignmentFilter.hpp:24-34, io/BamIo.cpp:11-18; -o region: io/RegionLimitedBamReader.hpp:63-71).  The caller
+ * reads the file, finds the BGZF members (18-byte headers, 8-byte footers) and hands the bytes over as they are, in pieces of whole
+ * members; everything else happens on the GPU, and the file crosses PCIe compressed.
+ *
+ *   bdx_bamdec_create    sink != NULL: the decoded records are appended to that context's resident store (one file: the stream
+ *                        IS the file's record order) and the classifier follows them; bdx_run afterwards as usual.  sink == NULL:
+ *                        the decoder keeps the columns in HBM and bdx_bamdec_fetch copies them out (tests; callers that merge
+ *                        several files themselves).  first_record_offset: offset of the first record in the inflated stream,
+ *                        counted from the first member that will be submitted (the caller has parsed the BAM header).
+ *   bdx_bamdec_acquire   a pinned staging buffer for `bytes` of file and a table of max_blocks members, both owned by the decoder
+ *                        (a ring of four; blocks only while all are in flight)
+ *   bdx_bamdec_submit    the first `bytes` of the buffer are whole members, described by the first nblocks table entries
+ *                        (offset = start of the member's deflate payload in the buffer); last != 0 with the file's final piece.
+ *                        Asynchronous: copy, inflate and record kernels are enqueued, one piece behind for the records
+ *   bdx_bamdec_progress  non-blocking: records appended so far, records seen, whether a record behind the -o region was met
+ *                        (a caller that seeked through the index may stop there), device-side error code
+ *   bdx_bamdec_finish    waits for everything; errors of the decode (corrupt block, corrupt or truncated record chain, a record
+ *                        beyond the device path's 4 MiB) surface here.  Without a `last` piece it ends the stream where it is
+ *   bdx_inflate_blocks   kernel-level entry point for parity tests: members inflated by the GPU, host buffers in and out;
+ *                        status[i] != 0: member i was rejected (the caller lets zlib judge it) */
+typedef struct bdx_bamdec bdx_bamdec;
+typedef struct bdx_bgzf_block {
+    uint64_t offset;        /* of the member's deflate payload within the submitted bytes */
+    uint32_t payload_len;   /* BSIZE + 1 - XLEN - 20 */
+    uint32_t inflated_len;  /* ISIZE, at most 65536 */
+} bdx_bgzf_block;
+typedef struct bdx_bamdec_params {
+    int32_t device;               /* used when there is no sink */
+    int32_t n_targets;            /* reference sequences of the file's header */
+    int32_t bam_index;            /* index of the file among the configuration's BAMs (the records' `bam` column) */
+    int32_t only_tid, region_beg, region_end;  /* -o region; only_tid < 0: every placed record */
+    uint32_t n_read_groups;       /* read-group ids of the configuration and their library indices */
+    const char* const* rg_ids;
+    const uint8_t* rg_lib;
+    uint8_t fallback_lib;         /* library of records without (or with an unknown) read group */
+    uint64_t first_record_offset;
+    size_t ring_bytes;            /* inflated bytes kept in flight, 0: 1 GiB */
+} bdx_bamdec_params;
+int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* p);
+void bdx_bamdec_destroy(bdx_bamdec* d);
+const char* bdx_bamdec_last_error(const bdx_bamdec* d);
+int bdx_bamdec_acquire(bdx_bamdec* d, size_t bytes, size_t max_blocks, void** buf, bdx_bgzf_block** blocks);
+int bdx_bamdec_submit(bdx_bamdec* d, size_t bytes, size_t nblocks, int last);
+int bdx_bamdec_progress(bdx_bamdec* d, uint64_t* n_records, uint64_t* n_raw, int* past_region, uint32_t* error);
+int bdx_bamdec_finish(bdx_bamdec* d, uint64_t* n_records);
+int bdx_bamdec_fetch(bdx_bamdec* d, uint64_t first, uint64_t n, const bdx_batch_buf* out);
+int bdx_bamdec_stats(const bdx_bamdec* d, uint64_t* compressed_bytes, uint64_t* inflated_bytes, uint64_t* pieces, uint64_t* blocks_walked_twice);
+int bdx_inflate_blocks(int device, const void* compressed, size_t bytes, const bdx_bgzf_block* blocks, size_t nblocks, void* out,
+                       size_t out_bytes, uint32_t* status, float* kernel_ms);
+
 /* device the context is bound to and the HIP stream it launches on (as void*), for callers that time it */
 int bdx_device(const bdx_ctx* ctx);
 void* bdx_stream(const bdx_ctx* ctx);

@@ -1,0 +1,241 @@
+"""GPU tests of the device-side BAM decode (include/bdx.h bdx_bamdec_*, csrc/kz_inflate.hip, csrc/kb_records.hip):
+the inflate kernel against zlib byte for byte, the record columns against the independent pure-Python decode of
+tests/helpers.py (and through it against what the host reader produces, tests/test_producer.py)."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, read_bam
+
+pytestmark = pytest.mark.gpu
+
+CHR21 = os.path.join(GOLDEN, "chr21")
+BAMS = ["NA19238_chr21_del_inv.bam", "NA19240_chr21_del_inv.bam"]
+
+
+def member(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, mem_level=8):
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, mem_level, strategy)
+    comp = co.compress(data) + co.flush()
+    bsize = len(comp) + 25
+    assert bsize <= 65535, "test payload does not fit a BGZF member"
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + comp +
+            struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+
+
+def payloads(rng):
+    """(label, bytes) inputs that exercise stored / fixed / dynamic blocks, long and overlapping matches, long codes"""
+    words = [bytes(rng.integers(97, 123, rng.integers(2, 9), dtype=np.uint8)) for _ in range(300)]
+    text = b" ".join(words[i] for i in rng.integers(0, len(words), 12000))
+    skew = rng.choice(np.arange(256, dtype=np.uint8), size=60000, p=np.r_[np.full(8, 0.11), np.full(248, 0.12 / 248)]).tobytes()
+    out = [
+        ("empty", b""), ("one", b"x"), ("two", b"ab"), ("zeros", bytes(65280)), ("ones-short", b"\x01" * 700),
+        ("pattern3", (b"abc" * 30000)[:65280]), ("pattern7", (b"0123456" * 9400)[:65280]),
+        ("random", rng.integers(0, 256, 60000, dtype=np.uint8).tobytes()), ("random-small", rng.integers(0, 256, 517, dtype=np.uint8).tobytes()),
+        ("text", text[:65280]), ("skewed", skew),   # skewed: a few short codes, 248 long ones (beyond the primary table)
+        ("nibbles", (rng.integers(0, 4, 65280, dtype=np.uint8) * 17).tobytes()),
+        ("runs", np.repeat(rng.integers(0, 256, 400, dtype=np.uint8), rng.integers(1, 400, 400))[:65000].tobytes()),
+    ]
+    return out
+
+
+def test_inflate_matches_zlib_on_synthetic_members():
+    from breakdancer_amd import bamdec
+    rng = np.random.default_rng(5)
+    blobs, want, labels = [], [], []
+    for label, data in payloads(rng):
+        for level in (0, 1, 6, 9):
+            for strategy, mem in ((zlib.Z_DEFAULT_STRATEGY, 8), (zlib.Z_FIXED, 8), (zlib.Z_HUFFMAN_ONLY, 8), (zlib.Z_RLE, 8), (zlib.Z_FILTERED, 1),
+                                  (zlib.Z_DEFAULT_STRATEGY, 1)):
+                blobs.append(member(data, level, strategy, mem))
+                want.append(data)
+                labels.append("%s/l%d/s%d/m%d" % (label, level, strategy, mem))
+    image = b"".join(blobs)
+    members = bamdec.scan_bgzf(image)
+    assert len(members) == len(blobs)
+    out, status, ms = bamdec.inflate_blocks(image, members)
+    bad = [labels[i] for i in range(len(blobs)) if status[i] != 0]
+    assert not bad, "rejected: %s" % bad[:10]
+    o = 0
+    for i, w in enumerate(want):
+        got = out[o:o + len(w)].tobytes()
+        assert got == w, "member %d (%s) differs at byte %d" % (i, labels[i], next(k for k in range(len(w)) if got[k] != w[k]))
+        o += len(w)
+    assert o == len(out)
+
+
+def test_inflate_matches_zlib_on_the_reference_bams():
+    from breakdancer_amd import bamdec
+    for name in BAMS:
+        image = open(os.path.join(CHR21, name), "rb").read()
+        members = bamdec.scan_bgzf(image)
+        out, status, ms = bamdec.inflate_blocks(image, members)
+        assert not status.any()
+        want = b"".join(zlib.decompress(image[int(m["payload"]):int(m["payload"]) + int(m["payload_len"])], -15) for m in members)
+        assert out.tobytes() == want
+
+
+def test_inflate_verdict_on_corrupted_members_agrees_with_zlib():
+    """a member is accepted only if zlib accepts it with the same bytes; what zlib rejects is rejected"""
+    from breakdancer_amd import bamdec
+    rng = np.random.default_rng(9)
+    base = []
+    for label, data in payloads(rng)[3:]:
+        base.append((member(data, 6), data))
+        base.append((member(data, 1, zlib.Z_FIXED), data))
+    blobs, verdicts = [], []
+    for blob, data in base:
+        for _ in range(6):
+            b = bytearray(blob)
+            k = int(rng.integers(18, len(b) - 8))
+            b[k] ^= 1 << int(rng.integers(0, 8))
+            payload = bytes(b[18:len(b) - 8])
+            d = zlib.decompressobj(-15)
+            try:
+                got = d.decompress(payload, len(data) + 1)
+                ok = d.eof and len(got) == len(data)
+            except zlib.error:
+                got, ok = b"", False
+            blobs.append(bytes(b))
+            verdicts.append((ok, got))
+    image = b"".join(blobs)
+    members = bamdec.scan_bgzf(image)
+    out, status, ms = bamdec.inflate_blocks(image, members)
+    o = 0
+    stricter = 0
+    for i, (ok, got) in enumerate(verdicts):
+        n = int(members["inflated_len"][i])
+        if status[i] == 0:
+            assert ok, "member %d accepted by the GPU, rejected by zlib" % i
+            assert out[o:o + n].tobytes() == got
+        elif ok:
+            stricter += 1
+        o += n
+    assert stricter <= len(verdicts) // 20   # (zlib tolerates garbage behind the final block; so does the kernel -- nearly always the same verdict)
+
+
+# ---- records ----
+def hash_name(b):
+    M = (1 << 64) - 1
+    n = len(b)
+    h = 0x9E3779B97F4A7C15 ^ n
+    i = 0
+    while i + 8 <= n:
+        w = int.from_bytes(b[i:i + 8], "little")
+        h = ((h ^ w) * 0xff51afd7ed558ccd) & M
+        h ^= h >> 32
+        i += 8
+    w = int.from_bytes(b[i:], "little") if i < n else 0
+    h = ((h ^ w) * 0xc4ceb9fe1a85ec53) & M
+    h ^= h >> 29
+    h = (h * 0xbf58476d1ce4e5b9) & M
+    h ^= h >> 32
+    return h
+
+
+def config_read_groups(path):
+    """read group -> library index (libraries in sorted name order, io/BamConfig.cpp:97-101) of a bam2cfg configuration"""
+    rows = []
+    for line in open(path):
+        f = dict(x.split(":", 1) for x in line.rstrip("\n").split("\t") if ":" in x)
+        rows.append((f["readgroup"], f["lib"], f["map"]))
+    libs = sorted({r[1] for r in rows})
+    return rows, libs
+
+
+def check_columns(cols, recs, rg_to_lib, fallback, region=None):
+    keep = np.ones(len(recs["tid"]), bool)
+    if region is not None:
+        tid, beg, end = region
+        keep = (recs["tid"] == tid) & (recs["rend"].astype(np.int64) > beg) & (recs["pos"].astype(np.int64) < end)
+    idx = np.nonzero(keep)[0]
+    assert len(cols["tid"]) == len(idx)
+    for k in ("tid", "pos", "mtid", "mpos", "isize", "flag"):
+        np.testing.assert_array_equal(cols[k].astype(np.int64), recs[k][idx].astype(np.int64), err_msg=k)
+    np.testing.assert_array_equal(cols["qlen"].astype(np.int64), np.minimum(recs["qlen"][idx].astype(np.int64), 65535))
+    np.testing.assert_array_equal(cols["mapq"], recs["bdqual"][idx])
+    want_lib = np.array([rg_to_lib.get(recs["rg"][i], fallback) for i in idx], dtype=np.uint8)
+    np.testing.assert_array_equal(cols["lib"], want_lib)
+    want_key = np.array([hash_name(recs["name"][i].encode()) for i in idx], dtype=np.uint64)
+    np.testing.assert_array_equal(cols["name_key"], want_key)
+
+
+@pytest.mark.parametrize("piece_blocks,ring", [(512, 0), (1, 1 << 20), (3, 1 << 20), (2, 0)])
+def test_reference_bams_columns(piece_blocks, ring):
+    from breakdancer_amd import bamdec
+    rows, libs = config_read_groups(os.path.join(CHR21, "inv_del_bam_config"))
+    rg_ids = [r[0] for r in rows]
+    rg_lib = [libs.index(r[1]) for r in rows]
+    rg_to_lib = dict(zip(rg_ids, rg_lib))
+    for bi, name in enumerate(BAMS):
+        path = os.path.join(CHR21, name)
+        targets, recs = read_bam(path)
+        cols, names, stats = bamdec.decode_file(path, rg_ids=rg_ids, rg_lib=rg_lib, fallback_lib=1, bam_index=bi, piece_blocks=piece_blocks, ring_bytes=ring)
+        assert names == targets
+        check_columns(cols, recs, rg_to_lib, 1)
+        assert (cols["bam"] == bi).all()
+        # -o 21 style region filter (bam_index.c:571-576 overlap rule)
+        t21 = targets.index("21")
+        cols, _, _ = bamdec.decode_file(path, rg_ids=rg_ids, rg_lib=rg_lib, fallback_lib=1, region=(t21, 14_500_000, 14_600_000), piece_blocks=piece_blocks, ring_bytes=ring)
+        check_columns(cols, recs, rg_to_lib, 1, region=(t21, 14_500_000, 14_600_000))
+
+
+def synthetic_records(n, rng, tids=3):
+    recs = []
+    pos = 0
+    for i in range(n):
+        pos += int(rng.integers(0, 40))
+        L = int(rng.choice([0, 1, 36, 100, 101, 250]))
+        r = dict(tid=int(rng.integers(0, tids)) if rng.random() < 0.97 else -1, pos=pos, mtid=int(rng.integers(-1, tids)), mpos=int(rng.integers(0, 1 << 20)),
+                 isize=int(rng.integers(-2000, 2000)), flag=int(rng.integers(0, 1 << 12)), qlen=L, mapq=int(rng.integers(0, 61)),
+                 name="r%d_%s" % (i, "x" * int(rng.integers(0, 40))), rg=str(rng.choice(["a", "bb", "unknown", ""])),
+                 am=(int(rng.integers(0, 300)) if rng.random() < 0.3 else None))
+        recs.append(r)
+    recs.sort(key=lambda r: (r["tid"] if r["tid"] >= 0 else 1 << 30, r["pos"]))
+    return recs
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_synthetic_records_with_odd_shapes(seed, tmp_path):
+    """records of many sizes (no sequence, aux tags of several types, unknown and missing read groups, unplaced reads,
+    secondary / supplementary alignments) cut at arbitrary places by the members' boundaries"""
+    from breakdancer_amd import bamdec
+    from breakdancer_amd.bamwrite import write_bam_records
+    rng = np.random.default_rng(100 + seed)
+    recs = synthetic_records(6000, rng)
+    path = str(tmp_path / "odd.bam")
+    write_bam_records(path, recs, ["c0", "c1", "c2"], rgs=("a", "bb"), level=[1, 6, 0, 9][seed], seed=seed)
+    targets, want = read_bam(path)
+    cols, names, stats = bamdec.decode_file(path, rg_ids=["a", "bb"], rg_lib=[0, 1], fallback_lib=1, piece_blocks=[512, 1, 2, 5][seed],
+                                            ring_bytes=[0, 1 << 20, 1 << 20, 0][seed])
+    assert names == targets
+    check_columns(cols, want, {"a": 0, "bb": 1}, 1)
+
+
+def test_truncated_and_corrupt_files_are_errors(tmp_path):
+    from breakdancer_amd import bamdec
+    from breakdancer_amd.bamwrite import write_bam_records
+    rng = np.random.default_rng(3)
+    recs = synthetic_records(3000, rng)
+    path = str(tmp_path / "t.bam")
+    write_bam_records(path, recs, ["c0", "c1", "c2"], rgs=("a", "bb"), level=1)
+    image = np.fromfile(path, dtype=np.uint8)
+    members = bamdec.scan_bgzf(image)
+    names, lens, k, off = bamdec.bam_header(image, members)
+    data = members[members["inflated_len"] > 0]
+    # the last data member missing: the final record is cut off
+    d = bamdec.BamDecoder(len(names), first_record_offset=off)
+    d.feed(image, data[k:-1], 4)
+    with pytest.raises(RuntimeError, match="truncated|corrupt"):
+        d.finish()
+    d.close()
+    # a flipped bit in a payload: the member does not inflate (or the chain breaks)
+    bad = image.copy()
+    bad[int(data["payload"][k + 2]) + 40] ^= 0x10
+    d = bamdec.BamDecoder(len(names), first_record_offset=off)
+    d.feed(bad, data[k:], 4)
+    with pytest.raises(RuntimeError):
+        d.finish()
+    d.close()
