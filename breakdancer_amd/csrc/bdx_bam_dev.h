@@ -25,7 +25,8 @@ enum : uint32_t {
 };
 
 // in: compressed bytes (at least 16 readable bytes behind the last payload), out: inflated bytes; status[nblk]
-void launch_kz_inflate(const uint8_t* in, const BgzfBlock* blocks, uint32_t nblk, uint8_t* out, uint32_t* status, hipStream_t s);
+void launch_kz_inflate(const uint8_t* in, const BgzfBlock* blocks, uint32_t nblk, uint8_t* out, uint32_t* status, hipStream_t s,
+                       unsigned long long* prof = nullptr);
 
 // ---- records ----
 constexpr uint32_t kRecSlots = 2048;        // record starts a BGZF block can hold at most ((65536 / 36) + 1 < 2048)

@@ -589,10 +589,21 @@ int bdx_inflate_blocks(int device, const void* compressed, size_t bytes, const b
         return done(BDX_EHIP);
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return done(BDX_EHIP);
     (void)hipEventRecord(e0, nullptr);
-    launch_kz_inflate(d_in.as<uint8_t>(), d_tb.as<BgzfBlock>(), (uint32_t)nblocks, d_out.as<uint8_t>(), d_st.as<uint32_t>(), nullptr);
+    // BDX_KZ_PROF=<file>: the kernel's own clocks per member, for tools/bamdec_probe.py
+    DevBuf d_prof;
+    const char* prof_path = getenv("BDX_KZ_PROF");
+    if (prof_path && nblocks && (d_prof.ensure(nblocks * 48) != hipSuccess || hipMemset(d_prof.p, 0, nblocks * 48) != hipSuccess)) prof_path = nullptr;
+    launch_kz_inflate(d_in.as<uint8_t>(), d_tb.as<BgzfBlock>(), (uint32_t)nblocks, d_out.as<uint8_t>(), d_st.as<uint32_t>(), nullptr,
+                      prof_path ? d_prof.as<unsigned long long>() : nullptr);
     (void)hipEventRecord(e1, nullptr);
     if (hipDeviceSynchronize() != hipSuccess) return done(BDX_EHIP);
     if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, e0, e1);
+    if (prof_path && nblocks) {
+        std::vector<unsigned long long> hp(nblocks * 6);
+        if (hipMemcpy(hp.data(), d_prof.p, nblocks * 48, hipMemcpyDeviceToHost) == hipSuccess)
+            if (FILE* f = fopen(prof_path, "wb")) { fwrite(hp.data(), 8, hp.size(), f); fclose(f); }
+    }
+    d_prof.release();
     if ((o && hipMemcpy(out, d_out.p, o, hipMemcpyDeviceToHost) != hipSuccess) ||
         (nblocks && hipMemcpy(status, d_st.p, nblocks * 4, hipMemcpyDeviceToHost) != hipSuccess))
         return done(BDX_EHIP);

@@ -18,8 +18,11 @@
 // Tables are built per deflate block by the wave itself: lengths read with the same canonical decoder (the code-length
 // code has 19 symbols of <= 7 bits), canonical codes by a per-length scan, table filled symbol by symbol across the lanes.
 //
-// Memory: input and output stay in HBM / L2; the wave's own stores must be visible to its later match copies, which a
-// workgroup-scope fence gives (one CU, one L1).  LDS per wave ~7 KB -> about 22 waves per compute unit.
+// Memory: the last 2 KiB of output live in an LDS window; literals and matches up to ~1.7 KiB back never touch HBM, and the
+// window is written out 512 bytes at a time (one 8-byte store per lane).  This matters more than anything else here: with
+// one byte store per step, every step's input load queued behind the previous step's store and waited for its write
+// acknowledgement (loads and stores return in order on this part) -- 1.9 us per step, 24 GB/s in all.  Matches further back
+// read HBM, where those bytes have been for at least one chunk.  LDS per wave ~9 KB -> 17 waves per compute unit.
 #include <hip/hip_runtime.h>
 
 #include "bdx_bam_dev.h"
@@ -70,7 +73,11 @@ struct __attribute__((aligned(16))) Lds {
     uint16_t pre_cnt[16];
     uint16_t codes[320];   // canonical code of every symbol (table build)
     uint8_t lens[320];     // code lengths: literal/length alphabet, then distances
+    uint8_t obuf[2048];    // the last 2 KiB of output (position p at p mod 2048): literals and near matches never touch HBM
 };
+constexpr uint32_t kOB = 2048, kOBM = kOB - 1;
+constexpr uint32_t kFlush = 512;                    // bytes written to HBM at a time (64 lanes x 8 bytes)
+constexpr uint32_t kNearDist = kOB - 258 - 64;      // matches up to this distance are copied inside the window
 
 // 64 bits of the stream starting at bit `bitpos` (>= 57 of them valid)
 __device__ __forceinline__ uint64_t peek(const uint8_t* in, uint32_t bitpos) {
@@ -164,9 +171,29 @@ __device__ bool build_tables(const uint8_t* lens, uint32_t n, uint32_t* table, i
     return true;
 }
 
+// LDS accesses of a wave are executed in program order; this only keeps the compiler from moving them across
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
+
+// 512 bytes of the window, [flushed, flushed + 512), to HBM: lane l takes 8 of them
+__device__ __forceinline__ void flush_chunk(const uint8_t* obuf, uint8_t* out, uint32_t flushed, uint32_t lane) {
+    const uint32_t at = flushed + 8u * lane;
+    uint64_t v;
+    if ((flushed & 7u) == 0) {
+        v = *(const uint64_t*)(obuf + (at & kOBM));
+    } else {
+        v = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v |= (uint64_t)obuf[(at + k) & kOBM] << (8 * k);
+    }
+    __builtin_memcpy(out + at, &v, 8);
+}
+
 __global__ __launch_bounds__(64) void kz_inflate_kernel(const uint8_t* __restrict__ in_all, const BgzfBlock* __restrict__ blocks, uint32_t nblk,
-                                                        uint8_t* out_all, uint32_t* __restrict__ status) {
+                                                        uint8_t* out_all, uint32_t* __restrict__ status, unsigned long long* __restrict__ prof) {
     __shared__ Lds L;
+    // measurement hook (tools/bamdec_probe.py --prof): per member {cycles in all, in headers + tables, steps, matches, slow codes, deflate blocks}
+    unsigned long long t_begin = 0, t_tables = 0, n_steps = 0, n_match = 0, n_slow = 0, n_dblk = 0;
+    if (prof) t_begin = __builtin_readcyclecounter();
     const uint32_t b = blockIdx.x;
     if (b >= nblk) return;
     const uint32_t lane = threadIdx.x;
@@ -176,9 +203,12 @@ __global__ __launch_bounds__(64) void kz_inflate_kernel(const uint8_t* __restric
     const uint32_t clen = blk.in_len, ulen = blk.out_len;
     const uint32_t bit_limit = clen * 8u;
     uint32_t bitpos = 0, outpos = 0, err = KZ_OK;
+    uint32_t flushed = 0;   // output bytes already in HBM; [flushed, outpos) sit in the LDS window only
     bool last = false;
 
     while (!last && err == KZ_OK) {
+        const unsigned long long t_hdr = prof ? __builtin_readcyclecounter() : 0;
+        ++n_dblk;
         if (bitpos + 3 > bit_limit) { err = KZ_INPUT_OVERRUN; break; }
         uint64_t w = peek(in, bitpos);
         // (header fields are the same in all lanes; saying so keeps the loops they bound scalar)
@@ -192,8 +222,13 @@ __global__ __launch_bounds__(64) void kz_inflate_kernel(const uint8_t* __restric
             const uint32_t len = uni(in[at] | ((uint32_t)in[at + 1] << 8)), nlen = uni(in[at + 2] | ((uint32_t)in[at + 3] << 8));
             if ((len ^ 0xFFFFu) != nlen || at + 4 + len > clen) { err = KZ_BAD_STORED; break; }
             if (len > ulen - outpos) { err = KZ_OUTPUT_OVERRUN; break; }
+            lds_order();
+            for (uint32_t i = flushed + lane; i < outpos; i += 64) out[i] = L.obuf[i & kOBM];   // what the window still holds
             for (uint32_t i = lane; i < len; i += 64) out[outpos + i] = in[at + 4 + i];
+            for (uint32_t i = (len > kOB ? len - kOB : 0) + lane; i < len; i += 64) L.obuf[(outpos + i) & kOBM] = in[at + 4 + i];   // the window follows
+            lds_order();
             outpos += len;
+            flushed = outpos;
             bitpos = (at + 4 + len) * 8u;
             continue;
         }
@@ -271,31 +306,46 @@ __global__ __launch_bounds__(64) void kz_inflate_kernel(const uint8_t* __restric
         if (!build_tables<true>(L.lens + hlit, hdist, L.dist, kDB, L.dist_cnt, L.dist_sorted, L.codes, true)) { err = KZ_BAD_LENGTHS; break; }
 
         // ---- the block's symbols ----
+        if (prof) t_tables += __builtin_readcyclecounter() - t_hdr;
+        const uint64_t lane_bit = 1ull << lane;
         for (;;) {
+            ++n_steps;
             if (bitpos > bit_limit) { err = KZ_INPUT_OVERRUN; break; }
             // every lane's candidate symbol
             const uint64_t wl = peek(in, bitpos + lane);
             const uint32_t e = L.lit[(uint32_t)wl & ((1u << kLB) - 1)];
-            // the chain of literals that starts at the cursor
-            uint32_t pos = 0;
+            // Where the chain goes from each lane, two symbols at a time.  nxt: the offset behind a literal (1..78), 128 + lane
+            // for anything else.  t2: where a chain that stands on this lane stands two literals later -- or 64..78: the window
+            // is used up, go on there; >= 128: stopped at lane (t2 - 128), which is no literal.  pm: the literal lanes passed.
+            const bool lit = e_kind(e) == K_LIT;
+            const uint32_t nxt = lit ? lane + e_len(e) : 128u + lane;
+            const uint32_t n2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((nxt & 63u) << 2), (int)nxt);
+            const uint32_t t2 = !lit ? nxt : (nxt >= 64 ? nxt : n2);
+            const bool two = lit && nxt < 64 && n2 < 128;
+            const uint64_t pm = lit ? (lane_bit | (two ? 1ull << nxt : 0ull)) : 0ull;
+            const uint32_t pm_lo = (uint32_t)pm, pm_hi = (uint32_t)(pm >> 32);
+            uint32_t cur = 0, v;
             uint64_t mask = 0;
-            uint32_t stop_e = 0;
-            bool stopped = false;
             for (;;) {
-                const uint32_t ee = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)pos);
-                if (e_kind(ee) != K_LIT) { stop_e = ee; stopped = true; break; }
-                mask |= 1ull << pos;
-                pos += e_len(ee);
-                if (pos >= 64) break;
+                v = (uint32_t)__builtin_amdgcn_readlane((int)t2, (int)cur);
+                mask |= ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)pm_hi, (int)cur) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)pm_lo, (int)cur);
+                if (v >= 64) break;
+                cur = v;
             }
+            const bool stopped = v >= 128;
+            const uint32_t pos = stopped ? v - 128 : v;
+            uint32_t stop_e = 0;
+            if (stopped) stop_e = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)pos);
             const uint32_t nlit = (uint32_t)__builtin_popcountll(mask);
             if (nlit) {
                 if (nlit > ulen - outpos) { err = KZ_OUTPUT_OVERRUN; break; }
                 if ((mask >> lane) & 1) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-                    out[outpos + rank] = (uint8_t)e_value(e);
+                    L.obuf[(outpos + rank) & kOBM] = (uint8_t)e_value(e);
                 }
                 outpos += nlit;
+                lds_order();
+                if (outpos - flushed >= kFlush) { flush_chunk(L.obuf, out, flushed, lane); flushed += kFlush; }
             }
             bitpos += pos;
             if (!stopped) continue;
@@ -304,6 +354,7 @@ __global__ __launch_bounds__(64) void kz_inflate_kernel(const uint8_t* __restric
                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wl, (int)pos);
             uint32_t se = stop_e;
             if (e_kind(se) == K_SLOW) {  // a code longer than the table's index
+                ++n_slow;
                 uint32_t sym = 0;
                 const uint32_t l = uni(canon_decode(ws, L.lit_cnt, L.lit_sorted, &sym));
                 if (l == 0) { err = KZ_BAD_CODE; break; }
@@ -314,13 +365,15 @@ __global__ __launch_bounds__(64) void kz_inflate_kernel(const uint8_t* __restric
             ws >>= used;
             if (kind == K_LIT) {
                 if (outpos >= ulen) { err = KZ_OUTPUT_OVERRUN; break; }
-                if (lane == 0) out[outpos] = (uint8_t)e_value(se);
+                if (lane == 0) L.obuf[outpos & kOBM] = (uint8_t)e_value(se);
                 ++outpos;
+                lds_order();
                 bitpos += used;
                 continue;
             }
             if (kind == K_EOB) { bitpos += used; break; }
             if (kind != K_LEN) { err = KZ_BAD_CODE; break; }
+            ++n_match;
             const uint32_t lx = e_extra(se);
             const uint32_t length = e_value(se) + ((uint32_t)ws & ((1u << lx) - 1));
             ws >>= lx;
@@ -341,29 +394,41 @@ __global__ __launch_bounds__(64) void kz_inflate_kernel(const uint8_t* __restric
             bitpos += used;
             if (dist > outpos) { err = KZ_BAD_DISTANCE; break; }
             if (length > ulen - outpos) { err = KZ_OUTPUT_OVERRUN; break; }
-            // the wave's own earlier stores are the source
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const uint8_t* src = out + outpos - dist;
-            uint8_t* dst = out + outpos;
-            if (dist >= length) {
-                for (uint32_t i = lane; i < length; i += 64) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            } else {  // overlapping: the pattern of `dist` bytes repeats
-                for (uint32_t i = lane; i < length; i += 64) dst[i] = __hip_atomic_load(src + (i % dist), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (dist <= kNearDist) {   // inside the window (sources lie below outpos, destinations at or above it: no overlap)
+                lds_order();
+                if (dist >= length) {
+                    for (uint32_t i = lane; i < length; i += 64) L.obuf[(outpos + i) & kOBM] = L.obuf[(outpos - dist + i) & kOBM];
+                } else {  // overlapping: the pattern of `dist` bytes repeats
+                    for (uint32_t i = lane; i < length; i += 64) L.obuf[(outpos + i) & kOBM] = L.obuf[(outpos - dist + i % dist) & kOBM];
+                }
+                lds_order();
+            } else {   // far back: those bytes left the window, but they were flushed at least one chunk ago
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const uint8_t* src = out + outpos - dist;
+                for (uint32_t i = lane; i < length; i += 64)
+                    L.obuf[(outpos + i) & kOBM] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lds_order();
             }
             outpos += length;
+            if (outpos - flushed >= kFlush) { flush_chunk(L.obuf, out, flushed, lane); flushed += kFlush; }
         }
     }
+    lds_order();
+    for (uint32_t i = flushed + lane; i < outpos; i += 64) out[i] = L.obuf[i & kOBM];   // the rest of the window
     if (err == KZ_OK && outpos != ulen) err = KZ_SIZE_MISMATCH;
     if (err == KZ_OK && ((bitpos + 7) >> 3) > clen) err = KZ_INPUT_OVERRUN;
     if (lane == 0) status[b] = err;
+    if (prof && lane == 0) {
+        unsigned long long* q = prof + (size_t)b * 6;
+        q[0] = __builtin_readcyclecounter() - t_begin; q[1] = t_tables; q[2] = n_steps; q[3] = n_match; q[4] = n_slow; q[5] = n_dblk;
+    }
 }
 
 }  // namespace
 
-void launch_kz_inflate(const uint8_t* in, const BgzfBlock* blocks, uint32_t nblk, uint8_t* out, uint32_t* status, hipStream_t s) {
+void launch_kz_inflate(const uint8_t* in, const BgzfBlock* blocks, uint32_t nblk, uint8_t* out, uint32_t* status, hipStream_t s, unsigned long long* prof) {
     if (!nblk) return;
-    hipLaunchKernelGGL(kz_inflate_kernel, dim3(nblk), dim3(64), 0, s, in, blocks, nblk, out, status);
+    hipLaunchKernelGGL(kz_inflate_kernel, dim3(nblk), dim3(64), 0, s, in, blocks, nblk, out, status, prof);
 }
 
 }  // namespace bdx

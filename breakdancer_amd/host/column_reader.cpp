@@ -176,6 +176,15 @@ void ColumnReader::read_header() {
     }
 }
 
+void ColumnReader::locate(const RecordFilter& f, size_t* member_offset, uint64_t* record_offset, bool* seeked) {
+    if (started_) throw std::logic_error("ColumnReader::locate after start");
+    bool used_index = false;
+    if (f.only_tid >= 0 && !getenv("BDX_BAM_NO_INDEX")) used_index = seek_with_index(f.only_tid, f.beg);
+    *member_offset = first_block_coff_;
+    *record_offset = first_rec_abs_;
+    *seeked = used_index;
+}
+
 void ColumnReader::start(const RecordFilter& f) {
     if (started_) throw std::logic_error("ColumnReader::start called twice");
     started_ = true;

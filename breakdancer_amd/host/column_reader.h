@@ -66,6 +66,12 @@ public:
     int tid_of(const std::string& name) const;
     // start decoding; must be called once, before next()
     void start(const RecordFilter& f);
+    // Where decoding would start for this filter, without starting it (the device-side decoder's feeder, producer.cpp): file
+    // offset of the BGZF member that holds the first record to look at, the record's offset in that member's inflated bytes,
+    // and whether the BAM index was used to get there (then the records behind the region may be left unread).
+    void locate(const RecordFilter& f, size_t* member_offset, uint64_t* record_offset, bool* seeked);
+    const uint8_t* mapped() const { return map_; }
+    size_t mapped_size() const { return map_size_; }
     // the next piece's columns in file order, or nullptr at the end of the file; valid until the following call
     const ColumnChunk* next();
 

@@ -221,6 +221,7 @@ int main(int argc, char** argv) {
         }
         reserve = std::min<size_t>(reserve, 0xFFFFFFFFull - 1024);
         size_t n_reads = 0;
+        bool device_decoded = false;
         auto t_decoded = now();
         if (sharded) {
             if (want_dumps) throw std::runtime_error("-g / -d need the supporting reads of every SV: run on one GPU (unset BDX_GPUS)");
@@ -251,8 +252,23 @@ int main(int argc, char** argv) {
         } else {
             GpuSink sink(ctx_ready, ctx, reserve);
             try {
-                n_reads = produce_stream(cfg, opts.chr, (int)io_threads, &targets, sink);
-                sink.bring_up();  // (an input without records never asked for a batch)
+                // One BAM: the file goes to the GPU as it is and is decoded there (bdx_bamdec_*: inflate, record boundaries, fields,
+                // RG -> library, reader filter in HBM).  Several BAMs are merged in the reference's order by the host producer, which
+                // also takes the files the device path does not (BDX_DECODE=host forces it).
+                const char* dm = getenv("BDX_DECODE");
+                bool decoded = false;
+                if (cfg.num_bams() == 1 && !(dm && !strcmp(dm, "host"))) {
+                    sink.bring_up();
+                    bool unsupported = false;
+                    n_reads = produce_on_device(cfg, opts.chr, (int)std::min(std::max(usable_cpus(), 2u), 16u), &targets, ctx, &unsupported);
+                    if (unsupported) check(ctx, bdx_reset_reads(ctx), "bdx_reset_reads");
+                    else decoded = true;
+                    device_decoded = decoded;
+                }
+                if (!decoded) {
+                    n_reads = produce_stream(cfg, opts.chr, (int)io_threads, &targets, sink);
+                    sink.bring_up();  // (an input without records never asked for a batch)
+                }
             } catch (...) {
                 if (ctx_ready.valid()) ctx_ready.wait();
                 throw;
@@ -410,9 +426,10 @@ int main(int argc, char** argv) {
         if (timing) {
             float ms[8] = {0};
             bdx_get_timings(ctx, ms, 8);
-            fprintf(stderr, "[bdx timing] reads=%zu decode+merge+stream=%.3fs (%u decode threads, single pass, batches copied and classified "
+            fprintf(stderr, "[bdx timing] reads=%zu decode+merge+stream=%.3fs (%s, single pass, records classified "
                             "as they are produced) bdx_run=%.4fs format=%.3fs total=%.3fs\n",
-                    n_reads, secs(t_start, t_decoded), io_threads, secs(t_decoded, t_ran), secs(t_ran, now()), secs(t_start, now()));
+                    n_reads, secs(t_start, t_decoded), device_decoded ? "BGZF inflate and record decode on the GPU" : "host decode threads",
+                    secs(t_decoded, t_ran), secs(t_ran, now()), secs(t_start, now()));
             fprintf(stderr, "[bdx timing] inside bdx_run (ms): classify kernel %.3f, host waits for its share of the groups %.3f, host walk %.3f, "
                             "final wait + scores %.3f, whole call %.3f\n", ms[0], ms[4], ms[5], ms[6], ms[7]);
         }

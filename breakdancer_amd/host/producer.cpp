@@ -5,8 +5,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <memory>
+#include <thread>
 #include <queue>
 #include <stdexcept>
 #include <unordered_map>
@@ -320,6 +323,148 @@ size_t produce_stream(const BamConfig& cfg, const std::string& chr, int threads,
     }
     w.finish();
     return w.total();
+}
+
+
+// ---- device-side decode of a one-BAM configuration ----
+namespace {
+
+inline uint32_t dle32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline uint32_t dle16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+
+// bytes [off, off + n) of the file into dst, by `threads` threads (page cache -> pinned memory is a plain copy: one core
+// moves 5-8 GB/s, the GPU side wants several times that)
+void read_range(int fd, size_t off, uint8_t* dst, size_t n, int threads, std::string* err) {
+    const size_t slice = std::max<size_t>((n + (size_t)threads - 1) / (size_t)threads, (size_t)1 << 20);
+    std::vector<std::thread> th;
+    std::vector<std::string> errs((n + slice - 1) / slice);
+    size_t k = 0;
+    for (size_t o = 0; o < n; o += slice, ++k) {
+        const size_t m = std::min(slice, n - o);
+        auto job = [fd, off, dst, o, m, &errs, k] {
+            size_t done = 0;
+            while (done < m) {
+                const ssize_t r = pread(fd, dst + o + done, m - done, (off_t)(off + o + done));
+                if (r <= 0) { errs[k] = "read error"; return; }
+                done += (size_t)r;
+            }
+        };
+        if (o + slice < n) th.emplace_back(job); else job();
+    }
+    for (auto& t : th) t.join();
+    for (auto& e : errs)
+        if (!e.empty()) *err = e;
+}
+
+}  // namespace
+
+size_t produce_on_device(const BamConfig& cfg, const std::string& chr, int threads, std::vector<std::string>* targets, bdx_ctx* ctx,
+                         bool* unsupported) {
+    if (unsupported) *unsupported = false;
+    if (cfg.num_bams() != 1) throw std::logic_error("produce_on_device: one BAM only");
+    const std::string& path = cfg.bam_files()[0];
+    ColumnReader hdr(path, 1, nullptr);   // (the header: reference names, where the first record lies; the index for -o)
+    RecordFilter f;
+    if (!chr.empty() && !parse_region(hdr, chr, f.only_tid, f.beg, f.end))
+        throw std::runtime_error("Failed to parse bam region '" + chr + "' in file " + path + ". ");
+    if (targets) *targets = hdr.target_names();
+    size_t member_off = 0;
+    uint64_t rec_off = 0;
+    bool seeked = false;
+    hdr.locate(f, &member_off, &rec_off, &seeked);
+    const size_t file_size = hdr.mapped_size();
+
+    std::vector<std::string> ids;
+    std::vector<uint8_t> libs;
+    for (auto const& kv : cfg.readgroup_index()) { ids.push_back(kv.first); libs.push_back((uint8_t)kv.second); }
+    std::vector<const char*> idp;
+    for (auto const& s : ids) idp.push_back(s.c_str());
+    bdx_bamdec_params p{};
+    p.device = 0;
+    p.n_targets = (int32_t)hdr.target_names().size();
+    p.bam_index = 0;
+    p.only_tid = f.only_tid; p.region_beg = f.beg; p.region_end = f.end;
+    p.n_read_groups = (uint32_t)ids.size();
+    p.rg_ids = idp.empty() ? nullptr : idp.data();
+    p.rg_lib = libs.empty() ? nullptr : libs.data();
+    p.fallback_lib = (uint8_t)cfg.fallback_library();
+    p.first_record_offset = rec_off;
+    const size_t kPiece = getenv("BDX_BAM_PIECE_BYTES") ? (size_t)std::max(1ll, atoll(getenv("BDX_BAM_PIECE_BYTES"))) : ((size_t)32 << 20);
+    p.ring_bytes = std::max<size_t>((size_t)1 << 30, kPiece * 12);
+    if (const char* rb = getenv("BDX_BAM_RING_BYTES")) p.ring_bytes = (size_t)std::max(1ll, atoll(rb));
+    bdx_bamdec* dec = nullptr;
+    int rc = bdx_bamdec_create(&dec, ctx, &p);
+    if (rc != BDX_OK) throw std::runtime_error(std::string("bdx_bamdec_create: ") + bdx_strerror(rc));
+    struct Guard { bdx_bamdec* d; ~Guard() { bdx_bamdec_destroy(d); } } guard{dec};
+    auto check = [&](int r, const char* what) {
+        if (r != BDX_OK) throw std::runtime_error(std::string(what) + ": " + bdx_strerror(r) + " (" + bdx_bamdec_last_error(dec) + ") in " + path);
+    };
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("Failed to open samfile " + path);
+    struct Fd { int fd; ~Fd() { close(fd); } } fdg{fd};
+
+    // pieces of about kPiece bytes, cut at member boundaries: the bytes behind the last whole member of a piece open the next
+    size_t off = member_off;
+    std::vector<uint8_t> carry;
+    const size_t max_blocks = kPiece / 28 + 4096;   // (an empty member has 28 bytes)
+    bool stop = false;
+    while (!stop) {
+        const size_t want = std::min(kPiece, file_size - off);
+        void* buf = nullptr;
+        bdx_bgzf_block* tab = nullptr;
+        check(bdx_bamdec_acquire(dec, carry.size() + want + 65536, max_blocks, &buf, &tab), "bdx_bamdec_acquire");
+        uint8_t* b = (uint8_t*)buf;
+        if (!carry.empty()) memcpy(b, carry.data(), carry.size());
+        std::string rerr;
+        if (want) read_range(fd, off, b + carry.size(), want, threads, &rerr);
+        if (!rerr.empty()) throw std::runtime_error("cannot read " + path);
+        const size_t have = carry.size() + want;
+        off += want;
+        const bool at_eof = off >= file_size;
+        // the members
+        size_t q = 0, nb = 0;
+        while (q + 18 <= have) {
+            const uint8_t* h = b + q;
+            if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) throw std::runtime_error("not a BGZF file: " + path);
+            const size_t xlen = dle16(h + 10);
+            if (q + 12 + xlen > have) break;
+            int bsize = -1;
+            for (size_t x = 12; x + 4 <= 12 + xlen;) {
+                const size_t slen = dle16(h + x + 2);
+                if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2) bsize = (int)dle16(h + x + 4);
+                x += 4 + slen;
+            }
+            if (bsize < 0) throw std::runtime_error("BGZF block without BC field: " + path);
+            const size_t total = (size_t)bsize + 1;
+            if (total < 12 + xlen + 8) throw std::runtime_error("truncated BGZF file: " + path);
+            if (q + total > have) break;
+            const uint32_t ulen = dle32(h + total - 4);
+            if (ulen > 65536) throw std::runtime_error("BGZF block larger than 64 KiB: " + path);
+            if (ulen) {   // (members that inflate to nothing -- the EOF marker, flush blocks -- are skipped)
+                if (nb >= max_blocks) break;
+                tab[nb].offset = q + 12 + xlen;
+                tab[nb].payload_len = (uint32_t)(total - 12 - xlen - 8);
+                tab[nb].inflated_len = ulen;
+                ++nb;
+            }
+            q += total;
+        }
+        if (at_eof && q != have) throw std::runtime_error("truncated BGZF file: " + path);
+        carry.assign(b + q, b + have);
+        if (q == 0 && !at_eof && want) throw std::runtime_error("BGZF member larger than a piece: " + path);
+        check(bdx_bamdec_submit(dec, q, nb, at_eof ? 1 : 0), "bdx_bamdec_submit");
+        if (at_eof) break;
+        if (seeked) {   // a region read through the index: nothing of it lies behind the first record past it
+            int past = 0;
+            check(bdx_bamdec_progress(dec, nullptr, nullptr, &past, nullptr), "bdx_bamdec_progress");
+            if (past) stop = true;
+        }
+    }
+    uint64_t n = 0;
+    rc = bdx_bamdec_finish(dec, &n);
+    if (rc == BDX_ELIMIT && unsupported) { *unsupported = true; return 0; }
+    check(rc, "bdx_bamdec_finish");
+    return (size_t)n;
 }
 
 void read_targets(const BamConfig& cfg, std::vector<std::string>& names, std::vector<uint32_t>& lengths) {

@@ -50,6 +50,13 @@ struct BatchSink {
 // order (io/BamMerger.cpp:40-126).  Returns the number of records; targets receives the first file's sequence names.
 size_t produce_stream(const BamConfig& cfg, const std::string& chr, int threads, std::vector<std::string>* targets, BatchSink& sink,
                       size_t batch_records = 1u << 20);
+// The same stream for a configuration of ONE BAM, decoded on the GPU (bdx_bamdec_*, include/bdx.h): this side reads the file into
+// the decoder's pinned staging buffers (several threads), finds the BGZF members and submits them; inflate, record boundaries,
+// fields, RG -> library and the reader filter run in HBM, and the records land in ctx's resident store with the classifier
+// behind them.  Returns the number of records appended.  Throws std::runtime_error; `unsupported` (may be null) is set instead
+// when the file is one the device path leaves to the host reader (a record of more than 4 MiB), with nothing appended.
+size_t produce_on_device(const BamConfig& cfg, const std::string& chr, int threads, std::vector<std::string>* targets, bdx_ctx* ctx,
+                         bool* unsupported);
 // reference sequences of the first BAM of the configuration (names and lengths from its header; io/BamMerger.cpp:78)
 void read_targets(const BamConfig& cfg, std::vector<std::string>& names, std::vector<uint32_t>& lengths);
 void produce(const BamConfig& cfg, const std::string& chr, int threads, ReadStream& out);

@@ -54,3 +54,35 @@ def test_cli_on_fuzz_bams_equals_oracle(seed, tmp_path):
             p = subprocess.run([EXE, "-y", "-1"] + args + ["cfg"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
             assert p.returncode == 0, p.stderr.decode()
             assert filter_cmd_lines(p.stdout.decode()) == filter_cmd_lines(run.text), ("sharded", args, p.stderr.decode())
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_cli_one_bam_decoded_on_the_gpu_equals_oracle(seed, tmp_path):
+    """a configuration of ONE BAM takes the device path (bdx_bamdec_*: BGZF inflate, record boundaries, fields, RG -> library and
+    reader filter on the GPU); same text as the oracle's rendering and as the host reader's (BDX_DECODE=host), also with pieces of a
+    few members and a ring that wraps, and the -g / -d dumps agree between the two readers"""
+    rng = np.random.default_rng(900 + seed)
+    cfg, streams, targets = make_case(700 + seed, n_pairs=int(rng.integers(800, 4000)))
+    cfg1 = "".join(l + "\n" for l in cfg.splitlines() if "map:a.bam" in l)
+    write_case(str(tmp_path), streams[:1], targets, rng)
+    (tmp_path / "cfg").write_text(cfg1)
+    for args, kw in (FLAGSETS[seed % len(FLAGSETS)], FLAGSETS[(3 * seed + 2) % len(FLAGSETS)]):
+        run = oracle_case(cfg1, streams[:1], targets, make_opts(score_threshold=-1, **kw))
+        texts = {}
+        for label, env in (("device", dict(BDX_TIMING="1")), ("device-small-pieces", dict(BDX_TIMING="1", BDX_BAM_PIECE_BYTES="100000", BDX_BAM_RING_BYTES="1048576")),
+                           ("host", dict(BDX_TIMING="1", BDX_DECODE="host"))):
+            p = subprocess.run([EXE, "-y", "-1"] + args + ["cfg"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+            assert p.returncode == 0, (label, p.stderr.decode())
+            assert ("on the GPU" in p.stderr.decode()) == label.startswith("device"), p.stderr.decode()
+            texts[label] = filter_cmd_lines(p.stdout.decode())
+            assert texts[label] == filter_cmd_lines(run.text), (label, args, p.stderr.decode())
+    # supporting reads of the SVs (BED and FASTQ dumps): the stream indices the dumps are fetched by are the same
+    outs = {}
+    for label, env in (("device", dict()), ("host", dict(BDX_DECODE="host"))):
+        d = tmp_path / label
+        d.mkdir()
+        p = subprocess.run([EXE, "-y", "-1", "-g", str(d / "out.bed"), "-d", str(d / "fq"), "cfg"], cwd=str(tmp_path), stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr.decode()
+        outs[label] = {f: open(os.path.join(str(d), f), "rb").read() for f in sorted(os.listdir(str(d)))}
+    assert outs["device"] == outs["host"] and outs["device"]

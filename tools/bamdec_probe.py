@@ -1,0 +1,75 @@
+"""Throughput probe of the device-side BAM decode on configs[1]-shaped data (tools, not the product):
+  * the inflate kernel alone (bdx_inflate_blocks: members already in HBM, kernel time by HIP events),
+  * the whole decode of a file into columns (read + pinned copy + H2D + inflate + record kernels), Python feeder.
+usage: python tools/bamdec_probe.py [--mbp 10] [--level 1] [--piece-blocks 512]"""
+import argparse
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mbp", type=float, default=10.0)
+    ap.add_argument("--level", type=int, default=1)
+    ap.add_argument("--piece-blocks", type=int, default=512)
+    ap.add_argument("--bam", default=None, help="decode this file instead of a synthetic one")
+    a = ap.parse_args()
+    from breakdancer_amd import bamdec
+    from breakdancer_amd.bamwrite import write_bam
+    from breakdancer_amd.synth import make_chromosome
+    with tempfile.TemporaryDirectory(prefix="bdx_probe_") as td:
+        if a.bam:
+            bam = a.bam
+        else:
+            d = make_chromosome(length=int(a.mbp * 1e6), seed=1)
+            bam = os.path.join(td, "syn.bam")
+            write_bam(bam, d, ["chrS"], seed=3, level=a.level)
+        image = np.fromfile(bam, dtype=np.uint8)
+        members = bamdec.scan_bgzf(image)
+        data = members[members["inflated_len"] > 0]
+        ulen = int(data["inflated_len"].astype(np.int64).sum())
+        print("file %.1f MB, %d members, %.1f MB inflated (ratio %.2f)" % (image.size / 1e6, len(data), ulen / 1e6, ulen / image.size))
+        # kernel alone, in slices of <= 1.5 GB of output
+        tot_ms, done = 0.0, 0
+        i = 0
+        while i < len(data):
+            j = i
+            acc = 0
+            while j < len(data) and acc < 1_500_000_000:
+                acc += int(data["inflated_len"][j])
+                j += 1
+            lo = int(data["member"][i])
+            hi = int(data["payload"][j - 1]) + int(data["payload_len"][j - 1]) + 8
+            sl = data[i:j].copy()
+            sl["payload"] -= np.uint64(lo)
+            sl["member"] -= np.uint64(lo)
+            for rep in range(2):
+                out, status, ms = bamdec.inflate_blocks(image[lo:hi], sl)
+            assert not status.any()
+            pf = os.environ.get("BDX_KZ_PROF")
+            if pf and os.path.exists(pf):
+                q = np.fromfile(pf, dtype=np.uint64).reshape(-1, 6).astype(np.float64)
+                print("kernel clocks per member (mean): cycles %.0f, of which headers+tables %.0f; steps %.0f, matches %.0f, slow codes %.0f, deflate blocks %.1f; "
+                      "cycles per step %.0f" % (q[:, 0].mean(), q[:, 1].mean(), q[:, 2].mean(), q[:, 3].mean(), q[:, 4].mean(), q[:, 5].mean(),
+                                                 (q[:, 0] - q[:, 1]).sum() / q[:, 2].sum()))
+            tot_ms += ms
+            done += acc
+            i = j
+        print("inflate kernel: %.2f ms for %.1f MB -> %.1f GB/s inflated, %.1f GB/s compressed" %
+              (tot_ms, done / 1e6, done / tot_ms / 1e6, image.size / tot_ms / 1e6))
+        for rep in range(3):
+            t0 = time.perf_counter()
+            cols, names, stats = bamdec.decode_file(bam, rg_ids=["rg1"], rg_lib=[0], piece_blocks=a.piece_blocks)
+            dt = time.perf_counter() - t0
+            print("decode_file: %.3f s, %d records, %.2f GB/s of file, %s" % (dt, len(cols["tid"]), image.size / dt / 1e9, stats))
+
+
+if __name__ == "__main__":
+    main()
