@@ -439,11 +439,10 @@ int bdx_bamdec_submit(bdx_bamdec* d, size_t bytes, size_t nblocks, int last) {
         }
         BHIP(d, hipStreamWaitEvent(d->s_inf, q.ev_records, 0));
     }
-    BHIP(d, sl.d_comp.ensure(bytes + 64));
+    BHIP(d, sl.d_comp.ensure(bytes + 2048));   // (the inflate kernel's input ring loads up to ~1.1 KiB behind a payload's end)
     BHIP(d, sl.d_blocks.ensure(std::max<size_t>(nblocks, 1) * sizeof(BgzfBlock)));
     BHIP(d, sl.d_status.ensure(std::max<size_t>(nblocks, 1) * 4));
-    memset((char*)sl.h_comp.p + bytes, 0, 64);
-    BHIP(d, hipMemcpyAsync(sl.d_comp.p, sl.h_comp.p, bytes + 64, hipMemcpyHostToDevice, d->s_copy));
+    if (bytes) BHIP(d, hipMemcpyAsync(sl.d_comp.p, sl.h_comp.p, bytes, hipMemcpyHostToDevice, d->s_copy));
     if (nblocks) BHIP(d, hipMemcpyAsync(sl.d_blocks.p, tb, nblocks * sizeof(BgzfBlock), hipMemcpyHostToDevice, d->s_copy));
     BHIP(d, hipEventRecord(sl.ev_copied, d->s_copy));
     BHIP(d, hipStreamWaitEvent(d->s_inf, sl.ev_copied, 0));
@@ -581,10 +580,10 @@ int bdx_inflate_blocks(int device, const void* compressed, size_t bytes, const b
         if (e1) (void)hipEventDestroy(e1);
         return code;
     };
-    if (d_in.ensure(bytes + 64) != hipSuccess || d_out.ensure(o + 64) != hipSuccess || d_tb.ensure(std::max<size_t>(nblocks, 1) * sizeof(BgzfBlock)) != hipSuccess ||
+    if (d_in.ensure(bytes + 2048) != hipSuccess || d_out.ensure(o + 64) != hipSuccess || d_tb.ensure(std::max<size_t>(nblocks, 1) * sizeof(BgzfBlock)) != hipSuccess ||
         d_st.ensure(std::max<size_t>(nblocks, 1) * 4) != hipSuccess)
         return done(BDX_ENOMEM);
-    if (hipMemset(d_in.p, 0, bytes + 64) != hipSuccess || hipMemcpy(d_in.p, compressed, bytes, hipMemcpyHostToDevice) != hipSuccess ||
+    if (hipMemset(d_in.p, 0, bytes + 2048) != hipSuccess || hipMemcpy(d_in.p, compressed, bytes, hipMemcpyHostToDevice) != hipSuccess ||
         (nblocks && hipMemcpy(d_tb.p, tb.data(), nblocks * sizeof(BgzfBlock), hipMemcpyHostToDevice) != hipSuccess))
         return done(BDX_EHIP);
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return done(BDX_EHIP);

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--level", type=int, default=1)
     ap.add_argument("--piece-blocks", type=int, default=512)
     ap.add_argument("--bam", default=None, help="decode this file instead of a synthetic one")
+    ap.add_argument("--inflate-only", action="store_true")
     a = ap.parse_args()
     from breakdancer_amd import bamdec
     from breakdancer_amd.bamwrite import write_bam
@@ -64,7 +65,7 @@ def main():
             i = j
         print("inflate kernel: %.2f ms for %.1f MB -> %.1f GB/s inflated, %.1f GB/s compressed" %
               (tot_ms, done / 1e6, done / tot_ms / 1e6, image.size / tot_ms / 1e6))
-        for rep in range(3):
+        for rep in range(0 if a.inflate_only else 3):
             t0 = time.perf_counter()
             cols, names, stats = bamdec.decode_file(bam, rg_ids=["rg1"], rg_lib=[0], piece_blocks=a.piece_blocks)
             dt = time.perf_counter() - t0
