@@ -20,7 +20,7 @@ class bdx_bamdec_params(C.Structure):
     _fields_ = [("device", C.c_int32), ("n_targets", C.c_int32), ("bam_index", C.c_int32), ("only_tid", C.c_int32),
                 ("region_beg", C.c_int32), ("region_end", C.c_int32), ("n_read_groups", C.c_uint32),
                 ("rg_ids", C.POINTER(C.c_char_p)), ("rg_lib", C.c_void_p), ("fallback_lib", C.c_uint8),
-                ("first_record_offset", C.c_uint64), ("ring_bytes", C.c_size_t)]
+                ("first_record_offset", C.c_uint64), ("ring_bytes", C.c_size_t), ("batch_bytes", C.c_size_t), ("batch_blocks", C.c_size_t)]
 
 
 BLOCK_DTYPE = np.dtype([("offset", "<u8"), ("payload_len", "<u4"), ("inflated_len", "<u4")])
@@ -137,7 +137,7 @@ class BamDecoder:
     (the columns stay in the decoder; fetch() copies them out)."""
 
     def __init__(self, n_targets, sink=None, device=0, bam_index=0, rg_ids=(), rg_lib=(), fallback_lib=0, region=None,
-                 first_record_offset=0, ring_bytes=0):
+                 first_record_offset=0, ring_bytes=0, batch_bytes=0, batch_blocks=0):
         self.lib = _lib()
         p = bdx_bamdec_params()
         p.device = device
@@ -152,6 +152,8 @@ class BamDecoder:
         p.fallback_lib = fallback_lib
         p.first_record_offset = first_record_offset
         p.ring_bytes = ring_bytes
+        p.batch_bytes = batch_bytes
+        p.batch_blocks = batch_blocks
         h = C.c_void_p()
         rc = self.lib.bdx_bamdec_create(C.byref(h), sink.h if sink is not None else None, C.byref(p))
         if rc != 0:
@@ -232,13 +234,14 @@ class BamDecoder:
             pass
 
 
-def decode_file(path, rg_ids=(), rg_lib=(), fallback_lib=0, bam_index=0, region=None, piece_blocks=512, ring_bytes=0, sink=None, device=0):
+def decode_file(path, rg_ids=(), rg_lib=(), fallback_lib=0, bam_index=0, region=None, piece_blocks=512, ring_bytes=0, sink=None, device=0,
+                batch_blocks=0):
     """whole file -> (columns or None with a sink, target names, decoder statistics)"""
     data = np.fromfile(path, dtype=np.uint8)
     members = scan_bgzf(data)
     names, lens, k, off = bam_header(data, members)
     d = BamDecoder(len(names), sink=sink, device=device, bam_index=bam_index, rg_ids=rg_ids, rg_lib=rg_lib, fallback_lib=fallback_lib,
-                   region=region, first_record_offset=off, ring_bytes=ring_bytes)
+                   region=region, first_record_offset=off, ring_bytes=ring_bytes, batch_blocks=batch_blocks)
     try:
         d.feed(data, members[k:], piece_blocks)
         d.finish()

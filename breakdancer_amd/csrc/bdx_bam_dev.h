@@ -84,9 +84,10 @@ struct PieceState {        // running state of one file's decode, in device memo
 void launch_kb_chain(const uint8_t* u, const BgzfBlock* blocks, uint32_t nblk, uint64_t avail_end, int32_t n_targets, ChainBlock* cb,
                      uint16_t* offs, hipStream_t s);
 // checks the guesses against the chain of true boundaries (walking blocks again where they disagree), numbers the records:
-// rec_base[nblk + 1]
+// rec_base[nblk + 1].  rebase_from / rebase_to: the carried boundary st->next_start is taken as next_start - rebase_from + rebase_to
+// (a piece that starts at the ring's front while its predecessor ended at rebase_from)
 void launch_kb_stitch(const uint8_t* u, const BgzfBlock* blocks, uint32_t nblk, uint64_t avail_end, int is_last, ChainBlock* cb, uint16_t* offs,
-                      uint32_t* rec_base, PieceState* st, const uint32_t* inflate_status, hipStream_t s);
+                      uint32_t* rec_base, PieceState* st, const uint32_t* inflate_status, uint64_t rebase_from, uint64_t rebase_to, hipStream_t s);
 void launch_kb_extract(const uint8_t* u, const BgzfBlock* blocks, uint32_t nblk, const ChainBlock* cb, const uint16_t* offs,
                        const uint32_t* rec_base, RgTable rg, RecordFilterDev f, RawColumns raw, PieceState* st, hipStream_t s);
 // kept records of the piece -> dst at st->n_kept, in order; advances st->n_kept / n_raw; progress (pinned host memory, may be

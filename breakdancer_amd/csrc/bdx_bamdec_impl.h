@@ -3,25 +3,32 @@
 //
 // The caller hands over the file as it is on disk, in pieces of whole BGZF members copied into pinned staging buffers
 // (bdx_bamdec_acquire / bdx_bamdec_submit) together with the members' table (payload offset and length, inflated length: the
-// 18-byte headers and 8-byte footers are the only bytes the host looks at).  Per piece, on three streams:
-//   copy     compressed bytes + block table -> HBM
+// 18-byte headers and 8-byte footers are the only bytes the host looks at).  A piece is the unit of TRANSFER (a staging buffer
+// is free again as soon as its copy is through); the unit of WORK is a batch of pieces, launched once it holds enough members
+// to fill the GPU: one member is one wave and takes ~9 ms alone, so a launch of a few hundred members costs what one of
+// 8,000 does (measured: 61 launches of 755 members each, 8.6 ms apiece, back to back).  Per batch, on three streams:
+//   copy     compressed bytes (per piece) + the batch's block table -> HBM
 //   inflate  KZ, one wave per member, into a ring of inflated bytes
-//   records  one piece behind (a record may end in the next piece): KB chain -> stitch -> fields -> ordered compaction into the
+//   records  one batch behind (a record may end in the next batch): KB chain -> stitch -> fields -> ordered compaction into the
 //            destination columns; the running state (next record boundary, counts, errors) lives in device memory, so the
-//            host never waits for a piece -- it reads a progress record in pinned memory when it wants to know
-// The ring holds a few pieces; a piece that does not fit behind its predecessor starts at the ring's front again, and the
+//            host never waits for a batch -- it reads a progress record in pinned memory when it wants to know
+// The ring holds a few batches; a batch that does not fit behind its predecessor starts at the ring's front again, and the
 // front of it is mirrored behind the predecessor so that the record that straddles the two stays contiguous.
 #include <deque>
 
 namespace {
 
 constexpr size_t kBamMargin = (size_t)kMaxDeviceRecord + 65536;   // bytes mirrored behind the piece in front of a wrap
-constexpr int kBamSlots = 4;                                       // staging / compressed buffers in flight
+constexpr int kBamSlots = 4;                                       // batches in flight (device-side compressed bytes, tables, status)
+constexpr int kBamStaging = 4;                                     // pinned staging buffers
+constexpr size_t kBatchBytesDefault = (size_t)256 << 20;           // compressed bytes per batch
+constexpr size_t kBatchBlocksDefault = 8192;                       // members per batch: more than the GPU has wave slots for this kernel
 
 struct BamPiece {
     uint64_t seq = 0;            // 1-based
     uint64_t ring_beg = 0, ring_end = 0;
     uint64_t mirror_end = 0;     // = ring_end, or behind it where the front of a wrapped successor is mirrored
+    uint64_t prev_end = 0;       // a wrapped piece: where its predecessor ends (the carried record boundary is relative to that)
     uint32_t nblk = 0;
     bool wrapped = false;        // starts at the ring's front although its predecessor does not end at the ring's end
     bool records_done = false;   // its record stage has been enqueued
@@ -36,16 +43,26 @@ struct bdx_bamdec {
     bdx_ctx* sink = nullptr;
     std::string err;
     hipStream_t s_copy = nullptr, s_inf = nullptr, s_rec = nullptr;
-    // per slot: pinned staging (compressed bytes, then the block table), device copy, status words
-    struct Slot {
-        PinBuf h_comp, h_blocks;
-        DevBuf d_comp, d_blocks, d_status;
-        hipEvent_t ev_copied = nullptr;   // H2D of this slot done (staging reusable)
-        hipEvent_t ev_free = nullptr;     // inflate of this slot done (device copy reusable)
+    // pinned staging: one piece's compressed bytes and the caller's member table
+    struct Staging {
+        PinBuf h_comp, h_tab;
+        hipEvent_t ev_copied = nullptr;   // H2D of this buffer done
         bool busy = false;
-        size_t cap = 0;
+        size_t cap = 0;                   // table entries
+    } staging[kBamStaging];
+    int next_staging = 0, cur_staging = -1;
+    // a batch: the compressed bytes of its pieces back to back in HBM, its member table, the inflate status words
+    struct Slot {
+        DevBuf d_comp, d_blocks, d_status;
+        PinBuf h_blocks;                  // the device-format table, built as the pieces arrive
+        hipEvent_t ev_copied = nullptr;   // all of the batch's bytes and its table are in HBM
+        hipEvent_t ev_free = nullptr;     // the batch's record stage is through (its device buffers are reusable)
+        bool busy = false, open = false;
+        size_t bytes = 0, nblk = 0, cap_blk = 0;
+        uint64_t ulen = 0;
     } slot[kBamSlots];
-    int next_slot = 0, cur_slot = -1;
+    int cur_slot = 0;
+    size_t batch_bytes = kBatchBytesDefault, batch_blocks = kBatchBlocksDefault;
     DevBuf d_ring;
     size_t ring_bytes = 0;        // usable bytes (the allocation has kBamMargin more)
     uint64_t cursor = 0;
@@ -230,7 +247,8 @@ int bam_record_stage(bdx_bamdec* d, BamPiece& p, const BamPiece* next, bool is_l
     uint32_t* base = d->d_base.as<uint32_t>();
     PieceState* st = d->d_state.as<PieceState>();
     launch_kb_chain(u, blocks, nblk, avail_end, d->filt.n_targets, cb, offs, s);
-    launch_kb_stitch(u, blocks, nblk, avail_end, is_last ? 1 : 0, cb, offs, base, st, sl.d_status.as<uint32_t>(), s);
+    launch_kb_stitch(u, blocks, nblk, avail_end, is_last ? 1 : 0, cb, offs, base, st, sl.d_status.as<uint32_t>(), p.wrapped ? p.prev_end : 0,
+                     p.wrapped ? p.ring_beg : 0, s);
     RawColumns raw{d->r_tid.as<int32_t>(), d->r_pos.as<int32_t>(), d->r_mtid.as<int32_t>(), d->r_mpos.as<int32_t>(), d->r_isize.as<int32_t>(),
                    d->r_flag.as<uint16_t>(), d->r_qlen.as<uint16_t>(), d->r_mapq.as<uint8_t>(), d->r_lib.as<uint8_t>(), d->r_keep.as<uint8_t>(),
                    d->r_key.as<uint64_t>()};
@@ -278,6 +296,10 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
     for (auto& sl : d->slot)
         if (hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&sl.ev_free, hipEventDisableTiming) != hipSuccess)
             return bad(BDX_EHIP);
+    for (auto& st : d->staging)
+        if (hipEventCreateWithFlags(&st.ev_copied, hipEventDisableTiming) != hipSuccess) return bad(BDX_EHIP);
+    if (p->batch_bytes) d->batch_bytes = p->batch_bytes;
+    if (p->batch_blocks) d->batch_blocks = p->batch_blocks;
     // read groups
     {
         const uint32_t n = p->n_read_groups;
@@ -309,7 +331,7 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
         d->rg.lib = d->d_rg_lib.as<uint8_t>(); d->rg.n = n; d->rg.fallback = p->fallback_lib;
     }
     // ring of inflated bytes
-    d->ring_bytes = p->ring_bytes ? p->ring_bytes : ((size_t)1 << 30);
+    d->ring_bytes = p->ring_bytes ? p->ring_bytes : ((size_t)3 << 30);
     if (d->ring_bytes < ((size_t)1 << 20)) d->ring_bytes = (size_t)1 << 20;
     if (d->d_ring.ensure(d->ring_bytes + kBamMargin + 64) != hipSuccess) return bad(BDX_ENOMEM);
     d->ring_bytes = d->d_ring.bytes - kBamMargin - 64;
@@ -345,9 +367,13 @@ void bdx_bamdec_destroy(bdx_bamdec* d) {
     for (hipStream_t s : {d->s_copy, d->s_inf, d->s_rec})
         if (s) (void)hipStreamSynchronize(s);
     for (auto& sl : d->slot) {
-        sl.h_comp.release(); sl.h_blocks.release(); sl.d_comp.release(); sl.d_blocks.release(); sl.d_status.release();
+        sl.h_blocks.release(); sl.d_comp.release(); sl.d_blocks.release(); sl.d_status.release();
         if (sl.ev_copied) (void)hipEventDestroy(sl.ev_copied);
         if (sl.ev_free) (void)hipEventDestroy(sl.ev_free);
+    }
+    for (auto& st : d->staging) {
+        st.h_comp.release(); st.h_tab.release();
+        if (st.ev_copied) (void)hipEventDestroy(st.ev_copied);
     }
     for (auto& p : d->pieces) {
         if (p.ev_inflated) (void)hipEventDestroy(p.ev_inflated);
@@ -369,80 +395,62 @@ const char* bdx_bamdec_last_error(const bdx_bamdec* d) { return d ? d->err.c_str
 
 int bdx_bamdec_acquire(bdx_bamdec* d, size_t bytes, size_t max_blocks, void** buf, bdx_bgzf_block** blocks) {
     if (!d || !buf || !blocks || bytes == 0 || max_blocks == 0) return BDX_EINVAL;
-    if (d->cur_slot >= 0) return bfail(d, BDX_ESTATE, "the previous piece was not submitted");
+    if (d->cur_staging >= 0) return bfail(d, BDX_ESTATE, "the previous piece was not submitted");
     if (d->finished) return bfail(d, BDX_ESTATE, "the decoder has finished");
     BHIP(d, hipSetDevice(d->device));
-    bdx_bamdec::Slot& sl = d->slot[d->next_slot];
-    if (sl.busy) {
-        BHIP(d, hipEventSynchronize(sl.ev_copied));
-        BHIP(d, hipEventSynchronize(sl.ev_free));
-        sl.busy = false;
+    bdx_bamdec::Staging& st = d->staging[d->next_staging];
+    if (st.busy) {
+        BHIP(d, hipEventSynchronize(st.ev_copied));
+        st.busy = false;
     }
-    BHIP(d, sl.h_comp.ensure(bytes + 64));
-    BHIP(d, sl.h_blocks.ensure(max_blocks * sizeof(bdx_bgzf_block) + max_blocks * sizeof(BgzfBlock)));
-    *buf = sl.h_comp.p;
-    *blocks = sl.h_blocks.as<bdx_bgzf_block>();
-    sl.cap = max_blocks;
-    d->cur_slot = d->next_slot;
-    d->next_slot = (d->next_slot + 1) % kBamSlots;
+    BHIP(d, st.h_comp.ensure(bytes + 64));
+    BHIP(d, st.h_tab.ensure(max_blocks * sizeof(bdx_bgzf_block)));
+    *buf = st.h_comp.p;
+    *blocks = st.h_tab.as<bdx_bgzf_block>();
+    st.cap = max_blocks;
+    d->cur_staging = d->next_staging;
+    d->next_staging = (d->next_staging + 1) % kBamStaging;
     return BDX_OK;
 }
 
-int bdx_bamdec_submit(bdx_bamdec* d, size_t bytes, size_t nblocks, int last) {
-    if (!d) return BDX_EINVAL;
-    if (d->cur_slot < 0) return bfail(d, BDX_ESTATE, "no piece was acquired");
-    BHIP(d, hipSetDevice(d->device));
-    const int si = d->cur_slot;
+}  // extern "C"
+
+namespace {
+
+// The batch in slot si goes to work: a place in the ring, its table to HBM, the inflate launch; the record stage of the batch
+// in front of it (which now has its successor's bytes behind it), and its own if it is the last.
+int bam_launch_batch(bdx_bamdec* d, int si, bool last) {
     bdx_bamdec::Slot& sl = d->slot[si];
-    d->cur_slot = -1;
-    if (nblocks > sl.cap) return bfail(d, BDX_EINVAL, "more blocks than the acquired table holds");
-    const bdx_bgzf_block* hb = sl.h_blocks.as<bdx_bgzf_block>();
-    BgzfBlock* tb = (BgzfBlock*)(hb + sl.cap);   // the device's table is built behind the caller's
-    uint64_t ulen = 0;
-    for (size_t i = 0; i < nblocks; ++i) {
-        if (hb[i].inflated_len > 65536 || hb[i].offset + hb[i].payload_len > bytes) return bfail(d, BDX_EINVAL, "BGZF block table does not fit the piece");
-        ulen += hb[i].inflated_len;
-    }
-    if (ulen * 4 > d->ring_bytes) return bfail(d, BDX_ELIMIT, "piece too large for the inflate ring (it holds four pieces)");
-    // place the piece in the ring
+    const uint64_t ulen = sl.ulen;
+    const size_t nblocks = sl.nblk;
+    if (ulen * 4 > d->ring_bytes) return bfail(d, BDX_ELIMIT, "batch too large for the inflate ring (it holds four batches)");
     BamPiece p;
     p.seq = ++d->n_pieces;
     p.slot = si;
     p.nblk = (uint32_t)nblocks;
-    if (d->cursor + ulen > d->ring_bytes) { p.wrapped = d->any_submitted; d->cursor = 0; }
-    if (!d->any_submitted) {   // the first record offset is relative to the first block: now it has a ring address
-        d->any_submitted = true;
-    }
+    if (d->cursor + ulen > d->ring_bytes) { p.wrapped = !d->pieces.empty(); d->cursor = 0; }
     p.ring_beg = d->cursor;
     p.ring_end = p.mirror_end = d->cursor + ulen;
     d->cursor = p.ring_end;
-    if (p.wrapped && !d->pieces.empty()) {   // the front of this piece will be mirrored behind its predecessor
+    if (p.wrapped && !d->pieces.empty()) {   // the front of this batch will be mirrored behind its predecessor
         BamPiece& prev = d->pieces.back();
         prev.mirror_end = prev.ring_end + std::min<uint64_t>(kBamMargin, ulen);
+        p.prev_end = prev.ring_end;
     }
-    uint64_t o = p.ring_beg;
-    for (size_t i = 0; i < nblocks; ++i) {
-        tb[i].in_off = hb[i].offset; tb[i].in_len = hb[i].payload_len; tb[i].out_off = o; tb[i].out_len = hb[i].inflated_len;
-        o += hb[i].inflated_len;
-    }
-    // the ring bytes this piece (and the mirror behind it) will overwrite must have been consumed: the record stages of the
-    // pieces that still live there
-    // (its own mirror, should its successor wrap, is written by ITS record stage, on the stream on which all older pieces'
+    BgzfBlock* tb = sl.h_blocks.as<BgzfBlock>();
+    for (size_t i = 0; i < nblocks; ++i) tb[i].out_off += p.ring_beg;   // (offsets within the batch so far)
+    // the ring bytes this batch will overwrite must have been consumed: the record stages of the batches that still live there
+    // (its own mirror, should its successor wrap, is written by ITS record stage, on the stream on which all older batches'
     // record stages have run by then)
     for (auto& q : d->pieces) {
         const bool overlap = q.ring_beg < p.ring_end && p.ring_beg < q.mirror_end;
         if (!overlap) continue;
-        if (!q.records_done) {
-            // its record stage waits for ITS successor, which would be this piece or an earlier one: cannot happen with a ring of
-            // several pieces, unless the pieces are too large for it
-            return bfail(d, BDX_ELIMIT, "inflate ring too small for the pieces in flight");
-        }
+        // (a batch whose record stage still waits for its successor -- this batch -- cannot give its bytes up: the ring is too small)
+        if (!q.records_done) return bfail(d, BDX_ELIMIT, "inflate ring too small for the batches in flight");
         BHIP(d, hipStreamWaitEvent(d->s_inf, q.ev_records, 0));
     }
-    BHIP(d, sl.d_comp.ensure(bytes + 2048));   // (the inflate kernel's input ring loads up to ~1.1 KiB behind a payload's end)
     BHIP(d, sl.d_blocks.ensure(std::max<size_t>(nblocks, 1) * sizeof(BgzfBlock)));
     BHIP(d, sl.d_status.ensure(std::max<size_t>(nblocks, 1) * 4));
-    if (bytes) BHIP(d, hipMemcpyAsync(sl.d_comp.p, sl.h_comp.p, bytes, hipMemcpyHostToDevice, d->s_copy));
     if (nblocks) BHIP(d, hipMemcpyAsync(sl.d_blocks.p, tb, nblocks * sizeof(BgzfBlock), hipMemcpyHostToDevice, d->s_copy));
     BHIP(d, hipEventRecord(sl.ev_copied, d->s_copy));
     BHIP(d, hipStreamWaitEvent(d->s_inf, sl.ev_copied, 0));
@@ -451,10 +459,10 @@ int bdx_bamdec_submit(bdx_bamdec* d, size_t bytes, size_t nblocks, int last) {
     if (!p.ev_inflated) return bfail(d, BDX_EHIP, "hipEventCreate");
     BHIP(d, hipEventRecord(p.ev_inflated, d->s_inf));
     sl.busy = true;
-    d->compressed_bytes += bytes;
+    sl.open = false;
     d->inflated_bytes += ulen;
     d->pieces.push_back(p);
-    // record stage of the piece in front, which now has its successor's bytes behind it
+    d->cur_slot = (si + 1) % kBamSlots;
     if (d->pieces.size() >= 2) {
         BamPiece& prev = d->pieces[d->pieces.size() - 2];
         if (!prev.records_done) {
@@ -467,14 +475,77 @@ int bdx_bamdec_submit(bdx_bamdec* d, size_t bytes, size_t nblocks, int last) {
         if (rc != BDX_OK) return rc;
         d->finished = true;
     }
-    // forget pieces whose ring bytes nobody can need any more: all but the last few
+    // forget batches whose ring bytes nobody can need any more: all but the last few
     while (d->pieces.size() > (size_t)kBamSlots + 2 && d->pieces.front().records_done) {
         BamPiece& f = d->pieces.front();
-        // (a later piece that lands on its bytes waits for ev_records; once the event has completed that wait is void)
+        // (a later batch that lands on its bytes waits for ev_records; once the event has completed that wait is void)
         if (hipEventQuery(f.ev_records) != hipSuccess) break;
         d->ev_pool.push_back(f.ev_inflated);
         d->ev_pool.push_back(f.ev_records);
         d->pieces.pop_front();
+    }
+    return BDX_OK;
+}
+
+// the batch that takes the next piece: the open one, or slot cur_slot once its previous tenant's record stage is through
+int bam_open_batch(bdx_bamdec* d, size_t piece_bytes, size_t piece_blocks) {
+    bdx_bamdec::Slot& sl = d->slot[d->cur_slot];
+    if (sl.open) return BDX_OK;
+    if (sl.busy) {
+        BHIP(d, hipEventSynchronize(sl.ev_free));
+        sl.busy = false;
+    }
+    // room for a batch plus the piece that takes it over the threshold (and the kernel's input ring reads ~1.1 KiB behind a payload)
+    BHIP(d, sl.d_comp.ensure(d->batch_bytes + piece_bytes + 4096));
+    const size_t cap = d->batch_blocks + piece_blocks + 64;
+    BHIP(d, sl.h_blocks.ensure(cap * sizeof(BgzfBlock)));
+    sl.cap_blk = sl.h_blocks.bytes / sizeof(BgzfBlock);
+    sl.bytes = 0; sl.nblk = 0; sl.ulen = 0;
+    sl.open = true;
+    return BDX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bdx_bamdec_submit(bdx_bamdec* d, size_t bytes, size_t nblocks, int last) {
+    if (!d) return BDX_EINVAL;
+    if (d->cur_staging < 0) return bfail(d, BDX_ESTATE, "no piece was acquired");
+    BHIP(d, hipSetDevice(d->device));
+    bdx_bamdec::Staging& st = d->staging[d->cur_staging];
+    d->cur_staging = -1;
+    if (nblocks > st.cap) return bfail(d, BDX_EINVAL, "more blocks than the acquired table holds");
+    const bdx_bgzf_block* hb = st.h_tab.as<bdx_bgzf_block>();
+    for (size_t i = 0; i < nblocks; ++i)
+        if (hb[i].inflated_len > 65536 || hb[i].offset + hb[i].payload_len > bytes) return bfail(d, BDX_EINVAL, "BGZF block table does not fit the piece");
+    int rc = bam_open_batch(d, bytes, nblocks);
+    if (rc != BDX_OK) return rc;
+    {   // a piece that does not fit the open batch's buffers any more: that batch goes first
+        bdx_bamdec::Slot& cur = d->slot[d->cur_slot];
+        if (cur.nblk && (cur.bytes + bytes + 4096 > cur.d_comp.bytes || cur.nblk + nblocks > cur.cap_blk)) {
+            rc = bam_launch_batch(d, d->cur_slot, false);
+            if (rc == BDX_OK) rc = bam_open_batch(d, bytes, nblocks);
+            if (rc != BDX_OK) return rc;
+        }
+    }
+    bdx_bamdec::Slot& sl = d->slot[d->cur_slot];
+    if (sl.bytes + bytes + 4096 > sl.d_comp.bytes || sl.nblk + nblocks > sl.cap_blk) return bfail(d, BDX_ELIMIT, "piece larger than a batch");
+    if (bytes) BHIP(d, hipMemcpyAsync((char*)sl.d_comp.p + sl.bytes, st.h_comp.p, bytes, hipMemcpyHostToDevice, d->s_copy));
+    BHIP(d, hipEventRecord(st.ev_copied, d->s_copy));
+    st.busy = true;
+    BgzfBlock* tb = sl.h_blocks.as<BgzfBlock>() + sl.nblk;
+    for (size_t i = 0; i < nblocks; ++i) {
+        tb[i].in_off = sl.bytes + hb[i].offset; tb[i].in_len = hb[i].payload_len; tb[i].out_off = sl.ulen; tb[i].out_len = hb[i].inflated_len;
+        sl.ulen += hb[i].inflated_len;
+    }
+    sl.nblk += nblocks;
+    sl.bytes += (bytes + 7) & ~(size_t)7;
+    d->compressed_bytes += bytes;
+    d->any_submitted = true;
+    if (last || sl.nblk >= d->batch_blocks || sl.bytes >= d->batch_bytes) {
+        rc = bam_launch_batch(d, d->cur_slot, last != 0);
+        if (rc != BDX_OK) return rc;
     }
     bam_poll(d);
     return bam_feed_classifier(d, false);
@@ -495,8 +566,11 @@ int bdx_bamdec_finish(bdx_bamdec* d, uint64_t* n_records) {
     if (!d) return BDX_EINVAL;
     BHIP(d, hipSetDevice(d->device));
     if (!d->finished) {
-        // the caller stops early (a region read through the index): the pieces in flight still hold whole records only up to the
-        // last stitched boundary; run the record stage of the last piece as far as its bytes go
+        // the caller stops early (a region read through the index): what has been submitted is decoded as far as its bytes go
+        if (d->slot[d->cur_slot].open && d->slot[d->cur_slot].nblk) {
+            const int rc = bam_launch_batch(d, d->cur_slot, false);
+            if (rc != BDX_OK) return rc;
+        }
         if (!d->pieces.empty() && !d->pieces.back().records_done) {
             const int rc = bam_record_stage(d, d->pieces.back(), nullptr, false);
             if (rc != BDX_OK) return rc;

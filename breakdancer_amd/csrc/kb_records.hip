@@ -94,7 +94,8 @@ __global__ __launch_bounds__(64) void kb_chain_kernel(const uint8_t* __restrict_
 constexpr int kStitchThreads = 1024;
 __global__ __launch_bounds__(kStitchThreads) void kb_stitch_kernel(const uint8_t* __restrict__ u, const BgzfBlock* __restrict__ blocks, uint32_t nblk,
                                                                    uint64_t avail_end, int is_last, ChainBlock* cb, uint16_t* offs, uint32_t* rec_base,
-                                                                   PieceState* st, const uint32_t* __restrict__ inflate_status) {
+                                                                   PieceState* st, const uint32_t* __restrict__ inflate_status, uint64_t rebase_from,
+                                                                   uint64_t rebase_to) {
     __shared__ uint32_t s_first_bad;
     __shared__ uint32_t s_inflate_bad;
     __shared__ uint32_t s_sum[kStitchThreads];
@@ -103,7 +104,8 @@ __global__ __launch_bounds__(kStitchThreads) void kb_stitch_kernel(const uint8_t
     __syncthreads();
     for (uint32_t b = t; b < nblk; b += kStitchThreads)
         if (inflate_status[b]) atomicOr(&s_inflate_bad, 1u);
-    const uint64_t start = st->next_start;
+    // (a piece that starts at the ring's front again: the carried boundary is an offset behind its predecessor's end)
+    const uint64_t start = st->next_start - rebase_from + rebase_to;
     // block b is fine if its walk started where its predecessor's ended (by induction the whole prefix of fine blocks is exact)
     for (uint32_t b = t; b < nblk; b += kStitchThreads) {
         const ChainBlock c = cb[b];
@@ -386,8 +388,9 @@ void launch_kb_chain(const uint8_t* u, const BgzfBlock* blocks, uint32_t nblk, u
 }
 
 void launch_kb_stitch(const uint8_t* u, const BgzfBlock* blocks, uint32_t nblk, uint64_t avail_end, int is_last, ChainBlock* cb, uint16_t* offs,
-                      uint32_t* rec_base, PieceState* st, const uint32_t* inflate_status, hipStream_t s) {
-    hipLaunchKernelGGL(kb_stitch_kernel, dim3(1), dim3(kStitchThreads), 0, s, u, blocks, nblk, avail_end, is_last, cb, offs, rec_base, st, inflate_status);
+                      uint32_t* rec_base, PieceState* st, const uint32_t* inflate_status, uint64_t rebase_from, uint64_t rebase_to, hipStream_t s) {
+    hipLaunchKernelGGL(kb_stitch_kernel, dim3(1), dim3(kStitchThreads), 0, s, u, blocks, nblk, avail_end, is_last, cb, offs, rec_base, st, inflate_status,
+                       rebase_from, rebase_to);
 }
 
 void launch_kb_extract(const uint8_t* u, const BgzfBlock* blocks, uint32_t nblk, const ChainBlock* cb, const uint16_t* offs,

@@ -258,7 +258,9 @@ int main(int argc, char** argv) {
                 const char* dm = getenv("BDX_DECODE");
                 bool decoded = false;
                 if (cfg.num_bams() == 1 && !(dm && !strcmp(dm, "host"))) {
+                    const auto tb = now();
                     sink.bring_up();
+                    if (timing) fprintf(stderr, "[bdx timing] GPU context + resident store ready %.3f s after start (waited %.3f s for it)\n", secs(t_start, now()), secs(tb, now()));
                     bool unsupported = false;
                     n_reads = produce_on_device(cfg, opts.chr, (int)std::min(std::max(usable_cpus(), 2u), 16u), &targets, ctx, &unsupported);
                     if (unsupported) check(ctx, bdx_reset_reads(ctx), "bdx_reset_reads");

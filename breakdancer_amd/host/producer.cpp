@@ -389,11 +389,19 @@ size_t produce_on_device(const BamConfig& cfg, const std::string& chr, int threa
     p.rg_lib = libs.empty() ? nullptr : libs.data();
     p.fallback_lib = (uint8_t)cfg.fallback_library();
     p.first_record_offset = rec_off;
-    const size_t kPiece = getenv("BDX_BAM_PIECE_BYTES") ? (size_t)std::max(1ll, atoll(getenv("BDX_BAM_PIECE_BYTES"))) : ((size_t)32 << 20);
-    p.ring_bytes = std::max<size_t>((size_t)1 << 30, kPiece * 12);
+    // pieces (transfer units) of 16 MiB; the decoder gathers them into batches of >= 8192 members before it launches kernels.
+    // Small files get small buffers.  Test knobs: BDX_BAM_PIECE_BYTES, BDX_BAM_BATCH_BLOCKS, BDX_BAM_RING_BYTES
+    const size_t kPiece = getenv("BDX_BAM_PIECE_BYTES") ? (size_t)std::max(1ll, atoll(getenv("BDX_BAM_PIECE_BYTES"))) : ((size_t)16 << 20);
+    const size_t rest = file_size - std::min(file_size, member_off);
+    p.batch_bytes = std::min<size_t>((size_t)256 << 20, ((rest + ((size_t)1 << 20)) >> 20) << 20);
+    p.batch_blocks = getenv("BDX_BAM_BATCH_BLOCKS") ? (size_t)std::max(1ll, atoll(getenv("BDX_BAM_BATCH_BLOCKS"))) : 0;
+    // four batches of inflated bytes: a batch is at most ~8192 + a piece's members of 64 KiB, or the whole file (assume <= 16 x its size)
+    p.ring_bytes = std::min<size_t>((size_t)3 << 30, std::max<size_t>((size_t)64 << 20, rest * 64));
     if (const char* rb = getenv("BDX_BAM_RING_BYTES")) p.ring_bytes = (size_t)std::max(1ll, atoll(rb));
     bdx_bamdec* dec = nullptr;
+    const auto t_create = std::chrono::steady_clock::now();
     int rc = bdx_bamdec_create(&dec, ctx, &p);
+    const double create_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_create).count();
     if (rc != BDX_OK) throw std::runtime_error(std::string("bdx_bamdec_create: ") + bdx_strerror(rc));
     struct Guard { bdx_bamdec* d; ~Guard() { bdx_bamdec_destroy(d); } } guard{dec};
     auto check = [&](int r, const char* what) {
@@ -404,19 +412,30 @@ size_t produce_on_device(const BamConfig& cfg, const std::string& chr, int threa
     struct Fd { int fd; ~Fd() { close(fd); } } fdg{fd};
 
     // pieces of about kPiece bytes, cut at member boundaries: the bytes behind the last whole member of a piece open the next
+    const bool timing = getenv("BDX_TIMING") != nullptr;
+    double t_acquire = 0, t_read = 0, t_scan = 0, t_submit = 0, t_finish = 0;
+    auto clk = [] { return std::chrono::steady_clock::now(); };
+    auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
+    size_t npieces = 0;
     size_t off = member_off;
     std::vector<uint8_t> carry;
-    const size_t max_blocks = kPiece / 28 + 4096;   // (an empty member has 28 bytes)
+    const size_t max_blocks = kPiece / 2048 + 4096;   // (a piece of many tiny members is simply cut earlier)
     bool stop = false;
     while (!stop) {
         const size_t want = std::min(kPiece, file_size - off);
         void* buf = nullptr;
         bdx_bgzf_block* tab = nullptr;
+        auto t0 = clk();
         check(bdx_bamdec_acquire(dec, carry.size() + want + 65536, max_blocks, &buf, &tab), "bdx_bamdec_acquire");
+        t_acquire += since(t0);
+        ++npieces;
         uint8_t* b = (uint8_t*)buf;
         if (!carry.empty()) memcpy(b, carry.data(), carry.size());
         std::string rerr;
+        t0 = clk();
         if (want) read_range(fd, off, b + carry.size(), want, threads, &rerr);
+        t_read += since(t0);
+        t0 = clk();
         if (!rerr.empty()) throw std::runtime_error("cannot read " + path);
         const size_t have = carry.size() + want;
         off += want;
@@ -452,7 +471,10 @@ size_t produce_on_device(const BamConfig& cfg, const std::string& chr, int threa
         if (at_eof && q != have) throw std::runtime_error("truncated BGZF file: " + path);
         carry.assign(b + q, b + have);
         if (q == 0 && !at_eof && want) throw std::runtime_error("BGZF member larger than a piece: " + path);
+        t_scan += since(t0);
+        t0 = clk();
         check(bdx_bamdec_submit(dec, q, nb, at_eof ? 1 : 0), "bdx_bamdec_submit");
+        t_submit += since(t0);
         if (at_eof) break;
         if (seeked) {   // a region read through the index: nothing of it lies behind the first record past it
             int past = 0;
@@ -461,7 +483,12 @@ size_t produce_on_device(const BamConfig& cfg, const std::string& chr, int threa
         }
     }
     uint64_t n = 0;
+    const auto tf = clk();
     rc = bdx_bamdec_finish(dec, &n);
+    t_finish = since(tf);
+    if (timing)
+        fprintf(stderr, "[bdx timing] device decode: decoder set up in %.3f s; %zu pieces; waiting for a staging buffer %.3f s, reading the file %.3f s (%d threads), member tables %.3f s, "
+                        "enqueueing %.3f s, waiting for the GPU at the end %.3f s\n", create_s, npieces, t_acquire, t_read, threads, t_scan, t_submit, t_finish);
     if (rc == BDX_ELIMIT && unsupported) { *unsupported = true; return 0; }
     check(rc, "bdx_bamdec_finish");
     return (size_t)n;

@@ -354,7 +354,8 @@ int bdx_dist_plan(const uint64_t* weight, int ntids, int world, int* rank_of_tid
  *                        (a ring of four; blocks only while all are in flight)
  *   bdx_bamdec_submit    the first `bytes` of the buffer are whole members, described by the first nblocks table entries
  *                        (offset = start of the member's deflate payload in the buffer); last != 0 with the file's final piece.
- *                        Asynchronous: copy, inflate and record kernels are enqueued, one piece behind for the records
+ *                        Asynchronous: the copy is enqueued at once; inflate and record kernels run per BATCH of pieces (one member is
+ *                        one wavefront, so a launch wants thousands of them), the record kernels one batch behind
  *   bdx_bamdec_progress  non-blocking: records appended so far, records seen, whether a record behind the -o region was met
  *                        (a caller that seeked through the index may stop there), device-side error code
  *   bdx_bamdec_finish    waits for everything; errors of the decode (corrupt block, corrupt or truncated record chain, a record
@@ -377,7 +378,9 @@ typedef struct bdx_bamdec_params {
     const uint8_t* rg_lib;
     uint8_t fallback_lib;         /* library of records without (or with an unknown) read group */
     uint64_t first_record_offset;
-    size_t ring_bytes;            /* inflated bytes kept in flight, 0: 1 GiB */
+    size_t ring_bytes;            /* inflated bytes kept in flight (at least four batches' worth), 0: 3 GiB */
+    size_t batch_bytes;           /* compressed bytes and members after which the pieces gathered so far are launched as one batch */
+    size_t batch_blocks;          /* (0: 256 MiB / 8192 members -- more members than the GPU has wave slots for the inflate kernel) */
 } bdx_bamdec_params;
 int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* p);
 void bdx_bamdec_destroy(bdx_bamdec* d);

@@ -162,8 +162,8 @@ def check_columns(cols, recs, rg_to_lib, fallback, region=None):
     np.testing.assert_array_equal(cols["name_key"], want_key)
 
 
-@pytest.mark.parametrize("piece_blocks,ring", [(512, 0), (1, 1 << 20), (3, 1 << 20), (2, 0)])
-def test_reference_bams_columns(piece_blocks, ring):
+@pytest.mark.parametrize("piece_blocks,ring,batch", [(512, 0, 0), (1, 1 << 20, 1), (2, 1 << 20, 3), (2, 0, 5), (1, 0, 0)])
+def test_reference_bams_columns(piece_blocks, ring, batch):
     from breakdancer_amd import bamdec
     rows, libs = config_read_groups(os.path.join(CHR21, "inv_del_bam_config"))
     rg_ids = [r[0] for r in rows]
@@ -172,13 +172,15 @@ def test_reference_bams_columns(piece_blocks, ring):
     for bi, name in enumerate(BAMS):
         path = os.path.join(CHR21, name)
         targets, recs = read_bam(path)
-        cols, names, stats = bamdec.decode_file(path, rg_ids=rg_ids, rg_lib=rg_lib, fallback_lib=1, bam_index=bi, piece_blocks=piece_blocks, ring_bytes=ring)
+        cols, names, stats = bamdec.decode_file(path, rg_ids=rg_ids, rg_lib=rg_lib, fallback_lib=1, bam_index=bi, piece_blocks=piece_blocks, ring_bytes=ring,
+                                                batch_blocks=batch)
         assert names == targets
         check_columns(cols, recs, rg_to_lib, 1)
         assert (cols["bam"] == bi).all()
         # -o 21 style region filter (bam_index.c:571-576 overlap rule)
         t21 = targets.index("21")
-        cols, _, _ = bamdec.decode_file(path, rg_ids=rg_ids, rg_lib=rg_lib, fallback_lib=1, region=(t21, 14_500_000, 14_600_000), piece_blocks=piece_blocks, ring_bytes=ring)
+        cols, _, _ = bamdec.decode_file(path, rg_ids=rg_ids, rg_lib=rg_lib, fallback_lib=1, region=(t21, 14_500_000, 14_600_000), piece_blocks=piece_blocks, ring_bytes=ring,
+                                        batch_blocks=batch)
         check_columns(cols, recs, rg_to_lib, 1, region=(t21, 14_500_000, 14_600_000))
 
 
@@ -204,14 +206,16 @@ def test_synthetic_records_with_odd_shapes(seed, tmp_path):
     from breakdancer_amd import bamdec
     from breakdancer_amd.bamwrite import write_bam_records
     rng = np.random.default_rng(100 + seed)
-    recs = synthetic_records(6000, rng)
+    recs = synthetic_records([6000, 30000, 30000, 6000][seed], rng)   # (seeds 1 and 2: several laps round a 1 MiB ring)
     path = str(tmp_path / "odd.bam")
     write_bam_records(path, recs, ["c0", "c1", "c2"], rgs=("a", "bb"), level=[1, 6, 0, 9][seed], seed=seed)
     targets, want = read_bam(path)
     cols, names, stats = bamdec.decode_file(path, rg_ids=["a", "bb"], rg_lib=[0, 1], fallback_lib=1, piece_blocks=[512, 1, 2, 5][seed],
-                                            ring_bytes=[0, 1 << 20, 1 << 20, 0][seed])
+                                            ring_bytes=[0, 1 << 20, 1 << 20, 0][seed], batch_blocks=[0, 1, 3, 7][seed])
     assert names == targets
     check_columns(cols, want, {"a": 0, "bb": 1}, 1)
+    if seed in (1, 2):
+        assert stats["inflated_bytes"] > 3 * (1 << 20)
 
 
 def test_truncated_and_corrupt_files_are_errors(tmp_path):
@@ -226,7 +230,7 @@ def test_truncated_and_corrupt_files_are_errors(tmp_path):
     names, lens, k, off = bamdec.bam_header(image, members)
     data = members[members["inflated_len"] > 0]
     # the last data member missing: the final record is cut off
-    d = bamdec.BamDecoder(len(names), first_record_offset=off)
+    d = bamdec.BamDecoder(len(names), first_record_offset=off, batch_blocks=6)
     d.feed(image, data[k:-1], 4)
     with pytest.raises(RuntimeError, match="truncated|corrupt"):
         d.finish()
@@ -234,7 +238,7 @@ def test_truncated_and_corrupt_files_are_errors(tmp_path):
     # a flipped bit in a payload: the member does not inflate (or the chain breaks)
     bad = image.copy()
     bad[int(data["payload"][k + 2]) + 40] ^= 0x10
-    d = bamdec.BamDecoder(len(names), first_record_offset=off)
+    d = bamdec.BamDecoder(len(names), first_record_offset=off, batch_blocks=6)
     d.feed(bad, data[k:], 4)
     with pytest.raises(RuntimeError):
         d.finish()
