@@ -22,7 +22,7 @@ constexpr size_t kBamMargin = (size_t)kMaxDeviceRecord + 65536;   // bytes mirro
 constexpr int kBamSlots = 4;                                       // batches in flight (device-side compressed bytes, tables, status)
 constexpr int kBamStaging = 4;                                     // pinned staging buffers
 constexpr size_t kBatchBytesDefault = (size_t)256 << 20;           // compressed bytes per batch
-constexpr size_t kBatchBlocksDefault = 8192;                       // members per batch: more than the GPU has wave slots for this kernel
+constexpr size_t kBatchBlocksDefault = 6144;                       // members per batch: about the wave slots the GPU has for this kernel (256 CUs x 23)
 
 struct BamPiece {
     uint64_t seq = 0;            // 1-based
@@ -42,7 +42,7 @@ struct bdx_bamdec {
     int device = 0;
     bdx_ctx* sink = nullptr;
     std::string err;
-    hipStream_t s_copy = nullptr, s_inf = nullptr, s_rec = nullptr;
+    hipStream_t s_copy = nullptr, s_inf = nullptr, s_inf2 = nullptr, s_rec = nullptr;   // (two inflate streams, taken in turn: see bam_launch_batch)
     // pinned staging: one piece's compressed bytes and the caller's member table
     struct Staging {
         PinBuf h_comp, h_tab;
@@ -91,6 +91,9 @@ struct bdx_bamdec {
     std::deque<std::pair<uint64_t, hipEvent_t>> rec_events;  // (sequence, records-done event) for the sink's classifier
     float ms_inflate = 0;
     uint64_t inflated_bytes = 0, compressed_bytes = 0;
+    size_t expected_bytes = 0;    // compressed bytes the caller announced (0: unknown)
+    uint64_t first_batch_bytes = 0;
+    bool presized = false;        // sink mode: the later stages' buffers have been sized from the first batch's record density
 };
 
 namespace {
@@ -173,6 +176,19 @@ int bam_feed_classifier(bdx_bamdec* d, bool final) {
     if (d->confirmed > c->n) {
         c->n = (size_t)d->confirmed;
         c->ran = false;
+    }
+    if (!d->presized && d->confirmed_seq >= 1 && d->expected_bytes && d->first_batch_bytes) {
+        // the first batch's records per byte, applied to the whole file: the stages behind pass 1 get their buffers now, while
+        // the GPU is busy with the batches in flight (~60 allocations, tens of milliseconds of page pinning for a chromosome)
+        d->presized = true;
+        const double est = (double)d->confirmed * (double)d->expected_bytes / (double)d->first_batch_bytes * 1.05;
+        if (est >= (double)(1u << 20) && !c->ran) {
+            const uint64_t prior = (uint64_t)est / 32 + 4096;
+            if (prior <= kMaxRegions) {
+                const int rc = presize_stages(c, (uint32_t)prior);
+                if (rc != BDX_OK) return bfail(d, rc, c->err);
+            }
+        }
     }
     if (latest) {
         const hipError_t e = hipStreamWaitEvent(c->stream, latest, 0);
@@ -291,6 +307,7 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
     d->filt.only_tid = p->only_tid; d->filt.beg = p->region_beg; d->filt.end = p->region_end; d->filt.n_targets = p->n_targets;
     auto bad = [&](int code) { bdx_bamdec_destroy(d); return code; };
     if (hipStreamCreateWithFlags(&d->s_copy, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&d->s_inf, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&d->s_inf2, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&d->s_rec, hipStreamNonBlocking) != hipSuccess)
         return bad(BDX_EHIP);
     for (auto& sl : d->slot)
@@ -298,6 +315,7 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
             return bad(BDX_EHIP);
     for (auto& st : d->staging)
         if (hipEventCreateWithFlags(&st.ev_copied, hipEventDisableTiming) != hipSuccess) return bad(BDX_EHIP);
+    d->expected_bytes = p->expected_bytes;
     if (p->batch_bytes) d->batch_bytes = p->batch_bytes;
     if (p->batch_blocks) d->batch_blocks = p->batch_blocks;
     // read groups
@@ -343,6 +361,10 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
     memset(d->h_progress.p, 0, 64);
     if (sink) {
         if (sink->adopted) return bad(BDX_ESTATE);
+        if (sink->n == 0 && sink->cap == 0 && p->expected_bytes) {   // (a record takes 50-150 bytes of BAM; a store that is too small grows)
+            const size_t want = std::min<size_t>(p->expected_bytes / 48 + ((size_t)1 << 20), 0xFFFFFFFFull - 1024);
+            if (alloc_reads(sink, want) != BDX_OK) return bad(BDX_ENOMEM);
+        }
         if (sink->n == 0 && sink->cap) {   // pass 1 runs as the records arrive
             sink->key_segs.clear();
             const uint64_t tiles = (sink->cap + kTile - 1) / kTile;
@@ -364,7 +386,7 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
 void bdx_bamdec_destroy(bdx_bamdec* d) {
     if (!d) return;
     (void)hipSetDevice(d->device);
-    for (hipStream_t s : {d->s_copy, d->s_inf, d->s_rec})
+    for (hipStream_t s : {d->s_copy, d->s_inf, d->s_inf2, d->s_rec})
         if (s) (void)hipStreamSynchronize(s);
     for (auto& sl : d->slot) {
         sl.h_blocks.release(); sl.d_comp.release(); sl.d_blocks.release(); sl.d_status.release();
@@ -386,7 +408,7 @@ void bdx_bamdec_destroy(bdx_bamdec* d) {
                       &d->o_tid, &d->o_pos, &d->o_mtid, &d->o_mpos, &d->o_isize, &d->o_flag, &d->o_qlen, &d->o_mapq, &d->o_lib, &d->o_bam, &d->o_key})
         b->release();
     d->h_progress.release();
-    for (hipStream_t s : {d->s_copy, d->s_inf, d->s_rec})
+    for (hipStream_t s : {d->s_copy, d->s_inf, d->s_inf2, d->s_rec})
         if (s) (void)hipStreamDestroy(s);
     delete d;
 }
@@ -428,6 +450,9 @@ int bam_launch_batch(bdx_bamdec* d, int si, bool last) {
     p.seq = ++d->n_pieces;
     p.slot = si;
     p.nblk = (uint32_t)nblocks;
+    // Batches alternate between two streams: a launch whose members outnumber the GPU's wave slots ends with the slots draining
+    // (a member takes ~10 ms however many run beside it), and the next batch's waves fill them as they come free.
+    hipStream_t s_inf = (p.seq & 1) ? d->s_inf : d->s_inf2;
     if (d->cursor + ulen > d->ring_bytes) { p.wrapped = !d->pieces.empty(); d->cursor = 0; }
     p.ring_beg = d->cursor;
     p.ring_end = p.mirror_end = d->cursor + ulen;
@@ -447,19 +472,20 @@ int bam_launch_batch(bdx_bamdec* d, int si, bool last) {
         if (!overlap) continue;
         // (a batch whose record stage still waits for its successor -- this batch -- cannot give its bytes up: the ring is too small)
         if (!q.records_done) return bfail(d, BDX_ELIMIT, "inflate ring too small for the batches in flight");
-        BHIP(d, hipStreamWaitEvent(d->s_inf, q.ev_records, 0));
+        BHIP(d, hipStreamWaitEvent(s_inf, q.ev_records, 0));
     }
     BHIP(d, sl.d_blocks.ensure(std::max<size_t>(nblocks, 1) * sizeof(BgzfBlock)));
     BHIP(d, sl.d_status.ensure(std::max<size_t>(nblocks, 1) * 4));
     if (nblocks) BHIP(d, hipMemcpyAsync(sl.d_blocks.p, tb, nblocks * sizeof(BgzfBlock), hipMemcpyHostToDevice, d->s_copy));
     BHIP(d, hipEventRecord(sl.ev_copied, d->s_copy));
-    BHIP(d, hipStreamWaitEvent(d->s_inf, sl.ev_copied, 0));
-    launch_kz_inflate(sl.d_comp.as<uint8_t>(), sl.d_blocks.as<BgzfBlock>(), (uint32_t)nblocks, d->d_ring.as<uint8_t>(), sl.d_status.as<uint32_t>(), d->s_inf);
+    BHIP(d, hipStreamWaitEvent(s_inf, sl.ev_copied, 0));
+    launch_kz_inflate(sl.d_comp.as<uint8_t>(), sl.d_blocks.as<BgzfBlock>(), (uint32_t)nblocks, d->d_ring.as<uint8_t>(), sl.d_status.as<uint32_t>(), s_inf);
     p.ev_inflated = bam_event(d);
     if (!p.ev_inflated) return bfail(d, BDX_EHIP, "hipEventCreate");
-    BHIP(d, hipEventRecord(p.ev_inflated, d->s_inf));
+    BHIP(d, hipEventRecord(p.ev_inflated, s_inf));
     sl.busy = true;
     sl.open = false;
+    if (p.seq == 1) d->first_batch_bytes = sl.bytes;
     d->inflated_bytes += ulen;
     d->pieces.push_back(p);
     d->cur_slot = (si + 1) % kBamSlots;
@@ -579,6 +605,7 @@ int bdx_bamdec_finish(bdx_bamdec* d, uint64_t* n_records) {
     }
     BHIP(d, hipStreamSynchronize(d->s_copy));
     BHIP(d, hipStreamSynchronize(d->s_inf));
+    BHIP(d, hipStreamSynchronize(d->s_inf2));
     BHIP(d, hipStreamSynchronize(d->s_rec));
     PieceState st{};
     BHIP(d, hipMemcpy(&st, d->d_state.p, sizeof(st), hipMemcpyDeviceToHost));

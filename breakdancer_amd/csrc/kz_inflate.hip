@@ -7,19 +7,20 @@
 // What a wave does with its 64 lanes.  Huffman decoding is a serial chain -- a symbol's position is known only once its
 // predecessor's length is -- so a CPU decoder pays one table look-up latency per symbol.  Here the look-ups of a whole
 // 64-bit window run at once: lane j takes the bits at offset (cursor + j) and looks ITS candidate symbol up in the LDS table
-// (one ds_read for 64 candidates; lanes that see a length code also look their distance code up); the chain of real symbols
-// is then followed through the lanes' results with v_readlane (scalar, no memory access), the literal lanes on the chain
-// store their bytes side by side (ballot rank), and the wave moves on by up to 64 + 9 bits.  A length/distance pair ends
-// the step: its extra bits and its distance entry are already in the stopping lane's registers, and the copy is done by all
-// lanes (lane i copies byte i, i mod distance for overlapping copies).  Codes longer than the primary table's index (rare
-// symbols by construction) are decoded canonically, bit by bit, from the count / sorted-symbol arrays: no second-level tables.
+// (one ds_read for 64 candidates) -- a literal, or a whole length / distance pair with its extra bits; the chain of real
+// tokens is then followed through the lanes' results with v_readlane (scalar, no memory access), the literal lanes on the
+// chain store their bytes at their places, the matches on it are copied in stream order by all lanes (lane i copies byte i,
+// i mod distance for overlapping copies), and the wave moves on by up to 64 + 35 bits.  Codes longer than the primary
+// table's index (rare symbols by construction) are decoded canonically, bit by bit, from the count / sorted-symbol arrays:
+// no second-level tables.
 //
-// Everything a step touches is in LDS.  The kernel is bound by the latency of a step's dependent accesses, not by
-// instruction issue or bandwidth (in-kernel clocks, tools/bamdec_probe.py: ~2,500 cycles per step with input and output in
-// HBM, and throughput proportional to the waves per compute unit), so: the compressed input is staged through a 1 KiB ring
-// (512 bytes per refill, one coalesced load), the last 1 KiB of output lives in a window that literals and near matches never
-// leave (flushed 256 bytes at a time, one 4-byte store per lane; matches further back read HBM, where their source has been
-// for at least one flush), tables are 16 bits per entry, and the whole footprint is ~5.7 KB per wave: 28 waves per compute unit.
+// Everything a step touches is in LDS: the compressed input is staged through a 1 KiB ring (512 bytes per refill, one
+// coalesced load), the last 2 KiB of output live in a window that literals and near matches never leave (flushed 256 bytes at
+// a time, one 4-byte store per lane; matches further back read HBM, where their source has been for at least one flush),
+// tables are 16 bits per entry; ~6.8 KB per wave.  What bounds the kernel is the scalar issue slot (SQ counters,
+// tools/pmc_inflate.sh: with one token per step it issued 116 scalar + 34 branch instructions per step against 62 vector ones,
+// the SIMDs' scalar slots 70-90 % taken, whatever the occupancy and wherever input and output lived -- 23 GB/s three times
+// over): hence everything per token that can be per lane is, and a step takes as many tokens as 64 bits hold.
 //
 // Tables are built per deflate block by the wave itself: lengths read with the same canonical decoder (the code-length
 // code has 19 symbols of <= 7 bits), canonical codes from a per-length scan, table filled symbol by symbol across the lanes.
@@ -36,9 +37,11 @@ constexpr int kDB = 8;             // primary distance table
 constexpr int kMaxBits = 15;
 // 16-bit table entry: bits 0-3 code length (0: not in the table), 4-5 kind, 6-13 literal byte / length symbol / distance symbol
 constexpr uint32_t T_SLOW = 0, T_LIT = 1, T_SYM = 2, T_EOB = 3;
-constexpr uint32_t kOB = 1024, kOBM = kOB - 1;      // output window
+constexpr uint32_t kOB = 2048, kOBM = kOB - 1;      // output window
 constexpr uint32_t kFlush = 256;                    // bytes written to HBM at a time (64 lanes x 4 bytes)
-constexpr uint32_t kNearDist = kOB - 258 - 64;      // matches up to this distance are copied inside the window
+constexpr uint32_t kStepCap = 192;                  // a step's chain ends once it has produced this much: a step writes < 192 + 258 bytes
+constexpr uint32_t kNearDist = kOB - (kStepCap + 258) - 64;   // matches up to this distance are copied inside the window: their
+                                                    // source cannot be overwritten by anything the step writes (positions are mod 2048)
 constexpr uint32_t kIB = 1024, kIBM = kIB - 1;      // input ring
 constexpr uint32_t kRefill = 512;
 
@@ -62,7 +65,7 @@ __device__ __forceinline__ void distance_of(uint32_t s, uint32_t* base, uint32_t
 
 struct __attribute__((aligned(16))) Lds {
     uint32_t ibuf[kIB / 4];    // compressed bytes: position p at p mod 1024
-    uint8_t obuf[kOB];         // the last 1 KiB of output: position p at p mod 1024
+    uint8_t obuf[kOB + 64];    // the last 2 KiB of output: position p at p mod 2048; 64 bytes behind it take masked-off stores
     uint16_t lit[1 << kLB];
     uint16_t dist[1 << kDB];
     uint16_t lit_sorted[288];
@@ -185,11 +188,12 @@ __device__ bool build_tables(Lds& L, const uint8_t* lens, uint32_t n, uint16_t* 
     return true;
 }
 
-__global__ __launch_bounds__(64, 7) void kz_inflate_kernel(const uint8_t* __restrict__ in_all, const BgzfBlock* __restrict__ blocks, uint32_t nblk,
+__global__ __launch_bounds__(64, 6) void kz_inflate_kernel(const uint8_t* __restrict__ in_all, const BgzfBlock* __restrict__ blocks, uint32_t nblk,
                                                         uint8_t* out_all, uint32_t* __restrict__ status, unsigned long long* __restrict__ prof) {
     __shared__ Lds L;
     // measurement hook (BDX_KZ_PROF, tools/bamdec_probe.py): per member {cycles in all, in headers + tables, steps, matches, slow codes, deflate blocks}
-    unsigned long long t_begin = 0, t_tables = 0, n_steps = 0, n_match = 0, n_slow = 0, n_dblk = 0;
+    unsigned long long t_begin = 0, t_tables = 0;
+    uint32_t n_steps = 0, n_match = 0, n_slow = 0, n_dblk = 0;
     if (prof) t_begin = __builtin_readcyclecounter();
     const uint32_t b = blockIdx.x;
     if (b >= nblk) return;
@@ -326,32 +330,90 @@ __global__ __launch_bounds__(64, 7) void kz_inflate_kernel(const uint8_t* __rest
             ++n_steps;
             if (bitpos > bit_limit) { err = KZ_INPUT_OVERRUN; break; }
             KZ_ENSURE(bitpos >> 3);
-            // every lane's candidate symbol, and the distance entry behind it if it is a length code
+            // Every lane decodes the token that would start at its bit: a literal, or a whole length/distance pair (length
+            // code, its extra bits, the distance code from the table, its extra bits -- 36 bits at most, all within the 64 the
+            // lane holds).  Tokens the tables do not resolve (codes longer than their index, the end-of-block code) stop the chain.
             const uint64_t wl = ring_peek(L.ibuf, bitpos + lane);
-            const uint32_t e = L.lit[(uint32_t)wl & ((1u << kLB) - 1)];
-            const bool lit = t_kind(e) == T_LIT;
-            const uint32_t nxt = lit ? lane + t_len(e) : 128u + lane;   // where the chain goes from here; >= 128: it stops here
-            const uint32_t de = L.dist[(uint32_t)(wl >> (t_len(e) + length_extra(t_value(e) & 31u))) & ((1u << kDB) - 1)];
-            // the chain of literals that starts at the cursor
-            uint32_t cur = 0;
+            const uint32_t w_lo = (uint32_t)wl, w_hi = (uint32_t)(wl >> 32);
+            const uint32_t e = L.lit[w_lo & ((1u << kLB) - 1)];
+            const uint32_t l1 = t_len(e), ek = t_kind(e), ev = t_value(e);
+            const uint32_t ls = ev & 31u;
+            const uint32_t lx = length_extra(ls);
+            const uint32_t lbase = ls < 8 ? 3 + ls : (ls == 28 ? 258u : 3 + ((4 + (ls & 3)) << lx));
+            const uint32_t a1 = __builtin_amdgcn_alignbit(w_hi, w_lo, l1);            // the bits behind the length code (l1 <= 10)
+            const uint32_t mlen = lbase + (a1 & ((1u << lx) - 1));
+            const uint32_t de = L.dist[(a1 >> lx) & ((1u << kDB) - 1)];
+            const uint32_t dl = t_len(de), ds = t_value(de) & 31u;
+            const uint32_t dx = ds < 4 ? 0u : (ds >> 1) - 1;
+            const uint32_t dbase = ds < 4 ? 1 + ds : 1 + ((2 + (ds & 1)) << dx);
+            const uint32_t a2 = __builtin_amdgcn_alignbit(w_hi, w_lo, l1 + lx + dl);  // the distance's extra bits (l1 + lx + dl <= 23)
+            const uint32_t mdist = dbase + (a2 & ((1u << dx) - 1));
+            const bool is_lit = ek == T_LIT;
+            const bool is_match = ek == T_SYM && t_kind(de) == T_SYM;
+            const uint32_t olen = is_lit ? 1u : mlen;                                   // bytes the token produces
+            const uint32_t nxt = (is_lit || is_match) ? lane + (is_lit ? l1 : l1 + lx + dl + dx) : 128u + lane;   // >= 128: the chain stops here
+            // matches of the usual kind -- at most 64 bytes, source not overlapping the destination, inside the window -- are copied
+            // without a branch; pk carries what the copy needs in one register
+            const bool easy = is_match && mlen <= 64 && mdist >= mlen && mdist <= kNearDist;
+            const uint32_t pk = mdist | (mlen << 16) | (easy ? 0x80000000u : 0u);
+            // The chain of tokens that starts at the cursor; offv: where each token's output begins, relative to outpos.  nxt < 64:
+            // the token at cur is taken and the chain goes on at nxt; 64 <= nxt < 128: taken, and the window is used up; >= 128:
+            // the chain stops in front of the token at cur.  It also ends once kStepCap bytes have been produced.
+            uint32_t cur = 0, o = 0, nn;
             uint64_t mask = 0;
-            bool stopped = false;
+            int offv = 0;
             for (;;) {
-                const uint32_t nn = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)cur);
-                if (nn >= 128) { stopped = true; break; }
+                nn = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)cur);
+                if (nn >= 64) break;
+                offv = lane == cur ? (int)o : offv;   // (two vector instructions; the scalar slot is what is scarce)
                 mask |= 1ull << cur;
+                o += (uint32_t)__builtin_amdgcn_readlane((int)olen, (int)cur);
                 cur = nn;
-                if (cur >= 64) break;
+                if (o >= kStepCap) { nn = 256; break; }   // (256: ended by the cap, nothing pending at cur)
+            }
+            bool stopped = false;
+            if (nn < 128) {   // the last token of the window
+                offv = lane == cur ? (int)o : offv;
+                mask |= 1ull << cur;
+                o += (uint32_t)__builtin_amdgcn_readlane((int)olen, (int)cur);
+                cur = nn;
+            } else if (nn < 256) {
+                stopped = true;
             }
             const uint32_t pos = cur;
-            const uint32_t nlit = (uint32_t)__builtin_popcountll(mask);
-            if (nlit) {
-                if (nlit > ulen - outpos) { err = KZ_OUTPUT_OVERRUN; break; }
-                if ((mask >> lane) & 1) {
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-                    L.obuf[(outpos + rank) & kOBM] = (uint8_t)t_value(e);
+            if (mask) {
+                if (o > ulen - outpos) { err = KZ_OUTPUT_OVERRUN; break; }
+                const bool on = (mask >> lane) & 1;
+                if (on && is_lit) L.obuf[(outpos + (uint32_t)offv) & kOBM] = (uint8_t)ev;
+                // the matches, in stream order (a later one may copy what an earlier one, or a literal of this step, produced)
+                uint64_t mm = mask & __ballot(is_match);
+                if (__ballot(on && is_match && mdist > outpos + (uint32_t)offv)) { err = KZ_BAD_DISTANCE; break; }   // a source before the member's first byte
+                n_match += (uint32_t)__builtin_popcountll(mm);
+                lds_order();
+                while (mm) {
+                    const uint32_t m = (uint32_t)__builtin_ctzll(mm);
+                    mm &= mm - 1;
+                    const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)m);
+                    const uint32_t dst = outpos + (uint32_t)__builtin_amdgcn_readlane(offv, (int)m);
+                    const uint32_t length = (k >> 16) & 0x1FFu, dist = k & 0xFFFFu;
+                    if (k >> 31) {
+                        const uint8_t v = L.obuf[(dst - dist + lane) & kOBM];
+                        L.obuf[lane < length ? ((dst + lane) & kOBM) : kOB + lane] = v;   // (lanes beyond the match write to a dump area)
+                    } else if (dist <= kNearDist) {
+                        if (dist >= length) {
+                            for (uint32_t i = lane; i < length; i += 64) L.obuf[(dst + i) & kOBM] = L.obuf[(dst - dist + i) & kOBM];
+                        } else {
+                            for (uint32_t i = lane; i < length; i += 64) L.obuf[(dst + i) & kOBM] = L.obuf[(dst - dist + i % dist) & kOBM];
+                        }
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        const uint8_t* src = out + dst - dist;
+                        for (uint32_t i = lane; i < length; i += 64)
+                            L.obuf[(dst + i) & kOBM] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    lds_order();
                 }
-                outpos += nlit;
+                outpos += o;
             }
             bitpos += pos;
             if (!stopped) { KZ_FLUSH(); continue; }
@@ -387,25 +449,25 @@ __global__ __launch_bounds__(64, 7) void kz_inflate_kernel(const uint8_t* __rest
             ws >>= used;
             if (kind == T_EOB) { bitpos += used; break; }
             ++n_match;
-            uint32_t lbase, lx;
-            length_of(lsym, &lbase, &lx);
-            const uint32_t length = lbase + ((uint32_t)ws & ((1u << lx) - 1));
-            ws >>= lx;
-            used += lx;
-            uint32_t dsym = t_value(sde), dl = t_len(sde);
+            uint32_t sbase, sx;
+            length_of(lsym, &sbase, &sx);
+            const uint32_t length = sbase + ((uint32_t)ws & ((1u << sx) - 1));
+            ws >>= sx;
+            used += sx;
+            uint32_t dsym = t_value(sde), sdl = t_len(sde);
             if (t_kind(sde) != T_SYM) {
                 uint32_t sym = 0;
-                dl = uni(canon_decode(ws, L.dist_cnt, L.dist_sorted, &sym));
-                if (dl == 0) { err = KZ_BAD_CODE; break; }
+                sdl = uni(canon_decode(ws, L.dist_cnt, L.dist_sorted, &sym));
+                if (sdl == 0) { err = KZ_BAD_CODE; break; }
                 dsym = uni(sym);
                 if (dsym > 29) { err = KZ_BAD_CODE; break; }
             }
-            ws >>= dl;
-            used += dl;
-            uint32_t dbase, dx;
-            distance_of(dsym, &dbase, &dx);
-            const uint32_t dist = dbase + ((uint32_t)ws & ((1u << dx) - 1));
-            used += dx;
+            ws >>= sdl;
+            used += sdl;
+            uint32_t sdbase, sdx;
+            distance_of(dsym, &sdbase, &sdx);
+            const uint32_t dist = sdbase + ((uint32_t)ws & ((1u << sdx) - 1));
+            used += sdx;
             bitpos += used;
             if (dist > outpos) { err = KZ_BAD_DISTANCE; break; }
             if (length > ulen - outpos) { err = KZ_OUTPUT_OVERRUN; break; }

@@ -394,6 +394,7 @@ size_t produce_on_device(const BamConfig& cfg, const std::string& chr, int threa
     const size_t kPiece = getenv("BDX_BAM_PIECE_BYTES") ? (size_t)std::max(1ll, atoll(getenv("BDX_BAM_PIECE_BYTES"))) : ((size_t)16 << 20);
     const size_t rest = file_size - std::min(file_size, member_off);
     p.batch_bytes = std::min<size_t>((size_t)256 << 20, ((rest + ((size_t)1 << 20)) >> 20) << 20);
+    p.expected_bytes = rest;
     p.batch_blocks = getenv("BDX_BAM_BATCH_BLOCKS") ? (size_t)std::max(1ll, atoll(getenv("BDX_BAM_BATCH_BLOCKS"))) : 0;
     // four batches of inflated bytes: a batch is at most ~8192 + a piece's members of 64 KiB, or the whole file (assume <= 16 x its size)
     p.ring_bytes = std::min<size_t>((size_t)3 << 30, std::max<size_t>((size_t)64 << 20, rest * 64));

@@ -381,6 +381,10 @@ typedef struct bdx_bamdec_params {
     size_t ring_bytes;            /* inflated bytes kept in flight (at least four batches' worth), 0: 3 GiB */
     size_t batch_bytes;           /* compressed bytes and members after which the pieces gathered so far are launched as one batch */
     size_t batch_blocks;          /* (0: 256 MiB / 8192 members -- more members than the GPU has wave slots for the inflate kernel) */
+    size_t expected_bytes;        /* compressed bytes the caller is going to submit (the file's size), 0: unknown.  With a sink whose
+                                     store is still empty the decoder sizes the store from it, and once the first batch has shown how
+                                     many records the bytes hold, the buffers of the stages behind pass 1 (what bdx_reserve does up
+                                     front) -- while the GPU inflates, not in front of it */
 } bdx_bamdec_params;
 int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* p);
 void bdx_bamdec_destroy(bdx_bamdec* d);
