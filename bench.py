@@ -56,7 +56,11 @@ def parse():
     ap.add_argument("--dry", action="store_true", help="rendezvous only (no GPU work): prints the world the ranks see")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip timings (ii) and (iii)")
-    ap.add_argument("--no-exchange", action="store_true", help="N > 1: skip the untimed whole-genome -t run over all ranks")
+    ap.add_argument("--no-exchange", "--no-genome", dest="no_exchange", action="store_true",
+                    help="skip the sharded whole-genome runs over all ranks (config.genome)")
+    ap.add_argument("--genome-fraction", type=float, default=GENOME_FRACTION, help="hg38 lengths x this for the genome leg (default 1/8: 116 M records)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 --pmc sub-run that measures roofline.traffic")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-parallel", type=int, default=-1,
                     help="processes of the README's one-process-per-chromosome mode in cpu_baseline (default: min(usable CPUs, 24), "
                          "bounded by free memory; 0 = skip)")
@@ -259,70 +263,192 @@ def time_host_soa(bda, Options, LibraryConfig, LIB_C2, d, n, local, torch):
                     % (n, bytes_per_read - lazy, bytes_per_read)}
 
 
+def measure_k1_traffic(length):
+    """HBM bytes of one launch of the dominant kernel, measured in THIS run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: one
+    counter per pass, as MI355X_MICROARCH.md prescribes) around a short child run of this script on the same workload.  gfx950
+    correction from the same guide: bytes read = FETCH_SIZE x 2 (the counter counts 64-byte units of 128-byte requests), both
+    counters in KB.  None if rocprofv3 is not there or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    rp = shutil.which("rocprofv3")
+    if not rp:
+        return None, "rocprofv3 not found"
+    vals = {}
+    with tempfile.TemporaryDirectory(prefix="bdx_pmc_", dir="/tmp") as td:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            od = os.path.join(td, c)
+            cmd = [rp, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", od, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-end-to-end", "--no-genome", "--no-pmc", "--length", str(length)]
+            try:
+                p = subprocess.run(cmd, cwd=td, env=dict(os.environ, TMPDIR=td), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+            except subprocess.TimeoutExpired:
+                return None, "%s pass timed out" % c
+            if p.returncode != 0:
+                return None, "%s pass failed: %s" % (c, p.stderr.decode()[-200:])
+            acc = []
+            for f in glob.glob(os.path.join(od, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "k1_classify_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c:
+                        acc.append(float(r["Counter_Value"]))
+            if not acc:
+                return None, "no %s rows for the classifier" % c
+            vals[c] = float(np.mean(acc))
+    return {"FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
+            "hbm_bytes_per_launch": int(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024)}, None
+
+
 def time_bam_cli(bam, cfg, n):
-    """(iii) BAM -> SV table through the CLI (process start to exit, page cache warm)"""
-    env = dict(os.environ, BDX_TIMING="1")
-    best = None
-    for _ in range(3):
-        t0 = time.perf_counter()
-        p = subprocess.run([os.path.join(ROOT, "bin", "breakdancer-max"), cfg], cwd=os.path.dirname(cfg), env=env,
-                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-        dt = time.perf_counter() - t0
-        if p.returncode != 0:
-            return {"error": p.stderr.decode()[-400:]}
-        rows = sum(1 for line in p.stdout.splitlines() if line and not line.startswith(b"#"))
-        tl = [x for x in p.stderr.decode().splitlines() if x.startswith("[bdx timing]")]
-        if best is None or dt < best[0]:
-            best = (dt, rows, tl[-1] if tl else "")
-    return {"seconds": best[0], "value": (n / 2) / best[0], "unit": "read-pairs/s", "sv_rows": best[1], "bam_bytes": os.path.getsize(bam),
-            "cli_breakdown": best[2],
-            "note": "bin/breakdancer-max <cfg> on the configs[1] chromosome as one BAM (%d records), process start to exit, best of 3" % n}
+    """(iii) BAM -> SV table through the CLI (process start to exit, page cache warm), best of 3 per reader: the default (a one-BAM
+    configuration is inflated and decoded on the GPU) and the host reader (BDX_DECODE=host) at the CPUs the container grants"""
+    def run(env_extra, label):
+        env = dict(os.environ, BDX_TIMING="1", **env_extra)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            p = subprocess.run([os.path.join(ROOT, "bin", "breakdancer-max"), cfg], cwd=os.path.dirname(cfg), env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            dt = time.perf_counter() - t0
+            if p.returncode != 0:
+                return {"error": p.stderr.decode()[-400:]}
+            rows = sum(1 for line in p.stdout.splitlines() if line and not line.startswith(b"#"))
+            tl = [x for x in p.stderr.decode().splitlines() if x.startswith("[bdx timing]")]
+            if best is None or dt < best[0]:
+                best = (dt, rows, tl)
+        return {"seconds": best[0], "value": (n / 2) / best[0], "unit": "read-pairs/s", "sv_rows": best[1], "reader": label, "cli_breakdown": best[2][:-1]}
+    dev = run({}, "device: BGZF inflate + record decode on the GPU (bdx_bamdec_*)")
+    if "error" in dev:
+        return dev
+    cpus = usable_cpus()
+    host = run({"BDX_DECODE": "host"}, "host: fast_inflate / zlib on %d decode threads (2 x the %d CPUs granted)" % (min(max(2 * cpus, 4), 64), cpus))
+    inflated = None
+    try:  # the file's inflated size (sum of the members' ISIZE words), for MB/s figures
+        from breakdancer_amd import bamdec
+        img = np.memmap(bam, dtype=np.uint8, mode="r")
+        inflated = int(bamdec.scan_bgzf(img)["inflated_len"].astype(np.int64).sum())
+    except Exception:  # noqa: BLE001
+        pass
+    out = dict(dev)
+    out.update({"bam_bytes": os.path.getsize(bam), "inflated_bytes": inflated, "usable_cpus": cpus, "host_reader": host,
+                "note": "bin/breakdancer-max <cfg> on the configs[1] chromosome as one BAM (%d records), process start to exit, best of 3; "
+                        "`seconds` / `value` are the default reader's" % n})
+    if inflated and "seconds" in host:
+        out["host_reader"]["inflate_mb_per_s_per_cpu"] = inflated / 1e6 / host["seconds"] / cpus
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# N > 1: one whole-genome run with -t over all ranks -- the path's one real exchange step (untimed extra)
+# One whole-genome run over all ranks of this launch (bdx_dist_*): what sharding by chromosome costs and buys
 # ---------------------------------------------------------------------------------------------------------------------
-EXCHANGE_CHROM_LEN = 5_000_000
-EXCHANGE_TRANSLOCATIONS_PER_RANK = 250
+# hg38 primary assembly, chr1-22, X, Y (Mbp); the genome leg runs it at GENOME_FRACTION of its length: 1/8 = 387 Mbp,
+# 116 M records at 30x -- one GPU's share of configs[2] when N = 1, a strong-scaling problem of fixed size for N > 1
+HG38_MBP = [248.96, 242.19, 198.30, 190.21, 181.54, 170.81, 159.35, 145.14, 138.39, 133.80, 135.09, 133.28, 114.36, 107.04,
+            101.99, 90.34, 83.26, 80.37, 58.62, 64.44, 46.71, 50.82, 156.04, 57.23]
+GENOME_FRACTION = 1.0 / 8
+LIBS4 = ((400.0, 30.0), (350.0, 40.0), (500.0, 50.0), (300.0, 25.0))
 
 
-def whole_genome_exchange(rank, world, local, dist, out, chroms_per_rank=1):
-    """configs[3] in miniature over the N GPUs of this run: every rank owns one 5 Mbp chromosome of a genome with planted
-    translocations between all of them; `-t` keeps only inter-chromosomal pairs, whose join records cross ranks in ONE
-    all-to-all over RCCL (bdx_dist_run, csrc/bdx_dist_impl.h).  Fills `out` on rank 0."""
+def genome_leg(rank, world, local, dist, out, fraction=GENOME_FRACTION, translocations=5000):
+    """configs[2] and configs[3] as ONE sharded run each over the N ranks of this launch: hg38-shaped genome, 4 libraries, 30x,
+    chromosomes dealt to the ranks by bdx_dist_plan (longest processing time first, on sequence length); every rank synthesises
+    and loads its own chromosomes, then all call bdx_dist_run (csrc/bdx_dist_impl.h: all-reduces of the pass-1 statistics, ONE
+    all-to-all of the inter-chromosomal join records, gather + walk on rank 0).  Timed between barriers, max over ranks; total
+    work is the same for every N (strong scaling).  The second run has 5,000 planted translocations and -t.  Fills `out` on rank 0."""
     import torch
     from breakdancer_amd import dist as D
     from breakdancer_amd.api import LibraryConfig, Options
-    from breakdancer_amd.synth import LIB_C2, make_genome
-    ntr = EXCHANGE_TRANSLOCATIONS_PER_RANK * world
-    nchrom = world * chroms_per_rank
-    mine = set(range(rank * chroms_per_rank, (rank + 1) * chroms_per_rank))
-    d = make_genome([EXCHANGE_CHROM_LEN] * nchrom, coverage=30.0, seed=77, n_translocations=ntr, only_tids=mine)
-    run = D.DistRun.from_process_group(Options(transchr_rearrange=True), [LibraryConfig(**LIB_C2)], 1, nchrom, 200, local)
-    for t in sorted(mine):
-        m = d["tid"] == t
-        run.chromosome(t).push_reads({k: v[m] for k, v in d.items()})
-    torch.cuda.synchronize()
-    dist.barrier()
-    t0 = time.perf_counter()
-    run.run()
-    torch.cuda.synchronize()
-    dist.barrier()
-    dt = time.perf_counter() - t0
-    ex = run.exchange()
-    stats = torch.tensor([ex["ctx_records_sent"], ex["ctx_records_received"], len(d["tid"])], dtype=torch.int64,
-                         device=torch.device("cpu") if SHARED_GPU_TEST else torch.device("cuda", local))
-    dist.all_reduce(stats)
+    from breakdancer_amd.synth import make_genome
+    lengths = [int(m * 1e6 * fraction) for m in HG38_MBP]
+    ntids = len(lengths)
+    rank_of = D.plan(lengths, world)
+    mine = set(t for t in range(ntids) if rank_of[t] == rank)
+    libs = [LibraryConfig(mean_insertsize=m, std_insertsize=sd, uppercutoff=m + 3 * sd, lowercutoff=m - 3 * sd, readlens=100.0, name="lib%d" % i)
+            for i, (m, sd) in enumerate(LIBS4)]
+    cpu_dev = torch.device("cpu") if (SHARED_GPU_TEST or dist is None) else torch.device("cuda", local)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def allsum(vals):
+        t = torch.tensor(vals, dtype=torch.int64, device=cpu_dev)
+        if dist is not None:
+            dist.all_reduce(t)
+        return [int(x) for x in t.tolist()]
+
+    def allmax(val):
+        t = torch.tensor([val], dtype=torch.float64, device=cpu_dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    tg = time.perf_counter()
+    d = make_genome(lengths, coverage=30.0, seed=11, libs=LIBS4, lib_bam=(0, 0, 0, 0), n_translocations=translocations, only_tids=mine)
+    gen_s = time.perf_counter() - tg
+    n_mine = len(d["tid"])
+    per_rank = [0] * world
+    per_rank[rank] = n_mine
+    per_rank = allsum(per_rank)
+    total = sum(per_rank)
+    legs = {}
+    threads_backend = SHARED_GPU_TEST and world > 1   # (test hook: RCCL refuses two ranks on one device; rank 0 drives all ranks as threads)
+    if threads_backend:
+        d_all = make_genome(lengths, coverage=30.0, seed=11, libs=LIBS4, lib_bam=(0, 0, 0, 0), n_translocations=translocations) if rank == 0 else None
+    for label, opts in (("default_options", Options()), ("t_option", Options(transchr_rearrange=True))):
+        if threads_backend:
+            if rank == 0:
+                ranks = D.DistRun.threads(opts, libs, 1, ntids, 200, [local] * world)
+                for t in range(ntids):
+                    m = d_all["tid"] == t
+                    if m.any():
+                        ranks[rank_of[t]].chromosome(t).push_reads({k: v[m] for k, v in d_all.items()})
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                res = D.run_threads(ranks)
+                dt = time.perf_counter() - t0
+                ex = ranks[0].exchange()
+                sm = res.summary()
+                legs[label] = {"seconds": dt, "value": total / 2 / dt, "unit": "read-pairs/s", "svs_printed": sm["n_svs_printed"], "regions": sm["n_regions"],
+                               "ctx_records_exchanged": sum(r.exchange()["ctx_records_sent"] for r in ranks), "gathered_bytes_on_rank0": ex["gathered_bytes"],
+                               "rank0_ms_exchange_and_ctx_join": ex["ms_exchange"], "bdx_dist_run_ms_per_rank": [r.exchange()["ms_total"] for r in ranks]}
+                for r in ranks:
+                    r.close()
+            continue
+        if dist is None:
+            run = D.DistRun.create(opts, libs, 1, ntids, 200, local, 0, 1, D.unique_id())
+        else:
+            run = D.DistRun.from_process_group(opts, libs, 1, ntids, 200, local)
+        tl = time.perf_counter()
+        for t in sorted(mine):
+            m = d["tid"] == t
+            run.chromosome(t).push_reads({k: v[m] for k, v in d.items()})
+        barrier()
+        load_s = time.perf_counter() - tl
+        t0 = time.perf_counter()
+        run.run()
+        barrier()
+        dt = allmax(time.perf_counter() - t0)
+        ex = run.exchange()
+        stats = allsum([ex["ctx_records_sent"], ex["ctx_records_received"]])
+        rank_ms = [0] * world
+        rank_ms[rank] = int(ex["ms_total"] * 1000)
+        rank_ms = allsum(rank_ms)
+        if rank == 0:
+            sm = run.result().summary()
+            legs[label] = {"seconds": dt, "value": total / 2 / dt, "unit": "read-pairs/s", "svs_printed": sm["n_svs_printed"], "regions": sm["n_regions"],
+                           "ctx_records_exchanged": stats[0], "gathered_bytes_on_rank0": ex["gathered_bytes"],
+                           "rank0_ms_exchange_and_ctx_join": ex["ms_exchange"], "bdx_dist_run_ms_per_rank": [x / 1000.0 for x in rank_ms],
+                           "load_seconds_untimed": load_s}
+        run.close()
     if rank == 0:
-        s = run.result().summary()
-        out.update({"ranks": world, "backend": "RCCL (ncclAllReduce, ncclAllToAllv, grouped ncclSend/ncclRecv on device buffers)",
-                    "workload": "one genome, %d chromosomes of %d Mbp at 30x (%d per rank), %d planted translocations, -t"
-                                % (nchrom, EXCHANGE_CHROM_LEN // 1000000, chroms_per_rank, ntr),
-                    "reads": int(stats[2]), "seconds": dt, "value": int(stats[2]) / 2 / dt, "unit": "read-pairs/s",
-                    "ctx_records_exchanged": int(stats[0]), "ctx_records_received": int(stats[1]),
-                    "rank0_ms_total": ex["ms_total"], "rank0_ms_exchange_and_ctx_join": ex["ms_exchange"],
-                    "ctx_svs_printed": s["n_svs_printed"], "planted_translocations": ntr})
-    run.close()
+        out.update({"ranks": world, "scaling": "strong",
+                    "backend": ("ranks as threads of rank 0's process sharing one device (test hook)" if threads_backend else
+                                "RCCL (ncclAllReduce, ncclAllToAllv, grouped ncclSend/ncclRecv on device buffers)"),
+                    "workload": "hg38-shaped genome at %.3g of its length (%d Mbp), 24 chromosomes, 4 libraries, 30x, %d planted translocations; "
+                                "chromosomes -> ranks by bdx_dist_plan" % (fraction, int(sum(lengths) / 1e6), translocations),
+                    "reads": total, "reads_per_rank": per_rank, "lpt_imbalance_max_over_mean": max(per_rank) / (total / world),
+                    "synthesis_seconds_untimed": gen_s, **legs})
 
 
 def main():
@@ -437,7 +563,7 @@ def main():
             stage[k] = stage.get(k, 0.0) + v
     bd.set_stage_timing(False)
     overlapped = None
-    if world == 1 and len(ctxs) == 1 and a.overlap:
+    if world == 1 and len(ctxs) == 1 and not a.pmc_child:   # (always: three contexts in flight is how a whole-genome caller keeps one GPU busy)
         import threading
         more = [bd, new_ctx(), new_ctx()]
         for x in more:
@@ -461,38 +587,34 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cpu") if SHARED_GPU_TEST else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    # untimed extra for N > 1: the sharded whole-genome -t run, whose CTX records cross ranks over RCCL.  It runs on a
-    # helper thread under a watchdog: whatever happens to it, the line below is printed.
+    # The sharded whole-genome runs (config.genome): timed by their own barriers, outside the K timed steps above.  They run on a
+    # helper thread under a watchdog: whatever happens to them -- RCCL with more than one rank runs here first -- the line is printed.
     exchange, exchange_hung = {}, False
-    if world > 1 and not a.no_exchange:
+    if not a.no_exchange and not a.pmc_child:
         import threading
 
         def guarded():
             try:
-                whole_genome_exchange(rank, world, local, dist, exchange)
+                genome_leg(rank, world, local, dist, exchange, fraction=a.genome_fraction)
             except Exception as e:  # noqa: BLE001
                 exchange["error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
         th = threading.Thread(target=guarded, daemon=True)
         th.start()
-        th.join(180)
+        th.join(600)
         if th.is_alive():
             exchange_hung = True
-            exchange["error"] = "no result after 180 s"
+            exchange["error"] = "no result after 600 s"
 
     if rank == 0:
         pairs = n // 2
         value = world * pairs * a.steps / dt
         k1_avg_ms = float(np.mean(k1_ms))
         achieved = ALGO_BYTES_PER_READ * n / (k1_avg_ms * 1e-3) / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "k1_traffic.json")
-        if os.path.exists(tp):
-            try:
-                tj = json.load(open(tp))
-                if tj.get("reads_per_launch") == n:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_note, traffic_detail = None, None, None
+        if world == 1 and not a.no_pmc and not a.pmc_child:
+            traffic_detail, traffic_note = measure_k1_traffic(a.length)
+            if traffic_detail:
+                traffic = traffic_detail["hbm_bytes_per_launch"]
         timings = {"hbm_resident": {"seconds": dt / a.steps, "value": value / world, "unit": "read-pairs/s",
                                     "note": "= `value` per GPU: one bdx_run on records already in HBM"}}
         cpu = None
@@ -513,7 +635,8 @@ def main():
                 if not a.no_cpu_baseline:
                     cpu = cpu_baseline(bam, n, a.cpu_parallel)
         out = {
-            "metric": "anomalous read-pairs/s (end-to-end SV call)", "value": value, "unit": "read-pairs/s",
+            "metric": "read-pairs/s, records resident in HBM -> scored SV table (SURVEY 8d timing i; BAM -> table is config.timings.bam_to_table)",
+            "value": value, "unit": "read-pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "configs[1]: synthetic single chromosome %d Mbp, 30x, 2x100 bp, 1 library, ~1%% discordant "
@@ -531,7 +654,10 @@ def main():
                        "stage_ms_profiled_steps": {k: v / 3 for k, v in stage.items()},
                        "sv_candidates": dict(zip(("assembled_on_device", "from_host_walk", "groups_to_host_walk", "device_placed_by_order_key"), split))},
             "roofline": {"bound": "hbm", "kernel": "k1_classify_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_READ * n,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE sub-runs of this invocation (FETCH_SIZE x 2 on gfx950): %s" % json.dumps(traffic_detail)
+                                            if traffic_detail else "not measured: %s" % (traffic_note or "skipped (--no-pmc, N > 1)")),
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_READ * n,
                          "avg_kernel_ms": k1_avg_ms,
                          # the same kernel by the bytes it really moves (PMC, `traffic`): fewer than the algorithmic figure, which
                          # counts 2 B/read of read length the classifier never needs and, with one library and one file as here,
@@ -545,9 +671,9 @@ def main():
                                         "frac": value / world * PATH_BYTES_PER_PAIR / 1e9 / HBM_PEAK_GBS}},
         }
         if overlapped:
-            out["config"]["overlapped_contexts_untimed"] = overlapped
-        if world > 1 and not a.no_exchange:
-            out["config"]["whole_genome_exchange_untimed"] = exchange
+            out["config"]["overlapped_contexts"] = overlapped
+        if not a.no_exchange and not a.pmc_child:
+            out["config"]["genome"] = exchange
         if SHARED_GPU_TEST:
             out["config"]["test_hook"] = "BDX_BENCH_TEST_SHARED_GPU: all ranks on device 0, gloo process group -- not a measurement"
         if cpu:
