@@ -1390,6 +1390,30 @@ int collect_support(bdx_ctx* c, uint32_t ph) {
     return BDX_OK;
 }
 
+// The read-level replay (H2) over compact records in stream order -- name key, accepted region id (or -1), meta, |isize| -- on the
+// context's region table (c->reg / c->rpk) and pass-1 statistics; scores from K5.  Shared by the single-context replay below and
+// by rank 0 of a sharded run, which gathers the records of all chromosomes first.
+int replay_arrays(bdx_ctx* c, uint32_t na, const uint64_t* key, const int32_t* region_of, const uint32_t* meta, const int32_t* isize, uint32_t ph,
+                  std::vector<uint32_t>* sup) {
+    ReadWalkInput ri{};
+    WalkInput& wi = ri.base;
+    wi.opts = c->opts; wi.libs = c->libs.data(); wi.nlibs = c->nlibs; wi.nbams = c->nbams; wi.nkeys = c->nkeys;
+    wi.hist = c->cnt.data(); wi.covered_ref_len = c->g_covered; wi.key_density = c->key_density.data();
+    wi.regions = c->reg; wi.nregions = c->nreg; wi.r_pk = c->rpk; wi.parts = nullptr; wi.last_maxq = c->counts.last_maxq;
+    wi.any_anomalous = na != 0;
+    ri.n_reads = na; ri.key = key; ri.region_of = region_of; ri.meta = meta; ri.isize = isize;
+    ri.phantom = ph;
+    if (sup) { ri.support_off = &c->sup_off; ri.support = sup; }
+    c->walk.clear();
+    read_level_walk(ri, c->walk);
+    c->counts.n_groups = 0; c->counts.n_pairs = 0;
+    int rc = score_host_terms(c);
+    if (rc == BDX_OK) rc = finish_host_walk(c);
+    if (rc != BDX_OK) return rc;
+    c->replayed = true;
+    return BDX_OK;
+}
+
 // A read name occurs more than twice (StageCounts::irregular): everything behind the region cut is replayed one read at a
 // time on the host (H2), from the compact records; the scores still come from K5.  Names clashing across merged BAMs are the
 // usual cause -- the reference keeps running on them (ReadRegionData.cpp:108-113), so does this.
@@ -1407,23 +1431,9 @@ int replay_reads(bdx_ctx* c, uint32_t ph) {
     if (ph)
         for (int32_t& r : region_of)
             if (r >= 0) r += (int32_t)ph;
-    ReadWalkInput ri{};
-    WalkInput& wi = ri.base;
-    wi.opts = c->opts; wi.libs = c->libs.data(); wi.nlibs = c->nlibs; wi.nbams = c->nbams; wi.nkeys = c->nkeys;
-    wi.hist = c->cnt.data(); wi.covered_ref_len = c->g_covered; wi.key_density = c->key_density.data();
-    wi.regions = c->reg; wi.nregions = c->nreg; wi.r_pk = c->rpk; wi.parts = nullptr; wi.last_maxq = c->counts.last_maxq;
-    wi.any_anomalous = na != 0;
-    ri.n_reads = na; ri.key = key.data(); ri.region_of = region_of.data(); ri.meta = meta.data(); ri.isize = isize.data();
-    ri.phantom = ph;
     std::vector<uint32_t> sup;
-    if (c->collect_support) { ri.support_off = &c->sup_off; ri.support = &sup; }
-    c->walk.clear();
-    read_level_walk(ri, c->walk);
-    c->counts.n_groups = 0; c->counts.n_pairs = 0;
-    int rc = score_host_terms(c);
-    if (rc == BDX_OK) rc = finish_host_walk(c);
+    int rc = replay_arrays(c, na, key.data(), region_of.data(), meta.data(), isize.data(), ph, c->collect_support ? &sup : nullptr);
     if (rc != BDX_OK) return rc;
-    c->replayed = true;
     if (c->collect_support) {  // compact indices -> stream indices and flags
         std::vector<uint32_t> idx(na);
         HIPCHK(c, hipMemcpy(idx.data(), c->cp.idx, (size_t)na * 4, hipMemcpyDeviceToHost));

@@ -177,11 +177,12 @@ int bam_feed_classifier(bdx_bamdec* d, bool final) {
         c->n = (size_t)d->confirmed;
         c->ran = false;
     }
-    if (!d->presized && d->confirmed_seq >= 1 && d->expected_bytes && d->first_batch_bytes) {
-        // the first batch's records per byte, applied to the whole file: the stages behind pass 1 get their buffers now, while
-        // the GPU is busy with the batches in flight (~60 allocations, tens of milliseconds of page pinning for a chromosome)
+    // The stages behind pass 1 get their buffers (~60 allocations, tens of milliseconds of page pinning for a chromosome) once the
+    // caller has handed over its last piece: the GPU still has the last batches to inflate, and the feeder has nothing else to do.
+    if (!d->presized && d->finished && d->confirmed_seq >= 1 && d->first_batch_bytes) {
         d->presized = true;
-        const double est = (double)d->confirmed * (double)d->expected_bytes / (double)d->first_batch_bytes * 1.05;
+        // the first batch's records per byte, applied to everything submitted
+        const double est = (double)d->confirmed / (double)std::min<uint64_t>(d->compressed_bytes, d->first_batch_bytes * d->confirmed_seq) * (double)d->compressed_bytes * 1.05;
         if (est >= (double)(1u << 20) && !c->ran) {
             const uint64_t prior = (uint64_t)est / 32 + 4096;
             if (prior <= kMaxRegions) {

@@ -207,6 +207,7 @@ struct bdx_dist {
     std::map<int, bdx_ctx*> chrom;   // the chromosomes this rank owns
     bdx_ctx* util = nullptr;         // joins the CTX records this rank owns, and on rank 0 walks and holds the result
     DevBuf b_words, b_cnt, b_send, b_recv, b_pack, b_all, b_gin;
+    DevBuf b_nsend, b_nrecv, b_ntab, b_ninfo, b_nft, b_nflag;   // the name census (k7_exchange.hip)
     std::string err;
     uint64_t ctx_sent = 0, ctx_received = 0, gathered_bytes = 0;
     float ms_total = 0, ms_exchange = 0;
@@ -303,7 +304,9 @@ void bdx_dist_destroy(bdx_dist* d) {
     (void)hipSetDevice(d->device);
     for (auto& kv : d->chrom) bdx_destroy(kv.second);
     if (d->util) bdx_destroy(d->util);
-    for (DevBuf* b : {&d->b_words, &d->b_cnt, &d->b_send, &d->b_recv, &d->b_pack, &d->b_all, &d->b_gin}) b->release();
+    for (DevBuf* b : {&d->b_words, &d->b_cnt, &d->b_send, &d->b_recv, &d->b_pack, &d->b_all, &d->b_gin, &d->b_nsend, &d->b_nrecv, &d->b_ntab, &d->b_ninfo,
+                      &d->b_nft, &d->b_nflag})
+        b->release();
     delete d;
 }
 
@@ -473,7 +476,8 @@ int bdx_dist_run(bdx_dist* d) {
     std::vector<uint64_t> v3((size_t)ntids * 2, 0);
     uint32_t* d_cnt = nullptr;      // [world] records per destination
     uint32_t* d_cur = nullptr;      // [world] scatter cursors
-    std::vector<uint32_t> h_cnt(world, 0);
+    uint32_t *d_ncnt = nullptr, *d_ncur = nullptr;
+    std::vector<uint32_t> h_cnt(world, 0), h_ncnt(world, 0);
     phase([&]() -> int {
         for (auto& kv : d->chrom) {
             bdx_ctx* c = kv.second;
@@ -488,19 +492,23 @@ int bdx_dist_run(bdx_dist* d) {
             v3[(size_t)kv.first * 2 + 1] = (uint32_t)c->counts.last_maxq;
         }
         // ---- joins: pairs within a chromosome where they are; CTX records to owner(name key) ----
-        DHIP(d, d->b_cnt.ensure((size_t)world * 8 + 64));
+        DHIP(d, d->b_cnt.ensure((size_t)world * 16 + 64));
         d_cnt = d->b_cnt.as<uint32_t>();
         d_cur = d_cnt + world;
-        DHIP(d, hipMemsetAsync(d_cnt, 0, (size_t)world * 4, us));
+        d_ncnt = d_cnt + 2 * world;    // the name census: every anomalous read's key
+        d_ncur = d_cnt + 3 * world;
+        DHIP(d, hipMemsetAsync(d_cnt, 0, (size_t)world * 16, us));
         DHIP(d, hipStreamSynchronize(us));
         // (the chromosomes' streams are independent: the counts are complete once each has been waited for, below)
         for (auto& kv : d->chrom) {
             bdx_ctx* c = kv.second;
             const uint32_t na = c->p1.n_anom;
             if (na) launch_k7_count(c->cp.key, c->cp.meta, &c->b_p1.as<Pass1>()->n_anom, na, (uint32_t)world, d_cnt, c->stream);
+            if (na) launch_k7_names_count(c->cp.key, &c->b_p1.as<Pass1>()->n_anom, na, (uint32_t)world, d_ncnt, c->stream);
         }
         for (auto& kv : d->chrom) DHIP(d, hipStreamSynchronize(kv.second->stream));
         DHIP(d, hipMemcpy(h_cnt.data(), d_cnt, (size_t)world * 4, hipMemcpyDeviceToHost));
+        DHIP(d, hipMemcpy(h_ncnt.data(), d_ncnt, (size_t)world * 4, hipMemcpyDeviceToHost));
         return BDX_OK;
     });
     rc = exchange(v3);
@@ -518,14 +526,19 @@ int bdx_dist_run(bdx_dist* d) {
     // failure still travels with it: the send buffer (sized by the rank's own counts), the chromosomes' own joins, the
     // packing of the CTX records per destination.
     std::vector<size_t> scount(world), sdispl(world), rcount(world), rdispl(world);
-    size_t nsend = 0, nrecv = 0;
+    std::vector<size_t> nscount(world), nsdispl(world), nrcount(world), nrdispl(world);   // the name census: two words per read
+    size_t nsend = 0, nrecv = 0, nnsend = 0, nnrecv = 0;
     for (int q = 0; q < world; ++q) { scount[q] = (size_t)h_cnt[q] * 3; sdispl[q] = nsend * 3; nsend += h_cnt[q]; }
+    for (int q = 0; q < world; ++q) { nscount[q] = (size_t)h_ncnt[q] * 2; nsdispl[q] = nnsend * 2; nnsend += h_ncnt[q]; }
     phase([&]() -> int {
         DHIP(d, d->b_send.ensure(std::max<size_t>(nsend, 1) * sizeof(ExchangeEntry)));
+        DHIP(d, d->b_nsend.ensure(std::max<size_t>(nnsend, 1) * 16));
         {
             std::vector<uint32_t> cur(world);
             for (int q = 0; q < world; ++q) cur[q] = (uint32_t)(sdispl[q] / 3);
             DHIP(d, hipMemcpy(d_cur, cur.data(), (size_t)world * 4, hipMemcpyHostToDevice));
+            for (int q = 0; q < world; ++q) cur[q] = (uint32_t)(nsdispl[q] / 2);
+            DHIP(d, hipMemcpy(d_ncur, cur.data(), (size_t)world * 4, hipMemcpyHostToDevice));
         }
         for (auto& kv : d->chrom) {
             bdx_ctx* c = kv.second;
@@ -538,15 +551,20 @@ int bdx_dist_run(bdx_dist* d) {
             DCTX(d, c, do_join_local(c, na, en, &c->b_p1.as<Pass1>()->n_anom, false));
             launch_k7_scatter(c->cp.key, c->k3.region_of, c->cp.meta, c->cp.isize, &c->b_p1.as<Pass1>()->n_anom, na, (uint32_t)world,
                               (uint32_t)base[(size_t)kv.first * tw], (int32_t)rbase[kv.first], d_cur, d->b_send.as<ExchangeEntry>(), c->stream);
+            launch_k7_names_scatter(c->cp.key, c->cp.meta, &c->b_p1.as<Pass1>()->n_anom, na, (uint32_t)world, (uint32_t)kv.first, d_ncur,
+                                    d->b_nsend.as<unsigned long long>(), c->stream);
         }
         for (auto& kv : d->chrom) DHIP(d, hipStreamSynchronize(kv.second->stream));
         return BDX_OK;
     });
-    std::vector<uint64_t> v4((size_t)world * world, 0);  // send-count matrix: row = sender
-    for (int q = 0; q < world; ++q) v4[(size_t)rank * world + q] = h_cnt[q];
+    std::vector<uint64_t> v4((size_t)world * world * 2, 0);  // send-count matrices (CTX records, census records): row = sender
+    const size_t W2 = (size_t)world * world;
+    for (int q = 0; q < world; ++q) { v4[(size_t)rank * world + q] = h_cnt[q]; v4[W2 + (size_t)rank * world + q] = h_ncnt[q]; }
     rc = exchange(v4);
     if (rc != BDX_OK) return rc;
     for (int q = 0; q < world; ++q) { rcount[q] = (size_t)v4[(size_t)q * world + rank] * 3; rdispl[q] = nrecv * 3; nrecv += v4[(size_t)q * world + rank]; }
+    for (int q = 0; q < world; ++q) { nrcount[q] = (size_t)v4[W2 + (size_t)q * world + rank] * 2; nrdispl[q] = nnrecv * 2; nnrecv += v4[W2 + (size_t)q * world + rank]; }
+    if (nnrecv > 0x7FFFFFFFull) return dfail(d, BDX_ELIMIT, "too many anomalous reads' names on one rank");
     {
         // (the column sums are the same table on every rank: the limit trips everywhere at once)
         for (int r = 0; r < world; ++r) {
@@ -560,13 +578,33 @@ int bdx_dist_run(bdx_dist* d) {
     // C4: the all-to-all of the CTX records (three 64-bit words each)
     if (!comm.alltoallv_u64(d->b_send.as<uint64_t>(), scount.data(), sdispl.data(), d->b_recv.as<uint64_t>(), rcount.data(), rdispl.data(), us))
         return leave(dfail(d, BDX_EHIP, comm.err));
+    if (d->b_nrecv.ensure(std::max<size_t>(nnrecv, 1) * 16) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "receive buffer of the name census"));
+    if (!comm.alltoallv_u64(d->b_nsend.as<uint64_t>(), nscount.data(), nsdispl.data(), d->b_nrecv.as<uint64_t>(), nrcount.data(), nrdispl.data(), us))
+        return leave(dfail(d, BDX_EHIP, comm.err));
     d->ctx_sent = nsend; d->ctx_received = nrecv;
     // join what arrived
     uint32_t ng_ctx = 0;
     auto t_x1 = std::chrono::steady_clock::now();
     size_t nreg_mine = 0, ng_mine = 0, pack_bytes = 0;
+    uint64_t irregular = 0;
     const size_t rrec = sizeof(RegionRec), rpk = (size_t)2 * nkeys * 4, grec = sizeof(GroupRec);
     phase([&]() -> int {
+        if (nnrecv) {   // the census of the names this rank owns
+            uint32_t slots = 1024;
+            while (slots < 2 * nnrecv) slots <<= 1;
+            DHIP(d, d->b_ntab.ensure((size_t)slots * 8)); DHIP(d, d->b_ninfo.ensure((size_t)slots * 8)); DHIP(d, d->b_nft.ensure((size_t)slots * 4));
+            DHIP(d, d->b_nflag.ensure(16));
+            DHIP(d, hipMemsetAsync(d->b_ntab.p, 0xFF, (size_t)slots * 8, us));
+            DHIP(d, hipMemsetAsync(d->b_ninfo.p, 0, (size_t)slots * 8, us));
+            DHIP(d, hipMemsetAsync(d->b_nft.p, 0xFF, (size_t)slots * 4, us));
+            DHIP(d, hipMemsetAsync(d->b_nflag.p, 0, 4, us));
+            launch_k7_names_census(d->b_nrecv.as<unsigned long long>(), (uint32_t)nnrecv, d->b_ntab.as<unsigned long long>(), d->b_ninfo.as<unsigned long long>(),
+                                   d->b_nft.as<uint32_t>(), slots - 1, d->b_nflag.as<uint32_t>(), us);
+            uint32_t flag = 0;
+            DHIP(d, hipMemcpyAsync(&flag, d->b_nflag.p, 4, hipMemcpyDeviceToHost, us));
+            DHIP(d, hipStreamSynchronize(us));
+            if (flag) irregular = 1;
+        }
         if (nrecv) {
             const uint32_t n32 = (uint32_t)nrecv;
             DHIP(d, U->b_x_key.ensure(nrecv * 8)); DHIP(d, U->b_x_order.ensure(nrecv * 4)); DHIP(d, U->b_x_region.ensure(nrecv * 4));
@@ -582,7 +620,7 @@ int bdx_dist_run(bdx_dist* d) {
             DHIP(d, hipMemcpyAsync(U->h_counts.p, U->b_counts.p, sizeof(StageCounts), hipMemcpyDeviceToHost, us));
             DHIP(d, hipStreamSynchronize(us));
             const StageCounts sc = *U->h_counts.as<StageCounts>();
-            if (sc.irregular) return dfail(d, BDX_ELIMIT, "a read name occurs more than twice among the inter-chromosomal reads: run the chromosomes in one context");
+            if (sc.irregular) irregular = 1;   // a read name seen more than twice: the run is replayed read by read on rank 0 (below)
             if (sc.overflow) return dfail(d, BDX_EINTERNAL, "group list overflow");
             ng_ctx = sc.n_groups;
         }
@@ -595,7 +633,7 @@ int bdx_dist_run(bdx_dist* d) {
             bdx_ctx* c = kv.second;
             if (!c->p1.n_anom) continue;
             DCTX(d, c, readback(c, true));
-            if (c->counts.irregular) return dfail(d, BDX_ELIMIT, "a read name occurs more than twice: run the chromosomes in one context");
+            if (c->counts.irregular) irregular = 1;
             nreg_mine += c->counts.n_regions;
             ng_mine += c->counts.n_groups;
         }
@@ -623,10 +661,12 @@ int bdx_dist_run(bdx_dist* d) {
         if (ng_ctx) DHIP(d, hipMemcpyAsync(p, U->k4.g_rec, (size_t)ng_ctx * grec, hipMemcpyDefault, us));
         return BDX_OK;
     });
-    std::vector<uint64_t> v5((size_t)world * 3, 0);
+    std::vector<uint64_t> v5((size_t)world * 3 + 1, 0);
     if (st.rc == BDX_OK) { v5[(size_t)rank * 3] = nreg_mine; v5[(size_t)rank * 3 + 1] = ng_mine; v5[(size_t)rank * 3 + 2] = pack_bytes; }
+    v5[(size_t)world * 3] = irregular;
     rc = exchange(v5);
     if (rc != BDX_OK) return rc;
+    const bool replay = v5[(size_t)world * 3] != 0;   // some rank met a read name more than twice
     std::vector<size_t> gcount(world), gdispl(world);
     size_t all_bytes = 0, ng_all = 0;
     for (int q = 0; q < world; ++q) { gcount[q] = (size_t)v5[(size_t)q * 3 + 2]; gdispl[q] = all_bytes; all_bytes += gcount[q]; ng_all += v5[(size_t)q * 3 + 1]; }
@@ -635,6 +675,63 @@ int bdx_dist_run(bdx_dist* d) {
     DHIP(d, hipStreamSynchronize(us));
     d->gathered_bytes = all_bytes;
     d->ms_exchange = ms_between(t_x0, t_x1);
+
+    // ---- a read name seen more than twice (clashing names across merged files): the pair model does not hold, and the reference's
+    // behaviour (ReadRegionData.cpp:108-113,152-175, SvBuilder.cpp:101-118) depends on the order of ALL sightings.  Every rank sends
+    // the compact records of its chromosomes (name key, genome-wide region id, meta, |isize|, tid: 24 bytes per anomalous read) to
+    // rank 0, which replays the run read by read (H2, bdx_walk_reads.cpp) on the gathered region table ----
+    std::vector<uint64_t> rp_host;   // rank 0: all ranks' records
+    std::vector<size_t> rp_count(world), rp_displ(world);
+    if (replay) {
+        std::vector<uint64_t> mine_rec;
+        phase([&]() -> int {
+            for (auto& kv : d->chrom) {
+                bdx_ctx* c = kv.second;
+                const uint32_t na = c->p1.n_anom;
+                if (!na) continue;
+                std::vector<uint64_t> key(na);
+                std::vector<int32_t> reg(na), isz(na);
+                std::vector<uint32_t> meta(na);
+                DHIP(d, hipStreamSynchronize(c->stream));
+                DHIP(d, hipMemcpy(key.data(), c->cp.key, (size_t)na * 8, hipMemcpyDeviceToHost));
+                DHIP(d, hipMemcpy(reg.data(), c->k3.region_of, (size_t)na * 4, hipMemcpyDeviceToHost));
+                DHIP(d, hipMemcpy(meta.data(), c->cp.meta, (size_t)na * 4, hipMemcpyDeviceToHost));
+                DHIP(d, hipMemcpy(isz.data(), c->cp.isize, (size_t)na * 4, hipMemcpyDeviceToHost));
+                const uint64_t rb = rbase[kv.first];
+                for (uint32_t j = 0; j < na; ++j) {
+                    const uint32_t g = reg[j] < 0 ? 0xFFFFFFFFu : (uint32_t)(reg[j] + (int64_t)rb);
+                    mine_rec.push_back(key[j]);
+                    mine_rec.push_back((uint64_t)g | ((uint64_t)meta[j] << 32));
+                    mine_rec.push_back((uint64_t)(uint32_t)isz[j] | ((uint64_t)(uint32_t)kv.first << 32));
+                }
+            }
+            DHIP(d, d->b_pack.ensure(std::max<size_t>(mine_rec.size() * 8, 8)));
+            if (!mine_rec.empty()) DHIP(d, hipMemcpyAsync(d->b_pack.p, mine_rec.data(), mine_rec.size() * 8, hipMemcpyHostToDevice, us));
+            DHIP(d, hipStreamSynchronize(us));
+            return BDX_OK;
+        });
+        std::vector<uint64_t> v6(world, 0);
+        if (st.rc == BDX_OK) v6[rank] = mine_rec.size() * 8;
+        rc = exchange(v6);
+        if (rc != BDX_OK) return rc;
+        size_t rp_bytes = 0;
+        for (int q = 0; q < world; ++q) { rp_count[q] = (size_t)v6[q]; rp_displ[q] = rp_bytes; rp_bytes += rp_count[q]; }
+        // (rank 0's region package is still in b_all: copy it out before the buffer takes the records)
+        std::vector<char> keep_regions;
+        if (rank == 0 && all_bytes) {
+            keep_regions.resize(all_bytes);
+            if (hipMemcpy(keep_regions.data(), d->b_all.p, all_bytes, hipMemcpyDeviceToHost) != hipSuccess) return leave(dfail(d, BDX_EHIP, "gather buffer"));
+        }
+        if (rank == 0 && d->b_all.ensure(std::max<size_t>(std::max(rp_bytes, all_bytes), 8)) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "gather buffer"));
+        if (!comm.gatherv_bytes(d->b_pack.p, mine_rec.size() * 8, d->b_all.p, rp_count.data(), rp_displ.data(), 0, us)) return leave(dfail(d, BDX_EHIP, comm.err));
+        DHIP(d, hipStreamSynchronize(us));
+        d->gathered_bytes += rp_bytes;
+        if (rank == 0) {
+            rp_host.resize(rp_bytes / 8);
+            if (rp_bytes) DHIP(d, hipMemcpy(rp_host.data(), d->b_all.p, rp_bytes, hipMemcpyDeviceToHost));
+            if (all_bytes) DHIP(d, hipMemcpy(d->b_all.p, keep_regions.data(), all_bytes, hipMemcpyHostToDevice));   // (read back below as usual)
+        }
+    }
 
     // (from here on nothing is collective any more: rank 0 finishes on its own)
     if (rank == 0) {
@@ -666,6 +763,33 @@ int bdx_dist_run(bdx_dist* d) {
         DCTX(d, U, set_pass1(U, cnt_g.data(), covered, window, true));
         U->n = 0;
         const int32_t lm = last_anom_tid >= 0 ? (int32_t)(uint32_t)v3[(size_t)last_anom_tid * 2 + 1] : 0;
+        if (replay) {
+            // the records of all chromosomes in stream order: chromosomes ascending, each rank's package holds its own in order
+            const uint64_t na_all = base[(size_t)ntids * tw];
+            if (rp_host.size() != (size_t)na_all * 3) return dfail(d, BDX_EINTERNAL, "compact records of the gather do not add up");
+            std::vector<uint64_t> key(na_all);
+            std::vector<int32_t> reg(na_all), isz(na_all);
+            std::vector<uint32_t> meta(na_all);
+            std::vector<uint64_t> at(ntids);
+            for (int t = 0; t < ntids; ++t) at[t] = base[(size_t)t * tw];
+            for (size_t i = 0; i < (size_t)na_all; ++i) {
+                const uint64_t w0 = rp_host[i * 3], w1 = rp_host[i * 3 + 1], w2 = rp_host[i * 3 + 2];
+                const uint32_t t = (uint32_t)(w2 >> 32);
+                if (t >= (uint32_t)ntids || at[t] >= base[(size_t)(t + 1) * tw]) return dfail(d, BDX_EINTERNAL, "compact records of the gather do not add up");
+                const size_t o = (size_t)at[t]++;
+                key[o] = w0; reg[o] = (int32_t)(uint32_t)w1; meta[o] = (uint32_t)(w1 >> 32); isz[o] = (int32_t)(uint32_t)w2;
+            }
+            // (a region's first read: its index in its chromosome's list -> in the genome-wide one)
+            for (size_t r = 0; r < NR; ++r) regs[r].first += (uint32_t)base[(size_t)regs[r].tid * tw];
+            decode_regions(U, regs.data(), pk.data(), (uint32_t)NR, 0, false);
+            U->counts.n_regions = (uint32_t)NR;
+            U->counts.last_maxq = lm;
+            DCTX(d, U, replay_arrays(U, (uint32_t)na_all, key.data(), reg.data(), meta.data(), isz.data(), 0, nullptr));
+            U->p1.n_anom = (uint32_t)na_all;
+            d->ran = true;
+            d->ms_total = ms_between(t_begin, std::chrono::steady_clock::now());
+            return BDX_OK;
+        }
         static const bool host_only = getenv("BDX_DIST_HOST_WALK") != nullptr;  // (A/B: the whole walk on the host, as in round 1)
         // slot space of K6: region r owns the slots [first, first + n) -- its reads' places in a single-context run; here
         // simply the regions laid end to end (every group owns at least one read of its later region, so they suffice)

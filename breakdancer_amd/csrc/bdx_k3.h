@@ -170,6 +170,11 @@ __host__ __device__ __forceinline__ uint32_t exchange_owner(uint64_t k, uint32_t
     k ^= k >> 29;
     return (uint32_t)(k % world);
 }
+void launch_k7_names_count(const uint64_t* key, const uint32_t* n_ptr, uint32_t n_upper, uint32_t world, uint32_t* cnt, hipStream_t s);
+void launch_k7_names_scatter(const uint64_t* key, const uint32_t* meta, const uint32_t* n_ptr, uint32_t n_upper, uint32_t world, uint32_t tid,
+                             uint32_t* cursor, unsigned long long* out, hipStream_t s);
+void launch_k7_names_census(const unsigned long long* in, uint32_t n, unsigned long long* table, unsigned long long* info, uint32_t* first_tid,
+                            uint32_t mask, uint32_t* irregular, hipStream_t s);
 void launch_k7_count(const uint64_t* key, const uint32_t* meta, const uint32_t* n_ptr, uint32_t n_upper, uint32_t world, uint32_t* cnt,
                      hipStream_t s);
 void launch_k7_scatter(const uint64_t* key, const int32_t* region_of, const uint32_t* meta, const int32_t* isize, const uint32_t* n_ptr,

@@ -48,6 +48,85 @@ __global__ __launch_bounds__(256) void k7_unpack_kernel(const ExchangeEntry* in,
     key[j] = e.key; order[j] = e.order; region[j] = e.region; meta[j] = e.meta; isize[j] = e.isize;
 }
 
+// ---- name census: is any read name met more than twice, or twice on two chromosomes without being an inter-chromosomal pair? ----
+// Every rank's joins see only its own chromosomes (and the CTX records it owns), but the reference keys its name map on the
+// whole genome (ReadRegionData.cpp:108-113): merged files with clashing read names put sightings of one name on several
+// chromosomes.  So the name key of EVERY anomalous read travels to owner(key) as well -- 16 bytes {key, tid << 1 | not CTX},
+// no join, only a census: a table of keys with a count, the first chromosome seen and whether another one followed.  A name is
+// regular if it has one sighting, two on one chromosome, or two CTX reads on two chromosomes; anything else makes the run
+// replay read by read on rank 0 (bdx_dist_impl.h).
+__global__ __launch_bounds__(256) void k7_names_count_kernel(const uint64_t* key, const uint32_t* n_ptr, uint32_t world, uint32_t* cnt) {
+    __shared__ uint32_t s_cnt[kMaxRanks];
+    for (uint32_t d = threadIdx.x; d < world; d += 256) s_cnt[d] = 0;
+    __syncthreads();
+    const uint32_t n = *n_ptr;
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) atomicAdd(&s_cnt[exchange_owner(key[j], world)], 1u);
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < world; d += 256)
+        if (s_cnt[d]) atomicAdd(&cnt[d], s_cnt[d]);
+}
+
+__global__ __launch_bounds__(256) void k7_names_scatter_kernel(const uint64_t* key, const uint32_t* meta, const uint32_t* n_ptr, uint32_t world,
+                                                               uint32_t tid, uint32_t* cursor, unsigned long long* out) {
+    const uint32_t n = *n_ptr;
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+        const uint64_t k = key[j];
+        const uint32_t slot = atomicAdd(&cursor[exchange_owner(k, world)], 1u);
+        out[2 * (size_t)slot] = k;
+        out[2 * (size_t)slot + 1] = ((unsigned long long)tid << 1) | (meta_flag(meta[j]) != F_CTX ? 1ull : 0ull);
+    }
+}
+
+// table[mask + 1] keys (all ones = empty), info[mask + 1] = count | not-CTX sightings << 16 | (another chromosome followed) << 32,
+// first_tid[mask + 1] (all ones = none yet); all three start out as 0xFF bytes except info, which starts at zero
+__global__ __launch_bounds__(256) void k7_names_insert_kernel(const unsigned long long* in, uint32_t n, unsigned long long* table,
+                                                              unsigned long long* info, uint32_t* first_tid, uint32_t mask) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const unsigned long long k = in[2 * (size_t)j], w = in[2 * (size_t)j + 1];
+    const uint32_t tid = (uint32_t)(w >> 1), nonctx = (uint32_t)(w & 1);
+    uint32_t s = (uint32_t)(((k ^ (k >> 31)) * 0x9E3779B97F4A7C15ull) >> 24) & mask;   // (not the owner's hash: the keys of one owner share that)
+    for (;;) {
+        const unsigned long long old = atomicCAS(&table[s], ~0ull, k);
+        if (old == ~0ull || old == k) break;
+        s = (s + 1) & mask;   // (the table has at least twice as many slots as there are records)
+    }
+    unsigned long long add = 1ull | ((unsigned long long)nonctx << 16);
+    const uint32_t ft = atomicCAS(&first_tid[s], 0xFFFFFFFFu, tid);
+    if (ft != 0xFFFFFFFFu && ft != tid) add |= 1ull << 32;   // (more than one such sighting only makes the field non-zero)
+    atomicAdd(&info[s], add);
+}
+
+__global__ __launch_bounds__(256) void k7_names_verdict_kernel(const unsigned long long* table, const unsigned long long* info, uint32_t slots,
+                                                               uint32_t* irregular) {
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= slots || table[s] == ~0ull) return;
+    const unsigned long long v = info[s];
+    const uint32_t count = (uint32_t)(v & 0xFFFF), nonctx = (uint32_t)((v >> 16) & 0xFFFF);
+    const bool spread = (v >> 32) != 0;
+    if (count > 2 || (count == 2 && spread && nonctx)) *irregular = 1;
+}
+
+void launch_k7_names_count(const uint64_t* key, const uint32_t* n_ptr, uint32_t n_upper, uint32_t world, uint32_t* cnt, hipStream_t s) {
+    if (!n_upper) return;
+    const uint32_t g = std::min<uint32_t>((n_upper + 255) / 256, 2048u);
+    hipLaunchKernelGGL(k7_names_count_kernel, dim3(g), dim3(256), 0, s, key, n_ptr, world, cnt);
+}
+
+void launch_k7_names_scatter(const uint64_t* key, const uint32_t* meta, const uint32_t* n_ptr, uint32_t n_upper, uint32_t world, uint32_t tid,
+                             uint32_t* cursor, unsigned long long* out, hipStream_t s) {
+    if (!n_upper) return;
+    const uint32_t g = std::min<uint32_t>((n_upper + 255) / 256, 2048u);
+    hipLaunchKernelGGL(k7_names_scatter_kernel, dim3(g), dim3(256), 0, s, key, meta, n_ptr, world, tid, cursor, out);
+}
+
+void launch_k7_names_census(const unsigned long long* in, uint32_t n, unsigned long long* table, unsigned long long* info, uint32_t* first_tid,
+                            uint32_t mask, uint32_t* irregular, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k7_names_insert_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, n, table, info, first_tid, mask);
+    hipLaunchKernelGGL(k7_names_verdict_kernel, dim3((mask + 256) / 256), dim3(256), 0, s, table, info, mask + 1, irregular);
+}
+
 void launch_k7_count(const uint64_t* key, const uint32_t* meta, const uint32_t* n_ptr, uint32_t n_upper, uint32_t world, uint32_t* cnt,
                      hipStream_t s) {
     if (!n_upper) return;

@@ -255,7 +255,7 @@ int main(int argc, char** argv) {
     try {
         for (int fi = optind; fi < argc; ++fi) {
             const std::string fbam = argv[fi];
-            bdhost::BamReader rd(fbam, 4);
+            bdhost::BamReader rd(fbam, 4, 32);  // (the loop below ends after ~3 x libraries x n records: small batches, little inflated in vain)
             std::vector<std::string> rg_order;
             std::map<std::string, std::string> rg_lib, rg_platform;
             std::map<std::string, bool> libs;  // still collecting

@@ -84,7 +84,8 @@ void BamReader::Chunk::reserve(size_t n) {
     cap = n;
 }
 
-BamReader::BamReader(const std::string& path, int threads) : path_(path), threads_(threads < 1 ? 1 : threads) {
+BamReader::BamReader(const std::string& path, int threads, size_t fill_blocks)
+    : path_(path), threads_(threads < 1 ? 1 : threads), fill_blocks_(fill_blocks ? fill_blocks : kMaxBlocksPerFill) {
     {
         const int fd = open(path.c_str(), O_RDONLY);
         if (fd < 0) throw std::runtime_error("Failed to open samfile " + path);
@@ -143,7 +144,7 @@ bool BamReader::fill(Chunk& c) {
     std::vector<Block> blocks;
     size_t uoff = kFrontGap;
     // the compressed file is mapped, not read: the inflate threads take their input straight from the page cache
-    while (blocks.size() < kMaxBlocksPerFill) {
+    while (blocks.size() < fill_blocks_) {
         const size_t avail = map_size_ - comp_off_;
         if (avail == 0) break;
         if (avail < 18) throw std::runtime_error("truncated BGZF file: " + path_);

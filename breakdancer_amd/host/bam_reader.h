@@ -30,7 +30,9 @@ struct BamRecord {
 
 class BamReader {
 public:
-    explicit BamReader(const std::string& path, int threads = 4);
+    // fill_blocks: BGZF blocks inflated per batch, 0 = the default (2048: <= 128 MiB).  A caller that stops after the first few
+    // thousand records (bam2cfg) asks for small batches: the batch after the current one is always inflated ahead
+    explicit BamReader(const std::string& path, int threads = 4, size_t fill_blocks = 0);
     ~BamReader();
     BamReader(const BamReader&) = delete;
     BamReader& operator=(const BamReader&) = delete;
@@ -68,6 +70,7 @@ private:
     const uint8_t* map_ = nullptr;     // the compressed file, memory-mapped
     size_t map_size_ = 0;
     int threads_;
+    size_t fill_blocks_ = 0;
     size_t comp_off_ = 0;              // first compressed byte not yet consumed
     Chunk chunk_[2];                   // one being parsed, one being inflated
     int cur_chunk_ = 1;                // (the first batch lands in chunk 0)

@@ -225,6 +225,13 @@ def test_full_size_properties():
     dels = sv_a[(sv_a["flag"] == 2) & (sv_a["printed"] == 1)]
     assert len(dels) > 1000
     assert abs(np.median(dels["size"]) - 1150) < 40
+    # (7) and the whole result bit for bit against ONE oracle run over the same 15 M records (the oracle takes under a second):
+    # class bytes, counters, window, region table, every SV field
+    from test_gpu_configs import cfg_line, oracle_from_soa
+    ref = oracle_from_soa(d, cfg_line("rg1", "syn.bam", "lib1", 400.0, 30.0), ["syn.bam"], make_opts(), ["chrS"])
+    assert ref.n_merged == n
+    s = compare(ref, product_from_oracle(ref))
+    assert s["n_svs"] == sa["n_svs"] and s["n_regions"] == sa["n_regions"]
 
 
 def _raw_case(n, keys, seed=3):

@@ -106,3 +106,28 @@ def test_per_chromosome_mode_equals_dash_o_runs(seed):
             np.testing.assert_array_equal(svs["score"], single.sv_i[:, 10])
             np.testing.assert_array_equal(svs["num_reads"], single.sv_i[:, 11])
         assert r["summary"]["window"] == single.W and r["summary"]["covered_ref_len"] == single.ref_len
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_sharded_run_with_read_names_seen_more_than_twice(seed):
+    """clashing read names (triples, quadruples, across files, across chromosomes and therefore across ranks) in a sharded run:
+    some rank's join notices a third sighting, all ranks agree on it with the next all-reduce, the compact records of every
+    chromosome are gathered and rank 0 replays the run read by read -- same output as ONE oracle run, no error and no hang
+    (ReadRegionData.cpp:108-113,152-175, SvBuilder.cpp:101-118)"""
+    from fuzzgen import GRAPH_OPTION_SETS, OPTION_SETS, clash_names, make_graph_case
+    if seed % 2 == 0:
+        cfg, streams, targets = make_case(940 + seed)
+        osets = OPTION_SETS
+    else:
+        cfg, streams, targets = make_graph_case(940 + seed)
+        osets = GRAPH_OPTION_SETS
+    streams = clash_names(streams, seed, frac=0.02 + 0.02 * (seed % 4))
+    replayed = 0
+    for i, o in enumerate((osets[seed % len(osets)], dict(transchr_rearrange=1, min_read_pair=1), dict(min_read_pair=1, buffer_size=1))):
+        if o.get("min_len", 0) < 0:
+            continue   # (a negative -s registers a read-less region 0: single-context runs only)
+        run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1, **o))
+        util = sharded_from_oracle(run, world=1 + (seed + i) % 3)
+        compare(run, util, check_cls=False)
+        replayed += util.was_replayed()
+    assert replayed > 0
