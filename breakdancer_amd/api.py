@@ -251,6 +251,11 @@ class BreakDancer:
         self._chk(self.lib.bdx_set_enqueue_ahead(self.h, mode), "bdx_set_enqueue_ahead")
         return self
 
+    def set_debug(self, name, value=1):
+        """test / measurement switches by name (include/bdx.h bdx_set_debug); before run()"""
+        self._chk(self.lib.bdx_set_debug(self.h, name.encode(), int(value)), "bdx_set_debug")
+        return self
+
     def set_host_walk(self, on=True):
         """Send every component of the region graph through the host walk (same results as the device assembly)."""
         self._chk(self.lib.bdx_set_host_walk(self.h, int(on)), "bdx_set_host_walk")

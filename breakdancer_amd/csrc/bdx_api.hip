@@ -105,6 +105,9 @@ struct bdx_ctx {
     DevBuf b_ins, b_member_ids;
     PinBuf h_flags;                   // [0] pass 1 ready, [1] host's groups ready, [2] final table ready (= run sequence number)
     uint32_t seq = 0;
+    // test / measurement switches (bdx_set_debug): all off by default
+    int dbg_no_stash = 0, dbg_max_chunks = 0, dbg_finalize2_fold = 0, dbg_no_forward = 0, dbg_scan3 = 0, dbg_label_rounds = 0, dbg_k1_grid = 0,
+        dbg_end_write_value = 0;
     uint32_t lb_seq = 0;              // launches of look-back scans so far: every launch stamps its words with its own number (bdx_scan.h)
     uint32_t k1_event_period = 4;     // K1 is bracketed by HIP events on every n-th run (an event pair idles the GPU ~10 us)
     float k1_ms_last = 0;
@@ -400,23 +403,6 @@ int bdx_create(bdx_ctx** out, const bdx_opts* opts, const bdx_lib* libs, int nli
         if (hipEventCreateWithFlags(&st.done, hipEventDisableTiming) != hipSuccess) { delete c; return BDX_EHIP; }
     if (hipEventCreateWithFlags(&c->ev_groups, hipEventDisableTiming) != hipSuccess) { delete c; return BDX_EHIP; }
     if (hipEventCreateWithFlags(&c->ev_regions, hipEventDisableTiming) != hipSuccess) { delete c; return BDX_EHIP; }
-    if (const char* nc = getenv("BDX_PIN_NONCOHERENT"); nc && nc[0] == '1')
-        for (PinBuf* b : {&c->h_sv_out, &c->h_lib_index, &c->h_lib_pairs, &c->h_cn_key, &c->h_cn_value, &c->h_ltail_dev, &c->h_regs, &c->h_pk})
-            b->flags = hipHostMallocNonCoherent;
-    {
-        const char* hw = getenv("BDX_HOST_WALK");
-        c->host_walk_only = hw && hw[0] == '1';
-        const char* stt = getenv("BDX_STAGE_TIMING");
-        c->stage_timing = stt && stt[0] == '1';
-        if (const char* kp = getenv("BDX_K1_EVENT_PERIOD")) c->k1_event_period = (uint32_t)std::max(1, atoi(kp));
-        if (const char* ns = getenv("BDX_NO_SPECULATE")) c->speculate = ns[0] == '1' ? 0 : 2;
-        if (const char* st = getenv("BDX_SPEC_TEST")) c->spec_test = atoi(st);
-        const char* np = getenv("BDX_NO_POLL");
-        c->poll = !(np && np[0] == '1');
-        const char* bj = getenv("BDX_BUCKETED_JOIN");
-        c->bucketed_join = bj && bj[0] == '1';
-        if (const char* bw = getenv("BDX_BIG_WALK")) c->big_walk_mode = bw[0] == '1' ? 1 : 0;
-    }
     std::vector<DevLib> dl(nlibs);
     for (int i = 0; i < nlibs; ++i) {
         dl[i].upper = libs[i].uppercutoff;
@@ -635,8 +621,7 @@ int pass1_prepare(bdx_ctx* c, uint32_t tiles_cap) {
     c->k1_done = 0;
     HIPCHK(c, c->b_cls.ensure(std::max<size_t>((size_t)tiles_cap * kTile, 16)));
     // K1's ready-made records for K2: 2 B per read of address space, written (and later read) only where reads are anomalous
-    static const bool no_stash = getenv("BDX_NO_STASH") != nullptr;  // (A/B: K2 gathers everything from the columns)
-    c->use_stash = !no_stash && nkeys <= kStashKeys;
+    c->use_stash = !c->dbg_no_stash && nkeys <= kStashKeys;   // (no_stash: K2 gathers everything from the columns)
     if (c->use_stash) HIPCHK(c, c->b_stash.ensure(std::max<size_t>((size_t)tiles_cap * kStashCap * sizeof(StashRec), 64)));
     HIPCHK(c, c->b_tile_tot.ensure((size_t)ncols * tstride * 4));
     HIPCHK(c, c->b_tile_pre.ensure((size_t)ncols * tstride * 4));
@@ -680,7 +665,7 @@ int pass1_classify(bdx_ctx* c, uint32_t upto, bool timed) {
     k1.blk_cnt = c->b_blk_cnt.as<uint32_t>();
     k1.stash = c->use_stash ? c->b_stash.as<StashRec>() : nullptr;
     const uint32_t span = upto - c->k1_done;
-    static const uint32_t grid_cap = getenv("BDX_K1_GRID") ? (uint32_t)std::max(1, atoi(getenv("BDX_K1_GRID"))) : (uint32_t)kK1MaxGrid;  // (tuning probe)
+    const uint32_t grid_cap = c->dbg_k1_grid > 0 ? (uint32_t)c->dbg_k1_grid : (uint32_t)kK1MaxGrid;  // (tuning probe)
     const int grid1 = (int)std::min<uint32_t>((span + kWaves - 1) / kWaves, grid_cap);
     launch_k1(k1, grid1, k1_lds_bytes(c->nlibs, c->nbams, c->nkeys), s, timed ? c->ev[0] : nullptr, timed ? c->ev[1] : nullptr);
     c->k1_done = upto;
@@ -732,8 +717,8 @@ int do_pass1(bdx_ctx* c, uint32_t na_cap, bool wait, bool defer_second) {
         const uint32_t nsuper = (ntiles + kK2TilesPerWave - 1) / kK2TilesPerWave;
         const uint32_t round = 4096;
         const uint32_t rounds = std::max<uint32_t>(1, (nsuper + round - 1) / round);
-        const char* mc = getenv("BDX_MAX_CHUNKS");  // (tests: chunks of several rounds at small sizes; read per run)
-        const uint32_t max_chunks = mc ? (uint32_t)std::min(std::max(atoi(mc), 1), kMaxChunks) : (uint32_t)kMaxChunks;
+        // (tests: chunks of several rounds at small sizes)
+        const uint32_t max_chunks = c->dbg_max_chunks > 0 ? (uint32_t)std::min(c->dbg_max_chunks, (int)kMaxChunks) : (uint32_t)kMaxChunks;
         fp.chunk_super = round * ((rounds + max_chunks - 1) / max_chunks);
         fp.nchunk = std::max<uint32_t>(1, (nsuper + fp.chunk_super - 1) / fp.chunk_super);
         HIPCHK(c, c->b_chunk_tot.ensure((size_t)ncols * kMaxChunks * 8));
@@ -751,7 +736,7 @@ int do_pass1(bdx_ctx* c, uint32_t na_cap, bool wait, bool defer_second) {
     fp.na_cap = na_cap;
     // The second level as the job of finalize_kernel's last workgroup (BDX_FINALIZE2_FOLD=1) was measured and lost: the
     // device-scope fences it needs right behind K1's 15 MB of class bytes cost more (step 0.324 ms) than the launch (0.308 ms)
-    static const bool fold = getenv("BDX_FINALIZE2_FOLD") != nullptr;
+    const bool fold = c->dbg_finalize2_fold != 0;
     fp.done = fold ? c->b_done.as<uint32_t>() : nullptr;
     // enqueue-ahead: K2 follows without a host decision in between, so its launch takes the one-workgroup second level along
     c->fp_deferred = fp;
@@ -941,10 +926,10 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool f
             HIPCHK(c, c->b_out_deg.ensure(cap * 6 * 4));
             k3.r_rec_dev = c->b_r_rec.as<RegionRec>(); k3.r_pk_dev = c->b_r_pk.as<uint32_t>(); k3.out_deg = c->b_out_deg.as<uint32_t>();
             // with the direct join right behind K3, that kernel forwards the table to the host
-            static const bool no_forward = getenv("BDX_NO_FORWARD") != nullptr;
+            const bool no_forward = c->dbg_no_forward != 0;
             k3.host_copy_later = (!no_forward && !c->bucketed_join && na <= kDirectJoinMax) ? 1 : 0;
         }
-        static const bool three_launch = getenv("BDX_SCAN3") != nullptr;  // (A/B: the block-sums / rescan pair of launches)
+        const bool three_launch = c->dbg_scan3 != 0;  // (A/B: the block-sums / rescan pair of launches)
         if (!three_launch) {
             const size_t words = 5 * nblk;
             if (c->b_lb.bytes < words * 8) {  // the look-back words must start out zero; afterwards every run brings its own stamp
@@ -1153,7 +1138,7 @@ int do_k6(bdx_ctx* c, bool force_host) {
     a.big_walk = big_walk;
     a.walk_lanes = 32;  // (measured at configs[1]: 64 regions per wave 23.7 us, 32: 22.4 us, 16: 24.5 us)
     {
-        static const int rounds = getenv("BDX_LABEL_ROUNDS") ? std::max(1, atoi(getenv("BDX_LABEL_ROUNDS"))) : 0;
+        const int rounds = c->dbg_label_rounds;
         // (long chains need more rounds to agree on one label; with the general walk on, the step is long enough not to care)
         a.label_rounds = rounds ? rounds : (a.big_walk ? kK6LabelRoundsBig : kK6LabelRounds);
     }
@@ -1235,7 +1220,7 @@ int do_k6_table(bdx_ctx* c) {
     // The word the host polls for the end of the run is set by a one-thread kernel behind the table kernel (a kernel boundary
     // orders it behind that kernel's stores to host memory).  A stream write-value command does the same as a one-thread kernel of
     // the runtime's own, but starts 5 us after the kernel before it has ended; back-to-back launches follow each other at once.
-    static const bool write_value = getenv("BDX_END_WRITE_VALUE") != nullptr;  // (A/B)
+    const bool write_value = c->dbg_end_write_value != 0;  // (A/B)
     if (c->poll && !write_value) { a.flag_done = c->h_flags.as<uint32_t>() + 2; a.flag_value = c->seq; }
     launch_k6_table(a, na, std::log(10), c->opts.score_threshold, c->opts.fisher ? 0 : 1, s);
     if (!a.flag_done) {  // (without polling: finish_table waits for the stream)
@@ -1835,6 +1820,25 @@ int bdx_set_enqueue_ahead(bdx_ctx* c, int on) {
     if (!c) return BDX_EINVAL;
     c->speculate = on < 0 ? 0 : (on > 2 ? 2 : on);
     return BDX_OK;
+}
+
+int bdx_set_debug(bdx_ctx* c, const char* name, int value) {
+    if (!c || !name) return BDX_EINVAL;
+    struct { const char* n; int* p; } ints[] = {{"no_stash", &c->dbg_no_stash}, {"max_chunks", &c->dbg_max_chunks}, {"finalize2_fold", &c->dbg_finalize2_fold},
+                                                 {"no_forward", &c->dbg_no_forward}, {"scan3", &c->dbg_scan3}, {"label_rounds", &c->dbg_label_rounds},
+                                                 {"k1_grid", &c->dbg_k1_grid}, {"end_write_value", &c->dbg_end_write_value}, {"spec_test", &c->spec_test},
+                                                 {"big_walk", &c->big_walk_mode}};
+    for (auto& e : ints)
+        if (!strcmp(name, e.n)) { *e.p = value; return BDX_OK; }
+    if (!strcmp(name, "bucketed_join")) { c->bucketed_join = value != 0; return BDX_OK; }
+    if (!strcmp(name, "no_poll")) { c->poll = value == 0; return BDX_OK; }
+    if (!strcmp(name, "k1_event_period")) { c->k1_event_period = (uint32_t)std::max(1, value); return BDX_OK; }
+    if (!strcmp(name, "pin_noncoherent")) {   // (before the first run: the result tables' pinned buffers are allocated non-coherent)
+        for (PinBuf* b : {&c->h_sv_out, &c->h_lib_index, &c->h_lib_pairs, &c->h_cn_key, &c->h_cn_value, &c->h_ltail_dev, &c->h_regs, &c->h_pk})
+            b->flags = value ? hipHostMallocNonCoherent : hipHostMallocDefault;
+        return BDX_OK;
+    }
+    return fail(c, BDX_EINVAL, std::string("unknown debug switch ") + name);
 }
 
 int bdx_set_host_walk(bdx_ctx* c, int on) {

@@ -790,7 +790,7 @@ int bdx_dist_run(bdx_dist* d) {
             d->ms_total = ms_between(t_begin, std::chrono::steady_clock::now());
             return BDX_OK;
         }
-        static const bool host_only = getenv("BDX_DIST_HOST_WALK") != nullptr;  // (A/B: the whole walk on the host, as in round 1)
+        const bool host_only = U->host_walk_only;  // (bdx_set_host_walk on the result context's owner: the whole walk on the host)
         // slot space of K6: region r owns the slots [first, first + n) -- its reads' places in a single-context run; here
         // simply the regions laid end to end (every group owns at least one read of its later region, so they suffice)
         uint64_t slots = 0;

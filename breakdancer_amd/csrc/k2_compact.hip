@@ -291,7 +291,7 @@ void launch_k2(const K2Params& p, size_t lds, hipStream_t s, const FinalizeParam
     const uint32_t nblk = (ntiles2 + kWaves - 1) / kWaves;
     // measured on MI355X at 58.6 k tiles: 2048 workgroups 54 us, 4096 46 us, 8192 43 us, one tile per wave (14.6 k) 45 us -- the
     // kernel is bound by its scattered 32-byte sector gathers (8 columns per anomalous read), not by wave count
-    static const uint32_t cap = getenv("BDX_K2_GRID") ? (uint32_t)atoi(getenv("BDX_K2_GRID")) : 8192u;
+    const uint32_t cap = 8192u;
     const uint32_t grid = nblk < cap ? nblk : cap;
     if (side) hipLaunchKernelGGL(k2_compact_side_kernel, dim3(grid + 1), dim3(kBlock), lds, s, p, *side);
     else hipLaunchKernelGGL(k2_compact_kernel, dim3(grid), dim3(kBlock), lds, s, p);

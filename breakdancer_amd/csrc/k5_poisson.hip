@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k5_poisson_lane_n_kernel(const double* __
 
 void launch_k5(const double* lambda, const int32_t* k, double* out, uint32_t n, hipStream_t s) {
     if (!n) return;
-    if (!getenv("BDX_K5_WAVE")) {
+    if (true) {   // (one lane per term; the wave-per-term kernels below are kept for the comparison in DESIGN.md)
         hipLaunchKernelGGL(k5_poisson_lane_n_kernel, dim3((n + 255) / 256), dim3(256), 0, s, lambda, k, out, n);
         return;
     }
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k5_poisson_lane_kernel(const double* __re
 
 void launch_k5_dev(const double* lambda, const int32_t* k, double* out, double* out2, const uint32_t* n_ptr, uint32_t n_upper,
                    hipStream_t s) {
-    if (!getenv("BDX_K5_WAVE")) {
+    if (true) {   // (one lane per term; the wave-per-term kernels below are kept for the comparison in DESIGN.md)
         if (!n_upper) return;
         const uint32_t g = (n_upper + 255) / 256;
         hipLaunchKernelGGL(k5_poisson_lane_kernel, dim3(g < 1024u ? g : 1024u), dim3(256), 0, s, lambda, k, out, out2, n_ptr);

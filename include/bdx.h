@@ -232,6 +232,11 @@ int bdx_set_enqueue_ahead(bdx_ctx* ctx, int on);
  * process_sv, BreakDancer.cpp:266-497); every other component goes through the host walk.  bdx_set_host_walk(ctx, 1)
  * sends everything through the host walk (same results; used by the parity tests).  Any pointer may be NULL. */
 int bdx_set_host_walk(bdx_ctx* ctx, int on);
+/* Test and measurement switches, by name (they used to be environment variables read inside the library): "no_stash",
+ * "max_chunks", "spec_test", "big_walk", "bucketed_join", "no_poll", "finalize2_fold", "no_forward", "scan3", "label_rounds",
+ * "k1_grid", "end_write_value", "k1_event_period", "pin_noncoherent".  Every switch selects another route to the same results
+ * (the parity tests force each route); none is needed in production.  BDX_EINVAL for an unknown name. */
+int bdx_set_debug(bdx_ctx* ctx, const char* name, int value);
 int bdx_get_walk_split(const bdx_ctx* ctx, uint32_t* n_sv_device, uint32_t* n_sv_host, uint32_t* n_groups_host);
 /* Of the device-assembled candidates, those whose traversal started from a region of an earlier flush window (the
  * reference's flush cadence, BreakDancer.cpp:254-264; they are placed in the output by order key, not by position). */

@@ -26,11 +26,27 @@ def product_options(opts):
                    chr="x" if opts["chr_tid"] >= 0 else "")
 
 
+# the tests select the product's alternative routes through bdx_set_debug; monkeypatch.setenv("BDX_<NAME>", value) in a test is
+# only the way the choice reaches this helper (the library itself reads no such variable)
+_SWITCHES = {"BDX_NO_STASH": "no_stash", "BDX_MAX_CHUNKS": "max_chunks", "BDX_SPEC_TEST": "spec_test", "BDX_BIG_WALK": "big_walk",
+             "BDX_BUCKETED_JOIN": "bucketed_join"}
+
+
+def apply_test_switches(bd):
+    import os
+    for env, name in _SWITCHES.items():
+        if env in os.environ:
+            bd.set_debug(name, int(os.environ[env]))
+    if os.environ.get("BDX_NO_SPECULATE") == "1":
+        bd.set_enqueue_ahead(0)
+    return bd
+
+
 def product_from_oracle(run, device=0, support=False, host_walk=False):
     """Feed the product the exact merged stream the oracle consumed (the producer's job in the CLI)."""
     libs = [LibraryConfig(*[float(x) for x in run.lib_f[i]], min_mapping_quality=int(run.lib_i[i, 0]),
                           bam_file_index=int(run.lib_i[i, 1]), name=run.lib_names[i]) for i in range(run.nlibs)]
-    bd = bda.BreakDancer(product_options(run.opts), libs, run.nbams, ntids=0, max_read_window_size=run.w0, device=device)
+    bd = apply_test_switches(bda.BreakDancer(product_options(run.opts), libs, run.nbams, ntids=0, max_read_window_size=run.w0, device=device))
     soa = run.merged_soa()
     if support:
         bd.collect_support()
