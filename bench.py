@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--no-exchange", "--no-genome", dest="no_exchange", action="store_true",
                     help="skip the sharded whole-genome runs over all ranks (config.genome)")
     ap.add_argument("--genome-fraction", type=float, default=GENOME_FRACTION, help="hg38 lengths x this for the genome leg (default 1/8: 116 M records)")
+    ap.add_argument("--no-overlap", action="store_true", help="skip the three-contexts-in-flight measurement (config.overlapped_contexts)")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 --pmc sub-run that measures roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-parallel", type=int, default=-1,
@@ -279,7 +280,7 @@ def measure_k1_traffic(length):
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             od = os.path.join(td, c)
             cmd = [rp, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", od, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
-                   "--pmc-child", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-end-to-end", "--no-genome", "--no-pmc", "--length", str(length)]
+                   "--pmc-child", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-end-to-end", "--no-genome", "--no-pmc", "--no-overlap", "--length", str(length)]
             try:
                 p = subprocess.run(cmd, cwd=td, env=dict(os.environ, TMPDIR=td), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
             except subprocess.TimeoutExpired:
@@ -563,7 +564,7 @@ def main():
             stage[k] = stage.get(k, 0.0) + v
     bd.set_stage_timing(False)
     overlapped = None
-    if world == 1 and len(ctxs) == 1 and not a.pmc_child:   # (always: three contexts in flight is how a whole-genome caller keeps one GPU busy)
+    if world == 1 and len(ctxs) == 1 and not a.pmc_child and not a.no_overlap:   # (by default: three contexts in flight is how a whole-genome caller keeps one GPU busy)
         import threading
         more = [bd, new_ctx(), new_ctx()]
         for x in more:

@@ -471,7 +471,7 @@ int bdx_reserve(bdx_ctx* c, size_t n_reads) {
     // caller still decodes or copies, not inside its first bdx_run.  Small inputs size theirs exactly, when they run.
     if (n_reads >= (1u << 20) && !c->ran) {
         const uint64_t prior = (uint64_t)n_reads / 32 + 4096;
-        if (prior <= kMaxRegions) return presize_stages(c, (uint32_t)prior);
+        if (prior <= kMaxAnomalous) return presize_stages(c, (uint32_t)prior);
     }
     return BDX_OK;
 }
@@ -757,10 +757,10 @@ int wait_pass1(bdx_ctx* c) {
         if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->k1_ms_last = ms;
     }
     c->stage_ms[0] = c->k1_ms_last;  // the latest measured launch
-    if (c->p1.n_anom > kMaxRegions) return fail(c, BDX_ELIMIT, "too many anomalous reads for the packed group key");
+    if (c->p1.n_anom > kMaxAnomalous) return fail(c, BDX_ELIMIT, "more than 2^31 anomalous reads in one context");
     // capacity of the later stages: the count plus the headroom an enqueue-ahead run of the same input will ask for, so that
     // its buffers are these buffers (an enqueue-ahead run has set its guess already)
-    if (!c->na_alloc && c->p1.n_anom) c->na_alloc = (uint32_t)std::min<uint64_t>((uint64_t)c->p1.n_anom + c->p1.n_anom / 8 + 1024, kMaxRegions);
+    if (!c->na_alloc && c->p1.n_anom) c->na_alloc = (uint32_t)std::min<uint64_t>((uint64_t)c->p1.n_anom + c->p1.n_anom / 8 + 1024, kMaxAnomalous);
     c->stage = 1;
     return BDX_OK;
 }
@@ -825,7 +825,7 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepa
     cp = Compact{};
     k3 = K3Arrays{};
     if (na) {
-        if (na > kMaxRegions) return fail(c, BDX_ELIMIT, "too many anomalous reads for the packed group key");
+        if (na > kMaxAnomalous) return fail(c, BDX_ELIMIT, "more than 2^31 anomalous reads in one context");
         const size_t cap = na;
         HIPCHK(c, c->b_c_tid.ensure(cap * 4)); HIPCHK(c, c->b_c_pos.ensure(cap * 4)); HIPCHK(c, c->b_c_isize.ensure(cap * 4));
         HIPCHK(c, c->b_c_meta.ensure(cap * 4)); HIPCHK(c, c->b_c_key.ensure(cap * 8)); HIPCHK(c, c->b_c_nn.ensure(cap * 4));
@@ -1474,7 +1474,7 @@ int bdx_run(bdx_ctx* c) {
     const bool restored = !c->ov_cnt.empty();  // (restored statistics are adopted between pass 1 and the rest: nothing ahead)
     if (!restored && c->speculate == 2 && c->ran && c->last_n == c->n && c->last_na) {
         guess = c->spec_test ? std::max(1u, c->last_na / 2) : c->last_na + c->last_na / 8 + 1024;
-        if (guess > kMaxRegions) guess = 0;
+        if (guess > kMaxAnomalous) guess = 0;
     } else if (!restored && c->speculate && c->n >= (1u << 20)) {
         // no history: a prior.  Anomalous reads are a few percent of a sorted BAM at most (1 % at configs[1]); 1/32 of the
         // reads covers that with room, costs a few microseconds of oversized grids when it is generous, and one more pass
@@ -1482,7 +1482,7 @@ int bdx_run(bdx_ctx* c) {
         // (measured at configs[1], 1.1 % anomalous: prior n/32 0.309 ms per step, n/64 0.300 ms, exact sizing after the read-back
         // 0.307 ms, sizing from the previous run 0.295 ms -- an oversized launch grid costs about what the host round trip does)
         const uint64_t prior = (uint64_t)c->n / (c->spec_test ? 4096 : 32) + 4096;
-        guess = prior > kMaxRegions ? 0 : (uint32_t)prior;
+        guess = prior > kMaxAnomalous ? 0 : (uint32_t)prior;
     }
     int rc;
     if (restored) {
@@ -1537,6 +1537,10 @@ int bdx_run(bdx_ctx* c) {
         }
         // (the table sits in pinned memory the device has just written: one streaming copy into ordinary memory is much
         // cheaper than the walk's scattered reads of it)
+        if ((uint64_t)c->h_counts0.as<StageCounts>()->n_regions + ph > kMaxRegions) {   // (region ids are 26-bit fields of the packed group key)
+            HIPCHK(c, hipStreamSynchronize(s));
+            return fail(c, BDX_ELIMIT, "more than 2^26 - 2 accepted regions in one context");
+        }
         decode_regions(c, c->h_regs.as<RegionRec>(), c->h_pk.as<uint32_t>(), c->h_counts0.as<StageCounts>()->n_regions, ph, false);
         if (!wait_flag(c, 1, c->seq)) {
             if (c->poll) HIPCHK(c, hipStreamSynchronize(s)); else HIPCHK(c, hipEventSynchronize(c->ev_groups));
@@ -1671,7 +1675,7 @@ int bdx_get_compact(const bdx_ctx* c, uint64_t* key, int32_t* region, uint32_t* 
 int bdx_join_entries(bdx_ctx* c, size_t n, const uint64_t* key, const uint32_t* order, const int32_t* region, const uint32_t* meta,
                      const int32_t* isize, bdx_group* out, size_t cap, uint32_t* n_groups, uint32_t* n_pairs) {
     if (!c || (n && (!key || !order || !region || !meta || !isize))) return BDX_EINVAL;
-    if (n > kMaxRegions) return fail(c, BDX_ELIMIT, "too many join entries");
+    if (n > kMaxAnomalous) return fail(c, BDX_ELIMIT, "too many join entries");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     if (n_groups) *n_groups = 0;

@@ -185,7 +185,7 @@ int bam_feed_classifier(bdx_bamdec* d, bool final) {
         const double est = (double)d->confirmed / (double)std::min<uint64_t>(d->compressed_bytes, d->first_batch_bytes * d->confirmed_seq) * (double)d->compressed_bytes * 1.05;
         if (est >= (double)(1u << 20) && !c->ran) {
             const uint64_t prior = (uint64_t)est / 32 + 4096;
-            if (prior <= kMaxRegions) {
+            if (prior <= kMaxAnomalous) {
                 const int rc = presize_stages(c, (uint32_t)prior);
                 if (rc != BDX_OK) return bfail(d, rc, c->err);
             }

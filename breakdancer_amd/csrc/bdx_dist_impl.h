@@ -440,7 +440,7 @@ int bdx_dist_run(bdx_dist* d) {
     for (int t = 0; t < ntids; ++t)
         for (size_t k = 0; k < tw; ++k) base[(size_t)(t + 1) * tw + k] = base[(size_t)t * tw + k] + tot(t, (int)k);
     // (the same sum on every rank: all of them return here, together)
-    if (base[(size_t)ntids * tw] > kMaxRegions) return dfail(d, BDX_ELIMIT, "too many anomalous reads for the packed group key");
+    if (base[(size_t)ntids * tw] > kMaxAnomalous) return dfail(d, BDX_ELIMIT, "more than 2^31 anomalous reads in one run");
 
     // ---- compaction with the counters of the chromosomes in front; C2: every chromosome's first anomalous read ----
     std::vector<uint64_t> v2((size_t)ntids * 3, 0);
@@ -570,7 +570,7 @@ int bdx_dist_run(bdx_dist* d) {
         for (int r = 0; r < world; ++r) {
             uint64_t col = 0;
             for (int q = 0; q < world; ++q) col += v4[(size_t)q * world + r];
-            if (col > kMaxRegions) return dfail(d, BDX_ELIMIT, "too many inter-chromosomal join records on one rank");
+            if (col > kMaxAnomalous) return dfail(d, BDX_ELIMIT, "too many inter-chromosomal join records on one rank");
         }
     }
     if (d->b_recv.ensure(std::max<size_t>(nrecv, 1) * sizeof(ExchangeEntry)) != hipSuccess)
@@ -795,7 +795,7 @@ int bdx_dist_run(bdx_dist* d) {
         // simply the regions laid end to end (every group owns at least one read of its later region, so they suffice)
         uint64_t slots = 0;
         for (size_t r = 0; r < NR; ++r) { regs[r].first = (uint32_t)slots; slots += regs[r].n; }
-        if (host_only || NR == 0 || ng_all == 0 || slots > kMaxRegions) {
+        if (host_only || NR == 0 || ng_all == 0 || slots > kMaxAnomalous) {
             decode_regions(U, regs.data(), pk.data(), (uint32_t)NR, 0, false);
             decode_groups(U, groups.data(), (uint32_t)ng_all, 0);
             U->counts.n_regions = (uint32_t)NR;

@@ -122,7 +122,8 @@ struct K4Arrays {
 __host__ __device__ __forceinline__ uint64_t group_pack(uint32_t rlo, uint32_t rhi, uint32_t lib, uint32_t flag) {
     return ((uint64_t)rlo << 38) | ((uint64_t)rhi << 12) | ((uint64_t)lib << 4) | (uint64_t)flag;
 }
-constexpr uint32_t kMaxRegions = (1u << 26) - 2;
+constexpr uint32_t kMaxRegions = (1u << 26) - 2;      // accepted regions of one result (26-bit region ids in the packed group key)
+constexpr uint32_t kMaxAnomalous = 0x7FFFFF00u;       // anomalous reads of one context / one sharded run (32-bit signed read indices)
 
 // join input: one entry per anomalous read (region < 0: in a rejected candidate region -- it still enters the table so that
 // a name seen three times is noticed wherever its reads lie, but it never forms a pair)

@@ -3,8 +3,8 @@
 
   configs[2]  hg38-shaped, 24 chromosomes, 4 libraries, 30x: 3.09 Gbp / 8 -> >= 116 M reads on this GPU
   configs[3]  the same share + 5,000 planted translocations, run with -t
-  configs[4]  tumour 60x + normal 30x, 6 read groups -> 3 libraries over 2 files, -a -h (a 1/24 share: 58 M reads; the
-              full per-GPU share of 350 M reads takes minutes to synthesise with numpy)
+  configs[4]  tumour 60x + normal 30x, 6 read groups -> 3 libraries over 2 files, -a -h: a 1/24 share (46 M reads) under both
+              option sets, and the full per-GPU share of 1/8 (348 M reads, 12 GB of records in HBM) under -a -h
 
 Every case is checked bit-exactly against ONE oracle run over the same records, plus size-independent properties that do
 not need the oracle: class bytes against a vectorised numpy restatement of the classifier, device walk == host walk,
@@ -150,19 +150,21 @@ def test_config3_five_thousand_translocations_with_dash_t(genome_share):
     assert min(e["ctx_records_received"] for e in ex) > n_ctx // 8
 
 
-def test_config4_tumour_normal_two_files_copy_number_and_allele_frequency():
+@pytest.mark.parametrize("fraction,min_reads,option_sets", [(1 / 24, 46_000_000, (dict(cn_lib=1, print_af=1), dict(print_af=1))),
+                                                            (1 / 8, 340_000_000, (dict(cn_lib=1, print_af=1),))])
+def test_config4_tumour_normal_two_files_copy_number_and_allele_frequency(fraction, min_reads, option_sets):
     """configs[4]: tumour 60x (two libraries of 30x) + normal 30x, 6 read groups -> 3 libraries over 2 files, -a -h"""
     from breakdancer_amd.synth import make_genome
     libs = ((400.0, 30.0), (420.0, 35.0), (380.0, 28.0))   # libN1 (normal), libT1, libT2 (tumour)
-    d = make_genome(share_lengths(1 / 24), coverage=(30.0, 30.0, 30.0), seed=13, libs=libs, lib_bam=(0, 1, 1), n_translocations=400)
-    assert len(d["tid"]) >= 46_000_000
+    d = make_genome(share_lengths(fraction), coverage=(30.0, 30.0, 30.0), seed=13, libs=libs, lib_bam=(0, 1, 1), n_translocations=int(9600 * fraction))
+    assert len(d["tid"]) >= min_reads
     cfg = ""
     for i, (lib, bam) in enumerate((("libN1", "normal.bam"), ("libT1", "tumour.bam"), ("libT2", "tumour.bam"))):
         for rg in ("a", "b"):
             cfg += cfg_line("rg%s%s" % (lib, rg), bam, lib, *libs[i])
-    for kw in (dict(cn_lib=1, print_af=1), dict(print_af=1)):
+    for kw in option_sets:
         run = oracle_from_soa(d, cfg, ["normal.bam", "tumour.bam"], make_opts(**kw), TARGETS)
-        assert run.lib_names == ["libN1", "libT1", "libT2"] and run.n_svs > 15000
+        assert run.lib_names == ["libN1", "libT1", "libT2"] and run.n_svs > 15000 * (fraction * 24)
         bd = product_from_oracle(run)
         compare(run, bd)
         region_invariants(bd.regions())
@@ -170,3 +172,42 @@ def test_config4_tumour_normal_two_files_copy_number_and_allele_frequency():
         two = svs[(svs["printed"] == 1) & (svs["region"][:, 1] >= 0) & (svs["flag"] != 8)]
         assert (two["cn_count"] == (3 if kw.get("cn_lib") else 2)).mean() > 0.8   # a copy number per library / per file
         bd.close()
+
+
+def test_more_than_two_to_the_26_anomalous_reads_in_one_context():
+    """The reference grows its containers as long as memory lasts (ReadRegionData.cpp:93).  Here read indices are 32-bit and only the
+    REGION ids are 26-bit fields of the packed group key: a context takes 2^31 anomalous reads as long as they form at most
+    2^26 - 2 accepted regions.  150 M reads of which half are discordant (75 M anomalous reads, ~3 M regions): no oracle run at
+    this size, nor the host walk (19 minutes for these 75 M reads) -- region-table invariants, census of the anomalous reads against
+    a numpy restatement, recovery of the planted clusters, and the same tables when the stream arrives in ragged batches."""
+    import breakdancer_amd as bda
+    from breakdancer_amd.api import LibraryConfig, Options
+    from breakdancer_amd.synth import LIB_C2, make_chromosome
+    d = make_chromosome(length=500_000_000, coverage=30.0, seed=5, discordant=0.5, cluster=24)
+    n = len(d["tid"])
+    mq_ok = d["mapq"] > 35
+    sam = d["flag"].astype(np.int64)
+    ai = np.abs(d["isize"])
+    fr = ((sam & 0x10) != 0) != ((sam & 0x20) != 0)
+    rf = fr & ((d["pos"] < d["mpos"]) == ((sam & 0x10) != 0))
+    anom = ((~fr) | rf | (fr & ~rf & ((ai > 490) | (ai < 310)))) & mq_ok
+    assert int(anom.sum()) > (1 << 26) + 5_000_000
+
+    def run(cuts):
+        bd = bda.BreakDancer(Options(), [LibraryConfig(**LIB_C2)], 1, max_read_window_size=200)
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            bd.push_reads({k: v[lo:hi] for k, v in d.items()})
+        return bd.run()
+    a = run([0, n])
+    sa = a.summary()
+    assert sa["n_reads"] == n and sa["n_anomalous"] == int(anom.sum())
+    assert 1_000_000 < sa["n_regions"] < (1 << 26)
+    region_invariants(a.regions())
+    svs, _, _ = a.svs()
+    dels = svs[(svs["flag"] == 2) & (svs["printed"] == 1)]
+    assert len(dels) > 10_000 and abs(np.median(dels["size"]) - 1150) < 60   # (most clusters of this dense input score below the print threshold)
+    b = run([0, 1, 70_000_001, 70_000_002, 140_000_000, n])
+    assert b.summary() == sa
+    tables_equal(a, b)
+    a.close()
+    b.close()

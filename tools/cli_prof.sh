@@ -13,7 +13,7 @@ d = make_chromosome(length=int($MBP * 1e6), seed=1)
 write_bam("syn.bam", d, ["chrS"], seed=3)
 open("cfg", "w").write("readgroup:rg1\tplatform:illumina\tmap:syn.bam\treadlen:100.00\tlib:lib1\tnum:10001\tlower:310.00\tupper:490.00\tmean:400.00\tstd:30.00\n")
 PY
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/cliprof/out -o p -- $R/bin/breakdancer-max cfg > /tmp/cliprof/stdout.txt 2> /tmp/cliprof/stderr.txt
+BDX_CLEAN_EXIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/cliprof/out -o p -- $R/bin/breakdancer-max cfg > /tmp/cliprof/stdout.txt 2> /tmp/cliprof/stderr.txt
 f=$(find /tmp/cliprof/out -name "*kernel_stats.csv" | head -1)
 head -25 "$f"
 mkdir -p $R/gpurun_out && cp "$f" $R/gpurun_out/cli_kernel_stats.csv
