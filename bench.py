@@ -219,7 +219,7 @@ def time_host_soa(bda, Options, LibraryConfig, LIB_C2, d, n, local, torch):
     """(ii) pinned host SoA -> SV table: bdx_push + bdx_run on a context whose read store is already reserved"""
     from breakdancer_amd.api import BATCH_FIELDS
     pinned, views = {}, {}
-    for k, dt in BATCH_FIELDS:
+    for k, dt in list(BATCH_FIELDS) + [("name_check", np.uint64)]:
         arr = np.ascontiguousarray(d[k], dtype=dt)
         view = {np.dtype(np.uint16): np.int16, np.dtype(np.uint64): np.int64}.get(arr.dtype)
         t = torch.from_numpy(arr.view(view) if view else arr).pin_memory()
@@ -233,7 +233,7 @@ def time_host_soa(bda, Options, LibraryConfig, LIB_C2, d, n, local, torch):
     for fresh in range(2):  # (two fresh contexts, the better one: the process's very first push can pay one-time costs of the runtime)
         if fresh:
             bd.close()
-        bd = bda.BreakDancer(Options(), [LibraryConfig(**LIB_C2)], 1, ntids=1, max_read_window_size=200, device=local)
+        bd = bda.BreakDancer(Options(), [LibraryConfig(**LIB_C2)], 1, ntids=1, max_read_window_size=200, device=local).use_name_check()
         bd.lib.bdx_reserve(bd.h, n)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -252,13 +252,13 @@ def time_host_soa(bda, Options, LibraryConfig, LIB_C2, d, n, local, torch):
         nsv = bd.summary()["n_svs_printed"]
         best = dt_ if best is None else min(best, dt_)
     bd.close()
-    bytes_per_read = sum(np.dtype(dt).itemsize for _, dt in BATCH_FIELDS)
-    lazy = sum(np.dtype(dt).itemsize for k, dt in BATCH_FIELDS if k in ("name_key", "qlen", "lib", "bam"))  # (one library, one file)
+    bytes_per_read = sum(np.dtype(dt).itemsize for _, dt in BATCH_FIELDS) + 8   # (+ the second name hash)
+    lazy = 8 + sum(np.dtype(dt).itemsize for k, dt in BATCH_FIELDS if k in ("name_key", "qlen", "lib", "bam"))  # (one library, one file)
     return {"seconds": best, "value": (n / 2) / best, "unit": "read-pairs/s", "svs": nsv,
             "pcie_gb_per_s": (bytes_per_read - lazy) * n / best / 1e9, "cold_context_seconds": cold,
             "note": "bdx_push of %d pinned host records + bdx_run on a context that has run before, best of 4 (cold_context_seconds: the "
                     "first push + run of a context fresh from bdx_reserve, which sizes the later stages' buffers as well).  %d of the %d B/read "
-                    "cross PCIe as copies (name key and read length stay in the caller's pinned arrays; K2 fetches them for the ~1 %% anomalous "
+                    "cross PCIe as copies (name key, second name hash and read length stay in the caller's pinned arrays; K2 fetches them for the ~1 %% anomalous "
                     "reads; the library and file index columns are not copied for a single library and file), so the rate is the "
                     "host-to-device bandwidth of the box (pcie_gb_per_s, run time included)"
                     % (n, bytes_per_read - lazy, bytes_per_read)}
@@ -487,16 +487,18 @@ def main():
 
     d = make_chromosome(length=a.length, seed=1 + rank, name_base=rank << 40)
     n = len(d["tid"])
+    # the second hash of the read name (bdx_use_name_check: mates are joined on both), as the readers compute it beside the key
+    d["name_check"] = (d["name_key"].astype(np.uint64) * np.uint64(0xD6E8FEB86659FD93)) ^ (d["name_key"].astype(np.uint64) >> np.uint64(29))
     # inputs resident in HBM before the timed region (torch owns the memory; libbdx adopts the pointers)
     tens = {}
-    for k, dt in BATCH_FIELDS:
+    for k, dt in list(BATCH_FIELDS) + [("name_check", np.uint64)]:
         arr = np.ascontiguousarray(d[k], dtype=dt)
         view = {np.dtype(np.uint16): np.int16, np.dtype(np.uint64): np.int64}.get(arr.dtype)
         tens[k] = torch.from_numpy(arr.view(view) if view else arr).to(dev)
     torch.cuda.synchronize()
 
     def new_ctx():
-        x = bda.BreakDancer(Options(), [LibraryConfig(**LIB_C2)], 1, ntids=1, max_read_window_size=200, device=local)
+        x = bda.BreakDancer(Options(), [LibraryConfig(**LIB_C2)], 1, ntids=1, max_read_window_size=200, device=local).use_name_check()
         x.set_device_reads({k: t.data_ptr() for k, t in tens.items()}, n)
         return x
 

@@ -84,6 +84,12 @@ def make_batch(arrs):
             raise ValueError("ragged batch: %s has %d rows, expected %d" % (k, len(a), n))
         keep.append(a)
         setattr(b, k, a.ctypes.data_as(C.c_void_p))
+    if arrs.get("name_check") is not None:  # the second name hash (looked at after use_name_check() only)
+        a = np.ascontiguousarray(arrs["name_check"], dtype=np.uint64)
+        if len(a) != (n or 0):
+            raise ValueError("ragged batch: name_check has %d rows, expected %d" % (len(a), n or 0))
+        keep.append(a)
+        b.name_check = a.ctypes.data_as(C.c_void_p)
     b.n = n or 0
     return b, keep
 
@@ -140,6 +146,11 @@ class BreakDancer:
         except Exception:
             pass
 
+    def use_name_check(self, on=True):
+        """every batch carries 'name_check', a second hash of the read name: mates must agree in it as well (bdx_use_name_check)"""
+        self._chk(self.lib.bdx_use_name_check(self.h, 1 if on else 0), "bdx_use_name_check")
+        return self
+
     def push_reads(self, arrs):
         b, keep = make_batch(arrs)
         self._keep.append(keep)  # the H2D copies are asynchronous: the arrays must outlive them (released by run())
@@ -157,11 +168,15 @@ class BreakDancer:
             if src is None and k == "name_key":
                 src = arrs.get("name_id")
             cols[k] = np.ascontiguousarray(src, dtype=dt)
+        fields = list(BATCH_FIELDS)
+        if arrs.get("name_check") is not None:
+            cols["name_check"] = np.ascontiguousarray(arrs["name_check"], dtype=np.uint64)
+            fields.append(("name_check", np.uint64))
         for lo in range(0, n, batch):
             m = min(batch, n - lo)
             buf = L.bdx_batch_buf()
             self._chk(self.lib.bdx_acquire_batch(self.h, m, C.byref(buf)), "bdx_acquire_batch")
-            for k, dt in BATCH_FIELDS:
+            for k, dt in fields:
                 C.memmove(getattr(buf, k), cols[k][lo:lo + m].ctypes.data, m * np.dtype(dt).itemsize)
             self._chk(self.lib.bdx_submit_batch(self.h, m), "bdx_submit_batch")
 
@@ -175,6 +190,8 @@ class BreakDancer:
         b = L.bdx_batch()
         for k, _ in BATCH_FIELDS:
             setattr(b, k, C.c_void_p(int(ptrs[k])))
+        if ptrs.get("name_check"):
+            b.name_check = C.c_void_p(int(ptrs["name_check"]))
         b.n = n
         self._chk(self.lib.bdx_set_device_reads(self.h, C.byref(b)), "bdx_set_device_reads")
 

@@ -214,7 +214,8 @@ class BamDecoder:
         n = self.n
         cols = dict(tid=np.zeros(n, np.int32), pos=np.zeros(n, np.int32), mtid=np.zeros(n, np.int32), mpos=np.zeros(n, np.int32),
                     isize=np.zeros(n, np.int32), flag=np.zeros(n, np.uint16), qlen=np.zeros(n, np.uint16), mapq=np.zeros(n, np.uint8),
-                    lib=np.zeros(n, np.uint8), bam=np.zeros(n, np.uint8), name_key=np.zeros(n, np.uint64))
+                    lib=np.zeros(n, np.uint8), bam=np.zeros(n, np.uint8), name_key=np.zeros(n, np.uint64),
+                    name_check=np.zeros(n, np.uint64))
         b = L.bdx_batch_buf()
         for k, v in cols.items():
             setattr(b, k, v.ctypes.data)

@@ -15,6 +15,8 @@
 #include <cstddef>
 #include <cstring>
 #include <string>
+#include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "../../include/bdx.h"
@@ -88,14 +90,15 @@ struct bdx_ctx {
     ReadsSoA d{};
     size_t n = 0, cap = 0;
     bool adopted = false;
-    DevBuf b_tid, b_pos, b_mtid, b_mpos, b_isize, b_flag, b_qlen, b_mapq, b_lib, b_bam, b_key;
+    DevBuf b_tid, b_pos, b_mtid, b_mpos, b_isize, b_flag, b_qlen, b_mapq, b_lib, b_bam, b_key, b_check;
+    bool use_check = false;           // bdx_use_name_check: every batch carries a second hash of the read name, mates must agree in it too
 
     // stage buffers
     DevBuf b_libs, b_cls, b_tile_tot, b_tile_pre, b_tile_mono, b_blk_cnt, b_cnt, b_p1, b_fold, b_stash, b_chunk_tot;
-    DevBuf b_c_tid, b_c_pos, b_c_isize, b_c_meta, b_c_key, b_c_idx, b_c_nn, b_c_pk;
+    DevBuf b_c_tid, b_c_pos, b_c_isize, b_c_meta, b_c_key, b_c_check, b_c_idx, b_c_nn, b_c_pk;
     DevBuf b_cand, b_pre_q, b_pre_rev, b_pre_nonctx, b_c_first, b_c_maxq, b_c_rid, b_region_of, b_ws_u4, b_ws_u32, b_totals, b_counts;
     DevBuf b_bcnt, b_boff, b_bcur, b_e_key, b_e_idx, b_partner, b_t_key, b_t_idx;
-    DevBuf b_x_key, b_x_order, b_x_region, b_x_meta, b_x_isize, b_x_n;
+    DevBuf b_x_key, b_x_check, b_x_order, b_x_region, b_x_meta, b_x_isize, b_x_n;
     DevBuf b_lib_mean;
     DevBuf b_r_rec, b_r_pk, b_out_deg, b_parts, b_kdens, b_rs, b_slot, b_members, b_own, b_lib_stage, b_cn_stage,
         b_t_lambda, b_t_k, b_ws6;
@@ -195,7 +198,7 @@ struct bdx_ctx {
     int ring_next = 0, ring_cur = -1;
     // name keys that stay in the caller's pinned memory (bdx_push): one segment per batch; host == nullptr: that range of
     // keys was copied into the resident column
-    struct KeySeg { uint64_t begin; const uint64_t* host; const uint16_t* host_qlen; };
+    struct KeySeg { uint64_t begin; const uint64_t* host; const uint16_t* host_qlen; const uint64_t* host_check; };
     std::vector<KeySeg> key_segs;
     DevBuf b_seg, b_done, b_lb;
 };
@@ -243,8 +246,9 @@ int alloc_reads(bdx_ctx* c, size_t cap) {
                   {&c->b_isize, 4, (const void**)&c->d.isize}, {&c->b_flag, 2, (const void**)&c->d.flag},
                   {&c->b_qlen, 2, (const void**)&c->d.qlen},   {&c->b_mapq, 1, (const void**)&c->d.mapq},
                   {&c->b_lib, 1, (const void**)&c->d.lib},     {&c->b_bam, 1, (const void**)&c->d.bam},
-                  {&c->b_key, 8, (const void**)&c->d.key}};
+                  {&c->b_key, 8, (const void**)&c->d.key},     {&c->b_check, 8, (const void**)&c->d.check}};
     for (Col& col : cols) {
+        if (col.b == &c->b_check && !c->use_check) continue;
         DevBuf nb;
         HIPCHK(c, nb.ensure(cap * col.esz));
         if (c->n) HIPCHK(c, hipMemcpyAsync(nb.p, col.b->p, c->n * col.esz, hipMemcpyDeviceToDevice, c->stream));
@@ -262,6 +266,7 @@ void stage_view(const bdx_ctx::Stage& st, bdx_batch_buf* out) {
     char* p = (char*)st.buf.p;
     const size_t K = st.cap;
     out->name_key = (uint64_t*)p; p += K * 8;
+    out->name_check = (uint64_t*)p; p += K * 8;
     out->tid = (int32_t*)p; p += K * 4;
     out->pos = (int32_t*)p; p += K * 4;
     out->mtid = (int32_t*)p; p += K * 4;
@@ -316,6 +321,7 @@ int enqueue_batch(bdx_ctx* c, const bdx_batch& b, bool lazy_keys) {
     // name keys and read lengths are only needed for the anomalous reads (about 1 %): pinned ones stay where they are
     const uint64_t* dev_view = nullptr;
     const uint16_t* dev_qlen = nullptr;
+    const uint64_t* dev_check = nullptr;
     if (lazy_keys && c->key_segs.size() < 64) {
         auto device_view = [](const void* hp) -> void* {
             hipPointerAttribute_t attr{};
@@ -328,13 +334,16 @@ int enqueue_batch(bdx_ctx* c, const bdx_batch& b, bool lazy_keys) {
         };
         dev_view = (const uint64_t*)device_view(b.name_key);
         dev_qlen = dev_view ? (const uint16_t*)device_view(b.qlen) : nullptr;
-        if (!dev_qlen) dev_view = nullptr;
+        if (dev_qlen && c->use_check) dev_check = (const uint64_t*)device_view(b.name_check);
+        if (!dev_qlen || (c->use_check && !dev_check)) dev_view = nullptr;
     }
     if (!dev_view) {
         HIPCHK(c, hipMemcpyAsync((void*)(c->d.key + o), b.name_key, n * 8, hipMemcpyHostToDevice, s2));
         HIPCHK(c, hipMemcpyAsync((void*)(c->d.qlen + o), b.qlen, n * 2, hipMemcpyHostToDevice, s));
+        if (c->use_check) HIPCHK(c, hipMemcpyAsync((void*)(c->d.check + o), b.name_check, n * 8, hipMemcpyHostToDevice, s2));
     }
-    if (c->key_segs.empty() || dev_view || c->key_segs.back().host) c->key_segs.push_back(bdx_ctx::KeySeg{(uint64_t)o, dev_view, dev_qlen});
+    if (c->key_segs.empty() || dev_view || c->key_segs.back().host)
+        c->key_segs.push_back(bdx_ctx::KeySeg{(uint64_t)o, dev_view, dev_qlen, dev_check});
     HIPCHK(c, hipEventRecord(c->ev_copy, s));
     c->copy_pending = true;
     c->n += n;
@@ -438,7 +447,7 @@ void bdx_destroy(bdx_ctx* c) {
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     DevBuf* bufs[] = {&c->b_tid, &c->b_pos, &c->b_mtid, &c->b_mpos, &c->b_isize, &c->b_flag, &c->b_qlen, &c->b_mapq, &c->b_lib,
-                      &c->b_bam, &c->b_key, &c->b_libs, &c->b_cls, &c->b_stash, &c->b_chunk_tot, &c->b_tile_tot, &c->b_tile_pre, &c->b_tile_mono,
+                      &c->b_bam, &c->b_key, &c->b_check, &c->b_c_check, &c->b_x_check, &c->b_libs, &c->b_cls, &c->b_stash, &c->b_chunk_tot, &c->b_tile_tot, &c->b_tile_pre, &c->b_tile_mono,
                       &c->b_blk_cnt, &c->b_cnt, &c->b_p1, &c->b_c_tid, &c->b_c_pos, &c->b_c_isize,
                       &c->b_c_meta, &c->b_c_key, &c->b_c_idx, &c->b_c_nn, &c->b_c_pk, &c->b_cand, &c->b_pre_q, &c->b_pre_rev,
                       &c->b_pre_nonctx, &c->b_c_first, &c->b_c_maxq, &c->b_c_rid, &c->b_region_of, &c->b_ws_u4, &c->b_ws_u32, &c->b_totals,
@@ -481,7 +490,7 @@ int bdx_push(bdx_ctx* c, const bdx_batch* b) {
     if (c->adopted) return fail(c, BDX_ESTATE, "reads were adopted from the caller");
     if (b->n == 0) return BDX_OK;
     if (!b->tid || !b->pos || !b->mtid || !b->mpos || !b->isize || !b->flag || !b->qlen || !b->mapq || !b->lib || !b->bam ||
-        !b->name_key)
+        !b->name_key || (c->use_check && !b->name_check))
         return fail(c, BDX_EINVAL, "null array in batch");
     HIPCHK(c, hipSetDevice(c->device));
     return enqueue_batch(c, *b, true);
@@ -498,7 +507,7 @@ int bdx_acquire_batch(bdx_ctx* c, size_t capacity, bdx_batch_buf* out) {
         st.busy = false;
     }
     st.cap = round_up(capacity, 64);
-    HIPCHK(c, st.buf.ensure(st.cap * 35 + 64));
+    HIPCHK(c, st.buf.ensure(st.cap * 43 + 64));
     stage_view(st, out);
     c->ring_cur = c->ring_next;
     c->ring_next = (c->ring_next + 1) % 4;
@@ -515,7 +524,7 @@ int bdx_submit_batch(bdx_ctx* c, size_t n) {
     bdx_batch_buf v{};
     stage_view(st, &v);  // the layout bdx_acquire_batch handed out
     if (n > v.capacity) return fail(c, BDX_EINVAL, "more records than the acquired batch holds");
-    bdx_batch b{v.tid, v.pos, v.mtid, v.mpos, v.isize, v.flag, v.qlen, v.mapq, v.lib, v.bam, v.name_key, n};
+    bdx_batch b{v.tid, v.pos, v.mtid, v.mpos, v.isize, v.flag, v.qlen, v.mapq, v.lib, v.bam, v.name_key, n, v.name_check};
     const int rc = enqueue_batch(c, b, false);  // (the buffer is recycled: its name keys travel with the other columns)
     if (rc != BDX_OK) return rc;
     HIPCHK(c, hipEventRecord(st.done, c->copy_stream));
@@ -547,11 +556,13 @@ int bdx_reset_reads(bdx_ctx* c) {
 int bdx_set_device_reads(bdx_ctx* c, const bdx_batch* b) {
     if (!c || !b) return BDX_EINVAL;
     if (c->n && !c->adopted) return fail(c, BDX_ESTATE, "context already holds pushed reads");
-    const void* ptrs[] = {b->tid, b->pos, b->mtid, b->mpos, b->isize, b->flag, b->qlen, b->mapq, b->lib, b->bam, b->name_key};
+    const void* ptrs[] = {b->tid, b->pos, b->mtid, b->mpos, b->isize, b->flag, b->qlen, b->mapq, b->lib, b->bam, b->name_key,
+                          c->use_check ? (const void*)b->name_check : (const void*)b->name_key};
     for (const void* p : ptrs)
         if (b->n && (!p || ((uintptr_t)p & 15))) return fail(c, BDX_EINVAL, "device arrays must be non-null and 16-byte aligned");
     c->d.tid = b->tid; c->d.pos = b->pos; c->d.mtid = b->mtid; c->d.mpos = b->mpos; c->d.isize = b->isize;
     c->d.flag = b->flag; c->d.qlen = b->qlen; c->d.mapq = b->mapq; c->d.lib = b->lib; c->d.bam = b->bam; c->d.key = b->name_key;
+    c->d.check = c->use_check ? b->name_check : nullptr;
     c->n = b->n;
     c->cap = b->n;
     c->adopted = true;
@@ -830,10 +841,12 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepa
         HIPCHK(c, c->b_c_tid.ensure(cap * 4)); HIPCHK(c, c->b_c_pos.ensure(cap * 4)); HIPCHK(c, c->b_c_isize.ensure(cap * 4));
         HIPCHK(c, c->b_c_meta.ensure(cap * 4)); HIPCHK(c, c->b_c_key.ensure(cap * 8)); HIPCHK(c, c->b_c_nn.ensure(cap * 4));
         HIPCHK(c, c->b_c_idx.ensure(cap * 4));
+        if (c->use_check) HIPCHK(c, c->b_c_check.ensure(cap * 8));
         HIPCHK(c, c->b_c_pk.ensure(cap * 4 * nkeys));
         cp.tid = c->b_c_tid.as<int32_t>(); cp.pos = c->b_c_pos.as<int32_t>(); cp.isize = c->b_c_isize.as<int32_t>();
         cp.meta = c->b_c_meta.as<uint32_t>(); cp.key = c->b_c_key.as<uint64_t>(); cp.nn = c->b_c_nn.as<uint32_t>();
         cp.idx = c->b_c_idx.as<uint32_t>();
+        cp.check = c->use_check ? c->b_c_check.as<uint64_t>() : nullptr;
         cp.pk = c->b_c_pk.as<uint32_t>(); cp.cap = na;
         K2Params k2{};
         k2.r = c->d; k2.n = c->n; k2.ntiles = c->ntiles; k2.tstride = c->tstride; k2.nkeys = nkeys; k2.nlibs = c->nlibs; k2.libs = c->b_libs.as<DevLib>();
@@ -862,12 +875,13 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepa
             for (auto const& sg : c->key_segs) any_host |= sg.host != nullptr;
             if (any_host && !c->adopted) {
                 const size_t ns = c->key_segs.size();
-                std::vector<uint64_t> tab(3 * ns + 1);
+                std::vector<uint64_t> tab(4 * ns + 1);
                 for (size_t i = 0; i < ns; ++i) {
                     const bdx_ctx::KeySeg& sg = c->key_segs[i];
                     tab[i] = sg.begin;
                     tab[ns + 1 + i] = (uint64_t)(uintptr_t)(sg.host ? sg.host - sg.begin : c->d.key);
                     tab[2 * ns + 1 + i] = (uint64_t)(uintptr_t)(sg.host ? sg.host_qlen - sg.begin : c->d.qlen);
+                    tab[3 * ns + 1 + i] = (uint64_t)(uintptr_t)(sg.host ? sg.host_check - sg.begin : c->d.check);
                 }
                 tab[ns] = c->n;
                 HIPCHK(c, c->b_seg.ensure(tab.size() * 8));
@@ -877,6 +891,7 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepa
                 k2.seg_begin = c->b_seg.as<uint64_t>();
                 k2.seg_ptr = (const uint64_t* const*)(c->b_seg.as<uint64_t>() + ns + 1);
                 k2.seg_qlen = (const uint16_t* const*)(c->b_seg.as<uint64_t>() + 2 * ns + 1);
+                k2.seg_check = (const uint64_t* const*)(c->b_seg.as<uint64_t>() + 3 * ns + 1);
             }
         }
         launch_k2(k2, k2_lds_bytes(nkeys), s, c->finalize2_deferred ? &c->fp_deferred : nullptr);
@@ -1399,6 +1414,17 @@ int replay_arrays(bdx_ctx* c, uint32_t na, const uint64_t* key, const int32_t* r
     return BDX_OK;
 }
 
+// The read-level replay tells names apart by one 64-bit word.  With a second name hash in the stream, two reads are the same
+// name only if both words agree: every (key, check) pair gets a number of its own, which then serves as the key.
+void unify_names(uint64_t* key, const uint64_t* check, size_t n) {
+    struct PairHash {
+        size_t operator()(const std::pair<uint64_t, uint64_t>& p) const { return (size_t)(p.first ^ (p.second * 0x9E3779B97F4A7C15ull)); }
+    };
+    std::unordered_map<std::pair<uint64_t, uint64_t>, uint64_t, PairHash> ids;
+    ids.reserve(n);
+    for (size_t i = 0; i < n; ++i) key[i] = ids.emplace(std::make_pair(key[i], check[i]), (uint64_t)ids.size()).first->second;
+}
+
 // A read name occurs more than twice (StageCounts::irregular): everything behind the region cut is replayed one read at a
 // time on the host (H2), from the compact records; the scores still come from K5.  Names clashing across merged BAMs are the
 // usual cause -- the reference keeps running on them (ReadRegionData.cpp:108-113), so does this.
@@ -1413,6 +1439,11 @@ int replay_reads(bdx_ctx* c, uint32_t ph) {
     HIPCHK(c, hipMemcpy(region_of.data(), c->k3.region_of, (size_t)na * 4, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(meta.data(), c->cp.meta, (size_t)na * 4, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(isize.data(), c->cp.isize, (size_t)na * 4, hipMemcpyDeviceToHost));
+    if (c->cp.check && na) {
+        std::vector<uint64_t> check(na);
+        HIPCHK(c, hipMemcpy(check.data(), c->cp.check, (size_t)na * 8, hipMemcpyDeviceToHost));
+        unify_names(key.data(), check.data(), na);
+    }
     if (ph)
         for (int32_t& r : region_of)
             if (r >= 0) r += (int32_t)ph;
@@ -1452,7 +1483,7 @@ int bdx_run(bdx_ctx* c) {
         if (!c->na_alloc) return BDX_OK;
         // the region table is final after K3: the host takes its copy while the device joins the mates
         Entries en{};
-        en.key = c->cp.key; en.region = c->k3.region_of; en.meta = c->cp.meta; en.isize = c->cp.isize;
+        en.key = c->cp.key; en.check = c->cp.check; en.region = c->k3.region_of; en.meta = c->cp.meta; en.isize = c->cp.isize;
         if (c->region_of_fused) {
             en.cand = c->k3.cand; en.c_rid = c->k3.c_rid; en.region_out = c->k3.region_of;
             en.k6_scratch = c->k3.out_deg; en.scratch_cap = c->k3.cap;
@@ -1823,6 +1854,20 @@ int bdx_set_stage_timing(bdx_ctx* c, int on) {
 int bdx_set_enqueue_ahead(bdx_ctx* c, int on) {
     if (!c) return BDX_EINVAL;
     c->speculate = on < 0 ? 0 : (on > 2 ? 2 : on);
+    return BDX_OK;
+}
+
+int bdx_use_name_check(bdx_ctx* c, int on) {
+    if (!c) return BDX_EINVAL;
+    if ((on != 0) == c->use_check) return BDX_OK;
+    if (c->n) return fail(c, BDX_ESTATE, "the second name hash is switched while the context holds no reads");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->use_check = on != 0;
+    if (c->use_check && c->cap && !c->adopted) {
+        HIPCHK(c, c->b_check.ensure(c->cap * 8));
+        c->d.check = c->b_check.as<uint64_t>();
+    }
+    if (!c->use_check) c->d.check = nullptr;
     return BDX_OK;
 }
 

@@ -59,6 +59,7 @@ struct RawColumns {        // columns of every record of a piece, before the rea
     uint16_t *flag, *qlen;
     uint8_t *mapq, *lib, *keep;
     uint64_t* key;
+    uint64_t* check;
 };
 
 struct DstColumns {        // where the kept records go (the context's resident store, or the decoder's own buffers)
@@ -66,6 +67,7 @@ struct DstColumns {        // where the kept records go (the context's resident 
     uint16_t *flag, *qlen;
     uint8_t *mapq, *lib, *bam;
     uint64_t* key;
+    uint64_t* check;       // nullptr: the destination keeps no second name hash
 };
 
 struct PieceState {        // running state of one file's decode, in device memory; one instance per decoder
@@ -104,6 +106,23 @@ __host__ __device__ inline uint64_t name_hash_finish(uint64_t h, uint64_t w) {
     h = (h ^ w) * 0xc4ceb9fe1a85ec53ull;
     h ^= h >> 29;
     h *= 0xbf58476d1ce4e5b9ull;
+    return h ^ (h >> 32);
+}
+
+// the second name hash (bdx_batch::name_check; host/bam_reader.cpp check_name): other constants, a rotation and an addition per
+// word instead of the key's xor-shift, seeded by the length differently -- names whose keys collide do not collide here as well
+__host__ __device__ inline uint64_t name_check_seed(uint64_t n) { return 0xD6E8FEB86659FD93ull + n * 0x9FB21C651E98DF25ull; }
+__host__ __device__ inline uint64_t name_check_step(uint64_t h, uint64_t w) {
+    h ^= w;
+    h = (h << 27) | (h >> 37);
+    return h * 0x9FB21C651E98DF25ull + 0x52DCE729ull;
+}
+__host__ __device__ inline uint64_t name_check_finish(uint64_t h, uint64_t w) {
+    h = name_check_step(h, w);
+    h ^= h >> 33;
+    h *= 0xC2B2AE3D27D4EB4Full;
+    h ^= h >> 29;
+    h *= 0x165667B19E3779F9ull;
     return h ^ (h >> 32);
 }
 

@@ -72,7 +72,7 @@ struct bdx_bamdec {
     bool finished = false, any_submitted = false;
     // record stage scratch (one piece at a time on s_rec)
     DevBuf d_cb, d_offs, d_base, d_scan, d_state;
-    DevBuf r_tid, r_pos, r_mtid, r_mpos, r_isize, r_flag, r_qlen, r_mapq, r_lib, r_keep, r_key;
+    DevBuf r_tid, r_pos, r_mtid, r_mpos, r_isize, r_flag, r_qlen, r_mapq, r_lib, r_keep, r_key, r_check;
     uint32_t raw_cap = 0;
     // read groups
     DevBuf d_rg_hash, d_rg_off, d_rg_chars, d_rg_lib;
@@ -80,7 +80,7 @@ struct bdx_bamdec {
     RecordFilterDev filt{};
     uint8_t bam_index = 0;
     // own destination (no sink)
-    DevBuf o_tid, o_pos, o_mtid, o_mpos, o_isize, o_flag, o_qlen, o_mapq, o_lib, o_bam, o_key;
+    DevBuf o_tid, o_pos, o_mtid, o_mpos, o_isize, o_flag, o_qlen, o_mapq, o_lib, o_bam, o_key, o_check;
     size_t own_cap = 0;
     // progress record in pinned memory: [0] kept records, [1] error | past_region << 8 | redo << 32, [2] raw records, [3] sequence
     PinBuf h_progress;
@@ -122,11 +122,13 @@ DstColumns bam_dst(bdx_bamdec* d, uint64_t* cap) {
         c.tid = (int32_t*)k->d.tid; c.pos = (int32_t*)k->d.pos; c.mtid = (int32_t*)k->d.mtid; c.mpos = (int32_t*)k->d.mpos;
         c.isize = (int32_t*)k->d.isize; c.flag = (uint16_t*)k->d.flag; c.qlen = (uint16_t*)k->d.qlen; c.mapq = (uint8_t*)k->d.mapq;
         c.lib = (uint8_t*)k->d.lib; c.bam = (uint8_t*)k->d.bam; c.key = (uint64_t*)k->d.key;
+        c.check = (uint64_t*)k->d.check;   // (null unless bdx_use_name_check)
         *cap = k->cap;
     } else {
         c.tid = d->o_tid.as<int32_t>(); c.pos = d->o_pos.as<int32_t>(); c.mtid = d->o_mtid.as<int32_t>(); c.mpos = d->o_mpos.as<int32_t>();
         c.isize = d->o_isize.as<int32_t>(); c.flag = d->o_flag.as<uint16_t>(); c.qlen = d->o_qlen.as<uint16_t>(); c.mapq = d->o_mapq.as<uint8_t>();
         c.lib = d->o_lib.as<uint8_t>(); c.bam = d->o_bam.as<uint8_t>(); c.key = d->o_key.as<uint64_t>();
+        c.check = d->o_check.as<uint64_t>();
         *cap = d->own_cap;
     }
     return c;
@@ -138,7 +140,7 @@ int bam_own_reserve(bdx_bamdec* d, size_t cap, uint64_t keep_records) {
     cap = round_up(cap, 1024);
     struct Col { DevBuf* b; size_t esz; };
     Col cols[] = {{&d->o_tid, 4}, {&d->o_pos, 4}, {&d->o_mtid, 4}, {&d->o_mpos, 4}, {&d->o_isize, 4}, {&d->o_flag, 2}, {&d->o_qlen, 2},
-                  {&d->o_mapq, 1}, {&d->o_lib, 1}, {&d->o_bam, 1}, {&d->o_key, 8}};
+                  {&d->o_mapq, 1}, {&d->o_lib, 1}, {&d->o_bam, 1}, {&d->o_key, 8}, {&d->o_check, 8}};
     if (d->own_cap) BHIP(d, hipStreamSynchronize(d->s_rec));
     for (Col& c : cols) {
         DevBuf nb;
@@ -230,7 +232,7 @@ int bam_record_stage(bdx_bamdec* d, BamPiece& p, const BamPiece* next, bool is_l
         const size_t cap = round_up((size_t)bound + bound / 8, 1024);
         BHIP(d, d->r_tid.ensure(cap * 4)); BHIP(d, d->r_pos.ensure(cap * 4)); BHIP(d, d->r_mtid.ensure(cap * 4)); BHIP(d, d->r_mpos.ensure(cap * 4));
         BHIP(d, d->r_isize.ensure(cap * 4)); BHIP(d, d->r_flag.ensure(cap * 2)); BHIP(d, d->r_qlen.ensure(cap * 2)); BHIP(d, d->r_mapq.ensure(cap));
-        BHIP(d, d->r_lib.ensure(cap)); BHIP(d, d->r_keep.ensure(cap)); BHIP(d, d->r_key.ensure(cap * 8));
+        BHIP(d, d->r_lib.ensure(cap)); BHIP(d, d->r_keep.ensure(cap)); BHIP(d, d->r_key.ensure(cap * 8)); BHIP(d, d->r_check.ensure(cap * 8));
         BHIP(d, d->d_scan.ensure((cap / 256 + 8) * 4));
         d->raw_cap = (uint32_t)cap;
     }
@@ -268,7 +270,7 @@ int bam_record_stage(bdx_bamdec* d, BamPiece& p, const BamPiece* next, bool is_l
                      p.wrapped ? p.ring_beg : 0, s);
     RawColumns raw{d->r_tid.as<int32_t>(), d->r_pos.as<int32_t>(), d->r_mtid.as<int32_t>(), d->r_mpos.as<int32_t>(), d->r_isize.as<int32_t>(),
                    d->r_flag.as<uint16_t>(), d->r_qlen.as<uint16_t>(), d->r_mapq.as<uint8_t>(), d->r_lib.as<uint8_t>(), d->r_keep.as<uint8_t>(),
-                   d->r_key.as<uint64_t>()};
+                   d->r_key.as<uint64_t>(), d->r_check.as<uint64_t>()};
     launch_kb_extract(u, blocks, nblk, cb, offs, base, d->rg, d->filt, raw, st, s);
     uint64_t dst_cap = 0;
     DstColumns dst = bam_dst(d, &dst_cap);
@@ -374,7 +376,7 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
                 sink->k1_live = true;
             }
         }
-        if (sink->key_segs.empty() || sink->key_segs.back().host) sink->key_segs.push_back(bdx_ctx::KeySeg{(uint64_t)sink->n, nullptr, nullptr});
+        if (sink->key_segs.empty() || sink->key_segs.back().host) sink->key_segs.push_back(bdx_ctx::KeySeg{(uint64_t)sink->n, nullptr, nullptr, nullptr});
         d->confirmed = sink->n;
         // (records this decoder appends come behind what the store already holds)
         st.n_kept = sink->n;
@@ -405,7 +407,7 @@ void bdx_bamdec_destroy(bdx_bamdec* d) {
     for (auto& e : d->rec_events) (void)hipEventDestroy(e.second);
     for (hipEvent_t e : d->ev_pool) (void)hipEventDestroy(e);
     for (DevBuf* b : {&d->d_ring, &d->d_cb, &d->d_offs, &d->d_base, &d->d_scan, &d->d_state, &d->r_tid, &d->r_pos, &d->r_mtid, &d->r_mpos, &d->r_isize,
-                      &d->r_flag, &d->r_qlen, &d->r_mapq, &d->r_lib, &d->r_keep, &d->r_key, &d->d_rg_hash, &d->d_rg_off, &d->d_rg_chars, &d->d_rg_lib,
+                      &d->r_flag, &d->r_qlen, &d->r_mapq, &d->r_lib, &d->r_keep, &d->r_key, &d->r_check, &d->o_check, &d->d_rg_hash, &d->d_rg_off, &d->d_rg_chars, &d->d_rg_lib,
                       &d->o_tid, &d->o_pos, &d->o_mtid, &d->o_mpos, &d->o_isize, &d->o_flag, &d->o_qlen, &d->o_mapq, &d->o_lib, &d->o_bam, &d->o_key})
         b->release();
     d->h_progress.release();
@@ -648,6 +650,7 @@ int bdx_bamdec_fetch(bdx_bamdec* d, uint64_t first, uint64_t n, const bdx_batch_
     BHIP(d, hipMemcpy(out->lib, d->o_lib.as<uint8_t>() + first, n, hipMemcpyDeviceToHost));
     BHIP(d, hipMemcpy(out->bam, d->o_bam.as<uint8_t>() + first, n, hipMemcpyDeviceToHost));
     BHIP(d, hipMemcpy(out->name_key, d->o_key.as<uint64_t>() + first, n * 8, hipMemcpyDeviceToHost));
+    if (out->name_check) BHIP(d, hipMemcpy(out->name_check, d->o_check.as<uint64_t>() + first, n * 8, hipMemcpyDeviceToHost));
     return BDX_OK;
 }
 

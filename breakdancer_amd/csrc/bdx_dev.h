@@ -43,6 +43,7 @@ struct ReadsSoA {
     const uint16_t *flag, *qlen;
     const uint8_t *mapq, *lib, *bam;
     const uint64_t* key;
+    const uint64_t* check;   // second, independent hash of the read name (nullptr: names are compared by key alone)
 };
 
 // reference-length monoid of one (tile, source file): BamSummary.cpp:70-74 adds pos - last_pos for consecutive
@@ -126,6 +127,7 @@ struct Compact {
     int32_t* isize;     // |isize|
     uint32_t* meta;     // flag (4) | rev<<4 | lib<<8 | qlen<<16
     uint64_t* key;
+    uint64_t* check;    // nullptr: the stream has no second name hash
     uint32_t* idx;      // index of the read in the resident stream
     uint32_t* nn;       // normal-leftmost reads seen before this read (stream order)
     uint32_t* pk;       // [nkeys][cap]: proper reads of key k seen up to and including this read
@@ -159,6 +161,7 @@ struct K2Params {
     const uint64_t* seg_begin;          // [nseg + 1]
     const uint64_t* const* seg_ptr;     // [nseg] device-visible, biased by -seg_begin[s]
     const uint16_t* const* seg_qlen;    // [nseg] likewise
+    const uint64_t* const* seg_check;   // [nseg] likewise (only read when c.check is set)
 };
 
 __device__ __forceinline__ uint32_t meta_pack(int flag, int rev, int lib, int qlen) {

@@ -212,6 +212,7 @@ struct bdx_dist {
     uint64_t ctx_sent = 0, ctx_received = 0, gathered_bytes = 0;
     float ms_total = 0, ms_exchange = 0;
     bool ran = false;
+    bool collect_support = false;    // bdx_dist_set_collect_support: the supporting reads of every SV (-g / -d) come with the result
 };
 
 namespace {
@@ -278,7 +279,11 @@ int bdx_dist_create(bdx_dist** out, const bdx_opts* opts, const bdx_lib* libs, i
     if (hipSetDevice(device) != hipSuccess) return BDX_EHIP;
     std::unique_ptr<RcclComm> c(new RcclComm);
     c->rank = rank; c->world = world;
-    if (rccl().CommInitRank(&c->comm, world, *id, rank) != 0) return BDX_EHIP;
+    if (const int nrc = rccl().CommInitRank(&c->comm, world, *id, rank)) {   // (no handle yet to keep the message in)
+        fprintf(stderr, "[bdx] ncclCommInitRank(rank %d of %d, device %d) failed: %s (%d)\n", rank, world, device,
+                rccl().GetErrorString ? rccl().GetErrorString(nrc) : "RCCL error", nrc);
+        return BDX_EHIP;
+    }
     return dist_create_common(out, opts, libs, nlibs, nbams, ntids, max_read_window_size0, device, std::move(c));
 }
 
@@ -322,6 +327,12 @@ bdx_ctx* bdx_dist_chromosome(bdx_dist* d, int tid) {
     if (bdx_create(&c, &d->opts, d->libs.data(), d->nlibs, d->nbams, d->ntids, d->w0, d->device) != BDX_OK) return nullptr;
     d->chrom[tid] = c;
     return c;
+}
+
+int bdx_dist_set_collect_support(bdx_dist* d, int on) {
+    if (!d) return BDX_EINVAL;
+    d->collect_support = on != 0;
+    return BDX_OK;
 }
 
 bdx_ctx* bdx_dist_result(bdx_dist* d) { return d && d->ran && d->comm->rank == 0 ? d->util : nullptr; }
@@ -412,7 +423,9 @@ int bdx_dist_run(bdx_dist* d) {
 
     // ---- pass 1 on the own chromosomes; C1: counters, per-file reference lengths, per-chromosome totals ----
     const size_t tw = 2 + (size_t)nkeys;  // per chromosome: anomalous reads, normal pairs, proper reads per key
-    std::vector<uint64_t> v1((size_t)ncnt + nbams + (size_t)ntids * tw, 0);
+    const size_t at_reads = (size_t)ncnt + nbams + (size_t)ntids * tw;  // then: reads per chromosome; ranks that want the supporting reads
+    std::vector<uint64_t> v1(at_reads + (size_t)ntids + 1, 0);
+    v1[at_reads + (size_t)ntids] = d->collect_support ? 1 : 0;
     phase([&]() -> int {
         for (auto& kv : d->chrom) DCTX(d, kv.second, do_pass1(kv.second, 0, false, false));  // all enqueued, then waited for
         for (auto& kv : d->chrom) {
@@ -423,12 +436,17 @@ int bdx_dist_run(bdx_dist* d) {
             uint64_t* t = &v1[(size_t)ncnt + nbams + (size_t)kv.first * tw];
             t[0] = c->p1.n_anom; t[1] = c->p1.n_normal;
             for (int k = 0; k < nkeys; ++k) t[2 + k] = c->p1.key_tot[k];
+            v1[at_reads + (size_t)kv.first] = c->n;
         }
         DCTX(d, U, do_pass1(U));  // (no reads: brings the utility context's buffers up)
         return BDX_OK;
     });
     int rc = exchange(v1);
     if (rc != BDX_OK) return rc;
+    const uint64_t want_support = v1[at_reads + (size_t)ntids];
+    if (want_support != 0 && want_support != (uint64_t)world) return dfail(d, BDX_EINVAL, "bdx_dist_set_collect_support is set on some ranks only");
+    std::vector<uint64_t> read_base((size_t)ntids + 1, 0);   // a chromosome's first read in the merged stream (position sorted: chromosomes ascending)
+    for (int t = 0; t < ntids; ++t) read_base[(size_t)t + 1] = read_base[t] + v1[at_reads + (size_t)t];
     std::vector<uint32_t> cnt_g(ncnt);
     for (int i = 0; i < ncnt; ++i) cnt_g[i] = (uint32_t)v1[i];
     uint32_t covered = 0;  // BamSummary.cpp:123-126: a uint32 maximum compared against each file's size_t sum
@@ -460,12 +478,19 @@ int bdx_dist_run(bdx_dist* d) {
             DHIP(d, hipMemcpyAsync(&nn, c->cp.nn, 4, hipMemcpyDeviceToHost, c->stream));
             DHIP(d, hipStreamSynchronize(c->stream));
             uint64_t* t = &v2[(size_t)kv.first * 3];
-            t[0] = 1; t[1] = (uint64_t)meta_qlen(meta); t[2] = nn;
+            t[0] = 1 | (c->use_check ? 2 : 0); t[1] = (uint64_t)meta_qlen(meta); t[2] = nn;
         }
         return BDX_OK;
     });
     rc = exchange(v2);
     if (rc != BDX_OK) return rc;
+    // (every chromosome has one owner, so the sums are the owners' words) the second name hash: on all chromosomes or on none
+    bool with_check = false, without_check = false;
+    for (int t = 0; t < ntids; ++t) {
+        if (v2[(size_t)t * 3] & 2) with_check = true;
+        else if (v2[(size_t)t * 3] & 1) without_check = true;
+    }
+    if (with_check && without_check) return dfail(d, BDX_EINVAL, "bdx_use_name_check is set on some chromosomes' contexts only");
 
     // ---- regions; the first anomalous read of the next chromosome closes a chromosome's last candidate.  C3 ----
     std::vector<int> next_anom(ntids, -1);
@@ -528,14 +553,15 @@ int bdx_dist_run(bdx_dist* d) {
     std::vector<size_t> scount(world), sdispl(world), rcount(world), rdispl(world);
     std::vector<size_t> nscount(world), nsdispl(world), nrcount(world), nrdispl(world);   // the name census: two words per read
     size_t nsend = 0, nrecv = 0, nnsend = 0, nnrecv = 0;
-    for (int q = 0; q < world; ++q) { scount[q] = (size_t)h_cnt[q] * 3; sdispl[q] = nsend * 3; nsend += h_cnt[q]; }
+    constexpr size_t kxw = sizeof(ExchangeEntry) / 8;
+    for (int q = 0; q < world; ++q) { scount[q] = (size_t)h_cnt[q] * kxw; sdispl[q] = nsend * kxw; nsend += h_cnt[q]; }
     for (int q = 0; q < world; ++q) { nscount[q] = (size_t)h_ncnt[q] * 2; nsdispl[q] = nnsend * 2; nnsend += h_ncnt[q]; }
     phase([&]() -> int {
         DHIP(d, d->b_send.ensure(std::max<size_t>(nsend, 1) * sizeof(ExchangeEntry)));
         DHIP(d, d->b_nsend.ensure(std::max<size_t>(nnsend, 1) * 16));
         {
             std::vector<uint32_t> cur(world);
-            for (int q = 0; q < world; ++q) cur[q] = (uint32_t)(sdispl[q] / 3);
+            for (int q = 0; q < world; ++q) cur[q] = (uint32_t)(sdispl[q] / kxw);
             DHIP(d, hipMemcpy(d_cur, cur.data(), (size_t)world * 4, hipMemcpyHostToDevice));
             for (int q = 0; q < world; ++q) cur[q] = (uint32_t)(nsdispl[q] / 2);
             DHIP(d, hipMemcpy(d_ncur, cur.data(), (size_t)world * 4, hipMemcpyHostToDevice));
@@ -546,12 +572,12 @@ int bdx_dist_run(bdx_dist* d) {
             if (!na) continue;
             // the chromosome's own pairs: K4 on its compact reads, pair groups with genome-wide region ids
             Entries en{};
-            en.key = c->cp.key; en.region = c->k3.region_of; en.meta = c->cp.meta; en.isize = c->cp.isize;
+            en.key = c->cp.key; en.check = c->cp.check; en.region = c->k3.region_of; en.meta = c->cp.meta; en.isize = c->cp.isize;
             en.region_base = (int32_t)rbase[kv.first];
             DCTX(d, c, do_join_local(c, na, en, &c->b_p1.as<Pass1>()->n_anom, false));
-            launch_k7_scatter(c->cp.key, c->k3.region_of, c->cp.meta, c->cp.isize, &c->b_p1.as<Pass1>()->n_anom, na, (uint32_t)world,
+            launch_k7_scatter(c->cp.key, c->cp.check, c->k3.region_of, c->cp.meta, c->cp.isize, &c->b_p1.as<Pass1>()->n_anom, na, (uint32_t)world,
                               (uint32_t)base[(size_t)kv.first * tw], (int32_t)rbase[kv.first], d_cur, d->b_send.as<ExchangeEntry>(), c->stream);
-            launch_k7_names_scatter(c->cp.key, c->cp.meta, &c->b_p1.as<Pass1>()->n_anom, na, (uint32_t)world, (uint32_t)kv.first, d_ncur,
+            launch_k7_names_scatter(c->cp.key, c->cp.check, c->cp.meta, &c->b_p1.as<Pass1>()->n_anom, na, (uint32_t)world, (uint32_t)kv.first, d_ncur,
                                     d->b_nsend.as<unsigned long long>(), c->stream);
         }
         for (auto& kv : d->chrom) DHIP(d, hipStreamSynchronize(kv.second->stream));
@@ -562,7 +588,7 @@ int bdx_dist_run(bdx_dist* d) {
     for (int q = 0; q < world; ++q) { v4[(size_t)rank * world + q] = h_cnt[q]; v4[W2 + (size_t)rank * world + q] = h_ncnt[q]; }
     rc = exchange(v4);
     if (rc != BDX_OK) return rc;
-    for (int q = 0; q < world; ++q) { rcount[q] = (size_t)v4[(size_t)q * world + rank] * 3; rdispl[q] = nrecv * 3; nrecv += v4[(size_t)q * world + rank]; }
+    for (int q = 0; q < world; ++q) { rcount[q] = (size_t)v4[(size_t)q * world + rank] * kxw; rdispl[q] = nrecv * kxw; nrecv += v4[(size_t)q * world + rank]; }
     for (int q = 0; q < world; ++q) { nrcount[q] = (size_t)v4[W2 + (size_t)q * world + rank] * 2; nrdispl[q] = nnrecv * 2; nnrecv += v4[W2 + (size_t)q * world + rank]; }
     if (nnrecv > 0x7FFFFFFFull) return dfail(d, BDX_ELIMIT, "too many anomalous reads' names on one rank");
     {
@@ -609,12 +635,14 @@ int bdx_dist_run(bdx_dist* d) {
             const uint32_t n32 = (uint32_t)nrecv;
             DHIP(d, U->b_x_key.ensure(nrecv * 8)); DHIP(d, U->b_x_order.ensure(nrecv * 4)); DHIP(d, U->b_x_region.ensure(nrecv * 4));
             DHIP(d, U->b_x_meta.ensure(nrecv * 4)); DHIP(d, U->b_x_isize.ensure(nrecv * 4)); DHIP(d, U->b_x_n.ensure(16));
-            launch_k7_unpack(d->b_recv.as<ExchangeEntry>(), n32, U->b_x_key.as<uint64_t>(), U->b_x_order.as<uint32_t>(), U->b_x_region.as<int32_t>(),
-                             U->b_x_meta.as<uint32_t>(), U->b_x_isize.as<int32_t>(), us);
+            if (with_check) DHIP(d, U->b_x_check.ensure(nrecv * 8));
+            launch_k7_unpack(d->b_recv.as<ExchangeEntry>(), n32, U->b_x_key.as<uint64_t>(), with_check ? U->b_x_check.as<uint64_t>() : nullptr,
+                             U->b_x_order.as<uint32_t>(), U->b_x_region.as<int32_t>(), U->b_x_meta.as<uint32_t>(), U->b_x_isize.as<int32_t>(), us);
             DHIP(d, hipMemcpyAsync(U->b_x_n.p, &n32, 4, hipMemcpyHostToDevice, us));
             DHIP(d, hipMemsetAsync(U->b_counts.p, 0, sizeof(StageCounts), us));
             Entries en{};
             en.key = U->b_x_key.as<uint64_t>(); en.region = U->b_x_region.as<int32_t>(); en.order = U->b_x_order.as<uint32_t>();
+            en.check = with_check ? U->b_x_check.as<uint64_t>() : nullptr;
             en.meta = U->b_x_meta.as<uint32_t>(); en.isize = U->b_x_isize.as<int32_t>();
             DCTX(d, U, do_join_local(U, n32, en, U->b_x_n.as<uint32_t>(), false));
             DHIP(d, hipMemcpyAsync(U->h_counts.p, U->b_counts.p, sizeof(StageCounts), hipMemcpyDeviceToHost, us));
@@ -666,7 +694,8 @@ int bdx_dist_run(bdx_dist* d) {
     v5[(size_t)world * 3] = irregular;
     rc = exchange(v5);
     if (rc != BDX_OK) return rc;
-    const bool replay = v5[(size_t)world * 3] != 0;   // some rank met a read name more than twice
+    // some rank met a read name more than twice -- or the caller wants the reads behind every SV, which only the read-level walk knows
+    const bool replay = v5[(size_t)world * 3] != 0 || want_support != 0;
     std::vector<size_t> gcount(world), gdispl(world);
     size_t all_bytes = 0, ng_all = 0;
     for (int q = 0; q < world; ++q) { gcount[q] = (size_t)v5[(size_t)q * 3 + 2]; gdispl[q] = all_bytes; all_bytes += gcount[q]; ng_all += v5[(size_t)q * 3 + 1]; }
@@ -678,8 +707,10 @@ int bdx_dist_run(bdx_dist* d) {
 
     // ---- a read name seen more than twice (clashing names across merged files): the pair model does not hold, and the reference's
     // behaviour (ReadRegionData.cpp:108-113,152-175, SvBuilder.cpp:101-118) depends on the order of ALL sightings.  Every rank sends
-    // the compact records of its chromosomes (name key, genome-wide region id, meta, |isize|, tid: 24 bytes per anomalous read) to
-    // rank 0, which replays the run read by read (H2, bdx_walk_reads.cpp) on the gathered region table ----
+    // the compact records of its chromosomes (name key, genome-wide region id, meta, |isize|, tid, second name hash, index in the
+    // chromosome's stream: 40 bytes per anomalous read) to rank 0, which replays the run read by read (H2, bdx_walk_reads.cpp) on the
+    // gathered region table.  The same route serves bdx_dist_set_collect_support: the supporting reads of an SV (-g / -d dumps,
+    // BreakDancer.cpp:514-534) are known to the read-level walk only ----
     std::vector<uint64_t> rp_host;   // rank 0: all ranks' records
     std::vector<size_t> rp_count(world), rp_displ(world);
     if (replay) {
@@ -689,11 +720,13 @@ int bdx_dist_run(bdx_dist* d) {
                 bdx_ctx* c = kv.second;
                 const uint32_t na = c->p1.n_anom;
                 if (!na) continue;
-                std::vector<uint64_t> key(na);
+                std::vector<uint64_t> key(na), chk(na, 0);
                 std::vector<int32_t> reg(na), isz(na);
-                std::vector<uint32_t> meta(na);
+                std::vector<uint32_t> meta(na), ridx(na);
                 DHIP(d, hipStreamSynchronize(c->stream));
+                DHIP(d, hipMemcpy(ridx.data(), c->cp.idx, (size_t)na * 4, hipMemcpyDeviceToHost));
                 DHIP(d, hipMemcpy(key.data(), c->cp.key, (size_t)na * 8, hipMemcpyDeviceToHost));
+                if (c->cp.check) DHIP(d, hipMemcpy(chk.data(), c->cp.check, (size_t)na * 8, hipMemcpyDeviceToHost));
                 DHIP(d, hipMemcpy(reg.data(), c->k3.region_of, (size_t)na * 4, hipMemcpyDeviceToHost));
                 DHIP(d, hipMemcpy(meta.data(), c->cp.meta, (size_t)na * 4, hipMemcpyDeviceToHost));
                 DHIP(d, hipMemcpy(isz.data(), c->cp.isize, (size_t)na * 4, hipMemcpyDeviceToHost));
@@ -703,6 +736,8 @@ int bdx_dist_run(bdx_dist* d) {
                     mine_rec.push_back(key[j]);
                     mine_rec.push_back((uint64_t)g | ((uint64_t)meta[j] << 32));
                     mine_rec.push_back((uint64_t)(uint32_t)isz[j] | ((uint64_t)(uint32_t)kv.first << 32));
+                    mine_rec.push_back(chk[j]);
+                    mine_rec.push_back(ridx[j]);
                 }
             }
             DHIP(d, d->b_pack.ensure(std::max<size_t>(mine_rec.size() * 8, 8)));
@@ -735,56 +770,95 @@ int bdx_dist_run(bdx_dist* d) {
 
     // (from here on nothing is collective any more: rank 0 finishes on its own)
     if (rank == 0) {
-        // which rank owns which chromosome follows from the packages themselves: every region record carries its tid
-        std::vector<char> host(all_bytes);
-        if (all_bytes) DHIP(d, hipMemcpy(host.data(), d->b_all.p, all_bytes, hipMemcpyDeviceToHost));
-        std::vector<RegionRec> regs(NR);
-        std::vector<uint32_t> pk((size_t)NR * 2 * nkeys);
-        std::vector<GroupRec> groups(ng_all);
-        std::vector<uint64_t> fill(ntids, 0);
-        size_t gi = 0;
+        // The packages sit in HBM (b_all): the region table is assembled there -- every record to rbase[tid] + its rank among its
+        // chromosome's records (k8_place_regions) -- and, unless the run is replayed, gets K6's slot space by a scan; the host takes
+        // ONE copy of the finished table (the getters and the host's share of the walk read it).
+        const uint64_t na_all = base[(size_t)ntids * tw];
+        const int nkeys2 = 2 * nkeys;
+        GatherDesc D{};
+        D.world = world;
+        uint32_t max_nr = 0, max_ng = 0;
+        size_t nr_sum = 0;
         for (int q = 0; q < world; ++q) {
             const size_t nr = (size_t)v5[(size_t)q * 3], ng = (size_t)v5[(size_t)q * 3 + 1];
-            const RegionRec* rr = (const RegionRec*)(host.data() + gdispl[q]);
-            const uint32_t* rp = (const uint32_t*)(host.data() + gdispl[q] + nr * rrec);
-            const GroupRec* rg = (const GroupRec*)(host.data() + gdispl[q] + nr * (rrec + rpk));
-            for (size_t i = 0; i < nr; ++i) {
-                const int t = rr[i].tid;
-                if (t < 0 || t >= ntids || fill[t] >= v3[(size_t)t * 2]) return dfail(d, BDX_EINTERNAL, "region table of the gather does not add up");
-                const size_t g = (size_t)rbase[t] + fill[t]++;
-                regs[g] = rr[i];
-                memcpy(&pk[g * 2 * nkeys], rp + i * 2 * nkeys, rpk);
-            }
-            if (ng) memcpy(&groups[gi], rg, ng * grec);
-            gi += ng;
+            D.p[q] = GatherPackage{gdispl[q], gdispl[q] + nr * rrec, gdispl[q] + nr * (rrec + rpk), (uint32_t)nr, (uint32_t)ng};
+            max_nr = std::max(max_nr, (uint32_t)nr); max_ng = std::max(max_ng, (uint32_t)ng);
+            nr_sum += nr;
         }
-        for (int t = 0; t < ntids; ++t)
-            if (fill[t] != v3[(size_t)t * 2]) return dfail(d, BDX_EINTERNAL, "region table of the gather does not add up");
+        if (nr_sum != NR) return dfail(d, BDX_EINTERNAL, "region table of the gather does not add up");
+        std::vector<RegionRec> regs(NR);
+        std::vector<uint32_t> pk((size_t)NR * nkeys2);
+        // scratch of the assembly, behind the bucketed groups: rbase[ntids + 1] | goff[NR + 2] | cnt[NR + 1] | scan ws | {n, err, slots}
+        const size_t cap_alloc = (size_t)std::max<uint64_t>(std::max<uint64_t>(na_all, NR), 1);
+        const size_t g_bytes = round_up(std::max<size_t>(ng_all, 1) * sizeof(GroupRec), 8);
+        const size_t ws_words = scan_grid((uint32_t)std::max<uint64_t>(NR, 1)) + 2;
+        DHIP(d, d->b_gin.ensure(g_bytes + ((size_t)ntids + 1) * 8 + ((size_t)NR + 2 + (size_t)NR + 1 + ws_words + 4) * 4));
+        GroupRec* d_groups = d->b_gin.as<GroupRec>();
+        uint64_t* d_rbase = (uint64_t*)((char*)d->b_gin.p + g_bytes);
+        uint32_t* d_goff = (uint32_t*)(d_rbase + ntids + 1);
+        uint32_t* d_gcnt = d_goff + NR + 2;
+        uint32_t* d_ws = d_gcnt + NR + 1;
+        uint32_t* d_misc = d_ws + ws_words;   // [0] number of regions, [1] error flag, [2] slots
+        uint32_t misc[4] = {(uint32_t)NR, 0, 0, 0};
+        if (NR) {
+            DHIP(d, U->b_r_rec.ensure(cap_alloc * sizeof(RegionRec))); DHIP(d, U->b_r_pk.ensure(cap_alloc * nkeys2 * 4));
+            DHIP(d, hipMemcpyAsync(d_rbase, rbase.data(), ((size_t)ntids + 1) * 8, hipMemcpyHostToDevice, us));
+            DHIP(d, hipMemcpyAsync(d_misc, misc, 16, hipMemcpyHostToDevice, us));
+            DHIP(d, hipMemsetAsync(d_gcnt, 0, ((size_t)NR + 1) * 4, us));
+            launch_k8_place_regions((const char*)d->b_all.p, D, max_nr, d_rbase, ntids, nkeys2, U->b_r_rec.as<RegionRec>(), U->b_r_pk.as<uint32_t>(),
+                                    d_misc + 1, us);
+            if (!replay) launch_k8_slot_space(U->b_r_rec.as<RegionRec>(), (uint32_t)NR, d_misc, d_misc + 2, d_ws, us);
+            DHIP(d, hipMemcpyAsync(regs.data(), U->b_r_rec.p, NR * sizeof(RegionRec), hipMemcpyDeviceToHost, us));
+            DHIP(d, hipMemcpyAsync(pk.data(), U->b_r_pk.p, pk.size() * 4, hipMemcpyDeviceToHost, us));
+            DHIP(d, hipMemcpyAsync(misc, d_misc, 16, hipMemcpyDeviceToHost, us));
+            DHIP(d, hipStreamSynchronize(us));
+            if (misc[1]) return dfail(d, BDX_EINTERNAL, "region table of the gather does not add up");
+        }
+        auto groups_to_host = [&](std::vector<GroupRec>& groups) -> int {   // the packages' pair groups as they came (the host-only walk)
+            groups.resize(ng_all);
+            size_t gi = 0;
+            for (int q = 0; q < world; ++q) {
+                if (D.p[q].ng) DHIP(d, hipMemcpy(&groups[gi], (const char*)d->b_all.p + D.p[q].groups_off, (size_t)D.p[q].ng * grec, hipMemcpyDeviceToHost));
+                gi += D.p[q].ng;
+            }
+            return BDX_OK;
+        };
         DCTX(d, U, set_pass1(U, cnt_g.data(), covered, window, true));
         U->n = 0;
         const int32_t lm = last_anom_tid >= 0 ? (int32_t)(uint32_t)v3[(size_t)last_anom_tid * 2 + 1] : 0;
         if (replay) {
             // the records of all chromosomes in stream order: chromosomes ascending, each rank's package holds its own in order
-            const uint64_t na_all = base[(size_t)ntids * tw];
-            if (rp_host.size() != (size_t)na_all * 3) return dfail(d, BDX_EINTERNAL, "compact records of the gather do not add up");
-            std::vector<uint64_t> key(na_all);
+            constexpr size_t kw = 5;
+            if (rp_host.size() != (size_t)na_all * kw) return dfail(d, BDX_EINTERNAL, "compact records of the gather do not add up");
+            std::vector<uint64_t> key(na_all), chk(with_check ? na_all : 0);
             std::vector<int32_t> reg(na_all), isz(na_all);
             std::vector<uint32_t> meta(na_all);
+            std::vector<uint64_t> sidx(want_support ? na_all : 0);   // index in the merged stream
             std::vector<uint64_t> at(ntids);
             for (int t = 0; t < ntids; ++t) at[t] = base[(size_t)t * tw];
             for (size_t i = 0; i < (size_t)na_all; ++i) {
-                const uint64_t w0 = rp_host[i * 3], w1 = rp_host[i * 3 + 1], w2 = rp_host[i * 3 + 2];
+                const uint64_t w0 = rp_host[i * kw], w1 = rp_host[i * kw + 1], w2 = rp_host[i * kw + 2];
                 const uint32_t t = (uint32_t)(w2 >> 32);
                 if (t >= (uint32_t)ntids || at[t] >= base[(size_t)(t + 1) * tw]) return dfail(d, BDX_EINTERNAL, "compact records of the gather do not add up");
                 const size_t o = (size_t)at[t]++;
                 key[o] = w0; reg[o] = (int32_t)(uint32_t)w1; meta[o] = (uint32_t)(w1 >> 32); isz[o] = (int32_t)(uint32_t)w2;
+                if (with_check) chk[o] = rp_host[i * kw + 3];
+                if (want_support) sidx[o] = read_base[t] + rp_host[i * kw + 4];
             }
             // (a region's first read: its index in its chromosome's list -> in the genome-wide one)
             for (size_t r = 0; r < NR; ++r) regs[r].first += (uint32_t)base[(size_t)regs[r].tid * tw];
             decode_regions(U, regs.data(), pk.data(), (uint32_t)NR, 0, false);
             U->counts.n_regions = (uint32_t)NR;
             U->counts.last_maxq = lm;
-            DCTX(d, U, replay_arrays(U, (uint32_t)na_all, key.data(), reg.data(), meta.data(), isz.data(), 0, nullptr));
+            if (with_check) unify_names(key.data(), chk.data(), (size_t)na_all);
+            std::vector<uint32_t> sup;
+            U->collect_support = want_support != 0;
+            DCTX(d, U, replay_arrays(U, (uint32_t)na_all, key.data(), reg.data(), meta.data(), isz.data(), 0, want_support ? &sup : nullptr));
+            if (want_support) {   // compact indices -> indices in the merged stream, and the reads' flags
+                U->sup_idx.resize(sup.size());
+                U->sup_flag.resize(sup.size());
+                for (size_t i = 0; i < sup.size(); ++i) { U->sup_idx[i] = sidx[sup[i]]; U->sup_flag[i] = (uint8_t)meta_flag(meta[sup[i]]); }
+            }
             U->p1.n_anom = (uint32_t)na_all;
             d->ran = true;
             d->ms_total = ms_between(t_begin, std::chrono::steady_clock::now());
@@ -793,9 +867,10 @@ int bdx_dist_run(bdx_dist* d) {
         const bool host_only = U->host_walk_only;  // (bdx_set_host_walk on the result context's owner: the whole walk on the host)
         // slot space of K6: region r owns the slots [first, first + n) -- its reads' places in a single-context run; here
         // simply the regions laid end to end (every group owns at least one read of its later region, so they suffice)
-        uint64_t slots = 0;
-        for (size_t r = 0; r < NR; ++r) { regs[r].first = (uint32_t)slots; slots += regs[r].n; }
+        const uint64_t slots = misc[2];   // (k8_slot_space: regs[r].first = the slots of the regions before r)
         if (host_only || NR == 0 || ng_all == 0 || slots > kMaxAnomalous) {
+            std::vector<GroupRec> groups;
+            if (const int gr = groups_to_host(groups)) return gr;
             decode_regions(U, regs.data(), pk.data(), (uint32_t)NR, 0, false);
             decode_groups(U, groups.data(), (uint32_t)ng_all, 0);
             U->counts.n_regions = (uint32_t)NR;
@@ -803,31 +878,19 @@ int bdx_dist_run(bdx_dist* d) {
             DCTX(d, U, score_host_terms(U));
             DCTX(d, U, finish_host_walk(U));
         } else {
-            // the device walk of a single-context run (K6), fed with the gathered groups bucketed by their later region
+            // the device walk of a single-context run (K6), fed with the gathered groups bucketed by their later region: a histogram, a
+            // scan and a scatter over the packages where they lie (k8_bucket_groups)
             const uint32_t cap = (uint32_t)slots;
-            std::vector<uint32_t> goff(NR + 2, 0);
-            for (const GroupRec& g : groups) ++goff[(size_t)((g.key >> 12) & ((1u << 26) - 1)) + 1];
-            for (size_t r = 0; r < NR; ++r) goff[r + 1] += goff[r];
-            std::vector<GroupRec> sorted(ng_all);
-            {
-                std::vector<uint32_t> cur(goff.begin(), goff.begin() + NR);
-                for (const GroupRec& g : groups) sorted[cur[(size_t)((g.key >> 12) & ((1u << 26) - 1))]++] = g;
-            }
-            DHIP(d, U->b_r_rec.ensure((size_t)cap * sizeof(RegionRec))); DHIP(d, U->b_r_pk.ensure((size_t)cap * 2 * nkeys * 4));
+            launch_k8_bucket_groups((const char*)d->b_all.p, D, max_ng, (uint32_t)NR, d_misc, d_gcnt, d_goff, d_groups, d_ws, d_misc + 1, us);
             DHIP(d, U->b_out_deg.ensure((size_t)cap * 6 * 4));
-            DHIP(d, d->b_gin.ensure(std::max<size_t>(ng_all, 1) * sizeof(GroupRec) + (NR + 2) * 4));
-            GroupRec* d_groups = d->b_gin.as<GroupRec>();
-            uint32_t* d_goff = (uint32_t*)(d_groups + std::max<size_t>(ng_all, 1));
-            DHIP(d, hipMemcpyAsync(U->b_r_rec.p, regs.data(), NR * sizeof(RegionRec), hipMemcpyHostToDevice, us));
-            DHIP(d, hipMemcpyAsync(U->b_r_pk.p, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, us));
-            DHIP(d, hipMemcpyAsync(d_groups, sorted.data(), ng_all * sizeof(GroupRec), hipMemcpyHostToDevice, us));
-            DHIP(d, hipMemcpyAsync(d_goff, goff.data(), (NR + 1) * 4, hipMemcpyHostToDevice, us));
             DHIP(d, hipMemcpyAsync(U->b_cnt.p, cnt_g.data(), (size_t)ncnt * 4, hipMemcpyHostToDevice, us));
             DHIP(d, hipMemcpyAsync(U->b_kdens.p, U->key_density.data(), U->key_density.size() * 4, hipMemcpyHostToDevice, us));
             StageCounts sc{};
             sc.n_regions = (uint32_t)NR; sc.last_maxq = lm;
             DHIP(d, hipMemcpyAsync(U->b_counts.p, &sc, sizeof(sc), hipMemcpyHostToDevice, us));
+            DHIP(d, hipMemcpyAsync(misc, d_misc, 16, hipMemcpyDeviceToHost, us));
             DHIP(d, hipStreamSynchronize(us));  // (host vectors above go out of use)
+            if (misc[1]) return dfail(d, BDX_EINTERNAL, "pair groups of the gather name regions that do not exist");
             launch_k6_scratch_init(U->b_out_deg.as<uint32_t>(), cap, us);
             U->na_alloc = cap;
             U->k3 = K3Arrays{}; U->k4 = K4Arrays{}; U->cp = Compact{};

@@ -129,6 +129,7 @@ constexpr uint32_t kMaxAnomalous = 0x7FFFFF00u;       // anomalous reads of one 
 // a name seen three times is noticed wherever its reads lie, but it never forms a pair)
 struct Entries {
     const uint64_t* key;
+    const uint64_t* check;   // second name hash: two entries are mates only if it agrees as well (nullptr: the key alone decides)
     const int32_t* region;   // region id (global ids when the entries come from several shards)
     const uint32_t* order;   // position in the merged stream order; nullptr = the entry index itself
     const uint32_t* meta;    // flag | rev<<4 | lib<<8 | qlen<<16
@@ -163,8 +164,9 @@ struct ExchangeEntry {  // one CTX read on its way to the rank that joins its na
     int32_t region;     // global region id, -1: the read sits in a rejected candidate region
     uint32_t meta;
     int32_t isize;
+    uint64_t check;     // second name hash (0 when the streams carry none)
 };
-static_assert(sizeof(ExchangeEntry) == 24, "exchange entries travel as three 64-bit words");
+static_assert(sizeof(ExchangeEntry) == 32, "exchange entries travel as four 64-bit words");
 // the rank that joins a name key: a mixed hash, so that the two mates of a pair (same key) meet on one rank
 __host__ __device__ __forceinline__ uint32_t exchange_owner(uint64_t k, uint32_t world) {
     k = (k ^ (k >> 33)) * 0xff51afd7ed558ccdull;
@@ -172,17 +174,26 @@ __host__ __device__ __forceinline__ uint32_t exchange_owner(uint64_t k, uint32_t
     return (uint32_t)(k % world);
 }
 void launch_k7_names_count(const uint64_t* key, const uint32_t* n_ptr, uint32_t n_upper, uint32_t world, uint32_t* cnt, hipStream_t s);
-void launch_k7_names_scatter(const uint64_t* key, const uint32_t* meta, const uint32_t* n_ptr, uint32_t n_upper, uint32_t world, uint32_t tid,
-                             uint32_t* cursor, unsigned long long* out, hipStream_t s);
+void launch_k7_names_scatter(const uint64_t* key, const uint64_t* check, const uint32_t* meta, const uint32_t* n_ptr, uint32_t n_upper, uint32_t world,
+                             uint32_t tid, uint32_t* cursor, unsigned long long* out, hipStream_t s);
 void launch_k7_names_census(const unsigned long long* in, uint32_t n, unsigned long long* table, unsigned long long* info, uint32_t* first_tid,
                             uint32_t mask, uint32_t* irregular, hipStream_t s);
 void launch_k7_count(const uint64_t* key, const uint32_t* meta, const uint32_t* n_ptr, uint32_t n_upper, uint32_t world, uint32_t* cnt,
                      hipStream_t s);
-void launch_k7_scatter(const uint64_t* key, const int32_t* region_of, const uint32_t* meta, const int32_t* isize, const uint32_t* n_ptr,
+void launch_k7_scatter(const uint64_t* key, const uint64_t* check, const int32_t* region_of, const uint32_t* meta, const int32_t* isize, const uint32_t* n_ptr,
                        uint32_t n_upper, uint32_t world, uint32_t order_base, int32_t region_base, uint32_t* cursor, ExchangeEntry* out,
                        hipStream_t s);
-void launch_k7_unpack(const ExchangeEntry* in, uint32_t n, uint64_t* key, uint32_t* order, int32_t* region, uint32_t* meta, int32_t* isize,
-                      hipStream_t s);
+// rank 0: the packages of the gather (byte offsets into the gather buffer; a package = its rank's region records, their prefix
+// samples, its pair groups)
+struct GatherPackage { uint64_t regions_off, pk_off, groups_off; uint32_t nr, ng; };
+struct GatherDesc { GatherPackage p[kMaxRanks]; int world; };
+void launch_k8_place_regions(const char* all, const GatherDesc& D, uint32_t max_nr, const uint64_t* rbase, int ntids, int nkeys2, RegionRec* r_rec,
+                             uint32_t* r_pk, uint32_t* err, hipStream_t s);
+void launch_k8_bucket_groups(const char* all, const GatherDesc& D, uint32_t max_ng, uint32_t nregions, const uint32_t* n_dev, uint32_t* cnt,
+                             uint32_t* goff, GroupRec* out, uint32_t* ws, uint32_t* err, hipStream_t s);
+void launch_k8_slot_space(RegionRec* r_rec, uint32_t nregions, const uint32_t* n_dev, uint32_t* total, uint32_t* ws, hipStream_t s);
+void launch_k7_unpack(const ExchangeEntry* in, uint32_t n, uint64_t* key, uint64_t* check, uint32_t* order, int32_t* region, uint32_t* meta,
+                      int32_t* isize, hipStream_t s);
 
 void launch_k4_join_only(const K4Arrays& k4, const Entries& e, const uint32_t* n_ptr, uint32_t n_upper, StageCounts* counts, hipStream_t s);
 

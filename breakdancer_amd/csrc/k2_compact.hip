@@ -40,10 +40,11 @@ __device__ __forceinline__ unsigned class_byte(const uint64_t (&cq)[kSub / 2], i
 
 // name key and length of read i: from the resident columns, or -- when bdx_push left them in the caller's pinned host
 // memory -- from the segment (one per pushed batch) that holds them; only anomalous reads (about 1 %) get here
-__device__ __forceinline__ void key_and_qlen_of(const K2Params& p, uint64_t i, uint64_t& key, int& qlen) {
+__device__ __forceinline__ void key_and_qlen_of(const K2Params& p, uint64_t i, uint64_t& key, int& qlen, uint64_t& check) {
     if (p.nseg == 0) {
         key = p.r.key[i];
         qlen = (int)p.r.qlen[i];
+        if (p.c.check) check = p.r.check[i];
         return;
     }
     int lo = 0, hi = p.nseg - 1;
@@ -53,6 +54,7 @@ __device__ __forceinline__ void key_and_qlen_of(const K2Params& p, uint64_t i, u
     }
     key = p.seg_ptr[lo][i];
     qlen = (int)p.seg_qlen[lo][i];
+    if (p.c.check) check = p.seg_check[lo][i];
 }
 
 // finalize_kernel scanned a tile-total column in chunks: the exclusive prefix at a super tile is its chunk-local prefix plus the
@@ -137,14 +139,16 @@ template <bool kBases> __device__ __forceinline__ void k2_body(const K2Params& p
                     if (q < A && j < p.c.cap) {  // (the capacity can be a guess of an enqueue-ahead run)
                         const uint64_t i = (uint64_t)tile * kTile + (r1.x & 255u);
                         const uint32_t k0 = (r1.x >> 20) & 63u;
-                        uint64_t key;
+                        uint64_t key, check = 0;
                         int qlen;
-                        key_and_qlen_of(p, i, key, qlen);
+                        key_and_qlen_of(p, i, key, qlen, check);
                         p.c.tid[j] = (int32_t)r0.x;
                         p.c.pos[j] = (int32_t)r0.y;
                         p.c.isize[j] = (int32_t)r0.z;
                         p.c.meta[j] = r0.w | ((uint32_t)qlen << 16);
                         p.c.key[j] = key;
+                    if (p.c.check) p.c.check[j] = check;
+                        if (p.c.check) p.c.check[j] = check;
                         p.c.idx[j] = (uint32_t)i;
                         p.c.nn[j] = p.nn_base + pre_norm + e[0] + ((r1.x >> 8) & 511u);
                         p.c.pk[j] = p.pk_base[0] + pre_k0 + e[1] + (k0 == 0 ? r1.y : 0u);
@@ -217,11 +221,12 @@ template <bool kBases> __device__ __forceinline__ void k2_body(const K2Params& p
                     p.c.tid[j] = p.r.tid[i];
                     p.c.pos[j] = p.r.pos[i];
                     p.c.isize[j] = abs(p.r.isize[i]);
-                    uint64_t key;
+                    uint64_t key, check = 0;
                     int qlen;
-                    key_and_qlen_of(p, i, key, qlen);
+                    key_and_qlen_of(p, i, key, qlen, check);
                     p.c.meta[j] = meta_pack((int)((src >> kOffBits) & 15u), (sam >> 4) & 1u, lib_of(p, i), qlen);
                     p.c.key[j] = key;
+                    if (p.c.check) p.c.check[j] = check;
                     p.c.idx[j] = (uint32_t)i;
                     p.c.nn[j] = s_nn[w * kSlice + q];
                 }

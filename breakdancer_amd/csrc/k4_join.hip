@@ -105,7 +105,7 @@ constexpr uint32_t kMaxProbes = 4096;  // a name key shared by thousands of read
 
 template <bool kLds>
 __device__ __forceinline__ void join_bucket(uint64_t* tkey, int32_t* tidx, uint32_t cap, const K4Arrays& k4, const int32_t* region,
-                                            uint32_t off, uint32_t cnt, StageCounts* counts) {
+                                            const uint64_t* check, uint32_t off, uint32_t cnt, StageCounts* counts) {
     for (uint32_t s = threadIdx.x; s < cap; s += blockDim.x) tidx[s] = -1;
     __syncthreads();
     for (uint32_t e = threadIdx.x; e < cnt; e += blockDim.x) {
@@ -131,7 +131,7 @@ __device__ __forceinline__ void join_bucket(uint64_t* tkey, int32_t* tidx, uint3
         for (uint32_t probes = 0; probes < lim; ++probes) {  // to the end of the probe run: a second match is a name seen three times
             const int32_t o = tidx[s];
             if (o == -1) break;
-            if (o != j && tkey[s] == key) {
+            if (o != j && tkey[s] == key && (!check || check[o] == check[j])) {  // (equal keys of two different names: not mates)
                 if (mate != -1) counts->irregular = 1;
                 mate = o;
             }
@@ -142,7 +142,7 @@ __device__ __forceinline__ void join_bucket(uint64_t* tkey, int32_t* tidx, uint3
     }
 }
 
-__global__ __launch_bounds__(256) void k4_join_kernel(K4Arrays k4, const int32_t* region, StageCounts* counts) {
+__global__ __launch_bounds__(256) void k4_join_kernel(K4Arrays k4, const int32_t* region, const uint64_t* check, StageCounts* counts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t b = blockIdx.x;
     const uint32_t off = k4.boff[b], cnt = k4.boff[b + 1] - off;
@@ -150,9 +150,9 @@ __global__ __launch_bounds__(256) void k4_join_kernel(K4Arrays k4, const int32_t
     if (2 * cnt <= (uint32_t)kJoinLdsSlots) {
         uint64_t* tkey = (uint64_t*)smem;
         int32_t* tidx = (int32_t*)(tkey + kJoinLdsSlots);
-        join_bucket<true>(tkey, tidx, 2 * cnt, k4, region, off, cnt, counts);
+        join_bucket<true>(tkey, tidx, 2 * cnt, k4, region, check, off, cnt, counts);
     } else {
-        join_bucket<false>(k4.t_key + 2 * (size_t)off, k4.t_idx + 2 * (size_t)off, 2 * cnt, k4, region, off, cnt, counts);
+        join_bucket<false>(k4.t_key + 2 * (size_t)off, k4.t_idx + 2 * (size_t)off, 2 * cnt, k4, region, check, off, cnt, counts);
     }
 }
 
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k4_direct_join_kernel(K4Arrays k4, Entrie
         if (old == ~0ull) return;  // first of its name so far
         if ((uint32_t)(old >> 32) == tag) {
             const uint32_t o = (uint32_t)old;
-            if (en.key[o] == key) {
+            if (en.key[o] == key && (!en.check || en.check[o] == en.check[j])) {  // (equal keys of two different names: probe on)
                 const int ro = en.c_rid ? en.c_rid[en.cand[o]] : en.region[o];
                 const bool alive = rj >= 0 && ro >= 0;  // both mates in accepted regions (ReadRegionData.cpp:177-199)
                 k4.partner[j] = alive ? (int32_t)o : -2;
@@ -312,7 +312,7 @@ static void launch_k4_impl(const K4Arrays& k4, const Entries& en, const uint32_t
         (void)hipFuncSetAttribute((const void*)k4_aggregate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kAggSlots * 16 + 32);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k4_join_kernel, dim3(k4.nbuckets), dim3(256), (size_t)kJoinLdsSlots * 12, s, k4, en.region, counts);
+    hipLaunchKernelGGL(k4_join_kernel, dim3(k4.nbuckets), dim3(256), (size_t)kJoinLdsSlots * 12, s, k4, en.region, en.check, counts);
     if (aggregate) hipLaunchKernelGGL(k4_aggregate_kernel, dim3(g), dim3(256), (size_t)kAggSlots * 16 + 32, s, k4, en, n_ptr, counts);
 }
 

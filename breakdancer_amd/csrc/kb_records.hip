@@ -177,6 +177,21 @@ __device__ __forceinline__ uint64_t hash_bytes(const uint8_t* s, uint32_t n) {  
     return name_hash_finish(h, w);
 }
 
+// key and second hash of a read name in one pass over its bytes
+__device__ __forceinline__ void hash_name_pair(const uint8_t* s, uint32_t n, uint64_t& key, uint64_t& check) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)n, g = name_check_seed(n);
+    uint32_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        const uint64_t w = ld64(s + i);
+        h = name_hash_step(h, w);
+        g = name_check_step(g, w);
+    }
+    uint64_t w = 0;
+    for (uint32_t k = 0; i + k < n; ++k) w |= (uint64_t)s[i + k] << (8 * k);
+    key = name_hash_finish(h, w);
+    check = name_check_finish(g, w);
+}
+
 __device__ __forceinline__ uint8_t resolve_library(const RgTable& rg, const uint8_t* s, uint32_t n, bool have) {
     if (!have) {   // no RG tag: the empty id (never configured) -> the fallback
         n = 0;
@@ -294,7 +309,10 @@ __global__ __launch_bounds__(64) void kb_extract_kernel(const uint8_t* __restric
         raw.qlen[r] = (uint16_t)(l_qseq > 65535 ? 65535 : l_qseq);
         raw.mapq[r] = (uint8_t)bdqual;
         raw.lib[r] = resolve_library(rg, rgp, rgl, rgp != nullptr);
-        raw.key[r] = hash_bytes(p + 32, l_read_name ? l_read_name - 1 : 0);
+        uint64_t nk, nc;
+        hash_name_pair(p + 32, l_read_name ? l_read_name - 1 : 0, nk, nc);
+        raw.key[r] = nk;
+        raw.check[r] = nc;
     }
 }
 
@@ -364,6 +382,7 @@ __global__ __launch_bounds__(kCompactThreads) void kb_compact_scatter_kernel(Raw
     dst.tid[d] = raw.tid[i]; dst.pos[d] = raw.pos[i]; dst.mtid[d] = raw.mtid[i]; dst.mpos[d] = raw.mpos[i]; dst.isize[d] = raw.isize[i];
     dst.flag[d] = raw.flag[i]; dst.qlen[d] = raw.qlen[i]; dst.mapq[d] = raw.mapq[i]; dst.lib[d] = raw.lib[i]; dst.bam[d] = bam_index;
     dst.key[d] = raw.key[i];
+    if (dst.check) dst.check[d] = raw.check[i];
 }
 
 __global__ void kb_compact_finish_kernel(const uint32_t* __restrict__ wg_cnt, uint32_t nwg_cap, PieceState* st, volatile uint64_t* progress, uint64_t sequence) {

@@ -39,6 +39,7 @@ def _lib():
         lib.bdx_dist_run.argtypes = [vp]
         lib.bdx_dist_result.argtypes = [vp]
         lib.bdx_dist_result.restype = vp
+        lib.bdx_dist_set_collect_support.argtypes = [vp, C.c_int]
         lib.bdx_dist_get_exchange.argtypes = [vp, vp, vp, vp, vp, vp]
         lib.bdx_dist_owner.argtypes = [C.c_uint64, C.c_int]
         lib.bdx_dist_plan.argtypes = [vp, C.c_int, C.c_int, vp]
@@ -137,6 +138,11 @@ class DistRun:
                 raise BdxError("bdx_dist_chromosome(%d) failed" % tid)
             self._chrom[tid] = BreakDancer.borrow(h, self.opts, self.libs, self.nbams)
         return self._chrom[tid]
+
+    def collect_support(self, on=True):
+        """the result also holds the supporting reads of every SV (every rank alike, before run)"""
+        self._chk(self.lib.bdx_dist_set_collect_support(self.h, 1 if on else 0), "bdx_dist_set_collect_support")
+        return self
 
     def run(self):
         self._chk(self.lib.bdx_dist_run(self.h), "bdx_dist_run")

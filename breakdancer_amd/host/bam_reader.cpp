@@ -72,6 +72,30 @@ uint64_t hash_name(const char* s, size_t n) {
     return h;
 }
 
+uint64_t check_name(const char* s, size_t n) {
+    // the second name hash (bdx_batch::name_check): csrc/bdx_bam_dev.h name_check_*, the same function as the device decoder's
+    uint64_t h = 0xD6E8FEB86659FD93ull + (uint64_t)n * 0x9FB21C651E98DF25ull;
+    auto step = [](uint64_t a, uint64_t w) {
+        a ^= w;
+        a = (a << 27) | (a >> 37);
+        return a * 0x9FB21C651E98DF25ull + 0x52DCE729ull;
+    };
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, s + i, 8);
+        h = step(h, w);
+    }
+    uint64_t w = 0;
+    if (i < n) memcpy(&w, s + i, n - i);
+    h = step(h, w);
+    h ^= h >> 33;
+    h *= 0xC2B2AE3D27D4EB4Full;
+    h ^= h >> 29;
+    h *= 0x165667B19E3779F9ull;
+    return h ^ (h >> 32);
+}
+
 namespace {
 constexpr size_t kFrontGap = 4u << 20;  // room in front of a batch for the unparsed tail of the previous one
 }  // namespace

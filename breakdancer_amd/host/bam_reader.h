@@ -83,6 +83,7 @@ private:
 };
 
 uint64_t hash_name(const char* s, size_t n);  // 64-bit name key shared by the two mates of a pair
+uint64_t check_name(const char* s, size_t n); // a second, independent hash of the name (bdx_batch::name_check)
 
 // first position in [from, seg_end) of `data` where three BAM records in a row look valid (field ranges, size equation, read
 // name; `end` bounds what may be read); seg_end if there is none.  A guess: callers verify it against the true boundary chain

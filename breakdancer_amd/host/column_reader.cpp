@@ -448,7 +448,7 @@ void ColumnReader::decode_piece(Scratch& sc, Piece& p, bool known_start, uint64_
     {
         const size_t guess = own / 180 + 16;
         c.tid.reserve(guess); c.pos.reserve(guess); c.mtid.reserve(guess); c.mpos.reserve(guess); c.isize.reserve(guess);
-        c.flag.reserve(guess); c.qlen.reserve(guess); c.mapq.reserve(guess); c.lib.reserve(guess); c.name_key.reserve(guess);
+        c.flag.reserve(guess); c.qlen.reserve(guess); c.mapq.reserve(guess); c.lib.reserve(guess); c.name_key.reserve(guess); c.name_check.reserve(guess);
     }
     while (pos < own) {
         while (pos + 4 > sc.filled)
@@ -519,6 +519,7 @@ void ColumnReader::decode_piece(Scratch& sc, Piece& p, bool known_start, uint64_
         c.mapq.push_back(r.bdqual);
         c.lib.push_back(lib);
         c.name_key.push_back(hash_name(r.qname, r.l_qname));
+        c.name_check.push_back(check_name(r.qname, r.l_qname));
     }
     p.next_abs = p.abs_begin + pos;
 }

@@ -45,11 +45,11 @@ struct ColumnChunk {
     std::vector<int32_t> tid, pos, mtid, mpos, isize;
     std::vector<uint16_t> flag, qlen;
     std::vector<uint8_t> mapq, lib;
-    std::vector<uint64_t> name_key;
+    std::vector<uint64_t> name_key, name_check;
     size_t size() const { return tid.size(); }
     void clear() {
         tid.clear(); pos.clear(); mtid.clear(); mpos.clear(); isize.clear(); flag.clear(); qlen.clear(); mapq.clear(); lib.clear();
-        name_key.clear();
+        name_key.clear(); name_check.clear();
     }
 };
 

@@ -24,9 +24,9 @@ int main(int argc, char** argv) {
                    l.mean_insertsize, l.std_insertsize, l.uppercutoff, l.lowercutoff, l.readlens, l.min_mapping_quality);
         }
         for (size_t i = 0; i < rs.size(); ++i)
-            printf("%d\t%d\t%d\t%d\t%d\t%u\t%u\t%u\t%u\t%u\t%llu\n", rs.tid[i], rs.pos[i], rs.mtid[i], rs.mpos[i], rs.isize[i],
+            printf("%d\t%d\t%d\t%d\t%d\t%u\t%u\t%u\t%u\t%u\t%llu\t%llu\n", rs.tid[i], rs.pos[i], rs.mtid[i], rs.mpos[i], rs.isize[i],
                    (unsigned)rs.flag[i], (unsigned)rs.qlen[i], (unsigned)rs.mapq[i], (unsigned)rs.lib[i], (unsigned)rs.bam[i],
-                   (unsigned long long)rs.name_key[i]);
+                   (unsigned long long)rs.name_key[i], (unsigned long long)rs.name_check[i]);
     } catch (std::exception const& e) {
         std::cerr << "ERROR: " << e.what() << "\n";
         return 1;

@@ -71,9 +71,10 @@ struct RoutingSink : BatchSink {
     RoutingSink(std::vector<bdx_dist*>& r, const std::vector<int>& ro) : ranks(r), rank_of(ro) {}
     bdx_batch_buf acquire(size_t capacity) override {
         const size_t K = (capacity + 63) / 64 * 64;
-        store.resize(K * 35 + 64);
+        store.resize(K * 43 + 64);
         char* p = store.data();
         cur.name_key = (uint64_t*)p; p += K * 8;
+        cur.name_check = (uint64_t*)p; p += K * 8;
         cur.tid = (int32_t*)p; p += K * 4; cur.pos = (int32_t*)p; p += K * 4; cur.mtid = (int32_t*)p; p += K * 4;
         cur.mpos = (int32_t*)p; p += K * 4; cur.isize = (int32_t*)p; p += K * 4;
         cur.flag = (uint16_t*)p; p += K * 2; cur.qlen = (uint16_t*)p; p += K * 2;
@@ -90,6 +91,7 @@ struct RoutingSink : BatchSink {
             if (tid < 0 || (size_t)tid >= rank_of.size()) throw std::runtime_error("record with a reference id beyond the header's sequences");
             bdx_ctx* c = bdx_dist_chromosome(ranks[rank_of[tid]], tid);
             if (!c) throw std::runtime_error("bdx_dist_chromosome failed");
+            check(c, bdx_use_name_check(c, 1), "bdx_use_name_check");
             const size_t m = hi - lo;
             bdx_batch_buf b{};
             check(c, bdx_acquire_batch(c, m, &b), "bdx_acquire_batch");
@@ -98,6 +100,7 @@ struct RoutingSink : BatchSink {
             memcpy(b.flag, cur.flag + lo, m * 2); memcpy(b.qlen, cur.qlen + lo, m * 2);
             memcpy(b.mapq, cur.mapq + lo, m); memcpy(b.lib, cur.lib + lo, m); memcpy(b.bam, cur.bam + lo, m);
             memcpy(b.name_key, cur.name_key + lo, m * 8);
+            memcpy(b.name_check, cur.name_check + lo, m * 8);
             check(c, bdx_submit_batch(c, m), "bdx_submit_batch");
             lo = hi;
         }
@@ -211,7 +214,9 @@ int main(int argc, char** argv) {
         std::future<int> ctx_ready;
         if (!sharded)
             ctx_ready = std::async(std::launch::async, [&] {
-                return bdx_create(&ctx, &opts.o, libs.data(), nlibs, nbams, 0, cfg.max_read_window_size(), opts.device);
+                int rc = bdx_create(&ctx, &opts.o, libs.data(), nlibs, nbams, 0, cfg.max_read_window_size(), opts.device);
+                if (rc == BDX_OK) rc = bdx_use_name_check(ctx, 1);   // mates are joined on two hashes of the read name
+                return rc;
             });
         // resident store sized from the compressed files (a record takes 50-150 bytes of BAM; a store that is too small
         // grows, at the price of classifying from the first tile again)
@@ -225,7 +230,6 @@ int main(int argc, char** argv) {
         bool device_decoded = false;
         auto t_decoded = now();
         if (sharded) {
-            if (want_dumps) throw std::runtime_error("-g / -d need the supporting reads of every SV: run on one GPU (unset BDX_GPUS)");
             if (restored) throw std::runtime_error("-R is not supported with BDX_GPUS");
             std::vector<std::string> names;
             std::vector<uint32_t> lengths;
@@ -233,6 +237,8 @@ int main(int argc, char** argv) {
             const int ntids = (int)std::max<size_t>(names.size(), 1), world = (int)devices.size();
             int rc = bdx_dist_create_threads(ranks.data(), &opts.o, libs.data(), nlibs, nbams, ntids, cfg.max_read_window_size(), devices.data(), world);
             if (rc != BDX_OK) throw std::runtime_error(std::string("bdx_dist_create_threads: ") + bdx_strerror(rc));
+            if (want_dumps)   // -g / -d: the supporting reads come with the result (gathered compact records, walked read by read on rank 0)
+                for (bdx_dist* r : ranks) bdx_dist_set_collect_support(r, 1);
             std::vector<uint64_t> weight(lengths.begin(), lengths.end());  // chromosomes -> ranks by sequence length
             weight.resize(ntids, 0);
             std::vector<int> rank_of(ntids, 0);

@@ -24,6 +24,7 @@ bdx_batch ReadStream::batch() const {
     b.tid = tid.data(); b.pos = pos.data(); b.mtid = mtid.data(); b.mpos = mpos.data(); b.isize = isize.data();
     b.flag = flag.data(); b.qlen = qlen.data(); b.mapq = mapq.data(); b.lib = lib.data(); b.bam = bam.data();
     b.name_key = name_key.data();
+    b.name_check = name_check.data();
     b.n = size();
     return b;
 }
@@ -183,6 +184,7 @@ public:
             memcpy(buf_.mapq + used_, c.mapq.data() + lo, m); memcpy(buf_.lib + used_, c.lib.data() + lo, m);
             memset(buf_.bam + used_, bam, m);
             memcpy(buf_.name_key + used_, c.name_key.data() + lo, m * 8);
+            memcpy(buf_.name_check + used_, c.name_check.data() + lo, m * 8);
             used_ += m; lo += m; total_ += m;
             if (used_ == buf_.capacity) close();
         }
@@ -193,6 +195,7 @@ public:
         buf_.tid[u] = c.tid[i]; buf_.pos[u] = c.pos[i]; buf_.mtid[u] = c.mtid[i]; buf_.mpos[u] = c.mpos[i]; buf_.isize[u] = c.isize[i];
         buf_.flag[u] = c.flag[i]; buf_.qlen[u] = c.qlen[i]; buf_.mapq[u] = c.mapq[i]; buf_.lib[u] = c.lib[i]; buf_.bam[u] = bam;
         buf_.name_key[u] = c.name_key[i];
+        buf_.name_check[u] = c.name_check[i];
         ++used_; ++total_;
         if (used_ == buf_.capacity) close();
     }
@@ -262,19 +265,20 @@ struct VectorSink : BatchSink {  // batches appended to a ReadStream
         base = out.size();
         const size_t n = base + cap;
         out.tid.resize(n); out.pos.resize(n); out.mtid.resize(n); out.mpos.resize(n); out.isize.resize(n); out.flag.resize(n);
-        out.qlen.resize(n); out.mapq.resize(n); out.lib.resize(n); out.bam.resize(n); out.name_key.resize(n);
+        out.qlen.resize(n); out.mapq.resize(n); out.lib.resize(n); out.bam.resize(n); out.name_key.resize(n); out.name_check.resize(n);
         bdx_batch_buf b{};
         b.tid = out.tid.data() + base; b.pos = out.pos.data() + base; b.mtid = out.mtid.data() + base; b.mpos = out.mpos.data() + base;
         b.isize = out.isize.data() + base; b.flag = out.flag.data() + base; b.qlen = out.qlen.data() + base;
         b.mapq = out.mapq.data() + base; b.lib = out.lib.data() + base; b.bam = out.bam.data() + base;
         b.name_key = out.name_key.data() + base;
+        b.name_check = out.name_check.data() + base;
         b.capacity = cap;
         return b;
     }
     void submit(size_t n) override {
         const size_t m = base + n;
         out.tid.resize(m); out.pos.resize(m); out.mtid.resize(m); out.mpos.resize(m); out.isize.resize(m); out.flag.resize(m);
-        out.qlen.resize(m); out.mapq.resize(m); out.lib.resize(m); out.bam.resize(m); out.name_key.resize(m);
+        out.qlen.resize(m); out.mapq.resize(m); out.lib.resize(m); out.bam.resize(m); out.name_key.resize(m); out.name_check.resize(m);
     }
 };
 

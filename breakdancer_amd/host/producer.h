@@ -16,7 +16,7 @@ struct ReadStream {
     std::vector<int32_t> tid, pos, mtid, mpos, isize;
     std::vector<uint16_t> flag, qlen;
     std::vector<uint8_t> mapq, lib, bam;
-    std::vector<uint64_t> name_key;
+    std::vector<uint64_t> name_key, name_check;
     std::vector<std::string> targets;  // sequence names of the first BAM (BamMerger.cpp:78)
     size_t size() const { return tid.size(); }
     bdx_batch batch() const;

@@ -144,13 +144,14 @@ class ShardedRun:
     longest-processing-time packing.  comm=TorchComm: one process per GPU over RCCL; add_chromosome only for the tids this
     rank owns (plan_chromosomes)."""
 
-    def __init__(self, opts, libs, nbams, max_read_window_size, comm=None, device=0, ntids=None, world=1):
+    def __init__(self, opts, libs, nbams, max_read_window_size, comm=None, device=0, ntids=None, world=1, support=False):
         from . import dist as D
         if opts.min_len < 0:
             raise BdxError("staged runs do not support a negative -s")
         self.opts, self.libs, self.nbams, self.w0 = opts, list(libs), nbams, max_read_window_size
         self.comm, self.device, self.ntids, self.world = comm, device, ntids, (comm.world if comm else world)
         self.D = D
+        self.support = support
         self.pending = {}
 
     def add_chromosome(self, tid, arrs):
@@ -162,20 +163,29 @@ class ShardedRun:
         if self.comm is not None and self.comm.world > 1:
             ntids = max(self.comm.allgather_obj(ntids))
             d = D.DistRun.from_process_group(self.opts, self.libs, self.nbams, ntids, self.w0, self.device)
+            if self.support:
+                d.collect_support()
             for tid, arrs in sorted(self.pending.items()):
                 c = d.chromosome(tid)
                 if len(arrs["tid"]):
+                    if arrs.get("name_check") is not None:
+                        c.use_name_check()
                     c.push_reads(arrs)
             d.run()
             self.exchange = d.exchange()
             self._ranks = [d]
             return d.result()
         ranks = D.DistRun.threads(self.opts, self.libs, self.nbams, ntids, self.w0, [self.device] * self.world)
+        if self.support:
+            for r in ranks:
+                r.collect_support()
         counts = {t: len(a["tid"]) for t, a in self.pending.items()}
         for r, tids in enumerate(plan_chromosomes(counts, self.world)):
             for tid in tids:
                 c = ranks[r].chromosome(tid)
                 if len(self.pending[tid]["tid"]):
+                    if self.pending[tid].get("name_check") is not None:
+                        c.use_name_check()
                     c.push_reads(self.pending[tid])
         res = D.run_threads(ranks)
         self.exchange = [r.exchange() for r in ranks]

@@ -87,13 +87,17 @@ typedef struct bdx_lib {
  *             io/BamSummary.cpp:123,135-138)
  *             (an index out of range counts as 0; a context with one library / one file therefore never looks at the
  *             respective array -- it still has to be there)
- *   name_key  64-bit key of the read name; mates share it (ReadRegionData.cpp:109 joins on qname) */
+ *   name_key  64-bit key of the read name; mates share it (ReadRegionData.cpp:109 joins on qname)
+ *   name_check a second, independent 64-bit hash of the read name (after bdx_use_name_check; ignored and may be NULL otherwise):
+ *             two reads are taken for one name only if key and check both agree, so that two names whose keys collide are
+ *             not joined (the reference compares the names themselves, ReadRegionData.cpp:109, SvBuilder.cpp:101-118) */
 typedef struct bdx_batch {
     const int32_t *tid, *pos, *mtid, *mpos, *isize;
     const uint16_t *flag, *qlen;
     const uint8_t *mapq, *lib, *bam;
     const uint64_t* name_key;
     size_t n;
+    const uint64_t* name_check;
 } bdx_batch;
 
 /* Replaces: ConfigLoader + BreakDancer construction (io/ConfigLoader.cpp:18-44, BreakDancer.cpp:87-128).
@@ -131,7 +135,12 @@ typedef struct bdx_batch_buf {
     uint8_t *mapq, *lib, *bam;
     uint64_t* name_key;
     size_t capacity;   /* records the buffer holds (>= the capacity asked for) */
+    uint64_t* name_check;   /* read by bdx_submit_batch after bdx_use_name_check(ctx, 1) only */
 } bdx_batch_buf;
+/* Declares that every batch of this context (pushed, staged, adopted, or decoded by a bdx_bamdec) carries name_check.  Only the
+ * anomalous reads' values are ever looked at: the mate join compares them on every key match, across GPUs as well (bdx_dist), and
+ * the read-level replay tells names apart by the pair.  To be called while the context holds no reads; default off. */
+int bdx_use_name_check(bdx_ctx* ctx, int on);
 int bdx_reserve(bdx_ctx* ctx, size_t n_reads);
 int bdx_push(bdx_ctx* ctx, const bdx_batch* host_batch);
 int bdx_acquire_batch(bdx_ctx* ctx, size_t capacity, bdx_batch_buf* out);
@@ -335,6 +344,11 @@ int bdx_dist_world(const bdx_dist* d);
 bdx_ctx* bdx_dist_chromosome(bdx_dist* d, int tid);
 int bdx_dist_run(bdx_dist* d);
 bdx_ctx* bdx_dist_result(bdx_dist* d);
+/* before bdx_dist_run, on every rank alike: the result context also holds the supporting reads of every SV (bdx_get_sv_support on
+ * bdx_dist_result; read_index = position in the merged stream of the whole run, chromosomes ascending) -- the input of the
+ * reference's -g / -d dumps (BreakDancer.cpp:514-534).  The compact records of all chromosomes are then gathered and rank 0 walks
+ * them read by read, as for read names seen more than twice. */
+int bdx_dist_set_collect_support(bdx_dist* d, int on);
 /* after bdx_dist_run: CTX join records this rank sent / received in the all-to-all, bytes gathered on rank 0, wall time
  * of the whole run and of the exchange + CTX join (ms).  Any pointer may be NULL. */
 int bdx_dist_get_exchange(const bdx_dist* d, uint64_t* ctx_records_sent, uint64_t* ctx_records_received, uint64_t* gathered_bytes,

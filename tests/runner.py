@@ -42,12 +42,26 @@ def apply_test_switches(bd):
     return bd
 
 
-def product_from_oracle(run, device=0, support=False, host_walk=False):
+def colliding_names(soa, share):
+    """the stream with name keys that `share` different read names have in common, and a second hash that tells them apart
+    (the oracle keeps the exact names: with bdx_use_name_check the product must still agree with it)"""
+    out = dict(soa)
+    ids = np.asarray(soa["name_id"], dtype=np.uint64)
+    out["name_id"] = ids // np.uint64(share)
+    out["name_check"] = (ids * np.uint64(0x9E3779B97F4A7C15)) ^ (ids >> np.uint64(7))
+    return out
+
+
+def product_from_oracle(run, device=0, support=False, host_walk=False, collide=0, name_check=True):
     """Feed the product the exact merged stream the oracle consumed (the producer's job in the CLI)."""
     libs = [LibraryConfig(*[float(x) for x in run.lib_f[i]], min_mapping_quality=int(run.lib_i[i, 0]),
                           bam_file_index=int(run.lib_i[i, 1]), name=run.lib_names[i]) for i in range(run.nlibs)]
     bd = apply_test_switches(bda.BreakDancer(product_options(run.opts), libs, run.nbams, ntids=0, max_read_window_size=run.w0, device=device))
     soa = run.merged_soa()
+    if collide:
+        soa = colliding_names(soa, collide)
+        if name_check:
+            bd.use_name_check()
     if support:
         bd.collect_support()
     if host_walk:
@@ -123,15 +137,18 @@ def split_by_tid(soa):
     return out
 
 
-def sharded_from_oracle(run, comm=None, device=0, world=1, keep=None):
+def sharded_from_oracle(run, comm=None, device=0, world=1, keep=None, collide=0, support=False):
     """the same whole-genome input through the chromosome-sharded path: one context per chromosome, the chromosomes dealt
     to `world` ranks (threads of this process on one GPU when comm is None)"""
     from breakdancer_amd.shard import ShardedRun
     libs = [LibraryConfig(*[float(x) for x in run.lib_f[i]], min_mapping_quality=int(run.lib_i[i, 0]),
                           bam_file_index=int(run.lib_i[i, 1]), name=run.lib_names[i]) for i in range(run.nlibs)]
     sr = ShardedRun(product_options(run.opts), libs, run.nbams, run.w0, comm=comm, device=device, world=world,
-                    ntids=len(getattr(run, "targets", [])) or None)
-    for tid, arrs in split_by_tid(run.merged_soa()).items():
+                    ntids=len(getattr(run, "targets", [])) or None, support=support)
+    soa = run.merged_soa()
+    if collide:
+        soa = colliding_names(soa, collide)
+    for tid, arrs in split_by_tid(soa).items():
         sr.add_chromosome(tid, arrs)
     res = sr.run()
     res._sharded_run = sr  # the result is a view into rank 0's context

@@ -31,7 +31,7 @@ def test_struct_layouts_match_the_header():
     assert L.SV_DTYPE.itemsize == 88 and L.SV_DTYPE.fields["logp"][1] == 80
     assert L.REGION_DTYPE.itemsize == 36
     import ctypes as C
-    assert C.sizeof(L.bdx_opts) == 56 and C.sizeof(L.bdx_lib) == 28 and C.sizeof(L.bdx_batch) == 96
+    assert C.sizeof(L.bdx_opts) == 56 and C.sizeof(L.bdx_lib) == 28 and C.sizeof(L.bdx_batch) == 104 and L.bdx_batch.name_check.offset == 96 and C.sizeof(L.bdx_batch_buf) == 104
     assert C.sizeof(L.bdx_summary) == 48
 
 

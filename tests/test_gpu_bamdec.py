@@ -117,22 +117,7 @@ def test_inflate_verdict_on_corrupted_members_agrees_with_zlib():
 
 
 # ---- records ----
-def hash_name(b):
-    M = (1 << 64) - 1
-    n = len(b)
-    h = 0x9E3779B97F4A7C15 ^ n
-    i = 0
-    while i + 8 <= n:
-        w = int.from_bytes(b[i:i + 8], "little")
-        h = ((h ^ w) * 0xff51afd7ed558ccd) & M
-        h ^= h >> 32
-        i += 8
-    w = int.from_bytes(b[i:], "little") if i < n else 0
-    h = ((h ^ w) * 0xc4ceb9fe1a85ec53) & M
-    h ^= h >> 29
-    h = (h * 0xbf58476d1ce4e5b9) & M
-    h ^= h >> 32
-    return h
+from namehash import check_name, hash_name  # noqa: E402
 
 
 def config_read_groups(path):
@@ -160,6 +145,8 @@ def check_columns(cols, recs, rg_to_lib, fallback, region=None):
     np.testing.assert_array_equal(cols["lib"], want_lib)
     want_key = np.array([hash_name(recs["name"][i].encode()) for i in idx], dtype=np.uint64)
     np.testing.assert_array_equal(cols["name_key"], want_key)
+    want_check = np.array([check_name(recs["name"][i].encode()) for i in idx], dtype=np.uint64)
+    np.testing.assert_array_equal(cols["name_check"], want_check)
 
 
 @pytest.mark.parametrize("piece_blocks,ring,batch", [(512, 0, 0), (1, 1 << 20, 1), (2, 1 << 20, 3), (2, 0, 5), (1, 0, 0)])

@@ -97,13 +97,20 @@ def test_cli_restored_statistics_are_the_ones_used(tmp_path):
 
 @pytest.mark.parametrize("gpus", ["0,0", "0,0,0"])
 @pytest.mark.parametrize("args,fn", [([], "expected_output"), (["-h"], "expected_output.af")])
-def test_cli_sharded_over_ranks_reproduces_the_golden_output(gpus, args, fn):
+def test_cli_sharded_over_ranks_reproduces_the_golden_output(gpus, args, fn, tmp_path):
     """BDX_GPUS: one whole-genome run with the chromosomes spread over several ranks (bdx_dist_*; here the ranks are
-    threads that share the one GPU) must print what the single-GPU run prints"""
+    threads that share the one GPU) must print what the single-GPU run prints -- the -g BED dump and the -d FASTQ dumps of
+    the supporting reads included (integration-test/breakdancer_test.py:117-146)"""
     p = subprocess.run([EXE] + args + ["inv_del_bam_config"], cwd=CWD, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        env=dict(os.environ, BDX_GPUS=gpus))
     assert p.returncode == 0, p.stderr.decode()
     assert filter_cmd_lines(p.stdout.decode()) == filter_cmd_lines(open(os.path.join(CWD, fn)).read())
-    p = subprocess.run([EXE, "-g", "/dev/null", "inv_del_bam_config"], cwd=CWD, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+    bed, prefix = str(tmp_path / "out.bed"), str(tmp_path / "actual")
+    p = subprocess.run([EXE, "-g", bed, "-d", prefix, "inv_del_bam_config"], cwd=CWD, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        env=dict(os.environ, BDX_GPUS=gpus))
-    assert p.returncode == 1 and b"run on one GPU" in p.stderr
+    assert p.returncode == 0, p.stderr.decode()
+    assert filter_cmd_lines(p.stdout.decode()) == filter_cmd_lines(open(os.path.join(CWD, "expected_output")).read())
+    assert open(bed).read() == open(os.path.join(CWD, "expected.bed")).read()
+    for lib in ("H_IJ-NA19238-NA19238-extlibs", "H_IJ-NA19240-NA19240-extlibs"):
+        for k in ("1", "2"):
+            assert open("%s.%s.%s.fastq" % (prefix, lib, k)).read() == open(os.path.join(CWD, "expected.%s.%s.fastq" % (lib, k))).read(), (lib, k)

@@ -131,3 +131,26 @@ def test_sharded_run_with_read_names_seen_more_than_twice(seed):
         compare(run, util, check_cls=False)
         replayed += util.was_replayed()
     assert replayed > 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_sharded_run_returns_the_supporting_reads(seed):
+    """-g / -d in a sharded run: the supporting reads of every SV, as positions in the merged stream of the whole genome, in
+    SvBuilder's observation order -- through the gather of the compact records and the read-level walk on rank 0
+    (BreakDancer.cpp:514-534, SvBuilder.cpp:101-118)"""
+    from fuzzgen import GRAPH_OPTION_SETS, OPTION_SETS, clash_names, make_graph_case
+    from runner import compare_support
+    cfg, streams, targets = (make_case if seed % 2 == 0 else make_graph_case)(1400 + seed)
+    if seed >= 4:
+        streams = clash_names(streams, seed, frac=0.03)
+    osets = OPTION_SETS if seed % 2 == 0 else GRAPH_OPTION_SETS
+    done = 0
+    for i, o in enumerate((osets[seed % len(osets)], dict(transchr_rearrange=1, min_read_pair=1), dict(min_read_pair=1, buffer_size=2))):
+        if o.get("min_len", 0) < 0:
+            continue
+        run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1, **o))
+        util = sharded_from_oracle(run, world=1 + (seed + i) % 3, support=True, collide=3 if seed == 3 else 0)
+        compare(run, util, check_cls=False)
+        compare_support(run, util)
+        done += 1
+    assert done >= 2

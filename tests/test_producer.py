@@ -22,6 +22,7 @@ def dump(args, cwd, env=None):
     data = [l.split("\t") for l in out.splitlines() if not l.startswith("#")]
     rows = np.array([[int(x) for x in f[:10]] for f in data], dtype=np.int64).reshape(-1, 10)
     keys = np.array([int(f[10]) for f in data], dtype=np.uint64)
+    dump.checks = np.array([int(f[11]) for f in data], dtype=np.uint64)   # (the second name hash of the same call)
     return head, rows, keys
 
 
@@ -99,6 +100,28 @@ def test_region_strings_follow_samtools_semantics(region, beg, end):
         want += int(((recs["tid"] == tid) & (recs["rend"] > beg) & (recs["pos"] < end)).sum())
     assert len(rows) == want and want > 0
     assert (rows[:, 0] == 22).all() and (rows[:, 1] < end).all()
+
+
+def test_both_name_hashes_follow_their_definitions(tmp_path):
+    """name_key and name_check of the host reader against the Python restatements of the two functions (tests/namehash.py; the
+    device-side decoder is held to the same restatements in test_gpu_bamdec.py) at name lengths that cover every tail of the
+    8-byte word loop, and: the two are independent of each other"""
+    from breakdancer_amd.bamwrite import write_bam
+    from breakdancer_amd.synth import make_chromosome
+    from namehash import check_name, hash_name
+    d = make_chromosome(length=20000, seed=3)
+    all_keys, all_checks, all_names = [], [], []
+    for width in (1, 2, 3, 5, 7, 8, 9, 12, 15, 16, 17, 24, 31, 40):
+        names = [("%032x" % (int(k) * 0x9E3779B97F4A7C15 % (1 << 128))).rjust(width, "g")[-width:] for k in d["name_key"].tolist()]
+        write_bam(str(tmp_path / "syn.bam"), d, ["chrS"], seed=1, names=names)
+        (tmp_path / "cfg").write_text("readgroup:rg1\tplatform:illumina\tmap:syn.bam\treadlen:100.00\tlib:lib1\tlower:310.00\tupper:490.00\tmean:400.00\tstd:30.00\n")
+        head, rows, keys = dump(["cfg"], str(tmp_path))
+        assert len(keys) == len(names)
+        np.testing.assert_array_equal(keys, np.array([hash_name(n.encode()) for n in names], dtype=np.uint64), err_msg=str(width))
+        np.testing.assert_array_equal(dump.checks, np.array([check_name(n.encode()) for n in names], dtype=np.uint64), err_msg=str(width))
+        all_keys += keys.tolist(); all_checks += dump.checks.tolist(); all_names += names
+    # no fixed relation between the two: the xor of key and check takes as many values as there are names
+    assert len({k ^ c for k, c in zip(all_keys, all_checks)}) == len(set(all_names))
 
 
 def test_read_names_the_boundary_guess_rejects_are_still_decoded(tmp_path):
