@@ -567,23 +567,21 @@ def main():
     bd.set_stage_timing(False)
     overlapped = None
     if world == 1 and len(ctxs) == 1 and not a.pmc_child and not a.no_overlap:   # (by default: three contexts in flight is how a whole-genome caller keeps one GPU busy)
-        import threading
-        more = [bd, new_ctx(), new_ctx()]
-        for x in more:
-            for _ in range(3):
-                x.run()
+        # the native driver (bdx_run_many): 24 contexts -- one per chromosome of a genome, here all on the same resident input --
+        # of which three are in flight at a time
+        from breakdancer_amd.api import run_many
+        more = [bd] + [new_ctx().set_enqueue_ahead(0) for _ in range(23)]
+        run_many(more, 3)
+        run_many(more, 3)
         torch.cuda.synchronize()
-        per = max(4, a.steps // 2)
-        th = [threading.Thread(target=lambda x=x: [x.run() for _ in range(per)]) for x in more]
+        rounds = max(1, a.steps // 24)
         to = time.perf_counter()
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
+        for _ in range(rounds):
+            run_many(more, 3)
         torch.cuda.synchronize()
         do = time.perf_counter() - to
-        overlapped = {"contexts_in_flight": len(more), "steps": per * len(more), "ms_per_step": do / (per * len(more)) * 1e3,
-                      "value": (n // 2) * per * len(more) / do, "unit": "read-pairs/s"}
+        overlapped = {"contexts_in_flight": 3, "contexts": len(more), "steps": rounds * len(more), "ms_per_step": do / (rounds * len(more)) * 1e3,
+                      "value": (n // 2) * rounds * len(more) / do, "unit": "read-pairs/s", "driver": "bdx_run_many"}
         for x in more[1:]:
             x.close()
     if world > 1:

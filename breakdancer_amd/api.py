@@ -94,6 +94,19 @@ def make_batch(arrs):
     return b, keep
 
 
+def run_many(contexts, in_flight=3):
+    """bdx_run_many: every context of the list runs, `in_flight` of them at a time (the native driver for one context per chromosome)"""
+    lib = L.load()
+    arr = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+    rc = lib.bdx_run_many(arr, len(contexts), in_flight)
+    if rc != 0:
+        msgs = [lib.bdx_last_error(c.h).decode() for c in contexts]
+        raise BdxError("bdx_run_many: %s (%s)" % (lib.bdx_strerror(rc).decode(), "; ".join(m for m in msgs if m)))
+    for c in contexts:
+        c._keep.clear()
+    return contexts
+
+
 class BreakDancer:
     """One clustering context on one GPU (reference: BreakDancer::BreakDancer / run, BreakDancer.cpp:87-144)."""
 

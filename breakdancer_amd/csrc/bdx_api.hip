@@ -15,6 +15,7 @@
 #include <cstddef>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <utility>
 #include <vector>
@@ -1855,6 +1856,43 @@ int bdx_set_enqueue_ahead(bdx_ctx* c, int on) {
     if (!c) return BDX_EINVAL;
     c->speculate = on < 0 ? 0 : (on > 2 ? 2 : on);
     return BDX_OK;
+}
+
+int bdx_run_many(bdx_ctx* const* ctxs, size_t n, int in_flight) {
+    if (!ctxs && n) return BDX_EINVAL;
+    for (size_t i = 0; i < n; ++i) {
+        if (!ctxs[i]) return BDX_EINVAL;
+        for (size_t k = 0; k < i; ++k)
+            if (ctxs[k] == ctxs[i]) return BDX_EINVAL;   // (one context cannot run twice at a time)
+    }
+    const size_t workers = std::min<size_t>(n, (size_t)std::max(1, in_flight));
+    if (workers <= 1) {
+        for (size_t i = 0; i < n; ++i) {
+            const int rc = bdx_run(ctxs[i]);
+            if (rc != BDX_OK) return rc;
+        }
+        return BDX_OK;
+    }
+    // one host thread per context in flight: a run's waits (pass-1 statistics, the exact sizes of the later stages, the table's
+    // arrival) are the thread's own, and the kernels of the contexts overlap on the GPU -- each context has its own streams
+    std::atomic<size_t> next{0};
+    std::atomic<int> first_error{BDX_OK};
+    std::vector<std::thread> pool;
+    pool.reserve(workers);
+    for (size_t w = 0; w < workers; ++w)
+        pool.emplace_back([&] {
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= n || first_error.load() != BDX_OK) return;
+                const int rc = bdx_run(ctxs[i]);
+                if (rc != BDX_OK) {
+                    int ok = BDX_OK;
+                    first_error.compare_exchange_strong(ok, rc);
+                }
+            }
+        });
+    for (auto& t : pool) t.join();
+    return first_error.load();
 }
 
 int bdx_use_name_check(bdx_ctx* c, int on) {

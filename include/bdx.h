@@ -158,6 +158,12 @@ int bdx_run(bdx_ctx* ctx);
  * instead of from their own reads.  NULL switches back to the run's own statistics. */
 int bdx_set_pass1_statistics(bdx_ctx* ctx, const uint32_t* counters, uint32_t covered_ref_len);
 
+/* Replaces: the reference run once per chromosome (`-o <chr>`, README:73; one process each) when the caller holds one context per
+ * chromosome on one GPU: bdx_run on every context of the list, at most in_flight of them at a time -- one host thread per context
+ * in flight, each context on its own streams, so that one context's latency-bound tail (region cut, join, walk) runs beside
+ * another's classifier.  The contexts must be distinct; results through each context's getters.  Returns the first error. */
+int bdx_run_many(bdx_ctx* const* ctxs, size_t n, int in_flight);
+
 typedef struct bdx_summary {
     uint64_t n_reads;
     uint64_t n_anomalous;        /* reads entering the region accumulator */

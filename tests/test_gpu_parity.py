@@ -440,3 +440,30 @@ def test_components_spanning_flush_windows_are_walked_on_the_device(buffer_size,
     assert bd.cross_window_svs() > min_cross, (bd.cross_window_svs(), n_dev, n_host)
     assert n_dev > 10 * max(n_host, 1), (n_dev, n_host)
     bd.close()
+
+
+def test_contexts_in_flight_under_the_native_driver():
+    """bdx_run_many: a list of contexts (one per chromosome of a caller that holds them all), three in flight at a time on threads of
+    the library -- every context's table equals its own oracle run; a list that names a context twice is refused"""
+    import breakdancer_amd as bda
+    from breakdancer_amd.api import run_many
+    runs, ctxs = [], []
+    for seed in range(9):
+        cfg, streams, targets = make_case(1500 + seed)
+        run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1, **OPTION_SETS[seed % len(OPTION_SETS)]))
+        libs = [bda.LibraryConfig(*[float(x) for x in run.lib_f[i]], min_mapping_quality=int(run.lib_i[i, 0]),
+                                  bam_file_index=int(run.lib_i[i, 1]), name=run.lib_names[i]) for i in range(run.nlibs)]
+        from runner import product_options
+        bd = bda.BreakDancer(product_options(run.opts), libs, run.nbams, ntids=0, max_read_window_size=run.w0)
+        if run.n_merged:
+            bd.push_reads(run.merged_soa())
+        runs.append(run)
+        ctxs.append(bd)
+    for in_flight in (3, 1, 16):
+        run_many(ctxs, in_flight)
+        for run, bd in zip(runs, ctxs):
+            compare(run, bd)
+    with pytest.raises(bda.BdxError):
+        run_many([ctxs[0], ctxs[1], ctxs[0]], 2)
+    for bd in ctxs:
+        bd.close()
