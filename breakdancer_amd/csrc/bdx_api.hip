@@ -39,13 +39,14 @@ struct DevBuf {
     size_t bytes = 0;
     hipError_t ensure(size_t b) {
         if (b <= bytes) return hipSuccess;
-        if (p) (void)hipFree(p);
+        const auto t0 = std::chrono::steady_clock::now();
+        const bool had = p != nullptr;
+        if (p) (void)hipFree(p);   // (waits for the device to go idle: steady-state code must not get here)
         p = nullptr;
         bytes = 0;
         size_t want = b + b / 8 + 256;
-        const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(&p, want);
-        if (alloc_trace()) fprintf(stderr, "[bdx alloc] device %12zu B %8.1f us\n", want, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+        if (alloc_trace()) fprintf(stderr, "[bdx alloc] device %12zu B %8.1f us%s\n", want, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), had ? " (regrown: hipFree first)" : "");
         if (e == hipSuccess) bytes = want;
         return e;
     }

@@ -43,12 +43,18 @@ struct bdx_bamdec {
     bdx_ctx* sink = nullptr;
     std::string err;
     hipStream_t s_copy = nullptr, s_inf = nullptr, s_inf2 = nullptr, s_rec = nullptr;   // (two inflate streams, taken in turn: see bam_launch_batch)
+    // A decoder that feeds a context copies on the context's copy stream and runs its record stages on the context's compute stream
+    // (the classifier follows them there anyway): four streams in all.  The HIP runtime spreads a process's streams over four hardware
+    // queues, and two streams on one queue run in order -- with six, the completion of a 0.3 ms copy waited behind a 19 ms inflate launch.
+    bool borrowed_streams = false;
     // pinned staging: one piece's compressed bytes and the caller's member table
     struct Staging {
         PinBuf h_comp, h_tab;
         hipEvent_t ev_copied = nullptr;   // H2D of this buffer done
         bool busy = false;
         size_t cap = 0;                   // table entries
+        std::thread pinning;              // (bdx_bamdec_params::piece_bytes: the buffer is being pinned)
+        hipError_t pin_status = hipSuccess;
     } staging[kBamStaging];
     int next_staging = 0, cur_staging = -1;
     // a batch: the compressed bytes of its pieces back to back in HBM, its member table, the inflate status words
@@ -69,9 +75,14 @@ struct bdx_bamdec {
     std::deque<BamPiece> pieces;  // submitted, oldest first; dropped once their record stage is enqueued and a successor exists
     std::vector<hipEvent_t> ev_pool;
     uint64_t n_pieces = 0;
+    // where the feeding thread's time goes (bdx_bamdec_host_ms): [0] waiting for a staging buffer's copy, [1] pinning staging memory,
+    // [2] waiting for a batch slot, [3] a slot's buffers, [4] the piece's copy calls, [5] a batch's launch, [6] a record stage's
+    // launches, [7] feeding the classifier
+    double host_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool finished = false, any_submitted = false;
     // record stage scratch (one piece at a time on s_rec)
     DevBuf d_cb, d_offs, d_base, d_scan, d_state;
+    size_t rec_cap_blk = 0;             // members d_cb / d_offs / d_base are sized for
     DevBuf r_tid, r_pos, r_mtid, r_mpos, r_isize, r_flag, r_qlen, r_mapq, r_lib, r_keep, r_key, r_check;
     uint32_t raw_cap = 0;
     // read groups
@@ -114,6 +125,13 @@ hipEvent_t bam_event(bdx_bamdec* d) {
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
     return e;
 }
+
+struct BamTimer {
+    double& acc;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit BamTimer(double& a) : acc(a) {}
+    ~BamTimer() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 DstColumns bam_dst(bdx_bamdec* d, uint64_t* cap) {
     DstColumns c{};
@@ -169,6 +187,7 @@ void bam_poll(bdx_bamdec* d) {
 int bam_feed_classifier(bdx_bamdec* d, bool final) {
     bdx_ctx* c = d->sink;
     if (!c) return BDX_OK;
+    BamTimer t7(d->host_ms[7]);
     hipEvent_t latest = nullptr;
     while (!d->rec_events.empty() && d->rec_events.front().first <= d->confirmed_seq) {
         if (latest) d->ev_pool.push_back(latest);
@@ -209,6 +228,7 @@ int bam_feed_classifier(bdx_bamdec* d, bool final) {
 }
 
 int bam_record_stage(bdx_bamdec* d, BamPiece& p, const BamPiece* next, bool is_last) {
+    BamTimer t6(d->host_ms[6]);
     hipStream_t s = d->s_rec;
     bdx_bamdec::Slot& sl = d->slot[p.slot];
     uint64_t avail_end = p.ring_end;
@@ -228,17 +248,24 @@ int bam_record_stage(bdx_bamdec* d, BamPiece& p, const BamPiece* next, bool is_l
     // upper bound of the piece's records (36 bytes is the smallest record) -> the raw columns
     const uint64_t bound = (p.ring_end - p.ring_beg) / 36 + 2;
     if (bound > d->raw_cap) {
+        // (batches differ by a piece's worth of members: half as much again, so that no later batch comes back here -- the wait
+        // below is for the record stage before this one, which waits for an inflate launch: the feeding thread would stand still)
         BHIP(d, hipStreamSynchronize(s));
-        const size_t cap = round_up((size_t)bound + bound / 8, 1024);
+        const size_t cap = round_up(std::max<size_t>((size_t)bound + bound / 2, (d->batch_blocks + d->batch_blocks / 4 + 64) * (size_t)65536 / 36), 1024);
         BHIP(d, d->r_tid.ensure(cap * 4)); BHIP(d, d->r_pos.ensure(cap * 4)); BHIP(d, d->r_mtid.ensure(cap * 4)); BHIP(d, d->r_mpos.ensure(cap * 4));
         BHIP(d, d->r_isize.ensure(cap * 4)); BHIP(d, d->r_flag.ensure(cap * 2)); BHIP(d, d->r_qlen.ensure(cap * 2)); BHIP(d, d->r_mapq.ensure(cap));
         BHIP(d, d->r_lib.ensure(cap)); BHIP(d, d->r_keep.ensure(cap)); BHIP(d, d->r_key.ensure(cap * 8)); BHIP(d, d->r_check.ensure(cap * 8));
         BHIP(d, d->d_scan.ensure((cap / 256 + 8) * 4));
         d->raw_cap = (uint32_t)cap;
     }
-    BHIP(d, d->d_cb.ensure((size_t)std::max(nblk, 1u) * sizeof(ChainBlock)));
-    BHIP(d, d->d_offs.ensure((size_t)std::max(nblk, 1u) * kRecSlots * 2));
-    BHIP(d, d->d_base.ensure(((size_t)nblk + 2) * 4));
+    if (nblk > d->rec_cap_blk) {   // (growing them frees them first, which waits for the device: sized for a full batch at once)
+        const size_t nb = std::max<size_t>((size_t)nblk + nblk / 2, d->batch_blocks + d->batch_blocks / 4 + 64);
+        d->rec_cap_blk = nb;
+        BHIP(d, hipStreamSynchronize(s));
+        BHIP(d, d->d_cb.ensure(nb * sizeof(ChainBlock)));
+        BHIP(d, d->d_offs.ensure(nb * kRecSlots * 2));
+        BHIP(d, d->d_base.ensure((nb + 2) * 4));
+    }
     // destination capacity: everything that may still arrive from pieces in flight must fit
     bam_poll(d);
     const uint64_t need = d->confirmed + d->bound_in_flight + bound;
@@ -309,9 +336,13 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
     d->bam_index = (uint8_t)p->bam_index;
     d->filt.only_tid = p->only_tid; d->filt.beg = p->region_beg; d->filt.end = p->region_end; d->filt.n_targets = p->n_targets;
     auto bad = [&](int code) { bdx_bamdec_destroy(d); return code; };
-    if (hipStreamCreateWithFlags(&d->s_copy, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&d->s_inf, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&d->s_inf2, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&d->s_rec, hipStreamNonBlocking) != hipSuccess)
+    if (sink && sink->stream && sink->copy_stream) {
+        d->s_copy = sink->copy_stream; d->s_rec = sink->stream;
+        d->borrowed_streams = true;
+    } else if (hipStreamCreateWithFlags(&d->s_copy, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&d->s_rec, hipStreamNonBlocking) != hipSuccess) {
+        return bad(BDX_EHIP);
+    }
+    if (hipStreamCreateWithFlags(&d->s_inf, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&d->s_inf2, hipStreamNonBlocking) != hipSuccess)
         return bad(BDX_EHIP);
     for (auto& sl : d->slot)
         if (hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&sl.ev_free, hipEventDisableTiming) != hipSuccess)
@@ -351,6 +382,17 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
         d->rg.hash = d->d_rg_hash.as<uint64_t>(); d->rg.off = d->d_rg_off.as<uint32_t>(); d->rg.chars = d->d_rg_chars.as<char>();
         d->rg.lib = d->d_rg_lib.as<uint8_t>(); d->rg.n = n; d->rg.fallback = p->fallback_lib;
     }
+    if (p->piece_bytes && p->piece_blocks)
+        for (auto& st : d->staging) {
+            bdx_bamdec::Staging* sp = &st;
+            const size_t nb = p->piece_bytes + 64, nt = p->piece_blocks * sizeof(bdx_bgzf_block);
+            st.pinning = std::thread([sp, nb, nt, device] {
+                hipError_t e = hipSetDevice(device);
+                if (e == hipSuccess) e = sp->h_comp.ensure(nb);
+                if (e == hipSuccess) e = sp->h_tab.ensure(nt);
+                sp->pin_status = e;
+            });
+        }
     // ring of inflated bytes
     d->ring_bytes = p->ring_bytes ? p->ring_bytes : ((size_t)3 << 30);
     if (d->ring_bytes < ((size_t)1 << 20)) d->ring_bytes = (size_t)1 << 20;
@@ -364,9 +406,12 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
     memset(d->h_progress.p, 0, 64);
     if (sink) {
         if (sink->adopted) return bad(BDX_ESTATE);
-        if (sink->n == 0 && sink->cap == 0 && p->expected_bytes) {   // (a record takes 50-150 bytes of BAM; a store that is too small grows)
-            const size_t want = std::min<size_t>(p->expected_bytes / 48 + ((size_t)1 << 20), 0xFFFFFFFFull - 1024);
-            if (alloc_reads(sink, want) != BDX_OK) return bad(BDX_ENOMEM);
+        if (sink->n == 0 && p->expected_bytes) {   // (a record takes 50-150 bytes of BAM; a store that is too small grows)
+            // ... plus room for what the batches in flight could hold at most (36 bytes is the smallest record): the store must be able to
+            // take them before their record counts are known, and growing it means waiting for the device and copying the columns
+            const size_t in_flight = (size_t)kBamSlots * (d->batch_blocks + d->batch_blocks / 4 + 64) * 65536 / 36;
+            const size_t want = std::min<size_t>(p->expected_bytes / 48 + ((size_t)1 << 20) + std::min<size_t>(in_flight, p->expected_bytes * 4), 0xFFFFFFFFull - 1024);
+            if (sink->cap < want && alloc_reads(sink, want) != BDX_OK) return bad(BDX_ENOMEM);
         }
         if (sink->n == 0 && sink->cap) {   // pass 1 runs as the records arrive
             sink->key_segs.clear();
@@ -411,6 +456,9 @@ void bdx_bamdec_destroy(bdx_bamdec* d) {
                       &d->o_tid, &d->o_pos, &d->o_mtid, &d->o_mpos, &d->o_isize, &d->o_flag, &d->o_qlen, &d->o_mapq, &d->o_lib, &d->o_bam, &d->o_key})
         b->release();
     d->h_progress.release();
+    for (auto& st : d->staging)
+        if (st.pinning.joinable()) st.pinning.join();
+    if (d->borrowed_streams) d->s_copy = d->s_rec = nullptr;
     for (hipStream_t s : {d->s_copy, d->s_inf, d->s_inf2, d->s_rec})
         if (s) (void)hipStreamDestroy(s);
     delete d;
@@ -425,11 +473,19 @@ int bdx_bamdec_acquire(bdx_bamdec* d, size_t bytes, size_t max_blocks, void** bu
     BHIP(d, hipSetDevice(d->device));
     bdx_bamdec::Staging& st = d->staging[d->next_staging];
     if (st.busy) {
+        BamTimer t(d->host_ms[0]);
         BHIP(d, hipEventSynchronize(st.ev_copied));
         st.busy = false;
     }
-    BHIP(d, st.h_comp.ensure(bytes + 64));
-    BHIP(d, st.h_tab.ensure(max_blocks * sizeof(bdx_bgzf_block)));
+    {
+        BamTimer t(d->host_ms[1]);
+        if (st.pinning.joinable()) {
+            st.pinning.join();
+            BHIP(d, st.pin_status);
+        }
+        BHIP(d, st.h_comp.ensure(bytes + 64));
+        BHIP(d, st.h_tab.ensure(max_blocks * sizeof(bdx_bgzf_block)));
+    }
     *buf = st.h_comp.p;
     *blocks = st.h_tab.as<bdx_bgzf_block>();
     st.cap = max_blocks;
@@ -445,6 +501,7 @@ namespace {
 // The batch in slot si goes to work: a place in the ring, its table to HBM, the inflate launch; the record stage of the batch
 // in front of it (which now has its successor's bytes behind it), and its own if it is the last.
 int bam_launch_batch(bdx_bamdec* d, int si, bool last) {
+    BamTimer t5(d->host_ms[5]);
     bdx_bamdec::Slot& sl = d->slot[si];
     const uint64_t ulen = sl.ulen;
     const size_t nblocks = sl.nblk;
@@ -521,9 +578,11 @@ int bam_open_batch(bdx_bamdec* d, size_t piece_bytes, size_t piece_blocks) {
     bdx_bamdec::Slot& sl = d->slot[d->cur_slot];
     if (sl.open) return BDX_OK;
     if (sl.busy) {
+        BamTimer t(d->host_ms[2]);
         BHIP(d, hipEventSynchronize(sl.ev_free));
         sl.busy = false;
     }
+    BamTimer t3(d->host_ms[3]);
     // room for a batch plus the piece that takes it over the threshold (and the kernel's input ring reads ~1.1 KiB behind a payload)
     BHIP(d, sl.d_comp.ensure(d->batch_bytes + piece_bytes + 4096));
     const size_t cap = d->batch_blocks + piece_blocks + 64;
@@ -560,8 +619,11 @@ int bdx_bamdec_submit(bdx_bamdec* d, size_t bytes, size_t nblocks, int last) {
     }
     bdx_bamdec::Slot& sl = d->slot[d->cur_slot];
     if (sl.bytes + bytes + 4096 > sl.d_comp.bytes || sl.nblk + nblocks > sl.cap_blk) return bfail(d, BDX_ELIMIT, "piece larger than a batch");
-    if (bytes) BHIP(d, hipMemcpyAsync((char*)sl.d_comp.p + sl.bytes, st.h_comp.p, bytes, hipMemcpyHostToDevice, d->s_copy));
-    BHIP(d, hipEventRecord(st.ev_copied, d->s_copy));
+    {
+        BamTimer t(d->host_ms[4]);
+        if (bytes) BHIP(d, hipMemcpyAsync((char*)sl.d_comp.p + sl.bytes, st.h_comp.p, bytes, hipMemcpyHostToDevice, d->s_copy));
+        BHIP(d, hipEventRecord(st.ev_copied, d->s_copy));
+    }
     st.busy = true;
     BgzfBlock* tb = sl.h_blocks.as<BgzfBlock>() + sl.nblk;
     for (size_t i = 0; i < nblocks; ++i) {
@@ -572,7 +634,11 @@ int bdx_bamdec_submit(bdx_bamdec* d, size_t bytes, size_t nblocks, int last) {
     sl.bytes += (bytes + 7) & ~(size_t)7;
     d->compressed_bytes += bytes;
     d->any_submitted = true;
-    if (last || sl.nblk >= d->batch_blocks || sl.bytes >= d->batch_bytes) {
+    // the first batches are smaller: the GPU starts on a third of a full batch while the next two thirds are read, and the two together
+    // fill it (a member takes its ~10 ms however few run beside it)
+    const uint64_t started = d->n_pieces;
+    const size_t goal_blocks = started == 0 ? std::max<size_t>(d->batch_blocks / 3, 1) : started == 1 ? std::max<size_t>(2 * d->batch_blocks / 3, 1) : d->batch_blocks;
+    if (last || sl.nblk >= goal_blocks || sl.bytes >= d->batch_bytes) {
         rc = bam_launch_batch(d, d->cur_slot, last != 0);
         if (rc != BDX_OK) return rc;
     }
@@ -660,6 +726,12 @@ int bdx_bamdec_stats(const bdx_bamdec* d, uint64_t* compressed_bytes, uint64_t* 
     if (inflated_bytes) *inflated_bytes = d->inflated_bytes;
     if (pieces) *pieces = d->n_pieces;
     if (blocks_walked_twice) *blocks_walked_twice = d->h_progress.p ? (((volatile uint64_t*)d->h_progress.p)[1] >> 32) : 0;
+    return BDX_OK;
+}
+
+int bdx_bamdec_host_ms(const bdx_bamdec* d, float* out, int n) {
+    if (!d || !out) return BDX_EINVAL;
+    for (int i = 0; i < n; ++i) out[i] = i < 8 ? (float)d->host_ms[i] : 0.0f;
     return BDX_OK;
 }
 

@@ -14,7 +14,11 @@
 #include <sstream>
 #include <stdexcept>
 #include <thread>
+#include <cerrno>
+#include <csignal>
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 #include <vector>
 
@@ -151,9 +155,65 @@ struct GpuSink : BatchSink {
     void submit(size_t n) override { check(ctx, bdx_submit_batch(ctx, n), "bdx_submit_batch"); }
 };
 
+// The command's result is complete (everything printed, the dump files closed): tell the process that was started, which returns
+// at once; this one -- which owns the GPU context -- goes on to hand gigabytes of HBM and the pinned buffers back to the driver
+// (~0.1 s for a chromosome), with its standard streams closed so that a reader of the pipe sees the end of the output now.
+int g_report_fd = -1;
+void report_result(int status) {
+    std::cout.flush();
+    fflush(nullptr);
+    if (g_report_fd < 0) return;
+    const ssize_t w = write(g_report_fd, &status, sizeof status);
+    (void)w;
+    close(g_report_fd);
+    g_report_fd = -1;
+    close(STDOUT_FILENO);
+    close(STDERR_FILENO);
+}
+
+int run(int argc, char** argv);
+
 }  // namespace
 
+// Releasing a GPU context takes the driver longer than the whole GPU path runs, and a process cannot return before its resources
+// are gone.  So the work is done by a child (forked before the HIP runtime is touched); the process the user started waits for the
+// child's word that the table is written and returns with its status, while the child's exit takes its time in the background.
+// BDX_FOREGROUND=1 (and BDX_CLEAN_EXIT=1, the leak checkers' mode) keep everything in the one process.
 int main(int argc, char** argv) {
+    if (!getenv("BDX_FOREGROUND") && !getenv("BDX_CLEAN_EXIT")) {
+        int pfd[2];
+        if (pipe(pfd) == 0) {
+            const pid_t pid = fork();
+            if (pid > 0) {
+                close(pfd[1]);
+                int status = 1;
+                ssize_t r;
+                do r = read(pfd[0], &status, sizeof status); while (r < 0 && errno == EINTR);
+                if (r == (ssize_t)sizeof status) _exit(status);
+                int ws = 0;   // the child ended without reporting: usage errors (exit inside the option parser), crashes
+                while (waitpid(pid, &ws, 0) < 0 && errno == EINTR) {}
+                if (WIFEXITED(ws)) _exit(WEXITSTATUS(ws));
+                if (WIFSIGNALED(ws)) { signal(WTERMSIG(ws), SIG_DFL); raise(WTERMSIG(ws)); }
+                _exit(1);
+            }
+            if (pid == 0) {
+                close(pfd[0]);
+                g_report_fd = pfd[1];
+                fcntl(g_report_fd, F_SETFD, FD_CLOEXEC);
+            } else {  // (no child: everything in this process)
+                close(pfd[0]);
+                close(pfd[1]);
+            }
+        }
+    }
+    const int rc = run(argc, argv);
+    report_result(rc);
+    return rc;
+}
+
+namespace {
+
+int run(int argc, char** argv) {
     bdx_ctx* ctx = nullptr;
     bool ctx_owned = true;  // false: ctx is a sharded run's result context, which belongs to rank 0's bdx_dist
     try {
@@ -448,8 +508,7 @@ int main(int argc, char** argv) {
         if (!getenv("BDX_CLEAN_EXIT")) {
             bed.reset();     // (the dump files are closed by their writers' destructors)
             fastq.reset();
-            std::cout.flush();
-            fflush(nullptr);
+            report_result(0);
             _exit(0);
         }
         if (ctx_owned) bdx_destroy(ctx);  // (a sharded run's result context belongs to rank 0, released with the ranks)
@@ -461,3 +520,5 @@ int main(int argc, char** argv) {
     }
     return 0;
 }
+
+}  // namespace

@@ -395,7 +395,7 @@ size_t produce_on_device(const BamConfig& cfg, const std::string& chr, int threa
     p.first_record_offset = rec_off;
     // pieces (transfer units) of 16 MiB; the decoder gathers them into batches of >= 8192 members before it launches kernels.
     // Small files get small buffers.  Test knobs: BDX_BAM_PIECE_BYTES, BDX_BAM_BATCH_BLOCKS, BDX_BAM_RING_BYTES
-    const size_t kPiece = getenv("BDX_BAM_PIECE_BYTES") ? (size_t)std::max(1ll, atoll(getenv("BDX_BAM_PIECE_BYTES"))) : ((size_t)16 << 20);
+    const size_t kPiece = getenv("BDX_BAM_PIECE_BYTES") ? (size_t)std::max(1ll, atoll(getenv("BDX_BAM_PIECE_BYTES"))) : ((size_t)8 << 20);   // (a staging buffer costs ~0.22 ms per MiB to pin and is reused dozens of times)
     const size_t rest = file_size - std::min(file_size, member_off);
     p.batch_bytes = std::min<size_t>((size_t)256 << 20, ((rest + ((size_t)1 << 20)) >> 20) << 20);
     p.expected_bytes = rest;
@@ -403,6 +403,9 @@ size_t produce_on_device(const BamConfig& cfg, const std::string& chr, int threa
     // four batches of inflated bytes: a batch is at most ~8192 + a piece's members of 64 KiB, or the whole file (assume <= 16 x its size)
     p.ring_bytes = std::min<size_t>((size_t)3 << 30, std::max<size_t>((size_t)64 << 20, rest * 64));
     if (const char* rb = getenv("BDX_BAM_RING_BYTES")) p.ring_bytes = (size_t)std::max(1ll, atoll(rb));
+    // (what bdx_bamdec_acquire will ask for: a piece, a member cut at the piece's end carried over from the one before, and slack)
+    p.piece_bytes = std::min(kPiece, rest) + 65536 + 65536;
+    p.piece_blocks = kPiece / 2048 + 4096;
     bdx_bamdec* dec = nullptr;
     const auto t_create = std::chrono::steady_clock::now();
     int rc = bdx_bamdec_create(&dec, ctx, &p);
@@ -491,6 +494,12 @@ size_t produce_on_device(const BamConfig& cfg, const std::string& chr, int threa
     const auto tf = clk();
     rc = bdx_bamdec_finish(dec, &n);
     t_finish = since(tf);
+    if (timing) {
+        float hm[8];
+        if (bdx_bamdec_host_ms(dec, hm, 8) == BDX_OK)
+            fprintf(stderr, "[bdx timing] inside the decoder (ms): staging wait %.1f, staging pinning %.1f, slot wait %.1f, slot buffers %.1f, copy calls %.1f, "
+                            "batch launches %.1f (of which record stages %.1f), classifier feed %.1f\n", hm[0], hm[1], hm[2], hm[3], hm[4], hm[5], hm[6], hm[7]);
+    }
     if (timing)
         fprintf(stderr, "[bdx timing] device decode: decoder set up in %.3f s; %zu pieces; waiting for a staging buffer %.3f s, reading the file %.3f s (%d threads), member tables %.3f s, "
                         "enqueueing %.3f s, waiting for the GPU at the end %.3f s\n", create_s, npieces, t_acquire, t_read, threads, t_scan, t_submit, t_finish);

@@ -410,6 +410,9 @@ typedef struct bdx_bamdec_params {
                                      store is still empty the decoder sizes the store from it, and once the first batch has shown how
                                      many records the bytes hold, the buffers of the stages behind pass 1 (what bdx_reserve does up
                                      front) -- while the GPU inflates, not in front of it */
+    size_t piece_bytes, piece_blocks;  /* the sizes bdx_bamdec_acquire will be called with, 0: unknown.  Known: the staging buffers are
+                                     pinned by threads of their own while the caller reads its first piece (pinning costs ~0.2 ms per
+                                     MiB, and the first pieces would otherwise wait for it one after the other) */
 } bdx_bamdec_params;
 int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* p);
 void bdx_bamdec_destroy(bdx_bamdec* d);
@@ -420,6 +423,10 @@ int bdx_bamdec_progress(bdx_bamdec* d, uint64_t* n_records, uint64_t* n_raw, int
 int bdx_bamdec_finish(bdx_bamdec* d, uint64_t* n_records);
 int bdx_bamdec_fetch(bdx_bamdec* d, uint64_t first, uint64_t n, const bdx_batch_buf* out);
 int bdx_bamdec_stats(const bdx_bamdec* d, uint64_t* compressed_bytes, uint64_t* inflated_bytes, uint64_t* pieces, uint64_t* blocks_walked_twice);
+/* milliseconds the feeding thread spent inside the decoder so far, by cause: [0] waiting for a staging buffer's copy, [1] pinning
+ * staging memory, [2] waiting for a batch slot, [3] sizing a slot's buffers, [4] the pieces' copy calls, [5] launching batches
+ * (includes [6]), [6] launching record stages, [7] feeding the classifier */
+int bdx_bamdec_host_ms(const bdx_bamdec* d, float* out, int n);
 int bdx_inflate_blocks(int device, const void* compressed, size_t bytes, const bdx_bgzf_block* blocks, size_t nblocks, void* out,
                        size_t out_bytes, uint32_t* status, float* kernel_ms);
 
