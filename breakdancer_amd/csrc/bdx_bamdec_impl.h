@@ -534,8 +534,9 @@ int bam_launch_batch(bdx_bamdec* d, int si, bool last) {
         if (!q.records_done) return bfail(d, BDX_ELIMIT, "inflate ring too small for the batches in flight");
         BHIP(d, hipStreamWaitEvent(s_inf, q.ev_records, 0));
     }
-    BHIP(d, sl.d_blocks.ensure(std::max<size_t>(nblocks, 1) * sizeof(BgzfBlock)));
-    BHIP(d, sl.d_status.ensure(std::max<size_t>(nblocks, 1) * 4));
+    // (sized for what the slot can hold, once: growing a buffer frees it first, and hipFree waits for the device)
+    BHIP(d, sl.d_blocks.ensure(std::max<size_t>(std::max(nblocks, sl.cap_blk), 1) * sizeof(BgzfBlock)));
+    BHIP(d, sl.d_status.ensure(std::max<size_t>(std::max(nblocks, sl.cap_blk), 1) * 4));
     if (nblocks) BHIP(d, hipMemcpyAsync(sl.d_blocks.p, tb, nblocks * sizeof(BgzfBlock), hipMemcpyHostToDevice, d->s_copy));
     BHIP(d, hipEventRecord(sl.ev_copied, d->s_copy));
     BHIP(d, hipStreamWaitEvent(s_inf, sl.ev_copied, 0));
