@@ -97,6 +97,19 @@ void launch_kb_extract(const uint8_t* u, const BgzfBlock* blocks, uint32_t nblk,
 void launch_kb_compact(RawColumns raw, uint32_t raw_cap, DstColumns dst, uint64_t dst_cap, uint8_t bam_index, uint32_t* scan_ws, PieceState* st,
                        volatile uint64_t* progress, uint64_t sequence, hipStream_t s);
 
+// ---- several files: their decoded columns gathered into one store in the caller's merge order ----
+constexpr int kMaxGatherSources = 16;
+struct GatherSource {      // a decoder's own columns
+    const int32_t *tid, *pos, *mtid, *mpos, *isize;
+    const uint16_t *flag, *qlen;
+    const uint8_t *mapq, *lib, *bam;
+    const uint64_t *key, *check;
+    uint64_t n;
+};
+struct GatherSources { GatherSource s[kMaxGatherSources]; int k; };
+// record i of the destination = record src_index[i] of source src_file[i]; err is raised by an index out of range
+void launch_kb_gather(const GatherSources& src, const uint8_t* src_file, const uint32_t* src_index, uint64_t n, DstColumns dst, uint32_t* err, hipStream_t s);
+
 // the 64-bit name key of the host producer (host/bam_reader.cpp hash_name), same function on both sides
 __host__ __device__ inline uint64_t name_hash_step(uint64_t h, uint64_t w) {
     h = (h ^ w) * 0xff51afd7ed558ccdull;

@@ -232,6 +232,8 @@ int bam_record_stage(bdx_bamdec* d, BamPiece& p, const BamPiece* next, bool is_l
     hipStream_t s = d->s_rec;
     bdx_bamdec::Slot& sl = d->slot[p.slot];
     uint64_t avail_end = p.ring_end;
+    // (the batch's own inflate launch and its successor's run on two streams: neither implies the other)
+    BHIP(d, hipStreamWaitEvent(s, p.ev_inflated, 0));
     if (next) {
         BHIP(d, hipStreamWaitEvent(s, next->ev_inflated, 0));
         if (next->wrapped) {   // mirror the front of the ring behind this piece: the straddling record stays contiguous
@@ -241,8 +243,6 @@ int bam_record_stage(bdx_bamdec* d, BamPiece& p, const BamPiece* next, bool is_l
         } else {
             avail_end = next->ring_end;
         }
-    } else {
-        BHIP(d, hipStreamWaitEvent(s, p.ev_inflated, 0));
     }
     const uint32_t nblk = p.nblk;
     // upper bound of the piece's records (36 bytes is the smallest record) -> the raw columns
@@ -426,6 +426,11 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
         // (records this decoder appends come behind what the store already holds)
         st.n_kept = sink->n;
         if (hipMemcpy(d->d_state.p, &st, sizeof(st), hipMemcpyHostToDevice) != hipSuccess) return bad(BDX_EHIP);
+    }
+    if (!sink && p->expected_bytes) {   // (the decoder's own columns, sized like a sink's store: growing them waits for the device and copies)
+        const size_t in_flight = (size_t)kBamSlots * (d->batch_blocks + d->batch_blocks / 4 + 64) * 65536 / 36;
+        const size_t want = std::min<size_t>(p->expected_bytes / 48 + ((size_t)1 << 20) + std::min<size_t>(in_flight, p->expected_bytes * 4), 0xFFFFFFFFull - 1024);
+        if (bam_own_reserve(d, want, 0) != BDX_OK) return bad(BDX_ENOMEM);
     }
     *out = d;
     return BDX_OK;
@@ -706,17 +711,18 @@ int bdx_bamdec_fetch(bdx_bamdec* d, uint64_t first, uint64_t n, const bdx_batch_
     if (first + n > d->confirmed || n > out->capacity) return bfail(d, BDX_EINVAL, "range beyond the decoded records");
     if (!n) return BDX_OK;
     BHIP(d, hipSetDevice(d->device));
-    BHIP(d, hipMemcpy(out->tid, d->o_tid.as<int32_t>() + first, n * 4, hipMemcpyDeviceToHost));
-    BHIP(d, hipMemcpy(out->pos, d->o_pos.as<int32_t>() + first, n * 4, hipMemcpyDeviceToHost));
-    BHIP(d, hipMemcpy(out->mtid, d->o_mtid.as<int32_t>() + first, n * 4, hipMemcpyDeviceToHost));
-    BHIP(d, hipMemcpy(out->mpos, d->o_mpos.as<int32_t>() + first, n * 4, hipMemcpyDeviceToHost));
-    BHIP(d, hipMemcpy(out->isize, d->o_isize.as<int32_t>() + first, n * 4, hipMemcpyDeviceToHost));
-    BHIP(d, hipMemcpy(out->flag, d->o_flag.as<uint16_t>() + first, n * 2, hipMemcpyDeviceToHost));
-    BHIP(d, hipMemcpy(out->qlen, d->o_qlen.as<uint16_t>() + first, n * 2, hipMemcpyDeviceToHost));
-    BHIP(d, hipMemcpy(out->mapq, d->o_mapq.as<uint8_t>() + first, n, hipMemcpyDeviceToHost));
-    BHIP(d, hipMemcpy(out->lib, d->o_lib.as<uint8_t>() + first, n, hipMemcpyDeviceToHost));
-    BHIP(d, hipMemcpy(out->bam, d->o_bam.as<uint8_t>() + first, n, hipMemcpyDeviceToHost));
-    BHIP(d, hipMemcpy(out->name_key, d->o_key.as<uint64_t>() + first, n * 8, hipMemcpyDeviceToHost));
+    // (only the columns the caller gave room for: a merge of several files needs tid, pos and flag)
+    if (out->tid) BHIP(d, hipMemcpy(out->tid, d->o_tid.as<int32_t>() + first, n * 4, hipMemcpyDeviceToHost));
+    if (out->pos) BHIP(d, hipMemcpy(out->pos, d->o_pos.as<int32_t>() + first, n * 4, hipMemcpyDeviceToHost));
+    if (out->mtid) BHIP(d, hipMemcpy(out->mtid, d->o_mtid.as<int32_t>() + first, n * 4, hipMemcpyDeviceToHost));
+    if (out->mpos) BHIP(d, hipMemcpy(out->mpos, d->o_mpos.as<int32_t>() + first, n * 4, hipMemcpyDeviceToHost));
+    if (out->isize) BHIP(d, hipMemcpy(out->isize, d->o_isize.as<int32_t>() + first, n * 4, hipMemcpyDeviceToHost));
+    if (out->flag) BHIP(d, hipMemcpy(out->flag, d->o_flag.as<uint16_t>() + first, n * 2, hipMemcpyDeviceToHost));
+    if (out->qlen) BHIP(d, hipMemcpy(out->qlen, d->o_qlen.as<uint16_t>() + first, n * 2, hipMemcpyDeviceToHost));
+    if (out->mapq) BHIP(d, hipMemcpy(out->mapq, d->o_mapq.as<uint8_t>() + first, n, hipMemcpyDeviceToHost));
+    if (out->lib) BHIP(d, hipMemcpy(out->lib, d->o_lib.as<uint8_t>() + first, n, hipMemcpyDeviceToHost));
+    if (out->bam) BHIP(d, hipMemcpy(out->bam, d->o_bam.as<uint8_t>() + first, n, hipMemcpyDeviceToHost));
+    if (out->name_key) BHIP(d, hipMemcpy(out->name_key, d->o_key.as<uint64_t>() + first, n * 8, hipMemcpyDeviceToHost));
     if (out->name_check) BHIP(d, hipMemcpy(out->name_check, d->o_check.as<uint64_t>() + first, n * 8, hipMemcpyDeviceToHost));
     return BDX_OK;
 }
@@ -727,6 +733,54 @@ int bdx_bamdec_stats(const bdx_bamdec* d, uint64_t* compressed_bytes, uint64_t* 
     if (inflated_bytes) *inflated_bytes = d->inflated_bytes;
     if (pieces) *pieces = d->n_pieces;
     if (blocks_walked_twice) *blocks_walked_twice = d->h_progress.p ? (((volatile uint64_t*)d->h_progress.p)[1] >> 32) : 0;
+    return BDX_OK;
+}
+
+int bdx_merge_decoded(bdx_ctx* c, bdx_bamdec* const* decs, int k, const uint8_t* src_file, const uint32_t* src_index, uint64_t n) {
+    if (!c || !decs || k < 1 || k > kMaxGatherSources || (n && (!src_file || !src_index))) return BDX_EINVAL;
+    if (c->adopted || c->n) return fail(c, BDX_ESTATE, "the context already holds reads");
+    if (n > 0xFFFFFFFFull - 1024) return fail(c, BDX_ELIMIT, "one context holds at most 2^32 - 1 reads");
+    HIPCHK(c, hipSetDevice(c->device));
+    GatherSources src{};
+    src.k = k;
+    uint64_t total = 0;
+    for (int b = 0; b < k; ++b) {
+        bdx_bamdec* d = decs[b];
+        if (!d || d->sink || !d->finished || d->device != c->device) return fail(c, BDX_EINVAL, "a decoder that is finished, keeps its own columns and sits on the context's device");
+        GatherSource& g = src.s[b];
+        g.tid = d->o_tid.as<int32_t>(); g.pos = d->o_pos.as<int32_t>(); g.mtid = d->o_mtid.as<int32_t>(); g.mpos = d->o_mpos.as<int32_t>();
+        g.isize = d->o_isize.as<int32_t>(); g.flag = d->o_flag.as<uint16_t>(); g.qlen = d->o_qlen.as<uint16_t>(); g.mapq = d->o_mapq.as<uint8_t>();
+        g.lib = d->o_lib.as<uint8_t>(); g.bam = d->o_bam.as<uint8_t>(); g.key = d->o_key.as<uint64_t>(); g.check = d->o_check.as<uint64_t>();
+        g.n = d->confirmed;
+        total += d->confirmed;
+    }
+    if (n != total) return fail(c, BDX_EINVAL, "the merge order does not cover the decoders' records");
+    if (!n) return BDX_OK;
+    const int rc = alloc_reads(c, (size_t)n);
+    if (rc != BDX_OK) return rc;
+    DevBuf d_file, d_index, d_err;
+    HIPCHK(c, d_file.ensure((size_t)n)); HIPCHK(c, d_index.ensure((size_t)n * 4)); HIPCHK(c, d_err.ensure(16));
+    hipStream_t s = c->stream;
+    hipError_t e = hipMemcpyAsync(d_file.p, src_file, (size_t)n, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_index.p, src_index, (size_t)n * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_err.p, 0, 4, s);
+    uint32_t err = 0;
+    if (e == hipSuccess) {
+        DstColumns dst{};
+        dst.tid = (int32_t*)c->d.tid; dst.pos = (int32_t*)c->d.pos; dst.mtid = (int32_t*)c->d.mtid; dst.mpos = (int32_t*)c->d.mpos;
+        dst.isize = (int32_t*)c->d.isize; dst.flag = (uint16_t*)c->d.flag; dst.qlen = (uint16_t*)c->d.qlen; dst.mapq = (uint8_t*)c->d.mapq;
+        dst.lib = (uint8_t*)c->d.lib; dst.bam = (uint8_t*)c->d.bam; dst.key = (uint64_t*)c->d.key; dst.check = (uint64_t*)c->d.check;
+        launch_kb_gather(src, d_file.as<uint8_t>(), d_index.as<uint32_t>(), n, dst, d_err.as<uint32_t>(), s);
+        e = hipMemcpyAsync(&err, d_err.p, 4, hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    d_file.release(); d_index.release(); d_err.release();
+    HIPCHK(c, e);
+    if (err) return fail(c, BDX_EINVAL, "the merge order names a record that does not exist");
+    c->n = (size_t)n;
+    c->ran = false;
+    c->k1_live = false;
+    c->key_segs.clear();
     return BDX_OK;
 }
 

@@ -400,6 +400,32 @@ __global__ void kb_compact_finish_kernel(const uint32_t* __restrict__ wg_cnt, ui
 
 }  // namespace
 
+// ---- merge of several files' records: a gather by the permutation the caller computed (the reference's merge order, ties included,
+// is the host's business: BamMerger.cpp:40-61 through a priority queue) ----
+__global__ __launch_bounds__(256) void kb_gather_kernel(GatherSources src, const uint8_t* __restrict__ src_file, const uint32_t* __restrict__ src_index, uint64_t n,
+                                                        DstColumns dst, uint32_t* err) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int f = src_file[i];
+    if (f >= src.k) { *err = 1; return; }
+    // (the sources' pointers live in kernel arguments: a run-time index into them would go through scratch memory)
+    GatherSource g = src.s[0];
+#pragma unroll
+    for (int q = 1; q < kMaxGatherSources; ++q)
+        if (q == f) g = src.s[q];
+    const uint64_t j = src_index[i];
+    if (j >= g.n) { *err = 1; return; }
+    dst.tid[i] = g.tid[j]; dst.pos[i] = g.pos[j]; dst.mtid[i] = g.mtid[j]; dst.mpos[i] = g.mpos[j]; dst.isize[i] = g.isize[j];
+    dst.flag[i] = g.flag[j]; dst.qlen[i] = g.qlen[j]; dst.mapq[i] = g.mapq[j]; dst.lib[i] = g.lib[j]; dst.bam[i] = g.bam[j];
+    dst.key[i] = g.key[j];
+    if (dst.check) dst.check[i] = g.check[j];
+}
+
+void launch_kb_gather(const GatherSources& src, const uint8_t* src_file, const uint32_t* src_index, uint64_t n, DstColumns dst, uint32_t* err, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(kb_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, src_file, src_index, n, dst, err);
+}
+
 void launch_kb_chain(const uint8_t* u, const BgzfBlock* blocks, uint32_t nblk, uint64_t avail_end, int32_t n_targets, ChainBlock* cb,
                      uint16_t* offs, hipStream_t s) {
     if (!nblk) return;

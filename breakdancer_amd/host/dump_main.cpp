@@ -16,7 +16,8 @@ int main(int argc, char** argv) {
         if (!in.is_open()) throw std::runtime_error("unable to open config file '" + opts.bam_config_path + "'");
         bdhost::BamConfig cfg(in, opts.o.cut_sd);
         bdhost::ReadStream rs;
-        bdhost::produce(cfg, opts.chr, 4, rs);
+        if (getenv("BDX_DUMP_MERGE")) bdhost::produce_merged_by_columns(cfg, opts.chr, 4, rs);   // (the device path's merge, on host-decoded columns)
+        else bdhost::produce(cfg, opts.chr, 4, rs);
         printf("#w0=%d nlibs=%zu nbams=%zu n=%zu\n", cfg.max_read_window_size(), cfg.num_libs(), cfg.num_bams(), rs.size());
         for (size_t i = 0; i < cfg.num_libs(); ++i) {
             const bdhost::LibraryConfig& l = cfg.library_config(i);

@@ -324,7 +324,7 @@ int run(int argc, char** argv) {
                 // also takes the files the device path does not (BDX_DECODE=host forces it).
                 const char* dm = getenv("BDX_DECODE");
                 bool decoded = false;
-                if (cfg.num_bams() == 1 && !(dm && !strcmp(dm, "host"))) {
+                if (cfg.num_bams() <= 16 && !(dm && !strcmp(dm, "host"))) {
                     const auto tb = now();
                     sink.bring_up(false);
                     if (timing) fprintf(stderr, "[bdx timing] GPU context + resident store ready %.3f s after start (waited %.3f s for it)\n", secs(t_start, now()), secs(tb, now()));

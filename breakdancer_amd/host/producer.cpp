@@ -362,11 +362,13 @@ void read_range(int fd, size_t off, uint8_t* dst, size_t n, int threads, std::st
 
 }  // namespace
 
-size_t produce_on_device(const BamConfig& cfg, const std::string& chr, int threads, std::vector<std::string>* targets, bdx_ctx* ctx,
-                         bool* unsupported) {
-    if (unsupported) *unsupported = false;
-    if (cfg.num_bams() != 1) throw std::logic_error("produce_on_device: one BAM only");
-    const std::string& path = cfg.bam_files()[0];
+namespace {
+
+// One file of the configuration through a device-side decoder.  With a sink the records go into its store (and are classified as
+// they arrive); without, they stay in the decoder's own columns and the decoder is handed back (*keep) for the merge.
+size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::string& chr, int threads, std::vector<std::string>* targets, bdx_ctx* ctx,
+                        int device, bool* unsupported, bdx_bamdec** keep) {
+    const std::string& path = cfg.bam_files()[bam_index];
     ColumnReader hdr(path, 1, nullptr);   // (the header: reference names, where the first record lies; the index for -o)
     RecordFilter f;
     if (!chr.empty() && !parse_region(hdr, chr, f.only_tid, f.beg, f.end))
@@ -384,9 +386,9 @@ size_t produce_on_device(const BamConfig& cfg, const std::string& chr, int threa
     std::vector<const char*> idp;
     for (auto const& s : ids) idp.push_back(s.c_str());
     bdx_bamdec_params p{};
-    p.device = 0;
+    p.device = device;
     p.n_targets = (int32_t)hdr.target_names().size();
-    p.bam_index = 0;
+    p.bam_index = (int32_t)bam_index;
     p.only_tid = f.only_tid; p.region_beg = f.beg; p.region_end = f.end;
     p.n_read_groups = (uint32_t)ids.size();
     p.rg_ids = idp.empty() ? nullptr : idp.data();
@@ -411,7 +413,7 @@ size_t produce_on_device(const BamConfig& cfg, const std::string& chr, int threa
     int rc = bdx_bamdec_create(&dec, ctx, &p);
     const double create_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_create).count();
     if (rc != BDX_OK) throw std::runtime_error(std::string("bdx_bamdec_create: ") + bdx_strerror(rc));
-    struct Guard { bdx_bamdec* d; ~Guard() { bdx_bamdec_destroy(d); } } guard{dec};
+    struct Guard { bdx_bamdec* d; ~Guard() { if (d) bdx_bamdec_destroy(d); } } guard{dec};
     auto check = [&](int r, const char* what) {
         if (r != BDX_OK) throw std::runtime_error(std::string(what) + ": " + bdx_strerror(r) + " (" + bdx_bamdec_last_error(dec) + ") in " + path);
     };
@@ -505,14 +507,155 @@ size_t produce_on_device(const BamConfig& cfg, const std::string& chr, int threa
                         "enqueueing %.3f s, waiting for the GPU at the end %.3f s\n", create_s, npieces, t_acquire, t_read, threads, t_scan, t_submit, t_finish);
     if (rc == BDX_ELIMIT && unsupported) { *unsupported = true; return 0; }
     check(rc, "bdx_bamdec_finish");
+    if (keep) { *keep = dec; guard.d = nullptr; }
     return (size_t)n;
 }
+
+// BamMerger's order over the files' (tid, pos, strand) columns: the same priority queue, the same push / pop sequence as the host
+// producer's merge (io/BamMerger.cpp:40-61, 78-110).  One short cut, for queues that hold at most ONE other file (two files in all,
+// the tumour / normal case): while the file just taken from stays STRICTLY below the other it would come out on top again, so its
+// records are taken without touching the queue.  With more files every record goes through the queue: a push that rises to the top
+// and the pop behind it rearrange the others, and their arrangement is what decides the ties that follow.
+struct KeyCursor {
+    const int32_t *tid, *pos;
+    const uint16_t* flag;
+    size_t i, n;
+    uint8_t file;
+};
+struct KeyGreater {
+    bool operator()(const KeyCursor* a, const KeyCursor* b) const {
+        const size_t i = a->i, j = b->i;
+        if (a->tid[i] > b->tid[j]) return true;
+        if (b->tid[j] > a->tid[i]) return false;
+        if (a->pos[i] > b->pos[j]) return true;
+        if (b->pos[j] > a->pos[i]) return false;
+        return ((a->flag[i] >> 4) & 1) > ((b->flag[j] >> 4) & 1);
+    }
+};
+
+}  // namespace
+
+void merge_order(const std::vector<const int32_t*>& tid, const std::vector<const int32_t*>& pos, const std::vector<const uint16_t*>& flag,
+                 const std::vector<size_t>& n, std::vector<uint8_t>& src_file, std::vector<uint32_t>& src_index) {
+    const size_t k = n.size();
+    size_t total = 0;
+    for (size_t b = 0; b < k; ++b) total += n[b];
+    src_file.resize(total);
+    src_index.resize(total);
+    std::vector<KeyCursor> cur(k);
+    std::priority_queue<KeyCursor*, std::vector<KeyCursor*>, KeyGreater> pq;
+    for (size_t b = 0; b < k; ++b) {
+        cur[b] = KeyCursor{tid[b], pos[b], flag[b], 0, n[b], (uint8_t)b};
+        if (n[b]) pq.push(&cur[b]);
+    }
+    const KeyGreater greater;
+    size_t o = 0;
+    while (!pq.empty()) {
+        KeyCursor* c = pq.top();
+        pq.pop();
+        src_file[o] = c->file; src_index[o] = (uint32_t)c->i; ++o;
+        ++c->i;
+        while (c->i < c->n && (pq.empty() || (pq.size() == 1 && greater(pq.top(), c)))) {   // strictly below the only other file
+            src_file[o] = c->file; src_index[o] = (uint32_t)c->i; ++o;
+            ++c->i;
+        }
+        if (c->i < c->n) pq.push(c);
+    }
+}
+
+size_t produce_on_device(const BamConfig& cfg, const std::string& chr, int threads, std::vector<std::string>* targets, bdx_ctx* ctx,
+                         bool* unsupported) {
+    if (unsupported) *unsupported = false;
+    const size_t nb = cfg.num_bams();
+    if (nb == 0) throw std::runtime_error("BamMerger created with no input streams!");
+    if (nb == 1) return decode_on_device(cfg, 0, chr, threads, targets, ctx, 0, unsupported, nullptr);
+    // several files: each decoded into its decoder's own columns, the merge order worked out from three of them, one gather in HBM
+    if (nb > 16) { if (unsupported) *unsupported = true; return 0; }
+    const bool timing = getenv("BDX_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    std::vector<bdx_bamdec*> decs(nb, nullptr);
+    struct Guard { std::vector<bdx_bamdec*>& d; ~Guard() { for (bdx_bamdec* x : d) if (x) bdx_bamdec_destroy(x); } } guard{decs};
+    std::vector<size_t> n(nb, 0);
+    const int device = bdx_device(ctx);
+    for (size_t b = 0; b < nb; ++b) {
+        bool un = false;
+        n[b] = decode_on_device(cfg, b, chr, threads, b == 0 ? targets : nullptr, nullptr, device, &un, &decs[b]);
+        if (un) { if (unsupported) *unsupported = true; return 0; }
+    }
+    const double t_dec = since();
+    std::vector<std::vector<int32_t>> tid(nb), pos(nb);
+    std::vector<std::vector<uint16_t>> flag(nb);
+    std::vector<const int32_t*> ptid(nb), ppos(nb);
+    std::vector<const uint16_t*> pflag(nb);
+    size_t total = 0;
+    for (size_t b = 0; b < nb; ++b) {
+        tid[b].resize(n[b]); pos[b].resize(n[b]); flag[b].resize(n[b]);
+        bdx_batch_buf out{};
+        out.tid = tid[b].data(); out.pos = pos[b].data(); out.flag = flag[b].data();
+        out.capacity = n[b];
+        const int rc = bdx_bamdec_fetch(decs[b], 0, n[b], &out);
+        if (rc != BDX_OK) throw std::runtime_error(std::string("bdx_bamdec_fetch: ") + bdx_strerror(rc) + " (" + bdx_bamdec_last_error(decs[b]) + ")");
+        ptid[b] = tid[b].data(); ppos[b] = pos[b].data(); pflag[b] = flag[b].data();
+        total += n[b];
+    }
+    if (total > 0xFFFFFFFFull - 1024) { if (unsupported) *unsupported = true; return 0; }
+    const double t_keys = since();
+    std::vector<uint8_t> src_file;
+    std::vector<uint32_t> src_index;
+    merge_order(ptid, ppos, pflag, n, src_file, src_index);
+    const double t_merge = since();
+    const int rc = bdx_merge_decoded(ctx, decs.data(), (int)nb, src_file.data(), src_index.data(), total);
+    if (rc != BDX_OK) throw std::runtime_error(std::string("bdx_merge_decoded: ") + bdx_strerror(rc) + " (" + bdx_last_error(ctx) + ")");
+    if (timing)
+        fprintf(stderr, "[bdx timing] %zu files decoded on the GPU in %.3f s, their keys fetched in %.3f s, merge order in %.3f s, gather in %.3f s\n", nb, t_dec,
+                t_keys - t_dec, t_merge - t_keys, since() - t_merge);
+    return total;
+}
+
 
 void read_targets(const BamConfig& cfg, std::vector<std::string>& names, std::vector<uint32_t>& lengths) {
     if (cfg.num_bams() == 0) throw std::runtime_error("BamMerger created with no input streams!");
     ColumnReader rd(cfg.bam_files()[0], 1, nullptr);  // (parses the header only: nothing is decoded before start())
     names = rd.target_names();
     lengths = rd.target_lengths();
+}
+
+void produce_merged_by_columns(const BamConfig& cfg, const std::string& chr, int threads, ReadStream& out) {
+    const LibraryResolver libs(cfg);
+    const size_t nb = cfg.num_bams();
+    if (nb == 0) throw std::runtime_error("BamMerger created with no input streams!");
+    std::vector<ReadStream> per(nb);
+    for (size_t b = 0; b < nb; ++b) {
+        ColumnReader rd(cfg.bam_files()[b], std::max(1, threads), &libs);
+        RecordFilter f;
+        if (!chr.empty() && !parse_region(rd, chr, f.only_tid, f.beg, f.end))
+            throw std::runtime_error("Failed to parse bam region '" + chr + "' in file " + cfg.bam_files()[b] + ". ");
+        rd.start(f);
+        if (b == 0) out.targets = rd.target_names();
+        VectorSink sink(per[b]);
+        BatchWriter w(sink, 1 << 16);
+        while (const ColumnChunk* ch = rd.next())
+            if (ch->size()) w.append_range(*ch, 0, ch->size(), (uint8_t)b);
+        w.finish();
+    }
+    std::vector<const int32_t*> tid(nb), pos(nb);
+    std::vector<const uint16_t*> flag(nb);
+    std::vector<size_t> n(nb);
+    for (size_t b = 0; b < nb; ++b) { tid[b] = per[b].tid.data(); pos[b] = per[b].pos.data(); flag[b] = per[b].flag.data(); n[b] = per[b].size(); }
+    std::vector<uint8_t> src_file;
+    std::vector<uint32_t> src_index;
+    merge_order(tid, pos, flag, n, src_file, src_index);
+    const size_t total = src_file.size();
+    out.tid.resize(total); out.pos.resize(total); out.mtid.resize(total); out.mpos.resize(total); out.isize.resize(total); out.flag.resize(total);
+    out.qlen.resize(total); out.mapq.resize(total); out.lib.resize(total); out.bam.resize(total); out.name_key.resize(total); out.name_check.resize(total);
+    for (size_t i = 0; i < total; ++i) {
+        const ReadStream& s = per[src_file[i]];
+        const size_t j = src_index[i];
+        out.tid[i] = s.tid[j]; out.pos[i] = s.pos[j]; out.mtid[i] = s.mtid[j]; out.mpos[i] = s.mpos[j]; out.isize[i] = s.isize[j]; out.flag[i] = s.flag[j];
+        out.qlen[i] = s.qlen[j]; out.mapq[i] = s.mapq[j]; out.lib[i] = s.lib[j]; out.bam[i] = s.bam[j]; out.name_key[i] = s.name_key[j];
+        out.name_check[i] = s.name_check[j];
+    }
 }
 
 void produce(const BamConfig& cfg, const std::string& chr, int threads, ReadStream& out) {

@@ -423,6 +423,11 @@ int bdx_bamdec_progress(bdx_bamdec* d, uint64_t* n_records, uint64_t* n_raw, int
 int bdx_bamdec_finish(bdx_bamdec* d, uint64_t* n_records);
 int bdx_bamdec_fetch(bdx_bamdec* d, uint64_t first, uint64_t n, const bdx_batch_buf* out);
 int bdx_bamdec_stats(const bdx_bamdec* d, uint64_t* compressed_bytes, uint64_t* inflated_bytes, uint64_t* pieces, uint64_t* blocks_walked_twice);
+/* Several BAMs decoded on the GPU, each by a decoder of its own (no sink: the records stay in the decoder's columns, bdx_bamdec_fetch
+ * returns the columns the caller gives room for -- tid, pos and flag are what BamMerger's order looks at, io/BamMerger.cpp:40-61).  The
+ * caller works out the merged order and hands it over as a permutation: record i of the context's store = record src_index[i] of
+ * decoder src_file[i].  The gather runs in HBM; the context must hold no reads yet and then stands as after bdx_push of the merged stream. */
+int bdx_merge_decoded(bdx_ctx* ctx, bdx_bamdec* const* decs, int k, const uint8_t* src_file, const uint32_t* src_index, uint64_t n);
 /* milliseconds the feeding thread spent inside the decoder so far, by cause: [0] waiting for a staging buffer's copy, [1] pinning
  * staging memory, [2] waiting for a batch slot, [3] sizing a slot's buffers, [4] the pieces' copy calls, [5] launching batches
  * (includes [6]), [6] launching record stages, [7] feeding the classifier */

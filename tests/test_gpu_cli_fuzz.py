@@ -46,9 +46,14 @@ def test_cli_on_fuzz_bams_equals_oracle(seed, tmp_path):
     (tmp_path / "cfg").write_text(cfg)
     for args, kw in (FLAGSETS[seed % len(FLAGSETS)], FLAGSETS[(3 * seed + 1) % len(FLAGSETS)]):
         run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1, **kw))
-        p = subprocess.run([EXE, "-y", "-1"] + args + ["cfg"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-        assert p.returncode == 0, p.stderr.decode()
-        assert filter_cmd_lines(p.stdout.decode()) == filter_cmd_lines(run.text), (args, p.stderr.decode())
+        # both files decoded on the GPU, merged by a gather in the order the host works out from (tid, pos, strand) -- and the host
+        # reader's merge of the same files
+        for label, env in (("device", dict(BDX_TIMING="1")), ("device-small-pieces", dict(BDX_TIMING="1", BDX_BAM_PIECE_BYTES="50000", BDX_BAM_BATCH_BLOCKS="2")),
+                           ("host", dict(BDX_TIMING="1", BDX_DECODE="host"))):
+            p = subprocess.run([EXE, "-y", "-1"] + args + ["cfg"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+            assert p.returncode == 0, (label, p.stderr.decode())
+            assert ("2 files decoded on the GPU" in p.stderr.decode()) == label.startswith("device"), (label, p.stderr.decode())
+            assert filter_cmd_lines(p.stdout.decode()) == filter_cmd_lines(run.text), (label, args, p.stderr.decode())
         if "-o" not in args:  # the same run with the chromosomes spread over ranks (here: threads sharing the one GPU)
             env = dict(os.environ, BDX_GPUS="0,0,0" if seed % 2 else "0,0")
             p = subprocess.run([EXE, "-y", "-1"] + args + ["cfg"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
