@@ -511,6 +511,7 @@ int run(int argc, char** argv) {
             report_result(0);
             _exit(0);
         }
+        release_device_decoders();   // (before their sink: a decoder borrows its context's streams)
         if (ctx_owned) bdx_destroy(ctx);  // (a sharded run's result context belongs to rank 0, released with the ranks)
         ctx = nullptr;
     } catch (std::exception const& e) {

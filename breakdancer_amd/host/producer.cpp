@@ -12,6 +12,8 @@
 #include <thread>
 #include <queue>
 #include <stdexcept>
+#include <future>
+#include <mutex>
 #include <unordered_map>
 
 #include "bam_reader.h"
@@ -364,6 +366,17 @@ void read_range(int fd, size_t off, uint8_t* dst, size_t n, int threads, std::st
 
 namespace {
 
+// Decoders that have done their work.  Releasing one (a 3 GiB ring, four batches' buffers, pinned staging, streams) takes the
+// driver tens of milliseconds, and the clustering run does not need the memory back: they are kept until
+// release_device_decoders(), which the CLI calls only when it walks its destructors.
+std::vector<bdx_bamdec*> g_retired;
+std::mutex g_retired_mu;
+void retire(bdx_bamdec* d) {
+    if (!d) return;
+    std::lock_guard<std::mutex> lk(g_retired_mu);
+    g_retired.push_back(d);
+}
+
 // One file of the configuration through a device-side decoder.  With a sink the records go into its store (and are classified as
 // they arrive); without, they stay in the decoder's own columns and the decoder is handed back (*keep) for the merge.
 size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::string& chr, int threads, std::vector<std::string>* targets, bdx_ctx* ctx,
@@ -413,7 +426,7 @@ size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::strin
     int rc = bdx_bamdec_create(&dec, ctx, &p);
     const double create_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_create).count();
     if (rc != BDX_OK) throw std::runtime_error(std::string("bdx_bamdec_create: ") + bdx_strerror(rc));
-    struct Guard { bdx_bamdec* d; ~Guard() { if (d) bdx_bamdec_destroy(d); } } guard{dec};
+    struct Guard { bdx_bamdec* d; ~Guard() { retire(d); } } guard{dec};
     auto check = [&](int r, const char* what) {
         if (r != BDX_OK) throw std::runtime_error(std::string(what) + ": " + bdx_strerror(r) + " (" + bdx_bamdec_last_error(dec) + ") in " + path);
     };
@@ -575,30 +588,42 @@ size_t produce_on_device(const BamConfig& cfg, const std::string& chr, int threa
     const auto t0 = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     std::vector<bdx_bamdec*> decs(nb, nullptr);
-    struct Guard { std::vector<bdx_bamdec*>& d; ~Guard() { for (bdx_bamdec* x : d) if (x) bdx_bamdec_destroy(x); } } guard{decs};
+    struct Guard { std::vector<bdx_bamdec*>& d; ~Guard() { for (bdx_bamdec* x : d) retire(x); } } guard{decs};
     std::vector<size_t> n(nb, 0);
     const int device = bdx_device(ctx);
-    for (size_t b = 0; b < nb; ++b) {
-        bool un = false;
-        n[b] = decode_on_device(cfg, b, chr, threads, b == 0 ? targets : nullptr, nullptr, device, &un, &decs[b]);
-        if (un) { if (unsupported) *unsupported = true; return 0; }
-    }
-    const double t_dec = since();
     std::vector<std::vector<int32_t>> tid(nb), pos(nb);
     std::vector<std::vector<uint16_t>> flag(nb);
     std::vector<const int32_t*> ptid(nb), ppos(nb);
     std::vector<const uint16_t*> pflag(nb);
+    std::vector<std::future<int>> fetched(nb);   // a file's key columns come to the host while the next file is decoded
     size_t total = 0;
     for (size_t b = 0; b < nb; ++b) {
-        tid[b].resize(n[b]); pos[b].resize(n[b]); flag[b].resize(n[b]);
-        bdx_batch_buf out{};
-        out.tid = tid[b].data(); out.pos = pos[b].data(); out.flag = flag[b].data();
-        out.capacity = n[b];
-        const int rc = bdx_bamdec_fetch(decs[b], 0, n[b], &out);
-        if (rc != BDX_OK) throw std::runtime_error(std::string("bdx_bamdec_fetch: ") + bdx_strerror(rc) + " (" + bdx_bamdec_last_error(decs[b]) + ")");
-        ptid[b] = tid[b].data(); ppos[b] = pos[b].data(); pflag[b] = flag[b].data();
+        bool un = false;
+        n[b] = decode_on_device(cfg, b, chr, threads, b == 0 ? targets : nullptr, nullptr, device, &un, &decs[b]);
+        if (un) {
+            for (auto& f : fetched) if (f.valid()) f.wait();
+            if (unsupported) *unsupported = true;
+            return 0;
+        }
         total += n[b];
+        fetched[b] = std::async(std::launch::async, [&, b]() -> int {
+            tid[b].resize(n[b]); pos[b].resize(n[b]); flag[b].resize(n[b]);
+            bdx_batch_buf out{};
+            out.tid = tid[b].data(); out.pos = pos[b].data(); out.flag = flag[b].data();
+            out.capacity = n[b];
+            return bdx_bamdec_fetch(decs[b], 0, n[b], &out);
+        });
     }
+    const double t_dec = since();
+    int fetch_rc = BDX_OK;
+    size_t fetch_bad = 0;
+    for (size_t b = 0; b < nb; ++b) {
+        const int rc = fetched[b].get();
+        if (rc != BDX_OK && fetch_rc == BDX_OK) { fetch_rc = rc; fetch_bad = b; }
+        ptid[b] = tid[b].data(); ppos[b] = pos[b].data(); pflag[b] = flag[b].data();
+    }
+    if (fetch_rc != BDX_OK)
+        throw std::runtime_error(std::string("bdx_bamdec_fetch: ") + bdx_strerror(fetch_rc) + " (" + bdx_bamdec_last_error(decs[fetch_bad]) + ")");
     if (total > 0xFFFFFFFFull - 1024) { if (unsupported) *unsupported = true; return 0; }
     const double t_keys = since();
     std::vector<uint8_t> src_file;
@@ -613,6 +638,12 @@ size_t produce_on_device(const BamConfig& cfg, const std::string& chr, int threa
     return total;
 }
 
+
+void release_device_decoders() {
+    std::lock_guard<std::mutex> lk(g_retired_mu);
+    for (bdx_bamdec* d : g_retired) bdx_bamdec_destroy(d);
+    g_retired.clear();
+}
 
 void read_targets(const BamConfig& cfg, std::vector<std::string>& names, std::vector<uint32_t>& lengths) {
     if (cfg.num_bams() == 0) throw std::runtime_error("BamMerger created with no input streams!");

@@ -57,6 +57,8 @@ size_t produce_stream(const BamConfig& cfg, const std::string& chr, int threads,
 // when the file is one the device path leaves to the host reader (a record of more than 4 MiB), with nothing appended.
 size_t produce_on_device(const BamConfig& cfg, const std::string& chr, int threads, std::vector<std::string>* targets, bdx_ctx* ctx,
                          bool* unsupported);
+// the decoders produce_on_device used are kept (releasing them costs more than the run that follows): this releases them
+void release_device_decoders();
 // reference sequences of the first BAM of the configuration (names and lengths from its header; io/BamMerger.cpp:78)
 void read_targets(const BamConfig& cfg, std::vector<std::string>& names, std::vector<uint32_t>& lengths);
 void produce(const BamConfig& cfg, const std::string& chr, int threads, ReadStream& out);
