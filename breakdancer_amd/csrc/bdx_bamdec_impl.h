@@ -231,19 +231,7 @@ int bam_record_stage(bdx_bamdec* d, BamPiece& p, const BamPiece* next, bool is_l
     BamTimer t6(d->host_ms[6]);
     hipStream_t s = d->s_rec;
     bdx_bamdec::Slot& sl = d->slot[p.slot];
-    uint64_t avail_end = p.ring_end;
-    // (the batch's own inflate launch and its successor's run on two streams: neither implies the other)
-    BHIP(d, hipStreamWaitEvent(s, p.ev_inflated, 0));
-    if (next) {
-        BHIP(d, hipStreamWaitEvent(s, next->ev_inflated, 0));
-        if (next->wrapped) {   // mirror the front of the ring behind this piece: the straddling record stays contiguous
-            const size_t n = std::min<uint64_t>(kBamMargin, next->ring_end - next->ring_beg);
-            BHIP(d, hipMemcpyAsync((char*)d->d_ring.p + p.ring_end, (char*)d->d_ring.p + next->ring_beg, n, hipMemcpyDeviceToDevice, s));
-            avail_end = p.ring_end + n;
-        } else {
-            avail_end = next->ring_end;
-        }
-    }
+    // (sizes first: a wait on the stream, should one be needed, must not find this stage's own waits for the inflate launches in it)
     const uint32_t nblk = p.nblk;
     // upper bound of the piece's records (36 bytes is the smallest record) -> the raw columns
     const uint64_t bound = (p.ring_end - p.ring_beg) / 36 + 2;
@@ -284,6 +272,19 @@ int bam_record_stage(bdx_bamdec* d, BamPiece& p, const BamPiece* next, bool is_l
             bam_poll(d);
             const int rc = bam_own_reserve(d, std::max<size_t>((size_t)need, d->own_cap + d->own_cap / 2), d->confirmed);
             if (rc != BDX_OK) return rc;
+        }
+    }
+    uint64_t avail_end = p.ring_end;
+    // (the batch's own inflate launch and its successor's run on two streams: neither implies the other)
+    BHIP(d, hipStreamWaitEvent(s, p.ev_inflated, 0));
+    if (next) {
+        BHIP(d, hipStreamWaitEvent(s, next->ev_inflated, 0));
+        if (next->wrapped) {   // mirror the front of the ring behind this piece: the straddling record stays contiguous
+            const size_t n = std::min<uint64_t>(kBamMargin, next->ring_end - next->ring_beg);
+            BHIP(d, hipMemcpyAsync((char*)d->d_ring.p + p.ring_end, (char*)d->d_ring.p + next->ring_beg, n, hipMemcpyDeviceToDevice, s));
+            avail_end = p.ring_end + n;
+        } else {
+            avail_end = next->ring_end;
         }
     }
     const uint8_t* u = d->d_ring.as<uint8_t>();
