@@ -114,3 +114,21 @@ def test_cli_sharded_over_ranks_reproduces_the_golden_output(gpus, args, fn, tmp
     for lib in ("H_IJ-NA19238-NA19238-extlibs", "H_IJ-NA19240-NA19240-extlibs"):
         for k in ("1", "2"):
             assert open("%s.%s.%s.fastq" % (prefix, lib, k)).read() == open(os.path.join(CWD, "expected.%s.%s.fastq" % (lib, k))).read(), (lib, k)
+
+
+@pytest.mark.parametrize("env", [{"BDX_FOREGROUND": "1"}, {"BDX_CLEAN_EXIT": "1"}, {"BDX_DECODE": "host"}])
+def test_cli_process_modes_print_the_same_table(env):
+    """the default (GPU work in a child whose exit the command does not wait for), one process (BDX_FOREGROUND), one process walking
+    its destructors (BDX_CLEAN_EXIT), the host reader: the reference's expected output every time, and the dumps complete when the
+    command returns"""
+    import tempfile
+    exp = filter_cmd_lines(open(os.path.join(CWD, "expected_output")).read())
+    with tempfile.TemporaryDirectory() as td:
+        bed = os.path.join(td, "out.bed")
+        p = subprocess.run([EXE, "-g", bed, "inv_del_bam_config"], cwd=CWD, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr.decode()
+        assert filter_cmd_lines(p.stdout.decode()) == exp
+        assert open(bed).read() == open(os.path.join(CWD, "expected.bed")).read()
+        p = subprocess.run([EXE, "-g", bed, "inv_del_bam_config"], cwd=CWD, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0 and filter_cmd_lines(p.stdout.decode()) == exp
+        assert open(bed).read() == open(os.path.join(CWD, "expected.bed")).read()   # (read the moment the command has returned)
