@@ -74,6 +74,10 @@ struct __attribute__((aligned(16))) Lds {
     uint16_t lit_cnt[16], dist_cnt[16], pre_cnt[16];
     uint16_t first_code[16], first_index[16];   // of the alphabet being built
     uint8_t lens[320];         // code lengths: literal/length alphabet, then distances
+    // length symbol -> base length | extra bits << 12; distance symbol -> base distance | extra bits << 16 (RFC 1951 3.2.5).  Two
+    // look-ups instead of two dozen vector instructions per step: the vector pipe is what this kernel runs out of
+    uint16_t lbx[32];
+    uint32_t dbx[32];
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -92,6 +96,14 @@ __device__ __forceinline__ uint64_t ring_peek(const uint32_t* ibuf, uint32_t p) 
 
 // bytes [from, from + 512) of the member's payload into the ring (from is a multiple of 512; what lies behind the payload
 // -- the footer, the next member, the buffer's padding -- is loaded too and never looked at)
+// the same for the step loop: the two halves straight from v_alignbit (which shifts by the low five bits of p itself)
+__device__ __forceinline__ void ring_peek2(const uint32_t* ibuf, uint32_t p, uint32_t& lo, uint32_t& hi) {
+    const uint32_t i0 = (p >> 5) & (kIB / 4 - 1);
+    const uint32_t d0 = ibuf[i0], d1 = ibuf[(i0 + 1) & (kIB / 4 - 1)], d2 = ibuf[(i0 + 2) & (kIB / 4 - 1)];
+    lo = __builtin_amdgcn_alignbit(d1, d0, p);
+    hi = __builtin_amdgcn_alignbit(d2, d1, p);
+}
+
 __device__ __forceinline__ void ring_load(uint32_t* ibuf, const uint8_t* in, uint32_t from, uint32_t lane) {
     uint64_t v;
     __builtin_memcpy(&v, in + from + 8u * lane, 8);
@@ -207,6 +219,14 @@ __global__ __launch_bounds__(64, 6) void kz_inflate_kernel(const uint8_t* __rest
     uint32_t flushed = 0;      // output bytes already in HBM; [flushed, outpos) sit in the LDS window only
     uint32_t loaded_end = 0;   // the input ring holds the bytes [loaded_end - 1024, loaded_end) (those it has loaded)
     bool last = false;
+    if (lane < 32) {
+        const uint32_t lx0 = length_extra(lane);
+        L.lbx[lane] = (uint16_t)((lane < 8 ? 3 + lane : (lane == 28 ? 258u : 3 + ((4 + (lane & 3)) << lx0))) | (lx0 << 12));
+        uint32_t dbase0, dx0;
+        distance_of(lane, &dbase0, &dx0);
+        L.dbx[lane] = dbase0 | (dx0 << 16);
+    }
+    __syncthreads();
 
     // the ring holds everything up to 96 bytes behind byte `at`
 #define KZ_ENSURE(at)                                                                   \
@@ -333,19 +353,18 @@ __global__ __launch_bounds__(64, 6) void kz_inflate_kernel(const uint8_t* __rest
             // Every lane decodes the token that would start at its bit: a literal, or a whole length/distance pair (length
             // code, its extra bits, the distance code from the table, its extra bits -- 36 bits at most, all within the 64 the
             // lane holds).  Tokens the tables do not resolve (codes longer than their index, the end-of-block code) stop the chain.
-            const uint64_t wl = ring_peek(L.ibuf, bitpos + lane);
-            const uint32_t w_lo = (uint32_t)wl, w_hi = (uint32_t)(wl >> 32);
+            uint32_t w_lo, w_hi;
+            ring_peek2(L.ibuf, bitpos + lane, w_lo, w_hi);
             const uint32_t e = L.lit[w_lo & ((1u << kLB) - 1)];
             const uint32_t l1 = t_len(e), ek = t_kind(e), ev = t_value(e);
-            const uint32_t ls = ev & 31u;
-            const uint32_t lx = length_extra(ls);
-            const uint32_t lbase = ls < 8 ? 3 + ls : (ls == 28 ? 258u : 3 + ((4 + (ls & 3)) << lx));
+            const uint32_t lb = L.lbx[ev & 31u];
+            const uint32_t lx = lb >> 12, lbase = lb & 0xFFFu;
             const uint32_t a1 = __builtin_amdgcn_alignbit(w_hi, w_lo, l1);            // the bits behind the length code (l1 <= 10)
             const uint32_t mlen = lbase + (a1 & ((1u << lx) - 1));
             const uint32_t de = L.dist[(a1 >> lx) & ((1u << kDB) - 1)];
-            const uint32_t dl = t_len(de), ds = t_value(de) & 31u;
-            const uint32_t dx = ds < 4 ? 0u : (ds >> 1) - 1;
-            const uint32_t dbase = ds < 4 ? 1 + ds : 1 + ((2 + (ds & 1)) << dx);
+            const uint32_t dl = t_len(de);
+            const uint32_t db = L.dbx[t_value(de) & 31u];
+            const uint32_t dx = db >> 16, dbase = db & 0xFFFFu;
             const uint32_t a2 = __builtin_amdgcn_alignbit(w_hi, w_lo, l1 + lx + dl);  // the distance's extra bits (l1 + lx + dl <= 23)
             const uint32_t mdist = dbase + (a2 & ((1u << dx) - 1));
             const bool is_lit = ek == T_LIT;
@@ -418,8 +437,8 @@ __global__ __launch_bounds__(64, 6) void kz_inflate_kernel(const uint8_t* __rest
             bitpos += pos;
             if (!stopped) { KZ_FLUSH(); continue; }
             // the symbol the chain stopped at, with the bits (and the distance entry) its lane holds
-            uint64_t ws = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wl >> 32), (int)pos) << 32) |
-                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wl, (int)pos);
+            uint64_t ws = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)w_hi, (int)pos) << 32) |
+                          (uint32_t)__builtin_amdgcn_readlane((int)w_lo, (int)pos);
             const uint32_t se = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)pos);
             uint32_t sde = (uint32_t)__builtin_amdgcn_readlane((int)de, (int)pos);
             uint32_t kind = t_kind(se), used = t_len(se), lsym = t_value(se);
