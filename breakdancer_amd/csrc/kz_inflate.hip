@@ -32,7 +32,7 @@ namespace bdx {
 
 namespace {
 
-constexpr int kLB = 10;            // primary literal/length table: 2^10 entries
+constexpr int kLB = 9;             // primary literal/length table: 2^9 entries (10 bits resolved 12 % fewer codes' worth of slow path and cost four waves per CU)
 constexpr int kDB = 8;             // primary distance table
 constexpr int kMaxBits = 15;
 // 16-bit table entry: bits 0-3 code length (0: not in the table), 4-5 kind, 6-13 literal byte / length symbol / distance symbol
@@ -200,7 +200,7 @@ __device__ bool build_tables(Lds& L, const uint8_t* lens, uint32_t n, uint16_t* 
     return true;
 }
 
-__global__ __launch_bounds__(64, 6) void kz_inflate_kernel(const uint8_t* __restrict__ in_all, const BgzfBlock* __restrict__ blocks, uint32_t nblk,
+__global__ __launch_bounds__(64, 7) void kz_inflate_kernel(const uint8_t* __restrict__ in_all, const BgzfBlock* __restrict__ blocks, uint32_t nblk,
                                                         uint8_t* out_all, uint32_t* __restrict__ status, unsigned long long* __restrict__ prof) {
     __shared__ Lds L;
     // measurement hook (BDX_KZ_PROF, tools/bamdec_probe.py): per member {cycles in all, in headers + tables, steps, matches, slow codes, deflate blocks}
