@@ -760,6 +760,7 @@ int bdx_merge_decoded(bdx_ctx* c, bdx_bamdec* const* decs, int k, const uint8_t*
     const int rc = alloc_reads(c, (size_t)n);
     if (rc != BDX_OK) return rc;
     DevBuf d_file, d_index, d_err;
+    struct Release { DevBuf &a, &b, &c; ~Release() { a.release(); b.release(); c.release(); } } release{d_file, d_index, d_err};
     HIPCHK(c, d_file.ensure((size_t)n)); HIPCHK(c, d_index.ensure((size_t)n * 4)); HIPCHK(c, d_err.ensure(16));
     hipStream_t s = c->stream;
     hipError_t e = hipMemcpyAsync(d_file.p, src_file, (size_t)n, hipMemcpyHostToDevice, s);
@@ -775,7 +776,6 @@ int bdx_merge_decoded(bdx_ctx* c, bdx_bamdec* const* decs, int k, const uint8_t*
         e = hipMemcpyAsync(&err, d_err.p, 4, hipMemcpyDeviceToHost, s);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    d_file.release(); d_index.release(); d_err.release();
     HIPCHK(c, e);
     if (err) return fail(c, BDX_EINVAL, "the merge order names a record that does not exist");
     c->n = (size_t)n;

@@ -147,7 +147,6 @@ template <bool kBases> __device__ __forceinline__ void k2_body(const K2Params& p
                         p.c.isize[j] = (int32_t)r0.z;
                         p.c.meta[j] = r0.w | ((uint32_t)qlen << 16);
                         p.c.key[j] = key;
-                    if (p.c.check) p.c.check[j] = check;
                         if (p.c.check) p.c.check[j] = check;
                         p.c.idx[j] = (uint32_t)i;
                         p.c.nn[j] = p.nn_base + pre_norm + e[0] + ((r1.x >> 8) & 511u);

@@ -17,6 +17,7 @@
 #include <cerrno>
 #include <csignal>
 #include <fcntl.h>
+#include <sys/prctl.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -200,6 +201,10 @@ int main(int argc, char** argv) {
                 close(pfd[0]);
                 g_report_fd = pfd[1];
                 fcntl(g_report_fd, F_SETFD, FD_CLOEXEC);
+                // (killing the command kills the work: the child is told when the process that was started goes -- after the report
+                // that only cuts its exit short)
+                prctl(PR_SET_PDEATHSIG, SIGTERM);
+                if (getppid() == 1) _exit(1);
             } else {  // (no child: everything in this process)
                 close(pfd[0]);
                 close(pfd[1]);
