@@ -412,7 +412,7 @@ size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::strin
     // Small files get small buffers.  Test knobs: BDX_BAM_PIECE_BYTES, BDX_BAM_BATCH_BLOCKS, BDX_BAM_RING_BYTES
     const size_t kPiece = getenv("BDX_BAM_PIECE_BYTES") ? (size_t)std::max(1ll, atoll(getenv("BDX_BAM_PIECE_BYTES"))) : ((size_t)8 << 20);   // (a staging buffer costs ~0.22 ms per MiB to pin and is reused dozens of times)
     const size_t rest = file_size - std::min(file_size, member_off);
-    p.batch_bytes = std::min<size_t>((size_t)256 << 20, ((rest + ((size_t)1 << 20)) >> 20) << 20);
+    p.batch_bytes = std::min<size_t>((size_t)384 << 20, ((rest + ((size_t)1 << 20)) >> 20) << 20);
     p.expected_bytes = rest;
     p.batch_blocks = getenv("BDX_BAM_BATCH_BLOCKS") ? (size_t)std::max(1ll, atoll(getenv("BDX_BAM_BATCH_BLOCKS"))) : 0;
     // four batches of inflated bytes: a batch is at most ~8192 + a piece's members of 64 KiB, or the whole file (assume <= 16 x its size)
