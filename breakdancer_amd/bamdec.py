@@ -236,6 +236,18 @@ class BamDecoder:
             pass
 
 
+def merge_decoded(sink, decoders, src_file, src_index):
+    """bdx_merge_decoded: the finished decoders' columns gathered into sink's store, record i = record src_index[i] of decoder src_file[i]"""
+    lib = _lib()
+    lib.bdx_merge_decoded.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
+    f = np.ascontiguousarray(src_file, dtype=np.uint8)
+    i = np.ascontiguousarray(src_index, dtype=np.uint32)
+    arr = (C.c_void_p * len(decoders))(*[d.h for d in decoders])
+    rc = lib.bdx_merge_decoded(sink.h, arr, len(decoders), f.ctypes.data, i.ctypes.data, len(f))
+    if rc != 0:
+        raise RuntimeError("bdx_merge_decoded: %s (%s)" % (lib.bdx_strerror(rc).decode(), lib.bdx_last_error(sink.h).decode()))
+
+
 def decode_file(path, rg_ids=(), rg_lib=(), fallback_lib=0, bam_index=0, region=None, piece_blocks=512, ring_bytes=0, sink=None, device=0,
                 batch_blocks=0):
     """whole file -> (columns or None with a sink, target names, decoder statistics)"""

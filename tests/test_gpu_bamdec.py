@@ -230,3 +230,50 @@ def test_truncated_and_corrupt_files_are_errors(tmp_path):
     with pytest.raises(RuntimeError):
         d.finish()
     d.close()
+
+
+def test_two_decoders_merged_by_a_gather_equal_the_oracle_run():
+    """the reference's two BAMs, each through a decoder of its own (no sink), the merged order of the oracle's stream as the
+    permutation: bdx_merge_decoded fills the context's store, the run prints the reference's table; a permutation that does not
+    cover the records, or names one that does not exist, is refused"""
+    from breakdancer_amd import bamdec
+    import breakdancer_amd as bda
+    from helpers import load_chr21, make_opts
+    from runner import compare, product_options
+    run = load_chr21(make_opts()).run()
+    rows, libs = config_read_groups(os.path.join(CHR21, "inv_del_bam_config"))
+    rg_ids = [r[0] for r in rows]
+    rg_lib = [libs.index(r[1]) for r in rows]
+    decs = []
+    for b, fn in enumerate(run.bam_names):
+        data = np.fromfile(os.path.join(CHR21, fn), dtype=np.uint8)
+        members = bamdec.scan_bgzf(data)
+        names, lens, k, off = bamdec.bam_header(data, members)
+        d = bamdec.BamDecoder(len(names), bam_index=b, rg_ids=rg_ids, rg_lib=rg_lib, fallback_lib=0, first_record_offset=off)
+        d.feed(data, members[k:], 3)
+        d.finish()
+        decs.append(d)
+    from breakdancer_amd.api import LibraryConfig
+    lcfg = [LibraryConfig(*[float(x) for x in run.lib_f[i]], min_mapping_quality=int(run.lib_i[i, 0]), bam_file_index=int(run.lib_i[i, 1]),
+                          name=run.lib_names[i]) for i in range(run.nlibs)]
+
+    def ctx():
+        return bda.BreakDancer(product_options(run.opts), lcfg, run.nbams, ntids=0, max_read_window_size=run.w0)
+
+    src_file = run.m_bam.astype(np.uint8)
+    src_index = run.m_src.astype(np.uint32)
+    bd = ctx()
+    bamdec.merge_decoded(bd, decs, src_file, src_index)
+    bd.run()
+    compare(run, bd)
+    bd.close()
+    bd = ctx()
+    with pytest.raises(RuntimeError):
+        bamdec.merge_decoded(bd, decs, src_file[:-1], src_index[:-1])     # does not cover the records
+    bad = src_index.copy()
+    bad[5] = 1 << 30
+    with pytest.raises(RuntimeError):
+        bamdec.merge_decoded(bd, decs, src_file, bad)                    # names a record that does not exist
+    bd.close()
+    for d in decs:
+        d.close()
