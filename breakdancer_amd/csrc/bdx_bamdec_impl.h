@@ -343,8 +343,10 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
     } else if (hipStreamCreateWithFlags(&d->s_copy, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&d->s_rec, hipStreamNonBlocking) != hipSuccess) {
         return bad(BDX_EHIP);
     }
-    if (hipStreamCreateWithFlags(&d->s_inf, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&d->s_inf2, hipStreamNonBlocking) != hipSuccess)
-        return bad(BDX_EHIP);
+    // ONE inflate stream: a stream costs the runtime 8-12 ms to create (a hardware queue each), and two launches of full batches have
+    // nothing to overlap -- a batch fills the GPU's wave slots for this kernel (with four streams the two landed on one queue anyway)
+    if (hipStreamCreateWithFlags(&d->s_inf, hipStreamNonBlocking) != hipSuccess) return bad(BDX_EHIP);
+    d->s_inf2 = d->s_inf;
     for (auto& sl : d->slot)
         if (hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&sl.ev_free, hipEventDisableTiming) != hipSuccess)
             return bad(BDX_EHIP);
@@ -383,17 +385,6 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
         d->rg.hash = d->d_rg_hash.as<uint64_t>(); d->rg.off = d->d_rg_off.as<uint32_t>(); d->rg.chars = d->d_rg_chars.as<char>();
         d->rg.lib = d->d_rg_lib.as<uint8_t>(); d->rg.n = n; d->rg.fallback = p->fallback_lib;
     }
-    if (p->piece_bytes && p->piece_blocks)
-        for (auto& st : d->staging) {
-            bdx_bamdec::Staging* sp = &st;
-            const size_t nb = p->piece_bytes + 64, nt = p->piece_blocks * sizeof(bdx_bgzf_block);
-            st.pinning = std::thread([sp, nb, nt, device] {
-                hipError_t e = hipSetDevice(device);
-                if (e == hipSuccess) e = sp->h_comp.ensure(nb);
-                if (e == hipSuccess) e = sp->h_tab.ensure(nt);
-                sp->pin_status = e;
-            });
-        }
     // ring of inflated bytes
     d->ring_bytes = p->ring_bytes ? p->ring_bytes : ((size_t)3 << 30);
     if (d->ring_bytes < ((size_t)1 << 20)) d->ring_bytes = (size_t)1 << 20;
@@ -405,6 +396,18 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
     if (hipMemcpy(d->d_state.p, &st, sizeof(st), hipMemcpyHostToDevice) != hipSuccess) return bad(BDX_EHIP);
     if (d->h_progress.ensure(64) != hipSuccess) return bad(BDX_ENOMEM);
     memset(d->h_progress.p, 0, 64);
+    // (behind the decoder's own pinned allocation: page pinning does not run in parallel with itself)
+    if (p->piece_bytes && p->piece_blocks)
+        for (auto& st : d->staging) {
+            bdx_bamdec::Staging* sp = &st;
+            const size_t nb = p->piece_bytes + 64, nt = p->piece_blocks * sizeof(bdx_bgzf_block);
+            st.pinning = std::thread([sp, nb, nt, device] {
+                hipError_t e = hipSetDevice(device);
+                if (e == hipSuccess) e = sp->h_comp.ensure(nb);
+                if (e == hipSuccess) e = sp->h_tab.ensure(nt);
+                sp->pin_status = e;
+            });
+        }
     if (sink) {
         if (sink->adopted) return bad(BDX_ESTATE);
         if (sink->n == 0 && p->expected_bytes) {   // (a record takes 50-150 bytes of BAM; a store that is too small grows)
@@ -465,6 +468,7 @@ void bdx_bamdec_destroy(bdx_bamdec* d) {
     for (auto& st : d->staging)
         if (st.pinning.joinable()) st.pinning.join();
     if (d->borrowed_streams) d->s_copy = d->s_rec = nullptr;
+    if (d->s_inf2 == d->s_inf) d->s_inf2 = nullptr;
     for (hipStream_t s : {d->s_copy, d->s_inf, d->s_inf2, d->s_rec})
         if (s) (void)hipStreamDestroy(s);
     delete d;
