@@ -548,13 +548,93 @@ struct KeyGreater {
 
 }  // namespace
 
+namespace {
+
+// Two files.  What the priority queue does with two streams is a rule with one bit of memory: the file that emitted last goes on
+// only while its next record is STRICTLY below the other file's; otherwise the other file is taken (ties: the file that waited).
+// Nothing ahead of a key influences what happens below it, so the merge can be cut wherever the memory cannot matter -- at a key
+// that only ONE of the files holds -- and the pieces merged by threads of their own.
+struct TwoWay {
+    const int32_t *tid[2], *pos[2];
+    const uint16_t* flag[2];
+    size_t n[2];
+    bool less(int a, size_t i, int b, size_t j) const {   // (tid, pos, strand): io/BamMerger.cpp:40-61
+        if (tid[a][i] != tid[b][j]) return tid[a][i] < tid[b][j];
+        if (pos[a][i] != pos[b][j]) return pos[a][i] < pos[b][j];
+        return ((flag[a][i] >> 4) & 1) < ((flag[b][j] >> 4) & 1);
+    }
+    // records [i, ie) of file 0 and [j, je) of file 1 into the output from i + j on; `last`: the file that emitted before them
+    void merge(size_t i, size_t ie, size_t j, size_t je, int last, uint8_t* src_file, uint32_t* src_index) const {
+        size_t o = i + j;
+        while (i < ie && j < je) {
+            const bool take0 = last == 0 ? less(0, i, 1, j) : !less(1, j, 0, i);
+            if (take0) { src_file[o] = 0; src_index[o] = (uint32_t)i; ++i; last = 0; }
+            else { src_file[o] = 1; src_index[o] = (uint32_t)j; ++j; last = 1; }
+            ++o;
+        }
+        for (; i < ie; ++i, ++o) { src_file[o] = 0; src_index[o] = (uint32_t)i; }
+        for (; j < je; ++j, ++o) { src_file[o] = 1; src_index[o] = (uint32_t)j; }
+    }
+    // (a file is sorted by reference and position; the strands at one position come in any order: seams are sought by position)
+    bool before(int a, size_t i, int b, size_t j) const { return tid[a][i] != tid[b][j] ? tid[a][i] < tid[b][j] : pos[a][i] < pos[b][j]; }
+    size_t lower_bound(int f, int kf, size_t ki) const {   // first record of file f whose position is not before that of record ki of file kf
+        size_t lo = 0, hi = n[f];
+        while (lo < hi) {
+            const size_t mid = (lo + hi) / 2;
+            if (before(f, mid, kf, ki)) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    }
+};
+
+void merge_two(const TwoWay& w, int threads, uint8_t* src_file, uint32_t* src_index) {
+    // seams: (i, j) with every record before them at a position before every record behind them, and file 1 holding nothing at record i's position
+    std::vector<std::pair<size_t, size_t>> seam{{0, 0}};
+    const int want = std::max(1, threads);
+    for (int t = 1; t < want; ++t) {
+        size_t i = w.n[0] * (size_t)t / (size_t)want;
+        bool found = false;
+        for (int tries = 0; tries < 64 && i < w.n[0]; ++tries) {
+            i = w.lower_bound(0, 0, i);                    // the first record of file 0 at this position
+            const size_t j = w.lower_bound(1, 0, i);
+            if (j == w.n[1] || w.before(0, i, 1, j)) {     // file 1 has no record there: the seam cannot see a tie
+                if (i > seam.back().first || j > seam.back().second) seam.emplace_back(i, j);
+                found = true;
+                break;
+            }
+            size_t lo = i, hi = w.n[0];                    // on to file 0's next position
+            while (lo < hi) {
+                const size_t mid = (lo + hi) / 2;
+                if (!w.before(0, i, 0, mid)) lo = mid + 1; else hi = mid;
+            }
+            i = lo;
+        }
+        (void)found;   // (no seam here: the piece before it is simply longer)
+    }
+    seam.emplace_back(w.n[0], w.n[1]);
+    std::vector<std::thread> th;
+    for (size_t s = 0; s + 1 < seam.size(); ++s) {
+        // (the file that emitted before a seam: nothing at a seam depends on it; the very first piece starts as the queue does -- file 0 on a tie)
+        auto job = [&w, &seam, s, src_file, src_index] { w.merge(seam[s].first, seam[s + 1].first, seam[s].second, seam[s + 1].second, 1, src_file, src_index); };
+        if (s + 2 < seam.size()) th.emplace_back(job); else job();
+    }
+    for (auto& t : th) t.join();
+}
+
+}  // namespace
+
 void merge_order(const std::vector<const int32_t*>& tid, const std::vector<const int32_t*>& pos, const std::vector<const uint16_t*>& flag,
-                 const std::vector<size_t>& n, std::vector<uint8_t>& src_file, std::vector<uint32_t>& src_index) {
+                 const std::vector<size_t>& n, std::vector<uint8_t>& src_file, std::vector<uint32_t>& src_index, int threads) {
     const size_t k = n.size();
     size_t total = 0;
     for (size_t b = 0; b < k; ++b) total += n[b];
     src_file.resize(total);
     src_index.resize(total);
+    if (k == 2 && threads > 0) {
+        const TwoWay w{{tid[0], tid[1]}, {pos[0], pos[1]}, {flag[0], flag[1]}, {n[0], n[1]}};
+        merge_two(w, total < ((size_t)1 << 16) && threads < 1000 ? 1 : std::min(threads, 64), src_file.data(), src_index.data());
+        return;
+    }
     std::vector<KeyCursor> cur(k);
     std::priority_queue<KeyCursor*, std::vector<KeyCursor*>, KeyGreater> pq;
     for (size_t b = 0; b < k; ++b) {
@@ -628,7 +708,7 @@ size_t produce_on_device(const BamConfig& cfg, const std::string& chr, int threa
     const double t_keys = since();
     std::vector<uint8_t> src_file;
     std::vector<uint32_t> src_index;
-    merge_order(ptid, ppos, pflag, n, src_file, src_index);
+    merge_order(ptid, ppos, pflag, n, src_file, src_index, std::max(1, threads));
     const double t_merge = since();
     const int rc = bdx_merge_decoded(ctx, decs.data(), (int)nb, src_file.data(), src_index.data(), total);
     if (rc != BDX_OK) throw std::runtime_error(std::string("bdx_merge_decoded: ") + bdx_strerror(rc) + " (" + bdx_last_error(ctx) + ")");
@@ -676,7 +756,9 @@ void produce_merged_by_columns(const BamConfig& cfg, const std::string& chr, int
     for (size_t b = 0; b < nb; ++b) { tid[b] = per[b].tid.data(); pos[b] = per[b].pos.data(); flag[b] = per[b].flag.data(); n[b] = per[b].size(); }
     std::vector<uint8_t> src_file;
     std::vector<uint32_t> src_index;
-    merge_order(tid, pos, flag, n, src_file, src_index);
+    // (BDX_DUMP_MERGE=queue: the priority queue itself; =pieces: the two-file rule cut into many pieces even on a small input)
+    const char* how = getenv("BDX_DUMP_MERGE");
+    merge_order(tid, pos, flag, n, src_file, src_index, how && !strcmp(how, "queue") ? 0 : how && !strcmp(how, "pieces") ? 1007 : 4);
     const size_t total = src_file.size();
     out.tid.resize(total); out.pos.resize(total); out.mtid.resize(total); out.mpos.resize(total); out.isize.resize(total); out.flag.resize(total);
     out.qlen.resize(total); out.mapq.resize(total); out.lib.resize(total); out.bam.resize(total); out.name_key.resize(total); out.name_check.resize(total);

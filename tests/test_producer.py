@@ -176,17 +176,19 @@ def test_merge_order_over_key_columns_equals_the_streaming_merge():
     columns, with runs below the queue's top taken without touching it) against the streaming merge of the host reader, on the
     reference's two BAMs -- whose records tie in position across the files -- through the tool that prints both"""
     head, rows, keys = dump(["inv_del_bam_config"], os.path.join(GOLDEN, "chr21"))
-    head2, rows2, keys2 = dump(["inv_del_bam_config"], os.path.join(GOLDEN, "chr21"), {"BDX_DUMP_MERGE": "columns"})
     assert len(rows) == 5917
-    np.testing.assert_array_equal(rows, rows2)
-    np.testing.assert_array_equal(keys, keys2)
+    # the two-file rule in one piece, the same cut into up to 64 pieces merged by threads of their own, the priority queue itself
+    for how in ("columns", "pieces", "queue"):
+        head2, rows2, keys2 = dump(["inv_del_bam_config"], os.path.join(GOLDEN, "chr21"), {"BDX_DUMP_MERGE": how})
+        np.testing.assert_array_equal(rows, rows2, err_msg=how)
+        np.testing.assert_array_equal(keys, keys2, err_msg=how)
     # ties across the two files exist in this input (equal tid and pos, records of both files)
     t = rows[:, 0] * (1 << 32) + rows[:, 1]
     same = (t[1:] == t[:-1]) & (rows[1:, 9] != rows[:-1, 9])
     assert same.sum() > 10
 
 
-@pytest.mark.parametrize("nfiles,seed", [(2, 1), (3, 2), (5, 3)])
+@pytest.mark.parametrize("nfiles,seed", [(2, 1), (2, 7), (2, 8), (3, 2), (5, 3)])
 def test_merge_order_with_heavy_ties_across_several_files(tmp_path, nfiles, seed):
     """2, 3 and 5 files whose records crowd on a few positions and both strands: the order among equal keys is whatever the
     reference's priority queue does with them -- merge_order must reproduce the streaming merge record for record"""
@@ -204,9 +206,10 @@ def test_merge_order_with_heavy_ties_across_several_files(tmp_path, nfiles, seed
         lines.append("readgroup:g%d\tplatform:illumina\tmap:f%d.bam\treadlen:50.00\tlib:lib%d\tnum:10001\tlower:310.00\tupper:490.00\tmean:400.00\tstd:30.00\n" % (b, b, b))
     (tmp_path / "cfg").write_text("".join(lines))
     head, rows, keys = dump(["cfg"], str(tmp_path))
-    head2, rows2, keys2 = dump(["cfg"], str(tmp_path), {"BDX_DUMP_MERGE": "columns"})
     assert len(rows) > 300 * nfiles
-    np.testing.assert_array_equal(rows, rows2)
-    np.testing.assert_array_equal(keys, keys2)
+    for how in ("columns", "pieces", "queue"):   # (two files: the one-bit rule, whole and in pieces; more: the queue either way)
+        head2, rows2, keys2 = dump(["cfg"], str(tmp_path), {"BDX_DUMP_MERGE": how})
+        np.testing.assert_array_equal(rows, rows2, err_msg=how)
+        np.testing.assert_array_equal(keys, keys2, err_msg=how)
     t = rows[:, 0] * (1 << 32) + rows[:, 1]
     assert ((t[1:] == t[:-1]) & (rows[1:, 9] != rows[:-1, 9])).sum() > 100   # neighbours with one key from two files
