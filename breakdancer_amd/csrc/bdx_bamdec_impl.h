@@ -246,7 +246,8 @@ int bam_record_stage(bdx_bamdec* d, BamPiece& p, const BamPiece* next, bool is_l
         BHIP(d, d->d_scan.ensure((cap / 256 + 8) * 4));
         d->raw_cap = (uint32_t)cap;
     }
-    if (nblk > d->rec_cap_blk) {   // (growing them frees them first, which waits for the device: sized for a full batch at once)
+    if (nblk > d->rec_cap_blk || !d->d_base.p) {   // (growing them frees them first, which waits for the device: sized for a full batch at once;
+                                                    // a batch without members still has its record count written)
         const size_t nb = std::max<size_t>((size_t)nblk + nblk / 2, d->batch_blocks + d->batch_blocks / 4 + 64);
         d->rec_cap_blk = nb;
         BHIP(d, hipStreamSynchronize(s));

@@ -91,3 +91,29 @@ def test_cli_one_bam_decoded_on_the_gpu_equals_oracle(seed, tmp_path):
         assert p.returncode == 0, p.stderr.decode()
         outs[label] = {f: open(os.path.join(str(d), f), "rb").read() for f in sorted(os.listdir(str(d)))}
     assert outs["device"] == outs["host"] and outs["device"]
+
+
+def test_cli_two_bams_one_of_them_without_records(tmp_path):
+    """a configuration whose second BAM holds a header and nothing else: decoded on the GPU like the other (zero records from it), merged,
+    same text as the oracle and as the host reader"""
+    rng = np.random.default_rng(77)
+    cfg, streams, targets = make_case(577)
+    empty = {k: (v[:0] if hasattr(v, "__len__") and not isinstance(v, str) else v) for k, v in streams[1].items()}
+    streams = [streams[0], empty]
+    write_case(str(tmp_path), streams, targets, rng)
+    (tmp_path / "cfg").write_text(cfg)
+    run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1))
+    for label, env in (("device", dict(BDX_TIMING="1")), ("host", dict(BDX_TIMING="1", BDX_DECODE="host"))):
+        p = subprocess.run([EXE, "-y", "-1", "cfg"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert p.returncode == 0, (label, p.stderr.decode())
+        assert ("2 files decoded on the GPU" in p.stderr.decode()) == (label == "device"), p.stderr.decode()
+        assert filter_cmd_lines(p.stdout.decode()) == filter_cmd_lines(run.text), (label, p.stderr.decode())
+    # the file without records as a configuration of its own: the statistics lines, no rows, on either reader
+    cfg_b = "".join(l + "\n" for l in cfg.splitlines() if "map:b.bam" in l)
+    (tmp_path / "cfgb").write_text(cfg_b)
+    texts = []
+    for env in (dict(), dict(BDX_DECODE="host")):
+        p = subprocess.run([EXE, "-y", "-1", "cfgb"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr.decode()
+        texts.append(filter_cmd_lines(p.stdout.decode()))
+    assert texts[0] == texts[1] and not [l for l in texts[0].splitlines() if not l.startswith("#")]
