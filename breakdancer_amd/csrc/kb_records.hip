@@ -53,7 +53,8 @@ __device__ __forceinline__ void walk_block(const uint8_t* u, uint64_t ubeg, uint
     while (p < ulen) {
         if (ubeg + p + 4 > avail_end) { bad = 2; break; }   // the size word is not there (yet): too long a record, or a truncated file
         const uint32_t bs = ld32(u + ubeg + p);
-        if (bs < 32 || bs > kMaxDeviceRecord) { bad = 1; break; }
+        if (bs < 32) { bad = 1; break; }
+        if (bs > kMaxDeviceRecord) { bad = 3; break; }   // (from a true boundary: a record longer than this path spans -- the host reader's case)
         if (store) offs[k] = (uint16_t)p;
         ++k;
         p += 4 + (uint64_t)bs;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(kStitchThreads) void kb_stitch_kernel(const uint8_t
                 cb[b] = c;
                 ++redo;
             }
-            if (c.bad) error = c.bad == 2 && is_last ? 4 : (c.bad == 2 ? 2 : 1);   // from a TRUE boundary: a corrupt or truncated file, or too long a record
+            if (c.bad) error = c.bad == 2 && is_last ? 4 : (c.bad == 1 ? 1 : 2);   // from a TRUE boundary: a corrupt or truncated file, or too long a record
             expect = beg + (uint64_t)c.end;
         }
         if (first_bad == nblk && nblk) expect = blocks[nblk - 1].out_off + (uint64_t)cb[nblk - 1].end;

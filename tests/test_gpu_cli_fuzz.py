@@ -117,3 +117,28 @@ def test_cli_two_bams_one_of_them_without_records(tmp_path):
         assert p.returncode == 0, p.stderr.decode()
         texts.append(filter_cmd_lines(p.stdout.decode()))
     assert texts[0] == texts[1] and not [l for l in texts[0].splitlines() if not l.startswith("#")]
+
+
+def test_cli_record_larger_than_the_device_path_takes_goes_to_the_host_reader(tmp_path):
+    """one read of 3 M bases (a 4.5 MB record: over the 4 MiB the device-side boundary search spans) among ordinary ones: the decoder
+    reports it, the CLI hands the file to the host reader -- same table as with BDX_DECODE=host, no error"""
+    from breakdancer_amd.bamwrite import write_bam_records
+    rng = np.random.default_rng(5)
+    cfg, streams, targets = make_case(590, n_pairs=600)
+    cfg1 = "".join(l + "\n" for l in cfg.splitlines() if "map:a.bam" in l)
+    st = streams[0]
+    recs = [dict(tid=st["tid"][i], pos=st["pos"][i], mtid=st["mtid"][i], mpos=st["mpos"][i], isize=st["isize"][i], flag=st["flag"][i], qlen=st["qlen"][i],
+                 mapq=int(st["bdqual"][i]), am=None, rg=st["rg"][i], name="read%d" % int(st["name_id"][i])) for i in range(len(st["tid"]))]
+    big = dict(recs[len(recs) // 2])
+    big["qlen"] = 3_000_000
+    big["flag"] = int(big["flag"]) | 0x100   # (secondary: the reader filter drops it, so the table does not depend on it)
+    recs.insert(len(recs) // 2, big)
+    write_bam_records(str(tmp_path / "a.bam"), recs, targets, rgs=("rg1", "rg2", "rg3"), seed=1)
+    (tmp_path / "cfg").write_text(cfg1)
+    out = {}
+    for label, env in (("default", dict(BDX_TIMING="1")), ("host", dict(BDX_TIMING="1", BDX_DECODE="host"))):
+        p = subprocess.run([EXE, "-y", "-1", "cfg"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert p.returncode == 0, (label, p.stderr.decode()[-600:])
+        assert "host decode threads" in p.stderr.decode(), (label, p.stderr.decode()[-600:])
+        out[label] = filter_cmd_lines(p.stdout.decode())
+    assert out["default"] == out["host"] and [l for l in out["host"].splitlines() if not l.startswith("#")]
