@@ -144,6 +144,9 @@ __global__ __launch_bounds__(kStitchThreads) void kb_stitch_kernel(const uint8_t
         st->next_start = expect;
         st->redo += redo;
         if (is_last && !error && expect != avail_end) error = 4;   // the last record is cut off
+        // (a record that begins in this batch and ends behind its successor: its tail -- the tags -- is not inflated yet.  Batches of the
+        // default size hold a hundred times the longest record this path takes; a caller's tiny batches can be outgrown)
+        if (!is_last && !error && expect > avail_end) error = 2;
         if (error && !st->error) st->error = error;
     }
     __syncthreads();

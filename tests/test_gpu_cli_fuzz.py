@@ -142,3 +142,50 @@ def test_cli_record_larger_than_the_device_path_takes_goes_to_the_host_reader(tm
         assert "host decode threads" in p.stderr.decode(), (label, p.stderr.decode()[-600:])
         out[label] = filter_cmd_lines(p.stdout.decode())
     assert out["default"] == out["host"] and [l for l in out["host"].splitlines() if not l.startswith("#")]
+
+
+def test_cli_header_longer_than_a_bgzf_member(tmp_path):
+    """6,000 reference sequences: the header fills three BGZF members, the first record starts in the middle of one -- the device path
+    is told where (member and offset) by the host's header parse; same table as the oracle's and the host reader's"""
+    rng = np.random.default_rng(9)
+    cfg, streams, targets = make_case(595, n_pairs=1500)
+    many = list(targets) + ["extra_contig_%05d" % i for i in range(6000)]
+    cfg1 = "".join(l + "\n" for l in cfg.splitlines() if "map:a.bam" in l)
+    write_case(str(tmp_path), streams[:1], many, rng)
+    (tmp_path / "cfg").write_text(cfg1)
+    assert os.path.getsize(str(tmp_path / "a.bam")) > 40000
+    run = oracle_case(cfg1, streams[:1], many, make_opts(score_threshold=-1))
+    for label, env in (("device", dict(BDX_TIMING="1")), ("device-small-pieces", dict(BDX_TIMING="1", BDX_BAM_PIECE_BYTES="70000", BDX_BAM_BATCH_BLOCKS="2")),
+                       ("host", dict(BDX_TIMING="1", BDX_DECODE="host"))):
+        p = subprocess.run([EXE, "-y", "-1", "cfg"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert p.returncode == 0, (label, p.stderr.decode()[-600:])
+        assert ("on the GPU" in p.stderr.decode()) == label.startswith("device"), p.stderr.decode()[-600:]
+        assert filter_cmd_lines(p.stdout.decode()) == filter_cmd_lines(run.text), (label, p.stderr.decode()[-600:])
+
+
+def test_cli_records_spanning_several_bgzf_members(tmp_path):
+    """reads of 100 k and 400 k bases (records of 150 KB and 600 KB: three and ten BGZF members each) among ordinary ones, at piece and
+    batch sizes that put their pieces into different batches: decoded on the GPU, same table as the host reader's"""
+    from breakdancer_amd.bamwrite import write_bam_records
+    cfg, streams, targets = make_case(596, n_pairs=900)
+    cfg1 = "".join(l + "\n" for l in cfg.splitlines() if "map:a.bam" in l)
+    st = streams[0]
+    recs = [dict(tid=st["tid"][i], pos=st["pos"][i], mtid=st["mtid"][i], mpos=st["mpos"][i], isize=st["isize"][i], flag=st["flag"][i], qlen=st["qlen"][i],
+                 mapq=int(st["bdqual"][i]), am=None, rg=st["rg"][i], name="read%d" % int(st["name_id"][i])) for i in range(len(st["tid"]))]
+    for at, ql in ((len(recs) // 3, 100_000), (2 * len(recs) // 3, 400_000)):
+        big = dict(recs[at])
+        big["qlen"] = ql
+        big["flag"] = int(big["flag"]) | 0x100   # (secondary: dropped by the reader filter on both sides)
+        recs.insert(at, big)
+    write_bam_records(str(tmp_path / "a.bam"), recs, targets, rgs=("rg1", "rg2", "rg3"), seed=2)
+    (tmp_path / "cfg").write_text(cfg1)
+    out = {}
+    for label, env in (("device", dict(BDX_TIMING="1")), ("device-small-pieces", dict(BDX_TIMING="1", BDX_BAM_PIECE_BYTES="70000", BDX_BAM_BATCH_BLOCKS="16", BDX_BAM_RING_BYTES="8388608")),
+                       ("host-after-all", dict(BDX_TIMING="1", BDX_BAM_PIECE_BYTES="70000", BDX_BAM_BATCH_BLOCKS="2", BDX_BAM_RING_BYTES="4194304")),
+                       ("host", dict(BDX_TIMING="1", BDX_DECODE="host"))):
+        p = subprocess.run([EXE, "-y", "-1", "cfg"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert p.returncode == 0, (label, p.stderr.decode()[-600:])
+        # (batches of two members are shorter than the 600 KB record: the decoder says so and the host reader takes the file)
+        assert ("on the GPU" in p.stderr.decode()) == label.startswith("device"), (label, p.stderr.decode()[-600:])
+        out[label] = filter_cmd_lines(p.stdout.decode())
+    assert out["device"] == out["host"] == out["device-small-pieces"] == out["host-after-all"] and [l for l in out["host"].splitlines() if not l.startswith("#")]
