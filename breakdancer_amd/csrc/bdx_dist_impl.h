@@ -212,6 +212,7 @@ struct bdx_dist {
     uint64_t ctx_sent = 0, ctx_received = 0, gathered_bytes = 0;
     float ms_total = 0, ms_exchange = 0;
     bool ran = false;
+    float phase_ms[12] = {0};        // bdx_dist_get_phase_ms: where the last run's time went on this rank
     bool collect_support = false;    // bdx_dist_set_collect_support: the supporting reads of every SV (-g / -d) come with the result
 };
 
@@ -329,6 +330,12 @@ bdx_ctx* bdx_dist_chromosome(bdx_dist* d, int tid) {
     return c;
 }
 
+int bdx_dist_get_phase_ms(const bdx_dist* d, float* out, int n) {
+    if (!d || !out) return BDX_EINVAL;
+    for (int i = 0; i < n; ++i) out[i] = i < 12 ? d->phase_ms[i] : 0.0f;
+    return BDX_OK;
+}
+
 int bdx_dist_set_collect_support(bdx_dist* d, int on) {
     if (!d) return BDX_EINVAL;
     d->collect_support = on != 0;
@@ -401,15 +408,23 @@ int bdx_dist_run(bdx_dist* d) {
     d->ctx_sent = d->ctx_received = d->gathered_bytes = 0;
     comm.begin_run();
     RunStatus st;
-    // a phase: local work between two collectives; its failure is recorded, not returned
+    // a phase: local work between two collectives; its failure is recorded, not returned.  Phases and collectives alternate:
+    // phase_ms[2k] = the k-th phase, phase_ms[2k + 1] = the collective behind it (which includes waiting for the slowest rank)
+    int n_phase = 0;
+    for (float& x : d->phase_ms) x = 0;
     auto phase = [&](const std::function<int()>& body) {
-        if (st.rc != BDX_OK) return;
-        d->err.clear();
-        const int rc = body();
-        if (rc != BDX_OK) { st.rc = rc; st.msg = d->err; }
+        const auto tp = std::chrono::steady_clock::now();
+        if (st.rc == BDX_OK) {
+            d->err.clear();
+            const int rc = body();
+            if (rc != BDX_OK) { st.rc = rc; st.msg = d->err; }
+        }
+        if (2 * n_phase < 12) d->phase_ms[2 * n_phase] += ms_between(tp, std::chrono::steady_clock::now());
     };
     // all-reduce of v with the ranks' status words appended; afterwards every rank knows whether anybody failed
     auto exchange = [&](std::vector<uint64_t>& v) -> int {
+        const auto tp = std::chrono::steady_clock::now();
+        struct Stamp { bdx_dist* d; int& n; std::chrono::steady_clock::time_point t; ~Stamp() { if (2 * n + 1 < 12) d->phase_ms[2 * n + 1] += ms_between(t, std::chrono::steady_clock::now()); ++n; } } stamp{d, n_phase, tp};
         const size_t at = v.size();
         v.resize(at + (size_t)world, 0);
         v[at + (size_t)rank] = (uint64_t)st.rc;

@@ -163,6 +163,12 @@ class DistRun:
         return dict(ctx_records_sent=sent.value, ctx_records_received=recv.value, gathered_bytes=gathered.value, ms_total=ms_total.value,
                     ms_exchange=ms_x.value)
 
+    def phase_ms(self):
+        out = (C.c_float * 12)()
+        self.lib.bdx_dist_get_phase_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
+        self._chk(self.lib.bdx_dist_get_phase_ms(self.h, out, 12), "bdx_dist_get_phase_ms")
+        return [float(x) for x in out]
+
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:
             self.lib.bdx_dist_destroy(self.h)

@@ -359,6 +359,11 @@ int bdx_dist_set_collect_support(bdx_dist* d, int on);
  * of the whole run and of the exchange + CTX join (ms).  Any pointer may be NULL. */
 int bdx_dist_get_exchange(const bdx_dist* d, uint64_t* ctx_records_sent, uint64_t* ctx_records_received, uint64_t* gathered_bytes,
                           float* ms_total, float* ms_exchange);
+/* this rank's milliseconds of the last bdx_dist_run, phase by phase: [0] pass 1 of its chromosomes, [1] all-reduce of the statistics,
+ * [2] compaction, [3] all-reduce, [4] region cut and counts, [5] all-reduce, [6] the chromosomes' own joins and the packing of the CTX records, [7] count
+ * exchange, [8] census and CTX join, package for rank 0, [9] all-reduce; the all-to-all and the gather are in ms_exchange / ms_total
+ * of bdx_dist_get_exchange.  A collective's figure includes waiting for the slowest rank. */
+int bdx_dist_get_phase_ms(const bdx_dist* d, float* out, int n);
 int bdx_dist_owner(uint64_t name_key, int world);
 int bdx_dist_plan(const uint64_t* weight, int ntids, int world, int* rank_of_tid);
 
