@@ -93,6 +93,8 @@ struct bdx_ctx {
     size_t n = 0, cap = 0;
     bool adopted = false;
     DevBuf b_tid, b_pos, b_mtid, b_mpos, b_isize, b_flag, b_qlen, b_mapq, b_lib, b_bam, b_key, b_check;
+    bool groups_in_hbm = false;       // (sharded runs) the join's pair groups stay in HBM instead of pinned host memory
+    DevBuf b_groups;
     bool use_check = false;           // bdx_use_name_check: every batch carries a second hash of the read name, mates must agree in it too
 
     // stage buffers
@@ -449,7 +451,7 @@ void bdx_destroy(bdx_ctx* c) {
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     DevBuf* bufs[] = {&c->b_tid, &c->b_pos, &c->b_mtid, &c->b_mpos, &c->b_isize, &c->b_flag, &c->b_qlen, &c->b_mapq, &c->b_lib,
-                      &c->b_bam, &c->b_key, &c->b_check, &c->b_c_check, &c->b_x_check, &c->b_libs, &c->b_cls, &c->b_stash, &c->b_chunk_tot, &c->b_tile_tot, &c->b_tile_pre, &c->b_tile_mono,
+                      &c->b_bam, &c->b_key, &c->b_check, &c->b_c_check, &c->b_x_check, &c->b_groups, &c->b_libs, &c->b_cls, &c->b_stash, &c->b_chunk_tot, &c->b_tile_tot, &c->b_tile_pre, &c->b_tile_mono,
                       &c->b_blk_cnt, &c->b_cnt, &c->b_p1, &c->b_c_tid, &c->b_c_pos, &c->b_c_isize,
                       &c->b_c_meta, &c->b_c_key, &c->b_c_idx, &c->b_c_nn, &c->b_c_pk, &c->b_cand, &c->b_pre_q, &c->b_pre_rev,
                       &c->b_pre_nonctx, &c->b_c_first, &c->b_c_maxq, &c->b_c_rid, &c->b_region_of, &c->b_ws_u4, &c->b_ws_u32, &c->b_totals,
@@ -926,8 +928,11 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool f
         for (DevBuf* b : u32bufs) HIPCHK(c, b->ensure(cap * 4));
         // the region table and (below) the group list are written by the kernels straight into pinned host memory:
         // they are write-once, read-never on the device, so the PCIe writes overlap the kernels and no D2H copy is needed
-        HIPCHK(c, c->h_regs.ensure(cap * sizeof(RegionRec)));
-        HIPCHK(c, c->h_pk.ensure(cap * 2 * nkeys * 4));
+        const bool hbm_only = keep_dev && !for_k6;   // sharded runs: a chromosome's table is sent on from HBM, nobody reads it on this host
+        if (!hbm_only) {
+            HIPCHK(c, c->h_regs.ensure(cap * sizeof(RegionRec)));
+            HIPCHK(c, c->h_pk.ensure(cap * 2 * nkeys * 4));
+        }
         const size_t nblk = scan_grid(na, 1) + 1;  // (sized for one element per thread, the finest split the scans use)
         HIPCHK(c, c->b_ws_u4.ensure(nblk * sizeof(U4)));
         HIPCHK(c, c->b_ws_u32.ensure(nblk * 4));
@@ -963,10 +968,11 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool f
             memset(c->h_counts0.p, 0, sizeof(StageCounts));
             k3.counts_host = c->h_counts0.as<StageCounts>();
         }
-        if (keep_dev && !for_k6) {  // sharded runs: the region table is sent on from HBM (and still mirrored to the host)
+        if (hbm_only) {  // (no pinned mirror: pinning 24 chromosomes' tables cost a sharded run tens of milliseconds)
             HIPCHK(c, c->b_r_rec.ensure(cap * sizeof(RegionRec)));
             HIPCHK(c, c->b_r_pk.ensure(cap * 2 * nkeys * 4));
-            k3.r_rec_dev = c->b_r_rec.as<RegionRec>(); k3.r_pk_dev = c->b_r_pk.as<uint32_t>();
+            k3.r_rec = c->b_r_rec.as<RegionRec>(); k3.r_pk = c->b_r_pk.as<uint32_t>();
+            k3.r_rec_dev = nullptr; k3.r_pk_dev = nullptr;
             k3.host_copy_later = 0;
         }
         if (c->alloc_only) return BDX_OK;
@@ -991,9 +997,15 @@ int do_join_local(bdx_ctx* c, uint32_t n, const Entries& en, const uint32_t* n_p
     k4 = K4Arrays{};
     if (!n) return BDX_OK;
     k4.g_cap = n / 2 + 1;
-    HIPCHK(c, c->h_groups.ensure((size_t)k4.g_cap * sizeof(GroupRec)));
+    if (c->groups_in_hbm) {   // sharded runs: the groups are packaged for rank 0 from HBM
+        HIPCHK(c, c->b_groups.ensure((size_t)k4.g_cap * sizeof(GroupRec)));
+        k4.g_rec = c->b_groups.as<GroupRec>();
+    } else {
+        HIPCHK(c, c->h_groups.ensure((size_t)k4.g_cap * sizeof(GroupRec)));
+        k4.g_rec = c->h_groups.as<GroupRec>();
+    }
     HIPCHK(c, c->b_partner.ensure((size_t)n * 4));
-    k4.partner = c->b_partner.as<int32_t>(); k4.g_rec = c->h_groups.as<GroupRec>();
+    k4.partner = c->b_partner.as<int32_t>();
     if (c->alloc_only) return BDX_OK;  // (the direct table is sized by do_compact; the bucketed join sizes its own when it runs)
     if (!c->bucketed_join && n <= kDirectJoinMax) {
         const uint32_t slots = direct_join_slots(n);

@@ -326,6 +326,7 @@ bdx_ctx* bdx_dist_chromosome(bdx_dist* d, int tid) {
     if (f != d->chrom.end()) return f->second;
     bdx_ctx* c = nullptr;
     if (bdx_create(&c, &d->opts, d->libs.data(), d->nlibs, d->nbams, d->ntids, d->w0, d->device) != BDX_OK) return nullptr;
+    c->groups_in_hbm = true;   // (its pair groups go to rank 0 from HBM)
     d->chrom[tid] = c;
     return c;
 }
@@ -659,7 +660,10 @@ int bdx_dist_run(bdx_dist* d) {
             en.key = U->b_x_key.as<uint64_t>(); en.region = U->b_x_region.as<int32_t>(); en.order = U->b_x_order.as<uint32_t>();
             en.check = with_check ? U->b_x_check.as<uint64_t>() : nullptr;
             en.meta = U->b_x_meta.as<uint32_t>(); en.isize = U->b_x_isize.as<int32_t>();
-            DCTX(d, U, do_join_local(U, n32, en, U->b_x_n.as<uint32_t>(), false));
+            U->groups_in_hbm = true;    // (packaged for rank 0 from HBM like the chromosomes' own)
+            const int jrc = do_join_local(U, n32, en, U->b_x_n.as<uint32_t>(), false);
+            U->groups_in_hbm = false;   // (rank 0's walk reads K6's groups on the host)
+            if (jrc != BDX_OK) return dfail(d, jrc, "do_join_local: " + U->err);
             DHIP(d, hipMemcpyAsync(U->h_counts.p, U->b_counts.p, sizeof(StageCounts), hipMemcpyDeviceToHost, us));
             DHIP(d, hipStreamSynchronize(us));
             const StageCounts sc = *U->h_counts.as<StageCounts>();

@@ -14,10 +14,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _devices():
+    # (asked of the HIP runtime this process already has -- libbdx's; importing torch here would bring its bundled copy of the
+    # runtime and of RCCL into a process that may have created a communicator with the system's: two runtimes, one exit)
+    import ctypes as C
     try:
-        import torch
-        return torch.cuda.device_count() if torch.cuda.is_available() else 0
-    except ImportError:
+        hip = C.CDLL("libamdhip64.so")
+        n = C.c_int(0)
+        return n.value if hip.hipGetDeviceCount(C.byref(n)) == 0 else 0
+    except OSError:
         return 0
 
 
