@@ -588,25 +588,6 @@ def main():
         for k, v in bd.timings().items():
             stage[k] = stage.get(k, 0.0) + v
     bd.set_stage_timing(False)
-    overlapped = None
-    if world == 1 and len(ctxs) == 1 and not a.pmc_child and not a.no_overlap:   # (by default: three contexts in flight is how a whole-genome caller keeps one GPU busy)
-        # the native driver (bdx_run_many): 24 contexts -- one per chromosome of a genome, here all on the same resident input --
-        # of which three are in flight at a time
-        from breakdancer_amd.api import run_many
-        more = [bd] + [new_ctx().set_enqueue_ahead(0) for _ in range(23)]
-        run_many(more, 3)
-        run_many(more, 3)
-        torch.cuda.synchronize()
-        rounds = max(1, a.steps // 24)
-        to = time.perf_counter()
-        for _ in range(rounds):
-            run_many(more, 3)
-        torch.cuda.synchronize()
-        do = time.perf_counter() - to
-        overlapped = {"contexts_in_flight": 3, "contexts": len(more), "steps": rounds * len(more), "ms_per_step": do / (rounds * len(more)) * 1e3,
-                      "value": (n // 2) * rounds * len(more) / do, "unit": "read-pairs/s", "driver": "bdx_run_many"}
-        for x in more[1:]:
-            x.close()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cpu") if SHARED_GPU_TEST else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -629,6 +610,27 @@ def main():
             exchange_hung = True
             exchange["error"] = "no result after 600 s"
 
+    # (behind the genome runs: two dozen contexts created, run and released leave the process in a state in which rank 0's part of a
+    # sharded run -- its first, with all its allocations -- took three times as long)
+    overlapped = None
+    if world == 1 and len(ctxs) == 1 and not a.pmc_child and not a.no_overlap:   # (by default: three contexts in flight is how a whole-genome caller keeps one GPU busy)
+        # the native driver (bdx_run_many): 24 contexts -- one per chromosome of a genome, here all on the same resident input --
+        # of which three are in flight at a time
+        from breakdancer_amd.api import run_many
+        more = [bd] + [new_ctx().set_enqueue_ahead(0) for _ in range(23)]
+        run_many(more, 3)
+        run_many(more, 3)
+        torch.cuda.synchronize()
+        rounds = max(1, a.steps // 24)
+        to = time.perf_counter()
+        for _ in range(rounds):
+            run_many(more, 3)
+        torch.cuda.synchronize()
+        do = time.perf_counter() - to
+        overlapped = {"contexts_in_flight": 3, "contexts": len(more), "steps": rounds * len(more), "ms_per_step": do / (rounds * len(more)) * 1e3,
+                      "value": (n // 2) * rounds * len(more) / do, "unit": "read-pairs/s", "driver": "bdx_run_many"}
+        for x in more[1:]:
+            x.close()
     if rank == 0:
         pairs = n // 2
         value = world * pairs * a.steps / dt
