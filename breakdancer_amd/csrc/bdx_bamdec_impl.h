@@ -14,6 +14,16 @@
 //            host never waits for a batch -- it reads a progress record in pinned memory when it wants to know
 // The ring holds a few batches; a batch that does not fit behind its predecessor starts at the ring's front again, and the
 // front of it is mirrored behind the predecessor so that the record that straddles the two stays contiguous.
+//
+// Rules the feeding thread's path keeps (each one was a stall of an inflate launch's length when it was broken):
+//   * nothing is freed or grown while batches are in flight -- hipFree waits for the device -- so a slot's tables, the record
+//     stage's scratch, the raw columns and the destination are sized once, for a full batch (and the batches a store must take
+//     before their record counts are known);
+//   * with a sink the copy and record streams are the sink's own: four streams in all, one per hardware queue of the runtime
+//     (two streams on one queue run in order: a copy's completion marker would sit behind an inflate launch);
+//   * a wait on a stream comes before that stream is given its waits for the inflate launches;
+//   * the first two batches are smaller (the GPU starts after a few milliseconds of reading), staging buffers are pinned by
+//     threads of their own while the first piece is read.
 #include <deque>
 
 namespace {
