@@ -199,9 +199,6 @@ void launch_k4_join_only(const K4Arrays& k4, const Entries& e, const uint32_t* n
 
 // ---- K5 ---------------------------------------------------------------------------------------------
 void launch_k5(const double* lambda, const int32_t* k, double* out, uint32_t n, hipStream_t s);
-// term count read from device memory (the SV assembly of K6 decides it); n_upper only sizes the grid
-void launch_k5_dev(const double* lambda, const int32_t* k, double* out, double* out2, const uint32_t* n_ptr, uint32_t n_upper,
-                   hipStream_t s);  // out2 (may be null): second copy of the results
 
 // ---- K6: pair groups per region, small components walked on the device -----------------------------------
 // Connectivity of the region graph comes from the groups whose weight passes the gate (-r): lighter groups are

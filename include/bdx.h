@@ -335,7 +335,8 @@ int bdx_stage_walk(bdx_ctx* ctx, size_t nregions, const bdx_region_rec* regions,
  *                            bdx_get_regions, bdx_get_svs, bdx_get_sv_lists) return the whole-genome result; NULL on other ranks
  *   bdx_dist_owner           the rank that joins a name key (the routing rule of the all-to-all)
  *   bdx_dist_plan            chromosomes -> ranks by longest-processing-time packing on `weight` (reads or length)
- * Not supported in sharded runs: a negative -s, the -g/-d support lists, read names that occur more than twice. */
+ * Not supported in sharded runs: a negative -s.  (The -g/-d support lists -- bdx_dist_set_collect_support -- and read names that
+ * occur more than twice are served: the compact records are gathered and rank 0 walks them read by read.) */
 typedef struct bdx_dist bdx_dist;
 typedef struct bdx_unique_id { char internal[128]; } bdx_unique_id;
 int bdx_dist_unique_id(bdx_unique_id* out);
