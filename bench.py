@@ -447,8 +447,7 @@ def genome_leg(rank, world, local, dist, out, fraction=GENOME_FRACTION, transloc
             legs[label] = {"seconds": dt, "value": total / 2 / dt, "unit": "read-pairs/s", "svs_printed": sm["n_svs_printed"], "regions": sm["n_regions"],
                            "ctx_records_exchanged": stats[0], "gathered_bytes_on_rank0": ex["gathered_bytes"],
                            "rank0_ms_exchange_and_ctx_join": ex["ms_exchange"], "bdx_dist_run_ms_per_rank": [x / 1000.0 for x in rank_ms],
-                           "rank0_phase_ms": dict(zip(("pass1", "allreduce_statistics", "compaction", "allreduce_first_reads", "cut_join_pack", "allreduce_regions",
-                                                       "own_joins_and_ctx_packing", "count_exchange", "census_ctx_join_package", "allreduce_sizes"), [round(x, 3) for x in run.phase_ms()[:10]])),
+                           "rank0_phase_ms": run.phases(),
                            "load_seconds_untimed": load_s}
         run.close()
     if rank == 0:

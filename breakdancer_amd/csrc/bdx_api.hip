@@ -23,6 +23,7 @@
 #include "../../include/bdx.h"
 #include "bdx_dev.h"
 #include "bdx_k3.h"
+#include "bdx_shard.h"
 #include "bdx_scan.h"
 #include "bdx_walk.h"
 #include "bdx_bam_dev.h"
@@ -133,8 +134,17 @@ struct bdx_ctx {
     bool bucketed_join = false;       // BDX_BUCKETED_JOIN=1: use the partitioned LDS join at every size (it is the path for > 4 M entries)
     bool host_walk_only = false;      // BDX_HOST_WALK=1: every component goes through the host walk (A/B testing of K6)
     K6Arrays k6{};
-    const GroupRec* k6_in_groups = nullptr;  // sharded runs, rank 0: K6 takes the gathered pair groups instead of counting pairs
+    const GroupRec* k6_in_groups = nullptr;  // (a caller that holds pair groups as aggregates: K6 takes them instead of counting pairs)
     const uint32_t* k6_in_goff = nullptr;
+    // sharded runs (bdx_dist_*): this context holds several chromosomes of a genome, in ascending order (bdx_shard.h)
+    bool force_direct_join = false;   // the join takes foreign entries: the direct table at every size
+    uint32_t k6_cap = 0;              // capacity of K6's per-region arrays: the GENOME's regions (0: this context's anomalous reads)
+    const RegionRec* k6_r_rec = nullptr;   // the region table laid out by genome-wide id (this rank's regions, n == 0 elsewhere)
+    const uint32_t* k6_r_pk = nullptr;
+    uint8_t* k6_taint = nullptr;
+    const uint32_t* k3_tid_tail = nullptr;
+    bool table_in_hbm = false;        // the final table stays in HBM (with its order keys): rank 0 merges the ranks' tables
+    DevBuf b_sv_out, b_lib_index_out, b_lib_pairs_out, b_cn_key_out, b_cn_value_out, b_ltail_out, b_sv_key;
 
     // results
     bool ran = false;
@@ -459,7 +469,8 @@ void bdx_destroy(bdx_ctx* c) {
                       &c->b_t_idx, &c->b_x_key, &c->b_x_order, &c->b_x_region,
                       &c->b_x_meta, &c->b_x_isize, &c->b_x_n, &c->b_fold, &c->b_lib_mean, &c->b_pair_lo, &c->b_sv_src, &c->b_dlists, &c->b_ltail, &c->b_r_rec, &c->b_r_pk, &c->b_out_deg,
                       &c->b_parts, &c->b_kdens, &c->b_rs, &c->b_slot, &c->b_members, &c->b_own, &c->b_lib_stage,
-                      &c->b_cn_stage, &c->b_t_lambda, &c->b_t_k, &c->b_ws6, &c->b_ins, &c->b_member_ids};
+                      &c->b_cn_stage, &c->b_t_lambda, &c->b_t_k, &c->b_ws6, &c->b_ins, &c->b_member_ids,
+                      &c->b_sv_out, &c->b_lib_index_out, &c->b_lib_pairs_out, &c->b_cn_key_out, &c->b_cn_value_out, &c->b_ltail_out, &c->b_sv_key};
     for (DevBuf* b : bufs) b->release();
     PinBuf* pins[] = {&c->h_p1, &c->h_cnt, &c->h_counts, &c->h_regs, &c->h_pk, &c->h_groups, &c->h_terms, &c->h_flags, &c->h_hs_rec, &c->h_hs_aux, &c->h_hs_lists, &c->h_printed, &c->h_counts0, &c->h_counts2,
                       &c->h_sv_out, &c->h_lib_index, &c->h_lib_pairs, &c->h_cn_key, &c->h_cn_value, &c->h_ltail_dev};
@@ -864,7 +875,7 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepa
         HIPCHK(c, c->b_c_maxq.ensure(cap * 4));
         k2.fill_ptr[0] = c->b_c_maxq.as<uint32_t>(); k2.fill_words[0] = na; k2.fill_value[0] = 0u;
         c->join_table_clean = 0;
-        if (prepare_join && !c->bucketed_join && na <= kDirectJoinMax) {
+        if (prepare_join && (c->force_direct_join || (!c->bucketed_join && na <= kDirectJoinMax))) {
             const uint32_t slots = direct_join_slots(na);
             HIPCHK(c, c->b_t_key.ensure((size_t)slots * 8)); HIPCHK(c, c->b_partner.ensure((size_t)na * 4));
             k2.fill_ptr[1] = c->b_t_key.as<uint32_t>(); k2.fill_words[1] = 2 * slots; k2.fill_value[1] = 0xFFFFFFFFu;
@@ -976,7 +987,7 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool f
             k3.host_copy_later = 0;
         }
         if (c->alloc_only) return BDX_OK;
-        K3Tail tail{has_next, next_qlen, next_nn};
+        K3Tail tail{has_next, next_qlen, next_nn, c->k3_tid_tail};
         // single-context runs that take the direct join let that kernel do k3_region_of_kernel's work
         c->region_of_fused = for_k6 && !c->bucketed_join && na <= kDirectJoinMax;
         launch_k3(k3, cp, c->b_p1.as<Pass1>(), na, c->opts.min_len, c->opts.seq_coverage_lim, nkeys, nn_base, tail, !c->region_of_fused, s);
@@ -1004,17 +1015,26 @@ int do_join_local(bdx_ctx* c, uint32_t n, const Entries& en, const uint32_t* n_p
         HIPCHK(c, c->h_groups.ensure((size_t)k4.g_cap * sizeof(GroupRec)));
         k4.g_rec = c->h_groups.as<GroupRec>();
     }
-    HIPCHK(c, c->b_partner.ensure((size_t)n * 4));
+    // (foreign entries of a sharded run have no partner[] / pair_lo[] entry: sized for the context's own reads, as K2 cleared them)
+    const size_t n_own = en.n_local ? std::min<size_t>(n, std::max<uint32_t>(c->na_alloc, 1u)) : n;
+    HIPCHK(c, c->b_partner.ensure(n_own * 4));
     k4.partner = c->b_partner.as<int32_t>();
     if (c->alloc_only) return BDX_OK;  // (the direct table is sized by do_compact; the bucketed join sizes its own when it runs)
-    if (!c->bucketed_join && n <= kDirectJoinMax) {
-        const uint32_t slots = direct_join_slots(n);
+    if (c->force_direct_join || (!c->bucketed_join && n <= kDirectJoinMax)) {
+        uint32_t slots = direct_join_slots(n);
+        // (the foreign entries of a sharded run come on top of the reads K2 sized the table for: it still has room at half its load)
+        if (c->join_table_clean && (uint64_t)n * 2 <= c->join_table_clean) slots = c->join_table_clean;
+        const bool want_lo = en.c_rid || en.want_pair_lo;
         if (c->join_table_clean != slots) {
             HIPCHK(c, c->b_t_key.ensure((size_t)slots * 8));
             HIPCHK(c, hipMemsetAsync(c->b_t_key.p, 0xFF, (size_t)slots * 8, s));
-            HIPCHK(c, hipMemsetAsync(c->b_partner.p, 0xFF, (size_t)n * 4, s));
+            HIPCHK(c, hipMemsetAsync(c->b_partner.p, 0xFF, n_own * 4, s));
+            if (en.want_pair_lo) {
+                HIPCHK(c, c->b_pair_lo.ensure(n_own * 4));
+                HIPCHK(c, hipMemsetAsync(c->b_pair_lo.p, 0xFF, n_own * 4, s));
+            }
         }
-        k4.pair_lo = (c->join_table_clean == slots && en.c_rid) ? c->b_pair_lo.as<int32_t>() : nullptr;  // preset to -1 by K2
+        k4.pair_lo = ((c->join_table_clean == slots && want_lo) || en.want_pair_lo) ? c->b_pair_lo.as<int32_t>() : nullptr;  // preset to -1 by K2
         c->join_table_clean = 0;
         k4.direct = 1; k4.t_mask = slots - 1;
         k4.t_key = c->b_t_key.as<uint64_t>(); k4.t_idx = c->b_t_idx.as<int32_t>();
@@ -1082,14 +1102,26 @@ void decode_groups(bdx_ctx* c, const GroupRec* gr, uint32_t ng, uint32_t ph) {
 
 // K6 on the context's own regions (single-context runs): pair groups per region, SV assembly of the components that need
 // no traversal, everything else listed for the host walk; then the dense results and K5 for the device-assembled SVs.
-int do_k6(bdx_ctx* c, bool force_host) {
+// part: 0 the whole first half; 1 up to and including k6_pairs_kernel, 2 the rest (a sharded run all-reduces the taint bytes in between)
+int do_k6(bdx_ctx* c, bool force_host, int part = 0) {
     hipStream_t s = c->stream;
-    const uint32_t na = c->na_alloc;
-    const int nkeys = c->nkeys, nlibs = c->nlibs;
     K6Arrays& a = c->k6;
+    if (part == 2) {
+        if (!a.cap) return BDX_OK;
+        launch_k6_components(a, a.cap, s);
+        if (!c->poll) {
+            const int rc = signal_ready(c, 1, c->ev_groups);
+            if (rc != BDX_OK) return rc;
+        }
+        launch_k6_walk(a, a.cap, s);
+        return BDX_OK;
+    }
+    const uint32_t na = std::max(c->na_alloc, c->k6_cap);   // (sharded runs: K6's arrays are indexed by genome-wide region id)
+    const int nkeys = c->nkeys, nlibs = c->nlibs;
     a = K6Arrays{};
     if (!na) return BDX_OK;
     const size_t cap = na;
+    HIPCHK(c, c->b_out_deg.ensure(cap * 6 * 4));
     HIPCHK(c, c->b_parts.ensure(cap * sizeof(PartRec)));
     HIPCHK(c, c->b_rs.ensure(cap * sizeof(RegSum)));
     HIPCHK(c, c->b_members.ensure(cap * kK6MaxMembers * sizeof(MemberInfo)));
@@ -1106,10 +1138,17 @@ int do_k6(bdx_ctx* c, bool force_host) {
     HIPCHK(c, c->b_cn_stage.ensure(cap * (size_t)nkeys * sizeof(CnStage) + 16));
     HIPCHK(c, c->b_t_lambda.ensure((size_t)a.term_cap * 8)); HIPCHK(c, c->b_t_k.ensure((size_t)a.term_cap * 4));
     const size_t nblk = scan_grid(na, 1) + 1;
-    HIPCHK(c, c->h_sv_out.ensure((size_t)a.sv_cap * sizeof(SvOut)));
-    HIPCHK(c, c->h_lib_index.ensure((size_t)a.term_cap * 4)); HIPCHK(c, c->h_lib_pairs.ensure((size_t)a.term_cap * 4));
-    HIPCHK(c, c->h_cn_key.ensure((size_t)a.cn_cap * 4 + 16)); HIPCHK(c, c->h_cn_value.ensure((size_t)a.cn_cap * 4 + 16));
-    HIPCHK(c, c->h_ltail_dev.ensure((size_t)a.term_cap * 8));
+    if (c->table_in_hbm) {   // (rank 0 of a sharded run merges the ranks' tables: this one goes there from HBM)
+        HIPCHK(c, c->b_sv_out.ensure((size_t)a.sv_cap * sizeof(SvOut))); HIPCHK(c, c->b_sv_key.ensure((size_t)a.sv_cap * 8));
+        HIPCHK(c, c->b_lib_index_out.ensure((size_t)a.term_cap * 4)); HIPCHK(c, c->b_lib_pairs_out.ensure((size_t)a.term_cap * 4));
+        HIPCHK(c, c->b_cn_key_out.ensure((size_t)a.cn_cap * 4 + 16)); HIPCHK(c, c->b_cn_value_out.ensure((size_t)a.cn_cap * 4 + 16));
+        HIPCHK(c, c->b_ltail_out.ensure((size_t)a.term_cap * 8));
+    } else {
+        HIPCHK(c, c->h_sv_out.ensure((size_t)a.sv_cap * sizeof(SvOut)));
+        HIPCHK(c, c->h_lib_index.ensure((size_t)a.term_cap * 4)); HIPCHK(c, c->h_lib_pairs.ensure((size_t)a.term_cap * 4));
+        HIPCHK(c, c->h_cn_key.ensure((size_t)a.cn_cap * 4 + 16)); HIPCHK(c, c->h_cn_value.ensure((size_t)a.cn_cap * 4 + 16));
+        HIPCHK(c, c->h_ltail_dev.ensure((size_t)a.term_cap * 8));
+    }
     HIPCHK(c, c->h_counts2.ensure(sizeof(StageCounts)));
     HIPCHK(c, c->b_sv_src.ensure((size_t)a.sv_cap * 12)); HIPCHK(c, c->b_ltail.ensure((size_t)a.term_cap * 8));
     HIPCHK(c, c->b_dlists.ensure((size_t)a.term_cap * 4 + (size_t)a.cn_cap * 8 + 64));
@@ -1125,7 +1164,8 @@ int do_k6(bdx_ctx* c, bool force_host) {
     a.sv_begin = c->b_sv_src.as<uint2>(); a.sv_src = (uint32_t*)(a.sv_begin + a.sv_cap); a.ltail = c->b_ltail.as<double>();
     a.d_lib_index = c->b_dlists.as<int32_t>(); a.d_cn_key = a.d_lib_index + a.term_cap; a.d_cn_value = (float*)(a.d_cn_key + a.cn_cap);
     a.cap = na;
-    a.r_rec = c->b_r_rec.as<RegionRec>(); a.r_pk = c->b_r_pk.as<uint32_t>();
+    a.r_rec = c->k6_r_rec ? c->k6_r_rec : c->b_r_rec.as<RegionRec>(); a.r_pk = c->k6_r_pk ? c->k6_r_pk : c->b_r_pk.as<uint32_t>();
+    a.taint = c->k6_taint;
     a.region_of = c->k3.region_of; a.partner = c->k4.partner; a.pair_lo = c->k4.pair_lo; a.meta = c->cp.meta; a.isize = c->cp.isize;
     a.in_groups = c->k6_in_groups; a.in_goff = c->k6_in_goff;
     a.parts = c->b_parts.as<PartRec>();
@@ -1136,8 +1176,14 @@ int do_k6(bdx_ctx* c, bool force_host) {
     a.own_nsv = c->b_own.as<uint32_t>(); a.own_nacc = a.own_nsv + cap; a.own_ncn = a.own_nsv + 2 * cap; a.own_first = a.own_nsv + 3 * cap; a.slot_next = a.own_nsv + 4 * cap; a.owners = a.own_nsv + 5 * cap; a.owners_big = a.own_nsv + 6 * cap;
     a.member_ids = big_walk ? c->b_member_ids.as<uint32_t>() : nullptr;
     a.sv_stage = c->b_slot.as<SvOut>(); a.lib_stage = c->b_lib_stage.as<LibStage>(); a.cn_stage = c->b_cn_stage.as<CnStage>();
-    a.sv_out = c->h_sv_out.as<SvOut>(); a.lib_index = c->h_lib_index.as<int32_t>(); a.lib_pairs = c->h_lib_pairs.as<int32_t>();
-    a.cn_key = c->h_cn_key.as<int32_t>(); a.cn_value = c->h_cn_value.as<float>();
+    if (c->table_in_hbm) {
+        a.sv_out = c->b_sv_out.as<SvOut>(); a.lib_index = c->b_lib_index_out.as<int32_t>(); a.lib_pairs = c->b_lib_pairs_out.as<int32_t>();
+        a.cn_key = c->b_cn_key_out.as<int32_t>(); a.cn_value = c->b_cn_value_out.as<float>();
+        a.sv_key = c->b_sv_key.as<unsigned long long>();
+    } else {
+        a.sv_out = c->h_sv_out.as<SvOut>(); a.lib_index = c->h_lib_index.as<int32_t>(); a.lib_pairs = c->h_lib_pairs.as<int32_t>();
+        a.cn_key = c->h_cn_key.as<int32_t>(); a.cn_value = c->h_cn_value.as<float>();
+    }
     a.t_lambda = c->b_t_lambda.as<double>(); a.t_k = c->b_t_k.as<int32_t>();
     a.g_rec = c->k4.g_rec; a.g_cap = c->k4.g_cap;
     {   // look-back words of the table scan: zero once, afterwards every run brings its own stamp
@@ -1177,6 +1223,10 @@ int do_k6(bdx_ctx* c, bool force_host) {
         if (c->k3.host_copy_later) a.flag_regions = c->h_flags.as<uint32_t>() + 3;
         a.mirror_in_walk = force_host ? 0 : 1;  // (k6_walk_kernel follows k6_emit_kernel unless everything goes to the host)
     }
+    if (part == 1) {
+        launch_k6_pairs(a, na, s);
+        return BDX_OK;
+    }
     launch_k6_groups(a, na, s);
     if (!c->poll) {  // the host's share of the groups is complete
         const int rc = signal_ready(c, 1, c->ev_groups);
@@ -1208,8 +1258,8 @@ int presize_stages(bdx_ctx* c, uint32_t na) {
 // the final table is assembled by the device in pinned host memory, in the reference's output order.
 int do_k6_table(bdx_ctx* c) {
     hipStream_t s = c->stream;
-    const uint32_t na = c->na_alloc;
     K6Arrays& a = c->k6;
+    const uint32_t na = a.cap;
     if (!na) return BDX_OK;
     const WalkResult& H = c->walk;
     const uint32_t nh = (uint32_t)H.svs.size(), nt = (uint32_t)H.terms.size(), nc = (uint32_t)H.cn_key.size();
@@ -1243,7 +1293,7 @@ int do_k6_table(bdx_ctx* c) {
         a.hs_rec = c->h_hs_rec.as<SvOut>(); a.hs_key = hkey; a.hs_cnt = hcnt;
         a.hs_lambda = lam; a.hs_lib_index = li; a.hs_lib_pairs = lp; a.hs_cn_key = ck; a.hs_cn_value = cv;
     }
-    a.ltail_host = c->h_ltail_dev.as<double>();  // (K5 runs inside the table kernel)
+    a.ltail_host = c->table_in_hbm ? c->b_ltail_out.as<double>() : c->h_ltail_dev.as<double>();  // (K5 runs inside the table kernel)
     HIPCHK(c, c->h_printed.ensure((size_t)k6_score_grid(a) * 4));
     a.printed_host = c->h_printed.as<uint32_t>();
     // The word the host polls for the end of the run is set by a one-thread kernel behind the table kernel (a kernel boundary
@@ -1301,7 +1351,7 @@ int finish_table(bdx_ctx* c) {
     }
     c->counts.n_old = c2.n_old;
     c->materialized = false;
-    if (c->opts.fisher) {  // Fisher's combination (BreakDancer.cpp:71-81) uses the host's exp / log
+    if (c->opts.fisher && !c->table_in_hbm) {  // Fisher's combination (BreakDancer.cpp:71-81) uses the host's exp / log (sharded: after the merge)
         materialize(c);
         finish_scores(c->opts, c->log_tail.data(), c->walk.svs.data(), c->walk.svs.size(), &c->n_printed);
     }

@@ -5,15 +5,20 @@
 // couples across chromosomes is small: the pass-1 statistics (window, lambda, densities: BamSummary.cpp:129-150,
 // BreakDancerMax.cpp:83-116), the running counters sampled at region boundaries, the read that closes a chromosome's
 // last candidate region (BreakDancer.cpp:202-231), the region numbering / flush cadence (BreakDancer.cpp:254-259), and the
-// inter-chromosomal read pairs (-t, ARP_CTX).  Every rank (one per GPU) runs K1-K4 on its own chromosomes; between the
-// stages the ranks exchange
-//   C1  an all-reduce of the pass-1 counters, per-file reference lengths and per-chromosome totals,
-//   C2  an all-reduce of each chromosome's first anomalous read and C3 of its region count / last read length
-//       (every table entry is owned by exactly one rank, so a sum is a gather),
-//   C4  ONE all-to-all of the CTX join records to owner(name key) (k7_exchange.hip): the only exchange on the data path.
-//       Pairs with both mates on one chromosome never leave their GPU,
-//   C5  a gather of the region tables and pair groups to rank 0, which walks the region graph (build_connection is
-//       inherently ordered: BreakDancer.cpp:266-346) and scores the candidates (K5).
+// inter-chromosomal read pairs (ARP_CTX).  Every rank (one per GPU) holds ALL of its chromosomes in ONE context and runs the
+// single-context launch sequence over them -- K1 ... K6 and the table kernel, one launch each whatever the number of
+// chromosomes --, with per-chromosome tables (k9_shard.hip) carrying what crosses a chromosome boundary.  Region ids are
+// genome-wide on every rank, so flush windows, order keys and the walk itself are the single run's.  Between the stages:
+//   C1  all-reduce: pass-1 counters, per-file reference lengths, per-chromosome totals and owners
+//   C2  all-reduce: each chromosome's first anomalous read;  C3: its region count  (every entry has one owner: a sum is a gather)
+//   C4  all-reduce of the exchange's count matrix, then ONE all-to-all of the CTX join records -- a CTX read whose mate lies on a
+//       later chromosome of another rank goes there and joins that rank's reads (k7_exchange.hip) -- and one of the name census
+//   C5  gather of the ranks' region tables on rank 0 (the result holds the genome's table; runs beside the joins)
+//   C6  all-reduce (payload stays in HBM): taint bytes of the regions that gate-passing groups connect ACROSS ranks, and the read
+//       length of each flush window's last region.  Components inside one rank are walked and scored where they live (K6);
+//       tainted ones go to the host's share
+//   C7  all-reduce: size of every rank's host share;  C8: gather of the host shares on rank 0, which walks them (H1)
+//   C9  gather of the ranks' finished tables (rows sorted by order key) on rank 0, merged by key into the result context
 // Payloads stay in HBM: the collectives run on device buffers through RCCL (ncclAllReduce, ncclAllToAllv, grouped
 // ncclSend / ncclRecv), xGMI between the GPUs of a node.  A second backend runs the ranks as threads of one process
 // (tests on a single GPU; a host program that drives several GPUs itself).
@@ -25,6 +30,8 @@
 #include <mutex>
 
 namespace {
+
+constexpr int kDistPhases = 18;   // bdx_dist_get_phase_ms / bdx_dist_phase_name
 
 // ------------------------------------------------------------------------------------------------------------------
 // communicators
@@ -204,15 +211,19 @@ struct bdx_dist {
     bdx_opts opts{};
     std::vector<bdx_lib> libs;
     std::unique_ptr<Comm> comm;
-    std::map<int, bdx_ctx*> chrom;   // the chromosomes this rank owns
-    bdx_ctx* util = nullptr;         // joins the CTX records this rank owns, and on rank 0 walks and holds the result
-    DevBuf b_words, b_cnt, b_send, b_recv, b_pack, b_all, b_gin;
-    DevBuf b_nsend, b_nrecv, b_ntab, b_ninfo, b_nft, b_nflag;   // the name census (k7_exchange.hip)
+    bdx_ctx* reads = nullptr;        // ALL chromosomes this rank owns, one after the other in ascending order: one launch sequence
+    bdx_ctx* util = nullptr;         // rank 0: holds the result
+    int last_tid = -1;               // bdx_dist_chromosome: the chromosomes must be fed in ascending order
+    size_t n_at_last = 0;
+    bool use_check = false;
+    DevBuf b_words, b_tab, b_send, b_recv, b_pack, b_all, b_nsend, b_nrecv, b_ntab, b_nflag, b_foreign, b_rg_rec, b_rg_pk, b_x, b_merge;
+    PinBuf h_tab;                    // what the small kernels report: per-chromosome tables, counts, ready words
+    uint32_t seq = 0;
     std::string err;
     uint64_t ctx_sent = 0, ctx_received = 0, gathered_bytes = 0;
     float ms_total = 0, ms_exchange = 0;
     bool ran = false;
-    float phase_ms[12] = {0};        // bdx_dist_get_phase_ms: where the last run's time went on this rank
+    float phase_ms[kDistPhases] = {0};   // bdx_dist_get_phase_ms: where the last run's time went on this rank
     bool collect_support = false;    // bdx_dist_set_collect_support: the supporting reads of every SV (-g / -d) come with the result
 };
 
@@ -234,9 +245,8 @@ int dfail(bdx_dist* d, int code, const std::string& msg) {
     } while (0)
 
 // host vector -> device words -> all-reduce -> host vector
-int allreduce_host(bdx_dist* d, std::vector<uint64_t>& v) {
+int allreduce_host(bdx_dist* d, std::vector<uint64_t>& v, hipStream_t s) {
     if (v.empty()) return BDX_OK;
-    hipStream_t s = d->util->stream;
     DHIP(d, d->b_words.ensure(v.size() * 8));
     DHIP(d, hipMemcpyAsync(d->b_words.p, v.data(), v.size() * 8, hipMemcpyHostToDevice, s));
     if (!d->comm->allreduce_u64(d->b_words.as<uint64_t>(), v.size(), s)) return dfail(d, BDX_EHIP, d->comm->err);
@@ -249,7 +259,7 @@ int dist_create_common(bdx_dist** out, const bdx_opts* opts, const bdx_lib* libs
                        std::unique_ptr<Comm> comm) {
     if (!out || !opts || !libs || nlibs < 1 || nbams < 1 || ntids < 1) return BDX_EINVAL;
     if (opts->min_len < 0) return BDX_ELIMIT;  // (a negative -s registers a read-less region 0: single-context runs only)
-    if (comm->world > kMaxRanks) return BDX_ELIMIT;
+    if (comm->world > kMaxRanks || ntids >= (1 << 24) - 1) return BDX_ELIMIT;
     bdx_dist* d = new (std::nothrow) bdx_dist;
     if (!d) return BDX_ENOMEM;
     d->device = device; d->ntids = ntids; d->nlibs = nlibs; d->nbams = nbams; d->w0 = w0;
@@ -257,10 +267,36 @@ int dist_create_common(bdx_dist** out, const bdx_opts* opts, const bdx_lib* libs
     d->libs.assign(libs, libs + nlibs);
     d->nkeys = opts->cn_lib ? nlibs : nbams;
     d->comm = std::move(comm);
-    const int rc = bdx_create(&d->util, opts, libs, nlibs, nbams, ntids, w0, device);
-    if (rc != BDX_OK) { delete d; return rc; }
+    int rc = bdx_create(&d->reads, opts, libs, nlibs, nbams, ntids, w0, device);
+    if (rc == BDX_OK && d->comm->rank == 0) rc = bdx_create(&d->util, opts, libs, nlibs, nbams, ntids, w0, device);
+    if (rc != BDX_OK) { if (d->reads) bdx_destroy(d->reads); delete d; return rc; }
+    d->reads->force_direct_join = true;
     *out = d;
     return BDX_OK;
+}
+
+// pinned report area of a rank: ready words, then the tables the small kernels write
+struct TabLayout {
+    size_t flags = 0, tidtab = 0, first = 0, rtab = 0, cnts = 0, misc = 0, words = 0;
+    TabLayout(int ntids, int ncols, int world) {
+        size_t o = 16;
+        tidtab = o; o += (size_t)(ntids + 1) * (1 + ncols) + 2;
+        first = o; o += (size_t)ntids * 4;
+        rtab = o; o += (size_t)ntids + 3;
+        cnts = o; o += (size_t)2 * world;
+        misc = o; o += 16;
+        words = o;
+    }
+};
+
+// spin on a pinned word a one-thread kernel sets behind the kernels whose results it announces
+bool wait_word(volatile uint32_t* w, uint32_t value) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spin = 0;; ++spin) {
+        if (*w == value) { std::atomic_thread_fence(std::memory_order_acquire); return true; }
+        __builtin_ia32_pause();
+        if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(500)) return false;
+    }
 }
 
 }  // namespace
@@ -308,11 +344,12 @@ int bdx_dist_create_threads(bdx_dist** out, const bdx_opts* opts, const bdx_lib*
 void bdx_dist_destroy(bdx_dist* d) {
     if (!d) return;
     (void)hipSetDevice(d->device);
-    for (auto& kv : d->chrom) bdx_destroy(kv.second);
+    if (d->reads) bdx_destroy(d->reads);
     if (d->util) bdx_destroy(d->util);
-    for (DevBuf* b : {&d->b_words, &d->b_cnt, &d->b_send, &d->b_recv, &d->b_pack, &d->b_all, &d->b_gin, &d->b_nsend, &d->b_nrecv, &d->b_ntab, &d->b_ninfo,
-                      &d->b_nft, &d->b_nflag})
+    for (DevBuf* b : {&d->b_words, &d->b_tab, &d->b_send, &d->b_recv, &d->b_pack, &d->b_all, &d->b_nsend, &d->b_nrecv, &d->b_ntab, &d->b_nflag, &d->b_foreign,
+                      &d->b_rg_rec, &d->b_rg_pk, &d->b_x, &d->b_merge})
         b->release();
+    d->h_tab.release();
     delete d;
 }
 
@@ -320,21 +357,64 @@ const char* bdx_dist_last_error(const bdx_dist* d) { return d ? d->err.c_str() :
 int bdx_dist_rank(const bdx_dist* d) { return d ? d->comm->rank : -1; }
 int bdx_dist_world(const bdx_dist* d) { return d ? d->comm->world : 0; }
 
+// One context per rank takes all of the rank's chromosomes; the handle is the same for every tid.  What the caller must keep to
+// is the order: a rank's chromosomes ascending, each chromosome's records together (the position-sorted stream gives both).
 bdx_ctx* bdx_dist_chromosome(bdx_dist* d, int tid) {
     if (!d || tid < 0 || tid >= d->ntids) return nullptr;
-    auto f = d->chrom.find(tid);
-    if (f != d->chrom.end()) return f->second;
-    bdx_ctx* c = nullptr;
-    if (bdx_create(&c, &d->opts, d->libs.data(), d->nlibs, d->nbams, d->ntids, d->w0, d->device) != BDX_OK) return nullptr;
-    c->groups_in_hbm = true;   // (its pair groups go to rank 0 from HBM)
-    d->chrom[tid] = c;
+    bdx_ctx* c = d->reads;
+    if (tid < d->last_tid && c->n != d->n_at_last) {
+        d->err = "bdx_dist_chromosome: a rank's chromosomes are fed in ascending order";
+        return nullptr;
+    }
+    if (tid != d->last_tid) { d->last_tid = tid; }
+    d->n_at_last = c->n;
     return c;
+}
+
+int bdx_dist_prepare(bdx_dist* d) {
+    if (!d) return BDX_EINVAL;
+    bdx_ctx* c = d->reads;
+    DHIP(d, hipSetDevice(d->device));
+    // the later stages' buffers for the prior a first run goes by (bdx_reserve does the same for a single context), with K6's
+    // per-region arrays sized for the genome's regions rather than this rank's
+    if (c->n >= (1u << 20) && !c->ran) {
+        const uint64_t prior = (uint64_t)c->n / 32 + 4096;
+        if (prior <= kMaxAnomalous) {
+            const uint32_t keep = c->k6_cap;
+            c->k6_cap = (uint32_t)std::min<uint64_t>(prior, kMaxRegions);
+            c->table_in_hbm = d->comm->world > 1;
+            c->groups_in_hbm = d->comm->world > 1;
+            const int rc = presize_stages(c, (uint32_t)prior);
+            c->k6_cap = keep;
+            if (rc != BDX_OK) return dfail(d, rc, c->err);
+            const size_t nr = (size_t)prior;
+            DHIP(d, d->b_rg_rec.ensure(nr * sizeof(RegionRec)));
+            DHIP(d, d->b_rg_pk.ensure(nr * 2 * d->nkeys * 4));
+            DHIP(d, d->b_x.ensure((nr / 8 + nr / 64 + (size_t)d->comm->world + 64) * 8));
+            const size_t nn = (size_t)prior;
+            DHIP(d, d->b_nsend.ensure(nn * 16)); DHIP(d, d->b_nrecv.ensure(nn * 16));
+            uint32_t slots = 1024;
+            while (slots < 2 * nn) slots <<= 1;
+            DHIP(d, d->b_ntab.ensure((size_t)slots * 16));
+            DHIP(d, d->b_pack.ensure(nn * 40)); DHIP(d, d->b_all.ensure(nn * 40));
+        }
+    }
+    return BDX_OK;
 }
 
 int bdx_dist_get_phase_ms(const bdx_dist* d, float* out, int n) {
     if (!d || !out) return BDX_EINVAL;
-    for (int i = 0; i < n; ++i) out[i] = i < 12 ? d->phase_ms[i] : 0.0f;
+    for (int i = 0; i < n; ++i) out[i] = i < kDistPhases ? d->phase_ms[i] : 0.0f;
     return BDX_OK;
+}
+
+const char* bdx_dist_phase_name(int i) {
+    static const char* names[kDistPhases] = {
+        "pass1_and_chromosome_table", "allreduce_statistics", "compaction_and_rebase", "allreduce_first_reads", "region_cut", "allreduce_regions",
+        "globalize_and_exchange_counts", "allreduce_exchange_sizes", "exchange_join_pair_groups", "allreduce_taint_and_windows",
+        "components_walk", "allreduce_host_share", "host_share_and_table", "allreduce_table_sizes", "rank0_only_merge", "replay_route",
+        "rank0_only_host_walk", ""};
+    return i >= 0 && i < kDistPhases ? names[i] : "";
 }
 
 int bdx_dist_set_collect_support(bdx_dist* d, int on) {
@@ -386,13 +466,26 @@ struct RunStatus {
     std::string msg;
 };
 
-static int agreed_failure(bdx_dist* d, const RunStatus& st, const std::vector<uint64_t>& v, size_t at, int world) {
+static int agreed_failure(bdx_dist* d, const RunStatus& st, const uint64_t* words, int world) {
     int first = -1, code = BDX_OK;
     for (int q = 0; q < world; ++q)
-        if (v[at + q]) { first = q; code = (int)v[at + q]; break; }
+        if (words[q]) { first = q; code = (int)words[q]; break; }
     if (first < 0) return BDX_OK;
     if (st.rc != BDX_OK) return dfail(d, st.rc, st.msg);
     return dfail(d, code, "rank " + std::to_string(first) + " failed (" + bdx_strerror(code) + "); all ranks stop");
+}
+
+// the result of a rank's context becomes the result context's: the pinned buffers the device assembled the table in change
+// hands (no copy), the counters are taken over
+static void adopt_table(bdx_ctx* U, bdx_ctx* C) {
+    std::swap(U->h_sv_out, C->h_sv_out); std::swap(U->h_lib_index, C->h_lib_index); std::swap(U->h_lib_pairs, C->h_lib_pairs);
+    std::swap(U->h_cn_key, C->h_cn_key); std::swap(U->h_cn_value, C->h_cn_value); std::swap(U->h_ltail_dev, C->h_ltail_dev);
+    std::swap(U->walk, C->walk); std::swap(U->log_tail, C->log_tail);
+    U->materialized = C->materialized;
+    U->n_sv_total = C->n_sv_total; U->n_terms_total = C->n_terms_total; U->n_cn_total = C->n_cn_total; U->n_printed = C->n_printed;
+    U->n_sv_host = C->n_sv_host; U->n_groups_total = C->n_groups_total;
+    U->counts = C->counts;
+    C->k6 = K6Arrays{};   // (its pointers into the swapped buffers are history)
 }
 
 int bdx_dist_run(bdx_dist* d) {
@@ -401,12 +494,14 @@ int bdx_dist_run(bdx_dist* d) {
     Comm& comm = *d->comm;
     const int world = comm.world, rank = comm.rank;
     const int nlibs = d->nlibs, nbams = d->nbams, nkeys = d->nkeys, ntids = d->ntids;
-    const int ncnt = nlibs * kNumFlags + nlibs + nbams;
+    const int ncnt = nlibs * kNumFlags + nlibs + nbams, ncols = 2 + nkeys, nkeys2 = 2 * nkeys;
     DHIP(d, hipSetDevice(d->device));
+    bdx_ctx* C = d->reads;
     bdx_ctx* U = d->util;
-    hipStream_t us = U->stream;
+    hipStream_t s = C->stream;
     d->ran = false;
     d->ctx_sent = d->ctx_received = d->gathered_bytes = 0;
+    ++d->seq;
     comm.begin_run();
     RunStatus st;
     // a phase: local work between two collectives; its failure is recorded, not returned.  Phases and collectives alternate:
@@ -420,47 +515,107 @@ int bdx_dist_run(bdx_dist* d) {
             const int rc = body();
             if (rc != BDX_OK) { st.rc = rc; st.msg = d->err; }
         }
-        if (2 * n_phase < 12) d->phase_ms[2 * n_phase] += ms_between(tp, std::chrono::steady_clock::now());
+        if (2 * n_phase < kDistPhases) d->phase_ms[2 * n_phase] += ms_between(tp, std::chrono::steady_clock::now());
+    };
+    struct Stamp {
+        bdx_dist* d; int& n; std::chrono::steady_clock::time_point t;
+        ~Stamp() { if (2 * n + 1 < kDistPhases) d->phase_ms[2 * n + 1] += ms_between(t, std::chrono::steady_clock::now()); ++n; }
     };
     // all-reduce of v with the ranks' status words appended; afterwards every rank knows whether anybody failed
     auto exchange = [&](std::vector<uint64_t>& v) -> int {
-        const auto tp = std::chrono::steady_clock::now();
-        struct Stamp { bdx_dist* d; int& n; std::chrono::steady_clock::time_point t; ~Stamp() { if (2 * n + 1 < 12) d->phase_ms[2 * n + 1] += ms_between(t, std::chrono::steady_clock::now()); ++n; } } stamp{d, n_phase, tp};
+        Stamp stamp{d, n_phase, std::chrono::steady_clock::now()};
         const size_t at = v.size();
         v.resize(at + (size_t)world, 0);
         v[at + (size_t)rank] = (uint64_t)st.rc;
-        const int rc = allreduce_host(d, v);
+        const int rc = allreduce_host(d, v, s);
         if (rc != BDX_OK) { comm.abort(); return rc; }
-        const int f = agreed_failure(d, st, v, at, world);
+        const int f = agreed_failure(d, st, &v[at], world);
         v.resize(at);
         return f;
     };
+    // the same for words that live in HBM (`words` of them, `world` more behind them for the status): the payload stays on the device
+    auto exchange_dev = [&](uint64_t* dev, size_t words) -> int {
+        Stamp stamp{d, n_phase, std::chrono::steady_clock::now()};
+        std::vector<uint64_t> tail((size_t)world, 0);
+        tail[(size_t)rank] = (uint64_t)st.rc;
+        bool good = hipMemcpyAsync(dev + words, tail.data(), (size_t)world * 8, hipMemcpyHostToDevice, s) == hipSuccess;
+        good = good && comm.allreduce_u64(dev, words + (size_t)world, s);
+        good = good && hipMemcpyAsync(tail.data(), dev + words, (size_t)world * 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+        if (!good) { comm.abort(); return dfail(d, BDX_EHIP, comm.err.empty() ? "all-reduce of device words" : comm.err); }
+        return agreed_failure(d, st, tail.data(), world);
+    };
     auto leave = [&](int rc) { comm.abort(); return rc; };  // failures past the last foldable point
+    // BDX_DIST_TRACE=1 (a measurement / debugging aid, like BDX_ALLOC_TRACE): waits for the stream at every step and names it on stderr
+    static const bool tracing = getenv("BDX_DIST_TRACE") != nullptr;
+    auto trace = [&](const char* what) {
+        if (!tracing) return;
+        const hipError_t e = hipStreamSynchronize(s);
+        fprintf(stderr, "[bdx dist %d/%d] %s: %s (%.3f ms)\n", rank, world, what, hipGetErrorString(e), ms_between(t_begin, std::chrono::steady_clock::now()));
+    };
 
-    // ---- pass 1 on the own chromosomes; C1: counters, per-file reference lengths, per-chromosome totals ----
-    const size_t tw = 2 + (size_t)nkeys;  // per chromosome: anomalous reads, normal pairs, proper reads per key
-    const size_t at_reads = (size_t)ncnt + nbams + (size_t)ntids * tw;  // then: reads per chromosome; ranks that want the supporting reads
-    std::vector<uint64_t> v1(at_reads + (size_t)ntids + 1, 0);
-    v1[at_reads + (size_t)ntids] = d->collect_support ? 1 : 0;
+    // the report area (pinned) and the small device tables
+    const TabLayout L(ntids, ncols, world);
+    DHIP(d, d->h_tab.ensure(L.words * 4));
+    uint32_t* H = d->h_tab.as<uint32_t>();
+    volatile uint32_t* flags = (volatile uint32_t*)H;
+    // device tables: tid_off [ntids][1 + nkeys] | tid_tail [ntids][4] | roff [ntids] | owner [ntids] | tid_start [ntids + 1] | cnt [4 world] | n_total [4] | rbase u64 [ntids + 1]
+    const size_t o_off = 0, o_tail = o_off + (size_t)ntids * (1 + nkeys), o_roff = o_tail + (size_t)ntids * 4, o_owner = o_roff + ntids,
+                 o_start = o_owner + ntids, o_cnt = o_start + ntids + 1, o_ntot = o_cnt + 4 * (size_t)world, o_rbase = (o_ntot + 4 + 1) / 2 * 2,
+                 tab_words = o_rbase + 2 * ((size_t)ntids + 1);
+    DHIP(d, d->b_tab.ensure(tab_words * 4));
+    uint32_t* T = d->b_tab.as<uint32_t>();
+
+    // ---- pass 1 over all of this rank's chromosomes; where each chromosome starts and what the counters read there.  C1 ----
+    const size_t tw = (size_t)ncols;  // per chromosome: anomalous reads, normal pairs, proper reads per key
+    const size_t at_tot = (size_t)ncnt + nbams, at_reads = at_tot + (size_t)ntids * tw, at_claim = at_reads + ntids, at_owner = at_claim + ntids,
+                 at_flags = at_owner + ntids;
+    std::vector<uint64_t> v1(at_flags + 3, 0);
+    std::vector<uint32_t> tidtab((size_t)(ntids + 1) * (1 + ncols), 0);   // [t][0] first read, [t][1 + c] counters in front of it
     phase([&]() -> int {
-        for (auto& kv : d->chrom) DCTX(d, kv.second, do_pass1(kv.second, 0, false, false));  // all enqueued, then waited for
-        for (auto& kv : d->chrom) {
-            bdx_ctx* c = kv.second;
-            DCTX(d, c, wait_pass1(c));
-            for (int i = 0; i < ncnt; ++i) v1[i] += c->cnt_local[i];
-            for (int b = 0; b < nbams; ++b) v1[ncnt + b] += c->p1.ref_len[b];
-            uint64_t* t = &v1[(size_t)ncnt + nbams + (size_t)kv.first * tw];
-            t[0] = c->p1.n_anom; t[1] = c->p1.n_normal;
-            for (int k = 0; k < nkeys; ++k) t[2 + k] = c->p1.key_tot[k];
-            v1[at_reads + (size_t)kv.first] = c->n;
+        C->table_in_hbm = world > 1;
+        C->groups_in_hbm = world > 1;
+        C->k6_cap = 0; C->k6_r_rec = nullptr; C->k6_r_pk = nullptr; C->k6_taint = nullptr; C->k3_tid_tail = nullptr;
+        DCTX(d, C, do_pass1(C, 0, true, false));
+        TidTableParams tp{};
+        tp.tid = C->d.tid; tp.lib = C->d.lib; tp.cls = C->b_cls.as<uint8_t>(); tp.n = C->n; tp.ntiles = C->ntiles; tp.tstride = C->tstride;
+        tp.ntids = ntids; tp.nkeys = nkeys; tp.nlibs = nlibs; tp.ncols = ncols; tp.libs = C->b_libs.as<DevLib>();
+        tp.tile_tot = C->b_tile_tot.as<uint32_t>(); tp.tile_pre = C->b_tile_pre.as<uint32_t>(); tp.chunk_base = C->fp_deferred.chunk_base;
+        tp.chunk_super = C->fp_deferred.chunk_super; tp.p1 = C->b_p1.as<Pass1>(); tp.out = H + L.tidtab;
+        trace("pass 1");
+        launch_k9_tid_table(tp, s);
+        launch_k9_signal(H + 0, d->seq, s);
+        if (!wait_word(flags + 0, d->seq)) DHIP(d, hipStreamSynchronize(s));
+        trace("chromosome table");
+        memcpy(tidtab.data(), H + L.tidtab, tidtab.size() * 4);
+        const uint32_t* terr = H + L.tidtab + tidtab.size();
+        if (terr[0] || terr[1]) return dfail(d, BDX_EINVAL, "record with a reference id outside [0, ntids)");
+        for (int i = 0; i < ncnt; ++i) v1[i] = C->cnt_local[i];
+        for (int b = 0; b < nbams; ++b) v1[ncnt + b] = C->p1.ref_len[b];
+        for (int t = 0; t < ntids; ++t) {
+            const uint32_t* a = &tidtab[(size_t)t * (1 + ncols)];
+            const uint32_t* b = a + (1 + ncols);
+            const uint64_t nreads = (uint64_t)b[0] - a[0];
+            if (!nreads) continue;
+            for (int c = 0; c < ncols; ++c) v1[at_tot + (size_t)t * tw + c] = (uint32_t)(b[1 + c] - a[1 + c]);
+            v1[at_reads + t] = nreads;
+            v1[at_claim + t] = 1;
+            v1[at_owner + t] = (uint64_t)rank + 1;
         }
-        DCTX(d, U, do_pass1(U));  // (no reads: brings the utility context's buffers up)
+        v1[at_flags] = d->collect_support ? 1 : 0;
+        if (C->n) v1[at_flags + (C->use_check ? 1 : 2)] = 1;
         return BDX_OK;
     });
     int rc = exchange(v1);
     if (rc != BDX_OK) return rc;
-    const uint64_t want_support = v1[at_reads + (size_t)ntids];
+    const uint64_t want_support = v1[at_flags];
     if (want_support != 0 && want_support != (uint64_t)world) return dfail(d, BDX_EINVAL, "bdx_dist_set_collect_support is set on some ranks only");
+    if (v1[at_flags + 1] && v1[at_flags + 2]) return dfail(d, BDX_EINVAL, "bdx_use_name_check is set on some ranks' contexts only");
+    const bool with_check = v1[at_flags + 1] != 0;
+    std::vector<int32_t> owner(ntids, -1);
+    for (int t = 0; t < ntids; ++t) {
+        if (v1[at_claim + t] > 1) return dfail(d, BDX_EINVAL, "chromosome " + std::to_string(t) + " has reads on more than one rank");
+        if (v1[at_claim + t]) owner[t] = (int32_t)v1[at_owner + t] - 1;
+    }
     std::vector<uint64_t> read_base((size_t)ntids + 1, 0);   // a chromosome's first read in the merged stream (position sorted: chromosomes ascending)
     for (int t = 0; t < ntids; ++t) read_base[(size_t)t + 1] = read_base[t] + v1[at_reads + (size_t)t];
     std::vector<uint32_t> cnt_g(ncnt);
@@ -468,135 +623,179 @@ int bdx_dist_run(bdx_dist* d) {
     uint32_t covered = 0;  // BamSummary.cpp:123-126: a uint32 maximum compared against each file's size_t sum
     for (int b = 0; b < nbams; ++b)
         if ((uint64_t)covered < v1[ncnt + b]) covered = (uint32_t)v1[ncnt + b];
-    const int32_t window = window_from(U, cnt_g.data(), covered);
-    auto tot = [&](int tid, int k) { return v1[(size_t)ncnt + nbams + (size_t)tid * tw + k]; };
+    const int32_t window = window_from(C, cnt_g.data(), covered);
+    auto tot = [&](int tid, int k) { return v1[at_tot + (size_t)tid * tw + k]; };
     std::vector<uint64_t> base((size_t)(ntids + 1) * tw, 0);  // exclusive prefix over the chromosomes in stream order
     for (int t = 0; t < ntids; ++t)
         for (size_t k = 0; k < tw; ++k) base[(size_t)(t + 1) * tw + k] = base[(size_t)t * tw + k] + tot(t, (int)k);
+    const uint64_t na_all = base[(size_t)ntids * tw];
     // (the same sum on every rank: all of them return here, together)
-    if (base[(size_t)ntids * tw] > kMaxAnomalous) return dfail(d, BDX_ELIMIT, "more than 2^31 anomalous reads in one run");
+    if (na_all > kMaxAnomalous) return dfail(d, BDX_ELIMIT, "more than 2^31 anomalous reads in one run");
+    int last_anom_tid = -1;
+    for (int t = 0; t < ntids; ++t)
+        if (tot(t, 0) > 0) last_anom_tid = t;
+    const uint32_t na = C->p1.n_anom;   // this rank's
 
-    // ---- compaction with the counters of the chromosomes in front; C2: every chromosome's first anomalous read ----
+    // ---- compaction; the counters of every chromosome start where the chromosomes in front of it (anybody's) left them.
+    // C2: every chromosome's first anomalous read ----
     std::vector<uint64_t> v2((size_t)ntids * 3, 0);
     phase([&]() -> int {
-        for (auto& kv : d->chrom) {
-            bdx_ctx* c = kv.second;
-            DCTX(d, c, set_pass1(c, cnt_g.data(), covered, window, true));
-            std::vector<uint32_t> pkb(nkeys);
-            for (int k = 0; k < nkeys; ++k) pkb[k] = (uint32_t)base[(size_t)kv.first * tw + 2 + k];
-            DCTX(d, c, do_compact(c, (uint32_t)base[(size_t)kv.first * tw + 1], pkb.data(), false));
+        DCTX(d, C, set_pass1(C, cnt_g.data(), covered, window, true));
+        DHIP(d, hipMemcpyAsync(C->b_cnt.p, cnt_g.data(), (size_t)ncnt * 4, hipMemcpyHostToDevice, s));
+        DHIP(d, hipMemcpyAsync(C->b_kdens.p, C->key_density.data(), C->key_density.size() * 4, hipMemcpyHostToDevice, s));
+        DCTX(d, C, do_compact(C, 0, nullptr, true));
+        trace("compaction");
+        if (!na) { C->k4 = K4Arrays{}; return BDX_OK; }
+        std::vector<uint32_t> up((size_t)ntids * (1 + nkeys) + ntids + 1, 0);
+        for (int t = 0; t < ntids; ++t) {
+            const uint32_t* a = &tidtab[(size_t)t * (1 + ncols)];
+            for (int k = 0; k < 1 + nkeys; ++k) up[(size_t)t * (1 + nkeys) + k] = (uint32_t)base[(size_t)t * tw + 1 + k] - a[1 + 1 + k];
         }
-        for (auto& kv : d->chrom) {
-            bdx_ctx* c = kv.second;
-            if (!c->p1.n_anom) continue;
-            uint32_t meta = 0, nn = 0;
-            DHIP(d, hipMemcpyAsync(&meta, c->cp.meta, 4, hipMemcpyDeviceToHost, c->stream));
-            DHIP(d, hipMemcpyAsync(&nn, c->cp.nn, 4, hipMemcpyDeviceToHost, c->stream));
-            DHIP(d, hipStreamSynchronize(c->stream));
-            uint64_t* t = &v2[(size_t)kv.first * 3];
-            t[0] = 1 | (c->use_check ? 2 : 0); t[1] = (uint64_t)meta_qlen(meta); t[2] = nn;
+        DHIP(d, hipMemcpyAsync(T + o_off, up.data(), (size_t)ntids * (1 + nkeys) * 4, hipMemcpyHostToDevice, s));
+        memset(H + L.first, 0, (size_t)ntids * 16);
+        launch_k9_rebase(C->cp, &C->b_p1.as<Pass1>()->n_anom, na, nkeys, T + o_off, H + L.first, s);
+        launch_k9_signal(H + 1, d->seq, s);
+        if (!wait_word(flags + 1, d->seq)) DHIP(d, hipStreamSynchronize(s));
+        DHIP(d, hipStreamSynchronize(s));   // (`up` goes out of use)
+        trace("rebase");
+        for (int t = 0; t < ntids; ++t) {
+            const uint32_t* f = H + L.first + (size_t)t * 4;
+            if (f[0]) { v2[(size_t)t * 3] = 1; v2[(size_t)t * 3 + 1] = f[1]; v2[(size_t)t * 3 + 2] = f[2]; }
         }
         return BDX_OK;
     });
     rc = exchange(v2);
     if (rc != BDX_OK) return rc;
-    // (every chromosome has one owner, so the sums are the owners' words) the second name hash: on all chromosomes or on none
-    bool with_check = false, without_check = false;
-    for (int t = 0; t < ntids; ++t) {
-        if (v2[(size_t)t * 3] & 2) with_check = true;
-        else if (v2[(size_t)t * 3] & 1) without_check = true;
-    }
-    if (with_check && without_check) return dfail(d, BDX_EINVAL, "bdx_use_name_check is set on some chromosomes' contexts only");
 
-    // ---- regions; the first anomalous read of the next chromosome closes a chromosome's last candidate.  C3 ----
-    std::vector<int> next_anom(ntids, -1);
-    for (int t = ntids - 1, nx = -1; t >= 0; --t) {
-        next_anom[t] = nx;
-        if (tot(t, 0) > 0) nx = t;
-    }
-    std::vector<uint64_t> v3((size_t)ntids * 2, 0);
-    uint32_t* d_cnt = nullptr;      // [world] records per destination
-    uint32_t* d_cur = nullptr;      // [world] scatter cursors
-    uint32_t *d_ncnt = nullptr, *d_ncur = nullptr;
-    std::vector<uint32_t> h_cnt(world, 0), h_ncnt(world, 0);
+    // ---- regions; the first anomalous read of the next chromosome that has one closes a chromosome's last candidate.  C3 ----
+    std::vector<uint64_t> v3((size_t)ntids + 1, 0);
+    std::vector<uint32_t> rtab((size_t)ntids + 3, 0);   // this rank's regions: first region of every chromosome, count, last_maxq
     phase([&]() -> int {
-        for (auto& kv : d->chrom) {
-            bdx_ctx* c = kv.second;
-            const int nx = next_anom[kv.first];
-            if (nx >= 0) DCTX(d, c, do_cut(c, 1, (int32_t)v2[(size_t)nx * 3 + 1], (uint32_t)v2[(size_t)nx * 3 + 2], false, true));
-            else DCTX(d, c, do_cut(c, 0, 0, 0, false, true));
+        if (!na) return BDX_OK;
+        std::vector<uint32_t> tails((size_t)ntids * 4, 0);
+        {
+            int nx = -1;
+            for (int t = ntids - 1; t >= 0; --t) {
+                uint32_t* q = &tails[(size_t)t * 4];
+                q[0] = nx >= 0 ? 1u : 0u;
+                q[1] = nx >= 0 ? (uint32_t)v2[(size_t)nx * 3 + 1] : 0u;
+                q[2] = nx >= 0 ? (uint32_t)v2[(size_t)nx * 3 + 2] : (uint32_t)base[(size_t)ntids * tw + 1];
+                if (v2[(size_t)t * 3]) nx = t;
+            }
         }
-        for (auto& kv : d->chrom) {
-            bdx_ctx* c = kv.second;
-            DCTX(d, c, readback(c, false));
-            v3[(size_t)kv.first * 2] = c->counts.n_regions;
-            v3[(size_t)kv.first * 2 + 1] = (uint32_t)c->counts.last_maxq;
-        }
-        // ---- joins: pairs within a chromosome where they are; CTX records to owner(name key) ----
-        DHIP(d, d->b_cnt.ensure((size_t)world * 16 + 64));
-        d_cnt = d->b_cnt.as<uint32_t>();
-        d_cur = d_cnt + world;
-        d_ncnt = d_cnt + 2 * world;    // the name census: every anomalous read's key
-        d_ncur = d_cnt + 3 * world;
-        DHIP(d, hipMemsetAsync(d_cnt, 0, (size_t)world * 16, us));
-        DHIP(d, hipStreamSynchronize(us));
-        // (the chromosomes' streams are independent: the counts are complete once each has been waited for, below)
-        for (auto& kv : d->chrom) {
-            bdx_ctx* c = kv.second;
-            const uint32_t na = c->p1.n_anom;
-            if (na) launch_k7_count(c->cp.key, c->cp.meta, &c->b_p1.as<Pass1>()->n_anom, na, (uint32_t)world, d_cnt, c->stream);
-            if (na) launch_k7_names_count(c->cp.key, &c->b_p1.as<Pass1>()->n_anom, na, (uint32_t)world, d_ncnt, c->stream);
-        }
-        for (auto& kv : d->chrom) DHIP(d, hipStreamSynchronize(kv.second->stream));
-        DHIP(d, hipMemcpy(h_cnt.data(), d_cnt, (size_t)world * 4, hipMemcpyDeviceToHost));
-        DHIP(d, hipMemcpy(h_ncnt.data(), d_ncnt, (size_t)world * 4, hipMemcpyDeviceToHost));
+        DHIP(d, hipMemcpyAsync(T + o_tail, tails.data(), tails.size() * 4, hipMemcpyHostToDevice, s));
+        C->k3_tid_tail = T + o_tail;
+        DCTX(d, C, do_cut(C, 0, 0, 0, false, true));
+        trace("region cut");
+        launch_k9_tid_regions(C->b_r_rec.as<RegionRec>(), C->b_counts.as<StageCounts>(), ntids, H + L.rtab, s);
+        launch_k9_signal(H + 2, d->seq, s);
+        if (!wait_word(flags + 2, d->seq)) DHIP(d, hipStreamSynchronize(s));
+        DHIP(d, hipStreamSynchronize(s));   // (`tails` goes out of use)
+        memcpy(rtab.data(), H + L.rtab, rtab.size() * 4);
+        for (int t = 0; t < ntids; ++t) v3[t] = rtab[t + 1] - rtab[t];
+        if (last_anom_tid >= 0 && owner[last_anom_tid] == rank) v3[ntids] = rtab[ntids + 2];
         return BDX_OK;
     });
     rc = exchange(v3);
     if (rc != BDX_OK) return rc;
     std::vector<uint64_t> rbase(ntids + 1, 0);
-    for (int t = 0; t < ntids; ++t) rbase[t + 1] = rbase[t] + v3[(size_t)t * 2];
+    for (int t = 0; t < ntids; ++t) rbase[t + 1] = rbase[t] + v3[t];
     const uint64_t NR = rbase[ntids];
     if (NR > kMaxRegions) return dfail(d, BDX_ELIMIT, "too many regions for the packed group key");  // (all ranks alike)
-    int last_anom_tid = -1;
+    const int32_t lm = (int32_t)(uint32_t)v3[ntids];
+    const uint32_t nr_local = rtab[ntids + 1];
+    std::vector<uint64_t> nr_of_rank(world, 0);
     for (int t = 0; t < ntids; ++t)
-        if (tot(t, 0) > 0) last_anom_tid = t;
+        if (owner[t] >= 0) nr_of_rank[owner[t]] += v3[t];
+    const uint32_t period = (uint32_t)std::max(1, d->opts.buffer_size + 1);
+    const uint32_t NW = (uint32_t)(NR / period);
+    const uint32_t capG = (uint32_t)std::max<uint64_t>(std::max<uint64_t>(C->na_alloc, NR), 1);
+
+    // the result context takes the run's statistics; with no region anywhere the run is over
+    auto finish_result = [&]() -> int {
+        d->ran = true;
+        d->ms_total = ms_between(t_begin, std::chrono::steady_clock::now());
+        return BDX_OK;
+    };
+    if (rank == 0) {
+        DCTX(d, U, set_pass1(U, cnt_g.data(), covered, window, false));
+        U->n = 0;
+        U->p1 = Pass1{};
+        U->p1.n_anom = (uint32_t)na_all; U->p1.covered_ref_len = covered; U->p1.window = window;
+        U->replayed = false;
+        U->sup_off.clear(); U->sup_idx.clear(); U->sup_flag.clear();
+        U->collect_support = false;
+        if (!U->walk_scratch) U->walk_scratch = walk_scratch_new();
+    }
 
     const auto t_x0 = std::chrono::steady_clock::now();
-    // Everything a rank can do before it knows what the others send happens in front of the count exchange, so that its
-    // failure still travels with it: the send buffer (sized by the rank's own counts), the chromosomes' own joins, the
-    // packing of the CTX records per destination.
+    // ---- genome-wide region ids; the exchange's counts ----
+    std::vector<uint32_t> h_cnt(world, 0), h_ncnt(world, 0);
     std::vector<size_t> scount(world), sdispl(world), rcount(world), rdispl(world);
     std::vector<size_t> nscount(world), nsdispl(world), nrcount(world), nrdispl(world);   // the name census: two words per read
     size_t nsend = 0, nrecv = 0, nnsend = 0, nnrecv = 0;
     constexpr size_t kxw = sizeof(ExchangeEntry) / 8;
-    for (int q = 0; q < world; ++q) { scount[q] = (size_t)h_cnt[q] * kxw; sdispl[q] = nsend * kxw; nsend += h_cnt[q]; }
-    for (int q = 0; q < world; ++q) { nscount[q] = (size_t)h_ncnt[q] * 2; nsdispl[q] = nnsend * 2; nnsend += h_ncnt[q]; }
+    uint64_t* X = nullptr;          // [NW] window read lengths | taint bytes (capG) | status words
+    const size_t x_taint = NW, x_words = (size_t)NW + ((size_t)capG + 7) / 8;
+    RegionRec* regs = nullptr;      // rank 0: the genome's region table (pinned: the copy runs beside the joins)
+    uint32_t* pk = nullptr;
+    bool regs_pending = false;
+    ExchangeSrc xs{};
     phase([&]() -> int {
+        if (!NR) return BDX_OK;
+        DHIP(d, d->b_rg_rec.ensure((size_t)NR * sizeof(RegionRec)));
+        DHIP(d, d->b_rg_pk.ensure(std::max<size_t>((size_t)NR * nkeys2 * 4, 16)));
+        DHIP(d, C->b_out_deg.ensure((size_t)capG * 6 * 4));
+        DHIP(d, d->b_x.ensure((x_words + (size_t)world + 8) * 8));
+        X = d->b_x.as<uint64_t>();
+        DHIP(d, hipMemsetAsync(d->b_rg_rec.p, 0, (size_t)NR * sizeof(RegionRec), s));
+        DHIP(d, hipMemsetAsync(X, 0, (x_words + (size_t)world) * 8, s));
+        {
+            std::vector<uint32_t> up((size_t)2 * ntids + ntids + 1, 0);
+            for (int t = 0; t < ntids; ++t) {
+                up[t] = (uint32_t)rbase[t] - rtab[t];            // roff
+                up[(size_t)ntids + t] = (uint32_t)owner[t];      // owner (int32)
+                up[(size_t)2 * ntids + t] = tidtab[(size_t)t * (1 + ncols)];   // first read of the chromosome in this context
+            }
+            up[(size_t)3 * ntids] = tidtab[(size_t)ntids * (1 + ncols)];
+            DHIP(d, hipMemcpyAsync(T + o_roff, up.data(), up.size() * 4, hipMemcpyHostToDevice, s));
+            DHIP(d, hipMemsetAsync(T + o_cnt, 0, (size_t)world * 16 + 16, s));
+            DHIP(d, hipStreamSynchronize(s));
+        }
+        GlobalizeParams gp{};
+        gp.tid = C->cp.tid; gp.region_of = C->k3.region_of; gp.n_ptr = &C->b_p1.as<Pass1>()->n_anom;
+        gp.r_rec = C->b_r_rec.as<RegionRec>(); gp.r_pk = C->b_r_pk.as<uint32_t>(); gp.nr_local = nr_local; gp.roff = T + o_roff;
+        gp.rg_rec = d->b_rg_rec.as<RegionRec>(); gp.rg_pk = d->b_rg_pk.as<uint32_t>(); gp.nkeys2 = nkeys2;
+        gp.scratch = C->b_out_deg.as<uint32_t>(); gp.cap = capG; gp.counts = C->b_counts.as<StageCounts>(); gp.nr_global = (uint32_t)NR; gp.last_maxq = lm;
+        launch_k9_globalize(gp, na, s);
+        trace("globalize");
+        launch_k9_window_collect(d->b_rg_rec.as<RegionRec>(), (uint32_t)NR, period, (unsigned long long*)X, s);
+        C->k6_cap = (uint32_t)NR; C->k6_r_rec = d->b_rg_rec.as<RegionRec>(); C->k6_r_pk = d->b_rg_pk.as<uint32_t>();
+        C->k6_taint = world > 1 ? (uint8_t*)(X + x_taint) : nullptr;
+        if (na) {
+            xs.key = C->cp.key; xs.check = C->cp.check; xs.meta = C->cp.meta; xs.tid = C->cp.tid; xs.idx = C->cp.idx; xs.mtid_col = C->d.mtid;
+            xs.region_of = C->k3.region_of; xs.n_ptr = &C->b_p1.as<Pass1>()->n_anom; xs.owner_of_tid = (const int32_t*)(T + o_owner);
+            xs.ntids = ntids; xs.me = rank; xs.world = (uint32_t)world;
+            launch_k7_count(xs, na, T + o_cnt, s);
+        }
+        trace("exchange counts");
+        DHIP(d, hipMemcpyAsync(H + L.cnts, T + o_cnt, (size_t)world * 8, hipMemcpyDeviceToHost, s));
+        DHIP(d, hipStreamSynchronize(s));
+        for (int q = 0; q < world; ++q) { h_cnt[q] = H[L.cnts + q]; h_ncnt[q] = H[L.cnts + world + q]; }
+        for (int q = 0; q < world; ++q) { scount[q] = (size_t)h_cnt[q] * kxw; sdispl[q] = nsend * kxw; nsend += h_cnt[q]; }
+        for (int q = 0; q < world; ++q) { nscount[q] = (size_t)h_ncnt[q] * 2; nsdispl[q] = nnsend * 2; nnsend += h_ncnt[q]; }
+        // Everything a rank can do before it knows what the others send happens in front of the count exchange, so that its
+        // failure still travels with it: the send buffers (sized by the rank's own counts) and the packing per destination
         DHIP(d, d->b_send.ensure(std::max<size_t>(nsend, 1) * sizeof(ExchangeEntry)));
         DHIP(d, d->b_nsend.ensure(std::max<size_t>(nnsend, 1) * 16));
-        {
-            std::vector<uint32_t> cur(world);
-            for (int q = 0; q < world; ++q) cur[q] = (uint32_t)(sdispl[q] / kxw);
-            DHIP(d, hipMemcpy(d_cur, cur.data(), (size_t)world * 4, hipMemcpyHostToDevice));
-            for (int q = 0; q < world; ++q) cur[q] = (uint32_t)(nsdispl[q] / 2);
-            DHIP(d, hipMemcpy(d_ncur, cur.data(), (size_t)world * 4, hipMemcpyHostToDevice));
+        if (na) {
+            std::vector<uint32_t> cur(2 * (size_t)world);
+            for (int q = 0; q < world; ++q) { cur[q] = (uint32_t)(sdispl[q] / kxw); cur[(size_t)world + q] = (uint32_t)(nsdispl[q] / 2); }
+            DHIP(d, hipMemcpyAsync(T + o_cnt + 2 * (size_t)world, cur.data(), cur.size() * 4, hipMemcpyHostToDevice, s));
+            launch_k7_scatter(xs, na, T + o_cnt + 2 * (size_t)world, d->b_send.as<ExchangeEntry>(), d->b_nsend.as<unsigned long long>(), s);
+            DHIP(d, hipStreamSynchronize(s));
         }
-        for (auto& kv : d->chrom) {
-            bdx_ctx* c = kv.second;
-            const uint32_t na = c->p1.n_anom;
-            if (!na) continue;
-            // the chromosome's own pairs: K4 on its compact reads, pair groups with genome-wide region ids
-            Entries en{};
-            en.key = c->cp.key; en.check = c->cp.check; en.region = c->k3.region_of; en.meta = c->cp.meta; en.isize = c->cp.isize;
-            en.region_base = (int32_t)rbase[kv.first];
-            DCTX(d, c, do_join_local(c, na, en, &c->b_p1.as<Pass1>()->n_anom, false));
-            launch_k7_scatter(c->cp.key, c->cp.check, c->k3.region_of, c->cp.meta, c->cp.isize, &c->b_p1.as<Pass1>()->n_anom, na, (uint32_t)world,
-                              (uint32_t)base[(size_t)kv.first * tw], (int32_t)rbase[kv.first], d_cur, d->b_send.as<ExchangeEntry>(), c->stream);
-            launch_k7_names_scatter(c->cp.key, c->cp.check, c->cp.meta, &c->b_p1.as<Pass1>()->n_anom, na, (uint32_t)world, (uint32_t)kv.first, d_ncur,
-                                    d->b_nsend.as<unsigned long long>(), c->stream);
-        }
-        for (auto& kv : d->chrom) DHIP(d, hipStreamSynchronize(kv.second->stream));
+        trace("scatter");
         return BDX_OK;
     });
     std::vector<uint64_t> v4((size_t)world * world * 2, 0);  // send-count matrices (CTX records, census records): row = sender
@@ -604,125 +803,167 @@ int bdx_dist_run(bdx_dist* d) {
     for (int q = 0; q < world; ++q) { v4[(size_t)rank * world + q] = h_cnt[q]; v4[W2 + (size_t)rank * world + q] = h_ncnt[q]; }
     rc = exchange(v4);
     if (rc != BDX_OK) return rc;
+    if (!NR) {   // no region anywhere: an empty table
+        if (rank == 0) {
+            U->regions.clear(); U->r_pk.clear(); U->reg = nullptr; U->nreg = 0; U->rpk = nullptr;
+            U->walk.clear(); U->log_tail.clear();
+            U->n_sv_total = U->n_terms_total = U->n_cn_total = U->n_printed = U->n_sv_host = U->n_groups_total = 0;
+            memset(&U->counts, 0, sizeof(U->counts));
+            U->materialized = true; U->ran = true; U->stage = 4;
+        }
+        return finish_result();
+    }
     for (int q = 0; q < world; ++q) { rcount[q] = (size_t)v4[(size_t)q * world + rank] * kxw; rdispl[q] = nrecv * kxw; nrecv += v4[(size_t)q * world + rank]; }
     for (int q = 0; q < world; ++q) { nrcount[q] = (size_t)v4[W2 + (size_t)q * world + rank] * 2; nrdispl[q] = nnrecv * 2; nnrecv += v4[W2 + (size_t)q * world + rank]; }
-    if (nnrecv > 0x7FFFFFFFull) return dfail(d, BDX_ELIMIT, "too many anomalous reads' names on one rank");
     {
-        // (the column sums are the same table on every rank: the limit trips everywhere at once)
+        // (the column sums are the same table on every rank: the limits trip everywhere at once)
         for (int r = 0; r < world; ++r) {
-            uint64_t col = 0;
-            for (int q = 0; q < world; ++q) col += v4[(size_t)q * world + r];
-            if (col > kMaxAnomalous) return dfail(d, BDX_ELIMIT, "too many inter-chromosomal join records on one rank");
+            uint64_t col = 0, ncol = 0;
+            for (int q = 0; q < world; ++q) { col += v4[(size_t)q * world + r]; ncol += v4[W2 + (size_t)q * world + r]; }
+            if (col > (1u << 28) || ncol > 0x7FFFFFFFull) return dfail(d, BDX_ELIMIT, "too many inter-chromosomal join records / names on one rank");
         }
     }
     if (d->b_recv.ensure(std::max<size_t>(nrecv, 1) * sizeof(ExchangeEntry)) != hipSuccess)
         return leave(dfail(d, BDX_ENOMEM, "receive buffer of the all-to-all"));
-    // C4: the all-to-all of the CTX records (three 64-bit words each)
-    if (!comm.alltoallv_u64(d->b_send.as<uint64_t>(), scount.data(), sdispl.data(), d->b_recv.as<uint64_t>(), rcount.data(), rdispl.data(), us))
+    // C4: the all-to-all of the CTX records (four 64-bit words each), then the census records
+    if (!comm.alltoallv_u64(d->b_send.as<uint64_t>(), scount.data(), sdispl.data(), d->b_recv.as<uint64_t>(), rcount.data(), rdispl.data(), s))
         return leave(dfail(d, BDX_EHIP, comm.err));
     if (d->b_nrecv.ensure(std::max<size_t>(nnrecv, 1) * 16) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "receive buffer of the name census"));
-    if (!comm.alltoallv_u64(d->b_nsend.as<uint64_t>(), nscount.data(), nsdispl.data(), d->b_nrecv.as<uint64_t>(), nrcount.data(), nrdispl.data(), us))
+    if (!comm.alltoallv_u64(d->b_nsend.as<uint64_t>(), nscount.data(), nsdispl.data(), d->b_nrecv.as<uint64_t>(), nrcount.data(), nrdispl.data(), s))
         return leave(dfail(d, BDX_EHIP, comm.err));
     d->ctx_sent = nsend; d->ctx_received = nrecv;
-    // join what arrived
-    uint32_t ng_ctx = 0;
+
+    // ---- the genome's region table on rank 0 (C5: a gather of the ranks' dense tables; with one rank it is there already) ----
+    size_t region_bytes = 0;
+    {
+        std::vector<size_t> gcount(world), gdispl(world);
+        const size_t rrec = sizeof(RegionRec), rpk = (size_t)nkeys2 * 4;
+        for (int q = 0; q < world; ++q) { gcount[q] = round_up((size_t)nr_of_rank[q] * (rrec + rpk), 8); gdispl[q] = region_bytes; region_bytes += gcount[q]; }
+        if (world > 1) {
+            const size_t mine = gcount[rank];
+            if (d->b_pack.ensure(std::max<size_t>(mine, 8)) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "region package"));
+            if (nr_local) {
+                if (hipMemcpyAsync(d->b_pack.p, C->b_r_rec.p, (size_t)nr_local * rrec, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+                    hipMemcpyAsync((char*)d->b_pack.p + (size_t)nr_local * rrec, C->b_r_pk.p, (size_t)nr_local * rpk, hipMemcpyDeviceToDevice, s) != hipSuccess)
+                    return leave(dfail(d, BDX_EHIP, "region package"));
+            }
+            if ((uint64_t)nr_local != nr_of_rank[rank]) return leave(dfail(d, BDX_EINTERNAL, "region counts of the chromosomes do not add up"));
+            if (rank == 0 && d->b_all.ensure(std::max<size_t>(region_bytes, 8)) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "gather buffer"));
+            if (!comm.gatherv_bytes(d->b_pack.p, mine, d->b_all.p, gcount.data(), gdispl.data(), 0, s)) return leave(dfail(d, BDX_EHIP, comm.err));
+            d->gathered_bytes += region_bytes;
+        }
+        if (rank == 0) {
+            if (C->h_regs.ensure((size_t)NR * rrec) != hipSuccess || C->h_pk.ensure(std::max<size_t>((size_t)NR * rpk, 16)) != hipSuccess)
+                return leave(dfail(d, BDX_ENOMEM, "region table"));
+            regs = C->h_regs.as<RegionRec>();
+            pk = C->h_pk.as<uint32_t>();
+            const RegionRec* src_rec = d->b_rg_rec.as<RegionRec>();
+            const uint32_t* src_pk = d->b_rg_pk.as<uint32_t>();
+            if (world > 1) {
+                GatherDesc D{};
+                D.world = world;
+                uint32_t max_nr = 0;
+                for (int q = 0; q < world; ++q) {
+                    const size_t nr = (size_t)nr_of_rank[q];
+                    D.p[q] = GatherPackage{gdispl[q], gdispl[q] + nr * rrec, 0, (uint32_t)nr, 0};
+                    max_nr = std::max(max_nr, (uint32_t)nr);
+                }
+                if (U->b_r_rec.ensure((size_t)NR * rrec) != hipSuccess || U->b_r_pk.ensure(std::max<size_t>((size_t)NR * rpk, 16)) != hipSuccess)
+                    return leave(dfail(d, BDX_ENOMEM, "region table"));
+                if (hipMemcpyAsync(T + o_rbase, rbase.data(), ((size_t)ntids + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess) return leave(dfail(d, BDX_EHIP, "region table"));
+                launch_k8_place_regions((const char*)d->b_all.p, D, max_nr, (const uint64_t*)(T + o_rbase), ntids, nkeys2, U->b_r_rec.as<RegionRec>(), U->b_r_pk.as<uint32_t>(),
+                                        T + o_ntot + 1, s);
+                src_rec = U->b_r_rec.as<RegionRec>(); src_pk = U->b_r_pk.as<uint32_t>();
+            }
+            // (on the context's second stream, behind what has been enqueued so far: the joins and the pair groups do not wait for it)
+            if (hipEventRecord(C->ev_copy, s) != hipSuccess || hipStreamWaitEvent(C->copy_stream, C->ev_copy, 0) != hipSuccess ||
+                hipMemcpyAsync(regs, src_rec, (size_t)NR * rrec, hipMemcpyDeviceToHost, C->copy_stream) != hipSuccess ||
+                (nkeys2 && hipMemcpyAsync(pk, src_pk, (size_t)NR * rpk, hipMemcpyDeviceToHost, C->copy_stream) != hipSuccess))
+                return leave(dfail(d, BDX_EHIP, "region table"));
+            regs_pending = true;
+        }
+    }
+
+    // ---- the joins (own reads + foreign entries), the name census, the pair groups per region.  C6: taint bytes, window lengths ----
+    const bool force_host = (rank == 0 ? U->host_walk_only : false) || C->host_walk_only || d->opts.min_read_pair < 1;
     auto t_x1 = std::chrono::steady_clock::now();
-    size_t nreg_mine = 0, ng_mine = 0, pack_bytes = 0;
-    uint64_t irregular = 0;
-    const size_t rrec = sizeof(RegionRec), rpk = (size_t)2 * nkeys * 4, grec = sizeof(GroupRec);
     phase([&]() -> int {
         if (nnrecv) {   // the census of the names this rank owns
             uint32_t slots = 1024;
             while (slots < 2 * nnrecv) slots <<= 1;
-            DHIP(d, d->b_ntab.ensure((size_t)slots * 8)); DHIP(d, d->b_ninfo.ensure((size_t)slots * 8)); DHIP(d, d->b_nft.ensure((size_t)slots * 4));
+            DHIP(d, d->b_ntab.ensure((size_t)slots * 16));
             DHIP(d, d->b_nflag.ensure(16));
-            DHIP(d, hipMemsetAsync(d->b_ntab.p, 0xFF, (size_t)slots * 8, us));
-            DHIP(d, hipMemsetAsync(d->b_ninfo.p, 0, (size_t)slots * 8, us));
-            DHIP(d, hipMemsetAsync(d->b_nft.p, 0xFF, (size_t)slots * 4, us));
-            DHIP(d, hipMemsetAsync(d->b_nflag.p, 0, 4, us));
-            launch_k7_names_census(d->b_nrecv.as<unsigned long long>(), (uint32_t)nnrecv, d->b_ntab.as<unsigned long long>(), d->b_ninfo.as<unsigned long long>(),
-                                   d->b_nft.as<uint32_t>(), slots - 1, d->b_nflag.as<uint32_t>(), us);
-            uint32_t flag = 0;
-            DHIP(d, hipMemcpyAsync(&flag, d->b_nflag.p, 4, hipMemcpyDeviceToHost, us));
-            DHIP(d, hipStreamSynchronize(us));
-            if (flag) irregular = 1;
+            launch_k7_names_clear(d->b_ntab.as<unsigned long long>(), slots, d->b_nflag.as<uint32_t>(), s);
+            launch_k7_names_census(d->b_nrecv.as<unsigned long long>(), (uint32_t)nnrecv, d->b_ntab.as<unsigned long long>(), slots - 1, d->b_nflag.as<uint32_t>(), s);
         }
-        if (nrecv) {
-            const uint32_t n32 = (uint32_t)nrecv;
-            DHIP(d, U->b_x_key.ensure(nrecv * 8)); DHIP(d, U->b_x_order.ensure(nrecv * 4)); DHIP(d, U->b_x_region.ensure(nrecv * 4));
-            DHIP(d, U->b_x_meta.ensure(nrecv * 4)); DHIP(d, U->b_x_isize.ensure(nrecv * 4)); DHIP(d, U->b_x_n.ensure(16));
-            if (with_check) DHIP(d, U->b_x_check.ensure(nrecv * 8));
-            launch_k7_unpack(d->b_recv.as<ExchangeEntry>(), n32, U->b_x_key.as<uint64_t>(), with_check ? U->b_x_check.as<uint64_t>() : nullptr,
-                             U->b_x_order.as<uint32_t>(), U->b_x_region.as<int32_t>(), U->b_x_meta.as<uint32_t>(), U->b_x_isize.as<int32_t>(), us);
-            DHIP(d, hipMemcpyAsync(U->b_x_n.p, &n32, 4, hipMemcpyHostToDevice, us));
-            DHIP(d, hipMemsetAsync(U->b_counts.p, 0, sizeof(StageCounts), us));
+        trace("census");
+        if (na) {
+            if ((uint64_t)C->na_alloc + nrecv > (1u << 28)) return dfail(d, BDX_ELIMIT, "too many join entries on one rank");
+            const uint32_t nf = (uint32_t)nrecv;
+            DHIP(d, d->b_foreign.ensure(std::max<size_t>(nf, 1) * 20 + 64));
+            uint64_t* fkey = d->b_foreign.as<uint64_t>();
+            uint64_t* fcheck = fkey + std::max<size_t>(nf, 1);
+            int32_t* fregion = (int32_t*)(fcheck + std::max<size_t>(nf, 1));
+            launch_k7_unpack(d->b_recv.as<ExchangeEntry>(), nf, fkey, with_check ? fcheck : nullptr, fregion, &C->b_p1.as<Pass1>()->n_anom, T + o_ntot, s);
             Entries en{};
-            en.key = U->b_x_key.as<uint64_t>(); en.region = U->b_x_region.as<int32_t>(); en.order = U->b_x_order.as<uint32_t>();
-            en.check = with_check ? U->b_x_check.as<uint64_t>() : nullptr;
-            en.meta = U->b_x_meta.as<uint32_t>(); en.isize = U->b_x_isize.as<int32_t>();
-            U->groups_in_hbm = true;    // (packaged for rank 0 from HBM like the chromosomes' own)
-            const int jrc = do_join_local(U, n32, en, U->b_x_n.as<uint32_t>(), false);
-            U->groups_in_hbm = false;   // (rank 0's walk reads K6's groups on the host)
-            if (jrc != BDX_OK) return dfail(d, jrc, "do_join_local: " + U->err);
-            DHIP(d, hipMemcpyAsync(U->h_counts.p, U->b_counts.p, sizeof(StageCounts), hipMemcpyDeviceToHost, us));
-            DHIP(d, hipStreamSynchronize(us));
-            const StageCounts sc = *U->h_counts.as<StageCounts>();
-            if (sc.irregular) irregular = 1;   // a read name seen more than twice: the run is replayed read by read on rank 0 (below)
-            if (sc.overflow) return dfail(d, BDX_EINTERNAL, "group list overflow");
-            ng_ctx = sc.n_groups;
+            en.key = C->cp.key; en.check = C->cp.check; en.region = C->k3.region_of; en.meta = C->cp.meta; en.isize = C->cp.isize;
+            en.n_local = &C->b_p1.as<Pass1>()->n_anom; en.fkey = fkey; en.fcheck = fcheck; en.fregion = fregion; en.want_pair_lo = 1;
+            DCTX(d, C, do_join_local(C, C->na_alloc + nf, en, T + o_ntot, true));
         }
+        trace("join");
         t_x1 = std::chrono::steady_clock::now();
-
-        // ---- C5: region tables and pair groups to rank 0 ----
-        // this rank's package: per owned chromosome (ascending) its region records and prefix samples, then all pair groups
-        ng_mine = ng_ctx;
-        for (auto& kv : d->chrom) {
-            bdx_ctx* c = kv.second;
-            if (!c->p1.n_anom) continue;
-            DCTX(d, c, readback(c, true));
-            if (c->counts.irregular) irregular = 1;
-            nreg_mine += c->counts.n_regions;
-            ng_mine += c->counts.n_groups;
-        }
-        pack_bytes = round_up(nreg_mine * (rrec + rpk) + ng_mine * grec, 8);
-        DHIP(d, d->b_pack.ensure(std::max<size_t>(pack_bytes, 8)));
-        char* p = (char*)d->b_pack.p;
-        for (auto& kv : d->chrom) {  // records of all own chromosomes, then their prefix samples, then the groups
-            bdx_ctx* c = kv.second;
-            const size_t nr = c->p1.n_anom ? c->counts.n_regions : 0;
-            if (nr) DHIP(d, hipMemcpyAsync(p, c->b_r_rec.p, nr * rrec, hipMemcpyDeviceToDevice, us));
-            p += nr * rrec;
-        }
-        for (auto& kv : d->chrom) {
-            bdx_ctx* c = kv.second;
-            const size_t nr = c->p1.n_anom ? c->counts.n_regions : 0;
-            if (nr) DHIP(d, hipMemcpyAsync(p, c->b_r_pk.p, nr * rpk, hipMemcpyDeviceToDevice, us));
-            p += nr * rpk;
-        }
-        for (auto& kv : d->chrom) {
-            bdx_ctx* c = kv.second;
-            const size_t ng = c->p1.n_anom ? c->counts.n_groups : 0;
-            if (ng) DHIP(d, hipMemcpyAsync(p, c->k4.g_rec, ng * grec, hipMemcpyDefault, us));
-            p += ng * grec;
-        }
-        if (ng_ctx) DHIP(d, hipMemcpyAsync(p, U->k4.g_rec, (size_t)ng_ctx * grec, hipMemcpyDefault, us));
+        DCTX(d, C, do_k6(C, force_host, 1));
+        trace("pair groups");
         return BDX_OK;
     });
-    std::vector<uint64_t> v5((size_t)world * 3 + 1, 0);
-    if (st.rc == BDX_OK) { v5[(size_t)rank * 3] = nreg_mine; v5[(size_t)rank * 3 + 1] = ng_mine; v5[(size_t)rank * 3 + 2] = pack_bytes; }
-    v5[(size_t)world * 3] = irregular;
+    if (world > 1) {
+        rc = exchange_dev(X, x_words);
+        if (rc != BDX_OK) return rc;
+    } else {
+        ++n_phase;
+    }
+    d->ms_exchange = ms_between(t_x0, t_x1);
+
+    // ---- components, the device's share of the walk; the host's share (pair groups of the components that are large, or span
+    // ranks) goes to rank 0.  C7: its size per rank, and whether a name misbehaved ----
+    uint64_t irregular = 0;
+    phase([&]() -> int {
+        if (world > 1) launch_k9_window_apply(d->b_rg_rec.as<RegionRec>(), (uint32_t)NR, period, (const unsigned long long*)X, s);
+        DCTX(d, C, do_k6(C, force_host, 2));
+        trace("components and walk");
+        if (!wait_flag(C, 1, C->seq)) {
+            if (C->poll) DHIP(d, hipStreamSynchronize(s)); else DHIP(d, hipEventSynchronize(C->ev_groups));
+        }
+        C->counts = *C->h_counts.as<StageCounts>();
+        if (C->counts.irregular) irregular = 1;   // a read name seen more than twice: the run is replayed read by read on rank 0 (below)
+        if (C->counts.overflow) return dfail(d, BDX_EINTERNAL, "group list overflow");
+        if (nnrecv) {
+            uint32_t flag = 0;
+            DHIP(d, hipMemcpy(&flag, d->b_nflag.p, 4, hipMemcpyDeviceToHost));
+            if (flag) irregular = 1;
+        }
+        return BDX_OK;
+    });
+    std::vector<uint64_t> v5((size_t)world + 1, 0);
+    if (st.rc == BDX_OK) v5[(size_t)rank] = C->counts.n_groups;
+    v5[(size_t)world] = irregular;
     rc = exchange(v5);
     if (rc != BDX_OK) return rc;
     // some rank met a read name more than twice -- or the caller wants the reads behind every SV, which only the read-level walk knows
-    const bool replay = v5[(size_t)world * 3] != 0 || want_support != 0;
-    std::vector<size_t> gcount(world), gdispl(world);
-    size_t all_bytes = 0, ng_all = 0;
-    for (int q = 0; q < world; ++q) { gcount[q] = (size_t)v5[(size_t)q * 3 + 2]; gdispl[q] = all_bytes; all_bytes += gcount[q]; ng_all += v5[(size_t)q * 3 + 1]; }
-    if (rank == 0 && d->b_all.ensure(std::max<size_t>(all_bytes, 8)) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "gather buffer"));
-    if (!comm.gatherv_bytes(d->b_pack.p, pack_bytes, d->b_all.p, gcount.data(), gdispl.data(), 0, us)) return leave(dfail(d, BDX_EHIP, comm.err));
-    DHIP(d, hipStreamSynchronize(us));
-    d->gathered_bytes = all_bytes;
-    d->ms_exchange = ms_between(t_x0, t_x1);
+    const bool replay = v5[(size_t)world] != 0 || want_support != 0;
+
+    auto wait_regions = [&]() -> int {
+        if (regs_pending) {
+            DHIP(d, hipStreamSynchronize(C->copy_stream));
+            regs_pending = false;
+            if (world > 1) {
+                uint32_t perr = 0;
+                DHIP(d, hipMemcpy(&perr, T + o_ntot + 1, 4, hipMemcpyDeviceToHost));
+                if (perr) return dfail(d, BDX_EINTERNAL, "region table of the gather does not add up");
+            }
+        }
+        return BDX_OK;
+    };
 
     // ---- a read name seen more than twice (clashing names across merged files): the pair model does not hold, and the reference's
     // behaviour (ReadRegionData.cpp:108-113,152-175, SvBuilder.cpp:101-118) depends on the order of ALL sightings.  Every rank sends
@@ -730,124 +971,27 @@ int bdx_dist_run(bdx_dist* d) {
     // chromosome's stream: 40 bytes per anomalous read) to rank 0, which replays the run read by read (H2, bdx_walk_reads.cpp) on the
     // gathered region table.  The same route serves bdx_dist_set_collect_support: the supporting reads of an SV (-g / -d dumps,
     // BreakDancer.cpp:514-534) are known to the read-level walk only ----
-    std::vector<uint64_t> rp_host;   // rank 0: all ranks' records
-    std::vector<size_t> rp_count(world), rp_displ(world);
     if (replay) {
-        std::vector<uint64_t> mine_rec;
-        phase([&]() -> int {
-            for (auto& kv : d->chrom) {
-                bdx_ctx* c = kv.second;
-                const uint32_t na = c->p1.n_anom;
-                if (!na) continue;
-                std::vector<uint64_t> key(na), chk(na, 0);
-                std::vector<int32_t> reg(na), isz(na);
-                std::vector<uint32_t> meta(na), ridx(na);
-                DHIP(d, hipStreamSynchronize(c->stream));
-                DHIP(d, hipMemcpy(ridx.data(), c->cp.idx, (size_t)na * 4, hipMemcpyDeviceToHost));
-                DHIP(d, hipMemcpy(key.data(), c->cp.key, (size_t)na * 8, hipMemcpyDeviceToHost));
-                if (c->cp.check) DHIP(d, hipMemcpy(chk.data(), c->cp.check, (size_t)na * 8, hipMemcpyDeviceToHost));
-                DHIP(d, hipMemcpy(reg.data(), c->k3.region_of, (size_t)na * 4, hipMemcpyDeviceToHost));
-                DHIP(d, hipMemcpy(meta.data(), c->cp.meta, (size_t)na * 4, hipMemcpyDeviceToHost));
-                DHIP(d, hipMemcpy(isz.data(), c->cp.isize, (size_t)na * 4, hipMemcpyDeviceToHost));
-                const uint64_t rb = rbase[kv.first];
-                for (uint32_t j = 0; j < na; ++j) {
-                    const uint32_t g = reg[j] < 0 ? 0xFFFFFFFFu : (uint32_t)(reg[j] + (int64_t)rb);
-                    mine_rec.push_back(key[j]);
-                    mine_rec.push_back((uint64_t)g | ((uint64_t)meta[j] << 32));
-                    mine_rec.push_back((uint64_t)(uint32_t)isz[j] | ((uint64_t)(uint32_t)kv.first << 32));
-                    mine_rec.push_back(chk[j]);
-                    mine_rec.push_back(ridx[j]);
-                }
-            }
-            DHIP(d, d->b_pack.ensure(std::max<size_t>(mine_rec.size() * 8, 8)));
-            if (!mine_rec.empty()) DHIP(d, hipMemcpyAsync(d->b_pack.p, mine_rec.data(), mine_rec.size() * 8, hipMemcpyHostToDevice, us));
-            DHIP(d, hipStreamSynchronize(us));
-            return BDX_OK;
-        });
-        std::vector<uint64_t> v6(world, 0);
-        if (st.rc == BDX_OK) v6[rank] = mine_rec.size() * 8;
-        rc = exchange(v6);
-        if (rc != BDX_OK) return rc;
+        const auto t_r0 = std::chrono::steady_clock::now();
+        constexpr size_t kw = 5;
+        std::vector<size_t> rp_count(world), rp_displ(world);
         size_t rp_bytes = 0;
-        for (int q = 0; q < world; ++q) { rp_count[q] = (size_t)v6[q]; rp_displ[q] = rp_bytes; rp_bytes += rp_count[q]; }
-        // (rank 0's region package is still in b_all: copy it out before the buffer takes the records)
-        std::vector<char> keep_regions;
-        if (rank == 0 && all_bytes) {
-            keep_regions.resize(all_bytes);
-            if (hipMemcpy(keep_regions.data(), d->b_all.p, all_bytes, hipMemcpyDeviceToHost) != hipSuccess) return leave(dfail(d, BDX_EHIP, "gather buffer"));
-        }
-        if (rank == 0 && d->b_all.ensure(std::max<size_t>(std::max(rp_bytes, all_bytes), 8)) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "gather buffer"));
-        if (!comm.gatherv_bytes(d->b_pack.p, mine_rec.size() * 8, d->b_all.p, rp_count.data(), rp_displ.data(), 0, us)) return leave(dfail(d, BDX_EHIP, comm.err));
-        DHIP(d, hipStreamSynchronize(us));
+        std::vector<uint64_t> na_of_rank(world, 0);
+        for (int t = 0; t < ntids; ++t)
+            if (owner[t] >= 0) na_of_rank[owner[t]] += tot(t, 0);
+        for (int q = 0; q < world; ++q) { rp_count[q] = (size_t)na_of_rank[q] * kw * 8; rp_displ[q] = rp_bytes; rp_bytes += rp_count[q]; }
+        DHIP(d, hipStreamSynchronize(s));   // (K6's kernels were enqueued on the pair model: let them finish, their results are dropped)
+        if (d->b_pack.ensure(std::max<size_t>(rp_count[rank], 8)) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "record package"));
+        if (na) launch_k9_pack_replay(C->cp, C->k3.region_of, &C->b_p1.as<Pass1>()->n_anom, na, T + o_start, d->b_pack.as<unsigned long long>(), s);
+        if (rank == 0 && d->b_all.ensure(std::max<size_t>(rp_bytes, 8)) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "gather buffer"));
+        if (rank == 0) { const int wr = wait_regions(); if (wr != BDX_OK) return leave(wr); }   // (the region package sat in b_all)
+        if (!comm.gatherv_bytes(d->b_pack.p, rp_count[rank], d->b_all.p, rp_count.data(), rp_displ.data(), 0, s)) return leave(dfail(d, BDX_EHIP, comm.err));
+        DHIP(d, hipStreamSynchronize(s));
         d->gathered_bytes += rp_bytes;
         if (rank == 0) {
-            rp_host.resize(rp_bytes / 8);
+            std::vector<uint64_t> rp_host(rp_bytes / 8);
             if (rp_bytes) DHIP(d, hipMemcpy(rp_host.data(), d->b_all.p, rp_bytes, hipMemcpyDeviceToHost));
-            if (all_bytes) DHIP(d, hipMemcpy(d->b_all.p, keep_regions.data(), all_bytes, hipMemcpyHostToDevice));   // (read back below as usual)
-        }
-    }
-
-    // (from here on nothing is collective any more: rank 0 finishes on its own)
-    if (rank == 0) {
-        // The packages sit in HBM (b_all): the region table is assembled there -- every record to rbase[tid] + its rank among its
-        // chromosome's records (k8_place_regions) -- and, unless the run is replayed, gets K6's slot space by a scan; the host takes
-        // ONE copy of the finished table (the getters and the host's share of the walk read it).
-        const uint64_t na_all = base[(size_t)ntids * tw];
-        const int nkeys2 = 2 * nkeys;
-        GatherDesc D{};
-        D.world = world;
-        uint32_t max_nr = 0, max_ng = 0;
-        size_t nr_sum = 0;
-        for (int q = 0; q < world; ++q) {
-            const size_t nr = (size_t)v5[(size_t)q * 3], ng = (size_t)v5[(size_t)q * 3 + 1];
-            D.p[q] = GatherPackage{gdispl[q], gdispl[q] + nr * rrec, gdispl[q] + nr * (rrec + rpk), (uint32_t)nr, (uint32_t)ng};
-            max_nr = std::max(max_nr, (uint32_t)nr); max_ng = std::max(max_ng, (uint32_t)ng);
-            nr_sum += nr;
-        }
-        if (nr_sum != NR) return dfail(d, BDX_EINTERNAL, "region table of the gather does not add up");
-        std::vector<RegionRec> regs(NR);
-        std::vector<uint32_t> pk((size_t)NR * nkeys2);
-        // scratch of the assembly, behind the bucketed groups: rbase[ntids + 1] | goff[NR + 2] | cnt[NR + 1] | scan ws | {n, err, slots}
-        const size_t cap_alloc = (size_t)std::max<uint64_t>(std::max<uint64_t>(na_all, NR), 1);
-        const size_t g_bytes = round_up(std::max<size_t>(ng_all, 1) * sizeof(GroupRec), 8);
-        const size_t ws_words = scan_grid((uint32_t)std::max<uint64_t>(NR, 1)) + 2;
-        DHIP(d, d->b_gin.ensure(g_bytes + ((size_t)ntids + 1) * 8 + ((size_t)NR + 2 + (size_t)NR + 1 + ws_words + 4) * 4));
-        GroupRec* d_groups = d->b_gin.as<GroupRec>();
-        uint64_t* d_rbase = (uint64_t*)((char*)d->b_gin.p + g_bytes);
-        uint32_t* d_goff = (uint32_t*)(d_rbase + ntids + 1);
-        uint32_t* d_gcnt = d_goff + NR + 2;
-        uint32_t* d_ws = d_gcnt + NR + 1;
-        uint32_t* d_misc = d_ws + ws_words;   // [0] number of regions, [1] error flag, [2] slots
-        uint32_t misc[4] = {(uint32_t)NR, 0, 0, 0};
-        if (NR) {
-            DHIP(d, U->b_r_rec.ensure(cap_alloc * sizeof(RegionRec))); DHIP(d, U->b_r_pk.ensure(cap_alloc * nkeys2 * 4));
-            DHIP(d, hipMemcpyAsync(d_rbase, rbase.data(), ((size_t)ntids + 1) * 8, hipMemcpyHostToDevice, us));
-            DHIP(d, hipMemcpyAsync(d_misc, misc, 16, hipMemcpyHostToDevice, us));
-            DHIP(d, hipMemsetAsync(d_gcnt, 0, ((size_t)NR + 1) * 4, us));
-            launch_k8_place_regions((const char*)d->b_all.p, D, max_nr, d_rbase, ntids, nkeys2, U->b_r_rec.as<RegionRec>(), U->b_r_pk.as<uint32_t>(),
-                                    d_misc + 1, us);
-            if (!replay) launch_k8_slot_space(U->b_r_rec.as<RegionRec>(), (uint32_t)NR, d_misc, d_misc + 2, d_ws, us);
-            DHIP(d, hipMemcpyAsync(regs.data(), U->b_r_rec.p, NR * sizeof(RegionRec), hipMemcpyDeviceToHost, us));
-            DHIP(d, hipMemcpyAsync(pk.data(), U->b_r_pk.p, pk.size() * 4, hipMemcpyDeviceToHost, us));
-            DHIP(d, hipMemcpyAsync(misc, d_misc, 16, hipMemcpyDeviceToHost, us));
-            DHIP(d, hipStreamSynchronize(us));
-            if (misc[1]) return dfail(d, BDX_EINTERNAL, "region table of the gather does not add up");
-        }
-        auto groups_to_host = [&](std::vector<GroupRec>& groups) -> int {   // the packages' pair groups as they came (the host-only walk)
-            groups.resize(ng_all);
-            size_t gi = 0;
-            for (int q = 0; q < world; ++q) {
-                if (D.p[q].ng) DHIP(d, hipMemcpy(&groups[gi], (const char*)d->b_all.p + D.p[q].groups_off, (size_t)D.p[q].ng * grec, hipMemcpyDeviceToHost));
-                gi += D.p[q].ng;
-            }
-            return BDX_OK;
-        };
-        DCTX(d, U, set_pass1(U, cnt_g.data(), covered, window, true));
-        U->n = 0;
-        const int32_t lm = last_anom_tid >= 0 ? (int32_t)(uint32_t)v3[(size_t)last_anom_tid * 2 + 1] : 0;
-        if (replay) {
             // the records of all chromosomes in stream order: chromosomes ascending, each rank's package holds its own in order
-            constexpr size_t kw = 5;
             if (rp_host.size() != (size_t)na_all * kw) return dfail(d, BDX_EINTERNAL, "compact records of the gather do not add up");
             std::vector<uint64_t> key(na_all), chk(with_check ? na_all : 0);
             std::vector<int32_t> reg(na_all), isz(na_all);
@@ -864,9 +1008,15 @@ int bdx_dist_run(bdx_dist* d) {
                 if (with_check) chk[o] = rp_host[i * kw + 3];
                 if (want_support) sidx[o] = read_base[t] + rp_host[i * kw + 4];
             }
-            // (a region's first read: its index in its chromosome's list -> in the genome-wide one)
-            for (size_t r = 0; r < NR; ++r) regs[r].first += (uint32_t)base[(size_t)regs[r].tid * tw];
-            decode_regions(U, regs.data(), pk.data(), (uint32_t)NR, 0, false);
+            // (a region's first read: its index in its rank's list -> in the genome-wide one)
+            {
+                std::vector<uint64_t> seen(world, 0), adj(ntids, 0);
+                for (int t = 0; t < ntids; ++t)
+                    if (owner[t] >= 0) { adj[t] = base[(size_t)t * tw] - seen[owner[t]]; seen[owner[t]] += tot(t, 0); }
+                decode_regions(U, regs, pk, (uint32_t)NR, 0, false);
+                for (size_t r = 0; r < NR; ++r) U->regions[r].first += (uint32_t)adj[U->regions[r].tid];
+            }
+            memset(&U->counts, 0, sizeof(U->counts));
             U->counts.n_regions = (uint32_t)NR;
             U->counts.last_maxq = lm;
             if (with_check) unify_names(key.data(), chk.data(), (size_t)na_all);
@@ -879,67 +1029,163 @@ int bdx_dist_run(bdx_dist* d) {
                 for (size_t i = 0; i < sup.size(); ++i) { U->sup_idx[i] = sidx[sup[i]]; U->sup_flag[i] = (uint8_t)meta_flag(meta[sup[i]]); }
             }
             U->p1.n_anom = (uint32_t)na_all;
-            d->ran = true;
-            d->ms_total = ms_between(t_begin, std::chrono::steady_clock::now());
-            return BDX_OK;
         }
-        const bool host_only = U->host_walk_only;  // (bdx_set_host_walk on the result context's owner: the whole walk on the host)
-        // slot space of K6: region r owns the slots [first, first + n) -- its reads' places in a single-context run; here
-        // simply the regions laid end to end (every group owns at least one read of its later region, so they suffice)
-        const uint64_t slots = misc[2];   // (k8_slot_space: regs[r].first = the slots of the regions before r)
-        if (host_only || NR == 0 || ng_all == 0 || slots > kMaxAnomalous) {
-            std::vector<GroupRec> groups;
-            if (const int gr = groups_to_host(groups)) return gr;
-            decode_regions(U, regs.data(), pk.data(), (uint32_t)NR, 0, false);
-            decode_groups(U, groups.data(), (uint32_t)ng_all, 0);
-            U->counts.n_regions = (uint32_t)NR;
-            DCTX(d, U, host_walk(U, lm, last_anom_tid >= 0));
-            DCTX(d, U, score_host_terms(U));
-            DCTX(d, U, finish_host_walk(U));
-        } else {
-            // the device walk of a single-context run (K6), fed with the gathered groups bucketed by their later region: a histogram, a
-            // scan and a scatter over the packages where they lie (k8_bucket_groups)
-            const uint32_t cap = (uint32_t)slots;
-            launch_k8_bucket_groups((const char*)d->b_all.p, D, max_ng, (uint32_t)NR, d_misc, d_gcnt, d_goff, d_groups, d_ws, d_misc + 1, us);
-            DHIP(d, U->b_out_deg.ensure((size_t)cap * 6 * 4));
-            DHIP(d, hipMemcpyAsync(U->b_cnt.p, cnt_g.data(), (size_t)ncnt * 4, hipMemcpyHostToDevice, us));
-            DHIP(d, hipMemcpyAsync(U->b_kdens.p, U->key_density.data(), U->key_density.size() * 4, hipMemcpyHostToDevice, us));
-            StageCounts sc{};
-            sc.n_regions = (uint32_t)NR; sc.last_maxq = lm;
-            DHIP(d, hipMemcpyAsync(U->b_counts.p, &sc, sizeof(sc), hipMemcpyHostToDevice, us));
-            DHIP(d, hipMemcpyAsync(misc, d_misc, 16, hipMemcpyDeviceToHost, us));
-            DHIP(d, hipStreamSynchronize(us));  // (host vectors above go out of use)
-            if (misc[1]) return dfail(d, BDX_EINTERNAL, "pair groups of the gather name regions that do not exist");
-            launch_k6_scratch_init(U->b_out_deg.as<uint32_t>(), cap, us);
-            U->na_alloc = cap;
-            U->k3 = K3Arrays{}; U->k4 = K4Arrays{}; U->cp = Compact{};
-            U->k4.g_cap = (uint32_t)ng_all + 1;
-            DHIP(d, U->h_groups.ensure((size_t)U->k4.g_cap * sizeof(GroupRec)));
-            U->k4.g_rec = U->h_groups.as<GroupRec>();
-            U->k6_in_groups = d_groups; U->k6_in_goff = d_goff;
-            U->counts.last_maxq = lm;
-            const bool force_host = U->host_walk_only || U->opts.min_read_pair < 1;
-            int rk = do_k6(U, force_host);
-            U->k6_in_groups = nullptr; U->k6_in_goff = nullptr;
-            if (rk != BDX_OK) return dfail(d, rk, "do_k6: " + U->err);
-            decode_regions(U, regs.data(), pk.data(), (uint32_t)NR, 0, false);
-            if (!wait_flag(U, 1, U->seq)) {
-                if (U->poll) DHIP(d, hipStreamSynchronize(us)); else DHIP(d, hipEventSynchronize(U->ev_groups));
-            }
-            U->counts = *U->h_counts.as<StageCounts>();
-            if (U->counts.overflow) return dfail(d, BDX_EINTERNAL, "group list overflow");
-            decode_groups(U, U->h_groups.as<GroupRec>(), U->counts.n_groups, 0);
-            DCTX(d, U, host_walk(U, lm, true));
-            DCTX(d, U, do_k6_table(U));
-            DCTX(d, U, finish_table(U));
-        }
-        U->p1.n_anom = (uint32_t)base[(size_t)ntids * tw];
-    } else {
-        DCTX(d, U, set_pass1(U, cnt_g.data(), covered, window, true));
+        d->phase_ms[15] = ms_between(t_r0, std::chrono::steady_clock::now());
+        return finish_result();
     }
-    d->ran = true;
-    d->ms_total = ms_between(t_begin, std::chrono::steady_clock::now());
-    return BDX_OK;
+
+    // ---- C8: the host's share -> rank 0; every rank finishes its own table ----
+    std::vector<size_t> hcount(world), hdispl(world);
+    size_t hbytes = 0, ng_all = 0;
+    for (int q = 0; q < world; ++q) { hcount[q] = (size_t)v5[q] * sizeof(GroupRec); hdispl[q] = hbytes; hbytes += hcount[q]; ng_all += (size_t)v5[q]; }
+    std::vector<GroupRec> host_groups;
+    if (world > 1) {
+        const void* mine = C->k4.g_rec ? (const void*)C->k4.g_rec : d->b_pack.p;
+        if (rank == 0) { const int wr = wait_regions(); if (wr != BDX_OK) return leave(wr); }   // (the region package sat in b_all)
+        if (rank == 0 && d->b_all.ensure(std::max<size_t>(hbytes, 8)) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "gather buffer"));
+        if (!comm.gatherv_bytes(mine, hcount[rank], d->b_all.p, hcount.data(), hdispl.data(), 0, s)) return leave(dfail(d, BDX_EHIP, comm.err));
+        d->gathered_bytes += hbytes;
+        if (rank == 0 && ng_all) {
+            host_groups.resize(ng_all);
+            if (hipMemcpyAsync(host_groups.data(), d->b_all.p, hbytes, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+                return leave(dfail(d, BDX_EHIP, "host share of the pair groups"));
+        }
+    }
+    uint64_t mine_counts[8] = {0};
+    phase([&]() -> int {
+        C->walk.clear();
+        if (rank == 0) {
+            const int wr = wait_regions();
+            if (wr != BDX_OK) return wr;
+            decode_regions(C, regs, pk, (uint32_t)NR, 0, false);
+            const GroupRec* g = world > 1 ? host_groups.data() : C->h_groups.as<GroupRec>();
+            decode_groups(C, g, (uint32_t)ng_all, 0);
+            C->last_big_groups = (int64_t)ng_all + C->counts.n_groups_big;
+            const auto tw0 = std::chrono::steady_clock::now();
+            DCTX(d, C, host_walk(C, lm, na_all != 0));
+            d->phase_ms[16] = ms_between(tw0, std::chrono::steady_clock::now());
+        }
+        C->counts.last_maxq = lm;
+        trace("host walk");
+        DCTX(d, C, do_k6_table(C));
+        DCTX(d, C, finish_table(C));
+        trace("table");
+        mine_counts[0] = C->n_sv_total; mine_counts[1] = C->n_terms_total; mine_counts[2] = C->n_cn_total; mine_counts[3] = C->n_printed;
+        mine_counts[4] = C->n_sv_host; mine_counts[5] = C->counts.n_pairs; mine_counts[6] = C->n_groups_total; mine_counts[7] = C->counts.n_old;
+        return BDX_OK;
+    });
+    if (world == 1) {
+        adopt_table(U, C);
+        std::swap(U->regions, C->regions); std::swap(U->r_pk, C->r_pk);
+        U->reg = U->regions.data(); U->nreg = U->regions.size(); U->rpk = U->r_pk.data();
+        C->reg = nullptr; C->nreg = 0; C->rpk = nullptr;
+        U->counts.n_regions = (uint32_t)NR;
+        U->ran = true; U->stage = 4;
+        d->phase_ms[14] = 0;
+        return finish_result();
+    }
+    std::vector<uint64_t> v6((size_t)world * 8, 0);
+    if (st.rc == BDX_OK)
+        for (int k = 0; k < 8; ++k) v6[(size_t)rank * 8 + k] = mine_counts[k];
+    rc = exchange(v6);
+    if (rc != BDX_OK) return rc;
+
+    // ---- C9: the ranks' tables -> rank 0, which merges them by order key into the result context's pinned buffers ----
+    const auto t_m0 = std::chrono::steady_clock::now();
+    TableDesc TD{};
+    TD.world = world;
+    std::vector<size_t> tcount(world), tdispl(world);
+    size_t tbytes = 0;
+    uint64_t n_sv_all = 0, n_terms_all = 0, n_cn_all = 0, n_printed_all = 0, n_pairs_all = 0, n_groups_all = 0, n_old_all = 0;
+    uint32_t max_sv = 0;
+    for (int q = 0; q < world; ++q) {
+        const size_t nsv = (size_t)v6[(size_t)q * 8], nt = (size_t)v6[(size_t)q * 8 + 1], nc = (size_t)v6[(size_t)q * 8 + 2];
+        size_t o = tbytes;
+        TablePackage& P = TD.p[q];
+        P.n_sv = (uint32_t)nsv; P.n_terms = (uint32_t)nt; P.n_cn = (uint32_t)nc;
+        P.rows_off = o; o += round_up(nsv * sizeof(SvOut), 8);
+        P.keys_off = o; o += nsv * 8;
+        P.lib_index_off = o; o += round_up(nt * 4, 8);
+        P.lib_pairs_off = o; o += round_up(nt * 4, 8);
+        P.ltail_off = o; o += nt * 8;
+        P.cn_key_off = o; o += round_up(nc * 4, 8);
+        P.cn_value_off = o; o += round_up(nc * 4, 8);
+        tdispl[q] = tbytes; tcount[q] = o - tbytes; tbytes = o;
+        n_sv_all += nsv; n_terms_all += nt; n_cn_all += nc; n_printed_all += v6[(size_t)q * 8 + 3];
+        n_pairs_all += v6[(size_t)q * 8 + 5]; n_groups_all += v6[(size_t)q * 8 + 6]; n_old_all += v6[(size_t)q * 8 + 7];
+        max_sv = std::max(max_sv, (uint32_t)nsv);
+    }
+    if (max_sv >= (1u << 26) || n_sv_all > 0xFFFFFFF0ull) return dfail(d, BDX_ELIMIT, "too many SV candidates for the merge");
+    {
+        const TablePackage& P = TD.p[rank];
+        if (d->b_pack.ensure(std::max<size_t>(tcount[rank], 8)) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "table package"));
+        char* pp = (char*)d->b_pack.p - tdispl[rank];
+        bool good = true;
+        auto put = [&](size_t off, const void* src, size_t bytes) { if (bytes && good) good = hipMemcpyAsync(pp + off, src, bytes, hipMemcpyDeviceToDevice, s) == hipSuccess; };
+        put(P.rows_off, C->b_sv_out.p, (size_t)P.n_sv * sizeof(SvOut)); put(P.keys_off, C->b_sv_key.p, (size_t)P.n_sv * 8);
+        put(P.lib_index_off, C->b_lib_index_out.p, (size_t)P.n_terms * 4); put(P.lib_pairs_off, C->b_lib_pairs_out.p, (size_t)P.n_terms * 4);
+        put(P.ltail_off, C->b_ltail_out.p, (size_t)P.n_terms * 8);
+        put(P.cn_key_off, C->b_cn_key_out.p, (size_t)P.n_cn * 4); put(P.cn_value_off, C->b_cn_value_out.p, (size_t)P.n_cn * 4);
+        if (!good) return leave(dfail(d, BDX_EHIP, "table package"));
+        trace("table packed");
+        if (rank == 0 && d->b_all.ensure(std::max<size_t>(tbytes, 8)) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "gather buffer"));
+        if (!comm.gatherv_bytes(d->b_pack.p, tcount[rank], d->b_all.p, tcount.data(), tdispl.data(), 0, s)) return leave(dfail(d, BDX_EHIP, comm.err));
+        d->gathered_bytes += tbytes;
+        trace("tables gathered");
+    }
+    if (rank == 0) {
+        const uint32_t n_total = (uint32_t)n_sv_all;
+        DHIP(d, U->h_sv_out.ensure(std::max<size_t>(n_total, 1) * sizeof(SvOut)));
+        DHIP(d, U->h_lib_index.ensure(std::max<size_t>(n_terms_all, 1) * 4)); DHIP(d, U->h_lib_pairs.ensure(std::max<size_t>(n_terms_all, 1) * 4));
+        DHIP(d, U->h_ltail_dev.ensure(std::max<size_t>(n_terms_all, 1) * 8));
+        DHIP(d, U->h_cn_key.ensure(std::max<size_t>(n_cn_all, 1) * 4 + 16)); DHIP(d, U->h_cn_value.ensure(std::max<size_t>(n_cn_all, 1) * 4 + 16));
+        if (n_total) {
+            const size_t ws_words = ((size_t)scan_grid(n_total) + 4) * 4;
+            DHIP(d, d->b_merge.ensure((size_t)n_total * 12 + ws_words * 4 + sizeof(TableDesc) + 128));
+            uint2* begins = d->b_merge.as<uint2>();
+            uint32_t* src = (uint32_t*)(begins + n_total);
+            uint32_t* ws = (uint32_t*)(((uintptr_t)(src + n_total) + 15) & ~(uintptr_t)15);
+            TableDesc* d_td = (TableDesc*)(((uintptr_t)(ws + ws_words) + 15) & ~(uintptr_t)15);
+            DHIP(d, hipMemcpyAsync(d_td, &TD, sizeof(TableDesc), hipMemcpyHostToDevice, s));
+            DHIP(d, hipMemcpyAsync(T + o_ntot + 2, &n_total, 4, hipMemcpyHostToDevice, s));
+            MergeOut mo{U->h_sv_out.as<SvOut>(), U->h_lib_index.as<int32_t>(), U->h_lib_pairs.as<int32_t>(), U->h_ltail_dev.as<double>(),
+                        U->h_cn_key.as<int32_t>(), U->h_cn_value.as<float>()};
+            if (tracing) {   // are the ranks' tables sorted by key, and are the keys distinct?
+                DHIP(d, hipStreamSynchronize(s));
+                for (int q = 0; q < world; ++q) {
+                    std::vector<unsigned long long> kk(TD.p[q].n_sv);
+                    if (!kk.empty()) DHIP(d, hipMemcpy(kk.data(), (const char*)d->b_all.p + TD.p[q].keys_off, kk.size() * 8, hipMemcpyDeviceToHost));
+                    size_t bad = 0;
+                    for (size_t i = 1; i < kk.size(); ++i) bad += kk[i] < kk[i - 1];
+                    fprintf(stderr, "[bdx dist] table of rank %d: %zu rows, %zu out of key order; first keys", q, kk.size(), bad);
+                    for (size_t i = 0; i < kk.size() && i < 6; ++i) fprintf(stderr, " (T %llu own %llu start %llu)", kk[i] >> 34, (kk[i] >> 33) & 1, (kk[i] >> 7) & 0x3FFFFFF);
+                    fprintf(stderr, "\n");
+                }
+            }
+            DHIP(d, hipMemsetAsync(src, 0xFF, (size_t)n_total * 4, s));
+            launch_k9_merge_tables((const char*)d->b_all.p, d_td, world, n_total, max_sv, src, begins, ws, T + o_ntot + 2, mo, s);
+        }
+        DHIP(d, hipStreamSynchronize(s));
+        DHIP(d, hipGetLastError());
+        trace("merge");
+        U->walk.clear(); U->log_tail.clear();
+        U->n_sv_total = n_total; U->n_terms_total = (uint32_t)n_terms_all; U->n_cn_total = (uint32_t)n_cn_all; U->n_printed = (uint32_t)n_printed_all;
+        U->n_sv_host = (uint32_t)v6[4]; U->n_groups_total = (uint32_t)n_groups_all;
+        memset(&U->counts, 0, sizeof(U->counts));
+        U->counts.n_regions = (uint32_t)NR; U->counts.last_maxq = lm; U->counts.n_pairs = (uint32_t)n_pairs_all; U->counts.n_old = (uint32_t)n_old_all;
+        U->counts.n_sv_dev = n_total - U->n_sv_host; U->counts.n_groups = (uint32_t)ng_all;
+        U->materialized = false;
+        std::swap(U->regions, C->regions); std::swap(U->r_pk, C->r_pk);
+        U->reg = U->regions.data(); U->nreg = U->regions.size(); U->rpk = U->r_pk.data();
+        C->reg = nullptr; C->nreg = 0; C->rpk = nullptr;
+        if (d->opts.fisher) {  // Fisher's combination (BreakDancer.cpp:71-81) uses the host's exp / log
+            materialize(U);
+            finish_scores(U->opts, U->log_tail.data(), U->walk.svs.data(), U->walk.svs.size(), &U->n_printed);
+        }
+        U->ran = true; U->stage = 4;
+    }
+    d->phase_ms[14] = ms_between(t_m0, std::chrono::steady_clock::now());
+    return finish_result();
 }
 
 }  // extern "C"

@@ -81,6 +81,11 @@ struct K3Tail {
     int has_next;
     int32_t qlen;
     uint32_t nn;
+    // a context that holds SEVERAL chromosomes of a sharded run, not necessarily neighbours in the genome: the read that closes the
+    // last candidate of chromosome t is the first anomalous read of the next chromosome that has any -- wherever it lives --, from
+    // this table of four words per chromosome: {has_next, its read length, the normal-pair count its candidate ends with (the next
+    // read's, or the genome's total), 0}.  Null: the compact list's own next read closes (single-context runs)
+    const uint32_t* tid_tail;
 };
 
 void launch_k3(const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n_anom_host, int min_len, int seq_coverage_lim,
@@ -152,6 +157,14 @@ struct Entries {
     uint32_t scratch_cap;
     uint32_t* flag_host;     // pinned word: the region table (written by the kernel before) is complete
     uint32_t flag_value;
+    // sharded runs: entries n_local .. n - 1 are FOREIGN -- inter-chromosomal reads of chromosomes another rank owns whose mates lie on
+    // a (later) chromosome of this rank (k7_exchange.hip) -- with their own arrays; they come first in stream order, are never the
+    // second-observed mate, and have no partner[] / pair_lo[] entry.  n_local null: every entry is the context's own
+    const uint32_t* n_local;
+    const uint64_t* fkey;
+    const uint64_t* fcheck;
+    const int32_t* fregion;
+    int want_pair_lo;        // fill K4Arrays::pair_lo from `region` (single-context runs derive it from c_rid)
 };
 
 void launch_k4(const K4Arrays& k4, const Entries& e, const uint32_t* n_ptr, uint32_t n_upper, StageCounts* counts, hipStream_t s);
@@ -173,27 +186,11 @@ __host__ __device__ __forceinline__ uint32_t exchange_owner(uint64_t k, uint32_t
     k ^= k >> 29;
     return (uint32_t)(k % world);
 }
-void launch_k7_names_count(const uint64_t* key, const uint32_t* n_ptr, uint32_t n_upper, uint32_t world, uint32_t* cnt, hipStream_t s);
-void launch_k7_names_scatter(const uint64_t* key, const uint64_t* check, const uint32_t* meta, const uint32_t* n_ptr, uint32_t n_upper, uint32_t world,
-                             uint32_t tid, uint32_t* cursor, unsigned long long* out, hipStream_t s);
-void launch_k7_names_census(const unsigned long long* in, uint32_t n, unsigned long long* table, unsigned long long* info, uint32_t* first_tid,
-                            uint32_t mask, uint32_t* irregular, hipStream_t s);
-void launch_k7_count(const uint64_t* key, const uint32_t* meta, const uint32_t* n_ptr, uint32_t n_upper, uint32_t world, uint32_t* cnt,
-                     hipStream_t s);
-void launch_k7_scatter(const uint64_t* key, const uint64_t* check, const int32_t* region_of, const uint32_t* meta, const int32_t* isize, const uint32_t* n_ptr,
-                       uint32_t n_upper, uint32_t world, uint32_t order_base, int32_t region_base, uint32_t* cursor, ExchangeEntry* out,
-                       hipStream_t s);
-// rank 0: the packages of the gather (byte offsets into the gather buffer; a package = its rank's region records, their prefix
-// samples, its pair groups)
+// rank 0: the packages of the gather (byte offsets into the gather buffer; a package = its rank's region records and their prefix samples)
 struct GatherPackage { uint64_t regions_off, pk_off, groups_off; uint32_t nr, ng; };
 struct GatherDesc { GatherPackage p[kMaxRanks]; int world; };
 void launch_k8_place_regions(const char* all, const GatherDesc& D, uint32_t max_nr, const uint64_t* rbase, int ntids, int nkeys2, RegionRec* r_rec,
                              uint32_t* r_pk, uint32_t* err, hipStream_t s);
-void launch_k8_bucket_groups(const char* all, const GatherDesc& D, uint32_t max_ng, uint32_t nregions, const uint32_t* n_dev, uint32_t* cnt,
-                             uint32_t* goff, GroupRec* out, uint32_t* ws, uint32_t* err, hipStream_t s);
-void launch_k8_slot_space(RegionRec* r_rec, uint32_t nregions, const uint32_t* n_dev, uint32_t* total, uint32_t* ws, hipStream_t s);
-void launch_k7_unpack(const ExchangeEntry* in, uint32_t n, uint64_t* key, uint64_t* check, uint32_t* order, int32_t* region, uint32_t* meta,
-                      int32_t* isize, hipStream_t s);
 
 void launch_k4_join_only(const K4Arrays& k4, const Entries& e, const uint32_t* n_ptr, uint32_t n_upper, StageCounts* counts, hipStream_t s);
 
@@ -358,9 +355,17 @@ struct K6Arrays {
     int big_walk;                  // components of up to kK6BigMembers regions are walked on the device (k6_walk_big_kernel); 0: up to kK6MaxMembers
     int walk_lanes;                // regions per wave of k6_walk_kernel (<= 64)
     int label_rounds;              // min-label propagation rounds incl. the one inside k6_pairs_kernel (default kK6LabelRounds)
+    // sharded runs: region ids are genome-wide, the table holds this rank's regions at their genome-wide places and n == 0 everywhere
+    // else.  A gate-passing group whose earlier region is another rank's makes both of its regions `tainted` (bytes, all-reduced over
+    // the ranks between k6_pairs_kernel and k6_classify_kernel): their components go to the host list, i.e. to rank 0's walk
+    uint8_t* taint;                // [cap]; null: single-context run
+    unsigned long long* sv_key;    // [sv_cap] order key of every row of the final table (T << 34 | own << 33 | start << 7): what rank 0 merges
+                                   // the ranks' tables by; null: not wanted
 };
 
 void launch_k6_groups(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s);   // pair groups, components, the host's list
+void launch_k6_pairs(const K6Arrays& a, uint32_t n_upper, hipStream_t s);        // ... in two parts: the pair groups (sharded runs exchange
+void launch_k6_components(const K6Arrays& a, uint32_t n_upper, hipStream_t s);   // the taint bytes in between), then the components
 // start values of the per-region scratch (out_deg, label = index, bad_v, bad, mcount, pcount) when no join kernel has set them
 void launch_k6_scratch_init(uint32_t* out_deg, uint32_t cap, hipStream_t s);
 void launch_k6_walk(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s);     // device-walked components -> SV staging

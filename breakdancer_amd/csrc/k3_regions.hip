@@ -31,6 +31,8 @@ struct HeadIn {
 
 struct HeadOut {
     K3Arrays a;
+    const int32_t* tid;   // with per_tid: the first read of a chromosome does not close the candidate before it (another chromosome's may)
+    int per_tid;
     __device__ void operator()(uint32_t j, uint32_t n, const U4& inc, const U4& e) const {
         const int c = (int)inc.x - 1;
         if (j == n - 1) a.counts->n_cand = inc.x;  // the accept scan runs over this many candidates
@@ -42,7 +44,8 @@ struct HeadOut {
         // Q4: the first read of a candidate is not counted for it, the breaking read (first read of the
         // next candidate) is (BreakDancer.cpp:209-212 runs before the break test at :216)
         const int target = e.x ? c - 1 : c;
-        if (target >= 0) atomicMax(&a.c_maxq[target], (int)e.y);
+        const bool other_chromosome = per_tid && e.x && j > 0 && tid[j] != tid[j - 1];
+        if (target >= 0 && !other_chromosome) atomicMax(&a.c_maxq[target], (int)e.y);
     }
 };
 
@@ -71,20 +74,25 @@ struct CandCtx {
         s.first = f; s.last = l; s.n = nxt - f;
         s.rev = a.pre_rev[l] - (f ? a.pre_rev[f - 1] : 0u);
         s.nonctx = a.pre_nonctx[l] - (f ? a.pre_nonctx[f - 1] : 0u);
-        const uint32_t e = c + 1 < nc ? nxt : l;
+        // sharded run, several chromosomes in this context: the last candidate of a chromosome is closed by the first anomalous read
+        // of the next chromosome that has one, which may live on another rank (K3Tail::tid_tail)
+        const bool chrom_last = tail.tid_tail && (c + 1 == nc || cp.tid[nxt] != cp.tid[f]);
+        const uint32_t* tl = chrom_last ? tail.tid_tail + 4 * (size_t)cp.tid[f] : nullptr;
+        const uint32_t e = (c + 1 < nc && !chrom_last) ? nxt : l;
         int qsum = (int)(a.pre_q[e] - a.pre_q[f]);
         int maxq = a.c_maxq[c];
-        const bool tail_closes = c + 1 == nc && tail.has_next;  // closed by the first anomalous read of the next chromosome
+        const bool tail_closes = chrom_last ? tl[0] != 0 : (c + 1 == nc && tail.has_next);  // closed by the first anomalous read of the next chromosome
+        const int tail_qlen = chrom_last ? (int)tl[1] : tail.qlen;
         if (tail_closes) {
-            qsum += tail.qlen;
-            maxq = max(maxq, tail.qlen);
+            qsum += tail_qlen;
+            maxq = max(maxq, tail_qlen);
         }
         s.maxq = maxq;
         const float cov = __fdiv_rn((float)qsum, (float)(end - start + 1 + maxq));
         s.accept = (end - start > min_len) && (cov < (float)seq_coverage_lim);
         // normal read pairs seen while the candidate was open (BreakDancer.cpp:202-206): between its first
         // read and the breaking read, or the end of the stream
-        const uint32_t nn_end = c + 1 < nc ? cp.nn[nxt] : (tail_closes ? tail.nn : nn_base + p1->n_normal);
+        const uint32_t nn_end = chrom_last ? tl[2] : (c + 1 < nc ? cp.nn[nxt] : (tail_closes ? tail.nn : nn_base + p1->n_normal));
         s.nnormal = nn_end - cp.nn[f];
         return s;
     }
@@ -155,7 +163,7 @@ void launch_k3(const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n
     // a.c_maxq[0 .. n_anom) must be zero on entry (K2 clears it while compacting)
     const uint32_t* n_ptr = &p1->n_anom;
     HeadIn hin{cp.tid, cp.pos, cp.meta, p1};
-    HeadOut hout{a};
+    HeadOut hout{a, cp.tid, tail.tid_tail ? 1 : 0};
     if (a.lb_state) {  // one launch per scan (decoupled look-back) instead of two
         const size_t nblk = scan_grid(a.cap, 1);
         scan_launch_lb<U4, 1>(hin, hout, n_ptr, n_anom_host, a.lb_state, a.lb_stamp, s);

@@ -178,8 +178,13 @@ __global__ __launch_bounds__(256) void k4_direct_join_kernel(K4Arrays k4, Entrie
         for (uint32_t i = j; i < nr * (uint32_t)en.nkeys2; i += gsz) en.r_pk_host[i] = en.r_pk_dev[i];
     }
     if (j >= na) return;
+    // (sharded runs: the entries behind the context's own are foreign -- see Entries::n_local)
+    const uint32_t nl = en.n_local ? *en.n_local : na;
+    const bool jf = j >= nl;
     int rj;
-    if (en.c_rid) {
+    if (jf) {
+        rj = en.fregion[j - nl];
+    } else if (en.c_rid) {
         rj = en.c_rid[en.cand[j]];
         en.region_out[j] = rj;
         if (en.k6_scratch) {  // out_deg, label, bad_v, bad, mcount, pcount
@@ -192,7 +197,8 @@ __global__ __launch_bounds__(256) void k4_direct_join_kernel(K4Arrays k4, Entrie
     }
     // (a read of a rejected candidate joins the table as well: it never forms a pair, but a third sighting of its name
     // must be noticed wherever the three reads lie)
-    const uint64_t key = en.key[j];
+    const uint64_t key = jf ? en.fkey[j - nl] : en.key[j];
+    const uint64_t chk = en.check ? (jf ? en.fcheck[j - nl] : en.check[j]) : 0ull;
     const uint64_t h = mix64(key);
     const uint32_t tag = (uint32_t)(h >> 32);
     unsigned long long* table = (unsigned long long*)k4.t_key;
@@ -203,14 +209,20 @@ __global__ __launch_bounds__(256) void k4_direct_join_kernel(K4Arrays k4, Entrie
         if (old == ~0ull) return;  // first of its name so far
         if ((uint32_t)(old >> 32) == tag) {
             const uint32_t o = (uint32_t)old;
-            if (en.key[o] == key && (!en.check || en.check[o] == en.check[j])) {  // (equal keys of two different names: probe on)
-                const int ro = en.c_rid ? en.c_rid[en.cand[o]] : en.region[o];
+            const bool of = o >= nl;
+            const uint64_t okey = of ? en.fkey[o - nl] : en.key[o];
+            if (okey == key && (!en.check || (of ? en.fcheck[o - nl] : en.check[o]) == chk)) {  // (equal keys of two different names: probe on)
+                const int ro = of ? en.fregion[o - nl] : (en.c_rid ? en.c_rid[en.cand[o]] : en.region[o]);
                 const bool alive = rj >= 0 && ro >= 0;  // both mates in accepted regions (ReadRegionData.cpp:177-199)
-                k4.partner[j] = alive ? (int32_t)o : -2;
-                if (atomicExch(&k4.partner[o], alive ? (int32_t)j : -2) != -1) counts->irregular = 1;  // a third read with this name
-                if (alive && k4.pair_lo && en.c_rid) {  // the later read in stream order is the second-observed mate
-                    if (o < j) k4.pair_lo[j] = ro;
-                    else k4.pair_lo[o] = rj;
+                if (!jf) k4.partner[j] = alive ? (int32_t)o : -2;
+                if (!of && atomicExch(&k4.partner[o], alive ? (int32_t)j : -2) != -1) counts->irregular = 1;  // a third read with this name
+                if (alive && k4.pair_lo) {  // the later read in stream order is the second-observed mate
+                    if (jf != of) {          // (a foreign entry lies on an earlier chromosome: the context's own read is the later one)
+                        if (jf) k4.pair_lo[o] = rj; else k4.pair_lo[j] = ro;
+                    } else if (!jf) {
+                        if (o < j) k4.pair_lo[j] = ro;
+                        else k4.pair_lo[o] = rj;
+                    }
                 }
                 return;
             }

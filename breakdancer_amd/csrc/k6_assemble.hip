@@ -193,6 +193,7 @@ __global__ __launch_bounds__(256) void k6_pairs_kernel(K6Arrays a) {
                     if (cm.gleader && clo < r) {
                         atomicAdd(&a.out_deg[clo], 1u);
                         a.bad_v[clo] = 1u;
+                        if (a.taint && a.r_rec[clo].n == 0) { a.taint[clo] = 1; a.taint[r] = 1; }  // (another rank's region)
                     }
                     if (lane == 0) a.bad_v[r] = 1u;
                     const uint32_t nl = (uint32_t)__popcll(cm.lmask);
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(256) void k6_pairs_kernel(K6Arrays a) {
                     if (cm.gleader && clo < r) {
                         atomicAdd(&a.out_deg[clo], 1u);
                         a.bad_v[clo] = 1u;
+                        if (a.taint && a.r_rec[clo].n == 0) { a.taint[clo] = 1; a.taint[r] = 1; }  // (another rank's region)
                     }
                     if (lane == 0) a.bad_v[r] = 1u;
                     const uint32_t nl = (uint32_t)__popcll(cm.lmask);
@@ -290,6 +292,9 @@ __global__ __launch_bounds__(256) void k6_pairs_kernel(K6Arrays a) {
             const bool in_edge = m.gleader && lo < r && strong;
             const uint64_t gl_in = __ballot(in_edge);
             if (in_edge) atomicAdd(&a.out_deg[lo], 1u);
+            // sharded run: the earlier region of a gate-passing group is another rank's (its place in this rank's table is empty): the
+            // component spans ranks -- both regions are tainted, every rank learns it, and rank 0 walks the component
+            if (a.taint && in_edge && a.r_rec[lo].n == 0) { a.taint[lo] = 1; a.taint[r] = 1; }
             rs.np_all = (uint32_t)__popcll(m.lmask);
             rs.np_self = (uint32_t)__popcll(__ballot(m.leader && lo == r));
             rs.np_emit = (uint32_t)__popcll(__ballot(m.leader && (lo == r || strong)));
@@ -353,7 +358,7 @@ __global__ __launch_bounds__(256) void k6_classify_kernel(K6Arrays a) {
     const bool hub = s->big || n_in > (uint32_t)kK6MaxIn;
     if (!hub && n_in == 0 && a.out_deg[r] == 0 && s->np_self == 0) return;  // no group that could ever be consumed
     const uint32_t L = a.label[r];
-    if (hub || a.bad_v[r]) a.bad[L] = 1u;
+    if (hub || a.bad_v[r] || (a.taint && a.taint[r])) a.bad[L] = 1u;
     if (!hub) {
 #pragma unroll
         for (uint32_t e = 0; e < (uint32_t)kK6MaxIn; ++e) {  // (static trip count: no private array behind the loop)
@@ -1261,6 +1266,7 @@ __global__ __launch_bounds__(kScanBlock) void k6_finish_kernel(K6Arrays a, doubl
     __shared__ uint32_t s_T[kFinT];
     __shared__ uint32_t s_from[kFinList];
     __shared__ uint2 s_bg[kFinList];
+    __shared__ uint32_t s_vx[kFinList];   // the vertex a listed candidate is placed at (order keys for the merge of a sharded run's tables)
     __shared__ uint32_t s_rec[kScanBlock / 64][64 * kSvWords];
     __shared__ uint32_t s_range[2];
     __shared__ uint32_t s_printed;
@@ -1320,6 +1326,7 @@ __global__ __launch_bounds__(kScanBlock) void k6_finish_kernel(K6Arrays a, doubl
                 if (pos < kFinList) {
                     s_from[pos] = a.ins_src[jj];
                     s_bg[pos] = make_uint2(ex_l + a.ins_pre_l[jj], ex_c + a.ins_pre_c[jj]);
+                    s_vx[pos] = j;
                 }
             }
             uint32_t lb = lb_own, cb = cb_own, slot = slot0;
@@ -1328,6 +1335,7 @@ __global__ __launch_bounds__(kScanBlock) void k6_finish_kernel(K6Arrays a, doubl
                 if (pos < kFinList) {
                     s_from[pos] = slot;
                     s_bg[pos] = make_uint2(lb, cb);
+                    s_vx[pos] = j;
                 } else if ((int32_t)pos > 0) {
                     break;  // past this pass's window
                 }
@@ -1407,6 +1415,10 @@ __global__ __launch_bounds__(kScanBlock) void k6_finish_kernel(K6Arrays a, doubl
                 o->sv.score = phred;
                 o->sv.printed = pr ? 1 : 0;
             }
+            if (a.sv_key && act) {   // placed at vertex T: before T's own candidates unless the traversal started at T itself
+                const unsigned long long T = s_vx[c0 + lane], st = o->start;
+                a.sv_key[win + c0 + lane] = (T << kKeyShiftT) | (T == st ? 1ull << 33 : 0ull) | (st << kKeyShiftStart);
+            }
             const uint32_t npr = (uint32_t)__popcll(__ballot(pr));
             if (lane == 0 && npr) atomicAdd(&s_printed, npr);
             KPROF(32768u + bid * 4 + w, 4);
@@ -1454,21 +1466,30 @@ void launch_k6_scratch_init(uint32_t* out_deg, uint32_t cap, hipStream_t s) {
     hipLaunchKernelGGL(k6_scratch_init_kernel, dim3(std::min<uint32_t>((cap + 255) / 256, 4096u)), dim3(256), 0, s, out_deg, cap);
 }
 
-void launch_k6_groups(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
+void launch_k6_pairs(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
     if (n_anom_host == 0) return;
     // regions <= anomalous reads, typically a tenth of them: about one wave per region, a grid-stride loop for the rest
     const uint32_t gp = std::min<uint32_t>((n_anom_host / 8 + 3) / 4 + 1, 16384u);
+    hipLaunchKernelGGL(k6_pairs_kernel, dim3(gp), dim3(256), 0, s, a);
+}
+
+void launch_k6_components(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
+    if (n_anom_host == 0) return;
     // one thread per region, a wave per workgroup: the regions are about a tenth of the grid's upper bound, and with 256 of them per
     // workgroup the ~12 k regions of configs[1] would keep 47 of the 256 compute units busy -- each with four waves' worth of
     // scattered requests (~64 address cycles per memory instruction) through one address pipeline
     constexpr uint32_t kRegionThreads = 64;  // (whole waves: the emit step's reservations are wave-aggregated; measured 256 / 128 / 64: step 0.2749 / 0.2730 / 0.2711 ms)
     const uint32_t grs = (n_anom_host + kRegionThreads - 1) / kRegionThreads;
-    hipLaunchKernelGGL(k6_pairs_kernel, dim3(gp), dim3(256), 0, s, a);
     if (!a.force_host)
         for (int i = 1; i < a.label_rounds; ++i) hipLaunchKernelGGL(k6_label_kernel, dim3(grs), dim3(kRegionThreads), 0, s, a);  // round 1: k6_pairs
     hipLaunchKernelGGL(k6_classify_kernel, dim3(grs), dim3(kRegionThreads), 0, s, a);
     hipLaunchKernelGGL(k6_emit_kernel, dim3(grs), dim3(kRegionThreads), 0, s, a);
     if (a.counts_host && !a.mirror_in_walk) hipLaunchKernelGGL(k6_mirror_kernel, dim3(1), dim3(64), 0, s, a);
+}
+
+void launch_k6_groups(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
+    launch_k6_pairs(a, n_anom_host, s);
+    launch_k6_components(a, n_anom_host, s);
 }
 
 void launch_k6_walk(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {

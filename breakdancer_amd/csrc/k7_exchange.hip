@@ -1,30 +1,26 @@
-// K7 -- the exchange step of a chromosome-sharded run: inter-chromosomal (CTX) mate records to the rank that joins them.
+// K7 -- the exchange steps of a chromosome-sharded run.
 //
 // Regions never span chromosomes (BreakDancer.cpp:216), so with the chromosomes spread over GPUs every read pair whose
-// mates lie on one chromosome is joined where it is (K4 on the chromosome's own context).  Only the reads classified
-// ARP_CTX (tid != mtid, IlluminaPEReadClassifier.cpp:78-80) have their mate elsewhere: their join records
-// {name key, stream order, global region id, meta, |isize|} go to owner(name key), one all-to-all over RCCL, and meet
-// there (ReadRegionData.cpp:108-113 joins on the read name only).  These kernels pack the records by destination rank
-// on the sending side and unpack them into the join's SoA layout on the receiving side; everything stays in HBM.
+// mates lie on one chromosome is joined where it is.  Only the reads classified ARP_CTX (tid != mtid,
+// IlluminaPEReadClassifier.cpp:78-80) have their mate elsewhere.  The pair is observed when its SECOND mate shows up
+// (SvBuilder.cpp:101-118), and the stream is position sorted, so the second mate is the one on the later chromosome: a CTX read
+// whose mate's chromosome comes later and belongs to another rank sends {name key, second hash, genome-wide region id} there --
+// ONE all-to-all over RCCL -- and joins that rank's own reads as a "foreign" entry (Entries::n_local, k4_join.hip); the rank of
+// the later chromosome then has everything its pair groups need where its reads are.  CTX pairs between two chromosomes of one
+// rank never leave it.
+//
+// The reference joins on the read NAME alone (ReadRegionData.cpp:108-113), whatever the records' mtid fields say, and appends every
+// sighting.  Routing by chromosome is only right for names that behave: one sighting, two on one chromosome, or two CTX reads that
+// name each other's chromosome.  The name census checks exactly that: the name key of EVERY anomalous read also travels to
+// owner(key) -- 16 bytes {key, tid, mtid, not CTX} -- where a table counts sightings; any other name makes the run replay read by
+// read on rank 0 (bdx_dist_impl.h), which is the reference's behaviour for any input.
 #include "bdx_k3.h"
+#include "bdx_shard.h"
 
 namespace bdx {
 
-__global__ __launch_bounds__(256) void k7_count_kernel(const uint64_t* key, const uint32_t* meta, const uint32_t* n_ptr, uint32_t world,
-                                                       uint32_t* cnt) {
-    __shared__ uint32_t s_cnt[kMaxRanks];
-    for (uint32_t d = threadIdx.x; d < world; d += 256) s_cnt[d] = 0;
-    __syncthreads();
-    const uint32_t n = *n_ptr;
-    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256)
-        if (meta_flag(meta[j]) == F_CTX) atomicAdd(&s_cnt[exchange_owner(key[j], world)], 1u);
-    __syncthreads();
-    for (uint32_t d = threadIdx.x; d < world; d += 256)
-        if (s_cnt[d]) atomicAdd(&cnt[d], s_cnt[d]);
-}
-
 // A place in destination d's part of the send buffer for every active lane: ONE atomic per wave and destination (lanes with the same
-// destination share it) -- with one rank every record of a chromosome has the same destination, and 250 k atomics on one word took a millisecond.
+// destination share it) -- with one rank every record has the same destination, and 250 k atomics on one word took a millisecond.
 __device__ __forceinline__ uint32_t wave_slots(uint32_t* cursor, uint32_t dest, bool active) {
     const int lane = threadIdx.x & 63;
     uint32_t slot = 0;
@@ -42,151 +38,155 @@ __device__ __forceinline__ uint32_t wave_slots(uint32_t* cursor, uint32_t dest, 
     return slot;
 }
 
-// cursor[d] starts at the destination's offset in the send buffer (entries)
-__global__ __launch_bounds__(256) void k7_scatter_kernel(const uint64_t* key, const uint64_t* check, const int32_t* region_of, const uint32_t* meta,
-                                                         const int32_t* isize, const uint32_t* n_ptr, uint32_t world, uint32_t order_base,
-                                                         int32_t region_base, uint32_t* cursor, ExchangeEntry* out) {
-    const uint32_t n = *n_ptr;
-    for (uint32_t j0 = blockIdx.x * 256; j0 < n; j0 += gridDim.x * 256) {   // (whole waves stay in the loop: the slots are handed out wave-wide)
-        const uint32_t j = j0 + threadIdx.x;
-        const uint32_t m = j < n ? meta[j] : 0u;
-        const bool ctx = j < n && meta_flag(m) == F_CTX;
-        const uint64_t k = ctx ? key[j] : 0ull;
-        const uint32_t slot = wave_slots(cursor, ctx ? exchange_owner(k, world) : 0u, ctx);
-        if (!ctx) continue;
-        const int32_t r = region_of[j];
-        ExchangeEntry e;
-        e.key = k; e.order = order_base + j; e.region = r < 0 ? -1 : r + region_base; e.meta = m; e.isize = isize[j];
-        e.check = check ? check[j] : 0ull;
-        out[slot] = e;
+// the rank a CTX read's join record travels to, or -1: its mate's chromosome comes later in the stream and belongs to another rank
+__device__ __forceinline__ int ctx_destination(const ExchangeSrc& x, uint32_t j, uint32_t m) {
+    if (meta_flag(m) != F_CTX) return -1;
+    const int32_t t = x.tid[j], mt = x.mtid_col[x.idx[j]];
+    if (mt <= t || mt >= x.ntids) return -1;
+    const int32_t o = x.owner_of_tid[mt];
+    return (o < 0 || o == x.me) ? -1 : o;
+}
+
+// cnt[0 .. world): CTX records per destination; cnt[world .. 2 world): census records per owner(key)
+__global__ __launch_bounds__(256) void k7_count_kernel(ExchangeSrc x, uint32_t* cnt) {
+    __shared__ uint32_t s_cnt[2 * kMaxRanks];
+    for (uint32_t d = threadIdx.x; d < 2 * x.world; d += 256) s_cnt[d] = 0;
+    __syncthreads();
+    const uint32_t n = *x.n_ptr;
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+        const int d = ctx_destination(x, j, x.meta[j]);
+        if (d >= 0) atomicAdd(&s_cnt[d], 1u);
+        atomicAdd(&s_cnt[x.world + exchange_owner(x.key[j], x.world)], 1u);
     }
-}
-
-__global__ __launch_bounds__(256) void k7_unpack_kernel(const ExchangeEntry* in, uint32_t n, uint64_t* key, uint64_t* check, uint32_t* order,
-                                                        int32_t* region, uint32_t* meta, int32_t* isize) {
-    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    const ExchangeEntry e = in[j];
-    key[j] = e.key; order[j] = e.order; region[j] = e.region; meta[j] = e.meta; isize[j] = e.isize;
-    if (check) check[j] = e.check;
-}
-
-// ---- name census: is any read name met more than twice, or twice on two chromosomes without being an inter-chromosomal pair? ----
-// Every rank's joins see only its own chromosomes (and the CTX records it owns), but the reference keys its name map on the
-// whole genome (ReadRegionData.cpp:108-113): merged files with clashing read names put sightings of one name on several
-// chromosomes.  So the name key of EVERY anomalous read travels to owner(key) as well -- 16 bytes {key, tid << 1 | not CTX},
-// no join, only a census: a table of keys with a count, the first chromosome seen and whether another one followed.  A name is
-// regular if it has one sighting, two on one chromosome, or two CTX reads on two chromosomes; anything else makes the run
-// replay read by read on rank 0 (bdx_dist_impl.h).
-__global__ __launch_bounds__(256) void k7_names_count_kernel(const uint64_t* key, const uint32_t* n_ptr, uint32_t world, uint32_t* cnt) {
-    __shared__ uint32_t s_cnt[kMaxRanks];
-    for (uint32_t d = threadIdx.x; d < world; d += 256) s_cnt[d] = 0;
     __syncthreads();
-    const uint32_t n = *n_ptr;
-    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) atomicAdd(&s_cnt[exchange_owner(key[j], world)], 1u);
-    __syncthreads();
-    for (uint32_t d = threadIdx.x; d < world; d += 256)
+    for (uint32_t d = threadIdx.x; d < 2 * x.world; d += 256)
         if (s_cnt[d]) atomicAdd(&cnt[d], s_cnt[d]);
 }
 
+// cursor[d] / cursor[world + d] start at the destination's offset in the respective send buffer (entries)
 // (with a second name hash in the stream the census counts (key, check) pairs: its word is a mix of the two, so two names whose keys
 // collide are two names here as well -- the joins tell them apart by the check -- and an equal mix of different pairs only costs a replay)
-__global__ __launch_bounds__(256) void k7_names_scatter_kernel(const uint64_t* key, const uint64_t* check, const uint32_t* meta, const uint32_t* n_ptr,
-                                                               uint32_t world, uint32_t tid, uint32_t* cursor, unsigned long long* out) {
-    const uint32_t n = *n_ptr;
-    for (uint32_t j0 = blockIdx.x * 256; j0 < n; j0 += gridDim.x * 256) {
+__global__ __launch_bounds__(256) void k7_scatter_kernel(ExchangeSrc x, uint32_t* cursor, ExchangeEntry* out, unsigned long long* names_out) {
+    const uint32_t n = *x.n_ptr;
+    for (uint32_t j0 = blockIdx.x * 256; j0 < n; j0 += gridDim.x * 256) {   // (whole waves stay in the loop: the slots are handed out wave-wide)
         const uint32_t j = j0 + threadIdx.x;
         const bool in = j < n;
-        const uint64_t k = in ? key[j] : 0ull;
-        const uint32_t slot = wave_slots(cursor, in ? exchange_owner(k, world) : 0u, in);
+        const uint32_t m = in ? x.meta[j] : 0u;
+        const int d = in ? ctx_destination(x, j, m) : -1;
+        const uint64_t k = in ? x.key[j] : 0ull;
+        const uint32_t slot = wave_slots(cursor, d >= 0 ? (uint32_t)d : 0u, d >= 0);
+        const uint32_t nslot = wave_slots(cursor + x.world, in ? exchange_owner(k, x.world) : 0u, in);
         if (!in) continue;
-        unsigned long long w = k;
-        if (check) {
-            const uint64_t c = check[j];
-            w = (k * 0x9E3779B97F4A7C15ull) ^ ((c << 31) | (c >> 33)) ^ (c * 0xC2B2AE3D27D4EB4Full);
-            if (w == ~0ull) w = 0;   // (all ones marks an empty slot of the census table)
+        const uint64_t c = x.check ? x.check[j] : 0ull;
+        if (d >= 0) {
+            ExchangeEntry e;
+            e.key = k; e.order = 0; e.region = x.region_of[j]; e.meta = m; e.isize = 0; e.check = c;
+            out[slot] = e;
         }
-        out[2 * (size_t)slot] = w;
-        out[2 * (size_t)slot + 1] = ((unsigned long long)tid << 1) | (meta_flag(meta[j]) != F_CTX ? 1ull : 0ull);
+        unsigned long long w = k;
+        if (x.check) w = (k * 0x9E3779B97F4A7C15ull) ^ ((c << 31) | (c >> 33)) ^ (c * 0xC2B2AE3D27D4EB4Full);
+        if (w == ~0ull) w = 0;   // (all ones marks an empty slot of the census table)
+        const uint32_t t1 = (uint32_t)(x.tid[j] + 1) & 0xFFFFFFu, mt1 = (uint32_t)(x.mtid_col[x.idx[j]] + 1) & 0xFFFFFFu;
+        names_out[2 * (size_t)nslot] = w;
+        names_out[2 * (size_t)nslot + 1] = (meta_flag(m) != F_CTX ? 1ull : 0ull) | ((unsigned long long)t1 << 8) | ((unsigned long long)mt1 << 32);
     }
 }
 
-// table[mask + 1] keys (all ones = empty), info[mask + 1] = count | not-CTX sightings << 16 | (another chromosome followed) << 32,
-// first_tid[mask + 1] (all ones = none yet); all three start out as 0xFF bytes except info, which starts at zero
-__global__ __launch_bounds__(256) void k7_names_insert_kernel(const unsigned long long* in, uint32_t n, unsigned long long* table,
-                                                              unsigned long long* info, uint32_t* first_tid, uint32_t mask) {
+// the foreign entries of the join, and its entry count (the context's own anomalous reads + these)
+__global__ __launch_bounds__(256) void k7_unpack_kernel(const ExchangeEntry* in, uint32_t n, uint64_t* key, uint64_t* check, int32_t* region,
+                                                        const uint32_t* n_local, uint32_t* n_total) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j == 0) *n_total = *n_local + n;
+    if (j >= n) return;
+    const ExchangeEntry e = in[j];
+    key[j] = e.key; region[j] = e.region;
+    if (check) check[j] = e.check;
+}
+
+// ---- name census ----
+// One 16-byte slot per name: {key word (all ones = empty), info}.  info: bits 0-1 sightings (saturating at 3), bit 2 a sighting that is
+// not a CTX read, bit 3 sightings on different chromosomes, bit 4 two CTX sightings that do not name each other's chromosome,
+// bits 8-31 the first sighting's chromosome + 1, bits 32-55 its mate chromosome + 1.  One line is dirtied per insert (three arrays
+// with one scattered atomic each wrote 7x the records' bytes: profiles/r03_pmc_all_kernels.txt).
+__global__ __launch_bounds__(256) void k7_names_insert_kernel(const unsigned long long* in, uint32_t n, unsigned long long* slots, uint32_t mask) {
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     const unsigned long long k = in[2 * (size_t)j], w = in[2 * (size_t)j + 1];
-    const uint32_t tid = (uint32_t)(w >> 1), nonctx = (uint32_t)(w & 1);
+    const unsigned long long nonctx = w & 1ull, t1 = (w >> 8) & 0xFFFFFFull, mt1 = (w >> 32) & 0xFFFFFFull;
     uint32_t s = (uint32_t)(((k ^ (k >> 31)) * 0x9E3779B97F4A7C15ull) >> 24) & mask;   // (not the owner's hash: the keys of one owner share that)
     for (;;) {
-        const unsigned long long old = atomicCAS(&table[s], ~0ull, k);
+        const unsigned long long old = atomicCAS(&slots[2 * (size_t)s], ~0ull, k);
         if (old == ~0ull || old == k) break;
         s = (s + 1) & mask;   // (the table has at least twice as many slots as there are records)
     }
-    unsigned long long add = 1ull | ((unsigned long long)nonctx << 16);
-    const uint32_t ft = atomicCAS(&first_tid[s], 0xFFFFFFFFu, tid);
-    if (ft != 0xFFFFFFFFu && ft != tid) add |= 1ull << 32;   // (more than one such sighting only makes the field non-zero)
-    atomicAdd(&info[s], add);
+    unsigned long long* info = &slots[2 * (size_t)s + 1];
+    unsigned long long seen = *(volatile unsigned long long*)info;
+    for (;;) {
+        unsigned long long next;
+        const unsigned long long cnt = seen & 3ull;
+        if (cnt == 0) {
+            next = 1ull | (nonctx << 2) | (t1 << 8) | (mt1 << 32);
+        } else {
+            const unsigned long long ft = (seen >> 8) & 0xFFFFFFull, fm = (seen >> 32) & 0xFFFFFFull;
+            next = (seen & ~3ull) | (cnt < 3 ? cnt + 1 : 3ull) | (nonctx << 2);
+            if (ft != t1) next |= 1ull << 3;
+            if (!(ft == mt1 && fm == t1)) next |= 1ull << 4;
+        }
+        const unsigned long long got = atomicCAS(info, seen, next);
+        if (got == seen) break;
+        seen = got;
+    }
 }
 
-__global__ __launch_bounds__(256) void k7_names_verdict_kernel(const unsigned long long* table, const unsigned long long* info, uint32_t slots,
-                                                               uint32_t* irregular) {
+__global__ __launch_bounds__(256) void k7_names_verdict_kernel(const unsigned long long* slots, uint32_t nslots, uint32_t* irregular) {
     const uint32_t s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= slots || table[s] == ~0ull) return;
-    const unsigned long long v = info[s];
-    const uint32_t count = (uint32_t)(v & 0xFFFF), nonctx = (uint32_t)((v >> 16) & 0xFFFF);
-    const bool spread = (v >> 32) != 0;
-    if (count > 2 || (count == 2 && spread && nonctx)) *irregular = 1;
+    if (s >= nslots || slots[2 * (size_t)s] == ~0ull) return;
+    const unsigned long long v = slots[2 * (size_t)s + 1];
+    const uint32_t count = (uint32_t)(v & 3ull);
+    const bool nonctx = (v >> 2) & 1ull, spread = (v >> 3) & 1ull, strangers = (v >> 4) & 1ull;
+    // regular: one sighting; two on one chromosome; two CTX reads on two chromosomes that name each other's
+    if (count > 2 || (count == 2 && spread && (nonctx || strangers))) *irregular = 1;
 }
 
-void launch_k7_names_count(const uint64_t* key, const uint32_t* n_ptr, uint32_t n_upper, uint32_t world, uint32_t* cnt, hipStream_t s) {
+void launch_k7_count(const ExchangeSrc& x, uint32_t n_upper, uint32_t* cnt, hipStream_t s) {
     if (!n_upper) return;
     const uint32_t g = std::min<uint32_t>((n_upper + 255) / 256, 2048u);
-    hipLaunchKernelGGL(k7_names_count_kernel, dim3(g), dim3(256), 0, s, key, n_ptr, world, cnt);
+    hipLaunchKernelGGL(k7_count_kernel, dim3(g), dim3(256), 0, s, x, cnt);
 }
 
-void launch_k7_names_scatter(const uint64_t* key, const uint64_t* check, const uint32_t* meta, const uint32_t* n_ptr, uint32_t n_upper, uint32_t world,
-                             uint32_t tid, uint32_t* cursor, unsigned long long* out, hipStream_t s) {
+void launch_k7_scatter(const ExchangeSrc& x, uint32_t n_upper, uint32_t* cursor, ExchangeEntry* out, unsigned long long* names_out, hipStream_t s) {
     if (!n_upper) return;
     const uint32_t g = std::min<uint32_t>((n_upper + 255) / 256, 2048u);
-    hipLaunchKernelGGL(k7_names_scatter_kernel, dim3(g), dim3(256), 0, s, key, check, meta, n_ptr, world, tid, cursor, out);
+    hipLaunchKernelGGL(k7_scatter_kernel, dim3(g), dim3(256), 0, s, x, cursor, out, names_out);
 }
 
-void launch_k7_names_census(const unsigned long long* in, uint32_t n, unsigned long long* table, unsigned long long* info, uint32_t* first_tid,
-                            uint32_t mask, uint32_t* irregular, hipStream_t s) {
+void launch_k7_unpack(const ExchangeEntry* in, uint32_t n, uint64_t* key, uint64_t* check, int32_t* region, const uint32_t* n_local, uint32_t* n_total,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(k7_unpack_kernel, dim3(std::max(1u, (n + 255) / 256)), dim3(256), 0, s, in, n, key, check, region, n_local, n_total);
+}
+
+// slots: [2 (mask + 1)] words, key words all ones and info words zero on entry
+void launch_k7_names_census(const unsigned long long* in, uint32_t n, unsigned long long* slots, uint32_t mask, uint32_t* irregular, hipStream_t s) {
     if (!n) return;
-    hipLaunchKernelGGL(k7_names_insert_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, n, table, info, first_tid, mask);
-    hipLaunchKernelGGL(k7_names_verdict_kernel, dim3((mask + 256) / 256), dim3(256), 0, s, table, info, mask + 1, irregular);
+    hipLaunchKernelGGL(k7_names_insert_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, n, slots, mask);
+    hipLaunchKernelGGL(k7_names_verdict_kernel, dim3((mask + 256) / 256), dim3(256), 0, s, slots, mask + 1, irregular);
 }
 
-void launch_k7_count(const uint64_t* key, const uint32_t* meta, const uint32_t* n_ptr, uint32_t n_upper, uint32_t world, uint32_t* cnt,
-                     hipStream_t s) {
-    if (!n_upper) return;
-    const uint32_t g = std::min<uint32_t>((n_upper + 255) / 256, 2048u);
-    hipLaunchKernelGGL(k7_count_kernel, dim3(g), dim3(256), 0, s, key, meta, n_ptr, world, cnt);
+// key words all ones, info words zero
+__global__ __launch_bounds__(256) void k7_names_clear_kernel(unsigned long long* slots, uint32_t nslots, uint32_t* irregular) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *irregular = 0;
+    for (uint32_t s = blockIdx.x * 256 + threadIdx.x; s < nslots; s += gridDim.x * 256) {
+        slots[2 * (size_t)s] = ~0ull;
+        slots[2 * (size_t)s + 1] = 0ull;
+    }
 }
-
-void launch_k7_scatter(const uint64_t* key, const uint64_t* check, const int32_t* region_of, const uint32_t* meta, const int32_t* isize, const uint32_t* n_ptr,
-                       uint32_t n_upper, uint32_t world, uint32_t order_base, int32_t region_base, uint32_t* cursor, ExchangeEntry* out,
-                       hipStream_t s) {
-    if (!n_upper) return;
-    const uint32_t g = std::min<uint32_t>((n_upper + 255) / 256, 2048u);
-    hipLaunchKernelGGL(k7_scatter_kernel, dim3(g), dim3(256), 0, s, key, check, region_of, meta, isize, n_ptr, world, order_base, region_base,
-                       cursor, out);
-}
-
-void launch_k7_unpack(const ExchangeEntry* in, uint32_t n, uint64_t* key, uint64_t* check, uint32_t* order, int32_t* region, uint32_t* meta,
-                      int32_t* isize, hipStream_t s) {
-    if (!n) return;
-    hipLaunchKernelGGL(k7_unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, n, key, check, order, region, meta, isize);
+void launch_k7_names_clear(unsigned long long* slots, uint32_t nslots, uint32_t* irregular, hipStream_t s) {
+    hipLaunchKernelGGL(k7_names_clear_kernel, dim3(std::min<uint32_t>((nslots + 255) / 256, 4096u)), dim3(256), 0, s, slots, nslots, irregular);
 }
 
 }  // namespace bdx
 
-// ---- rank 0 of a sharded run: the gathered packages -> ONE region table and the pair groups bucketed by their later region ----
-// (what the host did with memcpy loops and a counting sort until round 3; the packages arrive in HBM and K6 reads its input from HBM)
+// ---- rank 0 of a sharded run: the gathered packages of region records -> ONE region table (the packages arrive in HBM) ----
 #include "bdx_scan.h"
 
 namespace bdx {
@@ -215,81 +215,10 @@ __global__ __launch_bounds__(256) void k8_place_regions_kernel(const char* all, 
     for (int k = 0; k < nkeys2; ++k) r_pk[g * nkeys2 + k] = src[k];
 }
 
-__device__ __forceinline__ uint32_t later_region(const GroupRec& g) { return (uint32_t)((g.key >> 12) & ((1u << 26) - 1)); }
-// (a package's groups follow an odd or even number of 36-byte region records: 4-byte aligned only)
-__device__ __forceinline__ GroupRec load_group(const char* base, uint32_t i) {
-    const uint32_t* w = (const uint32_t*)base + 4 * (size_t)i;
-    GroupRec g;
-    g.key = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
-    g.pairs = w[2];
-    g.sum_isize = w[3];
-    return g;
-}
-
-__global__ __launch_bounds__(256) void k8_group_count_kernel(const char* all, GatherDesc D, uint32_t nregions, uint32_t* cnt, uint32_t* err) {
-    const GatherPackage P = D.p[blockIdx.y];
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < P.ng; i += gridDim.x * 256) {
-        const uint32_t r = later_region(load_group(all + P.groups_off, i));
-        if (r >= nregions) { *err = 1; continue; }
-        atomicAdd(&cnt[r], 1u);
-    }
-}
-
-// (the order of a region's groups is free: K6 and the host merge them by key, sums of integers)
-__global__ __launch_bounds__(256) void k8_group_scatter_kernel(const char* all, GatherDesc D, uint32_t nregions, uint32_t* cur, GroupRec* out) {
-    const GatherPackage P = D.p[blockIdx.y];
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < P.ng; i += gridDim.x * 256) {
-        const GroupRec g = load_group(all + P.groups_off, i);
-        const uint32_t r = later_region(g);
-        if (r < nregions) out[atomicAdd(&cur[r], 1u)] = g;
-    }
-}
-
-struct BucketIn {
-    const uint32_t* cnt;
-    __device__ uint32_t operator()(uint32_t j, uint32_t) const { return cnt[j]; }
-};
-struct BucketOut {   // goff[j + 1] = groups of the regions 0 .. j; the counter becomes the bucket's scatter cursor
-    uint32_t* goff;
-    uint32_t* cur;
-    __device__ void operator()(uint32_t j, uint32_t, uint32_t inc, uint32_t e) const {
-        if (j == 0) goff[0] = 0;
-        goff[j + 1] = inc;
-        cur[j] = inc - e;
-    }
-};
-struct SlotIn {
-    const RegionRec* r;
-    __device__ uint32_t operator()(uint32_t j, uint32_t) const { return r[j].n; }
-};
-struct SlotOut {     // K6's slot space: the regions laid end to end
-    RegionRec* r;
-    uint32_t* total;
-    __device__ void operator()(uint32_t j, uint32_t n, uint32_t inc, uint32_t e) const {
-        r[j].first = inc - e;
-        if (j + 1 == n) *total = inc;
-    }
-};
-
 void launch_k8_place_regions(const char* all, const GatherDesc& D, uint32_t max_nr, const uint64_t* rbase, int ntids, int nkeys2, RegionRec* r_rec,
                              uint32_t* r_pk, uint32_t* err, hipStream_t s) {
     if (!max_nr) return;
     hipLaunchKernelGGL(k8_place_regions_kernel, dim3((max_nr + 255) / 256, D.world), dim3(256), 0, s, all, D, rbase, ntids, nkeys2, r_rec, r_pk, err);
-}
-
-// cnt[nregions] zero on entry; ws: scan_grid(nregions) + 1 words; n_dev: device word holding nregions
-void launch_k8_bucket_groups(const char* all, const GatherDesc& D, uint32_t max_ng, uint32_t nregions, const uint32_t* n_dev, uint32_t* cnt,
-                             uint32_t* goff, GroupRec* out, uint32_t* ws, uint32_t* err, hipStream_t s) {
-    if (!nregions) return;
-    const uint32_t g = std::max(1u, std::min((max_ng + 255) / 256, 1024u));
-    if (max_ng) hipLaunchKernelGGL(k8_group_count_kernel, dim3(g, D.world), dim3(256), 0, s, all, D, nregions, cnt, err);
-    scan_launch<uint32_t>(BucketIn{cnt}, BucketOut{goff, cnt}, n_dev, nregions, ws + 1, ws, s);
-    if (max_ng) hipLaunchKernelGGL(k8_group_scatter_kernel, dim3(g, D.world), dim3(256), 0, s, all, D, nregions, cnt, out);
-}
-
-void launch_k8_slot_space(RegionRec* r_rec, uint32_t nregions, const uint32_t* n_dev, uint32_t* total, uint32_t* ws, hipStream_t s) {
-    if (!nregions) return;
-    scan_launch<uint32_t>(SlotIn{r_rec}, SlotOut{r_rec, total}, n_dev, nregions, ws + 1, ws, s);
 }
 
 }  // namespace bdx

@@ -42,6 +42,9 @@ def _lib():
         lib.bdx_dist_set_collect_support.argtypes = [vp, C.c_int]
         lib.bdx_dist_get_exchange.argtypes = [vp, vp, vp, vp, vp, vp]
         lib.bdx_dist_owner.argtypes = [C.c_uint64, C.c_int]
+        lib.bdx_dist_prepare.argtypes = [vp]
+        lib.bdx_dist_phase_name.argtypes = [C.c_int]
+        lib.bdx_dist_phase_name.restype = C.c_char_p
         lib.bdx_dist_plan.argtypes = [vp, C.c_int, C.c_int, vp]
         lib._dist_bound = True
     return lib
@@ -131,13 +134,14 @@ class DistRun:
             raise BdxError("%s: %s (%s)" % (what, self.lib.bdx_strerror(rc).decode(), self.lib.bdx_dist_last_error(self.h).decode()))
 
     def chromosome(self, tid):
-        """the context of a chromosome this rank owns: push_reads / stream_reads it, do not run it"""
-        if tid not in self._chrom:
-            h = self.lib.bdx_dist_chromosome(self.h, int(tid))
-            if not h:
-                raise BdxError("bdx_dist_chromosome(%d) failed" % tid)
-            self._chrom[tid] = BreakDancer.borrow(h, self.opts, self.libs, self.nbams)
-        return self._chrom[tid]
+        """the context that takes chromosome `tid`'s records (ONE per rank: a rank's chromosomes are fed in ascending order):
+        push_reads / stream_reads it, do not run it"""
+        h = self.lib.bdx_dist_chromosome(self.h, int(tid))
+        if not h:
+            raise BdxError("bdx_dist_chromosome(%d) failed: %s" % (tid, self.lib.bdx_dist_last_error(self.h).decode()))
+        if h not in self._chrom:
+            self._chrom[h] = BreakDancer.borrow(h, self.opts, self.libs, self.nbams)
+        return self._chrom[h]
 
     def collect_support(self, on=True):
         """the result also holds the supporting reads of every SV (every rank alike, before run)"""
@@ -167,11 +171,25 @@ class DistRun:
         return dict(ctx_records_sent=sent.value, ctx_records_received=recv.value, gathered_bytes=gathered.value, ms_total=ms_total.value,
                     ms_exchange=ms_x.value)
 
+    N_PHASES = 18
+
     def phase_ms(self):
-        out = (C.c_float * 12)()
+        out = (C.c_float * self.N_PHASES)()
         self.lib.bdx_dist_get_phase_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
-        self._chk(self.lib.bdx_dist_get_phase_ms(self.h, out, 12), "bdx_dist_get_phase_ms")
+        self._chk(self.lib.bdx_dist_get_phase_ms(self.h, out, self.N_PHASES), "bdx_dist_get_phase_ms")
         return [float(x) for x in out]
+
+    def phase_names(self):
+        return [self.lib.bdx_dist_phase_name(i).decode() for i in range(self.N_PHASES)]
+
+    def phases(self):
+        """{phase name: ms} of the last run on this rank"""
+        return {n: round(v, 3) for n, v in zip(self.phase_names(), self.phase_ms()) if n}
+
+    def prepare(self):
+        """after loading, outside the run: size the later stages' buffers for a first run (bdx_reserve's job for one context)"""
+        self._chk(self.lib.bdx_dist_prepare(self.h), "bdx_dist_prepare")
+        return self
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:

@@ -327,13 +327,17 @@ int bdx_stage_walk(bdx_ctx* ctx, size_t nregions, const bdx_region_rec* regions,
  *   bdx_dist_create_threads  the same ranks as threads of ONE process (out[world], one per device in `devices`, which may
  *                            repeat a device); every out[r] is then driven by its own thread.  Collectives are
  *                            device-to-device copies around a barrier
- *   bdx_dist_chromosome      the context of a chromosome this rank owns (created on first use): feed it with bdx_push /
- *                            bdx_acquire_batch as usual, do NOT call bdx_run on it.  ntids = number of reference sequences;
- *                            every chromosome that has reads must be owned by exactly one rank
+ *   bdx_dist_chromosome      the context that takes chromosome `tid`'s records: ONE context per rank holds all of the rank's
+ *                            chromosomes (the same handle for every tid), fed with bdx_push / bdx_acquire_batch as usual -- a rank's
+ *                            chromosomes in ASCENDING order, each chromosome's records together --; do NOT call bdx_run on it.
+ *                            ntids = number of reference sequences; every chromosome that has reads is fed to exactly one rank
+ *   bdx_dist_prepare         optional, after the chromosomes are loaded: sizes the buffers of the later stages for the prior a
+ *                            first run goes by (what bdx_reserve does for a single context), outside the run
  *   bdx_dist_run             collective: all ranks call it once their chromosomes are loaded
  *   bdx_dist_result          rank 0 after bdx_dist_run: a context whose getters (bdx_get_summary, bdx_get_counters,
  *                            bdx_get_regions, bdx_get_svs, bdx_get_sv_lists) return the whole-genome result; NULL on other ranks
- *   bdx_dist_owner           the rank that joins a name key (the routing rule of the all-to-all)
+ *   bdx_dist_owner           the rank that takes the census of a name key (the routing rule of the name census; the inter-chromosomal
+ *                            join records travel to the rank that holds the LATER of their two chromosomes)
  *   bdx_dist_plan            chromosomes -> ranks by longest-processing-time packing on `weight` (reads or length)
  * Not supported in sharded runs: a negative -s.  (The -g/-d support lists -- bdx_dist_set_collect_support -- and read names that
  * occur more than twice are served: the compact records are gathered and rank 0 walks them read by read.) */
@@ -349,6 +353,7 @@ const char* bdx_dist_last_error(const bdx_dist* d);
 int bdx_dist_rank(const bdx_dist* d);
 int bdx_dist_world(const bdx_dist* d);
 bdx_ctx* bdx_dist_chromosome(bdx_dist* d, int tid);
+int bdx_dist_prepare(bdx_dist* d);
 int bdx_dist_run(bdx_dist* d);
 bdx_ctx* bdx_dist_result(bdx_dist* d);
 /* before bdx_dist_run, on every rank alike: the result context also holds the supporting reads of every SV (bdx_get_sv_support on
@@ -360,11 +365,11 @@ int bdx_dist_set_collect_support(bdx_dist* d, int on);
  * of the whole run and of the exchange + CTX join (ms).  Any pointer may be NULL. */
 int bdx_dist_get_exchange(const bdx_dist* d, uint64_t* ctx_records_sent, uint64_t* ctx_records_received, uint64_t* gathered_bytes,
                           float* ms_total, float* ms_exchange);
-/* this rank's milliseconds of the last bdx_dist_run, phase by phase: [0] pass 1 of its chromosomes, [1] all-reduce of the statistics,
- * [2] compaction, [3] all-reduce, [4] region cut and counts, [5] all-reduce, [6] the chromosomes' own joins and the packing of the CTX records, [7] count
- * exchange, [8] census and CTX join, package for rank 0, [9] all-reduce; the all-to-all and the gather are in ms_exchange / ms_total
- * of bdx_dist_get_exchange.  A collective's figure includes waiting for the slowest rank. */
+/* this rank's milliseconds of the last bdx_dist_run, phase by phase: local phases and the collectives behind them alternate
+ * (bdx_dist_phase_name(i) names entry i; a collective's figure includes waiting for the slowest rank), then what only rank 0 does:
+ * the merge of the ranks' tables and its host walk of the components that span ranks. */
 int bdx_dist_get_phase_ms(const bdx_dist* d, float* out, int n);
+const char* bdx_dist_phase_name(int i);
 int bdx_dist_owner(uint64_t name_key, int world);
 int bdx_dist_plan(const uint64_t* weight, int ntids, int world, int* rank_of_tid);
 

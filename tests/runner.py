@@ -163,3 +163,21 @@ def compare_support(run, bd):
     np.testing.assert_array_equal(off.astype(np.int64), run.sup_off)
     np.testing.assert_array_equal(idx.astype(np.int64), run.sup_idx)
     np.testing.assert_array_equal(flg, run.sup_flag)
+
+
+def expected_ctx_travel(run, world):
+    """(inter-chromosomal reads that pass the filters, those of them that must cross ranks in a sharded run over `world` ranks): a CTX
+    read travels exactly when its mate lies on a LATER chromosome held by another rank (chromosomes dealt as ShardedRun deals them)"""
+    from breakdancer_amd.shard import plan_chromosomes
+    soa = run.merged_soa()
+    tid, mtid = soa["tid"].astype(np.int64), soa["mtid"].astype(np.int64)
+    nt = int(max(tid.max(), mtid.max())) + 1
+    counts = {int(t): int(c) for t, c in zip(*np.unique(tid, return_counts=True))}
+    ro = np.full(nt, -1, np.int64)
+    for r, tids in enumerate(plan_chromosomes(counts, world)):
+        for t in tids:
+            ro[t] = r
+    ctx = (run.cls & 0x1F) == (0x10 | 8)   # passing reads classified ARP_CTX
+    mt = np.clip(mtid, 0, nt - 1)
+    travels = ctx & (mtid > tid) & (ro[mt] >= 0) & (ro[mt] != ro[tid])
+    return int(ctx.sum()), int(travels.sum())
