@@ -7,12 +7,14 @@ The path shards by chromosome: regions never span tids (breakdancer/BreakDancer.
   independent units: no data-path collective, rank 0 only gathers the SV rows.
 * `ShardedRun`          -- one whole-genome run (what a single `breakdancer-max cfg` prints, incl. `-t`), with the
   chromosomes spread over ranks: a thin front end of the native path (dist.py, csrc/bdx_dist_impl.h), where the
-  orchestration and every exchange live -- all-reduces of the pass-1 statistics and per-chromosome totals, ONE
-  all-to-all over RCCL of the inter-chromosomal (CTX) join records to owner(hash(key)), a gather of region tables and
-  pair groups on rank 0 for the (inherently ordered) walk.
+  orchestration and every exchange live -- every rank runs ONE launch sequence over all of its chromosomes with genome-wide
+  region ids, all-reduces carry the pass-1 statistics and the per-chromosome tables, ONE all-to-all over RCCL takes an
+  inter-chromosomal (CTX) read to the rank that holds its mate's LATER chromosome, components of the region graph are walked
+  where they live, and rank 0 walks the ones that span ranks and merges the ranks' tables by order key.
 
-The numpy helpers below (owner_of, plan_chromosomes, covered_from, prefix_bases, TorchComm) restate the routing and
-bookkeeping rules of the native path so that they can be exercised without a GPU (tests/test_distributed.py).
+The numpy helpers below (owner_of, plan_chromosomes, covered_from, prefix_bases, ctx_destination, route_entries, taint_regions,
+merge_by_key, TorchComm) restate the routing and bookkeeping rules of the native path so that they can be exercised without a
+GPU (tests/test_distributed.py).
 """
 import ctypes as C
 
@@ -21,7 +23,7 @@ import numpy as np
 from . import _lib as L
 from .api import BATCH_FIELDS, BdxError, BreakDancer
 
-ENTRY_DTYPE = np.dtype([("key", "<u8"), ("order", "<u4"), ("region", "<i4"), ("meta", "<u4"), ("isize", "<i4")])
+ENTRY_DTYPE = np.dtype([("key", "<u8"), ("order", "<u4"), ("region", "<i4"), ("meta", "<u4"), ("isize", "<i4"), ("tid", "<i4"), ("mtid", "<i4")])
 
 
 def plan_chromosomes(read_counts, world):
@@ -107,12 +109,57 @@ class TorchComm:
         return out
 
 
-def route_entries(entries, world):
-    """split a structured ENTRY_DTYPE array by owner rank -> list of uint8 chunks (stable order within a chunk)"""
-    if world == 1:
-        return [entries.view(np.uint8).reshape(-1)]
-    own = owner_of(entries["key"], world)
-    return [np.ascontiguousarray(entries[own == d]).view(np.uint8).reshape(-1) for d in range(world)]
+def ctx_destination(tid, mtid, owner_of_tid, me):
+    """where an inter-chromosomal read's join record travels (k7_exchange.hip, ctx_destination): the rank that holds its mate's
+    chromosome if that chromosome comes LATER in the stream and is another rank's -- the pair is observed where its second mate is --,
+    else -1 (the record stays: its mate joins it here, or the mate's record comes to it)"""
+    tid, mtid = np.asarray(tid, np.int64), np.asarray(mtid, np.int64)
+    own = np.asarray(owner_of_tid, np.int64)
+    ok = (mtid > tid) & (mtid < len(own))
+    dest = np.where(ok, own[np.clip(mtid, 0, len(own) - 1)], -1)
+    return np.where((dest >= 0) & (dest != me), dest, -1)
+
+
+def route_entries(entries, owner_of_tid, me, world):
+    """split a rank's CTX entries (ENTRY_DTYPE incl. tid / mtid) by destination -> (list of uint8 chunks per rank, entries that stay)"""
+    dest = ctx_destination(entries["tid"], entries["mtid"], owner_of_tid, me)
+    chunks = [np.ascontiguousarray(entries[dest == d]).view(np.uint8).reshape(-1) for d in range(world)]
+    return chunks, entries[dest < 0]
+
+
+def taint_regions(groups_lo_hi, owner_of_region, n_regions):
+    """regions that a (gate-passing) pair group connects ACROSS ranks: both of its regions; every rank learns them through an
+    all-reduce and leaves their components to rank 0's walk (K6Arrays::taint)"""
+    t = np.zeros(n_regions, np.uint8)
+    own = np.asarray(owner_of_region)
+    for lo, hi in groups_lo_hi:
+        if own[lo] != own[hi]:
+            t[lo] = 1
+            t[hi] = 1
+    return t
+
+
+def order_key(T, start):
+    """order key of an SV row (k6_finish_kernel): the vertex it is placed at, before that vertex's own rows unless the traversal
+    started there, then the start vertex"""
+    T, start = np.asarray(T, np.uint64), np.asarray(start, np.uint64)
+    return (T << np.uint64(34)) | ((T == start).astype(np.uint64) << np.uint64(33)) | (start << np.uint64(7))
+
+
+def merge_by_key(keys_per_rank):
+    """rank 0's merge of the ranks' tables (k9_merge_rank_kernel): every table is sorted by key; row i of rank q goes to i + the
+    rows of the other tables in front of it (equal keys: the lower rank first).  Returns [(rank, row)] in final order."""
+    n = sum(len(k) for k in keys_per_rank)
+    out = [None] * n
+    for q, kq in enumerate(keys_per_rank):
+        pos = np.arange(len(kq))
+        for p, kp in enumerate(keys_per_rank):
+            if p != q and len(kp):
+                pos = pos + np.searchsorted(kp, kq, side="right" if p < q else "left")
+        for i, at in enumerate(pos.tolist()):
+            assert out[at] is None
+            out[at] = (q, i)
+    return out
 
 
 def covered_from(ref_len_per_bam):

@@ -1,8 +1,9 @@
 """Worker for the multi-process tests.  Launched by torch.distributed.run with N processes.
 
-mode "comm" (CPU, gloo): exercises breakdancer_amd.shard's collectives -- planning, counter all-reduce, base
-all-gather, the all-to-all routing of join entries, the gather to rank 0 -- with a numpy stand-in for the join so that
-the result can be checked against a single-process computation.  No GPU, no libbdx compute calls.
+mode "comm" (CPU, gloo): exercises breakdancer_amd.shard's restatement of the native sharded run's rules -- planning, counter
+all-reduce, per-chromosome bases, the all-to-all of the inter-chromosomal join entries to the rank of the LATER chromosome,
+the join there (own + foreign entries), the merge of the ranks' tables by order key on rank 0, the taint rule -- with a numpy
+stand-in for the join so that the result can be checked against a single-process computation.  No GPU, no libbdx compute calls.
 
 (The native multi-rank run needs GPUs: tests/test_gpu_sharded.py drives it with the ranks as threads on one device.)"""
 import json
@@ -18,7 +19,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 
 def numpy_join(ent):
-    """reference join on the routed entries: pairs = two entries with one key; second-observed = larger order"""
+    """reference join on a set of entries: pairs = two entries with one key; second-observed = larger order (stream order)"""
     out = {}
     if len(ent) == 0:
         return out
@@ -67,25 +68,44 @@ def mode_comm(out_path):
     for t in range(ntid):
         assert (bases[t] == acc).all()
         acc += tot[t]
-    # join entries: pairs whose mates live on different chromosomes (hence possibly different ranks)
+    # join entries: pairs whose mates live on different chromosomes (hence possibly different ranks).  Stream order follows the
+    # chromosome: a read on a later chromosome is observed later.
+    owner = np.full(ntid, -1, np.int64)
+    for r, tids in enumerate(plan):
+        owner[tids] = r
     npairs = 4000
     keys = rng.integers(1, 2**63, npairs, dtype=np.int64).astype(np.uint64)
-    ta, tb = rng.integers(0, ntid, npairs), rng.integers(0, ntid, npairs)
+    ta = rng.integers(0, ntid, npairs)
+    tb = (ta + rng.integers(1, ntid, npairs)) % ntid          # the mate's chromosome: another one
     ent_all = np.zeros(2 * npairs, shard.ENTRY_DTYPE)
     ent_all["key"] = np.concatenate([keys, keys])
-    ent_all["order"] = rng.permutation(2 * npairs).astype(np.uint32)
-    tid_of = np.concatenate([ta, tb])
-    ent_all["region"] = tid_of * 100 + rng.integers(0, 100, 2 * npairs)
-    ent_all["meta"] = rng.integers(1, 9, 2 * npairs) | (rng.integers(0, 3, 2 * npairs) << 8)
+    ent_all["tid"] = np.concatenate([ta, tb])
+    ent_all["mtid"] = np.concatenate([tb, ta])
+    ent_all["order"] = ent_all["tid"].astype(np.uint32) * np.uint32(100000) + rng.permutation(2 * npairs).astype(np.uint32)
+    ent_all["region"] = ent_all["tid"] * 100 + rng.integers(0, 100, 2 * npairs)
+    ent_all["meta"] = 8 | (rng.integers(0, 3, 2 * npairs) << 8)
     ent_all["isize"] = rng.integers(0, 5000, 2 * npairs)
-    mine_ent = ent_all[np.isin(tid_of, mine)]
-    recv = comm.alltoall_bytes(shard.route_entries(mine_ent, world))
-    got = np.concatenate([np.frombuffer(r.tobytes(), shard.ENTRY_DTYPE) for r in recv])
-    assert (shard.owner_of(got["key"], world) == rank).all()          # routed to the owner
-    uk, cnts = np.unique(got["key"], return_counts=True)
-    assert (cnts == 2).all()                                           # both mates met on this rank
-    part = numpy_join(got)
+    mine_ent = ent_all[np.isin(ent_all["tid"], mine)]
+    chunks, stay = shard.route_entries(mine_ent, owner, rank, world)
+    assert len(chunks[rank]) == 0                                      # nothing travels to oneself
+    recv = comm.alltoall_bytes(chunks)
+    foreign = np.concatenate([np.frombuffer(r.tobytes(), shard.ENTRY_DTYPE) for r in recv])
+    # a foreign entry's mate chromosome is one of mine and comes later than its own: it is the first-observed mate of a pair
+    assert np.isin(foreign["mtid"], mine).all() and (foreign["mtid"] > foreign["tid"]).all()
+    sent = sum(len(c) for c in chunks) // shard.ENTRY_DTYPE.itemsize
+    assert int(comm.allreduce_sum(np.array([sent], np.uint64))[0]) <= npairs   # at most one mate of a pair travels
+    # every pair whose SECOND mate is mine can be joined here: own entries + foreign ones
+    here = np.concatenate([mine_ent, foreign])
+    part = {k: v for k, v in numpy_join(here).items() if k[1] // 100 in mine}   # keyed by the later region = the second mate's
     gathered = comm.gather_obj(part, root=0)
+    # the tables of the ranks, each sorted by order key, merge into the genome's order (start vertices belong to one rank each)
+    nreg = ntid * 100
+    starts_all = np.sort(rng.choice(nreg, 600, replace=False))
+    T_all = np.where(rng.random(600) < 0.2, (starts_all // 101 + 1) * 101, starts_all)   # some rows are placed at a later window's first vertex
+    keys_all = shard.order_key(T_all, starts_all)
+    mine_rows = np.isin(starts_all // 100, mine)
+    my_keys = np.sort(keys_all[mine_rows])
+    tables = comm.gather_obj(my_keys, root=0)
     if rank == 0:
         merged = {}
         for d in gathered:
@@ -95,6 +115,14 @@ def mode_comm(out_path):
                 c[1] += v[1]
         truth = numpy_join(ent_all)
         assert merged == truth and sum(v[0] for v in truth.values()) == npairs
+        order = shard.merge_by_key(tables)
+        got = np.array([tables[q][i] for q, i in order], dtype=np.uint64)
+        assert (got == np.sort(keys_all)).all()
+        # taint: a group between regions of two ranks taints both
+        own_reg = owner[np.arange(nreg) // 100]
+        t = shard.taint_regions([(k[0], k[1]) for k in truth], own_reg, nreg)
+        for lo, hi, _, _ in truth:
+            assert (t[lo] == 1 and t[hi] == 1) == (own_reg[lo] != own_reg[hi]) or (t[lo] and t[hi])
         json.dump({"ok": True, "world": world, "groups": len(truth)}, open(out_path, "w"))
     dist.barrier()
     dist.destroy_process_group()
