@@ -1156,10 +1156,12 @@ int do_k6(bdx_ctx* c, bool force_host, int part = 0) {
         size_t p2 = 1;
         while (p2 < a.sv_cap) p2 <<= 1;
         const size_t svc = a.sv_cap;
-        HIPCHK(c, c->b_ins.ensure(p2 * 12 + svc * 8 + (svc + 1) * 16 + 64));
+        const size_t nsort = std::min<size_t>(svc, kK6RankSortMax);   // (k6_ranksort_kernel's output: lists of that many entries at most)
+        HIPCHK(c, c->b_ins.ensure(p2 * 12 + svc * 8 + (svc + 1) * 16 + nsort * 12 + 64));
         a.old_key = c->b_ins.as<uint64_t>(); a.hs_key_dev = a.old_key + p2;
         a.old_slot = (uint32_t*)(a.hs_key_dev + svc); a.ins_T = a.old_slot + p2; a.ins_src = a.ins_T + svc + 1;
         a.ins_pre_l = a.ins_src + svc + 1; a.ins_pre_c = a.ins_pre_l + svc + 1;
+        a.sorted_key = (uint64_t*)(((uintptr_t)(a.ins_pre_c + svc + 1) + 7) & ~(uintptr_t)7); a.sorted_slot = (uint32_t*)(a.sorted_key + nsort);
     }
     a.sv_begin = c->b_sv_src.as<uint2>(); a.sv_src = (uint32_t*)(a.sv_begin + a.sv_cap); a.ltail = c->b_ltail.as<double>();
     a.d_lib_index = c->b_dlists.as<int32_t>(); a.d_cn_key = a.d_lib_index + a.term_cap; a.d_cn_value = (float*)(a.d_cn_key + a.cn_cap);
@@ -2044,6 +2046,12 @@ int bdx_classify(const bdx_opts* opts, const bdx_lib* libs, int nlibs, const bdx
     if (rc == BDX_OK) rc = bdx_get_read_class(c, cls_out, b->n);
     bdx_destroy(c);
     return rc;
+}
+
+int bdx_warm_up(int device) {
+    if (hipSetDevice(device) != hipSuccess) return BDX_EHIP;
+    warm_k1(nullptr); warm_k2(nullptr); warm_k3(nullptr); warm_k4(nullptr); warm_k5(nullptr); warm_k6(nullptr); warm_k7(nullptr); warm_k9(nullptr);
+    return hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess ? BDX_OK : BDX_EHIP;
 }
 
 int bdx_poisson_log_upper_tail(const double* lambda, const int32_t* k, double* out, size_t n, int device) {

@@ -217,13 +217,16 @@ struct bdx_dist {
     size_t n_at_last = 0;
     bool use_check = false;
     DevBuf b_words, b_tab, b_send, b_recv, b_pack, b_all, b_nsend, b_nrecv, b_ntab, b_nflag, b_foreign, b_rg_rec, b_rg_pk, b_x, b_merge;
+    PinBuf h_words;                  // staging of the all-reduces' words (pinned: the copies either side of a collective are asynchronous)
     PinBuf h_tab;                    // what the small kernels report: per-chromosome tables, counts, ready words
+    hipEvent_t ev_side = nullptr;    // the name census runs on the context's second stream, beside the joins
     uint32_t seq = 0;
     std::string err;
     uint64_t ctx_sent = 0, ctx_received = 0, gathered_bytes = 0;
     float ms_total = 0, ms_exchange = 0;
     bool ran = false;
     float phase_ms[kDistPhases] = {0};   // bdx_dist_get_phase_ms: where the last run's time went on this rank
+    bool table_lent = false;         // (one rank) the result context holds this rank's pinned table buffers until the next run
     bool collect_support = false;    // bdx_dist_set_collect_support: the supporting reads of every SV (-g / -d) come with the result
 };
 
@@ -248,10 +251,13 @@ int dfail(bdx_dist* d, int code, const std::string& msg) {
 int allreduce_host(bdx_dist* d, std::vector<uint64_t>& v, hipStream_t s) {
     if (v.empty()) return BDX_OK;
     DHIP(d, d->b_words.ensure(v.size() * 8));
-    DHIP(d, hipMemcpyAsync(d->b_words.p, v.data(), v.size() * 8, hipMemcpyHostToDevice, s));
+    DHIP(d, d->h_words.ensure(v.size() * 8));
+    memcpy(d->h_words.p, v.data(), v.size() * 8);
+    DHIP(d, hipMemcpyAsync(d->b_words.p, d->h_words.p, v.size() * 8, hipMemcpyHostToDevice, s));
     if (!d->comm->allreduce_u64(d->b_words.as<uint64_t>(), v.size(), s)) return dfail(d, BDX_EHIP, d->comm->err);
-    DHIP(d, hipMemcpyAsync(v.data(), d->b_words.p, v.size() * 8, hipMemcpyDeviceToHost, s));
+    DHIP(d, hipMemcpyAsync(d->h_words.p, d->b_words.p, v.size() * 8, hipMemcpyDeviceToHost, s));
     DHIP(d, hipStreamSynchronize(s));
+    memcpy(v.data(), d->h_words.p, v.size() * 8);
     return BDX_OK;
 }
 
@@ -271,20 +277,30 @@ int dist_create_common(bdx_dist** out, const bdx_opts* opts, const bdx_lib* libs
     if (rc == BDX_OK && d->comm->rank == 0) rc = bdx_create(&d->util, opts, libs, nlibs, nbams, ntids, w0, device);
     if (rc != BDX_OK) { if (d->reads) bdx_destroy(d->reads); delete d; return rc; }
     d->reads->force_direct_join = true;
+    if (hipEventCreateWithFlags(&d->ev_side, hipEventDisableTiming) != hipSuccess) { bdx_dist_destroy(d); return BDX_EHIP; }
     *out = d;
     return BDX_OK;
 }
 
+inline size_t nkeys_words(int nkeys) { return (size_t)nkeys + 1; }
+
 // pinned report area of a rank: ready words, then the tables the small kernels write
 struct TabLayout {
-    size_t flags = 0, tidtab = 0, first = 0, rtab = 0, cnts = 0, misc = 0, words = 0;
-    TabLayout(int ntids, int ncols, int world) {
+    size_t flags = 0, tidtab = 0, first = 0, rtab = 0, cnts = 0, misc = 0, up_off = 0, up_tail = 0, up_misc = 0, up_cur = 0, up_stats = 0, words = 0;
+    TabLayout(int ntids, int ncols, int nkeys, int ncnt, int world) {
         size_t o = 16;
         tidtab = o; o += (size_t)(ntids + 1) * (1 + ncols) + 2;
         first = o; o += (size_t)ntids * 4;
         rtab = o; o += (size_t)ntids + 3;
         cnts = o; o += (size_t)2 * world;
         misc = o; o += 16;
+        // staging of the small tables that go UP to the device: pinned, so that the copies are asynchronous and the vectors they were
+        // built in need not outlive them (every table has its own place: nothing is overwritten within a run)
+        up_off = o; o += (size_t)ntids * (1 + nkeys);
+        up_tail = o; o += (size_t)ntids * 4;
+        up_misc = o; o += (size_t)3 * ntids + 1;
+        up_cur = o; o += (size_t)2 * world;
+        up_stats = o; o += (size_t)2 + ncnt + 64;
         words = o;
     }
 };
@@ -350,6 +366,8 @@ void bdx_dist_destroy(bdx_dist* d) {
                       &d->b_rg_rec, &d->b_rg_pk, &d->b_x, &d->b_merge})
         b->release();
     d->h_tab.release();
+    d->h_words.release();
+    if (d->ev_side) (void)hipEventDestroy(d->ev_side);
     delete d;
 }
 
@@ -375,8 +393,22 @@ int bdx_dist_prepare(bdx_dist* d) {
     if (!d) return BDX_EINVAL;
     bdx_ctx* c = d->reads;
     DHIP(d, hipSetDevice(d->device));
+    if (bdx_warm_up(d->device) != BDX_OK) return dfail(d, BDX_EHIP, "bdx_warm_up");
     // the later stages' buffers for the prior a first run goes by (bdx_reserve does the same for a single context), with K6's
     // per-region arrays sized for the genome's regions rather than this rank's
+    {
+        const int ncols = 2 + d->nkeys, ncnt = d->nlibs * kNumFlags + d->nlibs + d->nbams, world = d->comm->world;
+        const TabLayout L(d->ntids, ncols, d->nkeys, ncnt, world);
+        DHIP(d, d->h_tab.ensure(L.words * 4));
+        DHIP(d, d->h_words.ensure(((size_t)d->ntids * (ncols + 4) + ncnt + d->nbams + 2 * (size_t)world * world + 64) * 8));
+        DHIP(d, d->b_words.ensure(((size_t)d->ntids * (ncols + 4) + ncnt + d->nbams + 2 * (size_t)world * world + 64) * 8));
+        DHIP(d, d->b_tab.ensure(((size_t)d->ntids * (nkeys_words(d->nkeys) + 12) + 8 * (size_t)world + 64) * 4));
+        if (c->n && c->n < ((size_t)1 << 32)) {   // pass 1's tables for the reads that are loaded (a store that grew while it was filled lost them)
+            const int rc = pass1_prepare(c, (uint32_t)((c->n + kTile - 1) / kTile));
+            if (rc != BDX_OK) return dfail(d, rc, c->err);
+            c->k1_live = false;
+        }
+    }
     if (c->n >= (1u << 20) && !c->ran) {
         const uint64_t prior = (uint64_t)c->n / 32 + 4096;
         if (prior <= kMaxAnomalous) {
@@ -397,6 +429,13 @@ int bdx_dist_prepare(bdx_dist* d) {
             while (slots < 2 * nn) slots <<= 1;
             DHIP(d, d->b_ntab.ensure((size_t)slots * 16));
             DHIP(d, d->b_pack.ensure(nn * 40)); DHIP(d, d->b_all.ensure(nn * 40));
+            DHIP(d, d->b_foreign.ensure(nn * 20 / 8 + 64));
+            DHIP(d, d->b_send.ensure(nn * 4)); DHIP(d, d->b_recv.ensure(nn * 4));   // (an eighth of the anomalous reads inter-chromosomal and travelling)
+            if (d->comm->rank == 0) {   // the genome's region table in pinned memory (regions: about a tenth of the anomalous reads)
+                const size_t nreg = (size_t)c->n / 256 + 4096;
+                DHIP(d, c->h_regs.ensure(nreg * sizeof(RegionRec)));
+                DHIP(d, c->h_pk.ensure(nreg * 2 * d->nkeys * 4));
+            }
         }
     }
     return BDX_OK;
@@ -477,9 +516,12 @@ static int agreed_failure(bdx_dist* d, const RunStatus& st, const uint64_t* word
 
 // the result of a rank's context becomes the result context's: the pinned buffers the device assembled the table in change
 // hands (no copy), the counters are taken over
-static void adopt_table(bdx_ctx* U, bdx_ctx* C) {
+static void swap_table_buffers(bdx_ctx* U, bdx_ctx* C) {
     std::swap(U->h_sv_out, C->h_sv_out); std::swap(U->h_lib_index, C->h_lib_index); std::swap(U->h_lib_pairs, C->h_lib_pairs);
     std::swap(U->h_cn_key, C->h_cn_key); std::swap(U->h_cn_value, C->h_cn_value); std::swap(U->h_ltail_dev, C->h_ltail_dev);
+}
+static void adopt_table(bdx_ctx* U, bdx_ctx* C) {
+    swap_table_buffers(U, C);
     std::swap(U->walk, C->walk); std::swap(U->log_tail, C->log_tail);
     U->materialized = C->materialized;
     U->n_sv_total = C->n_sv_total; U->n_terms_total = C->n_terms_total; U->n_cn_total = C->n_cn_total; U->n_printed = C->n_printed;
@@ -501,6 +543,12 @@ int bdx_dist_run(bdx_dist* d) {
     hipStream_t s = C->stream;
     d->ran = false;
     d->ctx_sent = d->ctx_received = d->gathered_bytes = 0;
+    if (d->table_lent && U) {   // (the previous result is history: its buffers go back to the context that fills them)
+        swap_table_buffers(U, C);
+        U->ran = false;
+        d->table_lent = false;
+    }
+    if (U) { U->reg = nullptr; U->nreg = 0; U->rpk = nullptr; }
     ++d->seq;
     comm.begin_run();
     RunStatus st;
@@ -554,7 +602,7 @@ int bdx_dist_run(bdx_dist* d) {
     };
 
     // the report area (pinned) and the small device tables
-    const TabLayout L(ntids, ncols, world);
+    const TabLayout L(ntids, ncols, nkeys, ncnt, world);
     DHIP(d, d->h_tab.ensure(L.words * 4));
     uint32_t* H = d->h_tab.as<uint32_t>();
     volatile uint32_t* flags = (volatile uint32_t*)H;
@@ -575,15 +623,15 @@ int bdx_dist_run(bdx_dist* d) {
         C->table_in_hbm = world > 1;
         C->groups_in_hbm = world > 1;
         C->k6_cap = 0; C->k6_r_rec = nullptr; C->k6_r_pk = nullptr; C->k6_taint = nullptr; C->k3_tid_tail = nullptr;
-        DCTX(d, C, do_pass1(C, 0, true, false));
+        DCTX(d, C, do_pass1(C, 0, false, false));   // (its record is waited for together with the chromosome table)
         TidTableParams tp{};
         tp.tid = C->d.tid; tp.lib = C->d.lib; tp.cls = C->b_cls.as<uint8_t>(); tp.n = C->n; tp.ntiles = C->ntiles; tp.tstride = C->tstride;
         tp.ntids = ntids; tp.nkeys = nkeys; tp.nlibs = nlibs; tp.ncols = ncols; tp.libs = C->b_libs.as<DevLib>();
         tp.tile_tot = C->b_tile_tot.as<uint32_t>(); tp.tile_pre = C->b_tile_pre.as<uint32_t>(); tp.chunk_base = C->fp_deferred.chunk_base;
         tp.chunk_super = C->fp_deferred.chunk_super; tp.p1 = C->b_p1.as<Pass1>(); tp.out = H + L.tidtab;
-        trace("pass 1");
         launch_k9_tid_table(tp, s);
         launch_k9_signal(H + 0, d->seq, s);
+        DCTX(d, C, wait_pass1(C));
         if (!wait_word(flags + 0, d->seq)) DHIP(d, hipStreamSynchronize(s));
         trace("chromosome table");
         memcpy(tidtab.data(), H + L.tidtab, tidtab.size() * 4);
@@ -636,61 +684,106 @@ int bdx_dist_run(bdx_dist* d) {
         if (tot(t, 0) > 0) last_anom_tid = t;
     const uint32_t na = C->p1.n_anom;   // this rank's
 
-    // ---- compaction; the counters of every chromosome start where the chromosomes in front of it (anybody's) left them.
-    // C2: every chromosome's first anomalous read ----
-    std::vector<uint64_t> v2((size_t)ntids * 3, 0);
+    // ---- compaction; the counters of every chromosome start where the chromosomes in front of it (anybody's) left them; what the
+    // exchange will carry, per destination.  C2: every chromosome's first anomalous read, and the exchange's count matrices ----
+    const size_t W2 = (size_t)world * world;
+    const size_t at_mat = (size_t)ntids * 3;
+    std::vector<uint64_t> v2(at_mat + 2 * W2, 0);   // (send-count matrices of the CTX records and the census records: row = sender)
+    std::vector<uint32_t> h_cnt(world, 0), h_ncnt(world, 0);
+    ExchangeSrc xs{};
+    uint32_t* UP = H;   // (the staging places of L.up_*)
     phase([&]() -> int {
-        DCTX(d, C, set_pass1(C, cnt_g.data(), covered, window, true));
-        DHIP(d, hipMemcpyAsync(C->b_cnt.p, cnt_g.data(), (size_t)ncnt * 4, hipMemcpyHostToDevice, s));
-        DHIP(d, hipMemcpyAsync(C->b_kdens.p, C->key_density.data(), C->key_density.size() * 4, hipMemcpyHostToDevice, s));
+        DCTX(d, C, set_pass1(C, cnt_g.data(), covered, window, false));
+        {   // the statistics every kernel from here on runs with: window and covered length (Pass1's first words), flag histogram, densities
+            uint32_t* st_up = UP + L.up_stats;
+            st_up[0] = covered; st_up[1] = (uint32_t)window;
+            memcpy(st_up + 2, cnt_g.data(), (size_t)ncnt * 4);
+            memcpy(st_up + 2 + ncnt, C->key_density.data(), C->key_density.size() * 4);
+            DHIP(d, hipMemcpyAsync(C->b_p1.p, st_up, 8, hipMemcpyHostToDevice, s));
+            DHIP(d, hipMemcpyAsync(C->b_cnt.p, st_up + 2, (size_t)ncnt * 4, hipMemcpyHostToDevice, s));
+            DHIP(d, hipMemcpyAsync(C->b_kdens.p, st_up + 2 + ncnt, C->key_density.size() * 4, hipMemcpyHostToDevice, s));
+        }
         DCTX(d, C, do_compact(C, 0, nullptr, true));
         trace("compaction");
         if (!na) { C->k4 = K4Arrays{}; return BDX_OK; }
-        std::vector<uint32_t> up((size_t)ntids * (1 + nkeys) + ntids + 1, 0);
-        for (int t = 0; t < ntids; ++t) {
-            const uint32_t* a = &tidtab[(size_t)t * (1 + ncols)];
-            for (int k = 0; k < 1 + nkeys; ++k) up[(size_t)t * (1 + nkeys) + k] = (uint32_t)base[(size_t)t * tw + 1 + k] - a[1 + 1 + k];
+        {
+            uint32_t* up = UP + L.up_off;
+            for (int t = 0; t < ntids; ++t) {
+                const uint32_t* a = &tidtab[(size_t)t * (1 + ncols)];
+                for (int k = 0; k < 1 + nkeys; ++k) up[(size_t)t * (1 + nkeys) + k] = (uint32_t)base[(size_t)t * tw + 1 + k] - a[1 + 1 + k];
+            }
+            DHIP(d, hipMemcpyAsync(T + o_off, up, (size_t)ntids * (1 + nkeys) * 4, hipMemcpyHostToDevice, s));
+            uint32_t* um = UP + L.up_misc;   // owner [ntids] | first read of every chromosome in this context [ntids + 1]   (roff follows later)
+            for (int t = 0; t < ntids; ++t) { um[t] = (uint32_t)owner[t]; um[(size_t)ntids + t] = tidtab[(size_t)t * (1 + ncols)]; }
+            um[(size_t)2 * ntids] = tidtab[(size_t)ntids * (1 + ncols)];
+            DHIP(d, hipMemcpyAsync(T + o_owner, um, ((size_t)2 * ntids + 1) * 4, hipMemcpyHostToDevice, s));
+            DHIP(d, hipMemsetAsync(T + o_cnt, 0, (size_t)world * 16 + 16, s));
         }
-        DHIP(d, hipMemcpyAsync(T + o_off, up.data(), (size_t)ntids * (1 + nkeys) * 4, hipMemcpyHostToDevice, s));
         memset(H + L.first, 0, (size_t)ntids * 16);
         launch_k9_rebase(C->cp, &C->b_p1.as<Pass1>()->n_anom, na, nkeys, T + o_off, H + L.first, s);
-        launch_k9_signal(H + 1, d->seq, s);
+        xs.key = C->cp.key; xs.check = C->cp.check; xs.meta = C->cp.meta; xs.tid = C->cp.tid; xs.idx = C->cp.idx; xs.mtid_col = C->d.mtid;
+        xs.region_of = nullptr; xs.n_ptr = &C->b_p1.as<Pass1>()->n_anom; xs.owner_of_tid = (const int32_t*)(T + o_owner);
+        xs.ntids = ntids; xs.me = rank; xs.world = (uint32_t)world;
+        launch_k7_count(xs, na, T + o_cnt, s);
+        launch_k9_report(T + o_cnt, H + L.cnts, 2 * (uint32_t)world, H + 1, d->seq, s);
         if (!wait_word(flags + 1, d->seq)) DHIP(d, hipStreamSynchronize(s));
-        DHIP(d, hipStreamSynchronize(s));   // (`up` goes out of use)
-        trace("rebase");
+        trace("rebase and counts");
         for (int t = 0; t < ntids; ++t) {
             const uint32_t* f = H + L.first + (size_t)t * 4;
             if (f[0]) { v2[(size_t)t * 3] = 1; v2[(size_t)t * 3 + 1] = f[1]; v2[(size_t)t * 3 + 2] = f[2]; }
         }
+        for (int q = 0; q < world; ++q) { h_cnt[q] = H[L.cnts + q]; h_ncnt[q] = H[L.cnts + world + q]; }
+        for (int q = 0; q < world; ++q) { v2[at_mat + (size_t)rank * world + q] = h_cnt[q]; v2[at_mat + W2 + (size_t)rank * world + q] = h_ncnt[q]; }
         return BDX_OK;
     });
     rc = exchange(v2);
     if (rc != BDX_OK) return rc;
+    std::vector<size_t> scount(world), sdispl(world), rcount(world), rdispl(world);
+    std::vector<size_t> nscount(world), nsdispl(world), nrcount(world), nrdispl(world);   // the name census: two words per read
+    size_t nsend = 0, nrecv = 0, nnsend = 0, nnrecv = 0;
+    constexpr size_t kxw = sizeof(ExchangeEntry) / 8;
+    for (int q = 0; q < world; ++q) { scount[q] = (size_t)h_cnt[q] * kxw; sdispl[q] = nsend * kxw; nsend += h_cnt[q]; }
+    for (int q = 0; q < world; ++q) { nscount[q] = (size_t)h_ncnt[q] * 2; nsdispl[q] = nnsend * 2; nnsend += h_ncnt[q]; }
+    for (int q = 0; q < world; ++q) { rcount[q] = (size_t)v2[at_mat + (size_t)q * world + rank] * kxw; rdispl[q] = nrecv * kxw; nrecv += v2[at_mat + (size_t)q * world + rank]; }
+    for (int q = 0; q < world; ++q) { nrcount[q] = (size_t)v2[at_mat + W2 + (size_t)q * world + rank] * 2; nrdispl[q] = nnrecv * 2; nnrecv += v2[at_mat + W2 + (size_t)q * world + rank]; }
+    {
+        // (the column sums are the same table on every rank: the limits trip everywhere at once)
+        for (int r = 0; r < world; ++r) {
+            uint64_t col = 0, ncol = 0;
+            for (int q = 0; q < world; ++q) { col += v2[at_mat + (size_t)q * world + r]; ncol += v2[at_mat + W2 + (size_t)q * world + r]; }
+            if (col > (1u << 28) || ncol > 0x7FFFFFFFull) return dfail(d, BDX_ELIMIT, "too many inter-chromosomal join records / names on one rank");
+        }
+    }
 
     // ---- regions; the first anomalous read of the next chromosome that has one closes a chromosome's last candidate.  C3 ----
     std::vector<uint64_t> v3((size_t)ntids + 1, 0);
     std::vector<uint32_t> rtab((size_t)ntids + 3, 0);   // this rank's regions: first region of every chromosome, count, last_maxq
     phase([&]() -> int {
+        // (the exchange's buffers, sized by counts that are known since C2: a rank without reads still receives census records)
+        DHIP(d, d->b_send.ensure(std::max<size_t>(nsend, 1) * sizeof(ExchangeEntry)));
+        DHIP(d, d->b_nsend.ensure(std::max<size_t>(nnsend, 1) * 16));
+        DHIP(d, d->b_recv.ensure(std::max<size_t>(nrecv, 1) * sizeof(ExchangeEntry)));
+        DHIP(d, d->b_nrecv.ensure(std::max<size_t>(nnrecv, 1) * 16));
         if (!na) return BDX_OK;
-        std::vector<uint32_t> tails((size_t)ntids * 4, 0);
         {
+            uint32_t* tails = UP + L.up_tail;
             int nx = -1;
             for (int t = ntids - 1; t >= 0; --t) {
                 uint32_t* q = &tails[(size_t)t * 4];
                 q[0] = nx >= 0 ? 1u : 0u;
                 q[1] = nx >= 0 ? (uint32_t)v2[(size_t)nx * 3 + 1] : 0u;
                 q[2] = nx >= 0 ? (uint32_t)v2[(size_t)nx * 3 + 2] : (uint32_t)base[(size_t)ntids * tw + 1];
+                q[3] = 0;
                 if (v2[(size_t)t * 3]) nx = t;
             }
+            DHIP(d, hipMemcpyAsync(T + o_tail, tails, (size_t)ntids * 16, hipMemcpyHostToDevice, s));
         }
-        DHIP(d, hipMemcpyAsync(T + o_tail, tails.data(), tails.size() * 4, hipMemcpyHostToDevice, s));
         C->k3_tid_tail = T + o_tail;
         DCTX(d, C, do_cut(C, 0, 0, 0, false, true));
         trace("region cut");
         launch_k9_tid_regions(C->b_r_rec.as<RegionRec>(), C->b_counts.as<StageCounts>(), ntids, H + L.rtab, s);
         launch_k9_signal(H + 2, d->seq, s);
         if (!wait_word(flags + 2, d->seq)) DHIP(d, hipStreamSynchronize(s));
-        DHIP(d, hipStreamSynchronize(s));   // (`tails` goes out of use)
         memcpy(rtab.data(), H + L.rtab, rtab.size() * 4);
         for (int t = 0; t < ntids; ++t) v3[t] = rtab[t + 1] - rtab[t];
         if (last_anom_tid >= 0 && owner[last_anom_tid] == rank) v3[ntids] = rtab[ntids + 2];
@@ -727,82 +820,6 @@ int bdx_dist_run(bdx_dist* d) {
         U->collect_support = false;
         if (!U->walk_scratch) U->walk_scratch = walk_scratch_new();
     }
-
-    const auto t_x0 = std::chrono::steady_clock::now();
-    // ---- genome-wide region ids; the exchange's counts ----
-    std::vector<uint32_t> h_cnt(world, 0), h_ncnt(world, 0);
-    std::vector<size_t> scount(world), sdispl(world), rcount(world), rdispl(world);
-    std::vector<size_t> nscount(world), nsdispl(world), nrcount(world), nrdispl(world);   // the name census: two words per read
-    size_t nsend = 0, nrecv = 0, nnsend = 0, nnrecv = 0;
-    constexpr size_t kxw = sizeof(ExchangeEntry) / 8;
-    uint64_t* X = nullptr;          // [NW] window read lengths | taint bytes (capG) | status words
-    const size_t x_taint = NW, x_words = (size_t)NW + ((size_t)capG + 7) / 8;
-    RegionRec* regs = nullptr;      // rank 0: the genome's region table (pinned: the copy runs beside the joins)
-    uint32_t* pk = nullptr;
-    bool regs_pending = false;
-    ExchangeSrc xs{};
-    phase([&]() -> int {
-        if (!NR) return BDX_OK;
-        DHIP(d, d->b_rg_rec.ensure((size_t)NR * sizeof(RegionRec)));
-        DHIP(d, d->b_rg_pk.ensure(std::max<size_t>((size_t)NR * nkeys2 * 4, 16)));
-        DHIP(d, C->b_out_deg.ensure((size_t)capG * 6 * 4));
-        DHIP(d, d->b_x.ensure((x_words + (size_t)world + 8) * 8));
-        X = d->b_x.as<uint64_t>();
-        DHIP(d, hipMemsetAsync(d->b_rg_rec.p, 0, (size_t)NR * sizeof(RegionRec), s));
-        DHIP(d, hipMemsetAsync(X, 0, (x_words + (size_t)world) * 8, s));
-        {
-            std::vector<uint32_t> up((size_t)2 * ntids + ntids + 1, 0);
-            for (int t = 0; t < ntids; ++t) {
-                up[t] = (uint32_t)rbase[t] - rtab[t];            // roff
-                up[(size_t)ntids + t] = (uint32_t)owner[t];      // owner (int32)
-                up[(size_t)2 * ntids + t] = tidtab[(size_t)t * (1 + ncols)];   // first read of the chromosome in this context
-            }
-            up[(size_t)3 * ntids] = tidtab[(size_t)ntids * (1 + ncols)];
-            DHIP(d, hipMemcpyAsync(T + o_roff, up.data(), up.size() * 4, hipMemcpyHostToDevice, s));
-            DHIP(d, hipMemsetAsync(T + o_cnt, 0, (size_t)world * 16 + 16, s));
-            DHIP(d, hipStreamSynchronize(s));
-        }
-        GlobalizeParams gp{};
-        gp.tid = C->cp.tid; gp.region_of = C->k3.region_of; gp.n_ptr = &C->b_p1.as<Pass1>()->n_anom;
-        gp.r_rec = C->b_r_rec.as<RegionRec>(); gp.r_pk = C->b_r_pk.as<uint32_t>(); gp.nr_local = nr_local; gp.roff = T + o_roff;
-        gp.rg_rec = d->b_rg_rec.as<RegionRec>(); gp.rg_pk = d->b_rg_pk.as<uint32_t>(); gp.nkeys2 = nkeys2;
-        gp.scratch = C->b_out_deg.as<uint32_t>(); gp.cap = capG; gp.counts = C->b_counts.as<StageCounts>(); gp.nr_global = (uint32_t)NR; gp.last_maxq = lm;
-        launch_k9_globalize(gp, na, s);
-        trace("globalize");
-        launch_k9_window_collect(d->b_rg_rec.as<RegionRec>(), (uint32_t)NR, period, (unsigned long long*)X, s);
-        C->k6_cap = (uint32_t)NR; C->k6_r_rec = d->b_rg_rec.as<RegionRec>(); C->k6_r_pk = d->b_rg_pk.as<uint32_t>();
-        C->k6_taint = world > 1 ? (uint8_t*)(X + x_taint) : nullptr;
-        if (na) {
-            xs.key = C->cp.key; xs.check = C->cp.check; xs.meta = C->cp.meta; xs.tid = C->cp.tid; xs.idx = C->cp.idx; xs.mtid_col = C->d.mtid;
-            xs.region_of = C->k3.region_of; xs.n_ptr = &C->b_p1.as<Pass1>()->n_anom; xs.owner_of_tid = (const int32_t*)(T + o_owner);
-            xs.ntids = ntids; xs.me = rank; xs.world = (uint32_t)world;
-            launch_k7_count(xs, na, T + o_cnt, s);
-        }
-        trace("exchange counts");
-        DHIP(d, hipMemcpyAsync(H + L.cnts, T + o_cnt, (size_t)world * 8, hipMemcpyDeviceToHost, s));
-        DHIP(d, hipStreamSynchronize(s));
-        for (int q = 0; q < world; ++q) { h_cnt[q] = H[L.cnts + q]; h_ncnt[q] = H[L.cnts + world + q]; }
-        for (int q = 0; q < world; ++q) { scount[q] = (size_t)h_cnt[q] * kxw; sdispl[q] = nsend * kxw; nsend += h_cnt[q]; }
-        for (int q = 0; q < world; ++q) { nscount[q] = (size_t)h_ncnt[q] * 2; nsdispl[q] = nnsend * 2; nnsend += h_ncnt[q]; }
-        // Everything a rank can do before it knows what the others send happens in front of the count exchange, so that its
-        // failure still travels with it: the send buffers (sized by the rank's own counts) and the packing per destination
-        DHIP(d, d->b_send.ensure(std::max<size_t>(nsend, 1) * sizeof(ExchangeEntry)));
-        DHIP(d, d->b_nsend.ensure(std::max<size_t>(nnsend, 1) * 16));
-        if (na) {
-            std::vector<uint32_t> cur(2 * (size_t)world);
-            for (int q = 0; q < world; ++q) { cur[q] = (uint32_t)(sdispl[q] / kxw); cur[(size_t)world + q] = (uint32_t)(nsdispl[q] / 2); }
-            DHIP(d, hipMemcpyAsync(T + o_cnt + 2 * (size_t)world, cur.data(), cur.size() * 4, hipMemcpyHostToDevice, s));
-            launch_k7_scatter(xs, na, T + o_cnt + 2 * (size_t)world, d->b_send.as<ExchangeEntry>(), d->b_nsend.as<unsigned long long>(), s);
-            DHIP(d, hipStreamSynchronize(s));
-        }
-        trace("scatter");
-        return BDX_OK;
-    });
-    std::vector<uint64_t> v4((size_t)world * world * 2, 0);  // send-count matrices (CTX records, census records): row = sender
-    const size_t W2 = (size_t)world * world;
-    for (int q = 0; q < world; ++q) { v4[(size_t)rank * world + q] = h_cnt[q]; v4[W2 + (size_t)rank * world + q] = h_ncnt[q]; }
-    rc = exchange(v4);
-    if (rc != BDX_OK) return rc;
     if (!NR) {   // no region anywhere: an empty table
         if (rank == 0) {
             U->regions.clear(); U->r_pk.clear(); U->reg = nullptr; U->nreg = 0; U->rpk = nullptr;
@@ -813,25 +830,72 @@ int bdx_dist_run(bdx_dist* d) {
         }
         return finish_result();
     }
-    for (int q = 0; q < world; ++q) { rcount[q] = (size_t)v4[(size_t)q * world + rank] * kxw; rdispl[q] = nrecv * kxw; nrecv += v4[(size_t)q * world + rank]; }
-    for (int q = 0; q < world; ++q) { nrcount[q] = (size_t)v4[W2 + (size_t)q * world + rank] * 2; nrdispl[q] = nnrecv * 2; nnrecv += v4[W2 + (size_t)q * world + rank]; }
+
+    const auto t_x0 = std::chrono::steady_clock::now();
+    // ---- genome-wide region ids, the CTX records and the census records packed per destination; C4: ONE all-to-all each.  No
+    // host round trip from here to the pair groups: failures of this stretch travel with the next all-reduce ----
+    uint64_t* X = nullptr;          // [NW] window read lengths | taint bytes (capG) | status words
+    const size_t x_taint = NW, x_words = (size_t)NW + ((size_t)capG + 7) / 8;
+    RegionRec* regs = nullptr;      // rank 0: the genome's region table (pinned: the copy runs beside the joins)
+    uint32_t* pk = nullptr;
+    bool regs_pending = false;
+    int local_rc = BDX_OK;          // (what `phase` would record: this stretch ends in point-to-point collectives, which cannot carry it)
     {
-        // (the column sums are the same table on every rank: the limits trip everywhere at once)
-        for (int r = 0; r < world; ++r) {
-            uint64_t col = 0, ncol = 0;
-            for (int q = 0; q < world; ++q) { col += v4[(size_t)q * world + r]; ncol += v4[W2 + (size_t)q * world + r]; }
-            if (col > (1u << 28) || ncol > 0x7FFFFFFFull) return dfail(d, BDX_ELIMIT, "too many inter-chromosomal join records / names on one rank");
-        }
+        const auto tp = std::chrono::steady_clock::now();
+        auto body = [&]() -> int {
+            DHIP(d, d->b_rg_rec.ensure((size_t)NR * sizeof(RegionRec)));
+            DHIP(d, d->b_rg_pk.ensure(std::max<size_t>((size_t)NR * nkeys2 * 4, 16)));
+            DHIP(d, C->b_out_deg.ensure((size_t)capG * 6 * 4));
+            DHIP(d, d->b_x.ensure((x_words + (size_t)world + 8) * 8));
+            X = d->b_x.as<uint64_t>();
+            DHIP(d, hipMemsetAsync(d->b_rg_rec.p, 0, (size_t)NR * sizeof(RegionRec), s));
+            DHIP(d, hipMemsetAsync(X, 0, (x_words + (size_t)world) * 8, s));
+            {
+                uint32_t* ur = UP + L.up_misc + (size_t)2 * ntids + 1;
+                for (int t = 0; t < ntids; ++t) ur[t] = (uint32_t)rbase[t] - rtab[t];
+                DHIP(d, hipMemcpyAsync(T + o_roff, ur, (size_t)ntids * 4, hipMemcpyHostToDevice, s));
+            }
+            GlobalizeParams gp{};
+            gp.tid = C->cp.tid; gp.region_of = C->k3.region_of; gp.n_ptr = &C->b_p1.as<Pass1>()->n_anom;
+            gp.r_rec = C->b_r_rec.as<RegionRec>(); gp.r_pk = C->b_r_pk.as<uint32_t>(); gp.nr_local = nr_local; gp.roff = T + o_roff;
+            gp.rg_rec = d->b_rg_rec.as<RegionRec>(); gp.rg_pk = d->b_rg_pk.as<uint32_t>(); gp.nkeys2 = nkeys2;
+            gp.scratch = C->b_out_deg.as<uint32_t>(); gp.cap = capG; gp.counts = C->b_counts.as<StageCounts>(); gp.nr_global = (uint32_t)NR; gp.last_maxq = lm;
+            launch_k9_globalize(gp, na, s);
+            trace("globalize");
+            launch_k9_window_collect(d->b_rg_rec.as<RegionRec>(), (uint32_t)NR, period, (unsigned long long*)X, s);
+            C->k6_cap = (uint32_t)NR; C->k6_r_rec = d->b_rg_rec.as<RegionRec>(); C->k6_r_pk = d->b_rg_pk.as<uint32_t>();
+            C->k6_taint = world > 1 ? (uint8_t*)(X + x_taint) : nullptr;
+            if (na) {
+                uint32_t* cur = UP + L.up_cur;
+                for (int q = 0; q < world; ++q) { cur[q] = (uint32_t)(sdispl[q] / kxw); cur[(size_t)world + q] = (uint32_t)(nsdispl[q] / 2); }
+                DHIP(d, hipMemcpyAsync(T + o_cnt + 2 * (size_t)world, cur, (size_t)world * 8, hipMemcpyHostToDevice, s));
+                xs.region_of = C->k3.region_of;
+                launch_k7_scatter(xs, na, T + o_cnt + 2 * (size_t)world, d->b_send.as<ExchangeEntry>(), d->b_nsend.as<unsigned long long>(), s);
+            }
+            trace("scatter");
+            return BDX_OK;
+        };
+        d->err.clear();
+        local_rc = st.rc == BDX_OK ? body() : BDX_OK;
+        if (local_rc != BDX_OK) { st.rc = local_rc; st.msg = d->err; }
+        d->phase_ms[6] += ms_between(tp, std::chrono::steady_clock::now());
+        n_phase = 4;   // (slots 6 / 7: this stretch and the all-to-alls)
     }
-    if (d->b_recv.ensure(std::max<size_t>(nrecv, 1) * sizeof(ExchangeEntry)) != hipSuccess)
-        return leave(dfail(d, BDX_ENOMEM, "receive buffer of the all-to-all"));
-    // C4: the all-to-all of the CTX records (four 64-bit words each), then the census records
-    if (!comm.alltoallv_u64(d->b_send.as<uint64_t>(), scount.data(), sdispl.data(), d->b_recv.as<uint64_t>(), rcount.data(), rdispl.data(), s))
-        return leave(dfail(d, BDX_EHIP, comm.err));
-    if (d->b_nrecv.ensure(std::max<size_t>(nnrecv, 1) * 16) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "receive buffer of the name census"));
-    if (!comm.alltoallv_u64(d->b_nsend.as<uint64_t>(), nscount.data(), nsdispl.data(), d->b_nrecv.as<uint64_t>(), nrcount.data(), nrdispl.data(), s))
-        return leave(dfail(d, BDX_EHIP, comm.err));
-    d->ctx_sent = nsend; d->ctx_received = nrecv;
+    if (st.rc != BDX_OK && world > 1) {
+        // (a rank that cannot take part in the all-to-all: the others would wait for it -- the communicator is given up)
+        return leave(dfail(d, st.rc, st.msg));
+    }
+    if (st.rc != BDX_OK) return dfail(d, st.rc, st.msg);
+    {
+        const auto tp = std::chrono::steady_clock::now();
+        // C4: the all-to-all of the CTX records (four 64-bit words each), then the census records
+        if (!comm.alltoallv_u64(d->b_send.as<uint64_t>(), scount.data(), sdispl.data(), d->b_recv.as<uint64_t>(), rcount.data(), rdispl.data(), s))
+            return leave(dfail(d, BDX_EHIP, comm.err));
+        if (!comm.alltoallv_u64(d->b_nsend.as<uint64_t>(), nscount.data(), nsdispl.data(), d->b_nrecv.as<uint64_t>(), nrcount.data(), nrdispl.data(), s))
+            return leave(dfail(d, BDX_EHIP, comm.err));
+        d->ctx_sent = nsend; d->ctx_received = nrecv;
+        d->phase_ms[7] += ms_between(tp, std::chrono::steady_clock::now());
+    }
 
     // ---- the genome's region table on rank 0 (C5: a gather of the ranks' dense tables; with one rank it is there already) ----
     size_t region_bytes = 0;
@@ -884,19 +948,34 @@ int bdx_dist_run(bdx_dist* d) {
         }
     }
 
+    auto wait_regions = [&]() -> int {
+        if (regs_pending) {
+            DHIP(d, hipStreamSynchronize(C->copy_stream));
+            regs_pending = false;
+            if (world > 1) {
+                uint32_t perr = 0;
+                DHIP(d, hipMemcpy(&perr, T + o_ntot + 1, 4, hipMemcpyDeviceToHost));
+                if (perr) return dfail(d, BDX_EINTERNAL, "region table of the gather does not add up");
+            }
+        }
+        return BDX_OK;
+    };
+
     // ---- the joins (own reads + foreign entries), the name census, the pair groups per region.  C6: taint bytes, window lengths ----
     const bool force_host = (rank == 0 ? U->host_walk_only : false) || C->host_walk_only || d->opts.min_read_pair < 1;
     auto t_x1 = std::chrono::steady_clock::now();
     phase([&]() -> int {
-        if (nnrecv) {   // the census of the names this rank owns
+        if (nnrecv) {   // the census of the names this rank owns: on the second stream, beside the joins (its verdict is read at the next all-reduce)
             uint32_t slots = 1024;
             while (slots < 2 * nnrecv) slots <<= 1;
             DHIP(d, d->b_ntab.ensure((size_t)slots * 16));
             DHIP(d, d->b_nflag.ensure(16));
-            launch_k7_names_clear(d->b_ntab.as<unsigned long long>(), slots, d->b_nflag.as<uint32_t>(), s);
-            launch_k7_names_census(d->b_nrecv.as<unsigned long long>(), (uint32_t)nnrecv, d->b_ntab.as<unsigned long long>(), slots - 1, d->b_nflag.as<uint32_t>(), s);
+            DHIP(d, hipEventRecord(d->ev_side, s));
+            DHIP(d, hipStreamWaitEvent(C->copy_stream, d->ev_side, 0));
+            launch_k7_names_clear(d->b_ntab.as<unsigned long long>(), slots, d->b_nflag.as<uint32_t>(), C->copy_stream);
+            launch_k7_names_census(d->b_nrecv.as<unsigned long long>(), (uint32_t)nnrecv, d->b_ntab.as<unsigned long long>(), slots - 1, d->b_nflag.as<uint32_t>(),
+                                   C->copy_stream);
         }
-        trace("census");
         if (na) {
             if ((uint64_t)C->na_alloc + nrecv > (1u << 28)) return dfail(d, BDX_ELIMIT, "too many join entries on one rank");
             const uint32_t nf = (uint32_t)nrecv;
@@ -931,6 +1010,11 @@ int bdx_dist_run(bdx_dist* d) {
         if (world > 1) launch_k9_window_apply(d->b_rg_rec.as<RegionRec>(), (uint32_t)NR, period, (const unsigned long long*)X, s);
         DCTX(d, C, do_k6(C, force_host, 2));
         trace("components and walk");
+        if (rank == 0) {   // while the device walks: the genome's region table for the host's share of the walk and for the result
+            const int wr = wait_regions();
+            if (wr != BDX_OK) return wr;
+            decode_regions(C, regs, pk, (uint32_t)NR, 0, true);   // (read where it arrived, in pinned memory: the host's share of the walk touches little of it)
+        }
         if (!wait_flag(C, 1, C->seq)) {
             if (C->poll) DHIP(d, hipStreamSynchronize(s)); else DHIP(d, hipEventSynchronize(C->ev_groups));
         }
@@ -939,7 +1023,8 @@ int bdx_dist_run(bdx_dist* d) {
         if (C->counts.overflow) return dfail(d, BDX_EINTERNAL, "group list overflow");
         if (nnrecv) {
             uint32_t flag = 0;
-            DHIP(d, hipMemcpy(&flag, d->b_nflag.p, 4, hipMemcpyDeviceToHost));
+            DHIP(d, hipMemcpyAsync(&flag, d->b_nflag.p, 4, hipMemcpyDeviceToHost, C->copy_stream));
+            DHIP(d, hipStreamSynchronize(C->copy_stream));
             if (flag) irregular = 1;
         }
         return BDX_OK;
@@ -952,18 +1037,6 @@ int bdx_dist_run(bdx_dist* d) {
     // some rank met a read name more than twice -- or the caller wants the reads behind every SV, which only the read-level walk knows
     const bool replay = v5[(size_t)world] != 0 || want_support != 0;
 
-    auto wait_regions = [&]() -> int {
-        if (regs_pending) {
-            DHIP(d, hipStreamSynchronize(C->copy_stream));
-            regs_pending = false;
-            if (world > 1) {
-                uint32_t perr = 0;
-                DHIP(d, hipMemcpy(&perr, T + o_ntot + 1, 4, hipMemcpyDeviceToHost));
-                if (perr) return dfail(d, BDX_EINTERNAL, "region table of the gather does not add up");
-            }
-        }
-        return BDX_OK;
-    };
 
     // ---- a read name seen more than twice (clashing names across merged files): the pair model does not hold, and the reference's
     // behaviour (ReadRegionData.cpp:108-113,152-175, SvBuilder.cpp:101-118) depends on the order of ALL sightings.  Every rank sends
@@ -1055,9 +1128,6 @@ int bdx_dist_run(bdx_dist* d) {
     phase([&]() -> int {
         C->walk.clear();
         if (rank == 0) {
-            const int wr = wait_regions();
-            if (wr != BDX_OK) return wr;
-            decode_regions(C, regs, pk, (uint32_t)NR, 0, false);
             const GroupRec* g = world > 1 ? host_groups.data() : C->h_groups.as<GroupRec>();
             decode_groups(C, g, (uint32_t)ng_all, 0);
             C->last_big_groups = (int64_t)ng_all + C->counts.n_groups_big;
@@ -1076,8 +1146,8 @@ int bdx_dist_run(bdx_dist* d) {
     });
     if (world == 1) {
         adopt_table(U, C);
-        std::swap(U->regions, C->regions); std::swap(U->r_pk, C->r_pk);
-        U->reg = U->regions.data(); U->nreg = U->regions.size(); U->rpk = U->r_pk.data();
+        d->table_lent = true;
+        U->reg = C->reg; U->nreg = C->nreg; U->rpk = C->rpk;   // (the genome's region table stays in this rank's pinned buffers until the next run)
         C->reg = nullptr; C->nreg = 0; C->rpk = nullptr;
         U->counts.n_regions = (uint32_t)NR;
         U->ran = true; U->stage = 4;
@@ -1175,8 +1245,7 @@ int bdx_dist_run(bdx_dist* d) {
         U->counts.n_regions = (uint32_t)NR; U->counts.last_maxq = lm; U->counts.n_pairs = (uint32_t)n_pairs_all; U->counts.n_old = (uint32_t)n_old_all;
         U->counts.n_sv_dev = n_total - U->n_sv_host; U->counts.n_groups = (uint32_t)ng_all;
         U->materialized = false;
-        std::swap(U->regions, C->regions); std::swap(U->r_pk, C->r_pk);
-        U->reg = U->regions.data(); U->nreg = U->regions.size(); U->rpk = U->r_pk.data();
+        U->reg = C->reg; U->nreg = C->nreg; U->rpk = C->rpk;   // (in rank 0's pinned buffers until the next run)
         C->reg = nullptr; C->nreg = 0; C->rpk = nullptr;
         if (d->opts.fisher) {  // Fisher's combination (BreakDancer.cpp:71-81) uses the host's exp / log
             materialize(U);

@@ -28,6 +28,7 @@ struct StageCounts {
     uint32_t n_groups_big; // K6: groups of those components
     uint32_t n_old;        // K6: device candidates of traversals started from a vertex of an earlier flush window
     uint32_t n_ins;        // K6: candidates the compaction inserts by order key (the host walk's + n_old)
+    uint32_t sort_done;    // K6: workgroups of the insertion list's rank sort that have finished (k6_insert_kernel's last workgroup waits for them)
     uint32_t irregular;    // K4: some read name was seen more than twice among the anomalous reads (ReadRegionData.cpp:108-113
                            // keeps appending): the pair model does not hold, the run is replayed read by read on the host
 };
@@ -208,6 +209,7 @@ constexpr int kK6MaxIn = 3;        // incoming gate-passing groups per region (a
 constexpr int kK6BigMembers = 64;  // regions per component walked by the general device path (one wave, member lists in LDS)
 constexpr int kK6LibStride = 16;   // staged (library, pairs) entries per candidate; components that could need more go to the host
 constexpr int kK6LabelRoundsBig = 8; // ... with the general walk (components of up to kK6BigMembers regions) enabled
+constexpr uint32_t kK6RankSortMax = 1u << 17;  // entries of the insertion list the all-pairs rank sort takes (whole GPU: microseconds)
 constexpr int kK6LabelRounds = 2;  // min-label propagation rounds (the first inside k6_pairs_kernel, the others with pointer jumping):
                                    // two settle chains of four regions in practice; a component that has not converged fails
                                    // the closure check and goes to the host
@@ -321,6 +323,8 @@ struct K6Arrays {
     const uint32_t* hs_cnt;        // [nh] lib_count | cn_count << 16
     uint64_t* old_key;             // device [pow2 >= sv_cap] order keys of the device's list (k6_walk_kernel, any order) ...
     uint32_t* old_slot;            // ... and their staging slots
+    uint64_t* sorted_key;          // device [kK6RankSortMax]: the device's list sorted by key (k6_ranksort_kernel) when it has more entries than
+    uint32_t* sorted_slot;         // one workgroup sorts quickly and at most kK6RankSortMax; null: k6_insert_kernel sorts by itself
     uint64_t* hs_key_dev;          // device [sv_cap] copy of hs_key
     uint32_t* ins_T;               // device [sv_cap] merged list: threshold vertex ...
     uint32_t* ins_src;             // ... staging slot, or 0x80000000 | j for the host walk's candidate j

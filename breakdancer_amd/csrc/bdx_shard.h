@@ -28,6 +28,8 @@ struct TidTableParams {
 void launch_k9_tid_table(const TidTableParams& p, hipStream_t s);
 // one thread behind a kernel boundary: *flag = value (the host polls the pinned word)
 void launch_k9_signal(uint32_t* flag, uint32_t value, hipStream_t s);
+// ... after n words of device memory have been copied into the (pinned) report area
+void launch_k9_report(const uint32_t* src, uint32_t* dst, uint32_t n, uint32_t* flag, uint32_t value, hipStream_t s);
 // compact records: the counters of chromosome t's reads get tid_off[t][0] (normal pairs) and tid_off[t][1 + k] (proper reads of key k)
 // added -- what the chromosomes in front of t (anybody's) have counted, minus what this context's own have; first_tab[t] = {1, read
 // length, normal-pair count} of chromosome t's first anomalous read (pinned host memory, zero on entry)
@@ -103,5 +105,9 @@ struct MergeOut {
 // D: the descriptor in device memory; ws: scan workspace words (device); src: [n_total] (rank << 26 | row) by final position
 void launch_k9_merge_tables(const char* all, const TableDesc* D, int world, uint32_t n_total, uint32_t max_n, uint32_t* src, uint2* begins, uint32_t* ws,
                             const uint32_t* n_dev, const MergeOut& out, hipStream_t s);
+
+// one no-op launch per translation unit (see bdx_warm_up)
+void warm_k1(hipStream_t s); void warm_k2(hipStream_t s); void warm_k3(hipStream_t s); void warm_k4(hipStream_t s);
+void warm_k5(hipStream_t s); void warm_k6(hipStream_t s); void warm_k7(hipStream_t s); void warm_k9(hipStream_t s);
 
 }  // namespace bdx

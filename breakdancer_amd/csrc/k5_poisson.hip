@@ -32,3 +32,7 @@ void launch_k5(const double* lambda, const int32_t* k, double* out, uint32_t n, 
 }
 
 }  // namespace bdx
+
+// (bdx_warm_up: the HIP runtime loads a translation unit's device code at the first launch of any of its kernels)
+__global__ void k5_noop_kernel() {}
+namespace bdx { void warm_k5(hipStream_t s) { hipLaunchKernelGGL(k5_noop_kernel, dim3(1), dim3(64), 0, s); } }

@@ -261,6 +261,11 @@ int bdx_get_cross_window_svs(const bdx_ctx* ctx, uint32_t* n_sv_device);
  * semantics for such names (ReadRegionData.cpp:108-113,152-175, SvBuilder.cpp:101-118, BreakDancer.cpp:357-368); 0 otherwise. */
 int bdx_was_replayed(const bdx_ctx* ctx);
 
+/* The HIP runtime loads a translation unit's device code at the first launch of one of its kernels (0.4-0.8 ms each, inside whatever
+ * run comes first in the process).  bdx_warm_up launches one no-op kernel per translation unit of the library and waits: a process
+ * that calls it while it still reads its input has its first run at the speed of the later ones.  bdx_dist_prepare calls it. */
+int bdx_warm_up(int device);
+
 /* Kernel-level entry points for parity tests.
  * bdx_classify replaces IAlignmentClassifier::classify (io/IlluminaPEReadClassifier.cpp:59-101) plus the
  * filter/remap half of push_read: host arrays in, class bytes out.
