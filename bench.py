@@ -58,7 +58,9 @@ def parse():
     ap.add_argument("--no-end-to-end", action="store_true", help="skip timings (ii) and (iii)")
     ap.add_argument("--no-exchange", "--no-genome", dest="no_exchange", action="store_true",
                     help="skip the sharded whole-genome runs over all ranks (config.genome)")
-    ap.add_argument("--genome-fraction", type=float, default=GENOME_FRACTION, help="hg38 lengths x this for the genome leg (default 1/8: 116 M records)")
+    ap.add_argument("--genome-fraction", type=float, default=None,
+                    help="hg38 lengths x this for the genome leg (default N/8: 116 M records per GPU at every N -- the whole genome of configs[2] / [3] at N = 8 -- "
+                         "plus, for N > 1, the fixed 1/8 spread over the N ranks)")
     ap.add_argument("--no-overlap", action="store_true", help="skip the three-contexts-in-flight measurement (config.overlapped_contexts)")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 --pmc sub-run that measures roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -302,11 +304,12 @@ def measure_k1_traffic(length):
 def time_bam_cli(bam, cfg, n):
     """(iii) BAM -> SV table through the CLI (process start to exit, page cache warm), best of 3 per reader: the default (a one-BAM
     configuration is inflated and decoded on the GPU) and the host reader (BDX_DECODE=host) at the CPUs the container grants"""
-    def run(env_extra, label):
+    def run(env_extra, label, settle=0.5):
         env = dict(os.environ, BDX_TIMING="1", **env_extra)
         best = None
         for _ in range(3):
-            time.sleep(0.5)   # (untimed: the run before this one is still handing its GPU context back to the driver, see the note)
+            if settle:
+                time.sleep(settle)   # (untimed, default command only: the child of the run before is still handing its GPU context back to the driver)
             t0 = time.perf_counter()
             p = subprocess.run([os.path.join(ROOT, "bin", "breakdancer-max"), cfg], cwd=os.path.dirname(cfg), env=env,
                                stdout=subprocess.PIPE, stderr=subprocess.PIPE)
@@ -330,15 +333,20 @@ def time_bam_cli(bam, cfg, n):
         inflated = int(bamdec.scan_bgzf(img)["inflated_len"].astype(np.int64).sum())
     except Exception:  # noqa: BLE001
         pass
-    fg = run({"BDX_FOREGROUND": "1"}, "device, one process")
+    time.sleep(0.5)
+    fg = run({"BDX_FOREGROUND": "1"}, "device: BGZF inflate + record decode on the GPU (bdx_bamdec_*), one process, exit included", settle=0)
     out = dict(dev)
     if "seconds" in fg:
-        out["one_process_exit_included"] = {"seconds": fg["seconds"], "value": fg["value"], "unit": "read-pairs/s"}
+        # the block's own figure is the ONE-process run, the release of the GPU context included; the default command returns
+        # earlier (the process that holds the GPU context is a child whose exit runs behind the command's return): kept beside it
+        out = dict(fg)
+        out["command_return"] = {"seconds": dev["seconds"], "value": dev["value"], "unit": "read-pairs/s", "cli_breakdown": dev.get("cli_breakdown"),
+                                 "note": "the default command: returns when the table is written; the GPU context's release (~0.1 s) runs behind it in a child process"}
     out.update({"bam_bytes": os.path.getsize(bam), "inflated_bytes": inflated, "usable_cpus": cpus, "host_reader": host,
-                "note": "bin/breakdancer-max <cfg> on the configs[1] chromosome as one BAM (%d records), from starting the command to its return "
-                        "with the whole table on stdout, best of 3; `seconds` / `value` are the default reader's.  The GPU work runs in a child "
-                        "of the command; the command returns when the child reports the table written, and the child's exit -- the driver "
-                        "taking back ~6 GB of HBM and the pinned buffers, ~0.1 s -- runs behind it (BDX_FOREGROUND=1: one process, exit included)" % n})
+                "note": "bin/breakdancer-max <cfg> on the configs[1] chromosome as one BAM (%d records), from starting the command to its exit "
+                        "with the whole table on stdout, best of 3; `seconds` / `value` are one process from start to exit (BDX_FOREGROUND=1), the "
+                        "driver taking back ~6 GB of HBM and the pinned buffers included; `command_return` is the default command, whose GPU work "
+                        "runs in a child that finishes its exit behind the command's return" % n})
     if inflated and "seconds" in host:
         out["host_reader"]["inflate_mb_per_s_per_cpu"] = inflated / 1e6 / host["seconds"] / cpus
     return out
@@ -355,23 +363,23 @@ GENOME_FRACTION = 1.0 / 8
 LIBS4 = ((400.0, 30.0), (350.0, 40.0), (500.0, 50.0), (300.0, 25.0))
 
 
-def genome_leg(rank, world, local, dist, out, fraction=GENOME_FRACTION, translocations=5000):
+def genome_leg(rank, world, local, dist, out, fraction=None, translocations=5000):
     """configs[2] and configs[3] as ONE sharded run each over the N ranks of this launch: hg38-shaped genome, 4 libraries, 30x,
     chromosomes dealt to the ranks by bdx_dist_plan (longest processing time first, on sequence length); every rank synthesises
-    and loads its own chromosomes, then all call bdx_dist_run (csrc/bdx_dist_impl.h: all-reduces of the pass-1 statistics, ONE
-    all-to-all of the inter-chromosomal join records, gather + walk on rank 0).  Timed between barriers, max over ranks; total
-    work is the same for every N (strong scaling).  The second run has 5,000 planted translocations and -t.  Fills `out` on rank 0."""
+    and loads its own chromosomes, then all call bdx_dist_run (csrc/bdx_dist_impl.h: one launch sequence per rank over all of its
+    chromosomes, all-reduces of the statistics and per-chromosome tables, ONE all-to-all of the inter-chromosomal join records,
+    components walked where they live, rank 0 walks what spans ranks and merges the ranks' tables).  Timed between barriers, max
+    over ranks.  Sizes: `weak` = hg38 x N/8, i.e. 116 M records per GPU at every N and the whole genome of configs[2] / [3] at N = 8;
+    `strong` (N > 1) = the fixed hg38 x 1/8 spread over the N ranks.  At N = 1 the same records also go through ONE context
+    (bdx_run): `single_context`, the figure the sharded run is measured against.  Fills `out` on rank 0."""
     import torch
     from breakdancer_amd import dist as D
     from breakdancer_amd.api import LibraryConfig, Options
     from breakdancer_amd.synth import make_genome
-    lengths = [int(m * 1e6 * fraction) for m in HG38_MBP]
-    ntids = len(lengths)
-    rank_of = D.plan(lengths, world)
-    mine = set(t for t in range(ntids) if rank_of[t] == rank)
     libs = [LibraryConfig(mean_insertsize=m, std_insertsize=sd, uppercutoff=m + 3 * sd, lowercutoff=m - 3 * sd, readlens=100.0, name="lib%d" % i)
             for i, (m, sd) in enumerate(LIBS4)]
     cpu_dev = torch.device("cpu") if (SHARED_GPU_TEST or dist is None) else torch.device("cuda", local)
+    threads_backend = SHARED_GPU_TEST and world > 1   # (test hook: RCCL refuses two ranks on one device; rank 0 drives all ranks as threads)
 
     def barrier():
         torch.cuda.synchronize()
@@ -390,74 +398,137 @@ def genome_leg(rank, world, local, dist, out, fraction=GENOME_FRACTION, transloc
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    tg = time.perf_counter()
-    d = make_genome(lengths, coverage=30.0, seed=11, libs=LIBS4, lib_bam=(0, 0, 0, 0), n_translocations=translocations, only_tids=mine)
-    gen_s = time.perf_counter() - tg
-    n_mine = len(d["tid"])
-    per_rank = [0] * world
-    per_rank[rank] = n_mine
-    per_rank = allsum(per_rank)
-    total = sum(per_rank)
-    legs = {}
-    threads_backend = SHARED_GPU_TEST and world > 1   # (test hook: RCCL refuses two ranks on one device; rank 0 drives all ranks as threads)
-    if threads_backend:
-        d_all = make_genome(lengths, coverage=30.0, seed=11, libs=LIBS4, lib_bam=(0, 0, 0, 0), n_translocations=translocations) if rank == 0 else None
-    for label, opts in (("default_options", Options()), ("t_option", Options(transchr_rearrange=True))):
+    def one_size(frac, scaling):
+        lengths = [int(m * 1e6 * frac) for m in HG38_MBP]
+        ntids = len(lengths)
+        rank_of = D.plan(lengths, world)
+        mine = set(t for t in range(ntids) if rank_of[t] == rank)
+        tg = time.perf_counter()
+        only = None if threads_backend else mine
+        d = make_genome(lengths, coverage=30.0, seed=11, libs=LIBS4, lib_bam=(0, 0, 0, 0), n_translocations=translocations, only_tids=only) \
+            if (not threads_backend or rank == 0) else None
+        gen_s = time.perf_counter() - tg
         if threads_backend:
+            per_rank = [0] * world
             if rank == 0:
-                ranks = D.DistRun.threads(opts, libs, 1, ntids, 200, [local] * world)
                 for t in range(ntids):
-                    m = d_all["tid"] == t
-                    if m.any():
-                        ranks[rank_of[t]].chromosome(t).push_reads({k: v[m] for k, v in d_all.items()})
+                    per_rank[rank_of[t]] += int((d["tid"] == t).sum())
+            per_rank = allsum(per_rank)
+        else:
+            per_rank = [0] * world
+            per_rank[rank] = len(d["tid"])
+            per_rank = allsum(per_rank)
+        total = sum(per_rank)
+        legs = {}
+        for label, opts in (("default_options", Options()), ("t_option", Options(transchr_rearrange=True))):
+            if threads_backend and rank != 0:
+                continue
+            if threads_backend:
+                ranks = D.DistRun.threads(opts, libs, 1, ntids, 200, [local] * world)
+                owned = lambda r: [t for t in range(ntids) if rank_of[t] == r]   # noqa: E731
+            elif dist is None:
+                ranks = [D.DistRun.create(opts, libs, 1, ntids, 200, local, 0, 1, D.unique_id())]
+                owned = lambda r: sorted(mine)   # noqa: E731
+            else:
+                ranks = [D.DistRun.from_process_group(opts, libs, 1, ntids, 200, local)]
+                owned = lambda r: sorted(mine)   # noqa: E731
+            tl = time.perf_counter()
+            bounds = np.searchsorted(d["tid"], np.arange(ntids + 1))
+            for r, run in enumerate(ranks):
+                for t in owned(r):
+                    lo, hi = int(bounds[t]), int(bounds[t + 1])
+                    if hi > lo:
+                        run.chromosome(t).push_reads({k: v[lo:hi] for k, v in d.items()})
+                run.prepare()   # (outside the run, like bdx_reserve: buffers of the later stages sized for a first run, device code loaded)
+            if not threads_backend:
+                barrier()
+            else:
+                torch.cuda.synchronize()
+            load_s = time.perf_counter() - tl
+            times = []
+            for it in range(2):   # the first run of the input, then the same handles once more
+                t0 = time.perf_counter()
+                if threads_backend:
+                    res = D.run_threads(ranks)
+                    times.append(time.perf_counter() - t0)
+                else:
+                    ranks[0].run(release=False)
+                    barrier()
+                    times.append(allmax(time.perf_counter() - t0))
+                    res = ranks[0].result()
+                if it == 0:
+                    first_phases = ranks[0].phases()
+            for run in ranks:
+                run.release_inputs()   # (the Python side's references to the loaded arrays: not part of the run)
+            ex = [r.exchange() for r in ranks]
+            if threads_backend:
+                sent, rank_ms = sum(e["ctx_records_sent"] for e in ex), [e["ms_total"] for e in ex]
+            else:
+                sent = allsum([ex[0]["ctx_records_sent"]])[0]
+                rank_ms = [0] * world
+                rank_ms[rank] = int(ex[0]["ms_total"] * 1000)
+                rank_ms = [x / 1000.0 for x in allsum(rank_ms)]
+            if rank == 0:
+                sm = res.summary()
+                ph = ranks[0].phases()
+                dt = times[0]
+                r0 = ph.get("rank0_only_merge", 0.0) + ph.get("rank0_only_host_walk", 0.0)
+                legs[label] = {"seconds": dt, "value": total / 2 / dt, "unit": "read-pairs/s", "second_run_seconds": times[1],
+                               "hbm_roofline_frac_whole_path": total / 2 / dt / world * PATH_BYTES_PER_PAIR / 1e9 / HBM_PEAK_GBS,
+                               "svs_printed": sm["n_svs_printed"], "regions": sm["n_regions"], "sv_candidates_device_host": list(res.walk_split())[:2],
+                               "ctx_records_exchanged": sent, "gathered_bytes_on_rank0": ex[0]["gathered_bytes"],
+                               "bdx_dist_run_ms_per_rank": rank_ms, "rank0_phase_ms_first_run": first_phases, "rank0_phase_ms": ph,
+                               "rank0_only": {"ms": r0, "share_of_run": r0 / (ex[0]["ms_total"] or 1.0),
+                                              "note": "what only rank 0 does (second run): the merge of the ranks' tables and its host walk of the "
+                                                      "components that span ranks or are too large for the device walk"},
+                               "load_and_prepare_seconds_untimed": load_s}
+            for run in ranks:
+                run.close()
+        single = None
+        if world == 1 and rank == 0:
+            # the same records through ONE context: the reference point of the sharded run
+            import breakdancer_amd as bda
+            bd = bda.BreakDancer(Options(), libs, 1, ntids=ntids, max_read_window_size=200, device=local)
+            bd.lib.bdx_reserve(bd.h, len(d["tid"]))
+            bd.push_reads(d)
+            torch.cuda.synchronize()
+            ts = []
+            for it in range(4):
+                if it == 1:
+                    bd.set_enqueue_ahead(0)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                res = D.run_threads(ranks)
-                dt = time.perf_counter() - t0
-                ex = ranks[0].exchange()
-                sm = res.summary()
-                legs[label] = {"seconds": dt, "value": total / 2 / dt, "unit": "read-pairs/s", "svs_printed": sm["n_svs_printed"], "regions": sm["n_regions"],
-                               "ctx_records_exchanged": sum(r.exchange()["ctx_records_sent"] for r in ranks), "gathered_bytes_on_rank0": ex["gathered_bytes"],
-                               "rank0_ms_exchange_and_ctx_join": ex["ms_exchange"], "bdx_dist_run_ms_per_rank": [r.exchange()["ms_total"] for r in ranks]}
-                for r in ranks:
-                    r.close()
-            continue
-        if dist is None:
-            run = D.DistRun.create(opts, libs, 1, ntids, 200, local, 0, 1, D.unique_id())
-        else:
-            run = D.DistRun.from_process_group(opts, libs, 1, ntids, 200, local)
-        tl = time.perf_counter()
-        for t in sorted(mine):
-            m = d["tid"] == t
-            run.chromosome(t).push_reads({k: v[m] for k, v in d.items()})
-        barrier()
-        load_s = time.perf_counter() - tl
-        t0 = time.perf_counter()
-        run.run(release=False)
-        barrier()
-        dt = allmax(time.perf_counter() - t0)
-        run.release_inputs()   # (the Python side's references to the loaded arrays: not part of the run)
-        ex = run.exchange()
-        stats = allsum([ex["ctx_records_sent"], ex["ctx_records_received"]])
-        rank_ms = [0] * world
-        rank_ms[rank] = int(ex["ms_total"] * 1000)
-        rank_ms = allsum(rank_ms)
-        if rank == 0:
-            sm = run.result().summary()
-            legs[label] = {"seconds": dt, "value": total / 2 / dt, "unit": "read-pairs/s", "svs_printed": sm["n_svs_printed"], "regions": sm["n_regions"],
-                           "ctx_records_exchanged": stats[0], "gathered_bytes_on_rank0": ex["gathered_bytes"],
-                           "rank0_ms_exchange_and_ctx_join": ex["ms_exchange"], "bdx_dist_run_ms_per_rank": [x / 1000.0 for x in rank_ms],
-                           "rank0_phase_ms": run.phases(),
-                           "load_seconds_untimed": load_s}
-        run.close()
+                bd.run()
+                ts.append(time.perf_counter() - t0)
+            single = {"first_run_seconds": ts[0], "seconds": min(ts[1:]), "value": total / 2 / min(ts[1:]), "unit": "read-pairs/s",
+                      "hbm_roofline_frac_whole_path": total / 2 / min(ts[1:]) * PATH_BYTES_PER_PAIR / 1e9 / HBM_PEAK_GBS,
+                      "svs_printed": bd.summary()["n_svs_printed"],
+                      "note": "bdx_run on ONE context holding all 24 chromosomes (default options; repeated runs without enqueue-ahead, best of 3)"}
+            bd.close()
+        if rank != 0:
+            return None
+        o = {"scaling": scaling, "genome_fraction": frac,
+             "workload": "hg38-shaped genome at %.3g of its length (%d Mbp), 24 chromosomes, 4 libraries, 30x, %d planted translocations; "
+                         "chromosomes -> ranks by bdx_dist_plan" % (frac, int(sum(lengths) / 1e6), translocations),
+             "reads": total, "reads_per_rank": per_rank, "lpt_imbalance_max_over_mean": max(per_rank) / (total / world),
+             "synthesis_seconds_untimed": gen_s, **legs}
+        if single:
+            o["single_context"] = single
+        return o
+
+    weak_frac = fraction if fraction is not None else world / 8.0
+    sizes = [(weak_frac, "weak")]
+    if fraction is None and world > 1:
+        sizes.append((GENOME_FRACTION, "strong"))
+    results = [one_size(f, sc) for f, sc in sizes]
     if rank == 0:
-        out.update({"ranks": world, "scaling": "strong",
+        first = results[0]
+        out.update({"ranks": world,
                     "backend": ("ranks as threads of rank 0's process sharing one device (test hook)" if threads_backend else
                                 "RCCL (ncclAllReduce, ncclAllToAllv, grouped ncclSend/ncclRecv on device buffers)"),
-                    "workload": "hg38-shaped genome at %.3g of its length (%d Mbp), 24 chromosomes, 4 libraries, 30x, %d planted translocations; "
-                                "chromosomes -> ranks by bdx_dist_plan" % (fraction, int(sum(lengths) / 1e6), translocations),
-                    "reads": total, "reads_per_rank": per_rank, "lpt_imbalance_max_over_mean": max(per_rank) / (total / world),
-                    "synthesis_seconds_untimed": gen_s, **legs})
+                    **first})
+        if len(results) > 1:
+            out["strong_scaling_fixed_size"] = results[1]
 
 
 _LINE_FD = None
@@ -660,7 +731,7 @@ def main():
                 if not a.no_cpu_baseline:
                     cpu = cpu_baseline(bam, n, a.cpu_parallel)
         out = {
-            "metric": "read-pairs/s, records resident in HBM -> scored SV table (SURVEY 8d timing i; BAM -> table is config.timings.bam_to_table)",
+            "metric": "read-pairs/s, records resident in HBM -> scored SV table (SURVEY 8d timing i); end to end from BAM: config.timings.bam_to_table (vs_baseline is taken there)",
             "value": value, "unit": "read-pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
@@ -703,6 +774,15 @@ def main():
             out["config"]["test_hook"] = "BDX_BENCH_TEST_SHARED_GPU: all ranks on device 0, gloo process group -- not a measurement"
         if cpu:
             out["cpu_baseline"] = cpu
+            e2e = timings.get("bam_to_table", {})
+            if "value" in e2e and cpu.get("value"):
+                # like for like: BAM -> SV table on this box, GPU path (one process, exit included) over the reference-shaped CPU path on one core
+                out["vs_baseline"] = e2e["value"] / cpu["value"]
+                out["vs_baseline_is"] = "config.timings.bam_to_table.value / cpu_baseline.value (both from the same BAM to the SV table on this box; BASELINE.md holds no published number)"
+                if e2e.get("host_reader", {}).get("value") and cpu.get("per_chromosome_mode", {}).get("value"):
+                    out["config"]["timings"]["bam_to_table"]["over_cpu_per_chromosome_mode"] = e2e["value"] / cpu["per_chromosome_mode"]["value"]
+            if cpu.get("compute_only", {}).get("value"):
+                out["config"]["timings"]["hbm_resident"]["over_cpu_compute_only"] = (value / world) / cpu["compute_only"]["value"]
         emit(out)
     if exchange_hung or "error" in exchange:  # a rank stuck (or a peer lost) in a collective cannot be joined: leave as is
         sys.stdout.flush()

@@ -64,6 +64,7 @@ struct bdx_bamdec {
         bool busy = false;
         size_t cap = 0;                   // table entries
         std::thread pinning;              // (bdx_bamdec_params::piece_bytes: the buffer is being pinned)
+        size_t cap_bytes = 0;             // bytes the last bdx_bamdec_acquire promised
         hipError_t pin_status = hipSuccess;
     } staging[kBamStaging];
     int next_staging = 0, cur_staging = -1;
@@ -237,7 +238,9 @@ int bam_feed_classifier(bdx_bamdec* d, bool final) {
     return BDX_OK;
 }
 
-int bam_record_stage(bdx_bamdec* d, BamPiece& p, const BamPiece* next, bool is_last) {
+// is_last: 0 more pieces follow, 1 the file ends here, 2 the caller stops here on purpose (a region read through the index: the
+// record that runs past the cut is dropped, not an error)
+int bam_record_stage(bdx_bamdec* d, BamPiece& p, const BamPiece* next, int is_last) {
     BamTimer t6(d->host_ms[6]);
     hipStream_t s = d->s_rec;
     bdx_bamdec::Slot& sl = d->slot[p.slot];
@@ -305,7 +308,7 @@ int bam_record_stage(bdx_bamdec* d, BamPiece& p, const BamPiece* next, bool is_l
     uint32_t* base = d->d_base.as<uint32_t>();
     PieceState* st = d->d_state.as<PieceState>();
     launch_kb_chain(u, blocks, nblk, avail_end, d->filt.n_targets, cb, offs, s);
-    launch_kb_stitch(u, blocks, nblk, avail_end, is_last ? 1 : 0, cb, offs, base, st, sl.d_status.as<uint32_t>(), p.wrapped ? p.prev_end : 0,
+    launch_kb_stitch(u, blocks, nblk, avail_end, is_last, cb, offs, base, st, sl.d_status.as<uint32_t>(), p.wrapped ? p.prev_end : 0,
                      p.wrapped ? p.ring_beg : 0, s);
     RawColumns raw{d->r_tid.as<int32_t>(), d->r_pos.as<int32_t>(), d->r_mtid.as<int32_t>(), d->r_mpos.as<int32_t>(), d->r_isize.as<int32_t>(),
                    d->r_flag.as<uint16_t>(), d->r_qlen.as<uint16_t>(), d->r_mapq.as<uint8_t>(), d->r_lib.as<uint8_t>(), d->r_keep.as<uint8_t>(),
@@ -407,6 +410,7 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
     if (hipMemcpy(d->d_state.p, &st, sizeof(st), hipMemcpyHostToDevice) != hipSuccess) return bad(BDX_EHIP);
     if (d->h_progress.ensure(64) != hipSuccess) return bad(BDX_ENOMEM);
     memset(d->h_progress.p, 0, 64);
+    if (sink && sink->adopted) return bad(BDX_ESTATE);   // (before the pinning threads start: a decoder that fails from here on is destroyed at once)
     // (behind the decoder's own pinned allocation: page pinning does not run in parallel with itself)
     if (p->piece_bytes && p->piece_blocks)
         for (auto& st : d->staging) {
@@ -454,6 +458,8 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
 void bdx_bamdec_destroy(bdx_bamdec* d) {
     if (!d) return;
     (void)hipSetDevice(d->device);
+    for (auto& st : d->staging)   // (before anything of theirs is released: a thread may still be pinning its staging buffer)
+        if (st.pinning.joinable()) st.pinning.join();
     for (hipStream_t s : {d->s_copy, d->s_inf, d->s_inf2, d->s_rec})
         if (s) (void)hipStreamSynchronize(s);
     for (auto& sl : d->slot) {
@@ -476,8 +482,6 @@ void bdx_bamdec_destroy(bdx_bamdec* d) {
                       &d->o_tid, &d->o_pos, &d->o_mtid, &d->o_mpos, &d->o_isize, &d->o_flag, &d->o_qlen, &d->o_mapq, &d->o_lib, &d->o_bam, &d->o_key})
         b->release();
     d->h_progress.release();
-    for (auto& st : d->staging)
-        if (st.pinning.joinable()) st.pinning.join();
     if (d->borrowed_streams) d->s_copy = d->s_rec = nullptr;
     if (d->s_inf2 == d->s_inf) d->s_inf2 = nullptr;
     for (hipStream_t s : {d->s_copy, d->s_inf, d->s_inf2, d->s_rec})
@@ -510,6 +514,7 @@ int bdx_bamdec_acquire(bdx_bamdec* d, size_t bytes, size_t max_blocks, void** bu
     *buf = st.h_comp.p;
     *blocks = st.h_tab.as<bdx_bgzf_block>();
     st.cap = max_blocks;
+    st.cap_bytes = bytes;
     d->cur_staging = d->next_staging;
     d->next_staging = (d->next_staging + 1) % kBamStaging;
     return BDX_OK;
@@ -574,12 +579,12 @@ int bam_launch_batch(bdx_bamdec* d, int si, bool last) {
     if (d->pieces.size() >= 2) {
         BamPiece& prev = d->pieces[d->pieces.size() - 2];
         if (!prev.records_done) {
-            const int rc = bam_record_stage(d, prev, &d->pieces.back(), false);
+            const int rc = bam_record_stage(d, prev, &d->pieces.back(), 0);
             if (rc != BDX_OK) return rc;
         }
     }
     if (last) {
-        const int rc = bam_record_stage(d, d->pieces.back(), nullptr, true);
+        const int rc = bam_record_stage(d, d->pieces.back(), nullptr, 1);
         if (rc != BDX_OK) return rc;
         d->finished = true;
     }
@@ -626,9 +631,10 @@ int bdx_bamdec_submit(bdx_bamdec* d, size_t bytes, size_t nblocks, int last) {
     bdx_bamdec::Staging& st = d->staging[d->cur_staging];
     d->cur_staging = -1;
     if (nblocks > st.cap) return bfail(d, BDX_EINVAL, "more blocks than the acquired table holds");
+    if (bytes > st.cap_bytes) return bfail(d, BDX_EINVAL, "more bytes than the acquired piece holds");
     const bdx_bgzf_block* hb = st.h_tab.as<bdx_bgzf_block>();
-    for (size_t i = 0; i < nblocks; ++i)
-        if (hb[i].inflated_len > 65536 || hb[i].offset + hb[i].payload_len > bytes) return bfail(d, BDX_EINVAL, "BGZF block table does not fit the piece");
+    for (size_t i = 0; i < nblocks; ++i)   // (offset near 2^64 must not wrap the sum)
+        if (hb[i].inflated_len > 65536 || hb[i].offset > bytes || hb[i].payload_len > bytes - hb[i].offset) return bfail(d, BDX_EINVAL, "BGZF block table does not fit the piece");
     int rc = bam_open_batch(d, bytes, nblocks);
     if (rc != BDX_OK) return rc;
     {   // a piece that does not fit the open batch's buffers any more: that batch goes first
@@ -689,7 +695,7 @@ int bdx_bamdec_finish(bdx_bamdec* d, uint64_t* n_records) {
             if (rc != BDX_OK) return rc;
         }
         if (!d->pieces.empty() && !d->pieces.back().records_done) {
-            const int rc = bam_record_stage(d, d->pieces.back(), nullptr, false);
+            const int rc = bam_record_stage(d, d->pieces.back(), nullptr, 2);
             if (rc != BDX_OK) return rc;
         }
         d->finished = true;
@@ -814,7 +820,7 @@ int bdx_inflate_blocks(int device, const void* compressed, size_t bytes, const b
     std::vector<BgzfBlock> tb(nblocks);
     uint64_t o = 0;
     for (size_t i = 0; i < nblocks; ++i) {
-        if (blocks[i].inflated_len > 65536 || blocks[i].offset + blocks[i].payload_len > bytes) return BDX_EINVAL;
+        if (blocks[i].inflated_len > 65536 || blocks[i].offset > bytes || blocks[i].payload_len > bytes - blocks[i].offset) return BDX_EINVAL;
         tb[i].in_off = blocks[i].offset; tb[i].in_len = blocks[i].payload_len; tb[i].out_off = o; tb[i].out_len = blocks[i].inflated_len;
         o += blocks[i].inflated_len;
     }

@@ -135,7 +135,9 @@ __global__ __launch_bounds__(kStitchThreads) void kb_stitch_kernel(const uint8_t
                 cb[b] = c;
                 ++redo;
             }
-            if (c.bad) error = c.bad == 2 && is_last ? 4 : (c.bad == 1 ? 1 : 2);   // from a TRUE boundary: a corrupt or truncated file, or too long a record
+            // from a TRUE boundary: a corrupt or truncated file, or too long a record -- unless the stream was cut here on purpose
+            // (is_last == 2: the size word of the record behind the cut is simply not there)
+            if (c.bad && !(is_last == 2 && c.bad == 2)) error = c.bad == 2 && is_last ? 4 : (c.bad == 1 ? 1 : 2);
             expect = beg + (uint64_t)c.end;
         }
         if (first_bad == nblk && nblk) expect = blocks[nblk - 1].out_off + (uint64_t)cb[nblk - 1].end;
@@ -143,7 +145,16 @@ __global__ __launch_bounds__(kStitchThreads) void kb_stitch_kernel(const uint8_t
         // (a fine prefix may still end in a walk that ran out of bytes)
         st->next_start = expect;
         st->redo += redo;
-        if (is_last && !error && expect != avail_end) error = 4;   // the last record is cut off
+        if (is_last == 2 && !error && expect > avail_end) {
+            // The caller stopped reading behind its region (a .bai seek): the record that begins in the last member handed over and ends
+            // behind it is not part of the result -- writers that do not align records to members (htsjdk, sambamba) produce one at
+            // nearly every cut.  It is the last record counted: taken back, no error.
+            for (uint32_t b = nblk; b-- > 0;)
+                if (cb[b].count) { cb[b].count -= 1; break; }
+            expect = avail_end;
+            st->next_start = expect;
+        }
+        if (is_last == 1 && !error && expect != avail_end) error = 4;   // the last record is cut off
         // (a record that begins in this batch and ends behind its successor: its tail -- the tags -- is not inflated yet.  Batches of the
         // default size hold a hundred times the longest record this path takes; a caller's tiny batches can be outgrown)
         if (!is_last && !error && expect > avail_end) error = 2;

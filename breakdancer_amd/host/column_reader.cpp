@@ -274,6 +274,61 @@ bool ColumnReader::seek_with_index(int tid, int beg) {
     return false;
 }
 
+bool ColumnReader::index_span(int tid, size_t* begin, size_t* end, bool* empty) const {
+    if (empty) *empty = false;
+    if (getenv("BDX_BAM_NO_INDEX")) return false;
+    std::string bai = path_ + ".bai";
+    FILE* f = fopen(bai.c_str(), "rb");
+    if (!f && path_.size() > 4 && path_.compare(path_.size() - 4, 4, ".bam") == 0) {
+        bai = path_.substr(0, path_.size() - 4) + ".bai";
+        f = fopen(bai.c_str(), "rb");
+    }
+    if (!f) return false;
+    std::vector<uint8_t> d;
+    {
+        uint8_t buf[1 << 16];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof(buf), f)) > 0) d.insert(d.end(), buf, buf + n);
+        fclose(f);
+    }
+    size_t p = 0;
+    auto u32 = [&](uint32_t& v) { if (p + 4 > d.size()) return false; v = le32(d.data() + p); p += 4; return true; };
+    auto u64 = [&](uint64_t& v) {
+        if (p + 8 > d.size()) return false;
+        v = (uint64_t)le32(d.data() + p) | ((uint64_t)le32(d.data() + p + 4) << 32);
+        p += 8;
+        return true;
+    };
+    uint32_t magic, n_ref;
+    if (!u32(magic) || magic != 0x01494142u || !u32(n_ref) || (uint32_t)tid >= n_ref) return false;
+    for (uint32_t r = 0; r < n_ref; ++r) {
+        uint32_t n_bin;
+        if (!u32(n_bin)) return false;
+        uint64_t lo = ~0ull, hi = 0;
+        for (uint32_t b = 0; b < n_bin; ++b) {
+            uint32_t bin, n_chunk;
+            if (!u32(bin) || !u32(n_chunk)) return false;
+            for (uint32_t c = 0; c < n_chunk; ++c) {
+                uint64_t cb, ce;
+                if (!u64(cb) || !u64(ce)) return false;
+                if (bin == 37450) continue;   // (the metadata pseudo-bin of newer indexers)
+                lo = std::min(lo, cb);
+                hi = std::max(hi, ce);
+            }
+        }
+        uint32_t n_intv;
+        if (!u32(n_intv)) return false;
+        if (p + 8ull * n_intv > d.size()) return false;
+        p += 8ull * n_intv;
+        if ((int)r != tid) continue;
+        if (lo == ~0ull) { if (empty) *empty = true; return false; }
+        *begin = (size_t)(lo >> 16);
+        *end = std::min<size_t>(map_size_, (size_t)(hi >> 16) + 65536 + 28);
+        return *begin < map_size_;
+    }
+    return false;
+}
+
 // Index blocks until block i exists (anyone may advance the index: a worker whose last record runs past the blocks indexed
 // so far does it itself).  Returns false if the file ends before block i.
 bool ColumnReader::wait_for_block(size_t i) {
@@ -395,6 +450,11 @@ void ColumnReader::inflate_into(Scratch& sc, const Piece& p, size_t block) {
     if (zlib_only || b.coff + b.clen + 32 > map_size_ ||
         !fast_inflate(map_ + b.coff, b.clen, sc.buf.data() + at, b.ulen, sc.buf.size() - (at + b.ulen)))
         inflate_raw(map_ + b.coff, b.clen, sc.buf.data() + at, b.ulen, path_);
+    // the member's CRC-32 (the four bytes behind its payload) against what came out: a flipped bit in a stored or literal-heavy block
+    // inflates without complaint (htslib checks it too; BDX_BAM_NO_CRC=1 skips the check)
+    static const bool no_crc = getenv("BDX_BAM_NO_CRC") != nullptr;
+    if (!no_crc && b.coff + b.clen + 4 <= map_size_ && crc32_fast(sc.buf.data() + at, b.ulen) != le32(map_ + b.coff + b.clen))
+        throw std::runtime_error("BGZF block fails its CRC-32 (corrupt file): " + path_);
     sc.filled = at + b.ulen;
 }
 

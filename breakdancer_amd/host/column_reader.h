@@ -72,6 +72,9 @@ public:
     void locate(const RecordFilter& f, size_t* member_offset, uint64_t* record_offset, bool* seeked);
     const uint8_t* mapped() const { return map_; }
     size_t mapped_size() const { return map_size_; }
+    // <path>.bai: the range of the file that holds sequence tid's records -- [begin, end) in compressed bytes, member aligned at its
+    // begin, a member's worth of slack at its end.  false: no index, or nothing indexed for the sequence (*empty tells which)
+    bool index_span(int tid, size_t* begin, size_t* end, bool* empty) const;
     // the next piece's columns in file order, or nullptr at the end of the file; valid until the following call
     const ColumnChunk* next();
 

@@ -324,4 +324,38 @@ bool fast_inflate(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len
     return consumed_bits <= in_len * 8;
 }
 
+
+namespace {
+struct CrcTables {
+    uint32_t t[16][256];
+    CrcTables() {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            t[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int k = 1; k < 16; ++k) t[k][i] = (t[k - 1][i] >> 8) ^ t[0][t[k - 1][i] & 0xFFu];
+    }
+};
+const CrcTables& crc_tables() { static const CrcTables t; return t; }
+}  // namespace
+
+uint32_t crc32_fast(const uint8_t* p, size_t n) {
+    const CrcTables& T = crc_tables();
+    uint32_t c = 0xFFFFFFFFu;
+    while (n >= 16) {
+        uint32_t a, b, d, e;
+        memcpy(&a, p, 4); memcpy(&b, p + 4, 4); memcpy(&d, p + 8, 4); memcpy(&e, p + 12, 4);
+        a ^= c;
+        c = T.t[15][a & 0xFFu] ^ T.t[14][(a >> 8) & 0xFFu] ^ T.t[13][(a >> 16) & 0xFFu] ^ T.t[12][a >> 24] ^
+            T.t[11][b & 0xFFu] ^ T.t[10][(b >> 8) & 0xFFu] ^ T.t[9][(b >> 16) & 0xFFu] ^ T.t[8][b >> 24] ^
+            T.t[7][d & 0xFFu] ^ T.t[6][(d >> 8) & 0xFFu] ^ T.t[5][(d >> 16) & 0xFFu] ^ T.t[4][d >> 24] ^
+            T.t[3][e & 0xFFu] ^ T.t[2][(e >> 8) & 0xFFu] ^ T.t[1][(e >> 16) & 0xFFu] ^ T.t[0][e >> 24];
+        p += 16; n -= 16;
+    }
+    while (n--) c = T.t[0][(c ^ *p++) & 0xFFu] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+
 }  // namespace bdhost

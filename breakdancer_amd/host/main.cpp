@@ -184,6 +184,7 @@ int main(int argc, char** argv) {
     if (!getenv("BDX_FOREGROUND") && !getenv("BDX_CLEAN_EXIT")) {
         int pfd[2];
         if (pipe(pfd) == 0) {
+            const pid_t parent = getpid();   // (may be 1: a container's entry point)
             const pid_t pid = fork();
             if (pid > 0) {
                 close(pfd[1]);
@@ -204,7 +205,7 @@ int main(int argc, char** argv) {
                 // (killing the command kills the work: the child is told when the process that was started goes -- after the report
                 // that only cuts its exit short)
                 prctl(PR_SET_PDEATHSIG, SIGTERM);
-                if (getppid() == 1) _exit(1);
+                if (getppid() != parent) _exit(1);   // (the parent went before the signal was armed)
             } else {  // (no child: everything in this process)
                 close(pfd[0]);
                 close(pfd[1]);

@@ -379,12 +379,18 @@ void retire(bdx_bamdec* d) {
 
 // One file of the configuration through a device-side decoder.  With a sink the records go into its store (and are classified as
 // they arrive); without, they stay in the decoder's own columns and the decoder is handed back (*keep) for the merge.
+// whole_tid >= 0 (sharded runs): ALL records of that sequence -- through the index, which must be there; span_bytes: what the sequence
+// takes of the file (sizes the decoder's buffers and the sink's store instead of "the rest of the file")
 size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::string& chr, int threads, std::vector<std::string>* targets, bdx_ctx* ctx,
-                        int device, bool* unsupported, bdx_bamdec** keep) {
+                        int device, bool* unsupported, bdx_bamdec** keep, int whole_tid = -1, size_t span_bytes = 0) {
     const std::string& path = cfg.bam_files()[bam_index];
     ColumnReader hdr(path, 1, nullptr);   // (the header: reference names, where the first record lies; the index for -o)
     RecordFilter f;
-    if (!chr.empty() && !parse_region(hdr, chr, f.only_tid, f.beg, f.end))
+    if (whole_tid >= 0) {
+        f.only_tid = whole_tid;
+        f.beg = -(1 << 30);       // (every record of the sequence, whatever its position says: the whole-genome run keeps them all)
+        f.end = 0x7FFFFFFF;
+    } else if (!chr.empty() && !parse_region(hdr, chr, f.only_tid, f.beg, f.end))
         throw std::runtime_error("Failed to parse bam region '" + chr + "' in file " + path + ". ");
     if (targets) *targets = hdr.target_names();
     size_t member_off = 0;
@@ -411,7 +417,8 @@ size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::strin
     // pieces (transfer units) of 16 MiB; the decoder gathers them into batches of >= 8192 members before it launches kernels.
     // Small files get small buffers.  Test knobs: BDX_BAM_PIECE_BYTES, BDX_BAM_BATCH_BLOCKS, BDX_BAM_RING_BYTES
     const size_t kPiece = getenv("BDX_BAM_PIECE_BYTES") ? (size_t)std::max(1ll, atoll(getenv("BDX_BAM_PIECE_BYTES"))) : ((size_t)8 << 20);   // (a staging buffer costs ~0.22 ms per MiB to pin and is reused dozens of times)
-    const size_t rest = file_size - std::min(file_size, member_off);
+    size_t rest = file_size - std::min(file_size, member_off);
+    if (span_bytes) rest = std::min(rest, span_bytes);
     p.batch_bytes = std::min<size_t>((size_t)384 << 20, ((rest + ((size_t)1 << 20)) >> 20) << 20);
     p.expected_bytes = rest;
     p.batch_blocks = getenv("BDX_BAM_BATCH_BLOCKS") ? (size_t)std::max(1ll, atoll(getenv("BDX_BAM_BATCH_BLOCKS"))) : 0;
@@ -654,6 +661,65 @@ void merge_order(const std::vector<const int32_t*>& tid, const std::vector<const
         }
         if (c->i < c->n) pq.push(c);
     }
+}
+
+// ONE BAM with its index, the chromosomes of one whole-genome run spread over ranks (bdx_dist_*): every rank's thread reads the BGZF
+// ranges of ITS chromosomes (the index says where they lie) and decodes them on ITS GPU, straight into the rank's context -- the
+// reference's answer to "one chromosome" is the same indexed seek (io/RegionLimitedBamReader.hpp:43-71: bam_index_load, bam_iter_query).
+// Nothing is decoded twice and no record crosses the host.  unsupported: no index (or not one file), nothing was done.
+size_t produce_sharded_on_device(const BamConfig& cfg, int threads, std::vector<std::string>* targets, const std::vector<bdx_dist*>& ranks,
+                                 const std::vector<int>& devices, const std::vector<int>& rank_of, bool* unsupported) {
+    *unsupported = true;
+    if (cfg.num_bams() != 1) return 0;
+    const std::string& path = cfg.bam_files()[0];
+    std::vector<std::string> names;
+    struct Span { size_t begin = 0, end = 0; bool has = false; };
+    std::vector<Span> span;
+    {
+        ColumnReader hdr(path, 1, nullptr);
+        names = hdr.target_names();
+        span.resize(names.size());
+        bool any_index = false;
+        for (size_t t = 0; t < names.size(); ++t) {
+            bool empty = false;
+            span[t].has = hdr.index_span((int)t, &span[t].begin, &span[t].end, &empty);
+            if (span[t].has || empty) any_index = true;
+            if (!span[t].has && !empty) return 0;   // (no index, or one that does not cover the header's sequences: the host producer takes the file)
+        }
+        if (!any_index) return 0;
+    }
+    if (targets) *targets = names;
+    const int world = (int)ranks.size();
+    std::vector<size_t> n_of(world, 0);
+    std::vector<std::string> errs(world);
+    std::vector<int> gave_up(world, 0);
+    std::vector<std::thread> th;
+    const int per = std::max(2, threads / std::max(1, world));
+    for (int r = 0; r < world; ++r)
+        th.emplace_back([&, r] {
+            try {
+                for (size_t t = 0; t < names.size(); ++t) {
+                    if (rank_of[t] != r || !span[t].has) continue;
+                    bdx_ctx* c = bdx_dist_chromosome(ranks[r], (int)t);
+                    if (!c) throw std::runtime_error(std::string("bdx_dist_chromosome: ") + bdx_dist_last_error(ranks[r]));
+                    if (bdx_use_name_check(c, 1) != BDX_OK) throw std::runtime_error("bdx_use_name_check");
+                    bool un = false;
+                    n_of[r] += decode_on_device(cfg, 0, "", per, nullptr, c, devices[r], &un, nullptr, (int)t, span[t].end - span[t].begin);
+                    if (un) { gave_up[r] = 1; return; }
+                }
+            } catch (std::exception const& e) {
+                errs[r] = e.what();
+            }
+        });
+    for (auto& t : th) t.join();
+    for (auto const& e : errs)
+        if (!e.empty()) throw std::runtime_error(e);
+    for (int g : gave_up)
+        if (g) return 0;   // (a record the device path does not take: the caller starts over with the host producer)
+    *unsupported = false;
+    size_t n = 0;
+    for (size_t x : n_of) n += x;
+    return n;
 }
 
 size_t produce_on_device(const BamConfig& cfg, const std::string& chr, int threads, std::vector<std::string>* targets, bdx_ctx* ctx,

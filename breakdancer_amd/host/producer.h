@@ -57,6 +57,11 @@ size_t produce_stream(const BamConfig& cfg, const std::string& chr, int threads,
 // when the file is one the device path leaves to the host reader (a record of more than 4 MiB), with nothing appended.
 size_t produce_on_device(const BamConfig& cfg, const std::string& chr, int threads, std::vector<std::string>* targets, bdx_ctx* ctx,
                          bool* unsupported);
+// One whole-genome run over several GPUs from ONE indexed BAM: rank r's thread decodes the chromosomes t with rank_of[t] == r on
+// devices[r], into bdx_dist_chromosome(ranks[r], t).  *unsupported: no index / several files -- nothing was appended, or a file the
+// device path gives up on (the caller then recreates the ranks and takes the host producer).
+size_t produce_sharded_on_device(const BamConfig& cfg, int threads, std::vector<std::string>* targets, const std::vector<bdx_dist*>& ranks,
+                                 const std::vector<int>& devices, const std::vector<int>& rank_of, bool* unsupported);
 // the decoders produce_on_device used are kept (releasing them costs more than the run that follows): this releases them
 void release_device_decoders();
 // reference sequences of the first BAM of the configuration (names and lengths from its header; io/BamMerger.cpp:78)

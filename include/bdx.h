@@ -385,6 +385,9 @@ int bdx_dist_plan(const uint64_t* weight, int ntids, int world, int* rank_of_tid
  * (primary, placed: io/AlignmentFilter.hpp:24-34, io/BamIo.cpp:11-18; -o region: io/RegionLimitedBamReader.hpp:63-71).  The caller
  * reads the file, finds the BGZF members (18-byte headers, 8-byte footers) and hands the bytes over as they are, in pieces of whole
  * members; everything else happens on the GPU, and the file crosses PCIe compressed.
+ * Integrity: the inflate kernel rejects what zlib rejects (invalid codes, distances before the window, a member that does not end
+ * at its ISIZE) and the record stage rejects chains that do not add up; the members' CRC-32 words are NOT checked on the device --
+ * the host reader (host/column_reader.cpp, BDX_DECODE=host) checks every member's, as htslib does.
  *
  *   bdx_bamdec_create    sink != NULL: the decoded records are appended to that context's resident store (one file: the stream
  *                        IS the file's record order) and the classifier follows them; bdx_run afterwards as usual.  sink == NULL:

@@ -45,3 +45,15 @@ def test_no_gpu_means_exit_status_one_and_a_message():
         pass
     p = run(["inv_del_bam_config"], cwd=os.path.join(GOLDEN, "chr21"))
     assert p.returncode == 1 and b"ERROR: bdx_create" in p.stderr and not [l for l in p.stdout.splitlines() if not l.startswith(b"#")]
+
+
+def test_the_command_as_pid_1_of_a_container(tmp_path):
+    """the started process can legitimately be PID 1 (a container's entry point): the child must not take its parent for gone"""
+    import shutil
+    if not shutil.which("unshare"):
+        pytest.skip("no unshare")
+    probe = subprocess.run(["unshare", "-pf", "true"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if probe.returncode != 0:
+        pytest.skip("unshare -pf not permitted here")
+    p = subprocess.run(["unshare", "-pf", EXE, str(tmp_path / "nothing.cfg")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 1 and b"unable to open config file" in p.stderr

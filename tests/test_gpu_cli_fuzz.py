@@ -189,3 +189,28 @@ def test_cli_records_spanning_several_bgzf_members(tmp_path):
         assert ("on the GPU" in p.stderr.decode()) == label.startswith("device"), (label, p.stderr.decode()[-600:])
         out[label] = filter_cmd_lines(p.stdout.decode())
     assert out["device"] == out["host"] == out["device-small-pieces"] == out["host-after-all"] and [l for l in out["host"].splitlines() if not l.startswith("#")]
+
+
+@pytest.mark.parametrize("region,seed", [("c2", 1), ("c2:9000-21000", 2), ("c1:1-6000", 3), ("c3:15,000", 4)])
+def test_cli_region_through_the_index_on_the_device_reader(region, seed, tmp_path):
+    """-o with a .bai beside the BAM, decoded on the GPU: decoding starts at the region and STOPS behind it -- the feeder hands over no
+    further piece, and a record that begins in the last member handed over and ends behind it (records are not aligned to members in
+    this file, as in htsjdk's / sambamba's output) is dropped, not an error that sends the file to the host reader (io/RegionLimitedBamReader.hpp:43-71)"""
+    from breakdancer_amd.bamwrite import write_bam_records
+    cfg, streams, targets = make_case(810 + seed, n_pairs=40000)
+    cfg1 = "".join(l + "\n" for l in cfg.splitlines() if "map:a.bam" in l)
+    st = streams[0]
+    recs = [dict(tid=st["tid"][i], pos=st["pos"][i], mtid=st["mtid"][i], mpos=st["mpos"][i], isize=st["isize"][i], flag=st["flag"][i],
+                 qlen=st["qlen"][i], mapq=int(st["bdqual"][i]), rg=st["rg"][i], name="read%d" % int(st["name_id"][i])) for i in range(len(st["tid"]))]
+    write_bam_records(str(tmp_path / "a.bam"), recs, targets, rgs=("rg1", "rg2", "rg3"), seed=seed, index=True)
+    assert os.path.getsize(str(tmp_path / "a.bam")) > 8 * 65536 and os.path.exists(str(tmp_path / "a.bam.bai"))
+    (tmp_path / "cfg").write_text(cfg1)
+    texts = {}
+    for label, env in (("device", dict(BDX_TIMING="1", BDX_BAM_PIECE_BYTES="131072", BDX_BAM_BATCH_BLOCKS="2")), ("device-default", dict(BDX_TIMING="1")),
+                       ("host", dict(BDX_TIMING="1", BDX_DECODE="host")), ("host-full-scan", dict(BDX_TIMING="1", BDX_DECODE="host", BDX_BAM_NO_INDEX="1"))):
+        p = subprocess.run([EXE, "-y", "-1", "-o", region, "cfg"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert p.returncode == 0, (label, p.stderr.decode())
+        assert ("on the GPU" in p.stderr.decode()) == label.startswith("device"), (label, p.stderr.decode())   # (no silent hand-over to the host reader)
+        texts[label] = filter_cmd_lines(p.stdout.decode())
+    assert texts["device"] == texts["device-default"] == texts["host"] == texts["host-full-scan"]
+    assert [l for l in texts["host"].splitlines() if not l.startswith("#")]

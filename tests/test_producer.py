@@ -213,3 +213,28 @@ def test_merge_order_with_heavy_ties_across_several_files(tmp_path, nfiles, seed
         np.testing.assert_array_equal(keys, keys2, err_msg=how)
     t = rows[:, 0] * (1 << 32) + rows[:, 1]
     assert ((t[1:] == t[:-1]) & (rows[1:, 9] != rows[:-1, 9])).sum() > 100   # neighbours with one key from two files
+
+
+def test_a_block_that_fails_its_crc_is_an_error(tmp_path):
+    """a member whose stored CRC-32 does not match what it inflates to (here: the CRC word itself is changed; a flipped bit in a stored
+    or literal-only block looks the same): the host reader reports a corrupt file instead of decoding on"""
+    import shutil
+    import struct
+    src = os.path.join(GOLDEN, "chr21")
+    for f in ("NA19238_chr21_del_inv.bam", "NA19240_chr21_del_inv.bam", "inv_del_bam_config"):
+        shutil.copy(os.path.join(src, f), str(tmp_path / f))
+    path = str(tmp_path / "NA19238_chr21_del_inv.bam")
+    data = bytearray(open(path, "rb").read())
+    off, k = 0, 0
+    while off < len(data):   # the third member's footer
+        bsize = struct.unpack_from("<H", data, off + 16)[0] + 1
+        if k == 2:
+            data[off + bsize - 8] ^= 0x40
+            break
+        off += bsize
+        k += 1
+    open(path, "wb").write(bytes(data))
+    p = subprocess.run([DUMP, "inv_del_bam_config"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 1 and b"CRC-32" in p.stderr
+    p = subprocess.run([DUMP, "inv_del_bam_config"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, BDX_BAM_NO_CRC="1"))
+    assert p.returncode == 0
