@@ -389,6 +389,16 @@ bdx_ctx* bdx_dist_chromosome(bdx_dist* d, int tid) {
     return c;
 }
 
+int bdx_dist_reset_reads(bdx_dist* d) {
+    if (!d) return BDX_EINVAL;
+    const int rc = bdx_reset_reads(d->reads);
+    if (rc != BDX_OK) return dfail(d, rc, d->reads->err);
+    d->last_tid = -1;
+    d->n_at_last = 0;
+    d->ran = false;
+    return BDX_OK;
+}
+
 int bdx_dist_prepare(bdx_dist* d) {
     if (!d) return BDX_EINVAL;
     bdx_ctx* c = d->reads;

@@ -309,8 +309,28 @@ int run(int argc, char** argv) {
             weight.resize(ntids, 0);
             std::vector<int> rank_of(ntids, 0);
             bdx_dist_plan(weight.data(), ntids, world, rank_of.data());
-            RoutingSink sink(ranks, rank_of);
-            n_reads = produce_stream(cfg, opts.chr, (int)io_threads, &targets, sink);
+            // One BAM with its index: every rank pulls the BGZF ranges of ITS chromosomes and decodes them on ITS GPU (bdx_bamdec_*), as the
+            // reference reads one chromosome through the index (io/RegionLimitedBamReader.hpp:43-71).  Without an index, with several
+            // files or with BDX_DECODE=host: the host producer decodes everything once and routes the records to the ranks.
+            const char* dm = getenv("BDX_DECODE");
+            bool on_device = false;
+            if (!(dm && !strcmp(dm, "host")) && cfg.num_bams() == 1) {
+                bool unsupported = true;
+                n_reads = produce_sharded_on_device(cfg, (int)std::min(std::max(usable_cpus(), 2u), 32u), &targets, ranks, devices, rank_of, &unsupported);
+                on_device = !unsupported;
+                if (unsupported)   // (no index: nothing was appended; a file the device path gave up on half way: what it appended goes again)
+                    for (bdx_dist* r : ranks)
+                        if (bdx_dist_reset_reads(r) != BDX_OK) throw std::runtime_error(std::string("bdx_dist_reset_reads: ") + bdx_dist_last_error(r));
+            }
+            if (!on_device) {
+                RoutingSink sink(ranks, rank_of);
+                n_reads = produce_stream(cfg, opts.chr, (int)io_threads, &targets, sink);
+            }
+            if (timing)
+                fprintf(stderr, "[bdx timing] sharded run over %d ranks: %s\n", world,
+                        on_device ? "every rank decoded its chromosomes' BGZF ranges on its own GPU (through the BAM index)"
+                                  : "records decoded by the host producer and routed to the ranks");
+            for (bdx_dist* r : ranks) (void)bdx_dist_prepare(r);   // (device code loaded, the later stages' buffers sized: beside nothing, but outside the run)
             t_decoded = now();
             std::vector<int> rcs(world, BDX_OK);
             std::vector<std::thread> th;

@@ -388,7 +388,7 @@ size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::strin
     RecordFilter f;
     if (whole_tid >= 0) {
         f.only_tid = whole_tid;
-        f.beg = -(1 << 30);       // (every record of the sequence, whatever its position says: the whole-genome run keeps them all)
+        f.beg = 0;                // (every placed record of the sequence: the device's overlap test compares unsigned)
         f.end = 0x7FFFFFFF;
     } else if (!chr.empty() && !parse_region(hdr, chr, f.only_tid, f.beg, f.end))
         throw std::runtime_error("Failed to parse bam region '" + chr + "' in file " + path + ". ");

@@ -359,6 +359,7 @@ int bdx_dist_rank(const bdx_dist* d);
 int bdx_dist_world(const bdx_dist* d);
 bdx_ctx* bdx_dist_chromosome(bdx_dist* d, int tid);
 int bdx_dist_prepare(bdx_dist* d);
+int bdx_dist_reset_reads(bdx_dist* d);   /* empties the rank's store (capacity kept): the chromosomes are fed again */
 int bdx_dist_run(bdx_dist* d);
 bdx_ctx* bdx_dist_result(bdx_dist* d);
 /* before bdx_dist_run, on every rank alike: the result context also holds the supporting reads of every SV (bdx_get_sv_support on

@@ -214,3 +214,44 @@ def test_cli_region_through_the_index_on_the_device_reader(region, seed, tmp_pat
         texts[label] = filter_cmd_lines(p.stdout.decode())
     assert texts["device"] == texts["device-default"] == texts["host"] == texts["host-full-scan"]
     assert [l for l in texts["host"].splitlines() if not l.startswith("#")]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_cli_sharded_run_decodes_every_ranks_chromosomes_on_its_own_gpu(seed, tmp_path):
+    """BDX_GPUS with ONE indexed BAM: every rank pulls the BGZF ranges of its chromosomes through the .bai and decodes them on its GPU
+    (bdx_bamdec_* with the rank's context as sink) -- same text as the oracle's whole-genome run, as the host producer's routing
+    (no index / BDX_DECODE=host) and as the single-GPU run"""
+    from breakdancer_amd.bamwrite import write_bam_records
+    rng = np.random.default_rng(40 + seed)
+    cfg, streams, targets = make_case(860 + seed, n_pairs=int(rng.integers(1500, 6000)))
+    cfg1 = "".join(l + "\n" for l in cfg.splitlines() if "map:a.bam" in l)
+    st = streams[0]
+    recs = [dict(tid=st["tid"][i], pos=st["pos"][i], mtid=st["mtid"][i], mpos=st["mpos"][i], isize=st["isize"][i], flag=st["flag"][i],
+                 qlen=st["qlen"][i], mapq=int(st["bdqual"][i]), rg=st["rg"][i], name="read%d" % int(st["name_id"][i])) for i in range(len(st["tid"]))]
+    write_bam_records(str(tmp_path / "a.bam"), recs, targets, rgs=("rg1", "rg2", "rg3"), seed=seed, index=True)
+    (tmp_path / "cfg").write_text(cfg1)
+    args, kw = FLAGSETS[(2 * seed) % len(FLAGSETS)]
+    if "-o" in args:
+        args, kw = [], dict()
+    run = oracle_case(cfg1, streams[:1], targets, make_opts(score_threshold=-1, **kw))
+    want = filter_cmd_lines(run.text)
+    gpus = "0,0,0" if seed % 2 else "0,0"
+    for label, env, marker in (("device", dict(BDX_GPUS=gpus, BDX_TIMING="1"), "on its own GPU"),
+                               ("device-small-pieces", dict(BDX_GPUS=gpus, BDX_TIMING="1", BDX_BAM_PIECE_BYTES="100000", BDX_BAM_BATCH_BLOCKS="3"), "on its own GPU"),
+                               ("host-routing", dict(BDX_GPUS=gpus, BDX_TIMING="1", BDX_DECODE="host"), "routed to the ranks"),
+                               ("no-index", dict(BDX_GPUS=gpus, BDX_TIMING="1", BDX_BAM_NO_INDEX="1"), "routed to the ranks"),
+                               ("one-gpu", dict(BDX_TIMING="1"), "on the GPU")):
+        p = subprocess.run([EXE, "-y", "-1"] + args + ["cfg"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert p.returncode == 0, (label, p.stderr.decode())
+        assert marker in p.stderr.decode(), (label, p.stderr.decode())
+        assert filter_cmd_lines(p.stdout.decode()) == want, (label, args, p.stderr.decode())
+    # -g / -d through the sharded device reader: the dumps' stream indices are positions in the merged stream of the whole file
+    outs = {}
+    for label, env in (("sharded", dict(BDX_GPUS=gpus)), ("one", dict())):
+        d = tmp_path / label
+        d.mkdir()
+        p = subprocess.run([EXE, "-y", "-1", "-g", str(d / "out.bed"), "-d", str(d / "fq"), "cfg"], cwd=str(tmp_path), stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr.decode()
+        outs[label] = {f: open(os.path.join(str(d), f), "rb").read() for f in sorted(os.listdir(str(d)))}
+    assert outs["sharded"] == outs["one"] and outs["one"]
