@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--genome-fraction", type=float, default=None,
                     help="hg38 lengths x this for the genome leg (default N/8: 116 M records per GPU at every N -- the whole genome of configs[2] / [3] at N = 8 -- "
                          "plus, for N > 1, the fixed 1/8 spread over the N ranks)")
+    ap.add_argument("--no-sharded-cli", action="store_true", help="skip config.timings.bam_to_table_sharded (BDX_GPUS on one indexed genome BAM)")
+    ap.add_argument("--sharded-cli-fraction", type=float, default=1.0 / 64, help="hg38 lengths x this for that BAM (default 1/64: 14.5 M records)")
     ap.add_argument("--no-overlap", action="store_true", help="skip the three-contexts-in-flight measurement (config.overlapped_contexts)")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 --pmc sub-run that measures roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -352,6 +354,50 @@ def time_bam_cli(bam, cfg, n):
     return out
 
 
+def time_bam_cli_sharded(td, n_gpus_visible, fraction=1.0 / 64):
+    """BAM -> SV table with the chromosomes of ONE indexed BAM spread over ranks (BDX_GPUS): every rank decodes its chromosomes' BGZF
+    ranges on its own GPU.  A 24-chromosome genome at 1/64 of hg38 (14.5 M records, ~2 GB of BAM), one library.  With one GPU
+    visible the two ranks SHARE it (the path, not a scaling measurement); the same file on one GPU without BDX_GPUS beside it."""
+    from breakdancer_amd.bamwrite import write_bam
+    from breakdancer_amd.synth import make_genome
+    lengths = [int(m * 1e6 * fraction) for m in HG38_MBP]
+    tg = time.perf_counter()
+    d = make_genome(lengths, coverage=30.0, seed=21, n_translocations=max(20, int(600 * fraction * 64)))
+    n = len(d["tid"])
+    bam = os.path.join(td, "genome.bam")
+    write_bam(bam, d, ["chr%d" % (i + 1) for i in range(len(lengths))], seed=5, index=True)
+    prep_s = time.perf_counter() - tg
+    cfg = os.path.join(td, "gcfg")
+    open(cfg, "w").write(CFG_LINE % "genome.bam")
+    gpus = ",".join(str(i) for i in range(n_gpus_visible)) if n_gpus_visible > 1 else "0,0"
+
+    def run(env_extra):
+        env = dict(os.environ, BDX_TIMING="1", BDX_FOREGROUND="1", **env_extra)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            p = subprocess.run([os.path.join(ROOT, "bin", "breakdancer-max"), cfg], cwd=td, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            dt = time.perf_counter() - t0
+            if p.returncode != 0:
+                return {"error": p.stderr.decode()[-400:]}
+            rows = [line for line in p.stdout.splitlines() if line and not line.startswith(b"#")]
+            if best is None or dt < best[0]:
+                best = (dt, rows, p.stderr.decode())
+        return {"seconds": best[0], "value": (n / 2) / best[0], "unit": "read-pairs/s", "sv_rows": len(best[1]), "_rows": best[1], "_err": best[2]}
+    sh = run({"BDX_GPUS": gpus})
+    one = run({})
+    if "error" in sh or "error" in one:
+        return {"error": sh.get("error") or one.get("error")}
+    out = {"seconds": sh["seconds"], "value": sh["value"], "unit": "read-pairs/s", "sv_rows": sh["sv_rows"], "BDX_GPUS": gpus,
+           "every_rank_decoded_on_its_gpu": "on its own GPU" in sh["_err"], "same_table_as_one_gpu": sh["_rows"] == one["_rows"],
+           "one_gpu": {"seconds": one["seconds"], "value": one["value"], "unit": "read-pairs/s"},
+           "records": n, "bam_bytes": os.path.getsize(bam), "synthesis_and_bam_write_seconds_untimed": prep_s,
+           "note": "bin/breakdancer-max on ONE indexed 24-chromosome BAM, one process from start to exit (BDX_FOREGROUND=1), best of 3: the "
+                   "chromosomes spread over the ranks of BDX_GPUS, each rank pulling its chromosomes' BGZF ranges through the .bai and decoding them "
+                   "on its GPU" + ("; ONE GPU is visible here, the two ranks share it: this shows the path, not a speed-up" if n_gpus_visible <= 1 else "")}
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # One whole-genome run over all ranks of this launch (bdx_dist_*): what sharding by chromosome costs and buys
 # ---------------------------------------------------------------------------------------------------------------------
@@ -445,6 +491,9 @@ def genome_leg(rank, world, local, dist, out, fraction=None, translocations=5000
             else:
                 torch.cuda.synchronize()
             load_s = time.perf_counter() - tl
+            import gc
+            gc.collect()
+            gc.disable()   # (a collection inside a 2 ms run would be most of it)
             times = []
             for it in range(2):   # the first run of the input, then the same handles once more
                 t0 = time.perf_counter()
@@ -458,6 +507,8 @@ def genome_leg(rank, world, local, dist, out, fraction=None, translocations=5000
                     res = ranks[0].result()
                 if it == 0:
                     first_phases = ranks[0].phases()
+                    first_ms_total = ranks[0].exchange()["ms_total"]
+            gc.enable()
             for run in ranks:
                 run.release_inputs()   # (the Python side's references to the loaded arrays: not part of the run)
             ex = [r.exchange() for r in ranks]
@@ -477,7 +528,7 @@ def genome_leg(rank, world, local, dist, out, fraction=None, translocations=5000
                                "hbm_roofline_frac_whole_path": total / 2 / dt / world * PATH_BYTES_PER_PAIR / 1e9 / HBM_PEAK_GBS,
                                "svs_printed": sm["n_svs_printed"], "regions": sm["n_regions"], "sv_candidates_device_host": list(res.walk_split())[:2],
                                "ctx_records_exchanged": sent, "gathered_bytes_on_rank0": ex[0]["gathered_bytes"],
-                               "bdx_dist_run_ms_per_rank": rank_ms, "rank0_phase_ms_first_run": first_phases, "rank0_phase_ms": ph,
+                               "bdx_dist_run_ms_per_rank": rank_ms, "rank0_bdx_dist_run_ms_first_run": first_ms_total, "rank0_phase_ms_first_run": first_phases, "rank0_phase_ms": ph,
                                "rank0_only": {"ms": r0, "share_of_run": r0 / (ex[0]["ms_total"] or 1.0),
                                               "note": "what only rank 0 does (second run): the merge of the ranks' tables and its host walk of the "
                                                       "components that span ranks or are too large for the device walk"},
@@ -728,6 +779,11 @@ def main():
                 if not a.no_end_to_end:
                     timings["bam_to_table"] = time_bam_cli(bam, cfg, n)
                     timings["bam_to_table"]["bam_write_s_untimed"] = bam_write_s
+                    if not a.no_sharded_cli:
+                        try:
+                            timings["bam_to_table_sharded"] = time_bam_cli_sharded(td, torch.cuda.device_count(), a.sharded_cli_fraction)
+                        except Exception as e:  # noqa: BLE001
+                            timings["bam_to_table_sharded"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
                 if not a.no_cpu_baseline:
                     cpu = cpu_baseline(bam, n, a.cpu_parallel)
         out = {

@@ -67,8 +67,11 @@ def _fixed_records(soa, lo, hi, L, rg, rng, names=None):
     return rec
 
 
-def write_bam(path, soa, targets, rg="rg1", readlen=None, level=1, seed=0, names=None, threads=None, chunk=500_000):
+def write_bam(path, soa, targets, rg="rg1", readlen=None, level=1, seed=0, names=None, threads=None, chunk=500_000, index=False):
     """soa: dict with tid,pos,mtid,mpos,isize,flag,qlen,mapq (+name_key used to derive the read names).
+    index=True also writes <path>.bai: per sequence ONE chunk (first record .. behind the last, in the root bin -- legal, if coarser
+    than samtools') and the linear index of 16 kb windows, vectorised (the records have one size, so every virtual offset follows
+    from the compressed sizes of the blocks).
     Every record gets `readlen` random bases / qualities (default: soa['qlen'][0]), a 100M-style CIGAR and RG:Z:<rg>.
     Records are built and deflated `chunk` at a time on `threads` threads (numpy and zlib release the GIL), so a
     configs[1]-sized file (15 M records, ~3 GB of record bytes) takes seconds on a many-core host and bounded memory."""
@@ -85,7 +88,8 @@ def write_bam(path, soa, targets, rg="rg1", readlen=None, level=1, seed=0, names
     def piece(i):
         lo, hi = i * chunk, min(n, (i + 1) * chunk)
         raw = _fixed_records(soa, lo, hi, L, rg, np.random.default_rng([seed, i]), names).tobytes()
-        return b"".join(_bgzf_block(raw[j:j + 65280], level) for j in range(0, len(raw), 65280))
+        blocks = [_bgzf_block(raw[j:j + 65280], level) for j in range(0, len(raw), 65280)]
+        return b"".join(blocks), [len(b) for b in blocks], len(raw)
 
     nchunks = (n + chunk - 1) // chunk
     if threads is None:
@@ -93,6 +97,7 @@ def write_bam(path, soa, targets, rg="rg1", readlen=None, level=1, seed=0, names
     with open(path, "wb") as f:
         for j in range(0, len(hdr), 65280):
             f.write(_bgzf_block(hdr[j:j + 65280], level))
+        chunk_coff, chunk_blocks, rec_bytes = [], [], 0   # per chunk: compressed offset of its first block, its blocks' compressed sizes
         with ThreadPoolExecutor(max_workers=threads) as ex:
             window = []  # at most 2 x threads chunks in flight: bounded memory, written in order
             nxt = 0
@@ -100,8 +105,52 @@ def write_bam(path, soa, targets, rg="rg1", readlen=None, level=1, seed=0, names
                 while nxt < nchunks and len(window) < 2 * threads:
                     window.append(ex.submit(piece, nxt))
                     nxt += 1
-                f.write(window.pop(0).result())
+                data, sizes, raw_len = window.pop(0).result()
+                chunk_coff.append(f.tell())
+                chunk_blocks.append(sizes)
+                if raw_len:
+                    rec_bytes = raw_len // (min(n, (len(chunk_coff)) * chunk) - (len(chunk_coff) - 1) * chunk)
+                f.write(data)
+        end_coff = f.tell()
         f.write(_EOF)
+    if index and n:
+        # virtual offset of every record: chunk c starts a fresh run of 65280-byte blocks; record k of the chunk begins at raw offset k * rec_bytes
+        idx = np.arange(n, dtype=np.int64)
+        c = idx // chunk
+        raw_off = (idx - c * chunk) * rec_bytes
+        blk = raw_off // 65280
+        within = raw_off - blk * 65280
+        starts = [np.concatenate([[0], np.cumsum(np.asarray(sz, np.int64))[:-1]]) + co for sz, co in zip(chunk_blocks, chunk_coff)]
+        blk_coff = np.concatenate(starts)
+        first_blk = np.concatenate([[0], np.cumsum([len(sz) for sz in chunk_blocks])[:-1]])
+        voff = (blk_coff[first_blk[c] + blk].astype(np.uint64) << np.uint64(16)) | within.astype(np.uint64)
+        tid = np.asarray(soa["tid"]).astype(np.int64)
+        pos = np.asarray(soa["pos"]).astype(np.int64)
+        out = bytearray(b"BAI\1" + struct.pack("<i", len(targets)))
+        bounds = np.searchsorted(tid, np.arange(len(targets) + 1))
+        for t in range(len(targets)):
+            lo, hi = int(bounds[t]), int(bounds[t + 1])
+            if hi <= lo:
+                out += struct.pack("<ii", 0, 0)
+                continue
+            v_end = int(voff[hi]) if hi < n else (end_coff << 16)
+            out += struct.pack("<i", 1) + struct.pack("<Ii", 0, 1) + struct.pack("<QQ", int(voff[lo]), v_end)
+            # linear index: the first record that STARTS in the window before (reads are far shorter than a window: never later than
+            # the first record that overlaps the window)
+            w = np.maximum(pos[lo:hi], 0) >> 14
+            n_intv = int(w.max()) + 1
+            first = np.full(n_intv, -1, np.int64)
+            uw, ui = np.unique(w, return_index=True)
+            first[uw] = ui + lo
+            lin = np.zeros(n_intv, np.uint64)
+            last = int(voff[lo])
+            prev = last
+            for k in range(n_intv):
+                cur = int(voff[first[k]]) if first[k] >= 0 else prev
+                lin[k] = prev if k else cur   # window k: what started in window k - 1 may reach into it
+                prev = cur if first[k] >= 0 else prev
+            out += struct.pack("<i", n_intv) + lin.astype("<u8").tobytes()
+        open(path + ".bai", "wb").write(bytes(out))
     return path
 
 

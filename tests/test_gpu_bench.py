@@ -45,7 +45,7 @@ def test_one_rank_line_carries_the_end_to_end_ratio_and_the_single_context_figur
     run, and the genome leg holds the single-context figure beside the sharded run"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--length", "4000000", "--genome-fraction", "0.004",
-                        "--no-pmc", "--no-overlap", "--cpu-parallel", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+                        "--no-pmc", "--no-overlap", "--cpu-parallel", "0", "--sharded-cli-fraction", "0.002"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     out = json.loads([x for x in p.stdout.decode().splitlines() if x.startswith("{")][0])
     e2e = out["config"]["timings"]["bam_to_table"]
@@ -53,6 +53,9 @@ def test_one_rank_line_carries_the_end_to_end_ratio_and_the_single_context_figur
     assert e2e["seconds"] >= e2e["command_return"]["seconds"] * 0.5 and "exit included" in e2e["reader"]
     assert abs(out["vs_baseline"] - e2e["value"] / out["cpu_baseline"]["value"]) < 1e-9 * out["vs_baseline"] and "vs_baseline_is" in out
     assert out["config"]["timings"]["hbm_resident"]["over_cpu_compute_only"] > 1
+    sh = out["config"]["timings"]["bam_to_table_sharded"]
+    assert "error" not in sh, sh
+    assert sh["every_rank_decoded_on_its_gpu"] and sh["same_table_as_one_gpu"] and sh["sv_rows"] > 0 and sh["seconds"] > 0
     g = out["config"]["genome"]
     assert "error" not in g, g
     assert g["ranks"] == 1 and g["single_context"]["seconds"] > 0 and g["default_options"]["svs_printed"] == g["single_context"]["svs_printed"]
