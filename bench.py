@@ -375,6 +375,7 @@ def time_bam_cli_sharded(td, n_gpus_visible, fraction=1.0 / 64):
         env = dict(os.environ, BDX_TIMING="1", BDX_FOREGROUND="1", **env_extra)
         best = None
         for _ in range(3):
+            time.sleep(1.0)   # (untimed: the driver is still reclaiming the previous process's HBM -- tens of GB of decoder rings in a sharded run)
             t0 = time.perf_counter()
             p = subprocess.run([os.path.join(ROOT, "bin", "breakdancer-max"), cfg], cwd=td, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             dt = time.perf_counter() - t0

@@ -351,6 +351,11 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
     d->bam_index = (uint8_t)p->bam_index;
     d->filt.only_tid = p->only_tid; d->filt.beg = p->region_beg; d->filt.end = p->region_end; d->filt.n_targets = p->n_targets;
     auto bad = [&](int code) { bdx_bamdec_destroy(d); return code; };
+    static const bool create_trace = getenv("BDX_BAMDEC_TRACE") != nullptr;   // (where a decoder's set-up time goes, on stderr)
+    const auto t_c0 = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (create_trace) fprintf(stderr, "[bdx bamdec create] %s at %.3f ms\n", what, ms_between(t_c0, std::chrono::steady_clock::now()));
+    };
     if (sink && sink->stream && sink->copy_stream) {
         d->s_copy = sink->copy_stream; d->s_rec = sink->stream;
         d->borrowed_streams = true;
@@ -366,6 +371,7 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
             return bad(BDX_EHIP);
     for (auto& st : d->staging)
         if (hipEventCreateWithFlags(&st.ev_copied, hipEventDisableTiming) != hipSuccess) return bad(BDX_EHIP);
+    mark("streams and events");
     d->expected_bytes = p->expected_bytes;
     if (p->batch_bytes) d->batch_bytes = p->batch_bytes;
     if (p->batch_blocks) d->batch_blocks = p->batch_blocks;
@@ -399,6 +405,7 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
         d->rg.hash = d->d_rg_hash.as<uint64_t>(); d->rg.off = d->d_rg_off.as<uint32_t>(); d->rg.chars = d->d_rg_chars.as<char>();
         d->rg.lib = d->d_rg_lib.as<uint8_t>(); d->rg.n = n; d->rg.fallback = p->fallback_lib;
     }
+    mark("read-group tables");
     // ring of inflated bytes
     d->ring_bytes = p->ring_bytes ? p->ring_bytes : ((size_t)3 << 30);
     if (d->ring_bytes < ((size_t)1 << 20)) d->ring_bytes = (size_t)1 << 20;
@@ -410,6 +417,7 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
     if (hipMemcpy(d->d_state.p, &st, sizeof(st), hipMemcpyHostToDevice) != hipSuccess) return bad(BDX_EHIP);
     if (d->h_progress.ensure(64) != hipSuccess) return bad(BDX_ENOMEM);
     memset(d->h_progress.p, 0, 64);
+    mark("ring and state");
     if (sink && sink->adopted) return bad(BDX_ESTATE);   // (before the pinning threads start: a decoder that fails from here on is destroyed at once)
     // (behind the decoder's own pinned allocation: page pinning does not run in parallel with itself)
     if (p->piece_bytes && p->piece_blocks)
@@ -431,6 +439,7 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
             const size_t in_flight = (size_t)kBamSlots * (d->batch_blocks + d->batch_blocks / 4 + 64) * 65536 / 36;
             const size_t want = std::min<size_t>(p->expected_bytes / 48 + ((size_t)1 << 20) + std::min<size_t>(in_flight, p->expected_bytes * 4), 0xFFFFFFFFull - 1024);
             if (sink->cap < want && alloc_reads(sink, want) != BDX_OK) return bad(BDX_ENOMEM);
+            mark("sink store");
         }
         if (sink->n == 0 && sink->cap) {   // pass 1 runs as the records arrive
             sink->key_segs.clear();
@@ -440,6 +449,7 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
                 sink->k1_live = true;
             }
         }
+        mark("pass-1 tables");
         if (sink->key_segs.empty() || sink->key_segs.back().host) sink->key_segs.push_back(bdx_ctx::KeySeg{(uint64_t)sink->n, nullptr, nullptr, nullptr});
         d->confirmed = sink->n;
         // (records this decoder appends come behind what the store already holds)
@@ -451,6 +461,7 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
         const size_t want = std::min<size_t>(p->expected_bytes / 48 + ((size_t)1 << 20) + std::min<size_t>(in_flight, p->expected_bytes * 4), 0xFFFFFFFFull - 1024);
         if (bam_own_reserve(d, want, 0) != BDX_OK) return bad(BDX_ENOMEM);
     }
+    mark("done");
     *out = d;
     return BDX_OK;
 }
@@ -723,6 +734,48 @@ int bdx_bamdec_finish(bdx_bamdec* d, uint64_t* n_records) {
         d->sink->ran = false;
     }
     if (n_records) *n_records = st.n_kept;
+    return BDX_OK;
+}
+
+// A finished decoder takes another stretch of the same file: all of its buffers, streams and events stay (a decoder's set-up is tens
+// of milliseconds -- a 3 GiB ring, four batches' buffers, pinned staging, a stream --, a sequence read through the index is a few), the
+// running state starts over: the region filter, where the first record begins, the record chain.  With a sink the records are
+// appended behind what its store holds.
+int bdx_bamdec_rearm(bdx_bamdec* d, int32_t only_tid, int32_t region_beg, int32_t region_end, uint64_t first_record_offset, size_t expected_bytes) {
+    if (!d) return BDX_EINVAL;
+    if (!d->finished) return bfail(d, BDX_ESTATE, "bdx_bamdec_finish first");
+    BHIP(d, hipSetDevice(d->device));
+    for (hipStream_t s : {d->s_copy, d->s_inf, d->s_inf2, d->s_rec})
+        if (s) BHIP(d, hipStreamSynchronize(s));
+    d->filt.only_tid = only_tid; d->filt.beg = region_beg; d->filt.end = region_end;
+    for (auto& st : d->staging) st.busy = false;
+    d->next_staging = 0; d->cur_staging = -1;
+    for (auto& sl : d->slot) { sl.busy = false; sl.open = false; sl.bytes = 0; sl.nblk = 0; sl.ulen = 0; }
+    d->cur_slot = 0;
+    d->cursor = 0;
+    for (auto& p : d->pieces) {
+        if (p.ev_inflated) d->ev_pool.push_back(p.ev_inflated);
+        if (p.ev_records) d->ev_pool.push_back(p.ev_records);
+    }
+    d->pieces.clear();
+    for (auto& e : d->rec_events) d->ev_pool.push_back(e.second);
+    d->rec_events.clear();
+    d->bounds.clear();
+    d->bound_in_flight = 0;
+    d->finished = false; d->any_submitted = false;
+    d->expected_bytes = expected_bytes;
+    PieceState st{};
+    st.next_start = first_record_offset;
+    st.n_kept = d->sink ? d->sink->n : 0;
+    BHIP(d, hipMemcpy(d->d_state.p, &st, sizeof(st), hipMemcpyHostToDevice));
+    if (d->h_progress.p) {
+        volatile uint64_t* pr = (volatile uint64_t*)d->h_progress.p;
+        pr[0] = st.n_kept; pr[1] = 0; pr[2] = 0;   // (the sequence word stays: piece numbers go on counting)
+    }
+    d->confirmed = st.n_kept;
+    d->confirmed_seq = d->n_pieces;
+    if (d->sink && (d->sink->key_segs.empty() || d->sink->key_segs.back().host))
+        d->sink->key_segs.push_back(bdx_ctx::KeySeg{(uint64_t)d->sink->n, nullptr, nullptr, nullptr});
     return BDX_OK;
 }
 

@@ -293,7 +293,7 @@ int run(int argc, char** argv) {
         }
         reserve = std::min<size_t>(reserve, 0xFFFFFFFFull - 1024);
         size_t n_reads = 0;
-        bool device_decoded = false;
+        bool device_decoded = false, sharded_on_device = false;
         auto t_decoded = now();
         if (sharded) {
             if (restored) throw std::runtime_error("-R is not supported with BDX_GPUS");
@@ -301,8 +301,10 @@ int run(int argc, char** argv) {
             std::vector<uint32_t> lengths;
             read_targets(cfg, names, lengths);
             const int ntids = (int)std::max<size_t>(names.size(), 1), world = (int)devices.size();
+            const auto t_create = now();
             int rc = bdx_dist_create_threads(ranks.data(), &opts.o, libs.data(), nlibs, nbams, ntids, cfg.max_read_window_size(), devices.data(), world);
             if (rc != BDX_OK) throw std::runtime_error(std::string("bdx_dist_create_threads: ") + bdx_strerror(rc));
+            const auto t_created = now();
             if (want_dumps)   // -g / -d: the supporting reads come with the result (gathered compact records, walked read by read on rank 0)
                 for (bdx_dist* r : ranks) bdx_dist_set_collect_support(r, 1);
             std::vector<uint64_t> weight(lengths.begin(), lengths.end());  // chromosomes -> ranks by sequence length
@@ -330,8 +332,13 @@ int run(int argc, char** argv) {
                 fprintf(stderr, "[bdx timing] sharded run over %d ranks: %s\n", world,
                         on_device ? "every rank decoded its chromosomes' BGZF ranges on its own GPU (through the BAM index)"
                                   : "records decoded by the host producer and routed to the ranks");
+            const auto t_fed = now();
             for (bdx_dist* r : ranks) (void)bdx_dist_prepare(r);   // (device code loaded, the later stages' buffers sized: beside nothing, but outside the run)
             t_decoded = now();
+            if (timing)
+                fprintf(stderr, "[bdx timing] sharded run: ranks created %.3f s after start, in %.3f s; reads on the ranks %.3f s later; prepared in %.3f s\n",
+                        secs(t_start, t_create), secs(t_create, t_created), secs(t_created, t_fed), secs(t_fed, t_decoded));
+            sharded_on_device = on_device;
             std::vector<int> rcs(world, BDX_OK);
             std::vector<std::thread> th;
             for (int r = 0; r < world; ++r) th.emplace_back([&, r] { rcs[r] = bdx_dist_run(ranks[r]); });
@@ -523,7 +530,7 @@ int run(int argc, char** argv) {
             bdx_get_timings(ctx, ms, 8);
             fprintf(stderr, "[bdx timing] reads=%zu decode+merge+stream=%.3fs (%s, single pass, records classified "
                             "as they are produced) bdx_run=%.4fs format=%.3fs total=%.3fs\n",
-                    n_reads, secs(t_start, t_decoded), device_decoded ? "BGZF inflate and record decode on the GPU" : "host decode threads",
+                    n_reads, secs(t_start, t_decoded), device_decoded || sharded_on_device ? "BGZF inflate and record decode on the GPU" : "host decode threads",
                     secs(t_decoded, t_ran), secs(t_ran, now()), secs(t_start, now()));
             fprintf(stderr, "[bdx timing] inside bdx_run (ms): classify kernel %.3f, host waits for its share of the groups %.3f, host walk %.3f, "
                             "final wait + scores %.3f, whole call %.3f\n", ms[0], ms[4], ms[5], ms[6], ms[7]);

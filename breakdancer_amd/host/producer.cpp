@@ -381,8 +381,11 @@ void retire(bdx_bamdec* d) {
 // they arrive); without, they stay in the decoder's own columns and the decoder is handed back (*keep) for the merge.
 // whole_tid >= 0 (sharded runs): ALL records of that sequence -- through the index, which must be there; span_bytes: what the sequence
 // takes of the file (sizes the decoder's buffers and the sink's store instead of "the rest of the file")
+// reuse (sharded runs): in / out -- a finished decoder of the same file and sink is armed again (bdx_bamdec_rearm) instead of a new one
+// being set up; sized_for: the largest span it will be used for (its buffers are sized once)
 size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::string& chr, int threads, std::vector<std::string>* targets, bdx_ctx* ctx,
-                        int device, bool* unsupported, bdx_bamdec** keep, int whole_tid = -1, size_t span_bytes = 0) {
+                        int device, bool* unsupported, bdx_bamdec** keep, int whole_tid = -1, size_t span_bytes = 0, bdx_bamdec** reuse = nullptr,
+                        size_t sized_for = 0) {
     const std::string& path = cfg.bam_files()[bam_index];
     ColumnReader hdr(path, 1, nullptr);   // (the header: reference names, where the first record lies; the index for -o)
     RecordFilter f;
@@ -419,21 +422,33 @@ size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::strin
     const size_t kPiece = getenv("BDX_BAM_PIECE_BYTES") ? (size_t)std::max(1ll, atoll(getenv("BDX_BAM_PIECE_BYTES"))) : ((size_t)8 << 20);   // (a staging buffer costs ~0.22 ms per MiB to pin and is reused dozens of times)
     size_t rest = file_size - std::min(file_size, member_off);
     if (span_bytes) rest = std::min(rest, span_bytes);
+    const size_t this_span = rest;
+    if (sized_for) rest = std::max(rest, std::min(sized_for, file_size));   // (the buffers of a decoder that is armed again: for its largest stretch)
     p.batch_bytes = std::min<size_t>((size_t)384 << 20, ((rest + ((size_t)1 << 20)) >> 20) << 20);
     p.expected_bytes = rest;
     p.batch_blocks = getenv("BDX_BAM_BATCH_BLOCKS") ? (size_t)std::max(1ll, atoll(getenv("BDX_BAM_BATCH_BLOCKS"))) : 0;
     // four batches of inflated bytes: a batch is at most ~8192 + a piece's members of 64 KiB, or the whole file (assume <= 16 x its size)
     p.ring_bytes = std::min<size_t>((size_t)3 << 30, std::max<size_t>((size_t)64 << 20, rest * 64));
+    // (one sequence of a sharded run: two dozen decoders follow each other on a rank and are kept until the process ends -- 3 GiB each
+    // would be 72 GiB that the driver takes seconds to reclaim, with the next process waiting behind it; what a span inflates to is enough)
+    if (span_bytes) p.ring_bytes = std::min<size_t>((size_t)3 << 30, std::max<size_t>((size_t)256 << 20, rest * 12));
     if (const char* rb = getenv("BDX_BAM_RING_BYTES")) p.ring_bytes = (size_t)std::max(1ll, atoll(rb));
     // (what bdx_bamdec_acquire will ask for: a piece, a member cut at the piece's end carried over from the one before, and slack)
     p.piece_bytes = std::min(kPiece, rest) + 65536 + 65536;
     p.piece_blocks = kPiece / 2048 + 4096;
-    bdx_bamdec* dec = nullptr;
+    bdx_bamdec* dec = reuse ? *reuse : nullptr;
     const auto t_create = std::chrono::steady_clock::now();
-    int rc = bdx_bamdec_create(&dec, ctx, &p);
+    int rc;
+    if (dec) {
+        rc = bdx_bamdec_rearm(dec, f.only_tid, f.beg, f.end, rec_off, this_span);
+        if (rc != BDX_OK) throw std::runtime_error(std::string("bdx_bamdec_rearm: ") + bdx_strerror(rc) + " (" + bdx_bamdec_last_error(dec) + ")");
+    } else {
+        rc = bdx_bamdec_create(&dec, ctx, &p);
+        if (rc != BDX_OK) throw std::runtime_error(std::string("bdx_bamdec_create: ") + bdx_strerror(rc));
+        if (reuse) *reuse = dec;
+    }
     const double create_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_create).count();
-    if (rc != BDX_OK) throw std::runtime_error(std::string("bdx_bamdec_create: ") + bdx_strerror(rc));
-    struct Guard { bdx_bamdec* d; ~Guard() { retire(d); } } guard{dec};
+    struct Guard { bdx_bamdec* d; ~Guard() { retire(d); } } guard{reuse ? nullptr : dec};   // (a reused decoder is its caller's to retire)
     auto check = [&](int r, const char* what) {
         if (r != BDX_OK) throw std::runtime_error(std::string(what) + ": " + bdx_strerror(r) + " (" + bdx_bamdec_last_error(dec) + ") in " + path);
     };
@@ -451,8 +466,10 @@ size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::strin
     std::vector<uint8_t> carry;
     const size_t max_blocks = kPiece / 2048 + 4096;   // (a piece of many tiny members is simply cut earlier)
     bool stop = false;
+    // (a sequence read through the index: its records end where the index says -- nothing behind that is read, let alone inflated)
+    const size_t read_end = span_bytes ? std::min(file_size, member_off + span_bytes) : file_size;
     while (!stop) {
-        const size_t want = std::min(kPiece, file_size - off);
+        const size_t want = std::min(kPiece, read_end - std::min(read_end, off));
         void* buf = nullptr;
         bdx_bgzf_block* tab = nullptr;
         auto t0 = clk();
@@ -500,12 +517,13 @@ size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::strin
         }
         if (at_eof && q != have) throw std::runtime_error("truncated BGZF file: " + path);
         carry.assign(b + q, b + have);
-        if (q == 0 && !at_eof && want) throw std::runtime_error("BGZF member larger than a piece: " + path);
+        if (q == 0 && !at_eof && want && off < read_end) throw std::runtime_error("BGZF member larger than a piece: " + path);
         t_scan += since(t0);
         t0 = clk();
         check(bdx_bamdec_submit(dec, q, nb, at_eof ? 1 : 0), "bdx_bamdec_submit");
         t_submit += since(t0);
         if (at_eof) break;
+        if (off >= read_end) break;   // (the end of the sequence's span: the stream is cut here, bdx_bamdec_finish drops a record that runs past it)
         if (seeked) {   // a region read through the index: nothing of it lies behind the first record past it
             int past = 0;
             check(bdx_bamdec_progress(dec, nullptr, nullptr, &past, nullptr), "bdx_bamdec_progress");
@@ -698,13 +716,32 @@ size_t produce_sharded_on_device(const BamConfig& cfg, int threads, std::vector<
     for (int r = 0; r < world; ++r)
         th.emplace_back([&, r] {
             try {
+                size_t bytes_mine = 0;
+                for (size_t t = 0; t < names.size(); ++t)
+                    if (rank_of[t] == r && span[t].has) bytes_mine += span[t].end - span[t].begin;
+                bool reserved = false;
+                size_t largest = 0;
+                for (size_t t = 0; t < names.size(); ++t)
+                    if (rank_of[t] == r && span[t].has) largest = std::max(largest, span[t].end - span[t].begin);
+                bdx_bamdec* dec = nullptr;   // ONE decoder per rank, armed again for every chromosome
+                struct Retire { bdx_bamdec*& d; ~Retire() { retire(d); } } retire_guard{dec};
                 for (size_t t = 0; t < names.size(); ++t) {
                     if (rank_of[t] != r || !span[t].has) continue;
                     bdx_ctx* c = bdx_dist_chromosome(ranks[r], (int)t);
                     if (!c) throw std::runtime_error(std::string("bdx_dist_chromosome: ") + bdx_dist_last_error(ranks[r]));
                     if (bdx_use_name_check(c, 1) != BDX_OK) throw std::runtime_error("bdx_use_name_check");
+                    if (!reserved) {   // the rank's store for ALL of its chromosomes (a record takes 50-150 bytes of BAM): no growing between them
+                        // (plus what the decoder must assume of a batch in flight before its records are counted: 36 bytes is the smallest record)
+                        if (bdx_reserve(c, std::min<size_t>(bytes_mine / 48 + largest * 8 / 36 + ((size_t)1 << 20), 0xFFFFFFFFull - 1024)) != BDX_OK) throw std::runtime_error("bdx_reserve");
+                        reserved = true;
+                    }
                     bool un = false;
-                    n_of[r] += decode_on_device(cfg, 0, "", per, nullptr, c, devices[r], &un, nullptr, (int)t, span[t].end - span[t].begin);
+                    const auto tc = std::chrono::steady_clock::now();
+                    // (the decoder reports the store's record count: the rank's total so far)
+                    n_of[r] = decode_on_device(cfg, 0, "", per, nullptr, c, devices[r], &un, nullptr, (int)t, span[t].end - span[t].begin, &dec, largest);
+                    if (getenv("BDX_TIMING"))
+                        fprintf(stderr, "[bdx timing] rank %d: %s (%zu bytes of the file) in %.3f s\n", r, names[t].c_str(), span[t].end - span[t].begin,
+                                std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count());
                     if (un) { gave_up[r] = 1; return; }
                 }
             } catch (std::exception const& e) {

@@ -441,6 +441,9 @@ int bdx_bamdec_acquire(bdx_bamdec* d, size_t bytes, size_t max_blocks, void** bu
 int bdx_bamdec_submit(bdx_bamdec* d, size_t bytes, size_t nblocks, int last);
 int bdx_bamdec_progress(bdx_bamdec* d, uint64_t* n_records, uint64_t* n_raw, int* past_region, uint32_t* error);
 int bdx_bamdec_finish(bdx_bamdec* d, uint64_t* n_records);
+/* a finished decoder takes another stretch of the same file (another sequence's range, found through the index): buffers, streams and
+ * events are kept, the region filter and the record chain start over; with a sink the records go behind what its store holds */
+int bdx_bamdec_rearm(bdx_bamdec* d, int32_t only_tid, int32_t region_beg, int32_t region_end, uint64_t first_record_offset, size_t expected_bytes);
 int bdx_bamdec_fetch(bdx_bamdec* d, uint64_t first, uint64_t n, const bdx_batch_buf* out);
 int bdx_bamdec_stats(const bdx_bamdec* d, uint64_t* compressed_bytes, uint64_t* inflated_bytes, uint64_t* pieces, uint64_t* blocks_walked_twice);
 /* Several BAMs decoded on the GPU, each by a decoder of its own (no sink: the records stay in the decoder's columns, bdx_bamdec_fetch
