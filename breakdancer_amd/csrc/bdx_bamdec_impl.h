@@ -70,7 +70,7 @@ struct bdx_bamdec {
     int next_staging = 0, cur_staging = -1;
     // a batch: the compressed bytes of its pieces back to back in HBM, its member table, the inflate status words
     struct Slot {
-        DevBuf d_comp, d_blocks, d_status;
+        DevBuf d_comp, d_blocks, d_status, d_bitmap;   // (d_bitmap: the match-start map of the two-kernel inflate path)
         PinBuf h_blocks;                  // the device-format table, built as the pieces arrive
         hipEvent_t ev_copied = nullptr;   // all of the batch's bytes and its table are in HBM
         hipEvent_t ev_free = nullptr;     // the batch's record stage is through (its device buffers are reusable)
@@ -474,7 +474,7 @@ void bdx_bamdec_destroy(bdx_bamdec* d) {
     for (hipStream_t s : {d->s_copy, d->s_inf, d->s_inf2, d->s_rec})
         if (s) (void)hipStreamSynchronize(s);
     for (auto& sl : d->slot) {
-        sl.h_blocks.release(); sl.d_comp.release(); sl.d_blocks.release(); sl.d_status.release();
+        sl.h_blocks.release(); sl.d_comp.release(); sl.d_blocks.release(); sl.d_status.release(); sl.d_bitmap.release();
         if (sl.ev_copied) (void)hipEventDestroy(sl.ev_copied);
         if (sl.ev_free) (void)hipEventDestroy(sl.ev_free);
     }
@@ -577,7 +577,13 @@ int bam_launch_batch(bdx_bamdec* d, int si, bool last) {
     if (nblocks) BHIP(d, hipMemcpyAsync(sl.d_blocks.p, tb, nblocks * sizeof(BgzfBlock), hipMemcpyHostToDevice, d->s_copy));
     BHIP(d, hipEventRecord(sl.ev_copied, d->s_copy));
     BHIP(d, hipStreamWaitEvent(s_inf, sl.ev_copied, 0));
-    launch_kz_inflate(sl.d_comp.as<uint8_t>(), sl.d_blocks.as<BgzfBlock>(), (uint32_t)nblocks, d->d_ring.as<uint8_t>(), sl.d_status.as<uint32_t>(), s_inf);
+    if (kz_pick_lanes(nblocks, sl.bytes, ulen)) {
+        const size_t words = kz_bitmap_words(ulen, nblocks);
+        BHIP(d, sl.d_bitmap.ensure(std::max(words, kz_bitmap_words(d->ring_bytes / 4, std::max(nblocks, sl.cap_blk))) * 4));   // (once: what a batch can be)
+        launch_kz_inflate_lanes(sl.d_comp.as<uint8_t>(), sl.d_blocks.as<BgzfBlock>(), (uint32_t)nblocks, d->d_ring.as<uint8_t>(), sl.d_status.as<uint32_t>(),
+                                sl.d_bitmap.as<uint32_t>(), words, p.ring_beg, s_inf);
+    } else
+        launch_kz_inflate(sl.d_comp.as<uint8_t>(), sl.d_blocks.as<BgzfBlock>(), (uint32_t)nblocks, d->d_ring.as<uint8_t>(), sl.d_status.as<uint32_t>(), s_inf);
     p.ev_inflated = bam_event(d);
     if (!p.ev_inflated) return bfail(d, BDX_EHIP, "hipEventCreate");
     BHIP(d, hipEventRecord(p.ev_inflated, s_inf));
@@ -899,8 +905,16 @@ int bdx_inflate_blocks(int device, const void* compressed, size_t bytes, const b
     DevBuf d_prof;
     const char* prof_path = getenv("BDX_KZ_PROF");
     if (prof_path && nblocks && (d_prof.ensure(nblocks * 48) != hipSuccess || hipMemset(d_prof.p, 0, nblocks * 48) != hipSuccess)) prof_path = nullptr;
-    launch_kz_inflate(d_in.as<uint8_t>(), d_tb.as<BgzfBlock>(), (uint32_t)nblocks, d_out.as<uint8_t>(), d_st.as<uint32_t>(), nullptr,
-                      prof_path ? d_prof.as<unsigned long long>() : nullptr);
+    size_t comp = 0;
+    for (size_t i = 0; i < nblocks; ++i) comp += blocks[i].payload_len;
+    DevBuf d_bm;
+    if (!prof_path && kz_pick_lanes(nblocks, comp, o)) {
+        const size_t words = kz_bitmap_words(o, nblocks);
+        if (d_bm.ensure(words * 4) != hipSuccess) return done(BDX_ENOMEM);
+        launch_kz_inflate_lanes(d_in.as<uint8_t>(), d_tb.as<BgzfBlock>(), (uint32_t)nblocks, d_out.as<uint8_t>(), d_st.as<uint32_t>(), d_bm.as<uint32_t>(), words, 0, nullptr);
+    } else
+        launch_kz_inflate(d_in.as<uint8_t>(), d_tb.as<BgzfBlock>(), (uint32_t)nblocks, d_out.as<uint8_t>(), d_st.as<uint32_t>(), nullptr,
+                          prof_path ? d_prof.as<unsigned long long>() : nullptr);
     (void)hipEventRecord(e1, nullptr);
     if (hipDeviceSynchronize() != hipSuccess) return done(BDX_EHIP);
     if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, e0, e1);
@@ -910,6 +924,7 @@ int bdx_inflate_blocks(int device, const void* compressed, size_t bytes, const b
             if (FILE* f = fopen(prof_path, "wb")) { fwrite(hp.data(), 8, hp.size(), f); fclose(f); }
     }
     d_prof.release();
+    d_bm.release();
     if ((o && hipMemcpy(out, d_out.p, o, hipMemcpyDeviceToHost) != hipSuccess) ||
         (nblocks && hipMemcpy(status, d_st.p, nblocks * 4, hipMemcpyDeviceToHost) != hipSuccess))
         return done(BDX_EHIP);

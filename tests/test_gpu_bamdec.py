@@ -41,8 +41,13 @@ def payloads(rng):
     return out
 
 
-def test_inflate_matches_zlib_on_synthetic_members():
+KZ = pytest.mark.parametrize("kz", ["wave", "lanes"])   # kz_inflate.hip (a wave per member) / kz_inflate_lanes.hip (a lane per member)
+
+
+@KZ
+def test_inflate_matches_zlib_on_synthetic_members(kz, monkeypatch):
     from breakdancer_amd import bamdec
+    monkeypatch.setenv("BDX_KZ", kz)
     rng = np.random.default_rng(5)
     blobs, want, labels = [], [], []
     for label, data in payloads(rng):
@@ -66,8 +71,10 @@ def test_inflate_matches_zlib_on_synthetic_members():
     assert o == len(out)
 
 
-def test_inflate_matches_zlib_on_the_reference_bams():
+@KZ
+def test_inflate_matches_zlib_on_the_reference_bams(kz, monkeypatch):
     from breakdancer_amd import bamdec
+    monkeypatch.setenv("BDX_KZ", kz)
     for name in BAMS:
         image = open(os.path.join(CHR21, name), "rb").read()
         members = bamdec.scan_bgzf(image)
@@ -77,9 +84,11 @@ def test_inflate_matches_zlib_on_the_reference_bams():
         assert out.tobytes() == want
 
 
-def test_inflate_verdict_on_corrupted_members_agrees_with_zlib():
+@KZ
+def test_inflate_verdict_on_corrupted_members_agrees_with_zlib(kz, monkeypatch):
     """a member is accepted only if zlib accepts it with the same bytes; what zlib rejects is rejected"""
     from breakdancer_amd import bamdec
+    monkeypatch.setenv("BDX_KZ", kz)
     rng = np.random.default_rng(9)
     base = []
     for label, data in payloads(rng)[3:]:

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--piece-blocks", type=int, default=512)
     ap.add_argument("--bam", default=None, help="decode this file instead of a synthetic one")
     ap.add_argument("--inflate-only", action="store_true")
+    ap.add_argument("--slice-gb", type=float, default=1.5, help="inflated bytes per bdx_inflate_blocks call (the kernel-alone measurement)")
     a = ap.parse_args()
     from breakdancer_amd import bamdec
     from breakdancer_amd.bamwrite import write_bam
@@ -37,13 +38,13 @@ def main():
         data = members[members["inflated_len"] > 0]
         ulen = int(data["inflated_len"].astype(np.int64).sum())
         print("file %.1f MB, %d members, %.1f MB inflated (ratio %.2f)" % (image.size / 1e6, len(data), ulen / 1e6, ulen / image.size))
-        # kernel alone, in slices of <= 1.5 GB of output
+        # kernel alone, in slices of <= --slice-gb of output
         tot_ms, done = 0.0, 0
         i = 0
         while i < len(data):
             j = i
             acc = 0
-            while j < len(data) and acc < 1_500_000_000:
+            while j < len(data) and acc < int(a.slice_gb * 1e9):
                 acc += int(data["inflated_len"][j])
                 j += 1
             lo = int(data["member"][i])
