@@ -345,15 +345,22 @@ int bdx_dist_create_threads(bdx_dist** out, const bdx_opts* opts, const bdx_lib*
     if (!out || !devices || world < 1) return BDX_EINVAL;
     std::shared_ptr<ThreadGroup> g(new ThreadGroup(world));
     for (int r = 0; r < world; ++r) out[r] = nullptr;
-    for (int r = 0; r < world; ++r) {
-        std::unique_ptr<ThreadComm> c(new ThreadComm);
-        c->rank = r; c->world = world; c->g = g;
-        const int rc = dist_create_common(&out[r], opts, libs, nlibs, nbams, ntids, max_read_window_size0, devices[r], std::move(c));
-        if (rc != BDX_OK) {
-            for (int q = 0; q < r; ++q) { bdx_dist_destroy(out[q]); out[q] = nullptr; }
+    // every rank's context (device set-up, streams, pinned words) on its own thread: side by side on different devices
+    std::vector<int> rcs(world, BDX_OK);
+    std::vector<std::thread> th;
+    for (int r = 0; r < world; ++r)
+        th.emplace_back([&, r] {
+            std::unique_ptr<ThreadComm> c(new ThreadComm);
+            c->rank = r; c->world = world; c->g = g;
+            rcs[r] = dist_create_common(&out[r], opts, libs, nlibs, nbams, ntids, max_read_window_size0, devices[r], std::move(c));
+        });
+    for (auto& t : th) t.join();
+    for (int r = 0; r < world; ++r)
+        if (rcs[r] != BDX_OK) {
+            const int rc = rcs[r];
+            for (int q = 0; q < world; ++q) { if (out[q]) bdx_dist_destroy(out[q]); out[q] = nullptr; }
             return rc;
         }
-    }
     return BDX_OK;
 }
 

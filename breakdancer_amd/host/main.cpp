@@ -333,7 +333,11 @@ int run(int argc, char** argv) {
                         on_device ? "every rank decoded its chromosomes' BGZF ranges on its own GPU (through the BAM index)"
                                   : "records decoded by the host producer and routed to the ranks");
             const auto t_fed = now();
-            for (bdx_dist* r : ranks) (void)bdx_dist_prepare(r);   // (device code loaded, the later stages' buffers sized: beside nothing, but outside the run)
+            {   // (device code loaded, the later stages' buffers sized: beside nothing, but outside the run; every rank on its own thread)
+                std::vector<std::thread> pt;
+                for (bdx_dist* r : ranks) pt.emplace_back([r] { (void)bdx_dist_prepare(r); });
+                for (auto& t : pt) t.join();
+            }
             t_decoded = now();
             if (timing)
                 fprintf(stderr, "[bdx timing] sharded run: ranks created %.3f s after start, in %.3f s; reads on the ranks %.3f s later; prepared in %.3f s\n",
