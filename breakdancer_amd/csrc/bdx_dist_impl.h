@@ -442,9 +442,7 @@ int bdx_dist_prepare(bdx_dist* d) {
             DHIP(d, d->b_x.ensure((nr / 8 + nr / 64 + (size_t)d->comm->world + 64) * 8));
             const size_t nn = (size_t)prior;
             DHIP(d, d->b_nsend.ensure(nn * 16)); DHIP(d, d->b_nrecv.ensure(nn * 16));
-            uint32_t slots = 1024;
-            while (slots < 2 * nn) slots <<= 1;
-            DHIP(d, d->b_ntab.ensure((size_t)slots * 16));
+            DHIP(d, d->b_ntab.ensure((size_t)k7_names_slots(nn) * 16));
             DHIP(d, d->b_pack.ensure(nn * 40)); DHIP(d, d->b_all.ensure(nn * 40));
             DHIP(d, d->b_foreign.ensure(nn * 20 / 8 + 64));
             DHIP(d, d->b_send.ensure(nn * 4)); DHIP(d, d->b_recv.ensure(nn * 4));   // (an eighth of the anomalous reads inter-chromosomal and travelling)
@@ -983,14 +981,13 @@ int bdx_dist_run(bdx_dist* d) {
     auto t_x1 = std::chrono::steady_clock::now();
     phase([&]() -> int {
         if (nnrecv) {   // the census of the names this rank owns: on the second stream, beside the joins (its verdict is read at the next all-reduce)
-            uint32_t slots = 1024;
-            while (slots < 2 * nnrecv) slots <<= 1;
+            const uint32_t slots = k7_names_slots(nnrecv);
             DHIP(d, d->b_ntab.ensure((size_t)slots * 16));
             DHIP(d, d->b_nflag.ensure(16));
             DHIP(d, hipEventRecord(d->ev_side, s));
             DHIP(d, hipStreamWaitEvent(C->copy_stream, d->ev_side, 0));
             launch_k7_names_clear(d->b_ntab.as<unsigned long long>(), slots, d->b_nflag.as<uint32_t>(), C->copy_stream);
-            launch_k7_names_census(d->b_nrecv.as<unsigned long long>(), (uint32_t)nnrecv, d->b_ntab.as<unsigned long long>(), slots - 1, d->b_nflag.as<uint32_t>(),
+            launch_k7_names_census(d->b_nrecv.as<unsigned long long>(), (uint32_t)nnrecv, d->b_ntab.as<unsigned long long>(), slots, d->b_nflag.as<uint32_t>(),
                                    C->copy_stream);
         }
         if (na) {

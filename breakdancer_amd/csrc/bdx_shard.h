@@ -86,7 +86,8 @@ void launch_k7_scatter(const ExchangeSrc& x, uint32_t n_upper, uint32_t* cursor,
 void launch_k7_unpack(const ExchangeEntry* in, uint32_t n, uint64_t* key, uint64_t* check, int32_t* region, const uint32_t* n_local, uint32_t* n_total,
                       hipStream_t s);
 void launch_k7_names_clear(unsigned long long* slots, uint32_t nslots, uint32_t* irregular, hipStream_t s);
-void launch_k7_names_census(const unsigned long long* in, uint32_t n, unsigned long long* slots, uint32_t mask, uint32_t* irregular, hipStream_t s);
+void launch_k7_names_census(const unsigned long long* in, uint32_t n, unsigned long long* slots, uint32_t nslots, uint32_t* irregular, hipStream_t s);
+uint32_t k7_names_slots(size_t records);   // the census table for so many sightings (1.5 slots each)
 
 // ---- rank 0: the ranks' SV tables -> one table --------------------------------------------------------------------------
 // Every rank's table is sorted by order key (K6Arrays::sv_key) and two ranks never hold the same key (a key names the traversal's

@@ -121,16 +121,16 @@ __global__ __launch_bounds__(256) void k7_unpack_kernel(const ExchangeEntry* in,
 // not a CTX read, bit 3 sightings on different chromosomes, bit 4 two CTX sightings that do not name each other's chromosome,
 // bits 8-31 the first sighting's chromosome + 1, bits 32-55 its mate chromosome + 1.  One line is dirtied per insert (three arrays
 // with one scattered atomic each wrote 7x the records' bytes: profiles/r03_pmc_all_kernels.txt).
-__global__ __launch_bounds__(256) void k7_names_insert_kernel(const unsigned long long* in, uint32_t n, unsigned long long* slots, uint32_t mask) {
+__global__ __launch_bounds__(256) void k7_names_insert_kernel(const unsigned long long* in, uint32_t n, unsigned long long* slots, uint32_t nslots) {
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     const unsigned long long k = in[2 * (size_t)j], w = in[2 * (size_t)j + 1];
     const unsigned long long nonctx = w & 1ull, t1 = (w >> 8) & 0xFFFFFFull, mt1 = (w >> 32) & 0xFFFFFFull;
-    uint32_t s = (uint32_t)(((k ^ (k >> 31)) * 0x9E3779B97F4A7C15ull) >> 24) & mask;   // (not the owner's hash: the keys of one owner share that)
+    uint32_t s = (uint32_t)(((k ^ (k >> 31)) * 0x9E3779B97F4A7C15ull) >> 32) % nslots;   // (not the owner's hash: the keys of one owner share that)
     for (;;) {
         const unsigned long long old = atomicCAS(&slots[2 * (size_t)s], ~0ull, k);
         if (old == ~0ull || old == k) break;
-        s = (s + 1) & mask;   // (the table has at least twice as many slots as there are records)
+        s = s + 1 == nslots ? 0 : s + 1;   // (the table has 1.5 slots per record: at most two names in three slots)
     }
     unsigned long long* info = &slots[2 * (size_t)s + 1];
     unsigned long long seen = *(volatile unsigned long long*)info;
@@ -178,12 +178,13 @@ void launch_k7_unpack(const ExchangeEntry* in, uint32_t n, uint64_t* key, uint64
     hipLaunchKernelGGL(k7_unpack_kernel, dim3(std::max(1u, (n + 255) / 256)), dim3(256), 0, s, in, n, key, check, region, n_local, n_total);
 }
 
-// slots: [2 (mask + 1)] words, key words all ones and info words zero on entry
-void launch_k7_names_census(const unsigned long long* in, uint32_t n, unsigned long long* slots, uint32_t mask, uint32_t* irregular, hipStream_t s) {
+// slots: [2 nslots] words, key words all ones and info words zero on entry
+void launch_k7_names_census(const unsigned long long* in, uint32_t n, unsigned long long* slots, uint32_t nslots, uint32_t* irregular, hipStream_t s) {
     if (!n) return;
-    hipLaunchKernelGGL(k7_names_insert_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, n, slots, mask);
-    hipLaunchKernelGGL(k7_names_verdict_kernel, dim3((mask + 256) / 256), dim3(256), 0, s, slots, mask + 1, irregular);
+    hipLaunchKernelGGL(k7_names_insert_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, n, slots, nslots);
+    hipLaunchKernelGGL(k7_names_verdict_kernel, dim3((nslots + 255) / 256), dim3(256), 0, s, slots, nslots, irregular);
 }
+uint32_t k7_names_slots(size_t records) { return (uint32_t)std::max<size_t>(1024, records + records / 2); }
 
 // key words all ones, info words zero
 __global__ __launch_bounds__(256) void k7_names_clear_kernel(unsigned long long* slots, uint32_t nslots, uint32_t* irregular) {
