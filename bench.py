@@ -369,7 +369,7 @@ def time_bam_cli_sharded(td, n_gpus_visible, fraction=1.0 / 64):
     prep_s = time.perf_counter() - tg
     cfg = os.path.join(td, "gcfg")
     open(cfg, "w").write(CFG_LINE % "genome.bam")
-    gpus = ",".join(str(i) for i in range(n_gpus_visible)) if n_gpus_visible > 1 else "0,0"
+    gpus = ",".join(str(i) for i in range(n_gpus_visible)) if n_gpus_visible > 1 and not SHARED_GPU_TEST else "0,0"
 
     def run(env_extra):
         env = dict(os.environ, BDX_TIMING="1", BDX_FOREGROUND="1", **env_extra)
@@ -377,7 +377,10 @@ def time_bam_cli_sharded(td, n_gpus_visible, fraction=1.0 / 64):
         for _ in range(3):
             time.sleep(1.0)   # (untimed: the driver is still reclaiming the previous process's HBM -- tens of GB of decoder rings in a sharded run)
             t0 = time.perf_counter()
-            p = subprocess.run([os.path.join(ROOT, "bin", "breakdancer-max"), cfg], cwd=td, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            try:
+                p = subprocess.run([os.path.join(ROOT, "bin", "breakdancer-max"), cfg], cwd=td, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            except subprocess.TimeoutExpired:
+                return {"error": "no result after 300 s (%s)" % env_extra}
             dt = time.perf_counter() - t0
             if p.returncode != 0:
                 return {"error": p.stderr.decode()[-400:]}
@@ -606,6 +609,8 @@ def main():
         local = 0
     import torch
     dist = init_group(a, world, local)
+    # (a second, host-side group: ranks that wait while rank 0 runs the sharded CLI must not keep a barrier kernel spinning on their GPUs)
+    host_group = dist.new_group(backend="gloo") if dist is not None and dist.get_backend() != "gloo" else None
     if a.dry:
         ranks = [rank]
         if dist is not None:
@@ -732,6 +737,18 @@ def main():
             exchange_hung = True
             exchange["error"] = "no result after 600 s"
 
+    # N > 1: BAM -> table with the chromosomes of ONE indexed BAM spread over the N GPUs of this launch (rank 0 starts the one command,
+    # BDX_GPUS=0..N-1; the other ranks wait on the host)
+    sharded_cli = None
+    if world > 1 and not a.no_end_to_end and not a.no_sharded_cli and not a.pmc_child and not exchange_hung:
+        if rank == 0:
+            try:
+                with tempfile.TemporaryDirectory(prefix="bdx_bench_sh_") as td_sh:
+                    sharded_cli = time_bam_cli_sharded(td_sh, world, a.sharded_cli_fraction)
+            except Exception as e:  # noqa: BLE001
+                sharded_cli = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        dist.barrier(group=host_group) if host_group is not None else dist.barrier()
+
     # (behind the genome runs: two dozen contexts created, run and released leave the process in a state in which rank 0's part of a
     # sharded run -- its first, with all its allocations -- took three times as long)
     overlapped = None
@@ -766,6 +783,8 @@ def main():
         timings = {"hbm_resident": {"seconds": dt / a.steps, "value": value / world, "unit": "read-pairs/s",
                                     "note": "= `value` per GPU: one bdx_run on records already in HBM"}}
         cpu = None
+        if sharded_cli is not None:
+            timings["bam_to_table_sharded"] = sharded_cli
         if world == 1 and not (a.no_end_to_end and a.no_cpu_baseline):
             from breakdancer_amd.bamwrite import write_bam
             with tempfile.TemporaryDirectory(prefix="bdx_bench_") as td:

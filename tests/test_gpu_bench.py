@@ -17,12 +17,16 @@ def test_two_ranks_print_one_aggregate_line():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["BDX_BENCH_TEST_SHARED_GPU"] = "1"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--length", "6000000",
-                        "--genome-fraction", "0.004"],
+                        "--genome-fraction", "0.004", "--sharded-cli-fraction", "0.002"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [x for x in p.stdout.decode().splitlines() if x.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
+    # N > 1: rank 0 runs the one command whose ranks decode their chromosomes of ONE indexed BAM on their GPUs (here: both on device 0)
+    sh = out["config"]["timings"]["bam_to_table_sharded"]
+    assert "error" not in sh, sh
+    assert sh["every_rank_decoded_on_its_gpu"] and sh["same_table_as_one_gpu"] and sh["sv_rows"] > 0 and sh["BDX_GPUS"] == "0,0"
     assert out["n_gpus"] == 2 and out["steps"] == 8 and out["scaling"] == "weak"
     pairs = 6_000_000 * 30 // 200
     assert abs(out["value"] - 2 * pairs / (out["ms_per_step"] * 1e-3)) < 1e-3 * out["value"]
