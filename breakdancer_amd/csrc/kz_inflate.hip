@@ -409,6 +409,36 @@ __global__ __launch_bounds__(64, 7) void kz_inflate_kernel(const uint8_t* __rest
                 if (__ballot(on && is_match && mdist > outpos + (uint32_t)offv)) { err = KZ_BAD_DISTANCE; break; }   // a source before the member's first byte
                 n_match += (uint32_t)__builtin_popcountll(mm);
                 lds_order();
+                // Far matches first, all at once.  A source beyond the window is in HBM (written back at least two flushes ago) and depends on
+                // nothing this step produces, while in the loop below every far match costs the wave a round trip to memory of its own --
+                // and two matches in three of configs[1]'s members are far (level-1 deflate of random fields: distances all over the 32 KiB
+                // window, tools/deflate_tokens.py).  So every lane whose token is a far match of at most 8 bytes fetches its own source -- ONE
+                // load instruction for all of them -- and stores the bytes itself; the loop keeps the rest.  (31.9 -> 35.5 GB/s on the 49 k-member
+                // file.  The same for near matches whose source ends before the step's first byte was measured too: 33.8 -- a single LDS
+                // round trip saved does not pay for the instructions every step then carries.)
+                {
+                    const uint32_t dstf = outpos + (uint32_t)offv;
+                    const bool farm = on && is_match && mdist > kNearDist && mlen <= 8 && ((dstf & kOBM) + 8 <= kOB);
+                    const uint64_t fmask = __ballot(farm);
+                    if (fmask) {
+                        if (farm) {
+                            uint64_t v;
+                            const uint8_t* srcp = out + dstf - mdist;
+                            // (behind the write-backs issued so far; past this CU's L1, which may hold the line from before them)
+                            asm volatile("s_waitcnt vmcnt(0)\n\tglobal_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(srcp) : "memory");
+                            uint8_t* q = L.obuf + (dstf & kOBM);
+                            if (mlen == 8) {
+                                __builtin_memcpy(q, &v, 8);
+                            } else {
+                                if (mlen & 4) { const uint32_t x = (uint32_t)v; __builtin_memcpy(q, &x, 4); q += 4; v >>= 32; }
+                                if (mlen & 2) { const uint16_t x = (uint16_t)v; __builtin_memcpy(q, &x, 2); q += 2; v >>= 16; }
+                                if (mlen & 1) *q = (uint8_t)v;
+                            }
+                        }
+                        mm &= ~fmask;
+                        lds_order();
+                    }
+                }
                 while (mm) {
                     const uint32_t m = (uint32_t)__builtin_ctzll(mm);
                     mm &= mm - 1;
