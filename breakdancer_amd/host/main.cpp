@@ -545,6 +545,10 @@ int run(int argc, char** argv) {
         if (!getenv("BDX_CLEAN_EXIT")) {
             bed.reset();     // (the dump files are closed by their writers' destructors)
             fastq.reset();
+            // (but not with work still queued on a device -- a record stage of the decoder's last batch, a copy nobody waits for: the
+            // driver then takes 0.11-0.16 s to tear the queues down, against 0.015 s for an idle device.  bdx_warm_up ends in a device-wide wait)
+            if (sharded) { for (int dv : devices) (void)bdx_warm_up(dv); }
+            else (void)bdx_warm_up(bdx_device(ctx));
             report_result(0);
             _exit(0);
         }
