@@ -15,9 +15,9 @@
 // no second-level tables.
 //
 // Everything a step touches is in LDS: the compressed input is staged through a 1 KiB ring (512 bytes per refill, one
-// coalesced load), the last 2 KiB of output live in a window that literals and near matches never leave (flushed 256 bytes at
+// coalesced load), the last 1 KiB of output live in a window that literals and near matches never leave (flushed 256 bytes at
 // a time, one 4-byte store per lane; matches further back read HBM, where their source has been for at least one flush),
-// tables are 16 bits per entry; ~6.8 KB per wave.  What bounds the kernel is the scalar issue slot (SQ counters,
+// tables are 16 bits per entry; 4.9 KB per wave (32 waves per CU with 64 vector registers: round 4; 2 KiB window and 27 waves before: 35.5 -> 38.5 GB/s).  What bounds the kernel is the scalar issue slot (SQ counters,
 // tools/pmc_inflate.sh: with one token per step it issued 116 scalar + 34 branch instructions per step against 62 vector ones,
 // the SIMDs' scalar slots 70-90 % taken, whatever the occupancy and wherever input and output lived -- 23 GB/s three times
 // over): hence everything per token that can be per lane is, and a step takes as many tokens as 64 bits hold.
@@ -37,7 +37,7 @@ constexpr int kDB = 8;             // primary distance table
 constexpr int kMaxBits = 15;
 // 16-bit table entry: bits 0-3 code length (0: not in the table), 4-5 kind, 6-13 literal byte / length symbol / distance symbol
 constexpr uint32_t T_SLOW = 0, T_LIT = 1, T_SYM = 2, T_EOB = 3;
-constexpr uint32_t kOB = 2048, kOBM = kOB - 1;      // output window
+constexpr uint32_t kOB = 1024, kOBM = kOB - 1;      // output window (1 KiB + 64 VGPRs: 32 waves per CU; what lies further back is fetched from HBM, a step's far matches all at once)
 constexpr uint32_t kFlush = 256;                    // bytes written to HBM at a time (64 lanes x 4 bytes)
 constexpr uint32_t kStepCap = 192;                  // a step's chain ends once it has produced this much: a step writes < 192 + 258 bytes
 constexpr uint32_t kNearDist = kOB - (kStepCap + 258) - 64;   // matches up to this distance are copied inside the window: their
@@ -65,7 +65,7 @@ __device__ __forceinline__ void distance_of(uint32_t s, uint32_t* base, uint32_t
 
 struct __attribute__((aligned(16))) Lds {
     uint32_t ibuf[kIB / 4];    // compressed bytes: position p at p mod 1024
-    uint8_t obuf[kOB + 64];    // the last 2 KiB of output: position p at p mod 2048; 64 bytes behind it take masked-off stores
+    uint8_t obuf[kOB + 64];    // the last 1 KiB of output: position p at p mod 1024; 64 bytes behind it take masked-off stores
     uint16_t lit[1 << kLB];
     uint16_t dist[1 << kDB];
     uint16_t lit_sorted[288];
@@ -200,7 +200,7 @@ __device__ bool build_tables(Lds& L, const uint8_t* lens, uint32_t n, uint16_t* 
     return true;
 }
 
-__global__ __launch_bounds__(64, 7) void kz_inflate_kernel(const uint8_t* __restrict__ in_all, const BgzfBlock* __restrict__ blocks, uint32_t nblk,
+__global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __restrict__ in_all, const BgzfBlock* __restrict__ blocks, uint32_t nblk,
                                                         uint8_t* out_all, uint32_t* __restrict__ status, unsigned long long* __restrict__ prof) {
     __shared__ Lds L;
     // measurement hook (BDX_KZ_PROF, tools/bamdec_probe.py): per member {cycles in all, in headers + tables, steps, matches, slow codes, deflate blocks}
