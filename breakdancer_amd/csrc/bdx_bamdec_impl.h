@@ -32,7 +32,7 @@ constexpr size_t kBamMargin = (size_t)kMaxDeviceRecord + 65536;   // bytes mirro
 constexpr int kBamSlots = 4;                                       // batches in flight (device-side compressed bytes, tables, status)
 constexpr int kBamStaging = 4;                                     // pinned staging buffers
 constexpr size_t kBatchBytesDefault = (size_t)384 << 20;           // compressed bytes per batch
-constexpr size_t kBatchBlocksDefault = 7168;                       // members per batch: a little more than the wave slots the GPU has for this kernel (256 CUs x 27)
+constexpr size_t kBatchBlocksDefault = 8448;                       // members per batch: a little more than the wave slots the GPU has for this kernel (256 CUs x 32)
 
 struct BamPiece {
     uint64_t seq = 0;            // 1-based
