@@ -610,7 +610,12 @@ def main():
     import torch
     dist = init_group(a, world, local)
     # (a second, host-side group: ranks that wait while rank 0 runs the sharded CLI must not keep a barrier kernel spinning on their GPUs)
-    host_group = dist.new_group(backend="gloo") if dist is not None and dist.get_backend() != "gloo" else None
+    host_group = None
+    if dist is not None and dist.get_backend() != "gloo":
+        try:
+            host_group = dist.new_group(backend="gloo")
+        except Exception:  # noqa: BLE001  (no gloo in this build: the waiting ranks use the default group's barrier)
+            host_group = None
     if a.dry:
         ranks = [rank]
         if dist is not None:
