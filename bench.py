@@ -378,9 +378,9 @@ def time_bam_cli_sharded(td, n_gpus_visible, fraction=1.0 / 64):
             time.sleep(1.0)   # (untimed: the driver is still reclaiming the previous process's HBM -- tens of GB of decoder rings in a sharded run)
             t0 = time.perf_counter()
             try:
-                p = subprocess.run([os.path.join(ROOT, "bin", "breakdancer-max"), cfg], cwd=td, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+                p = subprocess.run([os.path.join(ROOT, "bin", "breakdancer-max"), cfg], cwd=td, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
             except subprocess.TimeoutExpired:
-                return {"error": "no result after 300 s (%s)" % env_extra}
+                return {"error": "no result after 120 s (%s)" % env_extra}
             dt = time.perf_counter() - t0
             if p.returncode != 0:
                 return {"error": p.stderr.decode()[-400:]}
@@ -737,10 +737,10 @@ def main():
                 exchange["error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
         th = threading.Thread(target=guarded, daemon=True)
         th.start()
-        th.join(600)
+        th.join(360)
         if th.is_alive():
             exchange_hung = True
-            exchange["error"] = "no result after 600 s"
+            exchange["error"] = "no result after 360 s"
 
     # N > 1: BAM -> table with the chromosomes of ONE indexed BAM spread over the N GPUs of this launch (rank 0 starts the one command,
     # BDX_GPUS=0..N-1; the other ranks wait on the host)
