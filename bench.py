@@ -745,7 +745,16 @@ def main():
     # N > 1: BAM -> table with the chromosomes of ONE indexed BAM spread over the N GPUs of this launch (rank 0 starts the one command,
     # BDX_GPUS=0..N-1; the other ranks wait on the host)
     sharded_cli = None
-    if world > 1 and not a.no_end_to_end and not a.no_sharded_cli and not a.pmc_child and not exchange_hung:
+    hung_any = exchange_hung
+    if world > 1:   # (every rank takes the same way from here: a genome leg that hung on ANY rank leaves its GPU in an unknown state)
+        try:
+            on_host = host_group is not None or dist.get_backend() == "gloo"
+            flag = torch.tensor([1 if exchange_hung else 0], dtype=torch.int32, device=torch.device("cpu") if on_host else dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=host_group)
+            hung_any = bool(int(flag.item()))
+        except Exception:  # noqa: BLE001
+            hung_any = True
+    if world > 1 and not a.no_end_to_end and not a.no_sharded_cli and not a.pmc_child and not hung_any:
         if rank == 0:
             try:
                 with tempfile.TemporaryDirectory(prefix="bdx_bench_sh_") as td_sh:
