@@ -84,7 +84,7 @@ def read_bam(path, keep_all=False):
         targets.append(d[o:o + l - 1].decode())
         o += l + 4
     cols = {k: [] for k in ("tid", "pos", "mtid", "mpos", "isize", "flag", "qlen", "mapq", "bdqual", "rend")}
-    names, rgs, seqs, quals = [], [], [], []
+    names, rgs, seqs, quals, auxes = [], [], [], [], []
     while o < len(d):
         bs, = struct.unpack_from("<i", d, o)
         o += 4
@@ -116,6 +116,8 @@ def read_bam(path, keep_all=False):
         rgs.append(rg[1] if rg is not None and rg[0] == b"Z" else "")
         seqs.append(seq)
         quals.append(qual)
+        if keep_all:
+            auxes.append(aux)
     dt = dict(tid=np.int32, pos=np.int32, mtid=np.int32, mpos=np.int32, isize=np.int32, flag=np.uint16,
               qlen=np.int32, mapq=np.uint8, bdqual=np.uint8, rend=np.int32)
     recs = {k: np.array(v, dtype=dt[k]) for k, v in cols.items()}
@@ -125,6 +127,7 @@ def read_bam(path, keep_all=False):
     recs["qual"] = quals
     if keep_all:
         recs["header"] = header_text
+        recs["aux"] = auxes   # {tag: (type, value)} per record: the integer and string tags
     return targets, recs
 
 
