@@ -2,8 +2,9 @@
 tests/golden/make_bam2cfg_vectors.py from the documented rules of perl/bam2cfg.pl and AlnParser.pm), on the reference's
 chr21 fixtures and on a synthetic BAM that reaches the script's early exits.  The reference's own golden config
 (test-data/inv_del_bam_config) was made from the full BAMs, of which the fixtures are excerpts, so it pins the format and
-the plausibility of the figures, not their digits; the Perl script itself cannot run here (no samtools, no
-Statistics::Descriptive): parity with it is unpinned.  bam2cfg stays a CPU tool."""
+the plausibility of the figures, not their digits; the Perl script as a whole cannot run here (no samtools, no
+Statistics::Descriptive), but its record classifier (AlnParser.pm) and its Shapiro-Wilk sub can: the second half of this file
+holds the tool to their outputs, column by column (tests/golden/make_bam2cfg_perl_vectors.py).  bam2cfg stays a CPU tool."""
 import json
 import os
 import subprocess
@@ -80,3 +81,51 @@ def test_early_exit_two_libraries_and_quality_gate(tmp_path):
     assert [r["lib"] for r in rows] == ["libA", "libB"]
     assert all(1480 <= int(r["num"]) <= 1501 for r in rows)
     assert abs(float(rows[0]["mean"]) - 300) < 3 and abs(float(rows[1]["mean"]) - 450) < 4
+
+
+# ---- pinned on the parts of the reference's Perl that run (tests/golden/make_bam2cfg_perl_vectors.py): AlnParser::in of
+# perl/AlnParser.pm on every record (orientation code, quality, read length, insert size, read group) and the ShapiroWilk sub
+# of perl/bam2cfg.pl:284-770 on the collected insert sizes -- every column of the output line, the -g histogram included ----
+PERL_VECTORS = json.load(open(os.path.join(GOLDEN, "bam2cfg_perl_vectors.json")))
+
+
+def check_exact(path, args, expect):
+    rows = run_tool([path], *args)
+    assert [r["readgroup"] for r in rows] == [e["readgroup"] for e in expect] and rows
+    for row, e in zip(rows, expect):
+        assert row["map"] == path and row["exe"] == "samtools view"
+        for k in ("platform", "lib", "num", "readlen", "lower", "upper", "mean", "std", "SWnormality", "flag"):
+            assert row.get(k) == e[k], (e["readgroup"], k, row.get(k), e[k])
+
+
+@pytest.mark.parametrize("name", ["NA19240_chr21_del_inv.bam", "NA19238_chr21_del_inv.bam"])
+@pytest.mark.parametrize("args", ["-g", "-q 20 -c 3 -n 1200 -g", "-m -g"])
+def test_chr21_fixtures_against_the_reference_perl(name, args):
+    check_exact(os.path.join(GOLD, name), args.split(), PERL_VECTORS[name][args])
+
+
+def test_two_libraries_against_the_reference_perl(tmp_path):
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from make_bam2cfg_vectors import two_library_records
+    from breakdancer_amd.bamwrite import write_bam_records
+    recs, rgs = two_library_records()
+    path = str(tmp_path / "two.bam")
+    write_bam_records(path, recs, ["c1"], rgs=rgs)
+    check_exact(path, ["-n", "1500", "-g"], PERL_VECTORS["two_libraries_synthetic"]["-n 1500 -g"])
+
+
+@pytest.mark.parametrize("args", ["-q 0 -g", "-q 35 -g", "-m -q 35 -g"])
+def test_every_orientation_code_against_alnparser(tmp_path, args):
+    """every combination of the flag bits AlnParser.pm:57-126 looks at, the mate on either side / another chromosome, AM tags
+    above and below the quality gate, records without a read group: the -g histogram is AlnParser's, code by code"""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from make_bam2cfg_perl_vectors import orientation_records
+    from breakdancer_amd.bamwrite import write_bam_records
+    recs, rgs = orientation_records()
+    path = str(tmp_path / "orientations.bam")
+    write_bam_records(path, recs, ["c1", "c2"], rgs=rgs)
+    expect = PERL_VECTORS["orientations_synthetic"][args]
+    assert len({c.split("(")[0] for c in expect[0]["flag"].split(")")[:-1]}) == 10   # all ten codes occur
+    check_exact(path, args.split(), expect)
