@@ -842,6 +842,7 @@ int bdx_dist_run(bdx_dist* d) {
             U->n_sv_total = U->n_terms_total = U->n_cn_total = U->n_printed = U->n_sv_host = U->n_groups_total = 0;
             memset(&U->counts, 0, sizeof(U->counts));
             U->materialized = true; U->ran = true; U->stage = 4;
+            if (want_support) { U->collect_support = true; U->sup_off.assign(1, 0); }   // (no SV, no supporting read: an empty list, not a missing one)
         }
         return finish_result();
     }

@@ -39,7 +39,9 @@ constexpr int kMaxBits = 15;
 constexpr uint32_t T_SLOW = 0, T_LIT = 1, T_SYM = 2, T_EOB = 3;
 constexpr uint32_t kOB = 1024, kOBM = kOB - 1;      // output window (1 KiB + 64 VGPRs: 32 waves per CU; what lies further back is fetched from HBM, a step's far matches all at once)
 constexpr uint32_t kFlush = 256;                    // bytes written to HBM at a time (64 lanes x 4 bytes)
-constexpr uint32_t kStepCap = 192;                  // a step's chain ends once it has produced this much: a step writes < 192 + 258 bytes
+constexpr uint32_t kStepCap = 128;                  // a step's chain ends once it has produced this much: a step writes < 128 + 258 bytes (a power of two: the walk tests it with one AND)
+constexpr uint32_t kWalkStop = 1u << 30;            // walk word of a token the tables do not resolve
+constexpr uint32_t kWalkExit = 0xC0u | ((kStepCap | (kStepCap << 1)) << 8) | kWalkStop;   // cursor >= 64 | output >= kStepCap (< 4 kStepCap) | unresolved
 constexpr uint32_t kNearDist = kOB - (kStepCap + 258) - 64;   // matches up to this distance are copied inside the window: their
                                                     // source cannot be overwritten by anything the step writes (positions are mod 2048)
 constexpr uint32_t kIB = 1024, kIBM = kIB - 1;      // input ring
@@ -64,7 +66,7 @@ __device__ __forceinline__ void distance_of(uint32_t s, uint32_t* base, uint32_t
 }
 
 struct __attribute__((aligned(16))) Lds {
-    uint32_t ibuf[kIB / 4];    // compressed bytes: position p at p mod 1024
+    uint32_t ibuf[kIB / 4 + 2];   // compressed bytes: position p at p mod 1024; the first 8 bytes once more behind the end (a step's three words need no wrap)
     uint8_t obuf[kOB + 64];    // the last 1 KiB of output: position p at p mod 1024; 64 bytes behind it take masked-off stores
     uint16_t lit[1 << kLB];
     uint16_t dist[1 << kDB];
@@ -79,6 +81,25 @@ struct __attribute__((aligned(16))) Lds {
     uint16_t lbx[32];
     uint32_t dbx[32];
 };
+
+// Lane predicates as scalar masks.  All 64 lanes are active wherever these are used (the step loop's control flow is uniform), so a
+// vector compare's result IS the ballot; written as such the compare stays one instruction (the ballot builtin costs a v_cndmask and
+// a second compare on this compiler), and a mask goes back to a lane predicate without any (inverse ballot: the mask becomes EXEC).
+__device__ __forceinline__ uint64_t mask_eq(uint32_t a, uint32_t b) { uint64_t r; asm("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ uint64_t mask_gt(uint32_t a, uint32_t b) { uint64_t r; asm("v_cmp_gt_u32_e64 %0, %1, %2" : "=s"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ uint64_t mask_le(uint32_t a, uint32_t b) { uint64_t r; asm("v_cmp_le_u32_e64 %0, %1, %2" : "=s"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ bool lanes_of(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
+// inclusive prefix sum over the wave's 64 lanes: within rows of 16 by four shifted adds, then across the rows (DPP row_shr / row_bcast)
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);   // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);   // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);   // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);   // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+    return x;
+}
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // LDS accesses of a wave are executed in program order; this only keeps the compiler from moving them across
@@ -99,7 +120,7 @@ __device__ __forceinline__ uint64_t ring_peek(const uint32_t* ibuf, uint32_t p) 
 // the same for the step loop: the two halves straight from v_alignbit (which shifts by the low five bits of p itself)
 __device__ __forceinline__ void ring_peek2(const uint32_t* ibuf, uint32_t p, uint32_t& lo, uint32_t& hi) {
     const uint32_t i0 = (p >> 5) & (kIB / 4 - 1);
-    const uint32_t d0 = ibuf[i0], d1 = ibuf[(i0 + 1) & (kIB / 4 - 1)], d2 = ibuf[(i0 + 2) & (kIB / 4 - 1)];
+    const uint32_t d0 = ibuf[i0], d1 = ibuf[i0 + 1], d2 = ibuf[i0 + 2];   // (ibuf[256], ibuf[257] mirror ibuf[0], ibuf[1]: ring_load)
     lo = __builtin_amdgcn_alignbit(d1, d0, p);
     hi = __builtin_amdgcn_alignbit(d2, d1, p);
 }
@@ -107,7 +128,9 @@ __device__ __forceinline__ void ring_peek2(const uint32_t* ibuf, uint32_t p, uin
 __device__ __forceinline__ void ring_load(uint32_t* ibuf, const uint8_t* in, uint32_t from, uint32_t lane) {
     uint64_t v;
     __builtin_memcpy(&v, in + from + 8u * lane, 8);
-    *(uint64_t*)((uint8_t*)ibuf + ((from + 8u * lane) & kIBM)) = v;
+    const uint32_t at = (from + 8u * lane) & kIBM;
+    *(uint64_t*)((uint8_t*)ibuf + at) = v;
+    if (at == 0) *(uint64_t*)((uint8_t*)ibuf + kIB) = v;   // the mirror of the ring's first 8 bytes
 }
 
 // canonical decode, one bit at a time (codes are packed starting with their most significant bit): returns the code's
@@ -367,46 +390,49 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
             const uint32_t dx = db >> 16, dbase = db & 0xFFFFu;
             const uint32_t a2 = __builtin_amdgcn_alignbit(w_hi, w_lo, l1 + lx + dl);  // the distance's extra bits (l1 + lx + dl <= 23)
             const uint32_t mdist = dbase + (a2 & ((1u << dx) - 1));
-            const bool is_lit = ek == T_LIT;
-            const bool is_match = ek == T_SYM && t_kind(de) == T_SYM;
+            const uint64_t m_lit = mask_eq(ek, T_LIT), m_match = mask_eq(ek, T_SYM) & mask_eq(t_kind(de), T_SYM);
+            const bool is_lit = lanes_of(m_lit);
+            const bool is_match = lanes_of(m_match);
             const uint32_t olen = is_lit ? 1u : mlen;                                   // bytes the token produces
-            const uint32_t nxt = (is_lit || is_match) ? lane + (is_lit ? l1 : l1 + lx + dl + dx) : 128u + lane;   // >= 128: the chain stops here
             // matches of the usual kind -- at most 64 bytes, source not overlapping the destination, inside the window -- are copied
             // without a branch; pk carries what the copy needs in one register
             const bool easy = is_match && mlen <= 64 && mdist >= mlen && mdist <= kNearDist;
             const uint32_t pk = mdist | (mlen << 16) | (easy ? 0x80000000u : 0u);
-            // The chain of tokens that starts at the cursor; offv: where each token's output begins, relative to outpos.  nxt < 64:
-            // the token at cur is taken and the chain goes on at nxt; 64 <= nxt < 128: taken, and the window is used up; >= 128:
-            // the chain stops in front of the token at cur.  It also ends once kStepCap bytes have been produced.
-            uint32_t cur = 0, o = 0, nn;
+            // The chain of tokens that starts at the cursor, followed through the lanes' results.  What bounds this kernel is the number of
+            // INSTRUCTIONS a step issues, of whatever kind (each of a CU's four SIMDs takes one instruction per wave every fourth cycle and
+            // shares its fetch with 31 other waves that are somewhere else in this loop; builds that traded vector instructions for more
+            // scalar ones ran slower: tools/kz_ab.sh, profiles/r04_inflate_ab.txt), so the walk is five instructions per token: one register
+            // per lane holds the token's bits in its low byte and its output length above it (a token the tables do not resolve: bit 30
+            // alone), and ONE scalar word carries cursor and output count the same way -- the token's register is added to it, and one
+            // AND tells whether the walk goes on: not once the cursor has left the 64-bit window, kStepCap bytes have been produced or
+            // the chain met a token the tables do not resolve (the step then stops in front of it).  v_readlane and s_bitset1 take the
+            // cursor from the word's low six bits as it is.
+            const uint32_t walk = lanes_of(m_lit | m_match) ? ((is_lit ? l1 : l1 + lx + dl + dx) | (olen << 8)) : kWalkStop;
+            uint32_t co = 0, wtok, wtest;
             uint64_t mask = 0;
-            int offv = 0;
-            for (;;) {
-                nn = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)cur);
-                if (nn >= 64) break;
-                offv = lane == cur ? (int)o : offv;   // (two vector instructions; the scalar slot is what is scarce)
-                mask |= 1ull << cur;
-                o += (uint32_t)__builtin_amdgcn_readlane((int)olen, (int)cur);
-                cur = nn;
-                if (o >= kStepCap) { nn = 256; break; }   // (256: ended by the cap, nothing pending at cur)
-            }
-            bool stopped = false;
-            if (nn < 128) {   // the last token of the window
-                offv = lane == cur ? (int)o : offv;
-                mask |= 1ull << cur;
-                o += (uint32_t)__builtin_amdgcn_readlane((int)olen, (int)cur);
-                cur = nn;
-            } else if (nn < 256) {
-                stopped = true;
-            }
+            asm volatile(
+                "1:\n\t"
+                "v_readlane_b32 %[w], %[walk], %[co]\n\t"
+                "s_bitset1_b64 %[mask], %[co]\n\t"
+                "s_add_u32 %[co], %[co], %[w]\n\t"
+                "s_and_b32 %[t], %[co], %[exit]\n\t"
+                "s_cbranch_scc0 1b"
+                : [w] "=&s"(wtok), [t] "=&s"(wtest), [mask] "+s"(mask), [co] "+s"(co)
+                : [walk] "v"(walk), [exit] "s"(kWalkExit)
+                : "scc");
+            const bool stopped = (co & kWalkStop) != 0;
+            mask ^= (uint64_t)((co >> 30) & 1u) << (co & 63u);   // (the unresolved token was marked before its register was seen; its bits and bytes are 0)
+            const uint32_t o = (co >> 8) & 0x1FFu, cur = co & 0xFFu;
+            // where each taken token's output begins, relative to outpos: an exclusive prefix sum of the output lengths over the chain
+            const uint32_t contrib = lanes_of(mask) ? olen : 0u;
+            const int offv = (int)(wave_inclusive_sum(contrib) - contrib);
             const uint32_t pos = cur;
             if (mask) {
                 if (o > ulen - outpos) { err = KZ_OUTPUT_OVERRUN; break; }
-                const bool on = (mask >> lane) & 1;
-                if (on && is_lit) L.obuf[(outpos + (uint32_t)offv) & kOBM] = (uint8_t)ev;
+                if (lanes_of(mask & m_lit)) L.obuf[(outpos + (uint32_t)offv) & kOBM] = (uint8_t)ev;
                 // the matches, in stream order (a later one may copy what an earlier one, or a literal of this step, produced)
-                uint64_t mm = mask & __ballot(is_match);
-                if (__ballot(on && is_match && mdist > outpos + (uint32_t)offv)) { err = KZ_BAD_DISTANCE; break; }   // a source before the member's first byte
+                uint64_t mm = mask & m_match;
+                if (mm & mask_gt(mdist, outpos + (uint32_t)offv)) { err = KZ_BAD_DISTANCE; break; }   // a source before the member's first byte
                 n_match += (uint32_t)__builtin_popcountll(mm);
                 lds_order();
                 // Far matches first, all at once.  A source beyond the window is in HBM (written back at least two flushes ago) and depends on
@@ -418,8 +444,8 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
                 // round trip saved does not pay for the instructions every step then carries.)
                 {
                     const uint32_t dstf = outpos + (uint32_t)offv;
-                    const bool farm = on && is_match && mdist > kNearDist && mlen <= 8 && ((dstf & kOBM) + 8 <= kOB);
-                    const uint64_t fmask = __ballot(farm);
+                    const uint64_t fmask = mm & mask_gt(mdist, kNearDist) & mask_le(mlen, 8u) & mask_le(dstf & kOBM, kOB - 8u);
+                    const bool farm = lanes_of(fmask);
                     if (fmask) {
                         if (farm) {
                             uint64_t v;

@@ -159,3 +159,17 @@ def test_sharded_run_returns_the_supporting_reads(seed):
         compare_support(run, util)
         done += 1
     assert done >= 2
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_sharded_run_with_supporting_reads_and_no_region(world):
+    """-t on an input without inter-chromosomal pairs: no region, no SV -- and an EMPTY list of supporting reads, not a missing one
+    (found by tools/extended_fuzz_sharded.py: the early exit for an empty table left the list unset and bdx_get_sv_support refused)"""
+    from fuzzgen import make_graph_case
+    from runner import compare_support
+    cfg, streams, targets = make_graph_case(8011)
+    run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1, transchr_rearrange=1, min_read_pair=1))
+    assert len(run.sup_off) == 1 and len(run.sup_idx) == 0   # the oracle's table is empty
+    util = sharded_from_oracle(run, world=world, support=True)
+    compare(run, util, check_cls=False)
+    compare_support(run, util)

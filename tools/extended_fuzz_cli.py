@@ -19,7 +19,7 @@ for seed in range(a, b):
         open(os.path.join(td, "cfg"), "w").write(cfg)
         args = FLAGSETS[seed % len(FLAGSETS)][0]
         texts = {}
-        for label, env in (("device", {}), ("small", dict(BDX_BAM_PIECE_BYTES=str(int(rng.integers(40000, 200000))), BDX_BAM_BATCH_BLOCKS=str(int(rng.integers(1, 6))),
+        for label, env in (("device", {}), ("small", dict(BDX_BAM_PIECE_BYTES=str(int(rng.integers(70000, 200000))), BDX_BAM_BATCH_BLOCKS=str(int(rng.integers(1, 6))),
                                                           BDX_BAM_RING_BYTES=str(1 << 21))), ("host", dict(BDX_DECODE="host"))):
             p = subprocess.run([EXE, "-y", "-1"] + args + ["cfg"], cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
             texts[label] = (p.returncode, filter_cmd_lines(p.stdout.decode()), p.stderr.decode()[-300:])
