@@ -30,7 +30,10 @@ namespace {
 
 constexpr size_t kBamMargin = (size_t)kMaxDeviceRecord + 65536;   // bytes mirrored behind the piece in front of a wrap
 constexpr int kBamSlots = 4;                                       // batches in flight (device-side compressed bytes, tables, status)
-constexpr int kBamStaging = 4;                                     // pinned staging buffers
+#ifndef BDX_BAM_STAGING
+#define BDX_BAM_STAGING 4
+#endif
+constexpr int kBamStaging = BDX_BAM_STAGING;                                     // pinned staging buffers (a caller may hold several: it reads pieces ahead of the one it submits)
 constexpr size_t kBatchBytesDefault = (size_t)384 << 20;           // compressed bytes per batch
 constexpr size_t kBatchBlocksDefault = 8448;                       // members per batch: a little more than the wave slots the GPU has for this kernel (256 CUs x 32)
 
@@ -67,7 +70,7 @@ struct bdx_bamdec {
         size_t cap_bytes = 0;             // bytes the last bdx_bamdec_acquire promised
         hipError_t pin_status = hipSuccess;
     } staging[kBamStaging];
-    int next_staging = 0, cur_staging = -1;
+    int next_staging = 0, held_staging = 0;   // the held_staging buffers before next_staging are acquired and not submitted yet (oldest first)
     // a batch: the compressed bytes of its pieces back to back in HBM, its member table, the inflate status words
     struct Slot {
         DevBuf d_comp, d_blocks, d_status, d_bitmap;   // (d_bitmap: the match-start map of the two-kernel inflate path)
@@ -504,7 +507,7 @@ const char* bdx_bamdec_last_error(const bdx_bamdec* d) { return d ? d->err.c_str
 
 int bdx_bamdec_acquire(bdx_bamdec* d, size_t bytes, size_t max_blocks, void** buf, bdx_bgzf_block** blocks) {
     if (!d || !buf || !blocks || bytes == 0 || max_blocks == 0) return BDX_EINVAL;
-    if (d->cur_staging >= 0) return bfail(d, BDX_ESTATE, "the previous piece was not submitted");
+    if (d->held_staging >= kBamStaging) return bfail(d, BDX_ESTATE, "every staging buffer is acquired: submit a piece first");
     if (d->finished) return bfail(d, BDX_ESTATE, "the decoder has finished");
     BHIP(d, hipSetDevice(d->device));
     bdx_bamdec::Staging& st = d->staging[d->next_staging];
@@ -526,7 +529,7 @@ int bdx_bamdec_acquire(bdx_bamdec* d, size_t bytes, size_t max_blocks, void** bu
     *blocks = st.h_tab.as<bdx_bgzf_block>();
     st.cap = max_blocks;
     st.cap_bytes = bytes;
-    d->cur_staging = d->next_staging;
+    ++d->held_staging;
     d->next_staging = (d->next_staging + 1) % kBamStaging;
     return BDX_OK;
 }
@@ -643,10 +646,10 @@ extern "C" {
 
 int bdx_bamdec_submit(bdx_bamdec* d, size_t bytes, size_t nblocks, int last) {
     if (!d) return BDX_EINVAL;
-    if (d->cur_staging < 0) return bfail(d, BDX_ESTATE, "no piece was acquired");
+    if (d->held_staging <= 0) return bfail(d, BDX_ESTATE, "no piece was acquired");
     BHIP(d, hipSetDevice(d->device));
-    bdx_bamdec::Staging& st = d->staging[d->cur_staging];
-    d->cur_staging = -1;
+    bdx_bamdec::Staging& st = d->staging[(d->next_staging + kBamStaging - d->held_staging) % kBamStaging];   // the oldest piece held
+    --d->held_staging;
     if (nblocks > st.cap) return bfail(d, BDX_EINVAL, "more blocks than the acquired table holds");
     if (bytes > st.cap_bytes) return bfail(d, BDX_EINVAL, "more bytes than the acquired piece holds");
     const bdx_bgzf_block* hb = st.h_tab.as<bdx_bgzf_block>();
@@ -716,6 +719,7 @@ int bdx_bamdec_finish(bdx_bamdec* d, uint64_t* n_records) {
             if (rc != BDX_OK) return rc;
         }
         d->finished = true;
+        d->held_staging = 0;   // (pieces acquired ahead and never submitted -- a caller that stopped early -- are dropped)
     }
     BHIP(d, hipStreamSynchronize(d->s_copy));
     BHIP(d, hipStreamSynchronize(d->s_inf));
@@ -755,7 +759,7 @@ int bdx_bamdec_rearm(bdx_bamdec* d, int32_t only_tid, int32_t region_beg, int32_
         if (s) BHIP(d, hipStreamSynchronize(s));
     d->filt.only_tid = only_tid; d->filt.beg = region_beg; d->filt.end = region_end;
     for (auto& st : d->staging) st.busy = false;
-    d->next_staging = 0; d->cur_staging = -1;
+    d->next_staging = 0; d->held_staging = 0;
     for (auto& sl : d->slot) { sl.busy = false; sl.open = false; sl.bytes = 0; sl.nblk = 0; sl.ulen = 0; }
     d->cur_slot = 0;
     d->cursor = 0;

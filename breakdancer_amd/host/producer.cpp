@@ -1,6 +1,8 @@
 #include "producer.h"
 
 #include <cctype>
+#include <condition_variable>
+#include <deque>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -338,29 +340,72 @@ namespace {
 inline uint32_t dle32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 inline uint32_t dle16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
 
-// bytes [off, off + n) of the file into dst, by `threads` threads (page cache -> pinned memory is a plain copy: one core
-// moves 5-8 GB/s, the GPU side wants several times that)
-void read_range(int fd, size_t off, uint8_t* dst, size_t n, int threads, std::string* err) {
-    const size_t slice = std::max<size_t>((n + (size_t)threads - 1) / (size_t)threads, (size_t)1 << 20);
-    std::vector<std::thread> th;
-    std::vector<std::string> errs((n + slice - 1) / slice);
-    size_t k = 0;
-    for (size_t o = 0; o < n; o += slice, ++k) {
-        const size_t m = std::min(slice, n - o);
-        auto job = [fd, off, dst, o, m, &errs, k] {
-            size_t done = 0;
-            while (done < m) {
-                const ssize_t r = pread(fd, dst + o + done, m - done, (off_t)(off + o + done));
-                if (r <= 0) { errs[k] = "read error"; return; }
+// Pieces of a file read AHEAD of the one being cut into members: a pool of threads that lives as long as the decode, fed with slices of 1 MiB.
+// (Page cache -> pinned memory is a plain copy, one core moves 2-5 GB/s of it.  Until round 4 every piece was read by threads started for
+// it -- 244 pieces x 7 threads for a 2 GB file, the piece all they had to work on: 26 GB/s on 16 CPUs; a pool working on up to four pieces at
+// a time moves 40 GB/s on the same box, tools/register_probe.hip.)
+class ReadPool {
+public:
+    struct Piece {
+        std::mutex mu;
+        std::condition_variable cv;
+        size_t left = 0;
+        bool failed = false;
+    };
+    explicit ReadPool(int n) {
+        for (int i = 0; i < std::max(1, n); ++i) th_.emplace_back([this] { work(); });
+    }
+    ~ReadPool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    // bytes [off, off + n) of fd into dst; pc->left counts the slices still on their way
+    void read(int fd, size_t off, uint8_t* dst, size_t n, Piece* pc) {
+        const size_t slice = (size_t)1 << 20;
+        const size_t k = (n + slice - 1) / slice;
+        { std::lock_guard<std::mutex> lk(pc->mu); pc->left += k; }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (size_t o = 0; o < n; o += slice) q_.push_back(Task{fd, off + o, dst + o, std::min(slice, n - o), pc});
+        }
+        cv_.notify_all();
+    }
+    static bool wait(Piece* pc) {   // true: every byte arrived
+        std::unique_lock<std::mutex> lk(pc->mu);
+        pc->cv.wait(lk, [pc] { return pc->left == 0; });
+        return !pc->failed;
+    }
+
+private:
+    struct Task { int fd; size_t off; uint8_t* dst; size_t n; Piece* pc; };
+    void work() {
+        for (;;) {
+            Task t;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;
+                t = q_.front();
+                q_.pop_front();
+            }
+            bool ok = true;
+            for (size_t done = 0; done < t.n;) {
+                const ssize_t r = pread(t.fd, t.dst + done, t.n - done, (off_t)(t.off + done));
+                if (r <= 0) { ok = false; break; }
                 done += (size_t)r;
             }
-        };
-        if (o + slice < n) th.emplace_back(job); else job();
+            std::lock_guard<std::mutex> lk(t.pc->mu);
+            if (!ok) t.pc->failed = true;
+            if (--t.pc->left == 0) t.pc->cv.notify_all();
+        }
     }
-    for (auto& t : th) t.join();
-    for (auto& e : errs)
-        if (!e.empty()) *err = e;
-}
+    std::vector<std::thread> th_;
+    std::deque<Task> q_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool stop_ = false;
+};
 
 }  // namespace
 
@@ -434,8 +479,8 @@ size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::strin
     if (span_bytes) p.ring_bytes = std::min<size_t>((size_t)3 << 30, std::max<size_t>((size_t)256 << 20, rest * 12));
     if (const char* rb = getenv("BDX_BAM_RING_BYTES")) p.ring_bytes = (size_t)std::max(1ll, atoll(rb));
     // (what bdx_bamdec_acquire will ask for: a piece, a member cut at the piece's end carried over from the one before, and slack)
-    p.piece_bytes = std::min(kPiece, rest) + 65536 + 65536;
-    p.piece_blocks = kPiece / 2048 + 4096;
+    p.piece_bytes = std::min(kPiece, rest) + 65536 + 65536;   // (in front: the tail of the piece before; behind: slack)
+    p.piece_blocks = kPiece / 512 + 4096;
     bdx_bamdec* dec = reuse ? *reuse : nullptr;
     const auto t_create = std::chrono::steady_clock::now();
     int rc;
@@ -462,31 +507,58 @@ size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::strin
     auto clk = [] { return std::chrono::steady_clock::now(); };
     auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
     size_t npieces = 0;
-    size_t off = member_off;
     std::vector<uint8_t> carry;
-    const size_t max_blocks = kPiece / 2048 + 4096;   // (a piece of many tiny members is simply cut earlier)
-    bool stop = false;
+    const size_t max_blocks = p.piece_blocks;   // (a piece of more members than that -- 512 bytes each on average -- is left to the host reader)
+    bool stop = false, too_many_members = false;
     // (a sequence read through the index: its records end where the index says -- nothing behind that is read, let alone inflated)
     const size_t read_end = span_bytes ? std::min(file_size, member_off + span_bytes) : file_size;
+    // The file is read AHEAD of the piece being cut: up to kAhead pieces are on their way into staging buffers (ReadPool) while this
+    // thread finds the members of the oldest one and submits it.  A piece's bytes land kLead bytes into its buffer: the tail of the
+    // piece before it -- the member cut at that piece's end, known only once that piece has been cut -- is put in front of them.
+    const size_t kLead = 65536;
+    // (a region read through the index stops at the first record behind it: nothing is read in vain.  Test knob: BDX_BAM_AHEAD)
+    const int kAhead = seeked ? 1 : getenv("BDX_BAM_AHEAD") ? std::max(1, std::min(4, atoi(getenv("BDX_BAM_AHEAD")))) : 4;
+    struct Ahead { uint8_t* b = nullptr; bdx_bgzf_block* tab = nullptr; size_t off = 0, want = 0; ReadPool::Piece pc; };
+    std::deque<std::unique_ptr<Ahead>> ahead;
+    ReadPool pool(threads);
+    size_t next_off = member_off;
+    bool queued_all = false;
+    struct Drain {   // (whatever ends the loop: no thread may still be writing into a staging buffer when the decoder goes on)
+        std::deque<std::unique_ptr<Ahead>>& a;
+        ~Drain() { for (auto& x : a) (void)ReadPool::wait(&x->pc); }
+    } drain{ahead};
     while (!stop) {
-        const size_t want = std::min(kPiece, read_end - std::min(read_end, off));
-        void* buf = nullptr;
-        bdx_bgzf_block* tab = nullptr;
-        auto t0 = clk();
-        check(bdx_bamdec_acquire(dec, carry.size() + want + 65536, max_blocks, &buf, &tab), "bdx_bamdec_acquire");
-        t_acquire += since(t0);
+        while (!queued_all && (int)ahead.size() < kAhead) {
+            std::unique_ptr<Ahead> a(new Ahead);
+            a->off = next_off;
+            a->want = std::min(kPiece, read_end - std::min(read_end, next_off));
+            void* buf = nullptr;
+            auto t0 = clk();
+            check(bdx_bamdec_acquire(dec, kLead + a->want + 65536, max_blocks, &buf, &a->tab), "bdx_bamdec_acquire");
+            t_acquire += since(t0);
+            a->b = (uint8_t*)buf;
+            if (a->want) pool.read(fd, a->off, a->b + kLead, a->want, &a->pc);
+            next_off += a->want;
+            if (next_off >= read_end) queued_all = true;
+            ahead.push_back(std::move(a));
+        }
+        if (ahead.empty()) break;
+        std::unique_ptr<Ahead> cur = std::move(ahead.front());
+        ahead.pop_front();
         ++npieces;
-        uint8_t* b = (uint8_t*)buf;
-        if (!carry.empty()) memcpy(b, carry.data(), carry.size());
-        std::string rerr;
-        t0 = clk();
-        if (want) read_range(fd, off, b + carry.size(), want, threads, &rerr);
+        auto t0 = clk();
+        const bool read_ok = ReadPool::wait(&cur->pc);
         t_read += since(t0);
         t0 = clk();
-        if (!rerr.empty()) throw std::runtime_error("cannot read " + path);
-        const size_t have = carry.size() + want;
-        off += want;
+        if (!read_ok) throw std::runtime_error("cannot read " + path);
+        if (carry.size() > kLead) throw std::runtime_error("BGZF member larger than 64 KiB: " + path);
+        const size_t base = kLead - carry.size();
+        uint8_t* b = cur->b + base;
+        if (!carry.empty()) memcpy(b, carry.data(), carry.size());
+        const size_t have = carry.size() + cur->want;
+        const size_t off = cur->off + cur->want;
         const bool at_eof = off >= file_size;
+        bdx_bgzf_block* tab = cur->tab;
         // the members
         size_t q = 0, nb = 0;
         while (q + 18 <= have) {
@@ -507,20 +579,22 @@ size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::strin
             const uint32_t ulen = dle32(h + total - 4);
             if (ulen > 65536) throw std::runtime_error("BGZF block larger than 64 KiB: " + path);
             if (ulen) {   // (members that inflate to nothing -- the EOF marker, flush blocks -- are skipped)
-                if (nb >= max_blocks) break;
-                tab[nb].offset = q + 12 + xlen;
+                if (nb >= max_blocks) { too_many_members = true; break; }
+                tab[nb].offset = base + q + 12 + xlen;
                 tab[nb].payload_len = (uint32_t)(total - 12 - xlen - 8);
                 tab[nb].inflated_len = ulen;
                 ++nb;
             }
             q += total;
         }
+        if (too_many_members) break;
         if (at_eof && q != have) throw std::runtime_error("truncated BGZF file: " + path);
         carry.assign(b + q, b + have);
-        if (q == 0 && !at_eof && want && off < read_end) throw std::runtime_error("BGZF member larger than a piece: " + path);
+        if (q == 0 && !at_eof && cur->want && off < read_end) throw std::runtime_error("BGZF member larger than a piece: " + path);
         t_scan += since(t0);
         t0 = clk();
-        check(bdx_bamdec_submit(dec, q, nb, at_eof ? 1 : 0), "bdx_bamdec_submit");
+        // (the bytes in front of `base` travel with the piece -- at most 64 KiB of 8 MiB -- and no table entry points at them)
+        check(bdx_bamdec_submit(dec, base + q, nb, at_eof ? 1 : 0), "bdx_bamdec_submit");
         t_submit += since(t0);
         if (at_eof) break;
         if (off >= read_end) break;   // (the end of the sequence's span: the stream is cut here, bdx_bamdec_finish drops a record that runs past it)
@@ -530,6 +604,7 @@ size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::strin
             if (past) stop = true;
         }
     }
+    for (auto& x : ahead) (void)ReadPool::wait(&x->pc);   // (pieces read ahead and not needed: their readers are through before the decoder is)
     uint64_t n = 0;
     const auto tf = clk();
     rc = bdx_bamdec_finish(dec, &n);
@@ -543,7 +618,8 @@ size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::strin
     if (timing)
         fprintf(stderr, "[bdx timing] device decode: decoder set up in %.3f s; %zu pieces; waiting for a staging buffer %.3f s, reading the file %.3f s (%d threads), member tables %.3f s, "
                         "enqueueing %.3f s, waiting for the GPU at the end %.3f s\n", create_s, npieces, t_acquire, t_read, threads, t_scan, t_submit, t_finish);
-    if (rc == BDX_ELIMIT && unsupported) { *unsupported = true; return 0; }
+    if ((rc == BDX_ELIMIT || too_many_members) && unsupported) { *unsupported = true; return 0; }
+    if (too_many_members) throw std::runtime_error("too many BGZF members in a piece: " + path);
     check(rc, "bdx_bamdec_finish");
     if (keep) { *keep = dec; guard.d = nullptr; }
     return (size_t)n;
