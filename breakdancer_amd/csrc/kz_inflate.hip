@@ -72,9 +72,11 @@ struct __attribute__((aligned(16))) Lds {
     uint16_t dist[1 << kDB];
     uint16_t lit_sorted[288];
     uint16_t dist_sorted[32];
-    uint16_t pre_sorted[20];
-    uint16_t lit_cnt[16], dist_cnt[16], pre_cnt[16];
+    uint16_t lit_cnt[16], dist_cnt[16];
     uint16_t first_code[16], first_index[16];   // of the alphabet being built
+    // literal/length alphabet, for codes the primary table does not hold: lit_limit[l] = end of the codes of length <= l among the 15-bit
+    // prefixes (first bit on top), lit_cf[l] = first index - first code of length l (mod 2^16): one compare per length, all lengths at once
+    uint16_t lit_limit[16], lit_cf[16], dist_limit[16], dist_cf[16];   // (the same for the distance alphabet)
     uint8_t lens[320];         // code lengths: literal/length alphabet, then distances
     // length symbol -> base length | extra bits << 12; distance symbol -> base distance | extra bits << 16 (RFC 1951 3.2.5).  Two
     // look-ups instead of two dozen vector instructions per step: the vector pipe is what this kernel runs out of
@@ -88,18 +90,8 @@ struct __attribute__((aligned(16))) Lds {
 __device__ __forceinline__ uint64_t mask_eq(uint32_t a, uint32_t b) { uint64_t r; asm("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ uint64_t mask_gt(uint32_t a, uint32_t b) { uint64_t r; asm("v_cmp_gt_u32_e64 %0, %1, %2" : "=s"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ uint64_t mask_le(uint32_t a, uint32_t b) { uint64_t r; asm("v_cmp_le_u32_e64 %0, %1, %2" : "=s"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ uint64_t mask_gt_s(uint32_t a, uint32_t sb) { uint64_t r; asm("v_cmp_gt_u32_e64 %0, %1, %2" : "=s"(r) : "v"(a), "s"(sb)); return r; }
 __device__ __forceinline__ bool lanes_of(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
-
-// inclusive prefix sum over the wave's 64 lanes: within rows of 16 by four shifted adds, then across the rows (DPP row_shr / row_bcast)
-__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);   // row_shr:1
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);   // row_shr:2
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);   // row_shr:4
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);   // row_shr:8
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
-    return x;
-}
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 // LDS accesses of a wave are executed in program order; this only keeps the compiler from moving them across
@@ -133,26 +125,6 @@ __device__ __forceinline__ void ring_load(uint32_t* ibuf, const uint8_t* in, uin
     if (at == 0) *(uint64_t*)((uint8_t*)ibuf + kIB) = v;   // the mirror of the ring's first 8 bytes
 }
 
-// canonical decode, one bit at a time (codes are packed starting with their most significant bit): returns the code's
-// length and its symbol, 0 if the bits are no code.  cnt[l] = codes of length l, sorted = symbols by (length, value).
-__device__ __forceinline__ uint32_t canon_decode(uint64_t w, const uint16_t* cnt, const uint16_t* sorted, uint32_t* sym) {
-    int code = 0, first = 0, index = 0;
-    for (int l = 1; l <= kMaxBits; ++l) {
-        code |= (int)(w & 1);
-        w >>= 1;
-        const int count = cnt[l];
-        if (code - count < first) {
-            *sym = sorted[index + (code - first)];
-            return (uint32_t)l;
-        }
-        index += count;
-        first += count;
-        first <<= 1;
-        code <<= 1;
-    }
-    return 0;
-}
-
 __device__ __forceinline__ uint32_t bitrev(uint32_t code, uint32_t len) { return __builtin_bitreverse32(code) >> (32 - len); }
 
 // lens[0, n) -> cnt[16], sorted[], and (tbits > 0) the primary table.  All 64 lanes.  An incomplete code is accepted only
@@ -177,6 +149,10 @@ __device__ bool build_tables(Lds& L, const uint8_t* lens, uint32_t n, uint16_t* 
         left -= (int)c;
         if (left < 0) over = true;
         if (l == lane) { my_index = first_index; L.first_code[l] = (uint16_t)first_code; L.first_index[l] = (uint16_t)first_index; }
+        if (kAlphabet != 2 && l == lane) {
+            (kAlphabet == 0 ? L.lit_limit : L.dist_limit)[l] = (uint16_t)((first_code + c) << (kMaxBits - l));
+            (kAlphabet == 0 ? L.lit_cf : L.dist_cf)[l] = (uint16_t)(first_index - first_code);
+        }
         first_code = (first_code + c) << 1;
         first_index += c;
         used += c;
@@ -324,7 +300,8 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
             }
             bitpos += 3u * hclen;
             __syncthreads();
-            if (!build_tables<2>(L, L.lens, 19, nullptr, 0, L.pre_cnt, L.pre_sorted)) { err = KZ_BAD_LENGTHS; break; }
+            // (the code-length code's 7-bit table, its counts and its sorted symbols live where the distance alphabet's will be built)
+            if (!build_tables<2>(L, L.lens, 19, L.dist, 7, L.dist_cnt, L.dist_sorted)) { err = KZ_BAD_LENGTHS; break; }
             // the two alphabets' code lengths, run-length coded (every lane runs the same sequence)
             const uint32_t total = hlit + hdist;
             uint32_t n = 0, prev = 0;
@@ -332,10 +309,9 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
                 if (bitpos > bit_limit) { err = KZ_INPUT_OVERRUN; break; }
                 KZ_ENSURE(bitpos >> 3);
                 const uint64_t ww = ring_peek(L.ibuf, bitpos);
-                uint32_t sym = 0;
-                const uint32_t l = uni(canon_decode(ww, L.pre_cnt, L.pre_sorted, &sym));
+                const uint32_t pe = uni(L.dist[(uint32_t)ww & 127u]);   // (codes of at most 7 bits: one look-up)
+                const uint32_t l = t_len(pe), sym = t_value(pe);
                 if (l == 0) { err = KZ_BAD_LENGTHS; break; }
-                sym = uni(sym);
                 uint32_t used = l, rep = 1, val = sym;
                 if (sym == 16) {
                     if (n == 0) { err = KZ_BAD_LENGTHS; break; }
@@ -408,24 +384,24 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
             // the chain met a token the tables do not resolve (the step then stops in front of it).  v_readlane and s_bitset1 take the
             // cursor from the word's low six bits as it is.
             const uint32_t walk = lanes_of(m_lit | m_match) ? ((is_lit ? l1 : l1 + lx + dl + dx) | (olen << 8)) : kWalkStop;
-            uint32_t co = 0, wtok, wtest;
+            uint32_t co = 0, wtok, wtest, offs = 0;
             uint64_t mask = 0;
             asm volatile(
                 "1:\n\t"
                 "v_readlane_b32 %[w], %[walk], %[co]\n\t"
+                "v_writelane_b32 %[offs], %[co], %[co]\n\t"
                 "s_bitset1_b64 %[mask], %[co]\n\t"
                 "s_add_u32 %[co], %[co], %[w]\n\t"
                 "s_and_b32 %[t], %[co], %[exit]\n\t"
                 "s_cbranch_scc0 1b"
-                : [w] "=&s"(wtok), [t] "=&s"(wtest), [mask] "+s"(mask), [co] "+s"(co)
+                : [w] "=&s"(wtok), [t] "=&s"(wtest), [mask] "+s"(mask), [co] "+s"(co), [offs] "+v"(offs)
                 : [walk] "v"(walk), [exit] "s"(kWalkExit)
                 : "scc");
             const bool stopped = (co & kWalkStop) != 0;
             mask ^= (uint64_t)((co >> 30) & 1u) << (co & 63u);   // (the unresolved token was marked before its register was seen; its bits and bytes are 0)
             const uint32_t o = (co >> 8) & 0x1FFu, cur = co & 0xFFu;
             // where each taken token's output begins, relative to outpos: an exclusive prefix sum of the output lengths over the chain
-            const uint32_t contrib = lanes_of(mask) ? olen : 0u;
-            const int offv = (int)(wave_inclusive_sum(contrib) - contrib);
+            const int offv = (int)((offs >> 8) & 0x1FFu);   // (the walk left its word -- cursor and output count before the token -- in the token's lane)
             const uint32_t pos = cur;
             if (mask) {
                 if (o > ulen - outpos) { err = KZ_OUTPUT_OVERRUN; break; }
@@ -449,9 +425,9 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
                     if (fmask) {
                         if (farm) {
                             uint64_t v;
-                            const uint8_t* srcp = out + dstf - mdist;
+                            const uint32_t srco = dstf - mdist;   // (offset in the member's output, below 64 Ki: the member's base stays in scalar registers)
                             // (behind the write-backs issued so far; past this CU's L1, which may hold the line from before them)
-                            asm volatile("s_waitcnt vmcnt(0)\n\tglobal_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(srcp) : "memory");
+                            asm volatile("s_waitcnt vmcnt(0)\n\tglobal_load_dwordx2 %0, %1, %2 sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(srco), "s"(out) : "memory");
                             uint8_t* q = L.obuf + (dstf & kOBM);
                             if (mlen == 8) {
                                 __builtin_memcpy(q, &v, 8);
@@ -500,10 +476,12 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
             uint32_t kind = t_kind(se), used = t_len(se), lsym = t_value(se);
             if (kind == T_SLOW) {  // a code longer than the table's index (or none at all)
                 ++n_slow;
-                uint32_t sym = 0;
-                const uint32_t l = uni(canon_decode(ws, L.lit_cnt, L.lit_sorted, &sym));
-                if (l == 0) { err = KZ_BAD_CODE; break; }
-                sym = uni(sym);
+                // canonical decoding, every length at once: lane l holds where the codes of length <= l end among the 15-bit prefixes
+                const uint32_t code15 = __builtin_bitreverse32((uint32_t)ws) >> 17;   // the next 15 bits, the first on top
+                const uint64_t shorter = mask_gt_s(L.lit_limit[lane & 15u], code15) & 0xFFFEull;
+                if (!shorter) { err = KZ_BAD_CODE; break; }
+                const uint32_t l = (uint32_t)__builtin_ctzll(shorter);
+                const uint32_t sym = uni(L.lit_sorted[((code15 >> (kMaxBits - l)) + L.lit_cf[l]) & 0xFFFFu]);
                 used = l;
                 if (sym < 256) {
                     if (outpos >= ulen) { err = KZ_OUTPUT_OVERRUN; break; }
@@ -531,10 +509,11 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
             used += sx;
             uint32_t dsym = t_value(sde), sdl = t_len(sde);
             if (t_kind(sde) != T_SYM) {
-                uint32_t sym = 0;
-                sdl = uni(canon_decode(ws, L.dist_cnt, L.dist_sorted, &sym));
-                if (sdl == 0) { err = KZ_BAD_CODE; break; }
-                dsym = uni(sym);
+                const uint32_t dcode15 = __builtin_bitreverse32((uint32_t)ws) >> 17;
+                const uint64_t dshorter = mask_gt_s(L.dist_limit[lane & 15u], dcode15) & 0xFFFEull;
+                if (!dshorter) { err = KZ_BAD_CODE; break; }
+                sdl = (uint32_t)__builtin_ctzll(dshorter);
+                dsym = uni(L.dist_sorted[(((dcode15 >> (kMaxBits - sdl)) + L.dist_cf[sdl]) & 0xFFFFu) & 31u]);
                 if (dsym > 29) { err = KZ_BAD_CODE; break; }
             }
             ws >>= sdl;
