@@ -8,22 +8,29 @@
 // predecessor's length is -- so a CPU decoder pays one table look-up latency per symbol.  Here the look-ups of a whole
 // 64-bit window run at once: lane j takes the bits at offset (cursor + j) and looks ITS candidate symbol up in the LDS table
 // (one ds_read for 64 candidates) -- a literal, or a whole length / distance pair with its extra bits; the chain of real
-// tokens is then followed through the lanes' results with v_readlane (scalar, no memory access), the literal lanes on the
-// chain store their bytes at their places, the matches on it are copied in stream order by all lanes (lane i copies byte i,
-// i mod distance for overlapping copies), and the wave moves on by up to 64 + 35 bits.  Codes longer than the primary
-// table's index (rare symbols by construction) are decoded canonically, bit by bit, from the count / sorted-symbol arrays:
-// no second-level tables.
+// tokens is then followed through the lanes' results (the walk: one v_readlane, one v_writelane and four scalar instructions per
+// token), the literal lanes on the chain store their bytes at their places, the matches on it are copied in stream order by all
+// lanes (lane i copies byte i, i mod distance for overlapping copies; sources beyond the window are fetched from HBM by their
+// own lanes, all of a step's at once), and the wave moves on by up to 64 + 35 bits.  Codes longer than the primary table's index
+// (rare symbols by construction) are decoded canonically for every length at once -- lane l holds where the codes of length <= l
+// end among the 15-bit prefixes: one compare and one ballot -- no second-level tables.
 //
 // Everything a step touches is in LDS: the compressed input is staged through a 1 KiB ring (512 bytes per refill, one
 // coalesced load), the last 1 KiB of output live in a window that literals and near matches never leave (flushed 256 bytes at
 // a time, one 4-byte store per lane; matches further back read HBM, where their source has been for at least one flush),
-// tables are 16 bits per entry; 4.9 KB per wave (32 waves per CU with 64 vector registers: round 4; 2 KiB window and 27 waves before: 35.5 -> 38.5 GB/s).  What bounds the kernel is the scalar issue slot (SQ counters,
-// tools/pmc_inflate.sh: with one token per step it issued 116 scalar + 34 branch instructions per step against 62 vector ones,
-// the SIMDs' scalar slots 70-90 % taken, whatever the occupancy and wherever input and output lived -- 23 GB/s three times
-// over): hence everything per token that can be per lane is, and a step takes as many tokens as 64 bits hold.
+// tables are 16 bits per entry; 5.0 KB per wave: 32 waves per CU with 64 vector registers.
 //
-// Tables are built per deflate block by the wave itself: lengths read with the same canonical decoder (the code-length
-// code has 19 symbols of <= 7 bits), canonical codes from a per-length scan, table filled symbol by symbol across the lanes.
+// What bounds the kernel is the number of INSTRUCTIONS a step issues, of whatever kind: a wave's step is one long dependent
+// stream, eight of them share a SIMD, and builds that traded vector instructions for more scalar ones and branches ran slower
+// (tools/kz_ab.sh; profiles/r04_inflate_ab.txt, r04_inflate_ab2.txt): round 4 took the walk from ~18 instructions per token to
+// 6, the lane predicates from ballots to scalar masks, the long codes from a bit-by-bit loop to one compare -- 4,880 -> 3,420
+// cycles per step, 38 -> 55 GB/s of inflated bytes in launches of <= 1.5 GB (43 -> 62 in one launch).  Half the waves
+// take 2,900 cycles per step: the rest is the latency of the step's chain (five dependent LDS look-ups, the walk, a round trip to
+// memory for the far matches in two steps out of three); leaving the far matches' bytes pending across steps was built and
+// measured -- its bookkeeping cost more than the wait it hid.
+//
+// Tables are built per deflate block by the wave itself: the code lengths read through a 7-bit table of the code-length code
+// (19 symbols of <= 7 bits), canonical codes from a per-length scan, table filled symbol by symbol across the lanes.
 #include <hip/hip_runtime.h>
 
 #include "bdx_bam_dev.h"
@@ -377,11 +384,12 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
             // The chain of tokens that starts at the cursor, followed through the lanes' results.  What bounds this kernel is the number of
             // INSTRUCTIONS a step issues, of whatever kind (each of a CU's four SIMDs takes one instruction per wave every fourth cycle and
             // shares its fetch with 31 other waves that are somewhere else in this loop; builds that traded vector instructions for more
-            // scalar ones ran slower: tools/kz_ab.sh, profiles/r04_inflate_ab.txt), so the walk is five instructions per token: one register
+            // scalar ones ran slower: tools/kz_ab.sh, profiles/r04_inflate_ab.txt), so the walk is six instructions per token: one register
             // per lane holds the token's bits in its low byte and its output length above it (a token the tables do not resolve: bit 30
             // alone), and ONE scalar word carries cursor and output count the same way -- the token's register is added to it, and one
             // AND tells whether the walk goes on: not once the cursor has left the 64-bit window, kStepCap bytes have been produced or
-            // the chain met a token the tables do not resolve (the step then stops in front of it).  v_readlane and s_bitset1 take the
+            // the chain met a token the tables do not resolve (the step then stops in front of it).  The word as it stands before a token
+            // is left in the token's lane (v_writelane): where its output begins.  v_readlane, v_writelane and s_bitset1 take the
             // cursor from the word's low six bits as it is.
             const uint32_t walk = lanes_of(m_lit | m_match) ? ((is_lit ? l1 : l1 + lx + dl + dx) | (olen << 8)) : kWalkStop;
             uint32_t co = 0, wtok, wtest, offs = 0;
