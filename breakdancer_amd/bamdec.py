@@ -180,8 +180,26 @@ class BamDecoder:
         t["inflated_len"] = members["inflated_len"]
         self._check(self.lib.bdx_bamdec_submit(self.h, nbytes, len(members), 1 if last else 0), "bdx_bamdec_submit")
 
-    def feed(self, data, members, piece_blocks=512):
-        """all of `members` (non-empty ones) in pieces of piece_blocks members"""
+    def acquire_fill(self, data, members):
+        """first half of submit(): a staging buffer acquired and filled, NOT submitted yet (several may be held; submit_held takes them in order)"""
+        lo = int(members["member"][0])
+        hi = int(members["payload"][-1]) + int(members["payload_len"][-1]) + 8
+        nbytes = hi - lo
+        buf, tab = C.c_void_p(), C.c_void_p()
+        self._check(self.lib.bdx_bamdec_acquire(self.h, nbytes, len(members), C.byref(buf), C.byref(tab)), "bdx_bamdec_acquire")
+        C.memmove(buf.value, np.frombuffer(data, dtype=np.uint8, count=nbytes, offset=lo).ctypes.data, nbytes)
+        t = np.ctypeslib.as_array(C.cast(tab.value, C.POINTER(C.c_uint8)), shape=(len(members) * BLOCK_DTYPE.itemsize,)).view(BLOCK_DTYPE)
+        t["offset"] = members["payload"] - np.uint64(lo)
+        t["payload_len"] = members["payload_len"]
+        t["inflated_len"] = members["inflated_len"]
+        return nbytes, len(members)
+
+    def submit_held(self, held, last):
+        self._check(self.lib.bdx_bamdec_submit(self.h, held[0], held[1], 1 if last else 0), "bdx_bamdec_submit")
+
+    def feed(self, data, members, piece_blocks=512, ahead=1):
+        """all of `members` (non-empty ones) in pieces of piece_blocks members; ahead > 1: that many pieces are acquired and filled before
+        the oldest is submitted (what a caller that reads the file ahead does: bdx_bamdec_acquire several times, bdx_bamdec_submit in order)"""
         m = members[members["inflated_len"] > 0]
         if len(m) == 0:
             return
@@ -192,8 +210,20 @@ class BamDecoder:
             if not contiguous or i - cuts[-1] >= piece_blocks:
                 cuts.append(i)
         cuts.append(len(m))
-        for a, b in zip(cuts[:-1], cuts[1:]):
-            self.submit(data, m[a:b], last=(b == len(m)))
+        if ahead <= 1:
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                self.submit(data, m[a:b], last=(b == len(m)))
+            return
+        held = []
+        pieces = list(zip(cuts[:-1], cuts[1:]))
+        nxt = 0
+        while nxt < len(pieces) or held:
+            while nxt < len(pieces) and len(held) < ahead:
+                a, b = pieces[nxt]
+                held.append((self.acquire_fill(data, m[a:b]), b == len(m)))
+                nxt += 1
+            h, last = held.pop(0)
+            self.submit_held(h, last)
 
     def finish(self):
         n = C.c_uint64(0)
@@ -249,7 +279,7 @@ def merge_decoded(sink, decoders, src_file, src_index):
 
 
 def decode_file(path, rg_ids=(), rg_lib=(), fallback_lib=0, bam_index=0, region=None, piece_blocks=512, ring_bytes=0, sink=None, device=0,
-                batch_blocks=0):
+                batch_blocks=0, ahead=1):
     """whole file -> (columns or None with a sink, target names, decoder statistics)"""
     data = np.fromfile(path, dtype=np.uint8)
     members = scan_bgzf(data)
@@ -257,7 +287,7 @@ def decode_file(path, rg_ids=(), rg_lib=(), fallback_lib=0, bam_index=0, region=
     d = BamDecoder(len(names), sink=sink, device=device, bam_index=bam_index, rg_ids=rg_ids, rg_lib=rg_lib, fallback_lib=fallback_lib,
                    region=region, first_record_offset=off, ring_bytes=ring_bytes, batch_blocks=batch_blocks)
     try:
-        d.feed(data, members[k:], piece_blocks)
+        d.feed(data, members[k:], piece_blocks, ahead=ahead)
         d.finish()
         cols = d.fetch() if sink is None else None
         return cols, names, d.stats()

@@ -180,6 +180,38 @@ def test_reference_bams_columns(piece_blocks, ring, batch):
         check_columns(cols, recs, rg_to_lib, 1, region=(t21, 14_500_000, 14_600_000))
 
 
+@pytest.mark.parametrize("ahead,piece_blocks", [(2, 1), (4, 1), (4, 2), (3, 512)])
+def test_pieces_acquired_ahead_of_the_one_submitted(ahead, piece_blocks):
+    """bdx_bamdec_acquire several times before bdx_bamdec_submit (a caller that reads the file ahead, as the CLI's feeder does): the pieces are
+    taken in the order they were acquired, a fifth acquisition without a submit is refused, what was acquired and never submitted is dropped
+    by bdx_bamdec_finish"""
+    import ctypes as C
+    from breakdancer_amd import bamdec
+    rows, libs = config_read_groups(os.path.join(CHR21, "inv_del_bam_config"))
+    rg_ids = [r[0] for r in rows]
+    rg_lib = [libs.index(r[1]) for r in rows]
+    path = os.path.join(CHR21, BAMS[0])
+    targets, recs = read_bam(path)
+    cols, names, stats = bamdec.decode_file(path, rg_ids=rg_ids, rg_lib=rg_lib, fallback_lib=1, piece_blocks=piece_blocks, ahead=ahead, batch_blocks=3)
+    assert names == targets
+    check_columns(cols, recs, dict(zip(rg_ids, rg_lib)), 1)
+    if ahead == 4 and piece_blocks == 1:   # the ring holds four: the fifth is refused, and finish drops the held ones
+        data = np.fromfile(path, dtype=np.uint8)
+        members = bamdec.scan_bgzf(data)
+        _, _, k, off = bamdec.bam_header(data, members)
+        m = members[k:][members[k:]["inflated_len"] > 0]
+        d = bamdec.BamDecoder(len(names), rg_ids=rg_ids, rg_lib=rg_lib, fallback_lib=1, first_record_offset=off)
+        try:
+            held = [d.acquire_fill(data, m[i:i + 1]) for i in range(4)]
+            buf, tab = C.c_void_p(), C.c_void_p()
+            assert d.lib.bdx_bamdec_acquire(d.h, 100, 1, C.byref(buf), C.byref(tab)) != 0
+            d.submit_held(held[0], False)
+            d.submit_held(held[1], False)
+            assert d.finish() > 0        # two pieces decoded as far as their bytes go, two dropped
+        finally:
+            d.close()
+
+
 def synthetic_records(n, rng, tids=3):
     recs = []
     pos = 0

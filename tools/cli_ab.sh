@@ -18,7 +18,7 @@ for spec in "$@"; do
     [ "$spec" != "$lib" ] && envs=$(echo "${spec#*:}" | tr ',' ' ')
     cp $lib breakdancer_amd/libbdx.so
     echo "== $spec"
-    for i in 1 2 3; do
+    for i in $(seq 1 ${RUNS:-3}); do
         sleep 0.5
         ( cd /tmp/cli_ab && s=$(date +%s%N) && env BDX_TIMING=1 BDX_FOREGROUND=1 $envs $R/bin/breakdancer-max cfg > out.txt 2> err.txt; e=$(date +%s%N); echo "wall $(( (e - s) / 1000000 )) ms, $(grep -vc '^#' out.txt) rows"; grep "device decode\|inside the decoder\|total=" err.txt | cut -c1-260 )
     done
