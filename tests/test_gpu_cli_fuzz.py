@@ -255,3 +255,37 @@ def test_cli_sharded_run_decodes_every_ranks_chromosomes_on_its_own_gpu(seed, tm
         assert p.returncode == 0, p.stderr.decode()
         outs[label] = {f: open(os.path.join(str(d), f), "rb").read() for f in sorted(os.listdir(str(d)))}
     assert outs["sharded"] == outs["one"] and outs["one"]
+
+
+def test_cli_file_of_tens_of_thousands_of_tiny_members(tmp_path):
+    """a BAM re-blocked into BGZF members of 160 inflated bytes (33 k members in 6 MB: more members than a piece's table holds,
+    512 bytes per member on average being the device path's assumption): the device path says so and the host reader takes the
+    file -- the same table as from the ordinary blocking, no error"""
+    import gzip
+    import struct
+    from breakdancer_amd.bamwrite import _bgzf_block, _EOF, write_bam_records
+    cfg, streams, targets = make_case(905, n_pairs=17000)
+    cfg1 = "".join(l + "\n" for l in cfg.splitlines() if "map:a.bam" in l)
+    st = streams[0]
+    recs = [dict(tid=st["tid"][i], pos=st["pos"][i], mtid=st["mtid"][i], mpos=st["mpos"][i], isize=st["isize"][i], flag=st["flag"][i],
+                 qlen=st["qlen"][i], mapq=int(st["bdqual"][i]), rg=st["rg"][i], name="read%d" % int(st["name_id"][i])) for i in range(len(st["tid"]))]
+    write_bam_records(str(tmp_path / "big.bam"), recs, targets, rgs=("rg1", "rg2", "rg3"), seed=5)
+    raw = gzip.decompress((tmp_path / "big.bam").read_bytes())
+    with open(str(tmp_path / "a.bam"), "wb") as f:
+        n_members = 0
+        for i in range(0, len(raw), 160):
+            f.write(_bgzf_block(raw[i:i + 160], 1))
+            n_members += 1
+        f.write(_EOF)
+    assert n_members > 8 * 1024 * 1024 // 512 + 4096 and os.path.getsize(str(tmp_path / "a.bam")) < 8 * 1024 * 1024
+    (tmp_path / "cfg").write_text(cfg1)
+    (tmp_path / "cfg_big").write_text(cfg1.replace("map:a.bam", "map:big.bam"))
+    texts = {}
+    for label, cfgname, env in (("tiny", "cfg", dict(BDX_TIMING="1")), ("tiny-host", "cfg", dict(BDX_TIMING="1", BDX_DECODE="host")), ("ordinary", "cfg_big", dict(BDX_TIMING="1"))):
+        p = subprocess.run([EXE, "-y", "-1", cfgname], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert p.returncode == 0, (label, p.stderr.decode())
+        texts[label] = (filter_cmd_lines(p.stdout.decode()), p.stderr.decode())
+    assert "host decode threads" in texts["tiny"][1] and "on the GPU" in texts["ordinary"][1]
+    strip = lambda t: t.replace("big.bam", "a.bam")
+    assert texts["tiny"][0] == texts["tiny-host"][0] == strip(texts["ordinary"][0])
+    assert [l for l in texts["tiny"][0].splitlines() if not l.startswith("#")]
