@@ -58,6 +58,10 @@ def main():
             pf = os.environ.get("BDX_KZ_PROF")
             if pf and os.path.exists(pf):
                 q = np.fromfile(pf, dtype=np.uint64).reshape(-1, 6).astype(np.float64)
+                c0 = q[:, 0]
+                print("kernel clocks per member: min %.0f, 10 %% %.0f, median %.0f, 90 %% %.0f, 99 %% %.0f, max %.0f cycles; steps min %.0f max %.0f; by launch order (eighths of the members, mean cycles): %s" %
+                      (c0.min(), np.percentile(c0, 10), np.median(c0), np.percentile(c0, 90), np.percentile(c0, 99), c0.max(), q[:, 2].min(), q[:, 2].max(),
+                       " ".join("%.1fM" % (x.mean() / 1e6) for x in np.array_split(c0, 8))))
                 print("kernel clocks per member (mean): cycles %.0f, of which headers+tables %.0f; steps %.0f, matches %.0f, slow codes %.0f, deflate blocks %.1f; "
                       "cycles per step %.0f" % (q[:, 0].mean(), q[:, 1].mean(), q[:, 2].mean(), q[:, 3].mean(), q[:, 4].mean(), q[:, 5].mean(),
                                                  (q[:, 0] - q[:, 1]).sum() / q[:, 2].sum()))
