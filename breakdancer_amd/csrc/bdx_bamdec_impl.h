@@ -31,11 +31,13 @@ namespace {
 constexpr size_t kBamMargin = (size_t)kMaxDeviceRecord + 65536;   // bytes mirrored behind the piece in front of a wrap
 constexpr int kBamSlots = 4;                                       // batches in flight (device-side compressed bytes, tables, status)
 #ifndef BDX_BAM_STAGING
-#define BDX_BAM_STAGING 4
+#define BDX_BAM_STAGING 6
 #endif
 constexpr int kBamStaging = BDX_BAM_STAGING;                                     // pinned staging buffers (a caller may hold several: it reads pieces ahead of the one it submits)
 constexpr size_t kBatchBytesDefault = (size_t)384 << 20;           // compressed bytes per batch
-constexpr size_t kBatchBlocksDefault = 8448;                       // members per batch: a little more than the wave slots the GPU has for this kernel (256 CUs x 32)
+constexpr size_t kBatchBlocksDefault = 7680;                       // members per batch: with the piece that takes it over this, still within the wave slots the GPU has for this kernel
+                                                                   // (256 CUs x 32 = 8,192).  The kernel's waves give way as they get ahead (s_setprio), so a launch's members end together:
+                                                                   // members beyond the slots would start when all the others end -- 13.6 ms per launch at 8,448 against 9.0 at 7,680 -- 7,936 left no room for the record stages that run beside it: some launches at 13 ms again
 
 struct BamPiece {
     uint64_t seq = 0;            // 1-based

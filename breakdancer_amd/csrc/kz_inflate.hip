@@ -225,6 +225,12 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
     uint32_t flushed = 0;      // output bytes already in HBM; [flushed, outpos) sit in the LDS window only
     uint32_t loaded_end = 0;   // the input ring holds the bytes [loaded_end - 1024, loaded_end) (those it has loaded)
     bool last = false;
+    // A SIMD serves its oldest wave first: left alone, the eight members of a SIMD finish one after the other and the SIMD runs emptier
+    // and emptier (a step is latency-bound: fewer waves, less throughput) -- a launch of one round of the wave slots lasted 24 M cycles
+    // for members that take 18.8 M when the slots stay full (profiles/r04_inflate_member_clocks.txt).  So a wave gives way as it gets
+    // ahead: priority 3 for its first 16 KiB of output, 2, 1, 0 for the next ones (s_setprio ranks above age).
+    uint32_t prio = 3;
+    asm volatile("s_setprio 3");
     if (lane < 32) {
         const uint32_t lx0 = length_extra(lane);
         L.lbx[lane] = (uint16_t)((lane < 8 ? 3 + lane : (lane == 28 ? 258u : 3 + ((4 + (lane & 3)) << lx0))) | (lx0 << 12));
@@ -244,6 +250,15 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
 #define KZ_FLUSH()                                                                      \
     do {                                                                                \
         lds_order();                                                                    \
+        if (outpos - flushed >= kFlush) {                                               \
+            const uint32_t want_ = 3u - (outpos >> 14 > 3u ? 3u : outpos >> 14);        \
+            if (want_ != prio) {                                                        \
+                prio = want_;                                                           \
+                if (want_ == 2) asm volatile("s_setprio 2");                            \
+                else if (want_ == 1) asm volatile("s_setprio 1");                       \
+                else asm volatile("s_setprio 0");                                       \
+            }                                                                           \
+        }                                                                               \
         while (outpos - flushed >= kFlush) {                                            \
             const uint32_t at_ = flushed + 4u * lane;                                   \
             uint32_t v_;                                                                \

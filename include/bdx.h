@@ -396,8 +396,8 @@ int bdx_dist_plan(const uint64_t* weight, int ntids, int world, int* rank_of_tid
  *                        several files themselves).  first_record_offset: offset of the first record in the inflated stream,
  *                        counted from the first member that will be submitted (the caller has parsed the BAM header).
  *   bdx_bamdec_acquire   a pinned staging buffer for `bytes` of file and a table of max_blocks members, both owned by the decoder
- *                        (a ring of four; blocks only while the next one's copy is in flight).  A caller may acquire several before it
- *                        submits -- reading the file ahead of the piece it is cutting into members -- up to all four; bdx_bamdec_submit
+ *                        (a ring of six; blocks only while the next one's copy is in flight).  A caller may acquire several before it
+ *                        submits -- reading the file ahead of the piece it is cutting into members -- up to all six; bdx_bamdec_submit
  *                        takes them in the order they were acquired, bdx_bamdec_finish drops what was acquired and never submitted
  *   bdx_bamdec_submit    the first `bytes` of the buffer are whole members, described by the first nblocks table entries
  *                        (offset = start of the member's deflate payload in the buffer); last != 0 with the file's final piece.

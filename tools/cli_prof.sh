@@ -44,5 +44,8 @@ for s, e, n, q, kind in rows:
     busy_end = max(busy_end, e)
 cp = [(s - t0) / 1e6 for s, e, n, q, kind in rows if n.startswith("MEMORY_COPY_HOST_TO_DEVICE") and e - s > 100000]
 print("H2D piece copies start at (ms): " + " ".join("%.1f" % x for x in cp))
+cd = sorted((e - s) / 1e6 for s, e, n, q, kind in rows if n.startswith("MEMORY_COPY_HOST_TO_DEVICE") and e - s > 100000)
+if cd:
+    print("H2D piece copies: %d, duration min %.3f / median %.3f / max %.3f ms, %.1f ms in all" % (len(cd), cd[0], cd[len(cd) // 2], cd[-1], sum(cd)))
 print("span %.3f ms, GPU idle inside it %.3f ms, launches %d" % ((busy_end - t0) / 1e6, idle / 1e6, len(rows)))
 PY
