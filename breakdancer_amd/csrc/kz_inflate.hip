@@ -24,7 +24,7 @@
 // stream, eight of them share a SIMD, and builds that traded vector instructions for more scalar ones and branches ran slower
 // (tools/kz_ab.sh; profiles/r04_inflate_ab.txt, r04_inflate_ab2.txt): round 4 took the walk from ~18 instructions per token to
 // 6, the lane predicates from ballots to scalar masks, the long codes from a bit-by-bit loop to one compare -- 4,880 -> 3,420
-// cycles per step, 38 -> 55 GB/s of inflated bytes in launches of <= 1.5 GB (43 -> 62 in one launch).  Half the waves
+// cycles per step, 38 -> 57 GB/s of inflated bytes in launches of <= 1.5 GB (43 -> 62 in one launch).  Half the waves
 // take 2,900 cycles per step: the rest is the latency of the step's chain (five dependent LDS look-ups, the walk, a round trip to
 // memory for the far matches in two steps out of three); leaving the far matches' bytes pending across steps was built and
 // measured -- its bookkeeping cost more than the wait it hid.
