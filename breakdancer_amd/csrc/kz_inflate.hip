@@ -17,7 +17,7 @@
 //
 // Everything a step touches is in LDS: the compressed input is staged through a 1 KiB ring (512 bytes per refill, one
 // coalesced load), the last 1 KiB of output live in a window that literals and near matches never leave (flushed 256 bytes at
-// a time, one 4-byte store per lane; matches further back read HBM, where their source has been for at least one flush),
+// a time, one 4-byte store per lane; a match further back reads HBM if its whole source has been written back, the window otherwise),
 // tables are 16 bits per entry; 5.0 KB per wave: 32 waves per CU with 64 vector registers.
 //
 // What bounds the kernel is the number of INSTRUCTIONS a step issues, of whatever kind: a wave's step is one long dependent
@@ -50,7 +50,16 @@ constexpr uint32_t kStepCap = 128;                  // a step's chain ends once 
 constexpr uint32_t kWalkStop = 1u << 30;            // walk word of a token the tables do not resolve
 constexpr uint32_t kWalkExit = 0xC0u | ((kStepCap | (kStepCap << 1)) << 8) | kWalkStop;   // cursor >= 64 | output >= kStepCap (< 4 kStepCap) | unresolved
 constexpr uint32_t kNearDist = kOB - (kStepCap + 258) - 64;   // matches up to this distance are copied inside the window: their
-                                                    // source cannot be overwritten by anything the step writes (positions are mod 2048)
+                                                    // source cannot be overwritten by anything the step writes (positions are mod kOB)
+// The window's invariants.  A step (and the token it stopped at) starts with less than kFlush bytes not yet written back -- KZ_FLUSH runs
+// behind every step, BEFORE the token the chain stopped at and before a deflate block ends -- and writes at most kStepMax bytes.
+constexpr uint32_t kStepMax = kStepCap - 1 + 258, kPending = kFlush - 1;
+static_assert(kPending + kStepMax < kOB, "a step's writes never wrap onto bytes that are not in HBM yet");
+static_assert(kNearDist + kStepMax < kOB, "a near match's source is not overwritten by anything its step writes");
+// A match further back than kNearDist reads HBM only if its whole source has been written back (source end <= flushed: decided per
+// match, not by the distance); one whose source reaches into [flushed, outpos) is served from the window, which still holds it:
+static_assert(kPending + 258 + kStepMax < kOB, "a source that ends above `flushed` starts inside the window");
+static_assert(kNearDist >= kPending + (kStepCap - 1) + 8, "the far matches of <= 8 bytes fetched by their own lanes lie below `flushed`");
 constexpr uint32_t kIB = 1024, kIBM = kIB - 1;      // input ring
 constexpr uint32_t kRefill = 512;
 
@@ -473,7 +482,7 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
                     if (k >> 31) {
                         const uint8_t v = L.obuf[(dst - dist + lane) & kOBM];
                         L.obuf[lane < length ? ((dst + lane) & kOBM) : kOB + lane] = v;   // (lanes beyond the match write to a dump area)
-                    } else if (dist <= kNearDist) {
+                    } else if (dist <= kNearDist || dst - dist + length > flushed) {   // inside the window (the second case: a source that is not in HBM yet)
                         if (dist >= length) {
                             for (uint32_t i = lane; i < length; i += 64) L.obuf[(dst + i) & kOBM] = L.obuf[(dst - dist + i) & kOBM];
                         } else {
@@ -490,7 +499,8 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
                 outpos += o;
             }
             bitpos += pos;
-            if (!stopped) { KZ_FLUSH(); continue; }
+            KZ_FLUSH();   // (before the token the chain stopped at too: that one, and the next deflate block's first step, count on < kFlush pending bytes)
+            if (!stopped) continue;
             // the symbol the chain stopped at, with the bits (and the distance entry) its lane holds
             uint64_t ws = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)w_hi, (int)pos) << 32) |
                           (uint32_t)__builtin_amdgcn_readlane((int)w_lo, (int)pos);
@@ -549,13 +559,13 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
             if (dist > outpos) { err = KZ_BAD_DISTANCE; break; }
             if (length > ulen - outpos) { err = KZ_OUTPUT_OVERRUN; break; }
             lds_order();
-            if (dist <= kNearDist) {   // inside the window (sources lie below outpos, destinations at or above it: no overlap)
+            if (dist <= kNearDist || outpos - dist + length > flushed) {   // inside the window (sources lie below outpos, destinations at or above it: no overlap)
                 if (dist >= length) {
                     for (uint32_t i = lane; i < length; i += 64) L.obuf[(outpos + i) & kOBM] = L.obuf[(outpos - dist + i) & kOBM];
                 } else {  // overlapping: the pattern of `dist` bytes repeats
                     for (uint32_t i = lane; i < length; i += 64) L.obuf[(outpos + i) & kOBM] = L.obuf[(outpos - dist + i % dist) & kOBM];
                 }
-            } else {   // far back: those bytes left the window, and were flushed at least one chunk ago
+            } else {   // far back: the whole source is in HBM
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const uint8_t* src = out + outpos - dist;
                 for (uint32_t i = lane; i < length; i += 64)

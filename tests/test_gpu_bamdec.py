@@ -71,6 +71,141 @@ def test_inflate_matches_zlib_on_synthetic_members(kz, monkeypatch):
     assert o == len(out)
 
 
+class TokenDeflate:
+    """a DEFLATE writer for chosen token sequences (RFC 1951): zlib picks its own matches, the window tests below need a match of a
+    given length at a given distance right behind given tokens.  One block: the fixed code (3.2.6), or a dynamic block (3.2.7)
+    with the code lengths the caller gives (complete codes; sent without run lengths)"""
+    LBASE = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258]
+    LEXTRA = [0] * 8 + [1] * 4 + [2] * 4 + [3] * 4 + [4] * 4 + [5] * 4 + [0]
+    DBASE = [1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577]
+    DEXTRA = [0, 0, 0, 0] + [i // 2 for i in range(2, 28)]
+
+    @staticmethod
+    def canonical(lens):   # symbol -> (code, length), RFC 1951 3.2.2
+        code, out = 0, {}
+        for l in range(1, 16):
+            for s, x in enumerate(lens):
+                if x == l:
+                    out[s] = (code, l)
+                    code += 1
+            code <<= 1
+        return out
+
+    def __init__(self, lit_lens=None, dist_lens=None):
+        self.acc, self.nbits, self.out, self.data = 0, 0, bytearray(), bytearray()
+        self.bits(1, 1)   # BFINAL
+        if lit_lens is None:
+            self.bits(1, 2)
+            lit_lens = [8] * 144 + [9] * 112 + [7] * 24 + [8] * 8
+            dist_lens = [5] * 30
+        else:
+            assert len(lit_lens) == 286 and len(dist_lens) == 30
+            assert sum(2.0 ** -l for l in lit_lens if l) == 1.0 and sum(2.0 ** -l for l in dist_lens if l) == 1.0
+            self.bits(2, 2)
+            self.bits(286 - 257, 5); self.bits(30 - 1, 5); self.bits(19 - 4, 4)
+            for sym in (16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15):   # the code-length code: 0..15 in four bits each
+                self.bits(0 if sym >= 16 else 4, 3)
+            for l in list(lit_lens) + list(dist_lens):
+                self.code(l, 4)
+        self.lit, self.dist = self.canonical(lit_lens), self.canonical(dist_lens)
+
+    def bits(self, v, n):   # n bits of v, least significant first
+        self.acc |= (v & ((1 << n) - 1)) << self.nbits
+        self.nbits += n
+        while self.nbits >= 8:
+            self.out.append(self.acc & 255)
+            self.acc >>= 8
+            self.nbits -= 8
+
+    def code(self, c, n):   # a Huffman code: most significant bit first
+        self.bits(int(format(c, "0%db" % n)[::-1], 2), n)
+
+    def literal(self, b):
+        self.code(*self.lit[b])
+        self.data.append(b)
+
+    def match(self, length, dist):
+        assert 3 <= length <= 258 and 1 <= dist <= len(self.data) and dist <= 32768
+        ls = max(i for i in range(29) if self.LBASE[i] <= length) if length < 258 else 28
+        self.code(*self.lit[257 + ls])
+        self.bits(length - self.LBASE[ls], self.LEXTRA[ls])
+        ds = max(i for i in range(30) if self.DBASE[i] <= dist)
+        self.code(*self.dist[ds])
+        self.bits(dist - self.DBASE[ds], self.DEXTRA[ds])
+        for _ in range(length):
+            self.data.append(self.data[-dist])
+
+    def finish(self):
+        self.code(*self.lit[256])
+        if self.nbits: self.bits(0, 8 - self.nbits)
+        data, comp = bytes(self.data), bytes(self.out)
+        assert zlib.decompress(comp, -15) == data
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(comp) + 25) + comp +
+                struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data))), data
+
+
+# a dynamic code whose longest matches have codes beyond any primary table (length 258: 10 bits; lengths 3..10: 4..10 bits), a match
+# of 99..114 bytes in two bits, literals in nine
+LONG_258 = [9] * 256 + [3] + [4, 5, 6, 7, 8, 9, 10] + [0] * 15 + [2] + [0] * 5 + [10]
+DIST_LENS = [4, 4] + [5] * 28
+
+
+def window_members(rng):
+    """members whose matches reach back about as far as the kernels' LDS windows do (with a 1 KiB window the source of a
+    long match at a distance of 575..640 that follows ~100 bytes of output in its step is neither wholly inside the window nor wholly
+    written back): a long match at every distance around the windows' edges right behind a match of 60..127 bytes (so that it starts
+    well into its step) -- in the fixed code, where every token is resolved by the tables, and in a dynamic code that gives the long
+    match a 10-bit code, the kernel's path for tokens its tables do not hold --, behind runs of literals, alone and in pairs; near-duplicate
+    records of 560..1100 bytes (what a BAM's neighbouring records look like) through zlib at levels 6 and 9"""
+    out = []
+    for dynamic in (False, True):
+        for lo, hi in ((540, 760), (760, 1100), (1400, 2300)):
+            for rep in range(10):
+                f = TokenDeflate(LONG_258, DIST_LENS) if dynamic else TokenDeflate()
+                for b in rng.integers(0, 256, 2600, dtype=np.uint8): f.literal(int(b))
+                dist = lo + int(rng.integers(0, hi - lo))
+                while len(f.data) < 58000 and len(f.out) < 60000:
+                    k = int(rng.integers(0, 6))
+                    for b in rng.integers(0, 256, int(rng.integers(0, 6)) if k else int(rng.integers(0, 141)), dtype=np.uint8): f.literal(int(b))
+                    if k >= 2:   # ~100 bytes of output in front of the long match, in the same step
+                        f.match(int(rng.integers(99, 115)) if dynamic else int(rng.integers(60, 128)), int(rng.integers(1, 500)))
+                        for b in rng.integers(0, 256, int(rng.integers(0, 3)), dtype=np.uint8): f.literal(int(b))
+                    f.match(258 if dynamic else int(rng.choice([258, 258, 258, 200, 131, 67])), dist)
+                    if k == 5: f.match(258, dist)
+                    dist = lo + (dist - lo + 1) % (hi - lo)
+                out.append(f.finish() + ("tokens/%s/%d-%d/%d" % ("dynamic" if dynamic else "fixed", lo, hi, rep),))
+    for rec_len in list(range(560, 1100, 45)) + [1500, 1800, 2100]:
+        base = rng.integers(0, 256, rec_len, dtype=np.uint8)
+        recs = []
+        while sum(len(r) for r in recs) < 64000:
+            base = base.copy()
+            base[rng.integers(0, rec_len, int(rng.integers(1, 4)))] = rng.integers(0, 256, 1, dtype=np.uint8)
+            recs.append(base.tobytes())
+        data = b"".join(recs)[:65000]
+        for level in (6, 9):
+            out.append((member(data, level), data, "records/%d/l%d" % (rec_len, level)))
+    return out
+
+
+@KZ
+def test_inflate_matches_that_reach_the_edge_of_the_window(kz, monkeypatch):
+    from breakdancer_amd import bamdec
+    monkeypatch.setenv("BDX_KZ", kz)
+    cases = window_members(np.random.default_rng(11))
+    image = b"".join(c[0] for c in cases)
+    members = bamdec.scan_bgzf(image)
+    assert len(members) == len(cases)
+    out, status, ms = bamdec.inflate_blocks(image, members)
+    bad = [cases[i][2] for i in range(len(cases)) if status[i] != 0]
+    assert not bad, "rejected: %s" % bad[:10]
+    o = 0
+    for i, (_, w, label) in enumerate(cases):
+        got = out[o:o + len(w)].tobytes()
+        assert got == w, "member %d (%s) differs at byte %d" % (i, label, next(k for k in range(len(w)) if got[k] != w[k]))
+        o += len(w)
+    assert o == len(out)
+
+
 @KZ
 def test_inflate_matches_zlib_on_the_reference_bams(kz, monkeypatch):
     from breakdancer_amd import bamdec
