@@ -8,7 +8,7 @@ KERNELS := $(CSRC)/k1_classify.hip $(CSRC)/k2_compact.hip $(CSRC)/k3_regions.hip
 OBJS := $(KERNELS:.hip=.o) $(CSRC)/bdx_walk.o $(CSRC)/bdx_walk_reads.o
 HOSTCOMMON := $(HOST)/options.cpp $(HOST)/config.cpp $(HOST)/bam_reader.cpp $(HOST)/fast_inflate.cpp $(HOST)/column_reader.cpp $(HOST)/producer.cpp $(HOST)/dumps.cpp $(HOST)/cache.cpp
 
-all: breakdancer_amd/libbdx.so bin/breakdancer-max bin/bdx-dump-reads bin/bam2cfg bin/bdx-inflate-check oracle
+all: breakdancer_amd/libbdx.so bin/breakdancer-max bin/bdx-dump-reads bin/bam2cfg bin/bdx-inflate-check bin/bdx-feed-probe oracle
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/bdx.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -32,6 +32,11 @@ bin/bdx-inflate-check: $(HOST)/inflate_check_main.cpp $(HOST)/fast_inflate.cpp $
 	@mkdir -p bin
 	g++ $(HOSTFLAGS) -O3 -o $@ $(HOST)/inflate_check_main.cpp $(HOST)/fast_inflate.cpp -lz
 
+# measurement tool (bench.py): the feeder's ceilings -- page cache -> pinned -> HBM
+bin/bdx-feed-probe: tools/feed_probe.hip
+	@mkdir -p bin
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -o $@ $< -lpthread
+
 bin/bam2cfg: $(HOST)/bam2cfg_main.cpp $(HOST)/bam_reader.cpp $(HOST)/bam_reader.h
 	@mkdir -p bin
 	g++ $(HOSTFLAGS) -o $@ $(HOST)/bam2cfg_main.cpp $(HOST)/bam_reader.cpp -lz -lpthread
@@ -44,7 +49,7 @@ oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(CSRC)/*.o breakdancer_amd/libbdx.so bin/breakdancer-max bin/bdx-dump-reads bin/bam2cfg
+	rm -f $(CSRC)/*.o breakdancer_amd/libbdx.so bin/breakdancer-max bin/bdx-dump-reads bin/bam2cfg bin/bdx-feed-probe
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

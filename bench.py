@@ -63,6 +63,8 @@ def parse():
                          "plus, for N > 1, the fixed 1/8 spread over the N ranks)")
     ap.add_argument("--no-sharded-cli", action="store_true", help="skip config.timings.bam_to_table_sharded (BDX_GPUS on one indexed genome BAM)")
     ap.add_argument("--sharded-cli-fraction", type=float, default=1.0 / 64, help="hg38 lengths x this for that BAM (default 1/64: 14.5 M records)")
+    ap.add_argument("--no-genome-bam", action="store_true", help="skip config.timings.bam_to_table_genome (one GPU's share of a 30x genome as ONE BAM through the CLI)")
+    ap.add_argument("--genome-bam-fraction", type=float, default=1.0 / 8, help="hg38 lengths x this for that BAM (default 1/8: 116 M records, 15.9 GB)")
     ap.add_argument("--no-overlap", action="store_true", help="skip the three-contexts-in-flight measurement (config.overlapped_contexts)")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 --pmc sub-run that measures roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -141,7 +143,8 @@ def cpu_worker(bam, passes):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import OracleRun, make_opts
     t0 = time.perf_counter()
-    run = OracleRun(CFG_LINE % bam, make_opts())
+    cfg_path = os.environ.get("BDX_CPU_WORKER_CFG")   # (a configuration file beside the BAM: the genome slice's four read groups)
+    run = OracleRun(open(cfg_path).read().replace(os.path.basename(bam), bam) if cfg_path else CFG_LINE % bam, make_opts())
     n, dec = run.load_bam(0, bam, passes=passes, set_targets=True)
     t1 = time.perf_counter()
     rc = run.L.bdo_run(run.h)
@@ -352,6 +355,102 @@ def time_bam_cli(bam, cfg, n):
     if inflated and "seconds" in host:
         out["host_reader"]["inflate_mb_per_s_per_cpu"] = inflated / 1e6 / host["seconds"] / cpus
     return out
+
+
+def time_bam_cli_genome(fraction, n_gpu_visible):
+    """BAM -> SV table at the size the metric is about: ONE indexed 24-chromosome, 4-library BAM of one GPU's share of a 30x genome
+    (hg38 lengths x 1/8: 116 M records, 15.9 GB; smaller if memory does not hold it: stated), bin/breakdancer-max in one process from
+    start to exit, page cache warm, best of 3.  Beside it, measured in this invocation on the same file: the ceilings of the three
+    things the file has to get through -- page cache -> pinned -> HBM (bin/bdx-feed-probe), the inflate kernel alone on a slice's
+    members in one launch -- and the reference-shaped CPU path on a stated slice (two chromosomes of the same genome as their own BAM)."""
+    from breakdancer_amd.bamwrite import write_genome_bam
+    need_gb = 15.9 * fraction * 8
+    avail = mem_available_gb()
+    note = None
+    while fraction > 1.0 / 512 and avail < 3.5 * need_gb + 8:   # (the file in tmpfs / page cache, the synthesis' columns, the pinned and mapped copies of the ceilings' slice)
+        fraction /= 2
+        need_gb /= 2
+        note = "memory available %.0f GB: genome fraction reduced to %g" % (avail, fraction)
+    td = tempfile.mkdtemp(prefix="bdx_genome_", dir="/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp")
+    try:
+        t0 = time.perf_counter()
+        bam, cfg, n = write_genome_bam(td, fraction)
+        prep_s = time.perf_counter() - t0
+        size = os.path.getsize(bam)
+        best = None
+        for _ in range(3):
+            time.sleep(2.5)   # (untimed: the driver is still taking back the previous process's tens of GB of HBM)
+            t0 = time.perf_counter()
+            p = subprocess.run([os.path.join(ROOT, "bin", "breakdancer-max"), cfg], cwd=td, env=dict(os.environ, BDX_TIMING="1", BDX_FOREGROUND="1"),
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            dt = time.perf_counter() - t0
+            if p.returncode != 0:
+                return {"error": p.stderr.decode()[-400:]}
+            rows = sum(1 for line in p.stdout.splitlines() if line and not line.startswith(b"#"))
+            if best is None or dt < best[0]:
+                best = (dt, rows, [x for x in p.stderr.decode().splitlines() if x.startswith("[bdx timing]")])
+        out = {"seconds": best[0], "value": (n / 2) / best[0], "unit": "read-pairs/s", "file_gb_per_s": size / best[0] / 1e9, "sv_rows": best[1],
+               "records": n, "bam_bytes": size, "genome_fraction": fraction, "synthesis_and_bam_write_seconds_untimed": prep_s, "cli_breakdown": best[2][:-1],
+               "note": "bin/breakdancer-max <cfg> on ONE indexed 24-chromosome, 4-library BAM (hg38 x %g, 30x: one GPU's share of configs[2]), one process from "
+                       "start to exit (BDX_FOREGROUND=1), best of 3, file in the page cache (tmpfs)%s" % (fraction, "; " + note if note else "")}
+        import re
+        for line in best[2]:
+            m = re.search(r"steady state: ([0-9.]+) GB of BAM .* first inflate launch \(([0-9.]+) s after .* last record \(([0-9.]+) s\): ([0-9.]+) s, ([0-9.]+) GB/s", line)
+            if m:
+                out["steady_state_gb_s"] = float(m.group(5))
+                out["steady_state"] = {"seconds": float(m.group(4)), "first_inflate_launch_s_after_decoder_setup": float(m.group(2)),
+                                       "note": "file bytes / (last record decoded - first inflate launch): what a file of any size approaches"}
+            m = re.search(r"total=([0-9.]+)s", line)
+            if m:
+                out["inside_the_process_seconds"] = float(m.group(1))
+        # ceilings, on this file, now
+        ceil = {}
+        try:
+            fp = subprocess.run([os.path.join(ROOT, "bin", "bdx-feed-probe"), bam, "6", str(min(usable_cpus(), 16)), "12"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+            ceil["feed"] = json.loads(fp.stdout.decode().strip().splitlines()[-1]) if fp.returncode == 0 else {"error": fp.stderr.decode()[-200:]}
+        except Exception as e:  # noqa: BLE001
+            ceil["feed"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        try:
+            from breakdancer_amd import bamdec
+            img = np.memmap(bam, dtype=np.uint8, mode="r")
+            members = bamdec.scan_bgzf(img)
+            data = members[members["inflated_len"] > 0]
+            out["inflated_bytes"] = int(data["inflated_len"].astype(np.int64).sum())
+            k = min(len(data), 61440)   # eight rounds of the wave slots: ~2.5 GB of the file
+            lo = int(data["member"][0])
+            hi = int(data["payload"][k - 1]) + int(data["payload_len"][k - 1]) + 8
+            sl = data[:k].copy()
+            sl["payload"] -= np.uint64(lo)
+            sl["member"] -= np.uint64(lo)
+            piece = np.ascontiguousarray(img[lo:hi])
+            ms = None
+            for _ in range(2):
+                _o, status, ms = bamdec.inflate_blocks(piece, sl)
+            ulen = int(sl["inflated_len"].astype(np.int64).sum())
+            ceil["inflate_kernel_alone"] = {"members": int(k), "launches": 1, "inflated_gb_s": ulen / ms / 1e6, "file_gb_s": (hi - lo) / ms / 1e6, "ok": not bool(status.any()),
+                                            "note": "kz_inflate_kernel on the file's first %d members in ONE launch, bytes already in HBM (HIP events)" % k}
+            del _o, piece
+        except Exception as e:  # noqa: BLE001
+            ceil["inflate_kernel_alone"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        out["ceilings"] = ceil
+        lows = [v for v in (ceil.get("feed", {}).get("both_pipelined_gb_s"), ceil.get("inflate_kernel_alone", {}).get("file_gb_s")) if v]
+        if lows and out.get("steady_state_gb_s"):
+            out["steady_state_over_lowest_ceiling"] = out["steady_state_gb_s"] / min(lows)
+        # the CPU path on a slice of the same genome: its two smallest chromosomes (chr21, chr22) as their own BAM, one core, two decode passes
+        try:
+            sbam, scfg, sn = write_genome_bam(td, fraction, only_tids=(20, 21), tag="slice", translocations=0)
+            one = json.loads(subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", sbam, "2"], check=True, stdout=subprocess.PIPE,
+                                            env=dict(os.environ, BDX_CPU_WORKER_CFG=scfg)).stdout.decode().strip().splitlines()[-1])
+            out["cpu_port_on_a_slice"] = {"value": (sn / 2) / one["total_s"], "unit": "read-pairs/s", "cores": 1, "kind": "port", "seconds": one["total_s"], "records": sn,
+                                          "sample": "chr21 + chr22 of the same genome (same seed, four libraries) as their own BAM: BGZF inflate + record decode x 2 passes "
+                                                    "+ the oracle's sequential path, one core"}
+            out["over_cpu_port"] = out["value"] / out["cpu_port_on_a_slice"]["value"]
+        except Exception as e:  # noqa: BLE001
+            out["cpu_port_on_a_slice"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        return out
+    finally:
+        import shutil
+        shutil.rmtree(td, ignore_errors=True)
 
 
 def time_bam_cli_sharded(td, n_gpus_visible, fraction=1.0 / 64):
@@ -794,6 +893,7 @@ def main():
             traffic_detail, traffic_note = measure_k1_traffic(a.length)
             if traffic_detail:
                 traffic = traffic_detail["hbm_bytes_per_launch"]
+        n_ctxs_timed = len(ctxs)
         timings = {"hbm_resident": {"seconds": dt / a.steps, "value": value / world, "unit": "read-pairs/s",
                                     "note": "= `value` per GPU: one bdx_run on records already in HBM"}}
         cpu = None
@@ -820,6 +920,15 @@ def main():
                             timings["bam_to_table_sharded"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
                 if not a.no_cpu_baseline:
                     cpu = cpu_baseline(bam, n, a.cpu_parallel)
+            if not a.no_end_to_end and not a.no_genome_bam:
+                n_ctxs_timed = len(ctxs)
+                for x in ctxs:   # (the timed contexts' HBM is not needed any more: the CLI below reserves tens of GB)
+                    x.close()
+                ctxs = []
+                try:
+                    timings["bam_to_table_genome"] = time_bam_cli_genome(a.genome_bam_fraction, torch.cuda.device_count())
+                except Exception as e:  # noqa: BLE001
+                    timings["bam_to_table_genome"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         out = {
             "metric": "read-pairs/s, records resident in HBM -> scored SV table (SURVEY 8d timing i); end to end from BAM: config.timings.bam_to_table (vs_baseline is taken there)",
             "value": value, "unit": "read-pairs/s",
@@ -828,7 +937,7 @@ def main():
             "config": {"workload": "configs[1]: synthetic single chromosome %d Mbp, 30x, 2x100 bp, 1 library, ~1%% discordant "
                                    "pairs; %d read pairs (%d records) per GPU, HBM-resident SoA; every timed step runs pass 1, reads its "
                                    "record back and sizes the later stages exactly (no enqueue-ahead)" % (a.length // 1000000, pairs, n),
-                       "sharding": "one chromosome per GPU, no data-path collective", "contexts_in_flight": len(ctxs),
+                       "sharding": "one chromosome per GPU, no data-path collective", "contexts_in_flight": n_ctxs_timed,
                        "svs_per_gpu": summary["n_svs_printed"],
                        "timings": timings,
                        "repeat_run_enqueue_ahead": {"ms_per_step": repeat_ms, "value": pairs / (repeat_ms * 1e-3), "unit": "read-pairs/s",

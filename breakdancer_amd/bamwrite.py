@@ -32,7 +32,9 @@ def _fixed_records(soa, lo, hi, L, rg, rng, names=None):
         for i, x in enumerate(names[lo:hi]):
             nm[i, :len(x)] = np.frombuffer(x.encode(), np.uint8)
     lname = nm.shape[1]
-    aux = b"RGZ" + rg.encode() + b"\0"
+    rgs = [rg] if isinstance(rg, str) else list(rg)   # several read groups (ids of one width: records keep one size): record i carries rgs[soa["lib"][i]]
+    assert len({len(r) for r in rgs}) == 1
+    aux = b"RGZ" + rgs[0].encode() + b"\0"
     rec_len = 32 + lname + 4 + (L + 1) // 2 + L + len(aux)
     rec = np.zeros((n, 4 + rec_len), np.uint8)
 
@@ -63,7 +65,11 @@ def _fixed_records(soa, lo, hi, L, rg, rng, names=None):
     o += nb
     rec[:, o:o + L] = rng.integers(2, 41, (n, L), dtype=np.uint8)
     o += L
-    rec[:, o:o + len(aux)] = np.frombuffer(aux, np.uint8)
+    if len(rgs) == 1:
+        rec[:, o:o + len(aux)] = np.frombuffer(aux, np.uint8)
+    else:
+        table = np.stack([np.frombuffer(b"RGZ" + r.encode() + b"\0", np.uint8) for r in rgs])
+        rec[:, o:o + len(aux)] = table[np.asarray(soa["lib"][lo:hi]).astype(np.int64)]
     return rec
 
 
@@ -80,7 +86,7 @@ def write_bam(path, soa, targets, rg="rg1", readlen=None, level=1, seed=0, names
     n = len(soa["tid"])
     L = int(readlen if readlen is not None else (soa["qlen"][0] if n else 100))
     text = "@HD\tVN:1.0\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (t, 300000000) for t in targets) + \
-           "@RG\tID:%s\tLB:lib1\tSM:s\n" % rg
+           "".join("@RG\tID:%s\tLB:lib%d\tSM:s\n" % (r, i + 1) for i, r in enumerate([rg] if isinstance(rg, str) else rg))
     hdr = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(targets))
     for t in targets:
         hdr += struct.pack("<i", len(t) + 1) + t.encode() + b"\0" + struct.pack("<i", 300000000)
@@ -241,3 +247,32 @@ def write_bam_records(path, recs, targets, rgs=(), level=1, seed=0, index=False)
             return (coffs[o // 65280] << 16) | (o % 65280) if o < len(raw) else (coffs[-1] << 16)
         _write_bai(path + ".bai", len(targets), [(t, b, e, voff(s0), voff(s1)) for t, b, e, s0, s1 in spans])
     return path
+
+
+# hg38 primary assembly, chr1-22, X, Y (Mbp) and the four libraries of BASELINE.json configs[2]
+HG38_MBP = [248.96, 242.19, 198.30, 190.21, 181.54, 170.81, 159.35, 145.14, 138.39, 133.80, 135.09, 133.28, 114.36, 107.04,
+            101.99, 90.34, 83.26, 80.37, 58.62, 64.44, 46.71, 50.82, 156.04, 57.23]
+LIBS4 = ((400.0, 30.0), (350.0, 40.0), (500.0, 50.0), (300.0, 25.0))
+
+
+def write_genome_bam(td, fraction, only_tids=None, tag="genome", translocations=None, seed=11):
+    """ONE indexed, position-sorted 24-chromosome BAM of the configs[2]/[3] genome at `fraction` of hg38's lengths -- 30x, 2x100 bp, four
+    libraries as four read groups, planted translocations -- and its bam2cfg-format configuration (one line per read group), in directory
+    td.  fraction 1/8: 116 M records, 15.9 GB, one GPU's share of the 8-GPU configurations.  only_tids: just these chromosomes' records of
+    the same genome (the slice the CPU baseline is timed on).  Returns (bam, cfg, records); files that exist are kept."""
+    import os
+    from .synth import make_genome
+    os.makedirs(td, exist_ok=True)
+    bam = os.path.join(td, "%s_%g.bam" % (tag, fraction))
+    cfg = os.path.join(td, "%s_%g.cfg" % (tag, fraction))
+    if not (os.path.exists(bam) and os.path.exists(cfg) and os.path.exists(bam + ".n")):
+        lengths = [int(m * 1e6 * fraction) for m in HG38_MBP]
+        d = make_genome(lengths, coverage=30.0, seed=seed, libs=LIBS4, lib_bam=(0, 0, 0, 0),
+                        n_translocations=max(20, int(5000 * fraction * 8)) if translocations is None else translocations, only_tids=only_tids)
+        write_bam(bam, d, ["chr%d" % (i + 1) for i in range(len(lengths))], rg=["rg%d" % (i + 1) for i in range(len(LIBS4))], seed=5, index=True)
+        with open(cfg, "w") as f:
+            for i, (m, sd) in enumerate(LIBS4):
+                f.write("readgroup:rg%d\tplatform:illumina\tmap:%s\treadlen:100.00\tlib:lib%d\tlower:%.2f\tupper:%.2f\tmean:%.2f\tstd:%.2f\n"
+                        % (i + 1, os.path.basename(bam), i + 1, m - 3 * sd, m + 3 * sd, m, sd))
+        open(bam + ".n", "w").write(str(len(d["tid"])))
+    return bam, cfg, int(open(bam + ".n").read())

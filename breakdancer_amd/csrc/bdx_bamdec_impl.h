@@ -31,9 +31,11 @@ namespace {
 constexpr size_t kBamMargin = (size_t)kMaxDeviceRecord + 65536;   // bytes mirrored behind the piece in front of a wrap
 constexpr int kBamSlots = 4;                                       // batches in flight (device-side compressed bytes, tables, status)
 #ifndef BDX_BAM_STAGING
-#define BDX_BAM_STAGING 6
+#define BDX_BAM_STAGING 12
 #endif
-constexpr int kBamStaging = BDX_BAM_STAGING;                                     // pinned staging buffers (a caller may hold several: it reads pieces ahead of the one it submits)
+constexpr int kBamStaging = BDX_BAM_STAGING;   // pinned staging buffers.  A caller holds several (it reads pieces ahead of the one it submits) and the REST are what the copy engine
+                                               // has queued: with six, four of them being read, two copies in flight did not keep it busy -- a piece every 0.26 ms for copies of
+                                               // 0.16 ms, 32 GB/s (profiles/r05_genome_probe_mid.txt); pinned one after the other by ONE thread, in the order they are asked for
 constexpr size_t kBatchBytesDefault = (size_t)384 << 20;           // compressed bytes per batch
 constexpr size_t kBatchBlocksDefault = 7680;                       // members per batch: with the piece that takes it over this, still within the wave slots the GPU has for this kernel
                                                                    // (256 CUs x 32 = 8,192).  The kernel's waves give way as they get ahead (s_setprio), so a launch's members end together:
@@ -57,21 +59,23 @@ struct bdx_bamdec {
     int device = 0;
     bdx_ctx* sink = nullptr;
     std::string err;
-    hipStream_t s_copy = nullptr, s_inf = nullptr, s_inf2 = nullptr, s_rec = nullptr;   // (two inflate streams, taken in turn: see bam_launch_batch)
-    // A decoder that feeds a context copies on the context's copy stream and runs its record stages on the context's compute stream
-    // (the classifier follows them there anyway): four streams in all.  The HIP runtime spreads a process's streams over four hardware
-    // queues, and two streams on one queue run in order -- with six, the completion of a 0.3 ms copy waited behind a 19 ms inflate launch.
-    bool borrowed_streams = false;
+    hipStream_t s_copy = nullptr, s_inf = nullptr, s_inf2 = nullptr, s_rec = nullptr;   // (s_inf == s_inf2 == s_rec unless BDX_KZ_STREAM=own: bdx_bamdec_create)
+    // A decoder that feeds a context copies on the context's copy stream; with the context's compute and side streams and the decoder's
+    // own that makes four streams in all.  The HIP runtime spreads a process's streams over four hardware queues, and two streams on one
+    // queue run in order -- with six, the completion of a 0.3 ms copy waited behind a 19 ms inflate launch.
+    bool borrowed_copy = false, borrowed_rec = false;   // (a stream of the sink's: not the decoder's to destroy)
+    bool own_inf_stream = false;      // (BDX_KZ_STREAM=own) the inflate launches have a stream of their own; else they run in s_rec
     // pinned staging: one piece's compressed bytes and the caller's member table
     struct Staging {
         PinBuf h_comp, h_tab;
         hipEvent_t ev_copied = nullptr;   // H2D of this buffer done
         bool busy = false;
         size_t cap = 0;                   // table entries
-        std::thread pinning;              // (bdx_bamdec_params::piece_bytes: the buffer is being pinned)
+        std::atomic<int> pinned{1};       // 0: the pinning thread has not got to this buffer yet (bdx_bamdec_params::piece_bytes), 1: ready
         size_t cap_bytes = 0;             // bytes the last bdx_bamdec_acquire promised
         hipError_t pin_status = hipSuccess;
     } staging[kBamStaging];
+    std::thread pin_thread;              // (pins the staging buffers one after the other: page pinning does not run in parallel with itself)
     int next_staging = 0, held_staging = 0;   // the held_staging buffers before next_staging are acquired and not submitted yet (oldest first)
     // a batch: the compressed bytes of its pieces back to back in HBM, its member table, the inflate status words
     struct Slot {
@@ -84,7 +88,8 @@ struct bdx_bamdec {
         uint64_t ulen = 0;
     } slot[kBamSlots];
     int cur_slot = 0;
-    size_t batch_bytes = kBatchBytesDefault, batch_blocks = kBatchBlocksDefault;
+    size_t batch_bytes = kBatchBytesDefault, batch_blocks = kBatchBlocksDefault;   // the LARGEST batch
+    size_t round_blocks = kBatchBlocksDefault;   // one round of the wave slots: the batches grow from a third of it to batch_blocks (bdx_bamdec_submit)
     DevBuf d_ring;
     size_t ring_bytes = 0;        // usable bytes (the allocation has kBamMargin more)
     uint64_t cursor = 0;
@@ -94,7 +99,9 @@ struct bdx_bamdec {
     // where the feeding thread's time goes (bdx_bamdec_host_ms): [0] waiting for a staging buffer's copy, [1] pinning staging memory,
     // [2] waiting for a batch slot, [3] a slot's buffers, [4] the piece's copy calls, [5] a batch's launch, [6] a record stage's
     // launches, [7] feeding the classifier
-    double host_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // [8] first inflate launch, [9] bdx_bamdec_finish's return: ms after the decoder's creation (or its last re-arming)
+    double host_ms[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // ([10] of [7]: sizing the later stages' buffers, [11] of [7]: classifier launches)
+    std::chrono::steady_clock::time_point t_armed = std::chrono::steady_clock::now();
     bool finished = false, any_submitted = false;
     // record stage scratch (one piece at a time on s_rec)
     DevBuf d_cb, d_offs, d_base, d_scan, d_state;
@@ -121,6 +128,11 @@ struct bdx_bamdec {
     size_t expected_bytes = 0;    // compressed bytes the caller announced (0: unknown)
     uint64_t first_batch_bytes = 0;
     bool presized = false;        // sink mode: the later stages' buffers have been sized from the first batch's record density
+    std::thread presize_thread;   // (the sizing runs beside the decode; joined by bdx_bamdec_finish)
+    int presize_rc = 0;
+    std::deque<std::pair<uint64_t, uint64_t>> batch_end_bytes;   // (batch sequence, compressed bytes submitted up to its end)
+    uint64_t records_at_arm = 0;  // what the sink held when the decoder was created / armed again
+    uint64_t bytes_at_arm = 0;    // compressed bytes submitted before that
 };
 
 namespace {
@@ -214,17 +226,31 @@ int bam_feed_classifier(bdx_bamdec* d, bool final) {
         c->n = (size_t)d->confirmed;
         c->ran = false;
     }
-    // The stages behind pass 1 get their buffers (~60 allocations, tens of milliseconds of page pinning for a chromosome) once the
-    // caller has handed over its last piece: the GPU still has the last batches to inflate, and the feeder has nothing else to do.
-    if (!d->presized && d->finished && d->confirmed_seq >= 1 && d->first_batch_bytes) {
-        d->presized = true;
-        // the first batch's records per byte, applied to everything submitted
-        const double est = (double)d->confirmed / (double)std::min<uint64_t>(d->compressed_bytes, d->first_batch_bytes * d->confirmed_seq) * (double)d->compressed_bytes * 1.05;
-        if (est >= (double)(1u << 20) && !c->ran) {
-            const uint64_t prior = (uint64_t)est / 32 + 4096;
-            if (prior <= kMaxAnomalous) {
-                const int rc = presize_stages(c, (uint32_t)prior);
-                if (rc != BDX_OK) return bfail(d, rc, c->err);
+    // The stages behind pass 1 get their buffers (~60 allocations; with a genome's share of records 0.25-0.35 s of page pinning for the
+    // result tables) on a thread of their own, as soon as the first batch's records are counted: its records per byte applied to the
+    // bytes the caller announced (or, without an announcement, to what has been submitted once the last piece is in).  Until round 5 the
+    // feeding thread did this itself behind its last piece -- the GPU was through with the file long before (profiles/r05_genome_probe_before.txt).
+    if (!d->presized && d->confirmed_seq >= 1 && (d->finished || d->expected_bytes) && !d->batch_end_bytes.empty()) {
+        uint64_t bytes_counted = 0;
+        for (auto const& be : d->batch_end_bytes)
+            if (be.first <= d->confirmed_seq) bytes_counted = be.second;
+        const uint64_t total = d->finished ? d->compressed_bytes - d->bytes_at_arm : std::max<uint64_t>(d->expected_bytes, d->compressed_bytes - d->bytes_at_arm);
+        const uint64_t counted = d->confirmed > d->records_at_arm ? d->confirmed - d->records_at_arm : 0;
+        if (bytes_counted && counted) {
+            d->presized = true;
+            const double est = (double)counted / (double)bytes_counted * (double)total * 1.10 + (double)d->records_at_arm;
+            if (est >= (double)(1u << 20) && !c->ran) {
+                const uint64_t prior = (uint64_t)est / 32 + 4096;
+                if (prior <= kMaxAnomalous) {
+                    const int device = d->device;
+                    d->presize_thread = std::thread([d, c, prior, device] {
+                        const auto t0 = std::chrono::steady_clock::now();
+                        int rc = hipSetDevice(device) == hipSuccess ? BDX_OK : BDX_EHIP;
+                        if (rc == BDX_OK) rc = presize_stages(c, (uint32_t)prior);
+                        d->presize_rc = rc;
+                        d->host_ms[10] = ms_between(t0, std::chrono::steady_clock::now());
+                    });
+                }
             }
         }
     }
@@ -236,6 +262,7 @@ int bam_feed_classifier(bdx_bamdec* d, bool final) {
     if (c->k1_live) {
         const uint32_t full = (uint32_t)(c->n / kTile);
         if (full >= c->k1_done + kStreamTilesMin || (final && full > c->k1_done)) {
+            BamTimer t11(d->host_ms[11]);
             const int rc = pass1_classify(c, full, false);
             if (rc != BDX_OK) return bfail(d, rc, c->err);
         }
@@ -280,6 +307,7 @@ int bam_record_stage(bdx_bamdec* d, BamPiece& p, const BamPiece* next, int is_la
         bdx_ctx* c = d->sink;
         if (need > c->cap) {
             BHIP(d, hipStreamSynchronize(s));   // pieces in flight write through the old columns
+            BHIP(d, hipStreamSynchronize(c->stream));   // (and the classifier reads them)
             bam_poll(d);
             c->n = (size_t)d->confirmed;
             const int rc = alloc_reads(c, std::max<size_t>((size_t)need, c->cap + c->cap / 2));
@@ -361,15 +389,39 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
     auto mark = [&](const char* what) {
         if (create_trace) fprintf(stderr, "[bdx bamdec create] %s at %.3f ms\n", what, ms_between(t_c0, std::chrono::steady_clock::now()));
     };
-    if (sink && sink->stream && sink->copy_stream) {
-        d->s_copy = sink->copy_stream; d->s_rec = sink->stream;
-        d->borrowed_streams = true;
-    } else if (hipStreamCreateWithFlags(&d->s_copy, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&d->s_rec, hipStreamNonBlocking) != hipSuccess) {
+    // Streams.  The copies go through the sink's copy stream (or one of the decoder's own); the inflate launches and the record stages
+    // share ONE stream of the decoder's, in order: KZ(b + 1), records(b), KZ(b + 2), records(b + 1) ...
+    // Beside an inflate launch a record stage crawls -- a launch takes every wave slot, the record kernels' workgroups wait for slots that
+    // free up (kb_stitch 6 ms instead of 0.03) and the launch's own last workgroups start late behind them: 12.4 ms per launch of 7,680
+    // members in the pipeline against 8.6 ms alone (profiles/r05_genome_timeline_before.txt) -- and nothing can be kept going beside a
+    // kernel that outlives its batch either: on this stack a kernel submitted to an idle queue starts only when every running kernel has
+    // ended (tools/latecomer_probe.hip, tools/chain_probe.hip), and a CU-masked queue holds 16 waves per CU (tools/cumask_probe.hip).
+    // Taking turns costs the record stages' own time, ~1 ms per 7,680 members.  The stream is NOT the sink's compute stream: the runtime
+    // spreads a process's streams over four hardware queues, two streams on one queue run in order, and a copy's completion marker behind
+    // a 30 ms inflate launch kept the feeder waiting for its staging buffers; the classifier, on the sink's stream, follows the record
+    // stages through their events.  BDX_KZ_STREAM=own: the inflate launches in a third stream, beside the record stages, as until round 4.
+    if (sink && sink->copy_stream) {
+        d->s_copy = sink->copy_stream;
+        d->borrowed_copy = true;
+    } else if (hipStreamCreateWithFlags(&d->s_copy, hipStreamNonBlocking) != hipSuccess) {
         return bad(BDX_EHIP);
     }
-    // ONE inflate stream: a stream costs the runtime 8-12 ms to create (a hardware queue each), and two launches of full batches have
-    // nothing to overlap -- a batch fills the GPU's wave slots for this kernel (with four streams the two landed on one queue anyway)
-    if (hipStreamCreateWithFlags(&d->s_inf, hipStreamNonBlocking) != hipSuccess) return bad(BDX_EHIP);
+    {
+        const char* ks = getenv("BDX_KZ_STREAM");
+        const bool third = ks && !strcmp(ks, "own");
+        if (third && sink && sink->stream) {
+            d->s_rec = sink->stream;
+            d->borrowed_rec = true;
+        } else if (hipStreamCreateWithFlags(&d->s_rec, hipStreamNonBlocking) != hipSuccess) {
+            return bad(BDX_EHIP);
+        }
+        if (third) {
+            if (hipStreamCreateWithFlags(&d->s_inf, hipStreamNonBlocking) != hipSuccess) return bad(BDX_EHIP);
+            d->own_inf_stream = true;
+        } else {
+            d->s_inf = d->s_rec;
+        }
+    }
     d->s_inf2 = d->s_inf;
     for (auto& sl : d->slot)
         if (hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&sl.ev_free, hipEventDisableTiming) != hipSuccess)
@@ -378,8 +430,17 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
         if (hipEventCreateWithFlags(&st.ev_copied, hipEventDisableTiming) != hipSuccess) return bad(BDX_EHIP);
     mark("streams and events");
     d->expected_bytes = p->expected_bytes;
-    if (p->batch_bytes) d->batch_bytes = p->batch_bytes;
-    if (p->batch_blocks) d->batch_blocks = p->batch_blocks;
+    // A launch of ONE round of the wave slots ends with the slots draining (58 GB/s of inflated bytes against 68 in launches of four rounds
+    // and 70 with a 16 GB file in one launch, profiles/r05_genome_inflate_alone.txt), so a large input is decoded in batches of up to four
+    // rounds -- 30,720 members, 2 GB inflated; the buffers grow with them, which a small file would pay for in its set-up: one round per
+    // 2.5 GB announced.  A caller's batch_blocks is taken as it is.  Test knob: BDX_BAM_BATCH_ROUNDS.
+    {
+        size_t rounds = std::max<size_t>(1, std::min<size_t>(4, p->expected_bytes / ((size_t)2560 << 20)));
+        if (const char* br = getenv("BDX_BAM_BATCH_ROUNDS")) rounds = (size_t)std::max(1, std::min(16, atoi(br)));
+        if (p->batch_blocks) { d->batch_blocks = d->round_blocks = p->batch_blocks; rounds = 1; }
+        else d->batch_blocks = d->round_blocks * rounds;
+        d->batch_bytes = p->batch_bytes ? p->batch_bytes : kBatchBytesDefault * rounds;
+    }
     // read groups
     {
         const uint32_t n = p->n_read_groups;
@@ -425,17 +486,19 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
     mark("ring and state");
     if (sink && sink->adopted) return bad(BDX_ESTATE);   // (before the pinning threads start: a decoder that fails from here on is destroyed at once)
     // (behind the decoder's own pinned allocation: page pinning does not run in parallel with itself)
-    if (p->piece_bytes && p->piece_blocks)
-        for (auto& st : d->staging) {
-            bdx_bamdec::Staging* sp = &st;
-            const size_t nb = p->piece_bytes + 64, nt = p->piece_blocks * sizeof(bdx_bgzf_block);
-            st.pinning = std::thread([sp, nb, nt, device] {
-                hipError_t e = hipSetDevice(device);
-                if (e == hipSuccess) e = sp->h_comp.ensure(nb);
-                if (e == hipSuccess) e = sp->h_tab.ensure(nt);
-                sp->pin_status = e;
-            });
-        }
+    if (p->piece_bytes && p->piece_blocks) {
+        for (auto& st : d->staging) st.pinned.store(0);
+        const size_t nb = p->piece_bytes + 64, nt = p->piece_blocks * sizeof(bdx_bgzf_block);
+        d->pin_thread = std::thread([d, nb, nt, device] {
+            hipError_t e = hipSetDevice(device);
+            for (auto& st : d->staging) {
+                if (e == hipSuccess) e = st.h_comp.ensure(nb);
+                if (e == hipSuccess) e = st.h_tab.ensure(nt);
+                st.pin_status = e;
+                st.pinned.store(1, std::memory_order_release);
+            }
+        });
+    }
     if (sink) {
         if (sink->adopted) return bad(BDX_ESTATE);
         if (sink->n == 0 && p->expected_bytes) {   // (a record takes 50-150 bytes of BAM; a store that is too small grows)
@@ -457,6 +520,7 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
         mark("pass-1 tables");
         if (sink->key_segs.empty() || sink->key_segs.back().host) sink->key_segs.push_back(bdx_ctx::KeySeg{(uint64_t)sink->n, nullptr, nullptr, nullptr});
         d->confirmed = sink->n;
+        d->records_at_arm = sink->n;
         // (records this decoder appends come behind what the store already holds)
         st.n_kept = sink->n;
         if (hipMemcpy(d->d_state.p, &st, sizeof(st), hipMemcpyHostToDevice) != hipSuccess) return bad(BDX_EHIP);
@@ -474,8 +538,8 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
 void bdx_bamdec_destroy(bdx_bamdec* d) {
     if (!d) return;
     (void)hipSetDevice(d->device);
-    for (auto& st : d->staging)   // (before anything of theirs is released: a thread may still be pinning its staging buffer)
-        if (st.pinning.joinable()) st.pinning.join();
+    if (d->presize_thread.joinable()) d->presize_thread.join();
+    if (d->pin_thread.joinable()) d->pin_thread.join();   // (before anything is released: the thread may still be pinning staging buffers)
     for (hipStream_t s : {d->s_copy, d->s_inf, d->s_inf2, d->s_rec})
         if (s) (void)hipStreamSynchronize(s);
     for (auto& sl : d->slot) {
@@ -498,8 +562,10 @@ void bdx_bamdec_destroy(bdx_bamdec* d) {
                       &d->o_tid, &d->o_pos, &d->o_mtid, &d->o_mpos, &d->o_isize, &d->o_flag, &d->o_qlen, &d->o_mapq, &d->o_lib, &d->o_bam, &d->o_key})
         b->release();
     d->h_progress.release();
-    if (d->borrowed_streams) d->s_copy = d->s_rec = nullptr;
-    if (d->s_inf2 == d->s_inf) d->s_inf2 = nullptr;
+    if (!d->own_inf_stream) d->s_inf = nullptr;
+    d->s_inf2 = nullptr;
+    if (d->borrowed_copy) d->s_copy = nullptr;
+    if (d->borrowed_rec) d->s_rec = nullptr;
     for (hipStream_t s : {d->s_copy, d->s_inf, d->s_inf2, d->s_rec})
         if (s) (void)hipStreamDestroy(s);
     delete d;
@@ -520,10 +586,8 @@ int bdx_bamdec_acquire(bdx_bamdec* d, size_t bytes, size_t max_blocks, void** bu
     }
     {
         BamTimer t(d->host_ms[1]);
-        if (st.pinning.joinable()) {
-            st.pinning.join();
-            BHIP(d, st.pin_status);
-        }
+        while (!st.pinned.load(std::memory_order_acquire)) std::this_thread::yield();
+        BHIP(d, st.pin_status);
         BHIP(d, st.h_comp.ensure(bytes + 64));
         BHIP(d, st.h_tab.ensure(max_blocks * sizeof(bdx_bgzf_block)));
     }
@@ -595,6 +659,9 @@ int bam_launch_batch(bdx_bamdec* d, int si, bool last) {
     sl.busy = true;
     sl.open = false;
     if (p.seq == 1) d->first_batch_bytes = sl.bytes;
+    d->batch_end_bytes.emplace_back(p.seq, d->compressed_bytes - d->bytes_at_arm);
+    while (d->batch_end_bytes.size() > 64) d->batch_end_bytes.pop_front();
+    if (d->host_ms[8] == 0) d->host_ms[8] = ms_between(d->t_armed, std::chrono::steady_clock::now());
     d->inflated_bytes += ulen;
     d->pieces.push_back(p);
     d->cur_slot = (si + 1) % kBamSlots;
@@ -684,10 +751,12 @@ int bdx_bamdec_submit(bdx_bamdec* d, size_t bytes, size_t nblocks, int last) {
     sl.bytes += (bytes + 7) & ~(size_t)7;
     d->compressed_bytes += bytes;
     d->any_submitted = true;
-    // the first batches are smaller: the GPU starts on a third of a full batch while the next two thirds are read, and the two together
-    // fill it (a member takes its ~10 ms however few run beside it)
+    // the first batches are smaller: the GPU starts on an eighth of a round of its wave slots (five pieces of the file) while the next ones
+    // are read -- a third, two thirds, a round, two, then four (a member takes its 4-8 ms however few run beside it)
     const uint64_t started = d->n_pieces;
-    const size_t goal_blocks = started == 0 ? std::max<size_t>(d->batch_blocks / 3, 1) : started == 1 ? std::max<size_t>(2 * d->batch_blocks / 3, 1) : d->batch_blocks;
+    const size_t rb = d->round_blocks;
+    const size_t goal_blocks = std::min(d->batch_blocks, started == 0 ? std::max<size_t>(rb / 8, 1) : started == 1 ? std::max<size_t>(rb / 3, 1) : started == 2 ? std::max<size_t>(2 * rb / 3, 1) :
+                                                         started == 3 ? rb : started == 4 ? 2 * rb : 4 * rb);
     if (last || sl.nblk >= goal_blocks || sl.bytes >= d->batch_bytes) {
         rc = bam_launch_batch(d, d->cur_slot, last != 0);
         if (rc != BDX_OK) return rc;
@@ -739,6 +808,10 @@ int bdx_bamdec_finish(bdx_bamdec* d, uint64_t* n_records) {
     d->confirmed_seq = d->n_pieces;
     d->bounds.clear();
     d->bound_in_flight = 0;
+    if (d->presize_thread.joinable()) {
+        d->presize_thread.join();
+        if (d->presize_rc != BDX_OK) return bfail(d, d->presize_rc, d->sink ? d->sink->err : "sizing the later stages");
+    }
     if (d->sink) {
         const int rc = bam_feed_classifier(d, true);
         if (rc != BDX_OK) return rc;
@@ -746,6 +819,7 @@ int bdx_bamdec_finish(bdx_bamdec* d, uint64_t* n_records) {
         d->sink->ran = false;
     }
     if (n_records) *n_records = st.n_kept;
+    d->host_ms[9] = ms_between(d->t_armed, std::chrono::steady_clock::now());
     return BDX_OK;
 }
 
@@ -774,7 +848,12 @@ int bdx_bamdec_rearm(bdx_bamdec* d, int32_t only_tid, int32_t region_beg, int32_
     d->rec_events.clear();
     d->bounds.clear();
     d->bound_in_flight = 0;
+    d->batch_end_bytes.clear();
+    d->bytes_at_arm = d->compressed_bytes;
+    d->records_at_arm = d->sink ? d->sink->n : 0;
     d->finished = false; d->any_submitted = false;
+    d->host_ms[8] = d->host_ms[9] = 0;
+    d->t_armed = std::chrono::steady_clock::now();
     d->expected_bytes = expected_bytes;
     PieceState st{};
     st.next_start = first_record_offset;
@@ -873,7 +952,7 @@ int bdx_merge_decoded(bdx_ctx* c, bdx_bamdec* const* decs, int k, const uint8_t*
 
 int bdx_bamdec_host_ms(const bdx_bamdec* d, float* out, int n) {
     if (!d || !out) return BDX_EINVAL;
-    for (int i = 0; i < n; ++i) out[i] = i < 8 ? (float)d->host_ms[i] : 0.0f;
+    for (int i = 0; i < n; ++i) out[i] = i < 12 ? (float)d->host_ms[i] : 0.0f;
     return BDX_OK;
 }
 

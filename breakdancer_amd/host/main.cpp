@@ -366,7 +366,7 @@ int run(int argc, char** argv) {
                     sink.bring_up(false);
                     if (timing) fprintf(stderr, "[bdx timing] GPU context + resident store ready %.3f s after start (waited %.3f s for it)\n", secs(t_start, now()), secs(tb, now()));
                     bool unsupported = false;
-                    n_reads = produce_on_device(cfg, opts.chr, (int)std::min(std::max(usable_cpus(), 2u), 16u), &targets, ctx, &unsupported);
+                    n_reads = produce_on_device(cfg, opts.chr, getenv("BDX_READ_THREADS") ? std::max(1, atoi(getenv("BDX_READ_THREADS"))) : (int)std::min(std::max(usable_cpus(), 2u), 16u), &targets, ctx, &unsupported);
                     if (unsupported) check(ctx, bdx_reset_reads(ctx), "bdx_reset_reads");
                     else { decoded = true; sink.up = true; }
                     device_decoded = decoded;

@@ -469,14 +469,21 @@ size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::strin
     if (span_bytes) rest = std::min(rest, span_bytes);
     const size_t this_span = rest;
     if (sized_for) rest = std::max(rest, std::min(sized_for, file_size));   // (the buffers of a decoder that is armed again: for its largest stretch)
-    p.batch_bytes = std::min<size_t>((size_t)384 << 20, ((rest + ((size_t)1 << 20)) >> 20) << 20);
+    // (a file of less than a batch: buffers of its size; else the decoder picks the batches -- up to four rounds of the wave slots for a large input)
+    p.batch_bytes = rest < ((size_t)384 << 20) ? ((rest + ((size_t)1 << 20)) >> 20) << 20 : 0;
     p.expected_bytes = rest;
     p.batch_blocks = getenv("BDX_BAM_BATCH_BLOCKS") ? (size_t)std::max(1ll, atoll(getenv("BDX_BAM_BATCH_BLOCKS"))) : 0;
-    // four batches of inflated bytes: a batch is at most ~8192 + a piece's members of 64 KiB, or the whole file (assume <= 16 x its size)
-    p.ring_bytes = std::min<size_t>((size_t)3 << 30, std::max<size_t>((size_t)64 << 20, rest * 64));
-    // (one sequence of a sharded run: two dozen decoders follow each other on a rank and are kept until the process ends -- 3 GiB each
-    // would be 72 GiB that the driver takes seconds to reclaim, with the next process waiting behind it; what a span inflates to is enough)
-    if (span_bytes) p.ring_bytes = std::min<size_t>((size_t)3 << 30, std::max<size_t>((size_t)256 << 20, rest * 12));
+    // The ring of inflated bytes holds FOUR batches (the one whose records are being read, its successor, the one being inflated, slack).
+    // A batch is at most the decoder's largest -- rounds x 7,680 members and the piece that took it there, 64 KiB each -- or everything that
+    // is read (a BGZF member inflates to at most ~16 x its size; 8 x is assumed of a whole stretch: beyond that the decoder says BDX_ELIMIT
+    // and the host reader takes the file).  Sharded runs keep one decoder per rank for all of its sequences: sized for the largest.
+    {
+        const size_t rounds = getenv("BDX_BAM_BATCH_ROUNDS") ? (size_t)std::max(1, std::min(16, atoi(getenv("BDX_BAM_BATCH_ROUNDS")))) : std::max<size_t>(1, std::min<size_t>(4, rest / ((size_t)2560 << 20)));
+        const size_t blocks = p.batch_blocks ? p.batch_blocks : 7680 * rounds;
+        const size_t batch_inflated = (blocks + kPiece / 16384 + 64) * 65536;
+        p.ring_bytes = std::max<size_t>((size_t)64 << 20, std::min<size_t>(rest * 32, 4 * batch_inflated));
+        if (span_bytes) p.ring_bytes = std::max<size_t>(p.ring_bytes, (size_t)256 << 20);
+    }
     if (const char* rb = getenv("BDX_BAM_RING_BYTES")) p.ring_bytes = (size_t)std::max(1ll, atoll(rb));
     // (what bdx_bamdec_acquire will ask for: a piece, a member cut at the piece's end carried over from the one before, and slack)
     p.piece_bytes = std::min(kPiece, rest) + 65536 + 65536;   // (in front: the tail of the piece before; behind: slack)
@@ -509,7 +516,7 @@ size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::strin
     size_t npieces = 0;
     std::vector<uint8_t> carry;
     const size_t max_blocks = p.piece_blocks;   // (a piece of more members than that -- 512 bytes each on average -- is left to the host reader)
-    bool stop = false, too_many_members = false;
+    bool stop = false, too_many_members = false, gave_up_in_submit = false;
     // (a sequence read through the index: its records end where the index says -- nothing behind that is read, let alone inflated)
     const size_t read_end = span_bytes ? std::min(file_size, member_off + span_bytes) : file_size;
     // The file is read AHEAD of the piece being cut: up to kAhead pieces are on their way into staging buffers (ReadPool) while this
@@ -594,7 +601,11 @@ size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::strin
         t_scan += since(t0);
         t0 = clk();
         // (the bytes in front of `base` travel with the piece -- at most 64 KiB of 8 MiB -- and no table entry points at them)
-        check(bdx_bamdec_submit(dec, base + q, nb, at_eof ? 1 : 0), "bdx_bamdec_submit");
+        {
+            const int src = bdx_bamdec_submit(dec, base + q, nb, at_eof ? 1 : 0);
+            if (src == BDX_ELIMIT && unsupported) { gave_up_in_submit = true; break; }   // (a stretch that inflates beyond what the ring was sized for, ...: the host reader's)
+            check(src, "bdx_bamdec_submit");
+        }
         t_submit += since(t0);
         if (at_eof) break;
         if (off >= read_end) break;   // (the end of the sequence's span: the stream is cut here, bdx_bamdec_finish drops a record that runs past it)
@@ -607,10 +618,19 @@ size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::strin
     for (auto& x : ahead) (void)ReadPool::wait(&x->pc);   // (pieces read ahead and not needed: their readers are through before the decoder is)
     uint64_t n = 0;
     const auto tf = clk();
-    rc = bdx_bamdec_finish(dec, &n);
+    rc = bdx_bamdec_finish(dec, &n);   // (also when a piece was refused: what is in flight is waited for before the caller starts over)
+    if (gave_up_in_submit) rc = BDX_ELIMIT;
     t_finish = since(tf);
     if (timing) {
-        float hm[8];
+        float hm[12];
+        if (bdx_bamdec_host_ms(dec, hm, 12) == BDX_OK) {
+            fprintf(stderr, "[bdx timing] of the classifier feed: sizing the later stages %.1f ms, classifier launches %.1f ms\n", hm[10], hm[11]);
+            // (the rate the file moves at once the GPU has its first batch: what a file of any size approaches)
+            const double steady = (hm[9] - hm[8]) * 1e-3;
+            fprintf(stderr, "[bdx timing] steady state: %.3f GB of BAM (%zu pieces) between the first inflate launch (%.3f s after the decoder's set-up) and the last record "
+                            "(%.3f s): %.3f s, %.2f GB/s\n", (double)(read_end - member_off) * 1e-9, npieces, hm[8] * 1e-3, hm[9] * 1e-3, steady,
+                    steady > 0 ? (double)(read_end - member_off) * 1e-9 / steady : 0.0);
+        }
         if (bdx_bamdec_host_ms(dec, hm, 8) == BDX_OK)
             fprintf(stderr, "[bdx timing] inside the decoder (ms): staging wait %.1f, staging pinning %.1f, slot wait %.1f, slot buffers %.1f, copy calls %.1f, "
                             "batch launches %.1f (of which record stages %.1f), classifier feed %.1f\n", hm[0], hm[1], hm[2], hm[3], hm[4], hm[5], hm[6], hm[7]);

@@ -455,7 +455,8 @@ int bdx_bamdec_stats(const bdx_bamdec* d, uint64_t* compressed_bytes, uint64_t* 
 int bdx_merge_decoded(bdx_ctx* ctx, bdx_bamdec* const* decs, int k, const uint8_t* src_file, const uint32_t* src_index, uint64_t n);
 /* milliseconds the feeding thread spent inside the decoder so far, by cause: [0] waiting for a staging buffer's copy, [1] pinning
  * staging memory, [2] waiting for a batch slot, [3] sizing a slot's buffers, [4] the pieces' copy calls, [5] launching batches
- * (includes [6]), [6] launching record stages, [7] feeding the classifier */
+ * (includes [6]), [6] launching record stages, [7] feeding the classifier; and two marks, ms after the decoder's creation (or its last
+ * bdx_bamdec_rearm): [8] the first inflate launch, [9] bdx_bamdec_finish's return */
 int bdx_bamdec_host_ms(const bdx_bamdec* d, float* out, int n);
 int bdx_inflate_blocks(int device, const void* compressed, size_t bytes, const bdx_bgzf_block* blocks, size_t nblocks, void* out,
                        size_t out_bytes, uint32_t* status, float* kernel_ms);

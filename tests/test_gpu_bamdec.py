@@ -318,7 +318,7 @@ def test_reference_bams_columns(piece_blocks, ring, batch):
 @pytest.mark.parametrize("ahead,piece_blocks", [(2, 1), (4, 1), (4, 2), (3, 512)])
 def test_pieces_acquired_ahead_of_the_one_submitted(ahead, piece_blocks):
     """bdx_bamdec_acquire several times before bdx_bamdec_submit (a caller that reads the file ahead, as the CLI's feeder does): the pieces are
-    taken in the order they were acquired, a seventh acquisition without a submit is refused, what was acquired and never submitted is dropped
+    taken in the order they were acquired, a thirteenth acquisition without a submit is refused (the decoder has twelve staging buffers), what was acquired and never submitted is dropped
     by bdx_bamdec_finish"""
     import ctypes as C
     from breakdancer_amd import bamdec
@@ -330,19 +330,19 @@ def test_pieces_acquired_ahead_of_the_one_submitted(ahead, piece_blocks):
     cols, names, stats = bamdec.decode_file(path, rg_ids=rg_ids, rg_lib=rg_lib, fallback_lib=1, piece_blocks=piece_blocks, ahead=ahead, batch_blocks=3)
     assert names == targets
     check_columns(cols, recs, dict(zip(rg_ids, rg_lib)), 1)
-    if ahead == 4 and piece_blocks == 1:   # the ring holds six: the seventh is refused, and finish drops the held ones
+    if ahead == 4 and piece_blocks == 1:   # the ring holds twelve: the thirteenth is refused, and finish drops the held ones
         data = np.fromfile(path, dtype=np.uint8)
         members = bamdec.scan_bgzf(data)
         _, _, k, off = bamdec.bam_header(data, members)
         m = members[k:][members[k:]["inflated_len"] > 0]
         d = bamdec.BamDecoder(len(names), rg_ids=rg_ids, rg_lib=rg_lib, fallback_lib=1, first_record_offset=off)
         try:
-            held = [d.acquire_fill(data, m[i:i + 1]) for i in range(6)]
+            held = [d.acquire_fill(data, m[i:i + 1]) for i in range(12)]
             buf, tab = C.c_void_p(), C.c_void_p()
             assert d.lib.bdx_bamdec_acquire(d.h, 100, 1, C.byref(buf), C.byref(tab)) != 0
             d.submit_held(held[0], False)
             d.submit_held(held[1], False)
-            assert d.finish() > 0        # two pieces decoded as far as their bytes go, four dropped
+            assert d.finish() > 0        # two pieces decoded as far as their bytes go, ten dropped
         finally:
             d.close()
 
