@@ -35,7 +35,7 @@ bin/bdx-inflate-check: $(HOST)/inflate_check_main.cpp $(HOST)/fast_inflate.cpp $
 # measurement tool (bench.py): the feeder's ceilings -- page cache -> pinned -> HBM
 bin/bdx-feed-probe: tools/feed_probe.hip
 	@mkdir -p bin
-	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -o $@ $< -lpthread
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -mavx2 -o $@ $< -lpthread
 
 bin/bam2cfg: $(HOST)/bam2cfg_main.cpp $(HOST)/bam_reader.cpp $(HOST)/bam_reader.h
 	@mkdir -p bin

@@ -406,7 +406,7 @@ def time_bam_cli_genome(fraction, n_gpu_visible):
         # ceilings, on this file, now
         ceil = {}
         try:
-            fp = subprocess.run([os.path.join(ROOT, "bin", "bdx-feed-probe"), bam, "6", str(min(usable_cpus(), 16)), "12"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+            fp = subprocess.run([os.path.join(ROOT, "bin", "bdx-feed-probe"), bam, "6", str(min(usable_cpus(), 16)), "12", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
             ceil["feed"] = json.loads(fp.stdout.decode().strip().splitlines()[-1]) if fp.returncode == 0 else {"error": fp.stderr.decode()[-200:]}
         except Exception as e:  # noqa: BLE001
             ceil["feed"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <fcntl.h>
 #include <sys/stat.h>
+#include <sys/mman.h>
 #include <unistd.h>
 #include <memory>
 #include <thread>
@@ -341,7 +342,10 @@ inline uint32_t dle32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1
 inline uint32_t dle16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
 
 // Pieces of a file read AHEAD of the one being cut into members: a pool of threads that lives as long as the decode, fed with slices of 1 MiB.
-// (Page cache -> pinned memory is a plain copy, one core moves 2-5 GB/s of it.  Until round 4 every piece was read by threads started for
+// The slices are copied out of the file's MAPPING (the reader's own, ColumnReader::mapped) when there is one: pread() of the same bytes from the
+// page cache fed the copy engine 39-42 GB/s, memcpy from the mapping 51 -- the engine's own rate -- with half the threads
+// (tools/feed_probe.hip, profiles/r05_feed_probe.txt); BDX_READ=pread keeps the system call.
+// (Page cache -> pinned memory is a plain copy, one core moves 2-5 GB/s of it through pread.  Until round 4 every piece was read by threads started for
 // it -- 244 pieces x 7 threads for a 2 GB file, the piece all they had to work on: 26 GB/s on 16 CPUs; a pool working on up to four pieces at
 // a time moves 40 GB/s on the same box, tools/register_probe.hip.)
 class ReadPool {
@@ -361,13 +365,13 @@ public:
         for (auto& t : th_) t.join();
     }
     // bytes [off, off + n) of fd into dst; pc->left counts the slices still on their way
-    void read(int fd, size_t off, uint8_t* dst, size_t n, Piece* pc) {
+    void read(int fd, const uint8_t* map, size_t off, uint8_t* dst, size_t n, Piece* pc) {
         const size_t slice = (size_t)1 << 20;
         const size_t k = (n + slice - 1) / slice;
         { std::lock_guard<std::mutex> lk(pc->mu); pc->left += k; }
         {
             std::lock_guard<std::mutex> lk(mu_);
-            for (size_t o = 0; o < n; o += slice) q_.push_back(Task{fd, off + o, dst + o, std::min(slice, n - o), pc});
+            for (size_t o = 0; o < n; o += slice) q_.push_back(Task{fd, map, off + o, dst + o, std::min(slice, n - o), pc});
         }
         cv_.notify_all();
     }
@@ -378,7 +382,7 @@ public:
     }
 
 private:
-    struct Task { int fd; size_t off; uint8_t* dst; size_t n; Piece* pc; };
+    struct Task { int fd; const uint8_t* map; size_t off; uint8_t* dst; size_t n; Piece* pc; };
     void work() {
         for (;;) {
             Task t;
@@ -390,7 +394,13 @@ private:
                 q_.pop_front();
             }
             bool ok = true;
-            for (size_t done = 0; done < t.n;) {
+            if (t.map) {
+                memcpy(t.dst, t.map + t.off, t.n);
+                // (the pages' mappings go again at once, here, on sixteen threads: left to the end, tearing down 16 GB of populated page
+                // tables took the thread that unmaps the file 0.2 s)
+                const uintptr_t lo = ((uintptr_t)(t.map + t.off) + 4095) & ~(uintptr_t)4095, hi = (uintptr_t)(t.map + t.off + t.n) & ~(uintptr_t)4095;
+                if (hi > lo) (void)madvise((void*)lo, hi - lo, MADV_DONTNEED);
+            } else for (size_t done = 0; done < t.n;) {
                 const ssize_t r = pread(t.fd, t.dst + done, t.n - done, (off_t)(t.off + done));
                 if (r <= 0) { ok = false; break; }
                 done += (size_t)r;
@@ -528,6 +538,8 @@ size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::strin
     struct Ahead { uint8_t* b = nullptr; bdx_bgzf_block* tab = nullptr; size_t off = 0, want = 0; ReadPool::Piece pc; };
     std::deque<std::unique_ptr<Ahead>> ahead;
     ReadPool pool(threads);
+    const char* read_how = getenv("BDX_READ");
+    const uint8_t* read_map = read_how && !strcmp(read_how, "pread") ? nullptr : hdr.mapped();
     size_t next_off = member_off;
     bool queued_all = false;
     struct Drain {   // (whatever ends the loop: no thread may still be writing into a staging buffer when the decoder goes on)
@@ -544,7 +556,7 @@ size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::strin
             check(bdx_bamdec_acquire(dec, kLead + a->want + 65536, max_blocks, &buf, &a->tab), "bdx_bamdec_acquire");
             t_acquire += since(t0);
             a->b = (uint8_t*)buf;
-            if (a->want) pool.read(fd, a->off, a->b + kLead, a->want, &a->pc);
+            if (a->want) pool.read(fd, read_map, a->off, a->b + kLead, a->want, &a->pc);
             next_off += a->want;
             if (next_off >= read_end) queued_all = true;
             ahead.push_back(std::move(a));
