@@ -902,10 +902,15 @@ int bdx_bamdec_stats(const bdx_bamdec* d, uint64_t* compressed_bytes, uint64_t* 
     return BDX_OK;
 }
 
-int bdx_merge_decoded(bdx_ctx* c, bdx_bamdec* const* decs, int k, const uint8_t* src_file, const uint32_t* src_index, uint64_t n) {
+}  // extern "C"
+
+namespace {
+
+// the decoders' columns gathered into the context's store behind the `base` records it holds (0: the store is filled from empty)
+int gather_decoded(bdx_ctx* c, bdx_bamdec* const* decs, int k, const uint8_t* src_file, const uint32_t* src_index, uint64_t n, uint64_t base) {
     if (!c || !decs || k < 1 || k > kMaxGatherSources || (n && (!src_file || !src_index))) return BDX_EINVAL;
-    if (c->adopted || c->n) return fail(c, BDX_ESTATE, "the context already holds reads");
-    if (n > 0xFFFFFFFFull - 1024) return fail(c, BDX_ELIMIT, "one context holds at most 2^32 - 1 reads");
+    if (c->adopted) return fail(c, BDX_ESTATE, "the context's reads are not its own");
+    if (base + n > 0xFFFFFFFFull - 1024) return fail(c, BDX_ELIMIT, "one context holds at most 2^32 - 1 reads");
     HIPCHK(c, hipSetDevice(c->device));
     GatherSources src{};
     src.k = k;
@@ -922,7 +927,7 @@ int bdx_merge_decoded(bdx_ctx* c, bdx_bamdec* const* decs, int k, const uint8_t*
     }
     if (n != total) return fail(c, BDX_EINVAL, "the merge order does not cover the decoders' records");
     if (!n) return BDX_OK;
-    const int rc = alloc_reads(c, (size_t)n);
+    const int rc = alloc_reads(c, (size_t)(base + n));   // (keeps what the store holds)
     if (rc != BDX_OK) return rc;
     DevBuf d_file, d_index, d_err;
     struct Release { DevBuf &a, &b, &c; ~Release() { a.release(); b.release(); c.release(); } } release{d_file, d_index, d_err};
@@ -934,20 +939,37 @@ int bdx_merge_decoded(bdx_ctx* c, bdx_bamdec* const* decs, int k, const uint8_t*
     uint32_t err = 0;
     if (e == hipSuccess) {
         DstColumns dst{};
-        dst.tid = (int32_t*)c->d.tid; dst.pos = (int32_t*)c->d.pos; dst.mtid = (int32_t*)c->d.mtid; dst.mpos = (int32_t*)c->d.mpos;
-        dst.isize = (int32_t*)c->d.isize; dst.flag = (uint16_t*)c->d.flag; dst.qlen = (uint16_t*)c->d.qlen; dst.mapq = (uint8_t*)c->d.mapq;
-        dst.lib = (uint8_t*)c->d.lib; dst.bam = (uint8_t*)c->d.bam; dst.key = (uint64_t*)c->d.key; dst.check = (uint64_t*)c->d.check;
+        dst.tid = (int32_t*)c->d.tid + base; dst.pos = (int32_t*)c->d.pos + base; dst.mtid = (int32_t*)c->d.mtid + base; dst.mpos = (int32_t*)c->d.mpos + base;
+        dst.isize = (int32_t*)c->d.isize + base; dst.flag = (uint16_t*)c->d.flag + base; dst.qlen = (uint16_t*)c->d.qlen + base; dst.mapq = (uint8_t*)c->d.mapq + base;
+        dst.lib = (uint8_t*)c->d.lib + base; dst.bam = (uint8_t*)c->d.bam + base; dst.key = (uint64_t*)c->d.key + base;
+        dst.check = c->d.check ? (uint64_t*)c->d.check + base : nullptr;
         launch_kb_gather(src, d_file.as<uint8_t>(), d_index.as<uint32_t>(), n, dst, d_err.as<uint32_t>(), s);
         e = hipMemcpyAsync(&err, d_err.p, 4, hipMemcpyDeviceToHost, s);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     HIPCHK(c, e);
     if (err) return fail(c, BDX_EINVAL, "the merge order names a record that does not exist");
-    c->n = (size_t)n;
+    c->n = (size_t)(base + n);
     c->ran = false;
     c->k1_live = false;
-    c->key_segs.clear();
+    if (!base) c->key_segs.clear();
     return BDX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bdx_merge_decoded(bdx_ctx* c, bdx_bamdec* const* decs, int k, const uint8_t* src_file, const uint32_t* src_index, uint64_t n) {
+    if (c && c->n) return fail(c, BDX_ESTATE, "the context already holds reads");
+    return gather_decoded(c, decs, k, src_file, src_index, n, 0);
+}
+
+int bdx_append_decoded(bdx_ctx* c, bdx_bamdec* const* decs, int k, const uint8_t* src_file, const uint32_t* src_index, uint64_t n) {
+    if (!c) return BDX_EINVAL;
+    for (auto const& sg : c->key_segs)
+        if (sg.host) return fail(c, BDX_ESTATE, "the context holds batches whose name keys are still in the caller's memory (bdx_push)");
+    return gather_decoded(c, decs, k, src_file, src_index, n, c->n);
 }
 
 int bdx_bamdec_host_ms(const bdx_bamdec* d, float* out, int n) {

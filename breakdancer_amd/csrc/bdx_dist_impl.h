@@ -720,6 +720,9 @@ int bdx_dist_run(bdx_dist* d) {
         }
         DCTX(d, C, do_compact(C, 0, nullptr, true));
         trace("compaction");
+        // (the exchange counters and the error words of the later kernels: also on a rank without anomalous reads -- rank 0 checks the word
+        // k8_place_regions leaves whether or not it holds reads itself)
+        DHIP(d, hipMemsetAsync(T + o_cnt, 0, (size_t)world * 16 + 16, s));
         if (!na) { C->k4 = K4Arrays{}; return BDX_OK; }
         {
             uint32_t* up = UP + L.up_off;
@@ -732,7 +735,6 @@ int bdx_dist_run(bdx_dist* d) {
             for (int t = 0; t < ntids; ++t) { um[t] = (uint32_t)owner[t]; um[(size_t)ntids + t] = tidtab[(size_t)t * (1 + ncols)]; }
             um[(size_t)2 * ntids] = tidtab[(size_t)ntids * (1 + ncols)];
             DHIP(d, hipMemcpyAsync(T + o_owner, um, ((size_t)2 * ntids + 1) * 4, hipMemcpyHostToDevice, s));
-            DHIP(d, hipMemsetAsync(T + o_cnt, 0, (size_t)world * 16 + 16, s));
         }
         memset(H + L.first, 0, (size_t)ntids * 16);
         launch_k9_rebase(C->cp, &C->b_p1.as<Pass1>()->n_anom, na, nkeys, T + o_off, H + L.first, s);

@@ -311,12 +311,13 @@ int run(int argc, char** argv) {
             weight.resize(ntids, 0);
             std::vector<int> rank_of(ntids, 0);
             bdx_dist_plan(weight.data(), ntids, world, rank_of.data());
-            // One BAM with its index: every rank pulls the BGZF ranges of ITS chromosomes and decodes them on ITS GPU (bdx_bamdec_*), as the
-            // reference reads one chromosome through the index (io/RegionLimitedBamReader.hpp:43-71).  Without an index, with several
-            // files or with BDX_DECODE=host: the host producer decodes everything once and routes the records to the ranks.
+            // BAMs with their indexes: every rank pulls the BGZF ranges of ITS chromosomes and decodes them on ITS GPU (bdx_bamdec_*), as the
+            // reference reads one chromosome through the index (io/RegionLimitedBamReader.hpp:43-71); several files are merged per
+            // chromosome in the reference's order by a gather in HBM.  Without an index or with BDX_DECODE=host: the host producer
+            // decodes everything once and routes the records to the ranks.
             const char* dm = getenv("BDX_DECODE");
             bool on_device = false;
-            if (!(dm && !strcmp(dm, "host")) && cfg.num_bams() == 1) {
+            if (!(dm && !strcmp(dm, "host"))) {
                 bool unsupported = true;
                 n_reads = produce_sharded_on_device(cfg, (int)std::min(std::max(usable_cpus(), 2u), 32u), &targets, ranks, devices, rank_of, &unsupported);
                 on_device = !unsupported;

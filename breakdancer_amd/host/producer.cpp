@@ -1,5 +1,6 @@
 #include "producer.h"
 
+#include <algorithm>
 #include <cctype>
 #include <condition_variable>
 #include <deque>
@@ -789,28 +790,32 @@ void merge_order(const std::vector<const int32_t*>& tid, const std::vector<const
     }
 }
 
-// ONE BAM with its index, the chromosomes of one whole-genome run spread over ranks (bdx_dist_*): every rank's thread reads the BGZF
-// ranges of ITS chromosomes (the index says where they lie) and decodes them on ITS GPU, straight into the rank's context -- the
-// reference's answer to "one chromosome" is the same indexed seek (io/RegionLimitedBamReader.hpp:43-71: bam_index_load, bam_iter_query).
-// Nothing is decoded twice and no record crosses the host.  unsupported: no index (or not one file), nothing was done.
+// Indexed BAMs, the chromosomes of one whole-genome run spread over ranks (bdx_dist_*): every rank's thread reads the BGZF ranges of ITS
+// chromosomes (the index says where they lie) and decodes them on ITS GPU -- the reference's answer to "one chromosome" is the same indexed
+// seek (io/RegionLimitedBamReader.hpp:43-71: bam_index_load, bam_iter_query).  ONE file: straight into the rank's context.  SEVERAL files
+// (the tumour / normal pair): per chromosome one decoder per file over that file's range (the decoders are the rank's, armed again for every
+// chromosome), the merge order worked out from three columns as for one GPU (merge_order: BamMerger's queue, io/BamMerger.cpp:40-126),
+// one gather in HBM behind what the rank's store holds (bdx_append_decoded).  Nothing is decoded twice and no record crosses the host.
+// unsupported: a file without an index (or one that does not cover the header's sequences), nothing was done.
 size_t produce_sharded_on_device(const BamConfig& cfg, int threads, std::vector<std::string>* targets, const std::vector<bdx_dist*>& ranks,
                                  const std::vector<int>& devices, const std::vector<int>& rank_of, bool* unsupported) {
     *unsupported = true;
-    if (cfg.num_bams() != 1) return 0;
-    const std::string& path = cfg.bam_files()[0];
+    const size_t nb = cfg.num_bams();
+    if (nb < 1 || nb > 16) return 0;
     std::vector<std::string> names;
     struct Span { size_t begin = 0, end = 0; bool has = false; };
-    std::vector<Span> span;
-    {
-        ColumnReader hdr(path, 1, nullptr);
-        names = hdr.target_names();
-        span.resize(names.size());
+    std::vector<std::vector<Span>> span(nb);
+    for (size_t b = 0; b < nb; ++b) {
+        ColumnReader hdr(cfg.bam_files()[b], 1, nullptr);
+        if (b == 0) names = hdr.target_names();
+        else if (hdr.target_names() != names) return 0;   // (files that disagree about the sequences: the host reader's error message)
+        span[b].resize(names.size());
         bool any_index = false;
         for (size_t t = 0; t < names.size(); ++t) {
             bool empty = false;
-            span[t].has = hdr.index_span((int)t, &span[t].begin, &span[t].end, &empty);
-            if (span[t].has || empty) any_index = true;
-            if (!span[t].has && !empty) return 0;   // (no index, or one that does not cover the header's sequences: the host producer takes the file)
+            span[b][t].has = hdr.index_span((int)t, &span[b][t].begin, &span[b][t].end, &empty);
+            if (span[b][t].has || empty) any_index = true;
+            if (!span[b][t].has && !empty) return 0;   // (no index, or one that does not cover the header's sequences: the host producer takes the files)
         }
         if (!any_index) return 0;
     }
@@ -821,36 +826,75 @@ size_t produce_sharded_on_device(const BamConfig& cfg, int threads, std::vector<
     std::vector<int> gave_up(world, 0);
     std::vector<std::thread> th;
     const int per = std::max(2, threads / std::max(1, world));
+    const bool timing = getenv("BDX_TIMING") != nullptr;
     for (int r = 0; r < world; ++r)
         th.emplace_back([&, r] {
             try {
                 size_t bytes_mine = 0;
-                for (size_t t = 0; t < names.size(); ++t)
-                    if (rank_of[t] == r && span[t].has) bytes_mine += span[t].end - span[t].begin;
+                std::vector<size_t> largest(nb, 0);
+                for (size_t b = 0; b < nb; ++b)
+                    for (size_t t = 0; t < names.size(); ++t)
+                        if (rank_of[t] == r && span[b][t].has) {
+                            bytes_mine += span[b][t].end - span[b][t].begin;
+                            largest[b] = std::max(largest[b], span[b][t].end - span[b][t].begin);
+                        }
+                const size_t largest_any = *std::max_element(largest.begin(), largest.end());
                 bool reserved = false;
-                size_t largest = 0;
-                for (size_t t = 0; t < names.size(); ++t)
-                    if (rank_of[t] == r && span[t].has) largest = std::max(largest, span[t].end - span[t].begin);
-                bdx_bamdec* dec = nullptr;   // ONE decoder per rank, armed again for every chromosome
-                struct Retire { bdx_bamdec*& d; ~Retire() { retire(d); } } retire_guard{dec};
+                std::vector<bdx_bamdec*> decs(nb, nullptr);   // ONE decoder per rank and file, armed again for every chromosome
+                struct Retire { std::vector<bdx_bamdec*>& d; ~Retire() { for (bdx_bamdec* x : d) retire(x); } } retire_guard{decs};
+                std::vector<std::vector<int32_t>> tid(nb), pos(nb);
+                std::vector<std::vector<uint16_t>> flag(nb);
+                std::vector<uint8_t> src_file;
+                std::vector<uint32_t> src_index;
                 for (size_t t = 0; t < names.size(); ++t) {
-                    if (rank_of[t] != r || !span[t].has) continue;
+                    if (rank_of[t] != r) continue;
+                    std::vector<size_t> files;   // the files that hold records of this chromosome
+                    for (size_t b = 0; b < nb; ++b)
+                        if (span[b][t].has) files.push_back(b);
+                    if (files.empty()) continue;
                     bdx_ctx* c = bdx_dist_chromosome(ranks[r], (int)t);
                     if (!c) throw std::runtime_error(std::string("bdx_dist_chromosome: ") + bdx_dist_last_error(ranks[r]));
                     if (bdx_use_name_check(c, 1) != BDX_OK) throw std::runtime_error("bdx_use_name_check");
                     if (!reserved) {   // the rank's store for ALL of its chromosomes (a record takes 50-150 bytes of BAM): no growing between them
                         // (plus what the decoder must assume of a batch in flight before its records are counted: 36 bytes is the smallest record)
-                        if (bdx_reserve(c, std::min<size_t>(bytes_mine / 48 + largest * 8 / 36 + ((size_t)1 << 20), 0xFFFFFFFFull - 1024)) != BDX_OK) throw std::runtime_error("bdx_reserve");
+                        if (bdx_reserve(c, std::min<size_t>(bytes_mine / 48 + largest_any * 8 / 36 + ((size_t)1 << 20), 0xFFFFFFFFull - 1024)) != BDX_OK) throw std::runtime_error("bdx_reserve");
                         reserved = true;
                     }
                     bool un = false;
                     const auto tc = std::chrono::steady_clock::now();
-                    // (the decoder reports the store's record count: the rank's total so far)
-                    n_of[r] = decode_on_device(cfg, 0, "", per, nullptr, c, devices[r], &un, nullptr, (int)t, span[t].end - span[t].begin, &dec, largest);
-                    if (getenv("BDX_TIMING"))
-                        fprintf(stderr, "[bdx timing] rank %d: %s (%zu bytes of the file) in %.3f s\n", r, names[t].c_str(), span[t].end - span[t].begin,
+                    if (nb == 1) {
+                        // (the decoder reports the store's record count: the rank's total so far)
+                        n_of[r] = decode_on_device(cfg, 0, "", per, nullptr, c, devices[r], &un, nullptr, (int)t, span[0][t].end - span[0][t].begin, &decs[0], largest[0]);
+                        if (un) { gave_up[r] = 1; return; }
+                    } else {
+                        std::vector<size_t> n;
+                        std::vector<bdx_bamdec*> use;
+                        std::vector<const int32_t*> ptid, ppos;
+                        std::vector<const uint16_t*> pflag;
+                        size_t total = 0;
+                        for (size_t b : files) {
+                            const size_t nr = decode_on_device(cfg, b, "", per, nullptr, nullptr, devices[r], &un, nullptr, (int)t, span[b][t].end - span[b][t].begin, &decs[b], largest[b]);
+                            if (un) { gave_up[r] = 1; return; }
+                            tid[b].resize(nr); pos[b].resize(nr); flag[b].resize(nr);
+                            bdx_batch_buf out{};
+                            out.tid = tid[b].data(); out.pos = pos[b].data(); out.flag = flag[b].data();
+                            out.capacity = nr;
+                            const int frc = bdx_bamdec_fetch(decs[b], 0, nr, &out);
+                            if (frc != BDX_OK) throw std::runtime_error(std::string("bdx_bamdec_fetch: ") + bdx_strerror(frc) + " (" + bdx_bamdec_last_error(decs[b]) + ")");
+                            n.push_back(nr); use.push_back(decs[b]);
+                            ptid.push_back(tid[b].data()); ppos.push_back(pos[b].data()); pflag.push_back(flag[b].data());
+                            total += nr;
+                        }
+                        // (BamMerger's order among the files that hold the chromosome: a file without records of it is not in the queue at that point either)
+                        merge_order(ptid, ppos, pflag, n, src_file, src_index, std::max(1, per));
+                        const int mrc = bdx_append_decoded(c, use.data(), (int)use.size(), src_file.data(), src_index.data(), total);
+                        if (mrc == BDX_ELIMIT) { gave_up[r] = 1; return; }
+                        if (mrc != BDX_OK) throw std::runtime_error(std::string("bdx_append_decoded: ") + bdx_strerror(mrc) + " (" + bdx_last_error(c) + ")");
+                        n_of[r] += total;
+                    }
+                    if (timing)
+                        fprintf(stderr, "[bdx timing] rank %d: %s (%zu file%s) in %.3f s\n", r, names[t].c_str(), files.size(), files.size() == 1 ? "" : "s",
                                 std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count());
-                    if (un) { gave_up[r] = 1; return; }
                 }
             } catch (std::exception const& e) {
                 errs[r] = e.what();

@@ -453,6 +453,10 @@ int bdx_bamdec_stats(const bdx_bamdec* d, uint64_t* compressed_bytes, uint64_t* 
  * caller works out the merged order and hands it over as a permutation: record i of the context's store = record src_index[i] of
  * decoder src_file[i].  The gather runs in HBM; the context must hold no reads yet and then stands as after bdx_push of the merged stream. */
 int bdx_merge_decoded(bdx_ctx* ctx, bdx_bamdec* const* decs, int k, const uint8_t* src_file, const uint32_t* src_index, uint64_t n);
+/* The same gather BEHIND what the context's store holds (a rank of a sharded run takes its chromosomes one after the other: every chromosome
+ * of a several-BAM configuration is decoded per file through the files' indexes, io/RegionLimitedBamReader.hpp:43-71, and merged in
+ * BamMerger's order, io/BamMerger.cpp:40-126).  The store keeps its records; it must not hold batches whose name keys are still the caller's. */
+int bdx_append_decoded(bdx_ctx* ctx, bdx_bamdec* const* decs, int k, const uint8_t* src_file, const uint32_t* src_index, uint64_t n);
 /* milliseconds the feeding thread spent inside the decoder so far, by cause: [0] waiting for a staging buffer's copy, [1] pinning
  * staging memory, [2] waiting for a batch slot, [3] sizing a slot's buffers, [4] the pieces' copy calls, [5] launching batches
  * (includes [6]), [6] launching record stages, [7] feeding the classifier; and two marks, ms after the decoder's creation (or its last

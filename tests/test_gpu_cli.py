@@ -96,15 +96,19 @@ def test_cli_restored_statistics_are_the_ones_used(tmp_path):
 
 
 @pytest.mark.parametrize("gpus", ["0,0", "0,0,0"])
-@pytest.mark.parametrize("args,fn", [([], "expected_output"), (["-h"], "expected_output.af")])
+@pytest.mark.parametrize("args,fn", [([], "expected_output"), (["-h"], "expected_output.af"), (["-a"], "expected_output.cn_per_lib"), (["-a", "-h"], "expected_output.cn_per_lib.af")])
 def test_cli_sharded_over_ranks_reproduces_the_golden_output(gpus, args, fn, tmp_path):
     """BDX_GPUS: one whole-genome run with the chromosomes spread over several ranks (bdx_dist_*; here the ranks are
     threads that share the one GPU) must print what the single-GPU run prints -- the -g BED dump and the -d FASTQ dumps of
     the supporting reads included (integration-test/breakdancer_test.py:117-146)"""
     p = subprocess.run([EXE] + args + ["inv_del_bam_config"], cwd=CWD, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                       env=dict(os.environ, BDX_GPUS=gpus))
+                       env=dict(os.environ, BDX_GPUS=gpus, BDX_TIMING="1"))
     assert p.returncode == 0, p.stderr.decode()
     assert filter_cmd_lines(p.stdout.decode()) == filter_cmd_lines(open(os.path.join(CWD, fn)).read())
+    # the two indexed BAMs of the reference's configuration: every rank decodes its chromosomes' ranges of BOTH files on its GPU and merges them there
+    assert "on its own GPU" in p.stderr.decode() and "(2 files)" in p.stderr.decode(), p.stderr.decode()
+    if args:
+        return
     bed, prefix = str(tmp_path / "out.bed"), str(tmp_path / "actual")
     p = subprocess.run([EXE, "-g", bed, "-d", prefix, "inv_del_bam_config"], cwd=CWD, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        env=dict(os.environ, BDX_GPUS=gpus))

@@ -20,7 +20,7 @@ FLAGSETS = [([], dict()), (["-a", "-h"], dict(cn_lib=1, print_af=1)), (["-t"], d
             (["-m", "900", "-x", "3", "-c", "2", "-f"], dict(max_sd=900, seq_coverage_lim=3, cut_sd=2, fisher=1))]
 
 
-def write_case(tmp, streams, targets, rng):
+def write_case(tmp, streams, targets, rng, index=False):
     from breakdancer_amd.bamwrite import write_bam_records
     for b, (fn, st) in enumerate(zip(("a.bam", "b.bam"), streams)):
         recs = []
@@ -35,7 +35,7 @@ def write_case(tmp, streams, targets, rng):
                 extra = dict(recs[-1])
                 extra["flag"] = int(extra["flag"]) | (0x100 if rng.random() < 0.5 else 0x800)
                 recs.append(extra)
-        write_bam_records(os.path.join(tmp, fn), recs, targets, rgs=("rg1", "rg2", "rg3"), seed=b)
+        write_bam_records(os.path.join(tmp, fn), recs, targets, rgs=("rg1", "rg2", "rg3"), seed=b, index=index)
 
 
 @pytest.mark.parametrize("seed", range(10))
@@ -246,6 +246,46 @@ def test_cli_sharded_run_decodes_every_ranks_chromosomes_on_its_own_gpu(seed, tm
         assert marker in p.stderr.decode(), (label, p.stderr.decode())
         assert filter_cmd_lines(p.stdout.decode()) == want, (label, args, p.stderr.decode())
     # -g / -d through the sharded device reader: the dumps' stream indices are positions in the merged stream of the whole file
+    outs = {}
+    for label, env in (("sharded", dict(BDX_GPUS=gpus)), ("one", dict())):
+        d = tmp_path / label
+        d.mkdir()
+        p = subprocess.run([EXE, "-y", "-1", "-g", str(d / "out.bed"), "-d", str(d / "fq"), "cfg"], cwd=str(tmp_path), stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr.decode()
+        outs[label] = {f: open(os.path.join(str(d), f), "rb").read() for f in sorted(os.listdir(str(d)))}
+    assert outs["sharded"] == outs["one"] and outs["one"]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_cli_sharded_run_of_two_indexed_bams_decodes_and_merges_on_the_ranks_gpus(seed, tmp_path):
+    """BDX_GPUS with TWO indexed BAMs (the tumour / normal shape of configs[4]): per rank and chromosome one decoder per file over that file's
+    range of the .bai, BamMerger's order from three columns (ties between the files included: the fuzz cases put reads of both files on the same
+    positions and strands), one gather behind what the rank's store holds -- the oracle's text, the single-GPU run's, the host producer's routing"""
+    rng = np.random.default_rng(140 + seed)
+    cfg, streams, targets = make_case(940 + seed, n_pairs=int(rng.integers(1500, 5000)))
+    write_case(str(tmp_path), streams, targets, rng, index=True)
+    assert os.path.exists(str(tmp_path / "a.bam.bai")) and os.path.exists(str(tmp_path / "b.bam.bai"))
+    (tmp_path / "cfg").write_text(cfg)
+    # (positions shared by the two files exist in this case: the order of ties is on trial)
+    a, b = streams[0], streams[1]
+    assert set(zip(a["tid"].tolist(), a["pos"].tolist())) & set(zip(b["tid"].tolist(), b["pos"].tolist()))
+    gpus = "0,0,0" if seed % 2 else "0,0"
+    for args, kw in (FLAGSETS[1], FLAGSETS[(2 * seed) % len(FLAGSETS)]):
+        if "-o" in args:
+            args, kw = [], dict()
+        want = filter_cmd_lines(oracle_case(cfg, streams, targets, make_opts(score_threshold=-1, **kw)).text)
+        for label, env, marker in (("device", dict(BDX_GPUS=gpus, BDX_TIMING="1"), "on its own GPU"),
+                                   ("device-small-pieces", dict(BDX_GPUS=gpus, BDX_TIMING="1", BDX_BAM_PIECE_BYTES="100000", BDX_BAM_BATCH_BLOCKS="3"), "on its own GPU"),
+                                   ("host-routing", dict(BDX_GPUS=gpus, BDX_TIMING="1", BDX_DECODE="host"), "routed to the ranks"),
+                                   ("one-gpu", dict(BDX_TIMING="1"), "2 files decoded on the GPU")):
+            p = subprocess.run([EXE, "-y", "-1"] + args + ["cfg"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+            assert p.returncode == 0, (label, p.stderr.decode())
+            assert marker in p.stderr.decode(), (label, p.stderr.decode())
+            if label.startswith("device"):
+                assert "(2 files)" in p.stderr.decode(), p.stderr.decode()
+            assert filter_cmd_lines(p.stdout.decode()) == want, (label, args, p.stderr.decode())
+    # -g / -d: the supporting reads' stream indices are positions in the merged stream of both files
     outs = {}
     for label, env in (("sharded", dict(BDX_GPUS=gpus)), ("one", dict())):
         d = tmp_path / label
