@@ -264,7 +264,6 @@ int allreduce_host(bdx_dist* d, std::vector<uint64_t>& v, hipStream_t s) {
 int dist_create_common(bdx_dist** out, const bdx_opts* opts, const bdx_lib* libs, int nlibs, int nbams, int ntids, int w0, int device,
                        std::unique_ptr<Comm> comm) {
     if (!out || !opts || !libs || nlibs < 1 || nbams < 1 || ntids < 1) return BDX_EINVAL;
-    if (opts->min_len < 0) return BDX_ELIMIT;  // (a negative -s registers a read-less region 0: single-context runs only)
     if (comm->world > kMaxRanks || ntids >= (1 << 24) - 1) return BDX_ELIMIT;
     bdx_dist* d = new (std::nothrow) bdx_dist;
     if (!d) return BDX_ENOMEM;
@@ -980,7 +979,9 @@ int bdx_dist_run(bdx_dist* d) {
     };
 
     // ---- the joins (own reads + foreign entries), the name census, the pair groups per region.  C6: taint bytes, window lengths ----
-    const bool force_host = (rank == 0 ? U->host_walk_only : false) || C->host_walk_only || d->opts.min_read_pair < 1;
+    // (a negative -s: shifted region ids are the read-level walk's business below; the pair model's device walk is not enqueued for them, as in bdx_run)
+    const bool ph_opt = 0 > d->opts.min_len && 0.0f < (float)d->opts.seq_coverage_lim;
+    const bool force_host = (rank == 0 ? U->host_walk_only : false) || C->host_walk_only || d->opts.min_read_pair < 1 || ph_opt;
     auto t_x1 = std::chrono::steady_clock::now();
     phase([&]() -> int {
         if (nnrecv) {   // the census of the names this rank owns: on the second stream, beside the joins (its verdict is read at the next all-reduce)
@@ -1052,7 +1053,11 @@ int bdx_dist_run(bdx_dist* d) {
     rc = exchange(v5);
     if (rc != BDX_OK) return rc;
     // some rank met a read name more than twice -- or the caller wants the reads behind every SV, which only the read-level walk knows
-    const bool replay = v5[(size_t)world] != 0 || want_support != 0;
+    // ... or -s is negative: the very first anomalous read of the genome then registers a read-less region 0 (BreakDancer.cpp:216-231,
+    // 244-252; bdx_run's `ph`), every real region's id shifts by one and with it the flush cadence -- the read-level walk knows how
+    // (ReadWalkInput::phantom), the pair model's kernels do not
+    const uint32_t ph = (na_all && ph_opt) ? 1u : 0u;
+    const bool replay = v5[(size_t)world] != 0 || want_support != 0 || ph != 0;
 
 
     // ---- a read name seen more than twice (clashing names across merged files): the pair model does not hold, and the reference's
@@ -1095,6 +1100,7 @@ int bdx_dist_run(bdx_dist* d) {
                 if (t >= (uint32_t)ntids || at[t] >= base[(size_t)(t + 1) * tw]) return dfail(d, BDX_EINTERNAL, "compact records of the gather do not add up");
                 const size_t o = (size_t)at[t]++;
                 key[o] = w0; reg[o] = (int32_t)(uint32_t)w1; meta[o] = (uint32_t)(w1 >> 32); isz[o] = (int32_t)(uint32_t)w2;
+                if (ph && reg[o] >= 0) reg[o] += (int32_t)ph;   // (the read-less region 0 in front: replay_reads does the same)
                 if (with_check) chk[o] = rp_host[i * kw + 3];
                 if (want_support) sidx[o] = read_base[t] + rp_host[i * kw + 4];
             }
@@ -1103,8 +1109,8 @@ int bdx_dist_run(bdx_dist* d) {
                 std::vector<uint64_t> seen(world, 0), adj(ntids, 0);
                 for (int t = 0; t < ntids; ++t)
                     if (owner[t] >= 0) { adj[t] = base[(size_t)t * tw] - seen[owner[t]]; seen[owner[t]] += tot(t, 0); }
-                decode_regions(U, regs, pk, (uint32_t)NR, 0, false);
-                for (size_t r = 0; r < NR; ++r) U->regions[r].first += (uint32_t)adj[U->regions[r].tid];
+                decode_regions(U, regs, pk, (uint32_t)NR, ph, false);
+                for (size_t r = ph; r < NR + ph; ++r) U->regions[r].first += (uint32_t)adj[U->regions[r].tid];
             }
             memset(&U->counts, 0, sizeof(U->counts));
             U->counts.n_regions = (uint32_t)NR;
@@ -1112,7 +1118,7 @@ int bdx_dist_run(bdx_dist* d) {
             if (with_check) unify_names(key.data(), chk.data(), (size_t)na_all);
             std::vector<uint32_t> sup;
             U->collect_support = want_support != 0;
-            DCTX(d, U, replay_arrays(U, (uint32_t)na_all, key.data(), reg.data(), meta.data(), isz.data(), 0, want_support ? &sup : nullptr));
+            DCTX(d, U, replay_arrays(U, (uint32_t)na_all, key.data(), reg.data(), meta.data(), isz.data(), ph, want_support ? &sup : nullptr));
             if (want_support) {   // compact indices -> indices in the merged stream, and the reads' flags
                 U->sup_idx.resize(sup.size());
                 U->sup_flag.resize(sup.size());

@@ -193,8 +193,6 @@ class ShardedRun:
 
     def __init__(self, opts, libs, nbams, max_read_window_size, comm=None, device=0, ntids=None, world=1, support=False):
         from . import dist as D
-        if opts.min_len < 0:
-            raise BdxError("staged runs do not support a negative -s")
         self.opts, self.libs, self.nbams, self.w0 = opts, list(libs), nbams, max_read_window_size
         self.comm, self.device, self.ntids, self.world = comm, device, ntids, (comm.world if comm else world)
         self.D = D

@@ -344,8 +344,9 @@ int bdx_stage_walk(bdx_ctx* ctx, size_t nregions, const bdx_region_rec* regions,
  *   bdx_dist_owner           the rank that takes the census of a name key (the routing rule of the name census; the inter-chromosomal
  *                            join records travel to the rank that holds the LATER of their two chromosomes)
  *   bdx_dist_plan            chromosomes -> ranks by longest-processing-time packing on `weight` (reads or length)
- * Not supported in sharded runs: a negative -s.  (The -g/-d support lists -- bdx_dist_set_collect_support -- and read names that
- * occur more than twice are served: the compact records are gathered and rank 0 walks them read by read.) */
+ * The -g/-d support lists (bdx_dist_set_collect_support), read names that occur more than twice and a negative -s (the read-less region 0
+ * of BreakDancer.cpp:244-264, registered once for the genome) are served by the read-level walk: the compact records are gathered and
+ * rank 0 walks them read by read. */
 typedef struct bdx_dist bdx_dist;
 typedef struct bdx_unique_id { char internal[128]; } bdx_unique_id;
 int bdx_dist_unique_id(bdx_unique_id* out);

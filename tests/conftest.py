@@ -11,6 +11,9 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # no test may sit on the GPU box for ever (a kernel that never ends, ranks that wait for each other): pytest-timeout where it is installed
+    if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
+        config.option.timeout = 900
 
 
 @pytest.fixture(scope="session", autouse=True)

@@ -34,6 +34,20 @@ def test_staged_whole_genome_equals_single_run(seed):
         assert dev_total[0] > 100   # the components inside one rank go through the device walk (K6) where they live, not only rank 0's host walk
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_sharded_run_with_a_negative_min_len(seed):
+    """-s -1: the genome's very first anomalous read registers a read-less region 0 (BreakDancer.cpp:244-264, the reference accepts any -s,
+    common/Options.cpp:44-74) -- once, on whichever rank holds the first chromosome with anomalous reads; every real region id shifts by one
+    and the flush cadence with it.  1-3 ranks against the oracle and against the single context"""
+    cfg, streams, targets = make_case(1200 + seed)
+    for o in (dict(min_len=-1), dict(min_len=-5, buffer_size=2), dict(min_len=-1, transchr_rearrange=1))[seed % 3:][:2]:
+        run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1, **o))
+        assert run.n_regions > 1
+        for world in (1, 2, 3):
+            util = sharded_from_oracle(run, world=world)
+            compare(run, util, check_cls=False)
+
+
 def test_staged_chr21_all_sequences():
     run = load_chr21(make_opts()).run()
     for world in (1, 2):
@@ -129,8 +143,6 @@ def test_sharded_run_with_read_names_seen_more_than_twice(seed):
     streams = clash_names(streams, seed, frac=0.02 + 0.02 * (seed % 4))
     replayed = 0
     for i, o in enumerate((osets[seed % len(osets)], dict(transchr_rearrange=1, min_read_pair=1), dict(min_read_pair=1, buffer_size=1))):
-        if o.get("min_len", 0) < 0:
-            continue   # (a negative -s registers a read-less region 0: single-context runs only)
         run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1, **o))
         util = sharded_from_oracle(run, world=1 + (seed + i) % 3)
         compare(run, util, check_cls=False)
