@@ -62,7 +62,7 @@ def parse():
                     help="hg38 lengths x this for the genome leg (default N/8: 116 M records per GPU at every N -- the whole genome of configs[2] / [3] at N = 8 -- "
                          "plus, for N > 1, the fixed 1/8 spread over the N ranks)")
     ap.add_argument("--no-sharded-cli", action="store_true", help="skip config.timings.bam_to_table_sharded (BDX_GPUS on one indexed genome BAM)")
-    ap.add_argument("--sharded-cli-fraction", type=float, default=1.0 / 64, help="hg38 lengths x this for that BAM (default 1/64: 14.5 M records)")
+    ap.add_argument("--sharded-cli-fraction", type=float, default=None, help="hg38 lengths x this for that BAM (default N/64: 14.5 M records, ~2 GB of BAM, per rank)")
     ap.add_argument("--no-genome-bam", action="store_true", help="skip config.timings.bam_to_table_genome (one GPU's share of a 30x genome as ONE BAM through the CLI)")
     ap.add_argument("--genome-bam-fraction", type=float, default=1.0 / 8, help="hg38 lengths x this for that BAM (default 1/8: 116 M records, 15.9 GB)")
     ap.add_argument("--no-overlap", action="store_true", help="skip the three-contexts-in-flight measurement (config.overlapped_contexts)")
@@ -470,7 +470,7 @@ def time_bam_cli_sharded(td, n_gpus_visible, fraction=1.0 / 64):
     open(cfg, "w").write(CFG_LINE % "genome.bam")
     gpus = ",".join(str(i) for i in range(n_gpus_visible)) if n_gpus_visible > 1 and not SHARED_GPU_TEST else "0,0"
 
-    def run(env_extra):
+    def run(env_extra, cfg=cfg, n=n):
         env = dict(os.environ, BDX_TIMING="1", BDX_FOREGROUND="1", **env_extra)
         best = None
         for _ in range(3):
@@ -498,6 +498,47 @@ def time_bam_cli_sharded(td, n_gpus_visible, fraction=1.0 / 64):
            "note": "bin/breakdancer-max on ONE indexed 24-chromosome BAM, one process from start to exit (BDX_FOREGROUND=1), best of 3: the "
                    "chromosomes spread over the ranks of BDX_GPUS, each rank pulling its chromosomes' BGZF ranges through the .bai and decoding them "
                    "on its GPU" + ("; ONE GPU is visible here, the two ranks share it: this shows the path, not a speed-up" if n_gpus_visible <= 1 else "")}
+    # the tumour / normal shape of configs[4]: TWO indexed BAMs (20x + 10x of the same genome, a library each) with -a -h -- per rank and chromosome
+    # one decoder per file, BamMerger's order, one gather in HBM
+    try:
+        d2 = make_genome(lengths, coverage=(20.0, 10.0), seed=22, libs=((400.0, 30.0), (350.0, 40.0)), lib_bam=(0, 1), n_translocations=max(20, int(600 * fraction * 64)))
+        names = ["chr%d" % (i + 1) for i in range(len(lengths))]
+        sizes = 0
+        for b, fn in enumerate(("tumour.bam", "normal.bam")):
+            m = d2["bam"] == b
+            write_bam(os.path.join(td, fn), {k: v[m] for k, v in d2.items()}, names, rg="rg%d" % (b + 1), seed=7 + b, index=True)
+            sizes += os.path.getsize(os.path.join(td, fn))
+        cfg2 = os.path.join(td, "gcfg2")
+        with open(cfg2, "w") as f:
+            for b, (fn, (mean, sd)) in enumerate(zip(("tumour.bam", "normal.bam"), ((400.0, 30.0), (350.0, 40.0)))):
+                f.write("readgroup:rg%d\tplatform:illumina\tmap:%s\treadlen:100.00\tlib:lib%d\tlower:%.2f\tupper:%.2f\tmean:%.2f\tstd:%.2f\n"
+                        % (b + 1, fn, b + 1, mean - 3 * sd, mean + 3 * sd, mean, sd))
+        n2 = len(d2["tid"])
+
+        def run2(env_extra):
+            env = dict(os.environ, BDX_TIMING="1", BDX_FOREGROUND="1", **env_extra)
+            best = None
+            for _ in range(2):
+                time.sleep(1.0)
+                t0 = time.perf_counter()
+                p = subprocess.run([os.path.join(ROOT, "bin", "breakdancer-max"), "-a", "-h", cfg2], cwd=td, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
+                dt = time.perf_counter() - t0
+                if p.returncode != 0:
+                    return {"error": p.stderr.decode()[-400:]}
+                rows = [line for line in p.stdout.splitlines() if line and not line.startswith(b"#")]
+                if best is None or dt < best[0]:
+                    best = (dt, rows, p.stderr.decode())
+            return {"seconds": best[0], "_rows": best[1], "_err": best[2]}
+        sh2, one2 = run2({"BDX_GPUS": gpus}), run2({})
+        if "error" in sh2 or "error" in one2:
+            out["two_files"] = {"error": sh2.get("error") or one2.get("error")}
+        else:
+            out["two_files"] = {"seconds": sh2["seconds"], "value": (n2 / 2) / sh2["seconds"], "unit": "read-pairs/s", "sv_rows": len(sh2["_rows"]), "records": n2, "bam_bytes": sizes,
+                                "every_rank_decoded_on_its_gpu": "on its own GPU" in sh2["_err"] and "(2 files)" in sh2["_err"], "same_table_as_one_gpu": sh2["_rows"] == one2["_rows"],
+                                "one_gpu": {"seconds": one2["seconds"], "value": (n2 / 2) / one2["seconds"], "unit": "read-pairs/s"},
+                                "note": "-a -h on two indexed BAMs (20x + 10x, a library each): every rank decodes its chromosomes' ranges of BOTH files on its GPU and merges them there"}
+    except Exception as e:  # noqa: BLE001
+        out["two_files"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     return out
 
 
@@ -512,7 +553,7 @@ GENOME_FRACTION = 1.0 / 8
 LIBS4 = ((400.0, 30.0), (350.0, 40.0), (500.0, 50.0), (300.0, 25.0))
 
 
-def genome_leg(rank, world, local, dist, out, fraction=None, translocations=5000):
+def genome_leg(rank, world, local, dist, out, fraction=None, translocations=5000, steps=0, warmup=0):
     """configs[2] and configs[3] as ONE sharded run each over the N ranks of this launch: hg38-shaped genome, 4 libraries, 30x,
     chromosomes dealt to the ranks by bdx_dist_plan (longest processing time first, on sequence length); every rank synthesises
     and loads its own chromosomes, then all call bdx_dist_run (csrc/bdx_dist_impl.h: one launch sequence per rank over all of its
@@ -611,6 +652,30 @@ def genome_leg(rank, world, local, dist, out, fraction=None, translocations=5000
                 if it == 0:
                     first_phases = ranks[0].phases()
                     first_ms_total = ranks[0].exchange()["ms_total"]
+            timed = None
+            if steps and label == "default_options":   # N > 1: the benchmark line's own K steps -- one step = one bdx_dist_run over the loaded genome
+                for _ in range(warmup):
+                    if threads_backend:
+                        D.run_threads(ranks)
+                    else:
+                        ranks[0].run(release=False)
+                if threads_backend:
+                    torch.cuda.synchronize()
+                else:
+                    barrier()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    if threads_backend:
+                        res = D.run_threads(ranks)
+                    else:
+                        ranks[0].run(release=False)
+                if threads_backend:
+                    torch.cuda.synchronize()
+                    timed = time.perf_counter() - t0
+                else:
+                    barrier()
+                    timed = allmax(time.perf_counter() - t0)
+                    res = ranks[0].result()
             gc.enable()
             for run in ranks:
                 run.release_inputs()   # (the Python side's references to the loaded arrays: not part of the run)
@@ -636,6 +701,10 @@ def genome_leg(rank, world, local, dist, out, fraction=None, translocations=5000
                                               "note": "what only rank 0 does (second run): the merge of the ranks' tables and its host walk of the "
                                                       "components that span ranks or are too large for the device walk"},
                                "load_and_prepare_seconds_untimed": load_s}
+                if timed is not None:
+                    legs[label]["timed_steps"] = {"steps": steps, "warmup": warmup, "seconds": timed, "ms_per_step": timed / steps * 1e3,
+                                                  "value": total / 2 * steps / timed, "unit": "read-pairs/s",
+                                                  "note": "K runs of bdx_dist_run on the loaded handles between two barriers, max over ranks: the N > 1 line's `value`"}
             for run in ranks:
                 run.close()
         single = None
@@ -831,7 +900,7 @@ def main():
 
         def guarded():
             try:
-                genome_leg(rank, world, local, dist, exchange, fraction=a.genome_fraction)
+                genome_leg(rank, world, local, dist, exchange, fraction=a.genome_fraction, steps=a.steps if world > 1 else 0, warmup=a.warmup)
             except Exception as e:  # noqa: BLE001
                 exchange["error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
         th = threading.Thread(target=guarded, daemon=True)
@@ -857,7 +926,7 @@ def main():
         if rank == 0:
             try:
                 with tempfile.TemporaryDirectory(prefix="bdx_bench_sh_") as td_sh:
-                    sharded_cli = time_bam_cli_sharded(td_sh, world, a.sharded_cli_fraction)
+                    sharded_cli = time_bam_cli_sharded(td_sh, world, a.sharded_cli_fraction if a.sharded_cli_fraction is not None else world / 64.0)
             except Exception as e:  # noqa: BLE001
                 sharded_cli = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         dist.barrier(group=host_group) if host_group is not None else dist.barrier()
@@ -915,7 +984,7 @@ def main():
                     timings["bam_to_table"]["bam_write_s_untimed"] = bam_write_s
                     if not a.no_sharded_cli:
                         try:
-                            timings["bam_to_table_sharded"] = time_bam_cli_sharded(td, torch.cuda.device_count(), a.sharded_cli_fraction)
+                            timings["bam_to_table_sharded"] = time_bam_cli_sharded(td, torch.cuda.device_count(), a.sharded_cli_fraction if a.sharded_cli_fraction is not None else 1.0 / 64)
                         except Exception as e:  # noqa: BLE001
                             timings["bam_to_table_sharded"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
                 if not a.no_cpu_baseline:
@@ -965,6 +1034,23 @@ def main():
                                         "achieved": value / world * PATH_BYTES_PER_PAIR / 1e9,
                                         "frac": value / world * PATH_BYTES_PER_PAIR / 1e9 / HBM_PEAK_GBS}},
         }
+        ts = exchange.get("default_options", {}).get("timed_steps") if world > 1 else None
+        if ts:
+            # N > 1: the line is about the path that SHARDS -- configs[2], one whole-genome run over the N ranks (bdx_dist_run: chromosomes
+            # dealt to the ranks, all-reduces of the statistics, the all-to-all of the inter-chromosomal join records), N/8 of the genome
+            # so that every GPU holds what one of eight would (weak scaling); N replicas of configs[1] scale by construction and are kept as a note
+            out["config"]["per_rank_replicas"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "unit": "read-pairs/s", "workload": out["config"]["workload"],
+                                                  "note": "configs[1] replicated on every rank, no data-path collective (the N = 1 line's workload): linear by construction"}
+            out["value"] = ts["value"]
+            out["ms_per_step"] = ts["ms_per_step"]
+            out["metric"] = "read-pairs/s, records resident in HBM -> scored SV table, ONE whole-genome run sharded by chromosome over the N GPUs (config.genome; per-GPU work fixed)"
+            out["config"]["workload"] = ("configs[2]: " + exchange.get("workload", "") + "; %d records (%s per rank), HBM-resident; one timed step = one bdx_dist_run over all ranks"
+                                         % (exchange.get("reads", 0), "/".join(str(x) for x in exchange.get("reads_per_rank", []))))
+            out["config"]["sharding"] = "chromosomes -> ranks (longest first), RCCL all-reduces of the statistics and per-chromosome tables, one all-to-all of the inter-chromosomal join records"
+            for k in ("roofline",):   # (the dominant kernel's figure was measured on the replicas' steps: it stays, and says so)
+                out[k]["measured_on"] = "config.per_rank_replicas (configs[1] on every rank)"
+            out["roofline"]["whole_path"] = {"algorithmic_bytes_per_read_pair": PATH_BYTES_PER_PAIR, "achieved": ts["value"] / world * PATH_BYTES_PER_PAIR / 1e9,
+                                             "frac": ts["value"] / world * PATH_BYTES_PER_PAIR / 1e9 / HBM_PEAK_GBS}
         if overlapped:
             out["config"]["overlapped_contexts"] = overlapped
         if not a.no_exchange and not a.pmc_child:

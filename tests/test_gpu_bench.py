@@ -27,12 +27,19 @@ def test_two_ranks_print_one_aggregate_line():
     sh = out["config"]["timings"]["bam_to_table_sharded"]
     assert "error" not in sh, sh
     assert sh["every_rank_decoded_on_its_gpu"] and sh["same_table_as_one_gpu"] and sh["sv_rows"] > 0 and sh["BDX_GPUS"] == "0,0"
+    assert "error" not in sh["two_files"], sh["two_files"]
+    assert sh["two_files"]["every_rank_decoded_on_its_gpu"] and sh["two_files"]["same_table_as_one_gpu"] and sh["two_files"]["sv_rows"] > 0
     assert out["n_gpus"] == 2 and out["steps"] == 8 and out["scaling"] == "weak"
-    pairs = 6_000_000 * 30 // 200
-    assert abs(out["value"] - 2 * pairs / (out["ms_per_step"] * 1e-3)) < 1e-3 * out["value"]
     assert "cpu_baseline" not in out and "test_hook" in out["config"]
     g = out["config"]["genome"]
     assert "error" not in g, g
+    # N > 1: the line's value is the sharded whole-genome run's -- K timed bdx_dist_run steps over all ranks -- and the N replicas of configs[1] are a note
+    ts = g["default_options"]["timed_steps"]
+    assert ts["steps"] == 8 and out["value"] == ts["value"] and abs(out["ms_per_step"] - ts["ms_per_step"]) < 1e-9
+    assert abs(out["value"] - g["reads"] / 2 * 8 / ts["seconds"]) < 1e-6 * out["value"] and out["config"]["workload"].startswith("configs[2]")
+    pairs = 6_000_000 * 30 // 200
+    rep = out["config"]["per_rank_replicas"]
+    assert abs(rep["value"] - 2 * pairs / (rep["ms_per_step"] * 1e-3)) < 1e-3 * rep["value"]
     # the weak-scaling size (hg38 x N/8 unless --genome-fraction says otherwise) ...
     assert g["ranks"] == 2 and g["scaling"] == "weak" and len(g["reads_per_rank"]) == 2 and sum(g["reads_per_rank"]) == g["reads"]
     assert 1.0 <= g["lpt_imbalance_max_over_mean"] < 1.2
@@ -49,7 +56,7 @@ def test_one_rank_line_carries_the_end_to_end_ratio_and_the_single_context_figur
     run, and the genome leg holds the single-context figure beside the sharded run"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--length", "4000000", "--genome-fraction", "0.004",
-                        "--no-pmc", "--no-overlap", "--cpu-parallel", "0", "--sharded-cli-fraction", "0.002"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+                        "--no-pmc", "--no-overlap", "--cpu-parallel", "0", "--sharded-cli-fraction", "0.002", "--genome-bam-fraction", "0.004"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     out = json.loads([x for x in p.stdout.decode().splitlines() if x.startswith("{")][0])
     e2e = out["config"]["timings"]["bam_to_table"]
@@ -60,6 +67,12 @@ def test_one_rank_line_carries_the_end_to_end_ratio_and_the_single_context_figur
     sh = out["config"]["timings"]["bam_to_table_sharded"]
     assert "error" not in sh, sh
     assert sh["every_rank_decoded_on_its_gpu"] and sh["same_table_as_one_gpu"] and sh["sv_rows"] > 0 and sh["seconds"] > 0
+    # BAM -> table at (here: a sliver of) a GPU's share of a genome, with the ceilings measured beside it and the CPU path on a slice of the same genome
+    gb = out["config"]["timings"]["bam_to_table_genome"]
+    assert "error" not in gb, gb
+    assert gb["sv_rows"] > 0 and gb["records"] > 3_000_000 and gb["steady_state_gb_s"] > 0 and gb["file_gb_per_s"] > 0
+    assert gb["ceilings"]["feed"]["both_pipelined_gb_s"] > 1 and gb["ceilings"]["inflate_kernel_alone"]["ok"] and gb["ceilings"]["inflate_kernel_alone"]["file_gb_s"] > 1
+    assert gb["cpu_port_on_a_slice"]["value"] > 0 and gb["over_cpu_port"] > 1
     g = out["config"]["genome"]
     assert "error" not in g, g
     assert g["ranks"] == 1 and g["single_context"]["seconds"] > 0 and g["default_options"]["svs_printed"] == g["single_context"]["svs_printed"]
