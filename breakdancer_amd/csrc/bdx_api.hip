@@ -1157,11 +1157,12 @@ int do_k6(bdx_ctx* c, bool force_host, int part = 0) {
         while (p2 < a.sv_cap) p2 <<= 1;
         const size_t svc = a.sv_cap;
         const size_t nsort = std::min<size_t>(svc, kK6RankSortMax);   // (k6_ranksort_kernel's output: lists of that many entries at most)
-        HIPCHK(c, c->b_ins.ensure(p2 * 12 + svc * 8 + (svc + 1) * 16 + nsort * 12 + 64));
+        HIPCHK(c, c->b_ins.ensure(p2 * 12 + svc * 8 + (svc + 1) * 16 + nsort * 12 + nsort * 4 * kK6RankSlices + 64));
         a.old_key = c->b_ins.as<uint64_t>(); a.hs_key_dev = a.old_key + p2;
         a.old_slot = (uint32_t*)(a.hs_key_dev + svc); a.ins_T = a.old_slot + p2; a.ins_src = a.ins_T + svc + 1;
         a.ins_pre_l = a.ins_src + svc + 1; a.ins_pre_c = a.ins_pre_l + svc + 1;
         a.sorted_key = (uint64_t*)(((uintptr_t)(a.ins_pre_c + svc + 1) + 7) & ~(uintptr_t)7); a.sorted_slot = (uint32_t*)(a.sorted_key + nsort);
+        a.rank_part = na > 65536u ? a.sorted_slot + nsort : nullptr;   // (k6_ranksort_kernel is launched, and its ranks are read, for inputs of this size only: a short list is sorted by k6_insert_kernel's one workgroup)
     }
     a.sv_begin = c->b_sv_src.as<uint2>(); a.sv_src = (uint32_t*)(a.sv_begin + a.sv_cap); a.ltail = c->b_ltail.as<double>();
     a.d_lib_index = c->b_dlists.as<int32_t>(); a.d_cn_key = a.d_lib_index + a.term_cap; a.d_cn_value = (float*)(a.d_cn_key + a.cn_cap);

@@ -209,6 +209,7 @@ constexpr int kK6MaxIn = 3;        // incoming gate-passing groups per region (a
 constexpr int kK6BigMembers = 64;  // regions per component walked by the general device path (one wave, member lists in LDS)
 constexpr int kK6LibStride = 16;   // staged (library, pairs) entries per candidate; components that could need more go to the host
 constexpr int kK6LabelRoundsBig = 8; // ... with the general walk (components of up to kK6BigMembers regions) enabled
+constexpr uint32_t kK6RankSlices = 16;       // the list is compared against in up to this many slices (k6_ranksort_kernel)
 constexpr uint32_t kK6RankSortMax = 1u << 17;  // entries of the insertion list the all-pairs rank sort takes (whole GPU: microseconds)
 constexpr int kK6LabelRounds = 2;  // min-label propagation rounds (the first inside k6_pairs_kernel, the others with pointer jumping):
                                    // two settle chains of four regions in practice; a component that has not converged fails
@@ -323,8 +324,9 @@ struct K6Arrays {
     const uint32_t* hs_cnt;        // [nh] lib_count | cn_count << 16
     uint64_t* old_key;             // device [pow2 >= sv_cap] order keys of the device's list (k6_walk_kernel, any order) ...
     uint32_t* old_slot;            // ... and their staging slots
-    uint64_t* sorted_key;          // device [kK6RankSortMax]: the device's list sorted by key (k6_ranksort_kernel) when it has more entries than
-    uint32_t* sorted_slot;         // one workgroup sorts quickly and at most kK6RankSortMax; null: k6_insert_kernel sorts by itself
+    uint64_t* sorted_key;          // device [kK6RankSortMax]: the device's list sorted by key when it has more entries than one workgroup sorts
+    uint32_t* sorted_slot;         // quickly (and at most kK6RankSortMax): placed by k6_insert_kernel from k6_ranksort_kernel's ranks; null: k6_insert_kernel sorts by itself
+    uint32_t* rank_part;           // device [kK6RankSlices][n_old]: every entry's number of smaller keys within a slice of the list (k6_ranksort_kernel)
     uint64_t* hs_key_dev;          // device [sv_cap] copy of hs_key
     uint32_t* ins_T;               // device [sv_cap] merged list: threshold vertex ...
     uint32_t* ins_src;             // ... staging slot, or 0x80000000 | j for the host walk's candidate j

@@ -1095,10 +1095,19 @@ __device__ __forceinline__ uint32_t count_below64(const uint64_t* v, uint32_t n,
 
 // The candidates that are placed by order key -- the host walk's list (sorted, pinned host memory) and the device's
 // candidates from traversals started at a vertex of an earlier window (k6_walk_kernel's list, any order) -- merged into
-// one list sorted by key, with the running totals of their list entries.  One workgroup (k6_insert_kernel): sort the device's list
-// (bitonic, in LDS when it fits), then every entry finds its place by a binary search in the other list (no key occurs
-// in both: a start vertex belongs to one component, and that is walked either here or by the host).
+// one list sorted by key, with the running totals of their list entries.  One workgroup of 1,024 threads (k6_insert_kernel): sort the
+// device's list (by rank counting up to 1,024 entries, bitonic in LDS up to 2,048; a longer list arrives with its ranks counted by the
+// whole GPU, k6_ranksort_kernel, launched behind the device walk so that it runs beside the host's), then every entry finds its place by a
+// binary search in the other list (no key occurs in both: a start vertex belongs to one component, and that is walked either here or by the host).
 constexpr uint32_t kInsLds = 2048;
+constexpr uint32_t kInsThreads = 1024;
+constexpr uint32_t kRankGrid = 256;          // workgroups of k6_ranksort_kernel
+// how k6_ranksort_kernel cuts its work for a list of nd entries: chunks of 256 entries x slices of the list they are compared against
+__device__ __forceinline__ void rank_layout(uint32_t nd, uint32_t* nchunk, uint32_t* nslice, uint32_t* per) {
+    *nchunk = (nd + kScanBlock - 1) / kScanBlock;
+    *nslice = min(kK6RankSlices, max(1u, kRankGrid / *nchunk));
+    *per = (nd + *nslice - 1) / *nslice;
+}
 
 struct InsertJob {
     K6Arrays a;
@@ -1106,7 +1115,7 @@ struct InsertJob {
 };
 
 __device__ void InsertJob::operator()() const {
-    constexpr uint32_t kThreads = kScanBlock;
+    constexpr uint32_t kThreads = kInsThreads;
     constexpr uint32_t kPer = kInsLds / kThreads;  // list entries per thread in the LDS prefix pass
     __shared__ uint64_t s_dk[kInsLds];
     __shared__ uint32_t s_dv[kInsLds];
@@ -1155,14 +1164,18 @@ __device__ void InsertJob::operator()() const {
             if (small) s_cnt[pos] = my_cnt;
             else { a.ins_pre_l[pos] = my_cnt & 0xffffu; a.ins_pre_c[pos] = my_cnt >> 16; }
         }
-    } else if (gridDim.x > 1 && nd > kInsLds && nd <= kK6RankSortMax) {
-        // (sorted by the other workgroups of this launch, rank_sort_body: a bitonic sort of this many keys in HBM by ONE workgroup took
-        // half a millisecond.  They are resident beside this one -- a few hundred workgroups on 256 compute units -- and were dispatched first)
-        if (tid == 0) {
-            while (__hip_atomic_load(&a.counts->sort_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x - 1) __builtin_amdgcn_s_sleep(8);
-            __threadfence();
-            a.counts->sort_done = 0;   // (the table stage can be launched again within a run)
+    } else if (a.rank_part && nd > kInsLds && nd <= kK6RankSortMax) {
+        // (ranked by the whole GPU in the launch before this one: a bitonic sort of this many keys in HBM by ONE workgroup took half a millisecond,
+        // one workgroup per 256 entries counting against the whole list 0.4 ms at 6 k entries -- a wave's compare loop is instruction-bound)
+        uint32_t nchunk, nslice, per;
+        rank_layout(nd, &nchunk, &nslice, &per);
+        for (uint32_t d = tid; d < nd; d += kThreads) {
+            uint32_t rank = 0;
+            for (uint32_t sl = 0; sl < nslice; ++sl) rank += a.rank_part[(size_t)sl * nd + d];
+            a.sorted_key[rank] = a.old_key[d];
+            a.sorted_slot[rank] = a.old_slot[d];
         }
+        __threadfence();
         __syncthreads();
         dk = a.sorted_key; dv = a.sorted_slot;
         for (uint32_t d = tid; d < nd; d += kThreads) {
@@ -1276,22 +1289,28 @@ constexpr int kSvWords = sizeof(SvOut) / 4;
 constexpr uint32_t kFinList = 1024;  // candidates of a workgroup placed per pass (more: further passes)
 constexpr uint32_t kFinT = 1024;     // thresholds of the inserted list kept in LDS (more: searched in HBM)
 
-// The device's insertion list (order keys of the candidates whose traversal started in an earlier flush window, any order) sorted
-// by ALL of the GPU: every entry counts the keys below its own -- tiles of the list pass through LDS, a broadcast read per
-// comparison -- and goes to that place.  n^2 comparisons: 2.7e8 at 16 k entries, microseconds on 256 compute units; the one-workgroup
-// bitonic sort it replaces took 0.5 ms there.  The sorting workgroups ride in k6_insert_kernel's launch (its LAST workgroup is the
-// insertion job, which waits for them only when the list is that long): no launch of their own, and with a short list they leave at once.
+// The device's insertion list (order keys of the candidates whose traversal started in an earlier flush window, any order) ranked by
+// ALL of the GPU: every entry's rank is the number of keys below its own.  n^2 comparisons -- 3.5e7 at the 6 k entries of a GPU's share of
+// a genome, microseconds on 256 compute units IF they are spread: a workgroup takes 256 entries and ONE SLICE of the list (up to 16 slices
+// while there are fewer chunks than workgroups), tiles of the slice pass through LDS, a broadcast read per comparison, and leaves the
+// partial ranks in rank_part[slice][entry]; k6_insert_kernel adds the slices up and places the entries.  Its own launch, enqueued behind the
+// device walk: it runs while the host walks its share (until round 5 these workgroups rode in k6_insert_kernel's launch, whose last
+// workgroup spun until they were through: one slice per entry, 0.4 ms, on the critical path -- and a wait HIP does not promise to end).
 constexpr uint32_t kRankTile = 2048;
-__device__ __forceinline__ void rank_sort_body(const K6Arrays& a, uint32_t nblocks) {
+__global__ __launch_bounds__(kScanBlock) void k6_ranksort_kernel(K6Arrays a) {
     __shared__ uint64_t s_k[kRankTile];
     const uint32_t nd = a.counts->n_old;
     if (nd <= kInsLds || nd > kK6RankSortMax) return;
-    for (uint32_t base = blockIdx.x * kScanBlock; base < nd; base += nblocks * kScanBlock) {   // (whole workgroups stay in the loop: barriers inside)
-        const uint32_t i = base + threadIdx.x;
+    uint32_t nchunk, nslice, per;
+    rank_layout(nd, &nchunk, &nslice, &per);
+    for (uint32_t item = blockIdx.x; item < nchunk * nslice; item += gridDim.x) {   // (whole workgroups stay in the loop: barriers inside)
+        const uint32_t chunk = item % nchunk, slice = item / nchunk;
+        const uint32_t i = chunk * kScanBlock + threadIdx.x;
         const uint64_t key = i < nd ? a.old_key[i] : ~0ull;
+        const uint32_t k0 = min(nd, slice * per), k1 = min(nd, k0 + per);
         uint32_t rank = 0;
-        for (uint32_t t0 = 0; t0 < nd; t0 += kRankTile) {
-            const uint32_t cnt = min(kRankTile, nd - t0);
+        for (uint32_t t0 = k0; t0 < k1; t0 += kRankTile) {
+            const uint32_t cnt = min(kRankTile, k1 - t0);
             __syncthreads();
             for (uint32_t q = threadIdx.x; q < cnt; q += kScanBlock) s_k[q] = a.old_key[t0 + q];
             __syncthreads();
@@ -1300,17 +1319,11 @@ __device__ __forceinline__ void rank_sort_body(const K6Arrays& a, uint32_t nbloc
                 rank += (k < key || (k == key && t0 + q < i)) ? 1u : 0u;   // (keys of one run differ; the index settles it if they ever do not)
             }
         }
-        if (i < nd) { a.sorted_key[rank] = key; a.sorted_slot[rank] = a.old_slot[i]; }
+        if (i < nd) a.rank_part[(size_t)slice * nd + i] = rank;
     }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&a.counts->sort_done, 1u);
 }
 
-__global__ __launch_bounds__(kScanBlock) void k6_insert_kernel(K6Arrays a) {
-    if (blockIdx.x + 1 < gridDim.x) rank_sort_body(a, gridDim.x - 1);
-    else InsertJob{a}();
-}
+__global__ __launch_bounds__(kInsThreads) void k6_insert_kernel(K6Arrays a) { InsertJob{a}(); }
 
 __global__ __launch_bounds__(kScanBlock) void k6_finish_kernel(K6Arrays a, double ln10, int score_threshold, int with_scores) {
     __shared__ U4 s_ws[kScanBlock / 64];
@@ -1549,6 +1562,8 @@ void launch_k6_walk(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
     const uint32_t gp = std::min<uint32_t>((n_anom_host / 8 + 3) / 4 + 1, 16384u);
     hipLaunchKernelGGL(k6_walk_kernel, dim3(std::min<uint32_t>(n_anom_host / (uint32_t)a.walk_lanes / 4 + 1, 8192u)), dim3(64), 0, s, a);  // a lane per region, grid-stride: regions are typically a tenth of the reads
     if (a.big_walk) hipLaunchKernelGGL(k6_walk_big_kernel, dim3(gp / 8 + 1), dim3(256), 0, s, a);
+    // (the ranks of the device's insertion list, should it be long: beside the host's walk.  Small inputs do without the launch)
+    if (a.rank_part) hipLaunchKernelGGL(k6_ranksort_kernel, dim3(kRankGrid), dim3(kScanBlock), 0, s, a);
 }
 
 uint32_t k6_score_grid(const K6Arrays& a) { return scan_grid(a.cap, 1); }  // workgroups of k6_finish_kernel (one per 256 regions of the upper bound)
@@ -1556,9 +1571,7 @@ uint32_t k6_score_grid(const K6Arrays& a) { return scan_grid(a.cap, 1); }  // wo
 // the merged list of the candidates that are placed by key, then the table itself
 void launch_k6_table(const K6Arrays& a, uint32_t n_anom_host, double ln10, int score_threshold, int with_scores, hipStream_t s) {
     if (n_anom_host) {
-        // (the sorting workgroups of the insertion list: see rank_sort_body; small inputs do without them)
-        const uint32_t nsort = (a.sorted_key && n_anom_host > 32 * kInsLds) ? 256u : 0u;
-        hipLaunchKernelGGL(k6_insert_kernel, dim3(nsort + 1), dim3(kScanBlock), 0, s, a);
+        hipLaunchKernelGGL(k6_insert_kernel, dim3(1), dim3(kInsThreads), 0, s, a);
         hipLaunchKernelGGL(k6_finish_kernel, dim3(scan_grid(n_anom_host, 1)), dim3(kScanBlock), 0, s, a, ln10, score_threshold, with_scores);
     }
     if (!a.printed_host || a.flag_done) hipLaunchKernelGGL(k6_done_kernel, dim3(1), dim3(64), 0, s, a);
