@@ -322,8 +322,13 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
             const bool uni = __all(lib[0] == L0 && lib[1] == L0 && lib[2] == L0 && lib[3] == L0 && bam[0] == B0 &&
                                    bam[1] == B0 && bam[2] == B0 && bam[3] == B0);
             one_file = uni; file0 = B0;
-            // this body leaves no ready-made records: the slots say so, K2 compacts the tile from the columns
-            if (p.stash && (unsigned)lane_r < (na < (unsigned)kStashCap ? na : (unsigned)kStashCap)) p.stash[(size_t)tile * kStashCap + lane_r].where = 0xFFFFFFFFu;  // (every slot K2 would read)
+            // Ready-made records for K2 from this body too when the tile is full and its reads share ONE counter key -- the tiles of a genome
+            // of several libraries in one file (configs[2]-[3]: every tile is "mixed", and until round 5 K2 then re-read the class bytes of all
+            // reads and gathered nine columns per anomalous read: 613 MB fetched for ~120 MB of payload at a GPU's share of a genome).  A
+            // record carries its own library; the prefix counts are those of the uniform body.  Otherwise the slots say that there are none
+            // and K2 compacts the tile from the columns.
+            const int k_first = __shfl(key[0], 0);
+            const bool one_key = __all(nvalid == 4 && key[0] == k_first && key[1] == k_first && key[2] == k_first && key[3] == k_first);
             if (uni) {
                 unsigned c1 = 0, ck = 0;
 #pragma unroll
@@ -375,6 +380,49 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
                 }
             }
             if (lane_r < ncols_r) p.tile_tot[(size_t)lane_r * p.tstride + tile] = colval;
+            // (here, behind the totals: the classification's per-library temporaries are dead)
+            if (p.stash && na && one_key) {
+                // (written so that it needs few registers beside the classification's -- built like the uniform body's, from the lanes that own
+                // the reads, this body spilled 73 registers and the kernel took three times as long: an owning lane only leaves its reads'
+                // in-tile indices in the wave's LDS slice, by rank; lane j then puts record j together itself -- its fields gathered from the
+                // columns the tile has just been loaded from, its prefix counts from the ballots, which are scalar registers)
+                unsigned ra = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ra = __builtin_amdgcn_mbcnt_hi((uint32_t)(ba[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ba[r], ra));
+                uint32_t* idx = (uint32_t*)s_stash[w];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (anom[r] && ra < (unsigned)kStashCap) idx[ra] = (uint32_t)(lane_r * 4 + r);
+                    ra += anom[r] ? 1u : 0u;
+                }
+                __builtin_amdgcn_wave_barrier();
+                const unsigned nrec = na < (unsigned)kStashCap ? na : (unsigned)kStashCap;
+                const uint32_t where = idx[(unsigned)lane_r < nrec ? lane_r : 0];
+                const unsigned l = where >> 2, rr = where & 3u;
+                const uint64_t below = (1ull << l) - 1ull;
+                unsigned rn = 0, rk = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {   // (every ballot is used up at once: scalar registers are as scarce here as vector ones)
+                    const uint64_t mn = ballot64(nleft[r]), mp = ballot64(pk[r]);
+                    rn += popc64(mn & below) + ((unsigned)r < rr ? (unsigned)((mn >> l) & 1ull) : 0u);
+                    rk += popc64(mp & below) + ((unsigned)r <= rr ? (unsigned)((mp >> l) & 1ull) : 0u);   // (up to and including the read itself)
+                }
+                if ((unsigned)lane_r < nrec) {
+                    const uint64_t i = (uint64_t)tile * kTile + where;
+                    const unsigned cb = p.cls[i];   // (stored by this wave above)
+                    unsigned L = nlibs_r > 1 ? (unsigned)p.r.lib[i] : 0u;
+                    if (L >= (unsigned)nlibs_r) L = 0;
+                    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                    const v4u x0 = {(uint32_t)p.r.tid[i], (uint32_t)p.r.pos[i], (uint32_t)abs(p.r.isize[i]), (cb & 15u) | ((((unsigned)p.r.flag[i] >> 4) & 1u) << 4) | (L << 8)};
+                    const v4u x1 = {where | (rn << 8) | ((uint32_t)k_first << 20), rk, 0u, 0u};
+                    v4u* dst = (v4u*)(p.stash + (size_t)tile * kStashCap + lane_r);
+                    dst[0] = x0;
+                    dst[1] = x1;
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else if (p.stash && (unsigned)lane_r < (na < (unsigned)kStashCap ? na : (unsigned)kStashCap)) {
+                p.stash[(size_t)tile * kStashCap + lane_r].where = 0xFFFFFFFFu;  // (every slot K2 would read)
+            }
         }
         }
 
