@@ -214,9 +214,11 @@ struct bdx_dist {
     bdx_ctx* reads = nullptr;        // ALL chromosomes this rank owns, one after the other in ascending order: one launch sequence
     bdx_ctx* util = nullptr;         // rank 0: holds the result
     int last_tid = -1;               // bdx_dist_chromosome: the chromosomes must be fed in ascending order
+    size_t sorted_n = 0;             // the reads whose reference-id column has been checked (check_order): this many ...
+    const void* sorted_ptr = nullptr;  // ... at this address
     size_t n_at_last = 0;
     bool use_check = false;
-    DevBuf b_words, b_tab, b_send, b_recv, b_pack, b_all, b_nsend, b_nrecv, b_ntab, b_nflag, b_foreign, b_rg_rec, b_rg_pk, b_x, b_merge;
+    DevBuf b_words, b_tab, b_send, b_recv, b_pack, b_all, b_nsend, b_nrecv, b_ntab, b_nflag, b_foreign, b_rg_rec, b_rg_pk, b_x, b_merge, b_chk;
     PinBuf h_words;                  // staging of the all-reduces' words (pinned: the copies either side of a collective are asynchronous)
     PinBuf h_tab;                    // what the small kernels report: per-chromosome tables, counts, ready words
     hipEvent_t ev_side = nullptr;    // the name census runs on the context's second stream, beside the joins
@@ -369,7 +371,7 @@ void bdx_dist_destroy(bdx_dist* d) {
     if (d->reads) bdx_destroy(d->reads);
     if (d->util) bdx_destroy(d->util);
     for (DevBuf* b : {&d->b_words, &d->b_tab, &d->b_send, &d->b_recv, &d->b_pack, &d->b_all, &d->b_nsend, &d->b_nrecv, &d->b_ntab, &d->b_nflag, &d->b_foreign,
-                      &d->b_rg_rec, &d->b_rg_pk, &d->b_x, &d->b_merge})
+                      &d->b_rg_rec, &d->b_rg_pk, &d->b_x, &d->b_merge, &d->b_chk})
         b->release();
     d->h_tab.release();
     d->h_words.release();
@@ -405,11 +407,36 @@ int bdx_dist_reset_reads(bdx_dist* d) {
     return BDX_OK;
 }
 
+namespace {
+// The chromosome table is found by binary searches in the reference-id column (k9_tid_table_kernel): that column must be ascending with
+// every id inside the header's sequences -- a rank's chromosomes fed in order, each chromosome's records together.  bdx_dist_chromosome
+// sees to the order of the CALLS; what the batches hold is checked here, once per set of reads.
+int check_order(bdx_dist* d) {
+    bdx_ctx* c = d->reads;
+    if (!c->n || (d->sorted_n == c->n && d->sorted_ptr == (const void*)c->d.tid)) return BDX_OK;
+    DHIP(d, d->b_chk.ensure(64));
+    uint32_t* err = d->b_chk.as<uint32_t>();
+    uint32_t bad = 0;
+    DHIP(d, hipMemsetAsync(err, 0, 4, c->stream));
+    if (c->copy_pending) { DHIP(d, hipStreamWaitEvent(c->stream, c->ev_copy, 0)); }
+    launch_k9_check_sorted((const int32_t*)c->d.tid, c->n, d->ntids, err, c->stream);
+    DHIP(d, hipMemcpyAsync(&bad, err, 4, hipMemcpyDeviceToHost, c->stream));
+    DHIP(d, hipStreamSynchronize(c->stream));
+    if (bad) return dfail(d, BDX_EINVAL, "the reads of a rank are not in ascending order of their reference ids (or an id lies outside the header's sequences)");
+    d->sorted_n = c->n; d->sorted_ptr = (const void*)c->d.tid;
+    return BDX_OK;
+}
+}  // namespace
+
 int bdx_dist_prepare(bdx_dist* d) {
     if (!d) return BDX_EINVAL;
     bdx_ctx* c = d->reads;
     DHIP(d, hipSetDevice(d->device));
     if (bdx_warm_up(d->device) != BDX_OK) return dfail(d, BDX_EHIP, "bdx_warm_up");
+    {
+        const int orc = check_order(d);
+        if (orc != BDX_OK) return orc;
+    }
     // the later stages' buffers for the prior a first run goes by (bdx_reserve does the same for a single context), with K6's
     // per-region arrays sized for the genome's regions rather than this rank's
     {
@@ -637,6 +664,10 @@ int bdx_dist_run(bdx_dist* d) {
         C->table_in_hbm = world > 1;
         C->groups_in_hbm = world > 1;
         C->k6_cap = 0; C->k6_r_rec = nullptr; C->k6_r_pk = nullptr; C->k6_taint = nullptr; C->k3_tid_tail = nullptr;
+        {   // (a set of reads bdx_dist_prepare has not seen: its order is checked before the chromosome table is searched in it)
+            const int orc = check_order(d);
+            if (orc != BDX_OK) return orc;
+        }
         DCTX(d, C, do_pass1(C, 0, false, false));   // (its record is waited for together with the chromosome table)
         TidTableParams tp{};
         tp.tid = C->d.tid; tp.lib = C->d.lib; tp.cls = C->b_cls.as<uint8_t>(); tp.n = C->n; tp.ntiles = C->ntiles; tp.tstride = C->tstride;

@@ -26,6 +26,7 @@ struct TidTableParams {
     uint32_t* out;
 };
 void launch_k9_tid_table(const TidTableParams& p, hipStream_t s);
+void launch_k9_check_sorted(const int32_t* tid, uint64_t n, int ntids, uint32_t* err, hipStream_t s);
 // one thread behind a kernel boundary: *flag = value (the host polls the pinned word)
 void launch_k9_signal(uint32_t* flag, uint32_t value, hipStream_t s);
 // ... after n words of device memory have been copied into the (pinned) report area

@@ -79,6 +79,23 @@ __global__ __launch_bounds__(64) void k9_tid_table_kernel(TidTableParams p) {
     }
 }
 
+// Is the reference-id column what k9_tid_table_kernel's binary searches take it for -- ascending, every id within [0, ntids)?  One pass over
+// the column (464 MB for a GPU's share of a genome: ~80 us); bdx_dist_prepare / the first bdx_dist_run on a set of reads run it once.
+__global__ __launch_bounds__(256) void k9_check_sorted_kernel(const int32_t* __restrict__ tid, uint64_t n, int ntids, uint32_t* err) {
+    bool bad = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const int32_t t = tid[i];
+        bad |= t < 0 || t >= ntids || (i + 1 < n && tid[i + 1] < t);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) *err = 1u;
+}
+
+void launch_k9_check_sorted(const int32_t* tid, uint64_t n, int ntids, uint32_t* err, hipStream_t s) {
+    if (!n) return;
+    const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 8192);
+    hipLaunchKernelGGL(k9_check_sorted_kernel, dim3(grid), dim3(256), 0, s, tid, n, ntids, err);
+}
+
 void launch_k9_tid_table(const TidTableParams& p, hipStream_t s) {
     hipLaunchKernelGGL(k9_tid_table_kernel, dim3((uint32_t)p.ntids + 1), dim3(64), 0, s, p);
 }

@@ -101,6 +101,34 @@ def test_rccl_backend_with_a_communicator_of_one():
     d.close()
 
 
+@pytest.mark.parametrize("how", ["prepare", "run"])
+def test_a_rank_whose_reads_are_not_in_reference_order_is_refused(how):
+    """the chromosome table is found by binary searches in the reference-id column: a batch that holds ids out of order -- here two records of the
+    first chromosome in the middle of the second's -- or an id beyond the header's sequences is an error of the caller's, said so before anything
+    is searched (by bdx_dist_prepare, or by the first bdx_dist_run on reads that were not prepared), not a silently wrong table"""
+    from breakdancer_amd import dist as D
+    from breakdancer_amd.api import BdxError, LibraryConfig
+    cfg, streams, targets = make_case(133)
+    run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1))
+    libs = [LibraryConfig(*[float(x) for x in run.lib_f[i]], min_mapping_quality=int(run.lib_i[i, 0]),
+                          bam_file_index=int(run.lib_i[i, 1]), name=run.lib_names[i]) for i in range(run.nlibs)]
+    parts = split_by_tid(run.merged_soa())
+    tids = sorted(parts)
+    assert len(tids) >= 2
+    for mode in ("swapped", "beyond"):
+        d = D.DistRun.create(product_options(run.opts), libs, run.nbams, len(targets), run.w0, 0, 0, 1, D.unique_id())
+        for tid in tids:
+            arrs = {k: np.array(v, copy=True) for k, v in parts[tid].items()}
+            if tid == tids[1]:
+                mid = len(arrs["tid"]) // 2
+                arrs["tid"][mid:mid + 2] = tids[0] if mode == "swapped" else len(targets) + 3
+            d.chromosome(tid).push_reads(arrs)
+        with pytest.raises(BdxError) as e:
+            d.prepare() if how == "prepare" else d.run()
+        assert mode == "beyond" or "ascending order" in str(e.value), str(e.value)
+        d.close()
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_per_chromosome_mode_equals_dash_o_runs(seed):
     """README:31 parallel mode: results of chromosome t == `breakdancer-max -o t`"""
