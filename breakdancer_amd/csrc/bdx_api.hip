@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <sys/mman.h>
 #include <atomic>
 #include <functional>
 #include <chrono>
@@ -59,19 +60,47 @@ struct PinBuf {
     void* p = nullptr;
     size_t bytes = 0;
     unsigned flags = hipHostMallocDefault;
+    // A large buffer is anonymous memory on transparent huge pages, registered with the runtime (hipHostRegister): 0.02 s per 0.5 GB
+    // against hipHostMalloc's 0.09-0.11 -- pinning is paid per page -- and a quarter less to hand back when the process ends
+    // (tools/pin_probe.hip, profiles/r05_pin_probe.txt); the device sees it at the same address.  Small buffers -- the words the host
+    // polls, the records kernels and host exchange mid-run -- stay with hipHostMalloc (fine-grained by default).  BDX_PIN=malloc: all of them.
+    void* map_base = nullptr;
+    size_t map_len = 0;
+    static bool use_registered() { static const bool on = !(getenv("BDX_PIN") && !strcmp(getenv("BDX_PIN"), "malloc")); return on; }
     hipError_t ensure(size_t b) {
         if (b <= bytes) return hipSuccess;
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        bytes = 0;
+        release();
         size_t want = b + b / 8 + 256;
         const auto t0 = std::chrono::steady_clock::now();
-        hipError_t e = hipHostMalloc(&p, want, flags);
-        if (alloc_trace()) fprintf(stderr, "[bdx alloc] pinned %12zu B %8.1f us\n", want, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
-        if (e == hipSuccess) bytes = want;
+        hipError_t e = hipErrorOutOfMemory;
+        constexpr size_t kHuge = (size_t)2 << 20;
+        if (want >= 2 * kHuge && flags == hipHostMallocDefault && use_registered()) {
+            const size_t len = (want + kHuge - 1) & ~(kHuge - 1);
+            void* base = mmap(nullptr, len + kHuge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (base != MAP_FAILED) {
+                void* al = (void*)(((uintptr_t)base + kHuge - 1) & ~(uintptr_t)(kHuge - 1));
+                (void)madvise(al, len, MADV_HUGEPAGE);
+                for (size_t o = 0; o < len; o += 4096) ((volatile char*)al)[o] = 0;   // (faulted in before it is pinned: one fault per huge page)
+                void* dev = nullptr;
+                if (hipHostRegister(al, len, hipHostRegisterMapped) == hipSuccess && hipHostGetDevicePointer(&dev, al, 0) == hipSuccess && dev == al) {
+                    p = al; map_base = base; map_len = len + kHuge; want = len; e = hipSuccess;
+                } else {
+                    (void)hipHostUnregister(al);
+                    (void)hipGetLastError();
+                    munmap(base, len + kHuge);
+                }
+            }
+        }
+        if (e != hipSuccess) e = hipHostMalloc(&p, want, flags);
+        if (alloc_trace()) fprintf(stderr, "[bdx alloc] pinned %12zu B %8.1f us%s\n", want, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), map_base ? " (registered huge pages)" : "");
+        if (e == hipSuccess) bytes = want; else p = nullptr;
         return e;
     }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
+    void release() {
+        if (p && map_base) { (void)hipHostUnregister(p); munmap(map_base, map_len); }
+        else if (p) (void)hipHostFree(p);
+        p = nullptr; bytes = 0; map_base = nullptr; map_len = 0;
+    }
     template <class T> T* as() const { return (T*)p; }
 };
 

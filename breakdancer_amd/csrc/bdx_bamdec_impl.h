@@ -75,7 +75,11 @@ struct bdx_bamdec {
         size_t cap_bytes = 0;             // bytes the last bdx_bamdec_acquire promised
         hipError_t pin_status = hipSuccess;
     } staging[kBamStaging];
-    std::thread pin_thread;              // (pins the staging buffers one after the other: page pinning does not run in parallel with itself)
+    std::thread pin_thread;              // (pins the staging buffers one after the other: page pinning does not run in parallel with itself -- and then
+                                         // allocates the batch slots' and the record stage's buffers, which the feeding thread would otherwise size as it
+                                         // first meets them, in the middle of the first batches: profiles/r05_cli_timeline.txt, the gaps before 150 ms)
+    std::atomic<int> slot_ready[kBamSlots];   // 0: the pin thread has not got to this slot's buffers yet, 1: the feeding thread may look at them
+    std::atomic<int> rec_ready{1};            // (the same for the record stage's scratch and raw columns)
     int next_staging = 0, held_staging = 0;   // the held_staging buffers before next_staging are acquired and not submitted yet (oldest first)
     // a batch: the compressed bytes of its pieces back to back in HBM, its member table, the inflate status words
     struct Slot {
@@ -227,10 +231,11 @@ int bam_feed_classifier(bdx_bamdec* d, bool final) {
         c->ran = false;
     }
     // The stages behind pass 1 get their buffers (~60 allocations; with a genome's share of records 0.25-0.35 s of page pinning for the
-    // result tables) on a thread of their own, as soon as the first batch's records are counted: its records per byte applied to the
+    // result tables) on a thread of their own, once the first four batches' records are counted (not earlier: its allocations would
+    // contend with the first batches' own): their records per byte applied to the
     // bytes the caller announced (or, without an announcement, to what has been submitted once the last piece is in).  Until round 5 the
     // feeding thread did this itself behind its last piece -- the GPU was through with the file long before (profiles/r05_genome_probe_before.txt).
-    if (!d->presized && d->confirmed_seq >= 1 && (d->finished || d->expected_bytes) && !d->batch_end_bytes.empty()) {
+    if (!d->presized && (d->confirmed_seq >= 4 || (d->finished && d->confirmed_seq >= 1)) && (d->finished || d->expected_bytes) && !d->batch_end_bytes.empty()) {
         uint64_t bytes_counted = 0;
         for (auto const& be : d->batch_end_bytes)
             if (be.first <= d->confirmed_seq) bytes_counted = be.second;
@@ -274,6 +279,7 @@ int bam_feed_classifier(bdx_bamdec* d, bool final) {
 // record that runs past the cut is dropped, not an error)
 int bam_record_stage(bdx_bamdec* d, BamPiece& p, const BamPiece* next, int is_last) {
     BamTimer t6(d->host_ms[6]);
+    while (!d->rec_ready.load(std::memory_order_acquire)) std::this_thread::yield();   // (the pin thread is sizing the stage's buffers)
     hipStream_t s = d->s_rec;
     bdx_bamdec::Slot& sl = d->slot[p.slot];
     // (sizes first: a wait on the stream, should one be needed, must not find this stage's own waits for the inflate launches in it)
@@ -381,6 +387,7 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
     if (!d) return BDX_ENOMEM;
     d->device = device;
     d->sink = sink;
+    for (auto& r : d->slot_ready) r.store(1);
     d->bam_index = (uint8_t)p->bam_index;
     d->filt.only_tid = p->only_tid; d->filt.beg = p->region_beg; d->filt.end = p->region_end; d->filt.n_targets = p->n_targets;
     auto bad = [&](int code) { bdx_bamdec_destroy(d); return code; };
@@ -488,15 +495,44 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
     // (behind the decoder's own pinned allocation: page pinning does not run in parallel with itself)
     if (p->piece_bytes && p->piece_blocks) {
         for (auto& st : d->staging) st.pinned.store(0);
+        for (auto& r : d->slot_ready) r.store(0);
+        d->rec_ready.store(0);
         const size_t nb = p->piece_bytes + 64, nt = p->piece_blocks * sizeof(bdx_bgzf_block);
-        d->pin_thread = std::thread([d, nb, nt, device] {
+        const size_t slot_bytes = d->batch_bytes + p->piece_bytes + 4096, slot_blocks = d->batch_blocks + p->piece_blocks + 64;
+        d->pin_thread = std::thread([d, nb, nt, device, slot_bytes, slot_blocks] {
             hipError_t e = hipSetDevice(device);
-            for (auto& st : d->staging) {
+            auto pin = [&](bdx_bamdec::Staging& st) {
                 if (e == hipSuccess) e = st.h_comp.ensure(nb);
                 if (e == hipSuccess) e = st.h_tab.ensure(nt);
                 st.pin_status = e;
                 st.pinned.store(1, std::memory_order_release);
+            };
+            auto slot = [&](int k) {   // (what bam_open_batch / bam_launch_batch would size: a failure here is met again, and reported, there)
+                bdx_bamdec::Slot& sl = d->slot[k];
+                if (e == hipSuccess && sl.d_comp.ensure(slot_bytes) == hipSuccess && sl.h_blocks.ensure(slot_blocks * sizeof(BgzfBlock)) == hipSuccess) {
+                    (void)sl.d_blocks.ensure(slot_blocks * sizeof(BgzfBlock));
+                    (void)sl.d_status.ensure(slot_blocks * 4);
+                }
+                d->slot_ready[k].store(1, std::memory_order_release);
+            };
+            // in the order the feeding thread asks for them: the first pieces' buffers, the first batch's slot, the rest
+            pin(d->staging[0]);
+            slot(0);
+            for (int i = 1; i < kBamStaging; ++i) { pin(d->staging[i]); if (i == 2) slot(1); if (i == 5) slot(2); }
+            for (int k = 3; k < kBamSlots; ++k) slot(k);
+            if (e == hipSuccess) {   // the record stage's scratch and raw columns, for the largest batch (bam_record_stage's sizes)
+                const size_t nbk = d->batch_blocks + d->batch_blocks / 4 + 64;
+                const size_t cap = round_up(nbk * (size_t)65536 / 36, 1024);
+                bool ok = cap <= 0xFFFFFFFFull;
+                for (DevBuf* b : {&d->r_tid, &d->r_pos, &d->r_mtid, &d->r_mpos, &d->r_isize}) ok = ok && b->ensure(cap * 4) == hipSuccess;
+                ok = ok && d->r_flag.ensure(cap * 2) == hipSuccess && d->r_qlen.ensure(cap * 2) == hipSuccess && d->r_mapq.ensure(cap) == hipSuccess &&
+                     d->r_lib.ensure(cap) == hipSuccess && d->r_keep.ensure(cap) == hipSuccess && d->r_key.ensure(cap * 8) == hipSuccess && d->r_check.ensure(cap * 8) == hipSuccess &&
+                     d->d_scan.ensure((cap / 256 + 8) * 4) == hipSuccess;
+                if (ok) d->raw_cap = (uint32_t)cap;
+                if (ok && d->d_cb.ensure(nbk * sizeof(ChainBlock)) == hipSuccess && d->d_offs.ensure(nbk * kRecSlots * 2) == hipSuccess && d->d_base.ensure((nbk + 2) * 4) == hipSuccess)
+                    d->rec_cap_blk = nbk;
             }
+            d->rec_ready.store(1, std::memory_order_release);
         });
     }
     if (sink) {
@@ -693,6 +729,7 @@ int bam_launch_batch(bdx_bamdec* d, int si, bool last) {
 int bam_open_batch(bdx_bamdec* d, size_t piece_bytes, size_t piece_blocks) {
     bdx_bamdec::Slot& sl = d->slot[d->cur_slot];
     if (sl.open) return BDX_OK;
+    while (!d->slot_ready[d->cur_slot].load(std::memory_order_acquire)) std::this_thread::yield();   // (its buffers are being allocated by the pin thread)
     if (sl.busy) {
         BamTimer t(d->host_ms[2]);
         BHIP(d, hipEventSynchronize(sl.ev_free));

@@ -14,6 +14,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <thread>
+#include <time.h>
 #include <cerrno>
 #include <csignal>
 #include <fcntl.h>
@@ -181,6 +182,11 @@ int run(int argc, char** argv);
 // child's word that the table is written and returns with its status, while the child's exit takes its time in the background.
 // BDX_FOREGROUND=1 (and BDX_CLEAN_EXIT=1, the leak checkers' mode) keep everything in the one process.
 int main(int argc, char** argv) {
+    if (getenv("BDX_TIMING")) {   // (for whoever times the process from outside: when main() was reached, on the wall clock)
+        struct timespec ts;
+        clock_gettime(CLOCK_REALTIME, &ts);
+        fprintf(stderr, "[bdx timing] main() entered at %.6f (wall clock)\n", (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec);
+    }
     if (!getenv("BDX_FOREGROUND") && !getenv("BDX_CLEAN_EXIT")) {
         int pfd[2];
         if (pipe(pfd) == 0) {
@@ -551,6 +557,11 @@ int run(int argc, char** argv) {
             if (sharded) { for (int dv : devices) (void)bdx_warm_up(dv); }
             else (void)bdx_warm_up(bdx_device(ctx));
             report_result(0);
+            if (timing) {
+                struct timespec ts;
+                clock_gettime(CLOCK_REALTIME, &ts);
+                fprintf(stderr, "[bdx timing] _exit called at %.6f (wall clock)\n", (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec);
+            }
             _exit(0);
         }
         release_device_decoders();   // (before their sink: a decoder borrows its context's streams)

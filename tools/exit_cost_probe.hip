@@ -2,6 +2,8 @@
 // usage: exit_cost_probe <GB device untouched> <GB device written> <GB pinned> [free]   (prints the time of its own allocations; time the process from outside)
 #include <hip/hip_runtime.h>
 #include <chrono>
+#include <time.h>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -25,6 +27,11 @@ int main(int argc, char** argv) {
     if (argc > 4) { for (void* p : ptrs) CK(hipFree(p)); if (hp) CK(hipHostFree(hp)); }
     const double t5 = now();
     printf("runtime up %.3f s; %.0f GB untouched %.3f s; %.0f GB written %.3f s; %.1f GB pinned %.3f s; freeing %.3f s; ", t1 - t0, gu, t2 - t1, gw, t3 - t2, gp, t4 - t3, t5 - t4);
+    {
+        struct timespec ts;
+        clock_gettime(CLOCK_REALTIME, &ts);
+        printf("exit_at %.6f ", (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec);
+    }
     fflush(stdout);
-    return 0;
+    _exit(0);
 }

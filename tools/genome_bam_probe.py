@@ -28,9 +28,16 @@ if __name__ == "__main__":
         env = dict(os.environ, BDX_TIMING="1", BDX_FOREGROUND="1", **extra)
         time.sleep(2.5)   # (untimed: the driver is still taking back the previous process's tens of GB)
         t0 = time.perf_counter()
+        w0 = time.time()
         p = subprocess.run([os.path.join(ROOT, "bin", "breakdancer-max"), cfg], cwd=td, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         dt = time.perf_counter() - t0
+        w1 = time.time()
         rows = sum(1 for l in p.stdout.splitlines() if l and not l.startswith(b"#"))
+        import re
+        m0 = re.search(r"main\(\) entered at ([0-9.]+)", p.stderr.decode())
+        m1 = re.search(r"_exit called at ([0-9.]+)", p.stderr.decode())
+        if m0 and m1:
+            print("      start -> main() %.3f s, main() -> _exit %.3f s, _exit -> process gone %.3f s" % (float(m0.group(1)) - w0, float(m1.group(1)) - float(m0.group(1)), w1 - float(m1.group(1))))
         print("run %d %s: rc %d, %.3f s, %.1f M read-pairs/s, %.2f GB/s of BAM, %d SV rows" % (r, extra, p.returncode, dt, n / 2 / dt / 1e6, size / dt / 1e9, rows), flush=True)
         if r == runs - 1 or p.returncode:
             print("\n".join(l for l in p.stderr.decode().splitlines() if "bdx timing" in l or p.returncode))
