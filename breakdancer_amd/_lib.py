@@ -52,7 +52,7 @@ EXPORTS = ["bdx_opts_default", "bdx_create", "bdx_destroy", "bdx_strerror", "bdx
            "bdx_get_sv_lists", "bdx_get_read_class", "bdx_get_timings", "bdx_classify", "bdx_poisson_log_upper_tail",
            "bdx_device", "bdx_stream", "bdx_stage_pass1", "bdx_get_pass1_local", "bdx_set_pass1_global", "bdx_stage_compact", "bdx_stage_regions",
            "bdx_get_stage_regions", "bdx_get_region_records", "bdx_get_compact", "bdx_join_entries", "bdx_stage_walk", "bdx_set_collect_support", "bdx_get_sv_support",
-           "bdx_set_host_walk", "bdx_set_debug", "bdx_use_name_check", "bdx_run_many", "bdx_get_walk_split", "bdx_set_stage_timing", "bdx_get_cross_window_svs",
+           "bdx_set_host_walk", "bdx_set_debug", "bdx_use_name_check", "bdx_run_many", "bdx_get_walk_split", "bdx_trim_results", "bdx_set_stage_timing", "bdx_get_cross_window_svs",
            "bdx_set_enqueue_ahead", "bdx_was_replayed", "bdx_acquire_batch", "bdx_submit_batch", "bdx_reset_reads", "bdx_set_pass1_statistics",
            "bdx_warm_up", "bdx_dist_unique_id", "bdx_dist_create", "bdx_dist_create_threads", "bdx_dist_destroy", "bdx_dist_last_error", "bdx_dist_rank",
            "bdx_dist_world", "bdx_dist_chromosome", "bdx_dist_run", "bdx_dist_result", "bdx_dist_set_collect_support", "bdx_dist_get_phase_ms", "bdx_dist_phase_name", "bdx_dist_prepare", "bdx_dist_reset_reads", "bdx_dist_get_exchange", "bdx_dist_owner", "bdx_dist_plan",

@@ -1778,7 +1778,7 @@ int bdx_get_stage_regions(const bdx_ctx* c, uint32_t* n_regions, uint32_t* n_ano
 
 int bdx_get_region_records(const bdx_ctx* c, bdx_region_rec* out, uint32_t* pk, size_t cap) {
     if (!c) return BDX_EINVAL;
-    if (c->stage < 3) return BDX_ESTATE;
+    if (c->stage < 3 || !c->h_regs.p) return BDX_ESTATE;   // (no table yet, or handed back by bdx_trim_results)
     const size_t n = std::min<size_t>(cap, c->counts.n_regions);
     static_assert(sizeof(bdx_region_rec) == sizeof(RegionRec), "region record layout");
     if (out && n) memcpy(out, c->h_regs.p, n * sizeof(RegionRec));
@@ -1899,6 +1899,25 @@ int bdx_get_svs(const bdx_ctx* c, bdx_sv* out, size_t cap) {
     materialize(const_cast<bdx_ctx*>(c));
     const size_t n = std::min(cap, c->walk.svs.size());
     for (size_t i = 0; i < n; ++i) out[i] = c->walk.svs[i].sv;
+    return BDX_OK;
+}
+
+int bdx_trim_results(bdx_ctx* c) {
+    if (!c) return BDX_EINVAL;
+    if (!c->ran) return BDX_ESTATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    materialize(c);
+    if (c->reg && (const void*)c->reg == c->h_regs.p) {   // (a region table read where the device left it: the getters go on from a copy)
+        const HostRegion* r = c->reg;
+        const uint32_t* pk = c->rpk;
+        const size_t n = c->nreg;
+        std::vector<HostRegion> keep(r, r + n);
+        std::vector<uint32_t> keep_pk(pk, pk + n * 2 * (size_t)c->nkeys);
+        c->regions.swap(keep); c->r_pk.swap(keep_pk);
+        c->reg = c->regions.data(); c->rpk = c->r_pk.data();
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (PinBuf* b : {&c->h_regs, &c->h_pk, &c->h_groups, &c->h_sv_out, &c->h_lib_index, &c->h_lib_pairs, &c->h_cn_key, &c->h_cn_value, &c->h_ltail_dev}) b->release();
     return BDX_OK;
 }
 

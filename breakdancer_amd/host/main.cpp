@@ -450,6 +450,11 @@ int run(int argc, char** argv) {
         std::vector<float> cv(nc);
         check(ctx, bdx_get_sv_lists(ctx, li.data(), lp.data(), nl, ck.data(), cv.data(), nc), "bdx_get_sv_lists");
 
+        // (a large run's pinned result tables go back while the table is printed: the process's end is that much shorter.  BDX_TRIM=0: kept)
+        if (n_reads > (size_t)(8u << 20) && !want_dumps && !getenv("BDX_CLEAN_EXIT") && !(getenv("BDX_TRIM") && !strcmp(getenv("BDX_TRIM"), "0"))) {
+            bdx_ctx* tc = ctx;
+            std::thread([tc] { (void)bdx_trim_results(tc); }).detach();
+        }
         auto tname = [&](int t) { return (t >= 0 && (size_t)t < targets.size()) ? targets[t] : std::to_string(t); };
 
         // supporting reads of the printed SVs: a second decode pass fetches just those records (the reference keeps

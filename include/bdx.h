@@ -253,6 +253,12 @@ int bdx_set_host_walk(bdx_ctx* ctx, int on);
  * (the parity tests force each route); none is needed in production.  BDX_EINVAL for an unknown name. */
 int bdx_set_debug(bdx_ctx* ctx, const char* name, int value);
 int bdx_get_walk_split(const bdx_ctx* ctx, uint32_t* n_sv_device, uint32_t* n_sv_host, uint32_t* n_groups_host);
+/* After a run, once the caller has what it wants: the result tables are copied out of the pinned host buffers the device assembled them
+ * in (every getter keeps working, from the copies) and those buffers -- sized for the worst case of a prior, hundreds of MB for a genome --
+ * are handed back.  A process pays for pinned memory when it ends (0.15 s per GB on this platform: tools/exit_cost_probe.hip); the CLI calls
+ * this on a thread of its own while it prints the table.  The reference's counterpart is the end of BreakDancer::run (BreakDancer.cpp:131-144):
+ * nothing is kept.  A later bdx_run allocates them again. */
+int bdx_trim_results(bdx_ctx* ctx);
 /* Of the device-assembled candidates, those whose traversal started from a region of an earlier flush window (the
  * reference's flush cadence, BreakDancer.cpp:254-264; they are placed in the output by order key, not by position). */
 int bdx_get_cross_window_svs(const bdx_ctx* ctx, uint32_t* n_sv_device);
