@@ -124,6 +124,8 @@ struct bdx_ctx {
     bool adopted = false;
     DevBuf b_tid, b_pos, b_mtid, b_mpos, b_isize, b_flag, b_qlen, b_mapq, b_lib, b_bam, b_key, b_check;
     bool groups_in_hbm = false;       // (sharded runs) the join's pair groups stay in HBM instead of pinned host memory
+    bool defer_walk = false;          // (sharded runs over several ranks) do_k6 part 2 stops behind the components; the device walk (part 3) is
+                                      // enqueued once the host's share has left for rank 0, and runs beside the collectives and rank 0's walk
     DevBuf b_groups;
     bool use_check = false;           // bdx_use_name_check: every batch carries a second hash of the read name, mates must agree in it too
 
@@ -1142,7 +1144,11 @@ int do_k6(bdx_ctx* c, bool force_host, int part = 0) {
             const int rc = signal_ready(c, 1, c->ev_groups);
             if (rc != BDX_OK) return rc;
         }
-        launch_k6_walk(a, a.cap, s);
+        if (!c->defer_walk) launch_k6_walk(a, a.cap, s);
+        return BDX_OK;
+    }
+    if (part == 3) {   // (the deferred device walk)
+        if (a.cap) launch_k6_walk(a, a.cap, s);
         return BDX_OK;
     }
     const uint32_t na = std::max(c->na_alloc, c->k6_cap);   // (sharded runs: K6's arrays are indexed by genome-wide region id)
@@ -1253,7 +1259,7 @@ int do_k6(bdx_ctx* c, bool force_host, int part = 0) {
         a.flag_value = c->seq;
         a.flag_groups = c->h_flags.as<uint32_t>() + 1;
         if (c->k3.host_copy_later) a.flag_regions = c->h_flags.as<uint32_t>() + 3;
-        a.mirror_in_walk = force_host ? 0 : 1;  // (k6_walk_kernel follows k6_emit_kernel unless everything goes to the host)
+        a.mirror_in_walk = (force_host || c->defer_walk) ? 0 : 1;  // (k6_walk_kernel follows k6_emit_kernel unless everything goes to the host, or the walk waits for the ranks' collectives)
     }
     if (part == 1) {
         launch_k6_pairs(a, na, s);

@@ -252,6 +252,9 @@ int dfail(bdx_dist* d, int code, const std::string& msg) {
 // host vector -> device words -> all-reduce -> host vector
 int allreduce_host(bdx_dist* d, std::vector<uint64_t>& v, hipStream_t s) {
     if (v.empty()) return BDX_OK;
+    // (one rank: the sum is the vector itself -- no copies, no collective, and above all no wait for the stream: the device walk that is
+    // enqueued when the host's share is agreed on keeps running beside the host's walk, as in bdx_run)
+    if (d->comm->world == 1) return BDX_OK;
     DHIP(d, d->b_words.ensure(v.size() * 8));
     DHIP(d, d->h_words.ensure(v.size() * 8));
     memcpy(d->h_words.p, v.data(), v.size() * 8);
@@ -663,6 +666,7 @@ int bdx_dist_run(bdx_dist* d) {
     phase([&]() -> int {
         C->table_in_hbm = world > 1;
         C->groups_in_hbm = world > 1;
+        C->defer_walk = world > 1;
         C->k6_cap = 0; C->k6_r_rec = nullptr; C->k6_r_pk = nullptr; C->k6_taint = nullptr; C->k3_tid_tail = nullptr;
         {   // (a set of reads bdx_dist_prepare has not seen: its order is checked before the chromosome table is searched in it)
             const int orc = check_order(d);
@@ -1181,6 +1185,9 @@ int bdx_dist_run(bdx_dist* d) {
     uint64_t mine_counts[8] = {0};
     phase([&]() -> int {
         C->walk.clear();
+        // (several ranks: the device's share of the walk starts here, behind the gather of the host's share -- C7's all-reduce and that
+        // gather did not have to wait for it, and rank 0 walks the gathered groups while every device walks its own)
+        if (C->defer_walk) DCTX(d, C, do_k6(C, force_host, 3));
         if (rank == 0) {
             const GroupRec* g = world > 1 ? host_groups.data() : C->h_groups.as<GroupRec>();
             decode_groups(C, g, (uint32_t)ng_all, 0);

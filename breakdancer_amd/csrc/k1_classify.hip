@@ -35,6 +35,8 @@
 
 namespace bdx {
 
+constexpr int kMixedLibs = 8;   // the several-libraries tile body counts proper reads per library with one ballot per library and slot
+
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef unsigned short v4us __attribute__((ext_vector_type(4)));
 typedef unsigned char v4uc __attribute__((ext_vector_type(4)));
@@ -134,6 +136,75 @@ __device__ __forceinline__ unsigned classify_uniform_tile(const K1Params& p, con
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         if (hist_on[r]) atomicAdd(&s_hist[hist_f[r]], 1u);
+    return word;
+}
+
+// The usual tile of a genome of several libraries in one file (configs[2]-[3]: every tile holds reads of all four read groups): full,
+// one source file, a library per READ.  The body of classify_uniform_tile with the library record fetched per slot from LDS (one
+// 16-byte read each) instead of held in scalar registers; the masks and the class bytes are the same.  Leaves, beside the totals'
+// masks, the proper-and-well-mapped mask per slot (the per-library counts of BamSummary.cpp:100-108 are taken from it by the caller)
+// and whether every read's library counts for the counter key k0.
+struct MixedMasks {
+    uint64_t bq[4];   // proper reads above their library's mapping-quality cutoff, per slot
+    bool one_key;     // (wave-uniform) every library in the tile has the counter key k0
+};
+
+template <bool kLongInsert>
+__device__ __forceinline__ unsigned classify_mixed_tile(const K1Params& p, const DevLib* s_lib, uint32_t* s_cnt, const unsigned (&L)[4], int k0,
+                                                        const int (&tid)[4], const int (&pos)[4], const int (&mtid)[4], const int (&mpos)[4],
+                                                        const int (&isz)[4], const unsigned (&sam)[4], unsigned mqp, TileMasks& tm, MixedMasks& mx) {
+    unsigned word = 0;
+    tm.c1 = 0;
+    const bool opt_t = p.opt_t != 0;
+    const uint64_t m_opt_t = opt_t ? ~0ull : 0ull;
+    int hist_i[4];
+    bool hist_on[4];
+    bool same_key = true;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const DevLib dl = s_lib[L[r]];
+        same_key = same_key && dl.key == k0;
+        const unsigned s = sam[r];
+        const int ai = abs(isz[r]);
+        const float fi = (float)ai;  // the reference compares int against the float cutoffs
+        const bool rr = (s & 0x10u) != 0;
+        const bool same_strand = ((s ^ (s >> 1)) & 0x10u) == 0;
+        const bool left = pos[r] < mpos[r];
+        const bool same_tid = tid[r] == mtid[r];
+        int f = fi < dl.lower ? F_SMALL : F_NORMAL_FR;
+        f = fi > dl.upper ? F_LARGE : f;
+        f = (left == rr) ? F_RF : f;
+        const int ss = rr ? F_RR : F_FF;
+        f = same_strand ? ss : f;
+        f = same_tid ? f : F_CTX;
+        f = (s & 0x8u) ? F_MATE_UNMAPPED : f;
+        f = (s & 0x4u) ? F_UNMAPPED : f;
+        f = ((s & 0x401u) != 0x1u) ? F_NA : f;
+        const bool mq_ok = (int)((mqp >> (8 * r)) & 0xffu) > dl.min_mapq;
+        const bool proper = (s & 0x40Fu) == 0x3u;
+        const bool plain = (s & 0x40Du) == 0x1u;
+        const bool h_ok = mq_ok & plain & !(opt_t & same_tid);
+        const int f1 = kLongInsert ? remap_long_insert(f, ai, dl.upper, dl.lower) : f;
+        const bool normal1 = (f1 & 14) == F_NORMAL_FR;
+        hist_i[r] = (int)L[r] * kNumFlags + f1; hist_on[r] = h_ok & !normal1;
+        const bool is_ctx = f == F_CTX, near = ai <= p.max_sd;
+        const bool pass = h_ok & (is_ctx | near);
+        const int f2 = (f1 == F_RR) ? F_FF : f1;
+        const bool nl = pass & normal1 & left;
+        const uint64_t m_mq = ballot64(mq_ok), m_prop = ballot64(proper), m_norm = ballot64(normal1);
+        const uint64_t m_hok = m_mq & ballot64(plain) & ~(m_opt_t & ballot64(same_tid));
+        const uint64_t m_pass = m_hok & (ballot64(is_ctx) | ballot64(near));
+        tm.ba[r] = m_pass & ~m_norm; tm.bn[r] = m_pass & m_norm & ballot64(left); tm.bp[r] = m_pass & m_prop;
+        mx.bq[r] = m_mq & m_prop;
+        tm.c1 += popc64(mx.bq[r]);
+        const unsigned hi = 0x10u | (proper ? 0x20u : 0u) | (nl ? 0x40u : 0u);
+        const unsigned byte = pass ? ((unsigned)f2 | hi) : (unsigned)f;
+        word |= byte << (8 * r);
+    }
+    mx.one_key = __all(same_key);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (hist_on[r]) atomicAdd(&s_cnt[hist_i[r]], 1u);
     return word;
 }
 
@@ -264,6 +335,79 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
                 const unsigned pieces = 2u * (na < (unsigned)kStashCap ? na : (unsigned)kStashCap);
                 if ((unsigned)lane < pieces) *((v4u*)(p.stash + (size_t)tile * kStashCap) + lane) = mine[lane];  // (plain store: K2 finds some of it in L2)
                 __builtin_amdgcn_wave_barrier();
+            }
+        } else if (nlibs <= kMixedLibs && __all(nvalid == 4 && bamp == b0 * 0x01010101u)) {
+            // ---- full, one source file, several libraries: the tiles of a genome whose read groups are different libraries ----------
+            const unsigned B0 = b0 < (unsigned)nbams ? b0 : 0u;
+            unsigned L[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const unsigned x = (libp >> (8 * r)) & 0xffu; L[r] = x < (unsigned)nlibs ? x : 0u; }
+            const int k0 = __builtin_amdgcn_readfirstlane(s_lib[L[0]].key);
+            TileMasks tm;
+            MixedMasks mx;
+            const unsigned word = classify_mixed_tile<kLongInsert>(p, s_lib, s_cnt, L, k0, tid, pos, mtid, mpos, isz, sam, mqp, tm, mx);
+            unsigned na = 0, nn = 0, ck = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { na += popc64(tm.ba[r]); nn += popc64(tm.bn[r]); ck += popc64(tm.bp[r]); }
+            *(uint32_t*)(p.cls + base) = word;
+            unsigned colval = lane == kColAnom ? na : (lane == kColNormal ? nn : 0u);
+            if (mx.one_key) {
+                if (lane == kColKey0 + k0) colval = ck;
+            } else {
+                for (int k = 0; k < nkeys; ++k) {   // (-a: a counter key per library)
+                    unsigned c = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) c += popc64(tm.bp[r] & ballot64(s_lib[L[r]].key == k));
+                    if (lane == kColKey0 + k) colval = c;
+                }
+            }
+            if (lane < ncols) p.tile_tot[(uint32_t)lane * p.tstride + tile] = colval;
+            if (tm.c1) {   // (wave-uniform) proper reads per library: one ballot per library and slot
+                for (int v = 0; v < nlibs; ++v) {
+                    unsigned c = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) c += popc64(mx.bq[r] & ballot64(L[r] == (unsigned)v));
+                    if (lane == 0 && c) atomicAdd(&s_libcnt[v], c);
+                }
+                if (lane == 0) atomicAdd(&s_bamcnt[B0], tm.c1);
+            }
+            one_file = true; file0 = B0;
+            if (p.stash && na) {
+                if (mx.one_key) {   // ready-made records for K2, as in the one-library tile; a record carries its own library
+                    unsigned ra = 0, rn = 0, rk = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ra = __builtin_amdgcn_mbcnt_hi((uint32_t)(tm.ba[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tm.ba[r], ra));
+                        rn = __builtin_amdgcn_mbcnt_hi((uint32_t)(tm.bn[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tm.bn[r], rn));
+                        rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(tm.bp[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tm.bp[r], rk));
+                    }
+                    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                    v4u* mine = s_stash[w];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned cb = (word >> (8 * r)) & 0xffu;
+                        const bool pass = (cb & 0x10u) != 0;
+                        const bool an = pass && (cb & 14u) != (unsigned)F_NORMAL_FR;
+                        rk += (cb & 0x30u) == 0x30u ? 1u : 0u;
+                        if (an && ra < (unsigned)kStashCap) {
+                            const v4u x0 = {(uint32_t)tid[r], (uint32_t)pos[r], (uint32_t)abs(isz[r]), (cb & 15u) | (((sam[r] >> 4) & 1u) << 4) | (L[r] << 8)};
+                            const v4u x1 = {(uint32_t)(lane * 4 + r) | (rn << 8) | ((uint32_t)k0 << 20), rk, 0u, 0u};
+                            mine[2 * ra] = x0;
+                            mine[2 * ra + 1] = x1;
+                        }
+                        ra += an ? 1u : 0u;
+                        rn += (cb & 0x40u) ? 1u : 0u;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const unsigned pieces = 2u * (na < (unsigned)kStashCap ? na : (unsigned)kStashCap);
+                    if ((unsigned)lane < pieces) *((v4u*)(p.stash + (size_t)tile * kStashCap) + lane) = mine[lane];
+                    __builtin_amdgcn_wave_barrier();
+                } else {
+                    int lane_o = lane;   // (opaque: the slot's address is worked out here, not kept in registers across the tile loop)
+                    asm volatile("" : "+v"(lane_o));
+                    if ((unsigned)lane_o < (na < (unsigned)kStashCap ? na : (unsigned)kStashCap))
+                        p.stash[(size_t)tile * kStashCap + lane_o].where = 0xFFFFFFFFu;  // (several counter keys in the tile: K2 compacts it from the columns)
+                }
             }
         } else {
         // ---- any other tile: ragged end of the input, several libraries or files in it ----------------------------------

@@ -480,10 +480,8 @@ int run(int argc, char** argv) {
             wanted.erase(std::unique(wanted.begin(), wanted.end()), wanted.end());
             collect_reads(cfg, opts.chr, (int)io_threads, wanted, sup_reads);
         }
-        size_t sv_i = 0;
-        for (auto const& s : svs) {  // BreakDancer.cpp:395-497
-            const size_t this_sv = sv_i++;
-            if (!s.printed) continue;
+        // one row of the table (BreakDancer.cpp:395-497) into `os`; returns nothing, the stream's manipulators carry over to the next row
+        auto print_row = [&](std::ostream& os, const bdx_sv& s) {
             std::map<int, float> cn;  // key -> copy number
             for (int i = 0; i < s.cn_count; ++i) cn[ck[s.cn_begin + i]] = cv[s.cn_begin + i];
             std::string sptype;
@@ -511,34 +509,80 @@ int run(int argc, char** argv) {
                 }
                 if (sptype.empty()) sptype = "NA";
             }
-            cout << tname(s.chr[0]) << "\t" << s.pos[0] << "\t" << s.fwd[0] << "+" << s.rev[0] << "-"
-                 << "\t" << tname(s.chr[1]) << "\t" << s.pos[1] << "\t" << s.fwd[1] << "+" << s.rev[1] << "-"
-                 << "\t" << opts.sv_type(s.flag) << "\t" << s.size << "\t" << s.score << "\t" << s.num_reads << "\t" << sptype;
-            if (opts.o.print_af) cout << "\t" << s.allele_frequency;
+            os << tname(s.chr[0]) << "\t" << s.pos[0] << "\t" << s.fwd[0] << "+" << s.rev[0] << "-"
+               << "\t" << tname(s.chr[1]) << "\t" << s.pos[1] << "\t" << s.fwd[1] << "+" << s.rev[1] << "-"
+               << "\t" << opts.sv_type(s.flag) << "\t" << s.size << "\t" << s.score << "\t" << s.num_reads << "\t" << sptype;
+            if (opts.o.print_af) os << "\t" << s.allele_frequency;
             if (!opts.o.cn_lib && s.flag != BDX_ARP_CTX) {
                 for (size_t b = 0; b < cfg.num_bams(); ++b) {
                     auto f = cn.find((int)b);
-                    if (f == cn.end()) cout << "\tNA";
+                    if (f == cn.end()) os << "\tNA";
                     else {
                         // the reference never resets these manipulators on cout: later allele frequencies print
                         // fixed with two decimals as well (BreakDancer.cpp:492-493)
-                        cout << "\t";
-                        cout << std::fixed;
-                        cout << std::setprecision(2) << f->second;
+                        os << "\t";
+                        os << std::fixed;
+                        os << std::setprecision(2) << f->second;
                     }
                 }
             }
-            cout << "\n";
-            if (want_dumps) {
-                SvForDump d;
-                d.chr0 = tname(s.chr[0]); d.pos0 = s.pos[0]; d.type = opts.sv_type(s.flag); d.size = s.size; d.flag = s.flag;
-                for (uint32_t k = sup_off[this_sv]; k < sup_off[this_sv + 1]; ++k) {
-                    const size_t w = std::lower_bound(wanted.begin(), wanted.end(), sup_idx[k]) - wanted.begin();
-                    d.reads.push_back(&sup_reads[w]);
-                    d.read_flags.push_back(sup_flag[k]);
+            os << "\n";
+        };
+        // does this row leave the stream printing fixed with two decimals (see print_row)?
+        auto sets_fixed = [&](const bdx_sv& s) {
+            if (opts.o.cn_lib || s.flag == BDX_ARP_CTX) return false;
+            for (int i = 0; i < s.cn_count; ++i)
+                if (ck[s.cn_begin + i] >= 0 && (size_t)ck[s.cn_begin + i] < cfg.num_bams()) return true;
+            return false;
+        };
+        // A large table (a genome's: tens of thousands of rows, 0.7 us each through the stream's formatting) is written by several threads,
+        // each into its own string stream that starts in the state the sequential loop would have reached at its first row; the strings
+        // leave in order.  The dumps (-g / -d) keep the sequential loop.
+        std::vector<size_t> printed_rows;
+        for (size_t i = 0; i < svs.size(); ++i)
+            if (svs[i].printed) printed_rows.push_back(i);
+        size_t fmt_threads = want_dumps || printed_rows.size() < 8192 ? 1 : std::min<size_t>(std::min<size_t>(io_threads, 8), printed_rows.size() / 2048);
+        if (const char* ft = getenv("BDX_FORMAT_THREADS"))   // (tests, A/B: 1 = the sequential loop; n = n threads whatever the table's size)
+            if (!want_dumps) fmt_threads = std::max<size_t>(1, std::min<size_t>((size_t)atoi(ft), std::max<size_t>(printed_rows.size(), 1)));
+        if (fmt_threads > 1) {
+            cout.flush();
+            const size_t none = (size_t)-1;
+            size_t flip_row = none;   // the first printed row that leaves the stream printing fixed (the rows behind it start that way)
+            const bool fixed_already = (cout.flags() & std::ios_base::fixed) != 0;
+            for (size_t k = 0; k < printed_rows.size() && !fixed_already; ++k)
+                if (sets_fixed(svs[printed_rows[k]])) { flip_row = k; break; }
+            std::vector<std::string> parts(fmt_threads);
+            std::vector<std::thread> workers;
+            for (size_t t = 0; t < fmt_threads; ++t)
+                workers.emplace_back([&, t] {
+                    const size_t k0 = printed_rows.size() * t / fmt_threads, k1 = printed_rows.size() * (t + 1) / fmt_threads;
+                    std::ostringstream os;
+                    os.flags(cout.flags());
+                    os.precision(cout.precision());
+                    if (flip_row != none && k0 > flip_row) { os << std::fixed; os << std::setprecision(2); }
+                    for (size_t k = k0; k < k1; ++k) print_row(os, svs[printed_rows[k]]);
+                    parts[t] = os.str();
+                });
+            for (auto& w : workers) w.join();
+            for (auto const& part : parts) cout.write(part.data(), (std::streamsize)part.size());
+            if (flip_row != none) { cout << std::fixed; cout << std::setprecision(2); }
+        } else {
+            size_t sv_i = 0;
+            for (auto const& s : svs) {
+                const size_t this_sv = sv_i++;
+                if (!s.printed) continue;
+                print_row(cout, s);
+                if (want_dumps) {
+                    SvForDump d;
+                    d.chr0 = tname(s.chr[0]); d.pos0 = s.pos[0]; d.type = opts.sv_type(s.flag); d.size = s.size; d.flag = s.flag;
+                    for (uint32_t k = sup_off[this_sv]; k < sup_off[this_sv + 1]; ++k) {
+                        const size_t w = std::lower_bound(wanted.begin(), wanted.end(), sup_idx[k]) - wanted.begin();
+                        d.reads.push_back(&sup_reads[w]);
+                        d.read_flags.push_back(sup_flag[k]);
+                    }
+                    if (bed) bed->write(d);
+                    if (fastq) fastq->write(d);
                 }
-                if (bed) bed->write(d);
-                if (fastq) fastq->write(d);
             }
         }
         if (timing) {

@@ -38,7 +38,9 @@ if __name__ == "__main__":
         m1 = re.search(r"_exit called at ([0-9.]+)", p.stderr.decode())
         if m0 and m1:
             print("      start -> main() %.3f s, main() -> _exit %.3f s, _exit -> process gone %.3f s" % (float(m0.group(1)) - w0, float(m1.group(1)) - float(m0.group(1)), w1 - float(m1.group(1))))
-        print("run %d %s: rc %d, %.3f s, %.1f M read-pairs/s, %.2f GB/s of BAM, %d SV rows" % (r, extra, p.returncode, dt, n / 2 / dt / 1e6, size / dt / 1e9, rows), flush=True)
+        import hashlib
+        digest = hashlib.md5(b"\n".join(l for l in p.stdout.splitlines() if not l.startswith(b"#Command") and not l.startswith(b"#Software"))).hexdigest()[:12]
+        print("run %d %s: rc %d, %.3f s, %.1f M read-pairs/s, %.2f GB/s of BAM, %d SV rows (md5 of the table %s)" % (r, extra, p.returncode, dt, n / 2 / dt / 1e6, size / dt / 1e9, rows, digest), flush=True)
         if r == runs - 1 or p.returncode:
             print("\n".join(l for l in p.stderr.decode().splitlines() if "bdx timing" in l or p.returncode))
     if prof:   # one more run under rocprofv3: kernel statistics and the timeline (gpurun_out/genome_kernel_stats.csv, genome_timeline.txt)
