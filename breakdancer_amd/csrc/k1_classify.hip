@@ -14,6 +14,11 @@
 // workgroup, and the per-file reference-length monoid of each tile goes to a plain per-tile table that a tiny
 // follow-up kernel folds in order.
 //
+// Three tile bodies, chosen per tile by two wave-wide tests: the usual tile of one library and one file (library record in scalar
+// registers), the tile of SEVERAL LIBRARIES IN ONE FILE (a genome whose read groups are different libraries: the record per read from LDS,
+// the same masks; 0.626 -> 0.527 ms for 116 M records of four libraries, 6.2 TB/s by 28 B/read), and the general body for everything
+// else (ragged end, several files in a tile, more than kMixedLibs libraries).
+//
 // Where the time goes (configs[1], 15 M reads, 400 MB): a kernel that only reads the nine columns in this shape takes 57 us, with
 // the 1 B/read class-byte store 64-66 us (tools/stream_probe.hip: next to the read stream a byte written costs about four read);
 // this kernel takes 68 us without and 73-75 us with the ready-made records for K2.  The instruction stream is not what bounds it:

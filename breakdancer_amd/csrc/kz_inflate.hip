@@ -215,8 +215,11 @@ __device__ bool build_tables(Lds& L, const uint8_t* lens, uint32_t n, uint16_t* 
     return true;
 }
 
+// kProf: the measurement build (its counters cost every step half a dozen instructions: they live in spilled scalar registers)
+template <bool kProf>
 __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __restrict__ in_all, const BgzfBlock* __restrict__ blocks, uint32_t nblk,
-                                                        uint8_t* out_all, uint32_t* __restrict__ status, unsigned long long* __restrict__ prof) {
+                                                        uint8_t* out_all, uint32_t* __restrict__ status, unsigned long long* __restrict__ prof_) {
+    unsigned long long* const prof = kProf ? prof_ : nullptr;
     __shared__ Lds L;
     // measurement hook (BDX_KZ_PROF, tools/bamdec_probe.py): per member {cycles in all, in headers + tables, steps, matches, slow codes, deflate blocks}
     unsigned long long t_begin = 0, t_tables = 0;
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
 
     while (!last && err == KZ_OK) {
         const unsigned long long t_hdr = prof ? __builtin_readcyclecounter() : 0;
-        ++n_dblk;
+        if (kProf) ++n_dblk;
         if (bitpos + 3 > bit_limit) { err = KZ_INPUT_OVERRUN; break; }
         KZ_ENSURE(bitpos >> 3);
         uint64_t w = ring_peek(L.ibuf, bitpos);
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
 
         // ---- the block's symbols ----
         for (;;) {
-            ++n_steps;
+            if (kProf) ++n_steps;
             if (bitpos > bit_limit) { err = KZ_INPUT_OVERRUN; break; }
             KZ_ENSURE(bitpos >> 3);
             // Every lane decodes the token that would start at its bit: a literal, or a whole length/distance pair (length
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
                 // the matches, in stream order (a later one may copy what an earlier one, or a literal of this step, produced)
                 uint64_t mm = mask & m_match;
                 if (mm & mask_gt(mdist, outpos + (uint32_t)offv)) { err = KZ_BAD_DISTANCE; break; }   // a source before the member's first byte
-                n_match += (uint32_t)__builtin_popcountll(mm);
+                if (kProf) n_match += (uint32_t)__builtin_popcountll(mm);
                 lds_order();
                 // Far matches first, all at once.  A source beyond the window is in HBM (written back at least two flushes ago) and depends on
                 // nothing this step produces, while in the loop below every far match costs the wave a round trip to memory of its own --
@@ -508,7 +511,7 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
             uint32_t sde = (uint32_t)__builtin_amdgcn_readlane((int)de, (int)pos);
             uint32_t kind = t_kind(se), used = t_len(se), lsym = t_value(se);
             if (kind == T_SLOW) {  // a code longer than the table's index (or none at all)
-                ++n_slow;
+                if (kProf) ++n_slow;
                 // canonical decoding, every length at once: lane l holds where the codes of length <= l end among the 15-bit prefixes
                 const uint32_t code15 = __builtin_bitreverse32((uint32_t)ws) >> 17;   // the next 15 bits, the first on top
                 const uint64_t shorter = mask_gt_s(L.lit_limit[lane & 15u], code15) & 0xFFFEull;
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
             }
             ws >>= used;
             if (kind == T_EOB) { bitpos += used; break; }
-            ++n_match;
+            if (kProf) ++n_match;
             uint32_t sbase, sx;
             length_of(lsym, &sbase, &sx);
             const uint32_t length = sbase + ((uint32_t)ws & ((1u << sx) - 1));
@@ -592,7 +595,8 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
 
 void launch_kz_inflate(const uint8_t* in, const BgzfBlock* blocks, uint32_t nblk, uint8_t* out, uint32_t* status, hipStream_t s, unsigned long long* prof) {
     if (!nblk) return;
-    hipLaunchKernelGGL(kz_inflate_kernel, dim3(nblk), dim3(64), 0, s, in, blocks, nblk, out, status, prof);
+    if (prof) hipLaunchKernelGGL(kz_inflate_kernel<true>, dim3(nblk), dim3(64), 0, s, in, blocks, nblk, out, status, prof);
+    else hipLaunchKernelGGL(kz_inflate_kernel<false>, dim3(nblk), dim3(64), 0, s, in, blocks, nblk, out, status, prof);
 }
 
 }  // namespace bdx

@@ -44,6 +44,20 @@ def test_config2_shape_four_libraries_three_chromosomes():
         compare(run, sharded_from_oracle(run, world=3), check_cls=False)
 
 
+def test_two_libraries_in_one_file_through_k1_s_several_libraries_tile_body():
+    """every tile holds reads of both read groups of ONE file: K1's body for such tiles (library record per read) -- with one counter
+    key for the tile (the ready-made records carry the read's own library), with a key per library (-a: two keys, the slots K2 would read
+    say that the tile has several), with the -l remaps and with -t"""
+    from breakdancer_amd.synth import make_genome
+    libs = ((400.0, 30.0), (300.0, 25.0))
+    d = make_genome([3_000_000, 2_000_000], coverage=20.0, seed=21, libs=libs, lib_bam=(0, 0), n_translocations=40)
+    cfg = "".join(cfg_line("rg%d" % i, "wgs.bam", "lib%d" % i, m, s) for i, (m, s) in enumerate(libs))
+    for kw in (dict(), dict(cn_lib=1, print_af=1), dict(illumina_long_insert=1), dict(transchr_rearrange=1, cn_lib=1), dict(min_map_qual=10)):
+        run = oracle_from_soa(d, cfg, ["wgs.bam"], make_opts(**kw), ["c1", "c2"])
+        assert run.n_svs > 30
+        compare(run, product_from_oracle(run))
+
+
 def test_config3_shape_translocations_with_dash_t():
     from breakdancer_amd.synth import make_genome
     d = make_genome([3_000_000, 2_500_000, 2_000_000, 1_500_000], coverage=15.0, seed=5, n_translocations=300)
