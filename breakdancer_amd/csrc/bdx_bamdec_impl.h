@@ -415,15 +415,21 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
     }
     {
         const char* ks = getenv("BDX_KZ_STREAM");
-        const bool third = ks && !strcmp(ks, "own");
-        if (third && sink && sink->stream) {
+        const bool prio = ks && !strcmp(ks, "prio");   // (experiment: the three streams with queue priorities -- record stages high, inflate low)
+        const bool third = (ks && !strcmp(ks, "own")) || prio;
+        int pr_least = 0, pr_greatest = 0;
+        if (prio && hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest) != hipSuccess) return bad(BDX_EHIP);
+        if (prio) {
+            if (hipStreamCreateWithPriority(&d->s_rec, hipStreamNonBlocking, pr_greatest) != hipSuccess) return bad(BDX_EHIP);
+        } else if (third && sink && sink->stream) {
             d->s_rec = sink->stream;
             d->borrowed_rec = true;
         } else if (hipStreamCreateWithFlags(&d->s_rec, hipStreamNonBlocking) != hipSuccess) {
             return bad(BDX_EHIP);
         }
         if (third) {
-            if (hipStreamCreateWithFlags(&d->s_inf, hipStreamNonBlocking) != hipSuccess) return bad(BDX_EHIP);
+            if (prio ? hipStreamCreateWithPriority(&d->s_inf, hipStreamNonBlocking, pr_least) != hipSuccess
+                     : hipStreamCreateWithFlags(&d->s_inf, hipStreamNonBlocking) != hipSuccess) return bad(BDX_EHIP);
             d->own_inf_stream = true;
         } else {
             d->s_inf = d->s_rec;

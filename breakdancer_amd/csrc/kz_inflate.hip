@@ -105,8 +105,8 @@ struct __attribute__((aligned(16))) Lds {
 // a second compare on this compiler), and a mask goes back to a lane predicate without any (inverse ballot: the mask becomes EXEC).
 __device__ __forceinline__ uint64_t mask_eq(uint32_t a, uint32_t b) { uint64_t r; asm("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ uint64_t mask_gt(uint32_t a, uint32_t b) { uint64_t r; asm("v_cmp_gt_u32_e64 %0, %1, %2" : "=s"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ uint64_t mask_le(uint32_t a, uint32_t b) { uint64_t r; asm("v_cmp_le_u32_e64 %0, %1, %2" : "=s"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ uint64_t mask_gt_s(uint32_t a, uint32_t sb) { uint64_t r; asm("v_cmp_gt_u32_e64 %0, %1, %2" : "=s"(r) : "v"(a), "s"(sb)); return r; }
+__device__ __forceinline__ uint64_t mask_le_s(uint32_t a, uint32_t sb) { uint64_t r; asm("v_cmp_le_u32_e64 %0, %1, %2" : "=s"(r) : "v"(a), "s"(sb)); return r; }   // (a constant in a scalar register: as a "v" operand it cost a v_mov per step)
 __device__ __forceinline__ bool lanes_of(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -443,6 +443,7 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
                 if (lanes_of(mask & m_lit)) L.obuf[(outpos + (uint32_t)offv) & kOBM] = (uint8_t)ev;
                 // the matches, in stream order (a later one may copy what an earlier one, or a literal of this step, produced)
                 uint64_t mm = mask & m_match;
+                if (mm) {   // (one step in six takes literals only: it skips the distances' arithmetic and the far-match tests)
                 if (mm & mask_gt(mdist, outpos + (uint32_t)offv)) { err = KZ_BAD_DISTANCE; break; }   // a source before the member's first byte
                 if (kProf) n_match += (uint32_t)__builtin_popcountll(mm);
                 lds_order();
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
                 // round trip saved does not pay for the instructions every step then carries.)
                 {
                     const uint32_t dstf = outpos + (uint32_t)offv;
-                    const uint64_t fmask = mm & mask_gt(mdist, kNearDist) & mask_le(mlen, 8u) & mask_le(dstf & kOBM, kOB - 8u);
+                    const uint64_t fmask = mm & mask_gt_s(mdist, kNearDist) & mask_le_s(mlen, 8u) & mask_le_s(dstf & kOBM, kOB - 8u);
                     const bool farm = lanes_of(fmask);
                     if (fmask) {
                         if (farm) {
@@ -498,6 +499,7 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
                             L.obuf[(dst + i) & kOBM] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     lds_order();
+                }
                 }
                 outpos += o;
             }
