@@ -727,6 +727,19 @@ def genome_leg(rank, world, local, dist, out, fraction=None, translocations=5000
                       "hbm_roofline_frac_whole_path": total / 2 / min(ts[1:]) * PATH_BYTES_PER_PAIR / 1e9 / HBM_PEAK_GBS,
                       "svs_printed": bd.summary()["n_svs_printed"],
                       "note": "bdx_run on ONE context holding all 24 chromosomes (default options; repeated runs without enqueue-ahead, best of 3)"}
+            # K1 on these records (every tile holds reads of the four libraries: its several-libraries tile body), by kernel-level HIP events
+            bd.set_stage_timing(True)
+            k1 = []
+            for it in range(6):
+                bd.run()
+                k1.append(bd.timings()["classify"])
+            bd.set_stage_timing(False)
+            k1 = [x for x in k1 if x > 0]
+            if k1:
+                k1_ms = sum(k1) / len(k1)
+                single["k1_classify"] = {"avg_kernel_ms": k1_ms, "achieved": total * 28 / (k1_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": total * 28 / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                         "note": "28 algorithmic bytes per read (SURVEY 8d), as in `roofline`; 4 libraries in one file"}
             bd.close()
         if rank != 0:
             return None
