@@ -417,7 +417,8 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
             // AND tells whether the walk goes on: not once the cursor has left the 64-bit window, kStepCap bytes have been produced or
             // the chain met a token the tables do not resolve (the step then stops in front of it).  The word as it stands before a token
             // is left in the token's lane (v_writelane): where its output begins.  v_readlane, v_writelane and s_bitset1 take the
-            // cursor from the word's low six bits as it is.
+            // cursor from the word's low six bits as it is.  Four tokens per turn of the loop: three of four branches fall through (63.4 against
+            // 62.7 GB/s; eight per turn the same).
             const uint32_t walk = lanes_of(m_lit | m_match) ? ((is_lit ? l1 : l1 + lx + dl + dx) | (olen << 8)) : kWalkStop;
             uint32_t co = 0, wtok, wtest, offs = 0;
             uint64_t mask = 0;
@@ -428,7 +429,26 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
                 "s_bitset1_b64 %[mask], %[co]\n\t"
                 "s_add_u32 %[co], %[co], %[w]\n\t"
                 "s_and_b32 %[t], %[co], %[exit]\n\t"
-                "s_cbranch_scc0 1b"
+                "s_cbranch_scc1 2f\n\t"
+                "v_readlane_b32 %[w], %[walk], %[co]\n\t"
+                "v_writelane_b32 %[offs], %[co], %[co]\n\t"
+                "s_bitset1_b64 %[mask], %[co]\n\t"
+                "s_add_u32 %[co], %[co], %[w]\n\t"
+                "s_and_b32 %[t], %[co], %[exit]\n\t"
+                "s_cbranch_scc1 2f\n\t"
+                "v_readlane_b32 %[w], %[walk], %[co]\n\t"
+                "v_writelane_b32 %[offs], %[co], %[co]\n\t"
+                "s_bitset1_b64 %[mask], %[co]\n\t"
+                "s_add_u32 %[co], %[co], %[w]\n\t"
+                "s_and_b32 %[t], %[co], %[exit]\n\t"
+                "s_cbranch_scc1 2f\n\t"
+                "v_readlane_b32 %[w], %[walk], %[co]\n\t"
+                "v_writelane_b32 %[offs], %[co], %[co]\n\t"
+                "s_bitset1_b64 %[mask], %[co]\n\t"
+                "s_add_u32 %[co], %[co], %[w]\n\t"
+                "s_and_b32 %[t], %[co], %[exit]\n\t"
+                "s_cbranch_scc0 1b\n\t"
+                "2:"
                 : [w] "=&s"(wtok), [t] "=&s"(wtest), [mask] "+s"(mask), [co] "+s"(co), [offs] "+v"(offs)
                 : [walk] "v"(walk), [exit] "s"(kWalkExit)
                 : "scc");
