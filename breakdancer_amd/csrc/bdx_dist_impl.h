@@ -797,6 +797,10 @@ int bdx_dist_run(bdx_dist* d) {
     for (int q = 0; q < world; ++q) { nscount[q] = (size_t)h_ncnt[q] * 2; nsdispl[q] = nnsend * 2; nnsend += h_ncnt[q]; }
     for (int q = 0; q < world; ++q) { rcount[q] = (size_t)v2[at_mat + (size_t)q * world + rank] * kxw; rdispl[q] = nrecv * kxw; nrecv += v2[at_mat + (size_t)q * world + rank]; }
     for (int q = 0; q < world; ++q) { nrcount[q] = (size_t)v2[at_mat + W2 + (size_t)q * world + rank] * 2; nrdispl[q] = nnrecv * 2; nnrecv += v2[at_mat + W2 + (size_t)q * world + rank]; }
+    // One rank: nothing travels -- its join sees every sighting of every name itself (a third one is K4's to report, as in bdx_run), so the
+    // census of names is not taken, and neither all-to-all is called (the CTX records of a lone rank are all its own: none is packed).
+    const bool solo = world == 1;
+    if (solo) nnrecv = 0;
     {
         // (the column sums are the same table on every rank: the limits trip everywhere at once)
         for (int r = 0; r < world; ++r) {
@@ -941,9 +945,10 @@ int bdx_dist_run(bdx_dist* d) {
     {
         const auto tp = std::chrono::steady_clock::now();
         // C4: the all-to-all of the CTX records (four 64-bit words each), then the census records
-        if (!comm.alltoallv_u64(d->b_send.as<uint64_t>(), scount.data(), sdispl.data(), d->b_recv.as<uint64_t>(), rcount.data(), rdispl.data(), s))
+        if (solo && nsend) return leave(dfail(d, BDX_EINTERNAL, "a lone rank packed inter-chromosomal records for another"));
+        if (!solo && !comm.alltoallv_u64(d->b_send.as<uint64_t>(), scount.data(), sdispl.data(), d->b_recv.as<uint64_t>(), rcount.data(), rdispl.data(), s))
             return leave(dfail(d, BDX_EHIP, comm.err));
-        if (!comm.alltoallv_u64(d->b_nsend.as<uint64_t>(), nscount.data(), nsdispl.data(), d->b_nrecv.as<uint64_t>(), nrcount.data(), nrdispl.data(), s))
+        if (!solo && !comm.alltoallv_u64(d->b_nsend.as<uint64_t>(), nscount.data(), nsdispl.data(), d->b_nrecv.as<uint64_t>(), nrcount.data(), nrdispl.data(), s))
             return leave(dfail(d, BDX_EHIP, comm.err));
         d->ctx_sent = nsend; d->ctx_received = nrecv;
         d->phase_ms[7] += ms_between(tp, std::chrono::steady_clock::now());
