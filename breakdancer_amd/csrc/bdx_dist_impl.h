@@ -748,28 +748,32 @@ int bdx_dist_run(bdx_dist* d) {
             st_up[0] = covered; st_up[1] = (uint32_t)window;
             memcpy(st_up + 2, cnt_g.data(), (size_t)ncnt * 4);
             memcpy(st_up + 2 + ncnt, C->key_density.data(), C->key_density.size() * 4);
-            DHIP(d, hipMemcpyAsync(C->b_p1.p, st_up, 8, hipMemcpyHostToDevice, s));
-            DHIP(d, hipMemcpyAsync(C->b_cnt.p, st_up + 2, (size_t)ncnt * 4, hipMemcpyHostToDevice, s));
-            DHIP(d, hipMemcpyAsync(C->b_kdens.p, st_up + 2 + ncnt, C->key_density.size() * 4, hipMemcpyHostToDevice, s));
+            // (these tables, the exchange counters' start values and -- with anomalous reads -- the chromosomes' offsets and owners go up in
+            // ONE launch that reads them from the pinned report area: as six copy / fill commands they were six 5 us blits with their gaps)
+            UploadList ul{};
+            ul.copy(C->b_p1.p, st_up, 2);
+            ul.copy(C->b_cnt.p, st_up + 2, (size_t)ncnt);
+            ul.copy(C->b_kdens.p, st_up + 2 + ncnt, C->key_density.size());
+            // (the exchange counters and the error words of the later kernels: also on a rank without anomalous reads -- rank 0 checks the word
+            // k8_place_regions leaves whether or not it holds reads itself)
+            ul.fill(T + o_cnt, 0u, (size_t)world * 4 + 4);
+            if (na) {
+                uint32_t* up = UP + L.up_off;
+                for (int t = 0; t < ntids; ++t) {
+                    const uint32_t* a = &tidtab[(size_t)t * (1 + ncols)];
+                    for (int k = 0; k < 1 + nkeys; ++k) up[(size_t)t * (1 + nkeys) + k] = (uint32_t)base[(size_t)t * tw + 1 + k] - a[1 + 1 + k];
+                }
+                ul.copy(T + o_off, up, (size_t)ntids * (1 + nkeys));
+                uint32_t* um = UP + L.up_misc;   // owner [ntids] | first read of every chromosome in this context [ntids + 1]   (roff follows later)
+                for (int t = 0; t < ntids; ++t) { um[t] = (uint32_t)owner[t]; um[(size_t)ntids + t] = tidtab[(size_t)t * (1 + ncols)]; }
+                um[(size_t)2 * ntids] = tidtab[(size_t)ntids * (1 + ncols)];
+                ul.copy(T + o_owner, um, (size_t)2 * ntids + 1);
+            }
+            launch_k9_upload(ul, s);
         }
         DCTX(d, C, do_compact(C, 0, nullptr, true));
         trace("compaction");
-        // (the exchange counters and the error words of the later kernels: also on a rank without anomalous reads -- rank 0 checks the word
-        // k8_place_regions leaves whether or not it holds reads itself)
-        DHIP(d, hipMemsetAsync(T + o_cnt, 0, (size_t)world * 16 + 16, s));
         if (!na) { C->k4 = K4Arrays{}; return BDX_OK; }
-        {
-            uint32_t* up = UP + L.up_off;
-            for (int t = 0; t < ntids; ++t) {
-                const uint32_t* a = &tidtab[(size_t)t * (1 + ncols)];
-                for (int k = 0; k < 1 + nkeys; ++k) up[(size_t)t * (1 + nkeys) + k] = (uint32_t)base[(size_t)t * tw + 1 + k] - a[1 + 1 + k];
-            }
-            DHIP(d, hipMemcpyAsync(T + o_off, up, (size_t)ntids * (1 + nkeys) * 4, hipMemcpyHostToDevice, s));
-            uint32_t* um = UP + L.up_misc;   // owner [ntids] | first read of every chromosome in this context [ntids + 1]   (roff follows later)
-            for (int t = 0; t < ntids; ++t) { um[t] = (uint32_t)owner[t]; um[(size_t)ntids + t] = tidtab[(size_t)t * (1 + ncols)]; }
-            um[(size_t)2 * ntids] = tidtab[(size_t)ntids * (1 + ncols)];
-            DHIP(d, hipMemcpyAsync(T + o_owner, um, ((size_t)2 * ntids + 1) * 4, hipMemcpyHostToDevice, s));
-        }
         memset(H + L.first, 0, (size_t)ntids * 16);
         launch_k9_rebase(C->cp, &C->b_p1.as<Pass1>()->n_anom, na, nkeys, T + o_off, H + L.first, s);
         xs.key = C->cp.key; xs.check = C->cp.check; xs.meta = C->cp.meta; xs.tid = C->cp.tid; xs.idx = C->cp.idx; xs.mtid_col = C->d.mtid;
@@ -906,10 +910,17 @@ int bdx_dist_run(bdx_dist* d) {
             X = d->b_x.as<uint64_t>();
             DHIP(d, hipMemsetAsync(d->b_rg_rec.p, 0, (size_t)NR * sizeof(RegionRec), s));
             DHIP(d, hipMemsetAsync(X, 0, (x_words + (size_t)world) * 8, s));
-            {
+            {   // (the chromosomes' region offsets and the exchange's cursors: one launch, as above)
+                UploadList ul{};
                 uint32_t* ur = UP + L.up_misc + (size_t)2 * ntids + 1;
                 for (int t = 0; t < ntids; ++t) ur[t] = (uint32_t)rbase[t] - rtab[t];
-                DHIP(d, hipMemcpyAsync(T + o_roff, ur, (size_t)ntids * 4, hipMemcpyHostToDevice, s));
+                ul.copy(T + o_roff, ur, (size_t)ntids);
+                if (na) {
+                    uint32_t* cur = UP + L.up_cur;
+                    for (int q = 0; q < world; ++q) { cur[q] = (uint32_t)(sdispl[q] / kxw); cur[(size_t)world + q] = (uint32_t)(nsdispl[q] / 2); }
+                    ul.copy(T + o_cnt + 2 * (size_t)world, cur, (size_t)world * 2);
+                }
+                launch_k9_upload(ul, s);
             }
             GlobalizeParams gp{};
             gp.tid = C->cp.tid; gp.region_of = C->k3.region_of; gp.n_ptr = &C->b_p1.as<Pass1>()->n_anom;
@@ -922,9 +933,6 @@ int bdx_dist_run(bdx_dist* d) {
             C->k6_cap = (uint32_t)NR; C->k6_r_rec = d->b_rg_rec.as<RegionRec>(); C->k6_r_pk = d->b_rg_pk.as<uint32_t>();
             C->k6_taint = world > 1 ? (uint8_t*)(X + x_taint) : nullptr;
             if (na) {
-                uint32_t* cur = UP + L.up_cur;
-                for (int q = 0; q < world; ++q) { cur[q] = (uint32_t)(sdispl[q] / kxw); cur[(size_t)world + q] = (uint32_t)(nsdispl[q] / 2); }
-                DHIP(d, hipMemcpyAsync(T + o_cnt + 2 * (size_t)world, cur, (size_t)world * 8, hipMemcpyHostToDevice, s));
                 xs.region_of = C->k3.region_of;
                 launch_k7_scatter(xs, na, T + o_cnt + 2 * (size_t)world, d->b_send.as<ExchangeEntry>(), d->b_nsend.as<unsigned long long>(), s);
             }

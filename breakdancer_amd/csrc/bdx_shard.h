@@ -29,6 +29,18 @@ void launch_k9_tid_table(const TidTableParams& p, hipStream_t s);
 void launch_k9_check_sorted(const int32_t* tid, uint64_t n, int ntids, uint32_t* err, hipStream_t s);
 // one thread behind a kernel boundary: *flag = value (the host polls the pinned word)
 void launch_k9_signal(uint32_t* flag, uint32_t value, hipStream_t s);
+// A handful of small tables from the rank's pinned report area into HBM (and small fills) in ONE launch: each of them as a copy or fill
+// command of its own is a 5 us blit kernel with a gap in front of it (six of them between pass 1 and the compaction of a sharded run).
+struct UploadList {
+    uint32_t* dst[8];
+    const uint32_t* src[8];   // pinned host memory, read by the kernel (null: fill with `value`)
+    uint32_t words[8];
+    uint32_t value[8];
+    int n;
+    void copy(void* d, const void* s_, size_t w) { dst[n] = (uint32_t*)d; src[n] = (const uint32_t*)s_; words[n] = (uint32_t)w; value[n] = 0; ++n; }
+    void fill(void* d, uint32_t v, size_t w) { dst[n] = (uint32_t*)d; src[n] = nullptr; words[n] = (uint32_t)w; value[n] = v; ++n; }
+};
+void launch_k9_upload(const UploadList& l, hipStream_t s);
 // ... after n words of device memory have been copied into the (pinned) report area
 void launch_k9_report(const uint32_t* src, uint32_t* dst, uint32_t n, uint32_t* flag, uint32_t value, hipStream_t s);
 // compact records: the counters of chromosome t's reads get tid_off[t][0] (normal pairs) and tid_off[t][1 + k] (proper reads of key k)

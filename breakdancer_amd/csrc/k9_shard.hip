@@ -108,6 +108,20 @@ __global__ __launch_bounds__(64) void k9_signal_kernel(uint32_t* flag, uint32_t 
 }
 void launch_k9_signal(uint32_t* flag, uint32_t value, hipStream_t s) { hipLaunchKernelGGL(k9_signal_kernel, dim3(1), dim3(64), 0, s, flag, value); }
 
+__global__ __launch_bounds__(256) void k9_upload_kernel(const UploadList l) {
+    for (int f = 0; f < l.n; ++f) {
+        const uint32_t* src = l.src[f];
+        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < l.words[f]; i += gridDim.x * 256) l.dst[f][i] = src ? src[i] : l.value[f];
+    }
+}
+void launch_k9_upload(const UploadList& l, hipStream_t s) {
+    uint32_t mx = 0;
+    for (int f = 0; f < l.n; ++f) mx = l.words[f] > mx ? l.words[f] : mx;
+    if (!mx) return;
+    const uint32_t g = (mx + 255) / 256;
+    hipLaunchKernelGGL(k9_upload_kernel, dim3(g < 64u ? g : 64u), dim3(256), 0, s, l);
+}
+
 // a few words from HBM into the host's report area, then the ready word (one small launch instead of a copy command and a launch)
 __global__ __launch_bounds__(64) void k9_report_kernel(const uint32_t* src, uint32_t* dst, uint32_t n, uint32_t* flag, uint32_t value) {
     for (uint32_t i = threadIdx.x; i < n; i += 64) dst[i] = src[i];
