@@ -806,7 +806,12 @@ int do_pass1(bdx_ctx* c, uint32_t na_cap, bool wait, bool defer_second) {
 // the pass-1 record and counters, written into pinned memory by finalize2_kernel
 int wait_pass1(bdx_ctx* c) {
     const int ncnt = c->nlibs * kNumFlags + c->nlibs + c->nbams;
-    if (!wait_flag(c, 0, c->seq)) HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!wait_flag(c, 0, c->seq)) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        // (the word is set by the kernel that writes the record, whether or not the host polls for it: a stream that has drained without it
+        // means that kernel was never launched -- an empty pass-1 record must not pass for a BAM without reads)
+        if (c->h_flags.p && *((volatile uint32_t*)c->h_flags.p) != c->seq) return fail(c, BDX_EINTERNAL, "the pass-1 record did not arrive: its kernel was not launched");
+    }
     c->p1 = *c->h_p1.as<Pass1>();
     c->cnt_local.assign(c->h_cnt.as<uint32_t>(), c->h_cnt.as<uint32_t>() + ncnt);
     if (c->k1_timed) {

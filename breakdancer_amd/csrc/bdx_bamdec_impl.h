@@ -857,6 +857,14 @@ int bdx_bamdec_finish(bdx_bamdec* d, uint64_t* n_records) {
     }
     if (d->sink) {
         const int rc = bam_feed_classifier(d, true);
+        // (a file of fewer than four batches: the sizing thread is started by this last feed -- and must be through before the caller's
+        // bdx_run works on the same context: running beside it, its `alloc_only` made the run's stages return without launching anything,
+        // the pass-1 record never arrived and the run ended, after its 200 ms wait, with an EMPTY table and no error: 13 of 30 runs of a
+        // 0.5 GB BAM, found by tools/determinism_probe.py in round 5)
+        if (d->presize_thread.joinable()) {
+            d->presize_thread.join();
+            if (rc == BDX_OK && d->presize_rc != BDX_OK) return bfail(d, d->presize_rc, d->sink->err);
+        }
         if (rc != BDX_OK) return rc;
         d->sink->n = (size_t)st.n_kept;
         d->sink->ran = false;

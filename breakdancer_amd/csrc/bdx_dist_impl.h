@@ -779,8 +779,13 @@ int bdx_dist_run(bdx_dist* d) {
         xs.key = C->cp.key; xs.check = C->cp.check; xs.meta = C->cp.meta; xs.tid = C->cp.tid; xs.idx = C->cp.idx; xs.mtid_col = C->d.mtid;
         xs.region_of = nullptr; xs.n_ptr = &C->b_p1.as<Pass1>()->n_anom; xs.owner_of_tid = (const int32_t*)(T + o_owner);
         xs.ntids = ntids; xs.me = rank; xs.world = (uint32_t)world;
-        launch_k7_count(xs, na, T + o_cnt, s);
-        launch_k9_report(T + o_cnt, H + L.cnts, 2 * (uint32_t)world, H + 1, d->seq, s);
+        if (world == 1) {   // (a lone rank: nothing travels, nothing is counted or packed for the exchange; the ready word behind the rebase)
+            H[L.cnts] = 0; H[L.cnts + 1] = 0;
+            launch_k9_signal(H + 1, d->seq, s);
+        } else {
+            launch_k7_count(xs, na, T + o_cnt, s);
+            launch_k9_report(T + o_cnt, H + L.cnts, 2 * (uint32_t)world, H + 1, d->seq, s);
+        }
         if (!wait_word(flags + 1, d->seq)) DHIP(d, hipStreamSynchronize(s));
         trace("rebase and counts");
         for (int t = 0; t < ntids; ++t) {
@@ -932,7 +937,7 @@ int bdx_dist_run(bdx_dist* d) {
             launch_k9_window_collect(d->b_rg_rec.as<RegionRec>(), (uint32_t)NR, period, (unsigned long long*)X, s);
             C->k6_cap = (uint32_t)NR; C->k6_r_rec = d->b_rg_rec.as<RegionRec>(); C->k6_r_pk = d->b_rg_pk.as<uint32_t>();
             C->k6_taint = world > 1 ? (uint8_t*)(X + x_taint) : nullptr;
-            if (na) {
+            if (na && world > 1) {
                 xs.region_of = C->k3.region_of;
                 launch_k7_scatter(xs, na, T + o_cnt + 2 * (size_t)world, d->b_send.as<ExchangeEntry>(), d->b_nsend.as<unsigned long long>(), s);
             }

@@ -335,3 +335,20 @@ def test_cli_file_of_tens_of_thousands_of_tiny_members(tmp_path):
     strip = lambda t: t.replace("big.bam", "a.bam")
     assert texts["tiny"][0] == texts["tiny-host"][0] == strip(texts["ordinary"][0])
     assert [l for l in texts["tiny"][0].splitlines() if not l.startswith("#")]
+
+
+def test_cli_prints_the_same_table_every_time_on_a_file_of_few_batches(tmp_path):
+    """a BAM of a few million records in fewer than four decoder batches: the thread that sizes the later stages is started by the decoder's
+    LAST feed, and bdx_bamdec_finish must wait for it -- beside bdx_run its `alloc_only` made the run's stages return without launching
+    anything, and four runs in ten ended with an EMPTY table and no error (round 5, tools/determinism_probe.py).  Ten runs, one table."""
+    from breakdancer_amd.bamwrite import write_genome_bam
+    bam, cfg, n = write_genome_bam(str(tmp_path), 0.004)
+    assert n > (1 << 20) and os.path.getsize(bam) < (1 << 30)
+    texts = set()
+    for _ in range(10):
+        p = subprocess.run([EXE, cfg], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, BDX_FOREGROUND="1"))
+        assert p.returncode == 0, p.stderr.decode()
+        texts.add(filter_cmd_lines(p.stdout.decode()))
+    assert len(texts) == 1
+    rows = [l for l in texts.pop().splitlines() if l and not l.startswith("#")]
+    assert len(rows) > 1000
