@@ -639,6 +639,12 @@ bool wait_flag(const bdx_ctx* c, int idx, uint32_t value) {
     }
 }
 
+// behind a poll that timed out and a stream that has drained: was the word written at all?  (A kernel that was never launched -- a
+// launch that failed, a stage that returned early -- leaves zeros where its results should be; they must not pass for an empty input.)
+bool flag_arrived(const bdx_ctx* c, int idx) {
+    return !c->poll || !c->h_flags.p || ((volatile uint32_t*)c->h_flags.p)[idx] == c->seq;
+}
+
 // Tell the host that everything enqueued so far has completed: a stream write-value into a polled pinned word, or (polling
 // off / the stream operation unavailable) an event.  The word must be written AFTER a kernel boundary behind the kernels
 // whose results it announces (their stores to host memory come from several compute dies; only the end of the kernel
@@ -1374,7 +1380,10 @@ int materialize(bdx_ctx* c) {
 int finish_table(bdx_ctx* c) {
     hipStream_t s = c->stream;
     const auto tf0 = std::chrono::steady_clock::now();
-    if (!wait_flag(c, 2, c->seq)) HIPCHK(c, hipStreamSynchronize(s));
+    if (!wait_flag(c, 2, c->seq)) {
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (!flag_arrived(c, 2)) return fail(c, BDX_EINTERNAL, "the SV table did not arrive: its kernels were not launched");
+    }
     const auto tf1 = std::chrono::steady_clock::now();
     static_assert(sizeof(HostSv) == sizeof(SvOut) && offsetof(HostSv, grp_mask) == offsetof(SvOut, grp_mask) &&
                       offsetof(HostSv, start) == offsetof(SvOut, start), "SV record layout");
@@ -1672,6 +1681,7 @@ int bdx_run(bdx_ctx* c) {
     if (na) {
         if (!wait_flag(c, 3, c->seq)) {
             if (c->poll) HIPCHK(c, hipStreamSynchronize(s)); else HIPCHK(c, hipEventSynchronize(c->ev_regions));
+            if (!flag_arrived(c, 3)) return fail(c, BDX_EINTERNAL, "the region table did not arrive: its kernels were not launched");
         }
         // (the table sits in pinned memory the device has just written: one streaming copy into ordinary memory is much
         // cheaper than the walk's scattered reads of it)
@@ -1682,6 +1692,7 @@ int bdx_run(bdx_ctx* c) {
         decode_regions(c, c->h_regs.as<RegionRec>(), c->h_pk.as<uint32_t>(), c->h_counts0.as<StageCounts>()->n_regions, ph, false);
         if (!wait_flag(c, 1, c->seq)) {
             if (c->poll) HIPCHK(c, hipStreamSynchronize(s)); else HIPCHK(c, hipEventSynchronize(c->ev_groups));
+            if (!flag_arrived(c, 1)) return fail(c, BDX_EINTERNAL, "the pair groups did not arrive: their kernels were not launched");
         }
         c->counts = *c->h_counts.as<StageCounts>();
         if (c->counts.irregular) {  // a read name seen more than twice: the pair model does not hold (see bdx_walk_reads.cpp)

@@ -681,7 +681,10 @@ int bdx_dist_run(bdx_dist* d) {
         launch_k9_tid_table(tp, s);
         launch_k9_signal(H + 0, d->seq, s);
         DCTX(d, C, wait_pass1(C));
-        if (!wait_word(flags + 0, d->seq)) DHIP(d, hipStreamSynchronize(s));
+        if (!wait_word(flags + 0, d->seq)) {
+            DHIP(d, hipStreamSynchronize(s));
+            if (flags[0] != d->seq) return dfail(d, BDX_EINTERNAL, "the chromosome table did not arrive: its kernels were not launched");
+        }
         trace("chromosome table");
         memcpy(tidtab.data(), H + L.tidtab, tidtab.size() * 4);
         const uint32_t* terr = H + L.tidtab + tidtab.size();
@@ -786,7 +789,10 @@ int bdx_dist_run(bdx_dist* d) {
             launch_k7_count(xs, na, T + o_cnt, s);
             launch_k9_report(T + o_cnt, H + L.cnts, 2 * (uint32_t)world, H + 1, d->seq, s);
         }
-        if (!wait_word(flags + 1, d->seq)) DHIP(d, hipStreamSynchronize(s));
+        if (!wait_word(flags + 1, d->seq)) {
+            DHIP(d, hipStreamSynchronize(s));
+            if (flags[1] != d->seq) return dfail(d, BDX_EINTERNAL, "the chromosomes' first reads did not arrive: its kernels were not launched");
+        }
         trace("rebase and counts");
         for (int t = 0; t < ntids; ++t) {
             const uint32_t* f = H + L.first + (size_t)t * 4;
@@ -847,7 +853,10 @@ int bdx_dist_run(bdx_dist* d) {
         trace("region cut");
         launch_k9_tid_regions(C->b_r_rec.as<RegionRec>(), C->b_counts.as<StageCounts>(), ntids, H + L.rtab, s);
         launch_k9_signal(H + 2, d->seq, s);
-        if (!wait_word(flags + 2, d->seq)) DHIP(d, hipStreamSynchronize(s));
+        if (!wait_word(flags + 2, d->seq)) {
+            DHIP(d, hipStreamSynchronize(s));
+            if (flags[2] != d->seq) return dfail(d, BDX_EINTERNAL, "the chromosomes' region counts did not arrive: its kernels were not launched");
+        }
         memcpy(rtab.data(), H + L.rtab, rtab.size() * 4);
         for (int t = 0; t < ntids; ++t) v3[t] = rtab[t + 1] - rtab[t];
         if (last_anom_tid >= 0 && owner[last_anom_tid] == rank) v3[ntids] = rtab[ntids + 2];
@@ -1088,6 +1097,7 @@ int bdx_dist_run(bdx_dist* d) {
         }
         if (!wait_flag(C, 1, C->seq)) {
             if (C->poll) DHIP(d, hipStreamSynchronize(s)); else DHIP(d, hipEventSynchronize(C->ev_groups));
+            if (!flag_arrived(C, 1)) return dfail(d, BDX_EINTERNAL, "the pair groups did not arrive: their kernels were not launched");
         }
         C->counts = *C->h_counts.as<StageCounts>();
         if (C->counts.irregular) irregular = 1;   // a read name seen more than twice: the run is replayed read by read on rank 0 (below)
