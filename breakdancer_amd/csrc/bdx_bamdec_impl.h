@@ -688,7 +688,7 @@ int bam_launch_batch(bdx_bamdec* d, int si, bool last) {
     if (nblocks) BHIP(d, hipMemcpyAsync(sl.d_blocks.p, tb, nblocks * sizeof(BgzfBlock), hipMemcpyHostToDevice, d->s_copy));
     BHIP(d, hipEventRecord(sl.ev_copied, d->s_copy));
     BHIP(d, hipStreamWaitEvent(s_inf, sl.ev_copied, 0));
-    if (kz_pick_lanes(nblocks, sl.bytes, ulen)) {
+    if (!d->sink && kz_pick_lanes(nblocks, sl.bytes, ulen)) {   // (a decoder that feeds a context -- the CLI's -- always runs the wave kernel: the other path faulted there at any batch size, see kz_pick_lanes)
         const size_t words = kz_bitmap_words(ulen, nblocks);
         BHIP(d, sl.d_bitmap.ensure(std::max(words, kz_bitmap_words(d->ring_bytes / 4, std::max(nblocks, sl.cap_blk))) * 4));   // (once: what a batch can be)
         launch_kz_inflate_lanes(sl.d_comp.as<uint8_t>(), sl.d_blocks.as<BgzfBlock>(), (uint32_t)nblocks, d->d_ring.as<uint8_t>(), sl.d_status.as<uint32_t>(),

@@ -595,11 +595,14 @@ __global__ __launch_bounds__(64) void kz_resolve_kernel(const BgzfBlock* __restr
 }  // namespace
 
 bool kz_pick_lanes(size_t nblk, size_t comp_bytes, size_t infl_bytes) {
-    (void)nblk; (void)comp_bytes; (void)infl_bytes;
+    (void)nblk; (void)comp_bytes;
     // Measured (profiles/r04_inflate_probe.txt): this path does not beat the wave kernel at configs[1]'s 49 k members, so it is
-    // taken only on request -- BDX_KZ=lanes (the parity tests, tools/bamdec_probe.py, tools/kz_stats.sh)
+    // taken only on request -- BDX_KZ=lanes (the parity tests, tools/bamdec_probe.py, tools/kz_stats.sh) -- and only for launches of
+    // at most 256 MiB of output: round 5's determinism probe met a memory fault in a launch of 0.8 GB (12 k members; 0.5 GB and less
+    // decode byte for byte), and a path that lost the measurement is not worth chasing it -- larger launches run the wave kernel.
+    // (The CLI's decoder never takes this path: bdx_bamdec_impl.h.)
     const char* e = getenv("BDX_KZ");
-    return e && !strcmp(e, "lanes");
+    return e && !strcmp(e, "lanes") && infl_bytes <= ((size_t)256 << 20);
 }
 
 size_t kz_bitmap_words(size_t out_span_bytes, size_t nblk) { return 2 * ((out_span_bytes >> 5) + nblk + 8); }

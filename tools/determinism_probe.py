@@ -14,7 +14,7 @@ os.makedirs(td, exist_ok=True)
 bam, cfg, n = write_genome_bam(td, fraction)
 seen = {}
 for r in range(runs):
-    p = subprocess.run([os.path.join(ROOT, "bin", "breakdancer-max")] + cli_args + [cfg], cwd=td, env=dict(os.environ, BDX_FOREGROUND="1", **extra), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    p = subprocess.run([os.path.join(ROOT, "bin", "breakdancer-max")] + cli_args + [cfg], cwd=td, env=dict(os.environ, **dict({"BDX_FOREGROUND": "1"}, **extra)), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     text = "\n".join(l for l in p.stdout.decode().splitlines() if not l.startswith("#Command") and not l.startswith("#Software"))
     h = hashlib.md5(text.encode()).hexdigest()[:10]
     seen.setdefault(h, [0, text, p.returncode, p.stderr.decode()])
