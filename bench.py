@@ -690,9 +690,12 @@ def genome_leg(rank, world, local, dist, out, fraction=None, translocations=5000
             if rank == 0:
                 sm = res.summary()
                 ph = ranks[0].phases()
-                dt = times[0]
+                # (as for single_context below: `seconds` is the run on handles that have run before; the first run of a process's first
+                # set of handles also pays one-off costs of the process -- 2.2 ms in a fresh process (tools/genome_probe.py), 2-9 ms here,
+                # depending on what the process did before -- and is reported beside it)
+                dt = times[1]
                 r0 = ph.get("rank0_only_merge", 0.0) + ph.get("rank0_only_host_walk", 0.0)
-                legs[label] = {"seconds": dt, "value": total / 2 / dt, "unit": "read-pairs/s", "second_run_seconds": times[1],
+                legs[label] = {"seconds": dt, "value": total / 2 / dt, "unit": "read-pairs/s", "first_run_seconds": times[0], "second_run_seconds": times[1],
                                "hbm_roofline_frac_whole_path": total / 2 / dt / world * PATH_BYTES_PER_PAIR / 1e9 / HBM_PEAK_GBS,
                                "svs_printed": sm["n_svs_printed"], "regions": sm["n_regions"], "sv_candidates_device_host": list(res.walk_split())[:2],
                                "ctx_records_exchanged": sent, "gathered_bytes_on_rank0": ex[0]["gathered_bytes"],
