@@ -690,9 +690,9 @@ def genome_leg(rank, world, local, dist, out, fraction=None, translocations=5000
             if rank == 0:
                 sm = res.summary()
                 ph = ranks[0].phases()
-                # (as for single_context below: `seconds` is the run on handles that have run before; the first run of a process's first
-                # set of handles also pays one-off costs of the process -- 2.2 ms in a fresh process (tools/genome_probe.py), 2-9 ms here,
-                # depending on what the process did before -- and is reported beside it)
+                # (as for single_context below: `seconds` is the run on handles that have run before; the first run is reported beside it --
+                # 2.0-2.2 ms since the region table goes to the host through a kernel: the first device-to-host copy COMMAND of a process
+                # sets up a copy-engine queue, 6 ms inside this process's first run until then)
                 dt = times[1]
                 r0 = ph.get("rank0_only_merge", 0.0) + ph.get("rank0_only_host_walk", 0.0)
                 legs[label] = {"seconds": dt, "value": total / 2 / dt, "unit": "read-pairs/s", "first_run_seconds": times[0], "second_run_seconds": times[1],

@@ -1019,10 +1019,18 @@ int bdx_dist_run(bdx_dist* d) {
                 src_rec = U->b_r_rec.as<RegionRec>(); src_pk = U->b_r_pk.as<uint32_t>();
             }
             // (on the context's second stream, behind what has been enqueued so far: the joins and the pair groups do not wait for it)
-            if (hipEventRecord(C->ev_copy, s) != hipSuccess || hipStreamWaitEvent(C->copy_stream, C->ev_copy, 0) != hipSuccess ||
-                hipMemcpyAsync(regs, src_rec, (size_t)NR * rrec, hipMemcpyDeviceToHost, C->copy_stream) != hipSuccess ||
-                (nkeys2 && hipMemcpyAsync(pk, src_pk, (size_t)NR * rpk, hipMemcpyDeviceToHost, C->copy_stream) != hipSuccess))
+            // (written into the pinned table by a kernel, not by copy commands: the first device-to-host copy command of a process sets up a
+            // copy-engine queue -- 6 ms in front of the joins of a process's first run, BDX_DIST_TRACE -- and the kernel's stores cross PCIe
+            // as the result tables of bdx_run do)
+            if (hipEventRecord(C->ev_copy, s) != hipSuccess || hipStreamWaitEvent(C->copy_stream, C->ev_copy, 0) != hipSuccess)
                 return leave(dfail(d, BDX_EHIP, "region table"));
+            {
+                static_assert(sizeof(RegionRec) % 4 == 0, "copied by words");
+                UploadList ul{};
+                ul.copy(regs, src_rec, (size_t)NR * rrec / 4);
+                if (nkeys2) ul.copy(pk, src_pk, (size_t)NR * rpk / 4);
+                launch_k9_upload(ul, C->copy_stream);
+            }
             regs_pending = true;
         }
     }
