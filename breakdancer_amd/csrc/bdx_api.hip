@@ -63,10 +63,11 @@ struct PinBuf {
     // A large buffer is anonymous memory on transparent huge pages, registered with the runtime (hipHostRegister): 0.02 s per 0.5 GB
     // against hipHostMalloc's 0.09-0.11 -- pinning is paid per page -- and a quarter less to hand back when the process ends
     // (tools/pin_probe.hip, profiles/r05_pin_probe.txt); the device sees it at the same address.  Small buffers -- the words the host
-    // polls, the records kernels and host exchange mid-run -- stay with hipHostMalloc (fine-grained by default).  BDX_PIN=malloc: all of them.
+    // polls, the records kernels and host exchange mid-run -- stay with hipHostMalloc (fine-grained by default).  bdx_set_process_option("pin_malloc", 1): all of them.
     void* map_base = nullptr;
     size_t map_len = 0;
-    static bool use_registered() { static const bool on = !(getenv("BDX_PIN") && !strcmp(getenv("BDX_PIN"), "malloc")); return on; }
+    static std::atomic<bool>& registered_switch() { static std::atomic<bool> on{true}; return on; }   // bdx_set_process_option("pin_malloc", 1) turns it off
+    static bool use_registered() { return registered_switch().load(std::memory_order_relaxed); }
     hipError_t ensure(size_t b) {
         if (b <= bytes) return hipSuccess;
         release();
@@ -197,7 +198,12 @@ struct bdx_ctx {
     uint32_t ov_covered = 0;
     bool replayed = false;            // the last run went through the read-level host replay (a read name seen more than twice)
     bool use_stash = false;           // K1 leaves ready-made records of the anomalous reads for K2 (at most kStashKeys counter keys)
-    bool alloc_only = false;          // the stage functions only size their buffers (bdx_reserve: a first run's allocations ahead of the data)
+    // Sizing passes (bdx_reserve, the BAM decoder's sizing thread): the stage functions called with a `Sizing` only grow the buffers of the
+    // stages behind pass 1 -- they read the context's configuration and touch those buffers, nothing of its run state (no flag on the
+    // context says "sizing": round 5's did, and a run beside the sizing thread saw it and launched nothing).  While one is in flight the
+    // entry points that launch those stages refuse with BDX_ESTATE; its error text goes to sizing_err (the feeding thread owns `err`).
+    std::atomic<int> sizing{0};
+    std::string sizing_err;
     std::vector<uint32_t> sup_off;    // [n_svs + 1]
     std::vector<uint64_t> sup_idx;
     std::vector<uint8_t> sup_flag;
@@ -250,10 +256,20 @@ struct bdx_ctx {
 
 namespace {
 
+thread_local std::string* t_err_sink = nullptr;   // a sizing pass on a thread of its own: its messages do not go to the context's `err`
 int fail(bdx_ctx* c, int code, const std::string& msg) {
-    if (c) c->err = msg;
+    if (t_err_sink) *t_err_sink = msg;
+    else if (c) c->err = msg;
     return code;
 }
+// what a sizing pass hands the stage functions instead of the context's run state
+struct Sizing { uint32_t na; };
+// entry points that launch the stages behind pass 1: not while their buffers are being sized on another thread
+#define NOT_WHILE_SIZING(c)                                                                                                              \
+    do {                                                                                                                                 \
+        if ((c)->sizing.load(std::memory_order_acquire))                                                                                 \
+            return fail(c, BDX_ESTATE, "the buffers of the later stages are being sized on another thread (bdx_bamdec_finish has not returned)"); \
+    } while (0)
 int hipfail(bdx_ctx* c, hipError_t e, const char* what) {
     return fail(c, BDX_EHIP, std::string(what) + ": " + hipGetErrorString(e));
 }
@@ -327,6 +343,7 @@ void stage_view(const bdx_ctx::Stage& st, bdx_batch_buf* out) {
 
 int pass1_prepare(bdx_ctx* c, uint32_t tiles_cap);
 int presize_stages(bdx_ctx* c, uint32_t na);
+int presize_stages_here(bdx_ctx* c, uint32_t na);
 int pass1_classify(bdx_ctx* c, uint32_t upto, bool timed);
 
 constexpr uint32_t kStreamTilesMin = 4096;  // classify behind a batch only once this many new tiles (1 M reads) are complete
@@ -518,6 +535,7 @@ void bdx_destroy(bdx_ctx* c) {
 int bdx_reserve(bdx_ctx* c, size_t n_reads) {
     if (!c) return BDX_EINVAL;
     if (c->adopted) return fail(c, BDX_ESTATE, "reads were adopted from the caller");
+    NOT_WHILE_SIZING(c);
     HIPCHK(c, hipSetDevice(c->device));
     const int rc = alloc_reads(c, n_reads);
     if (rc != BDX_OK) return rc;
@@ -526,7 +544,7 @@ int bdx_reserve(bdx_ctx* c, size_t n_reads) {
     // caller still decodes or copies, not inside its first bdx_run.  Small inputs size theirs exactly, when they run.
     if (n_reads >= (1u << 20) && !c->ran) {
         const uint64_t prior = (uint64_t)n_reads / 32 + 4096;
-        if (prior <= kMaxAnomalous) return presize_stages(c, (uint32_t)prior);
+        if (prior <= kMaxAnomalous) return presize_stages_here(c, (uint32_t)prior);
     }
     return BDX_OK;
 }
@@ -882,14 +900,16 @@ int set_pass1(bdx_ctx* c, const uint32_t* cnt, uint32_t covered, int32_t window,
 }
 
 // K2: compact anomalous reads (prefix counters offset by the bases of earlier shards)
-int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepare_join) {
+int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepare_join, const Sizing* sz = nullptr) {
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const int nkeys = c->nkeys;
-    const uint32_t na = c->na_alloc;
-    if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
-    Compact& cp = c->cp;
-    K3Arrays& k3 = c->k3;
+    const uint32_t na = sz ? sz->na : c->na_alloc;
+    if (c->stage_timing && !sz) HIPCHK(c, hipEventRecord(c->ev[2], s));
+    Compact cp_sz{};
+    K3Arrays k3_sz{};
+    Compact& cp = sz ? cp_sz : c->cp;
+    K3Arrays& k3 = sz ? k3_sz : c->k3;
     cp = Compact{};
     k3 = K3Arrays{};
     if (na) {
@@ -916,7 +936,7 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepa
         // context joins its own reads) the slot indices of K4's direct table
         HIPCHK(c, c->b_c_maxq.ensure(cap * 4));
         k2.fill_ptr[0] = c->b_c_maxq.as<uint32_t>(); k2.fill_words[0] = na; k2.fill_value[0] = 0u;
-        c->join_table_clean = 0;
+        if (!sz) c->join_table_clean = 0;
         if (prepare_join && (c->force_direct_join || (!c->bucketed_join && na <= kDirectJoinMax))) {
             const uint32_t slots = direct_join_slots(na);
             HIPCHK(c, c->b_t_key.ensure((size_t)slots * 8)); HIPCHK(c, c->b_partner.ensure((size_t)na * 4));
@@ -924,9 +944,9 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepa
             k2.fill_ptr[2] = c->b_partner.as<uint32_t>(); k2.fill_words[2] = na; k2.fill_value[2] = 0xFFFFFFFFu;
             HIPCHK(c, c->b_pair_lo.ensure((size_t)na * 4));
             k2.fill_ptr[3] = c->b_pair_lo.as<uint32_t>(); k2.fill_words[3] = na; k2.fill_value[3] = 0xFFFFFFFFu;
-            c->join_table_clean = slots;
+            if (!sz) c->join_table_clean = slots;
         }
-        if (c->alloc_only) return BDX_OK;
+        if (sz) return BDX_OK;
         {   // name keys the caller's pinned batches still hold (bdx_push): one segment per batch
             bool any_host = false;
             for (auto const& sg : c->key_segs) any_host |= sg.host != nullptr;
@@ -954,6 +974,7 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepa
         launch_k2(k2, k2_lds_bytes(nkeys), s, c->finalize2_deferred ? &c->fp_deferred : nullptr);
         c->finalize2_deferred = false;
     }
+    if (sz) return BDX_OK;
     if (c->finalize2_deferred) {  // (no K2 launch to ride on)
         launch_finalize2_only(c->fp_deferred, s);
         c->finalize2_deferred = false;
@@ -966,14 +987,15 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepa
 // K3: cut regions.  In a whole-genome run the last candidate of a chromosome is closed by the first anomalous read
 // of the next chromosome, which still counts for its nucleotide sum / max read length / normal-pair count
 // (BreakDancer.cpp:202-231): has_next / next_qlen / next_nn carry that read across contexts.
-int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool for_k6, bool keep_dev = false) {
+int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool for_k6, bool keep_dev = false, const Sizing* sz = nullptr) {
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const int nkeys = c->nkeys;
-    const uint32_t na = c->na_alloc;
+    const uint32_t na = sz ? sz->na : c->na_alloc;
     const uint32_t nn_base = c->nn_base;
     Compact& cp = c->cp;
-    K3Arrays& k3 = c->k3;
+    K3Arrays k3_sz{};
+    K3Arrays& k3 = sz ? k3_sz : c->k3;
     if (na) {
         const size_t cap = na;
         DevBuf* u32bufs[] = {&c->b_cand, &c->b_pre_q, &c->b_pre_rev, &c->b_pre_nonctx, &c->b_c_first, &c->b_c_maxq, &c->b_c_rid,
@@ -1012,13 +1034,13 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool f
                 HIPCHK(c, hipMemsetAsync(c->b_lb.p, 0, c->b_lb.bytes, s));
             }
             k3.lb_state = c->b_lb.as<unsigned long long>();
-            HIPCHK(c, next_lb_stamp(c, &k3.lb_stamp));
+            if (!sz) HIPCHK(c, next_lb_stamp(c, &k3.lb_stamp));
         }
         k3.ws_u4 = c->b_ws_u4.as<U4>(); k3.head_total = (U4*)c->b_totals.p; k3.ws_u32 = c->b_ws_u32.as<uint32_t>();
         k3.acc_total = (uint32_t*)((char*)c->b_totals.p + 32); k3.counts = c->b_counts.as<StageCounts>();
         if (for_k6) {
             HIPCHK(c, c->h_counts0.ensure(sizeof(StageCounts)));
-            memset(c->h_counts0.p, 0, sizeof(StageCounts));
+            if (!sz) memset(c->h_counts0.p, 0, sizeof(StageCounts));
             k3.counts_host = c->h_counts0.as<StageCounts>();
         }
         if (hbm_only) {  // (no pinned mirror: pinning 24 chromosomes' tables cost a sharded run tens of milliseconds)
@@ -1028,7 +1050,7 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool f
             k3.r_rec_dev = nullptr; k3.r_pk_dev = nullptr;
             k3.host_copy_later = 0;
         }
-        if (c->alloc_only) return BDX_OK;
+        if (sz) return BDX_OK;
         K3Tail tail{has_next, next_qlen, next_nn, c->k3_tid_tail};
         // single-context runs that take the direct join let that kernel do k3_region_of_kernel's work
         c->region_of_fused = for_k6 && !c->bucketed_join && na <= kDirectJoinMax;
@@ -1038,15 +1060,17 @@ int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool f
             if (rc != BDX_OK) return rc;
         }
     }
+    if (sz) return BDX_OK;
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[4], s));
     c->stage = 3;
     return BDX_OK;
 }
 
 // K4 on the context's own reads (single-context run)
-int do_join_local(bdx_ctx* c, uint32_t n, const Entries& en, const uint32_t* n_ptr, bool join_only) {
+int do_join_local(bdx_ctx* c, uint32_t n, const Entries& en, const uint32_t* n_ptr, bool join_only, const Sizing* sz = nullptr) {
     hipStream_t s = c->stream;
-    K4Arrays& k4 = c->k4;
+    K4Arrays k4_sz{};
+    K4Arrays& k4 = sz ? k4_sz : c->k4;
     k4 = K4Arrays{};
     if (!n) return BDX_OK;
     k4.g_cap = n / 2 + 1;
@@ -1061,7 +1085,7 @@ int do_join_local(bdx_ctx* c, uint32_t n, const Entries& en, const uint32_t* n_p
     const size_t n_own = en.n_local ? std::min<size_t>(n, std::max<uint32_t>(c->na_alloc, 1u)) : n;
     HIPCHK(c, c->b_partner.ensure(n_own * 4));
     k4.partner = c->b_partner.as<int32_t>();
-    if (c->alloc_only) return BDX_OK;  // (the direct table is sized by do_compact; the bucketed join sizes its own when it runs)
+    if (sz) return BDX_OK;  // (the direct table is sized by do_compact; the bucketed join sizes its own when it runs)
     if (c->force_direct_join || (!c->bucketed_join && n <= kDirectJoinMax)) {
         uint32_t slots = direct_join_slots(n);
         // (the foreign entries of a sharded run come on top of the reads K2 sized the table for: it still has room at half its load)
@@ -1145,9 +1169,10 @@ void decode_groups(bdx_ctx* c, const GroupRec* gr, uint32_t ng, uint32_t ph) {
 // K6 on the context's own regions (single-context runs): pair groups per region, SV assembly of the components that need
 // no traversal, everything else listed for the host walk; then the dense results and K5 for the device-assembled SVs.
 // part: 0 the whole first half; 1 up to and including k6_pairs_kernel, 2 the rest (a sharded run all-reduces the taint bytes in between)
-int do_k6(bdx_ctx* c, bool force_host, int part = 0) {
+int do_k6(bdx_ctx* c, bool force_host, int part = 0, const Sizing* sz = nullptr) {
     hipStream_t s = c->stream;
-    K6Arrays& a = c->k6;
+    K6Arrays a_sz{};
+    K6Arrays& a = sz ? a_sz : c->k6;
     if (part == 2) {
         if (!a.cap) return BDX_OK;
         launch_k6_components(a, a.cap, s);
@@ -1162,7 +1187,7 @@ int do_k6(bdx_ctx* c, bool force_host, int part = 0) {
         if (a.cap) launch_k6_walk(a, a.cap, s);
         return BDX_OK;
     }
-    const uint32_t na = std::max(c->na_alloc, c->k6_cap);   // (sharded runs: K6's arrays are indexed by genome-wide region id)
+    const uint32_t na = std::max(sz ? sz->na : c->na_alloc, c->k6_cap);   // (sharded runs: K6's arrays are indexed by genome-wide region id)
     const int nkeys = c->nkeys, nlibs = c->nlibs;
     a = K6Arrays{};
     if (!na) return BDX_OK;
@@ -1242,9 +1267,9 @@ int do_k6(bdx_ctx* c, bool force_host, int part = 0) {
             HIPCHK(c, hipMemsetAsync(c->b_ws6.p, 0, c->b_ws6.bytes, s));
         }
         a.lb_state = c->b_ws6.as<unsigned long long>();
-        HIPCHK(c, next_lb_stamp(c, &a.lb_stamp));
+        if (!sz) HIPCHK(c, next_lb_stamp(c, &a.lb_stamp));
     }
-    if (c->alloc_only) return BDX_OK;
+    if (sz) return BDX_OK;
     a.counts = c->b_counts.as<StageCounts>();
     // run constants: the flag histogram is the device's own reduced counter table (a single-context run adopts its own
     // statistics), the read densities per counter key travel in the kernel arguments
@@ -1287,18 +1312,26 @@ int do_k6(bdx_ctx* c, bool force_host, int part = 0) {
 
 // bdx_reserve: the stage functions run for their allocations only
 int presize_stages(bdx_ctx* c, uint32_t na) {
-    const uint32_t keep_na = c->na_alloc;
-    const int keep_stage = c->stage;
-    c->alloc_only = true;
-    c->na_alloc = na;
-    int r = do_compact(c, 0, nullptr, true);
-    if (r == BDX_OK) r = do_cut(c, 0, 0, 0, true);
-    if (r == BDX_OK) r = do_join_local(c, na, Entries{}, nullptr, true);
-    if (r == BDX_OK) r = do_k6(c, false);
-    c->alloc_only = false;
-    c->na_alloc = keep_na;
-    c->stage = keep_stage;
-    c->join_table_clean = 0;
+    // (may run on a thread of its own beside the thread that feeds the context: it touches the later stages' buffers and nothing else --
+    // see bdx_ctx::sizing.  Its messages go to sizing_err.)
+    struct Guard {
+        bdx_ctx* c;
+        std::string* keep;
+        explicit Guard(bdx_ctx* c_) : c(c_), keep(t_err_sink) { c->sizing.fetch_add(1, std::memory_order_acq_rel); c->sizing_err.clear(); t_err_sink = &c->sizing_err; }
+        ~Guard() { t_err_sink = keep; c->sizing.fetch_sub(1, std::memory_order_acq_rel); }
+    } guard(c);
+    const Sizing sz{na};
+    int r = do_compact(c, 0, nullptr, true, &sz);
+    if (r == BDX_OK) r = do_cut(c, 0, 0, 0, true, false, &sz);
+    if (r == BDX_OK) r = do_join_local(c, na, Entries{}, nullptr, true, &sz);
+    if (r == BDX_OK) r = do_k6(c, false, 0, &sz);
+    return r;
+}
+
+// a sizing pass on the caller's own thread: its message is the context's
+int presize_stages_here(bdx_ctx* c, uint32_t na) {
+    const int r = presize_stages(c, na);
+    if (r != BDX_OK) c->err = c->sizing_err;
     return r;
 }
 
@@ -1582,6 +1615,7 @@ extern "C" {
 
 int bdx_run(bdx_ctx* c) {
     if (!c) return BDX_EINVAL;
+    NOT_WHILE_SIZING(c);
     const auto t_begin = std::chrono::steady_clock::now();
     hipStream_t s = c->stream;
     // The very first anomalous read "breaks" an empty accumulator (start = end = -1, no reads).  With a negative
@@ -1740,7 +1774,11 @@ int bdx_run(bdx_ctx* c) {
 }
 
 // ---- staged entry points (multi-context / multi-GPU runs) ------------------------------------------------------
-int bdx_stage_pass1(bdx_ctx* c) { return c ? do_pass1(c) : BDX_EINVAL; }
+int bdx_stage_pass1(bdx_ctx* c) {
+    if (!c) return BDX_EINVAL;
+    NOT_WHILE_SIZING(c);
+    return do_pass1(c);
+}
 
 int bdx_get_pass1_local(const bdx_ctx* c, uint32_t* counters, uint64_t* ref_len_per_bam, uint32_t* totals) {
     if (!c) return BDX_EINVAL;
@@ -1765,6 +1803,7 @@ int bdx_set_pass1_global(bdx_ctx* c, const uint32_t* counters, uint32_t covered_
 int bdx_stage_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, int32_t* first_qlen, uint32_t* first_nn) {
     if (!c) return BDX_EINVAL;
     if (c->stage < 2) return BDX_ESTATE;
+    NOT_WHILE_SIZING(c);
     if (c->opts.min_len < 0) return fail(c, BDX_ELIMIT, "staged runs do not support a negative -s");
     int rc = do_compact(c, nn_base, pk_base, false);
     if (rc != BDX_OK) return rc;
@@ -1784,6 +1823,7 @@ int bdx_stage_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, int
 int bdx_stage_regions(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn) {
     if (!c) return BDX_EINVAL;
     if (c->stage < 2) return BDX_ESTATE;
+    NOT_WHILE_SIZING(c);
     int rc = do_cut(c, has_next, next_qlen, next_nn, false);
     if (rc != BDX_OK) return rc;
     return readback(c, false);
@@ -1825,6 +1865,7 @@ int bdx_join_entries(bdx_ctx* c, size_t n, const uint64_t* key, const uint32_t* 
                      const int32_t* isize, bdx_group* out, size_t cap, uint32_t* n_groups, uint32_t* n_pairs) {
     if (!c || (n && (!key || !order || !region || !meta || !isize))) return BDX_EINVAL;
     if (n > kMaxAnomalous) return fail(c, BDX_ELIMIT, "too many join entries");
+    NOT_WHILE_SIZING(c);
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     if (n_groups) *n_groups = 0;
@@ -1864,6 +1905,7 @@ int bdx_stage_walk(bdx_ctx* c, size_t nregions, const bdx_region_rec* regions, c
                    const bdx_group* groups, int32_t last_maxq, int any_anomalous) {
     if (!c || (nregions && (!regions || !pk)) || (ngroups && !groups)) return BDX_EINVAL;
     if (c->stage < 2) return BDX_ESTATE;
+    NOT_WHILE_SIZING(c);
     decode_regions(c, (const RegionRec*)regions, pk, (uint32_t)nregions, 0, false);
     decode_groups(c, (const GroupRec*)groups, (uint32_t)ngroups, 0);
     c->counts.n_regions = (uint32_t)nregions;
@@ -1927,6 +1969,7 @@ int bdx_get_svs(const bdx_ctx* c, bdx_sv* out, size_t cap) {
 int bdx_trim_results(bdx_ctx* c) {
     if (!c) return BDX_EINVAL;
     if (!c->ran) return BDX_ESTATE;
+    NOT_WHILE_SIZING(c);
     HIPCHK(c, hipSetDevice(c->device));
     materialize(c);
     if (c->reg && (const void*)c->reg == c->h_regs.p) {   // (a region table read where the device left it: the getters go on from a copy)
@@ -2117,6 +2160,12 @@ int bdx_classify(const bdx_opts* opts, const bdx_lib* libs, int nlibs, const bdx
     if (rc == BDX_OK) rc = bdx_get_read_class(c, cls_out, b->n);
     bdx_destroy(c);
     return rc;
+}
+
+int bdx_set_process_option(const char* name, int value) {
+    if (!name) return BDX_EINVAL;
+    if (!strcmp(name, "pin_malloc")) { PinBuf::registered_switch().store(value == 0); return BDX_OK; }
+    return BDX_EINVAL;
 }
 
 int bdx_warm_up(int device) {

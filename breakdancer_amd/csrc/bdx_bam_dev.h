@@ -27,18 +27,6 @@ enum : uint32_t {
 // in: compressed bytes (at least 16 readable bytes behind the last payload), out: inflated bytes; status[nblk]
 void launch_kz_inflate(const uint8_t* in, const BgzfBlock* blocks, uint32_t nblk, uint8_t* out, uint32_t* status, hipStream_t s,
                        unsigned long long* prof = nullptr);
-// the same result by the two-kernel path (kz_inflate_lanes.hip): Huffman decoding with one LANE per member, matches resolved behind it
-// (kz_huffman_lanes_kernel, then kz_resolve_kernel with 16 lanes per member).  The members' out_off ascend without overlap from
-// out_origin on; bitmap: scratch of kz_bitmap_words(bytes from out_origin to the last member's end, nblk) dwords (zeroed by the call)
-size_t kz_bitmap_words(size_t out_span_bytes, size_t nblk);
-void launch_kz_inflate_lanes(const uint8_t* in, const BgzfBlock* blocks, uint32_t nblk, uint8_t* out, uint32_t* status, uint32_t* bitmap, size_t bitmap_words,
-                             uint64_t out_origin, hipStream_t s);
-// Which of the two a launch of nblk members (comp_bytes of payload inflating to infl_bytes) takes: true = one lane per member.
-// A lane decodes its member sequentially (a member takes as long however few there are), so launches that do not fill the chip's
-// waves stay with the wave kernel, and so do members that are mostly stored (a lane copies stored bytes alone).
-// BDX_KZ=wave / BDX_KZ=lanes overrides (measurements, and the parity tests run both).
-bool kz_pick_lanes(size_t nblk, size_t comp_bytes, size_t infl_bytes);
-
 // ---- records ----
 constexpr uint32_t kRecSlots = 2048;        // record starts a BGZF block can hold at most ((65536 / 36) + 1 < 2048)
 constexpr uint32_t kNoGuess = 0xFFFFFFFFu;

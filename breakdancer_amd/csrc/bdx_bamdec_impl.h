@@ -59,12 +59,12 @@ struct bdx_bamdec {
     int device = 0;
     bdx_ctx* sink = nullptr;
     std::string err;
-    hipStream_t s_copy = nullptr, s_inf = nullptr, s_inf2 = nullptr, s_rec = nullptr;   // (s_inf == s_inf2 == s_rec unless BDX_KZ_STREAM=own: bdx_bamdec_create)
+    hipStream_t s_copy = nullptr, s_inf = nullptr, s_inf2 = nullptr, s_rec = nullptr;   // (s_inf == s_inf2 == s_rec unless stream_mode != 0: bdx_bamdec_create)
     // A decoder that feeds a context copies on the context's copy stream; with the context's compute and side streams and the decoder's
     // own that makes four streams in all.  The HIP runtime spreads a process's streams over four hardware queues, and two streams on one
     // queue run in order -- with six, the completion of a 0.3 ms copy waited behind a 19 ms inflate launch.
     bool borrowed_copy = false, borrowed_rec = false;   // (a stream of the sink's: not the decoder's to destroy)
-    bool own_inf_stream = false;      // (BDX_KZ_STREAM=own) the inflate launches have a stream of their own; else they run in s_rec
+    bool own_inf_stream = false;      // (stream_mode 1 / 2) the inflate launches have a stream of their own; else they run in s_rec
     // pinned staging: one piece's compressed bytes and the caller's member table
     struct Staging {
         PinBuf h_comp, h_tab;
@@ -83,7 +83,7 @@ struct bdx_bamdec {
     int next_staging = 0, held_staging = 0;   // the held_staging buffers before next_staging are acquired and not submitted yet (oldest first)
     // a batch: the compressed bytes of its pieces back to back in HBM, its member table, the inflate status words
     struct Slot {
-        DevBuf d_comp, d_blocks, d_status, d_bitmap;   // (d_bitmap: the match-start map of the two-kernel inflate path)
+        DevBuf d_comp, d_blocks, d_status;
         PinBuf h_blocks;                  // the device-format table, built as the pieces arrive
         hipEvent_t ev_copied = nullptr;   // all of the batch's bytes and its table are in HBM
         hipEvent_t ev_free = nullptr;     // the batch's record stage is through (its device buffers are reusable)
@@ -406,7 +406,7 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
     // Taking turns costs the record stages' own time, ~1 ms per 7,680 members.  The stream is NOT the sink's compute stream: the runtime
     // spreads a process's streams over four hardware queues, two streams on one queue run in order, and a copy's completion marker behind
     // a 30 ms inflate launch kept the feeder waiting for its staging buffers; the classifier, on the sink's stream, follows the record
-    // stages through their events.  BDX_KZ_STREAM=own: the inflate launches in a third stream, beside the record stages, as until round 4.
+    // stages through their events.  bdx_bamdec_params::stream_mode 1: the inflate launches in a third stream, beside the record stages, as until round 4.
     if (sink && sink->copy_stream) {
         d->s_copy = sink->copy_stream;
         d->borrowed_copy = true;
@@ -414,9 +414,8 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
         return bad(BDX_EHIP);
     }
     {
-        const char* ks = getenv("BDX_KZ_STREAM");
-        const bool prio = ks && !strcmp(ks, "prio");   // (experiment: the three streams with queue priorities -- record stages high, inflate low)
-        const bool third = (ks && !strcmp(ks, "own")) || prio;
+        const bool prio = p->stream_mode == 2;   // (experiment: the three streams with queue priorities -- record stages high, inflate low)
+        const bool third = p->stream_mode == 1 || prio;
         int pr_least = 0, pr_greatest = 0;
         if (prio && hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest) != hipSuccess) return bad(BDX_EHIP);
         if (prio) {
@@ -446,10 +445,10 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
     // A launch of ONE round of the wave slots ends with the slots draining (58 GB/s of inflated bytes against 68 in launches of four rounds
     // and 70 with a 16 GB file in one launch, profiles/r05_genome_inflate_alone.txt), so a large input is decoded in batches of up to four
     // rounds -- 30,720 members, 2 GB inflated; the buffers grow with them, which a small file would pay for in its set-up: one round per
-    // 2.5 GB announced.  A caller's batch_blocks is taken as it is.  Test knob: BDX_BAM_BATCH_ROUNDS.
+    // 2.5 GB announced.  A caller's batch_blocks is taken as it is; batch_rounds overrides the rounds.
     {
         size_t rounds = std::max<size_t>(1, std::min<size_t>(4, p->expected_bytes / ((size_t)2560 << 20)));
-        if (const char* br = getenv("BDX_BAM_BATCH_ROUNDS")) rounds = (size_t)std::max(1, std::min(16, atoi(br)));
+        if (p->batch_rounds > 0) rounds = (size_t)std::min(16, p->batch_rounds);
         if (p->batch_blocks) { d->batch_blocks = d->round_blocks = p->batch_blocks; rounds = 1; }
         else d->batch_blocks = d->round_blocks * rounds;
         d->batch_bytes = p->batch_bytes ? p->batch_bytes : kBatchBytesDefault * rounds;
@@ -585,7 +584,7 @@ void bdx_bamdec_destroy(bdx_bamdec* d) {
     for (hipStream_t s : {d->s_copy, d->s_inf, d->s_inf2, d->s_rec})
         if (s) (void)hipStreamSynchronize(s);
     for (auto& sl : d->slot) {
-        sl.h_blocks.release(); sl.d_comp.release(); sl.d_blocks.release(); sl.d_status.release(); sl.d_bitmap.release();
+        sl.h_blocks.release(); sl.d_comp.release(); sl.d_blocks.release(); sl.d_status.release();
         if (sl.ev_copied) (void)hipEventDestroy(sl.ev_copied);
         if (sl.ev_free) (void)hipEventDestroy(sl.ev_free);
     }
@@ -688,13 +687,7 @@ int bam_launch_batch(bdx_bamdec* d, int si, bool last) {
     if (nblocks) BHIP(d, hipMemcpyAsync(sl.d_blocks.p, tb, nblocks * sizeof(BgzfBlock), hipMemcpyHostToDevice, d->s_copy));
     BHIP(d, hipEventRecord(sl.ev_copied, d->s_copy));
     BHIP(d, hipStreamWaitEvent(s_inf, sl.ev_copied, 0));
-    if (!d->sink && kz_pick_lanes(nblocks, sl.bytes, ulen)) {   // (a decoder that feeds a context -- the CLI's -- always runs the wave kernel: the other path faulted there at any batch size, see kz_pick_lanes)
-        const size_t words = kz_bitmap_words(ulen, nblocks);
-        BHIP(d, sl.d_bitmap.ensure(std::max(words, kz_bitmap_words(d->ring_bytes / 4, std::max(nblocks, sl.cap_blk))) * 4));   // (once: what a batch can be)
-        launch_kz_inflate_lanes(sl.d_comp.as<uint8_t>(), sl.d_blocks.as<BgzfBlock>(), (uint32_t)nblocks, d->d_ring.as<uint8_t>(), sl.d_status.as<uint32_t>(),
-                                sl.d_bitmap.as<uint32_t>(), words, p.ring_beg, s_inf);
-    } else
-        launch_kz_inflate(sl.d_comp.as<uint8_t>(), sl.d_blocks.as<BgzfBlock>(), (uint32_t)nblocks, d->d_ring.as<uint8_t>(), sl.d_status.as<uint32_t>(), s_inf);
+    launch_kz_inflate(sl.d_comp.as<uint8_t>(), sl.d_blocks.as<BgzfBlock>(), (uint32_t)nblocks, d->d_ring.as<uint8_t>(), sl.d_status.as<uint32_t>(), s_inf);
     p.ev_inflated = bam_event(d);
     if (!p.ev_inflated) return bfail(d, BDX_EHIP, "hipEventCreate");
     BHIP(d, hipEventRecord(p.ev_inflated, s_inf));
@@ -853,17 +846,17 @@ int bdx_bamdec_finish(bdx_bamdec* d, uint64_t* n_records) {
     d->bound_in_flight = 0;
     if (d->presize_thread.joinable()) {
         d->presize_thread.join();
-        if (d->presize_rc != BDX_OK) return bfail(d, d->presize_rc, d->sink ? d->sink->err : "sizing the later stages");
+        if (d->presize_rc != BDX_OK) return bfail(d, d->presize_rc, d->sink ? d->sink->sizing_err : "sizing the later stages");
     }
     if (d->sink) {
         const int rc = bam_feed_classifier(d, true);
-        // (a file of fewer than four batches: the sizing thread is started by this last feed -- and must be through before the caller's
-        // bdx_run works on the same context: running beside it, its `alloc_only` made the run's stages return without launching anything,
-        // the pass-1 record never arrived and the run ended, after its 200 ms wait, with an EMPTY table and no error: 13 of 30 runs of a
-        // 0.5 GB BAM, found by tools/determinism_probe.py in round 5)
+        // (a file of fewer than four batches: the sizing thread is started by this last feed -- and is through before finish returns: the
+        // caller's bdx_run grows the same buffers.  Round 5's sizing pass signalled through a flag on the context that a run beside it
+        // saw: an EMPTY table with status 0, tools/determinism_probe.py.  The pass now works on an argument of its own, and a run that
+        // finds it in flight refuses with BDX_ESTATE -- bdx_ctx::sizing)
         if (d->presize_thread.joinable()) {
             d->presize_thread.join();
-            if (rc == BDX_OK && d->presize_rc != BDX_OK) return bfail(d, d->presize_rc, d->sink->err);
+            if (rc == BDX_OK && d->presize_rc != BDX_OK) return bfail(d, d->presize_rc, d->sink->sizing_err);
         }
         if (rc != BDX_OK) return rc;
         d->sink->n = (size_t)st.n_kept;
@@ -1061,17 +1054,10 @@ int bdx_inflate_blocks(int device, const void* compressed, size_t bytes, const b
     (void)hipEventRecord(e0, nullptr);
     // BDX_KZ_PROF=<file>: the kernel's own clocks per member, for tools/bamdec_probe.py
     DevBuf d_prof;
-    const char* prof_path = getenv("BDX_KZ_PROF");
+    static const char* const prof_env = getenv("BDX_KZ_PROF");   // (tracing: read once per process)
+    const char* prof_path = prof_env;
     if (prof_path && nblocks && (d_prof.ensure(nblocks * 48) != hipSuccess || hipMemset(d_prof.p, 0, nblocks * 48) != hipSuccess)) prof_path = nullptr;
-    size_t comp = 0;
-    for (size_t i = 0; i < nblocks; ++i) comp += blocks[i].payload_len;
-    DevBuf d_bm;
-    if (!prof_path && kz_pick_lanes(nblocks, comp, o)) {
-        const size_t words = kz_bitmap_words(o, nblocks);
-        if (d_bm.ensure(words * 4) != hipSuccess) return done(BDX_ENOMEM);
-        launch_kz_inflate_lanes(d_in.as<uint8_t>(), d_tb.as<BgzfBlock>(), (uint32_t)nblocks, d_out.as<uint8_t>(), d_st.as<uint32_t>(), d_bm.as<uint32_t>(), words, 0, nullptr);
-    } else
-        launch_kz_inflate(d_in.as<uint8_t>(), d_tb.as<BgzfBlock>(), (uint32_t)nblocks, d_out.as<uint8_t>(), d_st.as<uint32_t>(), nullptr,
+    launch_kz_inflate(d_in.as<uint8_t>(), d_tb.as<BgzfBlock>(), (uint32_t)nblocks, d_out.as<uint8_t>(), d_st.as<uint32_t>(), nullptr,
                           prof_path ? d_prof.as<unsigned long long>() : nullptr);
     (void)hipEventRecord(e1, nullptr);
     if (hipDeviceSynchronize() != hipSuccess) return done(BDX_EHIP);
@@ -1082,7 +1068,6 @@ int bdx_inflate_blocks(int device, const void* compressed, size_t bytes, const b
             if (FILE* f = fopen(prof_path, "wb")) { fwrite(hp.data(), 8, hp.size(), f); fclose(f); }
     }
     d_prof.release();
-    d_bm.release();
     if ((o && hipMemcpy(out, d_out.p, o, hipMemcpyDeviceToHost) != hipSuccess) ||
         (nblocks && hipMemcpy(status, d_st.p, nblocks * 4, hipMemcpyDeviceToHost) != hipSuccess))
         return done(BDX_EHIP);

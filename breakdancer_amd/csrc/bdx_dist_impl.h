@@ -407,6 +407,7 @@ int bdx_dist_reset_reads(bdx_dist* d) {
     d->last_tid = -1;
     d->n_at_last = 0;
     d->ran = false;
+    d->sorted_n = 0; d->sorted_ptr = nullptr;   // (the next set of reads may have this one's count and address: its order is checked again)
     return BDX_OK;
 }
 
@@ -462,7 +463,7 @@ int bdx_dist_prepare(bdx_dist* d) {
             c->k6_cap = (uint32_t)std::min<uint64_t>(prior, kMaxRegions);
             c->table_in_hbm = d->comm->world > 1;
             c->groups_in_hbm = d->comm->world > 1;
-            const int rc = presize_stages(c, (uint32_t)prior);
+            const int rc = presize_stages_here(c, (uint32_t)prior);
             c->k6_cap = keep;
             if (rc != BDX_OK) return dfail(d, rc, c->err);
             const size_t nr = (size_t)prior;
@@ -584,6 +585,7 @@ int bdx_dist_run(bdx_dist* d) {
     DHIP(d, hipSetDevice(d->device));
     bdx_ctx* C = d->reads;
     bdx_ctx* U = d->util;
+    if (C->sizing.load(std::memory_order_acquire)) return dfail(d, BDX_ESTATE, "the buffers of the later stages are being sized on another thread (bdx_bamdec_finish has not returned)");
     hipStream_t s = C->stream;
     d->ran = false;
     d->ctx_sent = d->ctx_received = d->gathered_bytes = 0;

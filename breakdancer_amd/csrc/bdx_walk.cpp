@@ -154,7 +154,7 @@ struct Walker {
           win_head(s.win_head), win_tail(s.win_tail), win_visited(s.win_visited), olds(s.olds), tails(s.tails), newtails(s.newtails) {}
 
     void build_groups() {
-        const bool prof = getenv("BDX_WALK_PROFILE") != nullptr;
+        static const bool prof = getenv("BDX_WALK_PROFILE") != nullptr;   // (tracing on stderr; read once per process)
         auto tnow = [] { return std::chrono::steady_clock::now(); };
         auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
         const auto b0 = tnow();
@@ -413,7 +413,7 @@ struct Walker {
     }
 
     void run() {
-        const bool prof = getenv("BDX_WALK_PROFILE") != nullptr;
+        static const bool prof = getenv("BDX_WALK_PROFILE") != nullptr;
         prof_on = prof;
         const auto tp0 = std::chrono::steady_clock::now();
         build_groups();

@@ -237,6 +237,7 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
 
     typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
     __shared__ v4u_t s_stash[kWaves][2 * kStashCap];  // a wave's ready-made records of one tile, before they leave
+    static_assert(kStashCap + 64 <= 2 * kStashCap * 4, "the general tile body keeps 16 rank slots and the lanes' 64 class words in a wave's slice");
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     for (int i = t; i < nlibs; i += kBlock) s_lib[i] = p.libs[i];
     for (int i = t; i < ncnt; i += kBlock) s_cnt[i] = 0;
@@ -451,8 +452,11 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
             key[r] = dl.key;
             cls4[r] = pass ? ((unsigned)f2 | 0x10u | (proper ? 0x20u : 0u) | (nleft[r] ? 0x40u : 0u)) : (unsigned)f;
         }
+        // (the lane's four class bytes also go to the wave's LDS slice, words [16, 80): the record stash below takes a read's byte from there)
+        const unsigned clsp = cls4[0] | (cls4[1] << 8) | (cls4[2] << 16) | (cls4[3] << 24);
+        if (p.stash) ((uint32_t*)s_stash[w])[kStashCap + lane_r] = clsp;
         if (nvalid == 4) {
-            *(uchar4*)(p.cls + base) = make_uchar4(cls4[0], cls4[1], cls4[2], cls4[3]);
+            *(unsigned*)(p.cls + base) = clsp;
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -533,8 +537,10 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
             if (p.stash && na && one_key) {
                 // (written so that it needs few registers beside the classification's -- built like the uniform body's, from the lanes that own
                 // the reads, this body spilled 73 registers and the kernel took three times as long: an owning lane only leaves its reads'
-                // in-tile indices in the wave's LDS slice, by rank; lane j then puts record j together itself -- its fields gathered from the
-                // columns the tile has just been loaded from, its prefix counts from the ballots, which are scalar registers)
+                // in-tile indices AND CLASS BYTES in the wave's LDS slice, by rank; lane j then puts record j together itself -- its other
+                // fields gathered from the columns the tile has just been loaded from (input columns, nobody writes them), its prefix counts
+                // from the ballots, which are scalar registers.  The class byte does not come back from p.cls: another lane stored it with a
+                // plain store a moment ago, and nothing orders that store before this lane's load -- ADVICE r5)
                 unsigned ra = 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ra = __builtin_amdgcn_mbcnt_hi((uint32_t)(ba[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ba[r], ra));
@@ -558,7 +564,7 @@ __global__ __launch_bounds__(kBlock, 6) void k1_classify_kernel(const K1Params p
                 }
                 if ((unsigned)lane_r < nrec) {
                     const uint64_t i = (uint64_t)tile * kTile + where;
-                    const unsigned cb = p.cls[i];   // (stored by this wave above)
+                    const unsigned cb = (idx[kStashCap + l] >> (8 * rr)) & 0xffu;   // (the owning lane's word, written at the classification)
                     unsigned L = nlibs_r > 1 ? (unsigned)p.r.lib[i] : 0u;
                     if (L >= (unsigned)nlibs_r) L = 0;
                     typedef unsigned v4u __attribute__((ext_vector_type(4)));

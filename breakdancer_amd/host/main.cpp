@@ -228,6 +228,7 @@ namespace {
 int run(int argc, char** argv) {
     bdx_ctx* ctx = nullptr;
     bool ctx_owned = true;  // false: ctx is a sharded run's result context, which belongs to rank 0's bdx_dist
+    std::thread trimmer;    // hands the pinned result tables back while the table is printed; joined before anything destroys the context
     try {
         std::unique_ptr<Options> opts_p(new Options(argc, argv));
         Pass1Cache cache;
@@ -453,7 +454,7 @@ int run(int argc, char** argv) {
         // (a large run's pinned result tables go back while the table is printed: the process's end is that much shorter.  BDX_TRIM=0: kept)
         if (n_reads > (size_t)(8u << 20) && !want_dumps && !getenv("BDX_CLEAN_EXIT") && !(getenv("BDX_TRIM") && !strcmp(getenv("BDX_TRIM"), "0"))) {
             bdx_ctx* tc = ctx;
-            std::thread([tc] { (void)bdx_trim_results(tc); }).detach();
+            trimmer = std::thread([tc] { (void)bdx_trim_results(tc); });   // (only _exit may leave it behind: every path that destroys the context joins it first)
         }
         auto tname = [&](int t) { return (t >= 0 && (size_t)t < targets.size()) ? targets[t] : std::to_string(t); };
 
@@ -613,11 +614,13 @@ int run(int argc, char** argv) {
             }
             _exit(0);
         }
+        if (trimmer.joinable()) trimmer.join();
         release_device_decoders();   // (before their sink: a decoder borrows its context's streams)
         if (ctx_owned) bdx_destroy(ctx);  // (a sharded run's result context belongs to rank 0, released with the ranks)
         ctx = nullptr;
     } catch (std::exception const& e) {
         std::cerr << "ERROR: " << e.what() << "\n";
+        if (trimmer.joinable()) trimmer.join();
         if (ctx && ctx_owned) bdx_destroy(ctx);
         return 1;
     }

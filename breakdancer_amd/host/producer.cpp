@@ -489,7 +489,10 @@ size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::strin
     // is read (a BGZF member inflates to at most ~16 x its size; 8 x is assumed of a whole stretch: beyond that the decoder says BDX_ELIMIT
     // and the host reader takes the file).  Sharded runs keep one decoder per rank for all of its sequences: sized for the largest.
     {
-        const size_t rounds = getenv("BDX_BAM_BATCH_ROUNDS") ? (size_t)std::max(1, std::min(16, atoi(getenv("BDX_BAM_BATCH_ROUNDS")))) : std::max<size_t>(1, std::min<size_t>(4, rest / ((size_t)2560 << 20)));
+        // (test / measurement knobs of the CLI; the library reads no environment variable for them: they travel in the parameters)
+        if (const char* br = getenv("BDX_BAM_BATCH_ROUNDS")) p.batch_rounds = std::max(1, std::min(16, atoi(br)));
+        if (const char* ks = getenv("BDX_KZ_STREAM")) p.stream_mode = !strcmp(ks, "own") ? 1 : !strcmp(ks, "prio") ? 2 : 0;
+        const size_t rounds = p.batch_rounds ? (size_t)p.batch_rounds : std::max<size_t>(1, std::min<size_t>(4, rest / ((size_t)2560 << 20)));
         const size_t blocks = p.batch_blocks ? p.batch_blocks : 7680 * rounds;
         const size_t batch_inflated = (blocks + kPiece / 16384 + 64) * 65536;
         p.ring_bytes = std::max<size_t>((size_t)64 << 20, std::min<size_t>(rest * 32, 4 * batch_inflated));

@@ -271,6 +271,10 @@ int bdx_was_replayed(const bdx_ctx* ctx);
  * run comes first in the process).  bdx_warm_up launches one no-op kernel per translation unit of the library and waits: a process
  * that calls it while it still reads its input has its first run at the speed of the later ones.  bdx_dist_prepare calls it. */
 int bdx_warm_up(int device);
+/* Process-wide test / measurement switches (the library reads no environment variable for a behaviour switch; BDX_*_TRACE / BDX_*_PROF
+ * variables only add output).  "pin_malloc" 1: every pinned buffer comes from hipHostMalloc (default: large ones are registered
+ * huge pages).  Takes effect for buffers allocated afterwards.  BDX_EINVAL for an unknown name. */
+int bdx_set_process_option(const char* name, int value);
 
 /* Kernel-level entry points for parity tests.
  * bdx_classify replaces IAlignmentClassifier::classify (io/IlluminaPEReadClassifier.cpp:59-101) plus the
@@ -442,6 +446,11 @@ typedef struct bdx_bamdec_params {
     size_t piece_bytes, piece_blocks;  /* the sizes bdx_bamdec_acquire will be called with, 0: unknown.  Known: the staging buffers are
                                      pinned by threads of their own while the caller reads its first piece (pinning costs ~0.2 ms per
                                      MiB, and the first pieces would otherwise wait for it one after the other) */
+    int32_t batch_rounds;         /* rounds of the GPU's wave slots an inflate launch takes (7,680 members each), 1..16; 0: from expected_bytes
+                                     (one round per 2.5 GB, at most four).  Ignored when batch_blocks is given */
+    int32_t stream_mode;          /* 0: inflate launches and record stages take turns on one stream (the product's arrangement);
+                                     1: the inflate launches on a stream of their own beside the record stages (round 4's arrangement);
+                                     2: as 1, with queue priorities.  1 and 2 are measurement / test arrangements */
 } bdx_bamdec_params;
 int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* p);
 void bdx_bamdec_destroy(bdx_bamdec* d);

@@ -27,7 +27,9 @@ def product_options(opts):
 
 
 # the tests select the product's alternative routes through bdx_set_debug; monkeypatch.setenv("BDX_<NAME>", value) in a test is
-# only the way the choice reaches this helper (the library itself reads no such variable)
+# only the way the choice reaches this helper.  libbdx.so reads no environment variable for a behaviour switch: they travel through
+# bdx_set_debug, bdx_set_process_option and bdx_bamdec_params; what it does read only adds output (BDX_ALLOC_TRACE, BDX_DIST_TRACE,
+# BDX_BAMDEC_TRACE, BDX_WALK_PROFILE on stderr, BDX_KZ_PROF=<file>) -- tests/test_abi.py greps csrc/ for anything else
 _SWITCHES = {"BDX_NO_STASH": "no_stash", "BDX_MAX_CHUNKS": "max_chunks", "BDX_SPEC_TEST": "spec_test", "BDX_BIG_WALK": "big_walk",
              "BDX_BUCKETED_JOIN": "bucketed_join"}
 

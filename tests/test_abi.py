@@ -53,3 +53,27 @@ def test_no_gpu_means_loud_failure():
     rc = lib.bdx_create(C.byref(h), C.byref(o), libs, 1, 1, 1, 100, 0)
     assert rc != 0
     assert lib.bdx_strerror(rc).decode() != "ok"
+
+
+def test_the_library_reads_no_environment_variable_for_a_behaviour_switch():
+    """csrc/ may call getenv for tracing / profiling output only: switches travel through bdx_set_debug,
+    bdx_set_process_option and bdx_bamdec_params."""
+    allowed = {"BDX_ALLOC_TRACE", "BDX_DIST_TRACE", "BDX_BAMDEC_TRACE", "BDX_WALK_PROFILE", "BDX_KZ_PROF"}
+    csrc = os.path.join(ROOT, "breakdancer_amd", "csrc")
+    seen = set()
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".hip", ".h", ".cpp")):
+            continue
+        for m in re.finditer(r'getenv\(\s*"([A-Z0-9_]+)"\s*\)', open(os.path.join(csrc, name)).read()):
+            seen.add(m.group(1))
+        assert "getenv(" not in re.sub(r'getenv\(\s*"[A-Z0-9_]+"\s*\)', "", open(os.path.join(csrc, name)).read()), name + ": getenv of a computed name"
+    assert seen <= allowed, "behaviour switches read from the environment: %s" % sorted(seen - allowed)
+    assert not os.path.exists(os.path.join(csrc, "kz_inflate_lanes.hip"))
+
+
+def test_process_option_names():
+    lib = L.load()
+    lib.bdx_set_process_option.argtypes = [__import__("ctypes").c_char_p, __import__("ctypes").c_int]
+    assert lib.bdx_set_process_option(b"pin_malloc", 0) == 0
+    assert lib.bdx_set_process_option(b"no_such_option", 1) != 0
+    assert lib.bdx_set_process_option(None, 1) != 0
