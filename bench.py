@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--sharded-cli-fraction", type=float, default=None, help="hg38 lengths x this for that BAM (default N/64: 14.5 M records, ~2 GB of BAM, per rank)")
     ap.add_argument("--no-genome-bam", action="store_true", help="skip config.timings.bam_to_table_genome (one GPU's share of a 30x genome as ONE BAM through the CLI)")
     ap.add_argument("--genome-bam-fraction", type=float, default=1.0 / 8, help="hg38 lengths x this for that BAM (default 1/8: 116 M records, 15.9 GB)")
+    ap.add_argument("--no-realistic-bam", action="store_true", help="skip config.timings.bam_to_table_genome_realistic (the same records as a level-6 BAM of reference-drawn bases)")
+    ap.add_argument("--realistic-bam-fraction", type=float, default=1.0 / 8, help="hg38 lengths x this for the realistic BAM")
     ap.add_argument("--no-overlap", action="store_true", help="skip the three-contexts-in-flight measurement (config.overlapped_contexts)")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 --pmc sub-run that measures roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -357,12 +359,15 @@ def time_bam_cli(bam, cfg, n):
     return out
 
 
-def time_bam_cli_genome(fraction, n_gpu_visible):
+def time_bam_cli_genome(fraction, n_gpu_visible, realistic=False):
     """BAM -> SV table at the size the metric is about: ONE indexed 24-chromosome, 4-library BAM of one GPU's share of a 30x genome
     (hg38 lengths x 1/8: 116 M records, 15.9 GB; smaller if memory does not hold it: stated), bin/breakdancer-max in one process from
     start to exit, page cache warm, best of 3.  Beside it, measured in this invocation on the same file: the ceilings of the three
     things the file has to get through -- page cache -> pinned -> HBM (bin/bdx-feed-probe), the inflate kernel alone on a slice's
-    members in one launch -- and the reference-shaped CPU path on a stated slice (two chromosomes of the same genome as their own BAM)."""
+    members in one launch -- and the reference-shaped CPU path on a stated slice (two chromosomes of the same genome as their own BAM).
+    realistic=True: the same records as a BAM that compresses like one -- bases from a shared random reference (the ~30 reads that cover a
+    locus share sequence), qualities in four bins, zlib level 6 (samtools' default; bamwrite.Reference) -- where the default file holds
+    random bases and qualities at level 1 (ratio 1.57): the token mix decides the inflate kernel's speed."""
     from breakdancer_amd.bamwrite import write_genome_bam
     need_gb = 15.9 * fraction * 8
     avail = mem_available_gb()
@@ -374,7 +379,7 @@ def time_bam_cli_genome(fraction, n_gpu_visible):
     td = tempfile.mkdtemp(prefix="bdx_genome_", dir="/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp")
     try:
         t0 = time.perf_counter()
-        bam, cfg, n = write_genome_bam(td, fraction)
+        bam, cfg, n = write_genome_bam(td, fraction, realistic=realistic, tag="realistic" if realistic else "genome")
         prep_s = time.perf_counter() - t0
         size = os.path.getsize(bam)
         best = None
@@ -392,7 +397,8 @@ def time_bam_cli_genome(fraction, n_gpu_visible):
         out = {"seconds": best[0], "value": (n / 2) / best[0], "unit": "read-pairs/s", "file_gb_per_s": size / best[0] / 1e9, "sv_rows": best[1],
                "records": n, "bam_bytes": size, "genome_fraction": fraction, "synthesis_and_bam_write_seconds_untimed": prep_s, "cli_breakdown": best[2][:-1],
                "note": "bin/breakdancer-max <cfg> on ONE indexed 24-chromosome, 4-library BAM (hg38 x %g, 30x: one GPU's share of configs[2]), one process from "
-                       "start to exit (BDX_FOREGROUND=1), best of 3, file in the page cache (tmpfs)%s" % (fraction, "; " + note if note else "")}
+                       "start to exit (BDX_FOREGROUND=1), best of 3, file in the page cache (tmpfs)%s%s" % (fraction, "; " + note if note else "",
+                       "; bases from a shared random reference, binned qualities, zlib level 6" if realistic else "; random bases and qualities, zlib level 1")}
         import re
         for line in best[2]:
             m = re.search(r"steady state: ([0-9.]+) GB of BAM .* first inflate launch \(([0-9.]+) s after .* last record \(([0-9.]+) s\): ([0-9.]+) s, ([0-9.]+) GB/s", line)
@@ -436,6 +442,15 @@ def time_bam_cli_genome(fraction, n_gpu_visible):
         lows = [v for v in (ceil.get("feed", {}).get("both_pipelined_gb_s"), ceil.get("inflate_kernel_alone", {}).get("file_gb_s")) if v]
         if lows and out.get("steady_state_gb_s"):
             out["steady_state_over_lowest_ceiling"] = out["steady_state_gb_s"] / min(lows)
+        if out.get("inflated_bytes"):
+            out["deflate_ratio"] = out["inflated_bytes"] / size
+            for line in best[2]:
+                m = re.search(r"inflate kernel in the pipeline: ([0-9.]+) ms in ([0-9]+) launches", line)
+                if m:
+                    out["inflate_in_situ"] = {"kernel_ms": float(m.group(1)), "launches": int(m.group(2)), "inflated_gb_s": out["inflated_bytes"] / float(m.group(1)) / 1e6,
+                                              "file_gb_s": size / float(m.group(1)) / 1e6, "note": "kz_inflate_kernel inside the CLI's pipeline, HIP events around every launch"}
+        if realistic:
+            return out
         # the CPU path on a slice of the same genome: its two smallest chromosomes (chr21, chr22) as their own BAM, one core, two decode passes
         try:
             sbam, scfg, sn = write_genome_bam(td, fraction, only_tids=(20, 21), tag="slice", translocations=0)
@@ -694,15 +709,15 @@ def genome_leg(rank, world, local, dist, out, fraction=None, translocations=5000
                 # 2.0-2.2 ms since the region table goes to the host through a kernel: the first device-to-host copy COMMAND of a process
                 # sets up a copy-engine queue, 6 ms inside this process's first run until then)
                 dt = times[1]
-                r0 = ph.get("rank0_only_merge", 0.0) + ph.get("rank0_only_host_walk", 0.0)
+                r0 = ph.get("rank0_only_merge", 0.0) + ph.get("rank0_only_host_walk", 0.0) + ph.get("rank0_only_device_walk_of_gathered_groups", 0.0)
                 legs[label] = {"seconds": dt, "value": total / 2 / dt, "unit": "read-pairs/s", "first_run_seconds": times[0], "second_run_seconds": times[1],
                                "hbm_roofline_frac_whole_path": total / 2 / dt / world * PATH_BYTES_PER_PAIR / 1e9 / HBM_PEAK_GBS,
                                "svs_printed": sm["n_svs_printed"], "regions": sm["n_regions"], "sv_candidates_device_host": list(res.walk_split())[:2],
-                               "ctx_records_exchanged": sent, "gathered_bytes_on_rank0": ex[0]["gathered_bytes"],
+                               "ctx_records_exchanged": sent, "gathered_bytes_on_rank0": ex[0]["gathered_bytes"], "collectives_per_run": ranks[0].collectives(),
                                "bdx_dist_run_ms_per_rank": rank_ms, "rank0_bdx_dist_run_ms_first_run": first_ms_total, "rank0_phase_ms_first_run": first_phases, "rank0_phase_ms": ph,
                                "rank0_only": {"ms": r0, "share_of_run": r0 / (ex[0]["ms_total"] or 1.0),
-                                              "note": "what only rank 0 does (second run): the merge of the ranks' tables and its host walk of the "
-                                                      "components that span ranks or are too large for the device walk"},
+                                              "note": "what only rank 0 does (second run): the merge of the ranks' tables, the device walk of the gathered "
+                                                      "components that span ranks (its result context's K6) and the host walk of what that leaves"},
                                "load_and_prepare_seconds_untimed": load_s}
                 if timed is not None:
                     legs[label]["timed_steps"] = {"steps": steps, "warmup": warmup, "seconds": timed, "ms_per_step": timed / steps * 1e3,
@@ -744,6 +759,54 @@ def genome_leg(rank, world, local, dist, out, fraction=None, translocations=5000
                                          "frac": total * 28 / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                          "note": "28 algorithmic bytes per read (SURVEY 8d), as in `roofline`; 4 libraries in one file"}
             bd.close()
+        threads_entries = {}
+        if world == 1 and rank == 0 and not SHARED_GPU_TEST:
+            # The protocol of the 8-GPU configurations on the ONE GPU at hand: the same records dealt to 8 (and 2) ranks that run as threads of
+            # this process and share the device -- every collective, the LPT packing of 24 chromosomes into 8 bins, 7 of 8 inter-chromosomal
+            # pairs crossing ranks, rank 0's own part.  The ranks' kernels take turns on one GPU: a check of the path and of what is serial
+            # in it, not a speed-up.
+            for nr_threads in (8, 2):
+                ent = {}
+                plan_t = D.plan(lengths, nr_threads)
+                per_t = [0] * nr_threads
+                bounds = np.searchsorted(d["tid"], np.arange(ntids + 1))
+                for t in range(ntids):
+                    per_t[plan_t[t]] += int(bounds[t + 1] - bounds[t])
+                for label, opts in (("default_options", Options()), ("t_option", Options(transchr_rearrange=True))):
+                    try:
+                        rk = D.DistRun.threads(opts, libs, 1, ntids, 200, [local] * nr_threads)
+                        for r, run in enumerate(rk):
+                            for t in range(ntids):
+                                if plan_t[t] == r and bounds[t + 1] > bounds[t]:
+                                    run.chromosome(t).push_reads({k: v[int(bounds[t]):int(bounds[t + 1])] for k, v in d.items()})
+                            run.prepare()
+                        torch.cuda.synchronize()
+                        tt = []
+                        for it in range(4):
+                            t0 = time.perf_counter()
+                            res = D.run_threads(rk)
+                            tt.append(time.perf_counter() - t0)
+                        ph = rk[0].phases()
+                        exs = [r.exchange() for r in rk]
+                        r0 = ph.get("rank0_only_merge", 0.0) + ph.get("rank0_only_host_walk", 0.0) + ph.get("rank0_only_device_walk_of_gathered_groups", 0.0)
+                        coll_ms = {k: v for k, v in ph.items() if k.startswith(("allreduce", "alltoall", "gather"))}
+                        sm = res.summary()
+                        ent[label] = {"seconds": min(tt[1:]), "first_run_seconds": tt[0], "svs_printed": sm["n_svs_printed"], "regions": sm["n_regions"],
+                                      "sv_candidates_device_host": list(res.walk_split())[:2],
+                                      "ctx_records_travelled": sum(e["ctx_records_sent"] for e in exs), "gathered_bytes_on_rank0": exs[0]["gathered_bytes"],
+                                      "collectives_per_run": rk[0].collectives(), "rank0_collective_ms": coll_ms, "rank0_phase_ms": ph,
+                                      "bdx_dist_run_ms_per_rank": [round(e["ms_total"], 3) for e in exs],
+                                      "rank0_only": {"ms": r0, "share_of_run": r0 / (exs[0]["ms_total"] or 1.0)}}
+                        for run in rk:
+                            run.release_inputs()
+                            run.close()
+                    except Exception as e:  # noqa: BLE001
+                        ent[label] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+                ent["reads_per_rank"] = per_t
+                ent["lpt_imbalance_max_over_mean"] = max(per_t) / (sum(per_t) / nr_threads)
+                ent["note"] = ("%d ranks as threads of one process sharing this GPU (bdx_dist_create_threads): the multi-GPU protocol end to end on one device; "
+                               "seconds = best of 3 runs on handles that have run before" % nr_threads)
+                threads_entries["ranks_as_threads_%d" % nr_threads] = ent
         if rank != 0:
             return None
         o = {"scaling": scaling, "genome_fraction": frac,
@@ -753,6 +816,7 @@ def genome_leg(rank, world, local, dist, out, fraction=None, translocations=5000
              "synthesis_seconds_untimed": gen_s, **legs}
         if single:
             o["single_context"] = single
+        o.update(threads_entries)
         return o
 
     weak_frac = fraction if fraction is not None else world / 8.0
@@ -1014,6 +1078,11 @@ def main():
                     timings["bam_to_table_genome"] = time_bam_cli_genome(a.genome_bam_fraction, torch.cuda.device_count())
                 except Exception as e:  # noqa: BLE001
                     timings["bam_to_table_genome"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+                if not a.no_realistic_bam:
+                    try:
+                        timings["bam_to_table_genome_realistic"] = time_bam_cli_genome(a.realistic_bam_fraction, torch.cuda.device_count(), realistic=True)
+                    except Exception as e:  # noqa: BLE001
+                        timings["bam_to_table_genome_realistic"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         out = {
             "metric": "read-pairs/s, records resident in HBM -> scored SV table (SURVEY 8d timing i); end to end from BAM: config.timings.bam_to_table (vs_baseline is taken there)",
             "value": value, "unit": "read-pairs/s",
@@ -1067,6 +1136,22 @@ def main():
                 out[k]["measured_on"] = "config.per_rank_replicas (configs[1] on every rank)"
             out["roofline"]["whole_path"] = {"algorithmic_bytes_per_read_pair": PATH_BYTES_PER_PAIR, "achieved": ts["value"] / world * PATH_BYTES_PER_PAIR / 1e9,
                                              "frac": ts["value"] / world * PATH_BYTES_PER_PAIR / 1e9 / HBM_PEAK_GBS}
+        # the quantity the metric's name ends with, at the top level: BAM -> SV table, one process, exit included
+        g2 = timings.get("bam_to_table_genome", {})
+        g1 = timings.get("bam_to_table", {})
+        gs = timings.get("bam_to_table_sharded", {})
+        if world == 1 and "seconds" in g2:
+            out["end_to_end"] = {"seconds": g2["seconds"], "value": g2["value"], "unit": "read-pairs/s", "file_gb_per_s": g2.get("file_gb_per_s"),
+                                 "workload": "one GPU's share of a 30x genome as ONE indexed 24-chromosome, 4-library BAM (%d records, %.1f GB): bin/breakdancer-max <cfg>, "
+                                             "one process from start to exit, file in the page cache" % (g2.get("records", 0), g2.get("bam_bytes", 0) / 1e9),
+                                 "configs1_as_one_bam": ({"seconds": g1["seconds"], "value": g1["value"]} if "seconds" in g1 else None),
+                                 "source": "config.timings.bam_to_table_genome (configs[1] as one BAM: config.timings.bam_to_table, where vs_baseline is taken)"}
+        elif world == 1 and "seconds" in g1:
+            out["end_to_end"] = {"seconds": g1["seconds"], "value": g1["value"], "unit": "read-pairs/s", "workload": "configs[1] as one BAM through bin/breakdancer-max",
+                                 "source": "config.timings.bam_to_table"}
+        elif world > 1 and "seconds" in gs:
+            out["end_to_end"] = {"seconds": gs["seconds"], "value": gs.get("value"), "unit": "read-pairs/s", "workload": "one indexed 24-chromosome BAM sharded over the ranks (BDX_GPUS)",
+                                 "source": "config.timings.bam_to_table_sharded"}
         if overlapped:
             out["config"]["overlapped_contexts"] = overlapped
         if not a.no_exchange and not a.pmc_child:

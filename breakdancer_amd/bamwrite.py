@@ -16,7 +16,61 @@ def _bgzf_block(data, level):
             struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
 
 
-def _fixed_records(soa, lo, hi, L, rg, rng, names=None):
+_BIN_QUALS = np.array([37, 23, 12, 2], np.uint8)   # the four quality bins of current Illumina instruments
+
+
+class Reference:
+    """A seeded random reference, one sequence per chromosome, generated when first asked for (uint8 BAM base codes 1 / 2 / 4 / 8).
+    Reads drawn from it share sequence with their neighbours in a position-sorted file -- what a real BAM's deflate streams are made of
+    (matches between the ~30 records that cover a locus), and what records of independent random bases cannot show."""
+
+    def __init__(self, seed=1234, pad=1024):
+        import threading
+        self.seed, self.pad = seed, pad
+        self._seqs = {}
+        self._lock = threading.Lock()
+
+    def seq(self, tid, upto):
+        with self._lock:
+            s = self._seqs.get(tid)
+            if s is None or len(s) < upto + self.pad:
+                n = max(upto + self.pad, 2 * len(s) if s is not None else 0)
+                codes = np.array([1, 2, 4, 8], np.uint8)
+                s = codes[np.random.default_rng([self.seed, tid]).integers(0, 4, n, dtype=np.uint8)]   # (a prefix of the same stream: deterministic in tid)
+                self._seqs[tid] = s
+            return s
+
+
+def _realistic_payload(soa, lo, hi, L, rng, ref):
+    """(bases as packed nybbles, qualities) of records [lo, hi): bases = the reference at the read's position with 0.5 % substitutions,
+    qualities in four bins -- a read starts in the top bin and steps down towards its 3' end, with a few isolated dips"""
+    n = hi - lo
+    nb = (L + 1) // 2
+    tid = np.asarray(soa["tid"][lo:hi]).astype(np.int64)
+    pos = np.maximum(np.asarray(soa["pos"][lo:hi]).astype(np.int64), 0)
+    bases = np.empty((n, 2 * nb), np.uint8)
+    bases[:, L:] = 0
+    for t in np.unique(tid):
+        m = tid == t
+        s = ref.seq(int(t), int(pos[m].max()) + L)
+        win = np.lib.stride_tricks.sliding_window_view(s, L)
+        bases[m, :L] = win[pos[m]]
+    nsub = int(n * L * 0.005)
+    if nsub:
+        codes = np.array([1, 2, 4, 8], np.uint8)
+        bases[rng.integers(0, n, nsub), rng.integers(0, L, nsub)] = codes[rng.integers(0, 4, nsub)]
+    packed = (bases[:, 0::2] << 4) | bases[:, 1::2]
+    col = np.arange(L, dtype=np.int32)[None, :]
+    k1 = rng.integers(int(L * 0.6), int(L * 1.6), n, dtype=np.int32)[:, None]          # where the read leaves the top bin (often: never)
+    k2 = k1 + rng.integers(int(L * 0.05), int(L * 0.5), n, dtype=np.int32)[:, None]
+    q = np.where(col < k1, 0, np.where(col < k2, 1, 2)).astype(np.uint8)
+    ndip = int(n * L * 0.06)
+    if ndip:
+        q[rng.integers(0, n, ndip), rng.integers(0, L, ndip)] = rng.choice(np.array([1, 2, 3], np.uint8), ndip, p=[0.6, 0.3, 0.1])
+    return packed, _BIN_QUALS[q]
+
+
+def _fixed_records(soa, lo, hi, L, rg, rng, names=None, ref=None):
     """records [lo, hi) of the SoA as one uint8 matrix (fixed-size records: same name width, read length, aux block)"""
     n = hi - lo
     if names is None:  # mates share the name: derive it from the name key (16 hex digits)
@@ -60,10 +114,16 @@ def _fixed_records(soa, lo, hi, L, rg, rng, names=None):
     put(o, np.full(n, (L << 4) | 0), "<u4")
     o += 4
     nb = (L + 1) // 2
-    codes = np.array([1, 2, 4, 8], np.uint8)
-    rec[:, o:o + nb] = (codes[rng.integers(0, 4, (n, nb))] << 4) | codes[rng.integers(0, 4, (n, nb))]
-    o += nb
-    rec[:, o:o + L] = rng.integers(2, 41, (n, L), dtype=np.uint8)
+    if ref is not None:
+        packed, quals = _realistic_payload(soa, lo, hi, L, rng, ref)
+        rec[:, o:o + nb] = packed
+        o += nb
+        rec[:, o:o + L] = quals
+    else:
+        codes = np.array([1, 2, 4, 8], np.uint8)
+        rec[:, o:o + nb] = (codes[rng.integers(0, 4, (n, nb))] << 4) | codes[rng.integers(0, 4, (n, nb))]
+        o += nb
+        rec[:, o:o + L] = rng.integers(2, 41, (n, L), dtype=np.uint8)
     o += L
     if len(rgs) == 1:
         rec[:, o:o + len(aux)] = np.frombuffer(aux, np.uint8)
@@ -73,12 +133,14 @@ def _fixed_records(soa, lo, hi, L, rg, rng, names=None):
     return rec
 
 
-def write_bam(path, soa, targets, rg="rg1", readlen=None, level=1, seed=0, names=None, threads=None, chunk=500_000, index=False):
+def write_bam(path, soa, targets, rg="rg1", readlen=None, level=1, seed=0, names=None, threads=None, chunk=500_000, index=False, realistic=False):
     """soa: dict with tid,pos,mtid,mpos,isize,flag,qlen,mapq (+name_key used to derive the read names).
     index=True also writes <path>.bai: per sequence ONE chunk (first record .. behind the last, in the root bin -- legal, if coarser
     than samtools') and the linear index of 16 kb windows, vectorised (the records have one size, so every virtual offset follows
     from the compressed sizes of the blocks).
     Every record gets `readlen` random bases / qualities (default: soa['qlen'][0]), a 100M-style CIGAR and RG:Z:<rg>.
+    realistic=True: bases drawn from a seeded random REFERENCE at the read's position (overlapping reads share sequence) and qualities in
+    four bins (class Reference, _realistic_payload); with level=6 -- samtools' default, bgzf.c -- the file compresses like a real 30x BAM.
     Records are built and deflated `chunk` at a time on `threads` threads (numpy and zlib release the GIL), so a
     configs[1]-sized file (15 M records, ~3 GB of record bytes) takes seconds on a many-core host and bounded memory."""
     import os
@@ -91,9 +153,11 @@ def write_bam(path, soa, targets, rg="rg1", readlen=None, level=1, seed=0, names
     for t in targets:
         hdr += struct.pack("<i", len(t) + 1) + t.encode() + b"\0" + struct.pack("<i", 300000000)
 
+    ref = Reference(seed=seed + 977) if realistic else None
+
     def piece(i):
         lo, hi = i * chunk, min(n, (i + 1) * chunk)
-        raw = _fixed_records(soa, lo, hi, L, rg, np.random.default_rng([seed, i]), names).tobytes()
+        raw = _fixed_records(soa, lo, hi, L, rg, np.random.default_rng([seed, i]), names, ref).tobytes()
         blocks = [_bgzf_block(raw[j:j + 65280], level) for j in range(0, len(raw), 65280)]
         return b"".join(blocks), [len(b) for b in blocks], len(raw)
 
@@ -255,11 +319,13 @@ HG38_MBP = [248.96, 242.19, 198.30, 190.21, 181.54, 170.81, 159.35, 145.14, 138.
 LIBS4 = ((400.0, 30.0), (350.0, 40.0), (500.0, 50.0), (300.0, 25.0))
 
 
-def write_genome_bam(td, fraction, only_tids=None, tag="genome", translocations=None, seed=11):
+def write_genome_bam(td, fraction, only_tids=None, tag="genome", translocations=None, seed=11, realistic=False):
     """ONE indexed, position-sorted 24-chromosome BAM of the configs[2]/[3] genome at `fraction` of hg38's lengths -- 30x, 2x100 bp, four
     libraries as four read groups, planted translocations -- and its bam2cfg-format configuration (one line per read group), in directory
     td.  fraction 1/8: 116 M records, 15.9 GB, one GPU's share of the 8-GPU configurations.  only_tids: just these chromosomes' records of
-    the same genome (the slice the CPU baseline is timed on).  Returns (bam, cfg, records); files that exist are kept."""
+    the same genome (the slice the CPU baseline is timed on).  realistic=True: the same records with bases from a random reference and
+    binned qualities, deflated at level 6 (tag it differently: the file name says only tag and fraction).  Returns (bam, cfg, records);
+    files that exist are kept."""
     import os
     from .synth import make_genome
     os.makedirs(td, exist_ok=True)
@@ -269,7 +335,8 @@ def write_genome_bam(td, fraction, only_tids=None, tag="genome", translocations=
         lengths = [int(m * 1e6 * fraction) for m in HG38_MBP]
         d = make_genome(lengths, coverage=30.0, seed=seed, libs=LIBS4, lib_bam=(0, 0, 0, 0),
                         n_translocations=max(20, int(5000 * fraction * 8)) if translocations is None else translocations, only_tids=only_tids)
-        write_bam(bam, d, ["chr%d" % (i + 1) for i in range(len(lengths))], rg=["rg%d" % (i + 1) for i in range(len(LIBS4))], seed=5, index=True)
+        write_bam(bam, d, ["chr%d" % (i + 1) for i in range(len(lengths))], rg=["rg%d" % (i + 1) for i in range(len(LIBS4))], seed=5, index=True,
+                  realistic=realistic, level=6 if realistic else 1)
         with open(cfg, "w") as f:
             for i, (m, sd) in enumerate(LIBS4):
                 f.write("readgroup:rg%d\tplatform:illumina\tmap:%s\treadlen:100.00\tlib:lib%d\tlower:%.2f\tupper:%.2f\tmean:%.2f\tstd:%.2f\n"

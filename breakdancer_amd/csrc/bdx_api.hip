@@ -92,7 +92,12 @@ struct PinBuf {
                 }
             }
         }
-        if (e != hipSuccess) e = hipHostMalloc(&p, want, flags);
+        if (e != hipSuccess) {
+            e = hipHostMalloc(&p, want, flags);
+            // (small buffers hold the words the host polls and the counters kernels report: a block the allocator hands out again may still
+            // hold another context's ready word -- the same sequence number -- and a poll would return before the kernel has run)
+            if (e == hipSuccess && want <= ((size_t)1 << 20)) memset(p, 0, want);
+        }
         if (alloc_trace()) fprintf(stderr, "[bdx alloc] pinned %12zu B %8.1f us%s\n", want, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), map_base ? " (registered huge pages)" : "");
         if (e == hipSuccess) bytes = want; else p = nullptr;
         return e;
@@ -1233,7 +1238,10 @@ int do_k6(bdx_ctx* c, bool force_host, int part = 0, const Sizing* sz = nullptr)
         a.old_slot = (uint32_t*)(a.hs_key_dev + svc); a.ins_T = a.old_slot + p2; a.ins_src = a.ins_T + svc + 1;
         a.ins_pre_l = a.ins_src + svc + 1; a.ins_pre_c = a.ins_pre_l + svc + 1;
         a.sorted_key = (uint64_t*)(((uintptr_t)(a.ins_pre_c + svc + 1) + 7) & ~(uintptr_t)7); a.sorted_slot = (uint32_t*)(a.sorted_key + nsort);
-        a.rank_part = na > 65536u ? a.sorted_slot + nsort : nullptr;   // (k6_ranksort_kernel is launched, and its ranks are read, for inputs of this size only: a short list is sorted by k6_insert_kernel's one workgroup)
+        // (k6_ranksort_kernel is launched, and its ranks are read, where the list of candidates placed by key CAN outgrow what k6_insert_kernel's
+        // one workgroup sorts in LDS (2,048 entries) -- a -t run's candidates are all of that kind: 5-10 k of them at a genome share took that
+        // workgroup's bitonic sort in HBM half a millisecond.  Smaller inputs do without the launch)
+        a.rank_part = a.sv_cap > 2048u ? a.sorted_slot + nsort : nullptr;
     }
     a.sv_begin = c->b_sv_src.as<uint2>(); a.sv_src = (uint32_t*)(a.sv_begin + a.sv_cap); a.ltail = c->b_ltail.as<double>();
     a.d_lib_index = c->b_dlists.as<int32_t>(); a.d_cn_key = a.d_lib_index + a.term_cap; a.d_cn_value = (float*)(a.d_cn_key + a.cn_cap);
@@ -1375,7 +1383,9 @@ int do_k6_table(bdx_ctx* c) {
         a.hs_rec = c->h_hs_rec.as<SvOut>(); a.hs_key = hkey; a.hs_cnt = hcnt;
         a.hs_lambda = lam; a.hs_lib_index = li; a.hs_lib_pairs = lp; a.hs_cn_key = ck; a.hs_cn_value = cv;
     }
-    a.ltail_host = c->table_in_hbm ? c->b_ltail_out.as<double>() : c->h_ltail_dev.as<double>();  // (K5 runs inside the table kernel)
+    // (K5 runs inside the table kernel.  The terms' log tails go to the host for Fisher's combination only -- BreakDancer.cpp:71-81 uses the
+    // host's exp / log --; otherwise they are 8 bytes per term over PCIe that nobody reads)
+    a.ltail_host = c->table_in_hbm ? c->b_ltail_out.as<double>() : (c->opts.fisher ? c->h_ltail_dev.as<double>() : nullptr);
     HIPCHK(c, c->h_printed.ensure((size_t)k6_score_grid(a) * 4));
     a.printed_host = c->h_printed.as<uint32_t>();
     // The word the host polls for the end of the run is set by a one-thread kernel behind the table kernel (a kernel boundary
@@ -1403,7 +1413,7 @@ int materialize(bdx_ctx* c) {
     M.lib_pairs.assign(c->h_lib_pairs.as<int32_t>(), c->h_lib_pairs.as<int32_t>() + nt);
     M.cn_key.assign(c->h_cn_key.as<int32_t>(), c->h_cn_key.as<int32_t>() + nc);
     M.cn_value.assign(c->h_cn_value.as<float>(), c->h_cn_value.as<float>() + nc);
-    c->log_tail.assign(c->h_ltail_dev.as<double>(), c->h_ltail_dev.as<double>() + nt);
+    if (c->opts.fisher) c->log_tail.assign(c->h_ltail_dev.as<double>(), c->h_ltail_dev.as<double>() + nt); else c->log_tail.clear();
     M.n_groups = c->n_groups_total;
     c->materialized = true;
     return BDX_OK;

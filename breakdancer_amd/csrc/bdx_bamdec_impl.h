@@ -104,7 +104,10 @@ struct bdx_bamdec {
     // [2] waiting for a batch slot, [3] a slot's buffers, [4] the piece's copy calls, [5] a batch's launch, [6] a record stage's
     // launches, [7] feeding the classifier
     // [8] first inflate launch, [9] bdx_bamdec_finish's return: ms after the decoder's creation (or its last re-arming)
-    double host_ms[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // ([10] of [7]: sizing the later stages' buffers, [11] of [7]: classifier launches)
+    double host_ms[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // ([10] of [7]: sizing the later stages' buffers, [11] of [7]: classifier launches;
+                                                                       //  [12] / [13]: the inflate kernel's own time by HIP events / its launches, bdx_bamdec_params::time_kernels)
+    bool time_kernels = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> kz_events;   // (time_kernels) an event pair around every inflate launch, read by bdx_bamdec_finish
     std::chrono::steady_clock::time_point t_armed = std::chrono::steady_clock::now();
     bool finished = false, any_submitted = false;
     // record stage scratch (one piece at a time on s_rec)
@@ -442,6 +445,7 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
         if (hipEventCreateWithFlags(&st.ev_copied, hipEventDisableTiming) != hipSuccess) return bad(BDX_EHIP);
     mark("streams and events");
     d->expected_bytes = p->expected_bytes;
+    d->time_kernels = p->time_kernels != 0;
     // A launch of ONE round of the wave slots ends with the slots draining (58 GB/s of inflated bytes against 68 in launches of four rounds
     // and 70 with a 16 GB file in one launch, profiles/r05_genome_inflate_alone.txt), so a large input is decoded in batches of up to four
     // rounds -- 30,720 members, 2 GB inflated; the buffers grow with them, which a small file would pay for in its set-up: one round per
@@ -598,6 +602,7 @@ void bdx_bamdec_destroy(bdx_bamdec* d) {
     }
     for (auto& e : d->rec_events) (void)hipEventDestroy(e.second);
     for (hipEvent_t e : d->ev_pool) (void)hipEventDestroy(e);
+    for (auto& pr : d->kz_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (DevBuf* b : {&d->d_ring, &d->d_cb, &d->d_offs, &d->d_base, &d->d_scan, &d->d_state, &d->r_tid, &d->r_pos, &d->r_mtid, &d->r_mpos, &d->r_isize,
                       &d->r_flag, &d->r_qlen, &d->r_mapq, &d->r_lib, &d->r_keep, &d->r_key, &d->r_check, &d->o_check, &d->d_rg_hash, &d->d_rg_off, &d->d_rg_chars, &d->d_rg_lib,
                       &d->o_tid, &d->o_pos, &d->o_mtid, &d->o_mpos, &d->o_isize, &d->o_flag, &d->o_qlen, &d->o_mapq, &d->o_lib, &d->o_bam, &d->o_key})
@@ -687,7 +692,10 @@ int bam_launch_batch(bdx_bamdec* d, int si, bool last) {
     if (nblocks) BHIP(d, hipMemcpyAsync(sl.d_blocks.p, tb, nblocks * sizeof(BgzfBlock), hipMemcpyHostToDevice, d->s_copy));
     BHIP(d, hipEventRecord(sl.ev_copied, d->s_copy));
     BHIP(d, hipStreamWaitEvent(s_inf, sl.ev_copied, 0));
+    hipEvent_t kz0 = nullptr, kz1 = nullptr;
+    if (d->time_kernels && hipEventCreate(&kz0) == hipSuccess && hipEventCreate(&kz1) == hipSuccess) (void)hipEventRecord(kz0, s_inf);
     launch_kz_inflate(sl.d_comp.as<uint8_t>(), sl.d_blocks.as<BgzfBlock>(), (uint32_t)nblocks, d->d_ring.as<uint8_t>(), sl.d_status.as<uint32_t>(), s_inf);
+    if (kz0 && kz1) { (void)hipEventRecord(kz1, s_inf); d->kz_events.emplace_back(kz0, kz1); }
     p.ev_inflated = bam_event(d);
     if (!p.ev_inflated) return bfail(d, BDX_EHIP, "hipEventCreate");
     BHIP(d, hipEventRecord(p.ev_inflated, s_inf));
@@ -864,6 +872,12 @@ int bdx_bamdec_finish(bdx_bamdec* d, uint64_t* n_records) {
     }
     if (n_records) *n_records = st.n_kept;
     d->host_ms[9] = ms_between(d->t_armed, std::chrono::steady_clock::now());
+    for (auto& pr : d->kz_events) {   // (everything has been waited for above)
+        float ms = 0;
+        if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { d->host_ms[12] += ms; d->host_ms[13] += 1; }
+        (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+    }
+    d->kz_events.clear();
     return BDX_OK;
 }
 
@@ -1018,7 +1032,7 @@ int bdx_append_decoded(bdx_ctx* c, bdx_bamdec* const* decs, int k, const uint8_t
 
 int bdx_bamdec_host_ms(const bdx_bamdec* d, float* out, int n) {
     if (!d || !out) return BDX_EINVAL;
-    for (int i = 0; i < n; ++i) out[i] = i < 12 ? (float)d->host_ms[i] : 0.0f;
+    for (int i = 0; i < n; ++i) out[i] = i < 14 ? (float)d->host_ms[i] : 0.0f;
     return BDX_OK;
 }
 
@@ -1056,15 +1070,15 @@ int bdx_inflate_blocks(int device, const void* compressed, size_t bytes, const b
     DevBuf d_prof;
     static const char* const prof_env = getenv("BDX_KZ_PROF");   // (tracing: read once per process)
     const char* prof_path = prof_env;
-    if (prof_path && nblocks && (d_prof.ensure(nblocks * 48) != hipSuccess || hipMemset(d_prof.p, 0, nblocks * 48) != hipSuccess)) prof_path = nullptr;
+    if (prof_path && nblocks && (d_prof.ensure(nblocks * 64) != hipSuccess || hipMemset(d_prof.p, 0, nblocks * 64) != hipSuccess)) prof_path = nullptr;
     launch_kz_inflate(d_in.as<uint8_t>(), d_tb.as<BgzfBlock>(), (uint32_t)nblocks, d_out.as<uint8_t>(), d_st.as<uint32_t>(), nullptr,
                           prof_path ? d_prof.as<unsigned long long>() : nullptr);
     (void)hipEventRecord(e1, nullptr);
     if (hipDeviceSynchronize() != hipSuccess) return done(BDX_EHIP);
     if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, e0, e1);
     if (prof_path && nblocks) {
-        std::vector<unsigned long long> hp(nblocks * 6);
-        if (hipMemcpy(hp.data(), d_prof.p, nblocks * 48, hipMemcpyDeviceToHost) == hipSuccess)
+        std::vector<unsigned long long> hp(nblocks * 8);
+        if (hipMemcpy(hp.data(), d_prof.p, nblocks * 64, hipMemcpyDeviceToHost) == hipSuccess)
             if (FILE* f = fopen(prof_path, "wb")) { fwrite(hp.data(), 8, hp.size(), f); fclose(f); }
     }
     d_prof.release();

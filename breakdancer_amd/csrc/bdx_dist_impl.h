@@ -8,20 +8,23 @@
 // inter-chromosomal read pairs (ARP_CTX).  Every rank (one per GPU) holds ALL of its chromosomes in ONE context and runs the
 // single-context launch sequence over them -- K1 ... K6 and the table kernel, one launch each whatever the number of
 // chromosomes --, with per-chromosome tables (k9_shard.hip) carrying what crosses a chromosome boundary.  Region ids are
-// genome-wide on every rank, so flush windows, order keys and the walk itself are the single run's.  Between the stages:
-//   C1  all-reduce: pass-1 counters, per-file reference lengths, per-chromosome totals and owners
-//   C2  all-reduce: each chromosome's first anomalous read;  C3: its region count  (every entry has one owner: a sum is a gather)
-//   C4  all-reduce of the exchange's count matrix, then ONE all-to-all of the CTX join records -- a CTX read whose mate lies on a
-//       later chromosome of another rank goes there and joins that rank's reads (k7_exchange.hip) -- and one of the name census
-//   C5  gather of the ranks' region tables on rank 0 (the result holds the genome's table; runs beside the joins)
-//   C6  all-reduce (payload stays in HBM): taint bytes of the regions that gate-passing groups connect ACROSS ranks, and the read
-//       length of each flush window's last region.  Components inside one rank are walked and scored where they live (K6);
-//       tainted ones go to the host's share
-//   C7  all-reduce: size of every rank's host share;  C8: gather of the host shares on rank 0, which walks them (H1)
-//   C9  gather of the ranks' finished tables (rows sorted by order key) on rank 0, merged by key into the result context
-// Payloads stay in HBM: the collectives run on device buffers through RCCL (ncclAllReduce, ncclAllToAllv, grouped
-// ncclSend / ncclRecv), xGMI between the GPUs of a node.  A second backend runs the ranks as threads of one process
-// (tests on a single GPU; a host program that drives several GPUs itself).
+// genome-wide on every rank, so flush windows, order keys and the walk itself are the single run's.  FIVE collectives per run
+// (round 5: eleven -- six all-reduces, two all-to-alls, three gathers, each behind a host round trip):
+//   A   all-reduce (host words): pass-1 counters, per-file reference lengths, per-chromosome totals and owners, every chromosome's
+//       first anomalous read, and what the one all-to-all will carry -- inter-chromosomal reads by mate chromosome, census records by
+//       owner (the compaction runs in front of it: it needs nothing of the other ranks)
+//   B   all-reduce (host words): every chromosome's region count -> genome-wide region ids (every entry has one owner: a sum is a gather)
+//   X   ONE all-to-all: per destination the inter-chromosomal join records -- a CTX read whose mate lies on a later chromosome of
+//       another rank goes there and joins that rank's reads (k7_exchange.hip) --, the census records of the names it owns, and the read
+//       lengths of the flush windows this rank closes.  From here to its finished table a rank waits for nobody: which components span
+//       ranks is known without an exchange (a region that sent a join record away, or was joined with a foreign one, is an end of one)
+//   S   all-reduce (host words): what every rank will send to rank 0 (pair groups of the components that span ranks or that its device
+//       walk leaves, rows and list entries of its table), and whether a read name misbehaved
+//   G   ONE gather: every rank's package -- its region records, those pair groups, its finished table (rows sorted by order key) -- to
+//       rank 0, which walks the gathered groups in its result context (K6 once more, on the device) and merges the tables by key
+// Payloads stay in HBM: the all-to-all and the gather run on device buffers through RCCL (ncclAllToAllv, grouped ncclSend / ncclRecv),
+// xGMI between the GPUs of a node; the three all-reduces carry a few KB of host words (staged through device words for RCCL).  A second
+// backend runs the ranks as threads of one process (tests on a single GPU; a host program that drives several GPUs itself).
 #include <dlfcn.h>
 
 #include <condition_variable>
@@ -40,8 +43,12 @@ struct Comm {
     int rank = 0, world = 1;
     std::string err;
     virtual ~Comm() {}
+    uint32_t n_allreduce = 0, n_alltoall = 0, n_gather = 0;   // collectives entered since begin_run (bdx_dist_get_collectives)
     virtual void begin_run() {}   // start of a bdx_dist_run (collective)
     virtual void abort() {}       // this rank leaves the run between two collectives: wake whoever waits for it
+    // in place sum over the ranks of n 64-bit words in HOST memory, without the device: false = this backend has no such path (the caller
+    // stages the words through device memory and calls allreduce_u64)
+    virtual bool allreduce_host_u64(uint64_t*, size_t, bool* done) { *done = false; return true; }
     // in place sum over the ranks of n 64-bit words in device memory
     virtual bool allreduce_u64(uint64_t* dev, size_t n, hipStream_t s) = 0;
     // rank r sends scount[d] words from send + sdispl[d] to rank d and receives rcount[d] words from rank d at recv + rdispl[d]
@@ -64,7 +71,9 @@ struct RcclApi {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
-    std::string err;
+    int (*GetVersion)(int*) = nullptr;
+    std::string err, path;
+    int version = 0;
     bool load() {
         if (lib) return true;
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
@@ -83,6 +92,12 @@ struct RcclApi {
         GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
         GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
         GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        GetVersion = (decltype(GetVersion))dlsym(lib, "ncclGetVersion");
+        if (GetVersion) (void)GetVersion(&version);
+        {   // which file the loader resolved the name to (a process that imported torch first has torch's bundled copy mapped already)
+            Dl_info info{};
+            if (GetUniqueId && dladdr((void*)GetUniqueId, &info) && info.dli_fname) path = info.dli_fname;
+        }
         return err.empty();
     }
 };
@@ -97,14 +112,18 @@ struct RcclComm : Comm {
         return false;
     }
     ~RcclComm() override { if (comm) (void)rccl().CommDestroy(comm); }
+    void begin_run() override { n_allreduce = n_alltoall = n_gather = 0; }
     bool allreduce_u64(uint64_t* dev, size_t n, hipStream_t s) override {
+        ++n_allreduce;
         return ok(rccl().AllReduce(dev, dev, n, kNcclUint64, kNcclSum, comm, s), "ncclAllReduce");
     }
     bool alltoallv_u64(const uint64_t* send, const size_t* scount, const size_t* sdispl, uint64_t* recv, const size_t* rcount,
                        const size_t* rdispl, hipStream_t s) override {
+        ++n_alltoall;
         return ok(rccl().AllToAllv(send, scount, sdispl, recv, rcount, rdispl, kNcclUint64, comm, s), "ncclAllToAllv");
     }
     bool gatherv_bytes(const void* send, size_t n, void* recv, const size_t* count, const size_t* displ, int root, hipStream_t s) override {
+        ++n_gather;
         if (!ok(rccl().GroupStart(), "ncclGroupStart")) return false;
         bool good = true;
         if (n) good = ok(rccl().Send(send, n, kNcclUint8, root, comm, s), "ncclSend");
@@ -119,29 +138,33 @@ struct RcclComm : Comm {
 // ---- ranks as threads of one process: collectives as device-to-device copies around a barrier ----
 struct ThreadGroup {
     int world = 1;
-    std::mutex mu;
-    std::condition_variable cv;
-    int arrived = 0;
-    uint64_t generation = 0;
+    std::atomic<int> arrived{0};
+    std::atomic<uint64_t> generation{0};
     std::vector<const void*> ptr;      // what every rank published for the collective in progress
     std::vector<const size_t*> cnt, dsp;
     std::vector<std::vector<uint64_t>> host;  // allreduce staging
+    std::vector<uint64_t*> hptr;       // host all-reduce: every rank's words
     std::atomic<bool> failed{false};   // a collective of the run in progress went wrong on some rank
     std::atomic<bool> aborted{false};  // a rank left bdx_dist_run early: nobody may wait for it at a barrier
-    explicit ThreadGroup(int w) : world(w), ptr(w), cnt(w), dsp(w), host(w) {}
-    // false: the group was aborted (by a rank that gave up between two collectives) -- the caller fails its collective
+    explicit ThreadGroup(int w) : world(w), ptr(w), cnt(w), dsp(w), host(w), hptr(w) {}
+    // false: the group was aborted (by a rank that gave up between two collectives) -- the caller fails its collective.
+    // The ranks spin (a run's barriers are microseconds apart and a condition variable's wake-up cost 30-50 us each, twice per
+    // collective: the larger part of round 5's 0.08-0.17 ms per all-reduce); a rank that has waited for a while yields its core.
     bool barrier() {
-        std::unique_lock<std::mutex> lk(mu);
-        if (aborted.load()) return false;
-        const uint64_t g = generation;
-        if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); return true; }
-        cv.wait(lk, [&] { return generation != g || aborted.load(); });
-        return generation != g;
+        if (aborted.load(std::memory_order_acquire)) return false;
+        const uint64_t g = generation.load(std::memory_order_acquire);
+        if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == world) {
+            arrived.store(0, std::memory_order_relaxed);
+            generation.fetch_add(1, std::memory_order_release);
+            return true;
+        }
+        for (uint32_t spin = 0;; ++spin) {
+            if (generation.load(std::memory_order_acquire) != g) return true;
+            if (aborted.load(std::memory_order_acquire)) return generation.load(std::memory_order_acquire) != g;
+            if (spin < 20000u) __builtin_ia32_pause(); else std::this_thread::yield();
+        }
     }
-    void abort() {
-        { std::lock_guard<std::mutex> lk(mu); aborted.store(true); }
-        cv.notify_all();
-    }
+    void abort() { aborted.store(true, std::memory_order_release); }
     // every rank calls this at the start of a run, before its first collective: the flags of the previous run are history.
     // (Two barriers: nobody clears while somebody may still be reading, nobody proceeds before the flags are clear.)
     void begin_run(int rank) {
@@ -161,9 +184,23 @@ struct ThreadComm : Comm {
         return false;
     }
     bool gone() { err = "another rank left the run"; return false; }
-    void begin_run() override { g->begin_run(rank); }
+    void begin_run() override { n_allreduce = n_alltoall = n_gather = 0; g->begin_run(rank); }
     void abort() override { g->abort(); }
+    bool allreduce_host_u64(uint64_t* v, size_t n, bool* done) override {
+        *done = true;
+        ++n_allreduce;
+        g->hptr[rank] = v;
+        if (!g->barrier()) return gone();
+        std::vector<uint64_t>& sum = g->host[rank];
+        sum.assign(n, 0);
+        for (int r = 0; r < world; ++r)
+            for (size_t i = 0; i < n; ++i) sum[i] += g->hptr[r][i];
+        if (!g->barrier()) return gone();  // (everybody has read everybody's words)
+        memcpy(v, sum.data(), n * 8);
+        return !g->failed;
+    }
     bool allreduce_u64(uint64_t* dev, size_t n, hipStream_t s) override {
+        ++n_allreduce;
         std::vector<uint64_t>& mine = g->host[rank];
         mine.resize(n);
         bool good = hip(hipMemcpyAsync(mine.data(), dev, n * 8, hipMemcpyDeviceToHost, s), "hipMemcpyAsync") && hip(hipStreamSynchronize(s), "sync");
@@ -177,6 +214,7 @@ struct ThreadComm : Comm {
     }
     bool alltoallv_u64(const uint64_t* send, const size_t* scount, const size_t* sdispl, uint64_t* recv, const size_t* rcount,
                        const size_t* rdispl, hipStream_t s) override {
+        ++n_alltoall;
         bool good = hip(hipStreamSynchronize(s), "sync");  // the send buffer is complete
         g->ptr[rank] = send; g->cnt[rank] = scount; g->dsp[rank] = sdispl;
         if (!g->barrier()) return gone();
@@ -190,6 +228,7 @@ struct ThreadComm : Comm {
         return good && !g->failed;
     }
     bool gatherv_bytes(const void* send, size_t n, void* recv, const size_t* count, const size_t* displ, int root, hipStream_t s) override {
+        ++n_gather;
         bool good = hip(hipStreamSynchronize(s), "sync");
         g->ptr[rank] = send;
         if (!g->barrier()) return gone();
@@ -218,7 +257,7 @@ struct bdx_dist {
     const void* sorted_ptr = nullptr;  // ... at this address
     size_t n_at_last = 0;
     bool use_check = false;
-    DevBuf b_words, b_tab, b_send, b_recv, b_pack, b_all, b_nsend, b_nrecv, b_ntab, b_nflag, b_foreign, b_rg_rec, b_rg_pk, b_x, b_merge, b_chk;
+    DevBuf b_words, b_tab, b_send, b_recv, b_pack, b_all, b_nsend, b_nrecv, b_ntab, b_nflag, b_foreign, b_rg_rec, b_rg_pk, b_x, b_merge, b_chk, b_bucket;
     PinBuf h_words;                  // staging of the all-reduces' words (pinned: the copies either side of a collective are asynchronous)
     PinBuf h_tab;                    // what the small kernels report: per-chromosome tables, counts, ready words
     hipEvent_t ev_side = nullptr;    // the name census runs on the context's second stream, beside the joins
@@ -255,6 +294,11 @@ int allreduce_host(bdx_dist* d, std::vector<uint64_t>& v, hipStream_t s) {
     // (one rank: the sum is the vector itself -- no copies, no collective, and above all no wait for the stream: the device walk that is
     // enqueued when the host's share is agreed on keeps running beside the host's walk, as in bdx_run)
     if (d->comm->world == 1) return BDX_OK;
+    {   // (ranks of one process: the words never leave the host)
+        bool done = false;
+        if (!d->comm->allreduce_host_u64(v.data(), v.size(), &done)) return dfail(d, BDX_EHIP, d->comm->err);
+        if (done) return BDX_OK;
+    }
     DHIP(d, d->b_words.ensure(v.size() * 8));
     DHIP(d, d->h_words.ensure(v.size() * 8));
     memcpy(d->h_words.p, v.data(), v.size() * 8);
@@ -269,7 +313,7 @@ int allreduce_host(bdx_dist* d, std::vector<uint64_t>& v, hipStream_t s) {
 int dist_create_common(bdx_dist** out, const bdx_opts* opts, const bdx_lib* libs, int nlibs, int nbams, int ntids, int w0, int device,
                        std::unique_ptr<Comm> comm) {
     if (!out || !opts || !libs || nlibs < 1 || nbams < 1 || ntids < 1) return BDX_EINVAL;
-    if (comm->world > kMaxRanks || ntids >= (1 << 24) - 1) return BDX_ELIMIT;
+    if (comm->world >= kMaxRanks || ntids >= (1 << 24) - 1) return BDX_ELIMIT;   // (one table package per rank and one for rank 0's result context: k9_merge_tables)
     bdx_dist* d = new (std::nothrow) bdx_dist;
     if (!d) return BDX_ENOMEM;
     d->device = device; d->ntids = ntids; d->nlibs = nlibs; d->nbams = nbams; d->w0 = w0;
@@ -290,13 +334,13 @@ inline size_t nkeys_words(int nkeys) { return (size_t)nkeys + 1; }
 
 // pinned report area of a rank: ready words, then the tables the small kernels write
 struct TabLayout {
-    size_t flags = 0, tidtab = 0, first = 0, rtab = 0, cnts = 0, misc = 0, up_off = 0, up_tail = 0, up_misc = 0, up_cur = 0, up_stats = 0, words = 0;
+    size_t flags = 0, tidtab = 0, first = 0, rtab = 0, cnts = 0, misc = 0, up_off = 0, up_tail = 0, up_misc = 0, up_cur = 0, up_stats = 0, up_counts = 0, words = 0;
     TabLayout(int ntids, int ncols, int nkeys, int ncnt, int world) {
         size_t o = 16;
         tidtab = o; o += (size_t)(ntids + 1) * (1 + ncols) + 2;
         first = o; o += (size_t)ntids * 4;
         rtab = o; o += (size_t)ntids + 3;
-        cnts = o; o += (size_t)2 * world;
+        cnts = o; o += (size_t)ntids + 2 * (size_t)world;   // (inter-chromosomal reads by mate chromosome | census records by owner)
         misc = o; o += 16;
         // staging of the small tables that go UP to the device: pinned, so that the copies are asynchronous and the vectors they were
         // built in need not outlive them (every table has its own place: nothing is overwritten within a run)
@@ -305,6 +349,7 @@ struct TabLayout {
         up_misc = o; o += (size_t)3 * ntids + 1;
         up_cur = o; o += (size_t)2 * world;
         up_stats = o; o += (size_t)2 + ncnt + 64;
+        up_counts = o; o += sizeof(StageCounts) / 4;
         words = o;
     }
 };
@@ -374,7 +419,7 @@ void bdx_dist_destroy(bdx_dist* d) {
     if (d->reads) bdx_destroy(d->reads);
     if (d->util) bdx_destroy(d->util);
     for (DevBuf* b : {&d->b_words, &d->b_tab, &d->b_send, &d->b_recv, &d->b_pack, &d->b_all, &d->b_nsend, &d->b_nrecv, &d->b_ntab, &d->b_nflag, &d->b_foreign,
-                      &d->b_rg_rec, &d->b_rg_pk, &d->b_x, &d->b_merge, &d->b_chk})
+                      &d->b_rg_rec, &d->b_rg_pk, &d->b_x, &d->b_merge, &d->b_chk, &d->b_bucket})
         b->release();
     d->h_tab.release();
     d->h_words.release();
@@ -447,8 +492,9 @@ int bdx_dist_prepare(bdx_dist* d) {
         const int ncols = 2 + d->nkeys, ncnt = d->nlibs * kNumFlags + d->nlibs + d->nbams, world = d->comm->world;
         const TabLayout L(d->ntids, ncols, d->nkeys, ncnt, world);
         DHIP(d, d->h_tab.ensure(L.words * 4));
-        DHIP(d, d->h_words.ensure(((size_t)d->ntids * (ncols + 4) + ncnt + d->nbams + 2 * (size_t)world * world + 64) * 8));
-        DHIP(d, d->b_words.ensure(((size_t)d->ntids * (ncols + 4) + ncnt + d->nbams + 2 * (size_t)world * world + 64) * 8));
+        const size_t v1_words = (size_t)d->ntids * (ncols + 7 + (size_t)world) + ncnt + d->nbams + 11 * (size_t)world + (size_t)world * world + 64;   // (the first all-reduce's vector, the largest)
+        DHIP(d, d->h_words.ensure(v1_words * 8));
+        DHIP(d, d->b_words.ensure(v1_words * 8));
         DHIP(d, d->b_tab.ensure(((size_t)d->ntids * (nkeys_words(d->nkeys) + 12) + 8 * (size_t)world + 64) * 4));
         if (c->n && c->n < ((size_t)1 << 32)) {   // pass 1's tables for the reads that are loaded (a store that grew while it was filled lost them)
             const int rc = pass1_prepare(c, (uint32_t)((c->n + kTile - 1) / kTile));
@@ -469,13 +515,12 @@ int bdx_dist_prepare(bdx_dist* d) {
             const size_t nr = (size_t)prior;
             DHIP(d, d->b_rg_rec.ensure(nr * sizeof(RegionRec)));
             DHIP(d, d->b_rg_pk.ensure(nr * 2 * d->nkeys * 4));
-            DHIP(d, d->b_x.ensure((nr / 8 + nr / 64 + (size_t)d->comm->world + 64) * 8));
+            DHIP(d, d->b_x.ensure(nr + nr / 8 + 1024));   // (taint bytes: one per region / anomalous read of the upper bound)
             const size_t nn = (size_t)prior;
-            DHIP(d, d->b_nsend.ensure(nn * 16)); DHIP(d, d->b_nrecv.ensure(nn * 16));
             DHIP(d, d->b_ntab.ensure((size_t)k7_names_slots(nn) * 16));
             DHIP(d, d->b_pack.ensure(nn * 40)); DHIP(d, d->b_all.ensure(nn * 40));
             DHIP(d, d->b_foreign.ensure(nn * 20 / 8 + 64));
-            DHIP(d, d->b_send.ensure(nn * 4)); DHIP(d, d->b_recv.ensure(nn * 4));   // (an eighth of the anomalous reads inter-chromosomal and travelling)
+            DHIP(d, d->b_send.ensure(nn * 20 + 4096)); DHIP(d, d->b_recv.ensure(nn * 20 + 4096));   // (a census record of 16 bytes per anomalous read; an eighth of them inter-chromosomal and travelling, 32 bytes each)
             if (d->comm->rank == 0) {   // the genome's region table in pinned memory (regions: about a tenth of the anomalous reads)
                 const size_t nreg = (size_t)c->n / 256 + 4096;
                 DHIP(d, c->h_regs.ensure(nreg * sizeof(RegionRec)));
@@ -494,10 +539,10 @@ int bdx_dist_get_phase_ms(const bdx_dist* d, float* out, int n) {
 
 const char* bdx_dist_phase_name(int i) {
     static const char* names[kDistPhases] = {
-        "pass1_and_chromosome_table", "allreduce_statistics", "compaction_and_rebase", "allreduce_first_reads", "region_cut", "allreduce_regions",
-        "globalize_and_exchange_counts", "allreduce_exchange_sizes", "exchange_join_pair_groups", "allreduce_taint_and_windows",
-        "components_walk", "allreduce_host_share", "host_share_and_table", "allreduce_table_sizes", "rank0_only_merge", "replay_route",
-        "rank0_only_host_walk", ""};
+        "pass1_compaction_first_reads", "allreduce_statistics_first_reads_exchange_counts", "", "", "rebase_and_region_cut", "allreduce_regions",
+        "globalize_and_pack", "alltoall_join_records_census_windows", "", "",
+        "joins_components_walk_table", "allreduce_package_sizes", "", "gather_packages_to_rank0", "rank0_only_merge", "replay_route",
+        "rank0_only_host_walk", "rank0_only_device_walk_of_gathered_groups"};
     return i >= 0 && i < kDistPhases ? names[i] : "";
 }
 
@@ -518,6 +563,16 @@ int bdx_dist_get_exchange(const bdx_dist* d, uint64_t* ctx_records_sent, uint64_
     if (gathered_bytes) *gathered_bytes = d->gathered_bytes;
     if (ms_total) *ms_total = d->ms_total;
     if (ms_exchange) *ms_exchange = d->ms_exchange;
+    return BDX_OK;
+}
+
+int bdx_dist_get_collectives(const bdx_dist* d, uint32_t out[3], const char** backend, int* rccl_version) {
+    if (!d) return BDX_EINVAL;
+    if (!d->ran) return BDX_ESTATE;
+    if (out) { out[0] = d->comm->n_allreduce; out[1] = d->comm->n_alltoall; out[2] = d->comm->n_gather; }
+    const bool is_rccl = dynamic_cast<const RcclComm*>(d->comm.get()) != nullptr;
+    if (backend) *backend = is_rccl ? rccl().path.c_str() : "threads";
+    if (rccl_version) *rccl_version = is_rccl ? rccl().version : 0;
     return BDX_OK;
 }
 
@@ -627,17 +682,6 @@ int bdx_dist_run(bdx_dist* d) {
         v.resize(at);
         return f;
     };
-    // the same for words that live in HBM (`words` of them, `world` more behind them for the status): the payload stays on the device
-    auto exchange_dev = [&](uint64_t* dev, size_t words) -> int {
-        Stamp stamp{d, n_phase, std::chrono::steady_clock::now()};
-        std::vector<uint64_t> tail((size_t)world, 0);
-        tail[(size_t)rank] = (uint64_t)st.rc;
-        bool good = hipMemcpyAsync(dev + words, tail.data(), (size_t)world * 8, hipMemcpyHostToDevice, s) == hipSuccess;
-        good = good && comm.allreduce_u64(dev, words + (size_t)world, s);
-        good = good && hipMemcpyAsync(tail.data(), dev + words, (size_t)world * 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
-        if (!good) { comm.abort(); return dfail(d, BDX_EHIP, comm.err.empty() ? "all-reduce of device words" : comm.err); }
-        return agreed_failure(d, st, tail.data(), world);
-    };
     auto leave = [&](int rc) { comm.abort(); return rc; };  // failures past the last foldable point
     // BDX_DIST_TRACE=1 (a measurement / debugging aid, like BDX_ALLOC_TRACE): waits for the stream at every step and names it on stderr
     static const bool tracing = getenv("BDX_DIST_TRACE") != nullptr;
@@ -652,23 +696,32 @@ int bdx_dist_run(bdx_dist* d) {
     DHIP(d, d->h_tab.ensure(L.words * 4));
     uint32_t* H = d->h_tab.as<uint32_t>();
     volatile uint32_t* flags = (volatile uint32_t*)H;
-    // device tables: tid_off [ntids][1 + nkeys] | tid_tail [ntids][4] | roff [ntids] | owner [ntids] | tid_start [ntids + 1] | cnt [4 world] | n_total [4] | rbase u64 [ntids + 1]
+    // device tables: tid_off [ntids][1 + nkeys] | tid_tail [ntids][4] | roff [ntids] | owner [ntids] | tid_start [ntids + 1] | cnt [4 world] | n_total [8] |
+    // rbase u64 [ntids + 1] | inter-chromosomal reads by mate chromosome [ntids]
     const size_t o_off = 0, o_tail = o_off + (size_t)ntids * (1 + nkeys), o_roff = o_tail + (size_t)ntids * 4, o_owner = o_roff + ntids,
-                 o_start = o_owner + ntids, o_cnt = o_start + ntids + 1, o_ntot = o_cnt + 4 * (size_t)world, o_rbase = (o_ntot + 4 + 1) / 2 * 2,
-                 tab_words = o_rbase + 2 * ((size_t)ntids + 1);
+                 o_start = o_owner + ntids, o_cnt = o_start + ntids + 1, o_ntot = o_cnt + 4 * (size_t)world, o_rbase = (o_ntot + 8 + 1) / 2 * 2,
+                 o_mt = o_rbase + 2 * ((size_t)ntids + 1), tab_words = o_mt + (size_t)ntids;
     DHIP(d, d->b_tab.ensure(tab_words * 4));
     uint32_t* T = d->b_tab.as<uint32_t>();
+    if ((uint64_t)world * (uint64_t)ntids > (1u << 22)) return dfail(d, BDX_ELIMIT, "ranks x sequences beyond the first all-reduce's table (2^22 words)");   // (every rank alike)
 
-    // ---- pass 1 over all of this rank's chromosomes; where each chromosome starts and what the counters read there.  C1 ----
+    // ---- A: pass 1 over all of this rank's chromosomes, where each chromosome starts and what the counters read there; the compaction
+    // (it needs nothing of the other ranks); what the compact records say before anything is known of the other ranks: every chromosome's
+    // first anomalous read, the inter-chromosomal reads by mate chromosome, the census records by owner.  ONE all-reduce carries all of it
+    // (round 5: three -- statistics, first reads + exchange counts, regions) ----
     const size_t tw = (size_t)ncols;  // per chromosome: anomalous reads, normal pairs, proper reads per key
+    const size_t W2 = (size_t)world * world;
     const size_t at_tot = (size_t)ncnt + nbams, at_reads = at_tot + (size_t)ntids * tw, at_claim = at_reads + ntids, at_owner = at_claim + ntids,
-                 at_flags = at_owner + ntids;
+                 at_first = at_owner + ntids, at_mt = at_first + (size_t)ntids * 3, at_cen = at_mt + (size_t)world * ntids, at_flags = at_cen + W2;
     std::vector<uint64_t> v1(at_flags + 3, 0);
     std::vector<uint32_t> tidtab((size_t)(ntids + 1) * (1 + ncols), 0);   // [t][0] first read, [t][1 + c] counters in front of it
+    const bool solo = world == 1;   // nothing travels: no census, no counts, no all-to-all, no gather
+    uint32_t na = 0;                // this rank's anomalous reads
+    uint32_t* UP = H;               // (the staging places of L.up_*)
     phase([&]() -> int {
         C->table_in_hbm = world > 1;
         C->groups_in_hbm = world > 1;
-        C->defer_walk = world > 1;
+        C->defer_walk = false;
         C->k6_cap = 0; C->k6_r_rec = nullptr; C->k6_r_pk = nullptr; C->k6_taint = nullptr; C->k3_tid_tail = nullptr;
         {   // (a set of reads bdx_dist_prepare has not seen: its order is checked before the chromosome table is searched in it)
             const int orc = check_order(d);
@@ -691,6 +744,39 @@ int bdx_dist_run(bdx_dist* d) {
         memcpy(tidtab.data(), H + L.tidtab, tidtab.size() * 4);
         const uint32_t* terr = H + L.tidtab + tidtab.size();
         if (terr[0] || terr[1]) return dfail(d, BDX_EINVAL, "record with a reference id outside [0, ntids)");
+        na = C->p1.n_anom;
+        // the compaction, and what its records say
+        {
+            UploadList ul{};
+            ul.fill(T + o_cnt, 0u, (size_t)world * 4 + 8);   // (the exchange's counters, the error words of the later kernels)
+            ul.fill(T + o_mt, 0u, (size_t)ntids);
+            launch_k9_upload(ul, s);
+        }
+        DCTX(d, C, do_compact(C, 0, nullptr, true));
+        trace("compaction");
+        memset(H + L.first, 0, (size_t)ntids * 16);
+        if (na) {
+            FirstCountsParams fc{};
+            fc.cp = C->cp; fc.mtid_col = C->d.mtid; fc.n_ptr = &C->b_p1.as<Pass1>()->n_anom; fc.ntids = ntids; fc.world = (uint32_t)world;
+            fc.first_tab = H + L.first; fc.cnt_mtid = T + o_mt; fc.cnt_owner = T + o_cnt + world;
+            launch_k9_first_counts(fc, na, s);
+            if (solo) {
+                launch_k9_signal(H + 1, d->seq, s);
+            } else {
+                UploadList rl{};   // (device words -> the pinned report area, then the ready word: one launch each)
+                rl.copy(H + L.cnts, T + o_mt, (size_t)ntids);
+                rl.copy(H + L.cnts + ntids, T + o_cnt + world, (size_t)world);
+                launch_k9_upload(rl, s);
+                launch_k9_signal(H + 1, d->seq, s);
+            }
+            if (!wait_word(flags + 1, d->seq)) {
+                DHIP(d, hipStreamSynchronize(s));
+                if (flags[1] != d->seq) return dfail(d, BDX_EINTERNAL, "the chromosomes' first reads did not arrive: its kernels were not launched");
+            }
+            trace("first reads and counts");
+        } else {
+            C->k4 = K4Arrays{};
+        }
         for (int i = 0; i < ncnt; ++i) v1[i] = C->cnt_local[i];
         for (int b = 0; b < nbams; ++b) v1[ncnt + b] = C->p1.ref_len[b];
         for (int t = 0; t < ntids; ++t) {
@@ -702,6 +788,15 @@ int bdx_dist_run(bdx_dist* d) {
             v1[at_reads + t] = nreads;
             v1[at_claim + t] = 1;
             v1[at_owner + t] = (uint64_t)rank + 1;
+            const uint32_t* f = H + L.first + (size_t)t * 4;
+            if (na && f[0]) {   // {has one, its read length, normal pairs of THIS chromosome in front of it (the chromosomes before are added by everybody alike)}
+                v1[at_first + (size_t)t * 3] = 1; v1[at_first + (size_t)t * 3 + 1] = f[1];
+                v1[at_first + (size_t)t * 3 + 2] = (uint32_t)(f[2] - a[1 + kColNormal]);
+            }
+        }
+        if (na && !solo) {
+            for (int t = 0; t < ntids; ++t) v1[at_mt + (size_t)rank * ntids + t] = H[L.cnts + t];
+            for (int q = 0; q < world; ++q) v1[at_cen + (size_t)rank * world + q] = H[L.cnts + ntids + q];
         }
         v1[at_flags] = d->collect_support ? 1 : 0;
         if (C->n) v1[at_flags + (C->use_check ? 1 : 2)] = 1;
@@ -736,32 +831,59 @@ int bdx_dist_run(bdx_dist* d) {
     int last_anom_tid = -1;
     for (int t = 0; t < ntids; ++t)
         if (tot(t, 0) > 0) last_anom_tid = t;
-    const uint32_t na = C->p1.n_anom;   // this rank's
+    // every chromosome's first anomalous read with the genome's normal-pair count: {has one, read length, count}
+    std::vector<uint64_t> v2((size_t)ntids * 3, 0);
+    for (int t = 0; t < ntids; ++t)
+        if (v1[at_first + (size_t)t * 3]) {
+            v2[(size_t)t * 3] = 1; v2[(size_t)t * 3 + 1] = v1[at_first + (size_t)t * 3 + 1];
+            v2[(size_t)t * 3 + 2] = (uint32_t)(base[(size_t)t * tw + kColNormal] + v1[at_first + (size_t)t * 3 + 2]);
+        }
+    // what the one all-to-all will carry, per destination: inter-chromosomal join records (to the owner of the mate's later chromosome),
+    // census records (to the owner of the name key), window read lengths (below, once the regions are counted)
+    std::vector<uint32_t> h_cnt(world, 0), h_ncnt(world, 0), r_cnt(world, 0), r_ncnt(world, 0);
+    if (!solo)
+        for (int q = 0; q < world; ++q) {
+            for (int t = 0; t < ntids; ++t) {
+                if (owner[t] < 0) continue;
+                if (owner[t] == q && q != rank) h_cnt[q] += (uint32_t)v1[at_mt + (size_t)rank * ntids + t];
+                if (owner[t] == rank && q != rank) r_cnt[q] += (uint32_t)v1[at_mt + (size_t)q * ntids + t];
+            }
+            h_ncnt[q] = (uint32_t)v1[at_cen + (size_t)rank * world + q];
+            r_ncnt[q] = (uint32_t)v1[at_cen + (size_t)q * world + rank];
+        }
+    size_t nsend = 0, nrecv = 0, nnrecv = 0;
+    for (int q = 0; q < world; ++q) { nsend += h_cnt[q]; nrecv += r_cnt[q]; nnrecv += r_ncnt[q]; }
+    {   // (the same matrices on every rank: the limits trip everywhere at once)
+        for (int r = 0; r < world && !solo; ++r) {
+            uint64_t col = 0, ncol = 0;
+            for (int q = 0; q < world; ++q) {
+                ncol += v1[at_cen + (size_t)q * world + r];
+                for (int t = 0; t < ntids; ++t)
+                    if (owner[t] == r && q != r) col += v1[at_mt + (size_t)q * ntids + t];
+            }
+            if (col > (1u << 28) || ncol > 0x7FFFFFFFull) return dfail(d, BDX_ELIMIT, "too many inter-chromosomal join records / names on one rank");
+        }
+    }
 
-    // ---- compaction; the counters of every chromosome start where the chromosomes in front of it (anybody's) left them; what the
-    // exchange will carry, per destination.  C2: every chromosome's first anomalous read, and the exchange's count matrices ----
-    const size_t W2 = (size_t)world * world;
-    const size_t at_mat = (size_t)ntids * 3;
-    std::vector<uint64_t> v2(at_mat + 2 * W2, 0);   // (send-count matrices of the CTX records and the census records: row = sender)
-    std::vector<uint32_t> h_cnt(world, 0), h_ncnt(world, 0);
-    ExchangeSrc xs{};
-    uint32_t* UP = H;   // (the staging places of L.up_*)
+    // ---- B: the statistics every kernel from here on runs with; the compact records' counters start where the chromosomes in front
+    // (anybody's) left them; regions -- the first anomalous read of the next chromosome that has one closes a chromosome's last candidate.
+    // The second all-reduce: every chromosome's region count ----
+    std::vector<uint64_t> v3((size_t)ntids + 1, 0);
+    std::vector<uint32_t> rtab((size_t)ntids + 3, 0);   // this rank's regions: first region of every chromosome, count, last_maxq
+    n_phase = 2;   // (slots 4 / 5)
     phase([&]() -> int {
         DCTX(d, C, set_pass1(C, cnt_g.data(), covered, window, false));
-        {   // the statistics every kernel from here on runs with: window and covered length (Pass1's first words), flag histogram, densities
+        {
             uint32_t* st_up = UP + L.up_stats;
             st_up[0] = covered; st_up[1] = (uint32_t)window;
             memcpy(st_up + 2, cnt_g.data(), (size_t)ncnt * 4);
             memcpy(st_up + 2 + ncnt, C->key_density.data(), C->key_density.size() * 4);
-            // (these tables, the exchange counters' start values and -- with anomalous reads -- the chromosomes' offsets and owners go up in
-            // ONE launch that reads them from the pinned report area: as six copy / fill commands they were six 5 us blits with their gaps)
+            // (window and covered length -- Pass1's first words --, flag histogram, densities; with anomalous reads the chromosomes' offsets, owners
+            // and closing reads: ONE launch that reads them from the pinned report area)
             UploadList ul{};
             ul.copy(C->b_p1.p, st_up, 2);
             ul.copy(C->b_cnt.p, st_up + 2, (size_t)ncnt);
             ul.copy(C->b_kdens.p, st_up + 2 + ncnt, C->key_density.size());
-            // (the exchange counters and the error words of the later kernels: also on a rank without anomalous reads -- rank 0 checks the word
-            // k8_place_regions leaves whether or not it holds reads itself)
-            ul.fill(T + o_cnt, 0u, (size_t)world * 4 + 4);
             if (na) {
                 uint32_t* up = UP + L.up_off;
                 for (int t = 0; t < ntids; ++t) {
@@ -773,83 +895,22 @@ int bdx_dist_run(bdx_dist* d) {
                 for (int t = 0; t < ntids; ++t) { um[t] = (uint32_t)owner[t]; um[(size_t)ntids + t] = tidtab[(size_t)t * (1 + ncols)]; }
                 um[(size_t)2 * ntids] = tidtab[(size_t)ntids * (1 + ncols)];
                 ul.copy(T + o_owner, um, (size_t)2 * ntids + 1);
+                uint32_t* tails = UP + L.up_tail;
+                int nx = -1;
+                for (int t = ntids - 1; t >= 0; --t) {
+                    uint32_t* q = &tails[(size_t)t * 4];
+                    q[0] = nx >= 0 ? 1u : 0u;
+                    q[1] = nx >= 0 ? (uint32_t)v2[(size_t)nx * 3 + 1] : 0u;
+                    q[2] = nx >= 0 ? (uint32_t)v2[(size_t)nx * 3 + 2] : (uint32_t)base[(size_t)ntids * tw + 1];
+                    q[3] = 0;
+                    if (v2[(size_t)t * 3]) nx = t;
+                }
+                ul.copy(T + o_tail, tails, (size_t)ntids * 4);
             }
             launch_k9_upload(ul, s);
         }
-        DCTX(d, C, do_compact(C, 0, nullptr, true));
-        trace("compaction");
-        if (!na) { C->k4 = K4Arrays{}; return BDX_OK; }
-        memset(H + L.first, 0, (size_t)ntids * 16);
-        launch_k9_rebase(C->cp, &C->b_p1.as<Pass1>()->n_anom, na, nkeys, T + o_off, H + L.first, s);
-        xs.key = C->cp.key; xs.check = C->cp.check; xs.meta = C->cp.meta; xs.tid = C->cp.tid; xs.idx = C->cp.idx; xs.mtid_col = C->d.mtid;
-        xs.region_of = nullptr; xs.n_ptr = &C->b_p1.as<Pass1>()->n_anom; xs.owner_of_tid = (const int32_t*)(T + o_owner);
-        xs.ntids = ntids; xs.me = rank; xs.world = (uint32_t)world;
-        if (world == 1) {   // (a lone rank: nothing travels, nothing is counted or packed for the exchange; the ready word behind the rebase)
-            H[L.cnts] = 0; H[L.cnts + 1] = 0;
-            launch_k9_signal(H + 1, d->seq, s);
-        } else {
-            launch_k7_count(xs, na, T + o_cnt, s);
-            launch_k9_report(T + o_cnt, H + L.cnts, 2 * (uint32_t)world, H + 1, d->seq, s);
-        }
-        if (!wait_word(flags + 1, d->seq)) {
-            DHIP(d, hipStreamSynchronize(s));
-            if (flags[1] != d->seq) return dfail(d, BDX_EINTERNAL, "the chromosomes' first reads did not arrive: its kernels were not launched");
-        }
-        trace("rebase and counts");
-        for (int t = 0; t < ntids; ++t) {
-            const uint32_t* f = H + L.first + (size_t)t * 4;
-            if (f[0]) { v2[(size_t)t * 3] = 1; v2[(size_t)t * 3 + 1] = f[1]; v2[(size_t)t * 3 + 2] = f[2]; }
-        }
-        for (int q = 0; q < world; ++q) { h_cnt[q] = H[L.cnts + q]; h_ncnt[q] = H[L.cnts + world + q]; }
-        for (int q = 0; q < world; ++q) { v2[at_mat + (size_t)rank * world + q] = h_cnt[q]; v2[at_mat + W2 + (size_t)rank * world + q] = h_ncnt[q]; }
-        return BDX_OK;
-    });
-    rc = exchange(v2);
-    if (rc != BDX_OK) return rc;
-    std::vector<size_t> scount(world), sdispl(world), rcount(world), rdispl(world);
-    std::vector<size_t> nscount(world), nsdispl(world), nrcount(world), nrdispl(world);   // the name census: two words per read
-    size_t nsend = 0, nrecv = 0, nnsend = 0, nnrecv = 0;
-    constexpr size_t kxw = sizeof(ExchangeEntry) / 8;
-    for (int q = 0; q < world; ++q) { scount[q] = (size_t)h_cnt[q] * kxw; sdispl[q] = nsend * kxw; nsend += h_cnt[q]; }
-    for (int q = 0; q < world; ++q) { nscount[q] = (size_t)h_ncnt[q] * 2; nsdispl[q] = nnsend * 2; nnsend += h_ncnt[q]; }
-    for (int q = 0; q < world; ++q) { rcount[q] = (size_t)v2[at_mat + (size_t)q * world + rank] * kxw; rdispl[q] = nrecv * kxw; nrecv += v2[at_mat + (size_t)q * world + rank]; }
-    for (int q = 0; q < world; ++q) { nrcount[q] = (size_t)v2[at_mat + W2 + (size_t)q * world + rank] * 2; nrdispl[q] = nnrecv * 2; nnrecv += v2[at_mat + W2 + (size_t)q * world + rank]; }
-    // One rank: nothing travels -- its join sees every sighting of every name itself (a third one is K4's to report, as in bdx_run), so the
-    // census of names is not taken, and neither all-to-all is called (the CTX records of a lone rank are all its own: none is packed).
-    const bool solo = world == 1;
-    if (solo) nnrecv = 0;
-    {
-        // (the column sums are the same table on every rank: the limits trip everywhere at once)
-        for (int r = 0; r < world; ++r) {
-            uint64_t col = 0, ncol = 0;
-            for (int q = 0; q < world; ++q) { col += v2[at_mat + (size_t)q * world + r]; ncol += v2[at_mat + W2 + (size_t)q * world + r]; }
-            if (col > (1u << 28) || ncol > 0x7FFFFFFFull) return dfail(d, BDX_ELIMIT, "too many inter-chromosomal join records / names on one rank");
-        }
-    }
-
-    // ---- regions; the first anomalous read of the next chromosome that has one closes a chromosome's last candidate.  C3 ----
-    std::vector<uint64_t> v3((size_t)ntids + 1, 0);
-    std::vector<uint32_t> rtab((size_t)ntids + 3, 0);   // this rank's regions: first region of every chromosome, count, last_maxq
-    phase([&]() -> int {
-        // (the exchange's buffers, sized by counts that are known since C2: a rank without reads still receives census records)
-        DHIP(d, d->b_send.ensure(std::max<size_t>(nsend, 1) * sizeof(ExchangeEntry)));
-        DHIP(d, d->b_nsend.ensure(std::max<size_t>(nnsend, 1) * 16));
-        DHIP(d, d->b_recv.ensure(std::max<size_t>(nrecv, 1) * sizeof(ExchangeEntry)));
-        DHIP(d, d->b_nrecv.ensure(std::max<size_t>(nnrecv, 1) * 16));
         if (!na) return BDX_OK;
-        {
-            uint32_t* tails = UP + L.up_tail;
-            int nx = -1;
-            for (int t = ntids - 1; t >= 0; --t) {
-                uint32_t* q = &tails[(size_t)t * 4];
-                q[0] = nx >= 0 ? 1u : 0u;
-                q[1] = nx >= 0 ? (uint32_t)v2[(size_t)nx * 3 + 1] : 0u;
-                q[2] = nx >= 0 ? (uint32_t)v2[(size_t)nx * 3 + 2] : (uint32_t)base[(size_t)ntids * tw + 1];
-                q[3] = 0;
-                if (v2[(size_t)t * 3]) nx = t;
-            }
-            DHIP(d, hipMemcpyAsync(T + o_tail, tails, (size_t)ntids * 16, hipMemcpyHostToDevice, s));
-        }
+        launch_k9_rebase(C->cp, &C->b_p1.as<Pass1>()->n_anom, na, nkeys, T + o_off, nullptr, s);
         C->k3_tid_tail = T + o_tail;
         DCTX(d, C, do_cut(C, 0, 0, 0, false, true));
         trace("region cut");
@@ -878,6 +939,10 @@ int bdx_dist_run(bdx_dist* d) {
     const uint32_t period = (uint32_t)std::max(1, d->opts.buffer_size + 1);
     const uint32_t NW = (uint32_t)(NR / period);
     const uint32_t capG = (uint32_t)std::max<uint64_t>(std::max<uint64_t>(C->na_alloc, NR), 1);
+    // flush windows whose last region (id (w + 1) period - 1) is rank q's: its read length is what every rank's walk uses at that flush
+    std::vector<uint32_t> nwin(world, 0);
+    for (int t = 0; t < ntids; ++t)
+        if (owner[t] >= 0 && rbase[t + 1] > rbase[t]) nwin[owner[t]] += (uint32_t)(std::min<uint64_t>(rbase[t + 1], (uint64_t)NW * period) / period - std::min<uint64_t>(rbase[t], (uint64_t)NW * period) / period);
 
     // the result context takes the run's statistics; with no region anywhere the run is over
     auto finish_result = [&]() -> int {
@@ -908,32 +973,58 @@ int bdx_dist_run(bdx_dist* d) {
     }
 
     const auto t_x0 = std::chrono::steady_clock::now();
-    // ---- genome-wide region ids, the CTX records and the census records packed per destination; C4: ONE all-to-all each.  No
-    // host round trip from here to the pair groups: failures of this stretch travel with the next all-reduce ----
-    uint64_t* X = nullptr;          // [NW] window read lengths | taint bytes (capG) | status words
-    const size_t x_taint = NW, x_words = (size_t)NW + ((size_t)capG + 7) / 8;
-    RegionRec* regs = nullptr;      // rank 0: the genome's region table (pinned: the copy runs beside the joins)
+    // ---- C: genome-wide region ids; ONE all-to-all carries, per destination, the inter-chromosomal join records (32 bytes), the census
+    // records (16) and the read lengths of the flush windows this rank closes (8) -- round 5: two all-to-alls and, for the windows and the
+    // taint bytes, an all-reduce of device words.  No host round trip from here to the rank's finished table ----
+    constexpr size_t kxw = sizeof(ExchangeEntry) / 8;
+    std::vector<size_t> scount(world, 0), sdispl(world, 0), rcount(world, 0), rdispl(world, 0);   // in 64-bit words
+    size_t swords = 0, rwords = 0;
+    for (int q = 0; q < world; ++q) {
+        const size_t sw = (size_t)h_cnt[q] * kxw + (size_t)h_ncnt[q] * 2 + (q != rank ? nwin[rank] : 0);
+        const size_t rw = (size_t)r_cnt[q] * kxw + (size_t)r_ncnt[q] * 2 + (q != rank ? nwin[q] : 0);
+        scount[q] = sw; sdispl[q] = swords; swords += round_up(sw, 4);   // (blocks start on 32-byte boundaries: a join record is stored as one)
+        rcount[q] = rw; rdispl[q] = rwords; rwords += round_up(rw, 4);
+    }
+    SegList seg_ctx{}, seg_cen{}, seg_win{};
+    {
+        uint32_t a = 0, b = 0, c = 0;
+        seg_ctx.n = seg_cen.n = seg_win.n = world;
+        for (int q = 0; q < world; ++q) {
+            seg_ctx.off[q] = rdispl[q]; seg_ctx.start[q] = a; a += r_cnt[q];
+            seg_cen.off[q] = rdispl[q] + (size_t)r_cnt[q] * kxw; seg_cen.start[q] = b; b += r_ncnt[q];
+            seg_win.off[q] = rdispl[q] + (size_t)r_cnt[q] * kxw + (size_t)r_ncnt[q] * 2; seg_win.start[q] = c; c += q != rank ? nwin[q] : 0;
+        }
+        seg_ctx.start[world] = a; seg_cen.start[world] = b; seg_win.start[world] = c;
+    }
+    const uint32_t nwin_recv = seg_win.start[world];
+    uint8_t* taint = nullptr;       // [capG] bytes: this rank's regions that are an end of a group formed on another rank, or of one formed here with another rank's region
+    RegionRec* regs = nullptr;      // rank 0: the genome's region table (pinned: the copy runs beside the result context's walk)
     uint32_t* pk = nullptr;
     bool regs_pending = false;
-    int local_rc = BDX_OK;          // (what `phase` would record: this stretch ends in point-to-point collectives, which cannot carry it)
+    ExchangeSrc xs{};
     {
         const auto tp = std::chrono::steady_clock::now();
         auto body = [&]() -> int {
+            DHIP(d, d->b_send.ensure(std::max<size_t>(swords, 4) * 8));
+            DHIP(d, d->b_recv.ensure(std::max<size_t>(rwords, 4) * 8));
             DHIP(d, d->b_rg_rec.ensure((size_t)NR * sizeof(RegionRec)));
             DHIP(d, d->b_rg_pk.ensure(std::max<size_t>((size_t)NR * nkeys2 * 4, 16)));
             DHIP(d, C->b_out_deg.ensure((size_t)capG * 6 * 4));
-            DHIP(d, d->b_x.ensure((x_words + (size_t)world + 8) * 8));
-            X = d->b_x.as<uint64_t>();
+            DHIP(d, d->b_x.ensure((size_t)capG + 64));
+            taint = d->b_x.as<uint8_t>();
             DHIP(d, hipMemsetAsync(d->b_rg_rec.p, 0, (size_t)NR * sizeof(RegionRec), s));
-            DHIP(d, hipMemsetAsync(X, 0, (x_words + (size_t)world) * 8, s));
+            DHIP(d, hipMemsetAsync(taint, 0, (size_t)capG, s));
             {   // (the chromosomes' region offsets and the exchange's cursors: one launch, as above)
                 UploadList ul{};
                 uint32_t* ur = UP + L.up_misc + (size_t)2 * ntids + 1;
                 for (int t = 0; t < ntids; ++t) ur[t] = (uint32_t)rbase[t] - rtab[t];
                 ul.copy(T + o_roff, ur, (size_t)ntids);
-                if (na) {
+                if (na && !solo) {   // where a destination's join records / census records start in the ONE send buffer, in records of their own size
                     uint32_t* cur = UP + L.up_cur;
-                    for (int q = 0; q < world; ++q) { cur[q] = (uint32_t)(sdispl[q] / kxw); cur[(size_t)world + q] = (uint32_t)(nsdispl[q] / 2); }
+                    for (int q = 0; q < world; ++q) {
+                        cur[q] = (uint32_t)(sdispl[q] / kxw);
+                        cur[(size_t)world + q] = (uint32_t)((sdispl[q] + (size_t)h_cnt[q] * kxw) / 2);
+                    }
                     ul.copy(T + o_cnt + 2 * (size_t)world, cur, (size_t)world * 2);
                 }
                 launch_k9_upload(ul, s);
@@ -945,21 +1036,44 @@ int bdx_dist_run(bdx_dist* d) {
             gp.scratch = C->b_out_deg.as<uint32_t>(); gp.cap = capG; gp.counts = C->b_counts.as<StageCounts>(); gp.nr_global = (uint32_t)NR; gp.last_maxq = lm;
             launch_k9_globalize(gp, na, s);
             trace("globalize");
-            launch_k9_window_collect(d->b_rg_rec.as<RegionRec>(), (uint32_t)NR, period, (unsigned long long*)X, s);
             C->k6_cap = (uint32_t)NR; C->k6_r_rec = d->b_rg_rec.as<RegionRec>(); C->k6_r_pk = d->b_rg_pk.as<uint32_t>();
-            C->k6_taint = world > 1 ? (uint8_t*)(X + x_taint) : nullptr;
-            if (na && world > 1) {
-                xs.region_of = C->k3.region_of;
-                launch_k7_scatter(xs, na, T + o_cnt + 2 * (size_t)world, d->b_send.as<ExchangeEntry>(), d->b_nsend.as<unsigned long long>(), s);
+            C->k6_taint = solo ? nullptr : taint;
+            if (solo && rank == 0) {   // one rank: the genome's table is this rank's -- to pinned memory beside the joins, for the host's share of the walk and the result
+                if (C->h_regs.ensure((size_t)NR * sizeof(RegionRec)) != hipSuccess || C->h_pk.ensure(std::max<size_t>((size_t)NR * nkeys2 * 4, 16)) != hipSuccess)
+                    return dfail(d, BDX_ENOMEM, "region table");
+                regs = C->h_regs.as<RegionRec>();
+                pk = C->h_pk.as<uint32_t>();
+                DHIP(d, hipEventRecord(C->ev_copy, s));
+                DHIP(d, hipStreamWaitEvent(C->copy_stream, C->ev_copy, 0));
+                static_assert(sizeof(RegionRec) % 4 == 0, "copied by words");
+                UploadList ul{};   // (a kernel, not copy commands: the first device-to-host copy command of a process sets up a copy-engine queue, round 5)
+                ul.copy(regs, d->b_rg_rec.p, (size_t)NR * sizeof(RegionRec) / 4);
+                if (nkeys2) ul.copy(pk, d->b_rg_pk.p, (size_t)NR * nkeys2);
+                launch_k9_upload(ul, C->copy_stream);
+            }
+            if (!solo) {
+                if (nwin[rank]) {
+                    WindowDst wd{};
+                    wd.world = world;
+                    for (int q = 0; q < world; ++q)
+                        wd.dst[q] = q == rank ? nullptr : d->b_send.as<unsigned long long>() + sdispl[q] + (size_t)h_cnt[q] * kxw + (size_t)h_ncnt[q] * 2;
+                    launch_k9_window_pack(d->b_rg_rec.as<RegionRec>(), (uint32_t)NR, period, wd, nwin[rank], T + o_ntot + 3, s);
+                }
+                if (na) {
+                    xs.key = C->cp.key; xs.check = C->cp.check; xs.meta = C->cp.meta; xs.tid = C->cp.tid; xs.idx = C->cp.idx; xs.mtid_col = C->d.mtid;
+                    xs.region_of = C->k3.region_of; xs.n_ptr = &C->b_p1.as<Pass1>()->n_anom; xs.owner_of_tid = (const int32_t*)(T + o_owner);
+                    xs.ntids = ntids; xs.me = rank; xs.world = (uint32_t)world; xs.taint = taint;
+                    launch_k7_scatter(xs, na, T + o_cnt + 2 * (size_t)world, d->b_send.as<ExchangeEntry>(), d->b_send.as<unsigned long long>(), s);
+                }
             }
             trace("scatter");
             return BDX_OK;
         };
         d->err.clear();
-        local_rc = st.rc == BDX_OK ? body() : BDX_OK;
+        const int local_rc = st.rc == BDX_OK ? body() : BDX_OK;
         if (local_rc != BDX_OK) { st.rc = local_rc; st.msg = d->err; }
         d->phase_ms[6] += ms_between(tp, std::chrono::steady_clock::now());
-        n_phase = 4;   // (slots 6 / 7: this stretch and the all-to-alls)
+        n_phase = 5;   // (slots 6 / 7 were this stretch and the all-to-all; 10 / 11 follow)
     }
     if (st.rc != BDX_OK && world > 1) {
         // (a rank that cannot take part in the all-to-all: the others would wait for it -- the communicator is given up)
@@ -968,103 +1082,36 @@ int bdx_dist_run(bdx_dist* d) {
     if (st.rc != BDX_OK) return dfail(d, st.rc, st.msg);
     {
         const auto tp = std::chrono::steady_clock::now();
-        // C4: the all-to-all of the CTX records (four 64-bit words each), then the census records
-        if (solo && nsend) return leave(dfail(d, BDX_EINTERNAL, "a lone rank packed inter-chromosomal records for another"));
         if (!solo && !comm.alltoallv_u64(d->b_send.as<uint64_t>(), scount.data(), sdispl.data(), d->b_recv.as<uint64_t>(), rcount.data(), rdispl.data(), s))
-            return leave(dfail(d, BDX_EHIP, comm.err));
-        if (!solo && !comm.alltoallv_u64(d->b_nsend.as<uint64_t>(), nscount.data(), nsdispl.data(), d->b_nrecv.as<uint64_t>(), nrcount.data(), nrdispl.data(), s))
             return leave(dfail(d, BDX_EHIP, comm.err));
         d->ctx_sent = nsend; d->ctx_received = nrecv;
         d->phase_ms[7] += ms_between(tp, std::chrono::steady_clock::now());
     }
 
-    // ---- the genome's region table on rank 0 (C5: a gather of the ranks' dense tables; with one rank it is there already) ----
-    size_t region_bytes = 0;
-    {
-        std::vector<size_t> gcount(world), gdispl(world);
-        const size_t rrec = sizeof(RegionRec), rpk = (size_t)nkeys2 * 4;
-        for (int q = 0; q < world; ++q) { gcount[q] = round_up((size_t)nr_of_rank[q] * (rrec + rpk), 8); gdispl[q] = region_bytes; region_bytes += gcount[q]; }
-        if (world > 1) {
-            const size_t mine = gcount[rank];
-            if (d->b_pack.ensure(std::max<size_t>(mine, 8)) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "region package"));
-            if (nr_local) {
-                if (hipMemcpyAsync(d->b_pack.p, C->b_r_rec.p, (size_t)nr_local * rrec, hipMemcpyDeviceToDevice, s) != hipSuccess ||
-                    hipMemcpyAsync((char*)d->b_pack.p + (size_t)nr_local * rrec, C->b_r_pk.p, (size_t)nr_local * rpk, hipMemcpyDeviceToDevice, s) != hipSuccess)
-                    return leave(dfail(d, BDX_EHIP, "region package"));
-            }
-            if ((uint64_t)nr_local != nr_of_rank[rank]) return leave(dfail(d, BDX_EINTERNAL, "region counts of the chromosomes do not add up"));
-            if (rank == 0 && d->b_all.ensure(std::max<size_t>(region_bytes, 8)) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "gather buffer"));
-            if (!comm.gatherv_bytes(d->b_pack.p, mine, d->b_all.p, gcount.data(), gdispl.data(), 0, s)) return leave(dfail(d, BDX_EHIP, comm.err));
-            d->gathered_bytes += region_bytes;
-        }
-        if (rank == 0) {
-            if (C->h_regs.ensure((size_t)NR * rrec) != hipSuccess || C->h_pk.ensure(std::max<size_t>((size_t)NR * rpk, 16)) != hipSuccess)
-                return leave(dfail(d, BDX_ENOMEM, "region table"));
-            regs = C->h_regs.as<RegionRec>();
-            pk = C->h_pk.as<uint32_t>();
-            const RegionRec* src_rec = d->b_rg_rec.as<RegionRec>();
-            const uint32_t* src_pk = d->b_rg_pk.as<uint32_t>();
-            if (world > 1) {
-                GatherDesc D{};
-                D.world = world;
-                uint32_t max_nr = 0;
-                for (int q = 0; q < world; ++q) {
-                    const size_t nr = (size_t)nr_of_rank[q];
-                    D.p[q] = GatherPackage{gdispl[q], gdispl[q] + nr * rrec, 0, (uint32_t)nr, 0};
-                    max_nr = std::max(max_nr, (uint32_t)nr);
-                }
-                if (U->b_r_rec.ensure((size_t)NR * rrec) != hipSuccess || U->b_r_pk.ensure(std::max<size_t>((size_t)NR * rpk, 16)) != hipSuccess)
-                    return leave(dfail(d, BDX_ENOMEM, "region table"));
-                if (hipMemcpyAsync(T + o_rbase, rbase.data(), ((size_t)ntids + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess) return leave(dfail(d, BDX_EHIP, "region table"));
-                launch_k8_place_regions((const char*)d->b_all.p, D, max_nr, (const uint64_t*)(T + o_rbase), ntids, nkeys2, U->b_r_rec.as<RegionRec>(), U->b_r_pk.as<uint32_t>(),
-                                        T + o_ntot + 1, s);
-                src_rec = U->b_r_rec.as<RegionRec>(); src_pk = U->b_r_pk.as<uint32_t>();
-            }
-            // (on the context's second stream, behind what has been enqueued so far: the joins and the pair groups do not wait for it)
-            // (written into the pinned table by a kernel, not by copy commands: the first device-to-host copy command of a process sets up a
-            // copy-engine queue -- 6 ms in front of the joins of a process's first run, BDX_DIST_TRACE -- and the kernel's stores cross PCIe
-            // as the result tables of bdx_run do)
-            if (hipEventRecord(C->ev_copy, s) != hipSuccess || hipStreamWaitEvent(C->copy_stream, C->ev_copy, 0) != hipSuccess)
-                return leave(dfail(d, BDX_EHIP, "region table"));
-            {
-                static_assert(sizeof(RegionRec) % 4 == 0, "copied by words");
-                UploadList ul{};
-                ul.copy(regs, src_rec, (size_t)NR * rrec / 4);
-                if (nkeys2) ul.copy(pk, src_pk, (size_t)NR * rpk / 4);
-                launch_k9_upload(ul, C->copy_stream);
-            }
-            regs_pending = true;
-        }
-    }
-
-    auto wait_regions = [&]() -> int {
-        if (regs_pending) {
-            DHIP(d, hipStreamSynchronize(C->copy_stream));
-            regs_pending = false;
-            if (world > 1) {
-                uint32_t perr = 0;
-                DHIP(d, hipMemcpy(&perr, T + o_ntot + 1, 4, hipMemcpyDeviceToHost));
-                if (perr) return dfail(d, BDX_EINTERNAL, "region table of the gather does not add up");
-            }
-        }
-        return BDX_OK;
-    };
-
-    // ---- the joins (own reads + foreign entries), the name census, the pair groups per region.  C6: taint bytes, window lengths ----
+    // ---- D: the joins (own reads + foreign entries), the name census beside them, the pair groups per region, the components, the device's
+    // walk of the ones that lie inside this rank, the rank's table -- enqueued in one go: nothing of it waits for the host or for another rank.
+    // A component that spans ranks is known as such WITHOUT an exchange: a region that sent a join record away is an end of a group another
+    // rank forms (k7_scatter marks it), a region joined with a foreign entry by a gate-passing group is one too (k6_pairs marks it) -- its
+    // groups go to rank 0 (round 5 all-reduced the marks).  The third all-reduce: what every rank will send to rank 0, and whether a name misbehaved ----
     // (a negative -s: shifted region ids are the read-level walk's business below; the pair model's device walk is not enqueued for them, as in bdx_run)
     const bool ph_opt = 0 > d->opts.min_len && 0.0f < (float)d->opts.seq_coverage_lim;
     const bool force_host = (rank == 0 ? U->host_walk_only : false) || C->host_walk_only || d->opts.min_read_pair < 1 || ph_opt;
+    const uint32_t ph = (na_all && ph_opt) ? 1u : 0u;
+    const bool replay_known = want_support != 0 || ph != 0;   // (the read-level walk on rank 0 serves these whatever the names look like)
     auto t_x1 = std::chrono::steady_clock::now();
+    uint64_t irregular = 0;
+    uint64_t mine_counts[10] = {0};
     phase([&]() -> int {
-        if (nnrecv) {   // the census of the names this rank owns: on the second stream, beside the joins (its verdict is read at the next all-reduce)
+        const unsigned long long* R = d->b_recv.as<unsigned long long>();
+        if (nwin_recv) launch_k9_window_unpack(d->b_rg_rec.as<RegionRec>(), (uint32_t)NR, period, R, seg_win, nwin_recv, T + o_ntot + 4, s);
+        if (nnrecv) {   // the census of the names this rank owns: on the second stream, beside the joins (its verdict is read below)
             const uint32_t slots = k7_names_slots(nnrecv);
             DHIP(d, d->b_ntab.ensure((size_t)slots * 16));
             DHIP(d, d->b_nflag.ensure(16));
             DHIP(d, hipEventRecord(d->ev_side, s));
             DHIP(d, hipStreamWaitEvent(C->copy_stream, d->ev_side, 0));
             launch_k7_names_clear(d->b_ntab.as<unsigned long long>(), slots, d->b_nflag.as<uint32_t>(), C->copy_stream);
-            launch_k7_names_census(d->b_nrecv.as<unsigned long long>(), (uint32_t)nnrecv, d->b_ntab.as<unsigned long long>(), slots, d->b_nflag.as<uint32_t>(),
-                                   C->copy_stream);
+            launch_k7_names_census_seg(R, seg_cen, (uint32_t)nnrecv, d->b_ntab.as<unsigned long long>(), slots, d->b_nflag.as<uint32_t>(), C->copy_stream);
         }
         if (na) {
             if ((uint64_t)C->na_alloc + nrecv > (1u << 28)) return dfail(d, BDX_ELIMIT, "too many join entries on one rank");
@@ -1073,7 +1120,7 @@ int bdx_dist_run(bdx_dist* d) {
             uint64_t* fkey = d->b_foreign.as<uint64_t>();
             uint64_t* fcheck = fkey + std::max<size_t>(nf, 1);
             int32_t* fregion = (int32_t*)(fcheck + std::max<size_t>(nf, 1));
-            launch_k7_unpack(d->b_recv.as<ExchangeEntry>(), nf, fkey, with_check ? fcheck : nullptr, fregion, &C->b_p1.as<Pass1>()->n_anom, T + o_ntot, s);
+            launch_k7_unpack_seg(R, seg_ctx, nf, fkey, with_check ? fcheck : nullptr, fregion, &C->b_p1.as<Pass1>()->n_anom, T + o_ntot, s);
             Entries en{};
             en.key = C->cp.key; en.check = C->cp.check; en.region = C->k3.region_of; en.meta = C->cp.meta; en.isize = C->cp.isize;
             en.n_local = &C->b_p1.as<Pass1>()->n_anom; en.fkey = fkey; en.fcheck = fcheck; en.fregion = fregion; en.want_pair_lo = 1;
@@ -1082,28 +1129,11 @@ int bdx_dist_run(bdx_dist* d) {
         trace("join");
         t_x1 = std::chrono::steady_clock::now();
         DCTX(d, C, do_k6(C, force_host, 1));
-        trace("pair groups");
-        return BDX_OK;
-    });
-    if (world > 1) {
-        rc = exchange_dev(X, x_words);
-        if (rc != BDX_OK) return rc;
-    } else {
-        ++n_phase;
-    }
-    d->ms_exchange = ms_between(t_x0, t_x1);
-
-    // ---- components, the device's share of the walk; the host's share (pair groups of the components that are large, or span
-    // ranks) goes to rank 0.  C7: its size per rank, and whether a name misbehaved ----
-    uint64_t irregular = 0;
-    phase([&]() -> int {
-        if (world > 1) launch_k9_window_apply(d->b_rg_rec.as<RegionRec>(), (uint32_t)NR, period, (const unsigned long long*)X, s);
-        DCTX(d, C, do_k6(C, force_host, 2));
+        DCTX(d, C, do_k6(C, force_host, 2));   // (components and, right behind them, the device's walk)
         trace("components and walk");
-        if (rank == 0) {   // while the device walks: the genome's region table for the host's share of the walk and for the result
-            const int wr = wait_regions();
-            if (wr != BDX_OK) return wr;
-            decode_regions(C, regs, pk, (uint32_t)NR, 0, true);   // (read where it arrived, in pinned memory: the host's share of the walk touches little of it)
+        if (solo && rank == 0) {   // one rank: its host walks what the device walk leaves, as in bdx_run -- on the table that went to pinned memory beside the joins
+            DHIP(d, hipStreamSynchronize(C->copy_stream));
+            decode_regions(C, regs, pk, (uint32_t)NR, 0, true);
         }
         if (!wait_flag(C, 1, C->seq)) {
             if (C->poll) DHIP(d, hipStreamSynchronize(s)); else DHIP(d, hipEventSynchronize(C->ev_groups));
@@ -1118,41 +1148,123 @@ int bdx_dist_run(bdx_dist* d) {
             DHIP(d, hipStreamSynchronize(C->copy_stream));
             if (flag) irregular = 1;
         }
+        if (nwin_recv) {
+            uint32_t werr = 0;
+            DHIP(d, hipMemcpy(&werr, T + o_ntot + 4, 4, hipMemcpyDeviceToHost));
+            if (werr) return dfail(d, BDX_EINTERNAL, "window read lengths of the exchange do not fit the region table");
+        }
+        if (irregular || replay_known) return BDX_OK;   // (the table of this model is not wanted)
+        C->walk.clear();
+        if (solo && rank == 0) {
+            decode_groups(C, C->h_groups.as<GroupRec>(), C->counts.n_groups, 0);
+            C->last_big_groups = (int64_t)C->counts.n_groups + C->counts.n_groups_big;
+            const auto tw0 = std::chrono::steady_clock::now();
+            DCTX(d, C, host_walk(C, lm, na_all != 0));
+            d->phase_ms[16] = ms_between(tw0, std::chrono::steady_clock::now());
+        }
+        C->counts.last_maxq = lm;
+        DCTX(d, C, do_k6_table(C));
+        DCTX(d, C, finish_table(C));
+        trace("table");
+        mine_counts[0] = C->counts.n_groups;   // (several ranks: the groups of the components that go to rank 0)
+        mine_counts[1] = C->n_sv_total; mine_counts[2] = C->n_terms_total; mine_counts[3] = C->n_cn_total; mine_counts[4] = C->n_printed;
+        mine_counts[5] = C->n_sv_host; mine_counts[6] = C->counts.n_pairs; mine_counts[7] = C->n_groups_total; mine_counts[8] = C->counts.n_old;
         return BDX_OK;
     });
-    std::vector<uint64_t> v5((size_t)world + 1, 0);
-    if (st.rc == BDX_OK) v5[(size_t)rank] = C->counts.n_groups;
-    v5[(size_t)world] = irregular;
+    d->ms_exchange = ms_between(t_x0, t_x1);
+    std::vector<uint64_t> v5((size_t)world * 10 + 1, 0);
+    if (st.rc == BDX_OK)
+        for (int k = 0; k < 10; ++k) v5[(size_t)rank * 10 + k] = mine_counts[k];
+    v5[(size_t)world * 10] = irregular;
     rc = exchange(v5);
     if (rc != BDX_OK) return rc;
     // some rank met a read name more than twice -- or the caller wants the reads behind every SV, which only the read-level walk knows
     // ... or -s is negative: the very first anomalous read of the genome then registers a read-less region 0 (BreakDancer.cpp:216-231,
     // 244-252; bdx_run's `ph`), every real region's id shifts by one and with it the flush cadence -- the read-level walk knows how
     // (ReadWalkInput::phantom), the pair model's kernels do not
-    const uint32_t ph = (na_all && ph_opt) ? 1u : 0u;
-    const bool replay = v5[(size_t)world] != 0 || want_support != 0 || ph != 0;
+    const bool replay = v5[(size_t)world * 10] != 0 || replay_known;
 
+    // the genome's region table on rank 0: the ranks' dense tables placed by genome-wide id (several ranks: from a gather's packages)
+    size_t region_bytes = 0;
+    std::vector<size_t> gcount(world), gdispl(world);
+    const size_t rrec = sizeof(RegionRec), rpk = (size_t)nkeys2 * 4;
+    for (int q = 0; q < world; ++q) { gcount[q] = round_up((size_t)nr_of_rank[q] * (rrec + rpk), 8); gdispl[q] = region_bytes; region_bytes += gcount[q]; }
+    if (!solo && (uint64_t)nr_local != nr_of_rank[rank]) return leave(dfail(d, BDX_EINTERNAL, "region counts of the chromosomes do not add up"));
+    // rank 0, several ranks: the packages' region records (at all + base_off + gdispl[q]) -> the result context's table in HBM and, on the side stream, in pinned memory
+    auto place_regions = [&](size_t base_off) -> int {
+        GatherDesc D{};
+        D.world = world;
+        uint32_t max_nr = 0;
+        for (int q = 0; q < world; ++q) {
+            const size_t nr = (size_t)nr_of_rank[q];
+            D.p[q] = GatherPackage{base_off + gdispl[q], base_off + gdispl[q] + nr * rrec, 0, (uint32_t)nr, 0};
+            max_nr = std::max(max_nr, (uint32_t)nr);
+        }
+        if (C->h_regs.ensure((size_t)NR * rrec) != hipSuccess || C->h_pk.ensure(std::max<size_t>((size_t)NR * rpk, 16)) != hipSuccess) return dfail(d, BDX_ENOMEM, "region table");
+        regs = C->h_regs.as<RegionRec>();
+        pk = C->h_pk.as<uint32_t>();
+        if (U->b_r_rec.ensure((size_t)NR * rrec) != hipSuccess || U->b_r_pk.ensure(std::max<size_t>((size_t)NR * rpk, 16)) != hipSuccess) return dfail(d, BDX_ENOMEM, "region table");
+        DHIP(d, hipMemcpyAsync(T + o_rbase, rbase.data(), ((size_t)ntids + 1) * 8, hipMemcpyHostToDevice, s));
+        launch_k8_place_regions((const char*)d->b_all.p, D, max_nr, (const uint64_t*)(T + o_rbase), ntids, nkeys2, U->b_r_rec.as<RegionRec>(), U->b_r_pk.as<uint32_t>(),
+                                T + o_ntot + 1, s);
+        DHIP(d, hipEventRecord(C->ev_copy, s));
+        DHIP(d, hipStreamWaitEvent(C->copy_stream, C->ev_copy, 0));
+        UploadList ul{};
+        ul.copy(regs, U->b_r_rec.p, (size_t)NR * rrec / 4);
+        if (nkeys2) ul.copy(pk, U->b_r_pk.p, (size_t)NR * rpk / 4);
+        launch_k9_upload(ul, C->copy_stream);
+        regs_pending = true;
+        return BDX_OK;
+    };
+    auto wait_regions = [&]() -> int {
+        if (regs_pending) {
+            DHIP(d, hipStreamSynchronize(C->copy_stream));
+            regs_pending = false;
+            uint32_t perr = 0;
+            DHIP(d, hipMemcpy(&perr, T + o_ntot + 1, 4, hipMemcpyDeviceToHost));
+            if (perr) return dfail(d, BDX_EINTERNAL, "region table of the gather does not add up");
+        }
+        return BDX_OK;
+    };
+    // this rank's region records and their prefix samples, one after the other, at dst (device memory)
+    auto pack_regions = [&](char* dst) -> bool {
+        if (!nr_local) return true;
+        return hipMemcpyAsync(dst, C->b_r_rec.p, (size_t)nr_local * rrec, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+               hipMemcpyAsync(dst + (size_t)nr_local * rrec, C->b_r_pk.p, (size_t)nr_local * rpk, hipMemcpyDeviceToDevice, s) == hipSuccess;
+    };
 
     // ---- a read name seen more than twice (clashing names across merged files): the pair model does not hold, and the reference's
     // behaviour (ReadRegionData.cpp:108-113,152-175, SvBuilder.cpp:101-118) depends on the order of ALL sightings.  Every rank sends
-    // the compact records of its chromosomes (name key, genome-wide region id, meta, |isize|, tid, second name hash, index in the
-    // chromosome's stream: 40 bytes per anomalous read) to rank 0, which replays the run read by read (H2, bdx_walk_reads.cpp) on the
-    // gathered region table.  The same route serves bdx_dist_set_collect_support: the supporting reads of an SV (-g / -d dumps,
-    // BreakDancer.cpp:514-534) are known to the read-level walk only ----
+    // its region records and the compact records of its chromosomes (name key, genome-wide region id, meta, |isize|, tid, second name
+    // hash, index in the chromosome's stream: 40 bytes per anomalous read) to rank 0, which replays the run read by read (H2,
+    // bdx_walk_reads.cpp) on the gathered region table.  The same route serves bdx_dist_set_collect_support: the supporting reads of an
+    // SV (-g / -d dumps, BreakDancer.cpp:514-534) are known to the read-level walk only ----
     if (replay) {
         const auto t_r0 = std::chrono::steady_clock::now();
         constexpr size_t kw = 5;
+        DHIP(d, hipStreamSynchronize(s));   // (K6's kernels were enqueued on the pair model: let them finish, their results are dropped)
+        if (!solo) {
+            if (d->b_pack.ensure(std::max<size_t>(gcount[rank], 8)) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "region package"));
+            if (!pack_regions((char*)d->b_pack.p)) return leave(dfail(d, BDX_EHIP, "region package"));
+            if (rank == 0 && d->b_all.ensure(std::max<size_t>(region_bytes, 8)) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "gather buffer"));
+            if (!comm.gatherv_bytes(d->b_pack.p, gcount[rank], d->b_all.p, gcount.data(), gdispl.data(), 0, s)) return leave(dfail(d, BDX_EHIP, comm.err));
+            d->gathered_bytes += region_bytes;
+            if (rank == 0) {
+                const int pr = place_regions(0);
+                if (pr != BDX_OK) return leave(pr);
+                const int wr = wait_regions();   // (the packages sit in b_all, which the records' gather takes next)
+                if (wr != BDX_OK) return leave(wr);
+            }
+        }
         std::vector<size_t> rp_count(world), rp_displ(world);
         size_t rp_bytes = 0;
         std::vector<uint64_t> na_of_rank(world, 0);
         for (int t = 0; t < ntids; ++t)
             if (owner[t] >= 0) na_of_rank[owner[t]] += tot(t, 0);
         for (int q = 0; q < world; ++q) { rp_count[q] = (size_t)na_of_rank[q] * kw * 8; rp_displ[q] = rp_bytes; rp_bytes += rp_count[q]; }
-        DHIP(d, hipStreamSynchronize(s));   // (K6's kernels were enqueued on the pair model: let them finish, their results are dropped)
         if (d->b_pack.ensure(std::max<size_t>(rp_count[rank], 8)) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "record package"));
         if (na) launch_k9_pack_replay(C->cp, C->k3.region_of, &C->b_p1.as<Pass1>()->n_anom, na, T + o_start, d->b_pack.as<unsigned long long>(), s);
         if (rank == 0 && d->b_all.ensure(std::max<size_t>(rp_bytes, 8)) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "gather buffer"));
-        if (rank == 0) { const int wr = wait_regions(); if (wr != BDX_OK) return leave(wr); }   // (the region package sat in b_all)
         if (!comm.gatherv_bytes(d->b_pack.p, rp_count[rank], d->b_all.p, rp_count.data(), rp_displ.data(), 0, s)) return leave(dfail(d, BDX_EHIP, comm.err));
         DHIP(d, hipStreamSynchronize(s));
         d->gathered_bytes += rp_bytes;
@@ -1176,6 +1288,14 @@ int bdx_dist_run(bdx_dist* d) {
                 if (ph && reg[o] >= 0) reg[o] += (int32_t)ph;   // (the read-less region 0 in front: replay_reads does the same)
                 if (with_check) chk[o] = rp_host[i * kw + 3];
                 if (want_support) sidx[o] = read_base[t] + rp_host[i * kw + 4];
+            }
+            if (solo) {   // (one rank: its table went to pinned memory beside the walk)
+                if (!regs) {
+                    if (C->h_regs.ensure((size_t)NR * rrec) != hipSuccess || C->h_pk.ensure(std::max<size_t>((size_t)NR * rpk, 16)) != hipSuccess) return dfail(d, BDX_ENOMEM, "region table");
+                    regs = C->h_regs.as<RegionRec>(); pk = C->h_pk.as<uint32_t>();
+                    DHIP(d, hipMemcpy(regs, d->b_rg_rec.p, (size_t)NR * rrec, hipMemcpyDeviceToHost));
+                    if (nkeys2) DHIP(d, hipMemcpy(pk, d->b_rg_pk.p, (size_t)NR * rpk, hipMemcpyDeviceToHost));
+                }
             }
             // (a region's first read: its index in its rank's list -> in the genome-wide one)
             {
@@ -1203,47 +1323,7 @@ int bdx_dist_run(bdx_dist* d) {
         return finish_result();
     }
 
-    // ---- C8: the host's share -> rank 0; every rank finishes its own table ----
-    std::vector<size_t> hcount(world), hdispl(world);
-    size_t hbytes = 0, ng_all = 0;
-    for (int q = 0; q < world; ++q) { hcount[q] = (size_t)v5[q] * sizeof(GroupRec); hdispl[q] = hbytes; hbytes += hcount[q]; ng_all += (size_t)v5[q]; }
-    std::vector<GroupRec> host_groups;
-    if (world > 1) {
-        const void* mine = C->k4.g_rec ? (const void*)C->k4.g_rec : d->b_pack.p;
-        if (rank == 0) { const int wr = wait_regions(); if (wr != BDX_OK) return leave(wr); }   // (the region package sat in b_all)
-        if (rank == 0 && d->b_all.ensure(std::max<size_t>(hbytes, 8)) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "gather buffer"));
-        if (!comm.gatherv_bytes(mine, hcount[rank], d->b_all.p, hcount.data(), hdispl.data(), 0, s)) return leave(dfail(d, BDX_EHIP, comm.err));
-        d->gathered_bytes += hbytes;
-        if (rank == 0 && ng_all) {
-            host_groups.resize(ng_all);
-            if (hipMemcpyAsync(host_groups.data(), d->b_all.p, hbytes, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
-                return leave(dfail(d, BDX_EHIP, "host share of the pair groups"));
-        }
-    }
-    uint64_t mine_counts[8] = {0};
-    phase([&]() -> int {
-        C->walk.clear();
-        // (several ranks: the device's share of the walk starts here, behind the gather of the host's share -- C7's all-reduce and that
-        // gather did not have to wait for it, and rank 0 walks the gathered groups while every device walks its own)
-        if (C->defer_walk) DCTX(d, C, do_k6(C, force_host, 3));
-        if (rank == 0) {
-            const GroupRec* g = world > 1 ? host_groups.data() : C->h_groups.as<GroupRec>();
-            decode_groups(C, g, (uint32_t)ng_all, 0);
-            C->last_big_groups = (int64_t)ng_all + C->counts.n_groups_big;
-            const auto tw0 = std::chrono::steady_clock::now();
-            DCTX(d, C, host_walk(C, lm, na_all != 0));
-            d->phase_ms[16] = ms_between(tw0, std::chrono::steady_clock::now());
-        }
-        C->counts.last_maxq = lm;
-        trace("host walk");
-        DCTX(d, C, do_k6_table(C));
-        DCTX(d, C, finish_table(C));
-        trace("table");
-        mine_counts[0] = C->n_sv_total; mine_counts[1] = C->n_terms_total; mine_counts[2] = C->n_cn_total; mine_counts[3] = C->n_printed;
-        mine_counts[4] = C->n_sv_host; mine_counts[5] = C->counts.n_pairs; mine_counts[6] = C->n_groups_total; mine_counts[7] = C->counts.n_old;
-        return BDX_OK;
-    });
-    if (world == 1) {
+    if (solo) {
         adopt_table(U, C);
         d->table_lent = true;
         U->reg = C->reg; U->nreg = C->nreg; U->rpk = C->rpk;   // (the genome's region table stays in this rank's pinned buffers until the next run)
@@ -1253,23 +1333,24 @@ int bdx_dist_run(bdx_dist* d) {
         d->phase_ms[14] = 0;
         return finish_result();
     }
-    std::vector<uint64_t> v6((size_t)world * 8, 0);
-    if (st.rc == BDX_OK)
-        for (int k = 0; k < 8; ++k) v6[(size_t)rank * 8 + k] = mine_counts[k];
-    rc = exchange(v6);
-    if (rc != BDX_OK) return rc;
 
-    // ---- C9: the ranks' tables -> rank 0, which merges them by order key into the result context's pinned buffers ----
+    // ---- E: ONE gather takes every rank's package to rank 0: its region records, the pair groups of the components it could not walk
+    // alone, its finished table (rows sorted by order key) -- round 5: three gathers with two all-reduces of sizes between them.  Rank 0 then
+    // walks the gathered groups in its result context (K6 once more: the groups bucketed by later region stand where a rank's K6 has its
+    // reads, components of up to 64 regions on the device, the rest by the host -- round 5's host walked all of them, BreakDancer.cpp:266-346
+    // being one global walk) and merges the ranks' tables and that one by order key into the result context's pinned buffers ----
     const auto t_m0 = std::chrono::steady_clock::now();
     TableDesc TD{};
     TD.world = world;
-    std::vector<size_t> tcount(world), tdispl(world);
-    size_t tbytes = 0;
-    uint64_t n_sv_all = 0, n_terms_all = 0, n_cn_all = 0, n_printed_all = 0, n_pairs_all = 0, n_groups_all = 0, n_old_all = 0;
+    std::vector<size_t> pcount(world), pdispl(world), grp_off(world);
+    size_t pbytes = 0, ng_all = 0;
+    uint64_t n_sv_all = 0, n_terms_all = 0, n_cn_all = 0, n_printed_all = 0, n_pairs_all = 0, n_groups_all = 0, n_old_all = 0, n_sv_host_all = 0;
     uint32_t max_sv = 0;
     for (int q = 0; q < world; ++q) {
-        const size_t nsv = (size_t)v6[(size_t)q * 8], nt = (size_t)v6[(size_t)q * 8 + 1], nc = (size_t)v6[(size_t)q * 8 + 2];
-        size_t o = tbytes;
+        const uint64_t* c = &v5[(size_t)q * 10];
+        const size_t ng = (size_t)c[0], nsv = (size_t)c[1], nt = (size_t)c[2], nc = (size_t)c[3];
+        size_t o = pbytes + gcount[q];          // (the package starts with the rank's region records: gdispl[q] is NOT their place here, pdispl[q] is)
+        grp_off[q] = o; o += ng * sizeof(GroupRec);
         TablePackage& P = TD.p[q];
         P.n_sv = (uint32_t)nsv; P.n_terms = (uint32_t)nt; P.n_cn = (uint32_t)nc;
         P.rows_off = o; o += round_up(nsv * sizeof(SvOut), 8);
@@ -1279,30 +1360,137 @@ int bdx_dist_run(bdx_dist* d) {
         P.ltail_off = o; o += nt * 8;
         P.cn_key_off = o; o += round_up(nc * 4, 8);
         P.cn_value_off = o; o += round_up(nc * 4, 8);
-        tdispl[q] = tbytes; tcount[q] = o - tbytes; tbytes = o;
-        n_sv_all += nsv; n_terms_all += nt; n_cn_all += nc; n_printed_all += v6[(size_t)q * 8 + 3];
-        n_pairs_all += v6[(size_t)q * 8 + 5]; n_groups_all += v6[(size_t)q * 8 + 6]; n_old_all += v6[(size_t)q * 8 + 7];
+        pdispl[q] = pbytes; pcount[q] = o - pbytes; pbytes = o;
+        ng_all += ng;
+        n_sv_all += nsv; n_terms_all += nt; n_cn_all += nc; n_printed_all += c[4]; n_sv_host_all += c[5];
+        n_pairs_all += c[6]; n_groups_all += c[7]; n_old_all += c[8];
         max_sv = std::max(max_sv, (uint32_t)nsv);
     }
+    if (ng_all > kMaxAnomalous / 4) return dfail(d, BDX_ELIMIT, "too many pair groups of components that span ranks");   // (the same sums on every rank)
     if (max_sv >= (1u << 26) || n_sv_all > 0xFFFFFFF0ull) return dfail(d, BDX_ELIMIT, "too many SV candidates for the merge");
     {
         const TablePackage& P = TD.p[rank];
-        if (d->b_pack.ensure(std::max<size_t>(tcount[rank], 8)) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "table package"));
-        char* pp = (char*)d->b_pack.p - tdispl[rank];
-        bool good = true;
+        if (d->b_pack.ensure(std::max<size_t>(pcount[rank], 8)) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "package for rank 0"));
+        char* pp = (char*)d->b_pack.p - pdispl[rank];
+        bool good = pack_regions((char*)d->b_pack.p);
         auto put = [&](size_t off, const void* src, size_t bytes) { if (bytes && good) good = hipMemcpyAsync(pp + off, src, bytes, hipMemcpyDeviceToDevice, s) == hipSuccess; };
+        put(grp_off[rank], C->k4.g_rec, (size_t)v5[(size_t)rank * 10] * sizeof(GroupRec));
         put(P.rows_off, C->b_sv_out.p, (size_t)P.n_sv * sizeof(SvOut)); put(P.keys_off, C->b_sv_key.p, (size_t)P.n_sv * 8);
         put(P.lib_index_off, C->b_lib_index_out.p, (size_t)P.n_terms * 4); put(P.lib_pairs_off, C->b_lib_pairs_out.p, (size_t)P.n_terms * 4);
         put(P.ltail_off, C->b_ltail_out.p, (size_t)P.n_terms * 8);
         put(P.cn_key_off, C->b_cn_key_out.p, (size_t)P.n_cn * 4); put(P.cn_value_off, C->b_cn_value_out.p, (size_t)P.n_cn * 4);
-        if (!good) return leave(dfail(d, BDX_EHIP, "table package"));
-        trace("table packed");
-        if (rank == 0 && d->b_all.ensure(std::max<size_t>(tbytes, 8)) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "gather buffer"));
-        if (!comm.gatherv_bytes(d->b_pack.p, tcount[rank], d->b_all.p, tcount.data(), tdispl.data(), 0, s)) return leave(dfail(d, BDX_EHIP, comm.err));
-        d->gathered_bytes += tbytes;
-        trace("tables gathered");
+        if (!good) return leave(dfail(d, BDX_EHIP, "package for rank 0"));
+        trace("package");
+        if (rank == 0 && d->b_all.ensure(std::max<size_t>(pbytes, 8)) != hipSuccess) return leave(dfail(d, BDX_ENOMEM, "gather buffer"));
+        const auto tg = std::chrono::steady_clock::now();
+        if (!comm.gatherv_bytes(d->b_pack.p, pcount[rank], d->b_all.p, pcount.data(), pdispl.data(), 0, s)) return leave(dfail(d, BDX_EHIP, comm.err));
+        d->phase_ms[13] += ms_between(tg, std::chrono::steady_clock::now());
+        d->gathered_bytes += pbytes;
+        trace("gathered");
     }
-    if (rank == 0) {
+    if (rank != 0) {
+        d->phase_ms[14] = ms_between(t_m0, std::chrono::steady_clock::now());
+        return finish_result();
+    }
+    // ---- rank 0 alone from here ----
+    uint64_t u_counts[9] = {0};
+    {
+        // (place_regions takes the packages' region records at base + gdispl[q]; here they start the packages: their own displacements)
+        for (int q = 0; q < world; ++q) gdispl[q] = pdispl[q];
+        const int pr = place_regions(0);
+        if (pr != BDX_OK) return pr;
+    }
+    if (ng_all) {
+        const auto tw0 = std::chrono::steady_clock::now();
+        const uint32_t ng = (uint32_t)ng_all, nr = (uint32_t)NR;
+        // (K6 sizes its lists for a context's anomalous reads -- candidates and list entries <= reads / 2, each consuming a read pair; here
+        // a candidate consumes at least one pair GROUP and a list entry is a part of one: twice the groups stands for the reads)
+        const uint32_t capU = 2 * std::max(nr, ng) + 2;
+        // buckets: cnt | goff | cur ([nr + 1] each) | scan workspace | n | err, then the groups in bucket order
+        const size_t w_scan = 2 * ((size_t)scan_grid(nr + 1) + 2), o_goff = (size_t)nr + 1, o_cur = 2 * o_goff, o_ws = 3 * o_goff, o_n = o_ws + w_scan, o_err = o_n + 1,
+                     o_grp = (o_err + 1 + 3) / 4 * 4;
+        DHIP(d, d->b_bucket.ensure(o_grp * 4 + (size_t)ng * sizeof(GroupRec)));
+        uint32_t* B = d->b_bucket.as<uint32_t>();
+        GroupRec* sorted = (GroupRec*)(B + o_grp);
+        SegList seg_grp{};
+        seg_grp.n = world;
+        {
+            uint32_t a = 0;
+            for (int q = 0; q < world; ++q) { seg_grp.off[q] = grp_off[q] / 8; seg_grp.start[q] = a; a += (uint32_t)v5[(size_t)q * 10]; }
+            seg_grp.start[world] = a;
+        }
+        // (the region table's `first` is rewritten for this context's slot space: the copy to pinned memory must have read it)
+        { const int wr = wait_regions(); if (wr != BDX_OK) return wr; }
+        hipStream_t su = U->stream;
+        DHIP(d, hipEventRecord(d->ev_side, s));   // (the gather, and the region table placed behind it)
+        DHIP(d, hipStreamWaitEvent(su, d->ev_side, 0));
+        launch_k9_bucket_groups((const unsigned long long*)d->b_all.p, seg_grp, ng, nr, B, B + o_goff, B + o_cur, sorted, U->b_r_rec.as<RegionRec>(), B + o_ws, B + o_n, B + o_err, su);
+        // the result context as a K6 context: the genome's statistics and region table, no reads
+        DHIP(d, U->b_counts.ensure(sizeof(StageCounts))); DHIP(d, U->h_counts.ensure(sizeof(StageCounts)));
+        DHIP(d, U->b_cnt.ensure((size_t)ncnt * 4)); DHIP(d, U->b_p1.ensure(sizeof(Pass1))); DHIP(d, U->b_kdens.ensure(64 * 4));
+        DHIP(d, U->h_flags.ensure(64)); DHIP(d, U->h_groups.ensure(((size_t)ng + 1) * sizeof(GroupRec)));
+        DHIP(d, U->b_out_deg.ensure((size_t)capU * 6 * 4));
+        {
+            StageCounts sc{};
+            sc.n_regions = nr; sc.last_maxq = lm;
+            memcpy(UP + L.up_counts, &sc, sizeof(sc));
+            const uint32_t* st_up = UP + L.up_stats;   // (covered, window | flag histogram | densities: as this rank's own context got them)
+            UploadList ul{};
+            ul.copy(U->b_counts.p, UP + L.up_counts, sizeof(StageCounts) / 4);
+            ul.copy(U->b_p1.p, st_up, 2);
+            ul.copy(U->b_cnt.p, st_up + 2, (size_t)ncnt);
+            ul.copy(U->b_kdens.p, st_up + 2 + ncnt, U->key_density.size());
+            launch_k9_upload(ul, su);
+        }
+        launch_k6_scratch_init(U->b_out_deg.as<uint32_t>(), capU, su);
+        ++U->seq;
+        U->na_alloc = 0; U->k6_cap = capU;
+        U->k6_r_rec = U->b_r_rec.as<RegionRec>(); U->k6_r_pk = U->b_r_pk.as<uint32_t>(); U->k6_taint = nullptr;
+        U->k6_in_groups = sorted; U->k6_in_goff = B + o_goff;
+        U->cp = Compact{}; U->k3 = K3Arrays{}; U->k4 = K4Arrays{};
+        U->k4.g_rec = U->h_groups.as<GroupRec>(); U->k4.g_cap = ng + 1;
+        U->table_in_hbm = true; U->groups_in_hbm = false; U->defer_walk = false;
+        if (U->big_walk_mode < 0) U->last_big_groups = 1 << 20;   // (components of 5..64 regions on the device as well: what is left is the host's, sequentially)
+        memset(&U->counts, 0, sizeof(U->counts));
+        decode_regions(U, regs, pk, nr, 0, true);   // (the host's share of this walk reads the table where it arrived, in pinned memory)
+        DCTX(d, U, do_k6(U, force_host, 0));
+        if (!wait_flag(U, 1, U->seq)) {
+            DHIP(d, hipStreamSynchronize(su));
+            if (!flag_arrived(U, 1)) return dfail(d, BDX_EINTERNAL, "the pair groups of the gathered components did not arrive: their kernels were not launched");
+        }
+        U->counts = *U->h_counts.as<StageCounts>();
+        if (U->counts.overflow) return dfail(d, BDX_EINTERNAL, "group list overflow (gathered components)");
+        {
+            uint32_t berr = 0;
+            DHIP(d, hipMemcpyAsync(&berr, B + o_err, 4, hipMemcpyDeviceToHost, su));   // (behind the kernels that have just reported)
+            DHIP(d, hipStreamSynchronize(su));
+            if (berr) return dfail(d, BDX_EINTERNAL, "a gathered pair group names a region outside the genome's table");
+        }
+        decode_groups(U, U->h_groups.as<GroupRec>(), U->counts.n_groups, 0);
+        U->last_big_groups = (int64_t)U->counts.n_groups + U->counts.n_groups_big;
+        const auto tw1 = std::chrono::steady_clock::now();
+        DCTX(d, U, host_walk(U, lm, na_all != 0));
+        d->phase_ms[16] = ms_between(tw1, std::chrono::steady_clock::now());
+        U->counts.last_maxq = lm;
+        DCTX(d, U, do_k6_table(U));
+        DCTX(d, U, finish_table(U));
+        u_counts[0] = U->n_sv_total; u_counts[1] = U->n_terms_total; u_counts[2] = U->n_cn_total; u_counts[3] = U->n_printed;
+        u_counts[4] = U->n_sv_host; u_counts[6] = U->n_groups_total; u_counts[7] = U->counts.n_old; u_counts[8] = U->counts.n_groups;
+        d->phase_ms[17] = ms_between(tw0, std::chrono::steady_clock::now()) - d->phase_ms[16];
+        TablePackage& P = TD.p[world];   // the table of the gathered components, where the result context's K6 left it (byte offsets relative to the gather buffer)
+        P.n_sv = (uint32_t)u_counts[0]; P.n_terms = (uint32_t)u_counts[1]; P.n_cn = (uint32_t)u_counts[2];
+        auto off = [&](const DevBuf& b) { return (uint64_t)((uintptr_t)b.p - (uintptr_t)d->b_all.p); };
+        P.rows_off = off(U->b_sv_out); P.keys_off = off(U->b_sv_key); P.lib_index_off = off(U->b_lib_index_out); P.lib_pairs_off = off(U->b_lib_pairs_out);
+        P.ltail_off = off(U->b_ltail_out); P.cn_key_off = off(U->b_cn_key_out); P.cn_value_off = off(U->b_cn_value_out);
+        n_sv_all += u_counts[0]; n_terms_all += u_counts[1]; n_cn_all += u_counts[2]; n_printed_all += u_counts[3]; n_sv_host_all += u_counts[4];
+        n_groups_all += u_counts[6]; n_old_all += u_counts[7];
+        max_sv = std::max(max_sv, (uint32_t)u_counts[0]);
+        TD.world = world + 1;
+        if (max_sv >= (1u << 26) || n_sv_all > 0xFFFFFFF0ull) return dfail(d, BDX_ELIMIT, "too many SV candidates for the merge");
+        DHIP(d, hipEventRecord(d->ev_side, su));   // (its table kernel: finish_table has seen its ready word, this orders the streams)
+        DHIP(d, hipStreamWaitEvent(s, d->ev_side, 0));
+    }
+    {
         const uint32_t n_total = (uint32_t)n_sv_all;
         DHIP(d, U->h_sv_out.ensure(std::max<size_t>(n_total, 1) * sizeof(SvOut)));
         DHIP(d, U->h_lib_index.ensure(std::max<size_t>(n_terms_all, 1) * 4)); DHIP(d, U->h_lib_pairs.ensure(std::max<size_t>(n_terms_all, 1) * 4));
@@ -1321,7 +1509,7 @@ int bdx_dist_run(bdx_dist* d) {
                         U->h_cn_key.as<int32_t>(), U->h_cn_value.as<float>()};
             if (tracing) {   // are the ranks' tables sorted by key, and are the keys distinct?
                 DHIP(d, hipStreamSynchronize(s));
-                for (int q = 0; q < world; ++q) {
+                for (int q = 0; q < TD.world; ++q) {
                     std::vector<unsigned long long> kk(TD.p[q].n_sv);
                     if (!kk.empty()) DHIP(d, hipMemcpy(kk.data(), (const char*)d->b_all.p + TD.p[q].keys_off, kk.size() * 8, hipMemcpyDeviceToHost));
                     size_t bad = 0;
@@ -1332,27 +1520,31 @@ int bdx_dist_run(bdx_dist* d) {
                 }
             }
             DHIP(d, hipMemsetAsync(src, 0xFF, (size_t)n_total * 4, s));
-            launch_k9_merge_tables((const char*)d->b_all.p, d_td, world, n_total, max_sv, src, begins, ws, T + o_ntot + 2, mo, s);
+            launch_k9_merge_tables((const char*)d->b_all.p, d_td, TD.world, n_total, max_sv, src, begins, ws, T + o_ntot + 2, mo, s);
         }
         DHIP(d, hipStreamSynchronize(s));
         DHIP(d, hipGetLastError());
         trace("merge");
         U->walk.clear(); U->log_tail.clear();
         U->n_sv_total = n_total; U->n_terms_total = (uint32_t)n_terms_all; U->n_cn_total = (uint32_t)n_cn_all; U->n_printed = (uint32_t)n_printed_all;
-        U->n_sv_host = (uint32_t)v6[4]; U->n_groups_total = (uint32_t)n_groups_all;
+        U->n_sv_host = (uint32_t)n_sv_host_all; U->n_groups_total = (uint32_t)n_groups_all;
         memset(&U->counts, 0, sizeof(U->counts));
         U->counts.n_regions = (uint32_t)NR; U->counts.last_maxq = lm; U->counts.n_pairs = (uint32_t)n_pairs_all; U->counts.n_old = (uint32_t)n_old_all;
-        U->counts.n_sv_dev = n_total - U->n_sv_host; U->counts.n_groups = (uint32_t)ng_all;
+        U->counts.n_sv_dev = n_total - U->n_sv_host; U->counts.n_groups = (uint32_t)u_counts[8];   // (what the host's walk took: components the device walk leaves out)
         U->materialized = false;
-        U->reg = C->reg; U->nreg = C->nreg; U->rpk = C->rpk;   // (in rank 0's pinned buffers until the next run)
-        C->reg = nullptr; C->nreg = 0; C->rpk = nullptr;
+        {   // the genome's region table: in rank 0's pinned buffers until the next run
+            const int wr = wait_regions();
+            if (wr != BDX_OK) return wr;
+            decode_regions(U, regs, pk, (uint32_t)NR, 0, true);
+            C->reg = nullptr; C->nreg = 0; C->rpk = nullptr;
+        }
         if (d->opts.fisher) {  // Fisher's combination (BreakDancer.cpp:71-81) uses the host's exp / log
             materialize(U);
             finish_scores(U->opts, U->log_tail.data(), U->walk.svs.data(), U->walk.svs.size(), &U->n_printed);
         }
         U->ran = true; U->stage = 4;
     }
-    d->phase_ms[14] = ms_between(t_m0, std::chrono::steady_clock::now());
+    d->phase_ms[14] = std::max(0.0f, ms_between(t_m0, std::chrono::steady_clock::now()) - d->phase_ms[16] - d->phase_ms[17] - d->phase_ms[13]);
     return finish_result();
 }
 

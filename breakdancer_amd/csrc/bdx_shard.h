@@ -46,7 +46,34 @@ void launch_k9_report(const uint32_t* src, uint32_t* dst, uint32_t n, uint32_t* 
 // compact records: the counters of chromosome t's reads get tid_off[t][0] (normal pairs) and tid_off[t][1 + k] (proper reads of key k)
 // added -- what the chromosomes in front of t (anybody's) have counted, minus what this context's own have; first_tab[t] = {1, read
 // length, normal-pair count} of chromosome t's first anomalous read (pinned host memory, zero on entry)
-void launch_k9_rebase(const Compact& cp, const uint32_t* n_ptr, uint32_t n_upper, int nkeys, const uint32_t* tid_off, uint32_t* first_tab, hipStream_t s);
+void launch_k9_rebase(const Compact& cp, const uint32_t* n_ptr, uint32_t n_upper, int nkeys, const uint32_t* tid_off, uint32_t* first_tab, hipStream_t s);   // (first_tab may be null)
+// What a rank can say about its compact records BEFORE it knows anything of the other ranks (it rides in the run's first all-reduce):
+// first_tab[t] = {1, read length, normal-pair count in THIS context's stream} of chromosome t's first anomalous read (pinned host memory,
+// zero on entry); cnt_mtid[mt] += inter-chromosomal reads whose mate lies on the LATER chromosome mt (whoever owns it: the host sorts them
+// by owner once the owners are known); cnt_owner[q] += anomalous reads whose name key belongs to rank q's census (world > 1 only)
+struct FirstCountsParams {
+    Compact cp;
+    const int32_t* mtid_col;
+    const uint32_t* n_ptr;
+    int32_t ntids;
+    uint32_t world;          // 1: only first_tab is filled
+    uint32_t* first_tab;
+    uint32_t* cnt_mtid;      // [ntids], zero on entry
+    uint32_t* cnt_owner;     // [world], zero on entry
+};
+void launch_k9_first_counts(const FirstCountsParams& p, uint32_t n_upper, hipStream_t s);
+// Records that arrive in per-rank blocks of one buffer (an all-to-all's receive buffer, a gather's): segment q holds records
+// [start[q], start[q + 1]) at base + off[q] (off in 64-bit words); a kernel finds record j's segment by a short search
+struct SegList {
+    uint64_t off[kMaxRanks];
+    uint32_t start[kMaxRanks + 1];
+    int n;
+    __host__ __device__ __forceinline__ int seg_of(uint32_t j) const {
+        int q = 0;
+        while (q + 1 < n && j >= start[q + 1]) ++q;
+        return q;
+    }
+};
 // out[t] = first of the context's regions with tid >= t (t = 0 .. ntids), out[ntids + 1] = its region count, out[ntids + 2] = last_maxq
 void launch_k9_tid_regions(const RegionRec* r_rec, const StageCounts* counts, int ntids, uint32_t* out, hipStream_t s);
 
@@ -93,11 +120,22 @@ struct ExchangeSrc {
     const int32_t* owner_of_tid;  // [ntids] rank that holds the chromosome, -1: nobody (it has no reads)
     int32_t ntids, me;
     uint32_t world;
+    uint8_t* taint;             // [regions] a region that sends a record to another rank is part of a component that spans ranks (may be null)
 };
 void launch_k7_count(const ExchangeSrc& x, uint32_t n_upper, uint32_t* cnt, hipStream_t s);
 void launch_k7_scatter(const ExchangeSrc& x, uint32_t n_upper, uint32_t* cursor, ExchangeEntry* out, unsigned long long* names_out, hipStream_t s);
 void launch_k7_unpack(const ExchangeEntry* in, uint32_t n, uint64_t* key, uint64_t* check, int32_t* region, const uint32_t* n_local, uint32_t* n_total,
                       hipStream_t s);
+// the same from the per-rank blocks of ONE all-to-all's receive buffer (base: 64-bit words; the segments' records are ExchangeEntry)
+void launch_k7_unpack_seg(const unsigned long long* base, const SegList& sg, uint32_t n, uint64_t* key, uint64_t* check, int32_t* region, const uint32_t* n_local,
+                          uint32_t* n_total, hipStream_t s);
+void launch_k7_names_census_seg(const unsigned long long* base, const SegList& sg, uint32_t n, unsigned long long* slots, uint32_t nslots, uint32_t* irregular, hipStream_t s);
+// window read lengths through the same all-to-all: every rank appends {window << 32 | read length} of the windows whose last region is its
+// own to every other rank's block (k9_window_pack: dst[q] = the place in block q, null for the rank itself; n_expected entries each), and
+// enters what it receives into the empty places of its region table (k9_window_unpack)
+struct WindowDst { unsigned long long* dst[kMaxRanks]; int world; };
+void launch_k9_window_pack(const RegionRec* rg_rec, uint32_t nr, uint32_t period, const WindowDst& wd, uint32_t n_expected, uint32_t* cursor, hipStream_t s);
+void launch_k9_window_unpack(RegionRec* rg_rec, uint32_t nr, uint32_t period, const unsigned long long* base, const SegList& sg, uint32_t n, uint32_t* err, hipStream_t s);
 void launch_k7_names_clear(unsigned long long* slots, uint32_t nslots, uint32_t* irregular, hipStream_t s);
 void launch_k7_names_census(const unsigned long long* in, uint32_t n, unsigned long long* slots, uint32_t nslots, uint32_t* irregular, hipStream_t s);
 uint32_t k7_names_slots(size_t records);   // the census table for so many sightings (1.5 slots each)
@@ -119,6 +157,15 @@ struct MergeOut {
 // D: the descriptor in device memory; ws: scan workspace words (device); src: [n_total] (rank << 26 | row) by final position
 void launch_k9_merge_tables(const char* all, const TableDesc* D, int world, uint32_t n_total, uint32_t max_n, uint32_t* src, uint2* begins, uint32_t* ws,
                             const uint32_t* n_dev, const MergeOut& out, hipStream_t s);
+
+// ---- rank 0: the pair groups of the components no rank could walk alone -> K6's `in_groups` input --------------------------
+// The gathered groups (any order) bucketed by their later region: goff[r] .. goff[r + 1] are region r's places in `out`; the region
+// table's `first` becomes goff[r] -- in a context that takes its pair groups as aggregates a region's parts and staging slots live in a
+// slot space of one slot per group (K6Arrays::in_groups), not in the compact read list of the rank that cut the region.
+// cnt / cur: [nr + 1] words each, scan_ws: 2 * (scan_grid(nr + 1) + 2) words; n_words[0] receives nr + 1; err: set to 1 if a group names
+// a region outside [0, nr)
+void launch_k9_bucket_groups(const unsigned long long* base, const SegList& sg, uint32_t n, uint32_t nr, uint32_t* cnt, uint32_t* goff, uint32_t* cur, GroupRec* out,
+                             RegionRec* r_rec, uint32_t* scan_ws, uint32_t* n_words, uint32_t* err, hipStream_t s);   // (in: the ranks' blocks of one gather buffer)
 
 // one no-op launch per translation unit (see bdx_warm_up)
 void warm_k1(hipStream_t s); void warm_k2(hipStream_t s); void warm_k3(hipStream_t s); void warm_k4(hipStream_t s);

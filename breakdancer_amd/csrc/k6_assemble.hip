@@ -371,19 +371,22 @@ __global__ __launch_bounds__(256) void k6_classify_kernel(K6Arrays a) {
     const uint32_t slot = atomicAdd(&a.mcount[L], 1u);
     if (a.big_walk && slot < (uint32_t)kK6BigMembers) a.member_ids[(size_t)L * kK6BigMembers + slot] = r;
     if (slot < (uint32_t)kK6MaxMembers) {
-        MemberInfo* mi = &a.members[(size_t)L * kK6MaxMembers + slot];  // (written field by field: no private copy)
-        mi->r = r;
-        {   // (word by word: a struct assignment goes through a private copy here)
-            const uint32_t* src = (const uint32_t*)&a.r_rec[r];
-            uint32_t* dst = (uint32_t*)&mi->rec;
-#pragma unroll
-            for (int wd = 0; wd < (int)(sizeof(RegionRec) / 4); ++wd) dst[wd] = src[wd];
-        }
-        mi->np_all = s->np_all; mi->np_self = s->np_self; mi->w_self = s->w_self; mi->n_in = hub ? 0u : n_in;
-#pragma unroll
-        for (int e = 0; e < kK6MaxIn; ++e) { mi->e_lo[e] = s->e_lo[e]; mi->e_w[e] = s->e_w[e]; mi->e_off[e] = s->e_off[e]; mi->e_cnt[e] = s->e_cnt[e]; }
-        mi->stored = (int)(a.chr_restricted ? a.r_rec[r].nonctx : a.r_rec[r].n) >= a.min_read_pair ? 1u : 0u;  // region_stored()
-        mi->pad = 0;
+        // The member record leaves as seven 16-byte stores (k6_walk_kernel fetches it as seven 16-byte words): written field by field it was
+        // 28 scattered 4-byte stores per region, each a 32-byte write at the memory side -- 138 MB for the 130 k regions of a genome share
+        // (profiles/r05_pmc_genome.txt).  Every word is named (no struct on the stack: a private copy would go through scratch memory).
+        static_assert(sizeof(MemberInfo) == 7 * 16 && sizeof(RegionRec) == 36 && offsetof(MemberInfo, rec) == 4 && offsetof(MemberInfo, np_all) == 40 &&
+                          offsetof(MemberInfo, e_lo) == 56 && offsetof(MemberInfo, stored) == 104, "a member's record is seven 16-byte words");
+        const uint32_t* rw = (const uint32_t*)&a.r_rec[r];
+        const uint32_t r0 = rw[0], r1 = rw[1], r2 = rw[2], r3 = rw[3], r4 = rw[4], r5 = rw[5], r6 = rw[6], r7 = rw[7], r8 = rw[8];
+        const uint32_t stored = (int)(a.chr_restricted ? r5 : r3) >= a.min_read_pair ? 1u : 0u;  // region_stored(): nonctx is word 5, n word 3
+        uint4* dst = (uint4*)&a.members[(size_t)L * kK6MaxMembers + slot];
+        dst[0] = make_uint4(r, r0, r1, r2);
+        dst[1] = make_uint4(r3, r4, r5, r6);
+        dst[2] = make_uint4(r7, r8, s->np_all, s->np_self);
+        dst[3] = make_uint4(s->w_self, hub ? 0u : n_in, s->e_lo[0], s->e_lo[1]);
+        dst[4] = make_uint4(s->e_lo[2], s->e_w[0], s->e_w[1], s->e_w[2]);
+        dst[5] = make_uint4(s->e_off[0], s->e_off[1], s->e_off[2], s->e_cnt[0]);
+        dst[6] = make_uint4(s->e_cnt[1], s->e_cnt[2], stored, 0u);
     }
     if (s->np_emit) atomicAdd(&a.pcount[L], s->np_emit);
 }
@@ -1450,7 +1453,7 @@ __global__ __launch_bounds__(kScanBlock) void k6_finish_kernel(K6Arrays a, doubl
                 if (a2) {
                     a.lib_index[bg.x + q] = li;
                     a.lib_pairs[bg.x + q] = k;
-                    a.ltail_host[bg.x + q] = lt;
+                    if (a.ltail_host) a.ltail_host[bg.x + q] = lt;
                     const double tmp_a = __dsub_rn(lt, err);
                     const double tmp_b = __dadd_rn(logp, tmp_a);
                     err = __dsub_rn(__dsub_rn(tmp_b, logp), tmp_a);

@@ -90,6 +90,9 @@ __global__ __launch_bounds__(256) void k7_scatter_kernel(ExchangeSrc x, uint32_t
                 ExchangeEntry e;
                 e.key = k; e.order = 0; e.region = x.region_of[j]; e.meta = m; e.isize = 0; e.check = c;
                 out[slot] = e;
+                // (the record's region is an end of a group another rank will form: whatever component it belongs to spans ranks -- it is walked
+                // where all of it comes together, on rank 0.  Said here, by the sender: the receiver's verdict on ITS end needs no exchange either)
+                if (x.taint && e.region >= 0) x.taint[e.region] = 1;
             }
             const uint32_t nslot = s_base[x.world + own[it]] + atomicAdd(&s_cnt[x.world + own[it]], 1u);
             unsigned long long w = k;
@@ -116,15 +119,40 @@ __global__ __launch_bounds__(256) void k7_unpack_kernel(const ExchangeEntry* in,
     if (check) check[j] = e.check;
 }
 
+__global__ __launch_bounds__(256) void k7_unpack_seg_kernel(const unsigned long long* base, SegList sg, uint32_t n, uint64_t* key, uint64_t* check, int32_t* region,
+                                                            const uint32_t* n_local, uint32_t* n_total) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j == 0) *n_total = *n_local + n;
+    if (j >= n) return;
+    const int q = sg.seg_of(j);
+    const ExchangeEntry e = ((const ExchangeEntry*)(base + sg.off[q]))[j - sg.start[q]];
+    key[j] = e.key; region[j] = e.region;
+    if (check) check[j] = e.check;
+}
+void launch_k7_unpack_seg(const unsigned long long* base, const SegList& sg, uint32_t n, uint64_t* key, uint64_t* check, int32_t* region, const uint32_t* n_local,
+                          uint32_t* n_total, hipStream_t s) {
+    hipLaunchKernelGGL(k7_unpack_seg_kernel, dim3(std::max(1u, (n + 255) / 256)), dim3(256), 0, s, base, sg, n, key, check, region, n_local, n_total);
+}
+
 // ---- name census ----
 // One 16-byte slot per name: {key word (all ones = empty), info}.  info: bits 0-1 sightings (saturating at 3), bit 2 a sighting that is
 // not a CTX read, bit 3 sightings on different chromosomes, bit 4 two CTX sightings that do not name each other's chromosome,
 // bits 8-31 the first sighting's chromosome + 1, bits 32-55 its mate chromosome + 1.  One line is dirtied per insert (three arrays
 // with one scattered atomic each wrote 7x the records' bytes: profiles/r03_pmc_all_kernels.txt).
+__device__ __forceinline__ void names_insert(unsigned long long k, unsigned long long w, unsigned long long* slots, uint32_t nslots);
 __global__ __launch_bounds__(256) void k7_names_insert_kernel(const unsigned long long* in, uint32_t n, unsigned long long* slots, uint32_t nslots) {
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
-    const unsigned long long k = in[2 * (size_t)j], w = in[2 * (size_t)j + 1];
+    names_insert(in[2 * (size_t)j], in[2 * (size_t)j + 1], slots, nslots);
+}
+__global__ __launch_bounds__(256) void k7_names_insert_seg_kernel(const unsigned long long* base, SegList sg, uint32_t n, unsigned long long* slots, uint32_t nslots) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const int q = sg.seg_of(j);
+    const unsigned long long* in = base + sg.off[q] + 2 * (size_t)(j - sg.start[q]);
+    names_insert(in[0], in[1], slots, nslots);
+}
+__device__ __forceinline__ void names_insert(unsigned long long k, unsigned long long w, unsigned long long* slots, uint32_t nslots) {
     const unsigned long long nonctx = w & 1ull, t1 = (w >> 8) & 0xFFFFFFull, mt1 = (w >> 32) & 0xFFFFFFull;
     uint32_t s = (uint32_t)(((k ^ (k >> 31)) * 0x9E3779B97F4A7C15ull) >> 32) % nslots;   // (not the owner's hash: the keys of one owner share that)
     for (;;) {
@@ -182,6 +210,11 @@ void launch_k7_unpack(const ExchangeEntry* in, uint32_t n, uint64_t* key, uint64
 void launch_k7_names_census(const unsigned long long* in, uint32_t n, unsigned long long* slots, uint32_t nslots, uint32_t* irregular, hipStream_t s) {
     if (!n) return;
     hipLaunchKernelGGL(k7_names_insert_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, n, slots, nslots);
+    hipLaunchKernelGGL(k7_names_verdict_kernel, dim3((nslots + 255) / 256), dim3(256), 0, s, slots, nslots, irregular);
+}
+void launch_k7_names_census_seg(const unsigned long long* base, const SegList& sg, uint32_t n, unsigned long long* slots, uint32_t nslots, uint32_t* irregular, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k7_names_insert_seg_kernel, dim3((n + 255) / 256), dim3(256), 0, s, base, sg, n, slots, nslots);
     hipLaunchKernelGGL(k7_names_verdict_kernel, dim3((nslots + 255) / 256), dim3(256), 0, s, slots, nslots, irregular);
 }
 uint32_t k7_names_slots(size_t records) { return (uint32_t)std::max<size_t>(1024, records + records / 2); }

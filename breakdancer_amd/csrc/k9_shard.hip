@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k9_rebase_kernel(Compact cp, const uint32
         const uint32_t nn = cp.nn[j] + o[0];
         cp.nn[j] = nn;
         for (int k = 0; k < nkeys; ++k) cp.pk[(size_t)k * cp.cap + j] += o[1 + k];
-        if (j == 0 || cp.tid[j - 1] != t) {   // the chromosome's first anomalous read: it closes the last candidate of the chromosome before
+        if (first_tab && (j == 0 || cp.tid[j - 1] != t)) {   // the chromosome's first anomalous read: it closes the last candidate of the chromosome before
             first_tab[4 * (size_t)t] = 1u;
             first_tab[4 * (size_t)t + 1] = (uint32_t)meta_qlen(cp.meta[j]);
             first_tab[4 * (size_t)t + 2] = nn;
@@ -151,6 +151,68 @@ __global__ __launch_bounds__(256) void k9_rebase_kernel(Compact cp, const uint32
 void launch_k9_rebase(const Compact& cp, const uint32_t* n_ptr, uint32_t n_upper, int nkeys, const uint32_t* tid_off, uint32_t* first_tab, hipStream_t s) {
     if (!n_upper) return;
     hipLaunchKernelGGL(k9_rebase_kernel, dim3(std::min<uint32_t>((n_upper + 255) / 256, 4096u)), dim3(256), 0, s, cp, n_ptr, nkeys, tid_off, first_tab);
+}
+
+__global__ __launch_bounds__(256) void k9_first_counts_kernel(FirstCountsParams p) {
+    __shared__ uint32_t s_own[kMaxRanks];
+    const Compact& cp = p.cp;
+    for (uint32_t d = threadIdx.x; d < p.world; d += 256) s_own[d] = 0;
+    __syncthreads();
+    const uint32_t n = *p.n_ptr;
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+        const int32_t t = cp.tid[j];
+        const uint32_t m = cp.meta[j];
+        if (j == 0 || cp.tid[j - 1] != t) {
+            p.first_tab[4 * (size_t)t] = 1u;
+            p.first_tab[4 * (size_t)t + 1] = (uint32_t)meta_qlen(m);
+            p.first_tab[4 * (size_t)t + 2] = cp.nn[j];
+        }
+        if (p.world > 1) {
+            if (meta_flag(m) == F_CTX) {   // (rare: a global atomic each)
+                const int32_t mt = p.mtid_col[cp.idx[j]];
+                if (mt > t && mt < p.ntids) atomicAdd(&p.cnt_mtid[mt], 1u);
+            }
+            atomicAdd(&s_own[exchange_owner(cp.key[j], p.world)], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < p.world; d += 256)
+        if (p.world > 1 && s_own[d]) atomicAdd(&p.cnt_owner[d], s_own[d]);
+}
+void launch_k9_first_counts(const FirstCountsParams& p, uint32_t n_upper, hipStream_t s) {
+    if (!n_upper) return;
+    hipLaunchKernelGGL(k9_first_counts_kernel, dim3(std::min<uint32_t>((n_upper + 255) / 256, 2048u)), dim3(256), 0, s, p);
+}
+
+// window read lengths: pack into the other ranks' blocks of the all-to-all, unpack from the blocks received
+__global__ __launch_bounds__(256) void k9_window_pack_kernel(const RegionRec* rg_rec, uint32_t nw, uint32_t period, WindowDst wd, uint32_t n_expected, uint32_t* cursor) {
+    const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= nw) return;
+    const RegionRec* r = &rg_rec[(size_t)(w + 1) * period - 1];
+    if (!r->n) return;   // (another rank's region: its place in this rank's table is empty)
+    const uint32_t i = atomicAdd(cursor, 1u);
+    if (i >= n_expected) return;   // (cannot happen: the host counted this rank's windows from the chromosomes' region ranges)
+    const unsigned long long e = ((unsigned long long)w << 32) | (unsigned long long)(uint32_t)r->maxq;
+    for (int q = 0; q < wd.world; ++q)
+        if (wd.dst[q]) wd.dst[q][i] = e;
+}
+__global__ __launch_bounds__(256) void k9_window_unpack_kernel(RegionRec* rg_rec, uint32_t nw, uint32_t period, const unsigned long long* base, SegList sg, uint32_t n, uint32_t* err) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const int q = sg.seg_of(j);
+    const unsigned long long e = base[sg.off[q] + (j - sg.start[q])];
+    const uint32_t w = (uint32_t)(e >> 32);
+    if (w >= nw) { *err = 1u; return; }
+    RegionRec* r = &rg_rec[(size_t)(w + 1) * period - 1];
+    if (r->n) { *err = 1u; return; }   // (a window's last region has one owner)
+    r->maxq = (int32_t)(uint32_t)e;
+}
+void launch_k9_window_pack(const RegionRec* rg_rec, uint32_t nr, uint32_t period, const WindowDst& wd, uint32_t n_expected, uint32_t* cursor, hipStream_t s) {
+    const uint32_t nw = nr / period;
+    if (nw && n_expected) hipLaunchKernelGGL(k9_window_pack_kernel, dim3((nw + 255) / 256), dim3(256), 0, s, rg_rec, nw, period, wd, n_expected, cursor);
+}
+void launch_k9_window_unpack(RegionRec* rg_rec, uint32_t nr, uint32_t period, const unsigned long long* base, const SegList& sg, uint32_t n, uint32_t* err, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k9_window_unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, rg_rec, nr / period, period, base, sg, n, err);
 }
 
 __global__ __launch_bounds__(64) void k9_tid_regions_kernel(const RegionRec* r_rec, const StageCounts* counts, int ntids, uint32_t* out) {
@@ -326,6 +388,50 @@ void launch_k9_merge_tables(const char* all, const TableDesc* D, int world, uint
     U4* wsu = (U4*)ws;
     scan_launch<U4>(BeginsIn{begins}, BeginsOut{begins}, n_dev, n_total, wsu + 1, wsu, s);
     hipLaunchKernelGGL(k9_merge_place_kernel, dim3((n_total + 255) / 256), dim3(256), 0, s, all, D, n_total, src, begins, out);
+}
+
+// ---- rank 0: gathered pair groups -> buckets by later region ------------------------------------------------------------
+__device__ __forceinline__ GroupRec seg_group(const unsigned long long* base, const SegList& sg, uint32_t i) {
+    const int q = sg.seg_of(i);
+    return ((const GroupRec*)(base + sg.off[q]))[i - sg.start[q]];
+}
+__global__ __launch_bounds__(256) void k9_group_count_kernel(const unsigned long long* __restrict__ base, SegList sg, uint32_t n, uint32_t nr, uint32_t* cnt, uint32_t* err) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t hi = (uint32_t)((seg_group(base, sg, i).key >> 12) & ((1u << 26) - 1));
+    if (hi < nr) atomicAdd(&cnt[hi], 1u); else *err = 1u;
+}
+struct BucketIn {
+    const uint32_t* cnt;
+    __device__ uint32_t operator()(uint32_t j, uint32_t) const { return cnt[j]; }
+};
+struct BucketOut {
+    uint32_t* goff;
+    RegionRec* r_rec;
+    __device__ void operator()(uint32_t j, uint32_t n, uint32_t inc, uint32_t e) const {
+        goff[j] = inc - e;
+        if (j + 1 < n) r_rec[j].first = inc - e;   // (element n - 1 is the sentinel behind the last region)
+    }
+};
+__global__ __launch_bounds__(256) void k9_group_scatter_kernel(const unsigned long long* __restrict__ base, SegList sg, uint32_t n, uint32_t nr, const uint32_t* goff, uint32_t* cur,
+                                                               GroupRec* out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const GroupRec g = seg_group(base, sg, i);
+    const uint32_t hi = (uint32_t)((g.key >> 12) & ((1u << 26) - 1));
+    if (hi < nr) out[goff[hi] + atomicAdd(&cur[hi], 1u)] = g;
+}
+void launch_k9_bucket_groups(const unsigned long long* base, const SegList& sg, uint32_t n, uint32_t nr, uint32_t* cnt, uint32_t* goff, uint32_t* cur, GroupRec* out,
+                             RegionRec* r_rec, uint32_t* scan_ws, uint32_t* n_words, uint32_t* err, hipStream_t s) {
+    UploadList ul{};
+    ul.fill(cnt, 0u, (size_t)nr + 1);
+    ul.fill(cur, 0u, (size_t)nr + 1);
+    ul.fill(n_words, nr + 1, 1);
+    ul.fill(err, 0u, 1);
+    launch_k9_upload(ul, s);
+    if (n) hipLaunchKernelGGL(k9_group_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, base, sg, n, nr, cnt, err);
+    scan_launch<uint32_t>(BucketIn{cnt}, BucketOut{goff, r_rec}, n_words, nr + 1, scan_ws + 2, scan_ws, s);
+    if (n) hipLaunchKernelGGL(k9_group_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, base, sg, n, nr, goff, cur, out);
 }
 
 }  // namespace bdx

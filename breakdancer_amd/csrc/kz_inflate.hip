@@ -221,9 +221,9 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
                                                         uint8_t* out_all, uint32_t* __restrict__ status, unsigned long long* __restrict__ prof_) {
     unsigned long long* const prof = kProf ? prof_ : nullptr;
     __shared__ Lds L;
-    // measurement hook (BDX_KZ_PROF, tools/bamdec_probe.py): per member {cycles in all, in headers + tables, steps, matches, slow codes, deflate blocks}
+    // measurement hook (BDX_KZ_PROF, tools/bamdec_probe.py): per member {cycles in all, in headers + tables, steps, matches, slow codes, deflate blocks, far matches fetched by their lanes, far matches copied from HBM by the wave}
     unsigned long long t_begin = 0, t_tables = 0;
-    uint32_t n_steps = 0, n_match = 0, n_slow = 0, n_dblk = 0;
+    uint32_t n_steps = 0, n_match = 0, n_slow = 0, n_dblk = 0, n_far_lane = 0, n_far_loop = 0;   // (matches: all / short far ones fetched from HBM by their own lanes / far ones copied from HBM by the wave)
     if (prof) t_begin = __builtin_readcyclecounter();
     const uint32_t b = blockIdx.x;
     if (b >= nblk) return;
@@ -478,6 +478,7 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
                     const uint32_t dstf = outpos + (uint32_t)offv;
                     const uint64_t fmask = mm & mask_gt_s(mdist, kNearDist) & mask_le_s(mlen, 8u) & mask_le_s(dstf & kOBM, kOB - 8u);
                     const bool farm = lanes_of(fmask);
+                    if (kProf) n_far_lane += (uint32_t)__builtin_popcountll(fmask);
                     if (fmask) {
                         if (farm) {
                             uint64_t v;
@@ -513,6 +514,7 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
                             for (uint32_t i = lane; i < length; i += 64) L.obuf[(dst + i) & kOBM] = L.obuf[(dst - dist + i % dist) & kOBM];
                         }
                     } else {
+                        if (kProf) ++n_far_loop;
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         const uint8_t* src = out + dst - dist;
                         for (uint32_t i = lane; i < length; i += 64)
@@ -591,6 +593,7 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
                     for (uint32_t i = lane; i < length; i += 64) L.obuf[(outpos + i) & kOBM] = L.obuf[(outpos - dist + i % dist) & kOBM];
                 }
             } else {   // far back: the whole source is in HBM
+                if (kProf) ++n_far_loop;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const uint8_t* src = out + outpos - dist;
                 for (uint32_t i = lane; i < length; i += 64)
@@ -606,8 +609,8 @@ __global__ __launch_bounds__(64, 8) void kz_inflate_kernel(const uint8_t* __rest
     if (err == KZ_OK && ((bitpos + 7) >> 3) > clen) err = KZ_INPUT_OVERRUN;
     if (lane == 0) status[b] = err;
     if (prof && lane == 0) {
-        unsigned long long* q = prof + (size_t)b * 6;
-        q[0] = __builtin_readcyclecounter() - t_begin; q[1] = t_tables; q[2] = n_steps; q[3] = n_match; q[4] = n_slow; q[5] = n_dblk;
+        unsigned long long* q = prof + (size_t)b * 8;
+        q[0] = __builtin_readcyclecounter() - t_begin; q[1] = t_tables; q[2] = n_steps; q[3] = n_match; q[4] = n_slow; q[5] = n_dblk; q[6] = n_far_lane; q[7] = n_far_loop;
     }
 #undef KZ_ENSURE
 #undef KZ_FLUSH

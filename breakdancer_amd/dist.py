@@ -41,6 +41,7 @@ def _lib():
         lib.bdx_dist_result.restype = vp
         lib.bdx_dist_set_collect_support.argtypes = [vp, C.c_int]
         lib.bdx_dist_get_exchange.argtypes = [vp, vp, vp, vp, vp, vp]
+        lib.bdx_dist_get_collectives.argtypes = [vp, vp, C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
         lib.bdx_dist_owner.argtypes = [C.c_uint64, C.c_int]
         lib.bdx_dist_prepare.argtypes = [vp]
         lib.bdx_dist_phase_name.argtypes = [C.c_int]
@@ -170,6 +171,13 @@ class DistRun:
                   "bdx_dist_get_exchange")
         return dict(ctx_records_sent=sent.value, ctx_records_received=recv.value, gathered_bytes=gathered.value, ms_total=ms_total.value,
                     ms_exchange=ms_x.value)
+
+    def collectives(self):
+        """collectives this rank entered in the last run, and what carried them"""
+        out = (C.c_uint32 * 3)()
+        name, ver = C.c_char_p(), C.c_int()
+        self._chk(self.lib.bdx_dist_get_collectives(self.h, out, C.byref(name), C.byref(ver)), "bdx_dist_get_collectives")
+        return dict(allreduce=int(out[0]), alltoall=int(out[1]), gather=int(out[2]), backend=(name.value or b"").decode(), rccl_version=int(ver.value))
 
     N_PHASES = 18
 

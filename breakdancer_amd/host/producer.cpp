@@ -492,6 +492,7 @@ size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::strin
         // (test / measurement knobs of the CLI; the library reads no environment variable for them: they travel in the parameters)
         if (const char* br = getenv("BDX_BAM_BATCH_ROUNDS")) p.batch_rounds = std::max(1, std::min(16, atoi(br)));
         if (const char* ks = getenv("BDX_KZ_STREAM")) p.stream_mode = !strcmp(ks, "own") ? 1 : !strcmp(ks, "prio") ? 2 : 0;
+        if (getenv("BDX_TIMING")) p.time_kernels = 1;   // (the timing lines say what the inflate kernel took inside the pipeline)
         const size_t rounds = p.batch_rounds ? (size_t)p.batch_rounds : std::max<size_t>(1, std::min<size_t>(4, rest / ((size_t)2560 << 20)));
         const size_t blocks = p.batch_blocks ? p.batch_blocks : 7680 * rounds;
         const size_t batch_inflated = (blocks + kPiece / 16384 + 64) * 65536;
@@ -638,8 +639,14 @@ size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::strin
     if (gave_up_in_submit) rc = BDX_ELIMIT;
     t_finish = since(tf);
     if (timing) {
-        float hm[12];
-        if (bdx_bamdec_host_ms(dec, hm, 12) == BDX_OK) {
+        float hm[14];
+        if (bdx_bamdec_host_ms(dec, hm, 14) == BDX_OK) {
+            if (hm[13] > 0) {
+                uint64_t cb = 0, ib = 0, np_ = 0, tw = 0;
+                (void)bdx_bamdec_stats(dec, &cb, &ib, &np_, &tw);
+                fprintf(stderr, "[bdx timing] inflate kernel in the pipeline: %.1f ms in %d launches (HIP events), %.3f GB inflated from %.3f GB: %.1f GB/s of inflated bytes\n",
+                        hm[12], (int)hm[13], (double)ib * 1e-9, (double)cb * 1e-9, hm[12] > 0 ? (double)ib * 1e-6 / hm[12] : 0.0);
+            }
             fprintf(stderr, "[bdx timing] of the classifier feed: sizing the later stages %.1f ms, classifier launches %.1f ms\n", hm[10], hm[11]);
             // (the rate the file moves at once the GPU has its first batch: what a file of any size approaches)
             const double steady = (hm[9] - hm[8]) * 1e-3;

@@ -382,6 +382,9 @@ int bdx_dist_set_collect_support(bdx_dist* d, int on);
  * of the whole run and of the exchange + CTX join (ms).  Any pointer may be NULL. */
 int bdx_dist_get_exchange(const bdx_dist* d, uint64_t* ctx_records_sent, uint64_t* ctx_records_received, uint64_t* gathered_bytes,
                           float* ms_total, float* ms_exchange);
+/* collectives this rank entered in the last bdx_dist_run: out[0] all-reduces, out[1] all-to-alls, out[2] gathers; the library that
+ * carried them ("threads" for the in-process backend, else the path of the librccl that was loaded) and its ncclGetVersion code (0: none) */
+int bdx_dist_get_collectives(const bdx_dist* d, uint32_t out[3], const char** backend, int* rccl_version);
 /* this rank's milliseconds of the last bdx_dist_run, phase by phase: local phases and the collectives behind them alternate
  * (bdx_dist_phase_name(i) names entry i; a collective's figure includes waiting for the slowest rank), then what only rank 0 does:
  * the merge of the ranks' tables and its host walk of the components that span ranks. */
@@ -451,6 +454,8 @@ typedef struct bdx_bamdec_params {
     int32_t stream_mode;          /* 0: inflate launches and record stages take turns on one stream (the product's arrangement);
                                      1: the inflate launches on a stream of their own beside the record stages (round 4's arrangement);
                                      2: as 1, with queue priorities.  1 and 2 are measurement / test arrangements */
+    int32_t time_kernels;         /* != 0: a HIP event pair around every inflate launch; bdx_bamdec_host_ms [12] = their sum in ms, [13] = launches
+                                     (a measurement: each pair idles the GPU for a few microseconds) */
 } bdx_bamdec_params;
 int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* p);
 void bdx_bamdec_destroy(bdx_bamdec* d);
@@ -476,7 +481,8 @@ int bdx_append_decoded(bdx_ctx* ctx, bdx_bamdec* const* decs, int k, const uint8
 /* milliseconds the feeding thread spent inside the decoder so far, by cause: [0] waiting for a staging buffer's copy, [1] pinning
  * staging memory, [2] waiting for a batch slot, [3] sizing a slot's buffers, [4] the pieces' copy calls, [5] launching batches
  * (includes [6]), [6] launching record stages, [7] feeding the classifier; and two marks, ms after the decoder's creation (or its last
- * bdx_bamdec_rearm): [8] the first inflate launch, [9] bdx_bamdec_finish's return */
+ * bdx_bamdec_rearm): [8] the first inflate launch, [9] bdx_bamdec_finish's return; [10] / [11] of [7]: sizing the later stages' buffers,
+ * classifier launches; [12] / [13] the inflate kernel's own milliseconds by HIP events and its launches (bdx_bamdec_params::time_kernels) */
 int bdx_bamdec_host_ms(const bdx_bamdec* d, float* out, int n);
 int bdx_inflate_blocks(int device, const void* compressed, size_t bytes, const bdx_bgzf_block* blocks, size_t nblocks, void* out,
                        size_t out_bytes, uint32_t* status, float* kernel_ms);

@@ -41,10 +41,11 @@ def main(out_path):
                 d.chromosome(tid).push_reads(arrs)
         d.run()
         ex = d.exchange()
+        coll = d.collectives()
         if rank == 0:
             res = d.result()
             compare(run, res, check_cls=False)
-            verdicts.append(dict(seed=seed, svs=int(run.n_svs), replayed=bool(res.was_replayed()), ctx_sent_rank0=ex["ctx_records_sent"]))
+            verdicts.append(dict(seed=seed, svs=int(run.n_svs), replayed=bool(res.was_replayed()), ctx_sent_rank0=ex["ctx_records_sent"], collectives=coll))
         dist.barrier()
         d.close()
     if rank == 0:

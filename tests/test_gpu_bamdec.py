@@ -216,6 +216,46 @@ def test_inflate_matches_zlib_on_the_reference_bams(kz, monkeypatch):
         assert out.tobytes() == want
 
 
+def test_inflate_and_decode_a_bam_that_looks_like_one(tmp_path):
+    """level-6 deflate of records whose bases come from a shared reference and whose qualities are binned (bamwrite.Reference): the token
+    mix of a real 30x BAM -- long matches between the ~30 records that cover a locus, most of them far back in the 32 KiB window, few
+    literals -- where the files of random bases the other tests use are mostly literals and short matches.  >= 256 MB of inflated
+    bytes: every member byte for byte against zlib, then the record columns of the device decode against the generator's"""
+    from concurrent.futures import ThreadPoolExecutor
+    from breakdancer_amd import bamdec
+    from breakdancer_amd.bamwrite import write_bam
+    from breakdancer_amd.synth import make_chromosome
+    d = make_chromosome(length=4_400_000, seed=31)
+    n = len(d["tid"])
+    assert n * 214 >= (256 << 20)
+    bam = str(tmp_path / "real.bam")
+    write_bam(bam, d, ["chrR"], seed=3, level=6, realistic=True)
+    image = np.fromfile(bam, dtype=np.uint8)
+    members = bamdec.scan_bgzf(image)
+    data = members[members["inflated_len"] > 0]
+    ulen = int(data["inflated_len"].astype(np.int64).sum())
+    assert ulen >= (256 << 20) and ulen / image.size > 3.5, (ulen, image.size)   # compresses like a BAM, not like noise (1.57)
+    out, status, ms = bamdec.inflate_blocks(image, data)
+    assert not status.any()
+    raw = image.tobytes()
+
+    def ref(lo, hi):
+        return b"".join(zlib.decompress(raw[int(m["payload"]):int(m["payload"]) + int(m["payload_len"])], -15) for m in data[lo:hi])
+    cuts = list(range(0, len(data), 256)) + [len(data)]
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        want = b"".join(ex.map(lambda ab: ref(*ab), zip(cuts[:-1], cuts[1:])))
+    got = out.tobytes()
+    assert len(got) == len(want)
+    if got != want:
+        k = next(i for i in range(0, len(want), 4096) if got[i:i + 4096] != want[i:i + 4096])
+        k = next(i for i in range(k, k + 4096) if got[i] != want[i])
+        raise AssertionError("inflated bytes differ from zlib's at byte %d" % k)
+    cols, names, stats = bamdec.decode_file(bam, rg_ids=["rg1"], rg_lib=[0])
+    assert len(cols["tid"]) == n
+    for k in ("tid", "pos", "mtid", "mpos", "isize", "flag", "mapq"):
+        np.testing.assert_array_equal(cols[k], d[k], err_msg=k)
+
+
 @KZ
 def test_inflate_verdict_on_corrupted_members_agrees_with_zlib(kz, monkeypatch):
     """a member is accepted only if zlib accepts it with the same bytes; what zlib rejects is rejected"""

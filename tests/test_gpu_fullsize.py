@@ -148,6 +148,14 @@ def test_config3_five_thousand_translocations_with_dash_t(genome_share):
     n_ctx, n_travel = expected_ctx_travel(run, 4)
     assert n_ctx > 100_000 and sum(e["ctx_records_sent"] for e in ex) == n_travel == sum(e["ctx_records_received"] for e in ex)
     assert n_ctx // 4 < n_travel <= n_ctx // 2   # (one mate per pair at most; 3 of 4 pairs span two ranks)
+    # ... and over 8 ranks, the configuration's own rank count: LPT over 24 chromosomes at 8 bins, 7 of 8 pairs crossing ranks
+    keep = []
+    util = sharded_from_oracle(run, world=8, keep=keep)
+    compare(run, util, check_cls=False)
+    ex = keep[0].exchange
+    n_ctx, n_travel = expected_ctx_travel(run, 8)
+    assert sum(e["ctx_records_sent"] for e in ex) == n_travel == sum(e["ctx_records_received"] for e in ex)
+    assert 3 * (n_ctx // 8) < n_travel <= n_ctx // 2
 
 
 @pytest.mark.parametrize("fraction,min_reads,option_sets", [(1 / 24, 46_000_000, (dict(cn_lib=1, print_af=1), dict(print_af=1))),

@@ -48,6 +48,30 @@ def test_sharded_run_with_a_negative_min_len(seed):
             compare(run, util, check_cls=False)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_sharded_run_over_five_and_eight_ranks(seed):
+    """the shape of the 8-GPU configurations on one GPU: 8 (and 5) ranks as threads -- more ranks than some cases have chromosomes (ranks
+    without reads take part in every collective), LPT packing at 8 bins, most inter-chromosomal pairs crossing ranks, rank 0 handling the
+    components that span ranks; -t, -a -h, small flush windows.  Against ONE oracle run"""
+    from fuzzgen import GRAPH_OPTION_SETS, make_graph_case
+    cfg, streams, targets = (make_case if seed % 2 == 0 else make_graph_case)(3100 + seed)
+    osets = (WG_OPTS[seed % len(WG_OPTS)], dict(transchr_rearrange=1, min_read_pair=1), dict(cn_lib=1, print_af=1, buffer_size=2)) if seed % 2 == 0 else \
+        (GRAPH_OPTION_SETS[seed % len(GRAPH_OPTION_SETS)], dict(transchr_rearrange=1, min_read_pair=1))
+    for i, o in enumerate(osets):
+        if o.get("min_len", 0) < 0:
+            continue
+        run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1, **o))
+        for world in ((8, 5) if i == 0 else (8,)):
+            keep = []
+            util = sharded_from_oracle(run, world=world, keep=keep)
+            compare(run, util, check_cls=False)
+            n_dev, n_host, _ = util.walk_split()
+            assert n_dev + n_host == run.n_svs
+            n_ctx, n_travel = expected_ctx_travel(run, world)
+            ex = keep[0].exchange
+            assert sum(e["ctx_records_sent"] for e in ex) == n_travel == sum(e["ctx_records_received"] for e in ex)
+
+
 def test_staged_chr21_all_sequences():
     run = load_chr21(make_opts()).run()
     for world in (1, 2):

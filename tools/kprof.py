@@ -21,6 +21,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--length", type=int, default=50_000_000)
     ap.add_argument("--lib", default=os.path.join(ROOT, "variants", "libbdx_kprof.so"))
+    ap.add_argument("--genome", type=float, default=0.0, help="hg38 lengths x this, 4 libraries (1/8: a GPU's share of a 30x genome) instead of configs[1]")
+    ap.add_argument("--set", action="append", default=[], help="name=value for bdx_set_debug")
     a = ap.parse_args()
     import breakdancer_amd._lib as lib
     lib.LIB_PATH = a.lib
@@ -28,11 +30,23 @@ def main():
     import breakdancer_amd.api as bda
     from breakdancer_amd.api import LibraryConfig, Options
     from breakdancer_amd.synth import LIB_C2, make_chromosome
-    d = make_chromosome(length=a.length, seed=1)
+    if a.genome:
+        from breakdancer_amd.bamwrite import HG38_MBP, LIBS4
+        from breakdancer_amd.synth import make_genome
+        lengths = [int(m * 1e6 * a.genome) for m in HG38_MBP]
+        d = make_genome(lengths, coverage=30.0, seed=11, libs=LIBS4, lib_bam=(0, 0, 0, 0), n_translocations=5000)
+        libs = [LibraryConfig(mean_insertsize=m, std_insertsize=sd, uppercutoff=m + 3 * sd, lowercutoff=m - 3 * sd, readlens=100.0, name="lib%d" % i) for i, (m, sd) in enumerate(LIBS4)]
+        ntids = len(lengths)
+    else:
+        d = make_chromosome(length=a.length, seed=1)
+        libs, ntids = [LibraryConfig(**LIB_C2)], 1
     n = len(d["pos"])
     dev = torch.device("cuda", 0)
     tens = {k: torch.from_numpy(v).to(dev) for k, v in d.items()}
-    bd = bda.BreakDancer(Options(), [LibraryConfig(**LIB_C2)], 1, ntids=1, max_read_window_size=200, device=0)
+    bd = bda.BreakDancer(Options(), libs, 1, ntids=ntids, max_read_window_size=200, device=0)
+    for kv in a.set:
+        k, v = kv.split("=")
+        bd.set_debug(k, int(v))
     bd.set_device_reads({k: t.data_ptr() for k, t in tens.items()}, n)
     bd.set_enqueue_ahead(0)
     L = lib.load()
