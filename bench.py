@@ -416,6 +416,21 @@ def time_bam_cli_genome(fraction, n_gpu_visible, realistic=False):
             ceil["feed"] = json.loads(fp.stdout.decode().strip().splitlines()[-1]) if fp.returncode == 0 else {"error": fp.stderr.decode()[-200:]}
         except Exception as e:  # noqa: BLE001
             ceil["feed"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        if not realistic:
+            # the feed when EIGHT GPUs' feeders share this host (tools/feed_scaling.py, profiles/r06_feed_scaling.txt): 8 concurrent probes with the
+            # usable CPUs divided between them; the leg that a node shares is page cache -> pinned (host memory bandwidth and cores)
+            try:
+                k = 8
+                t = max(1, min(usable_cpus(), 16) // k)
+                ps = [subprocess.Popen([os.path.join(ROOT, "bin", "bdx-feed-probe"), bam, "2", str(t), "12", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE) for _ in range(k)]
+                outs = [json.loads(p.communicate(timeout=180)[0].decode().strip().splitlines()[-1]) for p in ps]
+                host = [o["page_cache_to_pinned_gb_s"] for o in outs]
+                ceil["feed_with_8_feeders_on_this_host"] = {"instances": k, "threads_per_instance": t, "usable_cpus": usable_cpus(),
+                                                            "page_cache_to_pinned_gb_s_per_instance": sum(host) / k, "aggregate_gb_s": sum(host),
+                                                            "note": "8 concurrent bdx-feed-probe instances (mmap + memcpy into pinned staging): what each of eight GPUs' feeders "
+                                                                    "gets of this host; the inflate kernel takes 44 GB/s of this file per GPU, 30 of a level-6 file"}
+            except Exception as e:  # noqa: BLE001
+                ceil["feed_with_8_feeders_on_this_host"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         try:
             from breakdancer_amd import bamdec
             img = np.memmap(bam, dtype=np.uint8, mode="r")

@@ -152,7 +152,8 @@ struct bdx_ctx {
     uint32_t seq = 0;
     // test / measurement switches (bdx_set_debug): all off by default
     int dbg_no_stash = 0, dbg_max_chunks = 0, dbg_finalize2_fold = 0, dbg_no_forward = 0, dbg_scan3 = 0, dbg_label_rounds = 0, dbg_k1_grid = 0,
-        dbg_end_write_value = 0;
+        dbg_end_write_value = 0, dbg_forward_in_join = 0, dbg_walk_lanes = 0;
+    bool regions_by_side = false;     // this run's region table goes to the host on the copy stream (launch_k3_forward), not inside the join kernel
     uint32_t lb_seq = 0;              // launches of look-back scans so far: every launch stamps its words with its own number (bdx_scan.h)
     uint32_t k1_event_period = 4;     // K1 is bracketed by HIP events on every n-th run (an event pair idles the GPU ~10 us)
     float k1_ms_last = 0;
@@ -160,6 +161,7 @@ struct bdx_ctx {
     bool stage_timing = false;        // HIP events around K2 / K3 / K4+K6 (each costs a few microseconds of idle GPU)
     bool poll = true;                 // BDX_NO_POLL=1: wait with stream / event synchronisation only
     bool materialized = true;         // c->walk holds the final table (false: it still sits in the pinned buffers only)
+    bool rows_packed = false;         // ... as SvWire rows (48 bytes: what a single-context run's table kernel writes over PCIe), not SvOut
     uint32_t n_sv_total = 0, n_groups_total = 0, n_terms_total = 0, n_cn_total = 0;
     PinBuf h_counts0, h_counts2, h_sv_out, h_lib_index, h_lib_pairs, h_cn_key, h_cn_value, h_ltail_dev;
     hipEvent_t ev_groups = nullptr, ev_regions = nullptr;
@@ -1201,7 +1203,7 @@ int do_k6(bdx_ctx* c, bool force_host, int part = 0, const Sizing* sz = nullptr)
     HIPCHK(c, c->b_parts.ensure(cap * sizeof(PartRec)));
     HIPCHK(c, c->b_rs.ensure(cap * sizeof(RegSum)));
     HIPCHK(c, c->b_members.ensure(cap * kK6MaxMembers * sizeof(MemberInfo)));
-    HIPCHK(c, c->b_own.ensure(cap * 7 * 4));
+    HIPCHK(c, c->b_own.ensure(cap * 7 * 4 + 64 * 4 * 4));
     // Components of 5..64 regions cost one more launch (k6_walk_big_kernel) and a member table of 256 B per label.  Few of
     // them are walked by the host behind the device's own walk for free; many (dense data) make the host walk the longest
     // stage.  Without a previous run to go by, the number of anomalous reads decides.
@@ -1249,13 +1251,13 @@ int do_k6(bdx_ctx* c, bool force_host, int part = 0, const Sizing* sz = nullptr)
     a.r_rec = c->k6_r_rec ? c->k6_r_rec : c->b_r_rec.as<RegionRec>(); a.r_pk = c->k6_r_pk ? c->k6_r_pk : c->b_r_pk.as<uint32_t>();
     a.taint = c->k6_taint;
     a.region_of = c->k3.region_of; a.partner = c->k4.partner; a.pair_lo = c->k4.pair_lo; a.meta = c->cp.meta; a.isize = c->cp.isize;
-    a.in_groups = c->k6_in_groups; a.in_goff = c->k6_in_goff;
+    a.in_groups = c->k6_in_groups; a.in_goff = c->k6_in_goff; a.first_of = c->k6_in_groups ? c->k6_in_goff : nullptr;
     a.parts = c->b_parts.as<PartRec>();
     a.rs = c->b_rs.as<RegSum>();
     a.out_deg = c->b_out_deg.as<uint32_t>(); a.label = a.out_deg + cap; a.bad_v = a.out_deg + 2 * cap; a.bad = a.out_deg + 3 * cap;
     a.mcount = a.out_deg + 4 * cap; a.pcount = a.out_deg + 5 * cap;
     a.members = c->b_members.as<MemberInfo>();
-    a.own_nsv = c->b_own.as<uint32_t>(); a.own_nacc = a.own_nsv + cap; a.own_ncn = a.own_nsv + 2 * cap; a.own_first = a.own_nsv + 3 * cap; a.slot_next = a.own_nsv + 4 * cap; a.owners = a.own_nsv + 5 * cap; a.owners_big = a.own_nsv + 6 * cap;
+    a.own_nsv = c->b_own.as<uint32_t>(); a.own_nacc = a.own_nsv + cap; a.own_ncn = a.own_nsv + 2 * cap; a.own_first = a.own_nsv + 3 * cap; a.slot_next = a.own_nsv + 4 * cap; a.owners = a.own_nsv + 5 * cap; a.owners_big = a.own_nsv + 6 * cap; a.emit_part = a.own_nsv + 7 * cap;
     a.member_ids = big_walk ? c->b_member_ids.as<uint32_t>() : nullptr;
     a.sv_stage = c->b_slot.as<SvOut>(); a.lib_stage = c->b_lib_stage.as<LibStage>(); a.cn_stage = c->b_cn_stage.as<CnStage>();
     if (c->table_in_hbm) {
@@ -1293,7 +1295,7 @@ int do_k6(bdx_ctx* c, bool force_host, int part = 0, const Sizing* sz = nullptr)
     a.period = std::max(1, c->opts.buffer_size + 1);
     a.force_host = force_host ? 1 : 0;
     a.big_walk = big_walk;
-    a.walk_lanes = 32;  // (measured at configs[1]: 64 regions per wave 23.7 us, 32: 22.4 us, 16: 24.5 us)
+    a.walk_lanes = c->dbg_walk_lanes > 0 ? std::min(c->dbg_walk_lanes, 32) : 32;  // (measured at configs[1]: 64 regions per wave 23.7 us, 32: 22.4 us, 16: 24.5 us)
     {
         const int rounds = c->dbg_label_rounds;
         // (long chains need more rounds to agree on one label; with the general walk on, the step is long enough not to care)
@@ -1302,7 +1304,7 @@ int do_k6(bdx_ctx* c, bool force_host, int part = 0, const Sizing* sz = nullptr)
     if (c->poll) {  // ready words set by the kernels themselves (first thread of k6_pairs_kernel / first wave of k6_walk_kernel)
         a.flag_value = c->seq;
         a.flag_groups = c->h_flags.as<uint32_t>() + 1;
-        if (c->k3.host_copy_later) a.flag_regions = c->h_flags.as<uint32_t>() + 3;
+        if (c->k3.host_copy_later && !c->regions_by_side) a.flag_regions = c->h_flags.as<uint32_t>() + 3;
         a.mirror_in_walk = (force_host || c->defer_walk) ? 0 : 1;  // (k6_walk_kernel follows k6_emit_kernel unless everything goes to the host, or the walk waits for the ranks' collectives)
     }
     if (part == 1) {
@@ -1393,6 +1395,8 @@ int do_k6_table(bdx_ctx* c) {
     // the runtime's own, but starts 5 us after the kernel before it has ended; back-to-back launches follow each other at once.
     const bool write_value = c->dbg_end_write_value != 0;  // (A/B)
     if (c->poll && !write_value) { a.flag_done = c->h_flags.as<uint32_t>() + 2; a.flag_value = c->seq; }
+    a.wire_rows = c->table_in_hbm ? 0 : 1;   // (a table that stays in HBM for rank 0's merge keeps its full rows)
+    c->rows_packed = a.wire_rows != 0;
     launch_k6_table(a, na, std::log(10), c->opts.score_threshold, c->opts.fisher ? 0 : 1, s);
     if (!a.flag_done) {  // (without polling: finish_table waits for the stream)
         const int rc = signal_ready(c, 2, nullptr);
@@ -1407,8 +1411,33 @@ int materialize(bdx_ctx* c) {
     WalkResult& M = c->walk;
     M.clear();
     const uint32_t n = c->n_sv_total, nt = c->n_terms_total, nc = c->n_cn_total;
-    const HostSv* d = c->h_sv_out.as<HostSv>();
-    M.svs.assign(d, d + n);
+    if (c->rows_packed) {
+        // the rows crossed the link as SvWire: chromosomes and strand counts are the regions' (SvBuilder.cpp:18-99 takes them from there too),
+        // the list offsets the running sums of the counts in table order
+        const SvWire* w = c->h_sv_out.as<SvWire>();
+        M.svs.resize(n);
+        int32_t lb = 0, cb = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const SvWire& r = w[i];
+            HostSv& o = M.svs[i];
+            bdx_sv& v = o.sv;
+            const HostRegion& ra = c->reg[r.region[0]];
+            const HostRegion& rb = r.region[1] >= 0 ? c->reg[r.region[1]] : ra;
+            v.chr[0] = ra.tid; v.chr[1] = rb.tid;
+            v.pos[0] = r.pos[0]; v.pos[1] = r.pos[1];
+            v.fwd[0] = (int32_t)(ra.n - ra.rev); v.rev[0] = (int32_t)ra.rev;
+            v.fwd[1] = (int32_t)(rb.n - rb.rev); v.rev[1] = (int32_t)rb.rev;
+            v.flag = (int32_t)((r.bits >> 16) & 15u); v.size = r.size; v.score = r.score; v.num_reads = r.num_reads; v.printed = (int32_t)((r.bits >> 23) & 1u);
+            v.region[0] = r.region[0]; v.region[1] = r.region[1];
+            v.lib_begin = lb; v.lib_count = (int32_t)(r.bits & 255u); lb += v.lib_count;
+            v.cn_begin = cb; v.cn_count = (int32_t)((r.bits >> 8) & 255u); cb += v.cn_count;
+            v.allele_frequency = r.allele_frequency; v.logp = r.logp;
+            o.grp_mask = (r.bits >> 20) & 7u; o.start = r.start;
+        }
+    } else {
+        const HostSv* d = c->h_sv_out.as<HostSv>();
+        M.svs.assign(d, d + n);
+    }
     M.lib_index.assign(c->h_lib_index.as<int32_t>(), c->h_lib_index.as<int32_t>() + nt);
     M.lib_pairs.assign(c->h_lib_pairs.as<int32_t>(), c->h_lib_pairs.as<int32_t>() + nt);
     M.cn_key.assign(c->h_cn_key.as<int32_t>(), c->h_cn_key.as<int32_t>() + nc);
@@ -1647,10 +1676,20 @@ int bdx_run(bdx_ctx* c) {
         if (c->region_of_fused) {
             en.cand = c->k3.cand; en.c_rid = c->k3.c_rid; en.region_out = c->k3.region_of;
             en.k6_scratch = c->k3.out_deg; en.scratch_cap = c->k3.cap;
-            if (c->k3.host_copy_later) {
+            // The region table -> pinned host memory: by a kernel of its own on the copy stream, beside the join and the pair groups (the host
+            // needs it when its share of the walk starts, four kernels later).  Until round 6 the join kernel forwarded it -- and took as long as
+            // those 5.7 MB take over PCIe.  bdx_set_debug("forward_in_join", 1) restores that (A/B); without polling the join does it as well.
+            c->regions_by_side = c->k3.host_copy_later && c->poll && !c->dbg_forward_in_join && c->copy_stream;
+            if (c->regions_by_side) {
+                HIPCHK(c, hipEventRecord(c->ev_regions, s));
+                HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_regions, 0));
+                launch_k3_forward(c->k3, 2 * c->nkeys, c->na_alloc, c->h_flags.as<uint32_t>() + 3, c->seq, c->copy_stream);
+            } else if (c->k3.host_copy_later) {
                 en.r_rec_dev = c->k3.r_rec_dev; en.r_pk_dev = c->k3.r_pk_dev; en.r_rec_host = c->k3.r_rec; en.r_pk_host = c->k3.r_pk;
                 en.counts = c->b_counts.as<StageCounts>(); en.nkeys2 = 2 * c->nkeys;
             }
+        } else {
+            c->regions_by_side = false;
         }
         r = do_join_local(c, c->na_alloc, en, &c->b_p1.as<Pass1>()->n_anom, true);
         if (r != BDX_OK) return r;
@@ -2103,6 +2142,7 @@ int bdx_set_debug(bdx_ctx* c, const char* name, int value) {
     struct { const char* n; int* p; } ints[] = {{"no_stash", &c->dbg_no_stash}, {"max_chunks", &c->dbg_max_chunks}, {"finalize2_fold", &c->dbg_finalize2_fold},
                                                  {"no_forward", &c->dbg_no_forward}, {"scan3", &c->dbg_scan3}, {"label_rounds", &c->dbg_label_rounds},
                                                  {"k1_grid", &c->dbg_k1_grid}, {"end_write_value", &c->dbg_end_write_value}, {"spec_test", &c->spec_test},
+                                                 {"forward_in_join", &c->dbg_forward_in_join}, {"walk_lanes", &c->dbg_walk_lanes},
                                                  {"big_walk", &c->big_walk_mode}};
     for (auto& e : ints)
         if (!strcmp(name, e.n)) { *e.p = value; return BDX_OK; }

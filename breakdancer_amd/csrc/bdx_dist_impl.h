@@ -623,7 +623,7 @@ static void swap_table_buffers(bdx_ctx* U, bdx_ctx* C) {
 static void adopt_table(bdx_ctx* U, bdx_ctx* C) {
     swap_table_buffers(U, C);
     std::swap(U->walk, C->walk); std::swap(U->log_tail, C->log_tail);
-    U->materialized = C->materialized;
+    U->materialized = C->materialized; U->rows_packed = C->rows_packed;
     U->n_sv_total = C->n_sv_total; U->n_terms_total = C->n_terms_total; U->n_cn_total = C->n_cn_total; U->n_printed = C->n_printed;
     U->n_sv_host = C->n_sv_host; U->n_groups_total = C->n_groups_total;
     U->counts = C->counts;
@@ -1419,12 +1419,10 @@ int bdx_dist_run(bdx_dist* d) {
             for (int q = 0; q < world; ++q) { seg_grp.off[q] = grp_off[q] / 8; seg_grp.start[q] = a; a += (uint32_t)v5[(size_t)q * 10]; }
             seg_grp.start[world] = a;
         }
-        // (the region table's `first` is rewritten for this context's slot space: the copy to pinned memory must have read it)
-        { const int wr = wait_regions(); if (wr != BDX_OK) return wr; }
         hipStream_t su = U->stream;
         DHIP(d, hipEventRecord(d->ev_side, s));   // (the gather, and the region table placed behind it)
         DHIP(d, hipStreamWaitEvent(su, d->ev_side, 0));
-        launch_k9_bucket_groups((const unsigned long long*)d->b_all.p, seg_grp, ng, nr, B, B + o_goff, B + o_cur, sorted, U->b_r_rec.as<RegionRec>(), B + o_ws, B + o_n, B + o_err, su);
+        launch_k9_bucket_groups((const unsigned long long*)d->b_all.p, seg_grp, ng, nr, B, B + o_goff, B + o_cur, sorted, B + o_ws, B + o_n, B + o_err, su);
         // the result context as a K6 context: the genome's statistics and region table, no reads
         DHIP(d, U->b_counts.ensure(sizeof(StageCounts))); DHIP(d, U->h_counts.ensure(sizeof(StageCounts)));
         DHIP(d, U->b_cnt.ensure((size_t)ncnt * 4)); DHIP(d, U->b_p1.ensure(sizeof(Pass1))); DHIP(d, U->b_kdens.ensure(64 * 4));
@@ -1451,8 +1449,11 @@ int bdx_dist_run(bdx_dist* d) {
         U->k4.g_rec = U->h_groups.as<GroupRec>(); U->k4.g_cap = ng + 1;
         U->table_in_hbm = true; U->groups_in_hbm = false; U->defer_walk = false;
         if (U->big_walk_mode < 0) U->last_big_groups = 1 << 20;   // (components of 5..64 regions on the device as well: what is left is the host's, sequentially)
+        // (components that span ranks are mostly a translocation's two regions and their neighbours: three rounds of label propagation settle
+        // them -- the eight of a context that walks large components are seven launches on rank 0's own part of the run; what has not
+        // converged fails the closure check and is the host's)
+        if (!U->dbg_label_rounds) U->dbg_label_rounds = 3;
         memset(&U->counts, 0, sizeof(U->counts));
-        decode_regions(U, regs, pk, nr, 0, true);   // (the host's share of this walk reads the table where it arrived, in pinned memory)
         DCTX(d, U, do_k6(U, force_host, 0));
         if (!wait_flag(U, 1, U->seq)) {
             DHIP(d, hipStreamSynchronize(su));
@@ -1468,6 +1469,11 @@ int bdx_dist_run(bdx_dist* d) {
         }
         decode_groups(U, U->h_groups.as<GroupRec>(), U->counts.n_groups, 0);
         U->last_big_groups = (int64_t)U->counts.n_groups + U->counts.n_groups_big;
+        if (U->counts.n_groups) {   // (the host's share of this walk reads the table in pinned memory: its copy ran beside the device's walk)
+            const int wr = wait_regions();
+            if (wr != BDX_OK) return wr;
+        }
+        decode_regions(U, regs, pk, nr, 0, true);
         const auto tw1 = std::chrono::steady_clock::now();
         DCTX(d, U, host_walk(U, lm, na_all != 0));
         d->phase_ms[16] = ms_between(tw1, std::chrono::steady_clock::now());
@@ -1505,7 +1511,7 @@ int bdx_dist_run(bdx_dist* d) {
             TableDesc* d_td = (TableDesc*)(((uintptr_t)(ws + ws_words) + 15) & ~(uintptr_t)15);
             DHIP(d, hipMemcpyAsync(d_td, &TD, sizeof(TableDesc), hipMemcpyHostToDevice, s));
             DHIP(d, hipMemcpyAsync(T + o_ntot + 2, &n_total, 4, hipMemcpyHostToDevice, s));
-            MergeOut mo{U->h_sv_out.as<SvOut>(), U->h_lib_index.as<int32_t>(), U->h_lib_pairs.as<int32_t>(), U->h_ltail_dev.as<double>(),
+            MergeOut mo{U->h_sv_out.as<SvOut>(), U->h_lib_index.as<int32_t>(), U->h_lib_pairs.as<int32_t>(), d->opts.fisher ? U->h_ltail_dev.as<double>() : nullptr,
                         U->h_cn_key.as<int32_t>(), U->h_cn_value.as<float>()};
             if (tracing) {   // are the ranks' tables sorted by key, and are the keys distinct?
                 DHIP(d, hipStreamSynchronize(s));
@@ -1531,7 +1537,7 @@ int bdx_dist_run(bdx_dist* d) {
         memset(&U->counts, 0, sizeof(U->counts));
         U->counts.n_regions = (uint32_t)NR; U->counts.last_maxq = lm; U->counts.n_pairs = (uint32_t)n_pairs_all; U->counts.n_old = (uint32_t)n_old_all;
         U->counts.n_sv_dev = n_total - U->n_sv_host; U->counts.n_groups = (uint32_t)u_counts[8];   // (what the host's walk took: components the device walk leaves out)
-        U->materialized = false;
+        U->materialized = false; U->rows_packed = true;   // (k9_merge_tables writes SvWire rows, like a single context's table kernel)
         {   // the genome's region table: in rank 0's pinned buffers until the next run
             const int wr = wait_regions();
             if (wr != BDX_OK) return wr;

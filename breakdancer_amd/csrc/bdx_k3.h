@@ -91,6 +91,9 @@ struct K3Tail {
 
 void launch_k3(const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n_anom_host, int min_len, int seq_coverage_lim,
                int nkeys, uint32_t nn_base, K3Tail tail, bool region_of_launch, hipStream_t s);
+// the region table's device copies (r_rec_dev / r_pk_dev) -> its pinned host copies (r_rec / r_pk), then *flag = value; on a stream
+// that runs beside the join (K3Arrays::host_copy_later)
+void launch_k3_forward(const K3Arrays& a, int nkeys2, uint32_t n_anom_host, uint32_t* flag, uint32_t value, hipStream_t s);
 
 // ---- K4 ---------------------------------------------------------------------------------------------
 constexpr int kMaxBuckets = 8192;
@@ -253,6 +256,21 @@ struct SvOut {         // == HostSv (bdx_walk.h)
     uint32_t start;    // start vertex of the traversal that emitted it (output order key)
 };
 
+// A row of the final table as it crosses PCIe (single-context runs): 48 bytes instead of SvOut's 96.  What is left out the host has
+// already -- chromosomes and read counts by strand are the regions' (the region table is in host memory before the walk starts), the
+// list offsets are the running sums of the counts in table order -- and materialize() (bdx_api.hip) puts it back.  The table kernel's
+// time is its bytes over the link (profiles/r06_kprof_genome.txt: every wave is through by 150 us of 175, 6.6 MB at 44 GB/s).
+struct SvWire {
+    int32_t pos[2], region[2];
+    int32_t size, score, num_reads;
+    float allele_frequency;
+    double logp;
+    uint32_t start;
+    uint32_t bits;   // lib_count (8) | cn_count << 8 (8) | flag << 16 (4) | grp_mask << 20 (3) | printed << 23
+};
+static_assert(sizeof(SvWire) == 48, "twelve 32-bit words");
+constexpr int kWireWords = sizeof(SvWire) / 4;
+
 struct LibStage { int32_t lib, rc; double lambda; };
 struct CnStage { int32_t key; float value; };
 
@@ -270,6 +288,7 @@ struct K6Arrays {
     // are then unused, and a region's `first` is its place in a slot space laid out by the host)
     const GroupRec* in_groups;
     const uint32_t* in_goff;
+    const uint32_t* first_of;      // [regions] a region's place in that slot space, instead of RegionRec::first (null: the record's own)
     PartRec* parts;                // [cap] sorted parts of region r at [first_r, ...)
     RegSum* rs;                    // [cap]
     // component analysis; the six arrays below are reset by k3_region_of_kernel (label[r] = r, the others 0)
@@ -289,6 +308,7 @@ struct K6Arrays {
     uint32_t* own_ncn;             // [cap] ... and of their copy-number entries
     uint32_t* own_first;           // [cap] staging slot of the first of them ...
     uint32_t* slot_next;           // [cap] ... and, by staging slot, the slot of the next one in emission order
+    uint32_t* emit_part;           // [64][4] k6_emit_kernel's totals by slot (owners, pairs, groups on the device, groups of large components), zeroed by k6_pairs_kernel
     uint32_t* owners_big;          // [cap] smallest regions of the device-walked components of more than kK6MaxMembers regions
     uint32_t* member_ids;          // [cap][kK6BigMembers] by label: the regions of a component (k6_classify_kernel, any order)
     SvOut* sv_stage;               // [cap]
@@ -365,6 +385,7 @@ struct K6Arrays {
     // else.  A gate-passing group whose earlier region is another rank's makes both of its regions `tainted` (bytes, all-reduced over
     // the ranks between k6_pairs_kernel and k6_classify_kernel): their components go to the host list, i.e. to rank 0's walk
     uint8_t* taint;                // [cap]; null: single-context run
+    int wire_rows;                 // sv_out takes SvWire rows (the table goes to pinned host memory: single-context runs)
     unsigned long long* sv_key;    // [sv_cap] order key of every row of the final table (T << 34 | own << 33 | start << 7): what rank 0 merges
                                    // the ranks' tables by; null: not wanted
 };

@@ -159,13 +159,13 @@ void launch_k9_merge_tables(const char* all, const TableDesc* D, int world, uint
                             const uint32_t* n_dev, const MergeOut& out, hipStream_t s);
 
 // ---- rank 0: the pair groups of the components no rank could walk alone -> K6's `in_groups` input --------------------------
-// The gathered groups (any order) bucketed by their later region: goff[r] .. goff[r + 1] are region r's places in `out`; the region
-// table's `first` becomes goff[r] -- in a context that takes its pair groups as aggregates a region's parts and staging slots live in a
-// slot space of one slot per group (K6Arrays::in_groups), not in the compact read list of the rank that cut the region.
+// The gathered groups (any order) bucketed by their later region: goff[r] .. goff[r + 1] are region r's places in `out` -- and its
+// place in K6's slot space: in a context that takes its pair groups as aggregates a region's parts and staging slots live in a slot
+// space of one slot per group (K6Arrays::in_groups / first_of), not in the compact read list of the rank that cut the region.
 // cnt / cur: [nr + 1] words each, scan_ws: 2 * (scan_grid(nr + 1) + 2) words; n_words[0] receives nr + 1; err: set to 1 if a group names
 // a region outside [0, nr)
 void launch_k9_bucket_groups(const unsigned long long* base, const SegList& sg, uint32_t n, uint32_t nr, uint32_t* cnt, uint32_t* goff, uint32_t* cur, GroupRec* out,
-                             RegionRec* r_rec, uint32_t* scan_ws, uint32_t* n_words, uint32_t* err, hipStream_t s);   // (in: the ranks' blocks of one gather buffer)
+                             uint32_t* scan_ws, uint32_t* n_words, uint32_t* err, hipStream_t s);   // (in: the ranks' blocks of one gather buffer)
 
 // one no-op launch per translation unit (see bdx_warm_up)
 void warm_k1(hipStream_t s); void warm_k2(hipStream_t s); void warm_k3(hipStream_t s); void warm_k4(hipStream_t s);

@@ -129,11 +129,12 @@ __global__ __launch_bounds__(256) void k6_pairs_kernel(K6Arrays a) {
         __threadfence_system();
         *(volatile uint32_t*)a.flag_regions = a.flag_value;
     }
+    if (blockIdx.x == 0 && a.emit_part) a.emit_part[threadIdx.x] = 0;   // (k6_emit_kernel's partial totals: 64 slots x 4 counters)
     const uint32_t NR = a.counts->n_regions;
     const uint32_t mrp = (uint32_t)max(a.min_read_pair, 0);
     for (uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6); r < NR; r += nwaves) {
         const RegionRec rr = a.r_rec[r];
-        const uint32_t first = rr.first, n = rr.n;
+        const uint32_t first = a.first_of ? a.first_of[r] : rr.first, n = rr.n;
         RegSum rs{};
         // the lane's read of chunk c0: key = (region of the first-observed mate, library, flag) if it is the second-observed
         // mate of a pair (SvBuilder.cpp:101-118)
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(256) void k6_classify_kernel(K6Arrays a) {
         static_assert(sizeof(MemberInfo) == 7 * 16 && sizeof(RegionRec) == 36 && offsetof(MemberInfo, rec) == 4 && offsetof(MemberInfo, np_all) == 40 &&
                           offsetof(MemberInfo, e_lo) == 56 && offsetof(MemberInfo, stored) == 104, "a member's record is seven 16-byte words");
         const uint32_t* rw = (const uint32_t*)&a.r_rec[r];
-        const uint32_t r0 = rw[0], r1 = rw[1], r2 = rw[2], r3 = rw[3], r4 = rw[4], r5 = rw[5], r6 = rw[6], r7 = rw[7], r8 = rw[8];
+        const uint32_t r0 = rw[0], r1 = rw[1], r2 = rw[2], r3 = rw[3], r4 = rw[4], r5 = rw[5], r6 = rw[6], r7 = rw[7], r8 = a.first_of ? a.first_of[r] : rw[8];   // (word 8: `first`)
         const uint32_t stored = (int)(a.chr_restricted ? r5 : r3) >= a.min_read_pair ? 1u : 0u;  // region_stored(): nonctx is word 5, n word 3
         uint4* dst = (uint4*)&a.members[(size_t)L * kK6MaxMembers + slot];
         dst[0] = make_uint4(r, r0, r1, r2);
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(256) void k6_emit_kernel(K6Arrays a) {
         const uint32_t need = (registered && !covered && !s.big) ? s.np_emit : 0u;
         uint32_t o = wave_reserve(need, &a.counts->n_groups);
         if (need) {
-            const uint32_t first = a.r_rec[r].first;
+            const uint32_t first = a.first_of ? a.first_of[r] : a.r_rec[r].first;
             for (uint32_t i = 0; i < s.np_all; ++i) {
                 const PartRec q = a.parts[first + i];
                 const uint64_t key = q.key;
@@ -578,7 +579,10 @@ __global__ __launch_bounds__(256) void k6_emit_kernel(K6Arrays a) {
         const bool small = owner && a.mcount[L] <= (uint32_t)kK6MaxMembers;
         if (active) a.owners[r] = small ? a.mcount[L] : 0u;  // (the walk kernel takes one lane per region: no list, no indirection)
         const uint32_t no = (uint32_t)__popcll(__ballot(small));
-        if (lane == 0 && no) atomicAdd(&a.counts->n_owners, no);
+        // (this kernel's four totals go to one of 64 slots, summed by whoever mirrors the counters: as atomics on the counter record itself they were
+        // ~8,000 read-modify-writes of ONE cache line for a genome share's 130 k regions -- the kernel's 76 us)
+        uint32_t* part = a.emit_part ? a.emit_part + (blockIdx.x & 63u) * 4 : nullptr;
+        if (lane == 0 && no) atomicAdd(part ? &part[0] : &a.counts->n_owners, no);
         const uint32_t ob = wave_reserve(owner && !small ? 1u : 0u, &a.counts->n_owners_big);
         if (owner && !small) a.owners_big[ob] = r;
     }
@@ -588,17 +592,36 @@ __global__ __launch_bounds__(256) void k6_emit_kernel(K6Arrays a) {
         const uint32_t gb = (covered && a.mcount[L] > (uint32_t)kK6MaxMembers) ? s.n_in + (s.np_self ? 1u : 0u) : 0u;
         const uint32_t tp = wave_sum_u32(pairs), tg = wave_sum_u32(grp), tb = wave_sum_u32(gb);
         if (lane == 0) {
-            if (tp) atomicAdd(&a.counts->n_pairs, tp);
-            if (tg) atomicAdd(&a.counts->n_groups_dev, tg);
-            if (tb) atomicAdd(&a.counts->n_groups_big, tb);
+            uint32_t* part = a.emit_part ? a.emit_part + (blockIdx.x & 63u) * 4 : nullptr;
+            if (tp) atomicAdd(part ? &part[1] : &a.counts->n_pairs, tp);
+            if (tg) atomicAdd(part ? &part[2] : &a.counts->n_groups_dev, tg);
+            if (tb) atomicAdd(part ? &part[3] : &a.counts->n_groups_big, tb);
         }
     }
 }
 
+namespace {
+// the counter record as the host gets it: k6_emit_kernel's partial totals (64 slots of {owners, pairs, groups on the device, groups of large
+// components}) added to their words.  All 64 lanes of a wave call it; lane l returns word l (lanes past the record: 0)
+__device__ __forceinline__ uint32_t mirrored_count_word(const K6Arrays& a, int lane) {
+    constexpr int kWords = (int)(sizeof(StageCounts) / 4);
+    uint32_t v = lane < kWords ? ((const uint32_t*)a.counts)[lane] : 0u;
+    if (a.emit_part) {
+        uint32_t p0 = a.emit_part[lane * 4], p1 = a.emit_part[lane * 4 + 1], p2 = a.emit_part[lane * 4 + 2], p3 = a.emit_part[lane * 4 + 3];
+        p0 = wave_sum_u32(p0); p1 = wave_sum_u32(p1); p2 = wave_sum_u32(p2); p3 = wave_sum_u32(p3);
+        constexpr int iOwners = (int)(offsetof(StageCounts, n_owners) / 4), iPairs = (int)(offsetof(StageCounts, n_pairs) / 4),
+                      iDev = (int)(offsetof(StageCounts, n_groups_dev) / 4), iBig = (int)(offsetof(StageCounts, n_groups_big) / 4);
+        v += lane == iOwners ? p0 : lane == iPairs ? p1 : lane == iDev ? p2 : lane == iBig ? p3 : 0u;
+    }
+    return v;
+}
+}  // namespace
+
 // the counters after k6_emit_kernel, mirrored into pinned host memory (a per-workgroup fence + last-block copy inside
 // that kernel costs an L2 write-back per workgroup on this multi-die part; one tiny launch does not)
 __global__ __launch_bounds__(64) void k6_mirror_kernel(K6Arrays a) {
-    if (threadIdx.x < sizeof(StageCounts) / 4) ((uint32_t*)a.counts_host)[threadIdx.x] = ((const uint32_t*)a.counts)[threadIdx.x];
+    const uint32_t word = mirrored_count_word(a, (int)threadIdx.x);
+    if (threadIdx.x < sizeof(StageCounts) / 4) ((uint32_t*)a.counts_host)[threadIdx.x] = word;
     if (a.flag_groups) {
         __threadfence_system();
         __syncthreads();
@@ -637,7 +660,7 @@ __device__ __forceinline__ void walk_big(const K6Arrays& a, BigTab& B, uint32_t 
     for (int i = lane; i < k * (kRecW + kRsW); i += 64) {
         const int m = i / (kRecW + kRsW), wd = i - m * (kRecW + kRsW);
         const uint32_t r = B.rid[m];
-        if (wd < kRecW) ((uint32_t*)&B.rec[m])[wd] = ((const uint32_t*)&a.r_rec[r])[wd];
+        if (wd < kRecW) ((uint32_t*)&B.rec[m])[wd] = (wd == kRecW - 1 && a.first_of) ? a.first_of[r] : ((const uint32_t*)&a.r_rec[r])[wd];   // (the last word is `first`)
         else ((uint32_t*)&B.rs[m])[wd - kRecW] = ((const uint32_t*)&a.rs[r])[wd - kRecW];
     }
     __builtin_amdgcn_wave_barrier();
@@ -761,7 +784,8 @@ struct WalkTab {
     uint32_t* p;  // this lane's column
     static constexpr int kSbeg = 0, kScnt = 4, kEbeg = 8, kEcnt = 14, kSw = 20, kEw = 24, kSslot = 30, kEslot = 34, kOrd = 40, kRid = 44,
                          kCalls = 48, kRtid = 58, kRstart = 62, kRend = 66, kRn = 70, kRrev = 74, kFields = 78;
-    __device__ __forceinline__ uint32_t& at(int f) const { return p[f * 64]; }
+    static constexpr int kStride = 32;   // lanes of a wave that walk (K6Arrays::walk_lanes <= this): field f of lane l at word f * kStride + l
+    __device__ __forceinline__ uint32_t& at(int f) const { return p[f * kStride]; }
     __device__ __forceinline__ uint32_t& Sbeg(int i) const { return at(kSbeg + i); }
     __device__ __forceinline__ uint32_t& Scnt(int i) const { return at(kScnt + i); }
     __device__ __forceinline__ uint32_t& Ebeg(int e) const { return at(kEbeg + e); }
@@ -796,13 +820,16 @@ static_assert(kK6MaxMembers == 4 && kK6MaxIn == 3, "WalkTab layout");
 constexpr int kWalkLdsLibs = 16, kWalkLdsKeys = 16;  // run constants of up to this many libraries / counter keys live in LDS
 
 __global__ __launch_bounds__(64) void k6_walk_kernel(K6Arrays a) {
-    __shared__ uint32_t s_tab[WalkTab::kFields * 64];
+    // (32 walking lanes' columns, not 64: with 20 KB per one-wave workgroup a compute unit held 7 waves of this kernel -- 123 registers allow 16 --
+    // and the 8,192 waves of a genome share entered over 130 us, profiles/r06_kprof_genome.txt)
+    __shared__ uint32_t s_tab[WalkTab::kFields * WalkTab::kStride];
     __shared__ uint32_t s_const[kWalkLdsLibs * (1 + kNumFlags) + kWalkLdsKeys];
     const int lane = threadIdx.x;
     if (a.mirror_in_walk && blockIdx.x == 0) {
         // k6_mirror_kernel's job, done by the first wave of the kernel that follows k6_emit_kernel anyway: the counters are
         // final (kernel boundary), they go to the host's record and the word the host polls is set behind them
-        if (lane < (int)(sizeof(StageCounts) / 4)) ((uint32_t*)a.counts_host)[lane] = ((const uint32_t*)a.counts)[lane];
+        const uint32_t word = mirrored_count_word(a, lane);
+        if (lane < (int)(sizeof(StageCounts) / 4)) ((uint32_t*)a.counts_host)[lane] = word;
         __threadfence_system();
         __builtin_amdgcn_wave_barrier();
         if (lane == 0 && a.flag_groups) *(volatile uint32_t*)a.flag_groups = a.flag_value;
@@ -834,7 +861,7 @@ __global__ __launch_bounds__(64) void k6_walk_kernel(K6Arrays a) {
     // One lane per REGION; the smallest region of a device-walked component (k6_emit_kernel marked it with the component's
     // size) walks it.  Everything the first phase needs is requested at once, the description (indexed by label = this region)
     // before it is known whether the region is such an owner: a dependent round trip costs ~1.3 us here, bytes cost nothing.
-    const uint32_t wl = (uint32_t)a.walk_lanes;  // components per wave (the other lanes stay idle: fewer addresses per memory instruction)
+    const uint32_t wl = (uint32_t)min(a.walk_lanes, WalkTab::kStride);  // components per wave (the other lanes stay idle: fewer addresses per memory instruction)
     if ((uint32_t)lane >= wl) return;
     for (uint32_t r = blockIdx.x * wl + lane; r < NR; r += gridDim.x * wl) {
         const MemberInfo* D = a.members + (size_t)r * kK6MaxMembers;
@@ -1491,8 +1518,31 @@ __global__ __launch_bounds__(kScanBlock) void k6_finish_kernel(K6Arrays a, doubl
             if (lane == 0 && npr) atomicAdd(&s_printed, npr);
             KPROF(32768u + bid * 4 + w, 4);
             __builtin_amdgcn_wave_barrier();
-            uint32_t* dst = (uint32_t*)(a.sv_out + win + c0);
-            for (uint32_t i = lane; i < cnt * kSvWords; i += 64) dst[i] = rec[i];
+            if (a.wire_rows) {
+                // the row as it crosses the link: 12 words (SvWire).  Every lane takes its own record out of the slice, then the packed rows
+                // go into the slice's front and leave as one contiguous block
+                SvWire wr{};
+                if (act) {
+                    wr.pos[0] = o->sv.pos[0]; wr.pos[1] = o->sv.pos[1]; wr.region[0] = o->sv.region[0]; wr.region[1] = o->sv.region[1];
+                    wr.size = o->sv.size; wr.score = o->sv.score; wr.num_reads = o->sv.num_reads; wr.allele_frequency = o->sv.allele_frequency;
+                    wr.logp = o->sv.logp; wr.start = o->start;
+                    wr.bits = ((uint32_t)o->sv.lib_count & 255u) | (((uint32_t)o->sv.cn_count & 255u) << 8) | (((uint32_t)o->sv.flag & 15u) << 16) |
+                              ((o->grp_mask & 7u) << 20) | ((o->sv.printed ? 1u : 0u) << 23);
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (act) {
+                    uint32_t* q = rec + lane * kWireWords;
+                    const uint32_t* src = (const uint32_t*)&wr;
+#pragma unroll
+                    for (int k = 0; k < kWireWords; ++k) q[k] = src[k];
+                }
+                __builtin_amdgcn_wave_barrier();
+                uint32_t* dst = (uint32_t*)a.sv_out + (size_t)(win + c0) * kWireWords;
+                for (uint32_t i = lane; i < cnt * kWireWords; i += 64) dst[i] = rec[i];
+            } else {
+                uint32_t* dst = (uint32_t*)(a.sv_out + win + c0);
+                for (uint32_t i = lane; i < cnt * kSvWords; i += 64) dst[i] = rec[i];
+            }
             __builtin_amdgcn_wave_barrier();  // (the wave's next 64 candidates reuse the slice)
         }
         __syncthreads();  // the lists are rewritten by the next pass

@@ -340,7 +340,6 @@ __global__ __launch_bounds__(256) void k9_merge_rank_kernel(const char* all, con
 // times slower); the list entries go with their rows.
 __global__ __launch_bounds__(256) void k9_merge_place_kernel(const char* all, const TableDesc* Dp, uint32_t n_total, const uint32_t* src, const uint2* begins,
                                                              MergeOut out) {
-    constexpr int kW = sizeof(SvOut) / 4;
     constexpr int kLibBegin = (int)(offsetof(bdx_sv, lib_begin) / 4), kCnBegin = (int)(offsetof(bdx_sv, cn_begin) / 4);
     const int lane = threadIdx.x & 63;
     const uint32_t pos0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
@@ -358,25 +357,38 @@ __global__ __launch_bounds__(256) void k9_merge_place_kernel(const char* all, co
         const int32_t* li = (const int32_t*)(all + P.lib_index_off);
         const int32_t* lp = (const int32_t*)(all + P.lib_pairs_off);
         const double* lt = (const double*)(all + P.ltail_off);
-        for (int32_t e = 0; e < nl; ++e) { out.lib_index[bg.x + e] = li[l0 + e]; out.lib_pairs[bg.x + e] = lp[l0 + e]; out.ltail[bg.x + e] = lt[l0 + e]; }
+        for (int32_t e = 0; e < nl; ++e) {
+            out.lib_index[bg.x + e] = li[l0 + e]; out.lib_pairs[bg.x + e] = lp[l0 + e];
+            if (out.ltail) out.ltail[bg.x + e] = lt[l0 + e];   // (the terms' log tails: for Fisher's combination on the host only)
+        }
         const int32_t* ck = (const int32_t*)(all + P.cn_key_off);
         const float* cv = (const float*)(all + P.cn_value_off);
         for (int32_t e = 0; e < nc; ++e) { out.cn_key[bg.y + e] = ck[c0 + e]; out.cn_value[bg.y + e] = cv[c0 + e]; }
     }
     const unsigned long long rp = (unsigned long long)(uintptr_t)row;
-    uint32_t* dst = (uint32_t*)(out.sv_out + pos0);
+    // The rows cross PCIe as SvWire (48 bytes, bdx_k3.h) like a single context's: what is left out -- chromosomes, strand counts, list
+    // offsets -- the host puts back from the region table and the counts (materialize, bdx_api.hip).  Wire word k of a row is word
+    // kSrc[k] of the full row; the last one is put together from five of them.
+    static_assert(offsetof(bdx_sv, pos) == 8 && offsetof(bdx_sv, flag) == 32 && offsetof(bdx_sv, size) == 36 && offsetof(bdx_sv, score) == 40 &&
+                      offsetof(bdx_sv, num_reads) == 44 && offsetof(bdx_sv, printed) == 48 && offsetof(bdx_sv, region) == 52 && offsetof(bdx_sv, lib_count) == 64 &&
+                      offsetof(bdx_sv, cn_count) == 72 && offsetof(bdx_sv, allele_frequency) == 76 && offsetof(bdx_sv, logp) == 80 && offsetof(SvOut, grp_mask) == 88 &&
+                      offsetof(SvOut, start) == 92 && kWireWords == 12, "SvWire from SvOut, word by word");
+    uint32_t* dst = (uint32_t*)out.sv_out + (size_t)pos0 * kWireWords;
     // (every lane takes part in every shuffle: a lane that has left the loop would be read as zero)
     const uint64_t actmask = __ballot(act);
-    for (uint32_t w0 = 0; w0 < cnt * kW; w0 += 64) {
+    (void)kLibBegin; (void)kCnBegin; (void)bg;
+    for (uint32_t w0 = 0; w0 < cnt * kWireWords; w0 += 64) {
         const uint32_t w = w0 + lane;
-        const bool in = w < cnt * kW;
-        const int rr = in ? (int)(w / kW) : 0, wd = in ? (int)(w - (uint32_t)rr * kW) : 0;
+        const bool in = w < cnt * kWireWords;
+        const int rr = in ? (int)(w / kWireWords) : 0, wd = in ? (int)(w - (uint32_t)rr * kWireWords) : 0;
         const uint32_t plo = (uint32_t)__shfl((int)(uint32_t)rp, rr), phi = (uint32_t)__shfl((int)(uint32_t)(rp >> 32), rr);
-        const uint32_t bx = (uint32_t)__shfl((int)bg.x, rr), by = (uint32_t)__shfl((int)bg.y, rr);
         if (!in || !((actmask >> rr) & 1ull)) continue;
         const uint32_t* sp = (const uint32_t*)(uintptr_t)(((unsigned long long)phi << 32) | plo);
-        uint32_t v = sp[wd];
-        v = wd == kLibBegin ? bx : (wd == kCnBegin ? by : v);
+        // pos[0] pos[1] region[0] region[1] size score num_reads allele_frequency logp(lo) logp(hi) start | bits
+        const int src = wd == 0 ? 2 : wd == 1 ? 3 : wd == 2 ? 13 : wd == 3 ? 14 : wd == 4 ? 9 : wd == 5 ? 10 : wd == 6 ? 11 : wd == 7 ? 19 : wd == 8 ? 20 : wd == 9 ? 21 : 23;
+        uint32_t v;
+        if (wd < 11) v = sp[src];
+        else v = (sp[16] & 255u) | ((sp[18] & 255u) << 8) | ((sp[8] & 15u) << 16) | ((sp[22] & 7u) << 20) | ((sp[12] ? 1u : 0u) << 23);
         dst[w] = v;
     }
 }
@@ -407,11 +419,7 @@ struct BucketIn {
 };
 struct BucketOut {
     uint32_t* goff;
-    RegionRec* r_rec;
-    __device__ void operator()(uint32_t j, uint32_t n, uint32_t inc, uint32_t e) const {
-        goff[j] = inc - e;
-        if (j + 1 < n) r_rec[j].first = inc - e;   // (element n - 1 is the sentinel behind the last region)
-    }
+    __device__ void operator()(uint32_t j, uint32_t, uint32_t inc, uint32_t e) const { goff[j] = inc - e; }
 };
 __global__ __launch_bounds__(256) void k9_group_scatter_kernel(const unsigned long long* __restrict__ base, SegList sg, uint32_t n, uint32_t nr, const uint32_t* goff, uint32_t* cur,
                                                                GroupRec* out) {
@@ -422,7 +430,7 @@ __global__ __launch_bounds__(256) void k9_group_scatter_kernel(const unsigned lo
     if (hi < nr) out[goff[hi] + atomicAdd(&cur[hi], 1u)] = g;
 }
 void launch_k9_bucket_groups(const unsigned long long* base, const SegList& sg, uint32_t n, uint32_t nr, uint32_t* cnt, uint32_t* goff, uint32_t* cur, GroupRec* out,
-                             RegionRec* r_rec, uint32_t* scan_ws, uint32_t* n_words, uint32_t* err, hipStream_t s) {
+                             uint32_t* scan_ws, uint32_t* n_words, uint32_t* err, hipStream_t s) {
     UploadList ul{};
     ul.fill(cnt, 0u, (size_t)nr + 1);
     ul.fill(cur, 0u, (size_t)nr + 1);
@@ -430,7 +438,7 @@ void launch_k9_bucket_groups(const unsigned long long* base, const SegList& sg, 
     ul.fill(err, 0u, 1);
     launch_k9_upload(ul, s);
     if (n) hipLaunchKernelGGL(k9_group_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, base, sg, n, nr, cnt, err);
-    scan_launch<uint32_t>(BucketIn{cnt}, BucketOut{goff, r_rec}, n_words, nr + 1, scan_ws + 2, scan_ws, s);
+    scan_launch<uint32_t>(BucketIn{cnt}, BucketOut{goff}, n_words, nr + 1, scan_ws + 2, scan_ws, s);
     if (n) hipLaunchKernelGGL(k9_group_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, base, sg, n, nr, goff, cur, out);
 }
 

@@ -422,6 +422,9 @@ private:
 
 namespace {
 
+inline uint32_t le16_at(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+inline uint32_t le32_at(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
 // Decoders that have done their work.  Releasing one (a 3 GiB ring, four batches' buffers, pinned staging, streams) takes the
 // driver tens of milliseconds, and the clustering run does not need the memory back: they are kept until
 // release_device_decoders(), which the CLI calls only when it walks its destructors.
@@ -489,6 +492,25 @@ size_t decode_on_device(const BamConfig& cfg, size_t bam_index, const std::strin
     // is read (a BGZF member inflates to at most ~16 x its size; 8 x is assumed of a whole stretch: beyond that the decoder says BDX_ELIMIT
     // and the host reader takes the file).  Sharded runs keep one decoder per rank for all of its sequences: sized for the largest.
     {
+        // An inflate launch should take several rounds of the GPU's wave slots once the input is large (a one-round launch ends with the slots
+        // draining: 58 against 68-70 GB/s of inflated bytes on the level-1 file, 109 against 168 on a level-6 file of reference-drawn reads) --
+        // and "large" is about the INFLATED bytes: a real 30x BAM compresses 5 x, the random-base test files 1.57 x.  The ratio is read off
+        // the first members (BSIZE / ISIZE of their headers); one round per 4 GB of inflated bytes expected, at most four.
+        {
+            const uint8_t* m = hdr.mapped();
+            size_t off = member_off, comp = 0, infl = 0;
+            for (int k = 0; k < 64 && off + 28 <= file_size; ++k) {
+                if (m[off] != 31 || m[off + 1] != 139 || le16_at(m + off + 10) != 6 || m[off + 12] != 'B' || m[off + 13] != 'C') break;   // (the usual BGZF header: else no estimate)
+                const size_t total = (size_t)le16_at(m + off + 16) + 1;
+                if (total < 26 || off + total > file_size) break;
+                comp += total; infl += le32_at(m + off + total - 4);
+                off += total;
+            }
+            if (comp && infl && !p.batch_blocks) {
+                const double expected_inflated = (double)rest * (double)infl / (double)comp;
+                p.batch_rounds = (int32_t)std::max(1.0, std::min(4.0, expected_inflated / (double)((size_t)4 << 30)));
+            }
+        }
         // (test / measurement knobs of the CLI; the library reads no environment variable for them: they travel in the parameters)
         if (const char* br = getenv("BDX_BAM_BATCH_ROUNDS")) p.batch_rounds = std::max(1, std::min(16, atoi(br)));
         if (const char* ks = getenv("BDX_KZ_STREAM")) p.stream_mode = !strcmp(ks, "own") ? 1 : !strcmp(ks, "prio") ? 2 : 0;
@@ -731,7 +753,7 @@ struct TwoWay {
     }
 };
 
-void merge_two(const TwoWay& w, int threads, uint8_t* src_file, uint32_t* src_index) {
+void merge_two(const TwoWay& w, int threads, uint8_t* src_file, uint32_t* src_index, int first_last = 1) {
     // seams: (i, j) with every record before them at a position before every record behind them, and file 1 holding nothing at record i's position
     std::vector<std::pair<size_t, size_t>> seam{{0, 0}};
     const int want = std::max(1, threads);
@@ -759,7 +781,9 @@ void merge_two(const TwoWay& w, int threads, uint8_t* src_file, uint32_t* src_in
     std::vector<std::thread> th;
     for (size_t s = 0; s + 1 < seam.size(); ++s) {
         // (the file that emitted before a seam: nothing at a seam depends on it; the very first piece starts as the queue does -- file 0 on a tie)
-        auto job = [&w, &seam, s, src_file, src_index] { w.merge(seam[s].first, seam[s + 1].first, seam[s].second, seam[s + 1].second, 1, src_file, src_index); };
+        // (first_last: the caller merges a stretch of a longer stream and knows which file emitted in front of it)
+        const int last = s == 0 ? first_last : 1;
+        auto job = [&w, &seam, s, last, src_file, src_index] { w.merge(seam[s].first, seam[s + 1].first, seam[s].second, seam[s + 1].second, last, src_file, src_index); };
         if (s + 2 < seam.size()) th.emplace_back(job); else job();
     }
     for (auto& t : th) t.join();
@@ -768,7 +792,7 @@ void merge_two(const TwoWay& w, int threads, uint8_t* src_file, uint32_t* src_in
 }  // namespace
 
 void merge_order(const std::vector<const int32_t*>& tid, const std::vector<const int32_t*>& pos, const std::vector<const uint16_t*>& flag,
-                 const std::vector<size_t>& n, std::vector<uint8_t>& src_file, std::vector<uint32_t>& src_index, int threads) {
+                 const std::vector<size_t>& n, std::vector<uint8_t>& src_file, std::vector<uint32_t>& src_index, int threads, int emitted_last) {
     const size_t k = n.size();
     size_t total = 0;
     for (size_t b = 0; b < k; ++b) total += n[b];
@@ -776,7 +800,7 @@ void merge_order(const std::vector<const int32_t*>& tid, const std::vector<const
     src_index.resize(total);
     if (k == 2 && threads > 0) {
         const TwoWay w{{tid[0], tid[1]}, {pos[0], pos[1]}, {flag[0], flag[1]}, {n[0], n[1]}};
-        merge_two(w, total < ((size_t)1 << 16) && threads < 1000 ? 1 : std::min(threads, 64), src_file.data(), src_index.data());
+        merge_two(w, total < ((size_t)1 << 16) && threads < 1000 ? 1 : std::min(threads, 64), src_file.data(), src_index.data(), emitted_last == 0 ? 0 : 1);
         return;
     }
     std::vector<KeyCursor> cur(k);
@@ -799,6 +823,27 @@ void merge_order(const std::vector<const int32_t*>& tid, const std::vector<const
         if (c->i < c->n) pq.push(c);
     }
 }
+
+namespace {
+// (tid, pos, strand) of the LAST record of sequence tid in a file, by the host reader through the index: the tail of the sequence is
+// decoded (a window of 32 kb in front of the sequence's end, widened while it holds no record).  false: the file has none
+bool last_key_of(const std::string& path, int tid, int32_t* pos, int* strand) {
+    for (int64_t back = 2 * 16384;; back *= 32) {
+        ColumnReader rd(path, 1, nullptr);
+        const int64_t len = (size_t)tid < rd.target_lengths().size() ? (int64_t)rd.target_lengths()[tid] : ((int64_t)1 << 29);
+        RecordFilter f;
+        f.only_tid = tid;
+        f.beg = (int)std::max<int64_t>(0, len - back);
+        f.end = 0x7FFFFFFF;
+        rd.start(f);
+        bool any = false;
+        while (const ColumnChunk* c = rd.next())
+            if (c->size()) { any = true; *pos = c->pos.back(); *strand = (c->flag.back() >> 4) & 1; }
+        if (any) return true;
+        if (f.beg == 0) return false;
+    }
+}
+}  // namespace
 
 // Indexed BAMs, the chromosomes of one whole-genome run spread over ranks (bdx_dist_*): every rank's thread reads the BGZF ranges of ITS
 // chromosomes (the index says where they lie) and decodes them on ITS GPU -- the reference's answer to "one chromosome" is the same indexed
@@ -896,7 +941,31 @@ size_t produce_sharded_on_device(const BamConfig& cfg, int threads, std::vector<
                             total += nr;
                         }
                         // (BamMerger's order among the files that hold the chromosome: a file without records of it is not in the queue at that point either)
-                        merge_order(ptid, ppos, pflag, n, src_file, src_index, std::max(1, per));
+                        // The reference keeps ONE queue across chromosome boundaries (io/BamMerger.cpp:40-126): where the files' first records of a
+                        // chromosome tie (same position and strand -- the first mappable base behind a telomere's Ns), the file whose record has been
+                        // waiting at the top wins, and that is the one that did NOT emit the genome's last record in front of the chromosome.  Two
+                        // files (the tumour / normal pair): worked out from the files' last records on the chromosomes before -- whoever's rank they
+                        // were on.  More files: the tie goes to the lowest file index, as a queue filled afresh would have it (only the
+                        // order of equal-key records at a chromosome's first position can differ from the reference there).
+                        int emitted_last = 1;
+                        if (files.size() == 2 && n[0] && n[1] && ppos[0][0] == ppos[1][0] && ((pflag[0][0] >> 4) & 1) == ((pflag[1][0] >> 4) & 1)) {
+                            int prev[2] = {-1, -1};
+                            for (int x = 0; x < 2; ++x)
+                                for (int tp = (int)t - 1; tp >= 0 && prev[x] < 0; --tp)
+                                    if (span[files[x]][tp].has) prev[x] = tp;
+                            if (prev[0] >= 0 && prev[1] < 0) emitted_last = 0;
+                            else if (prev[0] < 0) emitted_last = 1;   // (file 1 alone emitted before; or neither did: the queue's first fill, file 0 on top)
+                            else if (prev[0] != prev[1]) emitted_last = prev[0] > prev[1] ? 0 : 1;
+                            else {
+                                int32_t lp[2] = {0, 0};
+                                int ls[2] = {0, 0};
+                                bool have = true;
+                                for (int x = 0; x < 2 && have; ++x) have = last_key_of(cfg.bam_files()[files[x]], prev[x], &lp[x], &ls[x]);
+                                if (have && (lp[0] != lp[1] || ls[0] != ls[1])) emitted_last = (lp[0] > lp[1] || (lp[0] == lp[1] && ls[0] > ls[1])) ? 0 : 1;
+                                // (equal last keys as well: what happened in front of THAT tie decides -- left as a fresh queue would have it)
+                            }
+                        }
+                        merge_order(ptid, ppos, pflag, n, src_file, src_index, std::max(1, per), emitted_last);
                         const int mrc = bdx_append_decoded(c, use.data(), (int)use.size(), src_file.data(), src_index.data(), total);
                         if (mrc == BDX_ELIMIT) { gave_up[r] = 1; return; }
                         if (mrc != BDX_OK) throw std::runtime_error(std::string("bdx_append_decoded: ") + bdx_strerror(mrc) + " (" + bdx_last_error(c) + ")");

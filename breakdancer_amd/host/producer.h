@@ -68,9 +68,10 @@ void release_device_decoders();
 void read_targets(const BamConfig& cfg, std::vector<std::string>& names, std::vector<uint32_t>& lengths);
 void produce(const BamConfig& cfg, const std::string& chr, int threads, ReadStream& out);
 // BamMerger's order worked out from the files' (tid, pos, flag) columns alone: entry i of the merged stream is record src_index[i] of
-// file src_file[i] (what the device path hands to bdx_merge_decoded)
+// file src_file[i] (what the device path hands to bdx_merge_decoded).  emitted_last (two files): the file that emitted the stream's last
+// record in FRONT of these -- a tie at the very first position goes to the other one, which has been waiting (1: as a queue filled afresh)
 void merge_order(const std::vector<const int32_t*>& tid, const std::vector<const int32_t*>& pos, const std::vector<const uint16_t*>& flag,
-                 const std::vector<size_t>& n, std::vector<uint8_t>& src_file, std::vector<uint32_t>& src_index, int threads = 1);
+                 const std::vector<size_t>& n, std::vector<uint8_t>& src_file, std::vector<uint32_t>& src_index, int threads = 1, int emitted_last = 1);
 // the same merged stream as produce(), by way of merge_order: every file decoded on its own, then permuted (bdx-dump-reads uses it to
 // hold the two merges against each other)
 void produce_merged_by_columns(const BamConfig& cfg, const std::string& chr, int threads, ReadStream& out);

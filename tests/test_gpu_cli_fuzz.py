@@ -337,18 +337,106 @@ def test_cli_file_of_tens_of_thousands_of_tiny_members(tmp_path):
     assert [l for l in texts["tiny"][0].splitlines() if not l.startswith("#")]
 
 
-def test_cli_prints_the_same_table_every_time_on_a_file_of_few_batches(tmp_path):
-    """a BAM of a few million records in fewer than four decoder batches: the thread that sizes the later stages is started by the decoder's
-    LAST feed, and bdx_bamdec_finish must wait for it -- beside bdx_run its `alloc_only` made the run's stages return without launching
-    anything, and four runs in ten ended with an EMPTY table and no error (round 5, tools/determinism_probe.py).  Ten runs, one table."""
+@pytest.mark.parametrize("fraction,min_rows", [(0.004, 1000), (0.02, 5000)])
+def test_cli_prints_the_same_table_every_time(tmp_path, fraction, min_rows):
+    """The same BAM through the CLI thirty times -- ten runs each on 1, 2 and 3 ranks (BDX_GPUS) -- prints ONE table.  Sizes: a file of fewer
+    than four decoder batches (3.7 M records: the thread that sizes the later stages is started by the decoder's LAST feed -- round 5's
+    sizing pass signalled through a flag on the context that a run beside it saw, and four runs in ten ended with an EMPTY table and no
+    error, tools/determinism_probe.py) and one of four to eight batches (18 M records: the sizing thread runs beside the decode).  The
+    genome share (116 M records) goes through the same probe outside the suite: profiles/r06_determinism_probe.txt."""
     from breakdancer_amd.bamwrite import write_genome_bam
-    bam, cfg, n = write_genome_bam(str(tmp_path), 0.004)
-    assert n > (1 << 20) and os.path.getsize(bam) < (1 << 30)
-    texts = set()
-    for _ in range(10):
-        p = subprocess.run([EXE, cfg], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, BDX_FOREGROUND="1"))
-        assert p.returncode == 0, p.stderr.decode()
-        texts.add(filter_cmd_lines(p.stdout.decode()))
-    assert len(texts) == 1
-    rows = [l for l in texts.pop().splitlines() if l and not l.startswith("#")]
-    assert len(rows) > 1000
+    bam, cfg, n = write_genome_bam(str(tmp_path), fraction)
+    assert n > (1 << 20)
+    texts = {}
+    for gpus in (None, "0,0", "0,0,0"):
+        env = dict(os.environ, BDX_FOREGROUND="1")
+        if gpus:
+            env["BDX_GPUS"] = gpus
+        for _ in range(10):
+            p = subprocess.run([EXE, cfg], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            assert p.returncode == 0, p.stderr.decode()
+            texts.setdefault(filter_cmd_lines(p.stdout.decode()), []).append(gpus or "one GPU")
+    assert len(texts) == 1, {k[:80]: v for k, v in texts.items()}
+    rows = [l for l in next(iter(texts)).splitlines() if l and not l.startswith("#")]
+    assert len(rows) > min_rows
+
+
+@pytest.mark.parametrize("a_emits_last", [True, False])
+def test_cli_sharded_two_bams_tie_at_a_chromosomes_first_position(tmp_path, a_emits_last):
+    """The reference merges the files through ONE queue (io/BamMerger.cpp:40-126): where the two files' first records of a chromosome have
+    the same position and strand, the file that has been waiting at the top wins -- the one that did NOT emit the genome's last record in
+    front of the chromosome.  A sharded run merges chromosome by chromosome, on whatever rank owns each: the file that emitted last is worked
+    out from the files' last records on the chromosome before (here another rank's).  The tie is made to matter: file a's first record on c2
+    opens a region (an inter-chromosomal cluster's mates), file b's is a proper read at the same position and strand -- whether it is counted
+    in front of the region's first read decides b.bam's copy number between the SV's regions, hence the row's allele frequency (-h).  Oracle (one queue) == sharded == one GPU, both ways."""
+    from breakdancer_amd.bamwrite import write_bam_records
+    targets = ["c1", "c2", "c3"]
+    cfg = "".join("readgroup:%s\tplatform:illumina\tmap:%s\treadlen:100.00\tlib:%s\tnum:10001\tlower:310.00\tupper:490.00\tmean:400.00\tstd:30.00\n" % x
+                  for x in (("rg1", "a.bam", "libA"), ("rg3", "b.bam", "libC")))
+    rows = {0: [], 1: []}   # (tid, pos, mtid, mpos, isize, flag, name_id) per file
+    nid = [0]
+
+    def pair(f, tid, p1, mtid, p2, rev1, rev2, proper):
+        nid[0] += 1
+        ins = (p2 + 100 - p1) if tid == mtid else 0
+        fl1 = 0x1 | (0x2 if proper else 0) | (0x10 if rev1 else 0) | (0x20 if rev2 else 0) | 0x40
+        fl2 = 0x1 | (0x2 if proper else 0) | (0x10 if rev2 else 0) | (0x20 if rev1 else 0) | 0x80
+        rows[f].append((tid, p1, mtid, p2, ins, fl1, nid[0]))
+        rows[f].append((mtid, p2, tid, p1, -ins, fl2, nid[0]))
+    rng = np.random.default_rng(77)
+    for f in (0, 1):   # normal pairs everywhere (the statistics), none of them at the first positions of c2
+        for tid in (0, 1, 2):
+            for p in rng.integers(6000, 20000, 150):
+                pair(f, tid, int(p), tid, int(p) + 300, False, True, True)
+    # who emits the genome's last record in front of c2: the file with the later last record on c1
+    pair(0, 0, 27000 if a_emits_last else 26000, 0, 27300 if a_emits_last else 26300, False, True, True)
+    pair(1, 0, 26000 if a_emits_last else 27000, 0, 26300 if a_emits_last else 27300, False, True, True)
+    for i in range(6):     # file a: an inter-chromosomal cluster c1:3000.. <-> c2:5000.. ; its first mate on c2 is c2's first record of file a
+        pair(0, 0, 3000 + 7 * i, 1, 5000 + 7 * i, False, False, False)
+    pair(1, 1, 5000, 1, 5300, False, True, True)   # file b: a proper read at c2:5000, forward -- ties with file a's first record there
+    streams = []
+    for f in (0, 1):
+        r = sorted(rows[f], key=lambda x: (x[0], x[1], (x[5] >> 4) & 1))
+        n = len(r)
+        streams.append(dict(tid=np.array([x[0] for x in r], np.int32), pos=np.array([x[1] for x in r], np.int32), mtid=np.array([x[2] for x in r], np.int32),
+                            mpos=np.array([x[3] for x in r], np.int32), isize=np.array([x[4] for x in r], np.int32), flag=np.array([x[5] for x in r], np.uint16),
+                            qlen=np.full(n, 100, np.uint16), bdqual=np.full(n, 60, np.uint8), rg=np.array(["rg1" if f == 0 else "rg3"] * n),
+                            name_id=np.array([x[6] for x in r], np.int64)))
+        assert (streams[f]["tid"] == 1).any() and streams[f]["pos"][streams[f]["tid"] == 1][0] == 5000
+    write_case(str(tmp_path), streams, targets, np.random.default_rng(5), index=True)
+    (tmp_path / "cfg").write_text(cfg)
+    run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1, min_read_pair=2, print_af=1))   # (-h: the allele frequency column is made of the copy numbers)
+    want = filter_cmd_lines(run.text)
+    ctx_rows = [l for l in want.splitlines() if l and not l.startswith("#") and "CTX" in l]
+    assert ctx_rows, want
+    texts = {}
+    for label, env in (("two-ranks", dict(BDX_GPUS="0,0", BDX_TIMING="1")), ("three-ranks", dict(BDX_GPUS="0,0,0", BDX_TIMING="1")), ("one-gpu", dict(BDX_TIMING="1"))):
+        p = subprocess.run([EXE, "-y", "-1", "-r", "2", "-h", "cfg"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert p.returncode == 0, (label, p.stderr.decode())
+        if label != "one-gpu":
+            assert "(2 files)" in p.stderr.decode(), p.stderr.decode()
+        texts[label] = filter_cmd_lines(p.stdout.decode())
+        assert texts[label] == want, (label, a_emits_last, p.stderr.decode()[-600:])
+
+
+def test_the_tie_of_the_previous_test_changes_the_table(tmp_path):
+    """... and it does: the oracle's tables for the two ways differ in the allele frequency of the inter-chromosomal SV"""
+    import importlib
+    me = importlib.import_module("test_gpu_cli_fuzz")
+    seen = []
+    orig = me.oracle_case
+
+    def spy(*a, **kw):
+        r = orig(*a, **kw)
+        seen.append(filter_cmd_lines(r.text))
+        return r
+    me.oracle_case = spy
+    try:
+        for way in (True, False):
+            d = tmp_path / str(way)
+            d.mkdir()
+            me.test_cli_sharded_two_bams_tie_at_a_chromosomes_first_position(d, way)
+    finally:
+        me.oracle_case = orig
+    strip = lambda t: "\n".join(l for l in t.splitlines() if not l.startswith("#"))
+    assert len(seen) == 2 and strip(seen[0]) != strip(seen[1])
