@@ -21,7 +21,7 @@ class bdx_bamdec_params(C.Structure):
                 ("region_beg", C.c_int32), ("region_end", C.c_int32), ("n_read_groups", C.c_uint32),
                 ("rg_ids", C.POINTER(C.c_char_p)), ("rg_lib", C.c_void_p), ("fallback_lib", C.c_uint8),
                 ("first_record_offset", C.c_uint64), ("ring_bytes", C.c_size_t), ("batch_bytes", C.c_size_t), ("batch_blocks", C.c_size_t), ("expected_bytes", C.c_size_t),
-                ("piece_bytes", C.c_size_t), ("piece_blocks", C.c_size_t), ("batch_rounds", C.c_int32), ("stream_mode", C.c_int32), ("time_kernels", C.c_int32)]
+                ("piece_bytes", C.c_size_t), ("piece_blocks", C.c_size_t), ("batch_rounds", C.c_int32), ("stream_mode", C.c_int32), ("record_mode", C.c_int32), ("missing_lib_plus1", C.c_int32), ("time_kernels", C.c_int32)]
 
 
 BLOCK_DTYPE = np.dtype([("offset", "<u8"), ("payload_len", "<u4"), ("inflated_len", "<u4")])

@@ -152,8 +152,7 @@ struct bdx_ctx {
     uint32_t seq = 0;
     // test / measurement switches (bdx_set_debug): all off by default
     int dbg_no_stash = 0, dbg_max_chunks = 0, dbg_finalize2_fold = 0, dbg_no_forward = 0, dbg_scan3 = 0, dbg_label_rounds = 0, dbg_k1_grid = 0,
-        dbg_end_write_value = 0, dbg_forward_in_join = 0, dbg_walk_lanes = 0;
-    bool regions_by_side = false;     // this run's region table goes to the host on the copy stream (launch_k3_forward), not inside the join kernel
+        dbg_end_write_value = 0, dbg_walk_lanes = 0;
     uint32_t lb_seq = 0;              // launches of look-back scans so far: every launch stamps its words with its own number (bdx_scan.h)
     uint32_t k1_event_period = 4;     // K1 is bracketed by HIP events on every n-th run (an event pair idles the GPU ~10 us)
     float k1_ms_last = 0;
@@ -1304,7 +1303,7 @@ int do_k6(bdx_ctx* c, bool force_host, int part = 0, const Sizing* sz = nullptr)
     if (c->poll) {  // ready words set by the kernels themselves (first thread of k6_pairs_kernel / first wave of k6_walk_kernel)
         a.flag_value = c->seq;
         a.flag_groups = c->h_flags.as<uint32_t>() + 1;
-        if (c->k3.host_copy_later && !c->regions_by_side) a.flag_regions = c->h_flags.as<uint32_t>() + 3;
+        if (c->k3.host_copy_later) a.flag_regions = c->h_flags.as<uint32_t>() + 3;
         a.mirror_in_walk = (force_host || c->defer_walk) ? 0 : 1;  // (k6_walk_kernel follows k6_emit_kernel unless everything goes to the host, or the walk waits for the ranks' collectives)
     }
     if (part == 1) {
@@ -1676,20 +1675,12 @@ int bdx_run(bdx_ctx* c) {
         if (c->region_of_fused) {
             en.cand = c->k3.cand; en.c_rid = c->k3.c_rid; en.region_out = c->k3.region_of;
             en.k6_scratch = c->k3.out_deg; en.scratch_cap = c->k3.cap;
-            // The region table -> pinned host memory: by a kernel of its own on the copy stream, beside the join and the pair groups (the host
-            // needs it when its share of the walk starts, four kernels later).  Until round 6 the join kernel forwarded it -- and took as long as
-            // those 5.7 MB take over PCIe.  bdx_set_debug("forward_in_join", 1) restores that (A/B); without polling the join does it as well.
-            c->regions_by_side = c->k3.host_copy_later && c->poll && !c->dbg_forward_in_join && c->copy_stream;
-            if (c->regions_by_side) {
-                HIPCHK(c, hipEventRecord(c->ev_regions, s));
-                HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_regions, 0));
-                launch_k3_forward(c->k3, 2 * c->nkeys, c->na_alloc, c->h_flags.as<uint32_t>() + 3, c->seq, c->copy_stream);
-            } else if (c->k3.host_copy_later) {
+            // (the join kernel forwards the region table to pinned host memory.  A kernel of its own on the copy stream, beside the join, was
+            // measured in round 6: 1.525 against 1.530 ms at a genome share -- the join does not wait for those 5.7 MB; profiles/r06_genome_ab.txt)
+            if (c->k3.host_copy_later) {
                 en.r_rec_dev = c->k3.r_rec_dev; en.r_pk_dev = c->k3.r_pk_dev; en.r_rec_host = c->k3.r_rec; en.r_pk_host = c->k3.r_pk;
                 en.counts = c->b_counts.as<StageCounts>(); en.nkeys2 = 2 * c->nkeys;
             }
-        } else {
-            c->regions_by_side = false;
         }
         r = do_join_local(c, c->na_alloc, en, &c->b_p1.as<Pass1>()->n_anom, true);
         if (r != BDX_OK) return r;
@@ -2142,7 +2133,7 @@ int bdx_set_debug(bdx_ctx* c, const char* name, int value) {
     struct { const char* n; int* p; } ints[] = {{"no_stash", &c->dbg_no_stash}, {"max_chunks", &c->dbg_max_chunks}, {"finalize2_fold", &c->dbg_finalize2_fold},
                                                  {"no_forward", &c->dbg_no_forward}, {"scan3", &c->dbg_scan3}, {"label_rounds", &c->dbg_label_rounds},
                                                  {"k1_grid", &c->dbg_k1_grid}, {"end_write_value", &c->dbg_end_write_value}, {"spec_test", &c->spec_test},
-                                                 {"forward_in_join", &c->dbg_forward_in_join}, {"walk_lanes", &c->dbg_walk_lanes},
+                                                 {"walk_lanes", &c->dbg_walk_lanes},
                                                  {"big_walk", &c->big_walk_mode}};
     for (auto& e : ints)
         if (!strcmp(name, e.n)) { *e.p = value; return BDX_OK; }

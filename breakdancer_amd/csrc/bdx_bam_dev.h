@@ -46,11 +46,14 @@ struct RgTable {           // read-group ids of the configuration, for the RG ->
     const uint8_t* lib;
     uint32_t n;
     uint8_t fallback;      // library of unknown / missing read groups (io/AlignmentSource.hpp:57-62)
+    uint8_t missing;       // ... of records WITHOUT a read-group tag (= fallback unless the caller tells them apart: bam2cfg does, perl/bam2cfg.pl:93-104)
 };
 
 struct RecordFilterDev {   // -o <region> (io/RegionLimitedBamReader.hpp:63-71, bam_index.c:571-576): only_tid < 0: everything
     int32_t only_tid, beg, end;
     int32_t n_targets;
+    int32_t keep_all;      // 1: every record passes (no reader filter: secondary / supplementary / unplaced records too -- bam2cfg reads what `samtools view` prints)
+    int32_t mapq_only;     // 1: the quality column is MAPQ whether or not the record carries an AM tag (bam2cfg -m)
 };
 
 struct RawColumns {        // columns of every record of a piece, before the reader filter (piece-local index)

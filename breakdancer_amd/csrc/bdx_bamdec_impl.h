@@ -393,6 +393,7 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
     for (auto& r : d->slot_ready) r.store(1);
     d->bam_index = (uint8_t)p->bam_index;
     d->filt.only_tid = p->only_tid; d->filt.beg = p->region_beg; d->filt.end = p->region_end; d->filt.n_targets = p->n_targets;
+    d->filt.keep_all = (p->record_mode & 1) ? 1 : 0; d->filt.mapq_only = (p->record_mode & 2) ? 1 : 0;
     auto bad = [&](int code) { bdx_bamdec_destroy(d); return code; };
     static const bool create_trace = getenv("BDX_BAMDEC_TRACE") != nullptr;   // (where a decoder's set-up time goes, on stderr)
     const auto t_c0 = std::chrono::steady_clock::now();
@@ -486,6 +487,7 @@ int bdx_bamdec_create(bdx_bamdec** out, bdx_ctx* sink, const bdx_bamdec_params* 
             return bad(BDX_EHIP);
         d->rg.hash = d->d_rg_hash.as<uint64_t>(); d->rg.off = d->d_rg_off.as<uint32_t>(); d->rg.chars = d->d_rg_chars.as<char>();
         d->rg.lib = d->d_rg_lib.as<uint8_t>(); d->rg.n = n; d->rg.fallback = p->fallback_lib;
+        d->rg.missing = p->missing_lib_plus1 > 0 ? (uint8_t)(p->missing_lib_plus1 - 1) : p->fallback_lib;
     }
     mark("read-group tables");
     // ring of inflated bytes

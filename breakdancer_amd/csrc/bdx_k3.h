@@ -91,9 +91,6 @@ struct K3Tail {
 
 void launch_k3(const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n_anom_host, int min_len, int seq_coverage_lim,
                int nkeys, uint32_t nn_base, K3Tail tail, bool region_of_launch, hipStream_t s);
-// the region table's device copies (r_rec_dev / r_pk_dev) -> its pinned host copies (r_rec / r_pk), then *flag = value; on a stream
-// that runs beside the join (K3Arrays::host_copy_later)
-void launch_k3_forward(const K3Arrays& a, int nkeys2, uint32_t n_anom_host, uint32_t* flag, uint32_t value, hipStream_t s);
 
 // ---- K4 ---------------------------------------------------------------------------------------------
 constexpr int kMaxBuckets = 8192;

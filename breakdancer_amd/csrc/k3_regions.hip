@@ -10,8 +10,6 @@
 // The reference walks reads one at a time; here the cut is a segmented scan: head flag = tid change or
 // gap > W to the previous anomalous read, candidate id = inclusive scan of heads, and every per-candidate
 // quantity is a difference of inclusive prefix sums (or one atomicMax for the max read length).
-#include <algorithm>
-
 #include "bdx_k3.h"
 
 #include "bdx_scan.h"
@@ -157,30 +155,6 @@ __global__ __launch_bounds__(256) void k3_region_of_kernel(K3Arrays a, const Pas
             a.out_deg[5 * (size_t)a.cap + j] = 0;
         }
     }
-}
-
-// The region table from HBM to pinned host memory, on a stream of its own beside the join and the pair groups: 5.7 MB for a genome
-// share's 130 k regions, ~120 us over PCIe -- inside the join kernel (round 2-5) that WAS the join kernel's duration (144 us, of which
-// its atomics are a third: profiles/r06_genome_kernel_stats.csv)
-__global__ __launch_bounds__(256) void k3_forward_kernel(const RegionRec* src, const uint32_t* src_pk, RegionRec* dst, uint32_t* dst_pk, const StageCounts* counts, int nkeys2) {
-    const uint32_t nr = counts->n_regions;
-    const uint32_t j = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
-    constexpr uint32_t kw = sizeof(RegionRec) / 4;
-    const uint32_t* s = (const uint32_t*)src;
-    uint32_t* d = (uint32_t*)dst;
-    for (uint32_t i = j; i < nr * kw; i += gsz) d[i] = s[i];
-    for (uint32_t i = j; i < nr * (uint32_t)nkeys2; i += gsz) dst_pk[i] = src_pk[i];
-}
-__global__ __launch_bounds__(64) void k3_signal_kernel(uint32_t* flag, uint32_t value) {
-    if (threadIdx.x == 0) {
-        __threadfence_system();
-        *(volatile uint32_t*)flag = value;
-    }
-}
-void launch_k3_forward(const K3Arrays& a, int nkeys2, uint32_t n_anom_host, uint32_t* flag, uint32_t value, hipStream_t s) {
-    const uint32_t g = std::max(1u, std::min<uint32_t>((n_anom_host / 8 * (sizeof(RegionRec) / 4) + 255) / 256, 2048u));
-    hipLaunchKernelGGL(k3_forward_kernel, dim3(g), dim3(256), 0, s, a.r_rec_dev, a.r_pk_dev, a.r_rec, a.r_pk, a.counts, nkeys2);
-    if (flag) hipLaunchKernelGGL(k3_signal_kernel, dim3(1), dim3(64), 0, s, flag, value);
 }
 
 void launch_k3(const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n_anom_host, int min_len, int seq_coverage_lim,

@@ -208,9 +208,7 @@ __device__ __forceinline__ void hash_name_pair(const uint8_t* s, uint32_t n, uin
 }
 
 __device__ __forceinline__ uint8_t resolve_library(const RgTable& rg, const uint8_t* s, uint32_t n, bool have) {
-    if (!have) {   // no RG tag: the empty id (never configured) -> the fallback
-        n = 0;
-    }
+    if (!have) return rg.missing;   // no RG tag
     const uint64_t h = hash_bytes(s, n);
     for (uint32_t i = 0; i < rg.n; ++i) {
         if (rg.hash[i] != h) continue;
@@ -252,7 +250,7 @@ __global__ __launch_bounds__(64) void kb_extract_kernel(const uint8_t* __restric
             continue;
         }
         // reader filter: primary, placed (io/AlignmentFilter.hpp:24-34, io/BamIo.cpp:11-18); -o keeps one region
-        bool keep = !(flag & (0x100u | 0x800u)) && tid >= 0;
+        bool keep = f.keep_all || (!(flag & (0x100u | 0x800u)) && tid >= 0);
         if (f.only_tid >= 0) {
             if (tid < 0 || tid > f.only_tid || (tid == f.only_tid && pos >= f.end)) st->past_region = 1;   // (benign race: all write 1)
             if (keep) {
@@ -316,7 +314,7 @@ __global__ __launch_bounds__(64) void kb_extract_kernel(const uint8_t* __restric
             }
             if (!fixed) continue;
             if (sz > left) { q = end; continue; }
-            if (t0 == 'A' && t1 == 'M' && !have_am) { bdqual = (uint8_t)(is_int ? ival : 0); have_am = true; }
+            if (t0 == 'A' && t1 == 'M' && !have_am) { if (!f.mapq_only) bdqual = (uint8_t)(is_int ? ival : 0); have_am = true; }
             q += sz;
         }
         raw.tid[r] = tid; raw.pos[r] = pos; raw.mtid[r] = mtid; raw.mpos[r] = mpos; raw.isize[r] = isize;

@@ -454,6 +454,9 @@ typedef struct bdx_bamdec_params {
     int32_t stream_mode;          /* 0: inflate launches and record stages take turns on one stream (the product's arrangement);
                                      1: the inflate launches on a stream of their own beside the record stages (round 4's arrangement);
                                      2: as 1, with queue priorities.  1 and 2 are measurement / test arrangements */
+    int32_t record_mode;          /* bits: 1 = no reader filter (secondary / supplementary / unplaced records are kept too), 2 = the quality column is
+                                     MAPQ whether or not a record carries an AM tag.  0 for breakdancer-max's reader; bam2cfg sets them */
+    int32_t missing_lib_plus1;    /* library of records WITHOUT a read-group tag, plus one; 0: fallback_lib, like an unknown read group */
     int32_t time_kernels;         /* != 0: a HIP event pair around every inflate launch; bdx_bamdec_host_ms [12] = their sum in ms, [13] = launches
                                      (a measurement: each pair idles the GPU for a few microseconds) */
 } bdx_bamdec_params;

@@ -7,10 +7,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def make(td, fraction):
+def make(td, fraction, realistic=False):
     from breakdancer_amd.bamwrite import write_genome_bam
     t0 = time.time()
-    bam, cfg, n = write_genome_bam(td, fraction)
+    bam, cfg, n = write_genome_bam(td, fraction, realistic=realistic, tag="realistic" if realistic else "genome")   # (--realistic: reference-drawn bases, binned qualities, level 6)
     if time.time() - t0 > 1:
         print("genome: %d records, BAM of %.2f GB synthesised and written in %.1f s" % (n, os.path.getsize(bam) / 1e9, time.time() - t0), flush=True)
     return bam, cfg, n
@@ -22,7 +22,7 @@ if __name__ == "__main__":
     extra = dict(a.split("=", 1) for a in sys.argv[3:] if "=" in a)
     prof = "--prof" in sys.argv[3:]
     td = os.environ.get("BDX_PROBE_DIR", "/dev/shm/bdx_genome")
-    bam, cfg, n = make(td, fraction)
+    bam, cfg, n = make(td, fraction, "--realistic" in sys.argv[3:])
     size = os.path.getsize(bam)
     for r in range(runs):
         env = dict(os.environ, BDX_TIMING="1", BDX_FOREGROUND="1", **extra)
