@@ -4,7 +4,7 @@ ARCH ?= gfx950
 CSRC := breakdancer_amd/csrc
 HOST := breakdancer_amd/host
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result -Iinclude
-KERNELS := $(CSRC)/k1_classify.hip $(CSRC)/k2_compact.hip $(CSRC)/k3_regions.hip $(CSRC)/k4_join.hip $(CSRC)/k5_poisson.hip $(CSRC)/k6_assemble.hip $(CSRC)/k7_exchange.hip $(CSRC)/k9_shard.hip $(CSRC)/kz_inflate.hip $(CSRC)/kb_records.hip $(CSRC)/bdx_api.hip
+KERNELS := $(CSRC)/k1_classify.hip $(CSRC)/k2_compact.hip $(CSRC)/k3_regions.hip $(CSRC)/k4_join.hip $(CSRC)/k5_poisson.hip $(CSRC)/k6_assemble.hip $(CSRC)/k7_exchange.hip $(CSRC)/k9_shard.hip $(CSRC)/kz_inflate.hip $(CSRC)/kb_records.hip $(CSRC)/kc_insert_stats.hip $(CSRC)/bdx_api.hip
 OBJS := $(KERNELS:.hip=.o) $(CSRC)/bdx_walk.o $(CSRC)/bdx_walk_reads.o
 HOSTCOMMON := $(HOST)/options.cpp $(HOST)/config.cpp $(HOST)/bam_reader.cpp $(HOST)/fast_inflate.cpp $(HOST)/column_reader.cpp $(HOST)/producer.cpp $(HOST)/dumps.cpp $(HOST)/cache.cpp
 
@@ -37,9 +37,9 @@ bin/bdx-feed-probe: tools/feed_probe.hip
 	@mkdir -p bin
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -mavx2 -o $@ $< -lpthread
 
-bin/bam2cfg: $(HOST)/bam2cfg_main.cpp $(HOST)/bam_reader.cpp $(HOST)/bam_reader.h
+bin/bam2cfg: $(HOST)/bam2cfg_main.cpp $(HOST)/bam_reader.cpp $(HOST)/bam_reader.h breakdancer_amd/libbdx.so
 	@mkdir -p bin
-	g++ $(HOSTFLAGS) -o $@ $(HOST)/bam2cfg_main.cpp $(HOST)/bam_reader.cpp -lz -lpthread
+	g++ $(HOSTFLAGS) -o $@ $(HOST)/bam2cfg_main.cpp $(HOST)/bam_reader.cpp -Lbreakdancer_amd -lbdx -lz -lpthread -Wl,-rpath,'$$ORIGIN/../breakdancer_amd' -Wl,-rpath,/opt/rocm/lib
 
 bin/bdx-dump-reads: $(HOSTCOMMON) $(HOST)/dump_main.cpp $(wildcard $(HOST)/*.h) breakdancer_amd/libbdx.so
 	@mkdir -p bin

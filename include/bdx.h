@@ -490,6 +490,16 @@ int bdx_bamdec_host_ms(const bdx_bamdec* d, float* out, int n);
 int bdx_inflate_blocks(int device, const void* compressed, size_t bytes, const bdx_bgzf_block* blocks, size_t nblocks, void* out,
                        size_t out_bytes, uint32_t* status, float* kernel_ms);
 
+/* bam2cfg's insert-size statistics of nlibs libraries on the GPU (perl/bam2cfg.pl:153-197; `bam2cfg --device`): library i's observations
+ * are x[offsets[i] .. offsets[i + 1]).  mean_all / sd_all over all of them (n - 1); mean / sd over the n_kept that are not more than five
+ * standard deviations above mean_all; sd_minus / sd_plus the one-sided deviations around mean (n_minus observations <= mean, n_plus above,
+ * each with n - 1).  Summed in the script's order with round-to-nearest operations: the figures equal the CPU tool's bit for bit. */
+typedef struct bdx_insert_stats {
+    double mean_all, sd_all, mean, sd, sd_minus, sd_plus;
+    uint64_t n_kept, n_minus, n_plus;
+} bdx_insert_stats;
+int bdx_insert_size_stats(int device, const double* x, const uint32_t* offsets, int nlibs, bdx_insert_stats* out);
+
 /* device the context is bound to and the HIP stream it launches on (as void*), for callers that time it */
 int bdx_device(const bdx_ctx* ctx);
 void* bdx_stream(const bdx_ctx* ctx);
