@@ -4,7 +4,8 @@ chr21 fixtures and on a synthetic BAM that reaches the script's early exits.  Th
 (test-data/inv_del_bam_config) was made from the full BAMs, of which the fixtures are excerpts, so it pins the format and
 the plausibility of the figures, not their digits; the Perl script as a whole cannot run here (no samtools, no
 Statistics::Descriptive), but its record classifier (AlnParser.pm) and its Shapiro-Wilk sub can: the second half of this file
-holds the tool to their outputs, column by column (tests/golden/make_bam2cfg_perl_vectors.py).  bam2cfg stays a CPU tool."""
+holds the tool to their outputs, column by column (tests/golden/make_bam2cfg_perl_vectors.py).  These are the tool's CPU source and
+sums; `--device` (records decoded and statistics summed on the GPU) is held to the same vectors in tests/test_gpu_bam2cfg.py."""
 import json
 import os
 import subprocess
