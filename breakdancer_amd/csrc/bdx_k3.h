@@ -377,6 +377,8 @@ struct K6Arrays {
     int mirror_in_walk;            // the first wave of k6_walk_kernel mirrors the counters and sets flag_groups (no k6_mirror_kernel launch)
     int big_walk;                  // components of up to kK6BigMembers regions are walked on the device (k6_walk_big_kernel); 0: up to kK6MaxMembers
     int walk_lanes;                // regions per wave of k6_walk_kernel (<= 64)
+    int ins_plain;                 // test switch (bdx_set_debug "ins_plain"): 1 = the insertion list is ranked as before round 6 (k6_ranksort_kernel / LDS bitonic),
+                                   // 2 = the bucket path declares its list crowded (the bitonic sort takes it)
     int label_rounds;              // min-label propagation rounds incl. the one inside k6_pairs_kernel (default kK6LabelRounds)
     // sharded runs: region ids are genome-wide, the table holds this rank's regions at their genome-wide places and n == 0 everywhere
     // else.  A gate-passing group whose earlier region is another rank's makes both of its regions `tainted` (bytes, all-reduced over

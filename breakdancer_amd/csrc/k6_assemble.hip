@@ -1129,8 +1129,17 @@ __device__ __forceinline__ uint32_t count_below64(const uint64_t* v, uint32_t n,
 // device's list (by rank counting up to 1,024 entries, bitonic in LDS up to 2,048; a longer list arrives with its ranks counted by the
 // whole GPU, k6_ranksort_kernel, launched behind the device walk so that it runs beside the host's), then every entry finds its place by a
 // binary search in the other list (no key occurs in both: a start vertex belongs to one component, and that is walked either here or by the host).
+// Round 6: lists of 1,025..8,192 device entries (a GPU's share of a genome has ~6 k) are ranked inside this launch through BUCKETS of the
+// keys' flush threshold -- a histogram in LDS, its running sums, every entry compared with its own bucket's few others: 127 us of rank-sort
+// launch + one workgroup adding up ten partial ranks per entry became one pass over keys that stay in LDS (profiles/r06_insert_buckets.txt).
+// A list whose keys crowd into one bucket (kInsBucketDepth) takes the old bitonic sort.
 constexpr uint32_t kInsLds = 2048;
 constexpr uint32_t kInsThreads = 1024;
+constexpr uint32_t kInsBucketMax = 8192;     // device entries the bucket path takes
+constexpr uint32_t kInsCntLds = 10240;       // merged entries whose counts stay in LDS
+constexpr uint32_t kInsBuckets = 2048;
+constexpr uint32_t kInsBucketDepth = 128;    // entries of one bucket beyond which the bucket path gives up
+constexpr uint32_t kInsPerBucketPath = kInsBucketMax / kInsThreads;
 constexpr uint32_t kRankGrid = 256;          // workgroups of k6_ranksort_kernel
 // how k6_ranksort_kernel cuts its work for a list of nd entries: chunks of 256 entries x slices of the list they are compared against
 __device__ __forceinline__ void rank_layout(uint32_t nd, uint32_t* nchunk, uint32_t* nslice, uint32_t* per) {
@@ -1146,13 +1155,19 @@ struct InsertJob {
 
 __device__ void InsertJob::operator()() const {
     constexpr uint32_t kThreads = kInsThreads;
-    constexpr uint32_t kPer = kInsLds / kThreads;  // list entries per thread in the LDS prefix pass
-    __shared__ uint64_t s_dk[kInsLds];
-    __shared__ uint32_t s_dv[kInsLds];
+    constexpr uint32_t kPer = kInsCntLds / kThreads;  // list entries per thread in the LDS prefix pass
+    // One workgroup, nothing else on its compute unit: 130 of gfx950's 160 KB of LDS.  s_ord: the device's keys bucket by bucket (bucket
+    // path); the other paths keep their keys, slots and rank-counting copy in it
+    __shared__ uint64_t s_ord[kInsBucketMax];
+    __shared__ uint32_t s_cnt[kInsCntLds];        // lib_count | cn_count << 16 of the merged list
     __shared__ uint64_t s_hk[kInsLds];
-    __shared__ uint32_t s_cnt[kInsLds];   // lib_count | cn_count << 16 of the merged list
-    __shared__ uint64_t s_tmp[kThreads];
+    __shared__ uint32_t s_hist[kInsBuckets + 1];
     __shared__ uint32_t s_ws[2][kThreads / 64];
+    __shared__ uint32_t s_crowded;
+    uint64_t* const s_dk = s_ord;
+    uint32_t* const s_dv = (uint32_t*)(s_ord + kInsLds);
+    uint64_t* const s_tmp = s_ord + 2 * kInsLds;
+    static_assert(2 * kInsLds + kThreads <= kInsBucketMax, "keys, slots and the rank-counting copy of the smaller paths fit s_ord");
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const uint32_t nh = a.nh;
@@ -1170,12 +1185,100 @@ __device__ void InsertJob::operator()() const {
         if (tid == 0) { a.ins_pre_l[0] = 0; a.ins_pre_c[0] = 0; }
         return;
     }
-    const bool small = n <= kInsLds;  // the merged list's counts stay in LDS for the running totals
-    uint64_t* dk;
-    uint32_t* dv;
-    uint32_t my_cnt = 0;              // rank-sort path: lib_count | cn_count << 16 of this thread's device entry
     const bool by_rank = nd <= kThreads;
-    if (by_rank) {
+    bool by_bucket = !by_rank && nd <= kInsBucketMax && a.ins_plain != 1;
+    const bool small = n <= kInsCntLds;  // the merged list's counts stay in LDS for the running totals
+    uint64_t* dk = nullptr;
+    uint32_t* dv = nullptr;
+    uint32_t my_cnt = 0;              // rank-sort path: lib_count | cn_count << 16 of this thread's device entry
+    if (by_bucket) {
+        // An entry's bucket is a monotone function of its key (so a bucket's entries lie between its neighbours') that spreads what the keys
+        // crowd around: the device's entries all carry a flush threshold T = window x period and differ in their start vertex -- mostly one of
+        // the window before (local links), any earlier one for translocations.  Windows x 64 sub-slots by the start vertex, scaled to kInsBuckets.
+        const uint32_t period = (uint32_t)max(a.period, 1);
+        const uint32_t nwin = a.counts->n_regions / period + 2;
+        constexpr uint32_t kSub = 64;
+        const uint64_t span = (uint64_t)nwin * kSub + 1;
+        auto bucket_of = [&](uint64_t key) {
+            const uint32_t T = (uint32_t)(key >> kKeyShiftT), own = (uint32_t)(key >> 33) & 1u, start = (uint32_t)(key >> kKeyShiftStart) & 0x3FFFFFFu;
+            const uint32_t W = T / period, r = T - W * period;
+            uint32_t sub = kSub;   // (a threshold inside a window, or a candidate of its own window: behind every entry of that flush)
+            if (!r && !own) {
+                if (start >= T) sub = kSub - 1;
+                else if (start + period >= T) sub = kSub / 2 + min(kSub / 2 - 1, (uint32_t)(((uint64_t)(start + period - T) * (kSub / 2)) / period));
+                else sub = (uint32_t)(((uint64_t)start * (kSub / 2)) / T);
+            }
+            return (uint32_t)min((uint64_t)(kInsBuckets - 1), (((uint64_t)W * kSub + sub) * kInsBuckets) / span);
+        };
+        for (uint32_t i = tid; i <= kInsBuckets; i += kThreads) s_hist[i] = 0;
+        if (tid == 0) s_crowded = a.ins_plain == 2 ? 1u : 0u;
+        __syncthreads();
+        uint64_t key[kInsPerBucketPath];
+        uint32_t slot[kInsPerBucketPath], bk[kInsPerBucketPath], at[kInsPerBucketPath], cnt[kInsPerBucketPath];
+#pragma unroll
+        for (uint32_t k = 0; k < kInsPerBucketPath; ++k) {
+            const uint32_t d = tid + k * kThreads;
+            key[k] = d < nd ? a.old_key[d] : ~0ull;
+            slot[k] = d < nd ? a.old_slot[d] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kInsPerBucketPath; ++k) {
+            const uint32_t d = tid + k * kThreads;
+            bk[k] = 0; at[k] = 0; cnt[k] = 0;
+            if (d < nd) {
+                cnt[k] = (uint32_t)a.sv_stage[slot[k]].sv.lib_count | ((uint32_t)a.sv_stage[slot[k]].sv.cn_count << 16);
+                bk[k] = bucket_of(key[k]);
+                at[k] = atomicAdd(&s_hist[bk[k]], 1u);
+                if (at[k] >= kInsBucketDepth) s_crowded = 1u;
+            }
+        }
+        __syncthreads();
+        by_bucket = s_crowded == 0;   // (the same answer in every thread)
+        if (by_bucket) {
+            // running sums of the histogram: s_hist[b] = first place of bucket b in the bucket-ordered list, s_hist[kInsBuckets] = nd
+            static_assert(kInsBuckets == 2 * kThreads, "two buckets per thread");
+            const uint32_t h0 = s_hist[2 * tid], h1 = s_hist[2 * tid + 1];
+            const uint32_t inc = wave_incl_scan_t(h0 + h1);
+            if (lane == 63) s_ws[0][w] = inc;
+            __syncthreads();
+            uint32_t off = inc - (h0 + h1);
+            for (int q = 0; q < w; ++q) off += s_ws[0][q];
+            s_hist[2 * tid] = off; s_hist[2 * tid + 1] = off + h0;
+            if (tid == 0) s_hist[kInsBuckets] = nd;
+            __syncthreads();
+#pragma unroll
+            for (uint32_t k = 0; k < kInsPerBucketPath; ++k)
+                if (tid + k * kThreads < nd) s_ord[s_hist[bk[k]] + at[k]] = key[k];
+            __syncthreads();
+            auto below = [&](uint64_t x, uint32_t b) {   // keys of the device's list below x, b = x's bucket
+                const uint32_t lo = s_hist[b], hi = s_hist[b + 1];
+                uint32_t r = lo;
+                for (uint32_t j = lo; j < hi; ++j) r += s_ord[j] < x ? 1u : 0u;
+                return r;
+            };
+#pragma unroll
+            for (uint32_t k = 0; k < kInsPerBucketPath; ++k)
+                if (tid + k * kThreads < nd) {
+                    const uint32_t pos = below(key[k], bk[k]) + count_below64(hk, nh, key[k]);
+                    a.ins_T[pos] = (uint32_t)(key[k] >> kKeyShiftT);
+                    a.ins_src[pos] = slot[k];
+                    if (small) s_cnt[pos] = cnt[k];
+                    else { a.ins_pre_l[pos] = cnt[k] & 0xffffu; a.ins_pre_c[pos] = cnt[k] >> 16; }
+                }
+            for (uint32_t j = tid; j < nh; j += kThreads) {
+                const uint64_t x = hk[j];
+                const uint32_t pos = j + below(x, bucket_of(x)), c = a.hs_cnt[j];
+                a.ins_T[pos] = (uint32_t)(x >> kKeyShiftT);
+                a.ins_src[pos] = 0x80000000u | j;
+                if (small) s_cnt[pos] = c;
+                else { a.ins_pre_l[pos] = c & 0xffffu; a.ins_pre_c[pos] = c >> 16; }
+            }
+        }
+        __syncthreads();   // (s_ord is the other paths' from here)
+    }
+    if (by_bucket) {
+        // (placed above, the host's entries too)
+    } else if (by_rank) {
         // one entry per thread: its rank is the number of smaller keys (all keys differ)
         dk = s_dk; dv = s_dv;
         const uint64_t key = tid < nd ? a.old_key[tid] : ~0ull;
@@ -1194,7 +1297,7 @@ __device__ void InsertJob::operator()() const {
             if (small) s_cnt[pos] = my_cnt;
             else { a.ins_pre_l[pos] = my_cnt & 0xffffu; a.ins_pre_c[pos] = my_cnt >> 16; }
         }
-    } else if (a.rank_part && nd > kInsLds && nd <= kK6RankSortMax) {
+    } else if (a.rank_part && nd > kInsLds && nd <= kK6RankSortMax && (nd > kInsBucketMax || a.ins_plain == 1)) {
         // (ranked by the whole GPU in the launch before this one: a bitonic sort of this many keys in HBM by ONE workgroup took half a millisecond,
         // one workgroup per 256 entries counting against the whole list 0.4 ms at 6 k entries -- a wave's compare loop is instruction-bound)
         uint32_t nchunk, nslice, per;
@@ -1214,7 +1317,8 @@ __device__ void InsertJob::operator()() const {
             const uint32_t cnt = (uint32_t)a.sv_stage[slot].sv.lib_count | ((uint32_t)a.sv_stage[slot].sv.cn_count << 16);
             a.ins_T[pos] = (uint32_t)(key >> kKeyShiftT);
             a.ins_src[pos] = slot;
-            a.ins_pre_l[pos] = cnt & 0xffffu; a.ins_pre_c[pos] = cnt >> 16;
+            if (small) s_cnt[pos] = cnt;
+            else { a.ins_pre_l[pos] = cnt & 0xffffu; a.ins_pre_c[pos] = cnt >> 16; }
         }
     } else {
         uint32_t m = 1;
@@ -1251,7 +1355,7 @@ __device__ void InsertJob::operator()() const {
             else { a.ins_pre_l[pos] = cnt & 0xffffu; a.ins_pre_c[pos] = cnt >> 16; }
         }
     }
-    for (uint32_t j = tid; j < nh; j += kThreads) {
+    for (uint32_t j = tid; j < nh && !by_bucket; j += kThreads) {
         const uint64_t key = hk[j];
         const uint32_t pos = j + count_below64(dk, nd, key), cnt = a.hs_cnt[j];
         a.ins_T[pos] = (uint32_t)(key >> kKeyShiftT);
@@ -1331,6 +1435,7 @@ __global__ __launch_bounds__(kScanBlock) void k6_ranksort_kernel(K6Arrays a) {
     __shared__ uint64_t s_k[kRankTile];
     const uint32_t nd = a.counts->n_old;
     if (nd <= kInsLds || nd > kK6RankSortMax) return;
+    if (nd <= kInsBucketMax && a.ins_plain != 1) return;   // (k6_insert_kernel ranks these through its buckets)
     uint32_t nchunk, nslice, per;
     rank_layout(nd, &nchunk, &nslice, &per);
     for (uint32_t item = blockIdx.x; item < nchunk * nslice; item += gridDim.x) {   // (whole workgroups stay in the loop: barriers inside)

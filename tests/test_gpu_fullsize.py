@@ -117,6 +117,13 @@ def test_config2_one_gpu_share_of_the_genome(genome_share):
     assert n_dev > 20 * max(1, n_host)
     bh = product_from_oracle(run, host_walk=True)
     tables_equal(bd, bh)
+    # the candidates placed by order key (traversals started in an earlier flush window) were ranked through k6_insert_kernel's buckets;
+    # the same table from the rank sort over the whole GPU (1) and from the bitonic sort a crowded bucket falls back to (2)
+    assert 1024 < bd.cross_window_svs() <= 8192
+    for mode in (1, 2):
+        bd.set_debug("ins_plain", mode)
+        bd.run()
+        tables_equal(bd, bh)
     bd.close()
     bh.close()
 

@@ -59,6 +59,7 @@ def main():
             if ref is None:
                 ref = sig
             assert sig == ref, (s, sig, ref)
+    print("walk split (device SVs, host SVs, groups to the host) %s; candidates placed by key (started in an earlier flush window) %d" % (bd.walk_split(), bd.cross_window_svs()))
     print("records %d; best of 6 runs per round, %d rounds interleaved; every setting gives the same table" % (n, a.rounds))
     for s in settings:
         print("  %-40s %s  -> best %.3f ms" % (s, " ".join("%.3f" % (x * 1e3) for x in res[s]), min(res[s]) * 1e3))
