@@ -1227,7 +1227,7 @@ int do_k6(bdx_ctx* c, bool force_host, int part = 0, const Sizing* sz = nullptr)
         HIPCHK(c, c->h_ltail_dev.ensure((size_t)a.term_cap * 8));
     }
     HIPCHK(c, c->h_counts2.ensure(sizeof(StageCounts)));
-    HIPCHK(c, c->b_sv_src.ensure((size_t)a.sv_cap * 12)); HIPCHK(c, c->b_ltail.ensure((size_t)a.term_cap * 8));
+    HIPCHK(c, c->b_sv_src.ensure((size_t)a.sv_cap * 16)); HIPCHK(c, c->b_ltail.ensure((size_t)a.term_cap * 8));
     HIPCHK(c, c->b_dlists.ensure((size_t)a.term_cap * 4 + (size_t)a.cn_cap * 8 + 64));
     {   // the inserted list (k6_insert_kernel): device order keys padded to a power of two for the sort
         size_t p2 = 1;
@@ -1267,6 +1267,7 @@ int do_k6(bdx_ctx* c, bool force_host, int part = 0, const Sizing* sz = nullptr)
         a.sv_out = c->h_sv_out.as<SvOut>(); a.lib_index = c->h_lib_index.as<int32_t>(); a.lib_pairs = c->h_lib_pairs.as<int32_t>();
         a.cn_key = c->h_cn_key.as<int32_t>(); a.cn_value = c->h_cn_value.as<float>();
     }
+    a.sv_vx = a.sv_key ? a.sv_src + a.sv_cap : nullptr;
     a.t_lambda = c->b_t_lambda.as<double>(); a.t_k = c->b_t_k.as<int32_t>();
     a.g_rec = c->k4.g_rec; a.g_cap = c->k4.g_cap;
     {   // look-back words of the table scan: zero once, afterwards every run brings its own stamp
@@ -1388,6 +1389,8 @@ int do_k6_table(bdx_ctx* c) {
     // (K5 runs inside the table kernel.  The terms' log tails go to the host for Fisher's combination only -- BreakDancer.cpp:71-81 uses the
     // host's exp / log --; otherwise they are 8 bytes per term over PCIe that nobody reads)
     a.ltail_host = c->table_in_hbm ? c->b_ltail_out.as<double>() : (c->opts.fisher ? c->h_ltail_dev.as<double>() : nullptr);
+    // (the table kernel's launch: for the regions the pair groups' report named -- the host has read it by now -- not for their upper bound)
+    a.fin_regions = (c->counts.n_regions && c->counts.n_regions <= na) ? c->counts.n_regions : na;
     HIPCHK(c, c->h_printed.ensure((size_t)k6_score_grid(a) * 4));
     a.printed_host = c->h_printed.as<uint32_t>();
     // The word the host polls for the end of the run is set by a one-thread kernel behind the table kernel (a kernel boundary

@@ -317,6 +317,7 @@ struct K6Arrays {
     uint32_t* sv_src;              // device [sv_cap]: staging slot of the candidate at each final position, or 0x80000000 | j for
                                    // the host walk's candidate j
     uint2* sv_begin;               // device [sv_cap]: its first entries in the two flat lists
+    uint32_t* sv_vx;               // device [sv_cap]: the vertex it is placed at (with sv_key: the order keys for the merge of a sharded run's tables); else null
     int32_t* d_lib_index;          // device [term_cap]
     int32_t* d_cn_key;             // device [cn_cap]
     float* d_cn_value;             // device [cn_cap]
@@ -329,7 +330,7 @@ struct K6Arrays {
     float* cn_value;               // pinned host
     uint32_t sv_cap, term_cap, cn_cap;
     double* ltail;                 // device [term_cap]: log tails of the terms ...
-    uint32_t* printed_host;        // pinned host [k6_score_grid()]: printed candidates per workgroup of k6_finish_kernel; may be null
+    uint32_t* printed_host;        // pinned host [k6_score_grid()]: printed candidates per workgroup of k6_score_kernel; may be null
     double* ltail_host;            // ... and their copy in pinned host memory (both written by k6_score_kernel)
     // Candidates that are placed by their order key instead of by their start vertex: the host walk's (pinned host
     // memory) and the device's own whose traversal started from a vertex of an earlier flush window.  k6_insert_kernel
@@ -358,7 +359,7 @@ struct K6Arrays {
     // groups of the components left to the host
     GroupRec* g_rec;               // pinned host
     uint32_t g_cap;
-    unsigned long long* lb_state;  // look-back words of k6_finish_kernel's scan: [scan_grid(cap, 1)][4], zero at allocation
+    unsigned long long* lb_state;  // look-back words of k6_place_kernel's scan: [scan_grid(cap, 1)][4], zero at allocation
     uint32_t lb_stamp;             // run stamp of those words (never 0, changes every run)
     StageCounts* counts;
     StageCounts* counts_host;      // pinned: all counters after k6_emit_kernel (k6_mirror_kernel, or the first wave of k6_walk_kernel)
@@ -376,6 +377,7 @@ struct K6Arrays {
     int nlibs, nkeys, min_read_pair, chr_restricted, period, force_host;
     int mirror_in_walk;            // the first wave of k6_walk_kernel mirrors the counters and sets flag_groups (no k6_mirror_kernel launch)
     int big_walk;                  // components of up to kK6BigMembers regions are walked on the device (k6_walk_big_kernel); 0: up to kK6MaxMembers
+    uint32_t fin_regions;          // regions k6_place_kernel's launch is sized for (the host's count once it has read it; 0: cap)
     int walk_lanes;                // regions per wave of k6_walk_kernel (<= 64)
     int ins_plain;                 // test switch (bdx_set_debug "ins_plain"): 1 = the insertion list is ranked as before round 6 (k6_ranksort_kernel / LDS bitonic),
                                    // 2 = the bucket path declares its list crowded (the bitonic sort takes it)
@@ -395,9 +397,9 @@ void launch_k6_components(const K6Arrays& a, uint32_t n_upper, hipStream_t s);  
 // start values of the per-region scratch (out_deg, label = index, bad_v, bad, mcount, pcount) when no join kernel has set them
 void launch_k6_scratch_init(uint32_t* out_deg, uint32_t cap, hipStream_t s);
 void launch_k6_walk(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s);     // device-walked components -> SV staging
-// staging + host candidates -> final table in pinned host memory, scored (k6_insert_kernel, k6_finish_kernel)
+// staging + host candidates -> final table in pinned host memory, scored (k6_insert_kernel, k6_place_kernel, k6_score_kernel)
 void launch_k6_table(const K6Arrays& a, uint32_t n_anom_host, double ln10, int score_threshold, int with_scores, hipStream_t s);
 // ComputeProbScore's combination (BreakDancer.cpp:56-69) + PhredQ (:459-465) for every candidate of the final table
-uint32_t k6_score_grid(const K6Arrays& a);  // workgroups of k6_finish_kernel == entries of K6Arrays::printed_host
+uint32_t k6_score_grid(const K6Arrays& a);  // workgroups of k6_score_kernel == entries of K6Arrays::printed_host
 
 }  // namespace bdx

@@ -1460,26 +1460,30 @@ __global__ __launch_bounds__(kScanBlock) void k6_ranksort_kernel(K6Arrays a) {
 
 __global__ __launch_bounds__(kInsThreads) void k6_insert_kernel(K6Arrays a) { InsertJob{a}(); }
 
-__global__ __launch_bounds__(kScanBlock) void k6_finish_kernel(K6Arrays a, double ln10, int score_threshold, int with_scores) {
+// Round 6: two launches again.  The single launch gave every workgroup the candidates of ITS 256 vertices to finish: at a GPU's share of a
+// genome the densest workgroups had three 64-candidate passes per wave to work through, one after the other -- gather, K5, scores, ~25 us a
+// pass -- while most had none left: 110-125 us for 55 k candidates, 75 us for the 6.5 k of a -t run (profiles/r06_table_split.txt).
+//   k6_place_kernel   the look-back scan over the start vertices; every vertex writes where its candidates come from (staging slot or host
+//                     entry), their first entries in the two flat lists and, for the merge of a sharded run's tables, the vertex itself,
+//                     at the candidates' places in the table
+//   k6_score_kernel   a wave per 64 CONSECUTIVE candidates of the table, whichever vertices they belong to: records through LDS, K5,
+//                     scores, one contiguous write
+__global__ __launch_bounds__(kScanBlock) void k6_place_kernel(K6Arrays a) {
     __shared__ U4 s_ws[kScanBlock / 64];
     __shared__ uint32_t s_prefix[4];
     __shared__ uint32_t s_T[kFinT];
-    __shared__ uint32_t s_from[kFinList];
-    __shared__ uint2 s_bg[kFinList];
-    __shared__ uint32_t s_vx[kFinList];   // the vertex a listed candidate is placed at (order keys for the merge of a sharded run's tables)
-    __shared__ uint32_t s_rec[kScanBlock / 64][64 * kSvWords];
-    __shared__ uint32_t s_range[2];
-    __shared__ uint32_t s_printed;
+    __shared__ uint32_t s_ex[3][kScanBlock];
+    __shared__ uint32_t s_lohi[2];
     const uint32_t tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6;
+    const int w = tid >> 6;
     const uint32_t n = a.counts->n_regions;
     const uint32_t bid = blockIdx.x, base = bid * kScanBlock;
-    KPROF(32768u + bid * 4 + w, 0);
-    if (base >= n) {
-        if (tid == 0 && a.printed_host) a.printed_host[bid] = 0;
-        return;
+    if (w == 0 && bid < 16384u) KPROF(32768u + bid, 0);
+    if (bid == 0 && tid == 0 && (uint64_t)gridDim.x * kScanBlock < n) {   // (the host sized the launch for fewer regions than there are: cannot happen, and must not pass)
+        a.counts->overflow = 1;
+        if (a.counts_host2) a.counts_host2->overflow = 1;
     }
-    if (tid == 0) s_printed = 0;
+    if (base >= n) return;
     const uint32_t j = base + tid;
     const bool valid = j < n;
     const U4 e = valid ? U4{a.own_nsv[j], a.own_nacc[j], a.own_ncn[j], 0u} : U4{0u, 0u, 0u, 0u};
@@ -1490,17 +1494,20 @@ __global__ __launch_bounds__(kScanBlock) void k6_finish_kernel(K6Arrays a, doubl
     if (t_lds)
         for (uint32_t i = tid; i < nh; i += kScanBlock) s_T[i] = a.ins_T[i];
     U4 tot;
-    const U4 inc_local = block_incl_scan(e, s_ws, &tot);  // (its barriers also publish s_T and s_printed)
-    KPROF(32768u + bid * 4 + w, 1);
+    const U4 inc_local = block_incl_scan(e, s_ws, &tot);  // (its barriers also publish s_T)
+    if (w == 0 && bid < 16384u) KPROF(32768u + bid, 1);
     const U4 carry = lookback_exclusive<U4>(tot, a.lb_state, a.lb_stamp, bid, s_prefix);
-    KPROF(32768u + bid * 4 + w, 2);
+    if (w == 0 && bid < 16384u) KPROF(32768u + bid, 2);
     const U4 inc = carry + inc_local;
     const uint32_t* Tt = t_lds ? s_T : a.ins_T;
     uint32_t hb0 = 0, hb1 = 0;
     if (valid && nh) {
         hb0 = count_below(Tt, nh, j);
-        hb1 = hb0;  // (entries with threshold j follow each other: a look ahead instead of a second search)
-        while (hb1 < nh && Tt[hb1] == j) ++hb1;
+        hb1 = hb0;  // (entries with threshold j follow each other: a short look ahead, then a second search -- a -t run's vertices have dozens)
+        for (int g = 0; hb1 < nh && Tt[hb1] == j; ++g) {
+            ++hb1;
+            if (g == 3) { hb1 = count_below(Tt, nh, j + 1); break; }
+        }
     }
     const uint32_t ex_sv = inc.x - e.x, ex_l = inc.y - e.y, ex_c = inc.z - e.z;
     if (valid && j == n - 1) {
@@ -1512,145 +1519,153 @@ __global__ __launch_bounds__(kScanBlock) void k6_finish_kernel(K6Arrays a, doubl
             if (a.counts_host2) a.counts_host2->overflow = 1;
         }
     }
-    // the workgroup's slice of the table: [P0, P1) (nothing is placed past a capacity: the last vertex reports that)
+    // (nothing is placed past a capacity: the last vertex reports that, and the score kernel stays away from the table)
     const bool wg_ok = !(carry.x + tot.x + nh > a.sv_cap || carry.y + tot.y + h_l > a.term_cap || carry.z + tot.z + h_c > a.cn_cap);
-    if (tid == 0) s_range[0] = ex_sv + hb0;
-    if (valid && (j == n - 1 || tid == kScanBlock - 1)) s_range[1] = inc.x + hb1;
+    if (!wg_ok) return;   // (the same answer in every thread of the workgroup)
+    // The inserted candidates that come right before a vertex's own: the workgroup's vertices' entries of the inserted list lie together,
+    // [lo, hi), and are placed by ALL its threads -- a -t run hangs every candidate of a flush on ONE vertex (~50 at a genome share), and that
+    // vertex's thread placed them one dependent load after the other: 52 us of a 75 us launch
+    s_ex[0][tid] = ex_sv; s_ex[1][tid] = ex_l; s_ex[2][tid] = ex_c;
+    if (tid == 0) { s_lohi[0] = nh ? count_below(Tt, nh, base) : 0u; s_lohi[1] = nh ? count_below(Tt, nh, min(n, base + kScanBlock)) : 0u; }
     __syncthreads();
-    const uint32_t P0 = s_range[0], P1 = wg_ok ? s_range[1] : s_range[0];
-    const uint32_t lb_own = ex_l + a.ins_pre_l[hb1], cb_own = ex_c + a.ins_pre_c[hb1];
-    for (uint32_t win = P0; win < P1; win += kFinList) {
-        if (valid && (hb1 > hb0 || e.x)) {
-            for (uint32_t jj = hb0; jj < hb1; ++jj) {  // the inserted candidates that come right before this vertex's own
-                const uint32_t pos = ex_sv + jj - win;
-                if (pos < kFinList) {
-                    s_from[pos] = a.ins_src[jj];
-                    s_bg[pos] = make_uint2(ex_l + a.ins_pre_l[jj], ex_c + a.ins_pre_c[jj]);
-                    s_vx[pos] = j;
-                }
+    for (uint32_t jj = s_lohi[0] + tid; jj < s_lohi[1]; jj += kScanBlock) {
+        const uint32_t v = Tt[jj], vt = v - base;   // (its vertex: one of this workgroup's)
+        const uint32_t pos = s_ex[0][vt] + jj;
+        a.sv_src[pos] = a.ins_src[jj];
+        a.sv_begin[pos] = make_uint2(s_ex[1][vt] + a.ins_pre_l[jj], s_ex[2][vt] + a.ins_pre_c[jj]);
+        if (a.sv_vx) a.sv_vx[pos] = v;
+    }
+    if (!valid || !e.x) return;
+    uint32_t lb = ex_l + a.ins_pre_l[hb1], cb = ex_c + a.ins_pre_c[hb1], slot = slot0;
+    for (uint32_t q = 0; q < e.x; ++q) {
+        const uint32_t pos = ex_sv + hb1 + q;
+        a.sv_src[pos] = slot;
+        a.sv_begin[pos] = make_uint2(lb, cb);
+        if (a.sv_vx) a.sv_vx[pos] = j;
+        if (q + 1 < e.x) {  // (a single candidate's entries are the vertex's totals: nothing to look up)
+            lb += (uint32_t)a.sv_stage[slot].sv.lib_count;
+            cb += (uint32_t)a.sv_stage[slot].sv.cn_count;
+            slot = a.slot_next[slot];
+        }
+    }
+}
+
+__global__ __launch_bounds__(kScanBlock) void k6_score_kernel(K6Arrays a, double ln10, int score_threshold, int with_scores) {
+    __shared__ uint32_t s_rec[kScanBlock / 64][64 * kSvWords];
+    __shared__ uint32_t s_fromw[kScanBlock / 64][64];
+    __shared__ uint32_t s_printed;
+    const uint32_t tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const uint32_t bid = blockIdx.x;
+    const uint32_t kp = 32768u + 16384u + (bid * 4 + w < 16384u ? bid * 4 + w : 16383u);
+    (void)kp;
+    KPROF(kp, 0);
+    if (tid == 0) s_printed = 0;
+    __syncthreads();
+    const uint32_t n_sv = a.counts->overflow ? 0u : a.counts->n_sv_dev;
+    for (uint32_t c0 = (bid * (kScanBlock / 64) + (uint32_t)w) * 64u; c0 < n_sv; c0 += gridDim.x * kScanBlock) {
+        const uint32_t cnt = min(64u, n_sv - c0);
+        const bool act = (uint32_t)lane < cnt;
+        uint32_t* rec = s_rec[w];
+        const uint32_t from = act ? a.sv_src[c0 + lane] : 0u;
+        const uint2 bg = act ? a.sv_begin[c0 + lane] : make_uint2(0u, 0u);
+        s_fromw[w][lane] = from;
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i = lane; i < cnt * kSvWords; i += 64) {  // gather the records from the staging slots / the host's list
+            const uint32_t sv = i / kSvWords, wd = i - sv * kSvWords;
+            const uint32_t f = s_fromw[w][sv];
+            const uint32_t* src = (f & 0x80000000u) ? (const uint32_t*)(a.hs_rec + (f & 0x7FFFFFFFu)) : (const uint32_t*)(a.sv_stage + f);
+            rec[i] = src[wd];
+        }
+        __builtin_amdgcn_wave_barrier();
+        KPROF(kp, 3);
+        SvOut* o = (SvOut*)rec + (act ? lane : 0);
+        const bool hosted = (from & 0x80000000u) != 0;
+        const int32_t nl = act ? o->sv.lib_count : 0, ncn = act ? o->sv.cn_count : 0;
+        const int32_t l0 = o->sv.lib_begin, k0 = o->sv.cn_begin;  // (a host candidate's entries in the host's lists)
+        if (act) { o->sv.lib_begin = (int32_t)bg.x; o->sv.cn_begin = (int32_t)bg.y; }
+        int32_t max_nl = nl, max_ncn = ncn;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { max_nl = max(max_nl, __shfl_xor(max_nl, off)); max_ncn = max(max_ncn, __shfl_xor(max_ncn, off)); }
+        // one candidate per lane: K5 for its terms (all 64 lanes take part: a term with a long series is summed by the whole
+        // wave); the entries of the two flat lists go straight to the host's arrays
+        double logp = 0.0, err = 0.0;
+        for (int32_t q = 0; q < max_nl; ++q) {
+            const bool a2 = q < nl;
+            double lam = 1.0;
+            int32_t k = 0, li = 0;
+            if (a2) {
+                if (hosted) { lam = a.hs_lambda[l0 + q]; k = a.hs_lib_pairs[l0 + q]; li = a.hs_lib_index[l0 + q]; }
+                else { const LibStage t = a.lib_stage[(size_t)from * a.lib_stride + q]; lam = t.lambda; k = t.rc; li = t.lib; }
             }
-            uint32_t lb = lb_own, cb = cb_own, slot = slot0;
-            for (uint32_t q = 0; q < e.x; ++q) {
-                const uint32_t pos = ex_sv + hb1 + q - win;
-                if (pos < kFinList) {
-                    s_from[pos] = slot;
-                    s_bg[pos] = make_uint2(lb, cb);
-                    s_vx[pos] = j;
-                } else if ((int32_t)pos > 0) {
-                    break;  // past this pass's window
-                }
-                if (q + 1 < e.x) {  // (a single candidate's entries are the vertex's totals: nothing to look up)
-                    lb += (uint32_t)a.sv_stage[slot].sv.lib_count;
-                    cb += (uint32_t)a.sv_stage[slot].sv.cn_count;
-                    slot = a.slot_next[slot];
-                }
+            const double lt = poisson_term(lam, k, a2, lane);
+            if (a2) {
+                a.lib_index[bg.x + q] = li;
+                a.lib_pairs[bg.x + q] = k;
+                if (a.ltail_host) a.ltail_host[bg.x + q] = lt;
+                const double tmp_a = __dsub_rn(lt, err);
+                const double tmp_b = __dadd_rn(logp, tmp_a);
+                err = __dsub_rn(__dsub_rn(tmp_b, logp), tmp_a);
+                logp = tmp_b;
             }
         }
-        __syncthreads();
-        const uint32_t cntw = min(kFinList, P1 - win);
-        for (uint32_t c0 = (uint32_t)w * 64; c0 < cntw; c0 += kScanBlock) {
-            const uint32_t cnt = min(64u, cntw - c0);
-            const bool act = (uint32_t)lane < cnt;
-            uint32_t* rec = s_rec[w];
-            for (uint32_t i = lane; i < cnt * kSvWords; i += 64) {  // gather the records from the staging slots / the host's list
-                const uint32_t sv = i / kSvWords, wd = i - sv * kSvWords;
-                const uint32_t from = s_from[c0 + sv];
-                const uint32_t* src = (from & 0x80000000u) ? (const uint32_t*)(a.hs_rec + (from & 0x7FFFFFFFu)) : (const uint32_t*)(a.sv_stage + from);
-                rec[i] = src[wd];
+        for (int32_t t = 0; t < max_ncn; ++t) {
+            if (t < ncn) {
+                int32_t key;
+                float value;
+                if (hosted) { key = a.hs_cn_key[k0 + t]; value = a.hs_cn_value[k0 + t]; }
+                else { const CnStage cn = a.cn_stage[(size_t)from * a.nkeys + t]; key = cn.key; value = cn.value; }
+                a.cn_key[bg.y + t] = key;
+                a.cn_value[bg.y + t] = value;
             }
-            __builtin_amdgcn_wave_barrier();
-            KPROF(32768u + bid * 4 + w, 3);
-            SvOut* o = (SvOut*)rec + (act ? lane : 0);
-            const uint32_t from = act ? s_from[c0 + lane] : 0u;
-            const uint2 bg = act ? s_bg[c0 + lane] : make_uint2(0u, 0u);
-            const bool hosted = (from & 0x80000000u) != 0;
-            const int32_t nl = act ? o->sv.lib_count : 0, ncn = act ? o->sv.cn_count : 0;
-            const int32_t l0 = o->sv.lib_begin, k0 = o->sv.cn_begin;  // (a host candidate's entries in the host's lists)
-            if (act) { o->sv.lib_begin = (int32_t)bg.x; o->sv.cn_begin = (int32_t)bg.y; }
-            int32_t max_nl = nl, max_ncn = ncn;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { max_nl = max(max_nl, __shfl_xor(max_nl, off)); max_ncn = max(max_ncn, __shfl_xor(max_ncn, off)); }
-            // one candidate per lane: K5 for its terms (all 64 lanes take part: a term with a long series is summed by the whole
-            // wave); the entries of the two flat lists go straight to the host's arrays
-            double logp = 0.0, err = 0.0;
-            for (int32_t q = 0; q < max_nl; ++q) {
-                const bool a2 = q < nl;
-                double lam = 1.0;
-                int32_t k = 0, li = 0;
-                if (a2) {
-                    if (hosted) { lam = a.hs_lambda[l0 + q]; k = a.hs_lib_pairs[l0 + q]; li = a.hs_lib_index[l0 + q]; }
-                    else { const LibStage t = a.lib_stage[(size_t)from * a.lib_stride + q]; lam = t.lambda; k = t.rc; li = t.lib; }
-                }
-                const double lt = poisson_term(lam, k, a2, lane);
-                if (a2) {
-                    a.lib_index[bg.x + q] = li;
-                    a.lib_pairs[bg.x + q] = k;
-                    if (a.ltail_host) a.ltail_host[bg.x + q] = lt;
-                    const double tmp_a = __dsub_rn(lt, err);
-                    const double tmp_b = __dadd_rn(logp, tmp_a);
-                    err = __dsub_rn(__dsub_rn(tmp_b, logp), tmp_a);
-                    logp = tmp_b;
-                }
-            }
-            for (int32_t t = 0; t < max_ncn; ++t) {
-                if (t < ncn) {
-                    int32_t key;
-                    float value;
-                    if (hosted) { key = a.hs_cn_key[k0 + t]; value = a.hs_cn_value[k0 + t]; }
-                    else { const CnStage cn = a.cn_stage[(size_t)from * a.nkeys + t]; key = cn.key; value = cn.value; }
-                    a.cn_key[bg.y + t] = key;
-                    a.cn_value[bg.y + t] = value;
-                }
-            }
-            bool pr = false;
-            if (act && with_scores) {
-                const double phred_tmp = __ddiv_rn(__dmul_rn(-10.0, logp), ln10);
-                const double r = __dadd_rn(phred_tmp, 0.5);
-                int phred;
-                if (phred_tmp > 99.0) phred = 99;
-                else if (r != r || r >= 2147483648.0 || r <= -2147483649.0) phred = INT32_MIN;
-                else phred = (int)r;
-                pr = phred > score_threshold;
-                o->sv.logp = logp;
-                o->sv.score = phred;
-                o->sv.printed = pr ? 1 : 0;
-            }
-            if (a.sv_key && act) {   // placed at vertex T: before T's own candidates unless the traversal started at T itself
-                const unsigned long long T = s_vx[c0 + lane], st = o->start;
-                a.sv_key[win + c0 + lane] = (T << kKeyShiftT) | (T == st ? 1ull << 33 : 0ull) | (st << kKeyShiftStart);
-            }
-            const uint32_t npr = (uint32_t)__popcll(__ballot(pr));
-            if (lane == 0 && npr) atomicAdd(&s_printed, npr);
-            KPROF(32768u + bid * 4 + w, 4);
-            __builtin_amdgcn_wave_barrier();
-            if (a.wire_rows) {
-                // the row as it crosses the link: 12 words (SvWire).  Every lane takes its own record out of the slice, then the packed rows
-                // go into the slice's front and leave as one contiguous block
-                SvWire wr{};
-                if (act) {
-                    wr.pos[0] = o->sv.pos[0]; wr.pos[1] = o->sv.pos[1]; wr.region[0] = o->sv.region[0]; wr.region[1] = o->sv.region[1];
-                    wr.size = o->sv.size; wr.score = o->sv.score; wr.num_reads = o->sv.num_reads; wr.allele_frequency = o->sv.allele_frequency;
-                    wr.logp = o->sv.logp; wr.start = o->start;
-                    wr.bits = ((uint32_t)o->sv.lib_count & 255u) | (((uint32_t)o->sv.cn_count & 255u) << 8) | (((uint32_t)o->sv.flag & 15u) << 16) |
-                              ((o->grp_mask & 7u) << 20) | ((o->sv.printed ? 1u : 0u) << 23);
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (act) {
-                    uint32_t* q = rec + lane * kWireWords;
-                    const uint32_t* src = (const uint32_t*)&wr;
-#pragma unroll
-                    for (int k = 0; k < kWireWords; ++k) q[k] = src[k];
-                }
-                __builtin_amdgcn_wave_barrier();
-                uint32_t* dst = (uint32_t*)a.sv_out + (size_t)(win + c0) * kWireWords;
-                for (uint32_t i = lane; i < cnt * kWireWords; i += 64) dst[i] = rec[i];
-            } else {
-                uint32_t* dst = (uint32_t*)(a.sv_out + win + c0);
-                for (uint32_t i = lane; i < cnt * kSvWords; i += 64) dst[i] = rec[i];
-            }
-            __builtin_amdgcn_wave_barrier();  // (the wave's next 64 candidates reuse the slice)
         }
-        __syncthreads();  // the lists are rewritten by the next pass
+        bool pr = false;
+        if (act && with_scores) {
+            const double phred_tmp = __ddiv_rn(__dmul_rn(-10.0, logp), ln10);
+            const double r = __dadd_rn(phred_tmp, 0.5);
+            int phred;
+            if (phred_tmp > 99.0) phred = 99;
+            else if (r != r || r >= 2147483648.0 || r <= -2147483649.0) phred = INT32_MIN;
+            else phred = (int)r;
+            pr = phred > score_threshold;
+            o->sv.logp = logp;
+            o->sv.score = phred;
+            o->sv.printed = pr ? 1 : 0;
+        }
+        if (a.sv_key && act) {   // placed at vertex T: before T's own candidates unless the traversal started at T itself
+            const unsigned long long T = a.sv_vx[c0 + lane], st = o->start;
+            a.sv_key[c0 + lane] = (T << kKeyShiftT) | (T == st ? 1ull << 33 : 0ull) | (st << kKeyShiftStart);
+        }
+        const uint32_t npr = (uint32_t)__popcll(__ballot(pr));
+        if (lane == 0 && npr) atomicAdd(&s_printed, npr);
+        KPROF(kp, 4);
+        __builtin_amdgcn_wave_barrier();
+        if (a.wire_rows) {
+            // the row as it crosses the link: 12 words (SvWire).  Every lane takes its own record out of the slice, then the packed rows
+            // go into the slice's front and leave as one contiguous block
+            SvWire wr{};
+            if (act) {
+                wr.pos[0] = o->sv.pos[0]; wr.pos[1] = o->sv.pos[1]; wr.region[0] = o->sv.region[0]; wr.region[1] = o->sv.region[1];
+                wr.size = o->sv.size; wr.score = o->sv.score; wr.num_reads = o->sv.num_reads; wr.allele_frequency = o->sv.allele_frequency;
+                wr.logp = o->sv.logp; wr.start = o->start;
+                wr.bits = ((uint32_t)o->sv.lib_count & 255u) | (((uint32_t)o->sv.cn_count & 255u) << 8) | (((uint32_t)o->sv.flag & 15u) << 16) |
+                          ((o->grp_mask & 7u) << 20) | ((o->sv.printed ? 1u : 0u) << 23);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (act) {
+                uint32_t* q = rec + lane * kWireWords;
+                const uint32_t* src = (const uint32_t*)&wr;
+#pragma unroll
+                for (int k = 0; k < kWireWords; ++k) q[k] = src[k];
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint32_t* dst = (uint32_t*)a.sv_out + (size_t)c0 * kWireWords;
+            for (uint32_t i = lane; i < cnt * kWireWords; i += 64) dst[i] = rec[i];
+        } else {
+            uint32_t* dst = (uint32_t*)(a.sv_out + c0);
+            for (uint32_t i = lane; i < cnt * kSvWords; i += 64) dst[i] = rec[i];
+        }
+        __builtin_amdgcn_wave_barrier();  // (the wave's next 64 candidates reuse the slice)
     }
     __syncthreads();
     if (tid == 0) {
@@ -1659,7 +1674,7 @@ __global__ __launch_bounds__(kScanBlock) void k6_finish_kernel(K6Arrays a, doubl
         // that copies the total (system-scope atomics on host memory are ~1 us each and serialise)
         if (a.printed_host) a.printed_host[bid] = s_printed;
     }
-    KPROF(32768u + bid * 4 + w, 5);
+    KPROF(kp, 5);
 }
 
 // the end of the run: printed count and the word the host polls
@@ -1724,13 +1739,17 @@ void launch_k6_walk(const K6Arrays& a, uint32_t n_anom_host, hipStream_t s) {
     if (a.rank_part) hipLaunchKernelGGL(k6_ranksort_kernel, dim3(kRankGrid), dim3(kScanBlock), 0, s, a);
 }
 
-uint32_t k6_score_grid(const K6Arrays& a) { return scan_grid(a.cap, 1); }  // workgroups of k6_finish_kernel (one per 256 regions of the upper bound)
+// workgroups of k6_score_kernel (a wave per 64 candidates, grid-stride: the host does not know how many there are) == entries of
+// K6Arrays::printed_host
+uint32_t k6_score_grid(const K6Arrays& a) { return std::max(1u, std::min(1024u, (a.sv_cap + kScanBlock - 1) / kScanBlock)); }
 
 // the merged list of the candidates that are placed by key, then the table itself
 void launch_k6_table(const K6Arrays& a, uint32_t n_anom_host, double ln10, int score_threshold, int with_scores, hipStream_t s) {
     if (n_anom_host) {
         hipLaunchKernelGGL(k6_insert_kernel, dim3(1), dim3(kInsThreads), 0, s, a);
-        hipLaunchKernelGGL(k6_finish_kernel, dim3(scan_grid(n_anom_host, 1)), dim3(kScanBlock), 0, s, a, ln10, score_threshold, with_scores);
+        // (the placement's launch: for the regions the pair groups' report named where the host has read it, for their upper bound otherwise)
+        hipLaunchKernelGGL(k6_place_kernel, dim3(scan_grid(a.fin_regions ? a.fin_regions : a.cap, 1)), dim3(kScanBlock), 0, s, a);
+        hipLaunchKernelGGL(k6_score_kernel, dim3(k6_score_grid(a)), dim3(kScanBlock), 0, s, a, ln10, score_threshold, with_scores);
     }
     if (!a.printed_host || a.flag_done) hipLaunchKernelGGL(k6_done_kernel, dim3(1), dim3(64), 0, s, a);
 }
