@@ -1461,12 +1461,6 @@ int bdx_dist_run(bdx_dist* d) {
         }
         U->counts = *U->h_counts.as<StageCounts>();
         if (U->counts.overflow) return dfail(d, BDX_EINTERNAL, "group list overflow (gathered components)");
-        {
-            uint32_t berr = 0;
-            DHIP(d, hipMemcpyAsync(&berr, B + o_err, 4, hipMemcpyDeviceToHost, su));   // (behind the kernels that have just reported)
-            DHIP(d, hipStreamSynchronize(su));
-            if (berr) return dfail(d, BDX_EINTERNAL, "a gathered pair group names a region outside the genome's table");
-        }
         decode_groups(U, U->h_groups.as<GroupRec>(), U->counts.n_groups, 0);
         U->last_big_groups = (int64_t)U->counts.n_groups + U->counts.n_groups_big;
         if (U->counts.n_groups) {   // (the host's share of this walk reads the table in pinned memory: its copy ran beside the device's walk)
@@ -1480,6 +1474,13 @@ int bdx_dist_run(bdx_dist* d) {
         U->counts.last_maxq = lm;
         DCTX(d, U, do_k6_table(U));
         DCTX(d, U, finish_table(U));
+        {   // (the bucket kernel's verdict, read once the table is there: a wait for it in front of the host's share of the walk kept the host from
+            // enqueueing the table stage while the device walked -- 40 us of rank 0's time alone; a group outside the table is skipped by the kernels)
+            uint32_t berr = 0;
+            DHIP(d, hipMemcpyAsync(&berr, B + o_err, 4, hipMemcpyDeviceToHost, su));
+            DHIP(d, hipStreamSynchronize(su));
+            if (berr) return dfail(d, BDX_EINTERNAL, "a gathered pair group names a region outside the genome's table");
+        }
         u_counts[0] = U->n_sv_total; u_counts[1] = U->n_terms_total; u_counts[2] = U->n_cn_total; u_counts[3] = U->n_printed;
         u_counts[4] = U->n_sv_host; u_counts[6] = U->n_groups_total; u_counts[7] = U->counts.n_old; u_counts[8] = U->counts.n_groups;
         d->phase_ms[17] = ms_between(tw0, std::chrono::steady_clock::now()) - d->phase_ms[16];

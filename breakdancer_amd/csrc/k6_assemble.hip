@@ -1175,6 +1175,9 @@ __device__ void InsertJob::operator()() const {
     // the host's keys and counts come over the link: ask for them before anything waits
     uint64_t* hk = nh <= kInsLds ? s_hk : a.hs_key_dev;
     for (uint32_t i = tid; i < nh; i += kThreads) hk[i] = a.hs_key[i];
+    uint32_t hc[kInsLds / kThreads];   // (the counts of this thread's host entries on the bucket path: the same round trip over the link as the keys')
+#pragma unroll
+    for (uint32_t q = 0; q < kInsLds / kThreads; ++q) hc[q] = (nh <= kInsLds && tid + q * kThreads < nh) ? a.hs_cnt[tid + q * kThreads] : 0u;
     const uint32_t n = nh + nd;
     if (n > a.sv_cap) {  // cannot happen: every candidate consumes at least one read pair
         if (tid == 0) { a.counts->overflow = 1; a.counts->n_ins = 0; a.ins_pre_l[0] = 0; a.ins_pre_c[0] = 0; }
@@ -1265,9 +1268,10 @@ __device__ void InsertJob::operator()() const {
                     if (small) s_cnt[pos] = cnt[k];
                     else { a.ins_pre_l[pos] = cnt[k] & 0xffffu; a.ins_pre_c[pos] = cnt[k] >> 16; }
                 }
+            static_assert(kInsLds / kThreads == 2, "two prefetched host counts per thread");
             for (uint32_t j = tid; j < nh; j += kThreads) {
                 const uint64_t x = hk[j];
-                const uint32_t pos = j + below(x, bucket_of(x)), c = a.hs_cnt[j];
+                const uint32_t pos = j + below(x, bucket_of(x)), c = nh <= kInsLds ? (j < kThreads ? hc[0] : hc[1]) : a.hs_cnt[j];
                 a.ins_T[pos] = (uint32_t)(x >> kKeyShiftT);
                 a.ins_src[pos] = 0x80000000u | j;
                 if (small) s_cnt[pos] = c;

@@ -6,7 +6,7 @@ C=breakdancer_amd/csrc
 mkdir -p variants
 name=$1; shift
 objs=""
-for o in k1_classify k2_compact k3_regions k4_join k5_poisson k6_assemble k7_exchange k9_shard kz_inflate kb_records bdx_api bdx_walk bdx_walk_reads; do
+for o in k1_classify k2_compact k3_regions k4_join k5_poisson k6_assemble k7_exchange k9_shard kz_inflate kb_records kc_insert_stats bdx_api bdx_walk bdx_walk_reads; do
     use=$C/$o.o
     for r in "$@"; do case "$(basename $r)" in ${o%%_*}_*) use=$r;; esac; done
     objs="$objs $use"
