@@ -1424,7 +1424,6 @@ __device__ void InsertJob::operator()() const {
 // 6 KiB write (single scattered stores over PCIe are several times slower); the list entries of a wave's candidates are
 // neighbours too.  (Three launches before: block sums, rescan + placement into HBM lists, score kernel; 52 us -> see DESIGN.md.)
 constexpr int kSvWords = sizeof(SvOut) / 4;
-constexpr uint32_t kFinList = 1024;  // candidates of a workgroup placed per pass (more: further passes)
 constexpr uint32_t kFinT = 1024;     // thresholds of the inserted list kept in LDS (more: searched in HBM)
 
 // The device's insertion list (order keys of the candidates whose traversal started in an earlier flush window, any order) ranked by

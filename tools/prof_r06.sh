@@ -13,8 +13,11 @@ rm -rf /tmp/gp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gp -o p -- python $R/tools/genome_probe.py --repeat 5 > $O/r06_genome_probe.txt 2>&1 < /dev/null
 f=$(find /tmp/gp -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/r06_genome_kernel_stats.csv
 cd $R
+# one context alone (bdx_run repeated on resident records), default options and -t, kernel by kernel
+bash tools/single_trace.sh $O > $O/r06_single_context_trace.txt 2>&1 < /dev/null
+cd $R
 # run-time switches A/B on one box: the LDS-first join, the region table's forward, the walk's lanes
-timeout 500 python tools/genome_ab.py --rounds 3 default walk_lanes=16 > $O/r06_genome_ab.txt 2>&1 < /dev/null
+timeout 500 python tools/genome_ab.py --rounds 3 default ins_plain=1 ins_plain=2 walk_lanes=16 > $O/r06_genome_ab.txt 2>&1 < /dev/null
 # HBM traffic per kernel (PMC, one pass per counter) of a genome-share run
 timeout 700 bash tools/pmc_traffic.sh genome > $O/r06_pmc_genome.txt 2>&1 < /dev/null
 # the multi-GPU protocol with the ranks as threads on this GPU: 2 and 8 ranks, default options and -t, against the single context
