@@ -123,62 +123,6 @@ def main():
         stats("records -> host, end", sc[g, 5] - sc[g, 4])
         stats("wave end", sc[hs, 5] - s0)
     if have1:
-        L.bdx_debug_kprof1.argtypes = [C.c_void_p, C.c_size_t]
-    for _ in range(5):
-        bd.run()
-    torch.cuda.synchronize()
-    if have1:
-        L.bdx_debug_kprof1(buf1.ctypes.data_as(C.c_void_p), buf1.size)
-    L.bdx_debug_kprof(buf.ctypes.data_as(C.c_void_p), buf.size)  # (clears the device buffer)
-    if have3:
-        L.bdx_debug_kprof3(buf3.ctypes.data_as(C.c_void_p), buf3.size)
-    bd.run()
-    torch.cuda.synchronize()
-    rc = L.bdx_debug_kprof(buf.ctypes.data_as(C.c_void_p), buf.size)
-    assert rc == 0, rc
-    t = buf.reshape(65536, 8).astype(np.int64)
-    if have3:
-        L.bdx_debug_kprof3(buf3.ctypes.data_as(C.c_void_p), buf3.size)
-        t3 = buf3.reshape(65536, 8).astype(np.int64)
-    split = bd.walk_split()
-    print("reads", n, "svs", bd.summary().get("n_sv") if hasattr(bd.summary(), "get") else "", "walk split", split)
-
-    def stats(name, x):
-        x = np.asarray(x, dtype=np.float64) / 100.0  # us
-        if len(x) == 0:
-            print("  %-34s (none)" % name)
-            return
-        print("  %-34s n=%6d  min %7.2f  p50 %7.2f  p90 %7.2f  max %7.2f us" % (name, len(x), x.min(), np.percentile(x, 50), np.percentile(x, 90), x.max()))
-
-    # walk kernel: one lane per component, rows = workgroup (clocks of its lane 0 / of the whole wave at the end)
-    own = t[:32768]
-    k0 = own[:, 0][own[:, 0] > 0].min()
-    have = own[:, 4] > 0  # waves whose lane 0 walks a component
-    print("walk kernel: %d waves, %d with components (clocks of lane 0)" % ((own[:, 7] > 0).sum(), have.sum()))
-    stats("wave entry", own[have, 0] - k0)
-    stats("run constants in LDS", own[have, 1] - own[have, 0])
-    stats("n_regions known", own[have, 2] - own[have, 1])
-    stats("description arrived", own[have, 3] - own[have, 2])
-    stats("tables built (phase 0)", own[have, 4] - own[have, 3])
-    stats("traversal (phase 1) + touches", own[have, 5] - own[have, 4])
-    c1 = have & (own[:, 6] > 0)
-    stats("first call", own[c1, 6] - own[c1, 5])
-    stats("rest + end", own[c1, 7] - own[c1, 6])
-    stats("wave end", own[have, 7] - k0)
-    sc = t[32768:]
-    hs = sc[:, 5] > 0
-    if hs.any():
-        s0 = sc[:, 0][sc[:, 0] > 0].min()
-        print("table kernel: %d waves entered, %d waves of workgroups with regions, %d with candidates" % ((sc[:, 0] > 0).sum(), hs.sum(), (sc[:, 4] > 0).sum()))
-        stats("wave entry", sc[:, 0][sc[:, 0] > 0] - s0)
-        stats("loads + block scan", sc[hs, 1] - sc[hs, 0])
-        stats("look-back", sc[hs, 2] - sc[hs, 1])
-        g = sc[:, 4] > 0
-        stats("placement + first gather", sc[g, 3] - sc[g, 2])
-        stats("terms, K5, scores (last chunk)", sc[g, 4] - sc[g, 3])
-        stats("records -> host, end", sc[g, 5] - sc[g, 4])
-        stats("wave end", sc[hs, 5] - s0)
-    if have1:
         L.bdx_debug_kprof1(buf1.ctypes.data_as(C.c_void_p), buf1.size)
         t1 = buf1.reshape(65536, 8).astype(np.int64)
         h = t1[:, 2] > 0
