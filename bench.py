@@ -356,6 +356,26 @@ def time_bam_cli(bam, cfg, n):
                         "runs in a child that finishes its exit behind the command's return" % n})
     if inflated and "seconds" in host:
         out["host_reader"]["inflate_mb_per_s_per_cpu"] = inflated / 1e6 / host["seconds"] / cpus
+    # bam2cfg on the same BAM: its CPU record source and `--device` (records decoded by the GPU decoder, statistics summed on
+    # the GPU); the tool stops after ~3 x libraries x 10,000 records of good quality, so both are start-up costs more than anything
+    try:
+        b2c, texts = {}, []
+        for label, extra in (("cpu", []), ("device", ["--device"])):
+            best, text = None, None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                p = subprocess.run([os.path.join(ROOT, "bin", "bam2cfg"), *extra, bam], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                dt = time.perf_counter() - t0
+                if p.returncode != 0:
+                    raise RuntimeError(p.stderr.decode()[-300:])
+                if best is None or dt < best:
+                    best, text = dt, p.stdout
+            b2c[label] = {"seconds": best, "stdout_bytes": len(text)}
+            texts.append(text)
+        b2c["same_output"] = texts[0] == texts[1]
+        out["bam2cfg"] = b2c
+    except Exception as e:  # noqa: BLE001
+        out["bam2cfg"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     return out
 
 
