@@ -55,7 +55,7 @@ EXPORTS = ["bdx_opts_default", "bdx_create", "bdx_destroy", "bdx_strerror", "bdx
            "bdx_set_host_walk", "bdx_set_debug", "bdx_use_name_check", "bdx_run_many", "bdx_get_walk_split", "bdx_trim_results", "bdx_set_stage_timing", "bdx_get_cross_window_svs",
            "bdx_set_enqueue_ahead", "bdx_was_replayed", "bdx_acquire_batch", "bdx_submit_batch", "bdx_reset_reads", "bdx_set_pass1_statistics",
            "bdx_warm_up", "bdx_set_process_option", "bdx_dist_unique_id", "bdx_dist_create", "bdx_dist_create_threads", "bdx_dist_destroy", "bdx_dist_last_error", "bdx_dist_rank",
-           "bdx_dist_world", "bdx_dist_chromosome", "bdx_dist_run", "bdx_dist_result", "bdx_dist_set_collect_support", "bdx_dist_get_phase_ms", "bdx_dist_phase_name", "bdx_dist_prepare", "bdx_dist_reset_reads", "bdx_dist_get_exchange", "bdx_dist_get_collectives", "bdx_dist_owner", "bdx_dist_plan",
+           "bdx_dist_world", "bdx_dist_chromosome", "bdx_dist_run", "bdx_dist_result", "bdx_dist_set_collect_support", "bdx_dist_get_phase_ms", "bdx_dist_phase_name", "bdx_dist_prepare", "bdx_dist_reset_reads", "bdx_dist_get_exchange", "bdx_dist_get_collectives", "bdx_dist_set_debug", "bdx_dist_owner", "bdx_dist_plan",
            "bdx_bamdec_create", "bdx_bamdec_destroy", "bdx_bamdec_last_error", "bdx_bamdec_acquire", "bdx_bamdec_submit", "bdx_bamdec_progress",
            "bdx_bamdec_finish", "bdx_bamdec_rearm", "bdx_bamdec_fetch", "bdx_bamdec_stats", "bdx_bamdec_host_ms", "bdx_merge_decoded", "bdx_append_decoded", "bdx_inflate_blocks", "bdx_insert_size_stats"]
 

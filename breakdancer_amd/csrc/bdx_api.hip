@@ -152,7 +152,7 @@ struct bdx_ctx {
     uint32_t seq = 0;
     // test / measurement switches (bdx_set_debug): all off by default
     int dbg_no_stash = 0, dbg_max_chunks = 0, dbg_finalize2_fold = 0, dbg_no_forward = 0, dbg_scan3 = 0, dbg_label_rounds = 0, dbg_k1_grid = 0,
-        dbg_end_write_value = 0, dbg_walk_lanes = 0, dbg_ins_plain = 0;
+        dbg_end_write_value = 0, dbg_walk_lanes = 0, dbg_ins_plain = 0, dbg_gather_walk = 0;
     uint32_t lb_seq = 0;              // launches of look-back scans so far: every launch stamps its words with its own number (bdx_scan.h)
     uint32_t k1_event_period = 4;     // K1 is bracketed by HIP events on every n-th run (an event pair idles the GPU ~10 us)
     float k1_ms_last = 0;
@@ -1174,7 +1174,7 @@ void decode_groups(bdx_ctx* c, const GroupRec* gr, uint32_t ng, uint32_t ph) {
 
 // K6 on the context's own regions (single-context runs): pair groups per region, SV assembly of the components that need
 // no traversal, everything else listed for the host walk; then the dense results and K5 for the device-assembled SVs.
-// part: 0 the whole first half; 1 up to and including k6_pairs_kernel, 2 the rest (a sharded run all-reduces the taint bytes in between)
+// part: 0 the whole first half; 1 up to and including k6_pairs_kernel, 2 the rest; 3 the deferred device walk; 4 the arrays and no launch
 int do_k6(bdx_ctx* c, bool force_host, int part = 0, const Sizing* sz = nullptr) {
     hipStream_t s = c->stream;
     K6Arrays a_sz{};
@@ -1308,6 +1308,7 @@ int do_k6(bdx_ctx* c, bool force_host, int part = 0, const Sizing* sz = nullptr)
         if (c->k3.host_copy_later) a.flag_regions = c->h_flags.as<uint32_t>() + 3;
         a.mirror_in_walk = (force_host || c->defer_walk) ? 0 : 1;  // (k6_walk_kernel follows k6_emit_kernel unless everything goes to the host, or the walk waits for the ranks' collectives)
     }
+    if (part == 4) return BDX_OK;   // (the arrays only: rank 0 of a sharded run whose host walks the few gathered groups -- the table stage follows)
     if (part == 1) {
         launch_k6_pairs(a, na, s);
         return BDX_OK;
@@ -2137,7 +2138,7 @@ int bdx_set_debug(bdx_ctx* c, const char* name, int value) {
     struct { const char* n; int* p; } ints[] = {{"no_stash", &c->dbg_no_stash}, {"max_chunks", &c->dbg_max_chunks}, {"finalize2_fold", &c->dbg_finalize2_fold},
                                                  {"no_forward", &c->dbg_no_forward}, {"scan3", &c->dbg_scan3}, {"label_rounds", &c->dbg_label_rounds},
                                                  {"k1_grid", &c->dbg_k1_grid}, {"end_write_value", &c->dbg_end_write_value}, {"spec_test", &c->spec_test},
-                                                 {"walk_lanes", &c->dbg_walk_lanes}, {"ins_plain", &c->dbg_ins_plain},
+                                                 {"walk_lanes", &c->dbg_walk_lanes}, {"ins_plain", &c->dbg_ins_plain}, {"gather_walk", &c->dbg_gather_walk},
                                                  {"big_walk", &c->big_walk_mode}};
     for (auto& e : ints)
         if (!strcmp(name, e.n)) { *e.p = value; return BDX_OK; }

@@ -35,6 +35,7 @@
 namespace {
 
 constexpr int kDistPhases = 18;   // bdx_dist_get_phase_ms / bdx_dist_phase_name
+constexpr size_t kGatherHostMax = 2048;   // gathered pair groups up to which rank 0's HOST walks them (more: K6 on the device)
 
 // ------------------------------------------------------------------------------------------------------------------
 // communicators
@@ -553,6 +554,14 @@ int bdx_dist_set_collect_support(bdx_dist* d, int on) {
 }
 
 bdx_ctx* bdx_dist_result(bdx_dist* d) { return d && d->ran && d->comm->rank == 0 ? d->util : nullptr; }
+
+// a test / measurement switch (bdx_set_debug's names) for the contexts of this rank: its own and, on rank 0, the result context
+int bdx_dist_set_debug(bdx_dist* d, const char* name, int value) {
+    if (!d || !name) return BDX_EINVAL;
+    int rc = d->reads ? bdx_set_debug(d->reads, name, value) : BDX_OK;
+    if (rc == BDX_OK && d->util) rc = bdx_set_debug(d->util, name, value);
+    return rc;
+}
 
 int bdx_dist_get_exchange(const bdx_dist* d, uint64_t* ctx_records_sent, uint64_t* ctx_records_received, uint64_t* gathered_bytes,
                           float* ms_total, float* ms_exchange) {
@@ -1366,6 +1375,7 @@ int bdx_dist_run(bdx_dist* d) {
         n_pairs_all += c[6]; n_groups_all += c[7]; n_old_all += c[8];
         max_sv = std::max(max_sv, (uint32_t)nsv);
     }
+    if (tracing && rank == 0) fprintf(stderr, "[bdx dist] pair groups gathered on rank 0: %zu\n", ng_all);
     if (ng_all > kMaxAnomalous / 4) return dfail(d, BDX_ELIMIT, "too many pair groups of components that span ranks");   // (the same sums on every rank)
     if (max_sv >= (1u << 26) || n_sv_all > 0xFFFFFFF0ull) return dfail(d, BDX_ELIMIT, "too many SV candidates for the merge");
     {
@@ -1403,64 +1413,116 @@ int bdx_dist_run(bdx_dist* d) {
     if (ng_all) {
         const auto tw0 = std::chrono::steady_clock::now();
         const uint32_t ng = (uint32_t)ng_all, nr = (uint32_t)NR;
-        // (K6 sizes its lists for a context's anomalous reads -- candidates and list entries <= reads / 2, each consuming a read pair; here
-        // a candidate consumes at least one pair GROUP and a list entry is a part of one: twice the groups stands for the reads)
-        const uint32_t capU = 2 * std::max(nr, ng) + 2;
-        // buckets: cnt | goff | cur ([nr + 1] each) | scan workspace | n | err, then the groups in bucket order
-        const size_t w_scan = 2 * ((size_t)scan_grid(nr + 1) + 2), o_goff = (size_t)nr + 1, o_cur = 2 * o_goff, o_ws = 3 * o_goff, o_n = o_ws + w_scan, o_err = o_n + 1,
-                     o_grp = (o_err + 1 + 3) / 4 * 4;
-        DHIP(d, d->b_bucket.ensure(o_grp * 4 + (size_t)ng * sizeof(GroupRec)));
-        uint32_t* B = d->b_bucket.as<uint32_t>();
-        GroupRec* sorted = (GroupRec*)(B + o_grp);
-        SegList seg_grp{};
-        seg_grp.n = world;
-        {
-            uint32_t a = 0;
-            for (int q = 0; q < world; ++q) { seg_grp.off[q] = grp_off[q] / 8; seg_grp.start[q] = a; a += (uint32_t)v5[(size_t)q * 10]; }
-            seg_grp.start[world] = a;
+        // FEW gathered groups (a real genome's inter-chromosomal clusters: dozens of components) are walked by rank 0's HOST: K6 once more on
+        // the device is twenty launches -- 0.3 ms of rank 0's time alone for 52 components -- where the host walks them in microseconds.  MANY
+        // (thousands of translocations) stay on the device: round 5's host took 1.1-1.3 ms for 13 k groups.  Test switch "gather_walk" on the
+        // result context: 1 always the device, 2 always the host.
+        const bool host_gather = U->dbg_gather_walk == 2 || (U->dbg_gather_walk == 0 && ng_all <= kGatherHostMax);
+        uint32_t* bucket_err = nullptr;   // (device walk: the bucket kernel's verdict)
+        if (host_gather) {
+            hipStream_t su = U->stream;
+            const uint32_t capU = 2 * std::max(nr, ng) + 2;   // (sized as for the device walk below: a candidate consumes at least one pair group)
+            DHIP(d, U->b_counts.ensure(sizeof(StageCounts))); DHIP(d, U->h_counts.ensure(sizeof(StageCounts)));
+            DHIP(d, U->b_cnt.ensure((size_t)ncnt * 4)); DHIP(d, U->b_p1.ensure(sizeof(Pass1))); DHIP(d, U->b_kdens.ensure(64 * 4));
+            DHIP(d, U->h_flags.ensure(64)); DHIP(d, U->h_groups.ensure(((size_t)ng + 1) * sizeof(GroupRec)));
+            // the gathered groups: out of every rank's package into pinned memory, behind the gather
+            {
+                GroupRec* hg = U->h_groups.as<GroupRec>();
+                size_t at = 0;
+                for (int q = 0; q < world; ++q) {
+                    const size_t nq = (size_t)v5[(size_t)q * 10];
+                    if (nq) DHIP(d, hipMemcpyAsync(hg + at, (const char*)d->b_all.p + grp_off[q], nq * sizeof(GroupRec), hipMemcpyDeviceToHost, s));
+                    at += nq;
+                }
+            }
+            DHIP(d, hipEventRecord(d->ev_side, s));   // (the gather, the region table placed behind it, the groups' copies)
+            DHIP(d, hipStreamWaitEvent(su, d->ev_side, 0));
+            {
+                StageCounts sc{};
+                sc.n_regions = nr; sc.last_maxq = lm;
+                memcpy(UP + L.up_counts, &sc, sizeof(sc));
+                const uint32_t* st_up = UP + L.up_stats;
+                UploadList ul{};
+                ul.copy(U->b_counts.p, UP + L.up_counts, sizeof(StageCounts) / 4);
+                ul.copy(U->b_p1.p, st_up, 2);
+                ul.copy(U->b_cnt.p, st_up + 2, (size_t)ncnt);
+                ul.copy(U->b_kdens.p, st_up + 2 + ncnt, U->key_density.size());
+                launch_k9_upload(ul, su);
+            }
+            ++U->seq;
+            U->na_alloc = 0; U->k6_cap = capU;
+            U->k6_r_rec = U->b_r_rec.as<RegionRec>(); U->k6_r_pk = U->b_r_pk.as<uint32_t>(); U->k6_taint = nullptr;
+            U->k6_in_groups = nullptr; U->k6_in_goff = nullptr;
+            U->cp = Compact{}; U->k3 = K3Arrays{}; U->k4 = K4Arrays{};
+            U->k4.g_rec = U->h_groups.as<GroupRec>(); U->k4.g_cap = ng + 1;
+            U->table_in_hbm = true; U->groups_in_hbm = false; U->defer_walk = false;
+            memset(&U->counts, 0, sizeof(U->counts));
+            DCTX(d, U, do_k6(U, false, 4));   // (K6's arrays, no launch: the table stage below finds no candidate of the device's; NOT force_host -- that zeroes
+                                              // the host candidates' order keys, which the merge of the ranks' tables goes by)
+            DHIP(d, hipMemsetAsync(U->k6.own_nsv, 0, (size_t)capU * 3 * 4, su));   // own_nsv | own_nacc | own_ncn: no vertex has candidates of its own
+            DHIP(d, hipStreamSynchronize(s));   // (the groups are in pinned memory)
+            U->counts.n_regions = nr; U->counts.n_groups = ng; U->counts.last_maxq = lm;
+        } else {
+            // (K6 sizes its lists for a context's anomalous reads -- candidates and list entries <= reads / 2, each consuming a read pair; here
+            // a candidate consumes at least one pair GROUP and a list entry is a part of one: twice the groups stands for the reads)
+            const uint32_t capU = 2 * std::max(nr, ng) + 2;
+            // buckets: cnt | goff | cur ([nr + 1] each) | scan workspace | n | err, then the groups in bucket order
+            const size_t w_scan = 2 * ((size_t)scan_grid(nr + 1) + 2), o_goff = (size_t)nr + 1, o_cur = 2 * o_goff, o_ws = 3 * o_goff, o_n = o_ws + w_scan, o_err = o_n + 1,
+                         o_grp = (o_err + 1 + 3) / 4 * 4;
+            DHIP(d, d->b_bucket.ensure(o_grp * 4 + (size_t)ng * sizeof(GroupRec)));
+            uint32_t* B = d->b_bucket.as<uint32_t>();
+            GroupRec* sorted = (GroupRec*)(B + o_grp);
+            SegList seg_grp{};
+            seg_grp.n = world;
+            {
+                uint32_t a = 0;
+                for (int q = 0; q < world; ++q) { seg_grp.off[q] = grp_off[q] / 8; seg_grp.start[q] = a; a += (uint32_t)v5[(size_t)q * 10]; }
+                seg_grp.start[world] = a;
+            }
+            hipStream_t su = U->stream;
+            DHIP(d, hipEventRecord(d->ev_side, s));   // (the gather, and the region table placed behind it)
+            DHIP(d, hipStreamWaitEvent(su, d->ev_side, 0));
+            launch_k9_bucket_groups((const unsigned long long*)d->b_all.p, seg_grp, ng, nr, B, B + o_goff, B + o_cur, sorted, B + o_ws, B + o_n, B + o_err, su);
+            bucket_err = B + o_err;
+            // the result context as a K6 context: the genome's statistics and region table, no reads
+            DHIP(d, U->b_counts.ensure(sizeof(StageCounts))); DHIP(d, U->h_counts.ensure(sizeof(StageCounts)));
+            DHIP(d, U->b_cnt.ensure((size_t)ncnt * 4)); DHIP(d, U->b_p1.ensure(sizeof(Pass1))); DHIP(d, U->b_kdens.ensure(64 * 4));
+            DHIP(d, U->h_flags.ensure(64)); DHIP(d, U->h_groups.ensure(((size_t)ng + 1) * sizeof(GroupRec)));
+            DHIP(d, U->b_out_deg.ensure((size_t)capU * 6 * 4));
+            {
+                StageCounts sc{};
+                sc.n_regions = nr; sc.last_maxq = lm;
+                memcpy(UP + L.up_counts, &sc, sizeof(sc));
+                const uint32_t* st_up = UP + L.up_stats;   // (covered, window | flag histogram | densities: as this rank's own context got them)
+                UploadList ul{};
+                ul.copy(U->b_counts.p, UP + L.up_counts, sizeof(StageCounts) / 4);
+                ul.copy(U->b_p1.p, st_up, 2);
+                ul.copy(U->b_cnt.p, st_up + 2, (size_t)ncnt);
+                ul.copy(U->b_kdens.p, st_up + 2 + ncnt, U->key_density.size());
+                launch_k9_upload(ul, su);
+            }
+            launch_k6_scratch_init(U->b_out_deg.as<uint32_t>(), capU, su);
+            ++U->seq;
+            U->na_alloc = 0; U->k6_cap = capU;
+            U->k6_r_rec = U->b_r_rec.as<RegionRec>(); U->k6_r_pk = U->b_r_pk.as<uint32_t>(); U->k6_taint = nullptr;
+            U->k6_in_groups = sorted; U->k6_in_goff = B + o_goff;
+            U->cp = Compact{}; U->k3 = K3Arrays{}; U->k4 = K4Arrays{};
+            U->k4.g_rec = U->h_groups.as<GroupRec>(); U->k4.g_cap = ng + 1;
+            U->table_in_hbm = true; U->groups_in_hbm = false; U->defer_walk = false;
+            if (U->big_walk_mode < 0) U->last_big_groups = 1 << 20;   // (components of 5..64 regions on the device as well: what is left is the host's, sequentially)
+            // (components that span ranks are mostly a translocation's two regions and their neighbours: three rounds of label propagation settle
+            // them -- the eight of a context that walks large components are seven launches on rank 0's own part of the run; what has not
+            // converged fails the closure check and is the host's)
+            if (!U->dbg_label_rounds) U->dbg_label_rounds = 3;
+            memset(&U->counts, 0, sizeof(U->counts));
+            DCTX(d, U, do_k6(U, force_host, 0));
+            if (!wait_flag(U, 1, U->seq)) {
+                DHIP(d, hipStreamSynchronize(su));
+                if (!flag_arrived(U, 1)) return dfail(d, BDX_EINTERNAL, "the pair groups of the gathered components did not arrive: their kernels were not launched");
+            }
+            U->counts = *U->h_counts.as<StageCounts>();
+            if (U->counts.overflow) return dfail(d, BDX_EINTERNAL, "group list overflow (gathered components)");
         }
-        hipStream_t su = U->stream;
-        DHIP(d, hipEventRecord(d->ev_side, s));   // (the gather, and the region table placed behind it)
-        DHIP(d, hipStreamWaitEvent(su, d->ev_side, 0));
-        launch_k9_bucket_groups((const unsigned long long*)d->b_all.p, seg_grp, ng, nr, B, B + o_goff, B + o_cur, sorted, B + o_ws, B + o_n, B + o_err, su);
-        // the result context as a K6 context: the genome's statistics and region table, no reads
-        DHIP(d, U->b_counts.ensure(sizeof(StageCounts))); DHIP(d, U->h_counts.ensure(sizeof(StageCounts)));
-        DHIP(d, U->b_cnt.ensure((size_t)ncnt * 4)); DHIP(d, U->b_p1.ensure(sizeof(Pass1))); DHIP(d, U->b_kdens.ensure(64 * 4));
-        DHIP(d, U->h_flags.ensure(64)); DHIP(d, U->h_groups.ensure(((size_t)ng + 1) * sizeof(GroupRec)));
-        DHIP(d, U->b_out_deg.ensure((size_t)capU * 6 * 4));
-        {
-            StageCounts sc{};
-            sc.n_regions = nr; sc.last_maxq = lm;
-            memcpy(UP + L.up_counts, &sc, sizeof(sc));
-            const uint32_t* st_up = UP + L.up_stats;   // (covered, window | flag histogram | densities: as this rank's own context got them)
-            UploadList ul{};
-            ul.copy(U->b_counts.p, UP + L.up_counts, sizeof(StageCounts) / 4);
-            ul.copy(U->b_p1.p, st_up, 2);
-            ul.copy(U->b_cnt.p, st_up + 2, (size_t)ncnt);
-            ul.copy(U->b_kdens.p, st_up + 2 + ncnt, U->key_density.size());
-            launch_k9_upload(ul, su);
-        }
-        launch_k6_scratch_init(U->b_out_deg.as<uint32_t>(), capU, su);
-        ++U->seq;
-        U->na_alloc = 0; U->k6_cap = capU;
-        U->k6_r_rec = U->b_r_rec.as<RegionRec>(); U->k6_r_pk = U->b_r_pk.as<uint32_t>(); U->k6_taint = nullptr;
-        U->k6_in_groups = sorted; U->k6_in_goff = B + o_goff;
-        U->cp = Compact{}; U->k3 = K3Arrays{}; U->k4 = K4Arrays{};
-        U->k4.g_rec = U->h_groups.as<GroupRec>(); U->k4.g_cap = ng + 1;
-        U->table_in_hbm = true; U->groups_in_hbm = false; U->defer_walk = false;
-        if (U->big_walk_mode < 0) U->last_big_groups = 1 << 20;   // (components of 5..64 regions on the device as well: what is left is the host's, sequentially)
-        // (components that span ranks are mostly a translocation's two regions and their neighbours: three rounds of label propagation settle
-        // them -- the eight of a context that walks large components are seven launches on rank 0's own part of the run; what has not
-        // converged fails the closure check and is the host's)
-        if (!U->dbg_label_rounds) U->dbg_label_rounds = 3;
-        memset(&U->counts, 0, sizeof(U->counts));
-        DCTX(d, U, do_k6(U, force_host, 0));
-        if (!wait_flag(U, 1, U->seq)) {
-            DHIP(d, hipStreamSynchronize(su));
-            if (!flag_arrived(U, 1)) return dfail(d, BDX_EINTERNAL, "the pair groups of the gathered components did not arrive: their kernels were not launched");
-        }
-        U->counts = *U->h_counts.as<StageCounts>();
-        if (U->counts.overflow) return dfail(d, BDX_EINTERNAL, "group list overflow (gathered components)");
         decode_groups(U, U->h_groups.as<GroupRec>(), U->counts.n_groups, 0);
         U->last_big_groups = (int64_t)U->counts.n_groups + U->counts.n_groups_big;
         if (U->counts.n_groups) {   // (the host's share of this walk reads the table in pinned memory: its copy ran beside the device's walk)
@@ -1474,11 +1536,11 @@ int bdx_dist_run(bdx_dist* d) {
         U->counts.last_maxq = lm;
         DCTX(d, U, do_k6_table(U));
         DCTX(d, U, finish_table(U));
-        {   // (the bucket kernel's verdict, read once the table is there: a wait for it in front of the host's share of the walk kept the host from
+        if (bucket_err) {   // (the bucket kernel's verdict, read once the table is there: a wait for it in front of the host's share of the walk kept the host from
             // enqueueing the table stage while the device walked -- 40 us of rank 0's time alone; a group outside the table is skipped by the kernels)
             uint32_t berr = 0;
-            DHIP(d, hipMemcpyAsync(&berr, B + o_err, 4, hipMemcpyDeviceToHost, su));
-            DHIP(d, hipStreamSynchronize(su));
+            DHIP(d, hipMemcpyAsync(&berr, bucket_err, 4, hipMemcpyDeviceToHost, U->stream));
+            DHIP(d, hipStreamSynchronize(U->stream));
             if (berr) return dfail(d, BDX_EINTERNAL, "a gathered pair group names a region outside the genome's table");
         }
         u_counts[0] = U->n_sv_total; u_counts[1] = U->n_terms_total; u_counts[2] = U->n_cn_total; u_counts[3] = U->n_printed;
@@ -1494,7 +1556,7 @@ int bdx_dist_run(bdx_dist* d) {
         max_sv = std::max(max_sv, (uint32_t)u_counts[0]);
         TD.world = world + 1;
         if (max_sv >= (1u << 26) || n_sv_all > 0xFFFFFFF0ull) return dfail(d, BDX_ELIMIT, "too many SV candidates for the merge");
-        DHIP(d, hipEventRecord(d->ev_side, su));   // (its table kernel: finish_table has seen its ready word, this orders the streams)
+        DHIP(d, hipEventRecord(d->ev_side, U->stream));   // (its table kernel: finish_table has seen its ready word, this orders the streams)
         DHIP(d, hipStreamWaitEvent(s, d->ev_side, 0));
     }
     {

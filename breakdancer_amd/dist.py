@@ -172,6 +172,12 @@ class DistRun:
         return dict(ctx_records_sent=sent.value, ctx_records_received=recv.value, gathered_bytes=gathered.value, ms_total=ms_total.value,
                     ms_exchange=ms_x.value)
 
+    def set_debug(self, name, value=1):
+        """a test / measurement switch for this rank's contexts, the result context included (bdx_dist_set_debug)"""
+        self.lib.bdx_dist_set_debug.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        self._chk(self.lib.bdx_dist_set_debug(self.h, name.encode(), int(value)), "bdx_dist_set_debug")
+        return self
+
     def collectives(self):
         """collectives this rank entered in the last run, and what carried them"""
         out = (C.c_uint32 * 3)()

@@ -198,6 +198,7 @@ class ShardedRun:
         self.D = D
         self.support = support
         self.pending = {}
+        self.result_debug = {}   # bdx_set_debug switches for rank 0's result context (tests: "gather_walk")
 
     def add_chromosome(self, tid, arrs):
         self.pending[int(tid)] = arrs
@@ -232,6 +233,9 @@ class ShardedRun:
                     if self.pending[tid].get("name_check") is not None:
                         c.use_name_check()
                     c.push_reads(self.pending[tid])
+        for k, v in self.result_debug.items():
+            for r in ranks:
+                r.set_debug(k, v)
         res = D.run_threads(ranks)
         self.exchange = [r.exchange() for r in ranks]
         self._ranks = ranks  # (the result lives in rank 0's context: keep the ranks alive with it)

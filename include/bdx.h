@@ -249,7 +249,7 @@ int bdx_set_enqueue_ahead(bdx_ctx* ctx, int on);
 int bdx_set_host_walk(bdx_ctx* ctx, int on);
 /* Test and measurement switches, by name (they used to be environment variables read inside the library): "no_stash",
  * "max_chunks", "spec_test", "big_walk", "bucketed_join", "no_poll", "finalize2_fold", "no_forward", "scan3", "label_rounds",
- * "k1_grid", "end_write_value", "k1_event_period", "pin_noncoherent".  Every switch selects another route to the same results
+ * "k1_grid", "end_write_value", "k1_event_period", "pin_noncoherent", "walk_lanes", "ins_plain", "gather_walk".  Every switch selects another route to the same results
  * (the parity tests force each route); none is needed in production.  BDX_EINVAL for an unknown name. */
 int bdx_set_debug(bdx_ctx* ctx, const char* name, int value);
 int bdx_get_walk_split(const bdx_ctx* ctx, uint32_t* n_sv_device, uint32_t* n_sv_host, uint32_t* n_groups_host);
@@ -385,6 +385,9 @@ int bdx_dist_get_exchange(const bdx_dist* d, uint64_t* ctx_records_sent, uint64_
 /* collectives this rank entered in the last bdx_dist_run: out[0] all-reduces, out[1] all-to-alls, out[2] gathers; the library that
  * carried them ("threads" for the in-process backend, else the path of the librccl that was loaded) and its ncclGetVersion code (0: none) */
 int bdx_dist_get_collectives(const bdx_dist* d, uint32_t out[3], const char** backend, int* rccl_version);
+/* bdx_set_debug for this rank's contexts -- its own and, on rank 0, the result context ("gather_walk": 1 = rank 0 walks the gathered
+ * components on its device whatever their number, 2 = on its host; 0 = by their number).  Routes to the same results; tests force each */
+int bdx_dist_set_debug(bdx_dist* d, const char* name, int value);
 /* this rank's milliseconds of the last bdx_dist_run, phase by phase: local phases and the collectives behind them alternate
  * (bdx_dist_phase_name(i) names entry i; a collective's figure includes waiting for the slowest rank), then what only rank 0 does:
  * the merge of the ranks' tables and its host walk of the components that span ranks. */

@@ -139,7 +139,7 @@ def split_by_tid(soa):
     return out
 
 
-def sharded_from_oracle(run, comm=None, device=0, world=1, keep=None, collide=0, support=False):
+def sharded_from_oracle(run, comm=None, device=0, world=1, keep=None, collide=0, support=False, result_debug=None):
     """the same whole-genome input through the chromosome-sharded path: one context per chromosome, the chromosomes dealt
     to `world` ranks (threads of this process on one GPU when comm is None)"""
     from breakdancer_amd.shard import ShardedRun
@@ -147,6 +147,8 @@ def sharded_from_oracle(run, comm=None, device=0, world=1, keep=None, collide=0,
                           bam_file_index=int(run.lib_i[i, 1]), name=run.lib_names[i]) for i in range(run.nlibs)]
     sr = ShardedRun(product_options(run.opts), libs, run.nbams, run.w0, comm=comm, device=device, world=world,
                     ntids=len(getattr(run, "targets", [])) or None, support=support)
+    if result_debug:
+        sr.result_debug.update(result_debug)
     soa = run.merged_soa()
     if collide:
         soa = colliding_names(soa, collide)

@@ -149,7 +149,7 @@ def test_config3_five_thousand_translocations_with_dash_t(genome_share):
     # chromosome of another rank cross in the one all-to-all, rank 0 walks the components that span ranks -- the multi-GPU shape of configs[3]
     from runner import expected_ctx_travel, sharded_from_oracle
     keep = []
-    util = sharded_from_oracle(run, world=4, keep=keep)
+    util = sharded_from_oracle(run, world=4, keep=keep, result_debug={"gather_walk": 1})   # (rank 0 walks the gathered components on its device; the 8-rank run below on its host)
     compare(run, util, check_cls=False)
     ex = keep[0].exchange
     n_ctx, n_travel = expected_ctx_travel(run, 4)

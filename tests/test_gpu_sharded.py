@@ -25,7 +25,8 @@ def test_staged_whole_genome_equals_single_run(seed):
     cfg, streams, targets = make_case(100 + seed)
     for i, o in enumerate((WG_OPTS[seed % len(WG_OPTS)], WG_OPTS[(seed * 5 + 2) % len(WG_OPTS)])):
         run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1, **o))
-        util = sharded_from_oracle(run, world=1 + (seed + i) % 3)
+        # (rank 0 walks the components that span ranks: few gathered groups on its host, many on its device -- here the route is forced in turn)
+        util = sharded_from_oracle(run, world=1 + (seed + i) % 3, result_debug={"gather_walk": 1 + (seed // 3 + i) % 2})
         compare(run, util, check_cls=False)
         n_dev, n_host, _ = util.walk_split()
         assert n_dev + n_host == run.n_svs
@@ -63,7 +64,7 @@ def test_sharded_run_over_five_and_eight_ranks(seed):
         run = oracle_case(cfg, streams, targets, make_opts(score_threshold=-1, **o))
         for world in ((8, 5) if i == 0 else (8,)):
             keep = []
-            util = sharded_from_oracle(run, world=world, keep=keep)
+            util = sharded_from_oracle(run, world=world, keep=keep, result_debug={"gather_walk": (0, 1, 2)[(seed + i + world) % 3]})
             compare(run, util, check_cls=False)
             n_dev, n_host, _ = util.walk_split()
             assert n_dev + n_host == run.n_svs
@@ -90,6 +91,9 @@ def test_only_inter_chromosomal_records_cross_ranks():
     cfg = cfg_line("rg0", "wgs.bam", "lib0", 400.0, 30.0)
     for kw in (dict(transchr_rearrange=1), dict()):
         run = oracle_from_soa(d, cfg, ["wgs.bam"], make_opts(**kw), ["c1", "c2", "c3", "c4"])
+        for route in (1, 2):   # rank 0's walk of the gathered components: on its device, on its host
+            util = sharded_from_oracle(run, world=3, result_debug={"gather_walk": route})
+            compare(run, util, check_cls=False)
         keep = []
         util = sharded_from_oracle(run, world=3, keep=keep)
         compare(run, util, check_cls=False)
