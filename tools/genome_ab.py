@@ -41,11 +41,16 @@ def main():
     for rnd in range(a.rounds):
         for s in settings:
             for nm in names:
-                bd.set_debug(nm, 0)
+                if nm != "enqueue_ahead":
+                    bd.set_debug(nm, 0)
+            bd.set_enqueue_ahead(0)
             if s != "default":
                 for kv in s.split(","):
                     k, v = kv.split("=")
-                    bd.set_debug(k, int(v))
+                    if k == "enqueue_ahead":   # (not a debug switch: bdx_set_enqueue_ahead -- 1 = the later stages sized by the prior and launched while K1 runs)
+                        bd.set_enqueue_ahead(int(v))
+                    else:
+                        bd.set_debug(k, int(v))
             bd.run()   # (settle)
             ts = []
             for _ in range(6):
