@@ -1701,12 +1701,16 @@ int bdx_run(bdx_ctx* c) {
     if (!restored && c->speculate == 2 && c->ran && c->last_n == c->n && c->last_na) {
         guess = c->spec_test ? std::max(1u, c->last_na / 2) : c->last_na + c->last_na / 8 + 1024;
         if (guess > kMaxAnomalous) guess = 0;
-    } else if (!restored && c->speculate && c->n >= (1u << 20)) {
+    } else if (!restored && c->speculate && c->n >= (1u << 20) && (c->speculate == 1 || c->n < (1u << 25))) {
         // no history: a prior.  Anomalous reads are a few percent of a sorted BAM at most (1 % at configs[1]); 1/32 of the
         // reads covers that with room, costs a few microseconds of oversized grids when it is generous, and one more pass
         // over the (short) later stages when it is not.  Small inputs are not worth it: their whole run is launch latency.
         // (measured at configs[1], 1.1 % anomalous: prior n/32 0.309 ms per step, n/64 0.300 ms, exact sizing after the read-back
         // 0.307 ms, sizing from the previous run 0.295 ms -- an oversized launch grid costs about what the host round trip does)
+        // (a GPU's share of a genome -- 2^25 reads and more -- does not take the prior by itself: K1's half millisecond covers the launches either way,
+        // and a prior twice the truth, eighteen times with -t, costs its oversized grids and tables: 1.534 against 1.514 ms, 0.92 against 0.83 with -t.
+        // The compaction ALONE ahead under the prior, the rest sized exactly, was built too: 1.656 against 1.612 ms, 0.90 against 0.83 -- the tables K2
+        // clears for K3 and K4 are sized by the guess.  profiles/r06_genome_ab.txt)
         const uint64_t prior = (uint64_t)c->n / (c->spec_test ? 4096 : 32) + 4096;
         guess = prior > kMaxAnomalous ? 0 : (uint32_t)prior;
     }
