@@ -152,7 +152,8 @@ struct bdx_ctx {
     uint32_t seq = 0;
     // test / measurement switches (bdx_set_debug): all off by default
     int dbg_no_stash = 0, dbg_max_chunks = 0, dbg_finalize2_fold = 0, dbg_no_forward = 0, dbg_scan3 = 0, dbg_label_rounds = 0, dbg_k1_grid = 0,
-        dbg_end_write_value = 0, dbg_walk_lanes = 0, dbg_ins_plain = 0, dbg_gather_walk = 0;
+        dbg_end_write_value = 0, dbg_walk_lanes = 0, dbg_ins_plain = 0, dbg_gather_walk = 0, dbg_region_dma = 0;
+    bool region_dma_now = false;      // this run's region table goes to the host by a copy command once the host knows its size (see bdx_run)
     uint32_t lb_seq = 0;              // launches of look-back scans so far: every launch stamps its words with its own number (bdx_scan.h)
     uint32_t k1_event_period = 4;     // K1 is bracketed by HIP events on every n-th run (an event pair idles the GPU ~10 us)
     float k1_ms_last = 0;
@@ -1305,7 +1306,7 @@ int do_k6(bdx_ctx* c, bool force_host, int part = 0, const Sizing* sz = nullptr)
     if (c->poll) {  // ready words set by the kernels themselves (first thread of k6_pairs_kernel / first wave of k6_walk_kernel)
         a.flag_value = c->seq;
         a.flag_groups = c->h_flags.as<uint32_t>() + 1;
-        if (c->k3.host_copy_later) a.flag_regions = c->h_flags.as<uint32_t>() + 3;
+        if (c->k3.host_copy_later && !c->region_dma_now) a.flag_regions = c->h_flags.as<uint32_t>() + 3;
         a.mirror_in_walk = (force_host || c->defer_walk) ? 0 : 1;  // (k6_walk_kernel follows k6_emit_kernel unless everything goes to the host, or the walk waits for the ranks' collectives)
     }
     if (part == 4) return BDX_OK;   // (the arrays only: rank 0 of a sharded run whose host walks the few gathered groups -- the table stage follows)
@@ -1669,6 +1670,7 @@ int bdx_run(bdx_ctx* c) {
     const bool force_host = c->host_walk_only || ph_opt || c->opts.min_read_pair < 1;
     // K2 .. K6 (first half) for c->na_alloc anomalous reads
     auto enqueue_middle = [&]() -> int {
+        c->region_dma_now = false;
         int r = do_compact(c, 0, nullptr, true);
         if (r != BDX_OK) return r;
         r = do_cut(c, 0, 0, 0, true);
@@ -1682,7 +1684,11 @@ int bdx_run(bdx_ctx* c) {
             en.k6_scratch = c->k3.out_deg; en.scratch_cap = c->k3.cap;
             // (the join kernel forwards the region table to pinned host memory.  A kernel of its own on the copy stream, beside the join, was
             // measured in round 6: 1.525 against 1.530 ms at a genome share -- the join does not wait for those 5.7 MB; profiles/r06_genome_ab.txt)
-            if (c->k3.host_copy_later) {
+            c->region_dma_now = c->k3.host_copy_later && c->poll && c->dbg_region_dma != 0;
+            if (c->region_dma_now) {
+                // (the join kernel only says that K3 is through: the host reads the region count and has the copy engine fetch the table)
+                en.flag_host = c->h_flags.as<uint32_t>() + 4; en.flag_value = c->seq;
+            } else if (c->k3.host_copy_later) {
                 en.r_rec_dev = c->k3.r_rec_dev; en.r_pk_dev = c->k3.r_pk_dev; en.r_rec_host = c->k3.r_rec; en.r_pk_host = c->k3.r_pk;
                 en.counts = c->b_counts.as<StageCounts>(); en.nkeys2 = 2 * c->nkeys;
             }
@@ -1761,11 +1767,24 @@ int bdx_run(bdx_ctx* c) {
     if (c->stage_timing) HIPCHK(c, hipEventRecord(c->ev[5], s));
     const auto t_h0 = std::chrono::steady_clock::now();
     auto t_h1 = t_h0;
-    if (na) {
+    if (na && c->region_dma_now) {
+        if (!wait_flag(c, 4, c->seq)) {
+            HIPCHK(c, hipStreamSynchronize(s));
+            if (!flag_arrived(c, 4)) return fail(c, BDX_EINTERNAL, "the region count did not arrive: its kernels were not launched");
+        }
+        const size_t nr = c->h_counts0.as<StageCounts>()->n_regions;
+        if (nr) {
+            HIPCHK(c, hipMemcpyAsync(c->h_regs.p, c->b_r_rec.p, nr * sizeof(RegionRec), hipMemcpyDeviceToHost, c->copy_stream));
+            if (c->nkeys) HIPCHK(c, hipMemcpyAsync(c->h_pk.p, c->b_r_pk.p, nr * 2 * (size_t)c->nkeys * 4, hipMemcpyDeviceToHost, c->copy_stream));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    } else if (na) {
         if (!wait_flag(c, 3, c->seq)) {
             if (c->poll) HIPCHK(c, hipStreamSynchronize(s)); else HIPCHK(c, hipEventSynchronize(c->ev_regions));
             if (!flag_arrived(c, 3)) return fail(c, BDX_EINTERNAL, "the region table did not arrive: its kernels were not launched");
         }
+    }
+    if (na) {
         // (the table sits in pinned memory the device has just written: one streaming copy into ordinary memory is much
         // cheaper than the walk's scattered reads of it)
         if ((uint64_t)c->h_counts0.as<StageCounts>()->n_regions + ph > kMaxRegions) {   // (region ids are 26-bit fields of the packed group key)
@@ -2142,7 +2161,7 @@ int bdx_set_debug(bdx_ctx* c, const char* name, int value) {
     struct { const char* n; int* p; } ints[] = {{"no_stash", &c->dbg_no_stash}, {"max_chunks", &c->dbg_max_chunks}, {"finalize2_fold", &c->dbg_finalize2_fold},
                                                  {"no_forward", &c->dbg_no_forward}, {"scan3", &c->dbg_scan3}, {"label_rounds", &c->dbg_label_rounds},
                                                  {"k1_grid", &c->dbg_k1_grid}, {"end_write_value", &c->dbg_end_write_value}, {"spec_test", &c->spec_test},
-                                                 {"walk_lanes", &c->dbg_walk_lanes}, {"ins_plain", &c->dbg_ins_plain}, {"gather_walk", &c->dbg_gather_walk},
+                                                 {"walk_lanes", &c->dbg_walk_lanes}, {"ins_plain", &c->dbg_ins_plain}, {"gather_walk", &c->dbg_gather_walk}, {"region_dma", &c->dbg_region_dma},
                                                  {"big_walk", &c->big_walk_mode}};
     for (auto& e : ints)
         if (!strcmp(name, e.n)) { *e.p = value; return BDX_OK; }

@@ -12,6 +12,7 @@
 // (region_lo, region_hi, flag, library) in a second LDS table keyed by the packed group id.  The edge
 // weight of the reference's graph is the sum of a group's pair counts.
 #include "bdx_k3.h"
+#include "bdx_scan.h"
 
 namespace bdx {
 
@@ -164,6 +165,9 @@ __global__ __launch_bounds__(256) void k4_join_kernel(K4Arrays k4, const int32_t
 __global__ __launch_bounds__(256) void k4_direct_join_kernel(K4Arrays k4, Entries en, const uint32_t* n_ptr, StageCounts* counts) {
     const uint32_t na = *n_ptr;
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t kp = blockIdx.x * 4 + (threadIdx.x >> 6);   // (measurement build: this wave's row of clocks)
+    (void)kp;
+    KPROF(kp, 0);
     if (j == 0 && en.flag_host) {  // the kernel before this one wrote the last region record
         __threadfence_system();
         *(volatile uint32_t*)en.flag_host = en.flag_value;
@@ -177,6 +181,7 @@ __global__ __launch_bounds__(256) void k4_direct_join_kernel(K4Arrays k4, Entrie
         for (uint32_t i = j; i < nr * kw; i += gsz) dst[i] = src[i];
         for (uint32_t i = j; i < nr * (uint32_t)en.nkeys2; i += gsz) en.r_pk_host[i] = en.r_pk_dev[i];
     }
+    KPROF(kp, 1);
     if (j >= na) return;
     // (sharded runs: the entries behind the context's own are foreign -- see Entries::n_local)
     const uint32_t nl = en.n_local ? *en.n_local : na;
@@ -200,12 +205,14 @@ __global__ __launch_bounds__(256) void k4_direct_join_kernel(K4Arrays k4, Entrie
     const uint64_t key = jf ? en.fkey[j - nl] : en.key[j];
     const uint64_t chk = en.check ? (jf ? en.fcheck[j - nl] : en.check[j]) : 0ull;
     const uint64_t h = mix64(key);
+    if (key != 0x5555AAAA5555AAAAull) KPROF(kp, 2);   // (the key and the region have arrived)
     const uint32_t tag = (uint32_t)(h >> 32);
     unsigned long long* table = (unsigned long long*)k4.t_key;
     const unsigned long long mine = ((unsigned long long)tag << 32) | j;
     uint32_t s = (uint32_t)h & k4.t_mask;
     for (uint32_t probes = 0; probes <= kMaxProbes; ++probes) {
         const unsigned long long old = atomicCAS(&table[s], ~0ull, mine);
+        if (probes == 0 && old != 0x5555AAAA5555AAAAull) KPROF(kp, 3);   // (lane 0's first compare-and-swap is back)
         if (old == ~0ull) return;  // first of its name so far
         if ((uint32_t)(old >> 32) == tag) {
             const uint32_t o = (uint32_t)old;
@@ -224,6 +231,7 @@ __global__ __launch_bounds__(256) void k4_direct_join_kernel(K4Arrays k4, Entrie
                         else k4.pair_lo[o] = rj;
                     }
                 }
+                KPROF(kp, 4);   // (lane 0 was a second mate: its partner's key, region and the exchange are done)
                 return;
             }
         }
@@ -342,3 +350,12 @@ void launch_k4_join_only(const K4Arrays& k4, const Entries& en, const uint32_t* 
 // (bdx_warm_up: the HIP runtime loads a translation unit's device code at the first launch of any of its kernels)
 __global__ void k4_noop_kernel() {}
 namespace bdx { void warm_k4(hipStream_t s) { hipLaunchKernelGGL(k4_noop_kernel, dim3(1), dim3(64), 0, s); } }
+
+#ifdef BDX_KPROF
+extern "C" int bdx_debug_kprof4(unsigned long long* out, size_t n) {
+    const int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bdx::g_kprof), n * sizeof(unsigned long long));
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(bdx::g_kprof)) == hipSuccess) (void)hipMemset(p, 0, sizeof(unsigned long long) * 8 * 65536);
+    return rc;
+}
+#endif

@@ -124,6 +124,12 @@ def test_config2_one_gpu_share_of_the_genome(genome_share):
         bd.set_debug("ins_plain", mode)
         bd.run()
         tables_equal(bd, bh)
+    bd.set_debug("ins_plain", 0)
+    # the region table fetched by a copy command once the host knows its size, instead of forwarded by the join kernel (a measured route)
+    bd.set_debug("region_dma", 1)
+    bd.run()
+    tables_equal(bd, bh)
+    region_invariants(bd.regions())
     bd.close()
     bh.close()
 

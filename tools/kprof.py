@@ -53,6 +53,10 @@ def main():
     buf = np.zeros(8 * 65536, dtype=np.uint64)
     L.bdx_debug_kprof.argtypes = [C.c_void_p, C.c_size_t]
     buf3 = np.zeros(8 * 65536, dtype=np.uint64)
+    have4 = hasattr(L, "bdx_debug_kprof4")
+    if have4:
+        L.bdx_debug_kprof4.argtypes = [C.c_void_p, C.c_size_t]
+        buf4 = np.zeros(65536 * 8, np.uint64)
     have3 = hasattr(L, "bdx_debug_kprof3")
     if have3:
         L.bdx_debug_kprof3.argtypes = [C.c_void_p, C.c_size_t]
@@ -68,6 +72,8 @@ def main():
     L.bdx_debug_kprof(buf.ctypes.data_as(C.c_void_p), buf.size)  # (clears the device buffer)
     if have3:
         L.bdx_debug_kprof3(buf3.ctypes.data_as(C.c_void_p), buf3.size)
+    if have4:
+        L.bdx_debug_kprof4(buf4.ctypes.data_as(C.c_void_p), buf4.size)
     bd.run()
     torch.cuda.synchronize()
     rc = L.bdx_debug_kprof(buf.ctypes.data_as(C.c_void_p), buf.size)
@@ -147,6 +153,22 @@ def main():
             stats("look-back", rows[h, 2] - rows[h, 1])
             stats("outputs issued", rows[h, 3] - rows[h, 2])
             stats("wave end", rows[h, 3] - z)
+    if have4:
+        # join kernel: rows = wave (the first 65,536), clocks of lane 0: entry, region table forwarded, key and region arrived, first
+        # compare-and-swap back, (second mates) partner confirmed and exchanged
+        L.bdx_debug_kprof4(buf4.ctypes.data_as(C.c_void_p), buf4.size)
+        t4 = buf4.reshape(65536, 8).astype(np.int64)
+        h = t4[:, 3] > 0
+        if h.any():
+            z = t4[t4[:, 0] > 0, 0].min()
+            print("join kernel: %d waves entered, %d with entries, %d whose lane 0 held a second mate" % ((t4[:, 0] > 0).sum(), h.sum(), (t4[:, 4] > 0).sum()))
+            stats("wave entry", t4[h, 0] - z)
+            stats("region table forwarded (issue)", t4[h, 1] - t4[h, 0])
+            stats("key + region arrived", t4[h, 2] - t4[h, 1])
+            stats("first compare-and-swap back", t4[h, 3] - t4[h, 2])
+            m = t4[:, 4] > 0
+            stats("second mate: partner done", t4[m, 4] - t4[m, 3])
+            stats("wave's lane 0 done", np.maximum(t4[h, 3], t4[h, 4]) - z)
     bd.close()
 
 
