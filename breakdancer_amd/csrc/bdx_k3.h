@@ -158,6 +158,7 @@ struct Entries {
     uint32_t scratch_cap;
     uint32_t* flag_host;     // pinned word: the region table (written by the kernel before) is complete
     uint32_t flag_value;
+    uint32_t fwd_blocks;     // workgroups in front of the joining ones that forward the region table (0: kJoinForwardBlocks; ~0: every wave forwards, A/B)
     // sharded runs: entries n_local .. n - 1 are FOREIGN -- inter-chromosomal reads of chromosomes another rank owns whose mates lie on
     // a (later) chromosome of this rank (k7_exchange.hip) -- with their own arrays; they come first in stream order, are never the
     // second-observed mate, and have no partner[] / pair_lo[] entry.  n_local null: every entry is the context's own

@@ -162,24 +162,43 @@ __global__ __launch_bounds__(256) void k4_join_kernel(K4Arrays k4, const int32_t
 // (slots are never freed), confirms the full key and records the pair for both.  At the sizes of one chromosome the
 // table (8 B per slot, load <= 0.25) lives in L2 / Infinity Cache, and the partitioning launches of the bucketed
 // path are not worth their latency.  partner[] must be -1 and the table all ones on entry.
+constexpr uint32_t kJoinForwardBlocks = 32;
 __global__ __launch_bounds__(256) void k4_direct_join_kernel(K4Arrays k4, Entries en, const uint32_t* n_ptr, StageCounts* counts) {
     const uint32_t na = *n_ptr;
-    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t kp = blockIdx.x * 4 + (threadIdx.x >> 6);   // (measurement build: this wave's row of clocks)
+    // The region table's way to the host (single-context runs: the host's share of the walk reads it): kJoinForwardBlocks workgroups IN FRONT
+    // of the joining ones do nothing else.  When every joining wave forwarded a few words before its own work, those stores -- 5.7 MB at a
+    // genome share, 110 us of link time -- sat in front of every wave's loads: 6 us for a coalesced load at the median, 145 us for a launch
+    // that takes 94 by itself (profiles/r06_join_kernel.txt).  32 workgroups keep the link busy (16 bytes per lane in flight); they are
+    // dispatched first and run beside the join.
+    const bool fwd_all = en.fwd_blocks == 0xFFFFFFFFu;   // (A/B switch: every joining wave forwards its share first, as before round 6)
+    const uint32_t fwd = (en.r_rec_host && !fwd_all) ? (en.fwd_blocks ? en.fwd_blocks : kJoinForwardBlocks) : 0u;
+    if (blockIdx.x < fwd || (fwd_all && en.r_rec_host)) {
+        const uint32_t nr = en.counts->n_regions;
+        const uint32_t t = blockIdx.x * 256 + threadIdx.x, gsz = (fwd_all ? gridDim.x : fwd) * 256;
+        constexpr uint32_t kw = sizeof(RegionRec) / 4;
+        {
+            const uint32_t words = nr * kw, quads = words / 4;   // (the tables start on 256-byte boundaries)
+            const uint4* src = (const uint4*)en.r_rec_dev;
+            uint4* dst = (uint4*)en.r_rec_host;
+            for (uint32_t i = t; i < quads; i += gsz) dst[i] = src[i];
+            if (t < words - quads * 4) ((uint32_t*)en.r_rec_host)[quads * 4 + t] = ((const uint32_t*)en.r_rec_dev)[quads * 4 + t];
+        }
+        {
+            const uint32_t words = nr * (uint32_t)en.nkeys2, quads = words / 4;
+            const uint4* src = (const uint4*)en.r_pk_dev;
+            uint4* dst = (uint4*)en.r_pk_host;
+            for (uint32_t i = t; i < quads; i += gsz) dst[i] = src[i];
+            if (t < words - quads * 4) en.r_pk_host[quads * 4 + t] = en.r_pk_dev[quads * 4 + t];
+        }
+        if (!fwd_all) return;
+    }
+    const uint32_t j = (blockIdx.x - fwd) * 256 + threadIdx.x;
+    const uint32_t kp = (blockIdx.x - fwd) * 4 + (threadIdx.x >> 6);   // (measurement build: this wave's row of clocks)
     (void)kp;
     KPROF(kp, 0);
     if (j == 0 && en.flag_host) {  // the kernel before this one wrote the last region record
         __threadfence_system();
         *(volatile uint32_t*)en.flag_host = en.flag_value;
-    }
-    if (en.r_rec_host) {  // forward the region table to the host (grid-stride over its words; the grid covers na >= regions)
-        const uint32_t nr = en.counts->n_regions;
-        const uint32_t gsz = gridDim.x * 256;
-        const uint32_t* src = (const uint32_t*)en.r_rec_dev;
-        uint32_t* dst = (uint32_t*)en.r_rec_host;
-        constexpr uint32_t kw = sizeof(RegionRec) / 4;
-        for (uint32_t i = j; i < nr * kw; i += gsz) dst[i] = src[i];
-        for (uint32_t i = j; i < nr * (uint32_t)en.nkeys2; i += gsz) en.r_pk_host[i] = en.r_pk_dev[i];
     }
     KPROF(kp, 1);
     if (j >= na) return;
@@ -313,7 +332,7 @@ static void launch_k4_impl(const K4Arrays& k4, const Entries& en, const uint32_t
     if (n_anom_host == 0) return;
     const uint32_t g = (n_anom_host + kPartChunk - 1) / kPartChunk;
     if (k4.direct) {
-        const uint32_t gd = (n_anom_host + 255) / 256;
+        const uint32_t gd = (n_anom_host + 255) / 256 + ((en.r_rec_host && en.fwd_blocks != 0xFFFFFFFFu) ? (en.fwd_blocks ? en.fwd_blocks : kJoinForwardBlocks) : 0u);
         hipLaunchKernelGGL(k4_direct_join_kernel, dim3(gd), dim3(256), 0, s, k4, en, n_ptr, counts);
         if (aggregate) {
             (void)hipFuncSetAttribute((const void*)k4_aggregate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kAggSlots * 16 + 32);
