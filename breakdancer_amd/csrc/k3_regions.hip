@@ -179,7 +179,8 @@ void launch_k3(const K3Arrays& a, const Compact& cp, const Pass1* p1, uint32_t n
     HeadOut hout{a, cp.tid, tail.tid_tail ? 1 : 0};
     if (a.lb_state) {  // one launch per scan (decoupled look-back) instead of two
         const size_t nblk = scan_grid(a.cap, 1);
-        scan_launch_lb<U4, 1>(hin, hout, n_ptr, n_anom_host, a.lb_state, a.lb_stamp, s);
+        if (n_anom_host > (1u << 19)) scan_launch_lb<U4, 2>(hin, hout, n_ptr, n_anom_host, a.lb_state, a.lb_stamp, s);   // (two reads per lane: half the workgroups and look-back words -- 45 -> 35 us at a genome share; four: 39)
+        else scan_launch_lb<U4, 1>(hin, hout, n_ptr, n_anom_host, a.lb_state, a.lb_stamp, s);
         const CandCtx cx{a, cp, p1, min_len, seq_coverage_lim, nn_base, tail};
         scan_launch_lb<uint32_t, 1>(AcceptIn{cx}, AcceptOut{cx, nkeys}, &a.counts->n_cand, n_anom_host, a.lb_state + 4 * nblk, a.lb_stamp, s);
         if (region_of_launch) hipLaunchKernelGGL(k3_region_of_kernel, dim3((n_anom_host + 255) / 256), dim3(256), 0, s, a, p1);
