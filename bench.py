@@ -793,7 +793,7 @@ def genome_leg(rank, world, local, dist, out, fraction=None, translocations=5000
                                                         "hbm_roofline_frac_whole_path": total / 2 / min(tp[1:]) * PATH_BYTES_PER_PAIR / 1e9 / HBM_PEAK_GBS,
                                                         "note": "bdx_set_enqueue_ahead(1), as the headline step: the later stages are launched while K1 runs, sized by the prior (no gain at this size: profiles/r06_genome_ab.txt)"},
                       "note": "bdx_run on ONE context holding all 24 chromosomes (default options; `seconds`: repeated runs WITHOUT enqueue-ahead -- the later stages are "
-                              "sized after pass 1's read-back --, best of 3; the first run of the context took the prior, as enqueued_ahead_from_the_prior does)"}
+                              "sized after pass 1's read-back --, best of 3; first_run_seconds is NOT comparable: the records were classified tile by tile while they were pushed, so the context's first run finds K1's work done)"}
             # K1 on these records (every tile holds reads of the four libraries: its several-libraries tile body), by kernel-level HIP events
             bd.set_stage_timing(True)
             k1 = []
