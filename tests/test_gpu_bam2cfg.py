@@ -108,6 +108,23 @@ def test_the_loop_runs_off_the_first_stretch(tmp_path):
     assert [r["readgroup"] for r in rows] == ["NA"] and rows[0]["lib"] == "NA"
 
 
+def test_a_header_of_several_bgzf_members(tmp_path):
+    """8,000 reference sequences: the BAM header spans several BGZF members and the first record lies in the middle of one -- the device
+    path measures the header itself (magic, l_text, text, n_ref, names) to tell the decoder where the records start"""
+    sys.path.insert(0, GOLDEN)
+    from make_bam2cfg_vectors import two_library_records
+    from breakdancer_amd.bamwrite import write_bam_records
+    recs, rgs = two_library_records()
+    targets = ["contig_%05d_of_a_fragmented_assembly" % i for i in range(8000)]
+    for r in recs[len(recs) // 2:]:
+        r["tid"] = r["mtid"] = 7999
+    path = str(tmp_path / "many.bam")
+    write_bam_records(path, recs, targets, rgs=rgs)
+    assert os.path.getsize(path) > 100_000
+    rows = same_as_cpu(path, "-n", "1500", "-g")
+    assert [r["lib"] for r in rows] == ["libA", "libB"]
+
+
 def test_insert_size_stats_kernel_bit_for_bit():
     """bdx_insert_size_stats against the same sums in numpy float64 scalar arithmetic, in the script's order (perl/bam2cfg.pl:153-197)"""
     from breakdancer_amd._lib import load
