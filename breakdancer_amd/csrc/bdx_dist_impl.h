@@ -1200,7 +1200,7 @@ int bdx_dist_run(bdx_dist* d) {
     for (int q = 0; q < world; ++q) { gcount[q] = round_up((size_t)nr_of_rank[q] * (rrec + rpk), 8); gdispl[q] = region_bytes; region_bytes += gcount[q]; }
     if (!solo && (uint64_t)nr_local != nr_of_rank[rank]) return leave(dfail(d, BDX_EINTERNAL, "region counts of the chromosomes do not add up"));
     // rank 0, several ranks: the packages' region records (at all + base_off + gdispl[q]) -> the result context's table in HBM and, on the side stream, in pinned memory
-    auto place_regions = [&](size_t base_off) -> int {
+    auto place_regions = [&](size_t base_off, bool with_pk = true) -> int {
         GatherDesc D{};
         D.world = world;
         uint32_t max_nr = 0;
@@ -1220,7 +1220,7 @@ int bdx_dist_run(bdx_dist* d) {
         DHIP(d, hipStreamWaitEvent(C->copy_stream, C->ev_copy, 0));
         UploadList ul{};
         ul.copy(regs, U->b_r_rec.p, (size_t)NR * rrec / 4);
-        if (nkeys2) ul.copy(pk, U->b_r_pk.p, (size_t)NR * rpk / 4);
+        if (nkeys2 && with_pk) ul.copy(pk, U->b_r_pk.p, (size_t)NR * rpk / 4);   // (without: the rows the host's walk touches follow, launch_k9_pk_rows)
         launch_k9_upload(ul, C->copy_stream);
         regs_pending = true;
         return BDX_OK;
@@ -1407,7 +1407,7 @@ int bdx_dist_run(bdx_dist* d) {
     {
         // (place_regions takes the packages' region records at base + gdispl[q]; here they start the packages: their own displacements)
         for (int q = 0; q < world; ++q) gdispl[q] = pdispl[q];
-        const int pr = place_regions(0);
+        const int pr = place_regions(0, false);
         if (pr != BDX_OK) return pr;
     }
     if (ng_all) {
@@ -1526,6 +1526,10 @@ int bdx_dist_run(bdx_dist* d) {
         decode_groups(U, U->h_groups.as<GroupRec>(), U->counts.n_groups, 0);
         U->last_big_groups = (int64_t)U->counts.n_groups + U->counts.n_groups_big;
         if (U->counts.n_groups) {   // (the host's share of this walk reads the table in pinned memory: its copy ran beside the device's walk)
+            // ... and the proper-read samples of the regions its groups name: those rows only
+            // (on the stream of the table's copy, behind it: the result context's own stream is still walking)
+            launch_k9_pk_rows(U->h_groups.as<GroupRec>(), U->counts.n_groups, U->b_r_pk.as<uint32_t>(), pk, (uint32_t)nkeys2, nr, C->copy_stream);
+            regs_pending = true;
             const int wr = wait_regions();
             if (wr != BDX_OK) return wr;
         }

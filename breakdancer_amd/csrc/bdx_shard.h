@@ -164,6 +164,7 @@ void launch_k9_merge_tables(const char* all, const TableDesc* D, int world, uint
 // space of one slot per group (K6Arrays::in_groups / first_of), not in the compact read list of the rank that cut the region.
 // cnt / cur: [nr + 1] words each, scan_ws: 2 * (scan_grid(nr + 1) + 2) words; n_words[0] receives nr + 1; err: set to 1 if a group names
 // a region outside [0, nr)
+void launch_k9_pk_rows(const GroupRec* groups, uint32_t ng, const uint32_t* pk_dev, uint32_t* pk_host, uint32_t row_words, uint32_t nr, hipStream_t s);
 void launch_k9_bucket_groups(const unsigned long long* base, const SegList& sg, uint32_t n, uint32_t nr, uint32_t* cnt, uint32_t* goff, uint32_t* cur, GroupRec* out,
                              uint32_t* scan_ws, uint32_t* n_words, uint32_t* err, hipStream_t s);   // (in: the ranks' blocks of one gather buffer)
 

@@ -442,6 +442,23 @@ void launch_k9_bucket_groups(const unsigned long long* base, const SegList& sg, 
     if (n) hipLaunchKernelGGL(k9_group_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, base, sg, n, nr, goff, cur, out);
 }
 
+// The proper-read samples (2 x nkeys words per region) of the regions the HOST's share of rank 0's walk touches -- the two regions of every
+// pair group it was handed -- copied from HBM into the full-size pinned table at their own places.  The rest of that table never crosses the
+// link: at a whole genome it is 40 MB of the 76 MB the region table would take (the host walks dozens of groups, the samples serve nothing else).
+__global__ __launch_bounds__(256) void k9_pk_rows_kernel(const GroupRec* __restrict__ groups, uint32_t ng, const uint32_t* __restrict__ pk_dev, uint32_t* pk_host,
+                                                         uint32_t row_words, uint32_t nr) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * ng) return;
+    const uint64_t k = groups[i >> 1].key;
+    const uint32_t r = (i & 1u) ? (uint32_t)((k >> 12) & ((1u << 26) - 1)) : (uint32_t)(k >> 38);
+    if (r >= nr) return;
+    for (uint32_t w = 0; w < row_words; ++w) pk_host[(size_t)r * row_words + w] = pk_dev[(size_t)r * row_words + w];
+}
+void launch_k9_pk_rows(const GroupRec* groups, uint32_t ng, const uint32_t* pk_dev, uint32_t* pk_host, uint32_t row_words, uint32_t nr, hipStream_t s) {
+    if (!ng || !row_words) return;
+    hipLaunchKernelGGL(k9_pk_rows_kernel, dim3((2 * ng + 255) / 256), dim3(256), 0, s, groups, ng, pk_dev, pk_host, row_words, nr);
+}
+
 }  // namespace bdx
 
 // (bdx_warm_up: the HIP runtime loads a translation unit's device code at the first launch of any of its kernels)
