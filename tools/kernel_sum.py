@@ -1,3 +1,5 @@
+"""usage: kernel_sum.py <rocprofv3 kernel_stats.csv of tools/single_trace.sh> -> the kernels' time per bdx_run (15 runs in that trace), to set beside the
+unprofiled wall time of tools/genome_ab.py on the same box"""
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 tot=0

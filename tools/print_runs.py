@@ -1,3 +1,4 @@
+"""stdin: tools/genome_probe.py's output -> one line per run of the single context: milliseconds and the host's stage timings (bdx_get_timings)"""
 import sys,json
 for line in sys.stdin:
     if line.startswith('{"first_run_seconds"'):
