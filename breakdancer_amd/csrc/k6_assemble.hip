@@ -404,25 +404,37 @@ struct RunConst {  // run constants of process_sv, wherever the caller keeps the
     uint32_t covered;          // covered_ref_len
 };
 
+constexpr int kFewLibs = 4;   // libraries up to which assemble_sv adds the parts up per library in registers
 __device__ bool assemble_sv(const K6Arrays& a, const RunConst& rc_, const PartRec* P, uint32_t A, int32_t B, const RegionRec& ra, const RegionRec& rb,
                             const uint32_t* pk_last_a, const uint32_t* pk_first_b, const GrpRange (&gs)[3], int max_readlen,
-                            uint32_t slot, uint32_t start, bool store, uint32_t* nacc_out, uint32_t* ncn_out) {
+                            uint32_t slot, uint32_t start, bool store, uint32_t* nacc_out, uint32_t* ncn_out, uint32_t kprow = ~0u) {
+    (void)kprow;   // (measurement build: the row of clocks of this call, tools/kprof.py)
+    KPROF(kprow, 0);
     const uint32_t lib_room = a.lib_stride;
     const int mrp = a.min_read_pair;
     int cv[kNumFlags];  // pairs per flag: registers, every index static (a counter array in LDS costs a dependent round trip per update)
 #pragma unroll
     for (int f = 0; f < kNumFlags; ++f) cv[f] = 0;
     int num_pairs = 0;
+    // (four parts of a group requested at once: a loop that fetches one part per turn waits for every one of them in turn -- ~1.5 us each
+    // with sixteen waves of scattered requests on the compute unit -- and a group has up to flags x libraries parts)
+    const PartRec none_part{0ull, 0u, 0u};
 #pragma unroll
     for (int g = 0; g < 3; ++g)
-        for (uint32_t i = 0; i < gs[g].cnt; ++i) {
-            const PartRec q = P[gs[g].beg + i];
-            const int f = (int)(q.key & 15);
-            const int pr = (int)q.pairs;
+        for (uint32_t i = 0; i < gs[g].cnt; i += 4) {
+            PartRec q[4];
 #pragma unroll
-            for (int ff = 0; ff < kNumFlags; ++ff) cv[ff] += f == ff ? pr : 0;
-            num_pairs += pr;
+            for (int u = 0; u < 4; ++u) q[u] = i + u < gs[g].cnt ? P[gs[g].beg + i + u] : none_part;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = (int)(q[u].key & 15);
+                const int pr = (int)q[u].pairs;   // (0 for the padding: it counts for nothing)
+#pragma unroll
+                for (int ff = 0; ff < kNumFlags; ++ff) cv[ff] += f == ff ? pr : 0;
+                num_pairs += pr;
+            }
         }
+    if (num_pairs != 0x7FFFFFFF) KPROF(kprow, 1);   // (the groups' parts have arrived)
     if (num_pairs < mrp) return false;
     int flag = BDX_NA, flag_count;
     {   // the dominant flag (lowest one on ties)
@@ -451,15 +463,52 @@ __device__ bool assemble_sv(const K6Arrays& a, const RunConst& rc_, const PartRe
         fwd[1] = fwd[0]; rev[1] = rev[0]; chr[1] = ra.tid; pos[1] = ra.end;
     }
 
+    LibStage* ls = a.lib_stage + (size_t)slot * a.lib_stride;
+    uint32_t nacc = 0;
+    float diff = 0.0f;
+    if (a.nlibs <= kFewLibs) {
+        // Few libraries (a run has one to four): ONE more pass over the groups' parts -- the loads of the first pass again, independent of each
+        // other, out of the cache -- adds the dominant flag's pairs and spans up per library in registers (static indices), then the libraries
+        // in ascending order.  The three-way merge below walks the parts by dependent loads -- P[beg + idx] decides the next idx --: 28 of a
+        // call's 45 us at the median at a genome share (in-kernel clocks, profiles/r06_walk_kernel.txt).  Integer sums: the order of the
+        // parts does not matter; the float accumulation runs over the libraries in ascending order as the merge does.
+        int rcL[kFewLibs], spL[kFewLibs];
+#pragma unroll
+        for (int l = 0; l < kFewLibs; ++l) { rcL[l] = 0; spL[l] = 0; }
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+            for (uint32_t i = 0; i < gs[g].cnt; i += 4) {
+                PartRec q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q[u] = i + u < gs[g].cnt ? P[gs[g].beg + i + u] : none_part;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool mine = (int)(q[u].key & 15) == flag;   // (the padding's pairs and sum are 0)
+                    const int lib = (int)((q[u].key >> 4) & 255);
+#pragma unroll
+                    for (int l = 0; l < kFewLibs; ++l) {
+                        rcL[l] += (mine && lib == l) ? (int)q[u].pairs : 0;
+                        spL[l] += (mine && lib == l) ? (int)q[u].sum : 0;
+                    }
+                }
+            }
+#pragma unroll
+        for (int l = 0; l < kFewLibs; ++l) {
+            if (rcL[l] == 0) continue;   // (a part holds at least one pair)
+            diff = __fadd_rn(diff, __fsub_rn((float)spL[l], __fmul_rn((float)rcL[l], rc_.lib_mean[l])));
+            const uint32_t nflag = rc_.hist[(size_t)l * kNumFlags + flag];
+            double lambda = __dmul_rn((double)total_region_size, __ddiv_rn((double)nflag, (double)rc_.covered));
+            lambda = (1.0e-10 < lambda) ? lambda : 1.0e-10;
+            if (store && nacc < lib_room) ls[nacc] = LibStage{l, rcL[l], lambda};
+            ++nacc;
+        }
+    } else {
     // per-library pairs / spans of the dominant flag in ascending library order: a three-way merge, the parts of a
     // group being sorted by (flag, library)
     uint32_t idx[3] = {0, 0, 0};  // (every loop over g below is unrolled: static indices, registers)
 #pragma unroll
     for (int g = 0; g < 3; ++g)
         while (idx[g] < gs[g].cnt && (int)(P[gs[g].beg + idx[g]].key & 15) != flag) ++idx[g];
-    LibStage* ls = a.lib_stage + (size_t)slot * a.lib_stride;
-    uint32_t nacc = 0;
-    float diff = 0.0f;
     while (true) {
         int best = 256;
 #pragma unroll
@@ -482,6 +531,8 @@ __device__ bool assemble_sv(const K6Arrays& a, const RunConst& rc_, const PartRe
         if (store && nacc < lib_room) ls[nacc] = LibStage{best, rc, lambda};
         ++nacc;
     }
+    }
+    if (nacc != 0x7FFFFFFFu) KPROF(kprow, 2);   // (per-library merge done)
     if (nacc > lib_room) { a.counts->overflow = 3; return false; }  // cannot happen: distinct libraries <= min(nlibs, parts)
 
     // normal reads between the regions: proper reads after A's last read up to and including B's first
@@ -505,6 +556,7 @@ __device__ bool assemble_sv(const K6Arrays& a, const RunConst& rc_, const PartRe
     const float allele_frequency =
         ncn ? __fsub_rn(1.0f, __fdiv_rn(cn_sum, __fmul_rn(2.0f, (float)ncn))) : __uint_as_float(0xFFC00000u);
 
+    if (ncn != 0x7FFFFFFFu) KPROF(kprow, 3);   // (the proper-read samples have arrived: copy numbers done)
     if (flag != BDX_ARP_RF && flag != BDX_ARP_RR && pos[0] + max_readlen - 5 < pos[1]) pos[0] += max_readlen - 5;
     const int diffspan = (int)((double)__fdiv_rn(diff, (float)flag_count) + 0.5);
 
@@ -518,6 +570,7 @@ __device__ bool assemble_sv(const K6Arrays& a, const RunConst& rc_, const PartRe
     o.grp_mask = (gs[0].cnt ? 1u : 0u) | (gs[1].cnt ? 2u : 0u) | (gs[2].cnt ? 4u : 0u);
     o.start = start;
     if (store) a.sv_stage[slot] = o;
+    KPROF(kprow, 4);
     *nacc_out = nacc;
     *ncn_out = ncn;
     return true;
@@ -1070,7 +1123,8 @@ __global__ __launch_bounds__(64) void k6_walk_kernel(K6Arrays a) {
                 const uint32_t* pkA = a.r_pk + (size_t)rA * 2 * nk + nk;
                 const uint32_t* pkB = a.r_pk + (size_t)rB * 2 * nk;
                 uint32_t nacc = 0, ncn = 0;
-                if (assemble_sv(a, rc_, P, rA, B >= 0 ? (int32_t)rB : -1, recA, recB, pkA, pkB, gs, max_readlen, slot, start, true, &nacc, &ncn)) {
+                if (assemble_sv(a, rc_, P, rA, B >= 0 ? (int32_t)rB : -1, recA, recB, pkA, pkB, gs, max_readlen, slot, start, true, &nacc, &ncn,
+                                c == 0 ? 16384u + blockIdx.x : ~0u)) {
                     if (from_old) {  // placed by its order key: after the earlier windows, before this window's own
                         const uint32_t q = atomicAdd(&a.counts->n_old, 1u);
                         a.old_key[q] = ((uint64_t)(W * period) << kKeyShiftT) | ((uint64_t)start << kKeyShiftStart) | (uint64_t)(nseq & kKeySeqMask);

@@ -17,8 +17,12 @@ def main():
     ap.add_argument("--fraction", type=float, default=0.125)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--t", action="store_true")
+    ap.add_argument("--lib", default=None, help="another build of libbdx.so (variants/...: tools/link_variant.sh), for A/Bs of builds on one box")
     ap.add_argument("settings", nargs="*", help="name=value[,name=value]; 'default' = no switch")
     a = ap.parse_args()
+    if a.lib:
+        import breakdancer_amd._lib as _l
+        _l.LIB_PATH = os.path.abspath(a.lib)
     import torch
     import breakdancer_amd as bda
     from breakdancer_amd.api import LibraryConfig, Options

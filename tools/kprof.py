@@ -93,7 +93,7 @@ def main():
         print("  %-34s n=%6d  min %7.2f  p50 %7.2f  p90 %7.2f  max %7.2f us" % (name, len(x), x.min(), np.percentile(x, 50), np.percentile(x, 90), x.max()))
 
     # walk kernel: one lane per component, rows = workgroup (clocks of its lane 0 / of the whole wave at the end)
-    own = t[:32768]
+    own = t[:16384]
     k0 = own[:, 0][own[:, 0] > 0].min()
     have = own[:, 4] > 0  # waves whose lane 0 walks a component
     print("walk kernel: %d waves, %d with components (clocks of lane 0)" % ((own[:, 7] > 0).sum(), have.sum()))
@@ -107,6 +107,15 @@ def main():
     stats("first call", own[c1, 6] - own[c1, 5])
     stats("rest + end", own[c1, 7] - own[c1, 6])
     stats("wave end", own[have, 7] - k0)
+    # the walk kernel's FIRST assemble_sv call of a wave (rows 16384 + workgroup, lane 0's clocks)
+    ac = t[16384:16384 + 8192]
+    ha = ac[:, 4] > 0
+    if ha.any():
+        print("walk kernel, first call of a wave (lane 0 has one in %d waves):" % ha.sum())
+        stats("parts of the groups arrived", ac[ha, 1] - ac[ha, 0])
+        stats("per-library merge", ac[ha, 2] - ac[ha, 1])
+        stats("proper-read samples, copy numbers", ac[ha, 3] - ac[ha, 2])
+        stats("record stored", ac[ha, 4] - ac[ha, 3])
     # table kernels (round 6: placement and scores are two launches).  Rows 32768 + workgroup: k6_place_kernel's wave 0; rows 49152 + wave:
     # k6_score_kernel
     pl = t[32768:49152]
