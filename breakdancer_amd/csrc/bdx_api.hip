@@ -152,7 +152,7 @@ struct bdx_ctx {
     uint32_t seq = 0;
     // test / measurement switches (bdx_set_debug): all off by default
     int dbg_no_stash = 0, dbg_max_chunks = 0, dbg_finalize2_fold = 0, dbg_no_forward = 0, dbg_scan3 = 0, dbg_label_rounds = 0, dbg_k1_grid = 0,
-        dbg_end_write_value = 0, dbg_walk_lanes = 0, dbg_ins_plain = 0, dbg_gather_walk = 0, dbg_region_dma = 0, dbg_join_fwd = 0;
+        dbg_end_write_value = 0, dbg_walk_lanes = 0, dbg_ins_plain = 0, dbg_gather_walk = 0, dbg_region_dma = 0, dbg_join_fwd = 0, dbg_regions_copy = 0;
     bool region_dma_now = false;      // this run's region table goes to the host by a copy command once the host knows its size (see bdx_run)
     uint32_t lb_seq = 0;              // launches of look-back scans so far: every launch stamps its words with its own number (bdx_scan.h)
     uint32_t k1_event_period = 4;     // K1 is bracketed by HIP events on every n-th run (an event pair idles the GPU ~10 us)
@@ -1149,6 +1149,7 @@ int readback(bdx_ctx* c, bool with_groups) {
 
 // region table for the host side.  borrow: rr / pk stay valid (the context's pinned buffers) and no id shift is
 // needed, so the walk and the getters read them in place.
+constexpr uint32_t kBorrowRegionsMin = 32768;   // regions from which on the host's share of the walk may read the table in pinned memory (bdx_run)
 void decode_regions(bdx_ctx* c, const RegionRec* rr, const uint32_t* pk, uint32_t nr, uint32_t ph, bool borrow) {
     static_assert(sizeof(HostRegion) == sizeof(RegionRec) && offsetof(HostRegion, first) == offsetof(RegionRec, first), "region layout");
     const int nkeys = c->nkeys;
@@ -1792,12 +1793,23 @@ int bdx_run(bdx_ctx* c) {
             HIPCHK(c, hipStreamSynchronize(s));
             return fail(c, BDX_ELIMIT, "more than 2^26 - 2 accepted regions in one context");
         }
-        decode_regions(c, c->h_regs.as<RegionRec>(), c->h_pk.as<uint32_t>(), c->h_counts0.as<StageCounts>()->n_regions, ph, false);
+        // The host's share of the walk reads the table where the device left it, in pinned memory.  (Until round 6 the table was copied into
+        // ordinary memory first -- "one streaming copy is cheaper than the walk's scattered reads", true when the host walked every component:
+        // 5.7 MB at a genome share, 0.28 ms of this thread between the join kernel's end and the pair groups' arrival 0.14 ms later; the
+        // host's walk of its ~1,200 groups then started late and the device stood idle in front of the table stage.)  A large share
+        // (debug "regions_copy" = 1: always) still gets its copy, once the groups have said how large it is.
+        const uint32_t nr_host = c->h_counts0.as<StageCounts>()->n_regions;
+        // (a small table is copied at once, as ever: its copy fits between the join kernel's end and the groups' arrival -- 32 k regions are 70 us)
+        const bool copy_first = c->dbg_regions_copy == 1 || (c->dbg_regions_copy == 0 && nr_host < kBorrowRegionsMin);
+        if (copy_first) decode_regions(c, c->h_regs.as<RegionRec>(), c->h_pk.as<uint32_t>(), nr_host, ph, false);
         if (!wait_flag(c, 1, c->seq)) {
             if (c->poll) HIPCHK(c, hipStreamSynchronize(s)); else HIPCHK(c, hipEventSynchronize(c->ev_groups));
             if (!flag_arrived(c, 1)) return fail(c, BDX_EINTERNAL, "the pair groups did not arrive: their kernels were not launched");
         }
         c->counts = *c->h_counts.as<StageCounts>();
+        if (!copy_first) decode_regions(c, c->h_regs.as<RegionRec>(), c->h_pk.as<uint32_t>(), nr_host, ph,
+                                        c->dbg_regions_copy == 2 || (uint64_t)c->counts.n_groups * 8 < nr_host);   // (borrowed while the walk touches a fraction of the table:
+                                        // a walk of 20 k groups over 15 k regions was 46 us faster on its copy)
         if (c->counts.irregular) {  // a read name seen more than twice: the pair model does not hold (see bdx_walk_reads.cpp)
             t_h1 = std::chrono::steady_clock::now();
             rc = replay_reads(c, ph);
@@ -2162,7 +2174,7 @@ int bdx_set_debug(bdx_ctx* c, const char* name, int value) {
     struct { const char* n; int* p; } ints[] = {{"no_stash", &c->dbg_no_stash}, {"max_chunks", &c->dbg_max_chunks}, {"finalize2_fold", &c->dbg_finalize2_fold},
                                                  {"no_forward", &c->dbg_no_forward}, {"scan3", &c->dbg_scan3}, {"label_rounds", &c->dbg_label_rounds},
                                                  {"k1_grid", &c->dbg_k1_grid}, {"end_write_value", &c->dbg_end_write_value}, {"spec_test", &c->spec_test},
-                                                 {"walk_lanes", &c->dbg_walk_lanes}, {"ins_plain", &c->dbg_ins_plain}, {"gather_walk", &c->dbg_gather_walk}, {"region_dma", &c->dbg_region_dma}, {"join_fwd", &c->dbg_join_fwd},
+                                                 {"walk_lanes", &c->dbg_walk_lanes}, {"ins_plain", &c->dbg_ins_plain}, {"gather_walk", &c->dbg_gather_walk}, {"region_dma", &c->dbg_region_dma}, {"join_fwd", &c->dbg_join_fwd}, {"regions_copy", &c->dbg_regions_copy},
                                                  {"big_walk", &c->big_walk_mode}};
     for (auto& e : ints)
         if (!strcmp(name, e.n)) { *e.p = value; return BDX_OK; }

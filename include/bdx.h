@@ -249,7 +249,7 @@ int bdx_set_enqueue_ahead(bdx_ctx* ctx, int on);
 int bdx_set_host_walk(bdx_ctx* ctx, int on);
 /* Test and measurement switches, by name (they used to be environment variables read inside the library): "no_stash",
  * "max_chunks", "spec_test", "big_walk", "bucketed_join", "no_poll", "finalize2_fold", "no_forward", "scan3", "label_rounds",
- * "k1_grid", "end_write_value", "k1_event_period", "pin_noncoherent", "walk_lanes", "ins_plain", "gather_walk", "region_dma", "join_fwd".  Every switch selects another route to the same results
+ * "k1_grid", "end_write_value", "k1_event_period", "pin_noncoherent", "walk_lanes", "ins_plain", "gather_walk", "region_dma", "join_fwd", "regions_copy".  Every switch selects another route to the same results
  * (the parity tests force each route); none is needed in production.  BDX_EINVAL for an unknown name. */
 int bdx_set_debug(bdx_ctx* ctx, const char* name, int value);
 int bdx_get_walk_split(const bdx_ctx* ctx, uint32_t* n_sv_device, uint32_t* n_sv_host, uint32_t* n_groups_host);
