@@ -131,6 +131,12 @@ def test_config2_one_gpu_share_of_the_genome(genome_share):
     tables_equal(bd, bh)
     region_invariants(bd.regions())
     bd.set_debug("region_dma", 0)
+    for mode in (1, 2):   # the host's share of the walk on its own copy of the region table (as before round 6) / on the table in pinned memory
+        bd.set_debug("regions_copy", mode)
+        bd.run()
+        tables_equal(bd, bh)
+        np.testing.assert_array_equal(bd.regions(), bh.regions())
+    bd.set_debug("regions_copy", 0)
     for fwd in (-1, 3):   # ... by every joining wave (as before round 6), by three workgroups in front of them (default: 32)
         bd.set_debug("join_fwd", fwd)
         bd.run()
