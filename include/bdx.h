@@ -249,8 +249,12 @@ int bdx_set_enqueue_ahead(bdx_ctx* ctx, int on);
 int bdx_set_host_walk(bdx_ctx* ctx, int on);
 /* Test and measurement switches, by name (they used to be environment variables read inside the library): "no_stash",
  * "max_chunks", "spec_test", "big_walk", "bucketed_join", "no_poll", "finalize2_fold", "no_forward", "scan3", "label_rounds",
- * "k1_grid", "end_write_value", "k1_event_period", "pin_noncoherent", "walk_lanes", "ins_plain", "gather_walk", "region_dma", "join_fwd", "regions_copy".  Every switch selects another route to the same results
- * (the parity tests force each route); none is needed in production.  BDX_EINVAL for an unknown name. */
+ * "k1_grid", "end_write_value", "k1_event_period", "pin_noncoherent", and from round 6: "walk_lanes" (regions per wave of the walk kernel),
+ * "ins_plain" (1: the insertion list ranked by the rank-sort launch, 2: by the bitonic fall-back), "gather_walk" (sharded runs, rank 0's walk
+ * of the gathered components: 1 device, 2 host), "region_dma" (the region table fetched by copy commands instead of forwarded by the join
+ * kernel), "join_fwd" (-1: every joining wave forwards its share; n: that many forwarding workgroups), "regions_copy" (1: the host copies the
+ * region table before its share of the walk, 2: never).  Every switch selects another route to the same results (the parity tests force each
+ * route); none is needed in production.  BDX_EINVAL for an unknown name. */
 int bdx_set_debug(bdx_ctx* ctx, const char* name, int value);
 int bdx_get_walk_split(const bdx_ctx* ctx, uint32_t* n_sv_device, uint32_t* n_sv_host, uint32_t* n_groups_host);
 /* After a run, once the caller has what it wants: the result tables are copied out of the pinned host buffers the device assembled them
