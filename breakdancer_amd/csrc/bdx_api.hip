@@ -152,7 +152,7 @@ struct bdx_ctx {
     uint32_t seq = 0;
     // test / measurement switches (bdx_set_debug): all off by default
     int dbg_no_stash = 0, dbg_max_chunks = 0, dbg_finalize2_fold = 0, dbg_no_forward = 0, dbg_scan3 = 0, dbg_label_rounds = 0, dbg_k1_grid = 0,
-        dbg_end_write_value = 0, dbg_walk_lanes = 0, dbg_ins_plain = 0, dbg_gather_walk = 0, dbg_region_dma = 0, dbg_join_fwd = 0, dbg_regions_copy = 0;
+        dbg_end_write_value = 0, dbg_walk_lanes = 0, dbg_ins_plain = 0, dbg_gather_walk = 0, dbg_region_dma = 0, dbg_join_fwd = 0, dbg_regions_copy = 0, dbg_asm_plain = 0;
     bool region_dma_now = false;      // this run's region table goes to the host by a copy command once the host knows its size (see bdx_run)
     uint32_t lb_seq = 0;              // launches of look-back scans so far: every launch stamps its words with its own number (bdx_scan.h)
     uint32_t k1_event_period = 4;     // K1 is bracketed by HIP events on every n-th run (an event pair idles the GPU ~10 us)
@@ -1298,6 +1298,7 @@ int do_k6(bdx_ctx* c, bool force_host, int part = 0, const Sizing* sz = nullptr)
     a.force_host = force_host ? 1 : 0;
     a.big_walk = big_walk;
     a.ins_plain = c->dbg_ins_plain;
+    a.asm_plain = c->dbg_asm_plain;
     a.walk_lanes = c->dbg_walk_lanes > 0 ? std::min(c->dbg_walk_lanes, 32) : 32;  // (measured at configs[1]: 64 regions per wave 23.7 us, 32: 22.4 us, 16: 24.5 us)
     {
         const int rounds = c->dbg_label_rounds;
@@ -2174,7 +2175,7 @@ int bdx_set_debug(bdx_ctx* c, const char* name, int value) {
     struct { const char* n; int* p; } ints[] = {{"no_stash", &c->dbg_no_stash}, {"max_chunks", &c->dbg_max_chunks}, {"finalize2_fold", &c->dbg_finalize2_fold},
                                                  {"no_forward", &c->dbg_no_forward}, {"scan3", &c->dbg_scan3}, {"label_rounds", &c->dbg_label_rounds},
                                                  {"k1_grid", &c->dbg_k1_grid}, {"end_write_value", &c->dbg_end_write_value}, {"spec_test", &c->spec_test},
-                                                 {"walk_lanes", &c->dbg_walk_lanes}, {"ins_plain", &c->dbg_ins_plain}, {"gather_walk", &c->dbg_gather_walk}, {"region_dma", &c->dbg_region_dma}, {"join_fwd", &c->dbg_join_fwd}, {"regions_copy", &c->dbg_regions_copy},
+                                                 {"walk_lanes", &c->dbg_walk_lanes}, {"ins_plain", &c->dbg_ins_plain}, {"gather_walk", &c->dbg_gather_walk}, {"region_dma", &c->dbg_region_dma}, {"join_fwd", &c->dbg_join_fwd}, {"regions_copy", &c->dbg_regions_copy}, {"asm_plain", &c->dbg_asm_plain},
                                                  {"big_walk", &c->big_walk_mode}};
     for (auto& e : ints)
         if (!strcmp(name, e.n)) { *e.p = value; return BDX_OK; }

@@ -380,6 +380,7 @@ struct K6Arrays {
     int big_walk;                  // components of up to kK6BigMembers regions are walked on the device (k6_walk_big_kernel); 0: up to kK6MaxMembers
     uint32_t fin_regions;          // regions k6_place_kernel's launch is sized for (the host's count once it has read it; 0: cap)
     int walk_lanes;                // regions per wave of k6_walk_kernel (<= 64)
+    int asm_plain;                 // test switch (bdx_set_debug "asm_plain"): the candidate assembly merges its parts by the three-way merge whatever the number of libraries
     int ins_plain;                 // test switch (bdx_set_debug "ins_plain"): 1 = the insertion list is ranked as before round 6 (k6_ranksort_kernel / LDS bitonic),
                                    // 2 = the bucket path declares its list crowded (the bitonic sort takes it)
     int label_rounds;              // min-label propagation rounds incl. the one inside k6_pairs_kernel (default kK6LabelRounds)

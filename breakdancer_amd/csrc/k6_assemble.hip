@@ -466,7 +466,7 @@ __device__ bool assemble_sv(const K6Arrays& a, const RunConst& rc_, const PartRe
     LibStage* ls = a.lib_stage + (size_t)slot * a.lib_stride;
     uint32_t nacc = 0;
     float diff = 0.0f;
-    if (a.nlibs <= kFewLibs) {
+    if (a.nlibs >= 2 && a.nlibs <= kFewLibs && !a.asm_plain) {   // (one library: the merge below is one short loop -- 0.2492 against 0.2512 ms per configs[1] step)
         // Few libraries (a run has one to four): ONE more pass over the groups' parts -- the loads of the first pass again, independent of each
         // other, out of the cache -- adds the dominant flag's pairs and spans up per library in registers (static indices), then the libraries
         // in ascending order.  The three-way merge below walks the parts by dependent loads -- P[beg + idx] decides the next idx --: 28 of a

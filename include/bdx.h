@@ -253,7 +253,7 @@ int bdx_set_host_walk(bdx_ctx* ctx, int on);
  * "ins_plain" (1: the insertion list ranked by the rank-sort launch, 2: by the bitonic fall-back), "gather_walk" (sharded runs, rank 0's walk
  * of the gathered components: 1 device, 2 host), "region_dma" (the region table fetched by copy commands instead of forwarded by the join
  * kernel), "join_fwd" (-1: every joining wave forwards its share; n: that many forwarding workgroups), "regions_copy" (1: the host copies the
- * region table before its share of the walk, 2: never).  Every switch selects another route to the same results (the parity tests force each
+ * region table before its share of the walk, 2: never), "asm_plain" (the walk's candidate assembly merges its parts by the three-way merge).  Every switch selects another route to the same results (the parity tests force each
  * route); none is needed in production.  BDX_EINVAL for an unknown name. */
 int bdx_set_debug(bdx_ctx* ctx, const char* name, int value);
 int bdx_get_walk_split(const bdx_ctx* ctx, uint32_t* n_sv_device, uint32_t* n_sv_host, uint32_t* n_groups_host);

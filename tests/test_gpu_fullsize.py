@@ -137,6 +137,10 @@ def test_config2_one_gpu_share_of_the_genome(genome_share):
         tables_equal(bd, bh)
         np.testing.assert_array_equal(bd.regions(), bh.regions())
     bd.set_debug("regions_copy", 0)
+    bd.set_debug("asm_plain", 1)   # the walk's candidate assembly by its three-way merge (four libraries take per-library sums in registers by default)
+    bd.run()
+    tables_equal(bd, bh)
+    bd.set_debug("asm_plain", 0)
     for fwd in (-1, 3):   # ... by every joining wave (as before round 6), by three workgroups in front of them (default: 32)
         bd.set_debug("join_fwd", fwd)
         bd.run()
