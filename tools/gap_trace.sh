@@ -3,7 +3,7 @@
 R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_gap
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_gap -o g -- python $R/bench.py --steps ${1:-40} --warmup 5 --no-cpu-baseline --no-end-to-end > /tmp/prof_gap.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_gap -o g -- python $R/bench.py --steps ${1:-40} --warmup 5 --no-cpu-baseline --no-end-to-end --no-genome --no-pmc --no-overlap > /tmp/prof_gap.log 2>&1
 cd $R
 f=$(find /tmp/prof_gap -name '*kernel_trace.csv' | head -1)
 python - "$f" <<'PY'
