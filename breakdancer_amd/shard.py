@@ -140,7 +140,7 @@ def taint_regions(groups_lo_hi, owner_of_region, n_regions):
 
 
 def order_key(T, start):
-    """order key of an SV row (k6_finish_kernel): the vertex it is placed at, before that vertex's own rows unless the traversal
+    """order key of an SV row (k6_score_kernel): the vertex it is placed at, before that vertex's own rows unless the traversal
     started there, then the start vertex"""
     T, start = np.asarray(T, np.uint64), np.asarray(start, np.uint64)
     return (T << np.uint64(34)) | ((T == start).astype(np.uint64) << np.uint64(33)) | (start << np.uint64(7))

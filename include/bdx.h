@@ -394,7 +394,7 @@ int bdx_dist_get_collectives(const bdx_dist* d, uint32_t out[3], const char** ba
 int bdx_dist_set_debug(bdx_dist* d, const char* name, int value);
 /* this rank's milliseconds of the last bdx_dist_run, phase by phase: local phases and the collectives behind them alternate
  * (bdx_dist_phase_name(i) names entry i; a collective's figure includes waiting for the slowest rank), then what only rank 0 does:
- * the merge of the ranks' tables and its host walk of the components that span ranks. */
+ * the merge of the ranks' tables, its walk of the gathered components on the device (K6 on the result context) and what of it its host takes. */
 int bdx_dist_get_phase_ms(const bdx_dist* d, float* out, int n);
 const char* bdx_dist_phase_name(int i);
 int bdx_dist_owner(uint64_t name_key, int world);
