@@ -130,3 +130,12 @@ def test_every_orientation_code_against_alnparser(tmp_path, args):
     expect = PERL_VECTORS["orientations_synthetic"][args]
     assert len({c.split("(")[0] for c in expect[0]["flag"].split(")")[:-1]}) == 10   # all ten codes occur
     check_exact(path, args.split(), expect)
+
+
+def test_device_source_fails_loudly_without_a_gpu():
+    """`--device` is the GPU record source and nothing else: without a GPU it says so and prints no configuration (no quiet CPU fallback)"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the device source works here (tests/test_gpu_bam2cfg.py)")
+    p = subprocess.run([BIN, "--device", os.path.join(GOLD, "NA19240_chr21_del_inv.bam")], capture_output=True, text=True)
+    assert p.returncode != 0 and p.stdout == "" and "ERROR" in p.stderr
