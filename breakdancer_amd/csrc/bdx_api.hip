@@ -994,8 +994,24 @@ int do_compact(bdx_ctx* c, uint32_t nn_base, const uint32_t* pk_base, bool prepa
 // K3: cut regions.  In a whole-genome run the last candidate of a chromosome is closed by the first anomalous read
 // of the next chromosome, which still counts for its nucleotide sum / max read length / normal-pair count
 // (BreakDancer.cpp:202-231): has_next / next_qlen / next_nn carry that read across contexts.
+// a result whose region table is read where the device left it (c->reg == h_regs.p: bdx_run on a large table, sharded runs) gets its own copy:
+// called before the pinned buffers may be reallocated under it (a sizing pass for a larger input) or handed back (bdx_trim_results)
+void own_borrowed_regions(bdx_ctx* c) {
+    if (!c->reg || (const void*)c->reg != c->h_regs.p) return;
+    const HostRegion* r = c->reg;
+    const uint32_t* pk = c->rpk;
+    const size_t n = c->nreg;
+    std::vector<HostRegion> keep(r, r + n);
+    std::vector<uint32_t> keep_pk;
+    if (pk) keep_pk.assign(pk, pk + n * 2 * (size_t)c->nkeys);
+    c->regions.swap(keep); c->r_pk.swap(keep_pk);
+    c->reg = c->regions.data(); c->rpk = c->r_pk.data();
+}
+
 int do_cut(bdx_ctx* c, int has_next, int32_t next_qlen, uint32_t next_nn, bool for_k6, bool keep_dev = false, const Sizing* sz = nullptr) {
     HIPCHK(c, hipSetDevice(c->device));
+    if (sz) own_borrowed_regions(c);   // (a sizing pass may grow the pinned table below.  bdx_reserve sizes nothing once the context has run, and the decoder's
+                                       // pass follows a reset -- no live result should be here; if one is, it keeps a copy)
     hipStream_t s = c->stream;
     const int nkeys = c->nkeys;
     const uint32_t na = sz ? sz->na : c->na_alloc;
@@ -2054,15 +2070,7 @@ int bdx_trim_results(bdx_ctx* c) {
     NOT_WHILE_SIZING(c);
     HIPCHK(c, hipSetDevice(c->device));
     materialize(c);
-    if (c->reg && (const void*)c->reg == c->h_regs.p) {   // (a region table read where the device left it: the getters go on from a copy)
-        const HostRegion* r = c->reg;
-        const uint32_t* pk = c->rpk;
-        const size_t n = c->nreg;
-        std::vector<HostRegion> keep(r, r + n);
-        std::vector<uint32_t> keep_pk(pk, pk + n * 2 * (size_t)c->nkeys);
-        c->regions.swap(keep); c->r_pk.swap(keep_pk);
-        c->reg = c->regions.data(); c->rpk = c->r_pk.data();
-    }
+    own_borrowed_regions(c);   // (a region table read where the device left it: the getters go on from a copy)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (PinBuf* b : {&c->h_regs, &c->h_pk, &c->h_groups, &c->h_sv_out, &c->h_lib_index, &c->h_lib_pairs, &c->h_cn_key, &c->h_cn_value, &c->h_ltail_dev}) b->release();
     return BDX_OK;
