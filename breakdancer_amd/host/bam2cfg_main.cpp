@@ -346,11 +346,17 @@ struct Mapped {
     explicit Mapped(const std::string& path) {
         fd = open(path.c_str(), O_RDONLY);
         struct stat sb;
-        if (fd < 0 || fstat(fd, &sb) != 0) throw std::runtime_error("cannot open " + path);
+        if (fd < 0 || fstat(fd, &sb) != 0) {
+            if (fd >= 0) close(fd);
+            throw std::runtime_error("cannot open " + path);
+        }
         n = (size_t)sb.st_size;
         if (n) {
             void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (m == MAP_FAILED) throw std::runtime_error("cannot map " + path);
+            if (m == MAP_FAILED) {
+                close(fd);
+                throw std::runtime_error("cannot map " + path);
+            }
             p = (const uint8_t*)m;
         }
     }
@@ -358,6 +364,8 @@ struct Mapped {
         if (p) munmap((void*)p, n);
         if (fd >= 0) close(fd);
     }
+    Mapped(const Mapped&) = delete;
+    Mapped& operator=(const Mapped&) = delete;
 };
 
 inline uint32_t rd16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
